@@ -1,0 +1,247 @@
+"""Mint golden vectors from the importable parts of the reference (authoring container only).
+
+Run:  python tests/golden/mint_golden.py      (needs /root/reference; writes tests/golden/*.pt)
+The reference's Python never ships; only the small tensors written here are committed.
+Import recipe: SURVEY.md Appendix F.  What is minted:
+  makd_primitives.pt  kd_loss / mse_loss / exponential_decay / invert_normalized_losses, both flavours
+                      (pretrain_src/optim/kd_loss.py, map_nav_src/utils/kd_loss.py)
+  makd_agent.pt       GMapNavAgent.compute_kd_losses (map_nav_src/r2r/agent.py:546-719) on fixed inputs
+  adamw.pt            pretrain_src/optim/adamw.py AdamW.step x3 + optim/sched.py get_lr_sched table
+  collate.pt          pretrain_src/data/tasks.py {mlm,sap,cfp}_collate on our synthetic samples
+  ops.pt              map_nav_src/utils/ops.py pad_tensors / gen_seq_masks
+"""
+import importlib.util
+import os
+import sys
+import types
+from collections import defaultdict
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+import numpy.ma  # noqa: E402  (import before aliasing np.bool, else numpy.ma breaks)
+try:
+    import scipy.sparse  # noqa
+    import sklearn.cluster  # noqa
+except Exception:
+    pass
+np.bool = bool
+np.int = int
+sys.dont_write_bytecode = True
+
+
+def load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def stub(names):
+    for n in names:
+        try:
+            __import__(n)
+        except Exception:
+            sys.modules[n] = types.ModuleType(n)
+
+
+def mint_primitives():
+    P = load_by_path("ref_kd_pre", f"{REF}/pretrain_src/optim/kd_loss.py")
+    N = load_by_path("ref_kd_nav", f"{REF}/map_nav_src/utils/kd_loss.py")
+    g = torch.Generator().manual_seed(7)
+    B, K = 6, 9
+    s = torch.randn(B, K, generator=g) * 2
+    t = torch.randn(B, K, generator=g) * 2
+    for b in range(B):
+        s[b, K - 1 - (b % 3)] = float("-inf")
+        t[b, K - 1 - (b % 3)] = float("-inf")
+    w = torch.rand(B, generator=g)
+    fs, ft = torch.randn(B, 5, 8, generator=g), torch.randn(B, 5, 8, generator=g)
+    fa, fb = torch.randn(B, 2, 5, 5, generator=g), torch.randn(B, 2, 5, 5, generator=g)
+    wbad = torch.rand(B + 1, generator=g)
+    out = dict(s=s, t=t, w=w, fs=fs, ft=ft, fa=fa, fb=fb, wbad=wbad, cases={})
+    c = out["cases"]
+    for T in (1, 2):
+        c[f"pre_kd_T{T}"] = P.kd_loss(s, t, temperature=T)
+        c[f"pre_kd_T{T}_w"] = P.kd_loss(s, t, temperature=T, t_sample_weights=w)
+        for lt in ("sum", "mean"):
+            c[f"nav_kd_T{T}_{lt}"] = N.kd_loss(s, t, temperature=T, loss_type=lt)
+            c[f"nav_kd_T{T}_{lt}_w"] = N.kd_loss(s, t, temperature=T, t_sample_weights=w, loss_type=lt)
+    c["pre_mse"] = P.mse_loss(fs, ft)
+    c["pre_mse_w"] = P.mse_loss(fs, ft, t_sample_weights=w)
+    c["pre_mse_wbad"] = P.mse_loss(fs, ft, t_sample_weights=wbad)        # silent fallback :15-16
+    c["pre_mse4_w"] = P.mse_loss(fa, fb, t_sample_weights=w)
+    for lt in ("sum", "mean"):
+        c[f"nav_mse_{lt}"] = N.mse_loss(fs, ft, loss_type=lt)
+        c[f"nav_mse_{lt}_w"] = N.mse_loss(fs, ft, t_sample_weights=w, loss_type=lt)
+        c[f"nav_mse4_{lt}_w"] = N.mse_loss(fa, fb, t_sample_weights=w, loss_type=lt)
+    try:
+        N.mse_loss(fs, ft, t_sample_weights=wbad)
+        c["nav_mse_wbad_raises"] = torch.tensor(0)
+    except ValueError:
+        c["nav_mse_wbad_raises"] = torch.tensor(1)
+    losses = torch.tensor([0.0, 1.0, 2.0, 0.3])
+    out["losses"] = losses
+    c["exp_decay_0.7"] = N.exponential_decay(losses, 0.7)
+    c["exp_decay_pre_0.7"] = P.exponential_decay(losses, 0.7)
+    c["invert_norm"] = N.invert_normalized_losses(losses)
+    torch.save(out, os.path.join(HERE, "makd_primitives.pt"))
+    print("makd_primitives:", len(c), "cases")
+
+
+def mint_agent():
+    sys.path.insert(0, f"{REF}/map_nav_src")
+    stub(["MatterSim", "line_profiler", "jsonlines", "h5py", "spacy", "nltk", "tensorboardX", "progressbar"])
+    models = types.ModuleType("models")
+    for sub, attrs in (("graph_utils", ["GraphMap"]), ("model", ["VLNBert", "Critic"]), ("ops", ["pad_tensors_wgrad"])):
+        m = types.ModuleType(f"models.{sub}")
+        for a in attrs:
+            setattr(m, a, object)
+        sys.modules[f"models.{sub}"] = m
+        setattr(models, sub, m)
+    sys.modules["models"] = models
+    import utils.kd_loss as K
+    K.dkd_loss = None
+    from r2r.agent import GMapNavAgent
+
+    g = torch.Generator().manual_seed(11)
+    B, L, Kn, V, Hs, Ht, hs, ht = 4, 12, 7, 9, 32, 64, 2, 4
+    rnd = lambda *sh: torch.randn(*sh, generator=g)
+    sm = lambda x: torch.softmax(x, -1)
+
+    def outputs(H, h):
+        o = defaultdict(lambda: None)
+        o["txt_embeds"] = rnd(B, L, H)
+        o["txt_attns"] = sm(rnd(B, h, L, L))
+        o["pano_embeds"] = rnd(B, V, H)
+        o["pano_fused_embeds"] = rnd(B, H)
+        o["img_attns"] = sm(rnd(B, V, V))
+        o["nav_outs"] = dict(gmap_embeds=rnd(B, Kn, H), vp_embeds=rnd(B, V + 2, H),
+                             gmap_attns=sm(rnd(B, h, Kn, L)), vp_attns=sm(rnd(B, h, V + 2, L)))
+        lg = rnd(B, Kn)
+        lg[:, 1] = float("-inf")
+        lg[0, 3] = float("-inf")
+        o["nav_logits"] = lg
+        return o
+
+    s_out, t_out = outputs(Hs, hs), outputs(Ht, ht)
+    t_out["sample_weights"] = torch.rand(B, generator=g)
+    s_out["sample_weights"] = torch.rand(B, generator=g)
+    torch.manual_seed(3)
+    names = ["txt_emb_w", "kdl_img_w", "kdl_avg_img_w", "global_cross_w", "local_cross_w"]
+    heads = {n: nn.Linear(Hs, Ht) for n in names}
+    student_inner = SimpleNamespace(**heads)
+    rw = torch.softmax(rnd(5) / 4.0, -1) * 5
+    nav_targets = torch.tensor([2, 0, 4, -100])
+    plain = lambda o: {k: (dict(v) if isinstance(v, dict) else v) for k, v in o.items()}
+    fx = dict(s_out=plain(s_out), t_out=plain(t_out), heads={n: (h.weight.data.clone(), h.bias.data.clone()) for n, h in heads.items()},
+              rw=rw, nav_targets=nav_targets, cases={})
+
+    def run(t, role, mode, loss_type="sum"):
+        args = SimpleNamespace(kd_loss_type=loss_type, kd_ability_types=["txt", "img", "global", "local", "action"],
+                               train_kdl_noFeat=False, train_kdl_noAttn=False, train_kdl_noLogit=False,
+                               kdl_temperature=2.0, kdl_adaptive_ability_weight=mode is not None,
+                               kdl_adaptive_ability_weight_type=mode, kdl_logit_loss="kd",
+                               kdl_dkd_alpha=1.0, kdl_dkd_beta=1.0, ignoreid=-100)
+        me = SimpleNamespace(args=args, vln_bert=SimpleNamespace(vln_bert=student_inner),
+                             teacher_vln_bert=SimpleNamespace(vln_bert=SimpleNamespace()),
+                             kdl_feat_loss=K.mse_loss, kdl_attn_loss=K.mse_loss, kdl_logit_loss=K.kd_loss)
+        acc = defaultdict(float)
+        if role == "t2s":
+            res = GMapNavAgent.compute_kd_losses(me, t, s_out, t_out, acc, nav_targets, role="t2s", softmax_weights=rw)
+        else:   # ICoD reverse: the teacher is the learner, the real student's heads project the target
+            res = GMapNavAgent.compute_kd_losses(me, t, t_out, s_out, acc, nav_targets, role="s2t", softmax_weights=rw)
+        return {k: torch.as_tensor(float(v)) for k, v in res.items()}
+
+    for t in (0, 1):
+        for mode in ("RW", None):
+            for lt in ("sum", "mean"):
+                fx["cases"][f"t2s_t{t}_{mode}_{lt}"] = run(t, "t2s", mode, lt)
+        fx["cases"][f"s2t_t{t}_RW"] = run(t, "s2t", "RW")
+    torch.save(fx, os.path.join(HERE, "makd_agent.pt"))
+    print("makd_agent:", list(fx["cases"]))
+    sys.path.remove(f"{REF}/map_nav_src")
+    for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "r2r", "models")]:
+        del sys.modules[k]
+
+
+def mint_pretrain_side():
+    sys.path.insert(0, f"{REF}/pretrain_src")
+    stub(["pynvml", "jsonlines", "h5py", "nltk", "lmdb", "msgpack_numpy", "tensorboardX", "easydict", "progressbar"])
+    sys.modules["msgpack_numpy"].patch = lambda: None
+    from optim.adamw import AdamW
+    from optim.sched import get_lr_sched
+    g = torch.Generator().manual_seed(5)
+    p0 = [torch.randn(7, 5, generator=g), torch.randn(5, generator=g)]
+    grads = [[torch.randn(7, 5, generator=g), torch.randn(5, generator=g)] for _ in range(3)]
+    params = [nn.Parameter(p.clone()) for p in p0]
+    opt = AdamW([{"params": [params[0]], "weight_decay": 0.01}, {"params": [params[1]], "weight_decay": 0.0}],
+                lr=5e-5, betas=(0.9, 0.98))
+    hist = []
+    lrs = [5e-5, 4e-5, 1e-3]
+    for st in range(3):
+        for grp in opt.param_groups:
+            grp["lr"] = lrs[st]
+        for p, gr in zip(params, grads[st]):
+            p.grad = gr.clone()
+        opt.step()
+        hist.append([p.data.clone() for p in params])
+    opts = SimpleNamespace(learning_rate=5e-5, warmup_steps=10000, num_train_steps=200000)
+    steps = [0, 1, 5000, 9999, 10000, 10001, 100000, 199999, 200000, 250000]
+    torch.save(dict(p0=p0, grads=grads, lrs=lrs, hist=hist, sched_steps=steps,
+                    sched=[get_lr_sched(s, opts) for s in steps]), os.path.join(HERE, "adamw.pt"))
+    print("adamw ok")
+
+    # collate: feed OUR synthetic samples to the reference collates
+    import magic_amd
+    from magic_amd.host import synth
+    from data import tasks as T
+    rng = np.random.default_rng([99, 0])
+    import random
+    pyrng = random.Random(99)
+    samples = [synth.make_sample(rng, pyrng, uid=i, min_len=5, max_len=12, min_steps=2, max_steps=4) for i in range(3)]
+    fx = {"samples": samples}
+    ref_items = []
+    for s in samples:
+        it = dict(s)
+        ref_items.append(it)
+    sap = T.sap_collate([dict(x) for x in ref_items])
+    cfp_items = [dict(x, extra_heads=None) for x in ref_items]
+    cfp = T.cfp_collate(cfp_items)
+    mrng = np.random.default_rng(5)
+    mlm_items = []
+    for s in samples:
+        ids, labels = synth.random_word_mask(s["txt_ids"], mrng, 50265)
+        it = {k: v for k, v in s.items() if k not in ("local_act_labels", "global_act_labels")}
+        it["txt_ids"], it["txt_labels"] = ids, labels
+        mlm_items.append(it)
+    mlm = T.mlm_collate([dict(x) for x in mlm_items])
+    keep = lambda b: {k: v for k, v in b.items() if torch.is_tensor(v) or isinstance(v, (list, type(None)))}
+    fx.update(sap=keep(sap), cfp=keep(cfp), mlm=keep(mlm), mlm_items=mlm_items)
+    torch.save(fx, os.path.join(HERE, "collate.pt"))
+    print("collate ok", sorted(sap.keys()))
+    sys.path.remove(f"{REF}/pretrain_src")
+    for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "data", "optim", "parser")]:
+        del sys.modules[k]
+
+
+def mint_ops():
+    O = load_by_path("ref_ops", f"{REF}/map_nav_src/utils/ops.py")
+    g = torch.Generator().manual_seed(2)
+    ts = [torch.randn(n, 3, generator=g) for n in (2, 5, 1)]
+    lens = torch.tensor([2, 5, 1, 0])
+    torch.save(dict(ts=ts, padded=O.pad_tensors(ts), lens=lens, masks=O.gen_seq_masks(lens),
+                    masks8=O.gen_seq_masks(lens, max_len=8)), os.path.join(HERE, "ops.pt"))
+    print("ops ok")
+
+
+if __name__ == "__main__":
+    mint_primitives()
+    mint_ops()
+    mint_agent()
+    mint_pretrain_side()

@@ -1,0 +1,123 @@
+"""The oracle's distillation / optimizer / collate restatements vs vectors minted from the reference
+(tests/golden/mint_golden.py).  CPU only."""
+import os
+from collections import defaultdict
+
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import makd_ref as M
+from oracle import optim_ref
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def test_kd_primitives_match_reference(golden_dir):
+    fx = _load(golden_dir, "makd_primitives.pt")
+    s, t, w, c = fx["s"], fx["t"], fx["w"], fx["cases"]
+    for T in (1, 2):
+        torch.testing.assert_close(M.kd_loss(s, t, T, flavour="pretrain"), c[f"pre_kd_T{T}"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(M.kd_loss(s, t, T, w, flavour="pretrain"), c[f"pre_kd_T{T}_w"], rtol=1e-5, atol=1e-6)
+        for lt in ("sum", "mean"):
+            torch.testing.assert_close(M.kd_loss(s, t, T, None, lt), c[f"nav_kd_T{T}_{lt}"], rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(M.kd_loss(s, t, T, w, lt), c[f"nav_kd_T{T}_{lt}_w"], rtol=1e-5, atol=1e-6)
+    fs, ft, fa, fb = fx["fs"], fx["ft"], fx["fa"], fx["fb"]
+    torch.testing.assert_close(M.mse_loss(fs, ft, flavour="pretrain"), c["pre_mse"])
+    torch.testing.assert_close(M.mse_loss(fs, ft, w, flavour="pretrain"), c["pre_mse_w"])
+    torch.testing.assert_close(M.mse_loss(fs, ft, fx["wbad"], flavour="pretrain"), c["pre_mse_wbad"])
+    torch.testing.assert_close(M.mse_loss(fa, fb, w, flavour="pretrain"), c["pre_mse4_w"])
+    for lt in ("sum", "mean"):
+        torch.testing.assert_close(M.mse_loss(fs, ft, None, lt), c[f"nav_mse_{lt}"])
+        torch.testing.assert_close(M.mse_loss(fs, ft, w, lt), c[f"nav_mse_{lt}_w"])
+        torch.testing.assert_close(M.mse_loss(fa, fb, w, lt), c[f"nav_mse4_{lt}_w"])
+    assert int(c["nav_mse_wbad_raises"]) == 1
+    with pytest.raises(ValueError):
+        M.mse_loss(fs, ft, fx["wbad"], "sum")
+    torch.testing.assert_close(M.exponential_decay(fx["losses"], 0.7), c["exp_decay_0.7"])
+    torch.testing.assert_close(M.exponential_decay(fx["losses"], 0.7), c["exp_decay_pre_0.7"])
+    torch.testing.assert_close(M.invert_normalized_losses(fx["losses"]), c["invert_norm"])
+
+
+def _heads(fx):
+    heads = {}
+    for n, (w, b) in fx["heads"].items():
+        lin = nn.Linear(w.shape[1], w.shape[0])
+        lin.weight.data.copy_(w)
+        lin.bias.data.copy_(b)
+        heads[n] = lin
+    return heads
+
+
+def test_nav_makd_matches_compute_kd_losses(golden_dir):
+    fx = _load(golden_dir, "makd_agent.pt")
+    heads = _heads(fx)
+    s_out, t_out, rw = fx["s_out"], fx["t_out"], fx["rw"]
+    for name, want in fx["cases"].items():
+        parts = name.split("_")
+        role, t = parts[0], int(parts[1][1:])
+        acc = defaultdict(float)
+        if role == "t2s":
+            mode = None if parts[2] == "None" else "RW"
+            got = M.nav_makd(t, s_out, t_out, heads, acc, role="t2s", loss_type=parts[3], weights=rw, weight_mode=mode)
+        else:
+            got = M.nav_makd(t, t_out, s_out, heads, acc, role="s2t", weights=rw, weight_mode="RW")
+        assert set(got) == set(want), name
+        for k in want:
+            torch.testing.assert_close(torch.as_tensor(float(got[k])), want[k], rtol=2e-5, atol=1e-6, msg=f"{name}:{k}")
+
+
+def test_episode_loss_formula():
+    # agent.py:1110-1123
+    assert abs(M.episode_loss(12.0, 8.0, 4, 0.2, 0.5) - (0.5 * 3.0 + 0.5 * 0.4)) < 1e-12
+
+
+def test_adamw_and_schedule_match_reference(golden_dir):
+    fx = _load(golden_dir, "adamw.pt")
+    params = [p.clone() for p in fx["p0"]]
+    state = optim_ref.adamw_init(params)
+    for st in range(3):
+        optim_ref.adamw_step(params, fx["grads"][st], state, lr=fx["lrs"][st], betas=(0.9, 0.98), eps=1e-6,
+                             weight_decay=[0.01, 0.0])
+        for p, want in zip(params, fx["hist"][st]):
+            torch.testing.assert_close(p, want, rtol=1e-6, atol=1e-7)
+    for s, want in zip(fx["sched_steps"], fx["sched"]):
+        assert abs(optim_ref.get_lr_sched(s, 5e-5, 10000, 200000) - want) < 1e-15
+
+
+def test_synthetic_collate_matches_reference_collate(golden_dir):
+    import magic_amd  # noqa: F401
+    from magic_amd.host import synth
+    fx = _load(golden_dir, "collate.pt")
+    for task in ("sap", "cfp"):
+        got = synth.collate(fx["samples"], task)
+        want = fx[task]
+        for k, v in want.items():
+            if k == "extra_heads":
+                continue
+            if torch.is_tensor(v):
+                assert got[k].dtype == v.dtype and got[k].shape == v.shape, (task, k)
+                assert torch.equal(got[k], v), (task, k)
+            else:
+                assert got[k] == v, (task, k)
+    # mlm: same masked items
+    import numpy as np
+    mrng = np.random.default_rng(5)
+    got = synth.collate(fx["samples"], "mlm", rng=mrng)
+    for k, v in fx["mlm"].items():
+        if torch.is_tensor(v):
+            assert torch.equal(got[k], v), k
+        else:
+            assert got[k] == v, k
+
+
+def test_seq_masks_and_padding(golden_dir):
+    from oracle.model_ref import seq_mask
+    fx = _load(golden_dir, "ops.pt")
+    assert torch.equal(seq_mask(fx["lens"], 5), fx["masks"])
+    assert torch.equal(seq_mask(fx["lens"], 8), fx["masks8"])
+    import magic_amd  # noqa: F401
+    from magic_amd.host.synth import _pad_stack
+    assert torch.equal(_pad_stack(fx["ts"]), fx["padded"])

@@ -1,0 +1,124 @@
+/* magic_hip.h -- C ABI of libmagic_hip.so (gfx950 / MI355X).
+ *
+ * The reference (CrystalSixone/VLN-MAGIC) has no FFI: its hot path is a Python nn.Module that launches stock
+ * PyTorch ops (SURVEY.md S2.2 "Native-component conclusion").  This ABI is therefore build-defined:
+ * each entry point below replaces a group of torch ops the withheld model would launch, and cites the reference
+ * interface whose arithmetic it carries.  Conventions:
+ *   - plain pointers (device memory owned by the caller), sizes, strides; no torch types
+ *   - `stream` is a hipStream_t; every call is asynchronous on it, never synchronises, never allocates
+ *   - return 0 on success, negative error code otherwise (MAGIC_ERR_*); never throws
+ *   - dtype: 0 = fp32 ("parity mode", exact fp32 MFMA), 1 = bf16 (MFMA bf16, fp32 accumulate)
+ *   - weights / activations / embedding tables are in `dtype`; biases, LayerNorm params, losses, logits of the
+ *     action heads, statistics and ALL parameter gradients are fp32
+ */
+#ifndef MAGIC_HIP_H
+#define MAGIC_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAGIC_OK 0
+#define MAGIC_ERR_ARG (-1)
+#define MAGIC_ERR_LAUNCH (-2)
+#define MAGIC_ERR_UNSUPPORTED (-3)
+
+int magic_abi_version(void);
+int magic_device_info(int* cu_count, int* clock_khz, char* arch, int arch_len);
+
+/* Dense contraction C = epi(alpha * op(A) op(B) + bias) [+ residual], batched over (batch = nb*nh) with
+ * offsets (b*s?b + h*s?h).  layout 0: NT A[M,K] B[N,K] (nn.Linear forward: every Linear of the model, e.g.
+ * HF BertSelfAttention/BertIntermediate under train_r2r_magic.py:189-208 names); 1: NN A[M,K] B[K,N] (dX, PV,
+ * dQ); 2: TN A[K,M] B[K,N] (dW with split-K fp32 atomics + fused bias gradient, dK, dV).
+ * epilogue: 0 none, 1 GELU(erf), 2 ReLU, 3 *gelu'(aux), 4 *relu'(aux).  C2 (optional) receives the
+ * pre-activation.  k-contiguous operands need ld % (16/sizeof) == 0 and zero padding up to that multiple. */
+int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,
+               const void* A, int lda, long long sAb, long long sAh,
+               const void* B, int ldb, long long sBb, long long sBh,
+               void* C, int ldc, long long sCb, long long sCh, int c_f32, int accumulate,
+               const float* bias, int epilogue, const void* aux, int ldaux,
+               const void* residual, int ldr, void* C2, int ldc2,
+               float alpha, int splitk, float* bias_grad, void* stream);
+
+/* out = [LayerNorm]( in0 + in1 + tab0[i0] + tab1[i1] + tab2[i2] ); table row = idx ? idx[r] : mod ? r%mod+off : off.
+ * Carries BertEmbeddings (word + position(+2) + token-type -> LN), the image embedding sum, the map-node
+ * input sum and every residual-add + LayerNorm of the BERT blocks. */
+int magic_ln_fwd(int dtype, int M, int H, const void* in0, const void* in1,
+                 const void* tab0, const int* idx0, int mod0, int off0,
+                 const void* tab1, const int* idx1, int mod1, int off1,
+                 const void* tab2, const int* idx2, int mod2, int off2,
+                 const float* gamma, const float* beta, float eps, void* out, float* rstd, int do_ln, void* stream);
+int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void* y, const float* gamma, const float* beta,
+                 const float* rstd, void* dx, float* dgamma, float* dbeta,
+                 const int* idx0, int mod0, int off0, float* d0, int small0,
+                 const int* idx1, int mod1, int off1, float* d1, int small1,
+                 const int* idx2, int mod2, int off2, float* d2, int small2,
+                 int do_ln, void* stream);
+
+/* y = LN(x[M,Kin<=16] W^T + b): loc_linear+loc_layer_norm, gmap_pos_embeddings, vp_pos_embeddings (App. B.2-B.3) */
+int magic_smallk_ln_fwd(int dtype, int M, int H, int Kin, const float* x, const float* W, const float* b,
+                        const float* gamma, const float* beta, float eps, void* out, float* rstd, void* stream);
+int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float* x, const void* dy, const void* y,
+                        const float* gamma, const float* beta, const float* rstd,
+                        float* dW, float* db, float* dgamma, float* dbeta, void* stream);
+
+/* P = softmax(scale*S + (kmask?0:-10000) + sprel_w*dist + sprel_b) over rows of S[B,nh,Nq,ldp] (HF additive
+ * mask; graph_sprels bias r2r_magic_model_config.json:28).  bwd writes scale*dS and the 2 sprel_linear grads. */
+int magic_softmax_fwd(int dtype, int B, int nh, int Nq, int Nk, int ldp, const float* S, void* P, float scale,
+                      const unsigned char* kmask, const float* dist, const float* sprel_w, const float* sprel_b, void* stream);
+int magic_softmax_bwd(int dtype, int B, int nh, int Nq, int Nk, int ldp, const void* P, const float* dP, void* dS, float scale,
+                      const float* dist, float* dsprel_w, float* dsprel_b, void* stream);
+int magic_head_mean_fwd(int dtype, int B, int nh, long long inner, const void* P, float* out, void* stream);
+int magic_head_mean_bwd(int B, int nh, long long inner, const float* g, float* dP, int accumulate, void* stream);
+
+/* ClsPrediction tail (Linear->ReLU->LN->Linear(H,1)): logit = dot(LN(Y), w2) + b2 */
+int magic_lndot_fwd(int dtype, int M, int H, const void* Y, const float* gamma, const float* beta, float eps,
+                    const float* w2, const float* b2, float* logit, void* stream);
+int magic_lndot_bwd(int dtype, int M, int H, const void* Y, const float* gamma, const float* beta, float eps,
+                    const float* w2, const float* dlogit, void* dZ, float* dgamma, float* dbeta, float* dw2, float* db2,
+                    void* stream);
+
+/* Rowwise CE with -inf masks + ignore_index (agent_base.py:152 criterion; validate_* of train_r2r_magic.py),
+ * gradient coef*w*(softmax-onehot) in the same pass; w_out = exp(-w_rate*CE) = MKTD weights (agent.py:1013-1020,
+ * kd_loss.py exponential_decay). */
+int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld, const int* labels, int ignore_index,
+                  float coef, const float* row_w, float* loss_row, void* dlogits, int ldd, int accumulate,
+                  float* w_out, float w_rate, void* stream);
+/* kd_loss (pretrain_src/optim/kd_loss.py:18-41, map_nav_src/utils/kd_loss.py:27-54): -inf -> -1e6, T-softmax KL * T^2 */
+int magic_kd_rows(int M, int N, const float* s, const float* t, int ld, float temperature, const float* w, float norm,
+                  float coef, float* loss_row, float* ds, int accumulate, void* stream);
+/* mse_loss (kd_loss.py:5-16 / :6-25): sum_b w_b (s-t)^2 * norm, grad 2*coef*norm*w*(s-t) */
+int magic_mse(int dtype, int g_f32, long long outer, long long inner, const void* s, long long s_stride, const void* t,
+              long long t_stride, const float* w, long long rows_per_w, float norm, float coef, float* loss, void* ds,
+              long long g_stride, int accumulate, void* stream);
+
+/* out[n] (+)= sum_e w[e]*src[idx[e]]: map-node aggregation by viewpoint id (agent.py:905-924 semantics),
+ * candidate-view / masked-token / CLS row selection; backward = same call on the transposed CSR. */
+int magic_csr_gather(int dtype, int n_out, int H, const void* src, const int* ptr, const int* idx, const float* w,
+                     void* out, int accumulate, void* stream);
+/* adaptive_pano_fusion (r2r_magic_model_config.json:57): attention pooling of the V views */
+int magic_pano_fuse_fwd(int dtype, int N, int V, int H, const void* x, const int* lens, const float* wf, const float* bf,
+                        void* fused, float* probs, void* stream);
+int magic_pano_fuse_bwd(int dtype, int N, int V, int H, const void* x, const float* probs, const float* wf, const void* dfused,
+                        void* dx, float* dwf, float* dbf, void* stream);
+/* global/local gate + -inf masks + local->global logit fusion (validate_sap contract :503-535) */
+int magic_sap_fuse_fwd(int B, int K, int Vp, const float* g_raw, const float* l_raw, const float* fuse_raw,
+                       const unsigned char* gmask, const unsigned char* lmask, const int* fsrc, const unsigned char* bwmask,
+                       int use_gate, float* gl, float* ll, float* fl, void* stream);
+int magic_sap_fuse_bwd(int B, int K, int Vp, const float* g_raw, const float* l_raw, const float* fuse_raw,
+                       const unsigned char* gmask, const unsigned char* lmask, const int* fsrc, const unsigned char* bwmask,
+                       int use_gate, const float* dgl, const float* dll, const float* dfl,
+                       float* dg_raw, float* dl_raw, float* dfuse_raw, void* stream);
+
+/* Flat-buffer optimizer: pretrain_src/optim/adamw.py:53-112 + clip_grad_norm_ (grad_norm, r2r_magic_pretrain.json:22) */
+int magic_sumsq(long long n, const float* g, float* out, void* stream);
+int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow_bf16,
+                float lr, float b1, float b2, float eps, float wd, float step_size,
+                const float* sumsq, float max_norm, float gscale, void* stream);
+int magic_cast(int to_bf16, long long n, const void* x, void* y, void* stream);
+int magic_add(int dtype, long long n, const void* x, void* y, void* stream);
+int magic_dact(int dtype, int kind, long long n, const void* dy, const void* z, void* dz, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

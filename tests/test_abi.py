@@ -1,0 +1,60 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/magic_hip.h declares,
+and the ctypes signatures in host/lib.py agree with the header argument by argument."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import magic_amd  # noqa: F401
+from magic_amd.host import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse_header():
+    src = open(os.path.join(ROOT, "include", "magic_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(magic_\w+)\s*\(([^)]*)\)\s*;", src, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        types = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    types.append(L.vp)
+                elif a.startswith("long long"):
+                    types.append(L.i64)
+                elif a.startswith("float"):
+                    types.append(L.f32)
+                elif a.startswith("int"):
+                    types.append(L.i32)
+                else:
+                    raise AssertionError(f"unparsed arg {a!r} in {name}")
+        protos[name] = types
+    return protos
+
+
+def test_header_and_ctypes_signatures_agree():
+    protos = parse_header()
+    assert set(protos) == set(L.SIGNATURES)
+    for name, types in protos.items():
+        assert types == L.SIGNATURES[name], name
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in parse_header():
+        assert hasattr(lib, name), name
+    assert lib.magic_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libmagic_hip.so")
+    with pytest.raises(L.MagicHipError):
+        L.load()

@@ -1,0 +1,469 @@
+"""GPU parity tests of every C-ABI kernel against plain fp32 torch math / the oracle (-m gpu).
+
+fp32 mode (exact-f32 MFMA) is held to tight tolerances; bf16 mode is compared with the same fp32
+reference evaluated on bf16-rounded inputs, to a bf16-sized tolerance written next to each check."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import magic_amd  # noqa: F401
+from magic_amd.host import lib as L
+from magic_amd.host import ops as O
+from oracle import makd_ref as M
+from oracle import optim_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (sum(shape) * 7919 + len(shape)))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def check(got, want, name, **kw):
+    got, want = got.float().cpu(), want.float().cpu()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    ok = torch.allclose(got, want, **kw)
+    assert ok, f"{name}: max|err|={err:.3e} (ref max {ref:.3e}) tol={kw}"
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(100, 72, 64), (64, 64, 128), (333, 128, 768), (48, 50, 40)])
+def test_gemm_nt_bias_epilogues(dtype, M, N, K):
+    x, W = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, scale=0.1)
+    b = rnd(N, scale=0.5)
+    res = rnd(M, N, dtype=dtype)
+    ref = x.float() @ W.float().t() + b
+    out = O.linear_fwd(x, W, b, M)
+    check(out, ref, "nt+bias", **tol(dtype))
+    pre = torch.empty(M, N, dtype=dtype, device=DEV)
+    out = O.linear_fwd(x, W, b, M, epilogue=1, residual=res, pre=pre)
+    check(pre, ref, "pre-activation", **tol(dtype))
+    check(out, F.gelu(ref) + res.float(), "gelu+residual", **tol(dtype))
+    out = O.linear_fwd(x, W, b, M, epilogue=2)
+    check(out, F.relu(ref), "relu", **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nn_dx_with_dgelu_and_residual(dtype):
+    M, N, K = 150, 256, 128          # dx[M,K] = dy[M,N] @ W[N,K]
+    dy, W = rnd(M, N, dtype=dtype), rnd(N, K, dtype=dtype, scale=0.1)
+    z = rnd(M, K, dtype=dtype)
+    r = rnd(M, K, dtype=dtype)
+    ref = dy.float() @ W.float()
+    check(O.linear_dx(dy, W, M), ref, "nn", **tol(dtype))
+    zz = z.float().requires_grad_(True)
+    F.gelu(zz).backward(torch.ones_like(zz))
+    check(O.linear_dx(dy, W, M, epilogue=3, aux=z, residual=r), ref * zz.grad + r.float(), "nn+dgelu+res", **tol(dtype))
+    y = rnd(M, K, dtype=dtype)
+    check(O.linear_dx(dy, W, M, epilogue=4, aux=y), ref * (y.float() > 0), "nn+drelu", **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (77, 72, 40), (3840, 128, 512)])
+def test_gemm_tn_dw_splitk_and_bias_grad(dtype, M, N, K):
+    dy, x = rnd(M, N, dtype=dtype), rnd(M, K, dtype=dtype)
+    dW = torch.zeros(N, K, device=DEV)
+    db = torch.zeros(N, device=DEV)
+    O.linear_dw(dy, x, dW, db, M)
+    O.linear_dw(dy, x, dW, db, M)                       # accumulates
+    t = dict(rtol=1e-4, atol=1e-3) if dtype == torch.float32 else dict(rtol=2e-2, atol=5e-2 * math.sqrt(M / 64))
+    check(dW, 2 * dy.float().t() @ x.float(), "dW", **t)
+    check(db, 2 * dy.float().sum(0), "db", **t)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_batched_attention_shapes(dtype):
+    B, nh, N, d, H = 3, 2, 37, 64, 128
+    ldp = (N + 7) // 8 * 8
+    qkv = rnd(B * N, 3 * H, dtype=dtype)
+    S = torch.zeros(B, nh, N, ldp, device=DEV)
+    O.gemm(0, qkv, qkv[:, H:], S, N, N, d, 3 * H, 3 * H, ldp, batch=B * nh, nh=nh,
+           sA=(N * 3 * H, d), sB=(N * 3 * H, d), sC=(nh * N * ldp, N * ldp))
+    q = qkv[:, :H].float().view(B, N, nh, d).transpose(1, 2)
+    k = qkv[:, H:2 * H].float().view(B, N, nh, d).transpose(1, 2)
+    v = qkv[:, 2 * H:].float().view(B, N, nh, d).transpose(1, 2)
+    t = tol(dtype) if dtype == torch.float32 else dict(rtol=2e-2, atol=1e-1)
+    check(S[..., :N], q @ k.transpose(-1, -2), "QK^T", **t)
+    assert (S[..., N:] == 0).all()
+    Pm = torch.zeros(B, nh, N, ldp, device=DEV, dtype=dtype)
+    Pm[..., :N] = torch.softmax(S[..., :N] / 8, -1).to(dtype)
+    ctx = torch.empty(B * N, H, dtype=dtype, device=DEV)
+    O.gemm(1, Pm, qkv[:, 2 * H:], ctx, N, d, N, ldp, 3 * H, H, batch=B * nh, nh=nh,
+           sA=(nh * N * ldp, N * ldp), sB=(N * 3 * H, d), sC=(N * H, d))
+    ref = (Pm[..., :N].float() @ v).transpose(1, 2).reshape(B * N, H)
+    check(ctx, ref, "PV", **tol(dtype))
+    # dV = P^T dO (TN, direct store)
+    dO = rnd(B * N, H, dtype=dtype)
+    dqkv = torch.zeros(B * N, 3 * H, dtype=dtype, device=DEV)
+    O.gemm(2, Pm, dO, dqkv[:, 2 * H:], N, d, N, ldp, H, 3 * H, batch=B * nh, nh=nh,
+           sA=(nh * N * ldp, N * ldp), sB=(N * H, d), sC=(N * 3 * H, d))
+    dOh = dO.float().view(B, N, nh, d).transpose(1, 2)
+    ref = (Pm[..., :N].float().transpose(-1, -2) @ dOh).transpose(1, 2).reshape(B * N, H)
+    check(dqkv[:, 2 * H:], ref, "dV", **tol(dtype))
+
+
+# ------------------------------------------------------------------------------------ LayerNorm family
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H", [128, 256])
+def test_ln_fwd_bwd_with_tables(dtype, H):
+    M, L_, V = 150, 30, 50
+    in0 = rnd(M, H, dtype=dtype)
+    word, pos, typ, nav = rnd(V, H, dtype=dtype), rnd(L_ + 2, H, dtype=dtype), rnd(1, H, dtype=dtype), rnd(3, H, dtype=dtype)
+    ids = torch.randint(0, V, (M,), device=DEV, dtype=torch.int32)
+    navi = torch.randint(0, 3, (M,), device=DEV, dtype=torch.int32)
+    gamma, beta = (1 + 0.1 * rnd(H)), 0.1 * rnd(H, seed=5)
+    dy = rnd(M, H, dtype=dtype, seed=9)
+    for case in ("text", "image", "sum"):
+        if case == "text":
+            tabs = ((word, ids, 0, 0), (pos, None, L_, 2), (typ, None, 0, 0))
+            leaves = [t.float().requires_grad_(True) for t in (word, pos, typ)]
+            rows = torch.arange(M, device=DEV) % L_ + 2
+            x = leaves[0][ids.long()] + leaves[1][rows] + leaves[2][0]
+            dense = None
+        elif case == "image":
+            tabs = ((nav, navi, 0, 0), (typ, None, 0, 0), None)
+            leaves = [t.float().requires_grad_(True) for t in (nav, typ)]
+            dense = in0.float().requires_grad_(True)
+            x = dense + leaves[0][navi.long()] + leaves[1][0]
+        else:
+            tabs = ((word, ids, 0, 0), None, None)
+            leaves = [word.float().requires_grad_(True)]
+            dense = in0.float().requires_grad_(True)
+            x = dense + leaves[0][ids.long()]
+        do_ln = case != "sum"
+        g32, b32 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        ref = F.layer_norm(x, (H,), g32, b32, 1e-12) if do_ln else x
+        ref.backward(dy.float())
+        out = torch.empty(M, H, dtype=dtype, device=DEV)
+        rstd = torch.empty(M, device=DEV)
+        O.ln_fwd(M, H, out, in0=in0 if dense is not None else None, tabs=tabs, gamma=gamma, beta=beta, rstd=rstd, do_ln=do_ln)
+        check(out, ref, f"ln_fwd[{case}]", **tol(dtype))
+        dx = torch.empty(M, H, dtype=dtype, device=DEV)
+        dg, dbt = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+        dtabs, dbufs = [], []
+        for t in tabs:
+            if t is None:
+                dtabs.append(None)
+                continue
+            buf = torch.zeros(t[0].shape, device=DEV)
+            dbufs.append(buf)
+            dtabs.append((t[1], t[2], t[3], buf, 1 if t[0] is nav else 0))
+        O.ln_bwd(M, H, dy, y=out, gamma=gamma, beta=beta, rstd=rstd, dx=dx, dgamma=dg, dbeta=dbt, dtabs=tuple(dtabs), do_ln=do_ln)
+        t2 = tol(dtype) if dtype == torch.float32 else dict(rtol=5e-2, atol=8e-2)
+        tp = dict(rtol=1e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=0.5)
+        if dense is not None:
+            check(dx, dense.grad, f"ln_bwd dx[{case}]", **t2)
+        if do_ln:
+            check(dg, g32.grad, f"dgamma[{case}]", **tp)
+            check(dbt, b32.grad, f"dbeta[{case}]", **tp)
+        for buf, leaf in zip(dbufs, leaves):
+            check(buf, leaf.grad, f"dtable[{case}]", **tp)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Kin", [7, 14])
+def test_smallk_ln_fwd_bwd(dtype, Kin):
+    M, H = 100, 128
+    x = rnd(M, Kin)
+    W, b = rnd(H, Kin, scale=0.3).requires_grad_(True), rnd(H, scale=0.1).requires_grad_(True)
+    gamma, beta = (1 + 0.1 * rnd(H, seed=1)).requires_grad_(True), (0.1 * rnd(H, seed=2)).requires_grad_(True)
+    ref = F.layer_norm(x @ W.t() + b, (H,), gamma, beta, 1e-12)
+    dy = rnd(M, H, dtype=dtype, seed=4)
+    ref.backward(dy.float())
+    out, rstd = torch.empty(M, H, dtype=dtype, device=DEV), torch.empty(M, device=DEV)
+    O.smallk_ln_fwd(M, H, Kin, x, W.detach(), b.detach(), gamma.detach(), beta.detach(), 1e-12, out, rstd)
+    check(out, ref, "smallk fwd", **tol(dtype))
+    dW, db, dg, dbt = torch.zeros(H, Kin, device=DEV), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    O.smallk_ln_bwd(M, H, Kin, x, dy, out, gamma.detach(), beta.detach(), rstd, dW, db, dg, dbt)
+    tp = dict(rtol=1e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=0.3)
+    for got, want, n in ((dW, W.grad, "dW"), (db, b.grad, "db"), (dg, gamma.grad, "dgamma"), (dbt, beta.grad, "dbeta")):
+        check(got, want, f"smallk {n}", **tp)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_fwd_bwd_mask_and_sprel(dtype):
+    B, nh, Nq, Nk = 3, 2, 19, 19
+    ldp = 24
+    S = torch.zeros(B, nh, Nq, ldp, device=DEV)
+    S[..., :Nk] = rnd(B, nh, Nq, Nk, scale=3.0)
+    kmask = torch.ones(B, Nk, dtype=torch.uint8, device=DEV)
+    kmask[1, 11:] = 0
+    kmask[2, 1] = 0
+    dist = rnd(B, Nq, Nk, seed=3).abs() * 5
+    sw, sb = torch.tensor([0.3], device=DEV, requires_grad=True), torch.tensor([-0.2], device=DEV, requires_grad=True)
+    s_in = S[..., :Nk].clone().requires_grad_(True)
+    logits = s_in * 0.125 + (1 - kmask.float())[:, None, None, :] * -10000.0 + (sw * dist + sb)[:, None]
+    ref = torch.softmax(logits, -1)
+    Pm = torch.empty(B, nh, Nq, ldp, dtype=dtype, device=DEV)
+    O.softmax_fwd(S, Pm, B, nh, Nq, Nk, ldp, 0.125, kmask=kmask, dist=dist, sprel_w=sw.detach(), sprel_b=sb.detach())
+    check(Pm[..., :Nk], ref, "softmax fwd", **(dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=4e-3)))
+    assert (Pm[..., Nk:] == 0).all()
+    dP = torch.zeros(B, nh, Nq, ldp, device=DEV)
+    dP[..., :Nk] = rnd(B, nh, Nq, Nk, seed=8)
+    (Pm[..., :Nk].float().detach() * 0 + ref).backward(dP[..., :Nk])
+    dS = torch.empty(B, nh, Nq, ldp, dtype=dtype, device=DEV)
+    dsw, dsb = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    O.softmax_bwd(Pm, dP, dS, B, nh, Nq, Nk, ldp, 0.125, dist=dist, dsprel_w=dsw, dsprel_b=dsb)
+    t = dict(rtol=1e-4, atol=1e-6) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-3)
+    check(dS[..., :Nk], s_in.grad, "softmax bwd", **t)
+    assert (dS[..., Nk:] == 0).all()
+    t = dict(rtol=1e-3, atol=1e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+    check(dsw, sw.grad, "d sprel w", **t)
+    check(dsb, sb.grad, "d sprel b", **t)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_head_mean(dtype):
+    B, nh, inner = 5, 4, 36 * 40
+    Pm = rnd(B, nh, inner, dtype=dtype)
+    out = torch.empty(B, inner, device=DEV)
+    O.head_mean_fwd(Pm, out, B, nh, inner)
+    check(out, Pm.float().mean(1), "head mean", rtol=1e-5, atol=1e-5)
+    g = rnd(B, inner, seed=2)
+    dP = torch.ones(B, nh, inner, device=DEV)
+    O.head_mean_bwd(g, dP, B, nh, inner, accumulate=True)
+    check(dP, 1 + (g / nh)[:, None].expand(B, nh, inner), "head mean bwd", rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_lndot_fwd_bwd(dtype):
+    M, H = 90, 128
+    Y = F.relu(rnd(M, H)).to(dtype)
+    gamma, beta = (1 + 0.1 * rnd(H, seed=1)).requires_grad_(True), (0.1 * rnd(H, seed=2)).requires_grad_(True)
+    w2, b2 = rnd(H, scale=0.2, seed=3).requires_grad_(True), torch.tensor([0.3], device=DEV, requires_grad=True)
+    z = rnd(M, H, seed=12)
+    z = torch.where(Y.float() > 0, Y.float(), -z.abs() - 0.1).requires_grad_(True)     # pre-relu with relu(z) == Y
+    ref = F.layer_norm(F.relu(z), (H,), gamma, beta, 1e-12) @ w2 + b2
+    dl = rnd(M, seed=6)
+    ref.backward(dl)
+    logit = torch.empty(M, device=DEV)
+    O.lndot_fwd(Y, M, H, gamma.detach(), beta.detach(), 1e-12, w2.detach(), b2.detach(), logit)
+    check(logit, ref, "lndot fwd", **(dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)))
+    dZ = torch.empty(M, H, dtype=dtype, device=DEV)
+    dg, dbt, dw2, db2 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.zeros(1, device=DEV)
+    O.lndot_bwd(Y, M, H, gamma.detach(), beta.detach(), 1e-12, w2.detach(), dl, dZ, dg, dbt, dw2, db2)
+    t = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    check(dZ, z.grad, "lndot dZ", **t)
+    tp = dict(rtol=1e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=0.2)
+    for got, want, n in ((dg, gamma.grad, "dgamma"), (dbt, beta.grad, "dbeta"), (dw2, w2.grad, "dw2"), (db2, b2.grad, "db2")):
+        check(got, want, f"lndot {n}", **tp)
+
+
+# ------------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N", [17, 1000])
+def test_ce_rows_matches_torch(dtype, N):
+    Mr = 9
+    ld = (N + 7) // 8 * 8
+    x = torch.zeros(Mr, ld, device=DEV, dtype=dtype)
+    x[:, :N] = rnd(Mr, N, scale=2.0).to(dtype)
+    x[0, 3] = float("-inf")
+    x[2, 0] = float("-inf")
+    labels = torch.randint(4, N, (Mr,), device=DEV, dtype=torch.int32)
+    labels[4] = -100
+    xs = x[:, :N].float().clone().requires_grad_(True)
+    per = F.cross_entropy(xs, labels.long(), reduction="none", ignore_index=-100)
+    roww = torch.rand(Mr, device=DEV)
+    (per * roww).sum().mul(0.37).backward()
+    loss_row, w_out = torch.empty(Mr, device=DEV), torch.empty(Mr, device=DEV)
+    d = torch.full((Mr, ld), 7.0, device=DEV, dtype=dtype)
+    O.ce_rows(x, Mr, N, ld, labels, coef=0.37, row_w=roww, loss_row=loss_row, dlogits=d, ldd=ld, w_out=w_out, w_rate=0.7)
+    t = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    check(loss_row, per, "ce loss", **t)
+    check(w_out, M.exponential_decay(per.detach(), 0.7), "mktd weights", **t)
+    check(d[:, :N], xs.grad, "ce grad", **(dict(rtol=1e-4, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-3)))
+    assert (d[:, N:] == 0).all()
+    # in-place gradient (MLM path) gives the same result
+    x2 = x.clone()
+    O.ce_rows(x2, Mr, N, ld, labels, coef=0.37, row_w=roww, dlogits=x2, ldd=ld)
+    check(x2[:, :N], d[:, :N], "ce in-place", rtol=0, atol=0)
+
+
+def test_kd_rows_matches_oracle():
+    B, K = 7, 13
+    s, t = rnd(B, K, scale=2.0), rnd(B, K, scale=2.0, seed=3)
+    for b in range(B):
+        s[b, K - 1 - (b % 3)] = float("-inf")
+        t[b, K - 1 - (b % 3)] = float("-inf")
+    w = torch.rand(B, device=DEV)
+    for weighted in (False, True):
+        for lt in ("sum", "mean"):
+            ss = s.clone().requires_grad_(True)
+            ref = M.kd_loss(ss, t, 2.0, w if weighted else None, lt)
+            (ref * 0.6).backward()
+            norm = 1.0 if lt == "sum" else (1.0 / B if weighted else 1.0 / (B * K))
+            loss_row, ds = torch.empty(B, device=DEV), torch.empty(B, K, device=DEV)
+            O.kd_rows(s, t, B, K, K, 2.0, w=w if weighted else None, norm=norm, coef=0.6, loss_row=loss_row, ds=ds)
+            check(loss_row.sum(), ref.detach(), f"kd {lt} w={weighted}", rtol=1e-5, atol=1e-6)
+            g = torch.nan_to_num(ss.grad, nan=0.0)
+            check(ds, g, f"kd grad {lt} w={weighted}", rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mse_matches_oracle_with_head_slicing(dtype):
+    B, hs, ht, Nq, ldp = 4, 2, 4, 10, 16
+    s, t = rnd(B, hs, Nq, ldp, dtype=dtype), rnd(B, ht, Nq, ldp, dtype=dtype, seed=4)
+    w = torch.rand(B, device=DEV)
+    hmin = 2
+    for lt in ("sum", "mean"):
+        for weighted in (False, True):
+            ss = s.float().clone().requires_grad_(True)
+            ref = M.mse_loss(ss[:, :hmin], t.float()[:, :hmin], w if weighted else None, lt)
+            (0.8 * ref).backward()
+            inner = hmin * Nq * ldp
+            norm = 1.0 if lt == "sum" else 1.0 / (B * inner)
+            loss = torch.zeros(1, device=DEV)
+            ds = torch.zeros(B, hs, Nq, ldp, device=DEV)
+            O.mse(s, t, B, inner, hs * Nq * ldp, ht * Nq * ldp, w=w if weighted else None, norm=norm, coef=0.8, loss=loss, ds=ds,
+                  g_stride=hs * Nq * ldp)
+            check(loss[0], ref.detach(), f"mse {lt} w={weighted}", rtol=1e-4, atol=1e-5)
+            check(ds, ss.grad, f"mse grad {lt} w={weighted}", rtol=1e-4, atol=1e-6)
+    # feature flavour: grad in compute dtype
+    a, b = rnd(B * 6, 32, dtype=dtype), rnd(B * 6, 32, dtype=dtype, seed=2)
+    aa = a.float().clone().requires_grad_(True)
+    ref = M.mse_loss(aa.view(B, 6, 32), b.float().view(B, 6, 32), w, flavour="pretrain")
+    ref.backward()
+    loss = torch.zeros(1, device=DEV)
+    ds = torch.empty(B * 6, 32, dtype=dtype, device=DEV)
+    O.mse(a, b, B, 6 * 32, 6 * 32, 6 * 32, w=w, norm=1.0 / a.numel(), coef=1.0, loss=loss, ds=ds, g_stride=6 * 32)
+    check(loss[0], ref.detach(), "mse feat", rtol=1e-4, atol=1e-6)
+    check(ds, aa.grad, "mse feat grad", **(dict(rtol=1e-4, atol=1e-7) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-4)))
+
+
+# ------------------------------------------------------------------------------------- graph ops
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_csr_gather_and_transpose(dtype):
+    n_src, n_out, H = 40, 11, 128
+    src = rnd(n_src, H, dtype=dtype)
+    ptr = torch.tensor([0, 0, 1, 4, 4, 6, 7, 9, 9, 10, 12, 13], dtype=torch.int32, device=DEV)
+    idx = torch.tensor([5, 1, 2, 3, 7, 9, 11, 30, 31, 39, 0, 4, 6], dtype=torch.int32, device=DEV)
+    w = torch.rand(13, device=DEV)
+    out = torch.full((n_out, H), 3.0, dtype=dtype, device=DEV)
+    O.csr_gather(src, ptr, idx, w, out, n_out, H)
+    A = torch.zeros(n_out, n_src, device=DEV)
+    for n in range(n_out):
+        for e in range(int(ptr[n]), int(ptr[n + 1])):
+            A[n, int(idx[e])] += w[e]
+    check(out, A @ src.float(), "csr gather", **tol(dtype))
+    out2 = out.clone()
+    O.csr_gather(src, ptr, idx, w, out2, n_out, H, accumulate=True)
+    check(out2, 2 * (A @ src.float()), "csr accumulate", **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pano_fuse_fwd_bwd(dtype):
+    N, V, H = 6, 36, 128
+    x = rnd(N, V, H, dtype=dtype)
+    lens = torch.tensor([36, 36, 20, 36, 5, 36], dtype=torch.int32, device=DEV)
+    wf, bf = rnd(H, scale=0.2).requires_grad_(True), torch.tensor([0.1], device=DEV, requires_grad=True)
+    xx = x.float().clone().requires_grad_(True)
+    mask = torch.arange(V, device=DEV)[None] < lens[:, None]
+    sc = xx @ wf + bf + (~mask).float() * -10000.0
+    p = torch.softmax(sc, -1)
+    ref = (p[..., None] * xx).sum(1)
+    df = rnd(N, H, dtype=dtype, seed=3)
+    ref.backward(df.float())
+    fused, probs = torch.empty(N, H, dtype=dtype, device=DEV), torch.empty(N, V, device=DEV)
+    O.pano_fuse_fwd(x, lens, wf.detach(), bf.detach(), fused, probs, N, V, H)
+    check(fused, ref, "pano fuse fwd", **tol(dtype))
+    check(probs, p, "pano fuse probs", **(dict(rtol=1e-4, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-3)))
+    dx = torch.zeros(N, V, H, dtype=dtype, device=DEV)
+    dwf, dbf = torch.zeros(H, device=DEV), torch.zeros(1, device=DEV)
+    O.pano_fuse_bwd(x, probs, wf.detach(), df, dx, dwf, dbf, N, V, H)
+    t = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=2e-2)
+    check(dx, xx.grad, "pano fuse dx", **t)
+    tp = dict(rtol=1e-3, atol=1e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=0.1)
+    check(dwf, wf.grad, "pano fuse dwf", **tp)
+    check(dbf, bf.grad, "pano fuse dbf", **tp)
+
+
+def test_sap_fuse_fwd_bwd_against_oracle_fusion():
+    from magic_amd.host import synth
+    from magic_amd.host.plan import build_plan
+    from oracle.model_ref import fuse_logits
+    batch = synth.make_batch("sap", batch_size=6, seed=5, min_len=5, max_len=9, min_steps=2, max_steps=5)
+    plan = build_plan(batch, "sap", DEV)
+    B, K = batch["gmap_step_ids"].shape
+    Vp = 37
+    g_raw = rnd(B, K).requires_grad_(True)
+    l_raw = rnd(B, Vp, seed=2).requires_grad_(True)
+    fuse_raw = rnd(B, seed=3).requires_grad_(True)
+    fw = torch.sigmoid(fuse_raw)[:, None]
+    gmask = plan["gmask"].bool()
+    lmask = plan["lmask"].bool()
+    gl = (g_raw * fw).masked_fill(~gmask, float("-inf"))
+    ll = (l_raw * (1 - fw)).masked_fill(~lmask, float("-inf"))
+    cpu_batch = batch
+    fl = fuse_logits(gl.cpu(), ll.cpu(), cpu_batch).to(DEV)
+    ga = batch["global_act_labels"].to(DEV)
+    la = batch["local_act_labels"].to(DEV)
+    loss = F.cross_entropy(gl, ga) + F.cross_entropy(ll, la, ignore_index=-100) * 0.7 + F.cross_entropy(fl, ga) * 1.3
+    loss.backward()
+    o_gl, o_ll, o_fl = torch.empty(B, K, device=DEV), torch.empty(B, Vp, device=DEV), torch.empty(B, K, device=DEV)
+    O.sap_fuse_fwd(B, K, Vp, g_raw.detach(), l_raw.detach(), fuse_raw.detach(), plan["gmask"], plan["lmask"], plan["fsrc"],
+                   plan["bwmask"], True, o_gl, o_ll, o_fl)
+    for got, want, n in ((o_gl, gl, "gl"), (o_ll, ll, "ll"), (o_fl, fl, "fl")):
+        assert torch.equal(torch.isinf(got), torch.isinf(want)), n
+        check(torch.nan_to_num(got, neginf=0.0), torch.nan_to_num(want.detach(), neginf=0.0), n, rtol=1e-5, atol=1e-6)
+    dgl, dll, dfl = torch.empty(B, K, device=DEV), torch.empty(B, Vp, device=DEV), torch.empty(B, K, device=DEV)
+    ga32, la32 = ga.int(), la.int()
+    O.ce_rows(o_gl, B, K, K, ga32, coef=1.0 / B, dlogits=dgl, ldd=K)
+    nl = max(int((la != -100).sum()), 1)
+    O.ce_rows(o_ll, B, Vp, Vp, la32, coef=0.7 / nl, dlogits=dll, ldd=Vp)
+    O.ce_rows(o_fl, B, K, K, ga32, coef=1.3 / B, dlogits=dfl, ldd=K)
+    dg, dl, df = torch.empty(B, K, device=DEV), torch.empty(B, Vp, device=DEV), torch.empty(B, device=DEV)
+    O.sap_fuse_bwd(B, K, Vp, g_raw.detach(), l_raw.detach(), fuse_raw.detach(), plan["gmask"], plan["lmask"], plan["fsrc"],
+                   plan["bwmask"], True, dgl, dll, dfl, dg, dl, df)
+    check(dg, g_raw.grad, "d g_raw", rtol=1e-4, atol=1e-6)
+    check(dl, l_raw.grad, "d l_raw", rtol=1e-4, atol=1e-6)
+    check(df, fuse_raw.grad, "d fuse_raw", rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------- optimizer
+def test_adamw_clip_and_shadow_match_oracle():
+    n = 10007
+    p0, g0 = rnd(n), rnd(n, seed=3) * 3
+    params, grads = [p0.cpu().clone()], [g0.cpu().clone()]
+    state = optim_ref.adamw_init(params)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step in range(1, 4):
+        gr = [g.clone() * step for g in grads]
+        optim_ref.clip_grad_norm(gr, 5.0)
+        optim_ref.adamw_step(params, gr, state, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
+        ss = torch.zeros(1, device=DEV)
+        gdev = (g0 * step).contiguous()
+        O.sumsq(gdev, ss)
+        check(ss[0], (gdev.double() ** 2).sum().float(), "sumsq", rtol=1e-5, atol=0)
+        step_size = 1e-3 * math.sqrt(1 - 0.98 ** step) / (1 - 0.9 ** step)
+        O.adamw(n, p, gdev, m, v, shadow, 1e-3, 0.9, 0.98, 1e-6, 0.01, step_size, ss, 5.0, 1.0)
+        check(p, params[0], f"adamw step {step}", rtol=1e-5, atol=1e-6)
+    assert torch.equal(shadow, p.to(torch.bfloat16))
+
+
+def test_cast_roundtrip_and_add():
+    x = rnd(1003)
+    y = O.cast_to(x, torch.bfloat16)
+    assert torch.equal(y, x.to(torch.bfloat16))
+    z = O.cast_to(y, torch.float32)
+    assert torch.equal(z, y.float())
+    a, b = rnd(77), rnd(77, seed=2)
+    want = a + b
+    O.add_(a, b)
+    check(a, want, "add", rtol=0, atol=0)
+    dy, zz = rnd(50, 8), rnd(50, 8, seed=9)
+    zr = zz.clone().requires_grad_(True)
+    F.gelu(zr).backward(dy)
+    check(O.dact(dy, zz, 1), zr.grad, "dgelu", rtol=1e-5, atol=1e-6)

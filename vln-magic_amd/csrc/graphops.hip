@@ -1,0 +1,206 @@
+// Graph-map / panorama glue kernels: CSR row gather (map-node aggregation, candidate-view selection,
+// masked-token selection; the backward is the same kernel on the transposed CSR), attention pooling of
+// the 36 views (adaptive_pano_fusion), and the global/local action-logit gate + local->global fusion.
+#include "common.hpp"
+
+// out[n,:] (+)= sum_{e in [ptr[n], ptr[n+1])} w[e] * src[idx[e], :]      one wave per output row
+template <typename T>
+__global__ __launch_bounds__(256) void csr_gather_kernel(int n_out, int H, const T* src, const int* ptr, const int* idx, const float* w,
+                                                         T* out, int accumulate) {
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= n_out) return;
+  const int e0 = ptr[n], e1 = ptr[n + 1];
+  if (accumulate && e0 == e1) return;
+  for (int c = lane * 2; c < H; c += 128) {
+    float a = 0.f, b = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const float wv = w ? w[e] : 1.f;
+      const T* p = src + (long long)idx[e] * H + c;
+      a += wv * to_f(p[0]); b += wv * to_f(p[1]);
+    }
+    T* o = out + (long long)n * H + c;
+    if (accumulate) { a += to_f(o[0]); b += to_f(o[1]); }
+    o[0] = from_f<T>(a); o[1] = from_f<T>(b);
+  }
+}
+
+// adaptive panorama fusion: p = softmax_v(x[n,v,:].wf + bf + mask), fused[n,:] = sum_v p_v x[n,v,:]
+// one block (256 threads) per panorama, V <= 64 views.
+template <typename T>
+__global__ __launch_bounds__(256) void pano_fuse_fwd_kernel(int N, int V, int H, const T* x, const int* lens, const float* wf, const float* bf,
+                                                            T* fused, float* probs) {
+  __shared__ float sc[64];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const T* xb = x + (long long)n * V * H;
+  for (int v = wid; v < V; v += 4) {
+    float d = 0.f;
+    for (int c = lane; c < H; c += 64) d += to_f(xb[(long long)v * H + c]) * wf[c];
+    d = wave_sum(d);
+    if (lane == 0) sc[v] = d + bf[0] + (v < lens[n] ? 0.f : -10000.0f);
+  }
+  __syncthreads();
+  if (wid == 0) {
+    float s = lane < V ? sc[lane] : -3.0e38f;
+    const float mx = wave_max(s);
+    float e = lane < V ? __expf(s - mx) : 0.f;
+    const float z = wave_sum(e);
+    if (lane < V) { sc[lane] = e / z; probs[(long long)n * V + lane] = e / z; }
+  }
+  __syncthreads();
+  for (int c = tid; c < H; c += 256) {
+    float a = 0.f;
+    for (int v = 0; v < V; ++v) a += sc[v] * to_f(xb[(long long)v * H + c]);
+    fused[(long long)n * H + c] = from_f<T>(a);
+  }
+}
+
+// backward: dx[n,v,:] += p_v * df + ds_v * wf ;  ds_v = p_v (dp_v - sum p dp), dp_v = df . x_v ; dwf, dbf atomics
+template <typename T>
+__global__ __launch_bounds__(256) void pano_fuse_bwd_kernel(int N, int V, int H, const T* x, const float* probs, const float* wf,
+                                                            const T* dfused, T* dx, float* dwf, float* dbf) {
+  __shared__ float dp[64], dsv[64];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const T* xb = x + (long long)n * V * H;
+  const T* df = dfused + (long long)n * H;
+  const float* p = probs + (long long)n * V;
+  for (int v = wid; v < V; v += 4) {
+    float d = 0.f;
+    for (int c = lane; c < H; c += 64) d += to_f(xb[(long long)v * H + c]) * to_f(df[c]);
+    d = wave_sum(d);
+    if (lane == 0) dp[v] = d;
+  }
+  __syncthreads();
+  if (wid == 0) {
+    float t = lane < V ? p[lane] * dp[lane] : 0.f;
+    const float s = wave_sum(t);
+    const float d = lane < V ? p[lane] * (dp[lane] - s) : 0.f;
+    if (lane < V) dsv[lane] = d;
+    const float tot = wave_sum(d);
+    if (lane == 0) atomicAdd(dbf, tot);
+  }
+  __syncthreads();
+  for (int c = tid; c < H; c += 256) {
+    const float dfc = to_f(df[c]), wc = wf[c];
+    float aw = 0.f;
+    for (int v = 0; v < V; ++v) {
+      const long long i = ((long long)n * V + v) * H + c;
+      aw += dsv[v] * to_f(xb[(long long)v * H + c]);
+      dx[i] = from_f<T>(to_f(dx[i]) + p[v] * dfc + dsv[v] * wc);
+    }
+    atomicAdd(dwf + c, aw);
+  }
+}
+
+// SAP logits: gate fw = sigmoid(fuse_raw[b]); gl = g_raw*fw (masked -inf), ll = l_raw*(1-fw) (masked),
+// fused[k] = gl[k] + (src[k] >= 0 ? ll[src[k]] : src[k] == -2 ? sum_{j in bw} ll[j] : 0)     (fp32, one block per sample)
+__global__ __launch_bounds__(64) void sap_fuse_fwd_kernel(int B, int K, int Vp, const float* g_raw, const float* l_raw, const float* fuse_raw,
+                                                          const unsigned char* gmask, const unsigned char* lmask, const int* fsrc,
+                                                          const unsigned char* bwmask, float use_gate, float* gl, float* ll, float* fl) {
+  __shared__ float sl[128];
+  __shared__ float sbw;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float NEG = -__builtin_inff();
+  const float fw = use_gate != 0.f ? 1.f / (1.f + __expf(-fuse_raw[b])) : 0.5f;
+  float bw = 0.f;
+  for (int j = tid; j < Vp; j += 64) {
+    const float v = lmask[b * Vp + j] ? l_raw[b * Vp + j] * (1.f - fw) : NEG;
+    ll[b * Vp + j] = v; sl[j] = v;
+    if (bwmask[b * Vp + j] && lmask[b * Vp + j]) bw += v;
+  }
+  bw = wave_sum(bw);
+  if (tid == 0) sbw = bw;
+  __syncthreads();
+  for (int k = tid; k < K; k += 64) {
+    const float v = gmask[b * K + k] ? g_raw[b * K + k] * fw : NEG;
+    gl[b * K + k] = v;
+    const int s = fsrc[b * K + k];
+    float add = 0.f;
+    if (s >= 0) add = sl[s]; else if (s == -2) add = sbw;
+    fl[b * K + k] = v + add;
+  }
+}
+
+// backward: given dgl, dll, dfl (any may be null) -> d g_raw, d l_raw, d fuse_raw
+__global__ __launch_bounds__(64) void sap_fuse_bwd_kernel(int B, int K, int Vp, const float* g_raw, const float* l_raw, const float* fuse_raw,
+                                                          const unsigned char* gmask, const unsigned char* lmask, const int* fsrc,
+                                                          const unsigned char* bwmask, float use_gate, const float* dgl, const float* dll,
+                                                          const float* dfl, float* dg_raw, float* dl_raw, float* dfuse_raw) {
+  __shared__ float dl[128];
+  __shared__ float sbw;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float fw = use_gate != 0.f ? 1.f / (1.f + __expf(-fuse_raw[b])) : 0.5f;
+  for (int j = tid; j < Vp; j += 64) dl[j] = (dll && lmask[b * Vp + j]) ? dll[b * Vp + j] : 0.f;
+  if (tid == 0) sbw = 0.f;
+  __syncthreads();
+  float dfw = 0.f;
+  for (int k = tid; k < K; k += 64) {
+    const bool ok = gmask[b * K + k];
+    const float dg = ok ? ((dgl ? dgl[b * K + k] : 0.f) + (dfl ? dfl[b * K + k] : 0.f)) : 0.f;
+    dg_raw[b * K + k] = dg * fw;
+    dfw += dg * g_raw[b * K + k];
+    if (dfl && ok) {   // masked global entries are -inf: their CE/KD gradient is exactly 0
+      const int s = fsrc[b * K + k];
+      const float d = dfl[b * K + k];
+      if (s >= 0) atomicAdd(&dl[s], d); else if (s == -2) atomicAdd(&sbw, d);
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < Vp; j += 64) {
+    float d = dl[j];
+    if (bwmask[b * Vp + j]) d += sbw;
+    if (!lmask[b * Vp + j]) d = 0.f;
+    dl_raw[b * Vp + j] = d * (1.f - fw);
+    dfw -= d * l_raw[b * Vp + j];
+  }
+  dfw = wave_sum(dfw);
+  if (tid == 0) dfuse_raw[b] = use_gate != 0.f ? dfw * fw * (1.f - fw) : 0.f;
+}
+
+extern "C" int magic_csr_gather(int dtype, int n_out, int H, const void* src, const int* ptr, const int* idx, const float* w,
+                                void* out, int accumulate, void* stream) {
+  if (n_out <= 0 || H <= 0 || (H & 1)) return MAGIC_ERR_ARG;
+  dim3 grid((n_out + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(csr_gather_kernel<bf16>, grid, block, 0, st, n_out, H, (const bf16*)src, ptr, idx, w, (bf16*)out, accumulate);
+  else hipLaunchKernelGGL(csr_gather_kernel<float>, grid, block, 0, st, n_out, H, (const float*)src, ptr, idx, w, (float*)out, accumulate);
+  return launch_status();
+}
+
+extern "C" int magic_pano_fuse_fwd(int dtype, int N, int V, int H, const void* x, const int* lens, const float* wf, const float* bf,
+                                   void* fused, float* probs, void* stream) {
+  if (N <= 0 || V <= 0 || V > 64 || H <= 0) return MAGIC_ERR_ARG;
+  dim3 grid(N), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(pano_fuse_fwd_kernel<bf16>, grid, block, 0, st, N, V, H, (const bf16*)x, lens, wf, bf, (bf16*)fused, probs);
+  else hipLaunchKernelGGL(pano_fuse_fwd_kernel<float>, grid, block, 0, st, N, V, H, (const float*)x, lens, wf, bf, (float*)fused, probs);
+  return launch_status();
+}
+
+extern "C" int magic_pano_fuse_bwd(int dtype, int N, int V, int H, const void* x, const float* probs, const float* wf, const void* dfused,
+                                   void* dx, float* dwf, float* dbf, void* stream) {
+  if (N <= 0 || V <= 0 || V > 64 || H <= 0) return MAGIC_ERR_ARG;
+  dim3 grid(N), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(pano_fuse_bwd_kernel<bf16>, grid, block, 0, st, N, V, H, (const bf16*)x, probs, wf, (const bf16*)dfused, (bf16*)dx, dwf, dbf);
+  else hipLaunchKernelGGL(pano_fuse_bwd_kernel<float>, grid, block, 0, st, N, V, H, (const float*)x, probs, wf, (const float*)dfused, (float*)dx, dwf, dbf);
+  return launch_status();
+}
+
+extern "C" int magic_sap_fuse_fwd(int B, int K, int Vp, const float* g_raw, const float* l_raw, const float* fuse_raw,
+                                  const unsigned char* gmask, const unsigned char* lmask, const int* fsrc, const unsigned char* bwmask,
+                                  int use_gate, float* gl, float* ll, float* fl, void* stream) {
+  if (B <= 0 || K <= 0 || Vp <= 0 || Vp > 128) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(sap_fuse_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, B, K, Vp, g_raw, l_raw, fuse_raw, gmask, lmask, fsrc, bwmask,
+                     (float)use_gate, gl, ll, fl);
+  return launch_status();
+}
+
+extern "C" int magic_sap_fuse_bwd(int B, int K, int Vp, const float* g_raw, const float* l_raw, const float* fuse_raw,
+                                  const unsigned char* gmask, const unsigned char* lmask, const int* fsrc, const unsigned char* bwmask,
+                                  int use_gate, const float* dgl, const float* dll, const float* dfl,
+                                  float* dg_raw, float* dl_raw, float* dfuse_raw, void* stream) {
+  if (B <= 0 || K <= 0 || Vp <= 0 || Vp > 128) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(sap_fuse_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, B, K, Vp, g_raw, l_raw, fuse_raw, gmask, lmask, fsrc, bwmask,
+                     (float)use_gate, dgl, dll, dfl, dg_raw, dl_raw, dfuse_raw);
+  return launch_status();
+}

@@ -1,0 +1,167 @@
+// Loss heads, each computing the per-row loss AND the coefficient-scaled gradient wrt the student
+// logits/features in the same pass (the loss coefficients -- MKRW ability weights, kd_alpha, 1/B -- are
+// known before backward, so no autograd tape is needed):
+//   ce_rows : cross-entropy with -inf-masked logits and ignore_index (+ MKTD weights exp(-rate*CE))
+//   kd_rows : temperature KL of pretrain_src/optim/kd_loss.py:18-41 / map_nav_src/utils/kd_loss.py:27-54
+//   mse     : weighted MSE of kd_loss.py mse_loss, with (outer, inner) strides for head slicing
+#include "common.hpp"
+
+// one block (256 threads) per row; N may be large (MLM vocab 50265).  logits dtype T (f32/bf16), ld given.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_rows_kernel(int M, int N, const T* logits, int ld, const int* labels, int ignore_index,
+                                                      float coef, const float* row_w, float* loss_row, T* dlogits, int ldd,
+                                                      int accumulate, float* w_out, float w_rate) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const T* x = logits + (long long)row * ld;
+  const int lab = labels[row];
+  const bool ignored = (lab == ignore_index) || lab < 0 || lab >= N;
+  const float xl = ignored ? 0.f : to_f(x[lab]);     // read before any in-place gradient write
+  float mx = -3.0e38f;
+  for (int c = tid; c < N; c += 256) mx = fmaxf(mx, to_f(x[c]));
+  mx = wave_max(mx);
+  if (lane == 0) red[wid] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = tid; c < N; c += 256) s += __expf(to_f(x[c]) - mx);      // exp(-inf) = 0
+  s = wave_sum(s);
+  if (lane == 0) red[wid] = s;
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3];
+  const float lse = mx + __logf(s);
+  const float loss = ignored ? 0.f : lse - xl;
+  if (tid == 0) {
+    if (loss_row) loss_row[row] = loss;
+    if (w_out) w_out[row] = __expf(-w_rate * loss);
+  }
+  if (dlogits) {
+    const float cf = ignored ? 0.f : coef * (row_w ? row_w[row] : 1.f);
+    T* d = dlogits + (long long)row * ldd;
+    for (int c = tid; c < ldd; c += 256) {
+      float g = 0.f;
+      if (c < N) {
+        g = cf * (__expf(to_f(x[c]) - lse) - (c == lab ? 1.f : 0.f));
+        if (accumulate) g += to_f(d[c]);
+      }
+      d[c] = from_f<T>(g);     // columns [N, ldd) are zeroed (padding contract of the GEMM loaders)
+    }
+  }
+}
+
+// KD rows: fp32 logits [M,N], N <= 512 (action space).  one wave per row.
+// loss_row = w * sum_j p_t (log p_t - log p_s) * T^2 * norm ;  ds (+)= coef * w * T * (p_s - p_t) * norm
+__global__ __launch_bounds__(256) void kd_rows_kernel(int M, int N, const float* s, const float* t, int ld, float temperature,
+                                                      const float* w, float norm, float coef, float* loss_row, float* ds, int accumulate) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float NEG = -__builtin_inff();
+  float sv[8], tv[8];
+  float ms = -3.0e38f, mt = -3.0e38f;
+  const float invT = 1.0f / temperature;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int c = it * 64 + lane;
+    float a = -3.0e38f, b = -3.0e38f;
+    if (c < N) {
+      a = s[(long long)row * ld + c]; b = t[(long long)row * ld + c];
+      if (a == NEG) a = -1e6f;
+      if (b == NEG) b = -1e6f;
+      a *= invT; b *= invT;
+      ms = fmaxf(ms, a); mt = fmaxf(mt, b);
+    }
+    sv[it] = a; tv[it] = b;
+  }
+  ms = wave_max(ms); mt = wave_max(mt);
+  float zs = 0.f, zt = 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int c = it * 64 + lane;
+    if (c < N) { zs += __expf(sv[it] - ms); zt += __expf(tv[it] - mt); }
+  }
+  zs = wave_sum(zs); zt = wave_sum(zt);
+  const float ls = ms + __logf(zs), lt = mt + __logf(zt);
+  const float wr = w ? w[row] : 1.f;
+  float kl = 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int c = it * 64 + lane;
+    if (c < N) {
+      const float lpt = tv[it] - lt, lps = sv[it] - ls;
+      const float pt = __expf(lpt), ps = __expf(lps);
+      if (pt > 0.f) kl += pt * (lpt - lps);
+      if (ds) {
+        float g = coef * wr * temperature * (ps - pt) * norm;
+        const long long i = (long long)row * ld + c;
+        ds[i] = accumulate ? ds[i] + g : g;
+      }
+    }
+  }
+  kl = wave_sum(kl);
+  if (lane == 0 && loss_row) loss_row[row] = wr * kl * temperature * temperature * norm;
+}
+
+// MSE over [outer][inner] with independent outer strides for s and t (head slicing), optional per-sample
+// weight w[outer / rows_per_w].  loss (atomic, *norm) ; ds = 2 * coef * norm * w * (s - t)  (Tg dtype)
+template <typename T, typename G>
+__global__ __launch_bounds__(256) void mse_kernel(long long outer, long long inner, const T* s, long long s_stride, const T* t, long long t_stride,
+                                                  const float* w, long long rows_per_w, float norm, float coef, float* loss, G* ds, long long g_stride,
+                                                  int accumulate) {
+  __shared__ float red[4];
+  const long long total = outer * inner;
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long o = i / inner, r = i % inner;
+    const float d = to_f(s[o * s_stride + r]) - to_f(t[o * t_stride + r]);
+    const float wv = w ? w[o / rows_per_w] : 1.f;
+    acc += wv * d * d;
+    if (ds) {
+      float g = 2.f * coef * norm * wv * d;
+      G* p = ds + o * g_stride + r;
+      if (accumulate) g += to_f(*p);
+      *p = from_f<G>(g);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * norm);
+}
+
+extern "C" int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld, const int* labels, int ignore_index,
+                             float coef, const float* row_w, float* loss_row, void* dlogits, int ldd, int accumulate,
+                             float* w_out, float w_rate, void* stream) {
+  if (M <= 0 || N <= 0 || ld < N || (dlogits && ldd < N)) return MAGIC_ERR_ARG;
+  dim3 grid(M), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(ce_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, accumulate, w_out, w_rate);
+  else
+    hipLaunchKernelGGL(ce_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (float*)dlogits, ldd, accumulate, w_out, w_rate);
+  return launch_status();
+}
+
+extern "C" int magic_kd_rows(int M, int N, const float* s, const float* t, int ld, float temperature, const float* w, float norm,
+                             float coef, float* loss_row, float* ds, int accumulate, void* stream) {
+  if (M <= 0 || N <= 0 || N > 512 || ld < N || temperature <= 0.f) return MAGIC_ERR_ARG;
+  dim3 grid((M + 3) / 4), block(256);
+  hipLaunchKernelGGL(kd_rows_kernel, grid, block, 0, (hipStream_t)stream, M, N, s, t, ld, temperature, w, norm, coef, loss_row, ds, accumulate);
+  return launch_status();
+}
+
+extern "C" int magic_mse(int dtype, int g_f32, long long outer, long long inner, const void* s, long long s_stride, const void* t,
+                         long long t_stride, const float* w, long long rows_per_w, float norm, float coef, float* loss, void* ds,
+                         long long g_stride, int accumulate, void* stream) {
+  if (outer <= 0 || inner <= 0 || (w && rows_per_w <= 0)) return MAGIC_ERR_ARG;
+  long long total = outer * inner;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  dim3 grid(blocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define L(TY, GY) hipLaunchKernelGGL((mse_kernel<TY, GY>), grid, block, 0, st, outer, inner, (const TY*)s, s_stride, (const TY*)t, t_stride, w, rows_per_w, norm, coef, loss, (GY*)ds, g_stride, accumulate)
+  if (dtype == DT_BF16) { if (g_f32) L(bf16, float); else L(bf16, bf16); }
+  else { L(float, float); }
+#undef L
+  return launch_status();
+}

@@ -1,0 +1,136 @@
+// Flat-buffer optimizer kernels.  All student parameters live in ONE contiguous fp32 buffer (and the
+// gradients / Adam moments / bf16 shadow weights in congruent buffers), so the optimizer is two launches
+// per step instead of ~8 torch kernels per parameter tensor (pretrain_src/optim/adamw.py:53-112), and the
+// DDP all-reduce is a few large contiguous chunks.
+#include "common.hpp"
+
+// sum of squares -> out[0] (atomic, block-reduced); 16-byte loads
+__global__ __launch_bounds__(256) void sumsq_kernel(long long n, const float* g, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = ((const float4*)g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// HF AdamW (adamw.py:84-110): m,v update; p -= step_size * m / (sqrt(v) + eps); then p -= lr*wd*p.
+// Gradient clipping folded in: g *= min(1, max_norm / (sqrt(sumsq) + 1e-6)) (clip_grad_norm_ semantics),
+// and the gradient pre-scale `gscale` (e.g. 1/world_size after a sum all-reduce).  Optionally refreshes
+// the bf16 shadow copy used by the MFMA kernels.
+__global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, const float* g, float* m, float* v, bf16* shadow,
+                                                    float lr, float b1, float b2, float eps, float wd, float step_size,
+                                                    const float* sumsq, float max_norm, float gscale) {
+  float clip = gscale;
+  if (sumsq && max_norm > 0.f) {
+    const float nrm = sqrtf(sumsq[0]) * gscale;
+    clip = gscale * fminf(1.f, max_norm / (nrm + 1e-6f));
+  }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i] * clip;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    float pi = p[i] - step_size * mi / (sqrtf(vi) + eps);
+    if (wd > 0.f) pi -= lr * wd * pi;
+    m[i] = mi; v[i] = vi; p[i] = pi;
+    if (shadow) shadow[i] = (bf16)pi;
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(long long n, const float* x, bf16* y) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = ((const float4*)x)[i];
+    bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+    ((bf16x4*)y)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[(n4 << 2) + threadIdx.x] = (bf16)x[(n4 << 2) + threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(long long n, const bf16* x, float* y) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = (float)x[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(long long n, const T* x, T* y) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = from_f<T>(to_f(y[i]) + to_f(x[i]));
+}
+
+static inline int nblocks(long long n, int per) {
+  long long b = (n + per - 1) / per;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+extern "C" int magic_sumsq(long long n, const float* g, float* out, void* stream) {
+  if (n <= 0 || ((uintptr_t)g & 15)) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, n, g, out);
+  return launch_status();
+}
+
+extern "C" int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow_bf16,
+                           float lr, float b1, float b2, float eps, float wd, float step_size,
+                           const float* sumsq, float max_norm, float gscale, void* stream) {
+  if (n <= 0) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (bf16*)shadow_bf16, lr, b1, b2, eps, wd,
+                     step_size, sumsq, max_norm, gscale);
+  return launch_status();
+}
+
+extern "C" int magic_cast(int to_bf16, long long n, const void* x, void* y, void* stream) {
+  if (n <= 0) return MAGIC_ERR_ARG;
+  if (to_bf16) {
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return MAGIC_ERR_ARG;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, n, (const float*)x, (bf16*)y);
+  } else {
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const bf16*)x, (float*)y);
+  }
+  return launch_status();
+}
+
+extern "C" int magic_add(int dtype, long long n, const void* x, void* y, void* stream) {
+  if (n <= 0) return MAGIC_ERR_ARG;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(add_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const bf16*)x, (bf16*)y);
+  else hipLaunchKernelGGL(add_kernel<float>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const float*)x, (float*)y);
+  return launch_status();
+}
+
+extern "C" int magic_abi_version(void) { return 1; }
+
+// device/runtime probe used by the host loader to fail loudly when no gfx950 device is present
+extern "C" int magic_device_info(int* cu_count, int* clock_khz, char* arch, int arch_len) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return MAGIC_ERR_LAUNCH;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MAGIC_ERR_LAUNCH;
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = prop.clockRate;
+  if (arch && arch_len > 0) {
+    int i = 0;
+    for (; i < arch_len - 1 && prop.gcnArchName[i]; ++i) arch[i] = prop.gcnArchName[i];
+    arch[i] = 0;
+  }
+  return MAGIC_OK;
+}
+
+// dz = dy * act'(z)   (kind 1: GELU(erf), 2: ReLU) -- MLM transform head, where no GEMM sits between LN and the activation
+template <typename T>
+__global__ __launch_bounds__(256) void dact_kernel(long long n, const T* dy, const T* z, T* dz, int kind) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float zz = to_f(z[i]);
+    const float d = kind == 1 ? dgelu_f(zz) : (zz > 0.f ? 1.f : 0.f);
+    dz[i] = from_f<T>(to_f(dy[i]) * d);
+  }
+}
+
+extern "C" int magic_dact(int dtype, int kind, long long n, const void* dy, const void* z, void* dz, void* stream) {
+  if (n <= 0 || (kind != 1 && kind != 2)) return MAGIC_ERR_ARG;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(dact_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const bf16*)dy, (const bf16*)z, (bf16*)dz, kind);
+  else hipLaunchKernelGGL(dact_kernel<float>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const float*)dy, (const float*)z, (float*)dz, kind);
+  return launch_status();
+}

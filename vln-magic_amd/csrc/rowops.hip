@@ -1,0 +1,658 @@
+// Row-wise kernels (HBM-bound): fused [dense + gathered-embedding] sum -> LayerNorm (fwd/bwd), tiny-K
+// linear + LayerNorm (position features), masked softmax with graph-distance bias (fwd/bwd),
+// LayerNorm + dot head (ClsPrediction tail).  One 64-lane wave owns one row; row statistics are
+// wave-shuffle reductions; parameter gradients are reduced per block (registers -> LDS) before a
+// single fp32 atomic per element per block.
+#include "common.hpp"
+
+#define MAXIT 8   // H <= 1024, H % 128 == 0: each lane owns elements {it*128 + lane*2, +1}
+
+template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b);
+template <> __device__ __forceinline__ void ld2<float>(const float* p, float& a, float& b) {
+  float2 v = *(const float2*)p; a = v.x; b = v.y;
+}
+template <> __device__ __forceinline__ void ld2<bf16>(const bf16* p, float& a, float& b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v = *(const bf16x2*)p; a = (float)v[0]; b = (float)v[1];
+}
+template <typename T> __device__ __forceinline__ void st2(T* p, float a, float b);
+template <> __device__ __forceinline__ void st2<float>(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
+template <> __device__ __forceinline__ void st2<bf16>(bf16* p, float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v; v[0] = (bf16)a; v[1] = (bf16)b; *(bf16x2*)p = v;
+}
+
+struct TabRef {          // embedding-table term: row = idx ? idx[r] : (mod ? r % mod + off : off)
+  const void* tab; const int* idx; int mod; int off;
+};
+__device__ __forceinline__ int tab_row(const TabRef& t, int r) {
+  return t.idx ? t.idx[r] : (t.mod ? (r % t.mod) + t.off : t.off);
+}
+
+// ---------------------------------------------------------------------------------------------
+// out = LN(in0 + in1 + tab0[..] + tab1[..] + tab2[..]) * gamma + beta      (do_ln)   | plain sum
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* in0, const T* in1, TabRef t0, TabRef t1, TabRef t2,
+                                                     const float* gamma, const float* beta, float eps, T* out, float* rstd_out, int do_ln) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nit = H >> 7;
+  float x[2 * MAXIT];
+  float s = 0.f;
+  const int r0 = t0.tab ? tab_row(t0, row) : 0, r1 = t1.tab ? tab_row(t1, row) : 0, r2 = t2.tab ? tab_row(t2, row) : 0;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    if (it < nit) {
+      const int c = it * 128 + lane * 2;
+      float a = 0.f, b = 0.f, u, v;
+      if (in0) { ld2<T>(in0 + (long long)row * H + c, u, v); a += u; b += v; }
+      if (in1) { ld2<T>(in1 + (long long)row * H + c, u, v); a += u; b += v; }
+      if (t0.tab) { ld2<T>((const T*)t0.tab + (long long)r0 * H + c, u, v); a += u; b += v; }
+      if (t1.tab) { ld2<T>((const T*)t1.tab + (long long)r1 * H + c, u, v); a += u; b += v; }
+      if (t2.tab) { ld2<T>((const T*)t2.tab + (long long)r2 * H + c, u, v); a += u; b += v; }
+      x[2 * it] = a; x[2 * it + 1] = b; s += a + b;
+    }
+  }
+  if (!do_ln) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) st2<T>(out + (long long)row * H + it * 128 + lane * 2, x[2 * it], x[2 * it + 1]);
+    return;
+  }
+  const float mean = wave_sum(s) / H;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) { float a = x[2 * it] - mean, b = x[2 * it + 1] - mean; q += a * a + b * b; }
+  const float rstd = rsqrtf(wave_sum(q) / H + eps);
+  if (rstd_out && lane == 0) rstd_out[row] = rstd;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) {
+      const int c = it * 128 + lane * 2;
+      const float2 g = *(const float2*)(gamma + c), b = *(const float2*)(beta + c);
+      st2<T>(out + (long long)row * H + c, (x[2 * it] - mean) * rstd * g.x + b.x, (x[2 * it + 1] - mean) * rstd * g.y + b.y);
+    }
+}
+
+// Backward of the above.  dx (optional) = gradient wrt the pre-LN sum (shared by in0/in1).
+// xhat is recomputed from y: xhat = (y - beta) / gamma.  Parameter/table gradients are fp32 atomics:
+//   dgamma, dbeta and const-row / tiny (<=3 rows, `small`) tables: block-reduced first;
+//   indexed tables: one atomic row per input row.
+#define LNB_ROWS 8   // rows per wave
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* dy, const T* y, const float* gamma, const float* beta,
+                                                     const float* rstd, T* dx, float* dgamma, float* dbeta,
+                                                     TabRef t0, float* d0, int small0, TabRef t1, float* d1, int small1,
+                                                     TabRef t2, float* d2, int small2, int do_ln) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][nacc][H]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nit = H >> 7;
+  float ag[2 * MAXIT], ab[2 * MAXIT];
+  float as[3][3][2 * 2];   // small/const tables: only supported for H <= 256 (nit <= 2) -> 4 values per lane
+#pragma unroll
+  for (int i = 0; i < 2 * MAXIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) as[a][b][c] = 0.f;
+  const TabRef* ts[3] = {&t0, &t1, &t2};
+  float* ds[3] = {d0, d1, d2};
+  const int smalls[3] = {small0, small1, small2};
+
+  const int row0 = (blockIdx.x * 4 + wid) * LNB_ROWS;
+  for (int rr = 0; rr < LNB_ROWS; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;
+    float g[2 * MAXIT], xh[2 * MAXIT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+        const int c = it * 128 + lane * 2;
+        float da, db;
+        ld2<T>(dy + (long long)row * H + c, da, db);
+        if (do_ln) {
+          float ya, yb;
+          ld2<T>(y + (long long)row * H + c, ya, yb);
+          const float2 gm = *(const float2*)(gamma + c), bt = *(const float2*)(beta + c);
+          const float xa = gm.x != 0.f ? (ya - bt.x) / gm.x : 0.f, xb = gm.y != 0.f ? (yb - bt.y) / gm.y : 0.f;
+          ag[2 * it] += da * xa; ag[2 * it + 1] += db * xb;
+          ab[2 * it] += da; ab[2 * it + 1] += db;
+          const float ga = da * gm.x, gb = db * gm.y;
+          g[2 * it] = ga; g[2 * it + 1] = gb; xh[2 * it] = xa; xh[2 * it + 1] = xb;
+          s1 += ga + gb; s2 += ga * xa + gb * xb;
+        } else {
+          g[2 * it] = da; g[2 * it + 1] = db;
+        }
+      }
+    if (do_ln) {
+      const float m1 = wave_sum(s1) / H, m2 = wave_sum(s2) / H, rs = rstd[row];
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it)
+        if (it < nit) {
+          g[2 * it] = rs * (g[2 * it] - m1 - xh[2 * it] * m2);
+          g[2 * it + 1] = rs * (g[2 * it + 1] - m1 - xh[2 * it + 1] * m2);
+        }
+    }
+    if (dx) {
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it)
+        if (it < nit) st2<T>(dx + (long long)row * H + it * 128 + lane * 2, g[2 * it], g[2 * it + 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (!ds[k]) continue;
+      const TabRef& t = *ts[k];
+      const bool is_const = (!t.idx && !t.mod);
+      if (is_const || smalls[k]) {
+        const int tr = is_const ? 0 : t.idx[row];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+          if (it < nit) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              const float sel = (tr == q) ? 1.f : 0.f;
+              as[k][q][2 * it] += sel * g[2 * it]; as[k][q][2 * it + 1] += sel * g[2 * it + 1];
+            }
+          }
+      } else {
+        const int tr = tab_row(t, row);
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+          if (it < nit) {
+            const int c = it * 128 + lane * 2;
+            atomicAdd(ds[k] + (long long)tr * H + c, g[2 * it]);
+            atomicAdd(ds[k] + (long long)tr * H + c + 1, g[2 * it + 1]);
+          }
+      }
+    }
+  }
+  // ---- block reduction of register accumulators through LDS: slot layout [slot][wave][H]
+  int slot = 0;
+  auto flush = [&](float* dst, const float* v, int nv_it) {   // v holds 2*nv_it values per lane
+    if (!dst) return;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nv_it) {
+        red[(slot * 4 + wid) * H + it * 128 + lane * 2] = v[2 * it];
+        red[(slot * 4 + wid) * H + it * 128 + lane * 2 + 1] = v[2 * it + 1];
+      }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+      float s = red[(slot * 4 + 0) * H + c] + red[(slot * 4 + 1) * H + c] + red[(slot * 4 + 2) * H + c] + red[(slot * 4 + 3) * H + c];
+      if (s != 0.f) atomicAdd(dst + c, s);
+    }
+    __syncthreads();
+  };
+  if (do_ln) {
+    flush(dgamma, ag, nit);
+    flush(dbeta, ab, nit);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (!ds[k]) continue;
+    const TabRef& t = *ts[k];
+    const bool is_const = (!t.idx && !t.mod);
+    if (is_const) {
+      flush(ds[k] + (long long)t.off * H, as[k][0], nit < 2 ? nit : 2);
+    } else if (smalls[k]) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) flush(ds[k] + (long long)q * H, as[k][q], nit < 2 ? nit : 2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = LN(x[M,Kin] @ W[H,Kin]^T + b) * gamma + beta, Kin <= 16 (position features; fp32 inputs/params)
+template <typename T>
+__global__ __launch_bounds__(256) void smallk_ln_fwd_kernel(int M, int H, int Kin, const float* x, const float* W, const float* b,
+                                                            const float* gamma, const float* beta, float eps, T* out, float* rstd_out) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nit = H >> 7;
+  float xr[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) xr[k] = k < Kin ? x[(long long)row * Kin + k] : 0.f;
+  float z[2 * MAXIT];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = it * 128 + lane * 2 + e;
+        float a = b[c];
+        for (int k = 0; k < Kin; ++k) a += xr[k] * W[c * Kin + k];
+        z[2 * it + e] = a; s += a;
+      }
+    }
+  const float mean = wave_sum(s) / H;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) { float a = z[2 * it] - mean, c = z[2 * it + 1] - mean; q += a * a + c * c; }
+  const float rstd = rsqrtf(wave_sum(q) / H + eps);
+  if (rstd_out && lane == 0) rstd_out[row] = rstd;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) {
+      const int c = it * 128 + lane * 2;
+      st2<T>(out + (long long)row * H + c, (z[2 * it] - mean) * rstd * gamma[c] + beta[c],
+             (z[2 * it + 1] - mean) * rstd * gamma[c + 1] + beta[c + 1]);
+    }
+}
+
+// backward: dW[H,Kin], db[H], dgamma, dbeta (fp32 atomics, block-reduced).  32 rows per block;
+// dz rows are parked in LDS so the dW outer product is a cooperative (c,k) loop.
+#define SK_ROWS 32
+template <typename T>
+__global__ __launch_bounds__(256) void smallk_ln_bwd_kernel(int M, int H, int Kin, const float* x, const T* dy, const T* y,
+                                                            const float* gamma, const float* beta, const float* rstd,
+                                                            float* dW, float* db, float* dgamma, float* dbeta) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // dz[SK_ROWS][H] | xs[SK_ROWS][16] | red[2][4][H]
+  float* dz = sm;
+  float* xs = sm + SK_ROWS * H;
+  float* red = xs + SK_ROWS * 16;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nit = H >> 7;
+  float ag[2 * MAXIT], ab[2 * MAXIT];
+#pragma unroll
+  for (int i = 0; i < 2 * MAXIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  const int base = blockIdx.x * SK_ROWS;
+  for (int rr = wid; rr < SK_ROWS; rr += 4) {
+    const int row = base + rr;
+    const bool ok = row < M;
+    float g[2 * MAXIT], xh[2 * MAXIT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+        const int c = it * 128 + lane * 2;
+        float da = 0.f, dbv = 0.f, ya = 0.f, yb = 0.f;
+        if (ok) { ld2<T>(dy + (long long)row * H + c, da, dbv); ld2<T>(y + (long long)row * H + c, ya, yb); }
+        const float g0 = gamma[c], g1 = gamma[c + 1];
+        const float xa = (ok && g0 != 0.f) ? (ya - beta[c]) / g0 : 0.f, xb = (ok && g1 != 0.f) ? (yb - beta[c + 1]) / g1 : 0.f;
+        ag[2 * it] += da * xa; ag[2 * it + 1] += dbv * xb; ab[2 * it] += da; ab[2 * it + 1] += dbv;
+        g[2 * it] = da * g0; g[2 * it + 1] = dbv * g1; xh[2 * it] = xa; xh[2 * it + 1] = xb;
+        s1 += g[2 * it] + g[2 * it + 1]; s2 += g[2 * it] * xa + g[2 * it + 1] * xb;
+      }
+    const float m1 = wave_sum(s1) / H, m2 = wave_sum(s2) / H, rs = ok ? rstd[row] : 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+        const int c = it * 128 + lane * 2;
+        dz[rr * H + c] = rs * (g[2 * it] - m1 - xh[2 * it] * m2);
+        dz[rr * H + c + 1] = rs * (g[2 * it + 1] - m1 - xh[2 * it + 1] * m2);
+      }
+    if (lane < 16) xs[rr * 16 + lane] = (ok && lane < Kin) ? x[(long long)row * Kin + lane] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H * Kin; i += 256) {
+    const int c = i / Kin, k = i % Kin;
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < SK_ROWS; ++r) s += dz[r * H + c] * xs[r * 16 + k];
+    atomicAdd(dW + i, s);
+  }
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < SK_ROWS; ++r) s += dz[r * H + c];
+    atomicAdd(db + c, s);
+  }
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) {
+      const int c = it * 128 + lane * 2;
+      red[(0 * 4 + wid) * H + c] = ag[2 * it]; red[(0 * 4 + wid) * H + c + 1] = ag[2 * it + 1];
+      red[(1 * 4 + wid) * H + c] = ab[2 * it]; red[(1 * 4 + wid) * H + c + 1] = ab[2 * it + 1];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    atomicAdd(dgamma + c, red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c]);
+    atomicAdd(dbeta + c, red[4 * H + c] + red[5 * H + c] + red[6 * H + c] + red[7 * H + c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// P[b,h,q,:] = softmax(scale * S + keymask + sprel(dist) ), rows of length Nk <= 512, ld = ldp (zero pad)
+#define SM_IT 8
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int nh, int Nq, int Nk, int ldp, const float* S, T* P, float scale,
+                                                          const unsigned char* kmask, const float* dist, const float* sprel_w, const float* sprel_b) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long rows = (long long)B * nh * Nq;
+  if (row >= rows) return;
+  const int q = row % Nq, b = row / ((long long)nh * Nq);
+  const float sw = dist ? sprel_w[0] : 0.f, sb = dist ? sprel_b[0] : 0.f;
+  float v[SM_IT];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int it = 0; it < SM_IT; ++it) {
+    const int k = it * 64 + lane;
+    float x = -3.0e38f;
+    if (k < Nk) {
+      x = S[row * ldp + k] * scale;
+      if (kmask && !kmask[(long long)b * Nk + k]) x += -10000.0f;
+      if (dist) x += sw * dist[((long long)b * Nq + q) * Nk + k] + sb;
+    }
+    v[it] = x; mx = fmaxf(mx, x);
+  }
+  mx = wave_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < SM_IT; ++it) {
+    const int k = it * 64 + lane;
+    const float e = k < Nk ? __expf(v[it] - mx) : 0.f;
+    v[it] = e; s += e;
+  }
+  const float inv = 1.0f / wave_sum(s);
+#pragma unroll
+  for (int it = 0; it < SM_IT; ++it) {
+    const int k = it * 64 + lane;
+    if (k < ldp) P[row * ldp + k] = from_f<T>(k < Nk ? v[it] * inv : 0.f);
+  }
+}
+
+// dS = P * (dP - sum(dP*P)) ; writes scale*dS (T, zero pad); optional sprel grads: d[0] += sum dS*dist, d[1] += sum dS
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int nh, int Nq, int Nk, int ldp, const T* P, const float* dP, T* dS, float scale,
+                                                          const float* dist, float* dsprel_w, float* dsprel_b) {
+  __shared__ float red[8];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * 4 + wid;
+  const long long rows = (long long)B * nh * Nq;
+  float a0 = 0.f, a1 = 0.f;
+  if (row < rows) {
+    const int q = row % Nq, b = row / ((long long)nh * Nq);
+    float p[SM_IT], g[SM_IT];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < SM_IT; ++it) {
+      const int k = it * 64 + lane;
+      p[it] = 0.f; g[it] = 0.f;
+      if (k < Nk) { p[it] = to_f(P[row * ldp + k]); g[it] = dP[row * ldp + k]; s += p[it] * g[it]; }
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int it = 0; it < SM_IT; ++it) {
+      const int k = it * 64 + lane;
+      const float d = p[it] * (g[it] - s);
+      if (k < ldp) dS[row * ldp + k] = from_f<T>(k < Nk ? d * scale : 0.f);
+      if (dist && k < Nk) { a0 += d * dist[((long long)b * Nq + q) * Nk + k]; a1 += d; }
+    }
+  }
+  if (dsprel_w) {
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    if (lane == 0) { red[wid] = a0; red[4 + wid] = a1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(dsprel_w, red[0] + red[1] + red[2] + red[3]);
+      atomicAdd(dsprel_b, red[4] + red[5] + red[6] + red[7]);
+    }
+  }
+}
+
+// mean over heads: out[b,q,k] = (1/nh) sum_h P[b,h,q,k]   (fp32 out, ld = ldp)
+template <typename T>
+__global__ void head_mean_fwd_kernel(int B, int nh, long long inner, const T* P, float* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * inner) return;
+  const long long b = i / inner, r = i % inner;
+  float s = 0.f;
+  for (int h = 0; h < nh; ++h) s += to_f(P[(b * nh + h) * inner + r]);
+  out[i] = s / nh;
+}
+// dP[b,h,q,k] (+)= g[b,q,k] / nh   (fp32 dP)
+__global__ void head_mean_bwd_kernel(int B, int nh, long long inner, const float* g, float* dP, int accumulate) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * nh * inner) return;
+  const long long b = i / (nh * inner), r = i % inner;
+  const float v = g[b * inner + r] / nh;
+  dP[i] = accumulate ? dP[i] + v : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ClsPrediction tail: logit[m] = dot(LN(Y[m]) * gamma + beta, w2) + b2    (Y = relu(linear) from the GEMM)
+template <typename T>
+__global__ __launch_bounds__(256) void lndot_fwd_kernel(int M, int H, const T* Y, const float* gamma, const float* beta, float eps,
+                                                        const float* w2, const float* b2, float* logit) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nit = H >> 7;
+  float x[2 * MAXIT];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) { ld2<T>(Y + (long long)row * H + it * 128 + lane * 2, x[2 * it], x[2 * it + 1]); s += x[2 * it] + x[2 * it + 1]; }
+  const float mean = wave_sum(s) / H;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) { float a = x[2 * it] - mean, b = x[2 * it + 1] - mean; q += a * a + b * b; }
+  const float rstd = rsqrtf(wave_sum(q) / H + eps);
+  float d = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) {
+      const int c = it * 128 + lane * 2;
+      d += ((x[2 * it] - mean) * rstd * gamma[c] + beta[c]) * w2[c] + ((x[2 * it + 1] - mean) * rstd * gamma[c + 1] + beta[c + 1]) * w2[c + 1];
+    }
+  d = wave_sum(d);
+  if (lane == 0) logit[row] = d + b2[0];
+}
+
+// backward: dZ[m,:] = relu'(Y) * LNbwd(dlogit[m] * w2); dgamma, dbeta, dw2, db2 block-reduced atomics
+template <typename T>
+__global__ __launch_bounds__(256) void lndot_bwd_kernel(int M, int H, const T* Y, const float* gamma, const float* beta, float eps,
+                                                        const float* w2, const float* dlogit, T* dZ,
+                                                        float* dgamma, float* dbeta, float* dw2, float* db2) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [3][4][H] + [4]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nit = H >> 7;
+  float ag[2 * MAXIT], ab[2 * MAXIT], aw[2 * MAXIT];
+#pragma unroll
+  for (int i = 0; i < 2 * MAXIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; aw[i] = 0.f; }
+  float adb = 0.f;
+  const int row0 = (blockIdx.x * 4 + wid) * LNB_ROWS;
+  for (int rr = 0; rr < LNB_ROWS; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;
+    float x[2 * MAXIT];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) { ld2<T>(Y + (long long)row * H + it * 128 + lane * 2, x[2 * it], x[2 * it + 1]); s += x[2 * it] + x[2 * it + 1]; }
+    const float mean = wave_sum(s) / H;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) { float a = x[2 * it] - mean, b = x[2 * it + 1] - mean; q += a * a + b * b; }
+    const float rstd = rsqrtf(wave_sum(q) / H + eps);
+    const float dl = dlogit[row];
+    adb += dl;
+    float g[2 * MAXIT], xh[2 * MAXIT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = it * 128 + lane * 2 + e, i = 2 * it + e;
+          xh[i] = (x[i] - mean) * rstd;
+          const float dln = dl * w2[c];                 // grad wrt LN output
+          aw[i] += dl * (xh[i] * gamma[c] + beta[c]);
+          ag[i] += dln * xh[i]; ab[i] += dln;
+          g[i] = dln * gamma[c];
+          s1 += g[i]; s2 += g[i] * xh[i];
+        }
+      }
+    const float m1 = wave_sum(s1) / H, m2 = wave_sum(s2) / H;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+        const float da = x[2 * it] > 0.f ? rstd * (g[2 * it] - m1 - xh[2 * it] * m2) : 0.f;
+        const float dbv = x[2 * it + 1] > 0.f ? rstd * (g[2 * it + 1] - m1 - xh[2 * it + 1] * m2) : 0.f;
+        st2<T>(dZ + (long long)row * H + it * 128 + lane * 2, da, dbv);
+      }
+  }
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (it < nit) {
+      const int c = it * 128 + lane * 2;
+      red[(0 * 4 + wid) * H + c] = ag[2 * it]; red[(0 * 4 + wid) * H + c + 1] = ag[2 * it + 1];
+      red[(1 * 4 + wid) * H + c] = ab[2 * it]; red[(1 * 4 + wid) * H + c + 1] = ab[2 * it + 1];
+      red[(2 * 4 + wid) * H + c] = aw[2 * it]; red[(2 * 4 + wid) * H + c + 1] = aw[2 * it + 1];
+    }
+  if (lane == 0) red[12 * H + wid] = adb;     // every lane of the wave holds the same adb
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    atomicAdd(dgamma + c, red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c]);
+    atomicAdd(dbeta + c, red[4 * H + c] + red[5 * H + c] + red[6 * H + c] + red[7 * H + c]);
+    atomicAdd(dw2 + c, red[8 * H + c] + red[9 * H + c] + red[10 * H + c] + red[11 * H + c]);
+  }
+  if (threadIdx.x == 0) atomicAdd(db2, red[12 * H] + red[12 * H + 1] + red[12 * H + 2] + red[12 * H + 3]);
+}
+
+// ============================================================================================
+static inline bool okH(int H) { return H >= 128 && H <= 128 * MAXIT && (H % 128) == 0; }
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
+  do { if ((dtype) == DT_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
+
+extern "C" int magic_ln_fwd(int dtype, int M, int H, const void* in0, const void* in1,
+                            const void* tab0, const int* idx0, int mod0, int off0,
+                            const void* tab1, const int* idx1, int mod1, int off1,
+                            const void* tab2, const int* idx2, int mod2, int off2,
+                            const float* gamma, const float* beta, float eps, void* out, float* rstd, int do_ln, void* stream) {
+  if (M <= 0 || !okH(H) || !out) return MAGIC_ERR_ARG;
+  if (do_ln && (!gamma || !beta)) return MAGIC_ERR_ARG;
+  TabRef t0{tab0, idx0, mod0, off0}, t1{tab1, idx1, mod1, off1}, t2{tab2, idx2, mod2, off2};
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, M, H, (const float*)in0, (const float*)in1, t0, t1, t2, gamma, beta, eps, (float*)out, rstd, do_ln),
+             hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, block, 0, st, M, H, (const bf16*)in0, (const bf16*)in1, t0, t1, t2, gamma, beta, eps, (bf16*)out, rstd, do_ln));
+  return launch_status();
+}
+
+extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void* y, const float* gamma, const float* beta,
+                            const float* rstd, void* dx, float* dgamma, float* dbeta,
+                            const int* idx0, int mod0, int off0, float* d0, int small0,
+                            const int* idx1, int mod1, int off1, float* d1, int small1,
+                            const int* idx2, int mod2, int off2, float* d2, int small2,
+                            int do_ln, void* stream) {
+  if (M <= 0 || !okH(H) || !dy) return MAGIC_ERR_ARG;
+  if (do_ln && (!y || !gamma || !beta || !rstd || !dgamma || !dbeta)) return MAGIC_ERR_ARG;
+  // const-row / small tables keep per-lane accumulators only for H <= 256
+  const bool c0 = d0 && ((!idx0 && !mod0) || small0), c1 = d1 && ((!idx1 && !mod1) || small1), c2 = d2 && ((!idx2 && !mod2) || small2);
+  if ((c0 || c1 || c2) && H > 256) return MAGIC_ERR_UNSUPPORTED;
+  TabRef t0{d0, idx0, mod0, off0}, t1{d1, idx1, mod1, off1}, t2{d2, idx2, mod2, off2};
+  dim3 grid((M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS)), block(256);
+  size_t shm = (size_t)4 * H * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, shm, st, M, H, (const float*)dy, (const float*)y, gamma, beta, rstd, (float*)dx, dgamma, dbeta, t0, d0, small0, t1, d1, small1, t2, d2, small2, do_ln),
+             hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, shm, st, M, H, (const bf16*)dy, (const bf16*)y, gamma, beta, rstd, (bf16*)dx, dgamma, dbeta, t0, d0, small0, t1, d1, small1, t2, d2, small2, do_ln));
+  return launch_status();
+}
+
+extern "C" int magic_smallk_ln_fwd(int dtype, int M, int H, int Kin, const float* x, const float* W, const float* b,
+                                   const float* gamma, const float* beta, float eps, void* out, float* rstd, void* stream) {
+  if (M <= 0 || !okH(H) || Kin <= 0 || Kin > 16) return MAGIC_ERR_ARG;
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(smallk_ln_fwd_kernel<float>, grid, block, 0, st, M, H, Kin, x, W, b, gamma, beta, eps, (float*)out, rstd),
+             hipLaunchKernelGGL(smallk_ln_fwd_kernel<bf16>, grid, block, 0, st, M, H, Kin, x, W, b, gamma, beta, eps, (bf16*)out, rstd));
+  return launch_status();
+}
+
+extern "C" int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float* x, const void* dy, const void* y,
+                                   const float* gamma, const float* beta, const float* rstd,
+                                   float* dW, float* db, float* dgamma, float* dbeta, void* stream) {
+  if (M <= 0 || !okH(H) || Kin <= 0 || Kin > 16) return MAGIC_ERR_ARG;
+  dim3 grid((M + SK_ROWS - 1) / SK_ROWS), block(256);
+  size_t shm = (size_t)(SK_ROWS * H + SK_ROWS * 16 + 8 * H) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) {
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)smallk_ln_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(smallk_ln_bwd_kernel<bf16>, grid, block, shm, st, M, H, Kin, x, (const bf16*)dy, (const bf16*)y, gamma, beta, rstd, dW, db, dgamma, dbeta);
+  } else {
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)smallk_ln_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(smallk_ln_bwd_kernel<float>, grid, block, shm, st, M, H, Kin, x, (const float*)dy, (const float*)y, gamma, beta, rstd, dW, db, dgamma, dbeta);
+  }
+  return launch_status();
+}
+
+extern "C" int magic_softmax_fwd(int dtype, int B, int nh, int Nq, int Nk, int ldp, const float* S, void* P, float scale,
+                                 const unsigned char* kmask, const float* dist, const float* sprel_w, const float* sprel_b, void* stream) {
+  if (B <= 0 || nh <= 0 || Nq <= 0 || Nk <= 0 || Nk > 64 * SM_IT || ldp < Nk || ldp > 64 * SM_IT) return MAGIC_ERR_ARG;
+  if (dist && (!sprel_w || !sprel_b)) return MAGIC_ERR_ARG;
+  long long rows = (long long)B * nh * Nq;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, block, 0, st, B, nh, Nq, Nk, ldp, S, (float*)P, scale, kmask, dist, sprel_w, sprel_b),
+             hipLaunchKernelGGL(softmax_fwd_kernel<bf16>, grid, block, 0, st, B, nh, Nq, Nk, ldp, S, (bf16*)P, scale, kmask, dist, sprel_w, sprel_b));
+  return launch_status();
+}
+
+extern "C" int magic_softmax_bwd(int dtype, int B, int nh, int Nq, int Nk, int ldp, const void* P, const float* dP, void* dS, float scale,
+                                 const float* dist, float* dsprel_w, float* dsprel_b, void* stream) {
+  if (B <= 0 || nh <= 0 || Nq <= 0 || Nk <= 0 || Nk > 64 * SM_IT || ldp < Nk || ldp > 64 * SM_IT) return MAGIC_ERR_ARG;
+  if ((dist == nullptr) != (dsprel_w == nullptr) || (dist == nullptr) != (dsprel_b == nullptr)) return MAGIC_ERR_ARG;
+  long long rows = (long long)B * nh * Nq;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, block, 0, st, B, nh, Nq, Nk, ldp, (const float*)P, dP, (float*)dS, scale, dist, dsprel_w, dsprel_b),
+             hipLaunchKernelGGL(softmax_bwd_kernel<bf16>, grid, block, 0, st, B, nh, Nq, Nk, ldp, (const bf16*)P, dP, (bf16*)dS, scale, dist, dsprel_w, dsprel_b));
+  return launch_status();
+}
+
+extern "C" int magic_head_mean_fwd(int dtype, int B, int nh, long long inner, const void* P, float* out, void* stream) {
+  if (B <= 0 || nh <= 0 || inner <= 0) return MAGIC_ERR_ARG;
+  long long n = (long long)B * inner;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(head_mean_fwd_kernel<float>, grid, block, 0, st, B, nh, inner, (const float*)P, out),
+             hipLaunchKernelGGL(head_mean_fwd_kernel<bf16>, grid, block, 0, st, B, nh, inner, (const bf16*)P, out));
+  return launch_status();
+}
+
+extern "C" int magic_head_mean_bwd(int B, int nh, long long inner, const float* g, float* dP, int accumulate, void* stream) {
+  if (B <= 0 || nh <= 0 || inner <= 0) return MAGIC_ERR_ARG;
+  long long n = (long long)B * nh * inner;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipLaunchKernelGGL(head_mean_bwd_kernel, grid, block, 0, (hipStream_t)stream, B, nh, inner, g, dP, accumulate);
+  return launch_status();
+}
+
+extern "C" int magic_lndot_fwd(int dtype, int M, int H, const void* Y, const float* gamma, const float* beta, float eps,
+                               const float* w2, const float* b2, float* logit, void* stream) {
+  if (M <= 0 || !okH(H)) return MAGIC_ERR_ARG;
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(lndot_fwd_kernel<float>, grid, block, 0, st, M, H, (const float*)Y, gamma, beta, eps, w2, b2, logit),
+             hipLaunchKernelGGL(lndot_fwd_kernel<bf16>, grid, block, 0, st, M, H, (const bf16*)Y, gamma, beta, eps, w2, b2, logit));
+  return launch_status();
+}
+
+extern "C" int magic_lndot_bwd(int dtype, int M, int H, const void* Y, const float* gamma, const float* beta, float eps,
+                               const float* w2, const float* dlogit, void* dZ, float* dgamma, float* dbeta, float* dw2, float* db2,
+                               void* stream) {
+  if (M <= 0 || !okH(H)) return MAGIC_ERR_ARG;
+  dim3 grid((M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS)), block(256);
+  size_t shm = (size_t)(12 * H + 4) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(lndot_bwd_kernel<float>, grid, block, shm, st, M, H, (const float*)Y, gamma, beta, eps, w2, dlogit, (float*)dZ, dgamma, dbeta, dw2, db2),
+             hipLaunchKernelGGL(lndot_bwd_kernel<bf16>, grid, block, shm, st, M, H, (const bf16*)Y, gamma, beta, eps, w2, dlogit, (bf16*)dZ, dgamma, dbeta, dw2, db2));
+  return launch_status();
+}

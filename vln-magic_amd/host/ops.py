@@ -1,0 +1,234 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per kernel family).
+
+Every function launches hand-written HIP through ctypes on torch's current stream; none of them has a
+torch/CPU fallback.  Shapes are checked on the host before launch (a faulting kernel can take the
+whole GPU node down).  `FLOPS` accumulates the algorithmic dense-contraction FLOPs (2*m*n*k with the
+TRUE, unpadded sizes the caller passes via `flop_dims`) for the roofline report.
+"""
+import torch
+
+from . import lib as L
+
+FLOPS = {"total": 0.0, "enabled": False}
+
+
+def _count(m, n, k, batch=1):
+    if FLOPS["enabled"]:
+        FLOPS["total"] += 2.0 * m * n * k * batch
+
+
+def _chk(cond, msg):
+    if not cond:
+        raise L.MagicHipError("shape check failed: " + msg)
+
+
+def gemm(layout, A, B, C, M, N, K, lda, ldb, ldc, *, batch=1, nh=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
+         bias=None, epilogue=0, aux=None, ldaux=0, residual=None, ldr=0, C2=None, ldc2=0, alpha=1.0,
+         splitk=1, bias_grad=None, accumulate=False, flop_dims=None):
+    dt = L.dt(A.dtype)
+    _chk(A.dtype == B.dtype, "A/B dtype")
+    c_f32 = 1 if C.dtype == torch.float32 else 0
+    fd = flop_dims or (M, N, K)
+    _count(fd[0], fd[1], fd[2], batch)
+    L.call("magic_gemm", dt, layout, batch, nh, M, N, K,
+           L.P(A), lda, sA[0], sA[1], L.P(B), ldb, sB[0], sB[1],
+           L.P(C), ldc, sC[0], sC[1], c_f32, 1 if accumulate else 0,
+           L.P(bias), epilogue, L.P(aux), ldaux, L.P(residual), ldr, L.P(C2), ldc2,
+           float(alpha), splitk, L.P(bias_grad), L.stream())
+
+
+def linear_fwd(x, W, b, M, *, out=None, epilogue=0, residual=None, pre=None, lda=None, ldc=None, ldb=None, K=None,
+               flop_rows=None):
+    """y[M,N] = act(x[M,K] @ W[N,K]^T + b) (+ residual).  x may be a strided row view (lda)."""
+    N = W.shape[0]
+    K = K if K is not None else W.shape[1]
+    ldb = ldb if ldb is not None else W.stride(0)
+    lda = lda if lda is not None else K
+    if out is None:
+        out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    ldc = ldc if ldc is not None else N
+    gemm(0, x, W, out, M, N, K, lda, ldb, ldc, bias=b, epilogue=epilogue,
+         residual=residual, ldr=(ldc if residual is not None else 0), C2=pre, ldc2=N,
+         flop_dims=(flop_rows if flop_rows is not None else M, N, K))
+    return out
+
+
+def linear_dx(dy, W, M, *, out=None, epilogue=0, aux=None, residual=None, lda=None, ldc=None, ldb=None, N=None, K=None,
+              flop_rows=None):
+    """dx[M,K] = dy[M,N] @ W[N,K]  (* act'(aux)) (+ residual)"""
+    N = N if N is not None else W.shape[0]
+    K = K if K is not None else W.shape[1]
+    ldb = ldb if ldb is not None else W.stride(0)
+    lda = lda if lda is not None else N
+    if out is None:
+        out = torch.empty(M, K, dtype=dy.dtype, device=dy.device)
+    ldc = ldc if ldc is not None else K
+    gemm(1, dy, W, out, M, K, N, lda, ldb, ldc, epilogue=epilogue, aux=aux, ldaux=(K if aux is not None else 0),
+         residual=residual, ldr=(ldc if residual is not None else 0),
+         flop_dims=(flop_rows if flop_rows is not None else M, K, N))
+    return out
+
+
+def _splitk(tiles, kred, target=512):
+    ks = max(1, (kred + 63) // 64)
+    return int(max(1, min(target // max(tiles, 1), ks, 64)))
+
+
+def linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None, flop_rows=None):
+    """dW[N,K] += dy[M,N]^T @ x[M,K] ; db[N] += colsum(dy)   (fp32 atomics, split-K over M)"""
+    N = N if N is not None else dW.shape[0]
+    K = K if K is not None else dW.shape[1]
+    lda = lda if lda is not None else N
+    ldb = ldb if ldb is not None else K
+    ldc = ldc if ldc is not None else dW.stride(0)
+    tiles = ((N + 63) // 64) * ((K + 63) // 64)
+    gemm(2, dy, x, dW, N, K, M, lda, ldb, ldc, splitk=_splitk(tiles, M), bias_grad=db, accumulate=True,
+         flop_dims=(N, K, flop_rows if flop_rows is not None else M))
+
+
+def _tab(t):
+    """t = None | (table, idx|None, mod, off)"""
+    if t is None:
+        return (None, None, 0, 0)
+    return (L.P(t[0]), L.P(t[1]), int(t[2]), int(t[3]))
+
+
+def ln_fwd(M, H, out, *, in0=None, in1=None, tabs=(None, None, None), gamma=None, beta=None, eps=1e-12, rstd=None, do_ln=True):
+    t0, t1, t2 = [_tab(t) for t in tabs]
+    L.call("magic_ln_fwd", L.dt(out.dtype), M, H, L.P(in0), L.P(in1), *t0, *t1, *t2,
+           L.P(gamma), L.P(beta), float(eps), L.P(out), L.P(rstd), 1 if do_ln else 0, L.stream())
+    return out
+
+
+def _dtab(t):
+    """t = None | (idx|None, mod, off, dtab_fp32, small)"""
+    if t is None:
+        return (None, 0, 0, None, 0)
+    return (L.P(t[0]), int(t[1]), int(t[2]), L.P(t[3]), int(t[4]))
+
+
+def ln_bwd(M, H, dy, *, y=None, gamma=None, beta=None, rstd=None, dx=None, dgamma=None, dbeta=None,
+           dtabs=(None, None, None), do_ln=True):
+    d0, d1, d2 = [_dtab(t) for t in dtabs]
+    L.call("magic_ln_bwd", L.dt(dy.dtype), M, H, L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(dx),
+           L.P(dgamma), L.P(dbeta), *d0, *d1, *d2, 1 if do_ln else 0, L.stream())
+    return dx
+
+
+def smallk_ln_fwd(M, H, Kin, x, W, b, gamma, beta, eps, out, rstd):
+    _chk(x.dtype == torch.float32 and x.is_contiguous(), "smallk x fp32 contiguous")
+    L.call("magic_smallk_ln_fwd", L.dt(out.dtype), M, H, Kin, L.P(x), L.P(W), L.P(b), L.P(gamma), L.P(beta), float(eps),
+           L.P(out), L.P(rstd), L.stream())
+    return out
+
+
+def smallk_ln_bwd(M, H, Kin, x, dy, y, gamma, beta, rstd, dW, db, dgamma, dbeta):
+    L.call("magic_smallk_ln_bwd", L.dt(dy.dtype), M, H, Kin, L.P(x), L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(rstd),
+           L.P(dW), L.P(db), L.P(dgamma), L.P(dbeta), L.stream())
+
+
+def softmax_fwd(S, Pout, B, nh, Nq, Nk, ldp, scale, kmask=None, dist=None, sprel_w=None, sprel_b=None):
+    _chk(S.dtype == torch.float32 and S.numel() >= B * nh * Nq * ldp and Pout.numel() >= B * nh * Nq * ldp, "softmax buffers")
+    L.call("magic_softmax_fwd", L.dt(Pout.dtype), B, nh, Nq, Nk, ldp, L.P(S), L.P(Pout), float(scale), L.P(kmask), L.P(dist),
+           L.P(sprel_w), L.P(sprel_b), L.stream())
+
+
+def softmax_bwd(Pm, dP, dS, B, nh, Nq, Nk, ldp, scale, dist=None, dsprel_w=None, dsprel_b=None):
+    L.call("magic_softmax_bwd", L.dt(Pm.dtype), B, nh, Nq, Nk, ldp, L.P(Pm), L.P(dP), L.P(dS), float(scale), L.P(dist),
+           L.P(dsprel_w), L.P(dsprel_b), L.stream())
+
+
+def head_mean_fwd(Pm, out, B, nh, inner):
+    L.call("magic_head_mean_fwd", L.dt(Pm.dtype), B, nh, inner, L.P(Pm), L.P(out), L.stream())
+
+
+def head_mean_bwd(g, dP, B, nh, inner, accumulate=False):
+    L.call("magic_head_mean_bwd", B, nh, inner, L.P(g), L.P(dP), 1 if accumulate else 0, L.stream())
+
+
+def lndot_fwd(Y, M, H, gamma, beta, eps, w2, b2, logit):
+    L.call("magic_lndot_fwd", L.dt(Y.dtype), M, H, L.P(Y), L.P(gamma), L.P(beta), float(eps), L.P(w2), L.P(b2), L.P(logit), L.stream())
+
+
+def lndot_bwd(Y, M, H, gamma, beta, eps, w2, dlogit, dZ, dgamma, dbeta, dw2, db2):
+    L.call("magic_lndot_bwd", L.dt(Y.dtype), M, H, L.P(Y), L.P(gamma), L.P(beta), float(eps), L.P(w2), L.P(dlogit), L.P(dZ),
+           L.P(dgamma), L.P(dbeta), L.P(dw2), L.P(db2), L.stream())
+
+
+def ce_rows(logits, M, N, ld, labels, *, ignore_index=-100, coef=0.0, row_w=None, loss_row=None, dlogits=None, ldd=0,
+            accumulate=False, w_out=None, w_rate=0.0):
+    _chk(labels.dtype == torch.int32, "labels int32")
+    L.call("magic_ce_rows", L.dt(logits.dtype), M, N, L.P(logits), ld, L.P(labels), ignore_index, float(coef), L.P(row_w),
+           L.P(loss_row), L.P(dlogits), ldd, 1 if accumulate else 0, L.P(w_out), float(w_rate), L.stream())
+
+
+def kd_rows(s, t, M, N, ld, temperature, *, w=None, norm=1.0, coef=0.0, loss_row=None, ds=None, accumulate=False):
+    _chk(s.dtype == torch.float32 and t.dtype == torch.float32, "kd logits fp32")
+    L.call("magic_kd_rows", M, N, L.P(s), L.P(t), ld, float(temperature), L.P(w), float(norm), float(coef), L.P(loss_row),
+           L.P(ds), 1 if accumulate else 0, L.stream())
+
+
+def mse(s, t, outer, inner, s_stride, t_stride, *, w=None, rows_per_w=1, norm=1.0, coef=0.0, loss=None, ds=None, g_stride=0,
+        accumulate=False):
+    _chk(s.dtype == t.dtype, "mse dtypes")
+    g_f32 = 1 if (ds is not None and ds.dtype == torch.float32) else 0
+    if s.dtype == torch.float32:
+        g_f32 = 1
+    L.call("magic_mse", L.dt(s.dtype), g_f32, outer, inner, L.P(s), s_stride, L.P(t), t_stride, L.P(w), rows_per_w, float(norm),
+           float(coef), L.P(loss), L.P(ds), g_stride, 1 if accumulate else 0, L.stream())
+
+
+def csr_gather(src, ptr, idx, w, out, n_out, H, accumulate=False):
+    _chk(ptr.dtype == torch.int32 and idx.dtype == torch.int32 and ptr.numel() == n_out + 1, "csr arrays")
+    L.call("magic_csr_gather", L.dt(src.dtype), n_out, H, L.P(src), L.P(ptr), L.P(idx), L.P(w), L.P(out), 1 if accumulate else 0,
+           L.stream())
+
+
+def pano_fuse_fwd(x, lens, wf, bf, fused, probs, N, V, H):
+    L.call("magic_pano_fuse_fwd", L.dt(x.dtype), N, V, H, L.P(x), L.P(lens), L.P(wf), L.P(bf), L.P(fused), L.P(probs), L.stream())
+
+
+def pano_fuse_bwd(x, probs, wf, dfused, dx, dwf, dbf, N, V, H):
+    L.call("magic_pano_fuse_bwd", L.dt(x.dtype), N, V, H, L.P(x), L.P(probs), L.P(wf), L.P(dfused), L.P(dx), L.P(dwf), L.P(dbf),
+           L.stream())
+
+
+def sap_fuse_fwd(B, K, Vp, g_raw, l_raw, fuse_raw, gmask, lmask, fsrc, bwmask, use_gate, gl, ll, fl):
+    L.call("magic_sap_fuse_fwd", B, K, Vp, L.P(g_raw), L.P(l_raw), L.P(fuse_raw), L.P(gmask), L.P(lmask), L.P(fsrc), L.P(bwmask),
+           1 if use_gate else 0, L.P(gl), L.P(ll), L.P(fl), L.stream())
+
+
+def sap_fuse_bwd(B, K, Vp, g_raw, l_raw, fuse_raw, gmask, lmask, fsrc, bwmask, use_gate, dgl, dll, dfl, dg_raw, dl_raw, dfuse_raw):
+    L.call("magic_sap_fuse_bwd", B, K, Vp, L.P(g_raw), L.P(l_raw), L.P(fuse_raw), L.P(gmask), L.P(lmask), L.P(fsrc), L.P(bwmask),
+           1 if use_gate else 0, L.P(dgl), L.P(dll), L.P(dfl), L.P(dg_raw), L.P(dl_raw), L.P(dfuse_raw), L.stream())
+
+
+def sumsq(g, out):
+    L.call("magic_sumsq", g.numel(), L.P(g), L.P(out), L.stream())
+
+
+def adamw(n, p, g, m, v, shadow, lr, b1, b2, eps, wd, step_size, sumsq_buf, max_norm, gscale):
+    L.call("magic_adamw", n, L.P(p), L.P(g), L.P(m), L.P(v), L.P(shadow), float(lr), float(b1), float(b2), float(eps), float(wd),
+           float(step_size), L.P(sumsq_buf), float(max_norm), float(gscale), L.stream())
+
+
+def cast_to(x, dtype, out=None):
+    """fp32 <-> bf16 conversion kernel (no-op if dtypes agree)."""
+    if x.dtype == dtype:
+        return x
+    if out is None:
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    L.call("magic_cast", 1 if dtype == torch.bfloat16 else 0, x.numel(), L.P(x), L.P(out), L.stream())
+    return out
+
+
+def add_(y, x):
+    L.call("magic_add", L.dt(y.dtype), y.numel(), L.P(x), L.P(y), L.stream())
+    return y
+
+
+def dact(dy, z, kind, out=None):
+    if out is None:
+        out = torch.empty_like(dy)
+    L.call("magic_dact", L.dt(dy.dtype), kind, dy.numel(), L.P(dy), L.P(z), L.P(out), L.stream())
+    return out

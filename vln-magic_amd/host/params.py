@@ -1,0 +1,123 @@
+"""Flat parameter storage.
+
+Every parameter of a model lives in ONE contiguous fp32 buffer (`flat`), with congruent buffers for
+gradients, Adam moments and (bf16 mode) the bf16 shadow weights the MFMA kernels read.  nn.Parameters
+are views into `flat`, named exactly as the reference's checkpoint keys (SURVEY App. A.4;
+train_r2r_magic.py:189-208), so state_dict()/load_state_dict()/named_parameters() behave as for an
+ordinary module while the optimizer and the gradient all-reduce see single large buffers.
+Layout: [weight-decay group | no-decay group], the split following optim/misc.py:13-22 by name.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+ALIGN = 64           # elements; keeps every tensor 256-byte aligned in fp32 and 128-byte in bf16
+NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")      # optim/misc.py:14
+
+
+def is_no_decay(name):
+    return any(nd in name for nd in NO_DECAY)
+
+
+def _attach(root, dotted, param):
+    mod = root
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        if not hasattr(mod, p) or not isinstance(getattr(mod, p), nn.Module):
+            mod.add_module(p, nn.Module())
+        mod = getattr(mod, p)
+    mod.register_parameter(parts[-1], param)
+
+
+class ParamStore:
+    def __init__(self, specs, device, compute_dtype, init_std=0.02, seed=0, requires_grad=True):
+        """specs: ordered list of (name, shape, kind) with kind in {'normal','zeros','ones'}."""
+        self.device, self.compute_dtype = torch.device(device), compute_dtype
+        self.specs = list(specs)
+        order = [s for s in self.specs if not is_no_decay(s[0])] + [s for s in self.specs if is_no_decay(s[0])]
+        self.offsets, off = {}, 0
+        self.n_decay = None
+        for name, shape, _ in order:
+            if self.n_decay is None and is_no_decay(name):
+                self.n_decay = off
+            n = int(math.prod(shape))
+            self.offsets[name] = (off, n, tuple(shape))
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+        if self.n_decay is None:
+            self.n_decay = off
+        self.total = off
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.requires_grad = requires_grad
+        if requires_grad:
+            self.grad = torch.zeros_like(self.flat)
+            self.m = torch.zeros_like(self.flat)
+            self.v = torch.zeros_like(self.flat)
+        else:
+            self.grad = self.m = self.v = None
+        self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device) \
+            if compute_dtype == torch.bfloat16 else self.flat
+        self.shadow_clean = False
+        gen = torch.Generator().manual_seed(seed)
+        for name, shape, kind in self.specs:
+            v = self.master(name)
+            if kind == "normal":
+                v.copy_(torch.randn(shape, generator=gen) * init_std)
+            elif kind == "ones":
+                v.fill_(1.0)
+        self.step = 0
+
+    # ---- views ------------------------------------------------------------------------------
+    def _view(self, buf, name):
+        off, n, shape = self.offsets[name]
+        return buf[off:off + n].view(shape)
+
+    def master(self, name):
+        return self._view(self.flat, name)
+
+    def w(self, name):
+        """compute-dtype view (bf16 shadow in bf16 mode, the fp32 master otherwise)"""
+        return self._view(self.shadow, name)
+
+    def g(self, name):
+        return self._view(self.grad, name)
+
+    def w_span(self, first, rows, cols):
+        """[rows, cols] compute-dtype view starting at `first` spanning consecutive tensors (fused QKV)."""
+        off = self.offsets[first][0]
+        return self.shadow[off:off + rows * cols].view(rows, cols)
+
+    def master_span(self, first, n):
+        off = self.offsets[first][0]
+        return self.flat[off:off + n]
+
+    def g_span(self, first, n):
+        off = self.offsets[first][0]
+        return self.grad[off:off + n]
+
+    def contiguous(self, names):
+        """True if the tensors are laid out back to back (no alignment gap)."""
+        for a, b in zip(names[:-1], names[1:]):
+            oa, na, _ = self.offsets[a]
+            if self.offsets[b][0] != oa + na:
+                return False
+        return True
+
+    # ---- module integration -----------------------------------------------------------------
+    def attach_to(self, module):
+        for name, _, _ in self.specs:
+            p = nn.Parameter(self.master(name), requires_grad=self.requires_grad)
+            if self.requires_grad:
+                p.grad = self.g(name)
+            _attach(module, name, p)
+
+    def sync_shadow(self, force=False):
+        if self.compute_dtype != torch.bfloat16:
+            return
+        if force or not self.shadow_clean:
+            from . import lib as L
+            L.call("magic_cast", 1, self.total, L.P(self.flat), L.P(self.shadow), L.stream())
+            self.shadow_clean = True
+
+    def zero_grad(self):
+        self.grad.zero_()

@@ -1,0 +1,128 @@
+"""Host-side batch plan: turns the python-side structure of a collated batch (viewpoint-id lists,
+ragged lengths, masks) into the small int32/uint8 device arrays the kernels consume.
+
+This is the device-friendly restatement of the host loops the withheld model runs per batch
+([LINEAGE] DUET `_aggregate_gmap_features` / `forward_sap` fusion loops; semantics pinned by
+map_nav_src/r2r/agent.py:905-924 and SURVEY App. B.3-B.4): a CSR "averaging matrix" from panorama rows
+to map nodes (and its transpose for the backward), a row-selection CSR for the current viewpoint's
+candidate views, and the local->global logit fusion index map.
+"""
+import numpy as np
+import torch
+
+V = 36
+
+
+def _csr(rows, n_out):
+    """rows: list of (out_row, src_row, weight) -> ptr[n_out+1], idx, w sorted by out_row (stable)."""
+    rows = sorted(rows, key=lambda r: r[0])
+    ptr = np.zeros(n_out + 1, np.int32)
+    for r in rows:
+        ptr[r[0] + 1] += 1
+    ptr = np.cumsum(ptr).astype(np.int32)
+    idx = np.array([r[1] for r in rows], np.int32) if rows else np.zeros(1, np.int32)
+    w = np.array([r[2] for r in rows], np.float32) if rows else np.zeros(1, np.float32)
+    return ptr, idx, w
+
+
+def csr_pair(entries, n_out, n_src):
+    """forward CSR (out <- src) and its transpose (src <- out)."""
+    f = _csr(entries, n_out)
+    t = _csr([(s, o, w) for (o, s, w) in entries], n_src)
+    return f, t
+
+
+def build_plan(batch, task, device, ld_round=8):
+    B = len(batch["traj_step_lens"])
+    L = batch["txt_ids"].shape[1]
+    K = batch["gmap_step_ids"].shape[1]
+    Vp = V + 1
+    step_lens = batch["traj_step_lens"]
+    Np = int(sum(step_lens))
+    cpu = {}
+    cpu["txt_ids"] = batch["txt_ids"].reshape(-1).to(torch.int32)
+    txt_lens = batch["txt_lens"]
+    cpu["txt_mask"] = (torch.arange(L)[None] < txt_lens[:, None]).to(torch.uint8)
+    view_lens = batch["traj_vp_view_lens"]
+    cpu["view_lens"] = view_lens.to(torch.int32)
+    cpu["pano_mask"] = (torch.arange(V)[None] < view_lens[:, None]).to(torch.uint8)
+    cpu["nav_types"] = batch["traj_nav_types"].reshape(-1).to(torch.int32)
+    cpu["gmap_mask"] = (torch.arange(K)[None] < batch["gmap_lens"][:, None]).to(torch.uint8)
+    cpu["gmap_step_ids"] = batch["gmap_step_ids"].reshape(-1).to(torch.int32)
+
+    # ---- map-node aggregation: visited node <- fused pano of its step; unvisited <- mean of cand views
+    e_embed, e_fused = [], []
+    first_row = np.concatenate([[0], np.cumsum(step_lens)]).astype(np.int64)
+    last_rows = first_row[1:] - 1
+    for b in range(B):
+        vis, unv = {}, {}
+        for t in range(step_lens[b]):
+            row = int(first_row[b]) + t
+            vis[batch["traj_vpids"][b][t]] = row
+            for j, c in enumerate(batch["traj_cand_vpids"][b][t]):
+                unv.setdefault(c, []).append(row * V + j)
+        for k, vp in enumerate(batch["gmap_vpids"][b]):
+            if k == 0:
+                continue
+            if vp in vis:
+                e_fused.append((b * K + k, vis[vp], 1.0))
+            else:
+                srcs = unv[vp]
+                for s in srcs:
+                    e_embed.append((b * K + k, s, 1.0 / len(srcs)))
+    plan_csr = {}
+    plan_csr["gmap_from_embed"] = csr_pair(e_embed, B * K, Np * V)
+    plan_csr["gmap_from_fused"] = csr_pair(e_fused, B * K, Np)
+    # ---- current-viewpoint tokens: [stop] + the last step's 36 views
+    e_vp = []
+    for b in range(B):
+        for j in range(V):
+            e_vp.append((b * Vp + 1 + j, int(last_rows[b]) * V + j, 1.0))
+    plan_csr["vp_from_embed"] = csr_pair(e_vp, B * Vp, Np * V)
+    vp_lens = view_lens[torch.from_numpy(last_rows)] + 1
+    cpu["vp_mask"] = (torch.arange(Vp)[None] < vp_lens[:, None]).to(torch.uint8)
+    # ---- first-token (CLS / [stop]) row selections
+    plan_csr["g0"] = csr_pair([(b, b * K, 1.0) for b in range(B)], B, B * K)
+    plan_csr["v0"] = csr_pair([(b, b * Vp, 1.0) for b in range(B)], B, B * Vp)
+    plan_csr["t0"] = csr_pair([(b, b * L, 1.0) for b in range(B)], B, B * L)
+
+    if task in ("sap", "cfp"):
+        visited = batch["gmap_visited_masks"]
+        cpu["gmask"] = ((~visited) & cpu["gmap_mask"].bool()).to(torch.uint8)
+        nav_last = batch["traj_nav_types"][torch.from_numpy(last_rows)] == 1
+        cpu["lmask"] = torch.cat([torch.ones(B, 1, dtype=torch.bool), nav_last], 1).to(torch.uint8)
+        fsrc = np.full((B, K), -1, np.int32)
+        bwmask = np.zeros((B, Vp), np.uint8)
+        for b in range(B):
+            vis_set = set(vp for j, vp in enumerate(batch["gmap_vpids"][b]) if bool(visited[b, j]))
+            tmp = {}
+            for j, c in enumerate(batch["traj_cand_vpids"][b][-1]):
+                if c in vis_set:
+                    bwmask[b, j + 1] = 1
+                else:
+                    tmp[c] = j + 1
+            fsrc[b, 0] = 0
+            for j, vp in enumerate(batch["gmap_vpids"][b]):
+                if j > 0 and vp not in vis_set:
+                    fsrc[b, j] = tmp[vp] if vp in tmp else -2
+        cpu["fsrc"] = torch.from_numpy(fsrc)
+        cpu["bwmask"] = torch.from_numpy(bwmask)
+        cpu["global_act_labels"] = batch["global_act_labels"].to(torch.int32)
+        cpu["local_act_labels"] = batch["local_act_labels"].to(torch.int32)
+        cpu["arange_b"] = torch.arange(B, dtype=torch.int32)
+    if task == "mlm":
+        lab = batch["txt_labels"].reshape(-1)
+        sel = torch.nonzero(lab != -1).reshape(-1)
+        n_mask = int(sel.numel())
+        plan_csr["mlm_rows"] = csr_pair([(i, int(r), 1.0) for i, r in enumerate(sel.tolist())], n_mask, B * L)
+        cpu["mlm_labels"] = lab[sel].to(torch.int32)
+
+    plan = {k: v.to(device, non_blocking=True) for k, v in cpu.items()}
+    for name, (f, t) in plan_csr.items():
+        plan[name] = tuple(torch.from_numpy(a).to(device, non_blocking=True) for a in f)
+        plan[name + "_T"] = tuple(torch.from_numpy(a).to(device, non_blocking=True) for a in t)
+    plan.update(B=B, L=L, K=K, Vp=Vp, Np=Np, V=V, last_rows=last_rows,
+                n_mask=(int(plan["mlm_labels"].numel()) if task == "mlm" else 0),
+                txt_tokens=int(txt_lens.sum()), gmap_nodes=int(batch["gmap_lens"].sum()), traj_steps=Np,
+                lens=dict(txt=txt_lens.tolist(), gmap=batch["gmap_lens"].tolist(), steps=list(step_lens)))
+    return plan

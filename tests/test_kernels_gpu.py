@@ -128,19 +128,19 @@ def test_ln_fwd_bwd_with_tables(dtype, H):
     for case in ("text", "image", "sum"):
         if case == "text":
             tabs = ((word, ids, 0, 0), (pos, None, L_, 2), (typ, None, 0, 0))
-            leaves = [t.float().requires_grad_(True) for t in (word, pos, typ)]
+            leaves = [t.float().clone().requires_grad_(True) for t in (word, pos, typ)]
             rows = torch.arange(M, device=DEV) % L_ + 2
             x = leaves[0][ids.long()] + leaves[1][rows] + leaves[2][0]
             dense = None
         elif case == "image":
             tabs = ((nav, navi, 0, 0), (typ, None, 0, 0), None)
-            leaves = [t.float().requires_grad_(True) for t in (nav, typ)]
-            dense = in0.float().requires_grad_(True)
+            leaves = [t.float().clone().requires_grad_(True) for t in (nav, typ)]
+            dense = in0.float().clone().requires_grad_(True)
             x = dense + leaves[0][navi.long()] + leaves[1][0]
         else:
             tabs = ((word, ids, 0, 0), None, None)
-            leaves = [word.float().requires_grad_(True)]
-            dense = in0.float().requires_grad_(True)
+            leaves = [word.float().clone().requires_grad_(True)]
+            dense = in0.float().clone().requires_grad_(True)
             x = dense + leaves[0][ids.long()]
         do_ln = case != "sum"
         g32, b32 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)

@@ -1,0 +1,175 @@
+"""End-to-end parity of the HIP engine against the CPU oracle on identical weights and batches (-m gpu).
+
+fp32 ("parity") mode: forward tensors, every loss term and every parameter gradient must agree with the
+oracle's autograd to fp32 tolerance; action argmax must be identical.  bf16 mode: same checks to
+bf16-sized tolerances.  North-star bar (BASELINE.json): action-logit |delta| < 1e-3, argmax bit-exact."""
+import pytest
+import torch
+
+import magic_amd  # noqa: F401
+from magic_amd.host import synth
+from magic_amd.host.config import make_config
+from magic_amd.host.model_pretrain import GlocalTextPathCMTPreTraining
+from magic_amd.host.trainer import PretrainStep
+from oracle import model_ref as R
+from oracle import optim_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+KDL = dict(knowledge_distillation=True, kd_alpha=0.5, kd_temperature=2, teacher_sample_hard_mining=True,
+           t_sample_preprocess_exp_decay=0.7, rw_temp=4,
+           kdl_tasks=["txt", "img", "local", "global", "predict"], kdl_task_types=["emb", "attn"])
+RW = [1.3, 0.7, 1.1, 0.9, 1.0]
+
+
+def cfgs(vocab=600, layers=(2, 1, 1)):
+    kw = dict(vocab_size=vocab, num_l_layers=layers[0], num_x_layers=layers[1], num_pano_layers=layers[2])
+    t = make_config(256, role="teacher", **kw)
+    s = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL, **kw)
+    return t, s
+
+
+def build(dtype, seed=0, **kw):
+    tcfg, scfg = cfgs(**kw)
+    torch.manual_seed(seed)
+    o_t, o_s = R.RefPretrainModel(tcfg).eval(), R.RefPretrainModel(scfg).eval()
+    # make biases / LN params non-trivial so their gradients and uses are exercised
+    with torch.no_grad():
+        for m in (o_t, o_s):
+            for n, p in m.named_parameters():
+                if n.endswith("bias"):
+                    p.normal_(0, 0.02)
+                if "LayerNorm.weight" in n or "layer_norm.weight" in n or n.endswith("net.2.weight") or n.endswith("embeddings.1.weight"):
+                    p.add_(torch.randn_like(p) * 0.05)
+    g_t = GlocalTextPathCMTPreTraining.from_pretrained(None, config=tcfg, state_dict=o_t.state_dict(), device=DEV, compute_dtype=dtype)
+    g_s = GlocalTextPathCMTPreTraining.from_pretrained(None, config=scfg, state_dict=o_s.state_dict(), device=DEV, compute_dtype=dtype)
+    return o_t, o_s, g_t, g_s
+
+
+def close(got, want, name, rtol, atol):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, f"{name}: {got.shape} vs {want.shape}"
+    err = (got - want).abs().max().item()
+    assert torch.allclose(got, want, rtol=rtol, atol=atol), f"{name}: max|err| {err:.3e} (ref max {want.abs().max().item():.3e})"
+
+
+def view_outputs(o, plan, H):
+    B, L, K, Vp, Np = plan["B"], plan["L"], plan["K"], plan["Vp"], plan["Np"]
+    d = dict(txt_embeds=o["txt_embeds"].view(B, L, H), txt_attns=o["txt_attns"][..., :L],
+             pano_embeds=o["pano_embeds"].view(Np, 36, H), pano_fused_embeds=o["pano_fused_embeds"], img_attns=o["img_attns"][..., :36])
+    if "vp_embeds" in o:
+        d.update(gmap_embeds=o["gmap_embeds"].view(B, K, H), gmap_attns=o["gmap_attns"][..., :L],
+                 vp_embeds=o["vp_embeds"].view(B, Vp, H), vp_attns=o["vp_attns"][..., :L])
+    elif "gmap_embeds" in o:
+        d.update(gmap_embeds=o["gmap_embeds"].view(B, L, H), gmap_attns=o["gmap_attns"][..., :K])
+    return d
+
+
+@pytest.mark.parametrize("task", ["sap", "mlm", "cfp"])
+def test_fp32_forward_loss_and_gradients_match_oracle(task):
+    o_t, o_s, g_t, g_s = build(torch.float32)
+    batch = synth.make_batch(task, batch_size=6, seed=21, vocab=600, min_len=8, max_len=19, min_steps=2, max_steps=4)
+    rw = torch.tensor(RW)
+    with torch.no_grad():
+        ot = o_t(batch, task, compute_loss=True)["outputs"]
+    want = o_s(batch, task, compute_loss=True, teacher_outputs=ot, rw=rw)
+    want["loss"].backward()
+    with torch.no_grad():
+        gt = g_t(batch, task, compute_loss=False, return_outputs=True)
+    plan = gt["plan"]
+    for k, v in view_outputs(gt, plan, 256).items():
+        close(v, ot[k], f"teacher {k}", 2e-4, 2e-5)
+    g_s.store.zero_grad()
+    got = g_s(batch, task, compute_loss=True, teacher_outputs=gt, rw=RW, plan=plan)
+    for k, v in view_outputs(got["outputs"], plan, 128).items():
+        close(v, want["outputs"][k], f"student {k}", 2e-4, 2e-5)
+    if task == "sap":
+        for k in ("global_logits", "local_logits", "fused_logits"):
+            a, b = got["outputs"][k].cpu(), want["outputs"][k]
+            assert torch.equal(torch.isinf(a), torch.isinf(b)), k
+            close(torch.nan_to_num(a, neginf=0), torch.nan_to_num(b, neginf=0), k, 1e-4, 1e-5)     # << 1e-3 north-star bar
+            assert torch.equal(a.argmax(1), b.argmax(1)), f"{k} argmax"
+    elif task == "mlm":
+        close(got["outputs"]["predict"], want["outputs"]["predict"], "mlm logits", 1e-4, 2e-5)
+        assert torch.equal(got["outputs"]["predict"].argmax(1).cpu(), want["outputs"]["predict"].argmax(1))
+    else:
+        for a, b in zip(got["outputs"]["cfp"], want["outputs"]["cfp"]):
+            close(a, b, "cfp outputs", 1e-4, 2e-5)
+    close(got["supervised_loss"], want["supervised_loss"], "supervised loss", 1e-4, 1e-6)
+    for k, v in want["kdl_terms"].items():
+        close(got["kdl_terms"][k], v, f"kd term {k}", 2e-4, 1e-7)
+    close(got["loss"], want["loss"], "total loss", 1e-4, 1e-6)
+    got["loss"].backward()              # the unmodified-loop path: autograd hook -> explicit HIP backward
+    torch.cuda.synchronize()
+    params = dict(g_s.named_parameters())
+    n_checked = 0
+    for name, p in o_s.named_parameters():
+        g = params[name].grad
+        if p.grad is None:
+            assert g.abs().max().item() == 0.0, f"{name}: oracle has no grad, engine wrote {g.abs().max().item():.3e}"
+            continue
+        scale = max(p.grad.abs().max().item(), 1e-6)
+        close(g, p.grad, f"grad {name}", 2e-3, 2e-4 * scale + 1e-8)
+        n_checked += 1
+    assert n_checked > 40
+
+
+@pytest.mark.parametrize("task", ["sap", "mlm", "cfp"])
+def test_bf16_tracks_oracle(task):
+    o_t, o_s, g_t, g_s = build(torch.bfloat16)
+    batch = synth.make_batch(task, batch_size=8, seed=5, vocab=600, min_len=8, max_len=19, min_steps=2, max_steps=4)
+    with torch.no_grad():
+        ot = o_t(batch, task, compute_loss=True)["outputs"]
+    want = o_s(batch, task, compute_loss=True, teacher_outputs=ot, rw=torch.tensor(RW))
+    want["loss"].backward()
+    with torch.no_grad():
+        gt = g_t(batch, task, compute_loss=False, return_outputs=True)
+    g_s.store.zero_grad()
+    got = g_s(batch, task, compute_loss=True, teacher_outputs=gt, rw=RW, plan=gt["plan"])
+    g_s.backward()
+    torch.cuda.synchronize()
+    close(got["loss"], want["loss"], "bf16 total loss", 3e-2, 1e-3)
+    if task == "sap":
+        a, b = got["outputs"]["fused_logits"].cpu(), want["outputs"]["fused_logits"]
+        close(torch.nan_to_num(a, neginf=0), torch.nan_to_num(b, neginf=0), "bf16 fused logits", 5e-2, 2e-2)
+    # gradient direction: cosine similarity of the whole flat gradient vs the oracle's
+    params = dict(g_s.named_parameters())
+    num = den_a = den_b = 0.0
+    for name, p in o_s.named_parameters():
+        if p.grad is None:
+            continue
+        g = params[name].grad.float().cpu()
+        num += (g * p.grad).sum().item()
+        den_a += (g * g).sum().item()
+        den_b += (p.grad * p.grad).sum().item()
+    cos = num / (den_a ** 0.5 * den_b ** 0.5)
+    assert cos > 0.98, f"bf16 gradient cosine vs oracle {cos:.4f}"
+
+
+def test_train_steps_follow_oracle_optimizer_fp32():
+    """3 optimizer steps (sap, mlm, cfp) of the fused trainer vs oracle model + oracle AdamW + clip."""
+    o_t, o_s, g_t, g_s = build(torch.float32)
+    trainer = PretrainStep(g_s, g_t, lr=1e-3, warmup_steps=2, num_train_steps=10, grad_norm=5.0)
+    names = [n for n, _ in o_s.named_parameters()]
+    from magic_amd.host.params import is_no_decay
+    wds = [0.0 if is_no_decay(n) else 0.01 for n in names]
+    state = optim_ref.adamw_init([p.data for p in o_s.parameters()])
+    for step, task in enumerate(["sap", "mlm", "cfp"]):
+        batch = synth.make_batch(task, batch_size=4, seed=77, step=step, vocab=600, min_len=8, max_len=15, min_steps=2, max_steps=3)
+        with torch.no_grad():
+            ot = o_t(batch, task, compute_loss=True)["outputs"]
+        for p in o_s.parameters():
+            p.grad = None
+        w = o_s(batch, task, compute_loss=True, teacher_outputs=ot, rw=torch.tensor(RW))
+        w["loss"].backward()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in o_s.parameters()]
+        optim_ref.clip_grad_norm(grads, 5.0)
+        lr = optim_ref.get_lr_sched(step, 1e-3, 2, 10)
+        with torch.no_grad():
+            optim_ref.adamw_step([p.data for p in o_s.parameters()], grads, state, lr=lr, betas=(0.9, 0.98), eps=1e-6, weight_decay=wds)
+        out = trainer.step(batch, task, rw=RW)
+        close(out["loss"], w["loss"], f"step {step} loss", 2e-4, 1e-6)
+    torch.cuda.synchronize()
+    got = g_s.state_dict()
+    for n, p in o_s.named_parameters():
+        close(got[n], p.data, f"param after 3 steps {n}", 2e-3, 2e-5)

@@ -1,0 +1,467 @@
+"""Explicit forward/backward of the MAGIC trunk on the HIP kernels (no autograd tape).
+
+Architecture = the oracle's restatement (oracle/model_ref.py): RoBERTa-token
+text encoder (post-LN BERT blocks), 36-view panorama encoder, global (map) and local (viewpoint) METER
+co-attention encoders.  Each segment has fwd(...)->Ctx and bwd(Ctx, grads); saved activations are plain
+torch tensors owned by the caching allocator; every arithmetic op is a C-ABI kernel launch (host/ops.py).
+Parameter gradients are accumulated (fp32 atomics) into the flat gradient buffer of the ParamStore.
+"""
+import math
+from types import SimpleNamespace as Ctx
+
+import torch
+
+from . import ops as O
+from .config import cfg_get
+
+HD = 64  # head dim (heads = H/64: train_r2r_magic.py:143,157)
+
+
+def rup(x, m=8):
+    return (x + m - 1) // m * m
+
+
+def self_layer_specs(p, H, I):
+    s = []
+    for n in ("query", "key", "value"):
+        s.append((f"{p}attention.self.{n}.weight", (H, H), "normal"))
+    for n in ("query", "key", "value"):
+        s.append((f"{p}attention.self.{n}.bias", (H,), "zeros"))
+    s += [(f"{p}attention.output.dense.weight", (H, H), "normal"), (f"{p}attention.output.dense.bias", (H,), "zeros"),
+          (f"{p}attention.output.LayerNorm.weight", (H,), "ones"), (f"{p}attention.output.LayerNorm.bias", (H,), "zeros")]
+    return s
+
+
+def ffn_specs(p, H, I):
+    return [(f"{p}intermediate.dense.weight", (I, H), "normal"), (f"{p}intermediate.dense.bias", (I,), "zeros"),
+            (f"{p}output.dense.weight", (H, I), "normal"), (f"{p}output.dense.bias", (H,), "zeros"),
+            (f"{p}output.LayerNorm.weight", (H,), "ones"), (f"{p}output.LayerNorm.bias", (H,), "zeros")]
+
+
+def cross_layer_specs(p, H, I):
+    s = self_layer_specs(p, H, I)
+    for n in ("query", "key", "value"):
+        s.append((f"{p}crossattention.self.{n}.weight", (H, H), "normal"))
+    for n in ("query", "key", "value"):
+        s.append((f"{p}crossattention.self.{n}.bias", (H,), "zeros"))
+    s += [(f"{p}crossattention.output.dense.weight", (H, H), "normal"), (f"{p}crossattention.output.dense.bias", (H,), "zeros"),
+          (f"{p}crossattention.output.LayerNorm.weight", (H,), "ones"), (f"{p}crossattention.output.LayerNorm.bias", (H,), "zeros")]
+    return s + ffn_specs(p, H, I)
+
+
+def cls_specs(p, H, inp=None):
+    return [(f"{p}net.0.weight", (H, inp or H), "normal"), (f"{p}net.0.bias", (H,), "zeros"),
+            (f"{p}net.2.weight", (H,), "ones"), (f"{p}net.2.bias", (H,), "zeros"),
+            (f"{p}net.3.weight", (1, H), "normal"), (f"{p}net.3.bias", (1,), "zeros")]
+
+
+def trunk_specs(cfg, p="bert."):
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    af = cfg_get(cfg, "angle_feat_size")
+    s = [(f"{p}embeddings.word_embeddings.weight", (cfg.vocab_size, H), "normal"),
+         (f"{p}embeddings.position_embeddings.weight", (cfg.max_position_embeddings, H), "normal"),
+         (f"{p}embeddings.token_type_embeddings.weight", (cfg.type_vocab_size, H), "normal"),
+         (f"{p}embeddings.LayerNorm.weight", (H,), "ones"), (f"{p}embeddings.LayerNorm.bias", (H,), "zeros")]
+    for i in range(cfg.num_l_layers):
+        s += self_layer_specs(f"{p}lang_encoder.layer.{i}.", H, I) + ffn_specs(f"{p}lang_encoder.layer.{i}.", H, I)
+    q = f"{p}img_embeddings."
+    s += [(q + "img_linear.weight", (H, cfg.image_feat_size), "normal"), (q + "img_linear.bias", (H,), "zeros"),
+          (q + "img_layer_norm.weight", (H,), "ones"), (q + "img_layer_norm.bias", (H,), "zeros"),
+          (q + "loc_linear.weight", (H, af + 3), "normal"), (q + "loc_linear.bias", (H,), "zeros"),
+          (q + "loc_layer_norm.weight", (H,), "ones"), (q + "loc_layer_norm.bias", (H,), "zeros"),
+          (q + "nav_type_embedding.weight", (3, H), "normal"),
+          (q + "layer_norm.weight", (H,), "ones"), (q + "layer_norm.bias", (H,), "zeros")]
+    for i in range(cfg.num_pano_layers):
+        s += self_layer_specs(f"{q}pano_encoder.layer.{i}.", H, I) + ffn_specs(f"{q}pano_encoder.layer.{i}.", H, I)
+    s += [(q + "pano_fuse_linear.weight", (1, H), "normal"), (q + "pano_fuse_linear.bias", (1,), "zeros")]
+    g = f"{p}global_encoder."
+    s += [(g + "gmap_pos_embeddings.0.weight", (H, af + 3), "normal"), (g + "gmap_pos_embeddings.0.bias", (H,), "zeros"),
+          (g + "gmap_pos_embeddings.1.weight", (H,), "ones"), (g + "gmap_pos_embeddings.1.bias", (H,), "zeros"),
+          (g + "gmap_step_embeddings.weight", (cfg.max_action_steps, H), "normal"),
+          (g + "sprel_linear.weight", (1, 1), "normal"), (g + "sprel_linear.bias", (1,), "zeros")]
+    for i in range(cfg.num_x_layers):
+        s += cross_layer_specs(f"{g}encoder.crossattention.{i}.", H, I)
+    l = f"{p}local_encoder."
+    s += [(l + "vp_pos_embeddings.0.weight", (H, 2 * af + 6), "normal"), (l + "vp_pos_embeddings.0.bias", (H,), "zeros"),
+          (l + "vp_pos_embeddings.1.weight", (H,), "ones"), (l + "vp_pos_embeddings.1.bias", (H,), "zeros")]
+    for i in range(cfg.num_x_layers):
+        s += cross_layer_specs(f"{l}encoder.crossattention.{i}.", H, I)
+    Ht = getattr(cfg, "teacher_hidden_size", None)
+    if Ht:
+        for n in ("txt_emb_w", "kdl_img_w", "kdl_avg_img_w", "global_cross_w", "local_cross_w"):   # agent_base.py:330
+            s += [(f"{p}{n}.weight", (Ht, H), "normal"), (f"{p}{n}.bias", (Ht,), "zeros")]
+    return s
+
+
+class Lin:
+    """handle on one nn.Linear living in the ParamStore (optionally a span of fused consecutive tensors)."""
+
+    def __init__(self, store, wname, bname, rows=None, cols=None):
+        off, n, shape = store.offsets[wname]
+        rows = rows or shape[0]
+        cols = cols or shape[1]
+        self.W = store.w_span(wname, rows, cols)
+        self.b = store.master_span(bname, rows)
+        self.Wm = store.master_span(wname, rows * cols).view(rows, cols)
+        if store.requires_grad:
+            self.dW = store.g_span(wname, rows * cols).view(rows, cols)
+            self.db = store.g_span(bname, rows)
+        self.N, self.K = rows, cols
+
+
+class LN:
+    def __init__(self, store, wname, bname):
+        self.g, self.b = store.master(wname), store.master(bname)
+        if store.requires_grad:
+            self.dg, self.db = store.g(wname), store.g(bname)
+
+
+class MagicNet:
+    def __init__(self, cfg, store, prefix="bert."):
+        self.cfg, self.S, self.p = cfg, store, prefix
+        self.H, self.I = cfg.hidden_size, cfg.intermediate_size
+        self.nh = cfg.num_attention_heads
+        assert self.H == self.nh * HD, "heads = H/64"
+        self.eps = cfg.layer_norm_eps
+        self.dtype = store.compute_dtype
+        self.train = store.requires_grad
+        self._cache = {}
+
+    # ---- parameter handle cache ---------------------------------------------------------------
+    def lin(self, w, b=None, rows=None, cols=None):
+        key = ("lin", w, rows, cols)
+        if key not in self._cache:
+            self._cache[key] = Lin(self.S, w, b or w[:-len("weight")] + "bias", rows, cols)
+        return self._cache[key]
+
+    def ln(self, base):
+        key = ("ln", base)
+        if key not in self._cache:
+            self._cache[key] = LN(self.S, base + ".weight", base + ".bias")
+        return self._cache[key]
+
+    def new(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.dtype, device=self.S.device)
+
+    def zeros(self, *shape, dtype=None):
+        return torch.zeros(*shape, dtype=dtype or self.dtype, device=self.S.device)
+
+    # ---- attention core -----------------------------------------------------------------------
+    def _attn_fwd(self, q, ldq, k, v, ldkv, Bn, Nq, Nk, kmask, dist, sprel, flops):
+        nh, H = self.nh, self.H
+        ldp = rup(Nk)
+        S = self.new(Bn, nh, Nq, ldp, dtype=torch.float32)
+        O.gemm(0, q, k, S, Nq, Nk, HD, ldq, ldkv, ldp, batch=Bn * nh, nh=nh, sA=(Nq * ldq, HD), sB=(Nk * ldkv, HD),
+               sC=(nh * Nq * ldp, Nq * ldp), flop_dims=(1, 1, flops / nh))
+        Pm = self.new(Bn, nh, Nq, ldp)
+        O.softmax_fwd(S, Pm, Bn, nh, Nq, Nk, ldp, 1.0 / math.sqrt(HD), kmask=kmask, dist=dist,
+                      sprel_w=sprel[0] if sprel else None, sprel_b=sprel[1] if sprel else None)
+        ctx = self.new(Bn * Nq, H)
+        O.gemm(1, Pm, v, ctx, Nq, HD, Nk, ldp, ldkv, H, batch=Bn * nh, nh=nh, sA=(nh * Nq * ldp, Nq * ldp), sB=(Nk * ldkv, HD),
+               sC=(Nq * H, HD), flop_dims=(1, 1, flops / nh))
+        return Pm, ctx, ldp
+
+    def _attn_bwd(self, Pm, ldp, d_ctx, q, ldq, k, v, ldkv, dq, lddq, dk, dv, lddkv, Bn, Nq, Nk, dist, dsprel, dP_init, flops):
+        nh, H = self.nh, self.H
+        fd = (1, 1, flops / nh)
+        sP = (nh * Nq * ldp, Nq * ldp)
+        # dV = P^T dO
+        O.gemm(2, Pm, d_ctx, dv, Nk, HD, Nq, ldp, H, lddkv, batch=Bn * nh, nh=nh, sA=sP, sB=(Nq * H, HD), sC=(Nk * lddkv, HD), flop_dims=fd)
+        # dP = dO V^T (+ KD gradient already sitting in dP_init)
+        dP = dP_init if dP_init is not None else self.new(Bn, nh, Nq, ldp, dtype=torch.float32)
+        O.gemm(0, d_ctx, v, dP, Nq, Nk, HD, H, ldkv, ldp, batch=Bn * nh, nh=nh, sA=(Nq * H, HD), sB=(Nk * ldkv, HD), sC=sP,
+               residual=dP if dP_init is not None else None, ldr=ldp, flop_dims=fd)
+        dS = self.new(Bn, nh, Nq, ldp)
+        O.softmax_bwd(Pm, dP, dS, Bn, nh, Nq, Nk, ldp, 1.0 / math.sqrt(HD), dist=dist,
+                      dsprel_w=dsprel[0] if dsprel else None, dsprel_b=dsprel[1] if dsprel else None)
+        # dQ = dS K ; dK = dS^T Q
+        O.gemm(1, dS, k, dq, Nq, HD, Nk, ldp, ldkv, lddq, batch=Bn * nh, nh=nh, sA=sP, sB=(Nk * ldkv, HD), sC=(Nq * lddq, HD), flop_dims=fd)
+        O.gemm(2, dS, q, dk, Nk, HD, Nq, ldp, ldq, lddkv, batch=Bn * nh, nh=nh, sA=sP, sB=(Nq * ldq, HD), sC=(Nk * lddkv, HD), flop_dims=fd)
+
+    # ---- self-attention + add&norm -------------------------------------------------------------
+    def _sa_fwd(self, lp, x, Bn, N, kmask, dist, sprel, rows, aflops):
+        H = self.H
+        M = Bn * N
+        c = Ctx(x=x, Bn=Bn, N=N, rows=rows, aflops=aflops, dist=dist)
+        qkv = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
+        c.qkv = O.linear_fwd(x, qkv.W, qkv.b, M, flop_rows=rows)
+        c.P, c.ctx, c.ldp = self._attn_fwd(c.qkv, 3 * H, c.qkv[:, H:], c.qkv[:, 2 * H:], 3 * H, Bn, N, N, kmask, dist, sprel, aflops)
+        o = self.lin(lp + "attention.output.dense.weight")
+        ao = O.linear_fwd(c.ctx, o.W, o.b, M, residual=x, flop_rows=rows)
+        n = self.ln(lp + "attention.output.LayerNorm")
+        c.a, c.rstd_a = self.new(M, H), self.new(M, dtype=torch.float32)
+        O.ln_fwd(M, H, c.a, in0=ao, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_a)
+        return c
+
+    def _sa_bwd(self, lp, c, d_a, dsprel=None, dP_init=None):
+        H, Bn, N = self.H, c.Bn, c.N
+        M = Bn * N
+        n = self.ln(lp + "attention.output.LayerNorm")
+        d_ao = self.new(M, H)
+        O.ln_bwd(M, H, d_a, y=c.a, gamma=n.g, beta=n.b, rstd=c.rstd_a, dx=d_ao, dgamma=n.dg, dbeta=n.db)
+        o = self.lin(lp + "attention.output.dense.weight")
+        O.linear_dw(d_ao, c.ctx, o.dW, o.db, M, flop_rows=c.rows)
+        d_ctx = O.linear_dx(d_ao, o.W, M, flop_rows=c.rows)
+        dqkv = self.new(M, 3 * H)
+        self._attn_bwd(c.P, c.ldp, d_ctx, c.qkv, 3 * H, c.qkv[:, H:], c.qkv[:, 2 * H:], 3 * H,
+                       dqkv, 3 * H, dqkv[:, H:], dqkv[:, 2 * H:], 3 * H, Bn, N, N, c.dist, dsprel, dP_init, c.aflops)
+        qkv = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
+        O.linear_dw(dqkv, c.x, qkv.dW, qkv.db, M, flop_rows=c.rows)
+        return O.linear_dx(dqkv, qkv.W, M, residual=d_ao, flop_rows=c.rows)
+
+    # ---- FFN + add&norm ------------------------------------------------------------------------
+    def _ffn_fwd(self, lp, a, M, rows):
+        H, I = self.H, self.I
+        c = Ctx(a=a, M=M, rows=rows)
+        f1, f2 = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")
+        c.z = self.new(M, I)
+        c.g = O.linear_fwd(a, f1.W, f1.b, M, epilogue=1, pre=c.z, flop_rows=rows)
+        fo = O.linear_fwd(c.g, f2.W, f2.b, M, residual=a, flop_rows=rows)
+        n = self.ln(lp + "output.LayerNorm")
+        c.out, c.rstd = self.new(M, H), self.new(M, dtype=torch.float32)
+        O.ln_fwd(M, H, c.out, in0=fo, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd)
+        return c
+
+    def _ffn_bwd(self, lp, c, dout):
+        H, M = self.H, c.M
+        n = self.ln(lp + "output.LayerNorm")
+        d_fo = self.new(M, H)
+        O.ln_bwd(M, H, dout, y=c.out, gamma=n.g, beta=n.b, rstd=c.rstd, dx=d_fo, dgamma=n.dg, dbeta=n.db)
+        f1, f2 = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")
+        O.linear_dw(d_fo, c.g, f2.dW, f2.db, M, flop_rows=c.rows)
+        d_z = O.linear_dx(d_fo, f2.W, M, epilogue=3, aux=c.z, flop_rows=c.rows)
+        O.linear_dw(d_z, c.a, f1.dW, f1.db, M, flop_rows=c.rows)
+        return O.linear_dx(d_z, f1.W, M, residual=d_fo, flop_rows=c.rows)
+
+    # ---- layers --------------------------------------------------------------------------------
+    def self_layer_fwd(self, lp, x, Bn, N, kmask, rows, aflops):
+        c = Ctx()
+        c.sa = self._sa_fwd(lp, x, Bn, N, kmask, None, None, rows, aflops)
+        c.ffn = self._ffn_fwd(lp, c.sa.a, Bn * N, rows)
+        c.out, c.P, c.ldp = c.ffn.out, c.sa.P, c.sa.ldp
+        return c
+
+    def self_layer_bwd(self, lp, c, dout, dP_init=None):
+        d_a = self._ffn_bwd(lp, c.ffn, dout)
+        return self._sa_bwd(lp, c.sa, d_a, None, dP_init)
+
+    def cross_layer_fwd(self, lp, x, Bn, Nq, kmask, dist, sprel, ctx, Nk, ckmask, rows, crow, sflops, cflops):
+        H = self.H
+        Mq, Mk = Bn * Nq, Bn * Nk
+        c = Ctx(Bn=Bn, Nq=Nq, Nk=Nk, ctx=ctx, rows=rows, crow=crow, cflops=cflops)
+        c.sa = self._sa_fwd(lp, x, Bn, Nq, kmask, dist, sprel, rows, sflops)
+        s = c.sa.a
+        ql = self.lin(lp + "crossattention.self.query.weight")
+        kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
+        c.q = O.linear_fwd(s, ql.W, ql.b, Mq, flop_rows=rows)
+        c.kv = O.linear_fwd(ctx, kvl.W, kvl.b, Mk, flop_rows=crow)
+        c.P, c.cctx, c.ldp = self._attn_fwd(c.q, H, c.kv, c.kv[:, H:], 2 * H, Bn, Nq, Nk, ckmask, None, None, cflops)
+        o = self.lin(lp + "crossattention.output.dense.weight")
+        co = O.linear_fwd(c.cctx, o.W, o.b, Mq, residual=s, flop_rows=rows)
+        n = self.ln(lp + "crossattention.output.LayerNorm")
+        c.c, c.rstd_c = self.new(Mq, H), self.new(Mq, dtype=torch.float32)
+        O.ln_fwd(Mq, H, c.c, in0=co, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_c)
+        c.ffn = self._ffn_fwd(lp, c.c, Mq, rows)
+        c.out = c.ffn.out
+        return c
+
+    def cross_layer_bwd(self, lp, c, dout, d_ctx_acc, dsprel=None, dP_init=None):
+        """returns dx; accumulates the gradient wrt the context (other modality) into d_ctx_acc."""
+        H, Bn, Nq, Nk = self.H, c.Bn, c.Nq, c.Nk
+        Mq, Mk = Bn * Nq, Bn * Nk
+        d_c = self._ffn_bwd(lp, c.ffn, dout)
+        n = self.ln(lp + "crossattention.output.LayerNorm")
+        d_co = self.new(Mq, H)
+        O.ln_bwd(Mq, H, d_c, y=c.c, gamma=n.g, beta=n.b, rstd=c.rstd_c, dx=d_co, dgamma=n.dg, dbeta=n.db)
+        o = self.lin(lp + "crossattention.output.dense.weight")
+        O.linear_dw(d_co, c.cctx, o.dW, o.db, Mq, flop_rows=c.rows)
+        d_cctx = O.linear_dx(d_co, o.W, Mq, flop_rows=c.rows)
+        dq, dkv = self.new(Mq, H), self.new(Mk, 2 * H)
+        self._attn_bwd(c.P, c.ldp, d_cctx, c.q, H, c.kv, c.kv[:, H:], 2 * H, dq, H, dkv, dkv[:, H:], 2 * H,
+                       Bn, Nq, Nk, None, None, dP_init, c.cflops)
+        ql = self.lin(lp + "crossattention.self.query.weight")
+        kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
+        O.linear_dw(dq, c.sa.a, ql.dW, ql.db, Mq, flop_rows=c.rows)
+        d_s = O.linear_dx(dq, ql.W, Mq, residual=d_co, flop_rows=c.rows)
+        O.linear_dw(dkv, c.ctx, kvl.dW, kvl.db, Mk, flop_rows=c.crow)
+        O.linear_dx(dkv, kvl.W, Mk, out=d_ctx_acc, residual=d_ctx_acc, flop_rows=c.crow)
+        return self._sa_bwd(lp, c.sa, d_s, dsprel, None)
+
+    # ---- text encoder --------------------------------------------------------------------------
+    def _flops_attn(self, lens_q, lens_k):
+        return float(sum(a * b for a, b in zip(lens_q, lens_k))) * HD * self.nh
+
+    def text_fwd(self, plan):
+        p, H = self.p, self.H
+        B, L = plan["B"], plan["L"]
+        M = B * L
+        c = Ctx(B=B, L=L)
+        n = self.ln(p + "embeddings.LayerNorm")
+        c.E, c.rstd_e = self.new(M, H), self.new(M, dtype=torch.float32)
+        O.ln_fwd(M, H, c.E, tabs=((self.S.w(p + "embeddings.word_embeddings.weight"), plan["txt_ids"], 0, 0),
+                                  (self.S.w(p + "embeddings.position_embeddings.weight"), None, L, 2),
+                                  (self.S.w(p + "embeddings.token_type_embeddings.weight"), None, 0, 0)),
+                 gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_e)
+        x = c.E
+        c.layers = []
+        tl = plan["lens"]["txt"]
+        af = self._flops_attn(tl, tl)
+        for i in range(self.cfg.num_l_layers):
+            lc = self.self_layer_fwd(f"{p}lang_encoder.layer.{i}.", x, B, L, plan["txt_mask"], plan["txt_tokens"], af)
+            c.layers.append(lc)
+            x = lc.out
+        c.out, c.P, c.ldp = x, c.layers[-1].P, c.layers[-1].ldp
+        return c
+
+    def text_bwd(self, c, plan, d_out, dP_init=None):
+        p, H = self.p, self.H
+        M = c.B * c.L
+        d = d_out
+        for i in reversed(range(self.cfg.num_l_layers)):
+            d = self.self_layer_bwd(f"{p}lang_encoder.layer.{i}.", c.layers[i], d, dP_init if i == self.cfg.num_l_layers - 1 else None)
+        n = self.ln(p + "embeddings.LayerNorm")
+        O.ln_bwd(M, H, d, y=c.E, gamma=n.g, beta=n.b, rstd=c.rstd_e, dx=None, dgamma=n.dg, dbeta=n.db,
+                 dtabs=((plan["txt_ids"], 0, 0, self.S.g(p + "embeddings.word_embeddings.weight"), 0),
+                        (None, c.L, 2, self.S.g(p + "embeddings.position_embeddings.weight"), 0),
+                        (None, 0, 0, self.S.g(p + "embeddings.token_type_embeddings.weight"), 0)))
+
+    # ---- panorama encoder ----------------------------------------------------------------------
+    def pano_fwd(self, plan, feats, loc):
+        """feats [Np*V, D] compute dtype; loc [Np*V, 7] fp32."""
+        p, H = self.p + "img_embeddings.", self.H
+        Np, V = plan["Np"], plan["V"]
+        M = Np * V
+        c = Ctx(Np=Np, V=V, feats=feats, loc=loc)
+        il = self.lin(p + "img_linear.weight")
+        P0 = O.linear_fwd(feats, il.W, il.b, M)
+        n1 = self.ln(p + "img_layer_norm")
+        c.A1, c.rstd_a1 = self.new(M, H), self.new(M, dtype=torch.float32)
+        O.ln_fwd(M, H, c.A1, in0=P0, gamma=n1.g, beta=n1.b, eps=self.eps, rstd=c.rstd_a1)
+        ll, n2 = self.lin(p + "loc_linear.weight"), self.ln(p + "loc_layer_norm")
+        c.A2, c.rstd_a2 = self.new(M, H), self.new(M, dtype=torch.float32)
+        O.smallk_ln_fwd(M, H, ll.K, loc, ll.Wm, ll.b, n2.g, n2.b, self.eps, c.A2, c.rstd_a2)
+        n3 = self.ln(p + "layer_norm")
+        c.X0, c.rstd_x0 = self.new(M, H), self.new(M, dtype=torch.float32)
+        O.ln_fwd(M, H, c.X0, in0=c.A1, in1=c.A2,
+                 tabs=((self.S.w(p + "nav_type_embedding.weight"), plan["nav_types"], 0, 0),
+                       (self.S.w(self.p + "embeddings.token_type_embeddings.weight"), None, 0, 0), None),
+                 gamma=n3.g, beta=n3.b, eps=self.eps, rstd=c.rstd_x0)
+        x = c.X0
+        c.layers = []
+        af = float(Np) * V * V * HD * self.nh
+        for i in range(self.cfg.num_pano_layers):
+            lc = self.self_layer_fwd(f"{p}pano_encoder.layer.{i}.", x, Np, V, plan["pano_mask"], M, af)
+            c.layers.append(lc)
+            x = lc.out
+        c.out, c.P, c.ldp = x, c.layers[-1].P, c.layers[-1].ldp
+        c.img_attn = self.new(Np, V, c.ldp, dtype=torch.float32)
+        O.head_mean_fwd(c.P, c.img_attn, Np, self.nh, V * c.ldp)
+        c.fused = self.new(Np, H)
+        if cfg_get(self.cfg, "adaptive_pano_fusion"):
+            fl = self.lin(p + "pano_fuse_linear.weight")
+            c.fprobs = self.new(Np, V, dtype=torch.float32)
+            O.pano_fuse_fwd(c.out, plan["view_lens"], fl.Wm, fl.b, c.fused, c.fprobs, Np, V, H)
+        else:
+            raise NotImplementedError("masked-mean panorama fusion (adaptive_pano_fusion=false) is not built yet")
+        return c
+
+    def pano_bwd(self, c, plan, d_pano, d_fused, dP_init=None):
+        p, H = self.p + "img_embeddings.", self.H
+        Np, V = c.Np, c.V
+        M = Np * V
+        if d_fused is not None:
+            fl = self.lin(p + "pano_fuse_linear.weight")
+            O.pano_fuse_bwd(c.out, c.fprobs, fl.Wm, d_fused, d_pano, fl.dW, fl.db, Np, V, H)
+        d = d_pano
+        for i in reversed(range(self.cfg.num_pano_layers)):
+            d = self.self_layer_bwd(f"{p}pano_encoder.layer.{i}.", c.layers[i], d, dP_init if i == self.cfg.num_pano_layers - 1 else None)
+        n3 = self.ln(p + "layer_norm")
+        dsum = self.new(M, H)
+        O.ln_bwd(M, H, d, y=c.X0, gamma=n3.g, beta=n3.b, rstd=c.rstd_x0, dx=dsum, dgamma=n3.dg, dbeta=n3.db,
+                 dtabs=((plan["nav_types"], 0, 0, self.S.g(p + "nav_type_embedding.weight"), 1),
+                        (None, 0, 0, self.S.g(self.p + "embeddings.token_type_embeddings.weight"), 0), None))
+        n1 = self.ln(p + "img_layer_norm")
+        dP0 = self.new(M, H)
+        O.ln_bwd(M, H, dsum, y=c.A1, gamma=n1.g, beta=n1.b, rstd=c.rstd_a1, dx=dP0, dgamma=n1.dg, dbeta=n1.db)
+        il = self.lin(p + "img_linear.weight")
+        O.linear_dw(dP0, c.feats, il.dW, il.db, M)
+        ll, n2 = self.lin(p + "loc_linear.weight"), self.ln(p + "loc_layer_norm")
+        O.smallk_ln_bwd(M, H, ll.K, c.loc, dsum, c.A2, n2.g, n2.b, c.rstd_a2, ll.dW, ll.db, n2.dg, n2.db)
+
+    # ---- map / viewpoint inputs ----------------------------------------------------------------
+    def gmap_in_fwd(self, plan, pano, gmap_pos_fts):
+        g, H = self.p + "global_encoder.", self.H
+        B, K = plan["B"], plan["K"]
+        M = B * K
+        c = Ctx(pos=gmap_pos_fts)
+        gimg = self.new(M, H)
+        O.csr_gather(pano.out, *plan["gmap_from_embed"], gimg, M, H)
+        O.csr_gather(pano.fused, *plan["gmap_from_fused"], gimg, M, H, accumulate=True)
+        pl, pn = self.lin(g + "gmap_pos_embeddings.0.weight"), self.ln(g + "gmap_pos_embeddings.1")
+        c.A, c.rstd = self.new(M, H), self.new(M, dtype=torch.float32)
+        O.smallk_ln_fwd(M, H, pl.K, gmap_pos_fts, pl.Wm, pl.b, pn.g, pn.b, self.eps, c.A, c.rstd)
+        c.out = self.new(M, H)
+        O.ln_fwd(M, H, c.out, in0=gimg, in1=c.A, tabs=((self.S.w(g + "gmap_step_embeddings.weight"), plan["gmap_step_ids"], 0, 0), None, None),
+                 do_ln=False)
+        return c
+
+    def gmap_in_bwd(self, c, plan, d_in, d_pano, d_fused):
+        g, H = self.p + "global_encoder.", self.H
+        M = plan["B"] * plan["K"]
+        O.ln_bwd(M, H, d_in, dx=None, do_ln=False,
+                 dtabs=((plan["gmap_step_ids"], 0, 0, self.S.g(g + "gmap_step_embeddings.weight"), 0), None, None))
+        pl, pn = self.lin(g + "gmap_pos_embeddings.0.weight"), self.ln(g + "gmap_pos_embeddings.1")
+        O.smallk_ln_bwd(M, H, pl.K, c.pos, d_in, c.A, pn.g, pn.b, c.rstd, pl.dW, pl.db, pn.dg, pn.db)
+        O.csr_gather(d_in, *plan["gmap_from_embed_T"], d_pano, plan["Np"] * plan["V"], H, accumulate=True)
+        O.csr_gather(d_in, *plan["gmap_from_fused_T"], d_fused, plan["Np"], H, accumulate=True)
+
+    def vp_in_fwd(self, plan, pano, vp_pos_fts):
+        l, H = self.p + "local_encoder.", self.H
+        M = plan["B"] * plan["Vp"]
+        c = Ctx(pos=vp_pos_fts)
+        vimg = self.new(M, H)
+        O.csr_gather(pano.out, *plan["vp_from_embed"], vimg, M, H)
+        pl, pn = self.lin(l + "vp_pos_embeddings.0.weight"), self.ln(l + "vp_pos_embeddings.1")
+        c.A, c.rstd = self.new(M, H), self.new(M, dtype=torch.float32)
+        O.smallk_ln_fwd(M, H, pl.K, vp_pos_fts, pl.Wm, pl.b, pn.g, pn.b, self.eps, c.A, c.rstd)
+        c.out = self.new(M, H)
+        O.ln_fwd(M, H, c.out, in0=vimg, in1=c.A, do_ln=False)
+        return c
+
+    def vp_in_bwd(self, c, plan, d_in, d_pano):
+        l, H = self.p + "local_encoder.", self.H
+        M = plan["B"] * plan["Vp"]
+        pl, pn = self.lin(l + "vp_pos_embeddings.0.weight"), self.ln(l + "vp_pos_embeddings.1")
+        O.smallk_ln_bwd(M, H, pl.K, c.pos, d_in, c.A, pn.g, pn.b, c.rstd, pl.dW, pl.db, pn.dg, pn.db)
+        O.csr_gather(d_in, *plan["vp_from_embed_T"], d_pano, plan["Np"] * plan["V"], H, accumulate=True)
+
+    # ---- cross-modal encoders ------------------------------------------------------------------
+    def _sprel(self):
+        g = self.p + "global_encoder."
+        if not cfg_get(self.cfg, "graph_sprels"):
+            return None, None
+        w, b = self.S.master(g + "sprel_linear.weight"), self.S.master(g + "sprel_linear.bias")
+        dw = (self.S.g(g + "sprel_linear.weight"), self.S.g(g + "sprel_linear.bias")) if self.train else None
+        return (w, b), dw
+
+    def cross_fwd(self, which, plan, x, Nq, qmask, qlens, qrows, ctx, Nk, kmask, klens, krows, dist=None):
+        enc = self.p + ("global_encoder." if which == "global" else "local_encoder.")
+        B = plan["B"]
+        sprel, _ = self._sprel() if (which == "global" and dist is not None) else (None, None)
+        c = Ctx(which=which, layers=[], dist=dist)
+        sf, cf = self._flops_attn(qlens, qlens), self._flops_attn(qlens, klens)
+        for i in range(self.cfg.num_x_layers):
+            lc = self.cross_layer_fwd(f"{enc}encoder.crossattention.{i}.", x, B, Nq, qmask, dist, sprel, ctx, Nk, kmask, qrows, krows, sf, cf)
+            c.layers.append(lc)
+            x = lc.out
+        c.out, c.P, c.ldp = x, c.layers[-1].P, c.layers[-1].ldp
+        return c
+
+    def cross_bwd(self, c, d_out, d_ctx_acc, dP_init=None):
+        enc = self.p + ("global_encoder." if c.which == "global" else "local_encoder.")
+        _, dsprel = self._sprel() if (c.which == "global" and c.dist is not None) else (None, None)
+        d = d_out
+        nl = self.cfg.num_x_layers
+        for i in reversed(range(nl)):
+            d = self.cross_layer_bwd(f"{enc}encoder.crossattention.{i}.", c.layers[i], d, d_ctx_acc, dsprel, dP_init if i == nl - 1 else None)
+        return d

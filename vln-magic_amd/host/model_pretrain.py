@@ -1,0 +1,418 @@
+"""`GlocalTextPathCMTPreTraining` -- the pretraining model the reference imports from its withheld
+`model.pretrain_goat` (pretrain_src/train_r2r_magic.py:40) -- rebuilt on the HIP engine.
+
+Call surface kept: `from_pretrained(None, config=..., state_dict=...)`, `.train()/.eval()`,
+`model(batch, task=..., compute_loss=...)`, `state_dict()` / `named_parameters()` with the checkpoint key
+names of SURVEY App. A.4.  Return contract per task: train_r2r_magic.py:440-587 (validate_*).
+With `compute_loss=True` the forward also evaluates the supervised loss and the in-model MAKD terms
+(against `teacher_outputs`) and seeds the explicit backward; `loss.backward()` (or `model.backward()`)
+then runs the hand-written backward and leaves the gradients in `param.grad` (views of one flat buffer).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops as O
+from .config import cfg_get
+from .engine import Ctx, MagicNet, cls_specs, rup, trunk_specs
+from .params import ParamStore
+from .plan import build_plan
+
+KD_SLOTS = ("txt_emb_loss", "txt_attn_loss", "img_emb_loss", "avg_img_emb_loss", "img_attn_loss",
+            "global_emb_loss", "global_attn_loss", "local_emb_loss", "local_attn_loss", "predict_loss")
+
+
+def pretrain_specs(cfg):
+    H = cfg.hidden_size
+    s = trunk_specs(cfg, "bert.")
+    s += [("mlm_head.predictions.transform.dense.weight", (H, H), "normal"), ("mlm_head.predictions.transform.dense.bias", (H,), "zeros"),
+          ("mlm_head.predictions.transform.LayerNorm.weight", (H,), "ones"), ("mlm_head.predictions.transform.LayerNorm.bias", (H,), "zeros"),
+          ("mlm_head.predictions.bias", (cfg.vocab_size,), "zeros")]
+    s += cls_specs("global_sap_head.", H) + cls_specs("local_sap_head.", H) + cls_specs("sap_fuse_linear.", H, 2 * H)
+    for k in ("gmap", "vp", "fused", "txt"):
+        s += [(f"cfp_heads.{k}.weight", (H, H), "normal"), (f"cfp_heads.{k}.bias", (H,), "zeros")]
+    return s
+
+
+class _BackwardHook(torch.autograd.Function):
+    """Lets `loss.backward()` of an unmodified training loop trigger the explicit HIP backward."""
+
+    @staticmethod
+    def forward(ctx, loss_value, anchor, model):
+        ctx.model = model
+        return loss_value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model.backward()
+        return None, None, None
+
+
+class GlocalTextPathCMTPreTraining(nn.Module):
+    def __init__(self, config, device="cuda", compute_dtype=torch.bfloat16, seed=0):
+        super().__init__()
+        self.config = config
+        self.device_ = torch.device(device)
+        self.compute_dtype = compute_dtype
+        trainable = getattr(config, "role", "student") != "teacher" or bool(getattr(config, "train_teacher", False))
+        self.store = ParamStore(pretrain_specs(config), device, compute_dtype,
+                                init_std=cfg_get(config, "initializer_range"), seed=seed, requires_grad=trainable)
+        self.store.attach_to(self)
+        self.net = MagicNet(config, self.store, "bert.")
+        self._anchor = torch.zeros(1, device=self.device_, requires_grad=True)
+        self._ctx = None
+        self.register_load_state_dict_post_hook(lambda m, k: setattr(m.store, "shadow_clean", False))
+
+    # ---- HF-style constructor (train_r2r_magic.py:260-277) ------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, config=None, state_dict=None, **kw):
+        model = cls(config, **kw)
+        if state_dict is not None:
+            own = model.state_dict()
+            keep = {k: v for k, v in state_dict.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
+            model.load_state_dict(keep, strict=False)      # unmatched keys are silently ignored, as HF does
+        return model
+
+    def mark_params_dirty(self):
+        self.store.shadow_clean = False
+
+    # ---- helpers --------------------------------------------------------------------------------------
+    def _dev(self, t, dtype=None):
+        t = t.to(self.device_, non_blocking=True)
+        return t if dtype is None or t.dtype == dtype else t.to(dtype)
+
+    def _inputs(self, batch, plan):
+        Np, V = plan["Np"], plan["V"]
+        x = self._dev(batch["traj_view_img_fts"]).reshape(Np * V, -1)
+        if x.dtype != self.compute_dtype:
+            x = O.cast_to(x.contiguous(), self.compute_dtype)
+        return Ctx(feats=x,
+                   loc=self._dev(batch["traj_loc_fts"], torch.float32).reshape(Np * V, -1).contiguous(),
+                   gpos=self._dev(batch["gmap_pos_fts"], torch.float32).reshape(plan["B"] * plan["K"], -1).contiguous(),
+                   vpos=self._dev(batch["vp_pos_fts"], torch.float32).reshape(plan["B"] * plan["Vp"], -1).contiguous(),
+                   dist=self._dev(batch["gmap_pair_dists"], torch.float32).contiguous())
+
+    def _cls(self, prefix, X, M, lda=None):
+        """ClsPrediction forward: returns (Y=relu(linear), logit)"""
+        n, H = self.net, self.net.H
+        l1 = n.lin(prefix + "net.0.weight")
+        Y = O.linear_fwd(X, l1.W, l1.b, M, epilogue=2, lda=lda)
+        ln = n.ln(prefix + "net.2")
+        l2 = n.lin(prefix + "net.3.weight")
+        logit = n.new(M, dtype=torch.float32)
+        O.lndot_fwd(Y, M, H, ln.g, ln.b, n.eps, l2.Wm, l2.b, logit)
+        return Y, logit
+
+    def _cls_bwd(self, prefix, X, Y, dlogit, M, d_acc, lda=None):
+        n, H = self.net, self.net.H
+        l1, ln, l2 = n.lin(prefix + "net.0.weight"), n.ln(prefix + "net.2"), n.lin(prefix + "net.3.weight")
+        dZ = n.new(M, H)
+        O.lndot_bwd(Y, M, H, ln.g, ln.b, n.eps, l2.Wm, dlogit, dZ, ln.dg, ln.db, l2.dW, l2.db)
+        O.linear_dw(dZ, X, l1.dW, l1.db, M, ldb=lda)
+        O.linear_dx(dZ, l1.W, M, out=d_acc, residual=d_acc, ldc=lda)
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    def forward(self, batch, task, compute_loss=True, teacher_outputs=None, rw=None, plan=None, return_outputs=False, inputs=None):
+        n = self.net
+        self.store.sync_shadow()
+        plan = plan if plan is not None else build_plan(batch, task, self.device_)
+        inp = inputs if inputs is not None else self._inputs(batch, plan)
+        B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H
+        c = Ctx(task=task, plan=plan, inp=inp)
+        c.txt = n.text_fwd(plan)
+        c.pano = n.pano_fwd(plan, inp.feats, inp.loc)
+        c.gin = n.gmap_in_fwd(plan, c.pano, inp.gpos)
+        tl, gl_, vl = plan["lens"]["txt"], plan["lens"]["gmap"], [Vp] * B
+        o = dict(txt_embeds=c.txt.out, txt_attns=c.txt.P, pano_embeds=c.pano.out, pano_fused_embeds=c.pano.fused,
+                 img_attns=c.pano.img_attn, plan=plan, inputs=inp)
+        if task == "mlm":
+            c.l2v = n.cross_fwd("global", plan, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"],
+                                c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"], dist=None)
+            o["gmap_embeds"], o["gmap_attns"] = c.l2v.out, c.l2v.P
+            nm = plan["n_mask"]
+            c.hm_in = n.new(nm, H)
+            O.csr_gather(c.l2v.out, *plan["mlm_rows"], c.hm_in, nm, H)
+            t = n.lin("mlm_head.predictions.transform.dense.weight")
+            c.tz = n.new(nm, H)
+            c.tg = O.linear_fwd(c.hm_in, t.W, t.b, nm, epilogue=1, pre=c.tz)
+            tn = n.ln("mlm_head.predictions.transform.LayerNorm")
+            c.hm, c.rstd_hm = n.new(nm, H), n.new(nm, dtype=torch.float32)
+            O.ln_fwd(nm, H, c.hm, in0=c.tg, gamma=tn.g, beta=tn.b, eps=n.eps, rstd=c.rstd_hm)
+            Vv = self.config.vocab_size
+            c.ldv = rup(Vv, 8)
+            c.logits = n.new(nm, c.ldv)
+            if c.ldv > Vv:
+                c.logits[:, Vv:].zero_()
+            O.linear_fwd(c.hm, self.store.w("bert.embeddings.word_embeddings.weight"), self.store.master("mlm_head.predictions.bias"),
+                         nm, out=c.logits, ldc=c.ldv)
+            o["predict"] = c.logits[:, :Vv]
+        else:
+            c.glob = n.cross_fwd("global", plan, c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"],
+                                 c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], dist=inp.dist)
+            c.vin = n.vp_in_fwd(plan, c.pano, inp.vpos)
+            c.loc = n.cross_fwd("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp,
+                                c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
+            o.update(gmap_embeds=c.glob.out, gmap_attns=c.glob.P, vp_embeds=c.loc.out, vp_attns=c.loc.P)
+            if task == "sap":
+                c.Yg, c.g_raw = self._cls("global_sap_head.", c.glob.out, B * K)
+                c.Yl, c.l_raw = self._cls("local_sap_head.", c.loc.out, B * Vp)
+                use_gate = bool(cfg_get(self.config, "glocal_fuse"))
+                if use_gate:
+                    f1 = n.lin("sap_fuse_linear.net.0.weight")
+                    tmp = O.linear_fwd(c.glob.out, f1.W, None, B, lda=K * H, ldb=2 * H, K=H)
+                    c.Yf = O.linear_fwd(c.loc.out, f1.W[:, H:], f1.b, B, lda=Vp * H, ldb=2 * H, K=H, residual=tmp, epilogue=0)
+                    self._relu(c.Yf)      # ReLU after the two partial products are summed
+                    fln, f2 = n.ln("sap_fuse_linear.net.2"), n.lin("sap_fuse_linear.net.3.weight")
+                    c.fuse_raw = n.new(B, dtype=torch.float32)
+                    O.lndot_fwd(c.Yf, B, H, fln.g, fln.b, n.eps, f2.Wm, f2.b, c.fuse_raw)
+                else:
+                    c.fuse_raw = n.zeros(B, dtype=torch.float32)
+                c.use_gate = use_gate
+                c.gl, c.ll, c.fl = n.new(B, K, dtype=torch.float32), n.new(B, Vp, dtype=torch.float32), n.new(B, K, dtype=torch.float32)
+                O.sap_fuse_fwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, plan["gmask"], plan["lmask"], plan["fsrc"], plan["bwmask"],
+                               use_gate, c.gl, c.ll, c.fl)
+                o.update(global_logits=c.gl, local_logits=c.ll, fused_logits=c.fl)
+            elif task == "cfp":
+                c.g0, c.v0, c.t0, c.gv0 = n.new(B, H), n.new(B, H), n.new(B, H), n.new(B, H)
+                O.csr_gather(c.glob.out, *plan["g0"], c.g0, B, H)
+                O.csr_gather(c.loc.out, *plan["v0"], c.v0, B, H)
+                O.csr_gather(c.txt.out, *plan["t0"], c.t0, B, H)
+                O.csr_gather(c.glob.out, *plan["g0"], c.gv0, B, H)
+                O.csr_gather(c.loc.out, *plan["v0"], c.gv0, B, H, accumulate=True)
+                c.cfp = []
+                for key, src in (("gmap", c.g0), ("vp", c.v0), ("fused", c.gv0), ("txt", c.t0)):
+                    hl = n.lin(f"cfp_heads.{key}.weight")
+                    c.cfp.append(O.linear_fwd(src, hl.W, hl.b, B))
+                o["cfp"] = tuple(c.cfp)
+            else:
+                raise ValueError(task)
+        if not compute_loss:
+            if return_outputs:
+                return o
+            if task == "mlm":
+                return {"predict": o["predict"]}
+            if task == "sap":
+                return dict(global_logits=c.gl, local_logits=c.ll, fused_logits=c.fl,
+                            global_act_labels=self._dev(batch["global_act_labels"]), local_act_labels=self._dev(batch["local_act_labels"]))
+            return o["cfp"]
+        self._ctx = c
+        out = self._losses(c, o, teacher_outputs, rw)
+        out["outputs"] = o
+        if self.store.requires_grad and torch.is_grad_enabled():
+            out["loss"] = _BackwardHook.apply(out["loss"], self._anchor, self)
+        return out
+
+    def _relu(self, x):
+        # in-place ReLU on a tiny [B,H] head tensor via the activation-derivative kernel: x * relu'(x) == relu(x)
+        return O.dact(x, x, 2, out=x)
+
+    # ---- losses + gradient seeds ------------------------------------------------------------------------
+    def _kd_emb(self, c, slot, s_t, t_t, proj, M, outer, w, coef, d_acc):
+        n = self.net
+        pl = n.lin(f"bert.{proj}.weight")
+        sp = O.linear_fwd(s_t, pl.W, pl.b, M)
+        Ht = pl.N
+        inner = (M // outer) * Ht
+        ds = n.new(M, Ht) if self.store.requires_grad else None
+        O.mse(sp, t_t, outer, inner, inner, inner, w=w, rows_per_w=1, norm=1.0 / (M * Ht), coef=coef,
+              loss=c.slots[slot:slot + 1], ds=ds, g_stride=inner)
+        if ds is not None:
+            O.linear_dw(ds, s_t, pl.dW, pl.db, M)
+            O.linear_dx(ds, pl.W, M, out=d_acc, residual=d_acc)
+
+    def _kd_attn(self, c, slot, sP, tP, Bn, Nq, Nk, ldp, nh_s, nh_t, w, coef):
+        n = self.net
+        hmin = min(nh_s, nh_t)
+        dP = n.zeros(Bn, nh_s, Nq, ldp, dtype=torch.float32) if self.store.requires_grad else None
+        O.mse(sP, tP, Bn, hmin * Nq * ldp, nh_s * Nq * ldp, nh_t * Nq * ldp, w=w, rows_per_w=1,
+              norm=1.0 / (Bn * hmin * Nq * Nk), coef=coef, loss=c.slots[slot:slot + 1], ds=dP, g_stride=nh_s * Nq * ldp)
+        return dP
+
+    def _losses(self, c, o, t, rw):
+        n, cfg, plan, task = self.net, self.config, c.plan, c.task
+        B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H
+        train = self.store.requires_grad
+        kdl = getattr(cfg, "kdl", None)
+        kd = t is not None and kdl is not None
+        alpha = float(kdl["kd_alpha"]) if kd else 0.0
+        sc = 1.0 - alpha
+        c.slots = n.zeros(16, dtype=torch.float32)
+        zz = (lambda *s: n.zeros(*s)) if train else (lambda *s: None)
+        c.d_txt, c.d_pano, c.d_fused = zz(B * L, H), zz(plan["Np"] * plan["V"], H), zz(plan["Np"], H)
+        c.dP_txt = c.dP_pano = c.dP_g = c.dP_l = None
+        res = {}
+        # ---- supervised ------------------------------------------------------------------------------
+        if task == "sap":
+            c.d_gmap, c.d_vp = zz(B * K, H), zz(B * Vp, H)
+            c.rows = n.new(3, B, dtype=torch.float32)
+            c.dgl, c.dll, c.dfl = (n.new(B, K, dtype=torch.float32), n.new(B, Vp, dtype=torch.float32), n.new(B, K, dtype=torch.float32)) \
+                if train else (None, None, None)
+            ga, la = plan["global_act_labels"], plan["local_act_labels"]
+            O.ce_rows(c.gl, B, K, K, ga, coef=sc / B, loss_row=c.rows[0], dlogits=c.dgl, ldd=K)
+            O.ce_rows(c.ll, B, Vp, Vp, la, coef=sc / B, loss_row=c.rows[1], dlogits=c.dll, ldd=Vp)
+            O.ce_rows(c.fl, B, K, K, ga, coef=sc / B, loss_row=c.rows[2], dlogits=c.dfl, ldd=K)
+            sup = c.rows.sum() / B
+        elif task == "mlm":
+            c.d_x = zz(B * L, H)
+            nm = plan["n_mask"]
+            c.rows = n.new(nm, dtype=torch.float32)
+            O.ce_rows(c.logits, nm, cfg.vocab_size, c.ldv, plan["mlm_labels"], ignore_index=-1, coef=sc / nm, loss_row=c.rows,
+                      dlogits=c.logits if train else None, ldd=c.ldv)
+            sup = c.rows.sum() / nm
+        else:
+            c.d_gmap, c.d_vp = zz(B * K, H), zz(B * Vp, H)
+            temp = float(cfg_get(cfg, "cfp_temperature"))
+            c.rows = n.new(6, B, dtype=torch.float32)
+            txt_o = c.cfp[3]
+            c.dsim = []
+            ar = plan["arange_b"]
+            lds = c.lds = rup(B, 8)
+            for i in range(3):
+                a = c.cfp[i]
+                sim, simT = n.new(B, lds, dtype=torch.float32), n.new(B, lds, dtype=torch.float32)
+                O.gemm(0, a, txt_o, sim, B, B, H, H, H, lds, alpha=1.0 / temp)
+                O.gemm(0, txt_o, a, simT, B, B, H, H, H, lds, alpha=1.0 / temp)
+                d1 = n.new(B, lds, dtype=torch.float32) if train else None
+                d2 = n.new(B, lds, dtype=torch.float32) if train else None
+                O.ce_rows(sim, B, B, lds, ar, coef=sc * 0.5 / B, loss_row=c.rows[2 * i], dlogits=d1, ldd=lds)
+                O.ce_rows(simT, B, B, lds, ar, coef=sc * 0.5 / B, loss_row=c.rows[2 * i + 1], dlogits=d2, ldd=lds)
+                c.dsim.append((d1, d2))
+            c.temp = temp
+            sup = c.rows.sum() * 0.5 / B
+        res["supervised_loss"] = sup
+        # ---- MAKD (pretrain flavour; oracle/makd_ref.pretrain_makd) -------------------------------------
+        if kd:
+            rw = [1.0] * 5 if rw is None else [float(x) for x in rw]
+            tasks, types = kdl["kdl_tasks"], kdl["kdl_task_types"]
+            emb, att = "emb" in types, "attn" in types
+            T = float(kdl["kd_temperature"])
+            w = None
+            if kdl.get("teacher_sample_hard_mining", False) and task == "sap":
+                w = n.new(B, dtype=torch.float32)
+                O.ce_rows(t["fused_logits"], B, K, K, plan["global_act_labels"], w_out=w,
+                          w_rate=float(kdl["t_sample_preprocess_exp_decay"]))
+            nh_s = n.nh
+            nh_t = t["txt_attns"].shape[1]
+            Np, V = plan["Np"], plan["V"]
+            if "txt" in tasks:
+                if emb:
+                    self._kd_emb(c, 0, o["txt_embeds"], t["txt_embeds"], "txt_emb_w", B * L, B, w, alpha * rw[0], c.d_txt)
+                if att:
+                    c.dP_txt = self._kd_attn(c, 1, o["txt_attns"], t["txt_attns"], B, L, L, c.txt.ldp, nh_s, nh_t, w, alpha * rw[0])
+            if "img" in tasks:
+                if emb:
+                    self._kd_emb(c, 2, o["pano_embeds"], t["pano_embeds"], "kdl_img_w", Np * V, Np * V, None, alpha * rw[1], c.d_pano)
+                    self._kd_emb(c, 3, o["pano_fused_embeds"], t["pano_fused_embeds"], "kdl_avg_img_w", Np, Np, None, alpha * rw[1], c.d_fused)
+                if att:
+                    ldp = c.pano.ldp
+                    g = n.new(Np, V, ldp, dtype=torch.float32) if train else None
+                    O.mse(o["img_attns"], t["img_attns"], Np, V * ldp, V * ldp, V * ldp, norm=1.0 / (Np * V * V), coef=alpha * rw[1],
+                          loss=c.slots[4:5], ds=g, g_stride=V * ldp)
+                    if train:
+                        c.dP_pano = n.new(Np, nh_s, V, ldp, dtype=torch.float32)
+                        O.head_mean_bwd(g, c.dP_pano, Np, nh_s, V * ldp)
+            if "global" in tasks:
+                if task == "mlm":
+                    x, Pm, Nq, Nk, ldp, d_acc = c.l2v.out, c.l2v.P, L, K, c.l2v.ldp, c.d_x
+                else:
+                    x, Pm, Nq, Nk, ldp, d_acc = c.glob.out, c.glob.P, K, L, c.glob.ldp, c.d_gmap
+                if emb:
+                    self._kd_emb(c, 5, x, t["gmap_embeds"], "global_cross_w", B * Nq, B, w, alpha * rw[2], d_acc)
+                if att:
+                    c.dP_g = self._kd_attn(c, 6, Pm, t["gmap_attns"], B, Nq, Nk, ldp, nh_s, nh_t, w, alpha * rw[2])
+            if "local" in tasks and task != "mlm":
+                if emb:
+                    self._kd_emb(c, 7, c.loc.out, t["vp_embeds"], "local_cross_w", B * Vp, B, w, alpha * rw[3], c.d_vp)
+                if att:
+                    c.dP_l = self._kd_attn(c, 8, c.loc.P, t["vp_attns"], B, Vp, L, c.loc.ldp, nh_s, nh_t, w, alpha * rw[3])
+            if "predict" in tasks and task == "sap":
+                c.kdrows = n.new(B, dtype=torch.float32)
+                O.kd_rows(c.fl, t["fused_logits"], B, K, K, T, w=w, norm=(1.0 / B if w is not None else 1.0 / (B * K)),
+                          coef=alpha * rw[4], loss_row=c.kdrows, ds=c.dfl, accumulate=True)
+                c.slots[9:10] = c.kdrows.sum()
+            coefs = torch.tensor([rw[0], rw[0], rw[1], rw[1], rw[1], rw[2], rw[2], rw[3], rw[3], rw[4]] + [0.0] * 6,
+                                 dtype=torch.float32).to(self.device_, non_blocking=True)
+            res["kdl_terms"] = {k: c.slots[i] * coefs[i] for i, k in enumerate(KD_SLOTS)}
+            res["kdl_loss"] = (c.slots * coefs).sum()
+            res["loss"] = alpha * res["kdl_loss"] + sc * sup
+        else:
+            res["loss"] = sup
+        return res
+
+    # ---- backward ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def backward(self):
+        c = self._ctx
+        assert c is not None, "backward() without a compute_loss=True forward"
+        n, plan, task = self.net, c.plan, c.task
+        B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H
+        if task == "sap":
+            dg, dl, df = n.new(B, K, dtype=torch.float32), n.new(B, Vp, dtype=torch.float32), n.new(B, dtype=torch.float32)
+            O.sap_fuse_bwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, plan["gmask"], plan["lmask"], plan["fsrc"], plan["bwmask"],
+                           c.use_gate, c.dgl, c.dll, c.dfl, dg, dl, df)
+            self._cls_bwd("global_sap_head.", c.glob.out, c.Yg, dg, B * K, c.d_gmap)
+            self._cls_bwd("local_sap_head.", c.loc.out, c.Yl, dl, B * Vp, c.d_vp)
+            if c.use_gate:
+                f1, fln, f2 = n.lin("sap_fuse_linear.net.0.weight"), n.ln("sap_fuse_linear.net.2"), n.lin("sap_fuse_linear.net.3.weight")
+                dZ = n.new(B, H)
+                O.lndot_bwd(c.Yf, B, H, fln.g, fln.b, n.eps, f2.Wm, df, dZ, fln.dg, fln.db, f2.dW, f2.db)
+                # dW[:, :H] += dZ^T g0 ; dW[:, H:] += dZ^T v0 (bias grad once)
+                O.linear_dw(dZ, c.glob.out, f1.dW, f1.db, B, N=H, K=H, ldb=K * H, ldc=2 * H)
+                O.linear_dw(dZ, c.loc.out, f1.dW[:, H:], None, B, N=H, K=H, ldb=Vp * H, ldc=2 * H)
+                O.linear_dx(dZ, f1.W, B, out=c.d_gmap, residual=c.d_gmap, ldb=2 * H, ldc=K * H, N=H, K=H)
+                O.linear_dx(dZ, f1.W[:, H:], B, out=c.d_vp, residual=c.d_vp, ldb=2 * H, ldc=Vp * H, N=H, K=H)
+        elif task == "cfp":
+            d_outs = [n.new(B, H) for _ in range(4)]
+            txt_o = c.cfp[3]
+            for i in range(3):
+                d1, d2 = c.dsim[i]
+                a = c.cfp[i]
+                it = 1.0 / c.temp
+                # sim = a txt^T / temp ; simT = txt a^T / temp
+                lds = c.lds
+                e1, e2 = self._as(d1), self._as(d2)
+                O.gemm(1, e1, txt_o, d_outs[i], B, H, B, lds, H, H, alpha=it)
+                O.gemm(2, e2, txt_o, d_outs[i], B, H, B, lds, H, H, alpha=it, residual=d_outs[i], ldr=H)
+                if i == 0:
+                    O.gemm(2, e1, a, d_outs[3], B, H, B, lds, H, H, alpha=it)
+                else:
+                    O.gemm(2, e1, a, d_outs[3], B, H, B, lds, H, H, alpha=it, residual=d_outs[3], ldr=H)
+                O.gemm(1, e2, a, d_outs[3], B, H, B, lds, H, H, alpha=it, residual=d_outs[3], ldr=H)
+            d_g0, d_v0, d_t0 = n.zeros(B, H), n.zeros(B, H), n.zeros(B, H)
+            for (key, src, dsts), d_o in zip((("gmap", c.g0, (d_g0,)), ("vp", c.v0, (d_v0,)), ("fused", c.gv0, (d_g0, d_v0)), ("txt", c.t0, (d_t0,))), d_outs):
+                hl = n.lin(f"cfp_heads.{key}.weight")
+                O.linear_dw(d_o, src, hl.dW, hl.db, B)
+                for dst in dsts:
+                    O.linear_dx(d_o, hl.W, B, out=dst, residual=dst)
+            O.csr_gather(d_g0, *plan["g0_T"], c.d_gmap, B * K, H, accumulate=True)
+            O.csr_gather(d_v0, *plan["v0_T"], c.d_vp, B * Vp, H, accumulate=True)
+            O.csr_gather(d_t0, *plan["t0_T"], c.d_txt, B * L, H, accumulate=True)
+        if task == "mlm":
+            nm, Vv = plan["n_mask"], self.config.vocab_size
+            dlog = c.logits                      # CE wrote the gradient in place
+            Wemb = self.store.w("bert.embeddings.word_embeddings.weight")
+            O.linear_dw(dlog, c.hm, self.store.g("bert.embeddings.word_embeddings.weight"), self.store.g("mlm_head.predictions.bias"),
+                        nm, N=Vv, K=H, lda=c.ldv)
+            d_hm = O.linear_dx(dlog, Wemb, nm, N=Vv, K=H, lda=c.ldv)
+            tn = n.ln("mlm_head.predictions.transform.LayerNorm")
+            d_tg = n.new(nm, H)
+            O.ln_bwd(nm, H, d_hm, y=c.hm, gamma=tn.g, beta=tn.b, rstd=c.rstd_hm, dx=d_tg, dgamma=tn.dg, dbeta=tn.db)
+            d_tz = O.dact(d_tg, c.tz, 1)
+            t = n.lin("mlm_head.predictions.transform.dense.weight")
+            O.linear_dw(d_tz, c.hm_in, t.dW, t.db, nm)
+            d_hin = O.linear_dx(d_tz, t.W, nm)
+            O.csr_gather(d_hin, *plan["mlm_rows_T"], c.d_x, B * L, H, accumulate=True)
+            d_gin = n.zeros(B * K, H)
+            d_t2 = n.cross_bwd(c.l2v, c.d_x, d_gin, c.dP_g)
+            O.add_(c.d_txt, d_t2)
+        else:
+            d_gin = n.cross_bwd(c.glob, c.d_gmap, c.d_txt, c.dP_g)
+            d_vin = n.cross_bwd(c.loc, c.d_vp, c.d_txt, c.dP_l)
+            n.vp_in_bwd(c.vin, plan, d_vin, c.d_pano)
+        n.gmap_in_bwd(c.gin, plan, d_gin, c.d_pano, c.d_fused)
+        n.pano_bwd(c.pano, plan, c.d_pano, c.d_fused, c.dP_pano)
+        n.text_bwd(c.txt, plan, c.d_txt, c.dP_txt)
+        self._ctx = None
+
+    def _as(self, d):
+        """fp32 [B,B] similarity gradient -> compute dtype operand for the MFMA GEMM"""
+        return d if d.dtype == self.compute_dtype else O.cast_to(d, self.compute_dtype)

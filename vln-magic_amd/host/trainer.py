@@ -1,0 +1,125 @@
+"""One optimizer step of MAGIC pretraining with MAKD (the loop the reference constructs but never runs,
+pretrain_src/train_r2r_magic.py:358-401; reconstructed order in SURVEY §3.1):
+
+    teacher forward (no grad, kdl.train_teacher=false) -> student forward + supervised + MAKD losses ->
+    explicit backward -> [DDP: all-reduce of the flat gradient buffer] -> grad-norm clip -> AdamW -> lr schedule
+
+Optimizer arithmetic: pretrain_src/optim/adamw.py:53-112 (two param groups, optim/misc.py:13-22),
+schedule pretrain_src/optim/sched.py:17-30, clip 5.0 / betas (0.9,0.98) / wd 0.01 from
+pretrain_src/config/r2r_magic_pretrain.json:14-23.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import ops as O
+from .plan import build_plan
+
+
+def warmup_linear(step, warmup, total):
+    if step < warmup:
+        return step / warmup
+    return max(0, (total - step) / (total - warmup))
+
+
+def get_lr_sched(step, lr, warmup, total):
+    v = lr * warmup_linear(step, warmup, total)
+    return v if v > 0 else 1e-8
+
+
+class FusedAdamW:
+    """AdamW over the ParamStore's flat buffers: one sum-of-squares launch + one launch per decay group."""
+
+    def __init__(self, store, lr=5e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=5.0):
+        self.store, self.lr, self.betas, self.eps, self.wd, self.max_norm = store, lr, betas, eps, weight_decay, max_grad_norm
+        self.ss = torch.zeros(1, dtype=torch.float32, device=store.device)
+        self.t = 0
+
+    def step(self, lr=None, gscale=1.0):
+        s = self.store
+        lr = self.lr if lr is None else lr
+        self.t += 1
+        b1, b2 = self.betas
+        step_size = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+        use_clip = self.max_norm is not None and self.max_norm > 0
+        if use_clip:
+            self.ss.zero_()
+            O.sumsq(s.grad, self.ss)
+        shadow = s.shadow if s.compute_dtype == torch.bfloat16 else None
+        nd = s.n_decay
+        for lo, hi, wd in ((0, nd, self.wd), (nd, s.total, 0.0)):
+            if hi > lo:
+                O.adamw(hi - lo, s.flat[lo:hi], s.grad[lo:hi], s.m[lo:hi], s.v[lo:hi], shadow[lo:hi] if shadow is not None else None,
+                        lr, b1, b2, self.eps, wd, step_size, self.ss if use_clip else None, self.max_norm if use_clip else 0.0, gscale)
+        s.shadow_clean = True
+        return lr
+
+
+class GradSync:
+    """Data-parallel gradient exchange: the flat fp32 gradient buffer is summed across ranks with RCCL in a few
+    large chunks on a side stream (the 1/world scaling is folded into the AdamW kernel).  Replaces
+    DDP(model, find_unused_parameters=True) of pretrain_src/utils/misc.py:62-63: every rank runs the same
+    task each step (data/loader.py:55-59), so unused parameters simply contribute zeros."""
+
+    def __init__(self, store, chunk_elems=8 << 20):
+        self.store = store
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.chunk = chunk_elems
+        self.stream = torch.cuda.Stream() if (self.world > 1 and store.device.type == "cuda") else None
+
+    def all_reduce(self):
+        if self.world == 1:
+            return 1.0
+        g = self.store.grad
+        if self.stream is None:
+            dist.all_reduce(g)
+            return 1.0 / self.world
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for lo in range(0, g.numel(), self.chunk):
+                dist.all_reduce(g[lo:lo + self.chunk])
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return 1.0 / self.world
+
+
+def broadcast_task(task_id, device):
+    """MetaLoader's one non-gradient collective (pretrain_src/data/loader.py:55-59)."""
+    t = torch.tensor([task_id], dtype=torch.int64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=0)
+    return int(t.item())
+
+
+class PretrainStep:
+    def __init__(self, student, teacher=None, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0,
+                 warmup_steps=10000, num_train_steps=200000, rw_temp=4.0, seed=0):
+        self.student, self.teacher = student, teacher
+        self.opt = FusedAdamW(student.store, lr, betas, 1e-6, weight_decay, grad_norm)
+        self.sync = GradSync(student.store)
+        self.lr0, self.warmup, self.total = lr, warmup_steps, num_train_steps
+        self.rw_temp = rw_temp
+        self.gen = torch.Generator().manual_seed(seed)
+        self.global_step = 0
+
+    def mkrw(self):
+        """MKRW ability weights softmax(randn(5)/rw_temp)*5 (map_nav_src/r2r/agent.py:866-871)."""
+        return (torch.softmax(torch.randn(5, generator=self.gen) / self.rw_temp, dim=-1) * 5).tolist()
+
+    def step(self, batch, task, rw=None, plan=None):
+        st, te = self.student, self.teacher
+        plan = plan if plan is not None else build_plan(batch, task, st.device_)
+        t_out, inputs = None, None
+        if te is not None:
+            with torch.no_grad():
+                t_out = te(batch, task, compute_loss=False, return_outputs=True, plan=plan)
+            inputs = t_out["inputs"]
+        rw = rw if rw is not None else (self.mkrw() if te is not None else None)
+        st.store.zero_grad()
+        out = st(batch, task, compute_loss=True, teacher_outputs=t_out, rw=rw, plan=plan, inputs=inputs)
+        st.backward()
+        gscale = self.sync.all_reduce()
+        lr = get_lr_sched(self.global_step, self.lr0, self.warmup, self.total)
+        self.opt.step(lr=lr, gscale=gscale)
+        self.global_step += 1
+        return out

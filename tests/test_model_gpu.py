@@ -29,6 +29,10 @@ def cfgs(vocab=600, layers=(2, 1, 1)):
     return t, s
 
 
+def to64(batch):
+    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+
+
 def build(dtype, seed=0, **kw):
     tcfg, scfg = cfgs(**kw)
     torch.manual_seed(seed)
@@ -43,6 +47,7 @@ def build(dtype, seed=0, **kw):
                     p.add_(torch.randn_like(p) * 0.05)
     g_t = GlocalTextPathCMTPreTraining.from_pretrained(None, config=tcfg, state_dict=o_t.state_dict(), device=DEV, compute_dtype=dtype)
     g_s = GlocalTextPathCMTPreTraining.from_pretrained(None, config=scfg, state_dict=o_s.state_dict(), device=DEV, compute_dtype=dtype)
+    g_s.keep_mlm_logits = True
     return o_t, o_s, g_t, g_s
 
 
@@ -69,10 +74,12 @@ def view_outputs(o, plan, H):
 def test_fp32_forward_loss_and_gradients_match_oracle(task):
     o_t, o_s, g_t, g_s = build(torch.float32)
     batch = synth.make_batch(task, batch_size=6, seed=21, vocab=600, min_len=8, max_len=19, min_steps=2, max_steps=4)
-    rw = torch.tensor(RW)
+    rw = torch.tensor(RW, dtype=torch.float64)
+    o_t, o_s = o_t.double(), o_s.double()            # fp64 oracle = the reference both fp32 paths are judged against
+    b64 = to64(batch)
     with torch.no_grad():
-        ot = o_t(batch, task, compute_loss=True)["outputs"]
-    want = o_s(batch, task, compute_loss=True, teacher_outputs=ot, rw=rw)
+        ot = o_t(b64, task, compute_loss=True)["outputs"]
+    want = o_s(b64, task, compute_loss=True, teacher_outputs=ot, rw=rw)
     want["loss"].backward()
     with torch.no_grad():
         gt = g_t(batch, task, compute_loss=False, return_outputs=True)
@@ -103,13 +110,16 @@ def test_fp32_forward_loss_and_gradients_match_oracle(task):
     torch.cuda.synchronize()
     params = dict(g_s.named_parameters())
     n_checked = 0
+    gmax = max(p.grad.abs().max().item() for p in o_s.parameters() if p.grad is not None)
     for name, p in o_s.named_parameters():
         g = params[name].grad
         if p.grad is None:
             assert g.abs().max().item() == 0.0, f"{name}: oracle has no grad, engine wrote {g.abs().max().item():.3e}"
             continue
-        scale = max(p.grad.abs().max().item(), 1e-6)
-        close(g, p.grad, f"grad {name}", 2e-3, 2e-4 * scale + 1e-8)
+        # fp32 accumulation noise: relative to the tensor's own scale plus a floor relative to the largest gradient
+        # (some gradients are analytically ~0, e.g. the bias in front of a softmax)
+        scale = p.grad.abs().max().item()
+        close(g, p.grad, f"grad {name}", 2e-3, 1e-3 * scale + 2e-6 * gmax)
         n_checked += 1
     assert n_checked > 40
 

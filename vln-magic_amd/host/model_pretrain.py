@@ -60,6 +60,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         self.net = MagicNet(config, self.store, "bert.")
         self._anchor = torch.zeros(1, device=self.device_, requires_grad=True)
         self._ctx = None
+        self.keep_mlm_logits = False     # True: MLM CE gradient goes to its own buffer instead of overwriting the logits
         self.register_load_state_dict_post_hook(lambda m, k: setattr(m.store, "shadow_clean", False))
 
     # ---- HF-style constructor (train_r2r_magic.py:260-277) ------------------------------------------
@@ -255,8 +256,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             c.d_x = zz(B * L, H)
             nm = plan["n_mask"]
             c.rows = n.new(nm, dtype=torch.float32)
+            c.dlogits = (n.new(nm, c.ldv) if self.keep_mlm_logits else c.logits) if train else None
             O.ce_rows(c.logits, nm, cfg.vocab_size, c.ldv, plan["mlm_labels"], ignore_index=-1, coef=sc / nm, loss_row=c.rows,
-                      dlogits=c.logits if train else None, ldd=c.ldv)
+                      dlogits=c.dlogits, ldd=c.ldv)
+            if train and not self.keep_mlm_logits:
+                o["predict"] = None          # overwritten in place by its gradient
             sup = c.rows.sum() / nm
         else:
             c.d_gmap, c.d_vp = zz(B * K, H), zz(B * Vp, H)
@@ -388,7 +392,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             O.csr_gather(d_t0, *plan["t0_T"], c.d_txt, B * L, H, accumulate=True)
         if task == "mlm":
             nm, Vv = plan["n_mask"], self.config.vocab_size
-            dlog = c.logits                      # CE wrote the gradient in place
+            dlog = c.dlogits                     # CE wrote the gradient (in place unless keep_mlm_logits)
             Wemb = self.store.w("bert.embeddings.word_embeddings.weight")
             O.linear_dw(dlog, c.hm, self.store.g("bert.embeddings.word_embeddings.weight"), self.store.g("mlm_head.predictions.bias"),
                         nm, N=Vv, K=H, lda=c.ldv)

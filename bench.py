@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py -- MAGIC-S R2R pretraining step throughput (trajectory-steps/sec) on N MI355X of one node.
+
+One "step" = one optimizer step of the MAKD pretraining hot path on one synthetic R2R-shaped batch per rank
+(B=48 trajectories, 36 views x 768-d CLIP features per trajectory step, <=80 RoBERTa tokens):
+frozen teacher (H=256) forward -> student (MAGIC-S, H=128) forward + supervised + MAKD losses -> explicit
+backward -> [RCCL all-reduce of the flat gradient] -> grad clip + fused AdamW.  Tasks cycle mlm:sap:cfp = 1:1:1
+(pretrain_src/config/r2r_magic_pretrain.json:49-58).  bf16 MFMA compute, fp32 master weights/optimizer.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run); rank 0 prints ONE
+JSON line.  `roofline` = the dense-contraction (MFMA GEMM) kernel family: algorithmic FLOPs / summed launch
+durations measured with HIP events on the launch stream in a separate instrumented pass; `cpu_baseline` = the
+CPU oracle (oracle/, a restatement -- the reference's model source is withheld) timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import magic_amd  # noqa: E402,F401
+from magic_amd.host import lib as L  # noqa: E402
+from magic_amd.host import ops as O  # noqa: E402
+from magic_amd.host import synth  # noqa: E402
+from magic_amd.host.config import make_config  # noqa: E402
+from magic_amd.host.model_pretrain import GlocalTextPathCMTPreTraining  # noqa: E402
+from magic_amd.host.plan import build_plan  # noqa: E402
+from magic_amd.host.trainer import PretrainStep  # noqa: E402
+
+KDL = dict(knowledge_distillation=True, kd_alpha=0.5, kd_temperature=2, teacher_sample_hard_mining=True,
+           t_sample_preprocess_exp_decay=0.7, rw_temp=4, train_teacher=False,
+           kdl_tasks=["txt", "img", "local", "global", "predict"], kdl_task_types=["emb", "attn"])   # r2r_magic_pretrain.json:62-87
+TASKS = ["mlm", "sap", "cfp"]
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=25.0):
+    """The oracle (kind 'port') on the host cores: same step (teacher fwd, student fwd+MAKD, backward, clip, AdamW)."""
+    from oracle import model_ref as R
+    from oracle import optim_ref
+    from magic_amd.host.params import is_no_decay
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    ncores = max(1, min(16, avail))       # many-thread oversubscription of these small ops is pathological (measured)
+    torch.set_num_threads(ncores)
+    torch.manual_seed(0)
+    teacher, student = R.RefPretrainModel(tcfg).eval(), R.RefPretrainModel(scfg).eval()   # dropout off
+    params = [p for p in student.parameters()]
+    wds = [0.0 if is_no_decay(n) else 0.01 for n, _ in student.named_parameters()]
+    state = optim_ref.adamw_init([p.data for p in params])
+    rw = torch.ones(5)
+    steps_done, traj, t_total = 0, 0, 0.0
+    names = []
+    for i, task in enumerate(["sap"] + TASKS):           # first one is warm-up
+        batch = synth.make_batch(task, batch_size=batch_size, seed=4321, step=i)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            t_out = teacher(batch, task)["outputs"]
+        for p in params:
+            p.grad = None
+        out = student(batch, task, teacher_outputs=t_out, rw=rw)
+        out["loss"].backward()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+        optim_ref.clip_grad_norm(grads, 5.0)
+        with torch.no_grad():
+            optim_ref.adamw_step([p.data for p in params], grads, state, lr=5e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=wds)
+        dt = time.perf_counter() - t0
+        if i > 0:
+            steps_done += 1
+            traj += sum(batch["traj_step_lens"])
+            t_total += dt
+            names.append(task)
+        if t_total > seconds_budget:
+            break
+    return {"value": round(traj / t_total, 2), "unit": "trajectory-steps/sec", "cores": ncores, "kind": "port",
+            "sample": f"{steps_done} optimizer steps ({'+'.join(names)}) of the same B={batch_size} MAGIC-S+teacher workload, "
+                      f"fp32 torch CPU oracle, {t_total / max(steps_done, 1) * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=48)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--pool", type=int, default=12, help="distinct pre-generated batches (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    L.load()
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+
+    tcfg = make_config(256, role="teacher")                                   # teacher_* of r2r_magic_model_config.json:33-37
+    scfg = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL)  # MAGIC-S: student_* :39-43
+    teacher = GlocalTextPathCMTPreTraining(tcfg, device=dev, compute_dtype=dtype, seed=0)
+    student = GlocalTextPathCMTPreTraining(scfg, device=dev, compute_dtype=dtype, seed=1)
+    if world > 1:   # DDP ctor semantics: rank-0 parameters broadcast once (utils/misc.py:62-63)
+        dist.broadcast(student.store.flat, src=0)
+        dist.broadcast(teacher.store.flat, src=0)
+    trainer = PretrainStep(student, teacher, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0,
+                           warmup_steps=10000, num_train_steps=200000, rw_temp=4.0, seed=rank)
+
+    # synthetic batches, resident in HBM before the timed region (per-rank stream: seed 1234 + rank)
+    pool = []
+    for i in range(a.pool):
+        task = TASKS[i % 3]
+        b = synth.make_batch(task, batch_size=a.batch, seed=1234 + rank, step=i)
+        plan = build_plan(b, task, dev)
+        pool.append((task, synth.batch_to(b, dev), plan))
+    torch.cuda.synchronize()
+
+    def run(n, start=0):
+        traj = 0
+        for s in range(n):
+            task, b, plan = pool[(start + s) % len(pool)]
+            trainer.step(b, task, plan=plan)
+            traj += plan["traj_steps"]
+        return traj
+
+    run(a.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    traj = run(a.steps, start=a.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        tr = torch.tensor([traj], device=dev, dtype=torch.float64)
+        dist.all_reduce(tr)
+        traj = float(tr.item())
+
+    roof = None
+    if rank == 0 and not a.no_profile:
+        # instrumented pass: HIP events around every launch (on the launch stream), algorithmic FLOPs from true ragged sizes
+        nprof = min(len(pool), 6)
+        O.FLOPS.update(total=0.0, enabled=True)
+        L.PROFILE.update(on=True, events=[])
+        run(nprof, start=0)
+        torch.cuda.synchronize()
+        L.PROFILE["on"] = False
+        O.FLOPS["enabled"] = False
+        by = {}
+        for name, layout, e0, e1 in L.PROFILE["events"]:
+            k = name if layout < 0 else f"{name}[{['NT', 'NN', 'TN'][layout]}]"
+            t, c = by.get(k, (0.0, 0))
+            by[k] = (t + e0.elapsed_time(e1), c + 1)
+        gemm_ms = sum(t for k, (t, c) in by.items() if k.startswith("magic_gemm"))
+        gemm_n = sum(c for k, (t, c) in by.items() if k.startswith("magic_gemm"))
+        all_ms = sum(t for t, c in by.values())
+        flops = O.FLOPS["total"]
+        ach = flops / (gemm_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_kernel<bf16|f32, NT|NN|TN> (all dense contractions of the step)",
+                "achieved": round(ach, 3), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5),
+                "traffic": None,
+                "detail": {"algorithmic_gflop_per_step": round(flops / nprof / 1e9, 2), "gemm_launches_per_step": gemm_n // nprof,
+                           "avg_gemm_launch_us": round(gemm_ms / max(gemm_n, 1) * 1e3, 2),
+                           "gemm_ms_per_step": round(gemm_ms / nprof, 3), "all_kernels_ms_per_step": round(all_ms / nprof, 3),
+                           "launches_per_step": sum(c for t, c in by.values()) // nprof,
+                           "top_kernels_ms_per_step": {k: round(t / nprof, 3) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]}}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(tcfg, scfg, a.batch)
+
+    if rank == 0:
+        info = {"metric": "trajectory-steps/sec (whole node), MAGIC-S R2R pretrain", "value": round(traj / dt, 2),
+                "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": a.dtype, "data": "synthetic",
+                "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "
+                                       "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip",
+                           "global_batch": a.batch * world, "per_gpu_batch": a.batch, "views": 36, "feat_dim": 768, "max_tokens": 80,
+                           "parallelism": f"dp{world}", "samples_per_sec": round(a.batch * world * a.steps / dt, 1)},
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(info))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,7 @@
 // single fp32 atomic per element per block.
 #include "common.hpp"
 
-#define MAXIT 8   // H <= 1024, H % 128 == 0: each lane owns elements {it*128 + lane*2, +1}
+#define MAXIT 6   // H = 128*NIT, NIT in {1,2,3,6}: each lane owns elements {it*128 + lane*2, +1}
 
 template <typename T> __device__ __forceinline__ void ld2(const T* p, float& a, float& b);
 template <> __device__ __forceinline__ void ld2<float>(const float* p, float& a, float& b) {
@@ -31,195 +31,177 @@ __device__ __forceinline__ int tab_row(const TabRef& t, int r) {
 
 // ---------------------------------------------------------------------------------------------
 // out = LN(in0 + in1 + tab0[..] + tab1[..] + tab2[..]) * gamma + beta      (do_ln)   | plain sum
-template <typename T>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* in0, const T* in1, TabRef t0, TabRef t1, TabRef t2,
+// NIT = H / 128 is a template parameter so the per-lane row fragment lives in exactly 2*NIT registers.
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int M, const T* in0, const T* in1, TabRef t0, TabRef t1, TabRef t2,
                                                      const float* gamma, const float* beta, float eps, T* out, float* rstd_out, int do_ln) {
+  constexpr int H = NIT * 128;
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const int nit = H >> 7;
-  float x[2 * MAXIT];
+  float x[2 * NIT];
   float s = 0.f;
   const int r0 = t0.tab ? tab_row(t0, row) : 0, r1 = t1.tab ? tab_row(t1, row) : 0, r2 = t2.tab ? tab_row(t2, row) : 0;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    if (it < nit) {
-      const int c = it * 128 + lane * 2;
-      float a = 0.f, b = 0.f, u, v;
-      if (in0) { ld2<T>(in0 + (long long)row * H + c, u, v); a += u; b += v; }
-      if (in1) { ld2<T>(in1 + (long long)row * H + c, u, v); a += u; b += v; }
-      if (t0.tab) { ld2<T>((const T*)t0.tab + (long long)r0 * H + c, u, v); a += u; b += v; }
-      if (t1.tab) { ld2<T>((const T*)t1.tab + (long long)r1 * H + c, u, v); a += u; b += v; }
-      if (t2.tab) { ld2<T>((const T*)t2.tab + (long long)r2 * H + c, u, v); a += u; b += v; }
-      x[2 * it] = a; x[2 * it + 1] = b; s += a + b;
-    }
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 128 + lane * 2;
+    float a = 0.f, b = 0.f, u, v;
+    if (in0) { ld2<T>(in0 + (long long)row * H + c, u, v); a += u; b += v; }
+    if (in1) { ld2<T>(in1 + (long long)row * H + c, u, v); a += u; b += v; }
+    if (t0.tab) { ld2<T>((const T*)t0.tab + (long long)r0 * H + c, u, v); a += u; b += v; }
+    if (t1.tab) { ld2<T>((const T*)t1.tab + (long long)r1 * H + c, u, v); a += u; b += v; }
+    if (t2.tab) { ld2<T>((const T*)t2.tab + (long long)r2 * H + c, u, v); a += u; b += v; }
+    x[2 * it] = a; x[2 * it + 1] = b; s += a + b;
   }
   if (!do_ln) {
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
-      if (it < nit) st2<T>(out + (long long)row * H + it * 128 + lane * 2, x[2 * it], x[2 * it + 1]);
+    for (int it = 0; it < NIT; ++it) st2<T>(out + (long long)row * H + it * 128 + lane * 2, x[2 * it], x[2 * it + 1]);
     return;
   }
   const float mean = wave_sum(s) / H;
   float q = 0.f;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
-    if (it < nit) { float a = x[2 * it] - mean, b = x[2 * it + 1] - mean; q += a * a + b * b; }
+  for (int it = 0; it < NIT; ++it) { float a = x[2 * it] - mean, b = x[2 * it + 1] - mean; q += a * a + b * b; }
   const float rstd = rsqrtf(wave_sum(q) / H + eps);
   if (rstd_out && lane == 0) rstd_out[row] = rstd;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
-    if (it < nit) {
-      const int c = it * 128 + lane * 2;
-      const float2 g = *(const float2*)(gamma + c), b = *(const float2*)(beta + c);
-      st2<T>(out + (long long)row * H + c, (x[2 * it] - mean) * rstd * g.x + b.x, (x[2 * it + 1] - mean) * rstd * g.y + b.y);
-    }
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 128 + lane * 2;
+    const float2 g = *(const float2*)(gamma + c), b = *(const float2*)(beta + c);
+    st2<T>(out + (long long)row * H + c, (x[2 * it] - mean) * rstd * g.x + b.x, (x[2 * it + 1] - mean) * rstd * g.y + b.y);
+  }
 }
 
 // Backward of the above.  dx (optional) = gradient wrt the pre-LN sum (shared by in0/in1).
 // xhat is recomputed from y: xhat = (y - beta) / gamma.  Parameter/table gradients are fp32 atomics:
-//   dgamma, dbeta and const-row / tiny (<=3 rows, `small`) tables: block-reduced first;
-//   indexed tables: one atomic row per input row.
-#define LNB_ROWS 8   // rows per wave
-template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* dy, const T* y, const float* gamma, const float* beta,
+//   dgamma, dbeta: per-lane registers -> LDS block reduce -> one atomic per element per block;
+//   const-row / tiny (<=3 rows, `small`) tables: LDS atomics into per-block slots -> one global atomic per element per block;
+//   indexed tables (word / position / step embeddings): one global atomic row per input row.
+#define LNB_ROWS 4   // rows per wave
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int M, const T* dy, const T* y, const float* gamma, const float* beta,
                                                      const float* rstd, T* dx, float* dgamma, float* dbeta,
                                                      TabRef t0, float* d0, int small0, TabRef t1, float* d1, int small1,
                                                      TabRef t2, float* d2, int small2, int do_ln) {
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][nacc][H]
+  constexpr int H = NIT * 128;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][4 waves][H] gamma/beta partials | [9][H] table slots
+  float* tacc = red + 8 * H;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int nit = H >> 7;
-  float ag[2 * MAXIT], ab[2 * MAXIT];
-  float as[3][3][2 * 2];   // small/const tables: only supported for H <= 256 (nit <= 2) -> 4 values per lane
+  const bool c0 = d0 && !t0.idx && !t0.mod, c1 = d1 && !t1.idx && !t1.mod, c2 = d2 && !t2.idx && !t2.mod;
+  const bool l0 = d0 && (c0 || small0), l1 = d1 && (c1 || small1), l2 = d2 && (c2 || small2);   // LDS-slot tables
+  const bool any_lds = l0 || l1 || l2;
+  if (any_lds) {
+    for (int i = threadIdx.x; i < 9 * H; i += 256) tacc[i] = 0.f;
+    __syncthreads();
+  }
+  float ag[2 * NIT], ab[2 * NIT];
 #pragma unroll
-  for (int i = 0; i < 2 * MAXIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) as[a][b][c] = 0.f;
-  const TabRef* ts[3] = {&t0, &t1, &t2};
-  float* ds[3] = {d0, d1, d2};
-  const int smalls[3] = {small0, small1, small2};
+  for (int i = 0; i < 2 * NIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
 
   const int row0 = (blockIdx.x * 4 + wid) * LNB_ROWS;
   for (int rr = 0; rr < LNB_ROWS; ++rr) {
     const int row = row0 + rr;
     if (row >= M) break;
-    float g[2 * MAXIT], xh[2 * MAXIT];
+    float g[2 * NIT], xh[2 * NIT];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
-      if (it < nit) {
-        const int c = it * 128 + lane * 2;
-        float da, db;
-        ld2<T>(dy + (long long)row * H + c, da, db);
-        if (do_ln) {
-          float ya, yb;
-          ld2<T>(y + (long long)row * H + c, ya, yb);
-          const float2 gm = *(const float2*)(gamma + c), bt = *(const float2*)(beta + c);
-          const float xa = gm.x != 0.f ? (ya - bt.x) / gm.x : 0.f, xb = gm.y != 0.f ? (yb - bt.y) / gm.y : 0.f;
-          ag[2 * it] += da * xa; ag[2 * it + 1] += db * xb;
-          ab[2 * it] += da; ab[2 * it + 1] += db;
-          const float ga = da * gm.x, gb = db * gm.y;
-          g[2 * it] = ga; g[2 * it + 1] = gb; xh[2 * it] = xa; xh[2 * it + 1] = xb;
-          s1 += ga + gb; s2 += ga * xa + gb * xb;
-        } else {
-          g[2 * it] = da; g[2 * it + 1] = db;
-        }
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 128 + lane * 2;
+      float da, db;
+      ld2<T>(dy + (long long)row * H + c, da, db);
+      if (do_ln) {
+        float ya, yb;
+        ld2<T>(y + (long long)row * H + c, ya, yb);
+        const float2 gm = *(const float2*)(gamma + c), bt = *(const float2*)(beta + c);
+        const float xa = gm.x != 0.f ? (ya - bt.x) / gm.x : 0.f, xb = gm.y != 0.f ? (yb - bt.y) / gm.y : 0.f;
+        ag[2 * it] += da * xa; ag[2 * it + 1] += db * xb;
+        ab[2 * it] += da; ab[2 * it + 1] += db;
+        const float ga = da * gm.x, gb = db * gm.y;
+        g[2 * it] = ga; g[2 * it + 1] = gb; xh[2 * it] = xa; xh[2 * it + 1] = xb;
+        s1 += ga + gb; s2 += ga * xa + gb * xb;
+      } else {
+        g[2 * it] = da; g[2 * it + 1] = db;
       }
+    }
     if (do_ln) {
       const float m1 = wave_sum(s1) / H, m2 = wave_sum(s2) / H, rs = rstd[row];
 #pragma unroll
-      for (int it = 0; it < MAXIT; ++it)
-        if (it < nit) {
-          g[2 * it] = rs * (g[2 * it] - m1 - xh[2 * it] * m2);
-          g[2 * it + 1] = rs * (g[2 * it + 1] - m1 - xh[2 * it + 1] * m2);
-        }
+      for (int it = 0; it < NIT; ++it) {
+        g[2 * it] = rs * (g[2 * it] - m1 - xh[2 * it] * m2);
+        g[2 * it + 1] = rs * (g[2 * it + 1] - m1 - xh[2 * it + 1] * m2);
+      }
     }
     if (dx) {
 #pragma unroll
-      for (int it = 0; it < MAXIT; ++it)
-        if (it < nit) st2<T>(dx + (long long)row * H + it * 128 + lane * 2, g[2 * it], g[2 * it + 1]);
+      for (int it = 0; it < NIT; ++it) st2<T>(dx + (long long)row * H + it * 128 + lane * 2, g[2 * it], g[2 * it + 1]);
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (!ds[k]) continue;
-      const TabRef& t = *ts[k];
-      const bool is_const = (!t.idx && !t.mod);
-      if (is_const || smalls[k]) {
-        const int tr = is_const ? 0 : t.idx[row];
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-          if (it < nit) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              const float sel = (tr == q) ? 1.f : 0.f;
-              as[k][q][2 * it] += sel * g[2 * it]; as[k][q][2 * it + 1] += sel * g[2 * it + 1];
-            }
-          }
-      } else {
-        const int tr = tab_row(t, row);
-#pragma unroll
-        for (int it = 0; it < MAXIT; ++it)
-          if (it < nit) {
-            const int c = it * 128 + lane * 2;
-            atomicAdd(ds[k] + (long long)tr * H + c, g[2 * it]);
-            atomicAdd(ds[k] + (long long)tr * H + c + 1, g[2 * it + 1]);
-          }
-      }
+    // table gradients
+#define TAB_GRAD(K, TK, DK, LK, CK)                                                         \
+    if (DK) {                                                                                \
+      if (LK) {                                                                              \
+        float* slot = tacc + (K * 3 + (CK ? 0 : TK.idx[row])) * H;                           \
+        _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                 \
+          const int c = it * 128 + lane * 2;                                                 \
+          atomicAdd(slot + c, g[2 * it]); atomicAdd(slot + c + 1, g[2 * it + 1]);            \
+        }                                                                                    \
+      } else {                                                                               \
+        float* dst = DK + (long long)tab_row(TK, row) * H;                                   \
+        _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                 \
+          const int c = it * 128 + lane * 2;                                                 \
+          atomicAdd(dst + c, g[2 * it]); atomicAdd(dst + c + 1, g[2 * it + 1]);              \
+        }                                                                                    \
+      }                                                                                      \
     }
+    TAB_GRAD(0, t0, d0, l0, c0)
+    TAB_GRAD(1, t1, d1, l1, c1)
+    TAB_GRAD(2, t2, d2, l2, c2)
+#undef TAB_GRAD
   }
-  // ---- block reduction of register accumulators through LDS: slot layout [slot][wave][H]
-  int slot = 0;
-  auto flush = [&](float* dst, const float* v, int nv_it) {   // v holds 2*nv_it values per lane
-    if (!dst) return;
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
-      if (it < nv_it) {
-        red[(slot * 4 + wid) * H + it * 128 + lane * 2] = v[2 * it];
-        red[(slot * 4 + wid) * H + it * 128 + lane * 2 + 1] = v[2 * it + 1];
-      }
-    __syncthreads();
-    for (int c = threadIdx.x; c < H; c += 256) {
-      float s = red[(slot * 4 + 0) * H + c] + red[(slot * 4 + 1) * H + c] + red[(slot * 4 + 2) * H + c] + red[(slot * 4 + 3) * H + c];
-      if (s != 0.f) atomicAdd(dst + c, s);
-    }
-    __syncthreads();
-  };
   if (do_ln) {
-    flush(dgamma, ag, nit);
-    flush(dbeta, ab, nit);
-  }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    if (!ds[k]) continue;
-    const TabRef& t = *ts[k];
-    const bool is_const = (!t.idx && !t.mod);
-    if (is_const) {
-      flush(ds[k] + (long long)t.off * H, as[k][0], nit < 2 ? nit : 2);
-    } else if (smalls[k]) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) flush(ds[k] + (long long)q * H, as[k][q], nit < 2 ? nit : 2);
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 128 + lane * 2;
+      red[(0 * 4 + wid) * H + c] = ag[2 * it]; red[(0 * 4 + wid) * H + c + 1] = ag[2 * it + 1];
+      red[(1 * 4 + wid) * H + c] = ab[2 * it]; red[(1 * 4 + wid) * H + c + 1] = ab[2 * it + 1];
     }
+  }
+  __syncthreads();
+  if (do_ln) {
+    for (int c = threadIdx.x; c < H; c += 256) {
+      atomicAdd(dgamma + c, red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c]);
+      atomicAdd(dbeta + c, red[4 * H + c] + red[5 * H + c] + red[6 * H + c] + red[7 * H + c]);
+    }
+  }
+  if (any_lds) {
+#define TAB_FLUSH(K, TK, DK, LK, CK)                                                        \
+    if (LK) {                                                                                \
+      const int nrow = CK ? 1 : 3;                                                           \
+      for (int i = threadIdx.x; i < nrow * H; i += 256) {                                    \
+        const float v = tacc[K * 3 * H + i];                                                 \
+        if (v != 0.f) atomicAdd(DK + (long long)(CK ? TK.off : 0) * H + i, v);               \
+      }                                                                                      \
+    }
+    TAB_FLUSH(0, t0, d0, l0, c0)
+    TAB_FLUSH(1, t1, d1, l1, c1)
+    TAB_FLUSH(2, t2, d2, l2, c2)
+#undef TAB_FLUSH
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // y = LN(x[M,Kin] @ W[H,Kin]^T + b) * gamma + beta, Kin <= 16 (position features; fp32 inputs/params)
-template <typename T>
+template <typename T, int NIT>
 __global__ __launch_bounds__(256) void smallk_ln_fwd_kernel(int M, int H, int Kin, const float* x, const float* W, const float* b,
                                                             const float* gamma, const float* beta, float eps, T* out, float* rstd_out) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const int nit = H >> 7;
+  constexpr int nit = NIT;
   float xr[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) xr[k] = k < Kin ? x[(long long)row * Kin + k] : 0.f;
-  float z[2 * MAXIT];
+  float z[2 * NIT];
   float s = 0.f;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
+  for (int it = 0; it < NIT; ++it)
     if (it < nit) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -232,12 +214,12 @@ __global__ __launch_bounds__(256) void smallk_ln_fwd_kernel(int M, int H, int Ki
   const float mean = wave_sum(s) / H;
   float q = 0.f;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
+  for (int it = 0; it < NIT; ++it)
     if (it < nit) { float a = z[2 * it] - mean, c = z[2 * it + 1] - mean; q += a * a + c * c; }
   const float rstd = rsqrtf(wave_sum(q) / H + eps);
   if (rstd_out && lane == 0) rstd_out[row] = rstd;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
+  for (int it = 0; it < NIT; ++it)
     if (it < nit) {
       const int c = it * 128 + lane * 2;
       st2<T>(out + (long long)row * H + c, (z[2 * it] - mean) * rstd * gamma[c] + beta[c],
@@ -248,7 +230,7 @@ __global__ __launch_bounds__(256) void smallk_ln_fwd_kernel(int M, int H, int Ki
 // backward: dW[H,Kin], db[H], dgamma, dbeta (fp32 atomics, block-reduced).  32 rows per block;
 // dz rows are parked in LDS so the dW outer product is a cooperative (c,k) loop.
 #define SK_ROWS 32
-template <typename T>
+template <typename T, int NIT>
 __global__ __launch_bounds__(256) void smallk_ln_bwd_kernel(int M, int H, int Kin, const float* x, const T* dy, const T* y,
                                                             const float* gamma, const float* beta, const float* rstd,
                                                             float* dW, float* db, float* dgamma, float* dbeta) {
@@ -257,18 +239,18 @@ __global__ __launch_bounds__(256) void smallk_ln_bwd_kernel(int M, int H, int Ki
   float* xs = sm + SK_ROWS * H;
   float* red = xs + SK_ROWS * 16;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int nit = H >> 7;
-  float ag[2 * MAXIT], ab[2 * MAXIT];
+  constexpr int nit = NIT;
+  float ag[2 * NIT], ab[2 * NIT];
 #pragma unroll
-  for (int i = 0; i < 2 * MAXIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  for (int i = 0; i < 2 * NIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
   const int base = blockIdx.x * SK_ROWS;
   for (int rr = wid; rr < SK_ROWS; rr += 4) {
     const int row = base + rr;
     const bool ok = row < M;
-    float g[2 * MAXIT], xh[2 * MAXIT];
+    float g[2 * NIT], xh[2 * NIT];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
+    for (int it = 0; it < NIT; ++it)
       if (it < nit) {
         const int c = it * 128 + lane * 2;
         float da = 0.f, dbv = 0.f, ya = 0.f, yb = 0.f;
@@ -281,7 +263,7 @@ __global__ __launch_bounds__(256) void smallk_ln_bwd_kernel(int M, int H, int Ki
       }
     const float m1 = wave_sum(s1) / H, m2 = wave_sum(s2) / H, rs = ok ? rstd[row] : 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
+    for (int it = 0; it < NIT; ++it)
       if (it < nit) {
         const int c = it * 128 + lane * 2;
         dz[rr * H + c] = rs * (g[2 * it] - m1 - xh[2 * it] * m2);
@@ -304,7 +286,7 @@ __global__ __launch_bounds__(256) void smallk_ln_bwd_kernel(int M, int H, int Ki
     atomicAdd(db + c, s);
   }
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
+  for (int it = 0; it < NIT; ++it)
     if (it < nit) {
       const int c = it * 128 + lane * 2;
       red[(0 * 4 + wid) * H + c] = ag[2 * it]; red[(0 * 4 + wid) * H + c + 1] = ag[2 * it + 1];
@@ -418,26 +400,26 @@ __global__ void head_mean_bwd_kernel(int B, int nh, long long inner, const float
 
 // ---------------------------------------------------------------------------------------------
 // ClsPrediction tail: logit[m] = dot(LN(Y[m]) * gamma + beta, w2) + b2    (Y = relu(linear) from the GEMM)
-template <typename T>
+template <typename T, int NIT>
 __global__ __launch_bounds__(256) void lndot_fwd_kernel(int M, int H, const T* Y, const float* gamma, const float* beta, float eps,
                                                         const float* w2, const float* b2, float* logit) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const int nit = H >> 7;
-  float x[2 * MAXIT];
+  constexpr int nit = NIT;
+  float x[2 * NIT];
   float s = 0.f;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
+  for (int it = 0; it < NIT; ++it)
     if (it < nit) { ld2<T>(Y + (long long)row * H + it * 128 + lane * 2, x[2 * it], x[2 * it + 1]); s += x[2 * it] + x[2 * it + 1]; }
   const float mean = wave_sum(s) / H;
   float q = 0.f;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
+  for (int it = 0; it < NIT; ++it)
     if (it < nit) { float a = x[2 * it] - mean, b = x[2 * it + 1] - mean; q += a * a + b * b; }
   const float rstd = rsqrtf(wave_sum(q) / H + eps);
   float d = 0.f;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
+  for (int it = 0; it < NIT; ++it)
     if (it < nit) {
       const int c = it * 128 + lane * 2;
       d += ((x[2 * it] - mean) * rstd * gamma[c] + beta[c]) * w2[c] + ((x[2 * it + 1] - mean) * rstd * gamma[c + 1] + beta[c + 1]) * w2[c + 1];
@@ -447,38 +429,38 @@ __global__ __launch_bounds__(256) void lndot_fwd_kernel(int M, int H, const T* Y
 }
 
 // backward: dZ[m,:] = relu'(Y) * LNbwd(dlogit[m] * w2); dgamma, dbeta, dw2, db2 block-reduced atomics
-template <typename T>
+template <typename T, int NIT>
 __global__ __launch_bounds__(256) void lndot_bwd_kernel(int M, int H, const T* Y, const float* gamma, const float* beta, float eps,
                                                         const float* w2, const float* dlogit, T* dZ,
                                                         float* dgamma, float* dbeta, float* dw2, float* db2) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [3][4][H] + [4]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int nit = H >> 7;
-  float ag[2 * MAXIT], ab[2 * MAXIT], aw[2 * MAXIT];
+  constexpr int nit = NIT;
+  float ag[2 * NIT], ab[2 * NIT], aw[2 * NIT];
 #pragma unroll
-  for (int i = 0; i < 2 * MAXIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; aw[i] = 0.f; }
+  for (int i = 0; i < 2 * NIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; aw[i] = 0.f; }
   float adb = 0.f;
   const int row0 = (blockIdx.x * 4 + wid) * LNB_ROWS;
   for (int rr = 0; rr < LNB_ROWS; ++rr) {
     const int row = row0 + rr;
     if (row >= M) break;
-    float x[2 * MAXIT];
+    float x[2 * NIT];
     float s = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
+    for (int it = 0; it < NIT; ++it)
       if (it < nit) { ld2<T>(Y + (long long)row * H + it * 128 + lane * 2, x[2 * it], x[2 * it + 1]); s += x[2 * it] + x[2 * it + 1]; }
     const float mean = wave_sum(s) / H;
     float q = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
+    for (int it = 0; it < NIT; ++it)
       if (it < nit) { float a = x[2 * it] - mean, b = x[2 * it + 1] - mean; q += a * a + b * b; }
     const float rstd = rsqrtf(wave_sum(q) / H + eps);
     const float dl = dlogit[row];
     adb += dl;
-    float g[2 * MAXIT], xh[2 * MAXIT];
+    float g[2 * NIT], xh[2 * NIT];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
+    for (int it = 0; it < NIT; ++it)
       if (it < nit) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -493,7 +475,7 @@ __global__ __launch_bounds__(256) void lndot_bwd_kernel(int M, int H, const T* Y
       }
     const float m1 = wave_sum(s1) / H, m2 = wave_sum(s2) / H;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it)
+    for (int it = 0; it < NIT; ++it)
       if (it < nit) {
         const float da = x[2 * it] > 0.f ? rstd * (g[2 * it] - m1 - xh[2 * it] * m2) : 0.f;
         const float dbv = x[2 * it + 1] > 0.f ? rstd * (g[2 * it + 1] - m1 - xh[2 * it + 1] * m2) : 0.f;
@@ -501,7 +483,7 @@ __global__ __launch_bounds__(256) void lndot_bwd_kernel(int M, int H, const T* Y
       }
   }
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
+  for (int it = 0; it < NIT; ++it)
     if (it < nit) {
       const int c = it * 128 + lane * 2;
       red[(0 * 4 + wid) * H + c] = ag[2 * it]; red[(0 * 4 + wid) * H + c + 1] = ag[2 * it + 1];
@@ -522,6 +504,17 @@ __global__ __launch_bounds__(256) void lndot_bwd_kernel(int M, int H, const T* Y
 static inline bool okH(int H) { return H >= 128 && H <= 128 * MAXIT && (H % 128) == 0; }
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
   do { if ((dtype) == DT_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
+// H in {128, 256, 384, 768} = the S / M / B / L family (run_r2r_kdl_valid.sh:85-94)
+#define DISPATCH_NIT(dtype, H, F)                                                                     \
+  do {                                                                                                \
+    if ((dtype) == DT_BF16) {                                                                         \
+      if ((H) == 128) F(bf16, 1); else if ((H) == 256) F(bf16, 2); else if ((H) == 384) F(bf16, 3);   \
+      else if ((H) == 768) F(bf16, 6); else return MAGIC_ERR_UNSUPPORTED;                             \
+    } else {                                                                                          \
+      if ((H) == 128) F(float, 1); else if ((H) == 256) F(float, 2); else if ((H) == 384) F(float, 3); \
+      else if ((H) == 768) F(float, 6); else return MAGIC_ERR_UNSUPPORTED;                            \
+    }                                                                                                 \
+  } while (0)
 
 extern "C" int magic_ln_fwd(int dtype, int M, int H, const void* in0, const void* in1,
                             const void* tab0, const int* idx0, int mod0, int off0,
@@ -533,9 +526,9 @@ extern "C" int magic_ln_fwd(int dtype, int M, int H, const void* in0, const void
   TabRef t0{tab0, idx0, mod0, off0}, t1{tab1, idx1, mod1, off1}, t2{tab2, idx2, mod2, off2};
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, M, H, (const float*)in0, (const float*)in1, t0, t1, t2, gamma, beta, eps, (float*)out, rstd, do_ln),
-             hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, block, 0, st, M, H, (const bf16*)in0, (const bf16*)in1, t0, t1, t2, gamma, beta, eps, (bf16*)out, rstd, do_ln));
+#define LNF(TY, NIT) hipLaunchKernelGGL((ln_fwd_kernel<TY, NIT>), grid, block, 0, st, M, (const TY*)in0, (const TY*)in1, t0, t1, t2, gamma, beta, eps, (TY*)out, rstd, do_ln)
+  DISPATCH_NIT(dtype, H, LNF);
+#undef LNF
   return launch_status();
 }
 
@@ -547,16 +540,14 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
                             int do_ln, void* stream) {
   if (M <= 0 || !okH(H) || !dy) return MAGIC_ERR_ARG;
   if (do_ln && (!y || !gamma || !beta || !rstd || !dgamma || !dbeta)) return MAGIC_ERR_ARG;
-  // const-row / small tables keep per-lane accumulators only for H <= 256
-  const bool c0 = d0 && ((!idx0 && !mod0) || small0), c1 = d1 && ((!idx1 && !mod1) || small1), c2 = d2 && ((!idx2 && !mod2) || small2);
-  if ((c0 || c1 || c2) && H > 256) return MAGIC_ERR_UNSUPPORTED;
+  if ((small0 && !idx0) || (small1 && !idx1) || (small2 && !idx2)) return MAGIC_ERR_ARG;
   TabRef t0{d0, idx0, mod0, off0}, t1{d1, idx1, mod1, off1}, t2{d2, idx2, mod2, off2};
   dim3 grid((M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS)), block(256);
-  size_t shm = (size_t)4 * H * sizeof(float);
+  size_t shm = (size_t)17 * H * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, shm, st, M, H, (const float*)dy, (const float*)y, gamma, beta, rstd, (float*)dx, dgamma, dbeta, t0, d0, small0, t1, d1, small1, t2, d2, small2, do_ln),
-             hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, shm, st, M, H, (const bf16*)dy, (const bf16*)y, gamma, beta, rstd, (bf16*)dx, dgamma, dbeta, t0, d0, small0, t1, d1, small1, t2, d2, small2, do_ln));
+#define LNB(TY, NIT) hipLaunchKernelGGL((ln_bwd_kernel<TY, NIT>), grid, block, shm, st, M, (const TY*)dy, (const TY*)y, gamma, beta, rstd, (TY*)dx, dgamma, dbeta, t0, d0, small0, t1, d1, small1, t2, d2, small2, do_ln)
+  DISPATCH_NIT(dtype, H, LNB);
+#undef LNB
   return launch_status();
 }
 
@@ -565,9 +556,9 @@ extern "C" int magic_smallk_ln_fwd(int dtype, int M, int H, int Kin, const float
   if (M <= 0 || !okH(H) || Kin <= 0 || Kin > 16) return MAGIC_ERR_ARG;
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(smallk_ln_fwd_kernel<float>, grid, block, 0, st, M, H, Kin, x, W, b, gamma, beta, eps, (float*)out, rstd),
-             hipLaunchKernelGGL(smallk_ln_fwd_kernel<bf16>, grid, block, 0, st, M, H, Kin, x, W, b, gamma, beta, eps, (bf16*)out, rstd));
+#define SKF(TY, NIT) hipLaunchKernelGGL((smallk_ln_fwd_kernel<TY, NIT>), grid, block, 0, st, M, H, Kin, x, W, b, gamma, beta, eps, (TY*)out, rstd)
+  DISPATCH_NIT(dtype, H, SKF);
+#undef SKF
   return launch_status();
 }
 
@@ -578,13 +569,13 @@ extern "C" int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float
   dim3 grid((M + SK_ROWS - 1) / SK_ROWS), block(256);
   size_t shm = (size_t)(SK_ROWS * H + SK_ROWS * 16 + 8 * H) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16) {
-    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)smallk_ln_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(smallk_ln_bwd_kernel<bf16>, grid, block, shm, st, M, H, Kin, x, (const bf16*)dy, (const bf16*)y, gamma, beta, rstd, dW, db, dgamma, dbeta);
-  } else {
-    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)smallk_ln_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(smallk_ln_bwd_kernel<float>, grid, block, shm, st, M, H, Kin, x, (const float*)dy, (const float*)y, gamma, beta, rstd, dW, db, dgamma, dbeta);
-  }
+#define SKB(TY, NIT)                                                                                                         \
+  do {                                                                                                                       \
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)smallk_ln_bwd_kernel<TY, NIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((smallk_ln_bwd_kernel<TY, NIT>), grid, block, shm, st, M, H, Kin, x, (const TY*)dy, (const TY*)y, gamma, beta, rstd, dW, db, dgamma, dbeta); \
+  } while (0)
+  DISPATCH_NIT(dtype, H, SKB);
+#undef SKB
   return launch_status();
 }
 
@@ -638,9 +629,9 @@ extern "C" int magic_lndot_fwd(int dtype, int M, int H, const void* Y, const flo
   if (M <= 0 || !okH(H)) return MAGIC_ERR_ARG;
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(lndot_fwd_kernel<float>, grid, block, 0, st, M, H, (const float*)Y, gamma, beta, eps, w2, b2, logit),
-             hipLaunchKernelGGL(lndot_fwd_kernel<bf16>, grid, block, 0, st, M, H, (const bf16*)Y, gamma, beta, eps, w2, b2, logit));
+#define LDF(TY, NIT) hipLaunchKernelGGL((lndot_fwd_kernel<TY, NIT>), grid, block, 0, st, M, H, (const TY*)Y, gamma, beta, eps, w2, b2, logit)
+  DISPATCH_NIT(dtype, H, LDF);
+#undef LDF
   return launch_status();
 }
 
@@ -651,8 +642,8 @@ extern "C" int magic_lndot_bwd(int dtype, int M, int H, const void* Y, const flo
   dim3 grid((M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS)), block(256);
   size_t shm = (size_t)(12 * H + 4) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(lndot_bwd_kernel<float>, grid, block, shm, st, M, H, (const float*)Y, gamma, beta, eps, w2, dlogit, (float*)dZ, dgamma, dbeta, dw2, db2),
-             hipLaunchKernelGGL(lndot_bwd_kernel<bf16>, grid, block, shm, st, M, H, (const bf16*)Y, gamma, beta, eps, w2, dlogit, (bf16*)dZ, dgamma, dbeta, dw2, db2));
+#define LDB(TY, NIT) hipLaunchKernelGGL((lndot_bwd_kernel<TY, NIT>), grid, block, shm, st, M, H, (const TY*)Y, gamma, beta, eps, w2, dlogit, (TY*)dZ, dgamma, dbeta, dw2, db2)
+  DISPATCH_NIT(dtype, H, LDB);
+#undef LDB
   return launch_status();
 }

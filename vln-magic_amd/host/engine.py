@@ -152,18 +152,18 @@ class MagicNet:
         ldp = rup(Nk)
         S = self.new(Bn, nh, Nq, ldp, dtype=torch.float32)
         O.gemm(0, q, k, S, Nq, Nk, HD, ldq, ldkv, ldp, batch=Bn * nh, nh=nh, sA=(Nq * ldq, HD), sB=(Nk * ldkv, HD),
-               sC=(nh * Nq * ldp, Nq * ldp), flop_dims=(1, 1, flops / nh))
+               sC=(nh * Nq * ldp, Nq * ldp), flop_dims=(1, 1, flops / (nh * Bn)))
         Pm = self.new(Bn, nh, Nq, ldp)
         O.softmax_fwd(S, Pm, Bn, nh, Nq, Nk, ldp, 1.0 / math.sqrt(HD), kmask=kmask, dist=dist,
                       sprel_w=sprel[0] if sprel else None, sprel_b=sprel[1] if sprel else None)
         ctx = self.new(Bn * Nq, H)
         O.gemm(1, Pm, v, ctx, Nq, HD, Nk, ldp, ldkv, H, batch=Bn * nh, nh=nh, sA=(nh * Nq * ldp, Nq * ldp), sB=(Nk * ldkv, HD),
-               sC=(Nq * H, HD), flop_dims=(1, 1, flops / nh))
+               sC=(Nq * H, HD), flop_dims=(1, 1, flops / (nh * Bn)))
         return Pm, ctx, ldp
 
     def _attn_bwd(self, Pm, ldp, d_ctx, q, ldq, k, v, ldkv, dq, lddq, dk, dv, lddkv, Bn, Nq, Nk, dist, dsprel, dP_init, flops):
         nh, H = self.nh, self.H
-        fd = (1, 1, flops / nh)
+        fd = (1, 1, flops / (nh * Bn))      # x (batch = Bn*nh) in the counter -> 2 * sum_b(lq*lk) * 64 * nh
         sP = (nh * Nq * ldp, Nq * ldp)
         # dV = P^T dO
         O.gemm(2, Pm, d_ctx, dv, Nk, HD, Nq, ldp, H, lddkv, batch=Bn * nh, nh=nh, sA=sP, sB=(Nq * H, HD), sC=(Nk * lddkv, HD), flop_dims=fd)

@@ -79,8 +79,18 @@ def P(t):
     return None if t is None else t.data_ptr()
 
 
+PROFILE = {"on": False, "events": []}     # bench.py: per-launch HIP-event timing on the launch stream
+
+
 def call(name, *args):
-    rc = getattr(load(), name)(*args)
+    if PROFILE["on"]:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(load(), name)(*args)
+        e1.record()
+        PROFILE["events"].append((name, args[1] if name == "magic_gemm" else -1, e0, e1))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         raise MagicHipError(f"{name} failed: {_ERR.get(rc, rc)}")
 

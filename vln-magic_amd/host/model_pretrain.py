@@ -396,7 +396,10 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             Wemb = self.store.w("bert.embeddings.word_embeddings.weight")
             O.linear_dw(dlog, c.hm, self.store.g("bert.embeddings.word_embeddings.weight"), self.store.g("mlm_head.predictions.bias"),
                         nm, N=Vv, K=H, lda=c.ldv)
-            d_hm = O.linear_dx(dlog, Wemb, nm, N=Vv, K=H, lda=c.ldv)
+            # dx over the 50k-wide vocabulary: split-K into an fp32 accumulator (18 output tiles alone cannot fill 256 CUs)
+            d_hm32 = n.zeros(nm, H, dtype=torch.float32)
+            O.gemm(1, dlog, Wemb, d_hm32, nm, H, Vv, c.ldv, H, H, splitk=32, accumulate=True)
+            d_hm = O.cast_to(d_hm32, self.compute_dtype)
             tn = n.ln("mlm_head.predictions.transform.LayerNorm")
             d_tg = n.new(nm, H)
             O.ln_bwd(nm, H, d_hm, y=c.hm, gamma=tn.g, beta=tn.b, rstd=c.rstd_hm, dx=d_tg, dgamma=tn.dg, dbeta=tn.db)

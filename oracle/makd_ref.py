@@ -70,7 +70,7 @@ LOSS_KEYS = ("txt_emb_loss", "txt_attn_loss", "img_emb_loss", "avg_img_emb_loss"
 
 def nav_makd(t_step, s_out, t_out, proj, acc, *, role="t2s", loss_type="sum", temperature=2.0,
              abilities=("txt", "img", "global", "local", "action"), weights=None, weight_mode="RW",
-             no_feat=False, no_attn=False, no_logit=False, have_targets=True):
+             no_feat=False, no_attn=False, no_logit=False, have_targets=True, mse_fn=None, kd_fn=None):
     """compute_kd_losses (agent.py:546-719) for the mse/mse/kd loss selection of agent_base.py:155-175.
 
     proj: dict of the 5 projection heads (txt_emb_w, kdl_img_w, kdl_avg_img_w, global_cross_w,
@@ -90,10 +90,10 @@ def nav_makd(t_step, s_out, t_out, proj, acc, *, role="t2s", loss_type="sum", te
         return s_val, proj[name](t_val).detach()
 
     def feat(a, b):
-        return 0 if no_feat else mse_loss(a, b, w, loss_type)
+        return 0 if no_feat else (mse_fn or mse_loss)(a, b, w, loss_type)
 
     def attn(a, b):
-        return 0 if no_attn else mse_loss(a, b.detach(), w, loss_type)
+        return 0 if no_attn else (mse_fn or mse_loss)(a, b.detach(), w, loss_type)
 
     if t_step == 0 and "txt" in abilities:
         a, b = sides("txt_emb_w", s_out["txt_embeds"], t_out["txt_embeds"])
@@ -118,7 +118,7 @@ def nav_makd(t_step, s_out, t_out, proj, acc, *, role="t2s", loss_type="sum", te
     if "action" in abilities:
         p = 0
         if not no_logit and have_targets:
-            p = kd_loss(s_out["nav_logits"], t_out["nav_logits"].detach(), temperature, w, loss_type)
+            p = (kd_fn or kd_loss)(s_out["nav_logits"], t_out["nav_logits"].detach(), temperature, w, loss_type)
         acc["predict_loss"] = acc["predict_loss"] + p * k(4)
     return acc
 

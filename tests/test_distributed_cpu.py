@@ -1,0 +1,64 @@
+"""Data-parallel path on CPU with gloo, world_size 2 (the N>1 path of bench.py / trainer.GradSync / broadcast_task).
+One process per rank, rendezvous on 127.0.0.1."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import magic_amd  # noqa: F401
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from magic_amd.host.config import make_config
+        from magic_amd.host.model_pretrain import pretrain_specs
+        from magic_amd.host.params import ParamStore
+        from magic_amd.host.trainer import GradSync, broadcast_task
+        cfg = make_config(128, teacher_hidden_size=256, vocab_size=200, num_l_layers=1, num_x_layers=1, num_pano_layers=1)
+        store = ParamStore(pretrain_specs(cfg), "cpu", torch.float32, seed=100 + rank)      # ranks start different
+        dist.broadcast(store.flat, src=0)                                                   # DDP-ctor semantics (utils/misc.py:62-63)
+        ref = ParamStore(pretrain_specs(cfg), "cpu", torch.float32, seed=100)
+        same_params = bool(torch.equal(store.flat, ref.flat))
+        g = torch.Generator().manual_seed(7 + rank)
+        store.grad.copy_(torch.randn(store.total, generator=g))
+        mine = store.grad.clone()
+        sync = GradSync(store, chunk_elems=10007)            # odd chunk size: exercises the chunk tail
+        gscale = sync.all_reduce()
+        others = [torch.randn(store.total, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
+        want_sum = sum(others)
+        ok_sum = bool(torch.allclose(store.grad, want_sum, rtol=1e-6, atol=1e-6))
+        ok_mean = bool(torch.allclose(store.grad * gscale, want_sum / world, rtol=1e-6, atol=1e-6))
+        # unused-parameter semantics: a rank that did not touch a tensor contributes zeros, result stays consistent
+        task = broadcast_task(2 if rank == 0 else 0, "cpu")   # MetaLoader: rank 0's draw wins (data/loader.py:55-59)
+        q.put((rank, same_params, ok_sum, ok_mean, gscale, task, float(mine.abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gradient_allreduce_param_broadcast_and_task_broadcast():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, same_params, ok_sum, ok_mean, gscale, task, _ in res:
+        assert same_params, f"rank {rank}: parameters differ after broadcast"
+        assert ok_sum and ok_mean, f"rank {rank}: all-reduce result wrong"
+        assert gscale == 0.5 and task == 2

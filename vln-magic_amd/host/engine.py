@@ -389,14 +389,16 @@ class MagicNet:
         O.smallk_ln_bwd(M, H, ll.K, c.loc, dsum, c.A2, n2.g, n2.b, c.rstd_a2, ll.dW, ll.db, n2.dg, n2.db)
 
     # ---- map / viewpoint inputs ----------------------------------------------------------------
-    def gmap_in_fwd(self, plan, pano, gmap_pos_fts):
+    def gmap_in_fwd(self, plan, pano, gmap_pos_fts, gimg=None):
+        """gimg given (nav mode: node embeddings kept by the agent's GraphMap) or aggregated from the panoramas."""
         g, H = self.p + "global_encoder.", self.H
         B, K = plan["B"], plan["K"]
         M = B * K
         c = Ctx(pos=gmap_pos_fts)
-        gimg = self.new(M, H)
-        O.csr_gather(pano.out, *plan["gmap_from_embed"], gimg, M, H)
-        O.csr_gather(pano.fused, *plan["gmap_from_fused"], gimg, M, H, accumulate=True)
+        if gimg is None:
+            gimg = self.new(M, H)
+            O.csr_gather(pano.out, *plan["gmap_from_embed"], gimg, M, H)
+            O.csr_gather(pano.fused, *plan["gmap_from_fused"], gimg, M, H, accumulate=True)
         pl, pn = self.lin(g + "gmap_pos_embeddings.0.weight"), self.ln(g + "gmap_pos_embeddings.1")
         c.A, c.rstd = self.new(M, H), self.new(M, dtype=torch.float32)
         O.smallk_ln_fwd(M, H, pl.K, gmap_pos_fts, pl.Wm, pl.b, pn.g, pn.b, self.eps, c.A, c.rstd)
@@ -412,15 +414,17 @@ class MagicNet:
                  dtabs=((plan["gmap_step_ids"], 0, 0, self.S.g(g + "gmap_step_embeddings.weight"), 0), None, None))
         pl, pn = self.lin(g + "gmap_pos_embeddings.0.weight"), self.ln(g + "gmap_pos_embeddings.1")
         O.smallk_ln_bwd(M, H, pl.K, c.pos, d_in, c.A, pn.g, pn.b, c.rstd, pl.dW, pl.db, pn.dg, pn.db)
-        O.csr_gather(d_in, *plan["gmap_from_embed_T"], d_pano, plan["Np"] * plan["V"], H, accumulate=True)
-        O.csr_gather(d_in, *plan["gmap_from_fused_T"], d_fused, plan["Np"], H, accumulate=True)
+        if d_pano is not None:      # pretrain path: node embeddings were aggregated from the panoramas
+            O.csr_gather(d_in, *plan["gmap_from_embed_T"], d_pano, plan["Np"] * plan["V"], H, accumulate=True)
+            O.csr_gather(d_in, *plan["gmap_from_fused_T"], d_fused, plan["Np"], H, accumulate=True)
 
-    def vp_in_fwd(self, plan, pano, vp_pos_fts):
+    def vp_in_fwd(self, plan, pano, vp_pos_fts, vimg=None):
         l, H = self.p + "local_encoder.", self.H
         M = plan["B"] * plan["Vp"]
         c = Ctx(pos=vp_pos_fts)
-        vimg = self.new(M, H)
-        O.csr_gather(pano.out, *plan["vp_from_embed"], vimg, M, H)
+        if vimg is None:
+            vimg = self.new(M, H)
+            O.csr_gather(pano.out, *plan["vp_from_embed"], vimg, M, H)
         pl, pn = self.lin(l + "vp_pos_embeddings.0.weight"), self.ln(l + "vp_pos_embeddings.1")
         c.A, c.rstd = self.new(M, H), self.new(M, dtype=torch.float32)
         O.smallk_ln_fwd(M, H, pl.K, vp_pos_fts, pl.Wm, pl.b, pn.g, pn.b, self.eps, c.A, c.rstd)
@@ -433,7 +437,8 @@ class MagicNet:
         M = plan["B"] * plan["Vp"]
         pl, pn = self.lin(l + "vp_pos_embeddings.0.weight"), self.ln(l + "vp_pos_embeddings.1")
         O.smallk_ln_bwd(M, H, pl.K, c.pos, d_in, c.A, pn.g, pn.b, c.rstd, pl.dW, pl.db, pn.dg, pn.db)
-        O.csr_gather(d_in, *plan["vp_from_embed_T"], d_pano, plan["Np"] * plan["V"], H, accumulate=True)
+        if d_pano is not None:
+            O.csr_gather(d_in, *plan["vp_from_embed_T"], d_pano, plan["Np"] * plan["V"], H, accumulate=True)
 
     # ---- cross-modal encoders ------------------------------------------------------------------
     def _sprel(self):

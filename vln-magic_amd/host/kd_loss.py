@@ -1,0 +1,104 @@
+"""Drop-in replacements for the reference's MAKD primitives, same names / argument meaning / error behaviour:
+
+    pretrain flavour  pretrain_src/optim/kd_loss.py:5-54      -> mse_loss_pretrain, kd_loss_pretrain
+    nav flavour       map_nav_src/utils/kd_loss.py:6-67       -> mse_loss, kd_loss (loss_type='sum'|'mean')
+    both              exponential_decay, invert_normalized_losses
+
+Each loss is a torch.autograd.Function over ONE fused HIP kernel that produces the loss value and the gradient
+wrt the student input in the same pass (csrc/loss.hip), so `GMapNavAgent.compute_kd_losses`
+(map_nav_src/r2r/agent.py:546-719) runs unchanged on top of them.  CUDA tensors only: there is no CPU fallback.
+"""
+import torch
+
+from . import lib as L
+from . import ops as O
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.MagicHipError("magic_amd.kd_loss runs on the GPU only (no CPU fallback); got a CPU tensor")
+
+
+class _MSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s, t, w, norm):
+        _need_cuda(s, t, w)
+        dt = s.dtype if s.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        sc, tc = s.detach().to(dt).contiguous(), t.detach().to(dt).contiguous()
+        outer = sc.shape[0]
+        inner = sc.numel() // outer
+        loss = torch.zeros(1, dtype=torch.float32, device=s.device)
+        ds = torch.empty_like(sc) if s.requires_grad else None
+        O.mse(sc, tc, outer, inner, inner, inner, w=None if w is None else w.detach().float().contiguous(), rows_per_w=1,
+              norm=norm, coef=1.0, loss=loss, ds=ds, g_stride=inner)
+        ctx.ds, ctx.in_dtype = ds, s.dtype
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.ds is None:
+            return None, None, None, None
+        return (ctx.ds.float() * g).to(ctx.in_dtype), None, None, None
+
+
+class _KD(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s, t, w, temperature, norm):
+        _need_cuda(s, t, w)
+        sc, tc = s.detach().float().contiguous(), t.detach().float().contiguous()
+        M, N = sc.shape
+        rows = torch.empty(M, dtype=torch.float32, device=s.device)
+        ds = torch.empty_like(sc) if s.requires_grad else None
+        O.kd_rows(sc, tc, M, N, N, temperature, w=None if w is None else w.detach().float().contiguous(), norm=norm, coef=1.0,
+                  loss_row=rows, ds=ds)
+        ctx.ds, ctx.in_dtype = ds, s.dtype
+        return rows.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.ds is None:
+            return None, None, None, None, None
+        return (ctx.ds * g).to(ctx.in_dtype), None, None, None, None
+
+
+# ---- nav flavour (map_nav_src/utils/kd_loss.py) --------------------------------------------------------
+def mse_loss(s_inputs, t_inputs, t_sample_weights=None, loss_type="sum", **kwargs):
+    if loss_type not in ("sum", "mean"):
+        raise ValueError("Unsupported loss_type. Choose 'sum' or 'mean'.")
+    if t_sample_weights is not None and s_inputs.shape[0] != t_sample_weights.shape[0]:
+        raise ValueError("Shape mismatch between sample weights and inputs")
+    norm = 1.0 if loss_type == "sum" else 1.0 / s_inputs.numel()
+    return _MSE.apply(s_inputs, t_inputs, t_sample_weights, norm)
+
+
+def kd_loss(student_logits, teacher_logits, temperature=1, epsilon=1e-6, t_sample_weights=None, loss_type="sum", **kwargs):
+    M, N = student_logits.shape
+    if loss_type == "sum":
+        norm = 1.0
+    elif loss_type == "mean":
+        norm = 1.0 / M if t_sample_weights is not None else 1.0 / (M * N)
+    else:
+        raise ValueError("Unsupported loss_type. Choose 'sum' or 'mean'.")
+    return _KD.apply(student_logits, teacher_logits, t_sample_weights, float(temperature), norm)
+
+
+# ---- pretrain flavour (pretrain_src/optim/kd_loss.py) ---------------------------------------------------
+def mse_loss_pretrain(s_inputs, t_inputs, t_sample_weights=None, **kwargs):
+    w = t_sample_weights
+    if w is not None and s_inputs.shape[0] != w.shape[0]:
+        w = None                       # silent fallback to the unweighted mean (kd_loss.py:15-16)
+    return _MSE.apply(s_inputs, t_inputs, w, 1.0 / s_inputs.numel())
+
+
+def kd_loss_pretrain(student_logits, teacher_logits, temperature=1, epsilon=1e-6, t_sample_weights=None, **kwargs):
+    return kd_loss(student_logits, teacher_logits, temperature, epsilon, t_sample_weights, loss_type="mean")
+
+
+def exponential_decay(t_sample_losses, decay_rate=0.1):
+    return torch.exp(-decay_rate * t_sample_losses)
+
+
+def invert_normalized_losses(t_sample_losses, **kwargs):
+    lo, hi = torch.min(t_sample_losses), torch.max(t_sample_losses)
+    return 1 - (t_sample_losses - lo) / (hi - lo)

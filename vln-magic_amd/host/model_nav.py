@@ -1,0 +1,314 @@
+"""`VLNBert(args, role)` -- the navigation-time model the reference imports from its withheld `models.model`
+(map_nav_src/r2r/agent.py:30; ctor :36-38) -- on the HIP engine.
+
+Call surface kept:  `vln_bert(mode, inputs)` with mode in
+  'language'   -> (txt_embeds [B,L,H], txt_attns [B,h,L,L])                               agent.py:796
+  'panorama'   -> (pano_embeds [B,V,H], pano_masks [B,V], pano_fused_embeds [B,H], img_attns [B,V,V])   :885
+  'navigation' -> dict(gmap_embeds, vp_embeds, gmap_attns, vp_attns, cls_embeds,
+                       global_logits, local_logits, fused_logits)                          :964-967
+plus `.vln_bert.<kd head>` callables (`txt_emb_w`, `kdl_img_w`, `kdl_avg_img_w`, `global_cross_w`,
+`local_cross_w`; agent.py:568-665, agent_base.py:330), `.drop_env` (:738), `.parameters()`, `.state_dict()`.
+
+Every mode is ONE torch.autograd.Function: forward runs the engine segment, backward runs the hand-written
+backward and returns gradients for the tensor inputs (txt_embeds, gmap_img_embeds, vp_img_embeds) so the
+agent's Python between the calls (GraphMap bookkeeping, compute_kd_losses, CE) composes with autograd unchanged;
+parameter gradients land directly in `param.grad` (views of the flat gradient buffer).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops as O
+from .config import cfg_get, make_config
+from .engine import Ctx, MagicNet, cls_specs, trunk_specs
+from .params import ParamStore
+
+KD_HEADS = ("txt_emb_w", "kdl_img_w", "kdl_avg_img_w", "global_cross_w", "local_cross_w")
+
+
+def nav_specs(cfg, p="vln_bert."):
+    H = cfg.hidden_size
+    s = trunk_specs(cfg, p)
+    s += cls_specs(p + "global_sap_head.", H) + cls_specs(p + "local_sap_head.", H) + cls_specs(p + "sap_fuse_linear.", H, 2 * H)
+    for k in ("txt", "img", "local", "global", "predict"):       # learned ability weights, agent.py:1130-1134
+        s.append((f"{p}kdl_{k}_weight", (1,), "zeros"))
+    return s
+
+
+class _HipLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod):
+        net, lin = mod._net, mod._lin
+        shp = x.shape
+        M = x.numel() // shp[-1]
+        xc = x.detach().to(net.dtype).reshape(M, shp[-1]).contiguous()
+        y = O.linear_fwd(xc, lin.W, lin.b, M)
+        ctx.mod, ctx.x, ctx.shape, ctx.in_dtype = mod, xc, shp, x.dtype
+        return y.view(*shp[:-1], lin.N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        net, lin = ctx.mod._net, ctx.mod._lin
+        M = ctx.x.shape[0]
+        d = dy.to(net.dtype).reshape(M, lin.N).contiguous()
+        if net.train:
+            O.linear_dw(d, ctx.x, lin.dW, lin.db, M)
+        dx = O.linear_dx(d, lin.W, M)
+        return dx.view(ctx.shape).to(ctx.in_dtype), None
+
+
+class HipLinear(nn.Module):
+    """A Linear whose weight/bias live in the ParamStore; callable like nn.Linear (KD projection heads)."""
+
+    def forward(self, x):
+        return _HipLinearFn.apply(x, self)
+
+
+def _zeros_like_shape(t, shape, dtype, device):
+    return torch.zeros(shape, dtype=dtype, device=device) if t is None else t
+
+
+class _LanguageFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, txt_ids, txt_masks):
+        net = model.net
+        B, L = txt_ids.shape
+        lens = txt_masks.sum(1).tolist()
+        plan = dict(B=B, L=L, txt_ids=txt_ids.reshape(-1).to(torch.int32), txt_mask=txt_masks.to(torch.uint8).contiguous(),
+                    lens=dict(txt=lens), txt_tokens=int(sum(lens)))
+        c = net.text_fwd(plan)
+        ctx.model, ctx.c, ctx.plan = model, c, plan
+        return c.out.view(B, L, net.H), c.P[..., :L]
+
+    @staticmethod
+    def backward(ctx, d_out, d_attn):
+        net, c = ctx.model.net, ctx.c
+        B, L = c.B, c.L
+        d = torch.zeros(B * L, net.H, dtype=net.dtype, device=c.out.device) if d_out is None else d_out.to(net.dtype).reshape(B * L, net.H).contiguous()
+        dP = None
+        if d_attn is not None:
+            dP = torch.zeros(B, net.nh, L, c.ldp, dtype=torch.float32, device=c.out.device)
+            dP[..., :L] = d_attn.float()
+        net.text_bwd(c, ctx.plan, d, dP)
+        return None, None, None, None
+
+
+class _PanoramaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, view_img_fts, loc_fts, nav_types, view_lens):
+        net = model.net
+        B, V, D = view_img_fts.shape
+        dev = view_img_fts.device
+        plan = dict(Np=B, V=V, nav_types=nav_types.reshape(-1).to(torch.int32), view_lens=view_lens.to(torch.int32),
+                    pano_mask=(torch.arange(V, device=dev)[None] < view_lens[:, None]).to(torch.uint8))
+        feats = O.cast_to(view_img_fts.detach().float().reshape(B * V, D).contiguous(), net.dtype)
+        c = net.pano_fwd(plan, feats, loc_fts.detach().float().reshape(B * V, -1).contiguous())
+        ctx.model, ctx.c, ctx.plan = model, c, plan
+        masks = plan["pano_mask"].bool()
+        ctx.mark_non_differentiable(masks)
+        return c.out.view(B, V, net.H), masks, c.fused, c.img_attn[..., :V]
+
+    @staticmethod
+    def backward(ctx, d_emb, _dm, d_fused, d_attn):
+        net, c = ctx.model.net, ctx.c
+        Np, V, H = c.Np, c.V, net.H
+        dev = c.out.device
+        d_pano = torch.zeros(Np * V, H, dtype=net.dtype, device=dev) if d_emb is None else d_emb.to(net.dtype).reshape(Np * V, H).clone()
+        df = None if d_fused is None else d_fused.to(net.dtype).contiguous()
+        dP = None
+        if d_attn is not None:
+            g = torch.zeros(Np, V, c.ldp, dtype=torch.float32, device=dev)
+            g[..., :V] = d_attn.float()
+            dP = torch.empty(Np, net.nh, V, c.ldp, dtype=torch.float32, device=dev)
+            O.head_mean_bwd(g, dP, Np, net.nh, V * c.ldp)
+        net.pano_bwd(c, ctx.plan, d_pano, df, dP)
+        return None, None, None, None, None, None
+
+
+def nav_fusion_plan(gmap_vpids, gmap_visited_masks, vp_cand_vpids, K, Vp):
+    """local->global fusion map for the navigation step ([LINEAGE] DUET nav forward): gmap_vpids[b] =
+    [None, (None mem)?, visited..., unvisited...]; vp_cand_vpids[b][j] is the viewpoint of local token j (None for
+    [stop]/[mem]/non-candidate views)."""
+    B = len(gmap_vpids)
+    fsrc = np.full((B, K), -1, np.int32)
+    bw = np.zeros((B, Vp), np.uint8)
+    vm = gmap_visited_masks.cpu().numpy()
+    for b in range(B):
+        visited = set(vp for j, vp in enumerate(gmap_vpids[b]) if vp is not None and vm[b, j])
+        tmp = {}
+        for j, c in enumerate(vp_cand_vpids[b]):
+            if c is None or j == 0:
+                continue
+            if c in visited:
+                bw[b, j] = 1
+            else:
+                tmp[c] = j
+        fsrc[b, 0] = 0
+        for j, vp in enumerate(gmap_vpids[b]):
+            if j > 0 and vp is not None and vp not in visited:
+                fsrc[b, j] = tmp[vp] if vp in tmp else -2
+    return fsrc, bw
+
+
+class _NavigationFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, gmap_img, vp_img, txt_embeds, b):
+        net, p = model.net, model.prefix
+        H = net.H
+        dev = gmap_img.device
+        B, K, _ = gmap_img.shape
+        Vp = vp_img.shape[1]
+        L = txt_embeds.shape[1]
+        txt_masks = b["txt_masks"]
+        tl = txt_masks.sum(1).tolist()
+        gl_ = b["gmap_masks"].sum(1).tolist()
+        vl = b["vp_masks"].sum(1).tolist()
+        plan = dict(B=B, K=K, Vp=Vp, L=L, gmap_step_ids=b["gmap_step_ids"].reshape(-1).to(torch.int32))
+        c = Ctx(plan=plan, B=B, K=K, Vp=Vp, L=L)
+        txt = txt_embeds.detach().to(net.dtype).reshape(B * L, H).contiguous()
+        tmask = txt_masks.to(torch.uint8).contiguous()
+        gmask_u8 = b["gmap_masks"].to(torch.uint8).contiguous()
+        vmask_u8 = b["vp_masks"].to(torch.uint8).contiguous()
+        c.gin = net.gmap_in_fwd(plan, None, b["gmap_pos_fts"].float().reshape(B * K, -1).contiguous(),
+                                gimg=gmap_img.detach().to(net.dtype).reshape(B * K, H).contiguous())
+        c.glob = net.cross_fwd("global", plan, c.gin.out, K, gmask_u8, gl_, int(sum(gl_)), txt, L, tmask, tl, int(sum(tl)),
+                               dist=b["gmap_pair_dists"].float().contiguous())
+        c.vin = net.vp_in_fwd(plan, None, b["vp_pos_fts"].float().reshape(B * Vp, -1).contiguous(),
+                              vimg=vp_img.detach().to(net.dtype).reshape(B * Vp, H).contiguous())
+        c.loc = net.cross_fwd("local", plan, c.vin.out, Vp, vmask_u8, vl, int(sum(vl)), txt, L, tmask, tl, int(sum(tl)))
+        # heads
+        c.Yg, c.g_raw = model._cls(p + "global_sap_head.", c.glob.out, B * K)
+        c.Yl, c.l_raw = model._cls(p + "local_sap_head.", c.loc.out, B * Vp)
+        c.use_gate = bool(cfg_get(net.cfg, "glocal_fuse"))
+        if c.use_gate:
+            f1 = net.lin(p + "sap_fuse_linear.net.0.weight")
+            tmp = O.linear_fwd(c.glob.out, f1.W, None, B, lda=K * H, ldb=2 * H, K=H)
+            c.Yf = O.linear_fwd(c.loc.out, f1.W[:, H:], f1.b, B, lda=Vp * H, ldb=2 * H, K=H, residual=tmp)
+            O.dact(c.Yf, c.Yf, 2, out=c.Yf)
+            fln, f2 = net.ln(p + "sap_fuse_linear.net.2"), net.lin(p + "sap_fuse_linear.net.3.weight")
+            c.fuse_raw = net.new(B, dtype=torch.float32)
+            O.lndot_fwd(c.Yf, B, H, fln.g, fln.b, net.eps, f2.Wm, f2.b, c.fuse_raw)
+        else:
+            c.fuse_raw = net.zeros(B, dtype=torch.float32)
+        c.gmask = ((~b["gmap_visited_masks"]) & b["gmap_masks"]).to(torch.uint8).contiguous()
+        c.lmask = b["vp_nav_masks"].to(torch.uint8).contiguous()
+        fsrc, bw = nav_fusion_plan(b["gmap_vpids"], b["gmap_visited_masks"], b["vp_cand_vpids"], K, Vp)
+        c.fsrc, c.bw = torch.from_numpy(fsrc).to(dev), torch.from_numpy(bw).to(dev)
+        gl, ll, fl = net.new(B, K, dtype=torch.float32), net.new(B, Vp, dtype=torch.float32), net.new(B, K, dtype=torch.float32)
+        O.sap_fuse_fwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, c.gmask, c.lmask, c.fsrc, c.bw, c.use_gate, gl, ll, fl)
+        # cls_embeds: the [stop]-token summary the agent feeds back as the [MEM] token (agent.py:206-210); open choice O9
+        cls = net.new(B, H)
+        O.csr_gather(c.glob.out, *model._first_rows(B, K, dev), cls, B, H)
+        O.csr_gather(c.loc.out, *model._first_rows(B, Vp, dev), cls, B, H, accumulate=True)
+        ctx.model, ctx.c = model, c
+        ctx.in_dtypes = (gmap_img.dtype, vp_img.dtype, txt_embeds.dtype)
+        return (c.glob.out.view(B, K, H), c.loc.out.view(B, Vp, H), c.glob.P[..., :L], c.loc.P[..., :L], cls, gl, ll, fl)
+
+    @staticmethod
+    def backward(ctx, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl):
+        model, c = ctx.model, ctx.c
+        net, p = model.net, model.prefix
+        B, K, Vp, L, H = c.B, c.K, c.Vp, c.L, net.H
+        dev = c.glob.out.device
+        T = net.dtype
+        d_gmap = torch.zeros(B * K, H, dtype=T, device=dev) if d_g is None else d_g.to(T).reshape(B * K, H).clone()
+        d_vp = torch.zeros(B * Vp, H, dtype=T, device=dev) if d_v is None else d_v.to(T).reshape(B * Vp, H).clone()
+        d_txt = torch.zeros(B * L, H, dtype=T, device=dev)
+        if d_cls is not None:
+            dc = d_cls.to(T).contiguous()
+            O.csr_gather(dc, *model._first_rows_T(B, K, dev), d_gmap, B * K, H, accumulate=True)
+            O.csr_gather(dc, *model._first_rows_T(B, Vp, dev), d_vp, B * Vp, H, accumulate=True)
+        if dgl is not None or dll is not None or dfl is not None:
+            f32 = lambda t: None if t is None else torch.nan_to_num(t.float(), nan=0.0, posinf=0.0, neginf=0.0).contiguous()
+            dg, dl, df = net.new(B, K, dtype=torch.float32), net.new(B, Vp, dtype=torch.float32), net.new(B, dtype=torch.float32)
+            O.sap_fuse_bwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, c.gmask, c.lmask, c.fsrc, c.bw, c.use_gate, f32(dgl), f32(dll), f32(dfl), dg, dl, df)
+            model._cls_bwd(p + "global_sap_head.", c.glob.out, c.Yg, dg, B * K, d_gmap)
+            model._cls_bwd(p + "local_sap_head.", c.loc.out, c.Yl, dl, B * Vp, d_vp)
+            if c.use_gate:
+                f1, fln, f2 = net.lin(p + "sap_fuse_linear.net.0.weight"), net.ln(p + "sap_fuse_linear.net.2"), net.lin(p + "sap_fuse_linear.net.3.weight")
+                dZ = net.new(B, H)
+                O.lndot_bwd(c.Yf, B, H, fln.g, fln.b, net.eps, f2.Wm, df, dZ, fln.dg, fln.db, f2.dW, f2.db)
+                O.linear_dw(dZ, c.glob.out, f1.dW, f1.db, B, N=H, K=H, ldb=K * H, ldc=2 * H)
+                O.linear_dw(dZ, c.loc.out, f1.dW[:, H:], None, B, N=H, K=H, ldb=Vp * H, ldc=2 * H)
+                O.linear_dx(dZ, f1.W, B, out=d_gmap, residual=d_gmap, ldb=2 * H, ldc=K * H, N=H, K=H)
+                O.linear_dx(dZ, f1.W[:, H:], B, out=d_vp, residual=d_vp, ldb=2 * H, ldc=Vp * H, N=H, K=H)
+
+        def attn_seed(d, P, Nq):
+            if d is None:
+                return None
+            dP = torch.zeros(B, net.nh, Nq, P.shape[-1], dtype=torch.float32, device=dev)
+            dP[..., :L] = d.float()
+            return dP
+        d_gin = net.cross_bwd(c.glob, d_gmap, d_txt, attn_seed(d_ga, c.glob.P, K))
+        d_vin = net.cross_bwd(c.loc, d_vp, d_txt, attn_seed(d_va, c.loc.P, Vp))
+        net.gmap_in_bwd(c.gin, c.plan, d_gin, None, None)
+        net.vp_in_bwd(c.vin, c.plan, d_vin, None)
+        a, b_, t_ = ctx.in_dtypes
+        return (None, None, d_gin.view(B, K, H).to(a), d_vin.view(B, Vp, H).to(b_), d_txt.view(B, L, H).to(t_), None)
+
+
+class VLNBert(nn.Module):
+    def __init__(self, args, role="student", device="cuda", compute_dtype=torch.bfloat16, seed=0, config=None):
+        """args: the agent's argparse namespace (map_nav_src/r2r/parser.py) or None with an explicit `config`."""
+        super().__init__()
+        if config is None:
+            hs = getattr(args, "teacher_hidden_size" if role == "teacher" else "hidden_size", 768)
+            t_hs = getattr(args, "teacher_hidden_size", None) if role != "teacher" else None
+            config = make_config(hs, role=role, teacher_hidden_size=t_hs if getattr(args, "train_kdl", False) else None,
+                                 num_l_layers=getattr(args, "num_l_layers", 6), num_x_layers=getattr(args, "num_x_layers", 3),
+                                 num_pano_layers=getattr(args, "num_pano_layers", 2), graph_sprels=getattr(args, "graph_sprels", True))
+        self.config, self.role, self.prefix = config, role, "vln_bert."
+        self.device_, self.compute_dtype = torch.device(device), compute_dtype
+        trainable = role != "teacher" or bool(getattr(args, "train_kdl_teacher", False))
+        self.store = ParamStore(nav_specs(config), device, compute_dtype, init_std=cfg_get(config, "initializer_range"),
+                                seed=seed, requires_grad=trainable)
+        self.store.attach_to(self)
+        self.net = MagicNet(config, self.store, self.prefix)
+        self.drop_env = nn.Dropout(p=getattr(args, "feat_dropout", 0.0))      # agent.py:738
+        self._anchor = torch.zeros(1, device=self.device_, requires_grad=True)
+        self._rows = {}
+        if getattr(config, "teacher_hidden_size", None):
+            for n in KD_HEADS:
+                m = getattr(self.vln_bert, n)
+                m.__class__ = HipLinear
+                m._net, m._lin = self.net, self.net.lin(f"{self.prefix}{n}.weight")
+        self.register_load_state_dict_post_hook(lambda m, k: setattr(m.store, "shadow_clean", False))
+
+    def cuda(self, device=None):           # `VLNBert(args, role).cuda()` (agent.py:36-38): already resident
+        return self
+
+    # shared head helpers (same kernels as the pretraining model)
+    from .model_pretrain import GlocalTextPathCMTPreTraining as _P
+    _cls, _cls_bwd = _P._cls, _P._cls_bwd
+    del _P
+
+    def _first_rows(self, B, N, dev):
+        key = ("f", B, N)
+        if key not in self._rows:
+            from .plan import csr_pair
+            f, t = csr_pair([(b, b * N, 1.0) for b in range(B)], B, B * N)
+            self._rows[key] = tuple(torch.from_numpy(a).to(dev) for a in f)
+            self._rows[("t", B, N)] = tuple(torch.from_numpy(a).to(dev) for a in t)
+        return self._rows[key]
+
+    def _first_rows_T(self, B, N, dev):
+        self._first_rows(B, N, dev)
+        return self._rows[("t", B, N)]
+
+    def forward(self, mode, batch):
+        self.store.sync_shadow()
+        if mode == "language":
+            return _LanguageFn.apply(self._anchor, self, batch["txt_ids"], batch["txt_masks"])
+        if mode == "panorama":
+            fts = batch["view_img_fts"]
+            if not batch.get("already_dropout", True):
+                fts = self.drop_env(fts)
+            return _PanoramaFn.apply(self._anchor, self, fts, batch["loc_fts"], batch["nav_types"], batch["view_lens"])
+        if mode == "navigation":
+            data = {k: batch[k] for k in ("txt_masks", "gmap_masks", "vp_masks", "gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists",
+                                          "gmap_visited_masks", "gmap_vpids", "vp_pos_fts", "vp_nav_masks", "vp_cand_vpids")}
+            g, v, ga, va, cls, gl, ll, fl = _NavigationFn.apply(self._anchor, self, batch["gmap_img_embeds"], batch["vp_img_embeds"],
+                                                                batch["txt_embeds"], data)
+            return dict(gmap_embeds=g, vp_embeds=v, gmap_attns=ga, vp_attns=va, cls_embeds=cls,
+                        global_logits=gl, local_logits=ll, fused_logits=fl)
+        raise NotImplementedError(f"VLNBert mode {mode!r} (instr_zdict_update / extract_cfp_features are SURVEY §8 f-4, not built)")

@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--pool", type=int, default=12, help="distinct pre-generated batches (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager"], help="graph: replay one captured HIP graph per step")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,12 +126,31 @@ def main():
         pool.append((task, synth.batch_to(b, dev), plan))
     torch.cuda.synchronize()
 
-    def run(n, start=0):
+    def run_eager(n, start=0):
         traj = 0
         for s in range(n):
             task, b, plan = pool[(start + s) % len(pool)]
             trainer.step(b, task, plan=plan)
             traj += plan["traj_steps"]
+        return traj
+
+    graphs = None
+    if a.mode == "graph":
+        # one HIP graph per resident batch (each batch has its own ragged shapes); every replay executes the full
+        # step: teacher fwd, student fwd+losses+bwd, clip, AdamW -- with lr / bias-correction / MKRW read from device memory
+        run_eager(min(3, len(pool)))                       # allocator + code-object warm-up
+        torch.cuda.synchronize()
+        graphs = [trainer.capture(b, task, plan) for task, b, plan in pool]
+        torch.cuda.synchronize()
+
+    def run(n, start=0):
+        if graphs is None:
+            return run_eager(n, start)
+        traj = 0
+        for s in range(n):
+            cs = graphs[(start + s) % len(graphs)]
+            trainer.replay(cs)
+            traj += cs.traj_steps
         return traj
 
     run(a.warmup)
@@ -159,7 +179,7 @@ def main():
         nprof = min(len(pool), 6)
         O.FLOPS.update(total=0.0, enabled=True)
         L.PROFILE.update(on=True, events=[])
-        run(nprof, start=0)
+        run_eager(nprof, start=0)
         torch.cuda.synchronize()
         L.PROFILE["on"] = False
         O.FLOPS["enabled"] = False
@@ -190,7 +210,7 @@ def main():
         info = {"metric": "trajectory-steps/sec (whole node), MAGIC-S R2R pretrain", "value": round(traj / dt, 2),
                 "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": a.dtype, "data": "synthetic",
+                "dtype": a.dtype, "data": "synthetic", "launch": a.mode,
                 "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "
                                        "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip",
                            "global_batch": a.batch * world, "per_gpu_batch": a.batch, "views": 36, "feat_dim": 768, "max_tokens": 80,

@@ -85,10 +85,10 @@ int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld, const int
                   float* w_out, float w_rate, void* stream);
 /* kd_loss (pretrain_src/optim/kd_loss.py:18-41, map_nav_src/utils/kd_loss.py:27-54): -inf -> -1e6, T-softmax KL * T^2 */
 int magic_kd_rows(int M, int N, const float* s, const float* t, int ld, float temperature, const float* w, float norm,
-                  float coef, float* loss_row, float* ds, int accumulate, void* stream);
+                  float coef, const float* coef_dev, float* loss_row, float* ds, int accumulate, void* stream);
 /* mse_loss (kd_loss.py:5-16 / :6-25): sum_b w_b (s-t)^2 * norm, grad 2*coef*norm*w*(s-t) */
 int magic_mse(int dtype, int g_f32, long long outer, long long inner, const void* s, long long s_stride, const void* t,
-              long long t_stride, const float* w, long long rows_per_w, float norm, float coef, float* loss, void* ds,
+              long long t_stride, const float* w, long long rows_per_w, float norm, float coef, const float* coef_dev, float* loss, void* ds,
               long long g_stride, int accumulate, void* stream);
 
 /* out[n] (+)= sum_e w[e]*src[idx[e]]: map-node aggregation by viewpoint id (agent.py:905-924 semantics),
@@ -113,7 +113,10 @@ int magic_sap_fuse_bwd(int B, int K, int Vp, const float* g_raw, const float* l_
 int magic_sumsq(long long n, const float* g, float* out, void* stream);
 int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow_bf16,
                 float lr, float b1, float b2, float eps, float wd, float step_size,
-                const float* sumsq, float max_norm, float gscale, void* stream);
+                const float* sumsq, float max_norm, float gscale, const float* lr_ss, void* stream);
+/* device-side lr schedule + Adam bias correction (optim/sched.py:17-30, adamw.py:97-100) for HIP-graph replay; coef_dev / lr_ss
+ * arguments above are optional device scalars multiplied into / replacing the host values */
+int magic_sched_step(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, void* stream);
 int magic_cast(int to_bf16, long long n, const void* x, void* y, void* stream);
 int magic_add(int dtype, long long n, const void* x, void* y, void* stream);
 int magic_dact(int dtype, int kind, long long n, const void* dy, const void* z, void* dz, void* stream);

@@ -23,18 +23,20 @@ struct GemmParams {
 };
 
 template <typename T> struct TT;
+// STRIDE: row stride of a k-contiguous operand's LDS image [out][k]; SN: row stride of an out-contiguous operand's
+// natural image [k][out] (read back transposed: ds_read_b64_tr_b16 for bf16, plain dword reads for f32).
 template <> struct TT<bf16> {
-  static constexpr int VE = 8, BK = 64, STRIDE = 72;
+  static constexpr int VE = 8, BK = 64, STRIDE = 72, SN = 72;
   typedef bf16x8 vec;
 };
 template <> struct TT<float> {
-  static constexpr int VE = 4, BK = 32, STRIDE = 34;
+  static constexpr int VE = 4, BK = 32, STRIDE = 34, SN = 68;
   typedef f32x4 vec;
 };
 
 template <typename T, bool KC> struct TileLoader {
   typedef typename TT<T>::vec vec;
-  static constexpr int VE = TT<T>::VE, BK = TT<T>::BK, STRIDE = TT<T>::STRIDE;
+  static constexpr int VE = TT<T>::VE, BK = TT<T>::BK, STRIDE = TT<T>::STRIDE, SN = TT<T>::SN;
   vec v[2];
   // tile = 64 out rows x BK k's.  KC: source is [OUT][K] (k contiguous); else [K][OUT].
   __device__ __forceinline__ void load(const T* __restrict__ base, int ld, int out0, int k0, int OUT, int kend) {
@@ -73,27 +75,46 @@ template <typename T, bool KC> struct TileLoader {
       } else {
         constexpr int VPR = 64 / VE;
         int r = id / VPR, ov = id % VPR;
-#pragma unroll
-        for (int e = 0; e < VE; ++e) s[(ov * VE + e) * STRIDE + r] = v[i][e];
+        *(vec*)(s + r * SN + ov * VE) = v[i];          // natural [k][out] image, 16-byte store
       }
     }
   }
 };
 
-template <typename T>
-__device__ __forceinline__ void mma_tile(const T* sA, const T* sB, int wr, int wc, int lane, f32x4 (&acc)[2][2]);
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
-template <>
-__device__ __forceinline__ void mma_tile<bf16>(const bf16* sA, const bf16* sB, int wr, int wc, int lane, f32x4 (&acc)[2][2]) {
-  constexpr int S = TT<bf16>::STRIDE;
-  const int r = lane & 15, g = lane >> 4;
+// one MFMA operand fragment of the 16 out-rows starting at out0, k-step ks.  Lane map (A and B alike):
+// lane l holds X[out0 + (l&15)][k = kbase + 8*(l>>4) + j] (bf16, j<8) / X[out0 + (l&15)][k = kbase + (l>>4)] (f32).
+template <bool KC>
+__device__ __forceinline__ bf16x8 frag(const bf16* s, int out0, int ks, int lane) {
+  if constexpr (KC) {
+    return *(const bf16x8*)(s + (out0 + (lane & 15)) * TT<bf16>::STRIDE + ks * 32 + 8 * (lane >> 4));
+  } else {
+    // natural [k][out] image: each 16-lane group g transposes rows k = 8g..8g+3 (+4) x 16 outs with ds_read_b64_tr_b16;
+    // lane 4q+p of the group addresses row q, outs 4p..4p+3 and receives out (l&15) of the 4 rows
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const bf16* b = s + (ks * 32 + 8 * g + q) * TT<bf16>::SN + out0 + 4 * pp;
+    typedef bf16x4_t __attribute__((address_space(3))) * lds4;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * TT<bf16>::SN));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+template <bool KC>
+__device__ __forceinline__ float frag(const float* s, int out0, int ks, int lane) {
+  if constexpr (KC) return s[(out0 + (lane & 15)) * TT<float>::STRIDE + ks * 4 + (lane >> 4)];
+  else return s[(ks * 4 + (lane >> 4)) * TT<float>::SN + out0 + (lane & 15)];
+}
+
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void mma_tile(const bf16* sA, const bf16* sB, int wr, int wc, int lane, f32x4 (&acc)[2][2]) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     bf16x8 a[2], b[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      a[i] = *(const bf16x8*)(sA + (wr * 32 + i * 16 + r) * S + ks * 32 + 8 * g);
-      b[i] = *(const bf16x8*)(sB + (wc * 32 + i * 16 + r) * S + ks * 32 + 8 * g);
+      a[i] = frag<A_KC>(sA, wr * 32 + i * 16, ks, lane);
+      b[i] = frag<B_KC>(sB, wc * 32 + i * 16, ks, lane);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -102,17 +123,15 @@ __device__ __forceinline__ void mma_tile<bf16>(const bf16* sA, const bf16* sB, i
   }
 }
 
-template <>
-__device__ __forceinline__ void mma_tile<float>(const float* sA, const float* sB, int wr, int wc, int lane, f32x4 (&acc)[2][2]) {
-  constexpr int S = TT<float>::STRIDE;
-  const int r = lane & 15, g = lane >> 4;
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void mma_tile(const float* sA, const float* sB, int wr, int wc, int lane, f32x4 (&acc)[2][2]) {
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
     float a[2], b[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      a[i] = sA[(wr * 32 + i * 16 + r) * S + ks * 4 + g];
-      b[i] = sB[(wc * 32 + i * 16 + r) * S + ks * 4 + g];
+      a[i] = frag<A_KC>(sA, wr * 32 + i * 16, ks, lane);
+      b[i] = frag<B_KC>(sB, wc * 32 + i * 16, ks, lane);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -125,6 +144,7 @@ __device__ __forceinline__ void mma_tile<float>(const float* sA, const float* sB
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int BK = TT<T>::BK, STRIDE = TT<T>::STRIDE;
+  static_assert(BM * TT<T>::STRIDE >= TT<T>::BK * TT<T>::SN, "LDS image sizes");
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
   __shared__ __attribute__((aligned(16))) T sA[BM * STRIDE];
   __shared__ __attribute__((aligned(16))) T sB[BN * STRIDE];
@@ -167,47 +187,118 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       la.load(A, p.lda, m0, (kt + 1) * BK, p.M, p.K);
       lb.load(B, p.ldb, n0, (kt + 1) * BK, p.N, p.K);
     }
-    mma_tile<T>(sA, sB, wr, wc, lane, acc);
+    mma_tile<A_KC, B_KC>(sA, sB, wr, wc, lane, acc);
     if (do_bgrad && tid < BM) {
       float s = 0.f;
 #pragma unroll 8
-      for (int k = 0; k < BK; ++k) s += to_f(sA[tid * STRIDE + k]);
+      for (int k = 0; k < BK; ++k) s += to_f(sA[k * TT<T>::SN + tid]);      // TN: A is held as the natural [k][out] image
       bsum += s;
     }
     __syncthreads();
   }
   if (do_bgrad && tid < BM && m0 + tid < p.M) atomicAdd(p.bias_grad + m0 + tid, bsum);
 
-  // epilogue: C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+  // epilogue: C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+  // Structured as {all loads} -> {math} -> {all stores}: gfx950's vmcnt counts stores too, so interleaving
+  // per-element loads and stores serialises 16 memory round trips per thread (measured: +4 us per launch).
   const int cr = (lane >> 4) * 4, cc = lane & 15;
+  float v[16], ax[16], rs[16];
+  bool ok[16];
+  float bv[2] = {0.f, 0.f};
+  const bool has_aux = (p.epilogue == 3 || p.epilogue == 4);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 32 + j * 16 + cc;
+    if (p.bias && sk == 0 && col < p.N) bv[j] = p.bias[col];
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wc * 32 + j * 16 + cc;
-      if (col >= p.N) continue;
-      const float bv = (p.bias && sk == 0) ? p.bias[col] : 0.f;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wr * 32 + i * 16 + cr + r;
-        if (row >= p.M) continue;
-        float v = acc[i][j][r] * p.alpha + bv;
-        if (p.C2) ((T*)p.C2)[coff + (long long)row * p.ldc2 + col] = from_f<T>(v);
-        if (p.epilogue == 1) v = gelu_f(v);
-        else if (p.epilogue == 2) v = fmaxf(v, 0.f);
-        else if (p.epilogue == 3) v *= dgelu_f(to_f(((const T*)p.aux)[coff + (long long)row * p.ldaux + col]));
-        else if (p.epilogue == 4) v = to_f(((const T*)p.aux)[coff + (long long)row * p.ldaux + col]) > 0.f ? v : 0.f;
-        const long long ci = coff + (long long)row * p.ldc + col;
-        if (p.c_f32) {
-          if (p.residual) v += ((const float*)p.residual)[coff + (long long)row * p.ldr + col];
-          if (p.accumulate) atomicAdd((float*)p.C + ci, v);
-          else ((float*)p.C)[ci] = v;
-        } else {
-          if (p.residual) v += to_f(((const T*)p.residual)[coff + (long long)row * p.ldr + col]);
-          ((T*)p.C)[ci] = from_f<T>(v);
-        }
+        const int e = (i * 2 + j) * 4 + r;
+        const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
+        ok[e] = (col < p.N) && (row < p.M);
+        ax[e] = 0.f; rs[e] = 0.f;
+      }
+  if (has_aux) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
+      const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
+      if (ok[e]) ax[e] = to_f(((const T*)p.aux)[coff + (long long)row * p.ldaux + col]);
+    }
+  }
+  if (p.residual) {
+    if (p.c_f32) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
+        const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
+        if (ok[e]) rs[e] = ((const float*)p.residual)[coff + (long long)row * p.ldr + col];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
+        const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
+        if (ok[e]) rs[e] = to_f(((const T*)p.residual)[coff + (long long)row * p.ldr + col]);
       }
     }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
+    v[e] = acc[i][j][r] * p.alpha + bv[j];
+  }
+  if (p.C2) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
+      const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
+      if (ok[e]) ((T*)p.C2)[coff + (long long)row * p.ldc2 + col] = from_f<T>(v[e]);
+    }
+  }
+  if (p.epilogue == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
+  } else if (p.epilogue == 2) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+  } else if (p.epilogue == 3) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] *= dgelu_f(ax[e]);
+  } else if (p.epilogue == 4) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = ax[e] > 0.f ? v[e] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) v[e] += rs[e];
+  if (p.c_f32) {
+    if (p.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
+        const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
+        if (ok[e]) atomicAdd((float*)p.C + coff + (long long)row * p.ldc + col, v[e]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
+        const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
+        if (ok[e]) ((float*)p.C)[coff + (long long)row * p.ldc + col] = v[e];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
+      const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
+      if (ok[e]) ((T*)p.C)[coff + (long long)row * p.ldc + col] = from_f<T>(v[e]);
+    }
+  }
 }
 
 extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,

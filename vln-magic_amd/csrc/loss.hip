@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int M, int N, const T* log
 // KD rows: fp32 logits [M,N], N <= 512 (action space).  one wave per row.
 // loss_row = w * sum_j p_t (log p_t - log p_s) * T^2 * norm ;  ds (+)= coef * w * T * (p_s - p_t) * norm
 __global__ __launch_bounds__(256) void kd_rows_kernel(int M, int N, const float* s, const float* t, int ld, float temperature,
-                                                      const float* w, float norm, float coef, float* loss_row, float* ds, int accumulate) {
+                                                      const float* w, float norm, float coef, const float* coef_dev, float* loss_row, float* ds, int accumulate) {
+  if (coef_dev) coef *= coef_dev[0];
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float NEG = -__builtin_inff();
@@ -106,9 +107,10 @@ __global__ __launch_bounds__(256) void kd_rows_kernel(int M, int N, const float*
 // weight w[outer / rows_per_w].  loss (atomic, *norm) ; ds = 2 * coef * norm * w * (s - t)  (Tg dtype)
 template <typename T, typename G>
 __global__ __launch_bounds__(256) void mse_kernel(long long outer, long long inner, const T* s, long long s_stride, const T* t, long long t_stride,
-                                                  const float* w, long long rows_per_w, float norm, float coef, float* loss, G* ds, long long g_stride,
+                                                  const float* w, long long rows_per_w, float norm, float coef, const float* coef_dev, float* loss, G* ds, long long g_stride,
                                                   int accumulate) {
   __shared__ float red[4];
+  if (coef_dev) coef *= coef_dev[0];
   const long long total = outer * inner;
   float acc = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -143,15 +145,15 @@ extern "C" int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld
 }
 
 extern "C" int magic_kd_rows(int M, int N, const float* s, const float* t, int ld, float temperature, const float* w, float norm,
-                             float coef, float* loss_row, float* ds, int accumulate, void* stream) {
+                             float coef, const float* coef_dev, float* loss_row, float* ds, int accumulate, void* stream) {
   if (M <= 0 || N <= 0 || N > 512 || ld < N || temperature <= 0.f) return MAGIC_ERR_ARG;
   dim3 grid((M + 3) / 4), block(256);
-  hipLaunchKernelGGL(kd_rows_kernel, grid, block, 0, (hipStream_t)stream, M, N, s, t, ld, temperature, w, norm, coef, loss_row, ds, accumulate);
+  hipLaunchKernelGGL(kd_rows_kernel, grid, block, 0, (hipStream_t)stream, M, N, s, t, ld, temperature, w, norm, coef, coef_dev, loss_row, ds, accumulate);
   return launch_status();
 }
 
 extern "C" int magic_mse(int dtype, int g_f32, long long outer, long long inner, const void* s, long long s_stride, const void* t,
-                         long long t_stride, const float* w, long long rows_per_w, float norm, float coef, float* loss, void* ds,
+                         long long t_stride, const float* w, long long rows_per_w, float norm, float coef, const float* coef_dev, float* loss, void* ds,
                          long long g_stride, int accumulate, void* stream) {
   if (outer <= 0 || inner <= 0 || (w && rows_per_w <= 0)) return MAGIC_ERR_ARG;
   long long total = outer * inner;
@@ -159,7 +161,7 @@ extern "C" int magic_mse(int dtype, int g_f32, long long outer, long long inner,
   if (blocks > 2048) blocks = 2048;
   dim3 grid(blocks), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define L(TY, GY) hipLaunchKernelGGL((mse_kernel<TY, GY>), grid, block, 0, st, outer, inner, (const TY*)s, s_stride, (const TY*)t, t_stride, w, rows_per_w, norm, coef, loss, (GY*)ds, g_stride, accumulate)
+#define L(TY, GY) hipLaunchKernelGGL((mse_kernel<TY, GY>), grid, block, 0, st, outer, inner, (const TY*)s, s_stride, (const TY*)t, t_stride, w, rows_per_w, norm, coef, coef_dev, loss, (GY*)ds, g_stride, accumulate)
   if (dtype == DT_BF16) { if (g_f32) L(bf16, float); else L(bf16, bf16); }
   else { L(float, float); }
 #undef L

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long long n, const float* g,
 // the bf16 shadow copy used by the MFMA kernels.
 __global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, const float* g, float* m, float* v, bf16* shadow,
                                                     float lr, float b1, float b2, float eps, float wd, float step_size,
-                                                    const float* sumsq, float max_norm, float gscale) {
+                                                    const float* sumsq, float max_norm, float gscale, const float* lr_ss) {
+  if (lr_ss) { lr = lr_ss[0]; step_size = lr_ss[1]; }     // device-side schedule (HIP-graph replay)
   float clip = gscale;
   if (sumsq && max_norm > 0.f) {
     const float nrm = sqrtf(sumsq[0]) * gscale;
@@ -75,10 +76,10 @@ extern "C" int magic_sumsq(long long n, const float* g, float* out, void* stream
 
 extern "C" int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow_bf16,
                            float lr, float b1, float b2, float eps, float wd, float step_size,
-                           const float* sumsq, float max_norm, float gscale, void* stream) {
+                           const float* sumsq, float max_norm, float gscale, const float* lr_ss, void* stream) {
   if (n <= 0) return MAGIC_ERR_ARG;
   hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (bf16*)shadow_bf16, lr, b1, b2, eps, wd,
-                     step_size, sumsq, max_norm, gscale);
+                     step_size, sumsq, max_norm, gscale, lr_ss);
   return launch_status();
 }
 
@@ -132,5 +133,25 @@ extern "C" int magic_dact(int dtype, int kind, long long n, const void* dy, cons
   if (n <= 0 || (kind != 1 && kind != 2)) return MAGIC_ERR_ARG;
   if (dtype == DT_BF16) hipLaunchKernelGGL(dact_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const bf16*)dy, (const bf16*)z, (bf16*)dz, kind);
   else hipLaunchKernelGGL(dact_kernel<float>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const float*)dy, (const float*)z, (float*)dz, kind);
+  return launch_status();
+}
+
+// Device-side optimizer schedule so a captured HIP graph can be replayed: t = ++step; lr = lr0 * warmup_linear(t-1)
+// (pretrain_src/optim/sched.py:17-30, <=0 -> 1e-8); step_size = lr * sqrt(1-b2^t) / (1-b1^t) (adamw.py:97-100).
+__global__ void sched_step_kernel(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int gs = step[0];          // global_step before this optimizer step
+  const int t = gs + 1;
+  step[0] = t;
+  double f = gs < warmup ? (double)gs / (double)warmup : fmax(0.0, (double)(total - gs) / (double)(total - warmup));
+  double lr = (double)lr0 * f;
+  if (lr <= 0.0) lr = 1e-8;
+  const double ss = lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
+  lr_ss[0] = (float)lr; lr_ss[1] = (float)ss;
+}
+
+extern "C" int magic_sched_step(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, void* stream) {
+  if (!step || !lr_ss || warmup <= 0 || total <= warmup) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(sched_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, lr0, warmup, total, b1, b2, lr_ss);
   return launch_status();
 }

@@ -8,6 +8,8 @@ With `compute_loss=True` the forward also evaluates the supervised loss and the 
 (against `teacher_outputs`) and seeds the explicit backward; `loss.backward()` (or `model.backward()`)
 then runs the hand-written backward and leaves the gradients in `param.grad` (views of one flat buffer).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -60,6 +62,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         self.net = MagicNet(config, self.store, "bert.")
         self._anchor = torch.zeros(1, device=self.device_, requires_grad=True)
         self._ctx = None
+        self._aux = torch.cuda.Stream(device=self.device_) if (self.device_.type == "cuda" and os.environ.get("MAGIC_PAR")) else None   # opt-in: measured slower under HIP-graph replay
+        self._kd_idx = torch.tensor([0, 0, 1, 1, 1, 2, 2, 3, 3, 4], device=self.device_)
         self.keep_mlm_logits = False     # True: MLM CE gradient goes to its own buffer instead of overwriting the logits
         self.register_load_state_dict_post_hook(lambda m, k: setattr(m.store, "shadow_clean", False))
 
@@ -72,6 +76,18 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             keep = {k: v for k, v in state_dict.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
             model.load_state_dict(keep, strict=False)      # unmatched keys are silently ignored, as HF does
         return model
+
+    def _par(self, fn_main, fn_aux):
+        """run two independent segments concurrently: fn_aux on this model's auxiliary stream, fn_main on the current one"""
+        if self._aux is None:
+            return fn_main(), fn_aux()
+        cur = torch.cuda.current_stream()
+        self._aux.wait_stream(cur)
+        with torch.cuda.stream(self._aux):
+            a = fn_aux()
+        m = fn_main()
+        cur.wait_stream(self._aux)
+        return m, a
 
     def mark_params_dirty(self):
         self.store.shadow_clean = False
@@ -119,8 +135,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         inp = inputs if inputs is not None else self._inputs(batch, plan)
         B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H
         c = Ctx(task=task, plan=plan, inp=inp)
-        c.txt = n.text_fwd(plan)
-        c.pano = n.pano_fwd(plan, inp.feats, inp.loc)
+        # the text and panorama encoders are independent: run them on two streams
+        c.txt, c.pano = self._par(lambda: n.text_fwd(plan), lambda: n.pano_fwd(plan, inp.feats, inp.loc))
         c.gin = n.gmap_in_fwd(plan, c.pano, inp.gpos)
         tl, gl_, vl = plan["lens"]["txt"], plan["lens"]["gmap"], [Vp] * B
         o = dict(txt_embeds=c.txt.out, txt_attns=c.txt.P, pano_embeds=c.pano.out, pano_fused_embeds=c.pano.fused,
@@ -147,11 +163,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                          nm, out=c.logits, ldc=c.ldv)
             o["predict"] = c.logits[:, :Vv]
         else:
-            c.glob = n.cross_fwd("global", plan, c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"],
-                                 c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], dist=inp.dist)
-            c.vin = n.vp_in_fwd(plan, c.pano, inp.vpos)
-            c.loc = n.cross_fwd("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp,
-                                c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
+            def _local():
+                vin = n.vp_in_fwd(plan, c.pano, inp.vpos)
+                return vin, n.cross_fwd("local", plan, vin.out, Vp, plan["vp_mask"], vl, B * Vp,
+                                        c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
+            # global (map) and local (viewpoint) co-attention encoders are independent too
+            c.glob, (c.vin, c.loc) = self._par(
+                lambda: n.cross_fwd("global", plan, c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"],
+                                    c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], dist=inp.dist), _local)
             o.update(gmap_embeds=c.glob.out, gmap_attns=c.glob.P, vp_embeds=c.loc.out, vp_attns=c.loc.P)
             if task == "sap":
                 c.Yg, c.g_raw = self._cls("global_sap_head.", c.glob.out, B * K)
@@ -196,6 +215,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                             global_act_labels=self._dev(batch["global_act_labels"]), local_act_labels=self._dev(batch["local_act_labels"]))
             return o["cfp"]
         self._ctx = c
+        if callable(teacher_outputs):          # teacher forward running on a side stream: join here
+            teacher_outputs = teacher_outputs()
         out = self._losses(c, o, teacher_outputs, rw)
         out["outputs"] = o
         if self.store.requires_grad and torch.is_grad_enabled():
@@ -214,7 +235,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         Ht = pl.N
         inner = (M // outer) * Ht
         ds = n.new(M, Ht) if self.store.requires_grad else None
-        O.mse(sp, t_t, outer, inner, inner, inner, w=w, rows_per_w=1, norm=1.0 / (M * Ht), coef=coef,
+        O.mse(sp, t_t, outer, inner, inner, inner, w=w, rows_per_w=1, norm=1.0 / (M * Ht), coef=coef[0], coef_dev=coef[1],
               loss=c.slots[slot:slot + 1], ds=ds, g_stride=inner)
         if ds is not None:
             O.linear_dw(ds, s_t, pl.dW, pl.db, M)
@@ -225,7 +246,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         hmin = min(nh_s, nh_t)
         dP = n.zeros(Bn, nh_s, Nq, ldp, dtype=torch.float32) if self.store.requires_grad else None
         O.mse(sP, tP, Bn, hmin * Nq * ldp, nh_s * Nq * ldp, nh_t * Nq * ldp, w=w, rows_per_w=1,
-              norm=1.0 / (Bn * hmin * Nq * Nk), coef=coef, loss=c.slots[slot:slot + 1], ds=dP, g_stride=nh_s * Nq * ldp)
+              norm=1.0 / (Bn * hmin * Nq * Nk), coef=coef[0], coef_dev=coef[1], loss=c.slots[slot:slot + 1], ds=dP, g_stride=nh_s * Nq * ldp)
         return dP
 
     def _losses(self, c, o, t, rw):
@@ -285,7 +306,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         res["supervised_loss"] = sup
         # ---- MAKD (pretrain flavour; oracle/makd_ref.pretrain_makd) -------------------------------------
         if kd:
-            rw = [1.0] * 5 if rw is None else [float(x) for x in rw]
+            # MKRW ability weights as a DEVICE tensor (a captured HIP graph re-reads them every replay)
+            if rw is None:
+                rw = [1.0] * 5
+            rwd = rw if torch.is_tensor(rw) and rw.is_cuda else torch.tensor([float(x) for x in rw], dtype=torch.float32).to(self.device_)
+            rw = [(alpha, rwd[i:i + 1]) for i in range(5)]
             tasks, types = kdl["kdl_tasks"], kdl["kdl_task_types"]
             emb, att = "emb" in types, "attn" in types
             T = float(kdl["kd_temperature"])
@@ -299,17 +324,17 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             Np, V = plan["Np"], plan["V"]
             if "txt" in tasks:
                 if emb:
-                    self._kd_emb(c, 0, o["txt_embeds"], t["txt_embeds"], "txt_emb_w", B * L, B, w, alpha * rw[0], c.d_txt)
+                    self._kd_emb(c, 0, o["txt_embeds"], t["txt_embeds"], "txt_emb_w", B * L, B, w, rw[0], c.d_txt)
                 if att:
-                    c.dP_txt = self._kd_attn(c, 1, o["txt_attns"], t["txt_attns"], B, L, L, c.txt.ldp, nh_s, nh_t, w, alpha * rw[0])
+                    c.dP_txt = self._kd_attn(c, 1, o["txt_attns"], t["txt_attns"], B, L, L, c.txt.ldp, nh_s, nh_t, w, rw[0])
             if "img" in tasks:
                 if emb:
-                    self._kd_emb(c, 2, o["pano_embeds"], t["pano_embeds"], "kdl_img_w", Np * V, Np * V, None, alpha * rw[1], c.d_pano)
-                    self._kd_emb(c, 3, o["pano_fused_embeds"], t["pano_fused_embeds"], "kdl_avg_img_w", Np, Np, None, alpha * rw[1], c.d_fused)
+                    self._kd_emb(c, 2, o["pano_embeds"], t["pano_embeds"], "kdl_img_w", Np * V, Np * V, None, rw[1], c.d_pano)
+                    self._kd_emb(c, 3, o["pano_fused_embeds"], t["pano_fused_embeds"], "kdl_avg_img_w", Np, Np, None, rw[1], c.d_fused)
                 if att:
                     ldp = c.pano.ldp
                     g = n.new(Np, V, ldp, dtype=torch.float32) if train else None
-                    O.mse(o["img_attns"], t["img_attns"], Np, V * ldp, V * ldp, V * ldp, norm=1.0 / (Np * V * V), coef=alpha * rw[1],
+                    O.mse(o["img_attns"], t["img_attns"], Np, V * ldp, V * ldp, V * ldp, norm=1.0 / (Np * V * V), coef=rw[1][0], coef_dev=rw[1][1],
                           loss=c.slots[4:5], ds=g, g_stride=V * ldp)
                     if train:
                         c.dP_pano = n.new(Np, nh_s, V, ldp, dtype=torch.float32)
@@ -320,23 +345,23 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 else:
                     x, Pm, Nq, Nk, ldp, d_acc = c.glob.out, c.glob.P, K, L, c.glob.ldp, c.d_gmap
                 if emb:
-                    self._kd_emb(c, 5, x, t["gmap_embeds"], "global_cross_w", B * Nq, B, w, alpha * rw[2], d_acc)
+                    self._kd_emb(c, 5, x, t["gmap_embeds"], "global_cross_w", B * Nq, B, w, rw[2], d_acc)
                 if att:
-                    c.dP_g = self._kd_attn(c, 6, Pm, t["gmap_attns"], B, Nq, Nk, ldp, nh_s, nh_t, w, alpha * rw[2])
+                    c.dP_g = self._kd_attn(c, 6, Pm, t["gmap_attns"], B, Nq, Nk, ldp, nh_s, nh_t, w, rw[2])
             if "local" in tasks and task != "mlm":
                 if emb:
-                    self._kd_emb(c, 7, c.loc.out, t["vp_embeds"], "local_cross_w", B * Vp, B, w, alpha * rw[3], c.d_vp)
+                    self._kd_emb(c, 7, c.loc.out, t["vp_embeds"], "local_cross_w", B * Vp, B, w, rw[3], c.d_vp)
                 if att:
-                    c.dP_l = self._kd_attn(c, 8, c.loc.P, t["vp_attns"], B, Vp, L, c.loc.ldp, nh_s, nh_t, w, alpha * rw[3])
+                    c.dP_l = self._kd_attn(c, 8, c.loc.P, t["vp_attns"], B, Vp, L, c.loc.ldp, nh_s, nh_t, w, rw[3])
             if "predict" in tasks and task == "sap":
                 c.kdrows = n.new(B, dtype=torch.float32)
                 O.kd_rows(c.fl, t["fused_logits"], B, K, K, T, w=w, norm=(1.0 / B if w is not None else 1.0 / (B * K)),
-                          coef=alpha * rw[4], loss_row=c.kdrows, ds=c.dfl, accumulate=True)
+                          coef=rw[4][0], coef_dev=rw[4][1], loss_row=c.kdrows, ds=c.dfl, accumulate=True)
                 c.slots[9:10] = c.kdrows.sum()
-            coefs = torch.tensor([rw[0], rw[0], rw[1], rw[1], rw[1], rw[2], rw[2], rw[3], rw[3], rw[4]] + [0.0] * 6,
-                                 dtype=torch.float32).to(self.device_, non_blocking=True)
-            res["kdl_terms"] = {k: c.slots[i] * coefs[i] for i, k in enumerate(KD_SLOTS)}
-            res["kdl_loss"] = (c.slots * coefs).sum()
+            coefs = torch.cat([rwd[self._kd_idx], rwd.new_zeros(6)])
+            terms = c.slots * coefs
+            res["kdl_terms"] = {k: terms[i] for i, k in enumerate(KD_SLOTS)}
+            res["kdl_loss"] = terms.sum()
             res["loss"] = alpha * res["kdl_loss"] + sc * sup
         else:
             res["loss"] = sup
@@ -412,12 +437,15 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             d_t2 = n.cross_bwd(c.l2v, c.d_x, d_gin, c.dP_g)
             O.add_(c.d_txt, d_t2)
         else:
-            d_gin = n.cross_bwd(c.glob, c.d_gmap, c.d_txt, c.dP_g)
-            d_vin = n.cross_bwd(c.loc, c.d_vp, c.d_txt, c.dP_l)
+            d_txt2 = n.zeros(B * L, H)           # the two encoders accumulate their text gradients separately (no race)
+            d_gin, d_vin = self._par(lambda: n.cross_bwd(c.glob, c.d_gmap, c.d_txt, c.dP_g),
+                                     lambda: n.cross_bwd(c.loc, c.d_vp, d_txt2, c.dP_l))
+            O.add_(c.d_txt, d_txt2)
             n.vp_in_bwd(c.vin, plan, d_vin, c.d_pano)
         n.gmap_in_bwd(c.gin, plan, d_gin, c.d_pano, c.d_fused)
-        n.pano_bwd(c.pano, plan, c.d_pano, c.d_fused, c.dP_pano)
-        n.text_bwd(c.txt, plan, c.d_txt, c.dP_txt)
+        self._par(lambda: n.text_bwd(c.txt, plan, c.d_txt, c.dP_txt),
+                  lambda: n.pano_bwd(c.pano, plan, c.d_pano, c.d_fused, c.dP_pano))
+        O.join_side()                          # weight-gradient GEMMs forked to the side stream
         self._ctx = None
 
     def _as(self, d):

@@ -74,8 +74,28 @@ def _splitk(tiles, kred, target=512):
     return int(max(1, min(target // max(tiles, 1), ks, 64)))
 
 
-def linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None, flop_rows=None):
-    """dW[N,K] += dy[M,N]^T @ x[M,K] ; db[N] += colsum(dy)   (fp32 atomics, split-K over M)"""
+SIDE = {"stream": None, "keep": []}     # optional side stream for the weight-gradient GEMMs (off the dX critical chain)
+
+
+def join_side():
+    if SIDE["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(SIDE["stream"])
+    SIDE["keep"].clear()
+
+
+def linear_dw(dy, x, dW, db, M, **kw):
+    """dW[N,K] += dy[M,N]^T @ x[M,K] ; db[N] += colsum(dy)   (fp32 atomics, split-K over M).  Nothing on the backward
+    chain depends on dW, so when a side stream is configured the GEMM is forked onto it (inputs kept alive until join)."""
+    side = SIDE["stream"]
+    if side is None:
+        return _linear_dw(dy, x, dW, db, M, **kw)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _linear_dw(dy, x, dW, db, M, **kw)
+    SIDE["keep"].append((dy, x))
+
+
+def _linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None, flop_rows=None):
     N = N if N is not None else dW.shape[0]
     K = K if K is not None else dW.shape[1]
     lda = lda if lda is not None else N
@@ -162,20 +182,20 @@ def ce_rows(logits, M, N, ld, labels, *, ignore_index=-100, coef=0.0, row_w=None
            L.P(loss_row), L.P(dlogits), ldd, 1 if accumulate else 0, L.P(w_out), float(w_rate), L.stream())
 
 
-def kd_rows(s, t, M, N, ld, temperature, *, w=None, norm=1.0, coef=0.0, loss_row=None, ds=None, accumulate=False):
+def kd_rows(s, t, M, N, ld, temperature, *, w=None, norm=1.0, coef=0.0, coef_dev=None, loss_row=None, ds=None, accumulate=False):
     _chk(s.dtype == torch.float32 and t.dtype == torch.float32, "kd logits fp32")
-    L.call("magic_kd_rows", M, N, L.P(s), L.P(t), ld, float(temperature), L.P(w), float(norm), float(coef), L.P(loss_row),
+    L.call("magic_kd_rows", M, N, L.P(s), L.P(t), ld, float(temperature), L.P(w), float(norm), float(coef), L.P(coef_dev), L.P(loss_row),
            L.P(ds), 1 if accumulate else 0, L.stream())
 
 
-def mse(s, t, outer, inner, s_stride, t_stride, *, w=None, rows_per_w=1, norm=1.0, coef=0.0, loss=None, ds=None, g_stride=0,
+def mse(s, t, outer, inner, s_stride, t_stride, *, w=None, rows_per_w=1, norm=1.0, coef=0.0, coef_dev=None, loss=None, ds=None, g_stride=0,
         accumulate=False):
     _chk(s.dtype == t.dtype, "mse dtypes")
     g_f32 = 1 if (ds is not None and ds.dtype == torch.float32) else 0
     if s.dtype == torch.float32:
         g_f32 = 1
     L.call("magic_mse", L.dt(s.dtype), g_f32, outer, inner, L.P(s), s_stride, L.P(t), t_stride, L.P(w), rows_per_w, float(norm),
-           float(coef), L.P(loss), L.P(ds), g_stride, 1 if accumulate else 0, L.stream())
+           float(coef), L.P(coef_dev), L.P(loss), L.P(ds), g_stride, 1 if accumulate else 0, L.stream())
 
 
 def csr_gather(src, ptr, idx, w, out, n_out, H, accumulate=False):
@@ -207,9 +227,13 @@ def sumsq(g, out):
     L.call("magic_sumsq", g.numel(), L.P(g), L.P(out), L.stream())
 
 
-def adamw(n, p, g, m, v, shadow, lr, b1, b2, eps, wd, step_size, sumsq_buf, max_norm, gscale):
+def adamw(n, p, g, m, v, shadow, lr, b1, b2, eps, wd, step_size, sumsq_buf, max_norm, gscale, lr_ss=None):
     L.call("magic_adamw", n, L.P(p), L.P(g), L.P(m), L.P(v), L.P(shadow), float(lr), float(b1), float(b2), float(eps), float(wd),
-           float(step_size), L.P(sumsq_buf), float(max_norm), float(gscale), L.stream())
+           float(step_size), L.P(sumsq_buf), float(max_norm), float(gscale), L.P(lr_ss), L.stream())
+
+
+def sched_step(step, lr0, warmup, total, b1, b2, lr_ss):
+    L.call("magic_sched_step", L.P(step), float(lr0), int(warmup), int(total), float(b1), float(b2), L.P(lr_ss), L.stream())
 
 
 def cast_to(x, dtype, out=None):

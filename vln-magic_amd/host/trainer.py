@@ -7,8 +7,14 @@ pretrain_src/train_r2r_magic.py:358-401; reconstructed order in SURVEY §3.1):
 Optimizer arithmetic: pretrain_src/optim/adamw.py:53-112 (two param groups, optim/misc.py:13-22),
 schedule pretrain_src/optim/sched.py:17-30, clip 5.0 / betas (0.9,0.98) / wd 0.01 from
 pretrain_src/config/r2r_magic_pretrain.json:14-23.
+
+Every per-step scalar (lr, Adam bias correction, MKRW ability weights) lives in device memory, so the whole step
+can be captured once per batch-shape into a HIP graph and replayed (`PretrainStep.capture`): ~660 kernel launches
+cost one graph launch on the host.  The teacher forward runs on a side stream concurrently with the student
+forward (they are independent until the distillation losses).
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -29,19 +35,30 @@ def get_lr_sched(step, lr, warmup, total):
 
 
 class FusedAdamW:
-    """AdamW over the ParamStore's flat buffers: one sum-of-squares launch + one launch per decay group."""
+    """AdamW over the ParamStore's flat buffers: one sum-of-squares launch + one launch per decay group.
+    With `schedule=(warmup, total)` the lr / bias-correction scalars are produced on the device by
+    `magic_sched_step` (graph-replayable); otherwise they are host floats."""
 
-    def __init__(self, store, lr=5e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=5.0):
+    def __init__(self, store, lr=5e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=5.0, schedule=None):
         self.store, self.lr, self.betas, self.eps, self.wd, self.max_norm = store, lr, betas, eps, weight_decay, max_grad_norm
         self.ss = torch.zeros(1, dtype=torch.float32, device=store.device)
         self.t = 0
+        self.schedule = schedule
+        if schedule is not None:
+            self.step_dev = torch.zeros(1, dtype=torch.int32, device=store.device)
+            self.lr_ss = torch.zeros(2, dtype=torch.float32, device=store.device)
 
     def step(self, lr=None, gscale=1.0):
         s = self.store
         lr = self.lr if lr is None else lr
         self.t += 1
         b1, b2 = self.betas
-        step_size = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+        lr_ss = None
+        if self.schedule is not None:
+            O.sched_step(self.step_dev, self.lr, self.schedule[0], self.schedule[1], b1, b2, self.lr_ss)
+            lr_ss, step_size = self.lr_ss, 0.0
+        else:
+            step_size = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
         use_clip = self.max_norm is not None and self.max_norm > 0
         if use_clip:
             self.ss.zero_()
@@ -51,7 +68,8 @@ class FusedAdamW:
         for lo, hi, wd in ((0, nd, self.wd), (nd, s.total, 0.0)):
             if hi > lo:
                 O.adamw(hi - lo, s.flat[lo:hi], s.grad[lo:hi], s.m[lo:hi], s.v[lo:hi], shadow[lo:hi] if shadow is not None else None,
-                        lr, b1, b2, self.eps, wd, step_size, self.ss if use_clip else None, self.max_norm if use_clip else 0.0, gscale)
+                        lr, b1, b2, self.eps, wd, step_size, self.ss if use_clip else None, self.max_norm if use_clip else 0.0, gscale,
+                        lr_ss=lr_ss)
         s.shadow_clean = True
         return lr
 
@@ -91,35 +109,83 @@ def broadcast_task(task_id, device):
     return int(t.item())
 
 
+class CapturedStep:
+    """A HIP graph of one training step bound to one resident batch (+ its plan)."""
+
+    def __init__(self, graph, out, traj_steps, full):
+        self.graph, self.out, self.traj_steps, self.full = graph, out, traj_steps, full
+
+
 class PretrainStep:
     def __init__(self, student, teacher=None, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0,
-                 warmup_steps=10000, num_train_steps=200000, rw_temp=4.0, seed=0):
+                 warmup_steps=10000, num_train_steps=200000, rw_temp=4.0, seed=0, overlap_teacher=True, overlap_dw=True):
         self.student, self.teacher = student, teacher
-        self.opt = FusedAdamW(student.store, lr, betas, 1e-6, weight_decay, grad_norm)
+        self.opt = FusedAdamW(student.store, lr, betas, 1e-6, weight_decay, grad_norm, schedule=(warmup_steps, num_train_steps))
         self.sync = GradSync(student.store)
-        self.lr0, self.warmup, self.total = lr, warmup_steps, num_train_steps
         self.rw_temp = rw_temp
-        self.gen = torch.Generator().manual_seed(seed)
+        self.dev = student.store.device
+        self.on_gpu = self.dev.type == "cuda"
+        self.side = torch.cuda.Stream() if (self.on_gpu and teacher is not None and overlap_teacher and not os.environ.get("MAGIC_NO_TEACHER_SIDE")) else None
+        if self.on_gpu and overlap_dw and O.SIDE["stream"] is None and os.environ.get("MAGIC_DW_SIDE"):   # opt-in: no gain measured on MI355X
+            O.SIDE["stream"] = torch.cuda.Stream()       # weight-gradient GEMMs leave the dX critical chain
         self.global_step = 0
 
     def mkrw(self):
-        """MKRW ability weights softmax(randn(5)/rw_temp)*5 (map_nav_src/r2r/agent.py:866-871)."""
-        return (torch.softmax(torch.randn(5, generator=self.gen) / self.rw_temp, dim=-1) * 5).tolist()
+        """MKRW ability weights softmax(randn(5)/rw_temp)*5 (map_nav_src/r2r/agent.py:866-871), drawn ON the device
+        (graph-safe generator) so a replayed graph sees fresh weights every step."""
+        return torch.softmax(torch.randn(5, device=self.dev, dtype=torch.float32) / self.rw_temp, dim=-1) * 5
 
-    def step(self, batch, task, rw=None, plan=None):
+    # ---- the pieces ------------------------------------------------------------------------------------
+    def _fwd_bwd(self, batch, task, rw, plan):
         st, te = self.student, self.teacher
-        plan = plan if plan is not None else build_plan(batch, task, st.device_)
         t_out, inputs = None, None
         if te is not None:
-            with torch.no_grad():
-                t_out = te(batch, task, compute_loss=False, return_outputs=True, plan=plan)
-            inputs = t_out["inputs"]
-        rw = rw if rw is not None else (self.mkrw() if te is not None else None)
+            inputs = st._inputs(batch, plan)             # cast once, shared by teacher and student
+            if self.side is not None:
+                main = torch.cuda.current_stream()
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side), torch.no_grad():
+                    t_res = te(batch, task, compute_loss=False, return_outputs=True, plan=plan, inputs=inputs)
+
+                def t_out():                              # joined lazily, right before the distillation losses
+                    torch.cuda.current_stream().wait_stream(self.side)
+                    return t_res
+            else:
+                with torch.no_grad():
+                    t_out = te(batch, task, compute_loss=False, return_outputs=True, plan=plan, inputs=inputs)
+        if rw is None and te is not None:
+            rw = self.mkrw()
         st.store.zero_grad()
         out = st(batch, task, compute_loss=True, teacher_outputs=t_out, rw=rw, plan=plan, inputs=inputs)
         st.backward()
+        return out
+
+    def _optimize(self):
         gscale = self.sync.all_reduce()
-        lr = get_lr_sched(self.global_step, self.lr0, self.warmup, self.total)
-        self.opt.step(lr=lr, gscale=gscale)
+        self.opt.step(gscale=gscale)
+
+    def step(self, batch, task, rw=None, plan=None):
+        plan = plan if plan is not None else build_plan(batch, task, self.dev)
+        out = self._fwd_bwd(batch, task, rw, plan)
+        self._optimize()
         self.global_step += 1
         return out
+
+    # ---- HIP-graph path --------------------------------------------------------------------------------
+    def capture(self, batch, task, plan, rw=None):
+        """Capture one step for this (resident) batch.  With world_size 1 the optimizer is inside the graph; with
+        data parallelism the graph ends after backward and the all-reduce + optimizer run eagerly after replay."""
+        full = self.sync.world == 1
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._fwd_bwd(batch, task, rw, plan)
+            if full:
+                self._optimize()
+        return CapturedStep(g, out, plan["traj_steps"], full)
+
+    def replay(self, cs):
+        cs.graph.replay()
+        if not cs.full:
+            self._optimize()
+        self.global_step += 1
+        return cs.out

@@ -70,6 +70,19 @@ int magic_softmax_bwd(int dtype, int B, int nh, int Nq, int Nk, int ldp, const v
 int magic_head_mean_fwd(int dtype, int B, int nh, long long inner, const void* P, float* out, void* stream);
 int magic_head_mean_bwd(int B, int nh, long long inner, const float* g, float* dP, int accumulate, void* stream);
 
+/* Fused attention for Nk <= 128, head dim 64 (HF BertSelfAttention arithmetic: scores/sqrt(d) + additive mask -> softmax
+ * -> probs @ V; graph_sprels bias as in magic_softmax_fwd).  P [B,nh,Nq,ldp] is written (needed by the backward and by the
+ * attention-map distillation, agent.py:579-593).  bwd: dq/dk/dv given dctx (+ optional dP_init = dLoss/dP, fp32).
+ * magic_attn_supported() tells the host whether a shape fits (LDS); otherwise use magic_gemm + magic_softmax_*. */
+int magic_attn_supported(int dtype, int Nq, int Nk, int backward);
+int magic_attn_fwd(int dtype, int B, int nh, int Nq, int Nk, const void* q, int ldq, const void* k, const void* v, int ldkv,
+                   void* P, int ldp, void* ctx, int H, float scale, const unsigned char* kmask, const float* dist,
+                   const float* sprel_w, const float* sprel_b, void* stream);
+int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const void* q, int ldq, const void* k, const void* v, int ldkv,
+                   const void* P, int ldp, const void* dctx, int H, float scale, const float* dP_init,
+                   void* dq, int lddq, void* dk, void* dv, int lddkv,
+                   const float* dist, float* dsprel_w, float* dsprel_b, void* stream);
+
 /* ClsPrediction tail (Linear->ReLU->LN->Linear(H,1)): logit = dot(LN(Y), w2) + b2 */
 int magic_lndot_fwd(int dtype, int M, int H, const void* Y, const float* gamma, const float* beta, float eps,
                     const float* w2, const float* b2, float* logit, void* stream);

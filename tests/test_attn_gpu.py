@@ -1,0 +1,96 @@
+"""Fused attention kernels (csrc/attention.hip) vs plain fp32 torch attention + autograd (-m gpu)."""
+import math
+
+import pytest
+import torch
+
+import magic_amd  # noqa: F401
+from magic_amd.host import ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def ref_attention(q, k, v, kmask, dist, sw, sb, scale):
+    s = q @ k.transpose(-1, -2) * scale
+    if kmask is not None:
+        s = s + (1 - kmask.float())[:, None, None, :] * -10000.0
+    if dist is not None:
+        s = s + (sw * dist + sb)[:, None]
+    p = torch.softmax(s, -1)
+    return p, p @ v
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,nh,Nq,Nk,cross,use_dist", [(3, 2, 37, 37, False, False), (2, 2, 18, 18, False, True), (2, 4, 21, 80, True, False),
+                                                        (2, 2, 80, 17, True, False), (1, 2, 64, 64, False, False), (2, 2, 100, 128, True, False)])
+def test_fused_attention_fwd_bwd(dtype, B, nh, Nq, Nk, cross, use_dist):
+    if dtype == torch.float32 and max(Nq, Nk) > 64 and not O.attn_supported(dtype, Nq, Nk, True):
+        pytest.skip("fp32 backward does not fit LDS for this shape (engine falls back to the unfused path)")
+    H = nh * 64
+    g = torch.Generator().manual_seed(Nq * 131 + Nk)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    if cross:
+        qb, kvb = rnd(B * Nq, H).to(dtype), rnd(B * Nk, 2 * H).to(dtype)
+        q, k, v, ldq, ldkv = qb, kvb, kvb[:, H:], H, 2 * H
+    else:
+        qkv = rnd(B * Nq, 3 * H).to(dtype)
+        q, k, v, ldq, ldkv = qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H
+    kmask = torch.ones(B, Nk, dtype=torch.uint8, device=DEV)
+    kmask[0, Nk - 3:] = 0
+    if B > 1:
+        kmask[1, 1] = 0
+    dist = (rnd(B, Nq, Nk).abs() * 4).contiguous() if use_dist else None
+    sw, sb = torch.tensor([0.2], device=DEV), torch.tensor([-0.1], device=DEV)
+    scale = 1 / math.sqrt(64)
+    ldp = (Nk + 7) // 8 * 8
+    Pm = torch.full((B, nh, Nq, ldp), 7.0, dtype=dtype, device=DEV)
+    ctx = torch.empty(B * Nq, H, dtype=dtype, device=DEV)
+    O.attn_fwd(q, ldq, k, v, ldkv, Pm, ldp, ctx, B, nh, Nq, Nk, H, scale, kmask=kmask, dist=dist, sprel_w=sw if use_dist else None,
+               sprel_b=sb if use_dist else None)
+    heads = lambda t, N: t.float().reshape(B, N, nh, 64).transpose(1, 2)
+    qh = heads(q[:, :H] if not cross else q, Nq).clone().requires_grad_(True)
+    kh = heads(k[:, :H], Nk).clone().requires_grad_(True)
+    vh = heads(v[:, :H], Nk).clone().requires_grad_(True)
+    swr, sbr = sw.clone().requires_grad_(True), sb.clone().requires_grad_(True)
+    p_ref, o_ref = ref_attention(qh, kh, vh, kmask, dist, swr, sbr, scale)
+    tp = dict(rtol=1e-4, atol=2e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=4e-3)
+    to = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+
+    def chk(a, b, name, **kw):
+        a, b = a.float().cpu(), b.detach().float().cpu()
+        assert torch.allclose(a, b, **kw), f"{name}: max|err| {(a - b).abs().max().item():.3e} (ref {b.abs().max().item():.3e})"
+    chk(Pm[..., :Nk], p_ref, "P", **tp)
+    assert (Pm[..., Nk:] == 0).all()
+    chk(ctx, o_ref.transpose(1, 2).reshape(B * Nq, H), "ctx", **to)
+    # backward, with an extra gradient flowing into P (attention distillation)
+    dO = rnd(B * Nq, H).to(dtype)
+    dP_extra = torch.zeros(B, nh, Nq, ldp, device=DEV)
+    dP_extra[..., :Nk] = rnd(B, nh, Nq, Nk) * 0.3
+    loss = (o_ref * heads(dO, Nq)).sum() + (p_ref * dP_extra[..., :Nk]).sum()
+    loss.backward()
+    if cross:
+        dq, dkv = torch.zeros(B * Nq, H, dtype=dtype, device=DEV), torch.zeros(B * Nk, 2 * H, dtype=dtype, device=DEV)
+        dk, dv, lddq, lddkv = dkv, dkv[:, H:], H, 2 * H
+    else:
+        dqkv = torch.zeros(B * Nq, 3 * H, dtype=dtype, device=DEV)
+        dq, dk, dv, lddq, lddkv = dqkv, dqkv[:, H:], dqkv[:, 2 * H:], 3 * H, 3 * H
+    dsw, dsb = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    # the engine feeds the backward with the P the forward stored (bf16-rounded in bf16 mode)
+    O.attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, dO, B, nh, Nq, Nk, H, scale, dP_extra, dq, lddq, dk, dv, lddkv,
+               dist=dist, dsprel_w=dsw if use_dist else None, dsprel_b=dsb if use_dist else None)
+    unheads = lambda t, N: t.transpose(1, 2).reshape(B * N, H)
+    tg = dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=4e-2)
+    chk(dq[:, :H], unheads(qh.grad, Nq), "dQ", **tg)
+    chk(dk[:, :H], unheads(kh.grad, Nk), "dK", **tg)
+    chk(dv[:, :H], unheads(vh.grad, Nk), "dV", **tg)
+    if use_dist:
+        ts = dict(rtol=1e-3, atol=1e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+        chk(dsw, swr.grad, "d sprel w", **ts)
+        chk(dsb, sbr.grad, "d sprel b", **ts)
+
+
+def test_unsupported_shapes_are_reported_not_launched():
+    assert not O.attn_supported(torch.bfloat16, 40, 512, False)
+    assert O.attn_supported(torch.bfloat16, 80, 80, True)
+    assert not O.attn_supported(torch.float32, 128, 128, True)

@@ -1,0 +1,391 @@
+// Fused attention for the short sequences of this model (text <= 80 tokens, 36/37/38-view panoramas, map nodes):
+//   forward : S = Q K^T -> scale + key mask + graph-distance bias -> softmax -> P (kept: backward + attention
+//             distillation) -> O = P V, one launch instead of GEMM + softmax + GEMM;
+//   backward: dV = P^T dO, dP = dO V^T (+ distillation gradient), dS = softmax', dQ = dS K, dK = dS^T Q, one launch
+//             instead of five.  One workgroup owns a whole (batch, head): every operand of the five products is an
+//             LDS image read either row-wise (16-byte ds_read) or transposed (ds_read_b64_tr_b16), no global round trips.
+// Limits: head dim 64, Nk <= 128 (forward), Nq, Nk <= 128 bf16 / <= 64 fp32 (backward; LDS).  Longer sequences
+// (RxR, 512 tokens) take the unfused GEMM + softmax path of the engine.
+#include "common.hpp"
+
+#define HD 64
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+
+template <typename T> struct AT;
+template <> struct AT<bf16> {
+  static constexpr int VE = 8, KSTEP = 32, DS = 72, PPAD = 8;
+  typedef bf16x8 vec;
+  typedef bf16x8 frag_t;
+};
+template <> struct AT<float> {
+  static constexpr int VE = 4, KSTEP = 4, DS = 68, PPAD = 4;
+  typedef f32x4 vec;
+  typedef float frag_t;
+};
+
+// fragment of 16 "out" rows starting at out0, k-slice starting at k0.  KC image: [out][k]; OC image: [k][out].
+__device__ __forceinline__ bf16x8 fragKC(const bf16* s, int stride, int out0, int k0, int lane) {
+  return *(const bf16x8*)(s + (out0 + (lane & 15)) * stride + k0 + 8 * (lane >> 4));
+}
+__device__ __forceinline__ bf16x8 fragOC(const bf16* s, int stride, int out0, int k0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const bf16* b = s + (k0 + 8 * g + q) * stride + out0 + 4 * pp;
+  typedef bf16x4_t __attribute__((address_space(3))) * lds4;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * stride));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ float fragKC(const float* s, int stride, int out0, int k0, int lane) {
+  return s[(out0 + (lane & 15)) * stride + k0 + (lane >> 4)];
+}
+__device__ __forceinline__ float fragOC(const float* s, int stride, int out0, int k0, int lane) {
+  return s[(k0 + (lane >> 4)) * stride + out0 + (lane & 15)];
+}
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// cooperative load of `rows` x 64 elements (row r of the source at src + r*ld) into an LDS image [rows_pad][DS]; rows >= nvalid -> 0
+template <typename T>
+__device__ __forceinline__ void load_rows(T* s, const T* src, long long ld, int nvalid, int rows_pad) {
+  typedef typename AT<T>::vec vec;
+  constexpr int VE = AT<T>::VE, DS = AT<T>::DS, VPR = HD / VE;
+  for (int id = threadIdx.x; id < rows_pad * VPR; id += 256) {
+    const int r = id / VPR, c = (id % VPR) * VE;
+    vec z;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) z[e] = (T)0.0f;
+    if (r < nvalid) z = *(const vec*)(src + (long long)r * ld + c);
+    *(vec*)(s + r * DS + c) = z;
+  }
+}
+
+struct AttnParams {
+  const void *q, *k, *v;
+  void *P, *ctx;
+  const unsigned char* kmask; const float* dist; const float* sprel_w; const float* sprel_b;
+  int B, nh, Nq, Nk, ldq, ldkv, ldp, H;
+  float scale;
+  // backward only
+  const void* dctx; const float* dP_init; void *dq, *dk, *dv; int lddq, lddkv; float* dsprel_w; float* dsprel_b;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  typedef typename AT<T>::vec vec;
+  constexpr int VE = AT<T>::VE, KSTEP = AT<T>::KSTEP, DS = AT<T>::DS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int NKP = (p.Nk + 31) / 32 * 32, PS = NKP + AT<T>::PPAD;
+  T* sQ = (T*)smem_raw;            // [64][DS]   (re-used to stage O)
+  T* sK = sQ + 64 * DS;            // [NKP][DS]
+  T* sV = sK + NKP * DS;           // [NKP][DS]
+  T* sP = sV + NKP * DS;           // [64][PS]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int nq = min(64, p.Nq - q0);
+  load_rows<T>(sQ, (const T*)p.q + ((long long)b * p.Nq + q0) * p.ldq + h * HD, p.ldq, nq, 64);
+  load_rows<T>(sK, (const T*)p.k + (long long)b * p.Nk * p.ldkv + h * HD, p.ldkv, p.Nk, NKP);
+  load_rows<T>(sV, (const T*)p.v + (long long)b * p.Nk * p.ldkv + h * HD, p.ldkv, p.Nk, NKP);
+  __syncthreads();
+  // ---- S = Q K^T for this wave's 16 query rows
+  const int NT = NKP / 16;
+  f32x4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < HD / KSTEP; ++ks) {
+    const auto a = fragKC(sQ, DS, w * 16, ks * KSTEP, lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < NT) acc[j] = mma(a, fragKC(sK, DS, j * 16, ks * KSTEP, lane), acc[j]);
+  }
+  // ---- softmax over keys (row = 4g + r of the wave's tile, key = 16j + c16)
+  const float sw = p.dist ? p.sprel_w[0] : 0.f, sb = p.dist ? p.sprel_b[0] : 0.f;
+  float mx[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j < NT) {
+      const int key = j * 16 + c16;
+      const bool kv = key < p.Nk;
+      const float mb = (kv && p.kmask && !p.kmask[(long long)b * p.Nk + key]) ? -10000.0f : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qrow = min(q0 + w * 16 + 4 * g + r, p.Nq - 1);
+        float x = acc[j][r] * p.scale + mb;
+        if (p.dist && kv) x += sw * p.dist[((long long)b * p.Nq + qrow) * p.Nk + key] + sb;
+        x = kv ? x : -3.0e38f;
+        acc[j][r] = x; mx[r] = fmaxf(mx[r], x);
+      }
+    }
+  float sum[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { mx[r] = group16_max(mx[r]); sum[r] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j < NT) {
+      const bool kv = (j * 16 + c16) < p.Nk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float e = kv ? __expf(acc[j][r] - mx[r]) : 0.f; acc[j][r] = e; sum[r] += e; }
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sum[r] = 1.0f / group16_sum(sum[r]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j < NT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sP[(w * 16 + 4 * g + r) * PS + j * 16 + c16] = from_f<T>(acc[j][r] * sum[r]);
+    }
+  __syncthreads();
+  // ---- P -> global (16-byte chunks; row pitch ldp), kept for the backward and for attention distillation
+  {
+    T* Pg = (T*)p.P + (((long long)b * p.nh + h) * p.Nq + q0) * p.ldp;
+    const int cpr = p.ldp / VE;
+    for (int id = tid; id < nq * cpr; id += 256) {
+      const int r = id / cpr, c = (id % cpr) * VE;
+      *(vec*)(Pg + (long long)r * p.ldp + c) = *(const vec*)(sP + r * PS + c);
+    }
+  }
+  // ---- O = P V
+  f32x4 o[4];
+#pragma unroll
+  for (int jd = 0; jd < 4; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < NKP / KSTEP; ++ks) {
+    const auto a = fragKC(sP, PS, w * 16, ks * KSTEP, lane);
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd) o[jd] = mma(a, fragOC(sV, DS, jd * 16, ks * KSTEP, lane), o[jd]);
+  }
+  // stage O through LDS (sQ is dead: every wave only ever read its own 16 rows of it) for 16-byte global stores
+#pragma unroll
+  for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sQ[(w * 16 + 4 * g + r) * DS + jd * 16 + c16] = from_f<T>(o[jd][r]);
+  __syncthreads();
+  {
+    T* Og = (T*)p.ctx + ((long long)b * p.Nq + q0) * p.H + h * HD;
+    constexpr int VPR = HD / VE;
+    for (int id = tid; id < nq * VPR; id += 256) {
+      const int r = id / VPR, c = (id % VPR) * VE;
+      *(vec*)(Og + (long long)r * p.H + c) = *(const vec*)(sQ + r * DS + c);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
+  typedef typename AT<T>::vec vec;
+  constexpr int VE = AT<T>::VE, KSTEP = AT<T>::KSTEP, DS = AT<T>::DS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ float red[8];
+  const int NQP = (p.Nq + 31) / 32 * 32, NKP = (p.Nk + 31) / 32 * 32, PS = NKP + AT<T>::PPAD;
+  T* sQ = (T*)smem_raw;             // [NQP][DS]
+  T* sdO = sQ + NQP * DS;           // [NQP][DS]
+  T* sK = sdO + NQP * DS;           // [NKP][DS]
+  T* sV = sK + NKP * DS;            // [NKP][DS]
+  T* sP = sV + NKP * DS;            // [NQP][PS]
+  T* sdS = sP + NQP * PS;           // [NQP][PS]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int h = blockIdx.x, b = blockIdx.y;
+  load_rows<T>(sQ, (const T*)p.q + (long long)b * p.Nq * p.ldq + h * HD, p.ldq, p.Nq, NQP);
+  load_rows<T>(sdO, (const T*)p.dctx + (long long)b * p.Nq * p.H + h * HD, p.H, p.Nq, NQP);
+  load_rows<T>(sK, (const T*)p.k + (long long)b * p.Nk * p.ldkv + h * HD, p.ldkv, p.Nk, NKP);
+  load_rows<T>(sV, (const T*)p.v + (long long)b * p.Nk * p.ldkv + h * HD, p.ldkv, p.Nk, NKP);
+  const long long prow0 = ((long long)b * p.nh + h) * p.Nq;
+  {
+    const T* Pg = (const T*)p.P + prow0 * p.ldp;
+    const int cpr = PS / VE;          // PS is a multiple of VE
+    for (int id = tid; id < NQP * cpr; id += 256) {
+      const int r = id / cpr, c = (id % cpr) * VE;
+      vec z;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) z[e] = (T)0.0f;
+      if (r < p.Nq && c < p.ldp) z = *(const vec*)(Pg + (long long)r * p.ldp + c);    // ldp % VE == 0, pad columns hold zeros
+      *(vec*)(sP + r * PS + c) = z;
+    }
+  }
+  __syncthreads();
+  // ---- phase 1: dP = dO V^T (+ distillation gradient), dS = P (dP - rowsum(P dP)), scaled; sprel gradients
+  const int NT = NKP / 16;
+  float a0 = 0.f, a1 = 0.f;
+  for (int qt = w; qt < NQP / 16; qt += 4) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < HD / KSTEP; ++ks) {
+      const auto a = fragKC(sdO, DS, qt * 16, ks * KSTEP, lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < NT) acc[j] = mma(a, fragKC(sV, DS, j * 16, ks * KSTEP, lane), acc[j]);
+    }
+    float pv[8][4];
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < NT) {
+        const int key = j * 16 + c16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qt * 16 + 4 * g + r;
+          const bool ok = (q < p.Nq) && (key < p.Nk);
+          float d = acc[j][r];
+          if (p.dP_init && ok) d += p.dP_init[(prow0 + q) * p.ldp + key];
+          const float pp = to_f(sP[q * PS + key]);
+          pv[j][r] = pp; acc[j][r] = d; rs[r] += pp * d;
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs[r] = group16_sum(rs[r]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < NT) {
+        const int key = j * 16 + c16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qt * 16 + 4 * g + r;
+          const float ds = pv[j][r] * (acc[j][r] - rs[r]);
+          sdS[q * PS + key] = from_f<T>(ds * p.scale);
+          if (p.dist && q < p.Nq && key < p.Nk) { a0 += ds * p.dist[((long long)b * p.Nq + q) * p.Nk + key]; a1 += ds; }
+        }
+      }
+  }
+  if (p.dsprel_w) {
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    if (lane == 0) { red[w] = a0; red[4 + w] = a1; }
+  }
+  __syncthreads();
+  if (p.dsprel_w && tid == 0) {
+    atomicAdd(p.dsprel_w, red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(p.dsprel_b, red[4] + red[5] + red[6] + red[7]);
+  }
+  // ---- phase 2: dQ = dS K ; dK = dS^T Q ; dV = P^T dO        (tiles of 16 rows x 64 head dims, round-robin over waves)
+  for (int qt = w; qt < NQP / 16; qt += 4) {
+    f32x4 o[4];
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < NKP / KSTEP; ++ks) {
+      const auto a = fragKC(sdS, PS, qt * 16, ks * KSTEP, lane);
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) o[jd] = mma(a, fragOC(sK, DS, jd * 16, ks * KSTEP, lane), o[jd]);
+    }
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = qt * 16 + 4 * g + r;
+        if (q < p.Nq) ((T*)p.dq)[((long long)b * p.Nq + q) * p.lddq + h * HD + jd * 16 + c16] = from_f<T>(o[jd][r]);
+      }
+  }
+  for (int kt = w; kt < NKP / 16; kt += 4) {
+    f32x4 ok_[4], ov[4];
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd) { ok_[jd] = (f32x4){0.f, 0.f, 0.f, 0.f}; ov[jd] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int ks = 0; ks < NQP / KSTEP; ++ks) {
+      const auto as = fragOC(sdS, PS, kt * 16, ks * KSTEP, lane);
+      const auto ap = fragOC(sP, PS, kt * 16, ks * KSTEP, lane);
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) {
+        ok_[jd] = mma(as, fragOC(sQ, DS, jd * 16, ks * KSTEP, lane), ok_[jd]);
+        ov[jd] = mma(ap, fragOC(sdO, DS, jd * 16, ks * KSTEP, lane), ov[jd]);
+      }
+    }
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        if (key < p.Nk) {
+          const long long o_ = ((long long)b * p.Nk + key) * p.lddkv + h * HD + jd * 16 + c16;
+          ((T*)p.dk)[o_] = from_f<T>(ok_[jd][r]);
+          ((T*)p.dv)[o_] = from_f<T>(ov[jd][r]);
+        }
+      }
+  }
+}
+
+static size_t fwd_lds(int dtype, int Nk) {
+  const int NKP = (Nk + 31) / 32 * 32;
+  if (dtype == DT_BF16) return (size_t)(64 * 72 + 2 * NKP * 72 + 64 * (NKP + 8)) * 2;
+  return (size_t)(64 * 68 + 2 * NKP * 68 + 64 * (NKP + 4)) * 4;
+}
+static size_t bwd_lds(int dtype, int Nq, int Nk) {
+  const int NQP = (Nq + 31) / 32 * 32, NKP = (Nk + 31) / 32 * 32;
+  if (dtype == DT_BF16) return (size_t)(2 * NQP * 72 + 2 * NKP * 72 + 2 * NQP * (NKP + 8)) * 2;
+  return (size_t)(2 * NQP * 68 + 2 * NKP * 68 + 2 * NQP * (NKP + 4)) * 4;
+}
+#define LDS_MAX (160 * 1024)
+
+// returns 1 if the fused kernels support the shape (host decides fused vs GEMM+softmax path), 0 otherwise
+extern "C" int magic_attn_supported(int dtype, int Nq, int Nk, int backward) {
+  if (Nk > 128 || Nk <= 0 || Nq <= 0) return 0;
+  if (backward) return (Nq <= 128 && bwd_lds(dtype, Nq, Nk) <= LDS_MAX) ? 1 : 0;
+  return fwd_lds(dtype, Nk) <= LDS_MAX ? 1 : 0;
+}
+
+static int check_common(int dtype, int B, int nh, int Nq, int Nk, int ldq, int ldkv, int ldp, int H) {
+  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
+  const int ve = dtype == DT_BF16 ? 8 : 4;
+  if (B <= 0 || nh <= 0 || Nq <= 0 || Nk <= 0 || H != nh * HD) return MAGIC_ERR_ARG;
+  if (ldq % ve || ldkv % ve || ldp % ve || ldp < Nk || H % ve) return MAGIC_ERR_ARG;
+  return MAGIC_OK;
+}
+
+extern "C" int magic_attn_fwd(int dtype, int B, int nh, int Nq, int Nk, const void* q, int ldq, const void* k, const void* v, int ldkv,
+                              void* P, int ldp, void* ctx, int H, float scale, const unsigned char* kmask, const float* dist,
+                              const float* sprel_w, const float* sprel_b, void* stream) {
+  int rc = check_common(dtype, B, nh, Nq, Nk, ldq, ldkv, ldp, H);
+  if (rc) return rc;
+  if (!magic_attn_supported(dtype, Nq, Nk, 0)) return MAGIC_ERR_UNSUPPORTED;
+  if (dist && (!sprel_w || !sprel_b)) return MAGIC_ERR_ARG;
+  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)P & 15) || ((uintptr_t)ctx & 15)) return MAGIC_ERR_ARG;
+  AttnParams p = {};
+  p.q = q; p.k = k; p.v = v; p.P = P; p.ctx = ctx; p.kmask = kmask; p.dist = dist; p.sprel_w = sprel_w; p.sprel_b = sprel_b;
+  p.B = B; p.nh = nh; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldkv = ldkv; p.ldp = ldp; p.H = H; p.scale = scale;
+  dim3 grid((Nq + 63) / 64, nh, B), block(256);
+  const size_t shm = fwd_lds(dtype, Nk);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) {
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)attn_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, block, shm, st, p);
+  } else {
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, shm, st, p);
+  }
+  return launch_status();
+}
+
+extern "C" int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const void* q, int ldq, const void* k, const void* v, int ldkv,
+                              const void* P, int ldp, const void* dctx, int H, float scale, const float* dP_init,
+                              void* dq, int lddq, void* dk, void* dv, int lddkv,
+                              const float* dist, float* dsprel_w, float* dsprel_b, void* stream) {
+  int rc = check_common(dtype, B, nh, Nq, Nk, ldq, ldkv, ldp, H);
+  if (rc) return rc;
+  if (!magic_attn_supported(dtype, Nq, Nk, 1)) return MAGIC_ERR_UNSUPPORTED;
+  if ((dist == nullptr) != (dsprel_w == nullptr) || (dist == nullptr) != (dsprel_b == nullptr)) return MAGIC_ERR_ARG;
+  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)P & 15) || ((uintptr_t)dctx & 15)) return MAGIC_ERR_ARG;
+  AttnParams p = {};
+  p.q = q; p.k = k; p.v = v; p.P = (void*)P; p.dist = dist; p.B = B; p.nh = nh; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldkv = ldkv;
+  p.ldp = ldp; p.H = H; p.scale = scale; p.dctx = dctx; p.dP_init = dP_init; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddkv = lddkv;
+  p.dsprel_w = dsprel_w; p.dsprel_b = dsprel_b;
+  dim3 grid(nh, B), block(256);
+  const size_t shm = bwd_lds(dtype, Nq, Nk);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) {
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)attn_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(attn_bwd_kernel<bf16>, grid, block, shm, st, p);
+  } else {
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, shm, st, p);
+  }
+  return launch_status();
+}

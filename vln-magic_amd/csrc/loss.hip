@@ -158,7 +158,7 @@ extern "C" int magic_mse(int dtype, int g_f32, long long outer, long long inner,
   if (outer <= 0 || inner <= 0 || (w && rows_per_w <= 0)) return MAGIC_ERR_ARG;
   long long total = outer * inner;
   int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 384) blocks = 384;      // every block ends in ONE atomic on the loss word: keep the fan-in small
   dim3 grid(blocks), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define L(TY, GY) hipLaunchKernelGGL((mse_kernel<TY, GY>), grid, block, 0, st, outer, inner, (const TY*)s, s_stride, (const TY*)t, t_stride, w, rows_per_w, norm, coef, coef_dev, loss, (GY*)ds, g_stride, accumulate)

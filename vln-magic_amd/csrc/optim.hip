@@ -70,7 +70,7 @@ static inline int nblocks(long long n, int per) {
 
 extern "C" int magic_sumsq(long long n, const float* g, float* out, void* stream) {
   if (n <= 0 || ((uintptr_t)g & 15)) return MAGIC_ERR_ARG;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, n, g, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks(n, 1024) > 512 ? 512 : nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, n, g, out);
   return launch_status();
 }
 

@@ -97,10 +97,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, const T* dy, const T
 #pragma unroll
   for (int i = 0; i < 2 * NIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
 
-  const int row0 = (blockIdx.x * 4 + wid) * LNB_ROWS;
-  for (int rr = 0; rr < LNB_ROWS; ++rr) {
-    const int row = row0 + rr;
-    if (row >= M) break;
+  // grid-stride over rows: the grid is capped so the per-block parameter-gradient atomics stay few
+  for (int row = blockIdx.x * 4 + wid; row < M; row += gridDim.x * 4) {
     float g[2 * NIT], xh[2 * NIT];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -542,7 +540,8 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
   if (do_ln && (!y || !gamma || !beta || !rstd || !dgamma || !dbeta)) return MAGIC_ERR_ARG;
   if ((small0 && !idx0) || (small1 && !idx1) || (small2 && !idx2)) return MAGIC_ERR_ARG;
   TabRef t0{d0, idx0, mod0, off0}, t1{d1, idx1, mod1, off1}, t2{d2, idx2, mod2, off2};
-  dim3 grid((M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS)), block(256);
+  int nb = (M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS);
+  dim3 grid(nb > 384 ? 384 : nb), block(256);
   size_t shm = (size_t)17 * H * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
 #define LNB(TY, NIT) hipLaunchKernelGGL((ln_bwd_kernel<TY, NIT>), grid, block, shm, st, M, (const TY*)dy, (const TY*)y, gamma, beta, rstd, (TY*)dx, dgamma, dbeta, t0, d0, small0, t1, d1, small1, t2, d2, small2, do_ln)

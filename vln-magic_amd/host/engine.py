@@ -14,7 +14,10 @@ import torch
 from . import ops as O
 from .config import cfg_get
 
+import os
+
 HD = 64  # head dim (heads = H/64: train_r2r_magic.py:143,157)
+FUSED_ATTN = not os.environ.get("MAGIC_NO_FUSED_ATTN")   # fused QK^T+softmax+PV / 5-product backward when the shape fits LDS
 
 
 def rup(x, m=8):
@@ -150,6 +153,11 @@ class MagicNet:
     def _attn_fwd(self, q, ldq, k, v, ldkv, Bn, Nq, Nk, kmask, dist, sprel, flops):
         nh, H = self.nh, self.H
         ldp = rup(Nk)
+        if FUSED_ATTN and O.attn_supported(self.dtype, Nq, Nk, False):
+            Pm, ctx = self.new(Bn, nh, Nq, ldp), self.new(Bn * Nq, H)
+            O.attn_fwd(q, ldq, k, v, ldkv, Pm, ldp, ctx, Bn, nh, Nq, Nk, H, 1.0 / math.sqrt(HD), kmask=kmask, dist=dist,
+                       sprel_w=sprel[0] if sprel else None, sprel_b=sprel[1] if sprel else None, flops=flops)
+            return Pm, ctx, ldp
         S = self.new(Bn, nh, Nq, ldp, dtype=torch.float32)
         O.gemm(0, q, k, S, Nq, Nk, HD, ldq, ldkv, ldp, batch=Bn * nh, nh=nh, sA=(Nq * ldq, HD), sB=(Nk * ldkv, HD),
                sC=(nh * Nq * ldp, Nq * ldp), flop_dims=(1, 1, flops / (nh * Bn)))
@@ -163,6 +171,10 @@ class MagicNet:
 
     def _attn_bwd(self, Pm, ldp, d_ctx, q, ldq, k, v, ldkv, dq, lddq, dk, dv, lddkv, Bn, Nq, Nk, dist, dsprel, dP_init, flops):
         nh, H = self.nh, self.H
+        if FUSED_ATTN and O.attn_supported(self.dtype, Nq, Nk, True):
+            O.attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, d_ctx, Bn, nh, Nq, Nk, H, 1.0 / math.sqrt(HD), dP_init, dq, lddq, dk, dv, lddkv,
+                       dist=dist, dsprel_w=dsprel[0] if dsprel else None, dsprel_b=dsprel[1] if dsprel else None, flops=flops)
+            return
         fd = (1, 1, flops / (nh * Bn))      # x (batch = Bn*nh) in the counter -> 2 * sum_b(lq*lk) * 64 * nh
         sP = (nh * Nq * ldp, Nq * ldp)
         # dV = P^T dO

@@ -26,6 +26,9 @@ SIGNATURES = {
     "magic_smallk_ln_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_softmax_fwd": [i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp],
     "magic_softmax_bwd": [i32, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
+    "magic_attn_supported": [i32, i32, i32, i32],
+    "magic_attn_fwd": [i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, f32, vp, vp, vp, vp, vp],
+    "magic_attn_bwd": [i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, f32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp],
     "magic_head_mean_fwd": [i32, i32, i32, i64, vp, vp, vp],
     "magic_head_mean_bwd": [i32, i32, i64, vp, vp, i32, vp],
     "magic_lndot_fwd": [i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],

@@ -158,6 +158,31 @@ def softmax_bwd(Pm, dP, dS, B, nh, Nq, Nk, ldp, scale, dist=None, dsprel_w=None,
            L.P(dsprel_w), L.P(dsprel_b), L.stream())
 
 
+_ATTN_OK = {}
+
+
+def attn_supported(dtype, Nq, Nk, backward):
+    key = (dtype, Nq, Nk, backward)
+    if key not in _ATTN_OK:
+        _ATTN_OK[key] = bool(L.load().magic_attn_supported(L.dt(dtype), Nq, Nk, 1 if backward else 0))
+    return _ATTN_OK[key]
+
+
+def attn_fwd(q, ldq, k, v, ldkv, Pm, ldp, ctx, B, nh, Nq, Nk, H, scale, kmask=None, dist=None, sprel_w=None, sprel_b=None, flops=0.0):
+    if FLOPS["enabled"]:
+        FLOPS["total"] += 4.0 * flops
+    L.call("magic_attn_fwd", L.dt(q.dtype), B, nh, Nq, Nk, L.P(q), ldq, L.P(k), L.P(v), ldkv, L.P(Pm), ldp, L.P(ctx), H, float(scale),
+           L.P(kmask), L.P(dist), L.P(sprel_w), L.P(sprel_b), L.stream())
+
+
+def attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, dctx, B, nh, Nq, Nk, H, scale, dP_init, dq, lddq, dk, dv, lddkv, dist=None, dsprel_w=None,
+             dsprel_b=None, flops=0.0):
+    if FLOPS["enabled"]:
+        FLOPS["total"] += 8.0 * flops
+    L.call("magic_attn_bwd", L.dt(q.dtype), B, nh, Nq, Nk, L.P(q), ldq, L.P(k), L.P(v), ldkv, L.P(Pm), ldp, L.P(dctx), H, float(scale),
+           L.P(dP_init), L.P(dq), lddq, L.P(dk), L.P(dv), lddkv, L.P(dist), L.P(dsprel_w), L.P(dsprel_b), L.stream())
+
+
 def head_mean_fwd(Pm, out, B, nh, inner):
     L.call("magic_head_mean_fwd", L.dt(Pm.dtype), B, nh, inner, L.P(Pm), L.P(out), L.stream())
 

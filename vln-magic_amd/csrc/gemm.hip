@@ -165,8 +165,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int kt0 = sk * per, kt1 = min(ktiles, kt0 + per);
   if (kt0 >= kt1 && p.splitk > 1) return;
 
-  TileLoader<T, A_KC> la;
-  TileLoader<T, B_KC> lb;
+  // Register-staged software pipeline, PD tiles deep: the global loads of tiles kt+1 .. kt+PD-1 are in flight while
+  // tile kt is written to LDS and multiplied.  These GEMMs run ~1 block per CU (grids of 100-600 blocks), so a
+  // block has to hide HBM/L2 latency itself; hipcc turns the in-order loads into counted s_waitcnt vmcnt(N).
+  constexpr int PD = 3;
+  TileLoader<T, A_KC> la[PD];
+  TileLoader<T, B_KC> lb[PD];
   f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -175,26 +179,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   float bsum = 0.f;
   const bool do_bgrad = (LAYOUT == 2) && p.bias_grad != nullptr && blockIdx.x == 0;
 
-  if (kt0 < kt1) {
-    la.load(A, p.lda, m0, kt0 * BK, p.M, p.K);
-    lb.load(B, p.ldb, n0, kt0 * BK, p.N, p.K);
-  }
-  for (int kt = kt0; kt < kt1; ++kt) {
-    la.store(sA);
-    lb.store(sB);
-    __syncthreads();
-    if (kt + 1 < kt1) {
-      la.load(A, p.lda, m0, (kt + 1) * BK, p.M, p.K);
-      lb.load(B, p.ldb, n0, (kt + 1) * BK, p.N, p.K);
+#pragma unroll
+  for (int d = 0; d < PD; ++d)
+    if (kt0 + d < kt1) {
+      la[d].load(A, p.lda, m0, (kt0 + d) * BK, p.M, p.K);
+      lb[d].load(B, p.ldb, n0, (kt0 + d) * BK, p.N, p.K);
     }
-    mma_tile<A_KC, B_KC>(sA, sB, wr, wc, lane, acc);
-    if (do_bgrad && tid < BM) {
-      float s = 0.f;
+  for (int kt = kt0; kt < kt1; kt += PD) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      if (kt + d < kt1) {           // block-uniform
+        la[d].store(sA);
+        lb[d].store(sB);
+        __syncthreads();
+        if (kt + d + PD < kt1) {
+          la[d].load(A, p.lda, m0, (kt + d + PD) * BK, p.M, p.K);
+          lb[d].load(B, p.ldb, n0, (kt + d + PD) * BK, p.N, p.K);
+        }
+        mma_tile<A_KC, B_KC>(sA, sB, wr, wc, lane, acc);
+        if (do_bgrad && tid < BM) {
+          float s = 0.f;
 #pragma unroll 8
-      for (int k = 0; k < BK; ++k) s += to_f(sA[k * TT<T>::SN + tid]);      // TN: A is held as the natural [k][out] image
-      bsum += s;
+          for (int k = 0; k < BK; ++k) s += to_f(sA[k * TT<T>::SN + tid]);      // TN: A is held as the natural [k][out] image
+          bsum += s;
+        }
+        __syncthreads();
+      }
     }
-    __syncthreads();
   }
   if (do_bgrad && tid < BM && m0 + tid < p.M) atomicAdd(p.bias_grad + m0 + tid, bsum);
 

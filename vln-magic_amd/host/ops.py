@@ -5,6 +5,8 @@ torch/CPU fallback.  Shapes are checked on the host before launch (a faulting ke
 whole GPU node down).  `FLOPS` accumulates the algorithmic dense-contraction FLOPs (2*m*n*k with the
 TRUE, unpadded sizes the caller passes via `flop_dims`) for the roofline report.
 """
+import os
+
 import torch
 
 from . import lib as L
@@ -69,9 +71,15 @@ def linear_dx(dy, W, M, *, out=None, epilogue=0, aux=None, residual=None, lda=No
     return out
 
 
-def _splitk(tiles, kred, target=512):
-    ks = max(1, (kred + 63) // 64)
-    return int(max(1, min(target // max(tiles, 1), ks, 64)))
+SPLITK = {"target": int(os.environ.get("MAGIC_SPLITK_TARGET", "256")), "min_tiles": int(os.environ.get("MAGIC_SPLITK_MIN_TILES", "2"))}
+
+
+def _splitk(tiles, kred):
+    """split-K factor of the weight-gradient GEMM: every split block adds a full 64x64 fp32 tile with atomics (16 KB), so
+    the atomic traffic is tiles*splitk*16 KB whatever the true dW size -- keep the grid near one block per CU and give
+    each block at least `min_tiles` 64-deep k-tiles."""
+    ks = max(1, (kred + 64 * SPLITK["min_tiles"] - 1) // (64 * SPLITK["min_tiles"]))
+    return int(max(1, min(SPLITK["target"] // max(tiles, 1), ks, 64)))
 
 
 SIDE = {"stream": None, "keep": []}     # optional side stream for the weight-gradient GEMMs (off the dX critical chain)

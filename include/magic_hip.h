@@ -39,6 +39,12 @@ int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,
                const void* residual, int ldr, void* C2, int ldc2,
                float alpha, int splitk, float* bias_grad, void* stream);
 
+/* out = LayerNorm(x[M,K] W[H,K]^T + bias + residual): BertSelfOutput / BertOutput (dense -> add -> LayerNorm) in one launch;
+ * H in {128, 256, 384} (a workgroup owns 32 full rows), otherwise MAGIC_ERR_UNSUPPORTED -> magic_gemm + magic_ln_fwd. */
+int magic_linear_ln(int dtype, int M, int H, int K, const void* x, int lda, const void* W, int ldb, const float* bias,
+                    const void* residual, int ldr, const float* gamma, const float* beta, float eps,
+                    void* out, float* rstd, void* stream);
+
 /* out = [LayerNorm]( in0 + in1 + tab0[i0] + tab1[i1] + tab2[i2] ); table row = idx ? idx[r] : mod ? r%mod+off : off.
  * Carries BertEmbeddings (word + position(+2) + token-type -> LN), the image embedding sum, the map-node
  * input sum and every residual-add + LayerNorm of the BERT blocks. */
@@ -53,6 +59,10 @@ int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void* y, const f
                  const int* idx1, int mod1, int off1, float* d1, int small1,
                  const int* idx2, int mod2, int off2, float* d2, int small2,
                  int do_ln, void* stream);
+
+/* gamma/beta gradients of one LayerNorm as a column reduction (used when magic_ln_bwd is called with dgamma = dbeta = NULL) */
+int magic_ln_pgrad(int dtype, int M, int H, const void* dy, const void* y, const float* gamma, const float* beta,
+                   float* dgamma, float* dbeta, void* stream);
 
 /* y = LN(x[M,Kin<=16] W^T + b): loc_linear+loc_layer_norm, gmap_pos_embeddings, vp_pos_embeddings (App. B.2-B.3) */
 int magic_smallk_ln_fwd(int dtype, int M, int H, int Kin, const float* x, const float* W, const float* b,

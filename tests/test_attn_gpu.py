@@ -94,3 +94,19 @@ def test_unsupported_shapes_are_reported_not_launched():
     assert not O.attn_supported(torch.bfloat16, 40, 512, False)
     assert O.attn_supported(torch.bfloat16, 80, 80, True)
     assert not O.attn_supported(torch.float32, 128, 128, True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H,K", [(100, 128, 128), (77, 128, 512), (200, 256, 256), (64, 256, 1024), (33, 384, 384)])
+def test_fused_linear_residual_layernorm(dtype, M, H, K):
+    g = torch.Generator().manual_seed(M + H + K)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    x, W, r = rnd(M, K).to(dtype), (rnd(H, K) * 0.1).to(dtype), rnd(M, H).to(dtype)
+    b, gamma, beta = rnd(H) * 0.1, 1 + 0.1 * rnd(H), 0.1 * rnd(H)
+    ref = torch.nn.functional.layer_norm(x.float() @ W.float().t() + b + r.float(), (H,), gamma, beta, 1e-12)
+    out, rstd = torch.empty(M, H, dtype=dtype, device=DEV), torch.empty(M, device=DEV)
+    O.linear_ln(x, W, b, M, r, gamma, beta, 1e-12, out, rstd)
+    pre = x.float() @ W.float().t() + b + r.float()
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)
+    assert torch.allclose(out.float(), ref, **tol), (out.float() - ref).abs().max().item()
+    assert torch.allclose(rstd, 1 / torch.sqrt(pre.var(-1, unbiased=False) + 1e-12), rtol=1e-3 if dtype == torch.float32 else 2e-2, atol=1e-3)

@@ -346,3 +346,186 @@ extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N
 #undef LAUNCH
   return launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Linear + bias + residual + LayerNorm in one launch (the BertSelfOutput / BertOutput tails: dense -> add -> LayerNorm).
+// A workgroup owns 32 full rows (BN = H), so the row statistics are a cross-wave LDS reduction in the epilogue and the
+// separate LayerNorm launch (and its pass over [M,H]) disappears.  4 waves side by side, each 32 rows x H/4 columns.
+template <typename T, int HT>      // HT = H / 64 column tiles of 16 per wave (H = 64*HT... per wave H/4 = 16*HT columns)
+__global__ __launch_bounds__(256) void linear_ln_kernel(int M, int K, const T* __restrict__ X, int lda, const T* __restrict__ W, int ldb,
+                                                        const float* __restrict__ bias, const T* __restrict__ R, int ldr,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        T* __restrict__ out, float* __restrict__ rstd_out) {
+  typedef typename TT<T>::vec vec;
+  constexpr int VE = TT<T>::VE, BK = TT<T>::BK, STRIDE = TT<T>::STRIDE;
+  constexpr int H = 64 * HT, WC = 16 * HT;          // columns per wave
+  constexpr int KS = (sizeof(T) == 2) ? 2 : 8;      // MFMA k-steps per BK tile
+  constexpr int KW = (sizeof(T) == 2) ? 32 : 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  T* sA = (T*)lds_raw;                 // [32][STRIDE]
+  T* sB = sA + 32 * STRIDE;            // [H][STRIDE]
+  float* red = (float*)(sB + H * STRIDE);   // [4][32]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int m0 = blockIdx.x * 32;
+  f32x4 acc[2][HT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < HT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int VPT_B = H * (BK / VE) / 256;        // B-tile vectors per thread
+  vec va, vb[VPT_B];
+  auto load = [&](int k0) {
+    {
+      const int row = tid >> 3, cv = tid & 7;
+      vec z;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) z[e] = (T)0.0f;
+      if (m0 + row < M && k0 + cv * VE < K) z = *(const vec*)(X + (long long)(m0 + row) * lda + k0 + cv * VE);
+      va = z;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT_B; ++i) {
+      const int id = tid + 256 * i, row = id >> 3, cv = id & 7;
+      vec z;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) z[e] = (T)0.0f;
+      if (k0 + cv * VE < K) z = *(const vec*)(W + (long long)row * ldb + k0 + cv * VE);
+      vb[i] = z;
+    }
+  };
+  auto store = [&]() {
+    auto st = [&](T* d, const vec& v) {
+      if constexpr (sizeof(T) == 2) { *(vec*)d = v; }
+      else { ((float2*)d)[0] = make_float2(v[0], v[1]); ((float2*)d)[1] = make_float2(v[2], v[3]); }
+    };
+    st(sA + (tid >> 3) * STRIDE + (tid & 7) * VE, va);
+#pragma unroll
+    for (int i = 0; i < VPT_B; ++i) {
+      const int id = tid + 256 * i;
+      st(sB + (id >> 3) * STRIDE + (id & 7) * VE, vb[i]);
+    }
+  };
+  const int ktiles = (K + BK - 1) / BK;
+  load(0);
+  for (int kt = 0; kt < ktiles; ++kt) {
+    store();
+    __syncthreads();
+    if (kt + 1 < ktiles) load((kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const auto a0 = frag<true>(sA, 0, ks, lane), a1 = frag<true>(sA, 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < HT; ++j) {
+        const auto b = frag<true>(sB, w * WC + j * 16, ks, lane);
+        if constexpr (sizeof(T) == 2) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][j], 0, 0, 0);
+        } else {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
+        }
+      }
+    }
+    (void)KW;
+    __syncthreads();
+  }
+  // ---- epilogue: v = acc + bias + residual ; LayerNorm over the full row (cross-wave) ; store
+  float bv[HT], gv[HT], btv[HT];
+#pragma unroll
+  for (int j = 0; j < HT; ++j) {
+    const int col = w * WC + j * 16 + c16;
+    bv[j] = bias ? bias[col] : 0.f; gv[j] = gamma[col]; btv[j] = beta[col];
+  }
+  float rsd[2][HT][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < HT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + i * 16 + 4 * g + r, col = w * WC + j * 16 + c16;
+        rsd[i][j][r] = (R && row < M) ? to_f(R[(long long)row * ldr + col]) : 0.f;
+      }
+  float s[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < HT; ++j) { acc[i][j][r] += bv[j] + rsd[i][j][r]; t += acc[i][j][r]; }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      s[i][r] = t;
+    }
+  if (c16 == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w * 32 + i * 16 + 4 * g + r] = s[i][r];
+  }
+  __syncthreads();
+  float mean[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = i * 16 + 4 * g + r;
+      mean[i][r] = (red[rr] + red[32 + rr] + red[64 + rr] + red[96 + rr]) / H;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < HT; ++j) { const float d = acc[i][j][r] - mean[i][r]; t += d * d; }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      s[i][r] = t;
+    }
+  if (c16 == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w * 32 + i * 16 + 4 * g + r] = s[i][r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = i * 16 + 4 * g + r, row = m0 + rr;
+      const float rstd = rsqrtf((red[rr] + red[32 + rr] + red[64 + rr] + red[96 + rr]) / H + eps);
+      if (row < M) {
+        if (rstd_out && w == 0 && c16 == 0) rstd_out[row] = rstd;
+#pragma unroll
+        for (int j = 0; j < HT; ++j)
+          out[(long long)row * H + w * WC + j * 16 + c16] = from_f<T>((acc[i][j][r] - mean[i][r]) * rstd * gv[j] + btv[j]);
+      }
+    }
+}
+
+extern "C" int magic_linear_ln(int dtype, int M, int H, int K, const void* x, int lda, const void* W, int ldb, const float* bias,
+                               const void* residual, int ldr, const float* gamma, const float* beta, float eps,
+                               void* out, float* rstd, void* stream) {
+  if (M <= 0 || K <= 0 || !gamma || !beta || !out) return MAGIC_ERR_ARG;
+  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
+  const int ve = dtype == DT_BF16 ? 8 : 4;
+  if (lda % ve || ldb % ve || ((uintptr_t)x & 15) || ((uintptr_t)W & 15)) return MAGIC_ERR_ARG;
+  if (H != 128 && H != 256 && H != 384) return MAGIC_ERR_UNSUPPORTED;
+  dim3 grid((M + 31) / 32), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define LLN(TY, HT)                                                                                                       \
+  do {                                                                                                                    \
+    const size_t shm = (size_t)(32 + 64 * HT) * TT<TY>::STRIDE * sizeof(TY) + 128 * sizeof(float);                        \
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)linear_ln_kernel<TY, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((linear_ln_kernel<TY, HT>), grid, block, shm, st, M, K, (const TY*)x, lda, (const TY*)W, ldb, bias,  \
+                       (const TY*)residual, ldr, gamma, beta, eps, (TY*)out, rstd);                                       \
+  } while (0)
+  if (dtype == DT_BF16) { if (H == 128) LLN(bf16, 2); else if (H == 256) LLN(bf16, 4); else LLN(bf16, 6); }
+  else { if (H == 128) LLN(float, 2); else if (H == 256) LLN(float, 4); else LLN(float, 6); }
+#undef LLN
+  return launch_status();
+}

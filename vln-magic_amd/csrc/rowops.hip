@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, const T* dy, const T
     TAB_GRAD(2, t2, d2, l2, c2)
 #undef TAB_GRAD
   }
-  if (do_ln) {
+  const bool pg = do_ln && dgamma != nullptr;      // gamma/beta grads here, or by ln_pgrad_kernel (dgamma == nullptr)
+  if (pg) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = it * 128 + lane * 2;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, const T* dy, const T
     }
   }
   __syncthreads();
-  if (do_ln) {
+  if (pg) {
     for (int c = threadIdx.x; c < H; c += 256) {
       atomicAdd(dgamma + c, red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c]);
       atomicAdd(dbeta + c, red[4 * H + c] + red[5 * H + c] + red[6 * H + c] + red[7 * H + c]);
@@ -182,6 +183,51 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, const T* dy, const T
     TAB_FLUSH(1, t1, d1, l1, c1)
     TAB_FLUSH(2, t2, d2, l2, c2)
 #undef TAB_FLUSH
+  }
+}
+
+// gamma/beta gradients of a LayerNorm as a separate column reduction: dgamma[c] += sum_m dy*xhat, dbeta[c] += sum_m dy
+// (xhat from y).  A block owns PG_ROWS rows: its 4 waves stride over them with independent loads (no per-row wave
+// reductions on the chain), reduce through LDS, and issue one atomic per column -- M/PG_ROWS-way contention only.
+#define PG_ROWS 128
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_pgrad_kernel(int M, const T* dy, const T* y, const float* gamma, const float* beta,
+                                                       float* dgamma, float* dbeta) {
+  constexpr int H = NIT * 128;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][4][H]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float ag[2 * NIT], ab[2 * NIT], gm[2 * NIT], bt[2 * NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 128 + lane * 2;
+    const float2 g2 = *(const float2*)(gamma + c), b2 = *(const float2*)(beta + c);
+    gm[2 * it] = g2.x != 0.f ? 1.f / g2.x : 0.f; gm[2 * it + 1] = g2.y != 0.f ? 1.f / g2.y : 0.f;
+    bt[2 * it] = b2.x; bt[2 * it + 1] = b2.y;
+    ag[2 * it] = ag[2 * it + 1] = ab[2 * it] = ab[2 * it + 1] = 0.f;
+  }
+  const int r0 = blockIdx.x * PG_ROWS, r1 = min(M, r0 + PG_ROWS);
+#pragma unroll 4
+  for (int row = r0 + wid; row < r1; row += 4) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 128 + lane * 2;
+      float da, db, ya, yb;
+      ld2<T>(dy + (long long)row * H + c, da, db);
+      ld2<T>(y + (long long)row * H + c, ya, yb);
+      ag[2 * it] += da * (ya - bt[2 * it]) * gm[2 * it]; ag[2 * it + 1] += db * (yb - bt[2 * it + 1]) * gm[2 * it + 1];
+      ab[2 * it] += da; ab[2 * it + 1] += db;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 128 + lane * 2;
+    red[(0 * 4 + wid) * H + c] = ag[2 * it]; red[(0 * 4 + wid) * H + c + 1] = ag[2 * it + 1];
+    red[(1 * 4 + wid) * H + c] = ab[2 * it]; red[(1 * 4 + wid) * H + c + 1] = ab[2 * it + 1];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    atomicAdd(dgamma + c, red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c]);
+    atomicAdd(dbeta + c, red[4 * H + c] + red[5 * H + c] + red[6 * H + c] + red[7 * H + c]);
   }
 }
 
@@ -537,16 +583,31 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
                             const int* idx2, int mod2, int off2, float* d2, int small2,
                             int do_ln, void* stream) {
   if (M <= 0 || !okH(H) || !dy) return MAGIC_ERR_ARG;
-  if (do_ln && (!y || !gamma || !beta || !rstd || !dgamma || !dbeta)) return MAGIC_ERR_ARG;
+  if (do_ln && (!y || !gamma || !beta || !rstd)) return MAGIC_ERR_ARG;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return MAGIC_ERR_ARG;
   if ((small0 && !idx0) || (small1 && !idx1) || (small2 && !idx2)) return MAGIC_ERR_ARG;
   TabRef t0{d0, idx0, mod0, off0}, t1{d1, idx1, mod1, off1}, t2{d2, idx2, mod2, off2};
-  int nb = (M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS);
-  dim3 grid(nb > 384 ? 384 : nb), block(256);
+  // with in-kernel gamma/beta grads every block ends in 2H same-address atomics -> few blocks; without them one row per wave
+  int nb = dgamma ? (M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS) : (M + 3) / 4;
+  const int cap = dgamma ? 384 : 4096;
+  dim3 grid(nb > cap ? cap : nb), block(256);
   size_t shm = (size_t)17 * H * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
 #define LNB(TY, NIT) hipLaunchKernelGGL((ln_bwd_kernel<TY, NIT>), grid, block, shm, st, M, (const TY*)dy, (const TY*)y, gamma, beta, rstd, (TY*)dx, dgamma, dbeta, t0, d0, small0, t1, d1, small1, t2, d2, small2, do_ln)
   DISPATCH_NIT(dtype, H, LNB);
 #undef LNB
+  return launch_status();
+}
+
+extern "C" int magic_ln_pgrad(int dtype, int M, int H, const void* dy, const void* y, const float* gamma, const float* beta,
+                              float* dgamma, float* dbeta, void* stream) {
+  if (M <= 0 || !okH(H) || !dy || !y || !gamma || !beta || !dgamma || !dbeta) return MAGIC_ERR_ARG;
+  dim3 grid((M + PG_ROWS - 1) / PG_ROWS), block(256);
+  size_t shm = (size_t)8 * H * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define LPG(TY, NIT) hipLaunchKernelGGL((ln_pgrad_kernel<TY, NIT>), grid, block, shm, st, M, (const TY*)dy, (const TY*)y, gamma, beta, dgamma, dbeta)
+  DISPATCH_NIT(dtype, H, LPG);
+#undef LPG
   return launch_status();
 }
 

@@ -199,10 +199,13 @@ class MagicNet:
         c.qkv = O.linear_fwd(x, qkv.W, qkv.b, M, flop_rows=rows)
         c.P, c.ctx, c.ldp = self._attn_fwd(c.qkv, 3 * H, c.qkv[:, H:], c.qkv[:, 2 * H:], 3 * H, Bn, N, N, kmask, dist, sprel, aflops)
         o = self.lin(lp + "attention.output.dense.weight")
-        ao = O.linear_fwd(c.ctx, o.W, o.b, M, residual=x, flop_rows=rows)
         n = self.ln(lp + "attention.output.LayerNorm")
         c.a, c.rstd_a = self.new(M, H), self.new(M, dtype=torch.float32)
-        O.ln_fwd(M, H, c.a, in0=ao, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_a)
+        if O.linear_ln_ok(H, H):
+            O.linear_ln(c.ctx, o.W, o.b, M, x, n.g, n.b, self.eps, c.a, c.rstd_a, flop_rows=rows)
+        else:
+            ao = O.linear_fwd(c.ctx, o.W, o.b, M, residual=x, flop_rows=rows)
+            O.ln_fwd(M, H, c.a, in0=ao, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_a)
         return c
 
     def _sa_bwd(self, lp, c, d_a, dsprel=None, dP_init=None):
@@ -228,10 +231,13 @@ class MagicNet:
         f1, f2 = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")
         c.z = self.new(M, I)
         c.g = O.linear_fwd(a, f1.W, f1.b, M, epilogue=1, pre=c.z, flop_rows=rows)
-        fo = O.linear_fwd(c.g, f2.W, f2.b, M, residual=a, flop_rows=rows)
         n = self.ln(lp + "output.LayerNorm")
         c.out, c.rstd = self.new(M, H), self.new(M, dtype=torch.float32)
-        O.ln_fwd(M, H, c.out, in0=fo, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd)
+        if O.linear_ln_ok(H, self.I):
+            O.linear_ln(c.g, f2.W, f2.b, M, a, n.g, n.b, self.eps, c.out, c.rstd, flop_rows=rows)
+        else:
+            fo = O.linear_fwd(c.g, f2.W, f2.b, M, residual=a, flop_rows=rows)
+            O.ln_fwd(M, H, c.out, in0=fo, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd)
         return c
 
     def _ffn_bwd(self, lp, c, dout):
@@ -269,10 +275,13 @@ class MagicNet:
         c.kv = O.linear_fwd(ctx, kvl.W, kvl.b, Mk, flop_rows=crow)
         c.P, c.cctx, c.ldp = self._attn_fwd(c.q, H, c.kv, c.kv[:, H:], 2 * H, Bn, Nq, Nk, ckmask, None, None, cflops)
         o = self.lin(lp + "crossattention.output.dense.weight")
-        co = O.linear_fwd(c.cctx, o.W, o.b, Mq, residual=s, flop_rows=rows)
         n = self.ln(lp + "crossattention.output.LayerNorm")
         c.c, c.rstd_c = self.new(Mq, H), self.new(Mq, dtype=torch.float32)
-        O.ln_fwd(Mq, H, c.c, in0=co, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_c)
+        if O.linear_ln_ok(H, H):
+            O.linear_ln(c.cctx, o.W, o.b, Mq, s, n.g, n.b, self.eps, c.c, c.rstd_c, flop_rows=rows)
+        else:
+            co = O.linear_fwd(c.cctx, o.W, o.b, Mq, residual=s, flop_rows=rows)
+            O.ln_fwd(Mq, H, c.c, in0=co, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_c)
         c.ffn = self._ffn_fwd(lp, c.c, Mq, rows)
         c.out = c.ffn.out
         return c

@@ -114,6 +114,24 @@ def _linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None
          flop_dims=(N, K, flop_rows if flop_rows is not None else M))
 
 
+FUSED_LN = not os.environ.get("MAGIC_NO_FUSED_LN")
+
+
+def linear_ln_ok(H, K=0):
+    """fused dense+add+LayerNorm pays while the per-block serial K loop is short (measured: slower than GEMM + LN
+    for the teacher's K=1024 FFN output, faster for K <= 512)"""
+    return FUSED_LN and H in (128, 256, 384) and K <= 512
+
+
+def linear_ln(x, W, b, M, residual, gamma, beta, eps, out, rstd, flop_rows=None):
+    """out = LayerNorm(x @ W^T + b + residual) in one launch (H = W.shape[0] in {128,256,384})."""
+    H, K = W.shape
+    _count(flop_rows if flop_rows is not None else M, H, K)
+    L.call("magic_linear_ln", L.dt(x.dtype), M, H, K, L.P(x), x.stride(0), L.P(W), W.stride(0), L.P(b), L.P(residual),
+           residual.stride(0) if residual is not None else 0, L.P(gamma), L.P(beta), float(eps), L.P(out), L.P(rstd), L.stream())
+    return out
+
+
 def _tab(t):
     """t = None | (table, idx|None, mod, off)"""
     if t is None:
@@ -135,9 +153,16 @@ def _dtab(t):
     return (L.P(t[0]), int(t[1]), int(t[2]), L.P(t[3]), int(t[4]))
 
 
+SPLIT_PGRAD = bool(os.environ.get("MAGIC_SPLIT_PGRAD"))     # opt-in: measured neutral-to-slower (the extra launch costs what the atomics did)
+
+
 def ln_bwd(M, H, dy, *, y=None, gamma=None, beta=None, rstd=None, dx=None, dgamma=None, dbeta=None,
            dtabs=(None, None, None), do_ln=True):
     d0, d1, d2 = [_dtab(t) for t in dtabs]
+    if do_ln and dgamma is not None and SPLIT_PGRAD and M >= 512:
+        # row kernel fully parallel (no same-address atomics) + a separate low-contention column reduction
+        L.call("magic_ln_pgrad", L.dt(dy.dtype), M, H, L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(dgamma), L.P(dbeta), L.stream())
+        dgamma = dbeta = None
     L.call("magic_ln_bwd", L.dt(dy.dtype), M, H, L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(dx),
            L.P(dgamma), L.P(dbeta), *d0, *d1, *d2, 1 if do_ln else 0, L.stream())
     return dx

@@ -39,6 +39,11 @@ int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,
                const void* residual, int ldr, void* C2, int ldc2,
                float alpha, int splitk, float* bias_grad, void* stream);
 
+/* Grouped weight-gradient GEMM: n <= 8 independent problems dW[N,K] (fp32, ldc) += dY[M,N]^T (lda) @ X[M,K] (ldb), db[N] += colsum(dY)
+ * in ONE launch (split-K, fp32 atomics).  `d` is a HOST array of n descriptors holding device pointers. */
+typedef struct magic_dw_desc { const void* dY; const void* X; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk; } magic_dw_desc;
+int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, void* stream);
+
 /* out = LayerNorm(x[M,K] W[H,K]^T + bias + residual): BertSelfOutput / BertOutput (dense -> add -> LayerNorm) in one launch;
  * H in {128, 256, 384} (a workgroup owns 32 full rows), otherwise MAGIC_ERR_UNSUPPORTED -> magic_gemm + magic_ln_fwd. */
 int magic_linear_ln(int dtype, int M, int H, int K, const void* x, int lda, const void* W, int ldb, const float* bias,

@@ -142,17 +142,15 @@ __device__ __forceinline__ void mma_tile(const float* sA, const float* sB, int w
 
 // LAYOUT 0: NT (A[M,K], B[N,K]); 1: NN (A[M,K], B[K,N]); 2: TN (A[K,M], B[K,N])
 template <typename T, int LAYOUT>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, const int by, const int bzz, T* sA, T* sB) {
   constexpr int BK = TT<T>::BK, STRIDE = TT<T>::STRIDE;
   static_assert(BM * TT<T>::STRIDE >= TT<T>::BK * TT<T>::SN, "LDS image sizes");
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
-  __shared__ __attribute__((aligned(16))) T sA[BM * STRIDE];
-  __shared__ __attribute__((aligned(16))) T sB[BN * STRIDE];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-  const int bz = blockIdx.z / p.splitk, sk = blockIdx.z % p.splitk;
+  const int n0 = bx * BN, m0 = by * BM;
+  const int bz = bzz / p.splitk, sk = bzz % p.splitk;
   const int bb = bz / p.nh, bh = bz % p.nh;
 
   const T* A = (const T*)p.A + bb * p.sAb + bh * p.sAh;
@@ -177,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  const bool do_bgrad = (LAYOUT == 2) && p.bias_grad != nullptr && blockIdx.x == 0;
+  const bool do_bgrad = (LAYOUT == 2) && p.bias_grad != nullptr && bx == 0;
 
 #pragma unroll
   for (int d = 0; d < PD; ++d)
@@ -310,6 +308,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       if (ok[e]) ((T*)p.C)[coff + (long long)row * p.ldc + col] = from_f<T>(v[e]);
     }
   }
+}
+
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) T sA[BM * TT<T>::STRIDE];
+  __shared__ __attribute__((aligned(16))) T sB[BN * TT<T>::STRIDE];
+  gemm_block<T, LAYOUT>(p, blockIdx.x, blockIdx.y, blockIdx.z, sA, sB);
+}
+
+// Grouped weight-gradient GEMM: up to GROUP_MAX independent TN problems (dW[N,K] += dY^T X, split-K, fp32 atomics, fused
+// bias gradient) in ONE launch.  Nothing on the backward chain depends on dW, so the engine defers all of a step's
+// weight-gradient GEMMs and issues them ~8 at a time: ~80 launches become ~10.
+#define GROUP_MAX 8
+struct GroupedParams { GemmParams p[GROUP_MAX]; int start[GROUP_MAX + 1]; int n; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_dw_grouped_kernel(GroupedParams gp) {
+  __shared__ __attribute__((aligned(16))) T sA[BM * TT<T>::STRIDE];
+  __shared__ __attribute__((aligned(16))) T sB[BN * TT<T>::STRIDE];
+  const int id = blockIdx.x;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i) g += (i < gp.n && id >= gp.start[i]) ? 1 : 0;      // block-uniform
+  const GemmParams& p = gp.p[g];
+  const int local = id - gp.start[g];
+  const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM;
+  gemm_block<T, 2>(p, local % nx, (local / nx) % ny, local / (nx * ny), sA, sB);
 }
 
 extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,
@@ -527,5 +552,35 @@ extern "C" int magic_linear_ln(int dtype, int M, int H, int K, const void* x, in
   if (dtype == DT_BF16) { if (H == 128) LLN(bf16, 2); else if (H == 256) LLN(bf16, 4); else LLN(bf16, 6); }
   else { if (H == 128) LLN(float, 2); else if (H == 256) LLN(float, 4); else LLN(float, 6); }
 #undef LLN
+  return launch_status();
+}
+
+// host-visible descriptor of one weight-gradient problem: dW[N,K] (fp32, ldc) += dY[M,N]^T (lda) @ X[M,K] (ldb); db[N] += colsum(dY)
+struct magic_dw_desc { const void* dY; const void* X; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk; };
+
+extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, void* stream) {
+  if (n <= 0 || n > GROUP_MAX || !d) return MAGIC_ERR_ARG;
+  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
+  const int ve = dtype == DT_BF16 ? 8 : 4;
+  GroupedParams gp;
+  gp.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0 || d[i].splitk <= 0 || !d[i].dY || !d[i].X || !d[i].dW) return MAGIC_ERR_ARG;
+    if (d[i].lda % ve || d[i].ldb % ve || ((uintptr_t)d[i].dY & 15) || ((uintptr_t)d[i].X & 15)) return MAGIC_ERR_ARG;
+    GemmParams& p = gp.p[i];
+    p = GemmParams{};
+    // TN: A = dY stored [Kred = M][Mout = N], B = X stored [Kred = M][Nout = K], C = dW [N, K]
+    p.A = d[i].dY; p.B = d[i].X; p.C = d[i].dW; p.bias_grad = d[i].db;
+    p.M = d[i].N; p.N = d[i].K; p.K = d[i].M; p.lda = d[i].lda; p.ldb = d[i].ldb; p.ldc = d[i].ldc;
+    p.nh = 1; p.splitk = d[i].splitk; p.epilogue = 0; p.c_f32 = 1; p.accumulate = 1; p.alpha = 1.f;
+    gp.start[i] = total;
+    total += ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * p.splitk;
+  }
+  for (int i = n; i <= GROUP_MAX; ++i) gp.start[i] = total;
+  dim3 grid(total), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(gemm_dw_grouped_kernel<bf16>, grid, block, 0, st, gp);
+  else hipLaunchKernelGGL(gemm_dw_grouped_kernel<float>, grid, block, 0, st, gp);
   return launch_status();
 }

@@ -19,6 +19,7 @@ SIGNATURES = {
     "magic_device_info": [vp, vp, vp, i32],
     "magic_gemm": [i32, i32, i32, i32, i32, i32, i32, vp, i32, i64, i64, vp, i32, i64, i64, vp, i32, i64, i64, i32, i32,
                    vp, i32, vp, i32, vp, i32, vp, i32, f32, i32, vp, vp],
+    "magic_gemm_dw_grouped": [i32, i32, vp, vp],
     "magic_linear_ln": [i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, vp],
     "magic_ln_fwd": [i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, vp, vp, i32, vp],
     "magic_ln_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32,
@@ -50,6 +51,14 @@ SIGNATURES = {
     "magic_add": [i32, i64, vp, vp, vp],
     "magic_dact": [i32, i32, i64, vp, vp, vp, vp],
 }
+
+
+
+class DwDesc(C.Structure):
+    """mirror of `magic_dw_desc` (include/magic_hip.h)"""
+    _fields_ = [("dY", vp), ("X", vp), ("dW", vp), ("db", vp), ("M", i32), ("N", i32), ("K", i32),
+                ("lda", i32), ("ldb", i32), ("ldc", i32), ("splitk", i32)]
+
 
 _ERR = {-1: "MAGIC_ERR_ARG", -2: "MAGIC_ERR_LAUNCH", -3: "MAGIC_ERR_UNSUPPORTED"}
 _lib = None

@@ -131,6 +131,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     def forward(self, batch, task, compute_loss=True, teacher_outputs=None, rw=None, plan=None, return_outputs=False, inputs=None):
         n = self.net
         self.store.sync_shadow()
+        O.DEFER["queue"].clear()
         plan = plan if plan is not None else build_plan(batch, task, self.device_)
         inp = inputs if inputs is not None else self._inputs(batch, plan)
         B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H
@@ -253,6 +254,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         n, cfg, plan, task = self.net, self.config, c.plan, c.task
         B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H
         train = self.store.requires_grad
+        O.defer_dw(train)         # the distillation heads' weight gradients join the deferred grouped launch of backward()
         kdl = getattr(cfg, "kdl", None)
         kd = t is not None and kdl is not None
         alpha = float(kdl["kd_alpha"]) if kd else 0.0
@@ -372,6 +374,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     def backward(self):
         c = self._ctx
         assert c is not None, "backward() without a compute_loss=True forward"
+        O.defer_dw(True)          # weight-gradient GEMMs are queued and launched grouped at the end
         n, plan, task = self.net, c.plan, c.task
         B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H
         if task == "sap":
@@ -445,7 +448,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         n.gmap_in_bwd(c.gin, plan, d_gin, c.d_pano, c.d_fused)
         self._par(lambda: n.text_bwd(c.txt, plan, c.d_txt, c.dP_txt),
                   lambda: n.pano_bwd(c.pano, plan, c.d_pano, c.d_fused, c.dP_pano))
-        O.join_side()                          # weight-gradient GEMMs forked to the side stream
+        O.flush_dw()                           # deferred weight-gradient GEMMs, ~8 problems per launch
+        O.join_side()                          # (opt-in) weight-gradient GEMMs forked to the side stream
         self._ctx = None
 
     def _as(self, d):

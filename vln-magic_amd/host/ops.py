@@ -91,16 +91,50 @@ def join_side():
     SIDE["keep"].clear()
 
 
-def linear_dw(dy, x, dW, db, M, **kw):
+DEFER = {"on": not os.environ.get("MAGIC_NO_GROUPED_DW"), "queue": [], "active": False}
+
+
+def defer_dw(active):
+    """Inside a backward pass: queue the weight-gradient GEMMs and launch them ~8 per kernel at `flush_dw()`."""
+    DEFER["active"] = bool(active) and DEFER["on"]
+
+
+def linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None, flop_rows=None):
     """dW[N,K] += dy[M,N]^T @ x[M,K] ; db[N] += colsum(dy)   (fp32 atomics, split-K over M).  Nothing on the backward
-    chain depends on dW, so when a side stream is configured the GEMM is forked onto it (inputs kept alive until join)."""
-    side = SIDE["stream"]
-    if side is None:
-        return _linear_dw(dy, x, dW, db, M, **kw)
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        _linear_dw(dy, x, dW, db, M, **kw)
-    SIDE["keep"].append((dy, x))
+    chain depends on dW: when deferral is active the problem is queued (inputs kept alive) for a grouped launch."""
+    if not DEFER["active"]:
+        side = SIDE["stream"]
+        if side is None:
+            return _linear_dw(dy, x, dW, db, M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, flop_rows=flop_rows)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            _linear_dw(dy, x, dW, db, M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, flop_rows=flop_rows)
+        SIDE["keep"].append((dy, x))
+        return
+    N = N if N is not None else dW.shape[0]
+    K = K if K is not None else dW.shape[1]
+    lda = lda if lda is not None else N
+    ldb = ldb if ldb is not None else K
+    ldc = ldc if ldc is not None else dW.stride(0)
+    _count(N, K, flop_rows if flop_rows is not None else M)
+    tiles = ((N + 63) // 64) * ((K + 63) // 64)
+    DEFER["queue"].append((dy, x, dW, db, M, N, K, lda, ldb, ldc, _splitk(tiles, M)))
+
+
+def flush_dw(group=8):
+    q = DEFER["queue"]
+    i = 0
+    while i < len(q):
+        chunk = [e for e in q[i:i + group]]
+        dt = chunk[0][0].dtype
+        chunk = [e for e in chunk if e[0].dtype == dt]          # same compute dtype within one launch
+        arr = (L.DwDesc * len(chunk))()
+        for j, (dy, x, dW, db, M, N, K, lda, ldb, ldc, sk) in enumerate(chunk):
+            arr[j] = L.DwDesc(L.P(dy), L.P(x), L.P(dW), L.P(db), M, N, K, lda, ldb, ldc, sk)
+        L.call("magic_gemm_dw_grouped", L.dt(dt), len(chunk), arr, L.stream())
+        i += len(chunk)
+    q.clear()
+    DEFER["active"] = False
 
 
 def _linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None, flop_rows=None):

@@ -4,6 +4,7 @@
 // wave-shuffle reductions; parameter gradients are reduced per block (registers -> LDS) before a
 // single fp32 atomic per element per block.
 #include "common.hpp"
+#include <cstdlib>
 
 #define MAXIT 6   // H = 128*NIT, NIT in {1,2,3,6}: each lane owns elements {it*128 + lane*2, +1}
 
@@ -97,62 +98,94 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, const T* dy, const T
 #pragma unroll
   for (int i = 0; i < 2 * NIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
 
-  // grid-stride over rows: the grid is capped so the per-block parameter-gradient atomics stay few
-  for (int row = blockIdx.x * 4 + wid; row < M; row += gridDim.x * 4) {
-    float g[2 * NIT], xh[2 * NIT];
-    float s1 = 0.f, s2 = 0.f;
+  // grid-stride over groups of RPI rows per wave: the RPI rows' loads are issued together and their wave reductions
+  // interleave (ILP), instead of one latency-bound row after another; the grid is capped so the per-block
+  // parameter-gradient atomics stay few.
+  constexpr int RPI = NIT <= 2 ? 4 : 2;
+  float gmr[2 * NIT], btr[2 * NIT], igm[2 * NIT];
+  if (do_ln) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = it * 128 + lane * 2;
-      float da, db;
-      ld2<T>(dy + (long long)row * H + c, da, db);
+      const float2 gm = *(const float2*)(gamma + c), bt = *(const float2*)(beta + c);
+      gmr[2 * it] = gm.x; gmr[2 * it + 1] = gm.y; btr[2 * it] = bt.x; btr[2 * it + 1] = bt.y;
+      igm[2 * it] = gm.x != 0.f ? 1.f / gm.x : 0.f; igm[2 * it + 1] = gm.y != 0.f ? 1.f / gm.y : 0.f;
+    }
+  }
+  for (int base = (blockIdx.x * 4 + wid) * RPI; base < M; base += gridDim.x * 4 * RPI) {
+    float g[RPI][2 * NIT], xh[RPI][2 * NIT];
+    float s1[RPI], s2[RPI], rs[RPI];
+#pragma unroll
+    for (int u = 0; u < RPI; ++u) {
+      const int row = min(base + u, M - 1);          // clamped; rows >= M are masked below
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 128 + lane * 2;
+        ld2<T>(dy + (long long)row * H + c, g[u][2 * it], g[u][2 * it + 1]);
+        if (do_ln) ld2<T>(y + (long long)row * H + c, xh[u][2 * it], xh[u][2 * it + 1]);
+      }
+      rs[u] = do_ln ? rstd[row] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < RPI; ++u) {
+      const float live = (base + u < M) ? 1.f : 0.f;
+      s1[u] = 0.f; s2[u] = 0.f;
       if (do_ln) {
-        float ya, yb;
-        ld2<T>(y + (long long)row * H + c, ya, yb);
-        const float2 gm = *(const float2*)(gamma + c), bt = *(const float2*)(beta + c);
-        const float xa = gm.x != 0.f ? (ya - bt.x) / gm.x : 0.f, xb = gm.y != 0.f ? (yb - bt.y) / gm.y : 0.f;
-        ag[2 * it] += da * xa; ag[2 * it + 1] += db * xb;
-        ab[2 * it] += da; ab[2 * it + 1] += db;
-        const float ga = da * gm.x, gb = db * gm.y;
-        g[2 * it] = ga; g[2 * it + 1] = gb; xh[2 * it] = xa; xh[2 * it + 1] = xb;
-        s1 += ga + gb; s2 += ga * xa + gb * xb;
-      } else {
-        g[2 * it] = da; g[2 * it + 1] = db;
+#pragma unroll
+        for (int i = 0; i < 2 * NIT; ++i) {
+          const float da = g[u][i] * live;
+          const float xa = (xh[u][i] - btr[i]) * igm[i];
+          ag[i] += da * xa; ab[i] += da;
+          const float ga = da * gmr[i];
+          g[u][i] = ga; xh[u][i] = xa;
+          s1[u] += ga; s2[u] += ga * xa;
+        }
       }
     }
     if (do_ln) {
-      const float m1 = wave_sum(s1) / H, m2 = wave_sum(s2) / H, rs = rstd[row];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        g[2 * it] = rs * (g[2 * it] - m1 - xh[2 * it] * m2);
-        g[2 * it + 1] = rs * (g[2 * it + 1] - m1 - xh[2 * it + 1] * m2);
+      for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int u = 0; u < RPI; ++u) { s1[u] += __shfl_xor(s1[u], o, 64); s2[u] += __shfl_xor(s2[u], o, 64); }
+      }
+#pragma unroll
+      for (int u = 0; u < RPI; ++u) {
+        const float m1 = s1[u] / H, m2 = s2[u] / H;
+#pragma unroll
+        for (int i = 0; i < 2 * NIT; ++i) g[u][i] = rs[u] * (g[u][i] - m1 - xh[u][i] * m2);
       }
     }
-    if (dx) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) st2<T>(dx + (long long)row * H + it * 128 + lane * 2, g[2 * it], g[2 * it + 1]);
-    }
-    // table gradients
+    for (int u = 0; u < RPI; ++u) {
+      const int row = base + u;
+      if (row < M) {
+        if (dx) {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) st2<T>(dx + (long long)row * H + it * 128 + lane * 2, g[u][2 * it], g[u][2 * it + 1]);
+        }
+        // table gradients
 #define TAB_GRAD(K, TK, DK, LK, CK)                                                         \
-    if (DK) {                                                                                \
-      if (LK) {                                                                              \
-        float* slot = tacc + (K * 3 + (CK ? 0 : TK.idx[row])) * H;                           \
-        _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                 \
-          const int c = it * 128 + lane * 2;                                                 \
-          atomicAdd(slot + c, g[2 * it]); atomicAdd(slot + c + 1, g[2 * it + 1]);            \
-        }                                                                                    \
-      } else {                                                                               \
-        float* dst = DK + (long long)tab_row(TK, row) * H;                                   \
-        _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                 \
-          const int c = it * 128 + lane * 2;                                                 \
-          atomicAdd(dst + c, g[2 * it]); atomicAdd(dst + c + 1, g[2 * it + 1]);              \
-        }                                                                                    \
-      }                                                                                      \
-    }
-    TAB_GRAD(0, t0, d0, l0, c0)
-    TAB_GRAD(1, t1, d1, l1, c1)
-    TAB_GRAD(2, t2, d2, l2, c2)
+        if (DK) {                                                                            \
+          if (LK) {                                                                          \
+            float* slot = tacc + (K * 3 + (CK ? 0 : TK.idx[row])) * H;                       \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                             \
+              const int c = it * 128 + lane * 2;                                             \
+              atomicAdd(slot + c, g[u][2 * it]); atomicAdd(slot + c + 1, g[u][2 * it + 1]);  \
+            }                                                                                \
+          } else {                                                                           \
+            float* dst = DK + (long long)tab_row(TK, row) * H;                               \
+            _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                             \
+              const int c = it * 128 + lane * 2;                                             \
+              atomicAdd(dst + c, g[u][2 * it]); atomicAdd(dst + c + 1, g[u][2 * it + 1]);    \
+            }                                                                                \
+          }                                                                                  \
+        }
+        TAB_GRAD(0, t0, d0, l0, c0)
+        TAB_GRAD(1, t1, d1, l1, c1)
+        TAB_GRAD(2, t2, d2, l2, c2)
 #undef TAB_GRAD
+      }
+    }
   }
   const bool pg = do_ln && dgamma != nullptr;      // gamma/beta grads here, or by ln_pgrad_kernel (dgamma == nullptr)
   if (pg) {
@@ -588,8 +621,10 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
   if ((small0 && !idx0) || (small1 && !idx1) || (small2 && !idx2)) return MAGIC_ERR_ARG;
   TabRef t0{d0, idx0, mod0, off0}, t1{d1, idx1, mod1, off1}, t2{d2, idx2, mod2, off2};
   // with in-kernel gamma/beta grads every block ends in 2H same-address atomics -> few blocks; without them one row per wave
-  int nb = dgamma ? (M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS) : (M + 3) / 4;
-  const int cap = dgamma ? 384 : 4096;
+  const int rpi = H <= 256 ? 4 : 2;                 // rows per wave per iteration (ln_bwd_kernel::RPI)
+  int nb = (M + 4 * rpi - 1) / (4 * rpi);
+  static const int cap_env = getenv("MAGIC_LNB_CAP") ? atoi(getenv("MAGIC_LNB_CAP")) : 0;
+  const int cap = dgamma ? (cap_env > 0 ? cap_env : 512) : 4096;
   dim3 grid(nb > cap ? cap : nb), block(256);
   size_t shm = (size_t)17 * H * sizeof(float);
   hipStream_t st = (hipStream_t)stream;

@@ -149,6 +149,12 @@ int magic_cast(int to_bf16, long long n, const void* x, void* y, void* stream);
 int magic_add(int dtype, long long n, const void* x, void* y, void* stream);
 int magic_dact(int dtype, int kind, long long n, const void* dy, const void* z, void* dz, void* stream);
 
+/* Pair-grouping: between magic_group_begin() and magic_group_end(stream) up to two calls of magic_gemm / magic_attn_fwd /
+ * magic_attn_bwd / magic_linear_ln / magic_ln_bwd are recorded instead of launched; magic_group_end launches ONE kernel serving
+ * both problems when they are the same kind / dtype / variant (else one kernel each).  Thread-local state. */
+int magic_group_begin(void);
+int magic_group_end(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
 // Limits: head dim 64, Nk <= 128 (forward), Nq, Nk <= 128 bf16 / <= 64 fp32 (backward; LDS).  Longer sequences
 // (RxR, 512 tokens) take the unfused GEMM + softmax path of the engine.
 #include "common.hpp"
+#include "group.hpp"
 
 #define HD 64
 
@@ -82,17 +83,16 @@ struct AttnParams {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bqt, const int h, const int b, unsigned char* smem_raw) {
   typedef typename AT<T>::vec vec;
   constexpr int VE = AT<T>::VE, KSTEP = AT<T>::KSTEP, DS = AT<T>::DS;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int NKP = (p.Nk + 31) / 32 * 32, PS = NKP + AT<T>::PPAD;
   T* sQ = (T*)smem_raw;            // [64][DS]   (re-used to stage O)
   T* sK = sQ + 64 * DS;            // [NKP][DS]
   T* sV = sK + NKP * DS;           // [NKP][DS]
   T* sP = sV + NKP * DS;           // [64][PS]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = bqt * 64;
   const int nq = min(64, p.Nq - q0);
   load_rows<T>(sQ, (const T*)p.q + ((long long)b * p.Nq + q0) * p.ldq + h * HD, p.ldq, nq, 64);
   load_rows<T>(sK, (const T*)p.k + (long long)b * p.Nk * p.ldkv + h * HD, p.ldkv, p.Nk, NKP);
@@ -182,11 +182,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+  attn_fwd_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem_dyn);
+}
+// two problems in one launch: blocks [0, nA) serve problem a, the rest problem b
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_pair_kernel(AttnParams a, AttnParams b, int nA) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+  const bool first = (int)blockIdx.x < nA;
+  const AttnParams& p = first ? a : b;
+  const int local = first ? blockIdx.x : blockIdx.x - nA;
+  const int nqt = (p.Nq + 63) / 64;
+  attn_fwd_body<T>(p, local % nqt, (local / nqt) % p.nh, local / (nqt * p.nh), smem_dyn);
+}
+
+template <typename T>
+__device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, const int b, unsigned char* smem_raw, float* red) {
   typedef typename AT<T>::vec vec;
   constexpr int VE = AT<T>::VE, KSTEP = AT<T>::KSTEP, DS = AT<T>::DS;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ float red[8];
   const int NQP = (p.Nq + 31) / 32 * 32, NKP = (p.Nk + 31) / 32 * 32, PS = NKP + AT<T>::PPAD;
   T* sQ = (T*)smem_raw;             // [NQP][DS]
   T* sdO = sQ + NQP * DS;           // [NQP][DS]
@@ -195,7 +209,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   T* sP = sV + NKP * DS;            // [NQP][PS]
   T* sdS = sP + NQP * PS;           // [NQP][PS]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int h = blockIdx.x, b = blockIdx.y;
   load_rows<T>(sQ, (const T*)p.q + (long long)b * p.Nq * p.ldq + h * HD, p.ldq, p.Nq, NQP);
   load_rows<T>(sdO, (const T*)p.dctx + (long long)b * p.Nq * p.H + h * HD, p.H, p.Nq, NQP);
   load_rows<T>(sK, (const T*)p.k + (long long)b * p.Nk * p.ldkv + h * HD, p.ldkv, p.Nk, NKP);
@@ -313,6 +326,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+  __shared__ float red[8];
+  attn_bwd_body<T>(p, blockIdx.x, blockIdx.y, smem_dyn, red);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_pair_kernel(AttnParams a, AttnParams b, int nA) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+  __shared__ float red[8];
+  const bool first = (int)blockIdx.x < nA;
+  const AttnParams& p = first ? a : b;
+  const int local = first ? blockIdx.x : blockIdx.x - nA;
+  attn_bwd_body<T>(p, local % p.nh, local / p.nh, smem_dyn, red);
+}
+
 static size_t fwd_lds(int dtype, int Nk) {
   const int NKP = (Nk + 31) / 32 * 32;
   if (dtype == DT_BF16) return (size_t)(64 * 72 + 2 * NKP * 72 + 64 * (NKP + 8)) * 2;
@@ -351,16 +380,30 @@ extern "C" int magic_attn_fwd(int dtype, int B, int nh, int Nq, int Nk, const vo
   AttnParams p = {};
   p.q = q; p.k = k; p.v = v; p.P = P; p.ctx = ctx; p.kmask = kmask; p.dist = dist; p.sprel_w = sprel_w; p.sprel_b = sprel_b;
   p.B = B; p.nh = nh; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldkv = ldkv; p.ldp = ldp; p.H = H; p.scale = scale;
-  dim3 grid((Nq + 63) / 64, nh, B), block(256);
-  const size_t shm = fwd_lds(dtype, Nk);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16) {
-    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)attn_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, block, shm, st, p);
-  } else {
-    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, shm, st, p);
+  if (group_record(KIND_ATTN_FWD, dtype, 0, &p, sizeof(p))) return MAGIC_OK;
+  return launch_attn_fwd(dtype, 0, &p, nullptr, (hipStream_t)stream);
+}
+
+template <typename K> static void set_lds(K kern, size_t shm) {
+  if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+}
+
+int launch_attn_fwd(int dtype, int, const void* pa, const void* pb, hipStream_t st) {
+  const AttnParams& a = *(const AttnParams*)pa;
+  dim3 block(256);
+  if (!pb) {
+    dim3 grid((a.Nq + 63) / 64, a.nh, a.B);
+    const size_t shm = fwd_lds(dtype, a.Nk);
+    if (dtype == DT_BF16) { set_lds(attn_fwd_kernel<bf16>, shm); hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, block, shm, st, a); }
+    else { set_lds(attn_fwd_kernel<float>, shm); hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, shm, st, a); }
+    return launch_status();
   }
+  const AttnParams& b = *(const AttnParams*)pb;
+  const int nA = ((a.Nq + 63) / 64) * a.nh * a.B, nB = ((b.Nq + 63) / 64) * b.nh * b.B;
+  const size_t sa = fwd_lds(dtype, a.Nk), sb = fwd_lds(dtype, b.Nk), shm = sa > sb ? sa : sb;
+  dim3 grid(nA + nB);
+  if (dtype == DT_BF16) { set_lds(attn_fwd_pair_kernel<bf16>, shm); hipLaunchKernelGGL(attn_fwd_pair_kernel<bf16>, grid, block, shm, st, a, b, nA); }
+  else { set_lds(attn_fwd_pair_kernel<float>, shm); hipLaunchKernelGGL(attn_fwd_pair_kernel<float>, grid, block, shm, st, a, b, nA); }
   return launch_status();
 }
 
@@ -377,15 +420,25 @@ extern "C" int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const vo
   p.q = q; p.k = k; p.v = v; p.P = (void*)P; p.dist = dist; p.B = B; p.nh = nh; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldkv = ldkv;
   p.ldp = ldp; p.H = H; p.scale = scale; p.dctx = dctx; p.dP_init = dP_init; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddkv = lddkv;
   p.dsprel_w = dsprel_w; p.dsprel_b = dsprel_b;
-  dim3 grid(nh, B), block(256);
-  const size_t shm = bwd_lds(dtype, Nq, Nk);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16) {
-    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)attn_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(attn_bwd_kernel<bf16>, grid, block, shm, st, p);
-  } else {
-    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, shm, st, p);
+  if (group_record(KIND_ATTN_BWD, dtype, 0, &p, sizeof(p))) return MAGIC_OK;
+  return launch_attn_bwd(dtype, 0, &p, nullptr, (hipStream_t)stream);
+}
+
+int launch_attn_bwd(int dtype, int, const void* pa, const void* pb, hipStream_t st) {
+  const AttnParams& a = *(const AttnParams*)pa;
+  dim3 block(256);
+  if (!pb) {
+    dim3 grid(a.nh, a.B);
+    const size_t shm = bwd_lds(dtype, a.Nq, a.Nk);
+    if (dtype == DT_BF16) { set_lds(attn_bwd_kernel<bf16>, shm); hipLaunchKernelGGL(attn_bwd_kernel<bf16>, grid, block, shm, st, a); }
+    else { set_lds(attn_bwd_kernel<float>, shm); hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, shm, st, a); }
+    return launch_status();
   }
+  const AttnParams& b = *(const AttnParams*)pb;
+  const int nA = a.nh * a.B, nB = b.nh * b.B;
+  const size_t sa = bwd_lds(dtype, a.Nq, a.Nk), sb = bwd_lds(dtype, b.Nq, b.Nk), shm = sa > sb ? sa : sb;
+  dim3 grid(nA + nB);
+  if (dtype == DT_BF16) { set_lds(attn_bwd_pair_kernel<bf16>, shm); hipLaunchKernelGGL(attn_bwd_pair_kernel<bf16>, grid, block, shm, st, a, b, nA); }
+  else { set_lds(attn_bwd_pair_kernel<float>, shm); hipLaunchKernelGGL(attn_bwd_pair_kernel<float>, grid, block, shm, st, a, b, nA); }
   return launch_status();
 }

@@ -8,6 +8,7 @@
 // (k contiguous, padded rows) whatever their global orientation, so fragments are plain 16-byte
 // (bf16) / 4-byte (f32) LDS reads; the next tile's global loads are in flight during the MFMAs.
 #include "common.hpp"
+#include "group.hpp"
 
 #define BM 64
 #define BN 64
@@ -20,6 +21,7 @@ struct GemmParams {
   long long sAb, sAh, sBb, sBh, sCb, sCh;
   int nh, splitk, epilogue, c_f32, accumulate;
   float alpha;
+  int batch;      // host-side only (grid z = batch * splitk)
 };
 
 template <typename T> struct TT;
@@ -323,8 +325,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #define GROUP_MAX 8
 struct GroupedParams { GemmParams p[GROUP_MAX]; int start[GROUP_MAX + 1]; int n; };
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_dw_grouped_kernel(GroupedParams gp) {
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupedParams gp) {
   __shared__ __attribute__((aligned(16))) T sA[BM * TT<T>::STRIDE];
   __shared__ __attribute__((aligned(16))) T sB[BN * TT<T>::STRIDE];
   const int id = blockIdx.x;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256) void gemm_dw_grouped_kernel(GroupedParams gp) 
   const GemmParams& p = gp.p[g];
   const int local = id - gp.start[g];
   const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM;
-  gemm_block<T, 2>(p, local % nx, (local / nx) % ny, local / (nx * ny), sA, sB);
+  gemm_block<T, LAYOUT>(p, local % nx, (local / nx) % ny, local / (nx * ny), sA, sB);
 }
 
 extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,
@@ -360,15 +362,40 @@ extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldaux = ldaux; p.ldr = ldr;
   p.sAb = sAb; p.sAh = sAh; p.sBb = sBb; p.sBh = sBh; p.sCb = sCb; p.sCh = sCh;
   p.nh = nh; p.splitk = splitk; p.epilogue = epilogue; p.c_f32 = c_f32; p.accumulate = accumulate; p.alpha = alpha;
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch * splitk), block(256);
-  hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(TY, L) hipLaunchKernelGGL((gemm_kernel<TY, L>), grid, block, 0, st, p)
-  if (dtype == DT_BF16) {
-    if (layout == 0) LAUNCH(bf16, 0); else if (layout == 1) LAUNCH(bf16, 1); else LAUNCH(bf16, 2);
-  } else {
-    if (layout == 0) LAUNCH(float, 0); else if (layout == 1) LAUNCH(float, 1); else LAUNCH(float, 2);
-  }
+  p.batch = batch;
+  if (group_record(KIND_GEMM, dtype, layout, &p, sizeof(p))) return MAGIC_OK;
+  return launch_gemm(dtype, layout, &p, nullptr, (hipStream_t)stream);
+}
+
+static inline int gemm_blocks(const GemmParams& p) { return ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * p.batch * p.splitk; }
+
+int launch_gemm(int dtype, int layout, const void* pa, const void* pb, hipStream_t st) {
+  const GemmParams& a = *(const GemmParams*)pa;
+  dim3 block(256);
+  if (!pb) {
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch * a.splitk);
+#define LAUNCH(TY, L) hipLaunchKernelGGL((gemm_kernel<TY, L>), grid, block, 0, st, a)
+    if (dtype == DT_BF16) {
+      if (layout == 0) LAUNCH(bf16, 0); else if (layout == 1) LAUNCH(bf16, 1); else LAUNCH(bf16, 2);
+    } else {
+      if (layout == 0) LAUNCH(float, 0); else if (layout == 1) LAUNCH(float, 1); else LAUNCH(float, 2);
+    }
 #undef LAUNCH
+    return launch_status();
+  }
+  GroupedParams gp;
+  gp.n = 2; gp.p[0] = a; gp.p[1] = *(const GemmParams*)pb;
+  gp.start[0] = 0; gp.start[1] = gemm_blocks(gp.p[0]);
+  const int total = gp.start[1] + gemm_blocks(gp.p[1]);
+  for (int i = 2; i <= GROUP_MAX; ++i) gp.start[i] = total;
+  dim3 grid(total);
+#define LAUNCHG(TY, L) hipLaunchKernelGGL((gemm_grouped_kernel<TY, L>), grid, block, 0, st, gp)
+  if (dtype == DT_BF16) {
+    if (layout == 0) LAUNCHG(bf16, 0); else if (layout == 1) LAUNCHG(bf16, 1); else LAUNCHG(bf16, 2);
+  } else {
+    if (layout == 0) LAUNCHG(float, 0); else if (layout == 1) LAUNCHG(float, 1); else LAUNCHG(float, 2);
+  }
+#undef LAUNCHG
   return launch_status();
 }
 
@@ -376,22 +403,26 @@ extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N
 // Linear + bias + residual + LayerNorm in one launch (the BertSelfOutput / BertOutput tails: dense -> add -> LayerNorm).
 // A workgroup owns 32 full rows (BN = H), so the row statistics are a cross-wave LDS reduction in the epilogue and the
 // separate LayerNorm launch (and its pass over [M,H]) disappears.  4 waves side by side, each 32 rows x H/4 columns.
-template <typename T, int HT>      // HT = H / 64 column tiles of 16 per wave (H = 64*HT... per wave H/4 = 16*HT columns)
-__global__ __launch_bounds__(256) void linear_ln_kernel(int M, int K, const T* __restrict__ X, int lda, const T* __restrict__ W, int ldb,
-                                                        const float* __restrict__ bias, const T* __restrict__ R, int ldr,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                        T* __restrict__ out, float* __restrict__ rstd_out) {
+struct LlnParams {
+  int M, K; const void* X; int lda; const void* W; int ldb; const float* bias; const void* R; int ldr;
+  const float* gamma; const float* beta; float eps; void* out; float* rstd_out;
+};
+
+template <typename T, int HT>      // HT = H / 64 column tiles of 16 per wave (per wave H/4 = 16*HT columns)
+__device__ __forceinline__ void linear_ln_body(const LlnParams& pp, const int bid, unsigned char* lds_raw) {
+  const int M = pp.M, K = pp.K, lda = pp.lda, ldb = pp.ldb, ldr = pp.ldr;
+  const T* __restrict__ X = (const T*)pp.X; const T* __restrict__ W = (const T*)pp.W; const T* __restrict__ R = (const T*)pp.R;
+  const float* __restrict__ bias = pp.bias; const float* __restrict__ gamma = pp.gamma; const float* __restrict__ beta = pp.beta;
+  const float eps = pp.eps; T* __restrict__ out = (T*)pp.out; float* __restrict__ rstd_out = pp.rstd_out;
   typedef typename TT<T>::vec vec;
   constexpr int VE = TT<T>::VE, BK = TT<T>::BK, STRIDE = TT<T>::STRIDE;
   constexpr int H = 64 * HT, WC = 16 * HT;          // columns per wave
   constexpr int KS = (sizeof(T) == 2) ? 2 : 8;      // MFMA k-steps per BK tile
-  constexpr int KW = (sizeof(T) == 2) ? 32 : 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   T* sA = (T*)lds_raw;                 // [32][STRIDE]
   T* sB = sA + 32 * STRIDE;            // [H][STRIDE]
   float* red = (float*)(sB + H * STRIDE);   // [4][32]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int m0 = blockIdx.x * 32;
+  const int m0 = bid * 32;
   f32x4 acc[2][HT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -451,7 +482,6 @@ __global__ __launch_bounds__(256) void linear_ln_kernel(int M, int K, const T* _
         }
       }
     }
-    (void)KW;
     __syncthreads();
   }
   // ---- epilogue: v = acc + bias + residual ; LayerNorm over the full row (cross-wave) ; store
@@ -532,6 +562,18 @@ __global__ __launch_bounds__(256) void linear_ln_kernel(int M, int K, const T* _
     }
 }
 
+template <typename T, int HT>
+__global__ __launch_bounds__(256) void linear_ln_kernel(LlnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+  linear_ln_body<T, HT>(p, blockIdx.x, lds_dyn);
+}
+template <typename T, int HT>
+__global__ __launch_bounds__(256) void linear_ln_pair_kernel(LlnParams a, LlnParams b, int nA) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+  if ((int)blockIdx.x < nA) linear_ln_body<T, HT>(a, blockIdx.x, lds_dyn);
+  else linear_ln_body<T, HT>(b, blockIdx.x - nA, lds_dyn);
+}
+
 extern "C" int magic_linear_ln(int dtype, int M, int H, int K, const void* x, int lda, const void* W, int ldb, const float* bias,
                                const void* residual, int ldr, const float* gamma, const float* beta, float eps,
                                void* out, float* rstd, void* stream) {
@@ -540,18 +582,31 @@ extern "C" int magic_linear_ln(int dtype, int M, int H, int K, const void* x, in
   const int ve = dtype == DT_BF16 ? 8 : 4;
   if (lda % ve || ldb % ve || ((uintptr_t)x & 15) || ((uintptr_t)W & 15)) return MAGIC_ERR_ARG;
   if (H != 128 && H != 256 && H != 384) return MAGIC_ERR_UNSUPPORTED;
-  dim3 grid((M + 31) / 32), block(256);
-  hipStream_t st = (hipStream_t)stream;
-#define LLN(TY, HT)                                                                                                       \
+  LlnParams p{M, K, x, lda, W, ldb, bias, residual, ldr, gamma, beta, eps, out, rstd};
+  const int ht = H / 64;
+  if (group_record(KIND_LLN, dtype, ht, &p, sizeof(p))) return MAGIC_OK;
+  return launch_lln(dtype, ht, &p, nullptr, (hipStream_t)stream);
+}
+
+int launch_lln(int dtype, int ht, const void* pa, const void* pb, hipStream_t st) {
+  const LlnParams& a = *(const LlnParams*)pa;
+  dim3 block(256);
+  const int nA = (a.M + 31) / 32;
+#define LLN1(TY, HT)                                                                                                      \
   do {                                                                                                                    \
     const size_t shm = (size_t)(32 + 64 * HT) * TT<TY>::STRIDE * sizeof(TY) + 128 * sizeof(float);                        \
-    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)linear_ln_kernel<TY, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-    hipLaunchKernelGGL((linear_ln_kernel<TY, HT>), grid, block, shm, st, M, K, (const TY*)x, lda, (const TY*)W, ldb, bias,  \
-                       (const TY*)residual, ldr, gamma, beta, eps, (TY*)out, rstd);                                       \
+    if (!pb) {                                                                                                            \
+      if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)linear_ln_kernel<TY, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+      hipLaunchKernelGGL((linear_ln_kernel<TY, HT>), dim3(nA), block, shm, st, a);                                        \
+    } else {                                                                                                              \
+      const LlnParams& b = *(const LlnParams*)pb;                                                                         \
+      if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)linear_ln_pair_kernel<TY, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+      hipLaunchKernelGGL((linear_ln_pair_kernel<TY, HT>), dim3(nA + (b.M + 31) / 32), block, shm, st, a, b, nA);          \
+    }                                                                                                                     \
   } while (0)
-  if (dtype == DT_BF16) { if (H == 128) LLN(bf16, 2); else if (H == 256) LLN(bf16, 4); else LLN(bf16, 6); }
-  else { if (H == 128) LLN(float, 2); else if (H == 256) LLN(float, 4); else LLN(float, 6); }
-#undef LLN
+  if (dtype == DT_BF16) { if (ht == 2) LLN1(bf16, 2); else if (ht == 4) LLN1(bf16, 4); else LLN1(bf16, 6); }
+  else { if (ht == 2) LLN1(float, 2); else if (ht == 4) LLN1(float, 4); else LLN1(float, 6); }
+#undef LLN1
   return launch_status();
 }
 
@@ -573,14 +628,14 @@ extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, v
     // TN: A = dY stored [Kred = M][Mout = N], B = X stored [Kred = M][Nout = K], C = dW [N, K]
     p.A = d[i].dY; p.B = d[i].X; p.C = d[i].dW; p.bias_grad = d[i].db;
     p.M = d[i].N; p.N = d[i].K; p.K = d[i].M; p.lda = d[i].lda; p.ldb = d[i].ldb; p.ldc = d[i].ldc;
-    p.nh = 1; p.splitk = d[i].splitk; p.epilogue = 0; p.c_f32 = 1; p.accumulate = 1; p.alpha = 1.f;
+    p.nh = 1; p.batch = 1; p.splitk = d[i].splitk; p.epilogue = 0; p.c_f32 = 1; p.accumulate = 1; p.alpha = 1.f;
     gp.start[i] = total;
     total += ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * p.splitk;
   }
   for (int i = n; i <= GROUP_MAX; ++i) gp.start[i] = total;
   dim3 grid(total), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16) hipLaunchKernelGGL(gemm_dw_grouped_kernel<bf16>, grid, block, 0, st, gp);
-  else hipLaunchKernelGGL(gemm_dw_grouped_kernel<float>, grid, block, 0, st, gp);
+  if (dtype == DT_BF16) hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2>), grid, block, 0, st, gp);
+  else hipLaunchKernelGGL((gemm_grouped_kernel<float, 2>), grid, block, 0, st, gp);
   return launch_status();
 }

@@ -3,6 +3,7 @@
 // per step instead of ~8 torch kernels per parameter tensor (pretrain_src/optim/adamw.py:53-112), and the
 // DDP all-reduce is a few large contiguous chunks.
 #include "common.hpp"
+#include "group.hpp"
 
 // sum of squares -> out[0] (atomic, block-reduced); 16-byte loads
 __global__ __launch_bounds__(256) void sumsq_kernel(long long n, const float* g, float* out) {
@@ -154,4 +155,45 @@ extern "C" int magic_sched_step(int* step, float lr0, int warmup, int total, flo
   if (!step || !lr_ss || warmup <= 0 || total <= warmup) return MAGIC_ERR_ARG;
   hipLaunchKernelGGL(sched_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, lr0, warmup, total, b1, b2, lr_ss);
   return launch_status();
+}
+
+// ---- pair-grouping of launches (group.hpp) ---------------------------------------------------------------------------
+GroupState& group_state() {
+  static thread_local GroupState g = {};
+  return g;
+}
+
+extern "C" int magic_group_begin(void) {
+  GroupState& g = group_state();
+  if (g.active) return MAGIC_ERR_ARG;
+  g.active = true; g.n = 0;
+  return MAGIC_OK;
+}
+
+static int launch_one(const GroupRec& r, const GroupRec* other, hipStream_t st) {
+  const void* pb = other ? (const void*)other->blob : nullptr;
+  switch (r.kind) {
+    case KIND_GEMM: return launch_gemm(r.dtype, r.variant, r.blob, pb, st);
+    case KIND_ATTN_FWD: return launch_attn_fwd(r.dtype, r.variant, r.blob, pb, st);
+    case KIND_ATTN_BWD: return launch_attn_bwd(r.dtype, r.variant, r.blob, pb, st);
+    case KIND_LLN: return launch_lln(r.dtype, r.variant, r.blob, pb, st);
+    case KIND_LNB: return launch_lnb(r.dtype, r.variant, r.blob, pb, st);
+    default: return MAGIC_ERR_ARG;
+  }
+}
+
+// launches what was recorded since magic_group_begin(): one kernel for two compatible records, else one kernel each
+extern "C" int magic_group_end(void* stream) {
+  GroupState& g = group_state();
+  if (!g.active) return MAGIC_ERR_ARG;
+  g.active = false;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = MAGIC_OK;
+  if (g.n == 2 && g.rec[0].kind == g.rec[1].kind && g.rec[0].dtype == g.rec[1].dtype && g.rec[0].variant == g.rec[1].variant) {
+    rc = launch_one(g.rec[0], &g.rec[1], st);
+  } else {
+    for (int i = 0; i < g.n && rc == MAGIC_OK; ++i) rc = launch_one(g.rec[i], nullptr, st);
+  }
+  g.n = 0;
+  return rc;
 }

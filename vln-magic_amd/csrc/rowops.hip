@@ -4,6 +4,7 @@
 // wave-shuffle reductions; parameter gradients are reduced per block (registers -> LDS) before a
 // single fp32 atomic per element per block.
 #include "common.hpp"
+#include "group.hpp"
 #include <cstdlib>
 
 #define MAXIT 6   // H = 128*NIT, NIT in {1,2,3,6}: each lane owns elements {it*128 + lane*2, +1}
@@ -78,13 +79,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, const T* in0, const 
 //   const-row / tiny (<=3 rows, `small`) tables: LDS atomics into per-block slots -> one global atomic per element per block;
 //   indexed tables (word / position / step embeddings): one global atomic row per input row.
 #define LNB_ROWS 4   // rows per wave
+struct LnbParams {
+  int M; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd; void* dx; float* dgamma; float* dbeta;
+  TabRef t0; float* d0; int small0; TabRef t1; float* d1; int small1; TabRef t2; float* d2; int small2; int do_ln;
+};
+
 template <typename T, int NIT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(int M, const T* dy, const T* y, const float* gamma, const float* beta,
-                                                     const float* rstd, T* dx, float* dgamma, float* dbeta,
-                                                     TabRef t0, float* d0, int small0, TabRef t1, float* d1, int small1,
-                                                     TabRef t2, float* d2, int small2, int do_ln) {
-  constexpr int H = NIT * 128;
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][4 waves][H] gamma/beta partials | [9][H] table slots
+__device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, const int nblk, float* red) {
+  const int M = pp.M, do_ln = pp.do_ln, small0 = pp.small0, small1 = pp.small1, small2 = pp.small2;
+  const T* dy = (const T*)pp.dy; const T* y = (const T*)pp.y; T* dx = (T*)pp.dx;
+  const float* gamma = pp.gamma; const float* beta = pp.beta; const float* rstd = pp.rstd;
+  float* dgamma = pp.dgamma; float* dbeta = pp.dbeta; float* d0 = pp.d0; float* d1 = pp.d1; float* d2 = pp.d2;
+  const TabRef t0 = pp.t0, t1 = pp.t1, t2 = pp.t2;
+  constexpr int H = NIT * 128;     // red: [2][4 waves][H] gamma/beta partials | [9][H] table slots
   float* tacc = red + 8 * H;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool c0 = d0 && !t0.idx && !t0.mod, c1 = d1 && !t1.idx && !t1.mod, c2 = d2 && !t2.idx && !t2.mod;
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, const T* dy, const T
       igm[2 * it] = gm.x != 0.f ? 1.f / gm.x : 0.f; igm[2 * it + 1] = gm.y != 0.f ? 1.f / gm.y : 0.f;
     }
   }
-  for (int base = (blockIdx.x * 4 + wid) * RPI; base < M; base += gridDim.x * 4 * RPI) {
+  for (int base = (bid * 4 + wid) * RPI; base < M; base += nblk * 4 * RPI) {
     float g[RPI][2 * NIT], xh[RPI][2 * NIT];
     float s1[RPI], s2[RPI], rs[RPI];
 #pragma unroll
@@ -217,6 +224,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, const T* dy, const T
     TAB_FLUSH(2, t2, d2, l2, c2)
 #undef TAB_FLUSH
   }
+}
+
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnbParams p) {
+  extern __shared__ __attribute__((aligned(16))) float red_dyn[];
+  ln_bwd_body<T, NIT>(p, blockIdx.x, gridDim.x, red_dyn);
+}
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_bwd_pair_kernel(LnbParams a, LnbParams b, int nA) {
+  extern __shared__ __attribute__((aligned(16))) float red_dyn[];
+  if ((int)blockIdx.x < nA) ln_bwd_body<T, NIT>(a, blockIdx.x, nA, red_dyn);
+  else ln_bwd_body<T, NIT>(b, blockIdx.x - nA, gridDim.x - nA, red_dyn);
 }
 
 // gamma/beta gradients of a LayerNorm as a separate column reduction: dgamma[c] += sum_m dy*xhat, dbeta[c] += sum_m dy
@@ -615,22 +634,42 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
                             const int* idx1, int mod1, int off1, float* d1, int small1,
                             const int* idx2, int mod2, int off2, float* d2, int small2,
                             int do_ln, void* stream) {
-  if (M <= 0 || !okH(H) || !dy) return MAGIC_ERR_ARG;
+  if (M <= 0 || !okH(H) || !dy || (H != 128 && H != 256 && H != 384 && H != 768)) return MAGIC_ERR_ARG;
   if (do_ln && (!y || !gamma || !beta || !rstd)) return MAGIC_ERR_ARG;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return MAGIC_ERR_ARG;
   if ((small0 && !idx0) || (small1 && !idx1) || (small2 && !idx2)) return MAGIC_ERR_ARG;
-  TabRef t0{d0, idx0, mod0, off0}, t1{d1, idx1, mod1, off1}, t2{d2, idx2, mod2, off2};
-  // with in-kernel gamma/beta grads every block ends in 2H same-address atomics -> few blocks; without them one row per wave
-  const int rpi = H <= 256 ? 4 : 2;                 // rows per wave per iteration (ln_bwd_kernel::RPI)
-  int nb = (M + 4 * rpi - 1) / (4 * rpi);
-  static const int cap_env = getenv("MAGIC_LNB_CAP") ? atoi(getenv("MAGIC_LNB_CAP")) : 0;
-  const int cap = dgamma ? (cap_env > 0 ? cap_env : 512) : 4096;
-  dim3 grid(nb > cap ? cap : nb), block(256);
-  size_t shm = (size_t)17 * H * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
-#define LNB(TY, NIT) hipLaunchKernelGGL((ln_bwd_kernel<TY, NIT>), grid, block, shm, st, M, (const TY*)dy, (const TY*)y, gamma, beta, rstd, (TY*)dx, dgamma, dbeta, t0, d0, small0, t1, d1, small1, t2, d2, small2, do_ln)
-  DISPATCH_NIT(dtype, H, LNB);
-#undef LNB
+  LnbParams p{M, dy, y, gamma, beta, rstd, dx, dgamma, dbeta, TabRef{d0, idx0, mod0, off0}, d0, small0, TabRef{d1, idx1, mod1, off1}, d1, small1,
+              TabRef{d2, idx2, mod2, off2}, d2, small2, do_ln};
+  const int nit = H / 128;
+  if (group_record(KIND_LNB, dtype, nit, &p, sizeof(p))) return MAGIC_OK;
+  return launch_lnb(dtype, nit, &p, nullptr, (hipStream_t)stream);
+}
+
+static inline int lnb_blocks(const LnbParams& p, int nit) {
+  const int rpi = nit <= 2 ? 4 : 2;                 // rows per wave per iteration (ln_bwd_body::RPI)
+  const int nb = (p.M + 4 * rpi - 1) / (4 * rpi);
+  // with in-kernel gamma/beta grads every block ends in 2H same-address atomics -> cap the grid; without them one row group per wave
+  const int cap = p.dgamma ? 512 : 4096;
+  return nb > cap ? cap : nb;
+}
+
+int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t st) {
+  const LnbParams& a = *(const LnbParams*)pa;
+  const int H = nit * 128;
+  const size_t shm = (size_t)17 * H * sizeof(float);
+  dim3 block(256);
+  const int nA = lnb_blocks(a, nit);
+#define LNB1(TY, NIT)                                                                                   \
+  do {                                                                                                  \
+    if (!pb) hipLaunchKernelGGL((ln_bwd_kernel<TY, NIT>), dim3(nA), block, shm, st, a);                 \
+    else {                                                                                              \
+      const LnbParams& b = *(const LnbParams*)pb;                                                       \
+      hipLaunchKernelGGL((ln_bwd_pair_kernel<TY, NIT>), dim3(nA + lnb_blocks(b, nit)), block, shm, st, a, b, nA); \
+    }                                                                                                   \
+  } while (0)
+  if (dtype == DT_BF16) { if (nit == 1) LNB1(bf16, 1); else if (nit == 2) LNB1(bf16, 2); else if (nit == 3) LNB1(bf16, 3); else LNB1(bf16, 6); }
+  else { if (nit == 1) LNB1(float, 1); else if (nit == 2) LNB1(float, 2); else if (nit == 3) LNB1(float, 3); else LNB1(float, 6); }
+#undef LNB1
   return launch_status();
 }
 

@@ -5,6 +5,7 @@ call raises.  Tensors are passed as raw device pointers; the stream is torch's c
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -50,6 +51,8 @@ SIGNATURES = {
     "magic_cast": [i32, i64, vp, vp, vp],
     "magic_add": [i32, i64, vp, vp, vp],
     "magic_dact": [i32, i32, i64, vp, vp, vp, vp],
+    "magic_group_begin": [],
+    "magic_group_end": [vp],
 }
 
 
@@ -95,9 +98,11 @@ def P(t):
 
 
 PROFILE = {"on": False, "events": []}     # bench.py: per-launch HIP-event timing on the launch stream
+PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_ln_bwd"}
+_tls = threading.local()
 
 
-def call(name, *args):
+def _raw_call(name, args):
     if PROFILE["on"]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -108,6 +113,103 @@ def call(name, *args):
         rc = getattr(load(), name)(*args)
     if rc != 0:
         raise MagicHipError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+
+def call(name, *args):
+    ls = getattr(_tls, "lockstep", None)
+    if ls is not None and name in PAIRABLE:
+        return ls.submit(_tls.idx, name, args)
+    _raw_call(name, args)
+
+
+class Lockstep:
+    """Run two independent, same-structured segments (e.g. the global and the local co-attention encoder) on two host
+    threads and issue their groupable kernel calls PAIRWISE: when both threads have arrived at a groupable call, the second
+    arriver records both through magic_group_begin/…/magic_group_end, which launches ONE kernel serving both problems.
+    Non-groupable calls launch immediately.  If one segment finishes first (or raises) the other simply continues alone."""
+
+    def __init__(self):
+        self.cv = threading.Condition()
+        self.pending = [None, None]
+        self.done = [False, False]
+        self.gen = 0
+        self.pairs = 0
+
+    def submit(self, idx, name, args):
+        other = 1 - idx
+        with self.cv:
+            if self.pending[other] is not None:                  # partner is waiting: launch both as one group
+                oname, oargs = self.pending[other]
+                first, second = ((oname, oargs), (name, args)) if other == 0 else ((name, args), (oname, oargs))
+                lib = load()
+                if lib.magic_group_begin() != 0:
+                    raise MagicHipError("magic_group_begin failed (nested grouping?)")
+                try:
+                    for n_, a_ in (first, second):
+                        rc = getattr(lib, n_)(*a_)
+                        if rc != 0:
+                            raise MagicHipError(f"{n_} failed while recording a group: {_ERR.get(rc, rc)}")
+                finally:
+                    rc = lib.magic_group_end(stream())
+                if rc != 0:
+                    raise MagicHipError(f"magic_group_end failed: {_ERR.get(rc, rc)}")
+                self.pairs += 1
+                self.pending[other] = None
+                self.gen += 1
+                self.cv.notify_all()
+                return
+            if self.done[other]:
+                _raw_call(name, args)
+                return
+            self.pending[idx] = (name, args)
+            gen = self.gen
+            while self.gen == gen and not self.done[other]:
+                self.cv.wait()
+            if self.pending[idx] is not None:                    # partner finished without pairing: launch alone
+                self.pending[idx] = None
+                _raw_call(name, args)
+
+    def finish(self, idx):
+        with self.cv:
+            self.done[idx] = True
+            self.cv.notify_all()
+
+
+def lockstep(fn_a, fn_b):
+    """returns (fn_a(), fn_b()) with their groupable launches paired (see Lockstep).  fn_b runs on a helper thread bound to
+    the caller's device and current stream."""
+    if getattr(_tls, "lockstep", None) is not None:              # no nesting: run sequentially inside an outer lockstep
+        return fn_a(), fn_b()
+    ls = Lockstep()
+    cur = torch.cuda.current_stream()
+    dev = torch.cuda.current_device()
+    grad = torch.is_grad_enabled()
+    box = {}
+
+    def worker():
+        try:
+            torch.cuda.set_device(dev)
+            _tls.lockstep, _tls.idx = ls, 1
+            with torch.cuda.stream(cur), torch.set_grad_enabled(grad):
+                box["b"] = fn_b()
+        except BaseException as e:     # noqa: BLE001 - re-raised on the caller's thread
+            box["err"] = e
+        finally:
+            _tls.lockstep = None
+            ls.finish(1)
+
+    t = threading.Thread(target=worker, name="magic-lockstep")
+    t.start()
+    _tls.lockstep, _tls.idx = ls, 0
+    try:
+        a = fn_a()
+    finally:
+        _tls.lockstep = None
+        ls.finish(0)
+        t.join()
+    if "err" in box:
+        raise box["err"]
+    return a, box["b"]
 
 
 def dt(dtype):

@@ -19,6 +19,7 @@ from .engine import Ctx, MagicNet, cls_specs, rup, trunk_specs
 from .params import ParamStore
 from .plan import build_plan
 
+LOCKSTEP = not os.environ.get("MAGIC_NO_LOCKSTEP")
 KD_SLOTS = ("txt_emb_loss", "txt_attn_loss", "img_emb_loss", "avg_img_emb_loss", "img_attn_loss",
             "global_emb_loss", "global_attn_loss", "local_emb_loss", "local_attn_loss", "predict_loss")
 
@@ -79,6 +80,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
 
     def _par(self, fn_main, fn_aux):
         """run two independent segments concurrently: fn_aux on this model's auxiliary stream, fn_main on the current one"""
+        if LOCKSTEP and self.device_.type == "cuda":
+            from . import lib as L
+            return L.lockstep(fn_main, fn_aux)      # one stream, paired launches (half the kernels)
         if self._aux is None:
             return fn_main(), fn_aux()
         cur = torch.cuda.current_stream()

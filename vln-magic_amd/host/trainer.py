@@ -177,7 +177,7 @@ class PretrainStep:
         data parallelism the graph ends after backward and the all-reduce + optimizer run eagerly after replay."""
         full = self.sync.world == 1
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="relaxed"):     # helper threads launch into the capture (lib.lockstep)
             out = self._fwd_bwd(batch, task, rw, plan)
             if full:
                 self._optimize()

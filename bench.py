@@ -202,15 +202,21 @@ def main():
         gemm_n = sum(c for k, (t, c) in by.items() if k.startswith("magic_gemm"))
         all_ms = sum(t for t, c in by.values())
         flops = O.FLOPS["total"]
-        ach = flops / (gemm_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_kernel<bf16|f32, NT|NN|TN> (all dense contractions of the step)",
+        # The instrumented pass launches eagerly with an event pair per launch, so it is host-bound and every duration is
+        # inflated by launch gaps; the product path replays a HIP graph.  The GEMM family's SHARE of kernel time is taken
+        # from the instrumented pass and applied to the graph-replay step time measured above.
+        share = gemm_ms / all_ms
+        gemm_ms_step = share * (dt / a.steps * 1e3) if a.mode == "graph" else gemm_ms / nprof
+        ach = (flops / nprof) / (gemm_ms_step * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_kernel / gemm_grouped_kernel <bf16, NT|NN|TN> (every dense contraction of the step)",
                 "achieved": round(ach, 3), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5),
                 "traffic": pmc_traffic(),
                 "detail": {"algorithmic_gflop_per_step": round(flops / nprof / 1e9, 2), "gemm_launches_per_step": gemm_n // nprof,
-                           "avg_gemm_launch_us": round(gemm_ms / max(gemm_n, 1) * 1e3, 2),
-                           "gemm_ms_per_step": round(gemm_ms / nprof, 3), "all_kernels_ms_per_step": round(all_ms / nprof, 3),
+                           "gemm_share_of_kernel_time": round(share, 4), "gemm_ms_per_step": round(gemm_ms_step, 3),
+                           "avg_gemm_launch_us": round(gemm_ms_step / max(gemm_n / nprof, 1) * 1e3, 2),
+                           "instrumented_pass_all_kernels_ms_per_step": round(all_ms / nprof, 3),
                            "launches_per_step": sum(c for t, c in by.values()) // nprof,
-                           "top_kernels_ms_per_step": {k: round(t / nprof, 3) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]}}}
+                           "top_kernels_share": {k: round(t / all_ms, 4) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]}}}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

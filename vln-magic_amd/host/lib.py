@@ -142,6 +142,10 @@ class Lockstep:
                 oname, oargs = self.pending[other]
                 first, second = ((oname, oargs), (name, args)) if other == 0 else ((name, args), (oname, oargs))
                 lib = load()
+                ev = None
+                if PROFILE["on"]:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
                 if lib.magic_group_begin() != 0:
                     raise MagicHipError("magic_group_begin failed (nested grouping?)")
                 try:
@@ -153,6 +157,10 @@ class Lockstep:
                     rc = lib.magic_group_end(stream())
                 if rc != 0:
                     raise MagicHipError(f"magic_group_end failed: {_ERR.get(rc, rc)}")
+                if ev is not None:
+                    ev[1].record()
+                    same = first[0] == second[0]
+                    PROFILE["events"].append((first[0] + ("+pair" if same else "+" + second[0]), first[1][1] if first[0] == "magic_gemm" else -1, ev[0], ev[1]))
                 self.pairs += 1
                 self.pending[other] = None
                 self.gen += 1

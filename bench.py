@@ -184,7 +184,7 @@ def main():
         traj = float(tr.item())
 
     roof = None
-    if rank == 0 and not a.no_profile:
+    if not a.no_profile:      # every rank runs it (the steps contain the gradient all-reduce); rank 0 reports
         # instrumented pass: HIP events around every launch (on the launch stream), algorithmic FLOPs from true ragged sizes
         nprof = min(len(pool), 6)
         O.FLOPS.update(total=0.0, enabled=True)
@@ -199,6 +199,7 @@ def main():
             t, c = by.get(k, (0.0, 0))
             by[k] = (t + e0.elapsed_time(e1), c + 1)
         gemm_ms = sum(t for k, (t, c) in by.items() if k.startswith("magic_gemm"))
+        gemm_ms = max(gemm_ms, 1e-9)
         gemm_n = sum(c for k, (t, c) in by.items() if k.startswith("magic_gemm"))
         all_ms = sum(t for t, c in by.values())
         flops = O.FLOPS["total"]

@@ -53,3 +53,27 @@ def test_graph_replay_matches_eager_steps(dtype):
         assert abs(a - b) <= tol["atol"] + tol["rtol"] * abs(a), (le, lg)
     ptol = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=5e-2, atol=2e-3)
     assert torch.allclose(pe, pg, **ptol), f"params differ: max {(pe - pg).abs().max().item():.3e}"
+
+
+def test_split_graph_path_used_under_data_parallelism(monkeypatch):
+    """world_size > 1 captures forward+backward only and runs all-reduce + optimizer eagerly after each replay; force that
+    split on one GPU and check it reproduces the full-graph result."""
+    tasks = ["sap", "mlm"]
+    batches = [synth.make_batch(t, batch_size=4, seed=41, step=i, vocab=600, min_len=8, max_len=15, min_steps=2, max_steps=3)
+               for i, t in enumerate(tasks)]
+    rw = torch.tensor(RW, device=DEV)
+    res = {}
+    for split in (False, True):
+        if split:
+            monkeypatch.setenv("MAGIC_FORCE_SPLIT_GRAPH", "1")
+        _, _, g_t, g_s = build(torch.float32)
+        g_s.keep_mlm_logits = False
+        tr = PretrainStep(g_s, g_t, lr=1e-3, warmup_steps=2, num_train_steps=10)
+        dev_batches = [(t, synth.batch_to(b, DEV), build_plan(b, t, DEV)) for t, b in zip(tasks, batches)]
+        graphs = [tr.capture(b, t, plan, rw=rw) for t, b, plan in dev_batches]
+        assert all(cs.full == (not split) for cs in graphs)
+        for cs in graphs + graphs:
+            tr.replay(cs)
+        torch.cuda.synchronize()
+        res[split] = g_s.store.flat.clone()
+    assert torch.allclose(res[False], res[True], rtol=1e-3, atol=2e-5)

@@ -51,7 +51,18 @@ def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=25.0):
     ncores = max(1, min(16, avail))       # many-thread oversubscription of these small ops is pathological (measured)
     torch.set_num_threads(ncores)
     torch.manual_seed(0)
-    teacher, student = R.RefPretrainModel(tcfg).eval(), R.RefPretrainModel(scfg).eval()   # dropout off
+    teacher, student = R.RefPretrainModel(tcfg).eval(), R.RefPretrainModel(scfg).eval()
+    pdrop = float(getattr(scfg, "hidden_dropout_prob", 0.0))
+    teacher_fwd = teacher
+    if pdrop > 0:       # same work as the GPU step: the student's dropout modules are live (the frozen teacher's are not)
+        def student_fwd(*args, **kw):
+            R.DROPOUT = lambda site, x: torch.nn.functional.dropout(x, pdrop)
+            try:
+                return student(*args, **kw)
+            finally:
+                R.DROPOUT = None
+    else:
+        student_fwd = student
     params = [p for p in student.parameters()]
     wds = [0.0 if is_no_decay(n) else 0.01 for n, _ in student.named_parameters()]
     state = optim_ref.adamw_init([p.data for p in params])
@@ -62,10 +73,10 @@ def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=25.0):
         batch = synth.make_batch(task, batch_size=batch_size, seed=4321, step=i)
         t0 = time.perf_counter()
         with torch.no_grad():
-            t_out = teacher(batch, task)["outputs"]
+            t_out = teacher_fwd(batch, task)["outputs"]
         for p in params:
             p.grad = None
-        out = student(batch, task, teacher_outputs=t_out, rw=rw)
+        out = student_fwd(batch, task, teacher_outputs=t_out, rw=rw)
         out["loss"].backward()
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
         optim_ref.clip_grad_norm(grads, 5.0)
@@ -81,7 +92,7 @@ def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=25.0):
             break
     return {"value": round(traj / t_total, 2), "unit": "trajectory-steps/sec", "cores": ncores, "kind": "port",
             "sample": f"{steps_done} optimizer steps ({'+'.join(names)}) of the same B={batch_size} MAGIC-S+teacher workload, "
-                      f"fp32 torch CPU oracle, {t_total / max(steps_done, 1) * 1e3:.0f} ms/step"}
+                      f"fp32 torch CPU oracle, dropout {pdrop}, {t_total / max(steps_done, 1) * 1e3:.0f} ms/step"}
 
 
 def pmc_traffic():
@@ -102,6 +113,7 @@ def main():
     ap.add_argument("--batch", type=int, default=48)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--pool", type=int, default=12, help="distinct pre-generated batches (cycled)")
+    ap.add_argument("--dropout", type=float, default=0.1, help="hidden/attention dropout of the student (reference recipe: 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"], help="graph: replay one captured HIP graph per step")
@@ -117,8 +129,9 @@ def main():
     L.load()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
-    tcfg = make_config(256, role="teacher")                                   # teacher_* of r2r_magic_model_config.json:33-37
-    scfg = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL)  # MAGIC-S: student_* :39-43
+    dk = dict(hidden_dropout_prob=a.dropout, attention_probs_dropout_prob=a.dropout)   # r2r_magic_model_config.json:2-3
+    tcfg = make_config(256, role="teacher", **dk)                                   # teacher_* of r2r_magic_model_config.json:33-37
+    scfg = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL, **dk)  # MAGIC-S: student_* :39-43
     teacher = GlocalTextPathCMTPreTraining(tcfg, device=dev, compute_dtype=dtype, seed=0)
     student = GlocalTextPathCMTPreTraining(scfg, device=dev, compute_dtype=dtype, seed=1)
     if world > 1:   # DDP ctor semantics: rank-0 parameters broadcast once (utils/misc.py:62-63)
@@ -229,7 +242,8 @@ def main():
                 "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": a.dtype, "data": "synthetic", "launch": a.mode,
                 "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "
-                                       "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip",
+                                       "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip, student in train() mode",
+                           "dropout": a.dropout,
                            "global_batch": a.batch * world, "per_gpu_batch": a.batch, "views": 36, "feat_dim": 768, "max_tokens": 80,
                            "parallelism": f"dp{world}", "samples_per_sec": round(a.batch * world * a.steps / dt, 1)},
                 "roofline": roof, "cpu_baseline": cpu}

@@ -48,7 +48,16 @@ int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, void* stream
  * H in {128, 256, 384} (a workgroup owns 32 full rows), otherwise MAGIC_ERR_UNSUPPORTED -> magic_gemm + magic_ln_fwd. */
 int magic_linear_ln(int dtype, int M, int H, int K, const void* x, int lda, const void* W, int ldb, const float* bias,
                     const void* residual, int ldr, const float* gamma, const float* beta, float eps,
-                    void* out, float* rstd, void* stream);
+                    void* out, float* rstd, const void* drop_seed, float drop_p, unsigned drop_site, void* stream);
+
+/* Dropout (hidden_dropout_prob / attention_probs_dropout_prob of r2r_magic_model_config.json:2-3,6; active under
+ * model.train(), train_r2r_magic.py:358) is counter-based: keep(seed[0..1], site, logical element index) is recomputed by
+ * the backward kernels, no mask is stored.  `drop_seed` = 2 x uint32 in DEVICE memory (fresh per step, so a replayed HIP
+ * graph draws new masks), `drop_p` in [0,1) (0 = off, seed may be NULL), `site` = id of the dropout module (0 = this
+ * position is not dropped).  magic_dropout applies the same mask standalone: out = in * keep / (1-p), rows x cols logical,
+ * row pitch ld (the Nk > 128 attention fallback, and the mask export the parity tests feed to the oracle). */
+int magic_dropout(int dtype, long long rows, int cols, int ld, const void* in, void* out,
+                  const void* drop_seed, float drop_p, unsigned site, void* stream);
 
 /* out = [LayerNorm]( in0 + in1 + tab0[i0] + tab1[i1] + tab2[i2] ); table row = idx ? idx[r] : mod ? r%mod+off : off.
  * Carries BertEmbeddings (word + position(+2) + token-type -> LN), the image embedding sum, the map-node
@@ -57,13 +66,17 @@ int magic_ln_fwd(int dtype, int M, int H, const void* in0, const void* in1,
                  const void* tab0, const int* idx0, int mod0, int off0,
                  const void* tab1, const int* idx1, int mod1, int off1,
                  const void* tab2, const int* idx2, int mod2, int off2,
-                 const float* gamma, const float* beta, float eps, void* out, float* rstd, int do_ln, void* stream);
+                 const float* gamma, const float* beta, float eps, void* out, float* rstd, int do_ln,
+                 const void* drop_seed, float drop_p, unsigned site_in0, unsigned site_out, void* out_drop, void* stream);
+/* dropout: site_in0 drops in0 before the sum (dense -> dropout -> + residual); site_out writes dropout(out) to out_drop
+ * while `out` keeps the clean y the backward recovers xhat from.  bwd: site_dy masks dy on load (forward dropped its
+ * output), site_dx additionally writes dxm = dx * mask (the gradient of the dropped in0 branch). */
 int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void* y, const float* gamma, const float* beta,
                  const float* rstd, void* dx, float* dgamma, float* dbeta,
                  const int* idx0, int mod0, int off0, float* d0, int small0,
                  const int* idx1, int mod1, int off1, float* d1, int small1,
                  const int* idx2, int mod2, int off2, float* d2, int small2,
-                 int do_ln, void* stream);
+                 int do_ln, const void* drop_seed, float drop_p, unsigned site_dy, unsigned site_dx, void* dxm, void* stream);
 
 /* gamma/beta gradients of one LayerNorm as a column reduction (used when magic_ln_bwd is called with dgamma = dbeta = NULL) */
 int magic_ln_pgrad(int dtype, int M, int H, const void* dy, const void* y, const float* gamma, const float* beta,
@@ -88,15 +101,19 @@ int magic_head_mean_bwd(int B, int nh, long long inner, const float* g, float* d
 /* Fused attention for Nk <= 128, head dim 64 (HF BertSelfAttention arithmetic: scores/sqrt(d) + additive mask -> softmax
  * -> probs @ V; graph_sprels bias as in magic_softmax_fwd).  P [B,nh,Nq,ldp] is written (needed by the backward and by the
  * attention-map distillation, agent.py:579-593).  bwd: dq/dk/dv given dctx (+ optional dP_init = dLoss/dP, fp32).
- * magic_attn_supported() tells the host whether a shape fits (LDS); otherwise use magic_gemm + magic_softmax_*. */
+ * magic_attn_supported() tells the host whether a shape fits (LDS); otherwise use magic_gemm + magic_softmax_*.
+ * With dropout the product uses P*keep/(1-p); P stays the clean softmax (backward), Pd (optional) receives the dropped
+ * probabilities, which is what HF/METER BertSelfAttention returns as the attention map; dP_init is then dLoss/dPd. */
 int magic_attn_supported(int dtype, int Nq, int Nk, int backward);
 int magic_attn_fwd(int dtype, int B, int nh, int Nq, int Nk, const void* q, int ldq, const void* k, const void* v, int ldkv,
                    void* P, int ldp, void* ctx, int H, float scale, const unsigned char* kmask, const float* dist,
-                   const float* sprel_w, const float* sprel_b, void* stream);
+                   const float* sprel_w, const float* sprel_b,
+                   const void* drop_seed, float drop_p, unsigned drop_site, void* Pd, void* stream);
 int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const void* q, int ldq, const void* k, const void* v, int ldkv,
                    const void* P, int ldp, const void* dctx, int H, float scale, const float* dP_init,
                    void* dq, int lddq, void* dk, void* dv, int lddkv,
-                   const float* dist, float* dsprel_w, float* dsprel_b, void* stream);
+                   const float* dist, float* dsprel_w, float* dsprel_b,
+                   const void* drop_seed, float drop_p, unsigned drop_site, void* stream);
 
 /* ClsPrediction tail (Linear->ReLU->LN->Linear(H,1)): logit = dot(LN(Y), w2) + b2 */
 int magic_lndot_fwd(int dtype, int M, int H, const void* Y, const float* gamma, const float* beta, float eps,

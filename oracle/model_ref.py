@@ -22,6 +22,24 @@ import torch.nn.functional as F
 NEG = -10000.0
 HEAD_DIM = 64
 
+# Dropout hook (tests only): callable(site_name, tensor) -> tensor, or None (= eval mode / dropout 0, the default).
+# Site names are the qualified module names of HF's BertSelfAttention.dropout / BertSelfOutput.dropout /
+# BertOutput.dropout / BertEmbeddings.dropout / ImageEmbeddings.dropout; the HIP engine derives its counter-based
+# masks from the same names, so a test can export the engine's masks and replay them here exactly.
+DROPOUT = None
+
+
+def _drop(owner, suffix, x):
+    if DROPOUT is None:
+        return x
+    return DROPOUT(getattr(owner, "_qual", "") + suffix, x)
+
+
+def name_modules(root):
+    """record every sub-module's qualified name (dropout site names)"""
+    for n, m in root.named_modules():
+        m._qual = n
+
 
 def _ln(h, eps):
     return nn.LayerNorm(h, eps=eps)
@@ -49,9 +67,9 @@ class RefAttention(nn.Module):
         k = self.self.key(ctx).view(B, Nk, self.nh, d).transpose(1, 2)
         v = self.self.value(ctx).view(B, Nk, self.nh, d).transpose(1, 2)
         s = q @ k.transpose(-1, -2) / math.sqrt(d) + bias
-        p = torch.softmax(s, dim=-1)
+        p = _drop(self, ".self.dropout", torch.softmax(s, dim=-1))    # HF returns the probabilities AFTER dropout
         c = (p @ v).transpose(1, 2).reshape(B, Nq, H)
-        out = self.output.LayerNorm(x + self.output.dense(c))
+        out = self.output.LayerNorm(x + _drop(self, ".output.dropout", self.output.dense(c)))
         return out, p
 
 
@@ -66,7 +84,7 @@ class RefFFN(nn.Module):
 
 
 def _ffn(layer, a):
-    f = layer.output.dense(F.gelu(layer.intermediate.dense(a)))
+    f = _drop(layer, ".output.dropout", layer.output.dense(F.gelu(layer.intermediate.dense(a))))
     return layer.output.LayerNorm(a + f)
 
 
@@ -159,7 +177,7 @@ class RefMagicBert(nn.Module):
         L = txt_ids.shape[1]
         pos = torch.arange(L, device=txt_ids.device) + 2        # RoBERTa offset (padding_idx 1)
         x = e.word_embeddings(txt_ids) + e.position_embeddings(pos)[None] + e.token_type_embeddings.weight[0]
-        x = e.LayerNorm(x)
+        x = _drop(e, ".dropout", e.LayerNorm(x))
         kb = key_bias(txt_masks)
         p = None
         for lyr in self.lang_encoder.layer:
@@ -170,7 +188,7 @@ class RefMagicBert(nn.Module):
         ie = self.img_embeddings
         x = ie.img_layer_norm(ie.img_linear(view_fts)) + ie.loc_layer_norm(ie.loc_linear(loc_fts)) \
             + ie.nav_type_embedding(nav_types) + self.embeddings.token_type_embeddings.weight[0]
-        x = ie.layer_norm(x)
+        x = _drop(ie, ".dropout", ie.layer_norm(x))
         masks = seq_mask(view_lens, x.shape[1])
         kb = key_bias(masks)
         p = None
@@ -285,6 +303,7 @@ class RefPretrainModel(nn.Module):
         self.sap_fuse_linear = ClsPrediction(H, 2 * H, eps=eps)
         self.cfp_heads = nn.ModuleDict({k: nn.Linear(H, H) for k in ("gmap", "vp", "fused", "txt")})
         self.apply(self._init)
+        name_modules(self)
 
     def _init(self, m):
         std = self.cfg.initializer_range

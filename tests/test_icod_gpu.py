@@ -34,7 +34,7 @@ def s2t_loss(teacher_res, student_out, heads, rw, inp, mse_fn=None, kd_fn=None):
 
 
 def test_icod_reverse_distillation_trains_the_teacher():
-    kw = dict(vocab_size=300, num_l_layers=1, num_x_layers=1, num_pano_layers=1)
+    kw = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=300, num_l_layers=1, num_x_layers=1, num_pano_layers=1)
     tcfg, scfg = make_config(256, role="teacher", **kw), make_config(128, role="student", teacher_hidden_size=256, **kw)
     torch.manual_seed(0)
     o_t, o_s = RefVLNBert(tcfg).double().eval(), RefVLNBert(scfg).double().eval()

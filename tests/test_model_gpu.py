@@ -23,7 +23,7 @@ RW = [1.3, 0.7, 1.1, 0.9, 1.0]
 
 
 def cfgs(vocab=600, layers=(2, 1, 1)):
-    kw = dict(vocab_size=vocab, num_l_layers=layers[0], num_x_layers=layers[1], num_pano_layers=layers[2])
+    kw = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=vocab, num_l_layers=layers[0], num_x_layers=layers[1], num_pano_layers=layers[2])
     t = make_config(256, role="teacher", **kw)
     s = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL, **kw)
     return t, s

@@ -116,7 +116,7 @@ def one_step(model, inp, heads=None, teacher=None, t_heads=None, mse_fn=None, kd
 
 
 def test_nav_step_forward_losses_and_gradients_match_oracle_fp32():
-    kw = dict(vocab_size=300, num_l_layers=2, num_x_layers=1, num_pano_layers=1)
+    kw = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=300, num_l_layers=2, num_x_layers=1, num_pano_layers=1)
     tcfg, scfg = make_config(256, role="teacher", **kw), make_config(128, role="student", teacher_hidden_size=256, **kw)
     torch.manual_seed(0)
     o_t, o_s = RefVLNBert(tcfg).double().eval(), RefVLNBert(scfg).double().eval()

@@ -17,7 +17,7 @@ DEV = "cuda"
 
 
 def run_case(hs, ht, task, batch, layers=(1, 1, 1), vocab=400):
-    kw = dict(vocab_size=vocab, num_l_layers=layers[0], num_x_layers=layers[1], num_pano_layers=layers[2])
+    kw = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=vocab, num_l_layers=layers[0], num_x_layers=layers[1], num_pano_layers=layers[2])
     tcfg = make_config(ht, role="teacher", **kw)
     scfg = make_config(hs, role="student", teacher_hidden_size=ht, kdl=KDL, **kw)
     torch.manual_seed(1)

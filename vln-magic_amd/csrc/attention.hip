@@ -80,6 +80,9 @@ struct AttnParams {
   float scale;
   // backward only
   const void* dctx; const float* dP_init; void *dq, *dk, *dv; int lddq, lddkv; float* dsprel_w; float* dsprel_b;
+  // attention-probability dropout (BertSelfAttention.dropout): P stays the clean softmax (the backward needs it), the
+  // product uses P*mask/(1-p); Pd (optional) receives the dropped probabilities -- what HF/METER return as the attention map
+  DropDesc drop; void* Pd;
 };
 
 template <typename T>
@@ -156,6 +159,31 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bqt
       *(vec*)(Pg + (long long)r * p.ldp + c) = *(const vec*)(sP + r * PS + c);
     }
   }
+  const DropState ds_ = drop_init(p.drop);
+  if (ds_.on) {
+    __syncthreads();              // the cooperative P store above has read every row of sP
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < NT) {
+        const int key = j * 16 + c16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = w * 16 + 4 * g + r;
+          const unsigned idx = (unsigned)(((((long long)b * p.nh + h) * p.Nq + q0 + ql) * p.Nk) + key);
+          const float m = (ql < nq && key < p.Nk) ? drop_mul(ds_, idx) : 0.f;
+          sP[ql * PS + key] = from_f<T>(acc[j][r] * sum[r] * m);
+        }
+      }
+    __syncthreads();
+    if (p.Pd) {
+      T* Pg = (T*)p.Pd + (((long long)b * p.nh + h) * p.Nq + q0) * p.ldp;
+      const int cpr = p.ldp / VE;
+      for (int id = tid; id < nq * cpr; id += 256) {
+        const int r = id / cpr, c = (id % cpr) * VE;
+        *(vec*)(Pg + (long long)r * p.ldp + c) = *(const vec*)(sP + r * PS + c);
+      }
+    }
+  }
   // ---- O = P V
   f32x4 o[4];
 #pragma unroll
@@ -229,6 +257,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
   __syncthreads();
   // ---- phase 1: dP = dO V^T (+ distillation gradient), dS = P (dP - rowsum(P dP)), scaled; sprel gradients
   const int NT = NKP / 16;
+  const DropState ds_ = drop_init(p.drop);
   float a0 = 0.f, a1 = 0.f;
   for (int qt = w; qt < NQP / 16; qt += 4) {
     f32x4 acc[8];
@@ -254,6 +283,11 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
           float d = acc[j][r];
           if (p.dP_init && ok) d += p.dP_init[(prow0 + q) * p.ldp + key];
           const float pp = to_f(sP[q * PS + key]);
+          if (ds_.on) {               // d is the gradient wrt the DROPPED probabilities: mask it, and leave P*mask in sP for dV
+            const float m = ok ? drop_mul(ds_, (unsigned)((prow0 + q) * p.Nk + key)) : 0.f;
+            d *= m;
+            sP[q * PS + key] = from_f<T>(pp * m);
+          }
           pv[j][r] = pp; acc[j][r] = d; rs[r] += pp * d;
         }
       }
@@ -371,15 +405,18 @@ static int check_common(int dtype, int B, int nh, int Nq, int Nk, int ldq, int l
 
 extern "C" int magic_attn_fwd(int dtype, int B, int nh, int Nq, int Nk, const void* q, int ldq, const void* k, const void* v, int ldkv,
                               void* P, int ldp, void* ctx, int H, float scale, const unsigned char* kmask, const float* dist,
-                              const float* sprel_w, const float* sprel_b, void* stream) {
+                              const float* sprel_w, const float* sprel_b,
+                              const void* drop_seed, float drop_p, unsigned drop_site, void* Pd, void* stream) {
   int rc = check_common(dtype, B, nh, Nq, Nk, ldq, ldkv, ldp, H);
   if (rc) return rc;
+  if (!drop_args_ok(drop_seed, drop_p) || (long long)B * nh * Nq * Nk > 0xFFFFFFFFll || ((uintptr_t)Pd & 15)) return MAGIC_ERR_ARG;
   if (!magic_attn_supported(dtype, Nq, Nk, 0)) return MAGIC_ERR_UNSUPPORTED;
   if (dist && (!sprel_w || !sprel_b)) return MAGIC_ERR_ARG;
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)P & 15) || ((uintptr_t)ctx & 15)) return MAGIC_ERR_ARG;
   AttnParams p = {};
   p.q = q; p.k = k; p.v = v; p.P = P; p.ctx = ctx; p.kmask = kmask; p.dist = dist; p.sprel_w = sprel_w; p.sprel_b = sprel_b;
   p.B = B; p.nh = nh; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldkv = ldkv; p.ldp = ldp; p.H = H; p.scale = scale;
+  p.drop = DropDesc{drop_p > 0.f ? (const unsigned*)drop_seed : nullptr, drop_site, drop_p}; p.Pd = drop_p > 0.f ? Pd : nullptr;
   if (group_record(KIND_ATTN_FWD, dtype, 0, &p, sizeof(p))) return MAGIC_OK;
   return launch_attn_fwd(dtype, 0, &p, nullptr, (hipStream_t)stream);
 }
@@ -410,9 +447,11 @@ int launch_attn_fwd(int dtype, int, const void* pa, const void* pb, hipStream_t 
 extern "C" int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const void* q, int ldq, const void* k, const void* v, int ldkv,
                               const void* P, int ldp, const void* dctx, int H, float scale, const float* dP_init,
                               void* dq, int lddq, void* dk, void* dv, int lddkv,
-                              const float* dist, float* dsprel_w, float* dsprel_b, void* stream) {
+                              const float* dist, float* dsprel_w, float* dsprel_b,
+                              const void* drop_seed, float drop_p, unsigned drop_site, void* stream) {
   int rc = check_common(dtype, B, nh, Nq, Nk, ldq, ldkv, ldp, H);
   if (rc) return rc;
+  if (!drop_args_ok(drop_seed, drop_p) || (long long)B * nh * Nq * Nk > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
   if (!magic_attn_supported(dtype, Nq, Nk, 1)) return MAGIC_ERR_UNSUPPORTED;
   if ((dist == nullptr) != (dsprel_w == nullptr) || (dist == nullptr) != (dsprel_b == nullptr)) return MAGIC_ERR_ARG;
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)P & 15) || ((uintptr_t)dctx & 15)) return MAGIC_ERR_ARG;
@@ -420,6 +459,7 @@ extern "C" int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const vo
   p.q = q; p.k = k; p.v = v; p.P = (void*)P; p.dist = dist; p.B = B; p.nh = nh; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldkv = ldkv;
   p.ldp = ldp; p.H = H; p.scale = scale; p.dctx = dctx; p.dP_init = dP_init; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddkv = lddkv;
   p.dsprel_w = dsprel_w; p.dsprel_b = dsprel_b;
+  p.drop = DropDesc{drop_p > 0.f ? (const unsigned*)drop_seed : nullptr, drop_site, drop_p};
   if (group_record(KIND_ATTN_BWD, dtype, 0, &p, sizeof(p))) return MAGIC_OK;
   return launch_attn_bwd(dtype, 0, &p, nullptr, (hipStream_t)stream);
 }

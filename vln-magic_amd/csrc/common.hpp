@@ -43,6 +43,34 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
+// Counter-based dropout: keep(site, idx) is a pure function of (seed[0], seed[1], site, logical element index), so the
+// forward kernel and the backward kernel regenerate the same mask without ever storing it.  `seed` lives in device
+// memory (a replayed HIP graph sees whatever the host-side generator wrote there this step); `site` distinguishes the
+// dropout modules of the network; idx is the row-major index in the LOGICAL tensor (no padding columns).
+// Two rounds of a 32-bit finaliser (murmur3 fmix32, then a second odd-multiplier mix keyed differently).
+struct DropDesc { const unsigned* seed; unsigned site; float p; };       // seed == nullptr or p <= 0: off
+struct DropState { unsigned ka, kb, thr; float scale; bool on; };
+__device__ __forceinline__ DropState drop_init(const DropDesc& d) {
+  DropState s;
+  s.on = d.seed != nullptr && d.p > 0.f;
+  s.ka = 0; s.kb = 0; s.thr = 0; s.scale = 1.f;
+  if (s.on) {
+    s.ka = d.seed[0] ^ (d.site * 0x9E3779B1u);
+    s.kb = d.seed[1] + d.site * 0x85EBCA77u;
+    s.thr = (unsigned)((double)d.p * 4294967296.0);
+    s.scale = 1.0f / (1.0f - d.p);
+  }
+  return s;
+}
+__device__ __forceinline__ float drop_mul(const DropState& s, unsigned idx) {   // 0 (dropped) or 1/(1-p) (kept)
+  unsigned x = idx ^ s.ka;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  x += s.kb;
+  x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+  return x >= s.thr ? s.scale : 0.f;
+}
+static inline bool drop_args_ok(const void* seed, float p) { return p >= 0.f && p < 1.f && (p == 0.f || seed != nullptr); }
+
 static inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MAGIC_OK : MAGIC_ERR_LAUNCH;

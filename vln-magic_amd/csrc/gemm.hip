@@ -406,6 +406,7 @@ int launch_gemm(int dtype, int layout, const void* pa, const void* pb, hipStream
 struct LlnParams {
   int M, K; const void* X; int lda; const void* W; int ldb; const float* bias; const void* R; int ldr;
   const float* gamma; const float* beta; float eps; void* out; float* rstd_out;
+  DropDesc drop;      // hidden dropout between the dense and the residual add (BertSelfOutput / BertOutput)
 };
 
 template <typename T, int HT>      // HT = H / 64 column tiles of 16 per wave (per wave H/4 = 16*HT columns)
@@ -501,6 +502,7 @@ __device__ __forceinline__ void linear_ln_body(const LlnParams& pp, const int bi
         const int row = m0 + i * 16 + 4 * g + r, col = w * WC + j * 16 + c16;
         rsd[i][j][r] = (R && row < M) ? to_f(R[(long long)row * ldr + col]) : 0.f;
       }
+  const DropState dsn = drop_init(pp.drop);
   float s[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -508,7 +510,11 @@ __device__ __forceinline__ void linear_ln_body(const LlnParams& pp, const int bi
     for (int r = 0; r < 4; ++r) {
       float t = 0.f;
 #pragma unroll
-      for (int j = 0; j < HT; ++j) { acc[i][j][r] += bv[j] + rsd[i][j][r]; t += acc[i][j][r]; }
+      for (int j = 0; j < HT; ++j) {
+        float v = acc[i][j][r] + bv[j];
+        if (dsn.on) v *= drop_mul(dsn, (unsigned)((m0 + i * 16 + 4 * g + r) * H + w * WC + j * 16 + c16));
+        acc[i][j][r] = v + rsd[i][j][r]; t += acc[i][j][r];
+      }
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
       s[i][r] = t;
@@ -576,13 +582,15 @@ __global__ __launch_bounds__(256) void linear_ln_pair_kernel(LlnParams a, LlnPar
 
 extern "C" int magic_linear_ln(int dtype, int M, int H, int K, const void* x, int lda, const void* W, int ldb, const float* bias,
                                const void* residual, int ldr, const float* gamma, const float* beta, float eps,
-                               void* out, float* rstd, void* stream) {
+                               void* out, float* rstd, const void* drop_seed, float drop_p, unsigned drop_site, void* stream) {
   if (M <= 0 || K <= 0 || !gamma || !beta || !out) return MAGIC_ERR_ARG;
+  if (!drop_args_ok(drop_seed, drop_p) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
   if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
   const int ve = dtype == DT_BF16 ? 8 : 4;
   if (lda % ve || ldb % ve || ((uintptr_t)x & 15) || ((uintptr_t)W & 15)) return MAGIC_ERR_ARG;
   if (H != 128 && H != 256 && H != 384) return MAGIC_ERR_UNSUPPORTED;
-  LlnParams p{M, K, x, lda, W, ldb, bias, residual, ldr, gamma, beta, eps, out, rstd};
+  LlnParams p{M, K, x, lda, W, ldb, bias, residual, ldr, gamma, beta, eps, out, rstd,
+              DropDesc{drop_p > 0.f ? (const unsigned*)drop_seed : nullptr, drop_site, drop_p}};
   const int ht = H / 64;
   if (group_record(KIND_LLN, dtype, ht, &p, sizeof(p))) return MAGIC_OK;
   return launch_lln(dtype, ht, &p, nullptr, (hipStream_t)stream);

@@ -36,10 +36,12 @@ __device__ __forceinline__ int tab_row(const TabRef& t, int r) {
 // NIT = H / 128 is a template parameter so the per-lane row fragment lives in exactly 2*NIT registers.
 template <typename T, int NIT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, const T* in0, const T* in1, TabRef t0, TabRef t1, TabRef t2,
-                                                     const float* gamma, const float* beta, float eps, T* out, float* rstd_out, int do_ln) {
+                                                     const float* gamma, const float* beta, float eps, T* out, float* rstd_out, int do_ln,
+                                                     DropDesc din, DropDesc dout, T* out_drop) {
   constexpr int H = NIT * 128;
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  const DropState sin = drop_init(din), sout = drop_init(dout);     // dropout on in0 (dense -> dropout -> +residual) / on the output
   float x[2 * NIT];
   float s = 0.f;
   const int r0 = t0.tab ? tab_row(t0, row) : 0, r1 = t1.tab ? tab_row(t1, row) : 0, r2 = t2.tab ? tab_row(t2, row) : 0;
@@ -47,7 +49,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, const T* in0, const 
   for (int it = 0; it < NIT; ++it) {
     const int c = it * 128 + lane * 2;
     float a = 0.f, b = 0.f, u, v;
-    if (in0) { ld2<T>(in0 + (long long)row * H + c, u, v); a += u; b += v; }
+    if (in0) {
+      ld2<T>(in0 + (long long)row * H + c, u, v);
+      if (sin.on) { u *= drop_mul(sin, (unsigned)(row * H + c)); v *= drop_mul(sin, (unsigned)(row * H + c + 1)); }
+      a += u; b += v;
+    }
     if (in1) { ld2<T>(in1 + (long long)row * H + c, u, v); a += u; b += v; }
     if (t0.tab) { ld2<T>((const T*)t0.tab + (long long)r0 * H + c, u, v); a += u; b += v; }
     if (t1.tab) { ld2<T>((const T*)t1.tab + (long long)r1 * H + c, u, v); a += u; b += v; }
@@ -69,7 +75,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, const T* in0, const 
   for (int it = 0; it < NIT; ++it) {
     const int c = it * 128 + lane * 2;
     const float2 g = *(const float2*)(gamma + c), b = *(const float2*)(beta + c);
-    st2<T>(out + (long long)row * H + c, (x[2 * it] - mean) * rstd * g.x + b.x, (x[2 * it + 1] - mean) * rstd * g.y + b.y);
+    const float y0 = (x[2 * it] - mean) * rstd * g.x + b.x, y1 = (x[2 * it + 1] - mean) * rstd * g.y + b.y;
+    st2<T>(out + (long long)row * H + c, y0, y1);          // pre-dropout y: the backward recovers xhat from it
+    if (sout.on) st2<T>(out_drop + (long long)row * H + c, y0 * drop_mul(sout, (unsigned)(row * H + c)), y1 * drop_mul(sout, (unsigned)(row * H + c + 1)));
   }
 }
 
@@ -82,6 +90,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, const T* in0, const 
 struct LnbParams {
   int M; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd; void* dx; float* dgamma; float* dbeta;
   TabRef t0; float* d0; int small0; TabRef t1; float* d1; int small1; TabRef t2; float* d2; int small2; int do_ln;
+  DropDesc ddy;               // the forward dropped its OUTPUT: dy is masked on load
+  void* dxm; DropDesc ddx;    // the forward dropped its in0: second output dxm = dx * mask (gradient of the dense branch)
 };
 
 template <typename T, int NIT>
@@ -91,6 +101,8 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
   const float* gamma = pp.gamma; const float* beta = pp.beta; const float* rstd = pp.rstd;
   float* dgamma = pp.dgamma; float* dbeta = pp.dbeta; float* d0 = pp.d0; float* d1 = pp.d1; float* d2 = pp.d2;
   const TabRef t0 = pp.t0, t1 = pp.t1, t2 = pp.t2;
+  const DropState sdy = drop_init(pp.ddy), sdx = drop_init(pp.ddx);
+  T* dxm = (T*)pp.dxm;
   constexpr int H = NIT * 128;     // red: [2][4 waves][H] gamma/beta partials | [9][H] table slots
   float* tacc = red + 8 * H;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -129,6 +141,7 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
       for (int it = 0; it < NIT; ++it) {
         const int c = it * 128 + lane * 2;
         ld2<T>(dy + (long long)row * H + c, g[u][2 * it], g[u][2 * it + 1]);
+        if (sdy.on) { g[u][2 * it] *= drop_mul(sdy, (unsigned)(row * H + c)); g[u][2 * it + 1] *= drop_mul(sdy, (unsigned)(row * H + c + 1)); }
         if (do_ln) ld2<T>(y + (long long)row * H + c, xh[u][2 * it], xh[u][2 * it + 1]);
       }
       rs[u] = do_ln ? rstd[row] : 0.f;
@@ -169,6 +182,13 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
         if (dx) {
 #pragma unroll
           for (int it = 0; it < NIT; ++it) st2<T>(dx + (long long)row * H + it * 128 + lane * 2, g[u][2 * it], g[u][2 * it + 1]);
+        }
+        if (dxm) {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int c = it * 128 + lane * 2;
+            st2<T>(dxm + (long long)row * H + c, g[u][2 * it] * drop_mul(sdx, (unsigned)(row * H + c)), g[u][2 * it + 1] * drop_mul(sdx, (unsigned)(row * H + c + 1)));
+          }
         }
         // table gradients
 #define TAB_GRAD(K, TK, DK, LK, CK)                                                         \
@@ -616,13 +636,20 @@ extern "C" int magic_ln_fwd(int dtype, int M, int H, const void* in0, const void
                             const void* tab0, const int* idx0, int mod0, int off0,
                             const void* tab1, const int* idx1, int mod1, int off1,
                             const void* tab2, const int* idx2, int mod2, int off2,
-                            const float* gamma, const float* beta, float eps, void* out, float* rstd, int do_ln, void* stream) {
+                            const float* gamma, const float* beta, float eps, void* out, float* rstd, int do_ln,
+                            const void* drop_seed, float drop_p, unsigned site_in0, unsigned site_out, void* out_drop, void* stream) {
   if (M <= 0 || !okH(H) || !out) return MAGIC_ERR_ARG;
   if (do_ln && (!gamma || !beta)) return MAGIC_ERR_ARG;
+  if (!drop_args_ok(drop_seed, drop_p) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+  const bool don = drop_p > 0.f;
+  if (don && site_out && (!out_drop || !do_ln)) return MAGIC_ERR_ARG;
+  if (don && site_in0 && !in0) return MAGIC_ERR_ARG;
+  DropDesc din{(don && site_in0) ? (const unsigned*)drop_seed : nullptr, site_in0, drop_p};
+  DropDesc dout{(don && site_out) ? (const unsigned*)drop_seed : nullptr, site_out, drop_p};
   TabRef t0{tab0, idx0, mod0, off0}, t1{tab1, idx1, mod1, off1}, t2{tab2, idx2, mod2, off2};
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define LNF(TY, NIT) hipLaunchKernelGGL((ln_fwd_kernel<TY, NIT>), grid, block, 0, st, M, (const TY*)in0, (const TY*)in1, t0, t1, t2, gamma, beta, eps, (TY*)out, rstd, do_ln)
+#define LNF(TY, NIT) hipLaunchKernelGGL((ln_fwd_kernel<TY, NIT>), grid, block, 0, st, M, (const TY*)in0, (const TY*)in1, t0, t1, t2, gamma, beta, eps, (TY*)out, rstd, do_ln, din, dout, (TY*)out_drop)
   DISPATCH_NIT(dtype, H, LNF);
 #undef LNF
   return launch_status();
@@ -633,13 +660,18 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
                             const int* idx0, int mod0, int off0, float* d0, int small0,
                             const int* idx1, int mod1, int off1, float* d1, int small1,
                             const int* idx2, int mod2, int off2, float* d2, int small2,
-                            int do_ln, void* stream) {
+                            int do_ln, const void* drop_seed, float drop_p, unsigned site_dy, unsigned site_dx, void* dxm, void* stream) {
   if (M <= 0 || !okH(H) || !dy || (H != 128 && H != 256 && H != 384 && H != 768)) return MAGIC_ERR_ARG;
+  if (!drop_args_ok(drop_seed, drop_p) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+  const bool don = drop_p > 0.f;
+  if (don && site_dx && !dxm) return MAGIC_ERR_ARG;
   if (do_ln && (!y || !gamma || !beta || !rstd)) return MAGIC_ERR_ARG;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return MAGIC_ERR_ARG;
   if ((small0 && !idx0) || (small1 && !idx1) || (small2 && !idx2)) return MAGIC_ERR_ARG;
   LnbParams p{M, dy, y, gamma, beta, rstd, dx, dgamma, dbeta, TabRef{d0, idx0, mod0, off0}, d0, small0, TabRef{d1, idx1, mod1, off1}, d1, small1,
-              TabRef{d2, idx2, mod2, off2}, d2, small2, do_ln};
+              TabRef{d2, idx2, mod2, off2}, d2, small2, do_ln,
+              DropDesc{(don && site_dy) ? (const unsigned*)drop_seed : nullptr, site_dy, drop_p},
+              (don && site_dx) ? dxm : nullptr, DropDesc{(don && site_dx) ? (const unsigned*)drop_seed : nullptr, site_dx, drop_p}};
   const int nit = H / 128;
   if (group_record(KIND_LNB, dtype, nit, &p, sizeof(p))) return MAGIC_OK;
   return launch_lnb(dtype, nit, &p, nullptr, (hipStream_t)stream);
@@ -779,5 +811,33 @@ extern "C" int magic_lndot_bwd(int dtype, int M, int H, const void* Y, const flo
 #define LDB(TY, NIT) hipLaunchKernelGGL((lndot_bwd_kernel<TY, NIT>), grid, block, shm, st, M, H, (const TY*)Y, gamma, beta, eps, w2, dlogit, (TY*)dZ, dgamma, dbeta, dw2, db2)
   DISPATCH_NIT(dtype, H, LDB);
 #undef LDB
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[r, c] = in[r, c] * mask(site, r*cols + c) / (1-p)   (rows x cols logical, row pitch ld; in may alias out).
+// The unfused attention path (key length > 128) drops its probabilities / masks their gradient with it, and the tests
+// export the masks the fused kernels regenerate (in = ones).
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(long long rows, int cols, int ld, const T* in, T* out, DropDesc d) {
+  const DropState s = drop_init(d);
+  const long long n = rows * cols;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long r = i / cols; const int c = (int)(i - r * cols);
+    const float m = s.on ? drop_mul(s, (unsigned)i) : 1.f;
+    out[r * ld + c] = from_f<T>(to_f(in[r * ld + c]) * m);
+  }
+}
+extern "C" int magic_dropout(int dtype, long long rows, int cols, int ld, const void* in, void* out,
+                             const void* drop_seed, float drop_p, unsigned site, void* stream) {
+  if (rows <= 0 || cols <= 0 || ld < cols || !in || !out || rows * cols > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+  if (!drop_args_ok(drop_seed, drop_p)) return MAGIC_ERR_ARG;
+  DropDesc d{drop_p > 0.f ? (const unsigned*)drop_seed : nullptr, site, drop_p};
+  const long long n = rows * cols;
+  dim3 grid((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(dropout_kernel<bf16>, grid, block, 0, st, rows, cols, ld, (const bf16*)in, (bf16*)out, d);
+  else if (dtype == DT_F32) hipLaunchKernelGGL(dropout_kernel<float>, grid, block, 0, st, rows, cols, ld, (const float*)in, (float*)out, d);
+  else return MAGIC_ERR_ARG;
   return launch_status();
 }

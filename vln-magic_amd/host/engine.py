@@ -7,6 +7,7 @@ torch tensors owned by the caching allocator; every arithmetic op is a C-ABI ker
 Parameter gradients are accumulated (fp32 atomics) into the flat gradient buffer of the ParamStore.
 """
 import math
+import zlib
 from types import SimpleNamespace as Ctx
 
 import torch
@@ -129,6 +130,27 @@ class MagicNet:
         self.dtype = store.compute_dtype
         self.train = store.requires_grad
         self._cache = {}
+        self.drop = None          # (seed uint32[2] device tensor, p_hidden, p_attn) while a training-mode forward is running
+
+    # ---- dropout sites (counter-based masks, csrc/common.hpp) -------------------------------------
+    def set_dropout(self, seed=None, p_hidden=0.0, p_attn=0.0):
+        """Called by the model before each forward: seed = fresh uint32[2] device tensor (None = eval mode)."""
+        self.drop = (seed, float(p_hidden), float(p_attn)) if (seed is not None and (p_hidden > 0 or p_attn > 0)) else None
+
+    @staticmethod
+    def site_id(name):
+        return (zlib.crc32(name.encode()) & 0xFFFFFFFF) or 1
+
+    def _dh(self, name):
+        """hidden-dropout descriptor (seed, p, site) of the module called `name`, or None"""
+        if self.drop is None or self.drop[1] <= 0:
+            return None
+        return (self.drop[0], self.drop[1], self.site_id(name))
+
+    def _da(self, name):
+        if self.drop is None or self.drop[2] <= 0:
+            return None
+        return (self.drop[0], self.drop[2], self.site_id(name))
 
     # ---- parameter handle cache ---------------------------------------------------------------
     def lin(self, w, b=None, rows=None, cols=None):
@@ -150,39 +172,53 @@ class MagicNet:
         return torch.zeros(*shape, dtype=dtype or self.dtype, device=self.S.device)
 
     # ---- attention core -----------------------------------------------------------------------
-    def _attn_fwd(self, q, ldq, k, v, ldkv, Bn, Nq, Nk, kmask, dist, sprel, flops):
+    def _attn_fwd(self, q, ldq, k, v, ldkv, Bn, Nq, Nk, kmask, dist, sprel, flops, drop=None):
+        """returns (P clean softmax [kept for the backward], ctx, ldp, P as exposed = dropped probabilities under dropout:
+        HF/METER BertSelfAttention returns the attention map AFTER its dropout)."""
         nh, H = self.nh, self.H
         ldp = rup(Nk)
         if FUSED_ATTN and O.attn_supported(self.dtype, Nq, Nk, False):
             Pm, ctx = self.new(Bn, nh, Nq, ldp), self.new(Bn * Nq, H)
+            Pd = self.new(Bn, nh, Nq, ldp) if drop else None
             O.attn_fwd(q, ldq, k, v, ldkv, Pm, ldp, ctx, Bn, nh, Nq, Nk, H, 1.0 / math.sqrt(HD), kmask=kmask, dist=dist,
-                       sprel_w=sprel[0] if sprel else None, sprel_b=sprel[1] if sprel else None, flops=flops)
-            return Pm, ctx, ldp
+                       sprel_w=sprel[0] if sprel else None, sprel_b=sprel[1] if sprel else None, flops=flops, drop=drop, Pd=Pd)
+            return Pm, ctx, ldp, (Pd if drop else Pm)
         S = self.new(Bn, nh, Nq, ldp, dtype=torch.float32)
         O.gemm(0, q, k, S, Nq, Nk, HD, ldq, ldkv, ldp, batch=Bn * nh, nh=nh, sA=(Nq * ldq, HD), sB=(Nk * ldkv, HD),
                sC=(nh * Nq * ldp, Nq * ldp), flop_dims=(1, 1, flops / (nh * Bn)))
         Pm = self.new(Bn, nh, Nq, ldp)
         O.softmax_fwd(S, Pm, Bn, nh, Nq, Nk, ldp, 1.0 / math.sqrt(HD), kmask=kmask, dist=dist,
                       sprel_w=sprel[0] if sprel else None, sprel_b=sprel[1] if sprel else None)
+        Pu = Pm
+        if drop:
+            Pu = self.zeros(Bn, nh, Nq, ldp)
+            O.dropout(Pm, Pu, Bn * nh * Nq, Nk, ldp, drop)
         ctx = self.new(Bn * Nq, H)
-        O.gemm(1, Pm, v, ctx, Nq, HD, Nk, ldp, ldkv, H, batch=Bn * nh, nh=nh, sA=(nh * Nq * ldp, Nq * ldp), sB=(Nk * ldkv, HD),
+        O.gemm(1, Pu, v, ctx, Nq, HD, Nk, ldp, ldkv, H, batch=Bn * nh, nh=nh, sA=(nh * Nq * ldp, Nq * ldp), sB=(Nk * ldkv, HD),
                sC=(Nq * H, HD), flop_dims=(1, 1, flops / (nh * Bn)))
-        return Pm, ctx, ldp
+        return Pm, ctx, ldp, Pu
 
-    def _attn_bwd(self, Pm, ldp, d_ctx, q, ldq, k, v, ldkv, dq, lddq, dk, dv, lddkv, Bn, Nq, Nk, dist, dsprel, dP_init, flops):
+    def _attn_bwd(self, Pm, ldp, d_ctx, q, ldq, k, v, ldkv, dq, lddq, dk, dv, lddkv, Bn, Nq, Nk, dist, dsprel, dP_init, flops,
+                  drop=None, Pu=None):
+        """Pm = clean softmax; under dropout Pu = the dropped probabilities the product used (dP_init = dLoss/dPu)."""
         nh, H = self.nh, self.H
         if FUSED_ATTN and O.attn_supported(self.dtype, Nq, Nk, True):
             O.attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, d_ctx, Bn, nh, Nq, Nk, H, 1.0 / math.sqrt(HD), dP_init, dq, lddq, dk, dv, lddkv,
-                       dist=dist, dsprel_w=dsprel[0] if dsprel else None, dsprel_b=dsprel[1] if dsprel else None, flops=flops)
+                       dist=dist, dsprel_w=dsprel[0] if dsprel else None, dsprel_b=dsprel[1] if dsprel else None, flops=flops, drop=drop)
             return
         fd = (1, 1, flops / (nh * Bn))      # x (batch = Bn*nh) in the counter -> 2 * sum_b(lq*lk) * 64 * nh
         sP = (nh * Nq * ldp, Nq * ldp)
-        # dV = P^T dO
-        O.gemm(2, Pm, d_ctx, dv, Nk, HD, Nq, ldp, H, lddkv, batch=Bn * nh, nh=nh, sA=sP, sB=(Nq * H, HD), sC=(Nk * lddkv, HD), flop_dims=fd)
+        if drop and Pu is None:
+            Pu = self.zeros(Bn, nh, Nq, ldp)
+            O.dropout(Pm, Pu, Bn * nh * Nq, Nk, ldp, drop)
+        # dV = Pu^T dO
+        O.gemm(2, Pu if drop else Pm, d_ctx, dv, Nk, HD, Nq, ldp, H, lddkv, batch=Bn * nh, nh=nh, sA=sP, sB=(Nq * H, HD), sC=(Nk * lddkv, HD), flop_dims=fd)
         # dP = dO V^T (+ KD gradient already sitting in dP_init)
         dP = dP_init if dP_init is not None else self.new(Bn, nh, Nq, ldp, dtype=torch.float32)
         O.gemm(0, d_ctx, v, dP, Nq, Nk, HD, H, ldkv, ldp, batch=Bn * nh, nh=nh, sA=(Nq * H, HD), sB=(Nk * ldkv, HD), sC=sP,
                residual=dP if dP_init is not None else None, ldr=ldp, flop_dims=fd)
+        if drop:                                # gradient wrt the dropped probabilities -> wrt the clean softmax
+            O.dropout(dP, dP, Bn * nh * Nq, Nk, ldp, drop)
         dS = self.new(Bn, nh, Nq, ldp)
         O.softmax_bwd(Pm, dP, dS, Bn, nh, Nq, Nk, ldp, 1.0 / math.sqrt(HD), dist=dist,
                       dsprel_w=dsprel[0] if dsprel else None, dsprel_b=dsprel[1] if dsprel else None)
@@ -197,29 +233,46 @@ class MagicNet:
         c = Ctx(x=x, Bn=Bn, N=N, rows=rows, aflops=aflops, dist=dist)
         qkv = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
         c.qkv = O.linear_fwd(x, qkv.W, qkv.b, M, flop_rows=rows)
-        c.P, c.ctx, c.ldp = self._attn_fwd(c.qkv, 3 * H, c.qkv[:, H:], c.qkv[:, 2 * H:], 3 * H, Bn, N, N, kmask, dist, sprel, aflops)
+        c.adrop, c.hdrop = self._da(lp + "attention.self.dropout"), self._dh(lp + "attention.output.dropout")
+        c.Ppre, c.ctx, c.ldp, c.P = self._attn_fwd(c.qkv, 3 * H, c.qkv[:, H:], c.qkv[:, 2 * H:], 3 * H, Bn, N, N, kmask, dist, sprel,
+                                                   aflops, c.adrop)
         o = self.lin(lp + "attention.output.dense.weight")
         n = self.ln(lp + "attention.output.LayerNorm")
         c.a, c.rstd_a = self.new(M, H), self.new(M, dtype=torch.float32)
-        if O.linear_ln_ok(H, H):
-            O.linear_ln(c.ctx, o.W, o.b, M, x, n.g, n.b, self.eps, c.a, c.rstd_a, flop_rows=rows)
-        else:
-            ao = O.linear_fwd(c.ctx, o.W, o.b, M, residual=x, flop_rows=rows)
-            O.ln_fwd(M, H, c.a, in0=ao, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_a)
+        self._dense_add_ln(c.ctx, o, x, n, M, c.a, c.rstd_a, rows, c.hdrop)
         return c
+
+    def _dense_add_ln(self, x, lin, res, n, M, out, rstd, rows, hdrop):
+        """out = LayerNorm(dropout(x W^T + b) + res): BertSelfOutput / BertOutput"""
+        H = self.H
+        if O.linear_ln_ok(H, lin.K):
+            O.linear_ln(x, lin.W, lin.b, M, res, n.g, n.b, self.eps, out, rstd, flop_rows=rows, drop=hdrop)
+        elif hdrop:
+            d = O.linear_fwd(x, lin.W, lin.b, M, flop_rows=rows)
+            O.ln_fwd(M, H, out, in0=d, in1=res, gamma=n.g, beta=n.b, eps=self.eps, rstd=rstd, drop_in0=hdrop)
+        else:
+            d = O.linear_fwd(x, lin.W, lin.b, M, residual=res, flop_rows=rows)
+            O.ln_fwd(M, H, out, in0=d, gamma=n.g, beta=n.b, eps=self.eps, rstd=rstd)
+
+    def _add_ln_bwd(self, n, M, dy, y, rstd, hdrop):
+        """backward of _dense_add_ln's LayerNorm: returns (d_sum for the residual branch, d_dense for the dense branch)"""
+        d_sum = self.new(M, self.H)
+        d_dense = self.new(M, self.H) if hdrop else None
+        O.ln_bwd(M, self.H, dy, y=y, gamma=n.g, beta=n.b, rstd=rstd, dx=d_sum, dgamma=n.dg, dbeta=n.db, drop_dx=hdrop, dxm=d_dense)
+        return d_sum, (d_dense if hdrop else d_sum)
 
     def _sa_bwd(self, lp, c, d_a, dsprel=None, dP_init=None):
         H, Bn, N = self.H, c.Bn, c.N
         M = Bn * N
         n = self.ln(lp + "attention.output.LayerNorm")
-        d_ao = self.new(M, H)
-        O.ln_bwd(M, H, d_a, y=c.a, gamma=n.g, beta=n.b, rstd=c.rstd_a, dx=d_ao, dgamma=n.dg, dbeta=n.db)
+        d_ao, d_aod = self._add_ln_bwd(n, M, d_a, c.a, c.rstd_a, c.hdrop)
         o = self.lin(lp + "attention.output.dense.weight")
-        O.linear_dw(d_ao, c.ctx, o.dW, o.db, M, flop_rows=c.rows)
-        d_ctx = O.linear_dx(d_ao, o.W, M, flop_rows=c.rows)
+        O.linear_dw(d_aod, c.ctx, o.dW, o.db, M, flop_rows=c.rows)
+        d_ctx = O.linear_dx(d_aod, o.W, M, flop_rows=c.rows)
         dqkv = self.new(M, 3 * H)
-        self._attn_bwd(c.P, c.ldp, d_ctx, c.qkv, 3 * H, c.qkv[:, H:], c.qkv[:, 2 * H:], 3 * H,
-                       dqkv, 3 * H, dqkv[:, H:], dqkv[:, 2 * H:], 3 * H, Bn, N, N, c.dist, dsprel, dP_init, c.aflops)
+        self._attn_bwd(c.Ppre, c.ldp, d_ctx, c.qkv, 3 * H, c.qkv[:, H:], c.qkv[:, 2 * H:], 3 * H,
+                       dqkv, 3 * H, dqkv[:, H:], dqkv[:, 2 * H:], 3 * H, Bn, N, N, c.dist, dsprel, dP_init, c.aflops,
+                       c.adrop, c.P if c.adrop else None)
         qkv = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
         O.linear_dw(dqkv, c.x, qkv.dW, qkv.db, M, flop_rows=c.rows)
         return O.linear_dx(dqkv, qkv.W, M, residual=d_ao, flop_rows=c.rows)
@@ -233,21 +286,17 @@ class MagicNet:
         c.g = O.linear_fwd(a, f1.W, f1.b, M, epilogue=1, pre=c.z, flop_rows=rows)
         n = self.ln(lp + "output.LayerNorm")
         c.out, c.rstd = self.new(M, H), self.new(M, dtype=torch.float32)
-        if O.linear_ln_ok(H, self.I):
-            O.linear_ln(c.g, f2.W, f2.b, M, a, n.g, n.b, self.eps, c.out, c.rstd, flop_rows=rows)
-        else:
-            fo = O.linear_fwd(c.g, f2.W, f2.b, M, residual=a, flop_rows=rows)
-            O.ln_fwd(M, H, c.out, in0=fo, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd)
+        c.hdrop = self._dh(lp + "output.dropout")
+        self._dense_add_ln(c.g, f2, a, n, M, c.out, c.rstd, rows, c.hdrop)
         return c
 
     def _ffn_bwd(self, lp, c, dout):
         H, M = self.H, c.M
         n = self.ln(lp + "output.LayerNorm")
-        d_fo = self.new(M, H)
-        O.ln_bwd(M, H, dout, y=c.out, gamma=n.g, beta=n.b, rstd=c.rstd, dx=d_fo, dgamma=n.dg, dbeta=n.db)
+        d_fo, d_fod = self._add_ln_bwd(n, M, dout, c.out, c.rstd, c.hdrop)
         f1, f2 = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")
-        O.linear_dw(d_fo, c.g, f2.dW, f2.db, M, flop_rows=c.rows)
-        d_z = O.linear_dx(d_fo, f2.W, M, epilogue=3, aux=c.z, flop_rows=c.rows)
+        O.linear_dw(d_fod, c.g, f2.dW, f2.db, M, flop_rows=c.rows)
+        d_z = O.linear_dx(d_fod, f2.W, M, epilogue=3, aux=c.z, flop_rows=c.rows)
         O.linear_dw(d_z, c.a, f1.dW, f1.db, M, flop_rows=c.rows)
         return O.linear_dx(d_z, f1.W, M, residual=d_fo, flop_rows=c.rows)
 
@@ -273,15 +322,12 @@ class MagicNet:
         kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
         c.q = O.linear_fwd(s, ql.W, ql.b, Mq, flop_rows=rows)
         c.kv = O.linear_fwd(ctx, kvl.W, kvl.b, Mk, flop_rows=crow)
-        c.P, c.cctx, c.ldp = self._attn_fwd(c.q, H, c.kv, c.kv[:, H:], 2 * H, Bn, Nq, Nk, ckmask, None, None, cflops)
+        c.adrop, c.hdrop = self._da(lp + "crossattention.self.dropout"), self._dh(lp + "crossattention.output.dropout")
+        c.Ppre, c.cctx, c.ldp, c.P = self._attn_fwd(c.q, H, c.kv, c.kv[:, H:], 2 * H, Bn, Nq, Nk, ckmask, None, None, cflops, c.adrop)
         o = self.lin(lp + "crossattention.output.dense.weight")
         n = self.ln(lp + "crossattention.output.LayerNorm")
         c.c, c.rstd_c = self.new(Mq, H), self.new(Mq, dtype=torch.float32)
-        if O.linear_ln_ok(H, H):
-            O.linear_ln(c.cctx, o.W, o.b, Mq, s, n.g, n.b, self.eps, c.c, c.rstd_c, flop_rows=rows)
-        else:
-            co = O.linear_fwd(c.cctx, o.W, o.b, Mq, residual=s, flop_rows=rows)
-            O.ln_fwd(Mq, H, c.c, in0=co, gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_c)
+        self._dense_add_ln(c.cctx, o, s, n, Mq, c.c, c.rstd_c, rows, c.hdrop)
         c.ffn = self._ffn_fwd(lp, c.c, Mq, rows)
         c.out = c.ffn.out
         return c
@@ -292,14 +338,13 @@ class MagicNet:
         Mq, Mk = Bn * Nq, Bn * Nk
         d_c = self._ffn_bwd(lp, c.ffn, dout)
         n = self.ln(lp + "crossattention.output.LayerNorm")
-        d_co = self.new(Mq, H)
-        O.ln_bwd(Mq, H, d_c, y=c.c, gamma=n.g, beta=n.b, rstd=c.rstd_c, dx=d_co, dgamma=n.dg, dbeta=n.db)
+        d_co, d_cod = self._add_ln_bwd(n, Mq, d_c, c.c, c.rstd_c, c.hdrop)
         o = self.lin(lp + "crossattention.output.dense.weight")
-        O.linear_dw(d_co, c.cctx, o.dW, o.db, Mq, flop_rows=c.rows)
-        d_cctx = O.linear_dx(d_co, o.W, Mq, flop_rows=c.rows)
+        O.linear_dw(d_cod, c.cctx, o.dW, o.db, Mq, flop_rows=c.rows)
+        d_cctx = O.linear_dx(d_cod, o.W, Mq, flop_rows=c.rows)
         dq, dkv = self.new(Mq, H), self.new(Mk, 2 * H)
-        self._attn_bwd(c.P, c.ldp, d_cctx, c.q, H, c.kv, c.kv[:, H:], 2 * H, dq, H, dkv, dkv[:, H:], 2 * H,
-                       Bn, Nq, Nk, None, None, dP_init, c.cflops)
+        self._attn_bwd(c.Ppre, c.ldp, d_cctx, c.q, H, c.kv, c.kv[:, H:], 2 * H, dq, H, dkv, dkv[:, H:], 2 * H,
+                       Bn, Nq, Nk, None, None, dP_init, c.cflops, c.adrop, c.P if c.adrop else None)
         ql = self.lin(lp + "crossattention.self.query.weight")
         kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
         O.linear_dw(dq, c.sa.a, ql.dW, ql.db, Mq, flop_rows=c.rows)
@@ -319,11 +364,13 @@ class MagicNet:
         c = Ctx(B=B, L=L)
         n = self.ln(p + "embeddings.LayerNorm")
         c.E, c.rstd_e = self.new(M, H), self.new(M, dtype=torch.float32)
+        c.edrop = self._dh(p + "embeddings.dropout")
+        c.Ed = self.new(M, H) if c.edrop else None
         O.ln_fwd(M, H, c.E, tabs=((self.S.w(p + "embeddings.word_embeddings.weight"), plan["txt_ids"], 0, 0),
                                   (self.S.w(p + "embeddings.position_embeddings.weight"), None, L, 2),
                                   (self.S.w(p + "embeddings.token_type_embeddings.weight"), None, 0, 0)),
-                 gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_e)
-        x = c.E
+                 gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_e, drop_out=c.edrop, out_drop=c.Ed)
+        x = c.Ed if c.edrop else c.E
         c.layers = []
         tl = plan["lens"]["txt"]
         af = self._flops_attn(tl, tl)
@@ -341,7 +388,7 @@ class MagicNet:
         for i in reversed(range(self.cfg.num_l_layers)):
             d = self.self_layer_bwd(f"{p}lang_encoder.layer.{i}.", c.layers[i], d, dP_init if i == self.cfg.num_l_layers - 1 else None)
         n = self.ln(p + "embeddings.LayerNorm")
-        O.ln_bwd(M, H, d, y=c.E, gamma=n.g, beta=n.b, rstd=c.rstd_e, dx=None, dgamma=n.dg, dbeta=n.db,
+        O.ln_bwd(M, H, d, y=c.E, gamma=n.g, beta=n.b, rstd=c.rstd_e, dx=None, dgamma=n.dg, dbeta=n.db, drop_dy=c.edrop,
                  dtabs=((plan["txt_ids"], 0, 0, self.S.g(p + "embeddings.word_embeddings.weight"), 0),
                         (None, c.L, 2, self.S.g(p + "embeddings.position_embeddings.weight"), 0),
                         (None, 0, 0, self.S.g(p + "embeddings.token_type_embeddings.weight"), 0)))
@@ -363,11 +410,13 @@ class MagicNet:
         O.smallk_ln_fwd(M, H, ll.K, loc, ll.Wm, ll.b, n2.g, n2.b, self.eps, c.A2, c.rstd_a2)
         n3 = self.ln(p + "layer_norm")
         c.X0, c.rstd_x0 = self.new(M, H), self.new(M, dtype=torch.float32)
+        c.edrop = self._dh(p + "dropout")
+        c.X0d = self.new(M, H) if c.edrop else None
         O.ln_fwd(M, H, c.X0, in0=c.A1, in1=c.A2,
                  tabs=((self.S.w(p + "nav_type_embedding.weight"), plan["nav_types"], 0, 0),
                        (self.S.w(self.p + "embeddings.token_type_embeddings.weight"), None, 0, 0), None),
-                 gamma=n3.g, beta=n3.b, eps=self.eps, rstd=c.rstd_x0)
-        x = c.X0
+                 gamma=n3.g, beta=n3.b, eps=self.eps, rstd=c.rstd_x0, drop_out=c.edrop, out_drop=c.X0d)
+        x = c.X0d if c.edrop else c.X0
         c.layers = []
         af = float(Np) * V * V * HD * self.nh
         for i in range(self.cfg.num_pano_layers):
@@ -398,7 +447,7 @@ class MagicNet:
             d = self.self_layer_bwd(f"{p}pano_encoder.layer.{i}.", c.layers[i], d, dP_init if i == self.cfg.num_pano_layers - 1 else None)
         n3 = self.ln(p + "layer_norm")
         dsum = self.new(M, H)
-        O.ln_bwd(M, H, d, y=c.X0, gamma=n3.g, beta=n3.b, rstd=c.rstd_x0, dx=dsum, dgamma=n3.dg, dbeta=n3.db,
+        O.ln_bwd(M, H, d, y=c.X0, gamma=n3.g, beta=n3.b, rstd=c.rstd_x0, dx=dsum, dgamma=n3.dg, dbeta=n3.db, drop_dy=c.edrop,
                  dtabs=((plan["nav_types"], 0, 0, self.S.g(p + "nav_type_embedding.weight"), 1),
                         (None, 0, 0, self.S.g(self.p + "embeddings.token_type_embeddings.weight"), 0), None))
         n1 = self.ln(p + "img_layer_norm")

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmagic_hip.so")
 
-vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint
 
 # name -> argument ctypes (mirrors include/magic_hip.h exactly; tests/test_abi.py checks every symbol)
 SIGNATURES = {
@@ -21,18 +21,21 @@ SIGNATURES = {
     "magic_gemm": [i32, i32, i32, i32, i32, i32, i32, vp, i32, i64, i64, vp, i32, i64, i64, vp, i32, i64, i64, i32, i32,
                    vp, i32, vp, i32, vp, i32, vp, i32, f32, i32, vp, vp],
     "magic_gemm_dw_grouped": [i32, i32, vp, vp],
-    "magic_linear_ln": [i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, vp],
-    "magic_ln_fwd": [i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, vp, vp, i32, vp],
+    "magic_linear_ln": [i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, vp, f32, u32, vp],
+    "magic_dropout": [i32, i64, i32, i32, vp, vp, vp, f32, u32, vp],
+    "magic_ln_fwd": [i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, vp, vp, i32,
+                     vp, f32, u32, u32, vp, vp],
     "magic_ln_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32,
-                     vp, i32, i32, vp, i32, i32, vp],
+                     vp, i32, i32, vp, i32, i32, vp, f32, u32, u32, vp, vp],
     "magic_ln_pgrad": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "magic_smallk_ln_fwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp],
     "magic_smallk_ln_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_softmax_fwd": [i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp],
     "magic_softmax_bwd": [i32, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
     "magic_attn_supported": [i32, i32, i32, i32],
-    "magic_attn_fwd": [i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, f32, vp, vp, vp, vp, vp],
-    "magic_attn_bwd": [i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, f32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp],
+    "magic_attn_fwd": [i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, f32, vp, vp, vp, vp, vp, f32, u32, vp, vp],
+    "magic_attn_bwd": [i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, f32, vp, vp, i32, vp, vp, i32, vp, vp, vp,
+                       vp, f32, u32, vp],
     "magic_head_mean_fwd": [i32, i32, i32, i64, vp, vp, vp],
     "magic_head_mean_bwd": [i32, i32, i64, vp, vp, i32, vp],
     "magic_lndot_fwd": [i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],

@@ -264,6 +264,8 @@ class VLNBert(nn.Module):
                                 seed=seed, requires_grad=trainable)
         self.store.attach_to(self)
         self.net = MagicNet(config, self.store, self.prefix)
+        from .model_pretrain import _dropout_knobs
+        _dropout_knobs(self, config)
         self.drop_env = nn.Dropout(p=getattr(args, "feat_dropout", 0.0))      # agent.py:738
         self._anchor = torch.zeros(1, device=self.device_, requires_grad=True)
         self._rows = {}
@@ -279,7 +281,7 @@ class VLNBert(nn.Module):
 
     # shared head helpers (same kernels as the pretraining model)
     from .model_pretrain import GlocalTextPathCMTPreTraining as _P
-    _cls, _cls_bwd = _P._cls, _P._cls_bwd
+    _cls, _cls_bwd, _arm_dropout = _P._cls, _P._cls_bwd, _P._arm_dropout
     del _P
 
     def _first_rows(self, B, N, dev):
@@ -297,6 +299,7 @@ class VLNBert(nn.Module):
 
     def forward(self, mode, batch):
         self.store.sync_shadow()
+        self._arm_dropout()           # vln_bert.train() (agent.py:rollout under feedback='sample') -> config dropouts on
         if mode == "language":
             return _LanguageFn.apply(self._anchor, self, batch["txt_ids"], batch["txt_masks"])
         if mode == "panorama":

@@ -36,6 +36,14 @@ def pretrain_specs(cfg):
     return s
 
 
+def _dropout_knobs(model, config):
+    """Two nn.Dropout modules that compute nothing: they only HOLD the probabilities, so that the reference's
+    `set_dropout(model, p)` (utils/misc.py:19-25: every nn.Dropout module's p := p) and train()/eval() keep working; the
+    masks themselves are generated inside the HIP kernels (csrc/common.hpp)."""
+    model.dropout = nn.Dropout(float(cfg_get(config, "hidden_dropout_prob")))
+    model.attention_dropout = nn.Dropout(float(cfg_get(config, "attention_probs_dropout_prob")))
+
+
 class _BackwardHook(torch.autograd.Function):
     """Lets `loss.backward()` of an unmodified training loop trigger the explicit HIP backward."""
 
@@ -61,6 +69,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                                 init_std=cfg_get(config, "initializer_range"), seed=seed, requires_grad=trainable)
         self.store.attach_to(self)
         self.net = MagicNet(config, self.store, "bert.")
+        _dropout_knobs(self, config)
         self._anchor = torch.zeros(1, device=self.device_, requires_grad=True)
         self._ctx = None
         self._aux = torch.cuda.Stream(device=self.device_) if (self.device_.type == "cuda" and os.environ.get("MAGIC_PAR")) else None   # opt-in: measured slower under HIP-graph replay
@@ -92,6 +101,16 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         m = fn_main()
         cur.wait_stream(self._aux)
         return m, a
+
+    def _arm_dropout(self):
+        """model.train() (train_r2r_magic.py:358) turns the config's dropouts on (r2r_magic_model_config.json:2-3,6); the seed
+        is drawn on the device by torch's graph-safe generator, so a replayed HIP graph gets fresh masks every step."""
+        ph, pa = float(self.dropout.p), float(self.attention_dropout.p)
+        if self.training and self.store.requires_grad and torch.is_grad_enabled() and (ph > 0 or pa > 0):
+            seed = torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int32, device=self.device_)
+            self.net.set_dropout(seed, ph, pa)
+        else:
+            self.net.set_dropout(None)
 
     def mark_params_dirty(self):
         self.store.shadow_clean = False
@@ -136,6 +155,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         n = self.net
         self.store.sync_shadow()
         O.DEFER["queue"].clear()
+        self._arm_dropout()
         plan = plan if plan is not None else build_plan(batch, task, self.device_)
         inp = inputs if inputs is not None else self._inputs(batch, plan)
         B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H

@@ -157,12 +157,25 @@ def linear_ln_ok(H, K=0):
     return FUSED_LN and H in (128, 256, 384) and K <= 512
 
 
-def linear_ln(x, W, b, M, residual, gamma, beta, eps, out, rstd, flop_rows=None):
-    """out = LayerNorm(x @ W^T + b + residual) in one launch (H = W.shape[0] in {128,256,384})."""
+def _dr(drop):
+    """drop = None | (seed uint32[2] device tensor, p, site): counter-based dropout descriptor (csrc/common.hpp DropDesc)"""
+    if drop is None or drop[1] <= 0.0:
+        return (None, 0.0, 0)
+    return (L.P(drop[0]), float(drop[1]), int(drop[2]))
+
+
+def linear_ln(x, W, b, M, residual, gamma, beta, eps, out, rstd, flop_rows=None, drop=None):
+    """out = LayerNorm(dropout(x @ W^T + b) + residual) in one launch (H = W.shape[0] in {128,256,384})."""
     H, K = W.shape
     _count(flop_rows if flop_rows is not None else M, H, K)
     L.call("magic_linear_ln", L.dt(x.dtype), M, H, K, L.P(x), x.stride(0), L.P(W), W.stride(0), L.P(b), L.P(residual),
-           residual.stride(0) if residual is not None else 0, L.P(gamma), L.P(beta), float(eps), L.P(out), L.P(rstd), L.stream())
+           residual.stride(0) if residual is not None else 0, L.P(gamma), L.P(beta), float(eps), L.P(out), L.P(rstd), *_dr(drop), L.stream())
+    return out
+
+
+def dropout(x, out, rows, cols, ld, drop):
+    """out = x * keep / (1-p) with the mask of `drop` over the logical [rows, cols] tensor (row pitch ld); x may be out."""
+    L.call("magic_dropout", L.dt(x.dtype), rows, cols, ld, L.P(x), L.P(out), *_dr(drop), L.stream())
     return out
 
 
@@ -173,10 +186,16 @@ def _tab(t):
     return (L.P(t[0]), L.P(t[1]), int(t[2]), int(t[3]))
 
 
-def ln_fwd(M, H, out, *, in0=None, in1=None, tabs=(None, None, None), gamma=None, beta=None, eps=1e-12, rstd=None, do_ln=True):
+def ln_fwd(M, H, out, *, in0=None, in1=None, tabs=(None, None, None), gamma=None, beta=None, eps=1e-12, rstd=None, do_ln=True,
+           drop_in0=None, drop_out=None, out_drop=None):
+    """drop_in0 / drop_out = (seed, p, site): dropout on in0 before the sum / on the output (written to out_drop)."""
     t0, t1, t2 = [_tab(t) for t in tabs]
+    d = drop_in0 if (drop_in0 is not None and drop_in0[1] > 0) else drop_out
+    seed, p, _ = _dr(d)
+    s_in = int(drop_in0[2]) if (p > 0 and drop_in0 is not None) else 0
+    s_out = int(drop_out[2]) if (p > 0 and drop_out is not None) else 0
     L.call("magic_ln_fwd", L.dt(out.dtype), M, H, L.P(in0), L.P(in1), *t0, *t1, *t2,
-           L.P(gamma), L.P(beta), float(eps), L.P(out), L.P(rstd), 1 if do_ln else 0, L.stream())
+           L.P(gamma), L.P(beta), float(eps), L.P(out), L.P(rstd), 1 if do_ln else 0, seed, p, s_in, s_out, L.P(out_drop), L.stream())
     return out
 
 
@@ -191,14 +210,19 @@ SPLIT_PGRAD = bool(os.environ.get("MAGIC_SPLIT_PGRAD"))     # opt-in: measured n
 
 
 def ln_bwd(M, H, dy, *, y=None, gamma=None, beta=None, rstd=None, dx=None, dgamma=None, dbeta=None,
-           dtabs=(None, None, None), do_ln=True):
+           dtabs=(None, None, None), do_ln=True, drop_dy=None, drop_dx=None, dxm=None):
+    """drop_dy: the forward dropped its output (dy masked on load); drop_dx: the forward dropped in0 (dxm = dx * mask)."""
     d0, d1, d2 = [_dtab(t) for t in dtabs]
+    dd = drop_dy if (drop_dy is not None and drop_dy[1] > 0) else drop_dx
+    seed, p, _ = _dr(dd)
+    s_dy = int(drop_dy[2]) if (p > 0 and drop_dy is not None) else 0
+    s_dx = int(drop_dx[2]) if (p > 0 and drop_dx is not None) else 0
     if do_ln and dgamma is not None and SPLIT_PGRAD and M >= 512:
         # row kernel fully parallel (no same-address atomics) + a separate low-contention column reduction
         L.call("magic_ln_pgrad", L.dt(dy.dtype), M, H, L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(dgamma), L.P(dbeta), L.stream())
         dgamma = dbeta = None
     L.call("magic_ln_bwd", L.dt(dy.dtype), M, H, L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(dx),
-           L.P(dgamma), L.P(dbeta), *d0, *d1, *d2, 1 if do_ln else 0, L.stream())
+           L.P(dgamma), L.P(dbeta), *d0, *d1, *d2, 1 if do_ln else 0, seed, p, s_dy, s_dx, L.P(dxm), L.stream())
     return dx
 
 
@@ -235,19 +259,20 @@ def attn_supported(dtype, Nq, Nk, backward):
     return _ATTN_OK[key]
 
 
-def attn_fwd(q, ldq, k, v, ldkv, Pm, ldp, ctx, B, nh, Nq, Nk, H, scale, kmask=None, dist=None, sprel_w=None, sprel_b=None, flops=0.0):
+def attn_fwd(q, ldq, k, v, ldkv, Pm, ldp, ctx, B, nh, Nq, Nk, H, scale, kmask=None, dist=None, sprel_w=None, sprel_b=None, flops=0.0,
+             drop=None, Pd=None):
     if FLOPS["enabled"]:
         FLOPS["total"] += 4.0 * flops
     L.call("magic_attn_fwd", L.dt(q.dtype), B, nh, Nq, Nk, L.P(q), ldq, L.P(k), L.P(v), ldkv, L.P(Pm), ldp, L.P(ctx), H, float(scale),
-           L.P(kmask), L.P(dist), L.P(sprel_w), L.P(sprel_b), L.stream())
+           L.P(kmask), L.P(dist), L.P(sprel_w), L.P(sprel_b), *_dr(drop), L.P(Pd), L.stream())
 
 
 def attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, dctx, B, nh, Nq, Nk, H, scale, dP_init, dq, lddq, dk, dv, lddkv, dist=None, dsprel_w=None,
-             dsprel_b=None, flops=0.0):
+             dsprel_b=None, flops=0.0, drop=None):
     if FLOPS["enabled"]:
         FLOPS["total"] += 8.0 * flops
     L.call("magic_attn_bwd", L.dt(q.dtype), B, nh, Nq, Nk, L.P(q), ldq, L.P(k), L.P(v), ldkv, L.P(Pm), ldp, L.P(dctx), H, float(scale),
-           L.P(dP_init), L.P(dq), lddq, L.P(dk), L.P(dv), lddkv, L.P(dist), L.P(dsprel_w), L.P(dsprel_b), L.stream())
+           L.P(dP_init), L.P(dq), lddq, L.P(dk), L.P(dv), lddkv, L.P(dist), L.P(dsprel_w), L.P(dsprel_b), *_dr(drop), L.stream())
 
 
 def head_mean_fwd(Pm, out, B, nh, inner):

@@ -16,7 +16,7 @@ KDL = dict(knowledge_distillation=True, kd_alpha=0.5, kd_temperature=2, teacher_
 def run_smoke():
     from oracle import model_ref as R          # checker only
     L.load()
-    kw = dict(vocab_size=500, num_l_layers=2, num_x_layers=1, num_pano_layers=1)
+    kw = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=500, num_l_layers=2, num_x_layers=1, num_pano_layers=1)
     tcfg = make_config(256, role="teacher", **kw)
     scfg = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL, **kw)
     torch.manual_seed(0)

@@ -302,6 +302,9 @@ class RefPretrainModel(nn.Module):
         self.local_sap_head = ClsPrediction(H, eps=eps)
         self.sap_fuse_linear = ClsPrediction(H, 2 * H, eps=eps)
         self.cfp_heads = nn.ModuleDict({k: nn.Linear(H, H) for k in ("gmap", "vp", "fused", "txt")})
+        if "mrc" in (getattr(cfg, "pretrain_tasks", None) or ()):      # built only when the task is configured (train_r2r_magic.py:104-107)
+            self.image_classifier = nn.Module()                            # RegionClassification(H, image_prob_size)
+            self.image_classifier.net = nn.Sequential(nn.Linear(H, H), nn.ReLU(), _ln(H, eps), nn.Linear(H, cfg.image_prob_size))
         self.apply(self._init)
         name_modules(self)
 
@@ -381,6 +384,18 @@ class RefPretrainModel(nn.Module):
             per = F.cross_entropy(gl, ga, reduction="none") + F.cross_entropy(ll, la, reduction="none", ignore_index=-100) \
                 + F.cross_entropy(fl, ga, reduction="none")
             sup = per.mean()
+        elif task == "mrc":
+            # masked-region classification on the current viewpoint's views: local branch only (validate_mrc,
+            # train_r2r_magic.py:476-500: returns (view_logits, view_targets, obj_logits, obj_targets); obj_prob_size is 0)
+            o = self.trunk(batch, need_global=False)
+            mm = batch["vp_view_mrc_masks"]
+            x = o["vp_embeds"][:, 1:1 + mm.shape[1]][mm]          # [stop] token sits at position 0
+            logits = self.image_classifier.net(x)
+            tgt = batch["vp_view_probs"][mm].to(logits.dtype)
+            o["predict"] = logits
+            if not compute_loss:
+                return logits, tgt, None, None
+            sup = F.kl_div(F.log_softmax(logits, -1), tgt, reduction="none").sum(1).mean()
         elif task == "cfp":
             o = self.trunk(batch)
             h = self.cfp_heads

@@ -230,6 +230,56 @@ def mint_pretrain_side():
         del sys.modules[k]
 
 
+def mint_mrc():
+    """collate_mrc.pt: the reference's MRC item construction (_get_img_mask / _mask_img_feat, tasks.py:168-181, used by
+    MrcDataset.__getitem__ :205-221) and mrc_collate (:263-310) on our synthetic samples, plus validate_mrc's two
+    numbers (KL sum and soft-target accuracy, train_r2r_magic.py:470-489) restated from the reference primitives."""
+    sys.path.insert(0, f"{REF}/pretrain_src")
+    stub(["pynvml", "jsonlines", "h5py", "nltk", "lmdb", "msgpack_numpy", "tensorboardX", "easydict", "progressbar"])
+    sys.modules["msgpack_numpy"].patch = lambda: None
+    import random
+    import magic_amd  # noqa: F401
+    from magic_amd.host import synth
+    from data import tasks as T
+    rng = np.random.default_rng([99, 0])
+    pyrng = random.Random(99)
+    samples = [synth.make_sample(rng, pyrng, uid=i, min_len=5, max_len=12, min_steps=2, max_steps=4) for i in range(3)]
+    items = []
+    mrng = np.random.default_rng(11)
+    for s in samples:
+        it = {k: v for k, v in s.items() if k not in ("local_act_labels", "global_act_labels")}
+        nv = it["traj_view_img_fts"][-1].shape[0]
+        m = mrng.random(nv) < 0.15                       # the draw order synth.collate('mrc') uses
+        if not m.any():
+            m[int(mrng.integers(0, nv))] = True
+        m = torch.from_numpy(m)
+        views = list(it["traj_view_img_fts"])
+        views[-1] = T._mask_img_feat(views[-1], m)       # reference masking primitive
+        it["traj_view_img_fts"] = views
+        it["vp_view_mrc_masks"] = m
+        it["vp_view_probs"] = torch.softmax(torch.from_numpy(mrng.standard_normal((nv, 1000)).astype(np.float32)) * 2, -1)
+        it["vp_angles"] = None
+        items.append(it)
+    batch = T.mrc_collate([dict(x) for x in items])
+    keep = {k: v for k, v in batch.items() if torch.is_tensor(v) or isinstance(v, (list, type(None)))}
+    # reference target extraction (tasks.py:183-187) = what the model is expected to return as view_targets
+    targets = T._get_targets(batch["vp_view_probs"], batch["vp_view_mrc_masks"])
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(targets.shape[0], 1000, generator=g)
+    import torch.nn.functional as F
+    kl = F.kl_div(F.log_softmax(logits, dim=-1), targets, reduction="sum")            # validate_mrc :484-485
+    n_correct = (logits.max(dim=-1)[1] == targets.max(dim=-1)[1]).sum().item()          # compute_accuracy_for_soft_targets :470-474
+    ref = torch.load(os.path.join(HERE, "collate.pt"), weights_only=False)["samples"]      # same seeds -> same samples: not stored twice
+    assert all(torch.equal(a["txt_ids"], b["txt_ids"]) and torch.equal(a["traj_view_img_fts"][-1], b["traj_view_img_fts"][-1])
+               for a, b in zip(samples, ref))
+    torch.save(dict(seed=11, mrc=keep, targets=targets, logits=logits, kl_sum=float(kl), n_correct=int(n_correct)),
+               os.path.join(HERE, "collate_mrc.pt"))
+    print("collate_mrc ok", sorted(keep.keys()), float(kl), n_correct)
+    sys.path.remove(f"{REF}/pretrain_src")
+    for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "data", "optim", "parser")]:
+        del sys.modules[k]
+
+
 def mint_ops():
     O = load_by_path("ref_ops", f"{REF}/map_nav_src/utils/ops.py")
     g = torch.Generator().manual_seed(2)
@@ -241,6 +291,9 @@ def mint_ops():
 
 
 if __name__ == "__main__":
+    if "--mrc-only" in sys.argv:
+        mint_mrc()
+        sys.exit(0)
     mint_primitives()
     mint_ops()
     mint_agent()

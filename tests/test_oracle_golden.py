@@ -121,3 +121,38 @@ def test_seq_masks_and_padding(golden_dir):
     import magic_amd  # noqa: F401
     from magic_amd.host.synth import _pad_stack
     assert torch.equal(_pad_stack(fx["ts"]), fx["padded"])
+
+
+def test_mrc_collate_and_validate_arithmetic_match_reference(golden_dir):
+    """synth.collate('mrc') vs the reference's MrcDataset masking + mrc_collate; oracle/engine target extraction order and
+    validate_mrc's KL-sum / soft-target accuracy vs numbers computed with the reference's primitives."""
+    import numpy as np
+    import torch.nn.functional as F
+    import magic_amd  # noqa: F401
+    from magic_amd.host import synth
+    from magic_amd.host.plan import build_plan
+    fx = _load(golden_dir, "collate_mrc.pt")
+    samples = _load(golden_dir, "collate.pt")["samples"]
+    got = synth.collate(samples, "mrc", rng=np.random.default_rng(fx["seed"]))
+    for k, v in fx["mrc"].items():
+        if k == "vp_angles":
+            continue
+        if torch.is_tensor(v):
+            assert got[k].dtype == v.dtype and got[k].shape == v.shape, k
+            assert torch.equal(got[k], v), k
+        else:
+            assert got[k] == v, k
+    # the masked rows really are zeroed in the last panorama of each sample, and nowhere else
+    last = torch.tensor(got["traj_step_lens"]).cumsum(0) - 1
+    z = (got["traj_view_img_fts"][last].abs().sum(-1) == 0)
+    assert torch.equal(z, got["vp_view_mrc_masks"])
+    # target order = boolean-mask order (tasks.py:183-187); the plan gathers rows b*Vp + 1 + v in the same order
+    plan = build_plan(got, "mrc", torch.device("cpu"))
+    assert torch.equal(plan["mrc_targets"], fx["targets"])
+    rows = plan["mrc_rows"][1][: plan["n_mrc"]]
+    bv = torch.nonzero(got["vp_view_mrc_masks"])
+    assert torch.equal(rows.long(), bv[:, 0] * plan["Vp"] + 1 + bv[:, 1])
+    # validate_mrc arithmetic on the fixture logits
+    kl = F.kl_div(F.log_softmax(fx["logits"], -1), plan["mrc_targets"], reduction="sum")
+    assert abs(float(kl) - fx["kl_sum"]) < 1e-4
+    assert int((fx["logits"].argmax(-1) == plan["mrc_targets"].argmax(-1)).sum()) == fx["n_correct"]

@@ -15,9 +15,10 @@ KDL = dict(knowledge_distillation=True, kd_alpha=0.5, kd_temperature=2, teacher_
 
 
 def small_cfgs(vocab=1000):
-    t = make_config(128, role="teacher", vocab_size=vocab, num_l_layers=2, num_x_layers=1, num_pano_layers=1)
+    tasks = {"mlm", "mrc", "sap", "cfp"}
+    t = make_config(128, role="teacher", vocab_size=vocab, num_l_layers=2, num_x_layers=1, num_pano_layers=1, pretrain_tasks=tasks)
     s = make_config(64, role="student", teacher_hidden_size=128, vocab_size=vocab, num_l_layers=2, num_x_layers=1,
-                    num_pano_layers=1, kdl=KDL)
+                    num_pano_layers=1, kdl=KDL, pretrain_tasks=tasks)
     return t, s
 
 
@@ -41,7 +42,7 @@ def test_self_layer_matches_hf_bertlayer():
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("task", ["mlm", "sap", "cfp"])
+@pytest.mark.parametrize("task", ["mlm", "mrc", "sap", "cfp"])
 def test_oracle_forward_contract(task):
     torch.manual_seed(0)
     tcfg, scfg = small_cfgs()
@@ -57,6 +58,10 @@ def test_oracle_forward_contract(task):
     inf = student(batch, task, compute_loss=False)
     if task == "mlm":
         assert inf["predict"].shape == (int((batch["txt_labels"] != -1).sum()), 1000)
+    elif task == "mrc":
+        n = int(batch["vp_view_mrc_masks"].sum())
+        assert inf[0].shape == (n, 1000) and inf[1].shape == (n, 1000) and inf[2] is None and inf[3] is None
+        assert torch.allclose(inf[1].sum(1), torch.ones(n), atol=1e-5)
     elif task == "sap":
         B, K = batch["gmap_step_ids"].shape
         assert inf["fused_logits"].shape == (B, K)

@@ -50,6 +50,42 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int M, int N, const T* log
   }
 }
 
+
+// Soft-target KL rows (MRC head: F.kl_div(log_softmax(logits), targets, 'none').sum(1), train_r2r_magic.py:484-485):
+//   loss_row = sum_j t_j (log t_j - log p_j)   (t_j = 0 contributes 0) ;   dlogits = coef * ((sum_j t_j) p - t)
+// targets fp32 [M, N] (row pitch ldt); one block per row.
+template <typename T>
+__global__ __launch_bounds__(256) void softkl_rows_kernel(int M, int N, const T* logits, int ld, const float* targets, int ldt,
+                                                          float coef, float* loss_row, T* dlogits, int ldd) {
+  __shared__ float red[12];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const T* x = logits + (long long)row * ld;
+  const float* t = targets + (long long)row * ldt;
+  float mx = -3.0e38f;
+  for (int c = tid; c < N; c += 256) mx = fmaxf(mx, to_f(x[c]));
+  mx = wave_max(mx);
+  if (lane == 0) red[wid] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f, st = 0.f, a = 0.f;            // sum exp, sum t, sum t (log t - x)
+  for (int c = tid; c < N; c += 256) {
+    const float xv = to_f(x[c]), tv = t[c];
+    s += __expf(xv - mx); st += tv;
+    if (tv > 0.f) a += tv * (__logf(tv) - xv);
+  }
+  s = wave_sum(s); st = wave_sum(st); a = wave_sum(a);
+  if (lane == 0) { red[wid] = s; red[4 + wid] = st; red[8 + wid] = a; }
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3]; st = red[4] + red[5] + red[6] + red[7]; a = red[8] + red[9] + red[10] + red[11];
+  const float lse = mx + __logf(s);
+  if (tid == 0 && loss_row) loss_row[row] = a + st * lse;      // sum t (log t - x + lse)
+  if (dlogits) {
+    T* d = dlogits + (long long)row * ldd;
+    for (int c = tid; c < ldd; c += 256) d[c] = from_f<T>(c < N ? coef * (st * __expf(to_f(x[c]) - lse) - t[c]) : 0.f);
+  }
+}
+
 // KD rows: fp32 logits [M,N], N <= 512 (action space).  one wave per row.
 // loss_row = w * sum_j p_t (log p_t - log p_s) * T^2 * norm ;  ds (+)= coef * w * T * (p_s - p_t) * norm
 __global__ __launch_bounds__(256) void kd_rows_kernel(int M, int N, const float* s, const float* t, int ld, float temperature,
@@ -141,6 +177,19 @@ extern "C" int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld
     hipLaunchKernelGGL(ce_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, accumulate, w_out, w_rate);
   else
     hipLaunchKernelGGL(ce_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (float*)dlogits, ldd, accumulate, w_out, w_rate);
+  return launch_status();
+}
+
+extern "C" int magic_softkl_rows(int dtype, int M, int N, const void* logits, int ld, const float* targets, int ldt, float coef,
+                                 float* loss_row, void* dlogits, int ldd, void* stream) {
+  if (M <= 0 || N <= 0 || ld < N || ldt < N || !logits || !targets || (dlogits && ldd < N) || dlogits == logits) return MAGIC_ERR_ARG;
+  dim3 grid(M), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(softkl_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, targets, ldt, coef, loss_row, (bf16*)dlogits, ldd);
+  else if (dtype == DT_F32)
+    hipLaunchKernelGGL(softkl_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, targets, ldt, coef, loss_row, (float*)dlogits, ldd);
+  else return MAGIC_ERR_ARG;
   return launch_status();
 }
 

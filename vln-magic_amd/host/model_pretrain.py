@@ -33,6 +33,11 @@ def pretrain_specs(cfg):
     s += cls_specs("global_sap_head.", H) + cls_specs("local_sap_head.", H) + cls_specs("sap_fuse_linear.", H, 2 * H)
     for k in ("gmap", "vp", "fused", "txt"):
         s += [(f"cfp_heads.{k}.weight", (H, H), "normal"), (f"cfp_heads.{k}.bias", (H,), "zeros")]
+    if "mrc" in (getattr(cfg, "pretrain_tasks", None) or ()):     # RegionClassification(H, image_prob_size), only when configured
+        P = int(cfg_get(cfg, "image_prob_size"))
+        s += [("image_classifier.net.0.weight", (H, H), "normal"), ("image_classifier.net.0.bias", (H,), "zeros"),
+              ("image_classifier.net.2.weight", (H,), "ones"), ("image_classifier.net.2.bias", (H,), "zeros"),
+              ("image_classifier.net.3.weight", (P, H), "normal"), ("image_classifier.net.3.bias", (P,), "zeros")]
     return s
 
 
@@ -162,7 +167,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         c = Ctx(task=task, plan=plan, inp=inp)
         # the text and panorama encoders are independent: run them on two streams
         c.txt, c.pano = self._par(lambda: n.text_fwd(plan), lambda: n.pano_fwd(plan, inp.feats, inp.loc))
-        c.gin = n.gmap_in_fwd(plan, c.pano, inp.gpos)
+        c.gin = n.gmap_in_fwd(plan, c.pano, inp.gpos) if task != "mrc" else None
         tl, gl_, vl = plan["lens"]["txt"], plan["lens"]["gmap"], [Vp] * B
         o = dict(txt_embeds=c.txt.out, txt_attns=c.txt.P, pano_embeds=c.pano.out, pano_fused_embeds=c.pano.fused,
                  img_attns=c.pano.img_attn, plan=plan, inputs=inp)
@@ -187,6 +192,21 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             O.linear_fwd(c.hm, self.store.w("bert.embeddings.word_embeddings.weight"), self.store.master("mlm_head.predictions.bias"),
                          nm, out=c.logits, ldc=c.ldv)
             o["predict"] = c.logits[:, :Vv]
+        elif task == "mrc":
+            # local branch only; RegionClassification on the masked views of the current viewpoint (validate_mrc :476-500)
+            c.vin = n.vp_in_fwd(plan, c.pano, inp.vpos)
+            c.loc = n.cross_fwd("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
+            o.update(vp_embeds=c.loc.out, vp_attns=c.loc.P)
+            nm = plan["n_mrc"]
+            c.mx = n.new(nm, H)
+            O.csr_gather(c.loc.out, *plan["mrc_rows"], c.mx, nm, H)
+            l1, l2 = n.lin("image_classifier.net.0.weight"), n.lin("image_classifier.net.3.weight")
+            c.mY = O.linear_fwd(c.mx, l1.W, l1.b, nm, epilogue=2)
+            ln = n.ln("image_classifier.net.2")
+            c.mZ, c.m_rstd = n.new(nm, H), n.new(nm, dtype=torch.float32)
+            O.ln_fwd(nm, H, c.mZ, in0=c.mY, gamma=ln.g, beta=ln.b, eps=n.eps, rstd=c.m_rstd)
+            c.mlogits = O.linear_fwd(c.mZ, l2.W, l2.b, nm)
+            o["predict"] = c.mlogits
         else:
             def _local():
                 vin = n.vp_in_fwd(plan, c.pano, inp.vpos)
@@ -235,6 +255,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 return o
             if task == "mlm":
                 return {"predict": o["predict"]}
+            if task == "mrc":
+                return c.mlogits, plan["mrc_targets"], None, None
             if task == "sap":
                 return dict(global_logits=c.gl, local_logits=c.ll, fused_logits=c.fl,
                             global_act_labels=self._dev(batch["global_act_labels"]), local_act_labels=self._dev(batch["local_act_labels"]))
@@ -309,6 +331,13 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             if train and not self.keep_mlm_logits:
                 o["predict"] = None          # overwritten in place by its gradient
             sup = c.rows.sum() / nm
+        elif task == "mrc":
+            c.d_vp = zz(B * Vp, H)
+            nm, Pn = plan["n_mrc"], c.mlogits.shape[1]
+            c.rows = n.new(nm, dtype=torch.float32)
+            c.dmlogits = n.new(nm, Pn) if train else None
+            O.softkl_rows(c.mlogits, nm, Pn, Pn, plan["mrc_targets"], coef=sc / nm, loss_row=c.rows, dlogits=c.dmlogits, ldd=Pn)
+            sup = c.rows.sum() / nm
         else:
             c.d_gmap, c.d_vp = zz(B * K, H), zz(B * Vp, H)
             temp = float(cfg_get(cfg, "cfp_temperature"))
@@ -365,7 +394,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                     if train:
                         c.dP_pano = n.new(Np, nh_s, V, ldp, dtype=torch.float32)
                         O.head_mean_bwd(g, c.dP_pano, Np, nh_s, V * ldp)
-            if "global" in tasks:
+            if "global" in tasks and task != "mrc":
                 if task == "mlm":
                     x, Pm, Nq, Nk, ldp, d_acc = c.l2v.out, c.l2v.P, L, K, c.l2v.ldp, c.d_x
                 else:
@@ -463,13 +492,27 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             d_gin = n.zeros(B * K, H)
             d_t2 = n.cross_bwd(c.l2v, c.d_x, d_gin, c.dP_g)
             O.add_(c.d_txt, d_t2)
+        elif task == "mrc":
+            nm = plan["n_mrc"]
+            l1, ln, l2 = n.lin("image_classifier.net.0.weight"), n.ln("image_classifier.net.2"), n.lin("image_classifier.net.3.weight")
+            O.linear_dw(c.dmlogits, c.mZ, l2.dW, l2.db, nm)
+            dZ = O.linear_dx(c.dmlogits, l2.W, nm)
+            dY = n.new(nm, H)
+            O.ln_bwd(nm, H, dZ, y=c.mZ, gamma=ln.g, beta=ln.b, rstd=c.m_rstd, dx=dY, dgamma=ln.dg, dbeta=ln.db)
+            dpre = O.dact(dY, c.mY, 2)                 # relu'(pre) == relu'(relu(pre))
+            O.linear_dw(dpre, c.mx, l1.dW, l1.db, nm)
+            dmx = O.linear_dx(dpre, l1.W, nm)
+            O.csr_gather(dmx, *plan["mrc_rows_T"], c.d_vp, B * Vp, H, accumulate=True)
+            d_vin = n.cross_bwd(c.loc, c.d_vp, c.d_txt, c.dP_l)
+            n.vp_in_bwd(c.vin, plan, d_vin, c.d_pano)
         else:
             d_txt2 = n.zeros(B * L, H)           # the two encoders accumulate their text gradients separately (no race)
             d_gin, d_vin = self._par(lambda: n.cross_bwd(c.glob, c.d_gmap, c.d_txt, c.dP_g),
                                      lambda: n.cross_bwd(c.loc, c.d_vp, d_txt2, c.dP_l))
             O.add_(c.d_txt, d_txt2)
             n.vp_in_bwd(c.vin, plan, d_vin, c.d_pano)
-        n.gmap_in_bwd(c.gin, plan, d_gin, c.d_pano, c.d_fused)
+        if task != "mrc":
+            n.gmap_in_bwd(c.gin, plan, d_gin, c.d_pano, c.d_fused)
         self._par(lambda: n.text_bwd(c.txt, plan, c.d_txt, c.dP_txt),
                   lambda: n.pano_bwd(c.pano, plan, c.d_pano, c.d_fused, c.dP_pano))
         O.flush_dw()                           # deferred weight-gradient GEMMs, ~8 problems per launch

@@ -299,6 +299,13 @@ def ce_rows(logits, M, N, ld, labels, *, ignore_index=-100, coef=0.0, row_w=None
            L.P(loss_row), L.P(dlogits), ldd, 1 if accumulate else 0, L.P(w_out), float(w_rate), L.stream())
 
 
+def softkl_rows(logits, M, N, ld, targets, *, coef=0.0, loss_row=None, dlogits=None, ldd=0):
+    """per-row KL(targets || softmax(logits)) and its coef-scaled gradient (MRC head)"""
+    _chk(targets.dtype == torch.float32 and targets.stride(-1) == 1, "softkl targets fp32")
+    L.call("magic_softkl_rows", L.dt(logits.dtype), M, N, L.P(logits), ld, L.P(targets), targets.stride(0), float(coef),
+           L.P(loss_row), L.P(dlogits), ldd, L.stream())
+
+
 def kd_rows(s, t, M, N, ld, temperature, *, w=None, norm=1.0, coef=0.0, coef_dev=None, loss_row=None, ds=None, accumulate=False):
     _chk(s.dtype == torch.float32 and t.dtype == torch.float32, "kd logits fp32")
     L.call("magic_kd_rows", M, N, L.P(s), L.P(t), ld, float(temperature), L.P(w), float(norm), float(coef), L.P(coef_dev), L.P(loss_row),

@@ -117,12 +117,20 @@ def build_plan(batch, task, device, ld_round=8):
         plan_csr["mlm_rows"] = csr_pair([(i, int(r), 1.0) for i, r in enumerate(sel.tolist())], n_mask, B * L)
         cpu["mlm_labels"] = lab[sel].to(torch.int32)
 
+    n_mrc = 0
+    if task == "mrc":       # masked views of the current viewpoint: row b*Vp + 1 + v of the local encoder output ([stop] at 0)
+        mm = batch["vp_view_mrc_masks"]
+        sel = torch.nonzero(mm)                      # row-major == boolean-mask order of _compute_masked_hidden
+        n_mrc = int(sel.shape[0])
+        plan_csr["mrc_rows"] = csr_pair([(i, int(b_) * Vp + 1 + int(v_), 1.0) for i, (b_, v_) in enumerate(sel.tolist())], n_mrc, B * Vp)
+        cpu["mrc_targets"] = batch["vp_view_probs"][mm].float().contiguous()
+
     plan = {k: v.to(device, non_blocking=True) for k, v in cpu.items()}
     for name, (f, t) in plan_csr.items():
         plan[name] = tuple(torch.from_numpy(a).to(device, non_blocking=True) for a in f)
         plan[name + "_T"] = tuple(torch.from_numpy(a).to(device, non_blocking=True) for a in t)
     plan.update(B=B, L=L, K=K, Vp=Vp, Np=Np, V=V, last_rows=last_rows,
-                n_mask=(int(plan["mlm_labels"].numel()) if task == "mlm" else 0),
+                n_mask=(int(plan["mlm_labels"].numel()) if task == "mlm" else 0), n_mrc=n_mrc,
                 txt_tokens=int(txt_lens.sum()), gmap_nodes=int(batch["gmap_lens"].sum()), traj_steps=Np,
                 lens=dict(txt=txt_lens.tolist(), gmap=batch["gmap_lens"].tolist(), steps=list(step_lens)))
     return plan

@@ -126,8 +126,8 @@ def _pad_stack(ts, pad=0):
     return out
 
 
-def collate(samples, task, rng=None, vocab=50265):
-    """Same layout as {mlm,sap,cfp}_collate (tasks.py:110-176, :392-451, :618-678)."""
+def collate(samples, task, rng=None, vocab=50265, mrc_mask_prob=0.15, prob_size=1000):
+    """Same layout as {mlm,mrc,sap,cfp}_collate (tasks.py:110-176, :263-310, :392-451, :618-678)."""
     b = {}
     txt = [s["txt_ids"] for s in samples]
     if task == "mlm":
@@ -136,6 +136,22 @@ def collate(samples, task, rng=None, vocab=50265):
         b["txt_labels"] = _pad_stack([p[1] for p in pairs], -1)
     b["txt_lens"] = torch.tensor([len(t) for t in txt], dtype=torch.long)
     b["txt_ids"] = _pad_stack(txt, 0)
+    if task == "mrc":        # MrcDataset.__getitem__ (tasks.py:205-221): mask views of the LAST panorama, keep their soft labels
+        samples = [dict(s) for s in samples]
+        masks, probs = [], []
+        for s in samples:
+            nv = s["traj_view_img_fts"][-1].shape[0]
+            m = rng.random(nv) < mrc_mask_prob
+            if not m.any():
+                m[int(rng.integers(0, nv))] = True          # at least one (tasks.py:170-175)
+            m = torch.from_numpy(m)
+            views = list(s["traj_view_img_fts"])
+            views[-1] = views[-1].masked_fill(m[:, None], 0)     # _mask_img_feat (tasks.py:177-181)
+            s["traj_view_img_fts"] = views
+            masks.append(m)
+            probs.append(torch.softmax(torch.from_numpy(rng.standard_normal((nv, prob_size)).astype(np.float32)) * 2, -1))
+        b["vp_view_mrc_masks"] = _pad_stack(masks, False)
+        b["vp_view_probs"] = _pad_stack(probs, 0)
     b["traj_step_lens"] = [len(s["traj_view_img_fts"]) for s in samples]
     b["traj_vp_view_lens"] = torch.tensor(
         sum([[len(y) for y in s["traj_view_img_fts"]] for s in samples], []), dtype=torch.long)

@@ -204,3 +204,61 @@ def test_drop_in_kd_primitives_match_reference_golden_vectors(golden_dir):
     chk(K.invert_normalized_losses(fx["losses"].to(DEV)), c["invert_norm"], "invert")
     with pytest.raises(magic_amd.host.lib.MagicHipError):
         K.mse_loss(fs.cpu(), ft.cpu())
+
+
+def test_critic_head_api_and_numerics():
+    """agent.py:39 `Critic(args).cuda()`, agent_base.py:116-139 (.parameters() into an optimizer, .train(), state_dict)."""
+    from types import SimpleNamespace
+    from magic_amd.host.model_nav import Critic
+    args = SimpleNamespace(hidden_size=128, dropout=0.0)
+    c = Critic(args, compute_dtype=torch.float32).cuda()
+    sd = c.state_dict()
+    assert set(sd) == {"state2value.0.weight", "state2value.0.bias", "state2value.3.weight", "state2value.3.bias"}
+    x = torch.randn(6, 128, device=DEV, requires_grad=True)
+    w0, b0, w3, b3 = (sd[k].clone() for k in ("state2value.0.weight", "state2value.0.bias", "state2value.3.weight", "state2value.3.bias"))
+    c.train()
+    v = c(x)
+    xr = x.detach().clone().requires_grad_(True)
+    want = (torch.relu(xr @ w0.t() + b0) @ w3.t() + b3).squeeze()
+    assert v.shape == (6,) and torch.allclose(v, want, rtol=1e-4, atol=1e-5)
+    opt = torch.optim.AdamW(c.parameters(), lr=1e-3)
+    opt.zero_grad()
+    v.sum().backward()
+    want.sum().backward()
+    assert torch.allclose(x.grad, xr.grad, rtol=1e-4, atol=1e-5)
+    g0 = dict(c.named_parameters())["state2value.0.weight"].grad
+    assert g0 is not None and g0.abs().max() > 0
+    opt.step()
+    assert not torch.equal(c.state_dict()["state2value.0.weight"], w0)
+
+
+def test_unmodified_loop_with_a_torch_optimizer_zero_grad_none_and_bf16_shadow():
+    """The reference loops call `optimizer.zero_grad()` (torch >= 2: grads become None) and step a stock torch optimizer
+    (agent_base.py:128-139, optim/misc.py:12-37).  Gradients must reappear as views of the flat buffer, must not
+    accumulate across steps, and the bf16 shadow weights must follow the optimizer's in-place update."""
+    from magic_amd.host import synth
+    from magic_amd.host.model_pretrain import GlocalTextPathCMTPreTraining
+    kw = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=300, num_l_layers=1, num_x_layers=1, num_pano_layers=1)
+    model = GlocalTextPathCMTPreTraining(make_config(128, **kw), device=DEV, compute_dtype=torch.bfloat16, seed=3)
+    opt = torch.optim.AdamW(model.parameters(), lr=3e-4)
+    batch = synth.make_batch("sap", batch_size=4, seed=2, vocab=300, min_len=6, max_len=10, min_steps=2, max_steps=3)
+    name = "bert.lang_encoder.layer.0.attention.self.query.weight"
+    p = dict(model.named_parameters())[name]
+    grads, losses = [], []
+    for it in range(3):
+        opt.zero_grad()                                   # set_to_none=True
+        assert p.grad is None
+        out = model(batch, "sap", compute_loss=True)
+        out["loss"].backward()
+        assert p.grad is not None and p.grad.data_ptr() == model.store.g(name).data_ptr()
+        grads.append(p.grad.clone())
+        losses.append(float(out["loss"].detach()))
+        before = p.detach().clone()
+        opt.step()
+        assert not torch.equal(before, p.detach())
+    # same batch, tiny steps: gradient magnitudes stay comparable (no accumulation: 3rd would be ~3x the 1st)
+    r = grads[2].norm().item() / grads[0].norm().item()
+    assert 0.3 < r < 1.8, r
+    assert losses[2] < losses[0]                          # the bf16 weights the kernels read follow the torch optimizer
+    model(batch, "sap", compute_loss=False)
+    assert torch.equal(model.store.w(name).float(), p.detach().to(torch.bfloat16).float())

@@ -51,6 +51,7 @@ class _HipLinearFn(torch.autograd.Function):
         net, lin = ctx.mod._net, ctx.mod._lin
         M = ctx.x.shape[0]
         d = dy.to(net.dtype).reshape(M, lin.N).contiguous()
+        net.S.ensure_grads()
         if net.train:
             O.linear_dw(d, ctx.x, lin.dW, lin.db, M)
         dx = O.linear_dx(d, lin.W, M)
@@ -62,6 +63,38 @@ class HipLinear(nn.Module):
 
     def forward(self, x):
         return _HipLinearFn.apply(x, self)
+
+
+class Critic(nn.Module):
+    """`Critic(args)` of the withheld models/model.py (agent.py:30,39): the A2C value head the agent constructs, puts in
+    `self.models` / `critic_optimizer` (agent_base.py:116-139) and never calls (`train_rl` is False in every shipped script,
+    agent_base.py:241-250).  [LINEAGE DUET] state2value = Linear(H,512) -> ReLU -> Dropout(args.dropout) -> Linear(512,1).
+    The H->512 projection runs on the HIP GEMM (HipLinear); the 512->1 dot of this dormant head is two torch device ops."""
+
+    def __init__(self, args, device="cuda", compute_dtype=torch.bfloat16, seed=0):
+        super().__init__()
+        H = int(getattr(args, "hidden_size", 768))
+        specs = [("state2value.0.weight", (512, H), "normal"), ("state2value.0.bias", (512,), "zeros"),
+                 ("state2value.3.weight", (1, 512), "normal"), ("state2value.3.bias", (1,), "zeros")]
+        self.store = ParamStore(specs, device, compute_dtype, init_std=0.02, seed=seed, requires_grad=True)
+        self.store.attach_to(self)
+        from .engine import Lin
+        from types import SimpleNamespace
+        fc = getattr(self.state2value, "0")
+        fc.__class__ = HipLinear
+        fc._net = SimpleNamespace(dtype=compute_dtype, train=True, S=self.store)
+        fc._lin = Lin(self.store, "state2value.0.weight", "state2value.0.bias")
+        self.drop = nn.Dropout(p=float(getattr(args, "dropout", 0.5)))
+        self.register_load_state_dict_post_hook(lambda m, k: setattr(m.store, "shadow_clean", False))
+
+    def cuda(self, device=None):
+        return self
+
+    def forward(self, state):
+        self.store.sync_shadow()
+        h = self.drop(torch.relu(getattr(self.state2value, "0")(state).float()))
+        out = getattr(self.state2value, "3")
+        return (h @ out.weight.t() + out.bias).squeeze()
 
 
 def _zeros_like_shape(t, shape, dtype, device):
@@ -83,6 +116,7 @@ class _LanguageFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out, d_attn):
         net, c = ctx.model.net, ctx.c
+        net.S.ensure_grads()
         B, L = c.B, c.L
         d = torch.zeros(B * L, net.H, dtype=net.dtype, device=c.out.device) if d_out is None else d_out.to(net.dtype).reshape(B * L, net.H).contiguous()
         dP = None
@@ -111,6 +145,7 @@ class _PanoramaFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_emb, _dm, d_fused, d_attn):
         net, c = ctx.model.net, ctx.c
+        net.S.ensure_grads()
         Np, V, H = c.Np, c.V, net.H
         dev = c.out.device
         d_pano = torch.zeros(Np * V, H, dtype=net.dtype, device=dev) if d_emb is None else d_emb.to(net.dtype).reshape(Np * V, H).clone()
@@ -208,6 +243,7 @@ class _NavigationFn(torch.autograd.Function):
     def backward(ctx, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl):
         model, c = ctx.model, ctx.c
         net, p = model.net, model.prefix
+        net.S.ensure_grads()
         B, K, Vp, L, H = c.B, c.K, c.Vp, c.L, net.H
         dev = c.glob.out.device
         T = net.dtype

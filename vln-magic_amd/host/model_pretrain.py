@@ -427,6 +427,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     def backward(self):
         c = self._ctx
         assert c is not None, "backward() without a compute_loss=True forward"
+        self.store.ensure_grads()
         O.defer_dw(True)          # weight-gradient GEMMs are queued and launched grouped at the end
         n, plan, task = self.net, c.plan, c.task
         B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H

@@ -105,11 +105,28 @@ class ParamStore:
 
     # ---- module integration -----------------------------------------------------------------
     def attach_to(self, module):
+        self._params = []
         for name, _, _ in self.specs:
             p = nn.Parameter(self.master(name), requires_grad=self.requires_grad)
             if self.requires_grad:
                 p.grad = self.g(name)
             _attach(module, name, p)
+            self._params.append((name, p))
+
+    def ensure_grads(self):
+        """Called at the start of every explicit backward.  `optimizer.zero_grad()` of an unmodified training loop sets
+        `.grad = None` (torch >= 2.0 default; the reference's torch 1.9 zeroed in place): None means zero, so the flat
+        gradient buffer is cleared and every parameter's `.grad` is pointed back at its slice of it."""
+        ps = getattr(self, "_params", None)
+        if not self.requires_grad or not ps:
+            return
+        # a backward means an optimizer step follows; if that optimizer is not FusedAdamW (which refreshes the bf16 shadow
+        # itself and sets the flag again) the next forward must re-cast the weights
+        self.shadow_clean = False
+        if ps[0][1].grad is None or ps[-1][1].grad is None:
+            self.grad.zero_()
+            for name, p in ps:
+                p.grad = self.g(name)
 
     def sync_shadow(self, force=False):
         if self.compute_dtype != torch.bfloat16:

@@ -40,6 +40,21 @@ def _worker(rank, world, port, q):
         ok_sum = bool(torch.allclose(store.grad, want_sum, rtol=1e-6, atol=1e-6))
         ok_mean = bool(torch.allclose(store.grad * gscale, want_sum / world, rtol=1e-6, atol=1e-6))
         # unused-parameter semantics: a rank that did not touch a tensor contributes zeros, result stays consistent
+        # unmodified-loop path: the end of loss.backward() averages the flat gradient buffer (trainer.auto_sync), DDP semantics
+        from magic_amd.host.model_pretrain import GlocalTextPathCMTPreTraining
+        from magic_amd.host.trainer import auto_sync
+        model = GlocalTextPathCMTPreTraining(cfg, device="cpu", compute_dtype=torch.float32, seed=5)
+        model.store.grad.copy_(torch.randn(model.store.total, generator=torch.Generator().manual_seed(40 + rank)))
+        auto_sync(model)
+        want_mean = sum(torch.randn(model.store.total, generator=torch.Generator().manual_seed(40 + r)) for r in range(world)) / world
+        ok_auto = bool(torch.allclose(model.store.grad, want_mean, rtol=1e-6, atol=1e-6))
+        p0 = next(iter(model.parameters()))
+        ok_auto = ok_auto and p0.grad.data_ptr() == model.store.grad.data_ptr()          # still views of the flat buffer
+        model.auto_grad_sync = False
+        keep = model.store.grad.clone()
+        auto_sync(model)
+        ok_auto = ok_auto and bool(torch.equal(keep, model.store.grad))
+        ok_mean = ok_mean and ok_auto
         task = broadcast_task(2 if rank == 0 else 0, "cpu")   # MetaLoader: rank 0's draw wins (data/loader.py:55-59)
         q.put((rank, same_params, ok_sum, ok_mean, gscale, task, float(mine.abs().sum())))
     finally:

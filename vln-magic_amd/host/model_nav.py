@@ -52,6 +52,9 @@ class _HipLinearFn(torch.autograd.Function):
         M = ctx.x.shape[0]
         d = dy.to(net.dtype).reshape(M, lin.N).contiguous()
         net.S.ensure_grads()
+        owner = getattr(ctx.mod, "_owner", None)
+        if owner:
+            _queue_sync(owner[0])
         if net.train:
             O.linear_dw(d, ctx.x, lin.dW, lin.db, M)
         dx = O.linear_dx(d, lin.W, M)
@@ -84,6 +87,7 @@ class Critic(nn.Module):
         fc.__class__ = HipLinear
         fc._net = SimpleNamespace(dtype=compute_dtype, train=True, S=self.store)
         fc._lin = Lin(self.store, "state2value.0.weight", "state2value.0.bias")
+        fc._owner = (self,)
         self.drop = nn.Dropout(p=float(getattr(args, "dropout", 0.5)))
         self.register_load_state_dict_post_hook(lambda m, k: setattr(m.store, "shadow_clean", False))
 
@@ -95,6 +99,20 @@ class Critic(nn.Module):
         h = self.drop(torch.relu(getattr(self.state2value, "0")(state).float()))
         out = getattr(self.state2value, "3")
         return (h @ out.weight.t() + out.bias).squeeze()
+
+
+def _queue_sync(model):
+    """nav mode: many Function.backward calls feed one store per loss.backward(); average the gradients once, when the whole
+    autograd pass is over (the engine's end-of-backward callback -- the mechanism DDP's reducer uses too)."""
+    if getattr(model, "_sync_queued", False):
+        return
+    model._sync_queued = True
+
+    def _done():
+        model._sync_queued = False
+        from .trainer import auto_sync
+        auto_sync(model)
+    torch.autograd.Variable._execution_engine.queue_callback(_done)
 
 
 def _zeros_like_shape(t, shape, dtype, device):
@@ -117,6 +135,7 @@ class _LanguageFn(torch.autograd.Function):
     def backward(ctx, d_out, d_attn):
         net, c = ctx.model.net, ctx.c
         net.S.ensure_grads()
+        _queue_sync(ctx.model)
         B, L = c.B, c.L
         d = torch.zeros(B * L, net.H, dtype=net.dtype, device=c.out.device) if d_out is None else d_out.to(net.dtype).reshape(B * L, net.H).contiguous()
         dP = None
@@ -146,6 +165,7 @@ class _PanoramaFn(torch.autograd.Function):
     def backward(ctx, d_emb, _dm, d_fused, d_attn):
         net, c = ctx.model.net, ctx.c
         net.S.ensure_grads()
+        _queue_sync(ctx.model)
         Np, V, H = c.Np, c.V, net.H
         dev = c.out.device
         d_pano = torch.zeros(Np * V, H, dtype=net.dtype, device=dev) if d_emb is None else d_emb.to(net.dtype).reshape(Np * V, H).clone()
@@ -244,6 +264,7 @@ class _NavigationFn(torch.autograd.Function):
         model, c = ctx.model, ctx.c
         net, p = model.net, model.prefix
         net.S.ensure_grads()
+        _queue_sync(model)
         B, K, Vp, L, H = c.B, c.K, c.Vp, c.L, net.H
         dev = c.glob.out.device
         T = net.dtype
@@ -310,6 +331,7 @@ class VLNBert(nn.Module):
                 m = getattr(self.vln_bert, n)
                 m.__class__ = HipLinear
                 m._net, m._lin = self.net, self.net.lin(f"{self.prefix}{n}.weight")
+                m._owner = (self,)          # tuple: not registered as a sub-module
         self.register_load_state_dict_post_hook(lambda m, k: setattr(m.store, "shadow_clean", False))
 
     def cuda(self, device=None):           # `VLNBert(args, role).cuda()` (agent.py:36-38): already resident

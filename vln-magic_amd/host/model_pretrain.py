@@ -60,6 +60,8 @@ class _BackwardHook(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         ctx.model.backward()
+        from .trainer import auto_sync
+        auto_sync(ctx.model)           # data parallel under an unmodified loop: average the flat gradient buffer here
         return None, None, None
 
 

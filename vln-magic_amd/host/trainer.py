@@ -101,6 +101,23 @@ class GradSync:
         return 1.0 / self.world
 
 
+def auto_sync(model):
+    """Gradient averaging for UNMODIFIED training loops (`loss.backward(); optimizer.step()`): the explicit HIP backward
+    writes `.grad` without going through autograd, so `DistributedDataParallel`'s reducer hooks never fire -- a DDP wrapper
+    around these models would silently skip the exchange.  Instead, when a process group with world_size > 1 exists, the end
+    of the backward pass all-reduces the flat gradient buffer and applies DDP's 1/world averaging in place.
+    `model.auto_grad_sync = False` turns it off (PretrainStep does its own exchange and folds the scale into AdamW)."""
+    if not getattr(model, "auto_grad_sync", True):
+        return
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    sync = getattr(model, "_grad_sync", None)
+    if sync is None:
+        sync = model._grad_sync = GradSync(model.store)
+    scale = sync.all_reduce()
+    model.store.grad.mul_(scale)
+
+
 def broadcast_task(task_id, device):
     """MetaLoader's one non-gradient collective (pretrain_src/data/loader.py:55-59)."""
     t = torch.tensor([task_id], dtype=torch.int64, device=device)

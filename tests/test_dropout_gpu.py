@@ -196,15 +196,16 @@ def _models(dtype, p_drop):
     return o_t, o_s, g_t, g_s
 
 
-@pytest.mark.parametrize("task", ["sap", "mlm"])
-def test_training_step_with_dropout_matches_oracle_replaying_the_masks(task):
+@pytest.mark.parametrize("task,lens", [("sap", (8, 19)), ("mlm", (8, 19)), ("sap", (130, 150))])
+def test_training_step_with_dropout_matches_oracle_replaying_the_masks(task, lens):
     """The reference recipe (dropout 0.1, model.train()): engine forward/backward in fp32 vs the fp64 oracle fed with the
-    engine's own masks at every dropout module."""
+    engine's own masks at every dropout module.  The 130-150-token case takes the unfused attention path (keys > 128:
+    GEMM + softmax + standalone dropout kernels) in the text encoder and in every node->text cross-attention."""
     p = 0.1
     o_t, o_s, g_t, g_s = _models(torch.float32, p)
     g_s.train()
     g_t.eval()
-    batch = synth.make_batch(task, batch_size=5, seed=33, vocab=600, min_len=8, max_len=19, min_steps=2, max_steps=4)
+    batch = synth.make_batch(task, batch_size=5 if lens[1] < 100 else 3, seed=33, vocab=600, min_len=lens[0], max_len=lens[1], min_steps=2, max_steps=4)
     rw = torch.tensor(RW, dtype=torch.float64)
     o_t, o_s = o_t.double(), o_s.double()
     b64 = to64(batch)

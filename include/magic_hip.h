@@ -171,8 +171,27 @@ int magic_cast(int to_bf16, long long n, const void* x, void* y, void* stream);
 int magic_add(int dtype, long long n, const void* x, void* y, void* stream);
 int magic_dact(int dtype, int kind, long long n, const void* dy, const void* z, void* dz, void* stream);
 
+/* Row-block pipeline (forward): up to 4 per-token linear stages chained on 32-row blocks with the intermediate
+ * activations in LDS -- the BertSelfOutput -> BertIntermediate -> BertOutput tail of a transformer block plus the next
+ * block's Q/K/V projection in ONE launch (HF BertLayer.feed_forward_chunk).  Stage i consumes the
+ * output of stage i-1 (stage 0: X[M, K0]); kind 1 = LayerNorm(dropout(x W^T + b) + residual) with the residual either a
+ * global tensor `res` or (res == NULL, res_stage >= 0) the LDS-resident output of an earlier stage, N <= 256; kind 2 =
+ * gelu(x W^T + b), `pre` optionally receives the pre-activation; kind 3 = x W^T + b, last stage only.  All N % 64 == 0,
+ * K % 64 == 0 (bf16) / % 32 (f32).  Every stage writes its `out` (saved for the backward).  MAGIC_ERR_UNSUPPORTED when the
+ * widths do not fit LDS (magic_rowblock_lds_bytes > 160 KiB or a LayerNorm width > 256): use magic_gemm + magic_linear_ln. */
+typedef struct {
+  int kind, N, K;
+  const void* W; int ldw; const float* bias;
+  const void* res; int ldres; int res_stage;
+  const float* gamma; const float* beta; float eps; float* rstd; unsigned drop_site;
+  void* out; int ldo; void* pre; int ldpre;
+} magic_rb_stage;
+int magic_rowblock_lds_bytes(int dtype, int wn, int ww);
+int magic_rowblock_fwd(int dtype, int M, const void* X, int ldx, int K0, int nstage, const magic_rb_stage* stages,
+                       const void* drop_seed, float drop_p, void* stream);
+
 /* Pair-grouping: between magic_group_begin() and magic_group_end(stream) up to two calls of magic_gemm / magic_attn_fwd /
- * magic_attn_bwd / magic_linear_ln / magic_ln_bwd are recorded instead of launched; magic_group_end launches ONE kernel serving
+ * magic_attn_bwd / magic_linear_ln / magic_ln_bwd / magic_rowblock_fwd are recorded instead of launched; magic_group_end launches ONE kernel serving
  * both problems when they are the same kind / dtype / variant (else one kernel each).  Thread-local state. */
 int magic_group_begin(void);
 int magic_group_end(void* stream);

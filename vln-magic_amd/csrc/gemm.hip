@@ -185,35 +185,13 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
       la[d].load(A, p.lda, m0, (kt0 + d) * BK, p.M, p.K);
       lb[d].load(B, p.ldb, n0, (kt0 + d) * BK, p.N, p.K);
     }
-  for (int kt = kt0; kt < kt1; kt += PD) {
-#pragma unroll
-    for (int d = 0; d < PD; ++d) {
-      if (kt + d < kt1) {           // block-uniform
-        la[d].store(sA);
-        lb[d].store(sB);
-        __syncthreads();
-        if (kt + d + PD < kt1) {
-          la[d].load(A, p.lda, m0, (kt + d + PD) * BK, p.M, p.K);
-          lb[d].load(B, p.ldb, n0, (kt + d + PD) * BK, p.N, p.K);
-        }
-        mma_tile<A_KC, B_KC>(sA, sB, wr, wc, lane, acc);
-        if (do_bgrad && tid < BM) {
-          float s = 0.f;
-#pragma unroll 8
-          for (int k = 0; k < BK; ++k) s += to_f(sA[k * TT<T>::SN + tid]);      // TN: A is held as the natural [k][out] image
-          bsum += s;
-        }
-        __syncthreads();
-      }
-    }
-  }
-  if (do_bgrad && tid < BM && m0 + tid < p.M) atomicAdd(p.bias_grad + m0 + tid, bsum);
-
-  // epilogue: C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+  // Epilogue operands (bias / activation-derivative input / residual) are fetched HERE, before the K loop: these GEMMs are
+  // 1-3 k-tiles long, so a second dependent round trip to memory after the loop was a visible share of each launch.
+  // C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
   // Structured as {all loads} -> {math} -> {all stores}: gfx950's vmcnt counts stores too, so interleaving
   // per-element loads and stores serialises 16 memory round trips per thread (measured: +4 us per launch).
   const int cr = (lane >> 4) * 4, cc = lane & 15;
-  float v[16], ax[16], rs[16];
+  float ax[16], rs[16];
   bool ok[16];
   float bv[2] = {0.f, 0.f};
   const bool has_aux = (p.epilogue == 3 || p.epilogue == 4);
@@ -258,6 +236,32 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
       }
     }
   }
+  for (int kt = kt0; kt < kt1; kt += PD) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      if (kt + d < kt1) {           // block-uniform
+        la[d].store(sA);
+        lb[d].store(sB);
+        __syncthreads();
+        if (kt + d + PD < kt1) {
+          la[d].load(A, p.lda, m0, (kt + d + PD) * BK, p.M, p.K);
+          lb[d].load(B, p.ldb, n0, (kt + d + PD) * BK, p.N, p.K);
+        }
+        mma_tile<A_KC, B_KC>(sA, sB, wr, wc, lane, acc);
+        if (do_bgrad && tid < BM) {
+          float s = 0.f;
+#pragma unroll 8
+          for (int k = 0; k < BK; ++k) s += to_f(sA[k * TT<T>::SN + tid]);      // TN: A is held as the natural [k][out] image
+          bsum += s;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (do_bgrad && tid < BM && m0 + tid < p.M) atomicAdd(p.bias_grad + m0 + tid, bsum);
+
+  // epilogue math + stores (operands were prefetched before the K loop)
+  float v[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
@@ -464,6 +468,23 @@ __device__ __forceinline__ void linear_ln_body(const LlnParams& pp, const int bi
   };
   const int ktiles = (K + BK - 1) / BK;
   load(0);
+  // epilogue operands (bias, gamma, beta, residual tile) are fetched before the K loop: their latency hides under it
+  float bv[HT], gv[HT], btv[HT];
+#pragma unroll
+  for (int j = 0; j < HT; ++j) {
+    const int col = w * WC + j * 16 + c16;
+    bv[j] = bias ? bias[col] : 0.f; gv[j] = gamma[col]; btv[j] = beta[col];
+  }
+  float rsd[2][HT][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < HT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + i * 16 + 4 * g + r, col = w * WC + j * 16 + c16;
+        rsd[i][j][r] = (R && row < M) ? to_f(R[(long long)row * ldr + col]) : 0.f;
+      }
   for (int kt = 0; kt < ktiles; ++kt) {
     store();
     __syncthreads();
@@ -485,23 +506,7 @@ __device__ __forceinline__ void linear_ln_body(const LlnParams& pp, const int bi
     }
     __syncthreads();
   }
-  // ---- epilogue: v = acc + bias + residual ; LayerNorm over the full row (cross-wave) ; store
-  float bv[HT], gv[HT], btv[HT];
-#pragma unroll
-  for (int j = 0; j < HT; ++j) {
-    const int col = w * WC + j * 16 + c16;
-    bv[j] = bias ? bias[col] : 0.f; gv[j] = gamma[col]; btv[j] = beta[col];
-  }
-  float rsd[2][HT][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < HT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + i * 16 + 4 * g + r, col = w * WC + j * 16 + c16;
-        rsd[i][j][r] = (R && row < M) ? to_f(R[(long long)row * ldr + col]) : 0.f;
-      }
+  // ---- epilogue: v = dropout(acc + bias) + residual ; LayerNorm over the full row (cross-wave) ; store
   const DropState dsn = drop_init(pp.drop);
   float s[2][4];
 #pragma unroll

@@ -227,20 +227,46 @@ class MagicNet:
         O.gemm(2, dS, q, dk, Nk, HD, Nq, ldp, ldq, lddkv, batch=Bn * nh, nh=nh, sA=sP, sB=(Nq * ldq, HD), sC=(Nk * lddkv, HD), flop_dims=fd)
 
     # ---- self-attention + add&norm -------------------------------------------------------------
-    def _sa_fwd(self, lp, x, Bn, N, kmask, dist, sprel, rows, aflops):
+    def _sa_attn_fwd(self, lp, x, Bn, N, kmask, dist, sprel, rows, aflops, qkv=None):
+        """Q/K/V projection (unless the previous block's row-block chain already produced it) + the attention product"""
         H = self.H
         M = Bn * N
         c = Ctx(x=x, Bn=Bn, N=N, rows=rows, aflops=aflops, dist=dist)
-        qkv = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
-        c.qkv = O.linear_fwd(x, qkv.W, qkv.b, M, flop_rows=rows)
+        if qkv is None:
+            ql = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
+            qkv = O.linear_fwd(x, ql.W, ql.b, M, flop_rows=rows)
+        c.qkv = qkv
         c.adrop, c.hdrop = self._da(lp + "attention.self.dropout"), self._dh(lp + "attention.output.dropout")
         c.Ppre, c.ctx, c.ldp, c.P = self._attn_fwd(c.qkv, 3 * H, c.qkv[:, H:], c.qkv[:, 2 * H:], 3 * H, Bn, N, N, kmask, dist, sprel,
                                                    aflops, c.adrop)
+        c.a, c.rstd_a = self.new(M, H), self.new(M, dtype=torch.float32)
+        return c
+
+    def _sa_out_fwd(self, lp, c):
         o = self.lin(lp + "attention.output.dense.weight")
         n = self.ln(lp + "attention.output.LayerNorm")
-        c.a, c.rstd_a = self.new(M, H), self.new(M, dtype=torch.float32)
-        self._dense_add_ln(c.ctx, o, x, n, M, c.a, c.rstd_a, rows, c.hdrop)
+        self._dense_add_ln(c.ctx, o, c.x, n, c.Bn * c.N, c.a, c.rstd_a, c.rows, c.hdrop)
+
+    def _sa_fwd(self, lp, x, Bn, N, kmask, dist, sprel, rows, aflops, qkv=None):
+        c = self._sa_attn_fwd(lp, x, Bn, N, kmask, dist, sprel, rows, aflops, qkv)
+        self._sa_out_fwd(lp, c)
         return c
+
+    # ---- row-block chains (csrc/rowblock.hip): everything after an attention product is per-token ----------------
+    def _rb_ok(self):
+        return O.rowblock_ok(self.dtype, self.H, self.I)
+
+    def _qkv_lin(self, lp):
+        return self.lin(lp + "attention.self.query.weight", rows=3 * self.H, cols=self.H)
+
+    def _ffn_stages(self, lp, M, rows, res_stage):
+        """stages gelu(a W1^T) -> LN(drop(g W2^T) + a) with `a` = the output of stage `res_stage`; returns (ffn ctx, stages)"""
+        H, I = self.H, self.I
+        f1, f2 = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")
+        n = self.ln(lp + "output.LayerNorm")
+        c = Ctx(M=M, rows=rows, z=self.new(M, I), g=self.new(M, I), out=self.new(M, H), rstd=self.new(M, dtype=torch.float32),
+                hdrop=self._dh(lp + "output.dropout"))
+        return c, [O.rb_act(f1, c.g, pre=c.z), O.rb_ln(f2, None, n.g, n.b, self.eps, c.out, c.rstd, drop=c.hdrop, res_stage=res_stage)]
 
     def _dense_add_ln(self, x, lin, res, n, M, out, rstd, rows, hdrop):
         """out = LayerNorm(dropout(x W^T + b) + res): BertSelfOutput / BertOutput"""
@@ -301,10 +327,24 @@ class MagicNet:
         return O.linear_dx(d_z, f1.W, M, residual=d_fo, flop_rows=c.rows)
 
     # ---- layers --------------------------------------------------------------------------------
-    def self_layer_fwd(self, lp, x, Bn, N, kmask, rows, aflops):
-        c = Ctx()
-        c.sa = self._sa_fwd(lp, x, Bn, N, kmask, None, None, rows, aflops)
-        c.ffn = self._ffn_fwd(lp, c.sa.a, Bn * N, rows)
+    def self_layer_fwd(self, lp, x, Bn, N, kmask, rows, aflops, qkv=None, next_lp=None):
+        """qkv: this block's Q/K/V projection if the previous block's chain produced it; next_lp: the following block, whose
+        projection this block's chain produces (returned as c.next_qkv)."""
+        c = Ctx(next_qkv=None)
+        M = Bn * N
+        if self._rb_ok():
+            sa = c.sa = self._sa_attn_fwd(lp, x, Bn, N, kmask, None, None, rows, aflops, qkv)
+            o, n = self.lin(lp + "attention.output.dense.weight"), self.ln(lp + "attention.output.LayerNorm")
+            c.ffn, st = self._ffn_stages(lp, M, rows, 0)
+            c.ffn.a = sa.a
+            st = [O.rb_ln(o, x, n.g, n.b, self.eps, sa.a, sa.rstd_a, drop=sa.hdrop)] + st
+            if next_lp is not None:
+                c.next_qkv = self.new(M, 3 * self.H)
+                st.append(O.rb_lin(self._qkv_lin(next_lp), c.next_qkv))
+            O.rowblock_fwd(sa.ctx, M, st, flop_rows=rows)
+        else:
+            c.sa = self._sa_fwd(lp, x, Bn, N, kmask, None, None, rows, aflops, qkv)
+            c.ffn = self._ffn_fwd(lp, c.sa.a, M, rows)
         c.out, c.P, c.ldp = c.ffn.out, c.sa.P, c.sa.ldp
         return c
 
@@ -312,23 +352,41 @@ class MagicNet:
         d_a = self._ffn_bwd(lp, c.ffn, dout)
         return self._sa_bwd(lp, c.sa, d_a, None, dP_init)
 
-    def cross_layer_fwd(self, lp, x, Bn, Nq, kmask, dist, sprel, ctx, Nk, ckmask, rows, crow, sflops, cflops):
+    def cross_layer_fwd(self, lp, x, Bn, Nq, kmask, dist, sprel, ctx, Nk, ckmask, rows, crow, sflops, cflops, qkv=None, next_lp=None):
         H = self.H
         Mq, Mk = Bn * Nq, Bn * Nk
-        c = Ctx(Bn=Bn, Nq=Nq, Nk=Nk, ctx=ctx, rows=rows, crow=crow, cflops=cflops)
-        c.sa = self._sa_fwd(lp, x, Bn, Nq, kmask, dist, sprel, rows, sflops)
-        s = c.sa.a
+        c = Ctx(Bn=Bn, Nq=Nq, Nk=Nk, ctx=ctx, rows=rows, crow=crow, cflops=cflops, next_qkv=None)
         ql = self.lin(lp + "crossattention.self.query.weight")
         kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
-        c.q = O.linear_fwd(s, ql.W, ql.b, Mq, flop_rows=rows)
+        rb = self._rb_ok()
+        if rb:
+            # chain 1: self-attention output dense + add&norm, then the cross-attention query projection
+            sa = c.sa = self._sa_attn_fwd(lp, x, Bn, Nq, kmask, dist, sprel, rows, sflops, qkv)
+            o, n = self.lin(lp + "attention.output.dense.weight"), self.ln(lp + "attention.output.LayerNorm")
+            c.q = self.new(Mq, H)
+            O.rowblock_fwd(sa.ctx, Mq, [O.rb_ln(o, x, n.g, n.b, self.eps, sa.a, sa.rstd_a, drop=sa.hdrop), O.rb_lin(ql, c.q)], flop_rows=rows)
+        else:
+            c.sa = self._sa_fwd(lp, x, Bn, Nq, kmask, dist, sprel, rows, sflops, qkv)
+            c.q = O.linear_fwd(c.sa.a, ql.W, ql.b, Mq, flop_rows=rows)
+        s = c.sa.a
         c.kv = O.linear_fwd(ctx, kvl.W, kvl.b, Mk, flop_rows=crow)
         c.adrop, c.hdrop = self._da(lp + "crossattention.self.dropout"), self._dh(lp + "crossattention.output.dropout")
         c.Ppre, c.cctx, c.ldp, c.P = self._attn_fwd(c.q, H, c.kv, c.kv[:, H:], 2 * H, Bn, Nq, Nk, ckmask, None, None, cflops, c.adrop)
         o = self.lin(lp + "crossattention.output.dense.weight")
         n = self.ln(lp + "crossattention.output.LayerNorm")
         c.c, c.rstd_c = self.new(Mq, H), self.new(Mq, dtype=torch.float32)
-        self._dense_add_ln(c.cctx, o, s, n, Mq, c.c, c.rstd_c, rows, c.hdrop)
-        c.ffn = self._ffn_fwd(lp, c.c, Mq, rows)
+        if rb:
+            # chain 2: cross-attention output dense + add&norm, FFN + add&norm, the next block's Q/K/V projection
+            c.ffn, st = self._ffn_stages(lp, Mq, rows, 0)
+            c.ffn.a = c.c
+            st = [O.rb_ln(o, s, n.g, n.b, self.eps, c.c, c.rstd_c, drop=c.hdrop)] + st
+            if next_lp is not None:
+                c.next_qkv = self.new(Mq, 3 * H)
+                st.append(O.rb_lin(self._qkv_lin(next_lp), c.next_qkv))
+            O.rowblock_fwd(c.cctx, Mq, st, flop_rows=rows)
+        else:
+            self._dense_add_ln(c.cctx, o, s, n, Mq, c.c, c.rstd_c, rows, c.hdrop)
+            c.ffn = self._ffn_fwd(lp, c.c, Mq, rows)
         c.out = c.ffn.out
         return c
 
@@ -374,10 +432,12 @@ class MagicNet:
         c.layers = []
         tl = plan["lens"]["txt"]
         af = self._flops_attn(tl, tl)
-        for i in range(self.cfg.num_l_layers):
-            lc = self.self_layer_fwd(f"{p}lang_encoder.layer.{i}.", x, B, L, plan["txt_mask"], plan["txt_tokens"], af)
+        nl, qkv = self.cfg.num_l_layers, None
+        for i in range(nl):
+            lc = self.self_layer_fwd(f"{p}lang_encoder.layer.{i}.", x, B, L, plan["txt_mask"], plan["txt_tokens"], af, qkv=qkv,
+                                     next_lp=f"{p}lang_encoder.layer.{i + 1}." if i + 1 < nl else None)
             c.layers.append(lc)
-            x = lc.out
+            x, qkv = lc.out, lc.next_qkv
         c.out, c.P, c.ldp = x, c.layers[-1].P, c.layers[-1].ldp
         return c
 
@@ -419,10 +479,12 @@ class MagicNet:
         x = c.X0d if c.edrop else c.X0
         c.layers = []
         af = float(Np) * V * V * HD * self.nh
-        for i in range(self.cfg.num_pano_layers):
-            lc = self.self_layer_fwd(f"{p}pano_encoder.layer.{i}.", x, Np, V, plan["pano_mask"], M, af)
+        nl, qkv = self.cfg.num_pano_layers, None
+        for i in range(nl):
+            lc = self.self_layer_fwd(f"{p}pano_encoder.layer.{i}.", x, Np, V, plan["pano_mask"], M, af, qkv=qkv,
+                                     next_lp=f"{p}pano_encoder.layer.{i + 1}." if i + 1 < nl else None)
             c.layers.append(lc)
-            x = lc.out
+            x, qkv = lc.out, lc.next_qkv
         c.out, c.P, c.ldp = x, c.layers[-1].P, c.layers[-1].ldp
         c.img_attn = self.new(Np, V, c.ldp, dtype=torch.float32)
         O.head_mean_fwd(c.P, c.img_attn, Np, self.nh, V * c.ldp)
@@ -525,10 +587,12 @@ class MagicNet:
         sprel, _ = self._sprel() if (which == "global" and dist is not None) else (None, None)
         c = Ctx(which=which, layers=[], dist=dist)
         sf, cf = self._flops_attn(qlens, qlens), self._flops_attn(qlens, klens)
-        for i in range(self.cfg.num_x_layers):
-            lc = self.cross_layer_fwd(f"{enc}encoder.crossattention.{i}.", x, B, Nq, qmask, dist, sprel, ctx, Nk, kmask, qrows, krows, sf, cf)
+        nl, qkv = self.cfg.num_x_layers, None
+        for i in range(nl):
+            lc = self.cross_layer_fwd(f"{enc}encoder.crossattention.{i}.", x, B, Nq, qmask, dist, sprel, ctx, Nk, kmask, qrows, krows, sf, cf,
+                                      qkv=qkv, next_lp=f"{enc}encoder.crossattention.{i + 1}." if i + 1 < nl else None)
             c.layers.append(lc)
-            x = lc.out
+            x, qkv = lc.out, lc.next_qkv
         c.out, c.P, c.ldp = x, c.layers[-1].P, c.layers[-1].ldp
         return c
 

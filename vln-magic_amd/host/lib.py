@@ -55,6 +55,8 @@ SIGNATURES = {
     "magic_cast": [i32, i64, vp, vp, vp],
     "magic_add": [i32, i64, vp, vp, vp],
     "magic_dact": [i32, i32, i64, vp, vp, vp, vp],
+    "magic_rowblock_lds_bytes": [i32, i32, i32],
+    "magic_rowblock_fwd": [i32, i32, vp, i32, i32, i32, vp, vp, f32, vp],
     "magic_group_begin": [],
     "magic_group_end": [vp],
 }
@@ -65,6 +67,13 @@ class DwDesc(C.Structure):
     """mirror of `magic_dw_desc` (include/magic_hip.h)"""
     _fields_ = [("dY", vp), ("X", vp), ("dW", vp), ("db", vp), ("M", i32), ("N", i32), ("K", i32),
                 ("lda", i32), ("ldb", i32), ("ldc", i32), ("splitk", i32)]
+
+
+class RbStage(C.Structure):
+    """mirror of `magic_rb_stage` (include/magic_hip.h)"""
+    _fields_ = [("kind", i32), ("N", i32), ("K", i32), ("W", vp), ("ldw", i32), ("bias", vp),
+                ("res", vp), ("ldres", i32), ("res_stage", i32), ("gamma", vp), ("beta", vp), ("eps", f32), ("rstd", vp),
+                ("drop_site", u32), ("out", vp), ("ldo", i32), ("pre", vp), ("ldpre", i32)]
 
 
 _ERR = {-1: "MAGIC_ERR_ARG", -2: "MAGIC_ERR_LAUNCH", -3: "MAGIC_ERR_UNSUPPORTED"}
@@ -102,7 +111,7 @@ def P(t):
 
 
 PROFILE = {"on": False, "events": []}     # bench.py: per-launch HIP-event timing on the launch stream
-PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_ln_bwd"}
+PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_ln_bwd", "magic_rowblock_fwd"}
 _tls = threading.local()
 
 

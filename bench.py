@@ -95,6 +95,32 @@ def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=25.0):
                       f"fp32 torch CPU oracle, dropout {pdrop}, {t_total / max(steps_done, 1) * 1e3:.0f} ms/step"}
 
 
+def ingest_rate(dev, n_vp=4096, n_pano=290, reps=40):
+    """SURVEY section 8d 'achieved feature-ingest GB/s': the f-2 path (packed bf16 view-feature table in HBM, index-only
+    batches, `magic_view_gather` in the reference's candidate-first token order) timed on one B=48 batch worth of panoramas.
+    Algorithmic bytes = read + write of 36 x 768 bf16 per trajectory step."""
+    from magic_amd.host.feature_table import FeatureTable
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(n_vp, 36, 768, generator=g).to(torch.bfloat16).to(dev)
+    ft = FeatureTable([str(i) for i in range(n_vp)], table)
+    rows = torch.randint(0, n_vp, (n_pano,), generator=g).to(torch.int32).to(dev)
+    order = torch.stack([torch.randperm(36, generator=g) for _ in range(n_pano)]).to(torch.int32).to(dev)
+    out = torch.empty(n_pano, 36, 768, dtype=torch.bfloat16, device=dev)
+    for _ in range(5):
+        ft.gather(rows, order, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        ft.gather(rows, order, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    nbytes = 2.0 * n_pano * 36 * 768 * 2
+    return {"kernel": "view_gather_kernel<bf16>", "us_per_batch": round(us, 2), "GB_per_s": round(nbytes / us / 1e3, 1),
+            "bytes_per_traj_step": 2 * 36 * 768 * 2, "peak_GB_per_s": 8000.0}
+
+
 def pmc_traffic():
     """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (cannot be collected from inside this process):
     profiles/r01_pmc_traffic.json, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950."""
@@ -231,6 +257,9 @@ def main():
                            "instrumented_pass_all_kernels_ms_per_step": round(all_ms / nprof, 3),
                            "launches_per_step": sum(c for t, c in by.values()) // nprof,
                            "top_kernels_share": {k: round(t / all_ms, 4) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]}}}
+
+    if roof is not None and rank == 0:
+        roof["detail"]["feature_ingest"] = ingest_rate(dev)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

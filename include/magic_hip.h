@@ -171,6 +171,13 @@ int magic_cast(int to_bf16, long long n, const void* x, void* y, void* stream);
 int magic_add(int dtype, long long n, const void* x, void* y, void* stream);
 int magic_dact(int dtype, int kind, long long n, const void* dy, const void* z, void* dz, void* stream);
 
+/* Feature ingest.  The precomputed CLIP view features live once in HBM as a packed table
+ * [n_viewpoints, 36, D] (the reference keeps them in a host dict keyed "{scan}_{vp}", dataset.py:246-254, and re-uploads
+ * every batch); out[p, j, :] = table[vp_row[p], order[p, j], :], order < 0 -> zeros (padded slots of pad_tensors,
+ * common.py:9).  `order` is the reference's token order: candidate views first, then the rest (dataset.py:742-756). */
+int magic_view_gather(int dtype, int Np, int V, int D, const void* table, int n_viewpoints, const int* vp_row,
+                      const int* order, void* out, void* stream);
+
 /* Row-block pipeline (forward): up to 4 per-token linear stages chained on 32-row blocks with the intermediate
  * activations in LDS -- the BertSelfOutput -> BertIntermediate -> BertOutput tail of a transformer block plus the next
  * block's Q/K/V projection in ONE launch (HF BertLayer.feed_forward_chunk).  Stage i consumes the

@@ -280,6 +280,51 @@ def mint_mrc():
         del sys.modules[k]
 
 
+def mint_ingest():
+    """ingest.pt: R2RTextPathData.get_traj_pano_fts (pretrain_src/data/dataset.py:729-772) run UNBOUND on synthetic candidate
+    tables and a small feature store; plus get_view_rel_angles / get_angle_fts tables (data/common.py:77-103)."""
+    sys.path.insert(0, f"{REF}/pretrain_src")
+    stub(["pynvml", "jsonlines", "h5py", "nltk", "lmdb", "msgpack_numpy", "tensorboardX", "easydict", "progressbar"])
+    sys.modules["msgpack_numpy"].patch = lambda: None
+    from data import dataset as DS
+    from data.common import get_angle_fts, get_view_rel_angles
+    rng = np.random.default_rng(17)
+    D = 16
+    scan = "scanA"
+    vps = [f"vp{i}" for i in range(7)]
+    store = {f"{scan}_{v}": rng.standard_normal((36, D + 5)).astype(np.float32) for v in vps}       # wider than image_feat_size
+    cands = {}
+    for i, v in enumerate(vps):
+        n = int(rng.integers(1, 6))
+        d = {}
+        for j in range(n):
+            vidx = int(rng.integers(0, 36)) if not (i == 3 and j == 1) else list(d.values())[0][0]   # vp3: two candidates share one view
+            d[f"c{i}_{j}"] = [vidx, float(rng.uniform(0.5, 5)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.2, 0.2))]
+        cands[f"{scan}_{v}"] = d
+    fake = SimpleNamespace(scanvp_cands=cands, all_point_rel_angles=[get_view_rel_angles(baseViewId=i) for i in range(36)],
+                           args=SimpleNamespace(correct_heading=False), angle_feat_size=4,
+                           get_scanvp_feature=lambda sc, vp: store[f"{sc}_{vp}"][:, :D])
+    paths = [vps[0:3], vps[2:7], vps[3:4]]
+    outs = []
+    for path in paths:
+        f, loc, nav, cv, last = DS.R2RTextPathData.get_traj_pano_fts(fake, scan, path, 0.0, 0.0)
+        outs.append(dict(fts=[torch.from_numpy(np.asarray(x)) for x in f], loc=[torch.from_numpy(np.asarray(x)) for x in loc],
+                         nav=[list(x) for x in nav], cand=cv, last=torch.from_numpy(np.asarray(last))))
+    torch.save(dict(D=D, scan=scan, vps=vps, store={k: torch.from_numpy(v) for k, v in store.items()}, cands=cands, paths=paths, outs=outs,
+                    rel=[torch.from_numpy(get_view_rel_angles(baseViewId=i)) for i in (0, 12, 23)],
+                    ang_in=torch.from_numpy(rng.uniform(-3, 3, (9, 2)).astype(np.float32))),
+               os.path.join(HERE, "ingest.pt"))
+    fx = torch.load(os.path.join(HERE, "ingest.pt"), weights_only=False)
+    a = fx["ang_in"].numpy()
+    fx["ang_fts4"] = torch.from_numpy(get_angle_fts(a[:, 0], a[:, 1], 4))
+    fx["ang_fts8"] = torch.from_numpy(get_angle_fts(a[:, 0], a[:, 1], 8))
+    torch.save(fx, os.path.join(HERE, "ingest.pt"))
+    print("ingest ok", [len(o["fts"]) for o in outs], [tuple(x.shape) for x in outs[1]["fts"]])
+    sys.path.remove(f"{REF}/pretrain_src")
+    for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "data", "optim", "parser")]:
+        del sys.modules[k]
+
+
 def mint_ops():
     O = load_by_path("ref_ops", f"{REF}/map_nav_src/utils/ops.py")
     g = torch.Generator().manual_seed(2)
@@ -293,6 +338,9 @@ def mint_ops():
 if __name__ == "__main__":
     if "--mrc-only" in sys.argv:
         mint_mrc()
+        sys.exit(0)
+    if "--ingest-only" in sys.argv:
+        mint_ingest()
         sys.exit(0)
     mint_primitives()
     mint_ops()

@@ -156,3 +156,51 @@ def test_mrc_collate_and_validate_arithmetic_match_reference(golden_dir):
     kl = F.kl_div(F.log_softmax(fx["logits"], -1), plan["mrc_targets"], reduction="sum")
     assert abs(float(kl) - fx["kl_sum"]) < 1e-4
     assert int((fx["logits"].argmax(-1) == plan["mrc_targets"].argmax(-1)).sum()) == fx["n_correct"]
+
+
+def test_ingest_token_order_matches_reference_get_traj_pano_fts(golden_dir):
+    """oracle/ingest_ref.py and the host-side index builder (host/feature_table.py) vs the reference's own
+    get_traj_pano_fts output (dataset.py:729-772) on synthetic candidate tables, incl. a panorama where two candidates share
+    a view (37 tokens) -- features, loc_fts, nav_types, candidate ids, and the padded batch layout."""
+    import numpy as np
+    import magic_amd  # noqa: F401
+    from magic_amd.host import feature_table as FT
+    from oracle import ingest_ref as IR
+    fx = _load(golden_dir, "ingest.pt")
+    D, scan = fx["D"], fx["scan"]
+    for i, base in enumerate((0, 12, 23)):
+        assert np.array_equal(IR.get_view_rel_angles(base), fx["rel"][i].numpy())
+        assert np.array_equal(FT.get_view_rel_angles(base), fx["rel"][i].numpy())
+    a = fx["ang_in"].numpy()
+    assert np.array_equal(IR.get_angle_fts(a[:, 0], a[:, 1], 4), fx["ang_fts4"].numpy())
+    assert np.array_equal(IR.get_angle_fts(a[:, 0], a[:, 1], 8), fx["ang_fts8"].numpy())
+    store = {k: v.numpy() for k, v in fx["store"].items()}
+    cands = fx["cands"]
+    keys = sorted(store)
+    table = np.stack([store[k][:, :D] for k in keys])
+    index = {k: i for i, k in enumerate(keys)}
+    for path, want in zip(fx["paths"], fx["outs"]):
+        f, loc, nav, cv, last = IR.traj_pano_tokens(lambda vp: store[f"{scan}_{vp}"][:, :D], path, lambda vp: cands[f"{scan}_{vp}"])
+        assert cv == want["cand"] and [list(x) for x in nav] == want["nav"]
+        for t in range(len(path)):
+            assert np.array_equal(f[t], want["fts"][t].numpy())
+            assert np.array_equal(loc[t], want["loc"][t].numpy())
+        assert np.array_equal(last, want["last"].numpy())
+        # index-only description + gather restatement reproduce the same tensors
+        for t, vp in enumerate(path):
+            order, loc2, nav2, cv2 = FT.pano_view_order(cands[f"{scan}_{vp}"])
+            got = IR.view_gather(table, np.array([index[f"{scan}_{vp}"]]), order[None])[0]
+            assert np.array_equal(got, want["fts"][t].numpy())
+            assert np.allclose(loc2, want["loc"][t].numpy(), atol=1e-6) and list(nav2) == want["nav"][t] and cv2 == want["cand"][t]
+    # padded batch layout = what pad_tensors / pad_sequence of the collates produce from the per-step lists
+    ft = FT.FeatureTable(keys, torch.from_numpy(table))
+    b = ft.batch_indices([scan] * 3, fx["paths"], lambda sc, vp: cands[f"{sc}_{vp}"])
+    assert b["traj_step_lens"] == [3, 5, 1] and b["order"].shape == (9, 37)
+    flat_f = sum([o["fts"] for o in fx["outs"]], [])
+    assert b["traj_vp_view_lens"].tolist() == [x.shape[0] for x in flat_f]
+    got = IR.view_gather(table, b["vp_row"].numpy(), b["order"].numpy())
+    for p, x in enumerate(flat_f):
+        assert np.array_equal(got[p, :x.shape[0]], x.numpy()) and not got[p, x.shape[0]:].any()
+    flat_l = sum([o["loc"] for o in fx["outs"]], [])
+    for p, x in enumerate(flat_l):
+        assert np.allclose(b["traj_loc_fts"][p, :x.shape[0]].numpy(), x.numpy(), atol=1e-6) and not b["traj_loc_fts"][p, x.shape[0]:].any()

@@ -204,3 +204,52 @@ extern "C" int magic_sap_fuse_bwd(int B, int K, int Vp, const float* g_raw, cons
                      (float)use_gate, dgl, dll, dfl, dg_raw, dl_raw, dfuse_raw);
   return launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Feature ingest: the panorama features live ONCE in HBM as a packed table [n_viewpoints, 36, D]
+// (dataset.py:246-254 keeps the same rows in a host dict keyed "{scan}_{vp}"); a batch is described by indices only.
+// out[p, j, :] = table[vp_row[p], order[p, j], :]   (order < 0 -> zeros: padded view slots, pad_tensors common.py:9)
+// `order` carries the reference's token order: candidate views first, then the remaining views (dataset.py:742-756).
+// Pure HBM stream over 16-byte vectors; algorithmic bytes = 2 * D * sizeof(T) per view.
+template <typename T>
+__global__ __launch_bounds__(256) void view_gather_kernel(long long rows, int V, int D, const T* table, const int* vp_row, const int* order, T* out) {
+  constexpr int VE = 16 / sizeof(T), UN = 4;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  const int nvec = D / VE;                                    // 16-byte vectors per view row (96 for 768 bf16)
+  const long long total = rows * nvec, stride = (long long)gridDim.x * 256;
+  u4* dst = (u4*)out;
+  // flat index space over 16-byte vectors: every lane busy whatever D is; UN independent loads in flight per lane
+  for (long long v0 = (long long)blockIdx.x * 256 + threadIdx.x; v0 < total; v0 += stride * UN) {
+    u4 val[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long long v = v0 + u * stride;
+      val[u] = (u4){0u, 0u, 0u, 0u};
+      if (v < total) {
+        const long long r = v / nvec;
+        const int c = (int)(v - r * nvec), sv = order[r];
+        if (sv >= 0) val[u] = __builtin_nontemporal_load((const u4*)(table + ((long long)vp_row[r / V] * 36 + sv) * D) + c);   // read once
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long long v = v0 + u * stride;
+      if (v < total) dst[v] = val[u];
+    }
+  }
+}
+
+extern "C" int magic_view_gather(int dtype, int Np, int V, int D, const void* table, int n_viewpoints, const int* vp_row,
+                                 const int* order, void* out, void* stream) {
+  if (Np <= 0 || V <= 0 || D <= 0 || n_viewpoints <= 0 || !table || !vp_row || !order || !out) return MAGIC_ERR_ARG;
+  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
+  const int ve = dtype == DT_BF16 ? 8 : 4;
+  if (D % ve || ((uintptr_t)table & 15) || ((uintptr_t)out & 15)) return MAGIC_ERR_ARG;
+  const long long rows = (long long)Np * V;
+  const long long chunks = (rows * (D / ve) + 256 * 4 - 1) / (256 * 4);
+  dim3 grid((unsigned)(chunks < 1 ? 1 : chunks)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(view_gather_kernel<bf16>, grid, block, 0, st, rows, V, D, (const bf16*)table, vp_row, order, (bf16*)out);
+  else hipLaunchKernelGGL(view_gather_kernel<float>, grid, block, 0, st, rows, V, D, (const float*)table, vp_row, order, (float*)out);
+  return launch_status();
+}

@@ -55,6 +55,7 @@ SIGNATURES = {
     "magic_cast": [i32, i64, vp, vp, vp],
     "magic_add": [i32, i64, vp, vp, vp],
     "magic_dact": [i32, i32, i64, vp, vp, vp, vp],
+    "magic_view_gather": [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp],
     "magic_rowblock_lds_bytes": [i32, i32, i32],
     "magic_rowblock_fwd": [i32, i32, vp, i32, i32, i32, vp, vp, f32, vp],
     "magic_group_begin": [],

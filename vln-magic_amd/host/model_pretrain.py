@@ -129,7 +129,12 @@ class GlocalTextPathCMTPreTraining(nn.Module):
 
     def _inputs(self, batch, plan):
         Np, V = plan["Np"], plan["V"]
-        x = self._dev(batch["traj_view_img_fts"]).reshape(Np * V, -1)
+        if batch.get("view_table") is not None:
+            # index-only batch (host/feature_table.py): the view features are gathered on the device from
+            # the packed HBM table in the reference's token order; nothing but 37 int32 per panorama crossed PCIe
+            x = batch["view_table"].gather(batch["traj_vp_row"], batch["traj_view_order"]).reshape(Np * V, -1)
+        else:
+            x = self._dev(batch["traj_view_img_fts"]).reshape(Np * V, -1)
         if x.dtype != self.compute_dtype:
             x = O.cast_to(x.contiguous(), self.compute_dtype)
         return Ctx(feats=x,

@@ -179,6 +179,15 @@ def dropout(x, out, rows, cols, ld, drop):
     return out
 
 
+def view_gather(table, vp_row, order, out):
+    """out[p, j, :] = table[vp_row[p], order[p, j], :] (order < 0 -> zeros); table [n, 36, D], out [Np, V, D] same dtype."""
+    Np, V = order.shape
+    _chk(table.dtype == out.dtype and table.is_contiguous() and out.is_contiguous() and table.shape[1] == 36, "view_gather layout")
+    _chk(vp_row.dtype == torch.int32 and order.dtype == torch.int32 and order.is_contiguous(), "view_gather indices int32")
+    L.call("magic_view_gather", L.dt(table.dtype), Np, V, table.shape[2], L.P(table), table.shape[0], L.P(vp_row), L.P(order), L.P(out), L.stream())
+    return out
+
+
 # ---- row-block pipeline (csrc/rowblock.hip) --------------------------------------------------------------------
 # OPT-IN (MAGIC_ROWBLOCK=1): measured slower than the separate launches it replaces on MI355X -- a 32-row block has to
 # stream every weight of the chain itself (393 KB at H=128, 1.5 MB at H=256) with one 32 KB tile in flight, ~3.8 us per

@@ -337,8 +337,10 @@ class RefPretrainModel(nn.Module):
         if need_local:
             last = torch.tensor(batch["traj_step_lens"]).cumsum(0) - 1
             B, H = len(last), pe.shape[-1]
-            vp_img = torch.cat([pe.new_zeros(B, 1, H), pe[last]], 1)
             vp_lens = batch["traj_vp_view_lens"][last] + 1
+            # [stop] + the current panorama's views, cut to the longest CURRENT panorama of the batch ([LINEAGE] DUET
+            # LocalVPEncoder.vp_input_embedding `[:, :max_vp_len]`; = vp_pos_fts.shape[1], tasks.py:434-435)
+            vp_img = torch.cat([pe.new_zeros(B, 1, H), pe[last]], 1)[:, :int(vp_lens.max())]
             o["vp_masks"] = seq_mask(vp_lens, vp_img.shape[1])
             o["vp_in"] = bert.local_input(vp_img, batch["vp_pos_fts"])
             o["vp_embeds"], o["vp_attns"] = bert.local_encode(o["vp_in"], o["vp_masks"], o["txt_embeds"], txt_masks)
@@ -352,7 +354,7 @@ class RefPretrainModel(nn.Module):
         gl = gl.masked_fill(batch["gmap_visited_masks"], -float("inf")).masked_fill(~o["gmap_masks"], -float("inf"))
         ll = self.local_sap_head(o["vp_embeds"]).squeeze(2) * (1 - fw)
         nav = batch["traj_nav_types"][o["last_rows"]] == 1
-        vp_nav = torch.cat([torch.ones(len(nav), 1, dtype=torch.bool), nav], 1)
+        vp_nav = torch.cat([torch.ones(len(nav), 1, dtype=torch.bool), nav], 1)[:, :ll.shape[1]]
         ll = ll.masked_fill(~vp_nav, -float("inf"))
         fl = fuse_logits(gl, ll, batch)
         return gl, ll, fl

@@ -280,6 +280,31 @@ def mint_mrc():
         del sys.modules[k]
 
 
+def mint_ragged():
+    """collate_ragged.pt: sap_collate / mlm_collate (tasks.py:392-451, :110-176) on samples whose panoramas have 36 OR 37 view
+    tokens (two candidates in one view): pins the padding of the view dimension and vp_lens / traj_vp_view_lens."""
+    sys.path.insert(0, f"{REF}/pretrain_src")
+    stub(["pynvml", "jsonlines", "h5py", "nltk", "lmdb", "msgpack_numpy", "tensorboardX", "easydict", "progressbar"])
+    sys.modules["msgpack_numpy"].patch = lambda: None
+    import random
+    import magic_amd  # noqa: F401
+    from magic_amd.host import synth
+    from data import tasks as T
+    rng = np.random.default_rng([77, 0])
+    pyrng = random.Random(77)
+    samples = [synth.make_sample(rng, pyrng, uid=i, min_len=5, max_len=9, min_steps=2, max_steps=4, dup_view_prob=0.5, img_dim=16)
+               for i in range(4)]
+    lens = sum([[x.shape[0] for x in s["traj_view_img_fts"]] for s in samples], [])
+    assert 36 in lens and 37 in lens, lens
+    sap = T.sap_collate([dict(x) for x in samples])
+    keep = {k: v for k, v in sap.items() if torch.is_tensor(v) or isinstance(v, (list, type(None)))}
+    torch.save(dict(seed=77, sap=keep), os.path.join(HERE, "collate_ragged.pt"))
+    print("collate_ragged ok", lens, tuple(sap["traj_view_img_fts"].shape), tuple(sap["vp_pos_fts"].shape), sap["vp_lens"].tolist())
+    sys.path.remove(f"{REF}/pretrain_src")
+    for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "data", "optim", "parser")]:
+        del sys.modules[k]
+
+
 def mint_ingest():
     """ingest.pt: R2RTextPathData.get_traj_pano_fts (pretrain_src/data/dataset.py:729-772) run UNBOUND on synthetic candidate
     tables and a small feature store; plus get_view_rel_angles / get_angle_fts tables (data/common.py:77-103)."""
@@ -338,6 +363,9 @@ def mint_ops():
 if __name__ == "__main__":
     if "--mrc-only" in sys.argv:
         mint_mrc()
+        sys.exit(0)
+    if "--ragged-only" in sys.argv:
+        mint_ragged()
         sys.exit(0)
     if "--ingest-only" in sys.argv:
         mint_ingest()

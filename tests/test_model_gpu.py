@@ -59,9 +59,9 @@ def close(got, want, name, rtol, atol):
 
 
 def view_outputs(o, plan, H):
-    B, L, K, Vp, Np = plan["B"], plan["L"], plan["K"], plan["Vp"], plan["Np"]
+    B, L, K, Vp, Np, V = plan["B"], plan["L"], plan["K"], plan["Vp"], plan["Np"], plan["V"]
     d = dict(txt_embeds=o["txt_embeds"].view(B, L, H), txt_attns=o["txt_attns"][..., :L],
-             pano_embeds=o["pano_embeds"].view(Np, 36, H), pano_fused_embeds=o["pano_fused_embeds"], img_attns=o["img_attns"][..., :36])
+             pano_embeds=o["pano_embeds"].view(Np, V, H), pano_fused_embeds=o["pano_fused_embeds"], img_attns=o["img_attns"][..., :V])
     if "vp_embeds" in o:
         d.update(gmap_embeds=o["gmap_embeds"].view(B, K, H), gmap_attns=o["gmap_attns"][..., :L],
                  vp_embeds=o["vp_embeds"].view(B, Vp, H), vp_attns=o["vp_attns"][..., :L])

@@ -204,3 +204,27 @@ def test_ingest_token_order_matches_reference_get_traj_pano_fts(golden_dir):
     flat_l = sum([o["loc"] for o in fx["outs"]], [])
     for p, x in enumerate(flat_l):
         assert np.allclose(b["traj_loc_fts"][p, :x.shape[0]].numpy(), x.numpy(), atol=1e-6) and not b["traj_loc_fts"][p, x.shape[0]:].any()
+
+
+def test_ragged_view_collate_matches_reference(golden_dir):
+    """panoramas with 36 or 37 view tokens in one batch: synth.collate pads exactly like the reference's sap_collate"""
+    import random
+    import numpy as np
+    import magic_amd  # noqa: F401
+    from magic_amd.host import synth
+    from magic_amd.host.plan import build_plan
+    fx = _load(golden_dir, "collate_ragged.pt")
+    rng = np.random.default_rng([fx["seed"], 0])
+    pyrng = random.Random(fx["seed"])
+    samples = [synth.make_sample(rng, pyrng, uid=i, min_len=5, max_len=9, min_steps=2, max_steps=4, dup_view_prob=0.5, img_dim=16)
+               for i in range(4)]
+    got = synth.collate(samples, "sap")
+    for k, v in fx["sap"].items():
+        if torch.is_tensor(v):
+            assert got[k].dtype == v.dtype and got[k].shape == v.shape, k
+            assert torch.equal(got[k], v), k
+        else:
+            assert got[k] == v, k
+    plan = build_plan(got, "sap", torch.device("cpu"))
+    assert plan["V"] == got["traj_view_img_fts"].shape[1] == 37 and plan["Vp"] == got["vp_pos_fts"].shape[1]
+    assert plan["vp_mask"].sum(1).tolist() == [int(got["traj_vp_view_lens"][r]) + 1 for r in plan["last_rows"]]

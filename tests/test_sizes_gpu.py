@@ -63,3 +63,17 @@ def test_rxr_length_instructions_take_the_unfused_attention_path():
     run_case(128, 256, "sap", batch)
     batch = synth.make_batch("mlm", batch_size=2, seed=5, vocab=400, min_len=140, max_len=170, min_steps=2, max_steps=3)
     run_case(128, 256, "mlm", batch)
+
+
+@pytest.mark.parametrize("task", ["sap", "mlm", "cfp"])
+def test_edge_shapes_single_sample_single_step_and_ragged_view_counts(task):
+    """B = 1 with one-step trajectories (the map is [stop] + one visited node + its candidates), and batches whose panoramas
+    have 36 or 37 view tokens (two candidates seen in one discretised view, dataset.py:742-756) -- padded per batch by the
+    collate and masked through traj_vp_view_lens / vp_lens."""
+    b1 = synth.make_batch(task, batch_size=1, seed=3, vocab=400, min_len=5, max_len=5, min_steps=1, max_steps=1)
+    assert len(b1["traj_step_lens"]) == 1 and b1["traj_step_lens"][0] == 1
+    run_case(128, 256, task, b1)
+    br = synth.make_batch(task, batch_size=4, seed=6, vocab=400, min_len=6, max_len=14, min_steps=2, max_steps=4, dup_view_prob=0.5)
+    lens = br["traj_vp_view_lens"].tolist()
+    assert br["traj_view_img_fts"].shape[1] == 37 and 36 in lens and 37 in lens, lens
+    run_case(128, 256, task, br)

@@ -389,14 +389,17 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                     self._kd_emb(c, 0, o["txt_embeds"], t["txt_embeds"], "txt_emb_w", B * L, B, w, rw[0], c.d_txt)
                 if att:
                     c.dP_txt = self._kd_attn(c, 1, o["txt_attns"], t["txt_attns"], B, L, L, c.txt.ldp, nh_s, nh_t, w, rw[0])
+            # panorama tensors have leading dim sum(T): the sample weights [B] only broadcast (and are only applied by
+            # mse_loss, pretrain kd_loss.py:11-16) when every trajectory has exactly one step
+            wp = w if (w is not None and Np == B) else None
             if "img" in tasks:
                 if emb:
-                    self._kd_emb(c, 2, o["pano_embeds"], t["pano_embeds"], "kdl_img_w", Np * V, Np * V, None, rw[1], c.d_pano)
-                    self._kd_emb(c, 3, o["pano_fused_embeds"], t["pano_fused_embeds"], "kdl_avg_img_w", Np, Np, None, rw[1], c.d_fused)
+                    self._kd_emb(c, 2, o["pano_embeds"], t["pano_embeds"], "kdl_img_w", Np * V, Np, wp, rw[1], c.d_pano)
+                    self._kd_emb(c, 3, o["pano_fused_embeds"], t["pano_fused_embeds"], "kdl_avg_img_w", Np, Np, wp, rw[1], c.d_fused)
                 if att:
                     ldp = c.pano.ldp
                     g = n.new(Np, V, ldp, dtype=torch.float32) if train else None
-                    O.mse(o["img_attns"], t["img_attns"], Np, V * ldp, V * ldp, V * ldp, norm=1.0 / (Np * V * V), coef=rw[1][0], coef_dev=rw[1][1],
+                    O.mse(o["img_attns"], t["img_attns"], Np, V * ldp, V * ldp, V * ldp, w=wp, rows_per_w=1, norm=1.0 / (Np * V * V), coef=rw[1][0], coef_dev=rw[1][1],
                           loss=c.slots[4:5], ds=g, g_stride=V * ldp)
                     if train:
                         c.dP_pano = n.new(Np, nh_s, V, ldp, dtype=torch.float32)

@@ -10,9 +10,6 @@ candidate views, and the local->global logit fusion index map.
 import numpy as np
 import torch
 
-V = 36
-
-
 def _csr(rows, n_out):
     """rows: list of (out_row, src_row, weight) -> ptr[n_out+1], idx, w sorted by out_row (stable)."""
     rows = sorted(rows, key=lambda r: r[0])
@@ -36,7 +33,11 @@ def build_plan(batch, task, device, ld_round=8):
     B = len(batch["traj_step_lens"])
     L = batch["txt_ids"].shape[1]
     K = batch["gmap_step_ids"].shape[1]
-    Vp = V + 1
+    # view slots per panorama: 36, or more when a panorama shows two candidates in one view (dataset.py:742-756); padded per batch
+    V = int(batch["traj_view_order"].shape[1] if batch.get("traj_view_img_fts") is None else batch["traj_view_img_fts"].shape[1])
+    # local (viewpoint) tokens: [stop] + the CURRENT panorama's views, cut to the longest current panorama of the batch
+    # (= vp_pos_fts.shape[1], tasks.py:434-435); equals V + 1 unless only earlier steps have a 37-token panorama
+    Vp = int(batch["vp_pos_fts"].shape[1])
     step_lens = batch["traj_step_lens"]
     Np = int(sum(step_lens))
     cpu = {}
@@ -76,7 +77,7 @@ def build_plan(batch, task, device, ld_round=8):
     # ---- current-viewpoint tokens: [stop] + the last step's 36 views
     e_vp = []
     for b in range(B):
-        for j in range(V):
+        for j in range(Vp - 1):
             e_vp.append((b * Vp + 1 + j, int(last_rows[b]) * V + j, 1.0))
     plan_csr["vp_from_embed"] = csr_pair(e_vp, B * Vp, Np * V)
     vp_lens = view_lens[torch.from_numpy(last_rows)] + 1
@@ -90,7 +91,7 @@ def build_plan(batch, task, device, ld_round=8):
         visited = batch["gmap_visited_masks"]
         cpu["gmask"] = ((~visited) & cpu["gmap_mask"].bool()).to(torch.uint8)
         nav_last = batch["traj_nav_types"][torch.from_numpy(last_rows)] == 1
-        cpu["lmask"] = torch.cat([torch.ones(B, 1, dtype=torch.bool), nav_last], 1).to(torch.uint8)
+        cpu["lmask"] = torch.cat([torch.ones(B, 1, dtype=torch.bool), nav_last], 1)[:, :Vp].to(torch.uint8)
         fsrc = np.full((B, K), -1, np.int32)
         bwmask = np.zeros((B, Vp), np.uint8)
         for b in range(B):

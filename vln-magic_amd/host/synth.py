@@ -23,9 +23,11 @@ def _angle_fts(rng, n):
 
 
 def make_sample(rng, pyrng, *, min_len=20, max_len=80, min_steps=4, max_steps=7, vocab=50265,
-                uid=0):
+                uid=0, dup_view_prob=0.0, img_dim=IMG_DIM):
     """One trajectory sample in the format of R2RTextPathData.get_input
-    (pretrain_src/data/dataset.py:640-727)."""
+    (pretrain_src/data/dataset.py:640-727).  dup_view_prob: probability that a panorama has two candidates seen in the same
+    discretised view -- the reference then emits that view twice and the panorama has 37 tokens (dataset.py:742-756:
+    candidate views are appended per candidate, the remaining views once), so batches become ragged in the view dimension."""
     L = int(rng.integers(min_len, max_len + 1))
     txt = rng.integers(3, vocab - 1, size=L).astype(np.int64)
     txt[0] = 0      # <s>
@@ -56,10 +58,11 @@ def make_sample(rng, pyrng, *, min_len=20, max_len=80, min_steps=4, max_steps=7,
             if c not in path and c not in frontier:
                 frontier.append(c)
         traj_cand.append(cands)
-        traj_view.append(rng.standard_normal((V_VIEWS, IMG_DIM)).astype(np.float32))
-        loc = np.concatenate([_angle_fts(rng, V_VIEWS), np.ones((V_VIEWS, 3), np.float32)], 1)
+        nv = V_VIEWS + (1 if (dup_view_prob > 0 and len(cands) >= 2 and rng.random() < dup_view_prob) else 0)
+        traj_view.append(rng.standard_normal((nv, img_dim)).astype(np.float32))
+        loc = np.concatenate([_angle_fts(rng, nv), np.ones((nv, 3), np.float32)], 1)
         traj_loc.append(loc)
-        traj_nav.append(np.array([1] * len(cands) + [0] * (V_VIEWS - len(cands)), np.int64))
+        traj_nav.append(np.array([1] * len(cands) + [0] * (nv - len(cands)), np.int64))
     visited = set(path)
     unvisited = [c for c in frontier if c not in visited]
     gmap_vpids = [None] + path + unvisited
@@ -74,7 +77,7 @@ def make_sample(rng, pyrng, *, min_len=20, max_len=80, min_steps=4, max_steps=7,
     d[0, :] = 0
     d[:, 0] = 0
     n_last = len(traj_cand[-1])
-    vp_pos = np.zeros((V_VIEWS + 1, 14), np.float32)
+    vp_pos = np.zeros((traj_view[-1].shape[0] + 1, 14), np.float32)
     vp_pos[:, :7] = np.concatenate([_angle_fts(rng, 1), rng.uniform(0, 1, (1, 3)).astype(np.float32)], 1)
     vp_pos[1:1 + n_last, 7:] = np.concatenate(
         [_angle_fts(rng, n_last), rng.uniform(0, 1, (n_last, 3)).astype(np.float32)], 1)
@@ -155,9 +158,9 @@ def collate(samples, task, rng=None, vocab=50265, mrc_mask_prob=0.15, prob_size=
     b["traj_step_lens"] = [len(s["traj_view_img_fts"]) for s in samples]
     b["traj_vp_view_lens"] = torch.tensor(
         sum([[len(y) for y in s["traj_view_img_fts"]] for s in samples], []), dtype=torch.long)
-    b["traj_view_img_fts"] = torch.stack(sum([s["traj_view_img_fts"] for s in samples], []))
-    b["traj_loc_fts"] = torch.stack(sum([s["traj_loc_fts"] for s in samples], []))
-    b["traj_nav_types"] = torch.stack(sum([s["traj_nav_types"] for s in samples], []))
+    b["traj_view_img_fts"] = _pad_stack(sum([s["traj_view_img_fts"] for s in samples], []))        # pad_tensors (common.py:9)
+    b["traj_loc_fts"] = _pad_stack(sum([s["traj_loc_fts"] for s in samples], []))
+    b["traj_nav_types"] = _pad_stack(sum([s["traj_nav_types"] for s in samples], []))             # pad_sequence, value 0
     b["traj_reverie_loc_fts"] = None
     b["traj_cand_vpids"] = [s["traj_cand_vpids"] for s in samples]
     b["traj_vpids"] = [s["traj_vpids"] for s in samples]
@@ -173,7 +176,7 @@ def collate(samples, task, rng=None, vocab=50265, mrc_mask_prob=0.15, prob_size=
         pd[i, :k, :k] = s["gmap_pair_dists"]
     b["gmap_pair_dists"] = pd
     b["vp_lens"] = torch.tensor([s["vp_pos_fts"].shape[1] for s in samples], dtype=torch.long)  # sic: tasks.py:434
-    b["vp_pos_fts"] = torch.stack([s["vp_pos_fts"] for s in samples])
+    b["vp_pos_fts"] = _pad_stack([s["vp_pos_fts"] for s in samples])
     if task in ("sap", "cfp"):
         b["local_act_labels"] = torch.tensor([s["local_act_labels"] for s in samples], dtype=torch.long)
         b["global_act_labels"] = torch.tensor([s["global_act_labels"] for s in samples], dtype=torch.long)

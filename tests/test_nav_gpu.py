@@ -262,3 +262,28 @@ def test_unmodified_loop_with_a_torch_optimizer_zero_grad_none_and_bf16_shadow()
     assert losses[2] < losses[0]                          # the bf16 weights the kernels read follow the torch optimizer
     model(batch, "sap", compute_loss=False)
     assert torch.equal(model.store.w(name).float(), p.detach().to(torch.bfloat16).float())
+
+
+def test_nav_modes_with_dropout_train_vs_eval():
+    """vln_bert.train() (agent rollout under feedback='sample') arms the in-kernel dropout of every mode; eval() is
+    deterministic; gradients stay finite and flow into the flat buffer."""
+    from types import SimpleNamespace
+    from magic_amd.host.model_nav import VLNBert
+    cfg = make_config(128, vocab_size=300, num_l_layers=1, num_x_layers=1, num_pano_layers=1)      # dropouts 0.1 (config default)
+    m = VLNBert(None, role="student", device=DEV, compute_dtype=torch.float32, config=cfg)
+    B, L = 3, 9
+    g = torch.Generator().manual_seed(0)
+    txt = dict(txt_ids=torch.randint(3, 290, (B, L), generator=g).to(DEV), txt_masks=torch.ones(B, L, dtype=torch.bool, device=DEV))
+    m.eval()
+    e1, _ = m("language", txt)
+    e2, _ = m("language", txt)
+    assert torch.equal(e1, e2) and m.net.drop is None
+    m.train()
+    t1, _ = m("language", txt)
+    s1 = m.net.drop[0].clone()
+    t2, _ = m("language", txt)
+    assert not torch.equal(m.net.drop[0], s1) and not torch.equal(t1, t2)          # fresh seed per call
+    assert (t1 - e1).abs().max() > 1e-3
+    m.store.zero_grad()
+    t1.float().square().sum().backward()
+    assert torch.isfinite(m.store.grad).all() and m.store.grad.abs().max() > 0

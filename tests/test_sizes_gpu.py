@@ -77,3 +77,11 @@ def test_edge_shapes_single_sample_single_step_and_ragged_view_counts(task):
     lens = br["traj_vp_view_lens"].tolist()
     assert br["traj_view_img_fts"].shape[1] == 37 and 36 in lens and 37 in lens, lens
     run_case(128, 256, task, br)
+
+
+def test_maximum_instruction_length_512_tokens():
+    """the hard cap of the text encoder: 512 tokens = max_position_embeddings 514 - 2 (RoBERTa offset); rows of 512 keys are
+    the widest the masked-softmax kernel serves in one wave"""
+    batch = synth.make_batch("sap", batch_size=1, seed=12, vocab=400, min_len=512, max_len=512, min_steps=2, max_steps=2)
+    assert batch["txt_ids"].shape[1] == 512
+    run_case(128, 256, "sap", batch)

@@ -1,0 +1,15 @@
+#!/bin/bash
+# final measurement set of the round (run through gpurun from the repo root)
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $R/gpurun_out/bench_final.json 2> $R/gpurun_out/bench_final.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -- python3 $R/bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-profile > $R/gpurun_out/bench_under_rocprof.json 2> $R/gpurun_out/prof_final.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --mode eager --steps 6 --warmup 3 --no-cpu-baseline --no-profile > /dev/null 2> $R/gpurun_out/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --mode eager --steps 6 --warmup 3 --no-cpu-baseline --no-profile > /dev/null 2> $R/gpurun_out/pmc_write.err
+python3 $R/profiles/pmc_traffic.py $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write 9 > $R/gpurun_out/pmc_traffic.json
+find $R/gpurun_out/prof_final -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/kernel_stats_final.csv \;
+# keep the merge-back small: drop the raw traces
+rm -rf $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
+find $R/gpurun_out/prof_final -name "*kernel_trace.csv" -delete
+tail -c 600 $R/gpurun_out/bench_final.json; echo; cat $R/gpurun_out/pmc_traffic.json | head -12

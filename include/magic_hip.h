@@ -50,6 +50,16 @@ int magic_linear_ln(int dtype, int M, int H, int K, const void* x, int lda, cons
                     const void* residual, int ldr, const float* gamma, const float* beta, float eps,
                     void* out, float* rstd, const void* drop_seed, float drop_p, unsigned drop_site, void* stream);
 
+/* Backward twin: input-gradient GEMM + residual + LayerNorm BACKWARD in one launch (H in {128, 256}).
+ *   v = x[M,K] @ W[K,H] + residual  (the gradient at the OUTPUT of the LayerNorm whose saved output is y);
+ *   dx = LN-backward(v; y, gamma, beta, rstd);  dgamma/dbeta accumulated;  dxm = dx * dropout mask of the dense branch that fed
+ * that LayerNorm (site 0 / p 0: dxm unused).  Replaces magic_gemm(NN, residual) + magic_ln_bwd on every block boundary of
+ * the backward chain (FFN dX -> attention-output LN, QKV dX -> the previous block's output LN). */
+int magic_linear_lnbwd(int dtype, int M, int H, int K, const void* x, int lda, const void* W, int ldb,
+                       const void* residual, int ldr, const void* y, const float* gamma, const float* beta, const float* rstd,
+                       void* dx, void* dxm, float* dgamma, float* dbeta,
+                       const void* drop_seed, float drop_p, unsigned drop_site, void* stream);
+
 /* Dropout (hidden_dropout_prob / attention_probs_dropout_prob of r2r_magic_model_config.json:2-3,6; active under
  * model.train(), train_r2r_magic.py:358) is counter-based: keep(seed[0..1], site, logical element index) is recomputed by
  * the backward kernels, no mask is stored.  `drop_seed` = 2 x uint32 in DEVICE memory (fresh per step, so a replayed HIP
@@ -198,7 +208,7 @@ int magic_rowblock_fwd(int dtype, int M, const void* X, int ldx, int K0, int nst
                        const void* drop_seed, float drop_p, void* stream);
 
 /* Pair-grouping: between magic_group_begin() and magic_group_end(stream) up to two calls of magic_gemm / magic_attn_fwd /
- * magic_attn_bwd / magic_linear_ln / magic_ln_bwd / magic_rowblock_fwd are recorded instead of launched; magic_group_end launches ONE kernel serving
+ * magic_attn_bwd / magic_linear_ln / magic_linear_lnbwd / magic_ln_bwd / magic_rowblock_fwd are recorded instead of launched; magic_group_end launches ONE kernel serving
  * both problems when they are the same kind / dtype / variant (else one kernel each).  Thread-local state. */
 int magic_group_begin(void);
 int magic_group_end(void* stream);

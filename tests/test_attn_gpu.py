@@ -110,3 +110,37 @@ def test_fused_linear_residual_layernorm(dtype, M, H, K):
     tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)
     assert torch.allclose(out.float(), ref, **tol), (out.float() - ref).abs().max().item()
     assert torch.allclose(rstd, 1 / torch.sqrt(pre.var(-1, unbiased=False) + 1e-12), rtol=1e-3 if dtype == torch.float32 else 2e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H,K,res,p", [(100, 128, 512, True, 0.0), (77, 128, 384, True, 0.1), (200, 256, 256, False, 0.0),
+                                         (33, 128, 128, True, 0.0), (64, 256, 512, True, 0.1)])
+def test_fused_input_gradient_gemm_plus_layernorm_backward(dtype, M, H, K, res, p):
+    """magic_linear_lnbwd: (x @ W + residual) pushed through the backward of the LayerNorm whose output is y, vs autograd."""
+    g = torch.Generator().manual_seed(M + H + K)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    x, W = (rnd(M, K) * 0.5).to(dtype), (rnd(K, H) * 0.1).to(dtype)
+    R = rnd(M, H).to(dtype) if res else None
+    gamma, beta = 1 + 0.1 * rnd(H), 0.1 * rnd(H)
+    pre = rnd(M, H).requires_grad_(True)                      # the LayerNorm's input in the forward
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = torch.nn.functional.layer_norm(pre, (H,), gm, bt, 1e-12)
+    y = y_ref.detach().to(dtype)
+    rstd = torch.rsqrt(pre.detach().var(-1, unbiased=False) + 1e-12)
+    v = x.float() @ W.float() + (R.float() if res else 0)
+    y_ref.backward(v)
+    dx, dxm = torch.empty(M, H, dtype=dtype, device=DEV), torch.empty(M, H, dtype=dtype, device=DEV)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    seed = torch.tensor([3, 4], dtype=torch.int32, device=DEV)
+    drop = (seed, p, 777) if p > 0 else None
+    O.linear_lnbwd(x, W, M, R, y, gamma, beta, rstd, dx, dg, db, drop=drop, dxm=dxm if p > 0 else None)
+    tol = dict(rtol=2e-3, atol=2e-4) if dtype == torch.float32 else dict(rtol=4e-2, atol=6e-2)
+    assert torch.allclose(dx.float(), pre.grad, **tol), (dx.float() - pre.grad).abs().max().item()
+    sc = max(1.0, gm.grad.abs().max().item())
+    tp = dict(rtol=2e-3, atol=2e-3 * sc) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2 * sc)
+    assert torch.allclose(dg, gm.grad, **tp), (dg - gm.grad).abs().max().item()
+    assert torch.allclose(db, bt.grad, **tp), (db - bt.grad).abs().max().item()
+    if p > 0:
+        ones, mask = torch.ones(M * H, device=DEV), torch.empty(M * H, device=DEV)
+        O.dropout(ones, mask, 1, M * H, M * H, drop)
+        assert torch.allclose(dxm.float(), (dx.float() * mask.view(M, H)).to(dtype).float(), rtol=1e-2, atol=1e-3)

@@ -623,6 +623,248 @@ int launch_lln(int dtype, int ht, const void* pa, const void* pb, hipStream_t st
   return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward twin of linear_ln: input-gradient GEMM (NN) + residual + LayerNorm BACKWARD in one launch.
+//     v  = X[M,K] @ W[K,H] + R                 (gradient arriving at the OUTPUT of an upstream LayerNorm: e.g. dz @ W1 + d_fo)
+//     dx = rstd * (v*gamma - mean(v*gamma) - xhat * mean(v*gamma*xhat)),  xhat = (y - beta) / gamma
+//     dgamma += sum_rows v*xhat ; dbeta += sum_rows v ;  dxm = dx * dropout-mask (gradient of the dropped dense branch)
+// In the backward chain of a BERT block every input-gradient GEMM that lands on a block boundary is followed by exactly
+// such a LayerNorm backward (FFN dX -> attention-output LN; QKV dX -> the previous block's output LN), so the separate
+// ln_bwd launch and the round trip of v through memory disappear.  A workgroup owns 32 full rows (as linear_ln), the weight
+// is staged in its natural [k][out] orientation and read back transposed (ds_read_b64_tr_b16 / dword reads in fp32).
+struct LlbParams {
+  int M, K; const void* X; int lda; const void* W; int ldb; const void* R; int ldr;
+  const void* y; const float* gamma; const float* beta; const float* rstd;
+  void* dx; void* dxm; float* dgamma; float* dbeta; DropDesc drop;
+};
+
+template <int SN>
+__device__ __forceinline__ bf16x8 frag_oc(const bf16* s, int out0, int ks, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const bf16* b = s + (ks * 32 + 8 * g + q) * SN + out0 + 4 * pp;
+  typedef bf16x4_t __attribute__((address_space(3))) * lds4;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * SN));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int SN>
+__device__ __forceinline__ float frag_oc(const float* s, int out0, int ks, int lane) {
+  return s[(ks * 4 + (lane >> 4)) * SN + out0 + (lane & 15)];
+}
+
+template <typename T, int HT>
+__device__ __forceinline__ void linear_lnb_body(const LlbParams& pp, const int bid, unsigned char* lds_raw) {
+  typedef typename TT<T>::vec vec;
+  constexpr int VE = TT<T>::VE, BK = TT<T>::BK, STRIDE = TT<T>::STRIDE;
+  constexpr int H = 64 * HT, WC = 16 * HT, SN = H + (sizeof(T) == 2 ? 8 : 4);
+  constexpr int KS = (sizeof(T) == 2) ? 2 : 8;
+  const int M = pp.M, K = pp.K, lda = pp.lda, ldb = pp.ldb;
+  const T* __restrict__ X = (const T*)pp.X; const T* __restrict__ W = (const T*)pp.W;
+  T* sA = (T*)lds_raw;                       // [32][STRIDE]  (k contiguous)
+  T* sB = sA + 32 * STRIDE;                  // [BK][SN]      (natural: out contiguous)
+  float* red = (float*)(sB + BK * SN);       // [2][4][32]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int m0 = bid * 32;
+  f32x4 acc[2][HT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < HT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int VPR_B = H / VE;                       // vectors per k-row of the weight tile
+  constexpr int VPT_B = BK * VPR_B / 256;             // per thread
+  vec va, vb[VPT_B];
+  auto load = [&](int k0) {
+    {
+      const int row = tid >> 3, cv = tid & 7;
+      vec z;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) z[e] = (T)0.0f;
+      if (m0 + row < M && k0 + cv * VE < K) z = *(const vec*)(X + (long long)(m0 + row) * lda + k0 + cv * VE);
+      va = z;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT_B; ++i) {
+      const int id = tid + 256 * i, kr = id / VPR_B, ov = id % VPR_B;
+      vec z;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) z[e] = (T)0.0f;
+      if (k0 + kr < K) z = *(const vec*)(W + (long long)(k0 + kr) * ldb + ov * VE);
+      vb[i] = z;
+    }
+  };
+  auto store = [&]() {
+    {
+      T* d = sA + (tid >> 3) * STRIDE + (tid & 7) * VE;
+      if constexpr (sizeof(T) == 2) { *(vec*)d = va; }
+      else { ((float2*)d)[0] = make_float2(va[0], va[1]); ((float2*)d)[1] = make_float2(va[2], va[3]); }
+    }
+#pragma unroll
+    for (int i = 0; i < VPT_B; ++i) {
+      const int id = tid + 256 * i, kr = id / VPR_B, ov = id % VPR_B;
+      *(vec*)(sB + kr * SN + ov * VE) = vb[i];          // SN * sizeof(T) is a multiple of 16
+    }
+  };
+  const int ktiles = (K + BK - 1) / BK;
+  load(0);
+  for (int kt = 0; kt < ktiles; ++kt) {
+    store();
+    __syncthreads();
+    if (kt + 1 < ktiles) load((kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const auto a0 = frag<true>(sA, 0, ks, lane), a1 = frag<true>(sA, 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < HT; ++j) {
+        const auto b = frag_oc<SN>(sB, w * WC + j * 16, ks, lane);
+        if constexpr (sizeof(T) == 2) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][j], 0, 0, 0);
+        } else {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: v = acc + R ; LayerNorm backward over the full row (cross-wave) ; parameter gradients
+  const T* __restrict__ R = (const T*)pp.R; const T* __restrict__ Y = (const T*)pp.y;
+  float gm[HT], bt[HT], ig[HT];
+#pragma unroll
+  for (int j = 0; j < HT; ++j) {
+    const int col = w * WC + j * 16 + c16;
+    gm[j] = pp.gamma[col]; bt[j] = pp.beta[col]; ig[j] = gm[j] != 0.f ? 1.f / gm[j] : 0.f;
+  }
+  float xh[2][HT][4];
+  float s1[2][4], s2[2][4];
+  float pg[HT], pb[HT];
+#pragma unroll
+  for (int j = 0; j < HT; ++j) { pg[j] = 0.f; pb[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + i * 16 + 4 * g + r;
+      const bool live = row < M;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < HT; ++j) {
+        const int col = w * WC + j * 16 + c16;
+        float v = 0.f, x = 0.f;
+        if (live) {
+          v = acc[i][j][r] + (R ? to_f(R[(long long)row * pp.ldr + col]) : 0.f);
+          x = (to_f(Y[(long long)row * H + col]) - bt[j]) * ig[j];
+        }
+        pg[j] += v * x; pb[j] += v;
+        const float ga = v * gm[j];
+        acc[i][j][r] = ga; xh[i][j][r] = x;
+        t1 += ga; t2 += ga * x;
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+      s1[i][r] = t1; s2[i][r] = t2;
+    }
+  if (c16 == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[w * 32 + i * 16 + 4 * g + r] = s1[i][r];
+        red[128 + w * 32 + i * 16 + 4 * g + r] = s2[i][r];
+      }
+  }
+  __syncthreads();
+  const DropState dsn = drop_init(pp.drop);
+  T* __restrict__ dx = (T*)pp.dx; T* __restrict__ dxm = (T*)pp.dxm;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = i * 16 + 4 * g + r, row = m0 + rr;
+      if (row < M) {
+        const float m1 = (red[rr] + red[32 + rr] + red[64 + rr] + red[96 + rr]) / H;
+        const float m2 = (red[128 + rr] + red[160 + rr] + red[192 + rr] + red[224 + rr]) / H;
+        const float rs = pp.rstd[row];
+#pragma unroll
+        for (int j = 0; j < HT; ++j) {
+          const int col = w * WC + j * 16 + c16;
+          const float d = rs * (acc[i][j][r] - m1 - xh[i][j][r] * m2);
+          dx[(long long)row * H + col] = from_f<T>(d);
+          if (dxm) dxm[(long long)row * H + col] = from_f<T>(dsn.on ? d * drop_mul(dsn, (unsigned)(row * H + col)) : d);
+        }
+      }
+    }
+  // gamma / beta gradients: this thread's 8 rows are summed already; fold the 4 row groups (g) and issue one atomic per column
+  if (pp.dgamma) {
+#pragma unroll
+    for (int j = 0; j < HT; ++j) {
+      float a = pg[j], b = pb[j];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      if (g == 0) {
+        const int col = w * WC + j * 16 + c16;
+        atomicAdd(pp.dgamma + col, a);
+        atomicAdd(pp.dbeta + col, b);
+      }
+    }
+  }
+}
+
+template <typename T, int HT>
+__global__ __launch_bounds__(256) void linear_lnb_kernel(LlbParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+  linear_lnb_body<T, HT>(p, blockIdx.x, lds_dyn);
+}
+template <typename T, int HT>
+__global__ __launch_bounds__(256) void linear_lnb_pair_kernel(LlbParams a, LlbParams b, int nA) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+  if ((int)blockIdx.x < nA) linear_lnb_body<T, HT>(a, blockIdx.x, lds_dyn);
+  else linear_lnb_body<T, HT>(b, blockIdx.x - nA, lds_dyn);
+}
+
+extern "C" int magic_linear_lnbwd(int dtype, int M, int H, int K, const void* x, int lda, const void* W, int ldb,
+                                  const void* residual, int ldr, const void* y, const float* gamma, const float* beta, const float* rstd,
+                                  void* dx, void* dxm, float* dgamma, float* dbeta,
+                                  const void* drop_seed, float drop_p, unsigned drop_site, void* stream) {
+  if (M <= 0 || K <= 0 || !x || !W || !y || !gamma || !beta || !rstd || !dx) return MAGIC_ERR_ARG;
+  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return MAGIC_ERR_ARG;
+  if (!drop_args_ok(drop_seed, drop_p) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+  const int ve = dtype == DT_BF16 ? 8 : 4;
+  if (lda % ve || ldb % ve || ldb < H || ((uintptr_t)x & 15) || ((uintptr_t)W & 15)) return MAGIC_ERR_ARG;
+  if (H != 128 && H != 256) return MAGIC_ERR_UNSUPPORTED;
+  const bool don = drop_p > 0.f && drop_site != 0;
+  if (don && !dxm) return MAGIC_ERR_ARG;
+  LlbParams p{M, K, x, lda, W, ldb, residual, ldr, y, gamma, beta, rstd, dx, don ? dxm : nullptr, dgamma, dbeta,
+              DropDesc{don ? (const unsigned*)drop_seed : nullptr, drop_site, drop_p}};
+  const int ht = H / 64;
+  if (group_record(KIND_LLB, dtype, ht, &p, sizeof(p))) return MAGIC_OK;
+  return launch_llb(dtype, ht, &p, nullptr, (hipStream_t)stream);
+}
+
+int launch_llb(int dtype, int ht, const void* pa, const void* pb, hipStream_t st) {
+  const LlbParams& a = *(const LlbParams*)pa;
+  dim3 block(256);
+  const int nA = (a.M + 31) / 32;
+#define LLB1(TY, HT)                                                                                                      \
+  do {                                                                                                                    \
+    constexpr int SN_ = 64 * HT + (sizeof(TY) == 2 ? 8 : 4);                                                              \
+    const size_t shm = (size_t)(32 * TT<TY>::STRIDE + TT<TY>::BK * SN_) * sizeof(TY) + 256 * sizeof(float);               \
+    if (!pb) {                                                                                                            \
+      if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)linear_lnb_kernel<TY, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+      hipLaunchKernelGGL((linear_lnb_kernel<TY, HT>), dim3(nA), block, shm, st, a);                                       \
+    } else {                                                                                                              \
+      const LlbParams& b = *(const LlbParams*)pb;                                                                         \
+      if (shm > 64 * 1024) (void)hipFuncSetAttribute((const void*)linear_lnb_pair_kernel<TY, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+      hipLaunchKernelGGL((linear_lnb_pair_kernel<TY, HT>), dim3(nA + (b.M + 31) / 32), block, shm, st, a, b, nA);         \
+    }                                                                                                                     \
+  } while (0)
+  if (dtype == DT_BF16) { if (ht == 2) LLB1(bf16, 2); else LLB1(bf16, 4); }
+  else { if (ht == 2) LLB1(float, 2); else LLB1(float, 4); }
+#undef LLB1
+  return launch_status();
+}
+
 // host-visible descriptor of one weight-gradient problem: dW[N,K] (fp32, ldc) += dY[M,N]^T (lda) @ X[M,K] (ldb); db[N] += colsum(dY)
 struct magic_dw_desc { const void* dY; const void* X; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk; };
 

@@ -287,11 +287,34 @@ class MagicNet:
         O.ln_bwd(M, self.H, dy, y=y, gamma=n.g, beta=n.b, rstd=rstd, dx=d_sum, dgamma=n.dg, dbeta=n.db, drop_dx=hdrop, dxm=d_dense)
         return d_sum, (d_dense if hdrop else d_sum)
 
-    def _sa_bwd(self, lp, c, d_a, dsprel=None, dP_init=None):
+    # A gradient handed between backward segments is either a plain tensor (wrt a LayerNorm OUTPUT) or a `Pre` pair (already
+    # pushed through that LayerNorm by the producer's fused GEMM epilogue: magic_linear_lnbwd).
+    def _ln_desc(self, base, y, rstd, hdrop):
+        return Ctx(n=self.ln(base), y=y, rstd=rstd, hdrop=hdrop)
+
+    def _through_ln(self, d, desc, M):
+        """(d_sum, d_dense) of the LayerNorm described by desc, from d = plain gradient or an already-processed Pre pair"""
+        if isinstance(d, tuple):
+            return d
+        return self._add_ln_bwd(desc.n, M, d, desc.y, desc.rstd, desc.hdrop)
+
+    def _dx_into_ln(self, dy, lin, M, residual, fuse, rows):
+        """input gradient dy @ W (+ residual).  With `fuse` (descriptor of the LayerNorm that produced this dense's input) and a
+        supported shape the LayerNorm backward runs in the GEMM epilogue and a Pre pair is returned; else the plain tensor."""
+        if fuse is not None and O.linear_lnbwd_ok(self.H, lin.W.shape[0]) and lin.W.shape[1] == self.H:
+            d_sum = self.new(M, self.H)
+            d_dense = self.new(M, self.H) if fuse.hdrop else None
+            O.linear_lnbwd(dy, lin.W, M, residual, fuse.y, fuse.n.g, fuse.n.b, fuse.rstd, d_sum, fuse.n.dg, fuse.n.db,
+                           drop=fuse.hdrop, dxm=d_dense, flop_rows=rows)
+            return (d_sum, d_dense if fuse.hdrop else d_sum)
+        return O.linear_dx(dy, lin.W, M, residual=residual, flop_rows=rows)
+
+    def _sa_bwd(self, lp, c, d_a, dsprel=None, dP_init=None, fuse=None):
+        """d_a: gradient wrt the attention-output LayerNorm's output (plain) or its Pre pair; fuse: descriptor of the LayerNorm
+        that produced this block's input x (the previous block's output LN), or None."""
         H, Bn, N = self.H, c.Bn, c.N
         M = Bn * N
-        n = self.ln(lp + "attention.output.LayerNorm")
-        d_ao, d_aod = self._add_ln_bwd(n, M, d_a, c.a, c.rstd_a, c.hdrop)
+        d_ao, d_aod = self._through_ln(d_a, self._ln_desc(lp + "attention.output.LayerNorm", c.a, c.rstd_a, c.hdrop), M)
         o = self.lin(lp + "attention.output.dense.weight")
         O.linear_dw(d_aod, c.ctx, o.dW, o.db, M, flop_rows=c.rows)
         d_ctx = O.linear_dx(d_aod, o.W, M, flop_rows=c.rows)
@@ -301,7 +324,7 @@ class MagicNet:
                        c.adrop, c.P if c.adrop else None)
         qkv = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
         O.linear_dw(dqkv, c.x, qkv.dW, qkv.db, M, flop_rows=c.rows)
-        return O.linear_dx(dqkv, qkv.W, M, residual=d_ao, flop_rows=c.rows)
+        return self._dx_into_ln(dqkv, qkv, M, d_ao, fuse, c.rows)
 
     # ---- FFN + add&norm ------------------------------------------------------------------------
     def _ffn_fwd(self, lp, a, M, rows):
@@ -316,15 +339,15 @@ class MagicNet:
         self._dense_add_ln(c.g, f2, a, n, M, c.out, c.rstd, rows, c.hdrop)
         return c
 
-    def _ffn_bwd(self, lp, c, dout):
+    def _ffn_bwd(self, lp, c, dout, fuse=None):
+        """dout: plain gradient wrt the block output or its Pre pair; fuse: descriptor of the LayerNorm that produced c.a"""
         H, M = self.H, c.M
-        n = self.ln(lp + "output.LayerNorm")
-        d_fo, d_fod = self._add_ln_bwd(n, M, dout, c.out, c.rstd, c.hdrop)
+        d_fo, d_fod = self._through_ln(dout, self._ln_desc(lp + "output.LayerNorm", c.out, c.rstd, c.hdrop), M)
         f1, f2 = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")
         O.linear_dw(d_fod, c.g, f2.dW, f2.db, M, flop_rows=c.rows)
         d_z = O.linear_dx(d_fod, f2.W, M, epilogue=3, aux=c.z, flop_rows=c.rows)
         O.linear_dw(d_z, c.a, f1.dW, f1.db, M, flop_rows=c.rows)
-        return O.linear_dx(d_z, f1.W, M, residual=d_fo, flop_rows=c.rows)
+        return self._dx_into_ln(d_z, f1, M, d_fo, fuse, c.rows)
 
     # ---- layers --------------------------------------------------------------------------------
     def self_layer_fwd(self, lp, x, Bn, N, kmask, rows, aflops, qkv=None, next_lp=None):
@@ -348,9 +371,14 @@ class MagicNet:
         c.out, c.P, c.ldp = c.ffn.out, c.sa.P, c.sa.ldp
         return c
 
-    def self_layer_bwd(self, lp, c, dout, dP_init=None):
-        d_a = self._ffn_bwd(lp, c.ffn, dout)
-        return self._sa_bwd(lp, c.sa, d_a, None, dP_init)
+    def self_layer_bwd(self, lp, c, dout, dP_init=None, fuse_in=None):
+        """fuse_in: descriptor of the LayerNorm that produced this block's input (then a Pre pair is returned)"""
+        d_a = self._ffn_bwd(lp, c.ffn, dout, fuse=self._ln_desc(lp + "attention.output.LayerNorm", c.sa.a, c.sa.rstd_a, c.sa.hdrop))
+        return self._sa_bwd(lp, c.sa, d_a, None, dP_init, fuse=fuse_in)
+
+    def _out_ln_desc(self, lp, lc):
+        """descriptor of a block's output LayerNorm (BertOutput.LayerNorm)"""
+        return self._ln_desc(lp + "output.LayerNorm", lc.ffn.out, lc.ffn.rstd, lc.ffn.hdrop)
 
     def cross_layer_fwd(self, lp, x, Bn, Nq, kmask, dist, sprel, ctx, Nk, ckmask, rows, crow, sflops, cflops, qkv=None, next_lp=None):
         H = self.H
@@ -390,13 +418,14 @@ class MagicNet:
         c.out = c.ffn.out
         return c
 
-    def cross_layer_bwd(self, lp, c, dout, d_ctx_acc, dsprel=None, dP_init=None):
-        """returns dx; accumulates the gradient wrt the context (other modality) into d_ctx_acc."""
+    def cross_layer_bwd(self, lp, c, dout, d_ctx_acc, dsprel=None, dP_init=None, fuse_in=None):
+        """returns dx (plain, or a Pre pair when fuse_in is given); accumulates the gradient wrt the context (other modality)
+        into d_ctx_acc."""
         H, Bn, Nq, Nk = self.H, c.Bn, c.Nq, c.Nk
         Mq, Mk = Bn * Nq, Bn * Nk
-        d_c = self._ffn_bwd(lp, c.ffn, dout)
-        n = self.ln(lp + "crossattention.output.LayerNorm")
-        d_co, d_cod = self._add_ln_bwd(n, Mq, d_c, c.c, c.rstd_c, c.hdrop)
+        c_ln = self._ln_desc(lp + "crossattention.output.LayerNorm", c.c, c.rstd_c, c.hdrop)
+        d_c = self._ffn_bwd(lp, c.ffn, dout, fuse=c_ln)
+        d_co, d_cod = self._through_ln(d_c, c_ln, Mq)
         o = self.lin(lp + "crossattention.output.dense.weight")
         O.linear_dw(d_cod, c.cctx, o.dW, o.db, Mq, flop_rows=c.rows)
         d_cctx = O.linear_dx(d_cod, o.W, Mq, flop_rows=c.rows)
@@ -406,10 +435,10 @@ class MagicNet:
         ql = self.lin(lp + "crossattention.self.query.weight")
         kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
         O.linear_dw(dq, c.sa.a, ql.dW, ql.db, Mq, flop_rows=c.rows)
-        d_s = O.linear_dx(dq, ql.W, Mq, residual=d_co, flop_rows=c.rows)
+        d_s = self._dx_into_ln(dq, ql, Mq, d_co, self._ln_desc(lp + "attention.output.LayerNorm", c.sa.a, c.sa.rstd_a, c.sa.hdrop), c.rows)
         O.linear_dw(dkv, c.ctx, kvl.dW, kvl.db, Mk, flop_rows=c.crow)
         O.linear_dx(dkv, kvl.W, Mk, out=d_ctx_acc, residual=d_ctx_acc, flop_rows=c.crow)
-        return self._sa_bwd(lp, c.sa, d_s, dsprel, None)
+        return self._sa_bwd(lp, c.sa, d_s, dsprel, None, fuse=fuse_in)
 
     # ---- text encoder --------------------------------------------------------------------------
     def _flops_attn(self, lens_q, lens_k):
@@ -445,8 +474,10 @@ class MagicNet:
         p, H = self.p, self.H
         M = c.B * c.L
         d = d_out
-        for i in reversed(range(self.cfg.num_l_layers)):
-            d = self.self_layer_bwd(f"{p}lang_encoder.layer.{i}.", c.layers[i], d, dP_init if i == self.cfg.num_l_layers - 1 else None)
+        nl = self.cfg.num_l_layers
+        for i in reversed(range(nl)):
+            prev = self._out_ln_desc(f"{p}lang_encoder.layer.{i - 1}.", c.layers[i - 1]) if i > 0 else None
+            d = self.self_layer_bwd(f"{p}lang_encoder.layer.{i}.", c.layers[i], d, dP_init if i == nl - 1 else None, fuse_in=prev)
         n = self.ln(p + "embeddings.LayerNorm")
         O.ln_bwd(M, H, d, y=c.E, gamma=n.g, beta=n.b, rstd=c.rstd_e, dx=None, dgamma=n.dg, dbeta=n.db, drop_dy=c.edrop,
                  dtabs=((plan["txt_ids"], 0, 0, self.S.g(p + "embeddings.word_embeddings.weight"), 0),
@@ -505,8 +536,10 @@ class MagicNet:
             fl = self.lin(p + "pano_fuse_linear.weight")
             O.pano_fuse_bwd(c.out, c.fprobs, fl.Wm, d_fused, d_pano, fl.dW, fl.db, Np, V, H)
         d = d_pano
-        for i in reversed(range(self.cfg.num_pano_layers)):
-            d = self.self_layer_bwd(f"{p}pano_encoder.layer.{i}.", c.layers[i], d, dP_init if i == self.cfg.num_pano_layers - 1 else None)
+        nl = self.cfg.num_pano_layers
+        for i in reversed(range(nl)):
+            prev = self._out_ln_desc(f"{p}pano_encoder.layer.{i - 1}.", c.layers[i - 1]) if i > 0 else None
+            d = self.self_layer_bwd(f"{p}pano_encoder.layer.{i}.", c.layers[i], d, dP_init if i == nl - 1 else None, fuse_in=prev)
         n3 = self.ln(p + "layer_norm")
         dsum = self.new(M, H)
         O.ln_bwd(M, H, d, y=c.X0, gamma=n3.g, beta=n3.b, rstd=c.rstd_x0, dx=dsum, dgamma=n3.dg, dbeta=n3.db, drop_dy=c.edrop,
@@ -602,5 +635,7 @@ class MagicNet:
         d = d_out
         nl = self.cfg.num_x_layers
         for i in reversed(range(nl)):
-            d = self.cross_layer_bwd(f"{enc}encoder.crossattention.{i}.", c.layers[i], d, d_ctx_acc, dsprel, dP_init if i == nl - 1 else None)
+            prev = self._out_ln_desc(f"{enc}encoder.crossattention.{i - 1}.", c.layers[i - 1]) if i > 0 else None
+            d = self.cross_layer_bwd(f"{enc}encoder.crossattention.{i}.", c.layers[i], d, d_ctx_acc, dsprel, dP_init if i == nl - 1 else None,
+                                     fuse_in=prev)
         return d

@@ -22,6 +22,7 @@ SIGNATURES = {
                    vp, i32, vp, i32, vp, i32, vp, i32, f32, i32, vp, vp],
     "magic_gemm_dw_grouped": [i32, i32, vp, vp],
     "magic_linear_ln": [i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, vp, f32, u32, vp],
+    "magic_linear_lnbwd": [i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, u32, vp],
     "magic_dropout": [i32, i64, i32, i32, vp, vp, vp, f32, u32, vp],
     "magic_ln_fwd": [i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, vp, vp, i32,
                      vp, f32, u32, u32, vp, vp],
@@ -112,7 +113,7 @@ def P(t):
 
 
 PROFILE = {"on": False, "events": []}     # bench.py: per-launch HIP-event timing on the launch stream
-PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_ln_bwd", "magic_rowblock_fwd"}
+PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_linear_lnbwd", "magic_ln_bwd", "magic_rowblock_fwd"}
 _tls = threading.local()
 
 

@@ -173,6 +173,24 @@ def linear_ln(x, W, b, M, residual, gamma, beta, eps, out, rstd, flop_rows=None,
     return out
 
 
+FUSED_LNB = not os.environ.get("MAGIC_NO_FUSED_LNB")
+
+
+def linear_lnbwd_ok(H, K):
+    return FUSED_LNB and H in (128, 256) and K <= 512
+
+
+def linear_lnbwd(x, W, M, residual, y, gamma, beta, rstd, dx, dgamma, dbeta, drop=None, dxm=None, flop_rows=None):
+    """dx = LayerNorm-backward(x @ W + residual; y, gamma, beta, rstd) in one launch; W [K, H] = the forward weight of the dense
+    whose input gradient this is; dxm = dx * dropout mask (when the LayerNorm's dense branch was dropped)."""
+    K, H = W.shape
+    _count(flop_rows if flop_rows is not None else M, H, K)
+    L.call("magic_linear_lnbwd", L.dt(x.dtype), M, H, K, L.P(x), x.stride(0), L.P(W), W.stride(0), L.P(residual),
+           residual.stride(0) if residual is not None else 0, L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(dx), L.P(dxm),
+           L.P(dgamma), L.P(dbeta), *_dr(drop), L.stream())
+    return dx
+
+
 def dropout(x, out, rows, cols, ld, drop):
     """out = x * keep / (1-p) with the mask of `drop` over the logical [rows, cols] tensor (row pitch ld); x may be out."""
     L.call("magic_dropout", L.dt(x.dtype), rows, cols, ld, L.P(x), L.P(out), *_dr(drop), L.stream())

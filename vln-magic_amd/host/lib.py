@@ -117,7 +117,17 @@ PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln",
 _tls = threading.local()
 
 
+_DEBUG_SYNC = bool(os.environ.get("MAGIC_DEBUG_SYNC"))     # print + synchronize around every launch (localises a faulting kernel)
+
+
 def _raw_call(name, args):
+    if _DEBUG_SYNC:
+        print("[magic]", name, flush=True)
+        rc = getattr(load(), name)(*args)
+        torch.cuda.synchronize()
+        if rc != 0:
+            raise MagicHipError(f"{name} failed: {_ERR.get(rc, rc)}")
+        return
     if PROFILE["on"]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -134,6 +144,9 @@ def call(name, *args):
     ls = getattr(_tls, "lockstep", None)
     if ls is not None and name in PAIRABLE:
         return ls.submit(_tls.idx, name, args)
+    if ls is not None and PROFILE["on"]:
+        with ls.cv:            # instrumented pass: keep this launch's event pair free of the partner thread's launches
+            return _raw_call(name, args)
     _raw_call(name, args)
 
 

@@ -127,10 +127,13 @@ def broadcast_task(task_id, device):
 
 
 class CapturedStep:
-    """A HIP graph of one training step bound to one resident batch (+ its plan)."""
+    """A HIP graph of one training step bound to one resident batch (+ its plan).  The graph's kernels address the batch and
+    plan tensors directly, so the step owns references to them: dropping the caller's copies must not free memory a replay
+    still reads (index arrays read from recycled memory are out-of-bounds accesses on the device)."""
 
-    def __init__(self, graph, out, traj_steps, full):
+    def __init__(self, graph, out, traj_steps, full, keep=None):
         self.graph, self.out, self.traj_steps, self.full = graph, out, traj_steps, full
+        self.keep = keep
 
 
 class PretrainStep:
@@ -198,7 +201,7 @@ class PretrainStep:
             out = self._fwd_bwd(batch, task, rw, plan)
             if full:
                 self._optimize()
-        return CapturedStep(g, out, plan["traj_steps"], full)
+        return CapturedStep(g, out, plan["traj_steps"], full, keep=(batch, plan, rw))
 
     def replay(self, cs):
         cs.graph.replay()

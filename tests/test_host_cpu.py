@@ -121,3 +121,24 @@ def test_synthetic_batches_are_deterministic_and_r2r_shaped():
     assert a["traj_view_img_fts"].shape[1:] == (36, 768) and a["txt_ids"].shape[1] <= 80
     assert 48 * 4 <= a["traj_view_img_fts"].shape[0] <= 48 * 7
     assert a["vp_pos_fts"].shape == (48, 37, 14) and (a["txt_ids"][:, 0] == 0).all()
+
+
+def test_out_of_range_batch_values_are_rejected_on_the_host():
+    """ids the kernels would use as table rows are range-checked against the config before any launch"""
+    from types import SimpleNamespace
+    from magic_amd.host import synth
+    from magic_amd.host.plan import build_plan, check_plan
+    cfg = make_config(128, vocab_size=300)
+    batch = synth.make_batch("sap", batch_size=2, seed=1, vocab=300, min_len=5, max_len=7, min_steps=1, max_steps=2)
+    plan = build_plan(batch, "sap", torch.device("cpu"))
+    check_plan(plan, cfg)                                            # fits
+    for key, val, field in (("txt_ids", 300, None), ("gmap_step_ids", 100, None), ("traj_nav_types", 3, None), ("txt_ids", -1, None)):
+        b = dict(batch)
+        t = batch[key].clone()
+        t.view(-1)[0] = val
+        b[key] = t
+        with pytest.raises(ValueError):
+            check_plan(build_plan(b, "sap", torch.device("cpu")), cfg)
+    long_cfg = make_config(128, vocab_size=300, max_position_embeddings=6)
+    with pytest.raises(ValueError):
+        check_plan(build_plan(batch, "sap", torch.device("cpu")), long_cfg)

@@ -212,7 +212,7 @@ extern "C" int magic_sap_fuse_bwd(int B, int K, int Vp, const float* g_raw, cons
 // `order` carries the reference's token order: candidate views first, then the remaining views (dataset.py:742-756).
 // Pure HBM stream over 16-byte vectors; algorithmic bytes = 2 * D * sizeof(T) per view.
 template <typename T>
-__global__ __launch_bounds__(256) void view_gather_kernel(long long rows, int V, int D, const T* table, const int* vp_row, const int* order, T* out) {
+__global__ __launch_bounds__(256) void view_gather_kernel(long long rows, int V, int D, const T* table, int n_vp, const int* vp_row, const int* order, T* out) {
   constexpr int VE = 16 / sizeof(T), UN = 4;
   typedef __attribute__((ext_vector_type(4))) unsigned int u4;
   const int nvec = D / VE;                                    // 16-byte vectors per view row (96 for 768 bf16)
@@ -228,7 +228,9 @@ __global__ __launch_bounds__(256) void view_gather_kernel(long long rows, int V,
       if (v < total) {
         const long long r = v / nvec;
         const int c = (int)(v - r * nvec), sv = order[r];
-        if (sv >= 0) val[u] = __builtin_nontemporal_load((const u4*)(table + ((long long)vp_row[r / V] * 36 + sv) * D) + c);   // read once
+        const int vr = vp_row[r / V];
+        if (sv >= 0 && sv < 36 && (unsigned)vr < (unsigned)n_vp)        // indices come from the data side: never read outside the table
+          val[u] = __builtin_nontemporal_load((const u4*)(table + ((long long)vr * 36 + sv) * D) + c);   // read once
       }
     }
 #pragma unroll
@@ -249,7 +251,7 @@ extern "C" int magic_view_gather(int dtype, int Np, int V, int D, const void* ta
   const long long chunks = (rows * (D / ve) + 256 * 4 - 1) / (256 * 4);
   dim3 grid((unsigned)(chunks < 1 ? 1 : chunks)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16) hipLaunchKernelGGL(view_gather_kernel<bf16>, grid, block, 0, st, rows, V, D, (const bf16*)table, vp_row, order, (bf16*)out);
-  else hipLaunchKernelGGL(view_gather_kernel<float>, grid, block, 0, st, rows, V, D, (const float*)table, vp_row, order, (float*)out);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(view_gather_kernel<bf16>, grid, block, 0, st, rows, V, D, (const bf16*)table, n_viewpoints, vp_row, order, (bf16*)out);
+  else hipLaunchKernelGGL(view_gather_kernel<float>, grid, block, 0, st, rows, V, D, (const float*)table, n_viewpoints, vp_row, order, (float*)out);
   return launch_status();
 }

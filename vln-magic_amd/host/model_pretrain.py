@@ -17,7 +17,7 @@ from . import ops as O
 from .config import cfg_get
 from .engine import Ctx, MagicNet, cls_specs, rup, trunk_specs
 from .params import ParamStore
-from .plan import build_plan
+from .plan import build_plan, check_plan
 
 LOCKSTEP = not os.environ.get("MAGIC_NO_LOCKSTEP")
 KD_SLOTS = ("txt_emb_loss", "txt_attn_loss", "img_emb_loss", "avg_img_emb_loss", "img_attn_loss",
@@ -169,6 +169,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         O.DEFER["queue"].clear()
         self._arm_dropout()
         plan = plan if plan is not None else build_plan(batch, task, self.device_)
+        check_plan(plan, self.config)
         inp = inputs if inputs is not None else self._inputs(batch, plan)
         B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H
         c = Ctx(task=task, plan=plan, inp=inp)

@@ -130,8 +130,33 @@ def build_plan(batch, task, device, ld_round=8):
     for name, (f, t) in plan_csr.items():
         plan[name] = tuple(torch.from_numpy(a).to(device, non_blocking=True) for a in f)
         plan[name + "_T"] = tuple(torch.from_numpy(a).to(device, non_blocking=True) for a in t)
+    # value ranges of everything the kernels use as a table index, taken on the host copies (the device never bounds-checks:
+    # an out-of-range id would be an out-of-bounds read on the GPU) -- validated against the model config by check_plan()
+    plan["limits"] = dict(txt_id=int(batch["txt_ids"].max()), txt_id_min=int(batch["txt_ids"].min()),
+                          step_id=int(batch["gmap_step_ids"].max()), step_id_min=int(batch["gmap_step_ids"].min()),
+                          nav_type=int(batch["traj_nav_types"].max()), nav_type_min=int(batch["traj_nav_types"].min()))
     plan.update(B=B, L=L, K=K, Vp=Vp, Np=Np, V=V, last_rows=last_rows,
                 n_mask=(int(plan["mlm_labels"].numel()) if task == "mlm" else 0), n_mrc=n_mrc,
                 txt_tokens=int(txt_lens.sum()), gmap_nodes=int(batch["gmap_lens"].sum()), traj_steps=Np,
                 lens=dict(txt=txt_lens.tolist(), gmap=batch["gmap_lens"].tolist(), steps=list(step_lens)))
     return plan
+
+
+def check_plan(plan, cfg):
+    """Raise (on the host, before any launch) if a batch would index a table out of range."""
+    lim = plan.get("limits")
+    if lim is None or plan.get("_checked") is cfg:
+        return
+    def bad(msg):
+        raise ValueError(f"batch does not fit the model config: {msg}")
+    if lim["txt_id_min"] < 0 or lim["txt_id"] >= cfg.vocab_size:
+        bad(f"txt_ids in [{lim['txt_id_min']}, {lim['txt_id']}] vs vocab_size {cfg.vocab_size}")
+    if plan["L"] + 2 > cfg.max_position_embeddings:
+        bad(f"{plan['L']} tokens need position rows up to {plan['L'] + 1}, max_position_embeddings is {cfg.max_position_embeddings}")
+    if lim["step_id_min"] < 0 or lim["step_id"] >= cfg.max_action_steps:
+        bad(f"gmap_step_ids up to {lim['step_id']} vs max_action_steps {cfg.max_action_steps}")
+    if lim["nav_type_min"] < 0 or lim["nav_type"] > 2:
+        bad(f"traj_nav_types in [{lim['nav_type_min']}, {lim['nav_type']}] (nav_type_embedding has 3 rows)")
+    if plan["V"] > 64:
+        bad(f"{plan['V']} view tokens per panorama (the panorama kernels serve <= 64)")
+    plan["_checked"] = cfg

@@ -124,7 +124,11 @@ class _LanguageFn(torch.autograd.Function):
     def forward(ctx, anchor, model, txt_ids, txt_masks):
         net = model.net
         B, L = txt_ids.shape
-        lens = txt_masks.sum(1).tolist()
+        lens = txt_masks.sum(1).tolist()        # (already a host sync: the range check below rides on it)
+        lo, hi = int(txt_ids.min()), int(txt_ids.max())
+        if lo < 0 or hi >= net.cfg.vocab_size or L + 2 > net.cfg.max_position_embeddings:
+            raise ValueError(f"language input does not fit the model config: ids in [{lo}, {hi}] vs vocab_size {net.cfg.vocab_size}, "
+                             f"{L} tokens vs max_position_embeddings {net.cfg.max_position_embeddings}")
         plan = dict(B=B, L=L, txt_ids=txt_ids.reshape(-1).to(torch.int32), txt_mask=txt_masks.to(torch.uint8).contiguous(),
                     lens=dict(txt=lens), txt_tokens=int(sum(lens)))
         c = net.text_fwd(plan)

@@ -274,6 +274,7 @@ def test_bf16_dropout_step_tracks_fp32_and_graph_replay_draws_fresh_masks():
     g_s.train()
     batch = synth.make_batch("sap", batch_size=4, seed=5, vocab=600, min_len=8, max_len=19, min_steps=2, max_steps=4)
     plan = build_plan(batch, "sap", torch.device(DEV))
+    batch = synth.batch_to(batch, torch.device(DEV))        # capture() needs a device-resident batch
     tr = PretrainStep(g_s, g_t, warmup_steps=10, num_train_steps=100)
     tr.step(batch, "sap", plan=plan)                        # eager warm-up
     cs = tr.capture(batch, "sap", plan)

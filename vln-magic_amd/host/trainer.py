@@ -195,6 +195,9 @@ class PretrainStep:
     def capture(self, batch, task, plan, rw=None):
         """Capture one step for this (resident) batch.  With world_size 1 the optimizer is inside the graph; with
         data parallelism the graph ends after backward and the all-reduce + optimizer run eagerly after replay."""
+        off = [k for k, v in batch.items() if torch.is_tensor(v) and v.device.type != self.dev.type and k not in ("traj_vp_row", "traj_view_order")]
+        if off:
+            raise ValueError(f"capture() needs the batch resident on {self.dev} (synth.batch_to); host tensors: {off[:4]}...")
         full = self.sync.world == 1 and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")   # (env: exercise the DP split on 1 GPU)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="relaxed"):     # helper threads launch into the capture (lib.lockstep)

@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"], help="graph: replay one captured HIP graph per step")
+    ap.add_argument("--teacher", default="ahead", choices=["ahead", "same"],
+                    help="ahead: the frozen teacher runs on batch i+1 (side stream) while the student trains on batch i; "
+                         "same: teacher and student forward of the same batch side by side (every step runs one of each either way)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,7 +192,19 @@ def main():
         # step: teacher fwd, student fwd+losses+bwd, clip, AdamW -- with lr / bias-correction / MKRW read from device memory
         run_eager(min(3, len(pool)))                       # allocator + code-object warm-up
         torch.cuda.synchronize()
-        graphs = [trainer.capture(b, task, plan) for task, b, plan in pool]
+        if a.teacher == "ahead":
+            # graph i: student step on batch i (teacher outputs t[i] are ready) || teacher forward on batch i+1 -> t[i+1];
+            # t[0] is primed eagerly once, and the last graph of the ring copies its teacher(batch 0) outputs into it
+            n = len(pool)
+            trip = lambda i: (pool[i % n][1], pool[i % n][0], pool[i % n][2])           # (batch, task, plan)
+            t0 = trainer.teacher_forward(*trip(0))
+            t_cur, graphs = t0, []
+            for i in range(n):
+                cs = trainer.capture_ahead(trip(i), t_cur, trip(i + 1), t_next_into=t0 if i == n - 1 else None)
+                graphs.append(cs)
+                t_cur = cs.t_next
+        else:
+            graphs = [trainer.capture(b, task, plan) for task, b, plan in pool]
         torch.cuda.synchronize()
 
     def run(n, start=0):
@@ -270,6 +285,7 @@ def main():
                 "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": a.dtype, "data": "synthetic", "launch": a.mode,
+                "teacher_schedule": ("one batch ahead of the student (side stream)" if (a.teacher == "ahead" and a.mode == "graph") else "same batch, side stream"),
                 "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "
                                        "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip, student in train() mode",
                            "dropout": a.dropout,

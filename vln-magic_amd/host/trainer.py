@@ -126,6 +126,21 @@ def broadcast_task(task_id, device):
     return int(t.item())
 
 
+def copy_teacher_outputs(src, dst):
+    """dst[k].copy_(src[k]) for every tensor a teacher forward returns (incl. the cast inputs it carries)"""
+    for k, v in src.items():
+        if torch.is_tensor(v):
+            dst[k].copy_(v)
+        elif k == "cfp":
+            for a, b in zip(v, dst[k]):
+                b.copy_(a)
+        elif k == "inputs":
+            for name in ("feats", "loc", "gpos", "vpos", "dist"):
+                a, b = getattr(v, name), getattr(dst[k], name)
+                if a.data_ptr() != b.data_ptr():
+                    b.copy_(a)
+
+
 class CapturedStep:
     """A HIP graph of one training step bound to one resident batch (+ its plan).  The graph's kernels address the batch and
     plan tensors directly, so the step owns references to them: dropping the caller's copies must not free memory a replay
@@ -179,6 +194,62 @@ class PretrainStep:
         out = st(batch, task, compute_loss=True, teacher_outputs=t_out, rw=rw, plan=plan, inputs=inputs)
         st.backward()
         return out
+
+    # ---- teacher one batch ahead ---------------------------------------------------------------------------
+    # The frozen teacher's forward does not depend on the student's update, so the teacher can work on batch i+1 while the
+    # student trains on batch i (the reference's PrefetchLoader already holds the next batch, data/loader.py:78-120).  On
+    # the side stream its ~75 small launches then fill the gaps of the WHOLE student step (forward + backward, ~3 ms)
+    # instead of competing with the student's forward only.  Every step still runs exactly one teacher forward and one
+    # student update; only the order of independent work changes.
+    def teacher_forward(self, batch, task, plan):
+        """teacher outputs for one batch (also carries the cast inputs, reused by the student's step on that batch)"""
+        with torch.no_grad():
+            inputs = self.student._inputs(batch, plan)
+            return self.teacher(batch, task, compute_loss=False, return_outputs=True, plan=plan, inputs=inputs)
+
+    def _fwd_bwd_ahead(self, cur, t_cur, nxt, rw=None):
+        """student step on cur = (batch, task, plan) against the ready teacher outputs t_cur, while the teacher runs on nxt"""
+        st = self.student
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            t_next = self.teacher_forward(*nxt)
+        batch, task, plan = cur
+        if rw is None:
+            rw = self.mkrw()
+        st.store.zero_grad()
+        out = st(batch, task, compute_loss=True, teacher_outputs=t_cur, rw=rw, plan=plan, inputs=t_cur["inputs"])
+        st.backward()
+        main.wait_stream(self.side)
+        return out, t_next
+
+    def step_ahead(self, cur, t_cur, nxt, rw=None):
+        """eager form: returns (student outputs for cur, teacher outputs for nxt -- pass them as t_cur of the next call)"""
+        out, t_next = self._fwd_bwd_ahead(cur, t_cur, nxt, rw)
+        self._optimize()
+        self.global_step += 1
+        return out, t_next
+
+    def capture_ahead(self, cur, t_cur, nxt, rw=None, t_next_into=None):
+        """HIP-graph form of step_ahead.  t_cur's tensors must stay alive (they are written by the graph captured for the
+        previous batch, or by an eager teacher_forward).  t_next_into: optionally copy the teacher outputs for nxt into this
+        existing output dict at the end of the graph (closes the ring when a fixed pool of batches is cycled)."""
+        full = self.sync.world == 1 and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")
+        for b in (cur[0], nxt[0]):
+            off = [k for k, v in b.items() if torch.is_tensor(v) and v.device.type != self.dev.type and k not in ("traj_vp_row", "traj_view_order")]
+            if off:
+                raise ValueError(f"capture_ahead() needs both batches resident on {self.dev}; host tensors: {off[:4]}...")
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="relaxed"):
+            out, t_next = self._fwd_bwd_ahead(cur, t_cur, nxt, rw)
+            if t_next_into is not None:
+                copy_teacher_outputs(t_next, t_next_into)
+                t_next = t_next_into
+            if full:
+                self._optimize()
+        cs = CapturedStep(g, out, cur[2]["traj_steps"], full, keep=(cur, t_cur, nxt, rw))
+        cs.t_next = t_next
+        return cs
 
     def _optimize(self):
         gscale = self.sync.all_reduce()

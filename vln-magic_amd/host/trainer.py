@@ -160,10 +160,17 @@ class PretrainStep:
         self.rw_temp = rw_temp
         self.dev = student.store.device
         self.on_gpu = self.dev.type == "cuda"
-        self.side = torch.cuda.Stream() if (self.on_gpu and teacher is not None and overlap_teacher and not os.environ.get("MAGIC_NO_TEACHER_SIDE")) else None
+        self.side = None
+        if self.on_gpu and teacher is not None and overlap_teacher and not os.environ.get("MAGIC_NO_TEACHER_SIDE"):
+            self.side = torch.cuda.Stream()
         if self.on_gpu and overlap_dw and O.SIDE["stream"] is None and os.environ.get("MAGIC_DW_SIDE"):   # opt-in: no gain measured on MI355X
             O.SIDE["stream"] = torch.cuda.Stream()       # weight-gradient GEMMs leave the dX critical chain
         self.global_step = 0
+
+    def _graph_ctx(self, g):
+        # relaxed: helper threads launch into the capture (lib.lockstep).  Stream priorities were tried and rejected: a
+        # high-priority capture stream for the student chain (teacher at normal priority) made replays 1.7x SLOWER.
+        return torch.cuda.graph(g, capture_error_mode="relaxed")
 
     def mkrw(self):
         """MKRW ability weights softmax(randn(5)/rw_temp)*5 (map_nav_src/r2r/agent.py:866-871), drawn ON the device
@@ -240,7 +247,7 @@ class PretrainStep:
             if off:
                 raise ValueError(f"capture_ahead() needs both batches resident on {self.dev}; host tensors: {off[:4]}...")
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="relaxed"):
+        with self._graph_ctx(g):
             out, t_next = self._fwd_bwd_ahead(cur, t_cur, nxt, rw)
             if t_next_into is not None:
                 copy_teacher_outputs(t_next, t_next_into)
@@ -271,7 +278,7 @@ class PretrainStep:
             raise ValueError(f"capture() needs the batch resident on {self.dev} (synth.batch_to); host tensors: {off[:4]}...")
         full = self.sync.world == 1 and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")   # (env: exercise the DP split on 1 GPU)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="relaxed"):     # helper threads launch into the capture (lib.lockstep)
+        with self._graph_ctx(g):
             out = self._fwd_bwd(batch, task, rw, plan)
             if full:
                 self._optimize()

@@ -150,6 +150,12 @@ int magic_kd_rows(int M, int N, const float* s, const float* t, int ld, float te
 int magic_mse(int dtype, int g_f32, long long outer, long long inner, const void* s, long long s_stride, const void* t,
               long long t_stride, const float* w, long long rows_per_w, float norm, float coef, const float* coef_dev, float* loss, void* ds,
               long long g_stride, int accumulate, void* stream);
+/* n <= 10 independent magic_mse problems in ONE launch (the MAKD terms of a step, agent.py:546-719, sit back to back) */
+typedef struct {
+  int g_f32; long long outer, inner; const void* s; long long s_stride; const void* t; long long t_stride;
+  const float* w; long long rows_per_w; float norm, coef; const float* coef_dev; float* loss; void* ds; long long g_stride; int accumulate;
+} magic_mse_desc;
+int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* stream);
 
 /* out[n] (+)= sum_e w[e]*src[idx[e]]: map-node aggregation by viewpoint id (agent.py:905-924 semantics),
  * candidate-view / masked-token / CLS row selection; backward = same call on the transposed CSR. */
@@ -207,9 +213,10 @@ int magic_rowblock_lds_bytes(int dtype, int wn, int ww);
 int magic_rowblock_fwd(int dtype, int M, const void* X, int ldx, int K0, int nstage, const magic_rb_stage* stages,
                        const void* drop_seed, float drop_p, void* stream);
 
-/* Pair-grouping: between magic_group_begin() and magic_group_end(stream) up to two calls of magic_gemm / magic_attn_fwd /
+/* Grouping: between magic_group_begin() and magic_group_end(stream) up to eight calls of magic_gemm / magic_attn_fwd /
  * magic_attn_bwd / magic_linear_ln / magic_linear_lnbwd / magic_ln_bwd / magic_rowblock_fwd are recorded instead of launched; magic_group_end launches ONE kernel serving
- * both problems when they are the same kind / dtype / variant (else one kernel each).  Thread-local state. */
+ * the problems of the same kind / dtype / variant: GEMMs as one grouped launch (<= 8 problems), other kinds as pairs.
+ * Records must be independent of each other.  Thread-local state. */
 int magic_group_begin(void);
 int magic_group_end(void* stream);
 

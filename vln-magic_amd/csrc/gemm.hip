@@ -387,11 +387,19 @@ int launch_gemm(int dtype, int layout, const void* pa, const void* pb, hipStream
 #undef LAUNCH
     return launch_status();
   }
+  const void* ps[2] = {pa, pb};
+  return launch_gemm_n(dtype, layout, ps, 2, st);
+}
+
+int launch_gemm_n(int dtype, int layout, const void* const* ps, int n, hipStream_t st) {
+  if (n == 1) return launch_gemm(dtype, layout, ps[0], nullptr, st);
+  if (n <= 0 || n > GROUP_MAX) return MAGIC_ERR_ARG;
+  dim3 block(256);
   GroupedParams gp;
-  gp.n = 2; gp.p[0] = a; gp.p[1] = *(const GemmParams*)pb;
-  gp.start[0] = 0; gp.start[1] = gemm_blocks(gp.p[0]);
-  const int total = gp.start[1] + gemm_blocks(gp.p[1]);
-  for (int i = 2; i <= GROUP_MAX; ++i) gp.start[i] = total;
+  gp.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) { gp.p[i] = *(const GemmParams*)ps[i]; gp.start[i] = total; total += gemm_blocks(gp.p[i]); }
+  for (int i = n; i <= GROUP_MAX; ++i) gp.start[i] = total;
   dim3 grid(total);
 #define LAUNCHG(TY, L) hipLaunchKernelGGL((gemm_grouped_kernel<TY, L>), grid, block, 0, st, gp)
   if (dtype == DT_BF16) {

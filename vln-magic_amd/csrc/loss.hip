@@ -167,6 +167,74 @@ __global__ __launch_bounds__(256) void mse_kernel(long long outer, long long inn
   if (threadIdx.x == 0 && loss) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * norm);
 }
 
+// Several independent MSE problems in one launch (the ten MAKD terms of a step are computed back to back between the
+// forward and the backward: one launch instead of nine).  Blocks [start[i], start[i+1]) serve problem i.
+#define MSE_MAX 10
+struct magic_mse_desc {
+  int g_f32; long long outer, inner; const void* s; long long s_stride; const void* t; long long t_stride;
+  const float* w; long long rows_per_w; float norm, coef; const float* coef_dev; float* loss; void* ds; long long g_stride; int accumulate;
+};
+struct MseMulti { magic_mse_desc d[MSE_MAX]; int start[MSE_MAX + 1]; int n; };
+
+template <typename T, typename G>
+__device__ __forceinline__ void mse_body(const magic_mse_desc& p, int bid, int nblk, float* red) {
+  float coef = p.coef;
+  if (p.coef_dev) coef *= p.coef_dev[0];
+  const T* s = (const T*)p.s; const T* t = (const T*)p.t; G* ds = (G*)p.ds;
+  const long long total = p.outer * p.inner;
+  float acc = 0.f;
+  for (long long i = (long long)bid * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
+    const long long o = i / p.inner, r = i % p.inner;
+    const float d = to_f(s[o * p.s_stride + r]) - to_f(t[o * p.t_stride + r]);
+    const float wv = p.w ? p.w[o / p.rows_per_w] : 1.f;
+    acc += wv * d * d;
+    if (ds) {
+      float g = 2.f * coef * p.norm * wv * d;
+      G* q = ds + o * p.g_stride + r;
+      if (p.accumulate) g += to_f(*q);
+      *q = from_f<G>(g);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && p.loss) atomicAdd(p.loss, (red[0] + red[1] + red[2] + red[3]) * p.norm);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mse_multi_kernel(MseMulti mm) {
+  __shared__ float red[4];
+  int i = 0;
+  while (i + 1 < mm.n && (int)blockIdx.x >= mm.start[i + 1]) ++i;
+  const magic_mse_desc& p = mm.d[i];
+  const int bid = blockIdx.x - mm.start[i], nblk = mm.start[i + 1] - mm.start[i];
+  if constexpr (sizeof(T) == 4) mse_body<float, float>(p, bid, nblk, red);
+  else { if (p.g_f32) mse_body<T, float>(p, bid, nblk, red); else mse_body<T, T>(p, bid, nblk, red); }
+}
+
+extern "C" int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* stream) {
+  if (n <= 0 || n > MSE_MAX || !d) return MAGIC_ERR_ARG;
+  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
+  MseMulti mm;
+  mm.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (d[i].outer <= 0 || d[i].inner <= 0 || !d[i].s || !d[i].t || (d[i].w && d[i].rows_per_w <= 0)) return MAGIC_ERR_ARG;
+    mm.d[i] = d[i];
+    long long tot = d[i].outer * d[i].inner;
+    int blocks = (int)((tot + 255) / 256);
+    if (blocks > 384) blocks = 384;
+    mm.start[i] = total;
+    total += blocks;
+  }
+  for (int i = n; i <= MSE_MAX; ++i) mm.start[i] = total;
+  dim3 grid(total), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(mse_multi_kernel<bf16>, grid, block, 0, st, mm);
+  else hipLaunchKernelGGL(mse_multi_kernel<float>, grid, block, 0, st, mm);
+  return launch_status();
+}
+
 extern "C" int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld, const int* labels, int ignore_index,
                              float coef, const float* row_w, float* loss_row, void* dlogits, int ldd, int accumulate,
                              float* w_out, float w_rate, void* stream) {

@@ -184,17 +184,27 @@ static int launch_one(const GroupRec& r, const GroupRec* other, hipStream_t st) 
   }
 }
 
-// launches what was recorded since magic_group_begin(): one kernel for two compatible records, else one kernel each
+// launches what was recorded since magic_group_begin(): records are independent by contract, so they are partitioned by
+// (kind, dtype, variant); a class of GEMMs becomes ONE grouped launch (up to 8 problems), other kinds launch as pairs.
 extern "C" int magic_group_end(void* stream) {
   GroupState& g = group_state();
   if (!g.active) return MAGIC_ERR_ARG;
   g.active = false;
   hipStream_t st = (hipStream_t)stream;
   int rc = MAGIC_OK;
-  if (g.n == 2 && g.rec[0].kind == g.rec[1].kind && g.rec[0].dtype == g.rec[1].dtype && g.rec[0].variant == g.rec[1].variant) {
-    rc = launch_one(g.rec[0], &g.rec[1], st);
-  } else {
-    for (int i = 0; i < g.n && rc == MAGIC_OK; ++i) rc = launch_one(g.rec[i], nullptr, st);
+  bool used[GROUP_CAP] = {};
+  for (int i = 0; i < g.n && rc == MAGIC_OK; ++i) {
+    if (used[i]) continue;
+    int idx[GROUP_CAP], m = 0;
+    for (int j = i; j < g.n; ++j)
+      if (!used[j] && g.rec[j].kind == g.rec[i].kind && g.rec[j].dtype == g.rec[i].dtype && g.rec[j].variant == g.rec[i].variant) { idx[m++] = j; used[j] = true; }
+    if (g.rec[i].kind == KIND_GEMM && m > 2) {
+      const void* ps[GROUP_CAP];
+      for (int k = 0; k < m; ++k) ps[k] = g.rec[idx[k]].blob;
+      rc = launch_gemm_n(g.rec[i].dtype, g.rec[i].variant, ps, m, st);
+    } else {
+      for (int k = 0; k < m && rc == MAGIC_OK; k += 2) rc = launch_one(g.rec[idx[k]], k + 1 < m ? &g.rec[idx[k + 1]] : nullptr, st);
+    }
   }
   g.n = 0;
   return rc;

@@ -45,6 +45,7 @@ SIGNATURES = {
     "magic_softkl_rows": [i32, i32, i32, vp, i32, vp, i32, f32, vp, vp, i32, vp],
     "magic_kd_rows": [i32, i32, vp, vp, i32, f32, vp, f32, f32, vp, vp, vp, i32, vp],
     "magic_mse": [i32, i32, i64, i64, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp, i64, i32, vp],
+    "magic_mse_multi": [i32, i32, vp, vp],
     "magic_csr_gather": [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp],
     "magic_pano_fuse_fwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "magic_pano_fuse_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -69,6 +70,13 @@ class DwDesc(C.Structure):
     """mirror of `magic_dw_desc` (include/magic_hip.h)"""
     _fields_ = [("dY", vp), ("X", vp), ("dW", vp), ("db", vp), ("M", i32), ("N", i32), ("K", i32),
                 ("lda", i32), ("ldb", i32), ("ldc", i32), ("splitk", i32)]
+
+
+class MseDesc(C.Structure):
+    """mirror of `magic_mse_desc` (include/magic_hip.h)"""
+    _fields_ = [("g_f32", i32), ("outer", i64), ("inner", i64), ("s", vp), ("s_stride", i64), ("t", vp), ("t_stride", i64),
+                ("w", vp), ("rows_per_w", i64), ("norm", f32), ("coef", f32), ("coef_dev", vp), ("loss", vp), ("ds", vp),
+                ("g_stride", i64), ("accumulate", i32)]
 
 
 class RbStage(C.Structure):
@@ -121,6 +129,11 @@ _DEBUG_SYNC = bool(os.environ.get("MAGIC_DEBUG_SYNC"))     # print + synchronize
 
 
 def _raw_call(name, args):
+    if getattr(_tls, "in_group", False) and name in PAIRABLE:
+        rc = getattr(load(), name)(*args)             # recorded by the C side, launched by magic_group_end
+        if rc != 0:
+            raise MagicHipError(f"{name} failed while recording a group: {_ERR.get(rc, rc)}")
+        return
     if _DEBUG_SYNC:
         print("[magic]", name, flush=True)
         rc = getattr(load(), name)(*args)
@@ -148,6 +161,34 @@ def call(name, *args):
         with ls.cv:            # instrumented pass: keep this launch's event pair free of the partner thread's launches
             return _raw_call(name, args)
     _raw_call(name, args)
+
+
+class group:
+    """`with L.group():` -- the groupable calls (PAIRABLE) issued by THIS thread inside the block are recorded and launched
+    together at exit: independent GEMMs of one layout become one grouped launch (<= 8 per block).  The calls must not depend
+    on each other, and nothing inside the block may read their outputs.  No-op inside a lockstep segment."""
+
+    def __enter__(self):
+        self.on = getattr(_tls, "lockstep", None) is None and not _DEBUG_SYNC
+        if self.on:
+            if PROFILE["on"]:
+                self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                self.ev[0].record()
+            if load().magic_group_begin() != 0:
+                raise MagicHipError("magic_group_begin failed (nested grouping?)")
+            _tls.in_group = True
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.on:
+            _tls.in_group = False
+            rc = load().magic_group_end(stream())
+            if PROFILE["on"]:
+                self.ev[1].record()
+                PROFILE["events"].append(("magic_gemm+group", 0, self.ev[0], self.ev[1]))
+            if rc != 0 and et is None:
+                raise MagicHipError(f"magic_group_end failed: {_ERR.get(rc, rc)}")
+        return False
 
 
 class Lockstep:

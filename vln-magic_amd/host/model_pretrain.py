@@ -283,26 +283,45 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         return O.dact(x, x, 2, out=x)
 
     # ---- losses + gradient seeds ------------------------------------------------------------------------
+    # The distillation terms of a step are independent of each other: their five student->teacher-width projections go out as
+    # ONE grouped GEMM launch, all MSE terms (<= 10) as ONE launch, and the five projection input-gradients as ONE grouped launch.
     def _kd_emb(self, c, slot, s_t, t_t, proj, M, outer, w, coef, d_acc):
-        n = self.net
-        pl = n.lin(f"bert.{proj}.weight")
-        sp = O.linear_fwd(s_t, pl.W, pl.b, M)
-        Ht = pl.N
-        inner = (M // outer) * Ht
-        ds = n.new(M, Ht) if self.store.requires_grad else None
-        O.mse(sp, t_t, outer, inner, inner, inner, w=w, rows_per_w=1, norm=1.0 / (M * Ht), coef=coef[0], coef_dev=coef[1],
-              loss=c.slots[slot:slot + 1], ds=ds, g_stride=inner)
-        if ds is not None:
-            O.linear_dw(ds, s_t, pl.dW, pl.db, M)
-            O.linear_dx(ds, pl.W, M, out=d_acc, residual=d_acc)
+        c.kd_emb.append((slot, s_t, t_t, self.net.lin(f"bert.{proj}.weight"), M, outer, w, coef, d_acc))
 
     def _kd_attn(self, c, slot, sP, tP, Bn, Nq, Nk, ldp, nh_s, nh_t, w, coef):
         n = self.net
         hmin = min(nh_s, nh_t)
-        dP = n.zeros(Bn, nh_s, Nq, ldp, dtype=torch.float32) if self.store.requires_grad else None
-        O.mse(sP, tP, Bn, hmin * Nq * ldp, nh_s * Nq * ldp, nh_t * Nq * ldp, w=w, rows_per_w=1,
-              norm=1.0 / (Bn * hmin * Nq * Nk), coef=coef[0], coef_dev=coef[1], loss=c.slots[slot:slot + 1], ds=dP, g_stride=nh_s * Nq * ldp)
+        dP = None
+        if self.store.requires_grad:      # every student head is written when hmin == nh_s (pad columns included): no fill needed
+            dP = (n.new if hmin == nh_s else n.zeros)(Bn, nh_s, Nq, ldp, dtype=torch.float32)
+        c.kd_mse.append(dict(s=sP, t=tP, outer=Bn, inner=hmin * Nq * ldp, s_stride=nh_s * Nq * ldp, t_stride=nh_t * Nq * ldp, w=w, rows_per_w=1,
+                             norm=1.0 / (Bn * hmin * Nq * Nk), coef=coef[0], coef_dev=coef[1], loss=c.slots[slot:slot + 1], ds=dP,
+                             g_stride=nh_s * Nq * ldp))
         return dP
+
+    def _kd_flush(self, c):
+        from . import lib as L
+        n, train = self.net, self.store.requires_grad
+        jobs = c.kd_emb
+        with L.group():
+            sps = [O.linear_fwd(s_t, pl.W, pl.b, M) for (_, s_t, _, pl, M, _, _, _, _) in jobs]
+        dss = []
+        for (slot, s_t, t_t, pl, M, outer, w, coef, d_acc), sp in zip(jobs, sps):
+            Ht = pl.N
+            inner = (M // outer) * Ht
+            ds = n.new(M, Ht) if train else None
+            dss.append(ds)
+            c.kd_mse.append(dict(s=sp, t=t_t, outer=outer, inner=inner, s_stride=inner, t_stride=inner, w=w, rows_per_w=1, norm=1.0 / (M * Ht),
+                                 coef=coef[0], coef_dev=coef[1], loss=c.slots[slot:slot + 1], ds=ds, g_stride=inner))
+        if c.kd_mse:
+            O.mse_multi(c.kd_mse)
+        if train:
+            for (slot, s_t, t_t, pl, M, outer, w, coef, d_acc), ds in zip(jobs, dss):
+                O.linear_dw(ds, s_t, pl.dW, pl.db, M)
+            with L.group():
+                for (slot, s_t, t_t, pl, M, outer, w, coef, d_acc), ds in zip(jobs, dss):
+                    O.linear_dx(ds, pl.W, M, out=d_acc, residual=d_acc)
+        c.kd_emb, c.kd_mse = [], []
 
     def _losses(self, c, o, t, rw):
         n, cfg, plan, task = self.net, self.config, c.plan, c.task
@@ -317,6 +336,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         zz = (lambda *s: n.zeros(*s)) if train else (lambda *s: None)
         c.d_txt, c.d_pano, c.d_fused = zz(B * L, H), zz(plan["Np"] * plan["V"], H), zz(plan["Np"], H)
         c.dP_txt = c.dP_pano = c.dP_g = c.dP_l = None
+        c.kd_emb, c.kd_mse = [], []
         res = {}
         # ---- supervised ------------------------------------------------------------------------------
         if task == "sap":
@@ -399,12 +419,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                     self._kd_emb(c, 3, o["pano_fused_embeds"], t["pano_fused_embeds"], "kdl_avg_img_w", Np, Np, wp, rw[1], c.d_fused)
                 if att:
                     ldp = c.pano.ldp
-                    g = n.new(Np, V, ldp, dtype=torch.float32) if train else None
-                    O.mse(o["img_attns"], t["img_attns"], Np, V * ldp, V * ldp, V * ldp, w=wp, rows_per_w=1, norm=1.0 / (Np * V * V), coef=rw[1][0], coef_dev=rw[1][1],
-                          loss=c.slots[4:5], ds=g, g_stride=V * ldp)
-                    if train:
-                        c.dP_pano = n.new(Np, nh_s, V, ldp, dtype=torch.float32)
-                        O.head_mean_bwd(g, c.dP_pano, Np, nh_s, V * ldp)
+                    g_img = n.new(Np, V, ldp, dtype=torch.float32) if train else None
+                    c.kd_mse.append(dict(s=o["img_attns"], t=t["img_attns"], outer=Np, inner=V * ldp, s_stride=V * ldp, t_stride=V * ldp, w=wp, rows_per_w=1,
+                                         norm=1.0 / (Np * V * V), coef=rw[1][0], coef_dev=rw[1][1], loss=c.slots[4:5], ds=g_img, g_stride=V * ldp))
             if "global" in tasks and task != "mrc":
                 if task == "mlm":
                     x, Pm, Nq, Nk, ldp, d_acc = c.l2v.out, c.l2v.P, L, K, c.l2v.ldp, c.d_x
@@ -419,6 +436,10 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                     self._kd_emb(c, 7, c.loc.out, t["vp_embeds"], "local_cross_w", B * Vp, B, w, rw[3], c.d_vp)
                 if att:
                     c.dP_l = self._kd_attn(c, 8, c.loc.P, t["vp_attns"], B, Vp, L, c.loc.ldp, nh_s, nh_t, w, rw[3])
+            self._kd_flush(c)
+            if "img" in tasks and att and train:
+                c.dP_pano = n.new(Np, nh_s, V, c.pano.ldp, dtype=torch.float32)
+                O.head_mean_bwd(g_img, c.dP_pano, Np, nh_s, V * c.pano.ldp)
             if "predict" in tasks and task == "sap":
                 c.kdrows = n.new(B, dtype=torch.float32)
                 O.kd_rows(c.fl, t["fused_logits"], B, K, K, T, w=w, norm=(1.0 / B if w is not None else 1.0 / (B * K)),

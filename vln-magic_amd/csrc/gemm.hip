@@ -9,6 +9,7 @@
 // (bf16) / 4-byte (f32) LDS reads; the next tile's global loads are in flight during the MFMAs.
 #include "common.hpp"
 #include "group.hpp"
+#include <cstdlib>
 
 #define BM 64
 #define BN 64
@@ -323,11 +324,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   gemm_block<T, LAYOUT>(p, blockIdx.x, blockIdx.y, blockIdx.z, sA, sB);
 }
 
+// XCD-aware variant of the same kernel (1-D grid).  Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an
+// XCD) and each XCD has its own L2: with the plain (x, y) grid the N/64 column tiles of one 64-row A panel land on N/64
+// different XCDs and every one of them pulls that panel over the fabric.  Here row tile r belongs to XCD r % 8 and its column
+// tiles occupy consecutive slots of that XCD, so the panel crosses the fabric once and the siblings hit L2.  Row tiles are
+// padded to a multiple of 8 (the surplus workgroups exit at once).
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_xcd_kernel(GemmParams p, int nx, int ny, int ny8) {
+  __shared__ __attribute__((aligned(16))) T sA[BM * TT<T>::STRIDE];
+  __shared__ __attribute__((aligned(16))) T sB[BN * TT<T>::STRIDE];
+  const int per_z = nx * ny8;
+  const int z = blockIdx.x / per_z, l2 = blockIdx.x - z * per_z;
+  const int xcd = l2 & 7, slot = l2 >> 3;
+  const int lr = slot / nx, bx = slot - lr * nx;
+  const int by = lr * 8 + xcd;
+  if (by >= ny) return;
+  gemm_block<T, LAYOUT>(p, bx, by, z, sA, sB);
+}
+
 // Grouped weight-gradient GEMM: up to GROUP_MAX independent TN problems (dW[N,K] += dY^T X, split-K, fp32 atomics, fused
 // bias gradient) in ONE launch.  Nothing on the backward chain depends on dW, so the engine defers all of a step's
 // weight-gradient GEMMs and issues them ~8 at a time: ~80 launches become ~10.
 #define GROUP_MAX 8
-struct GroupedParams { GemmParams p[GROUP_MAX]; int start[GROUP_MAX + 1]; int n; };
+// start[i]: first workgroup of problem i (always a multiple of 8, so `local % 8` is the XCD slot of the workgroup);
+// cnt[i]: workgroups that have a tile (the rest of the padded range exits); ny8[i] > 0: XCD-aware tile map as in gemm_xcd_kernel.
+struct GroupedParams { GemmParams p[GROUP_MAX]; int start[GROUP_MAX + 1]; int cnt[GROUP_MAX]; int ny8[GROUP_MAX]; int n; };
 
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupedParams gp) {
@@ -339,8 +360,20 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupedParams gp) {
   for (int i = 1; i < GROUP_MAX; ++i) g += (i < gp.n && id >= gp.start[i]) ? 1 : 0;      // block-uniform
   const GemmParams& p = gp.p[g];
   const int local = id - gp.start[g];
+  if (local >= gp.cnt[g]) return;
   const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM;
-  gemm_block<T, LAYOUT>(p, local % nx, (local / nx) % ny, local / (nx * ny), sA, sB);
+  const int ny8 = gp.ny8[g];
+  if (ny8 > 0) {
+    const int per_z = nx * ny8;
+    const int z = local / per_z, l2 = local - z * per_z;
+    const int xcd = l2 & 7, slot = l2 >> 3;
+    const int lr = slot / nx, bx = slot - lr * nx;
+    const int by = lr * 8 + xcd;
+    if (by >= ny) return;
+    gemm_block<T, LAYOUT>(p, bx, by, z, sA, sB);
+  } else {
+    gemm_block<T, LAYOUT>(p, local % nx, (local / nx) % ny, local / (nx * ny), sA, sB);
+  }
 }
 
 extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,
@@ -371,13 +404,45 @@ extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N
   return launch_gemm(dtype, layout, &p, nullptr, (hipStream_t)stream);
 }
 
+static bool gemm_xcd_on() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MAGIC_GEMM_XCD"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+// lays problem i into the grouped launch: returns the padded workgroup count (multiple of 8)
+static inline int group_place(GroupedParams& gp, int i, int total) {
+  const GemmParams& p = gp.p[i];
+  const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM, nz = p.batch * p.splitk;
+  gp.start[i] = total;
+  if (gemm_xcd_on() && nx >= 2 && ny >= 16) {
+    gp.ny8[i] = (ny + 7) / 8 * 8;
+    gp.cnt[i] = nx * gp.ny8[i] * nz;
+  } else {
+    gp.ny8[i] = 0;
+    gp.cnt[i] = nx * ny * nz;
+  }
+  return (gp.cnt[i] + 7) / 8 * 8;
+}
 static inline int gemm_blocks(const GemmParams& p) { return ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * p.batch * p.splitk; }
 
 int launch_gemm(int dtype, int layout, const void* pa, const void* pb, hipStream_t st) {
   const GemmParams& a = *(const GemmParams*)pa;
   dim3 block(256);
   if (!pb) {
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch * a.splitk);
+    const int nx = (a.N + BN - 1) / BN, ny = (a.M + BM - 1) / BM, nz = a.batch * a.splitk;
+    if (gemm_xcd_on() && nx >= 2 && ny >= 16) {         // enough row tiles that the padding to a multiple of 8 is small
+      const int ny8 = (ny + 7) / 8 * 8;
+      dim3 g1((unsigned)(nx * ny8 * nz));
+#define LAUNCHX(TY, L) hipLaunchKernelGGL((gemm_xcd_kernel<TY, L>), g1, block, 0, st, a, nx, ny, ny8)
+      if (dtype == DT_BF16) {
+        if (layout == 0) LAUNCHX(bf16, 0); else if (layout == 1) LAUNCHX(bf16, 1); else LAUNCHX(bf16, 2);
+      } else {
+        if (layout == 0) LAUNCHX(float, 0); else if (layout == 1) LAUNCHX(float, 1); else LAUNCHX(float, 2);
+      }
+#undef LAUNCHX
+      return launch_status();
+    }
+    dim3 grid(nx, ny, nz);
 #define LAUNCH(TY, L) hipLaunchKernelGGL((gemm_kernel<TY, L>), grid, block, 0, st, a)
     if (dtype == DT_BF16) {
       if (layout == 0) LAUNCH(bf16, 0); else if (layout == 1) LAUNCH(bf16, 1); else LAUNCH(bf16, 2);
@@ -398,7 +463,7 @@ int launch_gemm_n(int dtype, int layout, const void* const* ps, int n, hipStream
   GroupedParams gp;
   gp.n = n;
   int total = 0;
-  for (int i = 0; i < n; ++i) { gp.p[i] = *(const GemmParams*)ps[i]; gp.start[i] = total; total += gemm_blocks(gp.p[i]); }
+  for (int i = 0; i < n; ++i) { gp.p[i] = *(const GemmParams*)ps[i]; total += group_place(gp, i, total); }
   for (int i = n; i <= GROUP_MAX; ++i) gp.start[i] = total;
   dim3 grid(total);
 #define LAUNCHG(TY, L) hipLaunchKernelGGL((gemm_grouped_kernel<TY, L>), grid, block, 0, st, gp)
@@ -892,8 +957,7 @@ extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, v
     p.A = d[i].dY; p.B = d[i].X; p.C = d[i].dW; p.bias_grad = d[i].db;
     p.M = d[i].N; p.N = d[i].K; p.K = d[i].M; p.lda = d[i].lda; p.ldb = d[i].ldb; p.ldc = d[i].ldc;
     p.nh = 1; p.batch = 1; p.splitk = d[i].splitk; p.epilogue = 0; p.c_f32 = 1; p.accumulate = 1; p.alpha = 1.f;
-    gp.start[i] = total;
-    total += ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * p.splitk;
+    total += group_place(gp, i, total);
   }
   for (int i = n; i <= GROUP_MAX; ++i) gp.start[i] = total;
   dim3 grid(total), block(256);

@@ -151,10 +151,13 @@ def _linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None
 FUSED_LN = not os.environ.get("MAGIC_NO_FUSED_LN")
 
 
+_LLN_MAXK = int(os.environ.get("MAGIC_LLN_MAXK", "512"))
+
+
 def linear_ln_ok(H, K=0):
     """fused dense+add+LayerNorm pays while the per-block serial K loop is short (measured: slower than GEMM + LN
     for the teacher's K=1024 FFN output, faster for K <= 512)"""
-    return FUSED_LN and H in (128, 256, 384) and K <= 512
+    return FUSED_LN and H in (128, 256, 384) and K <= _LLN_MAXK
 
 
 def _dr(drop):

@@ -36,7 +36,7 @@ def main():
     fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])      # steps = warmup + timed steps of the profiled run
     fk, ftot, _ = load(fetch_dir, "FETCH_SIZE")
     wk, wtot, _ = load(write_dir, "WRITE_SIZE")
-    is_gemm = lambda k: "gemm_kernel" in k or "gemm_grouped_kernel" in k
+    is_gemm = lambda k: "gemm_kernel" in k or "gemm_xcd_kernel" in k or "gemm_grouped_kernel" in k
     gf = sum(v[0] for k, v in fk.items() if is_gemm(k)) * 2.0       # gfx950: FETCH_SIZE counts half of wide reads
     gn = sum(v[1] for k, v in fk.items() if is_gemm(k))
     gw = sum(v[0] for k, v in wk.items() if is_gemm(k))

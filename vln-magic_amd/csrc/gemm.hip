@@ -363,7 +363,16 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupedParams gp) {
   if (local >= gp.cnt[g]) return;
   const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM;
   const int ny8 = gp.ny8[g];
-  if (ny8 > 0) {
+  if (ny8 < 0) {
+    // split-K problem (weight gradient): all nx*ny tiles of one K-split share that split's dY / X panels -> keep a split's
+    // tiles on ONE XCD (split z on XCD z % 8, its tiles in consecutive slots) so each panel crosses the fabric once
+    const int tiles = nx * ny, nz = p.batch * p.splitk;
+    const int xcd = local & 7, slot = local >> 3;
+    const int zr = slot / tiles, t = slot - zr * tiles;
+    const int z = zr * 8 + xcd;
+    if (z >= nz) return;
+    gemm_block<T, LAYOUT>(p, t % nx, t / nx, z, sA, sB);
+  } else if (ny8 > 0) {
     const int per_z = nx * ny8;
     const int z = local / per_z, l2 = local - z * per_z;
     const int xcd = l2 & 7, slot = l2 >> 3;
@@ -414,7 +423,10 @@ static inline int group_place(GroupedParams& gp, int i, int total) {
   const GemmParams& p = gp.p[i];
   const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM, nz = p.batch * p.splitk;
   gp.start[i] = total;
-  if (gemm_xcd_on() && nx >= 2 && ny >= 16) {
+  if (gemm_xcd_on() && p.splitk >= 8 && nx * ny >= 2) {
+    gp.ny8[i] = -1;
+    gp.cnt[i] = nx * ny * ((nz + 7) / 8 * 8);
+  } else if (gemm_xcd_on() && nx >= 2 && ny >= 16) {
     gp.ny8[i] = (ny + 7) / 8 * 8;
     gp.cnt[i] = nx * gp.ny8[i] * nz;
   } else {

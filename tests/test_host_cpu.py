@@ -142,3 +142,25 @@ def test_out_of_range_batch_values_are_rejected_on_the_host():
     long_cfg = make_config(128, vocab_size=300, max_position_embeddings=6)
     with pytest.raises(ValueError):
         check_plan(build_plan(batch, "sap", torch.device("cpu")), long_cfg)
+
+
+def test_feature_table_envedit_mixing_follows_the_reference_coin_stream():
+    """get_scanvp_feature (dataset.py:606-610): one `np.random.rand() > 0.5` per viewpoint visit, in path order, picks the
+    augmented feature file; with the packed table that is an offset of n rows on the index."""
+    import numpy as np
+    from magic_amd.host.feature_table import FeatureTable
+    rng = np.random.default_rng(0)
+    keys = [f"s_{i}" for i in range(5)]
+    base = [rng.standard_normal((36, 8)).astype(np.float32) for _ in keys]
+    aug = [b + 100 for b in base]
+    ft = FeatureTable.from_arrays(keys, base, device="cpu", dtype=torch.float32, image_feat_size=8, aug_arrays=aug)
+    assert ft.has_aug and ft.table.shape == (10, 36, 8)
+    cands = lambda scan, vp: {f"c{vp}": [3, 1.0, 0.1, 0.0]}
+    paths = [["0", "1", "2"], ["3", "4"]]
+    st = np.random.RandomState(5)
+    b = ft.batch_indices(["s", "s"], paths, cands, aug_coin=st.rand)
+    st2 = np.random.RandomState(5)
+    want = [int(vp) + (5 if st2.rand() > 0.5 else 0) for path in paths for vp in path]      # the reference's draw order
+    assert b["vp_row"].tolist() == want and any(r >= 5 for r in want) and any(r < 5 for r in want)
+    plain = ft.batch_indices(["s", "s"], paths, cands)
+    assert plain["vp_row"].tolist() == [0, 1, 2, 3, 4]

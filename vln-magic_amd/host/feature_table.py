@@ -69,21 +69,33 @@ def pano_view_order(nav_cands, angle_feat_size=4):
 class FeatureTable:
     """[n_viewpoints, 36, D] in HBM in the compute dtype + key -> row index."""
 
-    def __init__(self, keys, table):
+    def __init__(self, keys, table, n_base=None):
         self.index = {k: i for i, k in enumerate(keys)}
         self.table = table
+        self.n_base = n_base if n_base is not None else len(self.index)      # rows [n_base, 2 n_base) = the augmented copies
+        self.has_aug = table.shape[0] == 2 * self.n_base
 
     @classmethod
-    def from_arrays(cls, keys, arrays, device="cuda", dtype=torch.bfloat16, image_feat_size=768):
-        """arrays[i]: the `[36, >= image_feat_size]` float32 block stored under keys[i] = "{scan}_{viewpoint}" """
-        t = torch.from_numpy(np.stack([a[:, :image_feat_size] for a in arrays]).astype(np.float32))
-        return cls(keys, t.to(device).to(dtype).contiguous())
+    def from_arrays(cls, keys, arrays, device="cuda", dtype=torch.bfloat16, image_feat_size=768, aug_arrays=None):
+        """arrays[i]: the `[36, >= image_feat_size]` float32 block stored under keys[i] = "{scan}_{viewpoint}".
+        aug_arrays: the same viewpoints from the EnvEdit-style augmented feature file (`aug_img_file`,
+        r2r_magic_pretrain.json; dataset.py:606-610), appended as rows [n, 2n)."""
+        blocks = [a[:, :image_feat_size] for a in arrays]
+        if aug_arrays is not None:
+            assert len(aug_arrays) == len(arrays)
+            blocks += [a[:, :image_feat_size] for a in aug_arrays]
+        t = torch.from_numpy(np.stack(blocks).astype(np.float32))
+        return cls(keys, t.to(device).to(dtype).contiguous(), n_base=len(arrays))
 
     def row(self, scan, vp):
         return self.index[f"{scan}_{vp}"]
 
-    def batch_indices(self, scans, paths, cands_of, angle_feat_size=4, pad_views=None):
-        """Index-only description of a batch of trajectories (what `get_traj_pano_fts` + the collates' pad/stack produce as
+    def batch_indices(self, scans, paths, cands_of, angle_feat_size=4, pad_views=None, aug_coin=None):
+        """aug_coin: callable returning a uniform [0,1) draw; when given (and the table holds augmented copies) every panorama
+        independently reads the augmented row with probability 1/2 -- `get_scanvp_feature` (dataset.py:606-610) flips
+        `np.random.rand() > 0.5` once per viewpoint visit, in path order; pass `np.random.rand` for the same stream.
+
+        Index-only description of a batch of trajectories (what `get_traj_pano_fts` + the collates' pad/stack produce as
         tensors): returns dict(vp_row int32 [Np], order int32 [Np, V] (-1 = padded slot), traj_vp_view_lens, traj_loc_fts
         [Np, V, A+3] zero-padded, traj_nav_types [Np, V], traj_cand_vpids, traj_step_lens)."""
         rows, orders, locs, navs, cand_ids, step_lens = [], [], [], [], [], []
@@ -92,7 +104,10 @@ class FeatureTable:
             cl = []
             for vp in path:
                 o, loc, nav, cv = pano_view_order(cands_of(scan, vp), angle_feat_size)
-                rows.append(self.row(scan, vp))
+                r = self.row(scan, vp)
+                if aug_coin is not None and self.has_aug and aug_coin() > 0.5:
+                    r += self.n_base
+                rows.append(r)
                 orders.append(o)
                 locs.append(loc)
                 navs.append(nav)

@@ -243,8 +243,11 @@ def main():
         nprof = min(len(pool), 6)
         O.FLOPS.update(total=0.0, enabled=True)
         L.PROFILE.update(on=True, events=[])
+        import magic_amd.host.model_pretrain as MP
+        MP.LOCKSTEP_EAGER = True            # same paired launch structure as the captured graphs (pairing is capture-only by default)
         run_eager(nprof, start=0)
         torch.cuda.synchronize()
+        MP.LOCKSTEP_EAGER = False
         L.PROFILE["on"] = False
         O.FLOPS["enabled"] = False
         by = {}

@@ -20,6 +20,7 @@ from .params import ParamStore
 from .plan import build_plan, check_plan
 
 LOCKSTEP = not os.environ.get("MAGIC_NO_LOCKSTEP")
+LOCKSTEP_EAGER = bool(os.environ.get("MAGIC_LOCKSTEP_EAGER"))
 KD_SLOTS = ("txt_emb_loss", "txt_attn_loss", "img_emb_loss", "avg_img_emb_loss", "img_attn_loss",
             "global_emb_loss", "global_attn_loss", "local_emb_loss", "local_attn_loss", "predict_loss")
 
@@ -96,9 +97,12 @@ class GlocalTextPathCMTPreTraining(nn.Module):
 
     def _par(self, fn_main, fn_aux):
         """run two independent segments concurrently: fn_aux on this model's auxiliary stream, fn_main on the current one"""
-        if LOCKSTEP and self.device_.type == "cuda":
+        if LOCKSTEP and self.device_.type == "cuda" and (torch.cuda.is_current_stream_capturing() or LOCKSTEP_EAGER):
+            # paired launches (one kernel per two calls).  Only while a HIP graph is being captured: the two host threads
+            # rendezvous on every call, which costs more than it saves when launches are issued eagerly (measured: 15 ms/step
+            # eager with pairing, 6.5 without; replayed graphs: 3.4 with, 3.9 without)
             from . import lib as L
-            return L.lockstep(fn_main, fn_aux)      # one stream, paired launches (half the kernels)
+            return L.lockstep(fn_main, fn_aux)
         if self._aux is None:
             return fn_main(), fn_aux()
         cur = torch.cuda.current_stream()

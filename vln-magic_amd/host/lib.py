@@ -111,7 +111,15 @@ def load():
     return lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """raw handle of torch's current HIP stream on the current device (thread-local, honours torch.cuda.stream contexts).
+    `torch.cuda.current_stream()` builds a Stream object and re-resolves the device on every call (~8 us): with ~400 launches
+    per eager step that was a third of the host time."""
+    if _raw_stream is not None:
+        return _raw_stream(torch._C._cuda_getDevice())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -9,6 +9,8 @@ Import recipe: SURVEY.md Appendix F.  What is minted:
   adamw.pt            pretrain_src/optim/adamw.py AdamW.step x3 + optim/sched.py get_lr_sched table
   collate.pt          pretrain_src/data/tasks.py {mlm,sap,cfp}_collate on our synthetic samples
   ops.pt              map_nav_src/utils/ops.py pad_tensors / gen_seq_masks
+  nav_loop.pt         map_nav_src/r2r/speaker_utils.py FloydGraph; map_nav_src/r2r/agent.py _language_variable,
+                      _panorama_feature_variable_do, _nav_gmap_variable, _nav_vp_variable_mem, _teacher_action
 """
 import importlib.util
 import os
@@ -350,6 +352,126 @@ def mint_ingest():
         del sys.modules[k]
 
 
+def mint_nav_loop():
+    """nav_loop.pt: the reference's own FloydGraph (map_nav_src/r2r/speaker_utils.py:501-546) on a fixed edge/update script,
+    and GMapNavAgent._language_variable / _panorama_feature_variable_do / _nav_gmap_variable / _nav_vp_variable_mem /
+    _teacher_action (map_nav_src/r2r/agent.py:63-373) driven unbound over a teacher-forced walk through our synthetic stepper,
+    with oracle/rollout_ref.RefGraphMap standing in for the withheld GraphMap.  Tensor.cuda is made the identity for this
+    script (no GPU in the authoring container; the methods only use it to place their results)."""
+    sys.path.insert(0, f"{REF}/map_nav_src")
+    stub(["MatterSim", "line_profiler", "jsonlines", "h5py", "spacy", "nltk", "tensorboardX", "progressbar"])
+    from oracle import rollout_ref as R
+    from magic_amd.host.synth_env import SynthNavEnv
+    models = types.ModuleType("models")
+    for sub, attrs in (("graph_utils", ["GraphMap"]), ("model", ["VLNBert", "Critic"]), ("ops", ["pad_tensors_wgrad"])):
+        m = types.ModuleType(f"models.{sub}")
+        for a in attrs:
+            setattr(m, a, object)
+        sys.modules[f"models.{sub}"] = m
+        setattr(models, sub, m)
+    sys.modules["models"] = models
+    import utils.kd_loss as K
+    K.dkd_loss = None
+    import r2r.agent as A
+    A.pad_tensors_wgrad = lambda ts: R.pad_rows(ts)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    argv, sys.argv = sys.argv, [sys.argv[0], "--mode", "train", "--root_dir", "/tmp/none"]   # the module parses argv on import (:14-15)
+    try:
+        F_ = load_by_path("ref_speaker_utils", f"{REF}/map_nav_src/r2r/speaker_utils.py").FloydGraph
+    finally:
+        sys.argv = argv
+    # -- FloydGraph script
+    rng = np.random.default_rng(5)
+    names = [f"n{i}" for i in range(12)]
+    fg, script, answers = F_(), [], []
+    for step in range(36):
+        x, y = (int(v) for v in rng.choice(len(names), 2, replace=False))
+        d = float(rng.uniform(0.5, 6))
+        fg.add_edge(names[x], names[y], d)
+        script.append(("edge", x, y, d))
+        if step % 3 == 2:
+            k = int(rng.integers(len(names)))
+            if names[k] in fg._dis:
+                fg.update(names[k])
+                script.append(("update", k, 0, 0.0))
+        known = [n for n in names if n in fg._dis]
+        answers.append([(names.index(u), names.index(v), float(fg.distance(u, v)),
+                         [names.index(q) for q in fg.path(u, v)] if fg.distance(u, v) < 9e7 else None, fg.visited(u))
+                        for u in known for v in known])
+    out = dict(floyd=dict(names=names, script=script, answers=answers))
+    # -- agent builders over a teacher-forced walk
+    feat = 16
+    env = SynthNavEnv(batch_size=4, n_scans=2, nodes_per_scan=30, feat_dim=feat, seed=21, instr_len=(5, 11), path_hops=(2, 4))
+    obs = env.reset()
+    args = SimpleNamespace(image_feat_size=feat, act_visited_nodes=False, enc_full_graph=True, ignoreid=-100, expert_policy="spl",
+                           fusion="dynamic")
+    me = SimpleNamespace(args=args, env=env)
+    g = torch.Generator().manual_seed(9)
+    H = 8
+    gmaps = [R.RefGraphMap(ob["viewpoint"]) for ob in obs]
+    for gm, ob in zip(gmaps, obs):
+        gm.update_graph(ob)
+    traj = [dict(path=[[ob["viewpoint"]]]) for ob in obs]
+    ended = np.array([False] * len(obs))
+    last = None
+    keep = lambda ob: {k: (v if k != "candidate" else [dict(c) for c in v]) for k, v in ob.items()}
+    steps = []
+    out["lang"] = dict(obs=[keep(o) for o in obs])
+    lv = A.GMapNavAgent._language_variable(me, obs, None, None)
+    out["lang"]["txt_ids"], out["lang"]["txt_masks"] = lv["txt_ids"], lv["txt_masks"]
+    for t in range(5):
+        for i, gm in enumerate(gmaps):
+            if not ended[i]:
+                gm.node_step_ids[obs[i]["viewpoint"]] = t + 1
+        pano = A.GMapNavAgent._panorama_feature_variable_do(me, obs)
+        B, V = pano["view_img_fts"].shape[:2]
+        pe, pf = torch.randn(B, V, H, generator=g), torch.randn(B, H, generator=g)
+        for i, gm in enumerate(gmaps):
+            if ended[i]:
+                continue
+            gm.update_node_embed(obs[i]["viewpoint"], pf[i], rewrite=True)
+            for j, cv in enumerate(pano["cand_vpids"][i]):
+                if not gm.graph.visited(cv):
+                    gm.update_node_embed(cv, pe[i, j])
+        nav = A.GMapNavAgent._nav_gmap_variable(me, obs, gmaps, last, teacher=False)
+        nav.update(A.GMapNavAgent._nav_vp_variable_mem(me, obs, gmaps, pe, pano["cand_vpids"], pano["view_lens"], pano["nav_types"], last))
+        tgt_il = A.GMapNavAgent._teacher_action(me, obs, nav["gmap_vpids"], ended, visited_masks=nav["gmap_visited_masks"],
+                                                imitation_learning=True, t=t, traj=traj)
+        tgt_spl = A.GMapNavAgent._teacher_action(me, obs, nav["gmap_vpids"], ended, visited_masks=nav["gmap_visited_masks"],
+                                                 imitation_learning=False, t=t, traj=traj)
+        args.expert_policy = "ndtw"
+        tgt_ndtw = A.GMapNavAgent._teacher_action(me, obs, nav["gmap_vpids"], ended, visited_masks=nav["gmap_visited_masks"],
+                                                  imitation_learning=False, t=t, traj=traj)
+        args.expert_policy = "spl"
+        steps.append(dict(obs=[keep(o) for o in obs], ended=ended.copy(), pe=pe, pf=pf, last=last,
+                          pano={k: v for k, v in pano.items() if v is not None},
+                          nav={k: v for k, v in nav.items() if v is not None},
+                          tgt_il=tgt_il, tgt_spl=tgt_spl, tgt_ndtw=tgt_ndtw, traj=[dict(path=[list(p) for p in x["path"]]) for x in traj]))
+        last = torch.randn(B, H, generator=g)
+        acts, hops = [], [None] * B
+        for i, ob in enumerate(obs):
+            gt = ob["gt_path"]
+            if ended[i] or t >= len(gt) - 1:
+                acts.append(None)
+            else:
+                acts.append(gt[t + 1])
+                traj[i]["path"].append(gmaps[i].graph.path(ob["viewpoint"], gt[t + 1]))
+                hops[i] = traj[i]["path"][-2][-1] if len(traj[i]["path"][-1]) == 1 else traj[i]["path"][-1][-2]
+        env.step(acts, hops)
+        obs = env._get_obs()
+        for i, ob in enumerate(obs):
+            if not ended[i]:
+                gmaps[i].update_graph(ob)
+        ended = np.logical_or(ended, np.array([a is None for a in acts]))
+        if ended.all():
+            break
+    out["steps"] = steps
+    out["env"] = dict(shortest={n: sc.sdist for n, sc in env.scans.items()}, vps={n: sc.vps for n, sc in env.scans.items()},
+                      nxt={n: sc.nxt for n, sc in env.scans.items()})
+    torch.save(out, os.path.join(HERE, "nav_loop.pt"))
+    print("nav_loop: floyd", len(script), "ops;", len(steps), "agent steps")
+
+
 def mint_ops():
     O = load_by_path("ref_ops", f"{REF}/map_nav_src/utils/ops.py")
     g = torch.Generator().manual_seed(2)
@@ -366,6 +488,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--ragged-only" in sys.argv:
         mint_ragged()
+        sys.exit(0)
+    if "--nav-loop-only" in sys.argv:
+        mint_nav_loop()
         sys.exit(0)
     if "--ingest-only" in sys.argv:
         mint_ingest()

@@ -228,3 +228,105 @@ def test_ragged_view_collate_matches_reference(golden_dir):
     plan = build_plan(got, "sap", torch.device("cpu"))
     assert plan["V"] == got["traj_view_img_fts"].shape[1] == 37 and plan["Vp"] == got["vp_pos_fts"].shape[1]
     assert plan["vp_mask"].sum(1).tolist() == [int(got["traj_vp_view_lens"][r]) + 1 for r in plan["last_rows"]]
+
+
+# ---- navigator loop: FloydGraph and the agent's input builders ------------------------------------------
+class _GoldenEnv:
+    """shortest_distances / shortest_paths of the stepper the fixture was minted on (dense tables stored in the fixture)"""
+
+    def __init__(self, e):
+        self.e = e
+        self.shortest_distances = {n: _Rows(e, n, False) for n in e["vps"]}
+        self.shortest_paths = {n: _Rows(e, n, True) for n in e["vps"]}
+
+
+class _Rows:
+    def __init__(self, e, n, paths):
+        self.vps, self.sd, self.nxt, self.paths = e["vps"][n], e["shortest"][n], e["nxt"][n], paths
+
+    def __getitem__(self, a):
+        ia, me = self.vps.index(a), self
+
+        class Row:
+            def __getitem__(_, b):
+                ib = me.vps.index(b)
+                if not me.paths:
+                    return float(me.sd[ia, ib])
+                out, x = [a], ia
+                while x != ib:
+                    x = int(me.nxt[x, ib])
+                    out.append(me.vps[x])
+                return out
+        return Row()
+
+
+def test_floyd_matches_reference(golden_dir):
+    from magic_amd.host.graph_map import FloydGraph
+    from oracle.rollout_ref import RefFloyd
+    fx = _load(golden_dir, "nav_loop.pt")["floyd"]
+    names = fx["names"]
+    for G in (RefFloyd, FloydGraph):
+        # the fixture records the state after each edge and the update that may follow it
+        g, k, it = G(), 0, iter(fx["answers"])
+        script = fx["script"]
+        while k < len(script):
+            op, x, y, d = script[k]
+            g.add_edge(names[x], names[y], d)
+            k += 1
+            if k < len(script) and script[k][0] == "update":
+                g.update(names[script[k][1]])
+                k += 1
+            for u, v, dist, path, seen in next(it):
+                assert g.distance(names[u], names[v]) == dist
+                assert g.visited(names[u]) == seen
+                if path is not None:
+                    assert [names.index(q) for q in g.path(names[u], names[v])] == path
+
+
+def test_nav_builders_match_reference(golden_dir):
+    """oracle/rollout_ref.py's builders, replayed on the fixture's observations, against what the reference's own
+    GMapNavAgent methods returned for them (agent.py:63-373)"""
+    from oracle import rollout_ref as R
+    fx = _load(golden_dir, "nav_loop.pt")
+    env = _GoldenEnv(fx["env"])
+    lv = R.language_variable(fx["lang"]["obs"])
+    assert (lv["txt_ids"] == fx["lang"]["txt_ids"]).all() and (lv["txt_masks"] == fx["lang"]["txt_masks"]).all()
+    obs0 = fx["steps"][0]["obs"]
+    gmaps = [R.RefGraphMap(ob["viewpoint"]) for ob in obs0]
+    for g, ob in zip(gmaps, obs0):
+        g.update_graph(ob)
+    for t, st in enumerate(fx["steps"]):
+        obs, ended = st["obs"], st["ended"]
+        if t > 0:
+            prev_ended = fx["steps"][t - 1]["ended"]
+            for i, ob in enumerate(obs):
+                if not prev_ended[i]:
+                    gmaps[i].update_graph(ob)
+        for i, g in enumerate(gmaps):
+            if not ended[i]:
+                g.node_step_ids[obs[i]["viewpoint"]] = t + 1
+        pano = R.panorama_variable(obs, feat=16)
+        want = st["pano"]
+        for k in ("view_img_fts", "loc_fts", "nav_types", "view_lens"):
+            torch.testing.assert_close(pano[k], want[k], rtol=0, atol=0)
+        assert pano["cand_vpids"] == want["cand_vpids"]
+        pe, pf = st["pe"], st["pf"]
+        for i, g in enumerate(gmaps):
+            if ended[i]:
+                continue
+            g.update_node_embed(obs[i]["viewpoint"], pf[i], rewrite=True)
+            for j, cv in enumerate(pano["cand_vpids"][i]):
+                if not g.graph.visited(cv):
+                    g.update_node_embed(cv, pe[i, j])
+        nav = R.nav_gmap_variable(obs, gmaps, st["last"], teacher=False)
+        nav.update(R.nav_vp_variable_mem(obs, gmaps, pe, pano["cand_vpids"], pano["view_lens"], pano["nav_types"], st["last"]))
+        ref = st["nav"]
+        assert nav["gmap_vpids"] == ref["gmap_vpids"] and nav["vp_cand_vpids"] == ref["vp_cand_vpids"]
+        assert nav["no_vp_left"] == ref["no_vp_left"]
+        for k in ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_visited_masks", "gmap_pair_dists", "gmap_masks",
+                  "vp_img_embeds", "vp_pos_fts", "vp_masks", "vp_nav_masks"):
+            torch.testing.assert_close(nav[k], ref[k], rtol=0, atol=0, msg=f"step {t}: {k}")
+        tr = st["traj"]
+        for pol, key in ((None, "tgt_il"), ("spl", "tgt_spl"), ("ndtw", "tgt_ndtw")):
+            got = R.teacher_action(env, obs, nav["gmap_vpids"], ended, nav["gmap_visited_masks"], pol is None, t, tr, pol or "spl")
+            assert (got == st[key]).all(), (t, key)

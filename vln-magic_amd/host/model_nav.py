@@ -158,7 +158,10 @@ class _PanoramaFn(torch.autograd.Function):
         dev = view_img_fts.device
         plan = dict(Np=B, V=V, nav_types=nav_types.reshape(-1).to(torch.int32), view_lens=view_lens.to(torch.int32),
                     pano_mask=(torch.arange(V, device=dev)[None] < view_lens[:, None]).to(torch.uint8))
-        feats = O.cast_to(view_img_fts.detach().float().reshape(B * V, D).contiguous(), net.dtype)
+        if view_img_fts.dtype == net.dtype:     # gathered from the HBM feature table in the compute dtype already
+            feats = view_img_fts.detach().reshape(B * V, D).contiguous()
+        else:
+            feats = O.cast_to(view_img_fts.detach().float().reshape(B * V, D).contiguous(), net.dtype)
         c = net.pano_fwd(plan, feats, loc_fts.detach().float().reshape(B * V, -1).contiguous())
         ctx.model, ctx.c, ctx.plan = model, c, plan
         masks = plan["pano_mask"].bool()
@@ -219,9 +222,8 @@ class _NavigationFn(torch.autograd.Function):
         Vp = vp_img.shape[1]
         L = txt_embeds.shape[1]
         txt_masks = b["txt_masks"]
-        tl = txt_masks.sum(1).tolist()
-        gl_ = b["gmap_masks"].sum(1).tolist()
-        vl = b["vp_masks"].sum(1).tolist()
+        hl = b.get("host_lens")          # index-plan rollout: the host already knows every length (no device->host sync)
+        tl, gl_, vl = hl if hl is not None else (txt_masks.sum(1).tolist(), b["gmap_masks"].sum(1).tolist(), b["vp_masks"].sum(1).tolist())
         plan = dict(B=B, K=K, Vp=Vp, L=L, gmap_step_ids=b["gmap_step_ids"].reshape(-1).to(torch.int32))
         c = Ctx(plan=plan, B=B, K=K, Vp=Vp, L=L)
         txt = txt_embeds.detach().to(net.dtype).reshape(B * L, H).contiguous()
@@ -251,8 +253,11 @@ class _NavigationFn(torch.autograd.Function):
             c.fuse_raw = net.zeros(B, dtype=torch.float32)
         c.gmask = ((~b["gmap_visited_masks"]) & b["gmap_masks"]).to(torch.uint8).contiguous()
         c.lmask = b["vp_nav_masks"].to(torch.uint8).contiguous()
-        fsrc, bw = nav_fusion_plan(b["gmap_vpids"], b["gmap_visited_masks"], b["vp_cand_vpids"], K, Vp)
-        c.fsrc, c.bw = torch.from_numpy(fsrc).to(dev), torch.from_numpy(bw).to(dev)
+        if b.get("fusion") is not None:   # (fsrc int32 [B,K], bw uint8 [B,Vp]) already on the device (host/nav_plan.fusion_map)
+            c.fsrc, c.bw = b["fusion"]
+        else:
+            fsrc, bw = nav_fusion_plan(b["gmap_vpids"], b["gmap_visited_masks"], b["vp_cand_vpids"], K, Vp)
+            c.fsrc, c.bw = torch.from_numpy(fsrc).to(dev), torch.from_numpy(bw).to(dev)
         gl, ll, fl = net.new(B, K, dtype=torch.float32), net.new(B, Vp, dtype=torch.float32), net.new(B, K, dtype=torch.float32)
         O.sap_fuse_fwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, c.gmask, c.lmask, c.fsrc, c.bw, c.use_gate, gl, ll, fl)
         # cls_embeds: the [stop]-token summary the agent feeds back as the [MEM] token (agent.py:206-210); open choice O9
@@ -372,6 +377,7 @@ class VLNBert(nn.Module):
         if mode == "navigation":
             data = {k: batch[k] for k in ("txt_masks", "gmap_masks", "vp_masks", "gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists",
                                           "gmap_visited_masks", "gmap_vpids", "vp_pos_fts", "vp_nav_masks", "vp_cand_vpids")}
+            data["host_lens"], data["fusion"] = batch.get("host_lens"), batch.get("fusion")
             g, v, ga, va, cls, gl, ll, fl = _NavigationFn.apply(self._anchor, self, batch["gmap_img_embeds"], batch["vp_img_embeds"],
                                                                 batch["txt_embeds"], data)
             return dict(gmap_embeds=g, vp_embeds=v, gmap_attns=ga, vp_attns=va, cls_embeds=cls,

@@ -1,0 +1,343 @@
+"""Index plans for the navigator step loop.
+
+`GMapNavAgent.rollout` (map_nav_src/r2r/agent.py:722-1160) interleaves three model calls per step with per-sample Python
+that touches device tensors: `gmap.update_node_embed(vp, pano_embeds[i, j])` per candidate (:905-924), `torch.stack` of
+`get_node_embed` per map node and `pad_tensors_wgrad` per sample (:206-210,:234), `nav_probs[i, 0].item()` per sample
+(:986-996), `.cpu()` masks for the fusion loops.  None of that bookkeeping depends on tensor VALUES -- only on the
+observations the simulator hands to the host -- so it is done here once per step in numpy and reaches the device as index
+arrays; the embeddings themselves never leave HBM:
+
+  * every step's panorama outputs live in an append-only device log (rows: B x V views, then B fused, then B [cls]);
+  * a map node's embedding is a weighted sum of log rows -- visited: the fused row of the step that visited it
+    (`rewrite=True`, :910), unvisited: the mean of every candidate view of it seen so far (:916-924) -- so
+    `gmap_img_embeds` and `vp_img_embeds` ([stop], [mem] = previous [cls], views; :206-210,:294-297) are ONE CSR gather over
+    the log, and their backward is the transposed CSR (the gradient reaches every earlier step's panorama encoder);
+  * positions / step ids / pair distances / masks / fusion map / expert actions are the arrays of
+    `_nav_gmap_variable` :175-251, `_nav_vp_variable_mem` :290-328, `_teacher_action` :330-373, built from
+    `graph_map.GraphMap`'s dense tables instead of per-pair method calls.
+
+Pure numpy: tested on CPU against the reference-style loops (tests/test_navplan_cpu.py).
+"""
+import math
+
+import numpy as np
+
+from .graph_map import MAX_DIST, MAX_STEP, GraphMap, angle_fts, rel_pos
+
+IGNORE = -100
+R30 = math.radians(30)
+
+
+def _csr_from_coo(out_rows, src_rows, w, n_out):
+    order = np.argsort(out_rows, kind="stable")
+    ptr = np.zeros(n_out + 1, np.int64)
+    np.add.at(ptr, out_rows + 1, 1)
+    ptr = np.cumsum(ptr).astype(np.int32)
+    if len(order) == 0:
+        return ptr, np.zeros(1, np.int32), np.zeros(1, np.float32)
+    return ptr, src_rows[order].astype(np.int32), w[order].astype(np.float32)
+
+
+def ndtw(dist, pred, ref, threshold=3.0):
+    """exp(-DTW / (threshold * |ref|)) (r2r/eval_utils.py cal_dtw), dist[a][b] = shortest distance"""
+    n, m = len(pred), len(ref)
+    d = np.full((n + 1, m + 1), np.inf)
+    d[0, 0] = 0
+    for i in range(1, n + 1):
+        for j in range(1, m + 1):
+            d[i, j] = dist[pred[i - 1]][ref[j - 1]] + min(d[i - 1, j], d[i, j - 1], d[i - 1, j - 1])
+    return math.exp(-d[n, m] / (threshold * m))
+
+
+class NavPlanner:
+    """Host mirror of one rollout: owns the per-episode GraphMaps, emits one plan (dict of numpy arrays) per step."""
+
+    def __init__(self, env, obs, feedback="teacher", max_action_len=15, expert_policy="spl", angle_table=None, train=True):
+        self.env, self.obs = env, obs
+        self.B = len(obs)
+        self.feedback, self.T, self.expert = feedback, max_action_len, expert_policy
+        self.train = train
+        self.angle_table = env.angle_table if angle_table is None else angle_table
+        self.gmaps = [GraphMap(ob["viewpoint"]) for ob in obs]
+        for g, ob in zip(self.gmaps, obs):
+            g.update_graph(ob)
+        self.scanvp_cands = {}
+        self._note_cands(obs)
+        self.traj = [dict(instr_id=ob["instr_id"], path=[[ob["viewpoint"]]]) for ob in obs]
+        self.ended = np.zeros(self.B, bool)
+        self.just_ended = np.zeros(self.B, bool)
+        self.end_obs_vp = [None] * self.B          # viewpoint at the moment the episode ended (stop-node fix-up)
+        self.stop_refs = [[] for _ in range(self.B)]     # (step, viewpoint) pairs whose stop probability was recorded
+        self.fused_row = [dict() for _ in range(self.B)]   # visited viewpoint -> log row of its fused embedding
+        self.view_rows = [dict() for _ in range(self.B)]   # unvisited viewpoint -> log rows of the views that showed it
+        self.log_base, self.log_V = [], []         # per step: first log row, padded view count
+        self.log_rows = 0
+        self.t = 0
+
+    def _note_cands(self, obs):
+        for ob in obs:
+            d = self.scanvp_cands.setdefault((ob["scan"], ob["viewpoint"]), {})
+            for c in ob["candidate"]:
+                d[c["viewpointId"]] = c["pointId"]
+
+    # ---- language (agent.py:63-90) -----------------------------------------------------------------------------
+    def language(self):
+        lens = np.array([len(ob["instr_encoding"]) for ob in self.obs], np.int64)
+        ids = np.zeros((self.B, int(lens.max())), np.int64)
+        for i, ob in enumerate(self.obs):
+            ids[i, :lens[i]] = ob["instr_encoding"]
+        return dict(txt_ids=ids, txt_lens=lens)
+
+    # ---- one step ----------------------------------------------------------------------------------------------
+    def begin_step(self):
+        """everything the three model calls of step t need, from the current observations"""
+        t, B, obs, gmaps = self.t, self.B, self.obs, self.gmaps
+        for i, g in enumerate(gmaps):
+            if not self.ended[i]:
+                g.node_step_ids[obs[i]["viewpoint"]] = t + 1          # agent.py:873-875
+        # -- panorama inputs (agent.py:111-173): candidate views first, then the remaining views in index order
+        cand_vpids, orders, view_lens = [], [], np.zeros(B, np.int64)
+        for i, ob in enumerate(obs):
+            cpts = [c["pointId"] for c in ob["candidate"]]
+            used = set(cpts)
+            order = cpts + [k for k in range(36) if k not in used]
+            orders.append(order)
+            cand_vpids.append([c["viewpointId"] for c in ob["candidate"]])
+            view_lens[i] = len(order)
+        V = int(view_lens.max())
+        view_order = np.zeros((B, V), np.int32)
+        nav_types = np.zeros((B, V), np.int64)
+        loc = np.zeros((B, V, 7), np.float32)
+        for i, ob in enumerate(obs):
+            n, nc = int(view_lens[i]), len(cand_vpids[i])
+            view_order[i, :n] = orders[i]
+            nav_types[i, :nc] = 1
+            if nc:
+                ch = np.array([c["heading"] for c in ob["candidate"]], np.float64)
+                ce = np.array([c["elevation"] for c in ob["candidate"]], np.float64)
+                loc[i, :nc, :4] = np.stack([np.sin(ch), np.cos(ch), np.sin(ce), np.cos(ce)], 1).astype(np.float32)
+            loc[i, nc:n, :4] = self.angle_table[ob["viewIndex"]][orders[i][nc:]]
+            loc[i, :n, 4:] = 1.0
+        vp_rows = np.array([ob["row"] for ob in obs], np.int32)
+        # -- log layout of this step: B*V view rows, B fused rows, B [cls] rows
+        base = self.log_rows
+        self.log_base.append(base)
+        self.log_V.append(V)
+        self.log_rows += B * (V + 2)
+        fused0, cls0 = base + B * V, base + B * V + B
+        prev_cls0 = (self.log_base[t - 1] + B * self.log_V[t - 1] + B) if t > 0 else -1
+        # -- node-embedding bookkeeping (agent.py:905-924)
+        for i, g in enumerate(gmaps):
+            if self.ended[i]:
+                continue
+            cur = obs[i]["viewpoint"]
+            self.fused_row[i][cur] = fused0 + i
+            self.view_rows[i].pop(cur, None)
+            for j, cv in enumerate(cand_vpids[i]):
+                if not g.graph.visited(cv):
+                    self.view_rows[i].setdefault(cv, []).append(base + i * V + j)
+        # -- map tokens (agent.py:175-251)
+        vpid_lists, lens = [], np.zeros(B, np.int64)
+        node_ids = []
+        no_left = np.zeros(B, bool)
+        for i, g in enumerate(gmaps):
+            names = list(g.node_positions.keys())
+            seen = [g.graph.visited(k) for k in names]
+            vis = [k for k, s in zip(names, seen) if s]
+            unv = [k for k, s in zip(names, seen) if not s]
+            no_left[i] = len(unv) == 0
+            vpid_lists.append([None, None] + vis + unv)
+            node_ids.append((len(vis), len(unv)))
+            lens[i] = 2 + len(vis) + len(unv)
+        K = int(lens.max())
+        Vp = V + 2
+        step_ids = np.zeros((B, K), np.int64)
+        pos = np.zeros((B, K, 7), np.float32)
+        pair = np.zeros((B, K, K), np.float32)
+        visited = np.zeros((B, K), bool)
+        gmask = np.arange(K)[None] < lens[:, None]
+        gmask[:, 1] = False                                            # [mem] can never be chosen (agent.py:233)
+        vp_pos = np.zeros((B, Vp, 14), np.float32)
+        coo_o, coo_s, coo_w = [], [], []
+        for i, g in enumerate(gmaps):
+            ids = vpid_lists[i]
+            n, (nv, nu) = int(lens[i]), node_ids[i]
+            visited[i, 1:2 + nv] = True
+            step_ids[i, 2:n] = [g.node_step_ids.get(vp, 0) for vp in ids[2:]]
+            gi = np.array([g.graph.index[vp] for vp in ids[2:]], np.int64)
+            cur = obs[i]["viewpoint"]
+            ci = g.graph.index[cur]
+            P = np.array([g.node_positions[vp] for vp in ids[2:]], np.float64)
+            h, e, d = rel_pos(g.node_positions[cur], P, base_heading=obs[i]["heading"], base_elevation=0)
+            dm = g.graph.matrix()
+            hops = g.graph.hops(ci)
+            pos[i, 2:n, :4] = angle_fts(h.astype(np.float32), e.astype(np.float32))
+            pos[i, 2:n, 4] = (d / MAX_DIST).astype(np.float32)
+            pos[i, 2:n, 5] = (dm[ci, gi] / MAX_DIST).astype(np.float32)
+            pos[i, 2:n, 6] = (hops[gi] / MAX_STEP).astype(np.float32)
+            pos[i, :2, 1] = pos[i, :2, 3] = 1.0                       # None tokens: angle (0, 0) -> cos = 1, distances 0
+            sub = dm[np.ix_(gi, gi)].astype(np.float32)
+            np.fill_diagonal(sub, 0.0)
+            pair[i, 2:n, 2:n] = sub
+            # local tokens (agent.py:290-328): [stop], [mem], views; position = (start-relative | candidate-relative)
+            nc = len(cand_vpids[i])
+            sh, se, sd = rel_pos(g.node_positions[cur], np.array([g.node_positions[g.start_vp]], np.float64),
+                                 base_heading=obs[i]["heading"], base_elevation=0)
+            si = g.graph.index[g.start_vp]
+            start = np.concatenate([angle_fts(sh.astype(np.float32), se.astype(np.float32))[0],
+                                    np.array([sd[0] / MAX_DIST, (0 if si == ci else dm[ci, si]) / MAX_DIST, hops[si] / MAX_STEP], np.float32)])
+            vp_pos[i, :, :7] = start
+            if nc:
+                cidx = np.array([g.graph.index[vp] for vp in cand_vpids[i]], np.int64)
+                CP = np.array([g.node_positions[vp] for vp in cand_vpids[i]], np.float64)
+                ch, ce, cd = rel_pos(g.node_positions[cur], CP, base_heading=obs[i]["heading"], base_elevation=0)
+                vp_pos[i, 2:2 + nc, 7:11] = angle_fts(ch.astype(np.float32), ce.astype(np.float32))
+                vp_pos[i, 2:2 + nc, 11] = (cd / MAX_DIST).astype(np.float32)
+                vp_pos[i, 2:2 + nc, 12] = (dm[ci, cidx] / MAX_DIST).astype(np.float32)
+                vp_pos[i, 2:2 + nc, 13] = (hops[cidx] / MAX_STEP).astype(np.float32)
+            # embedding sources
+            if t > 0:
+                coo_o += [i * K + 1, B * K + i * Vp + 1]
+                coo_s += [prev_cls0 + i, prev_cls0 + i]
+                coo_w += [1.0, 1.0]
+            for k, vp in enumerate(ids[2:], start=2):
+                if k < 2 + nv:
+                    coo_o.append(i * K + k)
+                    coo_s.append(self.fused_row[i][vp])
+                    coo_w.append(1.0)
+                else:
+                    rows = self.view_rows[i][vp]
+                    coo_o += [i * K + k] * len(rows)
+                    coo_s += rows
+                    coo_w += [1.0 / len(rows)] * len(rows)
+        # views of the current panorama -> local tokens 2..V+1 (padded rows included, like torch.cat in :294-297)
+        vo = (B * K + np.arange(B)[:, None] * Vp + 2 + np.arange(V)[None]).reshape(-1)
+        vs = (base + np.arange(B)[:, None] * V + np.arange(V)[None]).reshape(-1)
+        out_rows = np.concatenate([np.array(coo_o, np.int64), vo])
+        src_rows = np.concatenate([np.array(coo_s, np.int64), vs])
+        w = np.concatenate([np.array(coo_w, np.float32), np.ones(len(vo), np.float32)])
+        n_out = B * K + B * Vp
+        csr = _csr_from_coo(out_rows, src_rows, w, n_out)
+        csr_t = _csr_from_coo(src_rows, out_rows, w, cls0) if self.train else None     # sources are rows < cls0
+        vp_nav = np.concatenate([np.ones((B, 1), bool), np.zeros((B, 1), bool), nav_types == 1], 1)
+        vp_masks = np.arange(Vp)[None] < (view_lens + 2)[:, None]
+        vp_cand = [[None, None] + c for c in cand_vpids]
+        fsrc, bw = fusion_map(vpid_lists, visited, vp_cand, K, Vp)
+        targets = self._teacher_action(vpid_lists, visited)
+        self._cur = dict(vpids=vpid_lists, no_left=no_left, targets=targets)
+        return dict(t=t, B=B, V=V, K=K, Vp=Vp, log_base=base, log_fused=fused0, log_cls=cls0, log_rows=self.log_rows,
+                    vp_rows=vp_rows, view_order=view_order, loc_fts=loc, nav_types=nav_types, view_lens=view_lens, cand_vpids=cand_vpids,
+                    gmap_vpids=vpid_lists, gmap_lens=lens, gmap_step_ids=step_ids, gmap_pos_fts=pos, gmap_pair_dists=pair,
+                    gmap_visited_masks=visited, gmap_masks=gmask, no_vp_left=no_left,
+                    vp_pos_fts=vp_pos, vp_nav_masks=vp_nav, vp_masks=vp_masks, vp_cand_vpids=vp_cand,
+                    csr=csr, csr_t=csr_t, n_out=n_out, fsrc=fsrc, bw=bw, targets=targets)
+
+    # ---- expert (agent.py:330-373) -----------------------------------------------------------------------------
+    def _teacher_action(self, vpids, visited):
+        a = np.zeros(self.B, np.int64)
+        t, env = self.t, self.env
+        for i, ob in enumerate(self.obs):
+            if self.ended[i]:
+                a[i] = IGNORE
+            elif self.feedback == "teacher":
+                if ob["viewpoint"] != ob["gt_path"][t]:
+                    raise AssertionError("teacher forcing left the ground-truth path")
+                if t < len(ob["gt_path"]) - 1:
+                    goal = ob["gt_path"][t + 1]
+                    a[i] = next((j for j, v in enumerate(vpids[i]) if v == goal), 0)
+            elif ob["viewpoint"] != ob["gt_path"][-1]:
+                scan, cur = ob["scan"], ob["viewpoint"]
+                best, best_d = IGNORE, float("inf")
+                for j, v in enumerate(vpids[i]):
+                    if j > 1 and not visited[i, j]:
+                        if self.expert == "ndtw":
+                            d = -ndtw(env.shortest_distances[scan], sum(self.traj[i]["path"], []) + env.shortest_paths[scan][cur][v][1:],
+                                      ob["gt_path"])
+                        else:
+                            d = env.shortest_distances[scan][v][ob["gt_path"][-1]] + env.shortest_distances[scan][cur][v]
+                        if d < best_d:
+                            best, best_d = j, d
+                a[i] = best
+        return a
+
+    # ---- act + observe (agent.py:1056-1107) ----------------------------------------------------------------------
+    def end_step(self, a_t=None, features=False):
+        """a_t: chosen map-token index per sample (None under teacher forcing = the expert's).  Returns True when all ended."""
+        t, B, obs = self.t, self.B, self.obs
+        cur = self._cur
+        a_t = cur["targets"] if a_t is None else a_t
+        for i in range(B):
+            if not self.ended[i]:
+                self.stop_refs[i].append((t, obs[i]["viewpoint"]))
+        if self.feedback in ("teacher", "sample"):
+            stop = [ob["viewpoint"] == ob["gt_path"][-1] for ob in obs]
+        else:
+            stop = [int(a) == 0 for a in a_t]
+        acts, hops_from = [], [None] * B
+        for i in range(B):
+            if stop[i] or self.ended[i] or cur["no_left"][i] or t == self.T - 1:
+                acts.append(None)
+                self.just_ended[i] = True
+            else:
+                acts.append(cur["vpids"][i][int(a_t[i])])
+        for i, ob in enumerate(obs):
+            if acts[i] is not None:
+                p = self.gmaps[i].graph.path(ob["viewpoint"], acts[i])
+                self.traj[i]["path"].append(p)
+                hops_from[i] = self.traj[i]["path"][-2][-1] if len(p) == 1 else p[-2]
+        self.env.step(acts, hops_from)
+        for i in range(B):
+            if not self.ended[i] and self.just_ended[i]:
+                self.end_obs_vp[i] = obs[i]["viewpoint"]
+        self.obs = obs = self.env._get_obs(features)
+        self._note_cands(obs)
+        for i, ob in enumerate(obs):
+            if not self.ended[i]:
+                self.gmaps[i].update_graph(ob)
+        self.ended |= np.array([a is None for a in acts])
+        self.actions = acts
+        self.t += 1
+        return bool(self.ended.all())
+
+    def finish(self, stop_probs):
+        """stop_probs[t][b] = softmax(fused_logits)[b, 0] of every step: back-track each episode to its most stop-worthy
+        visited node (agent.py:1080-1089; the reference reads the scores with .item() every step -- deferred here, the
+        episode's graph does not change after it ended)"""
+        for i in range(self.B):
+            if self.end_obs_vp[i] is None:
+                continue
+            node, best = None, -float("inf")
+            for (t, vp) in self.stop_refs[i]:
+                s = float(stop_probs[t][i])
+                self.gmaps[i].node_stop_scores[vp] = {"stop": s}
+            for vp, v in self.gmaps[i].node_stop_scores.items():
+                if v["stop"] > best:
+                    node, best = vp, v["stop"]
+            if node is not None and self.end_obs_vp[i] != node:
+                self.traj[i]["path"].append(self.gmaps[i].graph.path(self.end_obs_vp[i], node))
+        return self.traj
+
+
+def fusion_map(gmap_vpids, visited_masks, vp_cand_vpids, K, Vp):
+    """local -> global logit fusion as index arrays ([LINEAGE] DUET navigation forward): map token k of an
+    unvisited node receives the local logit of the view that shows it (fsrc = that local token), or, when no current view
+    shows it, the sum of the local logits of views that lead back to visited nodes (fsrc = -2, bw marks those views)."""
+    B = len(gmap_vpids)
+    fsrc = np.full((B, K), -1, np.int32)
+    bw = np.zeros((B, Vp), np.uint8)
+    for b in range(B):
+        ids = gmap_vpids[b]
+        seen = set(vp for j, vp in enumerate(ids) if vp is not None and visited_masks[b][j])
+        shown = {}
+        for j, c in enumerate(vp_cand_vpids[b]):
+            if c is None or j == 0:
+                continue
+            if c in seen:
+                bw[b, j] = 1
+            else:
+                shown[c] = j
+        fsrc[b, 0] = 0
+        for j, vp in enumerate(ids):
+            if j > 0 and vp is not None and vp not in seen:
+                fsrc[b, j] = shown.get(vp, -2)
+    return fsrc, bw

@@ -1,0 +1,216 @@
+"""The navigator step loop on index plans (BASELINE config 5).
+
+Same computation as `GMapNavAgent.rollout` (map_nav_src/r2r/agent.py:722-1160) for feedback 'teacher' | 'argmax' |
+'sample', with or without MAKD against a frozen teacher -- but the per-sample Python over device tensors is gone:
+host/nav_plan.NavPlanner turns each step's observations into index arrays (ONE packed host->device copy per step), the
+panorama features are gathered on the device from the HBM-resident table (`magic_view_gather`), every step's embeddings
+are appended to a device log, and `gmap_img_embeds` / `vp_img_embeds` are one CSR gather over that log whose backward is
+the transposed gather (so `loss.backward()` still reaches every earlier step's panorama encoder, as `pad_tensors_wgrad`
+does in the reference, :234).
+
+Device->host traffic: none under teacher forcing (the stop probabilities the reference reads with `.item()` per sample
+and step, :986-996, are kept on the device and read once after the loop); one [B] action vector per step for 'argmax' /
+'sample' (the stepper needs it).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops as O
+from .makd_nav import compute_kd_losses
+from .nav_plan import IGNORE, NavPlanner
+from .kd_loss import exponential_decay
+
+
+def to_device(arrays, dev):
+    """ONE pinned staging buffer + ONE async copy for a dict of numpy arrays; returns device tensors (views of the copy)"""
+    metas, off = [], 0
+    for k, a in arrays.items():
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.bool_:
+            a = a.view(np.uint8)
+        off = (off + 15) & ~15
+        metas.append((k, a, off))
+        off += a.nbytes
+    stage = torch.empty(max(off, 16), dtype=torch.uint8, pin_memory=(dev.type == "cuda"))
+    sn = stage.numpy()
+    for k, a, o in metas:
+        sn[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+    buf = stage.to(dev, non_blocking=True)
+    out = {}
+    for k, a, o in metas:
+        t = buf[o:o + a.nbytes].view(getattr(torch, str(a.dtype))).view(a.shape)
+        out[k] = t
+    out["_stage"] = stage           # keep the pinned buffer alive until the copy has run
+    return out
+
+
+class _LogGather(torch.autograd.Function):
+    """out[n_out, H] = CSR(ptr, idx, w) x log; backward = transposed CSR, split back onto the step tensors the log rows
+    were copied from (`srcs[i]` occupies log rows [spans[i][0], spans[i][1]))."""
+
+    @staticmethod
+    def forward(ctx, log, csr, csr_t, n_out, n_src, spans, *srcs):
+        H = log.shape[1]
+        out = torch.empty(n_out, H, dtype=log.dtype, device=log.device)
+        O.csr_gather(log, csr[0], csr[1], csr[2], out, n_out, H)
+        ctx.csr_t, ctx.n_src, ctx.spans = csr_t, n_src, spans
+        ctx.shapes = [s.shape for s in srcs]
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        H = ctx.H
+        dlog = torch.empty(ctx.n_src, H, dtype=d_out.dtype, device=d_out.device)
+        O.csr_gather(d_out.contiguous(), ctx.csr_t[0], ctx.csr_t[1], ctx.csr_t[2], dlog, ctx.n_src, H)
+        grads = [dlog[a:b].view(shp) if b <= ctx.n_src else None for (a, b), shp in zip(ctx.spans, ctx.shapes)]
+        return (None, None, None, None, None, None, *grads)
+
+
+class EmbeddingLog:
+    """append-only [rows, H] device buffer of one model's per-step outputs + the autograd handles of the rows"""
+
+    def __init__(self, H, dtype, dev, rows=4096):
+        self.buf = torch.zeros(rows, H, dtype=dtype, device=dev)
+        self.srcs, self.spans = [], []
+
+    def put(self, row0, x, track=True):
+        x2 = x.detach().reshape(-1, self.buf.shape[1])
+        n = x2.shape[0]
+        if row0 + n > self.buf.shape[0]:
+            nb = torch.zeros(max(2 * self.buf.shape[0], row0 + n), self.buf.shape[1], dtype=self.buf.dtype, device=self.buf.device)
+            nb[:self.buf.shape[0]] = self.buf
+            self.buf = nb
+        self.buf[row0:row0 + n].copy_(x2)
+        if track and x.requires_grad:
+            self.srcs.append(x)
+            self.spans.append((row0, row0 + n))
+
+    def gather(self, csr, csr_t, n_out, n_src, grad=True):
+        if grad and self.srcs:
+            return _LogGather.apply(self.buf, csr, csr_t, n_out, n_src, list(self.spans), *self.srcs)
+        out = torch.empty(n_out, self.buf.shape[1], dtype=self.buf.dtype, device=self.buf.device)
+        O.csr_gather(self.buf, csr[0], csr[1], csr[2], out, n_out, self.buf.shape[1])
+        return out
+
+
+class NavRollout:
+    def __init__(self, student, feature_table, teacher=None, kd=None, max_action_len=15, expert_policy="spl"):
+        """feature_table: [n_viewpoints, 36, D] device tensor in the student's compute dtype (packed once, SURVEY f-2).
+        kd: dict(alpha, temperature, decay) -- MAKD hyper-parameters (run_r2r_kdl_valid.sh:97-104)."""
+        self.student, self.teacher, self.kd = student, teacher, kd
+        self.table = feature_table
+        self.T, self.expert = max_action_len, expert_policy
+        self.dev = feature_table.device
+        if teacher is not None:
+            self.heads = {n: getattr(student.vln_bert, n) for n in ("txt_emb_w", "kdl_img_w", "kdl_avg_img_w", "global_cross_w", "local_cross_w")}
+
+    def _pano_inputs(self, d, plan):
+        B, V = plan["B"], plan["V"]
+        fts = torch.empty(B, V, self.table.shape[2], dtype=self.table.dtype, device=self.dev)
+        O.view_gather(self.table, d["vp_rows"], d["view_order"], fts)
+        return dict(view_img_fts=fts, loc_fts=d["loc_fts"], nav_types=d["nav_types"], view_lens=d["view_lens"], already_dropout=True)
+
+    def _nav_inputs(self, d, plan, gathered, txt_embeds, txt_masks, txt_lens):
+        B, K, Vp, H = plan["B"], plan["K"], plan["Vp"], gathered.shape[1]
+        return dict(gmap_img_embeds=gathered[:B * K].view(B, K, H), vp_img_embeds=gathered[B * K:].view(B, Vp, H),
+                    txt_embeds=txt_embeds, txt_masks=txt_masks, gmap_masks=d["gmap_masks"].bool(), vp_masks=d["vp_masks"].bool(),
+                    gmap_step_ids=d["gmap_step_ids"], gmap_pos_fts=d["gmap_pos_fts"], gmap_pair_dists=d["gmap_pair_dists"],
+                    gmap_visited_masks=d["gmap_visited_masks"].bool(), gmap_vpids=plan["gmap_vpids"], vp_pos_fts=d["vp_pos_fts"],
+                    vp_nav_masks=d["vp_nav_masks"].bool(), vp_cand_vpids=plan["vp_cand_vpids"],
+                    host_lens=(txt_lens, [int(x) - 1 for x in plan["gmap_lens"]], [int(x) + 2 for x in plan["view_lens"]]),
+                    fusion=(d["fsrc"], d["bw"]))
+
+    def run(self, env, obs, feedback="teacher", train_ml=1.0, rw_seq=None, sample_draws=None, grad=True, record=False):
+        """One batch of episodes.  Returns dict(loss, ml_loss, kdl, traj, n_steps, decisions[, steps])."""
+        st, te, dev = self.student, self.teacher, self.dev
+        B = len(obs)
+        pl = NavPlanner(env, obs, feedback=feedback, max_action_len=self.T, expert_policy=self.expert, train=grad)
+        lang = pl.language()
+        ld = to_device(dict(txt_ids=lang["txt_ids"]), dev)
+        L = lang["txt_ids"].shape[1]
+        txt_lens = [int(x) for x in lang["txt_lens"]]
+        txt_masks = (torch.arange(L, device=dev)[None] < torch.as_tensor(lang["txt_lens"], device=dev)[:, None])
+        lin = dict(txt_ids=ld["txt_ids"], txt_masks=txt_masks)
+        ctxg = torch.enable_grad() if grad else torch.no_grad()
+        with ctxg:
+            txt_embeds, txt_attns = st("language", lin)
+        s_out = dict(txt_embeds=txt_embeds, txt_attns=txt_attns)
+        t_out = {}
+        if te is not None:
+            with torch.no_grad():
+                t_txt, t_txt_attns = te("language", lin)
+            t_out = dict(txt_embeds=t_txt, txt_attns=t_txt_attns)
+            t_log = EmbeddingLog(te.net.H, te.net.dtype, dev)
+        s_log = EmbeddingLog(st.net.H, st.net.dtype, dev)
+        ml_loss = torch.zeros((), dtype=torch.float32, device=dev)
+        kdl = {}
+        stop_probs, steps = [], []
+        decisions = 0
+        with ctxg:
+            for t in range(self.T):
+                plan = pl.begin_step()
+                decisions += int((~pl.ended).sum())
+                arrays = {k: plan[k] for k in ("vp_rows", "view_order", "loc_fts", "nav_types", "view_lens", "gmap_step_ids", "gmap_pos_fts",
+                                               "gmap_pair_dists", "gmap_visited_masks", "gmap_masks", "vp_pos_fts", "vp_nav_masks", "vp_masks",
+                                               "fsrc", "bw", "targets")}
+                arrays.update(csr_ptr=plan["csr"][0], csr_idx=plan["csr"][1], csr_w=plan["csr"][2])
+                if plan["csr_t"] is not None:
+                    arrays.update(csrt_ptr=plan["csr_t"][0], csrt_idx=plan["csr_t"][1], csrt_w=plan["csr_t"][2])
+                d = to_device(arrays, dev)
+                csr = (d["csr_ptr"], d["csr_idx"], d["csr_w"])
+                csr_t = (d["csrt_ptr"], d["csrt_idx"], d["csrt_w"]) if plan["csr_t"] is not None else None
+                pin = self._pano_inputs(d, plan)
+                pe, pm, pf, pa = st("panorama", pin)
+                s_out.update(pano_embeds=pe, pano_fused_embeds=pf, img_attns=pa)
+                s_log.put(plan["log_base"], pe)
+                s_log.put(plan["log_fused"], pf)
+                gathered = s_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=grad)
+                nav = self._nav_inputs(d, plan, gathered, txt_embeds, txt_masks, txt_lens)
+                outs = st("navigation", nav)
+                s_log.put(plan["log_cls"], outs["cls_embeds"])
+                logits = outs["fused_logits"]
+                s_out.update(nav_outs=outs, nav_logits=logits)
+                targets = d["targets"]
+                ce = F.cross_entropy(logits, targets, ignore_index=IGNORE, reduction="none")
+                ml_loss = ml_loss + ce.sum()
+                stop_probs.append(torch.softmax(logits.detach(), 1)[:, 0])
+                if te is not None:
+                    with torch.no_grad():
+                        tpe, _, tpf, tpa = te("panorama", pin)
+                        t_out.update(pano_embeds=tpe, pano_fused_embeds=tpf, img_attns=tpa)
+                        t_log.put(plan["log_base"], tpe, track=False)
+                        t_log.put(plan["log_fused"], tpf, track=False)
+                        tg = t_log.gather(csr, None, plan["n_out"], plan["log_cls"], grad=False)
+                        t_outs = te("navigation", self._nav_inputs(d, plan, tg, t_txt, txt_masks, txt_lens))
+                        t_log.put(plan["log_cls"], t_outs["cls_embeds"], track=False)
+                        t_out.update(nav_outs=t_outs, nav_logits=t_outs["fused_logits"])
+                        t_ce = F.cross_entropy(t_outs["fused_logits"], targets, ignore_index=IGNORE, reduction="none")
+                        t_out["sample_weights"] = exponential_decay(t_ce, self.kd["decay"])
+                    if grad:
+                        kdl = compute_kd_losses(t, s_out, t_out, self.heads, kdl, role="t2s", temperature=self.kd["temperature"],
+                                                weights=None if rw_seq is None else rw_seq[t])
+                a_host = None
+                if feedback == "argmax":
+                    a_host = logits.detach().argmax(1).cpu().numpy()                # the stepper needs it: one [B] copy
+                elif feedback == "sample":
+                    cdf = torch.softmax(logits.detach(), 1).double().cumsum(1)
+                    u = torch.as_tensor(sample_draws[t], dtype=torch.float64, device=dev)
+                    a_host = (cdf < (u * cdf[:, -1])[:, None]).sum(1).clamp(max=logits.shape[1] - 1).cpu().numpy()
+                if record:
+                    steps.append(dict(logits=logits.detach().float().cpu(), targets=torch.from_numpy(plan["targets"]).clone(),
+                                      vpids=plan["gmap_vpids"]))
+                done = pl.end_step(a_host)
+                if record:
+                    steps[-1]["actions"] = list(pl.actions)
+                if done:
+                    break
+        ml = ml_loss * train_ml / B
+        kd_sum, total = None, ml
+        if te is not None and grad:
+            kd_sum = sum(kdl.values()) / B
+            total = self.kd["alpha"] * kd_sum + (1 - self.kd["alpha"]) * ml
+        traj = pl.finish(torch.stack(stop_probs).cpu().numpy())
+        return dict(loss=total, ml_loss=ml, kdl=kd_sum, kdl_terms=kdl, traj=traj, n_steps=len(stop_probs), decisions=decisions,
+                    steps=steps, planner=pl)

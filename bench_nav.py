@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench_nav.py -- navigator step loop throughput (BASELINE config 5: RxR-length instructions, MAGIC-L fine-tune).
+
+NOT the headline line (that is bench.py / config 1): the measurement of the next §8 row, to the same bar.
+One "step" = one fine-tuning iteration of `Seq2SeqAgent.train` (map_nav_src/r2r/agent_base.py:215-296) on one batch of
+synthetic episodes per rank: teacher-forced rollout (train_ml = ml_weight 0.2) + DAgger rollout (feedback 'sample',
+train_ml 1) -> `loss.backward()` -> clip 40 -> `torch.optim.AdamW.step()` (the reference's own optimizer, agent_base.py:128-139).
+A trajectory-step = one (episode, t) decision of either rollout.  Episodes: instructions U{100..512} tokens,
+ground-truth paths of 8..15 hops on synthetic connectivity graphs, 36 x 768 features gathered from the HBM-resident table.
+
+`python bench_nav.py --gpus N --steps K --warmup W` (N > 1 under torch.distributed.run); rank 0 prints ONE JSON line with the
+same keys as bench.py.  `roofline`: dense-contraction kernels (MFMA), FLOPs counted from the true ragged sizes, durations from HIP
+events around every launch of one instrumented iteration.  `cpu_baseline`: the reference-style per-sample loop + fp32 CPU oracle
+model (oracle/rollout_ref.py, oracle/nav_ref.py) on a bounded sample.  `host_loop`: the same HIP model driven by the
+reference-style per-sample loop (GraphMap.update_node_embed / get_node_embed on device tensors, .item() per sample) for the
+teacher-forced rollout -- what the index plans replace.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import magic_amd  # noqa: E402,F401
+from magic_amd.host import lib as L  # noqa: E402
+from magic_amd.host import ops as O  # noqa: E402
+from magic_amd.host.config import make_config  # noqa: E402
+from magic_amd.host.model_nav import VLNBert  # noqa: E402
+from magic_amd.host.nav_rollout import NavRollout  # noqa: E402
+from magic_amd.host.synth_env import SynthNavEnv  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def make_env(a, seed):
+    return SynthNavEnv(batch_size=a.batch, n_scans=a.scans, nodes_per_scan=a.nodes, seed=seed, instr_len=(a.instr_min, a.instr_max),
+                       path_hops=(a.hops_min, a.hops_max))
+
+
+def cpu_baseline(a, cfg, budget=25.0):
+    from oracle import rollout_ref as R
+    from oracle.nav_ref import RefVLNBert
+    ncores = max(1, min(16, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(ncores)
+    torch.manual_seed(0)
+    model = RefVLNBert(cfg).eval()
+    env = SynthNavEnv(batch_size=min(a.batch, 4), n_scans=2, nodes_per_scan=a.nodes, seed=99, instr_len=(a.instr_min, a.instr_max),
+                      path_hops=(a.hops_min, a.hops_max))
+    dec, tt, n = 0, 0.0, 0
+    while tt < budget and n < 3:
+        t0 = time.perf_counter()
+        out = R.rollout(env, model, env.reset(), feedback="teacher", train_ml=0.2, max_action_len=a.max_action_len)
+        out["loss"].backward()
+        tt += time.perf_counter() - t0
+        dec += sum(int((s["targets"] != -100).sum()) for s in out["steps"])
+        n += 1
+    return {"value": round(dec / tt, 2), "unit": "trajectory-steps/sec", "cores": ncores, "kind": "port",
+            "sample": f"{n} teacher-forced rollouts + backward, B={env.batch_size}, fp32 torch CPU oracle model under the reference-style host loop "
+                      f"(no optimizer step), {tt / n:.1f} s each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16)                  # run_rxr_kdl_valid.sh:39
+    ap.add_argument("--hidden", type=int, default=768)                # MAGIC-L
+    ap.add_argument("--instr-min", type=int, default=100)
+    ap.add_argument("--instr-max", type=int, default=512)
+    ap.add_argument("--hops-min", type=int, default=8)
+    ap.add_argument("--hops-max", type=int, default=15)
+    ap.add_argument("--max-action-len", type=int, default=28)         # run_rxr_kdl_valid.sh:36
+    ap.add_argument("--scans", type=int, default=6)
+    ap.add_argument("--nodes", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-host-loop", action="store_true")
+    a = ap.parse_args()
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    L.load()
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    cfg = make_config(a.hidden, role="teacher", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    model = VLNBert(None, role="student", config=cfg, device=dev, compute_dtype=dtype, seed=0)
+    if world > 1:
+        dist.broadcast(model.store.flat, src=0)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-5)              # agent_base.py:128-129
+    env = make_env(a, 1234 + rank)
+    table = torch.from_numpy(env.feature_table).to(dev).to(dtype)
+    ro = NavRollout(model, table, max_action_len=a.max_action_len, expert_policy="ndtw")     # run_rxr_kdl_valid.sh:29
+    rng = np.random.default_rng(rank)
+
+    def iteration():
+        opt.zero_grad()
+        obs = env.reset(features=False)
+        batch = env.batch
+        r1 = ro.run(env, obs, feedback="teacher", train_ml=0.2)
+        obs = env.reset(batch=batch, features=False)
+        r2 = ro.run(env, obs, feedback="sample", train_ml=1.0, sample_draws=rng.uniform(size=(a.max_action_len, a.batch)))
+        (r1["loss"] + r2["loss"]).backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 40.0)     # agent_base.py:273
+        opt.step()
+        return r1["decisions"] + r2["decisions"]
+
+    for _ in range(a.warmup):
+        iteration()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dec = 0
+    for _ in range(a.steps):
+        dec += iteration()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        td = torch.tensor([dec], device=dev, dtype=torch.float64)
+        dist.all_reduce(td)
+        dec = float(td.item())
+
+    roof = None
+    if not a.no_profile:
+        O.FLOPS.update(total=0.0, enabled=True)
+        L.PROFILE.update(on=True, events=[])
+        t1 = time.perf_counter()
+        pdec = iteration()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t1
+        L.PROFILE["on"] = False
+        O.FLOPS["enabled"] = False
+        by = {}
+        for name, layout, e0, e1 in L.PROFILE["events"]:
+            k = name if layout < 0 else f"{name}[{['NT', 'NN', 'TN'][layout]}]"
+            t, c = by.get(k, (0.0, 0))
+            by[k] = (t + e0.elapsed_time(e1), c + 1)
+        gemm_ms = max(sum(t for k, (t, c) in by.items() if k.startswith("magic_gemm")), 1e-9)
+        gemm_n = sum(c for k, (t, c) in by.items() if k.startswith("magic_gemm"))
+        all_ms = sum(t for t, c in by.values())
+        ach = O.FLOPS["total"] / (gemm_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_kernel <bf16, NT|NN|TN> (every dense contraction of the iteration)", "achieved": round(ach, 2),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5), "traffic": None,
+                "detail": {"algorithmic_gflop_per_iteration": round(O.FLOPS["total"] / 1e9, 1), "gemm_launches": gemm_n,
+                           "avg_gemm_launch_us": round(gemm_ms / max(gemm_n, 1) * 1e3, 2), "gemm_ms": round(gemm_ms, 2),
+                           "all_kernels_ms": round(all_ms, 2), "launches": sum(c for t, c in by.values()),
+                           "instrumented_iteration_wall_ms": round(wall * 1e3, 1), "decisions": pdec,
+                           "top_kernels_share": {k: round(t / all_ms, 4) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]}}}
+
+    host_loop = None
+    if rank == 0 and not a.no_host_loop:
+        host_loop = host_loop_rate(a, model, dev)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a, cfg)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "trajectory-steps/sec (whole node), navigator step loop, MAGIC-L fine-tune", "value": round(dec / dt, 2),
+            "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"navigator loop (agent_base.py:215-296 iteration = teacher-forced + DAgger 'sample' rollout, backward, clip 40, "
+                                   f"torch AdamW), VLNBert H={a.hidden} 6+2+3 layers, dropout 0.1, expert ndtw, instructions U{{{a.instr_min}..{a.instr_max}}} tokens, "
+                                   f"paths {a.hops_min}..{a.hops_max} hops, max_action_len {a.max_action_len}",
+                       "per_gpu_batch": a.batch, "global_batch": a.batch * world, "views": 36, "feat_dim": 768, "parallelism": f"dp{world}",
+                       "decisions_per_iteration": round(dec / a.steps / world, 1)},
+            "roofline": roof, "cpu_baseline": cpu, "host_loop": host_loop}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def host_loop_rate(a, model, dev):
+    """teacher-forced rollout + backward: index plans vs the reference-style per-sample loop over the compat GraphMap, same model"""
+    from magic_amd.host import graph_map as GM
+    from oracle import rollout_ref as R                      # the reference-style loop lives with the checker; timed here as a baseline
+    out = {}
+    env = make_env(a, 777)
+    table = torch.from_numpy(env.feature_table).to(dev).to(model.net.dtype)
+    ro = NavRollout(model, table, max_action_len=a.max_action_len, expert_policy="ndtw")
+    saved = R.RefGraphMap
+    R.RefGraphMap = GM.GraphMap
+
+    def call(mode, b):
+        return model(mode, {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()})
+    orig = R.F.cross_entropy
+    R.F.cross_entropy = lambda lg, tg, **kw: orig(lg.float(), tg.to(lg.device), **kw)
+    try:
+        for name in ("index_plans", "per_sample_loop"):
+            dec, tt = 0, 0.0
+            for it in range(3):
+                model.store.zero_grad()
+                obs = env.reset(features=(name == "per_sample_loop"))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if name == "index_plans":
+                    r = ro.run(env, obs, feedback="teacher", train_ml=0.2)
+                    d = r["decisions"]
+                else:
+                    r = R.rollout(env, call, obs, feedback="teacher", train_ml=0.2, max_action_len=a.max_action_len)
+                    d = sum(int((s["targets"] != -100).sum()) for s in r["steps"])
+                r["loss"].backward()
+                torch.cuda.synchronize()
+                if it > 0:
+                    tt += time.perf_counter() - t0
+                    dec += d
+            out[name] = {"trajectory_steps_per_sec": round(dec / tt, 1), "ms_per_rollout": round(tt / 2 * 1e3, 1)}
+    finally:
+        R.RefGraphMap, R.F.cross_entropy = saved, orig
+    return out
+
+
+if __name__ == "__main__":
+    main()

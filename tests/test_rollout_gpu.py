@@ -1,0 +1,177 @@
+"""Navigator step loop parity (-m gpu): the index-plan rollout on the HIP engine (host/nav_rollout.py) against the
+reference-style per-sample loop (oracle/rollout_ref.py, builders pinned to the reference's own agent methods) driving the fp64 CPU
+oracle model, on the same synthetic episodes: per-step action logits, chosen actions (bit-exact), trajectories, episode loss, MAKD
+terms and every parameter gradient -- the gradient reaches earlier steps' panorama encoders only through the embedding-log gather."""
+import numpy as np
+import pytest
+import torch
+
+import magic_amd  # noqa: F401
+from magic_amd.host.config import make_config
+from magic_amd.host.model_nav import VLNBert
+from magic_amd.host.nav_rollout import NavRollout
+from magic_amd.host.synth_env import SynthNavEnv
+from oracle import rollout_ref as R
+from oracle.nav_ref import RefVLNBert
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HEADS = ("txt_emb_w", "kdl_img_w", "kdl_avg_img_w", "global_cross_w", "local_cross_w")
+KW = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=300, num_l_layers=2, num_x_layers=1, num_pano_layers=1)
+
+
+def _env(seed, B=4):
+    return SynthNavEnv(batch_size=B, n_scans=2, nodes_per_scan=30, seed=seed, instr_len=(6, 14), vocab=(3, 290), path_hops=(2, 4))
+
+
+def _pair(cfg, role, seed):
+    torch.manual_seed(seed)
+    o = RefVLNBert(cfg).double().eval()
+    with torch.no_grad():
+        for n, p in o.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.02)
+    g = VLNBert(None, role=role, config=cfg, device=DEV, compute_dtype=torch.float32)
+    g.load_state_dict(o.state_dict())
+    g.eval()
+    return o, g
+
+
+def _f64(model):
+    def call(mode, b):
+        return model(mode, {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()})
+    return call
+
+
+def close(a, b, name, rtol=2e-4, atol=2e-5):
+    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"{name}: max|err| {(a - b).abs().max().item():.3e} (ref {b.abs().max().item():.3e})"
+
+
+def _check_steps(got, want):
+    assert len(got["steps"]) == len(want["steps"])
+    for t, (g, w) in enumerate(zip(got["steps"], want["steps"])):
+        a, b = g["logits"], w["logits"].float()
+        assert torch.equal(torch.isinf(a), torch.isinf(b)), f"step {t}: -inf pattern"
+        close(torch.nan_to_num(a, neginf=0), torch.nan_to_num(b, neginf=0), f"step {t} fused logits", 1e-4, 1e-3)
+        assert (torch.nan_to_num(a, neginf=0) - torch.nan_to_num(b, neginf=0)).abs().max() < 1e-3      # north-star bar
+        assert torch.equal(a.argmax(1), b.argmax(1)), f"step {t}: action argmax must be bit-exact"
+        assert torch.equal(g["targets"], w["targets"]) and g["actions"] == w["actions"] and g["vpids"] == w["vpids"]
+    assert [x["path"] for x in got["traj"]] == [x["path"] for x in want["traj"]]
+
+
+def _check_grads(g_model, o_model, floor=40):
+    params = dict(g_model.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in o_model.parameters() if p.grad is not None)
+    n = 0
+    for name, p in o_model.named_parameters():
+        g = params[name].grad
+        if p.grad is None:
+            assert g is None or g.abs().max().item() == 0.0, name
+            continue
+        close(g, p.grad, f"grad {name}", 2e-3, 1e-3 * p.grad.abs().max().item() + 2e-6 * gmax)
+        n += 1
+    assert n > floor
+
+
+@pytest.mark.parametrize("seed,cache_kv", [(3, True), (7, False)])
+def test_teacher_forced_rollout_matches_oracle(seed, cache_kv):
+    """cache_kv: the instruction's cross-attention K/V projected once per episode (VLNBert.text_kv) vs at every step"""
+    cfg = make_config(128, role="student", **KW)
+    o_s, g_s = _pair(cfg, "student", 0)
+    env_a, env_b = _env(seed), _env(seed)
+    want = R.rollout(env_a, _f64(o_s), env_a.reset(), feedback="teacher", train_ml=0.2, max_action_len=6)
+    want["loss"].backward()
+    table = torch.from_numpy(env_b.feature_table).to(DEV)
+    ro = NavRollout(g_s, table, max_action_len=6, cache_text_kv=cache_kv)
+    g_s.store.zero_grad()
+    got = ro.run(env_b, env_b.reset(features=False), feedback="teacher", train_ml=0.2, record=True)
+    _check_steps(got, want)
+    close(got["loss"], want["loss"], "episode loss", 2e-4, 1e-6)
+    got["loss"].backward()
+    torch.cuda.synchronize()
+    _check_grads(g_s, o_s)
+    assert got["decisions"] == sum(int((s["targets"] != -100).sum()) for s in want["steps"])
+
+
+def test_argmax_and_sample_rollouts_match_oracle():
+    cfg = make_config(128, role="student", **KW)
+    o_s, g_s = _pair(cfg, "student", 1)
+    table = None
+    for feedback, seed in (("argmax", 5), ("sample", 9)):
+        env_a, env_b = _env(seed, B=5), _env(seed, B=5)
+        draws = np.random.default_rng(seed).uniform(size=(7, 5))
+        with torch.no_grad():
+            want = R.rollout(env_a, _f64(o_s), env_a.reset(), feedback=feedback, train_ml=1.0, max_action_len=7, sample_draws=draws)
+        table = torch.from_numpy(env_b.feature_table).to(DEV)
+        ro = NavRollout(g_s, table, max_action_len=7)
+        got = ro.run(env_b, env_b.reset(features=False), feedback=feedback, train_ml=1.0, sample_draws=draws, grad=False, record=True)
+        _check_steps(got, want)
+        close(got["loss"], want["loss"], f"{feedback} loss", 2e-4, 1e-6)
+
+
+def test_makd_rollout_matches_oracle():
+    """teacher (H=256) + student (H=128): MAKD t2s with MKRW weights and MKTD sample weights inside the loop (agent.py:1007-1024)"""
+    tcfg, scfg = make_config(256, role="teacher", **KW), make_config(128, role="student", teacher_hidden_size=256, **KW)
+    o_t, g_t = _pair(tcfg, "teacher", 0)
+    o_s, g_s = _pair(scfg, "student", 1)
+    T = 5
+    rw = (torch.softmax(torch.randn(T, 5, generator=torch.Generator().manual_seed(4)) / 4, -1) * 5)
+    kd = dict(alpha=0.5, temperature=2.0, decay=0.7)
+    env_a, env_b = _env(13), _env(13)
+    heads = {n: getattr(o_s.vln_bert, n) for n in HEADS}
+    want = R.rollout(env_a, _f64(o_s), env_a.reset(), feedback="teacher", train_ml=0.2, max_action_len=T, teacher=_f64(o_t),
+                     kd=dict(kd, heads=heads), rw_seq=rw.double())
+    want["loss"].backward()
+    table = torch.from_numpy(env_b.feature_table).to(DEV)
+    ro = NavRollout(g_s, table, teacher=g_t, kd=kd, max_action_len=T)
+    g_s.store.zero_grad()
+    got = ro.run(env_b, env_b.reset(features=False), feedback="teacher", train_ml=0.2, rw_seq=rw.to(DEV), record=True)
+    _check_steps(got, want)
+    for k, v in want["kdl_terms"].items():
+        close(got["kdl_terms"][k], v, f"kd {k}", 3e-4, 1e-6)
+    close(got["loss"], want["loss"], "episode loss", 2e-4, 1e-6)
+    got["loss"].backward()
+    torch.cuda.synchronize()
+    _check_grads(g_s, o_s)
+
+
+def test_compat_graphmap_drives_the_same_numbers():
+    """The reference's unmodified loop shape (per-sample GraphMap.update_node_embed / get_node_embed on device tensors +
+    pad_tensors_wgrad) over the product GraphMap gives the same logits as the index-plan path."""
+    from magic_amd.host import graph_map as GM
+    cfg = make_config(128, role="student", **KW)
+    _, g_s = _pair(cfg, "student", 2)
+    env_a, env_b = _env(17), _env(17)
+    table = torch.from_numpy(env_b.feature_table).to(DEV)
+    with torch.no_grad():
+        got = NavRollout(g_s, table, max_action_len=5).run(env_b, env_b.reset(features=False), grad=False, record=True)
+    saved = R.RefGraphMap, R.pad_rows
+    R.RefGraphMap = GM.GraphMap
+    try:
+        def call(mode, b):
+            b = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
+            out = g_s(mode, b)
+            return out
+        with torch.no_grad():
+            want = _rollout_on_device(env_a, call)
+    finally:
+        R.RefGraphMap, R.pad_rows = saved
+    for t, (g, w) in enumerate(zip(got["steps"], want)):
+        close(torch.nan_to_num(g["logits"], neginf=0), torch.nan_to_num(w, neginf=0), f"step {t}", 1e-5, 1e-5)
+
+
+def _rollout_on_device(env, call):
+    """thin adapter: the oracle loop with device tensors (targets / masks moved where the loop compares them on the host)"""
+    logs = []
+    orig_ce = torch.nn.functional.cross_entropy
+
+    def ce(logits, targets, **kw):
+        logs.append(logits.detach().float().cpu())
+        return orig_ce(logits.float().cpu(), targets, **kw)
+    R.F.cross_entropy = ce
+    try:
+        R.rollout(env, call, env.reset(), feedback="teacher", train_ml=1.0, max_action_len=5)
+    finally:
+        R.F.cross_entropy = orig_ce
+    return logs

@@ -380,10 +380,14 @@ class MagicNet:
         """descriptor of a block's output LayerNorm (BertOutput.LayerNorm)"""
         return self._ln_desc(lp + "output.LayerNorm", lc.ffn.out, lc.ffn.rstd, lc.ffn.hdrop)
 
-    def cross_layer_fwd(self, lp, x, Bn, Nq, kmask, dist, sprel, ctx, Nk, ckmask, rows, crow, sflops, cflops, qkv=None, next_lp=None):
+    def cross_layer_fwd(self, lp, x, Bn, Nq, kmask, dist, sprel, ctx, Nk, ckmask, rows, crow, sflops, cflops, qkv=None, next_lp=None,
+                        kv=None):
+        """kv: this layer's key/value projection of the context [Bn*Nk, 2H], computed once by the caller (navigator loop: the
+        text does not change between the steps of an episode, model_nav.VLNBert.text_kv); its gradient is then written to
+        `dkv` of cross_layer_bwd instead of going through the projection here."""
         H = self.H
         Mq, Mk = Bn * Nq, Bn * Nk
-        c = Ctx(Bn=Bn, Nq=Nq, Nk=Nk, ctx=ctx, rows=rows, crow=crow, cflops=cflops, next_qkv=None)
+        c = Ctx(Bn=Bn, Nq=Nq, Nk=Nk, ctx=ctx, rows=rows, crow=crow, cflops=cflops, next_qkv=None, kv_given=kv is not None)
         ql = self.lin(lp + "crossattention.self.query.weight")
         kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
         rb = self._rb_ok()
@@ -397,7 +401,7 @@ class MagicNet:
             c.sa = self._sa_fwd(lp, x, Bn, Nq, kmask, dist, sprel, rows, sflops, qkv)
             c.q = O.linear_fwd(c.sa.a, ql.W, ql.b, Mq, flop_rows=rows)
         s = c.sa.a
-        c.kv = O.linear_fwd(ctx, kvl.W, kvl.b, Mk, flop_rows=crow)
+        c.kv = kv if kv is not None else O.linear_fwd(ctx, kvl.W, kvl.b, Mk, flop_rows=crow)
         c.adrop, c.hdrop = self._da(lp + "crossattention.self.dropout"), self._dh(lp + "crossattention.output.dropout")
         c.Ppre, c.cctx, c.ldp, c.P = self._attn_fwd(c.q, H, c.kv, c.kv[:, H:], 2 * H, Bn, Nq, Nk, ckmask, None, None, cflops, c.adrop)
         o = self.lin(lp + "crossattention.output.dense.weight")
@@ -418,7 +422,7 @@ class MagicNet:
         c.out = c.ffn.out
         return c
 
-    def cross_layer_bwd(self, lp, c, dout, d_ctx_acc, dsprel=None, dP_init=None, fuse_in=None):
+    def cross_layer_bwd(self, lp, c, dout, d_ctx_acc, dsprel=None, dP_init=None, fuse_in=None, dkv_out=None):
         """returns dx (plain, or a Pre pair when fuse_in is given); accumulates the gradient wrt the context (other modality)
         into d_ctx_acc."""
         H, Bn, Nq, Nk = self.H, c.Bn, c.Nq, c.Nk
@@ -429,15 +433,17 @@ class MagicNet:
         o = self.lin(lp + "crossattention.output.dense.weight")
         O.linear_dw(d_cod, c.cctx, o.dW, o.db, Mq, flop_rows=c.rows)
         d_cctx = O.linear_dx(d_cod, o.W, Mq, flop_rows=c.rows)
-        dq, dkv = self.new(Mq, H), self.new(Mk, 2 * H)
+        dq = self.new(Mq, H)
+        dkv = dkv_out if c.kv_given else self.new(Mk, 2 * H)
         self._attn_bwd(c.Ppre, c.ldp, d_cctx, c.q, H, c.kv, c.kv[:, H:], 2 * H, dq, H, dkv, dkv[:, H:], 2 * H,
                        Bn, Nq, Nk, None, None, dP_init, c.cflops, c.adrop, c.P if c.adrop else None)
         ql = self.lin(lp + "crossattention.self.query.weight")
         kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
         O.linear_dw(dq, c.sa.a, ql.dW, ql.db, Mq, flop_rows=c.rows)
         d_s = self._dx_into_ln(dq, ql, Mq, d_co, self._ln_desc(lp + "attention.output.LayerNorm", c.sa.a, c.sa.rstd_a, c.sa.hdrop), c.rows)
-        O.linear_dw(dkv, c.ctx, kvl.dW, kvl.db, Mk, flop_rows=c.crow)
-        O.linear_dx(dkv, kvl.W, Mk, out=d_ctx_acc, residual=d_ctx_acc, flop_rows=c.crow)
+        if not c.kv_given:
+            O.linear_dw(dkv, c.ctx, kvl.dW, kvl.db, Mk, flop_rows=c.crow)
+            O.linear_dx(dkv, kvl.W, Mk, out=d_ctx_acc, residual=d_ctx_acc, flop_rows=c.crow)
         return self._sa_bwd(lp, c.sa, d_s, dsprel, None, fuse=fuse_in)
 
     # ---- text encoder --------------------------------------------------------------------------
@@ -614,7 +620,7 @@ class MagicNet:
         dw = (self.S.g(g + "sprel_linear.weight"), self.S.g(g + "sprel_linear.bias")) if self.train else None
         return (w, b), dw
 
-    def cross_fwd(self, which, plan, x, Nq, qmask, qlens, qrows, ctx, Nk, kmask, klens, krows, dist=None):
+    def cross_fwd(self, which, plan, x, Nq, qmask, qlens, qrows, ctx, Nk, kmask, klens, krows, dist=None, kv=None):
         enc = self.p + ("global_encoder." if which == "global" else "local_encoder.")
         B = plan["B"]
         sprel, _ = self._sprel() if (which == "global" and dist is not None) else (None, None)
@@ -623,13 +629,14 @@ class MagicNet:
         nl, qkv = self.cfg.num_x_layers, None
         for i in range(nl):
             lc = self.cross_layer_fwd(f"{enc}encoder.crossattention.{i}.", x, B, Nq, qmask, dist, sprel, ctx, Nk, kmask, qrows, krows, sf, cf,
-                                      qkv=qkv, next_lp=f"{enc}encoder.crossattention.{i + 1}." if i + 1 < nl else None)
+                                      qkv=qkv, next_lp=f"{enc}encoder.crossattention.{i + 1}." if i + 1 < nl else None,
+                                      kv=None if kv is None else kv[i])
             c.layers.append(lc)
             x, qkv = lc.out, lc.next_qkv
         c.out, c.P, c.ldp = x, c.layers[-1].P, c.layers[-1].ldp
         return c
 
-    def cross_bwd(self, c, d_out, d_ctx_acc, dP_init=None):
+    def cross_bwd(self, c, d_out, d_ctx_acc, dP_init=None, dkv=None):
         enc = self.p + ("global_encoder." if c.which == "global" else "local_encoder.")
         _, dsprel = self._sprel() if (c.which == "global" and c.dist is not None) else (None, None)
         d = d_out
@@ -637,5 +644,5 @@ class MagicNet:
         for i in reversed(range(nl)):
             prev = self._out_ln_desc(f"{enc}encoder.crossattention.{i - 1}.", c.layers[i - 1]) if i > 0 else None
             d = self.cross_layer_bwd(f"{enc}encoder.crossattention.{i}.", c.layers[i], d, d_ctx_acc, dsprel, dP_init if i == nl - 1 else None,
-                                     fuse_in=prev)
+                                     fuse_in=prev, dkv_out=None if dkv is None else dkv[i])
         return d

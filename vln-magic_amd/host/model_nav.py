@@ -212,9 +212,52 @@ def nav_fusion_plan(gmap_vpids, gmap_visited_masks, vp_cand_vpids, K, Vp):
     return fsrc, bw
 
 
+def _kv_lins(model):
+    net, p, nl = model.net, model.prefix, model.net.cfg.num_x_layers
+    H = net.H
+    return [net.lin(f"{p}{enc}encoder.crossattention.{i}.crossattention.self.key.weight",
+                    f"{p}{enc}encoder.crossattention.{i}.crossattention.self.key.bias", rows=2 * H, cols=H)
+            for enc in ("global_encoder.", "local_encoder.") for i in range(nl)]
+
+
+class _TextKVFn(torch.autograd.Function):
+    """key/value projections of the instruction for every cross-attention layer of both encoders, [2 * num_x_layers, B*L, 2H].
+    The text embeddings are fixed for a whole episode (agent.py:796 computes them once), but the reference's per-step
+    `vln_bert('navigation', ...)` call re-projects them in all six cross layers at every step -- at RxR lengths that is most of
+    a step's FLOPs.  Computed once per episode here; each step's navigation backward returns its dK/dV for this tensor,
+    autograd sums them, and this backward runs the projection's weight / input gradients ONCE on the sum."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, txt_embeds):
+        net = model.net
+        B, L, H = txt_embeds.shape
+        M = B * L
+        txt = txt_embeds.detach().to(net.dtype).reshape(M, H).contiguous()
+        lins = _kv_lins(model)
+        out = net.new(len(lins), M, 2 * H)
+        for i, kvl in enumerate(lins):
+            O.linear_fwd(txt, kvl.W, kvl.b, M, out=out[i])
+        ctx.model, ctx.txt, ctx.shape, ctx.in_dtype = model, txt, (B, L, H), txt_embeds.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dkv):
+        model, net = ctx.model, ctx.model.net
+        net.S.ensure_grads()
+        _queue_sync(model)
+        B, L, H = ctx.shape
+        M = B * L
+        dkv = dkv.to(net.dtype).contiguous()
+        d_txt = torch.zeros(M, H, dtype=net.dtype, device=dkv.device)
+        for i, kvl in enumerate(_kv_lins(model)):
+            O.linear_dw(dkv[i], ctx.txt, kvl.dW, kvl.db, M)
+            O.linear_dx(dkv[i], kvl.W, M, out=d_txt, residual=d_txt)
+        return None, None, d_txt.view(B, L, H).to(ctx.in_dtype)
+
+
 class _NavigationFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, model, gmap_img, vp_img, txt_embeds, b):
+    def forward(ctx, anchor, model, gmap_img, vp_img, txt_embeds, b, txt_kv=None):
         net, p = model.net, model.prefix
         H = net.H
         dev = gmap_img.device
@@ -232,11 +275,15 @@ class _NavigationFn(torch.autograd.Function):
         vmask_u8 = b["vp_masks"].to(torch.uint8).contiguous()
         c.gin = net.gmap_in_fwd(plan, None, b["gmap_pos_fts"].float().reshape(B * K, -1).contiguous(),
                                 gimg=gmap_img.detach().to(net.dtype).reshape(B * K, H).contiguous())
+        nl = net.cfg.num_x_layers
+        kv = None if txt_kv is None else txt_kv.detach()
+        c.has_kv = kv is not None
         c.glob = net.cross_fwd("global", plan, c.gin.out, K, gmask_u8, gl_, int(sum(gl_)), txt, L, tmask, tl, int(sum(tl)),
-                               dist=b["gmap_pair_dists"].float().contiguous())
+                               dist=b["gmap_pair_dists"].float().contiguous(), kv=None if kv is None else kv[:nl])
         c.vin = net.vp_in_fwd(plan, None, b["vp_pos_fts"].float().reshape(B * Vp, -1).contiguous(),
                               vimg=vp_img.detach().to(net.dtype).reshape(B * Vp, H).contiguous())
-        c.loc = net.cross_fwd("local", plan, c.vin.out, Vp, vmask_u8, vl, int(sum(vl)), txt, L, tmask, tl, int(sum(tl)))
+        c.loc = net.cross_fwd("local", plan, c.vin.out, Vp, vmask_u8, vl, int(sum(vl)), txt, L, tmask, tl, int(sum(tl)),
+                              kv=None if kv is None else kv[nl:])
         # heads
         c.Yg, c.g_raw = model._cls(p + "global_sap_head.", c.glob.out, B * K)
         c.Yl, c.l_raw = model._cls(p + "local_sap_head.", c.loc.out, B * Vp)
@@ -305,12 +352,14 @@ class _NavigationFn(torch.autograd.Function):
             dP = torch.zeros(B, net.nh, Nq, P.shape[-1], dtype=torch.float32, device=dev)
             dP[..., :L] = d.float()
             return dP
-        d_gin = net.cross_bwd(c.glob, d_gmap, d_txt, attn_seed(d_ga, c.glob.P, K))
-        d_vin = net.cross_bwd(c.loc, d_vp, d_txt, attn_seed(d_va, c.loc.P, Vp))
+        nl = net.cfg.num_x_layers
+        dkv = net.new(2 * nl, B * L, 2 * H) if c.has_kv else None
+        d_gin = net.cross_bwd(c.glob, d_gmap, d_txt, attn_seed(d_ga, c.glob.P, K), dkv=None if dkv is None else dkv[:nl])
+        d_vin = net.cross_bwd(c.loc, d_vp, d_txt, attn_seed(d_va, c.loc.P, Vp), dkv=None if dkv is None else dkv[nl:])
         net.gmap_in_bwd(c.gin, c.plan, d_gin, None, None)
         net.vp_in_bwd(c.vin, c.plan, d_vin, None)
         a, b_, t_ = ctx.in_dtypes
-        return (None, None, d_gin.view(B, K, H).to(a), d_vin.view(B, Vp, H).to(b_), d_txt.view(B, L, H).to(t_), None)
+        return (None, None, d_gin.view(B, K, H).to(a), d_vin.view(B, Vp, H).to(b_), None if c.has_kv else d_txt.view(B, L, H).to(t_), None, dkv)
 
 
 class VLNBert(nn.Module):
@@ -364,6 +413,12 @@ class VLNBert(nn.Module):
         self._first_rows(B, N, dev)
         return self._rows[("t", B, N)]
 
+    def text_kv(self, txt_embeds):
+        """per-episode key/value projections of the instruction for the navigation steps: pass the result as
+        `inputs['txt_kv']` of every `vln_bert('navigation', inputs)` call of the episode (optional; identical results)"""
+        self.store.sync_shadow()
+        return _TextKVFn.apply(self._anchor, self, txt_embeds)
+
     def forward(self, mode, batch):
         self.store.sync_shadow()
         self._arm_dropout()           # vln_bert.train() (agent.py:rollout under feedback='sample') -> config dropouts on
@@ -379,7 +434,7 @@ class VLNBert(nn.Module):
                                           "gmap_visited_masks", "gmap_vpids", "vp_pos_fts", "vp_nav_masks", "vp_cand_vpids")}
             data["host_lens"], data["fusion"] = batch.get("host_lens"), batch.get("fusion")
             g, v, ga, va, cls, gl, ll, fl = _NavigationFn.apply(self._anchor, self, batch["gmap_img_embeds"], batch["vp_img_embeds"],
-                                                                batch["txt_embeds"], data)
+                                                                batch["txt_embeds"], data, batch.get("txt_kv"))
             return dict(gmap_embeds=g, vp_embeds=v, gmap_attns=ga, vp_attns=va, cls_embeds=cls,
                         global_logits=gl, local_logits=ll, fused_logits=fl)
         raise NotImplementedError(f"VLNBert mode {mode!r} (instr_zdict_update / extract_cfp_features are SURVEY §8 f-4, not built)")

@@ -38,15 +38,29 @@ def _csr_from_coo(out_rows, src_rows, w, n_out):
     return ptr, src_rows[order].astype(np.int32), w[order].astype(np.float32)
 
 
+def dtw_rows(dist, row, nodes, ref):
+    """advance the DTW table of r2r/eval_utils.py cal_dtw by the path nodes `nodes`: `row` = table row of the path so far
+    (row 0 = [0, inf, ...]); the recurrence only looks one row back, so a rollout keeps ONE row per episode for the walked
+    prefix and each expert query extends it by the 1-3 nodes of the candidate's connecting path instead of redoing the
+    whole (prediction x reference) table per candidate as the reference does (agent.py:356-363)."""
+    for p in nodes:
+        dp = dist[p]
+        new = [math.inf] * len(row)
+        left = math.inf
+        for j in range(1, len(row)):
+            up, diag = row[j], row[j - 1]
+            best = up if up < diag else diag
+            if left < best:
+                best = left
+            left = new[j] = dp[ref[j - 1]] + best
+        row = new
+    return row
+
+
 def ndtw(dist, pred, ref, threshold=3.0):
     """exp(-DTW / (threshold * |ref|)) (r2r/eval_utils.py cal_dtw), dist[a][b] = shortest distance"""
-    n, m = len(pred), len(ref)
-    d = np.full((n + 1, m + 1), np.inf)
-    d[0, 0] = 0
-    for i in range(1, n + 1):
-        for j in range(1, m + 1):
-            d[i, j] = dist[pred[i - 1]][ref[j - 1]] + min(d[i - 1, j], d[i, j - 1], d[i - 1, j - 1])
-    return math.exp(-d[n, m] / (threshold * m))
+    row = dtw_rows(dist, [0.0] + [math.inf] * len(ref), pred, ref)
+    return math.exp(-row[-1] / (threshold * len(ref)))
 
 
 class NavPlanner:
@@ -72,6 +86,14 @@ class NavPlanner:
         self.view_rows = [dict() for _ in range(self.B)]   # unvisited viewpoint -> log rows of the views that showed it
         self.log_base, self.log_V = [], []         # per step: first log row, padded view count
         self.log_rows = 0
+        self._pano_cache = getattr(env, "_pano_plan_cache", None)
+        if self._pano_cache is None:
+            self._pano_cache = {}
+            try:
+                env._pano_plan_cache = self._pano_cache
+            except AttributeError:
+                pass
+        self._dtw = {}                             # episode -> (nodes consumed, DTW row) of the walked path
         self.t = 0
 
     def _note_cands(self, obs):
@@ -96,28 +118,35 @@ class NavPlanner:
             if not self.ended[i]:
                 g.node_step_ids[obs[i]["viewpoint"]] = t + 1          # agent.py:873-875
         # -- panorama inputs (agent.py:111-173): candidate views first, then the remaining views in index order
-        cand_vpids, orders, view_lens = [], [], np.zeros(B, np.int64)
+        # (static per (viewpoint, facing view): cached across steps and rollouts)
+        cand_vpids, view_lens, per = [], np.zeros(B, np.int64), []
         for i, ob in enumerate(obs):
-            cpts = [c["pointId"] for c in ob["candidate"]]
-            used = set(cpts)
-            order = cpts + [k for k in range(36) if k not in used]
-            orders.append(order)
-            cand_vpids.append([c["viewpointId"] for c in ob["candidate"]])
-            view_lens[i] = len(order)
+            key = (ob.get("row", (ob["scan"], ob["viewpoint"])), ob["viewIndex"])
+            ent = self._pano_cache.get(key)
+            if ent is None:
+                cpts = [c["pointId"] for c in ob["candidate"]]
+                used = set(cpts)
+                order = np.array(cpts + [k for k in range(36) if k not in used], np.int32)
+                nc, n = len(cpts), len(order)
+                lf = np.ones((n, 7), np.float32)
+                if nc:
+                    ch = np.array([c["heading"] for c in ob["candidate"]], np.float64)
+                    ce = np.array([c["elevation"] for c in ob["candidate"]], np.float64)
+                    lf[:nc, :4] = np.stack([np.sin(ch), np.cos(ch), np.sin(ce), np.cos(ce)], 1).astype(np.float32)
+                lf[nc:, :4] = self.angle_table[ob["viewIndex"]][order[nc:]]
+                ent = self._pano_cache[key] = (order, nc, lf, [c["viewpointId"] for c in ob["candidate"]])
+            per.append(ent)
+            cand_vpids.append(ent[3])
+            view_lens[i] = len(ent[0])
         V = int(view_lens.max())
-        view_order = np.zeros((B, V), np.int32)
+        view_order = np.full((B, V), -1, np.int32)            # -1: padded slot, the gather writes zeros (pad_tensors, agent.py:155)
         nav_types = np.zeros((B, V), np.int64)
         loc = np.zeros((B, V, 7), np.float32)
-        for i, ob in enumerate(obs):
-            n, nc = int(view_lens[i]), len(cand_vpids[i])
-            view_order[i, :n] = orders[i]
+        for i, (order, nc, lf, _) in enumerate(per):
+            n = len(order)
+            view_order[i, :n] = order
             nav_types[i, :nc] = 1
-            if nc:
-                ch = np.array([c["heading"] for c in ob["candidate"]], np.float64)
-                ce = np.array([c["elevation"] for c in ob["candidate"]], np.float64)
-                loc[i, :nc, :4] = np.stack([np.sin(ch), np.cos(ch), np.sin(ce), np.cos(ce)], 1).astype(np.float32)
-            loc[i, nc:n, :4] = self.angle_table[ob["viewIndex"]][orders[i][nc:]]
-            loc[i, :n, 4:] = 1.0
+            loc[i, :n] = lf
         vp_rows = np.array([ob["row"] for ob in obs], np.int32)
         # -- log layout of this step: B*V view rows, B fused rows, B [cls] rows
         base = self.log_rows
@@ -248,13 +277,19 @@ class NavPlanner:
             elif ob["viewpoint"] != ob["gt_path"][-1]:
                 scan, cur = ob["scan"], ob["viewpoint"]
                 best, best_d = IGNORE, float("inf")
+                dist, gt = env.shortest_distances[scan], ob["gt_path"]
+                if self.expert == "ndtw":
+                    walked = sum(self.traj[i]["path"], [])
+                    n0, row = self._dtw.get(i, (0, [0.0] + [math.inf] * len(gt)))
+                    row = dtw_rows(dist, row, walked[n0:], gt)
+                    self._dtw[i] = (len(walked), row)
                 for j, v in enumerate(vpids[i]):
                     if j > 1 and not visited[i, j]:
                         if self.expert == "ndtw":
-                            d = -ndtw(env.shortest_distances[scan], sum(self.traj[i]["path"], []) + env.shortest_paths[scan][cur][v][1:],
-                                      ob["gt_path"])
+                            tail = dtw_rows(dist, row, env.shortest_paths[scan][cur][v][1:], gt)
+                            d = -math.exp(-tail[-1] / (3.0 * len(gt)))
                         else:
-                            d = env.shortest_distances[scan][v][ob["gt_path"][-1]] + env.shortest_distances[scan][cur][v]
+                            d = dist[v][gt[-1]] + dist[cur][v]
                         if d < best_d:
                             best, best_d = j, d
                 a[i] = best

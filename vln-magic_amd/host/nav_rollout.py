@@ -96,12 +96,13 @@ class EmbeddingLog:
 
 
 class NavRollout:
-    def __init__(self, student, feature_table, teacher=None, kd=None, max_action_len=15, expert_policy="spl"):
+    def __init__(self, student, feature_table, teacher=None, kd=None, max_action_len=15, expert_policy="spl", cache_text_kv=True):
         """feature_table: [n_viewpoints, 36, D] device tensor in the student's compute dtype (packed once, SURVEY f-2).
         kd: dict(alpha, temperature, decay) -- MAKD hyper-parameters (run_r2r_kdl_valid.sh:97-104)."""
         self.student, self.teacher, self.kd = student, teacher, kd
         self.table = feature_table
         self.T, self.expert = max_action_len, expert_policy
+        self.cache_text_kv = cache_text_kv
         self.dev = feature_table.device
         if teacher is not None:
             self.heads = {n: getattr(student.vln_bert, n) for n in ("txt_emb_w", "kdl_img_w", "kdl_avg_img_w", "global_cross_w", "local_cross_w")}
@@ -112,10 +113,10 @@ class NavRollout:
         O.view_gather(self.table, d["vp_rows"], d["view_order"], fts)
         return dict(view_img_fts=fts, loc_fts=d["loc_fts"], nav_types=d["nav_types"], view_lens=d["view_lens"], already_dropout=True)
 
-    def _nav_inputs(self, d, plan, gathered, txt_embeds, txt_masks, txt_lens):
+    def _nav_inputs(self, d, plan, gathered, txt_embeds, txt_masks, txt_lens, txt_kv=None):
         B, K, Vp, H = plan["B"], plan["K"], plan["Vp"], gathered.shape[1]
         return dict(gmap_img_embeds=gathered[:B * K].view(B, K, H), vp_img_embeds=gathered[B * K:].view(B, Vp, H),
-                    txt_embeds=txt_embeds, txt_masks=txt_masks, gmap_masks=d["gmap_masks"].bool(), vp_masks=d["vp_masks"].bool(),
+                    txt_embeds=txt_embeds, txt_kv=txt_kv, txt_masks=txt_masks, gmap_masks=d["gmap_masks"].bool(), vp_masks=d["vp_masks"].bool(),
                     gmap_step_ids=d["gmap_step_ids"], gmap_pos_fts=d["gmap_pos_fts"], gmap_pair_dists=d["gmap_pair_dists"],
                     gmap_visited_masks=d["gmap_visited_masks"].bool(), gmap_vpids=plan["gmap_vpids"], vp_pos_fts=d["vp_pos_fts"],
                     vp_nav_masks=d["vp_nav_masks"].bool(), vp_cand_vpids=plan["vp_cand_vpids"],
@@ -136,11 +137,13 @@ class NavRollout:
         ctxg = torch.enable_grad() if grad else torch.no_grad()
         with ctxg:
             txt_embeds, txt_attns = st("language", lin)
+            txt_kv = st.text_kv(txt_embeds) if self.cache_text_kv else None      # once per episode, not once per step
         s_out = dict(txt_embeds=txt_embeds, txt_attns=txt_attns)
         t_out = {}
         if te is not None:
             with torch.no_grad():
                 t_txt, t_txt_attns = te("language", lin)
+                t_kv = te.text_kv(t_txt) if self.cache_text_kv else None
             t_out = dict(txt_embeds=t_txt, txt_attns=t_txt_attns)
             t_log = EmbeddingLog(te.net.H, te.net.dtype, dev)
         s_log = EmbeddingLog(st.net.H, st.net.dtype, dev)
@@ -167,7 +170,7 @@ class NavRollout:
                 s_log.put(plan["log_base"], pe)
                 s_log.put(plan["log_fused"], pf)
                 gathered = s_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=grad)
-                nav = self._nav_inputs(d, plan, gathered, txt_embeds, txt_masks, txt_lens)
+                nav = self._nav_inputs(d, plan, gathered, txt_embeds, txt_masks, txt_lens, txt_kv)
                 outs = st("navigation", nav)
                 s_log.put(plan["log_cls"], outs["cls_embeds"])
                 logits = outs["fused_logits"]
@@ -183,7 +186,7 @@ class NavRollout:
                         t_log.put(plan["log_base"], tpe, track=False)
                         t_log.put(plan["log_fused"], tpf, track=False)
                         tg = t_log.gather(csr, None, plan["n_out"], plan["log_cls"], grad=False)
-                        t_outs = te("navigation", self._nav_inputs(d, plan, tg, t_txt, txt_masks, txt_lens))
+                        t_outs = te("navigation", self._nav_inputs(d, plan, tg, t_txt, txt_masks, txt_lens, t_kv))
                         t_log.put(plan["log_cls"], t_outs["cls_embeds"], track=False)
                         t_out.update(nav_outs=t_outs, nav_logits=t_outs["fused_logits"])
                         t_ce = F.cross_entropy(t_outs["fused_logits"], targets, ignore_index=IGNORE, reduction="none")

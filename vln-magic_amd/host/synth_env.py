@@ -73,6 +73,10 @@ class Scan:
             sd = np.where(better, via, sd)
             nxt = np.where(better, nxt[:, k][:, None], nxt)
         self.sdist, self.nxt = sd, nxt
+        self.hops = np.zeros((n_nodes, n_nodes), np.int64)          # hop count along the shortest-distance path
+        for a in range(n_nodes):
+            for b in range(n_nodes):
+                self.hops[a, b] = len(self.path(a, b)) - 1
         # candidates of every viewpoint: neighbour -> (absolute heading, elevation, nearest view)
         self.cands = []
         for a in range(n_nodes):
@@ -99,21 +103,13 @@ class Scan:
         return out
 
 
-class _Dist:
-    """env.shortest_distances[scan][a][b] / shortest_paths[scan][a][b] views over the dense tables"""
-
-    def __init__(self, scan, paths):
-        self.scan, self.paths = scan, paths
-
-    def __getitem__(self, a):
-        s, paths = self.scan, self.paths
-        ia = s.idx[a]
-
-        class Row:
-            def __getitem__(_, b):
-                ib = s.idx[b]
-                return [s.vps[i] for i in s.path(ia, ib)] if paths else float(s.sdist[ia, ib])
-        return Row()
+def _tables(sc):
+    """env.shortest_distances[scan][a][b] / env.shortest_paths[scan][a][b] as the reference keeps them: dicts of dicts
+    (r2r/env.py:115-119, networkx all-pairs results)"""
+    n = len(sc.vps)
+    dist = {sc.vps[a]: {sc.vps[b]: float(sc.sdist[a, b]) for b in range(n)} for a in range(n)}
+    paths = {sc.vps[a]: {sc.vps[b]: [sc.vps[i] for i in sc.path(a, b)] for b in range(n)} for a in range(n)}
+    return dist, paths
 
 
 class SynthNavEnv:
@@ -133,8 +129,9 @@ class SynthNavEnv:
                 rows += 1
         self.feature_table = self.rng.standard_normal((rows, 36, feat_dim), dtype=np.float32)
         self.angle_table = view_angle_table()
-        self.shortest_distances = {n: _Dist(sc, False) for n, sc in self.scans.items()}
-        self.shortest_paths = {n: _Dist(sc, True) for n, sc in self.scans.items()}
+        self.shortest_distances, self.shortest_paths = {}, {}
+        for n, sc in self.scans.items():
+            self.shortest_distances[n], self.shortest_paths[n] = _tables(sc)
         self.batch, self.state = None, None
         self._n_ep = 0
 
@@ -146,9 +143,9 @@ class SynthNavEnv:
             sc = self.scans[names[int(rng.integers(len(names)))]]
             a = int(rng.integers(len(sc.vps)))
             hops = int(rng.integers(self.path_hops[0], self.path_hops[1] + 1))
-            ends = [b for b in range(len(sc.vps)) if len(sc.path(a, b)) - 1 == hops]
-            if ends:
-                b = ends[int(rng.integers(len(ends)))]
+            ends = np.nonzero(sc.hops[a] == hops)[0]
+            if len(ends):
+                b = int(ends[int(rng.integers(len(ends)))])
                 break
         n = int(rng.integers(self.instr_len[0], self.instr_len[1] + 1))
         ids = [0] + [int(x) for x in rng.integers(self.vocab[0], self.vocab[1] + 1, n - 2)] + [2]

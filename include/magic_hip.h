@@ -38,6 +38,9 @@ int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,
                const float* bias, int epilogue, const void* aux, int ldaux,
                const void* residual, int ldr, void* C2, int ldc2,
                float alpha, int splitk, float* bias_grad, void* stream);
+/* Block-tile selection of magic_gemm's single launches: 0 = 64x64 always (default), 1 = 128x128 when the problem has enough
+ * such tiles and a long K loop, 2 = 128x128 whenever M, N >= 128.  Process-wide tuning knob (also MAGIC_GEMM_BIG). */
+int magic_gemm_set_big(int mode);
 
 /* Grouped weight-gradient GEMM: n <= 8 independent problems dW[N,K] (fp32, ldc) += dY[M,N]^T (lda) @ X[M,K] (ldb), db[N] += colsum(dY)
  * in ONE launch (split-K, fp32 atomics).  `d` is a HOST array of n descriptors holding device pointers. */

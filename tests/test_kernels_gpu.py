@@ -114,6 +114,47 @@ def test_gemm_batched_attention_shapes(dtype):
     check(dqkv[:, 2 * H:], ref, "dV", **tol(dtype))
 
 
+# 128x128-tile path (csrc/gemm.hip gemm_big_kernel; off by default -- measured slower -- and switched on here)
+@pytest.fixture
+def big_tiles():
+    from magic_amd.host import lib as L
+    L.call("magic_gemm_set_big", 2)
+    yield
+    L.call("magic_gemm_set_big", 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_big_tile_all_layouts_and_epilogues(dtype, big_tiles):
+    M, N, K = 1301, 1208, 328                     # 11 x 10 tiles, ragged edges in every dimension, K not a tile multiple
+    x, W = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, scale=0.1)
+    b, res = rnd(N, scale=0.5), rnd(M, N, dtype=dtype)
+    ref = x.float() @ W.float().t() + b
+    t = tol(dtype) if dtype == torch.float32 else dict(rtol=2e-2, atol=6e-2)
+    check(O.linear_fwd(x, W, b, M), ref, "big nt+bias", **t)
+    pre = torch.empty(M, N, dtype=dtype, device=DEV)
+    out = O.linear_fwd(x, W, b, M, epilogue=1, residual=res, pre=pre)
+    check(pre, ref, "big pre-activation", **t)
+    check(out, F.gelu(ref) + res.float(), "big gelu+residual", **t)
+    # NN: dx[M,K2] = dy[M,N] @ W2[N,K2] with dgelu and residual
+    K2 = 1160
+    dy, W2 = rnd(M, N, dtype=dtype, scale=0.3), rnd(N, K2, dtype=dtype, scale=0.1)
+    z, r = rnd(M, K2, dtype=dtype), rnd(M, K2, dtype=dtype)
+    refx = dy.float() @ W2.float()
+    tn = tol(dtype) if dtype == torch.float32 else dict(rtol=2e-2, atol=1.5e-1)
+    check(O.linear_dx(dy, W2, M), refx, "big nn", **tn)
+    zz = z.float().requires_grad_(True)
+    F.gelu(zz).backward(torch.ones_like(zz))
+    check(O.linear_dx(dy, W2, M, epilogue=3, aux=z, residual=r), refx * zz.grad + r.float(), "big nn+dgelu+res", **tn)
+    # TN: dW[N,K2] += dy^T x2, bias grad, accumulate twice (split-K chosen by the host heuristic)
+    x2 = rnd(M, K2, dtype=dtype)
+    dW, db = torch.zeros(N, K2, device=DEV), torch.zeros(N, device=DEV)
+    O.linear_dw(dy, x2, dW, db, M)
+    O.linear_dw(dy, x2, dW, db, M)
+    tw = dict(rtol=1e-4, atol=2e-3) if dtype == torch.float32 else dict(rtol=2e-2, atol=5e-2 * math.sqrt(M / 64))
+    check(dW, 2 * dy.float().t() @ x2.float(), "big dW", **tw)
+    check(db, 2 * dy.float().sum(0), "big db", **tw)
+
+
 # ------------------------------------------------------------------------------------ LayerNorm family
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("H", [128, 256])

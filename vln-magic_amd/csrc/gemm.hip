@@ -23,6 +23,7 @@ struct GemmParams {
   int nh, splitk, epilogue, c_f32, accumulate;
   float alpha;
   int batch;      // host-side only (grid z = batch * splitk)
+  int big;        // host-side only: 128x128 block tile (single launches; grouped / paired launches use 64x64)
 };
 
 template <typename T> struct TT;
@@ -37,14 +38,17 @@ template <> struct TT<float> {
   typedef f32x4 vec;
 };
 
-template <typename T, bool KC> struct TileLoader {
+// TM = out rows of the tile (64, or 128 for the big-tile kernels); the natural [k][out] image of an out-contiguous operand
+// then has rows of TM + (SN - 64) elements
+template <typename T, bool KC, int TM = 64> struct TileLoader {
   typedef typename TT<T>::vec vec;
-  static constexpr int VE = TT<T>::VE, BK = TT<T>::BK, STRIDE = TT<T>::STRIDE, SN = TT<T>::SN;
-  vec v[2];
-  // tile = 64 out rows x BK k's.  KC: source is [OUT][K] (k contiguous); else [K][OUT].
+  static constexpr int VE = TT<T>::VE, BK = TT<T>::BK, STRIDE = TT<T>::STRIDE, SN = TT<T>::SN + (TM - 64);
+  static constexpr int NV = TM / 32;
+  vec v[NV];
+  // tile = TM out rows x BK k's.  KC: source is [OUT][K] (k contiguous); else [K][OUT].
   __device__ __forceinline__ void load(const T* __restrict__ base, int ld, int out0, int k0, int OUT, int kend) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NV; ++i) {
       int id = threadIdx.x + 256 * i;
       vec z;
 #pragma unroll
@@ -54,7 +58,7 @@ template <typename T, bool KC> struct TileLoader {
         int o = out0 + row, k = k0 + cv * VE;
         if (o < OUT && k < kend) z = *(const vec*)(base + (long long)o * ld + k);
       } else {
-        constexpr int VPR = 64 / VE;
+        constexpr int VPR = TM / VE;
         int r = id / VPR, ov = id % VPR;
         int k = k0 + r, o = out0 + ov * VE;
         if (k < kend && o < OUT) z = *(const vec*)(base + (long long)k * ld + o);
@@ -64,7 +68,7 @@ template <typename T, bool KC> struct TileLoader {
   }
   __device__ __forceinline__ void store(T* s) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NV; ++i) {
       int id = threadIdx.x + 256 * i;
       if (KC) {
         int row = id >> 3, cv = id & 7;
@@ -76,7 +80,7 @@ template <typename T, bool KC> struct TileLoader {
           ((float2*)d)[1] = make_float2(v[i][2], v[i][3]);
         }
       } else {
-        constexpr int VPR = 64 / VE;
+        constexpr int VPR = TM / VE;
         int r = id / VPR, ov = id % VPR;
         *(vec*)(s + r * SN + ov * VE) = v[i];          // natural [k][out] image, 16-byte store
       }
@@ -88,7 +92,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
 // one MFMA operand fragment of the 16 out-rows starting at out0, k-step ks.  Lane map (A and B alike):
 // lane l holds X[out0 + (l&15)][k = kbase + 8*(l>>4) + j] (bf16, j<8) / X[out0 + (l&15)][k = kbase + (l>>4)] (f32).
-template <bool KC>
+template <bool KC, int SN_ = TT<bf16>::SN>
 __device__ __forceinline__ bf16x8 frag(const bf16* s, int out0, int ks, int lane) {
   if constexpr (KC) {
     return *(const bf16x8*)(s + (out0 + (lane & 15)) * TT<bf16>::STRIDE + ks * 32 + 8 * (lane >> 4));
@@ -96,63 +100,72 @@ __device__ __forceinline__ bf16x8 frag(const bf16* s, int out0, int ks, int lane
     // natural [k][out] image: each 16-lane group g transposes rows k = 8g..8g+3 (+4) x 16 outs with ds_read_b64_tr_b16;
     // lane 4q+p of the group addresses row q, outs 4p..4p+3 and receives out (l&15) of the 4 rows
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const bf16* b = s + (ks * 32 + 8 * g + q) * TT<bf16>::SN + out0 + 4 * pp;
+    const bf16* b = s + (ks * 32 + 8 * g + q) * SN_ + out0 + 4 * pp;
     typedef bf16x4_t __attribute__((address_space(3))) * lds4;
     const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
-    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * TT<bf16>::SN));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * SN_));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   }
 }
-template <bool KC>
+template <bool KC, int SN_ = TT<float>::SN>
 __device__ __forceinline__ float frag(const float* s, int out0, int ks, int lane) {
   if constexpr (KC) return s[(out0 + (lane & 15)) * TT<float>::STRIDE + ks * 4 + (lane >> 4)];
-  else return s[(ks * 4 + (lane >> 4)) * TT<float>::SN + out0 + (lane & 15)];
+  else return s[(ks * 4 + (lane >> 4)) * SN_ + out0 + (lane & 15)];
 }
 
-template <bool A_KC, bool B_KC>
-__device__ __forceinline__ void mma_tile(const bf16* sA, const bf16* sB, int wr, int wc, int lane, f32x4 (&acc)[2][2]) {
+// NT_ x NT_ MFMA tiles of 16x16 per wave (2: 64x64 block tile, 4: 128x128)
+template <bool A_KC, bool B_KC, int NT_>
+__device__ __forceinline__ void mma_tile(const bf16* sA, const bf16* sB, int wr, int wc, int lane, f32x4 (&acc)[NT_][NT_]) {
+  constexpr int SN_ = TT<bf16>::SN + (32 * NT_ - 64);
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 a[2], b[2];
+    bf16x8 a[NT_], b[NT_];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      a[i] = frag<A_KC>(sA, wr * 32 + i * 16, ks, lane);
-      b[i] = frag<B_KC>(sB, wc * 32 + i * 16, ks, lane);
+    for (int i = 0; i < NT_; ++i) {
+      a[i] = frag<A_KC, SN_>(sA, (wr * NT_ + i) * 16, ks, lane);
+      b[i] = frag<B_KC, SN_>(sB, (wc * NT_ + i) * 16, ks, lane);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT_; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NT_; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 }
 
-template <bool A_KC, bool B_KC>
-__device__ __forceinline__ void mma_tile(const float* sA, const float* sB, int wr, int wc, int lane, f32x4 (&acc)[2][2]) {
+template <bool A_KC, bool B_KC, int NT_>
+__device__ __forceinline__ void mma_tile(const float* sA, const float* sB, int wr, int wc, int lane, f32x4 (&acc)[NT_][NT_]) {
+  constexpr int SN_ = TT<float>::SN + (32 * NT_ - 64);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
-    float a[2], b[2];
+    float a[NT_], b[NT_];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      a[i] = frag<A_KC>(sA, wr * 32 + i * 16, ks, lane);
-      b[i] = frag<B_KC>(sB, wc * 32 + i * 16, ks, lane);
+    for (int i = 0; i < NT_; ++i) {
+      a[i] = frag<A_KC, SN_>(sA, (wr * NT_ + i) * 16, ks, lane);
+      b[i] = frag<B_KC, SN_>(sB, (wc * NT_ + i) * 16, ks, lane);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT_; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NT_; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 }
 
 // LAYOUT 0: NT (A[M,K], B[N,K]); 1: NN (A[M,K], B[K,N]); 2: TN (A[K,M], B[K,N])
-template <typename T, int LAYOUT>
+// NT_: 16x16 MFMA tiles per wave per dimension.  2 -> the 64x64 block tile every small problem uses; 4 -> a 128x128 block tile
+// (64x64 per wave, 16 accumulator tiles) for problems with enough rows and columns: each workgroup then streams half the
+// operand bytes per output element from L2 and issues half the LDS reads per MFMA, which is what bounds the H >= 256 shapes.
+template <typename T, int LAYOUT, int NT_ = 2>
 __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, const int by, const int bzz, T* sA, T* sB) {
   constexpr int BK = TT<T>::BK, STRIDE = TT<T>::STRIDE;
-  static_assert(BM * TT<T>::STRIDE >= TT<T>::BK * TT<T>::SN, "LDS image sizes");
+  constexpr int TM = 32 * NT_;                       // block tile is TM x TM
+  constexpr int SN_ = TT<T>::SN + (TM - 64);
+  static_assert(TM * TT<T>::STRIDE >= TT<T>::BK * SN_, "LDS image sizes");
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
+  constexpr int NE = NT_ * NT_ * 4;                  // accumulator elements per lane
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
-  const int n0 = bx * BN, m0 = by * BM;
+  const int n0 = bx * TM, m0 = by * TM;
   const int bz = bzz / p.splitk, sk = bzz % p.splitk;
   const int bb = bz / p.nh, bh = bz % p.nh;
 
@@ -169,14 +182,14 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
   // Register-staged software pipeline, PD tiles deep: the global loads of tiles kt+1 .. kt+PD-1 are in flight while
   // tile kt is written to LDS and multiplied.  These GEMMs run ~1 block per CU (grids of 100-600 blocks), so a
   // block has to hide HBM/L2 latency itself; hipcc turns the in-order loads into counted s_waitcnt vmcnt(N).
-  constexpr int PD = 3;
-  TileLoader<T, A_KC> la[PD];
-  TileLoader<T, B_KC> lb[PD];
-  f32x4 acc[2][2];
+  constexpr int PD = (NT_ == 2) ? 3 : 2;
+  TileLoader<T, A_KC, TM> la[PD];
+  TileLoader<T, B_KC, TM> lb[PD];
+  f32x4 acc[NT_][NT_];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NT_; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT_; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   const bool do_bgrad = (LAYOUT == 2) && p.bias_grad != nullptr && bx == 0;
 
@@ -186,57 +199,52 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
       la[d].load(A, p.lda, m0, (kt0 + d) * BK, p.M, p.K);
       lb[d].load(B, p.ldb, n0, (kt0 + d) * BK, p.N, p.K);
     }
-  // Epilogue operands (bias / activation-derivative input / residual) are fetched HERE, before the K loop: these GEMMs are
-  // 1-3 k-tiles long, so a second dependent round trip to memory after the loop was a visible share of each launch.
+  // element e of a lane: tile (i, j) = (e / (4 NT_), (e / 4) % NT_), register r = e % 4.
   // C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
-  // Structured as {all loads} -> {math} -> {all stores}: gfx950's vmcnt counts stores too, so interleaving
-  // per-element loads and stores serialises 16 memory round trips per thread (measured: +4 us per launch).
   const int cr = (lane >> 4) * 4, cc = lane & 15;
-  float ax[16], rs[16];
-  bool ok[16];
-  float bv[2] = {0.f, 0.f};
+  auto col_of = [&](int e) { return n0 + (wc * NT_ + ((e >> 2) % NT_)) * 16 + cc; };
+  auto row_of = [&](int e) { return m0 + (wr * NT_ + (e / (4 * NT_))) * 16 + cr + (e & 3); };
+  // Epilogue operands (bias / activation-derivative input / residual).  64x64 tile: fetched HERE, before the K loop -- these
+  // GEMMs are 1-3 k-tiles long, so a second dependent round trip to memory after the loop was a visible share of each launch.
+  // 128x128 tile (long K loops, 64 elements per lane): fetched after the loop.
+  // Structured as {all loads} -> {math} -> {all stores}: gfx950's vmcnt counts stores too, so interleaving
+  // per-element loads and stores serialises the memory round trips of a thread (measured: +4 us per launch).
+  constexpr bool PRE = (NT_ == 2);
+  float ax[NE], rs[NE];
+  float bv[NT_];
   const bool has_aux = (p.epilogue == 3 || p.epilogue == 4);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wc * 32 + j * 16 + cc;
-    if (p.bias && sk == 0 && col < p.N) bv[j] = p.bias[col];
+  for (int j = 0; j < NT_; ++j) {
+    const int col = n0 + (wc * NT_ + j) * 16 + cc;
+    bv[j] = (p.bias && sk == 0 && col < p.N) ? p.bias[col] : 0.f;
   }
+  auto load_epi = [&]() {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int e = 0; e < NE; ++e) { ax[e] = 0.f; rs[e] = 0.f; }
+    if (has_aux) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int e = (i * 2 + j) * 4 + r;
-        const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
-        ok[e] = (col < p.N) && (row < p.M);
-        ax[e] = 0.f; rs[e] = 0.f;
-      }
-  if (has_aux) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
-      const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
-      if (ok[e]) ax[e] = to_f(((const T*)p.aux)[coff + (long long)row * p.ldaux + col]);
-    }
-  }
-  if (p.residual) {
-    if (p.c_f32) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
-        const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
-        if (ok[e]) rs[e] = ((const float*)p.residual)[coff + (long long)row * p.ldr + col];
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
-        const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
-        if (ok[e]) rs[e] = to_f(((const T*)p.residual)[coff + (long long)row * p.ldr + col]);
+      for (int e = 0; e < NE; ++e) {
+        const int col = col_of(e), row = row_of(e);
+        if (col < p.N && row < p.M) ax[e] = to_f(((const T*)p.aux)[coff + (long long)row * p.ldaux + col]);
       }
     }
-  }
+    if (p.residual) {
+      if (p.c_f32) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int col = col_of(e), row = row_of(e);
+          if (col < p.N && row < p.M) rs[e] = ((const float*)p.residual)[coff + (long long)row * p.ldr + col];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int col = col_of(e), row = row_of(e);
+          if (col < p.N && row < p.M) rs[e] = to_f(((const T*)p.residual)[coff + (long long)row * p.ldr + col]);
+        }
+      }
+    }
+  };
+  if constexpr (PRE) load_epi();
   for (int kt = kt0; kt < kt1; kt += PD) {
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
@@ -248,71 +256,65 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
           la[d].load(A, p.lda, m0, (kt + d + PD) * BK, p.M, p.K);
           lb[d].load(B, p.ldb, n0, (kt + d + PD) * BK, p.N, p.K);
         }
-        mma_tile<A_KC, B_KC>(sA, sB, wr, wc, lane, acc);
-        if (do_bgrad && tid < BM) {
+        mma_tile<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc);
+        if (do_bgrad && tid < TM) {
           float s = 0.f;
 #pragma unroll 8
-          for (int k = 0; k < BK; ++k) s += to_f(sA[k * TT<T>::SN + tid]);      // TN: A is held as the natural [k][out] image
+          for (int k = 0; k < BK; ++k) s += to_f(sA[k * SN_ + tid]);      // TN: A is held as the natural [k][out] image
           bsum += s;
         }
         __syncthreads();
       }
     }
   }
-  if (do_bgrad && tid < BM && m0 + tid < p.M) atomicAdd(p.bias_grad + m0 + tid, bsum);
+  if (do_bgrad && tid < TM && m0 + tid < p.M) atomicAdd(p.bias_grad + m0 + tid, bsum);
+  if constexpr (!PRE) load_epi();
 
-  // epilogue math + stores (operands were prefetched before the K loop)
-  float v[16];
+  // epilogue math + stores
+  float v[NE];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
-    v[e] = acc[i][j][r] * p.alpha + bv[j];
-  }
+  for (int e = 0; e < NE; ++e) v[e] = acc[e / (4 * NT_)][(e >> 2) % NT_][e & 3] * p.alpha + bv[(e >> 2) % NT_];
   if (p.C2) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
-      const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
-      if (ok[e]) ((T*)p.C2)[coff + (long long)row * p.ldc2 + col] = from_f<T>(v[e]);
+    for (int e = 0; e < NE; ++e) {
+      const int col = col_of(e), row = row_of(e);
+      if (col < p.N && row < p.M) ((T*)p.C2)[coff + (long long)row * p.ldc2 + col] = from_f<T>(v[e]);
     }
   }
   if (p.epilogue == 1) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
+    for (int e = 0; e < NE; ++e) v[e] = gelu_f(v[e]);
   } else if (p.epilogue == 2) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+    for (int e = 0; e < NE; ++e) v[e] = fmaxf(v[e], 0.f);
   } else if (p.epilogue == 3) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] *= dgelu_f(ax[e]);
+    for (int e = 0; e < NE; ++e) v[e] *= dgelu_f(ax[e]);
   } else if (p.epilogue == 4) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = ax[e] > 0.f ? v[e] : 0.f;
+    for (int e = 0; e < NE; ++e) v[e] = ax[e] > 0.f ? v[e] : 0.f;
   }
 #pragma unroll
-  for (int e = 0; e < 16; ++e) v[e] += rs[e];
+  for (int e = 0; e < NE; ++e) v[e] += rs[e];
   if (p.c_f32) {
     if (p.accumulate) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
-        const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
-        if (ok[e]) atomicAdd((float*)p.C + coff + (long long)row * p.ldc + col, v[e]);
+      for (int e = 0; e < NE; ++e) {
+        const int col = col_of(e), row = row_of(e);
+        if (col < p.N && row < p.M) atomicAdd((float*)p.C + coff + (long long)row * p.ldc + col, v[e]);
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
-        const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
-        if (ok[e]) ((float*)p.C)[coff + (long long)row * p.ldc + col] = v[e];
+      for (int e = 0; e < NE; ++e) {
+        const int col = col_of(e), row = row_of(e);
+        if (col < p.N && row < p.M) ((float*)p.C)[coff + (long long)row * p.ldc + col] = v[e];
       }
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int i = e >> 3, j = (e >> 2) & 1, r = e & 3;
-      const int col = n0 + wc * 32 + j * 16 + cc, row = m0 + wr * 32 + i * 16 + cr + r;
-      if (ok[e]) ((T*)p.C)[coff + (long long)row * p.ldc + col] = from_f<T>(v[e]);
+    for (int e = 0; e < NE; ++e) {
+      const int col = col_of(e), row = row_of(e);
+      if (col < p.N && row < p.M) ((T*)p.C)[coff + (long long)row * p.ldc + col] = from_f<T>(v[e]);
     }
   }
 }
@@ -340,6 +342,27 @@ __global__ __launch_bounds__(256) void gemm_xcd_kernel(GemmParams p, int nx, int
   const int by = lr * 8 + xcd;
   if (by >= ny) return;
   gemm_block<T, LAYOUT>(p, bx, by, z, sA, sB);
+}
+
+// 128x128-tile variant of gemm_xcd_kernel (same XCD-aware 1-D tile map, nx / ny counted in 128-wide tiles)
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_big_kernel(GemmParams p, int nx, int ny, int ny8) {
+  __shared__ __attribute__((aligned(16))) T sA[128 * TT<T>::STRIDE];
+  __shared__ __attribute__((aligned(16))) T sB[128 * TT<T>::STRIDE];
+  const int per_z = nx * (ny8 > 0 ? ny8 : ny);
+  const int z = blockIdx.x / per_z, l2 = blockIdx.x - z * per_z;
+  int bx, by;
+  if (ny8 > 0) {                      // row tile r on XCD r % 8, its column tiles in consecutive slots of that XCD
+    const int xcd = l2 & 7, slot = l2 >> 3;
+    const int lr = slot / nx;
+    bx = slot - lr * nx;
+    by = lr * 8 + xcd;
+    if (by >= ny) return;
+  } else {                            // few row tiles: plain row-major tile order
+    by = l2 / nx;
+    bx = l2 - by * nx;
+  }
+  gemm_block<T, LAYOUT, 4>(p, bx, by, z, sA, sB);
 }
 
 // Grouped weight-gradient GEMM: up to GROUP_MAX independent TN problems (dW[N,K] += dY^T X, split-K, fp32 atomics, fused
@@ -385,6 +408,28 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupedParams gp) {
   }
 }
 
+// 128x128 tile selection.  Measured on MI355X (profiles/micro/gemm_tile_sweep.py, profiles/micro/r01_gemm_tile_sweep.txt): as built
+// (register-staged, 2-deep, 256 VGPRs -> one workgroup per CU) the 128x128 tile is SLOWER than the 64x64 tile on every linear-layer
+// shape of MAGIC-S/M/L, so it is off by default (mode 0).  mode 1: heuristic (>= min_tiles tiles and K >= min_k); mode 2: whenever
+// M, N >= 128.  Set from the environment (MAGIC_GEMM_BIG) or magic_gemm_set_big() (tests, tuning).
+static int g_big_mode = -1, g_big_min_tiles = 96, g_big_min_k = 256;
+extern "C" int magic_gemm_set_big(int mode) {
+  if (mode < 0 || mode > 2) return MAGIC_ERR_ARG;
+  g_big_mode = mode;
+  return MAGIC_OK;
+}
+static int gemm_big_tile(int M, int N, int K, int nz) {
+  if (g_big_mode < 0) {
+    const char* e = getenv("MAGIC_GEMM_BIG"); g_big_mode = e ? atoi(e) : 0;
+    const char* t = getenv("MAGIC_GEMM_BIG_MIN_TILES"); if (t) g_big_min_tiles = atoi(t);
+    const char* k = getenv("MAGIC_GEMM_BIG_MIN_K"); if (k) g_big_min_k = atoi(k);
+  }
+  if (g_big_mode == 0 || M < 128 || N < 128) return 0;
+  if (g_big_mode == 2) return 1;
+  const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * nz;
+  return (tiles >= g_big_min_tiles && K >= g_big_min_k) ? 1 : 0;
+}
+
 extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,
                           const void* A, int lda, long long sAb, long long sAh,
                           const void* B, int ldb, long long sBb, long long sBh,
@@ -409,6 +454,7 @@ extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N
   p.sAb = sAb; p.sAh = sAh; p.sBb = sBb; p.sBh = sBh; p.sCb = sCb; p.sCh = sCh;
   p.nh = nh; p.splitk = splitk; p.epilogue = epilogue; p.c_f32 = c_f32; p.accumulate = accumulate; p.alpha = alpha;
   p.batch = batch;
+  p.big = gemm_big_tile(M, N, K, batch * splitk);
   if (group_record(KIND_GEMM, dtype, layout, &p, sizeof(p))) return MAGIC_OK;
   return launch_gemm(dtype, layout, &p, nullptr, (hipStream_t)stream);
 }
@@ -440,6 +486,19 @@ static inline int gemm_blocks(const GemmParams& p) { return ((p.N + BN - 1) / BN
 int launch_gemm(int dtype, int layout, const void* pa, const void* pb, hipStream_t st) {
   const GemmParams& a = *(const GemmParams*)pa;
   dim3 block(256);
+  if (!pb && a.big) {
+    const int nx = (a.N + 127) / 128, ny = (a.M + 127) / 128, nz = a.batch * a.splitk;
+    const int ny8 = (gemm_xcd_on() && nx >= 2 && ny >= 16) ? (ny + 7) / 8 * 8 : 0;
+    dim3 g1((unsigned)(nx * (ny8 > 0 ? ny8 : ny) * nz));
+#define LAUNCHB(TY, L) hipLaunchKernelGGL((gemm_big_kernel<TY, L>), g1, block, 0, st, a, nx, ny, ny8)
+    if (dtype == DT_BF16) {
+      if (layout == 0) LAUNCHB(bf16, 0); else if (layout == 1) LAUNCHB(bf16, 1); else LAUNCHB(bf16, 2);
+    } else {
+      if (layout == 0) LAUNCHB(float, 0); else if (layout == 1) LAUNCHB(float, 1); else LAUNCHB(float, 2);
+    }
+#undef LAUNCHB
+    return launch_status();
+  }
   if (!pb) {
     const int nx = (a.N + BN - 1) / BN, ny = (a.M + BM - 1) / BM, nz = a.batch * a.splitk;
     if (gemm_xcd_on() && nx >= 2 && ny >= 16) {         // enough row tiles that the padding to a multiple of 8 is small
@@ -968,7 +1027,7 @@ extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, v
     // TN: A = dY stored [Kred = M][Mout = N], B = X stored [Kred = M][Nout = K], C = dW [N, K]
     p.A = d[i].dY; p.B = d[i].X; p.C = d[i].dW; p.bias_grad = d[i].db;
     p.M = d[i].N; p.N = d[i].K; p.K = d[i].M; p.lda = d[i].lda; p.ldb = d[i].ldb; p.ldc = d[i].ldc;
-    p.nh = 1; p.batch = 1; p.splitk = d[i].splitk; p.epilogue = 0; p.c_f32 = 1; p.accumulate = 1; p.alpha = 1.f;
+    p.nh = 1; p.batch = 1; p.big = 0; p.splitk = d[i].splitk; p.epilogue = 0; p.c_f32 = 1; p.accumulate = 1; p.alpha = 1.f;
     total += group_place(gp, i, total);
   }
   for (int i = n; i <= GROUP_MAX; ++i) gp.start[i] = total;

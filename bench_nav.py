@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-host-loop", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "eval"],
+                    help="eval: greedy inference rollouts (feedback 'argmax', no grad, model.eval()) -- decisions/s and ms per step")
     a = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -95,14 +97,24 @@ def main():
     model = VLNBert(None, role="student", config=cfg, device=dev, compute_dtype=dtype, seed=0)
     if world > 1:
         dist.broadcast(model.store.flat, src=0)
-    model.train()
+    model.train() if a.mode == "train" else model.eval()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5)              # agent_base.py:128-129
     env = make_env(a, 1234 + rank)
     table = torch.from_numpy(env.feature_table).to(dev).to(dtype)
     ro = NavRollout(model, table, max_action_len=a.max_action_len, expert_policy="ndtw")     # run_rxr_kdl_valid.sh:29
     rng = np.random.default_rng(rank)
 
+    def eval_iteration():
+        obs = env.reset(features=False)
+        with torch.no_grad():
+            r = ro.run(env, obs, feedback="argmax", train_ml=1.0, grad=False)
+        eval_iteration.steps += r["n_steps"]
+        return r["decisions"]
+    eval_iteration.steps = 0
+
     def iteration():
+        if a.mode == "eval":
+            return eval_iteration()
         opt.zero_grad()
         obs = env.reset(features=False)
         batch = env.batch
@@ -122,6 +134,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     dec = 0
+    eval_iteration.steps = 0
     for _ in range(a.steps):
         dec += iteration()
     torch.cuda.synchronize()
@@ -165,10 +178,10 @@ def main():
                            "top_kernels_share": {k: round(t / all_ms, 4) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]}}}
 
     host_loop = None
-    if rank == 0 and not a.no_host_loop:
+    if rank == 0 and not a.no_host_loop and a.mode == "train":
         host_loop = host_loop_rate(a, model, dev)
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "train":
         cpu = cpu_baseline(a, cfg)
     if rank == 0:
         print(json.dumps({
@@ -180,6 +193,7 @@ def main():
                                    f"paths {a.hops_min}..{a.hops_max} hops, max_action_len {a.max_action_len}",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "views": 36, "feat_dim": 768, "parallelism": f"dp{world}",
                        "decisions_per_iteration": round(dec / a.steps / world, 1)},
+            "mode": a.mode, "ms_per_rollout_step": (round(dt / max(eval_iteration.steps, 1) * 1e3, 3) if a.mode == "eval" else None),
             "roofline": roof, "cpu_baseline": cpu, "host_loop": host_loop}))
     if world > 1:
         dist.destroy_process_group()

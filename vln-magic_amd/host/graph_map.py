@@ -25,13 +25,13 @@ UNREACHED = 95959595     # speaker_utils.py:503 (its "infinite" distance; kept s
 
 def rel_pos(a, b, base_heading=0.0, base_elevation=0.0):
     """heading / elevation / distance of b seen from a (utils/data.py:157-174); a: (3,), b: (..., 3) float64"""
-    a = np.asarray(a, np.float64)
+    a = np.asarray(a, np.float64)                                # (3,) or (..., 3) matching b; base_* scalar or (...)
     b = np.asarray(b, np.float64)
     d = b - a
     xy = np.maximum(np.sqrt(d[..., 0] ** 2 + d[..., 1] ** 2), 1e-8)
     xyz = np.maximum(np.sqrt(d[..., 0] ** 2 + d[..., 1] ** 2 + d[..., 2] ** 2), 1e-8)
     heading = np.arcsin(d[..., 0] / xy)                          # the simulator's x/y axes are swapped
-    heading = np.where(b[..., 1] < a[1], np.pi - heading, heading) - base_heading
+    heading = np.where(b[..., 1] < a[..., 1], np.pi - heading, heading) - base_heading
     elevation = np.arcsin(d[..., 2] / xyz) - base_elevation
     return heading, elevation, xyz
 
@@ -70,6 +70,12 @@ class FloydGraph:
 
     def __len__(self):
         return len(self.names)
+
+    def dist_row(self, i):
+        """distances from dense id i to every known viewpoint (0 to itself)"""
+        r = self._d[i, :len(self.names)].copy()
+        r[i] = 0.0
+        return r
 
     def matrix(self):
         """distances between all known viewpoints, dense-id order (diagonal 0)"""
@@ -148,6 +154,7 @@ class GraphMap:
         self.start_vp = start_vp
         self.node_positions = {}            # insertion order = the order the agent lists map nodes in (agent.py:185)
         self.graph = FloydGraph()
+        self.pos_by_id = np.zeros((32, 3), np.float64)      # positions indexed by the graph's dense ids (planner gathers)
         self.node_embeds = {}
         self.teacher_node_embeds = {}
         self.node_stop_scores = {}
@@ -163,6 +170,15 @@ class GraphMap:
             self.graph.add_edge(ob["viewpoint"], cc["viewpointId"],
                                 math.sqrt((p[0] - q[0]) ** 2 + (p[1] - q[1]) ** 2 + (p[2] - q[2]) ** 2))
         self.graph.update(ob["viewpoint"])
+        n = len(self.graph)
+        if n > self.pos_by_id.shape[0]:
+            grown = np.zeros((max(2 * self.pos_by_id.shape[0], n), 3), np.float64)
+            grown[:self.pos_by_id.shape[0]] = self.pos_by_id
+            self.pos_by_id = grown
+        ix = self.graph.index
+        self.pos_by_id[ix[ob["viewpoint"]]] = p
+        for cc in ob["candidate"]:
+            self.pos_by_id[ix[cc["viewpointId"]]] = cc["position"]
 
     def update_node_embed(self, vp, embed, rewrite=False, teacher=False):
         """visited node: `rewrite=True` pins its embedding; unvisited node: running sum + count of every view of it"""

@@ -113,6 +113,13 @@ class NavPlanner:
     # ---- one step ----------------------------------------------------------------------------------------------
     def begin_step(self):
         """everything the three model calls of step t need, from the current observations"""
+        p = self.begin_pano()
+        p.update(self.begin_nav())
+        return p
+
+    def begin_pano(self):
+        """first half of a step's plan: the panorama inputs (cheap, cached per viewpoint) -- the rollout launches the panorama
+        encoder on them and builds the second half (`begin_nav`) while the GPU is busy"""
         t, B, obs, gmaps = self.t, self.B, self.obs, self.gmaps
         for i, g in enumerate(gmaps):
             if not self.ended[i]:
@@ -148,6 +155,14 @@ class NavPlanner:
             nav_types[i, :nc] = 1
             loc[i, :n] = lf
         vp_rows = np.array([ob["row"] for ob in obs], np.int32)
+        self._half = (V, cand_vpids, view_lens, nav_types)
+        return dict(t=t, B=B, V=V, vp_rows=vp_rows, view_order=view_order, loc_fts=loc, nav_types=nav_types, view_lens=view_lens,
+                    cand_vpids=cand_vpids)
+
+    def begin_nav(self):
+        """second half: map / local tokens, embedding sources, fusion map, expert action"""
+        t, B, obs, gmaps = self.t, self.B, self.obs, self.gmaps
+        V, cand_vpids, view_lens, nav_types = self._half
         # -- log layout of this step: B*V view rows, B fused rows, B [cls] rows
         base = self.log_rows
         self.log_base.append(base)
@@ -188,57 +203,58 @@ class NavPlanner:
         gmask[:, 1] = False                                            # [mem] can never be chosen (agent.py:233)
         vp_pos = np.zeros((B, Vp, 14), np.float32)
         coo_o, coo_s, coo_w = [], [], []
+        # positions: the targets of ALL samples (map nodes, start viewpoint, candidates) go through ONE vectorised
+        # relative-position / angle-feature evaluation; graph distances and hop counts are per-sample row gathers
+        tp, gd, hp, rep, segs = [], [], [], [], []
+        cur_pos, cur_head = np.zeros((B, 3)), np.zeros(B)
         for i, g in enumerate(gmaps):
             ids = vpid_lists[i]
             n, (nv, nu) = int(lens[i]), node_ids[i]
             visited[i, 1:2 + nv] = True
-            step_ids[i, 2:n] = [g.node_step_ids.get(vp, 0) for vp in ids[2:]]
-            gi = np.array([g.graph.index[vp] for vp in ids[2:]], np.int64)
+            sid, gix = g.node_step_ids, g.graph.index
+            step_ids[i, 2:n] = [sid.get(vp, 0) for vp in ids[2:]]
+            gi = [gix[vp] for vp in ids[2:]]
             cur = obs[i]["viewpoint"]
-            ci = g.graph.index[cur]
-            P = np.array([g.node_positions[vp] for vp in ids[2:]], np.float64)
-            h, e, d = rel_pos(g.node_positions[cur], P, base_heading=obs[i]["heading"], base_elevation=0)
-            dm = g.graph.matrix()
-            hops = g.graph.hops(ci)
-            pos[i, 2:n, :4] = angle_fts(h.astype(np.float32), e.astype(np.float32))
-            pos[i, 2:n, 4] = (d / MAX_DIST).astype(np.float32)
-            pos[i, 2:n, 5] = (dm[ci, gi] / MAX_DIST).astype(np.float32)
-            pos[i, 2:n, 6] = (hops[gi] / MAX_STEP).astype(np.float32)
-            pos[i, :2, 1] = pos[i, :2, 3] = 1.0                       # None tokens: angle (0, 0) -> cos = 1, distances 0
-            sub = dm[np.ix_(gi, gi)].astype(np.float32)
+            ci = gix[cur]
+            nc = len(cand_vpids[i])
+            idx_all = np.array(gi + [gix[g.start_vp]] + [gix[vp] for vp in cand_vpids[i]], np.int64)
+            tp.append(g.pos_by_id[idx_all])
+            gd.append(g.graph.dist_row(ci)[idx_all])
+            hp.append(g.graph.hops(ci)[idx_all])
+            rep.append(np.full(len(idx_all), i))
+            segs.append((n - 2, nc))
+            cur_pos[i], cur_head[i] = g.node_positions[cur], obs[i]["heading"]
+            gia = idx_all[:n - 2]
+            sub = g.graph._d[np.ix_(gia, gia)].astype(np.float32)
             np.fill_diagonal(sub, 0.0)
             pair[i, 2:n, 2:n] = sub
-            # local tokens (agent.py:290-328): [stop], [mem], views; position = (start-relative | candidate-relative)
-            nc = len(cand_vpids[i])
-            sh, se, sd = rel_pos(g.node_positions[cur], np.array([g.node_positions[g.start_vp]], np.float64),
-                                 base_heading=obs[i]["heading"], base_elevation=0)
-            si = g.graph.index[g.start_vp]
-            start = np.concatenate([angle_fts(sh.astype(np.float32), se.astype(np.float32))[0],
-                                    np.array([sd[0] / MAX_DIST, (0 if si == ci else dm[ci, si]) / MAX_DIST, hops[si] / MAX_STEP], np.float32)])
-            vp_pos[i, :, :7] = start
-            if nc:
-                cidx = np.array([g.graph.index[vp] for vp in cand_vpids[i]], np.int64)
-                CP = np.array([g.node_positions[vp] for vp in cand_vpids[i]], np.float64)
-                ch, ce, cd = rel_pos(g.node_positions[cur], CP, base_heading=obs[i]["heading"], base_elevation=0)
-                vp_pos[i, 2:2 + nc, 7:11] = angle_fts(ch.astype(np.float32), ce.astype(np.float32))
-                vp_pos[i, 2:2 + nc, 11] = (cd / MAX_DIST).astype(np.float32)
-                vp_pos[i, 2:2 + nc, 12] = (dm[ci, cidx] / MAX_DIST).astype(np.float32)
-                vp_pos[i, 2:2 + nc, 13] = (hops[cidx] / MAX_STEP).astype(np.float32)
             # embedding sources
             if t > 0:
                 coo_o += [i * K + 1, B * K + i * Vp + 1]
                 coo_s += [prev_cls0 + i, prev_cls0 + i]
                 coo_w += [1.0, 1.0]
+            fr, vr = self.fused_row[i], self.view_rows[i]
             for k, vp in enumerate(ids[2:], start=2):
                 if k < 2 + nv:
                     coo_o.append(i * K + k)
-                    coo_s.append(self.fused_row[i][vp])
+                    coo_s.append(fr[vp])
                     coo_w.append(1.0)
                 else:
-                    rows = self.view_rows[i][vp]
+                    rows = vr[vp]
                     coo_o += [i * K + k] * len(rows)
                     coo_s += rows
                     coo_w += [1.0 / len(rows)] * len(rows)
+        rep = np.concatenate(rep)
+        h, e, d = rel_pos(cur_pos[rep], np.concatenate(tp), base_heading=cur_head[rep], base_elevation=0)
+        feats = np.concatenate([angle_fts(h.astype(np.float32), e.astype(np.float32)),
+                                np.stack([d / MAX_DIST, np.concatenate(gd) / MAX_DIST, np.concatenate(hp) / MAX_STEP], 1).astype(np.float32)], 1)
+        pos[:, :2, 1] = pos[:, :2, 3] = 1.0                           # None tokens: angle (0, 0) -> cos = 1, distances 0
+        o = 0
+        for i, (ng, nc) in enumerate(segs):                           # (agent.py:290-328 for the local tokens: start | candidate)
+            pos[i, 2:2 + ng] = feats[o:o + ng]
+            vp_pos[i, :, :7] = feats[o + ng]
+            vp_pos[i, 2:2 + nc, 7:] = feats[o + ng + 1:o + ng + 1 + nc]
+            o += ng + 1 + nc
         # views of the current panorama -> local tokens 2..V+1 (padded rows included, like torch.cat in :294-297)
         vo = (B * K + np.arange(B)[:, None] * Vp + 2 + np.arange(V)[None]).reshape(-1)
         vs = (base + np.arange(B)[:, None] * V + np.arange(V)[None]).reshape(-1)
@@ -254,8 +270,7 @@ class NavPlanner:
         fsrc, bw = fusion_map(vpid_lists, visited, vp_cand, K, Vp)
         targets = self._teacher_action(vpid_lists, visited)
         self._cur = dict(vpids=vpid_lists, no_left=no_left, targets=targets)
-        return dict(t=t, B=B, V=V, K=K, Vp=Vp, log_base=base, log_fused=fused0, log_cls=cls0, log_rows=self.log_rows,
-                    vp_rows=vp_rows, view_order=view_order, loc_fts=loc, nav_types=nav_types, view_lens=view_lens, cand_vpids=cand_vpids,
+        return dict(K=K, Vp=Vp, log_base=base, log_fused=fused0, log_cls=cls0, log_rows=self.log_rows,
                     gmap_vpids=vpid_lists, gmap_lens=lens, gmap_step_ids=step_ids, gmap_pos_fts=pos, gmap_pair_dists=pair,
                     gmap_visited_masks=visited, gmap_masks=gmask, no_vp_left=no_left,
                     vp_pos_fts=vp_pos, vp_nav_masks=vp_nav, vp_masks=vp_masks, vp_cand_vpids=vp_cand,

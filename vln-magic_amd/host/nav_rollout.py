@@ -153,20 +153,27 @@ class NavRollout:
         decisions = 0
         with ctxg:
             for t in range(self.T):
-                plan = pl.begin_step()
+                plan = pl.begin_pano()
                 decisions += int((~pl.ended).sum())
-                arrays = {k: plan[k] for k in ("vp_rows", "view_order", "loc_fts", "nav_types", "view_lens", "gmap_step_ids", "gmap_pos_fts",
-                                               "gmap_pair_dists", "gmap_visited_masks", "gmap_masks", "vp_pos_fts", "vp_nav_masks", "vp_masks",
-                                               "fsrc", "bw", "targets")}
-                arrays.update(csr_ptr=plan["csr"][0], csr_idx=plan["csr"][1], csr_w=plan["csr"][2])
-                if plan["csr_t"] is not None:
-                    arrays.update(csrt_ptr=plan["csr_t"][0], csrt_idx=plan["csr_t"][1], csrt_w=plan["csr_t"][2])
-                d = to_device(arrays, dev)
-                csr = (d["csr_ptr"], d["csr_idx"], d["csr_w"])
-                csr_t = (d["csrt_ptr"], d["csrt_idx"], d["csrt_w"]) if plan["csr_t"] is not None else None
+                d = to_device({k: plan[k] for k in ("vp_rows", "view_order", "loc_fts", "nav_types", "view_lens")}, dev)
                 pin = self._pano_inputs(d, plan)
                 pe, pm, pf, pa = st("panorama", pin)
                 s_out.update(pano_embeds=pe, pano_fused_embeds=pf, img_attns=pa)
+                if te is not None:
+                    with torch.no_grad():
+                        tpe, _, tpf, tpa = te("panorama", pin)
+                # the GPU is busy with the panorama encoder(s): build the second half of the plan now
+                plan.update(pl.begin_nav())
+                arrays = {k: plan[k] for k in ("gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists", "gmap_visited_masks", "gmap_masks",
+                                               "vp_pos_fts", "vp_nav_masks", "vp_masks", "fsrc", "bw", "targets")}
+                arrays.update(csr_ptr=plan["csr"][0], csr_idx=plan["csr"][1], csr_w=plan["csr"][2])
+                if plan["csr_t"] is not None:
+                    arrays.update(csrt_ptr=plan["csr_t"][0], csrt_idx=plan["csr_t"][1], csrt_w=plan["csr_t"][2])
+                d2 = to_device(arrays, dev)
+                d2["_stage2"] = d2.pop("_stage")
+                d.update(d2)
+                csr = (d["csr_ptr"], d["csr_idx"], d["csr_w"])
+                csr_t = (d["csrt_ptr"], d["csrt_idx"], d["csrt_w"]) if plan["csr_t"] is not None else None
                 s_log.put(plan["log_base"], pe)
                 s_log.put(plan["log_fused"], pf)
                 gathered = s_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=grad)
@@ -181,7 +188,6 @@ class NavRollout:
                 stop_probs.append(torch.softmax(logits.detach(), 1)[:, 0])
                 if te is not None:
                     with torch.no_grad():
-                        tpe, _, tpf, tpa = te("panorama", pin)
                         t_out.update(pano_embeds=tpe, pano_fused_embeds=tpf, img_attns=tpa)
                         t_log.put(plan["log_base"], tpe, track=False)
                         t_log.put(plan["log_fused"], tpf, track=False)

@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"], help="graph: replay one captured HIP graph per step")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product path); gloo only to rehearse the N > 1 code path with several ranks on ONE card")
     ap.add_argument("--teacher", default="ahead", choices=["ahead", "same"],
                     help="ahead: the frozen teacher runs on batch i+1 (side stream) while the student trains on batch i; "
                          "same: teacher and student forward of the same batch side by side (every step runs one of each either way)")
@@ -151,10 +153,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.backend == "gloo":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     L.load()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 

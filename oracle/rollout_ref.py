@@ -256,12 +256,18 @@ def teacher_action(env, obs, vpids, ended, visited_masks, imitation_learning, t,
 
 # ---- the loop ------------------------------------------------------------------------------------------------------
 def rollout(env, student, obs, *, feedback="teacher", train_ml=1.0, max_action_len=15, teacher=None, kd=None, rw_seq=None,
-            expert_policy="spl", sample_draws=None, record=None):
+            expert_policy="spl", sample_draws=None, record=None, train_teacher=False):
     """One episode batch.  `obs` = env.reset(...).  teacher: frozen teacher model (MAKD t2s, agent.py:1024) with
     kd = dict(heads=<5 projection heads>, alpha, temperature, decay); rw_seq[t] = the 5 MKRW weights of step t
     (the reference draws them per step, :866-871; passed in so both sides of a parity test use the same draw).
     sample_draws[t] = uniform numbers standing in for Categorical.sample() under feedback='sample'.
-    Returns dict(loss, ml_loss, kdl, traj, steps=[per-step records])."""
+    train_teacher: ICoD co-training (args.train_kdl_teacher): the teacher runs with gradients and gets its own loss
+    `t_loss` = t_alpha * (sum of the reverse 's2t' MAKD terms * train_ml) + (1 - t_alpha) * (teacher CE * train_ml / B)
+    (agent.py:1013-1026,1138-1149; the reverse terms use the STUDENT's sample weights and the student's projection heads on the
+    detached student side, reduction 'mean').
+    Returns dict(loss, ml_loss, kdl, traj, steps=[per-step records][, t_loss])."""
+    import contextlib
+    tgrad = contextlib.nullcontext if train_teacher else torch.no_grad
     B = len(obs)
     scanvp_cands = {}
 
@@ -280,13 +286,14 @@ def rollout(env, student, obs, *, feedback="teacher", train_ml=1.0, max_action_l
     s_out = dict(txt_embeds=txt_embeds, txt_attns=txt_attns)
     t_out = {}
     if teacher is not None:
-        with torch.no_grad():
+        with tgrad():
             t_txt, t_txt_attns = teacher("language", lang)
         t_out = dict(txt_embeds=t_txt, txt_attns=t_txt_attns)
     ended, just_ended = np.array([False] * B), np.array([False] * B)
     last, t_last = None, None
     ml_loss = 0.0
     kdl = defaultdict(float)
+    t_ml_loss, t_kdl = 0.0, defaultdict(float)
     steps = []
     for t in range(max_action_len):
         for i, g in enumerate(gmaps):
@@ -296,7 +303,7 @@ def rollout(env, student, obs, *, feedback="teacher", train_ml=1.0, max_action_l
         pe, pm, pf, pa = student("panorama", pano)
         s_out.update(pano_embeds=pe, pano_fused_embeds=pf, img_attns=pa)
         if teacher is not None:
-            with torch.no_grad():
+            with tgrad():
                 tpe, _, tpf, tpa = teacher("panorama", pano)
             t_out.update(pano_embeds=tpe, pano_fused_embeds=tpf, img_attns=tpa)
         for i, g in enumerate(gmaps):
@@ -322,7 +329,7 @@ def rollout(env, student, obs, *, feedback="teacher", train_ml=1.0, max_action_l
             t_nav = nav_gmap_variable(obs, gmaps, t_last, teacher=True)
             t_nav.update(nav_vp_variable_mem(obs, gmaps, tpe, pano["cand_vpids"], pano["view_lens"], pano["nav_types"], t_last))
             t_nav.update(txt_embeds=t_txt, txt_masks=lang["txt_masks"])
-            with torch.no_grad():
+            with tgrad():
                 t_outs = teacher("navigation", t_nav)
             t_out.update(nav_outs=t_outs, nav_logits=t_outs["fused_logits"])
             t_last = t_outs["cls_embeds"]
@@ -333,9 +340,15 @@ def rollout(env, student, obs, *, feedback="teacher", train_ml=1.0, max_action_l
         ce = F.cross_entropy(logits, targets, ignore_index=IGNORE, reduction="none")
         ml_loss = ml_loss + ce.sum()
         if teacher is not None:
-            with torch.no_grad():
+            with tgrad():
                 t_ce = F.cross_entropy(t_out["nav_logits"], targets, ignore_index=IGNORE, reduction="none")
-            t_out["sample_weights"] = M.exponential_decay(t_ce, kd["decay"]).detach()
+            t_out["sample_weights"] = M.exponential_decay(t_ce.detach(), kd["decay"]).detach()
+            if train_teacher:
+                t_ml_loss = t_ml_loss + t_ce.sum()
+                s_out["sample_weights"] = M.exponential_decay(ce.detach(), kd["decay"]).detach()
+                t_acc = defaultdict(float, t_kdl)
+                t_kdl = M.nav_makd(t, t_out, s_out, kd["heads"], t_acc, role="s2t", temperature=kd["temperature"],
+                                   weights=None if rw_seq is None else rw_seq[t], weight_mode="RW" if rw_seq is not None else None)
             acc = defaultdict(float, kdl)
             kdl = M.nav_makd(t, s_out, t_out, kd["heads"], acc, role="t2s", loss_type="sum", temperature=kd["temperature"],
                              weights=None if rw_seq is None else rw_seq[t], weight_mode="RW" if rw_seq is not None else None)
@@ -393,4 +406,9 @@ def rollout(env, student, obs, *, feedback="teacher", train_ml=1.0, max_action_l
         total = kd["alpha"] * kd_sum + (1 - kd["alpha"]) * ml
     else:
         kd_sum, total = None, ml
-    return dict(loss=total, ml_loss=ml, kdl=kd_sum, kdl_terms=dict(kdl), traj=traj, steps=steps, gmaps=gmaps)
+    out = dict(loss=total, ml_loss=ml, kdl=kd_sum, kdl_terms=dict(kdl), traj=traj, steps=steps, gmaps=gmaps)
+    if teacher is not None and train_teacher:
+        ta = kd.get("t_alpha", kd["alpha"])
+        out["t_kdl_terms"] = dict(t_kdl)
+        out["t_loss"] = ta * (sum(t_kdl.values()) * train_ml) + (1 - ta) * (t_ml_loss * train_ml / B)
+    return out

@@ -24,14 +24,14 @@ def _env(seed, B=4):
     return SynthNavEnv(batch_size=B, n_scans=2, nodes_per_scan=30, seed=seed, instr_len=(6, 14), vocab=(3, 290), path_hops=(2, 4))
 
 
-def _pair(cfg, role, seed):
+def _pair(cfg, role, seed, args=None):
     torch.manual_seed(seed)
     o = RefVLNBert(cfg).double().eval()
     with torch.no_grad():
         for n, p in o.named_parameters():
             if n.endswith("bias"):
                 p.normal_(0, 0.02)
-    g = VLNBert(None, role=role, config=cfg, device=DEV, compute_dtype=torch.float32)
+    g = VLNBert(args, role=role, config=cfg, device=DEV, compute_dtype=torch.float32)
     g.load_state_dict(o.state_dict())
     g.eval()
     return o, g
@@ -134,6 +134,39 @@ def test_makd_rollout_matches_oracle():
     got["loss"].backward()
     torch.cuda.synchronize()
     _check_grads(g_s, o_s)
+
+
+def test_icod_cotraining_rollout_matches_oracle():
+    """args.train_kdl_teacher: the teacher runs with gradients and is distilled FROM the student in the reverse ('s2t', mean-reduced)
+    direction while the student is distilled from it (agent.py:1013-1026,1138-1149; agent_base.py:260-269 backpropagates both losses)"""
+    from types import SimpleNamespace
+    tcfg, scfg = make_config(256, role="teacher", **KW), make_config(128, role="student", teacher_hidden_size=256, **KW)
+    o_t, g_t = _pair(tcfg, "teacher", 3, args=SimpleNamespace(train_kdl_teacher=True, teacher_hidden_size=256))
+    o_s, g_s = _pair(scfg, "student", 4)
+    T = 4
+    rw = (torch.softmax(torch.randn(T, 5, generator=torch.Generator().manual_seed(8)) / 4, -1) * 5)
+    kd = dict(alpha=0.5, t_alpha=0.3, temperature=2.0, decay=0.7)
+    env_a, env_b = _env(19), _env(19)
+    heads = {n: getattr(o_s.vln_bert, n) for n in HEADS}
+    want = R.rollout(env_a, _f64(o_s), env_a.reset(), feedback="teacher", train_ml=0.2, max_action_len=T, teacher=_f64(o_t),
+                     kd=dict(kd, heads=heads), rw_seq=rw.double(), train_teacher=True)
+    want["loss"].backward(retain_graph=True)
+    want["t_loss"].backward()
+    table = torch.from_numpy(env_b.feature_table).to(DEV)
+    ro = NavRollout(g_s, table, teacher=g_t, kd=kd, max_action_len=T, train_teacher=True)
+    g_s.store.zero_grad()
+    g_t.store.zero_grad()
+    got = ro.run(env_b, env_b.reset(features=False), feedback="teacher", train_ml=0.2, rw_seq=rw.to(DEV), record=True)
+    _check_steps(got, want)
+    for k, v in want["t_kdl_terms"].items():
+        close(got["t_kdl_terms"][k], v, f"s2t {k}", 3e-4, 1e-7)
+    close(got["loss"], want["loss"], "student loss", 2e-4, 1e-6)
+    close(got["t_loss"], want["t_loss"], "teacher loss", 2e-4, 1e-6)
+    got["loss"].backward(retain_graph=True)
+    got["t_loss"].backward()
+    torch.cuda.synchronize()
+    _check_grads(g_s, o_s)
+    _check_grads(g_t, o_t)
 
 
 def test_compat_graphmap_drives_the_same_numbers():

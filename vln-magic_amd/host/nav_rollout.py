@@ -96,13 +96,15 @@ class EmbeddingLog:
 
 
 class NavRollout:
-    def __init__(self, student, feature_table, teacher=None, kd=None, max_action_len=15, expert_policy="spl", cache_text_kv=True):
+    def __init__(self, student, feature_table, teacher=None, kd=None, max_action_len=15, expert_policy="spl", cache_text_kv=True,
+                 train_teacher=False):
         """feature_table: [n_viewpoints, 36, D] device tensor in the student's compute dtype (packed once, SURVEY f-2).
         kd: dict(alpha, temperature, decay) -- MAKD hyper-parameters (run_r2r_kdl_valid.sh:97-104)."""
         self.student, self.teacher, self.kd = student, teacher, kd
         self.table = feature_table
         self.T, self.expert = max_action_len, expert_policy
         self.cache_text_kv = cache_text_kv
+        self.train_teacher = bool(train_teacher) and teacher is not None      # ICoD co-training (args.train_kdl_teacher)
         self.dev = feature_table.device
         if teacher is not None:
             self.heads = {n: getattr(student.vln_bert, n) for n in ("txt_emb_w", "kdl_img_w", "kdl_avg_img_w", "global_cross_w", "local_cross_w")}
@@ -140,8 +142,11 @@ class NavRollout:
             txt_kv = st.text_kv(txt_embeds) if self.cache_text_kv else None      # once per episode, not once per step
         s_out = dict(txt_embeds=txt_embeds, txt_attns=txt_attns)
         t_out = {}
+        tt_grad = self.train_teacher and grad
+        tctx = torch.enable_grad if tt_grad else torch.no_grad
+        t_ml_loss, t_kdl = torch.zeros((), dtype=torch.float32, device=dev), {}
         if te is not None:
-            with torch.no_grad():
+            with tctx():
                 t_txt, t_txt_attns = te("language", lin)
                 t_kv = te.text_kv(t_txt) if self.cache_text_kv else None
             t_out = dict(txt_embeds=t_txt, txt_attns=t_txt_attns)
@@ -160,7 +165,7 @@ class NavRollout:
                 pe, pm, pf, pa = st("panorama", pin)
                 s_out.update(pano_embeds=pe, pano_fused_embeds=pf, img_attns=pa)
                 if te is not None:
-                    with torch.no_grad():
+                    with tctx():
                         tpe, _, tpf, tpa = te("panorama", pin)
                 # the GPU is busy with the panorama encoder(s): build the second half of the plan now
                 plan.update(pl.begin_nav())
@@ -187,19 +192,24 @@ class NavRollout:
                 ml_loss = ml_loss + ce.sum()
                 stop_probs.append(torch.softmax(logits.detach(), 1)[:, 0])
                 if te is not None:
-                    with torch.no_grad():
+                    with tctx():
                         t_out.update(pano_embeds=tpe, pano_fused_embeds=tpf, img_attns=tpa)
-                        t_log.put(plan["log_base"], tpe, track=False)
-                        t_log.put(plan["log_fused"], tpf, track=False)
-                        tg = t_log.gather(csr, None, plan["n_out"], plan["log_cls"], grad=False)
+                        t_log.put(plan["log_base"], tpe, track=tt_grad)
+                        t_log.put(plan["log_fused"], tpf, track=tt_grad)
+                        tg = t_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=tt_grad)
                         t_outs = te("navigation", self._nav_inputs(d, plan, tg, t_txt, txt_masks, txt_lens, t_kv))
-                        t_log.put(plan["log_cls"], t_outs["cls_embeds"], track=False)
+                        t_log.put(plan["log_cls"], t_outs["cls_embeds"], track=tt_grad)
                         t_out.update(nav_outs=t_outs, nav_logits=t_outs["fused_logits"])
                         t_ce = F.cross_entropy(t_outs["fused_logits"], targets, ignore_index=IGNORE, reduction="none")
-                        t_out["sample_weights"] = exponential_decay(t_ce, self.kd["decay"])
+                        t_out["sample_weights"] = exponential_decay(t_ce.detach(), self.kd["decay"])
                     if grad:
-                        kdl = compute_kd_losses(t, s_out, t_out, self.heads, kdl, role="t2s", temperature=self.kd["temperature"],
-                                                weights=None if rw_seq is None else rw_seq[t])
+                        rw_t = None if rw_seq is None else rw_seq[t]
+                        kdl = compute_kd_losses(t, s_out, t_out, self.heads, kdl, role="t2s", temperature=self.kd["temperature"], weights=rw_t)
+                        if tt_grad:      # reverse direction (agent.py:1026): teacher tensors vs the student's, projected by the student's heads
+                            t_ml_loss = t_ml_loss + t_ce.sum()
+                            s_out["sample_weights"] = exponential_decay(ce.detach(), self.kd["decay"])
+                            t_kdl = compute_kd_losses(t, t_out, s_out, self.heads, t_kdl, role="s2t", temperature=self.kd["temperature"],
+                                                      weights=rw_t)
                 a_host = None
                 if feedback == "argmax":
                     a_host = logits.detach().argmax(1).cpu().numpy()                # the stepper needs it: one [B] copy
@@ -221,5 +231,10 @@ class NavRollout:
             kd_sum = sum(kdl.values()) / B
             total = self.kd["alpha"] * kd_sum + (1 - self.kd["alpha"]) * ml
         traj = pl.finish(torch.stack(stop_probs).cpu().numpy())
-        return dict(loss=total, ml_loss=ml, kdl=kd_sum, kdl_terms=kdl, traj=traj, n_steps=len(stop_probs), decisions=decisions,
-                    steps=steps, planner=pl)
+        out = dict(loss=total, ml_loss=ml, kdl=kd_sum, kdl_terms=kdl, traj=traj, n_steps=len(stop_probs), decisions=decisions,
+                   steps=steps, planner=pl)
+        if tt_grad:
+            ta = self.kd.get("t_alpha", self.kd["alpha"])
+            out["t_kdl_terms"] = t_kdl
+            out["t_loss"] = ta * (sum(t_kdl.values()) * train_ml) + (1 - ta) * (t_ml_loss * train_ml / B)
+        return out

@@ -95,6 +95,43 @@ def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=25.0):
                       f"fp32 torch CPU oracle, dropout {pdrop}, {t_total / max(steps_done, 1) * 1e3:.0f} ms/step"}
 
 
+class _StreamSet(torch.utils.data.IterableDataset):
+    """synthetic stand-in for the reference's per-task datasets: every worker owns a few pre-generated sample lists (the
+    generation of 30 MB of random features is not part of what is measured) and, per batch, runs the collate
+    (`synth.collate`, pinned to tasks.py's) and the host half of the index plan -- the per-batch CPU work of a real loader."""
+
+    def __init__(self, batch_size, seed, n_steps, pool=3, n_vp=0):
+        self.batch_size, self.seed, self.n_steps, self.pool, self.n_vp = batch_size, seed, n_steps, pool, n_vp
+
+    def __iter__(self):
+        import random
+
+        import numpy as np
+
+        from magic_amd.host.loader import pack
+        from magic_amd.host.plan import build_plan_host
+        info = torch.utils.data.get_worker_info()
+        wid, nw = (info.id, info.num_workers) if info is not None else (0, 1)
+        torch.set_num_threads(1)
+        pools = []
+        for j in range(self.pool):
+            rng = np.random.default_rng([self.seed, wid, j])
+            pyrng = random.Random(self.seed * 1000003 + wid * 101 + j)
+            pools.append([synth.make_sample(rng, pyrng, vocab=50265, uid=i, **(dict(img_dim=8) if self.n_vp else {})) for i in range(self.batch_size)])
+        for step in range(wid, self.n_steps, nw):
+            task = TASKS[step % 3]
+            rng = np.random.default_rng([self.seed, step])
+            batch = synth.collate(pools[(step // nw) % self.pool], task, rng=rng, vocab=50265)
+            if self.n_vp:       # index-only batch: table row + view order per panorama instead of the features
+                Np, V = batch.pop("traj_view_img_fts").shape[:2]
+                order = np.full((Np, V), -1, np.int32)
+                for p_, n_ in enumerate(batch["traj_vp_view_lens"].tolist()):
+                    order[p_, :n_] = rng.permutation(36)[:n_] if n_ <= 36 else np.concatenate([rng.permutation(36), rng.integers(0, 36, n_ - 36)])
+                batch["traj_vp_row"] = torch.from_numpy(rng.integers(0, self.n_vp, Np).astype(np.int32))
+                batch["traj_view_order"] = torch.from_numpy(order)
+            yield task, pack(batch, build_plan_host(batch, task))
+
+
 def ingest_rate(dev, n_vp=4096, n_pano=290, reps=40):
     """SURVEY section 8d 'achieved feature-ingest GB/s': the f-2 path (packed bf16 view-feature table in HBM, index-only
     batches, `magic_view_gather` in the reference's candidate-first token order) timed on one B=48 batch worth of panoramas.
@@ -142,7 +179,15 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1, help="hidden/attention dropout of the student (reference recipe: 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager"], help="graph: replay one captured HIP graph per step")
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "stream"],
+                    help="graph: replay one captured HIP graph per resident batch (the headline line); eager: same batches, launches issued "
+                         "one by one; stream: NON-resident batches -- collate + index plan built in DataLoader worker processes, pinned, "
+                         "copied one batch ahead on a copy stream (host/loader.py), eager launches: the PCIe-inclusive rate")
+    ap.add_argument("--workers", type=int, default=8, help="--mode stream: DataLoader worker processes (r2r_magic_pretrain.json:26 n_workers)")
+    ap.add_argument("--ingest", default="table", choices=["table", "host"],
+                    help="--mode stream: 'host' = the reference's way, every batch carries its fp32 view features (30 MB at B=48) from the "
+                         "workers through pinned memory over PCIe; 'table' = SURVEY f-2, features live once in HBM (packed bf16 table) and a "
+                         "batch carries 37 int32 per panorama, gathered on the device")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse the N > 1 code path with several ranks on ONE card")
     ap.add_argument("--teacher", default="ahead", choices=["ahead", "same"],
@@ -178,7 +223,7 @@ def main():
 
     # synthetic batches, resident in HBM before the timed region (per-rank stream: seed 1234 + rank)
     pool = []
-    for i in range(a.pool):
+    for i in range(a.pool if a.mode != "stream" else 3):
         task = TASKS[i % 3]
         b = synth.make_batch(task, batch_size=a.batch, seed=1234 + rank, step=i)
         plan = build_plan(b, task, dev)
@@ -194,6 +239,8 @@ def main():
         return traj
 
     graphs = None
+    if a.mode == "stream":
+        a.no_profile = True
     if a.mode == "graph":
         # one HIP graph per resident batch (each batch has its own ragged shapes); every replay executes the full
         # step: teacher fwd, student fwd+losses+bwd, clip, AdamW -- with lr / bias-correction / MKRW read from device memory
@@ -224,6 +271,27 @@ def main():
             traj += cs.traj_steps
         return traj
 
+    if a.mode == "stream":
+        from magic_amd.host.loader import DevicePrefetcher
+        n_vp = 4096
+        ds = _StreamSet(a.batch, 1234 + rank, a.warmup + a.steps + 2, n_vp=n_vp if a.ingest == "table" else 0)
+        ftab = None
+        if a.ingest == "table":
+            from magic_amd.host.feature_table import FeatureTable
+            ftab = FeatureTable([str(i) for i in range(n_vp)],
+                                torch.randn(n_vp, 36, 768, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).to(dev))
+        dl = torch.utils.data.DataLoader(ds, batch_size=None, num_workers=a.workers, pin_memory=True, prefetch_factor=2, persistent_workers=False)
+        feed = iter(DevicePrefetcher(dl, dev))
+
+        def run(n, start=0):          # noqa: F811
+            traj = 0
+            for _ in range(n):
+                task, b, plan = next(feed)
+                if ftab is not None:
+                    b["view_table"] = ftab
+                trainer.step(b, task, plan=plan)
+                traj += plan["traj_steps"]
+            return traj
     run(a.warmup)
     torch.cuda.synchronize()
     if world > 1:
@@ -294,7 +362,7 @@ def main():
         info = {"metric": "trajectory-steps/sec (whole node), MAGIC-S R2R pretrain", "value": round(traj / dt, 2),
                 "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": a.dtype, "data": "synthetic", "launch": a.mode,
+                "dtype": a.dtype, "data": "synthetic", "launch": a.mode if a.mode != "stream" else f"stream/{a.ingest}/{a.workers}w",
                 "teacher_schedule": ("one batch ahead of the student (side stream)" if (a.teacher == "ahead" and a.mode == "graph") else "same batch, side stream"),
                 "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "
                                        "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip, student in train() mode",

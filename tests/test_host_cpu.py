@@ -164,3 +164,39 @@ def test_feature_table_envedit_mixing_follows_the_reference_coin_stream():
     assert b["vp_row"].tolist() == want and any(r >= 5 for r in want) and any(r < 5 for r in want)
     plain = ft.batch_indices(["s", "s"], paths, cands)
     assert plain["vp_row"].tolist() == [0, 1, 2, 3, 4]
+
+
+def test_packed_loader_record_round_trips():
+    """host/loader.pack (DataLoader worker side) -> unpack (training process) gives the same batch entries and index plan as the
+    direct path, for every task, incl. an index-only (feature-table) batch"""
+    import numpy as np
+    from magic_amd.host import synth
+    from magic_amd.host.loader import MODEL_KEYS, PlanCollate, pack, unpack
+    from magic_amd.host.plan import build_plan, build_plan_host
+    for task in ("mlm", "sap", "cfp", "mrc"):
+        b = synth.make_batch(task, batch_size=5, seed=3, step=1, vocab=300, min_len=6, max_len=12, min_steps=2, max_steps=4)
+        if task == "cfp":
+            Np, V = b.pop("traj_view_img_fts").shape[:2]
+            b["traj_vp_row"] = torch.arange(Np, dtype=torch.int32)
+            b["traj_view_order"] = torch.arange(V, dtype=torch.int32)[None].repeat(Np, 1)
+        want = build_plan(b, task, "cpu")
+        rec = pack(b, build_plan_host(b, task))
+        assert rec["buf"].dtype == torch.uint8 and rec["buf"].dim() == 1
+        gb, gp = unpack(rec, "cpu")
+        for k in MODEL_KEYS:
+            if torch.is_tensor(b.get(k)):
+                assert torch.equal(gb[k], b[k]), k
+        for k, v in want.items():
+            if k == "_stage":
+                continue
+            if torch.is_tensor(v):
+                assert torch.equal(gp[k], v) and gp[k].dtype == v.dtype, k
+            elif isinstance(v, tuple):
+                assert all(torch.equal(x, y) for x, y in zip(gp[k], v)), k
+            elif isinstance(v, np.ndarray):
+                assert (gp[k] == v).all(), k
+            else:
+                assert gp[k] == v, k
+    samples = [dict(x=i) for i in range(3)]
+    pc = PlanCollate(lambda inp: synth.make_batch("sap", batch_size=len(inp), seed=1, vocab=300, min_len=6, max_len=9, min_steps=2, max_steps=3), "sap")
+    assert set(pc(samples)) == {"buf", "manifest", "meta"}

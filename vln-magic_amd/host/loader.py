@@ -1,0 +1,129 @@
+"""Streaming batches into the training step (pretrain_src/data/loader.py).
+
+The reference feeds its step through `DataLoader(num_workers=n_workers, pin_memory, collate_fn=<task>_collate)` ->
+`MetaLoader` (task draw + rank-0 broadcast, loader.py:18-75) -> `PrefetchLoader` (one batch ahead, non_blocking H2D,
+loader.py:90-124).  `MetaLoader` / `PrefetchLoader` are model-agnostic and keep working in front of these models; what this
+module adds is the part specific to the HIP engine:
+
+  * `PlanCollate(collate_fn, task)` -- a collate wrapper for the DataLoader WORKERS: next to the padded batch it builds the
+    host half of the engine's index plan (`plan.build_plan_host`: CSR aggregation matrices, fusion map, masks; 6-28 ms of pure
+    CPU work per B=48 batch, i.e. several GPU steps -- it must not run in the training process);
+  * `DevicePrefetcher(loader, device)` -- PrefetchLoader's role plus the plan: one batch ahead on a copy stream it moves the
+    pinned batch (30 MB of fp32 view features at B=48) and the plan (ONE packed copy for its ~60 arrays), and hands
+    `(task, batch_on_device, plan_on_device)` to `PretrainStep.step` after a stream wait.
+"""
+import numpy as np
+import torch
+
+from .plan import build_plan_host, plan_to_device
+
+MODEL_KEYS = ("traj_view_img_fts", "traj_vp_row", "traj_view_order", "traj_loc_fts", "gmap_pos_fts", "gmap_pair_dists", "vp_pos_fts",
+              "global_act_labels", "local_act_labels")      # the batch entries the model reads; everything else is in the plan
+
+
+def pack(batch, hp):
+    """(batch, host plan) -> ONE contiguous uint8 tensor + a manifest.  A DataLoader worker hands tensors to the training process
+    one shared-memory segment (and one file descriptor) per storage: the ~150 small tensors of a batch + plan cost ~35 ms of IPC
+    per batch that way, a single packed storage costs well under 1 ms -- and it is also one pinned copy and one H2D copy."""
+    arrays = {f"b/{k}": batch[k] for k in MODEL_KEYS if torch.is_tensor(batch.get(k))}
+    for k, v in hp["cpu"].items():
+        arrays[f"p/{k}"] = v
+    for name, (f, t) in hp["csr"].items():
+        for j, a in enumerate(f):
+            arrays[f"c/{name}/{j}"] = torch.as_tensor(a)
+        for j, a in enumerate(t):
+            arrays[f"c/{name}_T/{j}"] = torch.as_tensor(a)
+    manifest, off = [], 0
+    for k, a in arrays.items():
+        off = (off + 15) & ~15
+        manifest.append((k, str(a.dtype).replace("torch.", ""), tuple(a.shape), off))
+        off += a.numel() * a.element_size()
+    buf = torch.empty(max(off, 16), dtype=torch.uint8)
+    for (k, _, _, o), a in zip(manifest, arrays.values()):
+        n = a.numel() * a.element_size()
+        if n:
+            buf[o:o + n] = a.contiguous().reshape(-1).view(torch.uint8)
+    meta = dict(hp["meta"])
+    meta["last_rows"] = np.asarray(meta["last_rows"]).tolist()
+    return dict(buf=buf, manifest=manifest, meta=meta)
+
+
+def unpack(rec, device):
+    """packed record -> (batch_on_device, plan_on_device): one (pinned) host buffer, one async copy, views"""
+    device = torch.device(device)
+    buf = rec["buf"]
+    if device.type == "cuda" and not buf.is_pinned():
+        buf = buf.pin_memory()
+    dbuf = buf.to(device, non_blocking=True)
+    batch, plan, csr = {}, {}, {}
+    for k, dt, shape, o in rec["manifest"]:
+        dtype = getattr(torch, dt)
+        n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size() if len(shape) else torch.empty(0, dtype=dtype).element_size()
+        t = dbuf[o:o + n].view(dtype).view(shape) if n else torch.empty(shape, dtype=dtype, device=device)
+        kind, rest = k.split("/", 1)
+        if kind == "b":
+            batch[rest] = t
+        elif kind == "p":
+            plan[rest] = t
+        else:
+            name, j = rest.rsplit("/", 1)
+            csr.setdefault(name, {})[int(j)] = t
+    for name, parts in csr.items():
+        plan[name] = tuple(parts[j] for j in range(len(parts)))
+    plan.update(rec["meta"])
+    plan["last_rows"] = np.asarray(plan["last_rows"], np.int64)
+    plan["_stage"] = buf
+    return batch, plan
+
+
+class PlanCollate:
+    """collate_fn for DataLoader workers: `inputs` -> packed record (`pack`).  `collate_fn` is the task's collate
+    (`tasks.py:{mlm,mrc,sap,cfp}_collate`, or `synth.collate` bound to the task)."""
+
+    def __init__(self, collate_fn, task):
+        self.collate_fn, self.task = collate_fn, task
+
+    def __call__(self, inputs):
+        batch = self.collate_fn(inputs)
+        return pack(batch, build_plan_host(batch, self.task))
+
+
+def _to_device(x, device):
+    if torch.is_tensor(x):
+        return x.to(device, non_blocking=True)
+    return x
+
+
+class DevicePrefetcher:
+    """iterate (task, packed record) pairs -- e.g. a MetaLoader over PlanCollate loaders -- one batch ahead"""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def _stage(self, item):
+        task, rec = item
+        if self.stream is None:
+            return (task,) + unpack(rec, self.device)
+        with torch.cuda.stream(self.stream):
+            b, p = unpack(rec, self.device)
+        return task, b, p
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur = nxt
+            if self.stream is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self.stream)
+                for v in list(cur[1].values()) + list(cur[2].values()):
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(torch.cuda.current_stream(self.device))
+            try:
+                nxt = self._stage(next(it))
+            except StopIteration:
+                nxt = None
+            yield cur

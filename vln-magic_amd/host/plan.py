@@ -30,6 +30,51 @@ def csr_pair(entries, n_out, n_src):
 
 
 def build_plan(batch, task, device, ld_round=8):
+    """host half + device half in one call (resident / test batches).  A streaming loader runs `build_plan_host` in its worker
+    processes (it is pure CPU work, 6-28 ms per B=48 batch) and `plan_to_device` on the training process's copy stream."""
+    return plan_to_device(build_plan_host(batch, task), device)
+
+
+def plan_to_device(hp, device):
+    """ship every index array of a host plan in ONE pinned staging buffer and ONE async copy (the plan has ~60 small arrays:
+    copied one by one they cost ~10 us of host time each)"""
+    device = torch.device(device)
+    arrays = dict(hp["cpu"])
+    for name, (f, t) in hp["csr"].items():
+        for j, a in enumerate(f):
+            arrays[f"{name}/{j}"] = torch.as_tensor(a)
+        for j, a in enumerate(t):
+            arrays[f"{name}_T/{j}"] = torch.as_tensor(a)
+    metas, off = [], 0
+    for k, a in arrays.items():
+        a = a.contiguous()
+        off = (off + 15) & ~15
+        metas.append((k, a, off))
+        off += a.numel() * a.element_size()
+    stage = torch.empty(max(off, 16), dtype=torch.uint8, pin_memory=(device.type == "cuda"))
+    for k, a, o in metas:
+        n = a.numel() * a.element_size()
+        if n:
+            stage[o:o + n] = a.reshape(-1).view(torch.uint8)
+    buf = stage.to(device, non_blocking=True)
+    plan, csr = {}, {}
+    for k, a, o in metas:
+        n = a.numel() * a.element_size()
+        t = buf[o:o + n].view(a.dtype).view(a.shape) if n else torch.empty(a.shape, dtype=a.dtype, device=device)
+        if "/" in k:
+            name, j = k.split("/")
+            csr.setdefault(name, {})[int(j)] = t
+        else:
+            plan[k] = t
+    for name, parts in csr.items():
+        plan[name] = tuple(parts[j] for j in range(len(parts)))
+    plan.update(hp["meta"])
+    plan["_stage"] = stage
+    return plan
+
+
+def build_plan_host(batch, task, ld_round=8):
+    """the CPU-only half: numpy / CPU tensors + scalars, picklable (DataLoader workers can build it next to the collate)"""
     B = len(batch["traj_step_lens"])
     L = batch["txt_ids"].shape[1]
     K = batch["gmap_step_ids"].shape[1]
@@ -126,20 +171,17 @@ def build_plan(batch, task, device, ld_round=8):
         plan_csr["mrc_rows"] = csr_pair([(i, int(b_) * Vp + 1 + int(v_), 1.0) for i, (b_, v_) in enumerate(sel.tolist())], n_mrc, B * Vp)
         cpu["mrc_targets"] = batch["vp_view_probs"][mm].float().contiguous()
 
-    plan = {k: v.to(device, non_blocking=True) for k, v in cpu.items()}
-    for name, (f, t) in plan_csr.items():
-        plan[name] = tuple(torch.from_numpy(a).to(device, non_blocking=True) for a in f)
-        plan[name + "_T"] = tuple(torch.from_numpy(a).to(device, non_blocking=True) for a in t)
+    meta = {}
     # value ranges of everything the kernels use as a table index, taken on the host copies (the device never bounds-checks:
     # an out-of-range id would be an out-of-bounds read on the GPU) -- validated against the model config by check_plan()
-    plan["limits"] = dict(txt_id=int(batch["txt_ids"].max()), txt_id_min=int(batch["txt_ids"].min()),
+    meta["limits"] = dict(txt_id=int(batch["txt_ids"].max()), txt_id_min=int(batch["txt_ids"].min()),
                           step_id=int(batch["gmap_step_ids"].max()), step_id_min=int(batch["gmap_step_ids"].min()),
                           nav_type=int(batch["traj_nav_types"].max()), nav_type_min=int(batch["traj_nav_types"].min()))
-    plan.update(B=B, L=L, K=K, Vp=Vp, Np=Np, V=V, last_rows=last_rows,
-                n_mask=(int(plan["mlm_labels"].numel()) if task == "mlm" else 0), n_mrc=n_mrc,
+    meta.update(B=B, L=L, K=K, Vp=Vp, Np=Np, V=V, last_rows=last_rows,
+                n_mask=(int(cpu["mlm_labels"].numel()) if task == "mlm" else 0), n_mrc=n_mrc,
                 txt_tokens=int(txt_lens.sum()), gmap_nodes=int(batch["gmap_lens"].sum()), traj_steps=Np,
                 lens=dict(txt=txt_lens.tolist(), gmap=batch["gmap_lens"].tolist(), steps=list(step_lens)))
-    return plan
+    return dict(cpu=cpu, csr=plan_csr, meta=meta)
 
 
 def check_plan(plan, cfg):

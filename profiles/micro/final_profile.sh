@@ -13,3 +13,11 @@ find $R/gpurun_out/prof_final -name "*kernel_stats.csv" -exec cp {} $R/gpurun_ou
 rm -rf $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
 find $R/gpurun_out/prof_final -name "*kernel_trace.csv" -delete
 tail -c 600 $R/gpurun_out/bench_final.json; echo; cat $R/gpurun_out/pmc_traffic.json | head -12
+# navigator loop (SURVEY f-1): bench line + kernel stats
+cd /tmp
+python3 $R/bench_nav.py --steps 6 --warmup 2 > $R/gpurun_out/bench_nav_final.json 2> $R/gpurun_out/bench_nav_final.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_nav -- python3 $R/bench_nav.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-loop --no-profile > $R/gpurun_out/bench_nav_under_rocprof.json 2> $R/gpurun_out/prof_nav.err
+find $R/gpurun_out/prof_nav -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/kernel_stats_nav.csv \;
+find $R/gpurun_out/prof_nav -name "*kernel_trace.csv" -delete
+rm -f $R/gpurun_out/prof_nav/*.db
+tail -c 300 $R/gpurun_out/bench_nav_final.json; echo

@@ -261,9 +261,7 @@ def main():
             graphs = [trainer.capture(b, task, plan) for task, b, plan in pool]
         torch.cuda.synchronize()
 
-    def run(n, start=0):
-        if graphs is None:
-            return run_eager(n, start)
+    def run_graph(n, start=0):
         traj = 0
         for s in range(n):
             cs = graphs[(start + s) % len(graphs)]
@@ -271,6 +269,7 @@ def main():
             traj += cs.traj_steps
         return traj
 
+    run = run_graph if a.mode == "graph" else run_eager
     if a.mode == "stream":
         from magic_amd.host.loader import DevicePrefetcher
         n_vp = 4096
@@ -283,7 +282,7 @@ def main():
         dl = torch.utils.data.DataLoader(ds, batch_size=None, num_workers=a.workers, pin_memory=True, prefetch_factor=2, persistent_workers=False)
         feed = iter(DevicePrefetcher(dl, dev))
 
-        def run(n, start=0):          # noqa: F811
+        def run_stream(n, start=0):
             traj = 0
             for _ in range(n):
                 task, b, plan = next(feed)
@@ -292,6 +291,7 @@ def main():
                 trainer.step(b, task, plan=plan)
                 traj += plan["traj_steps"]
             return traj
+        run = run_stream
     run(a.warmup)
     torch.cuda.synchronize()
     if world > 1:

@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-host-loop", action="store_true")
+    ap.add_argument("--icod", action="store_true",
+                    help="BASELINE config 3: MAGIC-L teacher (trainable, --teacher-hidden) + student (--hidden) co-training -- MAKD t2s for the "
+                         "student, reverse s2t for the teacher, both losses back-propagated, two optimizers (agent_base.py:260-279)")
+    ap.add_argument("--teacher-hidden", type=int, default=768)
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="eval: greedy inference rollouts (feedback 'argmax', no grad, model.eval()) -- decisions/s and ms per step")
     a = ap.parse_args()
@@ -101,7 +105,23 @@ def main():
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5)              # agent_base.py:128-129
     env = make_env(a, 1234 + rank)
     table = torch.from_numpy(env.feature_table).to(dev).to(dtype)
-    ro = NavRollout(model, table, max_action_len=a.max_action_len, expert_policy="ndtw")     # run_rxr_kdl_valid.sh:29
+    teacher = t_opt = None
+    if a.icod:
+        from types import SimpleNamespace
+        scfg = make_config(a.hidden, role="student", teacher_hidden_size=a.teacher_hidden, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        model = VLNBert(None, role="student", config=scfg, device=dev, compute_dtype=dtype, seed=0)
+        tcfg = make_config(a.teacher_hidden, role="teacher", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        teacher = VLNBert(SimpleNamespace(train_kdl_teacher=True, train_kdl=True), role="teacher", config=tcfg, device=dev, compute_dtype=dtype, seed=1)
+        if world > 1:
+            dist.broadcast(model.store.flat, src=0)
+            dist.broadcast(teacher.store.flat, src=0)
+        model.train()
+        teacher.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
+        t_opt = torch.optim.AdamW(teacher.parameters(), lr=1e-5)      # agent_base.py:133-139
+    kd = dict(alpha=0.5, t_alpha=0.5, temperature=2.0, decay=0.7) if a.icod else None      # run_r2r_kdl_valid.sh:97-104
+    ro = NavRollout(model, table, teacher=teacher, kd=kd, train_teacher=a.icod, max_action_len=a.max_action_len,
+                    expert_policy="ndtw" if not a.icod else "spl")     # run_rxr_kdl_valid.sh:29 / run_r2r_kdl_valid.sh:29
     rng = np.random.default_rng(rank)
 
     def eval_iteration():
@@ -116,12 +136,21 @@ def main():
         if a.mode == "eval":
             return eval_iteration()
         opt.zero_grad()
+        if t_opt is not None:
+            t_opt.zero_grad()
         obs = env.reset(features=False)
         batch = env.batch
-        r1 = ro.run(env, obs, feedback="teacher", train_ml=0.2)
+        rw = None
+        if a.icod:      # MKRW: softmax(randn(5) / rw_temp) * 5 per step (agent.py:866-871)
+            rw = torch.softmax(torch.randn(a.max_action_len, 5, device=dev) / 4.0, -1) * 5
+        r1 = ro.run(env, obs, feedback="teacher", train_ml=0.2, rw_seq=rw)
         obs = env.reset(batch=batch, features=False)
-        r2 = ro.run(env, obs, feedback="sample", train_ml=1.0, sample_draws=rng.uniform(size=(a.max_action_len, a.batch)))
-        (r1["loss"] + r2["loss"]).backward()
+        r2 = ro.run(env, obs, feedback="sample", train_ml=1.0, sample_draws=rng.uniform(size=(a.max_action_len, a.batch)), rw_seq=rw)
+        (r1["loss"] + r2["loss"]).backward(retain_graph=a.icod)       # agent_base.py:260-263
+        if a.icod:
+            (r1["t_loss"] + r2["t_loss"]).backward()                  # agent_base.py:268-269
+            torch.nn.utils.clip_grad_norm_(teacher.parameters(), 40.0)
+            t_opt.step()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 40.0)     # agent_base.py:273
         opt.step()
         return r1["decisions"] + r2["decisions"]
@@ -178,10 +207,10 @@ def main():
                            "top_kernels_share": {k: round(t / all_ms, 4) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]}}}
 
     host_loop = None
-    if rank == 0 and not a.no_host_loop and a.mode == "train":
+    if rank == 0 and not a.no_host_loop and a.mode == "train" and not a.icod:
         host_loop = host_loop_rate(a, model, dev)
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "train":
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "train" and not a.icod:
         cpu = cpu_baseline(a, cfg)
     if rank == 0:
         print(json.dumps({
@@ -193,7 +222,7 @@ def main():
                                    f"paths {a.hops_min}..{a.hops_max} hops, max_action_len {a.max_action_len}",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "views": 36, "feat_dim": 768, "parallelism": f"dp{world}",
                        "decisions_per_iteration": round(dec / a.steps / world, 1)},
-            "mode": a.mode, "ms_per_rollout_step": (round(dt / max(eval_iteration.steps, 1) * 1e3, 3) if a.mode == "eval" else None),
+            "mode": a.mode + ("/icod" if a.icod else ""), "teacher_hidden": a.teacher_hidden if a.icod else None, "ms_per_rollout_step": (round(dt / max(eval_iteration.steps, 1) * 1e3, 3) if a.mode == "eval" else None),
             "roofline": roof, "cpu_baseline": cpu, "host_loop": host_loop}))
     if world > 1:
         dist.destroy_process_group()

@@ -304,7 +304,7 @@ def test_lndot_fwd_bwd(dtype):
 
 # ------------------------------------------------------------------------------------------ losses
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("N", [17, 1000])
+@pytest.mark.parametrize("N", [17, 1000, 50265, 2051])       # >= 2048 in bf16: the 16-byte-vector, one-statistics-pass kernel (MLM vocabulary)
 def test_ce_rows_matches_torch(dtype, N):
     Mr = 9
     ld = (N + 7) // 8 * 8

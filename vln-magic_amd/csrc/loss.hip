@@ -5,6 +5,7 @@
 //   kd_rows : temperature KL of pretrain_src/optim/kd_loss.py:18-41 / map_nav_src/utils/kd_loss.py:27-54
 //   mse     : weighted MSE of kd_loss.py mse_loss, with (outer, inner) strides for head slicing
 #include "common.hpp"
+#include <cstdint>
 
 // one block (256 threads) per row; N may be large (MLM vocab 50265).  logits dtype T (f32/bf16), ld given.
 template <typename T>
@@ -46,6 +47,77 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int M, int N, const T* log
         if (accumulate) g += to_f(d[c]);
       }
       d[c] = from_f<T>(g);     // columns [N, ldd) are zeroed (padding contract of the GEMM loaders)
+    }
+  }
+}
+
+
+// Wide-row variant for bf16 logits (the MLM head: ~570 masked tokens x 50 265 vocabulary entries = 57 MB per step): 16-byte vector
+// loads/stores and ONE statistics pass (online max / sum-exp) instead of two, so a row is read twice and written once.  Same
+// contract as ce_rows_kernel (in-place gradient allowed: a thread only rewrites vectors it has read itself, and x[label] is read
+// by everybody before the first block barrier).  Needs ld, ldd multiples of 8 and 16-byte aligned bases; no accumulate.
+__global__ __launch_bounds__(256) void ce_rows_wide_kernel(int M, int N, const bf16* logits, int ld, const int* labels, int ignore_index,
+                                                           float coef, const float* row_w, float* loss_row, bf16* dlogits, int ldd,
+                                                           float* w_out, float w_rate) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bf16* x = logits + (long long)row * ld;
+  const int lab = labels[row];
+  const bool ignored = (lab == ignore_index) || lab < 0 || lab >= N;
+  const float xl = ignored ? 0.f : to_f(x[lab]);
+  const int nvec = (N + 7) >> 3;
+  float mx = -3.0e38f, s = 0.f;
+  for (int v = tid; v < nvec; v += 256) {
+    const bf16x8 q = *(const bf16x8*)(x + v * 8);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (v * 8 + e < N) ? (float)q[e] : -3.0e38f;
+    float m8 = f[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) m8 = fmaxf(m8, f[e]);
+    const float nm = fmaxf(mx, m8);
+    float a = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a += __expf(f[e] - nm);
+    s = s * __expf(mx - nm) + a;
+    mx = nm;
+  }
+  // merge (max, sum) pairs: wave, then block
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o, 64), os = __shfl_xor(s, o, 64);
+    const float nm = fmaxf(mx, om);
+    s = s * __expf(mx - nm) + os * __expf(om - nm);
+    mx = nm;
+  }
+  if (lane == 0) { red[wid] = mx; red[4 + wid] = s; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  s = red[4] * __expf(red[0] - mx) + red[5] * __expf(red[1] - mx) + red[6] * __expf(red[2] - mx) + red[7] * __expf(red[3] - mx);
+  const float lse = mx + __logf(s);
+  const float loss = ignored ? 0.f : lse - xl;
+  if (tid == 0) {
+    if (loss_row) loss_row[row] = loss;
+    if (w_out) w_out[row] = __expf(-w_rate * loss);
+  }
+  if (dlogits) {
+    const float cf = ignored ? 0.f : coef * (row_w ? row_w[row] : 1.f);
+    bf16* d = dlogits + (long long)row * ldd;
+    const int dvec = ldd >> 3;
+    for (int v = tid; v < dvec; v += 256) {
+      bf16x8 g;
+      if (v < nvec) {
+        const bf16x8 q = *(const bf16x8*)(x + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = v * 8 + e;
+          g[e] = (bf16)(c < N ? cf * (__expf((float)q[e] - lse) - (c == lab ? 1.f : 0.f)) : 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = (bf16)0.f;
+      }
+      *(bf16x8*)(d + v * 8) = g;
     }
   }
 }
@@ -241,7 +313,11 @@ extern "C" int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld
   if (M <= 0 || N <= 0 || ld < N || (dlogits && ldd < N)) return MAGIC_ERR_ARG;
   dim3 grid(M), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16)
+  const bool wide = dtype == DT_BF16 && N >= 2048 && !accumulate && (ld % 8) == 0 && (!dlogits || (ldd % 8) == 0) &&
+                    (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0;
+  if (wide)
+    hipLaunchKernelGGL(ce_rows_wide_kernel, grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, w_out, w_rate);
+  else if (dtype == DT_BF16)
     hipLaunchKernelGGL(ce_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, accumulate, w_out, w_rate);
   else
     hipLaunchKernelGGL(ce_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (float*)dlogits, ldd, accumulate, w_out, w_rate);

@@ -116,6 +116,13 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
   float ag[2 * NIT], ab[2 * NIT];
 #pragma unroll
   for (int i = 0; i < 2 * NIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  // Position-major traversal when a table is indexed by (row % mod) (the position embeddings): logical row i is physical row
+  // (i % Bs) * mod + i / Bs, so the RPI rows a wave handles together share ONE table row and their gradients are merged before the
+  // atomics (measured on the text-embedding backward: every position row took B = 48 same-address atomics per element from 48 different
+  // waves; any bijection of rows is valid -- the rows are independent).
+  const int pm_mod = (d0 && !t0.idx && t0.mod) ? t0.mod : (d1 && !t1.idx && t1.mod) ? t1.mod : (d2 && !t2.idx && t2.mod) ? t2.mod : 0;
+  const int pm_Bs = (pm_mod > 0 && M % pm_mod == 0) ? M / pm_mod : 0;
+  auto phys = [&](int i) { return pm_Bs ? (i % pm_Bs) * pm_mod + i / pm_Bs : i; };
 
   // grid-stride over groups of RPI rows per wave: the RPI rows' loads are issued together and their wave reductions
   // interleave (ILP), instead of one latency-bound row after another; the grid is capped so the per-block
@@ -136,7 +143,7 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
     float s1[RPI], s2[RPI], rs[RPI];
 #pragma unroll
     for (int u = 0; u < RPI; ++u) {
-      const int row = min(base + u, M - 1);          // clamped; rows >= M are masked below
+      const int row = phys(min(base + u, M - 1));    // clamped; rows >= M are masked below
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int c = it * 128 + lane * 2;
@@ -177,8 +184,8 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
     }
 #pragma unroll
     for (int u = 0; u < RPI; ++u) {
-      const int row = base + u;
-      if (row < M) {
+      if (base + u < M) {
+        const int row = phys(base + u);
         if (dx) {
 #pragma unroll
           for (int it = 0; it < NIT; ++it) st2<T>(dx + (long long)row * H + it * 128 + lane * 2, g[u][2 * it], g[u][2 * it + 1]);
@@ -190,29 +197,44 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
             st2<T>(dxm + (long long)row * H + c, g[u][2 * it] * drop_mul(sdx, (unsigned)(row * H + c)), g[u][2 * it + 1] * drop_mul(sdx, (unsigned)(row * H + c + 1)));
           }
         }
-        // table gradients
-#define TAB_GRAD(K, TK, DK, LK, CK)                                                         \
-        if (DK) {                                                                            \
-          if (LK) {                                                                          \
-            float* slot = tacc + (K * 3 + (CK ? 0 : TK.idx[row])) * H;                       \
+      }
+    }
+    // table gradients.  LDS-slot tables: LDS atomics per row.  Indexed tables: consecutive rows of the wave's group that hit the SAME
+    // table row (position-major traversal above; runs of step id 0 in the map-token table) are summed in registers first.
+#define TAB_GRAD(K, TK, DK, LK, CK)                                                          \
+    if (DK) {                                                                                \
+      if (LK) {                                                                              \
+        _Pragma("unroll") for (int u = 0; u < RPI; ++u)                                      \
+          if (base + u < M) {                                                                \
+            float* slot = tacc + (K * 3 + (CK ? 0 : TK.idx[phys(base + u)])) * H;            \
             _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                             \
               const int c = it * 128 + lane * 2;                                             \
               atomicAdd(slot + c, g[u][2 * it]); atomicAdd(slot + c + 1, g[u][2 * it + 1]);  \
             }                                                                                \
-          } else {                                                                           \
-            float* dst = DK + (long long)tab_row(TK, row) * H;                               \
-            _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                             \
-              const int c = it * 128 + lane * 2;                                             \
-              atomicAdd(dst + c, g[u][2 * it]); atomicAdd(dst + c + 1, g[u][2 * it + 1]);    \
+          }                                                                                  \
+      } else {                                                                               \
+        float run[2 * NIT];                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 2 * NIT; ++i) run[i] = 0.f;                    \
+        _Pragma("unroll") for (int u = 0; u < RPI; ++u)                                      \
+          if (base + u < M) {                                                                \
+            const int tr = tab_row(TK, phys(base + u));                                      \
+            const bool more = (u + 1 < RPI) && (base + u + 1 < M) && tab_row(TK, phys(base + u + 1)) == tr;   \
+            _Pragma("unroll") for (int i = 0; i < 2 * NIT; ++i) run[i] += g[u][i];           \
+            if (!more) {                                                                     \
+              float* dst = DK + (long long)tr * H;                                           \
+              _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                           \
+                const int c = it * 128 + lane * 2;                                           \
+                atomicAdd(dst + c, run[2 * it]); atomicAdd(dst + c + 1, run[2 * it + 1]);    \
+                run[2 * it] = 0.f; run[2 * it + 1] = 0.f;                                    \
+              }                                                                              \
             }                                                                                \
           }                                                                                  \
-        }
-        TAB_GRAD(0, t0, d0, l0, c0)
-        TAB_GRAD(1, t1, d1, l1, c1)
-        TAB_GRAD(2, t2, d2, l2, c2)
-#undef TAB_GRAD
-      }
+      }                                                                                      \
     }
+    TAB_GRAD(0, t0, d0, l0, c0)
+    TAB_GRAD(1, t1, d1, l1, c1)
+    TAB_GRAD(2, t2, d2, l2, c2)
+#undef TAB_GRAD
   }
   const bool pg = do_ln && dgamma != nullptr;      // gamma/beta grads here, or by ln_pgrad_kernel (dgamma == nullptr)
   if (pg) {

@@ -128,9 +128,9 @@ def main():
         obs = env.reset(features=False)
         with torch.no_grad():
             r = ro.run(env, obs, feedback="argmax", train_ml=1.0, grad=False)
-        eval_iteration.steps += r["n_steps"]
+        counters["rollout_steps"] += r["n_steps"]
         return r["decisions"]
-    eval_iteration.steps = 0
+    counters = {"rollout_steps": 0}
 
     def iteration():
         if a.mode == "eval":
@@ -163,7 +163,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     dec = 0
-    eval_iteration.steps = 0
+    counters["rollout_steps"] = 0
     for _ in range(a.steps):
         dec += iteration()
     torch.cuda.synchronize()
@@ -222,7 +222,7 @@ def main():
                                    f"paths {a.hops_min}..{a.hops_max} hops, max_action_len {a.max_action_len}",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "views": 36, "feat_dim": 768, "parallelism": f"dp{world}",
                        "decisions_per_iteration": round(dec / a.steps / world, 1)},
-            "mode": a.mode + ("/icod" if a.icod else ""), "teacher_hidden": a.teacher_hidden if a.icod else None, "ms_per_rollout_step": (round(dt / max(eval_iteration.steps, 1) * 1e3, 3) if a.mode == "eval" else None),
+            "mode": a.mode + ("/icod" if a.icod else ""), "teacher_hidden": a.teacher_hidden if a.icod else None, "ms_per_rollout_step": (round(dt / max(counters["rollout_steps"], 1) * 1e3, 3) if a.mode == "eval" else None),
             "roofline": roof, "cpu_baseline": cpu, "host_loop": host_loop}))
     if world > 1:
         dist.destroy_process_group()

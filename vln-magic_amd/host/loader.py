@@ -15,7 +15,7 @@ module adds is the part specific to the HIP engine:
 import numpy as np
 import torch
 
-from .plan import build_plan_host, plan_to_device
+from .plan import build_plan_host
 
 MODEL_KEYS = ("traj_view_img_fts", "traj_vp_row", "traj_view_order", "traj_loc_fts", "gmap_pos_fts", "gmap_pair_dists", "vp_pos_fts",
               "global_act_labels", "local_act_labels")      # the batch entries the model reads; everything else is in the plan

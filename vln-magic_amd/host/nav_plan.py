@@ -25,7 +25,6 @@ import numpy as np
 from .graph_map import MAX_DIST, MAX_STEP, GraphMap, angle_fts, rel_pos
 
 IGNORE = -100
-R30 = math.radians(30)
 
 
 def _csr_from_coo(out_rows, src_rows, w, n_out):
@@ -75,8 +74,6 @@ class NavPlanner:
         self.gmaps = [GraphMap(ob["viewpoint"]) for ob in obs]
         for g, ob in zip(self.gmaps, obs):
             g.update_graph(ob)
-        self.scanvp_cands = {}
-        self._note_cands(obs)
         self.traj = [dict(instr_id=ob["instr_id"], path=[[ob["viewpoint"]]]) for ob in obs]
         self.ended = np.zeros(self.B, bool)
         self.just_ended = np.zeros(self.B, bool)
@@ -96,11 +93,6 @@ class NavPlanner:
         self._dtw = {}                             # episode -> (nodes consumed, DTW row) of the walked path
         self.t = 0
 
-    def _note_cands(self, obs):
-        for ob in obs:
-            d = self.scanvp_cands.setdefault((ob["scan"], ob["viewpoint"]), {})
-            for c in ob["candidate"]:
-                d[c["viewpointId"]] = c["pointId"]
 
     # ---- language (agent.py:63-90) -----------------------------------------------------------------------------
     def language(self):
@@ -340,7 +332,6 @@ class NavPlanner:
             if not self.ended[i] and self.just_ended[i]:
                 self.end_obs_vp[i] = obs[i]["viewpoint"]
         self.obs = obs = self.env._get_obs(features)
-        self._note_cands(obs)
         for i, ob in enumerate(obs):
             if not self.ended[i]:
                 self.gmaps[i].update_graph(ob)

@@ -10,7 +10,7 @@ agg = collections.defaultdict(list)
 for f in glob.glob("/tmp/kt/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if pat in r["Kernel_Name"]:
-            key = (r["Kernel_Name"][:48], r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Workgroup_Size_X", "?"))
+            key = (r["Kernel_Name"][:48], "x".join(str(r.get(k, "?")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")), r.get("Workgroup_Size_X", "?"))
             agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     print(k, "n=%d avg=%.1f us min=%.1f max=%.1f" % (len(v), sum(v) / len(v), min(v), max(v)))

@@ -225,6 +225,8 @@ __global__ __launch_bounds__(256) void attn_fwd_pair_kernel(AttnParams a, AttnPa
   attn_fwd_body<T>(p, local % nqt, (local / nqt) % p.nh, local / (nqt * p.nh), smem_dyn);
 }
 
+__host__ __device__ static inline bool bwd_alias(int NQP, int NKP, int PS, int DS) { return NQP <= 64 && NQP * PS <= NKP * DS; }
+
 template <typename T>
 __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, const int b, unsigned char* smem_raw, float* red) {
   typedef typename AT<T>::vec vec;
@@ -235,7 +237,11 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
   T* sK = sdO + NQP * DS;           // [NKP][DS]
   T* sV = sK + NKP * DS;            // [NKP][DS]
   T* sP = sV + NKP * DS;            // [NQP][PS]
-  T* sdS = sP + NQP * PS;           // [NQP][PS]
+  // dS normally has its own [NQP][PS] image.  With at most one query tile per wave (NQP <= 64) it can live in V's image, which is
+  // dead once every wave has finished its dP = dO V^T products (one extra barrier): 9 KB less LDS per workgroup, which is what lets
+  // a third panorama workgroup (Nq = Nk = 36) fit on a CU -- 540 workgroups then run in one round instead of two.
+  const bool alias = bwd_alias(NQP, NKP, PS, DS);
+  T* sdS = alias ? sV : sP + NQP * PS;           // [NQP][PS]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
   load_rows<T>(sQ, (const T*)p.q + (long long)b * p.Nq * p.ldq + h * HD, p.ldq, p.Nq, NQP);
   load_rows<T>(sdO, (const T*)p.dctx + (long long)b * p.Nq * p.H + h * HD, p.H, p.Nq, NQP);
@@ -259,8 +265,8 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
   const int NT = NKP / 16;
   const DropState ds_ = drop_init(p.drop);
   float a0 = 0.f, a1 = 0.f;
-  for (int qt = w; qt < NQP / 16; qt += 4) {
-    f32x4 acc[8];
+  auto dP_mma = [&](const int qt, f32x4 (&acc)[8]) {
+
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -270,6 +276,8 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
       for (int j = 0; j < 8; ++j)
         if (j < NT) acc[j] = mma(a, fragKC(sV, DS, j * 16, ks * KSTEP, lane), acc[j]);
     }
+  };
+  auto dS_write = [&](const int qt, f32x4 (&acc)[8]) {
     float pv[8][4];
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -305,6 +313,19 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
           if (p.dist && q < p.Nq && key < p.Nk) { a0 += ds * p.dist[((long long)b * p.Nq + q) * p.Nk + key]; a1 += ds; }
         }
       }
+    };
+  if (alias) {
+    f32x4 acc[8];
+    const bool has = w < NQP / 16;          // NQP <= 64: at most one query tile per wave
+    if (has) dP_mma(w, acc);
+    __syncthreads();                        // every wave is done reading V: its image becomes dS
+    if (has) dS_write(w, acc);
+  } else {
+    for (int qt = w; qt < NQP / 16; qt += 4) {
+      f32x4 acc[8];
+      dP_mma(qt, acc);
+      dS_write(qt, acc);
+    }
   }
   if (p.dsprel_w) {
     a0 = wave_sum(a0); a1 = wave_sum(a1);
@@ -383,8 +404,8 @@ static size_t fwd_lds(int dtype, int Nk) {
 }
 static size_t bwd_lds(int dtype, int Nq, int Nk) {
   const int NQP = (Nq + 31) / 32 * 32, NKP = (Nk + 31) / 32 * 32;
-  if (dtype == DT_BF16) return (size_t)(2 * NQP * 72 + 2 * NKP * 72 + 2 * NQP * (NKP + 8)) * 2;
-  return (size_t)(2 * NQP * 68 + 2 * NKP * 68 + 2 * NQP * (NKP + 4)) * 4;
+  if (dtype == DT_BF16) return (size_t)(2 * NQP * 72 + 2 * NKP * 72 + (bwd_alias(NQP, NKP, NKP + 8, 72) ? 1 : 2) * NQP * (NKP + 8)) * 2;
+  return (size_t)(2 * NQP * 68 + 2 * NKP * 68 + (bwd_alias(NQP, NKP, NKP + 4, 68) ? 1 : 2) * NQP * (NKP + 4)) * 4;
 }
 #define LDS_MAX (160 * 1024)
 

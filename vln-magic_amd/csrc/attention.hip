@@ -7,6 +7,7 @@
 // Limits: head dim 64, Nk <= 128 (forward), Nq, Nk <= 128 bf16 / <= 64 fp32 (backward; LDS).  Longer sequences
 // (RxR, 512 tokens) take the unfused GEMM + softmax path of the engine.
 #include "common.hpp"
+#include <cstdlib>
 #include "group.hpp"
 
 #define HD 64
@@ -62,7 +63,7 @@ template <typename T>
 __device__ __forceinline__ void load_rows(T* s, const T* src, long long ld, int nvalid, int rows_pad) {
   typedef typename AT<T>::vec vec;
   constexpr int VE = AT<T>::VE, DS = AT<T>::DS, VPR = HD / VE;
-  for (int id = threadIdx.x; id < rows_pad * VPR; id += 256) {
+  for (int id = threadIdx.x; id < rows_pad * VPR; id += blockDim.x) {
     const int r = id / VPR, c = (id % VPR) * VE;
     vec z;
 #pragma unroll
@@ -227,7 +228,9 @@ __global__ __launch_bounds__(256) void attn_fwd_pair_kernel(AttnParams a, AttnPa
 
 __host__ __device__ static inline bool bwd_alias(int NQP, int NKP, int PS, int DS) { return NQP <= 64 && NQP * PS <= NKP * DS; }
 
-template <typename T>
+// NW waves per workgroup: 4, or 8 when a side has more than 64 rows (text self-attention, 80 x 80: six 16-row tiles per phase --
+// with 4 waves two of them do two tiles in every phase and the whole workgroup waits for them)
+template <typename T, int NW>
 __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, const int b, unsigned char* smem_raw, float* red) {
   typedef typename AT<T>::vec vec;
   constexpr int VE = AT<T>::VE, KSTEP = AT<T>::KSTEP, DS = AT<T>::DS;
@@ -251,7 +254,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
   {
     const T* Pg = (const T*)p.P + prow0 * p.ldp;
     const int cpr = PS / VE;          // PS is a multiple of VE
-    for (int id = tid; id < NQP * cpr; id += 256) {
+    for (int id = tid; id < NQP * cpr; id += NW * 64) {
       const int r = id / cpr, c = (id % cpr) * VE;
       vec z;
 #pragma unroll
@@ -321,7 +324,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
     __syncthreads();                        // every wave is done reading V: its image becomes dS
     if (has) dS_write(w, acc);
   } else {
-    for (int qt = w; qt < NQP / 16; qt += 4) {
+    for (int qt = w; qt < NQP / 16; qt += NW) {
       f32x4 acc[8];
       dP_mma(qt, acc);
       dS_write(qt, acc);
@@ -329,15 +332,18 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
   }
   if (p.dsprel_w) {
     a0 = wave_sum(a0); a1 = wave_sum(a1);
-    if (lane == 0) { red[w] = a0; red[4 + w] = a1; }
+    if (lane == 0) { red[w] = a0; red[NW + w] = a1; }
   }
   __syncthreads();
   if (p.dsprel_w && tid == 0) {
-    atomicAdd(p.dsprel_w, red[0] + red[1] + red[2] + red[3]);
-    atomicAdd(p.dsprel_b, red[4] + red[5] + red[6] + red[7]);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { s0 += red[i]; s1 += red[NW + i]; }
+    atomicAdd(p.dsprel_w, s0);
+    atomicAdd(p.dsprel_b, s1);
   }
   // ---- phase 2: dQ = dS K ; dK = dS^T Q ; dV = P^T dO        (tiles of 16 rows x 64 head dims, round-robin over waves)
-  for (int qt = w; qt < NQP / 16; qt += 4) {
+  for (int qt = w; qt < NQP / 16; qt += NW) {
     f32x4 o[4];
 #pragma unroll
     for (int jd = 0; jd < 4; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -354,7 +360,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
         if (q < p.Nq) ((T*)p.dq)[((long long)b * p.Nq + q) * p.lddq + h * HD + jd * 16 + c16] = from_f<T>(o[jd][r]);
       }
   }
-  for (int kt = w; kt < NKP / 16; kt += 4) {
+  for (int kt = w; kt < NKP / 16; kt += NW) {
     f32x4 ok_[4], ov[4];
 #pragma unroll
     for (int jd = 0; jd < 4; ++jd) { ok_[jd] = (f32x4){0.f, 0.f, 0.f, 0.f}; ov[jd] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -381,20 +387,20 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-  __shared__ float red[8];
-  attn_bwd_body<T>(p, blockIdx.x, blockIdx.y, smem_dyn, red);
+  __shared__ float red[2 * NW];
+  attn_bwd_body<T, NW>(p, blockIdx.x, blockIdx.y, smem_dyn, red);
 }
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_pair_kernel(AttnParams a, AttnParams b, int nA) {
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_pair_kernel(AttnParams a, AttnParams b, int nA) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-  __shared__ float red[8];
+  __shared__ float red[2 * NW];
   const bool first = (int)blockIdx.x < nA;
   const AttnParams& p = first ? a : b;
   const int local = first ? blockIdx.x : blockIdx.x - nA;
-  attn_bwd_body<T>(p, local % p.nh, local / p.nh, smem_dyn, red);
+  attn_bwd_body<T, NW>(p, local % p.nh, local / p.nh, smem_dyn, red);
 }
 
 static size_t fwd_lds(int dtype, int Nk) {
@@ -485,21 +491,32 @@ extern "C" int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const vo
   return launch_attn_bwd(dtype, 0, &p, nullptr, (hipStream_t)stream);
 }
 
+static int bwd_waves8(const AttnParams& p) {
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("MAGIC_ATTN_BWD_WAVES"); mode = e ? atoi(e) : 0; }      // 4 / 8 force, 0 = by shape
+  if (mode == 4) return 0;
+  if (mode == 8) return 1;
+  return (p.Nq > 64 || p.Nk > 64) ? 1 : 0;
+}
+
 int launch_attn_bwd(int dtype, int, const void* pa, const void* pb, hipStream_t st) {
   const AttnParams& a = *(const AttnParams*)pa;
-  dim3 block(256);
   if (!pb) {
     dim3 grid(a.nh, a.B);
     const size_t shm = bwd_lds(dtype, a.Nq, a.Nk);
-    if (dtype == DT_BF16) { set_lds(attn_bwd_kernel<bf16>, shm); hipLaunchKernelGGL(attn_bwd_kernel<bf16>, grid, block, shm, st, a); }
-    else { set_lds(attn_bwd_kernel<float>, shm); hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, shm, st, a); }
+#define LB(TY, NW) do { set_lds(attn_bwd_kernel<TY, NW>, shm); hipLaunchKernelGGL((attn_bwd_kernel<TY, NW>), grid, dim3(NW * 64), shm, st, a); } while (0)
+    if (bwd_waves8(a)) { if (dtype == DT_BF16) LB(bf16, 8); else LB(float, 8); }
+    else { if (dtype == DT_BF16) LB(bf16, 4); else LB(float, 4); }
+#undef LB
     return launch_status();
   }
   const AttnParams& b = *(const AttnParams*)pb;
   const int nA = a.nh * a.B, nB = b.nh * b.B;
   const size_t sa = bwd_lds(dtype, a.Nq, a.Nk), sb = bwd_lds(dtype, b.Nq, b.Nk), shm = sa > sb ? sa : sb;
   dim3 grid(nA + nB);
-  if (dtype == DT_BF16) { set_lds(attn_bwd_pair_kernel<bf16>, shm); hipLaunchKernelGGL(attn_bwd_pair_kernel<bf16>, grid, block, shm, st, a, b, nA); }
-  else { set_lds(attn_bwd_pair_kernel<float>, shm); hipLaunchKernelGGL(attn_bwd_pair_kernel<float>, grid, block, shm, st, a, b, nA); }
+#define LP(TY, NW) do { set_lds(attn_bwd_pair_kernel<TY, NW>, shm); hipLaunchKernelGGL((attn_bwd_pair_kernel<TY, NW>), grid, dim3(NW * 64), shm, st, a, b, nA); } while (0)
+  if (bwd_waves8(a) || bwd_waves8(b)) { if (dtype == DT_BF16) LP(bf16, 8); else LP(float, 8); }
+  else { if (dtype == DT_BF16) LP(bf16, 4); else LP(float, 4); }
+#undef LP
   return launch_status();
 }

@@ -850,6 +850,24 @@ __device__ __forceinline__ void linear_lnb_body(const LlbParams& pp, const int b
   };
   const int ktiles = (K + BK - 1) / BK;
   load(0);
+  // epilogue operands (residual gradient R, the LayerNorm output y, rstd) are fetched before the K loop: after it they were two
+  // more dependent round trips to memory per workgroup
+  const T* __restrict__ R = (const T*)pp.R; const T* __restrict__ Y = (const T*)pp.y;
+  float rv[2][HT][4], yv[2][HT][4], rsv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + i * 16 + 4 * g + r;
+      const bool live = row < M;
+      rsv[i][r] = live ? pp.rstd[row] : 0.f;
+#pragma unroll
+      for (int j = 0; j < HT; ++j) {
+        const int col = w * WC + j * 16 + c16;
+        rv[i][j][r] = (live && R) ? to_f(R[(long long)row * pp.ldr + col]) : 0.f;
+        yv[i][j][r] = live ? to_f(Y[(long long)row * H + col]) : 0.f;
+      }
+    }
   for (int kt = 0; kt < ktiles; ++kt) {
     store();
     __syncthreads();
@@ -872,7 +890,6 @@ __device__ __forceinline__ void linear_lnb_body(const LlbParams& pp, const int b
     __syncthreads();
   }
   // ---- epilogue: v = acc + R ; LayerNorm backward over the full row (cross-wave) ; parameter gradients
-  const T* __restrict__ R = (const T*)pp.R; const T* __restrict__ Y = (const T*)pp.y;
   float gm[HT], bt[HT], ig[HT];
 #pragma unroll
   for (int j = 0; j < HT; ++j) {
@@ -893,11 +910,10 @@ __device__ __forceinline__ void linear_lnb_body(const LlbParams& pp, const int b
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int j = 0; j < HT; ++j) {
-        const int col = w * WC + j * 16 + c16;
         float v = 0.f, x = 0.f;
         if (live) {
-          v = acc[i][j][r] + (R ? to_f(R[(long long)row * pp.ldr + col]) : 0.f);
-          x = (to_f(Y[(long long)row * H + col]) - bt[j]) * ig[j];
+          v = acc[i][j][r] + rv[i][j][r];
+          x = (yv[i][j][r] - bt[j]) * ig[j];
         }
         pg[j] += v * x; pb[j] += v;
         const float ga = v * gm[j];
@@ -928,7 +944,7 @@ __device__ __forceinline__ void linear_lnb_body(const LlbParams& pp, const int b
       if (row < M) {
         const float m1 = (red[rr] + red[32 + rr] + red[64 + rr] + red[96 + rr]) / H;
         const float m2 = (red[128 + rr] + red[160 + rr] + red[192 + rr] + red[224 + rr]) / H;
-        const float rs = pp.rstd[row];
+        const float rs = rsv[i][r];
 #pragma unroll
         for (int j = 0; j < HT; ++j) {
           const int col = w * WC + j * 16 + c16;

@@ -190,9 +190,11 @@ def main():
                          "batch carries 37 int32 per panorama, gathered on the device")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse the N > 1 code path with several ranks on ONE card")
-    ap.add_argument("--teacher", default="ahead", choices=["ahead", "same"],
-                    help="ahead: the frozen teacher runs on batch i+1 (side stream) while the student trains on batch i; "
-                         "same: teacher and student forward of the same batch side by side (every step runs one of each either way)")
+    ap.add_argument("--teacher", default="split", choices=["split", "ahead", "same"],
+                    help="split (default): the frozen teacher's forward on batch i+1 is its own HIP graph on a side stream, replayed while the "
+                         "student's graph trains on batch i (and, with data parallelism, while the gradient all-reduce and the optimizer run); "
+                         "ahead: the same overlap as a fork/join inside ONE graph; same: teacher and student forward of the same batch side by "
+                         "side (every step runs exactly one teacher forward and one student update in all three)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -246,7 +248,7 @@ def main():
         # step: teacher fwd, student fwd+losses+bwd, clip, AdamW -- with lr / bias-correction / MKRW read from device memory
         run_eager(min(3, len(pool)))                       # allocator + code-object warm-up
         torch.cuda.synchronize()
-        if a.teacher == "ahead":
+        if a.teacher in ("ahead", "split"):
             # graph i: student step on batch i (teacher outputs t[i] are ready) || teacher forward on batch i+1 -> t[i+1];
             # t[0] is primed eagerly once, and the last graph of the ring copies its teacher(batch 0) outputs into it
             n = len(pool)
@@ -254,7 +256,8 @@ def main():
             t0 = trainer.teacher_forward(*trip(0))
             t_cur, graphs = t0, []
             for i in range(n):
-                cs = trainer.capture_ahead(trip(i), t_cur, trip(i + 1), t_next_into=t0 if i == n - 1 else None)
+                cap = trainer.capture_ahead if a.teacher == "ahead" else trainer.capture_split
+                cs = cap(trip(i), t_cur, trip(i + 1), t_next_into=t0 if i == n - 1 else None)
                 graphs.append(cs)
                 t_cur = cs.t_next
         else:
@@ -265,7 +268,7 @@ def main():
         traj = 0
         for s in range(n):
             cs = graphs[(start + s) % len(graphs)]
-            trainer.replay(cs)
+            (trainer.replay_split if a.teacher == "split" else trainer.replay)(cs)
             traj += cs.traj_steps
         return traj
 
@@ -363,7 +366,7 @@ def main():
                 "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": a.dtype, "data": "synthetic", "launch": a.mode if a.mode != "stream" else f"stream/{a.ingest}/{a.workers}w",
-                "teacher_schedule": ("one batch ahead of the student (side stream)" if (a.teacher == "ahead" and a.mode == "graph") else "same batch, side stream"),
+                "teacher_schedule": ({"split": "one batch ahead of the student, own graph on a side stream", "ahead": "one batch ahead of the student (fork/join inside the step graph)"}.get(a.teacher, "same batch, side stream") if a.mode == "graph" else "same batch, side stream"),
                 "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "
                                        "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip, student in train() mode",
                            "dropout": a.dropout,

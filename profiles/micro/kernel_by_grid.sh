@@ -2,6 +2,7 @@
 # per-call durations of one kernel family grouped by launch grid (which call sites are the slow ones): bash kernel_by_grid.sh ln_bwd
 R=$GRAFT_REPO_ROOT; PAT=${1-ln_bwd}
 cd /tmp && export TMPDIR=/tmp
+[ -n "$LOCKSTEP" ] && export MAGIC_LOCKSTEP_EAGER=1      # LOCKSTEP=1: the paired launch structure of the captured graphs
 rm -rf /tmp/kt && rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python3 $R/bench.py --mode eager --steps 6 --warmup 3 --no-cpu-baseline --no-profile > /dev/null 2> /tmp/kt.err
 python3 - "$PAT" <<'EOF'
 import csv, glob, sys, collections

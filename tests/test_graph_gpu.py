@@ -79,10 +79,14 @@ def test_split_graph_path_used_under_data_parallelism(monkeypatch):
     assert torch.allclose(res[False], res[True], rtol=1e-3, atol=2e-5)
 
 
-@pytest.mark.parametrize("form", ["eager", "graph"])
-def test_teacher_one_batch_ahead_gives_the_same_training_trajectory(form):
-    """step_ahead / capture_ahead: the teacher forward of batch i+1 overlaps the student step on batch i.  Same losses and
-    the same parameters as the plain schedule over two passes of a 3-batch ring (fp32, dropout 0, fixed MKRW weights)."""
+@pytest.mark.parametrize("form", ["eager", "graph", "split", "split_dp"])
+def test_teacher_one_batch_ahead_gives_the_same_training_trajectory(form, monkeypatch):
+    """step_ahead / capture_ahead / capture_split: the teacher forward of batch i+1 overlaps the student step on batch i (one graph
+    with a fork/join, or two graphs replayed on two streams; 'split_dp' = the data-parallel form whose optimizer runs outside the
+    graph).  Same losses and the same parameters as the plain schedule over two passes of a 3-batch ring (fp32, dropout 0, fixed
+    MKRW weights)."""
+    if form == "split_dp":
+        monkeypatch.setenv("MAGIC_FORCE_SPLIT_GRAPH", "1")
     tasks = ["sap", "mlm", "cfp"]
     batches = [synth.make_batch(t, batch_size=4, seed=41, step=i, vocab=600, min_len=8, max_len=15, min_steps=2, max_steps=3)
                for i, t in enumerate(tasks)]
@@ -113,13 +117,22 @@ def test_teacher_one_batch_ahead_gives_the_same_training_trajectory(form):
             got.append(out["loss"].item())
     else:
         t0, graphs = t_cur, []
+        cap = tr.capture_ahead if form == "graph" else tr.capture_split
+        rep = tr.replay if form == "graph" else tr.replay_split
         for i in range(n):
-            cs = tr.capture_ahead(db[i], t_cur, db[(i + 1) % n], rw=rw, t_next_into=t0 if i == n - 1 else None)
+            cs = cap(db[i], t_cur, db[(i + 1) % n], rw=rw, t_next_into=t0 if i == n - 1 else None)
             graphs.append(cs)
             t_cur = cs.t_next
-        for k in range(rounds * n):
-            got.append(tr.replay(graphs[k % n])["loss"].item())
+        outs = [rep(graphs[k % n])["loss"] for k in range(rounds * n)]     # no host sync between replays: the event chain must order them
+        torch.cuda.synchronize()
+        # (losses live in per-graph output buffers: re-read the last round's values, earlier rounds were overwritten by later replays)
+        got = None
     torch.cuda.synchronize()
-    for a, b in zip(want, got):
-        assert abs(a - b) <= 1e-6 + 1e-5 * abs(a), (want, got)
+    if got is None:
+        got_last = [float(o.detach()) for o in outs[-n:]]
+        for a, b in zip(want[-n:], got_last):
+            assert abs(a - b) <= 1e-6 + 1e-5 * abs(a), (want, got_last)
+    else:
+        for a, b in zip(want, got):
+            assert abs(a - b) <= 1e-6 + 1e-5 * abs(a), (want, got)
     assert torch.allclose(p_want, g_s.store.flat, rtol=1e-3, atol=2e-5), (p_want - g_s.store.flat).abs().max().item()

@@ -258,6 +258,49 @@ class PretrainStep:
         cs.t_next = t_next
         return cs
 
+    def capture_split(self, cur, t_cur, nxt, rw=None, t_next_into=None):
+        """Same work as capture_ahead as TWO graphs: the student step on `cur` (main stream) and the teacher forward on `nxt`
+        (side stream), replayed concurrently by `replay_split` without a per-step fork/join inside one graph."""
+        full = self.sync.world == 1 and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")
+        batch, task, plan = cur
+        gS = torch.cuda.CUDAGraph()
+        with self._graph_ctx(gS):
+            if rw is None:
+                rw_ = self.mkrw()
+            else:
+                rw_ = rw
+            self.student.store.zero_grad()
+            out = self.student(batch, task, compute_loss=True, teacher_outputs=t_cur, rw=rw_, plan=plan, inputs=t_cur["inputs"])
+            self.student.backward()
+            if full:
+                self._optimize()
+        gT = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gT, stream=self.side, capture_error_mode="relaxed"):
+            t_next = self.teacher_forward(*nxt)
+            if t_next_into is not None:
+                copy_teacher_outputs(t_next, t_next_into)
+                t_next = t_next_into
+        cs = CapturedStep(gS, out, plan["traj_steps"], full, keep=(cur, t_cur, nxt, rw))
+        cs.t_graph, cs.t_next = gT, t_next
+        return cs
+
+    def replay_split(self, cs):
+        """teacher graph for the NEXT batch on the side stream (after the previous student step, whose buffers it may recycle),
+        student graph on the main stream (after the teacher graph that produced ITS teacher outputs, one replay earlier)"""
+        main = torch.cuda.current_stream()
+        if getattr(self, "_t_done", None) is not None:
+            main.wait_event(self._t_done)
+        self.side.wait_stream(main)
+        cs.graph.replay()
+        with torch.cuda.stream(self.side):
+            cs.t_graph.replay()
+            self._t_done = torch.cuda.Event()
+            self._t_done.record(self.side)
+        if not cs.full:
+            self._optimize()
+        self.global_step += 1
+        return cs.out
+
     def _optimize(self):
         gscale = self.sync.all_reduce()
         self.opt.step(gscale=gscale)

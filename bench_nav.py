@@ -87,6 +87,10 @@ def main():
                     help="BASELINE config 3: MAGIC-L teacher (trainable, --teacher-hidden) + student (--hidden) co-training -- MAKD t2s for the "
                          "student, reverse s2t for the teacher, both losses back-propagated, two optimizers (agent_base.py:260-279)")
     ap.add_argument("--teacher-hidden", type=int, default=768)
+    ap.add_argument("--fuse-rollouts", action="store_true",
+                    help="run the iteration's two rollouts as ONE batch of 2B episodes (per-episode feedback / loss weight, text encoded once) "
+                         "instead of one after the other as the reference does: 27 %% fewer launches and 11 %% less kernel time, but the same wall "
+                         "time -- every step then waits for the 'sample' half's action copy and the 2B-episode plan (measured 329 vs 332 ms)")
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="eval: greedy inference rollouts (feedback 'argmax', no grad, model.eval()) -- decisions/s and ms per step")
     a = ap.parse_args()
@@ -143,9 +147,18 @@ def main():
         rw = None
         if a.icod:      # MKRW: softmax(randn(5) / rw_temp) * 5 per step (agent.py:866-871)
             rw = torch.softmax(torch.randn(a.max_action_len, 5, device=dev) / 4.0, -1) * 5
-        r1 = ro.run(env, obs, feedback="teacher", train_ml=0.2, rw_seq=rw)
-        obs = env.reset(batch=batch, features=False)
-        r2 = ro.run(env, obs, feedback="sample", train_ml=1.0, sample_draws=rng.uniform(size=(a.max_action_len, a.batch)), rw_seq=rw)
+        if not a.fuse_rollouts or a.icod:
+            r1 = ro.run(env, obs, feedback="teacher", train_ml=0.2, rw_seq=rw)
+            obs = env.reset(batch=batch, features=False)
+            r2 = ro.run(env, obs, feedback="sample", train_ml=1.0, sample_draws=rng.uniform(size=(a.max_action_len, a.batch)), rw_seq=rw)
+        else:
+            # the two rollouts are independent per episode: one batch of 2B episodes with per-episode feedback and loss weight, text
+            # encoded once (tests/test_rollout_gpu.py: same logits, summed loss and gradients as the separate rollouts)
+            B = a.batch
+            obs = env.reset(batch=batch + batch, features=False)
+            draws = np.concatenate([np.zeros((a.max_action_len, B)), rng.uniform(size=(a.max_action_len, B))], 1)
+            r1 = ro.run(env, obs, feedback=["teacher"] * B + ["sample"] * B, train_ml=[0.2] * B + [1.0] * B, sample_draws=draws, text_copies=2)
+            r2 = {"loss": 0.0, "decisions": 0}
         (r1["loss"] + r2["loss"]).backward(retain_graph=a.icod)       # agent_base.py:260-263
         if a.icod:
             (r1["t_loss"] + r2["t_loss"]).backward()                  # agent_base.py:268-269
@@ -217,7 +230,8 @@ def main():
             "metric": "trajectory-steps/sec (whole node), navigator step loop, MAGIC-L fine-tune", "value": round(dec / dt, 2),
             "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"navigator loop (agent_base.py:215-296 iteration = teacher-forced + DAgger 'sample' rollout, backward, clip 40, "
+            "config": {"rollouts": "separate" if (not a.fuse_rollouts or a.icod) else "one batch of 2B episodes",
+                       "workload": f"navigator loop (agent_base.py:215-296 iteration = teacher-forced + DAgger 'sample' rollout, backward, clip 40, "
                                    f"torch AdamW), VLNBert H={a.hidden} 6+2+3 layers, dropout 0.1, expert ndtw, instructions U{{{a.instr_min}..{a.instr_max}}} tokens, "
                                    f"paths {a.hops_min}..{a.hops_max} hops, max_action_len {a.max_action_len}",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "views": 36, "feat_dim": 768, "parallelism": f"dp{world}",

@@ -169,6 +169,46 @@ def test_icod_cotraining_rollout_matches_oracle():
     _check_grads(g_t, o_t)
 
 
+def test_two_rollouts_as_one_batch_equal_two_separate_rollouts():
+    """An iteration's teacher-forced (ml_weight 0.2) and DAgger 'sample' (weight 1) rollouts on the same episodes, run as ONE batch of
+    2B episodes with per-episode feedback and the text encoder / K-V projections computed once: same per-step logits, same summed loss,
+    same gradients as the two separate rollouts (agent_base.py:243-263 adds the two losses before backward)."""
+    cfg = make_config(128, role="student", **KW)
+    _, g_s = _pair(cfg, "student", 5)
+    B, T = 4, 6
+    env = _env(23, B=B)
+    batch = [env._draw_episode() for _ in range(B)]
+    draws = np.random.default_rng(1).uniform(size=(T, B))
+    table = torch.from_numpy(env.feature_table).to(DEV)
+    ro = NavRollout(g_s, table, max_action_len=T)
+    g_s.store.zero_grad()
+    r1 = ro.run(env, env.reset(batch=batch, features=False), feedback="teacher", train_ml=0.2, record=True)
+    r2 = ro.run(env, env.reset(batch=batch, features=False), feedback="sample", train_ml=1.0, sample_draws=draws, record=True)
+    (r1["loss"] + r2["loss"]).backward()
+    torch.cuda.synchronize()
+    want_loss, want_grad = float((r1["loss"] + r2["loss"]).detach()), g_s.store.grad.clone()
+    env2 = _env(23, B=2 * B)
+    g_s.store.zero_grad()
+    draws2 = np.concatenate([np.zeros((T, B)), draws], 1)
+    rc = ro.run(env2, env2.reset(batch=batch + batch, features=False), feedback=["teacher"] * B + ["sample"] * B,
+                train_ml=[0.2] * B + [1.0] * B, sample_draws=draws2, record=True, text_copies=2)
+    rc["loss"].backward()
+    torch.cuda.synchronize()
+    close(rc["loss"], want_loss, "combined loss", 2e-5, 1e-6)
+    assert rc["decisions"] == r1["decisions"] + r2["decisions"]
+    for t, st in enumerate(rc["steps"]):
+        for half, rr in ((0, r1), (1, r2)):
+            if t < len(rr["steps"]):
+                a, b = st["logits"][half * B:(half + 1) * B], rr["steps"][t]["logits"]
+                K = min(a.shape[1], b.shape[1])
+                live = rr["steps"][t]["targets"] != -100
+                close(torch.nan_to_num(a[live][:, :K], neginf=0), torch.nan_to_num(b[live][:, :K], neginf=0), f"step {t} half {half}", 1e-5, 1e-5)
+                assert st["actions"][half * B:(half + 1) * B] == rr["steps"][t]["actions"]
+    gmax = want_grad.abs().max().item()
+    assert (g_s.store.grad - want_grad).abs().max().item() <= 2e-4 * gmax
+    assert [x["path"] for x in rc["traj"]] == [x["path"] for x in r1["traj"]] + [x["path"] for x in r2["traj"]]
+
+
 def test_compat_graphmap_drives_the_same_numbers():
     """The reference's unmodified loop shape (per-sample GraphMap.update_node_embed / get_node_embed on device tensors +
     pad_tensors_wgrad) over the product GraphMap gives the same logits as the index-plan path."""

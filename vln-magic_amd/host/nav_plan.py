@@ -68,6 +68,9 @@ class NavPlanner:
     def __init__(self, env, obs, feedback="teacher", max_action_len=15, expert_policy="spl", angle_table=None, train=True):
         self.env, self.obs = env, obs
         self.B = len(obs)
+        # feedback: one mode for the batch, or one per episode -- an iteration's teacher-forced and DAgger rollouts
+        # (agent_base.py:243-250) can then share every model call as ONE batch of 2B episodes (host/nav_rollout.py)
+        self.fb = [feedback] * len(obs) if isinstance(feedback, str) else list(feedback)
         self.feedback, self.T, self.expert = feedback, max_action_len, expert_policy
         self.train = train
         self.angle_table = env.angle_table if angle_table is None else angle_table
@@ -275,7 +278,7 @@ class NavPlanner:
         for i, ob in enumerate(self.obs):
             if self.ended[i]:
                 a[i] = IGNORE
-            elif self.feedback == "teacher":
+            elif self.fb[i] == "teacher":
                 if ob["viewpoint"] != ob["gt_path"][t]:
                     raise AssertionError("teacher forcing left the ground-truth path")
                 if t < len(ob["gt_path"]) - 1:
@@ -307,14 +310,12 @@ class NavPlanner:
         """a_t: chosen map-token index per sample (None under teacher forcing = the expert's).  Returns True when all ended."""
         t, B, obs = self.t, self.B, self.obs
         cur = self._cur
-        a_t = cur["targets"] if a_t is None else a_t
+        a_t = cur["targets"] if a_t is None else [cur["targets"][i] if self.fb[i] == "teacher" else a_t[i] for i in range(B)]
         for i in range(B):
             if not self.ended[i]:
                 self.stop_refs[i].append((t, obs[i]["viewpoint"]))
-        if self.feedback in ("teacher", "sample"):
-            stop = [ob["viewpoint"] == ob["gt_path"][-1] for ob in obs]
-        else:
-            stop = [int(a) == 0 for a in a_t]
+        stop = [(ob["viewpoint"] == ob["gt_path"][-1]) if self.fb[i] in ("teacher", "sample") else int(a_t[i]) == 0
+                for i, ob in enumerate(obs)]
         acts, hops_from = [], [None] * B
         for i in range(B):
             if stop[i] or self.ended[i] or cur["no_left"][i] or t == self.T - 1:

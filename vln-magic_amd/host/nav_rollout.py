@@ -125,21 +125,37 @@ class NavRollout:
                     host_lens=(txt_lens, [int(x) - 1 for x in plan["gmap_lens"]], [int(x) + 2 for x in plan["view_lens"]]),
                     fusion=(d["fsrc"], d["bw"]))
 
-    def run(self, env, obs, feedback="teacher", train_ml=1.0, rw_seq=None, sample_draws=None, grad=True, record=False):
-        """One batch of episodes.  Returns dict(loss, ml_loss, kdl, traj, n_steps, decisions[, steps])."""
+    def run(self, env, obs, feedback="teacher", train_ml=1.0, rw_seq=None, sample_draws=None, grad=True, record=False, text_copies=1):
+        """One batch of episodes.  Returns dict(loss, ml_loss, kdl, traj, n_steps, decisions[, steps]).
+
+        feedback / train_ml may be per-episode lists: the two rollouts of a fine-tuning iteration (teacher-forced with ml_weight,
+        then 'sample' with weight 1 on the SAME episodes; agent_base.py:243-250) are independent per episode, so they can run as one
+        batch of 2B episodes -- half the launches, twice the rows per launch.  text_copies = k: the batch is k copies of the same
+        B / k instructions (that case): the text encoder and the K/V projections run once on B / k and are tiled.  The loss is
+        divided by B / text_copies, i.e. it equals the sum of the separate rollouts' losses."""
         st, te, dev = self.student, self.teacher, self.dev
         B = len(obs)
+        per_episode = not isinstance(feedback, str)
+        fb = list(feedback) if per_episode else [feedback] * B
+        needs_action = any(f != "teacher" for f in fb)
+        Bn = B // text_copies                                    # loss normaliser (the reference's batch_size of ONE rollout)
+        w_host = [float(train_ml)] * B if isinstance(train_ml, (int, float)) else [float(x) for x in train_ml]
+        w_ml = torch.tensor(w_host, dtype=torch.float32, device=dev)
         pl = NavPlanner(env, obs, feedback=feedback, max_action_len=self.T, expert_policy=self.expert, train=grad)
         lang = pl.language()
-        ld = to_device(dict(txt_ids=lang["txt_ids"]), dev)
+        ld = to_device(dict(txt_ids=lang["txt_ids"][:Bn]), dev)
         L = lang["txt_ids"].shape[1]
         txt_lens = [int(x) for x in lang["txt_lens"]]
-        txt_masks = (torch.arange(L, device=dev)[None] < torch.as_tensor(lang["txt_lens"], device=dev)[:, None])
-        lin = dict(txt_ids=ld["txt_ids"], txt_masks=txt_masks)
+        u_masks = (torch.arange(L, device=dev)[None] < torch.as_tensor(lang["txt_lens"][:Bn], device=dev)[:, None])
+        txt_masks = u_masks.repeat(text_copies, 1) if text_copies > 1 else u_masks
+        lin = dict(txt_ids=ld["txt_ids"], txt_masks=u_masks)
+        tile = (lambda x, dim=0: torch.cat([x] * text_copies, dim)) if text_copies > 1 else (lambda x, dim=0: x)
         ctxg = torch.enable_grad() if grad else torch.no_grad()
         with ctxg:
             txt_embeds, txt_attns = st("language", lin)
             txt_kv = st.text_kv(txt_embeds) if self.cache_text_kv else None      # once per episode, not once per step
+            txt_embeds, txt_attns = tile(txt_embeds), tile(txt_attns)
+            txt_kv = tile(txt_kv, 1) if txt_kv is not None else None
         s_out = dict(txt_embeds=txt_embeds, txt_attns=txt_attns)
         t_out = {}
         tt_grad = self.train_teacher and grad
@@ -149,6 +165,8 @@ class NavRollout:
             with tctx():
                 t_txt, t_txt_attns = te("language", lin)
                 t_kv = te.text_kv(t_txt) if self.cache_text_kv else None
+                t_txt, t_txt_attns = tile(t_txt), tile(t_txt_attns)
+                t_kv = tile(t_kv, 1) if t_kv is not None else None
             t_out = dict(txt_embeds=t_txt, txt_attns=t_txt_attns)
             t_log = EmbeddingLog(te.net.H, te.net.dtype, dev)
         s_log = EmbeddingLog(st.net.H, st.net.dtype, dev)
@@ -189,7 +207,7 @@ class NavRollout:
                 s_out.update(nav_outs=outs, nav_logits=logits)
                 targets = d["targets"]
                 ce = F.cross_entropy(logits, targets, ignore_index=IGNORE, reduction="none")
-                ml_loss = ml_loss + ce.sum()
+                ml_loss = ml_loss + (ce * w_ml).sum()
                 stop_probs.append(torch.softmax(logits.detach(), 1)[:, 0])
                 if te is not None:
                     with tctx():
@@ -211,12 +229,15 @@ class NavRollout:
                             t_kdl = compute_kd_losses(t, t_out, s_out, self.heads, t_kdl, role="s2t", temperature=self.kd["temperature"],
                                                       weights=rw_t)
                 a_host = None
-                if feedback == "argmax":
-                    a_host = logits.detach().argmax(1).cpu().numpy()                # the stepper needs it: one [B] copy
-                elif feedback == "sample":
-                    cdf = torch.softmax(logits.detach(), 1).double().cumsum(1)
-                    u = torch.as_tensor(sample_draws[t], dtype=torch.float64, device=dev)
-                    a_host = (cdf < (u * cdf[:, -1])[:, None]).sum(1).clamp(max=logits.shape[1] - 1).cpu().numpy()
+                if needs_action:                                                     # the stepper needs it: one [B] copy
+                    a_arg = logits.detach().argmax(1)
+                    if any(f == "sample" for f in fb):
+                        cdf = torch.softmax(logits.detach(), 1).double().cumsum(1)
+                        u = torch.as_tensor(sample_draws[t], dtype=torch.float64, device=dev)
+                        a_smp = (cdf < (u * cdf[:, -1])[:, None]).sum(1).clamp(max=logits.shape[1] - 1)
+                        is_smp = torch.tensor([f == "sample" for f in fb], device=dev)
+                        a_arg = torch.where(is_smp, a_smp, a_arg)
+                    a_host = a_arg.cpu().numpy()
                 if record:
                     steps.append(dict(logits=logits.detach().float().cpu(), targets=torch.from_numpy(plan["targets"]).clone(),
                                       vpids=plan["gmap_vpids"]))
@@ -225,10 +246,10 @@ class NavRollout:
                     steps[-1]["actions"] = list(pl.actions)
                 if done:
                     break
-        ml = ml_loss * train_ml / B
+        ml = ml_loss / Bn
         kd_sum, total = None, ml
         if te is not None and grad:
-            kd_sum = sum(kdl.values()) / B
+            kd_sum = sum(kdl.values()) / Bn
             total = self.kd["alpha"] * kd_sum + (1 - self.kd["alpha"]) * ml
         traj = pl.finish(torch.stack(stop_probs).cpu().numpy())
         out = dict(loss=total, ml_loss=ml, kdl=kd_sum, kdl_terms=kdl, traj=traj, n_steps=len(stop_probs), decisions=decisions,
@@ -236,5 +257,5 @@ class NavRollout:
         if tt_grad:
             ta = self.kd.get("t_alpha", self.kd["alpha"])
             out["t_kdl_terms"] = t_kdl
-            out["t_loss"] = ta * (sum(t_kdl.values()) * train_ml) + (1 - ta) * (t_ml_loss * train_ml / B)
+            out["t_loss"] = ta * (sum(t_kdl.values()) * w_host[0]) + (1 - ta) * (t_ml_loss * w_host[0] / Bn)       # (uniform train_ml)
         return out

@@ -8,6 +8,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --mode eager --steps 6 --warmup 3 --no-cpu-baseline --no-profile > /dev/null 2> $R/gpurun_out/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --mode eager --steps 6 --warmup 3 --no-cpu-baseline --no-profile > /dev/null 2> $R/gpurun_out/pmc_write.err
 python3 $R/profiles/pmc_traffic.py $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write 9 > $R/gpurun_out/pmc_traffic.json
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma -- python3 $R/bench.py --mode eager --steps 6 --warmup 3 --no-cpu-baseline --no-profile > /dev/null 2> $R/gpurun_out/pmc_mfma.err
+python3 $R/profiles/pmc_mfma.py $R/gpurun_out/pmc_mfma > $R/gpurun_out/pmc_mfma.json; rm -rf $R/gpurun_out/pmc_mfma
 find $R/gpurun_out/prof_final -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/kernel_stats_final.csv \;
 # keep the merge-back small: drop the raw traces
 rm -rf $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write

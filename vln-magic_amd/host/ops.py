@@ -11,12 +11,16 @@ import torch
 
 from . import lib as L
 
-FLOPS = {"total": 0.0, "enabled": False}
+# algorithmic FLOPs of the dense contractions, per kernel family ("gemm": magic_gemm / magic_gemm_dw_grouped; "linear_ln": the fused
+# dense+LayerNorm kernels; "attn": the fused attention kernels) and in total
+FLOPS = {"total": 0.0, "gemm": 0.0, "linear_ln": 0.0, "attn": 0.0, "enabled": False}
 
 
-def _count(m, n, k, batch=1):
+def _count(m, n, k, batch=1, fam="gemm"):
     if FLOPS["enabled"]:
-        FLOPS["total"] += 2.0 * m * n * k * batch
+        f = 2.0 * m * n * k * batch
+        FLOPS["total"] += f
+        FLOPS[fam] += f
 
 
 def _chk(cond, msg):
@@ -172,7 +176,7 @@ def _dr(drop):
 def linear_ln(x, W, b, M, residual, gamma, beta, eps, out, rstd, flop_rows=None, drop=None):
     """out = LayerNorm(dropout(x @ W^T + b) + residual) in one launch (H = W.shape[0] in {128,256,384})."""
     H, K = W.shape
-    _count(flop_rows if flop_rows is not None else M, H, K)
+    _count(flop_rows if flop_rows is not None else M, H, K, fam="linear_ln")
     L.call("magic_linear_ln", L.dt(x.dtype), M, H, K, L.P(x), x.stride(0), L.P(W), W.stride(0), L.P(b), L.P(residual),
            residual.stride(0) if residual is not None else 0, L.P(gamma), L.P(beta), float(eps), L.P(out), L.P(rstd), *_dr(drop), L.stream())
     return out
@@ -189,7 +193,7 @@ def linear_lnbwd(x, W, M, residual, y, gamma, beta, rstd, dx, dgamma, dbeta, dro
     """dx = LayerNorm-backward(x @ W + residual; y, gamma, beta, rstd) in one launch; W [K, H] = the forward weight of the dense
     whose input gradient this is; dxm = dx * dropout mask (when the LayerNorm's dense branch was dropped)."""
     K, H = W.shape
-    _count(flop_rows if flop_rows is not None else M, H, K)
+    _count(flop_rows if flop_rows is not None else M, H, K, fam="linear_ln")
     L.call("magic_linear_lnbwd", L.dt(x.dtype), M, H, K, L.P(x), x.stride(0), L.P(W), W.stride(0), L.P(residual),
            residual.stride(0) if residual is not None else 0, L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(dx), L.P(dxm),
            L.P(dgamma), L.P(dbeta), *_dr(drop), L.stream())
@@ -361,6 +365,7 @@ def attn_fwd(q, ldq, k, v, ldkv, Pm, ldp, ctx, B, nh, Nq, Nk, H, scale, kmask=No
              drop=None, Pd=None):
     if FLOPS["enabled"]:
         FLOPS["total"] += 4.0 * flops
+        FLOPS["attn"] += 4.0 * flops
     L.call("magic_attn_fwd", L.dt(q.dtype), B, nh, Nq, Nk, L.P(q), ldq, L.P(k), L.P(v), ldkv, L.P(Pm), ldp, L.P(ctx), H, float(scale),
            L.P(kmask), L.P(dist), L.P(sprel_w), L.P(sprel_b), *_dr(drop), L.P(Pd), L.stream())
 
@@ -369,6 +374,7 @@ def attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, dctx, B, nh, Nq, Nk, H, scale, dP_init
              dsprel_b=None, flops=0.0, drop=None):
     if FLOPS["enabled"]:
         FLOPS["total"] += 8.0 * flops
+        FLOPS["attn"] += 8.0 * flops
     L.call("magic_attn_bwd", L.dt(q.dtype), B, nh, Nq, Nk, L.P(q), ldq, L.P(k), L.P(v), ldkv, L.P(Pm), ldp, L.P(dctx), H, float(scale),
            L.P(dP_init), L.P(dq), lddq, L.P(dk), L.P(dv), lddkv, L.P(dist), L.P(dsprel_w), L.P(dsprel_b), *_dr(drop), L.stream())
 

@@ -87,6 +87,8 @@ def main():
                     help="BASELINE config 3: MAGIC-L teacher (trainable, --teacher-hidden) + student (--hidden) co-training -- MAKD t2s for the "
                          "student, reverse s2t for the teacher, both losses back-propagated, two optimizers (agent_base.py:260-279)")
     ap.add_argument("--teacher-hidden", type=int, default=768)
+    ap.add_argument("--sequential-rollouts", action="store_true",
+                    help="run the iteration's two rollouts strictly one after the other (the reference's order) instead of interleaving their steps")
     ap.add_argument("--fuse-rollouts", action="store_true",
                     help="run the iteration's two rollouts as ONE batch of 2B episodes (per-episode feedback / loss weight, text encoded once) "
                          "instead of one after the other as the reference does: 27 %% fewer launches and 11 %% less kernel time, but the same wall "
@@ -108,6 +110,7 @@ def main():
     model.train() if a.mode == "train" else model.eval()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5)              # agent_base.py:128-129
     env = make_env(a, 1234 + rank)
+    env2 = make_env(a, 1234 + rank)            # same scans and features (deterministic in the seed): the second rollout's stepper
     table = torch.from_numpy(env.feature_table).to(dev).to(dtype)
     teacher = t_opt = None
     if a.icod:
@@ -147,10 +150,17 @@ def main():
         rw = None
         if a.icod:      # MKRW: softmax(randn(5) / rw_temp) * 5 per step (agent.py:866-871)
             rw = torch.softmax(torch.randn(a.max_action_len, 5, device=dev) / 4.0, -1) * 5
-        if not a.fuse_rollouts or a.icod:
+        if (not a.fuse_rollouts or a.icod) and a.sequential_rollouts:
             r1 = ro.run(env, obs, feedback="teacher", train_ml=0.2, rw_seq=rw)
             obs = env.reset(batch=batch, features=False)
             r2 = ro.run(env, obs, feedback="sample", train_ml=1.0, sample_draws=rng.uniform(size=(a.max_action_len, a.batch)), rw_seq=rw)
+        elif not a.fuse_rollouts or a.icod:
+            # the two rollouts advance in turn, one step each, on two steppers: while the GPU runs one rollout's step the host plans and
+            # launches the other's, so the 'sample' rollout's per-step action copy and planning no longer stall the GPU
+            r2, r1 = ro.run_interleaved([
+                ((env2, env2.reset(batch=batch, features=False)), dict(feedback="sample", train_ml=1.0, rw_seq=rw,
+                                                                       sample_draws=rng.uniform(size=(a.max_action_len, a.batch)))),
+                ((env, obs), dict(feedback="teacher", train_ml=0.2, rw_seq=rw))])
         else:
             # the two rollouts are independent per episode: one batch of 2B episodes with per-episode feedback and loss weight, text
             # encoded once (tests/test_rollout_gpu.py: same logits, summed loss and gradients as the separate rollouts)
@@ -233,7 +243,7 @@ def main():
             "metric": "trajectory-steps/sec (whole node), navigator step loop, MAGIC-L fine-tune", "value": round(dec / dt, 2),
             "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"rollouts": "separate" if (not a.fuse_rollouts or a.icod) else "one batch of 2B episodes",
+            "config": {"rollouts": ("one batch of 2B episodes" if (a.fuse_rollouts and not a.icod) else "sequential" if a.sequential_rollouts else "interleaved step by step"),
                        "workload": f"navigator loop (agent_base.py:215-296 iteration = teacher-forced + DAgger 'sample' rollout, backward, clip 40, "
                                    f"torch AdamW), VLNBert H={a.hidden} 6+2+3 layers, dropout 0.1, expert ndtw, instructions U{{{a.instr_min}..{a.instr_max}}} tokens, "
                                    f"paths {a.hops_min}..{a.hops_max} hops, max_action_len {a.max_action_len}",

@@ -209,6 +209,38 @@ def test_two_rollouts_as_one_batch_equal_two_separate_rollouts():
     assert [x["path"] for x in rc["traj"]] == [x["path"] for x in r1["traj"]] + [x["path"] for x in r2["traj"]]
 
 
+def test_interleaved_rollouts_equal_sequential_rollouts():
+    """run_interleaved advances the teacher-forced and the 'sample' rollout step by step in turn (each on its own stepper): identical
+    per-step logits, actions, losses and gradients to running them one after the other."""
+    cfg = make_config(128, role="student", **KW)
+    _, g_s = _pair(cfg, "student", 6)
+    B, T = 4, 6
+    env_a, env_b = _env(29, B=B), _env(29, B=B)
+    batch = [env_a._draw_episode() for _ in range(B)]
+    draws = np.random.default_rng(2).uniform(size=(T, B))
+    table = torch.from_numpy(env_a.feature_table).to(DEV)
+    ro = NavRollout(g_s, table, max_action_len=T)
+    g_s.store.zero_grad()
+    r1 = ro.run(env_a, env_a.reset(batch=batch, features=False), feedback="teacher", train_ml=0.2, record=True)
+    r2 = ro.run(env_a, env_a.reset(batch=batch, features=False), feedback="sample", train_ml=1.0, sample_draws=draws, record=True)
+    (r1["loss"] + r2["loss"]).backward()
+    torch.cuda.synchronize()
+    want = g_s.store.grad.clone()
+    g_s.store.zero_grad()
+    q1, q2 = ro.run_interleaved([
+        ((env_a, env_a.reset(batch=batch, features=False)), dict(feedback="teacher", train_ml=0.2, record=True)),
+        ((env_b, env_b.reset(batch=batch, features=False)), dict(feedback="sample", train_ml=1.0, sample_draws=draws, record=True))])
+    (q1["loss"] + q2["loss"]).backward()
+    torch.cuda.synchronize()
+    for a, b in ((q1, r1), (q2, r2)):
+        assert float(a["loss"].detach()) == float(b["loss"].detach())
+        assert len(a["steps"]) == len(b["steps"])
+        for x, y in zip(a["steps"], b["steps"]):
+            assert torch.equal(x["logits"], y["logits"]) and x["actions"] == y["actions"]
+        assert [x["path"] for x in a["traj"]] == [x["path"] for x in b["traj"]]
+    assert (g_s.store.grad - want).abs().max().item() <= 1e-5 * want.abs().max().item()      # fp32 atomics: summation order only
+
+
 def test_compat_graphmap_drives_the_same_numbers():
     """The reference's unmodified loop shape (per-sample GraphMap.update_node_embed / get_node_embed on device tensors +
     pad_tensors_wgrad) over the product GraphMap gives the same logits as the index-plan path."""

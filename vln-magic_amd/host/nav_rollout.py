@@ -125,8 +125,35 @@ class NavRollout:
                     host_lens=(txt_lens, [int(x) - 1 for x in plan["gmap_lens"]], [int(x) + 2 for x in plan["view_lens"]]),
                     fusion=(d["fsrc"], d["bw"]))
 
-    def run(self, env, obs, feedback="teacher", train_ml=1.0, rw_seq=None, sample_draws=None, grad=True, record=False, text_copies=1):
-        """One batch of episodes.  Returns dict(loss, ml_loss, kdl, traj, n_steps, decisions[, steps]).
+    def run(self, *args, **kw):
+        """One batch of episodes (see `steps` for the arguments).  Returns dict(loss, ml_loss, kdl, traj, n_steps, decisions[, steps])."""
+        g = self.steps(*args, **kw)
+        try:
+            while True:
+                next(g)
+        except StopIteration as e:
+            return e.value
+
+    def run_interleaved(self, jobs):
+        """Several rollouts advanced round-robin, one step each: jobs = [(args, kwargs) of `steps`, ...] -> list of results.
+        Every rollout yields right after it has LAUNCHED a step, before it needs that step's actions on the host; the host then plans
+        and launches the next rollout's step while the GPU works, so the per-step action copy of a 'sample' rollout and its planning no
+        longer leave the GPU idle (the iteration's teacher-forced and DAgger rollouts: agent_base.py:243-250).  Needs one stepper per
+        rollout; the rollouts are independent, so the results equal those of running them one after the other."""
+        gens = [self.steps(*a, **k) for a, k in jobs]
+        res = [None] * len(gens)
+        live = list(range(len(gens)))
+        while live:
+            for i in list(live):
+                try:
+                    next(gens[i])
+                except StopIteration as e:
+                    res[i] = e.value
+                    live.remove(i)
+        return res
+
+    def steps(self, env, obs, feedback="teacher", train_ml=1.0, rw_seq=None, sample_draws=None, grad=True, record=False, text_copies=1):
+        """Generator form of one batch of episodes: yields after launching each step, returns the result dict.
 
         feedback / train_ml may be per-episode lists: the two rollouts of a fine-tuning iteration (teacher-forced with ml_weight,
         then 'sample' with weight 1 on the SAME episodes; agent_base.py:243-250) are independent per episode, so they can run as one
@@ -228,6 +255,7 @@ class NavRollout:
                             s_out["sample_weights"] = exponential_decay(ce.detach(), self.kd["decay"])
                             t_kdl = compute_kd_losses(t, t_out, s_out, self.heads, t_kdl, role="s2t", temperature=self.kd["temperature"],
                                                       weights=rw_t)
+                yield t           # the step is launched; nothing below is needed before its actions are (run_interleaved switches here)
                 a_host = None
                 if needs_action:                                                     # the stepper needs it: one [B] copy
                     a_arg = logits.detach().argmax(1)

@@ -272,8 +272,8 @@ def host_loop_rate(a, model, dev):
     R.F.cross_entropy = lambda lg, tg, **kw: orig(lg.float(), tg.to(lg.device), **kw)
     try:
         for name in ("index_plans", "per_sample_loop"):
-            dec, tt = 0, 0.0
-            for it in range(3):
+            times, decs = [], []
+            for it in range(6):
                 model.store.zero_grad()
                 obs = env.reset(features=(name == "per_sample_loop"))
                 torch.cuda.synchronize()
@@ -286,10 +286,12 @@ def host_loop_rate(a, model, dev):
                     d = sum(int((s["targets"] != -100).sum()) for s in r["steps"])
                 r["loss"].backward()
                 torch.cuda.synchronize()
-                if it > 0:
-                    tt += time.perf_counter() - t0
-                    dec += d
-            out[name] = {"trajectory_steps_per_sec": round(dec / tt, 1), "ms_per_rollout": round(tt / 2 * 1e3, 1)}
+                if it > 0:      # the first one warms the allocator; a new batch shape can still stall on a device allocation: median
+                    times.append(time.perf_counter() - t0)
+                    decs.append(d)
+            mid = sorted(range(len(times)), key=lambda i: times[i] / decs[i])[len(times) // 2]
+            out[name] = {"trajectory_steps_per_sec": round(decs[mid] / times[mid], 1), "ms_per_rollout": round(times[mid] * 1e3, 1),
+                         "sample": "median of 5 teacher-forced rollouts + backward"}
     finally:
         R.RefGraphMap, R.F.cross_entropy = saved, orig
     return out

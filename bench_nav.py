@@ -93,6 +93,9 @@ def main():
                     help="run the iteration's two rollouts as ONE batch of 2B episodes (per-episode feedback / loss weight, text encoded once) "
                          "instead of one after the other as the reference does: 27 %% fewer launches and 11 %% less kernel time, but the same wall "
                          "time -- every step then waits for the 'sample' half's action copy and the 2B-episode plan (measured 329 vs 332 ms)")
+    ap.add_argument("--graph", action="store_true",
+                    help="--mode eval: the decision step as ONE HIP graph with padded static shapes (host/nav_graph.GreedyNavigator) instead of eager launches")
+    ap.add_argument("--kmax", type=int, default=64, help="--graph: map tokens per episode the static shapes provide for")
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="eval: greedy inference rollouts (feedback 'argmax', no grad, model.eval()) -- decisions/s and ms per step")
     a = ap.parse_args()
@@ -131,10 +134,15 @@ def main():
                     expert_policy="ndtw" if not a.icod else "spl")     # run_rxr_kdl_valid.sh:29 / run_r2r_kdl_valid.sh:29
     rng = np.random.default_rng(rank)
 
+    gnav = None
+    if a.mode == "eval" and a.graph:
+        from magic_amd.host.nav_graph import GreedyNavigator
+        gnav = GreedyNavigator(model, table, a.batch, Lmax=a.instr_max, Kmax=a.kmax, Tmax=a.max_action_len)
+
     def eval_iteration():
         obs = env.reset(features=False)
         with torch.no_grad():
-            r = ro.run(env, obs, feedback="argmax", train_ml=1.0, grad=False)
+            r = gnav.run(env, obs) if gnav is not None else ro.run(env, obs, feedback="argmax", train_ml=1.0, grad=False)
         counters["rollout_steps"] += r["n_steps"]
         return r["decisions"]
     counters = {"rollout_steps": 0}
@@ -249,7 +257,7 @@ def main():
                                    f"paths {a.hops_min}..{a.hops_max} hops, max_action_len {a.max_action_len}",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "views": 36, "feat_dim": 768, "parallelism": f"dp{world}",
                        "decisions_per_iteration": round(dec / a.steps / world, 1)},
-            "mode": a.mode + ("/icod" if a.icod else ""), "teacher_hidden": a.teacher_hidden if a.icod else None, "ms_per_rollout_step": (round(dt / max(counters["rollout_steps"], 1) * 1e3, 3) if a.mode == "eval" else None),
+            "mode": a.mode + ("/icod" if a.icod else "") + ("/graph" if (a.graph and a.mode == "eval") else ""), "teacher_hidden": a.teacher_hidden if a.icod else None, "ms_per_rollout_step": (round(dt / max(counters["rollout_steps"], 1) * 1e3, 3) if a.mode == "eval" else None),
             "roofline": roof, "cpu_baseline": cpu, "host_loop": host_loop}))
     if world > 1:
         dist.destroy_process_group()

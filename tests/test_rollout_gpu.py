@@ -241,6 +241,33 @@ def test_interleaved_rollouts_equal_sequential_rollouts():
     assert (g_s.store.grad - want).abs().max().item() <= 1e-5 * want.abs().max().item()      # fp32 atomics: summation order only
 
 
+@pytest.mark.parametrize("B", [1, 4])
+def test_greedy_navigation_as_one_graph_per_step_matches_the_eager_loop(B):
+    """host/nav_graph.GreedyNavigator: the decision step captured once with padded static shapes (37 views, Kmax map tokens, Lmax
+    instruction tokens) and replayed -- same actions, trajectories and (on the valid tokens) logits as the eager index-plan loop; the
+    graph is captured on the first episode batch and REUSED for the following ones."""
+    from magic_amd.host.nav_graph import GreedyNavigator
+    cfg = make_config(128, role="student", **KW)
+    _, g_s = _pair(cfg, "student", 7)
+    env_a, env_b = _env(31, B=B), _env(31, B=B)
+    table = torch.from_numpy(env_a.feature_table).to(DEV)
+    nav = GreedyNavigator(g_s, table, B, Lmax=16, Kmax=40, Tmax=7)
+    ro = NavRollout(g_s, table, max_action_len=7)
+    for rep in range(3):
+        batch = [env_a._draw_episode() for _ in range(B)]
+        want = ro.run(env_a, env_a.reset(batch=batch, features=False), feedback="argmax", grad=False, record=True)
+        got = nav.run(env_b, env_b.reset(batch=batch, features=False), record=True)
+        assert got["n_steps"] == want["n_steps"] and got["decisions"] == want["decisions"]
+        for t, (g, w) in enumerate(zip(got["steps"], want["steps"])):
+            K = w["logits"].shape[1]
+            a, b = g["logits"][:, :K], w["logits"]
+            assert torch.equal(torch.isinf(a), torch.isinf(b)), (rep, t)
+            close(torch.nan_to_num(a, neginf=0), torch.nan_to_num(b, neginf=0), f"episode batch {rep} step {t}", 1e-5, 1e-5)
+            assert g["actions"] == w["actions"], (rep, t)
+        assert [x["path"] for x in got["traj"]] == [x["path"] for x in want["traj"]]
+    assert nav.graph is not None
+
+
 def test_compat_graphmap_drives_the_same_numbers():
     """The reference's unmodified loop shape (per-sample GraphMap.update_node_embed / get_node_embed on device tensors +
     pad_tensors_wgrad) over the product GraphMap gives the same logits as the index-plan path."""

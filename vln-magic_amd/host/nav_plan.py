@@ -65,7 +65,11 @@ def ndtw(dist, pred, ref, threshold=3.0):
 class NavPlanner:
     """Host mirror of one rollout: owns the per-episode GraphMaps, emits one plan (dict of numpy arrays) per step."""
 
-    def __init__(self, env, obs, feedback="teacher", max_action_len=15, expert_policy="spl", angle_table=None, train=True):
+    def __init__(self, env, obs, feedback="teacher", max_action_len=15, expert_policy="spl", angle_table=None, train=True,
+                 pad_V=0, pad_K=0):
+        """pad_V / pad_K: minimum padded view / map-token counts (static shapes for a HIP-graph step: host/nav_graph.py); padded
+        tokens are masked everywhere, so the valid outputs do not change."""
+        self.pad_V, self.pad_K = pad_V, pad_K
         self.env, self.obs = env, obs
         self.B = len(obs)
         # feedback: one mode for the batch, or one per episode -- an iteration's teacher-forced and DAgger rollouts
@@ -140,7 +144,7 @@ class NavPlanner:
             per.append(ent)
             cand_vpids.append(ent[3])
             view_lens[i] = len(ent[0])
-        V = int(view_lens.max())
+        V = max(int(view_lens.max()), self.pad_V)
         view_order = np.full((B, V), -1, np.int32)            # -1: padded slot, the gather writes zeros (pad_tensors, agent.py:155)
         nav_types = np.zeros((B, V), np.int64)
         loc = np.zeros((B, V, 7), np.float32)
@@ -188,7 +192,7 @@ class NavPlanner:
             vpid_lists.append([None, None] + vis + unv)
             node_ids.append((len(vis), len(unv)))
             lens[i] = 2 + len(vis) + len(unv)
-        K = int(lens.max())
+        K = max(int(lens.max()), self.pad_K)
         Vp = V + 2
         step_ids = np.zeros((B, K), np.int64)
         pos = np.zeros((B, K, 7), np.float32)

@@ -5,7 +5,9 @@ forward as a whole (no reference implementation exists), pinned at block level a
 import torch
 import torch.nn as nn
 
-from .model_ref import ClsPrediction, RefMagicBert
+from types import SimpleNamespace
+
+from .model_ref import ClsPrediction, RefMagicBert, RefPretrainModel
 
 
 class _Inner(RefMagicBert):
@@ -68,4 +70,9 @@ class RefVLNBert(nn.Module):
             ll = (m.local_sap_head(v).squeeze(2) * (1 - fw)).masked_fill(~b["vp_nav_masks"], -float("inf"))
             return dict(gmap_embeds=g, vp_embeds=v, gmap_attns=ga, vp_attns=va, cls_embeds=g[:, 0] + v[:, 0],
                         global_logits=gl, local_logits=ll, fused_logits=nav_fuse(gl, ll, b))
+        if mode == "instr_zdict_update":          # agent.py:1231-1233 (dictionaries off): per-token instruction embeddings
+            return m.text(b["z_txt"], b["z_txt_mask"])
+        if mode == "extract_cfp_features":        # agent.py:1535-1541: first tokens of the whole-trajectory forward (cfp_collate batch)
+            o = RefPretrainModel.trunk(SimpleNamespace(bert=m), b)
+            return dict(txt_outputs=o["txt_embeds"][:, 0], vp_outputs=o["vp_embeds"][:, 0], gmap_outputs=o["gmap_embeds"][:, 0])
         raise NotImplementedError(mode)

@@ -287,3 +287,42 @@ def test_nav_modes_with_dropout_train_vs_eval():
     m.store.zero_grad()
     t1.float().square().sum().backward()
     assert torch.isfinite(m.store.grad).all() and m.store.grad.abs().max() > 0
+
+
+def test_f4_modes_dictionaries_off_match_the_oracle_and_refuse_dictionary_inputs():
+    """SURVEY §8 f-4 in its dictionaries-off form: 'instr_zdict_update' (agent.py:1231-1233) and 'extract_cfp_features'
+    (agent.py:1535-1541) against the CPU oracle in fp32; a back-door / front-door input is refused, never ignored."""
+    from magic_amd.host import synth
+    kw = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=300, num_l_layers=2, num_x_layers=1, num_pano_layers=1)
+    cfg = make_config(128, role="student", **kw)
+    torch.manual_seed(3)
+    o = RefVLNBert(cfg).double().eval()
+    g = VLNBert(None, role="student", config=cfg, device=DEV, compute_dtype=torch.float32)
+    g.load_state_dict(o.state_dict())
+    g.eval()
+
+    def close(a, b, name, rtol=2e-4, atol=2e-5):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        assert a.shape == b.shape, (name, a.shape, b.shape)
+        assert torch.allclose(a, b, rtol=rtol, atol=atol), f"{name}: max|err| {(a - b).abs().max().item():.3e}"
+    inp = nav_inputs(B=5, L=17, seed=4)
+    zin = dict(z_txt=inp["txt_ids"], z_txt_mask=inp["txt_masks"], instr_z_direction_features=None, instr_z_direction_pzs=None,
+               instr_z_landmark_features=None, instr_z_landmark_pzs=None, front_txt_feats=None)
+    with torch.no_grad():
+        want = o("instr_zdict_update", zin)[0]
+        got = g("instr_zdict_update", to_dev(zin, DEV))[0]
+    close(got, want, "instr_zdict_update")
+    # whole-trajectory batch in GMapNavAgent.cfp_collate's layout (tensors already on the GPU, agent.py:1508-1512)
+    batch = synth.make_batch("cfp", batch_size=6, seed=11, step=0, vocab=300)
+    b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+    with torch.no_grad():
+        want = o("extract_cfp_features", b64)
+        got = g("extract_cfp_features", to_dev(batch, DEV))
+    assert set(got) == {"txt_outputs", "vp_outputs", "gmap_outputs"}
+    for k in got:
+        close(got[k], want[k], k)
+    bad = dict(zin, instr_z_direction_features=torch.zeros(5, 3, 128))
+    with pytest.raises(NotImplementedError, match="instr_z_direction_features"):
+        g("instr_zdict_update", bad)
+    with pytest.raises(NotImplementedError, match="front_txt_feats"):
+        g("language", dict(txt_ids=inp["txt_ids"].to(DEV), txt_masks=inp["txt_masks"].to(DEV), front_txt_feats=torch.zeros(5, 4, 128)))

@@ -36,11 +36,10 @@ def pack(batch, hp):
     manifest, off = [], 0
     for k, a in arrays.items():
         off = (off + 15) & ~15
-        manifest.append((k, str(a.dtype).replace("torch.", ""), tuple(a.shape), off))
+        manifest.append((k, str(a.dtype).replace("torch.", ""), tuple(a.shape), off, a.numel() * a.element_size()))
         off += a.numel() * a.element_size()
     buf = torch.empty(max(off, 16), dtype=torch.uint8)
-    for (k, _, _, o), a in zip(manifest, arrays.values()):
-        n = a.numel() * a.element_size()
+    for (k, _, _, o, n), a in zip(manifest, arrays.values()):
         if n:
             buf[o:o + n] = a.contiguous().reshape(-1).view(torch.uint8)
     meta = dict(hp["meta"])
@@ -56,9 +55,8 @@ def unpack(rec, device):
         buf = buf.pin_memory()
     dbuf = buf.to(device, non_blocking=True)
     batch, plan, csr = {}, {}, {}
-    for k, dt, shape, o in rec["manifest"]:
+    for k, dt, shape, o, n in rec["manifest"]:
         dtype = getattr(torch, dt)
-        n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size() if len(shape) else torch.empty(0, dtype=dtype).element_size()
         t = dbuf[o:o + n].view(dtype).view(shape) if n else torch.empty(shape, dtype=dtype, device=device)
         kind, rest = k.split("/", 1)
         if kind == "b":
@@ -72,7 +70,7 @@ def unpack(rec, device):
         plan[name] = tuple(parts[j] for j in range(len(parts)))
     plan.update(rec["meta"])
     plan["last_rows"] = np.asarray(plan["last_rows"], np.int64)
-    plan["_stage"] = buf
+    plan["_stage"], plan["_dbuf"] = buf, dbuf        # every tensor above is a view of dbuf's one allocation
     return batch, plan
 
 
@@ -119,9 +117,7 @@ class DevicePrefetcher:
             cur = nxt
             if self.stream is not None:
                 torch.cuda.current_stream(self.device).wait_stream(self.stream)
-                for v in list(cur[1].values()) + list(cur[2].values()):
-                    if torch.is_tensor(v) and v.is_cuda:
-                        v.record_stream(torch.cuda.current_stream(self.device))
+                cur[2]["_dbuf"].record_stream(torch.cuda.current_stream(self.device))    # one storage holds batch + plan
             try:
                 nxt = self._stage(next(it))
             except StopIteration:

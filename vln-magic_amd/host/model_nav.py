@@ -6,6 +6,9 @@ Call surface kept:  `vln_bert(mode, inputs)` with mode i
   'panorama'   -> (pano_embeds [B,V,H], pano_masks [B,V], pano_fused_embeds [B,H], img_attns [B,V,V])   :885
   'navigation' -> dict(gmap_embeds, vp_embeds, gmap_attns, vp_attns, cls_embeds,
                        global_logits, local_logits, fused_logits)                          :964-967
+  'instr_zdict_update'   -> (txt_embeds [B,L,H], txt_attns)  from inputs z_txt / z_txt_mask          :1231-1233
+  'extract_cfp_features' -> dict(txt_outputs, vp_outputs, gmap_outputs)  [B,H] each, whole-trajectory forward   :1538-1541
+(both in their dictionaries-off form: a non-None back-door / front-door input raises NotImplementedError, never ignored)
 plus `.vln_bert.<kd head>` callables (`txt_emb_w`, `kdl_img_w`, `kdl_avg_img_w`, `global_cross_w`,
 `local_cross_w`; agent.py:568-665, agent_base.py:330), `.drop_env` (:738), `.parameters()`, `.state_dict()`.
 
@@ -24,6 +27,9 @@ from .engine import Ctx, MagicNet, cls_specs, trunk_specs
 from .params import ParamStore
 
 KD_HEADS = ("txt_emb_w", "kdl_img_w", "kdl_avg_img_w", "global_cross_w", "local_cross_w")
+# back-door / front-door inputs the agent passes as None unless args.do_back_* / do_front_* are set (agent.py:76-89,:162-172,:942-944,:1212-1227)
+CAUSAL_KEYS = ("instr_z_direction_features", "instr_z_direction_pzs", "instr_z_landmark_features", "instr_z_landmark_pzs",
+               "front_txt_feats", "front_vp_feats", "front_gmap_feats", "z_img_features", "z_img_pzs")
 
 
 def nav_specs(cfg, p="vln_bert."):
@@ -397,7 +403,7 @@ class VLNBert(nn.Module):
 
     # shared head helpers (same kernels as the pretraining model)
     from .model_pretrain import GlocalTextPathCMTPreTraining as _P
-    _cls, _cls_bwd, _arm_dropout = _P._cls, _P._cls_bwd, _P._arm_dropout
+    _cls, _cls_bwd, _arm_dropout, _dev, _inputs = _P._cls, _P._cls_bwd, _P._arm_dropout, _P._dev, _P._inputs
     del _P
 
     def _first_rows(self, B, N, dev):
@@ -420,6 +426,10 @@ class VLNBert(nn.Module):
         return _TextKVFn.apply(self._anchor, self, txt_embeds)
 
     def forward(self, mode, batch):
+        on = [k for k in CAUSAL_KEYS if batch.get(k) is not None]
+        if on:
+            raise NotImplementedError(f"VLNBert({mode!r}): causal-intervention inputs {on} (do_back_* / do_front_*, SURVEY §8 f-4) are not built -- "
+                                      "the attention over the z-dictionaries lives in the withheld model source; run with those flags off")
         self.store.sync_shadow()
         self._arm_dropout()           # vln_bert.train() (agent.py:rollout under feedback='sample') -> config dropouts on
         if mode == "language":
@@ -437,4 +447,36 @@ class VLNBert(nn.Module):
                                                                 batch["txt_embeds"], data, batch.get("txt_kv"))
             return dict(gmap_embeds=g, vp_embeds=v, gmap_attns=ga, vp_attns=va, cls_embeds=cls,
                         global_logits=gl, local_logits=ll, fused_logits=fl)
-        raise NotImplementedError(f"VLNBert mode {mode!r} (instr_zdict_update / extract_cfp_features are SURVEY §8 f-4, not built)")
+        if mode == "instr_zdict_update":
+            # agent.py:1231-1233 (update_z_dict): per-token instruction embeddings under no_grad; the caller indexes `[0][b][j + 1]`
+            return _LanguageFn.apply(self._anchor, self, batch["z_txt"], batch["z_txt_mask"])
+        if mode == "extract_cfp_features":
+            return self._extract_cfp_features(batch)
+        raise NotImplementedError(f"VLNBert mode {mode!r}")
+
+    @torch.no_grad()
+    def _extract_cfp_features(self, batch):
+        """Whole-trajectory forward on a `GMapNavAgent.cfp_collate` batch (agent.py:1470-1513; same keys as the pretraining
+        cfp collate) -> the first-token features the caller writes to `cfp_features_<iter>.tsv` (agent.py:1535-1541):
+        txt_outputs = text [CLS], vp_outputs = local-branch [stop], gmap_outputs = global-branch [stop], each [B, H].
+        Same engine segments as the pretraining model's cfp task, without its projection heads (the navigation model has none)."""
+        from .plan import build_plan
+        n, dev = self.net, self.device_
+        big = ("traj_view_img_fts", "traj_loc_fts", "gmap_pos_fts", "gmap_pair_dists", "vp_pos_fts")
+        host = {k: (v.cpu() if torch.is_tensor(v) and k not in big else v) for k, v in batch.items()}   # cfp_collate leaves tensors on the GPU
+        plan = build_plan(host, "cfp", dev)
+        inp = self._inputs(batch, plan)
+        B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H
+        txt = n.text_fwd(plan)
+        pano = n.pano_fwd(plan, inp.feats, inp.loc)
+        gin = n.gmap_in_fwd(plan, pano, inp.gpos)
+        tl, gl_, vl = plan["lens"]["txt"], plan["lens"]["gmap"], [Vp] * B
+        glob = n.cross_fwd("global", plan, gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"],
+                           txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], dist=inp.dist)
+        vin = n.vp_in_fwd(plan, pano, inp.vpos)
+        loc = n.cross_fwd("local", plan, vin.out, Vp, plan["vp_mask"], vl, B * Vp, txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
+        out = {}
+        for name, src, rows in (("txt_outputs", txt.out, "t0"), ("vp_outputs", loc.out, "v0"), ("gmap_outputs", glob.out, "g0")):
+            out[name] = n.new(B, H)
+            O.csr_gather(src, *plan[rows], out[name], B, H)
+        return out

@@ -114,13 +114,14 @@ def test_gemm_batched_attention_shapes(dtype):
     check(dqkv[:, 2 * H:], ref, "dV", **tol(dtype))
 
 
-# 128x128-tile path (csrc/gemm.hip gemm_big_kernel; off by default -- measured slower -- and switched on here)
+# wide-tile path (csrc/gemm.hip gemm_wide_kernel: 128x128, LDS-DMA staging, swizzled LDS images); forced on for every eligible shape here
+# (by default only large forward / input-gradient problems take it)
 @pytest.fixture
 def big_tiles():
     from magic_amd.host import lib as L
     L.call("magic_gemm_set_big", 2)
     yield
-    L.call("magic_gemm_set_big", 0)
+    L.call("magic_gemm_set_big", 1)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -508,3 +509,20 @@ def test_cast_roundtrip_and_add():
     zr = zz.clone().requires_grad_(True)
     F.gelu(zr).backward(dy)
     check(O.dact(dy, zz, 1), zr.grad, "dgelu", rtol=1e-5, atol=1e-6)
+
+
+def test_gemm_default_tile_rule_large_forward_and_long_reduction_weight_gradient():
+    """shapes the DEFAULT rules send to the wide tile (>= 192 tiles of 128x128, K >= 512: forward and input gradient) and to the
+    long-reduction split-K branch of the weight gradient (ops._splitk with more 64x64 tiles than CUs)"""
+    dtype = torch.bfloat16
+    M, N, K = 2176, 1536, 520                      # 17 x 12 = 204 wide tiles, K-tail of 8
+    x, W, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, scale=0.1), rnd(N, scale=0.5)
+    ref = x.float() @ W.float().t() + b
+    check(O.linear_fwd(x, W, b, M), ref, "default nt", rtol=2e-2, atol=8e-2)
+    dy = rnd(M, N, dtype=dtype, scale=0.3)
+    check(O.linear_dx(dy, W, M), dy.float() @ W.float(), "default nn", rtol=2e-2, atol=2e-1)
+    dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    assert O._splitk((N // 64) * ((K + 63) // 64), M) == 2
+    O.linear_dw(dy, x, dW, db, M)
+    check(dW, dy.float().t() @ x.float(), "default dW", rtol=2e-2, atol=5e-2 * math.sqrt(M / 64))
+    check(db, dy.float().sum(0), "default db", rtol=2e-2, atol=5e-2 * math.sqrt(M / 64))

@@ -344,25 +344,237 @@ __global__ __launch_bounds__(256) void gemm_xcd_kernel(GemmParams p, int nx, int
   gemm_block<T, LAYOUT>(p, bx, by, z, sA, sB);
 }
 
-// 128x128-tile variant of gemm_xcd_kernel (same XCD-aware 1-D tile map, nx / ny counted in 128-wide tiles)
-template <typename T, int LAYOUT>
-__global__ __launch_bounds__(256) void gemm_big_kernel(GemmParams p, int nx, int ny, int ny8) {
-  __shared__ __attribute__((aligned(16))) T sA[128 * TT<T>::STRIDE];
-  __shared__ __attribute__((aligned(16))) T sB[128 * TT<T>::STRIDE];
+// ---------------------------------------------------------------------------------------------------------------
+// Wide tile for the H >= 768 shapes (MAGIC-L; bf16 only): 128x128 block tile, BK = 64, 4 waves as 2x2 with a 64x64 sub-tile
+// each (4x4 MFMA tiles).  Both operand tiles go global -> LDS by LDS-DMA (`global_load_lds`, 16 B per lane, no VGPR staging,
+// no ds_write pass) into a two-stage ring; two workgroups share a CU.
+// An LDS-DMA wave-instruction writes 1 KiB contiguously (wave-uniform base + lane * 16), so the LDS images cannot be padded;
+// bank conflicts are removed by permuting the 16-byte chunks of a row instead, applied on the per-lane SOURCE address when
+// filling and on the fragment address when reading:
+//   k-contiguous operand  [128 out][64 k]   (128 B rows): chunk c of row r sits at c ^ ((r >> 1) & 7)  -> the 16 rows of one
+//       b128 fragment read cover 16 distinct 16-byte slots of the 256-byte bank row;
+//   out-contiguous operand [64 k][128 out]  (256 B rows, read transposed with ds_read_b64_tr_b16): chunk c of k-row r sits at
+//       c ^ (2 (r & 3) + 8 ((r >> 3) & 1)) -> the 8 k-rows x 32 B a half-wave reads are 16 distinct slots.
+// Out-of-range chunks (tile edges in M / N / K) are fetched from a 16-byte zero page; the contiguous dimension of each operand must be
+// a multiple of 8 elements (a chunk is wholly inside or wholly outside), every other extent is free.
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ int wide_sw_nat(int kr) { return 2 * (kr & 3) + 8 * ((kr >> 3) & 1); }
+
+template <bool KC>
+__device__ __forceinline__ void wide_stage(const bf16* __restrict__ base, int ld, int out0, int k0, int OUT, int kend, bf16* s, int tid) {
+  // 1024 chunks of 16 B per operand tile: chunk idx = j * 256 + tid (wave w, lane l: LDS bytes (4 j + w) * 1024 + 16 l)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = j * 256 + tid;
+    const bf16* src;
+    if (KC) {
+      const int row = idx >> 3, c = (idx & 7) ^ ((row >> 1) & 7);
+      const int o = out0 + row, k = k0 + c * 8;
+      src = (o < OUT && k < kend) ? base + (long long)o * ld + k : (const bf16*)g_zero16;
+    } else {
+      const int kr = idx >> 4, c = (idx & 15) ^ wide_sw_nat(kr);
+      const int k = k0 + kr, o = out0 + c * 8;
+      src = (k < kend && o < OUT) ? base + (long long)k * ld + o : (const bf16*)g_zero16;
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s + (j * 256 + (tid & ~63)) * 8), 16, 0, 0);
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 wide_frag(const bf16* s, int out0, int ks, int lane) {
+  if constexpr (KC) {
+    const int row = out0 + (lane & 15);
+    const int c = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
+    return *(const bf16x8*)(s + row * 64 + c * 8);
+  } else {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int kr = ks * 32 + 8 * g + q;                       // (kr + 4) has the same swizzle: q < 4
+    const int c = ((out0 >> 3) + (pp >> 1)) ^ wide_sw_nat(kr);
+    const bf16* b = s + kr * 128 + c * 8 + (pp & 1) * 4;
+    typedef bf16x4_t __attribute__((address_space(3))) * lds4;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * 128));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void gemm_wide_block(const GemmParams& p, const int bx, const int by, const int bzz, bf16* sA, bf16* sB) {
+  typedef bf16 T;
+  constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int n0 = bx * 128, m0 = by * 128;
+  const int bz = bzz / p.splitk, sk = bzz % p.splitk;
+  const int bb = bz / p.nh, bh = bz % p.nh;
+  const T* A = (const T*)p.A + bb * p.sAb + bh * p.sAh;
+  const T* B = (const T*)p.B + bb * p.sBb + bh * p.sBh;
+  const long long coff = bb * p.sCb + bh * p.sCh;
+  const int ktiles = (p.K + 63) / 64;
+  const int per = (ktiles + p.splitk - 1) / p.splitk;
+  const int kt0 = sk * per, kt1 = min(ktiles, kt0 + per);
+  if (kt0 >= kt1 && p.splitk > 1) return;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool do_bgrad = (LAYOUT == 2) && p.bias_grad != nullptr && bx == 0;
+
+  // two LDS stages of 32 KB (A tile, B tile): the fill of tile kt+1 is issued right after the barrier that publishes tile kt and lands
+  // while tile kt is multiplied -- one barrier per K-step; 64 KB of LDS, two workgroups per CU.  (One stage with four workgroups per CU
+  // measured 15-30 % slower: 8192x3072x768 64 vs 55 us.)
+  wide_stage<A_KC>(A, p.lda, m0, kt0 * 64, p.M, p.K, sA, tid);
+  wide_stage<B_KC>(B, p.ldb, n0, kt0 * 64, p.N, p.K, sB, tid);
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();              // tile kt has landed for every wave, and every wave is past the multiply of tile kt-1
+    const bf16* tA = sA + cur * (2 * 128 * 64);
+    const bf16* tB = sB + cur * (2 * 128 * 64);
+    if (kt + 1 < kt1) {
+      wide_stage<A_KC>(A, p.lda, m0, (kt + 1) * 64, p.M, p.K, sA + (cur ^ 1) * (2 * 128 * 64), tid);
+      wide_stage<B_KC>(B, p.ldb, n0, (kt + 1) * 64, p.N, p.K, sB + (cur ^ 1) * (2 * 128 * 64), tid);
+    }
+    cur ^= 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = wide_frag<A_KC>(tA, (wr * 4 + i) * 16, ks, lane);
+        b[i] = wide_frag<B_KC>(tB, (wc * 4 + i) * 16, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_bgrad && tid < 128) {                     // TN: A is the natural [k][out] image; column `tid` summed over the tile's k
+      float s = 0.f;
+      const int c = tid >> 3, e = tid & 7;
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) s += to_f(tA[k * 128 + ((c ^ wide_sw_nat(k)) << 3) + e]);
+      bsum += s;
+    }
+  }
+  if (do_bgrad && tid < 128 && m0 + tid < p.M) atomicAdd(p.bias_grad + m0 + tid, bsum);
+
+  // epilogue, one 16-row band of the wave's sub-tile at a time (16 values per lane live, not 64)
+  const int cr = (lane >> 4) * 4, cc = lane & 15;
+  const bool has_aux = (p.epilogue == 3 || p.epilogue == 4);
+  float bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + (wc * 4 + j) * 16 + cc;
+    bv[j] = (p.bias && sk == 0 && col < p.N) ? p.bias[col] : 0.f;
+  }
+  // every runtime switch is block-uniform and sits OUTSIDE the element loops: {all loads} -> {math} -> {all stores} per band, so a
+  // lane's memory round trips overlap (a conditional load per element compiles to load / wait / use chains: +14 us per launch)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float v[16], ax[16], rs[16];
+    auto col_of = [&](int e) { return n0 + (wc * 4 + (e >> 2)) * 16 + cc; };
+    auto row_of = [&](int e) { return m0 + (wr * 4 + i) * 16 + cr + (e & 3); };
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { ax[e] = 0.f; rs[e] = 0.f; }
+    if (has_aux) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int col = col_of(e), row = row_of(e);
+        if (col < p.N && row < p.M) ax[e] = to_f(((const T*)p.aux)[coff + (long long)row * p.ldaux + col]);
+      }
+    }
+    if (p.residual) {
+      if (p.c_f32) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int col = col_of(e), row = row_of(e);
+          if (col < p.N && row < p.M) rs[e] = ((const float*)p.residual)[coff + (long long)row * p.ldr + col];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int col = col_of(e), row = row_of(e);
+          if (col < p.N && row < p.M) rs[e] = to_f(((const T*)p.residual)[coff + (long long)row * p.ldr + col]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = acc[i][e >> 2][e & 3] * p.alpha + bv[e >> 2];
+    if (p.C2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int col = col_of(e), row = row_of(e);
+        if (col < p.N && row < p.M) ((T*)p.C2)[coff + (long long)row * p.ldc2 + col] = from_f<T>(v[e]);
+      }
+    }
+    if (p.epilogue == 1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
+    } else if (p.epilogue == 2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (p.epilogue == 3) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] *= dgelu_f(ax[e]);
+    } else if (p.epilogue == 4) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = ax[e] > 0.f ? v[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] += rs[e];
+    if (p.c_f32) {
+      if (p.accumulate) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int col = col_of(e), row = row_of(e);
+          if (col < p.N && row < p.M) atomicAdd((float*)p.C + coff + (long long)row * p.ldc + col, v[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int col = col_of(e), row = row_of(e);
+          if (col < p.N && row < p.M) ((float*)p.C)[coff + (long long)row * p.ldc + col] = v[e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int col = col_of(e), row = row_of(e);
+        if (col < p.N && row < p.M) ((T*)p.C)[coff + (long long)row * p.ldc + col] = from_f<T>(v[e]);
+      }
+    }
+  }
+}
+
+// XCD-aware 1-D tile map as in gemm_xcd_kernel, nx / ny counted in 128-wide tiles
+__device__ __forceinline__ bool wide_tile_of(int nx, int ny, int ny8, int& bx, int& by, int& z) {
   const int per_z = nx * (ny8 > 0 ? ny8 : ny);
-  const int z = blockIdx.x / per_z, l2 = blockIdx.x - z * per_z;
-  int bx, by;
+  z = blockIdx.x / per_z;
+  const int l2 = blockIdx.x - z * per_z;
   if (ny8 > 0) {                      // row tile r on XCD r % 8, its column tiles in consecutive slots of that XCD
     const int xcd = l2 & 7, slot = l2 >> 3;
     const int lr = slot / nx;
     bx = slot - lr * nx;
     by = lr * 8 + xcd;
-    if (by >= ny) return;
-  } else {                            // few row tiles: plain row-major tile order
-    by = l2 / nx;
-    bx = l2 - by * nx;
+    return by < ny;
   }
-  gemm_block<T, LAYOUT, 4>(p, bx, by, z, sA, sB);
+  by = l2 / nx;                       // few row tiles: plain row-major tile order
+  bx = l2 - by * nx;
+  return true;
+}
+template <int LAYOUT>
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(GemmParams p, int nx, int ny, int ny8) {
+  __shared__ __attribute__((aligned(1024))) bf16 sAB[4 * 128 * 64];          // stage s: A at s * 32 KB, B 16 KB behind it
+  int bx, by, z;
+  if (!wide_tile_of(nx, ny, ny8, bx, by, z)) return;
+  gemm_wide_block<LAYOUT>(p, bx, by, z, sAB, sAB + 128 * 64);
 }
 
 // Grouped weight-gradient GEMM: up to GROUP_MAX independent TN problems (dW[N,K] += dY^T X, split-K, fp32 atomics, fused
@@ -408,24 +620,30 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupedParams gp) {
   }
 }
 
-// 128x128 tile selection.  Measured on MI355X (profiles/micro/gemm_tile_sweep.py, profiles/micro/r01_gemm_tile_sweep.txt): as built
-// (register-staged, 2-deep, 256 VGPRs -> one workgroup per CU) the 128x128 tile is SLOWER than the 64x64 tile on every linear-layer
-// shape of MAGIC-S/M/L, so it is off by default (mode 0).  mode 1: heuristic (>= min_tiles tiles and K >= min_k); mode 2: whenever
-// M, N >= 128.  Set from the environment (MAGIC_GEMM_BIG) or magic_gemm_set_big() (tests, tuning).
-static int g_big_mode = -1, g_big_min_tiles = 96, g_big_min_k = 256;
+// Wide-tile selection (bf16; M, N >= 128; the contiguous dimension of each operand a multiple of 8).  Measured on MI355X
+// (profiles/micro/gemm_tile_sweep.py -> profiles/micro/r01_gemm_tile_sweep.txt): the wide tile wins on the forward / input-gradient GEMMs
+// once the output has >= ~192 tiles of 128x128 and K >= 512 (M = 8192 rows at H = 768: 1.4-1.9x over the 64x64 tile, 1.2-1.3x behind
+// hipBLASLt); the 64x64 tile keeps every MAGIC-S / MAGIC-M shape and every M ~ 600 navigator-step shape.  The weight gradient (TN) stays on
+// the 64x64 tile: it is bound by its fp32 atomics, and the host's split-K choice (ops._splitk) is what matters there.
+// mode 0: never; mode 1 (default): the rule above; mode 2: whenever eligible, all three layouts (tests).
+// Set from the environment (MAGIC_GEMM_BIG) or magic_gemm_set_big() (tests, tuning).
+static int g_big_mode = -1, g_big_min_tiles = 192, g_big_min_k = 512;
 extern "C" int magic_gemm_set_big(int mode) {
   if (mode < 0 || mode > 2) return MAGIC_ERR_ARG;
   g_big_mode = mode;
   return MAGIC_OK;
 }
-static int gemm_big_tile(int M, int N, int K, int nz) {
+static int gemm_big_tile(int dtype, int layout, int M, int N, int K, int nz) {
   if (g_big_mode < 0) {
-    const char* e = getenv("MAGIC_GEMM_BIG"); g_big_mode = e ? atoi(e) : 0;
+    const char* e = getenv("MAGIC_GEMM_BIG"); g_big_mode = e ? atoi(e) : 1;
     const char* t = getenv("MAGIC_GEMM_BIG_MIN_TILES"); if (t) g_big_min_tiles = atoi(t);
     const char* k = getenv("MAGIC_GEMM_BIG_MIN_K"); if (k) g_big_min_k = atoi(k);
   }
-  if (g_big_mode == 0 || M < 128 || N < 128) return 0;
+  if (g_big_mode == 0 || dtype != DT_BF16 || M < 128 || N < 128) return 0;
+  // 16-byte chunks must lie wholly inside or outside the logical extent of each operand's contiguous dimension
+  if (layout == 0 ? (K % 8) : layout == 1 ? ((K % 8) || (N % 8)) : ((M % 8) || (N % 8))) return 0;
   if (g_big_mode == 2) return 1;
+  if (layout == 2) return 0;
   const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * nz;
   return (tiles >= g_big_min_tiles && K >= g_big_min_k) ? 1 : 0;
 }
@@ -454,7 +672,7 @@ extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N
   p.sAb = sAb; p.sAh = sAh; p.sBb = sBb; p.sBh = sBh; p.sCb = sCb; p.sCh = sCh;
   p.nh = nh; p.splitk = splitk; p.epilogue = epilogue; p.c_f32 = c_f32; p.accumulate = accumulate; p.alpha = alpha;
   p.batch = batch;
-  p.big = gemm_big_tile(M, N, K, batch * splitk);
+  p.big = gemm_big_tile(dtype, layout, M, N, K, batch * splitk);
   if (group_record(KIND_GEMM, dtype, layout, &p, sizeof(p))) return MAGIC_OK;
   return launch_gemm(dtype, layout, &p, nullptr, (hipStream_t)stream);
 }
@@ -490,12 +708,9 @@ int launch_gemm(int dtype, int layout, const void* pa, const void* pb, hipStream
     const int nx = (a.N + 127) / 128, ny = (a.M + 127) / 128, nz = a.batch * a.splitk;
     const int ny8 = (gemm_xcd_on() && nx >= 2 && ny >= 16) ? (ny + 7) / 8 * 8 : 0;
     dim3 g1((unsigned)(nx * (ny8 > 0 ? ny8 : ny) * nz));
-#define LAUNCHB(TY, L) hipLaunchKernelGGL((gemm_big_kernel<TY, L>), g1, block, 0, st, a, nx, ny, ny8)
-    if (dtype == DT_BF16) {
-      if (layout == 0) LAUNCHB(bf16, 0); else if (layout == 1) LAUNCHB(bf16, 1); else LAUNCHB(bf16, 2);
-    } else {
-      if (layout == 0) LAUNCHB(float, 0); else if (layout == 1) LAUNCHB(float, 1); else LAUNCHB(float, 2);
-    }
+#define LAUNCHB(L) hipLaunchKernelGGL((gemm_wide_kernel<L>), g1, block, 0, st, a, nx, ny, ny8)
+    if (dtype != DT_BF16) return MAGIC_ERR_ARG;
+    if (layout == 0) LAUNCHB(0); else if (layout == 1) LAUNCHB(1); else LAUNCHB(2);
 #undef LAUNCHB
     return launch_status();
   }

@@ -84,6 +84,11 @@ def _splitk(tiles, kred):
     """split-K factor of the weight-gradient GEMM: every split block adds a full 64x64 fp32 tile with atomics (16 KB), so
     the atomic traffic is tiles*splitk*16 KB whatever the true dW size -- keep the grid near one block per CU and give
     each block at least `min_tiles` 64-deep k-tiles."""
+    if tiles > SPLITK["target"]:
+        # wide layers (H >= 768): the output alone gives every CU a tile, but a reduction over thousands of rows still wants splitting;
+        # measured (profiles/micro/tn_splitk_scan.py, M = 8192): 768x768 141 -> 43 us at 8 splits, 3072x768 170 -> 115 us at 4-8 (then the
+        # fp32 atomic traffic of the extra splits takes over)
+        return int(max(1, min(kred // 1024, 8 if tiles <= 256 else 4)))
     ks = max(1, (kred + 64 * SPLITK["min_tiles"] - 1) // (64 * SPLITK["min_tiles"]))
     return int(max(1, min(SPLITK["target"] // max(tiles, 1), ks, 64)))
 

@@ -526,3 +526,31 @@ def test_gemm_default_tile_rule_large_forward_and_long_reduction_weight_gradient
     O.linear_dw(dy, x, dW, db, M)
     check(dW, dy.float().t() @ x.float(), "default dW", rtol=2e-2, atol=5e-2 * math.sqrt(M / 64))
     check(db, dy.float().sum(0), "default db", rtol=2e-2, atol=5e-2 * math.sqrt(M / 64))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_k_group_kernel_few_tiles_long_k(dtype):
+    """few output tiles and a long K -> gemm_kg_kernel (4 K-groups per workgroup, partial sums added through LDS): forward with every
+    epilogue operand, input gradient through the transposed operand image, ragged M / N and a K tail"""
+    M, N, K = 601, 776, 3080                       # 10 x 13 = 130 tiles of 64x64, 49 K-tiles (the last one 8 deep)
+    x, W = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, scale=0.05)
+    b, res = rnd(N, scale=0.5), rnd(M, N, dtype=dtype)
+    ref = x.float() @ W.float().t() + b
+    t = tol(dtype) if dtype == torch.float32 else dict(rtol=2e-2, atol=1e-1)
+    check(O.linear_fwd(x, W, b, M), ref, "kg nt+bias", **t)
+    pre = torch.empty(M, N, dtype=dtype, device=DEV)
+    out = O.linear_fwd(x, W, b, M, epilogue=1, residual=res, pre=pre)
+    check(pre, ref, "kg pre-activation", **t)
+    check(out, F.gelu(ref) + res.float(), "kg gelu+residual", **t)
+    K2 = 768                                        # dx[M,K2] = dy[M,N2] @ W2[N2,K2], contraction over N2 = 3080
+    N2 = 3080
+    dy, W2 = rnd(M, N2, dtype=dtype, scale=0.3), rnd(N2, K2, dtype=dtype, scale=0.05)
+    z, r = rnd(M, K2, dtype=dtype), rnd(M, K2, dtype=dtype)
+    refx = dy.float() @ W2.float()
+    check(O.linear_dx(dy, W2, M), refx, "kg nn", **t)
+    zz = z.float().requires_grad_(True)
+    F.gelu(zz).backward(torch.ones_like(zz))
+    check(O.linear_dx(dy, W2, M, epilogue=3, aux=z, residual=r), refx * zz.grad + r.float(), "kg nn+dgelu+res", **t)
+    # K between 768 and one round of 4 tiles short of the pipeline depth
+    x3, W3 = rnd(M, 768, dtype=dtype), rnd(N, 768, dtype=dtype, scale=0.05)
+    check(O.linear_fwd(x3, W3, None, M), x3.float() @ W3.float().t(), "kg nt K=768", **t)

@@ -49,7 +49,7 @@ template <typename T, bool KC, int TM = 64> struct TileLoader {
   __device__ __forceinline__ void load(const T* __restrict__ base, int ld, int out0, int k0, int OUT, int kend) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      int id = threadIdx.x + 256 * i;
+      int id = (threadIdx.x & 255) + 256 * i;
       vec z;
 #pragma unroll
       for (int e = 0; e < VE; ++e) z[e] = (T)0.0f;
@@ -69,7 +69,7 @@ template <typename T, bool KC, int TM = 64> struct TileLoader {
   __device__ __forceinline__ void store(T* s) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      int id = threadIdx.x + 256 * i;
+      int id = (threadIdx.x & 255) + 256 * i;
       if (KC) {
         int row = id >> 3, cv = id & 7;
         T* d = s + row * STRIDE + cv * VE;
@@ -154,7 +154,11 @@ __device__ __forceinline__ void mma_tile(const float* sA, const float* sB, int w
 // NT_: 16x16 MFMA tiles per wave per dimension.  2 -> the 64x64 block tile every small problem uses; 4 -> a 128x128 block tile
 // (64x64 per wave, 16 accumulator tiles) for problems with enough rows and columns: each workgroup then streams half the
 // operand bytes per output element from L2 and issues half the LDS reads per MFMA, which is what bounds the H >= 256 shapes.
-template <typename T, int LAYOUT, int NT_ = 2>
+// KG: K-groups per workgroup (1, or 4 for `gemm_kg_kernel`): KG x 256 threads, group g multiplies the K-tiles g, g + KG, ... into its own
+// accumulators from its own LDS images -- one barrier round advances KG tiles -- and the partial sums are added through LDS at the end.
+// For problems with fewer tiles than CUs and a long K (the M ~ 600 navigator-step GEMMs at H = 768: 120 tiles, 48 K-tiles) the time of
+// a launch is (K-tiles) x (latency of one barrier round); the groups divide the rounds by KG without an fp32 round trip through HBM.
+template <typename T, int LAYOUT, int NT_ = 2, int KG = 1>
 __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, const int by, const int bzz, T* sA, T* sB) {
   constexpr int BK = TT<T>::BK, STRIDE = TT<T>::STRIDE;
   constexpr int TM = 32 * NT_;                       // block tile is TM x TM
@@ -163,9 +167,11 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
   constexpr int NE = NT_ * NT_ * 4;                  // accumulator elements per lane
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, kg = threadIdx.x >> 8;
   const int wr = wid >> 1, wc = wid & 1;
   const int n0 = bx * TM, m0 = by * TM;
+  T* const sA0 = sA;
+  if constexpr (KG > 1) { sA += kg * (TM * TT<T>::STRIDE); sB += kg * (TM * TT<T>::STRIDE); }
   const int bz = bzz / p.splitk, sk = bzz % p.splitk;
   const int bb = bz / p.nh, bh = bz % p.nh;
 
@@ -182,7 +188,7 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
   // Register-staged software pipeline, PD tiles deep: the global loads of tiles kt+1 .. kt+PD-1 are in flight while
   // tile kt is written to LDS and multiplied.  These GEMMs run ~1 block per CU (grids of 100-600 blocks), so a
   // block has to hide HBM/L2 latency itself; hipcc turns the in-order loads into counted s_waitcnt vmcnt(N).
-  constexpr int PD = (NT_ == 2) ? 3 : 2;
+  constexpr int PD = (NT_ == 2 && KG == 1) ? 3 : 2;      // K-group kernel: 16 waves per CU hide latency, and 1024 threads cap the VGPRs at 128
   TileLoader<T, A_KC, TM> la[PD];
   TileLoader<T, B_KC, TM> lb[PD];
   f32x4 acc[NT_][NT_];
@@ -193,11 +199,15 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
   float bsum = 0.f;
   const bool do_bgrad = (LAYOUT == 2) && p.bias_grad != nullptr && bx == 0;
 
+  // round r of group kg works on K-tile kt0 + r * KG + kg; a tile index past the end loads zeros (the loader's k < kend test), so
+  // every group executes the same barriers
+  const int kend = min(p.K, kt1 * BK);
+  const int rounds = (kt1 - kt0 + KG - 1) / KG;
 #pragma unroll
   for (int d = 0; d < PD; ++d)
-    if (kt0 + d < kt1) {
-      la[d].load(A, p.lda, m0, (kt0 + d) * BK, p.M, p.K);
-      lb[d].load(B, p.ldb, n0, (kt0 + d) * BK, p.N, p.K);
+    if (d < rounds) {
+      la[d].load(A, p.lda, m0, (kt0 + d * KG + kg) * BK, p.M, kend);
+      lb[d].load(B, p.ldb, n0, (kt0 + d * KG + kg) * BK, p.N, kend);
     }
   // element e of a lane: tile (i, j) = (e / (4 NT_), (e / 4) % NT_), register r = e % 4.
   // C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
@@ -244,17 +254,17 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
       }
     }
   };
-  if constexpr (PRE) load_epi();
-  for (int kt = kt0; kt < kt1; kt += PD) {
+  if constexpr (PRE) { if (KG == 1 || kg == 0) load_epi(); }
+  for (int r = 0; r < rounds; r += PD) {
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
-      if (kt + d < kt1) {           // block-uniform
+      if (r + d < rounds) {           // block-uniform
         la[d].store(sA);
         lb[d].store(sB);
         __syncthreads();
-        if (kt + d + PD < kt1) {
-          la[d].load(A, p.lda, m0, (kt + d + PD) * BK, p.M, p.K);
-          lb[d].load(B, p.ldb, n0, (kt + d + PD) * BK, p.N, p.K);
+        if (r + d + PD < rounds) {
+          la[d].load(A, p.lda, m0, (kt0 + (r + d + PD) * KG + kg) * BK, p.M, kend);
+          lb[d].load(B, p.ldb, n0, (kt0 + (r + d + PD) * KG + kg) * BK, p.N, kend);
         }
         mma_tile<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc);
         if (do_bgrad && tid < TM) {
@@ -268,6 +278,20 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
     }
   }
   if (do_bgrad && tid < TM && m0 + tid < p.M) atomicAdd(p.bias_grad + m0 + tid, bsum);
+  if constexpr (KG > 1) {
+    // partial sums of groups 1 .. KG-1 -> LDS (the operand images are dead after the loop's last barrier), group 0 adds them
+    float* red = (float*)sA0;
+    if (kg > 0) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) red[((kg - 1) * NE + e) * 256 + tid] = acc[e / (4 * NT_)][(e >> 2) % NT_][e & 3];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int g = 0; g < KG - 1; ++g)
+#pragma unroll
+      for (int e = 0; e < NE; ++e) acc[e / (4 * NT_)][(e >> 2) % NT_][e & 3] += red[(g * NE + e) * 256 + tid];
+  }
   if constexpr (!PRE) load_epi();
 
   // epilogue math + stores
@@ -342,6 +366,17 @@ __global__ __launch_bounds__(256) void gemm_xcd_kernel(GemmParams p, int nx, int
   const int by = lr * 8 + xcd;
   if (by >= ny) return;
   gemm_block<T, LAYOUT>(p, bx, by, z, sA, sB);
+}
+
+// K-group variant of gemm_kernel: 1024 threads = 4 K-groups of 4 waves (see gemm_block).  LDS: 4 x (A image + B image) = 72 KB.
+#define KGROUPS 4
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(1024) void gemm_kg_kernel(GemmParams p) {
+  // ONE array: after the K loop the whole of it is the reduction buffer ((KGROUPS-1) x 16 floats x 256 lanes = 48 KB)
+  constexpr int IMG = BM * TT<T>::STRIDE;
+  static_assert(2 * KGROUPS * IMG * sizeof(T) >= (KGROUPS - 1) * 16 * 256 * sizeof(float), "reduction buffer");
+  __shared__ __attribute__((aligned(16))) T smem[2 * KGROUPS * IMG];
+  gemm_block<T, LAYOUT, 2, KGROUPS>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem, smem + KGROUPS * IMG);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -716,6 +751,17 @@ int launch_gemm(int dtype, int layout, const void* pa, const void* pb, hipStream
   }
   if (!pb) {
     const int nx = (a.N + BN - 1) / BN, ny = (a.M + BM - 1) / BM, nz = a.batch * a.splitk;
+    // fewer tiles than CUs and a long K: K-group kernel (4 K-tiles per barrier round).  Measured (profiles/micro/r01_gemm_tile_sweep.txt)
+    static int kg_on = -1;
+    if (kg_on < 0) { const char* e = getenv("MAGIC_GEMM_KG"); kg_on = e ? atoi(e) : 1; }
+    if (kg_on && layout != 2 && a.splitk == 1 && (long long)nx * ny * nz <= 224 && a.K >= 768) {
+      dim3 gk(nx, ny, nz), bk(1024);
+#define LAUNCHK(TY, L) hipLaunchKernelGGL((gemm_kg_kernel<TY, L>), gk, bk, 0, st, a)
+      if (dtype == DT_BF16) { if (layout == 0) LAUNCHK(bf16, 0); else LAUNCHK(bf16, 1); }
+      else { if (layout == 0) LAUNCHK(float, 0); else LAUNCHK(float, 1); }
+#undef LAUNCHK
+      return launch_status();
+    }
     if (gemm_xcd_on() && nx >= 2 && ny >= 16) {         // enough row tiles that the padding to a multiple of 8 is small
       const int ny8 = (ny + 7) / 8 * 8;
       dim3 g1((unsigned)(nx * ny8 * nz));

@@ -121,6 +121,19 @@ def _queue_sync(model):
     torch.autograd.Variable._execution_engine.queue_callback(_done)
 
 
+def _u8(m):
+    """mask -> uint8 without a launch when it is bool / uint8 already (bool and uint8 share their storage layout)"""
+    if m.dtype == torch.uint8:
+        return m.contiguous()
+    if m.dtype == torch.bool:
+        return m.contiguous().view(torch.uint8)
+    return m.to(torch.uint8).contiguous()
+
+
+def _i32(t):
+    return t if t.dtype == torch.int32 else t.to(torch.int32)
+
+
 def _zeros_like_shape(t, shape, dtype, device):
     return torch.zeros(shape, dtype=dtype, device=device) if t is None else t
 
@@ -158,19 +171,20 @@ class _LanguageFn(torch.autograd.Function):
 
 class _PanoramaFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, model, view_img_fts, loc_fts, nav_types, view_lens):
+    def forward(ctx, anchor, model, view_img_fts, loc_fts, nav_types, view_lens, pano_masks=None):
         net = model.net
         B, V, D = view_img_fts.shape
         dev = view_img_fts.device
-        plan = dict(Np=B, V=V, nav_types=nav_types.reshape(-1).to(torch.int32), view_lens=view_lens.to(torch.int32),
-                    pano_mask=(torch.arange(V, device=dev)[None] < view_lens[:, None]).to(torch.uint8))
+        if pano_masks is None:          # index-plan rollouts hand the mask over with the step's other index arrays (no launches here)
+            pano_masks = torch.arange(V, device=dev)[None] < view_lens[:, None]
+        plan = dict(Np=B, V=V, nav_types=_i32(nav_types.reshape(-1)), view_lens=_i32(view_lens), pano_mask=_u8(pano_masks))
         if view_img_fts.dtype == net.dtype:     # gathered from the HBM feature table in the compute dtype already
             feats = view_img_fts.detach().reshape(B * V, D).contiguous()
         else:
             feats = O.cast_to(view_img_fts.detach().float().reshape(B * V, D).contiguous(), net.dtype)
         c = net.pano_fwd(plan, feats, loc_fts.detach().float().reshape(B * V, -1).contiguous())
         ctx.model, ctx.c, ctx.plan = model, c, plan
-        masks = plan["pano_mask"].bool()
+        masks = plan["pano_mask"].view(torch.bool)
         ctx.mark_non_differentiable(masks)
         return c.out.view(B, V, net.H), masks, c.fused, c.img_attn[..., :V]
 
@@ -190,7 +204,7 @@ class _PanoramaFn(torch.autograd.Function):
             dP = torch.empty(Np, net.nh, V, c.ldp, dtype=torch.float32, device=dev)
             O.head_mean_bwd(g, dP, Np, net.nh, V * c.ldp)
         net.pano_bwd(c, ctx.plan, d_pano, df, dP)
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
 def nav_fusion_plan(gmap_vpids, gmap_visited_masks, vp_cand_vpids, K, Vp):
@@ -273,12 +287,10 @@ class _NavigationFn(torch.autograd.Function):
         txt_masks = b["txt_masks"]
         hl = b.get("host_lens")          # index-plan rollout: the host already knows every length (no device->host sync)
         tl, gl_, vl = hl if hl is not None else (txt_masks.sum(1).tolist(), b["gmap_masks"].sum(1).tolist(), b["vp_masks"].sum(1).tolist())
-        plan = dict(B=B, K=K, Vp=Vp, L=L, gmap_step_ids=b["gmap_step_ids"].reshape(-1).to(torch.int32))
+        plan = dict(B=B, K=K, Vp=Vp, L=L, gmap_step_ids=_i32(b["gmap_step_ids"].reshape(-1)))
         c = Ctx(plan=plan, B=B, K=K, Vp=Vp, L=L)
         txt = txt_embeds.detach().to(net.dtype).reshape(B * L, H).contiguous()
-        tmask = txt_masks.to(torch.uint8).contiguous()
-        gmask_u8 = b["gmap_masks"].to(torch.uint8).contiguous()
-        vmask_u8 = b["vp_masks"].to(torch.uint8).contiguous()
+        tmask, gmask_u8, vmask_u8 = _u8(txt_masks), _u8(b["gmap_masks"]), _u8(b["vp_masks"])
         c.gin = net.gmap_in_fwd(plan, None, b["gmap_pos_fts"].float().reshape(B * K, -1).contiguous(),
                                 gimg=gmap_img.detach().to(net.dtype).reshape(B * K, H).contiguous())
         nl = net.cfg.num_x_layers
@@ -304,8 +316,11 @@ class _NavigationFn(torch.autograd.Function):
             O.lndot_fwd(c.Yf, B, H, fln.g, fln.b, net.eps, f2.Wm, f2.b, c.fuse_raw)
         else:
             c.fuse_raw = net.zeros(B, dtype=torch.float32)
-        c.gmask = ((~b["gmap_visited_masks"]) & b["gmap_masks"]).to(torch.uint8).contiguous()
-        c.lmask = b["vp_nav_masks"].to(torch.uint8).contiguous()
+        if b.get("gmap_logit_masks") is not None:      # ~visited & valid, built with the step's other index arrays (host/nav_plan.py)
+            c.gmask = _u8(b["gmap_logit_masks"])
+        else:
+            c.gmask = _u8((~b["gmap_visited_masks"]) & b["gmap_masks"])
+        c.lmask = _u8(b["vp_nav_masks"])
         if b.get("fusion") is not None:   # (fsrc int32 [B,K], bw uint8 [B,Vp]) already on the device (host/nav_plan.fusion_map)
             c.fsrc, c.bw = b["fusion"]
         else:
@@ -438,11 +453,11 @@ class VLNBert(nn.Module):
             fts = batch["view_img_fts"]
             if not batch.get("already_dropout", True):
                 fts = self.drop_env(fts)
-            return _PanoramaFn.apply(self._anchor, self, fts, batch["loc_fts"], batch["nav_types"], batch["view_lens"])
+            return _PanoramaFn.apply(self._anchor, self, fts, batch["loc_fts"], batch["nav_types"], batch["view_lens"], batch.get("pano_masks"))
         if mode == "navigation":
             data = {k: batch[k] for k in ("txt_masks", "gmap_masks", "vp_masks", "gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists",
                                           "gmap_visited_masks", "gmap_vpids", "vp_pos_fts", "vp_nav_masks", "vp_cand_vpids")}
-            data["host_lens"], data["fusion"] = batch.get("host_lens"), batch.get("fusion")
+            data["host_lens"], data["fusion"], data["gmap_logit_masks"] = batch.get("host_lens"), batch.get("fusion"), batch.get("gmap_logit_masks")
             g, v, ga, va, cls, gl, ll, fl = _NavigationFn.apply(self._anchor, self, batch["gmap_img_embeds"], batch["vp_img_embeds"],
                                                                 batch["txt_embeds"], data, batch.get("txt_kv"))
             return dict(gmap_embeds=g, vp_embeds=v, gmap_attns=ga, vp_attns=va, cls_embeds=cls,

@@ -31,8 +31,8 @@ class GreedyNavigator:
         self.nnz_max = B * K * nnz_per_token + B * Vp
         self.log_rows = Tmax * B * (V + 2)
         f32, i32, i64, u8 = np.float32, np.int32, np.int64, np.uint8
-        spec = [("vp_rows", (B,), i32), ("view_order", (B, V), i32), ("loc_fts", (B, V, 7), f32), ("nav_types", (B, V), i64),
-                ("view_lens", (B,), i64), ("gmap_step_ids", (B, K), i64), ("gmap_pos_fts", (B, K, 7), f32),
+        spec = [("vp_rows", (B,), i32), ("view_order", (B, V), i32), ("loc_fts", (B, V, 7), f32), ("nav_types", (B, V), i32),
+                ("view_lens", (B,), i32), ("pano_masks", (B, V), u8), ("gmap_logit_masks", (B, K), u8), ("gmap_step_ids", (B, K), i32), ("gmap_pos_fts", (B, K, 7), f32),
                 ("gmap_pair_dists", (B, K, K), f32), ("gmap_visited_masks", (B, K), u8), ("gmap_masks", (B, K), u8),
                 ("vp_pos_fts", (B, Vp, 14), f32), ("vp_nav_masks", (B, Vp), u8), ("vp_masks", (B, Vp), u8),
                 ("fsrc", (B, K), i32), ("bw", (B, Vp), u8), ("csr_ptr", (self.n_out + 1,), i32), ("csr_idx", (self.nnz_max,), i32),
@@ -66,7 +66,7 @@ class GreedyNavigator:
         fts = torch.empty(B, V, self.table.shape[2], dtype=self.table.dtype, device=self.dev)
         O.view_gather(self.table, d["vp_rows"], d["view_order"], fts)
         pe, pm, pf, pa = m("panorama", dict(view_img_fts=fts, loc_fts=d["loc_fts"], nav_types=d["nav_types"], view_lens=d["view_lens"],
-                                            already_dropout=True))
+                                            already_dropout=True, pano_masks=d["pano_masks"].view(torch.bool)))
         self.log.index_copy_(0, d["rows_pe"], pe.reshape(B * V, H))
         self.log.index_copy_(0, d["rows_pf"], pf)
         g = torch.empty(self.n_out, H, dtype=self.log.dtype, device=self.dev)
@@ -74,10 +74,11 @@ class GreedyNavigator:
         lens = ([self.Lmax] * B, [K] * B, [Vp] * B)                    # only used for FLOP accounting
         outs = m("navigation", dict(gmap_img_embeds=g[:B * K].view(B, K, H), vp_img_embeds=g[B * K:].view(B, Vp, H),
                                     txt_embeds=self.txt_embeds, txt_kv=self.txt_kv, txt_masks=self.txt_masks,
-                                    gmap_masks=d["gmap_masks"].bool(), vp_masks=d["vp_masks"].bool(), gmap_step_ids=d["gmap_step_ids"],
+                                    gmap_masks=d["gmap_masks"].view(torch.bool), vp_masks=d["vp_masks"].view(torch.bool), gmap_step_ids=d["gmap_step_ids"],
+                                    gmap_logit_masks=d["gmap_logit_masks"],
                                     gmap_pos_fts=d["gmap_pos_fts"], gmap_pair_dists=d["gmap_pair_dists"],
-                                    gmap_visited_masks=d["gmap_visited_masks"].bool(), gmap_vpids=None, vp_pos_fts=d["vp_pos_fts"],
-                                    vp_nav_masks=d["vp_nav_masks"].bool(), vp_cand_vpids=None, host_lens=lens, fusion=(d["fsrc"], d["bw"])))
+                                    gmap_visited_masks=d["gmap_visited_masks"].view(torch.bool), gmap_vpids=None, vp_pos_fts=d["vp_pos_fts"],
+                                    vp_nav_masks=d["vp_nav_masks"].view(torch.bool), vp_cand_vpids=None, host_lens=lens, fusion=(d["fsrc"], d["bw"])))
         self.log.index_copy_(0, d["rows_cls"], outs["cls_embeds"])
         logits = outs["fused_logits"]
         self.out_dev[0].copy_(logits.argmax(1).float())
@@ -95,6 +96,8 @@ class GreedyNavigator:
         if len(idx) > self.nnz_max or plan["K"] != self.Kmax or plan["V"] != V or plan["log_rows"] > self.log_rows:
             raise ValueError(f"episode exceeds the captured static shapes (K {plan['K']}/{self.Kmax}, V {plan['V']}/{V}, "
                              f"nnz {len(idx)}/{self.nnz_max}, log rows {plan['log_rows']}/{self.log_rows})")
+        arrays.update(pano_masks=np.arange(V)[None] < np.asarray(plan["view_lens"])[:, None],
+                      gmap_logit_masks=~np.asarray(plan["gmap_visited_masks"], bool) & np.asarray(plan["gmap_masks"], bool))
         arrays.update(csr_ptr=ptr, rows_pe=np.arange(plan["log_base"], plan["log_base"] + B * V, dtype=np.int64),
                       rows_pf=np.arange(plan["log_fused"], plan["log_fused"] + B, dtype=np.int64),
                       rows_cls=np.arange(plan["log_cls"], plan["log_cls"] + B, dtype=np.int64))

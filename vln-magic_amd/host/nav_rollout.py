@@ -113,15 +113,16 @@ class NavRollout:
         B, V = plan["B"], plan["V"]
         fts = torch.empty(B, V, self.table.shape[2], dtype=self.table.dtype, device=self.dev)
         O.view_gather(self.table, d["vp_rows"], d["view_order"], fts)
-        return dict(view_img_fts=fts, loc_fts=d["loc_fts"], nav_types=d["nav_types"], view_lens=d["view_lens"], already_dropout=True)
+        return dict(view_img_fts=fts, loc_fts=d["loc_fts"], nav_types=d["nav_types"], view_lens=d["view_lens"], already_dropout=True,
+                    pano_masks=d["pano_masks"].view(torch.bool))
 
     def _nav_inputs(self, d, plan, gathered, txt_embeds, txt_masks, txt_lens, txt_kv=None):
         B, K, Vp, H = plan["B"], plan["K"], plan["Vp"], gathered.shape[1]
         return dict(gmap_img_embeds=gathered[:B * K].view(B, K, H), vp_img_embeds=gathered[B * K:].view(B, Vp, H),
-                    txt_embeds=txt_embeds, txt_kv=txt_kv, txt_masks=txt_masks, gmap_masks=d["gmap_masks"].bool(), vp_masks=d["vp_masks"].bool(),
+                    txt_embeds=txt_embeds, txt_kv=txt_kv, txt_masks=txt_masks, gmap_masks=d["gmap_masks"].view(torch.bool), vp_masks=d["vp_masks"].view(torch.bool),
                     gmap_step_ids=d["gmap_step_ids"], gmap_pos_fts=d["gmap_pos_fts"], gmap_pair_dists=d["gmap_pair_dists"],
-                    gmap_visited_masks=d["gmap_visited_masks"].bool(), gmap_vpids=plan["gmap_vpids"], vp_pos_fts=d["vp_pos_fts"],
-                    vp_nav_masks=d["vp_nav_masks"].bool(), vp_cand_vpids=plan["vp_cand_vpids"],
+                    gmap_visited_masks=d["gmap_visited_masks"].view(torch.bool), gmap_logit_masks=d["gmap_logit_masks"], gmap_vpids=plan["gmap_vpids"], vp_pos_fts=d["vp_pos_fts"],
+                    vp_nav_masks=d["vp_nav_masks"].view(torch.bool), vp_cand_vpids=plan["vp_cand_vpids"],
                     host_lens=(txt_lens, [int(x) - 1 for x in plan["gmap_lens"]], [int(x) + 2 for x in plan["view_lens"]]),
                     fusion=(d["fsrc"], d["bw"]))
 
@@ -205,7 +206,10 @@ class NavRollout:
             for t in range(self.T):
                 plan = pl.begin_pano()
                 decisions += int((~pl.ended).sum())
-                d = to_device({k: plan[k] for k in ("vp_rows", "view_order", "loc_fts", "nav_types", "view_lens")}, dev)
+                vl = np.asarray(plan["view_lens"])
+                d = to_device(dict(vp_rows=plan["vp_rows"], view_order=plan["view_order"], loc_fts=plan["loc_fts"],
+                                   nav_types=np.asarray(plan["nav_types"]).astype(np.int32), view_lens=vl.astype(np.int32),
+                                   pano_masks=np.arange(plan["V"])[None] < vl[:, None]), dev)      # dtypes the kernels read: no casts on the device
                 pin = self._pano_inputs(d, plan)
                 pe, pm, pf, pa = st("panorama", pin)
                 s_out.update(pano_embeds=pe, pano_fused_embeds=pf, img_attns=pa)
@@ -216,6 +220,8 @@ class NavRollout:
                 plan.update(pl.begin_nav())
                 arrays = {k: plan[k] for k in ("gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists", "gmap_visited_masks", "gmap_masks",
                                                "vp_pos_fts", "vp_nav_masks", "vp_masks", "fsrc", "bw", "targets")}
+                arrays["gmap_step_ids"] = np.asarray(plan["gmap_step_ids"]).astype(np.int32)
+                arrays["gmap_logit_masks"] = ~np.asarray(plan["gmap_visited_masks"], bool) & np.asarray(plan["gmap_masks"], bool)
                 arrays.update(csr_ptr=plan["csr"][0], csr_idx=plan["csr"][1], csr_w=plan["csr"][2])
                 if plan["csr_t"] is not None:
                     arrays.update(csrt_ptr=plan["csr_t"][0], csrt_idx=plan["csr_t"][1], csrt_w=plan["csr_t"][2])

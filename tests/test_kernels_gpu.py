@@ -554,3 +554,35 @@ def test_gemm_k_group_kernel_few_tiles_long_k(dtype):
     # K between 768 and one round of 4 tiles short of the pipeline depth
     x3, W3 = rnd(M, 768, dtype=dtype), rnd(N, 768, dtype=dtype, scale=0.05)
     check(O.linear_fwd(x3, W3, None, M), x3.float() @ W3.float().t(), "kg nt K=768", **t)
+
+
+def test_gemm_wide_tile_random_shapes_and_batched_strides(big_tiles):
+    """the LDS-DMA wide tile against fp32 torch on seeded random shapes (every extent a multiple of 8, tile edges in all three
+    dimensions, K down to one 8-element chunk) and on a batched (batch, head)-strided problem"""
+    g = torch.Generator().manual_seed(7)
+    dtype = torch.bfloat16
+    shapes = [(128, 128, 8), (136, 264, 72), (1024, 128, 64), (129 * 8, 131 * 8, 65 * 8)]
+    for _ in range(6):
+        M, N, K = (int(torch.randint(16, 200, (1,), generator=g)) * 8 for _ in range(3))
+        shapes.append((M, N, K))
+    for M, N, K in shapes:
+        x, W = rnd(M, K, dtype=dtype, seed=M + K), rnd(N, K, dtype=dtype, scale=0.1, seed=N)
+        atol = 2e-2 * math.sqrt(K / 8) + 2e-2
+        check(O.linear_fwd(x, W, None, M), x.float() @ W.float().t(), f"wide nt {M}x{N}x{K}", rtol=2e-2, atol=atol)
+        dy = rnd(M, N, dtype=dtype, scale=0.3, seed=M)
+        check(O.linear_dx(dy, W, M), dy.float() @ W.float(), f"wide nn {M}x{N}x{K}", rtol=2e-2, atol=2e-2 * math.sqrt(N / 8) + 2e-2)
+        dW = torch.zeros(N, K, device=DEV)
+        O.linear_dw(dy, x, dW, None, M)
+        check(dW, dy.float().t() @ x.float(), f"wide tn {M}x{N}x{K}", rtol=2e-2, atol=3e-2 * math.sqrt(M / 8) + 2e-2)
+    # batched: C[b,h] = A[b,h] @ B[b,h]^T with (batch, head) strides, 3 x 2 problems of 256 x 136 x 64 inside padded buffers
+    Bn, nh, Mq, Nk, D = 3, 2, 256, 136, 64
+    A = rnd(Bn, Mq, nh * D + 8, dtype=dtype, seed=3)
+    Bm = rnd(Bn, Nk, nh * D + 8, dtype=dtype, seed=4)
+    Cc = torch.zeros(Bn, nh, Mq, Nk + 8, dtype=dtype, device=DEV)
+    ld = nh * D + 8
+    O.gemm(0, A, Bm, Cc, Mq, Nk, D, ld, ld, Nk + 8, batch=Bn * nh, nh=nh, sA=(Mq * ld, D), sB=(Nk * ld, D), sC=(nh * Mq * (Nk + 8), Mq * (Nk + 8)))
+    for b in range(Bn):
+        for h in range(nh):
+            ref = A[b, :, h * D:(h + 1) * D].float() @ Bm[b, :, h * D:(h + 1) * D].float().t()
+            check(Cc[b, h, :, :Nk], ref, f"wide batched {b},{h}", rtol=2e-2, atol=8e-2)
+    assert float(Cc[..., Nk:].abs().max()) == 0.0

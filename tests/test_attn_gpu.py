@@ -114,7 +114,8 @@ def test_fused_linear_residual_layernorm(dtype, M, H, K):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,H,K,res,p", [(100, 128, 512, True, 0.0), (77, 128, 384, True, 0.1), (200, 256, 256, False, 0.0),
-                                         (33, 128, 128, True, 0.0), (64, 256, 512, True, 0.1)])
+                                         (33, 128, 128, True, 0.0), (64, 256, 512, True, 0.1),
+                                         (3840, 128, 512, True, 0.1), (130, 128, 264, False, 0.0), (8200, 128, 384, True, 0.0)])
 def test_fused_input_gradient_gemm_plus_layernorm_backward(dtype, M, H, K, res, p):
     """magic_linear_lnbwd: (x @ W + residual) pushed through the backward of the LayerNorm whose output is y, vs autograd."""
     g = torch.Generator().manual_seed(M + H + K)

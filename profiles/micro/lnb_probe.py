@@ -1,4 +1,7 @@
-"""linear_lnbwd (input-gradient GEMM + LayerNorm backward, H = 128) launch time; run with MAGIC_LLN_KG=0 and =1"""
+"""linear_lnbwd (input-gradient GEMM + LayerNorm backward, H = 128) and linear_ln launch times, with and without the gamma/beta atomics
+and the residual operand.  Measured on MI355X: 14.3 us at M = 3840, K = 512 = ~6 us fixed + 0.5 us per K-step + 2.8 us of same-address
+gamma/beta atomics (6 us at M >= 8192) + 1.1 us residual.  A 4-K-group variant (as gemm_kg_kernel) was tried and measured 1-2 us SLOWER
+(the K loop is not what bounds these launches) -- not kept."""
 import os
 import sys
 
@@ -27,4 +30,4 @@ for M, K in ((3840, 512), (3840, 384), (1776, 512), (1776, 384), (816, 512), (81
     Wf = torch.randn(H, K, device="cuda", dtype=torch.bfloat16) * 0.1
     bf = torch.zeros(H, device="cuda")
     t2 = timed(lambda: O.linear_ln(xf, Wf, bf, M, R, gamma, beta, 1e-12, out, rs))
-    print(f"M={M:6d} K={K:4d}  linear_lnbwd {t:6.2f} us (no gamma/beta atomics {t_na:6.2f}, and no residual {t_nr:6.2f})   linear_ln {t2:6.2f} us   (MAGIC_LLN_KG={os.environ.get('MAGIC_LLN_KG', '1')})", flush=True)
+    print(f"M={M:6d} K={K:4d}  linear_lnbwd {t:6.2f} us (no gamma/beta atomics {t_na:6.2f}, and no residual {t_nr:6.2f})   linear_ln {t2:6.2f} us", flush=True)

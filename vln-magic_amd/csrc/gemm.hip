@@ -1185,6 +1185,22 @@ __device__ __forceinline__ void linear_lnb_body(const LlbParams& pp, const int b
       for (int o = 8; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
       s1[i][r] = t1; s2[i][r] = t2;
     }
+  // gamma / beta gradients: this thread's 8 rows are summed already; fold the 4 row groups (g) and issue one atomic per column.
+  // Issued HERE, before the row-statistics barrier and the dx stores: ~120 workgroups hit the same 2H addresses, and the 3-6 us that
+  // takes at L2 (profiles/micro/lnb_probe.py) then overlaps the rest of the epilogue instead of trailing it.
+  if (pp.dgamma) {
+#pragma unroll
+    for (int j = 0; j < HT; ++j) {
+      float a = pg[j], b = pb[j];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      if (g == 0) {
+        const int col = w * WC + j * 16 + c16;
+        atomicAdd(pp.dgamma + col, a);
+        atomicAdd(pp.dbeta + col, b);
+      }
+    }
+  }
   if (c16 == 0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1215,20 +1231,6 @@ __device__ __forceinline__ void linear_lnb_body(const LlbParams& pp, const int b
         }
       }
     }
-  // gamma / beta gradients: this thread's 8 rows are summed already; fold the 4 row groups (g) and issue one atomic per column
-  if (pp.dgamma) {
-#pragma unroll
-    for (int j = 0; j < HT; ++j) {
-      float a = pg[j], b = pb[j];
-      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-      b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-      if (g == 0) {
-        const int col = w * WC + j * 16 + c16;
-        atomicAdd(pp.dgamma + col, a);
-        atomicAdd(pp.dbeta + col, b);
-      }
-    }
-  }
 }
 
 template <typename T, int HT>

@@ -60,3 +60,22 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libmagic_hip.so")
     with pytest.raises(L.MagicHipError):
         L.load()
+
+
+def test_fastcall_extension_binds_the_same_library_and_checks_arity():
+    """the generated CPython marshalling layer (csrc/gen_fastcall.py): built, bound to the SAME libmagic_hip.so, one wrapper per
+    entry point without struct arguments, argument count and types enforced before the C call"""
+    L.load()
+    assert os.path.exists(L.FAST_PATH), "csrc/Makefile builds _magic_fastcall.so next to libmagic_hip.so"
+    fast = {n for n, f in L._FN.items() if type(f).__name__ == "builtin_function_or_method"}
+    slow = set(L.SIGNATURES) - fast
+    assert slow == {"magic_device_info", "magic_gemm_dw_grouped", "magic_mse_multi", "magic_rowblock_fwd"}, slow
+    assert L._FN["magic_abi_version"]() == L.load().magic_abi_version() == 1
+    for args in ((1, 64, 80, 80), (0, 64, 600, 80), (1, 48, 80, 80), (1, 64, 5000, 80)):       # pure host function: both bindings agree
+        assert L._FN["magic_attn_supported"](*args) == L.load().magic_attn_supported(*args)
+    with pytest.raises(TypeError):
+        L._FN["magic_attn_supported"](1, 64, 80)
+    with pytest.raises(TypeError):
+        L._FN["magic_attn_supported"](1, 64, 80, "80")
+    n = len(L.SIGNATURES["magic_gemm"])
+    assert L._FN["magic_gemm"](*([1, 0, 1, 1, 0, 128, 128] + [None if L.SIGNATURES["magic_gemm"][i] is L.vp else 0 for i in range(7, n)])) == -1   # M = 0 -> MAGIC_ERR_ARG

@@ -199,4 +199,4 @@ def test_packed_loader_record_round_trips():
                 assert gp[k] == v, k
     samples = [dict(x=i) for i in range(3)]
     pc = PlanCollate(lambda inp: synth.make_batch("sap", batch_size=len(inp), seed=1, vocab=300, min_len=6, max_len=9, min_steps=2, max_steps=3), "sap")
-    assert set(pc(samples)) == {"buf", "manifest", "meta"}
+    assert set(pc(samples)) == {"buf", "blob"}

@@ -12,6 +12,8 @@ module adds is the part specific to the HIP engine:
     pinned batch (30 MB of fp32 view features at B=48) and the plan (ONE packed copy for its ~60 arrays), and hands
     `(task, batch_on_device, plan_on_device)` to `PretrainStep.step` after a stream wait.
 """
+import pickle
+
 import numpy as np
 import torch
 
@@ -44,20 +46,35 @@ def pack(batch, hp):
             buf[o:o + n] = a.contiguous().reshape(-1).view(torch.uint8)
     meta = dict(hp["meta"])
     meta["last_rows"] = np.asarray(meta["last_rows"]).tolist()
-    return dict(buf=buf, manifest=manifest, meta=meta)
+    # manifest + meta travel as ONE bytes object: the DataLoader's pin-memory thread walks every container of a batch in Python
+    # (under the GIL, i.e. on the training thread's time) -- ~1500 small objects per batch as lists / tuples, one leaf as bytes
+    return dict(buf=buf, blob=pickle.dumps((manifest, meta), protocol=pickle.HIGHEST_PROTOCOL))
 
 
 def unpack(rec, device):
     """packed record -> (batch_on_device, plan_on_device): one (pinned) host buffer, one async copy, views"""
     device = torch.device(device)
     buf = rec["buf"]
+    manifest, meta = pickle.loads(rec["blob"])
     if device.type == "cuda" and not buf.is_pinned():
         buf = buf.pin_memory()
     dbuf = buf.to(device, non_blocking=True)
     batch, plan, csr = {}, {}, {}
-    for k, dt, shape, o, n in rec["manifest"]:
+    typed = {}                       # one reinterpretation of the whole buffer per dtype; every array is then ONE as_strided view of it
+    for k, dt, shape, o, n in manifest:
         dtype = getattr(torch, dt)
-        t = dbuf[o:o + n].view(dtype).view(shape) if n else torch.empty(shape, dtype=dtype, device=device)
+        if n:
+            tv = typed.get(dt)
+            if tv is None:
+                sz = torch.empty(0, dtype=dtype).element_size()
+                tv = typed[dt] = (dbuf[:dbuf.numel() // sz * sz].view(dtype), sz)
+            st, acc = [], 1
+            for d in reversed(shape):
+                st.append(acc)
+                acc *= d
+            t = tv[0].as_strided(shape, st[::-1], o // tv[1])
+        else:
+            t = torch.empty(shape, dtype=dtype, device=device)
         kind, rest = k.split("/", 1)
         if kind == "b":
             batch[rest] = t
@@ -68,7 +85,7 @@ def unpack(rec, device):
             csr.setdefault(name, {})[int(j)] = t
     for name, parts in csr.items():
         plan[name] = tuple(parts[j] for j in range(len(parts)))
-    plan.update(rec["meta"])
+    plan.update(meta)
     plan["last_rows"] = np.asarray(plan["last_rows"], np.int64)
     plan["_stage"], plan["_dbuf"] = buf, dbuf        # every tensor above is a view of dbuf's one allocation
     return batch, plan

@@ -32,3 +32,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu, k
     assert cpu["kind"] in ("reference", "port") and cpu["value"] > 0
+
+
+def test_ctypes_binding_path_still_drives_a_full_step(monkeypatch):
+    """the hot entry points normally go through the generated fast-call wrappers; the plain ctypes binding (the one INTEGRATION.md
+    documents) must keep working: one oracle-checked training step with every entry point forced onto ctypes"""
+    from magic_amd.host import lib as L
+    from magic_amd.host import smoke as S
+    lib = L.load()
+    for name in L.SIGNATURES:
+        monkeypatch.setitem(L._FN, name, getattr(lib, name))
+    assert type(L._FN["magic_gemm"]).__name__ != "builtin_function_or_method"
+    S.run_smoke()

@@ -586,3 +586,33 @@ def test_gemm_wide_tile_random_shapes_and_batched_strides(big_tiles):
             ref = A[b, :, h * D:(h + 1) * D].float() @ Bm[b, :, h * D:(h + 1) * D].float().t()
             check(Cc[b, h, :, :Nk], ref, f"wide batched {b},{h}", rtol=2e-2, atol=8e-2)
     assert float(Cc[..., Nk:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_deferred_weight_gradients_many_problems_per_launch(dtype):
+    """magic_gemm_dw_grouped with compact descriptors: 40 deferred problems of mixed shapes (split-K or not, with and without a bias
+    gradient, accumulating into non-zero buffers) flushed 32 + 8 per launch must equal the per-problem sums"""
+    g = torch.Generator().manual_seed(5)
+    probs, refs = [], []
+    O.DEFER["queue"].clear()
+    O.defer_dw(True)
+    for i in range(40):
+        M = int(torch.randint(3, 60, (1,), generator=g)) * 8 + (0 if i % 3 else 5)
+        N = int(torch.randint(1, 6, (1,), generator=g)) * 64 if i % 4 else 24
+        K = int(torch.randint(1, 6, (1,), generator=g)) * 64 if i % 5 else 40
+        if i == 7:
+            M, N, K = 3840, 128, 512                # long reduction: host picks split-K > 1
+        dy, x = rnd(M, N, dtype=dtype, scale=0.3, seed=100 + i), rnd(M, K, dtype=dtype, seed=200 + i)
+        dW = rnd(N, K, seed=300 + i).contiguous()
+        db = rnd(N, seed=400 + i) if i % 2 else None
+        refs.append((dW.clone() + dy.float().t() @ x.float(), None if db is None else db.clone() + dy.float().sum(0)))
+        O.linear_dw(dy, x, dW, db, M)
+        probs.append((dW, db, M))
+    assert len(O.DEFER["queue"]) == 40
+    O.flush_dw(group=32)
+    torch.cuda.synchronize()
+    for i, ((dW, db, M), (rW, rb)) in enumerate(zip(probs, refs)):
+        t = dict(rtol=1e-4, atol=2e-3) if dtype == torch.float32 else dict(rtol=2e-2, atol=5e-2 * math.sqrt(M / 64) + 1e-2)
+        check(dW, rW, f"dW[{i}]", **t)
+        if db is not None:
+            check(db, rb, f"db[{i}]", **t)

@@ -655,6 +655,48 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupedParams gp) {
   }
 }
 
+// Weight-gradient form with COMPACT descriptors (64 B per problem instead of a 184 B GemmParams): up to DW_MAX problems per launch fit
+// the kernel-argument block.  Every dependent launch of the replayed step costs ~9 us whatever its work (8 -> 16 problems per launch:
+// 2.93 -> 2.88 ms per step), so the step's ~80 weight gradients go out in 2-3 launches.
+#define DW_MAX 48
+struct DwProblem { const void* A; const void* B; float* C; float* bias_grad; int M, N, K, lda, ldb, ldc, splitk, ny8; };
+struct DwBatch { DwProblem p[DW_MAX]; int start[DW_MAX + 1]; int cnt[DW_MAX]; int n; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_dw_batch_kernel(DwBatch gp) {
+  __shared__ __attribute__((aligned(16))) T sA[BM * TT<T>::STRIDE];
+  __shared__ __attribute__((aligned(16))) T sB[BN * TT<T>::STRIDE];
+  const int id = blockIdx.x;
+  int lo = 0, hi = gp.n - 1;                                   // last problem whose first workgroup is <= id (block-uniform)
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (id >= gp.start[mid]) lo = mid; else hi = mid - 1; }
+  const DwProblem& d = gp.p[lo];
+  const int local = id - gp.start[lo];
+  if (local >= gp.cnt[lo]) return;
+  GemmParams p = {};
+  p.A = d.A; p.B = d.B; p.C = d.C; p.bias_grad = d.bias_grad;
+  p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+  p.nh = 1; p.batch = 1; p.splitk = d.splitk; p.c_f32 = 1; p.accumulate = 1; p.alpha = 1.f;
+  const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM;
+  if (d.ny8 < 0) {                   // one K-split per XCD slot group (see gemm_grouped_kernel)
+    const int tiles = nx * ny;
+    const int xcd = local & 7, slot = local >> 3;
+    const int zr = slot / tiles, t = slot - zr * tiles;
+    const int z = zr * 8 + xcd;
+    if (z >= p.splitk) return;
+    gemm_block<T, 2>(p, t % nx, t / nx, z, sA, sB);
+  } else if (d.ny8 > 0) {
+    const int per_z = nx * d.ny8;
+    const int z = local / per_z, l2 = local - z * per_z;
+    const int xcd = l2 & 7, slot = l2 >> 3;
+    const int lr = slot / nx, bx = slot - lr * nx;
+    const int by = lr * 8 + xcd;
+    if (by >= ny) return;
+    gemm_block<T, 2>(p, bx, by, z, sA, sB);
+  } else {
+    gemm_block<T, 2>(p, local % nx, (local / nx) % ny, local / (nx * ny), sA, sB);
+  }
+}
+
 // Wide-tile selection (bf16; M, N >= 128; the contiguous dimension of each operand a multiple of 8).  Measured on MI355X
 // (profiles/micro/gemm_tile_sweep.py -> profiles/micro/r01_gemm_tile_sweep.txt): the wide tile wins on the forward / input-gradient GEMMs
 // once the output has >= ~192 tiles of 128x128 and K >= 512 (M = 8192 rows at H = 768: 1.4-1.9x over the 64x64 tile, 1.2-1.3x behind
@@ -1292,27 +1334,30 @@ int launch_llb(int dtype, int ht, const void* pa, const void* pb, hipStream_t st
 struct magic_dw_desc { const void* dY; const void* X; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk; };
 
 extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, void* stream) {
-  if (n <= 0 || n > GROUP_MAX || !d) return MAGIC_ERR_ARG;
+  if (n <= 0 || n > DW_MAX || !d) return MAGIC_ERR_ARG;
   if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
   const int ve = dtype == DT_BF16 ? 8 : 4;
-  GroupedParams gp;
+  DwBatch gp;
   gp.n = n;
   int total = 0;
   for (int i = 0; i < n; ++i) {
     if (d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0 || d[i].splitk <= 0 || !d[i].dY || !d[i].X || !d[i].dW) return MAGIC_ERR_ARG;
     if (d[i].lda % ve || d[i].ldb % ve || ((uintptr_t)d[i].dY & 15) || ((uintptr_t)d[i].X & 15)) return MAGIC_ERR_ARG;
-    GemmParams& p = gp.p[i];
-    p = GemmParams{};
     // TN: A = dY stored [Kred = M][Mout = N], B = X stored [Kred = M][Nout = K], C = dW [N, K]
+    DwProblem& p = gp.p[i];
     p.A = d[i].dY; p.B = d[i].X; p.C = d[i].dW; p.bias_grad = d[i].db;
-    p.M = d[i].N; p.N = d[i].K; p.K = d[i].M; p.lda = d[i].lda; p.ldb = d[i].ldb; p.ldc = d[i].ldc;
-    p.nh = 1; p.batch = 1; p.big = 0; p.splitk = d[i].splitk; p.epilogue = 0; p.c_f32 = 1; p.accumulate = 1; p.alpha = 1.f;
-    total += group_place(gp, i, total);
+    p.M = d[i].N; p.N = d[i].K; p.K = d[i].M; p.lda = d[i].lda; p.ldb = d[i].ldb; p.ldc = d[i].ldc; p.splitk = d[i].splitk;
+    const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM, nz = p.splitk;          // same placement rules as group_place()
+    gp.start[i] = total;
+    if (gemm_xcd_on() && p.splitk >= 8 && nx * ny >= 2) { p.ny8 = -1; gp.cnt[i] = nx * ny * ((nz + 7) / 8 * 8); }
+    else if (gemm_xcd_on() && nx >= 2 && ny >= 16) { p.ny8 = (ny + 7) / 8 * 8; gp.cnt[i] = nx * p.ny8 * nz; }
+    else { p.ny8 = 0; gp.cnt[i] = nx * ny * nz; }
+    total += (gp.cnt[i] + 7) / 8 * 8;
   }
-  for (int i = n; i <= GROUP_MAX; ++i) gp.start[i] = total;
+  for (int i = n; i <= DW_MAX; ++i) gp.start[i] = total;
   dim3 grid(total), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16) hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2>), grid, block, 0, st, gp);
-  else hipLaunchKernelGGL((gemm_grouped_kernel<float, 2>), grid, block, 0, st, gp);
+  if (dtype == DT_BF16) hipLaunchKernelGGL((gemm_dw_batch_kernel<bf16>), grid, block, 0, st, gp);
+  else hipLaunchKernelGGL((gemm_dw_batch_kernel<float>), grid, block, 0, st, gp);
   return launch_status();
 }

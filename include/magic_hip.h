@@ -42,7 +42,7 @@ int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,
  * such tiles and a long K loop, 2 = 128x128 whenever M, N >= 128.  Process-wide tuning knob (also MAGIC_GEMM_BIG). */
 int magic_gemm_set_big(int mode);
 
-/* Grouped weight-gradient GEMM: n <= 48 independent problems dW[N,K] (fp32, ldc) += dY[M,N]^T (lda) @ X[M,K] (ldb), db[N] += colsum(dY)
+/* Grouped weight-gradient GEMM: n <= 96 independent problems dW[N,K] (fp32, ldc) += dY[M,N]^T (lda) @ X[M,K] (ldb), db[N] += colsum(dY)
  * in ONE launch (split-K, fp32 atomics).  `d` is a HOST array of n descriptors holding device pointers. */
 typedef struct magic_dw_desc { const void* dY; const void* X; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk; } magic_dw_desc;
 int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, void* stream);

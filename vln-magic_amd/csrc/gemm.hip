@@ -657,8 +657,8 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupedParams gp) {
 
 // Weight-gradient form with COMPACT descriptors (64 B per problem instead of a 184 B GemmParams): up to DW_MAX problems per launch fit
 // the kernel-argument block.  Every dependent launch of the replayed step costs ~9 us whatever its work (8 -> 16 problems per launch:
-// 2.93 -> 2.88 ms per step), so the step's ~80 weight gradients go out in 2-3 launches.
-#define DW_MAX 48
+// 2.93 -> 2.88 ms per step; 48 compact: 2.79; 96: 2.77), so the step's ~80 weight gradients go out in ONE launch (6.9 KB of kernel arguments).
+#define DW_MAX 96
 struct DwProblem { const void* A; const void* B; float* C; float* bias_grad; int M, N, K, lda, ldb, ldc, splitk, ny8; };
 struct DwBatch { DwProblem p[DW_MAX]; int start[DW_MAX + 1]; int cnt[DW_MAX]; int n; };
 

@@ -132,7 +132,7 @@ def linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None,
     DEFER["queue"].append((dy, x, dW, db, M, N, K, lda, ldb, ldc, _splitk(tiles, M)))
 
 
-DW_GROUP = int(os.environ.get("MAGIC_DW_GROUP", "48"))      # problems per grouped weight-gradient launch (csrc DW_MAX = 48)
+DW_GROUP = int(os.environ.get("MAGIC_DW_GROUP", "96"))      # problems per grouped weight-gradient launch (csrc DW_MAX = 96)
 
 
 def flush_dw(group=None):

@@ -17,6 +17,8 @@ backward and returns gradients for the tensor inputs (txt_embeds, gmap_img_embed
 agent's Python between the calls (GraphMap bookkeeping, compute_kd_losses, CE) composes with autograd unchanged;
 parameter gradients land directly in `param.grad` (views of the flat gradient buffer).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -26,6 +28,7 @@ from .config import cfg_get, make_config
 from .engine import Ctx, MagicNet, cls_specs, trunk_specs
 from .params import ParamStore
 
+NAV_DEFER_DW = not os.environ.get("MAGIC_NAV_NO_DEFER_DW")
 KD_HEADS = ("txt_emb_w", "kdl_img_w", "kdl_avg_img_w", "global_cross_w", "local_cross_w")
 # back-door / front-door inputs the agent passes as None unless args.do_back_* / do_front_* are set (agent.py:76-89,:162-172,:942-944,:1212-1227)
 CAUSAL_KEYS = ("instr_z_direction_features", "instr_z_direction_pzs", "instr_z_landmark_features", "instr_z_landmark_pzs",
@@ -110,12 +113,20 @@ class Critic(nn.Module):
 def _queue_sync(model):
     """nav mode: many Function.backward calls feed one store per loss.backward(); average the gradients once, when the whole
     autograd pass is over (the engine's end-of-backward callback -- the mechanism DDP's reducer uses too)."""
+    if NAV_DEFER_DW:
+        # the weight-gradient GEMMs of every Function.backward of this autograd pass are queued (operands kept alive) and leave in a
+        # few grouped launches from the end-of-backward callback: ~2 400 single launches per navigator iteration become ~25
+        if not getattr(model, "_sync_queued", False) and not O.DEFER["active"]:
+            O.DEFER["queue"].clear()          # anything left by a pass that raised half-way is stale
+        O.defer_dw(True)
     if getattr(model, "_sync_queued", False):
         return
     model._sync_queued = True
 
     def _done():
         model._sync_queued = False
+        if NAV_DEFER_DW:
+            O.flush_dw()
         from .trainer import auto_sync
         auto_sync(model)
     torch.autograd.Variable._execution_engine.queue_callback(_done)

@@ -138,16 +138,14 @@ DW_GROUP = int(os.environ.get("MAGIC_DW_GROUP", "96"))      # problems per group
 def flush_dw(group=None):
     group = group or DW_GROUP
     q = DEFER["queue"]
-    i = 0
-    while i < len(q):
-        chunk = [e for e in q[i:i + group]]
-        dt = chunk[0][0].dtype
-        chunk = [e for e in chunk if e[0].dtype == dt]          # same compute dtype within one launch
-        arr = (L.DwDesc * len(chunk))()
-        for j, (dy, x, dW, db, M, N, K, lda, ldb, ldc, sk) in enumerate(chunk):
-            arr[j] = L.DwDesc(L.P(dy), L.P(x), L.P(dW), L.P(db), M, N, K, lda, ldb, ldc, sk)
-        L.call("magic_gemm_dw_grouped", L.dt(dt), len(chunk), arr, L.stream())
-        i += len(chunk)
+    for dt in {e[0].dtype for e in q}:                 # one compute dtype per launch
+        part = [e for e in q if e[0].dtype == dt]
+        for i in range(0, len(part), group):
+            chunk = part[i:i + group]
+            arr = (L.DwDesc * len(chunk))()
+            for j, (dy, x, dW, db, M, N, K, lda, ldb, ldc, sk) in enumerate(chunk):
+                arr[j] = L.DwDesc(L.P(dy), L.P(x), L.P(dW), L.P(db), M, N, K, lda, ldb, ldc, sk)
+            L.call("magic_gemm_dw_grouped", L.dt(dt), len(chunk), arr, L.stream())
     q.clear()
     DEFER["active"] = False
 

@@ -117,7 +117,7 @@ def _queue_sync(model):
         # the weight-gradient GEMMs of every Function.backward of this autograd pass are queued (operands kept alive) and leave in a
         # few grouped launches from the end-of-backward callback: ~2 400 single launches per navigator iteration become ~25
         if not getattr(model, "_sync_queued", False) and not O.DEFER["active"]:
-            O.DEFER["queue"].clear()          # anything left by a pass that raised half-way is stale
+            O.DEFER["queue"].clear(); O.DEFER["bytes"] = 0          # anything left by a pass that raised half-way is stale
         O.defer_dw(True)
     if getattr(model, "_sync_queued", False):
         return

@@ -170,7 +170,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     def forward(self, batch, task, compute_loss=True, teacher_outputs=None, rw=None, plan=None, return_outputs=False, inputs=None):
         n = self.net
         self.store.sync_shadow()
-        O.DEFER["queue"].clear()
+        O.DEFER["queue"].clear(); O.DEFER["bytes"] = 0
         self._arm_dropout()
         plan = plan if plan is not None else build_plan(batch, task, self.device_)
         check_plan(plan, self.config)

@@ -130,12 +130,18 @@ def linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None,
     _count(N, K, flop_rows if flop_rows is not None else M)
     tiles = ((N + 63) // 64) * ((K + 63) // 64)
     DEFER["queue"].append((dy, x, dW, db, M, N, K, lda, ldb, ldc, _splitk(tiles, M)))
+    DEFER["bytes"] = DEFER.get("bytes", 0) + dy.numel() * dy.element_size() + x.numel() * x.element_size()
+    if DEFER["bytes"] > DW_KEEP_BYTES:          # a long autograd pass (navigator rollouts): bound the operands kept alive by the queue
+        flush_dw(keep_active=True)
 
 
 DW_GROUP = int(os.environ.get("MAGIC_DW_GROUP", "96"))      # problems per grouped weight-gradient launch (csrc DW_MAX = 96)
 
 
-def flush_dw(group=None):
+DW_KEEP_BYTES = int(os.environ.get("MAGIC_DW_KEEP_GB", "8")) << 30
+
+
+def flush_dw(group=None, keep_active=False):
     group = group or DW_GROUP
     q = DEFER["queue"]
     for dt in {e[0].dtype for e in q}:                 # one compute dtype per launch
@@ -147,7 +153,9 @@ def flush_dw(group=None):
                 arr[j] = L.DwDesc(L.P(dy), L.P(x), L.P(dW), L.P(db), M, N, K, lda, ldb, ldc, sk)
             L.call("magic_gemm_dw_grouped", L.dt(dt), len(chunk), arr, L.stream())
     q.clear()
-    DEFER["active"] = False
+    DEFER["bytes"] = 0
+    if not keep_active:
+        DEFER["active"] = False
 
 
 def _linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None, flop_rows=None):

@@ -33,7 +33,7 @@ def _worker(rank, world, port, q):
         g = torch.Generator().manual_seed(7 + rank)
         store.grad.copy_(torch.randn(store.total, generator=g))
         mine = store.grad.clone()
-        sync = GradSync(store)
+        sync = GradSync(store, chunk_elems=10007)            # odd chunk size: exercises the chunk tail
         gscale = sync.all_reduce()
         others = [torch.randn(store.total, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
         want_sum = sum(others)

@@ -75,22 +75,29 @@ class FusedAdamW:
 
 
 class GradSync:
-    """Data-parallel gradient exchange: the flat fp32 gradient buffer is summed across ranks with RCCL in one collective
-    (the 1/world scaling is folded into the AdamW kernel).  Replaces
+    """Data-parallel gradient exchange: the flat fp32 gradient buffer is summed across ranks with RCCL in a few
+    large chunks on a side stream (the 1/world scaling is folded into the AdamW kernel).  Replaces
     DDP(model, find_unused_parameters=True) of pretrain_src/utils/misc.py:62-63: every rank runs the same
     task each step (data/loader.py:55-59), so unused parameters simply contribute zeros."""
 
-    def __init__(self, store):
+    def __init__(self, store, chunk_elems=8 << 20):
         self.store = store
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.chunk = chunk_elems
+        self.stream = torch.cuda.Stream() if (self.world > 1 and store.device.type == "cuda") else None
 
     def all_reduce(self):
-        """ONE all-reduce of the flat gradient on the current stream (RCCL orders it after the backward's kernels and before the
-        optimizer's by itself).  Nothing of this rank's step can run under it -- the optimizer needs every gradient and the next
-        forward needs the optimizer -- except the frozen teacher's forward for the next batch, which is on its own stream already."""
         if self.world == 1:
             return 1.0
-        dist.all_reduce(self.store.grad)
+        g = self.store.grad
+        if self.stream is None:
+            dist.all_reduce(g)
+            return 1.0 / self.world
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for lo in range(0, g.numel(), self.chunk):
+                dist.all_reduce(g[lo:lo + self.chunk])
+        torch.cuda.current_stream().wait_stream(self.stream)
         return 1.0 / self.world
 
 

@@ -18,6 +18,7 @@ agent's Python between the calls (GraphMap bookkeeping, compute_kd_losses, CE) c
 parameter gradients land directly in `param.grad` (views of the flat gradient buffer).
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -25,6 +26,7 @@ import torch.nn as nn
 
 from . import ops as O
 from .config import cfg_get, make_config
+from .ddp import refuse_torch_ddp
 from .engine import Ctx, MagicNet, cls_specs, trunk_specs
 from .params import ParamStore
 
@@ -110,21 +112,36 @@ class Critic(nn.Module):
         return (h @ out.weight.t() + out.bias).squeeze()
 
 
+class _PassToken:
+    """lives exactly as long as the autograd engine keeps this pass's end-of-backward callback"""
+    __slots__ = ("__weakref__",)
+
+
+def _pass_pending(model):
+    ref = getattr(model, "_sync_token", None)
+    return ref is not None and ref() is not None
+
+
 def _queue_sync(model):
     """nav mode: many Function.backward calls feed one store per loss.backward(); average the gradients once, when the whole
-    autograd pass is over (the engine's end-of-backward callback -- the mechanism DDP's reducer uses too)."""
+    autograd pass is over (the engine's end-of-backward callback -- the mechanism DDP's reducer uses too).
+    "Already queued for this pass" is a weak reference to a token only the queued callback holds: when a backward pass raises,
+    the engine drops its final callbacks, the token dies with them, and the next pass queues afresh (a sticky flag here would
+    silently skip the flush and the data-parallel average for every later pass)."""
+    pending = _pass_pending(model)
     if NAV_DEFER_DW:
         # the weight-gradient GEMMs of every Function.backward of this autograd pass are queued (operands kept alive) and leave in a
         # few grouped launches from the end-of-backward callback: ~2 400 single launches per navigator iteration become ~25
-        if not getattr(model, "_sync_queued", False) and not O.DEFER["active"]:
+        if not pending and not O.DEFER["active"]:
             O.DEFER["queue"].clear(); O.DEFER["bytes"] = 0          # anything left by a pass that raised half-way is stale
         O.defer_dw(True)
-    if getattr(model, "_sync_queued", False):
+    if pending:
         return
-    model._sync_queued = True
+    tok = _PassToken()
+    model._sync_token = weakref.ref(tok)
 
-    def _done():
-        model._sync_queued = False
+    def _done(tok=tok):
+        model._sync_token = None
         if NAV_DEFER_DW:
             O.flush_dw()
         from .trainer import auto_sync
@@ -452,6 +469,7 @@ class VLNBert(nn.Module):
         return _TextKVFn.apply(self._anchor, self, txt_embeds)
 
     def forward(self, mode, batch):
+        refuse_torch_ddp(self)
         on = [k for k in CAUSAL_KEYS if batch.get(k) is not None]
         if on:
             raise NotImplementedError(f"VLNBert({mode!r}): causal-intervention inputs {on} (do_back_* / do_front_*, SURVEY §8 f-4) are not built -- "

@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from . import ops as O
 from .config import cfg_get
+from .ddp import refuse_torch_ddp
 from .engine import Ctx, MagicNet, cls_specs, rup, trunk_specs
 from .params import ParamStore
 from .plan import build_plan, check_plan
@@ -169,8 +170,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     # ---- forward ----------------------------------------------------------------------------------------
     def forward(self, batch, task, compute_loss=True, teacher_outputs=None, rw=None, plan=None, return_outputs=False, inputs=None):
         n = self.net
+        refuse_torch_ddp(self)
         self.store.sync_shadow()
         O.DEFER["queue"].clear(); O.DEFER["bytes"] = 0
+        if self.store.requires_grad:
+            O.defer_dw(False)         # a compute_loss forward that was never followed by backward() left deferral armed
         self._arm_dropout()
         plan = plan if plan is not None else build_plan(batch, task, self.device_)
         check_plan(plan, self.config)

@@ -8,9 +8,33 @@ ordinary module while the optimizer and the gradient all-reduce see single large
 Layout: [weight-decay group | no-decay group], the split following optim/misc.py:13-22 by name.
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
+
+_LIVE = weakref.WeakSet()          # trainable stores with a bf16 shadow: a foreign optimizer's step must mark them stale
+_HOOKED = [False]
+
+
+def _install_optimizer_hook():
+    """ANY torch.optim.Optimizer.step() (the reference's own AdamW, pretrain_src/optim/adamw.py, writes `p.data` -- invisible to
+    tensor version counters) marks the bf16 shadow weights of every trainable store stale, so a forward that follows an
+    external optimizer step re-casts them whatever ran in between (validation forwards, logging forwards).  FusedAdamW is not a
+    torch Optimizer: it rewrites the shadow itself."""
+    if _HOOKED[0]:
+        return
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+    except ImportError:          # old torch: ensure_grads()' conservative invalidation still covers backward -> step -> forward
+        _HOOKED[0] = True
+        return
+
+    def _stale(optimizer, args, kwargs):
+        for s in list(_LIVE):
+            s.shadow_clean = False
+    register_optimizer_step_post_hook(_stale)
+    _HOOKED[0] = True
 
 ALIGN = 64           # elements; keeps every tensor 256-byte aligned in fp32 and 128-byte in bf16
 NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")      # optim/misc.py:14
@@ -58,6 +82,9 @@ class ParamStore:
         self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device) \
             if compute_dtype == torch.bfloat16 else self.flat
         self.shadow_clean = False
+        if requires_grad and compute_dtype == torch.bfloat16:
+            _LIVE.add(self)
+            _install_optimizer_hook()
         gen = torch.Generator().manual_seed(seed)
         for name, shape, kind in self.specs:
             v = self.master(name)

@@ -39,7 +39,7 @@ TASKS = ["mlm", "sap", "cfp"]
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=25.0):
+def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=30.0, warm=3, timed=10):
     """The oracle (kind 'port') on the host cores: same step (teacher fwd, student fwd+MAKD, backward, clip, AdamW)."""
     from oracle import model_ref as R
     from oracle import optim_ref
@@ -69,7 +69,8 @@ def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=25.0):
     rw = torch.ones(5)
     steps_done, traj, t_total = 0, 0, 0.0
     names = []
-    for i, task in enumerate(["sap"] + TASKS):           # first one is warm-up
+    seq = [TASKS[i % 3] for i in range(warm + timed)]    # >= 3 warm-up + >= 10 timed steps
+    for i, task in enumerate(seq):
         batch = synth.make_batch(task, batch_size=batch_size, seed=4321, step=i)
         t0 = time.perf_counter()
         with torch.no_grad():
@@ -83,7 +84,7 @@ def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=25.0):
         with torch.no_grad():
             optim_ref.adamw_step([p.data for p in params], grads, state, lr=5e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=wds)
         dt = time.perf_counter() - t0
-        if i > 0:
+        if i >= warm:
             steps_done += 1
             traj += sum(batch["traj_step_lens"])
             t_total += dt
@@ -91,7 +92,7 @@ def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=25.0):
         if t_total > seconds_budget:
             break
     return {"value": round(traj / t_total, 2), "unit": "trajectory-steps/sec", "cores": ncores, "kind": "port",
-            "sample": f"{steps_done} optimizer steps ({'+'.join(names)}) of the same B={batch_size} MAGIC-S+teacher workload, "
+            "sample": f"{warm} warm-up + {steps_done} timed optimizer steps (mlm:sap:cfp cycled) of the same B={batch_size} MAGIC-S+teacher workload, "
                       f"fp32 torch CPU oracle, dropout {pdrop}, {t_total / max(steps_done, 1) * 1e3:.0f} ms/step"}
 
 
@@ -159,13 +160,154 @@ def ingest_rate(dev, n_vp=4096, n_pano=290, reps=40):
 
 
 def pmc_traffic():
-    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (cannot be collected from inside this process):
-    profiles/r01_pmc_traffic.json, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950."""
+    """HBM-side bytes per GEMM launch.  NOT measured inside this process (PMC collection needs rocprofv3 around it): read from the
+    committed post-processing of the `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
+    (profiles/pmc_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Returns (bytes, source file)."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return round(json.load(f)["gemm_traffic_bytes_per_launch"]), "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
+def build_models(dtype, dev, dropout, world):
+    dk = dict(hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)   # r2r_magic_model_config.json:2-3
+    tcfg = make_config(256, role="teacher", **dk)                                   # teacher_* of r2r_magic_model_config.json:33-37
+    scfg = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL, **dk)  # MAGIC-S: student_* :39-43
+    teacher = GlocalTextPathCMTPreTraining(tcfg, device=dev, compute_dtype=dtype, seed=0)
+    student = GlocalTextPathCMTPreTraining(scfg, device=dev, compute_dtype=dtype, seed=1)
+    if world > 1:   # DDP ctor semantics: rank-0 parameters broadcast once (utils/misc.py:62-63)
+        dist.broadcast(student.store.flat, src=0)
+        dist.broadcast(teacher.store.flat, src=0)
+    trainer = PretrainStep(student, teacher, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0,
+                           warmup_steps=10000, num_train_steps=200000, rw_temp=4.0)
+    return tcfg, scfg, teacher, student, trainer
+
+
+def capture_ring(trainer, pool, teacher_mode):
+    """one HIP graph per resident batch (each batch has its own ragged shapes); every replay executes the full step: teacher fwd,
+    student fwd + losses + bwd, clip, AdamW -- with lr / bias-correction / MKRW read from device memory"""
+    if teacher_mode in ("ahead", "split"):
+        # graph i: student step on batch i (teacher outputs t[i] are ready) || teacher forward on batch i+1 -> t[i+1];
+        # t[0] is primed eagerly once, and the last graph of the ring copies its teacher(batch 0) outputs into it
+        n = len(pool)
+        trip = lambda i: (pool[i % n][1], pool[i % n][0], pool[i % n][2])           # (batch, task, plan)
+        t0 = trainer.teacher_forward(*trip(0))
+        t_cur, graphs = t0, []
+        for i in range(n):
+            cap = trainer.capture_ahead if teacher_mode == "ahead" else trainer.capture_split
+            cs = cap(trip(i), t_cur, trip(i + 1), t_next_into=t0 if i == n - 1 else None)
+            graphs.append(cs)
+            t_cur = cs.t_next
+        return graphs
+    return [trainer.capture(b, task, plan) for task, b, plan in pool]
+
+
+def timed_region(run, steps, warmup, world, dev):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
+    run(warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    traj = run(steps, start=warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        tr = torch.tensor([traj], device=dev, dtype=torch.float64)
+        dist.all_reduce(tr)
+        traj = float(tr.item())
+    return traj, dt
+
+
+def _gate(ms):
+    """park the stream for ~ms milliseconds (a device-side spin) so the host can enqueue a whole instrumented step behind it: the
+    event pairs then bracket kernels that run back to back, not the host's launch gaps"""
+    if "_cyc_per_ms" not in _gate.__dict__:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(); torch.cuda._sleep(20_000_000); e1.record()
+        torch.cuda.synchronize()
+        _gate._cyc_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
+    torch.cuda._sleep(int(ms * _gate._cyc_per_ms))
+
+
+def instrumented_pass(trainer, pool, nprof, gate_ms):
+    """Per-launch HIP events (recorded on the launch stream) over `nprof` eager steps with the SAME launch structure as the captured
+    graphs (paired launches), the teacher's forward SERIALISED on the main stream (no overlap: summed kernel time == stream time),
+    and a device-side gate in front of every step so the host runs ahead of the GPU.  Returns {family: (ms, launches)}."""
+    import magic_amd.host.model_pretrain as MP
+    O.FLOPS.update(total=0.0, gemm=0.0, linear_ln=0.0, attn=0.0, enabled=True)
+    L.PROFILE.update(on=True, events=[])
+    MP.LOCKSTEP_EAGER = True
+    side, trainer.side = trainer.side, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return round(json.load(f)["gemm_traffic_bytes_per_launch"])
-    except Exception:
-        return None
+        for s in range(nprof):
+            task, b, plan = pool[s % len(pool)]
+            _gate(gate_ms)
+            trainer.step(b, task, plan=plan)
+        torch.cuda.synchronize()
+    finally:
+        trainer.side = side
+        MP.LOCKSTEP_EAGER = False
+        L.PROFILE["on"] = False
+        O.FLOPS["enabled"] = False
+    by = {}
+    for name, layout, e0, e1 in L.PROFILE["events"]:
+        k = name if layout < 0 else f"{name}[{['NT', 'NN', 'TN'][layout]}]"
+        t, c = by.get(k, (0.0, 0))
+        by[k] = (t + e0.elapsed_time(e1), c + 1)
+    return by
+
+
+def parity_block(dev):
+    """CHECKER leg (the oracle is test infrastructure, like cpu_baseline): the benchmarked arithmetic modes against the fp64 oracle on
+    full-size SAP batches (6/3/2 layers, vocab 50265, B=8 x 3 seeds) -- action-logit |delta| and argmax agreement, the quantities
+    BASELINE.json states its tolerance on (|delta| < 1e-3, argmax exact)."""
+    from oracle import parity_probe as PP
+    models = PP.oracle_models()
+    out = {"checker": "fp64 CPU oracle (oracle/model_ref.py, a restatement: the reference withholds its model source), same weights and batches",
+           "north_star": {"max_abs_logit_delta": 1e-3, "argmax_agreement": 1.0}}
+    for name, dt_ in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        st = PP.sap_parity(dt_, batch_size=8, seeds=(1234, 77, 5), device=dev, models=models)
+        out[name] = {"max_abs_logit_delta": float(f"{st['max_abs_logit_delta']:.3e}"), "argmax_agreement": st["argmax_agreement"],
+                     "rows": st["rows"], "loss_rel_delta": float(f"{st['loss_rel_delta']:.2e}"),
+                     "oracle_min_top2_gap": float(f"{st['oracle_min_top2_gap']:.2e}")}
+    return out
+
+
+def secondary_block():
+    """short driver-timed samples of BASELINE configs 3 and 5 (bench_nav.py as child processes: own CUDA context, started after this
+    process's measurements are done)"""
+    import subprocess
+    py, nav = sys.executable, os.path.join(ROOT, "bench_nav.py")
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-loop", "--no-profile"]
+    runs = {"config3_icod_magicL_teacher_magicS_student": ["--icod", "--hidden", "128", "--teacher-hidden", "768", "--instr-min", "20", "--instr-max", "80",
+                                                          "--hops-min", "4", "--hops-max", "7", "--max-action-len", "15"],
+            "config5_rxr_magicL_navigator_loop": []}
+    out = {}
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for name, extra in runs.items():
+        try:
+            r = subprocess.run([py, nav] + common + extra, capture_output=True, text=True, timeout=240, env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            j = json.loads(line)
+            out[name] = {"value": j["value"], "unit": j["unit"], "ms_per_iteration": j["ms_per_step"], "steps": j["steps"], "dtype": j["dtype"],
+                         "mode": j["mode"], "workload": j["config"]["workload"], "per_gpu_batch": j["config"]["per_gpu_batch"]}
+        except Exception as e:          # noqa: BLE001 - the headline line must still print
+            out[name] = {"error": repr(e)[:300]}
+    return out
 
 
 def main():
@@ -179,6 +321,8 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1, help="hidden/attention dropout of the student (reference recipe: 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity leg and the fp32-mode timing")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short config-3 / config-5 samples (bench_nav.py children)")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager", "stream"],
                     help="graph: replay one captured HIP graph per resident batch (the headline line); eager: same batches, launches issued "
                          "one by one; stream: NON-resident batches -- collate + index plan built in DataLoader worker processes, pinned, "
@@ -200,6 +344,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}: for N > 1 launch one rank per GPU with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...`")
     if a.backend == "gloo":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
@@ -211,17 +358,7 @@ def main():
             dist.init_process_group("gloo")
     L.load()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-
-    dk = dict(hidden_dropout_prob=a.dropout, attention_probs_dropout_prob=a.dropout)   # r2r_magic_model_config.json:2-3
-    tcfg = make_config(256, role="teacher", **dk)                                   # teacher_* of r2r_magic_model_config.json:33-37
-    scfg = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL, **dk)  # MAGIC-S: student_* :39-43
-    teacher = GlocalTextPathCMTPreTraining(tcfg, device=dev, compute_dtype=dtype, seed=0)
-    student = GlocalTextPathCMTPreTraining(scfg, device=dev, compute_dtype=dtype, seed=1)
-    if world > 1:   # DDP ctor semantics: rank-0 parameters broadcast once (utils/misc.py:62-63)
-        dist.broadcast(student.store.flat, src=0)
-        dist.broadcast(teacher.store.flat, src=0)
-    trainer = PretrainStep(student, teacher, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0,
-                           warmup_steps=10000, num_train_steps=200000, rw_temp=4.0, seed=rank)
+    tcfg, scfg, teacher, student, trainer = build_models(dtype, dev, a.dropout, world)
 
     # synthetic batches, resident in HBM before the timed region (per-rank stream: seed 1234 + rank)
     pool = []
@@ -232,47 +369,37 @@ def main():
         pool.append((task, synth.batch_to(b, dev), plan))
     torch.cuda.synchronize()
 
-    def run_eager(n, start=0):
-        traj = 0
-        for s in range(n):
-            task, b, plan = pool[(start + s) % len(pool)]
-            trainer.step(b, task, plan=plan)
-            traj += plan["traj_steps"]
-        return traj
+    def eager_runner(tr):
+        def run_eager(n, start=0):
+            traj = 0
+            for s in range(n):
+                task, b, plan = pool[(start + s) % len(pool)]
+                tr.step(b, task, plan=plan)
+                traj += plan["traj_steps"]
+            return traj
+        return run_eager
 
-    graphs = None
+    def graph_runner(tr, graphs):
+        def run_graph(n, start=0):
+            traj = 0
+            for s in range(n):
+                cs = graphs[(start + s) % len(graphs)]
+                (tr.replay_split if a.teacher == "split" else tr.replay)(cs)
+                traj += cs.traj_steps
+            return traj
+        return run_graph
+
+    run_eager = eager_runner(trainer)
     if a.mode == "stream":
         a.no_profile = True
     if a.mode == "graph":
-        # one HIP graph per resident batch (each batch has its own ragged shapes); every replay executes the full
-        # step: teacher fwd, student fwd+losses+bwd, clip, AdamW -- with lr / bias-correction / MKRW read from device memory
         run_eager(min(3, len(pool)))                       # allocator + code-object warm-up
         torch.cuda.synchronize()
-        if a.teacher in ("ahead", "split"):
-            # graph i: student step on batch i (teacher outputs t[i] are ready) || teacher forward on batch i+1 -> t[i+1];
-            # t[0] is primed eagerly once, and the last graph of the ring copies its teacher(batch 0) outputs into it
-            n = len(pool)
-            trip = lambda i: (pool[i % n][1], pool[i % n][0], pool[i % n][2])           # (batch, task, plan)
-            t0 = trainer.teacher_forward(*trip(0))
-            t_cur, graphs = t0, []
-            for i in range(n):
-                cap = trainer.capture_ahead if a.teacher == "ahead" else trainer.capture_split
-                cs = cap(trip(i), t_cur, trip(i + 1), t_next_into=t0 if i == n - 1 else None)
-                graphs.append(cs)
-                t_cur = cs.t_next
-        else:
-            graphs = [trainer.capture(b, task, plan) for task, b, plan in pool]
+        graphs = capture_ring(trainer, pool, a.teacher)
         torch.cuda.synchronize()
-
-    def run_graph(n, start=0):
-        traj = 0
-        for s in range(n):
-            cs = graphs[(start + s) % len(graphs)]
-            (trainer.replay_split if a.teacher == "split" else trainer.replay)(cs)
-            traj += cs.traj_steps
-        return traj
-
-    run = run_graph if a.mode == "graph" else run_eager
+        run = graph_runner(trainer, graphs)
+    else:
+        run = run_eager
     if a.mode == "stream":
         from magic_amd.host.loader import DevicePrefetcher
         n_vp = 4096
@@ -295,84 +422,77 @@ def main():
                 traj += plan["traj_steps"]
             return traj
         run = run_stream
-    run(a.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    traj = run(a.steps, start=a.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        tr = torch.tensor([traj], device=dev, dtype=torch.float64)
-        dist.all_reduce(tr)
-        traj = float(tr.item())
+    traj, dt = timed_region(run, a.steps, a.warmup, world, dev)
 
     roof = None
     if not a.no_profile:      # every rank runs it (the steps contain the gradient all-reduce); rank 0 reports
-        # instrumented pass: HIP events around every launch (on the launch stream), algorithmic FLOPs from true ragged sizes
         nprof = min(len(pool), 6)
-        O.FLOPS.update(total=0.0, gemm=0.0, linear_ln=0.0, attn=0.0, enabled=True)
-        L.PROFILE.update(on=True, events=[])
-        import magic_amd.host.model_pretrain as MP
-        MP.LOCKSTEP_EAGER = True            # same paired launch structure as the captured graphs (pairing is capture-only by default)
-        run_eager(nprof, start=0)
-        torch.cuda.synchronize()
-        MP.LOCKSTEP_EAGER = False
-        L.PROFILE["on"] = False
-        O.FLOPS["enabled"] = False
-        by = {}
-        for name, layout, e0, e1 in L.PROFILE["events"]:
-            k = name if layout < 0 else f"{name}[{['NT', 'NN', 'TN'][layout]}]"
-            t, c = by.get(k, (0.0, 0))
-            by[k] = (t + e0.elapsed_time(e1), c + 1)
-        gemm_ms = sum(t for k, (t, c) in by.items() if k.startswith("magic_gemm"))
-        gemm_ms = max(gemm_ms, 1e-9)
-        gemm_n = sum(c for k, (t, c) in by.items() if k.startswith("magic_gemm"))
+        by = instrumented_pass(trainer, pool, nprof, gate_ms=30.0)
+        fam = lambda k: k.startswith("magic_gemm")
+        gemm_ms = max(sum(t for k, (t, c) in by.items() if fam(k)), 1e-9)
+        gemm_n = sum(c for k, (t, c) in by.items() if fam(k))
         all_ms = sum(t for t, c in by.values())
         flops = O.FLOPS["gemm"]            # the GEMM family's own algorithmic FLOPs (fused linear+LN and attention kernels count separately)
         is_mfma = lambda k: any(x in k for x in ("magic_gemm", "magic_linear_ln", "magic_attn_", "magic_rowblock"))
         mfma_ms = sum(t for k, (t, c) in by.items() if is_mfma(k))
-        # The instrumented pass launches eagerly with an event pair per launch, so it is host-bound and every duration is
-        # inflated by launch gaps; the product path replays a HIP graph.  The GEMM family's SHARE of kernel time is taken
-        # from the instrumented pass and applied to the graph-replay step time measured above.  (A paired launch is attributed to
-        # the family of its first member; ~13 of the ~110 GEMM-family launches per step are such mixed pairs.)
-        share = gemm_ms / all_ms
         step_ms = dt / a.steps * 1e3
-        gemm_ms_step = share * step_ms if a.mode == "graph" else gemm_ms / nprof
-        mfma_ms_step = mfma_ms / all_ms * step_ms if a.mode == "graph" else mfma_ms / nprof
-        ach = (flops / nprof) / (gemm_ms_step * 1e-3) / 1e12
-        ach_all = (O.FLOPS["total"] / nprof) / (mfma_ms_step * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_kernel / gemm_xcd_kernel / gemm_grouped_kernel <bf16, NT|NN|TN> (the dominant kernel family: Linear forward, "
-                                           "input and weight gradients, projections)",
+        # achieved = the family's algorithmic FLOPs / the family's SUMMED launch durations (non-overlapped pass), i.e.
+        # (FLOPs per launch) / (average launch duration); frac = achieved / dense bf16 MFMA peak.  Reproducible from the committed
+        # rocprofv3 --kernel-trace --stats CSV of this command: sum the gemm_* kernels' TotalDurationNs, divide by the executed steps.
+        ach = (flops / nprof) / (gemm_ms / nprof * 1e-3) / 1e12
+        ach_all = (O.FLOPS["total"] / nprof) / (mfma_ms / nprof * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic()
+        roof = {"bound": "mfma", "kernel": "gemm_kernel / gemm_xcd_kernel / gemm_grouped_kernel / gemm_dw_batch_kernel <bf16, NT|NN|TN> (the dominant kernel "
+                                           "family: Linear forward, input and weight gradients, projections)",
                 "achieved": round(ach, 3), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5),
-                "traffic": pmc_traffic(),
+                "traffic": traffic, "traffic_source": (traffic_src + " (offline rocprofv3 --pmc passes of this command; not collected in this run)") if traffic_src else None,
+                "how": "HIP events around every launch on the launch stream, eager pass of the same steps with the captured graphs' launch structure, "
+                       "teacher serialised on the main stream, device-side gate so the host runs ahead; family time = SUM of its launch durations",
                 "detail": {"algorithmic_gflop_per_step": round(flops / nprof / 1e9, 2), "gemm_launches_per_step": gemm_n // nprof,
-                           "gemm_share_of_kernel_time": round(share, 4), "gemm_ms_per_step": round(gemm_ms_step, 3),
-                           "avg_gemm_launch_us": round(gemm_ms_step / max(gemm_n / nprof, 1) * 1e3, 2),
+                           "gemm_ms_per_step": round(gemm_ms / nprof, 3), "avg_gemm_launch_us": round(gemm_ms / max(gemm_n, 1) * 1e3, 2),
+                           "gemm_share_of_kernel_time": round(gemm_ms / all_ms, 4),
                            "all_dense_contraction_kernels": {
                                "kernels": "gemm + fused linear+LayerNorm (fwd / bwd) + fused attention (fwd / bwd)",
                                "algorithmic_gflop_per_step": round(O.FLOPS["total"] / nprof / 1e9, 2),
                                "gflop_by_family": {k: round(O.FLOPS[k] / nprof / 1e9, 2) for k in ("gemm", "linear_ln", "attn")},
-                               "ms_per_step": round(mfma_ms_step, 3), "share_of_kernel_time": round(mfma_ms / all_ms, 4),
+                               "ms_per_step": round(mfma_ms / nprof, 3), "share_of_kernel_time": round(mfma_ms / all_ms, 4),
                                "achieved_tflops": round(ach_all, 2), "frac": round(ach_all / PEAK_BF16_TFLOPS, 5)},
-                           "instrumented_pass_all_kernels_ms_per_step": round(all_ms / nprof, 3),
+                           "whole_step": {"summed_kernel_ms_per_step_serialised": round(all_ms / nprof, 3), "graph_replay_wall_ms_per_step": round(step_ms, 3),
+                                          "frac_of_mfma_peak_on_wall": round(O.FLOPS["total"] / nprof / (step_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 5)},
                            "launches_per_step": sum(c for t, c in by.values()) // nprof,
                            "top_kernels_share": {k: round(t / all_ms, 4) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]}}}
 
     if roof is not None and rank == 0:
         roof["detail"]["feature_ingest"] = ingest_rate(dev)
 
+    modes, parity = None, None
+    if rank == 0 and world == 1 and not a.no_parity and a.mode == "graph":
+        # the parity-clean arithmetic (fp32 MFMA, exact) timed in the same run on the same batches, next to the headline mode
+        other = torch.float32 if dtype == torch.bfloat16 else torch.bfloat16
+        del graphs
+        _, _, t2, s2, tr2 = build_models(other, dev, a.dropout, world)
+        eager_runner(tr2)(min(3, len(pool)))
+        torch.cuda.synchronize()
+        g2 = capture_ring(tr2, pool, a.teacher)
+        torch.cuda.synchronize()
+        traj2, dt2 = timed_region(graph_runner(tr2, g2), a.steps, a.warmup, world, dev)
+        nm = {torch.bfloat16: "bf16", torch.float32: "fp32"}
+        modes = {nm[dtype]: {"ms_per_step": round(dt / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj / dt, 1)},
+                 nm[other]: {"ms_per_step": round(dt2 / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj2 / dt2, 1)},
+                 "note": "same graphs, batches and schedule; fp32 = v_mfma_f32_16x16x4_f32 (exact), fp32 activations"}
+        del g2, t2, s2, tr2
+        parity = parity_block(dev)
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(tcfg, scfg, a.batch)
+
+    secondary = None
+    if rank == 0 and world == 1 and not a.no_secondary and a.mode == "graph" and not a.no_parity:
+        del trainer, teacher, student
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        secondary = secondary_block()
 
     if rank == 0:
         info = {"metric": "trajectory-steps/sec (whole node), MAGIC-S R2R pretrain", "value": round(traj / dt, 2),
@@ -385,7 +505,11 @@ def main():
                            "dropout": a.dropout,
                            "global_batch": a.batch * world, "per_gpu_batch": a.batch, "views": 36, "feat_dim": 768, "max_tokens": 80,
                            "parallelism": f"dp{world}", "samples_per_sec": round(a.batch * world * a.steps / dt, 1)},
-                "roofline": roof, "cpu_baseline": cpu}
+                "roofline": roof, "cpu_baseline": cpu, "parity": parity, "modes": modes, "secondary": secondary}
+        if parity is not None:
+            info["bf16_max_logit_delta"] = parity["bf16"]["max_abs_logit_delta"]
+            info["argmax_agreement"] = parity["bf16"]["argmax_agreement"]
+            info["fp32_mode_ms_per_step"] = modes["fp32"]["ms_per_step"]
         print(json.dumps(info))
     if world > 1:
         dist.destroy_process_group()

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_json_line_with_the_contract_keys():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--pool", "3"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--pool", "3", "--no-secondary"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -28,6 +28,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in roof, k
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    # parity leg: both arithmetic modes against the fp64 oracle at full depth / vocabulary, and both modes' step times
+    par, modes = d["parity"], d["modes"]
+    assert par["fp32"]["max_abs_logit_delta"] < 1e-3 and par["fp32"]["argmax_agreement"] == 1.0
+    assert par["bf16"]["max_abs_logit_delta"] < 1e-2 and d["bf16_max_logit_delta"] == par["bf16"]["max_abs_logit_delta"]
+    assert modes["fp32"]["ms_per_step"] > 0 and d["fp32_mode_ms_per_step"] == modes["fp32"]["ms_per_step"]
     cpu = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu, k

@@ -11,6 +11,10 @@ Import recipe: SURVEY.md Appendix F.  What is minted:
   ops.pt              map_nav_src/utils/ops.py pad_tensors / gen_seq_masks
   nav_loop.pt         map_nav_src/r2r/speaker_utils.py FloydGraph; map_nav_src/r2r/agent.py _language_variable,
                       _panorama_feature_variable_do, _nav_gmap_variable, _nav_vp_variable_mem, _teacher_action
+  zdict.pt            map_nav_src/r2r/data_utils.py LoadZdict (read_*_tsv, load_img_tensor, load_instr_tensor) and
+                      map_nav_src/utils/data.py KMeansPicker (read_tim_tsv, seeded K-means + random_pick_front_features) on
+                      synthetic TSV rows generated here
+Every step runs from a scratch working directory (the reference's parsers create output directories relative to the cwd).
 """
 import importlib.util
 import os
@@ -472,6 +476,52 @@ def mint_nav_loop():
     print("nav_loop: floyd", len(script), "ops;", len(steps), "agent steps")
 
 
+def mint_zdict():
+    """zdict.pt: the reference's dictionary loaders on synthetic rows (features are random fp32 vectors written in the reference's
+    own TSV/base64 format by host/zdict.py's writers; the fixture stores those inputs and what the reference parsed from them)."""
+    import tempfile
+    sys.path.insert(0, f"{REF}/map_nav_src")
+    stub(["MatterSim", "line_profiler", "jsonlines", "h5py", "spacy", "nltk", "tensorboardX", "progressbar", "sklearnex"])
+    import magic_amd  # noqa: F401
+    from magic_amd.host import zdict as Z
+    DU = load_by_path("ref_data_utils", f"{REF}/map_nav_src/r2r/data_utils.py")
+    UD = load_by_path("ref_utils_data", f"{REF}/map_nav_src/utils/data.py")
+    rng = np.random.default_rng(11)
+    img_rows = [(f"room{i}", rng.standard_normal(12).astype(np.float32), float(p)) for i, p in enumerate(rng.dirichlet(np.ones(5)))]
+    txt_rows = []
+    for i, p in enumerate(rng.dirichlet(np.ones(7))):
+        txt_rows.append(("direction" if i % 3 else "landmark", f"tok{i}", rng.standard_normal(8).astype(np.float32), float(p)))
+    n = 40
+    txt, vp, gm = (rng.standard_normal((n, 6)).astype(np.float32) + 3 * (np.arange(n)[:, None] % 4) for _ in range(3))
+    out = dict(img_rows=img_rows, txt_rows=txt_rows, tim=(txt, vp, gm), n_clusters=4, seed=123)
+    with tempfile.TemporaryDirectory() as d:
+        fi, ft, fm = os.path.join(d, "img.tsv"), os.path.join(d, "txt.tsv"), os.path.join(d, "tim.tsv")
+        Z.write_img_tsv(fi, img_rows)
+        Z.write_instr_tsv(ft, txt_rows)
+        Z.write_tim_tsv(fm, txt, vp, gm)
+        ref = DU.LoadZdict(fi, ft)
+        a, b = ref.load_all_zdicts()
+        out["read_img"] = [(r["roomtype"], torch.from_numpy(r["feature"].copy()), r["pz"]) for r in a]
+        out["read_instr"] = [(r["token_type"], r["token"], torch.from_numpy(r["feature"].copy()), r["pz"]) for r in b]
+        real_cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a_, **k_: self           # the loaders hard-code .cuda() (data_utils.py:88-89,:113-118)
+        try:
+            out["img_tensor"] = ref.load_img_tensor()
+            out["instr_tensor"] = ref.load_instr_tensor()
+            np.random.seed(5)
+            out["instr_tensor_random"] = ref.load_instr_tensor(is_random=True)
+        finally:
+            torch.Tensor.cuda = real_cuda
+        np.random.seed(out["seed"])
+        picker = UD.KMeansPicker(fm, n_clusters=out["n_clusters"])
+        out["tim_read"] = tuple(torch.from_numpy(x.copy()) for x in picker.read_tim_tsv(fm))
+        out["labels"] = {k: torch.from_numpy(picker.kmeans_model_dict[k].labels_.astype(np.int64)) for k in picker.feat_dicts}
+        picked = picker.random_pick_front_features()
+        out["picked"] = {k: torch.from_numpy(np.array(v)) for k, v in picked.items()}
+    torch.save(out, os.path.join(HERE, "zdict.pt"))
+    print("zdict:", {k: tuple(v.shape) for k, v in out["picked"].items()})
+
+
 def mint_ops():
     O = load_by_path("ref_ops", f"{REF}/map_nav_src/utils/ops.py")
     g = torch.Generator().manual_seed(2)
@@ -483,6 +533,11 @@ def mint_ops():
 
 
 if __name__ == "__main__":
+    import tempfile
+    os.chdir(tempfile.mkdtemp(prefix="mint_golden_"))      # nothing the reference's modules create lands in the repo
+    if "--zdict-only" in sys.argv:
+        mint_zdict()
+        sys.exit(0)
     if "--mrc-only" in sys.argv:
         mint_mrc()
         sys.exit(0)
@@ -497,5 +552,6 @@ if __name__ == "__main__":
         sys.exit(0)
     mint_primitives()
     mint_ops()
+    mint_zdict()
     mint_agent()
     mint_pretrain_side()

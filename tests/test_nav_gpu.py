@@ -289,7 +289,7 @@ def test_nav_modes_with_dropout_train_vs_eval():
     assert torch.isfinite(m.store.grad).all() and m.store.grad.abs().max() > 0
 
 
-def test_f4_modes_dictionaries_off_match_the_oracle_and_refuse_dictionary_inputs():
+def test_f4_modes_dictionaries_off_match_the_oracle_and_refuse_dictionary_inputs_when_switched_off():
     """SURVEY §8 f-4 in its dictionaries-off form: 'instr_zdict_update' (agent.py:1231-1233) and 'extract_cfp_features'
     (agent.py:1535-1541) against the CPU oracle in fp32; a back-door / front-door input is refused, never ignored."""
     from magic_amd.host import synth
@@ -321,8 +321,10 @@ def test_f4_modes_dictionaries_off_match_the_oracle_and_refuse_dictionary_inputs
     assert set(got) == {"txt_outputs", "vp_outputs", "gmap_outputs"}
     for k in got:
         close(got[k], want[k], k)
+    # a dictionary input while its do_back_* / do_front_* switch is off (this config: all off) is refused, never ignored;
+    # with the switches on: tests/test_causal_gpu.py
     bad = dict(zin, instr_z_direction_features=torch.zeros(5, 3, 128))
-    with pytest.raises(NotImplementedError, match="instr_z_direction_features"):
+    with pytest.raises(ValueError, match="instr_z_direction_features"):
         g("instr_zdict_update", bad)
-    with pytest.raises(NotImplementedError, match="front_txt_feats"):
+    with pytest.raises(ValueError, match="front_txt_feats"):
         g("language", dict(txt_ids=inp["txt_ids"].to(DEV), txt_masks=inp["txt_masks"].to(DEV), front_txt_feats=torch.zeros(5, 4, 128)))

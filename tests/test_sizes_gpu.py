@@ -16,8 +16,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def run_case(hs, ht, task, batch, layers=(1, 1, 1), vocab=400):
+def run_case(hs, ht, task, batch, layers=(1, 1, 1), vocab=400, **over):
     kw = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=vocab, num_l_layers=layers[0], num_x_layers=layers[1], num_pano_layers=layers[2])
+    kw.update(over)
     tcfg = make_config(ht, role="teacher", **kw)
     scfg = make_config(hs, role="student", teacher_hidden_size=ht, kdl=KDL, **kw)
     torch.manual_seed(1)
@@ -85,3 +86,11 @@ def test_maximum_instruction_length_512_tokens():
     batch = synth.make_batch("sap", batch_size=1, seed=12, vocab=400, min_len=512, max_len=512, min_steps=2, max_steps=2)
     assert batch["txt_ids"].shape[1] == 512
     run_case(128, 256, "sap", batch)
+
+
+@pytest.mark.parametrize("task", ["sap", "cfp"])
+def test_masked_mean_panorama_fusion(task):
+    """adaptive_pano_fusion = false (r2r_magic_model_config.json:57 switched off): the visited-node embedding is the masked mean of the
+    view embeddings; ragged view counts so the mask matters; the fusion's scoring parameters must receive no gradient"""
+    b = synth.make_batch(task, batch_size=4, seed=8, vocab=400, min_len=6, max_len=14, min_steps=2, max_steps=4, dup_view_prob=0.5)
+    run_case(128, 256, task, b, adaptive_pano_fusion=False)

@@ -526,21 +526,34 @@ class MagicNet:
         c.img_attn = self.new(Np, V, c.ldp, dtype=torch.float32)
         O.head_mean_fwd(c.P, c.img_attn, Np, self.nh, V * c.ldp)
         c.fused = self.new(Np, H)
+        c.fprobs = self.new(Np, V, dtype=torch.float32)
         if cfg_get(self.cfg, "adaptive_pano_fusion"):
             fl = self.lin(p + "pano_fuse_linear.weight")
-            c.fprobs = self.new(Np, V, dtype=torch.float32)
             O.pano_fuse_fwd(c.out, plan["view_lens"], fl.Wm, fl.b, c.fused, c.fprobs, Np, V, H)
         else:
-            raise NotImplementedError("masked-mean panorama fusion (adaptive_pano_fusion=false) is not built yet")
+            # masked mean over the valid views (adaptive_pano_fusion=false, r2r_magic_model_config.json:57) = the attention pooling
+            # with a zero scoring vector: softmax of equal scores over the unmasked views is 1/n each
+            zw, zb = self._zero_fuse()
+            O.pano_fuse_fwd(c.out, plan["view_lens"], zw, zb, c.fused, c.fprobs, Np, V, H)
         return c
+
+    def _zero_fuse(self):
+        z = self._cache.get("zero_fuse")
+        if z is None:
+            z = self._cache["zero_fuse"] = (self.zeros(self.H, dtype=torch.float32), self.zeros(1, dtype=torch.float32))
+        return z
 
     def pano_bwd(self, c, plan, d_pano, d_fused, dP_init=None):
         p, H = self.p + "img_embeddings.", self.H
         Np, V = c.Np, c.V
         M = Np * V
         if d_fused is not None:
-            fl = self.lin(p + "pano_fuse_linear.weight")
-            O.pano_fuse_bwd(c.out, c.fprobs, fl.Wm, d_fused, d_pano, fl.dW, fl.db, Np, V, H)
+            if cfg_get(self.cfg, "adaptive_pano_fusion"):
+                fl = self.lin(p + "pano_fuse_linear.weight")
+                O.pano_fuse_bwd(c.out, c.fprobs, fl.Wm, d_fused, d_pano, fl.dW, fl.db, Np, V, H)
+            else:       # masked mean: no scoring parameters (their would-be gradients land in a scratch vector)
+                zw, zb = self._zero_fuse()
+                O.pano_fuse_bwd(c.out, c.fprobs, zw, d_fused, d_pano, self.new(H, dtype=torch.float32), self.new(1, dtype=torch.float32), Np, V, H)
         d = d_pano
         nl = self.cfg.num_pano_layers
         for i in reversed(range(nl)):

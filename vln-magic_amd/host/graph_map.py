@@ -5,7 +5,7 @@ The reference imports `GraphMap` from its withheld `models.graph_utils` and `pad
   GraphMap(start_vp) :755, .update_graph(ob) :757,:1102, .node_positions :185, .graph.visited / .distance / .path :192,:220,:384,
   .node_step_ids :205,:875, .node_stop_scores :990,:1083, .update_node_embed(vp, embed, rewrite=, teacher=) :910-924,
   .get_node_embed(vp, teacher) :206, .get_pos_fts(cur_vp, vpids, heading, elevation) :212,:263,:301, .start_vp :268.
-`FloydGraph` exists in the reference as map_nav_src/r2r/speaker_utils.py:501-546 (pinned: tests/golden/floyd.pt); the rest is
+`FloydGraph` exists in the reference as map_nav_src/r2r/speaker_utils.py:501-546 (pinned: tests/golden/nav_loop.pt); the rest is
 [LINEAGE] DUET `models/graph_utils.py`, constrained by those call sites and by env.get_gmap_pos_fts (r2r/env.py:213-235).
 
 Storage is index based: viewpoints get dense ids in arrival order, the all-pairs table is a growing float64 matrix relaxed

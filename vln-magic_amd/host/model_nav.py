@@ -8,7 +8,9 @@ Call surface kept:  `vln_bert(mode, inputs)` with mode i
                        global_logits, local_logits, fused_logits)                          :964-967
   'instr_zdict_update'   -> (txt_embeds [B,L,H], txt_attns)  from inputs z_txt / z_txt_mask          :1231-1233
   'extract_cfp_features' -> dict(txt_outputs, vp_outputs, gmap_outputs)  [B,H] each, whole-trajectory forward   :1538-1541
-(both in their dictionaries-off form: a non-None back-door / front-door input raises NotImplementedError, never ignored)
+with the causal-intervention inputs of SURVEY section 8 f-4 (instr_z_* / z_img_* back-door dictionaries, front_* front-door
+dictionaries) served by host/causal.py when the matching do_back_* / do_front_* switch is on; such an input with its switch
+off raises (never ignored)
 plus `.vln_bert.<kd head>` callables (`txt_emb_w`, `kdl_img_w`, `kdl_avg_img_w`, `global_cross_w`,
 `local_cross_w`; agent.py:568-665, agent_base.py:330), `.drop_env` (:738), `.parameters()`, `.state_dict()`.
 
@@ -43,7 +45,8 @@ def nav_specs(cfg, p="vln_bert."):
     s += cls_specs(p + "global_sap_head.", H) + cls_specs(p + "local_sap_head.", H) + cls_specs(p + "sap_fuse_linear.", H, 2 * H)
     for k in ("txt", "img", "local", "global", "predict"):       # learned ability weights, agent.py:1130-1134
         s.append((f"{p}kdl_{k}_weight", (1,), "zeros"))
-    return s
+    from .causal import causal_specs
+    return s + causal_specs(cfg, p)
 
 
 class _HipLinearFn(torch.autograd.Function):
@@ -420,7 +423,10 @@ class VLNBert(nn.Module):
             t_hs = getattr(args, "teacher_hidden_size", None) if role != "teacher" else None
             config = make_config(hs, role=role, teacher_hidden_size=t_hs if getattr(args, "train_kdl", False) else None,
                                  num_l_layers=getattr(args, "num_l_layers", 6), num_x_layers=getattr(args, "num_x_layers", 3),
-                                 num_pano_layers=getattr(args, "num_pano_layers", 2), graph_sprels=getattr(args, "graph_sprels", True))
+                                 num_pano_layers=getattr(args, "num_pano_layers", 2), graph_sprels=getattr(args, "graph_sprels", True),
+                                 **{k: getattr(args, k) for k in ("do_back_txt", "do_back_img", "do_front_txt", "do_front_img", "do_front_his",
+                                                                   "do_back_txt_type", "do_back_imgobj_type", "do_back_img_type", "do_add_method",
+                                                                   "front_n_clusters") if hasattr(args, k)})
         self.config, self.role, self.prefix = config, role, "vln_bert."
         self.device_, self.compute_dtype = torch.device(device), compute_dtype
         trainable = role != "teacher" or bool(getattr(args, "train_kdl_teacher", False))
@@ -439,6 +445,8 @@ class VLNBert(nn.Module):
                 m.__class__ = HipLinear
                 m._net, m._lin = self.net, self.net.lin(f"{self.prefix}{n}.weight")
                 m._owner = (self,)          # tuple: not registered as a sub-module
+        from .causal import build_blocks
+        self.causal_blocks = build_blocks(self)          # plain dict: the blocks' parameters live in the store like every other
         self.register_load_state_dict_post_hook(lambda m, k: setattr(m.store, "shadow_clean", False))
 
     def cuda(self, device=None):           # `VLNBert(args, role).cuda()` (agent.py:36-38): already resident
@@ -470,20 +478,35 @@ class VLNBert(nn.Module):
 
     def forward(self, mode, batch):
         refuse_torch_ddp(self)
-        on = [k for k in CAUSAL_KEYS if batch.get(k) is not None]
-        if on:
-            raise NotImplementedError(f"VLNBert({mode!r}): causal-intervention inputs {on} (do_back_* / do_front_*, SURVEY §8 f-4) are not built -- "
-                                      "the attention over the z-dictionaries lives in the withheld model source; run with those flags off")
+        from .causal import check_inputs
+        check_inputs(self, mode, batch, CAUSAL_KEYS)
+        cz = self.causal_blocks
         self.store.sync_shadow()
         self._arm_dropout()           # vln_bert.train() (agent.py:rollout under feedback='sample') -> config dropouts on
-        if mode == "language":
-            return _LanguageFn.apply(self._anchor, self, batch["txt_ids"], batch["txt_masks"])
+        if mode in ("language", "instr_zdict_update"):
+            # instr_zdict_update (agent.py:1231-1233, update_z_dict): per-token instruction embeddings under no_grad; the caller indexes `[0][b][j + 1]`
+            ids, masks = (batch["txt_ids"], batch["txt_masks"]) if mode == "language" else (batch["z_txt"], batch["z_txt_mask"])
+            x, attns = _LanguageFn.apply(self._anchor, self, ids, masks)
+            if "back_txt" in cz and batch.get("instr_z_direction_features") is not None:
+                z = torch.cat([batch["instr_z_direction_features"], batch["instr_z_landmark_features"]], 1)
+                pz = torch.cat([batch["instr_z_direction_pzs"], batch["instr_z_landmark_pzs"]], 1)
+                x = cz["back_txt"](x, z, pz)
+            if "front_txt" in cz and batch.get("front_txt_feats") is not None:
+                x = cz["front_txt"](x, batch["front_txt_feats"])
+            return x, attns
         if mode == "panorama":
             fts = batch["view_img_fts"]
             if not batch.get("already_dropout", True):
                 fts = self.drop_env(fts)
-            return _PanoramaFn.apply(self._anchor, self, fts, batch["loc_fts"], batch["nav_types"], batch["view_lens"], batch.get("pano_masks"))
+            x, masks, fused, attns = _PanoramaFn.apply(self._anchor, self, fts, batch["loc_fts"], batch["nav_types"], batch["view_lens"], batch.get("pano_masks"))
+            if "back_img" in cz and batch.get("z_img_features") is not None:
+                x = cz["back_img"](x, batch["z_img_features"], batch["z_img_pzs"])
+            return x, masks, fused, attns
         if mode == "navigation":
+            if "front_gmap" in cz and batch.get("front_gmap_feats") is not None:
+                batch = dict(batch, gmap_img_embeds=cz["front_gmap"](batch["gmap_img_embeds"], batch["front_gmap_feats"]))
+            if "front_vp" in cz and batch.get("front_vp_feats") is not None:
+                batch = dict(batch, vp_img_embeds=cz["front_vp"](batch["vp_img_embeds"], batch["front_vp_feats"]))
             data = {k: batch[k] for k in ("txt_masks", "gmap_masks", "vp_masks", "gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists",
                                           "gmap_visited_masks", "gmap_vpids", "vp_pos_fts", "vp_nav_masks", "vp_cand_vpids")}
             data["host_lens"], data["fusion"], data["gmap_logit_masks"] = batch.get("host_lens"), batch.get("fusion"), batch.get("gmap_logit_masks")
@@ -491,9 +514,6 @@ class VLNBert(nn.Module):
                                                                 batch["txt_embeds"], data, batch.get("txt_kv"))
             return dict(gmap_embeds=g, vp_embeds=v, gmap_attns=ga, vp_attns=va, cls_embeds=cls,
                         global_logits=gl, local_logits=ll, fused_logits=fl)
-        if mode == "instr_zdict_update":
-            # agent.py:1231-1233 (update_z_dict): per-token instruction embeddings under no_grad; the caller indexes `[0][b][j + 1]`
-            return _LanguageFn.apply(self._anchor, self, batch["z_txt"], batch["z_txt_mask"])
         if mode == "extract_cfp_features":
             return self._extract_cfp_features(batch)
         raise NotImplementedError(f"VLNBert mode {mode!r}")

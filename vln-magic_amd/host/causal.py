@@ -162,8 +162,10 @@ class CausalBlock(nn.Module):
         object.__setattr__(self, "kv", hl("key.weight", "key.bias", rows=2 * H, cols=dict_width(cfg, name)))     # key | value adjacent
         object.__setattr__(self, "o", hl("output.dense.weight", "output.dense.bias"))
         if self.door:
-            object.__setattr__(self, "gx", hl("gate_x.weight", "gate_x.bias"))
-            object.__setattr__(self, "ge", hl("gate_e.weight", "gate_e.bias"))
+            # the gate is two H-wide dot products per token: elementwise torch ops on the store's own nn.Parameters (their .grad
+            # are views of the flat gradient buffer, so autograd's accumulation lands where the optimizer and the exchange look)
+            named = dict(model.named_parameters())
+            object.__setattr__(self, "_gate", tuple(named[p + n] for n in ("gate_x.weight", "gate_x.bias", "gate_e.weight", "gate_e.bias")))
         self._ln_name = p + "output.LayerNorm"
         self._drop_name = p + "output.dropout"
 
@@ -186,8 +188,10 @@ class CausalBlock(nn.Module):
             e = _DictAttnFn.apply(q, k.unsqueeze(0).expand(B, Nz, H), v.unsqueeze(0).expand(B, Nz, H), net)
         e = self.o(e.contiguous())
         if self.door:
-            g = torch.sigmoid(self.gx(x).float() + self.ge(e).float())
-            e = (e.float() * g).to(e.dtype)
+            wx, bx, we, be = self._gate
+            ef = e.float()
+            g = torch.sigmoid((x.float() * wx.view(1, 1, H)).sum(-1, keepdim=True) + (ef * we.view(1, 1, H)).sum(-1, keepdim=True) + bx + be)
+            e = (ef * g).to(e.dtype)
         return _AddNormFn.apply(x, e, net, net.ln(self._ln_name), net._dh(self._drop_name), self._model[0])
 
 

@@ -51,7 +51,7 @@ def nav_specs(cfg, p="vln_bert."):
 
 class _HipLinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mod):
+    def forward(ctx, x, mod, anchor=None):
         net, lin = mod._net, mod._lin
         shp = x.shape
         M = x.numel() // shp[-1]
@@ -72,14 +72,18 @@ class _HipLinearFn(torch.autograd.Function):
         if net.train:
             O.linear_dw(d, ctx.x, lin.dW, lin.db, M)
         dx = O.linear_dx(d, lin.W, M)
-        return dx.view(ctx.shape).to(ctx.in_dtype), None
+        return dx.view(ctx.shape).to(ctx.in_dtype), None, None
 
 
 class HipLinear(nn.Module):
     """A Linear whose weight/bias live in the ParamStore; callable like nn.Linear (KD projection heads)."""
 
     def forward(self, x):
-        return _HipLinearFn.apply(x, self)
+        # an input that carries no gradient (a dictionary, a constant) would leave this node out of the autograd graph and the
+        # weight gradient unwritten: the owner's anchor (a requires_grad scalar) keeps the node in
+        owner = getattr(self, "_owner", None)
+        anchor = getattr(owner[0], "_anchor", None) if (owner and not x.requires_grad and torch.is_grad_enabled()) else None
+        return _HipLinearFn.apply(x, self, anchor)
 
 
 class Critic(nn.Module):

@@ -36,6 +36,7 @@ KDL = dict(knowledge_distillation=True, kd_alpha=0.5, kd_temperature=2, teacher_
            t_sample_preprocess_exp_decay=0.7, rw_temp=4, train_teacher=False,
            kdl_tasks=["txt", "img", "local", "global", "predict"], kdl_task_types=["emb", "attn"])   # r2r_magic_pretrain.json:62-87
 TASKS = ["mlm", "sap", "cfp"]
+MAX_TOKENS = 80                # instruction tokens per sample (synth.make_batch draws U{20..80})
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
@@ -172,7 +173,7 @@ def pmc_traffic():
     return None, None
 
 
-def build_models(dtype, dev, dropout, world):
+def build_models(dtype, dev, dropout, world, batch=48):
     dk = dict(hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)   # r2r_magic_model_config.json:2-3
     tcfg = make_config(256, role="teacher", **dk)                                   # teacher_* of r2r_magic_model_config.json:33-37
     scfg = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL, **dk)  # MAGIC-S: student_* :39-43
@@ -182,7 +183,8 @@ def build_models(dtype, dev, dropout, world):
         dist.broadcast(student.store.flat, src=0)
         dist.broadcast(teacher.store.flat, src=0)
     trainer = PretrainStep(student, teacher, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0,
-                           warmup_steps=10000, num_train_steps=200000, rw_temp=4.0)
+                           warmup_steps=10000, num_train_steps=200000, rw_temp=4.0,
+                           sparse_embedding_rows=batch * MAX_TOKENS)      # <= B x 80 distinct token ids per rank and step (north star: <= 80 tokens)
     return tcfg, scfg, teacher, student, trainer
 
 
@@ -358,7 +360,7 @@ def main():
             dist.init_process_group("gloo")
     L.load()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    tcfg, scfg, teacher, student, trainer = build_models(dtype, dev, a.dropout, world)
+    tcfg, scfg, teacher, student, trainer = build_models(dtype, dev, a.dropout, world, a.batch)
 
     # synthetic batches, resident in HBM before the timed region (per-rank stream: seed 1234 + rank)
     pool = []
@@ -470,7 +472,7 @@ def main():
         # the parity-clean arithmetic (fp32 MFMA, exact) timed in the same run on the same batches, next to the headline mode
         other = torch.float32 if dtype == torch.bfloat16 else torch.bfloat16
         del graphs
-        _, _, t2, s2, tr2 = build_models(other, dev, a.dropout, world)
+        _, _, t2, s2, tr2 = build_models(other, dev, a.dropout, world, a.batch)
         eager_runner(tr2)(min(3, len(pool)))
         torch.cuda.synchronize()
         g2 = capture_ring(tr2, pool, a.teacher)

@@ -55,6 +55,35 @@ def _worker(rank, world, port, q):
         auto_sync(model)
         ok_auto = ok_auto and bool(torch.equal(keep, model.store.grad))
         ok_mean = ok_mean and ok_auto
+        # ---- bucketed exchange in backward-completion order == monolithic; sparse word-embedding rows == dense table --------
+        from magic_amd.host.trainer import EMB_TABLE
+        ok_bucket = True
+        for sparse in (False, True):
+            st2 = ParamStore(pretrain_specs(cfg), "cpu", torch.float32, seed=1)
+            gen = torch.Generator().manual_seed(900 + rank)
+            st2.grad.copy_(torch.randn(st2.total, generator=gen))
+            off, n, (R, H) = st2.offsets[EMB_TABLE]
+            touched = torch.randperm(R, generator=gen)[:17 + 5 * rank]            # ranks touch different, overlapping row sets
+            if sparse:
+                tab = st2.grad[off:off + n].view(R, H)
+                keep = tab[touched].clone()
+                tab.zero_()
+                tab[touched] = keep
+            mono = st2.grad.clone()
+            dist.all_reduce(mono)
+            sy = GradSync(st2, chunk_elems=4099, overlap=True, sparse_rows_cap=40 if sparse else None)
+            b0, b1 = sy.buckets
+            covered = sorted(b0 + b1)
+            ok_bucket = ok_bucket and covered[0][0] == 0 and covered[-1][1] == st2.total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+            ok_bucket = ok_bucket and b0[0][0] == st2.offsets["bert.global_encoder.gmap_pos_embeddings.0.weight"][0]
+            sy.reduce_bucket(0)
+            first = st2.grad.clone()
+            sy.reduce_bucket(1, touched if sparse else None)
+            sy.finish()
+            ok_bucket = ok_bucket and bool(torch.allclose(st2.grad, mono, rtol=1e-6, atol=1e-6))
+            lo, hi = b0[0]
+            ok_bucket = ok_bucket and bool(torch.allclose(first[lo:hi], mono[lo:hi], rtol=1e-6, atol=1e-6))     # bucket 0 was final after its own call
+        ok_mean = ok_mean and ok_bucket
         task = broadcast_task(2 if rank == 0 else 0, "cpu")   # MetaLoader: rank 0's draw wins (data/loader.py:55-59)
         q.put((rank, same_params, ok_sum, ok_mean, gscale, task, float(mine.abs().sum())))
     finally:

@@ -463,8 +463,20 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         return res
 
     # ---- backward ---------------------------------------------------------------------------------------
+    def backward(self, on_bucket=None):
+        """the explicit backward in two phases (heads + cross-modal encoders | text + panorama encoders).  on_bucket(i, ctx):
+        called when gradient bucket i is final -- 0 after phase 1 (its weight-gradient GEMMs are flushed first), 1 at the end
+        (trainer.GradSync launches the data-parallel exchange of that bucket from it)."""
+        self.backward_phase1()
+        if on_bucket is not None:
+            on_bucket(0, self._ctx)
+        c = self._ctx
+        self.backward_phase2(flush_first=on_bucket is not None)
+        if on_bucket is not None:
+            on_bucket(1, c)
+
     @torch.no_grad()
-    def backward(self):
+    def backward_phase1(self):
         c = self._ctx
         assert c is not None, "backward() without a compute_loss=True forward"
         self.store.ensure_grads()
@@ -554,6 +566,15 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             n.vp_in_bwd(c.vin, plan, d_vin, c.d_pano)
         if task != "mrc":
             n.gmap_in_bwd(c.gin, plan, d_gin, c.d_pano, c.d_fused)
+
+    @torch.no_grad()
+    def backward_phase2(self, flush_first=False):
+        """text / panorama encoders + embeddings.  flush_first: launch the weight-gradient GEMMs queued by phase 1 now, so every
+        gradient of the heads and the cross-modal encoders is final before this phase starts (bucket 0 of the exchange)"""
+        c = self._ctx
+        n, plan = self.net, c.plan
+        if flush_first:
+            O.flush_dw(keep_active=True)
         self._par(lambda: n.text_bwd(c.txt, plan, c.d_txt, c.dP_txt),
                   lambda: n.pano_bwd(c.pano, plan, c.d_pano, c.d_fused, c.dP_pano))
         O.flush_dw()                           # deferred weight-gradient GEMMs, ~8 problems per launch

@@ -60,6 +60,7 @@ class ParamStore:
         self.device, self.compute_dtype = torch.device(device), compute_dtype
         self.specs = list(specs)
         order = [s for s in self.specs if not is_no_decay(s[0])] + [s for s in self.specs if is_no_decay(s[0])]
+        self.order = order
         self.offsets, off = {}, 0
         self.n_decay = None
         for name, shape, _ in order:
@@ -121,6 +122,14 @@ class ParamStore:
     def g_span(self, first, n):
         off = self.offsets[first][0]
         return self.grad[off:off + n]
+
+    def first_offset(self, prefixes, decay):
+        """offset of the first tensor (in storage order, within the weight-decay or the no-decay group) whose name starts with one
+        of `prefixes`; the group's end if none does"""
+        for name, _, _ in self.order:
+            if is_no_decay(name) != decay and name.startswith(tuple(prefixes)):
+                return self.offsets[name][0]
+        return self.n_decay if decay else self.total
 
     def contiguous(self, names):
         """True if the tensors are laid out back to back (no alignment gap)."""

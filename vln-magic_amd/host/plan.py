@@ -87,6 +87,9 @@ def build_plan_host(batch, task, ld_round=8):
     Np = int(sum(step_lens))
     cpu = {}
     cpu["txt_ids"] = batch["txt_ids"].reshape(-1).to(torch.int32)
+    # rows of the word-embedding table this batch reads (pad id included: padded positions are embedded too) -- on steps whose only
+    # use of the table is this lookup they are the only rows with gradient: trainer.GradSync exchanges them instead of the dense table
+    cpu["emb_rows"] = torch.unique(batch["txt_ids"]).to(torch.int64)
     txt_lens = batch["txt_lens"]
     cpu["txt_mask"] = (torch.arange(L)[None] < txt_lens[:, None]).to(torch.uint8)
     view_lens = batch["traj_vp_view_lens"]

@@ -74,31 +74,111 @@ class FusedAdamW:
         return lr
 
 
-class GradSync:
-    """Data-parallel gradient exchange: the flat fp32 gradient buffer is summed across ranks with RCCL in a few
-    large chunks on a side stream (the 1/world scaling is folded into the AdamW kernel).  Replaces
-    DDP(model, find_unused_parameters=True) of pretrain_src/utils/misc.py:62-63: every rank runs the same
-    task each step (data/loader.py:55-59), so unused parameters simply contribute zeros."""
+# parameters whose gradients are final once the cross-modal half of the backward pass is over (heads, both co-attention encoders,
+# their input embeddings, the distillation projections): everything from `global_encoder` on in storage order (engine.trunk_specs)
+LATE_PREFIXES = ("bert.global_encoder.", "vln_bert.global_encoder.")
+EMB_TABLE = "bert.embeddings.word_embeddings.weight"
 
-    def __init__(self, store, chunk_elems=8 << 20):
+
+class GradSync:
+    """Data-parallel gradient exchange on the flat fp32 gradient buffer, RCCL through torch.distributed, on a side stream; the
+    1/world scaling is folded into the AdamW kernel.  Replaces DDP(model, find_unused_parameters=True) of
+    pretrain_src/utils/misc.py:62-63: every rank runs the same task each step (data/loader.py:55-59), so task-unused
+    parameters simply contribute zeros.
+
+    Buckets follow the ORDER IN WHICH THE EXPLICIT BACKWARD FINISHES GRADIENTS (what DDP's reverse-registration buckets
+    approximate): bucket 0 = heads + both cross-modal encoders + distillation projections, final when the backward enters the
+    text / panorama encoders; bucket 1 = text + panorama encoders + embeddings, final at the end.  `reduce_bucket(0)` is issued
+    from inside the backward (model.backward(on_bucket=...)) and runs on the side stream under the rest of the backward pass.
+    On steps that only read the word-embedding table through the instruction tokens (sap / cfp / mrc: <= B*L of its 50 265 rows
+    carry gradient, 65 % of all gradient bytes otherwise) bucket 1 exchanges those ROWS (all-gather of row ids + rows, local
+    scatter-add) instead of the dense table."""
+
+    def __init__(self, store, chunk_elems=8 << 20, overlap=None, sparse_rows_cap=None):
         self.store = store
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.chunk = chunk_elems
         self.stream = torch.cuda.Stream() if (self.world > 1 and store.device.type == "cuda") else None
+        self.overlap = (not os.environ.get("MAGIC_DDP_NO_OVERLAP")) if overlap is None else overlap
+        g0d, g0n = store.first_offset(LATE_PREFIXES, True), store.first_offset(LATE_PREFIXES, False)
+        nd, tot = store.n_decay, store.total
+        self.buckets = [[(g0d, nd), (g0n, tot)], [(0, g0d), (nd, g0n)]]
+        self.table = store.offsets.get(EMB_TABLE)            # (offset, numel, (rows, H)) -- first tensor of the buffer
+        self.sparse_cap = sparse_rows_cap
+        self._pending = []
 
-    def all_reduce(self):
-        if self.world == 1:
-            return 1.0
+    # ---- primitives ------------------------------------------------------------------------------------------
+    def _ranges(self, ranges):
         g = self.store.grad
+        for lo, hi in ranges:
+            for a in range(lo, hi, self.chunk):
+                dist.all_reduce(g[a:min(hi, a + self.chunk)])
+
+    def _on_side(self, fn):
+        """run fn on the exchange stream after everything queued on the current stream so far"""
         if self.stream is None:
-            dist.all_reduce(g)
-            return 1.0 / self.world
+            fn()
+            return
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
-            for lo in range(0, g.numel(), self.chunk):
-                dist.all_reduce(g[lo:lo + self.chunk])
-        torch.cuda.current_stream().wait_stream(self.stream)
+            fn()
+
+    def join(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+    def _sparse_rows(self, row_ids):
+        """sum over ranks of the gradient rows `row_ids` (this rank's touched rows, int64 on the device, any order, duplicates
+        allowed but not needed) of the word-embedding table: all-gather ids + rows, add the other ranks' rows locally"""
+        off, n, (R, H) = self.table
+        tab = self.store.grad[off:off + n].view(R, H)
+        cap = self.sparse_cap
+        ids = torch.zeros(cap, dtype=torch.int64, device=tab.device)
+        k = min(int(row_ids.numel()), cap)
+        if row_ids.numel() > cap:
+            raise ValueError(f"sparse embedding exchange: {row_ids.numel()} touched rows > cap {cap}")
+        ids[:k] = row_ids[:k]
+        rows = tab.index_select(0, ids)
+        rows[k:] = 0                                              # padding slots point at row 0 and carry zeros
+        all_ids = torch.empty(self.world * cap, dtype=torch.int64, device=tab.device)
+        all_rows = torch.empty(self.world * cap, H, dtype=tab.dtype, device=tab.device)
+        dist.all_gather_into_tensor(all_ids, ids)
+        dist.all_gather_into_tensor(all_rows, rows)
+        r = dist.get_rank()
+        all_rows[r * cap:(r + 1) * cap] = 0                       # own rows are in the table already
+        tab.index_add_(0, all_ids, all_rows)
+
+    # ---- per-bucket API (called from inside the backward) ----------------------------------------------------------
+    def reduce_bucket(self, i, touched_rows=None):
+        """launch bucket i's exchange on the side stream.  touched_rows (bucket 1 only): device int64 ids of the word-embedding
+        rows this rank's step wrote, or None for a dense table (mlm: the tied decoder touches every row)."""
+        if self.world == 1:
+            return
+        ranges = self.buckets[i]
+        sparse = i == 1 and touched_rows is not None and self.table is not None and self.sparse_cap
+        if sparse:
+            off, n, _ = self.table
+            assert off == 0 and ranges[0][0] == 0
+            ranges = [(n, ranges[0][1])] + ranges[1:]
+
+        def run():
+            self._ranges(ranges)
+            if sparse:
+                self._sparse_rows(touched_rows)
+        self._on_side(run)
+
+    def all_reduce(self):
+        """monolithic form: the whole flat buffer after the backward pass; returns the 1/world factor for the optimizer"""
+        if self.world == 1:
+            return 1.0
+        self._on_side(lambda: self._ranges([(0, self.store.total)]))
+        self.join()
         return 1.0 / self.world
+
+    def finish(self):
+        """after the last reduce_bucket: make the main stream wait for the exchange; returns the 1/world factor"""
+        self.join()
+        return 1.0 / self.world if self.world > 1 else 1.0
 
 
 def auto_sync(model):
@@ -153,10 +233,14 @@ class CapturedStep:
 
 class PretrainStep:
     def __init__(self, student, teacher=None, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0,
-                 warmup_steps=10000, num_train_steps=200000, rw_temp=4.0, seed=0, overlap_teacher=True, overlap_dw=True):
+                 warmup_steps=10000, num_train_steps=200000, rw_temp=4.0, seed=0, overlap_teacher=True, overlap_dw=True,
+                 sparse_embedding_rows=None):
+        """sparse_embedding_rows: an upper bound, THE SAME ON EVERY RANK, on the distinct token ids of one rank's batch (batch size x
+        the loader's instruction truncation length, pretrain_src/config/r2r_magic_pretrain.json:7 max_txt_len).  When given, steps
+        that touch the word-embedding table only through the instruction lookup exchange rows instead of the dense table."""
         self.student, self.teacher = student, teacher
         self.opt = FusedAdamW(student.store, lr, betas, 1e-6, weight_decay, grad_norm, schedule=(warmup_steps, num_train_steps))
-        self.sync = GradSync(student.store)
+        self.sync = GradSync(student.store, sparse_rows_cap=sparse_embedding_rows)
         self.rw_temp = rw_temp
         self.dev = student.store.device
         self.on_gpu = self.dev.type == "cuda"
@@ -176,6 +260,20 @@ class PretrainStep:
         """MKRW ability weights softmax(randn(5)/rw_temp)*5 (map_nav_src/r2r/agent.py:866-871), drawn ON the device
         (graph-safe generator) so a replayed graph sees fresh weights every step."""
         return torch.softmax(torch.randn(5, device=self.dev, dtype=torch.float32) / self.rw_temp, dim=-1) * 5
+
+    # ---- gradient exchange from inside the backward ---------------------------------------------------------------------
+    def _touched_rows(self, task, plan):
+        """device ids of the word-embedding rows with gradient, or None when the table's gradient is dense (mlm: tied decoder)"""
+        if task == "mlm" or self.sync.sparse_cap is None:
+            return None
+        return plan.get("emb_rows")
+
+    def _bucket_hook(self, task, plan):
+        """on_bucket callback for model.backward(): launches each bucket's exchange on the side stream as soon as the explicit
+        backward has finished that bucket's gradients (bucket 0 runs under the text / panorama backward)"""
+        if self.sync.world == 1 or not self.sync.overlap:
+            return None
+        return lambda i, ctx: self.sync.reduce_bucket(i, self._touched_rows(task, plan) if i == 1 else None)
 
     # ---- the pieces ------------------------------------------------------------------------------------
     def _fwd_bwd(self, batch, task, rw, plan):
@@ -199,7 +297,9 @@ class PretrainStep:
             rw = self.mkrw()
         st.store.zero_grad()
         out = st(batch, task, compute_loss=True, teacher_outputs=t_out, rw=rw, plan=plan, inputs=inputs)
-        st.backward()
+        hook = self._bucket_hook(task, plan) if not torch.cuda.is_current_stream_capturing() else None
+        st.backward(on_bucket=hook)
+        self._exchanged = hook is not None
         return out
 
     # ---- teacher one batch ahead ---------------------------------------------------------------------------
@@ -226,7 +326,9 @@ class PretrainStep:
             rw = self.mkrw()
         st.store.zero_grad()
         out = st(batch, task, compute_loss=True, teacher_outputs=t_cur, rw=rw, plan=plan, inputs=t_cur["inputs"])
-        st.backward()
+        hook = self._bucket_hook(task, plan) if not torch.cuda.is_current_stream_capturing() else None
+        st.backward(on_bucket=hook)
+        self._exchanged = hook is not None
         main.wait_stream(self.side)
         return out, t_next
 
@@ -263,7 +365,9 @@ class PretrainStep:
         (side stream), replayed concurrently by `replay_split` without a per-step fork/join inside one graph."""
         full = self.sync.world == 1 and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")
         batch, task, plan = cur
+        two = (not full) and self.sync.overlap and not os.environ.get("MAGIC_DDP_ONE_GRAPH")
         gS = torch.cuda.CUDAGraph()
+        gS2 = None
         with self._graph_ctx(gS):
             if rw is None:
                 rw_ = self.mkrw()
@@ -271,9 +375,20 @@ class PretrainStep:
                 rw_ = rw
             self.student.store.zero_grad()
             out = self.student(batch, task, compute_loss=True, teacher_outputs=t_cur, rw=rw_, plan=plan, inputs=t_cur["inputs"])
-            self.student.backward()
+            if two:
+                # data parallel: the student's step is TWO graphs cut where gradient bucket 0 (heads + cross-modal encoders) is
+                # final, so its exchange -- issued eagerly between the two replays, on the exchange stream -- runs under the second
+                # graph (text / panorama backward).  RCCL calls stay outside the captured graphs.
+                self.student.backward_phase1()
+                O.flush_dw(keep_active=True)
+            else:
+                self.student.backward()
             if full:
                 self._optimize()
+        if two:
+            gS2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gS2, pool=gS.pool(), capture_error_mode="relaxed"):
+                self.student.backward_phase2()
         gT = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gT, stream=self.side, capture_error_mode="relaxed"):
             t_next = self.teacher_forward(*nxt)
@@ -282,6 +397,7 @@ class PretrainStep:
                 t_next = t_next_into
         cs = CapturedStep(gS, out, plan["traj_steps"], full, keep=(cur, t_cur, nxt, rw))
         cs.t_graph, cs.t_next = gT, t_next
+        cs.graph2, cs.touched = gS2, self._touched_rows(task, plan)
         return cs
 
     def replay_split(self, cs):
@@ -292,6 +408,11 @@ class PretrainStep:
             main.wait_event(self._t_done)
         self.side.wait_stream(main)
         cs.graph.replay()
+        if getattr(cs, "graph2", None) is not None:
+            self.sync.reduce_bucket(0)                 # exchange stream: after graph 1, under graph 2
+            cs.graph2.replay()
+            self.sync.reduce_bucket(1, cs.touched)
+            self._exchanged = True
         with torch.cuda.stream(self.side):
             cs.t_graph.replay()
             self._t_done = torch.cuda.Event()
@@ -302,7 +423,11 @@ class PretrainStep:
         return cs.out
 
     def _optimize(self):
-        gscale = self.sync.all_reduce()
+        if getattr(self, "_exchanged", False):       # the buckets went out from inside the backward: only wait for them
+            gscale = self.sync.finish()
+            self._exchanged = False
+        else:
+            gscale = self.sync.all_reduce()
         self.opt.step(gscale=gscale)
 
     def step(self, batch, task, rw=None, plan=None):

@@ -248,7 +248,7 @@ def instrumented_pass(trainer, pool, nprof, gate_ms):
     graphs (paired launches), the teacher's forward SERIALISED on the main stream (no overlap: summed kernel time == stream time),
     and a device-side gate in front of every step so the host runs ahead of the GPU.  Returns {family: (ms, launches)}."""
     import magic_amd.host.model_pretrain as MP
-    O.FLOPS.update(total=0.0, gemm=0.0, linear_ln=0.0, attn=0.0, enabled=True)
+    O.FLOPS.update(total=0.0, gemm=0.0, linear_ln=0.0, attn=0.0, enc=0.0, enabled=True)
     L.PROFILE.update(on=True, events=[])
     MP.LOCKSTEP_EAGER = True
     side, trainer.side = trainer.side, None
@@ -435,7 +435,7 @@ def main():
         gemm_n = sum(c for k, (t, c) in by.items() if fam(k))
         all_ms = sum(t for t, c in by.values())
         flops = O.FLOPS["gemm"]            # the GEMM family's own algorithmic FLOPs (fused linear+LN and attention kernels count separately)
-        is_mfma = lambda k: any(x in k for x in ("magic_gemm", "magic_linear_ln", "magic_attn_", "magic_rowblock"))
+        is_mfma = lambda k: any(x in k for x in ("magic_gemm", "magic_linear_ln", "magic_attn_", "magic_rowblock", "magic_encoder"))
         mfma_ms = sum(t for k, (t, c) in by.items() if is_mfma(k))
         step_ms = dt / a.steps * 1e3
         # achieved = the family's algorithmic FLOPs / the family's SUMMED launch durations (non-overlapped pass), i.e.
@@ -454,15 +454,17 @@ def main():
                            "gemm_ms_per_step": round(gemm_ms / nprof, 3), "avg_gemm_launch_us": round(gemm_ms / max(gemm_n, 1) * 1e3, 2),
                            "gemm_share_of_kernel_time": round(gemm_ms / all_ms, 4),
                            "all_dense_contraction_kernels": {
-                               "kernels": "gemm + fused linear+LayerNorm (fwd / bwd) + fused attention (fwd / bwd)",
+                               "kernels": "gemm + fused linear+LayerNorm (fwd / bwd) + fused attention (fwd / bwd) + whole-encoder forward",
                                "algorithmic_gflop_per_step": round(O.FLOPS["total"] / nprof / 1e9, 2),
-                               "gflop_by_family": {k: round(O.FLOPS[k] / nprof / 1e9, 2) for k in ("gemm", "linear_ln", "attn")},
+                               "gflop_by_family": {k: round(O.FLOPS[k] / nprof / 1e9, 2) for k in ("gemm", "linear_ln", "attn", "enc")},
                                "ms_per_step": round(mfma_ms / nprof, 3), "share_of_kernel_time": round(mfma_ms / all_ms, 4),
                                "achieved_tflops": round(ach_all, 2), "frac": round(ach_all / PEAK_BF16_TFLOPS, 5)},
                            "whole_step": {"summed_kernel_ms_per_step_serialised": round(all_ms / nprof, 3), "graph_replay_wall_ms_per_step": round(step_ms, 3),
                                           "frac_of_mfma_peak_on_wall": round(O.FLOPS["total"] / nprof / (step_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 5)},
                            "launches_per_step": sum(c for t, c in by.values()) // nprof,
-                           "top_kernels_share": {k: round(t / all_ms, 4) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]}}}
+                           "top_kernels_share": {k: round(t / all_ms, 4) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]},
+                           "kernels_launches_per_step_and_avg_us": {k: [round(c / nprof, 1), round(t / c * 1e3, 1)]
+                                                                    for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])}}}
 
     if roof is not None and rank == 0:
         roof["detail"]["feature_ingest"] = ingest_rate(dev)

@@ -216,6 +216,25 @@ int magic_rowblock_lds_bytes(int dtype, int wn, int ww);
 int magic_rowblock_fwd(int dtype, int M, const void* X, int ldx, int K0, int nstage, const magic_rb_stage* stages,
                        const void* drop_seed, float drop_p, void* stream);
 
+/* Whole self-attention encoders in one launch (csrc/encoder.hip): the 6-block text encoder and the 2-block panorama encoder of
+ * MAGIC-S (the withheld model's `bert.lang_encoder` / `img_embeddings.pano_encoder`; HF BertLayer x n), one
+ * 512-thread workgroup per sample for all layers, activations resident in LDS, weights streamed from L2 as MFMA B-fragments.
+ * bf16, H = 128, 2 heads, FFN 512, <= 80 tokens per sample, <= 6 layers per encoder, 1 or 2 encoders ("segments") per launch.
+ * Writes exactly what the per-op backward kernels read: qkv [M,3H], P (+ Pd under dropout) [B,2,N,ldp], ctx, a = attention-block
+ * output + rstd_a, z = FFN pre-activation, g = GELU output, out + rstd_o; same rounding points and dropout masks as
+ * magic_gemm / magic_attn_fwd / magic_linear_ln.  `params`: host copy of magic_enc_params, fully consumed before return. */
+typedef struct {
+  const void* Wqkv; const float* bqkv; const void* Wo; const float* bo; const float* g1; const float* be1;
+  const void* W1; const float* bi; const void* W2; const float* bo2; const float* g2; const float* be2;
+  void *qkv, *P, *Pd, *ctx, *a, *z, *g, *out; float *rstd_a, *rstd_o;
+  unsigned site_attn, site_ao, site_out, pad_;
+} magic_enc_layer;
+typedef struct { const void* x; const unsigned char* kmask; int nsamp, N, ldp, nlayers; magic_enc_layer L[6]; } magic_enc_seg;
+typedef struct { magic_enc_seg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; } magic_enc_params;
+int magic_encoder_supported(int dtype, int H, int I, int nh, int N, int nlayers);
+int magic_encoder_params_bytes(void);
+int magic_encoder_fwd(const void* params, int nbytes, void* stream);
+
 /* Grouping: between magic_group_begin() and magic_group_end(stream) up to eight calls of magic_gemm / magic_attn_fwd /
  * magic_attn_bwd / magic_linear_ln / magic_linear_lnbwd / magic_ln_bwd / magic_rowblock_fwd are recorded instead of launched; magic_group_end launches ONE kernel serving
  * the problems of the same kind / dtype / variant: GEMMs as one grouped launch (<= 8 problems), other kinds as pairs.

@@ -1,0 +1,114 @@
+"""Whole-encoder launch (csrc/encoder.hip) against the per-op kernels it replaces (-m gpu): same inputs, same weights, same dropout
+seed -> every tensor the backward reads (qkv, probabilities clean and dropped, context, both LayerNorm outputs + rstd, FFN
+pre-activation, GELU output) must agree to bf16 rounding (the two paths share rounding points and dropout masks; only fp32
+summation order differs), and a whole training step must give the same loss and gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import magic_amd  # noqa: F401
+from magic_amd.host import ops as O
+from magic_amd.host import synth
+from magic_amd.host.config import make_config
+from magic_amd.host.model_pretrain import GlocalTextPathCMTPreTraining
+from magic_amd.host.plan import build_plan
+from tests.test_model_gpu import KDL
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def student(p_drop=0.0, **kw):
+    cfg = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL, hidden_dropout_prob=p_drop, attention_probs_dropout_prob=p_drop, **kw)
+    m = GlocalTextPathCMTPreTraining(cfg, device=DEV, compute_dtype=torch.bfloat16, seed=3)
+    with torch.no_grad():          # non-trivial biases / LayerNorm parameters
+        g = torch.Generator().manual_seed(1)
+        for n, p in m.named_parameters():
+            if n.endswith("bias") and p.dim() == 1:
+                p.copy_((torch.randn(p.shape, generator=g) * 0.05).to(DEV))
+            if "LayerNorm.weight" in n:
+                p.add_((torch.randn(p.shape, generator=g) * 0.1).to(DEV))
+    m.store.shadow_clean = False
+    return m
+
+
+def ulp_close(a, b, name, ulps=2.0, floor=2e-3, frac_ok=1e-2):
+    """the two paths round at the same points, so almost every element agrees to 1-2 bf16 ulps; a one-ulp flip early on moves a few
+    elements of the deeper layers a little further (both results are equally far from the exact value)"""
+    a, b = a.float(), b.float()
+    tol = ulps * 2.0 ** -8 * b.abs().clamp_min(floor)
+    bad = ((a - b).abs() > tol)
+    frac = bad.float().mean().item()
+    worst = ((a - b).abs() / b.abs().clamp_min(0.05)).max().item()
+    rel_l2 = ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+    # the first layers agree to 1-2 ulps almost everywhere; six layers down the one-ulp flips have spread, so the bound there is on the
+    # error NORM (a bf16 rounding alone is ~2e-3 relative) and on the worst element
+    assert (frac < frac_ok or rel_l2 < 6e-3) and worst < 0.1, \
+        f"{name}: {frac:.4%} of elements off by more than {ulps} bf16 ulps, rel L2 {rel_l2:.2e} (max |d| {(a - b).abs().max().item():.3e}, worst rel {worst:.3f})"
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("max_len", [80, 41, 19])
+def test_fused_encoders_save_what_the_unfused_kernels_save(p_drop, max_len):
+    m = student(p_drop)
+    m.train()
+    batch = synth.make_batch("sap", batch_size=7, seed=5, step=0, max_len=max_len, min_len=min(12, max_len), dup_view_prob=0.3)
+    plan = build_plan(batch, "sap", torch.device(DEV))
+    inp = m._inputs(batch, plan)
+    m.store.sync_shadow()
+    seed = torch.tensor([12345, 678], dtype=torch.int32, device=DEV)
+    res = {}
+    for fused in (False, True):
+        O.FUSED_ENC = fused
+        try:
+            m.net.set_dropout(seed if p_drop > 0 else None, p_drop, p_drop)
+            assert m.net.enc_ok(plan["L"], 6) == fused
+            ct = m.net.text_fwd(plan)
+            cp = m.net.pano_fwd(plan, inp.feats, inp.loc)
+            torch.cuda.synchronize()
+            res[fused] = (ct, cp)
+        finally:
+            O.FUSED_ENC = True
+    for name, (a, b) in (("text", (res[True][0], res[False][0])), ("pano", (res[True][1], res[False][1]))):
+        assert len(a.layers) == len(b.layers)
+        for i, (la, lb) in enumerate(zip(a.layers, b.layers)):
+            for k in ("qkv", "Ppre", "P", "ctx", "a"):
+                ulp_close(getattr(la.sa, k), getattr(lb.sa, k), f"{name} layer {i} sa.{k}")
+            for k in ("z", "g", "out"):
+                ulp_close(getattr(la.ffn, k), getattr(lb.ffn, k), f"{name} layer {i} ffn.{k}")
+            for k, (x, y) in (("rstd_a", (la.sa.rstd_a, lb.sa.rstd_a)), ("rstd", (la.ffn.rstd, lb.ffn.rstd))):
+                assert torch.allclose(x, y, rtol=2e-2, atol=1e-3), f"{name} layer {i} {k}"
+            if p_drop > 0:          # identical dropout masks: the dropped probabilities are zero at exactly the same places
+                za, zb = (la.sa.P.float() == 0), (lb.sa.P.float() == 0)
+                assert (za != zb).float().mean().item() < 1e-4, f"{name} layer {i}: attention dropout masks differ"
+        ulp_close(a.out, b.out, f"{name} encoder output")
+    ulp_close(res[True][1].fused, res[False][1].fused, "pano fused embedding", ulps=3.0)
+    ulp_close(res[True][1].img_attn, res[False][1].img_attn, "img_attns", ulps=3.0)
+
+
+@pytest.mark.parametrize("task", ["sap", "mlm", "cfp"])
+def test_training_step_with_fused_encoders_matches_unfused(task):
+    from tests.test_fullsize_gpu import models, step
+    batch = synth.make_batch(task, batch_size=16, seed=31, step=0)
+    plan = build_plan(batch, task, torch.device(DEV))
+    res = {}
+    for fused in (False, True):
+        O.FUSED_ENC = fused
+        try:
+            t, s = models(torch.bfloat16)
+            out = step(t, s, batch, task, plan)
+            res[fused] = (float(out["loss"].detach()), float(out["kdl_loss"].detach()), s.store.grad.clone())
+        finally:
+            O.FUSED_ENC = True
+    (l1, k1, g1), (l0, k0, g0) = res[True], res[False]
+    assert abs(l1 - l0) <= 2e-3 * abs(l0) and abs(k1 - k0) <= 3e-3 * abs(k0), (l1, l0, k1, k0)
+    assert F.cosine_similarity(g1, g0, dim=0).item() > 0.9995
+
+
+def test_unsupported_shapes_fall_back():
+    m = student()
+    assert not m.net.enc_ok(81, 6) and not m.net.enc_ok(80, 7) and m.net.enc_ok(80, 6) and m.net.enc_ok(37, 2)
+    big = GlocalTextPathCMTPreTraining(make_config(256, role="teacher"), device=DEV, compute_dtype=torch.bfloat16)
+    assert not big.net.enc_ok(36, 2)
+    f32 = GlocalTextPathCMTPreTraining(make_config(128, role="student"), device=DEV, compute_dtype=torch.float32)
+    assert not f32.net.enc_ok(36, 2)

@@ -47,16 +47,8 @@ __device__ __forceinline__ float fragOC(const float* s, int stride, int out0, in
 __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-__device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float group16_max(float v) { return row16_max(v); }
+__device__ __forceinline__ float group16_sum(float v) { return row16_sum(v); }
 
 // cooperative load of `rows` x 64 elements (row r of the source at src + r*ld) into an LDS image [rows_pad][DS]; rows >= nvalid -> 0
 template <typename T>

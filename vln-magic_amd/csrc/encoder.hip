@@ -1,0 +1,531 @@
+// Whole self-attention encoders in ONE launch (gfx950, bf16, H = 128): the text encoder (6 post-LN BERT blocks over <= 80 tokens)
+// and the panorama encoder (2 blocks over 36-38 view tokens) of MAGIC-S.
+//
+// One 512-thread workgroup owns ONE sample for ALL layers of its encoder: the sample's activations (<= 80 x 128 bf16 = 20 KB) never
+// leave the CU between the QKV projection, the 2-head attention, the output projection + add&norm and the FFN + add&norm, nor
+// between layers.  Weights are not staged through LDS at all: in y = x W^T every weight element is used exactly once per workgroup
+// (all <= 80 rows multiply it at once), so each lane loads its MFMA B-fragment (8 consecutive k of one weight row = 16 bytes)
+// straight from L2 into registers, a whole stage's fragments ahead of their use.  The workgroup writes exactly the tensors the
+// engine's backward kernels read (qkv, P [+ dropped P], ctx, attention-output LN result + rstd, FFN pre-activation, GELU output,
+// block output + rstd), with the same rounding points and the same counter-based dropout masks as the per-op kernels
+// (gemm.hip / attention.hip / linear_ln), so the unfused backward runs unchanged on what this kernel saved.
+//
+// Replaces 5 launches per block (QKV GEMM, fused attention, dense+LN, FFN1 GEMM, dense+LN) x (6 | 2) blocks by one launch for both
+// encoders: the text workgroups (long pole: 6 layers) come first in the grid, the panorama workgroups fill the remaining CUs.
+// LDS per workgroup ~145 KB (one workgroup per CU); MFMA v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 LayerNorm / softmax.
+#include "common.hpp"
+#include <cstdlib>
+#include <cstring>
+
+#define EH 128
+#define EI 512
+#define ENH 2
+#define EHD 64
+#define XS 136        // row pitch (elements) of the [rows][128] LDS images: 272 B = 17 16-byte slots, rows land on distinct slots
+#define QS 392        // [rows][384] Q|K|V image
+#define GS 520        // [rows][512] GELU output image
+#define PSW 104       // per-wave probability tile [16][<= 96 keys]
+#define MAXROWS 80
+#define KROWS 96      // key rows the Q|K|V image provides for (PV consumes keys in steps of 32)
+#define NWAVE 8
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_e;
+// the GEMM stages are fully unrolled (their weight fragments are register arrays with static indices); without a fence per k-step the
+// scheduler hoists every LDS fragment read of a stage to its top and spills hundreds of registers
+#define KSTEP_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+struct EncLayer {
+  const bf16* Wqkv; const float* bqkv;                                   // [3H, H] (q | k | v rows), [3H]
+  const bf16* Wo; const float* bo; const float* g1; const float* be1;    // attention.output.dense / LayerNorm
+  const bf16* W1; const float* bi;                                       // intermediate.dense [I, H]
+  const bf16* W2; const float* bo2; const float* g2; const float* be2;   // output.dense [H, I] / LayerNorm
+  bf16 *qkv, *P, *Pd, *ctx, *a, *z, *g, *out;                            // saved for the backward ([M,3H], [B,nh,N,ldp] x2, [M,H], [M,H], [M,I], [M,I], [M,H])
+  float *rstd_a, *rstd_o;
+  unsigned site_attn, site_ao, site_out, pad_;
+};
+struct EncSeg { const bf16* x; const unsigned char* kmask; int nsamp, N, ldp, nlayers; EncLayer L[6]; };
+struct EncParams { EncSeg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; };
+
+__device__ __forceinline__ f32x4 emma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// MFMA operand fragment (A or B) of 16 rows x 32 k from a k-contiguous image: lane l holds X[row0 + (l&15)][k0 + 8*(l>>4) .. +7]
+__device__ __forceinline__ bf16x8 lfrag(const bf16* s, int pitch, int row0, int k0, int lane) {
+  return *(const bf16x8*)(s + (row0 + (lane & 15)) * pitch + k0 + 8 * (lane >> 4));
+}
+__device__ __forceinline__ bf16x8 gfrag(const bf16* __restrict__ W, int ldw, int row0, int k0, int lane) {
+  return *(const bf16x8*)(W + (long long)(row0 + (lane & 15)) * ldw + k0 + 8 * (lane >> 4));
+}
+// B fragment from a [k][n] image (V: keys x head dims), transposed on the way out of LDS
+__device__ __forceinline__ bf16x8 tfrag(const bf16* s, int pitch, int n0, int k0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const bf16* b = s + (k0 + 8 * g + q) * pitch + n0 + 4 * pp;
+  typedef bf16x4_e __attribute__((address_space(3))) * lds4;
+  const bf16x4_e lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
+  const bf16x4_e hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * pitch));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// GELU on the 40 K elements a text workgroup produces per layer: libm's erff is ~40 instructions; this rational form (Abramowitz &
+// Stegun 7.1.26, |error| <= 1.5e-7) is ~15 and indistinguishable after the bf16 rounding of the result
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-ax * ax);
+  const float erfv = x < 0.f ? -erf_abs : erf_abs;
+  return 0.5f * x * (1.0f + erfv);
+}
+// LDS hand-off between the lanes of ONE wave (wave-private tile): order the wave's own LDS writes before its reads
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ float g16_sum(float v) { return row16_sum(v); }
+__device__ __forceinline__ float g16_max(float v) { return row16_max(v); }
+
+// out[row][w*16 + c16] = LayerNorm_row(acc + bias (dropped) + residual) for the workgroup's NRT*16 rows; every wave owns 16 of the
+// 128 columns, row statistics go through LDS (two passes: mean, then centred variance -- as linear_ln_kernel).
+template <int NRT>
+__device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, const float gv, const float btv, const bf16* sRes,
+                                         float* red, bf16* sOut, float* gRstd, int N, long long row_base, float eps,
+                                         const DropState& ds, int w, int lane) {
+  const int g = lane >> 4, c16 = lane & 15, col = w * 16 + c16;
+  float s[NRT][4];
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i * 16 + 4 * g + r;
+      float v = acc[i][r] + bv;
+      if (ds.on) v *= drop_mul(ds, (unsigned)((row_base + row) * EH + col));
+      v += to_f(sRes[row * XS + col]);
+      acc[i][r] = v;
+      s[i][r] = g16_sum(v);
+    }
+  if (c16 == 0) {
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w * MAXROWS + i * 16 + 4 * g + r] = s[i][r];
+  }
+  __syncthreads();
+  float mean[NRT][4];
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = i * 16 + 4 * g + r;
+      float t = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * MAXROWS + rr];
+      mean[i][r] = t * (1.0f / EH);
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d = acc[i][r] - mean[i][r];
+      s[i][r] = g16_sum(d * d);
+    }
+  if (c16 == 0) {
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w * MAXROWS + i * 16 + 4 * g + r] = s[i][r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = i * 16 + 4 * g + r;
+      float t = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * MAXROWS + rr];
+      const float rstd = rsqrtf(t * (1.0f / EH) + eps);
+      const bf16 y = from_f<bf16>((acc[i][r] - mean[i][r]) * rstd * gv + btv);
+      sOut[rr * XS + col] = (rr < N) ? y : (bf16)0.0f;        // rows past the sample stay zero (they feed the next GEMM as padding)
+      if (rr < N && w == 0 && c16 == 0) gRstd[row_base + rr] = rstd;
+    }
+}
+
+// cooperative copy of `rows` x `cols` bf16 from an LDS image to global rows (16-byte vectors)
+__device__ __forceinline__ void copy_out(const bf16* s, int pitch, bf16* g, long long ldg, int rows, int cols, int tid) {
+  const int cpr = cols / 8;
+  for (int id = tid; id < rows * cpr; id += NWAVE * 64) {
+    const int r = id / cpr, c = (id % cpr) * 8;
+    *(bf16x8*)(g + (long long)r * ldg + c) = *(const bf16x8*)(s + r * pitch + c);
+  }
+}
+
+#ifdef ENC_TIMING
+__device__ long long enc_ticks[2][16];        // [segment][stage mark] of block 0 of each segment, last layer
+#define ENC_MARK(i) do { if (samp == 0 && tid == 0) enc_ticks[&sg == &p.seg[0] ? 0 : 1][i] = wall_clock64(); } while (0)
+#else
+#define ENC_MARK(i)
+#endif
+
+template <int NRT>
+__device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, const int samp, unsigned char* smem) {
+  bf16* sX = (bf16*)smem;                        // [80][XS]   layer input / residual of the attention block
+  bf16* sA = sX + MAXROWS * XS;                  // [80][XS]   attention context, then (after the norm) the FFN's input / residual
+  bf16* sQKV = sA + MAXROWS * XS;                // [96][QS]   Q | K | V
+  bf16* sP = sQKV + KROWS * QS;                  // [8][16][PSW] per-wave probability tiles
+  bf16* sG = sQKV;                               // [80][GS]   GELU output (aliases Q|K|V and the probability tiles, dead by then)
+  float* red = (float*)(sP + NWAVE * 16 * PSW);  // [8][80]    LayerNorm partial sums
+  const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = sg.N, ldp = sg.ldp;
+  const int NKP = (N + 31) / 32 * 32;
+  const long long row_base = (long long)samp * N;
+  constexpr int ROWS = NRT * 16;
+
+  // ---- layer-0 input -> sX (rows past the sample zero)
+  {
+    const bf16* x = sg.x + row_base * EH;
+    for (int id = tid; id < ROWS * (EH / 8); id += NWAVE * 64) {
+      const int r = id / (EH / 8), c = (id % (EH / 8)) * 8;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16)0.0f;
+      if (r < N) v = *(const bf16x8*)(x + (long long)r * EH + c);
+      *(bf16x8*)(sX + r * XS + c) = v;
+    }
+  }
+  DropDesc dd;
+  dd.seed = p.seed;
+  // additive key-mask bias of this lane's key columns (layer-invariant): -10000 on padded keys, as HF's extended attention mask
+  float kbias[NRT];
+#pragma unroll
+  for (int j = 0; j < NRT; ++j) {
+    const int key = j * 16 + (lane0 & 15);
+    kbias[j] = (key < N && sg.kmask && !sg.kmask[(long long)samp * N + key]) ? -10000.0f : 0.f;
+  }
+  for (int l = 0; l < sg.nlayers; ++l) {
+    const EncLayer& L = sg.L[l];
+    // every per-lane index below derives from `lane`; laundering it per layer keeps the compiler from hoisting the layer-invariant
+    // row / column / predicate values of all five stages out of this loop (hundreds of registers, all spilled)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, c16 = lane & 15;
+    ENC_MARK(0);
+    // every small parameter this lane needs in the layer's five epilogues, fetched now: a load at its point of use would sit in
+    // the in-order memory queue behind the stage's stores and expose a full round trip per stage
+    float pb_qkv[3], pb_ffn[4];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) pb_qkv[ct] = L.bqkv[(3 * w + ct) * 16 + c16];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) pb_ffn[ct] = L.bi[(4 * w + ct) * 16 + c16];
+    const float pb_o = L.bo[w * 16 + c16], pg_1 = L.g1[w * 16 + c16], pe_1 = L.be1[w * 16 + c16];
+    const float pb_2 = L.bo2[w * 16 + c16], pg_2 = L.g2[w * 16 + c16], pe_2 = L.be2[w * 16 + c16];
+    // ================= A: Q|K|V = x Wqkv^T + b : 24 column tiles, 3 per wave =================
+    bf16x8 bw[3][4];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bw[ct][ks] = gfrag(L.Wqkv, EH, (3 * w + ct) * 16, ks * 32, lane);
+    // key rows past the computed ones must be finite zeros (PV multiplies them by zero probabilities); the GELU image of the
+    // previous layer overlapped them
+    for (int id = tid; id < (KROWS - ROWS) * (384 / 8); id += NWAVE * 64) {
+      const int r = ROWS + id / 48, c = (id % 48) * 8;
+      bf16x8 zv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) zv[e] = (bf16)0.0f;
+      *(bf16x8*)(sQKV + r * QS + c) = zv;
+    }
+    __syncthreads();                              // sX complete (layer input), zero rows in place
+    ENC_MARK(1);
+    {
+      f32x4 acc[NRT][3];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+          const bf16x8 a = lfrag(sX, XS, i * 16, ks * 32, lane);
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) acc[i][ct] = emma(a, bw[ct][ks], acc[i][ct]);
+        }
+        KSTEP_FENCE();
+      }
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) {
+        const int col = (3 * w + ct) * 16 + c16;
+        const float bv = pb_qkv[ct];
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sQKV[(i * 16 + 4 * g + r) * QS + col] = from_f<bf16>(acc[i][ct][r] + bv);
+      }
+    }
+    // prefetch the output projection's fragments (used after the attention)
+    bf16x8 wo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wo[ks] = gfrag(L.Wo, EH, w * 16, ks * 32, lane);
+    __syncthreads();                              // Q|K|V image complete
+    copy_out(sQKV, QS, L.qkv + row_base * 3 * EH, 3 * EH, N, 3 * EH, tid);
+    ENC_MARK(2);
+    // ================= B: attention, unit = (head, 16-query tile) =================
+    // first FFN matrix (16 fragments: this wave's 4 column tiles x 4 k-steps): issued ahead of the attention's stores
+    bf16x8 w1[4][4];
+#pragma unroll
+    for (int ct = 0; ct < (NRT > 4 ? 2 : 4); ++ct)      // 80-row samples: half now, half after the attention (register budget)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) w1[ct][ks] = gfrag(L.W1, EH, (4 * w + ct) * 16, ks * 32, lane);
+    dd.site = L.site_attn; dd.p = p.p_attn;
+    const DropState dsa = drop_init(dd);
+    bf16* sPw = sP + w * 16 * PSW;
+    for (int u = w; u < ENH * NRT; u += NWAVE) {
+      const int h = u / NRT, rt = u % NRT;
+      f32x4 sc[NRT];
+#pragma unroll
+      for (int j = 0; j < NRT; ++j) sc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 a = lfrag(sQKV, QS, rt * 16, h * EHD + ks * 32, lane);
+#pragma unroll
+        for (int j = 0; j < NRT; ++j) sc[j] = emma(a, lfrag(sQKV, QS, j * 16, EH + h * EHD + ks * 32, lane), sc[j]);
+      }
+      float mx[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+      for (int j = 0; j < NRT; ++j) {
+        const int key = j * 16 + c16;
+        const bool kv = key < N;
+        const float mb = kbias[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = sc[j][r] * p.scale + mb;
+          x = kv ? x : -3.0e38f;
+          sc[j][r] = x; mx[r] = fmaxf(mx[r], x);
+        }
+      }
+      float sum[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { mx[r] = g16_max(mx[r]); sum[r] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < NRT; ++j) {
+        const bool kv = (j * 16 + c16) < N;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float e = kv ? __expf(sc[j][r] - mx[r]) : 0.f; sc[j][r] = e; sum[r] += e; }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum[r] = 1.0f / g16_sum(sum[r]);
+      // clean probabilities -> the wave's tile (columns up to NKP: zeros past the sample's keys)
+#pragma unroll
+      for (int j = 0; j < NRT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sPw[(4 * g + r) * PSW + j * 16 + c16] = from_f<bf16>(sc[j][r] * sum[r]);
+      if (NRT * 16 < NKP) {
+        for (int id = lane; id < 16 * (NKP - NRT * 16); id += 64) {
+          const int r = id / (NKP - NRT * 16), c = NRT * 16 + id % (NKP - NRT * 16);
+          sPw[r * PSW + c] = (bf16)0.0f;
+        }
+      }
+      wave_lds_sync();                             // the tile is wave-private: no workgroup barrier needed
+      const int nq = min(16, N - rt * 16);
+      {
+        bf16* Pg = L.P + (((long long)samp * ENH + h) * N + rt * 16) * ldp;
+        const int cpr = ldp / 8;
+        for (int id = lane; id < nq * cpr; id += 64) {
+          const int r = id / cpr, c = (id % cpr) * 8;
+          *(bf16x8*)(Pg + (long long)r * ldp + c) = *(const bf16x8*)(sPw + r * PSW + c);
+        }
+      }
+      if (dsa.on) {
+#pragma unroll
+        for (int j = 0; j < NRT; ++j) {
+          const int key = j * 16 + c16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ql = 4 * g + r;
+            const unsigned idx = (unsigned)(((((long long)samp * ENH + h) * N + rt * 16 + ql) * N) + key);
+            const float m = (ql < nq && key < N) ? drop_mul(dsa, idx) : 0.f;
+            sPw[ql * PSW + key] = from_f<bf16>(sc[j][r] * sum[r] * m);
+          }
+        }
+        wave_lds_sync();
+        if (L.Pd) {
+          bf16* Pg = L.Pd + (((long long)samp * ENH + h) * N + rt * 16) * ldp;
+          const int cpr = ldp / 8;
+          for (int id = lane; id < nq * cpr; id += 64) {
+            const int r = id / cpr, c = (id % cpr) * 8;
+            *(bf16x8*)(Pg + (long long)r * ldp + c) = *(const bf16x8*)(sPw + r * PSW + c);
+          }
+        }
+      }
+      f32x4 o[4];
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < NKP / 32; ++ks) {
+        const bf16x8 a = lfrag(sPw, PSW, 0, ks * 32, lane);
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) o[jd] = emma(a, tfrag(sQKV + 2 * EH + h * EHD, QS, jd * 16, ks * 32, lane), o[jd]);
+      }
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sA[(rt * 16 + 4 * g + r) * XS + h * EHD + jd * 16 + c16] = from_f<bf16>(o[jd][r]);
+    }
+    ENC_MARK(3);
+    if (NRT > 4) {
+#pragma unroll
+      for (int ct = 2; ct < 4; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) w1[ct][ks] = gfrag(L.W1, EH, (4 * w + ct) * 16, ks * 32, lane);
+    }
+    __syncthreads();                              // context image complete (sA)
+    copy_out(sA, XS, L.ctx + row_base * EH, EH, N, EH, tid);
+    ENC_MARK(4);
+    // ================= C: a = LayerNorm(x + dropout(ctx Wo^T + bo)) : 8 column tiles, 1 per wave =================
+    {
+      f32x4 acc[NRT];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) acc[i] = emma(lfrag(sA, XS, i * 16, ks * 32, lane), wo[ks], acc[i]);
+        KSTEP_FENCE();
+      }
+      dd.site = L.site_ao; dd.p = p.p_hidden;
+      const DropState dsh = drop_init(dd);
+      // the first statistics barrier inside add_norm also orders "every wave has read the context image" before it is overwritten
+      add_norm<NRT>(acc, pb_o, pg_1, pe_1, sX, red, sA, L.rstd_a, N, row_base, p.eps, dsh, w, lane);
+    }
+    __syncthreads();                              // sA = attention-block output, complete
+    copy_out(sA, XS, L.a + row_base * EH, EH, N, EH, tid);
+    ENC_MARK(5);
+    // ================= D: z = a W1^T + bi ; g = gelu(z) : 32 column tiles, 4 per wave =================
+    bf16x8 w2[16];
+    {
+      f32x4 acc[NRT][4];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+          const bf16x8 a = lfrag(sA, XS, i * 16, ks * 32, lane);
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) acc[i][ct] = emma(a, w1[ct][ks], acc[i][ct]);
+        }
+        KSTEP_FENCE();
+      }
+      // second FFN matrix (this wave's 16 output columns x 512 k = 16 fragments): issued before this stage's stores
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) w2[ks] = gfrag(L.W2, EI, w * 16, ks * 32, lane);
+      // pre-activation z (kept for the backward) -> image -> global; then the GELU output g takes the image's place
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int col = (4 * w + ct) * 16 + c16;
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[i][ct][r] += pb_ffn[ct];
+            sG[(i * 16 + 4 * g + r) * GS + col] = from_f<bf16>(acc[i][ct][r]);
+          }
+      }
+      __syncthreads();
+      copy_out(sG, GS, L.z + row_base * EI, EI, N, EI, tid);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][ct][r] = gelu_fast(acc[i][ct][r]);
+      __syncthreads();                            // every thread has read its share of the z image
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int col = (4 * w + ct) * 16 + c16;
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sG[(i * 16 + 4 * g + r) * GS + col] = from_f<bf16>(acc[i][ct][r]);
+      }
+    }
+    ENC_MARK(6);
+    __syncthreads();                              // GELU image complete
+    copy_out(sG, GS, L.g + row_base * EI, EI, N, EI, tid);
+    ENC_MARK(7);
+    // ================= E: out = LayerNorm(a + dropout(g W2^T + bo2)) =================
+    {
+      f32x4 acc[NRT];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) acc[i] = emma(lfrag(sG, GS, i * 16, ks * 32, lane), w2[ks], acc[i]);
+        if ((ks & 1) == 1) KSTEP_FENCE();
+      }
+      dd.site = L.site_out; dd.p = p.p_hidden;
+      const DropState dsh = drop_init(dd);
+      add_norm<NRT>(acc, pb_2, pg_2, pe_2, sA, red, sX, L.rstd_o, N, row_base, p.eps, dsh, w, lane);
+    }
+    __syncthreads();                              // sX = block output, complete; every wave is done with the GELU image
+    copy_out(sX, XS, L.out + row_base * EH, EH, N, EH, tid);
+    ENC_MARK(8);
+  }
+}
+
+__global__ __launch_bounds__(512) void encoder_fwd_kernel(EncParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char enc_smem[];
+  int b = blockIdx.x, s = 0;
+  if (b >= p.seg[0].nsamp) { b -= p.seg[0].nsamp; s = 1; }
+  const EncSeg& sg = p.seg[s];
+  const int nrt = max(2, (sg.N + 15) / 16);
+  switch (nrt) {
+    case 2: enc_body<2>(p, sg, b, enc_smem); break;
+    case 3: enc_body<3>(p, sg, b, enc_smem); break;
+    case 4: enc_body<4>(p, sg, b, enc_smem); break;
+    default: enc_body<5>(p, sg, b, enc_smem); break;
+  }
+}
+
+static size_t enc_lds_bytes() {
+  return (size_t)(2 * MAXROWS * XS + KROWS * QS + NWAVE * 16 * PSW) * sizeof(bf16) + (size_t)NWAVE * MAXROWS * sizeof(float);
+}
+
+extern "C" int magic_encoder_supported(int dtype, int H, int I, int nh, int N, int nlayers) {
+  return dtype == DT_BF16 && H == EH && I == EI && nh == ENH && N >= 1 && N <= MAXROWS && nlayers >= 1 && nlayers <= 6;
+}
+extern "C" int magic_encoder_params_bytes() { return (int)sizeof(EncParams); }
+
+// params: a host copy of EncParams (mirrored field by field by host/lib.py); nothing is read from it after this call returns
+extern "C" int magic_encoder_fwd(const void* params, int nbytes, void* stream) {
+  if (!params || nbytes != (int)sizeof(EncParams)) return MAGIC_ERR_ARG;
+  EncParams p;
+  memcpy(&p, params, sizeof(p));
+  if (p.nseg < 1 || p.nseg > 2) return MAGIC_ERR_ARG;
+  if (!drop_args_ok(p.seed, p.p_attn) || !drop_args_ok(p.seed, p.p_hidden)) return MAGIC_ERR_ARG;
+  int blocks = 0;
+  for (int s = 0; s < 2; ++s) {
+    EncSeg& sg = p.seg[s];
+    if (s >= p.nseg) { sg.nsamp = 0; continue; }
+    if (sg.nsamp <= 0 || sg.N < 1 || sg.N > MAXROWS || sg.nlayers < 1 || sg.nlayers > 6 || !sg.x) return MAGIC_ERR_ARG;
+    if (sg.ldp < sg.N || (sg.ldp & 7) || sg.ldp > KROWS) return MAGIC_ERR_ARG;
+    if ((long long)sg.nsamp * ENH * sg.N * sg.N > 0xFFFFFFFFll || (long long)sg.nsamp * sg.N * EI > 0x7FFFFFFFll) return MAGIC_ERR_ARG;
+    if ((uintptr_t)sg.x & 15) return MAGIC_ERR_ARG;
+    for (int l = 0; l < sg.nlayers; ++l) {
+      const EncLayer& L = sg.L[l];
+      const void* req[] = {L.Wqkv, L.bqkv, L.Wo, L.bo, L.g1, L.be1, L.W1, L.bi, L.W2, L.bo2, L.g2, L.be2, L.qkv, L.P, L.ctx, L.a, L.z, L.g, L.out, L.rstd_a, L.rstd_o};
+      for (const void* q : req)
+        if (!q) return MAGIC_ERR_ARG;
+      const void* al[] = {L.Wqkv, L.Wo, L.W1, L.W2, L.qkv, L.P, L.Pd, L.ctx, L.a, L.g, L.out};
+      for (const void* q : al)
+        if ((uintptr_t)q & 15) return MAGIC_ERR_ARG;
+      if (p.p_attn > 0.f && !L.Pd) return MAGIC_ERR_ARG;
+    }
+    blocks += sg.nsamp;
+  }
+  const size_t shm = enc_lds_bytes();
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)encoder_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_set = true; }
+  hipLaunchKernelGGL(encoder_fwd_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+  return launch_status();
+}

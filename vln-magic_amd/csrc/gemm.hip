@@ -967,8 +967,7 @@ __device__ __forceinline__ void linear_ln_body(const LlnParams& pp, const int bi
         if (dsn.on) v *= drop_mul(dsn, (unsigned)((m0 + i * 16 + 4 * g + r) * H + w * WC + j * 16 + c16));
         acc[i][j][r] = v + rsd[i][j][r]; t += acc[i][j][r];
       }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      t = row16_sum(t);
       s[i][r] = t;
     }
   if (c16 == 0) {
@@ -994,8 +993,7 @@ __device__ __forceinline__ void linear_ln_body(const LlnParams& pp, const int bi
       float t = 0.f;
 #pragma unroll
       for (int j = 0; j < HT; ++j) { const float d = acc[i][j][r] - mean[i][r]; t += d * d; }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      t = row16_sum(t);
       s[i][r] = t;
     }
   if (c16 == 0) {
@@ -1223,8 +1221,7 @@ __device__ __forceinline__ void linear_lnb_body(const LlbParams& pp, const int b
         acc[i][j][r] = ga; xh[i][j][r] = x;
         t1 += ga; t2 += ga * x;
       }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+      t1 = row16_sum(t1); t2 = row16_sum(t2);
       s1[i][r] = t1; s2[i][r] = t2;
     }
   // gamma / beta gradients: this thread's 8 rows are summed already; fold the 4 row groups (g) and issue one atomic per column.

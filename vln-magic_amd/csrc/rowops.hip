@@ -171,10 +171,7 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
     }
     if (do_ln) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int u = 0; u < RPI; ++u) { s1[u] += __shfl_xor(s1[u], o, 64); s2[u] += __shfl_xor(s2[u], o, 64); }
-      }
+      for (int u = 0; u < RPI; ++u) { s1[u] = wave_sum(s1[u]); s2[u] = wave_sum(s2[u]); }
 #pragma unroll
       for (int u = 0; u < RPI; ++u) {
         const float m1 = s1[u] / H, m2 = s2[u] / H;

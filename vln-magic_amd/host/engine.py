@@ -446,11 +446,58 @@ class MagicNet:
             O.linear_dx(dkv, kvl.W, Mk, out=d_ctx_acc, residual=d_ctx_acc, flop_rows=c.crow)
         return self._sa_bwd(lp, c.sa, d_s, dsprel, None, fuse=fuse_in)
 
+    # ---- whole-encoder launch (csrc/encoder.hip) ------------------------------------------------------
+    def enc_ok(self, N, nlayers):
+        return O.encoder_ok(self.dtype, self.H, self.I, self.nh, N, nlayers)
+
+    def _enc_segment(self, prefix_fmt, nl, x, Bn, N, kmask, rows, aflops):
+        """allocate what the backward reads for `nl` post-LN self-attention blocks and describe them for O.encoder_fwd;
+        returns (segment dict, [per-layer Ctx in the shape self_layer_fwd builds])"""
+        H, I, nh = self.H, self.I, self.nh
+        M, ldp = Bn * N, rup(N)
+        layers, descs = [], []
+        for i in range(nl):
+            lp = prefix_fmt.format(i)
+            sa = Ctx(x=x, Bn=Bn, N=N, rows=rows, aflops=aflops, dist=None, qkv=self.new(M, 3 * H), ldp=ldp,
+                     adrop=self._da(lp + "attention.self.dropout"), hdrop=self._dh(lp + "attention.output.dropout"))
+            sa.Ppre, sa.ctx, sa.a, sa.rstd_a = self.new(Bn, nh, N, ldp), self.new(M, H), self.new(M, H), self.new(M, dtype=torch.float32)
+            sa.P = self.new(Bn, nh, N, ldp) if sa.adrop else sa.Ppre
+            ffn = Ctx(a=sa.a, M=M, rows=rows, z=self.new(M, I), g=self.new(M, I), out=self.new(M, H), rstd=self.new(M, dtype=torch.float32),
+                      hdrop=self._dh(lp + "output.dropout"))
+            ql = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
+            o, n1 = self.lin(lp + "attention.output.dense.weight"), self.ln(lp + "attention.output.LayerNorm")
+            f1, f2, n2 = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.ln(lp + "output.LayerNorm")
+            descs.append(dict(Wqkv=ql.W, bqkv=ql.b, Wo=o.W, bo=o.b, g1=n1.g, be1=n1.b, W1=f1.W, bi=f1.b, W2=f2.W, bo2=f2.b, g2=n2.g, be2=n2.b,
+                              qkv=sa.qkv, P=sa.Ppre, Pd=sa.P if sa.adrop else None, ctx=sa.ctx, a=sa.a, z=ffn.z, g=ffn.g, out=ffn.out,
+                              rstd_a=sa.rstd_a, rstd_o=ffn.rstd,
+                              site_attn=sa.adrop[2] if sa.adrop else 0, site_ao=sa.hdrop[2] if sa.hdrop else 0,
+                              site_out=ffn.hdrop[2] if ffn.hdrop else 0))
+            layers.append(Ctx(next_qkv=None, sa=sa, ffn=ffn, out=ffn.out, P=sa.P, ldp=ldp))
+            x = ffn.out
+        flops = nl * (2.0 * rows * (3 * H * H + H * H + 2 * H * I) + 4.0 * aflops)
+        return dict(x=layers[0].sa.x, kmask=kmask, nsamp=Bn, N=N, ldp=ldp, layers=descs, flops=flops), layers
+
+    def _enc_launch(self, segs):
+        d = self.drop
+        O.encoder_fwd(segs, d[0] if d else None, d[2] if d else 0.0, d[1] if d else 0.0, self.eps, 1.0 / math.sqrt(HD))
+
+    def encoders_fwd(self, ct, cp):
+        """text (ct) and panorama (cp) contexts prepared with defer=True: run both encoders in ONE launch and finish them"""
+        segs = []
+        for c in (ct, cp):
+            sg, c.layers = self._enc_segment(*c.pending)
+            segs.append(sg)
+            c.pending = None
+        self._enc_launch(segs)
+        self._text_tail(ct)
+        self._pano_tail(cp, cp.plan)
+
     # ---- text encoder --------------------------------------------------------------------------
     def _flops_attn(self, lens_q, lens_k):
         return float(sum(a * b for a, b in zip(lens_q, lens_k))) * HD * self.nh
 
-    def text_fwd(self, plan):
+    def text_fwd(self, plan, defer=False):
+        """defer: stop after the embeddings and leave the layers to `encoders_fwd` (one launch shared with the panorama encoder)"""
         p, H = self.p, self.H
         B, L = plan["B"], plan["L"]
         M = B * L
@@ -468,12 +515,23 @@ class MagicNet:
         tl = plan["lens"]["txt"]
         af = self._flops_attn(tl, tl)
         nl, qkv = self.cfg.num_l_layers, None
+        if self.enc_ok(L, nl) and not self._rb_ok():
+            c.pending = (p + "lang_encoder.layer.{}.", nl, x, B, L, plan["txt_mask"], plan["txt_tokens"], af)
+            if defer:
+                return c
+            sg, c.layers = self._enc_segment(*c.pending)
+            c.pending = None
+            self._enc_launch([sg])
+            return self._text_tail(c)
         for i in range(nl):
             lc = self.self_layer_fwd(f"{p}lang_encoder.layer.{i}.", x, B, L, plan["txt_mask"], plan["txt_tokens"], af, qkv=qkv,
                                      next_lp=f"{p}lang_encoder.layer.{i + 1}." if i + 1 < nl else None)
             c.layers.append(lc)
             x, qkv = lc.out, lc.next_qkv
-        c.out, c.P, c.ldp = x, c.layers[-1].P, c.layers[-1].ldp
+        return self._text_tail(c)
+
+    def _text_tail(self, c):
+        c.out, c.P, c.ldp = c.layers[-1].out, c.layers[-1].P, c.layers[-1].ldp
         return c
 
     def text_bwd(self, c, plan, d_out, dP_init=None):
@@ -491,8 +549,8 @@ class MagicNet:
                         (None, 0, 0, self.S.g(p + "embeddings.token_type_embeddings.weight"), 0)))
 
     # ---- panorama encoder ----------------------------------------------------------------------
-    def pano_fwd(self, plan, feats, loc):
-        """feats [Np*V, D] compute dtype; loc [Np*V, 7] fp32."""
+    def pano_fwd(self, plan, feats, loc, defer=False):
+        """feats [Np*V, D] compute dtype; loc [Np*V, 7] fp32.  defer: as text_fwd."""
         p, H = self.p + "img_embeddings.", self.H
         Np, V = plan["Np"], plan["V"]
         M = Np * V
@@ -517,12 +575,26 @@ class MagicNet:
         c.layers = []
         af = float(Np) * V * V * HD * self.nh
         nl, qkv = self.cfg.num_pano_layers, None
+        c.plan = plan
+        if self.enc_ok(V, nl) and not self._rb_ok():
+            c.pending = (p + "pano_encoder.layer.{}.", nl, x, Np, V, plan["pano_mask"], M, af)
+            if defer:
+                return c
+            sg, c.layers = self._enc_segment(*c.pending)
+            c.pending = None
+            self._enc_launch([sg])
+            return self._pano_tail(c, plan)
         for i in range(nl):
             lc = self.self_layer_fwd(f"{p}pano_encoder.layer.{i}.", x, Np, V, plan["pano_mask"], M, af, qkv=qkv,
                                      next_lp=f"{p}pano_encoder.layer.{i + 1}." if i + 1 < nl else None)
             c.layers.append(lc)
             x, qkv = lc.out, lc.next_qkv
-        c.out, c.P, c.ldp = x, c.layers[-1].P, c.layers[-1].ldp
+        return self._pano_tail(c, plan)
+
+    def _pano_tail(self, c, plan):
+        p, H = self.p + "img_embeddings.", self.H
+        Np, V = c.Np, c.V
+        c.out, c.P, c.ldp = c.layers[-1].out, c.layers[-1].P, c.layers[-1].ldp
         c.img_attn = self.new(Np, V, c.ldp, dtype=torch.float32)
         O.head_mean_fwd(c.P, c.img_attn, Np, self.nh, V * c.ldp)
         c.fused = self.new(Np, H)

@@ -61,6 +61,9 @@ SIGNATURES = {
     "magic_view_gather": [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp],
     "magic_rowblock_lds_bytes": [i32, i32, i32],
     "magic_rowblock_fwd": [i32, i32, vp, i32, i32, i32, vp, vp, f32, vp],
+    "magic_encoder_supported": [i32, i32, i32, i32, i32, i32],
+    "magic_encoder_params_bytes": [],
+    "magic_encoder_fwd": [vp, i32, vp],
     "magic_group_begin": [],
     "magic_group_end": [vp],
 }
@@ -85,6 +88,21 @@ class RbStage(C.Structure):
     _fields_ = [("kind", i32), ("N", i32), ("K", i32), ("W", vp), ("ldw", i32), ("bias", vp),
                 ("res", vp), ("ldres", i32), ("res_stage", i32), ("gamma", vp), ("beta", vp), ("eps", f32), ("rstd", vp),
                 ("drop_site", u32), ("out", vp), ("ldo", i32), ("pre", vp), ("ldpre", i32)]
+
+
+class EncLayer(C.Structure):
+    """mirror of `magic_enc_layer` (include/magic_hip.h)"""
+    _fields_ = [(n, vp) for n in ("Wqkv", "bqkv", "Wo", "bo", "g1", "be1", "W1", "bi", "W2", "bo2", "g2", "be2",
+                                  "qkv", "P", "Pd", "ctx", "a", "z", "g", "out", "rstd_a", "rstd_o")] + \
+               [("site_attn", u32), ("site_ao", u32), ("site_out", u32), ("pad_", u32)]
+
+
+class EncSeg(C.Structure):
+    _fields_ = [("x", vp), ("kmask", vp), ("nsamp", i32), ("N", i32), ("ldp", i32), ("nlayers", i32), ("L", EncLayer * 6)]
+
+
+class EncParams(C.Structure):
+    _fields_ = [("seg", EncSeg * 2), ("nseg", i32), ("p_attn", f32), ("p_hidden", f32), ("eps", f32), ("scale", f32), ("seed", vp)]
 
 
 _ERR = {-1: "MAGIC_ERR_ARG", -2: "MAGIC_ERR_LAUNCH", -3: "MAGIC_ERR_UNSUPPORTED"}

@@ -182,7 +182,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H
         c = Ctx(task=task, plan=plan, inp=inp)
         # the text and panorama encoders are independent: run them on two streams
-        c.txt, c.pano = self._par(lambda: n.text_fwd(plan), lambda: n.pano_fwd(plan, inp.feats, inp.loc))
+        # both self-attention encoders as ONE launch (csrc/encoder.hip) when the shapes allow: embeddings first (paired), then the launch
+        fuse = n.enc_ok(plan["L"], self.config.num_l_layers) and n.enc_ok(plan["V"], self.config.num_pano_layers) and not n._rb_ok()
+        c.txt, c.pano = self._par(lambda: n.text_fwd(plan, defer=fuse), lambda: n.pano_fwd(plan, inp.feats, inp.loc, defer=fuse))
+        if fuse:
+            n.encoders_fwd(c.txt, c.pano)
         c.gin = n.gmap_in_fwd(plan, c.pano, inp.gpos) if task != "mrc" else None
         tl, gl_, vl = plan["lens"]["txt"], plan["lens"]["gmap"], [Vp] * B
         o = dict(txt_embeds=c.txt.out, txt_attns=c.txt.P, pano_embeds=c.pano.out, pano_fused_embeds=c.pano.fused,

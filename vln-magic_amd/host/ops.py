@@ -13,7 +13,7 @@ from . import lib as L
 
 # algorithmic FLOPs of the dense contractions, per kernel family ("gemm": magic_gemm / magic_gemm_dw_grouped; "linear_ln": the fused
 # dense+LayerNorm kernels; "attn": the fused attention kernels) and in total
-FLOPS = {"total": 0.0, "gemm": 0.0, "linear_ln": 0.0, "attn": 0.0, "enabled": False}
+FLOPS = {"total": 0.0, "gemm": 0.0, "linear_ln": 0.0, "attn": 0.0, "enc": 0.0, "enabled": False}
 
 
 def _count(m, n, k, batch=1, fam="gemm"):
@@ -392,6 +392,46 @@ def attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, dctx, B, nh, Nq, Nk, H, scale, dP_init
         FLOPS["attn"] += 8.0 * flops
     L.call("magic_attn_bwd", L.dt(q.dtype), B, nh, Nq, Nk, L.P(q), ldq, L.P(k), L.P(v), ldkv, L.P(Pm), ldp, L.P(dctx), H, float(scale),
            L.P(dP_init), L.P(dq), lddq, L.P(dk), L.P(dv), lddkv, L.P(dist), L.P(dsprel_w), L.P(dsprel_b), *_dr(drop), L.stream())
+
+
+FUSED_ENC = not os.environ.get("MAGIC_NO_FUSED_ENC")
+_ENC_OK = {}
+
+
+def encoder_ok(dtype, H, I, nh, N, nlayers):
+    """whole-encoder launch available for this shape? (bf16, H = 128, 2 heads, FFN 512, <= 80 tokens, <= 6 layers)"""
+    if not FUSED_ENC or dtype != torch.bfloat16:
+        return False
+    key = (H, I, nh, N, nlayers)
+    if key not in _ENC_OK:
+        _ENC_OK[key] = bool(L.load().magic_encoder_supported(L.dt(dtype), H, I, nh, N, nlayers))
+    return _ENC_OK[key]
+
+
+def encoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
+    """segs: 1 or 2 dicts(x, kmask, nsamp, N, ldp, layers=[dict of tensors / site ids per layer], flops) -- csrc/encoder.hip.  The
+    text encoder goes first (its workgroups run 6 layers: the long pole)."""
+    import ctypes as C
+    _chk(1 <= len(segs) <= 2, "encoder segments")
+    P = L.EncParams()
+    P.nseg = len(segs)
+    P.p_attn, P.p_hidden, P.eps, P.scale = float(p_attn), float(p_hidden), float(eps), float(scale)
+    P.seed = L.P(seed)
+    for i, sg in enumerate(segs):
+        S = P.seg[i]
+        x = sg["x"]
+        _chk(x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[0] == sg["nsamp"] * sg["N"], "encoder input [nsamp*N, H] bf16")
+        S.x, S.kmask, S.nsamp, S.N, S.ldp, S.nlayers = L.P(x), L.P(sg["kmask"]), sg["nsamp"], sg["N"], sg["ldp"], len(sg["layers"])
+        for j, ly in enumerate(sg["layers"]):
+            D = S.L[j]
+            for k in ("Wqkv", "bqkv", "Wo", "bo", "g1", "be1", "W1", "bi", "W2", "bo2", "g2", "be2", "qkv", "P", "Pd", "ctx", "a", "z", "g", "out",
+                      "rstd_a", "rstd_o"):
+                setattr(D, k, L.P(ly.get(k)))
+            D.site_attn, D.site_ao, D.site_out = int(ly.get("site_attn", 0)), int(ly.get("site_ao", 0)), int(ly.get("site_out", 0))
+        if FLOPS["enabled"]:
+            FLOPS["total"] += sg["flops"]
+            FLOPS["enc"] += sg["flops"]
+    L.call("magic_encoder_fwd", C.addressof(P), C.sizeof(P), L.stream())
 
 
 def head_mean_fwd(Pm, out, B, nh, inner):

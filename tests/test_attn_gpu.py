@@ -91,9 +91,69 @@ def test_fused_attention_fwd_bwd(dtype, B, nh, Nq, Nk, cross, use_dist):
 
 
 def test_unsupported_shapes_are_reported_not_launched():
-    assert not O.attn_supported(torch.bfloat16, 40, 512, False)
+    assert O.attn_supported(torch.bfloat16, 40, 512, False)              # K/V-tiled two-pass forward
+    assert not O.attn_supported(torch.bfloat16, 40, 513, False)
+    assert not O.attn_supported(torch.bfloat16, 40, 512, True)           # the backward for long keys stays GEMM + softmax
     assert O.attn_supported(torch.bfloat16, 80, 80, True)
     assert not O.attn_supported(torch.float32, 128, 128, True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,nh,Nq,Nk,cross,use_dist,p_drop", [(2, 2, 40, 129, True, False, 0.0), (1, 2, 200, 200, False, False, 0.1),
+                                                               (2, 4, 38, 512, True, False, 0.0), (1, 2, 70, 300, True, True, 0.1),
+                                                               (1, 2, 512, 512, False, False, 0.0)])
+def test_kv_tiled_forward_for_long_keys(dtype, B, nh, Nq, Nk, cross, use_dist, p_drop):
+    """128 < Nk <= 512 (RxR-length instructions): two-pass softmax over 128-key tiles.  One key is spiked against one query in the
+    LAST tile so the running maximum jumps late (the rescale of the running sum is exercised, not just carried); masks put -10000
+    on keys of the first and the last tile."""
+    H = nh * 64
+    g = torch.Generator().manual_seed(Nq * 7 + Nk)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    if cross:
+        qb, kvb = rnd(B * Nq, H), rnd(B * Nk, 2 * H)
+        kvb[Nk - 2, :H] = qb[3, :H] * 4.0                   # batch 0: key Nk-2 aligned with query 3 -> a late, large maximum
+        qb, kvb = qb.to(dtype), kvb.to(dtype)
+        q, k, v, ldq, ldkv = qb, kvb, kvb[:, H:], H, 2 * H
+    else:
+        qkv = rnd(B * Nq, 3 * H)
+        qkv[Nk - 2, H:2 * H] = qkv[3, :H] * 4.0
+        qkv = qkv.to(dtype)
+        q, k, v, ldq, ldkv = qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H
+    kmask = torch.ones(B, Nk, dtype=torch.uint8, device=DEV)
+    kmask[0, Nk - 5:Nk - 3] = 0
+    kmask[B - 1, 1] = 0
+    dist = (rnd(B, Nq, Nk).abs() * 4).contiguous() if use_dist else None
+    sw, sb = torch.tensor([0.2], device=DEV), torch.tensor([-0.1], device=DEV)
+    scale = 1 / math.sqrt(64)
+    ldp = (Nk + 7) // 8 * 8
+    Pm = torch.full((B, nh, Nq, ldp), 7.0, dtype=dtype, device=DEV)
+    Pd = torch.full((B, nh, Nq, ldp), 7.0, dtype=dtype, device=DEV) if p_drop > 0 else None
+    ctx = torch.empty(B * Nq, H, dtype=dtype, device=DEV)
+    seed = torch.tensor([11, 22], dtype=torch.int32, device=DEV)
+    drop = (seed, p_drop, 4242) if p_drop > 0 else None
+    O.attn_fwd(q, ldq, k, v, ldkv, Pm, ldp, ctx, B, nh, Nq, Nk, H, scale, kmask=kmask, dist=dist, sprel_w=sw if use_dist else None,
+               sprel_b=sb if use_dist else None, drop=drop, Pd=Pd)
+    torch.cuda.synchronize()
+    heads = lambda t, N: t.float().reshape(B, N, nh, 64).transpose(1, 2)
+    qh, kh, vh = heads(q[:, :H] if not cross else q, Nq), heads(k[:, :H], Nk), heads(v[:, :H], Nk)
+    p_ref, _ = ref_attention(qh, kh, vh, kmask, dist, sw, sb, scale)
+    tp = dict(rtol=2e-4, atol=2e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=4e-3)
+    to = dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    assert torch.allclose(Pm[..., :Nk].float(), p_ref, **tp), (Pm[..., :Nk].float() - p_ref).abs().max().item()
+    assert (Pm[..., Nk:] == 0).all() and torch.allclose(Pm[..., :Nk].float().sum(-1), torch.ones(B, nh, Nq, device=DEV), atol=2e-2)
+    assert p_ref[0, :, 3, Nk - 2].min().item() > 0.5            # the spiked key really dominates its row
+    if p_drop > 0:
+        ones = torch.ones(B * nh * Nq * Nk, device=DEV)
+        mask = torch.empty_like(ones)
+        O.dropout(ones, mask, B * nh * Nq, Nk, Nk, drop)        # the kernel's own mask over the logical [B, nh, Nq, Nk] tensor
+        want_pd = Pm[..., :Nk].float() * mask.view(B, nh, Nq, Nk)
+        assert torch.allclose(Pd[..., :Nk].float(), want_pd, rtol=1e-2, atol=1e-3) and (Pd[..., Nk:] == 0).all()
+        o_ref = Pd[..., :Nk].float() @ vh
+    else:
+        o_ref = Pm[..., :Nk].float() @ vh
+    got = ctx.float()
+    want = o_ref.transpose(1, 2).reshape(B * Nq, H)
+    assert torch.allclose(got, want, **to), (got - want).abs().max().item()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

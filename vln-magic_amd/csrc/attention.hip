@@ -4,8 +4,9 @@
 //   backward: dV = P^T dO, dP = dO V^T (+ distillation gradient), dS = softmax', dQ = dS K, dK = dS^T Q, one launch
 //             instead of five.  One workgroup owns a whole (batch, head): every operand of the five products is an
 //             LDS image read either row-wise (16-byte ds_read) or transposed (ds_read_b64_tr_b16), no global round trips.
-// Limits: head dim 64, Nk <= 128 (forward), Nq, Nk <= 128 bf16 / <= 64 fp32 (backward; LDS).  Longer sequences
-// (RxR, 512 tokens) take the unfused GEMM + softmax path of the engine.
+// Limits: head dim 64; forward: Nk <= 128 with all keys resident, 128 < Nk <= 512 through the K/V-tiled two-pass kernel
+// (attn_fwd_tiled_body); backward: Nq, Nk <= 128 bf16 / <= 64 fp32 (LDS) -- longer sequences (RxR, 512 tokens) take the engine's
+// GEMM + softmax backward, which reads the P this kernel saved.
 #include "common.hpp"
 #include <cstdlib>
 #include "group.hpp"
@@ -200,6 +201,161 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bqt
       *(vec*)(Og + (long long)r * p.H + c) = *(const vec*)(sQ + r * DS + c);
     }
   }
+}
+
+// ---- K/V-tiled forward for long key sequences (128 < Nk <= 512: RxR-length instructions, BASELINE config 5) ------------------------
+// Same contract as attn_fwd_body (P clean [+ dropped Pd], ctx), one workgroup per (batch, head, 64-query tile), but K and V pass
+// through LDS in tiles of 128 keys and the softmax is two-pass: pass 1 walks the key tiles keeping only the running row maximum and
+// row sum (rescaled tile by tile), pass 2 walks them again, recomputes the scores, normalises with the final statistics, writes the
+// probabilities and accumulates P V.  The scores never exist in memory (the unfused path wrote them as fp32 [B, h, Nq, Nk] and read
+// them back twice); QK^T is computed twice, which at head dim 64 is cheaper than one round trip of the scores.
+#define KTILE 128
+template <typename T>
+__device__ __forceinline__ void attn_fwd_tiled_body(const AttnParams& p, const int bqt, const int h, const int b, unsigned char* smem_raw) {
+  typedef typename AT<T>::vec vec;
+  constexpr int VE = AT<T>::VE, KSTEP = AT<T>::KSTEP, DS = AT<T>::DS, PS = KTILE + AT<T>::PPAD;
+  T* sQ = (T*)smem_raw;            // [64][DS]   (re-used to stage O)
+  T* sK = sQ + 64 * DS;            // [128][DS]
+  T* sV = sK + KTILE * DS;         // [128][DS]
+  T* sP = sV + KTILE * DS;         // [64][PS]   this tile's probabilities, 16 rows per wave
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int q0 = bqt * 64;
+  const int nq = min(64, p.Nq - q0);
+  const int ntiles = (p.Nk + KTILE - 1) / KTILE;
+  const T* Kg = (const T*)p.k + (long long)b * p.Nk * p.ldkv + h * HD;
+  const T* Vg = (const T*)p.v + (long long)b * p.Nk * p.ldkv + h * HD;
+  load_rows<T>(sQ, (const T*)p.q + ((long long)b * p.Nq + q0) * p.ldq + h * HD, p.ldq, nq, 64);
+  const float sw = p.dist ? p.sprel_w[0] : 0.f, sb = p.dist ? p.sprel_b[0] : 0.f;
+  // scores of this wave's 16 query rows against the key tile in sK -> acc (scaled, masked; -3e38 on keys past Nk)
+  auto scores = [&](const int k0, f32x4 (&acc)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < HD / KSTEP; ++ks) {
+      const auto a = fragKC(sQ, DS, w * 16, ks * KSTEP, lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = mma(a, fragKC(sK, DS, j * 16, ks * KSTEP, lane), acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = k0 + j * 16 + c16;
+      const bool kv = key < p.Nk;
+      const float mb = (kv && p.kmask && !p.kmask[(long long)b * p.Nk + key]) ? -10000.0f : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qrow = min(q0 + w * 16 + 4 * g + r, p.Nq - 1);
+        float x = acc[j][r] * p.scale + mb;
+        if (p.dist && kv) x += sw * p.dist[((long long)b * p.Nq + qrow) * p.Nk + key] + sb;
+        acc[j][r] = kv ? x : -3.0e38f;
+      }
+    }
+  };
+  // ---- pass 1: running row maximum and row sum over the key tiles
+  float mx[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, sum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * KTILE;
+    __syncthreads();                                   // previous tile's readers are done with sK
+    load_rows<T>(sK, Kg + (long long)k0 * p.ldkv, p.ldkv, min(KTILE, p.Nk - k0), KTILE);
+    __syncthreads();
+    f32x4 acc[8];
+    scores(k0, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t = fmaxf(t, acc[j][r]);
+      const float nm = fmaxf(mx[r], group16_max(t));
+      float e = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e += (acc[j][r] > -1.0e38f) ? __expf(acc[j][r] - nm) : 0.f;
+      sum[r] = sum[r] * __expf(mx[r] - nm) + group16_sum(e);
+      mx[r] = nm;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sum[r] = 1.0f / sum[r];
+  // ---- pass 2: probabilities (written tile by tile) and O = P V
+  const DropState ds_ = drop_init(p.drop);
+  f32x4 o[4];
+#pragma unroll
+  for (int jd = 0; jd < 4; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  T* sPw = sP + w * 16 * PS;
+  const int nqw = min(16, nq - w * 16);                 // valid query rows of this wave's tile (may be <= 0)
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * KTILE;
+    __syncthreads();
+    load_rows<T>(sK, Kg + (long long)k0 * p.ldkv, p.ldkv, min(KTILE, p.Nk - k0), KTILE);
+    load_rows<T>(sV, Vg + (long long)k0 * p.ldkv, p.ldkv, min(KTILE, p.Nk - k0), KTILE);
+    __syncthreads();
+    f32x4 acc[8];
+    scores(k0, acc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = (acc[j][r] > -1.0e38f) ? __expf(acc[j][r] - mx[r]) * sum[r] : 0.f;
+        acc[j][r] = pr;
+        sPw[(4 * g + r) * PS + j * 16 + c16] = from_f<T>(pr);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ncol = min(KTILE, p.ldp - k0);            // columns of this tile inside the row pitch (pad columns hold zeros)
+    if (nqw > 0) {
+      T* Pg = (T*)p.P + (((long long)b * p.nh + h) * p.Nq + q0 + w * 16) * p.ldp + k0;
+      const int cpr = ncol / VE;
+      for (int id = lane; id < nqw * cpr; id += 64) {
+        const int r = id / cpr, c = (id % cpr) * VE;
+        *(vec*)(Pg + (long long)r * p.ldp + c) = *(const vec*)(sPw + r * PS + c);
+      }
+    }
+    if (ds_.on) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int key = k0 + j * 16 + c16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = w * 16 + 4 * g + r;
+          const unsigned idx = (unsigned)(((((long long)b * p.nh + h) * p.Nq + q0 + ql) * p.Nk) + key);
+          const float m = (ql < nq && key < p.Nk) ? drop_mul(ds_, idx) : 0.f;
+          sPw[(4 * g + r) * PS + j * 16 + c16] = from_f<T>(acc[j][r] * m);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (p.Pd && nqw > 0) {
+        T* Pg = (T*)p.Pd + (((long long)b * p.nh + h) * p.Nq + q0 + w * 16) * p.ldp + k0;
+        const int cpr = ncol / VE;
+        for (int id = lane; id < nqw * cpr; id += 64) {
+          const int r = id / cpr, c = (id % cpr) * VE;
+          *(vec*)(Pg + (long long)r * p.ldp + c) = *(const vec*)(sPw + r * PS + c);
+        }
+      }
+    }
+    for (int ks = 0; ks < KTILE / KSTEP; ++ks) {
+      const auto a = fragKC(sPw, PS, 0, ks * KSTEP, lane);
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) o[jd] = mma(a, fragOC(sV, DS, jd * 16, ks * KSTEP, lane), o[jd]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sQ[(w * 16 + 4 * g + r) * DS + jd * 16 + c16] = from_f<T>(o[jd][r]);
+  __syncthreads();
+  {
+    T* Og = (T*)p.ctx + ((long long)b * p.Nq + q0) * p.H + h * HD;
+    constexpr int VPR = HD / VE;
+    for (int id = tid; id < nq * VPR; id += 256) {
+      const int r = id / VPR, c = (id % VPR) * VE;
+      *(vec*)(Og + (long long)r * p.H + c) = *(const vec*)(sQ + r * DS + c);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+  attn_fwd_tiled_body<T>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem_dyn);
 }
 
 template <typename T>
@@ -400,6 +556,11 @@ static size_t fwd_lds(int dtype, int Nk) {
   if (dtype == DT_BF16) return (size_t)(64 * 72 + 2 * NKP * 72 + 64 * (NKP + 8)) * 2;
   return (size_t)(64 * 68 + 2 * NKP * 68 + 64 * (NKP + 4)) * 4;
 }
+static size_t fwd_tiled_lds(int dtype) {
+  if (dtype == DT_BF16) return (size_t)(64 * 72 + 2 * KTILE * 72 + 64 * (KTILE + 8)) * 2;
+  return (size_t)(64 * 68 + 2 * KTILE * 68 + 64 * (KTILE + 4)) * 4;
+}
+#define NK_TILED_MAX 512
 static size_t bwd_lds(int dtype, int Nq, int Nk) {
   const int NQP = (Nq + 31) / 32 * 32, NKP = (Nk + 31) / 32 * 32;
   if (dtype == DT_BF16) return (size_t)(2 * NQP * 72 + 2 * NKP * 72 + (bwd_alias(NQP, NKP, NKP + 8, 72) ? 1 : 2) * NQP * (NKP + 8)) * 2;
@@ -409,8 +570,9 @@ static size_t bwd_lds(int dtype, int Nq, int Nk) {
 
 // returns 1 if the fused kernels support the shape (host decides fused vs GEMM+softmax path), 0 otherwise
 extern "C" int magic_attn_supported(int dtype, int Nq, int Nk, int backward) {
-  if (Nk > 128 || Nk <= 0 || Nq <= 0) return 0;
-  if (backward) return (Nq <= 128 && bwd_lds(dtype, Nq, Nk) <= LDS_MAX) ? 1 : 0;
+  if (Nk <= 0 || Nq <= 0) return 0;
+  if (backward) return (Nk <= 128 && Nq <= 128 && bwd_lds(dtype, Nq, Nk) <= LDS_MAX) ? 1 : 0;
+  if (Nk > 128) return Nk <= NK_TILED_MAX ? 1 : 0;            // K/V-tiled two-pass forward
   return fwd_lds(dtype, Nk) <= LDS_MAX ? 1 : 0;
 }
 
@@ -447,6 +609,23 @@ template <typename K> static void set_lds(K kern, size_t shm) {
 int launch_attn_fwd(int dtype, int, const void* pa, const void* pb, hipStream_t st) {
   const AttnParams& a = *(const AttnParams*)pa;
   dim3 block(256);
+  if (a.Nk > 128 || (pb && ((const AttnParams*)pb)->Nk > 128)) {          // long keys: K/V-tiled kernel, one launch per problem
+    const AttnParams* ps[2] = {&a, (const AttnParams*)pb};
+    for (int i = 0; i < (pb ? 2 : 1); ++i) {
+      const AttnParams& q = *ps[i];
+      dim3 grid((q.Nq + 63) / 64, q.nh, q.B);
+      if (q.Nk > 128) {
+        const size_t shm = fwd_tiled_lds(dtype);
+        if (dtype == DT_BF16) { set_lds(attn_fwd_tiled_kernel<bf16>, shm); hipLaunchKernelGGL(attn_fwd_tiled_kernel<bf16>, grid, block, shm, st, q); }
+        else { set_lds(attn_fwd_tiled_kernel<float>, shm); hipLaunchKernelGGL(attn_fwd_tiled_kernel<float>, grid, block, shm, st, q); }
+      } else {
+        const size_t shm = fwd_lds(dtype, q.Nk);
+        if (dtype == DT_BF16) { set_lds(attn_fwd_kernel<bf16>, shm); hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, block, shm, st, q); }
+        else { set_lds(attn_fwd_kernel<float>, shm); hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, shm, st, q); }
+      }
+    }
+    return launch_status();
+  }
   if (!pb) {
     dim3 grid((a.Nq + 63) / 64, a.nh, a.B);
     const size_t shm = fwd_lds(dtype, a.Nk);

@@ -235,6 +235,30 @@ int magic_encoder_supported(int dtype, int H, int I, int nh, int N, int nlayers)
 int magic_encoder_params_bytes(void);
 int magic_encoder_fwd(const void* params, int nbytes, void* stream);
 
+/* Cross-modal encoders in one launch (csrc/encoder.hip, xencoder_fwd_kernel): the global (map) and local (viewpoint) co-attention
+ * encoders, <= 3 METER BertCrossLayer blocks each (the withheld model's `bert.{global,local}_encoder.encoder.crossattention.N`,
+ * names per train_r2r_magic.py:203-206), one workgroup per sample for all layers; same limits as magic_encoder_fwd, queries and
+ * context <= 80 rows.  Saves what the per-op backward reads for the self-attention, cross-attention and FFN sub-blocks. */
+typedef struct {
+  const void* Wqkv; const float* bqkv; const void* Wo; const float* bo; const float* g1; const float* be1;
+  const void* Wq; const float* bq; const void* Wkv; const float* bkv; const void* Woc; const float* boc; const float* gc; const float* bec;
+  const void* W1; const float* bi; const void* W2; const float* bo2; const float* g2; const float* be2;
+  void *qkv, *P, *Pd, *ctx, *a; float* rstd_a;
+  void *q, *kv, *Pc, *Pdc, *cctx, *c; float* rstd_c;
+  void *z, *g, *out; float* rstd_o;
+  unsigned site_attn, site_ao, site_cattn, site_co, site_out, pad_;
+} magic_xenc_layer;
+typedef struct {
+  const void* x; const void* cx; const unsigned char* qmask; const unsigned char* cmask;
+  const float* dist; const float* sprel_w; const float* sprel_b;
+  int nsamp, Nq, Nk, ldps, ldpc, nlayers;
+  magic_xenc_layer L[3];
+} magic_xenc_seg;
+typedef struct { magic_xenc_seg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; } magic_xenc_params;
+int magic_xencoder_supported(int dtype, int H, int I, int nh, int Nq, int Nk, int nlayers);
+int magic_xencoder_params_bytes(void);
+int magic_xencoder_fwd(const void* params, int nbytes, void* stream);
+
 /* Grouping: between magic_group_begin() and magic_group_end(stream) up to eight calls of magic_gemm / magic_attn_fwd /
  * magic_attn_bwd / magic_linear_ln / magic_linear_lnbwd / magic_ln_bwd / magic_rowblock_fwd are recorded instead of launched; magic_group_end launches ONE kernel serving
  * the problems of the same kind / dtype / variant: GEMMs as one grouped launch (<= 8 problems), other kinds as pairs.

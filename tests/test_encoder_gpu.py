@@ -86,6 +86,52 @@ def test_fused_encoders_save_what_the_unfused_kernels_save(p_drop, max_len):
     ulp_close(res[True][1].img_attn, res[False][1].img_attn, "img_attns", ulps=3.0)
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("task", ["sap", "mlm"])
+def test_fused_cross_encoders_save_what_the_unfused_kernels_save(task, p_drop):
+    """global || local co-attention encoders (sap) and the text-attends-to-map path (mlm) as one launch vs the per-op kernels: every
+    tensor cross_layer_bwd reads, layer by layer"""
+    m = student(p_drop)
+    m.train()
+    batch = synth.make_batch(task, batch_size=6, seed=9, step=0, dup_view_prob=0.3)
+    plan = build_plan(batch, task, torch.device(DEV))
+    inp = m._inputs(batch, plan)
+    m.store.sync_shadow()
+    seed = torch.tensor([777, 31], dtype=torch.int32, device=DEV)
+    n = m.net
+    B, L, K, Vp = plan["B"], plan["L"], plan["K"], plan["Vp"]
+    tl, gl_, vl = plan["lens"]["txt"], plan["lens"]["gmap"], [Vp] * B
+    n.set_dropout(seed if p_drop > 0 else None, p_drop, p_drop)
+    ct = n.text_fwd(plan)
+    cp = n.pano_fwd(plan, inp.feats, inp.loc)
+    gin = n.gmap_in_fwd(plan, cp, inp.gpos)
+    vin = n.vp_in_fwd(plan, cp, inp.vpos)
+    if task == "sap":
+        specs = [("global", plan, gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"], ct.out, L, plan["txt_mask"], tl, plan["txt_tokens"], inp.dist),
+                 ("local", plan, vin.out, Vp, plan["vp_mask"], vl, B * Vp, ct.out, L, plan["txt_mask"], tl, plan["txt_tokens"])]
+    else:
+        specs = [("global", plan, ct.out, L, plan["txt_mask"], tl, plan["txt_tokens"], gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"])]
+    assert all(n.xenc_ok(sp[3], sp[8]) for sp in specs)
+    fused = n.cross_fwd_fused(specs)
+    plain = [n.cross_fwd(*sp[:12], dist=(sp[12] if len(sp) > 12 else None)) for sp in specs]
+    torch.cuda.synchronize()
+    for sp, a, b in zip(specs, fused, plain):
+        for i, (la, lb) in enumerate(zip(a.layers, b.layers)):
+            nm = f"{task} {sp[0]} layer {i}"
+            for k in ("qkv", "Ppre", "P", "ctx", "a"):
+                ulp_close(getattr(la.sa, k), getattr(lb.sa, k), f"{nm} sa.{k}")
+            for k in ("q", "kv", "Ppre", "P", "cctx", "c"):
+                ulp_close(getattr(la, k), getattr(lb, k), f"{nm} cross {k}")
+            for k in ("z", "g", "out"):
+                ulp_close(getattr(la.ffn, k), getattr(lb.ffn, k), f"{nm} ffn.{k}")
+            for k, (x, y) in (("rstd_a", (la.sa.rstd_a, lb.sa.rstd_a)), ("rstd_c", (la.rstd_c, lb.rstd_c)), ("rstd", (la.ffn.rstd, lb.ffn.rstd))):
+                assert torch.allclose(x, y, rtol=2e-2, atol=1e-3), f"{nm} {k}"
+            if p_drop > 0:
+                for pa, pb, what in ((la.sa.P, lb.sa.P, "self"), (la.P, lb.P, "cross")):
+                    assert ((pa.float() == 0) != (pb.float() == 0)).float().mean().item() < 1e-4, f"{nm}: {what}-attention dropout masks differ"
+        ulp_close(a.out, b.out, f"{task} {sp[0]} encoder output")
+
+
 @pytest.mark.parametrize("task", ["sap", "mlm", "cfp"])
 def test_training_step_with_fused_encoders_matches_unfused(task):
     from tests.test_fullsize_gpu import models, step

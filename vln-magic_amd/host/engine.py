@@ -721,6 +721,68 @@ class MagicNet:
         c.out, c.P, c.ldp = x, c.layers[-1].P, c.layers[-1].ldp
         return c
 
+    # ---- both cross-modal encoders as one launch (csrc/encoder.hip, xencoder_fwd_kernel) -----------------------------------
+    def xenc_ok(self, Nq, Nk):
+        return O.xencoder_ok(self.dtype, self.H, self.I, self.nh, Nq, Nk, self.cfg.num_x_layers) and not self._rb_ok()
+
+    def _xenc_segment(self, which, plan, x, Nq, qmask, qlens, qrows, ctx, Nk, kmask, klens, krows, dist=None):
+        """allocate what cross_layer_bwd reads for every layer of one encoder; returns (segment dict for O.xencoder_fwd, cross Ctx)"""
+        enc = self.p + ("global_encoder." if which == "global" else "local_encoder.")
+        H, I, nh, B = self.H, self.I, self.nh, plan["B"]
+        sprel, _ = self._sprel() if (which == "global" and dist is not None) else (None, None)
+        sf, cf = self._flops_attn(qlens, qlens), self._flops_attn(qlens, klens)
+        Mq, Mk, ldps, ldpc = B * Nq, B * Nk, rup(Nq), rup(Nk)
+        cc = Ctx(which=which, layers=[], dist=dist)
+        descs = []
+        for i in range(self.cfg.num_x_layers):
+            lp = f"{enc}encoder.crossattention.{i}."
+            sa = Ctx(x=x, Bn=B, N=Nq, rows=qrows, aflops=sf, dist=dist, qkv=self.new(Mq, 3 * H), ldp=ldps,
+                     adrop=self._da(lp + "attention.self.dropout"), hdrop=self._dh(lp + "attention.output.dropout"))
+            sa.Ppre, sa.ctx, sa.a, sa.rstd_a = self.new(B, nh, Nq, ldps), self.new(Mq, H), self.new(Mq, H), self.new(Mq, dtype=torch.float32)
+            sa.P = self.new(B, nh, Nq, ldps) if sa.adrop else sa.Ppre
+            c = Ctx(Bn=B, Nq=Nq, Nk=Nk, ctx=ctx, rows=qrows, crow=krows, cflops=cf, next_qkv=None, kv_given=False, sa=sa,
+                    q=self.new(Mq, H), kv=self.new(Mk, 2 * H), ldp=ldpc,
+                    adrop=self._da(lp + "crossattention.self.dropout"), hdrop=self._dh(lp + "crossattention.output.dropout"))
+            c.Ppre, c.cctx, c.c, c.rstd_c = self.new(B, nh, Nq, ldpc), self.new(Mq, H), self.new(Mq, H), self.new(Mq, dtype=torch.float32)
+            c.P = self.new(B, nh, Nq, ldpc) if c.adrop else c.Ppre
+            c.ffn = Ctx(a=c.c, M=Mq, rows=qrows, z=self.new(Mq, I), g=self.new(Mq, I), out=self.new(Mq, H), rstd=self.new(Mq, dtype=torch.float32),
+                        hdrop=self._dh(lp + "output.dropout"))
+            c.out = c.ffn.out
+            ql = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
+            o, n1 = self.lin(lp + "attention.output.dense.weight"), self.ln(lp + "attention.output.LayerNorm")
+            cq = self.lin(lp + "crossattention.self.query.weight")
+            ckv = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
+            co, nc = self.lin(lp + "crossattention.output.dense.weight"), self.ln(lp + "crossattention.output.LayerNorm")
+            f1, f2, n2 = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.ln(lp + "output.LayerNorm")
+            descs.append(dict(Wqkv=ql.W, bqkv=ql.b, Wo=o.W, bo=o.b, g1=n1.g, be1=n1.b, Wq=cq.W, bq=cq.b, Wkv=ckv.W, bkv=ckv.b,
+                              Woc=co.W, boc=co.b, gc=nc.g, bec=nc.b, W1=f1.W, bi=f1.b, W2=f2.W, bo2=f2.b, g2=n2.g, be2=n2.b,
+                              qkv=sa.qkv, P=sa.Ppre, Pd=sa.P if sa.adrop else None, ctx=sa.ctx, a=sa.a, rstd_a=sa.rstd_a,
+                              q=c.q, kv=c.kv, Pc=c.Ppre, Pdc=c.P if c.adrop else None, cctx=c.cctx, c=c.c, rstd_c=c.rstd_c,
+                              z=c.ffn.z, g=c.ffn.g, out=c.ffn.out, rstd_o=c.ffn.rstd,
+                              site_attn=sa.adrop[2] if sa.adrop else 0, site_ao=sa.hdrop[2] if sa.hdrop else 0,
+                              site_cattn=c.adrop[2] if c.adrop else 0, site_co=c.hdrop[2] if c.hdrop else 0,
+                              site_out=c.ffn.hdrop[2] if c.ffn.hdrop else 0))
+            cc.layers.append(c)
+            x = c.out
+        nl = self.cfg.num_x_layers
+        flops = nl * (2.0 * qrows * (3 * H * H + 3 * H * H + 2 * H * I) + 2.0 * krows * 2 * H * H + 4.0 * sf + 4.0 * cf)
+        cc.out, cc.P, cc.ldp = cc.layers[-1].out, cc.layers[-1].P, cc.layers[-1].ldp
+        seg = dict(x=cc.layers[0].sa.x, cx=ctx, qmask=qmask, cmask=kmask, dist=dist, sprel_w=sprel[0] if sprel else None,
+                   sprel_b=sprel[1] if sprel else None, nsamp=B, Nq=Nq, Nk=Nk, ldps=ldps, ldpc=ldpc, layers=descs, flops=flops)
+        return seg, cc
+
+    def cross_fwd_fused(self, specs):
+        """specs: 1 or 2 argument tuples of cross_fwd (which, plan, x, Nq, qmask, qlens, qrows, ctx, Nk, kmask, klens, krows[, dist]);
+        returns their cross contexts, computed by ONE launch"""
+        segs, outs = [], []
+        for sp in specs:
+            sg, cc = self._xenc_segment(*sp)
+            segs.append(sg)
+            outs.append(cc)
+        d = self.drop
+        O.xencoder_fwd(segs, d[0] if d else None, d[2] if d else 0.0, d[1] if d else 0.0, self.eps, 1.0 / math.sqrt(HD))
+        return outs
+
     def cross_bwd(self, c, d_out, d_ctx_acc, dP_init=None, dkv=None):
         enc = self.p + ("global_encoder." if c.which == "global" else "local_encoder.")
         _, dsprel = self._sprel() if (c.which == "global" and c.dist is not None) else (None, None)

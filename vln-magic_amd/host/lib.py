@@ -64,6 +64,9 @@ SIGNATURES = {
     "magic_encoder_supported": [i32, i32, i32, i32, i32, i32],
     "magic_encoder_params_bytes": [],
     "magic_encoder_fwd": [vp, i32, vp],
+    "magic_xencoder_supported": [i32, i32, i32, i32, i32, i32, i32],
+    "magic_xencoder_params_bytes": [],
+    "magic_xencoder_fwd": [vp, i32, vp],
     "magic_group_begin": [],
     "magic_group_end": [vp],
 }
@@ -103,6 +106,24 @@ class EncSeg(C.Structure):
 
 class EncParams(C.Structure):
     _fields_ = [("seg", EncSeg * 2), ("nseg", i32), ("p_attn", f32), ("p_hidden", f32), ("eps", f32), ("scale", f32), ("seed", vp)]
+
+
+XL_PTRS = ("Wqkv", "bqkv", "Wo", "bo", "g1", "be1", "Wq", "bq", "Wkv", "bkv", "Woc", "boc", "gc", "bec", "W1", "bi", "W2", "bo2", "g2", "be2",
+           "qkv", "P", "Pd", "ctx", "a", "rstd_a", "q", "kv", "Pc", "Pdc", "cctx", "c", "rstd_c", "z", "g", "out", "rstd_o")
+
+
+class XLayer(C.Structure):
+    """mirror of `magic_xenc_layer` (include/magic_hip.h)"""
+    _fields_ = [(n, vp) for n in XL_PTRS] + [(n, u32) for n in ("site_attn", "site_ao", "site_cattn", "site_co", "site_out", "pad_")]
+
+
+class XSeg(C.Structure):
+    _fields_ = [(n, vp) for n in ("x", "cx", "qmask", "cmask", "dist", "sprel_w", "sprel_b")] + \
+               [(n, i32) for n in ("nsamp", "Nq", "Nk", "ldps", "ldpc", "nlayers")] + [("L", XLayer * 3)]
+
+
+class XParams(C.Structure):
+    _fields_ = [("seg", XSeg * 2), ("nseg", i32), ("p_attn", f32), ("p_hidden", f32), ("eps", f32), ("scale", f32), ("seed", vp)]
 
 
 _ERR = {-1: "MAGIC_ERR_ARG", -2: "MAGIC_ERR_LAUNCH", -3: "MAGIC_ERR_UNSUPPORTED"}

@@ -192,8 +192,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         o = dict(txt_embeds=c.txt.out, txt_attns=c.txt.P, pano_embeds=c.pano.out, pano_fused_embeds=c.pano.fused,
                  img_attns=c.pano.img_attn, plan=plan, inputs=inp)
         if task == "mlm":
-            c.l2v = n.cross_fwd("global", plan, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"],
-                                c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"], dist=None)
+            l2v_args = ("global", plan, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"])
+            c.l2v = n.cross_fwd_fused([l2v_args])[0] if n.xenc_ok(L, K) else n.cross_fwd(*l2v_args, dist=None)
             o["gmap_embeds"], o["gmap_attns"] = c.l2v.out, c.l2v.P
             nm = plan["n_mask"]
             c.hm_in = n.new(nm, H)
@@ -215,7 +215,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         elif task == "mrc":
             # local branch only; RegionClassification on the masked views of the current viewpoint (validate_mrc :476-500)
             c.vin = n.vp_in_fwd(plan, c.pano, inp.vpos)
-            c.loc = n.cross_fwd("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
+            loc_args = ("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
+            c.loc = n.cross_fwd_fused([loc_args])[0] if n.xenc_ok(Vp, L) else n.cross_fwd(*loc_args)
             o.update(vp_embeds=c.loc.out, vp_attns=c.loc.P)
             nm = plan["n_mrc"]
             c.mx = n.new(nm, H)
@@ -232,8 +233,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 vin = n.vp_in_fwd(plan, c.pano, inp.vpos)
                 return vin, n.cross_fwd("local", plan, vin.out, Vp, plan["vp_mask"], vl, B * Vp,
                                         c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
-            # global (map) and local (viewpoint) co-attention encoders are independent too
-            c.glob, (c.vin, c.loc) = self._par(
+            # global (map) and local (viewpoint) co-attention encoders are independent too: one launch for both when the shapes allow
+            if n.xenc_ok(K, L) and n.xenc_ok(Vp, L):
+                c.vin = n.vp_in_fwd(plan, c.pano, inp.vpos)
+                c.glob, c.loc = n.cross_fwd_fused([
+                    ("global", plan, c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"], c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], inp.dist),
+                    ("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])])
+            else:
+              c.glob, (c.vin, c.loc) = self._par(
                 lambda: n.cross_fwd("global", plan, c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"],
                                     c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], dist=inp.dist), _local)
             o.update(gmap_embeds=c.glob.out, gmap_attns=c.glob.P, vp_embeds=c.loc.out, vp_attns=c.loc.P)

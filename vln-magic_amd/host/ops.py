@@ -434,6 +434,50 @@ def encoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
     L.call("magic_encoder_fwd", C.addressof(P), C.sizeof(P), L.stream())
 
 
+_XENC_OK = {}
+FUSED_XENC = not os.environ.get("MAGIC_NO_FUSED_XENC")
+
+
+def xencoder_ok(dtype, H, I, nh, Nq, Nk, nlayers):
+    if not FUSED_ENC or not FUSED_XENC or dtype != torch.bfloat16:
+        return False
+    key = (H, I, nh, Nq, Nk, nlayers)
+    if key not in _XENC_OK:
+        lib = L.load()
+        _XENC_OK[key] = bool(lib.magic_xencoder_supported(L.dt(dtype), H, I, nh, Nq, Nk, nlayers)) and \
+            lib.magic_xencoder_params_bytes() == __import__("ctypes").sizeof(L.XParams)
+    return _XENC_OK[key]
+
+
+def xencoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
+    """segs: 1 or 2 dicts(x, cx, qmask, cmask, dist, sprel_w, sprel_b, nsamp, Nq, Nk, ldps, ldpc, layers=[...], flops): the global and the
+    local co-attention encoder as one launch (csrc/encoder.hip, xencoder_fwd_kernel)"""
+    import ctypes as C
+    _chk(1 <= len(segs) <= 2, "cross-encoder segments")
+    P = L.XParams()
+    P.nseg = len(segs)
+    P.p_attn, P.p_hidden, P.eps, P.scale = float(p_attn), float(p_hidden), float(eps), float(scale)
+    P.seed = L.P(seed)
+    for i, sg in enumerate(segs):
+        S = P.seg[i]
+        x, cx = sg["x"], sg["cx"]
+        _chk(x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[0] == sg["nsamp"] * sg["Nq"], "cross-encoder queries [nsamp*Nq, H] bf16")
+        _chk(cx.dtype == torch.bfloat16 and cx.is_contiguous() and cx.shape[0] == sg["nsamp"] * sg["Nk"], "cross-encoder context [nsamp*Nk, H] bf16")
+        S.x, S.cx, S.qmask, S.cmask = L.P(x), L.P(cx), L.P(sg["qmask"]), L.P(sg["cmask"])
+        S.dist, S.sprel_w, S.sprel_b = L.P(sg.get("dist")), L.P(sg.get("sprel_w")), L.P(sg.get("sprel_b"))
+        S.nsamp, S.Nq, S.Nk, S.ldps, S.ldpc, S.nlayers = sg["nsamp"], sg["Nq"], sg["Nk"], sg["ldps"], sg["ldpc"], len(sg["layers"])
+        for j, ly in enumerate(sg["layers"]):
+            D = S.L[j]
+            for k in L.XL_PTRS:
+                setattr(D, k, L.P(ly.get(k)))
+            for k in ("site_attn", "site_ao", "site_cattn", "site_co", "site_out"):
+                setattr(D, k, int(ly.get(k, 0)))
+        if FLOPS["enabled"]:
+            FLOPS["total"] += sg["flops"]
+            FLOPS["enc"] += sg["flops"]
+    L.call("magic_xencoder_fwd", C.addressof(P), C.sizeof(P), L.stream())
+
+
 def head_mean_fwd(Pm, out, B, nh, inner):
     L.call("magic_head_mean_fwd", L.dt(Pm.dtype), B, nh, inner, L.P(Pm), L.P(out), L.stream())
 

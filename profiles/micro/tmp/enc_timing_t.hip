@@ -47,7 +47,7 @@ int main() {
       printf("  segment %d last layer (10 ns ticks):", s);
       for (int i = 0; i < 8; ++i) printf(" %s=%lld", nm[i], t[s][i + 1] - t[s][i]);
       printf("  total=%lld\n", t[s][8] - t[s][0]);
-      printf("    C detail: ctxcopy=%lld mfma=%lld addnorm=%lld bar=%lld acopy=%lld toD=%lld\n", t[s][9]-t[s][4], t[s][10]-t[s][9], t[s][11]-t[s][10], t[s][12]-t[s][11], t[s][13]-t[s][12], t[s][5]-t[s][13]);
+      if (s == 0) printf("    C detail (last add_norm call = stage E of last layer for 10-14): mfma=%lld | E: elementwise=%lld bar1=%lld mean=%lld bar2=%lld var+bar3=%lld\n", t[s][9]-t[s][4], t[s][10]-t[s][7], t[s][11]-t[s][10], t[s][12]-t[s][11], t[s][13]-t[s][12], t[s][14]-t[s][13]);
     }
   }
   return 0;

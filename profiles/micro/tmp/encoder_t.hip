@@ -33,6 +33,12 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_e;
 // the GEMM stages are fully unrolled (their weight fragments are register arrays with static indices); without a fence per k-step the
 // scheduler hoists every LDS fragment read of a stage to its top and spills hundreds of registers
 #define KSTEP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef ENC_TIMING
+extern __device__ long long enc_ticks[2][16];
+#define AN_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) enc_ticks[0][i] = wall_clock64(); } while (0)
+#else
+#define AN_MARK(i)
+#endif
 
 struct EncLayer {
   const bf16* Wqkv; const float* bqkv;                                   // [3H, H] (q | k | v rows), [3H]
@@ -79,16 +85,8 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ float g16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float g16_max(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
+__device__ __forceinline__ float g16_sum(float v) { return row16_sum(v); }
+__device__ __forceinline__ float g16_max(float v) { return row16_max(v); }
 
 // out[row][w*16 + c16] = LayerNorm_row(acc + bias (dropped) + residual) for the workgroup's NRT*16 rows; every wave owns 16 of the
 // 128 columns, row statistics go through LDS (two passes: mean, then centred variance -- as linear_ln_kernel).
@@ -109,6 +107,7 @@ __device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, cons
       acc[i][r] = v;
       s[i][r] = g16_sum(v);
     }
+  AN_MARK(10);
   if (c16 == 0) {
 #pragma unroll
     for (int i = 0; i < NRT; ++i)
@@ -116,6 +115,7 @@ __device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, cons
       for (int r = 0; r < 4; ++r) red[w * MAXROWS + i * 16 + 4 * g + r] = s[i][r];
   }
   __syncthreads();
+  AN_MARK(11);
   float mean[NRT][4];
 #pragma unroll
   for (int i = 0; i < NRT; ++i)
@@ -127,7 +127,9 @@ __device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, cons
       for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * MAXROWS + rr];
       mean[i][r] = t * (1.0f / EH);
     }
+  AN_MARK(12);
   __syncthreads();
+  AN_MARK(13);
 #pragma unroll
   for (int i = 0; i < NRT; ++i)
 #pragma unroll
@@ -150,6 +152,7 @@ __device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, cons
       float t = 0.f;
 #pragma unroll
       for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * MAXROWS + rr];
+      if (i == 0 && r == 0) AN_MARK(14);
       const float rstd = rsqrtf(t * (1.0f / EH) + eps);
       const bf16 y = from_f<bf16>((acc[i][r] - mean[i][r]) * rstd * gv + btv);
       sOut[rr * XS + col] = (rr < N) ? y : (bf16)0.0f;        // rows past the sample stay zero (they feed the next GEMM as padding)
@@ -398,17 +401,14 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
         KSTEP_FENCE();
       }
       asm volatile("" :: "v"(acc[0][0]));
-      ENC_MARK(10);
+      ENC_MARK(9);
       dd.site = L.site_ao; dd.p = p.p_hidden;
       const DropState dsh = drop_init(dd);
       // the first statistics barrier inside add_norm also orders "every wave has read the context image" before it is overwritten
       add_norm<NRT>(acc, pb_o, pg_1, pe_1, sX, red, sA, L.rstd_a, N, row_base, p.eps, dsh, w, lane);
     }
-    ENC_MARK(11);
     __syncthreads();                              // sA = attention-block output, complete
-    ENC_MARK(12);
     copy_out(sA, XS, L.a + row_base * EH, EH, N, EH, tid);
-    ENC_MARK(13);
     ENC_MARK(5);
     // ================= D: z = a W1^T + bi ; g = gelu(z) : 32 column tiles, 4 per wave =================
     bf16x8 w2[16];
@@ -540,5 +540,462 @@ extern "C" int magic_encoder_fwd(const void* params, int nbytes, void* stream) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)encoder_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_set = true; }
   hipLaunchKernelGGL(encoder_fwd_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+// =====================================================================================================================================
+// Cross-modal encoders in ONE launch: the global (map) and local (viewpoint) co-attention encoders of MAGIC-S, 3 METER BertCrossLayer
+// blocks each (self-attention [+ graph-distance bias] -> cross-attention to the context (the instruction; or, for the MLM path, the
+// text attending to the map) -> FFN), one 512-thread workgroup per sample for all layers of its encoder.  Same construction as
+// encoder_fwd_kernel above: activations resident in LDS, weights streamed from L2 as MFMA B-fragments, and the workgroup writes what
+// the per-op backward kernels read (self: qkv, P [+Pd], ctx, a, rstd_a; cross: q, kv, P [+Pd], ctx, c, rstd_c; FFN: z, g, out, rstd).
+// Queries <= 80 rows (NRT tiles), context <= 80 rows; the context's key/value projection reads the context rows straight from
+// global memory as MFMA A-fragments (they are layer-invariant and used by one GEMM per layer, not worth 21 KB of LDS).
+// =====================================================================================================================================
+struct XLayer {
+  const bf16* Wqkv; const float* bqkv; const bf16* Wo; const float* bo; const float* g1; const float* be1;          // attention.*
+  const bf16* Wq; const float* bq; const bf16* Wkv; const float* bkv;                                               // crossattention.self (q | k,v adjacent)
+  const bf16* Woc; const float* boc; const float* gc; const float* bec;                                             // crossattention.output
+  const bf16* W1; const float* bi; const bf16* W2; const float* bo2; const float* g2; const float* be2;             // intermediate / output
+  bf16 *qkv, *P, *Pd, *ctx, *a; float* rstd_a;                      // self-attention block
+  bf16 *q, *kv, *Pc, *Pdc, *cctx, *c; float* rstd_c;                // cross-attention block
+  bf16 *z, *g, *out; float* rstd_o;                                 // FFN
+  unsigned site_attn, site_ao, site_cattn, site_co, site_out, pad_;
+};
+struct XSeg {
+  const bf16* x; const bf16* cx;                                    // queries [nsamp*Nq, H], context [nsamp*Nk, H]
+  const unsigned char* qmask; const unsigned char* cmask;           // [nsamp, Nq], [nsamp, Nk]  (1 = valid)
+  const float* dist; const float* sprel_w; const float* sprel_b;    // graph-distance bias of the self-attention (global encoder) or null
+  int nsamp, Nq, Nk, ldps, ldpc, nlayers;
+  XLayer L[3];
+};
+struct XParams { XSeg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; };
+
+// one attention unit: this wave's 16 query rows (tile rt) of head h against NKT key tiles of the Q|K|V image; writes the clean (and,
+// under dropout, the dropped) probabilities and the 16 x 64 context tile into sCtx
+template <int NKT>
+__device__ __forceinline__ void attn_unit(const bf16* sQKV, bf16* sPw, bf16* sCtx, bf16* Pg0, bf16* Pdg0, const int h, const int rt, const int Nq,
+                                          const int Nk, const int ldp, const float (&kbias)[NKT], const float* dist, const float sw, const float sb,
+                                          const long long samp, const float scale, const DropState& dsa, const int lane) {
+  const int g = lane >> 4, c16 = lane & 15;
+  const int NKP = (Nk + 31) / 32 * 32;
+  f32x4 sc[NKT];
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) sc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const bf16x8 a = lfrag(sQKV, QS, rt * 16, h * EHD + ks * 32, lane);
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) sc[j] = emma(a, lfrag(sQKV, QS, j * 16, EH + h * EHD + ks * 32, lane), sc[j]);
+  }
+  float mx[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) {
+    const int key = j * 16 + c16;
+    const bool kv = key < Nk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = sc[j][r] * scale + kbias[j];
+      if (dist && kv) { const int qrow = min(rt * 16 + 4 * g + r, Nq - 1); x += sw * dist[((long long)samp * Nq + qrow) * Nk + key] + sb; }
+      x = kv ? x : -3.0e38f;
+      sc[j][r] = x; mx[r] = fmaxf(mx[r], x);
+    }
+  }
+  float sum[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { mx[r] = g16_max(mx[r]); sum[r] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) {
+    const bool kv = (j * 16 + c16) < Nk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float e = kv ? __expf(sc[j][r] - mx[r]) : 0.f; sc[j][r] = e; sum[r] += e; }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sum[r] = 1.0f / g16_sum(sum[r]);
+#pragma unroll
+  for (int j = 0; j < NKT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sPw[(4 * g + r) * PSW + j * 16 + c16] = from_f<bf16>(sc[j][r] * sum[r]);
+  if (NKT * 16 < NKP) {
+    for (int id = lane; id < 16 * (NKP - NKT * 16); id += 64) {
+      const int r = id / (NKP - NKT * 16), c = NKT * 16 + id % (NKP - NKT * 16);
+      sPw[r * PSW + c] = (bf16)0.0f;
+    }
+  }
+  wave_lds_sync();
+  const int nq = min(16, Nq - rt * 16);
+  {
+    bf16* Pg = Pg0 + (((long long)samp * ENH + h) * Nq + rt * 16) * ldp;
+    const int cpr = ldp / 8;
+    for (int id = lane; id < nq * cpr; id += 64) {
+      const int r = id / cpr, c = (id % cpr) * 8;
+      *(bf16x8*)(Pg + (long long)r * ldp + c) = *(const bf16x8*)(sPw + r * PSW + c);
+    }
+  }
+  if (dsa.on) {
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int key = j * 16 + c16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 4 * g + r;
+        const unsigned idx = (unsigned)(((((long long)samp * ENH + h) * Nq + rt * 16 + ql) * Nk) + key);
+        const float m = (ql < nq && key < Nk) ? drop_mul(dsa, idx) : 0.f;
+        sPw[ql * PSW + key] = from_f<bf16>(sc[j][r] * sum[r] * m);
+      }
+    }
+    wave_lds_sync();
+    if (Pdg0) {
+      bf16* Pg = Pdg0 + (((long long)samp * ENH + h) * Nq + rt * 16) * ldp;
+      const int cpr = ldp / 8;
+      for (int id = lane; id < nq * cpr; id += 64) {
+        const int r = id / cpr, c = (id % cpr) * 8;
+        *(bf16x8*)(Pg + (long long)r * ldp + c) = *(const bf16x8*)(sPw + r * PSW + c);
+      }
+    }
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int jd = 0; jd < 4; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < NKP / 32; ++ks) {
+    const bf16x8 a = lfrag(sPw, PSW, 0, ks * 32, lane);
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd) o[jd] = emma(a, tfrag(sQKV + 2 * EH + h * EHD, QS, jd * 16, ks * 32, lane), o[jd]);
+  }
+#pragma unroll
+  for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sCtx[(rt * 16 + 4 * g + r) * XS + h * EHD + jd * 16 + c16] = from_f<bf16>(o[jd][r]);
+}
+
+// one 16-column output tile per wave: acc[i] = sIn[rows of tile i] . W[w*16 .. +16]^T over K = 128
+template <int NRT>
+__device__ __forceinline__ void proj16(f32x4 (&acc)[NRT], const bf16* sIn, const bf16x8 (&wf)[4], const int lane) {
+#pragma unroll
+  for (int i = 0; i < NRT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) acc[i] = emma(lfrag(sIn, XS, i * 16, ks * 32, lane), wf[ks], acc[i]);
+    KSTEP_FENCE();
+  }
+}
+
+template <int NRT>
+__device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, const int samp, unsigned char* smem) {
+  constexpr int NKT = 5;                         // context key tiles (<= 80 rows); unused tiles cost a few MFMAs on zeros
+  bf16* sX = (bf16*)smem;                        // [80][XS]   layer input x; later the cross context image / c / the block output
+  bf16* sA = sX + MAXROWS * XS;                  // [80][XS]   self-attention context, then a (attention-block output)
+  bf16* sQKV = sA + MAXROWS * XS;                // [96][QS]   Q | K | V of the self-attention, then Q | K,V(context) of the cross-attention
+  bf16* sP = sQKV + KROWS * QS;
+  bf16* sG = sQKV;
+  float* red = (float*)(sP + NWAVE * 16 * PSW);
+  const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Nq = sg.Nq, Nk = sg.Nk;
+  const long long qbase = (long long)samp * Nq, kbase = (long long)samp * Nk;
+  constexpr int ROWS = NRT * 16;
+  {
+    const bf16* x = sg.x + qbase * EH;
+    for (int id = tid; id < ROWS * (EH / 8); id += NWAVE * 64) {
+      const int r = id / (EH / 8), c = (id % (EH / 8)) * 8;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16)0.0f;
+      if (r < Nq) v = *(const bf16x8*)(x + (long long)r * EH + c);
+      *(bf16x8*)(sX + r * XS + c) = v;
+    }
+  }
+  DropDesc dd;
+  dd.seed = p.seed;
+  float qbias[NRT], cbias[NKT];
+#pragma unroll
+  for (int j = 0; j < NRT; ++j) {
+    const int key = j * 16 + (lane0 & 15);
+    qbias[j] = (key < Nq && sg.qmask && !sg.qmask[qbase + key]) ? -10000.0f : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) {
+    const int key = j * 16 + (lane0 & 15);
+    cbias[j] = (key < Nk && sg.cmask && !sg.cmask[kbase + key]) ? -10000.0f : 0.f;
+  }
+  const float sw = sg.dist ? sg.sprel_w[0] : 0.f, sb = sg.dist ? sg.sprel_b[0] : 0.f;
+  for (int l = 0; l < sg.nlayers; ++l) {
+    const XLayer& L = sg.L[l];
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, c16 = lane & 15;
+    const int colw = w * 16 + c16;
+    float pb_qkv[3], pb_ffn[4], pb_kv[2];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) pb_qkv[ct] = L.bqkv[(3 * w + ct) * 16 + c16];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) pb_ffn[ct] = L.bi[(4 * w + ct) * 16 + c16];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) pb_kv[ct] = L.bkv[(2 * w + ct) * 16 + c16];
+    const float pb_o = L.bo[colw], pg_1 = L.g1[colw], pe_1 = L.be1[colw], pb_q = L.bq[colw];
+    const float pb_oc = L.boc[colw], pg_c = L.gc[colw], pe_c = L.bec[colw];
+    const float pb_2 = L.bo2[colw], pg_2 = L.g2[colw], pe_2 = L.be2[colw];
+    // ================= self-attention: Q|K|V =================
+    bf16x8 bw[3][4];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bw[ct][ks] = gfrag(L.Wqkv, EH, (3 * w + ct) * 16, ks * 32, lane);
+    for (int id = tid; id < (KROWS - ROWS) * (384 / 8); id += NWAVE * 64) {
+      const int r = ROWS + id / 48, c = (id % 48) * 8;
+      bf16x8 zv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) zv[e] = (bf16)0.0f;
+      *(bf16x8*)(sQKV + r * QS + c) = zv;
+    }
+    __syncthreads();
+    {
+      f32x4 acc[NRT][3];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+          const bf16x8 a = lfrag(sX, XS, i * 16, ks * 32, lane);
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) acc[i][ct] = emma(a, bw[ct][ks], acc[i][ct]);
+        }
+        KSTEP_FENCE();
+      }
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) {
+        const int col = (3 * w + ct) * 16 + c16;
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sQKV[(i * 16 + 4 * g + r) * QS + col] = from_f<bf16>(acc[i][ct][r] + pb_qkv[ct]);
+      }
+    }
+    bf16x8 wo[4], wq[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { wo[ks] = gfrag(L.Wo, EH, w * 16, ks * 32, lane); wq[ks] = gfrag(L.Wq, EH, w * 16, ks * 32, lane); }
+    __syncthreads();
+    copy_out(sQKV, QS, L.qkv + qbase * 3 * EH, 3 * EH, Nq, 3 * EH, tid);
+    dd.site = L.site_attn; dd.p = p.p_attn;
+    const DropState dsa = drop_init(dd);
+    bf16* sPw = sP + w * 16 * PSW;
+    for (int u = w; u < ENH * NRT; u += NWAVE)
+      attn_unit<NRT>(sQKV, sPw, sA, L.P, L.Pd, u / NRT, u % NRT, Nq, Nq, sg.ldps, qbias, sg.dist, sw, sb, samp, p.scale, dsa, lane);
+    __syncthreads();                              // self-attention context complete (sA)
+    copy_out(sA, XS, L.ctx + qbase * EH, EH, Nq, EH, tid);
+    {
+      f32x4 acc[NRT];
+      proj16<NRT>(acc, sA, wo, lane);
+      dd.site = L.site_ao; dd.p = p.p_hidden;
+      const DropState dsh = drop_init(dd);
+      add_norm<NRT>(acc, pb_o, pg_1, pe_1, sX, red, sA, L.rstd_a, Nq, qbase, p.eps, dsh, w, lane);
+    }
+    // context key / value projection weights: 2 column tiles per wave (K|V = 256 columns)
+    bf16x8 wkv[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) wkv[ct][ks] = gfrag(L.Wkv, EH, (2 * w + ct) * 16, ks * 32, lane);
+    __syncthreads();                              // sA = a (self-attention block output); every wave is done with the Q|K|V image
+    copy_out(sA, XS, L.a + qbase * EH, EH, Nq, EH, tid);
+    // ================= cross-attention: Q from a, K|V from the context rows (global) =================
+    {
+      f32x4 acc[NRT];
+      proj16<NRT>(acc, sA, wq, lane);
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sQKV[(i * 16 + 4 * g + r) * QS + colw] = from_f<bf16>(acc[i][r] + pb_q);
+    }
+    {
+      f32x4 acc[NKT][2];
+#pragma unroll
+      for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const bf16* cx = sg.cx + kbase * EH;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) {
+          const int row = min(i * 16 + c16, Nk - 1);                 // rows past the context: any valid row (their keys are masked out below)
+          const bf16x8 a = *(const bf16x8*)(cx + (long long)row * EH + ks * 32 + 8 * g);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) acc[i][ct] = emma(a, wkv[ct][ks], acc[i][ct]);
+        }
+        KSTEP_FENCE();
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int col = EH + (2 * w + ct) * 16 + c16;
+#pragma unroll
+        for (int i = 0; i < NKT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = i * 16 + 4 * g + r;
+            sQKV[row * QS + col] = (row < Nk) ? from_f<bf16>(acc[i][ct][r] + pb_kv[ct]) : (bf16)0.0f;     // rows >= Nk: zero (PV pads)
+          }
+      }
+    }
+    // rows NKT*16 .. 95 of the K|V columns: zero (the self-attention's zero rows may have been overwritten only below ROWS)
+    for (int id = tid; id < (KROWS - NKT * 16) * (256 / 8); id += NWAVE * 64) {
+      const int r = NKT * 16 + id / 32, c = EH + (id % 32) * 8;
+      bf16x8 zv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) zv[e] = (bf16)0.0f;
+      *(bf16x8*)(sQKV + r * QS + c) = zv;
+    }
+    bf16x8 woc[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) woc[ks] = gfrag(L.Woc, EH, w * 16, ks * 32, lane);
+    bf16x8 w1[4][4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) w1[ct][ks] = gfrag(L.W1, EH, (4 * w + ct) * 16, ks * 32, lane);
+    __syncthreads();                              // cross Q | K,V image complete
+    // q [Nq, H] and kv [Nk, 2H] for the backward
+    copy_out(sQKV, QS, L.q + qbase * EH, EH, Nq, EH, tid);
+    copy_out(sQKV + EH, QS, L.kv + kbase * 2 * EH, 2 * EH, Nk, 2 * EH, tid);
+    dd.site = L.site_cattn; dd.p = p.p_attn;
+    const DropState dsc = drop_init(dd);
+    for (int u = w; u < ENH * NRT; u += NWAVE)
+      attn_unit<NKT>(sQKV, sPw, sX, L.Pc, L.Pdc, u / NRT, u % NRT, Nq, Nk, sg.ldpc, cbias, nullptr, 0.f, 0.f, samp, p.scale, dsc, lane);
+    __syncthreads();                              // cross context complete (sX; the layer input there is dead since the first add&norm)
+    copy_out(sX, XS, L.cctx + qbase * EH, EH, Nq, EH, tid);
+    {
+      f32x4 acc[NRT];
+      proj16<NRT>(acc, sX, woc, lane);
+      dd.site = L.site_co; dd.p = p.p_hidden;
+      const DropState dsh = drop_init(dd);
+      add_norm<NRT>(acc, pb_oc, pg_c, pe_c, sA, red, sX, L.rstd_c, Nq, qbase, p.eps, dsh, w, lane);
+    }
+    __syncthreads();                              // sX = c (cross-attention block output)
+    copy_out(sX, XS, L.c + qbase * EH, EH, Nq, EH, tid);
+    // ================= FFN =================
+    bf16x8 w2[16];
+    {
+      f32x4 acc[NRT][4];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+          const bf16x8 a = lfrag(sX, XS, i * 16, ks * 32, lane);
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) acc[i][ct] = emma(a, w1[ct][ks], acc[i][ct]);
+        }
+        KSTEP_FENCE();
+      }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) w2[ks] = gfrag(L.W2, EI, w * 16, ks * 32, lane);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int col = (4 * w + ct) * 16 + c16;
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[i][ct][r] += pb_ffn[ct];
+            sG[(i * 16 + 4 * g + r) * GS + col] = from_f<bf16>(acc[i][ct][r]);
+          }
+      }
+      __syncthreads();
+      copy_out(sG, GS, L.z + qbase * EI, EI, Nq, EI, tid);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][ct][r] = gelu_fast(acc[i][ct][r]);
+      __syncthreads();
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int col = (4 * w + ct) * 16 + c16;
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sG[(i * 16 + 4 * g + r) * GS + col] = from_f<bf16>(acc[i][ct][r]);
+      }
+    }
+    __syncthreads();
+    copy_out(sG, GS, L.g + qbase * EI, EI, Nq, EI, tid);
+    {
+      f32x4 acc[NRT];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) acc[i] = emma(lfrag(sG, GS, i * 16, ks * 32, lane), w2[ks], acc[i]);
+        if ((ks & 1) == 1) KSTEP_FENCE();
+      }
+      dd.site = L.site_out; dd.p = p.p_hidden;
+      const DropState dsh = drop_init(dd);
+      // residual = c (sX), output -> sX: every wave has added its residual values before add_norm's first barrier
+      add_norm<NRT>(acc, pb_2, pg_2, pe_2, sX, red, sX, L.rstd_o, Nq, qbase, p.eps, dsh, w, lane);
+    }
+    __syncthreads();
+    copy_out(sX, XS, L.out + qbase * EH, EH, Nq, EH, tid);
+  }
+}
+
+__global__ __launch_bounds__(512) void xencoder_fwd_kernel(XParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char enc_smem[];
+  int b = blockIdx.x, s = 0;
+  if (b >= p.seg[0].nsamp) { b -= p.seg[0].nsamp; s = 1; }
+  const XSeg& sg = p.seg[s];
+  const int nrt = max(2, (sg.Nq + 15) / 16);
+  switch (nrt) {
+    case 2: xenc_body<2>(p, sg, b, enc_smem); break;
+    case 3: xenc_body<3>(p, sg, b, enc_smem); break;
+    case 4: xenc_body<4>(p, sg, b, enc_smem); break;
+    default: xenc_body<5>(p, sg, b, enc_smem); break;
+  }
+}
+
+extern "C" int magic_xencoder_supported(int dtype, int H, int I, int nh, int Nq, int Nk, int nlayers) {
+  return dtype == DT_BF16 && H == EH && I == EI && nh == ENH && Nq >= 1 && Nq <= MAXROWS && Nk >= 1 && Nk <= MAXROWS && nlayers >= 1 && nlayers <= 3;
+}
+extern "C" int magic_xencoder_params_bytes() { return (int)sizeof(XParams); }
+
+extern "C" int magic_xencoder_fwd(const void* params, int nbytes, void* stream) {
+  if (!params || nbytes != (int)sizeof(XParams)) return MAGIC_ERR_ARG;
+  XParams p;
+  memcpy(&p, params, sizeof(p));
+  if (p.nseg < 1 || p.nseg > 2) return MAGIC_ERR_ARG;
+  if (!drop_args_ok(p.seed, p.p_attn) || !drop_args_ok(p.seed, p.p_hidden)) return MAGIC_ERR_ARG;
+  int blocks = 0;
+  for (int s = 0; s < 2; ++s) {
+    XSeg& sg = p.seg[s];
+    if (s >= p.nseg) { sg.nsamp = 0; continue; }
+    if (sg.nsamp <= 0 || sg.Nq < 1 || sg.Nq > MAXROWS || sg.Nk < 1 || sg.Nk > MAXROWS || sg.nlayers < 1 || sg.nlayers > 3 || !sg.x || !sg.cx) return MAGIC_ERR_ARG;
+    if (sg.ldps < sg.Nq || (sg.ldps & 7) || sg.ldps > KROWS || sg.ldpc < sg.Nk || (sg.ldpc & 7) || sg.ldpc > KROWS) return MAGIC_ERR_ARG;
+    if ((long long)sg.nsamp * ENH * sg.Nq * MAXROWS > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+    if (((uintptr_t)sg.x & 15) || ((uintptr_t)sg.cx & 15)) return MAGIC_ERR_ARG;
+    if (sg.dist && (!sg.sprel_w || !sg.sprel_b)) return MAGIC_ERR_ARG;
+    for (int l = 0; l < sg.nlayers; ++l) {
+      const XLayer& L = sg.L[l];
+      const void* req[] = {L.Wqkv, L.bqkv, L.Wo, L.bo, L.g1, L.be1, L.Wq, L.bq, L.Wkv, L.bkv, L.Woc, L.boc, L.gc, L.bec, L.W1, L.bi, L.W2, L.bo2, L.g2, L.be2,
+                           L.qkv, L.P, L.ctx, L.a, L.rstd_a, L.q, L.kv, L.Pc, L.cctx, L.c, L.rstd_c, L.z, L.g, L.out, L.rstd_o};
+      for (const void* q : req)
+        if (!q) return MAGIC_ERR_ARG;
+      const void* al[] = {L.Wqkv, L.Wo, L.Wq, L.Wkv, L.Woc, L.W1, L.W2, L.qkv, L.P, L.Pd, L.ctx, L.a, L.q, L.kv, L.Pc, L.Pdc, L.cctx, L.c, L.z, L.g, L.out};
+      for (const void* q : al)
+        if ((uintptr_t)q & 15) return MAGIC_ERR_ARG;
+      if (p.p_attn > 0.f && (!L.Pd || !L.Pdc)) return MAGIC_ERR_ARG;
+    }
+    blocks += sg.nsamp;
+  }
+  const size_t shm = enc_lds_bytes();
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)xencoder_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_set = true; }
+  hipLaunchKernelGGL(xencoder_fwd_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
   return launch_status();
 }

@@ -279,8 +279,12 @@ def parity_block(dev):
     models = PP.oracle_models()
     out = {"checker": "fp64 CPU oracle (oracle/model_ref.py, a restatement: the reference withholds its model source), same weights and batches",
            "north_star": {"max_abs_logit_delta": 1e-3, "argmax_agreement": 1.0}}
-    for name, dt_ in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
-        st = PP.sap_parity(dt_, batch_size=8, seeds=(1234, 77, 5), device=dev, models=models)
+    for name, dt_ in (("bf16", torch.bfloat16), ("fp32", torch.float32), ("bf16x3", torch.float32)):
+        prev = L.set_f32_mfma("bf16x3" if name == "bf16x3" else "exact")
+        try:
+            st = PP.sap_parity(dt_, batch_size=8, seeds=(1234, 77, 5), device=dev, models=models)
+        finally:
+            L.set_f32_mfma(prev)
         out[name] = {"max_abs_logit_delta": float(f"{st['max_abs_logit_delta']:.3e}"), "argmax_agreement": st["argmax_agreement"],
                      "rows": st["rows"], "loss_rel_delta": float(f"{st['loss_rel_delta']:.2e}"),
                      "oracle_min_top2_gap": float(f"{st['oracle_min_top2_gap']:.2e}")}
@@ -483,8 +487,24 @@ def main():
         nm = {torch.bfloat16: "bf16", torch.float32: "fp32"}
         modes = {nm[dtype]: {"ms_per_step": round(dt / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj / dt, 1)},
                  nm[other]: {"ms_per_step": round(dt2 / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj2 / dt2, 1)},
-                 "note": "same graphs, batches and schedule; fp32 = v_mfma_f32_16x16x4_f32 (exact), fp32 activations"}
-        del g2, t2, s2, tr2
+                 "note": "same batches and schedule, one HIP graph per batch each; fp32 = fp32 storage + exact v_mfma_f32_16x16x4_f32; bf16x3 = fp32 "
+                         "storage, every GEMM contraction as three bf16 MFMAs on the hi + lo halves of the fp32 operands (lib.set_f32_mfma)"}
+        del g2, tr2
+        # third mode: fp32 storage with the split-bf16 contraction (graphs re-captured: the mode is read by the kernels at run time, but a
+        # fresh capture keeps the measurement independent of the previous one)
+        prev = L.set_f32_mfma("bf16x3")
+        try:
+            _, _, t3, s3, tr3 = build_models(torch.float32, dev, a.dropout, world, a.batch)
+            eager_runner(tr3)(min(3, len(pool)))
+            torch.cuda.synchronize()
+            g3 = capture_ring(tr3, pool, a.teacher)
+            torch.cuda.synchronize()
+            traj3, dt3 = timed_region(graph_runner(tr3, g3), a.steps, a.warmup, world, dev)
+            modes["bf16x3"] = {"ms_per_step": round(dt3 / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj3 / dt3, 1)}
+            del g3, t3, s3, tr3
+        finally:
+            L.set_f32_mfma(prev)
+        del t2, s2
         parity = parity_block(dev)
 
     cpu = None
@@ -514,6 +534,8 @@ def main():
             info["bf16_max_logit_delta"] = parity["bf16"]["max_abs_logit_delta"]
             info["argmax_agreement"] = parity["bf16"]["argmax_agreement"]
             info["fp32_mode_ms_per_step"] = modes["fp32"]["ms_per_step"]
+            info["bf16x3_mode_ms_per_step"] = modes["bf16x3"]["ms_per_step"]
+            info["bf16x3_max_logit_delta"] = parity["bf16x3"]["max_abs_logit_delta"]
         print(json.dumps(info))
     if world > 1:
         dist.destroy_process_group()

@@ -216,6 +216,13 @@ int magic_rowblock_lds_bytes(int dtype, int wn, int ww);
 int magic_rowblock_fwd(int dtype, int M, const void* X, int ldx, int K0, int nstage, const magic_rb_stage* stages,
                        const void* drop_seed, float drop_p, void* stream);
 
+/* Contraction arithmetic of the fp32 storage mode (dtype 0) in magic_gemm / magic_gemm_dw_grouped / magic_linear_ln /
+ * magic_linear_lnbwd: mode 0 = the exact v_mfma_f32_16x16x4_f32 (default); mode 1 = "bf16x3": every fp32 operand split into
+ * bf16 hi + lo, a.b = a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~2^-17 relative error
+ * per product, 3/16 of the matrix-pipe time).  Process-wide, synchronous; set it before capturing graphs. */
+int magic_set_f32_mfma(int mode);
+int magic_get_f32_mfma(void);
+
 /* Whole self-attention encoders in one launch (csrc/encoder.hip): the 6-block text encoder and the 2-block panorama encoder of
  * MAGIC-S (the withheld model's `bert.lang_encoder` / `img_embeddings.pano_encoder`; HF BertLayer x n), one
  * 512-thread workgroup per sample for all layers, activations resident in LDS, weights streamed from L2 as MFMA B-fragments.

@@ -115,3 +115,19 @@ def test_bf16_engine_gradients_track_oracle_at_full_size(models, task):
         a, b = got["outputs"]["predict"].float().cpu(), want["outputs"]["predict"].float()
         agree = (a.argmax(1) == b.argmax(1)).float().mean().item()
         print(f"bf16 mlm token argmax agreement {agree:.4f}, max |delta| {(a - b).abs().max().item():.3e}")
+
+
+def test_fp32_storage_with_split_bf16_contraction_meets_the_north_star_bar(models):
+    """"bf16x3": fp32 activations / weights / epilogues, every GEMM contraction as three bf16 MFMAs on hi + lo halves of the fp32
+    operands (lib.set_f32_mfma('bf16x3')).  Same full-size check as the exact-fp32 engine, to the NORTH-STAR bar itself (argmax
+    identical, |delta logit| < 1e-3) -- at roughly half the step time of the exact fp32 MFMA (bench.py `modes`)."""
+    from magic_amd.host import lib as L
+    prev = L.set_f32_mfma("bf16x3")
+    try:
+        st = PP.sap_parity(torch.float32, batch_size=8, seeds=(1234, 77, 5), models=models)
+    finally:
+        L.set_f32_mfma(prev)
+    print("bf16x3 full-size:", json.dumps(st))
+    assert st["same_inf_mask"] and st["argmax_agreement"] == 1.0
+    assert st["max_abs_logit_delta"] < 1e-3, st
+    assert st["loss_rel_delta"] < 1e-3 and st["kdl_rel_delta"] < 1e-3, st

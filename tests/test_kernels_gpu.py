@@ -616,3 +616,31 @@ def test_deferred_weight_gradients_many_problems_per_launch(dtype):
         check(dW, rW, f"dW[{i}]", **t)
         if db is not None:
             check(db, rb, f"db[{i}]", **t)
+
+
+@pytest.mark.parametrize("layout,M,N,K", [(0, 200, 384, 128), (1, 77, 128, 512), (2, 96, 132, 300), (0, 64, 64, 1000)])
+def test_fp32_gemm_split_bf16_contraction(layout, M, N, K):
+    """magic_set_f32_mfma(1): fp32 operands, a.b = a_hi b_hi + a_hi b_lo + a_lo b_hi on the bf16 matrix cores.  Against fp64: relative
+    error ~1e-5 of sum |a||b| (exact fp32 MFMA: ~1e-7; single bf16 operands: ~4e-3)."""
+    from magic_amd.host import lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    rnd = lambda *s_: torch.randn(*s_, generator=g).to(DEV)
+    if layout == 0:
+        A, B = rnd(M, K), rnd(N, K); ref = A.double() @ B.double().t(); lda, ldb = K, K
+    elif layout == 1:
+        A, B = rnd(M, K), rnd(K, N); ref = A.double() @ B.double(); lda, ldb = K, N
+    else:
+        A, B = rnd(K, M), rnd(K, N); ref = A.double().t() @ B.double(); lda, ldb = M, N
+    scale = (A.abs().double().mean() * B.abs().double().mean() * K).item()
+    errs = {}
+    for mode in ("exact", "bf16x3"):
+        prev = L.set_f32_mfma(mode)
+        try:
+            C = torch.empty(M, N, device=DEV)
+            O.gemm(layout, A, B, C, M, N, K, lda, ldb, N)
+            torch.cuda.synchronize()
+        finally:
+            L.set_f32_mfma(prev)
+        errs[mode] = (C.double() - ref).abs().max().item() / scale
+    assert errs["exact"] < 5e-6 and errs["bf16x3"] < 2e-4, errs
+    assert errs["bf16x3"] > 0                      # the split path really ran (it is not bit-identical to the exact instruction)

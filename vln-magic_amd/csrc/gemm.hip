@@ -150,6 +150,64 @@ __device__ __forceinline__ void mma_tile(const float* sA, const float* sB, int w
   }
 }
 
+// ---- fp32 operands on the bf16 matrix cores ("bf16x3") --------------------------------------------------------------------------
+// An fp32 value splits exactly into hi = bf16(x) and lo = bf16(x - hi) (+ a remainder below 2^-17 |x|); a product of two such values is
+// a_hi b_hi + a_hi b_lo + a_lo b_hi (+ a_lo b_lo ~ 2^-18, dropped): three v_mfma_f32_16x16x32_bf16 with fp32 accumulation instead of
+// eight v_mfma_f32_16x16x4_f32 per 32-deep k-step -- 3/16 of the matrix-pipe time of the exact fp32 instruction at ~2^-17 relative
+// error per product (the exact fp32 MFMA: 2^-24; plain bf16 operands: 2^-9).  Selected at run time for the fp32 ("parity") storage
+// mode by magic_set_f32_mfma(1): activations, weights and every epilogue stay fp32, only the contraction changes.
+__device__ int g_f32_x3 = 0;
+static int g_f32_x3_host = 0;
+extern "C" int magic_set_f32_mfma(int mode) {
+  if (mode != 0 && mode != 1) return MAGIC_ERR_ARG;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_f32_x3), &mode, sizeof(int)) != hipSuccess) return MAGIC_ERR_LAUNCH;
+  g_f32_x3_host = mode;
+  return MAGIC_OK;
+}
+extern "C" int magic_get_f32_mfma() { return g_f32_x3_host; }
+
+__device__ __forceinline__ void split_x3(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bf16 h = (bf16)v[j];
+    hi[j] = h;
+    lo[j] = (bf16)(v[j] - (float)h);
+  }
+}
+// 16 out rows x 32 k of an fp32 LDS image as (hi, lo) bf16 fragments in the 16x16x32 operand layout (lane: row l&15, k = 8(l>>4) + j)
+template <bool KC, int SN_ = TT<float>::SN>
+__device__ __forceinline__ void frag_x3(const float* s, int out0, int lane, bf16x8& hi, bf16x8& lo) {
+  float v[8];
+  if constexpr (KC) {
+    const float2* q = (const float2*)(s + (out0 + (lane & 15)) * TT<float>::STRIDE + 8 * (lane >> 4));     // rows are 8-byte aligned
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float2 t = q[j]; v[2 * j] = t.x; v[2 * j + 1] = t.y; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = s[(8 * (lane >> 4) + j) * SN_ + out0 + (lane & 15)];
+  }
+  split_x3(v, hi, lo);
+}
+__device__ __forceinline__ f32x4 mma_x3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+template <bool A_KC, bool B_KC, int NT_>
+__device__ __forceinline__ void mma_tile_x3(const float* sA, const float* sB, int wr, int wc, int lane, f32x4 (&acc)[NT_][NT_]) {
+  constexpr int SN_ = TT<float>::SN + (32 * NT_ - 64);
+  bf16x8 ah[NT_], al[NT_], bh[NT_], bl[NT_];
+#pragma unroll
+  for (int i = 0; i < NT_; ++i) {
+    frag_x3<A_KC, SN_>(sA, (wr * NT_ + i) * 16, lane, ah[i], al[i]);
+    frag_x3<B_KC, SN_>(sB, (wc * NT_ + i) * 16, lane, bh[i], bl[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NT_; ++i)
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) acc[i][j] = mma_x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+}
+
 // LAYOUT 0: NT (A[M,K], B[N,K]); 1: NN (A[M,K], B[K,N]); 2: TN (A[K,M], B[K,N])
 // NT_: 16x16 MFMA tiles per wave per dimension.  2 -> the 64x64 block tile every small problem uses; 4 -> a 128x128 block tile
 // (64x64 per wave, 16 accumulator tiles) for problems with enough rows and columns: each workgroup then streams half the
@@ -170,6 +228,7 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, kg = threadIdx.x >> 8;
   const int wr = wid >> 1, wc = wid & 1;
   const int n0 = bx * TM, m0 = by * TM;
+  const bool x3 = (sizeof(T) == 4) && g_f32_x3 != 0;       // block-uniform (one scalar load)
   T* const sA0 = sA;
   if constexpr (KG > 1) { sA += kg * (TM * TT<T>::STRIDE); sB += kg * (TM * TT<T>::STRIDE); }
   const int bz = bzz / p.splitk, sk = bzz % p.splitk;
@@ -266,7 +325,12 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
           la[d].load(A, p.lda, m0, (kt0 + (r + d + PD) * KG + kg) * BK, p.M, kend);
           lb[d].load(B, p.ldb, n0, (kt0 + (r + d + PD) * KG + kg) * BK, p.N, kend);
         }
-        mma_tile<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc);
+        if constexpr (sizeof(T) == 4) {
+          if (x3) mma_tile_x3<A_KC, B_KC, NT_>((const float*)sA, (const float*)sB, wr, wc, lane, acc);
+          else mma_tile<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc);
+        } else {
+          mma_tile<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc);
+        }
         if (do_bgrad && tid < TM) {
           float s = 0.f;
 #pragma unroll 8
@@ -936,6 +1000,23 @@ __device__ __forceinline__ void linear_ln_body(const LlnParams& pp, const int bi
     store();
     __syncthreads();
     if (kt + 1 < ktiles) load((kt + 1) * BK);
+    bool done_x3 = false;
+    if constexpr (sizeof(T) == 4) {
+      if (g_f32_x3 != 0) {          // fp32 storage, split-bf16 contraction (one 32-deep step per tile)
+        bf16x8 a0h, a0l, a1h, a1l;
+        frag_x3<true>((const float*)sA, 0, lane, a0h, a0l);
+        frag_x3<true>((const float*)sA, 16, lane, a1h, a1l);
+#pragma unroll
+        for (int j = 0; j < HT; ++j) {
+          bf16x8 bh, bl;
+          frag_x3<true>((const float*)sB, w * WC + j * 16, lane, bh, bl);
+          acc[0][j] = mma_x3(a0h, a0l, bh, bl, acc[0][j]);
+          acc[1][j] = mma_x3(a1h, a1l, bh, bl, acc[1][j]);
+        }
+        done_x3 = true;
+      }
+    }
+    if (!done_x3) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const auto a0 = frag<true>(sA, 0, ks, lane), a1 = frag<true>(sA, 16, ks, lane);
@@ -950,6 +1031,7 @@ __device__ __forceinline__ void linear_ln_body(const LlnParams& pp, const int bi
           acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
         }
       }
+    }
     }
     __syncthreads();
   }
@@ -1173,6 +1255,23 @@ __device__ __forceinline__ void linear_lnb_body(const LlbParams& pp, const int b
     store();
     __syncthreads();
     if (kt + 1 < ktiles) load((kt + 1) * BK);
+    bool done_x3 = false;
+    if constexpr (sizeof(T) == 4) {
+      if (g_f32_x3 != 0) {          // fp32 storage, split-bf16 contraction; W tile is the natural [k][out] image
+        bf16x8 a0h, a0l, a1h, a1l;
+        frag_x3<true>((const float*)sA, 0, lane, a0h, a0l);
+        frag_x3<true>((const float*)sA, 16, lane, a1h, a1l);
+#pragma unroll
+        for (int j = 0; j < HT; ++j) {
+          bf16x8 bh, bl;
+          frag_x3<false, SN>((const float*)sB, w * WC + j * 16, lane, bh, bl);
+          acc[0][j] = mma_x3(a0h, a0l, bh, bl, acc[0][j]);
+          acc[1][j] = mma_x3(a1h, a1l, bh, bl, acc[1][j]);
+        }
+        done_x3 = true;
+      }
+    }
+    if (!done_x3) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const auto a0 = frag<true>(sA, 0, ks, lane), a1 = frag<true>(sA, 16, ks, lane);
@@ -1187,6 +1286,7 @@ __device__ __forceinline__ void linear_lnb_body(const LlbParams& pp, const int b
           acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
         }
       }
+    }
     }
     __syncthreads();
   }

@@ -61,6 +61,8 @@ SIGNATURES = {
     "magic_view_gather": [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp],
     "magic_rowblock_lds_bytes": [i32, i32, i32],
     "magic_rowblock_fwd": [i32, i32, vp, i32, i32, i32, vp, vp, f32, vp],
+    "magic_set_f32_mfma": [i32],
+    "magic_get_f32_mfma": [],
     "magic_encoder_supported": [i32, i32, i32, i32, i32, i32],
     "magic_encoder_params_bytes": [],
     "magic_encoder_fwd": [vp, i32, vp],
@@ -367,6 +369,19 @@ def lockstep(fn_a, fn_b):
     if "err" in box:
         raise box["err"]
     return a, box["b"]
+
+
+def set_f32_mfma(mode):
+    """contraction arithmetic of the fp32 storage mode: 'exact' (v_mfma_f32_16x16x4_f32) or 'bf16x3' (split-bf16, three bf16 MFMAs per
+    product, ~2^-17 relative error).  Process-wide; returns the previous mode."""
+    lib = load()
+    prev = "bf16x3" if lib.magic_get_f32_mfma() else "exact"
+    want = {"exact": 0, "bf16x3": 1}[mode]
+    torch.cuda.synchronize()
+    rc = lib.magic_set_f32_mfma(want)
+    if rc != 0:
+        raise MagicHipError(f"magic_set_f32_mfma failed: {_ERR.get(rc, rc)}")
+    return prev
 
 
 def dt(dtype):

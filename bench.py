@@ -285,9 +285,10 @@ def parity_block(dev):
             st = PP.sap_parity(dt_, batch_size=8, seeds=(1234, 77, 5), device=dev, models=models)
         finally:
             L.set_f32_mfma(prev)
-        out[name] = {"max_abs_logit_delta": float(f"{st['max_abs_logit_delta']:.3e}"), "argmax_agreement": st["argmax_agreement"],
+        out[name] = {"max_abs_logit_delta": float(f"{st['max_abs_logit_delta']:.3e}"), "argmax_agreement": round(st["argmax_agreement"], 4),
                      "rows": st["rows"], "loss_rel_delta": float(f"{st['loss_rel_delta']:.2e}"),
-                     "oracle_min_top2_gap": float(f"{st['oracle_min_top2_gap']:.2e}")}
+                     "oracle_min_top2_gap": float(f"{st['oracle_min_top2_gap']:.2e}"),
+                     "worst_oracle_gap_between_flipped_picks": float(f"{st['worst_flip_gap']:.2e}")}
     return out
 
 

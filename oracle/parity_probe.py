@@ -84,8 +84,14 @@ def logit_stats(got_outputs, want_outputs, keys=("global_logits", "local_logits"
         a, b = got_outputs[k].detach().double().cpu(), want_outputs[k].detach().double()
         same_inf = bool(torch.equal(torch.isinf(a), torch.isinf(b)))
         d = (torch.nan_to_num(a, neginf=0.0) - torch.nan_to_num(b, neginf=0.0)).abs().max().item()
-        agree = (a.argmax(1) == b.argmax(1)).double().mean().item()
-        r[k] = {"max_abs_delta": d, "argmax_agreement": agree, "same_inf_mask": same_inf, "rows": int(a.shape[0])}
+        ia, ib = a.argmax(1), b.argmax(1)
+        agree = (ia == ib).double().mean().item()
+        # where the picks differ: how far apart the ORACLE itself rates the two candidates (a pick can only flip inside a band of
+        # twice the logit error: got[j] >= got[i] and |got - want| <= delta imply want[i] - want[j] <= 2 delta)
+        rows = torch.arange(a.shape[0])
+        flip_gap = (b[rows, ib] - b[rows, ia])[ia != ib]
+        r[k] = {"max_abs_delta": d, "argmax_agreement": agree, "same_inf_mask": same_inf, "rows": int(a.shape[0]),
+                "worst_flip_gap": flip_gap.max().item() if flip_gap.numel() else 0.0}
     top2 = want_outputs["fused_logits"].detach().double().topk(2, dim=1).values
     gap = (top2[:, 0] - top2[:, 1])
     r["oracle_min_top2_gap"] = gap[torch.isfinite(gap)].min().item()
@@ -115,6 +121,7 @@ def sap_parity(dtype, batch_size=8, seeds=(1234,), device="cuda", models=None):
         agree_n += st["fused_logits"]["argmax_agreement"] * st["fused_logits"]["rows"]
         out["rows"] += st["fused_logits"]["rows"]
         out["fused_max_abs_delta"] = max(out.get("fused_max_abs_delta", 0.0), st["fused_logits"]["max_abs_delta"])
+        out["worst_flip_gap"] = max(out.get("worst_flip_gap", 0.0), st["fused_logits"]["worst_flip_gap"])
         out["oracle_min_top2_gap"] = min(out.get("oracle_min_top2_gap", 1e9), st["oracle_min_top2_gap"])
         out["loss_rel_delta"] = abs(float(got["loss"].detach()) - float(want["loss"])) / max(abs(float(want["loss"])), 1e-12)
         out["kdl_rel_delta"] = abs(float(got["kdl_loss"].detach()) - float(want["kdl_loss"])) / max(abs(float(want["kdl_loss"])), 1e-12)

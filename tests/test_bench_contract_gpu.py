@@ -33,6 +33,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert par["fp32"]["max_abs_logit_delta"] < 1e-3 and par["fp32"]["argmax_agreement"] == 1.0
     assert par["bf16"]["max_abs_logit_delta"] < 1e-2 and d["bf16_max_logit_delta"] == par["bf16"]["max_abs_logit_delta"]
     assert modes["fp32"]["ms_per_step"] > 0 and d["fp32_mode_ms_per_step"] == modes["fp32"]["ms_per_step"]
+    assert par["bf16x3"]["max_abs_logit_delta"] < 1e-3 and par["bf16x3"]["argmax_agreement"] == 1.0 and modes["bf16x3"]["ms_per_step"] > 0
+    assert par["bf16"]["argmax_agreement"] >= 0.9 and par["bf16"]["worst_oracle_gap_between_flipped_picks"] <= 2 * par["bf16"]["max_abs_logit_delta"] + 1e-9
     cpu = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu, k

@@ -26,7 +26,10 @@ FP32_LOGIT_TOL = 2e-4          # measured ~1e-5; north-star bar 1e-3
 # for single-bf16 operands by construction: rounding ONLY the weights to bf16 inside the fp64 oracle already moves its own logits
 # by 1.3e-3 -- the bar is met by the fp32-MFMA mode above, whose throughput bench.py prints next to bf16's.
 BF16_LOGIT_TOL = 1e-2
-BF16_ARGMAX_MIN = 1.0          # action selection identical on these batches
+# action selection in bf16: identical wherever the oracle separates its two best candidates by more than twice the logit error; on
+# random-init weights some rows are near-ties (smallest top-2 gap of these batches: 2.3e-4, far inside the 4.8e-3 error), and a pick
+# may flip THERE -- measured 23-24 of 24 rows identical.  The assertion: >= 90 % identical AND every flip inside the tie band.
+BF16_ARGMAX_MIN = 0.9
 
 
 @pytest.fixture(scope="module")
@@ -88,6 +91,7 @@ def test_bf16_engine_action_logits_within_stated_tolerance_of_oracle(models):
     assert st["same_inf_mask"]
     assert st["max_abs_logit_delta"] < BF16_LOGIT_TOL, st
     assert st["argmax_agreement"] >= BF16_ARGMAX_MIN, st
+    assert st["worst_flip_gap"] <= 2.0 * st["max_abs_logit_delta"] + 1e-9, st          # flips only between candidates the oracle itself rates within 2 delta
     assert st["loss_rel_delta"] < 2e-2 and st["kdl_rel_delta"] < 3e-2, st
 
 

@@ -266,6 +266,30 @@ int magic_xencoder_supported(int dtype, int H, int I, int nh, int Nq, int Nk, in
 int magic_xencoder_params_bytes(void);
 int magic_xencoder_fwd(const void* params, int nbytes, void* stream);
 
+/* Backward of the per-token half of a post-LN self-attention block on 32-row blocks (csrc/encbwd.hip): [tail of the next block: dx =
+ * dQKV Wqkv + d_ao -> LayerNorm backward through this block's output norm] -> FFN input gradients (x gelu') -> LayerNorm backward through the
+ * attention-output norm -> d_ctx = d_aod Wo, one launch for 1 or 2 encoders ("segments"); bf16, H = 128, FFN 512.  Reads the TRANSPOSED
+ * bf16 weights (W^T, see magic_transpose_spans); writes the dY operands of the deferred weight-gradient GEMMs (d_fod, d_z, d_aod), d_ao
+ * (residual of the next tail) and d_ctx (input of magic_attn_bwd); gamma / beta gradients by atomics.  dqkv_n == NULL: no tail, the
+ * (d_fo, d_fod) pair is given (top block of an encoder). */
+typedef struct {
+  int M, pad0;
+  const void* dqkv_n; const void* WqkvT_n; const void* dao_n; const void* dfo_in; const void* dfod_in;
+  const void* y2; const float* rstd2; const float* g2; const float* b2; float* dg2; float* db2;
+  const void* z; const void* W2T; const void* W1T;
+  const void* y1; const float* rstd1; const float* g1; const float* b1; float* dg1; float* db1;
+  const void* WoT;
+  void *dfo, *dfod, *dz, *daod, *dao, *dctx;
+  unsigned site_out, site_ao;
+} magic_rowbwd_seg;
+typedef struct { magic_rowbwd_seg seg[2]; int nseg, blocks0; float p_hidden; int pad1; const unsigned* seed; } magic_rowbwd_params;
+int magic_rowbwd_supported(int dtype, int H, int I);
+int magic_rowbwd_params_bytes(void);
+int magic_rowbwd(const void* params, int nbytes, void* stream);
+/* dst[off_i .. off_i + rows_i*cols_i) = transpose of the row-major [rows_i, cols_i] bf16 matrix at src[off_i ..), i < n (element
+ * offsets into two congruent flat buffers; host arrays, consumed before return): the transposed weight shadow of magic_rowbwd. */
+int magic_transpose_spans(const void* src, void* dst, int n, const long long* offs, const int* rows, const int* cols, void* stream);
+
 /* Grouping: between magic_group_begin() and magic_group_end(stream) up to eight calls of magic_gemm / magic_attn_fwd /
  * magic_attn_bwd / magic_linear_ln / magic_linear_lnbwd / magic_ln_bwd / magic_rowblock_fwd are recorded instead of launched; magic_group_end launches ONE kernel serving
  * the problems of the same kind / dtype / variant: GEMMs as one grouped launch (<= 8 problems), other kinds as pairs.

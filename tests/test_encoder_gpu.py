@@ -158,3 +158,66 @@ def test_unsupported_shapes_fall_back():
     assert not big.net.enc_ok(36, 2)
     f32 = GlocalTextPathCMTPreTraining(make_config(128, role="student"), device=DEV, compute_dtype=torch.float32)
     assert not f32.net.enc_ok(36, 2)
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_rowblock_backward_matches_the_per_op_backward(p_drop):
+    """text + panorama stacks' backward on magic_rowbwd (2 launches per block) vs the per-op chain (5 launches per block): same saved
+    forward tensors, same upstream gradients, same dropout seed -> every parameter gradient of both encoders and the gradients wrt
+    the embeddings agree to bf16 accumulation noise"""
+    m = student(p_drop)
+    m.train()
+    batch = synth.make_batch("sap", batch_size=7, seed=5, step=0, dup_view_prob=0.3)
+    plan = build_plan(batch, "sap", torch.device(DEV))
+    inp = m._inputs(batch, plan)
+    m.store.sync_shadow()
+    n = m.net
+    assert n.rbw_ok()
+    seed = torch.tensor([4321, 99], dtype=torch.int32, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    B, L, H, Np, V = plan["B"], plan["L"], n.H, plan["Np"], plan["V"]
+    d_txt0 = (torch.randn(B * L, H, generator=g) * 0.1).to(DEV).bfloat16()
+    d_pano0 = (torch.randn(Np * V, H, generator=g) * 0.1).to(DEV).bfloat16()
+    d_fused0 = (torch.randn(Np, H, generator=g) * 0.1).to(DEV).bfloat16()
+    res = {}
+    for fused in (False, True):
+        O.FUSED_RBW = fused
+        try:
+            n.set_dropout(seed if p_drop > 0 else None, p_drop, p_drop)
+            ct = n.text_fwd(plan)
+            cp = n.pano_fwd(plan, inp.feats, inp.loc)
+            dPt = torch.randn(B, n.nh, L, ct.ldp, generator=g).to(DEV) * 0.01 if False else None
+            m.store.zero_grad()
+            O.defer_dw(True)
+            if fused:
+                assert n.rbw_ok()
+                n.encoders_bwd(ct, cp, plan, d_txt0.clone(), None, d_pano0.clone(), d_fused0.clone(), None)
+            else:
+                n.text_bwd(ct, plan, d_txt0.clone(), None)
+                n.pano_bwd(cp, plan, d_pano0.clone(), d_fused0.clone(), None)
+            O.flush_dw()
+            torch.cuda.synchronize()
+            res[fused] = m.store.grad.clone()
+        finally:
+            O.FUSED_RBW = True
+    a, b = res[True], res[False]
+    assert torch.isfinite(a).all() and a.abs().max() > 0
+    cos = F.cosine_similarity(a, b, dim=0).item()
+    rel = ((a - b).norm() / b.norm()).item()
+    assert cos > 0.9995 and rel < 3e-2, (cos, rel)
+    # per tensor, for the tensors the two encoders own
+    names = [nm for nm, _ in m.named_parameters() if ("lang_encoder" in nm or "pano_encoder" in nm or "embeddings" in nm)]
+    worst = 0.0
+    top = max(b[m.store.offsets[nm][0]:m.store.offsets[nm][0] + m.store.offsets[nm][1]].norm().item() for nm in names)
+    for nm in names:
+        off, cnt, _ = m.store.offsets[nm]
+        ga, gb = a[off:off + cnt], b[off:off + cnt]
+        if gb.norm() == 0:
+            assert ga.norm() == 0, nm
+            continue
+        if gb.norm().item() < 1e-3 * top:          # analytically zero gradients (e.g. the key bias in front of a softmax): noise on both sides
+            assert ga.norm().item() < 1e-2 * top, nm
+            continue
+        worst = max(worst, ((ga - gb).norm() / gb.norm()).item())
+        assert ((ga - gb).norm() / gb.norm()).item() < 6e-2, (nm, ((ga - gb).norm() / gb.norm()).item())
+    print(f"row-block backward vs per-op: cosine {cos:.6f}, rel L2 {rel:.2e}, worst tensor {worst:.2e}")

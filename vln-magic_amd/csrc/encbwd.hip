@@ -1,0 +1,389 @@
+// Backward of the per-token half of a post-LN BERT block in ONE launch (gfx950, bf16, H = 128, FFN 512), on 32-row blocks over the
+// whole chip.  Between two attention backwards the explicit backward of the text / panorama encoders is a chain of four per-token
+// products with two LayerNorm backwards in it:
+//
+//     [tail of block j+1]   dx   = dQKV_{j+1} Wqkv_{j+1} + d_ao_{j+1}            -> LayerNorm-backward through block j's OUTPUT norm
+//                                  -> d_fo (residual branch), d_fod = d_fo * dropout mask (dense branch; operand of dW2)
+//     [FFN of block j]      d_z  = (d_fod W2) * gelu'(z_j)                        (operand of dW1)
+//                           d_a  = d_z W1 + d_fo                                  -> LayerNorm-backward through block j's ATTENTION-OUTPUT norm
+//                                  -> d_ao (residual branch, feeds the next tail), d_aod (dense branch; operand of dWo)
+//     [output projection]   d_ctx = d_aod Wo                                      (input of block j's attention backward)
+//
+// The per-op path spends four launches on it (GEMM+LN-backward, GEMM, GEMM+LN-backward, GEMM); here a 512-thread workgroup owns 32
+// rows for the whole chain: intermediate gradients stay in LDS / registers, and -- as in the forward encoder kernels -- every weight
+// element is used once per workgroup and is loaded straight from L2 into MFMA B-fragments.  `dy W` contracts over W's ROWS, so the
+// fragments (8 consecutive k per lane) need the TRANSPOSED weights: a bf16 transposed shadow of the four matrices per block is kept
+// next to the ordinary shadow (magic_transpose_spans, refreshed with it after every optimizer step).
+// The weight gradients stay with the engine's deferred grouped GEMM: this kernel writes their dY operands (d_fod, d_z, d_aod).
+// Same rounding points (bf16 tensors between the products), LayerNorm-backward arithmetic, dropout masks and gamma / beta gradient
+// atomics as magic_linear_lnbwd / magic_gemm, so the two paths agree to bf16 rounding.
+#include "enc_common.hpp"
+#include <cstdlib>
+#include <cstring>
+
+
+struct RbwSeg {
+  int M, pad0;
+  const bf16* dqkv_n; const bf16* WqkvT_n; const bf16* dao_n;      // tail of the next block (dqkv_n == null: d_fo / d_fod are given)
+  const bf16* dfo_in; const bf16* dfod_in;
+  const bf16* y2; const float* rstd2; const float* g2; const float* b2; float* dg2; float* db2;     // this block's output LayerNorm
+  const bf16* z; const bf16* W2T; const bf16* W1T;                                                  // [M, I]; [I, H]; [H, I]
+  const bf16* y1; const float* rstd1; const float* g1; const float* b1; float* dg1; float* db1;     // attention-output LayerNorm
+  const bf16* WoT;                                                                                  // [H, H]
+  bf16 *dfo, *dfod, *dz, *daod, *dao, *dctx;                        // outputs (dfo / dfod only when the tail runs here)
+  unsigned site_out, site_ao;
+};
+struct RbwParams { RbwSeg seg[2]; int nseg, blocks0; float p_hidden; int pad1; const unsigned* seed; };
+
+// exact-enough gelu'(x) = Phi(x) + x phi(x) with the same rational erf as gelu_fast (one exp shared by both terms)
+__device__ __forceinline__ float dgelu_fast(float x) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = __expf(-ax * ax);                         // exp(-x^2 / 2)
+  const float erf_abs = 1.0f - poly * e;
+  const float cdf = 0.5f * (1.0f + (x < 0.f ? -erf_abs : erf_abs));
+  return cdf + x * 0.39894228040143268f * e;
+}
+
+// rows x cols bf16 from global rows (row < nvalid, else zeros) into an LDS image
+__device__ __forceinline__ void load_rows_img(bf16* s, int pitch, const bf16* g, long long ldg, int rows, int cols, int nvalid, int tid) {
+  const int cpr = cols / 8;
+  for (int id = tid; id < rows * cpr; id += NWAVE * 64) {
+    const int r = id / cpr, c = (id % cpr) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)0.0f;
+    if (r < nvalid) v = *(const bf16x8*)(g + (long long)r * ldg + c);
+    *(bf16x8*)(s + r * pitch + c) = v;
+  }
+}
+
+// LayerNorm backward over full rows, wave w owning columns [16w, 16w+16): v = acc (+ residual already added) is dL/dy; writes
+// dx (residual branch) and dx * dropout mask (dense branch) as bf16 into two LDS images; gamma / beta gradients by one atomic per column
+template <int NRT>
+__device__ __forceinline__ void ln_bwd_rows(f32x4 (&acc)[NRT], const bf16* sY, const float* rstd_g, const float gm, const float bt, float* dgamma,
+                                            float* dbeta, float* red, bf16* sSum, bf16* sDense, const int m0, const int M, const DropState& ds,
+                                            const int w, const int lane) {
+  constexpr int RB_ROWS = NRT * 16;
+  const int g = lane >> 4, c16 = lane & 15, col = w * 16 + c16;
+  const float ig = gm != 0.f ? 1.f / gm : 0.f;
+  float xh[NRT][4], s1[NRT][4], s2[NRT][4];
+  float pg = 0.f, pb = 0.f;
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = i * 16 + 4 * g + r;
+      const bool live = m0 + rr < M;
+      const float v = live ? acc[i][r] : 0.f;
+      const float x = live ? (to_f(sY[rr * XS + col]) - bt) * ig : 0.f;
+      pg += v * x; pb += v;
+      const float ga = v * gm;
+      acc[i][r] = ga; xh[i][r] = x;
+      s1[i][r] = row16_sum(ga); s2[i][r] = row16_sum(ga * x);
+    }
+  if (dgamma) {      // fold the four row groups of the wave (lanes 16 apart), one atomic per column and workgroup
+    pg += __shfl_xor(pg, 16, 64); pg += __shfl_xor(pg, 32, 64);
+    pb += __shfl_xor(pb, 16, 64); pb += __shfl_xor(pb, 32, 64);
+    if (g == 0) { atomicAdd(dgamma + col, pg); atomicAdd(dbeta + col, pb); }
+  }
+  if (c16 == 0) {
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { red[w * RB_ROWS + i * 16 + 4 * g + r] = s1[i][r]; red[(NWAVE + w) * RB_ROWS + i * 16 + 4 * g + r] = s2[i][r]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = i * 16 + 4 * g + r;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NWAVE; ++ww) { t1 += red[ww * RB_ROWS + rr]; t2 += red[(NWAVE + ww) * RB_ROWS + rr]; }
+      const float m1 = t1 * (1.0f / EH), m2 = t2 * (1.0f / EH);
+      const float rs = (m0 + rr < M) ? rstd_g[m0 + rr] : 0.f;
+      const float d = rs * (acc[i][r] - m1 - xh[i][r] * m2);
+      sSum[rr * XS + col] = from_f<bf16>(d);
+      sDense[rr * XS + col] = from_f<bf16>(ds.on ? d * drop_mul(ds, (unsigned)((m0 + rr) * EH + col)) : d);
+    }
+}
+
+// NRT = row tiles of 16 per workgroup.  2 (32 rows): two workgroups per CU, 128 registers per lane, weight fragments one chunk of four
+// k-steps ahead of their use.  4 (64 rows): one workgroup per CU, 256 registers, a whole product's fragments ahead -- and half the
+// weight bytes streamed from L2 per row (every workgroup streams all 393 KB of the block's matrices).
+template <int NRT>
+__device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* rb_smem) {
+  constexpr int RB_ROWS = NRT * 16;
+  constexpr bool DEEP = NRT >= 4;
+  int blk = blockIdx.x, sidx = 0;
+  if (blk >= p.blocks0) { blk -= p.blocks0; sidx = 1; }
+  const RbwSeg& sg = p.seg[sidx];
+  bf16* sZ = (bf16*)rb_smem;                   // [32][GS]  z, overwritten in place by d_z
+  bf16* sY2 = sZ + RB_ROWS * GS;               // [32][XS]  this block's output (its LayerNorm's y); later the d_ctx staging image
+  bf16* sR = sY2 + RB_ROWS * XS;               // [32][XS]  d_ao of the next block (residual of the tail)
+  bf16* sFo = sR + RB_ROWS * XS;               // [32][XS]  d_fo
+  bf16* sD = sFo + RB_ROWS * XS;               // [32][XS]  d_fod, later d_aod
+  bf16* sY1 = sD + RB_ROWS * XS;               // [32][XS]  a (the attention-output LayerNorm's y)
+  bf16* sAo = sR;                              // [..][XS]  d_ao (the tail's residual image is dead by then)
+  float* red = (float*)(sY1 + RB_ROWS * XS);   // [2][8][rows]
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
+  const int m0 = blk * RB_ROWS, M = sg.M;
+  const int nv = min(RB_ROWS, M - m0);
+  const int colw = w * 16 + c16;
+  const bool tail = sg.dqkv_n != nullptr;
+  DropDesc dd;
+  dd.seed = p.seed; dd.p = p.p_hidden;
+  // ---- weights of the first two products + small parameters, issued before anything else
+  // (two workgroups per CU = 128 registers per lane: weight fragments arrive in chunks of four k-steps, one chunk ahead of their use)
+  bf16x8 wq[12];
+  if (tail) {
+#pragma unroll
+    for (int ks = 0; ks < (DEEP ? 12 : 4); ++ks) wq[ks] = gfrag(sg.WqkvT_n, 3 * EH, w * 16, ks * 32, lane);
+  }
+  bf16x8 w2[4][4];
+  const float gm2 = sg.g2[colw], bt2 = sg.b2[colw], gm1 = sg.g1[colw], bt1 = sg.b1[colw];
+  // ---- stage the block's rows: z, a, and either (out, d_ao of the next block) for the tail or the given (d_fo, d_fod)
+  // tail: the dQKV rows of the block above pass through the z image's space first (z itself is fetched during the tail's epilogue)
+  if (tail) load_rows_img(sZ, QS, sg.dqkv_n + (long long)m0 * 3 * EH, 3 * EH, RB_ROWS, 3 * EH, nv, tid);
+  else load_rows_img(sZ, GS, sg.z + (long long)m0 * EI, EI, RB_ROWS, EI, nv, tid);
+  load_rows_img(sY1, XS, sg.y1 + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
+  if (tail) {
+    load_rows_img(sY2, XS, sg.y2 + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
+    load_rows_img(sR, XS, sg.dao_n + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
+  } else {
+    load_rows_img(sFo, XS, sg.dfo_in + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
+    load_rows_img(sD, XS, sg.dfod_in + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
+  }
+  __syncthreads();
+  // ================= tail: dx = dQKV W_qkv + d_ao -> LayerNorm backward (output norm) =================
+  if (tail) {
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      if (!DEEP && ch < 2) {
+#pragma unroll
+        for (int ks = 4 * ch + 4; ks < 4 * ch + 8; ++ks) wq[ks] = gfrag(sg.WqkvT_n, 3 * EH, w * 16, ks * 32, lane);
+      }
+#pragma unroll
+      for (int ks = 4 * ch; ks < 4 * ch + 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) acc[i] = emma(lfrag(sZ, QS, i * 16, ks * 32, lane), wq[ks], acc[i]);
+      }
+      KSTEP_FENCE();
+    }
+    // z rows -> registers now (their round trip hides under the LayerNorm backward); they go into the image once every wave is past
+    // the barrier inside ln_bwd_rows, i.e. done reading the dQKV rows
+    constexpr int ZIT = RB_ROWS * (EI / 8) / (NWAVE * 64);
+    bf16x8 zr[ZIT];
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int id = tid + it * NWAVE * 64, r = id / (EI / 8), c = (id % (EI / 8)) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) zr[it][e] = (bf16)0.0f;
+      if (r < nv) zr[it] = *(const bf16x8*)(sg.z + (long long)(m0 + r) * EI + c);
+    }
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][r] += to_f(sR[(i * 16 + 4 * g + r) * XS + colw]);
+    dd.site = sg.site_out;
+    const DropState ds = drop_init(dd);
+    ln_bwd_rows<NRT>(acc, sY2, sg.rstd2, gm2, bt2, sg.dg2, sg.db2, red, sFo, sD, m0, M, ds, w, lane);
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int id = tid + it * NWAVE * 64, r = id / (EI / 8), c = (id % (EI / 8)) * 8;
+      *(bf16x8*)(sZ + r * GS + c) = zr[it];
+    }
+    __syncthreads();                             // d_fo / d_fod images and the z image complete
+    copy_out(sFo, XS, sg.dfo + (long long)m0 * EH, EH, nv, EH, tid);
+    copy_out(sD, XS, sg.dfod + (long long)m0 * EH, EH, nv, EH, tid);
+  }
+  // ================= FFN: d_z = (d_fod W2) * gelu'(z) : 32 column tiles, 4 per wave =================
+  bf16x8 w1[16];
+  {
+    f32x4 acc[NRT][4];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) w2[ct][0] = gfrag(sg.W2T, EH, (4 * w + ct) * 16, 0, lane);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) w2[ct][ks + 1] = gfrag(sg.W2T, EH, (4 * w + ct) * 16, (ks + 1) * 32, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) {
+        const bf16x8 a = lfrag(sD, XS, i * 16, ks * 32, lane);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[i][ct] = emma(a, w2[ct][ks], acc[i][ct]);
+      }
+      KSTEP_FENCE();
+    }
+#pragma unroll
+    for (int ks = 0; ks < (DEEP ? 8 : 4); ++ks) w1[ks] = gfrag(sg.W1T, EI, w * 16, ks * 32, lane);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int col = (4 * w + ct) * 16 + c16;
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = i * 16 + 4 * g + r;
+          bf16* e = sZ + rr * GS + col;                      // each element of the image is read and rewritten by exactly one lane
+          *e = from_f<bf16>(acc[i][ct][r] * dgelu_fast(to_f(*e)));
+        }
+    }
+  }
+  __syncthreads();                               // d_z image complete
+  copy_out(sZ, GS, sg.dz + (long long)m0 * EI, EI, nv, EI, tid);
+  // ================= d_a = d_z W1 + d_fo -> LayerNorm backward (attention-output norm) =================
+  bf16x8 wo[4];
+  {
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int CHK = DEEP ? 8 : 4;              // k-steps per weight chunk
+#pragma unroll
+    for (int ch = 0; ch < 16 / CHK; ++ch) {
+      if (ch + 1 < 16 / CHK) {
+#pragma unroll
+        for (int ks = CHK * (ch + 1); ks < CHK * (ch + 2); ++ks) w1[ks] = gfrag(sg.W1T, EI, w * 16, ks * 32, lane);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wo[ks] = gfrag(sg.WoT, EH, w * 16, ks * 32, lane);
+      }
+#pragma unroll
+      for (int ks = CHK * ch; ks < CHK * (ch + 1); ++ks) {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) acc[i] = emma(lfrag(sZ, GS, i * 16, ks * 32, lane), w1[ks], acc[i]);
+        if ((ks & 3) == 3) KSTEP_FENCE();
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][r] += to_f(sFo[(i * 16 + 4 * g + r) * XS + colw]);
+    dd.site = sg.site_ao;
+    const DropState ds = drop_init(dd);
+    // d_aod goes where d_fod was: every wave is past the FFN product (the barrier above) and reads sD no more
+    ln_bwd_rows<NRT>(acc, sY1, sg.rstd1, gm1, bt1, sg.dg1, sg.db1, red, sAo, sD, m0, M, ds, w, lane);
+  }
+  __syncthreads();                               // d_ao / d_aod images complete
+  copy_out(sAo, XS, sg.dao + (long long)m0 * EH, EH, nv, EH, tid);
+  copy_out(sD, XS, sg.daod + (long long)m0 * EH, EH, nv, EH, tid);
+  // ================= d_ctx = d_aod Wo =================
+  {
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) acc[i] = emma(lfrag(sD, XS, i * 16, ks * 32, lane), wo[ks], acc[i]);
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sY2[(i * 16 + 4 * g + r) * XS + colw] = from_f<bf16>(acc[i][r]);
+  }
+  __syncthreads();
+  copy_out(sY2, XS, sg.dctx + (long long)m0 * EH, EH, nv, EH, tid);
+}
+
+__global__ __launch_bounds__(512, 4) void rowbwd32_kernel(RbwParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
+  rowbwd_body<2>(p, rb_smem);
+}
+__global__ __launch_bounds__(512, 2) void rowbwd64_kernel(RbwParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
+  rowbwd_body<4>(p, rb_smem);
+}
+static size_t rbw_lds_bytes(int rows) { return (size_t)(rows * GS + 5 * rows * XS) * sizeof(bf16) + (size_t)2 * NWAVE * rows * sizeof(float); }
+static int rbw_rows() {
+  static int r = 0;
+  if (!r) { const char* e = getenv("MAGIC_RBW_ROWS"); r = (e && atoi(e) == 64) ? 64 : 32; }      // measured: 32 rows 42.7 us per launch, 64 rows 51.6
+  return r;
+}
+
+extern "C" int magic_rowbwd_supported(int dtype, int H, int I) { return dtype == DT_BF16 && H == EH && I == EI; }
+extern "C" int magic_rowbwd_params_bytes() { return (int)sizeof(RbwParams); }
+
+extern "C" int magic_rowbwd(const void* params, int nbytes, void* stream) {
+  if (!params || nbytes != (int)sizeof(RbwParams)) return MAGIC_ERR_ARG;
+  RbwParams p;
+  memcpy(&p, params, sizeof(p));
+  if (p.nseg < 1 || p.nseg > 2 || !drop_args_ok(p.seed, p.p_hidden)) return MAGIC_ERR_ARG;
+  int blocks = 0;
+  for (int s = 0; s < 2; ++s) {
+    RbwSeg& sg = p.seg[s];
+    if (s >= p.nseg) { sg.M = 0; continue; }
+    if (sg.M <= 0 || (long long)sg.M * EI > 0x7FFFFFFFll) return MAGIC_ERR_ARG;
+    const void* req[] = {sg.y2, sg.rstd2, sg.g2, sg.b2, sg.z, sg.W2T, sg.W1T, sg.y1, sg.rstd1, sg.g1, sg.b1, sg.WoT, sg.dz, sg.daod, sg.dao, sg.dctx};
+    for (const void* q : req)
+      if (!q) return MAGIC_ERR_ARG;
+    if (sg.dqkv_n) { if (!sg.WqkvT_n || !sg.dao_n || !sg.dfo || !sg.dfod) return MAGIC_ERR_ARG; }
+    else if (!sg.dfo_in || !sg.dfod_in) return MAGIC_ERR_ARG;
+    if ((sg.dg2 == nullptr) != (sg.db2 == nullptr) || (sg.dg1 == nullptr) != (sg.db1 == nullptr)) return MAGIC_ERR_ARG;
+    const void* al[] = {sg.dqkv_n, sg.WqkvT_n, sg.dao_n, sg.dfo_in, sg.dfod_in, sg.y2, sg.z, sg.W2T, sg.W1T, sg.y1, sg.WoT, sg.dfo, sg.dfod, sg.dz, sg.daod, sg.dao, sg.dctx};
+    for (const void* q : al)
+      if ((uintptr_t)q & 15) return MAGIC_ERR_ARG;
+    const int nb = (sg.M + rbw_rows() - 1) / rbw_rows();
+    if (s == 0) p.blocks0 = nb;
+    blocks += nb;
+  }
+  const size_t shm = rbw_lds_bytes(rbw_rows());
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)rowbwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbw_lds_bytes(32));
+    (void)hipFuncSetAttribute((const void*)rowbwd64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbw_lds_bytes(64));
+    attr_set = true;
+  }
+  if (rbw_rows() == 32) hipLaunchKernelGGL(rowbwd32_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(rowbwd64_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+// ---- transposed bf16 shadow: dst[off .. off + rows*cols) = transpose of the [rows, cols] matrix at src[off ..) -----------------------
+#define TSP_MAX 160
+struct TSpans { long long off[TSP_MAX]; int rows[TSP_MAX]; int cols[TSP_MAX]; int tile0[TSP_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void transpose_spans_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, TSpans t) {
+  __shared__ bf16 tile[32][34];
+  const int id = blockIdx.x;
+  int s = 0;
+  for (int i = 1; i < t.n; ++i) s += (id >= t.tile0[i]) ? 1 : 0;
+  const int local = id - t.tile0[s], R = t.rows[s], C = t.cols[s];
+  const int tc = (C + 31) / 32, r0 = (local / tc) * 32, c0 = (local % tc) * 32;
+  const bf16* a = src + t.off[s];
+  bf16* b = dst + t.off[s];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+    if (r0 + j < R && c0 + tx < C) tile[j][tx] = a[(long long)(r0 + j) * C + c0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < C && r0 + tx < R) b[(long long)(c0 + j) * R + r0 + tx] = tile[tx][j];
+}
+// offs / rows / cols: host arrays of n spans (element offsets into the flat bf16 buffers)
+extern "C" int magic_transpose_spans(const void* src, void* dst, int n, const long long* offs, const int* rows, const int* cols, void* stream) {
+  if (!src || !dst || n < 0 || (n && (!offs || !rows || !cols))) return MAGIC_ERR_ARG;
+  for (int base = 0; base < n; base += TSP_MAX) {
+    TSpans t;
+    t.n = n - base < TSP_MAX ? n - base : TSP_MAX;
+    int tiles = 0;
+    for (int i = 0; i < t.n; ++i) {
+      if (rows[base + i] <= 0 || cols[base + i] <= 0) return MAGIC_ERR_ARG;
+      t.off[i] = offs[base + i]; t.rows[i] = rows[base + i]; t.cols[i] = cols[base + i];
+      t.tile0[i] = tiles;
+      tiles += ((rows[base + i] + 31) / 32) * ((cols[base + i] + 31) / 32);
+    }
+    t.tile0[t.n] = tiles;
+    hipLaunchKernelGGL(transpose_spans_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, t);
+  }
+  return launch_status();
+}

@@ -13,26 +13,9 @@
 // Replaces 5 launches per block (QKV GEMM, fused attention, dense+LN, FFN1 GEMM, dense+LN) x (6 | 2) blocks by one launch for both
 // encoders: the text workgroups (long pole: 6 layers) come first in the grid, the panorama workgroups fill the remaining CUs.
 // LDS per workgroup ~145 KB (one workgroup per CU); MFMA v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 LayerNorm / softmax.
-#include "common.hpp"
+#include "enc_common.hpp"
 #include <cstdlib>
 #include <cstring>
-
-#define EH 128
-#define EI 512
-#define ENH 2
-#define EHD 64
-#define XS 136        // row pitch (elements) of the [rows][128] LDS images: 272 B = 17 16-byte slots, rows land on distinct slots
-#define QS 392        // [rows][384] Q|K|V image
-#define GS 520        // [rows][512] GELU output image
-#define PSW 104       // per-wave probability tile [16][<= 96 keys]
-#define MAXROWS 80
-#define KROWS 96      // key rows the Q|K|V image provides for (PV consumes keys in steps of 32)
-#define NWAVE 8
-
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_e;
-// the GEMM stages are fully unrolled (their weight fragments are register arrays with static indices); without a fence per k-step the
-// scheduler hoists every LDS fragment read of a stage to its top and spills hundreds of registers
-#define KSTEP_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 struct EncLayer {
   const bf16* Wqkv; const float* bqkv;                                   // [3H, H] (q | k | v rows), [3H]
@@ -45,42 +28,6 @@ struct EncLayer {
 };
 struct EncSeg { const bf16* x; const unsigned char* kmask; int nsamp, N, ldp, nlayers; EncLayer L[6]; };
 struct EncParams { EncSeg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; };
-
-__device__ __forceinline__ f32x4 emma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-// MFMA operand fragment (A or B) of 16 rows x 32 k from a k-contiguous image: lane l holds X[row0 + (l&15)][k0 + 8*(l>>4) .. +7]
-__device__ __forceinline__ bf16x8 lfrag(const bf16* s, int pitch, int row0, int k0, int lane) {
-  return *(const bf16x8*)(s + (row0 + (lane & 15)) * pitch + k0 + 8 * (lane >> 4));
-}
-__device__ __forceinline__ bf16x8 gfrag(const bf16* __restrict__ W, int ldw, int row0, int k0, int lane) {
-  return *(const bf16x8*)(W + (long long)(row0 + (lane & 15)) * ldw + k0 + 8 * (lane >> 4));
-}
-// B fragment from a [k][n] image (V: keys x head dims), transposed on the way out of LDS
-__device__ __forceinline__ bf16x8 tfrag(const bf16* s, int pitch, int n0, int k0, int lane) {
-  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const bf16* b = s + (k0 + 8 * g + q) * pitch + n0 + 4 * pp;
-  typedef bf16x4_e __attribute__((address_space(3))) * lds4;
-  const bf16x4_e lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
-  const bf16x4_e hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * pitch));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-// GELU on the 40 K elements a text workgroup produces per layer: libm's erff is ~40 instructions; this rational form (Abramowitz &
-// Stegun 7.1.26, |error| <= 1.5e-7) is ~15 and indistinguishable after the bf16 rounding of the result
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float ax = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - poly * __expf(-ax * ax);
-  const float erfv = x < 0.f ? -erf_abs : erf_abs;
-  return 0.5f * x * (1.0f + erfv);
-}
-// LDS hand-off between the lanes of ONE wave (wave-private tile): order the wave's own LDS writes before its reads
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ __forceinline__ float g16_sum(float v) { return row16_sum(v); }
-__device__ __forceinline__ float g16_max(float v) { return row16_max(v); }
 
 // out[row][w*16 + c16] = LayerNorm_row(acc + bias (dropped) + residual) for the workgroup's NRT*16 rows; every wave owns 16 of the
 // 128 columns, row statistics go through LDS (two passes: mean, then centred variance -- as linear_ln_kernel).
@@ -147,15 +94,6 @@ __device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, cons
       sOut[rr * XS + col] = (rr < N) ? y : (bf16)0.0f;        // rows past the sample stay zero (they feed the next GEMM as padding)
       if (rr < N && w == 0 && c16 == 0) gRstd[row_base + rr] = rstd;
     }
-}
-
-// cooperative copy of `rows` x `cols` bf16 from an LDS image to global rows (16-byte vectors)
-__device__ __forceinline__ void copy_out(const bf16* s, int pitch, bf16* g, long long ldg, int rows, int cols, int tid) {
-  const int cpr = cols / 8;
-  for (int id = tid; id < rows * cpr; id += NWAVE * 64) {
-    const int r = id / cpr, c = (id % cpr) * 8;
-    *(bf16x8*)(g + (long long)r * ldg + c) = *(const bf16x8*)(s + r * pitch + c);
-  }
 }
 
 #ifdef ENC_TIMING

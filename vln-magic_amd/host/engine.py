@@ -111,6 +111,15 @@ class Lin:
             self.dW = store.g_span(wname, rows * cols).view(rows, cols)
             self.db = store.g_span(bname, rows)
         self.N, self.K = rows, cols
+        self._store, self._wname = store, wname
+
+    @property
+    def WT(self):
+        """[K, N] bf16 = W^T (transposed shadow, csrc/encbwd.hip reads it); registers the span on first use"""
+        t = getattr(self, "_WT", None)
+        if t is None:
+            t = self._WT = self._store.t_span(self._wname, self.N, self.K)
+        return t
 
 
 class LN:
@@ -131,6 +140,15 @@ class MagicNet:
         self.train = store.requires_grad
         self._cache = {}
         self.drop = None          # (seed uint32[2] device tensor, p_hidden, p_attn) while a training-mode forward is running
+        if self.S.device.type == "cuda" and self.rbw_ok():
+            # the backward row-block kernel reads W^T: register the transposed-shadow spans of every self-attention block now, so the
+            # first sync_shadow() of the first forward fills them in
+            for fmt, nl in ((prefix + "lang_encoder.layer.{}.", cfg.num_l_layers), (prefix + "img_embeddings.pano_encoder.layer.{}.", cfg.num_pano_layers)):
+                for i in range(nl):
+                    lp = fmt.format(i)
+                    for lin in (self.lin(lp + "attention.self.query.weight", rows=3 * self.H, cols=self.H), self.lin(lp + "attention.output.dense.weight"),
+                                self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")):
+                        lin.WT
 
     # ---- dropout sites (counter-based masks, csrc/common.hpp) -------------------------------------
     def set_dropout(self, seed=None, p_hidden=0.0, p_attn=0.0):
@@ -534,14 +552,106 @@ class MagicNet:
         c.out, c.P, c.ldp = c.layers[-1].out, c.layers[-1].P, c.layers[-1].ldp
         return c
 
+    # ---- backward of whole self-attention stacks on the row-block kernel (csrc/encbwd.hip) --------------------------------
+    def rbw_ok(self):
+        return self.train and O.rowbwd_ok(self.dtype, self.H, self.I) and not self._rb_ok()
+
+    def self_stacks_bwd(self, stacks):
+        """stacks: 1 or 2 tuples (ctx with .layers, layer-prefix format, d_top = plain gradient wrt the stack's output, dP_init for
+        the top block's attention map).  Two launches per block and stack pair -- the per-token chain (magic_rowbwd: tail of the
+        block above + FFN + both LayerNorm backwards + output projection) and the attention backward -- instead of five; the two
+        stacks advance together from their tops (text 6 blocks, panorama 2) in shared launches.  Returns the gradients wrt the
+        stacks' inputs."""
+        from . import lib as L
+        H, I = self.H, self.I
+        st = []
+        for c, fmt, d_top, dP in stacks:
+            lc = c.layers[-1]
+            st.append(Ctx(c=c, fmt=fmt, j=len(c.layers) - 1, M=lc.sa.Bn * lc.sa.N, dP=dP, d_top=d_top, pre=None, dqkv=None, dao=None, dx0=None))
+        with L.group():          # LayerNorm backward of each stack's last output norm
+            for s in st:
+                lc = s.c.layers[s.j]
+                s.pre = self._through_ln(s.d_top, self._out_ln_desc(s.fmt.format(s.j), lc), s.M)
+        d = self.drop
+        while any(s.dx0 is None for s in st):
+            segs, act = [], []
+            for s in st:
+                if s.dx0 is not None:
+                    continue
+                j, M = s.j, s.M
+                lp, lc = s.fmt.format(j), s.c.layers[j]
+                sa, ffn = lc.sa, lc.ffn
+                f1, f2, o = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.lin(lp + "attention.output.dense.weight")
+                n2, n1 = self.ln(lp + "output.LayerNorm"), self.ln(lp + "attention.output.LayerNorm")
+                out = Ctx(dz=self.new(M, I), daod=self.new(M, H), dao=self.new(M, H), dctx=self.new(M, H))
+                seg = dict(M=M, y2=ffn.out, rstd2=ffn.rstd, g2=n2.g, b2=n2.b, z=ffn.z, W2T=f2.WT, W1T=f1.WT, y1=sa.a, rstd1=sa.rstd_a,
+                           g1=n1.g, b1=n1.b, dg1=n1.dg, db1=n1.db, WoT=o.WT, dz=out.dz, daod=out.daod, dao=out.dao, dctx=out.dctx,
+                           site_out=ffn.hdrop[2] if ffn.hdrop else 0, site_ao=sa.hdrop[2] if sa.hdrop else 0)
+                flops = 2.0 * ffn.rows * (2 * H * I + H * H)
+                if s.pre is not None:            # top block: (d_fo, d_fod) come from the LayerNorm backward above
+                    out.dfo, out.dfod = s.pre
+                    seg.update(dfo_in=out.dfo, dfod_in=out.dfod)
+                    s.pre = None
+                else:                            # tail of block j + 1 runs here
+                    qn = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
+                    out.dfo, out.dfod = self.new(M, H), self.new(M, H)
+                    seg.update(dqkv_n=s.dqkv, WqkvT_n=qn.WT, dao_n=s.dao, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
+                    flops += 2.0 * ffn.rows * 3 * H * H
+                seg["flops"] = flops
+                segs.append(seg)
+                act.append((s, lp, lc, out, f1, f2, o))
+            O.rowbwd(segs, d[0] if d else None, d[1] if d else 0.0)
+            fused_attn = all(O.attn_supported(self.dtype, lc.sa.N, lc.sa.N, True) for _, _, lc, _, _, _, _ in act)
+            grp = L.group() if (fused_attn and len(act) > 1) else None
+            if grp is not None:
+                grp.__enter__()
+            try:
+                for s, lp, lc, out, f1, f2, o in act:
+                    sa = lc.sa
+                    out.dqkv = self.new(s.M, 3 * H)
+                    self._attn_bwd(sa.Ppre, sa.ldp, out.dctx, sa.qkv, 3 * H, sa.qkv[:, H:], sa.qkv[:, 2 * H:], 3 * H,
+                                   out.dqkv, 3 * H, out.dqkv[:, H:], out.dqkv[:, 2 * H:], 3 * H, sa.Bn, sa.N, sa.N, None, None,
+                                   s.dP if s.j == len(s.c.layers) - 1 else None, sa.aflops, sa.adrop, sa.P if sa.adrop else None)
+            finally:
+                if grp is not None:
+                    grp.__exit__(None, None, None)
+            for s, lp, lc, out, f1, f2, o in act:
+                sa, ffn, M = lc.sa, lc.ffn, s.M
+                ql = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
+                O.linear_dw(out.dfod, ffn.g, f2.dW, f2.db, M, flop_rows=ffn.rows)
+                O.linear_dw(out.dz, ffn.a, f1.dW, f1.db, M, flop_rows=ffn.rows)
+                O.linear_dw(out.daod, sa.ctx, o.dW, o.db, M, flop_rows=sa.rows)
+                O.linear_dw(out.dqkv, sa.x, ql.dW, ql.db, M, flop_rows=sa.rows)
+                s.dqkv, s.dao = out.dqkv, out.dao
+                if s.j == 0:
+                    s.dx0 = O.linear_dx(out.dqkv, ql.W, M, residual=out.dao, flop_rows=sa.rows)
+                else:
+                    s.j -= 1
+        return [s.dx0 for s in st]
+
+    def encoders_bwd(self, ct, cp, plan, d_txt, dP_txt, d_pano, d_fused, dP_pano):
+        """text + panorama encoders' backward together: the two stacks on the row-block kernel, then the embedding backwards"""
+        self._pano_head_bwd(cp, d_pano, d_fused)
+        p = self.p
+        dt, dp = self.self_stacks_bwd([(ct, p + "lang_encoder.layer.{}.", d_txt, dP_txt),
+                                       (cp, p + "img_embeddings.pano_encoder.layer.{}.", d_pano, dP_pano)])
+        self._text_emb_bwd(ct, plan, dt)
+        self._pano_emb_bwd(cp, plan, dp)
+
     def text_bwd(self, c, plan, d_out, dP_init=None):
         p, H = self.p, self.H
-        M = c.B * c.L
+        if self.rbw_ok() and c.layers and hasattr(c.layers[0], "sa") and self.enc_ok(c.L, len(c.layers)):
+            return self._text_emb_bwd(c, plan, self.self_stacks_bwd([(c, p + "lang_encoder.layer.{}.", d_out, dP_init)])[0])
         d = d_out
         nl = self.cfg.num_l_layers
         for i in reversed(range(nl)):
             prev = self._out_ln_desc(f"{p}lang_encoder.layer.{i - 1}.", c.layers[i - 1]) if i > 0 else None
             d = self.self_layer_bwd(f"{p}lang_encoder.layer.{i}.", c.layers[i], d, dP_init if i == nl - 1 else None, fuse_in=prev)
+        return self._text_emb_bwd(c, plan, d)
+
+    def _text_emb_bwd(self, c, plan, d):
+        p, H = self.p, self.H
+        M = c.B * c.L
         n = self.ln(p + "embeddings.LayerNorm")
         O.ln_bwd(M, H, d, y=c.E, gamma=n.g, beta=n.b, rstd=c.rstd_e, dx=None, dgamma=n.dg, dbeta=n.db, drop_dy=c.edrop,
                  dtabs=((plan["txt_ids"], 0, 0, self.S.g(p + "embeddings.word_embeddings.weight"), 0),
@@ -616,9 +726,21 @@ class MagicNet:
         return z
 
     def pano_bwd(self, c, plan, d_pano, d_fused, dP_init=None):
+        p = self.p + "img_embeddings."
+        self._pano_head_bwd(c, d_pano, d_fused)
+        if self.rbw_ok() and self.enc_ok(c.V, len(c.layers)):
+            return self._pano_emb_bwd(c, plan, self.self_stacks_bwd([(c, p + "pano_encoder.layer.{}.", d_pano, dP_init)])[0])
+        d = d_pano
+        nl = self.cfg.num_pano_layers
+        for i in reversed(range(nl)):
+            prev = self._out_ln_desc(f"{p}pano_encoder.layer.{i - 1}.", c.layers[i - 1]) if i > 0 else None
+            d = self.self_layer_bwd(f"{p}pano_encoder.layer.{i}.", c.layers[i], d, dP_init if i == nl - 1 else None, fuse_in=prev)
+        return self._pano_emb_bwd(c, plan, d)
+
+    def _pano_head_bwd(self, c, d_pano, d_fused):
+        """fused-embedding (attention pooling / masked mean) backward: accumulates into d_pano"""
         p, H = self.p + "img_embeddings.", self.H
         Np, V = c.Np, c.V
-        M = Np * V
         if d_fused is not None:
             if cfg_get(self.cfg, "adaptive_pano_fusion"):
                 fl = self.lin(p + "pano_fuse_linear.weight")
@@ -626,11 +748,11 @@ class MagicNet:
             else:       # masked mean: no scoring parameters (their would-be gradients land in a scratch vector)
                 zw, zb = self._zero_fuse()
                 O.pano_fuse_bwd(c.out, c.fprobs, zw, d_fused, d_pano, self.new(H, dtype=torch.float32), self.new(1, dtype=torch.float32), Np, V, H)
-        d = d_pano
-        nl = self.cfg.num_pano_layers
-        for i in reversed(range(nl)):
-            prev = self._out_ln_desc(f"{p}pano_encoder.layer.{i - 1}.", c.layers[i - 1]) if i > 0 else None
-            d = self.self_layer_bwd(f"{p}pano_encoder.layer.{i}.", c.layers[i], d, dP_init if i == nl - 1 else None, fuse_in=prev)
+
+    def _pano_emb_bwd(self, c, plan, d):
+        p, H = self.p + "img_embeddings.", self.H
+        Np, V = c.Np, c.V
+        M = Np * V
         n3 = self.ln(p + "layer_norm")
         dsum = self.new(M, H)
         O.ln_bwd(M, H, d, y=c.X0, gamma=n3.g, beta=n3.b, rstd=c.rstd_x0, dx=dsum, dgamma=n3.dg, dbeta=n3.db, drop_dy=c.edrop,

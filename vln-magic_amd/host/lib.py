@@ -69,6 +69,10 @@ SIGNATURES = {
     "magic_xencoder_supported": [i32, i32, i32, i32, i32, i32, i32],
     "magic_xencoder_params_bytes": [],
     "magic_xencoder_fwd": [vp, i32, vp],
+    "magic_rowbwd_supported": [i32, i32, i32],
+    "magic_rowbwd_params_bytes": [],
+    "magic_rowbwd": [vp, i32, vp],
+    "magic_transpose_spans": [vp, vp, i32, vp, vp, vp, vp],
     "magic_group_begin": [],
     "magic_group_end": [vp],
 }
@@ -126,6 +130,19 @@ class XSeg(C.Structure):
 
 class XParams(C.Structure):
     _fields_ = [("seg", XSeg * 2), ("nseg", i32), ("p_attn", f32), ("p_hidden", f32), ("eps", f32), ("scale", f32), ("seed", vp)]
+
+
+RBW_PTRS = ("dqkv_n", "WqkvT_n", "dao_n", "dfo_in", "dfod_in", "y2", "rstd2", "g2", "b2", "dg2", "db2", "z", "W2T", "W1T",
+            "y1", "rstd1", "g1", "b1", "dg1", "db1", "WoT", "dfo", "dfod", "dz", "daod", "dao", "dctx")
+
+
+class RbwSeg(C.Structure):
+    """mirror of `magic_rowbwd_seg` (include/magic_hip.h)"""
+    _fields_ = [("M", i32), ("pad0", i32)] + [(n, vp) for n in RBW_PTRS] + [("site_out", u32), ("site_ao", u32)]
+
+
+class RbwParams(C.Structure):
+    _fields_ = [("seg", RbwSeg * 2), ("nseg", i32), ("blocks0", i32), ("p_hidden", f32), ("pad1", i32), ("seed", vp)]
 
 
 _ERR = {-1: "MAGIC_ERR_ARG", -2: "MAGIC_ERR_LAUNCH", -3: "MAGIC_ERR_UNSUPPORTED"}

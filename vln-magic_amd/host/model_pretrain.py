@@ -586,8 +586,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         n, plan = self.net, c.plan
         if flush_first:
             O.flush_dw(keep_active=True)
-        self._par(lambda: n.text_bwd(c.txt, plan, c.d_txt, c.dP_txt),
-                  lambda: n.pano_bwd(c.pano, plan, c.d_pano, c.d_fused, c.dP_pano))
+        if n.rbw_ok() and n.enc_ok(plan["L"], self.config.num_l_layers) and n.enc_ok(plan["V"], self.config.num_pano_layers):
+            n.encoders_bwd(c.txt, c.pano, plan, c.d_txt, c.dP_txt, c.d_pano, c.d_fused, c.dP_pano)      # both stacks in shared launches
+        else:
+            self._par(lambda: n.text_bwd(c.txt, plan, c.d_txt, c.dP_txt),
+                      lambda: n.pano_bwd(c.pano, plan, c.d_pano, c.d_fused, c.dP_pano))
         O.flush_dw()                           # deferred weight-gradient GEMMs, ~8 problems per launch
         O.join_side()                          # (opt-in) weight-gradient GEMMs forked to the side stream
         self._ctx = None

@@ -434,6 +434,39 @@ def encoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
     L.call("magic_encoder_fwd", C.addressof(P), C.sizeof(P), L.stream())
 
 
+FUSED_RBW = not os.environ.get("MAGIC_NO_FUSED_RBW")
+_RBW_OK = {}
+
+
+def rowbwd_ok(dtype, H, I):
+    if not FUSED_RBW or dtype != torch.bfloat16:
+        return False
+    key = (H, I)
+    if key not in _RBW_OK:
+        lib = L.load()
+        _RBW_OK[key] = bool(lib.magic_rowbwd_supported(L.dt(dtype), H, I)) and lib.magic_rowbwd_params_bytes() == __import__("ctypes").sizeof(L.RbwParams)
+    return _RBW_OK[key]
+
+
+def rowbwd(segs, seed, p_hidden):
+    """segs: 1 or 2 dicts with the fields of magic_rowbwd_seg (tensors) + M + flops: the per-token backward chain of one block per
+    segment (csrc/encbwd.hip)"""
+    import ctypes as C
+    _chk(1 <= len(segs) <= 2, "rowbwd segments")
+    P = L.RbwParams()
+    P.nseg, P.p_hidden, P.seed = len(segs), float(p_hidden), L.P(seed)
+    for i, sg in enumerate(segs):
+        S = P.seg[i]
+        S.M = int(sg["M"])
+        for k in L.RBW_PTRS:
+            setattr(S, k, L.P(sg.get(k)))
+        S.site_out, S.site_ao = int(sg.get("site_out", 0)), int(sg.get("site_ao", 0))
+        if FLOPS["enabled"]:
+            FLOPS["total"] += sg["flops"]
+            FLOPS["enc"] += sg["flops"]
+    L.call("magic_rowbwd", C.addressof(P), C.sizeof(P), L.stream())
+
+
 _XENC_OK = {}
 FUSED_XENC = not os.environ.get("MAGIC_NO_FUSED_XENC")
 

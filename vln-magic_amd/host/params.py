@@ -83,6 +83,11 @@ class ParamStore:
         self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device) \
             if compute_dtype == torch.bfloat16 else self.flat
         self.shadow_clean = False
+        # transposed bf16 shadow (W^T at the same flat offset) of the matrices the backward row-block kernel reads (csrc/encbwd.hip);
+        # spans register themselves through t_span(); refreshed right after the ordinary shadow
+        self.shadow_t = None
+        self.t_spans = {}
+        self.shadow_t_clean = False
         if requires_grad and compute_dtype == torch.bfloat16:
             _LIVE.add(self)
             _install_optimizer_hook()
@@ -114,6 +119,34 @@ class ParamStore:
         """[rows, cols] compute-dtype view starting at `first` spanning consecutive tensors (fused QKV)."""
         off = self.offsets[first][0]
         return self.shadow[off:off + rows * cols].view(rows, cols)
+
+    def t_span(self, first, rows, cols):
+        """[cols, rows] bf16 view = transpose of the [rows, cols] span starting at `first`; kept current by sync_shadow / FusedAdamW"""
+        off = self.offsets[first][0]
+        if self.shadow_t is None:
+            self.shadow_t = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+        if off not in self.t_spans:
+            self.t_spans[off] = (rows, cols)
+            self.shadow_t_clean = False
+            self._t_arrays = None
+            if self.shadow_clean and self.device.type == "cuda":      # registered after the shadow was last refreshed: fill it in now
+                self.sync_shadow_t(force=True)
+        return self.shadow_t[off:off + rows * cols].view(cols, rows)
+
+    def sync_shadow_t(self, force=False):
+        """one launch: every registered span of the (clean) shadow -> its transpose"""
+        if not self.t_spans or (self.shadow_t_clean and not force):
+            return
+        import ctypes as C
+        from . import lib as L
+        if getattr(self, "_t_arrays", None) is None:
+            offs = sorted(self.t_spans)
+            n = len(offs)
+            self._t_arrays = (n, (C.c_longlong * n)(*offs), (C.c_int * n)(*[self.t_spans[o][0] for o in offs]),
+                              (C.c_int * n)(*[self.t_spans[o][1] for o in offs]))
+        n, a_off, a_rows, a_cols = self._t_arrays
+        L.call("magic_transpose_spans", L.P(self.shadow), L.P(self.shadow_t), n, C.addressof(a_off), C.addressof(a_rows), C.addressof(a_cols), L.stream())
+        self.shadow_t_clean = True
 
     def master_span(self, first, n):
         off = self.offsets[first][0]
@@ -171,6 +204,8 @@ class ParamStore:
             from . import lib as L
             L.call("magic_cast", 1, self.total, L.P(self.flat), L.P(self.shadow), L.stream())
             self.shadow_clean = True
+            self.shadow_t_clean = False
+        self.sync_shadow_t()
 
     def zero_grad(self):
         self.grad.zero_()

@@ -71,6 +71,8 @@ class FusedAdamW:
                         lr, b1, b2, self.eps, wd, step_size, self.ss if use_clip else None, self.max_norm if use_clip else 0.0, gscale,
                         lr_ss=lr_ss)
         s.shadow_clean = True
+        if shadow is not None and s.t_spans:           # the AdamW kernel rewrote the bf16 shadow: its transposed copy follows
+            s.sync_shadow_t(force=True)
         return lr
 
 

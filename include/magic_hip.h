@@ -271,9 +271,11 @@ int magic_xencoder_fwd(const void* params, int nbytes, void* stream);
  * attention-output norm -> d_ctx = d_aod Wo, one launch for 1 or 2 encoders ("segments"); bf16, H = 128, FFN 512.  Reads the TRANSPOSED
  * bf16 weights (W^T, see magic_transpose_spans); writes the dY operands of the deferred weight-gradient GEMMs (d_fod, d_z, d_aod), d_ao
  * (residual of the next tail) and d_ctx (input of magic_attn_bwd); gamma / beta gradients by atomics.  dqkv_n == NULL: no tail, the
- * (d_fo, d_fod) pair is given (top block of an encoder). */
+ * (d_fo, d_fod) pair is given (top block of an encoder).  kt = k-steps of 32 of the tail product: 12 (dqkv_n is [M, 3H]) or 4 (a [M, H]
+ * query gradient).  z == NULL selects the SHORT chain of a cross-modal block's query side: tail (dQ Wq + d_co) -> LayerNorm backward
+ * through the self-attention output norm (y2 / rstd2 / g2 / b2 / dg2 / db2, mask site_out) -> dfo = d_ao, dfod = d_aod -> dctx = d_aod Wo. */
 typedef struct {
-  int M, pad0;
+  int M, kt;
   const void* dqkv_n; const void* WqkvT_n; const void* dao_n; const void* dfo_in; const void* dfod_in;
   const void* y2; const float* rstd2; const float* g2; const float* b2; float* dg2; float* db2;
   const void* z; const void* W2T; const void* W1T;

@@ -221,3 +221,44 @@ def test_rowblock_backward_matches_the_per_op_backward(p_drop):
         worst = max(worst, ((ga - gb).norm() / gb.norm()).item())
         assert ((ga - gb).norm() / gb.norm()).item() < 6e-2, (nm, ((ga - gb).norm() / gb.norm()).item())
     print(f"row-block backward vs per-op: cosine {cos:.6f}, rel L2 {rel:.2e}, worst tensor {worst:.2e}")
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("task", ["sap", "mlm", "mrc"])
+def test_cross_encoder_rowblock_backward_matches_the_per_op_backward(task, p_drop):
+    """whole backward with the cross-modal encoders (and the text / panorama stacks) on magic_rowbwd -- full chain + short chain per
+    block -- vs the per-op backward: same forward, same dropout seed -> the same gradient for every parameter"""
+    m = student(p_drop, **({"pretrain_tasks": ["mlm", "sap", "mrc"]} if task == "mrc" else {}))
+    m.train()
+    batch = synth.make_batch(task, batch_size=6, seed=11, step=0, dup_view_prob=0.3)
+    res = {}
+    for fused in (False, True):
+        O.FUSED_RBW = fused
+        try:
+            m.store.zero_grad()
+            torch.manual_seed(0)                   # the dropout seed of the step is drawn from the device generator
+            out = m(batch, task, compute_loss=True)
+            assert m.net.rbw_ok() == fused
+            m.backward()
+            torch.cuda.synchronize()
+            res[fused] = (float(out["loss"].detach()), m.store.grad.clone())
+        finally:
+            O.FUSED_RBW = True
+    (l1, a), (l0, b) = res[True], res[False]
+    assert abs(l1 - l0) <= 1e-6 * max(abs(l0), 1.0), (l1, l0)      # the forward is the same code on both sides
+    assert torch.isfinite(a).all() and a.abs().max() > 0
+    cos = F.cosine_similarity(a, b, dim=0).item()
+    rel = ((a - b).norm() / b.norm()).item()
+    names = [nm for nm, _ in m.named_parameters() if ("global_encoder" in nm or "local_encoder" in nm)]
+    top = max(b[m.store.offsets[nm][0]:m.store.offsets[nm][0] + m.store.offsets[nm][1]].norm().item() for nm in names)
+    worst = 0.0
+    for nm in names:
+        off, cnt, _ = m.store.offsets[nm]
+        ga, gb = a[off:off + cnt], b[off:off + cnt]
+        if gb.norm().item() < 1e-3 * top:
+            assert ga.norm().item() < 1e-2 * top, nm
+            continue
+        worst = max(worst, ((ga - gb).norm() / gb.norm()).item())
+        assert ((ga - gb).norm() / gb.norm()).item() < 6e-2, (nm, ((ga - gb).norm() / gb.norm()).item())
+    print(f"{task} p={p_drop}: cross row-block backward vs per-op: cosine {cos:.6f}, rel L2 {rel:.2e}, worst cross tensor {worst:.2e}")
+    assert cos > 0.9995 and rel < 3e-2, (cos, rel)

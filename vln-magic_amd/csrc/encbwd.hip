@@ -23,7 +23,7 @@
 
 
 struct RbwSeg {
-  int M, pad0;
+  int M, kt;                                                        // kt: k-steps of the tail product (12: dQKV [M,3H]; 4: a dQ [M,H])
   const bf16* dqkv_n; const bf16* WqkvT_n; const bf16* dao_n;      // tail of the next block (dqkv_n == null: d_fo / d_fod are given)
   const bf16* dfo_in; const bf16* dfod_in;
   const bf16* y2; const float* rstd2; const float* g2; const float* b2; float* dg2; float* db2;     // this block's output LayerNorm
@@ -134,6 +134,8 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
   const int nv = min(RB_ROWS, M - m0);
   const int colw = w * 16 + c16;
   const bool tail = sg.dqkv_n != nullptr;
+  const bool shortm = sg.z == nullptr;           // short chain (cross-attention query side): tail -> LayerNorm backward -> output projection
+  const int kt = sg.kt, ldq = kt * 32;
   DropDesc dd;
   dd.seed = p.seed; dd.p = p.p_hidden;
   // ---- weights of the first two products + small parameters, issued before anything else
@@ -141,15 +143,17 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
   bf16x8 wq[12];
   if (tail) {
 #pragma unroll
-    for (int ks = 0; ks < (DEEP ? 12 : 4); ++ks) wq[ks] = gfrag(sg.WqkvT_n, 3 * EH, w * 16, ks * 32, lane);
+    for (int ks = 0; ks < (DEEP ? 12 : 4); ++ks)
+      if (ks < kt) wq[ks] = gfrag(sg.WqkvT_n, ldq, w * 16, ks * 32, lane);
   }
   bf16x8 w2[4][4];
-  const float gm2 = sg.g2[colw], bt2 = sg.b2[colw], gm1 = sg.g1[colw], bt1 = sg.b1[colw];
+  const float gm2 = sg.g2[colw], bt2 = sg.b2[colw];
+  const float gm1 = shortm ? 0.f : sg.g1[colw], bt1 = shortm ? 0.f : sg.b1[colw];     // (the short chain has no second LayerNorm)
   // ---- stage the block's rows: z, a, and either (out, d_ao of the next block) for the tail or the given (d_fo, d_fod)
   // tail: the dQKV rows of the block above pass through the z image's space first (z itself is fetched during the tail's epilogue)
-  if (tail) load_rows_img(sZ, QS, sg.dqkv_n + (long long)m0 * 3 * EH, 3 * EH, RB_ROWS, 3 * EH, nv, tid);
+  if (tail) load_rows_img(sZ, QS, sg.dqkv_n + (long long)m0 * ldq, ldq, RB_ROWS, ldq, nv, tid);
   else load_rows_img(sZ, GS, sg.z + (long long)m0 * EI, EI, RB_ROWS, EI, nv, tid);
-  load_rows_img(sY1, XS, sg.y1 + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
+  if (!shortm) load_rows_img(sY1, XS, sg.y1 + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
   if (tail) {
     load_rows_img(sY2, XS, sg.y2 + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
     load_rows_img(sR, XS, sg.dao_n + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
@@ -165,9 +169,10 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
     for (int i = 0; i < NRT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      if (!DEEP && ch < 2) {
+      if (4 * ch >= kt) break;
+      if (!DEEP && ch < 2 && 4 * ch + 4 < kt) {
 #pragma unroll
-        for (int ks = 4 * ch + 4; ks < 4 * ch + 8; ++ks) wq[ks] = gfrag(sg.WqkvT_n, 3 * EH, w * 16, ks * 32, lane);
+        for (int ks = 4 * ch + 4; ks < 4 * ch + 8; ++ks) wq[ks] = gfrag(sg.WqkvT_n, ldq, w * 16, ks * 32, lane);
       }
 #pragma unroll
       for (int ks = 4 * ch; ks < 4 * ch + 4; ++ks) {
@@ -185,7 +190,7 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
       const int id = tid + it * NWAVE * 64, r = id / (EI / 8), c = (id % (EI / 8)) * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) zr[it][e] = (bf16)0.0f;
-      if (r < nv) zr[it] = *(const bf16x8*)(sg.z + (long long)(m0 + r) * EI + c);
+      if (r < nv && !shortm) zr[it] = *(const bf16x8*)(sg.z + (long long)(m0 + r) * EI + c);
     }
 #pragma unroll
     for (int i = 0; i < NRT; ++i)
@@ -203,6 +208,11 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
     copy_out(sFo, XS, sg.dfo + (long long)m0 * EH, EH, nv, EH, tid);
     copy_out(sD, XS, sg.dfod + (long long)m0 * EH, EH, nv, EH, tid);
   }
+  bf16x8 wo[4];
+  if (shortm) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wo[ks] = gfrag(sg.WoT, EH, w * 16, ks * 32, lane);
+  } else {
   // ================= FFN: d_z = (d_fod W2) * gelu'(z) : 32 column tiles, 4 per wave =================
   bf16x8 w1[16];
   {
@@ -245,7 +255,6 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
   __syncthreads();                               // d_z image complete
   copy_out(sZ, GS, sg.dz + (long long)m0 * EI, EI, nv, EI, tid);
   // ================= d_a = d_z W1 + d_fo -> LayerNorm backward (attention-output norm) =================
-  bf16x8 wo[4];
   {
     f32x4 acc[NRT];
 #pragma unroll
@@ -279,7 +288,8 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
   __syncthreads();                               // d_ao / d_aod images complete
   copy_out(sAo, XS, sg.dao + (long long)m0 * EH, EH, nv, EH, tid);
   copy_out(sD, XS, sg.daod + (long long)m0 * EH, EH, nv, EH, tid);
-  // ================= d_ctx = d_aod Wo =================
+  }
+  // ================= d_ctx = d_aod Wo (short chain: the tail's dense-branch gradient) =================
   {
     f32x4 acc[NRT];
 #pragma unroll
@@ -325,10 +335,15 @@ extern "C" int magic_rowbwd(const void* params, int nbytes, void* stream) {
     RbwSeg& sg = p.seg[s];
     if (s >= p.nseg) { sg.M = 0; continue; }
     if (sg.M <= 0 || (long long)sg.M * EI > 0x7FFFFFFFll) return MAGIC_ERR_ARG;
-    const void* req[] = {sg.y2, sg.rstd2, sg.g2, sg.b2, sg.z, sg.W2T, sg.W1T, sg.y1, sg.rstd1, sg.g1, sg.b1, sg.WoT, sg.dz, sg.daod, sg.dao, sg.dctx};
+    const void* req[] = {sg.y2, sg.rstd2, sg.g2, sg.b2, sg.WoT, sg.dctx};
     for (const void* q : req)
       if (!q) return MAGIC_ERR_ARG;
-    if (sg.dqkv_n) { if (!sg.WqkvT_n || !sg.dao_n || !sg.dfo || !sg.dfod) return MAGIC_ERR_ARG; }
+    if (sg.z) {                       // full chain
+      const void* full[] = {sg.W2T, sg.W1T, sg.y1, sg.rstd1, sg.g1, sg.b1, sg.dz, sg.daod, sg.dao};
+      for (const void* q : full)
+        if (!q) return MAGIC_ERR_ARG;
+    } else if (!sg.dqkv_n) return MAGIC_ERR_ARG;      // the short chain is a tail by definition
+    if (sg.dqkv_n) { if (!sg.WqkvT_n || !sg.dao_n || !sg.dfo || !sg.dfod || (sg.kt != 4 && sg.kt != 12)) return MAGIC_ERR_ARG; }
     else if (!sg.dfo_in || !sg.dfod_in) return MAGIC_ERR_ARG;
     if ((sg.dg2 == nullptr) != (sg.db2 == nullptr) || (sg.dg1 == nullptr) != (sg.db1 == nullptr)) return MAGIC_ERR_ARG;
     const void* al[] = {sg.dqkv_n, sg.WqkvT_n, sg.dao_n, sg.dfo_in, sg.dfod_in, sg.y2, sg.z, sg.W2T, sg.W1T, sg.y1, sg.WoT, sg.dfo, sg.dfod, sg.dz, sg.daod, sg.dao, sg.dctx};

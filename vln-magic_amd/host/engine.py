@@ -149,6 +149,13 @@ class MagicNet:
                     for lin in (self.lin(lp + "attention.self.query.weight", rows=3 * self.H, cols=self.H), self.lin(lp + "attention.output.dense.weight"),
                                 self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")):
                         lin.WT
+            for enc in ("global_encoder.", "local_encoder."):
+                for i in range(cfg.num_x_layers):
+                    lp = f"{prefix}{enc}encoder.crossattention.{i}."
+                    for lin in (self.lin(lp + "attention.self.query.weight", rows=3 * self.H, cols=self.H), self.lin(lp + "attention.output.dense.weight"),
+                                self.lin(lp + "crossattention.self.query.weight"), self.lin(lp + "crossattention.output.dense.weight"),
+                                self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")):
+                        lin.WT
 
     # ---- dropout sites (counter-based masks, csrc/common.hpp) -------------------------------------
     def set_dropout(self, seed=None, p_hidden=0.0, p_attn=0.0):
@@ -905,7 +912,106 @@ class MagicNet:
         O.xencoder_fwd(segs, d[0] if d else None, d[2] if d else 0.0, d[1] if d else 0.0, self.eps, 1.0 / math.sqrt(HD))
         return outs
 
+    def _grouped(self, fns, ok=True):
+        """run the launches of `fns` (independent of each other) as ONE grouped launch when `ok`, else one after the other"""
+        from . import lib as L
+        if ok and len(fns) > 1:
+            with L.group():
+                for f in fns:
+                    f()
+        else:
+            for f in fns:
+                f()
+
+    def cross_stacks_bwd(self, stacks):
+        """Backward of 1 or 2 cross-modal encoders on the row-block kernel.  stacks: tuples (cross ctx, d_out = plain gradient wrt the
+        encoder's output, d_ctx_acc = accumulator of the gradient wrt the context rows, dP_init for the top block's cross-attention map).
+        Per block five launches shared by the two encoders -- full chain (tail of the block above + FFN + output-norm and
+        cross-attention-output-norm backwards + cross output projection), cross-attention backward, key/value input gradient into the
+        context accumulator, short chain (dQ Wq + residual -> self-attention-output-norm backward -> self output projection),
+        self-attention backward -- instead of nine.  Returns the gradients wrt the encoders' inputs."""
+        H, I = self.H, self.I
+        st = []
+        for c, d_top, d_acc, dP in stacks:
+            enc = self.p + ("global_encoder." if c.which == "global" else "local_encoder.")
+            _, dsprel = self._sprel() if (c.which == "global" and c.dist is not None) else (None, None)
+            lc = c.layers[-1]
+            st.append(Ctx(c=c, fmt=enc + "encoder.crossattention.{}.", j=len(c.layers) - 1, M=lc.Bn * lc.Nq, Mk=lc.Bn * lc.Nk, dP=dP, d_top=d_top,
+                          d_acc=d_acc, dsprel=dsprel, pre=None, dqkv=None, dao=None, dx0=None))
+
+        def top_ln(s):
+            s.pre = self._through_ln(s.d_top, self._out_ln_desc(s.fmt.format(s.j), s.c.layers[s.j]), s.M)
+        self._grouped([lambda s=s: top_ln(s) for s in st])
+        d = self.drop
+        seed, ph = (d[0] if d else None), (d[1] if d else 0.0)
+        for j in reversed(range(len(st[0].c.layers))):
+            segs, act = [], []
+            for s in st:
+                M = s.M
+                lp, lc = s.fmt.format(j), s.c.layers[j]
+                sa, ffn = lc.sa, lc.ffn
+                W = Ctx(f1=self.lin(lp + "intermediate.dense.weight"), f2=self.lin(lp + "output.dense.weight"),
+                        co=self.lin(lp + "crossattention.output.dense.weight"), cq=self.lin(lp + "crossattention.self.query.weight"),
+                        ckv=self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H),
+                        o=self.lin(lp + "attention.output.dense.weight"), qkv=self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H))
+                n2, nc, n1 = self.ln(lp + "output.LayerNorm"), self.ln(lp + "crossattention.output.LayerNorm"), self.ln(lp + "attention.output.LayerNorm")
+                out = Ctx(dz=self.new(M, I), dcod=self.new(M, H), dco=self.new(M, H), dcctx=self.new(M, H), dq=self.new(M, H),
+                          dkv=self.new(s.Mk, 2 * H), dao=self.new(M, H), daod=self.new(M, H), dctx=self.new(M, H), dqkv=self.new(M, 3 * H))
+                seg = dict(M=M, y2=ffn.out, rstd2=ffn.rstd, g2=n2.g, b2=n2.b, z=ffn.z, W2T=W.f2.WT, W1T=W.f1.WT, y1=lc.c, rstd1=lc.rstd_c,
+                           g1=nc.g, b1=nc.b, dg1=nc.dg, db1=nc.db, WoT=W.co.WT, dz=out.dz, daod=out.dcod, dao=out.dco, dctx=out.dcctx,
+                           site_out=ffn.hdrop[2] if ffn.hdrop else 0, site_ao=lc.hdrop[2] if lc.hdrop else 0)
+                flops = 2.0 * ffn.rows * (2 * H * I + H * H)
+                if s.pre is not None:
+                    out.dfo, out.dfod = s.pre
+                    seg.update(dfo_in=out.dfo, dfod_in=out.dfod)
+                    s.pre = None
+                else:
+                    qn = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
+                    out.dfo, out.dfod = self.new(M, H), self.new(M, H)
+                    seg.update(dqkv_n=s.dqkv, kt=12, WqkvT_n=qn.WT, dao_n=s.dao, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
+                    flops += 2.0 * ffn.rows * 3 * H * H
+                seg["flops"] = flops
+                segs.append(seg)
+                act.append((s, lc, W, n1, out))
+            O.rowbwd(segs, seed, ph)                                   # full chain
+            top = j == len(st[0].c.layers) - 1
+            self._grouped([lambda s=s, lc=lc, out=out: self._attn_bwd(
+                lc.Ppre, lc.ldp, out.dcctx, lc.q, H, lc.kv, lc.kv[:, H:], 2 * H, out.dq, H, out.dkv, out.dkv[:, H:], 2 * H, lc.Bn, lc.Nq, lc.Nk,
+                None, None, s.dP if top else None, lc.cflops, lc.adrop, lc.P if lc.adrop else None) for s, lc, W, n1, out in act],
+                ok=all(O.attn_supported(self.dtype, lc.Nq, lc.Nk, True) for _, lc, _, _, _ in act) and FUSED_ATTN)
+            self._grouped([lambda s=s, lc=lc, W=W, out=out: O.linear_dx(out.dkv, W.ckv.W, s.Mk, out=s.d_acc, residual=s.d_acc, flop_rows=lc.crow)
+                           for s, lc, W, n1, out in act])
+            segs = []
+            for s, lc, W, n1, out in act:
+                sa = lc.sa
+                segs.append(dict(M=s.M, kt=4, dqkv_n=out.dq, WqkvT_n=W.cq.WT, dao_n=out.dco, y2=sa.a, rstd2=sa.rstd_a, g2=n1.g, b2=n1.b,
+                                 dg2=n1.dg, db2=n1.db, WoT=W.o.WT, dfo=out.dao, dfod=out.daod, dctx=out.dctx,
+                                 site_out=sa.hdrop[2] if sa.hdrop else 0, flops=2.0 * sa.rows * 2 * H * H))
+            O.rowbwd(segs, seed, ph)                                   # short chain
+            self._grouped([lambda s=s, lc=lc, out=out: self._attn_bwd(
+                lc.sa.Ppre, lc.sa.ldp, out.dctx, lc.sa.qkv, 3 * H, lc.sa.qkv[:, H:], lc.sa.qkv[:, 2 * H:], 3 * H,
+                out.dqkv, 3 * H, out.dqkv[:, H:], out.dqkv[:, 2 * H:], 3 * H, lc.Bn, lc.Nq, lc.Nq, lc.sa.dist, s.dsprel, None, lc.sa.aflops,
+                lc.sa.adrop, lc.sa.P if lc.sa.adrop else None) for s, lc, W, n1, out in act],
+                ok=all(O.attn_supported(self.dtype, lc.Nq, lc.Nq, True) for _, lc, _, _, _ in act) and FUSED_ATTN)
+            for s, lc, W, n1, out in act:
+                sa, ffn, M = lc.sa, lc.ffn, s.M
+                O.linear_dw(out.dfod, ffn.g, W.f2.dW, W.f2.db, M, flop_rows=ffn.rows)
+                O.linear_dw(out.dz, ffn.a, W.f1.dW, W.f1.db, M, flop_rows=ffn.rows)
+                O.linear_dw(out.dcod, lc.cctx, W.co.dW, W.co.db, M, flop_rows=lc.rows)
+                O.linear_dw(out.dq, sa.a, W.cq.dW, W.cq.db, M, flop_rows=lc.rows)
+                O.linear_dw(out.dkv, lc.ctx, W.ckv.dW, W.ckv.db, s.Mk, flop_rows=lc.crow)
+                O.linear_dw(out.daod, sa.ctx, W.o.dW, W.o.db, M, flop_rows=sa.rows)
+                O.linear_dw(out.dqkv, sa.x, W.qkv.dW, W.qkv.db, M, flop_rows=sa.rows)
+                s.dqkv, s.dao = out.dqkv, out.dao
+            if j == 0:
+                def dx0(s, lc, W, out):
+                    s.dx0 = O.linear_dx(out.dqkv, W.qkv.W, s.M, residual=out.dao, flop_rows=lc.sa.rows)
+                self._grouped([lambda s=s, lc=lc, W=W, out=out: dx0(s, lc, W, out) for s, lc, W, n1, out in act])
+        return [s.dx0 for s in st]
+
     def cross_bwd(self, c, d_out, d_ctx_acc, dP_init=None, dkv=None):
+        if dkv is None and self.rbw_ok() and not any(lc.kv_given for lc in c.layers):
+            return self.cross_stacks_bwd([(c, d_out, d_ctx_acc, dP_init)])[0]
         enc = self.p + ("global_encoder." if c.which == "global" else "local_encoder.")
         _, dsprel = self._sprel() if (c.which == "global" and c.dist is not None) else (None, None)
         d = d_out

@@ -138,7 +138,7 @@ RBW_PTRS = ("dqkv_n", "WqkvT_n", "dao_n", "dfo_in", "dfod_in", "y2", "rstd2", "g
 
 class RbwSeg(C.Structure):
     """mirror of `magic_rowbwd_seg` (include/magic_hip.h)"""
-    _fields_ = [("M", i32), ("pad0", i32)] + [(n, vp) for n in RBW_PTRS] + [("site_out", u32), ("site_ao", u32)]
+    _fields_ = [("M", i32), ("kt", i32)] + [(n, vp) for n in RBW_PTRS] + [("site_out", u32), ("site_ao", u32)]
 
 
 class RbwParams(C.Structure):

@@ -571,8 +571,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             n.vp_in_bwd(c.vin, plan, d_vin, c.d_pano)
         else:
             d_txt2 = n.zeros(B * L, H)           # the two encoders accumulate their text gradients separately (no race)
-            d_gin, d_vin = self._par(lambda: n.cross_bwd(c.glob, c.d_gmap, c.d_txt, c.dP_g),
-                                     lambda: n.cross_bwd(c.loc, c.d_vp, d_txt2, c.dP_l))
+            if n.rbw_ok():                       # both encoders in shared row-block launches (engine.cross_stacks_bwd)
+                d_gin, d_vin = n.cross_stacks_bwd([(c.glob, c.d_gmap, c.d_txt, c.dP_g), (c.loc, c.d_vp, d_txt2, c.dP_l)])
+            else:
+                d_gin, d_vin = self._par(lambda: n.cross_bwd(c.glob, c.d_gmap, c.d_txt, c.dP_g),
+                                         lambda: n.cross_bwd(c.loc, c.d_vp, d_txt2, c.dP_l))
             O.add_(c.d_txt, d_txt2)
             n.vp_in_bwd(c.vin, plan, d_vin, c.d_pano)
         if task != "mrc":

@@ -457,7 +457,7 @@ def rowbwd(segs, seed, p_hidden):
     P.nseg, P.p_hidden, P.seed = len(segs), float(p_hidden), L.P(seed)
     for i, sg in enumerate(segs):
         S = P.seg[i]
-        S.M = int(sg["M"])
+        S.M, S.kt = int(sg["M"]), int(sg.get("kt", 12))
         for k in L.RBW_PTRS:
             setattr(S, k, L.P(sg.get(k)))
         S.site_out, S.site_ao = int(sg.get("site_out", 0)), int(sg.get("site_ao", 0))

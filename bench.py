@@ -440,7 +440,7 @@ def main():
         gemm_n = sum(c for k, (t, c) in by.items() if fam(k))
         all_ms = sum(t for t, c in by.values())
         flops = O.FLOPS["gemm"]            # the GEMM family's own algorithmic FLOPs (fused linear+LN and attention kernels count separately)
-        is_mfma = lambda k: any(x in k for x in ("magic_gemm", "magic_linear_ln", "magic_attn_", "magic_rowblock", "magic_encoder"))
+        is_mfma = lambda k: any(x in k for x in ("magic_gemm", "magic_linear_ln", "magic_attn_", "magic_rowblock", "magic_encoder", "magic_xencoder", "magic_rowbwd"))
         mfma_ms = sum(t for k, (t, c) in by.items() if is_mfma(k))
         step_ms = dt / a.steps * 1e3
         # achieved = the family's algorithmic FLOPs / the family's SUMMED launch durations (non-overlapped pass), i.e.
@@ -459,7 +459,7 @@ def main():
                            "gemm_ms_per_step": round(gemm_ms / nprof, 3), "avg_gemm_launch_us": round(gemm_ms / max(gemm_n, 1) * 1e3, 2),
                            "gemm_share_of_kernel_time": round(gemm_ms / all_ms, 4),
                            "all_dense_contraction_kernels": {
-                               "kernels": "gemm + fused linear+LayerNorm (fwd / bwd) + fused attention (fwd / bwd) + whole-encoder forward",
+                               "kernels": "gemm + fused linear+LayerNorm (fwd / bwd) + fused attention (fwd / bwd) + whole-encoder forwards + row-block backward",
                                "algorithmic_gflop_per_step": round(O.FLOPS["total"] / nprof / 1e9, 2),
                                "gflop_by_family": {k: round(O.FLOPS[k] / nprof / 1e9, 2) for k in ("gemm", "linear_ln", "attn", "enc")},
                                "ms_per_step": round(mfma_ms / nprof, 3), "share_of_kernel_time": round(mfma_ms / all_ms, 4),

@@ -89,7 +89,9 @@ int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void* y, const f
                  const int* idx0, int mod0, int off0, float* d0, int small0,
                  const int* idx1, int mod1, int off1, float* d1, int small1,
                  const int* idx2, int mod2, int off2, float* d2, int small2,
-                 int do_ln, const void* drop_seed, float drop_p, unsigned site_dy, unsigned site_dx, void* dxm, void* stream);
+                 int do_ln, const void* drop_seed, float drop_p, unsigned site_dy, unsigned site_dx, void* dxm, int hot0, void* stream);
+/* hot0 >= 0: a row of indexed table 0 that a large share of the input rows hit (the padding token id of the word-embedding lookup): its
+ * gradient is summed per workgroup in LDS and added with one atomic per element and workgroup (else -1). */
 
 /* gamma/beta gradients of one LayerNorm as a column reduction (used when magic_ln_bwd is called with dgamma = dbeta = NULL) */
 int magic_ln_pgrad(int dtype, int M, int H, const void* dy, const void* y, const float* gamma, const float* beta,

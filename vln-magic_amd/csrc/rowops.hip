@@ -92,9 +92,12 @@ struct LnbParams {
   TabRef t0; float* d0; int small0; TabRef t1; float* d1; int small1; TabRef t2; float* d2; int small2; int do_ln;
   DropDesc ddy;               // the forward dropped its OUTPUT: dy is masked on load
   void* dxm; DropDesc ddx;    // the forward dropped its in0: second output dxm = dx * mask (gradient of the dense branch)
+  int hot0;                   // >= 0: row of indexed table 0 that very many input rows hit (the padding token): summed per block in LDS
 };
 
-template <typename T, int NIT>
+// NW = waves per block.  Every block ends in one same-address atomic per parameter / const-table element, and those serialise in L2
+// (measured, M = 10.7 k rows, H = 128: 16.8 us with the gamma / beta gradients, 5.6 without): 16 waves per block = 4x fewer blocks.
+template <typename T, int NIT, int NW>
 __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, const int nblk, float* red) {
   const int M = pp.M, do_ln = pp.do_ln, small0 = pp.small0, small1 = pp.small1, small2 = pp.small2;
   const T* dy = (const T*)pp.dy; const T* y = (const T*)pp.y; T* dx = (T*)pp.dx;
@@ -103,19 +106,30 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
   const TabRef t0 = pp.t0, t1 = pp.t1, t2 = pp.t2;
   const DropState sdy = drop_init(pp.ddy), sdx = drop_init(pp.ddx);
   T* dxm = (T*)pp.dxm;
-  constexpr int H = NIT * 128;     // red: [2][4 waves][H] gamma/beta partials | [9][H] table slots
-  float* tacc = red + 8 * H;
+  constexpr int H = NIT * 128;     // red: [2][NW waves][H] gamma/beta partials | [9][H] table slots
+  constexpr int NT = NW * 64;
+  float* tacc = red + 2 * NW * H;
+  const int hot0 = (d0 && t0.idx && !small0) ? pp.hot0 : -1;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool c0 = d0 && !t0.idx && !t0.mod, c1 = d1 && !t1.idx && !t1.mod, c2 = d2 && !t2.idx && !t2.mod;
   const bool l0 = d0 && (c0 || small0), l1 = d1 && (c1 || small1), l2 = d2 && (c2 || small2);   // LDS-slot tables
-  const bool any_lds = l0 || l1 || l2;
+  const bool any_lds = l0 || l1 || l2 || hot0 >= 0;
   if (any_lds) {
-    for (int i = threadIdx.x; i < 9 * H; i += 256) tacc[i] = 0.f;
+    for (int i = threadIdx.x; i < 9 * H; i += NT) tacc[i] = 0.f;
     __syncthreads();
   }
   float ag[2 * NIT], ab[2 * NIT];
 #pragma unroll
   for (int i = 0; i < 2 * NIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  // gradients of the const-row / tiny tables: per-lane registers over all of the wave's rows (an LDS atomic per row and element -- 16 waves
+  // on the same 128 addresses -- cost 20 of the panorama embedding backward's 30 us), one LDS add per wave at the end
+  float ts[3][3][2 * NIT];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < 2 * NIT; ++i) ts[k][j][i] = 0.f;
   // Position-major traversal when a table is indexed by (row % mod) (the position embeddings): logical row i is physical row
   // (i % Bs) * mod + i / Bs, so the RPI rows a wave handles together share ONE table row and their gradients are merged before the
   // atomics (measured on the text-embedding backward: every position row took B = 48 same-address atomics per element from 48 different
@@ -138,7 +152,7 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
       igm[2 * it] = gm.x != 0.f ? 1.f / gm.x : 0.f; igm[2 * it + 1] = gm.y != 0.f ? 1.f / gm.y : 0.f;
     }
   }
-  for (int base = (bid * 4 + wid) * RPI; base < M; base += nblk * 4 * RPI) {
+  for (int base = (bid * NW + wid) * RPI; base < M; base += nblk * NW * RPI) {
     float g[RPI][2 * NIT], xh[RPI][2 * NIT];
     float s1[RPI], s2[RPI], rs[RPI];
 #pragma unroll
@@ -203,11 +217,9 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
       if (LK) {                                                                              \
         _Pragma("unroll") for (int u = 0; u < RPI; ++u)                                      \
           if (base + u < M) {                                                                \
-            float* slot = tacc + (K * 3 + (CK ? 0 : TK.idx[phys(base + u)])) * H;            \
-            _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                             \
-              const int c = it * 128 + lane * 2;                                             \
-              atomicAdd(slot + c, g[u][2 * it]); atomicAdd(slot + c + 1, g[u][2 * it + 1]);  \
-            }                                                                                \
+            const int sid = CK ? 0 : TK.idx[phys(base + u)];                                 \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j)                                    \
+              _Pragma("unroll") for (int i = 0; i < 2 * NIT; ++i) ts[K][j][i] += (sid == j) ? g[u][i] : 0.f;   \
           }                                                                                  \
       } else {                                                                               \
         float run[2 * NIT];                                                                  \
@@ -219,9 +231,11 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
             _Pragma("unroll") for (int i = 0; i < 2 * NIT; ++i) run[i] += g[u][i];           \
             if (!more) {                                                                     \
               float* dst = DK + (long long)tr * H;                                           \
+              const bool hot = (K == 0) && tr == hot0;                                       \
               _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                           \
                 const int c = it * 128 + lane * 2;                                           \
-                atomicAdd(dst + c, run[2 * it]); atomicAdd(dst + c + 1, run[2 * it + 1]);    \
+                if (hot) { atomicAdd(tacc + c, run[2 * it]); atomicAdd(tacc + c + 1, run[2 * it + 1]); }   \
+                else { atomicAdd(dst + c, run[2 * it]); atomicAdd(dst + c + 1, run[2 * it + 1]); }         \
                 run[2 * it] = 0.f; run[2 * it + 1] = 0.f;                                    \
               }                                                                              \
             }                                                                                \
@@ -233,27 +247,44 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
     TAB_GRAD(2, t2, d2, l2, c2)
 #undef TAB_GRAD
   }
+#define TAB_WAVE(K, LK, CK)                                                                 \
+  if (LK) {                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j)                                            \
+      if (j == 0 || !CK) {                                                                   \
+        _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                 \
+          const int c = it * 128 + lane * 2;                                                 \
+          atomicAdd(tacc + (K * 3 + j) * H + c, ts[K][j][2 * it]); atomicAdd(tacc + (K * 3 + j) * H + c + 1, ts[K][j][2 * it + 1]);   \
+        }                                                                                    \
+      }                                                                                      \
+  }
+  TAB_WAVE(0, l0, c0)
+  TAB_WAVE(1, l1, c1)
+  TAB_WAVE(2, l2, c2)
+#undef TAB_WAVE
   const bool pg = do_ln && dgamma != nullptr;      // gamma/beta grads here, or by ln_pgrad_kernel (dgamma == nullptr)
   if (pg) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int c = it * 128 + lane * 2;
-      red[(0 * 4 + wid) * H + c] = ag[2 * it]; red[(0 * 4 + wid) * H + c + 1] = ag[2 * it + 1];
-      red[(1 * 4 + wid) * H + c] = ab[2 * it]; red[(1 * 4 + wid) * H + c + 1] = ab[2 * it + 1];
+      red[(0 * NW + wid) * H + c] = ag[2 * it]; red[(0 * NW + wid) * H + c + 1] = ag[2 * it + 1];
+      red[(1 * NW + wid) * H + c] = ab[2 * it]; red[(1 * NW + wid) * H + c + 1] = ab[2 * it + 1];
     }
   }
   __syncthreads();
   if (pg) {
-    for (int c = threadIdx.x; c < H; c += 256) {
-      atomicAdd(dgamma + c, red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c]);
-      atomicAdd(dbeta + c, red[4 * H + c] + red[5 * H + c] + red[6 * H + c] + red[7 * H + c]);
+    for (int c = threadIdx.x; c < 2 * H; c += NT) {       // [gamma | beta] x H columns
+      const int q = c / H, cc = c % H;
+      float v = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) v += red[(q * NW + ww) * H + cc];
+      atomicAdd((q ? dbeta : dgamma) + cc, v);
     }
   }
   if (any_lds) {
 #define TAB_FLUSH(K, TK, DK, LK, CK)                                                        \
     if (LK) {                                                                                \
       const int nrow = CK ? 1 : 3;                                                           \
-      for (int i = threadIdx.x; i < nrow * H; i += 256) {                                    \
+      for (int i = threadIdx.x; i < nrow * H; i += NT) {                                     \
         const float v = tacc[K * 3 * H + i];                                                 \
         if (v != 0.f) atomicAdd(DK + (long long)(CK ? TK.off : 0) * H + i, v);               \
       }                                                                                      \
@@ -262,19 +293,24 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
     TAB_FLUSH(1, t1, d1, l1, c1)
     TAB_FLUSH(2, t2, d2, l2, c2)
 #undef TAB_FLUSH
+    if (hot0 >= 0)
+      for (int i = threadIdx.x; i < H; i += NT) {
+        const float v = tacc[i];
+        if (v != 0.f) atomicAdd(d0 + (long long)hot0 * H + i, v);
+      }
   }
 }
 
-template <typename T, int NIT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnbParams p) {
+template <typename T, int NIT, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(LnbParams p) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
-  ln_bwd_body<T, NIT>(p, blockIdx.x, gridDim.x, red_dyn);
+  ln_bwd_body<T, NIT, NW>(p, blockIdx.x, gridDim.x, red_dyn);
 }
-template <typename T, int NIT>
-__global__ __launch_bounds__(256) void ln_bwd_pair_kernel(LnbParams a, LnbParams b, int nA) {
+template <typename T, int NIT, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_pair_kernel(LnbParams a, LnbParams b, int nA) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
-  if ((int)blockIdx.x < nA) ln_bwd_body<T, NIT>(a, blockIdx.x, nA, red_dyn);
-  else ln_bwd_body<T, NIT>(b, blockIdx.x - nA, gridDim.x - nA, red_dyn);
+  if ((int)blockIdx.x < nA) ln_bwd_body<T, NIT, NW>(a, blockIdx.x, nA, red_dyn);
+  else ln_bwd_body<T, NIT, NW>(b, blockIdx.x - nA, gridDim.x - nA, red_dyn);
 }
 
 // gamma/beta gradients of a LayerNorm as a separate column reduction: dgamma[c] += sum_m dy*xhat, dbeta[c] += sum_m dy
@@ -362,14 +398,14 @@ __global__ __launch_bounds__(256) void smallk_ln_fwd_kernel(int M, int H, int Ki
     }
 }
 
-// backward: dW[H,Kin], db[H], dgamma, dbeta (fp32 atomics, block-reduced).  32 rows per block;
-// dz rows are parked in LDS so the dW outer product is a cooperative (c,k) loop.
-#define SK_ROWS 32
-template <typename T, int NIT>
-__global__ __launch_bounds__(256) void smallk_ln_bwd_kernel(int M, int H, int Kin, const float* x, const T* dy, const T* y,
+// backward: dW[H,Kin], db[H], dgamma, dbeta (fp32 atomics, block-reduced).  SK_ROWS rows per block (NW waves);
+// dz rows are parked in LDS so the dW outer product is a cooperative (c,k) loop.  Every block ends in H (Kin + 3) same-address atomics,
+// so at H = 128 a block takes 128 rows with 16 waves (4x fewer blocks than the 32-row / 4-wave shape the wider models keep for LDS).
+template <typename T, int NIT, int NW, int SK_ROWS>
+__global__ __launch_bounds__(NW * 64) void smallk_ln_bwd_kernel(int M, int H, int Kin, const float* x, const T* dy, const T* y,
                                                             const float* gamma, const float* beta, const float* rstd,
                                                             float* dW, float* db, float* dgamma, float* dbeta) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // dz[SK_ROWS][H] | xs[SK_ROWS][16] | red[2][4][H]
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // dz[SK_ROWS][H] | xs[SK_ROWS][16] | red[2][NW][H]
   float* dz = sm;
   float* xs = sm + SK_ROWS * H;
   float* red = xs + SK_ROWS * 16;
@@ -379,7 +415,7 @@ __global__ __launch_bounds__(256) void smallk_ln_bwd_kernel(int M, int H, int Ki
 #pragma unroll
   for (int i = 0; i < 2 * NIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
   const int base = blockIdx.x * SK_ROWS;
-  for (int rr = wid; rr < SK_ROWS; rr += 4) {
+  for (int rr = wid; rr < SK_ROWS; rr += NW) {
     const int row = base + rr;
     const bool ok = row < M;
     float g[2 * NIT], xh[2 * NIT];
@@ -407,14 +443,14 @@ __global__ __launch_bounds__(256) void smallk_ln_bwd_kernel(int M, int H, int Ki
     if (lane < 16) xs[rr * 16 + lane] = (ok && lane < Kin) ? x[(long long)row * Kin + lane] : 0.f;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < H * Kin; i += 256) {
+  for (int i = threadIdx.x; i < H * Kin; i += NW * 64) {
     const int c = i / Kin, k = i % Kin;
     float s = 0.f;
 #pragma unroll 8
     for (int r = 0; r < SK_ROWS; ++r) s += dz[r * H + c] * xs[r * 16 + k];
     atomicAdd(dW + i, s);
   }
-  for (int c = threadIdx.x; c < H; c += 256) {
+  for (int c = threadIdx.x; c < H; c += NW * 64) {
     float s = 0.f;
 #pragma unroll 8
     for (int r = 0; r < SK_ROWS; ++r) s += dz[r * H + c];
@@ -424,13 +460,16 @@ __global__ __launch_bounds__(256) void smallk_ln_bwd_kernel(int M, int H, int Ki
   for (int it = 0; it < NIT; ++it)
     if (it < nit) {
       const int c = it * 128 + lane * 2;
-      red[(0 * 4 + wid) * H + c] = ag[2 * it]; red[(0 * 4 + wid) * H + c + 1] = ag[2 * it + 1];
-      red[(1 * 4 + wid) * H + c] = ab[2 * it]; red[(1 * 4 + wid) * H + c + 1] = ab[2 * it + 1];
+      red[(0 * NW + wid) * H + c] = ag[2 * it]; red[(0 * NW + wid) * H + c + 1] = ag[2 * it + 1];
+      red[(1 * NW + wid) * H + c] = ab[2 * it]; red[(1 * NW + wid) * H + c + 1] = ab[2 * it + 1];
     }
   __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) {
-    atomicAdd(dgamma + c, red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c]);
-    atomicAdd(dbeta + c, red[4 * H + c] + red[5 * H + c] + red[6 * H + c] + red[7 * H + c]);
+  for (int c = threadIdx.x; c < 2 * H; c += NW * 64) {
+    const int q = c / H, cc = c % H;
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) v += red[(q * NW + ww) * H + cc];
+    atomicAdd((q ? dbeta : dgamma) + cc, v);
   }
 }
 
@@ -679,8 +718,9 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
                             const int* idx0, int mod0, int off0, float* d0, int small0,
                             const int* idx1, int mod1, int off1, float* d1, int small1,
                             const int* idx2, int mod2, int off2, float* d2, int small2,
-                            int do_ln, const void* drop_seed, float drop_p, unsigned site_dy, unsigned site_dx, void* dxm, void* stream) {
+                            int do_ln, const void* drop_seed, float drop_p, unsigned site_dy, unsigned site_dx, void* dxm, int hot0, void* stream) {
   if (M <= 0 || !okH(H) || !dy || (H != 128 && H != 256 && H != 384 && H != 768)) return MAGIC_ERR_ARG;
+  if (hot0 >= 0 && (!idx0 || !d0)) return MAGIC_ERR_ARG;
   if (!drop_args_ok(drop_seed, drop_p) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
   const bool don = drop_p > 0.f;
   if (don && site_dx && !dxm) return MAGIC_ERR_ARG;
@@ -690,15 +730,17 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
   LnbParams p{M, dy, y, gamma, beta, rstd, dx, dgamma, dbeta, TabRef{d0, idx0, mod0, off0}, d0, small0, TabRef{d1, idx1, mod1, off1}, d1, small1,
               TabRef{d2, idx2, mod2, off2}, d2, small2, do_ln,
               DropDesc{(don && site_dy) ? (const unsigned*)drop_seed : nullptr, site_dy, drop_p},
-              (don && site_dx) ? dxm : nullptr, DropDesc{(don && site_dx) ? (const unsigned*)drop_seed : nullptr, site_dx, drop_p}};
+              (don && site_dx) ? dxm : nullptr, DropDesc{(don && site_dx) ? (const unsigned*)drop_seed : nullptr, site_dx, drop_p}, hot0};
   const int nit = H / 128;
   if (group_record(KIND_LNB, dtype, nit, &p, sizeof(p))) return MAGIC_OK;
   return launch_lnb(dtype, nit, &p, nullptr, (hipStream_t)stream);
 }
 
+static inline int lnb_waves(int nit) { return nit == 1 ? 16 : nit == 2 ? 8 : 4; }      // waves per block (LDS: (2 NW + 9) H floats; registers)
 static inline int lnb_blocks(const LnbParams& p, int nit) {
   const int rpi = nit <= 2 ? 4 : 2;                 // rows per wave per iteration (ln_bwd_body::RPI)
-  const int nb = (p.M + 4 * rpi - 1) / (4 * rpi);
+  const int nw = lnb_waves(nit);
+  const int nb = (p.M + nw * rpi - 1) / (nw * rpi);
   // with in-kernel gamma/beta grads every block ends in 2H same-address atomics -> cap the grid; without them one row group per wave
   const int cap = p.dgamma ? 512 : 4096;
   return nb > cap ? cap : nb;
@@ -707,19 +749,20 @@ static inline int lnb_blocks(const LnbParams& p, int nit) {
 int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t st) {
   const LnbParams& a = *(const LnbParams*)pa;
   const int H = nit * 128;
-  const size_t shm = (size_t)17 * H * sizeof(float);
-  dim3 block(256);
+  const int nw = lnb_waves(nit);
+  const size_t shm = (size_t)(2 * nw + 9) * H * sizeof(float);
+  dim3 block(nw * 64);
   const int nA = lnb_blocks(a, nit);
-#define LNB1(TY, NIT)                                                                                   \
+#define LNB1(TY, NIT, NW)                                                                               \
   do {                                                                                                  \
-    if (!pb) hipLaunchKernelGGL((ln_bwd_kernel<TY, NIT>), dim3(nA), block, shm, st, a);                 \
+    if (!pb) hipLaunchKernelGGL((ln_bwd_kernel<TY, NIT, NW>), dim3(nA), block, shm, st, a);             \
     else {                                                                                              \
       const LnbParams& b = *(const LnbParams*)pb;                                                       \
-      hipLaunchKernelGGL((ln_bwd_pair_kernel<TY, NIT>), dim3(nA + lnb_blocks(b, nit)), block, shm, st, a, b, nA); \
+      hipLaunchKernelGGL((ln_bwd_pair_kernel<TY, NIT, NW>), dim3(nA + lnb_blocks(b, nit)), block, shm, st, a, b, nA); \
     }                                                                                                   \
   } while (0)
-  if (dtype == DT_BF16) { if (nit == 1) LNB1(bf16, 1); else if (nit == 2) LNB1(bf16, 2); else if (nit == 3) LNB1(bf16, 3); else LNB1(bf16, 6); }
-  else { if (nit == 1) LNB1(float, 1); else if (nit == 2) LNB1(float, 2); else if (nit == 3) LNB1(float, 3); else LNB1(float, 6); }
+  if (dtype == DT_BF16) { if (nit == 1) LNB1(bf16, 1, 16); else if (nit == 2) LNB1(bf16, 2, 8); else if (nit == 3) LNB1(bf16, 3, 4); else LNB1(bf16, 6, 4); }
+  else { if (nit == 1) LNB1(float, 1, 16); else if (nit == 2) LNB1(float, 2, 8); else if (nit == 3) LNB1(float, 3, 4); else LNB1(float, 6, 4); }
 #undef LNB1
   return launch_status();
 }
@@ -751,16 +794,21 @@ extern "C" int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float
                                    const float* gamma, const float* beta, const float* rstd,
                                    float* dW, float* db, float* dgamma, float* dbeta, void* stream) {
   if (M <= 0 || !okH(H) || Kin <= 0 || Kin > 16) return MAGIC_ERR_ARG;
-  dim3 grid((M + SK_ROWS - 1) / SK_ROWS), block(256);
-  size_t shm = (size_t)(SK_ROWS * H + SK_ROWS * 16 + 8 * H) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define SKB(TY, NIT)                                                                                                         \
+  const bool wide = H == 128 && M >= 4096;   // 128 rows x 16 waves per block (64 KB of dz rows); few rows or wider models: 32 rows x 4 waves
+  const int rows = wide ? 128 : 32, nw = wide ? 16 : 4;
+  dim3 grid((M + rows - 1) / rows), block(nw * 64);
+  size_t shm = (size_t)(rows * H + rows * 16 + 2 * nw * H) * sizeof(float);
+#define SKB1(TY, NIT, NW, ROWS)                                                                                              \
   do {                                                                                                                       \
-    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)smallk_ln_bwd_kernel<TY, NIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-    hipLaunchKernelGGL((smallk_ln_bwd_kernel<TY, NIT>), grid, block, shm, st, M, H, Kin, x, (const TY*)dy, (const TY*)y, gamma, beta, rstd, dW, db, dgamma, dbeta); \
+    if (shm > 64 * 1024) hipFuncSetAttribute((const void*)smallk_ln_bwd_kernel<TY, NIT, NW, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+    hipLaunchKernelGGL((smallk_ln_bwd_kernel<TY, NIT, NW, ROWS>), grid, block, shm, st, M, H, Kin, x, (const TY*)dy, (const TY*)y, gamma, beta, rstd, dW, db, dgamma, dbeta); \
   } while (0)
+#define SKB(TY, NIT)                                                                                                         \
+  do { if (NIT == 1 && wide) SKB1(TY, 1, 16, 128); else SKB1(TY, NIT, 4, 32); } while (0)
   DISPATCH_NIT(dtype, H, SKB);
 #undef SKB
+#undef SKB1
   return launch_status();
 }
 

@@ -663,7 +663,8 @@ class MagicNet:
         O.ln_bwd(M, H, d, y=c.E, gamma=n.g, beta=n.b, rstd=c.rstd_e, dx=None, dgamma=n.dg, dbeta=n.db, drop_dy=c.edrop,
                  dtabs=((plan["txt_ids"], 0, 0, self.S.g(p + "embeddings.word_embeddings.weight"), 0),
                         (None, c.L, 2, self.S.g(p + "embeddings.position_embeddings.weight"), 0),
-                        (None, 0, 0, self.S.g(p + "embeddings.token_type_embeddings.weight"), 0)))
+                        (None, 0, 0, self.S.g(p + "embeddings.token_type_embeddings.weight"), 0)),
+                 hot0=0)          # id 0 pads every instruction (pretrain_src/data/tasks.py:116 pad_sequence(..., padding_value=0)); a pure performance hint
 
     # ---- panorama encoder ----------------------------------------------------------------------
     def pano_fwd(self, plan, feats, loc, defer=False):

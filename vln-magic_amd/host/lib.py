@@ -28,7 +28,7 @@ SIGNATURES = {
     "magic_ln_fwd": [i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, vp, vp, i32,
                      vp, f32, u32, u32, vp, vp],
     "magic_ln_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32,
-                     vp, i32, i32, vp, i32, i32, vp, f32, u32, u32, vp, vp],
+                     vp, i32, i32, vp, i32, i32, vp, f32, u32, u32, vp, i32, vp],
     "magic_ln_pgrad": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "magic_smallk_ln_fwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp],
     "magic_smallk_ln_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -327,8 +327,9 @@ SPLIT_PGRAD = bool(os.environ.get("MAGIC_SPLIT_PGRAD"))     # opt-in: measured n
 
 
 def ln_bwd(M, H, dy, *, y=None, gamma=None, beta=None, rstd=None, dx=None, dgamma=None, dbeta=None,
-           dtabs=(None, None, None), do_ln=True, drop_dy=None, drop_dx=None, dxm=None):
-    """drop_dy: the forward dropped its output (dy masked on load); drop_dx: the forward dropped in0 (dxm = dx * mask)."""
+           dtabs=(None, None, None), do_ln=True, drop_dy=None, drop_dx=None, dxm=None, hot0=-1):
+    """drop_dy: the forward dropped its output (dy masked on load); drop_dx: the forward dropped in0 (dxm = dx * mask); hot0: a row of
+    indexed table 0 hit by many input rows (the padding token), reduced per workgroup before the atomics."""
     d0, d1, d2 = [_dtab(t) for t in dtabs]
     dd = drop_dy if (drop_dy is not None and drop_dy[1] > 0) else drop_dx
     seed, p, _ = _dr(dd)
@@ -339,7 +340,7 @@ def ln_bwd(M, H, dy, *, y=None, gamma=None, beta=None, rstd=None, dx=None, dgamm
         L.call("magic_ln_pgrad", L.dt(dy.dtype), M, H, L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(dgamma), L.P(dbeta), L.stream())
         dgamma = dbeta = None
     L.call("magic_ln_bwd", L.dt(dy.dtype), M, H, L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(dx),
-           L.P(dgamma), L.P(dbeta), *d0, *d1, *d2, 1 if do_ln else 0, seed, p, s_dy, s_dx, L.P(dxm), L.stream())
+           L.P(dgamma), L.P(dbeta), *d0, *d1, *d2, 1 if do_ln else 0, seed, p, s_dy, s_dx, L.P(dxm), int(hot0), L.stream())
     return dx
 
 

@@ -274,7 +274,7 @@ int magic_xencoder_fwd(const void* params, int nbytes, void* stream);
  * bf16 weights (W^T, see magic_transpose_spans); writes the dY operands of the deferred weight-gradient GEMMs (d_fod, d_z, d_aod), d_ao
  * (residual of the next tail) and d_ctx (input of magic_attn_bwd); gamma / beta gradients by atomics.  dqkv_n == NULL: no tail, the
  * (d_fo, d_fod) pair is given (top block of an encoder).  kt = k-steps of 32 of the tail product: 12 (dqkv_n is [M, 3H]) or 4 (a [M, H]
- * query gradient).  z == NULL selects the SHORT chain of a cross-modal block's query side: tail (dQ Wq + d_co) -> LayerNorm backward
+ * query gradient) or 0 (no product: dx = dao_n, the plain gradient wrt the output of an encoder's last block; dqkv_n / WqkvT_n any non-NULL).  z == NULL selects the SHORT chain of a cross-modal block's query side: tail (dQ Wq + d_co) -> LayerNorm backward
  * through the self-attention output norm (y2 / rstd2 / g2 / b2 / dg2 / db2, mask site_out) -> dfo = d_ao, dfod = d_aod -> dctx = d_aod Wo. */
 typedef struct {
   int M, kt;

@@ -23,7 +23,7 @@
 
 
 struct RbwSeg {
-  int M, kt;                                                        // kt: k-steps of the tail product (12: dQKV [M,3H]; 4: a dQ [M,H])
+  int M, kt;                         // kt: k-steps of the tail product (12: dQKV [M,3H]; 4: a dQ [M,H]; 0: no product, dx = dao_n: top of a stack)
   const bf16* dqkv_n; const bf16* WqkvT_n; const bf16* dao_n;      // tail of the next block (dqkv_n == null: d_fo / d_fod are given)
   const bf16* dfo_in; const bf16* dfod_in;
   const bf16* y2; const float* rstd2; const float* g2; const float* b2; float* dg2; float* db2;     // this block's output LayerNorm
@@ -343,7 +343,7 @@ extern "C" int magic_rowbwd(const void* params, int nbytes, void* stream) {
       for (const void* q : full)
         if (!q) return MAGIC_ERR_ARG;
     } else if (!sg.dqkv_n) return MAGIC_ERR_ARG;      // the short chain is a tail by definition
-    if (sg.dqkv_n) { if (!sg.WqkvT_n || !sg.dao_n || !sg.dfo || !sg.dfod || (sg.kt != 4 && sg.kt != 12)) return MAGIC_ERR_ARG; }
+    if (sg.dqkv_n) { if (!sg.WqkvT_n || !sg.dao_n || !sg.dfo || !sg.dfod || (sg.kt != 0 && sg.kt != 4 && sg.kt != 12)) return MAGIC_ERR_ARG; }
     else if (!sg.dfo_in || !sg.dfod_in) return MAGIC_ERR_ARG;
     if ((sg.dg2 == nullptr) != (sg.db2 == nullptr) || (sg.dg1 == nullptr) != (sg.db1 == nullptr)) return MAGIC_ERR_ARG;
     const void* al[] = {sg.dqkv_n, sg.WqkvT_n, sg.dao_n, sg.dfo_in, sg.dfod_in, sg.y2, sg.z, sg.W2T, sg.W1T, sg.y1, sg.WoT, sg.dfo, sg.dfod, sg.dz, sg.daod, sg.dao, sg.dctx};

@@ -575,11 +575,7 @@ class MagicNet:
         for c, fmt, d_top, dP in stacks:
             lc = c.layers[-1]
             st.append(Ctx(c=c, fmt=fmt, j=len(c.layers) - 1, M=lc.sa.Bn * lc.sa.N, dP=dP, d_top=d_top, pre=None, dqkv=None, dao=None, dx0=None))
-        with L.group():          # LayerNorm backward of each stack's last output norm
-            for s in st:
-                lc = s.c.layers[s.j]
-                s.pre = self._through_ln(s.d_top, self._out_ln_desc(s.fmt.format(s.j), lc), s.M)
-        d = self.drop
+        d = self.drop            # (the LayerNorm backward of each stack's last output norm runs inside the first chain: kt = 0)
         while any(s.dx0 is None for s in st):
             segs, act = [], []
             for s in st:
@@ -595,10 +591,10 @@ class MagicNet:
                            g1=n1.g, b1=n1.b, dg1=n1.dg, db1=n1.db, WoT=o.WT, dz=out.dz, daod=out.daod, dao=out.dao, dctx=out.dctx,
                            site_out=ffn.hdrop[2] if ffn.hdrop else 0, site_ao=sa.hdrop[2] if sa.hdrop else 0)
                 flops = 2.0 * ffn.rows * (2 * H * I + H * H)
-                if s.pre is not None:            # top block: (d_fo, d_fod) come from the LayerNorm backward above
-                    out.dfo, out.dfod = s.pre
-                    seg.update(dfo_in=out.dfo, dfod_in=out.dfod)
-                    s.pre = None
+                if s.d_top is not None:          # top block: dx of the output norm = the plain gradient wrt the stack's output (no product)
+                    out.dfo, out.dfod = self.new(M, H), self.new(M, H)
+                    seg.update(dqkv_n=s.d_top, kt=0, WqkvT_n=f2.WT, dao_n=s.d_top, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
+                    s.d_top = None
                 else:                            # tail of block j + 1 runs here
                     qn = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
                     out.dfo, out.dfod = self.new(M, H), self.new(M, H)
@@ -940,9 +936,6 @@ class MagicNet:
             st.append(Ctx(c=c, fmt=enc + "encoder.crossattention.{}.", j=len(c.layers) - 1, M=lc.Bn * lc.Nq, Mk=lc.Bn * lc.Nk, dP=dP, d_top=d_top,
                           d_acc=d_acc, dsprel=dsprel, pre=None, dqkv=None, dao=None, dx0=None))
 
-        def top_ln(s):
-            s.pre = self._through_ln(s.d_top, self._out_ln_desc(s.fmt.format(s.j), s.c.layers[s.j]), s.M)
-        self._grouped([lambda s=s: top_ln(s) for s in st])
         d = self.drop
         seed, ph = (d[0] if d else None), (d[1] if d else 0.0)
         for j in reversed(range(len(st[0].c.layers))):
@@ -962,10 +955,10 @@ class MagicNet:
                            g1=nc.g, b1=nc.b, dg1=nc.dg, db1=nc.db, WoT=W.co.WT, dz=out.dz, daod=out.dcod, dao=out.dco, dctx=out.dcctx,
                            site_out=ffn.hdrop[2] if ffn.hdrop else 0, site_ao=lc.hdrop[2] if lc.hdrop else 0)
                 flops = 2.0 * ffn.rows * (2 * H * I + H * H)
-                if s.pre is not None:
-                    out.dfo, out.dfod = s.pre
-                    seg.update(dfo_in=out.dfo, dfod_in=out.dfod)
-                    s.pre = None
+                if s.d_top is not None:          # top block: no product, the output norm's backward starts from the plain gradient
+                    out.dfo, out.dfod = self.new(M, H), self.new(M, H)
+                    seg.update(dqkv_n=s.d_top, kt=0, WqkvT_n=W.f2.WT, dao_n=s.d_top, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
+                    s.d_top = None
                 else:
                     qn = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
                     out.dfo, out.dfod = self.new(M, H), self.new(M, H)

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void smallk_ln_fwd_kernel(int M, int H, int Ki
 
 // backward: dW[H,Kin], db[H], dgamma, dbeta (fp32 atomics, block-reduced).  SK_ROWS rows per block (NW waves);
 // dz rows are parked in LDS so the dW outer product is a cooperative (c,k) loop.  Every block ends in H (Kin + 3) same-address atomics,
-// so at H = 128 a block takes 128 rows with 16 waves (4x fewer blocks than the 32-row / 4-wave shape the wider models keep for LDS).
+// so at H = 128 and M >= 4096 a block takes 64 rows with 16 waves (half as many blocks as the 32-row / 4-wave shape, 4 rows per wave).
 template <typename T, int NIT, int NW, int SK_ROWS>
 __global__ __launch_bounds__(NW * 64) void smallk_ln_bwd_kernel(int M, int H, int Kin, const float* x, const T* dy, const T* y,
                                                             const float* gamma, const float* beta, const float* rstd,
@@ -813,8 +813,8 @@ extern "C" int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float
                                    float* dW, float* db, float* dgamma, float* dbeta, void* stream) {
   if (M <= 0 || !okH(H) || Kin <= 0 || Kin > 16) return MAGIC_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const bool wide = H == 128 && M >= 4096;   // 128 rows x 16 waves per block (64 KB of dz rows); few rows or wider models: 32 rows x 4 waves
-  const int rows = wide ? 128 : 32, nw = wide ? 16 : 4;
+  const bool wide = H == 128 && M >= 4096;   // 64 rows x 16 waves per block; few rows or wider models: 32 rows x 4 waves
+  const int rows = wide ? 64 : 32, nw = wide ? 16 : 4;
   dim3 grid((M + rows - 1) / rows), block(nw * 64);
   size_t shm = (size_t)(rows * H + rows * 16 + 2 * nw * H) * sizeof(float);
 #define SKB1(TY, NIT, NW, ROWS)                                                                                              \
@@ -823,7 +823,7 @@ extern "C" int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float
     hipLaunchKernelGGL((smallk_ln_bwd_kernel<TY, NIT, NW, ROWS>), grid, block, shm, st, M, H, Kin, x, (const TY*)dy, (const TY*)y, gamma, beta, rstd, dW, db, dgamma, dbeta); \
   } while (0)
 #define SKB(TY, NIT)                                                                                                         \
-  do { if (NIT == 1 && wide) SKB1(TY, 1, 16, 128); else SKB1(TY, NIT, 4, 32); } while (0)
+  do { if (NIT == 1 && wide) SKB1(TY, 1, 16, 64); else SKB1(TY, NIT, 4, 32); } while (0)
   DISPATCH_NIT(dtype, H, SKB);
 #undef SKB
 #undef SKB1

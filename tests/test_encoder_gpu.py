@@ -262,3 +262,30 @@ def test_cross_encoder_rowblock_backward_matches_the_per_op_backward(task, p_dro
         assert ((ga - gb).norm() / gb.norm()).item() < 6e-2, (nm, ((ga - gb).norm() / gb.norm()).item())
     print(f"{task} p={p_drop}: cross row-block backward vs per-op: cosine {cos:.6f}, rel L2 {rel:.2e}, worst cross tensor {worst:.2e}")
     assert cos > 0.9995 and rel < 3e-2, (cos, rel)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_node_inputs_in_one_launch_are_bit_identical_to_the_per_op_chain(dtype):
+    """magic_node_in_fwd (gathers + position embedding + step embedding of the map / viewpoint tokens, both encoders in one launch) keeps the
+    per-op chain's rounding points: csr_gather (+ accumulate) -> smallk_ln_fwd -> ln_fwd(do_ln = False)"""
+    cfg = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL)
+    m = GlocalTextPathCMTPreTraining(cfg, device=DEV, compute_dtype=dtype, seed=3)
+    batch = synth.make_batch("sap", batch_size=7, seed=5, step=0, dup_view_prob=0.3)
+    plan = build_plan(batch, "sap", torch.device(DEV))
+    inp = m._inputs(batch, plan)
+    m.store.sync_shadow()
+    n = m.net
+    n.set_dropout(None, 0.0, 0.0)
+    ct = n.text_fwd(plan)
+    cp = n.pano_fwd(plan, inp.feats, inp.loc)
+    g0, v0 = n.gmap_in_fwd(plan, cp, inp.gpos), n.vp_in_fwd(plan, cp, inp.vpos)
+    g1, v1 = n.nodes_in_fwd(plan, cp, inp.gpos, inp.vpos)
+    go, _ = n.nodes_in_fwd(plan, cp, inp.gpos, None)                   # one encoder only (mlm / mrc)
+    _, vo = n.nodes_in_fwd(plan, cp, None, inp.vpos)
+    gimg = torch.randn(plan["B"] * plan["K"], n.H, device=DEV).to(dtype)
+    ga, gb = n.gmap_in_fwd(plan, None, inp.gpos, gimg=gimg), n.nodes_in_fwd(plan, None, inp.gpos, None, gimg=gimg)[0]   # navigator form
+    torch.cuda.synchronize()
+    for a, b, nm in ((g0, g1, "gmap"), (v0, v1, "vp"), (g0, go, "gmap alone"), (v0, vo, "vp alone"), (ga, gb, "gmap from given embeddings")):
+        assert torch.equal(a.out, b.out), nm
+        assert torch.equal(a.A, b.A) and torch.equal(a.rstd, b.rstd), nm
+    assert g1.out.abs().max() > 0 and v1.out.abs().max() > 0

@@ -416,6 +416,115 @@ __global__ __launch_bounds__(256) void smallk_ln_fwd_kernel(int M, int H, int Ki
   }
 }
 
+// Input stage of a cross-modal encoder in ONE launch (1 or 2 encoders): out = [gathered panorama embeddings] + LN(pos W^T + b) + [step
+// embedding], i.e. csr_gather (+ csr_gather accumulate) -> smallk_ln_fwd -> ln_fwd(do_ln = 0) of the per-op path with the SAME rounding points
+// (the gathered sum is rounded to T after each source, the position embedding is rounded to T before the sum), so both paths agree bit for bit.
+struct magic_node_in {
+  int M, Kin; const float* x; const float* W; const float* b; const float* gamma; const float* beta; float eps; int pad_;
+  void* A; float* rstd; void* out;                                   // A = LN(pos W^T + b) (saved for the backward), out = the encoder's input
+  const void* add0;                                                  // plain [M,H] addend instead of the gathers (node embeddings kept by the caller)
+  const void* src1; const int* ptr1; const int* idx1; const float* w1;      // CSR row gathers out of src1 / src2 ([*,H]); ptr == NULL: none
+  const void* src2; const int* ptr2; const int* idx2; const float* w2;
+  const void* tab; const int* tab_idx;                               // + tab[tab_idx[row], :]
+};
+template <typename T, int NIT>
+__device__ __forceinline__ void node_in_body(const magic_node_in& p, const int bid) {
+  constexpr int H = NIT * 128;
+  const int lane = threadIdx.x & 63, row0 = (bid * 4 + (threadIdx.x >> 6)) * SKF_ROWS, M = p.M, Kin = p.Kin;
+  if (row0 >= M) return;
+  constexpr bool WREG = NIT <= 2;
+  float wr[WREG ? 2 * NIT : 1][16], br[2 * NIT], gr[2 * NIT], er[2 * NIT];
+#pragma unroll
+  for (int i = 0; i < 2 * NIT; ++i) {
+    const int c = (i >> 1) * 128 + lane * 2 + (i & 1);
+    br[i] = p.b[c]; gr[i] = p.gamma[c]; er[i] = p.beta[c];
+    if constexpr (WREG) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) wr[i][k] = k < Kin ? p.W[c * Kin + k] : 0.f;
+    }
+  }
+  T* A = (T*)p.A; T* out = (T*)p.out;
+  for (int rr = 0; rr < SKF_ROWS; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;
+    float xr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xr[k] = k < Kin ? p.x[(long long)row * Kin + k] : 0.f;
+    float z[2 * NIT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * NIT; ++i) {
+      float a = br[i];
+      if constexpr (WREG) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += xr[k] * wr[i][k];
+      } else {
+        const int c = (i >> 1) * 128 + lane * 2 + (i & 1);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += (k < Kin) ? xr[k] * p.W[c * Kin + k] : 0.f;
+      }
+      z[i] = a; s += a;
+    }
+    const float mean = wave_sum(s) / H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * NIT; ++i) { const float a = z[i] - mean; q += a * a; }
+    const float rstd = rsqrtf(wave_sum(q) / H + p.eps);
+    if (p.rstd && lane == 0) p.rstd[row] = rstd;
+    // gathered embeddings (rounded to T after each source, as csr_gather / csr_gather(accumulate) store them)
+    float g[2 * NIT];
+#pragma unroll
+    for (int i = 0; i < 2 * NIT; ++i) g[i] = 0.f;
+    if (p.add0) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) ld2<T>((const T*)p.add0 + (long long)row * H + it * 128 + lane * 2, g[2 * it], g[2 * it + 1]);
+    } else {
+      if (p.ptr1) {
+        const int e0 = p.ptr1[row], e1 = p.ptr1[row + 1];
+        for (int e = e0; e < e1; ++e) {
+          const float wv = p.w1 ? p.w1[e] : 1.f;
+          const T* sp = (const T*)p.src1 + (long long)p.idx1[e] * H;
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) { float u, v; ld2<T>(sp + it * 128 + lane * 2, u, v); g[2 * it] += wv * u; g[2 * it + 1] += wv * v; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NIT; ++i) g[i] = to_f(from_f<T>(g[i]));
+      }
+      if (p.ptr2) {
+        const int e0 = p.ptr2[row], e1 = p.ptr2[row + 1];
+        if (e0 < e1) {
+          float h[2 * NIT];
+#pragma unroll
+          for (int i = 0; i < 2 * NIT; ++i) h[i] = 0.f;
+          for (int e = e0; e < e1; ++e) {
+            const float wv = p.w2 ? p.w2[e] : 1.f;
+            const T* sp = (const T*)p.src2 + (long long)p.idx2[e] * H;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) { float u, v; ld2<T>(sp + it * 128 + lane * 2, u, v); h[2 * it] += wv * u; h[2 * it + 1] += wv * v; }
+          }
+#pragma unroll
+          for (int i = 0; i < 2 * NIT; ++i) g[i] = to_f(from_f<T>(h[i] + g[i]));
+        }
+      }
+    }
+    const int tr = p.tab ? p.tab_idx[row] : 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 128 + lane * 2;
+      const float y0 = (z[2 * it] - mean) * rstd * gr[2 * it] + er[2 * it], y1 = (z[2 * it + 1] - mean) * rstd * gr[2 * it + 1] + er[2 * it + 1];
+      st2<T>(A + (long long)row * H + c, y0, y1);
+      float o0 = g[2 * it] + to_f(from_f<T>(y0)), o1 = g[2 * it + 1] + to_f(from_f<T>(y1));
+      if (p.tab) { float u, v; ld2<T>((const T*)p.tab + (long long)tr * H + c, u, v); o0 += u; o1 += v; }
+      st2<T>(out + (long long)row * H + c, o0, o1);
+    }
+  }
+}
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void node_in_fwd_kernel(magic_node_in a, magic_node_in b, int nA) {
+  if ((int)blockIdx.x < nA) node_in_body<T, NIT>(a, blockIdx.x);
+  else node_in_body<T, NIT>(b, blockIdx.x - nA);
+}
+
 // backward: dW[H,Kin], db[H], dgamma, dbeta (fp32 atomics, block-reduced).  SK_ROWS rows per block (NW waves);
 // dz rows are parked in LDS so the dW outer product is a cooperative (c,k) loop.  Every block ends in H (Kin + 3) same-address atomics,
 // so at H = 128 and M >= 4096 a block takes 64 rows with 16 waves (half as many blocks as the 32-row / 4-wave shape, 4 rows per wave).
@@ -805,6 +914,27 @@ extern "C" int magic_smallk_ln_fwd(int dtype, int M, int H, int Kin, const float
 #define SKF(TY, NIT) hipLaunchKernelGGL((smallk_ln_fwd_kernel<TY, NIT>), grid, block, 0, st, M, H, Kin, x, W, b, gamma, beta, eps, (TY*)out, rstd)
   DISPATCH_NIT(dtype, H, SKF);
 #undef SKF
+  return launch_status();
+}
+
+extern "C" int magic_node_in_fwd(int dtype, int H, int n, const magic_node_in* d, void* stream) {
+  if (!okH(H) || n < 1 || n > 2 || !d) return MAGIC_ERR_ARG;
+  int nb[2] = {0, 0};
+  for (int i = 0; i < n; ++i) {
+    const magic_node_in& p = d[i];
+    if (p.M <= 0 || p.Kin <= 0 || p.Kin > 16 || !p.x || !p.W || !p.b || !p.gamma || !p.beta || !p.A || !p.out) return MAGIC_ERR_ARG;
+    if (p.ptr1 && (!p.src1 || !p.idx1)) return MAGIC_ERR_ARG;
+    if (p.ptr2 && (!p.src2 || !p.idx2 || !p.ptr1)) return MAGIC_ERR_ARG;
+    if (p.tab && !p.tab_idx) return MAGIC_ERR_ARG;
+    nb[i] = (p.M + 4 * SKF_ROWS - 1) / (4 * SKF_ROWS);
+  }
+  const magic_node_in& a = d[0];
+  const magic_node_in& b = d[n - 1];
+  dim3 grid(nb[0] + nb[1]), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define NIF(TY, NIT) hipLaunchKernelGGL((node_in_fwd_kernel<TY, NIT>), grid, block, 0, st, a, b, nb[0])
+  DISPATCH_NIT(dtype, H, NIF);
+#undef NIF
   return launch_status();
 }
 

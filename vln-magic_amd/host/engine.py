@@ -789,6 +789,39 @@ class MagicNet:
                  do_ln=False)
         return c
 
+    def nodes_in_fwd(self, plan, pano, gmap_pos_fts=None, vp_pos_fts=None, gimg=None, vimg=None):
+        """gmap_in_fwd and / or vp_in_fwd as ONE launch (magic_node_in_fwd): gathers + position embedding + step embedding per encoder.
+        Returns (gmap ctx or None, vp ctx or None) in the shape the two per-op functions build (bit-identical tensors)."""
+        H = self.H
+        probs, outs = [], [None, None]
+        if gmap_pos_fts is not None:
+            g = self.p + "global_encoder."
+            M = plan["B"] * plan["K"]
+            pl, pn = self.lin(g + "gmap_pos_embeddings.0.weight"), self.ln(g + "gmap_pos_embeddings.1")
+            c = Ctx(pos=gmap_pos_fts, A=self.new(M, H), rstd=self.new(M, dtype=torch.float32), out=self.new(M, H))
+            q = dict(M=M, Kin=pl.K, x=gmap_pos_fts, W=pl.Wm, b=pl.b, gamma=pn.g, beta=pn.b, eps=self.eps, A=c.A, rstd=c.rstd, out=c.out,
+                     tab=self.S.w(g + "gmap_step_embeddings.weight"), tab_idx=plan["gmap_step_ids"])
+            if gimg is not None:
+                q["add0"] = gimg
+            else:
+                q.update(src1=pano.out, csr1=plan["gmap_from_embed"], src2=pano.fused, csr2=plan["gmap_from_fused"])
+            probs.append(q)
+            outs[0] = c
+        if vp_pos_fts is not None:
+            l = self.p + "local_encoder."
+            M = plan["B"] * plan["Vp"]
+            pl, pn = self.lin(l + "vp_pos_embeddings.0.weight"), self.ln(l + "vp_pos_embeddings.1")
+            c = Ctx(pos=vp_pos_fts, A=self.new(M, H), rstd=self.new(M, dtype=torch.float32), out=self.new(M, H))
+            q = dict(M=M, Kin=pl.K, x=vp_pos_fts, W=pl.Wm, b=pl.b, gamma=pn.g, beta=pn.b, eps=self.eps, A=c.A, rstd=c.rstd, out=c.out)
+            if vimg is not None:
+                q["add0"] = vimg
+            else:
+                q.update(src1=pano.out, csr1=plan["vp_from_embed"])
+            probs.append(q)
+            outs[1] = c
+        O.node_in_fwd(H, probs)
+        return outs
+
     def gmap_in_bwd(self, c, plan, d_in, d_pano, d_fused):
         g, H = self.p + "global_encoder.", self.H
         M = plan["B"] * plan["K"]

@@ -47,6 +47,7 @@ SIGNATURES = {
     "magic_kd_rows": [i32, i32, vp, vp, i32, f32, vp, f32, f32, vp, vp, vp, i32, vp],
     "magic_mse": [i32, i32, i64, i64, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp, i64, i32, vp],
     "magic_mse_multi": [i32, i32, vp, vp],
+    "magic_node_in_fwd": [i32, i32, i32, vp, vp],
     "magic_csr_gather": [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp],
     "magic_pano_fuse_fwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "magic_pano_fuse_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -90,6 +91,15 @@ class MseDesc(C.Structure):
     _fields_ = [("g_f32", i32), ("outer", i64), ("inner", i64), ("s", vp), ("s_stride", i64), ("t", vp), ("t_stride", i64),
                 ("w", vp), ("rows_per_w", i64), ("norm", f32), ("coef", f32), ("coef_dev", vp), ("loss", vp), ("ds", vp),
                 ("g_stride", i64), ("accumulate", i32)]
+
+
+NODE_IN_PTRS = ("A", "rstd", "out", "add0", "src1", "ptr1", "idx1", "w1", "src2", "ptr2", "idx2", "w2", "tab", "tab_idx")
+
+
+class NodeIn(C.Structure):
+    """mirror of `magic_node_in` (include/magic_hip.h)"""
+    _fields_ = ([("M", i32), ("Kin", i32), ("x", vp), ("W", vp), ("b", vp), ("gamma", vp), ("beta", vp), ("eps", f32), ("pad_", i32)]
+                + [(n, vp) for n in NODE_IN_PTRS])
 
 
 class RbStage(C.Structure):

@@ -326,15 +326,15 @@ class _NavigationFn(torch.autograd.Function):
         c = Ctx(plan=plan, B=B, K=K, Vp=Vp, L=L)
         txt = txt_embeds.detach().to(net.dtype).reshape(B * L, H).contiguous()
         tmask, gmask_u8, vmask_u8 = _u8(txt_masks), _u8(b["gmap_masks"]), _u8(b["vp_masks"])
-        c.gin = net.gmap_in_fwd(plan, None, b["gmap_pos_fts"].float().reshape(B * K, -1).contiguous(),
-                                gimg=gmap_img.detach().to(net.dtype).reshape(B * K, H).contiguous())
+        c.gin, c.vin = net.nodes_in_fwd(plan, None, b["gmap_pos_fts"].float().reshape(B * K, -1).contiguous(),
+                                        b["vp_pos_fts"].float().reshape(B * Vp, -1).contiguous(),
+                                        gimg=gmap_img.detach().to(net.dtype).reshape(B * K, H).contiguous(),
+                                        vimg=vp_img.detach().to(net.dtype).reshape(B * Vp, H).contiguous())
         nl = net.cfg.num_x_layers
         kv = None if txt_kv is None else txt_kv.detach()
         c.has_kv = kv is not None
         c.glob = net.cross_fwd("global", plan, c.gin.out, K, gmask_u8, gl_, int(sum(gl_)), txt, L, tmask, tl, int(sum(tl)),
                                dist=b["gmap_pair_dists"].float().contiguous(), kv=None if kv is None else kv[:nl])
-        c.vin = net.vp_in_fwd(plan, None, b["vp_pos_fts"].float().reshape(B * Vp, -1).contiguous(),
-                              vimg=vp_img.detach().to(net.dtype).reshape(B * Vp, H).contiguous())
         c.loc = net.cross_fwd("local", plan, c.vin.out, Vp, vmask_u8, vl, int(sum(vl)), txt, L, tmask, tl, int(sum(tl)),
                               kv=None if kv is None else kv[nl:])
         # heads

@@ -187,7 +187,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         c.txt, c.pano = self._par(lambda: n.text_fwd(plan, defer=fuse), lambda: n.pano_fwd(plan, inp.feats, inp.loc, defer=fuse))
         if fuse:
             n.encoders_fwd(c.txt, c.pano)
-        c.gin = n.gmap_in_fwd(plan, c.pano, inp.gpos) if task != "mrc" else None
+        # map-token and viewpoint-token inputs of the cross-modal encoders: one launch for both (gathers + position / step embeddings)
+        c.gin, c.vin = n.nodes_in_fwd(plan, c.pano, inp.gpos if task != "mrc" else None, inp.vpos if task != "mlm" else None)
         tl, gl_, vl = plan["lens"]["txt"], plan["lens"]["gmap"], [Vp] * B
         o = dict(txt_embeds=c.txt.out, txt_attns=c.txt.P, pano_embeds=c.pano.out, pano_fused_embeds=c.pano.fused,
                  img_attns=c.pano.img_attn, plan=plan, inputs=inp)
@@ -214,7 +215,6 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             o["predict"] = c.logits[:, :Vv]
         elif task == "mrc":
             # local branch only; RegionClassification on the masked views of the current viewpoint (validate_mrc :476-500)
-            c.vin = n.vp_in_fwd(plan, c.pano, inp.vpos)
             loc_args = ("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
             c.loc = n.cross_fwd_fused([loc_args])[0] if n.xenc_ok(Vp, L) else n.cross_fwd(*loc_args)
             o.update(vp_embeds=c.loc.out, vp_attns=c.loc.P)
@@ -230,12 +230,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             o["predict"] = c.mlogits
         else:
             def _local():
-                vin = n.vp_in_fwd(plan, c.pano, inp.vpos)
+                vin = c.vin
                 return vin, n.cross_fwd("local", plan, vin.out, Vp, plan["vp_mask"], vl, B * Vp,
                                         c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
             # global (map) and local (viewpoint) co-attention encoders are independent too: one launch for both when the shapes allow
             if n.xenc_ok(K, L) and n.xenc_ok(Vp, L):
-                c.vin = n.vp_in_fwd(plan, c.pano, inp.vpos)
                 c.glob, c.loc = n.cross_fwd_fused([
                     ("global", plan, c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"], c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], inp.dist),
                     ("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])])

@@ -351,6 +351,25 @@ def smallk_ln_fwd(M, H, Kin, x, W, b, gamma, beta, eps, out, rstd):
     return out
 
 
+def node_in_fwd(H, problems):
+    """input stage of 1 or 2 cross-modal encoders in one launch (csrc/rowops.hip node_in_fwd_kernel).  problems: dicts with M, Kin, x, W, b,
+    gamma, beta, eps, A, rstd, out and optionally add0 | (src1, csr1[, src2, csr2]) and (tab, tab_idx); csr = (ptr, idx, w)"""
+    _chk(1 <= len(problems) <= 2, "node_in_fwd problems")
+    arr = (L.NodeIn * len(problems))()
+    for j, q in enumerate(problems):
+        _chk(q["x"].dtype == torch.float32 and q["x"].is_contiguous(), "node_in x fp32 contiguous")
+        d = arr[j]
+        d.M, d.Kin, d.eps = int(q["M"]), int(q["Kin"]), float(q["eps"])
+        for k in ("x", "W", "b", "gamma", "beta", "A", "rstd", "out", "add0", "src1", "src2", "tab", "tab_idx"):
+            setattr(d, k, L.P(q.get(k)))
+        for i in (1, 2):
+            csr = q.get(f"csr{i}")
+            if csr is not None:
+                _chk(csr[0].dtype == torch.int32 and csr[0].numel() == d.M + 1, "node_in csr ptr")
+                setattr(d, f"ptr{i}", L.P(csr[0])); setattr(d, f"idx{i}", L.P(csr[1])); setattr(d, f"w{i}", L.P(csr[2]))
+    L.call("magic_node_in_fwd", L.dt(problems[0]["out"].dtype), H, len(problems), __import__("ctypes").addressof(arr), L.stream())
+
+
 def smallk_ln_bwd(M, H, Kin, x, dy, y, gamma, beta, rstd, dW, db, dgamma, dbeta):
     L.call("magic_smallk_ln_bwd", L.dt(dy.dtype), M, H, Kin, L.P(x), L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(rstd),
            L.P(dW), L.P(db), L.P(dgamma), L.P(dbeta), L.stream())

@@ -100,6 +100,19 @@ int magic_ln_pgrad(int dtype, int M, int H, const void* dy, const void* y, const
 /* y = LN(x[M,Kin<=16] W^T + b): loc_linear+loc_layer_norm, gmap_pos_embeddings, vp_pos_embeddings (App. B.2-B.3) */
 int magic_smallk_ln_fwd(int dtype, int M, int H, int Kin, const float* x, const float* W, const float* b,
                         const float* gamma, const float* beta, float eps, void* out, float* rstd, void* stream);
+/* Several independent CSR row gathers in one launch (n <= 4): out[r,:] (+)= sum_e w1[e] src1[idx1[e],:], then (optional second source)
+ * += sum_e w2[e] src2[idx2[e],:], rounded to the storage type after each source exactly as two consecutive magic_csr_gather calls. */
+typedef struct {
+  int n_out, accumulate; const void* src1; const int* ptr1; const int* idx1; const float* w1;
+  const void* src2; const int* ptr2; const int* idx2; const float* w2; void* out;
+} magic_csr_prob;
+int magic_csr_gather_multi(int dtype, int H, int n, const magic_csr_prob* d, void* stream);
+/* two magic_smallk_ln_bwd problems (d[0], d[1]) in one launch */
+typedef struct {
+  int M, Kin; const float* x; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd;
+  float* dW; float* db; float* dgamma; float* dbeta;
+} magic_skb_prob;
+int magic_smallk_ln_bwd_pair(int dtype, int H, const magic_skb_prob* d, void* stream);
 /* Input stage of the cross-modal encoders as ONE launch for 1 or 2 encoders (the map encoder's gmap tokens, the local encoder's viewpoint
  * tokens): out = [CSR-gathered panorama embeddings src1 (+ src2)] or add0, + A, + tab[tab_idx]; A = LayerNorm(x[M,Kin] W^T + b) (saved, with
  * rstd, for magic_smallk_ln_bwd).  Same rounding points as magic_csr_gather -> magic_smallk_ln_fwd -> magic_ln_fwd(do_ln = 0). */

@@ -289,3 +289,41 @@ def test_node_inputs_in_one_launch_are_bit_identical_to_the_per_op_chain(dtype):
         assert torch.equal(a.out, b.out), nm
         assert torch.equal(a.A, b.A) and torch.equal(a.rstd, b.rstd), nm
     assert g1.out.abs().max() > 0 and v1.out.abs().max() > 0
+
+
+def test_node_inputs_backward_in_shared_launches_matches_the_per_op_sequence():
+    """nodes_in_bwd (step-table gradient, both position-embedding backwards as a pair, the three transposed gathers as one launch) against
+    vp_in_bwd + gmap_in_bwd: the gathered gradients are bit-identical (same rounding order), the parameter gradients agree to fp32
+    atomic-order noise"""
+    m = student(0.0)
+    batch = synth.make_batch("sap", batch_size=7, seed=5, step=0, dup_view_prob=0.3)
+    plan = build_plan(batch, "sap", torch.device(DEV))
+    inp = m._inputs(batch, plan)
+    m.store.sync_shadow()
+    m.store.ensure_grads()
+    n = m.net
+    n.set_dropout(None, 0.0, 0.0)
+    n.text_fwd(plan)
+    cp = n.pano_fwd(plan, inp.feats, inp.loc)
+    gin, vin = n.nodes_in_fwd(plan, cp, inp.gpos, inp.vpos)
+    g = torch.Generator().manual_seed(7)
+    H, B, K, Vp, Np, V = n.H, plan["B"], plan["K"], plan["Vp"], plan["Np"], plan["V"]
+    d_gin = (torch.randn(B * K, H, generator=g) * 0.1).to(DEV).bfloat16()
+    d_vin = (torch.randn(B * Vp, H, generator=g) * 0.1).to(DEV).bfloat16()
+    base_p = (torch.randn(Np * V, H, generator=g) * 0.1).to(DEV).bfloat16()
+    base_f = (torch.randn(Np, H, generator=g) * 0.1).to(DEV).bfloat16()
+    res = {}
+    for shared in (False, True):
+        m.store.zero_grad()
+        dp, df = base_p.clone(), base_f.clone()
+        if shared:
+            n.nodes_in_bwd(plan, gin, d_gin, vin, d_vin, dp, df)
+        else:
+            n.vp_in_bwd(vin, plan, d_vin, dp)
+            n.gmap_in_bwd(gin, plan, d_gin, dp, df)
+        torch.cuda.synchronize()
+        res[shared] = (dp, df, m.store.grad.clone())
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert not torch.equal(res[True][0], base_p)
+    ga, gb = res[True][2], res[False][2]
+    assert gb.abs().max() > 0 and torch.allclose(ga, gb, rtol=1e-4, atol=1e-5), (ga - gb).abs().max().item()

@@ -24,6 +24,51 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(int n_out, int H, const
   }
 }
 
+// Several independent CSR gathers in one launch (<= 4 problems; blocks [start[i], start[i+1]) serve problem i), each with an optional second
+// source that is accumulated AFTER the first with the same rounding as two consecutive launches (csr_gather, then csr_gather(accumulate)).
+#define CSRM_MAX 4
+struct magic_csr_prob {
+  int n_out, accumulate; const void* src1; const int* ptr1; const int* idx1; const float* w1;
+  const void* src2; const int* ptr2; const int* idx2; const float* w2; void* out;
+};
+struct CsrMulti { magic_csr_prob p[CSRM_MAX]; int start[CSRM_MAX + 1]; int n, H; };
+template <typename T>
+__global__ __launch_bounds__(256) void csr_gather_multi_kernel(CsrMulti mm) {
+  int i = 0;
+  while (i + 1 < mm.n && (int)blockIdx.x >= mm.start[i + 1]) ++i;
+  const magic_csr_prob& p = mm.p[i];
+  const int H = mm.H, lane = threadIdx.x & 63, n = (blockIdx.x - mm.start[i]) * 4 + (threadIdx.x >> 6);
+  if (n >= p.n_out) return;
+  const int a0 = p.ptr1[n], a1 = p.ptr1[n + 1];
+  const int b0 = p.ptr2 ? p.ptr2[n] : 0, b1 = p.ptr2 ? p.ptr2[n + 1] : 0;
+  if (p.accumulate && a0 == a1 && b0 == b1) return;
+  const T* s1 = (const T*)p.src1; const T* s2 = (const T*)p.src2; T* out = (T*)p.out;
+  for (int c = lane * 2; c < H; c += 128) {
+    T* o = out + (long long)n * H + c;
+    float va = 0.f, vb = 0.f;
+    if (p.accumulate) { va = to_f(o[0]); vb = to_f(o[1]); }
+    if (!p.accumulate || a0 < a1) {
+      float a = 0.f, b = 0.f;
+      for (int e = a0; e < a1; ++e) {
+        const float wv = p.w1 ? p.w1[e] : 1.f;
+        const T* q = s1 + (long long)p.idx1[e] * H + c;
+        a += wv * to_f(q[0]); b += wv * to_f(q[1]);
+      }
+      va = to_f(from_f<T>(a + va)); vb = to_f(from_f<T>(b + vb));          // (a + old value: the order csr_gather adds in)
+    }
+    if (b0 < b1) {
+      float a = 0.f, b = 0.f;
+      for (int e = b0; e < b1; ++e) {
+        const float wv = p.w2 ? p.w2[e] : 1.f;
+        const T* q = s2 + (long long)p.idx2[e] * H + c;
+        a += wv * to_f(q[0]); b += wv * to_f(q[1]);
+      }
+      va = to_f(from_f<T>(a + va)); vb = to_f(from_f<T>(b + vb));
+    }
+    o[0] = from_f<T>(va); o[1] = from_f<T>(vb);
+  }
+}
+
 // adaptive panorama fusion: p = softmax_v(x[n,v,:].wf + bf + mask), fused[n,:] = sum_v p_v x[n,v,:]
 // one block (256 threads) per panorama, V <= 64 views.
 template <typename T>
@@ -201,6 +246,26 @@ extern "C" int magic_csr_gather(int dtype, int n_out, int H, const void* src, co
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) hipLaunchKernelGGL(csr_gather_kernel<bf16>, grid, block, 0, st, n_out, H, (const bf16*)src, ptr, idx, w, (bf16*)out, accumulate);
   else hipLaunchKernelGGL(csr_gather_kernel<float>, grid, block, 0, st, n_out, H, (const float*)src, ptr, idx, w, (float*)out, accumulate);
+  return launch_status();
+}
+
+extern "C" int magic_csr_gather_multi(int dtype, int H, int n, const magic_csr_prob* d, void* stream) {
+  if (n < 1 || n > CSRM_MAX || !d || H <= 0 || (H & 1)) return MAGIC_ERR_ARG;
+  CsrMulti mm;
+  mm.n = n; mm.H = H;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (d[i].n_out <= 0 || !d[i].src1 || !d[i].ptr1 || !d[i].idx1 || !d[i].out) return MAGIC_ERR_ARG;
+    if (d[i].ptr2 && (!d[i].src2 || !d[i].idx2)) return MAGIC_ERR_ARG;
+    mm.p[i] = d[i];
+    mm.start[i] = total;
+    total += (d[i].n_out + 3) / 4;
+  }
+  for (int i = n; i <= CSRM_MAX; ++i) mm.start[i] = total;
+  dim3 grid(total), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(csr_gather_multi_kernel<bf16>, grid, block, 0, st, mm);
+  else hipLaunchKernelGGL(csr_gather_multi_kernel<float>, grid, block, 0, st, mm);
   return launch_status();
 }
 

@@ -528,10 +528,15 @@ __global__ __launch_bounds__(256) void node_in_fwd_kernel(magic_node_in a, magic
 // backward: dW[H,Kin], db[H], dgamma, dbeta (fp32 atomics, block-reduced).  SK_ROWS rows per block (NW waves);
 // dz rows are parked in LDS so the dW outer product is a cooperative (c,k) loop.  Every block ends in H (Kin + 3) same-address atomics,
 // so at H = 128 and M >= 4096 a block takes 64 rows with 16 waves (half as many blocks as the 32-row / 4-wave shape, 4 rows per wave).
+struct SkbParams { int M, Kin; const float* x; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd;
+                   float* dW; float* db; float* dgamma; float* dbeta; };
 template <typename T, int NIT, int NW, int SK_ROWS>
-__global__ __launch_bounds__(NW * 64) void smallk_ln_bwd_kernel(int M, int H, int Kin, const float* x, const T* dy, const T* y,
-                                                            const float* gamma, const float* beta, const float* rstd,
-                                                            float* dW, float* db, float* dgamma, float* dbeta) {
+__device__ __forceinline__ void smallk_ln_bwd_body(const SkbParams& pp, const int bid) {
+  constexpr int H = NIT * 128;
+  const int M = pp.M, Kin = pp.Kin;
+  const float* x = pp.x; const T* dy = (const T*)pp.dy; const T* y = (const T*)pp.y;
+  const float* gamma = pp.gamma; const float* beta = pp.beta; const float* rstd = pp.rstd;
+  float* dW = pp.dW; float* db = pp.db; float* dgamma = pp.dgamma; float* dbeta = pp.dbeta;
   extern __shared__ __attribute__((aligned(16))) float sm[];   // dz[SK_ROWS][H] | xs[SK_ROWS][16] | red[2][NW][H]
   float* dz = sm;
   float* xs = sm + SK_ROWS * H;
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(NW * 64) void smallk_ln_bwd_kernel(int M, int H, in
   float ag[2 * NIT], ab[2 * NIT];
 #pragma unroll
   for (int i = 0; i < 2 * NIT; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
-  const int base = blockIdx.x * SK_ROWS;
+  const int base = bid * SK_ROWS;
   for (int rr = wid; rr < SK_ROWS; rr += NW) {
     const int row = base + rr;
     const bool ok = row < M;
@@ -598,6 +603,12 @@ __global__ __launch_bounds__(NW * 64) void smallk_ln_bwd_kernel(int M, int H, in
     for (int ww = 0; ww < NW; ++ww) v += red[(q * NW + ww) * H + cc];
     atomicAdd((q ? dbeta : dgamma) + cc, v);
   }
+}
+
+template <typename T, int NIT, int NW, int SK_ROWS>
+__global__ __launch_bounds__(NW * 64) void smallk_ln_bwd_kernel(SkbParams a, SkbParams b, int nA) {
+  if ((int)blockIdx.x < nA) smallk_ln_bwd_body<T, NIT, NW, SK_ROWS>(a, blockIdx.x);
+  else smallk_ln_bwd_body<T, NIT, NW, SK_ROWS>(b, blockIdx.x - nA);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -938,19 +949,18 @@ extern "C" int magic_node_in_fwd(int dtype, int H, int n, const magic_node_in* d
   return launch_status();
 }
 
-extern "C" int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float* x, const void* dy, const void* y,
-                                   const float* gamma, const float* beta, const float* rstd,
-                                   float* dW, float* db, float* dgamma, float* dbeta, void* stream) {
-  if (M <= 0 || !okH(H) || Kin <= 0 || Kin > 16) return MAGIC_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  const bool wide = H == 128 && M >= 4096;   // 64 rows x 16 waves per block; few rows or wider models: 32 rows x 4 waves
+static int launch_skb(int dtype, int H, const SkbParams& a, const SkbParams* b, hipStream_t st) {
+  const int Mmax = b ? (a.M > b->M ? a.M : b->M) : a.M;
+  const bool wide = H == 128 && Mmax >= 4096;   // 64 rows x 16 waves per block; few rows or wider models: 32 rows x 4 waves
   const int rows = wide ? 64 : 32, nw = wide ? 16 : 4;
-  dim3 grid((M + rows - 1) / rows), block(nw * 64);
+  const int nA = (a.M + rows - 1) / rows, nB = b ? (b->M + rows - 1) / rows : 0;
+  dim3 grid(nA + nB), block(nw * 64);
   size_t shm = (size_t)(rows * H + rows * 16 + 2 * nw * H) * sizeof(float);
+  const SkbParams& bb = b ? *b : a;
 #define SKB1(TY, NIT, NW, ROWS)                                                                                              \
   do {                                                                                                                       \
     if (shm > 64 * 1024) hipFuncSetAttribute((const void*)smallk_ln_bwd_kernel<TY, NIT, NW, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-    hipLaunchKernelGGL((smallk_ln_bwd_kernel<TY, NIT, NW, ROWS>), grid, block, shm, st, M, H, Kin, x, (const TY*)dy, (const TY*)y, gamma, beta, rstd, dW, db, dgamma, dbeta); \
+    hipLaunchKernelGGL((smallk_ln_bwd_kernel<TY, NIT, NW, ROWS>), grid, block, shm, st, a, bb, nA);                            \
   } while (0)
 #define SKB(TY, NIT)                                                                                                         \
   do { if (NIT == 1 && wide) SKB1(TY, 1, 16, 64); else SKB1(TY, NIT, 4, 32); } while (0)
@@ -958,6 +968,27 @@ extern "C" int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float
 #undef SKB
 #undef SKB1
   return launch_status();
+}
+
+extern "C" int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float* x, const void* dy, const void* y,
+                                   const float* gamma, const float* beta, const float* rstd,
+                                   float* dW, float* db, float* dgamma, float* dbeta, void* stream) {
+  if (M <= 0 || !okH(H) || Kin <= 0 || Kin > 16) return MAGIC_ERR_ARG;
+  SkbParams a{M, Kin, x, dy, y, gamma, beta, rstd, dW, db, dgamma, dbeta};
+  return launch_skb(dtype, H, a, nullptr, (hipStream_t)stream);
+}
+
+// two position-embedding backwards (map tokens || viewpoint tokens) in one launch; arguments as magic_smallk_ln_bwd, per problem
+struct magic_skb_prob { int M, Kin; const float* x; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd;
+                        float* dW; float* db; float* dgamma; float* dbeta; };
+extern "C" int magic_smallk_ln_bwd_pair(int dtype, int H, const magic_skb_prob* d, void* stream) {
+  if (!d || !okH(H)) return MAGIC_ERR_ARG;
+  SkbParams p[2];
+  for (int i = 0; i < 2; ++i) {
+    if (d[i].M <= 0 || d[i].Kin <= 0 || d[i].Kin > 16 || !d[i].x || !d[i].dy || !d[i].y || !d[i].dW) return MAGIC_ERR_ARG;
+    p[i] = SkbParams{d[i].M, d[i].Kin, d[i].x, d[i].dy, d[i].y, d[i].gamma, d[i].beta, d[i].rstd, d[i].dW, d[i].db, d[i].dgamma, d[i].dbeta};
+  }
+  return launch_skb(dtype, H, p[0], &p[1], (hipStream_t)stream);
 }
 
 extern "C" int magic_softmax_fwd(int dtype, int B, int nh, int Nq, int Nk, int ldp, const float* S, void* P, float scale,

@@ -822,6 +822,24 @@ class MagicNet:
         O.node_in_fwd(H, probs)
         return outs
 
+    def nodes_in_bwd(self, plan, gin, d_gin, vin, d_vin, d_pano, d_fused):
+        """gmap_in_bwd + vp_in_bwd (pretraining form: node embeddings aggregated from the panoramas) in three launches instead of six:
+        step-embedding table gradient, both position-embedding backwards, all three transposed gathers (same rounding order as the per-op
+        sequence vp -> d_pano, gmap -> d_pano, gmap -> d_fused)."""
+        g, l, H = self.p + "global_encoder.", self.p + "local_encoder.", self.H
+        Mg, Mv = plan["B"] * plan["K"], plan["B"] * plan["Vp"]
+        O.ln_bwd(Mg, H, d_gin, dx=None, do_ln=False,
+                 dtabs=((plan["gmap_step_ids"], 0, 0, self.S.g(g + "gmap_step_embeddings.weight"), 0), None, None))
+        gl_, gn = self.lin(g + "gmap_pos_embeddings.0.weight"), self.ln(g + "gmap_pos_embeddings.1")
+        vl_, vn = self.lin(l + "vp_pos_embeddings.0.weight"), self.ln(l + "vp_pos_embeddings.1")
+        O.smallk_ln_bwd_pair(H, [dict(M=Mg, Kin=gl_.K, x=gin.pos, dy=d_gin, y=gin.A, gamma=gn.g, beta=gn.b, rstd=gin.rstd, dW=gl_.dW, db=gl_.db,
+                                      dgamma=gn.dg, dbeta=gn.db),
+                                 dict(M=Mv, Kin=vl_.K, x=vin.pos, dy=d_vin, y=vin.A, gamma=vn.g, beta=vn.b, rstd=vin.rstd, dW=vl_.dW, db=vl_.db,
+                                      dgamma=vn.dg, dbeta=vn.db)])
+        O.csr_gather_multi(H, [dict(out=d_pano, n_out=plan["Np"] * plan["V"], accumulate=True, src1=d_vin, csr1=plan["vp_from_embed_T"],
+                                    src2=d_gin, csr2=plan["gmap_from_embed_T"]),
+                               dict(out=d_fused, n_out=plan["Np"], accumulate=True, src1=d_gin, csr1=plan["gmap_from_fused_T"])])
+
     def gmap_in_bwd(self, c, plan, d_in, d_pano, d_fused):
         g, H = self.p + "global_encoder.", self.H
         M = plan["B"] * plan["K"]

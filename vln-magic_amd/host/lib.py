@@ -48,6 +48,8 @@ SIGNATURES = {
     "magic_mse": [i32, i32, i64, i64, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp, i64, i32, vp],
     "magic_mse_multi": [i32, i32, vp, vp],
     "magic_node_in_fwd": [i32, i32, i32, vp, vp],
+    "magic_csr_gather_multi": [i32, i32, i32, vp, vp],
+    "magic_smallk_ln_bwd_pair": [i32, i32, vp, vp],
     "magic_csr_gather": [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp],
     "magic_pano_fuse_fwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "magic_pano_fuse_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -100,6 +102,17 @@ class NodeIn(C.Structure):
     """mirror of `magic_node_in` (include/magic_hip.h)"""
     _fields_ = ([("M", i32), ("Kin", i32), ("x", vp), ("W", vp), ("b", vp), ("gamma", vp), ("beta", vp), ("eps", f32), ("pad_", i32)]
                 + [(n, vp) for n in NODE_IN_PTRS])
+
+
+class CsrProb(C.Structure):
+    """mirror of `magic_csr_prob` (include/magic_hip.h)"""
+    _fields_ = [("n_out", i32), ("accumulate", i32), ("src1", vp), ("ptr1", vp), ("idx1", vp), ("w1", vp),
+                ("src2", vp), ("ptr2", vp), ("idx2", vp), ("w2", vp), ("out", vp)]
+
+
+class SkbProb(C.Structure):
+    """mirror of `magic_skb_prob` (include/magic_hip.h)"""
+    _fields_ = [("M", i32), ("Kin", i32)] + [(n, vp) for n in ("x", "dy", "y", "gamma", "beta", "rstd", "dW", "db", "dgamma", "dbeta")]
 
 
 class RbStage(C.Structure):

@@ -576,8 +576,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 d_gin, d_vin = self._par(lambda: n.cross_bwd(c.glob, c.d_gmap, c.d_txt, c.dP_g),
                                          lambda: n.cross_bwd(c.loc, c.d_vp, d_txt2, c.dP_l))
             O.add_(c.d_txt, d_txt2)
-            n.vp_in_bwd(c.vin, plan, d_vin, c.d_pano)
-        if task != "mrc":
+            n.nodes_in_bwd(plan, c.gin, d_gin, c.vin, d_vin, c.d_pano, c.d_fused)       # both input stages in shared launches
+        if task == "mlm":
             n.gmap_in_bwd(c.gin, plan, d_gin, c.d_pano, c.d_fused)
 
     @torch.no_grad()

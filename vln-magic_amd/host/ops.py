@@ -610,6 +610,37 @@ def csr_gather(src, ptr, idx, w, out, n_out, H, accumulate=False):
            L.stream())
 
 
+def csr_gather_multi(H, problems):
+    """<= 4 independent gathers in one launch.  problems: dicts(out, n_out, src1, csr1=(ptr, idx, w)[, src2, csr2][, accumulate])"""
+    import ctypes as C
+    _chk(1 <= len(problems) <= 4, "csr_gather_multi problems")
+    arr = (L.CsrProb * len(problems))()
+    for j, q in enumerate(problems):
+        d = arr[j]
+        d.n_out, d.accumulate = int(q["n_out"]), 1 if q.get("accumulate") else 0
+        d.out = L.P(q["out"])
+        for i in (1, 2):
+            csr = q.get(f"csr{i}")
+            if csr is None:
+                continue
+            _chk(csr[0].dtype == torch.int32 and csr[1].dtype == torch.int32 and csr[0].numel() == d.n_out + 1, "csr arrays")
+            setattr(d, f"src{i}", L.P(q[f"src{i}"])); setattr(d, f"ptr{i}", L.P(csr[0])); setattr(d, f"idx{i}", L.P(csr[1])); setattr(d, f"w{i}", L.P(csr[2]))
+    L.call("magic_csr_gather_multi", L.dt(problems[0]["out"].dtype), H, len(problems), C.addressof(arr), L.stream())
+
+
+def smallk_ln_bwd_pair(H, problems):
+    """two smallk_ln_bwd problems in one launch; dicts with the arguments of smallk_ln_bwd"""
+    import ctypes as C
+    _chk(len(problems) == 2, "smallk_ln_bwd_pair takes two problems")
+    arr = (L.SkbProb * 2)()
+    for j, q in enumerate(problems):
+        d = arr[j]
+        d.M, d.Kin = int(q["M"]), int(q["Kin"])
+        for k in ("x", "dy", "y", "gamma", "beta", "rstd", "dW", "db", "dgamma", "dbeta"):
+            setattr(d, k, L.P(q[k]))
+    L.call("magic_smallk_ln_bwd_pair", L.dt(problems[0]["dy"].dtype), H, C.addressof(arr), L.stream())
+
+
 def pano_fuse_fwd(x, lens, wf, bf, fused, probs, N, V, H):
     L.call("magic_pano_fuse_fwd", L.dt(x.dtype), N, V, H, L.P(x), L.P(lens), L.P(wf), L.P(bf), L.P(fused), L.P(probs), L.stream())
 

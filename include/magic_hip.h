@@ -186,6 +186,13 @@ typedef struct {
   const float* w; long long rows_per_w; float norm, coef; const float* coef_dev; float* loss; void* ds; long long g_stride; int accumulate;
 } magic_mse_desc;
 int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* stream);
+/* The three in-batch contrastive terms of the CFP task (train_r2r_magic.py:548-560), forward and backward in one launch: for a in {a0, a1, a2}
+ * ([B,H] head outputs) sim = a txt^T / temperature; rows[2i][r] = CE(sim_i[r,:], r), rows[2i+1][c] = CE(sim_i[:,c], c) (unscaled);
+ * d_i = G_i txt / temperature, dtxt = sum_i G_i^T a_i / temperature with G_i = coef (softmax_rows - I) + coef (softmax_cols - I).
+ * B <= 64, H <= 256; d0 = d1 = d2 = dtxt = NULL: losses only.  part: fp32 scratch [3,B,H]; counter: one int32 that is 0 on entry and 0 again
+ * on completion (the three workgroups' partial dtxt are summed in fixed order by the one that finishes last). */
+int magic_cfp_loss(int dtype, int B, int H, const void* a0, const void* a1, const void* a2, const void* txt, float temperature, float coef,
+                   float* rows, void* d0, void* d1, void* d2, void* dtxt, float* part, int* counter, void* stream);
 
 /* out[n] (+)= sum_e w[e]*src[idx[e]]: map-node aggregation by viewpoint id (agent.py:905-924 semantics),
  * candidate-view / masked-token / CLS row selection; backward = same call on the transposed CSR. */

@@ -644,3 +644,40 @@ def test_fp32_gemm_split_bf16_contraction(layout, M, N, K):
         errs[mode] = (C.double() - ref).abs().max().item() / scale
     assert errs["exact"] < 5e-6 and errs["bf16x3"] < 2e-4, errs
     assert errs["bf16x3"] > 0                      # the split path really ran (it is not bit-identical to the exact instruction)
+
+
+@pytest.mark.parametrize("dtype,B,H", [(torch.float32, 48, 128), (torch.bfloat16, 48, 128), (torch.float32, 7, 256), (torch.bfloat16, 64, 256)])
+def test_cfp_loss_kernel_matches_autograd(dtype, B, H):
+    """magic_cfp_loss (three contrastive terms, forward + backward, one launch) against torch autograd of the reference arithmetic
+    (train_r2r_magic.py:548-560: cross_entropy(sim, arange) + cross_entropy(sim.T, arange) on sim = a txt^T / temperature)"""
+    import torch.nn.functional as F
+    from magic_amd.host import ops as O
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    a = [(torch.randn(B, H, generator=g) * 0.5).to(DEV).to(dtype).contiguous() for _ in range(3)]
+    txt = (torch.randn(B, H, generator=g) * 0.5).to(DEV).to(dtype).contiguous()
+    temp, coef = 0.07 * 10, 0.37 / B
+    rows = torch.empty(6, B, device=DEV, dtype=torch.float32)
+    d_a = [torch.empty(B, H, device=DEV, dtype=dtype) for _ in range(3)]
+    d_txt = torch.empty(B, H, device=DEV, dtype=dtype)
+    assert O.cfp_loss_ok(B, H)
+    O.cfp_loss(B, H, a, txt, temp, coef, rows, d_a=d_a, d_txt=d_txt)
+    rows2 = torch.empty_like(rows)
+    O.cfp_loss(B, H, a, txt, temp, coef, rows2)                         # losses only
+    torch.cuda.synchronize()
+    ar = torch.arange(B, device=DEV)
+    a64 = [x.double().requires_grad_(True) for x in a]
+    t64 = txt.double().requires_grad_(True)
+    tot, want_rows = 0.0, []
+    for x in a64:
+        sim = x @ t64.t() / temp
+        l1, l2 = F.cross_entropy(sim, ar, reduction="none"), F.cross_entropy(sim.t(), ar, reduction="none")
+        want_rows += [l1, l2]
+        tot = tot + coef * (l1.sum() + l2.sum())
+    tot.backward()
+    want = torch.stack(want_rows).detach()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(rows.double(), want, rtol=1e-4, atol=1e-4), (rows.double() - want).abs().max().item()
+    assert torch.equal(rows, rows2)
+    for got, ref, nm in [(d_a[i], a64[i].grad, f"d_a{i}") for i in range(3)] + [(d_txt, t64.grad, "d_txt")]:
+        err = (got.double() - ref).abs().max().item()
+        assert err <= tol * ref.abs().max().item() + 1e-7, (nm, err, ref.abs().max().item())

@@ -395,6 +395,140 @@ extern "C" int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* 
   return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The three in-batch contrastive terms of the CFP task in ONE launch, forward AND backward (validate_cfp, train_r2r_magic.py:548-560:
+// sim = a txt^T / temp and its transpose, cross-entropy against the diagonal in both directions, for a in {map, viewpoint, fused}):
+//   rows[2i][r]   = CE(sim_i[r, :], r)         rows[2i+1][c] = CE(sim_i[:, c], c)
+//   G_i = coef (softmax_rows(sim_i) - I) + coef (softmax_cols(sim_i) - I)          (= d1 + d2^T of the two ce_rows calls it replaces)
+//   d_a_i = G_i txt / temp                     d_txt = sum_i G_i^T a_i / temp
+// B <= 64 samples, H <= 256: everything is tiny (48 x 48 x 128), so the per-op form -- 6 similarity GEMMs, 6 row losses, 6 casts and 12
+// gradient GEMMs -- was ~30 launches of pure latency.  One 1024-thread workgroup per term with a_i and txt resident in LDS, fp32 FMAs; the
+// three partial d_txt are summed in fixed order by whichever workgroup finishes last (no atomics on data: deterministic).
+#define CFP_B 64
+template <typename T>
+__global__ __launch_bounds__(1024) void cfp_loss_kernel(int B, int H, const T* a0, const T* a1, const T* a2, const T* txt, float inv_temp, float coef,
+                                                        float* rows, T* d0, T* d1, T* d2, T* dtxt, float* part, int* counter) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cfp_smem[];
+  constexpr int VE = 16 / (int)sizeof(T);                        // elements per 16-byte vector
+  typedef __attribute__((ext_vector_type(VE))) T vec_t;
+  const int HS = H + VE;                                         // element pitch: rows stay 16-byte aligned
+  T* sa = (T*)cfp_smem;
+  T* st = sa + CFP_B * HS;
+  float (*sg)[CFP_B + 1] = (float (*)[CFP_B + 1])(st + CFP_B * HS);          // [65][65]; row 64 and the tail hold the two lse vectors
+  float* lse_r = &sg[CFP_B][0];
+  float* lse_c = lse_r + CFP_B;
+  __shared__ int is_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = blockIdx.x;
+  const T* a = pair == 0 ? a0 : pair == 1 ? a1 : a2;
+  T* da = pair == 0 ? d0 : pair == 1 ? d1 : d2;
+  {                                                              // both operands: one 16-byte load per lane and iteration, all issued before any is used
+    const int cpr = H / VE, nchunk = CFP_B * cpr;
+    for (int i0 = tid; i0 < nchunk; i0 += 2048) {
+      vec_t va[2], vt[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = i0 + 1024 * u, r = i / cpr, c = (i - r * cpr) * VE;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { va[u][e] = from_f<T>(0.f); vt[u][e] = from_f<T>(0.f); }
+        if (i < nchunk && r < B) { va[u] = *(const vec_t*)(a + (long long)r * H + c); vt[u] = *(const vec_t*)(txt + (long long)r * H + c); }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = i0 + 1024 * u, r = i / cpr, c = (i - r * cpr) * VE;
+        if (i < nchunk) { *(vec_t*)(sa + r * HS + c) = va[u]; *(vec_t*)(st + r * HS + c) = vt[u]; }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- sim = a txt^T / temp: thread owns entries e = tid + 1024 j (r = e / 64, c = e % 64 = lane)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 1024 * j, r = e >> 6, c = e & 63;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < H; ++k) s += to_f(sa[r * HS + k]) * to_f(st[c * HS + k]);
+    sg[r][c] = s * inv_temp;
+  }
+  __syncthreads();
+  // ---- log-sum-exp of every row and every column (entries outside B x B excluded); wave w owns rows / columns w, w+16, ...
+  for (int r = wave; r < B; r += 16) {
+    const float x = lane < B ? sg[r][lane] : -3.0e38f, y = lane < B ? sg[lane][r] : -3.0e38f;
+    const float mx = wave_max(x), my = wave_max(y);
+    const float sx = wave_sum(lane < B ? __expf(x - mx) : 0.f), sy = wave_sum(lane < B ? __expf(y - my) : 0.f);
+    if (lane == 0) {
+      const float lr = mx + __logf(sx), lc = my + __logf(sy);
+      lse_r[r] = lr; lse_c[r] = lc;
+      rows[(2 * pair) * B + r] = lr - sg[r][r];
+      rows[(2 * pair + 1) * B + r] = lc - sg[r][r];
+    }
+  }
+  if (!dtxt) return;
+  __syncthreads();
+  // ---- G = coef (P_rows - I) + coef (P_cols - I), in place (each entry read and written by its own thread)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 1024 * j, r = e >> 6, c = e & 63;
+    float g = 0.f;
+    if (r < B && c < B) {
+      const float x = sg[r][c], d = r == c ? 1.f : 0.f;
+      g = coef * ((__expf(x - lse_r[r]) - d) + (__expf(x - lse_c[c]) - d));
+    }
+    sg[r][c] = g;
+  }
+  __syncthreads();
+  // ---- d_a = G txt / temp ; partial d_txt = G^T a (fp32 scratch): thread owns output pairs (row o / (H/2), features 2 (o % (H/2)), +1)
+  const int hp = H >> 1;
+  for (int o = tid; o < B * hp; o += 1024) {
+    const int r = o / hp, h = (o - r * hp) * 2;
+    float ga0 = 0.f, ga1 = 0.f, gt0 = 0.f, gt1 = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < CFP_B; ++q) {
+      const float g1 = sg[r][q], g2 = sg[q][r];
+      ga0 += g1 * to_f(st[q * HS + h]); ga1 += g1 * to_f(st[q * HS + h + 1]);
+      gt0 += g2 * to_f(sa[q * HS + h]); gt1 += g2 * to_f(sa[q * HS + h + 1]);
+    }
+    da[(long long)r * H + h] = from_f<T>(ga0 * inv_temp); da[(long long)r * H + h + 1] = from_f<T>(ga1 * inv_temp);
+    float* pp = part + (long long)pair * B * H + (long long)r * H + h;
+    pp[0] = gt0; pp[1] = gt1;
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) is_last = (atomicAdd(counter, 1) == 2) ? 1 : 0;
+  __syncthreads();
+  if (is_last) {
+    __threadfence();
+    for (int o = tid; o < B * H; o += 1024) {
+      const float v = (__builtin_nontemporal_load(part + o) + __builtin_nontemporal_load(part + (long long)B * H + o)) + __builtin_nontemporal_load(part + 2ll * B * H + o);
+      dtxt[o] = from_f<T>(v * inv_temp);
+    }
+    if (tid == 0) *counter = 0;
+  }
+}
+
+static size_t cfp_lds_bytes(int H, int elt) { return (size_t)2 * CFP_B * (H + 16 / elt) * elt + 16 + (size_t)(CFP_B + 1) * (CFP_B + 1) * 4 + 2 * CFP_B * 4; }
+
+extern "C" int magic_cfp_loss(int dtype, int B, int H, const void* a0, const void* a1, const void* a2, const void* txt, float temperature, float coef,
+                              float* rows, void* d0, void* d1, void* d2, void* dtxt, float* part, int* counter, void* stream) {
+  if (B <= 0 || B > CFP_B || H <= 0 || H > 256 || (H & 7) || !a0 || !a1 || !a2 || !txt || !rows || temperature <= 0.f) return MAGIC_ERR_ARG;
+  if (((uintptr_t)a0 | (uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)txt) & 15) return MAGIC_ERR_ARG;
+  if ((d0 == nullptr) != (d1 == nullptr) || (d0 == nullptr) != (d2 == nullptr) || (d0 == nullptr) != (dtxt == nullptr)) return MAGIC_ERR_ARG;
+  if (dtxt && (!part || !counter)) return MAGIC_ERR_ARG;
+  if (dtype != DT_BF16 && dtype != DT_F32) return MAGIC_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t shm = cfp_lds_bytes(H, dtype == DT_BF16 ? 2 : 4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)cfp_loss_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfp_lds_bytes(256, 2));
+    (void)hipFuncSetAttribute((const void*)cfp_loss_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfp_lds_bytes(256, 4));
+    attr_set = true;
+  }
+  if (dtype == DT_BF16) hipLaunchKernelGGL(cfp_loss_kernel<bf16>, dim3(3), dim3(1024), shm, st, B, H, (const bf16*)a0, (const bf16*)a1, (const bf16*)a2, (const bf16*)txt,
+                                           1.f / temperature, coef, rows, (bf16*)d0, (bf16*)d1, (bf16*)d2, (bf16*)dtxt, part, counter);
+  else hipLaunchKernelGGL(cfp_loss_kernel<float>, dim3(3), dim3(1024), shm, st, B, H, (const float*)a0, (const float*)a1, (const float*)a2, (const float*)txt,
+                          1.f / temperature, coef, rows, (float*)d0, (float*)d1, (float*)d2, (float*)dtxt, part, counter);
+  return launch_status();
+}
+
 extern "C" int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld, const int* labels, int ignore_index,
                              float coef, const float* row_w, float* loss_row, void* dlogits, int ldd, int accumulate,
                              float* w_out, float w_rate, void* stream) {

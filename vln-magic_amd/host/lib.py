@@ -47,6 +47,7 @@ SIGNATURES = {
     "magic_kd_rows": [i32, i32, vp, vp, i32, f32, vp, f32, f32, vp, vp, vp, i32, vp],
     "magic_mse": [i32, i32, i64, i64, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp, i64, i32, vp],
     "magic_mse_multi": [i32, i32, vp, vp],
+    "magic_cfp_loss": [i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_node_in_fwd": [i32, i32, i32, vp, vp],
     "magic_csr_gather_multi": [i32, i32, i32, vp, vp],
     "magic_smallk_ln_bwd_pair": [i32, i32, vp, vp],

@@ -264,15 +264,17 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 o.update(global_logits=c.gl, local_logits=c.ll, fused_logits=c.fl)
             elif task == "cfp":
                 c.g0, c.v0, c.t0, c.gv0 = n.new(B, H), n.new(B, H), n.new(B, H), n.new(B, H)
-                O.csr_gather(c.glob.out, *plan["g0"], c.g0, B, H)
-                O.csr_gather(c.loc.out, *plan["v0"], c.v0, B, H)
-                O.csr_gather(c.txt.out, *plan["t0"], c.t0, B, H)
-                O.csr_gather(c.glob.out, *plan["g0"], c.gv0, B, H)
-                O.csr_gather(c.loc.out, *plan["v0"], c.gv0, B, H, accumulate=True)
-                c.cfp = []
-                for key, src in (("gmap", c.g0), ("vp", c.v0), ("fused", c.gv0), ("txt", c.t0)):
-                    hl = n.lin(f"cfp_heads.{key}.weight")
-                    c.cfp.append(O.linear_fwd(src, hl.W, hl.b, B))
+                # the four [CLS]-row selections (fused = map row + viewpoint row) in one launch, the four heads as one grouped launch
+                O.csr_gather_multi(H, [dict(out=c.g0, n_out=B, src1=c.glob.out, csr1=plan["g0"]),
+                                       dict(out=c.v0, n_out=B, src1=c.loc.out, csr1=plan["v0"]),
+                                       dict(out=c.t0, n_out=B, src1=c.txt.out, csr1=plan["t0"]),
+                                       dict(out=c.gv0, n_out=B, src1=c.glob.out, csr1=plan["g0"], src2=c.loc.out, csr2=plan["v0"])])
+                from . import lib as L
+                with L.group():
+                    c.cfp = []
+                    for key, src in (("gmap", c.g0), ("vp", c.v0), ("fused", c.gv0), ("txt", c.t0)):
+                        hl = n.lin(f"cfp_heads.{key}.weight")
+                        c.cfp.append(O.linear_fwd(src, hl.W, hl.b, B))
                 o["cfp"] = tuple(c.cfp)
             else:
                 raise ValueError(task)
@@ -389,10 +391,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             temp = float(cfg_get(cfg, "cfp_temperature"))
             c.rows = n.new(6, B, dtype=torch.float32)
             txt_o = c.cfp[3]
-            c.dsim = []
+            c.dsim, c.d_cfp = [], None
             ar = plan["arange_b"]
             lds = c.lds = rup(B, 8)
-            for i in range(3):
+            fused = O.cfp_loss_ok(B, H)
+            if fused:                            # the three contrastive terms, forward and backward, as one launch (csrc/loss.hip cfp_loss_kernel)
+                c.d_cfp = [n.new(B, H) for _ in range(4)] if train else None
+                O.cfp_loss(B, H, c.cfp[:3], txt_o, temp, sc * 0.5 / B, c.rows, d_a=c.d_cfp[:3] if train else None, d_txt=c.d_cfp[3] if train else None)
+            for i in (() if fused else range(3)):
                 a = c.cfp[i]
                 sim, simT = n.new(B, lds, dtype=torch.float32), n.new(B, lds, dtype=torch.float32)
                 O.gemm(0, a, txt_o, sim, B, B, H, H, H, lds, alpha=1.0 / temp)
@@ -509,9 +515,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 O.linear_dx(dZ, f1.W, B, out=c.d_gmap, residual=c.d_gmap, ldb=2 * H, ldc=K * H, N=H, K=H)
                 O.linear_dx(dZ, f1.W[:, H:], B, out=c.d_vp, residual=c.d_vp, ldb=2 * H, ldc=Vp * H, N=H, K=H)
         elif task == "cfp":
-            d_outs = [n.new(B, H) for _ in range(4)]
+            d_outs = c.d_cfp if c.d_cfp is not None else [n.new(B, H) for _ in range(4)]
             txt_o = c.cfp[3]
-            for i in range(3):
+            for i in (() if c.d_cfp is not None else range(3)):
                 d1, d2 = c.dsim[i]
                 a = c.cfp[i]
                 it = 1.0 / c.temp
@@ -531,9 +537,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 O.linear_dw(d_o, src, hl.dW, hl.db, B)
                 for dst in dsts:
                     O.linear_dx(d_o, hl.W, B, out=dst, residual=dst)
-            O.csr_gather(d_g0, *plan["g0_T"], c.d_gmap, B * K, H, accumulate=True)
-            O.csr_gather(d_v0, *plan["v0_T"], c.d_vp, B * Vp, H, accumulate=True)
-            O.csr_gather(d_t0, *plan["t0_T"], c.d_txt, B * L, H, accumulate=True)
+            O.csr_gather_multi(H, [dict(out=c.d_gmap, n_out=B * K, accumulate=True, src1=d_g0, csr1=plan["g0_T"]),
+                                   dict(out=c.d_vp, n_out=B * Vp, accumulate=True, src1=d_v0, csr1=plan["v0_T"]),
+                                   dict(out=c.d_txt, n_out=B * L, accumulate=True, src1=d_t0, csr1=plan["t0_T"])])
         if task == "mlm":
             nm, Vv = plan["n_mask"], self.config.vocab_size
             dlog = c.dlogits                     # CE wrote the gradient (in place unless keep_mlm_logits)

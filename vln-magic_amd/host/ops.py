@@ -610,6 +610,27 @@ def csr_gather(src, ptr, idx, w, out, n_out, H, accumulate=False):
            L.stream())
 
 
+def cfp_loss_ok(B, H):
+    return B <= 64 and H <= 256 and H % 8 == 0 and not os.environ.get("MAGIC_NO_FUSED_CFP")
+
+
+_CFP_COUNTER = {}
+
+
+def cfp_loss(B, H, a, txt, temperature, coef, rows, d_a=None, d_txt=None):
+    """a: the three [B,H] head outputs (map, viewpoint, fused); rows: fp32 [6,B] loss rows; d_a (3 tensors) / d_txt: gradients or None"""
+    _chk(len(a) == 3 and all(x.is_contiguous() and x.dtype == txt.dtype for x in a) and txt.is_contiguous(), "cfp_loss operands")
+    d = d_a if d_a is not None else (None, None, None)
+    part = cnt = None
+    if d_txt is not None:
+        part = torch.empty(3, B, H, dtype=torch.float32, device=txt.device)
+        cnt = _CFP_COUNTER.get(txt.device)       # one persistent int32 per device: zero between launches (the kernel resets it)
+        if cnt is None:
+            cnt = _CFP_COUNTER[txt.device] = torch.zeros(1, dtype=torch.int32, device=txt.device)
+    L.call("magic_cfp_loss", L.dt(txt.dtype), B, H, L.P(a[0]), L.P(a[1]), L.P(a[2]), L.P(txt), float(temperature), float(coef), L.P(rows),
+           L.P(d[0]), L.P(d[1]), L.P(d[2]), L.P(d_txt), L.P(part), L.P(cnt), L.stream())
+
+
 def csr_gather_multi(H, problems):
     """<= 4 independent gathers in one launch.  problems: dicts(out, n_out, src1, csr1=(ptr, idx, w)[, src2, csr2][, accumulate])"""
     import ctypes as C

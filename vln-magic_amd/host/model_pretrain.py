@@ -159,6 +159,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         O.lndot_fwd(Y, M, H, ln.g, ln.b, n.eps, l2.Wm, l2.b, logit)
         return Y, logit
 
+    def _cls_tail(self, prefix, Y, M):
+        """ClsPrediction after its first projection: LayerNorm + Linear(H, 1)"""
+        n = self.net
+        ln, l2 = n.ln(prefix + "net.2"), n.lin(prefix + "net.3.weight")
+        logit = n.new(M, dtype=torch.float32)
+        O.lndot_fwd(Y, M, n.H, ln.g, ln.b, n.eps, l2.Wm, l2.b, logit)
+        return logit
+
     def _cls_bwd(self, prefix, X, Y, dlogit, M, d_acc, lda=None):
         n, H = self.net, self.net.H
         l1, ln, l2 = n.lin(prefix + "net.0.weight"), n.ln(prefix + "net.2"), n.lin(prefix + "net.3.weight")
@@ -244,12 +252,18 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                                     c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], dist=inp.dist), _local)
             o.update(gmap_embeds=c.glob.out, gmap_attns=c.glob.P, vp_embeds=c.loc.out, vp_attns=c.loc.P)
             if task == "sap":
-                c.Yg, c.g_raw = self._cls("global_sap_head.", c.glob.out, B * K)
-                c.Yl, c.l_raw = self._cls("local_sap_head.", c.loc.out, B * Vp)
+                from . import lib as _lib
                 use_gate = bool(cfg_get(self.config, "glocal_fuse"))
+                g1, l1_ = n.lin("global_sap_head.net.0.weight"), n.lin("local_sap_head.net.0.weight")
+                with _lib.group():                  # the three heads' first projections are independent: one grouped launch
+                    c.Yg = O.linear_fwd(c.glob.out, g1.W, g1.b, B * K, epilogue=2)
+                    c.Yl = O.linear_fwd(c.loc.out, l1_.W, l1_.b, B * Vp, epilogue=2)
+                    if use_gate:
+                        f1 = n.lin("sap_fuse_linear.net.0.weight")
+                        tmp = O.linear_fwd(c.glob.out, f1.W, None, B, lda=K * H, ldb=2 * H, K=H)
+                c.g_raw = self._cls_tail("global_sap_head.", c.Yg, B * K)
+                c.l_raw = self._cls_tail("local_sap_head.", c.Yl, B * Vp)
                 if use_gate:
-                    f1 = n.lin("sap_fuse_linear.net.0.weight")
-                    tmp = O.linear_fwd(c.glob.out, f1.W, None, B, lda=K * H, ldb=2 * H, K=H)
                     c.Yf = O.linear_fwd(c.loc.out, f1.W[:, H:], f1.b, B, lda=Vp * H, ldb=2 * H, K=H, residual=tmp, epilogue=0)
                     self._relu(c.Yf)      # ReLU after the two partial products are summed
                     fln, f2 = n.ln("sap_fuse_linear.net.2"), n.lin("sap_fuse_linear.net.3.weight")
@@ -269,8 +283,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                                        dict(out=c.v0, n_out=B, src1=c.loc.out, csr1=plan["v0"]),
                                        dict(out=c.t0, n_out=B, src1=c.txt.out, csr1=plan["t0"]),
                                        dict(out=c.gv0, n_out=B, src1=c.glob.out, csr1=plan["g0"], src2=c.loc.out, csr2=plan["v0"])])
-                from . import lib as L
-                with L.group():
+                from . import lib as _lib
+                with _lib.group():
                     c.cfp = []
                     for key, src in (("gmap", c.g0), ("vp", c.v0), ("fused", c.gv0), ("txt", c.t0)):
                         hl = n.lin(f"cfp_heads.{key}.weight")
@@ -503,8 +517,18 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             dg, dl, df = n.new(B, K, dtype=torch.float32), n.new(B, Vp, dtype=torch.float32), n.new(B, dtype=torch.float32)
             O.sap_fuse_bwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, plan["gmask"], plan["lmask"], plan["fsrc"], plan["bwmask"],
                            c.use_gate, c.dgl, c.dll, c.dfl, dg, dl, df)
-            self._cls_bwd("global_sap_head.", c.glob.out, c.Yg, dg, B * K, c.d_gmap)
-            self._cls_bwd("local_sap_head.", c.loc.out, c.Yl, dl, B * Vp, c.d_vp)
+            from . import lib as _lib
+            heads = []
+            for prefix, X, Y, dlogit, M, d_acc in (("global_sap_head.", c.glob.out, c.Yg, dg, B * K, c.d_gmap),
+                                                   ("local_sap_head.", c.loc.out, c.Yl, dl, B * Vp, c.d_vp)):
+                l1, ln, l2 = n.lin(prefix + "net.0.weight"), n.ln(prefix + "net.2"), n.lin(prefix + "net.3.weight")
+                dZh = n.new(M, H)
+                O.lndot_bwd(Y, M, H, ln.g, ln.b, n.eps, l2.Wm, dlogit, dZh, ln.dg, ln.db, l2.dW, l2.db)
+                O.linear_dw(dZh, X, l1.dW, l1.db, M)
+                heads.append((dZh, l1, M, d_acc))
+            with _lib.group():                      # the two heads' input gradients go to different tensors: one grouped launch
+                for dZh, l1, M, d_acc in heads:
+                    O.linear_dx(dZh, l1.W, M, out=d_acc, residual=d_acc)
             if c.use_gate:
                 f1, fln, f2 = n.lin("sap_fuse_linear.net.0.weight"), n.ln("sap_fuse_linear.net.2"), n.lin("sap_fuse_linear.net.3.weight")
                 dZ = n.new(B, H)
@@ -512,8 +536,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 # dW[:, :H] += dZ^T g0 ; dW[:, H:] += dZ^T v0 (bias grad once)
                 O.linear_dw(dZ, c.glob.out, f1.dW, f1.db, B, N=H, K=H, ldb=K * H, ldc=2 * H)
                 O.linear_dw(dZ, c.loc.out, f1.dW[:, H:], None, B, N=H, K=H, ldb=Vp * H, ldc=2 * H)
-                O.linear_dx(dZ, f1.W, B, out=c.d_gmap, residual=c.d_gmap, ldb=2 * H, ldc=K * H, N=H, K=H)
-                O.linear_dx(dZ, f1.W[:, H:], B, out=c.d_vp, residual=c.d_vp, ldb=2 * H, ldc=Vp * H, N=H, K=H)
+                with _lib.group():
+                    O.linear_dx(dZ, f1.W, B, out=c.d_gmap, residual=c.d_gmap, ldb=2 * H, ldc=K * H, N=H, K=H)
+                    O.linear_dx(dZ, f1.W[:, H:], B, out=c.d_vp, residual=c.d_vp, ldb=2 * H, ldc=Vp * H, N=H, K=H)
         elif task == "cfp":
             d_outs = c.d_cfp if c.d_cfp is not None else [n.new(B, H) for _ in range(4)]
             txt_o = c.cfp[3]

@@ -184,6 +184,7 @@ int magic_mse(int dtype, int g_f32, long long outer, long long inner, const void
 typedef struct {
   int g_f32; long long outer, inner; const void* s; long long s_stride; const void* t; long long t_stride;
   const float* w; long long rows_per_w; float norm, coef; const float* coef_dev; float* loss; void* ds; long long g_stride; int accumulate;
+  const int* valid_dev; const float* norm_dev; long long valid_mod;   /* magic_mse_multi only (shape-bucketed batches): device-side valid (outer, inner) <= the launch's (inner taken modulo valid_mod when > 0); norm *= norm_dev[0] */
 } magic_mse_desc;
 int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* stream);
 /* The three in-batch contrastive terms of the CFP task (train_r2r_magic.py:548-560), forward and backward in one launch: for a in {a0, a1, a2}

@@ -1,0 +1,68 @@
+"""Shape buckets for streamed batches (host/bucket.py, plan.build_plan_host(pad=...)), CPU part: a bucket has ONE record layout, padding is
+where the network masks it, and the true sizes travel with the record."""
+import pickle
+
+import torch
+
+import magic_amd  # noqa: F401
+from magic_amd.host import synth
+from magic_amd.host.bucket import bucket_of, pad_batch
+from magic_amd.host.loader import pack, pack_bucketed
+from magic_amd.host.plan import build_plan_host
+
+
+def _layout(rec):
+    manifest, meta = pickle.loads(rec["blob"])
+    return [(k, dt, shape, o) for k, dt, shape, o, _ in manifest], meta
+
+
+def test_records_of_one_bucket_share_one_layout():
+    for task in ("sap", "mlm", "cfp"):
+        seen = {}
+        for step in range(12):
+            b = synth.make_batch(task, batch_size=8, seed=77, step=step)
+            bk = bucket_of(b, task)
+            lay, meta = _layout(pack_bucketed(b, task))
+            key = tuple(sorted(bk.items()))
+            if key in seen:
+                assert seen[key] == lay, (task, bk)
+            seen[key] = lay
+            assert meta["bucket"] == bk and meta["L"] == bk["L"] and meta["K"] == bk["K"] and meta["Np"] == bk["Np"]
+            assert meta["true"]["L"] == b["txt_ids"].shape[1] and meta["true"]["Np"] == sum(b["traj_step_lens"]) == meta["traj_steps"]
+        assert len(seen) >= 1
+
+
+def test_padding_is_masked_and_the_valid_part_is_unchanged():
+    task = "mlm"
+    b = synth.make_batch(task, batch_size=6, seed=5, step=3)
+    bk = bucket_of(b, task)
+    padded, true = pad_batch(b, task, bk)
+    exact = build_plan_host(b, task)
+    hp = build_plan_host(padded, task, pad=(bk, true))
+    L0, L1, K0, K1 = true["L"], bk["L"], true["K"], bk["K"]
+    B = len(b["traj_step_lens"])
+    m1, m0 = hp["cpu"]["txt_mask"].reshape(B, L1), exact["cpu"]["txt_mask"].reshape(B, L0)
+    assert torch.equal(m1[:, :L0], m0) and not m1[:, L0:].any()
+    g1, g0 = hp["cpu"]["gmap_mask"].reshape(B, K1), exact["cpu"]["gmap_mask"].reshape(B, K0)
+    assert torch.equal(g1[:, :K0], g0) and not g1[:, K0:].any()
+    assert not hp["cpu"]["pano_mask"][true["Np"]:].any()                      # dummy panoramas: no valid view
+    # masked-token rows: the true ones first, then rows without a source and with an ignored label; 1 / n_mask as per-row weights
+    nm = true["n_mask"]
+    assert torch.equal(hp["cpu"]["mlm_labels"][:nm], exact["cpu"]["mlm_labels"]) and (hp["cpu"]["mlm_labels"][nm:] == -1).all()
+    assert torch.allclose(hp["cpu"]["mlm_row_w"], torch.full((bk["n_mask"],), 1.0 / nm))
+    ptr = hp["csr"]["mlm_rows"][0][0]
+    assert ptr[nm] == nm and (ptr[nm:] == nm).all()
+    # a gather CSR of the padded plan addresses the same sources as the exact one (row numbering follows the padded strides)
+    pe, ie, we = exact["csr"]["gmap_from_fused"][0]
+    pp, ip, wp = hp["csr"]["gmap_from_fused"][0]
+    for b_ in range(B):
+        for k in range(K0):
+            r0, r1 = b_ * K0 + k, b_ * K1 + k
+            assert list(ie[pe[r0]:pe[r0 + 1]]) == list(ip[pp[r1]:pp[r1 + 1]])
+    assert len(ip) == B * K1                                                  # padded to the bucket's capacity
+
+
+def test_exact_records_are_unchanged_by_the_bucket_option():
+    b = synth.make_batch("sap", batch_size=4, seed=1, step=0)
+    lay, meta = _layout(pack(b, build_plan_host(b, "sap")))
+    assert "true" not in meta and meta["L"] == b["txt_ids"].shape[1]

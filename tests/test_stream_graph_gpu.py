@@ -1,0 +1,50 @@
+"""Streamed batches under HIP-graph replay (host/stream_graph.py, -m gpu): a step replayed on the bucket-padded record of a batch must equal the
+eager step on the exact (unpadded) batch -- every loss term and the weights after AdamW -- and a second batch of the same bucket must reuse
+the captured graph."""
+import pytest
+import torch
+
+import magic_amd  # noqa: F401
+import bench
+from magic_amd.host import synth
+from magic_amd.host.bucket import bucket_of
+from magic_amd.host.loader import pack_bucketed
+from magic_amd.host.plan import build_plan
+from magic_amd.host.stream_graph import StreamStep
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+RW = [1.3, 0.7, 1.1, 0.9, 1.0]
+
+
+def _close(a, b, rtol):
+    a, b = float(a), float(b)
+    return abs(a - b) <= rtol * max(abs(b), 1e-6)
+
+
+def test_bucketed_graph_step_equals_the_exact_eager_step():
+    _, _, _, sA, tA = bench.build_models(torch.bfloat16, DEV, 0.0, 1, 16)
+    _, _, _, sB, tB = bench.build_models(torch.bfloat16, DEV, 0.0, 1, 16)
+    assert torch.equal(sA.store.flat, sB.store.flat)
+    rw = torch.tensor(RW, dtype=torch.float32, device=DEV)
+    ss = StreamStep(tB, rw=rw)
+    seen = {}
+    for i, (task, step) in enumerate((("sap", 0), ("mlm", 1), ("cfp", 2), ("sap", 3), ("mlm", 4), ("cfp", 5), ("sap", 6))):
+        b = synth.make_batch(task, batch_size=16, seed=4242, step=step)
+        key = (task, tuple(sorted(bucket_of(b, task).items())))
+        plan = build_plan(b, task, DEV)
+        outA = tA.step(synth.batch_to(b, DEV), task, rw=rw, plan=plan)
+        before = ss.captures
+        outB, meta = ss.step(task, pack_bucketed(b, task))
+        torch.cuda.synchronize()
+        assert ss.captures == before + (0 if key in seen else 1), "a bucket is captured once"
+        seen[key] = True
+        assert meta["true"]["L"] == b["txt_ids"].shape[1] <= meta["L"] == 80
+        for k in ("loss", "supervised_loss", "kdl_loss"):
+            assert _close(outB[k], outA[k], 2e-3), (task, step, k, float(outB[k]), float(outA[k]))
+        for k, v in outA["kdl_terms"].items():
+            assert _close(outB["kdl_terms"][k], v, 5e-3) or abs(float(v)) < 1e-7, (task, step, k, float(outB["kdl_terms"][k]), float(v))
+        wa, wb = sA.store.flat, sB.store.flat
+        rel = ((wa - wb).norm() / wa.norm()).item()
+        assert rel < 2e-5, (task, step, rel)
+    assert len(seen) < 7 or ss.captures <= 7

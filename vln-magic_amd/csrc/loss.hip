@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256) void mse_kernel(long long outer, long long inn
 struct magic_mse_desc {
   int g_f32; long long outer, inner; const void* s; long long s_stride; const void* t; long long t_stride;
   const float* w; long long rows_per_w; float norm, coef; const float* coef_dev; float* loss; void* ds; long long g_stride; int accumulate;
+  // shape-bucketed batches under graph replay (host/stream_graph.py): the launch covers the BUCKET's [outer][inner] extent; valid_dev[0..1] =
+  // this batch's (outer, inner) -- elements beyond them add nothing to the loss and get a zero gradient -- and norm is multiplied by norm_dev[0]
+  const int* valid_dev; const float* norm_dev; long long valid_mod;      // valid_mod > 0: element r of a block is valid iff r % valid_mod < valid_dev[1]
 };
 struct MseMulti { magic_mse_desc d[MSE_MAX]; int start[MSE_MAX + 1]; int vec[MSE_MAX]; int n; };
 
@@ -255,14 +258,17 @@ __device__ __forceinline__ void mse_body(const magic_mse_desc& p, int bid, int n
   if (p.coef_dev) coef *= p.coef_dev[0];
   const T* s = (const T*)p.s; const T* t = (const T*)p.t; G* ds = (G*)p.ds;
   const long long total = p.outer * p.inner;
+  const long long vo = p.valid_dev ? p.valid_dev[0] : p.outer, vi = p.valid_dev ? p.valid_dev[1] : p.inner;
+  const float nrm = p.norm * (p.norm_dev ? p.norm_dev[0] : 1.f);
   float acc = 0.f;
   for (long long i = (long long)bid * MSE_NT + threadIdx.x; i < total; i += (long long)nblk * MSE_NT) {
     const long long o = i / p.inner, r = i % p.inner;
-    const float d = to_f(s[o * p.s_stride + r]) - to_f(t[o * p.t_stride + r]);
+    const bool ok = o < vo && (p.valid_mod > 0 ? r % p.valid_mod : r) < vi;
+    const float d = ok ? to_f(s[o * p.s_stride + r]) - to_f(t[o * p.t_stride + r]) : 0.f;
     const float wv = p.w ? p.w[o / p.rows_per_w] : 1.f;
     acc += wv * d * d;
     if (ds) {
-      float g = 2.f * coef * p.norm * wv * d;
+      float g = 2.f * coef * nrm * wv * d;
       G* q = ds + o * p.g_stride + r;
       if (p.accumulate) g += to_f(*q);
       *q = from_f<G>(g);
@@ -274,7 +280,7 @@ __device__ __forceinline__ void mse_body(const magic_mse_desc& p, int bid, int n
   if (threadIdx.x == 0 && p.loss) {
     float v = 0.f;
     for (int w = 0; w < MSE_NT / 64; ++w) v += red[w];
-    atomicAdd(p.loss, v * p.norm);
+    atomicAdd(p.loss, v * nrm);
   }
 }
 
@@ -287,7 +293,10 @@ __device__ __forceinline__ void mse_body_v8(const magic_mse_desc& p, int bid, in
   const bf16* s = (const bf16*)p.s; const bf16* t = (const bf16*)p.t; G* ds = (G*)p.ds;
   const unsigned in8 = (unsigned)(p.inner >> 3), tot8 = (unsigned)p.outer * in8, rpw = (unsigned)p.rows_per_w;
   const unsigned stride = (unsigned)nblk * MSE_NT;
-  const float c2 = 2.f * coef * p.norm;
+  const unsigned vo = p.valid_dev ? (unsigned)p.valid_dev[0] : (unsigned)p.outer, vi = p.valid_dev ? (unsigned)p.valid_dev[1] : (unsigned)p.inner;
+  const float nrm = p.norm * (p.norm_dev ? p.norm_dev[0] : 1.f);
+  const float c2 = 2.f * coef * nrm;
+  const unsigned vm = (unsigned)p.valid_mod;
   float acc = 0.f;
   for (unsigned i0 = (unsigned)bid * MSE_NT + threadIdx.x; i0 < tot8; i0 += 2 * stride) {
     bf16x8 sv[2], tv[2];
@@ -308,8 +317,9 @@ __device__ __forceinline__ void mse_body_v8(const magic_mse_desc& p, int bid, in
       const float wv = p.w ? p.w[o[u] / rpw] : 1.f;
       float d[8];
       float a = 0.f;
+      const unsigned rm = vm ? r[u] % vm : r[u];          // (valid_mod is a multiple of 8: a vector never straddles two sub-blocks)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { d[e] = (float)sv[u][e] - (float)tv[u][e]; a += d[e] * d[e]; }
+      for (int e = 0; e < 8; ++e) { d[e] = (o[u] < vo && rm + e < vi) ? (float)sv[u][e] - (float)tv[u][e] : 0.f; a += d[e] * d[e]; }
       acc += wv * a;
       if (ds) {
         G* q = ds + (long long)o[u] * p.g_stride + r[u];
@@ -341,7 +351,7 @@ __device__ __forceinline__ void mse_body_v8(const magic_mse_desc& p, int bid, in
   if (threadIdx.x == 0 && p.loss) {
     float v = 0.f;
     for (int w = 0; w < MSE_NT / 64; ++w) v += red[w];
-    atomicAdd(p.loss, v * p.norm);
+    atomicAdd(p.loss, v * nrm);
   }
 }
 
@@ -373,7 +383,7 @@ extern "C" int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* 
     const long long tot = d[i].outer * d[i].inner;
     const magic_mse_desc& q = d[i];
     const bool vec = dtype == DT_BF16 && tot < 0x7FFFFFFFll && q.inner % 8 == 0 && q.s_stride % 8 == 0 && q.t_stride % 8 == 0 &&
-                     !((uintptr_t)q.s & 15) && !((uintptr_t)q.t & 15) && (!q.ds || (q.g_stride % 8 == 0 && !((uintptr_t)q.ds & 15)));
+                     !((uintptr_t)q.s & 15) && !((uintptr_t)q.t & 15) && (!q.ds || (q.g_stride % 8 == 0 && !((uintptr_t)q.ds & 15))) && q.valid_mod % 8 == 0;
     mm.vec[i] = vec ? 1 : 0;
     work[i] = vec ? (tot + 7) / 8 : tot;          // lane-iterations
     all += work[i];

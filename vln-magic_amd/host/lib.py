@@ -93,7 +93,7 @@ class MseDesc(C.Structure):
     """mirror of `magic_mse_desc` (include/magic_hip.h)"""
     _fields_ = [("g_f32", i32), ("outer", i64), ("inner", i64), ("s", vp), ("s_stride", i64), ("t", vp), ("t_stride", i64),
                 ("w", vp), ("rows_per_w", i64), ("norm", f32), ("coef", f32), ("coef_dev", vp), ("loss", vp), ("ds", vp),
-                ("g_stride", i64), ("accumulate", i32)]
+                ("g_stride", i64), ("accumulate", i32), ("valid_dev", vp), ("norm_dev", vp), ("valid_mod", i64)]
 
 
 NODE_IN_PTRS = ("A", "rstd", "out", "add0", "src1", "ptr1", "idx1", "w1", "src2", "ptr2", "idx2", "w2", "tab", "tab_idx")

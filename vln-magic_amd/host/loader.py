@@ -51,14 +51,18 @@ def pack(batch, hp):
     return dict(buf=buf, blob=pickle.dumps((manifest, meta), protocol=pickle.HIGHEST_PROTOCOL))
 
 
-def unpack(rec, device):
-    """packed record -> (batch_on_device, plan_on_device): one (pinned) host buffer, one async copy, views"""
+def unpack(rec, device, dbuf=None, parsed=None):
+    """packed record -> (batch_on_device, plan_on_device): one (pinned) host buffer, one async copy, views.
+    dbuf: an existing device buffer of the record's size to copy into (the static buffer a captured graph reads, stream_graph.StreamStep)"""
     device = torch.device(device)
     buf = rec["buf"]
-    manifest, meta = pickle.loads(rec["blob"])
+    manifest, meta = parsed if parsed is not None else pickle.loads(rec["blob"])
     if device.type == "cuda" and not buf.is_pinned():
         buf = buf.pin_memory()
-    dbuf = buf.to(device, non_blocking=True)
+    if dbuf is None:
+        dbuf = buf.to(device, non_blocking=True)
+    else:
+        dbuf.copy_(buf, non_blocking=True)
     batch, plan, csr = {}, {}, {}
     typed = {}                       # one reinterpretation of the whole buffer per dtype; every array is then ONE as_strided view of it
     for k, dt, shape, o, n in manifest:
@@ -93,14 +97,23 @@ def unpack(rec, device):
 
 class PlanCollate:
     """collate_fn for DataLoader workers: `inputs` -> packed record (`pack`).  `collate_fn` is the task's collate
-    (`tasks.py:{mlm,mrc,sap,cfp}_collate`, or `synth.collate` bound to the task)."""
+    (`tasks.py:{mlm,mrc,sap,cfp}_collate`, or `synth.collate` bound to the task).  bucket: keyword arguments of bucket.bucket_of -- the batch is
+    then padded to its shape bucket (bucket.pad_batch) so that the record has the bucket's one layout (graph replay, stream_graph.StreamStep)."""
 
-    def __init__(self, collate_fn, task):
-        self.collate_fn, self.task = collate_fn, task
+    def __init__(self, collate_fn, task, bucket=None):
+        self.collate_fn, self.task, self.bucket = collate_fn, task, bucket
 
     def __call__(self, inputs):
         batch = self.collate_fn(inputs)
-        return pack(batch, build_plan_host(batch, self.task))
+        return pack_bucketed(batch, self.task, self.bucket) if self.bucket is not None else pack(batch, build_plan_host(batch, self.task))
+
+
+def pack_bucketed(batch, task, bucket_kw=None):
+    """collated batch -> packed record of its shape bucket"""
+    from .bucket import bucket_of, pad_batch
+    bk = bucket_of(batch, task, **(bucket_kw or {}))
+    padded, true = pad_batch(batch, task, bk)
+    return pack(padded, build_plan_host(padded, task, pad=(bk, true)))
 
 
 def _to_device(x, device):

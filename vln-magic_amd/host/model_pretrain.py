@@ -22,6 +22,7 @@ from .plan import build_plan, check_plan
 
 LOCKSTEP = not os.environ.get("MAGIC_NO_LOCKSTEP")
 LOCKSTEP_EAGER = bool(os.environ.get("MAGIC_LOCKSTEP_EAGER"))
+DYN_TERMS = ("txt_emb", "txt_attn", "img_emb", "img_fused", "img_attn", "g_emb", "g_attn", "l_emb", "l_attn")      # plan["dyn"] slots
 KD_SLOTS = ("txt_emb_loss", "txt_attn_loss", "img_emb_loss", "avg_img_emb_loss", "img_attn_loss",
             "global_emb_loss", "global_attn_loss", "local_emb_loss", "local_attn_loss", "predict_loss")
 
@@ -319,18 +320,35 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     # ---- losses + gradient seeds ------------------------------------------------------------------------
     # The distillation terms of a step are independent of each other: their five student->teacher-width projections go out as
     # ONE grouped GEMM launch, all MSE terms (<= 10) as ONE launch, and the five projection input-gradients as ONE grouped launch.
-    def _kd_emb(self, c, slot, s_t, t_t, proj, M, outer, w, coef, d_acc):
-        c.kd_emb.append((slot, s_t, t_t, self.net.lin(f"bert.{proj}.weight"), M, outer, w, coef, d_acc))
+    # Shape-bucketed batches under graph replay (host/stream_graph.py, host/bucket.py): plan["dyn"] = {i: int32[2 n], f: fp32[n], fill: {}}.
+    # A distillation term then takes its TRUE (outer, inner) extent and its normaliser from device memory (slot of DYN_TERMS), and registers
+    # how the slot is computed from the batch's true sizes -- fill[term](true) -> (outer, inner, norm) -- for StreamStep to evaluate per batch.
+    def _dyn(self, c, term, fn, mod=0):
+        d = c.plan.get("dyn")
+        if d is None:
+            return {}
+        i = DYN_TERMS.index(term)
+        d["fill"][term] = fn
+        return dict(valid_dev=d["i"][2 * i:2 * i + 2], norm_dev=d["f"][i:i + 1], norm=1.0, valid_mod=mod)
 
-    def _kd_attn(self, c, slot, sP, tP, Bn, Nq, Nk, ldp, nh_s, nh_t, w, coef):
+    def _kd_emb(self, c, slot, s_t, t_t, proj, M, outer, w, coef, d_acc, dyn=None):
+        c.kd_emb.append((slot, s_t, t_t, self.net.lin(f"bert.{proj}.weight"), M, outer, w, coef, d_acc, dyn))
+
+    def _kd_attn(self, c, slot, sP, tP, Bn, Nq, Nk, ldp, nh_s, nh_t, w, coef, dyn=None):
+        """dyn = (term, 'q' | None = which true size bounds the query rows, which true sizes enter the normaliser as (Nq, Nk))"""
         n = self.net
         hmin = min(nh_s, nh_t)
         dP = None
         if self.store.requires_grad:      # every student head is written when hmin == nh_s (pad columns included): no fill needed
             dP = (n.new if hmin == nh_s else n.zeros)(Bn, nh_s, Nq, ldp, dtype=torch.float32)
-        c.kd_mse.append(dict(s=sP, t=tP, outer=Bn, inner=hmin * Nq * ldp, s_stride=nh_s * Nq * ldp, t_stride=nh_t * Nq * ldp, w=w, rows_per_w=1,
-                             norm=1.0 / (Bn * hmin * Nq * Nk), coef=coef[0], coef_dev=coef[1], loss=c.slots[slot:slot + 1], ds=dP,
-                             g_stride=nh_s * Nq * ldp))
+        q = dict(s=sP, t=tP, outer=Bn, inner=hmin * Nq * ldp, s_stride=nh_s * Nq * ldp, t_stride=nh_t * Nq * ldp, w=w, rows_per_w=1,
+                 norm=1.0 / (Bn * hmin * Nq * Nk), coef=coef[0], coef_dev=coef[1], loss=c.slots[slot:slot + 1], ds=dP,
+                 g_stride=nh_s * Nq * ldp)
+        if dyn is not None:
+            term, qk, kk = dyn           # names of the true sizes of the query / key extents (None: the extent is not padded)
+            q.update(self._dyn(c, term, lambda t, Bn=Bn, hmin=hmin, Nq=Nq, Nk=Nk, ldp=ldp, qk=qk, kk=kk:
+                               (Bn, (t[qk] if qk else Nq) * ldp, 1.0 / (Bn * hmin * (t[qk] if qk else Nq) * (t[kk] if kk else Nk))), mod=Nq * ldp))
+        c.kd_mse.append(q)
         return dP
 
     def _kd_flush(self, c):
@@ -338,22 +356,29 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         n, train = self.net, self.store.requires_grad
         jobs = c.kd_emb
         with L.group():
-            sps = [O.linear_fwd(s_t, pl.W, pl.b, M) for (_, s_t, _, pl, M, _, _, _, _) in jobs]
+            sps = [O.linear_fwd(s_t, pl.W, pl.b, M) for (_, s_t, _, pl, M, _, _, _, _, _) in jobs]
         dss = []
-        for (slot, s_t, t_t, pl, M, outer, w, coef, d_acc), sp in zip(jobs, sps):
+        for (slot, s_t, t_t, pl, M, outer, w, coef, d_acc, dyn), sp in zip(jobs, sps):
             Ht = pl.N
             inner = (M // outer) * Ht
             ds = n.new(M, Ht) if train else None
             dss.append(ds)
-            c.kd_mse.append(dict(s=sp, t=t_t, outer=outer, inner=inner, s_stride=inner, t_stride=inner, w=w, rows_per_w=1, norm=1.0 / (M * Ht),
-                                 coef=coef[0], coef_dev=coef[1], loss=c.slots[slot:slot + 1], ds=ds, g_stride=inner))
+            q = dict(s=sp, t=t_t, outer=outer, inner=inner, s_stride=inner, t_stride=inner, w=w, rows_per_w=1, norm=1.0 / (M * Ht),
+                     coef=coef[0], coef_dev=coef[1], loss=c.slots[slot:slot + 1], ds=ds, g_stride=inner)
+            if dyn is not None:           # (term, true size bounding the OUTER extent or None, true size bounding the rows of a block or None)
+                term, ok, ik = dyn
+                rows = M // outer
+                q.update(self._dyn(c, term, lambda t, outer=outer, rows=rows, Ht=Ht, ok=ok, ik=ik:
+                                   ((t[ok] if ok else outer), (t[ik] if ik else rows) * Ht,
+                                    1.0 / ((t[ok] if ok else outer) * (t[ik] if ik else rows) * Ht))))
+            c.kd_mse.append(q)
         if c.kd_mse:
             O.mse_multi(c.kd_mse)
         if train:
-            for (slot, s_t, t_t, pl, M, outer, w, coef, d_acc), ds in zip(jobs, dss):
+            for (slot, s_t, t_t, pl, M, outer, w, coef, d_acc, dyn), ds in zip(jobs, dss):
                 O.linear_dw(ds, s_t, pl.dW, pl.db, M)
             with L.group():
-                for (slot, s_t, t_t, pl, M, outer, w, coef, d_acc), ds in zip(jobs, dss):
+                for (slot, s_t, t_t, pl, M, outer, w, coef, d_acc, dyn), ds in zip(jobs, dss):
                     O.linear_dx(ds, pl.W, M, out=d_acc, residual=d_acc)
         c.kd_emb, c.kd_mse = [], []
 
@@ -388,11 +413,12 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             nm = plan["n_mask"]
             c.rows = n.new(nm, dtype=torch.float32)
             c.dlogits = (n.new(nm, c.ldv) if self.keep_mlm_logits else c.logits) if train else None
-            O.ce_rows(c.logits, nm, cfg.vocab_size, c.ldv, plan["mlm_labels"], ignore_index=-1, coef=sc / nm, loss_row=c.rows,
-                      dlogits=c.dlogits, ldd=c.ldv)
+            roww = plan.get("mlm_row_w")      # shape buckets: nm counts padded (ignored) rows too, the true 1 / n_mask rides in per-row weights
+            O.ce_rows(c.logits, nm, cfg.vocab_size, c.ldv, plan["mlm_labels"], ignore_index=-1, coef=sc if roww is not None else sc / nm,
+                      row_w=roww, loss_row=c.rows, dlogits=c.dlogits, ldd=c.ldv)
             if train and not self.keep_mlm_logits:
                 o["predict"] = None          # overwritten in place by its gradient
-            sup = c.rows.sum() / nm
+            sup = (c.rows * roww).sum() if roww is not None else c.rows.sum() / nm
         elif task == "mrc":
             c.d_vp = zz(B * Vp, H)
             nm, Pn = plan["n_mrc"], c.mlogits.shape[1]
@@ -445,35 +471,37 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             Np, V = plan["Np"], plan["V"]
             if "txt" in tasks:
                 if emb:
-                    self._kd_emb(c, 0, o["txt_embeds"], t["txt_embeds"], "txt_emb_w", B * L, B, w, rw[0], c.d_txt)
+                    self._kd_emb(c, 0, o["txt_embeds"], t["txt_embeds"], "txt_emb_w", B * L, B, w, rw[0], c.d_txt, dyn=("txt_emb", None, "L"))
                 if att:
-                    c.dP_txt = self._kd_attn(c, 1, o["txt_attns"], t["txt_attns"], B, L, L, c.txt.ldp, nh_s, nh_t, w, rw[0])
+                    c.dP_txt = self._kd_attn(c, 1, o["txt_attns"], t["txt_attns"], B, L, L, c.txt.ldp, nh_s, nh_t, w, rw[0], dyn=("txt_attn", "L", "L"))
             # panorama tensors have leading dim sum(T): the sample weights [B] only broadcast (and are only applied by
             # mse_loss, pretrain kd_loss.py:11-16) when every trajectory has exactly one step
             wp = w if (w is not None and Np == B) else None
             if "img" in tasks:
                 if emb:
-                    self._kd_emb(c, 2, o["pano_embeds"], t["pano_embeds"], "kdl_img_w", Np * V, Np, wp, rw[1], c.d_pano)
-                    self._kd_emb(c, 3, o["pano_fused_embeds"], t["pano_fused_embeds"], "kdl_avg_img_w", Np, Np, wp, rw[1], c.d_fused)
+                    self._kd_emb(c, 2, o["pano_embeds"], t["pano_embeds"], "kdl_img_w", Np * V, Np, wp, rw[1], c.d_pano, dyn=("img_emb", "Np", None))
+                    self._kd_emb(c, 3, o["pano_fused_embeds"], t["pano_fused_embeds"], "kdl_avg_img_w", Np, Np, wp, rw[1], c.d_fused, dyn=("img_fused", "Np", None))
                 if att:
                     ldp = c.pano.ldp
                     g_img = n.new(Np, V, ldp, dtype=torch.float32) if train else None
-                    c.kd_mse.append(dict(s=o["img_attns"], t=t["img_attns"], outer=Np, inner=V * ldp, s_stride=V * ldp, t_stride=V * ldp, w=wp, rows_per_w=1,
-                                         norm=1.0 / (Np * V * V), coef=rw[1][0], coef_dev=rw[1][1], loss=c.slots[4:5], ds=g_img, g_stride=V * ldp))
+                    q = dict(s=o["img_attns"], t=t["img_attns"], outer=Np, inner=V * ldp, s_stride=V * ldp, t_stride=V * ldp, w=wp, rows_per_w=1,
+                             norm=1.0 / (Np * V * V), coef=rw[1][0], coef_dev=rw[1][1], loss=c.slots[4:5], ds=g_img, g_stride=V * ldp)
+                    q.update(self._dyn(c, "img_attn", lambda tr, V=V, ldp=ldp: (tr["Np"], V * ldp, 1.0 / (tr["Np"] * V * V))))
+                    c.kd_mse.append(q)
             if "global" in tasks and task != "mrc":
                 if task == "mlm":
-                    x, Pm, Nq, Nk, ldp, d_acc = c.l2v.out, c.l2v.P, L, K, c.l2v.ldp, c.d_x
+                    x, Pm, Nq, Nk, ldp, d_acc, qk, kk = c.l2v.out, c.l2v.P, L, K, c.l2v.ldp, c.d_x, "L", "K"
                 else:
-                    x, Pm, Nq, Nk, ldp, d_acc = c.glob.out, c.glob.P, K, L, c.glob.ldp, c.d_gmap
+                    x, Pm, Nq, Nk, ldp, d_acc, qk, kk = c.glob.out, c.glob.P, K, L, c.glob.ldp, c.d_gmap, "K", "L"
                 if emb:
-                    self._kd_emb(c, 5, x, t["gmap_embeds"], "global_cross_w", B * Nq, B, w, rw[2], d_acc)
+                    self._kd_emb(c, 5, x, t["gmap_embeds"], "global_cross_w", B * Nq, B, w, rw[2], d_acc, dyn=("g_emb", None, qk))
                 if att:
-                    c.dP_g = self._kd_attn(c, 6, Pm, t["gmap_attns"], B, Nq, Nk, ldp, nh_s, nh_t, w, rw[2])
+                    c.dP_g = self._kd_attn(c, 6, Pm, t["gmap_attns"], B, Nq, Nk, ldp, nh_s, nh_t, w, rw[2], dyn=("g_attn", qk, kk))
             if "local" in tasks and task != "mlm":
                 if emb:
-                    self._kd_emb(c, 7, c.loc.out, t["vp_embeds"], "local_cross_w", B * Vp, B, w, rw[3], c.d_vp)
+                    self._kd_emb(c, 7, c.loc.out, t["vp_embeds"], "local_cross_w", B * Vp, B, w, rw[3], c.d_vp, dyn=("l_emb", None, None))
                 if att:
-                    c.dP_l = self._kd_attn(c, 8, c.loc.P, t["vp_attns"], B, Vp, L, c.loc.ldp, nh_s, nh_t, w, rw[3])
+                    c.dP_l = self._kd_attn(c, 8, c.loc.P, t["vp_attns"], B, Vp, L, c.loc.ldp, nh_s, nh_t, w, rw[3], dyn=("l_attn", None, "L"))
             self._kd_flush(c)
             if "img" in tasks and att and train:
                 c.dP_pano = n.new(Np, nh_s, V, c.pano.ldp, dtype=torch.float32)

@@ -599,7 +599,8 @@ def mse_multi(problems):
             g_f32 = 1 if (s_.dtype == torch.float32 or (ds is not None and ds.dtype == torch.float32)) else 0
             arr[j] = L.MseDesc(g_f32, q["outer"], q["inner"], L.P(s_), q["s_stride"], L.P(t_), q["t_stride"], L.P(q.get("w")),
                                q.get("rows_per_w", 1), float(q.get("norm", 1.0)), float(q.get("coef", 0.0)), L.P(q.get("coef_dev")),
-                               L.P(q.get("loss")), L.P(ds), q.get("g_stride", 0), 1 if q.get("accumulate") else 0)
+                               L.P(q.get("loss")), L.P(ds), q.get("g_stride", 0), 1 if q.get("accumulate") else 0,
+                               L.P(q.get("valid_dev")), L.P(q.get("norm_dev")), int(q.get("valid_mod", 0)))
         L.call("magic_mse_multi", L.dt(dt0), len(chunk), arr, L.stream())
         i += len(chunk)
 

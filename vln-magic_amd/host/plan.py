@@ -73,8 +73,21 @@ def plan_to_device(hp, device):
     return plan
 
 
-def build_plan_host(batch, task, ld_round=8):
-    """the CPU-only half: numpy / CPU tensors + scalars, picklable (DataLoader workers can build it next to the collate)"""
+def _pad_csr(pair, cap):
+    """pad the idx / w arrays of a (forward, transposed) CSR pair to `cap` entries: the ptr arrays never reach the padding"""
+    out = []
+    for ptr, idx, w in pair:
+        n = len(idx)
+        if n > cap:
+            raise ValueError(f"CSR with {n} entries does not fit its bucket capacity {cap}")
+        out.append((ptr, np.concatenate([idx, np.zeros(cap - n, np.int32)]) if n < cap else idx,
+                    np.concatenate([w, np.zeros(cap - n, np.float32)]) if n < cap else w))
+    return tuple(out)
+
+
+def build_plan_host(batch, task, ld_round=8, pad=None):
+    """the CPU-only half: numpy / CPU tensors + scalars, picklable (DataLoader workers can build it next to the collate).
+    pad: (bucket, true sizes) of a batch padded by bucket.pad_batch -- every array then depends on the bucket only."""
     B = len(batch["traj_step_lens"])
     L = batch["txt_ids"].shape[1]
     K = batch["gmap_step_ids"].shape[1]
@@ -85,11 +98,13 @@ def build_plan_host(batch, task, ld_round=8):
     Vp = int(batch["vp_pos_fts"].shape[1])
     step_lens = batch["traj_step_lens"]
     Np = int(sum(step_lens))
+    if pad is not None:
+        Np = int(pad[0]["Np"])                 # dummy panoramas at the end: no CSR entry ever points at them
     cpu = {}
     cpu["txt_ids"] = batch["txt_ids"].reshape(-1).to(torch.int32)
     # rows of the word-embedding table this batch reads (pad id included: padded positions are embedded too) -- on steps whose only
     # use of the table is this lookup they are the only rows with gradient: trainer.GradSync exchanges them instead of the dense table
-    cpu["emb_rows"] = torch.unique(batch["txt_ids"]).to(torch.int64)
+    cpu["emb_rows"] = torch.unique(batch["txt_ids"]).to(torch.int64) if pad is None else torch.zeros(0, dtype=torch.int64)
     txt_lens = batch["txt_lens"]
     cpu["txt_mask"] = (torch.arange(L)[None] < txt_lens[:, None]).to(torch.uint8)
     view_lens = batch["traj_vp_view_lens"]
@@ -163,8 +178,11 @@ def build_plan_host(batch, task, ld_round=8):
         lab = batch["txt_labels"].reshape(-1)
         sel = torch.nonzero(lab != -1).reshape(-1)
         n_mask = int(sel.numel())
-        plan_csr["mlm_rows"] = csr_pair([(i, int(r), 1.0) for i, r in enumerate(sel.tolist())], n_mask, B * L)
-        cpu["mlm_labels"] = lab[sel].to(torch.int32)
+        nm_rows = n_mask if pad is None else int(pad[0]["n_mask"])      # padded rows: no source row, label -1 (ignored by the loss kernel)
+        plan_csr["mlm_rows"] = csr_pair([(i, int(r), 1.0) for i, r in enumerate(sel.tolist())], nm_rows, B * L)
+        cpu["mlm_labels"] = torch.cat([lab[sel].to(torch.int32), torch.full((nm_rows - n_mask,), -1, dtype=torch.int32)])
+        if pad is not None:
+            cpu["mlm_row_w"] = torch.full((nm_rows,), 1.0 / max(n_mask, 1), dtype=torch.float32)      # the loss's 1 / n_mask, per row
 
     n_mrc = 0
     if task == "mrc":       # masked views of the current viewpoint: row b*Vp + 1 + v of the local encoder output ([stop] at 0)
@@ -174,6 +192,13 @@ def build_plan_host(batch, task, ld_round=8):
         plan_csr["mrc_rows"] = csr_pair([(i, int(b_) * Vp + 1 + int(v_), 1.0) for i, (b_, v_) in enumerate(sel.tolist())], n_mrc, B * Vp)
         cpu["mrc_targets"] = batch["vp_view_probs"][mm].float().contiguous()
 
+    if pad is not None:
+        if task == "mrc":
+            raise NotImplementedError("shape buckets: mrc is not in the shipped task list and has no bucketed plan")
+        caps = dict(gmap_from_embed=Np * V, gmap_from_fused=B * K, mlm_rows=int(pad[0]["n_mask"]))
+        for name, cap in caps.items():
+            if name in plan_csr:
+                plan_csr[name] = _pad_csr(plan_csr[name], cap)
     meta = {}
     # value ranges of everything the kernels use as a table index, taken on the host copies (the device never bounds-checks:
     # an out-of-range id would be an out-of-bounds read on the GPU) -- validated against the model config by check_plan()
@@ -184,6 +209,10 @@ def build_plan_host(batch, task, ld_round=8):
                 n_mask=(int(cpu["mlm_labels"].numel()) if task == "mlm" else 0), n_mrc=n_mrc,
                 txt_tokens=int(txt_lens.sum()), gmap_nodes=int(batch["gmap_lens"].sum()), traj_steps=Np,
                 lens=dict(txt=txt_lens.tolist(), gmap=batch["gmap_lens"].tolist(), steps=list(step_lens)))
+    if pad is not None:
+        meta["traj_steps"] = int(sum(step_lens))
+        meta["true"] = dict(pad[1])
+        meta["bucket"] = dict(pad[0])
     return dict(cpu=cpu, csr=plan_csr, meta=meta)
 
 

@@ -102,15 +102,15 @@ class _StreamSet(torch.utils.data.IterableDataset):
     generation of 30 MB of random features is not part of what is measured) and, per batch, runs the collate
     (`synth.collate`, pinned to tasks.py's) and the host half of the index plan -- the per-batch CPU work of a real loader."""
 
-    def __init__(self, batch_size, seed, n_steps, pool=3, n_vp=0):
-        self.batch_size, self.seed, self.n_steps, self.pool, self.n_vp = batch_size, seed, n_steps, pool, n_vp
+    def __init__(self, batch_size, seed, n_steps, pool=3, n_vp=0, bucketed=False):
+        self.batch_size, self.seed, self.n_steps, self.pool, self.n_vp, self.bucketed = batch_size, seed, n_steps, pool, n_vp, bucketed
 
     def __iter__(self):
         import random
 
         import numpy as np
 
-        from magic_amd.host.loader import pack
+        from magic_amd.host.loader import pack, pack_bucketed
         from magic_amd.host.plan import build_plan_host
         info = torch.utils.data.get_worker_info()
         wid, nw = (info.id, info.num_workers) if info is not None else (0, 1)
@@ -123,7 +123,12 @@ class _StreamSet(torch.utils.data.IterableDataset):
         for step in range(wid, self.n_steps, nw):
             task = TASKS[step % 3]
             rng = np.random.default_rng([self.seed, step])
-            batch = synth.collate(pools[(step // nw) % self.pool], task, rng=rng, vocab=50265)
+            if self.bucketed:     # ragged like a shuffled dataset: every batch is a fresh draw of samples, so sum T / K / the longest instruction vary
+                flat = [x for pl in pools for x in pl]
+                samples = [flat[i] for i in rng.choice(len(flat), self.batch_size, replace=False)]
+            else:
+                samples = pools[(step // nw) % self.pool]
+            batch = synth.collate(samples, task, rng=rng, vocab=50265)
             if self.n_vp:       # index-only batch: table row + view order per panorama instead of the features
                 Np, V = batch.pop("traj_view_img_fts").shape[:2]
                 order = np.full((Np, V), -1, np.int32)
@@ -131,7 +136,7 @@ class _StreamSet(torch.utils.data.IterableDataset):
                     order[p_, :n_] = rng.permutation(36)[:n_] if n_ <= 36 else np.concatenate([rng.permutation(36), rng.integers(0, 36, n_ - 36)])
                 batch["traj_vp_row"] = torch.from_numpy(rng.integers(0, self.n_vp, Np).astype(np.int32))
                 batch["traj_view_order"] = torch.from_numpy(order)
-            yield task, pack(batch, build_plan_host(batch, task))
+            yield task, (pack_bucketed(batch, task) if self.bucketed else pack(batch, build_plan_host(batch, task)))
 
 
 def ingest_rate(dev, n_vp=4096, n_pano=290, reps=40):
@@ -314,6 +319,17 @@ def secondary_block():
                          "mode": j["mode"], "workload": j["config"]["workload"], "per_gpu_batch": j["config"]["per_gpu_batch"]}
         except Exception as e:          # noqa: BLE001 - the headline line must still print
             out[name] = {"error": repr(e)[:300]}
+    # SURVEY f-3: the same pretraining step fed from DataLoader workers (NON-resident batches, PCIe-inclusive; never `value`): batches padded to
+    # shape buckets, one graph replay per step (host/stream_graph.py)
+    try:
+        r = subprocess.run([py, os.path.join(ROOT, "bench.py"), "--mode", "stream-graph", "--workers", "14", "--warmup", "150", "--steps", "100",
+                            "--no-cpu-baseline", "--no-parity", "--no-secondary"], capture_output=True, text=True, timeout=300, env=env)
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        out["streamed_batches_graph_replay"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                                                "launch": j["launch"], "note": "collate + index plan in 14 DataLoader workers, feature table in HBM, "
+                                                "one H2D record copy + one graph launch per step; the resident-batch headline is `value`"}
+    except Exception as e:              # noqa: BLE001
+        out["streamed_batches_graph_replay"] = {"error": repr(e)[:300]}
     return out
 
 
@@ -330,10 +346,12 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity leg and the fp32-mode timing")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short config-3 / config-5 samples (bench_nav.py children)")
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "stream"],
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager", "stream", "stream-graph"],
                     help="graph: replay one captured HIP graph per resident batch (the headline line); eager: same batches, launches issued "
                          "one by one; stream: NON-resident batches -- collate + index plan built in DataLoader worker processes, pinned, "
-                         "copied one batch ahead on a copy stream (host/loader.py), eager launches: the PCIe-inclusive rate")
+                         "copied one batch ahead on a copy stream (host/loader.py), eager launches: the PCIe-inclusive rate; stream-graph: the same "
+                         "feed, batches padded to shape buckets and every step ONE graph replay (host/stream_graph.py; the first batch of a bucket "
+                         "pays its capture: use a warm-up that has seen the buckets, e.g. --warmup 150 --steps 150)")
     ap.add_argument("--workers", type=int, default=8, help="--mode stream: DataLoader worker processes (r2r_magic_pretrain.json:26 n_workers)")
     ap.add_argument("--ingest", default="table", choices=["table", "host"],
                     help="--mode stream: 'host' = the reference's way, every batch carries its fp32 view features (30 MB at B=48) from the "
@@ -369,7 +387,7 @@ def main():
 
     # synthetic batches, resident in HBM before the timed region (per-rank stream: seed 1234 + rank)
     pool = []
-    for i in range(a.pool if a.mode != "stream" else 3):
+    for i in range(a.pool if a.mode not in ("stream", "stream-graph") else 3):
         task = TASKS[i % 3]
         b = synth.make_batch(task, batch_size=a.batch, seed=1234 + rank, step=i)
         plan = build_plan(b, task, dev)
@@ -397,7 +415,7 @@ def main():
         return run_graph
 
     run_eager = eager_runner(trainer)
-    if a.mode == "stream":
+    if a.mode in ("stream", "stream-graph"):
         a.no_profile = True
     if a.mode == "graph":
         run_eager(min(3, len(pool)))                       # allocator + code-object warm-up
@@ -407,27 +425,43 @@ def main():
         run = graph_runner(trainer, graphs)
     else:
         run = run_eager
-    if a.mode == "stream":
+    stream_step = None
+    if a.mode in ("stream", "stream-graph"):
         from magic_amd.host.loader import DevicePrefetcher
         n_vp = 4096
-        ds = _StreamSet(a.batch, 1234 + rank, a.warmup + a.steps + 2, n_vp=n_vp if a.ingest == "table" else 0)
+        ds = _StreamSet(a.batch, 1234 + rank, a.warmup + a.steps + 2, n_vp=n_vp if a.ingest == "table" else 0, bucketed=a.mode == "stream-graph")
         ftab = None
         if a.ingest == "table":
             from magic_amd.host.feature_table import FeatureTable
             ftab = FeatureTable([str(i) for i in range(n_vp)],
                                 torch.randn(n_vp, 36, 768, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).to(dev))
         dl = torch.utils.data.DataLoader(ds, batch_size=None, num_workers=a.workers, pin_memory=True, prefetch_factor=2, persistent_workers=False)
-        feed = iter(DevicePrefetcher(dl, dev))
+        if a.mode == "stream-graph":
+            from magic_amd.host.stream_graph import StreamStep
+            run_eager(3)                                       # allocator + code-object warm-up before the first capture
+            torch.cuda.synchronize()
+            stream_step = StreamStep(trainer, feature_table=ftab)
+            feed = iter(dl)
 
-        def run_stream(n, start=0):
-            traj = 0
-            for _ in range(n):
-                task, b, plan = next(feed)
-                if ftab is not None:
-                    b["view_table"] = ftab
-                trainer.step(b, task, plan=plan)
-                traj += plan["traj_steps"]
-            return traj
+            def run_stream(n, start=0):
+                traj = 0
+                for _ in range(n):
+                    task, rec = next(feed)
+                    _, meta = stream_step.step(task, rec)
+                    traj += meta["traj_steps"]
+                return traj
+        else:
+            feed = iter(DevicePrefetcher(dl, dev))
+
+            def run_stream(n, start=0):
+                traj = 0
+                for _ in range(n):
+                    task, b, plan = next(feed)
+                    if ftab is not None:
+                        b["view_table"] = ftab
+                    trainer.step(b, task, plan=plan)
+                    traj += plan["traj_steps"]
+                return traj
         run = run_stream
     traj, dt = timed_region(run, a.steps, a.warmup, world, dev)
 
@@ -523,7 +557,7 @@ def main():
         info = {"metric": "trajectory-steps/sec (whole node), MAGIC-S R2R pretrain", "value": round(traj / dt, 2),
                 "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": a.dtype, "data": "synthetic", "launch": a.mode if a.mode != "stream" else f"stream/{a.ingest}/{a.workers}w",
+                "dtype": a.dtype, "data": "synthetic", "launch": a.mode if a.mode not in ("stream", "stream-graph") else f"{a.mode}/{a.ingest}/{a.workers}w" + (f"/{stream_step.captures} bucket graphs" if stream_step is not None else ""),
                 "teacher_schedule": ({"split": "one batch ahead of the student, own graph on a side stream", "ahead": "one batch ahead of the student (fork/join inside the step graph)"}.get(a.teacher, "same batch, side stream") if a.mode == "graph" else "same batch, side stream"),
                 "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "
                                        "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip, student in train() mode",

@@ -46,5 +46,12 @@ def test_bucketed_graph_step_equals_the_exact_eager_step():
             assert _close(outB["kdl_terms"][k], v, 5e-3) or abs(float(v)) < 1e-7, (task, step, k, float(outB["kdl_terms"][k]), float(v))
         wa, wb = sA.store.flat, sB.store.flat
         rel = ((wa - wb).norm() / wa.norm()).item()
+        worst = max(abs(float(outB["kdl_terms"][k]) - float(v)) / max(abs(float(v)), 1e-9) for k, v in outA["kdl_terms"].items() if abs(float(v)) > 1e-7)
+        print(f"{task} step {step}: loss {float(outA['loss']):.6f} vs {float(outB['loss']):.6f}, worst distillation term rel. diff {worst:.1e}, weights rel. diff {rel:.1e}, "
+              f"true sizes {meta['true']} in bucket {meta['bucket']}")
         assert rel < 2e-5, (task, step, rel)
+        # the Adam first moment is a running mean of the (clipped) gradients: it compares the two backward passes far more sharply than the weights
+        ma, mb = sA.store.m, sB.store.m
+        mrel = ((ma - mb).norm() / ma.norm()).item()
+        assert mrel < 2e-2 and torch.nn.functional.cosine_similarity(ma, mb, dim=0).item() > 0.9998, (task, step, mrel)
     assert len(seen) < 7 or ss.captures <= 7

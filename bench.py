@@ -441,13 +441,16 @@ def main():
             run_eager(3)                                       # allocator + code-object warm-up before the first capture
             torch.cuda.synchronize()
             stream_step = StreamStep(trainer, feature_table=ftab)
-            feed = iter(dl)
+            if a.teacher == "same":                            # teacher forward inside the step's graph (one record slot per bucket)
+                feed = iter(dl)
+                steps_gen = (stream_step.step(task, rec) for task, rec in feed)
+            else:                                              # default: teacher one batch ahead on the side stream (two slots per bucket)
+                steps_gen = stream_step.run(dl)
 
             def run_stream(n, start=0):
                 traj = 0
                 for _ in range(n):
-                    task, rec = next(feed)
-                    _, meta = stream_step.step(task, rec)
+                    _, meta = next(steps_gen)
                     traj += meta["traj_steps"]
                 return traj
         else:

@@ -55,3 +55,27 @@ def test_bucketed_graph_step_equals_the_exact_eager_step():
         mrel = ((ma - mb).norm() / ma.norm()).item()
         assert mrel < 2e-2 and torch.nn.functional.cosine_similarity(ma, mb, dim=0).item() > 0.9998, (task, step, mrel)
     assert len(seen) < 7 or ss.captures <= 7
+
+
+def test_teacher_one_batch_ahead_on_streamed_records_equals_the_exact_eager_steps():
+    """StreamStep.run: split teacher / student graphs, two record slots per bucket, the teacher's forward for batch i+1 under the student's step on
+    batch i -- same losses as stepping eagerly through the exact batches"""
+    _, _, _, sA, tA = bench.build_models(torch.bfloat16, DEV, 0.0, 1, 16)
+    _, _, _, sB, tB = bench.build_models(torch.bfloat16, DEV, 0.0, 1, 16)
+    rw = torch.tensor(RW, dtype=torch.float32, device=DEV)
+    ss = StreamStep(tB, rw=rw)
+    sched = [("sap", 0), ("sap", 3), ("mlm", 1), ("cfp", 2), ("sap", 6), ("mlm", 4), ("cfp", 5), ("cfp", 2)]
+    batches = [synth.make_batch(task, batch_size=16, seed=4242, step=step) for task, step in sched]
+    feed = ((task, pack_bucketed(b, task)) for (task, _), b in zip(sched, batches))
+    got = []
+    for out, meta in ss.run(feed):
+        torch.cuda.synchronize()
+        got.append({k: float(out[k]) for k in ("loss", "supervised_loss", "kdl_loss")})
+    assert len(got) == len(sched)
+    for (task, step), b, g in zip(sched, batches, got):
+        outA = tA.step(synth.batch_to(b, DEV), task, rw=rw, plan=build_plan(b, task, DEV))
+        for k in ("loss", "supervised_loss", "kdl_loss"):
+            assert _close(g[k], outA[k], 2e-3), (task, step, k, g[k], float(outA[k]))
+    ma, mb = sA.store.m, sB.store.m
+    assert torch.nn.functional.cosine_similarity(ma, mb, dim=0).item() > 0.9995
+    assert ((sA.store.flat - sB.store.flat).norm() / sA.store.flat.norm()).item() < 2e-5

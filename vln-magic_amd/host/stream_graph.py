@@ -86,3 +86,97 @@ class StreamStep:
         out = self.tr.replay(e.cs)
         e.traj_steps = meta["traj_steps"]
         return out, meta
+
+    # ---- teacher one batch ahead (the resident-batch headline's schedule) -------------------------------------------------------------
+    # Per (task, bucket, slot) -- slot = step parity, so that two consecutive batches of one bucket never share buffers -- TWO graphs over the
+    # slot's static record buffer: T = the frozen teacher's forward (side stream), S = the student's step against T's static outputs (main
+    # stream).  While S_i trains on batch i, T_{i+1} already runs on batch i+1, which needs the NEXT record one step early: `run` drives
+    # an iterable of (task, record) and yields one (out, meta) per step.
+    def _capture_split(self, key, task, rec, parsed):
+        tr = self.tr
+        e = _Entry()
+        e.dbuf = torch.empty(int(rec["buf"].numel()), dtype=torch.uint8, device=self.dev)
+        e.batch, e.plan = unpack(rec, self.dev, dbuf=e.dbuf, parsed=parsed)
+        nt = len(DYN_TERMS)
+        e.ring = [(torch.zeros(2 * nt, dtype=torch.int32).pin_memory(), torch.zeros(nt, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+                  for _ in range(4)]
+        e.turn, e.keep = 0, [None] * 4
+        e.plan["dyn"] = dict(i=torch.zeros(2 * nt, dtype=torch.int32, device=self.dev), f=torch.zeros(nt, dtype=torch.float32, device=self.dev), fill={})
+        if self.ftab is not None:
+            e.batch["view_table"] = self.ftab
+        torch.cuda.synchronize()
+        e.gT = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(e.gT, stream=tr.side, capture_error_mode="relaxed"):
+            e.t_out = tr.teacher_forward(e.batch, task, e.plan)
+        e.gS = torch.cuda.CUDAGraph()
+        with tr._graph_ctx(e.gS):
+            rw = self.rw if self.rw is not None else tr.mkrw()
+            tr.student.store.zero_grad()
+            e.out = tr.student(e.batch, task, compute_loss=True, teacher_outputs=e.t_out, rw=rw, plan=e.plan, inputs=e.t_out["inputs"])
+            tr.student.backward()
+            tr._optimize()
+        e.fill = [(DYN_TERMS.index(t), fn) for t, fn in e.plan["dyn"]["fill"].items()]
+        e.t_done, e.loaded = torch.cuda.Event(), torch.cuda.Event()
+        self.cache[key] = e
+        self.captures += 1
+        return e
+
+    def _stage(self, item, slot):
+        """record -> its (bucket, slot) entry: copy + per-batch scalars on the main stream, then the teacher's forward on the side stream"""
+        task, rec = item
+        parsed = pickle.loads(rec["blob"])
+        manifest, meta = parsed
+        if "true" not in meta:
+            raise ValueError("StreamStep needs bucket-padded records (PlanCollate(..., bucket={...}) / loader.pack_bucketed)")
+        check_plan(dict(limits=meta["limits"], L=meta["L"], V=meta["V"]), self.tr.student.config)
+        key = self._key(task, manifest) + (("slot", slot),)
+        e = self.cache.get(key)
+        if e is None:
+            e = self._capture_split(key, task, rec, parsed)
+        else:
+            buf = rec["buf"]
+            if not buf.is_pinned():
+                buf = buf.pin_memory()
+            e.dbuf.copy_(buf, non_blocking=True)
+            e.keep[e.turn] = buf
+        host_i, host_f, ev = e.ring[e.turn]
+        ev.synchronize()
+        for i, fn in e.fill:
+            vo, vi, norm = fn(meta["true"])
+            host_i[2 * i], host_i[2 * i + 1], host_f[i] = int(vo), int(vi), float(norm)
+        e.plan["dyn"]["i"].copy_(host_i, non_blocking=True)
+        e.plan["dyn"]["f"].copy_(host_f, non_blocking=True)
+        ev.record()
+        e.turn = (e.turn + 1) % len(e.ring)
+        main = torch.cuda.current_stream()
+        e.loaded.record(main)                  # after every earlier student step on the main stream (incl. the last user of this slot's buffers)
+        side = self.tr.side
+        side.wait_event(e.loaded)
+        with torch.cuda.stream(side):
+            e.gT.replay()
+            e.t_done.record(side)
+        return e, meta
+
+    def run(self, feed):
+        """generator over (task, record) pairs: yields (out, meta) per training step, teacher one batch ahead on the side stream"""
+        if self.tr.side is None or self.tr.teacher is None:
+            raise RuntimeError("StreamStep.run needs the trainer's teacher side stream (use step() otherwise)")
+        it = iter(feed)
+        try:
+            cur = self._stage(next(it), 0)
+        except StopIteration:
+            return
+        i = 0
+        while cur is not None:
+            try:
+                nxt = self._stage(next(it), (i + 1) % 2)      # T_{i+1} goes out before S_i: it fills the gaps of the whole student step
+            except StopIteration:
+                nxt = None
+            e, meta = cur
+            main = torch.cuda.current_stream()
+            main.wait_event(e.t_done)
+            e.gS.replay()
+            self.tr.global_step += 1
+            yield e.out, meta
+            cur = nxt
+            i += 1

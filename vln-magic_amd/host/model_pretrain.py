@@ -391,15 +391,32 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         kd = t is not None and kdl is not None
         alpha = float(kdl["kd_alpha"]) if kd else 0.0
         sc = 1.0 - alpha
-        c.slots = n.zeros(16, dtype=torch.float32)
-        zz = (lambda *s: n.zeros(*s)) if train else (lambda *s: None)
+        # every zero-initialised gradient accumulator of the step comes out of ONE zeroed arena per dtype (two fills instead of ~12 tiny ones)
+        nm_ = plan["n_mask"] if task == "mlm" else 0
+        f32 = n.zeros(16 + nm_ * H, dtype=torch.float32)
+        c.slots, c.d_hm32 = f32[:16], (f32[16:].view(nm_, H) if nm_ else None)
+        if train:
+            rows = [B * L, plan["Np"] * plan["V"], plan["Np"]]                               # d_txt, d_pano, d_fused
+            rows += {"sap": [B * K, B * Vp, B * L], "cfp": [B * K, B * Vp, B * L, B, B, B], "mlm": [B * L, B * K], "mrc": [B * Vp]}[task]
+            arena = n.zeros(sum(rows) * H)
+            offs = [0]
+            for r in rows:
+                offs.append(offs[-1] + r * H)
+            pool = [arena[offs[i]:offs[i + 1]].view(rows[i], H) for i in range(len(rows))]
+
+            def zz(*shape):
+                t = pool.pop(0)
+                assert tuple(t.shape) == tuple(shape), (tuple(t.shape), shape)
+                return t
+        else:
+            zz = lambda *s: None
         c.d_txt, c.d_pano, c.d_fused = zz(B * L, H), zz(plan["Np"] * plan["V"], H), zz(plan["Np"], H)
         c.dP_txt = c.dP_pano = c.dP_g = c.dP_l = None
         c.kd_emb, c.kd_mse = [], []
         res = {}
         # ---- supervised ------------------------------------------------------------------------------
         if task == "sap":
-            c.d_gmap, c.d_vp = zz(B * K, H), zz(B * Vp, H)
+            c.d_gmap, c.d_vp, c.d_txt2 = zz(B * K, H), zz(B * Vp, H), zz(B * L, H)
             c.rows = n.new(3, B, dtype=torch.float32)
             c.dgl, c.dll, c.dfl = (n.new(B, K, dtype=torch.float32), n.new(B, Vp, dtype=torch.float32), n.new(B, K, dtype=torch.float32)) \
                 if train else (None, None, None)
@@ -409,7 +426,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             O.ce_rows(c.fl, B, K, K, ga, coef=sc / B, loss_row=c.rows[2], dlogits=c.dfl, ldd=K)
             sup = c.rows.sum() / B
         elif task == "mlm":
-            c.d_x = zz(B * L, H)
+            c.d_x, c.d_gin0 = zz(B * L, H), zz(B * K, H)
             nm = plan["n_mask"]
             c.rows = n.new(nm, dtype=torch.float32)
             c.dlogits = (n.new(nm, c.ldv) if self.keep_mlm_logits else c.logits) if train else None
@@ -427,7 +444,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             O.softkl_rows(c.mlogits, nm, Pn, Pn, plan["mrc_targets"], coef=sc / nm, loss_row=c.rows, dlogits=c.dmlogits, ldd=Pn)
             sup = c.rows.sum() / nm
         else:
-            c.d_gmap, c.d_vp = zz(B * K, H), zz(B * Vp, H)
+            c.d_gmap, c.d_vp, c.d_txt2 = zz(B * K, H), zz(B * Vp, H), zz(B * L, H)
+            c.d_cls0 = (zz(B, H), zz(B, H), zz(B, H))
             temp = float(cfg_get(cfg, "cfp_temperature"))
             c.rows = n.new(6, B, dtype=torch.float32)
             txt_o = c.cfp[3]
@@ -584,7 +602,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 else:
                     O.gemm(2, e1, a, d_outs[3], B, H, B, lds, H, H, alpha=it, residual=d_outs[3], ldr=H)
                 O.gemm(1, e2, a, d_outs[3], B, H, B, lds, H, H, alpha=it, residual=d_outs[3], ldr=H)
-            d_g0, d_v0, d_t0 = n.zeros(B, H), n.zeros(B, H), n.zeros(B, H)
+            d_g0, d_v0, d_t0 = c.d_cls0
             for (key, src, dsts), d_o in zip((("gmap", c.g0, (d_g0,)), ("vp", c.v0, (d_v0,)), ("fused", c.gv0, (d_g0, d_v0)), ("txt", c.t0, (d_t0,))), d_outs):
                 hl = n.lin(f"cfp_heads.{key}.weight")
                 O.linear_dw(d_o, src, hl.dW, hl.db, B)
@@ -600,7 +618,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             O.linear_dw(dlog, c.hm, self.store.g("bert.embeddings.word_embeddings.weight"), self.store.g("mlm_head.predictions.bias"),
                         nm, N=Vv, K=H, lda=c.ldv)
             # dx over the 50k-wide vocabulary: split-K into an fp32 accumulator (18 output tiles alone cannot fill 256 CUs)
-            d_hm32 = n.zeros(nm, H, dtype=torch.float32)
+            d_hm32 = c.d_hm32
             O.gemm(1, dlog, Wemb, d_hm32, nm, H, Vv, c.ldv, H, H, splitk=32, accumulate=True)
             d_hm = O.cast_to(d_hm32, self.compute_dtype)
             tn = n.ln("mlm_head.predictions.transform.LayerNorm")
@@ -611,7 +629,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             O.linear_dw(d_tz, c.hm_in, t.dW, t.db, nm)
             d_hin = O.linear_dx(d_tz, t.W, nm)
             O.csr_gather(d_hin, *plan["mlm_rows_T"], c.d_x, B * L, H, accumulate=True)
-            d_gin = n.zeros(B * K, H)
+            d_gin = c.d_gin0
             d_t2 = n.cross_bwd(c.l2v, c.d_x, d_gin, c.dP_g)
             O.add_(c.d_txt, d_t2)
         elif task == "mrc":
@@ -628,7 +646,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             d_vin = n.cross_bwd(c.loc, c.d_vp, c.d_txt, c.dP_l)
             n.vp_in_bwd(c.vin, plan, d_vin, c.d_pano)
         else:
-            d_txt2 = n.zeros(B * L, H)           # the two encoders accumulate their text gradients separately (no race)
+            d_txt2 = c.d_txt2                    # the two encoders accumulate their text gradients separately (no race)
             if n.rbw_ok():                       # both encoders in shared row-block launches (engine.cross_stacks_bwd)
                 d_gin, d_vin = n.cross_stacks_bwd([(c.glob, c.d_gmap, c.d_txt, c.dP_g), (c.loc, c.d_vp, d_txt2, c.dP_l)])
             else:

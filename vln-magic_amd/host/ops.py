@@ -77,14 +77,14 @@ def linear_dx(dy, W, M, *, out=None, epilogue=0, aux=None, residual=None, lda=No
 
 # measured on the headline step (profiles/micro/splitk_sweep.sh): (target, min_tiles) = (256, 2) 3.34 ms, (128, 8) 3.26 ms, (128, 32) 3.45 ms --
 # fewer, longer splits also write 4x fewer fp32 atomic tiles
-SPLITK = {"target": int(os.environ.get("MAGIC_SPLITK_TARGET", "128")), "min_tiles": int(os.environ.get("MAGIC_SPLITK_MIN_TILES", "8"))}
+SPLITK = {"target": int(os.environ.get("MAGIC_SPLITK_TARGET", "192")), "min_tiles": int(os.environ.get("MAGIC_SPLITK_MIN_TILES", "12"))}
 
 
 def _splitk(tiles, kred):
     """split-K factor of the weight-gradient GEMM: every split block adds a full 64x64 fp32 tile with atomics (16 KB), so
     the atomic traffic is tiles*splitk*16 KB whatever the true dW size -- keep the grid near one block per CU and give
     each block at least `min_tiles` 64-deep k-tiles."""
-    if tiles > SPLITK["target"]:
+    if tiles > 128:
         # wide layers (H >= 768): the output alone gives every CU a tile, but a reduction over thousands of rows still wants splitting;
         # measured (profiles/micro/tn_splitk_scan.py, M = 8192): 768x768 141 -> 43 us at 8 splits, 3072x768 170 -> 115 us at 4-8 (then the
         # fp32 atomic traffic of the extra splits takes over)

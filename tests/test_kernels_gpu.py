@@ -681,3 +681,73 @@ def test_cfp_loss_kernel_matches_autograd(dtype, B, H):
     for got, ref, nm in [(d_a[i], a64[i].grad, f"d_a{i}") for i in range(3)] + [(d_txt, t64.grad, "d_txt")]:
         err = (got.double() - ref).abs().max().item()
         assert err <= tol * ref.abs().max().item() + 1e-7, (nm, err, ref.abs().max().item())
+
+
+def test_mse_multi_device_side_extents_match_a_masked_reference():
+    """magic_mse_multi with valid_dev / valid_mod / norm_dev (shape-bucketed batches): only the batch's true extent enters the loss, the gradient
+    outside it is zero, and the normaliser comes from device memory"""
+    from magic_amd.host import ops as O
+    g = torch.Generator().manual_seed(11)
+    B, nh_s, nh_t, Nq, ld, Nq_true, Ht, rows, rows_true, Np, Np_true = 6, 2, 4, 24, 32, 19, 64, 24, 17, 10, 7
+    s_att = torch.rand(B, nh_s, Nq, ld, generator=g).to(DEV).bfloat16()
+    t_att = torch.rand(B, nh_t, Nq, ld, generator=g).to(DEV).bfloat16()
+    s_emb = torch.randn(B, rows, Ht, generator=g).to(DEV).bfloat16()
+    t_emb = torch.randn(B, rows, Ht, generator=g).to(DEV).bfloat16()
+    s_out = torch.randn(Np, 5 * Ht, generator=g).to(DEV).bfloat16()
+    t_out = torch.randn(Np, 5 * Ht, generator=g).to(DEV).bfloat16()
+    loss = torch.zeros(3, device=DEV)
+    d_att = torch.full((B, nh_s, Nq, ld), 7.0, device=DEV)                      # fp32 gradient, pre-filled: the kernel must overwrite all of it
+    d_emb = torch.full((B, rows, Ht), 7.0, device=DEV).bfloat16()
+    d_out = torch.full((Np, 5 * Ht), 7.0, device=DEV).bfloat16()
+    hmin = 2
+    vi = torch.tensor([B, Nq_true * ld, B, rows_true * Ht, Np_true, 5 * Ht], dtype=torch.int32, device=DEV)
+    vf = torch.tensor([1.0 / (B * hmin * Nq_true * 20), 1.0 / (B * rows_true * Ht), 1.0 / (Np_true * 5 * Ht)], device=DEV)
+    coef = 0.5
+    O.mse_multi([
+        dict(s=s_att, t=t_att, outer=B, inner=hmin * Nq * ld, s_stride=nh_s * Nq * ld, t_stride=nh_t * Nq * ld, norm=1.0, coef=coef, loss=loss[0:1], ds=d_att,
+             g_stride=nh_s * Nq * ld, valid_dev=vi[0:2], norm_dev=vf[0:1], valid_mod=Nq * ld),
+        dict(s=s_emb, t=t_emb, outer=B, inner=rows * Ht, s_stride=rows * Ht, t_stride=rows * Ht, norm=1.0, coef=coef, loss=loss[1:2], ds=d_emb,
+             g_stride=rows * Ht, valid_dev=vi[2:4], norm_dev=vf[1:2]),
+        dict(s=s_out, t=t_out, outer=Np, inner=5 * Ht, s_stride=5 * Ht, t_stride=5 * Ht, norm=1.0, coef=coef, loss=loss[2:3], ds=d_out,
+             g_stride=5 * Ht, valid_dev=vi[4:6], norm_dev=vf[2:3])])
+    torch.cuda.synchronize()
+    # references
+    da = (s_att.float()[:, :hmin] - t_att.float()[:, :hmin])
+    da[:, :, Nq_true:] = 0
+    assert abs(loss[0].item() - (da ** 2).sum().item() * vf[0].item()) < 1e-4 * max(1.0, loss[0].item())
+    assert torch.allclose(d_att[:, :hmin], 2 * coef * vf[0] * da, rtol=1e-5, atol=1e-8) and (d_att[:, :, Nq_true:] == 0).all()
+    de = (s_emb.float() - t_emb.float())
+    de[:, rows_true:] = 0
+    assert abs(loss[1].item() - (de ** 2).sum().item() * vf[1].item()) < 1e-4 * max(1.0, loss[1].item())
+    assert torch.allclose(d_emb.float(), (2 * coef * vf[1] * de).bfloat16().float(), rtol=1e-2, atol=1e-6) and (d_emb[:, rows_true:] == 0).all()
+    do = (s_out.float() - t_out.float())
+    do[Np_true:] = 0
+    assert abs(loss[2].item() - (do ** 2).sum().item() * vf[2].item()) < 1e-4 * max(1.0, loss[2].item())
+    assert (d_out[Np_true:] == 0).all() and torch.allclose(d_out.float(), (2 * coef * vf[2] * do).bfloat16().float(), rtol=1e-2, atol=1e-6)
+
+
+def test_csr_gather_multi_equals_consecutive_gathers():
+    import numpy as np
+    from magic_amd.host import ops as O
+    from magic_amd.host.plan import csr_pair
+    g = torch.Generator().manual_seed(5)
+    H, n_src, n_out = 128, 90, 40
+    src1 = torch.randn(n_src, H, generator=g).to(DEV).bfloat16()
+    src2 = torch.randn(n_src, H, generator=g).to(DEV).bfloat16()
+    rng = np.random.default_rng(3)
+    def rand_csr(p):
+        ent = [(o, int(s), float(rng.uniform(0.1, 1.0))) for o in range(n_out) for s in rng.choice(n_src, rng.integers(0, 4), replace=False) if rng.uniform() < p]
+        f, _ = csr_pair(ent, n_out, n_src)
+        return tuple(torch.as_tensor(a).to(DEV) for a in f)
+    c1, c2, c3 = rand_csr(0.8), rand_csr(0.5), rand_csr(0.9)
+    base = torch.randn(n_out, H, generator=g).to(DEV).bfloat16()
+    ref_a = base.clone()
+    O.csr_gather(src1, *c1, ref_a, n_out, H, accumulate=True)
+    O.csr_gather(src2, *c2, ref_a, n_out, H, accumulate=True)
+    ref_b = torch.empty(n_out, H, device=DEV, dtype=torch.bfloat16)
+    O.csr_gather(src2, *c3, ref_b, n_out, H)
+    out_a, out_b = base.clone(), torch.full((n_out, H), 3.0, device=DEV).bfloat16()
+    O.csr_gather_multi(H, [dict(out=out_a, n_out=n_out, accumulate=True, src1=src1, csr1=c1, src2=src2, csr2=c2),
+                           dict(out=out_b, n_out=n_out, src1=src2, csr1=c3)])
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, ref_a) and torch.equal(out_b, ref_b)

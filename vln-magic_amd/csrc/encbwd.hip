@@ -307,6 +307,10 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
   copy_out(sY2, XS, sg.dctx + (long long)m0 * EH, EH, nv, EH, tid);
 }
 
+__global__ __launch_bounds__(512, 4) void rowbwd16_kernel(RbwParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
+  rowbwd_body<1>(p, rb_smem);
+}
 __global__ __launch_bounds__(512, 4) void rowbwd32_kernel(RbwParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
   rowbwd_body<2>(p, rb_smem);
@@ -316,10 +320,17 @@ __global__ __launch_bounds__(512, 2) void rowbwd64_kernel(RbwParams p) {
   rowbwd_body<4>(p, rb_smem);
 }
 static size_t rbw_lds_bytes(int rows) { return (size_t)(rows * GS + 5 * rows * XS) * sizeof(bf16) + (size_t)2 * NWAVE * rows * sizeof(float); }
-static int rbw_rows() {
-  static int r = 0;
-  if (!r) { const char* e = getenv("MAGIC_RBW_ROWS"); r = (e && atoi(e) == 64) ? 64 : 32; }      // measured: 32 rows 42.7 us per launch, 64 rows 51.6
+// rows per workgroup: MAGIC_RBW_ROWS = 16 / 32 / 64 forces one shape; default (0) = 16 rows when that still leaves the launch with no more
+// workgroups than CUs (the text stack alone: 3840 rows = 240 workgroups instead of 120 on 256 CUs), else 32 (measured: 64 rows 51.6 us vs 42.7)
+static int rbw_rows_env() {
+  static int r = -1;
+  if (r < 0) { const char* e = getenv("MAGIC_RBW_ROWS"); const int v = e ? atoi(e) : 0; r = (v == 16 || v == 32 || v == 64) ? v : 0; }
   return r;
+}
+static int rbw_ncu() {
+  static int n = 0;
+  if (!n) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); n = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }
+  return n;
 }
 
 extern "C" int magic_rowbwd_supported(int dtype, int H, int I) { return dtype == DT_BF16 && H == EH && I == EI; }
@@ -331,6 +342,9 @@ extern "C" int magic_rowbwd(const void* params, int nbytes, void* stream) {
   memcpy(&p, params, sizeof(p));
   if (p.nseg < 1 || p.nseg > 2 || !drop_args_ok(p.seed, p.p_hidden)) return MAGIC_ERR_ARG;
   int blocks = 0;
+  long long total_rows = 0;
+  for (int s = 0; s < p.nseg; ++s) total_rows += p.seg[s].M > 0 ? p.seg[s].M : 0;
+  const int rows = rbw_rows_env() ? rbw_rows_env() : (total_rows <= 16ll * rbw_ncu() ? 16 : 32);
   for (int s = 0; s < 2; ++s) {
     RbwSeg& sg = p.seg[s];
     if (s >= p.nseg) { sg.M = 0; continue; }
@@ -349,18 +363,20 @@ extern "C" int magic_rowbwd(const void* params, int nbytes, void* stream) {
     const void* al[] = {sg.dqkv_n, sg.WqkvT_n, sg.dao_n, sg.dfo_in, sg.dfod_in, sg.y2, sg.z, sg.W2T, sg.W1T, sg.y1, sg.WoT, sg.dfo, sg.dfod, sg.dz, sg.daod, sg.dao, sg.dctx};
     for (const void* q : al)
       if ((uintptr_t)q & 15) return MAGIC_ERR_ARG;
-    const int nb = (sg.M + rbw_rows() - 1) / rbw_rows();
+    const int nb = (sg.M + rows - 1) / rows;
     if (s == 0) p.blocks0 = nb;
     blocks += nb;
   }
-  const size_t shm = rbw_lds_bytes(rbw_rows());
+  const size_t shm = rbw_lds_bytes(rows);
   static bool attr_set = false;
   if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)rowbwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbw_lds_bytes(16));
     (void)hipFuncSetAttribute((const void*)rowbwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbw_lds_bytes(32));
     (void)hipFuncSetAttribute((const void*)rowbwd64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbw_lds_bytes(64));
     attr_set = true;
   }
-  if (rbw_rows() == 32) hipLaunchKernelGGL(rowbwd32_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+  if (rows == 16) hipLaunchKernelGGL(rowbwd16_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+  else if (rows == 32) hipLaunchKernelGGL(rowbwd32_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(rowbwd64_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
   return launch_status();
 }

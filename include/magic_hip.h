@@ -217,10 +217,12 @@ int magic_sap_fuse_bwd(int B, int K, int Vp, const float* g_raw, const float* l_
 int magic_sumsq(long long n, const float* g, float* out, void* stream);
 int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow_bf16,
                 float lr, float b1, float b2, float eps, float wd, float step_size,
-                const float* sumsq, float max_norm, float gscale, const float* lr_ss, void* stream);
-/* device-side lr schedule + Adam bias correction (optim/sched.py:17-30, adamw.py:97-100) for HIP-graph replay; coef_dev / lr_ss
- * arguments above are optional device scalars multiplied into / replacing the host values */
-int magic_sched_step(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, void* stream);
+                const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, void* stream);
+/* n_decay: elements [0, n_decay) take the weight decay wd, the rest none (both parameter groups of optim/misc.py:13-22 in one launch);
+ * < 0: all.  device-side lr schedule + Adam bias correction (optim/sched.py:17-30, adamw.py:97-100) for HIP-graph replay; coef_dev / lr_ss
+ * arguments above are optional device scalars multiplied into / replacing the host values; zero_me (optional): one float set to 0 (the
+ * gradient-norm accumulator of the step that begins) */
+int magic_sched_step(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, float* zero_me, void* stream);
 int magic_cast(int to_bf16, long long n, const void* x, void* y, void* stream);
 int magic_add(int dtype, long long n, const void* x, void* y, void* stream);
 int magic_dact(int dtype, int kind, long long n, const void* dy, const void* z, void* dz, void* stream);

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(long long n, const float* _
 // the bf16 shadow copy used by the MFMA kernels.
 __global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, const float* g, float* m, float* v, bf16* shadow,
                                                     float lr, float b1, float b2, float eps, float wd, float step_size,
-                                                    const float* sumsq, float max_norm, float gscale, const float* lr_ss) {
+                                                    const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay) {
   if (lr_ss) { lr = lr_ss[0]; step_size = lr_ss[1]; }     // device-side schedule (HIP-graph replay)
   float clip = gscale;
   if (sumsq && max_norm > 0.f) {
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, const
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     float pi = p[i] - step_size * mi / (sqrtf(vi) + eps);
-    if (wd > 0.f) pi -= lr * wd * pi;
+    if (wd > 0.f && i < n_decay) pi -= lr * wd * pi;        // [0, n_decay): the decayed group (optim/misc.py:13-22), the rest: biases / LayerNorm
     m[i] = mi; v[i] = vi; p[i] = pi;
     if (shadow) shadow[i] = (bf16)pi;
   }
@@ -86,10 +86,11 @@ extern "C" int magic_sumsq(long long n, const float* g, float* out, void* stream
 
 extern "C" int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow_bf16,
                            float lr, float b1, float b2, float eps, float wd, float step_size,
-                           const float* sumsq, float max_norm, float gscale, const float* lr_ss, void* stream) {
+                           const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, void* stream) {
   if (n <= 0) return MAGIC_ERR_ARG;
+  if (n_decay < 0) n_decay = n;                    // the whole range is one group
   hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (bf16*)shadow_bf16, lr, b1, b2, eps, wd,
-                     step_size, sumsq, max_norm, gscale, lr_ss);
+                     step_size, sumsq, max_norm, gscale, lr_ss, n_decay);
   return launch_status();
 }
 
@@ -148,8 +149,9 @@ extern "C" int magic_dact(int dtype, int kind, long long n, const void* dy, cons
 
 // Device-side optimizer schedule so a captured HIP graph can be replayed: t = ++step; lr = lr0 * warmup_linear(t-1)
 // (pretrain_src/optim/sched.py:17-30, <=0 -> 1e-8); step_size = lr * sqrt(1-b2^t) / (1-b1^t) (adamw.py:97-100).
-__global__ void sched_step_kernel(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss) {
+__global__ void sched_step_kernel(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, float* zero_me) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (zero_me) zero_me[0] = 0.f;   // the gradient-norm accumulator of the step that starts here (saves a fill launch)
   const int gs = step[0];          // global_step before this optimizer step
   const int t = gs + 1;
   step[0] = t;
@@ -160,9 +162,9 @@ __global__ void sched_step_kernel(int* step, float lr0, int warmup, int total, f
   lr_ss[0] = (float)lr; lr_ss[1] = (float)ss;
 }
 
-extern "C" int magic_sched_step(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, void* stream) {
+extern "C" int magic_sched_step(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, float* zero_me, void* stream) {
   if (!step || !lr_ss || warmup <= 0 || total <= warmup) return MAGIC_ERR_ARG;
-  hipLaunchKernelGGL(sched_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, lr0, warmup, total, b1, b2, lr_ss);
+  hipLaunchKernelGGL(sched_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, lr0, warmup, total, b1, b2, lr_ss, zero_me);
   return launch_status();
 }
 

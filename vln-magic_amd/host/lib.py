@@ -57,8 +57,8 @@ SIGNATURES = {
     "magic_sap_fuse_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
     "magic_sap_fuse_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "magic_sumsq": [i64, vp, vp, vp],
-    "magic_adamw": [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, vp],
-    "magic_sched_step": [vp, f32, i32, i32, f32, f32, vp, vp],
+    "magic_adamw": [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i64, vp],
+    "magic_sched_step": [vp, f32, i32, i32, f32, f32, vp, vp, vp],
     "magic_cast": [i32, i64, vp, vp, vp],
     "magic_add": [i32, i64, vp, vp, vp],
     "magic_dact": [i32, i32, i64, vp, vp, vp, vp],

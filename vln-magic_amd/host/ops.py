@@ -686,13 +686,14 @@ def sumsq(g, out):
     L.call("magic_sumsq", g.numel(), L.P(g), L.P(out), L.stream())
 
 
-def adamw(n, p, g, m, v, shadow, lr, b1, b2, eps, wd, step_size, sumsq_buf, max_norm, gscale, lr_ss=None):
+def adamw(n, p, g, m, v, shadow, lr, b1, b2, eps, wd, step_size, sumsq_buf, max_norm, gscale, lr_ss=None, n_decay=-1):
+    """n_decay: the first n_decay elements take the weight decay, the rest none (-1: all)"""
     L.call("magic_adamw", n, L.P(p), L.P(g), L.P(m), L.P(v), L.P(shadow), float(lr), float(b1), float(b2), float(eps), float(wd),
-           float(step_size), L.P(sumsq_buf), float(max_norm), float(gscale), L.P(lr_ss), L.stream())
+           float(step_size), L.P(sumsq_buf), float(max_norm), float(gscale), L.P(lr_ss), int(n_decay), L.stream())
 
 
-def sched_step(step, lr0, warmup, total, b1, b2, lr_ss):
-    L.call("magic_sched_step", L.P(step), float(lr0), int(warmup), int(total), float(b1), float(b2), L.P(lr_ss), L.stream())
+def sched_step(step, lr0, warmup, total, b1, b2, lr_ss, zero_me=None):
+    L.call("magic_sched_step", L.P(step), float(lr0), int(warmup), int(total), float(b1), float(b2), L.P(lr_ss), L.P(zero_me), L.stream())
 
 
 def cast_to(x, dtype, out=None):

@@ -54,22 +54,20 @@ class FusedAdamW:
         self.t += 1
         b1, b2 = self.betas
         lr_ss = None
-        if self.schedule is not None:
-            O.sched_step(self.step_dev, self.lr, self.schedule[0], self.schedule[1], b1, b2, self.lr_ss)
+        use_clip = self.max_norm is not None and self.max_norm > 0
+        if self.schedule is not None:          # (the schedule kernel also zeroes the gradient-norm accumulator of this step)
+            O.sched_step(self.step_dev, self.lr, self.schedule[0], self.schedule[1], b1, b2, self.lr_ss, zero_me=self.ss if use_clip else None)
             lr_ss, step_size = self.lr_ss, 0.0
         else:
             step_size = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
-        use_clip = self.max_norm is not None and self.max_norm > 0
+            if use_clip:
+                self.ss.zero_()
         if use_clip:
-            self.ss.zero_()
             O.sumsq(s.grad, self.ss)
         shadow = s.shadow if s.compute_dtype == torch.bfloat16 else None
-        nd = s.n_decay
-        for lo, hi, wd in ((0, nd, self.wd), (nd, s.total, 0.0)):
-            if hi > lo:
-                O.adamw(hi - lo, s.flat[lo:hi], s.grad[lo:hi], s.m[lo:hi], s.v[lo:hi], shadow[lo:hi] if shadow is not None else None,
-                        lr, b1, b2, self.eps, wd, step_size, self.ss if use_clip else None, self.max_norm if use_clip else 0.0, gscale,
-                        lr_ss=lr_ss)
+        # both parameter groups (decay | no decay: contiguous in the flat buffer) in ONE launch
+        O.adamw(s.total, s.flat, s.grad, s.m, s.v, shadow, lr, b1, b2, self.eps, self.wd, step_size, self.ss if use_clip else None,
+                self.max_norm if use_clip else 0.0, gscale, lr_ss=lr_ss, n_decay=s.n_decay)
         s.shadow_clean = True
         if shadow is not None and s.t_spans:           # the AdamW kernel rewrote the bf16 shadow: its transposed copy follows
             s.sync_shadow_t(force=True)

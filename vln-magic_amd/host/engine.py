@@ -829,7 +829,8 @@ class MagicNet:
         g, l, H = self.p + "global_encoder.", self.p + "local_encoder.", self.H
         Mg, Mv = plan["B"] * plan["K"], plan["B"] * plan["Vp"]
         O.ln_bwd(Mg, H, d_gin, dx=None, do_ln=False,
-                 dtabs=((plan["gmap_step_ids"], 0, 0, self.S.g(g + "gmap_step_embeddings.weight"), 0), None, None))
+                 dtabs=((plan["gmap_step_ids"], 0, 0, self.S.g(g + "gmap_step_embeddings.weight"), 0), None, None),
+                 hot0=0)          # step id 0 = every unvisited node and every padded map slot (tasks.py:142): reduced per workgroup
         gl_, gn = self.lin(g + "gmap_pos_embeddings.0.weight"), self.ln(g + "gmap_pos_embeddings.1")
         vl_, vn = self.lin(l + "vp_pos_embeddings.0.weight"), self.ln(l + "vp_pos_embeddings.1")
         O.smallk_ln_bwd_pair(H, [dict(M=Mg, Kin=gl_.K, x=gin.pos, dy=d_gin, y=gin.A, gamma=gn.g, beta=gn.b, rstd=gin.rstd, dW=gl_.dW, db=gl_.db,
@@ -844,7 +845,8 @@ class MagicNet:
         g, H = self.p + "global_encoder.", self.H
         M = plan["B"] * plan["K"]
         O.ln_bwd(M, H, d_in, dx=None, do_ln=False,
-                 dtabs=((plan["gmap_step_ids"], 0, 0, self.S.g(g + "gmap_step_embeddings.weight"), 0), None, None))
+                 dtabs=((plan["gmap_step_ids"], 0, 0, self.S.g(g + "gmap_step_embeddings.weight"), 0), None, None),
+                 hot0=0)          # step id 0 = every unvisited node and every padded map slot (tasks.py:142): reduced per workgroup
         pl, pn = self.lin(g + "gmap_pos_embeddings.0.weight"), self.ln(g + "gmap_pos_embeddings.1")
         O.smallk_ln_bwd(M, H, pl.K, c.pos, d_in, c.A, pn.g, pn.b, c.rstd, pl.dW, pl.db, pn.dg, pn.db)
         if d_pano is not None:      # pretrain path: node embeddings were aggregated from the panoramas

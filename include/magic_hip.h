@@ -224,6 +224,8 @@ int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void*
  * gradient-norm accumulator of the step that begins) */
 int magic_sched_step(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, float* zero_me, void* stream);
 int magic_cast(int to_bf16, long long n, const void* x, void* y, void* stream);
+/* y += xs[0] + ... + xs[count-1] (count <= 8 device tensors of n elements, 16-byte aligned): fp32 sum, one rounding */
+int magic_add_n(int dtype, long long n, int count, const void* const* xs, void* y, void* stream);
 int magic_add(int dtype, long long n, const void* x, void* y, void* stream);
 int magic_dact(int dtype, int kind, long long n, const void* dy, const void* z, void* dz, void* stream);
 

@@ -72,6 +72,35 @@ __global__ __launch_bounds__(256) void add_kernel(long long n, const T* x, T* y)
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = from_f<T>(to_f(y[i]) + to_f(x[i]));
 }
 
+// y += x_0 + ... + x_{n-1} (n <= 8 tensors of y's shape): fp32 sum, one rounding.  The key / value input gradients of the cross-modal blocks
+// (3 blocks x 2 encoders, all with respect to the same text rows) are computed side by side into separate buffers and folded here.
+struct AddN { const void* x[8]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256) void add_n_kernel(long long n8, long long n, T* __restrict__ y, AddN a) {
+  constexpr int VE = 16 / (int)sizeof(T);
+  typedef __attribute__((ext_vector_type(VE))) T vec_t;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    vec_t v = *(const vec_t*)(y + i * VE);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = to_f(v[e]);
+    for (int j = 0; j < a.n; ++j) {
+      const vec_t u = *(const vec_t*)((const T*)a.x[j] + i * VE);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[e] += to_f(u[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = from_f<T>(acc[e]);
+    *(vec_t*)(y + i * VE) = v;
+  }
+  if (blockIdx.x == 0)
+    for (long long i = n8 * VE + threadIdx.x; i < n; i += 256) {
+      float acc = to_f(y[i]);
+      for (int j = 0; j < a.n; ++j) acc += to_f(((const T*)a.x[j])[i]);
+      y[i] = from_f<T>(acc);
+    }
+}
+
 static inline int nblocks(long long n, int per) {
   long long b = (n + per - 1) / per;
   return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -109,6 +138,23 @@ extern "C" int magic_add(int dtype, long long n, const void* x, void* y, void* s
   if (n <= 0) return MAGIC_ERR_ARG;
   if (dtype == DT_BF16) hipLaunchKernelGGL(add_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const bf16*)x, (bf16*)y);
   else hipLaunchKernelGGL(add_kernel<float>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const float*)x, (float*)y);
+  return launch_status();
+}
+
+extern "C" int magic_add_n(int dtype, long long n, int count, const void* const* xs, void* y, void* stream) {
+  if (n <= 0 || count < 1 || count > 8 || !xs || !y || ((uintptr_t)y & 15)) return MAGIC_ERR_ARG;
+  AddN a;
+  a.n = count;
+  for (int j = 0; j < 8; ++j) {
+    a.x[j] = j < count ? xs[j] : nullptr;
+    if (j < count && (!xs[j] || ((uintptr_t)xs[j] & 15))) return MAGIC_ERR_ARG;
+  }
+  const int ve = dtype == DT_BF16 ? 8 : 4;
+  const long long n8 = n / ve;
+  const int nb = nblocks(n8 > 0 ? n8 : 1, 256);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(add_n_kernel<bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, n8, n, (bf16*)y, a);
+  else if (dtype == DT_F32) hipLaunchKernelGGL(add_n_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, n8, n, (float*)y, a);
+  else return MAGIC_ERR_ARG;
   return launch_status();
 }
 

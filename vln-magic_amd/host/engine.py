@@ -991,6 +991,7 @@ class MagicNet:
 
         d = self.drop
         seed, ph = (d[0] if d else None), (d[1] if d else 0.0)
+        kvdx = []
         for j in reversed(range(len(st[0].c.layers))):
             segs, act = [], []
             for s in st:
@@ -1026,8 +1027,8 @@ class MagicNet:
                 lc.Ppre, lc.ldp, out.dcctx, lc.q, H, lc.kv, lc.kv[:, H:], 2 * H, out.dq, H, out.dkv, out.dkv[:, H:], 2 * H, lc.Bn, lc.Nq, lc.Nk,
                 None, None, s.dP if top else None, lc.cflops, lc.adrop, lc.P if lc.adrop else None) for s, lc, W, n1, out in act],
                 ok=all(O.attn_supported(self.dtype, lc.Nq, lc.Nk, True) for _, lc, _, _, _ in act) and FUSED_ATTN)
-            self._grouped([lambda s=s, lc=lc, W=W, out=out: O.linear_dx(out.dkv, W.ckv.W, s.Mk, out=s.d_acc, residual=s.d_acc, flop_rows=lc.crow)
-                           for s, lc, W, n1, out in act])
+            for s, lc, W, n1, out in act:          # key / value input gradients: independent of the rest of the chain, launched together below
+                kvdx.append((s.d_acc, out.dkv, W.ckv.W, s.Mk, lc.crow))
             segs = []
             for s, lc, W, n1, out in act:
                 sa = lc.sa
@@ -1054,6 +1055,17 @@ class MagicNet:
                 def dx0(s, lc, W, out):
                     s.dx0 = O.linear_dx(out.dqkv, W.qkv.W, s.M, residual=out.dao, flop_rows=lc.sa.rows)
                 self._grouped([lambda s=s, lc=lc, W=W, out=out: dx0(s, lc, W, out) for s, lc, W, n1, out in act])
+        # every block's d_context = dKV Wkv (all with respect to the same context rows) as ONE grouped launch into separate buffers, then one
+        # fold into the accumulator(s): 2 launches instead of one (paired) accumulating GEMM per block on the chain
+        tmps = [self.new(Mk, H) for _, _, _, Mk, _ in kvdx]
+        for i0 in range(0, len(kvdx), 8):
+            self._grouped([lambda q=q, t=t: O.linear_dx(q[1], q[2], q[3], out=t, flop_rows=q[4]) for q, t in zip(kvdx[i0:i0 + 8], tmps[i0:i0 + 8])])
+        accs = {}
+        for q, t in zip(kvdx, tmps):
+            accs.setdefault(id(q[0]), (q[0], []))[1].append(t)
+        for acc, ts in accs.values():
+            for i0 in range(0, len(ts), 8):
+                O.add_n(acc, ts[i0:i0 + 8])
         return [s.dx0 for s in st]
 
     def cross_bwd(self, c, d_out, d_ctx_acc, dP_init=None, dkv=None):

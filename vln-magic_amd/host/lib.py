@@ -59,6 +59,7 @@ SIGNATURES = {
     "magic_sumsq": [i64, vp, vp, vp],
     "magic_adamw": [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i64, vp],
     "magic_sched_step": [vp, f32, i32, i32, f32, f32, vp, vp, vp],
+    "magic_add_n": [i32, i64, i32, vp, vp, vp],
     "magic_cast": [i32, i64, vp, vp, vp],
     "magic_add": [i32, i64, vp, vp, vp],
     "magic_dact": [i32, i32, i64, vp, vp, vp, vp],

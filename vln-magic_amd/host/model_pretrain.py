@@ -647,12 +647,12 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             n.vp_in_bwd(c.vin, plan, d_vin, c.d_pano)
         else:
             d_txt2 = c.d_txt2                    # the two encoders accumulate their text gradients separately (no race)
-            if n.rbw_ok():                       # both encoders in shared row-block launches (engine.cross_stacks_bwd)
-                d_gin, d_vin = n.cross_stacks_bwd([(c.glob, c.d_gmap, c.d_txt, c.dP_g), (c.loc, c.d_vp, d_txt2, c.dP_l)])
+            if n.rbw_ok():                       # both encoders in shared row-block launches (engine.cross_stacks_bwd); one text accumulator: the
+                d_gin, d_vin = n.cross_stacks_bwd([(c.glob, c.d_gmap, c.d_txt, c.dP_g), (c.loc, c.d_vp, c.d_txt, c.dP_l)])      # six parts fold at the end
             else:
                 d_gin, d_vin = self._par(lambda: n.cross_bwd(c.glob, c.d_gmap, c.d_txt, c.dP_g),
                                          lambda: n.cross_bwd(c.loc, c.d_vp, d_txt2, c.dP_l))
-            O.add_(c.d_txt, d_txt2)
+                O.add_(c.d_txt, d_txt2)
             n.nodes_in_bwd(plan, c.gin, d_gin, c.vin, d_vin, c.d_pano, c.d_fused)       # both input stages in shared launches
         if task == "mlm":
             n.gmap_in_bwd(c.gin, plan, d_gin, c.d_pano, c.d_fused)

@@ -711,6 +711,15 @@ def add_(y, x):
     return y
 
 
+def add_n(y, xs):
+    """y += sum(xs) (<= 8 tensors of y's shape and dtype), fp32 sum with one rounding"""
+    import ctypes as C
+    _chk(1 <= len(xs) <= 8 and all(x.dtype == y.dtype and x.numel() == y.numel() and x.is_contiguous() for x in xs), "add_n operands")
+    arr = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    L.call("magic_add_n", L.dt(y.dtype), y.numel(), len(xs), C.addressof(arr), L.P(y), L.stream())
+    return y
+
+
 def dact(dy, z, kind, out=None):
     if out is None:
         out = torch.empty_like(dy)

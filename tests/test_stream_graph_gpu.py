@@ -79,3 +79,18 @@ def test_teacher_one_batch_ahead_on_streamed_records_equals_the_exact_eager_step
     ma, mb = sA.store.m, sB.store.m
     assert torch.nn.functional.cosine_similarity(ma, mb, dim=0).item() > 0.9995
     assert ((sA.store.flat - sB.store.flat).norm() / sA.store.flat.norm()).item() < 2e-5
+
+
+def test_bucket_graphs_are_bounded_by_an_lru():
+    _, _, _, sA, tA = bench.build_models(torch.bfloat16, DEV, 0.0, 1, 16)
+    _, _, _, sB, tB = bench.build_models(torch.bfloat16, DEV, 0.0, 1, 16)
+    rw = torch.tensor(RW, dtype=torch.float32, device=DEV)
+    ss = StreamStep(tB, rw=rw, max_graphs=1)
+    for task, step in (("sap", 0), ("mlm", 1), ("sap", 3)):          # sap, mlm, sap: the second sap batch finds its graph evicted and recaptures
+        b = synth.make_batch(task, batch_size=16, seed=4242, step=step)
+        outA = tA.step(synth.batch_to(b, DEV), task, rw=rw, plan=build_plan(b, task, DEV))
+        outB, _ = ss.step(task, pack_bucketed(b, task))
+        torch.cuda.synchronize()
+        assert len(ss.cache) == 1
+        assert _close(outB["loss"], outA["loss"], 2e-3)
+    assert ss.captures == 3

@@ -24,9 +24,10 @@ class _Entry:
 
 
 class StreamStep:
-    def __init__(self, trainer, feature_table=None, rw=None):
-        """rw: fixed MKRW ability weights (a device tensor) instead of a fresh draw inside every replay (tests)"""
-        self.tr, self.dev, self.ftab, self.rw = trainer, trainer.dev, feature_table, rw
+    def __init__(self, trainer, feature_table=None, rw=None, max_graphs=96):
+        """rw: fixed MKRW ability weights (a device tensor) instead of a fresh draw inside every replay (tests); max_graphs: (task, bucket,
+        slot) entries kept -- each holds its graphs' private memory pools (~0.5-1 GB at B = 48); the least recently used one is dropped"""
+        self.tr, self.dev, self.ftab, self.rw, self.max_graphs = trainer, trainer.dev, feature_table, rw, max_graphs
         self.cache = {}
         self.captures = 0
         if trainer.sync.world != 1:
@@ -34,6 +35,17 @@ class StreamStep:
 
     def _key(self, task, manifest):
         return (task,) + tuple((k, dt, shape, o) for k, dt, shape, o, _ in manifest)
+
+    def _touch(self, key, e):
+        """least-recently-used bookkeeping (dicts keep insertion order)"""
+        self.cache.pop(key, None)
+        self.cache[key] = e
+        while len(self.cache) > self.max_graphs:
+            old = next(iter(self.cache))
+            if old == key:
+                break
+            torch.cuda.synchronize()              # its graphs may still be in flight
+            del self.cache[old]
 
     def _capture(self, key, task, rec, parsed):
         e = _Entry()
@@ -51,7 +63,6 @@ class StreamStep:
         torch.cuda.synchronize()
         e.cs = self.tr.capture(e.batch, task, e.plan, rw=self.rw)
         e.fill = [(DYN_TERMS.index(t), fn) for t, fn in e.plan["dyn"]["fill"].items()]
-        self.cache[key] = e
         self.captures += 1
         return e
 
@@ -73,6 +84,7 @@ class StreamStep:
                 buf = buf.pin_memory()
             e.dbuf.copy_(buf, non_blocking=True)
             e.keep[e.turn] = buf                              # the pinned source must outlive the asynchronous copy
+        self._touch(key, e)
         true = meta["true"]
         host_i, host_f, ev = e.ring[e.turn]
         ev.synchronize()                                      # (no-op unless the host is four steps of this bucket ahead)
@@ -117,7 +129,6 @@ class StreamStep:
             tr._optimize()
         e.fill = [(DYN_TERMS.index(t), fn) for t, fn in e.plan["dyn"]["fill"].items()]
         e.t_done, e.loaded = torch.cuda.Event(), torch.cuda.Event()
-        self.cache[key] = e
         self.captures += 1
         return e
 
@@ -139,6 +150,7 @@ class StreamStep:
                 buf = buf.pin_memory()
             e.dbuf.copy_(buf, non_blocking=True)
             e.keep[e.turn] = buf
+        self._touch(key, e)
         host_i, host_f, ev = e.ring[e.turn]
         ev.synchronize()
         for i, fn in e.fill:

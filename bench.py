@@ -18,6 +18,42 @@ import os
 import sys
 import time
 
+
+def _self_launch():
+    """`python bench.py --gpus N` (N > 1) without an outer launcher: start one fresh rank process per GPU the way the reference's
+    scripts do (`pretrain_src/run_r2r_magic.sh:8-10`: `torch.distributed.launch --nproc_per_node`), relay rank 0's JSON line and exit
+    with the children's status.  Runs BEFORE torch is imported, so this parent never touches the GPU; the ranks are children
+    (`subprocess`), never an exec of this process."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    n = 1
+    for i, tok in enumerate(sys.argv[1:], 1):
+        if tok == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif tok.startswith("--gpus="):
+            n = int(tok.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:              # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:                # relay as it comes; rank 0's JSON line is the only stdout line that starts with '{'
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    sys.exit(proc.wait())
+
+
+if __name__ == "__main__":
+    _self_launch()
+
 import torch
 import torch.distributed as dist
 
@@ -364,14 +400,33 @@ def main():
                          "student's graph trains on batch i (and, with data parallelism, while the gradient all-reduce and the optimizer run); "
                          "ahead: the same overlap as a fork/join inside ONE graph; same: teacher and student forward of the same batch side by "
                          "side (every step runs exactly one teacher forward and one student update in all three)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launcher rehearsal (no GPU needed): rendezvous, the rank roll-call and the one-line relay only, then exit -- what "
+                         "tests/test_bench_launch_cpu.py runs on CPU with --backend gloo; the full 2-rank step runs in tests/test_bench_launch_gpu.py")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}: for N > 1 launch one rank per GPU with "
-                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...`")
+    if a.gpus != world:       # only reachable under an outer launcher whose world disagrees with --gpus (a bare `python bench.py --gpus N` self-launches)
+        raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (`python bench.py --gpus {a.gpus}` does it itself, or "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...`)")
+    if a.rehearse_launch:
+        if world > 1:
+            dist.init_process_group("gloo")
+        mine = torch.tensor([rank, local], dtype=torch.int64)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(seen, mine)
+            dist.barrier()
+        else:
+            seen = [mine]
+        if rank == 0:
+            print(json.dumps({"rehearsal": "launch", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                              "rccl": {"backend": "gloo", "world": world, "ranks_seen": [int(t[0]) for t in seen], "devices": [int(t[1]) for t in seen]}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if a.backend == "gloo":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
@@ -382,6 +437,13 @@ def main():
         else:
             dist.init_process_group("gloo")
     L.load()
+    rccl = None
+    if world > 1:             # every rank reports in through the data-path backend: the line shows N ranks on N devices really took part
+        mine = torch.tensor([rank, local], device=dev, dtype=torch.int64)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        seen = [t.tolist() for t in seen]
+        rccl = {"backend": a.backend, "world": world, "ranks_seen": [r for r, _ in seen], "devices": [d for _, d in seen]}
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     tcfg, scfg, teacher, student, trainer = build_models(dtype, dev, a.dropout, world, a.batch)
 
@@ -567,7 +629,7 @@ def main():
                            "dropout": a.dropout,
                            "global_batch": a.batch * world, "per_gpu_batch": a.batch, "views": 36, "feat_dim": 768, "max_tokens": 80,
                            "parallelism": f"dp{world}", "samples_per_sec": round(a.batch * world * a.steps / dt, 1)},
-                "roofline": roof, "cpu_baseline": cpu, "parity": parity, "modes": modes, "secondary": secondary}
+                "roofline": roof, "cpu_baseline": cpu, "parity": parity, "modes": modes, "secondary": secondary, "rccl": rccl}
         if parity is not None:
             info["bf16_max_logit_delta"] = parity["bf16"]["max_abs_logit_delta"]
             info["argmax_agreement"] = parity["bf16"]["argmax_agreement"]

@@ -1,0 +1,78 @@
+"""Eager data-parallel step, 2 ranks on one card (gloo): with overlap ON the bucket exchanges are launched from inside the explicit backward
+(model.backward(on_bucket=...)); the result must equal the monolithic exchange after the backward (MAGIC_DDP_NO_OVERLAP).  Guards the ordering
+the round-2 advisor found broken: bucket 0's deferred weight-gradient GEMMs (heads, cross-modal encoders, distillation projections) must be ON
+THE STREAM before the exchange stream waits on it -- otherwise the all-reduce runs over a range the grouped dW kernel still adds into, the
+local dW part is never summed over ranks, and the replicas diverge."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import magic_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from magic_amd.host import synth
+        from magic_amd.host.plan import build_plan
+        from magic_amd.host.trainer import PretrainStep
+        from tests.test_model_gpu import RW, build
+        dev = "cuda"
+        torch.cuda.set_device(0)
+        rw = torch.tensor(RW, device=dev)
+        res = {}
+        for task in ("sap", "mlm", "cfp"):
+            b = synth.make_batch(task, batch_size=4, seed=77 + rank, step=0, vocab=600, min_len=8, max_len=15, min_steps=2, max_steps=3)   # ranks see different data
+            bd, plan = synth.batch_to(b, dev), build_plan(b, task, dev)
+            grads = {}
+            for overlap in (True, False):
+                _, _, g_t, g_s = build(torch.float32)          # same seeds on every rank = broadcast parameters
+                g_s.keep_mlm_logits = False
+                tr = PretrainStep(g_s, g_t, lr=1e-3, warmup_steps=2, num_train_steps=10, sparse_embedding_rows=4 * 15)
+                assert tr.sync.world == 2
+                tr.sync.overlap = overlap
+                tr._fwd_bwd(bd, task, rw, plan)
+                assert tr._exchanged == overlap
+                scale = tr.sync.finish() if overlap else tr.sync.all_reduce()
+                torch.cuda.synchronize()
+                grads[overlap] = (g_s.store.grad * scale).cpu()
+            every = [torch.empty_like(grads[True]) for _ in range(world)]
+            dist.all_gather(every, grads[True])
+            a, m = grads[True], grads[False]
+            res[task] = (float((a - m).abs().max()), float(m.abs().max()), bool(torch.equal(every[0], every[1])),
+                         float((a - m).norm() / m.norm()))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_overlapped_bucket_exchange_equals_monolithic_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in out:
+        for task, (dmax, gmax, same, rel) in res.items():
+            # fp32 engine; the two schedules differ only in the order of fp32 atomic additions
+            assert rel < 1e-4 and dmax <= 1e-5 + 1e-4 * gmax, f"rank {rank} {task}: overlapped exchange differs from monolithic: max {dmax:.3e} of {gmax:.3e}, rel {rel:.3e}"
+            assert same, f"rank {rank} {task}: replicas hold different averaged gradients after the overlapped exchange"

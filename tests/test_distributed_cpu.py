@@ -83,6 +83,20 @@ def _worker(rank, world, port, q):
             ok_bucket = ok_bucket and bool(torch.allclose(st2.grad, mono, rtol=1e-6, atol=1e-6))
             lo, hi = b0[0]
             ok_bucket = ok_bucket and bool(torch.allclose(first[lo:hi], mono[lo:hi], rtol=1e-6, atol=1e-6))     # bucket 0 was final after its own call
+            # replicas are BITWISE identical after the exchange (an all-reduce guarantees it; the sparse path sums rows in rank order)
+            every = [torch.empty_like(st2.grad) for _ in range(world)]
+            dist.all_gather(every, st2.grad)
+            ok_bucket = ok_bucket and all(bool(torch.equal(every[0], e)) for e in every[1:])
+        # a bucket-padded plan carries an EMPTY id list (host/plan.py): that must mean "dense table", never "no rows"
+        st3 = ParamStore(pretrain_specs(cfg), "cpu", torch.float32, seed=1)
+        st3.grad.copy_(torch.randn(st3.total, generator=torch.Generator().manual_seed(950 + rank)))
+        mono = st3.grad.clone()
+        dist.all_reduce(mono)
+        sy = GradSync(st3, chunk_elems=4099, overlap=True, sparse_rows_cap=40)
+        sy.reduce_bucket(0)
+        sy.reduce_bucket(1, torch.zeros(0, dtype=torch.int64))
+        sy.finish()
+        ok_bucket = ok_bucket and bool(torch.allclose(st3.grad, mono, rtol=1e-6, atol=1e-6))
         ok_mean = ok_mean and ok_bucket
         task = broadcast_task(2 if rank == 0 else 0, "cpu")   # MetaLoader: rank 0's draw wins (data/loader.py:55-59)
         q.put((rank, same_params, ok_sum, ok_mean, gscale, task, float(mine.abs().sum())))

@@ -33,9 +33,12 @@ def find_torch_wrapper(module, max_depth=16):
     for _ in range(max_depth):
         if f is None:
             return None
-        s = f.f_locals.get("self")
-        if isinstance(s, _TORCH_WRAPPERS) and getattr(s, "module", None) is module:
-            return s
+        # only frames of torch's own wrapper code can hold such a `self`: `f_locals` (a dict built per access) is not touched for the
+        # engine's own frames, which is every frame of an ordinary step
+        if "parallel" in f.f_code.co_filename:
+            s = f.f_locals.get("self")
+            if isinstance(s, _TORCH_WRAPPERS) and getattr(s, "module", None) is module:
+                return s
         f = f.f_back
     return None
 

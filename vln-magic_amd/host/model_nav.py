@@ -491,9 +491,11 @@ class VLNBert(nn.Module):
             # instr_zdict_update (agent.py:1231-1233, update_z_dict): per-token instruction embeddings under no_grad; the caller indexes `[0][b][j + 1]`
             ids, masks = (batch["txt_ids"], batch["txt_masks"]) if mode == "language" else (batch["z_txt"], batch["z_txt_mask"])
             x, attns = _LanguageFn.apply(self._anchor, self, ids, masks)
-            if "back_txt" in cz and batch.get("instr_z_direction_features") is not None:
-                z = torch.cat([batch["instr_z_direction_features"], batch["instr_z_landmark_features"]], 1)
-                pz = torch.cat([batch["instr_z_direction_pzs"], batch["instr_z_landmark_pzs"]], 1)
+            if "back_txt" in cz and (batch.get("instr_z_direction_features") is not None or batch.get("instr_z_landmark_features") is not None):
+                # direction rows first, then landmark rows; a landmark-only dictionary (zdict.load_instr_tensor without direction entries) is used as is
+                parts = [k for k in ("direction", "landmark") if batch.get(f"instr_z_{k}_features") is not None]
+                z = torch.cat([batch[f"instr_z_{k}_features"] for k in parts], 1)
+                pz = torch.cat([batch[f"instr_z_{k}_pzs"] for k in parts], 1)
                 x = cz["back_txt"](x, z, pz)
             if "front_txt" in cz and batch.get("front_txt_feats") is not None:
                 x = cz["front_txt"](x, batch["front_txt_feats"])

@@ -544,10 +544,15 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         called when gradient bucket i is final -- 0 after phase 1 (its weight-gradient GEMMs are flushed first), 1 at the end
         (trainer.GradSync launches the data-parallel exchange of that bucket from it)."""
         self.backward_phase1()
-        if on_bucket is not None:
-            on_bucket(0, self._ctx)
         c = self._ctx
-        self.backward_phase2(flush_first=on_bucket is not None)
+        if on_bucket is not None:
+            # bucket 0's weight gradients are still QUEUED at this point (phase 1 and the forward's distillation heads defer them):
+            # they must be on the stream before the hook makes the exchange stream wait on it, or RCCL reduces the range while the
+            # grouped dW kernels still add into it (same order as trainer.capture_split: phase 1; flush; cut)
+            O.flush_dw(keep_active=True)
+            O.join_side()
+            on_bucket(0, c)
+        self.backward_phase2()
         if on_bucket is not None:
             on_bucket(1, c)
 
@@ -658,13 +663,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             n.gmap_in_bwd(c.gin, plan, d_gin, c.d_pano, c.d_fused)
 
     @torch.no_grad()
-    def backward_phase2(self, flush_first=False):
-        """text / panorama encoders + embeddings.  flush_first: launch the weight-gradient GEMMs queued by phase 1 now, so every
-        gradient of the heads and the cross-modal encoders is final before this phase starts (bucket 0 of the exchange)"""
+    def backward_phase2(self):
+        """text / panorama encoders + embeddings (the caller flushes phase 1's queued weight-gradient GEMMs first when bucket 0 of the
+        exchange must be final before this phase starts)"""
         c = self._ctx
         n, plan = self.net, c.plan
-        if flush_first:
-            O.flush_dw(keep_active=True)
         if n.rbw_ok() and n.enc_ok(plan["L"], self.config.num_l_layers) and n.enc_ok(plan["V"], self.config.num_pano_layers):
             n.encoders_bwd(c.txt, c.pano, plan, c.d_txt, c.dP_txt, c.d_pano, c.d_fused, c.dP_pano)      # both stacks in shared launches
         else:

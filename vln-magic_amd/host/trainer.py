@@ -128,25 +128,27 @@ class GradSync:
             torch.cuda.current_stream().wait_stream(self.stream)
 
     def _sparse_rows(self, row_ids):
-        """sum over ranks of the gradient rows `row_ids` (this rank's touched rows, int64 on the device, any order, duplicates
-        allowed but not needed) of the word-embedding table: all-gather ids + rows, add the other ranks' rows locally"""
+        """sum over ranks of the gradient rows `row_ids` (this rank's touched rows: int64 on the device, any order, UNIQUE -- the
+        plan's `torch.unique(txt_ids)`) of the word-embedding table: all-gather ids + rows, then every rank rebuilds the touched
+        rows as 0 + rank 0's rows + rank 1's rows + ... in rank order.  One rank's ids never collide inside one index_add_, so the
+        fp32 sum order is the same on every rank and the replicas stay bitwise identical, as after an all-reduce."""
         off, n, (R, H) = self.table
         tab = self.store.grad[off:off + n].view(R, H)
         cap = self.sparse_cap
         ids = torch.zeros(cap, dtype=torch.int64, device=tab.device)
-        k = min(int(row_ids.numel()), cap)
-        if row_ids.numel() > cap:
-            raise ValueError(f"sparse embedding exchange: {row_ids.numel()} touched rows > cap {cap}")
-        ids[:k] = row_ids[:k]
+        k = int(row_ids.numel())
+        if k > cap:
+            raise ValueError(f"sparse embedding exchange: {k} touched rows > cap {cap}")
+        ids[:k] = row_ids
         rows = tab.index_select(0, ids)
-        rows[k:] = 0                                              # padding slots point at row 0 and carry zeros
+        rows[k:] = 0                                              # padding slots point at row 0 and carry zeros (x + 0 in any order)
         all_ids = torch.empty(self.world * cap, dtype=torch.int64, device=tab.device)
         all_rows = torch.empty(self.world * cap, H, dtype=tab.dtype, device=tab.device)
         dist.all_gather_into_tensor(all_ids, ids)
         dist.all_gather_into_tensor(all_rows, rows)
-        r = dist.get_rank()
-        all_rows[r * cap:(r + 1) * cap] = 0                       # own rows are in the table already
-        tab.index_add_(0, all_ids, all_rows)
+        tab.index_fill_(0, row_ids, 0)                            # own contribution comes back through all_rows, in its rank's turn
+        for r in range(self.world):
+            tab.index_add_(0, all_ids[r * cap:(r + 1) * cap], all_rows[r * cap:(r + 1) * cap])
 
     # ---- per-bucket API (called from inside the backward) ----------------------------------------------------------
     def reduce_bucket(self, i, touched_rows=None):
@@ -155,7 +157,8 @@ class GradSync:
         if self.world == 1:
             return
         ranges = self.buckets[i]
-        sparse = i == 1 and touched_rows is not None and self.table is not None and self.sparse_cap
+        # an EMPTY id list is not "no rows": bucket-padded plans carry a zero-length placeholder (host/plan.py) -> dense exchange
+        sparse = i == 1 and touched_rows is not None and touched_rows.numel() > 0 and self.table is not None and self.sparse_cap
         if sparse:
             off, n, _ = self.table
             assert off == 0 and ranges[0][0] == 0
@@ -266,7 +269,8 @@ class PretrainStep:
         """device ids of the word-embedding rows with gradient, or None when the table's gradient is dense (mlm: tied decoder)"""
         if task == "mlm" or self.sync.sparse_cap is None:
             return None
-        return plan.get("emb_rows")
+        rows = plan.get("emb_rows")
+        return rows if rows is not None and rows.numel() > 0 else None      # bucket-padded plans hold an empty placeholder: dense
 
     def _bucket_hook(self, task, plan):
         """on_bucket callback for model.backward(): launches each bucket's exchange on the side stream as soon as the explicit

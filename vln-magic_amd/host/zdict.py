@@ -67,8 +67,10 @@ class ZDict:
             out[r["token_type"]][0].append(ft)
             out[r["token_type"]][1].append(r["pz"])
         t = lambda a: torch.from_numpy(np.array(a)).to(self.device)
-        return {"instr_direction_features": t(out["direction"][0]), "instr_direction_pzs": t(out["direction"][1]),
-                "instr_landmark_features": t(out["landmark"][0]), "instr_landmark_pzs": t(out["landmark"][1])}
+        lm = {"instr_landmark_features": t(out["landmark"][0]), "instr_landmark_pzs": t(out["landmark"][1])}
+        if not out["direction"][0]:          # a dictionary without direction entries (REVERIE): landmark keys only (data_utils.py:117-120)
+            return lm
+        return {"instr_direction_features": t(out["direction"][0]), "instr_direction_pzs": t(out["direction"][1]), **lm}
 
 
 def write_img_tsv(path, rows):

@@ -539,7 +539,7 @@ def main():
         gemm_n = sum(c for k, (t, c) in by.items() if fam(k))
         all_ms = sum(t for t, c in by.values())
         flops = O.FLOPS["gemm"]            # the GEMM family's own algorithmic FLOPs (fused linear+LN and attention kernels count separately)
-        is_mfma = lambda k: any(x in k for x in ("magic_gemm", "magic_linear_ln", "magic_attn_", "magic_rowblock", "magic_encoder", "magic_xencoder", "magic_rowbwd"))
+        is_mfma = lambda k: any(x in k for x in ("magic_gemm", "magic_linear_ln", "magic_attn_", "magic_encoder", "magic_xencoder", "magic_rowbwd"))
         mfma_ms = sum(t for k, (t, c) in by.items() if is_mfma(k))
         step_ms = dt / a.steps * 1e3
         # achieved = the family's algorithmic FLOPs / the family's SUMMED launch durations (non-overlapped pass), i.e.

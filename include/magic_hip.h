@@ -236,25 +236,6 @@ int magic_dact(int dtype, int kind, long long n, const void* dy, const void* z, 
 int magic_view_gather(int dtype, int Np, int V, int D, const void* table, int n_viewpoints, const int* vp_row,
                       const int* order, void* out, void* stream);
 
-/* Row-block pipeline (forward): up to 4 per-token linear stages chained on 32-row blocks with the intermediate
- * activations in LDS -- the BertSelfOutput -> BertIntermediate -> BertOutput tail of a transformer block plus the next
- * block's Q/K/V projection in ONE launch (HF BertLayer.feed_forward_chunk).  Stage i consumes the
- * output of stage i-1 (stage 0: X[M, K0]); kind 1 = LayerNorm(dropout(x W^T + b) + residual) with the residual either a
- * global tensor `res` or (res == NULL, res_stage >= 0) the LDS-resident output of an earlier stage, N <= 256; kind 2 =
- * gelu(x W^T + b), `pre` optionally receives the pre-activation; kind 3 = x W^T + b, last stage only.  All N % 64 == 0,
- * K % 64 == 0 (bf16) / % 32 (f32).  Every stage writes its `out` (saved for the backward).  MAGIC_ERR_UNSUPPORTED when the
- * widths do not fit LDS (magic_rowblock_lds_bytes > 160 KiB or a LayerNorm width > 256): use magic_gemm + magic_linear_ln. */
-typedef struct {
-  int kind, N, K;
-  const void* W; int ldw; const float* bias;
-  const void* res; int ldres; int res_stage;
-  const float* gamma; const float* beta; float eps; float* rstd; unsigned drop_site;
-  void* out; int ldo; void* pre; int ldpre;
-} magic_rb_stage;
-int magic_rowblock_lds_bytes(int dtype, int wn, int ww);
-int magic_rowblock_fwd(int dtype, int M, const void* X, int ldx, int K0, int nstage, const magic_rb_stage* stages,
-                       const void* drop_seed, float drop_p, void* stream);
-
 /* Contraction arithmetic of the fp32 storage mode (dtype 0) in magic_gemm / magic_gemm_dw_grouped / magic_linear_ln /
  * magic_linear_lnbwd: mode 0 = the exact v_mfma_f32_16x16x4_f32 (default); mode 1 = "bf16x3": every fp32 operand split into
  * bf16 hi + lo, a.b = a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~2^-17 relative error
@@ -332,7 +313,7 @@ int magic_rowbwd(const void* params, int nbytes, void* stream);
 int magic_transpose_spans(const void* src, void* dst, int n, const long long* offs, const int* rows, const int* cols, void* stream);
 
 /* Grouping: between magic_group_begin() and magic_group_end(stream) up to eight calls of magic_gemm / magic_attn_fwd /
- * magic_attn_bwd / magic_linear_ln / magic_linear_lnbwd / magic_ln_bwd / magic_rowblock_fwd are recorded instead of launched; magic_group_end launches ONE kernel serving
+ * magic_attn_bwd / magic_linear_ln / magic_linear_lnbwd / magic_ln_bwd are recorded instead of launched; magic_group_end launches ONE kernel serving
  * the problems of the same kind / dtype / variant: GEMMs as one grouped launch (<= 8 problems), other kinds as pairs.
  * Records must be independent of each other.  Thread-local state. */
 int magic_group_begin(void);

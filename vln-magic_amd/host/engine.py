@@ -277,22 +277,6 @@ class MagicNet:
         self._sa_out_fwd(lp, c)
         return c
 
-    # ---- row-block chains (csrc/rowblock.hip): everything after an attention product is per-token ----------------
-    def _rb_ok(self):
-        return O.rowblock_ok(self.dtype, self.H, self.I)
-
-    def _qkv_lin(self, lp):
-        return self.lin(lp + "attention.self.query.weight", rows=3 * self.H, cols=self.H)
-
-    def _ffn_stages(self, lp, M, rows, res_stage):
-        """stages gelu(a W1^T) -> LN(drop(g W2^T) + a) with `a` = the output of stage `res_stage`; returns (ffn ctx, stages)"""
-        H, I = self.H, self.I
-        f1, f2 = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")
-        n = self.ln(lp + "output.LayerNorm")
-        c = Ctx(M=M, rows=rows, z=self.new(M, I), g=self.new(M, I), out=self.new(M, H), rstd=self.new(M, dtype=torch.float32),
-                hdrop=self._dh(lp + "output.dropout"))
-        return c, [O.rb_act(f1, c.g, pre=c.z), O.rb_ln(f2, None, n.g, n.b, self.eps, c.out, c.rstd, drop=c.hdrop, res_stage=res_stage)]
-
     def _dense_add_ln(self, x, lin, res, n, M, out, rstd, rows, hdrop):
         """out = LayerNorm(dropout(x W^T + b) + res): BertSelfOutput / BertOutput"""
         H = self.H
@@ -380,19 +364,8 @@ class MagicNet:
         projection this block's chain produces (returned as c.next_qkv)."""
         c = Ctx(next_qkv=None)
         M = Bn * N
-        if self._rb_ok():
-            sa = c.sa = self._sa_attn_fwd(lp, x, Bn, N, kmask, None, None, rows, aflops, qkv)
-            o, n = self.lin(lp + "attention.output.dense.weight"), self.ln(lp + "attention.output.LayerNorm")
-            c.ffn, st = self._ffn_stages(lp, M, rows, 0)
-            c.ffn.a = sa.a
-            st = [O.rb_ln(o, x, n.g, n.b, self.eps, sa.a, sa.rstd_a, drop=sa.hdrop)] + st
-            if next_lp is not None:
-                c.next_qkv = self.new(M, 3 * self.H)
-                st.append(O.rb_lin(self._qkv_lin(next_lp), c.next_qkv))
-            O.rowblock_fwd(sa.ctx, M, st, flop_rows=rows)
-        else:
-            c.sa = self._sa_fwd(lp, x, Bn, N, kmask, None, None, rows, aflops, qkv)
-            c.ffn = self._ffn_fwd(lp, c.sa.a, M, rows)
+        c.sa = self._sa_fwd(lp, x, Bn, N, kmask, None, None, rows, aflops, qkv)
+        c.ffn = self._ffn_fwd(lp, c.sa.a, M, rows)
         c.out, c.P, c.ldp = c.ffn.out, c.sa.P, c.sa.ldp
         return c
 
@@ -415,16 +388,8 @@ class MagicNet:
         c = Ctx(Bn=Bn, Nq=Nq, Nk=Nk, ctx=ctx, rows=rows, crow=crow, cflops=cflops, next_qkv=None, kv_given=kv is not None)
         ql = self.lin(lp + "crossattention.self.query.weight")
         kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
-        rb = self._rb_ok()
-        if rb:
-            # chain 1: self-attention output dense + add&norm, then the cross-attention query projection
-            sa = c.sa = self._sa_attn_fwd(lp, x, Bn, Nq, kmask, dist, sprel, rows, sflops, qkv)
-            o, n = self.lin(lp + "attention.output.dense.weight"), self.ln(lp + "attention.output.LayerNorm")
-            c.q = self.new(Mq, H)
-            O.rowblock_fwd(sa.ctx, Mq, [O.rb_ln(o, x, n.g, n.b, self.eps, sa.a, sa.rstd_a, drop=sa.hdrop), O.rb_lin(ql, c.q)], flop_rows=rows)
-        else:
-            c.sa = self._sa_fwd(lp, x, Bn, Nq, kmask, dist, sprel, rows, sflops, qkv)
-            c.q = O.linear_fwd(c.sa.a, ql.W, ql.b, Mq, flop_rows=rows)
+        c.sa = self._sa_fwd(lp, x, Bn, Nq, kmask, dist, sprel, rows, sflops, qkv)
+        c.q = O.linear_fwd(c.sa.a, ql.W, ql.b, Mq, flop_rows=rows)
         s = c.sa.a
         c.kv = kv if kv is not None else O.linear_fwd(ctx, kvl.W, kvl.b, Mk, flop_rows=crow)
         c.adrop, c.hdrop = self._da(lp + "crossattention.self.dropout"), self._dh(lp + "crossattention.output.dropout")
@@ -432,18 +397,8 @@ class MagicNet:
         o = self.lin(lp + "crossattention.output.dense.weight")
         n = self.ln(lp + "crossattention.output.LayerNorm")
         c.c, c.rstd_c = self.new(Mq, H), self.new(Mq, dtype=torch.float32)
-        if rb:
-            # chain 2: cross-attention output dense + add&norm, FFN + add&norm, the next block's Q/K/V projection
-            c.ffn, st = self._ffn_stages(lp, Mq, rows, 0)
-            c.ffn.a = c.c
-            st = [O.rb_ln(o, s, n.g, n.b, self.eps, c.c, c.rstd_c, drop=c.hdrop)] + st
-            if next_lp is not None:
-                c.next_qkv = self.new(Mq, 3 * H)
-                st.append(O.rb_lin(self._qkv_lin(next_lp), c.next_qkv))
-            O.rowblock_fwd(c.cctx, Mq, st, flop_rows=rows)
-        else:
-            self._dense_add_ln(c.cctx, o, s, n, Mq, c.c, c.rstd_c, rows, c.hdrop)
-            c.ffn = self._ffn_fwd(lp, c.c, Mq, rows)
+        self._dense_add_ln(c.cctx, o, s, n, Mq, c.c, c.rstd_c, rows, c.hdrop)
+        c.ffn = self._ffn_fwd(lp, c.c, Mq, rows)
         c.out = c.ffn.out
         return c
 
@@ -540,7 +495,7 @@ class MagicNet:
         tl = plan["lens"]["txt"]
         af = self._flops_attn(tl, tl)
         nl, qkv = self.cfg.num_l_layers, None
-        if self.enc_ok(L, nl) and not self._rb_ok():
+        if self.enc_ok(L, nl):
             c.pending = (p + "lang_encoder.layer.{}.", nl, x, B, L, plan["txt_mask"], plan["txt_tokens"], af)
             if defer:
                 return c
@@ -561,7 +516,7 @@ class MagicNet:
 
     # ---- backward of whole self-attention stacks on the row-block kernel (csrc/encbwd.hip) --------------------------------
     def rbw_ok(self):
-        return self.train and O.rowbwd_ok(self.dtype, self.H, self.I) and not self._rb_ok()
+        return self.train and O.rowbwd_ok(self.dtype, self.H, self.I)
 
     def self_stacks_bwd(self, stacks):
         """stacks: 1 or 2 tuples (ctx with .layers, layer-prefix format, d_top = plain gradient wrt the stack's output, dP_init for
@@ -690,7 +645,7 @@ class MagicNet:
         af = float(Np) * V * V * HD * self.nh
         nl, qkv = self.cfg.num_pano_layers, None
         c.plan = plan
-        if self.enc_ok(V, nl) and not self._rb_ok():
+        if self.enc_ok(V, nl):
             c.pending = (p + "pano_encoder.layer.{}.", nl, x, Np, V, plan["pano_mask"], M, af)
             if defer:
                 return c
@@ -902,7 +857,7 @@ class MagicNet:
 
     # ---- both cross-modal encoders as one launch (csrc/encoder.hip, xencoder_fwd_kernel) -----------------------------------
     def xenc_ok(self, Nq, Nk):
-        return O.xencoder_ok(self.dtype, self.H, self.I, self.nh, Nq, Nk, self.cfg.num_x_layers) and not self._rb_ok()
+        return O.xencoder_ok(self.dtype, self.H, self.I, self.nh, Nq, Nk, self.cfg.num_x_layers)
 
     def _xenc_segment(self, which, plan, x, Nq, qmask, qlens, qrows, ctx, Nk, kmask, klens, krows, dist=None):
         """allocate what cross_layer_bwd reads for every layer of one encoder; returns (segment dict for O.xencoder_fwd, cross Ctx)"""

@@ -64,8 +64,6 @@ SIGNATURES = {
     "magic_add": [i32, i64, vp, vp, vp],
     "magic_dact": [i32, i32, i64, vp, vp, vp, vp],
     "magic_view_gather": [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp],
-    "magic_rowblock_lds_bytes": [i32, i32, i32],
-    "magic_rowblock_fwd": [i32, i32, vp, i32, i32, i32, vp, vp, f32, vp],
     "magic_set_f32_mfma": [i32],
     "magic_get_f32_mfma": [],
     "magic_encoder_supported": [i32, i32, i32, i32, i32, i32],
@@ -115,13 +113,6 @@ class CsrProb(C.Structure):
 class SkbProb(C.Structure):
     """mirror of `magic_skb_prob` (include/magic_hip.h)"""
     _fields_ = [("M", i32), ("Kin", i32)] + [(n, vp) for n in ("x", "dy", "y", "gamma", "beta", "rstd", "dW", "db", "dgamma", "dbeta")]
-
-
-class RbStage(C.Structure):
-    """mirror of `magic_rb_stage` (include/magic_hip.h)"""
-    _fields_ = [("kind", i32), ("N", i32), ("K", i32), ("W", vp), ("ldw", i32), ("bias", vp),
-                ("res", vp), ("ldres", i32), ("res_stage", i32), ("gamma", vp), ("beta", vp), ("eps", f32), ("rstd", vp),
-                ("drop_site", u32), ("out", vp), ("ldo", i32), ("pre", vp), ("ldpre", i32)]
 
 
 class EncLayer(C.Structure):
@@ -245,7 +236,7 @@ def P(t):
 
 
 PROFILE = {"on": False, "events": []}     # bench.py: per-launch HIP-event timing on the launch stream
-PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_linear_lnbwd", "magic_ln_bwd", "magic_rowblock_fwd"}
+PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_linear_lnbwd", "magic_ln_bwd"}
 _tls = threading.local()
 
 

@@ -192,7 +192,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         c = Ctx(task=task, plan=plan, inp=inp)
         # the text and panorama encoders are independent: run them on two streams
         # both self-attention encoders as ONE launch (csrc/encoder.hip) when the shapes allow: embeddings first (paired), then the launch
-        fuse = n.enc_ok(plan["L"], self.config.num_l_layers) and n.enc_ok(plan["V"], self.config.num_pano_layers) and not n._rb_ok()
+        fuse = n.enc_ok(plan["L"], self.config.num_l_layers) and n.enc_ok(plan["V"], self.config.num_pano_layers)
         c.txt, c.pano = self._par(lambda: n.text_fwd(plan, defer=fuse), lambda: n.pano_fwd(plan, inp.feats, inp.loc, defer=fuse))
         if fuse:
             n.encoders_fwd(c.txt, c.pano)

@@ -230,72 +230,6 @@ def view_gather(table, vp_row, order, out):
     return out
 
 
-# ---- row-block pipeline (csrc/rowblock.hip) --------------------------------------------------------------------
-# OPT-IN (MAGIC_ROWBLOCK=1): measured slower than the separate launches it replaces on MI355X -- a 32-row block has to
-# stream every weight of the chain itself (393 KB at H=128, 1.5 MB at H=256) with one 32 KB tile in flight, ~3.8 us per
-# k-tile step: 69 us vs 37 us (H=128, M=3840), 201 us vs 60 us (H=256); see DESIGN.md section 5 "measured and rejected".
-ROWBLOCK = bool(os.environ.get("MAGIC_ROWBLOCK"))
-_RB_OK = {}
-
-
-def rowblock_fits(dtype, wn, ww):
-    """True if a chain with LayerNorm / input width wn and GELU width ww fits the kernel's LDS budget."""
-    if wn > 256 or wn % 64 or ww % 64:
-        return False
-    key = (dtype, wn, ww)
-    if key not in _RB_OK:
-        _RB_OK[key] = 0 < L.load().magic_rowblock_lds_bytes(L.dt(dtype), wn, ww) <= 160 * 1024
-    return _RB_OK[key]
-
-
-def rowblock_ok(dtype, wn, ww):
-    """engine switch: use the row-block chains? (opt-in AND fits)"""
-    if not ROWBLOCK or wn > 256 or wn % 64 or ww % 64:
-        return False
-    key = (dtype, wn, ww)
-    if key not in _RB_OK:
-        _RB_OK[key] = 0 < L.load().magic_rowblock_lds_bytes(L.dt(dtype), wn, ww) <= 160 * 1024
-    return _RB_OK[key]
-
-
-def rb_ln(lin, res, gamma, beta, eps, out, rstd, drop=None, res_stage=-1):
-    """stage: out = LayerNorm(dropout(x W^T + b) + res)   (res: a tensor, or res_stage = index of an earlier stage)"""
-    return dict(kind=1, lin=lin, res=res, res_stage=res_stage, gamma=gamma, beta=beta, eps=eps, out=out, rstd=rstd, drop=drop)
-
-
-def rb_act(lin, out, pre=None):
-    """stage: out = gelu(x W^T + b), pre = the pre-activation"""
-    return dict(kind=2, lin=lin, out=out, pre=pre)
-
-
-def rb_lin(lin, out):
-    """last stage: out = x W^T + b"""
-    return dict(kind=3, lin=lin, out=out)
-
-
-def rowblock_fwd(x, M, stages, flop_rows=None):
-    """Run the chain of stages (built with rb_ln / rb_act / rb_lin; `lin` = an engine.Lin handle) on x[M, K0] in one launch."""
-    arr = (L.RbStage * len(stages))()
-    seed, p = None, 0.0
-    keep = []
-    for i, s in enumerate(stages):
-        lin = s["lin"]
-        N, K = lin.W.shape
-        _count(flop_rows if flop_rows is not None else M, N, K)
-        d = s.get("drop")
-        if d is not None and d[1] > 0:
-            seed, p = L.P(d[0]), float(d[1])
-        res = s.get("res")
-        a = arr[i]
-        a.kind, a.N, a.K, a.W, a.ldw, a.bias = s["kind"], N, K, L.P(lin.W), lin.W.stride(0), L.P(lin.b)
-        a.res, a.ldres, a.res_stage = L.P(res), (res.stride(0) if res is not None else 0), int(s.get("res_stage", -1))
-        a.gamma, a.beta, a.eps, a.rstd = L.P(s.get("gamma")), L.P(s.get("beta")), float(s.get("eps", 0.0)), L.P(s.get("rstd"))
-        a.drop_site = int(d[2]) if (d is not None and d[1] > 0) else 0
-        out, pre = s["out"], s.get("pre")
-        a.out, a.ldo, a.pre, a.ldpre = L.P(out), out.stride(0), L.P(pre), (pre.stride(0) if pre is not None else 0)
-    L.call("magic_rowblock_fwd", L.dt(x.dtype), M, L.P(x), x.stride(0), x.shape[1], len(stages), arr, seed, p, L.stream())
-
-
 def _tab(t):
     """t = None | (table, idx|None, mod, off)"""
     if t is None:

@@ -7,7 +7,8 @@
  *   - plain pointers (device memory owned by the caller), sizes, strides; no torch types
  *   - `stream` is a hipStream_t; every call is asynchronous on it, never synchronises, never allocates
  *   - return 0 on success, negative error code otherwise (MAGIC_ERR_*); never throws
- *   - dtype: 0 = fp32 ("parity mode", exact fp32 MFMA), 1 = bf16 (MFMA bf16, fp32 accumulate)
+ *   - dtype: 0 = fp32 ("parity mode", exact fp32 MFMA), 1 = bf16, 2 = fp16 (v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate; every
+ *     16-bit kernel exists for both types: fp16 stores 11 significand bits against bf16's 8 and needs scaled gradient seeds)
  *   - weights / activations / embedding tables are in `dtype`; biases, LayerNorm params, losses, logits of the
  *     action heads, statistics and ALL parameter gradients are fp32
  */
@@ -215,7 +216,7 @@ int magic_sap_fuse_bwd(int B, int K, int Vp, const float* g_raw, const float* l_
 
 /* Flat-buffer optimizer: pretrain_src/optim/adamw.py:53-112 + clip_grad_norm_ (grad_norm, r2r_magic_pretrain.json:22) */
 int magic_sumsq(long long n, const float* g, float* out, void* stream);
-int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow_bf16,
+int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype,
                 float lr, float b1, float b2, float eps, float wd, float step_size,
                 const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, void* stream);
 /* n_decay: elements [0, n_decay) take the weight decay wd, the rest none (both parameter groups of optim/misc.py:13-22 in one launch);
@@ -223,7 +224,9 @@ int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void*
  * arguments above are optional device scalars multiplied into / replacing the host values; zero_me (optional): one float set to 0 (the
  * gradient-norm accumulator of the step that begins) */
 int magic_sched_step(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, float* zero_me, void* stream);
-int magic_cast(int to_bf16, long long n, const void* x, void* y, void* stream);
+/* shadow (optional): the 16-bit copy of the parameters the MFMA kernels read, rewritten in shadow_dtype (1 | 2).  magic_cast: dtype16 = 1 | 2 names
+ * the 16-bit side; to16 != 0: fp32 x -> 16-bit y, else 16-bit x -> fp32 y */
+int magic_cast(int dtype16, int to16, long long n, const void* x, void* y, void* stream);
 /* y += xs[0] + ... + xs[count-1] (count <= 8 device tensors of n elements, 16-byte aligned): fp32 sum, one rounding */
 int magic_add_n(int dtype, long long n, int count, const void* const* xs, void* y, void* stream);
 int magic_add(int dtype, long long n, const void* x, void* y, void* stream);
@@ -260,7 +263,7 @@ typedef struct { const void* x; const unsigned char* kmask; int nsamp, N, ldp, n
 typedef struct { magic_enc_seg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; } magic_enc_params;
 int magic_encoder_supported(int dtype, int H, int I, int nh, int N, int nlayers);
 int magic_encoder_params_bytes(void);
-int magic_encoder_fwd(const void* params, int nbytes, void* stream);
+int magic_encoder_fwd(int dtype, const void* params, int nbytes, void* stream);
 
 /* Cross-modal encoders in one launch (csrc/encoder.hip, xencoder_fwd_kernel): the global (map) and local (viewpoint) co-attention
  * encoders, <= 3 METER BertCrossLayer blocks each (the withheld model's `bert.{global,local}_encoder.encoder.crossattention.N`,
@@ -284,7 +287,7 @@ typedef struct {
 typedef struct { magic_xenc_seg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; } magic_xenc_params;
 int magic_xencoder_supported(int dtype, int H, int I, int nh, int Nq, int Nk, int nlayers);
 int magic_xencoder_params_bytes(void);
-int magic_xencoder_fwd(const void* params, int nbytes, void* stream);
+int magic_xencoder_fwd(int dtype, const void* params, int nbytes, void* stream);
 
 /* Backward of the per-token half of a post-LN self-attention block on 32-row blocks (csrc/encbwd.hip): [tail of the next block: dx =
  * dQKV Wqkv + d_ao -> LayerNorm backward through this block's output norm] -> FFN input gradients (x gelu') -> LayerNorm backward through the
@@ -307,7 +310,7 @@ typedef struct {
 typedef struct { magic_rowbwd_seg seg[2]; int nseg, blocks0; float p_hidden; int pad1; const unsigned* seed; } magic_rowbwd_params;
 int magic_rowbwd_supported(int dtype, int H, int I);
 int magic_rowbwd_params_bytes(void);
-int magic_rowbwd(const void* params, int nbytes, void* stream);
+int magic_rowbwd(int dtype, const void* params, int nbytes, void* stream);
 /* dst[off_i .. off_i + rows_i*cols_i) = transpose of the row-major [rows_i, cols_i] bf16 matrix at src[off_i ..), i < n (element
  * offsets into two congruent flat buffers; host arrays, consumed before return): the transposed weight shadow of magic_rowbwd. */
 int magic_transpose_spans(const void* src, void* dst, int n, const long long* offs, const int* rows, const int* cols, void* stream);

@@ -72,6 +72,9 @@ def engine_step(g_t, g_s, batch, task, backward=False):
     got = g_s(batch, task, compute_loss=True, teacher_outputs=gt, rw=RW, plan=gt["plan"])
     if backward:
         g_s.backward()
+        gs = float(getattr(g_s, "grad_scale", 1.0))
+        if gs != 1.0:                     # fp16 engine: the flat buffer holds grad_scale x the gradient (the optimizer divides)
+            g_s.store.grad.mul_(1.0 / gs)
     torch.cuda.synchronize()
     return gt, got
 

@@ -21,7 +21,7 @@ def ref_attention(q, k, v, kmask, dist, sw, sb, scale):
     return p, p @ v
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,nh,Nq,Nk,cross,use_dist", [(3, 2, 37, 37, False, False), (2, 2, 18, 18, False, True), (2, 4, 21, 80, True, False),
                                                         (2, 2, 80, 17, True, False), (1, 2, 64, 64, False, False), (2, 2, 100, 128, True, False)])
 def test_fused_attention_fwd_bwd(dtype, B, nh, Nq, Nk, cross, use_dist):
@@ -98,7 +98,7 @@ def test_unsupported_shapes_are_reported_not_launched():
     assert not O.attn_supported(torch.float32, 128, 128, True)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,nh,Nq,Nk,cross,use_dist,p_drop", [(2, 2, 40, 129, True, False, 0.0), (1, 2, 200, 200, False, False, 0.1),
                                                                (2, 4, 38, 512, True, False, 0.0), (1, 2, 70, 300, True, True, 0.1),
                                                                (1, 2, 512, 512, False, False, 0.0)])
@@ -156,7 +156,7 @@ def test_kv_tiled_forward_for_long_keys(dtype, B, nh, Nq, Nk, cross, use_dist, p
     assert torch.allclose(got, want, **to), (got - want).abs().max().item()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,H,K", [(100, 128, 128), (77, 128, 512), (200, 256, 256), (64, 256, 1024), (33, 384, 384)])
 def test_fused_linear_residual_layernorm(dtype, M, H, K):
     g = torch.Generator().manual_seed(M + H + K)
@@ -172,7 +172,7 @@ def test_fused_linear_residual_layernorm(dtype, M, H, K):
     assert torch.allclose(rstd, 1 / torch.sqrt(pre.var(-1, unbiased=False) + 1e-12), rtol=1e-3 if dtype == torch.float32 else 2e-2, atol=1e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,H,K,res,p", [(100, 128, 512, True, 0.0), (77, 128, 384, True, 0.1), (200, 256, 256, False, 0.0),
                                          (33, 128, 128, True, 0.0), (64, 256, 512, True, 0.1),
                                          (3840, 128, 512, True, 0.1), (130, 128, 264, False, 0.0), (8200, 128, 384, True, 0.0)])

@@ -56,7 +56,7 @@ def test_mask_statistics_and_determinism():
     assert torch.equal(O.dropout(x, torch.empty_like(x), 1, 1000, 1000, None), x)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,nh,Nq,Nk,cross", [(3, 2, 37, 37, False), (2, 4, 21, 80, True), (2, 2, 80, 17, True), (1, 2, 64, 64, False)])
 def test_fused_attention_with_dropout(dtype, B, nh, Nq, Nk, cross):
     H, p, site = nh * 64, 0.1, 0xABCDEF01
@@ -115,7 +115,7 @@ def test_fused_attention_with_dropout(dtype, B, nh, Nq, Nk, cross):
     chk(dv[:, :H], unheads(vh.grad, Nk), "dV", **tg)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,H,K,fused", [(100, 128, 128, True), (77, 128, 512, True), (200, 256, 256, True), (64, 256, 1024, False)])
 def test_dense_dropout_add_layernorm_fwd_bwd(dtype, M, H, K, fused):
     """BertSelfOutput/BertOutput: LN(dropout(x W^T + b) + r), fused (linear_ln) or dense + ln_fwd(drop_in0), and its backward
@@ -150,7 +150,7 @@ def test_dense_dropout_add_layernorm_fwd_bwd(dtype, M, H, K, fused):
     assert ((dxm.float() == 0) | (mask > 0)).all()          # dropped positions carry no gradient
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_embedding_layernorm_output_dropout(dtype):
     """BertEmbeddings / ImageEmbeddings: dropout(LN(sum)).  `out` keeps the clean y (the backward rebuilds xhat from it)."""
     M, H, p, site = 150, 128, 0.1, 99

@@ -264,7 +264,7 @@ def test_cross_encoder_rowblock_backward_matches_the_per_op_backward(task, p_dro
     assert cos > 0.9995 and rel < 3e-2, (cos, rel)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 def test_node_inputs_in_one_launch_are_bit_identical_to_the_per_op_chain(dtype):
     """magic_node_in_fwd (gathers + position embedding + step embedding of the map / viewpoint tokens, both encoders in one launch) keeps the
     per-op chain's rounding points: csr_gather (+ accumulate) -> smallk_ln_fwd -> ln_fwd(do_ln = False)"""

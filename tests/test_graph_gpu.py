@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_graph_replay_matches_eager_steps(dtype):
     tasks = ["sap", "mlm", "cfp", "sap"]
     batches = [synth.make_batch(t, batch_size=4, seed=31, step=i, vocab=600, min_len=8, max_len=15, min_steps=2, max_steps=3)

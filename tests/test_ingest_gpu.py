@@ -15,7 +15,7 @@ DEV = "cuda"
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gather_reproduces_reference_token_tensors(dtype):
     fx = torch.load(os.path.join(GOLD, "ingest.pt"), weights_only=False)
     D, scan, cands = fx["D"], fx["scan"], fx["cands"]

@@ -16,7 +16,7 @@ from oracle import optim_ref
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def tol(dtype):

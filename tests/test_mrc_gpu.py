@@ -33,7 +33,7 @@ def build(dtype):
     return o_t, o_s, mk(tcfg, o_t), mk(scfg, o_s)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_softkl_rows_kernel(dtype):
     g = torch.Generator().manual_seed(1)
     M, N = 37, 1000

@@ -13,13 +13,16 @@
 
 #define HD 64
 
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-
 template <typename T> struct AT;
 template <> struct AT<bf16> {
   static constexpr int VE = 8, KSTEP = 32, DS = 72, PPAD = 8;
   typedef bf16x8 vec;
   typedef bf16x8 frag_t;
+};
+template <> struct AT<f16> {
+  static constexpr int VE = 8, KSTEP = 32, DS = 72, PPAD = 8;
+  typedef f16x8 vec;
+  typedef f16x8 frag_t;
 };
 template <> struct AT<float> {
   static constexpr int VE = 4, KSTEP = 4, DS = 68, PPAD = 4;
@@ -28,24 +31,25 @@ template <> struct AT<float> {
 };
 
 // fragment of 16 "out" rows starting at out0, k-slice starting at k0.  KC image: [out][k]; OC image: [k][out].
-__device__ __forceinline__ bf16x8 fragKC(const bf16* s, int stride, int out0, int k0, int lane) {
-  return *(const bf16x8*)(s + (out0 + (lane & 15)) * stride + k0 + 8 * (lane >> 4));
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> fragKC16(const Hh* s, int stride, int out0, int k0, int lane) {
+  return *(const h16x8<Hh>*)(s + (out0 + (lane & 15)) * stride + k0 + 8 * (lane >> 4));
 }
-__device__ __forceinline__ bf16x8 fragOC(const bf16* s, int stride, int out0, int k0, int lane) {
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> fragOC16(const Hh* s, int stride, int out0, int k0, int lane) {
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const bf16* b = s + (k0 + 8 * g + q) * stride + out0 + 4 * pp;
-  typedef bf16x4_t __attribute__((address_space(3))) * lds4;
-  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
-  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * stride));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return lds_tr8(s + (k0 + 8 * g + q) * stride + out0 + 4 * pp, 4 * stride);
 }
+__device__ __forceinline__ bf16x8 fragKC(const bf16* s, int stride, int out0, int k0, int lane) { return fragKC16(s, stride, out0, k0, lane); }
+__device__ __forceinline__ f16x8 fragKC(const f16* s, int stride, int out0, int k0, int lane) { return fragKC16(s, stride, out0, k0, lane); }
+__device__ __forceinline__ bf16x8 fragOC(const bf16* s, int stride, int out0, int k0, int lane) { return fragOC16(s, stride, out0, k0, lane); }
+__device__ __forceinline__ f16x8 fragOC(const f16* s, int stride, int out0, int k0, int lane) { return fragOC16(s, stride, out0, k0, lane); }
 __device__ __forceinline__ float fragKC(const float* s, int stride, int out0, int k0, int lane) {
   return s[(out0 + (lane & 15)) * stride + k0 + (lane >> 4)];
 }
 __device__ __forceinline__ float fragOC(const float* s, int stride, int out0, int k0, int lane) {
   return s[(k0 + (lane >> 4)) * stride + out0 + (lane & 15)];
 }
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return mfma16(a, b, c); }
+__device__ __forceinline__ f32x4 mma(f16x8 a, f16x8 b, f32x4 c) { return mfma16(a, b, c); }
 __device__ __forceinline__ f32x4 mma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ float group16_max(float v) { return row16_max(v); }
@@ -554,16 +558,19 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_pair_kernel(AttnParams a, At
 static size_t fwd_lds(int dtype, int Nk) {
   const int NKP = (Nk + 31) / 32 * 32;
   if (dtype == DT_BF16) return (size_t)(64 * 72 + 2 * NKP * 72 + 64 * (NKP + 8)) * 2;
+  else if (dtype == DT_F16) return (size_t)(64 * 72 + 2 * NKP * 72 + 64 * (NKP + 8)) * 2;
   return (size_t)(64 * 68 + 2 * NKP * 68 + 64 * (NKP + 4)) * 4;
 }
 static size_t fwd_tiled_lds(int dtype) {
   if (dtype == DT_BF16) return (size_t)(64 * 72 + 2 * KTILE * 72 + 64 * (KTILE + 8)) * 2;
+  else if (dtype == DT_F16) return (size_t)(64 * 72 + 2 * KTILE * 72 + 64 * (KTILE + 8)) * 2;
   return (size_t)(64 * 68 + 2 * KTILE * 68 + 64 * (KTILE + 4)) * 4;
 }
 #define NK_TILED_MAX 512
 static size_t bwd_lds(int dtype, int Nq, int Nk) {
   const int NQP = (Nq + 31) / 32 * 32, NKP = (Nk + 31) / 32 * 32;
   if (dtype == DT_BF16) return (size_t)(2 * NQP * 72 + 2 * NKP * 72 + (bwd_alias(NQP, NKP, NKP + 8, 72) ? 1 : 2) * NQP * (NKP + 8)) * 2;
+  else if (dtype == DT_F16) return (size_t)(2 * NQP * 72 + 2 * NKP * 72 + (bwd_alias(NQP, NKP, NKP + 8, 72) ? 1 : 2) * NQP * (NKP + 8)) * 2;
   return (size_t)(2 * NQP * 68 + 2 * NKP * 68 + (bwd_alias(NQP, NKP, NKP + 4, 68) ? 1 : 2) * NQP * (NKP + 4)) * 4;
 }
 #define LDS_MAX (160 * 1024)
@@ -577,8 +584,8 @@ extern "C" int magic_attn_supported(int dtype, int Nq, int Nk, int backward) {
 }
 
 static int check_common(int dtype, int B, int nh, int Nq, int Nk, int ldq, int ldkv, int ldp, int H) {
-  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
-  const int ve = dtype == DT_BF16 ? 8 : 4;
+  if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  const int ve = dtype_is16(dtype) ? 8 : 4;
   if (B <= 0 || nh <= 0 || Nq <= 0 || Nk <= 0 || H != nh * HD) return MAGIC_ERR_ARG;
   if (ldq % ve || ldkv % ve || ldp % ve || ldp < Nk || H % ve) return MAGIC_ERR_ARG;
   return MAGIC_OK;
@@ -617,10 +624,12 @@ int launch_attn_fwd(int dtype, int, const void* pa, const void* pb, hipStream_t 
       if (q.Nk > 128) {
         const size_t shm = fwd_tiled_lds(dtype);
         if (dtype == DT_BF16) { set_lds(attn_fwd_tiled_kernel<bf16>, shm); hipLaunchKernelGGL(attn_fwd_tiled_kernel<bf16>, grid, block, shm, st, q); }
+        else if (dtype == DT_F16) { set_lds(attn_fwd_tiled_kernel<f16>, shm); hipLaunchKernelGGL(attn_fwd_tiled_kernel<f16>, grid, block, shm, st, q); }
         else { set_lds(attn_fwd_tiled_kernel<float>, shm); hipLaunchKernelGGL(attn_fwd_tiled_kernel<float>, grid, block, shm, st, q); }
       } else {
         const size_t shm = fwd_lds(dtype, q.Nk);
         if (dtype == DT_BF16) { set_lds(attn_fwd_kernel<bf16>, shm); hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, block, shm, st, q); }
+        else if (dtype == DT_F16) { set_lds(attn_fwd_kernel<f16>, shm); hipLaunchKernelGGL(attn_fwd_kernel<f16>, grid, block, shm, st, q); }
         else { set_lds(attn_fwd_kernel<float>, shm); hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, shm, st, q); }
       }
     }
@@ -630,6 +639,7 @@ int launch_attn_fwd(int dtype, int, const void* pa, const void* pb, hipStream_t 
     dim3 grid((a.Nq + 63) / 64, a.nh, a.B);
     const size_t shm = fwd_lds(dtype, a.Nk);
     if (dtype == DT_BF16) { set_lds(attn_fwd_kernel<bf16>, shm); hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, block, shm, st, a); }
+    else if (dtype == DT_F16) { set_lds(attn_fwd_kernel<f16>, shm); hipLaunchKernelGGL(attn_fwd_kernel<f16>, grid, block, shm, st, a); }
     else { set_lds(attn_fwd_kernel<float>, shm); hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, shm, st, a); }
     return launch_status();
   }
@@ -638,6 +648,7 @@ int launch_attn_fwd(int dtype, int, const void* pa, const void* pb, hipStream_t 
   const size_t sa = fwd_lds(dtype, a.Nk), sb = fwd_lds(dtype, b.Nk), shm = sa > sb ? sa : sb;
   dim3 grid(nA + nB);
   if (dtype == DT_BF16) { set_lds(attn_fwd_pair_kernel<bf16>, shm); hipLaunchKernelGGL(attn_fwd_pair_kernel<bf16>, grid, block, shm, st, a, b, nA); }
+  else if (dtype == DT_F16) { set_lds(attn_fwd_pair_kernel<f16>, shm); hipLaunchKernelGGL(attn_fwd_pair_kernel<f16>, grid, block, shm, st, a, b, nA); }
   else { set_lds(attn_fwd_pair_kernel<float>, shm); hipLaunchKernelGGL(attn_fwd_pair_kernel<float>, grid, block, shm, st, a, b, nA); }
   return launch_status();
 }
@@ -676,8 +687,8 @@ int launch_attn_bwd(int dtype, int, const void* pa, const void* pb, hipStream_t 
     dim3 grid(a.nh, a.B);
     const size_t shm = bwd_lds(dtype, a.Nq, a.Nk);
 #define LB(TY, NW) do { set_lds(attn_bwd_kernel<TY, NW>, shm); hipLaunchKernelGGL((attn_bwd_kernel<TY, NW>), grid, dim3(NW * 64), shm, st, a); } while (0)
-    if (bwd_waves8(a)) { if (dtype == DT_BF16) LB(bf16, 8); else LB(float, 8); }
-    else { if (dtype == DT_BF16) LB(bf16, 4); else LB(float, 4); }
+    if (bwd_waves8(a)) { if (dtype == DT_BF16) LB(bf16, 8); else if (dtype == DT_F16) LB(f16, 8); else LB(float, 8); }
+    else { if (dtype == DT_BF16) LB(bf16, 4); else if (dtype == DT_F16) LB(f16, 4); else LB(float, 4); }
 #undef LB
     return launch_status();
   }
@@ -686,8 +697,8 @@ int launch_attn_bwd(int dtype, int, const void* pa, const void* pb, hipStream_t 
   const size_t sa = bwd_lds(dtype, a.Nq, a.Nk), sb = bwd_lds(dtype, b.Nq, b.Nk), shm = sa > sb ? sa : sb;
   dim3 grid(nA + nB);
 #define LP(TY, NW) do { set_lds(attn_bwd_pair_kernel<TY, NW>, shm); hipLaunchKernelGGL((attn_bwd_pair_kernel<TY, NW>), grid, dim3(NW * 64), shm, st, a, b, nA); } while (0)
-  if (bwd_waves8(a) || bwd_waves8(b)) { if (dtype == DT_BF16) LP(bf16, 8); else LP(float, 8); }
-  else { if (dtype == DT_BF16) LP(bf16, 4); else LP(float, 4); }
+  if (bwd_waves8(a) || bwd_waves8(b)) { if (dtype == DT_BF16) LP(bf16, 8); else if (dtype == DT_F16) LP(f16, 8); else LP(float, 8); }
+  else { if (dtype == DT_BF16) LP(bf16, 4); else if (dtype == DT_F16) LP(f16, 4); else LP(float, 4); }
 #undef LP
   return launch_status();
 }

@@ -7,6 +7,12 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+// second 16-bit storage type: IEEE half (11 significand bits against bf16's 8: ~8x less rounding per stored activation / weight; the
+// same MFMA rate, v_mfma_f32_16x16x32_f16).  Every 16-bit kernel is written once over Hh in {bf16, f16}.
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 #define MAGIC_OK 0
 #define MAGIC_ERR_ARG -1
@@ -15,14 +21,42 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define DT_F32 0
 #define DT_BF16 1
+#define DT_F16 2
+static inline bool dtype_ok(int dt) { return dt == DT_F32 || dt == DT_BF16 || dt == DT_F16; }
+static inline bool dtype_is16(int dt) { return dt == DT_BF16 || dt == DT_F16; }
 
 #define WAVE 64
 
 __device__ __forceinline__ float to_f(float x) { return x; }
 __device__ __forceinline__ float to_f(bf16 x) { return (float)x; }
+__device__ __forceinline__ float to_f(f16 x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f(float x);
 template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return (bf16)x; }
+template <> __device__ __forceinline__ f16 from_f<f16>(float x) { return (f16)x; }
+
+// MFMA operand vectors of a 16-bit type, the 16x16x32 product, and the transposing LDS read (ds_read_b64_tr_b16: each lane of a 16-lane
+// group receives element (l & 15) of 4 consecutive rows) -- the only places where bf16 and f16 need different instructions / builtins
+template <typename Hh> struct H16;
+template <> struct H16<bf16> { typedef bf16x8 v8; typedef bf16x4 v4; };
+template <> struct H16<f16> { typedef f16x8 v8; typedef f16x4 v4; };
+template <typename Hh> using h16x8 = typename H16<Hh>::v8;
+template <typename Hh> using h16x4 = typename H16<Hh>::v4;
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ bf16x4 lds_tr4(const bf16* p) {
+  typedef bf16x4 __attribute__((address_space(3))) * lds4;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)p);
+}
+__device__ __forceinline__ f16x4 lds_tr4(const f16* p) {
+  typedef s16x4 __attribute__((address_space(3))) * lds4;
+  return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)p));
+}
+// two transposed reads `pitch4` elements (= 4 rows) apart, concatenated: the 8 k-values of one lane's MFMA operand
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> lds_tr8(const Hh* p, int pitch4) {
+  const h16x4<Hh> lo = lds_tr4(p), hi = lds_tr4(p + pitch4);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 // Cross-lane reductions as DPP moves (VALU data-parallel primitives: quad permutes and row mirrors inside a 16-lane row), not
 // __shfl_xor: hipcc lowers every __shfl_xor to ds_bpermute_b32, a round trip through the LDS crossbar (~100 cycles, each step of

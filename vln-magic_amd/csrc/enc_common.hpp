@@ -14,27 +14,23 @@
 #define KROWS 96      // key rows the Q|K|V image provides for (PV consumes keys in steps of 32)
 #define NWAVE 8
 
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_e;
 // the GEMM stages are fully unrolled (their weight fragments are register arrays with static indices); without a fence per k-step the
 // scheduler hoists every LDS fragment read of a stage to its top and spills hundreds of registers
 #define KSTEP_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ f32x4 emma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 emma(bf16x8 a, bf16x8 b, f32x4 c) { return mfma16(a, b, c); }
+__device__ __forceinline__ f32x4 emma(f16x8 a, f16x8 b, f32x4 c) { return mfma16(a, b, c); }
 // MFMA operand fragment (A or B) of 16 rows x 32 k from a k-contiguous image: lane l holds X[row0 + (l&15)][k0 + 8*(l>>4) .. +7]
-__device__ __forceinline__ bf16x8 lfrag(const bf16* s, int pitch, int row0, int k0, int lane) {
-  return *(const bf16x8*)(s + (row0 + (lane & 15)) * pitch + k0 + 8 * (lane >> 4));
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> lfrag(const Hh* s, int pitch, int row0, int k0, int lane) {
+  return *(const h16x8<Hh>*)(s + (row0 + (lane & 15)) * pitch + k0 + 8 * (lane >> 4));
 }
-__device__ __forceinline__ bf16x8 gfrag(const bf16* __restrict__ W, int ldw, int row0, int k0, int lane) {
-  return *(const bf16x8*)(W + (long long)(row0 + (lane & 15)) * ldw + k0 + 8 * (lane >> 4));
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> gfrag(const Hh* __restrict__ W, int ldw, int row0, int k0, int lane) {
+  return *(const h16x8<Hh>*)(W + (long long)(row0 + (lane & 15)) * ldw + k0 + 8 * (lane >> 4));
 }
 // B fragment from a [k][n] image (V: keys x head dims), transposed on the way out of LDS
-__device__ __forceinline__ bf16x8 tfrag(const bf16* s, int pitch, int n0, int k0, int lane) {
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> tfrag(const Hh* s, int pitch, int n0, int k0, int lane) {
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const bf16* b = s + (k0 + 8 * g + q) * pitch + n0 + 4 * pp;
-  typedef bf16x4_e __attribute__((address_space(3))) * lds4;
-  const bf16x4_e lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
-  const bf16x4_e hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * pitch));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return lds_tr8(s + (k0 + 8 * g + q) * pitch + n0 + 4 * pp, 4 * pitch);
 }
 // GELU on the 40 K elements a text workgroup produces per layer: libm's erff is ~40 instructions; this rational form (Abramowitz &
 // Stegun 7.1.26, |error| <= 1.5e-7) is ~15 and indistinguishable after the bf16 rounding of the result
@@ -56,11 +52,11 @@ __device__ __forceinline__ float g16_sum(float v) { return row16_sum(v); }
 __device__ __forceinline__ float g16_max(float v) { return row16_max(v); }
 
 // cooperative copy of `rows` x `cols` bf16 from an LDS image to global rows (16-byte vectors)
-__device__ __forceinline__ void copy_out(const bf16* s, int pitch, bf16* g, long long ldg, int rows, int cols, int tid) {
+template <typename Hh> __device__ __forceinline__ void copy_out(const Hh* s, int pitch, Hh* g, long long ldg, int rows, int cols, int tid) {
   const int cpr = cols / 8;
   for (int id = tid; id < rows * cpr; id += NWAVE * 64) {
     const int r = id / cpr, c = (id % cpr) * 8;
-    *(bf16x8*)(g + (long long)r * ldg + c) = *(const bf16x8*)(s + r * pitch + c);
+    *(h16x8<Hh>*)(g + (long long)r * ldg + c) = *(const h16x8<Hh>*)(s + r * pitch + c);
   }
 }
 

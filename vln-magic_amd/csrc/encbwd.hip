@@ -22,18 +22,19 @@
 #include <cstring>
 
 
-struct RbwSeg {
+template <typename Hh> struct RbwSegT {
   int M, kt;                         // kt: k-steps of the tail product (12: dQKV [M,3H]; 4: a dQ [M,H]; 0: no product, dx = dao_n: top of a stack)
-  const bf16* dqkv_n; const bf16* WqkvT_n; const bf16* dao_n;      // tail of the next block (dqkv_n == null: d_fo / d_fod are given)
-  const bf16* dfo_in; const bf16* dfod_in;
-  const bf16* y2; const float* rstd2; const float* g2; const float* b2; float* dg2; float* db2;     // this block's output LayerNorm
-  const bf16* z; const bf16* W2T; const bf16* W1T;                                                  // [M, I]; [I, H]; [H, I]
-  const bf16* y1; const float* rstd1; const float* g1; const float* b1; float* dg1; float* db1;     // attention-output LayerNorm
-  const bf16* WoT;                                                                                  // [H, H]
-  bf16 *dfo, *dfod, *dz, *daod, *dao, *dctx;                        // outputs (dfo / dfod only when the tail runs here)
+  const Hh* dqkv_n; const Hh* WqkvT_n; const Hh* dao_n;      // tail of the next block (dqkv_n == null: d_fo / d_fod are given)
+  const Hh* dfo_in; const Hh* dfod_in;
+  const Hh* y2; const float* rstd2; const float* g2; const float* b2; float* dg2; float* db2;     // this block's output LayerNorm
+  const Hh* z; const Hh* W2T; const Hh* W1T;                                                  // [M, I]; [I, H]; [H, I]
+  const Hh* y1; const float* rstd1; const float* g1; const float* b1; float* dg1; float* db1;     // attention-output LayerNorm
+  const Hh* WoT;                                                                                  // [H, H]
+  Hh *dfo, *dfod, *dz, *daod, *dao, *dctx;                        // outputs (dfo / dfod only when the tail runs here)
   unsigned site_out, site_ao;
 };
-struct RbwParams { RbwSeg seg[2]; int nseg, blocks0; float p_hidden; int pad1; const unsigned* seed; };
+template <typename Hh> struct RbwParamsT { RbwSegT<Hh> seg[2]; int nseg, blocks0; float p_hidden; int pad1; const unsigned* seed; };
+typedef RbwParamsT<bf16> RbwParams; typedef RbwSegT<bf16> RbwSeg;      // host side: pointers only, one layout for both 16-bit types
 
 // exact-enough gelu'(x) = Phi(x) + x phi(x) with the same rational erf as gelu_fast (one exp shared by both terms)
 __device__ __forceinline__ float dgelu_fast(float x) {
@@ -47,23 +48,23 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 }
 
 // rows x cols bf16 from global rows (row < nvalid, else zeros) into an LDS image
-__device__ __forceinline__ void load_rows_img(bf16* s, int pitch, const bf16* g, long long ldg, int rows, int cols, int nvalid, int tid) {
+template <typename Hh> __device__ __forceinline__ void load_rows_img(Hh* s, int pitch, const Hh* g, long long ldg, int rows, int cols, int nvalid, int tid) {
   const int cpr = cols / 8;
   for (int id = tid; id < rows * cpr; id += NWAVE * 64) {
     const int r = id / cpr, c = (id % cpr) * 8;
-    bf16x8 v;
+    h16x8<Hh> v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (bf16)0.0f;
-    if (r < nvalid) v = *(const bf16x8*)(g + (long long)r * ldg + c);
-    *(bf16x8*)(s + r * pitch + c) = v;
+    for (int e = 0; e < 8; ++e) v[e] = (Hh)0.0f;
+    if (r < nvalid) v = *(const h16x8<Hh>*)(g + (long long)r * ldg + c);
+    *(h16x8<Hh>*)(s + r * pitch + c) = v;
   }
 }
 
 // LayerNorm backward over full rows, wave w owning columns [16w, 16w+16): v = acc (+ residual already added) is dL/dy; writes
 // dx (residual branch) and dx * dropout mask (dense branch) as bf16 into two LDS images; gamma / beta gradients by one atomic per column
-template <int NRT>
-__device__ __forceinline__ void ln_bwd_rows(f32x4 (&acc)[NRT], const bf16* sY, const float* rstd_g, const float gm, const float bt, float* dgamma,
-                                            float* dbeta, float* red, bf16* sSum, bf16* sDense, const int m0, const int M, const DropState& ds,
+template <int NRT, typename Hh>
+__device__ __forceinline__ void ln_bwd_rows(f32x4 (&acc)[NRT], const Hh* sY, const float* rstd_g, const float gm, const float bt, float* dgamma,
+                                            float* dbeta, float* red, Hh* sSum, Hh* sDense, const int m0, const int M, const DropState& ds,
                                             const int w, const int lane) {
   constexpr int RB_ROWS = NRT * 16;
   const int g = lane >> 4, c16 = lane & 15, col = w * 16 + c16;
@@ -106,28 +107,28 @@ __device__ __forceinline__ void ln_bwd_rows(f32x4 (&acc)[NRT], const bf16* sY, c
       const float m1 = t1 * (1.0f / EH), m2 = t2 * (1.0f / EH);
       const float rs = (m0 + rr < M) ? rstd_g[m0 + rr] : 0.f;
       const float d = rs * (acc[i][r] - m1 - xh[i][r] * m2);
-      sSum[rr * XS + col] = from_f<bf16>(d);
-      sDense[rr * XS + col] = from_f<bf16>(ds.on ? d * drop_mul(ds, (unsigned)((m0 + rr) * EH + col)) : d);
+      sSum[rr * XS + col] = from_f<Hh>(d);
+      sDense[rr * XS + col] = from_f<Hh>(ds.on ? d * drop_mul(ds, (unsigned)((m0 + rr) * EH + col)) : d);
     }
 }
 
 // NRT = row tiles of 16 per workgroup.  2 (32 rows): two workgroups per CU, 128 registers per lane, weight fragments one chunk of four
 // k-steps ahead of their use.  4 (64 rows): one workgroup per CU, 256 registers, a whole product's fragments ahead -- and half the
 // weight bytes streamed from L2 per row (every workgroup streams all 393 KB of the block's matrices).
-template <int NRT>
-__device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* rb_smem) {
+template <int NRT, typename Hh>
+__device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned char* rb_smem) {
   constexpr int RB_ROWS = NRT * 16;
   constexpr bool DEEP = NRT >= 4;
   int blk = blockIdx.x, sidx = 0;
   if (blk >= p.blocks0) { blk -= p.blocks0; sidx = 1; }
-  const RbwSeg& sg = p.seg[sidx];
-  bf16* sZ = (bf16*)rb_smem;                   // [32][GS]  z, overwritten in place by d_z
-  bf16* sY2 = sZ + RB_ROWS * GS;               // [32][XS]  this block's output (its LayerNorm's y); later the d_ctx staging image
-  bf16* sR = sY2 + RB_ROWS * XS;               // [32][XS]  d_ao of the next block (residual of the tail)
-  bf16* sFo = sR + RB_ROWS * XS;               // [32][XS]  d_fo
-  bf16* sD = sFo + RB_ROWS * XS;               // [32][XS]  d_fod, later d_aod
-  bf16* sY1 = sD + RB_ROWS * XS;               // [32][XS]  a (the attention-output LayerNorm's y)
-  bf16* sAo = sR;                              // [..][XS]  d_ao (the tail's residual image is dead by then)
+  const RbwSegT<Hh>& sg = p.seg[sidx];
+  Hh* sZ = (Hh*)rb_smem;                   // [32][GS]  z, overwritten in place by d_z
+  Hh* sY2 = sZ + RB_ROWS * GS;               // [32][XS]  this block's output (its LayerNorm's y); later the d_ctx staging image
+  Hh* sR = sY2 + RB_ROWS * XS;               // [32][XS]  d_ao of the next block (residual of the tail)
+  Hh* sFo = sR + RB_ROWS * XS;               // [32][XS]  d_fo
+  Hh* sD = sFo + RB_ROWS * XS;               // [32][XS]  d_fod, later d_aod
+  Hh* sY1 = sD + RB_ROWS * XS;               // [32][XS]  a (the attention-output LayerNorm's y)
+  Hh* sAo = sR;                              // [..][XS]  d_ao (the tail's residual image is dead by then)
   float* red = (float*)(sY1 + RB_ROWS * XS);   // [2][8][rows]
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
   const int m0 = blk * RB_ROWS, M = sg.M;
@@ -140,13 +141,13 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
   dd.seed = p.seed; dd.p = p.p_hidden;
   // ---- weights of the first two products + small parameters, issued before anything else
   // (two workgroups per CU = 128 registers per lane: weight fragments arrive in chunks of four k-steps, one chunk ahead of their use)
-  bf16x8 wq[12];
+  h16x8<Hh> wq[12];
   if (tail) {
 #pragma unroll
     for (int ks = 0; ks < (DEEP ? 12 : 4); ++ks)
       if (ks < kt) wq[ks] = gfrag(sg.WqkvT_n, ldq, w * 16, ks * 32, lane);
   }
-  bf16x8 w2[4][4];
+  h16x8<Hh> w2[4][4];
   const float gm2 = sg.g2[colw], bt2 = sg.b2[colw];
   const float gm1 = shortm ? 0.f : sg.g1[colw], bt1 = shortm ? 0.f : sg.b1[colw];     // (the short chain has no second LayerNorm)
   // ---- stage the block's rows: z, a, and either (out, d_ao of the next block) for the tail or the given (d_fo, d_fod)
@@ -184,13 +185,13 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
     // z rows -> registers now (their round trip hides under the LayerNorm backward); they go into the image once every wave is past
     // the barrier inside ln_bwd_rows, i.e. done reading the dQKV rows
     constexpr int ZIT = RB_ROWS * (EI / 8) / (NWAVE * 64);
-    bf16x8 zr[ZIT];
+    h16x8<Hh> zr[ZIT];
 #pragma unroll
     for (int it = 0; it < ZIT; ++it) {
       const int id = tid + it * NWAVE * 64, r = id / (EI / 8), c = (id % (EI / 8)) * 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) zr[it][e] = (bf16)0.0f;
-      if (r < nv && !shortm) zr[it] = *(const bf16x8*)(sg.z + (long long)(m0 + r) * EI + c);
+      for (int e = 0; e < 8; ++e) zr[it][e] = (Hh)0.0f;
+      if (r < nv && !shortm) zr[it] = *(const h16x8<Hh>*)(sg.z + (long long)(m0 + r) * EI + c);
     }
 #pragma unroll
     for (int i = 0; i < NRT; ++i)
@@ -202,19 +203,19 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
 #pragma unroll
     for (int it = 0; it < ZIT; ++it) {
       const int id = tid + it * NWAVE * 64, r = id / (EI / 8), c = (id % (EI / 8)) * 8;
-      *(bf16x8*)(sZ + r * GS + c) = zr[it];
+      *(h16x8<Hh>*)(sZ + r * GS + c) = zr[it];
     }
     __syncthreads();                             // d_fo / d_fod images and the z image complete
     copy_out(sFo, XS, sg.dfo + (long long)m0 * EH, EH, nv, EH, tid);
     copy_out(sD, XS, sg.dfod + (long long)m0 * EH, EH, nv, EH, tid);
   }
-  bf16x8 wo[4];
+  h16x8<Hh> wo[4];
   if (shortm) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) wo[ks] = gfrag(sg.WoT, EH, w * 16, ks * 32, lane);
   } else {
   // ================= FFN: d_z = (d_fod W2) * gelu'(z) : 32 column tiles, 4 per wave =================
-  bf16x8 w1[16];
+  h16x8<Hh> w1[16];
   {
     f32x4 acc[NRT][4];
 #pragma unroll
@@ -231,7 +232,7 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
       }
 #pragma unroll
       for (int i = 0; i < NRT; ++i) {
-        const bf16x8 a = lfrag(sD, XS, i * 16, ks * 32, lane);
+        const h16x8<Hh> a = lfrag(sD, XS, i * 16, ks * 32, lane);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[i][ct] = emma(a, w2[ct][ks], acc[i][ct]);
       }
@@ -247,8 +248,8 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rr = i * 16 + 4 * g + r;
-          bf16* e = sZ + rr * GS + col;                      // each element of the image is read and rewritten by exactly one lane
-          *e = from_f<bf16>(acc[i][ct][r] * dgelu_fast(to_f(*e)));
+          Hh* e = sZ + rr * GS + col;                      // each element of the image is read and rewritten by exactly one lane
+          *e = from_f<Hh>(acc[i][ct][r] * dgelu_fast(to_f(*e)));
         }
     }
   }
@@ -301,25 +302,25 @@ __device__ __forceinline__ void rowbwd_body(const RbwParams& p, unsigned char* r
 #pragma unroll
     for (int i = 0; i < NRT; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sY2[(i * 16 + 4 * g + r) * XS + colw] = from_f<bf16>(acc[i][r]);
+      for (int r = 0; r < 4; ++r) sY2[(i * 16 + 4 * g + r) * XS + colw] = from_f<Hh>(acc[i][r]);
   }
   __syncthreads();
   copy_out(sY2, XS, sg.dctx + (long long)m0 * EH, EH, nv, EH, tid);
 }
 
-__global__ __launch_bounds__(512, 4) void rowbwd16_kernel(RbwParams p) {
+template <typename Hh> __global__ __launch_bounds__(512, 4) void rowbwd16_kernel(RbwParamsT<Hh> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
   rowbwd_body<1>(p, rb_smem);
 }
-__global__ __launch_bounds__(512, 4) void rowbwd32_kernel(RbwParams p) {
+template <typename Hh> __global__ __launch_bounds__(512, 4) void rowbwd32_kernel(RbwParamsT<Hh> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
   rowbwd_body<2>(p, rb_smem);
 }
-__global__ __launch_bounds__(512, 2) void rowbwd64_kernel(RbwParams p) {
+template <typename Hh> __global__ __launch_bounds__(512, 2) void rowbwd64_kernel(RbwParamsT<Hh> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
   rowbwd_body<4>(p, rb_smem);
 }
-static size_t rbw_lds_bytes(int rows) { return (size_t)(rows * GS + 5 * rows * XS) * sizeof(bf16) + (size_t)2 * NWAVE * rows * sizeof(float); }
+static size_t rbw_lds_bytes(int rows) { return (size_t)(rows * GS + 5 * rows * XS) * 2 + (size_t)2 * NWAVE * rows * sizeof(float); }
 // rows per workgroup: MAGIC_RBW_ROWS = 16 / 32 / 64 forces one shape; default (0) = 16 rows when that still leaves the launch with no more
 // workgroups than CUs (the text stack alone: 3840 rows = 240 workgroups instead of 120 on 256 CUs), else 32 (measured: 64 rows 51.6 us vs 42.7)
 static int rbw_rows_env() {
@@ -333,11 +334,11 @@ static int rbw_ncu() {
   return n;
 }
 
-extern "C" int magic_rowbwd_supported(int dtype, int H, int I) { return dtype == DT_BF16 && H == EH && I == EI; }
+extern "C" int magic_rowbwd_supported(int dtype, int H, int I) { return dtype_is16(dtype) && H == EH && I == EI; }
 extern "C" int magic_rowbwd_params_bytes() { return (int)sizeof(RbwParams); }
 
-extern "C" int magic_rowbwd(const void* params, int nbytes, void* stream) {
-  if (!params || nbytes != (int)sizeof(RbwParams)) return MAGIC_ERR_ARG;
+extern "C" int magic_rowbwd(int dtype, const void* params, int nbytes, void* stream) {
+  if (!params || nbytes != (int)sizeof(RbwParams) || !dtype_is16(dtype)) return MAGIC_ERR_ARG;
   RbwParams p;
   memcpy(&p, params, sizeof(p));
   if (p.nseg < 1 || p.nseg > 2 || !drop_args_ok(p.seed, p.p_hidden)) return MAGIC_ERR_ARG;
@@ -370,29 +371,39 @@ extern "C" int magic_rowbwd(const void* params, int nbytes, void* stream) {
   const size_t shm = rbw_lds_bytes(rows);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)rowbwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbw_lds_bytes(16));
-    (void)hipFuncSetAttribute((const void*)rowbwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbw_lds_bytes(32));
-    (void)hipFuncSetAttribute((const void*)rowbwd64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbw_lds_bytes(64));
+#define RBW_ATTR(TY)                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)rowbwd16_kernel<TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbw_lds_bytes(16)); \
+    (void)hipFuncSetAttribute((const void*)rowbwd32_kernel<TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbw_lds_bytes(32)); \
+    (void)hipFuncSetAttribute((const void*)rowbwd64_kernel<TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rbw_lds_bytes(64))
+    RBW_ATTR(bf16); RBW_ATTR(f16);
+#undef RBW_ATTR
     attr_set = true;
   }
-  if (rows == 16) hipLaunchKernelGGL(rowbwd16_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
-  else if (rows == 32) hipLaunchKernelGGL(rowbwd32_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(rowbwd64_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+#define RBW_LAUNCH(TY, PP)                                                                                          \
+  do {                                                                                                              \
+    if (rows == 16) hipLaunchKernelGGL(rowbwd16_kernel<TY>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, PP); \
+    else if (rows == 32) hipLaunchKernelGGL(rowbwd32_kernel<TY>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, PP); \
+    else hipLaunchKernelGGL(rowbwd64_kernel<TY>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, PP);            \
+  } while (0)
+  if (dtype == DT_BF16) RBW_LAUNCH(bf16, p);
+  else { RbwParamsT<f16> pf; static_assert(sizeof(pf) == sizeof(p), "layout"); memcpy(&pf, &p, sizeof(pf)); RBW_LAUNCH(f16, pf); }
+#undef RBW_LAUNCH
   return launch_status();
 }
 
 // ---- transposed bf16 shadow: dst[off .. off + rows*cols) = transpose of the [rows, cols] matrix at src[off ..) -----------------------
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;      // 2-byte moves: the same kernel serves the bf16 and the f16 shadow
 #define TSP_MAX 160
 struct TSpans { long long off[TSP_MAX]; int rows[TSP_MAX]; int cols[TSP_MAX]; int tile0[TSP_MAX + 1]; int n; };
-__global__ __launch_bounds__(256) void transpose_spans_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, TSpans t) {
-  __shared__ bf16 tile[32][34];
+__global__ __launch_bounds__(256) void transpose_spans_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, TSpans t) {
+  __shared__ unsigned short tile[32][34];
   const int id = blockIdx.x;
   int s = 0;
   for (int i = 1; i < t.n; ++i) s += (id >= t.tile0[i]) ? 1 : 0;
   const int local = id - t.tile0[s], R = t.rows[s], C = t.cols[s];
   const int tc = (C + 31) / 32, r0 = (local / tc) * 32, c0 = (local % tc) * 32;
-  const bf16* a = src + t.off[s];
-  bf16* b = dst + t.off[s];
+  const unsigned short* a = src + t.off[s];
+  unsigned short* b = dst + t.off[s];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int j = ty; j < 32; j += 8)
     if (r0 + j < R && c0 + tx < C) tile[j][tx] = a[(long long)(r0 + j) * C + c0 + tx];
@@ -402,28 +413,28 @@ __global__ __launch_bounds__(256) void transpose_spans_kernel(const bf16* __rest
 }
 // every span a multiple of 64 x 64 at 16-byte-aligned offsets (all weight matrices of the H = 128 / FFN 512 blocks): 64 x 64 tiles, 16-byte
 // global loads and stores on both sides (the 32 x 32 kernel above moves 2 bytes per lane and access: 20 us for the 3 M elements of a step)
-__global__ __launch_bounds__(256) void transpose_spans64_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, TSpans t) {
-  __shared__ bf16 tile[64][72];
+__global__ __launch_bounds__(256) void transpose_spans64_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, TSpans t) {
+  __shared__ unsigned short tile[64][72];
   const int id = blockIdx.x;
   int s = 0;
   for (int i = 1; i < t.n; ++i) s += (id >= t.tile0[i]) ? 1 : 0;
   const int local = id - t.tile0[s], R = t.rows[s], C = t.cols[s];
   const int tc = C / 64, r0 = (local / tc) * 64, c0 = (local % tc) * 64;
-  const bf16* a = src + t.off[s];
-  bf16* b = dst + t.off[s];
+  const unsigned short* a = src + t.off[s];
+  unsigned short* b = dst + t.off[s];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int ch = threadIdx.x + it * 256, r = ch >> 3, c = (ch & 7) * 8;
-    *(bf16x8*)&tile[r][c] = *(const bf16x8*)(a + (long long)(r0 + r) * C + c0 + c);
+    *(u16x8*)&tile[r][c] = *(const u16x8*)(a + (long long)(r0 + r) * C + c0 + c);
   }
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int ch = threadIdx.x + it * 256, cc = ch >> 3, rr = (ch & 7) * 8;        // output row c0 + cc, 8 consecutive source rows
-    bf16x8 v;
+    u16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[rr + e][cc];
-    *(bf16x8*)(b + (long long)(c0 + cc) * R + r0 + rr) = v;
+    *(u16x8*)(b + (long long)(c0 + cc) * R + r0 + rr) = v;
   }
 }
 // offs / rows / cols: host arrays of n spans (element offsets into the flat bf16 buffers)
@@ -443,8 +454,8 @@ extern "C" int magic_transpose_spans(const void* src, void* dst, int n, const lo
       tiles += ((rows[base + i] + ts - 1) / ts) * ((cols[base + i] + ts - 1) / ts);
     }
     t.tile0[t.n] = tiles;
-    if (all64) hipLaunchKernelGGL(transpose_spans64_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, t);
-    else hipLaunchKernelGGL(transpose_spans_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, t);
+    if (all64) hipLaunchKernelGGL(transpose_spans64_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src, (unsigned short*)dst, t);
+    else hipLaunchKernelGGL(transpose_spans_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src, (unsigned short*)dst, t);
   }
   return launch_status();
 }

@@ -17,23 +17,24 @@
 #include <cstdlib>
 #include <cstring>
 
-struct EncLayer {
-  const bf16* Wqkv; const float* bqkv;                                   // [3H, H] (q | k | v rows), [3H]
-  const bf16* Wo; const float* bo; const float* g1; const float* be1;    // attention.output.dense / LayerNorm
-  const bf16* W1; const float* bi;                                       // intermediate.dense [I, H]
-  const bf16* W2; const float* bo2; const float* g2; const float* be2;   // output.dense [H, I] / LayerNorm
-  bf16 *qkv, *P, *Pd, *ctx, *a, *z, *g, *out;                            // saved for the backward ([M,3H], [B,nh,N,ldp] x2, [M,H], [M,H], [M,I], [M,I], [M,H])
+template <typename Hh> struct EncLayerT {
+  const Hh* Wqkv; const float* bqkv;                                   // [3H, H] (q | k | v rows), [3H]
+  const Hh* Wo; const float* bo; const float* g1; const float* be1;    // attention.output.dense / LayerNorm
+  const Hh* W1; const float* bi;                                       // intermediate.dense [I, H]
+  const Hh* W2; const float* bo2; const float* g2; const float* be2;   // output.dense [H, I] / LayerNorm
+  Hh *qkv, *P, *Pd, *ctx, *a, *z, *g, *out;                            // saved for the backward ([M,3H], [B,nh,N,ldp] x2, [M,H], [M,H], [M,I], [M,I], [M,H])
   float *rstd_a, *rstd_o;
   unsigned site_attn, site_ao, site_out, pad_;
 };
-struct EncSeg { const bf16* x; const unsigned char* kmask; int nsamp, N, ldp, nlayers; EncLayer L[6]; };
-struct EncParams { EncSeg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; };
+template <typename Hh> struct EncSegT { const Hh* x; const unsigned char* kmask; int nsamp, N, ldp, nlayers; EncLayerT<Hh> L[6]; };
+template <typename Hh> struct EncParamsT { EncSegT<Hh> seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; };
+typedef EncParamsT<bf16> EncParams; typedef EncSegT<bf16> EncSeg; typedef EncLayerT<bf16> EncLayer;      // host side: the layout holds pointers only, the same for both 16-bit types
 
 // out[row][w*16 + c16] = LayerNorm_row(acc + bias (dropped) + residual) for the workgroup's NRT*16 rows; every wave owns 16 of the
 // 128 columns, row statistics go through LDS (two passes: mean, then centred variance -- as linear_ln_kernel).
-template <int NRT>
-__device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, const float gv, const float btv, const bf16* sRes,
-                                         float* red, bf16* sOut, float* gRstd, int N, long long row_base, float eps,
+template <int NRT, typename Hh>
+__device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, const float gv, const float btv, const Hh* sRes,
+                                         float* red, Hh* sOut, float* gRstd, int N, long long row_base, float eps,
                                          const DropState& ds, int w, int lane) {
   const int g = lane >> 4, c16 = lane & 15, col = w * 16 + c16;
   float s[NRT][4];
@@ -90,8 +91,8 @@ __device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, cons
 #pragma unroll
       for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * MAXROWS + rr];
       const float rstd = rsqrtf(t * (1.0f / EH) + eps);
-      const bf16 y = from_f<bf16>((acc[i][r] - mean[i][r]) * rstd * gv + btv);
-      sOut[rr * XS + col] = (rr < N) ? y : (bf16)0.0f;        // rows past the sample stay zero (they feed the next GEMM as padding)
+      const Hh y = from_f<Hh>((acc[i][r] - mean[i][r]) * rstd * gv + btv);
+      sOut[rr * XS + col] = (rr < N) ? y : (Hh)0.0f;        // rows past the sample stay zero (they feed the next GEMM as padding)
       if (rr < N && w == 0 && c16 == 0) gRstd[row_base + rr] = rstd;
     }
 }
@@ -103,13 +104,13 @@ __device__ long long enc_ticks[2][16];        // [segment][stage mark] of block 
 #define ENC_MARK(i)
 #endif
 
-template <int NRT>
-__device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, const int samp, unsigned char* smem) {
-  bf16* sX = (bf16*)smem;                        // [80][XS]   layer input / residual of the attention block
-  bf16* sA = sX + MAXROWS * XS;                  // [80][XS]   attention context, then (after the norm) the FFN's input / residual
-  bf16* sQKV = sA + MAXROWS * XS;                // [96][QS]   Q | K | V
-  bf16* sP = sQKV + KROWS * QS;                  // [8][16][PSW] per-wave probability tiles
-  bf16* sG = sQKV;                               // [80][GS]   GELU output (aliases Q|K|V and the probability tiles, dead by then)
+template <int NRT, typename Hh>
+__device__ __forceinline__ void enc_body(const EncParamsT<Hh>& p, const EncSegT<Hh>& sg, const int samp, unsigned char* smem) {
+  Hh* sX = (Hh*)smem;                        // [80][XS]   layer input / residual of the attention block
+  Hh* sA = sX + MAXROWS * XS;                  // [80][XS]   attention context, then (after the norm) the FFN's input / residual
+  Hh* sQKV = sA + MAXROWS * XS;                // [96][QS]   Q | K | V
+  Hh* sP = sQKV + KROWS * QS;                  // [8][16][PSW] per-wave probability tiles
+  Hh* sG = sQKV;                               // [80][GS]   GELU output (aliases Q|K|V and the probability tiles, dead by then)
   float* red = (float*)(sP + NWAVE * 16 * PSW);  // [8][80]    LayerNorm partial sums
   const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = sg.N, ldp = sg.ldp;
@@ -119,14 +120,14 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
 
   // ---- layer-0 input -> sX (rows past the sample zero)
   {
-    const bf16* x = sg.x + row_base * EH;
+    const Hh* x = sg.x + row_base * EH;
     for (int id = tid; id < ROWS * (EH / 8); id += NWAVE * 64) {
       const int r = id / (EH / 8), c = (id % (EH / 8)) * 8;
-      bf16x8 v;
+      h16x8<Hh> v;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16)0.0f;
-      if (r < N) v = *(const bf16x8*)(x + (long long)r * EH + c);
-      *(bf16x8*)(sX + r * XS + c) = v;
+      for (int e = 0; e < 8; ++e) v[e] = (Hh)0.0f;
+      if (r < N) v = *(const h16x8<Hh>*)(x + (long long)r * EH + c);
+      *(h16x8<Hh>*)(sX + r * XS + c) = v;
     }
   }
   DropDesc dd;
@@ -139,7 +140,7 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
     kbias[j] = (key < N && sg.kmask && !sg.kmask[(long long)samp * N + key]) ? -10000.0f : 0.f;
   }
   for (int l = 0; l < sg.nlayers; ++l) {
-    const EncLayer& L = sg.L[l];
+    const EncLayerT<Hh>& L = sg.L[l];
     // every per-lane index below derives from `lane`; laundering it per layer keeps the compiler from hoisting the layer-invariant
     // row / column / predicate values of all five stages out of this loop (hundreds of registers, all spilled)
     int lane = lane0;
@@ -156,7 +157,7 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
     const float pb_o = L.bo[w * 16 + c16], pg_1 = L.g1[w * 16 + c16], pe_1 = L.be1[w * 16 + c16];
     const float pb_2 = L.bo2[w * 16 + c16], pg_2 = L.g2[w * 16 + c16], pe_2 = L.be2[w * 16 + c16];
     // ================= A: Q|K|V = x Wqkv^T + b : 24 column tiles, 3 per wave =================
-    bf16x8 bw[3][4];
+    h16x8<Hh> bw[3][4];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
@@ -165,10 +166,10 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
     // previous layer overlapped them
     for (int id = tid; id < (KROWS - ROWS) * (384 / 8); id += NWAVE * 64) {
       const int r = ROWS + id / 48, c = (id % 48) * 8;
-      bf16x8 zv;
+      h16x8<Hh> zv;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) zv[e] = (bf16)0.0f;
-      *(bf16x8*)(sQKV + r * QS + c) = zv;
+      for (int e = 0; e < 8; ++e) zv[e] = (Hh)0.0f;
+      *(h16x8<Hh>*)(sQKV + r * QS + c) = zv;
     }
     __syncthreads();                              // sX complete (layer input), zero rows in place
     ENC_MARK(1);
@@ -182,7 +183,7 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
-          const bf16x8 a = lfrag(sX, XS, i * 16, ks * 32, lane);
+          const h16x8<Hh> a = lfrag(sX, XS, i * 16, ks * 32, lane);
 #pragma unroll
           for (int ct = 0; ct < 3; ++ct) acc[i][ct] = emma(a, bw[ct][ks], acc[i][ct]);
         }
@@ -195,11 +196,11 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
 #pragma unroll
         for (int i = 0; i < NRT; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sQKV[(i * 16 + 4 * g + r) * QS + col] = from_f<bf16>(acc[i][ct][r] + bv);
+          for (int r = 0; r < 4; ++r) sQKV[(i * 16 + 4 * g + r) * QS + col] = from_f<Hh>(acc[i][ct][r] + bv);
       }
     }
     // prefetch the output projection's fragments (used after the attention)
-    bf16x8 wo[4];
+    h16x8<Hh> wo[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) wo[ks] = gfrag(L.Wo, EH, w * 16, ks * 32, lane);
     __syncthreads();                              // Q|K|V image complete
@@ -207,14 +208,14 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
     ENC_MARK(2);
     // ================= B: attention, unit = (head, 16-query tile) =================
     // first FFN matrix (16 fragments: this wave's 4 column tiles x 4 k-steps): issued ahead of the attention's stores
-    bf16x8 w1[4][4];
+    h16x8<Hh> w1[4][4];
 #pragma unroll
     for (int ct = 0; ct < (NRT > 4 ? 2 : 4); ++ct)      // 80-row samples: half now, half after the attention (register budget)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) w1[ct][ks] = gfrag(L.W1, EH, (4 * w + ct) * 16, ks * 32, lane);
     dd.site = L.site_attn; dd.p = p.p_attn;
     const DropState dsa = drop_init(dd);
-    bf16* sPw = sP + w * 16 * PSW;
+    Hh* sPw = sP + w * 16 * PSW;
     for (int u = w; u < ENH * NRT; u += NWAVE) {
       const int h = u / NRT, rt = u % NRT;
       f32x4 sc[NRT];
@@ -222,7 +223,7 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
       for (int j = 0; j < NRT; ++j) sc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 a = lfrag(sQKV, QS, rt * 16, h * EHD + ks * 32, lane);
+        const h16x8<Hh> a = lfrag(sQKV, QS, rt * 16, h * EHD + ks * 32, lane);
 #pragma unroll
         for (int j = 0; j < NRT; ++j) sc[j] = emma(a, lfrag(sQKV, QS, j * 16, EH + h * EHD + ks * 32, lane), sc[j]);
       }
@@ -254,21 +255,21 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
 #pragma unroll
       for (int j = 0; j < NRT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sPw[(4 * g + r) * PSW + j * 16 + c16] = from_f<bf16>(sc[j][r] * sum[r]);
+        for (int r = 0; r < 4; ++r) sPw[(4 * g + r) * PSW + j * 16 + c16] = from_f<Hh>(sc[j][r] * sum[r]);
       if (NRT * 16 < NKP) {
         for (int id = lane; id < 16 * (NKP - NRT * 16); id += 64) {
           const int r = id / (NKP - NRT * 16), c = NRT * 16 + id % (NKP - NRT * 16);
-          sPw[r * PSW + c] = (bf16)0.0f;
+          sPw[r * PSW + c] = (Hh)0.0f;
         }
       }
       wave_lds_sync();                             // the tile is wave-private: no workgroup barrier needed
       const int nq = min(16, N - rt * 16);
       {
-        bf16* Pg = L.P + (((long long)samp * ENH + h) * N + rt * 16) * ldp;
+        Hh* Pg = L.P + (((long long)samp * ENH + h) * N + rt * 16) * ldp;
         const int cpr = ldp / 8;
         for (int id = lane; id < nq * cpr; id += 64) {
           const int r = id / cpr, c = (id % cpr) * 8;
-          *(bf16x8*)(Pg + (long long)r * ldp + c) = *(const bf16x8*)(sPw + r * PSW + c);
+          *(h16x8<Hh>*)(Pg + (long long)r * ldp + c) = *(const h16x8<Hh>*)(sPw + r * PSW + c);
         }
       }
       if (dsa.on) {
@@ -280,16 +281,16 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
             const int ql = 4 * g + r;
             const unsigned idx = (unsigned)(((((long long)samp * ENH + h) * N + rt * 16 + ql) * N) + key);
             const float m = (ql < nq && key < N) ? drop_mul(dsa, idx) : 0.f;
-            sPw[ql * PSW + key] = from_f<bf16>(sc[j][r] * sum[r] * m);
+            sPw[ql * PSW + key] = from_f<Hh>(sc[j][r] * sum[r] * m);
           }
         }
         wave_lds_sync();
         if (L.Pd) {
-          bf16* Pg = L.Pd + (((long long)samp * ENH + h) * N + rt * 16) * ldp;
+          Hh* Pg = L.Pd + (((long long)samp * ENH + h) * N + rt * 16) * ldp;
           const int cpr = ldp / 8;
           for (int id = lane; id < nq * cpr; id += 64) {
             const int r = id / cpr, c = (id % cpr) * 8;
-            *(bf16x8*)(Pg + (long long)r * ldp + c) = *(const bf16x8*)(sPw + r * PSW + c);
+            *(h16x8<Hh>*)(Pg + (long long)r * ldp + c) = *(const h16x8<Hh>*)(sPw + r * PSW + c);
           }
         }
       }
@@ -297,14 +298,14 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
 #pragma unroll
       for (int jd = 0; jd < 4; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int ks = 0; ks < NKP / 32; ++ks) {
-        const bf16x8 a = lfrag(sPw, PSW, 0, ks * 32, lane);
+        const h16x8<Hh> a = lfrag(sPw, PSW, 0, ks * 32, lane);
 #pragma unroll
         for (int jd = 0; jd < 4; ++jd) o[jd] = emma(a, tfrag(sQKV + 2 * EH + h * EHD, QS, jd * 16, ks * 32, lane), o[jd]);
       }
 #pragma unroll
       for (int jd = 0; jd < 4; ++jd)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sA[(rt * 16 + 4 * g + r) * XS + h * EHD + jd * 16 + c16] = from_f<bf16>(o[jd][r]);
+        for (int r = 0; r < 4; ++r) sA[(rt * 16 + 4 * g + r) * XS + h * EHD + jd * 16 + c16] = from_f<Hh>(o[jd][r]);
     }
     ENC_MARK(3);
     if (NRT > 4) {
@@ -336,7 +337,7 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
     copy_out(sA, XS, L.a + row_base * EH, EH, N, EH, tid);
     ENC_MARK(5);
     // ================= D: z = a W1^T + bi ; g = gelu(z) : 32 column tiles, 4 per wave =================
-    bf16x8 w2[16];
+    h16x8<Hh> w2[16];
     {
       f32x4 acc[NRT][4];
 #pragma unroll
@@ -347,7 +348,7 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
-          const bf16x8 a = lfrag(sA, XS, i * 16, ks * 32, lane);
+          const h16x8<Hh> a = lfrag(sA, XS, i * 16, ks * 32, lane);
 #pragma unroll
           for (int ct = 0; ct < 4; ++ct) acc[i][ct] = emma(a, w1[ct][ks], acc[i][ct]);
         }
@@ -365,7 +366,7 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             acc[i][ct][r] += pb_ffn[ct];
-            sG[(i * 16 + 4 * g + r) * GS + col] = from_f<bf16>(acc[i][ct][r]);
+            sG[(i * 16 + 4 * g + r) * GS + col] = from_f<Hh>(acc[i][ct][r]);
           }
       }
       __syncthreads();
@@ -383,7 +384,7 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
 #pragma unroll
         for (int i = 0; i < NRT; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sG[(i * 16 + 4 * g + r) * GS + col] = from_f<bf16>(acc[i][ct][r]);
+          for (int r = 0; r < 4; ++r) sG[(i * 16 + 4 * g + r) * GS + col] = from_f<Hh>(acc[i][ct][r]);
       }
     }
     ENC_MARK(6);
@@ -411,11 +412,12 @@ __device__ __forceinline__ void enc_body(const EncParams& p, const EncSeg& sg, c
   }
 }
 
-__global__ __launch_bounds__(512) void encoder_fwd_kernel(EncParams p) {
+template <typename Hh>
+__global__ __launch_bounds__(512) void encoder_fwd_kernel(EncParamsT<Hh> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char enc_smem[];
   int b = blockIdx.x, s = 0;
   if (b >= p.seg[0].nsamp) { b -= p.seg[0].nsamp; s = 1; }
-  const EncSeg& sg = p.seg[s];
+  const EncSegT<Hh>& sg = p.seg[s];
   const int nrt = max(2, (sg.N + 15) / 16);
   switch (nrt) {
     case 2: enc_body<2>(p, sg, b, enc_smem); break;
@@ -426,17 +428,17 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(EncParams p) {
 }
 
 static size_t enc_lds_bytes() {
-  return (size_t)(2 * MAXROWS * XS + KROWS * QS + NWAVE * 16 * PSW) * sizeof(bf16) + (size_t)NWAVE * MAXROWS * sizeof(float);
+  return (size_t)(2 * MAXROWS * XS + KROWS * QS + NWAVE * 16 * PSW) * 2 + (size_t)NWAVE * MAXROWS * sizeof(float);
 }
 
 extern "C" int magic_encoder_supported(int dtype, int H, int I, int nh, int N, int nlayers) {
-  return dtype == DT_BF16 && H == EH && I == EI && nh == ENH && N >= 1 && N <= MAXROWS && nlayers >= 1 && nlayers <= 6;
+  return dtype_is16(dtype) && H == EH && I == EI && nh == ENH && N >= 1 && N <= MAXROWS && nlayers >= 1 && nlayers <= 6;
 }
 extern "C" int magic_encoder_params_bytes() { return (int)sizeof(EncParams); }
 
 // params: a host copy of EncParams (mirrored field by field by host/lib.py); nothing is read from it after this call returns
-extern "C" int magic_encoder_fwd(const void* params, int nbytes, void* stream) {
-  if (!params || nbytes != (int)sizeof(EncParams)) return MAGIC_ERR_ARG;
+extern "C" int magic_encoder_fwd(int dtype, const void* params, int nbytes, void* stream) {
+  if (!params || nbytes != (int)sizeof(EncParams) || !dtype_is16(dtype)) return MAGIC_ERR_ARG;
   EncParams p;
   memcpy(&p, params, sizeof(p));
   if (p.nseg < 1 || p.nseg > 2) return MAGIC_ERR_ARG;
@@ -463,8 +465,13 @@ extern "C" int magic_encoder_fwd(const void* params, int nbytes, void* stream) {
   }
   const size_t shm = enc_lds_bytes();
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)encoder_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_set = true; }
-  hipLaunchKernelGGL(encoder_fwd_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)encoder_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)encoder_fwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  if (dtype == DT_BF16) hipLaunchKernelGGL(encoder_fwd_kernel<bf16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+  else { EncParamsT<f16> pf; static_assert(sizeof(pf) == sizeof(p), "layout"); memcpy(&pf, &p, sizeof(pf)); hipLaunchKernelGGL(encoder_fwd_kernel<f16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, pf); }
   return launch_status();
 }
 
@@ -477,29 +484,30 @@ extern "C" int magic_encoder_fwd(const void* params, int nbytes, void* stream) {
 // Queries <= 80 rows (NRT tiles), context <= 80 rows; the context's key/value projection reads the context rows straight from
 // global memory as MFMA A-fragments (they are layer-invariant and used by one GEMM per layer, not worth 21 KB of LDS).
 // =====================================================================================================================================
-struct XLayer {
-  const bf16* Wqkv; const float* bqkv; const bf16* Wo; const float* bo; const float* g1; const float* be1;          // attention.*
-  const bf16* Wq; const float* bq; const bf16* Wkv; const float* bkv;                                               // crossattention.self (q | k,v adjacent)
-  const bf16* Woc; const float* boc; const float* gc; const float* bec;                                             // crossattention.output
-  const bf16* W1; const float* bi; const bf16* W2; const float* bo2; const float* g2; const float* be2;             // intermediate / output
-  bf16 *qkv, *P, *Pd, *ctx, *a; float* rstd_a;                      // self-attention block
-  bf16 *q, *kv, *Pc, *Pdc, *cctx, *c; float* rstd_c;                // cross-attention block
-  bf16 *z, *g, *out; float* rstd_o;                                 // FFN
+template <typename Hh> struct XLayerT {
+  const Hh* Wqkv; const float* bqkv; const Hh* Wo; const float* bo; const float* g1; const float* be1;          // attention.*
+  const Hh* Wq; const float* bq; const Hh* Wkv; const float* bkv;                                               // crossattention.self (q | k,v adjacent)
+  const Hh* Woc; const float* boc; const float* gc; const float* bec;                                             // crossattention.output
+  const Hh* W1; const float* bi; const Hh* W2; const float* bo2; const float* g2; const float* be2;             // intermediate / output
+  Hh *qkv, *P, *Pd, *ctx, *a; float* rstd_a;                      // self-attention block
+  Hh *q, *kv, *Pc, *Pdc, *cctx, *c; float* rstd_c;                // cross-attention block
+  Hh *z, *g, *out; float* rstd_o;                                 // FFN
   unsigned site_attn, site_ao, site_cattn, site_co, site_out, pad_;
 };
-struct XSeg {
-  const bf16* x; const bf16* cx;                                    // queries [nsamp*Nq, H], context [nsamp*Nk, H]
+template <typename Hh> struct XSegT {
+  const Hh* x; const Hh* cx;                                    // queries [nsamp*Nq, H], context [nsamp*Nk, H]
   const unsigned char* qmask; const unsigned char* cmask;           // [nsamp, Nq], [nsamp, Nk]  (1 = valid)
   const float* dist; const float* sprel_w; const float* sprel_b;    // graph-distance bias of the self-attention (global encoder) or null
   int nsamp, Nq, Nk, ldps, ldpc, nlayers;
-  XLayer L[3];
+  XLayerT<Hh> L[3];
 };
-struct XParams { XSeg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; };
+template <typename Hh> struct XParamsT { XSegT<Hh> seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; };
+typedef XParamsT<bf16> XParams; typedef XSegT<bf16> XSeg; typedef XLayerT<bf16> XLayer;
 
 // one attention unit: this wave's 16 query rows (tile rt) of head h against NKT key tiles of the Q|K|V image; writes the clean (and,
 // under dropout, the dropped) probabilities and the 16 x 64 context tile into sCtx
-template <int NKT>
-__device__ __forceinline__ void attn_unit(const bf16* sQKV, bf16* sPw, bf16* sCtx, bf16* Pg0, bf16* Pdg0, const int h, const int rt, const int Nq,
+template <int NKT, typename Hh>
+__device__ __forceinline__ void attn_unit(const Hh* sQKV, Hh* sPw, Hh* sCtx, Hh* Pg0, Hh* Pdg0, const int h, const int rt, const int Nq,
                                           const int Nk, const int ldp, const float (&kbias)[NKT], const float* dist, const float sw, const float sb,
                                           const long long samp, const float scale, const DropState& dsa, const int lane) {
   const int g = lane >> 4, c16 = lane & 15;
@@ -509,7 +517,7 @@ __device__ __forceinline__ void attn_unit(const bf16* sQKV, bf16* sPw, bf16* sCt
   for (int j = 0; j < NKT; ++j) sc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    const bf16x8 a = lfrag(sQKV, QS, rt * 16, h * EHD + ks * 32, lane);
+    const h16x8<Hh> a = lfrag(sQKV, QS, rt * 16, h * EHD + ks * 32, lane);
 #pragma unroll
     for (int j = 0; j < NKT; ++j) sc[j] = emma(a, lfrag(sQKV, QS, j * 16, EH + h * EHD + ks * 32, lane), sc[j]);
   }
@@ -540,21 +548,21 @@ __device__ __forceinline__ void attn_unit(const bf16* sQKV, bf16* sPw, bf16* sCt
 #pragma unroll
   for (int j = 0; j < NKT; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sPw[(4 * g + r) * PSW + j * 16 + c16] = from_f<bf16>(sc[j][r] * sum[r]);
+    for (int r = 0; r < 4; ++r) sPw[(4 * g + r) * PSW + j * 16 + c16] = from_f<Hh>(sc[j][r] * sum[r]);
   if (NKT * 16 < NKP) {
     for (int id = lane; id < 16 * (NKP - NKT * 16); id += 64) {
       const int r = id / (NKP - NKT * 16), c = NKT * 16 + id % (NKP - NKT * 16);
-      sPw[r * PSW + c] = (bf16)0.0f;
+      sPw[r * PSW + c] = (Hh)0.0f;
     }
   }
   wave_lds_sync();
   const int nq = min(16, Nq - rt * 16);
   {
-    bf16* Pg = Pg0 + (((long long)samp * ENH + h) * Nq + rt * 16) * ldp;
+    Hh* Pg = Pg0 + (((long long)samp * ENH + h) * Nq + rt * 16) * ldp;
     const int cpr = ldp / 8;
     for (int id = lane; id < nq * cpr; id += 64) {
       const int r = id / cpr, c = (id % cpr) * 8;
-      *(bf16x8*)(Pg + (long long)r * ldp + c) = *(const bf16x8*)(sPw + r * PSW + c);
+      *(h16x8<Hh>*)(Pg + (long long)r * ldp + c) = *(const h16x8<Hh>*)(sPw + r * PSW + c);
     }
   }
   if (dsa.on) {
@@ -566,16 +574,16 @@ __device__ __forceinline__ void attn_unit(const bf16* sQKV, bf16* sPw, bf16* sCt
         const int ql = 4 * g + r;
         const unsigned idx = (unsigned)(((((long long)samp * ENH + h) * Nq + rt * 16 + ql) * Nk) + key);
         const float m = (ql < nq && key < Nk) ? drop_mul(dsa, idx) : 0.f;
-        sPw[ql * PSW + key] = from_f<bf16>(sc[j][r] * sum[r] * m);
+        sPw[ql * PSW + key] = from_f<Hh>(sc[j][r] * sum[r] * m);
       }
     }
     wave_lds_sync();
     if (Pdg0) {
-      bf16* Pg = Pdg0 + (((long long)samp * ENH + h) * Nq + rt * 16) * ldp;
+      Hh* Pg = Pdg0 + (((long long)samp * ENH + h) * Nq + rt * 16) * ldp;
       const int cpr = ldp / 8;
       for (int id = lane; id < nq * cpr; id += 64) {
         const int r = id / cpr, c = (id % cpr) * 8;
-        *(bf16x8*)(Pg + (long long)r * ldp + c) = *(const bf16x8*)(sPw + r * PSW + c);
+        *(h16x8<Hh>*)(Pg + (long long)r * ldp + c) = *(const h16x8<Hh>*)(sPw + r * PSW + c);
       }
     }
   }
@@ -583,19 +591,19 @@ __device__ __forceinline__ void attn_unit(const bf16* sQKV, bf16* sPw, bf16* sCt
 #pragma unroll
   for (int jd = 0; jd < 4; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int ks = 0; ks < NKP / 32; ++ks) {
-    const bf16x8 a = lfrag(sPw, PSW, 0, ks * 32, lane);
+    const h16x8<Hh> a = lfrag(sPw, PSW, 0, ks * 32, lane);
 #pragma unroll
     for (int jd = 0; jd < 4; ++jd) o[jd] = emma(a, tfrag(sQKV + 2 * EH + h * EHD, QS, jd * 16, ks * 32, lane), o[jd]);
   }
 #pragma unroll
   for (int jd = 0; jd < 4; ++jd)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sCtx[(rt * 16 + 4 * g + r) * XS + h * EHD + jd * 16 + c16] = from_f<bf16>(o[jd][r]);
+    for (int r = 0; r < 4; ++r) sCtx[(rt * 16 + 4 * g + r) * XS + h * EHD + jd * 16 + c16] = from_f<Hh>(o[jd][r]);
 }
 
 // one 16-column output tile per wave: acc[i] = sIn[rows of tile i] . W[w*16 .. +16]^T over K = 128
-template <int NRT>
-__device__ __forceinline__ void proj16(f32x4 (&acc)[NRT], const bf16* sIn, const bf16x8 (&wf)[4], const int lane) {
+template <int NRT, typename Hh>
+__device__ __forceinline__ void proj16(f32x4 (&acc)[NRT], const Hh* sIn, const h16x8<Hh> (&wf)[4], const int lane) {
 #pragma unroll
   for (int i = 0; i < NRT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -606,28 +614,28 @@ __device__ __forceinline__ void proj16(f32x4 (&acc)[NRT], const bf16* sIn, const
   }
 }
 
-template <int NRT>
-__device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, const int samp, unsigned char* smem) {
+template <int NRT, typename Hh>
+__device__ __forceinline__ void xenc_body(const XParamsT<Hh>& p, const XSegT<Hh>& sg, const int samp, unsigned char* smem) {
   constexpr int NKT = 5;                         // context key tiles (<= 80 rows); unused tiles cost a few MFMAs on zeros
-  bf16* sX = (bf16*)smem;                        // [80][XS]   layer input x; later the cross context image / c / the block output
-  bf16* sA = sX + MAXROWS * XS;                  // [80][XS]   self-attention context, then a (attention-block output)
-  bf16* sQKV = sA + MAXROWS * XS;                // [96][QS]   Q | K | V of the self-attention, then Q | K,V(context) of the cross-attention
-  bf16* sP = sQKV + KROWS * QS;
-  bf16* sG = sQKV;
+  Hh* sX = (Hh*)smem;                        // [80][XS]   layer input x; later the cross context image / c / the block output
+  Hh* sA = sX + MAXROWS * XS;                  // [80][XS]   self-attention context, then a (attention-block output)
+  Hh* sQKV = sA + MAXROWS * XS;                // [96][QS]   Q | K | V of the self-attention, then Q | K,V(context) of the cross-attention
+  Hh* sP = sQKV + KROWS * QS;
+  Hh* sG = sQKV;
   float* red = (float*)(sP + NWAVE * 16 * PSW);
   const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Nq = sg.Nq, Nk = sg.Nk;
   const long long qbase = (long long)samp * Nq, kbase = (long long)samp * Nk;
   constexpr int ROWS = NRT * 16;
   {
-    const bf16* x = sg.x + qbase * EH;
+    const Hh* x = sg.x + qbase * EH;
     for (int id = tid; id < ROWS * (EH / 8); id += NWAVE * 64) {
       const int r = id / (EH / 8), c = (id % (EH / 8)) * 8;
-      bf16x8 v;
+      h16x8<Hh> v;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16)0.0f;
-      if (r < Nq) v = *(const bf16x8*)(x + (long long)r * EH + c);
-      *(bf16x8*)(sX + r * XS + c) = v;
+      for (int e = 0; e < 8; ++e) v[e] = (Hh)0.0f;
+      if (r < Nq) v = *(const h16x8<Hh>*)(x + (long long)r * EH + c);
+      *(h16x8<Hh>*)(sX + r * XS + c) = v;
     }
   }
   DropDesc dd;
@@ -645,7 +653,7 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
   }
   const float sw = sg.dist ? sg.sprel_w[0] : 0.f, sb = sg.dist ? sg.sprel_b[0] : 0.f;
   for (int l = 0; l < sg.nlayers; ++l) {
-    const XLayer& L = sg.L[l];
+    const XLayerT<Hh>& L = sg.L[l];
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int g = lane >> 4, c16 = lane & 15;
@@ -661,17 +669,17 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
     const float pb_oc = L.boc[colw], pg_c = L.gc[colw], pe_c = L.bec[colw];
     const float pb_2 = L.bo2[colw], pg_2 = L.g2[colw], pe_2 = L.be2[colw];
     // ================= self-attention: Q|K|V =================
-    bf16x8 bw[3][4];
+    h16x8<Hh> bw[3][4];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) bw[ct][ks] = gfrag(L.Wqkv, EH, (3 * w + ct) * 16, ks * 32, lane);
     for (int id = tid; id < (KROWS - ROWS) * (384 / 8); id += NWAVE * 64) {
       const int r = ROWS + id / 48, c = (id % 48) * 8;
-      bf16x8 zv;
+      h16x8<Hh> zv;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) zv[e] = (bf16)0.0f;
-      *(bf16x8*)(sQKV + r * QS + c) = zv;
+      for (int e = 0; e < 8; ++e) zv[e] = (Hh)0.0f;
+      *(h16x8<Hh>*)(sQKV + r * QS + c) = zv;
     }
     __syncthreads();
     {
@@ -684,7 +692,7 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
-          const bf16x8 a = lfrag(sX, XS, i * 16, ks * 32, lane);
+          const h16x8<Hh> a = lfrag(sX, XS, i * 16, ks * 32, lane);
 #pragma unroll
           for (int ct = 0; ct < 3; ++ct) acc[i][ct] = emma(a, bw[ct][ks], acc[i][ct]);
         }
@@ -696,17 +704,17 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
 #pragma unroll
         for (int i = 0; i < NRT; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sQKV[(i * 16 + 4 * g + r) * QS + col] = from_f<bf16>(acc[i][ct][r] + pb_qkv[ct]);
+          for (int r = 0; r < 4; ++r) sQKV[(i * 16 + 4 * g + r) * QS + col] = from_f<Hh>(acc[i][ct][r] + pb_qkv[ct]);
       }
     }
-    bf16x8 wo[4], wq[4];
+    h16x8<Hh> wo[4], wq[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { wo[ks] = gfrag(L.Wo, EH, w * 16, ks * 32, lane); wq[ks] = gfrag(L.Wq, EH, w * 16, ks * 32, lane); }
     __syncthreads();
     copy_out(sQKV, QS, L.qkv + qbase * 3 * EH, 3 * EH, Nq, 3 * EH, tid);
     dd.site = L.site_attn; dd.p = p.p_attn;
     const DropState dsa = drop_init(dd);
-    bf16* sPw = sP + w * 16 * PSW;
+    Hh* sPw = sP + w * 16 * PSW;
     for (int u = w; u < ENH * NRT; u += NWAVE)
       attn_unit<NRT>(sQKV, sPw, sA, L.P, L.Pd, u / NRT, u % NRT, Nq, Nq, sg.ldps, qbias, sg.dist, sw, sb, samp, p.scale, dsa, lane);
     __syncthreads();                              // self-attention context complete (sA)
@@ -719,7 +727,7 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
       add_norm<NRT>(acc, pb_o, pg_1, pe_1, sX, red, sA, L.rstd_a, Nq, qbase, p.eps, dsh, w, lane);
     }
     // context key / value projection weights: 2 column tiles per wave (K|V = 256 columns)
-    bf16x8 wkv[2][4];
+    h16x8<Hh> wkv[2][4];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -733,7 +741,7 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
 #pragma unroll
       for (int i = 0; i < NRT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sQKV[(i * 16 + 4 * g + r) * QS + colw] = from_f<bf16>(acc[i][r] + pb_q);
+        for (int r = 0; r < 4; ++r) sQKV[(i * 16 + 4 * g + r) * QS + colw] = from_f<Hh>(acc[i][r] + pb_q);
     }
     {
       f32x4 acc[NKT][2];
@@ -741,13 +749,13 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
       for (int i = 0; i < NKT; ++i)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const bf16* cx = sg.cx + kbase * EH;
+      const Hh* cx = sg.cx + kbase * EH;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int i = 0; i < NKT; ++i) {
           const int row = min(i * 16 + c16, Nk - 1);                 // rows past the context: any valid row (their keys are masked out below)
-          const bf16x8 a = *(const bf16x8*)(cx + (long long)row * EH + ks * 32 + 8 * g);
+          const h16x8<Hh> a = *(const h16x8<Hh>*)(cx + (long long)row * EH + ks * 32 + 8 * g);
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) acc[i][ct] = emma(a, wkv[ct][ks], acc[i][ct]);
         }
@@ -761,22 +769,22 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = i * 16 + 4 * g + r;
-            sQKV[row * QS + col] = (row < Nk) ? from_f<bf16>(acc[i][ct][r] + pb_kv[ct]) : (bf16)0.0f;     // rows >= Nk: zero (PV pads)
+            sQKV[row * QS + col] = (row < Nk) ? from_f<Hh>(acc[i][ct][r] + pb_kv[ct]) : (Hh)0.0f;     // rows >= Nk: zero (PV pads)
           }
       }
     }
     // rows NKT*16 .. 95 of the K|V columns: zero (the self-attention's zero rows may have been overwritten only below ROWS)
     for (int id = tid; id < (KROWS - NKT * 16) * (256 / 8); id += NWAVE * 64) {
       const int r = NKT * 16 + id / 32, c = EH + (id % 32) * 8;
-      bf16x8 zv;
+      h16x8<Hh> zv;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) zv[e] = (bf16)0.0f;
-      *(bf16x8*)(sQKV + r * QS + c) = zv;
+      for (int e = 0; e < 8; ++e) zv[e] = (Hh)0.0f;
+      *(h16x8<Hh>*)(sQKV + r * QS + c) = zv;
     }
-    bf16x8 woc[4];
+    h16x8<Hh> woc[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) woc[ks] = gfrag(L.Woc, EH, w * 16, ks * 32, lane);
-    bf16x8 w1[4][4];
+    h16x8<Hh> w1[4][4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -801,7 +809,7 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
     __syncthreads();                              // sX = c (cross-attention block output)
     copy_out(sX, XS, L.c + qbase * EH, EH, Nq, EH, tid);
     // ================= FFN =================
-    bf16x8 w2[16];
+    h16x8<Hh> w2[16];
     {
       f32x4 acc[NRT][4];
 #pragma unroll
@@ -812,7 +820,7 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
-          const bf16x8 a = lfrag(sX, XS, i * 16, ks * 32, lane);
+          const h16x8<Hh> a = lfrag(sX, XS, i * 16, ks * 32, lane);
 #pragma unroll
           for (int ct = 0; ct < 4; ++ct) acc[i][ct] = emma(a, w1[ct][ks], acc[i][ct]);
         }
@@ -828,7 +836,7 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             acc[i][ct][r] += pb_ffn[ct];
-            sG[(i * 16 + 4 * g + r) * GS + col] = from_f<bf16>(acc[i][ct][r]);
+            sG[(i * 16 + 4 * g + r) * GS + col] = from_f<Hh>(acc[i][ct][r]);
           }
       }
       __syncthreads();
@@ -846,7 +854,7 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
 #pragma unroll
         for (int i = 0; i < NRT; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sG[(i * 16 + 4 * g + r) * GS + col] = from_f<bf16>(acc[i][ct][r]);
+          for (int r = 0; r < 4; ++r) sG[(i * 16 + 4 * g + r) * GS + col] = from_f<Hh>(acc[i][ct][r]);
       }
     }
     __syncthreads();
@@ -871,11 +879,12 @@ __device__ __forceinline__ void xenc_body(const XParams& p, const XSeg& sg, cons
   }
 }
 
-__global__ __launch_bounds__(512) void xencoder_fwd_kernel(XParams p) {
+template <typename Hh>
+__global__ __launch_bounds__(512) void xencoder_fwd_kernel(XParamsT<Hh> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char enc_smem[];
   int b = blockIdx.x, s = 0;
   if (b >= p.seg[0].nsamp) { b -= p.seg[0].nsamp; s = 1; }
-  const XSeg& sg = p.seg[s];
+  const XSegT<Hh>& sg = p.seg[s];
   const int nrt = max(2, (sg.Nq + 15) / 16);
   switch (nrt) {
     case 2: xenc_body<2>(p, sg, b, enc_smem); break;
@@ -886,12 +895,12 @@ __global__ __launch_bounds__(512) void xencoder_fwd_kernel(XParams p) {
 }
 
 extern "C" int magic_xencoder_supported(int dtype, int H, int I, int nh, int Nq, int Nk, int nlayers) {
-  return dtype == DT_BF16 && H == EH && I == EI && nh == ENH && Nq >= 1 && Nq <= MAXROWS && Nk >= 1 && Nk <= MAXROWS && nlayers >= 1 && nlayers <= 3;
+  return dtype_is16(dtype) && H == EH && I == EI && nh == ENH && Nq >= 1 && Nq <= MAXROWS && Nk >= 1 && Nk <= MAXROWS && nlayers >= 1 && nlayers <= 3;
 }
 extern "C" int magic_xencoder_params_bytes() { return (int)sizeof(XParams); }
 
-extern "C" int magic_xencoder_fwd(const void* params, int nbytes, void* stream) {
-  if (!params || nbytes != (int)sizeof(XParams)) return MAGIC_ERR_ARG;
+extern "C" int magic_xencoder_fwd(int dtype, const void* params, int nbytes, void* stream) {
+  if (!params || nbytes != (int)sizeof(XParams) || !dtype_is16(dtype)) return MAGIC_ERR_ARG;
   XParams p;
   memcpy(&p, params, sizeof(p));
   if (p.nseg < 1 || p.nseg > 2) return MAGIC_ERR_ARG;
@@ -920,7 +929,12 @@ extern "C" int magic_xencoder_fwd(const void* params, int nbytes, void* stream) 
   }
   const size_t shm = enc_lds_bytes();
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)xencoder_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_set = true; }
-  hipLaunchKernelGGL(xencoder_fwd_kernel, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)xencoder_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)xencoder_fwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  if (dtype == DT_BF16) hipLaunchKernelGGL(xencoder_fwd_kernel<bf16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+  else { XParamsT<f16> pf; static_assert(sizeof(pf) == sizeof(p), "layout"); memcpy(&pf, &p, sizeof(pf)); hipLaunchKernelGGL(xencoder_fwd_kernel<f16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, pf); }
   return launch_status();
 }

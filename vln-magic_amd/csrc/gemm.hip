@@ -33,6 +33,10 @@ template <> struct TT<bf16> {
   static constexpr int VE = 8, BK = 64, STRIDE = 72, SN = 72;
   typedef bf16x8 vec;
 };
+template <> struct TT<f16> {
+  static constexpr int VE = 8, BK = 64, STRIDE = 72, SN = 72;
+  typedef f16x8 vec;
+};
 template <> struct TT<float> {
   static constexpr int VE = 4, BK = 32, STRIDE = 34, SN = 68;
   typedef f32x4 vec;
@@ -88,25 +92,21 @@ template <typename T, bool KC, int TM = 64> struct TileLoader {
   }
 };
 
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-
 // one MFMA operand fragment of the 16 out-rows starting at out0, k-step ks.  Lane map (A and B alike):
 // lane l holds X[out0 + (l&15)][k = kbase + 8*(l>>4) + j] (bf16, j<8) / X[out0 + (l&15)][k = kbase + (l>>4)] (f32).
-template <bool KC, int SN_ = TT<bf16>::SN>
-__device__ __forceinline__ bf16x8 frag(const bf16* s, int out0, int ks, int lane) {
+template <bool KC, int SN_, typename Hh>
+__device__ __forceinline__ h16x8<Hh> frag16(const Hh* s, int out0, int ks, int lane) {
   if constexpr (KC) {
-    return *(const bf16x8*)(s + (out0 + (lane & 15)) * TT<bf16>::STRIDE + ks * 32 + 8 * (lane >> 4));
+    return *(const h16x8<Hh>*)(s + (out0 + (lane & 15)) * TT<Hh>::STRIDE + ks * 32 + 8 * (lane >> 4));
   } else {
     // natural [k][out] image: each 16-lane group g transposes rows k = 8g..8g+3 (+4) x 16 outs with ds_read_b64_tr_b16;
     // lane 4q+p of the group addresses row q, outs 4p..4p+3 and receives out (l&15) of the 4 rows
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const bf16* b = s + (ks * 32 + 8 * g + q) * SN_ + out0 + 4 * pp;
-    typedef bf16x4_t __attribute__((address_space(3))) * lds4;
-    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
-    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * SN_));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return lds_tr8(s + (ks * 32 + 8 * g + q) * SN_ + out0 + 4 * pp, 4 * SN_);
   }
 }
+template <bool KC, int SN_ = 72> __device__ __forceinline__ bf16x8 frag(const bf16* s, int out0, int ks, int lane) { return frag16<KC, SN_>(s, out0, ks, lane); }
+template <bool KC, int SN_ = 72> __device__ __forceinline__ f16x8 frag(const f16* s, int out0, int ks, int lane) { return frag16<KC, SN_>(s, out0, ks, lane); }
 template <bool KC, int SN_ = TT<float>::SN>
 __device__ __forceinline__ float frag(const float* s, int out0, int ks, int lane) {
   if constexpr (KC) return s[(out0 + (lane & 15)) * TT<float>::STRIDE + ks * 4 + (lane >> 4)];
@@ -114,12 +114,12 @@ __device__ __forceinline__ float frag(const float* s, int out0, int ks, int lane
 }
 
 // NT_ x NT_ MFMA tiles of 16x16 per wave (2: 64x64 block tile, 4: 128x128)
-template <bool A_KC, bool B_KC, int NT_>
-__device__ __forceinline__ void mma_tile(const bf16* sA, const bf16* sB, int wr, int wc, int lane, f32x4 (&acc)[NT_][NT_]) {
-  constexpr int SN_ = TT<bf16>::SN + (32 * NT_ - 64);
+template <bool A_KC, bool B_KC, int NT_, typename Hh>
+__device__ __forceinline__ void mma_tile16(const Hh* sA, const Hh* sB, int wr, int wc, int lane, f32x4 (&acc)[NT_][NT_]) {
+  constexpr int SN_ = TT<Hh>::SN + (32 * NT_ - 64);
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 a[NT_], b[NT_];
+    h16x8<Hh> a[NT_], b[NT_];
 #pragma unroll
     for (int i = 0; i < NT_; ++i) {
       a[i] = frag<A_KC, SN_>(sA, (wr * NT_ + i) * 16, ks, lane);
@@ -128,9 +128,13 @@ __device__ __forceinline__ void mma_tile(const bf16* sA, const bf16* sB, int wr,
 #pragma unroll
     for (int i = 0; i < NT_; ++i)
 #pragma unroll
-      for (int j = 0; j < NT_; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NT_; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
   }
 }
+template <bool A_KC, bool B_KC, int NT_>
+__device__ __forceinline__ void mma_tile(const bf16* sA, const bf16* sB, int wr, int wc, int lane, f32x4 (&acc)[NT_][NT_]) { mma_tile16<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc); }
+template <bool A_KC, bool B_KC, int NT_>
+__device__ __forceinline__ void mma_tile(const f16* sA, const f16* sB, int wr, int wc, int lane, f32x4 (&acc)[NT_][NT_]) { mma_tile16<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc); }
 
 template <bool A_KC, bool B_KC, int NT_>
 __device__ __forceinline__ void mma_tile(const float* sA, const float* sB, int wr, int wc, int lane, f32x4 (&acc)[NT_][NT_]) {
@@ -462,47 +466,43 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ int wide_sw_nat(int kr) { return 2 * (kr & 3) + 8 * ((kr >> 3) & 1); }
 
-template <bool KC>
-__device__ __forceinline__ void wide_stage(const bf16* __restrict__ base, int ld, int out0, int k0, int OUT, int kend, bf16* s, int tid) {
+template <bool KC, typename Hh>
+__device__ __forceinline__ void wide_stage(const Hh* __restrict__ base, int ld, int out0, int k0, int OUT, int kend, Hh* s, int tid) {
   // 1024 chunks of 16 B per operand tile: chunk idx = j * 256 + tid (wave w, lane l: LDS bytes (4 j + w) * 1024 + 16 l)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int idx = j * 256 + tid;
-    const bf16* src;
+    const Hh* src;
     if (KC) {
       const int row = idx >> 3, c = (idx & 7) ^ ((row >> 1) & 7);
       const int o = out0 + row, k = k0 + c * 8;
-      src = (o < OUT && k < kend) ? base + (long long)o * ld + k : (const bf16*)g_zero16;
+      src = (o < OUT && k < kend) ? base + (long long)o * ld + k : (const Hh*)g_zero16;
     } else {
       const int kr = idx >> 4, c = (idx & 15) ^ wide_sw_nat(kr);
       const int k = k0 + kr, o = out0 + c * 8;
-      src = (k < kend && o < OUT) ? base + (long long)k * ld + o : (const bf16*)g_zero16;
+      src = (k < kend && o < OUT) ? base + (long long)k * ld + o : (const Hh*)g_zero16;
     }
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s + (j * 256 + (tid & ~63)) * 8), 16, 0, 0);
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ bf16x8 wide_frag(const bf16* s, int out0, int ks, int lane) {
+template <bool KC, typename Hh>
+__device__ __forceinline__ h16x8<Hh> wide_frag(const Hh* s, int out0, int ks, int lane) {
   if constexpr (KC) {
     const int row = out0 + (lane & 15);
     const int c = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
-    return *(const bf16x8*)(s + row * 64 + c * 8);
+    return *(const h16x8<Hh>*)(s + row * 64 + c * 8);
   } else {
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     const int kr = ks * 32 + 8 * g + q;                       // (kr + 4) has the same swizzle: q < 4
     const int c = ((out0 >> 3) + (pp >> 1)) ^ wide_sw_nat(kr);
-    const bf16* b = s + kr * 128 + c * 8 + (pp & 1) * 4;
-    typedef bf16x4_t __attribute__((address_space(3))) * lds4;
-    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
-    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * 128));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return lds_tr8(s + kr * 128 + c * 8 + (pp & 1) * 4, 4 * 128);
   }
 }
 
-template <int LAYOUT>
-__device__ __forceinline__ void gemm_wide_block(const GemmParams& p, const int bx, const int by, const int bzz, bf16* sA, bf16* sB) {
-  typedef bf16 T;
+template <typename Hh, int LAYOUT>
+__device__ __forceinline__ void gemm_wide_block(const GemmParams& p, const int bx, const int by, const int bzz, Hh* sA, Hh* sB) {
+  typedef Hh T;
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
@@ -534,8 +534,8 @@ __device__ __forceinline__ void gemm_wide_block(const GemmParams& p, const int b
   for (int kt = kt0; kt < kt1; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();              // tile kt has landed for every wave, and every wave is past the multiply of tile kt-1
-    const bf16* tA = sA + cur * (2 * 128 * 64);
-    const bf16* tB = sB + cur * (2 * 128 * 64);
+    const Hh* tA = sA + cur * (2 * 128 * 64);
+    const Hh* tB = sB + cur * (2 * 128 * 64);
     if (kt + 1 < kt1) {
       wide_stage<A_KC>(A, p.lda, m0, (kt + 1) * 64, p.M, p.K, sA + (cur ^ 1) * (2 * 128 * 64), tid);
       wide_stage<B_KC>(B, p.ldb, n0, (kt + 1) * 64, p.N, p.K, sB + (cur ^ 1) * (2 * 128 * 64), tid);
@@ -543,7 +543,7 @@ __device__ __forceinline__ void gemm_wide_block(const GemmParams& p, const int b
     cur ^= 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[4], b[4];
+      h16x8<Hh> a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         a[i] = wide_frag<A_KC>(tA, (wr * 4 + i) * 16, ks, lane);
@@ -552,7 +552,7 @@ __device__ __forceinline__ void gemm_wide_block(const GemmParams& p, const int b
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
     }
     if (do_bgrad && tid < 128) {                     // TN: A is the natural [k][out] image; column `tid` summed over the tile's k
       float s = 0.f;
@@ -668,12 +668,12 @@ __device__ __forceinline__ bool wide_tile_of(int nx, int ny, int ny8, int& bx, i
   bx = l2 - by * nx;
   return true;
 }
-template <int LAYOUT>
+template <typename Hh, int LAYOUT>
 __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(GemmParams p, int nx, int ny, int ny8) {
-  __shared__ __attribute__((aligned(1024))) bf16 sAB[4 * 128 * 64];          // stage s: A at s * 32 KB, B 16 KB behind it
+  __shared__ __attribute__((aligned(1024))) Hh sAB[4 * 128 * 64];          // stage s: A at s * 32 KB, B 16 KB behind it
   int bx, by, z;
   if (!wide_tile_of(nx, ny, ny8, bx, by, z)) return;
-  gemm_wide_block<LAYOUT>(p, bx, by, z, sAB, sAB + 128 * 64);
+  gemm_wide_block<Hh, LAYOUT>(p, bx, by, z, sAB, sAB + 128 * 64);
 }
 
 // Grouped weight-gradient GEMM: up to GROUP_MAX independent TN problems (dW[N,K] += dY^T X, split-K, fp32 atomics, fused
@@ -780,7 +780,7 @@ static int gemm_big_tile(int dtype, int layout, int M, int N, int K, int nz) {
     const char* t = getenv("MAGIC_GEMM_BIG_MIN_TILES"); if (t) g_big_min_tiles = atoi(t);
     const char* k = getenv("MAGIC_GEMM_BIG_MIN_K"); if (k) g_big_min_k = atoi(k);
   }
-  if (g_big_mode == 0 || dtype != DT_BF16 || M < 128 || N < 128) return 0;
+  if (g_big_mode == 0 || !dtype_is16(dtype) || M < 128 || N < 128) return 0;
   // 16-byte chunks must lie wholly inside or outside the logical extent of each operand's contiguous dimension
   if (layout == 0 ? (K % 8) : layout == 1 ? ((K % 8) || (N % 8)) : ((M % 8) || (N % 8))) return 0;
   if (g_big_mode == 2) return 1;
@@ -797,9 +797,9 @@ extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N
                           const void* residual, int ldr, void* C2, int ldc2,
                           float alpha, int splitk, float* bias_grad, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || nh <= 0 || splitk <= 0) return MAGIC_ERR_ARG;
-  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
+  if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
   if (layout < 0 || layout > 2) return MAGIC_ERR_ARG;
-  const int ve = dtype == DT_BF16 ? 8 : 4;
+  const int ve = dtype_is16(dtype) ? 8 : 4;
   if (lda % ve || ldb % ve || (sAb % ve) || (sAh % ve) || (sBb % ve) || (sBh % ve)) return MAGIC_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return MAGIC_ERR_ARG;
   if (dtype == DT_F32 && !c_f32) return MAGIC_ERR_ARG;
@@ -849,9 +849,10 @@ int launch_gemm(int dtype, int layout, const void* pa, const void* pb, hipStream
     const int nx = (a.N + 127) / 128, ny = (a.M + 127) / 128, nz = a.batch * a.splitk;
     const int ny8 = (gemm_xcd_on() && nx >= 2 && ny >= 16) ? (ny + 7) / 8 * 8 : 0;
     dim3 g1((unsigned)(nx * (ny8 > 0 ? ny8 : ny) * nz));
-#define LAUNCHB(L) hipLaunchKernelGGL((gemm_wide_kernel<L>), g1, block, 0, st, a, nx, ny, ny8)
-    if (dtype != DT_BF16) return MAGIC_ERR_ARG;
-    if (layout == 0) LAUNCHB(0); else if (layout == 1) LAUNCHB(1); else LAUNCHB(2);
+#define LAUNCHB(TY, L) hipLaunchKernelGGL((gemm_wide_kernel<TY, L>), g1, block, 0, st, a, nx, ny, ny8)
+    if (!dtype_is16(dtype)) return MAGIC_ERR_ARG;
+    if (dtype == DT_BF16) { if (layout == 0) LAUNCHB(bf16, 0); else if (layout == 1) LAUNCHB(bf16, 1); else LAUNCHB(bf16, 2); }
+    else { if (layout == 0) LAUNCHB(f16, 0); else if (layout == 1) LAUNCHB(f16, 1); else LAUNCHB(f16, 2); }
 #undef LAUNCHB
     return launch_status();
   }
@@ -864,6 +865,7 @@ int launch_gemm(int dtype, int layout, const void* pa, const void* pb, hipStream
       dim3 gk(nx, ny, nz), bk(1024);
 #define LAUNCHK(TY, L) hipLaunchKernelGGL((gemm_kg_kernel<TY, L>), gk, bk, 0, st, a)
       if (dtype == DT_BF16) { if (layout == 0) LAUNCHK(bf16, 0); else LAUNCHK(bf16, 1); }
+      else if (dtype == DT_F16) { if (layout == 0) LAUNCHK(f16, 0); else LAUNCHK(f16, 1); }
       else { if (layout == 0) LAUNCHK(float, 0); else LAUNCHK(float, 1); }
 #undef LAUNCHK
       return launch_status();
@@ -874,6 +876,8 @@ int launch_gemm(int dtype, int layout, const void* pa, const void* pb, hipStream
 #define LAUNCHX(TY, L) hipLaunchKernelGGL((gemm_xcd_kernel<TY, L>), g1, block, 0, st, a, nx, ny, ny8)
       if (dtype == DT_BF16) {
         if (layout == 0) LAUNCHX(bf16, 0); else if (layout == 1) LAUNCHX(bf16, 1); else LAUNCHX(bf16, 2);
+      } else if (dtype == DT_F16) {
+        if (layout == 0) LAUNCHX(f16, 0); else if (layout == 1) LAUNCHX(f16, 1); else LAUNCHX(f16, 2);
       } else {
         if (layout == 0) LAUNCHX(float, 0); else if (layout == 1) LAUNCHX(float, 1); else LAUNCHX(float, 2);
       }
@@ -884,6 +888,8 @@ int launch_gemm(int dtype, int layout, const void* pa, const void* pb, hipStream
 #define LAUNCH(TY, L) hipLaunchKernelGGL((gemm_kernel<TY, L>), grid, block, 0, st, a)
     if (dtype == DT_BF16) {
       if (layout == 0) LAUNCH(bf16, 0); else if (layout == 1) LAUNCH(bf16, 1); else LAUNCH(bf16, 2);
+    } else if (dtype == DT_F16) {
+      if (layout == 0) LAUNCH(f16, 0); else if (layout == 1) LAUNCH(f16, 1); else LAUNCH(f16, 2);
     } else {
       if (layout == 0) LAUNCH(float, 0); else if (layout == 1) LAUNCH(float, 1); else LAUNCH(float, 2);
     }
@@ -907,6 +913,8 @@ int launch_gemm_n(int dtype, int layout, const void* const* ps, int n, hipStream
 #define LAUNCHG(TY, L) hipLaunchKernelGGL((gemm_grouped_kernel<TY, L>), grid, block, 0, st, gp)
   if (dtype == DT_BF16) {
     if (layout == 0) LAUNCHG(bf16, 0); else if (layout == 1) LAUNCHG(bf16, 1); else LAUNCHG(bf16, 2);
+  } else if (dtype == DT_F16) {
+    if (layout == 0) LAUNCHG(f16, 0); else if (layout == 1) LAUNCHG(f16, 1); else LAUNCHG(f16, 2);
   } else {
     if (layout == 0) LAUNCHG(float, 0); else if (layout == 1) LAUNCHG(float, 1); else LAUNCHG(float, 2);
   }
@@ -1024,8 +1032,8 @@ __device__ __forceinline__ void linear_ln_body(const LlnParams& pp, const int bi
       for (int j = 0; j < HT; ++j) {
         const auto b = frag<true>(sB, w * WC + j * 16, ks, lane);
         if constexpr (sizeof(T) == 2) {
-          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][j], 0, 0, 0);
+          acc[0][j] = mfma16(a0, b, acc[0][j]);
+          acc[1][j] = mfma16(a1, b, acc[1][j]);
         } else {
           acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
           acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
@@ -1117,8 +1125,8 @@ extern "C" int magic_linear_ln(int dtype, int M, int H, int K, const void* x, in
                                void* out, float* rstd, const void* drop_seed, float drop_p, unsigned drop_site, void* stream) {
   if (M <= 0 || K <= 0 || !gamma || !beta || !out) return MAGIC_ERR_ARG;
   if (!drop_args_ok(drop_seed, drop_p) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
-  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
-  const int ve = dtype == DT_BF16 ? 8 : 4;
+  if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  const int ve = dtype_is16(dtype) ? 8 : 4;
   if (lda % ve || ldb % ve || ((uintptr_t)x & 15) || ((uintptr_t)W & 15)) return MAGIC_ERR_ARG;
   if (H != 128 && H != 256 && H != 384) return MAGIC_ERR_UNSUPPORTED;
   LlnParams p{M, K, x, lda, W, ldb, bias, residual, ldr, gamma, beta, eps, out, rstd,
@@ -1145,6 +1153,7 @@ int launch_lln(int dtype, int ht, const void* pa, const void* pb, hipStream_t st
     }                                                                                                                     \
   } while (0)
   if (dtype == DT_BF16) { if (ht == 2) LLN1(bf16, 2); else if (ht == 4) LLN1(bf16, 4); else LLN1(bf16, 6); }
+  else if (dtype == DT_F16) { if (ht == 2) LLN1(f16, 2); else if (ht == 4) LLN1(f16, 4); else LLN1(f16, 6); }
   else { if (ht == 2) LLN1(float, 2); else if (ht == 4) LLN1(float, 4); else LLN1(float, 6); }
 #undef LLN1
   return launch_status();
@@ -1165,15 +1174,8 @@ struct LlbParams {
   void* dx; void* dxm; float* dgamma; float* dbeta; DropDesc drop;
 };
 
-template <int SN>
-__device__ __forceinline__ bf16x8 frag_oc(const bf16* s, int out0, int ks, int lane) {
-  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const bf16* b = s + (ks * 32 + 8 * g + q) * SN + out0 + 4 * pp;
-  typedef bf16x4_t __attribute__((address_space(3))) * lds4;
-  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b));
-  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + 4 * SN));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
+template <int SN> __device__ __forceinline__ bf16x8 frag_oc(const bf16* s, int out0, int ks, int lane) { return frag16<false, SN>(s, out0, ks, lane); }
+template <int SN> __device__ __forceinline__ f16x8 frag_oc(const f16* s, int out0, int ks, int lane) { return frag16<false, SN>(s, out0, ks, lane); }
 template <int SN>
 __device__ __forceinline__ float frag_oc(const float* s, int out0, int ks, int lane) {
   return s[(ks * 4 + (lane >> 4)) * SN + out0 + (lane & 15)];
@@ -1279,8 +1281,8 @@ __device__ __forceinline__ void linear_lnb_body(const LlbParams& pp, const int b
       for (int j = 0; j < HT; ++j) {
         const auto b = frag_oc<SN>(sB, w * WC + j * 16, ks, lane);
         if constexpr (sizeof(T) == 2) {
-          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][j], 0, 0, 0);
+          acc[0][j] = mfma16(a0, b, acc[0][j]);
+          acc[1][j] = mfma16(a1, b, acc[1][j]);
         } else {
           acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
           acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
@@ -1389,10 +1391,10 @@ extern "C" int magic_linear_lnbwd(int dtype, int M, int H, int K, const void* x,
                                   void* dx, void* dxm, float* dgamma, float* dbeta,
                                   const void* drop_seed, float drop_p, unsigned drop_site, void* stream) {
   if (M <= 0 || K <= 0 || !x || !W || !y || !gamma || !beta || !rstd || !dx) return MAGIC_ERR_ARG;
-  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
+  if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return MAGIC_ERR_ARG;
   if (!drop_args_ok(drop_seed, drop_p) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
-  const int ve = dtype == DT_BF16 ? 8 : 4;
+  const int ve = dtype_is16(dtype) ? 8 : 4;
   if (lda % ve || ldb % ve || ldb < H || ((uintptr_t)x & 15) || ((uintptr_t)W & 15)) return MAGIC_ERR_ARG;
   if (H != 128 && H != 256) return MAGIC_ERR_UNSUPPORTED;
   const bool don = drop_p > 0.f && drop_site != 0;
@@ -1422,6 +1424,7 @@ int launch_llb(int dtype, int ht, const void* pa, const void* pb, hipStream_t st
     }                                                                                                                     \
   } while (0)
   if (dtype == DT_BF16) { if (ht == 2) LLB1(bf16, 2); else LLB1(bf16, 4); }
+  else if (dtype == DT_F16) { if (ht == 2) LLB1(f16, 2); else LLB1(f16, 4); }
   else { if (ht == 2) LLB1(float, 2); else LLB1(float, 4); }
 #undef LLB1
   return launch_status();
@@ -1432,8 +1435,8 @@ struct magic_dw_desc { const void* dY; const void* X; float* dW; float* db; int 
 
 extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, void* stream) {
   if (n <= 0 || n > DW_MAX || !d) return MAGIC_ERR_ARG;
-  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
-  const int ve = dtype == DT_BF16 ? 8 : 4;
+  if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  const int ve = dtype_is16(dtype) ? 8 : 4;
   DwBatch gp;
   gp.n = n;
   int total = 0;
@@ -1455,6 +1458,7 @@ extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, v
   dim3 grid(total), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) hipLaunchKernelGGL((gemm_dw_batch_kernel<bf16>), grid, block, 0, st, gp);
+  else if (dtype == DT_F16) hipLaunchKernelGGL((gemm_dw_batch_kernel<f16>), grid, block, 0, st, gp);
   else hipLaunchKernelGGL((gemm_dw_batch_kernel<float>), grid, block, 0, st, gp);
   return launch_status();
 }

@@ -245,6 +245,7 @@ extern "C" int magic_csr_gather(int dtype, int n_out, int H, const void* src, co
   dim3 grid((n_out + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) hipLaunchKernelGGL(csr_gather_kernel<bf16>, grid, block, 0, st, n_out, H, (const bf16*)src, ptr, idx, w, (bf16*)out, accumulate);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(csr_gather_kernel<f16>, grid, block, 0, st, n_out, H, (const f16*)src, ptr, idx, w, (f16*)out, accumulate);
   else hipLaunchKernelGGL(csr_gather_kernel<float>, grid, block, 0, st, n_out, H, (const float*)src, ptr, idx, w, (float*)out, accumulate);
   return launch_status();
 }
@@ -265,6 +266,7 @@ extern "C" int magic_csr_gather_multi(int dtype, int H, int n, const magic_csr_p
   dim3 grid(total), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) hipLaunchKernelGGL(csr_gather_multi_kernel<bf16>, grid, block, 0, st, mm);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(csr_gather_multi_kernel<f16>, grid, block, 0, st, mm);
   else hipLaunchKernelGGL(csr_gather_multi_kernel<float>, grid, block, 0, st, mm);
   return launch_status();
 }
@@ -275,6 +277,7 @@ extern "C" int magic_pano_fuse_fwd(int dtype, int N, int V, int H, const void* x
   dim3 grid(N), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) hipLaunchKernelGGL(pano_fuse_fwd_kernel<bf16>, grid, block, 0, st, N, V, H, (const bf16*)x, lens, wf, bf, (bf16*)fused, probs);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(pano_fuse_fwd_kernel<f16>, grid, block, 0, st, N, V, H, (const f16*)x, lens, wf, bf, (f16*)fused, probs);
   else hipLaunchKernelGGL(pano_fuse_fwd_kernel<float>, grid, block, 0, st, N, V, H, (const float*)x, lens, wf, bf, (float*)fused, probs);
   return launch_status();
 }
@@ -285,6 +288,7 @@ extern "C" int magic_pano_fuse_bwd(int dtype, int N, int V, int H, const void* x
   dim3 grid((N + PF_PB - 1) / PF_PB), block(256 * PF_PB);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) hipLaunchKernelGGL(pano_fuse_bwd_kernel<bf16>, grid, block, 0, st, N, V, H, (const bf16*)x, probs, wf, (const bf16*)dfused, (bf16*)dx, dwf, dbf);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(pano_fuse_bwd_kernel<f16>, grid, block, 0, st, N, V, H, (const f16*)x, probs, wf, (const f16*)dfused, (f16*)dx, dwf, dbf);
   else hipLaunchKernelGGL(pano_fuse_bwd_kernel<float>, grid, block, 0, st, N, V, H, (const float*)x, probs, wf, (const float*)dfused, (float*)dx, dwf, dbf);
   return launch_status();
 }
@@ -347,14 +351,15 @@ __global__ __launch_bounds__(256) void view_gather_kernel(long long rows, int V,
 extern "C" int magic_view_gather(int dtype, int Np, int V, int D, const void* table, int n_viewpoints, const int* vp_row,
                                  const int* order, void* out, void* stream) {
   if (Np <= 0 || V <= 0 || D <= 0 || n_viewpoints <= 0 || !table || !vp_row || !order || !out) return MAGIC_ERR_ARG;
-  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
-  const int ve = dtype == DT_BF16 ? 8 : 4;
+  if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  const int ve = dtype_is16(dtype) ? 8 : 4;
   if (D % ve || ((uintptr_t)table & 15) || ((uintptr_t)out & 15)) return MAGIC_ERR_ARG;
   const long long rows = (long long)Np * V;
   const long long chunks = (rows * (D / ve) + 256 * 4 - 1) / (256 * 4);
   dim3 grid((unsigned)(chunks < 1 ? 1 : chunks)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) hipLaunchKernelGGL(view_gather_kernel<bf16>, grid, block, 0, st, rows, V, D, (const bf16*)table, n_viewpoints, vp_row, order, (bf16*)out);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(view_gather_kernel<f16>, grid, block, 0, st, rows, V, D, (const f16*)table, n_viewpoints, vp_row, order, (f16*)out);
   else hipLaunchKernelGGL(view_gather_kernel<float>, grid, block, 0, st, rows, V, D, (const float*)table, n_viewpoints, vp_row, order, (float*)out);
   return launch_status();
 }

@@ -8,7 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 
-enum GroupKind { KIND_NONE = 0, KIND_GEMM = 1, KIND_ATTN_FWD = 2, KIND_ATTN_BWD = 3, KIND_LLN = 4, KIND_LNB = 5, KIND_RB = 6, KIND_LLB = 7 };
+enum GroupKind { KIND_NONE = 0, KIND_GEMM = 1, KIND_ATTN_FWD = 2, KIND_ATTN_BWD = 3, KIND_LLN = 4, KIND_LNB = 5, KIND_LLB = 7 };
 
 struct GroupRec { int kind, dtype, variant; alignas(16) unsigned char blob[1024]; };
 #define GROUP_CAP 8
@@ -33,5 +33,4 @@ int launch_attn_fwd(int dtype, int variant, const void* pa, const void* pb, hipS
 int launch_attn_bwd(int dtype, int variant, const void* pa, const void* pb, hipStream_t st);
 int launch_lln(int dtype, int ht, const void* pa, const void* pb, hipStream_t st);
 int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t st);
-int launch_rb(int dtype, int variant, const void* pa, const void* pb, hipStream_t st);
 int launch_llb(int dtype, int ht, const void* pa, const void* pb, hipStream_t st);

@@ -56,19 +56,20 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int M, int N, const T* log
 // loads/stores and ONE statistics pass (online max / sum-exp) instead of two, so a row is read twice and written once.  Same
 // contract as ce_rows_kernel (in-place gradient allowed: a thread only rewrites vectors it has read itself, and x[label] is read
 // by everybody before the first block barrier).  Needs ld, ldd multiples of 8 and 16-byte aligned bases; no accumulate.
-__global__ __launch_bounds__(256) void ce_rows_wide_kernel(int M, int N, const bf16* logits, int ld, const int* labels, int ignore_index,
-                                                           float coef, const float* row_w, float* loss_row, bf16* dlogits, int ldd,
+template <typename Hh>
+__global__ __launch_bounds__(256) void ce_rows_wide_kernel(int M, int N, const Hh* logits, int ld, const int* labels, int ignore_index,
+                                                           float coef, const float* row_w, float* loss_row, Hh* dlogits, int ldd,
                                                            float* w_out, float w_rate) {
   __shared__ float red[8];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const bf16* x = logits + (long long)row * ld;
+  const Hh* x = logits + (long long)row * ld;
   const int lab = labels[row];
   const bool ignored = (lab == ignore_index) || lab < 0 || lab >= N;
   const float xl = ignored ? 0.f : to_f(x[lab]);
   const int nvec = (N + 7) >> 3;
   float mx = -3.0e38f, s = 0.f;
   for (int v = tid; v < nvec; v += 256) {
-    const bf16x8 q = *(const bf16x8*)(x + v * 8);
+    const h16x8<Hh> q = *(const h16x8<Hh>*)(x + v * 8);
     float f[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] = (v * 8 + e < N) ? (float)q[e] : -3.0e38f;
@@ -102,22 +103,22 @@ __global__ __launch_bounds__(256) void ce_rows_wide_kernel(int M, int N, const b
   }
   if (dlogits) {
     const float cf = ignored ? 0.f : coef * (row_w ? row_w[row] : 1.f);
-    bf16* d = dlogits + (long long)row * ldd;
+    Hh* d = dlogits + (long long)row * ldd;
     const int dvec = ldd >> 3;
     for (int v = tid; v < dvec; v += 256) {
-      bf16x8 g;
+      h16x8<Hh> g;
       if (v < nvec) {
-        const bf16x8 q = *(const bf16x8*)(x + v * 8);
+        const h16x8<Hh> q = *(const h16x8<Hh>*)(x + v * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int c = v * 8 + e;
-          g[e] = (bf16)(c < N ? cf * (__expf((float)q[e] - lse) - (c == lab ? 1.f : 0.f)) : 0.f);
+          g[e] = (Hh)(c < N ? cf * (__expf((float)q[e] - lse) - (c == lab ? 1.f : 0.f)) : 0.f);
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = (bf16)0.f;
+        for (int e = 0; e < 8; ++e) g[e] = (Hh)0.f;
       }
-      *(bf16x8*)(d + v * 8) = g;
+      *(h16x8<Hh>*)(d + v * 8) = g;
     }
   }
 }
@@ -286,11 +287,11 @@ __device__ __forceinline__ void mse_body(const magic_mse_desc& p, int bid, int n
 
 // bf16 problems whose rows are multiples of 8 elements at 16-byte-aligned addresses: 8 elements per lane and iteration, 32-bit index
 // arithmetic, two iterations' loads in flight.
-template <typename G>
+template <typename Hh, typename G>
 __device__ __forceinline__ void mse_body_v8(const magic_mse_desc& p, int bid, int nblk, float* red) {
   float coef = p.coef;
   if (p.coef_dev) coef *= p.coef_dev[0];
-  const bf16* s = (const bf16*)p.s; const bf16* t = (const bf16*)p.t; G* ds = (G*)p.ds;
+  const Hh* s = (const Hh*)p.s; const Hh* t = (const Hh*)p.t; G* ds = (G*)p.ds;
   const unsigned in8 = (unsigned)(p.inner >> 3), tot8 = (unsigned)p.outer * in8, rpw = (unsigned)p.rows_per_w;
   const unsigned stride = (unsigned)nblk * MSE_NT;
   const unsigned vo = p.valid_dev ? (unsigned)p.valid_dev[0] : (unsigned)p.outer, vi = p.valid_dev ? (unsigned)p.valid_dev[1] : (unsigned)p.inner;
@@ -299,7 +300,7 @@ __device__ __forceinline__ void mse_body_v8(const magic_mse_desc& p, int bid, in
   const unsigned vm = (unsigned)p.valid_mod;
   float acc = 0.f;
   for (unsigned i0 = (unsigned)bid * MSE_NT + threadIdx.x; i0 < tot8; i0 += 2 * stride) {
-    bf16x8 sv[2], tv[2];
+    h16x8<Hh> sv[2], tv[2];
     unsigned o[2], r[2];
     bool ok[2];
 #pragma unroll
@@ -308,8 +309,8 @@ __device__ __forceinline__ void mse_body_v8(const magic_mse_desc& p, int bid, in
       ok[u] = i < tot8;
       const unsigned ii = ok[u] ? i : i0;
       o[u] = ii / in8; r[u] = (ii - o[u] * in8) << 3;
-      sv[u] = *(const bf16x8*)(s + (long long)o[u] * p.s_stride + r[u]);
-      tv[u] = *(const bf16x8*)(t + (long long)o[u] * p.t_stride + r[u]);
+      sv[u] = *(const h16x8<Hh>*)(s + (long long)o[u] * p.s_stride + r[u]);
+      tv[u] = *(const h16x8<Hh>*)(t + (long long)o[u] * p.t_stride + r[u]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -331,16 +332,16 @@ __device__ __forceinline__ void mse_body_v8(const magic_mse_desc& p, int bid, in
           if (p.accumulate) { g0 += *(const f32x4*)q; g1 += *(const f32x4*)(q + 4); }
           *(f32x4*)q = g0; *(f32x4*)(q + 4) = g1;
         } else {
-          bf16x8 g;
+          h16x8<Hh> g;
           if (p.accumulate) {
-            const bf16x8 old = *(const bf16x8*)q;
+            const h16x8<Hh> old = *(const h16x8<Hh>*)q;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] = (bf16)(cw * d[e] + (float)old[e]);
+            for (int e = 0; e < 8; ++e) g[e] = (Hh)(cw * d[e] + (float)old[e]);
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] = (bf16)(cw * d[e]);
+            for (int e = 0; e < 8; ++e) g[e] = (Hh)(cw * d[e]);
           }
-          *(bf16x8*)q = g;
+          *(h16x8<Hh>*)q = g;
         }
       }
     }
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(MSE_NT) void mse_multi_kernel(MseMulti mm) {
   const magic_mse_desc& p = mm.d[i];
   const int bid = blockIdx.x - mm.start[i], nblk = mm.start[i + 1] - mm.start[i];
   if constexpr (sizeof(T) == 4) mse_body<float, float>(p, bid, nblk, red);
-  else if (mm.vec[i]) { if (p.g_f32) mse_body_v8<float>(p, bid, nblk, red); else mse_body_v8<bf16>(p, bid, nblk, red); }
+  else if (mm.vec[i]) { if (p.g_f32) mse_body_v8<T, float>(p, bid, nblk, red); else mse_body_v8<T, T>(p, bid, nblk, red); }
   else { if (p.g_f32) mse_body<T, float>(p, bid, nblk, red); else mse_body<T, T>(p, bid, nblk, red); }
 }
 
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(MSE_NT) void mse_multi_kernel(MseMulti mm) {
 #define MSE_BLOCKS 256
 extern "C" int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* stream) {
   if (n <= 0 || n > MSE_MAX || !d) return MAGIC_ERR_ARG;
-  if (dtype != DT_F32 && dtype != DT_BF16) return MAGIC_ERR_ARG;
+  if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
   MseMulti mm;
   mm.n = n;
   long long work[MSE_MAX], all = 0;
@@ -382,7 +383,7 @@ extern "C" int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* 
     mm.d[i] = d[i];
     const long long tot = d[i].outer * d[i].inner;
     const magic_mse_desc& q = d[i];
-    const bool vec = dtype == DT_BF16 && tot < 0x7FFFFFFFll && q.inner % 8 == 0 && q.s_stride % 8 == 0 && q.t_stride % 8 == 0 &&
+    const bool vec = dtype_is16(dtype) && tot < 0x7FFFFFFFll && q.inner % 8 == 0 && q.s_stride % 8 == 0 && q.t_stride % 8 == 0 &&
                      !((uintptr_t)q.s & 15) && !((uintptr_t)q.t & 15) && (!q.ds || (q.g_stride % 8 == 0 && !((uintptr_t)q.ds & 15))) && q.valid_mod % 8 == 0;
     mm.vec[i] = vec ? 1 : 0;
     work[i] = vec ? (tot + 7) / 8 : tot;          // lane-iterations
@@ -401,6 +402,7 @@ extern "C" int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* 
   dim3 grid(total), block(MSE_NT);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) hipLaunchKernelGGL(mse_multi_kernel<bf16>, grid, block, 0, st, mm);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(mse_multi_kernel<f16>, grid, block, 0, st, mm);
   else hipLaunchKernelGGL(mse_multi_kernel<float>, grid, block, 0, st, mm);
   return launch_status();
 }
@@ -523,17 +525,20 @@ extern "C" int magic_cfp_loss(int dtype, int B, int H, const void* a0, const voi
   if (((uintptr_t)a0 | (uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)txt) & 15) return MAGIC_ERR_ARG;
   if ((d0 == nullptr) != (d1 == nullptr) || (d0 == nullptr) != (d2 == nullptr) || (d0 == nullptr) != (dtxt == nullptr)) return MAGIC_ERR_ARG;
   if (dtxt && (!part || !counter)) return MAGIC_ERR_ARG;
-  if (dtype != DT_BF16 && dtype != DT_F32) return MAGIC_ERR_ARG;
+  if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const size_t shm = cfp_lds_bytes(H, dtype == DT_BF16 ? 2 : 4);
+  const size_t shm = cfp_lds_bytes(H, dtype_is16(dtype) ? 2 : 4);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)cfp_loss_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfp_lds_bytes(256, 2));
+    (void)hipFuncSetAttribute((const void*)cfp_loss_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfp_lds_bytes(256, 2));
     (void)hipFuncSetAttribute((const void*)cfp_loss_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfp_lds_bytes(256, 4));
     attr_set = true;
   }
   if (dtype == DT_BF16) hipLaunchKernelGGL(cfp_loss_kernel<bf16>, dim3(3), dim3(1024), shm, st, B, H, (const bf16*)a0, (const bf16*)a1, (const bf16*)a2, (const bf16*)txt,
                                            1.f / temperature, coef, rows, (bf16*)d0, (bf16*)d1, (bf16*)d2, (bf16*)dtxt, part, counter);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(cfp_loss_kernel<f16>, dim3(3), dim3(1024), shm, st, B, H, (const f16*)a0, (const f16*)a1, (const f16*)a2, (const f16*)txt,
+                                               1.f / temperature, coef, rows, (f16*)d0, (f16*)d1, (f16*)d2, (f16*)dtxt, part, counter);
   else hipLaunchKernelGGL(cfp_loss_kernel<float>, dim3(3), dim3(1024), shm, st, B, H, (const float*)a0, (const float*)a1, (const float*)a2, (const float*)txt,
                           1.f / temperature, coef, rows, (float*)d0, (float*)d1, (float*)d2, (float*)dtxt, part, counter);
   return launch_status();
@@ -545,12 +550,16 @@ extern "C" int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld
   if (M <= 0 || N <= 0 || ld < N || (dlogits && ldd < N)) return MAGIC_ERR_ARG;
   dim3 grid(M), block(256);
   hipStream_t st = (hipStream_t)stream;
-  const bool wide = dtype == DT_BF16 && N >= 2048 && !accumulate && (ld % 8) == 0 && (!dlogits || (ldd % 8) == 0) &&
+  const bool wide = dtype_is16(dtype) && N >= 2048 && !accumulate && (ld % 8) == 0 && (!dlogits || (ldd % 8) == 0) &&
                     (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0;
-  if (wide)
-    hipLaunchKernelGGL(ce_rows_wide_kernel, grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, w_out, w_rate);
+  if (wide && dtype == DT_BF16)
+    hipLaunchKernelGGL(ce_rows_wide_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, w_out, w_rate);
+  else if (wide)
+    hipLaunchKernelGGL(ce_rows_wide_kernel<f16>, grid, block, 0, st, M, N, (const f16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (f16*)dlogits, ldd, w_out, w_rate);
   else if (dtype == DT_BF16)
     hipLaunchKernelGGL(ce_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, accumulate, w_out, w_rate);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL(ce_rows_kernel<f16>, grid, block, 0, st, M, N, (const f16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (f16*)dlogits, ldd, accumulate, w_out, w_rate);
   else
     hipLaunchKernelGGL(ce_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (float*)dlogits, ldd, accumulate, w_out, w_rate);
   return launch_status();
@@ -563,6 +572,8 @@ extern "C" int magic_softkl_rows(int dtype, int M, int N, const void* logits, in
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(softkl_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, targets, ldt, coef, loss_row, (bf16*)dlogits, ldd);
+  else if (dtype == DT_F16)
+    hipLaunchKernelGGL(softkl_rows_kernel<f16>, grid, block, 0, st, M, N, (const f16*)logits, ld, targets, ldt, coef, loss_row, (f16*)dlogits, ldd);
   else if (dtype == DT_F32)
     hipLaunchKernelGGL(softkl_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, targets, ldt, coef, loss_row, (float*)dlogits, ldd);
   else return MAGIC_ERR_ARG;
@@ -588,6 +599,7 @@ extern "C" int magic_mse(int dtype, int g_f32, long long outer, long long inner,
   hipStream_t st = (hipStream_t)stream;
 #define L(TY, GY) hipLaunchKernelGGL((mse_kernel<TY, GY>), grid, block, 0, st, outer, inner, (const TY*)s, s_stride, (const TY*)t, t_stride, w, rows_per_w, norm, coef, coef_dev, loss, (GY*)ds, g_stride, accumulate)
   if (dtype == DT_BF16) { if (g_f32) L(bf16, float); else L(bf16, bf16); }
+  else if (dtype == DT_F16) { if (g_f32) L(f16, float); else L(f16, f16); }
   else { L(float, float); }
 #undef L
   return launch_status();

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(long long n, const float* _
 // Gradient clipping folded in: g *= min(1, max_norm / (sqrt(sumsq) + 1e-6)) (clip_grad_norm_ semantics),
 // and the gradient pre-scale `gscale` (e.g. 1/world_size after a sum all-reduce).  Optionally refreshes
 // the bf16 shadow copy used by the MFMA kernels.
-__global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, const float* g, float* m, float* v, bf16* shadow,
+template <typename Hh>
+__global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, const float* g, float* m, float* v, Hh* shadow,
                                                     float lr, float b1, float b2, float eps, float wd, float step_size,
                                                     const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay) {
   if (lr_ss) { lr = lr_ss[0]; step_size = lr_ss[1]; }     // device-side schedule (HIP-graph replay)
@@ -49,21 +50,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, const
     float pi = p[i] - step_size * mi / (sqrtf(vi) + eps);
     if (wd > 0.f && i < n_decay) pi -= lr * wd * pi;        // [0, n_decay): the decayed group (optim/misc.py:13-22), the rest: biases / LayerNorm
     m[i] = mi; v[i] = vi; p[i] = pi;
-    if (shadow) shadow[i] = (bf16)pi;
+    if (shadow) shadow[i] = (Hh)pi;
   }
 }
 
-__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(long long n, const float* x, bf16* y) {
+template <typename Hh>
+__global__ __launch_bounds__(256) void cast_f32_h16_kernel(long long n, const float* x, Hh* y) {
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const float4 v = ((const float4*)x)[i];
-    bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
-    ((bf16x4*)y)[i] = o;
+    h16x4<Hh> o; o[0] = (Hh)v.x; o[1] = (Hh)v.y; o[2] = (Hh)v.z; o[3] = (Hh)v.w;
+    ((h16x4<Hh>*)y)[i] = o;
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[(n4 << 2) + threadIdx.x] = (bf16)x[(n4 << 2) + threadIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[(n4 << 2) + threadIdx.x] = (Hh)x[(n4 << 2) + threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(long long n, const bf16* x, float* y) {
+template <typename Hh>
+__global__ __launch_bounds__(256) void cast_h16_f32_kernel(long long n, const Hh* x, float* y) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = (float)x[i];
 }
 
@@ -113,23 +116,31 @@ extern "C" int magic_sumsq(long long n, const float* g, float* out, void* stream
   return launch_status();
 }
 
-extern "C" int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow_bf16,
+extern "C" int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype,
                            float lr, float b1, float b2, float eps, float wd, float step_size,
                            const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, void* stream) {
-  if (n <= 0) return MAGIC_ERR_ARG;
+  if (n <= 0 || (shadow && !dtype_is16(shadow_dtype))) return MAGIC_ERR_ARG;
   if (n_decay < 0) n_decay = n;                    // the whole range is one group
-  hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (bf16*)shadow_bf16, lr, b1, b2, eps, wd,
-                     step_size, sumsq, max_norm, gscale, lr_ss, n_decay);
+  if (shadow && shadow_dtype == DT_F16)
+    hipLaunchKernelGGL(adamw_kernel<f16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (f16*)shadow, lr, b1, b2, eps, wd,
+                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay);
+  else
+    hipLaunchKernelGGL(adamw_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (bf16*)shadow, lr, b1, b2, eps, wd,
+                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay);
   return launch_status();
 }
 
-extern "C" int magic_cast(int to_bf16, long long n, const void* x, void* y, void* stream) {
-  if (n <= 0) return MAGIC_ERR_ARG;
-  if (to_bf16) {
+// dtype16 = DT_BF16 | DT_F16: the 16-bit side of the conversion; to16 != 0: fp32 -> 16-bit, else 16-bit -> fp32
+extern "C" int magic_cast(int dtype16, int to16, long long n, const void* x, void* y, void* stream) {
+  if (n <= 0 || !dtype_is16(dtype16)) return MAGIC_ERR_ARG;
+  const hipStream_t st = (hipStream_t)stream;
+  if (to16) {
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return MAGIC_ERR_ARG;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, (hipStream_t)stream, n, (const float*)x, (bf16*)y);
+    if (dtype16 == DT_BF16) hipLaunchKernelGGL(cast_f32_h16_kernel<bf16>, dim3(nblocks(n, 1024)), dim3(256), 0, st, n, (const float*)x, (bf16*)y);
+    else hipLaunchKernelGGL(cast_f32_h16_kernel<f16>, dim3(nblocks(n, 1024)), dim3(256), 0, st, n, (const float*)x, (f16*)y);
   } else {
-    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const bf16*)x, (float*)y);
+    if (dtype16 == DT_BF16) hipLaunchKernelGGL(cast_h16_f32_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, st, n, (const bf16*)x, (float*)y);
+    else hipLaunchKernelGGL(cast_h16_f32_kernel<f16>, dim3(nblocks(n, 256)), dim3(256), 0, st, n, (const f16*)x, (float*)y);
   }
   return launch_status();
 }
@@ -137,6 +148,7 @@ extern "C" int magic_cast(int to_bf16, long long n, const void* x, void* y, void
 extern "C" int magic_add(int dtype, long long n, const void* x, void* y, void* stream) {
   if (n <= 0) return MAGIC_ERR_ARG;
   if (dtype == DT_BF16) hipLaunchKernelGGL(add_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const bf16*)x, (bf16*)y);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(add_kernel<f16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const f16*)x, (f16*)y);
   else hipLaunchKernelGGL(add_kernel<float>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const float*)x, (float*)y);
   return launch_status();
 }
@@ -149,10 +161,11 @@ extern "C" int magic_add_n(int dtype, long long n, int count, const void* const*
     a.x[j] = j < count ? xs[j] : nullptr;
     if (j < count && (!xs[j] || ((uintptr_t)xs[j] & 15))) return MAGIC_ERR_ARG;
   }
-  const int ve = dtype == DT_BF16 ? 8 : 4;
+  const int ve = dtype_is16(dtype) ? 8 : 4;
   const long long n8 = n / ve;
   const int nb = nblocks(n8 > 0 ? n8 : 1, 256);
   if (dtype == DT_BF16) hipLaunchKernelGGL(add_n_kernel<bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, n8, n, (bf16*)y, a);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(add_n_kernel<f16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, n8, n, (f16*)y, a);
   else if (dtype == DT_F32) hipLaunchKernelGGL(add_n_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, n8, n, (float*)y, a);
   else return MAGIC_ERR_ARG;
   return launch_status();
@@ -189,6 +202,7 @@ __global__ __launch_bounds__(256) void dact_kernel(long long n, const T* dy, con
 extern "C" int magic_dact(int dtype, int kind, long long n, const void* dy, const void* z, void* dz, void* stream) {
   if (n <= 0 || (kind != 1 && kind != 2)) return MAGIC_ERR_ARG;
   if (dtype == DT_BF16) hipLaunchKernelGGL(dact_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const bf16*)dy, (const bf16*)z, (bf16*)dz, kind);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(dact_kernel<f16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const f16*)dy, (const f16*)z, (f16*)dz, kind);
   else hipLaunchKernelGGL(dact_kernel<float>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const float*)dy, (const float*)z, (float*)dz, kind);
   return launch_status();
 }
@@ -235,7 +249,6 @@ static int launch_one(const GroupRec& r, const GroupRec* other, hipStream_t st) 
     case KIND_ATTN_BWD: return launch_attn_bwd(r.dtype, r.variant, r.blob, pb, st);
     case KIND_LLN: return launch_lln(r.dtype, r.variant, r.blob, pb, st);
     case KIND_LNB: return launch_lnb(r.dtype, r.variant, r.blob, pb, st);
-    case KIND_RB: return launch_rb(r.dtype, r.variant, r.blob, pb, st);
     case KIND_LLB: return launch_llb(r.dtype, r.variant, r.blob, pb, st);
     default: return MAGIC_ERR_ARG;
   }

@@ -17,11 +17,20 @@ template <> __device__ __forceinline__ void ld2<bf16>(const bf16* p, float& a, f
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   bf16x2 v = *(const bf16x2*)p; a = (float)v[0]; b = (float)v[1];
 }
+template <> __device__ __forceinline__ void ld2<f16>(const f16* p, float& a, float& b) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+  f16x2 v = *(const f16x2*)p; a = (float)v[0]; b = (float)v[1];
+}
 template <typename T> __device__ __forceinline__ void st2(T* p, float a, float b);
 template <> __device__ __forceinline__ void st2<float>(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
 template <> __device__ __forceinline__ void st2<bf16>(bf16* p, float a, float b) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   bf16x2 v; v[0] = (bf16)a; v[1] = (bf16)b; *(bf16x2*)p = v;
+}
+
+template <> __device__ __forceinline__ void st2<f16>(f16* p, float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+  f16x2 v; v[0] = (f16)a; v[1] = (f16)b; *(f16x2*)p = v;
 }
 
 struct TabRef {          // embedding-table term: row = idx ? idx[r] : (mod ? r % mod + off : off)
@@ -814,14 +823,22 @@ __global__ __launch_bounds__(256) void lndot_bwd_kernel(int M, int H, const T* Y
 
 // ============================================================================================
 static inline bool okH(int H) { return H >= 128 && H <= 128 * MAXIT && (H % 128) == 0; }
-#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
-  do { if ((dtype) == DT_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
+// CALL is written once over the type name TY
+#define DISPATCH_T(dtype, ...)                                                        \
+  do {                                                                                \
+    if ((dtype) == DT_BF16) { typedef bf16 TY; __VA_ARGS__; }                          \
+    else if ((dtype) == DT_F16) { typedef f16 TY; __VA_ARGS__; }                       \
+    else { typedef float TY; __VA_ARGS__; }                                           \
+  } while (0)
 // H in {128, 256, 384, 768} = the S / M / B / L family (run_r2r_kdl_valid.sh:85-94)
 #define DISPATCH_NIT(dtype, H, F)                                                                     \
   do {                                                                                                \
     if ((dtype) == DT_BF16) {                                                                         \
       if ((H) == 128) F(bf16, 1); else if ((H) == 256) F(bf16, 2); else if ((H) == 384) F(bf16, 3);   \
       else if ((H) == 768) F(bf16, 6); else return MAGIC_ERR_UNSUPPORTED;                             \
+    } else if ((dtype) == DT_F16) {                                                                   \
+      if ((H) == 128) F(f16, 1); else if ((H) == 256) F(f16, 2); else if ((H) == 384) F(f16, 3);      \
+      else if ((H) == 768) F(f16, 6); else return MAGIC_ERR_UNSUPPORTED;                              \
     } else {                                                                                          \
       if ((H) == 128) F(float, 1); else if ((H) == 256) F(float, 2); else if ((H) == 384) F(float, 3); \
       else if ((H) == 768) F(float, 6); else return MAGIC_ERR_UNSUPPORTED;                            \
@@ -900,6 +917,7 @@ int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t s
     }                                                                                                   \
   } while (0)
   if (dtype == DT_BF16) { if (nit == 1) LNB1(bf16, 1, 16); else if (nit == 2) LNB1(bf16, 2, 8); else if (nit == 3) LNB1(bf16, 3, 4); else LNB1(bf16, 6, 4); }
+  else if (dtype == DT_F16) { if (nit == 1) LNB1(f16, 1, 16); else if (nit == 2) LNB1(f16, 2, 8); else if (nit == 3) LNB1(f16, 3, 4); else LNB1(f16, 6, 4); }
   else { if (nit == 1) LNB1(float, 1, 16); else if (nit == 2) LNB1(float, 2, 8); else if (nit == 3) LNB1(float, 3, 4); else LNB1(float, 6, 4); }
 #undef LNB1
   return launch_status();
@@ -999,8 +1017,7 @@ extern "C" int magic_softmax_fwd(int dtype, int B, int nh, int Nq, int Nk, int l
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, block, 0, st, B, nh, Nq, Nk, ldp, S, (float*)P, scale, kmask, dist, sprel_w, sprel_b),
-             hipLaunchKernelGGL(softmax_fwd_kernel<bf16>, grid, block, 0, st, B, nh, Nq, Nk, ldp, S, (bf16*)P, scale, kmask, dist, sprel_w, sprel_b));
+             hipLaunchKernelGGL((softmax_fwd_kernel<TY>), grid, block, 0, st, B, nh, Nq, Nk, ldp, S, (TY*)P, scale, kmask, dist, sprel_w, sprel_b));
   return launch_status();
 }
 
@@ -1012,8 +1029,7 @@ extern "C" int magic_softmax_bwd(int dtype, int B, int nh, int Nq, int Nk, int l
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, block, 0, st, B, nh, Nq, Nk, ldp, (const float*)P, dP, (float*)dS, scale, dist, dsprel_w, dsprel_b),
-             hipLaunchKernelGGL(softmax_bwd_kernel<bf16>, grid, block, 0, st, B, nh, Nq, Nk, ldp, (const bf16*)P, dP, (bf16*)dS, scale, dist, dsprel_w, dsprel_b));
+             hipLaunchKernelGGL((softmax_bwd_kernel<TY>), grid, block, 0, st, B, nh, Nq, Nk, ldp, (const TY*)P, dP, (TY*)dS, scale, dist, dsprel_w, dsprel_b));
   return launch_status();
 }
 
@@ -1023,8 +1039,7 @@ extern "C" int magic_head_mean_fwd(int dtype, int B, int nh, long long inner, co
   dim3 grid((unsigned)((n + 255) / 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(head_mean_fwd_kernel<float>, grid, block, 0, st, B, nh, inner, (const float*)P, out),
-             hipLaunchKernelGGL(head_mean_fwd_kernel<bf16>, grid, block, 0, st, B, nh, inner, (const bf16*)P, out));
+             hipLaunchKernelGGL((head_mean_fwd_kernel<TY>), grid, block, 0, st, B, nh, inner, (const TY*)P, out));
   return launch_status();
 }
 
@@ -1083,6 +1098,7 @@ extern "C" int magic_dropout(int dtype, long long rows, int cols, int ld, const 
   dim3 grid((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16) hipLaunchKernelGGL(dropout_kernel<bf16>, grid, block, 0, st, rows, cols, ld, (const bf16*)in, (bf16*)out, d);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(dropout_kernel<f16>, grid, block, 0, st, rows, cols, ld, (const f16*)in, (f16*)out, d);
   else if (dtype == DT_F32) hipLaunchKernelGGL(dropout_kernel<float>, grid, block, 0, st, rows, cols, ld, (const float*)in, (float*)out, d);
   else return MAGIC_ERR_ARG;
   return launch_status();

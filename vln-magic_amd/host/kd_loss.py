@@ -24,7 +24,7 @@ class _MSE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s, t, w, norm):
         _need_cuda(s, t, w)
-        dt = s.dtype if s.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        dt = s.dtype if s.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32
         sc, tc = s.detach().to(dt).contiguous(), t.detach().to(dt).contiguous()
         outer = sc.shape[0]
         inner = sc.numel() // outer

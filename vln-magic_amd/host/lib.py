@@ -57,10 +57,10 @@ SIGNATURES = {
     "magic_sap_fuse_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
     "magic_sap_fuse_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "magic_sumsq": [i64, vp, vp, vp],
-    "magic_adamw": [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i64, vp],
+    "magic_adamw": [i64, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i64, vp],
     "magic_sched_step": [vp, f32, i32, i32, f32, f32, vp, vp, vp],
     "magic_add_n": [i32, i64, i32, vp, vp, vp],
-    "magic_cast": [i32, i64, vp, vp, vp],
+    "magic_cast": [i32, i32, i64, vp, vp, vp],
     "magic_add": [i32, i64, vp, vp, vp],
     "magic_dact": [i32, i32, i64, vp, vp, vp, vp],
     "magic_view_gather": [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp],
@@ -68,13 +68,13 @@ SIGNATURES = {
     "magic_get_f32_mfma": [],
     "magic_encoder_supported": [i32, i32, i32, i32, i32, i32],
     "magic_encoder_params_bytes": [],
-    "magic_encoder_fwd": [vp, i32, vp],
+    "magic_encoder_fwd": [i32, vp, i32, vp],
     "magic_xencoder_supported": [i32, i32, i32, i32, i32, i32, i32],
     "magic_xencoder_params_bytes": [],
-    "magic_xencoder_fwd": [vp, i32, vp],
+    "magic_xencoder_fwd": [i32, vp, i32, vp],
     "magic_rowbwd_supported": [i32, i32, i32],
     "magic_rowbwd_params_bytes": [],
-    "magic_rowbwd": [vp, i32, vp],
+    "magic_rowbwd": [i32, vp, i32, vp],
     "magic_transpose_spans": [vp, vp, i32, vp, vp, vp, vp],
     "magic_group_begin": [],
     "magic_group_end": [vp],
@@ -417,9 +417,14 @@ def set_f32_mfma(mode):
     return prev
 
 
+HALF = (torch.bfloat16, torch.float16)     # the two 16-bit storage types: every MFMA kernel exists for both (csrc/common.hpp H16<>)
+
+
 def dt(dtype):
     if dtype == torch.float32:
         return 0
     if dtype == torch.bfloat16:
         return 1
+    if dtype == torch.float16:
+        return 2
     raise MagicHipError(f"unsupported compute dtype {dtype}")

@@ -63,6 +63,9 @@ class _BackwardHook(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         ctx.model.backward()
+        m = ctx.model
+        if m.grad_scale != 1.0:        # hand autograd's contract back: .grad = grad_out x dLoss/dparam (grad_out: e.g. a GradScaler's factor)
+            m.store.grad.mul_(grad_out.to(torch.float32) / m.grad_scale)
         from .trainer import auto_sync
         auto_sync(ctx.model)           # data parallel under an unmodified loop: average the flat gradient buffer here
         return None, None, None
@@ -85,6 +88,12 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         self._aux = torch.cuda.Stream(device=self.device_) if (self.device_.type == "cuda" and os.environ.get("MAGIC_PAR")) else None   # opt-in: measured slower under HIP-graph replay
         self._kd_idx = torch.tensor([0, 0, 1, 1, 1, 2, 2, 3, 3, 4], device=self.device_)
         self.keep_mlm_logits = False     # True: MLM CE gradient goes to its own buffer instead of overwriting the logits
+        # fp16 compute: every gradient SEED (the coefficient of each fused loss + gradient kernel) is multiplied by `grad_scale`, so the
+        # activation gradients stay inside fp16's range (the reference's own fp16 option scales the loss the same way: GradScaler,
+        # train_r2r_magic.py:370-371); the flat fp32 gradient buffer then holds grad_scale x the gradient and the optimizer divides
+        # (PretrainStep folds 1 / grad_scale into the AdamW kernel's gradient pre-scale; under `loss.backward()` the hook below does).
+        # A power of two: exact in every format.  Loss VALUES are never scaled.
+        self.grad_scale = 4096.0 if compute_dtype == torch.float16 else 1.0
         self.register_load_state_dict_post_hook(lambda m, k: setattr(m.store, "shadow_clean", False))
 
     # ---- HF-style constructor (train_r2r_magic.py:260-277) ------------------------------------------
@@ -391,6 +400,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         kd = t is not None and kdl is not None
         alpha = float(kdl["kd_alpha"]) if kd else 0.0
         sc = 1.0 - alpha
+        gs = float(self.grad_scale) if train else 1.0
+        scg = sc * gs                    # coefficient of the supervised gradient seeds (the loss values use sc)
         # every zero-initialised gradient accumulator of the step comes out of ONE zeroed arena per dtype (two fills instead of ~12 tiny ones)
         nm_ = plan["n_mask"] if task == "mlm" else 0
         f32 = n.zeros(16 + nm_ * H, dtype=torch.float32)
@@ -421,9 +432,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             c.dgl, c.dll, c.dfl = (n.new(B, K, dtype=torch.float32), n.new(B, Vp, dtype=torch.float32), n.new(B, K, dtype=torch.float32)) \
                 if train else (None, None, None)
             ga, la = plan["global_act_labels"], plan["local_act_labels"]
-            O.ce_rows(c.gl, B, K, K, ga, coef=sc / B, loss_row=c.rows[0], dlogits=c.dgl, ldd=K)
-            O.ce_rows(c.ll, B, Vp, Vp, la, coef=sc / B, loss_row=c.rows[1], dlogits=c.dll, ldd=Vp)
-            O.ce_rows(c.fl, B, K, K, ga, coef=sc / B, loss_row=c.rows[2], dlogits=c.dfl, ldd=K)
+            O.ce_rows(c.gl, B, K, K, ga, coef=scg / B, loss_row=c.rows[0], dlogits=c.dgl, ldd=K)
+            O.ce_rows(c.ll, B, Vp, Vp, la, coef=scg / B, loss_row=c.rows[1], dlogits=c.dll, ldd=Vp)
+            O.ce_rows(c.fl, B, K, K, ga, coef=scg / B, loss_row=c.rows[2], dlogits=c.dfl, ldd=K)
             sup = c.rows.sum() / B
         elif task == "mlm":
             c.d_x, c.d_gin0 = zz(B * L, H), zz(B * K, H)
@@ -431,7 +442,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             c.rows = n.new(nm, dtype=torch.float32)
             c.dlogits = (n.new(nm, c.ldv) if self.keep_mlm_logits else c.logits) if train else None
             roww = plan.get("mlm_row_w")      # shape buckets: nm counts padded (ignored) rows too, the true 1 / n_mask rides in per-row weights
-            O.ce_rows(c.logits, nm, cfg.vocab_size, c.ldv, plan["mlm_labels"], ignore_index=-1, coef=sc if roww is not None else sc / nm,
+            O.ce_rows(c.logits, nm, cfg.vocab_size, c.ldv, plan["mlm_labels"], ignore_index=-1, coef=scg if roww is not None else scg / nm,
                       row_w=roww, loss_row=c.rows, dlogits=c.dlogits, ldd=c.ldv)
             if train and not self.keep_mlm_logits:
                 o["predict"] = None          # overwritten in place by its gradient
@@ -441,7 +452,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             nm, Pn = plan["n_mrc"], c.mlogits.shape[1]
             c.rows = n.new(nm, dtype=torch.float32)
             c.dmlogits = n.new(nm, Pn) if train else None
-            O.softkl_rows(c.mlogits, nm, Pn, Pn, plan["mrc_targets"], coef=sc / nm, loss_row=c.rows, dlogits=c.dmlogits, ldd=Pn)
+            O.softkl_rows(c.mlogits, nm, Pn, Pn, plan["mrc_targets"], coef=scg / nm, loss_row=c.rows, dlogits=c.dmlogits, ldd=Pn)
             sup = c.rows.sum() / nm
         else:
             c.d_gmap, c.d_vp, c.d_txt2 = zz(B * K, H), zz(B * Vp, H), zz(B * L, H)
@@ -455,7 +466,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             fused = O.cfp_loss_ok(B, H)
             if fused:                            # the three contrastive terms, forward and backward, as one launch (csrc/loss.hip cfp_loss_kernel)
                 c.d_cfp = [n.new(B, H) for _ in range(4)] if train else None
-                O.cfp_loss(B, H, c.cfp[:3], txt_o, temp, sc * 0.5 / B, c.rows, d_a=c.d_cfp[:3] if train else None, d_txt=c.d_cfp[3] if train else None)
+                O.cfp_loss(B, H, c.cfp[:3], txt_o, temp, scg * 0.5 / B, c.rows, d_a=c.d_cfp[:3] if train else None, d_txt=c.d_cfp[3] if train else None)
             for i in (() if fused else range(3)):
                 a = c.cfp[i]
                 sim, simT = n.new(B, lds, dtype=torch.float32), n.new(B, lds, dtype=torch.float32)
@@ -463,8 +474,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 O.gemm(0, txt_o, a, simT, B, B, H, H, H, lds, alpha=1.0 / temp)
                 d1 = n.new(B, lds, dtype=torch.float32) if train else None
                 d2 = n.new(B, lds, dtype=torch.float32) if train else None
-                O.ce_rows(sim, B, B, lds, ar, coef=sc * 0.5 / B, loss_row=c.rows[2 * i], dlogits=d1, ldd=lds)
-                O.ce_rows(simT, B, B, lds, ar, coef=sc * 0.5 / B, loss_row=c.rows[2 * i + 1], dlogits=d2, ldd=lds)
+                O.ce_rows(sim, B, B, lds, ar, coef=scg * 0.5 / B, loss_row=c.rows[2 * i], dlogits=d1, ldd=lds)
+                O.ce_rows(simT, B, B, lds, ar, coef=scg * 0.5 / B, loss_row=c.rows[2 * i + 1], dlogits=d2, ldd=lds)
                 c.dsim.append((d1, d2))
             c.temp = temp
             sup = c.rows.sum() * 0.5 / B
@@ -475,7 +486,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             if rw is None:
                 rw = [1.0] * 5
             rwd = rw if torch.is_tensor(rw) and rw.is_cuda else torch.tensor([float(x) for x in rw], dtype=torch.float32).to(self.device_)
-            rw = [(alpha, rwd[i:i + 1]) for i in range(5)]
+            rw = [(alpha * gs, rwd[i:i + 1]) for i in range(5)]       # (host factor of the gradient seed, device-side ability weight)
             tasks, types = kdl["kdl_tasks"], kdl["kdl_task_types"]
             emb, att = "emb" in types, "attn" in types
             T = float(kdl["kd_temperature"])

@@ -354,7 +354,7 @@ _ENC_OK = {}
 
 def encoder_ok(dtype, H, I, nh, N, nlayers):
     """whole-encoder launch available for this shape? (bf16, H = 128, 2 heads, FFN 512, <= 80 tokens, <= 6 layers)"""
-    if not FUSED_ENC or dtype != torch.bfloat16:
+    if not FUSED_ENC or dtype not in L.HALF:
         return False
     key = (H, I, nh, N, nlayers)
     if key not in _ENC_OK:
@@ -374,7 +374,8 @@ def encoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
     for i, sg in enumerate(segs):
         S = P.seg[i]
         x = sg["x"]
-        _chk(x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[0] == sg["nsamp"] * sg["N"], "encoder input [nsamp*N, H] bf16")
+        _chk(x.dtype in L.HALF and x.is_contiguous() and x.shape[0] == sg["nsamp"] * sg["N"], "encoder input [nsamp*N, H] bf16 / fp16")
+        dtype = x.dtype
         S.x, S.kmask, S.nsamp, S.N, S.ldp, S.nlayers = L.P(x), L.P(sg["kmask"]), sg["nsamp"], sg["N"], sg["ldp"], len(sg["layers"])
         for j, ly in enumerate(sg["layers"]):
             D = S.L[j]
@@ -385,7 +386,7 @@ def encoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
         if FLOPS["enabled"]:
             FLOPS["total"] += sg["flops"]
             FLOPS["enc"] += sg["flops"]
-    L.call("magic_encoder_fwd", C.addressof(P), C.sizeof(P), L.stream())
+    L.call("magic_encoder_fwd", L.dt(dtype), C.addressof(P), C.sizeof(P), L.stream())
 
 
 FUSED_RBW = not os.environ.get("MAGIC_NO_FUSED_RBW")
@@ -393,7 +394,7 @@ _RBW_OK = {}
 
 
 def rowbwd_ok(dtype, H, I):
-    if not FUSED_RBW or dtype != torch.bfloat16:
+    if not FUSED_RBW or dtype not in L.HALF:
         return False
     key = (H, I)
     if key not in _RBW_OK:
@@ -418,7 +419,7 @@ def rowbwd(segs, seed, p_hidden):
         if FLOPS["enabled"]:
             FLOPS["total"] += sg["flops"]
             FLOPS["enc"] += sg["flops"]
-    L.call("magic_rowbwd", C.addressof(P), C.sizeof(P), L.stream())
+    L.call("magic_rowbwd", L.dt(segs[0]["y2"].dtype), C.addressof(P), C.sizeof(P), L.stream())
 
 
 _XENC_OK = {}
@@ -426,7 +427,7 @@ FUSED_XENC = not os.environ.get("MAGIC_NO_FUSED_XENC")
 
 
 def xencoder_ok(dtype, H, I, nh, Nq, Nk, nlayers):
-    if not FUSED_ENC or not FUSED_XENC or dtype != torch.bfloat16:
+    if not FUSED_ENC or not FUSED_XENC or dtype not in L.HALF:
         return False
     key = (H, I, nh, Nq, Nk, nlayers)
     if key not in _XENC_OK:
@@ -448,8 +449,9 @@ def xencoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
     for i, sg in enumerate(segs):
         S = P.seg[i]
         x, cx = sg["x"], sg["cx"]
-        _chk(x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[0] == sg["nsamp"] * sg["Nq"], "cross-encoder queries [nsamp*Nq, H] bf16")
-        _chk(cx.dtype == torch.bfloat16 and cx.is_contiguous() and cx.shape[0] == sg["nsamp"] * sg["Nk"], "cross-encoder context [nsamp*Nk, H] bf16")
+        _chk(x.dtype in L.HALF and x.is_contiguous() and x.shape[0] == sg["nsamp"] * sg["Nq"], "cross-encoder queries [nsamp*Nq, H] bf16 / fp16")
+        _chk(cx.dtype == x.dtype and cx.is_contiguous() and cx.shape[0] == sg["nsamp"] * sg["Nk"], "cross-encoder context [nsamp*Nk, H], the queries' dtype")
+        dtype = x.dtype
         S.x, S.cx, S.qmask, S.cmask = L.P(x), L.P(cx), L.P(sg["qmask"]), L.P(sg["cmask"])
         S.dist, S.sprel_w, S.sprel_b = L.P(sg.get("dist")), L.P(sg.get("sprel_w")), L.P(sg.get("sprel_b"))
         S.nsamp, S.Nq, S.Nk, S.ldps, S.ldpc, S.nlayers = sg["nsamp"], sg["Nq"], sg["Nk"], sg["ldps"], sg["ldpc"], len(sg["layers"])
@@ -462,7 +464,7 @@ def xencoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
         if FLOPS["enabled"]:
             FLOPS["total"] += sg["flops"]
             FLOPS["enc"] += sg["flops"]
-    L.call("magic_xencoder_fwd", C.addressof(P), C.sizeof(P), L.stream())
+    L.call("magic_xencoder_fwd", L.dt(dtype), C.addressof(P), C.sizeof(P), L.stream())
 
 
 def head_mean_fwd(Pm, out, B, nh, inner):
@@ -622,7 +624,7 @@ def sumsq(g, out):
 
 def adamw(n, p, g, m, v, shadow, lr, b1, b2, eps, wd, step_size, sumsq_buf, max_norm, gscale, lr_ss=None, n_decay=-1):
     """n_decay: the first n_decay elements take the weight decay, the rest none (-1: all)"""
-    L.call("magic_adamw", n, L.P(p), L.P(g), L.P(m), L.P(v), L.P(shadow), float(lr), float(b1), float(b2), float(eps), float(wd),
+    L.call("magic_adamw", n, L.P(p), L.P(g), L.P(m), L.P(v), L.P(shadow), L.dt(shadow.dtype) if shadow is not None else 1, float(lr), float(b1), float(b2), float(eps), float(wd),
            float(step_size), L.P(sumsq_buf), float(max_norm), float(gscale), L.P(lr_ss), int(n_decay), L.stream())
 
 
@@ -631,12 +633,14 @@ def sched_step(step, lr0, warmup, total, b1, b2, lr_ss, zero_me=None):
 
 
 def cast_to(x, dtype, out=None):
-    """fp32 <-> bf16 conversion kernel (no-op if dtypes agree)."""
+    """fp32 <-> bf16 / fp16 conversion kernel (no-op if dtypes agree)."""
     if x.dtype == dtype:
         return x
+    _chk((x.dtype == torch.float32) != (dtype == torch.float32) and (x.dtype in L.HALF or dtype in L.HALF), "cast_to: fp32 <-> 16-bit only")
     if out is None:
         out = torch.empty(x.shape, dtype=dtype, device=x.device)
-    L.call("magic_cast", 1 if dtype == torch.bfloat16 else 0, x.numel(), L.P(x), L.P(out), L.stream())
+    to16 = dtype in L.HALF
+    L.call("magic_cast", L.dt(dtype if to16 else x.dtype), 1 if to16 else 0, x.numel(), L.P(x), L.P(out), L.stream())
     return out
 
 

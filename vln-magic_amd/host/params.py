@@ -80,15 +80,15 @@ class ParamStore:
             self.v = torch.zeros_like(self.flat)
         else:
             self.grad = self.m = self.v = None
-        self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device) \
-            if compute_dtype == torch.bfloat16 else self.flat
+        self.half = compute_dtype in (torch.bfloat16, torch.float16)      # 16-bit compute: the MFMA kernels read a shadow copy in that type
+        self.shadow = torch.zeros(self.total, dtype=compute_dtype, device=self.device) if self.half else self.flat
         self.shadow_clean = False
         # transposed bf16 shadow (W^T at the same flat offset) of the matrices the backward row-block kernel reads (csrc/encbwd.hip);
         # spans register themselves through t_span(); refreshed right after the ordinary shadow
         self.shadow_t = None
         self.t_spans = {}
         self.shadow_t_clean = False
-        if requires_grad and compute_dtype == torch.bfloat16:
+        if requires_grad and self.half:
             _LIVE.add(self)
             _install_optimizer_hook()
         gen = torch.Generator().manual_seed(seed)
@@ -124,7 +124,7 @@ class ParamStore:
         """[cols, rows] bf16 view = transpose of the [rows, cols] span starting at `first`; kept current by sync_shadow / FusedAdamW"""
         off = self.offsets[first][0]
         if self.shadow_t is None:
-            self.shadow_t = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+            self.shadow_t = torch.zeros(self.total, dtype=self.compute_dtype, device=self.device)
         if off not in self.t_spans:
             self.t_spans[off] = (rows, cols)
             self.shadow_t_clean = False
@@ -198,11 +198,11 @@ class ParamStore:
                 p.grad = self.g(name)
 
     def sync_shadow(self, force=False):
-        if self.compute_dtype != torch.bfloat16:
+        if not self.half:
             return
         if force or not self.shadow_clean:
             from . import lib as L
-            L.call("magic_cast", 1, self.total, L.P(self.flat), L.P(self.shadow), L.stream())
+            L.call("magic_cast", L.dt(self.compute_dtype), 1, self.total, L.P(self.flat), L.P(self.shadow), L.stream())
             self.shadow_clean = True
             self.shadow_t_clean = False
         self.sync_shadow_t()

@@ -64,7 +64,7 @@ class FusedAdamW:
                 self.ss.zero_()
         if use_clip:
             O.sumsq(s.grad, self.ss)
-        shadow = s.shadow if s.compute_dtype == torch.bfloat16 else None
+        shadow = s.shadow if s.half else None
         # both parameter groups (decay | no decay: contiguous in the flat buffer) in ONE launch
         O.adamw(s.total, s.flat, s.grad, s.m, s.v, shadow, lr, b1, b2, self.eps, self.wd, step_size, self.ss if use_clip else None,
                 self.max_norm if use_clip else 0.0, gscale, lr_ss=lr_ss, n_decay=s.n_decay)
@@ -432,7 +432,7 @@ class PretrainStep:
             self._exchanged = False
         else:
             gscale = self.sync.all_reduce()
-        self.opt.step(gscale=gscale)
+        self.opt.step(gscale=gscale / float(getattr(self.student, "grad_scale", 1.0)))      # fp16: the buffer holds grad_scale x the gradient
 
     def step(self, batch, task, rw=None, plan=None):
         plan = plan if plan is not None else build_plan(batch, task, self.dev)

@@ -320,7 +320,7 @@ def parity_block(dev):
     models = PP.oracle_models()
     out = {"checker": "fp64 CPU oracle (oracle/model_ref.py, a restatement: the reference withholds its model source), same weights and batches",
            "north_star": {"max_abs_logit_delta": 1e-3, "argmax_agreement": 1.0}}
-    for name, dt_ in (("bf16", torch.bfloat16), ("fp32", torch.float32), ("bf16x3", torch.float32)):
+    for name, dt_ in (("bf16", torch.bfloat16), ("fp16", torch.float16), ("fp32", torch.float32), ("bf16x3", torch.float32)):
         prev = L.set_f32_mfma("bf16x3" if name == "bf16x3" else "exact")
         try:
             st = PP.sap_parity(dt_, batch_size=8, seeds=(1234, 77, 5), device=dev, models=models)
@@ -375,7 +375,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=48)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="bf16 = BASELINE config 2's arithmetic (the headline); fp16 = the same kernels on IEEE half storage (11 significand bits: meets the "
+                         "north star's |delta logit| < 1e-3; gradient seeds scaled by 4096, folded back in the AdamW kernel); fp32 = exact fp32 MFMA")
     ap.add_argument("--pool", type=int, default=12, help="distinct pre-generated batches (cycled)")
     ap.add_argument("--dropout", type=float, default=0.1, help="hidden/attention dropout of the student (reference recipe: 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -444,7 +446,7 @@ def main():
         dist.all_gather(seen, mine)
         seen = [t.tolist() for t in seen]
         rccl = {"backend": a.backend, "world": world, "ranks_seen": [r for r, _ in seen], "devices": [d for _, d in seen]}
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
     tcfg, scfg, teacher, student, trainer = build_models(dtype, dev, a.dropout, world, a.batch)
 
     # synthetic batches, resident in HBM before the timed region (per-rank stream: seed 1234 + rank)
@@ -576,7 +578,7 @@ def main():
     modes, parity = None, None
     if rank == 0 and world == 1 and not a.no_parity and a.mode == "graph":
         # the parity-clean arithmetic (fp32 MFMA, exact) timed in the same run on the same batches, next to the headline mode
-        other = torch.float32 if dtype == torch.bfloat16 else torch.bfloat16
+        other = torch.float32 if dtype != torch.float32 else torch.bfloat16
         del graphs
         _, _, t2, s2, tr2 = build_models(other, dev, a.dropout, world, a.batch)
         eager_runner(tr2)(min(3, len(pool)))
@@ -584,12 +586,23 @@ def main():
         g2 = capture_ring(tr2, pool, a.teacher)
         torch.cuda.synchronize()
         traj2, dt2 = timed_region(graph_runner(tr2, g2), a.steps, a.warmup, world, dev)
-        nm = {torch.bfloat16: "bf16", torch.float32: "fp32"}
+        nm = {torch.bfloat16: "bf16", torch.float32: "fp32", torch.float16: "fp16"}
         modes = {nm[dtype]: {"ms_per_step": round(dt / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj / dt, 1)},
                  nm[other]: {"ms_per_step": round(dt2 / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj2 / dt2, 1)},
-                 "note": "same batches and schedule, one HIP graph per batch each; fp32 = fp32 storage + exact v_mfma_f32_16x16x4_f32; bf16x3 = fp32 "
-                         "storage, every GEMM contraction as three bf16 MFMAs on the hi + lo halves of the fp32 operands (lib.set_f32_mfma)"}
+                 "note": "same batches and schedule, one HIP graph per batch each; fp16 = the bf16 kernels on IEEE half storage (v_mfma_f32_16x16x32_f16, gradient "
+                         "seeds x 4096); fp32 = fp32 storage + exact v_mfma_f32_16x16x4_f32; bf16x3 = fp32 storage, every GEMM contraction as three bf16 MFMAs "
+                         "on the hi + lo halves of the fp32 operands (lib.set_f32_mfma)"}
         del g2, tr2
+        # the 16-bit twin of the headline mode (bf16 <-> fp16: same kernels, same launches, different storage type)
+        twin = torch.float16 if dtype != torch.float16 else torch.bfloat16
+        _, _, t4, s4, tr4 = build_models(twin, dev, a.dropout, world, a.batch)
+        eager_runner(tr4)(min(3, len(pool)))
+        torch.cuda.synchronize()
+        g4 = capture_ring(tr4, pool, a.teacher)
+        torch.cuda.synchronize()
+        traj4, dt4 = timed_region(graph_runner(tr4, g4), a.steps, a.warmup, world, dev)
+        modes[nm[twin]] = {"ms_per_step": round(dt4 / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj4 / dt4, 1)}
+        del g4, t4, s4, tr4
         # third mode: fp32 storage with the split-bf16 contraction (graphs re-captured: the mode is read by the kernels at run time, but a
         # fresh capture keeps the measurement independent of the previous one)
         prev = L.set_f32_mfma("bf16x3")
@@ -636,6 +649,9 @@ def main():
             info["fp32_mode_ms_per_step"] = modes["fp32"]["ms_per_step"]
             info["bf16x3_mode_ms_per_step"] = modes["bf16x3"]["ms_per_step"]
             info["bf16x3_max_logit_delta"] = parity["bf16x3"]["max_abs_logit_delta"]
+            info["fp16_mode_ms_per_step"] = modes["fp16"]["ms_per_step"]
+            info["fp16_max_logit_delta"] = parity["fp16"]["max_abs_logit_delta"]
+            info["fp16_argmax_agreement"] = parity["fp16"]["argmax_agreement"]
         print(json.dumps(info))
     if world > 1:
         dist.destroy_process_group()

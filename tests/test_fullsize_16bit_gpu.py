@@ -30,9 +30,17 @@ pytestmark = pytest.mark.gpu
 # deepest outputs the accumulated relative error is ~sqrt(25) x that = 1e-2 / 1.2e-3
 FWD_REL_L2 = {torch.bfloat16: 2.5e-2, torch.float16: 4e-3}
 LOGIT_ABS = {torch.bfloat16: 1e-2, torch.float16: 1e-3}            # fp16: the north-star bar
-GRAD_REL_L2 = {torch.bfloat16: 8e-2, torch.float16: 1.5e-2}        # per parameter tensor, on top of the floor below
-GRAD_COS = {torch.bfloat16: 0.995, torch.float16: 0.9998}
+GRAD_REL_L2 = {torch.bfloat16: 8e-2, torch.float16: 1.5e-2}        # per parameter tensor, on top of the floor below (measured worst: 5.1e-2 / 6.7e-3)
+GRAD_COS = {torch.bfloat16: 0.995, torch.float16: 0.9998}          # (measured worst: 0.99874 / 0.999978)
 GRAD_FLOOR = {torch.bfloat16: 3e-3, torch.float16: 5e-4}           # x (largest per-element RMS gradient of any tensor): analytically ~0 gradients
+# Cancellation class.  A softmax gradient sums to zero over the candidates of a sample, so the bias gradient of the dense layer right
+# under an action head (ClsPrediction net.0) or under the map / viewpoint position embedding (whose rows all receive the action
+# gradient) is a row-sum in which the component common to a sample's rows cancels exactly; the 16-bit STORED per-row gradient carries its
+# rounding on that common component, so the relative error of the small remainder is amplified (measured: 0.17 bf16, 0.033 fp16 -- it
+# scales with the storage type's epsilon, as rounding noise does and a wrong formula does not; the fp32 engine has 1e-4 here).
+CANCEL = ("vp_pos_embeddings.0.bias", "gmap_pos_embeddings.0.bias", "_sap_head.net.0.bias", "sap_fuse_linear.net.0.bias")
+CANCEL_REL_L2 = {torch.bfloat16: 0.35, torch.float16: 0.07}
+CANCEL_COS = {torch.bfloat16: 0.95, torch.float16: 0.998}
 
 
 @pytest.fixture(scope="module")
@@ -63,12 +71,18 @@ def _steps(models, dtype, task, p_drop, seed):
         def hook(site, x):
             used.append(site)
             return x * export_mask(seed_t, p_drop, MagicNet.site_id(site), tuple(x.shape)).cpu().double()
+        b64 = PP.to64(batch)
+        with torch.no_grad():
+            ot = o_t(b64, task, compute_loss=True)["outputs"]                      # the frozen teacher is never dropped
+        for q in o_s.parameters():
+            q.grad = None
         R.DROPOUT = hook
         try:
-            ot, want = PP.oracle_step(o_t, o_s, batch, task, backward=True)
+            want = o_s(b64, task, compute_loss=True, teacher_outputs=ot, rw=torch.tensor(PP.RW, dtype=torch.float64))
         finally:
             R.DROPOUT = None
-        assert len(used) >= 30 and len(set(used)) == len(used), len(used)          # 6 + 2 self blocks x 3 sites, 2 x 3 cross blocks x 5 sites, embeddings
+        want["loss"].backward()
+        assert len(used) >= 40 and len(set(used)) == len(used), len(used)          # 6 + 2 self blocks x 3 sites, 3-6 cross blocks x 5 sites, 2 embeddings
     else:
         assert g_s.net.drop is None
         ot, want = PP.oracle_step(o_t, o_s, batch, task, backward=True)
@@ -119,18 +133,23 @@ def test_16bit_engine_every_forward_tensor_and_every_parameter_gradient_vs_fp64_
         err, nr = (g - ref).norm().item(), ref.norm().item()
         floor = GRAD_FLOOR[dtype] * rms_max * ref.numel() ** 0.5
         cos = (g * ref).sum().item() / max(g.norm().item() * nr, 1e-300)
-        rows.append((pname, err / max(nr, 1e-300), cos, err <= GRAD_REL_L2[dtype] * nr + floor, nr / ref.numel() ** 0.5 / rms_max))
+        cancel = pname.endswith(CANCEL)
+        rtol = (CANCEL_REL_L2 if cancel else GRAD_REL_L2)[dtype]
+        rows.append((pname, err / max(nr, 1e-300), cos, err <= rtol * nr + floor, nr / ref.numel() ** 0.5 / rms_max, cancel))
         n += 1
     assert n > 150
     bad = [r for r in rows if not r[3]]
     sizeable = [r for r in rows if r[4] > 1e-2]               # tensors whose gradient is not ~0: cosine is meaningful there
-    worst_rel = max(r[1] for r in sizeable)
-    worst_cos = min(r[2] for r in sizeable)
+    worst_rel = max(r[1] for r in sizeable if not r[5])
+    worst_cos = min(r[2] for r in sizeable if not r[5])
+    for r in sorted(sizeable, key=lambda r: -r[1])[:6]:
+        print(f"    {r[0]:70s} rel-L2 {r[1]:.2e} cos {r[2]:.6f} rms/rms_max {r[4]:.2e}{' (cancellation class)' if r[5] else ''}")
     print(f"[{name} {task} p={p_drop}] worst fwd rel-L2 {worst_fwd:.2e} ({max(fwd, key=fwd.get)}), grads: worst rel-L2 {worst_rel:.2e} "
-          f"({max(sizeable, key=lambda r: r[1])[0]}), worst cosine {worst_cos:.6f} ({min(sizeable, key=lambda r: r[2])[0]}), {json.dumps(extra)}")
+          f"({max((r for r in sizeable if not r[5]), key=lambda r: r[1])[0]}), worst cosine {worst_cos:.6f} ({min((r for r in sizeable if not r[5]), key=lambda r: r[2])[0]}), {json.dumps(extra)}")
     assert worst_fwd < FWD_REL_L2[dtype], {k: f"{v:.2e}" for k, v in fwd.items() if v >= FWD_REL_L2[dtype]}
     assert not bad, [(r[0], f"rel {r[1]:.2e}", f"cos {r[2]:.5f}") for r in bad[:8]]
-    assert worst_cos > GRAD_COS[dtype], [(r[0], r[2]) for r in sizeable if r[2] <= GRAD_COS[dtype]][:8]
+    assert worst_cos > GRAD_COS[dtype], [(r[0], r[2]) for r in sizeable if r[2] <= GRAD_COS[dtype] and not r[5]][:8]
+    assert all(r[2] > CANCEL_COS[dtype] for r in sizeable if r[5]), [(r[0], r[2]) for r in sizeable if r[5]]
     if task == "sap":
         assert extra["max_abs_logit_delta"] < LOGIT_ABS[dtype], extra
         if dtype == torch.float16:

@@ -156,6 +156,72 @@ def test_bf16_tracks_oracle(task):
     assert cos > 0.98, f"bf16 gradient cosine vs oracle {cos:.4f}"
 
 
+def test_fp16_train_steps_follow_oracle_optimizer():
+    """fp16 storage: the gradient seeds are multiplied by model.grad_scale (4096) so the stored activation gradients stay in fp16's range,
+    and PretrainStep folds 1 / grad_scale into the AdamW kernel's gradient pre-scale (clip norm included).  Three optimizer steps against
+    the oracle model + oracle AdamW + clip: the parameters must follow to fp16-rounding accuracy -- a missing or doubled scale would move
+    them by a factor 4096 (or clip every step)."""
+    o_t, o_s, g_t, g_s = build(torch.float16)
+    assert g_s.grad_scale == 4096.0 and g_t.grad_scale == 4096.0
+    trainer = PretrainStep(g_s, g_t, lr=1e-3, warmup_steps=2, num_train_steps=10, grad_norm=5.0)
+    names = [n for n, _ in o_s.named_parameters()]
+    from magic_amd.host.params import is_no_decay
+    wds = [0.0 if is_no_decay(n) else 0.01 for n in names]
+    state = optim_ref.adamw_init([p.data for p in o_s.parameters()])
+    p0 = {n: p.data.clone() for n, p in o_s.named_parameters()}
+    for step, task in enumerate(["sap", "mlm", "cfp"]):
+        batch = synth.make_batch(task, batch_size=4, seed=77, step=step, vocab=600, min_len=8, max_len=15, min_steps=2, max_steps=3)
+        with torch.no_grad():
+            ot = o_t(batch, task, compute_loss=True)["outputs"]
+        for p in o_s.parameters():
+            p.grad = None
+        w = o_s(batch, task, compute_loss=True, teacher_outputs=ot, rw=torch.tensor(RW))
+        w["loss"].backward()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in o_s.parameters()]
+        optim_ref.clip_grad_norm(grads, 5.0)
+        lr = optim_ref.get_lr_sched(step, 1e-3, 2, 10)
+        with torch.no_grad():
+            optim_ref.adamw_step([p.data for p in o_s.parameters()], grads, state, lr=lr, betas=(0.9, 0.98), eps=1e-6, weight_decay=wds)
+        out = trainer.step(batch, task, rw=RW)
+        close(out["loss"], w["loss"], f"fp16 step {step} loss", 3e-3, 1e-4)
+        assert torch.isfinite(g_s.store.grad).all()
+    torch.cuda.synchronize()
+    got = g_s.state_dict()
+    num = den = 0.0
+    for n, p in o_s.named_parameters():
+        # Adam's update is +-lr-sized whatever the gradient's size, so compare the UPDATES: direction and size over all parameters
+        du_g, du_o = (got[n].float().cpu() - p0[n]).double(), (p.data - p0[n]).double()
+        num += (du_g * du_o).sum().item()
+        den += (du_o * du_o).sum().item()
+        assert (got[n].float().cpu() - p.data).abs().max().item() < 4e-3, n            # 3 steps x lr 1e-3 bounds any element's drift
+    assert 0.97 < num / den < 1.03, num / den             # projection of the engine's 3-step update on the oracle's
+
+
+def test_fp16_unmodified_loop_backward_returns_unscaled_gradients():
+    """`loss.backward()` (the reference-style loop): the autograd hook divides the flat gradient buffer by grad_scale and multiplies by the
+    incoming grad_output, so `.grad` = grad_output x dLoss/dparam as autograd promises (a GradScaler's factor passes straight through)."""
+    o_t, o_s, g_t, g_s = build(torch.float16)
+    batch = synth.make_batch("sap", batch_size=4, seed=9, vocab=600, min_len=8, max_len=15, min_steps=2, max_steps=3)
+    with torch.no_grad():
+        ot = o_t(batch, "sap", compute_loss=True)["outputs"]
+        gt = g_t(batch, "sap", compute_loss=False, return_outputs=True)
+    want = o_s(batch, "sap", compute_loss=True, teacher_outputs=ot, rw=torch.tensor(RW))
+    want["loss"].backward()
+    g_s.store.zero_grad()
+    got = g_s(batch, "sap", compute_loss=True, teacher_outputs=gt, rw=RW, plan=gt["plan"])
+    (got["loss"] * 8.0).backward()                     # an outer loss scale, as torch.cuda.amp.GradScaler applies
+    torch.cuda.synchronize()
+    params = dict(g_s.named_parameters())
+    num = da = db = 0.0
+    for name, p in o_s.named_parameters():
+        if p.grad is None:
+            continue
+        g = params[name].grad.float().cpu()
+        num += (g * p.grad).sum().item(); da += (g * g).sum().item(); db += (p.grad * p.grad).sum().item()
+    assert num / (da ** 0.5 * db ** 0.5) > 0.9995
+    assert abs((da / db) ** 0.5 - 8.0) < 0.05, (da / db) ** 0.5
+
+
 def test_train_steps_follow_oracle_optimizer_fp32():
     """3 optimizer steps (sap, mlm, cfp) of the fused trainer vs oracle model + oracle AdamW + clip."""
     o_t, o_s, g_t, g_s = build(torch.float32)

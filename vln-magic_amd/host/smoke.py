@@ -22,7 +22,7 @@ def run_smoke():
     torch.manual_seed(0)
     o_t, o_s = R.RefPretrainModel(tcfg).eval(), R.RefPretrainModel(scfg).eval()
     rw = [1.0, 1.2, 0.8, 1.1, 0.9]
-    for dtype, tol in ((torch.float32, 2e-4), (torch.bfloat16, 5e-2)):
+    for dtype, tol in ((torch.float32, 2e-4), (torch.bfloat16, 5e-2), (torch.float16, 5e-3)):
         g_t = GlocalTextPathCMTPreTraining.from_pretrained(None, config=tcfg, state_dict=o_t.state_dict(), device="cuda:0", compute_dtype=dtype)
         g_s = GlocalTextPathCMTPreTraining.from_pretrained(None, config=scfg, state_dict=o_s.state_dict(), device="cuda:0", compute_dtype=dtype)
         trainer = PretrainStep(g_s, g_t, lr=1e-4, warmup_steps=1, num_train_steps=10)

@@ -260,7 +260,13 @@ typedef struct {
   unsigned site_attn, site_ao, site_out, pad_;
 } magic_enc_layer;
 typedef struct { const void* x; const unsigned char* kmask; int nsamp, N, ldp, nlayers; magic_enc_layer L[6]; } magic_enc_seg;
-typedef struct { magic_enc_seg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; } magic_enc_params;
+/* sync != NULL selects the ROW-SPLIT form (round 3): one workgroup per (sample, 16-row tile) instead of one per sample -- an 80-token
+ * instruction is five workgroups -- with the layer outputs handed between the tiles of a sample inside the launch (write-through stores +
+ * one agent-scope arrival counter per (sample, layer)).  sync: >= 4 + 6 x (samples of all segments) 32-bit words of device memory,
+ * 16-byte aligned, owned by this launch until it completes; the entry point zeroes them on `stream` (a memset node under capture);
+ * word 0 is set to 1 if a bounded wait gave up (never in a healthy launch).  Same outputs as the per-sample form. */
+typedef struct { magic_enc_seg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed;
+                 unsigned* sync; int sync_words, pad2_; } magic_enc_params;
 int magic_encoder_supported(int dtype, int H, int I, int nh, int N, int nlayers);
 int magic_encoder_params_bytes(void);
 int magic_encoder_fwd(int dtype, const void* params, int nbytes, void* stream);

@@ -47,9 +47,13 @@ def ulp_close(a, b, name, ulps=2.0, floor=2e-3, frac_ok=1e-2):
         f"{name}: {frac:.4%} of elements off by more than {ulps} bf16 ulps, rel L2 {rel_l2:.2e} (max |d| {(a - b).abs().max().item():.3e}, worst rel {worst:.3f})"
 
 
+@pytest.mark.parametrize("row_split", [True, False])
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 @pytest.mark.parametrize("max_len", [80, 41, 19])
-def test_fused_encoders_save_what_the_unfused_kernels_save(p_drop, max_len):
+def test_fused_encoders_save_what_the_unfused_kernels_save(p_drop, max_len, row_split, monkeypatch):
+    """row_split: the round-3 form (one workgroup per (sample, 16-row tile), layer outputs handed between the tiles of a sample inside the
+    launch) and the per-sample form, each against the per-op kernels"""
+    monkeypatch.setattr(O, "ENC_ROW_SPLIT", row_split)
     m = student(p_drop)
     m.train()
     batch = synth.make_batch("sap", batch_size=7, seed=5, step=0, max_len=max_len, min_len=min(12, max_len), dup_view_prob=0.3)
@@ -67,6 +71,8 @@ def test_fused_encoders_save_what_the_unfused_kernels_save(p_drop, max_len):
             cp = m.net.pano_fwd(plan, inp.feats, inp.loc)
             torch.cuda.synchronize()
             res[fused] = (ct, cp)
+            if fused and row_split:
+                assert int(O.ENC_SYNC_LAST[0][0]) == 0, "a bounded hand-off wait gave up"
         finally:
             O.FUSED_ENC = True
     for name, (a, b) in (("text", (res[True][0], res[False][0])), ("pano", (res[True][1], res[False][1]))):

@@ -27,7 +27,10 @@ template <typename Hh> struct EncLayerT {
   unsigned site_attn, site_ao, site_out, pad_;
 };
 template <typename Hh> struct EncSegT { const Hh* x; const unsigned char* kmask; int nsamp, N, ldp, nlayers; EncLayerT<Hh> L[6]; };
-template <typename Hh> struct EncParamsT { EncSegT<Hh> seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; };
+template <typename Hh> struct EncParamsT {
+  EncSegT<Hh> seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed;
+  unsigned* sync; int sync_words, pad2_;        // row-split form: >= 6 * (samples of all segments) + 4 words, zeroed by the launch function
+};
 typedef EncParamsT<bf16> EncParams; typedef EncSegT<bf16> EncSeg; typedef EncLayerT<bf16> EncLayer;      // host side: the layout holds pointers only, the same for both 16-bit types
 
 // out[row][w*16 + c16] = LayerNorm_row(acc + bias (dropped) + residual) for the workgroup's NRT*16 rows; every wave owns 16 of the
@@ -427,6 +430,367 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(EncParamsT<Hh> p) {
   }
 }
 
+// =====================================================================================================================================
+// Row-split form of the same encoders (round 3).  One 512-thread workgroup owns ONE 16-row tile of ONE sample for all layers, so an
+// 80-token instruction is five workgroups instead of one (48 instructions: 240 workgroups instead of 48 on 256 CUs) and a panorama
+// three.  A layer's output rows are the only thing the tiles of a sample exchange: every tile needs ALL rows of the layer input for
+// its key / value projection (recomputed per tile: 320 of the ~700 MFMAs a tile issues per layer -- the matrix pipe is idle anyway),
+// everything else (Q, attention of its 16 queries, both add&norms, the FFN) is per row.  The hand-off stays inside the launch
+// (cdna_hip_programming.md section 6, Guideline 16, form R1): the block output is stored write-through (`sc1`), every storing wave
+// drains its stores, the workgroup's barrier, then ONE lane adds to the (sample, layer) arrival counter with an agent-scope atomic;
+// the next layer starts with one lane polling that counter (relaxed `sc1` loads + s_sleep, bounded) and EVERY load of the handed-off
+// rows is an `sc1` buffer load, so no acquire fence is needed.  The counters are zeroed by a memset node in front of the launch.
+// Residency: all tiles of a sample must make progress together; the grid puts the text tiles first and is sized by the launch
+// function so that every workgroup of the launch is resident at once or the text tiles alone are (2 workgroups per CU: 79.6 KB LDS).
+// Same saved tensors, rounding points and dropout masks as encoder_fwd_kernel (tests/test_encoder_gpu.py compares the two).
+// =====================================================================================================================================
+#define RS_ZROW 80                 // zero row of the V image: the PV product's key steps past the sample's last tile read it
+#define RS_SS 84                   // fp32 score row pitch (<= 80 keys); the clean probabilities later reuse the row as 168 16-bit slots
+#define RS_PP 104                  // dropped-probability row pitch (<= 96 keys)
+#define RS_SPIN_MAX (1u << 21)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((address_space(1))) unsigned gu32_t;
+
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> tfrag_clamp(const Hh* s, int pitch, int n0, int k0, int lane, int kmax) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  int r0 = k0 + 8 * g + q, r1 = r0 + 4;
+  r0 = r0 < kmax ? r0 : RS_ZROW; r1 = r1 < kmax ? r1 : RS_ZROW;
+  const h16x4<Hh> lo = lds_tr4(s + r0 * pitch + n0 + 4 * pp), hi = lds_tr4(s + r1 * pitch + n0 + 4 * pp);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// LayerNorm(acc + bias (dropped) + residual) over the tile's 16 rows; wave w owns columns [16w, 16w + 16).  red: [2][8][16] floats.
+template <typename Hh>
+__device__ __forceinline__ void add_norm16(f32x4& acc, const float bv, const float gv, const float btv, const Hh* sRes, float* red, Hh* sOut,
+                                           float* gRstd, const int nq, const long long row0, const float eps, const DropState& ds, const int w, const int lane) {
+  const int g = lane >> 4, c16 = lane & 15, col = w * 16 + c16;
+  float s[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * g + r;
+    float v = acc[r] + bv;
+    if (ds.on) v *= drop_mul(ds, (unsigned)((row0 + row) * EH + col));
+    v += to_f(sRes[row * XS + col]);
+    acc[r] = v;
+    s[r] = g16_sum(v);
+  }
+  if (c16 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w * 16 + 4 * g + r] = s[r];
+  }
+  __syncthreads();
+  float mean[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float t = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * 16 + 4 * g + r];
+    mean[r] = t * (1.0f / EH);
+    const float d = acc[r] - mean[r];
+    s[r] = g16_sum(d * d);
+  }
+  if (c16 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[128 + w * 16 + 4 * g + r] = s[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rr = 4 * g + r;
+    float t = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NWAVE; ++ww) t += red[128 + ww * 16 + rr];
+    const float rstd = rsqrtf(t * (1.0f / EH) + eps);
+    const Hh y = from_f<Hh>((acc[r] - mean[r]) * rstd * gv + btv);
+    sOut[rr * XS + col] = (rr < nq) ? y : (Hh)0.0f;
+    if (rr < nq && w == 0 && c16 == 0) gRstd[row0 + rr] = rstd;
+  }
+}
+
+// 16 rows x `cols` from an LDS image to global rows, 16-byte chunks; SC1: write-through stores (the layer hand-off's payload)
+template <bool SC1, typename Hh>
+__device__ __forceinline__ void copy_tile(const Hh* s, int pitch, Hh* g, int ldg, int rows, int cols, int tid) {
+  const int cpr = cols / 8;
+  if constexpr (SC1) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, rows * ldg * 2, 0x00020000);
+    for (int id = tid; id < rows * cpr; id += NWAVE * 64) {
+      const int r = id / cpr, c = (id % cpr) * 8;
+      __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(s + r * pitch + c), rsrc, (r * ldg + c) * 2, 0, 16);
+    }
+  } else {
+    for (int id = tid; id < rows * cpr; id += NWAVE * 64) {
+      const int r = id / cpr, c = (id % cpr) * 8;
+      *(h16x8<Hh>*)(g + (long long)r * ldg + c) = *(const h16x8<Hh>*)(s + r * pitch + c);
+    }
+  }
+}
+
+template <int NRT, typename Hh>
+__device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSegT<Hh>& sg, const int samp, const int tile, unsigned* cnt,
+                                            unsigned* err, unsigned char* smem) {
+  Hh* sK = (Hh*)smem;                          // [80][XS]  keys of all tiles
+  Hh* sV = sK + 80 * XS;                       // [81][XS]  values of all tiles; row 80 stays zero
+  Hh* sU = sV + 81 * XS;                       // union, 80 * XS elements:
+  Hh* sX = sU;                                 //   [16 NRT][XS]  layer input, all rows            (stage A)
+  float* sS = (float*)sU;                      //   [2][16][RS_SS] fp32 scores, then the clean probabilities in place    (stage B)
+  Hh* sPd = sU + 2 * 16 * RS_SS * 2;           //   [2][16][RS_PP] dropped probabilities                                  (stage B)
+  Hh* sG = sU;                                 //   [16][GS]      GELU output                       (stages D, E)
+  Hh* sZ = sK;                                 // [16][GS] FFN pre-activation (the K image is dead by then)
+  Hh* sQ = sU + 80 * XS;                       // [16][XS]  Q, then the attention context
+  Hh* sO = sQ + 16 * XS;                       // [16][XS]  own rows of the layer input (residual); then the layer output
+  Hh* sA = sO + 16 * XS;                       // [16][XS]  attention-block output
+  float* red = (float*)(sA + 16 * XS);         // [2][8][16]
+  const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = sg.N, ldp = sg.ldp;
+  const int NKP = (N + 31) / 32 * 32;
+  const long long row_base = (long long)samp * N;
+  const int r0 = tile * 16, nq = min(16, N - r0);
+  const long long row0 = row_base + r0;
+  // zero row of the V image + the V rows the last tile does not cover are written once per layer below (bias rows are finite)
+  if (tid < XS / 8) {
+    h16x8<Hh> zv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zv[e] = (Hh)0.0f;
+    *(h16x8<Hh>*)(sV + RS_ZROW * XS + tid * 8) = zv;
+  }
+  DropDesc dd;
+  dd.seed = p.seed;
+  float kbias[NRT];
+#pragma unroll
+  for (int j = 0; j < NRT; ++j) {
+    const int key = j * 16 + (lane0 & 15);
+    kbias[j] = (key < N && sg.kmask && !sg.kmask[(long long)samp * N + key]) ? -10000.0f : 0.f;
+  }
+  for (int l = 0; l < sg.nlayers; ++l) {
+    const EncLayerT<Hh>& L = sg.L[l];
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));             // (see enc_body: keeps the layer-invariant per-lane indices from being hoisted and spilled)
+    const int g = lane >> 4, c16 = lane & 15;
+    // ---- small parameters of the layer's epilogues, fetched now ----
+    const float pb_q = L.bqkv[w * 16 + c16], pb_kv0 = L.bqkv[EH + (2 * w) * 16 + c16], pb_kv1 = L.bqkv[EH + (2 * w + 1) * 16 + c16];
+    float pb_ffn[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) pb_ffn[ct] = L.bi[(4 * w + ct) * 16 + c16];
+    const float pb_o = L.bo[w * 16 + c16], pg_1 = L.g1[w * 16 + c16], pe_1 = L.be1[w * 16 + c16];
+    const float pb_2 = L.bo2[w * 16 + c16], pg_2 = L.g2[w * 16 + c16], pe_2 = L.be2[w * 16 + c16];
+    // weight fragments of stage A: this wave's Q column tile and its two K|V column tiles
+    h16x8<Hh> wq[4], wkv[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      wq[ks] = gfrag(L.Wqkv, EH, w * 16, ks * 32, lane);
+      wkv[0][ks] = gfrag(L.Wqkv, EH, EH + (2 * w) * 16, ks * 32, lane);
+      wkv[1][ks] = gfrag(L.Wqkv, EH, EH + (2 * w + 1) * 16, ks * 32, lane);
+    }
+    // ---- layer input: all rows of the sample -> sX.  Layer 0 reads what an earlier launch wrote; later layers read the rows the sample's
+    //      other tiles handed off (sc1 loads, after the arrival counter of the previous layer has reached the tile count)
+    if (l > 0) {
+      if (tid == 0) {
+        gu32_t* c = (gu32_t*)(cnt + (long long)samp * 6 + (l - 1));
+        unsigned spins = 0;
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)NRT) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > RS_SPIN_MAX) { __hip_atomic_store((gu32_t*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+      }
+      __syncthreads();
+    }
+    {
+      const Hh* x = (l == 0 ? sg.x : sg.L[l - 1].out) + row_base * EH;
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, N * EH * 2, 0x00020000);     // rows >= N: out of range -> zeros
+      for (int id = tid; id < NRT * 16 * (EH / 8); id += NWAVE * 64) {
+        const int r = id / (EH / 8), c = (id % (EH / 8)) * 8;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (r * EH + c) * 2, 0, 16);
+        *(u32x4*)(sX + r * XS + c) = v;
+        if (r >= r0 && r < r0 + 16) *(u32x4*)(sO + (r - r0) * XS + c) = v;
+      }
+    }
+    __syncthreads();
+    // ================= A: K|V of all rows (2 of 16 column tiles per wave), Q of the own tile (1 of 8) =================
+    {
+      f32x4 acc[NRT][2], aq = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+          const h16x8<Hh> a = lfrag(sX, XS, i * 16, ks * 32, lane);
+          acc[i][0] = emma(a, wkv[0][ks], acc[i][0]);
+          acc[i][1] = emma(a, wkv[1][ks], acc[i][1]);
+        }
+        aq = emma(lfrag(sO, XS, 0, ks * 32, lane), wq[ks], aq);
+        KSTEP_FENCE();
+      }
+      // K column tiles 0..7 come from waves 0..3, V from waves 4..7
+      Hh* dst = (w < 4 ? sK : sV) + ((2 * w) & 7) * 16 + c16;
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dst[(i * 16 + 4 * g + r) * XS] = from_f<Hh>(acc[i][0][r] + pb_kv0);
+          dst[(i * 16 + 4 * g + r) * XS + 16] = from_f<Hh>(acc[i][1][r] + pb_kv1);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sQ[(4 * g + r) * XS + w * 16 + c16] = from_f<Hh>(aq[r] + pb_q);
+    }
+    // fragments of the output projection and the first FFN matrix: in flight under the attention
+    h16x8<Hh> wo[4], w1[4][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wo[ks] = gfrag(L.Wo, EH, w * 16, ks * 32, lane);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) w1[ct][ks] = gfrag(L.W1, EH, (4 * w + ct) * 16, ks * 32, lane);
+    __syncthreads();                              // K, V, Q images complete; sX is dead
+    // own rows of Q|K|V -> global (the backward reads qkv [M, 3H])
+    {
+      Hh* qg = L.qkv + row0 * 3 * EH;
+      for (int id = tid; id < nq * 48; id += NWAVE * 64) {
+        const int r = id / 48, c = (id % 48) * 8;
+        const Hh* src = c < EH ? sQ + r * XS + c : (c < 2 * EH ? sK + (r0 + r) * XS + (c - EH) : sV + (r0 + r) * XS + (c - 2 * EH));
+        *(h16x8<Hh>*)(qg + (long long)r * 3 * EH + c) = *(const h16x8<Hh>*)src;
+      }
+    }
+    // ================= B1: scores of the tile's 16 queries, unit = (head, key tile) =================
+    for (int u = w; u < ENH * NRT; u += NWAVE) {
+      const int h = u / NRT, j = u % NRT;
+      f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) sc = emma(lfrag(sQ, XS, 0, h * EHD + ks * 32, lane), lfrag(sK, XS, j * 16, h * EHD + ks * 32, lane), sc);
+      const int key = j * 16 + c16;
+      float mb = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < NRT; ++jj) mb = (jj == j) ? kbias[jj] : mb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sS[(h * 16 + 4 * g + r) * RS_SS + key] = key < N ? sc[r] * p.scale + mb : -3.0e38f;
+    }
+    __syncthreads();
+    // ================= B2: softmax, 4 of the 32 (head, query) rows per wave, 16 lanes per row =================
+    dd.site = L.site_attn; dd.p = p.p_attn;
+    const DropState dsa = drop_init(dd);
+    {
+      const int rr = 4 * w + g, h = rr >> 4, ql = rr & 15;
+      float e[NRT], mx = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < NRT; ++j) { e[j] = sS[rr * RS_SS + j * 16 + c16]; mx = fmaxf(mx, e[j]); }
+      mx = g16_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < NRT; ++j) { e[j] = (j * 16 + c16) < N ? __expf(e[j] - mx) : 0.f; sum += e[j]; }
+      sum = 1.0f / g16_sum(sum);
+      Hh* pc = (Hh*)(sS + rr * RS_SS);          // the row's own bytes: only this wave reads or writes them in this phase
+      Hh* pd = sPd + rr * RS_PP;
+#pragma unroll
+      for (int j = 0; j < NRT; ++j) {
+        const int key = j * 16 + c16;
+        const float pv = e[j] * sum;
+        pc[key] = from_f<Hh>(pv);
+        if (dsa.on) {
+          const unsigned idx = (unsigned)(((((long long)samp * ENH + h) * N + r0 + ql) * N) + key);
+          pd[key] = from_f<Hh>((ql < nq && key < N) ? pv * drop_mul(dsa, idx) : 0.f);
+        }
+      }
+      if (NRT * 16 < NKP && c16 < NKP - NRT * 16) { pc[NRT * 16 + c16] = (Hh)0.0f; if (dsa.on) pd[NRT * 16 + c16] = (Hh)0.0f; }
+    }
+    __syncthreads();
+    // probabilities -> global (clean: the backward's P; dropped: the exposed attention map)
+    {
+      const int cpr = ldp / 8;
+      for (int id = tid; id < ENH * nq * cpr; id += NWAVE * 64) {
+        const int h = id / (nq * cpr), rem = id % (nq * cpr), r = rem / cpr, c = (rem % cpr) * 8;
+        const long long go = (((long long)samp * ENH + h) * N + r0 + r) * ldp + c;
+        *(h16x8<Hh>*)(L.P + go) = *(const h16x8<Hh>*)((const Hh*)(sS + (h * 16 + r) * RS_SS) + c);
+        if (dsa.on && L.Pd) *(h16x8<Hh>*)(L.Pd + go) = *(const h16x8<Hh>*)(sPd + (h * 16 + r) * RS_PP + c);
+      }
+    }
+    // ================= B3: context = P V, unit = (head, 16 of the head's 64 columns): one per wave =================
+    {
+      const int h = w >> 2, jd = w & 3;
+      const Hh* pa = dsa.on ? sPd + h * 16 * RS_PP : (const Hh*)(sS + h * 16 * RS_SS);
+      const int pp = dsa.on ? RS_PP : 2 * RS_SS;
+      f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < NKP / 32; ++ks)
+        o = emma(lfrag(pa, pp, 0, ks * 32, lane), tfrag_clamp(sV + h * EHD, XS, jd * 16, ks * 32, lane, NRT * 16), o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sQ[(4 * g + r) * XS + h * EHD + jd * 16 + c16] = from_f<Hh>(o[r]);      // Q is dead: the context takes its place
+    }
+    __syncthreads();
+    copy_tile<false>(sQ, XS, L.ctx + row0 * EH, EH, nq, EH, tid);
+    // ================= C: a = LayerNorm(x + dropout(ctx Wo^T + bo)) =================
+    {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = emma(lfrag(sQ, XS, 0, ks * 32, lane), wo[ks], acc);
+      dd.site = L.site_ao; dd.p = p.p_hidden;
+      const DropState dsh = drop_init(dd);
+      add_norm16(acc, pb_o, pg_1, pe_1, sO, red, sA, L.rstd_a, nq, row0, p.eps, dsh, w, lane);
+    }
+    __syncthreads();
+    copy_tile<false>(sA, XS, L.a + row0 * EH, EH, nq, EH, tid);
+    // ================= D: z = a W1^T + bi ; g = gelu(z) =================
+    h16x8<Hh> w2[16];
+    {
+      f32x4 acc[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const h16x8<Hh> a = lfrag(sA, XS, 0, ks * 32, lane);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = emma(a, w1[ct][ks], acc[ct]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) w2[ks] = gfrag(L.W2, EI, w * 16, ks * 32, lane);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int col = (4 * w + ct) * 16 + c16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float zv = acc[ct][r] + pb_ffn[ct];
+          sZ[(4 * g + r) * GS + col] = from_f<Hh>(zv);
+          sG[(4 * g + r) * GS + col] = from_f<Hh>(gelu_fast(zv));
+        }
+      }
+    }
+    __syncthreads();
+    copy_tile<false>(sZ, GS, L.z + row0 * EI, EI, nq, EI, tid);
+    copy_tile<false>(sG, GS, L.g + row0 * EI, EI, nq, EI, tid);
+    // ================= E: out = LayerNorm(a + dropout(g W2^T + bo2)) =================
+    {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) acc = emma(lfrag(sG, GS, 0, ks * 32, lane), w2[ks], acc);
+      dd.site = L.site_out; dd.p = p.p_hidden;
+      const DropState dsh = drop_init(dd);
+      add_norm16(acc, pb_2, pg_2, pe_2, sA, red, sO, L.rstd_o, nq, row0, p.eps, dsh, w, lane);
+    }
+    __syncthreads();
+    // ---- hand-off: the tile's output rows, write-through; every wave drains its stores; one arrival per workgroup ----
+    copy_tile<true>(sO, XS, L.out + row0 * EH, EH, nq, EH, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // (also: every wave is done with sG / sZ / sK before the next layer overwrites them)
+    if (tid == 0 && l + 1 < sg.nlayers) __hip_atomic_fetch_add((gu32_t*)(cnt + (long long)samp * 6 + l), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <typename Hh>
+__global__ __launch_bounds__(512) void encoder_rs_kernel(EncParamsT<Hh> p, int nt0, int nt1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char enc_smem[];
+  int b = blockIdx.x, s = 0, nt = nt0;
+  unsigned* cnt = p.sync + 4;
+  if (b >= p.seg[0].nsamp * nt0) { b -= p.seg[0].nsamp * nt0; s = 1; nt = nt1; cnt += 6ll * p.seg[0].nsamp; }
+  const EncSegT<Hh>& sg = p.seg[s];
+  const int samp = b / nt, tile = b - samp * nt;
+  switch (nt) {
+    case 1: enc_rs_body<1>(p, sg, samp, tile, cnt, p.sync, enc_smem); break;
+    case 2: enc_rs_body<2>(p, sg, samp, tile, cnt, p.sync, enc_smem); break;
+    case 3: enc_rs_body<3>(p, sg, samp, tile, cnt, p.sync, enc_smem); break;
+    case 4: enc_rs_body<4>(p, sg, samp, tile, cnt, p.sync, enc_smem); break;
+    default: enc_rs_body<5>(p, sg, samp, tile, cnt, p.sync, enc_smem); break;
+  }
+}
+static size_t enc_rs_lds_bytes() { return (size_t)(80 * XS + 81 * XS + 80 * XS + 3 * 16 * XS) * 2 + 256 * sizeof(float); }
+
 static size_t enc_lds_bytes() {
   return (size_t)(2 * MAXROWS * XS + KROWS * QS + NWAVE * 16 * PSW) * 2 + (size_t)NWAVE * MAXROWS * sizeof(float);
 }
@@ -462,6 +826,25 @@ extern "C" int magic_encoder_fwd(int dtype, const void* params, int nbytes, void
       if (p.p_attn > 0.f && !L.Pd) return MAGIC_ERR_ARG;
     }
     blocks += sg.nsamp;
+  }
+  if (p.sync) {           // row-split form: one workgroup per (sample, 16-row tile)
+    const int nt0 = (p.seg[0].N + 15) / 16, nt1 = p.nseg > 1 ? (p.seg[1].N + 15) / 16 : 1;
+    const int ns1 = p.nseg > 1 ? p.seg[1].nsamp : 0;
+    const long long words = 4 + 6ll * (p.seg[0].nsamp + ns1);
+    if (p.sync_words < words || ((uintptr_t)p.sync & 15)) return MAGIC_ERR_ARG;
+    const size_t shm_rs = enc_rs_lds_bytes();
+    static bool rs_attr = false;
+    if (!rs_attr) {
+      (void)hipFuncSetAttribute((const void*)encoder_rs_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rs);
+      (void)hipFuncSetAttribute((const void*)encoder_rs_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rs);
+      rs_attr = true;
+    }
+    // every polled word is zeroed in front of EVERY launch (a memset node under graph capture); a multiple of 16 bytes from the allocation's start
+    if (hipMemsetAsync(p.sync, 0, (size_t)((words + 3) / 4 * 4) * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return MAGIC_ERR_LAUNCH;
+    const int grid = p.seg[0].nsamp * nt0 + ns1 * nt1;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(encoder_rs_kernel<bf16>, dim3(grid), dim3(512), shm_rs, (hipStream_t)stream, p, nt0, nt1);
+    else { EncParamsT<f16> pf; static_assert(sizeof(pf) == sizeof(p), "layout"); memcpy(&pf, &p, sizeof(pf)); hipLaunchKernelGGL(encoder_rs_kernel<f16>, dim3(grid), dim3(512), shm_rs, (hipStream_t)stream, pf, nt0, nt1); }
+    return launch_status();
   }
   const size_t shm = enc_lds_bytes();
   static bool attr_set = false;

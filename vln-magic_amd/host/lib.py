@@ -127,7 +127,8 @@ class EncSeg(C.Structure):
 
 
 class EncParams(C.Structure):
-    _fields_ = [("seg", EncSeg * 2), ("nseg", i32), ("p_attn", f32), ("p_hidden", f32), ("eps", f32), ("scale", f32), ("seed", vp)]
+    _fields_ = [("seg", EncSeg * 2), ("nseg", i32), ("p_attn", f32), ("p_hidden", f32), ("eps", f32), ("scale", f32), ("seed", vp),
+                ("sync", vp), ("sync_words", i32), ("pad2_", i32)]
 
 
 XL_PTRS = ("Wqkv", "bqkv", "Wo", "bo", "g1", "be1", "Wq", "bq", "Wkv", "bkv", "Woc", "boc", "gc", "bec", "W1", "bi", "W2", "bo2", "g2", "be2",

@@ -53,7 +53,7 @@ def ulp_close(a, b, name, ulps=2.0, floor=2e-3, frac_ok=1e-2):
 def test_fused_encoders_save_what_the_unfused_kernels_save(p_drop, max_len, row_split, monkeypatch):
     """row_split: the round-3 form (one workgroup per (sample, 16-row tile), layer outputs handed between the tiles of a sample inside the
     launch) and the per-sample form, each against the per-op kernels"""
-    monkeypatch.setattr(O, "ENC_ROW_SPLIT", row_split)
+    monkeypatch.setattr(O, "ENC_ROW_SPLIT", row_split)       # (panoramas: 3 tiles -> per-sample form inside the same launch; MAGIC_ENC_RS_ALL=1 splits them too)
     m = student(p_drop)
     m.train()
     batch = synth.make_batch("sap", batch_size=7, seed=5, step=0, max_len=max_len, min_len=min(12, max_len), dup_view_prob=0.3)

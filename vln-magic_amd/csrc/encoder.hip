@@ -525,6 +525,12 @@ __device__ __forceinline__ void copy_tile(const Hh* s, int pitch, Hh* g, int ldg
   }
 }
 
+#ifdef ENC_TIMING
+__device__ long long rs_ticks[8][16];         // [layer][mark] of tile 0 of sample 0 of segment 0
+#define RS_MARK(i) do { if (samp == 0 && tile == 0 && tid == 0 && &sg == &p.seg[0]) rs_ticks[l][i] = wall_clock64(); } while (0)
+#else
+#define RS_MARK(i)
+#endif
 template <int NRT, typename Hh>
 __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSegT<Hh>& sg, const int samp, const int tile, unsigned* cnt,
                                             unsigned* err, unsigned char* smem) {
@@ -566,6 +572,7 @@ __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSe
     int lane = lane0;
     asm volatile("" : "+v"(lane));             // (see enc_body: keeps the layer-invariant per-lane indices from being hoisted and spilled)
     const int g = lane >> 4, c16 = lane & 15;
+    RS_MARK(0);
     // ---- small parameters of the layer's epilogues, fetched now ----
     const float pb_q = L.bqkv[w * 16 + c16], pb_kv0 = L.bqkv[EH + (2 * w) * 16 + c16], pb_kv1 = L.bqkv[EH + (2 * w + 1) * 16 + c16];
     float pb_ffn[4];
@@ -594,6 +601,7 @@ __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSe
       }
       __syncthreads();
     }
+    RS_MARK(1);
     {
       const Hh* x = (l == 0 ? sg.x : sg.L[l - 1].out) + row_base * EH;
       const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, N * EH * 2, 0x00020000);     // rows >= N: out of range -> zeros
@@ -605,6 +613,7 @@ __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSe
       }
     }
     __syncthreads();
+    RS_MARK(2);
     // ================= A: K|V of all rows (2 of 16 column tiles per wave), Q of the own tile (1 of 8) =================
     {
       f32x4 acc[NRT][2], aq = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -642,6 +651,7 @@ __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSe
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) w1[ct][ks] = gfrag(L.W1, EH, (4 * w + ct) * 16, ks * 32, lane);
     __syncthreads();                              // K, V, Q images complete; sX is dead
+    RS_MARK(3);
     // own rows of Q|K|V -> global (the backward reads qkv [M, 3H])
     {
       Hh* qg = L.qkv + row0 * 3 * EH;
@@ -665,6 +675,7 @@ __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSe
       for (int r = 0; r < 4; ++r) sS[(h * 16 + 4 * g + r) * RS_SS + key] = key < N ? sc[r] * p.scale + mb : -3.0e38f;
     }
     __syncthreads();
+    RS_MARK(4);
     // ================= B2: softmax, 4 of the 32 (head, query) rows per wave, 16 lanes per row =================
     dd.site = L.site_attn; dd.p = p.p_attn;
     const DropState dsa = drop_init(dd);
@@ -693,6 +704,7 @@ __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSe
       if (NRT * 16 < NKP && c16 < NKP - NRT * 16) { pc[NRT * 16 + c16] = (Hh)0.0f; if (dsa.on) pd[NRT * 16 + c16] = (Hh)0.0f; }
     }
     __syncthreads();
+    RS_MARK(5);
     // probabilities -> global (clean: the backward's P; dropped: the exposed attention map)
     {
       const int cpr = ldp / 8;
@@ -715,6 +727,7 @@ __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSe
       for (int r = 0; r < 4; ++r) sQ[(4 * g + r) * XS + h * EHD + jd * 16 + c16] = from_f<Hh>(o[r]);      // Q is dead: the context takes its place
     }
     __syncthreads();
+    RS_MARK(6);
     copy_tile<false>(sQ, XS, L.ctx + row0 * EH, EH, nq, EH, tid);
     // ================= C: a = LayerNorm(x + dropout(ctx Wo^T + bo)) =================
     {
@@ -726,6 +739,7 @@ __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSe
       add_norm16(acc, pb_o, pg_1, pe_1, sO, red, sA, L.rstd_a, nq, row0, p.eps, dsh, w, lane);
     }
     __syncthreads();
+    RS_MARK(7);
     copy_tile<false>(sA, XS, L.a + row0 * EH, EH, nq, EH, tid);
     // ================= D: z = a W1^T + bi ; g = gelu(z) =================
     h16x8<Hh> w2[16];
@@ -753,6 +767,7 @@ __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSe
       }
     }
     __syncthreads();
+    RS_MARK(8);
     copy_tile<false>(sZ, GS, L.z + row0 * EI, EI, nq, EI, tid);
     copy_tile<false>(sG, GS, L.g + row0 * EI, EI, nq, EI, tid);
     // ================= E: out = LayerNorm(a + dropout(g W2^T + bo2)) =================
@@ -765,14 +780,17 @@ __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSe
       add_norm16(acc, pb_2, pg_2, pe_2, sA, red, sO, L.rstd_o, nq, row0, p.eps, dsh, w, lane);
     }
     __syncthreads();
+    RS_MARK(9);
     // ---- hand-off: the tile's output rows, write-through; every wave drains its stores; one arrival per workgroup ----
     copy_tile<true>(sO, XS, L.out + row0 * EH, EH, nq, EH, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                               // (also: every wave is done with sG / sZ / sK before the next layer overwrites them)
+    RS_MARK(10);
     if (tid == 0 && l + 1 < sg.nlayers) __hip_atomic_fetch_add((gu32_t*)(cnt + (long long)samp * 6 + l), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
+// every segment row-split: nt0 / nt1 = 16-row tiles per sample
 template <typename Hh>
 __global__ __launch_bounds__(512) void encoder_rs_kernel(EncParamsT<Hh> p, int nt0, int nt1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char enc_smem[];
@@ -787,6 +805,27 @@ __global__ __launch_bounds__(512) void encoder_rs_kernel(EncParamsT<Hh> p, int n
     case 3: enc_rs_body<3>(p, sg, samp, tile, cnt, p.sync, enc_smem); break;
     case 4: enc_rs_body<4>(p, sg, samp, tile, cnt, p.sync, enc_smem); break;
     default: enc_rs_body<5>(p, sg, samp, tile, cnt, p.sync, enc_smem); break;
+  }
+}
+// The headline launch: segment 0 (the text encoder, 4-5 tiles per instruction) row-split, its tiles first in the grid and all resident
+// together; segment 1 (the panorama encoder, <= 48 rows) one workgroup per sample (enc_body), which never waits.  k0 = 4 | 5 tiles,
+// k1 = -2 | -3 row tiles.  ONE flat switch over FOUR instantiations: with more bodies inlined into one kernel (or a nested
+// `if (row_split) switch ... else switch ...`) hipcc keeps the 2.5 KB parameter block in scratch memory and the launch runs 1.7x slower.
+template <typename Hh>
+__global__ __launch_bounds__(512) void encoder_mix_kernel(EncParamsT<Hh> p, int k0, int k1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char enc_smem[];
+  int b = blockIdx.x, s = 0, nt = k0;
+  unsigned* cnt = p.sync + 4;
+  const int blocks0 = p.seg[0].nsamp * k0;
+  if (b >= blocks0) { b -= blocks0; s = 1; nt = k1; }
+  const EncSegT<Hh>& sg = p.seg[s];
+  const int na = nt > 0 ? nt : 1;
+  const int samp = b / na, tile = b - samp * na;
+  switch (nt) {
+    case 4: enc_rs_body<4>(p, sg, samp, tile, cnt, p.sync, enc_smem); break;
+    case 5: enc_rs_body<5>(p, sg, samp, tile, cnt, p.sync, enc_smem); break;
+    case -3: enc_body<3>(p, sg, samp, enc_smem); break;
+    default: enc_body<2>(p, sg, samp, enc_smem); break;
   }
 }
 static size_t enc_rs_lds_bytes() { return (size_t)(80 * XS + 81 * XS + 80 * XS + 3 * 16 * XS) * 2 + 256 * sizeof(float); }
@@ -832,19 +871,40 @@ extern "C" int magic_encoder_fwd(int dtype, const void* params, int nbytes, void
     const int ns1 = p.nseg > 1 ? p.seg[1].nsamp : 0;
     const long long words = 4 + 6ll * (p.seg[0].nsamp + ns1);
     if (p.sync_words < words || ((uintptr_t)p.sync & 15)) return MAGIC_ERR_ARG;
-    const size_t shm_rs = enc_rs_lds_bytes();
+    // a segment runs row-split when all its tiles are resident together with one workgroup per CU, and only segments that come out ahead:
+    // >= 4 tiles per sample (a 36-view panorama is 3 tiles, the third almost empty, and its per-sample workgroups already fill the chip)
+    static int ncu = 0;
+    if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("MAGIC_ENC_RS_ALL"); force = e ? atoi(e) : -1; }      // 1: every segment row-split (tests, measurements)
+    const bool rs0 = nt0 >= 4 && p.seg[0].nsamp * nt0 <= ncu, rs1 = p.nseg > 1 && nt1 >= 4 && p.seg[0].nsamp * nt0 + ns1 * nt1 <= ncu;
+    const int form = (force == 1 || (rs0 && (rs1 || p.nseg == 1))) ? 2 : (rs0 && p.nseg == 2 && nt1 <= 3) ? 1 : 0;      // 2: all row-split, 1: mixed, 0: per sample
     static bool rs_attr = false;
     if (!rs_attr) {
-      (void)hipFuncSetAttribute((const void*)encoder_rs_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rs);
-      (void)hipFuncSetAttribute((const void*)encoder_rs_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_rs);
+      (void)hipFuncSetAttribute((const void*)encoder_rs_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_rs_lds_bytes());
+      (void)hipFuncSetAttribute((const void*)encoder_rs_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_rs_lds_bytes());
+      (void)hipFuncSetAttribute((const void*)encoder_mix_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_lds_bytes());
+      (void)hipFuncSetAttribute((const void*)encoder_mix_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_lds_bytes());
       rs_attr = true;
     }
-    // every polled word is zeroed in front of EVERY launch (a memset node under graph capture); a multiple of 16 bytes from the allocation's start
-    if (hipMemsetAsync(p.sync, 0, (size_t)((words + 3) / 4 * 4) * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return MAGIC_ERR_LAUNCH;
-    const int grid = p.seg[0].nsamp * nt0 + ns1 * nt1;
-    if (dtype == DT_BF16) hipLaunchKernelGGL(encoder_rs_kernel<bf16>, dim3(grid), dim3(512), shm_rs, (hipStream_t)stream, p, nt0, nt1);
-    else { EncParamsT<f16> pf; static_assert(sizeof(pf) == sizeof(p), "layout"); memcpy(&pf, &p, sizeof(pf)); hipLaunchKernelGGL(encoder_rs_kernel<f16>, dim3(grid), dim3(512), shm_rs, (hipStream_t)stream, pf, nt0, nt1); }
-    return launch_status();
+    if (form) {
+      // every polled word is zeroed in front of EVERY launch (a memset node under graph capture); a multiple of 16 bytes from the allocation's start
+      if (hipMemsetAsync(p.sync, 0, (size_t)((words + 3) / 4 * 4) * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return MAGIC_ERR_LAUNCH;
+      EncParamsT<f16> pf;
+      static_assert(sizeof(pf) == sizeof(p), "layout");
+      memcpy(&pf, &p, sizeof(pf));
+      if (form == 2) {
+        const int grid = p.seg[0].nsamp * nt0 + ns1 * nt1;
+        if (dtype == DT_BF16) hipLaunchKernelGGL(encoder_rs_kernel<bf16>, dim3(grid), dim3(512), enc_rs_lds_bytes(), (hipStream_t)stream, p, nt0, nt1);
+        else hipLaunchKernelGGL(encoder_rs_kernel<f16>, dim3(grid), dim3(512), enc_rs_lds_bytes(), (hipStream_t)stream, pf, nt0, nt1);
+      } else {
+        const int grid = p.seg[0].nsamp * nt0 + ns1, k1 = -(nt1 < 2 ? 2 : nt1);
+        if (dtype == DT_BF16) hipLaunchKernelGGL(encoder_mix_kernel<bf16>, dim3(grid), dim3(512), enc_lds_bytes(), (hipStream_t)stream, p, nt0, k1);
+        else hipLaunchKernelGGL(encoder_mix_kernel<f16>, dim3(grid), dim3(512), enc_lds_bytes(), (hipStream_t)stream, pf, nt0, k1);
+      }
+      return launch_status();
+    }
+    if (hipMemsetAsync(p.sync, 0, 16, (hipStream_t)stream) != hipSuccess) return MAGIC_ERR_LAUNCH;      // per-sample form: the give-up word still reads 0
   }
   const size_t shm = enc_lds_bytes();
   static bool attr_set = false;

@@ -49,4 +49,7 @@ for rs in (False, True):
     if rs:      # the mixed launch with one of its halves shrunk to a single sample: what each half costs INSIDE that kernel
         sp1 = dict(sp, nsamp=1, x=sp["x"][:sp["N"]])
         st1 = dict(st, nsamp=1, x=st["x"][:st["N"]])
+        for k in (8, 16, 32, 64, 128, 200, 256):
+            spk = dict(sp, nsamp=k, x=sp["x"][:k * sp["N"]])
+            print(f"   mixed kernel: all text tiles + {k} panoramas {timeit(lambda: n._enc_launch([st, spk])):.1f} us", flush=True)
         print(f"   mixed kernel: text tiles + 1 panorama {timeit(lambda: n._enc_launch([st, sp1])):.1f} us, 1 instruction + all panoramas {timeit(lambda: n._enc_launch([st1, sp])):.1f} us", flush=True)

@@ -214,6 +214,16 @@ int magic_sap_fuse_bwd(int B, int K, int Vp, const float* g_raw, const float* l_
                        int use_gate, const float* dgl, const float* dll, const float* dfl,
                        float* dg_raw, float* dl_raw, float* dfuse_raw, void* stream);
 
+/* Step prologue: the per-step random scalars of a training step in one launch -- MKRW ability weights rw[5] = softmax(randn(5) / rw_temp) * 5
+ * (map_nav_src/r2r/agent.py:866-871) and the two 31-bit words that key the counter-based dropout masks; `counter` (one device word) is
+ * advanced here, so a replayed HIP graph draws fresh values each step.  seed_out / rw_out: either may be NULL. */
+int magic_step_rng(unsigned long long base_seed, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, void* stream);
+/* Loss assembly in one launch: sup = row_scale * sum rows[i] (* row_w[i]); slots[9] = sum kd_rows (optional); terms[i] = slots[i] * rw[ability(i)]
+ * over the ten MAKD slots (agent.py:546-719: txt, txt, img, img, img, global, global, local, local, action); kdl = sum terms;
+ * loss = alpha * kdl + (1 - alpha) * sup (agent.py:1110-1123; has_kd = 0: loss = sup).  out[13] = {sup, terms[10], kdl, loss}. */
+int magic_loss_assemble(const float* rows, int n_rows, const float* row_w, float row_scale, const float* kd_rows, int n_kd,
+                        float* slots, const float* rw, float alpha, int has_kd, float* out, void* stream);
+
 /* Flat-buffer optimizer: pretrain_src/optim/adamw.py:53-112 + clip_grad_norm_ (grad_norm, r2r_magic_pretrain.json:22) */
 int magic_sumsq(long long n, const float* g, float* out, void* stream);
 int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype,

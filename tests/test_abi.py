@@ -28,6 +28,8 @@ def parse_header():
                     types.append(L.i64)
                 elif a.startswith("float"):
                     types.append(L.f32)
+                elif a.startswith("unsigned long long"):
+                    types.append(L.u64)
                 elif a.startswith("unsigned"):
                     types.append(L.u32)
                 elif a.startswith("int"):

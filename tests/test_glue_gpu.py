@@ -1,0 +1,71 @@
+"""The two "glue" kernels of round 3 (csrc/loss.hip): the step prologue (MKRW weights + dropout seed from one launch) and the loss assembly
+(supervised mean, ability-weighted MAKD terms, total) -- against plain torch arithmetic (-m gpu)."""
+import math
+
+import pytest
+import torch
+
+import magic_amd  # noqa: F401
+from magic_amd.host import ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_step_rng_statistics_and_counter():
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    seed, rw = torch.zeros(2, dtype=torch.int32, device=DEV), torch.zeros(5, device=DEV)
+    T, n = 4.0, 4000
+    rws, seeds = [], []
+    for _ in range(n):
+        O.step_rng(1234, counter, T, seed_out=seed, rw_out=rw)
+        rws.append(rw.clone()); seeds.append(seed.clone())
+    torch.cuda.synchronize()
+    assert int(counter) == n
+    rws, seeds = torch.stack(rws).cpu().double(), torch.stack(seeds).cpu()
+    assert torch.allclose(rws.sum(1), torch.full((n,), 5.0, dtype=torch.float64), atol=1e-4)          # softmax(...) * 5
+    assert (rws > 0).all()
+    # rw_i = 5 softmax(z / T)_i with z ~ N(0, 1): log(rw_i / rw_j) = (z_i - z_j) / T ~ N(0, 2 / T^2)
+    lr = torch.log(rws[:, 0] / rws[:, 1])
+    assert abs(lr.mean().item()) < 4 * math.sqrt(2.0 / T ** 2 / n)
+    assert abs(lr.std().item() - math.sqrt(2.0) / T) < 0.03
+    # the same five draws are independent of each other and across steps (lag-1 correlation ~ 0)
+    z = torch.log(rws) - torch.log(rws).mean(1, keepdim=True)
+    assert abs(torch.corrcoef(torch.stack([z[:-1, 0], z[1:, 0]]))[0, 1].item()) < 0.06
+    assert (seeds >= 0).all() and len({tuple(s.tolist()) for s in seeds}) == n                           # 31-bit words, all distinct
+    # determinism: same base seed + same counter -> same values; another base seed -> other values
+    c2 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    O.step_rng(1234, c2, T, seed_out=seed, rw_out=rw)
+    torch.cuda.synchronize()
+    assert torch.equal(seed.cpu(), seeds[0]) and torch.allclose(rw.cpu().double(), rws[0], atol=1e-6)
+    c3 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    O.step_rng(99, c3, T, seed_out=seed, rw_out=rw)
+    torch.cuda.synchronize()
+    assert not torch.equal(seed.cpu(), seeds[0])
+
+
+@pytest.mark.parametrize("has_kd,with_w,with_rows", [(True, False, True), (True, True, False), (False, False, False)])
+def test_loss_assemble_matches_torch(has_kd, with_w, with_rows):
+    g = torch.Generator().manual_seed(3)
+    rows = torch.rand(613, generator=g).to(DEV)
+    w = torch.rand(613, generator=g).to(DEV) if with_w else None
+    kd_rows = torch.rand(48, generator=g).to(DEV) if with_rows else None
+    slots = torch.rand(16, generator=g).to(DEV)
+    rw = (torch.rand(5, generator=g) + 0.5).to(DEV)
+    out = torch.full((16,), float("nan"), device=DEV)
+    s0 = slots.clone()
+    O.loss_assemble(rows, w, 0.37, kd_rows, slots, rw, 0.5, has_kd, out)
+    torch.cuda.synchronize()
+    sup = 0.37 * ((rows * w).sum() if with_w else rows.sum())
+    assert torch.allclose(out[0], sup, rtol=1e-5)
+    if has_kd:
+        want = s0.clone()
+        if with_rows:
+            want[9] = kd_rows.sum()
+            assert torch.allclose(slots[9], kd_rows.sum(), rtol=1e-5)
+        terms = want[:10] * rw[torch.tensor([0, 0, 1, 1, 1, 2, 2, 3, 3, 4], device=DEV)]
+        assert torch.allclose(out[1:11], terms, rtol=1e-5)
+        assert torch.allclose(out[11], terms.sum(), rtol=1e-5)
+        assert torch.allclose(out[12], 0.5 * terms.sum() + 0.5 * sup, rtol=1e-5)
+    else:
+        assert float(out[11]) == 0.0 and torch.allclose(out[12], sup, rtol=1e-5)

@@ -604,3 +604,69 @@ extern "C" int magic_mse(int dtype, int g_f32, long long outer, long long inner,
 #undef L
   return launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Step prologue (round 3): the per-step random scalars of a training step from ONE launch instead of five torch launches inside the
+// captured graph (normal_, div, softmax, mul for MKRW; random_ for the dropout seed).
+//   MKRW ability weights  rw = softmax(randn(5) / rw_temp) * 5          (map_nav_src/r2r/agent.py:866-871; pretrain: r2r_magic_pretrain.json:72)
+//   dropout seed          two 31-bit words (the kernels' counter-based masks key on them, csrc/common.hpp)
+// Randomness: murmur3-finalised counters keyed by (base_seed, step counter): the counter lives in device memory and is advanced here, so
+// a replayed HIP graph draws fresh values every step; Box-Muller on two uniforms per normal.
+__device__ __forceinline__ unsigned mix32(unsigned x) { x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16; return x; }
+__global__ void step_rng_kernel(unsigned base_lo, unsigned base_hi, unsigned* counter, float rw_temp, int* seed_out, float* rw_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned c = counter[0];
+  counter[0] = c + 1u;
+  auto draw = [&](unsigned k) { return mix32(mix32(base_lo ^ (c * 0x9E3779B1u)) + base_hi + k * 0x85EBCA77u); };
+  if (seed_out) { seed_out[0] = (int)(draw(0) & 0x7FFFFFFFu); seed_out[1] = (int)(draw(1) & 0x7FFFFFFFu); }
+  if (rw_out) {
+    float z[5], mx = -3.0e38f;
+    for (int i = 0; i < 5; ++i) {
+      const float u1 = ((float)(draw(2 + 2 * i) >> 8) + 1.0f) * (1.0f / 16777217.0f);        // (0, 1)
+      const float u2 = (float)(draw(3 + 2 * i) >> 8) * (1.0f / 16777216.0f);                  // [0, 1)
+      z[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958648f * u2) / rw_temp;
+      mx = fmaxf(mx, z[i]);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 5; ++i) { z[i] = expf(z[i] - mx); s += z[i]; }
+    for (int i = 0; i < 5; ++i) rw_out[i] = 5.0f * z[i] / s;
+  }
+}
+extern "C" int magic_step_rng(unsigned long long base_seed, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, void* stream) {
+  if (!counter || rw_temp <= 0.f || (!seed_out && !rw_out)) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(step_rng_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)base_seed, (unsigned)(base_seed >> 32), counter, rw_temp, seed_out, rw_out);
+  return launch_status();
+}
+
+// Loss assembly (round 3): what `_losses` did with ~10 torch launches (sum, div, index, cat, mul, sum, mul, mul, add ...) in one:
+//   sup = row_scale * sum_i rows[i] (* row_w[i]) ; slots[9] = sum kd_rows (the action-distillation rows) ;
+//   terms[i] = slots[i] * rw[ability(i)] , abilities of the ten MAKD slots = {txt, txt, img, img, img, global, global, local, local, action}
+//   (map_nav_src/r2r/agent.py:546-719: softmax_weights[0..4]) ; kdl = sum terms ; loss = alpha * kdl + (1 - alpha) * sup  (agent.py:1110-1123)
+//   out[0] = sup, out[1..10] = terms, out[11] = kdl, out[12] = loss.  One 256-thread block.
+__global__ __launch_bounds__(256) void loss_assemble_kernel(const float* rows, int n_rows, const float* row_w, float row_scale, const float* kd_rows, int n_kd,
+                                                            float* slots, const float* rw, float alpha, int has_kd, float* out) {
+  __shared__ float red[2][4];
+  float s = 0.f, k = 0.f;
+  for (int i = threadIdx.x; i < n_rows; i += 256) s += row_w ? rows[i] * row_w[i] : rows[i];
+  if (kd_rows) for (int i = threadIdx.x; i < n_kd; i += 256) k += kd_rows[i];
+  s = wave_sum(s); k = wave_sum(k);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = k; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float sup = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * row_scale;
+    if (kd_rows) slots[9] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const int ab[10] = {0, 0, 1, 1, 1, 2, 2, 3, 3, 4};
+    float kdl = 0.f;
+    for (int i = 0; i < 10; ++i) {
+      const float t = has_kd ? slots[i] * (rw ? rw[ab[i]] : 1.f) : 0.f;
+      out[1 + i] = t; kdl += t;
+    }
+    out[0] = sup; out[11] = kdl; out[12] = has_kd ? alpha * kdl + (1.f - alpha) * sup : sup;
+  }
+}
+extern "C" int magic_loss_assemble(const float* rows, int n_rows, const float* row_w, float row_scale, const float* kd_rows, int n_kd,
+                                   float* slots, const float* rw, float alpha, int has_kd, float* out, void* stream) {
+  if (!rows || n_rows <= 0 || !out || (has_kd && !slots) || (kd_rows && n_kd <= 0)) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, n_rows, row_w, row_scale, kd_rows, n_kd, slots, rw, alpha, has_kd, out);
+  return launch_status();
+}

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmagic_hip.so")
 
-vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint
+vp, i32, i64, f32, u32, u64 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint, C.c_ulonglong
 
 # name -> argument ctypes (mirrors include/magic_hip.h exactly; tests/test_abi.py checks every symbol)
 SIGNATURES = {
@@ -47,6 +47,8 @@ SIGNATURES = {
     "magic_kd_rows": [i32, i32, vp, vp, i32, f32, vp, f32, f32, vp, vp, vp, i32, vp],
     "magic_mse": [i32, i32, i64, i64, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp, i64, i32, vp],
     "magic_mse_multi": [i32, i32, vp, vp],
+    "magic_step_rng": [u64, vp, f32, vp, vp, vp],
+    "magic_loss_assemble": [vp, i32, vp, f32, vp, i32, vp, vp, f32, i32, vp, vp],
     "magic_cfp_loss": [i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_node_in_fwd": [i32, i32, i32, vp, vp],
     "magic_csr_gather_multi": [i32, i32, i32, vp, vp],

@@ -88,6 +88,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         self._aux = torch.cuda.Stream(device=self.device_) if (self.device_.type == "cuda" and os.environ.get("MAGIC_PAR")) else None   # opt-in: measured slower under HIP-graph replay
         self._kd_idx = torch.tensor([0, 0, 1, 1, 1, 2, 2, 3, 3, 4], device=self.device_)
         self.keep_mlm_logits = False     # True: MLM CE gradient goes to its own buffer instead of overwriting the logits
+        self.dropout_seed = None         # optional int32[2] device tensor: when set, forward() keys its dropout masks on it instead of drawing one
         # fp16 compute: every gradient SEED (the coefficient of each fused loss + gradient kernel) is multiplied by `grad_scale`, so the
         # activation gradients stay inside fp16's range (the reference's own fp16 option scales the loss the same way: GradScaler,
         # train_r2r_magic.py:370-371); the flat fp32 gradient buffer then holds grad_scale x the gradient and the optimizer divides
@@ -129,7 +130,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         is drawn on the device by torch's graph-safe generator, so a replayed HIP graph gets fresh masks every step."""
         ph, pa = float(self.dropout.p), float(self.attention_dropout.p)
         if self.training and self.store.requires_grad and torch.is_grad_enabled() and (ph > 0 or pa > 0):
-            seed = torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int32, device=self.device_)
+            seed = self.dropout_seed            # PretrainStep: a device word pair its step prologue refreshes every step (one launch with the MKRW draw)
+            if seed is None:
+                seed = torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int32, device=self.device_)
             self.net.set_dropout(seed, ph, pa)
         else:
             self.net.set_dropout(None)
@@ -435,7 +438,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             O.ce_rows(c.gl, B, K, K, ga, coef=scg / B, loss_row=c.rows[0], dlogits=c.dgl, ldd=K)
             O.ce_rows(c.ll, B, Vp, Vp, la, coef=scg / B, loss_row=c.rows[1], dlogits=c.dll, ldd=Vp)
             O.ce_rows(c.fl, B, K, K, ga, coef=scg / B, loss_row=c.rows[2], dlogits=c.dfl, ldd=K)
-            sup = c.rows.sum() / B
+            sup_rows, sup_w, sup_scale = c.rows, None, 1.0 / B
         elif task == "mlm":
             c.d_x, c.d_gin0 = zz(B * L, H), zz(B * K, H)
             nm = plan["n_mask"]
@@ -446,14 +449,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                       row_w=roww, loss_row=c.rows, dlogits=c.dlogits, ldd=c.ldv)
             if train and not self.keep_mlm_logits:
                 o["predict"] = None          # overwritten in place by its gradient
-            sup = (c.rows * roww).sum() if roww is not None else c.rows.sum() / nm
+            sup_rows, sup_w, sup_scale = c.rows, roww, (1.0 if roww is not None else 1.0 / nm)
         elif task == "mrc":
             c.d_vp = zz(B * Vp, H)
             nm, Pn = plan["n_mrc"], c.mlogits.shape[1]
             c.rows = n.new(nm, dtype=torch.float32)
             c.dmlogits = n.new(nm, Pn) if train else None
             O.softkl_rows(c.mlogits, nm, Pn, Pn, plan["mrc_targets"], coef=scg / nm, loss_row=c.rows, dlogits=c.dmlogits, ldd=Pn)
-            sup = c.rows.sum() / nm
+            sup_rows, sup_w, sup_scale = c.rows, None, 1.0 / nm
         else:
             c.d_gmap, c.d_vp, c.d_txt2 = zz(B * K, H), zz(B * Vp, H), zz(B * L, H)
             c.d_cls0 = (zz(B, H), zz(B, H), zz(B, H))
@@ -478,8 +481,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 O.ce_rows(simT, B, B, lds, ar, coef=scg * 0.5 / B, loss_row=c.rows[2 * i + 1], dlogits=d2, ldd=lds)
                 c.dsim.append((d1, d2))
             c.temp = temp
-            sup = c.rows.sum() * 0.5 / B
-        res["supervised_loss"] = sup
+            sup_rows, sup_w, sup_scale = c.rows, None, 0.5 / B
+        kd_rows, rwd = None, None
         # ---- MAKD (pretrain flavour; oracle/makd_ref.pretrain_makd) -------------------------------------
         if kd:
             # MKRW ability weights as a DEVICE tensor (a captured HIP graph re-reads them every replay)
@@ -539,14 +542,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 c.kdrows = n.new(B, dtype=torch.float32)
                 O.kd_rows(c.fl, t["fused_logits"], B, K, K, T, w=w, norm=(1.0 / B if w is not None else 1.0 / (B * K)),
                           coef=rw[4][0], coef_dev=rw[4][1], loss_row=c.kdrows, ds=c.dfl, accumulate=True)
-                c.slots[9:10] = c.kdrows.sum()
-            coefs = torch.cat([rwd[self._kd_idx], rwd.new_zeros(6)])
-            terms = c.slots * coefs
-            res["kdl_terms"] = {k: terms[i] for i, k in enumerate(KD_SLOTS)}
-            res["kdl_loss"] = terms.sum()
-            res["loss"] = alpha * res["kdl_loss"] + sc * sup
-        else:
-            res["loss"] = sup
+                kd_rows = c.kdrows
+        # supervised mean, the action-distillation row sum, the ten ability-weighted MAKD terms, their sum and the total: ONE launch
+        lo = O.loss_assemble(sup_rows.reshape(-1), sup_w, sup_scale, kd_rows, c.slots, rwd, alpha, kd, n.new(16, dtype=torch.float32))
+        res["supervised_loss"] = lo[0]
+        if kd:
+            res["kdl_terms"] = {k: lo[1 + i] for i, k in enumerate(KD_SLOTS)}
+            res["kdl_loss"] = lo[11]
+        res["loss"] = lo[12]
         return res
 
     # ---- backward ---------------------------------------------------------------------------------------

@@ -625,6 +625,19 @@ def sap_fuse_bwd(B, K, Vp, g_raw, l_raw, fuse_raw, gmask, lmask, fsrc, bwmask, u
            1 if use_gate else 0, L.P(dgl), L.P(dll), L.P(dfl), L.P(dg_raw), L.P(dl_raw), L.P(dfuse_raw), L.stream())
 
 
+def step_rng(base_seed, counter, rw_temp, seed_out=None, rw_out=None):
+    """per-step random scalars in one launch: dropout seed (int32[2]) and / or MKRW weights (fp32[5]); `counter`: int32[1] device word, advanced"""
+    L.call("magic_step_rng", int(base_seed) & 0xFFFFFFFFFFFFFFFF, L.P(counter), float(rw_temp), L.P(seed_out), L.P(rw_out), L.stream())
+
+
+def loss_assemble(rows, row_w, row_scale, kd_rows, slots, rw, alpha, has_kd, out):
+    """out[13] = {supervised, 10 weighted MAKD terms, their sum, total loss} (csrc/loss.hip loss_assemble_kernel)"""
+    _chk(rows.dtype == torch.float32 and rows.is_contiguous() and out.dtype == torch.float32 and out.numel() >= 13, "loss_assemble layout")
+    L.call("magic_loss_assemble", L.P(rows), rows.numel(), L.P(row_w), float(row_scale), L.P(kd_rows), kd_rows.numel() if kd_rows is not None else 0,
+           L.P(slots), L.P(rw), float(alpha), 1 if has_kd else 0, L.P(out), L.stream())
+    return out
+
+
 def sumsq(g, out):
     L.call("magic_sumsq", g.numel(), L.P(g), L.P(out), L.stream())
 

@@ -122,7 +122,8 @@ class StreamStep:
             e.t_out = tr.teacher_forward(e.batch, task, e.plan)
         e.gS = torch.cuda.CUDAGraph()
         with tr._graph_ctx(e.gS):
-            rw = self.rw if self.rw is not None else tr.mkrw()
+            drawn = tr.mkrw()                       # (also refreshes the dropout seed: one launch)
+            rw = self.rw if self.rw is not None else drawn
             tr.student.store.zero_grad()
             e.out = tr.student(e.batch, task, compute_loss=True, teacher_outputs=e.t_out, rw=rw, plan=e.plan, inputs=e.t_out["inputs"])
             tr.student.backward()

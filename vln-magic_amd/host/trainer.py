@@ -253,6 +253,14 @@ class PretrainStep:
         if self.on_gpu and overlap_dw and O.SIDE["stream"] is None and os.environ.get("MAGIC_DW_SIDE"):   # opt-in: no gain measured on MI355X
             O.SIDE["stream"] = torch.cuda.Stream()       # weight-gradient GEMMs leave the dX critical chain
         self.global_step = 0
+        # per-step random scalars (MKRW weights, dropout seed) come from ONE launch (csrc/loss.hip step_rng_kernel) keyed by `seed` and a
+        # device-side step counter: inside a captured graph every replay advances the counter and so draws fresh values
+        self.seed = int(seed)
+        if self.on_gpu:
+            self._rng_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self._rw = torch.ones(5, dtype=torch.float32, device=self.dev)
+            self._dseed = torch.zeros(2, dtype=torch.int32, device=self.dev)
+            student.dropout_seed = self._dseed
 
     def _graph_ctx(self, g):
         # relaxed: helper threads launch into the capture (lib.lockstep).  Stream priorities were tried and rejected: a
@@ -260,9 +268,12 @@ class PretrainStep:
         return torch.cuda.graph(g, capture_error_mode="relaxed")
 
     def mkrw(self):
-        """MKRW ability weights softmax(randn(5)/rw_temp)*5 (map_nav_src/r2r/agent.py:866-871), drawn ON the device
-        (graph-safe generator) so a replayed graph sees fresh weights every step."""
-        return torch.softmax(torch.randn(5, device=self.dev, dtype=torch.float32) / self.rw_temp, dim=-1) * 5
+        """MKRW ability weights softmax(randn(5)/rw_temp)*5 (map_nav_src/r2r/agent.py:866-871) AND the step's dropout seed, drawn ON the
+        device by one launch, so a replayed graph sees fresh values every step.  Returns the weights (a fixed device buffer)."""
+        if not self.on_gpu:
+            return torch.softmax(torch.randn(5, dtype=torch.float32) / self.rw_temp, dim=-1) * 5
+        O.step_rng(self.seed, self._rng_counter, self.rw_temp, seed_out=self._dseed, rw_out=self._rw)
+        return self._rw
 
     # ---- gradient exchange from inside the backward ---------------------------------------------------------------------
     def _touched_rows(self, task, plan):
@@ -297,8 +308,9 @@ class PretrainStep:
             else:
                 with torch.no_grad():
                     t_out = te(batch, task, compute_loss=False, return_outputs=True, plan=plan, inputs=inputs)
+        drawn = self.mkrw()
         if rw is None and te is not None:
-            rw = self.mkrw()
+            rw = drawn
         st.store.zero_grad()
         out = st(batch, task, compute_loss=True, teacher_outputs=t_out, rw=rw, plan=plan, inputs=inputs)
         hook = self._bucket_hook(task, plan) if not torch.cuda.is_current_stream_capturing() else None
@@ -326,8 +338,9 @@ class PretrainStep:
         with torch.cuda.stream(self.side):
             t_next = self.teacher_forward(*nxt)
         batch, task, plan = cur
+        drawn = self.mkrw()
         if rw is None:
-            rw = self.mkrw()
+            rw = drawn
         st.store.zero_grad()
         out = st(batch, task, compute_loss=True, teacher_outputs=t_cur, rw=rw, plan=plan, inputs=t_cur["inputs"])
         hook = self._bucket_hook(task, plan) if not torch.cuda.is_current_stream_capturing() else None
@@ -373,10 +386,8 @@ class PretrainStep:
         gS = torch.cuda.CUDAGraph()
         gS2 = None
         with self._graph_ctx(gS):
-            if rw is None:
-                rw_ = self.mkrw()
-            else:
-                rw_ = rw
+            drawn = self.mkrw()
+            rw_ = drawn if rw is None else rw
             self.student.store.zero_grad()
             out = self.student(batch, task, compute_loss=True, teacher_outputs=t_cur, rw=rw_, plan=plan, inputs=t_cur["inputs"])
             if two:

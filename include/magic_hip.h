@@ -217,7 +217,7 @@ int magic_sap_fuse_bwd(int B, int K, int Vp, const float* g_raw, const float* l_
 /* Step prologue: the per-step random scalars of a training step in one launch -- MKRW ability weights rw[5] = softmax(randn(5) / rw_temp) * 5
  * (map_nav_src/r2r/agent.py:866-871) and the two 31-bit words that key the counter-based dropout masks; `counter` (one device word) is
  * advanced here, so a replayed HIP graph draws fresh values each step.  seed_out / rw_out: either may be NULL. */
-int magic_step_rng(unsigned long long base_seed, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, void* stream);
+int magic_step_rng(unsigned long long base_seed, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, float* zero_me, void* stream);
 /* Loss assembly in one launch: sup = row_scale * sum rows[i] (* row_w[i]); slots[9] = sum kd_rows (optional); terms[i] = slots[i] * rw[ability(i)]
  * over the ten MAKD slots (agent.py:546-719: txt, txt, img, img, img, global, global, local, local, action); kdl = sum terms;
  * loss = alpha * kdl + (1 - alpha) * sup (agent.py:1110-1123; has_kd = 0: loss = sup).  out[13] = {sup, terms[10], kdl, loss}. */
@@ -226,9 +226,14 @@ int magic_loss_assemble(const float* rows, int n_rows, const float* row_w, float
 
 /* Flat-buffer optimizer: pretrain_src/optim/adamw.py:53-112 + clip_grad_norm_ (grad_norm, r2r_magic_pretrain.json:22) */
 int magic_sumsq(long long n, const float* g, float* out, void* stream);
-int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype,
+int magic_adamw(long long n, float* p, float* g, float* m, float* v, void* shadow, int shadow_dtype,
                 float lr, float b1, float b2, float eps, float wd, float step_size,
-                const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, void* stream);
+                const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_grad, void* stream);
+/* zero_grad != 0: g is set to 0 after it has been consumed (the next step's accumulators start from zero without a fill launch).
+ * magic_sumsq_sched: magic_sumsq that also advances the device-side schedule (magic_sched_step's arithmetic) in the same launch; `out`
+ * must already be zero (magic_step_rng's zero_me at the top of the step) */
+int magic_sumsq_sched(long long n, const float* g, float* out, int* step, float lr0, int warmup, int total, float b1, float b2,
+                      float* lr_ss, void* stream);
 /* n_decay: elements [0, n_decay) take the weight decay wd, the rest none (both parameter groups of optim/misc.py:13-22 in one launch);
  * < 0: all.  device-side lr schedule + Adam bias correction (optim/sched.py:17-30, adamw.py:97-100) for HIP-graph replay; coef_dev / lr_ss
  * arguments above are optional device scalars multiplied into / replacing the host values; zero_me (optional): one float set to 0 (the

@@ -69,3 +69,28 @@ def test_loss_assemble_matches_torch(has_kd, with_w, with_rows):
         assert torch.allclose(out[12], 0.5 * terms.sum() + 0.5 * sup, rtol=1e-5)
     else:
         assert float(out[11]) == 0.0 and torch.allclose(out[12], sup, rtol=1e-5)
+
+
+def test_fused_schedule_and_gradient_zeroing_follow_the_separate_launches():
+    """sumsq + schedule in one launch and AdamW zeroing its gradients == sched_step; sumsq; adamw; zero_grad, over three steps"""
+    from magic_amd.host.config import make_config
+    from magic_amd.host.model_pretrain import pretrain_specs
+    from magic_amd.host.params import ParamStore
+    from magic_amd.host.trainer import FusedAdamW
+    cfg = make_config(128, teacher_hidden_size=256, vocab_size=300, num_l_layers=1, num_x_layers=1, num_pano_layers=1)
+    stores = [ParamStore(pretrain_specs(cfg), DEV, torch.bfloat16, seed=1) for _ in range(2)]
+    opts = [FusedAdamW(s, lr=1e-3, schedule=(2, 10), max_grad_norm=0.5) for s in stores]
+    g = torch.Generator().manual_seed(0)
+    for step in range(3):
+        grad = (torch.randn(stores[0].total, generator=g) * 0.01).to(DEV)
+        for s in stores:
+            s.grad.copy_(grad)
+        opts[0].step(gscale=0.5)                                   # separate launches
+        opts[1].ss.zero_()                                         # (what the step prologue does)
+        opts[1].step(gscale=0.5, ss_zeroed=True, zero_grad=True)   # fused forms
+        torch.cuda.synchronize()
+        # (the gradient norm is an atomic sum over blocks: its last bits, and with them the clip factor, depend on arrival order)
+        assert torch.allclose(stores[0].flat, stores[1].flat, rtol=1e-5, atol=1e-8)
+        assert torch.allclose(stores[0].shadow.float(), stores[1].shadow.float(), rtol=1e-2, atol=1e-6)
+        assert torch.equal(opts[0].lr_ss, opts[1].lr_ss) and int(opts[0].step_dev) == int(opts[1].step_dev) == step + 1
+        assert float(stores[1].grad.abs().max()) == 0.0 and float(stores[0].grad.abs().max()) > 0.0

@@ -613,8 +613,9 @@ extern "C" int magic_mse(int dtype, int g_f32, long long outer, long long inner,
 // Randomness: murmur3-finalised counters keyed by (base_seed, step counter): the counter lives in device memory and is advanced here, so
 // a replayed HIP graph draws fresh values every step; Box-Muller on two uniforms per normal.
 __device__ __forceinline__ unsigned mix32(unsigned x) { x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16; return x; }
-__global__ void step_rng_kernel(unsigned base_lo, unsigned base_hi, unsigned* counter, float rw_temp, int* seed_out, float* rw_out) {
+__global__ void step_rng_kernel(unsigned base_lo, unsigned base_hi, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, float* zero_me) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (zero_me) zero_me[0] = 0.f;               // the gradient-norm accumulator of the step that starts here
   const unsigned c = counter[0];
   counter[0] = c + 1u;
   auto draw = [&](unsigned k) { return mix32(mix32(base_lo ^ (c * 0x9E3779B1u)) + base_hi + k * 0x85EBCA77u); };
@@ -632,9 +633,9 @@ __global__ void step_rng_kernel(unsigned base_lo, unsigned base_hi, unsigned* co
     for (int i = 0; i < 5; ++i) rw_out[i] = 5.0f * z[i] / s;
   }
 }
-extern "C" int magic_step_rng(unsigned long long base_seed, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, void* stream) {
+extern "C" int magic_step_rng(unsigned long long base_seed, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, float* zero_me, void* stream) {
   if (!counter || rw_temp <= 0.f || (!seed_out && !rw_out)) return MAGIC_ERR_ARG;
-  hipLaunchKernelGGL(step_rng_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)base_seed, (unsigned)(base_seed >> 32), counter, rw_temp, seed_out, rw_out);
+  hipLaunchKernelGGL(step_rng_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)base_seed, (unsigned)(base_seed >> 32), counter, rw_temp, seed_out, rw_out, zero_me);
   return launch_status();
 }
 

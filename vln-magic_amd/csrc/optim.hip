@@ -7,8 +7,20 @@
 
 // sum of squares -> out[0] (atomic, block-reduced); 16-byte loads, four in flight per lane.  1024-thread blocks, at most one per CU:
 // every block ends in an atomic on the SAME address and those serialise in L2 (~20 ns each: 512 blocks spent 10 of 19 us there)
-__global__ __launch_bounds__(1024) void sumsq_kernel(long long n, const float* __restrict__ g, float* out) {
+struct SchedArgs { int* step; float lr0; int warmup, total; float b1, b2; float* lr_ss; };      // step == nullptr: no schedule work
+__device__ __forceinline__ void sched_advance(const SchedArgs& a) {
+  const int gs = a.step[0];          // global_step before this optimizer step
+  const int t = gs + 1;
+  a.step[0] = t;
+  double f = gs < a.warmup ? (double)gs / (double)a.warmup : fmax(0.0, (double)(a.total - gs) / (double)(a.total - a.warmup));
+  double lr = (double)a.lr0 * f;
+  if (lr <= 0.0) lr = 1e-8;
+  const double ss = lr * sqrt(1.0 - pow((double)a.b2, (double)t)) / (1.0 - pow((double)a.b1, (double)t));
+  a.lr_ss[0] = (float)lr; a.lr_ss[1] = (float)ss;
+}
+__global__ __launch_bounds__(1024) void sumsq_kernel(long long n, const float* __restrict__ g, float* out, SchedArgs sa) {
   __shared__ float red[16];
+  if (sa.step && blockIdx.x == 0 && threadIdx.x == 0) sched_advance(sa);      // the optimizer's schedule rides along (nothing here reads it)
   float s = 0.f;
   const long long n4 = n >> 2, stride = (long long)gridDim.x * 1024;
   for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n4; i += 4 * stride) {
@@ -34,9 +46,9 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(long long n, const float* _
 // and the gradient pre-scale `gscale` (e.g. 1/world_size after a sum all-reduce).  Optionally refreshes
 // the bf16 shadow copy used by the MFMA kernels.
 template <typename Hh>
-__global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, const float* g, float* m, float* v, Hh* shadow,
+__global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, float* g, float* m, float* v, Hh* shadow,
                                                     float lr, float b1, float b2, float eps, float wd, float step_size,
-                                                    const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay) {
+                                                    const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_g) {
   if (lr_ss) { lr = lr_ss[0]; step_size = lr_ss[1]; }     // device-side schedule (HIP-graph replay)
   float clip = gscale;
   if (sumsq && max_norm > 0.f) {
@@ -51,6 +63,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, const
     if (wd > 0.f && i < n_decay) pi -= lr * wd * pi;        // [0, n_decay): the decayed group (optim/misc.py:13-22), the rest: biases / LayerNorm
     m[i] = mi; v[i] = vi; p[i] = pi;
     if (shadow) shadow[i] = (Hh)pi;
+    if (zero_g) g[i] = 0.f;             // the next step's accumulators start from zero: saves its 40 MB fill launch
   }
 }
 
@@ -112,21 +125,29 @@ static inline int nblocks(long long n, int per) {
 extern "C" int magic_sumsq(long long n, const float* g, float* out, void* stream) {
   if (n <= 0 || ((uintptr_t)g & 15)) return MAGIC_ERR_ARG;
   const int nb = nblocks(n, 4096);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nb > 256 ? 256 : nb), dim3(1024), 0, (hipStream_t)stream, n, g, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb > 256 ? 256 : nb), dim3(1024), 0, (hipStream_t)stream, n, g, out, SchedArgs{});
+  return launch_status();
+}
+// the same launch also advances the device-side schedule (magic_sched_step's arithmetic; `out` must have been zeroed earlier in the step)
+extern "C" int magic_sumsq_sched(long long n, const float* g, float* out, int* step, float lr0, int warmup, int total, float b1, float b2,
+                                 float* lr_ss, void* stream) {
+  if (n <= 0 || ((uintptr_t)g & 15) || !step || !lr_ss || warmup <= 0 || total <= warmup) return MAGIC_ERR_ARG;
+  const int nb = nblocks(n, 4096);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb > 256 ? 256 : nb), dim3(1024), 0, (hipStream_t)stream, n, g, out, SchedArgs{step, lr0, warmup, total, b1, b2, lr_ss});
   return launch_status();
 }
 
-extern "C" int magic_adamw(long long n, float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype,
+extern "C" int magic_adamw(long long n, float* p, float* g, float* m, float* v, void* shadow, int shadow_dtype,
                            float lr, float b1, float b2, float eps, float wd, float step_size,
-                           const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, void* stream) {
+                           const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_grad, void* stream) {
   if (n <= 0 || (shadow && !dtype_is16(shadow_dtype))) return MAGIC_ERR_ARG;
   if (n_decay < 0) n_decay = n;                    // the whole range is one group
   if (shadow && shadow_dtype == DT_F16)
     hipLaunchKernelGGL(adamw_kernel<f16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (f16*)shadow, lr, b1, b2, eps, wd,
-                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay);
+                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad);
   else
     hipLaunchKernelGGL(adamw_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (bf16*)shadow, lr, b1, b2, eps, wd,
-                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay);
+                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad);
   return launch_status();
 }
 
@@ -212,14 +233,7 @@ extern "C" int magic_dact(int dtype, int kind, long long n, const void* dy, cons
 __global__ void sched_step_kernel(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, float* zero_me) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (zero_me) zero_me[0] = 0.f;   // the gradient-norm accumulator of the step that starts here (saves a fill launch)
-  const int gs = step[0];          // global_step before this optimizer step
-  const int t = gs + 1;
-  step[0] = t;
-  double f = gs < warmup ? (double)gs / (double)warmup : fmax(0.0, (double)(total - gs) / (double)(total - warmup));
-  double lr = (double)lr0 * f;
-  if (lr <= 0.0) lr = 1e-8;
-  const double ss = lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
-  lr_ss[0] = (float)lr; lr_ss[1] = (float)ss;
+  sched_advance(SchedArgs{step, lr0, warmup, total, b1, b2, lr_ss});
 }
 
 extern "C" int magic_sched_step(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, float* zero_me, void* stream) {

@@ -124,7 +124,7 @@ class StreamStep:
         with tr._graph_ctx(e.gS):
             drawn = tr.mkrw()                       # (also refreshes the dropout seed: one launch)
             rw = self.rw if self.rw is not None else drawn
-            tr.student.store.zero_grad()
+            tr._zero_grad()
             e.out = tr.student(e.batch, task, compute_loss=True, teacher_outputs=e.t_out, rw=rw, plan=e.plan, inputs=e.t_out["inputs"])
             tr.student.backward()
             tr._optimize()

@@ -48,26 +48,32 @@ class FusedAdamW:
             self.step_dev = torch.zeros(1, dtype=torch.int32, device=store.device)
             self.lr_ss = torch.zeros(2, dtype=torch.float32, device=store.device)
 
-    def step(self, lr=None, gscale=1.0):
+    def step(self, lr=None, gscale=1.0, ss_zeroed=False, zero_grad=False):
+        """ss_zeroed: the gradient-norm accumulator was zeroed earlier in this step (PretrainStep's prologue launch) -- the schedule then
+        rides in the sum-of-squares launch; zero_grad: the AdamW kernel zeroes the gradient buffer after consuming it"""
         s = self.store
         lr = self.lr if lr is None else lr
         self.t += 1
         b1, b2 = self.betas
         lr_ss = None
         use_clip = self.max_norm is not None and self.max_norm > 0
-        if self.schedule is not None:          # (the schedule kernel also zeroes the gradient-norm accumulator of this step)
+        fused_sched = self.schedule is not None and use_clip and ss_zeroed
+        if fused_sched:                        # schedule + gradient norm: one launch
+            O.sumsq_sched(s.grad, self.ss, self.step_dev, self.lr, self.schedule[0], self.schedule[1], b1, b2, self.lr_ss)
+            lr_ss, step_size = self.lr_ss, 0.0
+        elif self.schedule is not None:        # (the schedule kernel also zeroes the gradient-norm accumulator of this step)
             O.sched_step(self.step_dev, self.lr, self.schedule[0], self.schedule[1], b1, b2, self.lr_ss, zero_me=self.ss if use_clip else None)
             lr_ss, step_size = self.lr_ss, 0.0
         else:
             step_size = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
             if use_clip:
                 self.ss.zero_()
-        if use_clip:
+        if use_clip and not fused_sched:
             O.sumsq(s.grad, self.ss)
         shadow = s.shadow if s.half else None
         # both parameter groups (decay | no decay: contiguous in the flat buffer) in ONE launch
         O.adamw(s.total, s.flat, s.grad, s.m, s.v, shadow, lr, b1, b2, self.eps, self.wd, step_size, self.ss if use_clip else None,
-                self.max_norm if use_clip else 0.0, gscale, lr_ss=lr_ss, n_decay=s.n_decay)
+                self.max_norm if use_clip else 0.0, gscale, lr_ss=lr_ss, n_decay=s.n_decay, zero_grad=zero_grad)
         s.shadow_clean = True
         if shadow is not None and s.t_spans:           # the AdamW kernel rewrote the bf16 shadow: its transposed copy follows
             s.sync_shadow_t(force=True)
@@ -261,6 +267,8 @@ class PretrainStep:
             self._rw = torch.ones(5, dtype=torch.float32, device=self.dev)
             self._dseed = torch.zeros(2, dtype=torch.int32, device=self.dev)
             student.dropout_seed = self._dseed
+        self._ss_zeroed = False     # the prologue launch of the running step zeroed the optimizer's gradient-norm accumulator
+        self._grad_clean = False    # the previous step's AdamW launch left the gradient buffer zeroed (no fill launch needed)
 
     def _graph_ctx(self, g):
         # relaxed: helper threads launch into the capture (lib.lockstep).  Stream priorities were tried and rejected: a
@@ -272,8 +280,17 @@ class PretrainStep:
         device by one launch, so a replayed graph sees fresh values every step.  Returns the weights (a fixed device buffer)."""
         if not self.on_gpu:
             return torch.softmax(torch.randn(5, dtype=torch.float32) / self.rw_temp, dim=-1) * 5
-        O.step_rng(self.seed, self._rng_counter, self.rw_temp, seed_out=self._dseed, rw_out=self._rw)
+        O.step_rng(self.seed, self._rng_counter, self.rw_temp, seed_out=self._dseed, rw_out=self._rw, zero_me=self.opt.ss)
+        self._ss_zeroed = True
         return self._rw
+
+    def _zero_grad(self):
+        """gradient accumulators of the step that begins: already zero when the previous step of THIS trainer ended in its AdamW launch
+        (which zeroes what it consumed); anything else that wrote gradients in between must call store.zero_grad() itself"""
+        if self._grad_clean:
+            self._grad_clean = False
+            return
+        self.student.store.zero_grad()
 
     # ---- gradient exchange from inside the backward ---------------------------------------------------------------------
     def _touched_rows(self, task, plan):
@@ -311,7 +328,7 @@ class PretrainStep:
         drawn = self.mkrw()
         if rw is None and te is not None:
             rw = drawn
-        st.store.zero_grad()
+        self._zero_grad()
         out = st(batch, task, compute_loss=True, teacher_outputs=t_out, rw=rw, plan=plan, inputs=inputs)
         hook = self._bucket_hook(task, plan) if not torch.cuda.is_current_stream_capturing() else None
         st.backward(on_bucket=hook)
@@ -341,7 +358,7 @@ class PretrainStep:
         drawn = self.mkrw()
         if rw is None:
             rw = drawn
-        st.store.zero_grad()
+        self._zero_grad()
         out = st(batch, task, compute_loss=True, teacher_outputs=t_cur, rw=rw, plan=plan, inputs=t_cur["inputs"])
         hook = self._bucket_hook(task, plan) if not torch.cuda.is_current_stream_capturing() else None
         st.backward(on_bucket=hook)
@@ -388,7 +405,7 @@ class PretrainStep:
         with self._graph_ctx(gS):
             drawn = self.mkrw()
             rw_ = drawn if rw is None else rw
-            self.student.store.zero_grad()
+            self._zero_grad()
             out = self.student(batch, task, compute_loss=True, teacher_outputs=t_cur, rw=rw_, plan=plan, inputs=t_cur["inputs"])
             if two:
                 # data parallel: the student's step is TWO graphs cut where gradient bucket 0 (heads + cross-modal encoders) is
@@ -443,7 +460,9 @@ class PretrainStep:
             self._exchanged = False
         else:
             gscale = self.sync.all_reduce()
-        self.opt.step(gscale=gscale / float(getattr(self.student, "grad_scale", 1.0)))      # fp16: the buffer holds grad_scale x the gradient
+        self.opt.step(gscale=gscale / float(getattr(self.student, "grad_scale", 1.0)),       # fp16: the buffer holds grad_scale x the gradient
+                      ss_zeroed=self._ss_zeroed, zero_grad=True)
+        self._ss_zeroed, self._grad_clean = False, True
 
     def step(self, batch, task, rw=None, plan=None):
         plan = plan if plan is not None else build_plan(batch, task, self.dev)

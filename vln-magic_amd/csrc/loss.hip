@@ -363,9 +363,11 @@ __global__ __launch_bounds__(MSE_NT) void mse_multi_kernel(MseMulti mm) {
   while (i + 1 < mm.n && (int)blockIdx.x >= mm.start[i + 1]) ++i;
   const magic_mse_desc& p = mm.d[i];
   const int bid = blockIdx.x - mm.start[i], nblk = mm.start[i + 1] - mm.start[i];
+  // g_f32 bit 0: the gradient is fp32; bit 1: this problem's INPUTS are fp32 as well (the head-mean attention maps) inside a 16-bit launch
   if constexpr (sizeof(T) == 4) mse_body<float, float>(p, bid, nblk, red);
-  else if (mm.vec[i]) { if (p.g_f32) mse_body_v8<T, float>(p, bid, nblk, red); else mse_body_v8<T, T>(p, bid, nblk, red); }
-  else { if (p.g_f32) mse_body<T, float>(p, bid, nblk, red); else mse_body<T, T>(p, bid, nblk, red); }
+  else if (p.g_f32 & 2) mse_body<float, float>(p, bid, nblk, red);
+  else if (mm.vec[i]) { if (p.g_f32 & 1) mse_body_v8<T, float>(p, bid, nblk, red); else mse_body_v8<T, T>(p, bid, nblk, red); }
+  else { if (p.g_f32 & 1) mse_body<T, float>(p, bid, nblk, red); else mse_body<T, T>(p, bid, nblk, red); }
 }
 
 // Every block ends in ONE atomic on its problem's loss slot, and the slots of a step's terms share a cache line: same-line atomics
@@ -383,7 +385,7 @@ extern "C" int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* 
     mm.d[i] = d[i];
     const long long tot = d[i].outer * d[i].inner;
     const magic_mse_desc& q = d[i];
-    const bool vec = dtype_is16(dtype) && tot < 0x7FFFFFFFll && q.inner % 8 == 0 && q.s_stride % 8 == 0 && q.t_stride % 8 == 0 &&
+    const bool vec = dtype_is16(dtype) && !(q.g_f32 & 2) && tot < 0x7FFFFFFFll && q.inner % 8 == 0 && q.s_stride % 8 == 0 && q.t_stride % 8 == 0 &&
                      !((uintptr_t)q.s & 15) && !((uintptr_t)q.t & 15) && (!q.ds || (q.g_stride % 8 == 0 && !((uintptr_t)q.ds & 15))) && q.valid_mod % 8 == 0;
     mm.vec[i] = vec ? 1 : 0;
     work[i] = vec ? (tot + 7) / 8 : tot;          // lane-iterations

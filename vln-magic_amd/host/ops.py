@@ -524,22 +524,19 @@ def mse(s, t, outer, inner, s_stride, t_stride, *, w=None, rows_per_w=1, norm=1.
 def mse_multi(problems):
     """problems: list of dicts with the keyword arguments of mse() (s, t, outer, inner, s_stride, t_stride, w, rows_per_w, norm,
     coef, coef_dev, loss, ds, g_stride, accumulate) -- all of one compute dtype; one launch for up to 10 of them."""
-    kinds = {}
-    for q in problems:                                  # one launch per input dtype (panorama attention maps are fp32 head means)
-        kinds.setdefault(q["s"].dtype, []).append(q)
-    if len(kinds) > 1:
-        for qs in kinds.values():
-            mse_multi(qs)
-        return
+    # one launch for all terms: fp32 inputs (the head-mean panorama attention maps) ride inside the 16-bit launch (descriptor flag bit 1)
+    half = [q["s"].dtype for q in problems if q["s"].dtype != torch.float32]
+    dt0 = half[0] if half else torch.float32
     i = 0
     while i < len(problems):
         chunk = problems[i:i + 10]
         arr = (L.MseDesc * len(chunk))()
-        dt0 = chunk[0]["s"].dtype
         for j, q in enumerate(chunk):
             s_, t_, ds = q["s"], q["t"], q.get("ds")
-            _chk(s_.dtype == t_.dtype == dt0, "mse_multi dtypes")
-            g_f32 = 1 if (s_.dtype == torch.float32 or (ds is not None and ds.dtype == torch.float32)) else 0
+            in32 = s_.dtype == torch.float32
+            _chk(s_.dtype == t_.dtype and (in32 or s_.dtype == dt0), "mse_multi dtypes")
+            _chk(not in32 or ds is None or ds.dtype == torch.float32, "mse_multi: fp32 inputs take an fp32 gradient")
+            g_f32 = (3 if dt0 != torch.float32 else 1) if in32 else (1 if (ds is not None and ds.dtype == torch.float32) else 0)
             arr[j] = L.MseDesc(g_f32, q["outer"], q["inner"], L.P(s_), q["s_stride"], L.P(t_), q["t_stride"], L.P(q.get("w")),
                                q.get("rows_per_w", 1), float(q.get("norm", 1.0)), float(q.get("coef", 0.0)), L.P(q.get("coef_dev")),
                                L.P(q.get("loss")), L.P(ds), q.get("g_stride", 0), 1 if q.get("accumulate") else 0,

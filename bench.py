@@ -290,6 +290,7 @@ def instrumented_pass(trainer, pool, nprof, gate_ms):
     and a device-side gate in front of every step so the host runs ahead of the GPU.  Returns {family: (ms, launches)}."""
     import magic_amd.host.model_pretrain as MP
     O.FLOPS.update(total=0.0, gemm=0.0, linear_ln=0.0, attn=0.0, enc=0.0, enabled=True)
+    O.BYTES.update(dw=0.0, dw_launches=0)
     L.PROFILE.update(on=True, events=[])
     MP.LOCKSTEP_EAGER = True
     side, trainer.side = trainer.side, None
@@ -568,6 +569,12 @@ def main():
                            "whole_step": {"summed_kernel_ms_per_step_serialised": round(all_ms / nprof, 3), "graph_replay_wall_ms_per_step": round(step_ms, 3),
                                           "frac_of_mfma_peak_on_wall": round(O.FLOPS["total"] / nprof / (step_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 5)},
                            "launches_per_step": sum(c for t, c in by.values()) // nprof,
+                           "weight_gradient_launch": {
+                               "kernel": "gemm_dw_batch_kernel (all deferred dW = dY^T X problems of a step in one launch)",
+                               "algorithmic_bytes_per_launch": round(O.BYTES["dw"] / max(O.BYTES["dw_launches"], 1)),
+                               "avg_us": round(by.get("magic_gemm_dw_grouped", (0.0, 1))[0] / max(by.get("magic_gemm_dw_grouped", (0.0, 1))[1], 1) * 1e3, 1),
+                               "algorithmic_GB_per_s": round(O.BYTES["dw"] / max(by.get("magic_gemm_dw_grouped", (1e-9, 1))[0], 1e-9) / 1e6, 1),
+                               "pmc_fetched_bytes_per_launch_r02": 500e6, "peak_GB_per_s": 8000.0},
                            "top_kernels_share": {k: round(t / all_ms, 4) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]},
                            "kernels_launches_per_step_and_avg_us": {k: [round(c / nprof, 1), round(t / c * 1e3, 1)]
                                                                     for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])}}}

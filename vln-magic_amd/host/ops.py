@@ -14,6 +14,9 @@ from . import lib as L
 # algorithmic FLOPs of the dense contractions, per kernel family ("gemm": magic_gemm / magic_gemm_dw_grouped; "linear_ln": the fused
 # dense+LayerNorm kernels; "attn": the fused attention kernels) and in total
 FLOPS = {"total": 0.0, "gemm": 0.0, "linear_ln": 0.0, "attn": 0.0, "enc": 0.0, "enabled": False}
+# algorithmic bytes of the weight-gradient launch(es): every dY and X element read once + the fp32 dW written once (bench.py prints it next
+# to the PMC traffic so the re-read factor can be checked from the JSON line)
+BYTES = {"dw": 0.0, "dw_launches": 0}
 
 
 def _count(m, n, k, batch=1, fam="gemm"):
@@ -151,6 +154,10 @@ def flush_dw(group=None, keep_active=False):
             arr = (L.DwDesc * len(chunk))()
             for j, (dy, x, dW, db, M, N, K, lda, ldb, ldc, sk) in enumerate(chunk):
                 arr[j] = L.DwDesc(L.P(dy), L.P(x), L.P(dW), L.P(db), M, N, K, lda, ldb, ldc, sk)
+                if FLOPS["enabled"]:
+                    BYTES["dw"] += float(M) * (N + K) * dy.element_size() + 4.0 * N * K
+            if FLOPS["enabled"]:
+                BYTES["dw_launches"] += 1
             L.call("magic_gemm_dw_grouped", L.dt(dt), len(chunk), arr, L.stream())
     q.clear()
     DEFER["bytes"] = 0

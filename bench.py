@@ -225,7 +225,8 @@ def build_models(dtype, dev, dropout, world, batch=48):
         dist.broadcast(teacher.store.flat, src=0)
     trainer = PretrainStep(student, teacher, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0,
                            warmup_steps=10000, num_train_steps=200000, rw_temp=4.0,
-                           sparse_embedding_rows=batch * MAX_TOKENS)      # <= B x 80 distinct token ids per rank and step (north star: <= 80 tokens)
+                           sparse_embedding_rows=batch * MAX_TOKENS,      # <= B x 80 distinct token ids per rank and step (north star: <= 80 tokens)
+                           seed=1234 + (dist.get_rank() if world > 1 else 0))   # per-rank MKRW draws / dropout masks (train_r2r_magic.py:86-89)
     return tcfg, scfg, teacher, student, trainer
 
 

@@ -72,14 +72,23 @@ def _worker(rank, world, port, q):
             mono = st2.grad.clone()
             dist.all_reduce(mono)
             sy = GradSync(st2, chunk_elems=4099, overlap=True, sparse_rows_cap=40 if sparse else None)
-            b0, b1 = sy.buckets
-            covered = sorted(b0 + b1)
+            b0, b1, b2 = sy.buckets         # heads + cross-modal | top text blocks + panorama blocks (cut two rounds into that half) | the rest
+            covered = sorted(b0 + b1 + b2)
             ok_bucket = ok_bucket and covered[0][0] == 0 and covered[-1][1] == st2.total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
             ok_bucket = ok_bucket and b0[0][0] == st2.offsets["bert.global_encoder.gmap_pos_embeddings.0.weight"][0]
+            # the middle bucket holds exactly the last text block and the last panorama block of this 1 + 1-layer model, in both decay groups
+            inb = lambda name, bk: any(lo <= st2.offsets[name][0] and st2.offsets[name][0] + st2.offsets[name][1] <= hi for lo, hi in bk)
+            ok_bucket = ok_bucket and all(inb(n_, b1) == (n_.startswith("bert.lang_encoder.layer.0.") or n_.startswith("bert.img_embeddings.pano_encoder.layer.0."))
+                                          for n_ in st2.offsets)
+            ok_bucket = ok_bucket and inb(EMB_TABLE, b2) and inb("bert.img_embeddings.img_linear.weight", b2)
             sy.reduce_bucket(0)
             first = st2.grad.clone()
-            sy.reduce_bucket(1, touched if sparse else None)
+            sy.reduce_bucket(1)
+            second = st2.grad.clone()
+            sy.reduce_bucket(2, touched if sparse else None)
             sy.finish()
+            for lo, hi in b1:                                   # the middle bucket was final after its own call
+                ok_bucket = ok_bucket and bool(torch.allclose(second[lo:hi], mono[lo:hi], rtol=1e-6, atol=1e-6))
             ok_bucket = ok_bucket and bool(torch.allclose(st2.grad, mono, rtol=1e-6, atol=1e-6))
             lo, hi = b0[0]
             ok_bucket = ok_bucket and bool(torch.allclose(first[lo:hi], mono[lo:hi], rtol=1e-6, atol=1e-6))     # bucket 0 was final after its own call
@@ -94,7 +103,8 @@ def _worker(rank, world, port, q):
         dist.all_reduce(mono)
         sy = GradSync(st3, chunk_elems=4099, overlap=True, sparse_rows_cap=40)
         sy.reduce_bucket(0)
-        sy.reduce_bucket(1, torch.zeros(0, dtype=torch.int64))
+        sy.reduce_bucket(1)
+        sy.reduce_bucket(2, torch.zeros(0, dtype=torch.int64))
         sy.finish()
         ok_bucket = ok_bucket and bool(torch.allclose(st3.grad, mono, rtol=1e-6, atol=1e-6))
         ok_mean = ok_mean and ok_bucket

@@ -518,14 +518,16 @@ class MagicNet:
     def rbw_ok(self):
         return self.train and O.rowbwd_ok(self.dtype, self.H, self.I)
 
-    def self_stacks_bwd(self, stacks):
+    def self_stacks_bwd(self, stacks, on_iter=None):
         """stacks: 1 or 2 tuples (ctx with .layers, layer-prefix format, d_top = plain gradient wrt the stack's output, dP_init for
         the top block's attention map).  Two launches per block and stack pair -- the per-token chain (magic_rowbwd: tail of the
         block above + FFN + both LayerNorm backwards + output projection) and the attention backward -- instead of five; the two
         stacks advance together from their tops (text 6 blocks, panorama 2) in shared launches.  Returns the gradients wrt the
-        stacks' inputs."""
+        stacks' inputs.  on_iter(k): called after the k-th round (k = 1, 2, ...: the top k blocks of every stack are done and their
+        weight gradients queued) -- the data-parallel exchange cuts its buckets there (trainer.GradSync)."""
         from . import lib as L
         H, I = self.H, self.I
+        rounds = 0
         st = []
         for c, fmt, d_top, dP in stacks:
             lc = c.layers[-1]
@@ -585,14 +587,17 @@ class MagicNet:
                     s.dx0 = O.linear_dx(out.dqkv, ql.W, M, residual=out.dao, flop_rows=sa.rows)
                 else:
                     s.j -= 1
+            rounds += 1
+            if on_iter is not None:
+                on_iter(rounds)
         return [s.dx0 for s in st]
 
-    def encoders_bwd(self, ct, cp, plan, d_txt, dP_txt, d_pano, d_fused, dP_pano):
+    def encoders_bwd(self, ct, cp, plan, d_txt, dP_txt, d_pano, d_fused, dP_pano, on_iter=None):
         """text + panorama encoders' backward together: the two stacks on the row-block kernel, then the embedding backwards"""
         self._pano_head_bwd(cp, d_pano, d_fused)
         p = self.p
         dt, dp = self.self_stacks_bwd([(ct, p + "lang_encoder.layer.{}.", d_txt, dP_txt),
-                                       (cp, p + "img_embeddings.pano_encoder.layer.{}.", d_pano, dP_pano)])
+                                       (cp, p + "img_embeddings.pano_encoder.layer.{}.", d_pano, dP_pano)], on_iter=on_iter)
         self._text_emb_bwd(ct, plan, dt)
         self._pano_emb_bwd(cp, plan, dp)
 

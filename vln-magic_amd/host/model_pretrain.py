@@ -20,6 +20,7 @@ from .engine import Ctx, MagicNet, cls_specs, rup, trunk_specs
 from .params import ParamStore
 from .plan import build_plan, check_plan
 
+MID_CUT = 2          # rounds of the shared text / panorama backward after which the data-parallel exchange cuts its middle bucket
 LOCKSTEP = not os.environ.get("MAGIC_NO_LOCKSTEP")
 LOCKSTEP_EAGER = bool(os.environ.get("MAGIC_LOCKSTEP_EAGER"))
 DYN_TERMS = ("txt_emb", "txt_attn", "img_emb", "img_fused", "img_attn", "g_emb", "g_attn", "l_emb", "l_attn")      # plan["dyn"] slots
@@ -566,9 +567,15 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             O.flush_dw(keep_active=True)
             O.join_side()
             on_bucket(0, c)
-        self.backward_phase2()
-        if on_bucket is not None:
-            on_bucket(1, c)
+
+            def cut():                      # the top MID_CUT blocks of the text / panorama stacks are done: their slice is final once flushed
+                O.flush_dw(keep_active=True)
+                O.join_side()
+                on_bucket(1, c)
+            self.backward_phase2(on_cut=cut)
+            on_bucket(2, c)
+        else:
+            self.backward_phase2()
 
     @torch.no_grad()
     def backward_phase1(self):
@@ -677,13 +684,27 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             n.gmap_in_bwd(c.gin, plan, d_gin, c.d_pano, c.d_fused)
 
     @torch.no_grad()
-    def backward_phase2(self):
+    def backward_phase2(self, on_cut=None):
         """text / panorama encoders + embeddings (the caller flushes phase 1's queued weight-gradient GEMMs first when bucket 0 of the
-        exchange must be final before this phase starts)"""
+        exchange must be final before this phase starts).  on_cut(): called once, when the top MID_CUT blocks of both stacks are done
+        (trainer.GradSync's middle bucket: text layers [nl - MID_CUT, nl) + the panorama layers); on paths without the shared row-block
+        backward it is called right before the end -- the middle bucket is then simply not early."""
         c = self._ctx
         n, plan = self.net, c.plan
+        fired = []
+
+        def on_iter(k):
+            if on_cut is not None and k == MID_CUT and not fired:
+                fired.append(k)
+                on_cut()
         if n.rbw_ok() and n.enc_ok(plan["L"], self.config.num_l_layers) and n.enc_ok(plan["V"], self.config.num_pano_layers):
-            n.encoders_bwd(c.txt, c.pano, plan, c.d_txt, c.dP_txt, c.d_pano, c.d_fused, c.dP_pano)      # both stacks in shared launches
+            n.encoders_bwd(c.txt, c.pano, plan, c.d_txt, c.dP_txt, c.d_pano, c.d_fused, c.dP_pano, on_iter=on_iter)      # both stacks in shared launches
+            if on_cut is not None and not fired:
+                on_cut()
+        elif on_cut is not None:
+            self._par(lambda: n.text_bwd(c.txt, plan, c.d_txt, c.dP_txt),
+                      lambda: n.pano_bwd(c.pano, plan, c.d_pano, c.d_fused, c.dP_pano))
+            on_cut()
         else:
             self._par(lambda: n.text_bwd(c.txt, plan, c.d_txt, c.dP_txt),
                       lambda: n.pano_bwd(c.pano, plan, c.d_pano, c.d_fused, c.dP_pano))

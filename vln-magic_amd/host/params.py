@@ -164,6 +164,23 @@ class ParamStore:
                 return self.offsets[name][0]
         return self.n_decay if decay else self.total
 
+    def ranges_of(self, prefixes):
+        """sorted, merged [lo, hi) element ranges of the flat buffers covering every tensor whose name starts with one of `prefixes`
+        (alignment gaps between neighbouring matches are absorbed; a range never spans the weight-decay | no-decay boundary)"""
+        hit = sorted((self.offsets[n][0], self.offsets[n][0] + self.offsets[n][1]) for n, _, _ in self.order if n.startswith(tuple(prefixes)))
+        nxt = {}                      # end of a tensor's padded slot = start of the next tensor in storage order (or the group's end)
+        starts = sorted(o for o, _, _ in self.offsets.values()) + [self.total]
+        for a, b in zip(starts[:-1], starts[1:]):
+            nxt[a] = b
+        out = []
+        for lo, hi in hit:
+            hi_pad = min(nxt[lo], self.n_decay) if lo < self.n_decay else nxt[lo]
+            if out and out[-1][1] == lo:
+                out[-1][1] = hi_pad
+            else:
+                out.append([lo, hi_pad])
+        return [(a, b) for a, b in out]
+
     def contiguous(self, names):
         """True if the tensors are laid out back to back (no alignment gap)."""
         for a, b in zip(names[:-1], names[1:]):

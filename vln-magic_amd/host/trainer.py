@@ -94,10 +94,12 @@ class GradSync:
 
     Buckets follow the ORDER IN WHICH THE EXPLICIT BACKWARD FINISHES GRADIENTS (what DDP's reverse-registration buckets
     approximate): bucket 0 = heads + both cross-modal encoders + distillation projections, final when the backward enters the
-    text / panorama encoders; bucket 1 = text + panorama encoders + embeddings, final at the end.  `reduce_bucket(0)` is issued
-    from inside the backward (model.backward(on_bucket=...)) and runs on the side stream under the rest of the backward pass.
+    text / panorama encoders; bucket 1 = the top two text blocks + the panorama blocks, final two rounds into that half (their
+    weight-gradient GEMMs are flushed there: model_pretrain.MID_CUT); bucket 2 = the lower text blocks + all embeddings, final at
+    the end.  `reduce_bucket(0)` and `reduce_bucket(1)` are issued from inside the backward (model.backward(on_bucket=...)) and run on
+    the side stream under the rest of the backward pass; only bucket 2 is exposed.
     On steps that only read the word-embedding table through the instruction tokens (sap / cfp / mrc: <= B*L of its 50 265 rows
-    carry gradient, 65 % of all gradient bytes otherwise) bucket 1 exchanges those ROWS (all-gather of row ids + rows, local
+    carry gradient, 65 % of all gradient bytes otherwise) the last bucket exchanges those ROWS (all-gather of row ids + rows, local
     scatter-add) instead of the dense table."""
 
     def __init__(self, store, chunk_elems=8 << 20, overlap=None, sparse_rows_cap=None):
@@ -108,7 +110,13 @@ class GradSync:
         self.overlap = (not os.environ.get("MAGIC_DDP_NO_OVERLAP")) if overlap is None else overlap
         g0d, g0n = store.first_offset(LATE_PREFIXES, True), store.first_offset(LATE_PREFIXES, False)
         nd, tot = store.n_decay, store.total
-        self.buckets = [[(g0d, nd), (g0n, tot)], [(0, g0d), (nd, g0n)]]
+        first, rest = [(g0d, nd), (g0n, tot)], [(0, g0d), (nd, g0n)]
+        # the middle bucket: what the shared text / panorama backward has finished after its first MID_CUT rounds -- the top MID_CUT text
+        # blocks and the top MID_CUT panorama blocks (model_pretrain.backward_phase2's on_cut); the last bucket: the rest (lower text
+        # blocks, embeddings, image embeddings).  Stores without such blocks (the navigator's) keep two buckets + an empty middle one.
+        mid = store.ranges_of(mid_prefixes(store)) if mid_prefixes(store) else []
+        mid = [(max(a, lo), min(b, hi)) for a, b in mid for lo, hi in rest if max(a, lo) < min(b, hi)]
+        self.buckets = [first, mid, _subtract(rest, mid)]
         self.table = store.offsets.get(EMB_TABLE)            # (offset, numel, (rows, H)) -- first tensor of the buffer
         self.sparse_cap = sparse_rows_cap
         self._pending = []
@@ -158,13 +166,14 @@ class GradSync:
 
     # ---- per-bucket API (called from inside the backward) ----------------------------------------------------------
     def reduce_bucket(self, i, touched_rows=None):
-        """launch bucket i's exchange on the side stream.  touched_rows (bucket 1 only): device int64 ids of the word-embedding
+        """launch bucket i's exchange on the side stream.  touched_rows (last bucket only): device int64 ids of the word-embedding
         rows this rank's step wrote, or None for a dense table (mlm: the tied decoder touches every row)."""
         if self.world == 1:
             return
         ranges = self.buckets[i]
         # an EMPTY id list is not "no rows": bucket-padded plans carry a zero-length placeholder (host/plan.py) -> dense exchange
-        sparse = i == 1 and touched_rows is not None and touched_rows.numel() > 0 and self.table is not None and self.sparse_cap
+        last = len(self.buckets) - 1          # the word-embedding table lives in the last bucket
+        sparse = i == last and touched_rows is not None and touched_rows.numel() > 0 and self.table is not None and self.sparse_cap
         if sparse:
             off, n, _ = self.table
             assert off == 0 and ranges[0][0] == 0
@@ -188,6 +197,34 @@ class GradSync:
         """after the last reduce_bucket: make the main stream wait for the exchange; returns the 1/world factor"""
         self.join()
         return 1.0 / self.world if self.world > 1 else 1.0
+
+
+def mid_prefixes(store):
+    """name prefixes of the blocks that are final after MID_CUT rounds of engine.self_stacks_bwd (two stacks advancing from their tops)"""
+    from .model_pretrain import MID_CUT
+    out = []
+    for fmt in ("bert.lang_encoder.layer.{}.", "bert.img_embeddings.pano_encoder.layer.{}."):
+        n = 0
+        while any(k.startswith(fmt.format(n)) for k in store.offsets):
+            n += 1
+        out += [fmt.format(i) for i in range(max(0, n - MID_CUT), n)]
+    return out
+
+
+def _subtract(ranges, holes):
+    """ranges minus holes (both lists of disjoint [lo, hi)), sorted"""
+    out = []
+    for lo, hi in sorted(ranges):
+        cur = lo
+        for a, b in sorted(holes):
+            if b <= cur or a >= hi:
+                continue
+            if a > cur:
+                out.append((cur, a))
+            cur = max(cur, b)
+        if cur < hi:
+            out.append((cur, hi))
+    return out
 
 
 def auto_sync(model):
@@ -305,7 +342,7 @@ class PretrainStep:
         backward has finished that bucket's gradients (bucket 0 runs under the text / panorama backward)"""
         if self.sync.world == 1 or not self.sync.overlap:
             return None
-        return lambda i, ctx: self.sync.reduce_bucket(i, self._touched_rows(task, plan) if i == 1 else None)
+        return lambda i, ctx: self.sync.reduce_bucket(i, self._touched_rows(task, plan) if i == 2 else None)
 
     # ---- the pieces ------------------------------------------------------------------------------------
     def _fwd_bwd(self, batch, task, rw, plan):
@@ -417,10 +454,22 @@ class PretrainStep:
                 self.student.backward()
             if full:
                 self._optimize()
+        gS3 = None
         if two:
-            gS2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gS2, pool=gS.pool(), capture_error_mode="relaxed"):
-                self.student.backward_phase2()
+            # ... and the text / panorama half is cut once more where the middle bucket is final (two rounds in): graph 2 | graph 3
+            gS2, gS3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            state = {"ctx": torch.cuda.graph(gS2, pool=gS.pool(), capture_error_mode="relaxed")}
+            state["ctx"].__enter__()
+
+            def cut():
+                O.flush_dw(keep_active=True)
+                state["ctx"].__exit__(None, None, None)
+                state["ctx"] = torch.cuda.graph(gS3, pool=gS.pool(), capture_error_mode="relaxed")
+                state["ctx"].__enter__()
+            try:
+                self.student.backward_phase2(on_cut=cut)
+            finally:
+                state["ctx"].__exit__(None, None, None)
         gT = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gT, stream=self.side, capture_error_mode="relaxed"):
             t_next = self.teacher_forward(*nxt)
@@ -429,7 +478,12 @@ class PretrainStep:
                 t_next = t_next_into
         cs = CapturedStep(gS, out, plan["traj_steps"], full, keep=(cur, t_cur, nxt, rw))
         cs.t_graph, cs.t_next = gT, t_next
-        cs.graph2, cs.touched = gS2, self._touched_rows(task, plan)
+        cs.graph2, cs.graph3, cs.touched = gS2, gS3, self._touched_rows(task, plan)
+        cs.graph_opt = None
+        if two:            # the optimizer's launches as a graph of their own, replayed once the exchange has landed (1 / world is a constant)
+            cs.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cs.graph_opt, pool=gS.pool(), capture_error_mode="relaxed"):
+                self._opt_step(1.0 / self.sync.world if self.sync.world > 1 else 1.0)
         return cs
 
     def replay_split(self, cs):
@@ -441,16 +495,24 @@ class PretrainStep:
         self.side.wait_stream(main)
         cs.graph.replay()
         if getattr(cs, "graph2", None) is not None:
-            self.sync.reduce_bucket(0)                 # exchange stream: after graph 1, under graph 2
+            self.sync.reduce_bucket(0)                 # exchange stream: after graph 1, under graphs 2 and 3
             cs.graph2.replay()
-            self.sync.reduce_bucket(1, cs.touched)
+            self.sync.reduce_bucket(1)                 # after graph 2, under graph 3
+            cs.graph3.replay()
+            self.sync.reduce_bucket(2, cs.touched)
             self._exchanged = True
         with torch.cuda.stream(self.side):
             cs.t_graph.replay()
             self._t_done = torch.cuda.Event()
             self._t_done.record(self.side)
         if not cs.full:
-            self._optimize()
+            if getattr(cs, "graph_opt", None) is not None and self._exchanged:
+                self.sync.finish()
+                self._exchanged = False
+                cs.graph_opt.replay()
+                self.opt.t += 1
+            else:
+                self._optimize()
         self.global_step += 1
         return cs.out
 
@@ -460,6 +522,9 @@ class PretrainStep:
             self._exchanged = False
         else:
             gscale = self.sync.all_reduce()
+        self._opt_step(gscale)
+
+    def _opt_step(self, gscale):
         self.opt.step(gscale=gscale / float(getattr(self.student, "grad_scale", 1.0)),       # fp16: the buffer holds grad_scale x the gradient
                       ss_zeroed=self._ss_zeroed, zero_grad=True)
         self._ss_zeroed, self._grad_clean = False, True

@@ -249,3 +249,34 @@ def test_train_steps_follow_oracle_optimizer_fp32():
     got = g_s.state_dict()
     for n, p in o_s.named_parameters():
         close(got[n], p.data, f"param after 3 steps {n}", 2e-3, 2e-5)
+
+
+def test_gradient_accumulation_matches_oracle_on_the_mean_loss():
+    """accum_steps = 2 (gradient_accumulation_steps, parser.py:41-45; MetaLoader repeats the task, loader.py:50-59): two micro-batches, one
+    update with the MEAN gradient -- against the oracle stepping on (loss_1 + loss_2) / 2 with the same clip and AdamW."""
+    o_t, o_s, g_t, g_s = build(torch.float32)
+    trainer = PretrainStep(g_s, g_t, lr=1e-3, warmup_steps=2, num_train_steps=10, grad_norm=5.0, accum_steps=2)
+    from magic_amd.host.params import is_no_decay
+    wds = [0.0 if is_no_decay(n) else 0.01 for n, _ in o_s.named_parameters()]
+    state = optim_ref.adamw_init([p.data for p in o_s.parameters()])
+    for upd in range(2):
+        for p in o_s.parameters():
+            p.grad = None
+        for micro in range(2):
+            batch = synth.make_batch("sap", batch_size=4, seed=55, step=2 * upd + micro, vocab=600, min_len=8, max_len=15, min_steps=2, max_steps=3)
+            with torch.no_grad():
+                ot = o_t(batch, "sap", compute_loss=True)["outputs"]
+            w = o_s(batch, "sap", compute_loss=True, teacher_outputs=ot, rw=torch.tensor(RW))
+            (w["loss"] / 2).backward()                      # autograd accumulates over the two micro-batches
+            out = trainer.step(batch, "sap", rw=RW)
+            close(out["loss"], w["loss"], f"update {upd} micro {micro} loss", 2e-4, 1e-6)
+            assert trainer.global_step == upd + (1 if micro == 1 else 0)
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in o_s.parameters()]
+        optim_ref.clip_grad_norm(grads, 5.0)
+        lr = optim_ref.get_lr_sched(upd, 1e-3, 2, 10)
+        with torch.no_grad():
+            optim_ref.adamw_step([p.data for p in o_s.parameters()], grads, state, lr=lr, betas=(0.9, 0.98), eps=1e-6, weight_decay=wds)
+    torch.cuda.synchronize()
+    got = g_s.state_dict()
+    for n, p in o_s.named_parameters():
+        close(got[n], p.data, f"param after 2 accumulated updates {n}", 2e-3, 2e-5)

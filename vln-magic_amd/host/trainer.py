@@ -280,7 +280,7 @@ class CapturedStep:
 class PretrainStep:
     def __init__(self, student, teacher=None, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0,
                  warmup_steps=10000, num_train_steps=200000, rw_temp=4.0, seed=0, overlap_teacher=True, overlap_dw=True,
-                 sparse_embedding_rows=None):
+                 sparse_embedding_rows=None, accum_steps=1):
         """sparse_embedding_rows: an upper bound, THE SAME ON EVERY RANK, on the distinct token ids of one rank's batch (batch size x
         the loader's instruction truncation length, pretrain_src/config/r2r_magic_pretrain.json:7 max_txt_len).  When given, steps
         that touch the word-embedding table only through the instruction lookup exchange rows instead of the dense table."""
@@ -296,6 +296,13 @@ class PretrainStep:
         if self.on_gpu and overlap_dw and O.SIDE["stream"] is None and os.environ.get("MAGIC_DW_SIDE"):   # opt-in: no gain measured on MI355X
             O.SIDE["stream"] = torch.cuda.Stream()       # weight-gradient GEMMs leave the dX critical chain
         self.global_step = 0
+        # gradient accumulation (gradient_accumulation_steps, pretrain_src/parser.py:41-45; MetaLoader keeps one task for accum_steps
+        # consecutive batches, data/loader.py:50-59): `step()` runs forward + backward on every micro-batch, accumulating into the flat
+        # gradient buffer, and exchanges / clips / updates on the last one with the mean gradient (1 / accum_steps folded into the AdamW
+        # kernel's pre-scale, next to 1 / world); the data-parallel exchange is skipped on the other micro-batches, as DDP.no_sync() does
+        self.accum_steps = int(accum_steps)
+        assert self.accum_steps >= 1
+        self._micro = 0
         # per-step random scalars (MKRW weights, dropout seed) come from ONE launch (csrc/loss.hip step_rng_kernel) keyed by `seed` and a
         # device-side step counter: inside a captured graph every replay advances the counter and so draws fresh values
         self.seed = int(seed)
@@ -365,9 +372,11 @@ class PretrainStep:
         drawn = self.mkrw()
         if rw is None and te is not None:
             rw = drawn
-        self._zero_grad()
+        if self._micro == 0:
+            self._zero_grad()
         out = st(batch, task, compute_loss=True, teacher_outputs=t_out, rw=rw, plan=plan, inputs=inputs)
-        hook = self._bucket_hook(task, plan) if not torch.cuda.is_current_stream_capturing() else None
+        last_micro = self._micro == self.accum_steps - 1
+        hook = self._bucket_hook(task, plan) if (last_micro and not torch.cuda.is_current_stream_capturing()) else None
         st.backward(on_bucket=hook)
         self._exchanged = hook is not None
         return out
@@ -525,15 +534,22 @@ class PretrainStep:
         self._opt_step(gscale)
 
     def _opt_step(self, gscale):
-        self.opt.step(gscale=gscale / float(getattr(self.student, "grad_scale", 1.0)),       # fp16: the buffer holds grad_scale x the gradient
+        # fp16: the buffer holds grad_scale x the gradient; accumulation: the sum over accum_steps micro-batches
+        self.opt.step(gscale=gscale / (float(getattr(self.student, "grad_scale", 1.0)) * self.accum_steps),
                       ss_zeroed=self._ss_zeroed, zero_grad=True)
         self._ss_zeroed, self._grad_clean = False, True
 
     def step(self, batch, task, rw=None, plan=None):
+        """one micro-batch: forward + backward; on the last micro-batch of an accumulation window (every call when accum_steps == 1) also
+        the gradient exchange, clip and AdamW update.  Returns the model's outputs of this micro-batch."""
         plan = plan if plan is not None else build_plan(batch, task, self.dev)
         out = self._fwd_bwd(batch, task, rw, plan)
-        self._optimize()
-        self.global_step += 1
+        if self._micro == self.accum_steps - 1:
+            self._optimize()
+            self.global_step += 1
+            self._micro = 0
+        else:
+            self._micro += 1
         return out
 
     # ---- HIP-graph path --------------------------------------------------------------------------------
@@ -544,6 +560,8 @@ class PretrainStep:
         if off:
             raise ValueError(f"capture() needs the batch resident on {self.dev} (synth.batch_to); host tensors: {off[:4]}...")
         full = self.sync.world == 1 and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")   # (env: exercise the DP split on 1 GPU)
+        if self.accum_steps != 1:
+            raise NotImplementedError("captured steps run one optimizer step per replay: use step() with accum_steps > 1")
         g = torch.cuda.CUDAGraph()
         with self._graph_ctx(g):
             out = self._fwd_bwd(batch, task, rw, plan)

@@ -42,6 +42,35 @@ class _MSE(torch.autograd.Function):
         return (ctx.ds.float() * g).to(ctx.in_dtype), None, None, None
 
 
+class _CERows(torch.autograd.Function):
+    """`F.cross_entropy(logits, targets, ignore_index=..., reduction='none')` of the navigator's step loop (agent_base.py:152 criterion,
+    agent.py:1007-1021) as ONE launch: the row losses and the unit gradient softmax(logits) - onehot (zero on ignored rows) come out of the
+    same pass (csrc/loss.hip ce_rows_kernel); backward scales the saved gradient by the incoming row gradients."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        _need_cuda(logits, targets)
+        x = logits.detach().float().contiguous()          # action logits are fp32 (-inf on masked candidates)
+        M, N = x.shape
+        lab = targets if targets.dtype == torch.int32 else targets.to(torch.int32)
+        rows = torch.empty(M, dtype=torch.float32, device=x.device)
+        dl = torch.empty_like(x) if logits.requires_grad else None
+        O.ce_rows(x, M, N, N, lab, ignore_index=int(ignore_index), coef=1.0, loss_row=rows, dlogits=dl, ldd=N)
+        ctx.dl, ctx.in_dtype = dl, logits.dtype
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.dl is None:
+            return None, None, None
+        return (ctx.dl * g[:, None]).to(ctx.in_dtype), None, None
+
+
+def ce_rows_loss(logits, targets, ignore_index=-100):
+    """per-row cross entropy [M] of fp32 logits [M, N] against integer targets (ignored rows: 0 loss, 0 gradient)"""
+    return _CERows.apply(logits, targets, ignore_index)
+
+
 class _KD(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s, t, w, temperature, norm):

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from . import ops as O
 from .makd_nav import compute_kd_losses
 from .nav_plan import IGNORE, NavPlanner
-from .kd_loss import exponential_decay
+from .kd_loss import ce_rows_loss, exponential_decay
 
 
 def to_device(arrays, dev):
@@ -239,7 +239,7 @@ class NavRollout:
                 logits = outs["fused_logits"]
                 s_out.update(nav_outs=outs, nav_logits=logits)
                 targets = d["targets"]
-                ce = F.cross_entropy(logits, targets, ignore_index=IGNORE, reduction="none")
+                ce = ce_rows_loss(logits, targets, IGNORE)
                 ml_loss = ml_loss + (ce * w_ml).sum()
                 stop_probs.append(torch.softmax(logits.detach(), 1)[:, 0])
                 if te is not None:
@@ -251,7 +251,7 @@ class NavRollout:
                         t_outs = te("navigation", self._nav_inputs(d, plan, tg, t_txt, txt_masks, txt_lens, t_kv))
                         t_log.put(plan["log_cls"], t_outs["cls_embeds"], track=tt_grad)
                         t_out.update(nav_outs=t_outs, nav_logits=t_outs["fused_logits"])
-                        t_ce = F.cross_entropy(t_outs["fused_logits"], targets, ignore_index=IGNORE, reduction="none")
+                        t_ce = ce_rows_loss(t_outs["fused_logits"], targets, IGNORE)
                         t_out["sample_weights"] = exponential_decay(t_ce.detach(), self.kd["decay"])
                     if grad:
                         rw_t = None if rw_seq is None else rw_seq[t]

@@ -105,28 +105,32 @@ def random_word_mask(txt, rng, vocab, mask_id=None, prob=0.15):
     """MLM corruption rule of tasks.py:random_word :11-52 (15 %; 80/10/10), -1 = not predicted.
     At least one token is masked (tasks.py:46-50)."""
     mask_id = vocab - 1 if mask_id is None else mask_id      # RoBERTa <mask> = 50264
-    out, labels = txt.clone(), torch.full_like(txt, -1)
-    for i in range(1, len(txt) - 1):
+    src = txt.tolist()                          # plain lists inside the loop: element-wise tensor indexing was 2/3 of the mlm collate's time
+    out, labels = list(src), [-1] * len(src)
+    hit = False
+    for i in range(1, len(src) - 1):
         p = rng.random()
         if p < prob:
             p /= prob
-            labels[i] = txt[i]
+            labels[i] = src[i]
+            hit = True
             if p < 0.8:
                 out[i] = mask_id
             elif p < 0.9:
                 out[i] = int(rng.integers(3, vocab - 1))
-    if (labels == -1).all():
-        labels[1] = txt[1]
+    if not hit:
+        labels[1] = src[1]
         out[1] = mask_id
-    return out, labels
+    return torch.tensor(out, dtype=txt.dtype), torch.tensor(labels, dtype=txt.dtype)
 
 
 def _pad_stack(ts, pad=0):
-    n = max(t.shape[0] for t in ts)
-    out = ts[0].new_full((len(ts), n) + tuple(ts[0].shape[1:]), pad)
-    for i, t in enumerate(ts):
-        out[i, :t.shape[0]] = t
-    return out
+    """pad_tensors / pad_sequence of the reference collates (common.py:9-24): [len(ts), max rows, ...] filled with `pad`.  One C++ call
+    instead of a Python loop over ~300 panoramas (5 of a worker's ~16 ms per B=48 batch)."""
+    n0 = ts[0].shape[0]
+    if all(t.shape[0] == n0 for t in ts):
+        return torch.stack(ts)
+    return torch.nn.utils.rnn.pad_sequence(ts, batch_first=True, padding_value=pad)
 
 
 def collate(samples, task, rng=None, vocab=50265, mrc_mask_prob=0.15, prob_size=1000):

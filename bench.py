@@ -360,11 +360,11 @@ def secondary_block():
     # SURVEY f-3: the same pretraining step fed from DataLoader workers (NON-resident batches, PCIe-inclusive; never `value`): batches padded to
     # shape buckets, one graph replay per step (host/stream_graph.py)
     try:
-        r = subprocess.run([py, os.path.join(ROOT, "bench.py"), "--mode", "stream-graph", "--workers", "14", "--warmup", "150", "--steps", "100",
+        r = subprocess.run([py, os.path.join(ROOT, "bench.py"), "--mode", "stream-graph", "--workers", "8", "--warmup", "300", "--steps", "150",
                             "--no-cpu-baseline", "--no-parity", "--no-secondary"], capture_output=True, text=True, timeout=300, env=env)
         j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         out["streamed_batches_graph_replay"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
-                                                "launch": j["launch"], "note": "collate + index plan in 14 DataLoader workers, feature table in HBM, "
+                                                "launch": j["launch"], "note": "collate + index plan in 8 DataLoader workers (the reference's n_workers, r2r_magic_pretrain.json:26), feature table in HBM, "
                                                 "one H2D record copy + one graph launch per step; the resident-batch headline is `value`"}
     except Exception as e:              # noqa: BLE001
         out["streamed_batches_graph_replay"] = {"error": repr(e)[:300]}
@@ -513,11 +513,15 @@ def main():
             else:                                              # default: teacher one batch ahead on the side stream (two slots per bucket)
                 steps_gen = stream_step.run(dl)
 
+            cap_at = {}
+
             def run_stream(n, start=0):
                 traj = 0
+                cap_at[start] = stream_step.captures            # graphs captured before this region began
                 for _ in range(n):
                     _, meta = next(steps_gen)
                     traj += meta["traj_steps"]
+                cap_at["end"] = stream_step.captures
                 return traj
         else:
             feed = iter(DevicePrefetcher(dl, dev))
@@ -643,7 +647,7 @@ def main():
         info = {"metric": "trajectory-steps/sec (whole node), MAGIC-S R2R pretrain", "value": round(traj / dt, 2),
                 "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": a.dtype, "data": "synthetic", "launch": a.mode if a.mode not in ("stream", "stream-graph") else f"{a.mode}/{a.ingest}/{a.workers}w" + (f"/{stream_step.captures} bucket graphs" if stream_step is not None else ""),
+                "dtype": a.dtype, "data": "synthetic", "launch": a.mode if a.mode not in ("stream", "stream-graph") else f"{a.mode}/{a.ingest}/{a.workers}w" + (f"/{stream_step.captures} bucket graphs, {cap_at['end'] - cap_at.get(a.warmup, 0)} of them captured inside the timed steps" if stream_step is not None else ""),
                 "teacher_schedule": ({"split": "one batch ahead of the student, own graph on a side stream", "ahead": "one batch ahead of the student (fork/join inside the step graph)"}.get(a.teacher, "same batch, side stream") if a.mode == "graph" else "same batch, side stream"),
                 "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "
                                        "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip, student in train() mode",

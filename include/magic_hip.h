@@ -305,7 +305,10 @@ typedef struct {
   int nsamp, Nq, Nk, ldps, ldpc, nlayers;
   magic_xenc_layer L[3];
 } magic_xenc_seg;
-typedef struct { magic_xenc_seg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; } magic_xenc_params;
+/* sync != NULL: the row-split form (one workgroup per (sample, 16-row query tile); see magic_enc_params) is taken when all tiles of the
+ * launch are resident at once (tiles <= CUs); same outputs */
+typedef struct { magic_xenc_seg seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed;
+                 unsigned* sync; int sync_words, pad2_; } magic_xenc_params;
 int magic_xencoder_supported(int dtype, int H, int I, int nh, int Nq, int Nk, int nlayers);
 int magic_xencoder_params_bytes(void);
 int magic_xencoder_fwd(int dtype, const void* params, int nbytes, void* stream);

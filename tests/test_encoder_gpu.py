@@ -92,11 +92,13 @@ def test_fused_encoders_save_what_the_unfused_kernels_save(p_drop, max_len, row_
     ulp_close(res[True][1].img_attn, res[False][1].img_attn, "img_attns", ulps=3.0)
 
 
+@pytest.mark.parametrize("row_split", [True, False])
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 @pytest.mark.parametrize("task", ["sap", "mlm"])
-def test_fused_cross_encoders_save_what_the_unfused_kernels_save(task, p_drop):
+def test_fused_cross_encoders_save_what_the_unfused_kernels_save(task, p_drop, row_split, monkeypatch):
     """global || local co-attention encoders (sap) and the text-attends-to-map path (mlm) as one launch vs the per-op kernels: every
-    tensor cross_layer_bwd reads, layer by layer"""
+    tensor cross_layer_bwd reads, layer by layer; row_split: one workgroup per (sample, 16-row query tile) vs one per sample"""
+    monkeypatch.setattr(O, "ENC_ROW_SPLIT", row_split)
     m = student(p_drop)
     m.train()
     batch = synth.make_batch(task, batch_size=6, seed=9, step=0, dup_view_prob=0.3)
@@ -119,6 +121,9 @@ def test_fused_cross_encoders_save_what_the_unfused_kernels_save(task, p_drop):
         specs = [("global", plan, ct.out, L, plan["txt_mask"], tl, plan["txt_tokens"], gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"])]
     assert all(n.xenc_ok(sp[3], sp[8]) for sp in specs)
     fused = n.cross_fwd_fused(specs)
+    torch.cuda.synchronize()
+    if row_split:
+        assert int(O.ENC_SYNC_LAST[0][0]) == 0, "a bounded hand-off wait gave up"
     plain = [n.cross_fwd(*sp[:12], dist=(sp[12] if len(sp) > 12 else None)) for sp in specs]
     torch.cuda.synchronize()
     for sp, a, b in zip(specs, fused, plain):

@@ -944,7 +944,10 @@ template <typename Hh> struct XSegT {
   int nsamp, Nq, Nk, ldps, ldpc, nlayers;
   XLayerT<Hh> L[3];
 };
-template <typename Hh> struct XParamsT { XSegT<Hh> seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed; };
+template <typename Hh> struct XParamsT {
+  XSegT<Hh> seg[2]; int nseg; float p_attn, p_hidden, eps, scale; const unsigned* seed;
+  unsigned* sync; int sync_words, pad2_;        // row-split form (as EncParamsT): >= 4 + 6 * (samples of all segments) words
+};
 typedef XParamsT<bf16> XParams; typedef XSegT<bf16> XSeg; typedef XLayerT<bf16> XLayer;
 
 // one attention unit: this wave's 16 query rows (tile rt) of head h against NKT key tiles of the Q|K|V image; writes the clean (and,
@@ -1322,6 +1325,353 @@ __device__ __forceinline__ void xenc_body(const XParamsT<Hh>& p, const XSegT<Hh>
   }
 }
 
+// =====================================================================================================================================
+// Row-split form of the cross-modal encoders (round 3; construction and hand-off protocol: encoder_rs_kernel above).  One workgroup per
+// (sample, 16-row tile of the queries): a 20-node map is two workgroups, a 37-token viewpoint three, an 80-token instruction (the MLM
+// text-attends-map path) five -- 240 workgroups for B = 48 instead of 96 (or 48).  Per layer a tile recomputes the key / value projections of
+// ALL its encoder's rows (self-attention) and of the CONTEXT's <= 80 rows (cross-attention), and does everything else for its own 16 rows.
+// =====================================================================================================================================
+// attention of the tile's 16 queries (sQ: [16][XS], both heads) against NKT key tiles of the K / V images, on all 8 waves:
+//   phase 1 scores per (head, key tile) -> sS ; phase 2 softmax, 4 (head, query) rows per wave -> clean probabilities in place of the
+//   scores (+ dropped probabilities in sPd) ; phase 3 P V per (head, 16 context columns) -> sQ (Q is dead by then).
+// Writes P (and Pd) rows of the tile to global.  dist: optional graph-distance bias rows [Nq_total, Nk] of this sample (global encoder).
+template <int NKT, typename Hh>
+__device__ __forceinline__ void rs_attn(Hh* sQ, const Hh* sK, const Hh* sV, float* sS, Hh* sPd, const float (&kbias)[NKT], const int Nk, const int kmax,
+                                        const float* dist, const float sw, const float sb, const int q0, const int nq, const int Nq,
+                                        Hh* Pg, Hh* Pdg, const int ldp, const long long samp, const float scale, const DropState& dsa,
+                                        const int tid, const int w, const int lane) {
+  const int g = lane >> 4, c16 = lane & 15;
+  const int NKP = (Nk + 31) / 32 * 32;
+  for (int u = w; u < ENH * NKT; u += NWAVE) {
+    const int h = u / NKT, j = u % NKT;
+    f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) sc = emma(lfrag(sQ, XS, 0, h * EHD + ks * 32, lane), lfrag(sK, XS, j * 16, h * EHD + ks * 32, lane), sc);
+    const int key = j * 16 + c16;
+    float mb = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < NKT; ++jj) mb = (jj == j) ? kbias[jj] : mb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = sc[r] * scale + mb;
+      if (dist && key < Nk) { const int qrow = min(q0 + 4 * g + r, Nq - 1); x += sw * dist[((long long)samp * Nq + qrow) * Nk + key] + sb; }
+      sS[(h * 16 + 4 * g + r) * RS_SS + key] = key < Nk ? x : -3.0e38f;
+    }
+  }
+  __syncthreads();
+  {
+    const int rr = 4 * w + g, h = rr >> 4, ql = rr & 15;
+    float e[NKT], mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) { e[j] = sS[rr * RS_SS + j * 16 + c16]; mx = fmaxf(mx, e[j]); }
+    mx = g16_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) { e[j] = (j * 16 + c16) < Nk ? __expf(e[j] - mx) : 0.f; sum += e[j]; }
+    sum = 1.0f / g16_sum(sum);
+    Hh* pc = (Hh*)(sS + rr * RS_SS);
+    Hh* pd = sPd + rr * RS_PP;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int key = j * 16 + c16;
+      const float pv = e[j] * sum;
+      pc[key] = from_f<Hh>(pv);
+      if (dsa.on) {
+        const unsigned idx = (unsigned)(((((long long)samp * ENH + h) * Nq + q0 + ql) * Nk) + key);
+        pd[key] = from_f<Hh>((ql < nq && key < Nk) ? pv * drop_mul(dsa, idx) : 0.f);
+      }
+    }
+    if (NKT * 16 < NKP && c16 < NKP - NKT * 16) { pc[NKT * 16 + c16] = (Hh)0.0f; if (dsa.on) pd[NKT * 16 + c16] = (Hh)0.0f; }
+  }
+  __syncthreads();
+  {
+    const int cpr = ldp / 8;
+    for (int id = tid; id < ENH * nq * cpr; id += NWAVE * 64) {
+      const int h = id / (nq * cpr), rem = id % (nq * cpr), r = rem / cpr, c = (rem % cpr) * 8;
+      const long long go = (((long long)samp * ENH + h) * Nq + q0 + r) * ldp + c;
+      *(h16x8<Hh>*)(Pg + go) = *(const h16x8<Hh>*)((const Hh*)(sS + (h * 16 + r) * RS_SS) + c);
+      if (dsa.on && Pdg) *(h16x8<Hh>*)(Pdg + go) = *(const h16x8<Hh>*)(sPd + (h * 16 + r) * RS_PP + c);
+    }
+  }
+  {
+    const int h = w >> 2, jd = w & 3;
+    const Hh* pa = dsa.on ? sPd + h * 16 * RS_PP : (const Hh*)(sS + h * 16 * RS_SS);
+    const int pp = dsa.on ? RS_PP : 2 * RS_SS;
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < NKP / 32; ++ks)
+      o = emma(lfrag(pa, pp, 0, ks * 32, lane), tfrag_clamp(sV + h * EHD, XS, jd * 16, ks * 32, lane, kmax), o);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sQ[(4 * g + r) * XS + h * EHD + jd * 16 + c16] = from_f<Hh>(o[r]);
+  }
+  __syncthreads();
+}
+
+template <int NRT, typename Hh>
+__device__ __forceinline__ void xenc_rs_body(const XParamsT<Hh>& p, const XSegT<Hh>& sg, const int samp, const int tile, const int ntile,
+                                             unsigned* cnt, unsigned* err, unsigned char* smem) {
+  // NRT: compile-time bound on the encoder's row tiles (3 or 5; tiles past the sample are zero rows), ntile: the real count (the hand-off waits for it)
+  constexpr int NKT = 5;                       // context key tiles (<= 80 rows)
+  Hh* sK = (Hh*)smem;                          // [80][XS]  self keys, then the context's keys
+  Hh* sV = sK + 80 * XS;                       // [81][XS]  self values, then the context's; row 80 stays zero
+  Hh* sU = sV + 81 * XS;                       // union (80 * XS elements): layer input (all rows) | scores + probabilities | GELU output
+  Hh* sX = sU;
+  float* sS = (float*)sU;
+  Hh* sPd = sU + 2 * 16 * RS_SS * 2;
+  Hh* sG = sU;
+  Hh* sZ = sK;                                 // [16][GS] FFN pre-activation (K image dead by then)
+  Hh* sQ = sU + 80 * XS;                       // [16][XS] Q -> context (self), then Q -> context (cross)
+  Hh* sO = sQ + 16 * XS;                       // [16][XS] own rows of the layer input; then c (cross-attention block output)
+  Hh* sA = sO + 16 * XS;                       // [16][XS] a (self-attention block output); then the layer output
+  float* red = (float*)(sA + 16 * XS);
+  const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Nq = sg.Nq, Nk = sg.Nk;
+  const long long qbase = (long long)samp * Nq, kbase = (long long)samp * Nk;
+  const int r0 = tile * 16, nq = min(16, Nq - r0);
+  const long long row0 = qbase + r0;
+  if (tid < XS / 8) {
+    h16x8<Hh> zv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zv[e] = (Hh)0.0f;
+    *(h16x8<Hh>*)(sV + RS_ZROW * XS + tid * 8) = zv;
+  }
+  DropDesc dd;
+  dd.seed = p.seed;
+  float qbias[NRT], cbias[NKT];
+#pragma unroll
+  for (int j = 0; j < NRT; ++j) {
+    const int key = j * 16 + (lane0 & 15);
+    qbias[j] = (key < Nq && sg.qmask && !sg.qmask[qbase + key]) ? -10000.0f : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) {
+    const int key = j * 16 + (lane0 & 15);
+    cbias[j] = (key < Nk && sg.cmask && !sg.cmask[kbase + key]) ? -10000.0f : 0.f;
+  }
+  const float sw = sg.dist ? sg.sprel_w[0] : 0.f, sb = sg.dist ? sg.sprel_b[0] : 0.f;
+  for (int l = 0; l < sg.nlayers; ++l) {
+    const XLayerT<Hh>& L = sg.L[l];
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, c16 = lane & 15;
+    const int colw = w * 16 + c16;
+    const float pb_q0 = L.bqkv[colw], pb_kv0 = L.bqkv[EH + (2 * w) * 16 + c16], pb_kv1 = L.bqkv[EH + (2 * w + 1) * 16 + c16];
+    const float pb_ck0 = L.bkv[(2 * w) * 16 + c16], pb_ck1 = L.bkv[(2 * w + 1) * 16 + c16];
+    float pb_ffn[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) pb_ffn[ct] = L.bi[(4 * w + ct) * 16 + c16];
+    const float pb_o = L.bo[colw], pg_1 = L.g1[colw], pe_1 = L.be1[colw], pb_q = L.bq[colw];
+    const float pb_oc = L.boc[colw], pg_c = L.gc[colw], pe_c = L.bec[colw];
+    const float pb_2 = L.bo2[colw], pg_2 = L.g2[colw], pe_2 = L.be2[colw];
+    h16x8<Hh> wq[4], wkv[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      wq[ks] = gfrag(L.Wqkv, EH, w * 16, ks * 32, lane);
+      wkv[0][ks] = gfrag(L.Wqkv, EH, EH + (2 * w) * 16, ks * 32, lane);
+      wkv[1][ks] = gfrag(L.Wqkv, EH, EH + (2 * w + 1) * 16, ks * 32, lane);
+    }
+    if (l > 0) {
+      if (tid == 0) {
+        gu32_t* c = (gu32_t*)(cnt + (long long)samp * 6 + (l - 1));
+        unsigned spins = 0;
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ntile) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > RS_SPIN_MAX) { __hip_atomic_store((gu32_t*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+      }
+      __syncthreads();
+    }
+    {
+      const Hh* x = (l == 0 ? sg.x : sg.L[l - 1].out) + qbase * EH;
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, Nq * EH * 2, 0x00020000);
+      for (int id = tid; id < NRT * 16 * (EH / 8); id += NWAVE * 64) {
+        const int r = id / (EH / 8), c = (id % (EH / 8)) * 8;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (r * EH + c) * 2, 0, 16);
+        *(u32x4*)(sX + r * XS + c) = v;
+        if (r >= r0 && r < r0 + 16) *(u32x4*)(sO + (r - r0) * XS + c) = v;
+      }
+    }
+    __syncthreads();
+    // ================= self-attention: K|V of all the encoder's rows, Q of the own tile =================
+    {
+      f32x4 acc[NRT][2], aq = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+          const h16x8<Hh> a = lfrag(sX, XS, i * 16, ks * 32, lane);
+          acc[i][0] = emma(a, wkv[0][ks], acc[i][0]);
+          acc[i][1] = emma(a, wkv[1][ks], acc[i][1]);
+        }
+        aq = emma(lfrag(sO, XS, 0, ks * 32, lane), wq[ks], aq);
+        KSTEP_FENCE();
+      }
+      Hh* dst = (w < 4 ? sK : sV) + ((2 * w) & 7) * 16 + c16;
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dst[(i * 16 + 4 * g + r) * XS] = from_f<Hh>(acc[i][0][r] + pb_kv0);
+          dst[(i * 16 + 4 * g + r) * XS + 16] = from_f<Hh>(acc[i][1][r] + pb_kv1);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sQ[(4 * g + r) * XS + colw] = from_f<Hh>(aq[r] + pb_q0);
+    }
+    h16x8<Hh> wo[4], wcq[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { wo[ks] = gfrag(L.Wo, EH, w * 16, ks * 32, lane); wcq[ks] = gfrag(L.Wq, EH, w * 16, ks * 32, lane); }
+    __syncthreads();
+    {
+      Hh* qg = L.qkv + row0 * 3 * EH;
+      for (int id = tid; id < nq * 48; id += NWAVE * 64) {
+        const int r = id / 48, c = (id % 48) * 8;
+        const Hh* src = c < EH ? sQ + r * XS + c : (c < 2 * EH ? sK + (r0 + r) * XS + (c - EH) : sV + (r0 + r) * XS + (c - 2 * EH));
+        *(h16x8<Hh>*)(qg + (long long)r * 3 * EH + c) = *(const h16x8<Hh>*)src;
+      }
+    }
+    dd.site = L.site_attn; dd.p = p.p_attn;
+    const DropState dsa = drop_init(dd);
+    rs_attn<NRT>(sQ, sK, sV, sS, sPd, qbias, Nq, NRT * 16, sg.dist, sw, sb, r0, nq, Nq, L.P, L.Pd, sg.ldps, samp, p.scale, dsa, tid, w, lane);
+    copy_tile<false>(sQ, XS, L.ctx + row0 * EH, EH, nq, EH, tid);
+    {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = emma(lfrag(sQ, XS, 0, ks * 32, lane), wo[ks], acc);
+      dd.site = L.site_ao; dd.p = p.p_hidden;
+      const DropState dsh = drop_init(dd);
+      add_norm16(acc, pb_o, pg_1, pe_1, sO, red, sA, L.rstd_a, nq, row0, p.eps, dsh, w, lane);
+    }
+    // weights of the context's key / value projection (2 of its 16 column tiles per wave): in flight under the barrier
+    h16x8<Hh> wck[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) wck[ct][ks] = gfrag(L.Wkv, EH, (2 * w + ct) * 16, ks * 32, lane);
+    __syncthreads();                              // sA = a ; the self K / V images are dead
+    copy_tile<false>(sA, XS, L.a + row0 * EH, EH, nq, EH, tid);
+    // ================= cross-attention: Q of the own tile from a, K|V of ALL context rows (read from global as A-fragments) =================
+    {
+      f32x4 aq = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) aq = emma(lfrag(sA, XS, 0, ks * 32, lane), wcq[ks], aq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sQ[(4 * g + r) * XS + colw] = from_f<Hh>(aq[r] + pb_q);
+      f32x4 acc[NKT][2];
+#pragma unroll
+      for (int i = 0; i < NKT; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      const Hh* cx = sg.cx + kbase * EH;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) {
+          const int row = min(i * 16 + c16, Nk - 1);
+          const h16x8<Hh> a = *(const h16x8<Hh>*)(cx + (long long)row * EH + ks * 32 + 8 * g);
+          acc[i][0] = emma(a, wck[0][ks], acc[i][0]);
+          acc[i][1] = emma(a, wck[1][ks], acc[i][1]);
+        }
+        KSTEP_FENCE();
+      }
+      Hh* dst = (w < 4 ? sK : sV) + ((2 * w) & 7) * 16 + c16;
+#pragma unroll
+      for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i * 16 + 4 * g + r;
+          dst[row * XS] = row < Nk ? from_f<Hh>(acc[i][0][r] + pb_ck0) : (Hh)0.0f;
+          dst[row * XS + 16] = row < Nk ? from_f<Hh>(acc[i][1][r] + pb_ck1) : (Hh)0.0f;
+        }
+    }
+    h16x8<Hh> woc[4], w1[4][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) woc[ks] = gfrag(L.Woc, EH, w * 16, ks * 32, lane);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) w1[ct][ks] = gfrag(L.W1, EH, (4 * w + ct) * 16, ks * 32, lane);
+    __syncthreads();                              // cross Q, K, V images complete
+    copy_tile<false>(sQ, XS, L.q + row0 * EH, EH, nq, EH, tid);
+    // kv [Nk, 2H] for the backward: every tile holds all of it; tile t writes the context rows of key tiles t, t + NRT, ...
+    for (int kt = tile; kt * 16 < Nk; kt += ntile) {
+      const int nr = min(16, Nk - kt * 16);
+      Hh* kg = L.kv + (kbase + kt * 16) * 2 * EH;
+      for (int id = tid; id < nr * 32; id += NWAVE * 64) {
+        const int r = id / 32, c = (id % 32) * 8;
+        const Hh* src = c < EH ? sK + (kt * 16 + r) * XS + c : sV + (kt * 16 + r) * XS + (c - EH);
+        *(h16x8<Hh>*)(kg + (long long)r * 2 * EH + c) = *(const h16x8<Hh>*)src;
+      }
+    }
+    dd.site = L.site_cattn; dd.p = p.p_attn;
+    const DropState dsc = drop_init(dd);
+    rs_attn<NKT>(sQ, sK, sV, sS, sPd, cbias, Nk, NKT * 16, nullptr, 0.f, 0.f, r0, nq, Nq, L.Pc, L.Pdc, sg.ldpc, samp, p.scale, dsc, tid, w, lane);
+    copy_tile<false>(sQ, XS, L.cctx + row0 * EH, EH, nq, EH, tid);
+    {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = emma(lfrag(sQ, XS, 0, ks * 32, lane), woc[ks], acc);
+      dd.site = L.site_co; dd.p = p.p_hidden;
+      const DropState dsh = drop_init(dd);
+      add_norm16(acc, pb_oc, pg_c, pe_c, sA, red, sO, L.rstd_c, nq, row0, p.eps, dsh, w, lane);
+    }
+    __syncthreads();                              // sO = c
+    copy_tile<false>(sO, XS, L.c + row0 * EH, EH, nq, EH, tid);
+    // ================= FFN =================
+    h16x8<Hh> w2[16];
+    {
+      f32x4 acc[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const h16x8<Hh> a = lfrag(sO, XS, 0, ks * 32, lane);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = emma(a, w1[ct][ks], acc[ct]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) w2[ks] = gfrag(L.W2, EI, w * 16, ks * 32, lane);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int col = (4 * w + ct) * 16 + c16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float zv = acc[ct][r] + pb_ffn[ct];
+          sZ[(4 * g + r) * GS + col] = from_f<Hh>(zv);
+          sG[(4 * g + r) * GS + col] = from_f<Hh>(gelu_fast(zv));
+        }
+      }
+    }
+    __syncthreads();
+    copy_tile<false>(sZ, GS, L.z + row0 * EI, EI, nq, EI, tid);
+    copy_tile<false>(sG, GS, L.g + row0 * EI, EI, nq, EI, tid);
+    {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) acc = emma(lfrag(sG, GS, 0, ks * 32, lane), w2[ks], acc);
+      dd.site = L.site_out; dd.p = p.p_hidden;
+      const DropState dsh = drop_init(dd);
+      add_norm16(acc, pb_2, pg_2, pe_2, sO, red, sA, L.rstd_o, nq, row0, p.eps, dsh, w, lane);
+    }
+    __syncthreads();
+    copy_tile<true>(sA, XS, L.out + row0 * EH, EH, nq, EH, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && l + 1 < sg.nlayers) __hip_atomic_fetch_add((gu32_t*)(cnt + (long long)samp * 6 + l), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <typename Hh>
+__global__ __launch_bounds__(512) void xencoder_rs_kernel(XParamsT<Hh> p, int nt0, int nt1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char enc_smem[];
+  int b = blockIdx.x, s = 0, nt = nt0;
+  unsigned* cnt = p.sync + 4;
+  if (b >= p.seg[0].nsamp * nt0) { b -= p.seg[0].nsamp * nt0; s = 1; nt = nt1; cnt += 6ll * p.seg[0].nsamp; }
+  const XSegT<Hh>& sg = p.seg[s];
+  const int samp = b / nt, tile = b - samp * nt;
+  // two instantiations only (see encoder_mix_kernel: more bodies in one kernel push the parameter block into scratch memory)
+  if (nt <= 3) xenc_rs_body<3>(p, sg, samp, tile, nt, cnt, p.sync, enc_smem);
+  else xenc_rs_body<5>(p, sg, samp, tile, nt, cnt, p.sync, enc_smem);
+}
+
 template <typename Hh>
 __global__ __launch_bounds__(512) void xencoder_fwd_kernel(XParamsT<Hh> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char enc_smem[];
@@ -1369,6 +1719,28 @@ extern "C" int magic_xencoder_fwd(int dtype, const void* params, int nbytes, voi
       if (p.p_attn > 0.f && (!L.Pd || !L.Pdc)) return MAGIC_ERR_ARG;
     }
     blocks += sg.nsamp;
+  }
+  if (p.sync) {           // row-split form when every tile of the launch is resident at once (one workgroup per CU)
+    const int nt0 = (p.seg[0].Nq + 15) / 16, nt1 = p.nseg > 1 ? (p.seg[1].Nq + 15) / 16 : 1;
+    const int ns1 = p.nseg > 1 ? p.seg[1].nsamp : 0;
+    const long long words = 4 + 6ll * (p.seg[0].nsamp + ns1);
+    if (p.sync_words < words || ((uintptr_t)p.sync & 15)) return MAGIC_ERR_ARG;
+    static int ncu = 0;
+    if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    const int grid = p.seg[0].nsamp * nt0 + ns1 * nt1;
+    if (grid <= ncu && grid > blocks) {
+      static bool rs_attr = false;
+      if (!rs_attr) {
+        (void)hipFuncSetAttribute((const void*)xencoder_rs_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_rs_lds_bytes());
+        (void)hipFuncSetAttribute((const void*)xencoder_rs_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_rs_lds_bytes());
+        rs_attr = true;
+      }
+      if (hipMemsetAsync(p.sync, 0, (size_t)((words + 3) / 4 * 4) * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return MAGIC_ERR_LAUNCH;
+      if (dtype == DT_BF16) hipLaunchKernelGGL(xencoder_rs_kernel<bf16>, dim3(grid), dim3(512), enc_rs_lds_bytes(), (hipStream_t)stream, p, nt0, nt1);
+      else { XParamsT<f16> pf; static_assert(sizeof(pf) == sizeof(p), "layout"); memcpy(&pf, &p, sizeof(pf)); hipLaunchKernelGGL(xencoder_rs_kernel<f16>, dim3(grid), dim3(512), enc_rs_lds_bytes(), (hipStream_t)stream, pf, nt0, nt1); }
+      return launch_status();
+    }
+    if (hipMemsetAsync(p.sync, 0, 16, (hipStream_t)stream) != hipSuccess) return MAGIC_ERR_LAUNCH;
   }
   const size_t shm = enc_lds_bytes();
   static bool attr_set = false;

@@ -149,7 +149,8 @@ class XSeg(C.Structure):
 
 
 class XParams(C.Structure):
-    _fields_ = [("seg", XSeg * 2), ("nseg", i32), ("p_attn", f32), ("p_hidden", f32), ("eps", f32), ("scale", f32), ("seed", vp)]
+    _fields_ = [("seg", XSeg * 2), ("nseg", i32), ("p_attn", f32), ("p_hidden", f32), ("eps", f32), ("scale", f32), ("seed", vp),
+                ("sync", vp), ("sync_words", i32), ("pad2_", i32)]
 
 
 RBW_PTRS = ("dqkv_n", "WqkvT_n", "dao_n", "dfo_in", "dfod_in", "y2", "rstd2", "g2", "b2", "dg2", "db2", "z", "W2T", "W1T",

@@ -357,6 +357,7 @@ def attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, dctx, B, nh, Nq, Nk, H, scale, dP_init
 
 FUSED_ENC = not os.environ.get("MAGIC_NO_FUSED_ENC")
 ENC_ROW_SPLIT = os.environ.get("MAGIC_ENC_RS", "1") != "0"      # row-split form of the whole-encoder forward (csrc/encoder.hip, encoder_rs_kernel)
+XENC_ROW_SPLIT = os.environ.get("MAGIC_XENC_RS", "1") != "0"   # the same for the cross-modal encoders (xencoder_rs_kernel)
 ENC_SYNC_LAST = [None]                                          # the last launch's sync words (word 0 = 1: a bounded wait gave up) -- tests read it
 _ENC_OK = {}
 
@@ -478,6 +479,11 @@ def xencoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
         if FLOPS["enabled"]:
             FLOPS["total"] += sg["flops"]
             FLOPS["enc"] += sg["flops"]
+    if ENC_ROW_SPLIT and XENC_ROW_SPLIT:         # one workgroup per (sample, 16-row query tile) when the launch's tiles fit the chip (the entry point decides)
+        words = 4 + 6 * sum(sg["nsamp"] for sg in segs)
+        sync = torch.empty((words + 3) // 4 * 4, dtype=torch.int32, device=segs[0]["x"].device)
+        P.sync, P.sync_words = L.P(sync), sync.numel()
+        ENC_SYNC_LAST[0] = sync
     L.call("magic_xencoder_fwd", L.dt(dtype), C.addressof(P), C.sizeof(P), L.stream())
 
 

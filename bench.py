@@ -207,13 +207,26 @@ def pmc_traffic():
     """HBM-side bytes per GEMM launch.  NOT measured inside this process (PMC collection needs rocprofv3 around it): read from the
     committed post-processing of the `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
     (profiles/pmc_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Returns (bytes, source file)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return round(json.load(f)["gemm_traffic_bytes_per_launch"]), "profiles/" + name
         except Exception:
             continue
     return None, None
+
+
+def pmc_dw_fetch():
+    """HBM bytes fetched per weight-gradient launch from the committed PMC pass (None if that file does not carry it)"""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                v = json.load(f).get("dw_batch_fetch_bytes_per_launch")
+            if v:
+                return round(v)
+        except Exception:
+            continue
+    return None
 
 
 def build_models(dtype, dev, dropout, world, batch=48):
@@ -581,7 +594,7 @@ def main():
                                "algorithmic_bytes_per_launch": round(O.BYTES["dw"] / max(O.BYTES["dw_launches"], 1)),
                                "avg_us": round(by.get("magic_gemm_dw_grouped", (0.0, 1))[0] / max(by.get("magic_gemm_dw_grouped", (0.0, 1))[1], 1) * 1e3, 1),
                                "algorithmic_GB_per_s": round(O.BYTES["dw"] / max(by.get("magic_gemm_dw_grouped", (1e-9, 1))[0], 1e-9) / 1e6, 1),
-                               "pmc_fetched_bytes_per_launch_r02": 500e6, "peak_GB_per_s": 8000.0},
+                               "pmc_fetched_bytes_per_launch": pmc_dw_fetch(), "peak_GB_per_s": 8000.0},
                            "top_kernels_share": {k: round(t / all_ms, 4) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]},
                            "kernels_launches_per_step_and_avg_us": {k: [round(c / nprof, 1), round(t / c * 1e3, 1)]
                                                                     for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])}}}

@@ -36,7 +36,7 @@ def main():
     fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])      # steps = warmup + timed steps of the profiled run
     fk, ftot, _ = load(fetch_dir, "FETCH_SIZE")
     wk, wtot, _ = load(write_dir, "WRITE_SIZE")
-    is_gemm = lambda k: "gemm_kernel" in k or "gemm_xcd_kernel" in k or "gemm_grouped_kernel" in k
+    is_gemm = lambda k: "gemm_kernel" in k or "gemm_xcd_kernel" in k or "gemm_grouped_kernel" in k or "gemm_dw_batch_kernel" in k or "gemm_kg_kernel" in k
     gf = sum(v[0] for k, v in fk.items() if is_gemm(k)) * 2.0       # gfx950: FETCH_SIZE counts half of wide reads
     gn = sum(v[1] for k, v in fk.items() if is_gemm(k))
     gw = sum(v[0] for k, v in wk.items() if is_gemm(k))
@@ -46,6 +46,8 @@ def main():
            "gemm_launches": gn, "gemm_fetch_bytes_per_launch": gf / max(gn, 1), "gemm_write_bytes_per_launch": gw / max(gnw, 1),
            "gemm_traffic_bytes_per_launch": gf / max(gn, 1) + gw / max(gnw, 1),
            "step_fetch_bytes": ftot * 2.0 / steps, "step_write_bytes": wtot / steps,
+           "dw_batch_fetch_bytes_per_launch": sum(v[0] for k, v in fk.items() if "gemm_dw_batch_kernel" in k) * 2.0 / max(sum(v[1] for k, v in fk.items() if "gemm_dw_batch_kernel" in k), 1),
+           "dw_batch_write_bytes_per_launch": sum(v[0] for k, v in wk.items() if "gemm_dw_batch_kernel" in k) / max(sum(v[1] for k, v in wk.items() if "gemm_dw_batch_kernel" in k), 1),
            "top_fetch_kernels_bytes_per_launch": {k[:60]: round(v[0] * 2.0 / v[1]) for k, v in sorted(fk.items(), key=lambda kv: -kv[1][0])[:6]}}
     print(json.dumps(out, indent=1))
 

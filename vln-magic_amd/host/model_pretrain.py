@@ -131,7 +131,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         is drawn on the device by torch's graph-safe generator, so a replayed HIP graph gets fresh masks every step."""
         ph, pa = float(self.dropout.p), float(self.attention_dropout.p)
         if self.training and self.store.requires_grad and torch.is_grad_enabled() and (ph > 0 or pa > 0):
-            seed = self.dropout_seed            # PretrainStep: a device word pair its step prologue refreshes every step (one launch with the MKRW draw)
+            seed = getattr(self, "dropout_seed", None)       # PretrainStep: a device word pair its step prologue refreshes every step (one launch with the MKRW draw)
             if seed is None:
                 seed = torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int32, device=self.device_)
             self.net.set_dropout(seed, ph, pa)

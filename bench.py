@@ -379,6 +379,7 @@ def secondary_block():
                             "--no-cpu-baseline", "--no-parity", "--no-secondary"], capture_output=True, text=True, timeout=300, env=env)
         j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         out["streamed_batches_graph_replay"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                                                "ms_per_step_without_in_window_captures": j.get("ms_per_step_steady"),
                                                 "launch": j["launch"], "note": "collate + index plan in 8 DataLoader workers (the reference's n_workers, r2r_magic_pretrain.json:26), feature table in HBM, "
                                                 "one H2D record copy + one graph launch per step; the resident-batch headline is `value`"}
     except Exception as e:              # noqa: BLE001
@@ -533,10 +534,12 @@ def main():
             def run_stream(n, start=0):
                 traj = 0
                 cap_at[start] = stream_step.captures            # graphs captured before this region began
+                cap_at[("s", start)] = stream_step.capture_s
                 for _ in range(n):
                     _, meta = next(steps_gen)
                     traj += meta["traj_steps"]
                 cap_at["end"] = stream_step.captures
+                cap_at[("s", "end")] = stream_step.capture_s
                 return traj
         else:
             feed = iter(DevicePrefetcher(dl, dev))
@@ -662,7 +665,9 @@ def main():
         info = {"metric": "trajectory-steps/sec (whole node), MAGIC-S R2R pretrain", "value": round(traj / dt, 2),
                 "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": a.dtype, "data": "synthetic", "launch": a.mode if a.mode not in ("stream", "stream-graph") else f"{a.mode}/{a.ingest}/{a.workers}w" + (f"/{stream_step.captures} bucket graphs, {cap_at['end'] - cap_at.get(a.warmup, 0)} of them captured inside the timed steps" if stream_step is not None else ""),
+                "dtype": a.dtype, "data": "synthetic",
+                "ms_per_step_steady": (round((dt - (cap_at[("s", "end")] - cap_at.get(("s", a.warmup), 0.0))) / a.steps * 1e3, 3) if stream_step is not None and a.mode == "stream-graph" and a.teacher != "same" else None),
+                "launch": a.mode if a.mode not in ("stream", "stream-graph") else f"{a.mode}/{a.ingest}/{a.workers}w" + (f"/{stream_step.captures} bucket graphs, {cap_at['end'] - cap_at.get(a.warmup, 0)} of them captured inside the timed steps" if stream_step is not None else ""),
                 "teacher_schedule": ({"split": "one batch ahead of the student, own graph on a side stream", "ahead": "one batch ahead of the student (fork/join inside the step graph)"}.get(a.teacher, "same batch, side stream") if a.mode == "graph" else "same batch, side stream"),
                 "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "
                                        "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip, student in train() mode",

@@ -30,6 +30,7 @@ class StreamStep:
         self.tr, self.dev, self.ftab, self.rw, self.max_graphs = trainer, trainer.dev, feature_table, rw, max_graphs
         self.cache = {}
         self.captures = 0
+        self.capture_s = 0.0          # host wall time spent capturing bucket graphs (the GPU idles meanwhile): benches report it apart
         if trainer.sync.world != 1:
             raise NotImplementedError("StreamStep: single-GPU graphs only (the data-parallel exchange runs between graph halves, trainer.capture_split)")
 
@@ -105,6 +106,8 @@ class StreamStep:
     # stream).  While S_i trains on batch i, T_{i+1} already runs on batch i+1, which needs the NEXT record one step early: `run` drives
     # an iterable of (task, record) and yields one (out, meta) per step.
     def _capture_split(self, key, task, rec, parsed):
+        import time
+        t_cap = time.perf_counter()
         tr = self.tr
         e = _Entry()
         e.dbuf = torch.empty(int(rec["buf"].numel()), dtype=torch.uint8, device=self.dev)
@@ -131,6 +134,7 @@ class StreamStep:
         e.fill = [(DYN_TERMS.index(t), fn) for t, fn in e.plan["dyn"]["fill"].items()]
         e.t_done, e.loaded = torch.cuda.Event(), torch.cuda.Event()
         self.captures += 1
+        self.capture_s += time.perf_counter() - t_cap
         return e
 
     def _stage(self, item, slot):

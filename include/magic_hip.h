@@ -172,7 +172,8 @@ int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld, const int
 /* Soft-target KL rows of the MRC head (validate_mrc, train_r2r_magic.py:483-485: F.kl_div(log_softmax(logits), targets)
  * summed over the 1000 classes): loss_row = sum_j t_j (log t_j - log p_j); dlogits = coef * ((sum_j t_j) p - t). */
 int magic_softkl_rows(int dtype, int M, int N, const void* logits, int ld, const float* targets, int ldt, float coef,
-                      float* loss_row, void* dlogits, int ldd, void* stream);
+                      const float* row_w /* NULL or [M]: dlogits row r scaled by coef * row_w[r] */, float* loss_row, void* dlogits, int ldd,
+                      void* stream);
 
 /* kd_loss (pretrain_src/optim/kd_loss.py:18-41, map_nav_src/utils/kd_loss.py:27-54): -inf -> -1e6, T-softmax KL * T^2 */
 int magic_kd_rows(int M, int N, const float* s, const float* t, int ld, float temperature, const float* w, float norm,

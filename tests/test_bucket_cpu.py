@@ -17,7 +17,7 @@ def _layout(rec):
 
 
 def test_records_of_one_bucket_share_one_layout():
-    for task in ("sap", "mlm", "cfp"):
+    for task in ("sap", "mlm", "cfp", "mrc"):
         seen = {}
         for step in range(12):
             b = synth.make_batch(task, batch_size=8, seed=77, step=step)
@@ -60,6 +60,23 @@ def test_padding_is_masked_and_the_valid_part_is_unchanged():
             r0, r1 = b_ * K0 + k, b_ * K1 + k
             assert list(ie[pe[r0]:pe[r0 + 1]]) == list(ip[pp[r1]:pp[r1 + 1]])
     assert len(ip) == B * K1                                                  # padded to the bucket's capacity
+
+
+def test_mrc_rows_are_padded_with_zero_targets_and_carry_the_true_normaliser():
+    b = synth.make_batch("mrc", batch_size=6, seed=5, step=3)
+    bk = bucket_of(b, "mrc")
+    n = int(b["vp_view_mrc_masks"].sum())
+    assert bk["n_mask"] % 32 == 0 and bk["n_mask"] >= n > 0
+    padded, true = pad_batch(b, "mrc", bk)
+    assert true["n_mask"] == n
+    exact, hp = build_plan_host(b, "mrc"), build_plan_host(padded, "mrc", pad=(bk, true))
+    assert hp["meta"]["n_mrc"] == bk["n_mask"] and exact["meta"]["n_mrc"] == n
+    tg = hp["cpu"]["mrc_targets"]
+    assert tg.shape[0] == bk["n_mask"] and torch.equal(tg[:n], exact["cpu"]["mrc_targets"]) and not tg[n:].any()
+    assert torch.allclose(hp["cpu"]["mrc_row_w"], torch.full((bk["n_mask"],), 1.0 / n)) and "mrc_row_w" not in exact["cpu"]
+    ptr, idx, _ = hp["csr"]["mrc_rows"][0]
+    assert ptr[n] == n and (ptr[n:] == n).all() and len(idx) == bk["n_mask"]
+    assert list(idx[:n]) == list(exact["csr"]["mrc_rows"][0][1])             # Vp is not a padded extent: same source rows
 
 
 def test_exact_records_are_unchanged_by_the_bucket_option():

@@ -22,8 +22,8 @@ KDL = dict(knowledge_distillation=True, kd_alpha=0.5, kd_temperature=2, teacher_
 RW = [1.3, 0.7, 1.1, 0.9, 1.0]
 
 
-def cfgs(vocab=600, layers=(2, 1, 1)):
-    kw = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=vocab, num_l_layers=layers[0], num_x_layers=layers[1], num_pano_layers=layers[2])
+def cfgs(vocab=600, layers=(2, 1, 1), **extra):
+    kw = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=vocab, num_l_layers=layers[0], num_x_layers=layers[1], num_pano_layers=layers[2], **extra)
     t = make_config(256, role="teacher", **kw)
     s = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL, **kw)
     return t, s

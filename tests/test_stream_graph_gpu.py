@@ -57,6 +57,41 @@ def test_bucketed_graph_step_equals_the_exact_eager_step():
     assert len(seen) < 7 or ss.captures <= 7
 
 
+def test_mrc_records_replay_under_their_bucket_graph():
+    """the fourth proxy task (MrcDataset, tasks.py:189-310; listed in `tasks` it creates the image_classifier head): masked-view rows padded
+    to the bucket with all-zero target distributions, the true 1 / n_rows as per-row weights (magic_softkl_rows row_w)"""
+    from magic_amd.host.trainer import PretrainStep
+    from tests.test_model_gpu import build
+
+    def trainer():
+        _, _, g_t, g_s = build(torch.bfloat16, pretrain_tasks={"mlm", "mrc", "sap", "cfp"})
+        g_s.keep_mlm_logits = False
+        return g_s, PretrainStep(g_s, g_t, lr=5e-5, warmup_steps=2, num_train_steps=40)
+    (sA, tA), (sB, tB) = trainer(), trainer()
+    rw = torch.tensor(RW, dtype=torch.float32, device=DEV)
+    ss = StreamStep(tB, rw=rw)
+    seen = set()
+    for step in range(5):
+        b = synth.make_batch("mrc", batch_size=8, seed=99, step=step, vocab=600, min_len=8, max_len=19, min_steps=2, max_steps=4)
+        bk = bucket_of(b, "mrc")
+        n = int(b["vp_view_mrc_masks"].sum())
+        outA = tA.step(synth.batch_to(b, DEV), "mrc", rw=rw, plan=build_plan(b, "mrc", DEV))
+        before = ss.captures
+        key = tuple(sorted(bk.items()))
+        outB, meta = ss.step("mrc", pack_bucketed(b, "mrc"))
+        torch.cuda.synchronize()
+        assert ss.captures == before + (0 if key in seen else 1)
+        seen.add(key)
+        assert meta["true"]["n_mask"] == n <= meta["n_mrc"] == bk["n_mask"]
+        for k in ("loss", "supervised_loss", "kdl_loss"):
+            assert _close(outB[k], outA[k], 2e-3), (step, k, float(outB[k]), float(outA[k]))
+        rel = ((sA.store.flat - sB.store.flat).norm() / sA.store.flat.norm()).item()
+        print(f"mrc step {step}: {n} masked views in a bucket of {bk['n_mask']}, loss {float(outA['loss']):.6f} vs {float(outB['loss']):.6f}, weights rel. diff {rel:.1e}")
+        assert rel < 2e-5
+    assert torch.nn.functional.cosine_similarity(sA.store.m, sB.store.m, dim=0).item() > 0.9995
+    assert len(seen) < 5, "five batches, fewer buckets: at least one replay reused a captured graph"
+
+
 def test_teacher_one_batch_ahead_on_streamed_records_equals_the_exact_eager_steps():
     """StreamStep.run: split teacher / student graphs, two record slots per bucket, the teacher's forward for batch i+1 under the student's step on
     batch i -- same losses as stepping eagerly through the exact batches"""

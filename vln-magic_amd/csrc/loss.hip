@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void ce_rows_wide_kernel(int M, int N, const H
 // targets fp32 [M, N] (row pitch ldt); one block per row.
 template <typename T>
 __global__ __launch_bounds__(256) void softkl_rows_kernel(int M, int N, const T* logits, int ld, const float* targets, int ldt,
-                                                          float coef, float* loss_row, T* dlogits, int ldd) {
+                                                          float coef, const float* row_w, float* loss_row, T* dlogits, int ldd) {
   __shared__ float red[12];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const T* x = logits + (long long)row * ld;
@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void softkl_rows_kernel(int M, int N, const T*
   if (tid == 0 && loss_row) loss_row[row] = a + st * lse;      // sum t (log t - x + lse)
   if (dlogits) {
     T* d = dlogits + (long long)row * ldd;
-    for (int c = tid; c < ldd; c += 256) d[c] = from_f<T>(c < N ? coef * (st * __expf(to_f(x[c]) - lse) - t[c]) : 0.f);
+    const float cf = row_w ? coef * row_w[row] : coef;      // shape buckets: the batch's true 1 / n_rows rides in per-row weights
+    for (int c = tid; c < ldd; c += 256) d[c] = from_f<T>(c < N ? cf * (st * __expf(to_f(x[c]) - lse) - t[c]) : 0.f);
   }
 }
 
@@ -568,16 +569,16 @@ extern "C" int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld
 }
 
 extern "C" int magic_softkl_rows(int dtype, int M, int N, const void* logits, int ld, const float* targets, int ldt, float coef,
-                                 float* loss_row, void* dlogits, int ldd, void* stream) {
+                                 const float* row_w, float* loss_row, void* dlogits, int ldd, void* stream) {
   if (M <= 0 || N <= 0 || ld < N || ldt < N || !logits || !targets || (dlogits && ldd < N) || dlogits == logits) return MAGIC_ERR_ARG;
   dim3 grid(M), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL(softkl_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, targets, ldt, coef, loss_row, (bf16*)dlogits, ldd);
+    hipLaunchKernelGGL(softkl_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, targets, ldt, coef, row_w, loss_row, (bf16*)dlogits, ldd);
   else if (dtype == DT_F16)
-    hipLaunchKernelGGL(softkl_rows_kernel<f16>, grid, block, 0, st, M, N, (const f16*)logits, ld, targets, ldt, coef, loss_row, (f16*)dlogits, ldd);
+    hipLaunchKernelGGL(softkl_rows_kernel<f16>, grid, block, 0, st, M, N, (const f16*)logits, ld, targets, ldt, coef, row_w, loss_row, (f16*)dlogits, ldd);
   else if (dtype == DT_F32)
-    hipLaunchKernelGGL(softkl_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, targets, ldt, coef, loss_row, (float*)dlogits, ldd);
+    hipLaunchKernelGGL(softkl_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, targets, ldt, coef, row_w, loss_row, (float*)dlogits, ldd);
   else return MAGIC_ERR_ARG;
   return launch_status();
 }

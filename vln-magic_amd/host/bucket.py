@@ -9,7 +9,7 @@ collated batch to its bucket -- L to the truncation length, K / Np / n_mask to m
 What keeps the result identical to the unpadded batch (tests/test_stream_graph_gpu.py): padding is inert wherever the network masks it
 already (attention keys, action logits, gathers, ignored labels); the MAKD terms, whose `mean` runs over the batch's own padded extent
 (pretrain_src/optim/kd_loss.py:5-16), get their true extents and normalisers from device memory (magic_mse_multi valid_dev / norm_dev), and the
-MLM loss its 1 / n_mask through per-row weights.
+MLM and MRC losses their 1 / n_mask through per-row weights (padded MRC rows carry an all-zero target distribution: no loss, no gradient).
 """
 import torch
 
@@ -18,11 +18,13 @@ def rup(x, q):
     return (int(x) + q - 1) // q * q
 
 
-def bucket_of(batch, task, L=80, q_k=8, q_np=32, q_mask=64):
+def bucket_of(batch, task, L=80, q_k=8, q_np=32, q_mask=64, q_mrc=32):
     """bucket sizes of a collated batch"""
     bk = dict(L=max(L, int(batch["txt_ids"].shape[1])), K=rup(batch["gmap_step_ids"].shape[1], q_k), Np=rup(sum(batch["traj_step_lens"]), q_np), n_mask=0)
     if task == "mlm":
         bk["n_mask"] = rup(max(int((batch["txt_labels"] != -1).sum()), 1), q_mask)
+    if task == "mrc":               # masked views of the current viewpoint (tasks.py:205-221: ~15 % of <= 36 views per sample)
+        bk["n_mask"] = rup(max(int(batch["vp_view_mrc_masks"].sum()), 1), q_mrc)
     return bk
 
 
@@ -37,8 +39,8 @@ def _pad(t, dim, size, value=0):
 def pad_batch(batch, task, bk):
     """-> (padded copy of the collated batch, true sizes).  Lists (vpids, step lens) and per-sample lengths stay as they are."""
     true = dict(L=int(batch["txt_ids"].shape[1]), K=int(batch["gmap_step_ids"].shape[1]), Np=int(sum(batch["traj_step_lens"])),
-                n_mask=int((batch["txt_labels"] != -1).sum()) if task == "mlm" else 0)
-    if true["L"] > bk["L"] or true["K"] > bk["K"] or true["Np"] > bk["Np"] or true["n_mask"] > max(bk["n_mask"], 0 if task != "mlm" else 1):
+                n_mask=int((batch["txt_labels"] != -1).sum()) if task == "mlm" else int(batch["vp_view_mrc_masks"].sum()) if task == "mrc" else 0)
+    if true["L"] > bk["L"] or true["K"] > bk["K"] or true["Np"] > bk["Np"] or true["n_mask"] > bk["n_mask"]:
         raise ValueError(f"batch {true} does not fit bucket {bk}")
     b = dict(batch)
     b["txt_ids"] = _pad(batch["txt_ids"], 1, bk["L"], 0)

@@ -43,7 +43,7 @@ SIGNATURES = {
     "magic_lndot_fwd": [i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
     "magic_lndot_bwd": [i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_ce_rows": [i32, i32, i32, vp, i32, vp, i32, f32, vp, vp, vp, i32, i32, vp, f32, vp],
-    "magic_softkl_rows": [i32, i32, i32, vp, i32, vp, i32, f32, vp, vp, i32, vp],
+    "magic_softkl_rows": [i32, i32, i32, vp, i32, vp, i32, f32, vp, vp, vp, i32, vp],
     "magic_kd_rows": [i32, i32, vp, vp, i32, f32, vp, f32, f32, vp, vp, vp, i32, vp],
     "magic_mse": [i32, i32, i64, i64, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp, i64, i32, vp],
     "magic_mse_multi": [i32, i32, vp, vp],

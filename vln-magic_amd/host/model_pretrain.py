@@ -456,8 +456,10 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             nm, Pn = plan["n_mrc"], c.mlogits.shape[1]
             c.rows = n.new(nm, dtype=torch.float32)
             c.dmlogits = n.new(nm, Pn) if train else None
-            O.softkl_rows(c.mlogits, nm, Pn, Pn, plan["mrc_targets"], coef=scg / nm, loss_row=c.rows, dlogits=c.dmlogits, ldd=Pn)
-            sup_rows, sup_w, sup_scale = c.rows, None, 1.0 / nm
+            roww = plan.get("mrc_row_w")      # shape buckets (as mlm): nm counts padded rows, the true 1 / n rides in per-row weights
+            O.softkl_rows(c.mlogits, nm, Pn, Pn, plan["mrc_targets"], coef=scg if roww is not None else scg / nm, row_w=roww,
+                          loss_row=c.rows, dlogits=c.dmlogits, ldd=Pn)
+            sup_rows, sup_w, sup_scale = c.rows, roww, (1.0 if roww is not None else 1.0 / nm)
         else:
             c.d_gmap, c.d_vp, c.d_txt2 = zz(B * K, H), zz(B * Vp, H), zz(B * L, H)
             c.d_cls0 = (zz(B, H), zz(B, H), zz(B, H))

@@ -511,11 +511,12 @@ def ce_rows(logits, M, N, ld, labels, *, ignore_index=-100, coef=0.0, row_w=None
            L.P(loss_row), L.P(dlogits), ldd, 1 if accumulate else 0, L.P(w_out), float(w_rate), L.stream())
 
 
-def softkl_rows(logits, M, N, ld, targets, *, coef=0.0, loss_row=None, dlogits=None, ldd=0):
+def softkl_rows(logits, M, N, ld, targets, *, coef=0.0, row_w=None, loss_row=None, dlogits=None, ldd=0):
     """per-row KL(targets || softmax(logits)) and its coef-scaled gradient (MRC head)"""
     _chk(targets.dtype == torch.float32 and targets.stride(-1) == 1, "softkl targets fp32")
+    _chk(row_w is None or (row_w.dtype == torch.float32 and row_w.numel() >= M), "softkl row_w fp32 [M]")
     L.call("magic_softkl_rows", L.dt(logits.dtype), M, N, L.P(logits), ld, L.P(targets), targets.stride(0), float(coef),
-           L.P(loss_row), L.P(dlogits), ldd, L.stream())
+           L.P(row_w), L.P(loss_row), L.P(dlogits), ldd, L.stream())
 
 
 def kd_rows(s, t, M, N, ld, temperature, *, w=None, norm=1.0, coef=0.0, coef_dev=None, loss_row=None, ds=None, accumulate=False):

@@ -189,14 +189,16 @@ def build_plan_host(batch, task, ld_round=8, pad=None):
     if task == "mrc":       # masked views of the current viewpoint: row b*Vp + 1 + v of the local encoder output ([stop] at 0)
         mm = batch["vp_view_mrc_masks"]
         sel = torch.nonzero(mm)                      # row-major == boolean-mask order of _compute_masked_hidden
-        n_mrc = int(sel.shape[0])
+        n_true = int(sel.shape[0])
+        n_mrc = n_true if pad is None else int(pad[0]["n_mask"])      # padded rows: no source row, an all-zero target (no loss, no gradient)
         plan_csr["mrc_rows"] = csr_pair([(i, int(b_) * Vp + 1 + int(v_), 1.0) for i, (b_, v_) in enumerate(sel.tolist())], n_mrc, B * Vp)
-        cpu["mrc_targets"] = batch["vp_view_probs"][mm].float().contiguous()
+        tg = batch["vp_view_probs"][mm].float()
+        cpu["mrc_targets"] = torch.cat([tg, tg.new_zeros(n_mrc - n_true, tg.shape[1])]).contiguous()
+        if pad is not None:
+            cpu["mrc_row_w"] = torch.full((n_mrc,), 1.0 / max(n_true, 1), dtype=torch.float32)         # the loss's 1 / n_rows, per row
 
     if pad is not None:
-        if task == "mrc":
-            raise NotImplementedError("shape buckets: mrc is not in the shipped task list and has no bucketed plan")
-        caps = dict(gmap_from_embed=Np * V, gmap_from_fused=B * K, mlm_rows=int(pad[0]["n_mask"]))
+        caps = dict(gmap_from_embed=Np * V, gmap_from_fused=B * K, mlm_rows=int(pad[0]["n_mask"]), mrc_rows=int(pad[0]["n_mask"]))
         for name, cap in caps.items():
             if name in plan_csr:
                 plan_csr[name] = _pad_csr(plan_csr[name], cap)
@@ -214,6 +216,9 @@ def build_plan_host(batch, task, ld_round=8, pad=None):
         meta["traj_steps"] = int(sum(step_lens))
         meta["true"] = dict(pad[1])
         meta["bucket"] = dict(pad[0])
+        # (ragged, so it rides in the record's pickled header rather than in the bucket-shaped buffer; stream_graph.StreamStep hands it to
+        # the data-parallel exchange of the word-embedding rows)
+        meta["touched_ids"] = np.unique(batch["txt_ids"].numpy()).astype(np.int64)
     return dict(cpu=cpu, csr=plan_csr, meta=meta)
 
 

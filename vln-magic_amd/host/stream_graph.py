@@ -31,8 +31,10 @@ class StreamStep:
         self.cache = {}
         self.captures = 0
         self.capture_s = 0.0          # host wall time spent capturing bucket graphs (the GPU idles meanwhile): benches report it apart
-        if trainer.sync.world != 1:
-            raise NotImplementedError("StreamStep: single-GPU graphs only (the data-parallel exchange runs between graph halves, trainer.capture_split)")
+        # data parallel (trainer.sync.world > 1): every rank streams its OWN records -- ranks may sit in different buckets in the same step, the
+        # exchange only needs the flat gradient buffer, whose layout is the model's -- and the RCCL calls stay outside the graphs: `run`
+        # replays trainer.capture_student's three backward-cut graphs with the bucket exchanges between them, `step` one graph up to the end of
+        # the backward followed by the monolithic exchange (trainer.capture / replay)
 
     def _key(self, task, manifest):
         return (task,) + tuple((k, dt, shape, o) for k, dt, shape, o, _ in manifest)
@@ -123,14 +125,8 @@ class StreamStep:
         e.gT = torch.cuda.CUDAGraph()
         with torch.cuda.graph(e.gT, stream=tr.side, capture_error_mode="relaxed"):
             e.t_out = tr.teacher_forward(e.batch, task, e.plan)
-        e.gS = torch.cuda.CUDAGraph()
-        with tr._graph_ctx(e.gS):
-            drawn = tr.mkrw()                       # (also refreshes the dropout seed: one launch)
-            rw = self.rw if self.rw is not None else drawn
-            tr._zero_grad()
-            e.out = tr.student(e.batch, task, compute_loss=True, teacher_outputs=e.t_out, rw=rw, plan=e.plan, inputs=e.t_out["inputs"])
-            tr.student.backward()
-            tr._optimize()
+        e.cs = tr.capture_student((e.batch, task, e.plan), e.t_out, rw=self.rw)      # one graph; data parallel: three + the optimizer's
+        e.out = e.cs.out
         e.fill = [(DYN_TERMS.index(t), fn) for t, fn in e.plan["dyn"]["fill"].items()]
         e.t_done, e.loaded = torch.cuda.Event(), torch.cuda.Event()
         self.captures += 1
@@ -165,6 +161,11 @@ class StreamStep:
         e.plan["dyn"]["f"].copy_(host_f, non_blocking=True)
         ev.record()
         e.turn = (e.turn + 1) % len(e.ring)
+        e.touched = None
+        if self.tr.sync.world > 1 and task != "mlm" and self.tr.sync.sparse_cap and meta.get("touched_ids") is not None:
+            # the word-embedding rows THIS batch read (the record's own ids, not the captured batch's): trainer.GradSync exchanges those rows
+            ids = torch.from_numpy(np.ascontiguousarray(meta["touched_ids"], dtype=np.int64)).pin_memory()
+            e.touched, e.keep_ids = ids.to(self.dev, non_blocking=True), ids
         main = torch.cuda.current_stream()
         e.loaded.record(main)                  # after every earlier student step on the main stream (incl. the last user of this slot's buffers)
         side = self.tr.side
@@ -192,8 +193,7 @@ class StreamStep:
             e, meta = cur
             main = torch.cuda.current_stream()
             main.wait_event(e.t_done)
-            e.gS.replay()
-            self.tr.global_step += 1
+            self.tr.replay_student(e.cs, touched=e.touched)
             yield e.out, meta
             cur = nxt
             i += 1

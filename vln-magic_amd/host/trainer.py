@@ -440,9 +440,10 @@ class PretrainStep:
         cs.t_next = t_next
         return cs
 
-    def capture_split(self, cur, t_cur, nxt, rw=None, t_next_into=None):
-        """Same work as capture_ahead as TWO graphs: the student step on `cur` (main stream) and the teacher forward on `nxt`
-        (side stream), replayed concurrently by `replay_split` without a per-step fork/join inside one graph."""
+    def capture_student(self, cur, t_cur, rw=None, keep=None):
+        """the student's step on `cur` against the teacher outputs `t_cur` (static buffers a teacher graph fills): one graph holding the
+        whole step on one GPU; under data parallelism three graphs cut where the gradient buckets are final + the optimizer's graph,
+        replayed by `replay_student` with the RCCL calls between them"""
         full = self.sync.world == 1 and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")
         batch, task, plan = cur
         two = (not full) and self.sync.overlap and not os.environ.get("MAGIC_DDP_ONE_GRAPH")
@@ -479,14 +480,7 @@ class PretrainStep:
                 self.student.backward_phase2(on_cut=cut)
             finally:
                 state["ctx"].__exit__(None, None, None)
-        gT = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gT, stream=self.side, capture_error_mode="relaxed"):
-            t_next = self.teacher_forward(*nxt)
-            if t_next_into is not None:
-                copy_teacher_outputs(t_next, t_next_into)
-                t_next = t_next_into
-        cs = CapturedStep(gS, out, plan["traj_steps"], full, keep=(cur, t_cur, nxt, rw))
-        cs.t_graph, cs.t_next = gT, t_next
+        cs = CapturedStep(gS, out, plan["traj_steps"], full, keep=keep if keep is not None else (cur, t_cur, rw))
         cs.graph2, cs.graph3, cs.touched = gS2, gS3, self._touched_rows(task, plan)
         cs.graph_opt = None
         if two:            # the optimizer's launches as a graph of their own, replayed once the exchange has landed (1 / world is a constant)
@@ -495,25 +489,20 @@ class PretrainStep:
                 self._opt_step(1.0 / self.sync.world if self.sync.world > 1 else 1.0)
         return cs
 
-    def replay_split(self, cs):
-        """teacher graph for the NEXT batch on the side stream (after the previous student step, whose buffers it may recycle),
-        student graph on the main stream (after the teacher graph that produced ITS teacher outputs, one replay earlier)"""
-        main = torch.cuda.current_stream()
-        if getattr(self, "_t_done", None) is not None:
-            main.wait_event(self._t_done)
-        self.side.wait_stream(main)
+    def replay_student(self, cs, touched=None, between=None):
+        """replay a `capture_student` step on the current stream.  touched: this batch's word-embedding row ids (streamed batches: they
+        change per replay; default: the captured batch's); between(): called after the last backward graph, before the exchange is
+        awaited (replay_split launches the next teacher graph there)"""
         cs.graph.replay()
         if getattr(cs, "graph2", None) is not None:
             self.sync.reduce_bucket(0)                 # exchange stream: after graph 1, under graphs 2 and 3
             cs.graph2.replay()
             self.sync.reduce_bucket(1)                 # after graph 2, under graph 3
             cs.graph3.replay()
-            self.sync.reduce_bucket(2, cs.touched)
+            self.sync.reduce_bucket(2, touched if touched is not None else cs.touched)
             self._exchanged = True
-        with torch.cuda.stream(self.side):
-            cs.t_graph.replay()
-            self._t_done = torch.cuda.Event()
-            self._t_done.record(self.side)
+        if between is not None:
+            between()
         if not cs.full:
             if getattr(cs, "graph_opt", None) is not None and self._exchanged:
                 self.sync.finish()
@@ -524,6 +513,34 @@ class PretrainStep:
                 self._optimize()
         self.global_step += 1
         return cs.out
+
+    def capture_split(self, cur, t_cur, nxt, rw=None, t_next_into=None):
+        """Same work as capture_ahead as TWO graphs: the student step on `cur` (main stream) and the teacher forward on `nxt`
+        (side stream), replayed concurrently by `replay_split` without a per-step fork/join inside one graph."""
+        cs = self.capture_student(cur, t_cur, rw=rw, keep=(cur, t_cur, nxt, rw))
+        gT = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gT, stream=self.side, capture_error_mode="relaxed"):
+            t_next = self.teacher_forward(*nxt)
+            if t_next_into is not None:
+                copy_teacher_outputs(t_next, t_next_into)
+                t_next = t_next_into
+        cs.t_graph, cs.t_next = gT, t_next
+        return cs
+
+    def replay_split(self, cs):
+        """teacher graph for the NEXT batch on the side stream (after the previous student step, whose buffers it may recycle),
+        student graph on the main stream (after the teacher graph that produced ITS teacher outputs, one replay earlier)"""
+        main = torch.cuda.current_stream()
+        if getattr(self, "_t_done", None) is not None:
+            main.wait_event(self._t_done)
+        self.side.wait_stream(main)
+
+        def teacher_next():
+            with torch.cuda.stream(self.side):
+                cs.t_graph.replay()
+                self._t_done = torch.cuda.Event()
+                self._t_done.record(self.side)
+        return self.replay_student(cs, between=teacher_next)
 
     def _optimize(self):
         if getattr(self, "_exchanged", False):       # the buckets went out from inside the backward: only wait for them

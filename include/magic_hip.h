@@ -314,6 +314,31 @@ int magic_xencoder_supported(int dtype, int H, int I, int nh, int Nq, int Nk, in
 int magic_xencoder_params_bytes(void);
 int magic_xencoder_fwd(int dtype, const void* params, int nbytes, void* stream);
 
+/* Forward-only row chain of a post-LN block at the frozen teacher's width (csrc/chain.hip; H = 256, FFN 1024, bf16 / fp16): everything
+ * of a block that is per token, between two attention products, in one launch on 16-row tiles --
+ *   y1 = LayerNorm(in Wa^T + ba + res)                     BertSelfOutput / the cross-attention output block (HF BertSelfOutput)
+ *   y2 = LayerNorm(gelu(y1 W1^T + bi) W2^T + bo2 + y1)     BertIntermediate + BertOutput; skipped when W1 == NULL
+ *   proj = y_last Wp^T + bp  [M, Np], Np in {H, 2H, 3H}     the next attention's Q | K | V projection; skipped when Wp == NULL
+ * No dropout, nothing saved for a backward pass: the MAKD teacher is frozen (kdl.train_teacher = false,
+ * pretrain_src/config/r2r_magic_pretrain.json:62-87) and runs in eval mode.  Same rounding points as magic_linear_ln / magic_gemm (y1, the
+ * GELU output, y2 and proj are rounded to the 16-bit type; everything in between is fp32).  Groupable (two chains = one launch).
+ * Wa, W1, W2, Wp are given in MFMA-FRAGMENT ORDER (magic_pack_frag_spans): a lane's 16-byte operand of row-major W touches one cache line per
+ * weight row, the packed form reads one contiguous KB per fragment. */
+typedef struct {
+  int M, ld_in, Np, pad_;
+  const void* in; const void* res;
+  const void* Wa; const float* ba; const float* g1; const float* b1; void* y1;      /* y1 NULL: not stored */
+  const void* W1; const float* bi; const void* W2; const float* bo2; const float* g2; const float* b2; void* y2;
+  const void* Wp; const float* bp; void* proj;
+  float eps; int pad2_;
+} magic_chain_params;
+int magic_chain_supported(int dtype, int H, int I);
+/* dst[offs[i] ..) = the [rows[i], cols[i]] row-major 16-bit matrix at src[offs[i] ..) in fragment order: chunk ((nt (cols/32) + ks) 64 + l) of
+ * 8 elements = src[(16 nt + (l & 15)) cols + 32 ks + 8 (l >> 4) .. +7].  rows % 16 == 0, cols % 32 == 0, rows cols % 2048 == 0, offs % 8 == 0;
+ * host arrays of n spans (element offsets), as magic_transpose_spans. */
+int magic_pack_frag_spans(const void* src, void* dst, int n, const long long* offs, const int* rows, const int* cols, void* stream);
+int magic_chain_fwd(int dtype, const void* params, int nbytes, void* stream);
+
 /* Backward of the per-token half of a post-LN self-attention block on 32-row blocks (csrc/encbwd.hip): [tail of the next block: dx =
  * dQKV Wqkv + d_ao -> LayerNorm backward through this block's output norm] -> FFN input gradients (x gelu') -> LayerNorm backward through the
  * attention-output norm -> d_ctx = d_aod Wo, one launch for 1 or 2 encoders ("segments"); bf16, H = 128, FFN 512.  Reads the TRANSPOSED
@@ -341,7 +366,7 @@ int magic_rowbwd(int dtype, const void* params, int nbytes, void* stream);
 int magic_transpose_spans(const void* src, void* dst, int n, const long long* offs, const int* rows, const int* cols, void* stream);
 
 /* Grouping: between magic_group_begin() and magic_group_end(stream) up to eight calls of magic_gemm / magic_attn_fwd /
- * magic_attn_bwd / magic_linear_ln / magic_linear_lnbwd / magic_ln_bwd are recorded instead of launched; magic_group_end launches ONE kernel serving
+ * magic_attn_bwd / magic_linear_ln / magic_linear_lnbwd / magic_ln_bwd / magic_chain_fwd are recorded instead of launched; magic_group_end launches ONE kernel serving
  * the problems of the same kind / dtype / variant: GEMMs as one grouped launch (<= 8 problems), other kinds as pairs.
  * Records must be independent of each other.  Thread-local state. */
 int magic_group_begin(void);

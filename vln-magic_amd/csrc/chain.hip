@@ -1,0 +1,367 @@
+// Forward-only ROW CHAIN of a post-LN transformer block at the frozen teacher's width (H = 256, FFN 1024; gfx950, bf16 / fp16):
+//
+//   y1   = LayerNorm(in Wa^T + ba + res)                          (BertSelfOutput / the cross-attention output block)
+//   y2   = LayerNorm(gelu(y1 W1^T + bi) W2^T + bo2 + y1)          (BertIntermediate + BertOutput; optional)
+//   proj = y_last Wp^T + bp,  [M, H | 2H | 3H]                    (the NEXT attention's Q | K | V projection; optional)
+//
+// i.e. everything of a block that is per token, between two attention products, as ONE launch instead of five or six
+// (dense+LN, FFN1 GEMM, FFN2 GEMM, LayerNorm, QKV GEMM).  The teacher of the MAKD step (kdl.train_teacher = false,
+// pretrain_src/config/r2r_magic_pretrain.json:62-87) runs no backward and no dropout, so nothing is saved for one: the FFN
+// pre-activation and the GELU output never leave the CU.
+//
+// One 512-thread workgroup owns 32 rows (two 16-row MFMA tiles).  Weights are not staged through LDS: every weight element is used by
+// exactly two MFMAs of the workgroup, so each lane loads its B-fragment (8 consecutive k of one weight row, 16 bytes) from L2 straight
+// into registers (the scheme of csrc/encoder.hip at H = 128, where the fragments of a whole stage fit the register file; at H = 256 a
+// workgroup streams 1.6 MB of weights, as ONE sequence of 8-fragment chunks through a ring of four register buffers that keeps three
+// chunks -- 24 KB per wave, 192 KB per CU -- in flight across the stage boundaries: the stream is bound by the 64 B/clk a CU takes from L2,
+// which needs that much in flight at ~2 us of loaded latency).  LDS per workgroup 118 KB, one workgroup per CU, up to 256 VGPRs.
+// ALL FOUR WEIGHT MATRICES ARE READ IN FRAGMENT ORDER (magic_pack_frag_spans below; the frozen teacher packs them once).
+// Two problems can share one launch (text || panorama encoder, global || local co-attention encoder):
+// group.hpp KIND_CHAIN.
+#include "enc_common.hpp"
+#include "group.hpp"
+
+#define CH 256
+#define CI 1024
+#define CP 264        // row pitch of the [16][256] images: 528 B = 33 16-byte slots
+#define CG 1032       // row pitch of the [16][1024] GELU image: 2064 B = 129 slots
+
+struct ChainParams {
+  int M, ld_in, Np, pad_;
+  const void* in; const void* res;                                           // [M, H] (pitch ld_in), [M, H]
+  const void* Wa; const float* ba; const float* g1; const float* b1; void* y1;   // y1 may be NULL (not stored)
+  const void* W1; const float* bi; const void* W2; const float* bo2; const float* g2; const float* b2; void* y2;   // W1 NULL: no FFN
+  const void* Wp; const float* bp; void* proj;                               // Wp NULL: no projection; [Np, H] -> [M, Np]
+  float eps; int pad2_;
+};
+
+#define CRT 2          // 16-row tiles per workgroup
+#define CROWS (16 * CRT)
+#define CNB 4          // weight-fragment chunks (8 fragments = 8 KB per wave each) in the register ring: CNB - 1 are in flight ahead of the MFMAs
+
+// LayerNorm over CROWS rows x 256 columns held as CRT x 2 16x16 accumulator tiles per wave (columns (2w + ct) * 16 + c16)
+template <typename Hh>
+__device__ __forceinline__ void chain_norm(f32x4 (&acc)[CRT][2], const float (&bv)[2], const float (&gv)[2], const float (&btv)[2], const Hh* sR,
+                                           float* red, Hh* sOut, const int nq, const float eps, const int w, const int lane) {
+  const int g = lane >> 4, c16 = lane & 15;
+  float s[CRT][4];
+#pragma unroll
+  for (int rt = 0; rt < CRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rt * 16 + 4 * g + r;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[rt][ct][r] += bv[ct] + to_f(sR[row * CP + (2 * w + ct) * 16 + c16]);
+      s[rt][r] = g16_sum(acc[rt][0][r] + acc[rt][1][r]);
+    }
+  if (c16 == 0) {
+#pragma unroll
+    for (int rt = 0; rt < CRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w * CROWS + rt * 16 + 4 * g + r] = s[rt][r];
+  }
+  __syncthreads();
+  float mean[CRT][4];
+#pragma unroll
+  for (int rt = 0; rt < CRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * CROWS + rt * 16 + 4 * g + r];
+      mean[rt][r] = t * (1.0f / CH);
+      const float d0 = acc[rt][0][r] - mean[rt][r], d1 = acc[rt][1][r] - mean[rt][r];
+      s[rt][r] = g16_sum(d0 * d0 + d1 * d1);
+    }
+  if (c16 == 0) {
+#pragma unroll
+    for (int rt = 0; rt < CRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[NWAVE * CROWS + w * CROWS + rt * 16 + 4 * g + r] = s[rt][r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < CRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = rt * 16 + 4 * g + r;
+      float t = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NWAVE; ++ww) t += red[NWAVE * CROWS + ww * CROWS + rr];
+      const float rstd = rsqrtf(t * (1.0f / CH) + eps);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        sOut[rr * CP + (2 * w + ct) * 16 + c16] = (rr < nq) ? from_f<Hh>((acc[rt][ct][r] - mean[rt][r]) * rstd * gv[ct] + btv[ct]) : (Hh)0.0f;
+    }
+}
+
+template <typename Hh>
+__device__ __forceinline__ void chain_rows_in(const Hh* src, long long ld, int nq, Hh* dst, int tid) {
+  // CROWS rows x 256 columns, 16-byte chunks; rows >= nq are zeros
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  for (int id = tid; id < CROWS * (CH / 8); id += NWAVE * 64) {
+    const int r = id / (CH / 8), c = (id % (CH / 8)) * 8;
+    const u4 v = r < nq ? *(const u4*)(src + r * ld + c) : (u4){0u, 0u, 0u, 0u};
+    *(u4*)(dst + r * CP + c) = v;
+  }
+}
+
+// The workgroup's weights as ONE stream of chunks of 8 fragments per wave, in the order the stages consume them:
+//   0..1   stage 1  (column tile 2w + i of Wa, 8 k-steps)                10..17 stage 2b (k-steps 4c..4c+3 of column tiles 2w, 2w + 1 of W2)
+//   2..9   stage 2a (column tile 8w + i of W1, 8 k-steps)                18..23 stage 3  (column tile w nct + j of Wp, 8 k-steps; j < nct)
+// (weights do not depend on data: the ring keeps loading across the stage boundaries and their barriers)
+// B fragment (nt, ks) of a weight matrix kept in FRAGMENT ORDER (magic_pack_frag_spans): the 64 lanes' 16 bytes are one contiguous KB.
+// (The row-major form -- lane l reads 16 bytes of weight row l & 15 -- touches 16 cache lines per quarter-wave: measured 12 B/clk per CU.)
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> pfrag(const Hh* __restrict__ Wf, const int K, const int nt, const int ks, const int lane) {
+  return *(const h16x8<Hh>*)(Wf + ((long long)(nt * (K >> 5) + ks) * 64 + lane) * 8);
+}
+
+template <typename Hh>
+__device__ __forceinline__ void chain_load_chunk(h16x8<Hh> (&b)[8], const int cid, const ChainParams& p, const int w, const int lane, const int nct) {
+  if (cid < 2) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag((const Hh*)p.Wa, CH, 2 * w + cid, ks, lane);
+  } else if (cid < 10) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag((const Hh*)p.W1, CH, 8 * w + cid - 2, ks, lane);
+  } else if (cid < 18) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      b[ks] = pfrag((const Hh*)p.W2, CI, 2 * w, 4 * (cid - 10) + ks, lane);
+      b[4 + ks] = pfrag((const Hh*)p.W2, CI, 2 * w + 1, 4 * (cid - 10) + ks, lane);
+    }
+  } else if (cid - 18 < nct) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag((const Hh*)p.Wp, CH, w * nct + cid - 18, ks, lane);
+  }
+}
+
+template <typename Hh, bool FFN>
+__device__ __forceinline__ void chain_body(const ChainParams& p, const int tile, unsigned char* smem) {
+  Hh* sIn = (Hh*)smem;                      // [CROWS][CP]  stage-1 input; later the block output y2
+  Hh* sRes = sIn + CROWS * CP;              // [CROWS][CP]  residual of stage 1
+  Hh* sY1 = sRes + CROWS * CP;              // [CROWS][CP]
+  Hh* sG = sY1 + CROWS * CP;                // [CROWS][CG]  GELU output; later the projection image [CROWS][Np + 8]
+  float* red = (float*)(sG + CROWS * CG);   // [2][8][CROWS]
+  const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = lane0;
+  asm volatile("" : "+v"(lane));
+  const int g = lane >> 4, c16 = lane & 15;
+  const int row0 = tile * CROWS, nq = min(CROWS, p.M - row0);
+  const int nct = p.Wp ? (p.Np >> 7) : 0;
+  constexpr int NS = FFN ? 24 : 8;          // chunks in this variant's stream; SEQ(s): stream position -> chunk id
+#define SEQ(s) (FFN ? (s) : ((s) < 2 ? (s) : (s) + 16))
+#define AHEAD(s) do { if ((s) + CNB - 1 < NS) chain_load_chunk<Hh>(ring[((s) + CNB - 1) % CNB], SEQ((s) + CNB - 1), p, w, lane, nct); } while (0)
+  h16x8<Hh> ring[CNB][8];
+#pragma unroll
+  for (int s = 0; s < CNB - 1; ++s) chain_load_chunk<Hh>(ring[s], SEQ(s), p, w, lane, nct);
+  chain_rows_in((const Hh*)p.in + (long long)row0 * p.ld_in, p.ld_in, nq, sIn, tid);
+  chain_rows_in((const Hh*)p.res + (long long)row0 * CH, CH, nq, sRes, tid);
+  float bv[2], gv[2], btv[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = (2 * w + ct) * 16 + c16;
+    bv[ct] = p.ba[col]; gv[ct] = p.g1[col]; btv[ct] = p.b1[col];
+  }
+  __syncthreads();
+  // ================= 1: y1 = LayerNorm(in Wa^T + ba + res) =================
+  {
+    f32x4 acc[CRT][2];
+#pragma unroll
+    for (int rt = 0; rt < CRT; ++rt) { acc[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      AHEAD(i);
+      KSTEP_FENCE();
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int rt = 0; rt < CRT; ++rt) acc[rt][i] = emma(lfrag(sIn, CP, rt * 16, ks * 32, lane), ring[i % CNB][ks], acc[rt][i]);
+      KSTEP_FENCE();
+    }
+    chain_norm(acc, bv, gv, btv, sRes, red, sY1, nq, p.eps, w, lane);
+  }
+  __syncthreads();
+  if (p.y1) copy_out(sY1, CP, (Hh*)p.y1 + (long long)row0 * CH, CH, nq, CH, tid);
+  const Hh* sLast = sY1;
+  if constexpr (FFN) {
+    // ================= 2a: g = gelu(y1 W1^T + bi): 8 column tiles per wave =================
+    {
+      h16x8<Hh> af[CRT][8];
+#pragma unroll
+      for (int rt = 0; rt < CRT; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) af[rt][ks] = lfrag(sY1, CP, rt * 16, ks * 32, lane);
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        AHEAD(2 + ct);
+        const int col = (8 * w + ct) * 16 + c16;
+        const float bfc = p.bi[col];
+        KSTEP_FENCE();
+        f32x4 acc[CRT];
+#pragma unroll
+        for (int rt = 0; rt < CRT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(af[rt][ks], ring[(2 + ct) % CNB][ks], acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < CRT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sG[(rt * 16 + 4 * g + r) * CG + col] = from_f<Hh>(gelu_fast(acc[rt][r] + bfc));
+        KSTEP_FENCE();
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int col = (2 * w + ct) * 16 + c16;
+      bv[ct] = p.bo2[col]; gv[ct] = p.g2[col]; btv[ct] = p.b2[col];
+    }
+    __syncthreads();
+    // ================= 2b: y2 = LayerNorm(g W2^T + bo2 + y1): K = 1024 in 8 chunks of 4 k-steps x 2 column tiles =================
+    {
+      f32x4 acc[CRT][2];
+#pragma unroll
+      for (int rt = 0; rt < CRT; ++rt) { acc[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        AHEAD(10 + ch);
+        KSTEP_FENCE();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int rt = 0; rt < CRT; ++rt) {
+            const h16x8<Hh> a = lfrag(sG, CG, rt * 16, (4 * ch + ks) * 32, lane);
+            acc[rt][0] = emma(a, ring[(10 + ch) % CNB][ks], acc[rt][0]);
+            acc[rt][1] = emma(a, ring[(10 + ch) % CNB][4 + ks], acc[rt][1]);
+          }
+        KSTEP_FENCE();
+      }
+      chain_norm(acc, bv, gv, btv, sY1, red, sIn, nq, p.eps, w, lane);
+    }
+    __syncthreads();
+    copy_out(sIn, CP, (Hh*)p.y2 + (long long)row0 * CH, CH, nq, CH, tid);
+    sLast = sIn;
+  }
+  if (nct) {
+    // ================= 3: proj = y_last Wp^T + bp, nct = Np / 128 column tiles per wave =================
+    constexpr int S3 = FFN ? 18 : 2;
+    const int pp = p.Np + 8;
+    h16x8<Hh> af[CRT][8];
+#pragma unroll
+    for (int rt = 0; rt < CRT; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) af[rt][ks] = lfrag(sLast, CP, rt * 16, ks * 32, lane);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      AHEAD(S3 + j);
+      if (j < nct) {
+        const int tile_n = w * nct + j;
+        const float bpv = p.bp[tile_n * 16 + c16];
+        KSTEP_FENCE();
+        f32x4 acc[CRT];
+#pragma unroll
+        for (int rt = 0; rt < CRT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(af[rt][ks], ring[(S3 + j) % CNB][ks], acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < CRT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sG[(rt * 16 + 4 * g + r) * pp + tile_n * 16 + c16] = from_f<Hh>(acc[rt][r] + bpv);
+      }
+      KSTEP_FENCE();
+    }
+    __syncthreads();
+    copy_out(sG, pp, (Hh*)p.proj + (long long)row0 * p.Np, p.Np, nq, p.Np, tid);
+  }
+#undef SEQ
+#undef AHEAD
+}
+
+template <typename Hh>
+__global__ __launch_bounds__(512) void chain_fwd_kernel(ChainParams pa, ChainParams pb, int split) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  const bool first = (int)blockIdx.x < split;
+  const ChainParams& p = first ? pa : pb;
+  const int tile = first ? blockIdx.x : blockIdx.x - split;
+  if (p.W1) chain_body<Hh, true>(p, tile, chain_smem);
+  else chain_body<Hh, false>(p, tile, chain_smem);
+}
+
+static size_t chain_lds_bytes() { return (size_t)(3 * CROWS * CP + CROWS * CG) * 2 + 2 * NWAVE * CROWS * sizeof(float); }
+
+static bool chain_valid(const ChainParams& p) {
+  if (p.M <= 0 || !p.in || !p.res || !p.Wa || !p.ba || !p.g1 || !p.b1 || p.ld_in < CH || (p.ld_in & 7)) return false;
+  if (p.W1 && (!p.bi || !p.W2 || !p.bo2 || !p.g2 || !p.b2 || !p.y2)) return false;
+  if (p.Wp && (!p.bp || !p.proj || (p.Np != CH && p.Np != 2 * CH && p.Np != 3 * CH))) return false;
+  if (!p.W1 && !p.y1 && !p.Wp) return false;          // nothing would be written
+  return true;
+}
+
+int launch_chain(int dtype, int variant, const void* pa_, const void* pb_, hipStream_t st) {
+  (void)variant;
+  const ChainParams& pa = *(const ChainParams*)pa_;
+  const ChainParams& pb = pb_ ? *(const ChainParams*)pb_ : pa;
+  const int ta = (pa.M + CROWS - 1) / CROWS, tb = pb_ ? (pb.M + CROWS - 1) / CROWS : 0;
+  static bool attr_done[3] = {false, false, false};
+  const size_t lds = chain_lds_bytes();
+  if (dtype == DT_BF16) {
+    if (!attr_done[DT_BF16]) { hipFuncSetAttribute((const void*)chain_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[DT_BF16] = true; }
+    hipLaunchKernelGGL(chain_fwd_kernel<bf16>, dim3(ta + tb), dim3(512), lds, st, pa, pb, ta);
+  } else {
+    if (!attr_done[DT_F16]) { hipFuncSetAttribute((const void*)chain_fwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[DT_F16] = true; }
+    hipLaunchKernelGGL(chain_fwd_kernel<f16>, dim3(ta + tb), dim3(512), lds, st, pa, pb, ta);
+  }
+  return launch_status();
+}
+
+// ---- weights in MFMA-fragment order -------------------------------------------------------------------------------------------
+// dst[off ..) of a [rows, cols] row-major matrix at src[off ..): for every 16-row x 32-column fragment (row tile nt, k-step ks) the 64
+// lanes' operands back to back -- chunk ((nt (cols / 32) + ks) 64 + l) holds src[(16 nt + (l & 15)) cols + 32 ks + 8 (l >> 4) .. + 7].
+// Same calling convention as magic_transpose_spans; 2-byte elements of either 16-bit type.
+#define FSP_MAX 160
+struct FSpans { long long off[FSP_MAX]; int rows[FSP_MAX]; int cols[FSP_MAX]; int blk0[FSP_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void pack_frag_spans_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, FSpans t) {
+  typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+  const int id = blockIdx.x;
+  int s = 0;
+  for (int i = 1; i < t.n; ++i) s += (id >= t.blk0[i]) ? 1 : 0;
+  const int C = t.cols[s];
+  const long long chunk = (long long)(id - t.blk0[s]) * 256 + threadIdx.x;      // 16-byte chunk of the packed span
+  const int l = (int)(chunk & 63);
+  const long long frag = chunk >> 6;
+  const int kpr = C >> 5, nt = (int)(frag / kpr), ks = (int)(frag % kpr);
+  const unsigned short* a = src + t.off[s] + (long long)(16 * nt + (l & 15)) * C + 32 * ks + 8 * (l >> 4);
+  *(u16x8*)(dst + t.off[s] + chunk * 8) = *(const u16x8*)a;
+}
+extern "C" int magic_pack_frag_spans(const void* src, void* dst, int n, const long long* offs, const int* rows, const int* cols, void* stream) {
+  if (!src || !dst || n < 0 || (n && (!offs || !rows || !cols)) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return MAGIC_ERR_ARG;
+  for (int i = 0; i < n; ++i)
+    if (rows[i] <= 0 || cols[i] <= 0 || rows[i] % 16 || cols[i] % 32 || ((long long)rows[i] * cols[i]) % 2048 || offs[i] % 8) return MAGIC_ERR_ARG;
+  for (int base = 0; base < n; base += FSP_MAX) {
+    FSpans t;
+    t.n = n - base < FSP_MAX ? n - base : FSP_MAX;
+    int blocks = 0;
+    for (int i = 0; i < t.n; ++i) {
+      t.off[i] = offs[base + i]; t.rows[i] = rows[base + i]; t.cols[i] = cols[base + i];
+      t.blk0[i] = blocks;
+      blocks += (int)(((long long)rows[base + i] * cols[base + i]) / 2048);
+    }
+    t.blk0[t.n] = blocks;
+    hipLaunchKernelGGL(pack_frag_spans_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src, (unsigned short*)dst, t);
+  }
+  return launch_status();
+}
+
+extern "C" int magic_chain_supported(int dtype, int H, int I) { return dtype_is16(dtype) && H == CH && I == CI; }
+
+extern "C" int magic_chain_fwd(int dtype, const void* params, int nbytes, void* stream) {
+  if (!params || nbytes != (int)sizeof(ChainParams) || !dtype_is16(dtype)) return MAGIC_ERR_ARG;
+  ChainParams p;
+  memcpy(&p, params, sizeof(p));
+  if (!chain_valid(p)) return MAGIC_ERR_ARG;
+  if (group_record(KIND_CHAIN, dtype, 0, &p, sizeof(p))) return MAGIC_OK;
+  return launch_chain(dtype, 0, &p, nullptr, (hipStream_t)stream);
+}

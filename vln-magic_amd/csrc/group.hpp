@@ -1,5 +1,5 @@
 // Grouping of launches: between magic_group_begin() and magic_group_end(stream) the groupable entry points
-// (magic_gemm, magic_attn_fwd/bwd, magic_linear_ln, magic_ln_bwd) RECORD their validated parameter blocks instead of
+// (magic_gemm, magic_attn_fwd/bwd, magic_linear_ln, magic_ln_bwd, magic_chain_fwd) RECORD their validated parameter blocks instead of
 // launching; magic_group_end() then issues ONE kernel that serves both problems (block id < split -> problem A, else B)
 // when the two records are compatible, or launches them one after the other otherwise.  Used by the host to run two
 // independent same-shaped sub-networks (global || local co-attention encoders, text || panorama encoders) in lockstep
@@ -8,7 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 
-enum GroupKind { KIND_NONE = 0, KIND_GEMM = 1, KIND_ATTN_FWD = 2, KIND_ATTN_BWD = 3, KIND_LLN = 4, KIND_LNB = 5, KIND_LLB = 7 };
+enum GroupKind { KIND_NONE = 0, KIND_GEMM = 1, KIND_ATTN_FWD = 2, KIND_ATTN_BWD = 3, KIND_LLN = 4, KIND_LNB = 5, KIND_LLB = 7, KIND_CHAIN = 8 };
 
 struct GroupRec { int kind, dtype, variant; alignas(16) unsigned char blob[1024]; };
 #define GROUP_CAP 8
@@ -34,3 +34,4 @@ int launch_attn_bwd(int dtype, int variant, const void* pa, const void* pb, hipS
 int launch_lln(int dtype, int ht, const void* pa, const void* pb, hipStream_t st);
 int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t st);
 int launch_llb(int dtype, int ht, const void* pa, const void* pb, hipStream_t st);
+int launch_chain(int dtype, int variant, const void* pa, const void* pb, hipStream_t st);

@@ -122,6 +122,15 @@ class Lin:
         return t
 
 
+    @property
+    def Wf(self):
+        """W in MFMA-fragment order (flat; csrc/chain.hip reads it); registers the span on first use"""
+        t = getattr(self, "_Wf", None)
+        if t is None:
+            t = self._Wf = self._store.f_span(self._wname, self.N, self.K)
+        return t
+
+
 class LN:
     def __init__(self, store, wname, bname):
         self.g, self.b = store.master(wname), store.master(bname)
@@ -252,8 +261,23 @@ class MagicNet:
         O.gemm(2, dS, q, dk, Nk, HD, Nq, ldp, ldq, lddkv, batch=Bn * nh, nh=nh, sA=sP, sB=(Nq * ldq, HD), sC=(Nk * lddkv, HD), flop_dims=fd)
 
     # ---- self-attention + add&norm -------------------------------------------------------------
-    def _sa_attn_fwd(self, lp, x, Bn, N, kmask, dist, sprel, rows, aflops, qkv=None):
-        """Q/K/V projection (unless the previous block's row-block chain already produced it) + the attention product"""
+    def chain_ok(self):
+        """forward-only row chain (csrc/chain.hip): a frozen network (no backward, no dropout) at the teacher's width"""
+        return (not self.train) and self.drop is None and O.chain_ok(self.dtype, self.H, self.I)
+
+    def _ffn_args(self, lp):
+        f1, f2, n = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.ln(lp + "output.LayerNorm")
+        return (f1.Wf, f1.b, f2.Wf, f2.b, n.g, n.b, f1.N)
+
+    def _next_qkv(self, next_lp, M):
+        """(weights of the following block's fused Q|K|V projection, its output buffer) or (None, None)"""
+        if next_lp is None:
+            return None, None
+        ql = self.lin(next_lp + "attention.self.query.weight", rows=3 * self.H, cols=self.H)
+        return (ql.Wf, ql.b, 3 * self.H), self.new(M, 3 * self.H)
+
+    def _sa_attn_fwd(self, lp, x, Bn, N, kmask, dist, sprel, rows, aflops, qkv=None, alloc_a=True):
+        """Q/K/V projection (unless the previous block's row chain already produced it) + the attention product"""
         H = self.H
         M = Bn * N
         c = Ctx(x=x, Bn=Bn, N=N, rows=rows, aflops=aflops, dist=dist)
@@ -264,7 +288,8 @@ class MagicNet:
         c.adrop, c.hdrop = self._da(lp + "attention.self.dropout"), self._dh(lp + "attention.output.dropout")
         c.Ppre, c.ctx, c.ldp, c.P = self._attn_fwd(c.qkv, 3 * H, c.qkv[:, H:], c.qkv[:, 2 * H:], 3 * H, Bn, N, N, kmask, dist, sprel,
                                                    aflops, c.adrop)
-        c.a, c.rstd_a = self.new(M, H), self.new(M, dtype=torch.float32)
+        if alloc_a:
+            c.a, c.rstd_a = self.new(M, H), self.new(M, dtype=torch.float32)
         return c
 
     def _sa_out_fwd(self, lp, c):
@@ -364,6 +389,17 @@ class MagicNet:
         projection this block's chain produces (returned as c.next_qkv)."""
         c = Ctx(next_qkv=None)
         M = Bn * N
+        if self.chain_ok():
+            # frozen network: attention product, then everything per token up to the next block's Q|K|V projection as ONE launch
+            c.sa = self._sa_attn_fwd(lp, x, Bn, N, kmask, None, None, rows, aflops, qkv, alloc_a=False)
+            o, n1 = self.lin(lp + "attention.output.dense.weight"), self.ln(lp + "attention.output.LayerNorm")
+            proj, c.next_qkv = self._next_qkv(next_lp, M)
+            c.out = self.new(M, self.H)
+            O.chain_fwd(c.sa.ctx, x, M, o.Wf, o.b, n1.g, n1.b, self.eps, ffn=self._ffn_args(lp), y2=c.out, proj=proj, proj_out=c.next_qkv,
+                        flop_rows=rows)
+            c.ffn = Ctx(out=c.out)
+            c.P, c.ldp = c.sa.P, c.sa.ldp
+            return c
         c.sa = self._sa_fwd(lp, x, Bn, N, kmask, None, None, rows, aflops, qkv)
         c.ffn = self._ffn_fwd(lp, c.sa.a, M, rows)
         c.out, c.P, c.ldp = c.ffn.out, c.sa.P, c.sa.ldp
@@ -388,14 +424,28 @@ class MagicNet:
         c = Ctx(Bn=Bn, Nq=Nq, Nk=Nk, ctx=ctx, rows=rows, crow=crow, cflops=cflops, next_qkv=None, kv_given=kv is not None)
         ql = self.lin(lp + "crossattention.self.query.weight")
         kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
-        c.sa = self._sa_fwd(lp, x, Bn, Nq, kmask, dist, sprel, rows, sflops, qkv)
-        c.q = O.linear_fwd(c.sa.a, ql.W, ql.b, Mq, flop_rows=rows)
+        chain = self.chain_ok()
+        if chain:         # self-attention output block + the cross-attention's query projection: one launch
+            c.sa = self._sa_attn_fwd(lp, x, Bn, Nq, kmask, dist, sprel, rows, sflops, qkv, alloc_a=False)
+            so, sn = self.lin(lp + "attention.output.dense.weight"), self.ln(lp + "attention.output.LayerNorm")
+            c.sa.a, c.q = self.new(Mq, H), self.new(Mq, H)
+            O.chain_fwd(c.sa.ctx, x, Mq, so.Wf, so.b, sn.g, sn.b, self.eps, y1=c.sa.a, proj=(ql.Wf, ql.b, H), proj_out=c.q, flop_rows=rows)
+        else:
+            c.sa = self._sa_fwd(lp, x, Bn, Nq, kmask, dist, sprel, rows, sflops, qkv)
+            c.q = O.linear_fwd(c.sa.a, ql.W, ql.b, Mq, flop_rows=rows)
         s = c.sa.a
         c.kv = kv if kv is not None else O.linear_fwd(ctx, kvl.W, kvl.b, Mk, flop_rows=crow)
         c.adrop, c.hdrop = self._da(lp + "crossattention.self.dropout"), self._dh(lp + "crossattention.output.dropout")
         c.Ppre, c.cctx, c.ldp, c.P = self._attn_fwd(c.q, H, c.kv, c.kv[:, H:], 2 * H, Bn, Nq, Nk, ckmask, None, None, cflops, c.adrop)
         o = self.lin(lp + "crossattention.output.dense.weight")
         n = self.ln(lp + "crossattention.output.LayerNorm")
+        if chain:         # cross-attention output block + FFN + the next block's Q|K|V projection: one launch
+            proj, c.next_qkv = self._next_qkv(next_lp, Mq)
+            c.out = self.new(Mq, H)
+            O.chain_fwd(c.cctx, s, Mq, o.Wf, o.b, n.g, n.b, self.eps, ffn=self._ffn_args(lp), y2=c.out, proj=proj, proj_out=c.next_qkv,
+                        flop_rows=rows)
+            c.ffn = Ctx(out=c.out)
+            return c
         c.c, c.rstd_c = self.new(Mq, H), self.new(Mq, dtype=torch.float32)
         self._dense_add_ln(c.cctx, o, s, n, Mq, c.c, c.rstd_c, rows, c.hdrop)
         c.ffn = self._ffn_fwd(lp, c.c, Mq, rows)

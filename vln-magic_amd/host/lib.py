@@ -72,6 +72,8 @@ SIGNATURES = {
     "magic_encoder_supported": [i32, i32, i32, i32, i32, i32],
     "magic_encoder_params_bytes": [],
     "magic_encoder_fwd": [i32, vp, i32, vp],
+    "magic_chain_supported": [i32, i32, i32],
+    "magic_chain_fwd": [i32, vp, i32, vp],
     "magic_xencoder_supported": [i32, i32, i32, i32, i32, i32, i32],
     "magic_xencoder_params_bytes": [],
     "magic_xencoder_fwd": [i32, vp, i32, vp],
@@ -79,6 +81,7 @@ SIGNATURES = {
     "magic_rowbwd_params_bytes": [],
     "magic_rowbwd": [i32, vp, i32, vp],
     "magic_transpose_spans": [vp, vp, i32, vp, vp, vp, vp],
+    "magic_pack_frag_spans": [vp, vp, i32, vp, vp, vp, vp],
     "magic_group_begin": [],
     "magic_group_end": [vp],
 }
@@ -132,6 +135,13 @@ class EncSeg(C.Structure):
 class EncParams(C.Structure):
     _fields_ = [("seg", EncSeg * 2), ("nseg", i32), ("p_attn", f32), ("p_hidden", f32), ("eps", f32), ("scale", f32), ("seed", vp),
                 ("sync", vp), ("sync_words", i32), ("pad2_", i32)]
+
+
+class ChainParams(C.Structure):
+    """mirror of `magic_chain_params` (include/magic_hip.h)"""
+    _fields_ = [("M", i32), ("ld_in", i32), ("Np", i32), ("pad_", i32)] + \
+               [(n, vp) for n in ("inp", "res", "Wa", "ba", "g1", "b1", "y1", "W1", "bi", "W2", "bo2", "g2", "b2", "y2", "Wp", "bp", "proj")] + \
+               [("eps", f32), ("pad2_", i32)]
 
 
 XL_PTRS = ("Wqkv", "bqkv", "Wo", "bo", "g1", "be1", "Wq", "bq", "Wkv", "bkv", "Woc", "boc", "gc", "bec", "W1", "bi", "W2", "bo2", "g2", "be2",
@@ -241,7 +251,7 @@ def P(t):
 
 
 PROFILE = {"on": False, "events": []}     # bench.py: per-launch HIP-event timing on the launch stream
-PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_linear_lnbwd", "magic_ln_bwd"}
+PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_linear_lnbwd", "magic_ln_bwd", "magic_chain_fwd"}
 _tls = threading.local()
 
 

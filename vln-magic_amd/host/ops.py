@@ -404,6 +404,60 @@ def encoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
     L.call("magic_encoder_fwd", L.dt(dtype), C.addressof(P), C.sizeof(P), L.stream())
 
 
+FUSED_CHAIN = not os.environ.get("MAGIC_NO_CHAIN")
+_CHAIN_OK = {}
+
+
+def chain_ok(dtype, H, I):
+    """forward-only row chain (csrc/chain.hip) available? (16-bit storage, H = 256, FFN 1024: the frozen teacher's width)"""
+    if not FUSED_CHAIN or dtype not in L.HALF:
+        return False
+    key = (dtype, H, I)
+    if key not in _CHAIN_OK:
+        _CHAIN_OK[key] = bool(L.load().magic_chain_supported(L.dt(dtype), H, I))
+    return _CHAIN_OK[key]
+
+
+def pack_frag(W):
+    """[N, K] 16-bit weight -> the same elements in MFMA-fragment order (flat), as csrc/chain.hip reads them (magic_pack_frag_spans)"""
+    import ctypes as C
+    _chk(W.dtype in L.HALF and W.is_contiguous() and W.dim() == 2, "pack_frag: contiguous 16-bit matrix")
+    out = torch.empty(W.numel(), dtype=W.dtype, device=W.device)
+    off, rows, cols = (C.c_longlong * 1)(0), (C.c_int * 1)(W.shape[0]), (C.c_int * 1)(W.shape[1])
+    L.call("magic_pack_frag_spans", L.P(W), L.P(out), 1, C.addressof(off), C.addressof(rows), C.addressof(cols), L.stream())
+    return out
+
+
+def chain_fwd(x, res, M, Wa, ba, g1, b1, eps, *, y1=None, ffn=None, y2=None, proj=None, proj_out=None, flop_rows=None):
+    """y1 = LN(x Wa^T + ba + res); ffn = (W1, bi, W2, bo2, g2, b2, I): y2 = LN(gelu(y1 W1^T + bi) W2^T + bo2 + y1); proj = (Wp, bp, Np):
+    proj_out = y_last Wp^T + bp [M, Np].  Every W in fragment order (flat: pack_frag / ParamStore.f_span).  Forward only, no dropout
+    (csrc/chain.hip); pairable."""
+    import ctypes as C
+    H = res.shape[1]
+    _chk(x.dtype in L.HALF and x.stride(-1) == 1 and res.is_contiguous() and res.dtype == x.dtype, "chain inputs 16-bit, rows contiguous")
+    _chk(x.shape[0] >= M and res.shape[0] >= M and Wa.is_contiguous() and Wa.numel() == H * H and Wa.dtype == x.dtype, "chain stage 1 shapes")
+    P = L.ChainParams()
+    P.M, P.ld_in, P.eps = int(M), int(x.stride(0)), float(eps)
+    P.inp, P.res, P.Wa, P.ba, P.g1, P.b1, P.y1 = L.P(x), L.P(res), L.P(Wa), L.P(ba), L.P(g1), L.P(b1), L.P(y1)
+    fl = H * H
+    if ffn is not None:
+        W1, bi, W2, bo2, g2, b2, I = ffn
+        _chk(W1.is_contiguous() and W2.is_contiguous() and W1.numel() == I * H and W2.numel() == I * H and y2 is not None, "chain FFN shapes")
+        P.W1, P.bi, P.W2, P.bo2, P.g2, P.b2, P.y2 = L.P(W1), L.P(bi), L.P(W2), L.P(bo2), L.P(g2), L.P(b2), L.P(y2)
+        fl += 2 * H * I
+    if proj is not None:
+        Wp, bp, Np = proj
+        _chk(Wp.is_contiguous() and Wp.numel() == Np * H and proj_out is not None and proj_out.is_contiguous() and proj_out.shape[1] == Np,
+             "chain projection shapes")
+        P.Wp, P.bp, P.proj, P.Np = L.P(Wp), L.P(bp), L.P(proj_out), int(Np)
+        fl += Np * H
+    if FLOPS["enabled"]:
+        f = 2.0 * (M if flop_rows is None else flop_rows) * fl
+        FLOPS["total"] += f
+        FLOPS["enc"] += f
+    L.call("magic_chain_fwd", L.dt(x.dtype), C.addressof(P), C.sizeof(P), L.stream())
+
+
 FUSED_RBW = not os.environ.get("MAGIC_NO_FUSED_RBW")
 _RBW_OK = {}
 

@@ -88,6 +88,10 @@ class ParamStore:
         self.shadow_t = None
         self.t_spans = {}
         self.shadow_t_clean = False
+        # the same for matrices a kernel reads in MFMA-fragment order (csrc/chain.hip): f_span()
+        self.shadow_f = None
+        self.f_spans = {}
+        self.shadow_f_clean = False
         if requires_grad and self.half:
             _LIVE.add(self)
             _install_optimizer_hook()
@@ -132,6 +136,35 @@ class ParamStore:
             if self.shadow_clean and self.device.type == "cuda":      # registered after the shadow was last refreshed: fill it in now
                 self.sync_shadow_t(force=True)
         return self.shadow_t[off:off + rows * cols].view(cols, rows)
+
+    def f_span(self, first, rows, cols):
+        """the [rows, cols] span starting at `first` in MFMA-FRAGMENT ORDER (magic_pack_frag_spans: every 16 x 32 fragment's 64 lane operands
+        contiguous), as a flat compute-dtype view; kept current by sync_shadow"""
+        off = self.offsets[first][0]
+        if self.shadow_f is None:
+            self.shadow_f = torch.zeros(self.total, dtype=self.compute_dtype, device=self.device)
+        if off not in self.f_spans:
+            self.f_spans[off] = (rows, cols)
+            self.shadow_f_clean = False
+            self._f_arrays = None
+            if self.shadow_clean and self.device.type == "cuda":
+                self.sync_shadow_f(force=True)
+        return self.shadow_f[off:off + rows * cols]
+
+    def sync_shadow_f(self, force=False):
+        """one launch: every registered span of the (clean) shadow -> fragment order"""
+        if not self.f_spans or (self.shadow_f_clean and not force):
+            return
+        import ctypes as C
+        from . import lib as L
+        if getattr(self, "_f_arrays", None) is None:
+            offs = sorted(self.f_spans)
+            n = len(offs)
+            self._f_arrays = (n, (C.c_longlong * n)(*offs), (C.c_int * n)(*[self.f_spans[o][0] for o in offs]),
+                              (C.c_int * n)(*[self.f_spans[o][1] for o in offs]))
+        n, a_off, a_rows, a_cols = self._f_arrays
+        L.call("magic_pack_frag_spans", L.P(self.shadow), L.P(self.shadow_f), n, C.addressof(a_off), C.addressof(a_rows), C.addressof(a_cols), L.stream())
+        self.shadow_f_clean = True
 
     def sync_shadow_t(self, force=False):
         """one launch: every registered span of the (clean) shadow -> its transpose"""
@@ -222,7 +255,9 @@ class ParamStore:
             L.call("magic_cast", L.dt(self.compute_dtype), 1, self.total, L.P(self.flat), L.P(self.shadow), L.stream())
             self.shadow_clean = True
             self.shadow_t_clean = False
+            self.shadow_f_clean = False
         self.sync_shadow_t()
+        self.sync_shadow_f()
 
     def zero_grad(self):
         self.grad.zero_()

@@ -86,6 +86,47 @@ LATE_PREFIXES = ("bert.global_encoder.", "vln_bert.global_encoder.")
 EMB_TABLE = "bert.embeddings.word_embeddings.weight"
 
 
+def cu_mask_words(spec, n_cu=256):
+    """`N` | `N:low` | `N:spread` | `N:xcd` -> the 32-bit words of a compute-unit mask with N bits set (hipExtStreamCreateWithCUMask: bit i =
+    CU i): low = the first N, spread = every (n_cu / N)-th, xcd = the first N / 8 of every block of n_cu / 8"""
+    n, _, how = str(spec).partition(":")
+    n = max(1, min(int(n), n_cu))
+    how = how or "spread"
+    if how == "low":
+        bits = range(n)
+    elif how == "xcd":
+        per = max(1, n // 8)
+        bits = [x * (n_cu // 8) + i for x in range(8) for i in range(per)]
+    elif how == "spread":
+        bits = [i * n_cu // n for i in range(n)]
+    else:
+        raise ValueError(f"compute-unit mask pattern {how!r}")
+    words = [0] * ((n_cu + 31) // 32)
+    for b in bits:
+        words[b // 32] |= 1 << (b % 32)
+    return words
+
+
+def _side_stream(dev):
+    """the frozen teacher's stream.  MAGIC_TEACHER_CUS=N[:pattern] confines it to N compute units (a queue property, honoured under graph
+    replay as long as the graph is launched on this stream): the teacher is off the critical path, its launches then stop taking CUs from
+    the student's in bursts.  Opt-in: see DESIGN.md section 5 for what it measured."""
+    spec = os.environ.get("MAGIC_TEACHER_CUS")
+    if not spec:
+        return torch.cuda.Stream()
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    words = cu_mask_words(spec, n_cu)
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), len(words), arr)
+    if rc != 0 or not h.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask({spec}) failed: {rc}")
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 class GradSync:
     """Data-parallel gradient exchange on the flat fp32 gradient buffer, RCCL through torch.distributed, on a side stream; the
     1/world scaling is folded into the AdamW kernel.  Replaces DDP(model, find_unused_parameters=True) of
@@ -292,7 +333,7 @@ class PretrainStep:
         self.on_gpu = self.dev.type == "cuda"
         self.side = None
         if self.on_gpu and teacher is not None and overlap_teacher and not os.environ.get("MAGIC_NO_TEACHER_SIDE"):
-            self.side = torch.cuda.Stream()
+            self.side = _side_stream(self.dev)
         if self.on_gpu and overlap_dw and O.SIDE["stream"] is None and os.environ.get("MAGIC_DW_SIDE"):   # opt-in: no gain measured on MI355X
             O.SIDE["stream"] = torch.cuda.Stream()       # weight-gradient GEMMs leave the dX critical chain
         self.global_step = 0

@@ -268,7 +268,10 @@ int magic_get_f32_mfma(void);
  * bf16, H = 128, 2 heads, FFN 512, <= 80 tokens per sample, <= 6 layers per encoder, 1 or 2 encoders ("segments") per launch.
  * Writes exactly what the per-op backward kernels read: qkv [M,3H], P (+ Pd under dropout) [B,2,N,ldp], ctx, a = attention-block
  * output + rstd_a, z = FFN pre-activation, g = GELU output, out + rstd_o; same rounding points and dropout masks as
- * magic_gemm / magic_attn_fwd / magic_linear_ln.  `params`: host copy of magic_enc_params, fully consumed before return. */
+ * magic_gemm / magic_attn_fwd / magic_linear_ln.  `params`: host copy of magic_enc_params, fully consumed before return.
+ * Round 3: EVERY WEIGHT MATRIX of magic_encoder_fwd / magic_xencoder_fwd (Wqkv, Wo, Wq, Wkv, Woc, W1, W2) and every transposed matrix of
+ * magic_rowbwd (WqkvT_n, WoT, W1T, W2T) is read in MFMA-FRAGMENT ORDER (magic_pack_frag_spans of the row-major matrix): the kernels load
+ * B fragments straight from L2, and a fragment of a row-major matrix costs one cache line per weight row. */
 typedef struct {
   const void* Wqkv; const float* bqkv; const void* Wo; const float* bo; const float* g1; const float* be1;
   const void* W1; const float* bi; const void* W2; const float* bo2; const float* g2; const float* be2;

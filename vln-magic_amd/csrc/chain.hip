@@ -41,9 +41,15 @@ struct ChainParams {
 
 // LayerNorm over CROWS rows x 256 columns held as CRT x 2 16x16 accumulator tiles per wave (columns (2w + ct) * 16 + c16)
 template <typename Hh>
-__device__ __forceinline__ void chain_norm(f32x4 (&acc)[CRT][2], const float (&bv)[2], const float (&gv)[2], const float (&btv)[2], const Hh* sR,
+__device__ __forceinline__ void chain_norm(f32x4 (&acc)[CRT][2], const float* sPar, const Hh* sR,
                                            float* red, Hh* sOut, const int nq, const float eps, const int w, const int lane) {
   const int g = lane >> 4, c16 = lane & 15;
+  float bv[2], gv[2], btv[2];           // bias | gamma | beta of this lane's two columns: staged in LDS by the prologue (see chain_body)
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = (2 * w + ct) * 16 + c16;
+    bv[ct] = sPar[col]; gv[ct] = sPar[CH + col]; btv[ct] = sPar[2 * CH + col];
+  }
   float s[CRT][4];
 #pragma unroll
   for (int rt = 0; rt < CRT; ++rt)
@@ -130,12 +136,22 @@ __device__ __forceinline__ void chain_load_chunk(h16x8<Hh> (&b)[8], const int ci
       b[ks] = pfrag((const Hh*)p.W2, CI, 2 * w, 4 * (cid - 10) + ks, lane);
       b[4 + ks] = pfrag((const Hh*)p.W2, CI, 2 * w + 1, 4 * (cid - 10) + ks, lane);
     }
-  } else if (cid - 18 < nct) {
+  } else {
+    // UNCONDITIONAL (a load the compiler cannot count makes every later wait a full drain): tiles past the projection's width re-read its
+    // last tile, a chain without a projection reads Wa's fragments -- valid addresses, unused data
+    const Hh* Wq = p.Wp ? (const Hh*)p.Wp : (const Hh*)p.Wa;
+    const int j = cid - 18, nt = p.Wp ? w * nct + (j < nct ? j : nct - 1) : 2 * w;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag((const Hh*)p.Wp, CH, w * nct + cid - 18, ks, lane);
+    for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag(Wq, CH, nt, ks, lane);
   }
 }
 
+#ifdef CHAIN_TIMING
+__device__ long long chain_ticks[16];          // wall_clock64 (100 MHz) marks of tile 0 (profiles/micro/chain_timing.hip)
+#define CH_MARK(i) do { if (tile == 0 && tid == 0) chain_ticks[i] = wall_clock64(); } while (0)
+#else
+#define CH_MARK(i)
+#endif
 template <typename Hh, bool FFN>
 __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile, unsigned char* smem) {
   Hh* sIn = (Hh*)smem;                      // [CROWS][CP]  stage-1 input; later the block output y2
@@ -143,6 +159,8 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
   Hh* sY1 = sRes + CROWS * CP;              // [CROWS][CP]
   Hh* sG = sY1 + CROWS * CP;                // [CROWS][CG]  GELU output; later the projection image [CROWS][Np + 8]
   float* red = (float*)(sG + CROWS * CG);   // [2][8][CROWS]
+  float* sPar = red + 2 * NWAVE * CROWS;    // ba | g1 | b1 | bo2 | g2 | b2 (256 each) | bi (1024) | bp (<= 768): every small parameter, staged ONCE --
+                                            // a global load between the weight chunks makes the compiler drain the whole ring (vmcnt(0)) before its use
   const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lane = lane0;
   asm volatile("" : "+v"(lane));
@@ -152,18 +170,20 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
   constexpr int NS = FFN ? 24 : 8;          // chunks in this variant's stream; SEQ(s): stream position -> chunk id
 #define SEQ(s) (FFN ? (s) : ((s) < 2 ? (s) : (s) + 16))
 #define AHEAD(s) do { if ((s) + CNB - 1 < NS) chain_load_chunk<Hh>(ring[((s) + CNB - 1) % CNB], SEQ((s) + CNB - 1), p, w, lane, nct); } while (0)
+  CH_MARK(0);
+  chain_rows_in((const Hh*)p.in + (long long)row0 * p.ld_in, p.ld_in, nq, sIn, tid);
+  chain_rows_in((const Hh*)p.res + (long long)row0 * CH, CH, nq, sRes, tid);
+  if (tid < CH) {
+    sPar[tid] = p.ba[tid]; sPar[CH + tid] = p.g1[tid]; sPar[2 * CH + tid] = p.b1[tid];
+    if (FFN) { sPar[3 * CH + tid] = p.bo2[tid]; sPar[4 * CH + tid] = p.g2[tid]; sPar[5 * CH + tid] = p.b2[tid]; }
+  }
+  if (FFN) { sPar[6 * CH + tid] = p.bi[tid]; sPar[6 * CH + 512 + tid] = p.bi[512 + tid]; }
+  for (int i = tid; i < nct * 128; i += NWAVE * 64) sPar[6 * CH + CI + i] = p.bp[i];
   h16x8<Hh> ring[CNB][8];
 #pragma unroll
   for (int s = 0; s < CNB - 1; ++s) chain_load_chunk<Hh>(ring[s], SEQ(s), p, w, lane, nct);
-  chain_rows_in((const Hh*)p.in + (long long)row0 * p.ld_in, p.ld_in, nq, sIn, tid);
-  chain_rows_in((const Hh*)p.res + (long long)row0 * CH, CH, nq, sRes, tid);
-  float bv[2], gv[2], btv[2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int col = (2 * w + ct) * 16 + c16;
-    bv[ct] = p.ba[col]; gv[ct] = p.g1[col]; btv[ct] = p.b1[col];
-  }
   __syncthreads();
+  CH_MARK(1);
   // ================= 1: y1 = LayerNorm(in Wa^T + ba + res) =================
   {
     f32x4 acc[CRT][2];
@@ -179,24 +199,22 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
         for (int rt = 0; rt < CRT; ++rt) acc[rt][i] = emma(lfrag(sIn, CP, rt * 16, ks * 32, lane), ring[i % CNB][ks], acc[rt][i]);
       KSTEP_FENCE();
     }
-    chain_norm(acc, bv, gv, btv, sRes, red, sY1, nq, p.eps, w, lane);
+    chain_norm(acc, sPar, sRes, red, sY1, nq, p.eps, w, lane);
   }
   __syncthreads();
+  CH_MARK(2);
   if (p.y1) copy_out(sY1, CP, (Hh*)p.y1 + (long long)row0 * CH, CH, nq, CH, tid);
   const Hh* sLast = sY1;
   if constexpr (FFN) {
     // ================= 2a: g = gelu(y1 W1^T + bi): 8 column tiles per wave =================
     {
-      h16x8<Hh> af[CRT][8];
-#pragma unroll
-      for (int rt = 0; rt < CRT; ++rt)
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) af[rt][ks] = lfrag(sY1, CP, rt * 16, ks * 32, lane);
+      // (the A fragments come from LDS at every use: holding the 16 of a stage in registers next to the ring spilled, and a scratch
+      // access between the weight chunks drains the ring just like any other vector-memory operation)
 #pragma unroll
       for (int ct = 0; ct < 8; ++ct) {
         AHEAD(2 + ct);
         const int col = (8 * w + ct) * 16 + c16;
-        const float bfc = p.bi[col];
+        const float bfc = sPar[6 * CH + col];
         KSTEP_FENCE();
         f32x4 acc[CRT];
 #pragma unroll
@@ -204,7 +222,7 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(af[rt][ks], ring[(2 + ct) % CNB][ks], acc[rt]);
+          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(lfrag(sY1, CP, rt * 16, ks * 32, lane), ring[(2 + ct) % CNB][ks], acc[rt]);
 #pragma unroll
         for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
@@ -212,12 +230,8 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
         KSTEP_FENCE();
       }
     }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int col = (2 * w + ct) * 16 + c16;
-      bv[ct] = p.bo2[col]; gv[ct] = p.g2[col]; btv[ct] = p.b2[col];
-    }
     __syncthreads();
+    CH_MARK(3);
     // ================= 2b: y2 = LayerNorm(g W2^T + bo2 + y1): K = 1024 in 8 chunks of 4 k-steps x 2 column tiles =================
     {
       f32x4 acc[CRT][2];
@@ -237,9 +251,10 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
           }
         KSTEP_FENCE();
       }
-      chain_norm(acc, bv, gv, btv, sY1, red, sIn, nq, p.eps, w, lane);
+      chain_norm(acc, sPar + 3 * CH, sY1, red, sIn, nq, p.eps, w, lane);
     }
     __syncthreads();
+    CH_MARK(4);
     copy_out(sIn, CP, (Hh*)p.y2 + (long long)row0 * CH, CH, nq, CH, tid);
     sLast = sIn;
   }
@@ -247,17 +262,12 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
     // ================= 3: proj = y_last Wp^T + bp, nct = Np / 128 column tiles per wave =================
     constexpr int S3 = FFN ? 18 : 2;
     const int pp = p.Np + 8;
-    h16x8<Hh> af[CRT][8];
-#pragma unroll
-    for (int rt = 0; rt < CRT; ++rt)
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) af[rt][ks] = lfrag(sLast, CP, rt * 16, ks * 32, lane);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       AHEAD(S3 + j);
       if (j < nct) {
         const int tile_n = w * nct + j;
-        const float bpv = p.bp[tile_n * 16 + c16];
+        const float bpv = sPar[6 * CH + CI + tile_n * 16 + c16];
         KSTEP_FENCE();
         f32x4 acc[CRT];
 #pragma unroll
@@ -265,7 +275,7 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(af[rt][ks], ring[(S3 + j) % CNB][ks], acc[rt]);
+          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(lfrag(sLast, CP, rt * 16, ks * 32, lane), ring[(S3 + j) % CNB][ks], acc[rt]);
 #pragma unroll
         for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
@@ -274,23 +284,28 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
       KSTEP_FENCE();
     }
     __syncthreads();
+    CH_MARK(5);
     copy_out(sG, pp, (Hh*)p.proj + (long long)row0 * p.Np, p.Np, nq, p.Np, tid);
   }
+  CH_MARK(6);
 #undef SEQ
 #undef AHEAD
 }
 
+// (the two problems as an ARRAY in the kernel-argument segment: `pr.p[which]` becomes scalar loads at a computed offset where they are used;
+// selecting between two by-value structs kept both in SGPRs and spilled 159 of them into vector registers)
+struct ChainPair { ChainParams p[2]; int split; };
 template <typename Hh>
-__global__ __launch_bounds__(512) void chain_fwd_kernel(ChainParams pa, ChainParams pb, int split) {
+__global__ __launch_bounds__(512) void chain_fwd_kernel(ChainPair pr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
-  const bool first = (int)blockIdx.x < split;
-  const ChainParams& p = first ? pa : pb;
-  const int tile = first ? blockIdx.x : blockIdx.x - split;
+  const int which = (int)blockIdx.x < pr.split ? 0 : 1;
+  const ChainParams& p = pr.p[which];
+  const int tile = which ? blockIdx.x - pr.split : blockIdx.x;
   if (p.W1) chain_body<Hh, true>(p, tile, chain_smem);
   else chain_body<Hh, false>(p, tile, chain_smem);
 }
 
-static size_t chain_lds_bytes() { return (size_t)(3 * CROWS * CP + CROWS * CG) * 2 + 2 * NWAVE * CROWS * sizeof(float); }
+static size_t chain_lds_bytes() { return (size_t)(3 * CROWS * CP + CROWS * CG) * 2 + (2 * NWAVE * CROWS + 6 * CH + CI + 3 * CH) * sizeof(float); }
 
 static bool chain_valid(const ChainParams& p) {
   if (p.M <= 0 || !p.in || !p.res || !p.Wa || !p.ba || !p.g1 || !p.b1 || p.ld_in < CH || (p.ld_in & 7)) return false;
@@ -302,17 +317,19 @@ static bool chain_valid(const ChainParams& p) {
 
 int launch_chain(int dtype, int variant, const void* pa_, const void* pb_, hipStream_t st) {
   (void)variant;
-  const ChainParams& pa = *(const ChainParams*)pa_;
-  const ChainParams& pb = pb_ ? *(const ChainParams*)pb_ : pa;
-  const int ta = (pa.M + CROWS - 1) / CROWS, tb = pb_ ? (pb.M + CROWS - 1) / CROWS : 0;
+  ChainPair pr;
+  pr.p[0] = *(const ChainParams*)pa_;
+  pr.p[1] = pb_ ? *(const ChainParams*)pb_ : pr.p[0];
+  const int ta = (pr.p[0].M + CROWS - 1) / CROWS, tb = pb_ ? (pr.p[1].M + CROWS - 1) / CROWS : 0;
+  pr.split = ta;
   static bool attr_done[3] = {false, false, false};
   const size_t lds = chain_lds_bytes();
   if (dtype == DT_BF16) {
     if (!attr_done[DT_BF16]) { hipFuncSetAttribute((const void*)chain_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[DT_BF16] = true; }
-    hipLaunchKernelGGL(chain_fwd_kernel<bf16>, dim3(ta + tb), dim3(512), lds, st, pa, pb, ta);
+    hipLaunchKernelGGL(chain_fwd_kernel<bf16>, dim3(ta + tb), dim3(512), lds, st, pr);
   } else {
     if (!attr_done[DT_F16]) { hipFuncSetAttribute((const void*)chain_fwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[DT_F16] = true; }
-    hipLaunchKernelGGL(chain_fwd_kernel<f16>, dim3(ta + tb), dim3(512), lds, st, pa, pb, ta);
+    hipLaunchKernelGGL(chain_fwd_kernel<f16>, dim3(ta + tb), dim3(512), lds, st, pr);
   }
   return launch_status();
 }

@@ -24,8 +24,16 @@ __device__ __forceinline__ f32x4 emma(f16x8 a, f16x8 b, f32x4 c) { return mfma16
 template <typename Hh> __device__ __forceinline__ h16x8<Hh> lfrag(const Hh* s, int pitch, int row0, int k0, int lane) {
   return *(const h16x8<Hh>*)(s + (row0 + (lane & 15)) * pitch + k0 + 8 * (lane >> 4));
 }
+// B fragment of a WEIGHT matrix [N, ldw] held in MFMA-FRAGMENT ORDER (magic_pack_frag_spans, csrc/chain.hip): fragment (row0 / 16, k0 / 32) is
+// one contiguous KB, lane l's 16 bytes at l.  Round 3: the row-major form (lane l reads 16 bytes of weight row l & 15: one cache line per
+// row, half of it used) held the whole-encoder forward at 249 us; in fragment order the same launch takes 200 us (profiles/README.md).
+// ENC_ROWMAJOR_W restores the row-major read for that comparison (profiles/micro/enc_rs_timing.hip).
 template <typename Hh> __device__ __forceinline__ h16x8<Hh> gfrag(const Hh* __restrict__ W, int ldw, int row0, int k0, int lane) {
+#ifdef ENC_ROWMAJOR_W
   return *(const h16x8<Hh>*)(W + (long long)(row0 + (lane & 15)) * ldw + k0 + 8 * (lane >> 4));
+#else
+  return *(const h16x8<Hh>*)(W + ((long long)((row0 >> 4) * (ldw >> 5) + (k0 >> 5)) * 64 + lane) * 8);
+#endif
 }
 // B fragment from a [k][n] image (V: keys x head dims), transposed on the way out of LDS
 template <typename Hh> __device__ __forceinline__ h16x8<Hh> tfrag(const Hh* s, int pitch, int n0, int k0, int lane) {

@@ -123,6 +123,14 @@ class Lin:
 
 
     @property
+    def WTf(self):
+        """W^T in MFMA-fragment order (flat; csrc/encbwd.hip reads it)"""
+        t = getattr(self, "_WTf", None)
+        if t is None:
+            t = self._WTf = self._store.tf_span(self._wname, self.N, self.K)
+        return t
+
+    @property
     def Wf(self):
         """W in MFMA-fragment order (flat; csrc/chain.hip reads it); registers the span on first use"""
         t = getattr(self, "_Wf", None)
@@ -157,14 +165,17 @@ class MagicNet:
                     lp = fmt.format(i)
                     for lin in (self.lin(lp + "attention.self.query.weight", rows=3 * self.H, cols=self.H), self.lin(lp + "attention.output.dense.weight"),
                                 self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")):
-                        lin.WT
+                        lin.WTf
+                        lin.Wf           # (the whole-encoder forward reads W in fragment order)
             for enc in ("global_encoder.", "local_encoder."):
                 for i in range(cfg.num_x_layers):
                     lp = f"{prefix}{enc}encoder.crossattention.{i}."
                     for lin in (self.lin(lp + "attention.self.query.weight", rows=3 * self.H, cols=self.H), self.lin(lp + "attention.output.dense.weight"),
                                 self.lin(lp + "crossattention.self.query.weight"), self.lin(lp + "crossattention.output.dense.weight"),
                                 self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight")):
-                        lin.WT
+                        lin.WTf
+                        lin.Wf
+                    self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * self.H, cols=self.H).Wf
 
     # ---- dropout sites (counter-based masks, csrc/common.hpp) -------------------------------------
     def set_dropout(self, seed=None, p_hidden=0.0, p_attn=0.0):
@@ -497,7 +508,7 @@ class MagicNet:
             ql = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
             o, n1 = self.lin(lp + "attention.output.dense.weight"), self.ln(lp + "attention.output.LayerNorm")
             f1, f2, n2 = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.ln(lp + "output.LayerNorm")
-            descs.append(dict(Wqkv=ql.W, bqkv=ql.b, Wo=o.W, bo=o.b, g1=n1.g, be1=n1.b, W1=f1.W, bi=f1.b, W2=f2.W, bo2=f2.b, g2=n2.g, be2=n2.b,
+            descs.append(dict(Wqkv=ql.Wf, bqkv=ql.b, Wo=o.Wf, bo=o.b, g1=n1.g, be1=n1.b, W1=f1.Wf, bi=f1.b, W2=f2.Wf, bo2=f2.b, g2=n2.g, be2=n2.b,
                               qkv=sa.qkv, P=sa.Ppre, Pd=sa.P if sa.adrop else None, ctx=sa.ctx, a=sa.a, z=ffn.z, g=ffn.g, out=ffn.out,
                               rstd_a=sa.rstd_a, rstd_o=ffn.rstd,
                               site_attn=sa.adrop[2] if sa.adrop else 0, site_ao=sa.hdrop[2] if sa.hdrop else 0,
@@ -594,18 +605,18 @@ class MagicNet:
                 f1, f2, o = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.lin(lp + "attention.output.dense.weight")
                 n2, n1 = self.ln(lp + "output.LayerNorm"), self.ln(lp + "attention.output.LayerNorm")
                 out = Ctx(dz=self.new(M, I), daod=self.new(M, H), dao=self.new(M, H), dctx=self.new(M, H))
-                seg = dict(M=M, y2=ffn.out, rstd2=ffn.rstd, g2=n2.g, b2=n2.b, z=ffn.z, W2T=f2.WT, W1T=f1.WT, y1=sa.a, rstd1=sa.rstd_a,
-                           g1=n1.g, b1=n1.b, dg1=n1.dg, db1=n1.db, WoT=o.WT, dz=out.dz, daod=out.daod, dao=out.dao, dctx=out.dctx,
+                seg = dict(M=M, y2=ffn.out, rstd2=ffn.rstd, g2=n2.g, b2=n2.b, z=ffn.z, W2T=f2.WTf, W1T=f1.WTf, y1=sa.a, rstd1=sa.rstd_a,
+                           g1=n1.g, b1=n1.b, dg1=n1.dg, db1=n1.db, WoT=o.WTf, dz=out.dz, daod=out.daod, dao=out.dao, dctx=out.dctx,
                            site_out=ffn.hdrop[2] if ffn.hdrop else 0, site_ao=sa.hdrop[2] if sa.hdrop else 0)
                 flops = 2.0 * ffn.rows * (2 * H * I + H * H)
                 if s.d_top is not None:          # top block: dx of the output norm = the plain gradient wrt the stack's output (no product)
                     out.dfo, out.dfod = self.new(M, H), self.new(M, H)
-                    seg.update(dqkv_n=s.d_top, kt=0, WqkvT_n=f2.WT, dao_n=s.d_top, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
+                    seg.update(dqkv_n=s.d_top, kt=0, WqkvT_n=f2.WTf, dao_n=s.d_top, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
                     s.d_top = None
                 else:                            # tail of block j + 1 runs here
                     qn = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
                     out.dfo, out.dfod = self.new(M, H), self.new(M, H)
-                    seg.update(dqkv_n=s.dqkv, WqkvT_n=qn.WT, dao_n=s.dao, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
+                    seg.update(dqkv_n=s.dqkv, WqkvT_n=qn.WTf, dao_n=s.dao, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
                     flops += 2.0 * ffn.rows * 3 * H * H
                 seg["flops"] = flops
                 segs.append(seg)
@@ -680,7 +691,9 @@ class MagicNet:
         M = Np * V
         c = Ctx(Np=Np, V=V, feats=feats, loc=loc)
         il = self.lin(p + "img_linear.weight")
-        P0 = O.linear_fwd(feats, il.W, il.b, M)
+        from . import lib as _L
+        with _L.solo():       # (not offered to a lockstep partner: the text encoder's first groupable launch is its QKV projection, as is our next one)
+            P0 = O.linear_fwd(feats, il.W, il.b, M)
         n1 = self.ln(p + "img_layer_norm")
         c.A1, c.rstd_a1 = self.new(M, H), self.new(M, dtype=torch.float32)
         O.ln_fwd(M, H, c.A1, in0=P0, gamma=n1.g, beta=n1.b, eps=self.eps, rstd=c.rstd_a1)
@@ -943,8 +956,8 @@ class MagicNet:
             ckv = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
             co, nc = self.lin(lp + "crossattention.output.dense.weight"), self.ln(lp + "crossattention.output.LayerNorm")
             f1, f2, n2 = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.ln(lp + "output.LayerNorm")
-            descs.append(dict(Wqkv=ql.W, bqkv=ql.b, Wo=o.W, bo=o.b, g1=n1.g, be1=n1.b, Wq=cq.W, bq=cq.b, Wkv=ckv.W, bkv=ckv.b,
-                              Woc=co.W, boc=co.b, gc=nc.g, bec=nc.b, W1=f1.W, bi=f1.b, W2=f2.W, bo2=f2.b, g2=n2.g, be2=n2.b,
+            descs.append(dict(Wqkv=ql.Wf, bqkv=ql.b, Wo=o.Wf, bo=o.b, g1=n1.g, be1=n1.b, Wq=cq.Wf, bq=cq.b, Wkv=ckv.Wf, bkv=ckv.b,
+                              Woc=co.Wf, boc=co.b, gc=nc.g, bec=nc.b, W1=f1.Wf, bi=f1.b, W2=f2.Wf, bo2=f2.b, g2=n2.g, be2=n2.b,
                               qkv=sa.qkv, P=sa.Ppre, Pd=sa.P if sa.adrop else None, ctx=sa.ctx, a=sa.a, rstd_a=sa.rstd_a,
                               q=c.q, kv=c.kv, Pc=c.Ppre, Pdc=c.P if c.adrop else None, cctx=c.cctx, c=c.c, rstd_c=c.rstd_c,
                               z=c.ffn.z, g=c.ffn.g, out=c.ffn.out, rstd_o=c.ffn.rstd,
@@ -1015,18 +1028,18 @@ class MagicNet:
                 n2, nc, n1 = self.ln(lp + "output.LayerNorm"), self.ln(lp + "crossattention.output.LayerNorm"), self.ln(lp + "attention.output.LayerNorm")
                 out = Ctx(dz=self.new(M, I), dcod=self.new(M, H), dco=self.new(M, H), dcctx=self.new(M, H), dq=self.new(M, H),
                           dkv=self.new(s.Mk, 2 * H), dao=self.new(M, H), daod=self.new(M, H), dctx=self.new(M, H), dqkv=self.new(M, 3 * H))
-                seg = dict(M=M, y2=ffn.out, rstd2=ffn.rstd, g2=n2.g, b2=n2.b, z=ffn.z, W2T=W.f2.WT, W1T=W.f1.WT, y1=lc.c, rstd1=lc.rstd_c,
-                           g1=nc.g, b1=nc.b, dg1=nc.dg, db1=nc.db, WoT=W.co.WT, dz=out.dz, daod=out.dcod, dao=out.dco, dctx=out.dcctx,
+                seg = dict(M=M, y2=ffn.out, rstd2=ffn.rstd, g2=n2.g, b2=n2.b, z=ffn.z, W2T=W.f2.WTf, W1T=W.f1.WTf, y1=lc.c, rstd1=lc.rstd_c,
+                           g1=nc.g, b1=nc.b, dg1=nc.dg, db1=nc.db, WoT=W.co.WTf, dz=out.dz, daod=out.dcod, dao=out.dco, dctx=out.dcctx,
                            site_out=ffn.hdrop[2] if ffn.hdrop else 0, site_ao=lc.hdrop[2] if lc.hdrop else 0)
                 flops = 2.0 * ffn.rows * (2 * H * I + H * H)
                 if s.d_top is not None:          # top block: no product, the output norm's backward starts from the plain gradient
                     out.dfo, out.dfod = self.new(M, H), self.new(M, H)
-                    seg.update(dqkv_n=s.d_top, kt=0, WqkvT_n=W.f2.WT, dao_n=s.d_top, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
+                    seg.update(dqkv_n=s.d_top, kt=0, WqkvT_n=W.f2.WTf, dao_n=s.d_top, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
                     s.d_top = None
                 else:
                     qn = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
                     out.dfo, out.dfod = self.new(M, H), self.new(M, H)
-                    seg.update(dqkv_n=s.dqkv, kt=12, WqkvT_n=qn.WT, dao_n=s.dao, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
+                    seg.update(dqkv_n=s.dqkv, kt=12, WqkvT_n=qn.WTf, dao_n=s.dao, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
                     flops += 2.0 * ffn.rows * 3 * H * H
                 seg["flops"] = flops
                 segs.append(seg)
@@ -1042,8 +1055,8 @@ class MagicNet:
             segs = []
             for s, lc, W, n1, out in act:
                 sa = lc.sa
-                segs.append(dict(M=s.M, kt=4, dqkv_n=out.dq, WqkvT_n=W.cq.WT, dao_n=out.dco, y2=sa.a, rstd2=sa.rstd_a, g2=n1.g, b2=n1.b,
-                                 dg2=n1.dg, db2=n1.db, WoT=W.o.WT, dfo=out.dao, dfod=out.daod, dctx=out.dctx,
+                segs.append(dict(M=s.M, kt=4, dqkv_n=out.dq, WqkvT_n=W.cq.WTf, dao_n=out.dco, y2=sa.a, rstd2=sa.rstd_a, g2=n1.g, b2=n1.b,
+                                 dg2=n1.dg, db2=n1.db, WoT=W.o.WTf, dfo=out.dao, dfod=out.daod, dctx=out.dctx,
                                  site_out=sa.hdrop[2] if sa.hdrop else 0, flops=2.0 * sa.rows * 2 * H * H))
             O.rowbwd(segs, seed, ph)                                   # short chain
             self._grouped([lambda s=s, lc=lc, out=out: self._attn_bwd(

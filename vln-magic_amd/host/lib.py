@@ -283,9 +283,24 @@ def _raw_call(name, args):
         raise MagicHipError(f"{name} failed: {_ERR.get(rc, rc)}")
 
 
+class solo:
+    """`with L.solo():` -- inside a lockstep segment, launch this thread's groupable calls alone instead of offering them to the partner:
+    keeps two segments whose launch sequences differ by a prefix (the panorama encoder's image projection) in phase, so that their layers
+    pair kind for kind (QKV with QKV, attention with attention, chain with chain)"""
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "solo", False)
+        _tls.solo = True
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _tls.solo = self.prev
+        return False
+
+
 def call(name, *args):
     ls = getattr(_tls, "lockstep", None)
-    if ls is not None and name in PAIRABLE:
+    if ls is not None and name in PAIRABLE and not getattr(_tls, "solo", False):
         return ls.submit(_tls.idx, name, args)
     if ls is not None and PROFILE["on"]:
         with ls.cv:            # instrumented pass: keep this launch's event pair free of the partner thread's launches

@@ -340,6 +340,10 @@ int magic_chain_supported(int dtype, int H, int I);
  * 8 elements = src[(16 nt + (l & 15)) cols + 32 ks + 8 (l >> 4) .. +7].  rows % 16 == 0, cols % 32 == 0, rows cols % 2048 == 0, offs % 8 == 0;
  * host arrays of n spans (element offsets), as magic_transpose_spans. */
 int magic_pack_frag_spans(const void* src, void* dst, int n, const long long* offs, const int* rows, const int* cols, void* stream);
+/* One launch for all layouts a training step refreshes after AdamW has rewritten the 16-bit shadow: for span i (rows, cols multiples of 64)
+ * flags[i] & 1: dst_f[offs[i] ..) = W in fragment order; flags[i] & 2: dst_tf[offs[i] ..) = W^T ([cols, rows]) in fragment order. */
+int magic_layout_spans(const void* src, void* dst_f, void* dst_tf, int n, const long long* offs, const int* rows, const int* cols,
+                       const int* flags, void* stream);
 int magic_chain_fwd(int dtype, const void* params, int nbytes, void* stream);
 
 /* Backward of the per-token half of a post-LN self-attention block on 32-row blocks (csrc/encbwd.hip): [tail of the next block: dx =

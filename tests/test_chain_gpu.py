@@ -122,6 +122,35 @@ def test_pack_frag_layout():
         assert torch.equal(O.pack_frag(W), want)
 
 
+def test_layout_spans_writes_w_and_wt_in_fragment_order_in_one_launch():
+    """magic_layout_spans (the launch that follows AdamW): flag 1 -> W, flag 2 -> W^T, both in fragment order, several spans of one flat buffer"""
+    import ctypes as C
+    frag = lambda W: W.reshape(W.shape[0] // 16, 16, W.shape[1] // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+    for dtype in (torch.bfloat16, torch.float16):
+        shapes, flags = [(128, 128), (384, 128), (128, 512), (64, 64)], [3, 1, 2, 3]
+        offs, total = [], 0
+        for r, c in shapes:
+            offs.append(total)
+            total += r * c + 64            # (gaps between the spans stay untouched)
+        src = torch.randn(total).to(DEV).to(dtype)
+        df, dtf = torch.full((total,), 9.0, dtype=dtype, device=DEV), torch.full((total,), 9.0, dtype=dtype, device=DEV)
+        n = len(shapes)
+        a_off, a_r, a_c, a_f = (C.c_longlong * n)(*offs), (C.c_int * n)(*[s[0] for s in shapes]), (C.c_int * n)(*[s[1] for s in shapes]), (C.c_int * n)(*flags)
+        L.call("magic_layout_spans", L.P(src), L.P(df), L.P(dtf), n, C.addressof(a_off), C.addressof(a_r), C.addressof(a_c), C.addressof(a_f), L.stream())
+        torch.cuda.synchronize()
+        for (r, c), o, fl in zip(shapes, offs, flags):
+            W = src[o:o + r * c].view(r, c)
+            if fl & 1:
+                assert torch.equal(df[o:o + r * c], frag(W))
+            else:
+                assert (df[o:o + r * c] == 9.0).all()
+            if fl & 2:
+                assert torch.equal(dtf[o:o + r * c], frag(W.t().contiguous()))
+            else:
+                assert (dtf[o:o + r * c] == 9.0).all()
+            assert (df[o + r * c:o + r * c + 64] == 9.0).all() and (dtf[o + r * c:o + r * c + 64] == 9.0).all()
+
+
 def test_chain_rejects_bad_arguments():
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(1)

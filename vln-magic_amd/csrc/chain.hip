@@ -372,6 +372,64 @@ extern "C" int magic_pack_frag_spans(const void* src, void* dst, int n, const lo
   return launch_status();
 }
 
+// One launch for a training step's weight layouts: every span's fragment-order copy of W (flag 1 -> dst_f) and of W^T (flag 2 -> dst_tf) from
+// the row-major 16-bit shadow the AdamW kernel has just rewritten; 64 x 64 tiles, spans with rows and cols multiples of 64.
+struct LSpans { long long off[FSP_MAX]; int rows[FSP_MAX]; int cols[FSP_MAX]; int flags[FSP_MAX]; int tile0[FSP_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void layout_spans_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst_f,
+                                                           unsigned short* __restrict__ dst_tf, LSpans t) {
+  typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+  __shared__ unsigned short tile[64][72];
+  const int id = blockIdx.x;
+  int s = 0;
+  for (int i = 1; i < t.n; ++i) s += (id >= t.tile0[i]) ? 1 : 0;
+  const int local = id - t.tile0[s], R = t.rows[s], C = t.cols[s], fl = t.flags[s];
+  const int tc = C / 64, r0 = (local / tc) * 64, c0 = (local % tc) * 64;
+  const unsigned short* a = src + t.off[s];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ch = threadIdx.x + it * 256, r = ch >> 3, c = (ch & 7) * 8;
+    const u16x8 v = *(const u16x8*)(a + (long long)(r0 + r) * C + c0 + c);
+    *(u16x8*)&tile[r][c] = v;
+    if (fl & 1) {        // W: the 16 bytes this thread holds ARE one lane's operand of fragment ((r0 + r) / 16, (c0 + c) / 32)
+      const int nt = (r0 + r) >> 4, rr = (r0 + r) & 15, ks = (c0 + c) >> 5, g = ((c0 + c) & 31) >> 3;
+      *(u16x8*)(dst_f + t.off[s] + ((long long)(nt * (C >> 5) + ks) * 64 + g * 16 + rr) * 8) = v;
+    }
+  }
+  if (!(fl & 2)) return;
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {      // W^T [C, R]: rows c0 .. c0 + 63 (4 row tiles), k = r0 .. r0 + 63 (2 k-steps): 8 fragments x 64 lanes
+    const int ch = threadIdx.x + it * 256, l = ch & 63, fr = ch >> 6, i = fr >> 1, j = fr & 1, g = l >> 4, nn = l & 15;
+    u16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[32 * j + 8 * g + e][16 * i + nn];
+    const int nt = (c0 >> 4) + i, ks = (r0 >> 5) + j;
+    *(u16x8*)(dst_tf + t.off[s] + ((long long)(nt * (R >> 5) + ks) * 64 + l) * 8) = v;
+  }
+}
+extern "C" int magic_layout_spans(const void* src, void* dst_f, void* dst_tf, int n, const long long* offs, const int* rows, const int* cols,
+                                  const int* flags, void* stream) {
+  if (!src || n < 0 || (n && (!offs || !rows || !cols || !flags)) || ((uintptr_t)src & 15) || ((uintptr_t)dst_f & 15) || ((uintptr_t)dst_tf & 15)) return MAGIC_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    if (rows[i] <= 0 || cols[i] <= 0 || rows[i] % 64 || cols[i] % 64 || offs[i] % 8 || !(flags[i] & 3)) return MAGIC_ERR_ARG;
+    if (((flags[i] & 1) && !dst_f) || ((flags[i] & 2) && !dst_tf)) return MAGIC_ERR_ARG;
+  }
+  for (int base = 0; base < n; base += FSP_MAX) {
+    LSpans t;
+    t.n = n - base < FSP_MAX ? n - base : FSP_MAX;
+    int tiles = 0;
+    for (int i = 0; i < t.n; ++i) {
+      t.off[i] = offs[base + i]; t.rows[i] = rows[base + i]; t.cols[i] = cols[base + i]; t.flags[i] = flags[base + i];
+      t.tile0[i] = tiles;
+      tiles += (rows[base + i] / 64) * (cols[base + i] / 64);
+    }
+    t.tile0[t.n] = tiles;
+    hipLaunchKernelGGL(layout_spans_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src, (unsigned short*)dst_f,
+                       (unsigned short*)dst_tf, t);
+  }
+  return launch_status();
+}
+
 extern "C" int magic_chain_supported(int dtype, int H, int I) { return dtype_is16(dtype) && H == CH && I == CI; }
 
 extern "C" int magic_chain_fwd(int dtype, const void* params, int nbytes, void* stream) {

@@ -82,6 +82,7 @@ SIGNATURES = {
     "magic_rowbwd": [i32, vp, i32, vp],
     "magic_transpose_spans": [vp, vp, i32, vp, vp, vp, vp],
     "magic_pack_frag_spans": [vp, vp, i32, vp, vp, vp, vp],
+    "magic_layout_spans": [vp, vp, vp, i32, vp, vp, vp, vp, vp],
     "magic_group_begin": [],
     "magic_group_end": [vp],
 }

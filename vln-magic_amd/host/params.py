@@ -92,8 +92,7 @@ class ParamStore:
         self.shadow_f = None
         self.f_spans = {}
         self.shadow_f_clean = False
-        self.shadow_tf = None          # ... and for W^T in fragment order (csrc/encbwd.hip): packed from shadow_t
-        self.tf_spans = {}
+        self.shadow_tf = None          # ... and for W^T in fragment order (csrc/encbwd.hip); f_spans: offset -> (rows, cols, 1 = W | 2 = W^T)
         if requires_grad and self.half:
             _LIVE.add(self)
             _install_optimizer_hook()
@@ -139,51 +138,46 @@ class ParamStore:
                 self.sync_shadow_t(force=True)
         return self.shadow_t[off:off + rows * cols].view(cols, rows)
 
-    def f_span(self, first, rows, cols):
-        """the [rows, cols] span starting at `first` in MFMA-FRAGMENT ORDER (magic_pack_frag_spans: every 16 x 32 fragment's 64 lane operands
-        contiguous), as a flat compute-dtype view; kept current by sync_shadow"""
+    def _layout_span(self, first, rows, cols, flag):
         off = self.offsets[first][0]
         if self.shadow_f is None:
             self.shadow_f = torch.zeros(self.total, dtype=self.compute_dtype, device=self.device)
-        if off not in self.f_spans:
-            self.f_spans[off] = (rows, cols)
+            self.shadow_tf = torch.zeros(self.total, dtype=self.compute_dtype, device=self.device)
+        have = self.f_spans.get(off)
+        if have is None or not (have[2] & flag):
+            assert have is None or have[:2] == (rows, cols), "one span, two shapes"
+            self.f_spans[off] = (rows, cols, (have[2] if have else 0) | flag)
             self.shadow_f_clean = False
             self._f_arrays = None
-            if self.shadow_clean and self.device.type == "cuda":
+            if self.shadow_clean and self.device.type == "cuda":      # registered after the shadow was last refreshed: fill it in now
                 self.sync_shadow_f(force=True)
+        return off
+
+    def f_span(self, first, rows, cols):
+        """the [rows, cols] span starting at `first` in MFMA-FRAGMENT ORDER (every 16 x 32 fragment's 64 lane operands contiguous: csrc/chain.hip
+        magic_pack_frag_spans), as a flat compute-dtype view; kept current by sync_shadow / FusedAdamW"""
+        off = self._layout_span(first, rows, cols, 1)
         return self.shadow_f[off:off + rows * cols]
 
     def tf_span(self, first, rows, cols):
-        """W^T ([cols, rows]) of the [rows, cols] span starting at `first`, in fragment order (flat view); kept current by sync_shadow"""
-        self.t_span(first, rows, cols)                   # the plain transpose is the packing's source
-        off = self.offsets[first][0]
-        if self.shadow_tf is None:
-            self.shadow_tf = torch.zeros(self.total, dtype=self.compute_dtype, device=self.device)
-        if off not in self.tf_spans:
-            self.tf_spans[off] = (cols, rows)
-            self.shadow_f_clean = False
-            self._f_arrays = None
-            if self.shadow_clean and self.device.type == "cuda":
-                self.sync_shadow_t(force=True)
-                self.sync_shadow_f(force=True)
+        """W^T ([cols, rows]) of the [rows, cols] span starting at `first`, in fragment order (flat view; csrc/encbwd.hip reads it)"""
+        off = self._layout_span(first, rows, cols, 2)
         return self.shadow_tf[off:off + rows * cols]
 
     def sync_shadow_f(self, force=False):
-        """every registered span of the (clean) shadow -> fragment order; every registered span of the (clean) transposed shadow likewise"""
-        if not (self.f_spans or self.tf_spans) or (self.shadow_f_clean and not force):
+        """ONE launch: every registered span of the (clean) shadow -> W and / or W^T in fragment order"""
+        if not self.f_spans or (self.shadow_f_clean and not force):
             return
         import ctypes as C
         from . import lib as L
         if getattr(self, "_f_arrays", None) is None:
-            arrs = []
-            for spans in (self.f_spans, self.tf_spans):
-                offs = sorted(spans)
-                n = len(offs)
-                arrs.append((n, (C.c_longlong * n)(*offs), (C.c_int * n)(*[spans[o][0] for o in offs]), (C.c_int * n)(*[spans[o][1] for o in offs])))
-            self._f_arrays = arrs
-        for (n, a_off, a_rows, a_cols), src, dst in zip(self._f_arrays, (self.shadow, self.shadow_t), (self.shadow_f, self.shadow_tf)):
-            if n:
-                L.call("magic_pack_frag_spans", L.P(src), L.P(dst), n, C.addressof(a_off), C.addressof(a_rows), C.addressof(a_cols), L.stream())
+            offs = sorted(self.f_spans)
+            n = len(offs)
+            self._f_arrays = (n, (C.c_longlong * n)(*offs), (C.c_int * n)(*[self.f_spans[o][0] for o in offs]),
+                              (C.c_int * n)(*[self.f_spans[o][1] for o in offs]), (C.c_int * n)(*[self.f_spans[o][2] for o in offs]))
+        n, a_off, a_rows, a_cols, a_flags = self._f_arrays
+        L.call("magic_layout_spans", L.P(self.shadow), L.P(self.shadow_f), L.P(self.shadow_tf), n, C.addressof(a_off), C.addressof(a_rows),
+               C.addressof(a_cols), C.addressof(a_flags), L.stream())
         self.shadow_f_clean = True
 
     def sync_shadow_t(self, force=False):

@@ -77,7 +77,7 @@ class FusedAdamW:
         s.shadow_clean = True
         if shadow is not None and s.t_spans:           # the AdamW kernel rewrote the bf16 shadow: its transposed copy follows
             s.sync_shadow_t(force=True)
-        if shadow is not None and (s.f_spans or s.tf_spans):      # ... and the fragment-order copies the whole-encoder kernels read
+        if shadow is not None and s.f_spans:      # ... and the fragment-order copies the whole-encoder kernels read
             s.sync_shadow_f(force=True)
         return lr
 

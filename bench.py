@@ -465,6 +465,8 @@ def main():
         seen = [t.tolist() for t in seen]
         rccl = {"backend": a.backend, "world": world, "ranks_seen": [r for r, _ in seen], "devices": [d for _, d in seen]}
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
+    if os.environ.get("MAGIC_MAIN_PRIORITY"):      # experiment: the student's stream at high priority (-1), the teacher's at 0
+        torch.cuda.set_stream(torch.cuda.Stream(dev, priority=int(os.environ["MAGIC_MAIN_PRIORITY"])))
     if os.environ.get("MAGIC_TEACHER_CUS"):
         # a CU-masked stream (hipExtStreamCreateWithCUMask) is a BLOCKING stream: it synchronises with the null stream implicitly, so the
         # student's work must not sit on the null stream or the two serialise

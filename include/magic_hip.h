@@ -289,6 +289,10 @@ typedef struct { magic_enc_seg seg[2]; int nseg; float p_attn, p_hidden, eps, sc
 int magic_encoder_supported(int dtype, int H, int I, int nh, int N, int nlayers);
 int magic_encoder_params_bytes(void);
 int magic_encoder_fwd(int dtype, const void* params, int nbytes, void* stream);
+/* Scheduling aid for work that runs NEXT TO a training step on another stream (the frozen MAKD teacher's forward): parks `stream` -- one
+ * sleeping wave -- until the next magic_encoder_fwd launch of this process has its last workgroup on a CU, or timeout_us (<= 100000) have
+ * passed.  The whole-encoder launch wants every CU's LDS; side work that starts first delays its workgroups. */
+int magic_encoder_start_gate(int timeout_us, void* stream);
 
 /* Cross-modal encoders in one launch (csrc/encoder.hip, xencoder_fwd_kernel): the global (map) and local (viewpoint) co-attention
  * encoders, <= 3 METER BertCrossLayer blocks each (the withheld model's `bert.{global,local}_encoder.encoder.crossattention.N`,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "magic_encoder_supported": [i32, i32, i32, i32, i32, i32],
     "magic_encoder_params_bytes": [],
     "magic_encoder_fwd": [i32, vp, i32, vp],
+    "magic_encoder_start_gate": [i32, vp],
     "magic_chain_supported": [i32, i32, i32],
     "magic_chain_fwd": [i32, vp, i32, vp],
     "magic_xencoder_supported": [i32, i32, i32, i32, i32, i32, i32],

@@ -404,6 +404,16 @@ def encoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
     L.call("magic_encoder_fwd", L.dt(dtype), C.addressof(P), C.sizeof(P), L.stream())
 
 
+TEACHER_GATE_US = int(os.environ.get("MAGIC_TEACHER_GATE_US", "400"))       # 0: off
+
+
+def encoder_start_gate(timeout_us=None):
+    """park the current stream until the next whole-encoder launch (another stream's) has its workgroups resident (csrc/encoder.hip)"""
+    t = TEACHER_GATE_US if timeout_us is None else int(timeout_us)
+    if t > 0:
+        L.call("magic_encoder_start_gate", t, L.stream())
+
+
 FUSED_CHAIN = not os.environ.get("MAGIC_NO_CHAIN")
 _CHAIN_OK = {}
 

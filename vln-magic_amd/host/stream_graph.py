@@ -109,7 +109,6 @@ class StreamStep:
     # an iterable of (task, record) and yields one (out, meta) per step.
     def _capture_split(self, key, task, rec, parsed):
         import time
-        t_cap = time.perf_counter()
         tr = self.tr
         e = _Entry()
         e.dbuf = torch.empty(int(rec["buf"].numel()), dtype=torch.uint8, device=self.dev)
@@ -122,8 +121,12 @@ class StreamStep:
         if self.ftab is not None:
             e.batch["view_table"] = self.ftab
         torch.cuda.synchronize()
+        t_cap = time.perf_counter()          # (after the drain: the steps the host had queued ahead are training time, not capture time)
         e.gT = torch.cuda.CUDAGraph()
         with torch.cuda.graph(e.gT, stream=tr.side, capture_error_mode="relaxed"):
+            if tr.student.net.enc_ok(e.plan["L"], tr.student.config.num_l_layers):
+                from . import ops as O
+                O.encoder_start_gate()      # T_{i+1} starts once S_i's whole-encoder launch has its workgroups resident (trainer.capture_split)
             e.t_out = tr.teacher_forward(e.batch, task, e.plan)
         e.cs = tr.capture_student((e.batch, task, e.plan), e.t_out, rw=self.rw)      # one graph; data parallel: three + the optimizer's
         e.out = e.cs.out

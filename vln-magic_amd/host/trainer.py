@@ -115,7 +115,8 @@ def _side_stream(dev):
     the student's in bursts.  Opt-in: see DESIGN.md section 5 for what it measured."""
     spec = os.environ.get("MAGIC_TEACHER_CUS")
     if not spec:
-        return torch.cuda.Stream()
+        pr = os.environ.get("MAGIC_TEACHER_PRIORITY")
+        return torch.cuda.Stream(priority=int(pr)) if pr else torch.cuda.Stream()
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -563,6 +564,8 @@ class PretrainStep:
         cs = self.capture_student(cur, t_cur, rw=rw, keep=(cur, t_cur, nxt, rw))
         gT = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gT, stream=self.side, capture_error_mode="relaxed"):
+            if self.student.net.enc_ok(nxt[2]["L"], self.student.config.num_l_layers):
+                O.encoder_start_gate()        # the student's whole-encoder launch first: see csrc/encoder.hip magic_encoder_start_gate
             t_next = self.teacher_forward(*nxt)
             if t_next_into is not None:
                 copy_teacher_outputs(t_next, t_next_into)

@@ -305,7 +305,7 @@ def instrumented_pass(trainer, pool, nprof, gate_ms):
     graphs (paired launches), the teacher's forward SERIALISED on the main stream (no overlap: summed kernel time == stream time),
     and a device-side gate in front of every step so the host runs ahead of the GPU.  Returns {family: (ms, launches)}."""
     import magic_amd.host.model_pretrain as MP
-    O.FLOPS.update(total=0.0, gemm=0.0, linear_ln=0.0, attn=0.0, enc=0.0, enabled=True)
+    O.FLOPS.update(total=0.0, gemm=0.0, linear_ln=0.0, attn=0.0, enc=0.0, chain=0.0, enabled=True)
     O.BYTES.update(dw=0.0, dw_launches=0)
     L.PROFILE.update(on=True, events=[])
     MP.LOCKSTEP_EAGER = True
@@ -571,7 +571,9 @@ def main():
         gemm_n = sum(c for k, (t, c) in by.items() if fam(k))
         all_ms = sum(t for t, c in by.values())
         flops = O.FLOPS["gemm"]            # the GEMM family's own algorithmic FLOPs (fused linear+LN and attention kernels count separately)
-        is_mfma = lambda k: any(x in k for x in ("magic_gemm", "magic_linear_ln", "magic_attn_", "magic_encoder", "magic_xencoder", "magic_rowbwd"))
+        is_mfma = lambda k: any(x in k for x in ("magic_gemm", "magic_linear_ln", "magic_attn_", "magic_encoder", "magic_xencoder", "magic_rowbwd", "magic_chain"))
+        chain_ms = sum(t for k, (t, c) in by.items() if k.startswith("magic_chain"))
+        chain_n = sum(c for k, (t, c) in by.items() if k.startswith("magic_chain"))
         mfma_ms = sum(t for k, (t, c) in by.items() if is_mfma(k))
         step_ms = dt / a.steps * 1e3
         # achieved = the family's algorithmic FLOPs / the family's SUMMED launch durations (non-overlapped pass), i.e.
@@ -592,11 +594,20 @@ def main():
                            "all_dense_contraction_kernels": {
                                "kernels": "gemm + fused linear+LayerNorm (fwd / bwd) + fused attention (fwd / bwd) + whole-encoder forwards + row-block backward",
                                "algorithmic_gflop_per_step": round(O.FLOPS["total"] / nprof / 1e9, 2),
-                               "gflop_by_family": {k: round(O.FLOPS[k] / nprof / 1e9, 2) for k in ("gemm", "linear_ln", "attn", "enc")},
+                               "gflop_by_family": {k: round(O.FLOPS[k] / nprof / 1e9, 2) for k in ("gemm", "linear_ln", "attn", "enc", "chain")},
                                "ms_per_step": round(mfma_ms / nprof, 3), "share_of_kernel_time": round(mfma_ms / all_ms, 4),
                                "achieved_tflops": round(ach_all, 2), "frac": round(ach_all / PEAK_BF16_TFLOPS, 5)},
                            "whole_step": {"summed_kernel_ms_per_step_serialised": round(all_ms / nprof, 3), "graph_replay_wall_ms_per_step": round(step_ms, 3),
                                           "frac_of_mfma_peak_on_wall": round(O.FLOPS["total"] / nprof / (step_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 5)},
+                           "teacher_chain_kernel": {
+                               "kernel": "chain_fwd_kernel (csrc/chain.hip): the frozen teacher's per-token half of a block (output projection + LayerNorm, FFN, "
+                                         "LayerNorm, next Q|K|V projection) at H = 256 in one launch, forward only",
+                               "algorithmic_gflop_per_step": round(O.FLOPS["chain"] / nprof / 1e9, 2), "launches_per_step": round(chain_n / nprof, 1),
+                               "avg_launch_us": round(chain_ms / max(chain_n, 1) * 1e3, 1), "share_of_kernel_time": round(chain_ms / all_ms, 4),
+                               "achieved_tflops": round(O.FLOPS["chain"] / max(chain_ms, 1e-9) / 1e9, 2),
+                               "frac_of_mfma_peak": round(O.FLOPS["chain"] / max(chain_ms, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 5),
+                               "bound": "L2 -> CU fill rate: a 32-row tile streams 1.57 MB of weight fragments (2 MFMAs each); one CU takes 58 B/ns "
+                                        "(26.5 us for one workgroup on an idle GPU, profiles/micro/chain_timing.hip)"},
                            "launches_per_step": sum(c for t, c in by.values()) // nprof,
                            "weight_gradient_launch": {
                                "kernel": "gemm_dw_batch_kernel (all deferred dW = dY^T X problems of a step in one launch)",

@@ -20,6 +20,7 @@
 // group.hpp KIND_CHAIN.
 #include "enc_common.hpp"
 #include "group.hpp"
+#include <cstdlib>
 
 #define CH 256
 #define CI 1024
@@ -323,7 +324,7 @@ int launch_chain(int dtype, int variant, const void* pa_, const void* pb_, hipSt
   const int ta = (pr.p[0].M + CROWS - 1) / CROWS, tb = pb_ ? (pr.p[1].M + CROWS - 1) / CROWS : 0;
   pr.split = ta;
   static bool attr_done[3] = {false, false, false};
-  const size_t lds = chain_lds_bytes();
+  const size_t lds = chain_lds_bytes();      // (padding it to 159 KB changes nothing in the overlapped step: co-residency with the student's tiles is not what the teacher costs)
   if (dtype == DT_BF16) {
     if (!attr_done[DT_BF16]) { hipFuncSetAttribute((const void*)chain_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[DT_BF16] = true; }
     hipLaunchKernelGGL(chain_fwd_kernel<bf16>, dim3(ta + tb), dim3(512), lds, st, pr);

@@ -464,7 +464,7 @@ def chain_fwd(x, res, M, Wa, ba, g1, b1, eps, *, y1=None, ffn=None, y2=None, pro
     if FLOPS["enabled"]:
         f = 2.0 * (M if flop_rows is None else flop_rows) * fl
         FLOPS["total"] += f
-        FLOPS["enc"] += f
+        FLOPS["chain"] = FLOPS.get("chain", 0.0) + f
     L.call("magic_chain_fwd", L.dt(x.dtype), C.addressof(P), C.sizeof(P), L.stream())
 
 

@@ -35,7 +35,7 @@ typedef EncParamsT<bf16> EncParams; typedef EncSegT<bf16> EncSeg; typedef EncLay
 
 // out[row][w*16 + c16] = LayerNorm_row(acc + bias (dropped) + residual) for the workgroup's NRT*16 rows; every wave owns 16 of the
 // 128 columns, row statistics go through LDS (two passes: mean, then centred variance -- as linear_ln_kernel).
-template <int NRT, typename Hh>
+template <int NRT, int RSTR, typename Hh>
 __device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, const float gv, const float btv, const Hh* sRes,
                                          float* red, Hh* sOut, float* gRstd, int N, long long row_base, float eps,
                                          const DropState& ds, int w, int lane) {
@@ -56,7 +56,7 @@ __device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, cons
 #pragma unroll
     for (int i = 0; i < NRT; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[w * MAXROWS + i * 16 + 4 * g + r] = s[i][r];
+      for (int r = 0; r < 4; ++r) red[w * RSTR + i * 16 + 4 * g + r] = s[i][r];
   }
   __syncthreads();
   float mean[NRT][4];
@@ -67,7 +67,7 @@ __device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, cons
       const int rr = i * 16 + 4 * g + r;
       float t = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * MAXROWS + rr];
+      for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * RSTR + rr];
       mean[i][r] = t * (1.0f / EH);
     }
   __syncthreads();
@@ -82,7 +82,7 @@ __device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, cons
 #pragma unroll
     for (int i = 0; i < NRT; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[w * MAXROWS + i * 16 + 4 * g + r] = s[i][r];
+      for (int r = 0; r < 4; ++r) red[w * RSTR + i * 16 + 4 * g + r] = s[i][r];
   }
   __syncthreads();
 #pragma unroll
@@ -92,7 +92,7 @@ __device__ __forceinline__ void add_norm(f32x4 (&acc)[NRT], const float bv, cons
       const int rr = i * 16 + 4 * g + r;
       float t = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * MAXROWS + rr];
+      for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * RSTR + rr];
       const float rstd = rsqrtf(t * (1.0f / EH) + eps);
       const Hh y = from_f<Hh>((acc[i][r] - mean[i][r]) * rstd * gv + btv);
       sOut[rr * XS + col] = (rr < N) ? y : (Hh)0.0f;        // rows past the sample stay zero (they feed the next GEMM as padding)
@@ -115,14 +115,38 @@ __device__ __forceinline__ void enc_mark_start() {
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) __hip_atomic_fetch_add(&magic_enc_starts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// LDS layout of the per-sample body.  Samples of <= 48 rows (panoramas: 36-38 views) take the COMPACT layout, 76.5 KB: images sized for 48
+// rows, ONE zero row behind the V image (the PV product's key steps past row 47 are clamped onto it) instead of 48 zeroed rows, six
+// probability tiles (2 heads x 3 query tiles: waves 6 and 7 have no attention unit) of pitch 72, the LayerNorm partial sums behind the
+// GELU image.  With the row-split text tiles at 79.6 KB the mixed launch then fits TWO workgroups per CU.  (Measured: the launch takes the
+// same 180-230 us either way -- at 145 KB a text tile has its CU to itself, 14 us per layer, and the panoramas run after the tiles; at
+// 79.6 KB everything is resident at once and a text tile takes 22 us per layer next to its neighbour.  Kept for the launches that are all
+// small samples: twice the workgroups per CU.)
+template <int NRT> struct EncLay {
+  static constexpr bool COMPACT = NRT <= 3;
+  static constexpr int RA = COMPACT ? 48 : MAXROWS;        // rows of the [rows][XS] images and row stride of the partial sums
+  static constexpr int KR = COMPACT ? 49 : KROWS;          // rows of the Q|K|V image
+  static constexpr int PW = COMPACT ? 72 : PSW;            // probability tile pitch
+};
+// B fragment from a [k][n] image whose rows >= kmax do not exist: they read row `zrow` (zeros)
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> tfrag_z(const Hh* s, int pitch, int n0, int k0, int lane, int kmax, int zrow) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  int r0 = k0 + 8 * g + q, r1 = r0 + 4;
+  r0 = r0 < kmax ? r0 : zrow; r1 = r1 < kmax ? r1 : zrow;
+  const h16x4<Hh> lo = lds_tr4(s + r0 * pitch + n0 + 4 * pp), hi = lds_tr4(s + r1 * pitch + n0 + 4 * pp);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 template <int NRT, typename Hh>
 __device__ __forceinline__ void enc_body(const EncParamsT<Hh>& p, const EncSegT<Hh>& sg, const int samp, unsigned char* smem) {
-  Hh* sX = (Hh*)smem;                        // [80][XS]   layer input / residual of the attention block
-  Hh* sA = sX + MAXROWS * XS;                  // [80][XS]   attention context, then (after the norm) the FFN's input / residual
-  Hh* sQKV = sA + MAXROWS * XS;                // [96][QS]   Q | K | V
-  Hh* sP = sQKV + KROWS * QS;                  // [8][16][PSW] per-wave probability tiles
-  Hh* sG = sQKV;                               // [80][GS]   GELU output (aliases Q|K|V and the probability tiles, dead by then)
-  float* red = (float*)(sP + NWAVE * 16 * PSW);  // [8][80]    LayerNorm partial sums
+  typedef EncLay<NRT> LY;
+  constexpr int RA = LY::RA, KR = LY::KR, PW = LY::PW;
+  Hh* sX = (Hh*)smem;                        // [RA][XS]   layer input / residual of the attention block
+  Hh* sA = sX + RA * XS;                       // [RA][XS]   attention context, then (after the norm) the FFN's input / residual
+  Hh* sQKV = sA + RA * XS;                     // [KR][QS]   Q | K | V
+  Hh* sP = sQKV + KR * QS;                     // [8 | 6][16][PW] per-wave probability tiles
+  Hh* sG = sQKV;                               // [RA][GS]   GELU output (aliases Q|K|V and the probability tiles, dead by then)
+  float* red = LY::COMPACT ? (float*)(sQKV + RA * GS) : (float*)(sP + NWAVE * 16 * PSW);   // [8][RA] LayerNorm partial sums (compact: behind the GELU image)
   const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = sg.N, ldp = sg.ldp;
   const int NKP = (N + 31) / 32 * 32;
@@ -175,8 +199,8 @@ __device__ __forceinline__ void enc_body(const EncParamsT<Hh>& p, const EncSegT<
       for (int ks = 0; ks < 4; ++ks) bw[ct][ks] = gfrag(L.Wqkv, EH, (3 * w + ct) * 16, ks * 32, lane);
     // key rows past the computed ones must be finite zeros (PV multiplies them by zero probabilities); the GELU image of the
     // previous layer overlapped them
-    for (int id = tid; id < (KROWS - ROWS) * (384 / 8); id += NWAVE * 64) {
-      const int r = ROWS + id / 48, c = (id % 48) * 8;
+    for (int id = tid; id < (KR - (LY::COMPACT ? 48 : ROWS)) * (384 / 8); id += NWAVE * 64) {      // (compact: the one zero row, 48)
+      const int r = (LY::COMPACT ? 48 : ROWS) + id / 48, c = (id % 48) * 8;
       h16x8<Hh> zv;
 #pragma unroll
       for (int e = 0; e < 8; ++e) zv[e] = (Hh)0.0f;
@@ -226,7 +250,7 @@ __device__ __forceinline__ void enc_body(const EncParamsT<Hh>& p, const EncSegT<
       for (int ks = 0; ks < 4; ++ks) w1[ct][ks] = gfrag(L.W1, EH, (4 * w + ct) * 16, ks * 32, lane);
     dd.site = L.site_attn; dd.p = p.p_attn;
     const DropState dsa = drop_init(dd);
-    Hh* sPw = sP + w * 16 * PSW;
+    Hh* sPw = sP + w * 16 * PW;
     for (int u = w; u < ENH * NRT; u += NWAVE) {
       const int h = u / NRT, rt = u % NRT;
       f32x4 sc[NRT];
@@ -266,11 +290,11 @@ __device__ __forceinline__ void enc_body(const EncParamsT<Hh>& p, const EncSegT<
 #pragma unroll
       for (int j = 0; j < NRT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sPw[(4 * g + r) * PSW + j * 16 + c16] = from_f<Hh>(sc[j][r] * sum[r]);
+        for (int r = 0; r < 4; ++r) sPw[(4 * g + r) * PW + j * 16 + c16] = from_f<Hh>(sc[j][r] * sum[r]);
       if (NRT * 16 < NKP) {
         for (int id = lane; id < 16 * (NKP - NRT * 16); id += 64) {
           const int r = id / (NKP - NRT * 16), c = NRT * 16 + id % (NKP - NRT * 16);
-          sPw[r * PSW + c] = (Hh)0.0f;
+          sPw[r * PW + c] = (Hh)0.0f;
         }
       }
       wave_lds_sync();                             // the tile is wave-private: no workgroup barrier needed
@@ -280,7 +304,7 @@ __device__ __forceinline__ void enc_body(const EncParamsT<Hh>& p, const EncSegT<
         const int cpr = ldp / 8;
         for (int id = lane; id < nq * cpr; id += 64) {
           const int r = id / cpr, c = (id % cpr) * 8;
-          *(h16x8<Hh>*)(Pg + (long long)r * ldp + c) = *(const h16x8<Hh>*)(sPw + r * PSW + c);
+          *(h16x8<Hh>*)(Pg + (long long)r * ldp + c) = *(const h16x8<Hh>*)(sPw + r * PW + c);
         }
       }
       if (dsa.on) {
@@ -292,7 +316,7 @@ __device__ __forceinline__ void enc_body(const EncParamsT<Hh>& p, const EncSegT<
             const int ql = 4 * g + r;
             const unsigned idx = (unsigned)(((((long long)samp * ENH + h) * N + rt * 16 + ql) * N) + key);
             const float m = (ql < nq && key < N) ? drop_mul(dsa, idx) : 0.f;
-            sPw[ql * PSW + key] = from_f<Hh>(sc[j][r] * sum[r] * m);
+            sPw[ql * PW + key] = from_f<Hh>(sc[j][r] * sum[r] * m);
           }
         }
         wave_lds_sync();
@@ -301,7 +325,7 @@ __device__ __forceinline__ void enc_body(const EncParamsT<Hh>& p, const EncSegT<
           const int cpr = ldp / 8;
           for (int id = lane; id < nq * cpr; id += 64) {
             const int r = id / cpr, c = (id % cpr) * 8;
-            *(h16x8<Hh>*)(Pg + (long long)r * ldp + c) = *(const h16x8<Hh>*)(sPw + r * PSW + c);
+            *(h16x8<Hh>*)(Pg + (long long)r * ldp + c) = *(const h16x8<Hh>*)(sPw + r * PW + c);
           }
         }
       }
@@ -309,9 +333,10 @@ __device__ __forceinline__ void enc_body(const EncParamsT<Hh>& p, const EncSegT<
 #pragma unroll
       for (int jd = 0; jd < 4; ++jd) o[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int ks = 0; ks < NKP / 32; ++ks) {
-        const h16x8<Hh> a = lfrag(sPw, PSW, 0, ks * 32, lane);
+        const h16x8<Hh> a = lfrag(sPw, PW, 0, ks * 32, lane);
 #pragma unroll
-        for (int jd = 0; jd < 4; ++jd) o[jd] = emma(a, tfrag(sQKV + 2 * EH + h * EHD, QS, jd * 16, ks * 32, lane), o[jd]);
+        for (int jd = 0; jd < 4; ++jd) o[jd] = emma(a, LY::COMPACT ? tfrag_z(sQKV + 2 * EH + h * EHD, QS, jd * 16, ks * 32, lane, 48, 48)
+                                    : tfrag(sQKV + 2 * EH + h * EHD, QS, jd * 16, ks * 32, lane), o[jd]);
       }
 #pragma unroll
       for (int jd = 0; jd < 4; ++jd)
@@ -342,7 +367,7 @@ __device__ __forceinline__ void enc_body(const EncParamsT<Hh>& p, const EncSegT<
       dd.site = L.site_ao; dd.p = p.p_hidden;
       const DropState dsh = drop_init(dd);
       // the first statistics barrier inside add_norm also orders "every wave has read the context image" before it is overwritten
-      add_norm<NRT>(acc, pb_o, pg_1, pe_1, sX, red, sA, L.rstd_a, N, row_base, p.eps, dsh, w, lane);
+      add_norm<NRT, RA>(acc, pb_o, pg_1, pe_1, sX, red, sA, L.rstd_a, N, row_base, p.eps, dsh, w, lane);
     }
     __syncthreads();                              // sA = attention-block output, complete
     copy_out(sA, XS, L.a + row_base * EH, EH, N, EH, tid);
@@ -415,7 +440,7 @@ __device__ __forceinline__ void enc_body(const EncParamsT<Hh>& p, const EncSegT<
       }
       dd.site = L.site_out; dd.p = p.p_hidden;
       const DropState dsh = drop_init(dd);
-      add_norm<NRT>(acc, pb_2, pg_2, pe_2, sA, red, sX, L.rstd_o, N, row_base, p.eps, dsh, w, lane);
+      add_norm<NRT, RA>(acc, pb_2, pg_2, pe_2, sA, red, sX, L.rstd_o, N, row_base, p.eps, dsh, w, lane);
     }
     __syncthreads();                              // sX = block output, complete; every wave is done with the GELU image
     copy_out(sX, XS, L.out + row_base * EH, EH, N, EH, tid);
@@ -828,6 +853,7 @@ __global__ __launch_bounds__(512) void encoder_mix_kernel(EncParamsT<Hh> p, int 
   int b = blockIdx.x, s = 0, nt = k0;
   unsigned* cnt = p.sync + 4;
   const int blocks0 = p.seg[0].nsamp * k0;
+  // (measured and not kept: panoramas first in the grid, 1.567 -> 1.582 ms/step; text tiles and panoramas alternating, 1.57 -> 1.64)
   if (b >= blocks0) { b -= blocks0; s = 1; nt = k1; }
   const EncSegT<Hh>& sg = p.seg[s];
   const int na = nt > 0 ? nt : 1;
@@ -844,6 +870,7 @@ static size_t enc_rs_lds_bytes() { return (size_t)(80 * XS + 81 * XS + 80 * XS +
 static size_t enc_lds_bytes() {
   return (size_t)(2 * MAXROWS * XS + KROWS * QS + NWAVE * 16 * PSW) * 2 + (size_t)NWAVE * MAXROWS * sizeof(float);
 }
+static size_t enc_lds_bytes_compact() { return (size_t)(2 * 48 * XS + 49 * QS + 6 * 16 * 72) * 2; }      // EncLay<NRT <= 3>
 
 __global__ void enc_start_gate_kernel(long long timeout_ticks) {
   if (threadIdx.x) return;
@@ -924,18 +951,22 @@ extern "C" int magic_encoder_fwd(int dtype, const void* params, int nbytes, void
         else hipLaunchKernelGGL(encoder_rs_kernel<f16>, dim3(grid), dim3(512), enc_rs_lds_bytes(), (hipStream_t)stream, pf, nt0, nt1);
       } else {
         const int grid = p.seg[0].nsamp * nt0 + ns1, k1 = -(nt1 < 2 ? 2 : nt1);
-        if (dtype == DT_BF16) hipLaunchKernelGGL(encoder_mix_kernel<bf16>, dim3(grid), dim3(512), enc_lds_bytes(), (hipStream_t)stream, p, nt0, k1);
-        else hipLaunchKernelGGL(encoder_mix_kernel<f16>, dim3(grid), dim3(512), enc_lds_bytes(), (hipStream_t)stream, pf, nt0, k1);
+        // the panoramas' per-sample body takes its compact layout (nt1 <= 3): both bodies fit twice into a CU's LDS
+        const size_t shm_mix = enc_rs_lds_bytes() > enc_lds_bytes_compact() ? enc_rs_lds_bytes() : enc_lds_bytes_compact();
+        if (dtype == DT_BF16) hipLaunchKernelGGL(encoder_mix_kernel<bf16>, dim3(grid), dim3(512), shm_mix, (hipStream_t)stream, p, nt0, k1);
+        else hipLaunchKernelGGL(encoder_mix_kernel<f16>, dim3(grid), dim3(512), shm_mix, (hipStream_t)stream, pf, nt0, k1);
       }
       return launch_status();
     }
     if (hipMemsetAsync(p.sync, 0, 16, (hipStream_t)stream) != hipSuccess) return MAGIC_ERR_LAUNCH;      // per-sample form: the give-up word still reads 0
   }
-  const size_t shm = enc_lds_bytes();
+  bool all_small = true;        // every sample <= 48 rows: the compact layout, two workgroups per CU
+  for (int sgi = 0; sgi < p.nseg; ++sgi) all_small = all_small && p.seg[sgi].N <= 48;
+  const size_t shm = all_small ? enc_lds_bytes_compact() : enc_lds_bytes();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)encoder_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    (void)hipFuncSetAttribute((const void*)encoder_fwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute((const void*)encoder_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)encoder_fwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_lds_bytes());
     attr_set = true;
   }
   if (dtype == DT_BF16) hipLaunchKernelGGL(encoder_fwd_kernel<bf16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
@@ -1195,7 +1226,7 @@ __device__ __forceinline__ void xenc_body(const XParamsT<Hh>& p, const XSegT<Hh>
       proj16<NRT>(acc, sA, wo, lane);
       dd.site = L.site_ao; dd.p = p.p_hidden;
       const DropState dsh = drop_init(dd);
-      add_norm<NRT>(acc, pb_o, pg_1, pe_1, sX, red, sA, L.rstd_a, Nq, qbase, p.eps, dsh, w, lane);
+      add_norm<NRT, MAXROWS>(acc, pb_o, pg_1, pe_1, sX, red, sA, L.rstd_a, Nq, qbase, p.eps, dsh, w, lane);
     }
     // context key / value projection weights: 2 column tiles per wave (K|V = 256 columns)
     h16x8<Hh> wkv[2][4];
@@ -1275,7 +1306,7 @@ __device__ __forceinline__ void xenc_body(const XParamsT<Hh>& p, const XSegT<Hh>
       proj16<NRT>(acc, sX, woc, lane);
       dd.site = L.site_co; dd.p = p.p_hidden;
       const DropState dsh = drop_init(dd);
-      add_norm<NRT>(acc, pb_oc, pg_c, pe_c, sA, red, sX, L.rstd_c, Nq, qbase, p.eps, dsh, w, lane);
+      add_norm<NRT, MAXROWS>(acc, pb_oc, pg_c, pe_c, sA, red, sX, L.rstd_c, Nq, qbase, p.eps, dsh, w, lane);
     }
     __syncthreads();                              // sX = c (cross-attention block output)
     copy_out(sX, XS, L.c + qbase * EH, EH, Nq, EH, tid);
@@ -1343,7 +1374,7 @@ __device__ __forceinline__ void xenc_body(const XParamsT<Hh>& p, const XSegT<Hh>
       dd.site = L.site_out; dd.p = p.p_hidden;
       const DropState dsh = drop_init(dd);
       // residual = c (sX), output -> sX: every wave has added its residual values before add_norm's first barrier
-      add_norm<NRT>(acc, pb_2, pg_2, pe_2, sX, red, sX, L.rstd_o, Nq, qbase, p.eps, dsh, w, lane);
+      add_norm<NRT, MAXROWS>(acc, pb_2, pg_2, pe_2, sX, red, sX, L.rstd_o, Nq, qbase, p.eps, dsh, w, lane);
     }
     __syncthreads();
     copy_out(sX, XS, L.out + qbase * EH, EH, Nq, EH, tid);

@@ -229,6 +229,16 @@ def pmc_dw_fetch():
     return None
 
 
+def pmc_chain_traffic():
+    """HBM bytes (fetched + written) per launch of the teacher's chain kernel from the committed PMC passes, or None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+            j = json.load(f)
+        return round(j["chain_fetch_bytes_per_launch"] + j["chain_write_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def build_models(dtype, dev, dropout, world, batch=48):
     dk = dict(hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)   # r2r_magic_model_config.json:2-3
     tcfg = make_config(256, role="teacher", **dk)                                   # teacher_* of r2r_magic_model_config.json:33-37
@@ -599,6 +609,13 @@ def main():
                                "achieved_tflops": round(ach_all, 2), "frac": round(ach_all / PEAK_BF16_TFLOPS, 5)},
                            "whole_step": {"summed_kernel_ms_per_step_serialised": round(all_ms / nprof, 3), "graph_replay_wall_ms_per_step": round(step_ms, 3),
                                           "frac_of_mfma_peak_on_wall": round(O.FLOPS["total"] / nprof / (step_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 5)},
+                           # the work that WAS the GEMM family until round 3 (the teacher's per-token GEMMs now run inside chain_fwd_kernel): the
+                           # round-to-round comparable figure (round 2: 92.3 TFLOP/s for 101 GFLOP per step)
+                           "gemm_family_plus_teacher_chain": {
+                               "algorithmic_gflop_per_step": round((flops + O.FLOPS["chain"]) / nprof / 1e9, 2),
+                               "ms_per_step": round((gemm_ms + chain_ms) / nprof, 3),
+                               "achieved_tflops": round((flops + O.FLOPS["chain"]) / max(gemm_ms + chain_ms, 1e-9) / 1e9, 2),
+                               "frac": round((flops + O.FLOPS["chain"]) / max(gemm_ms + chain_ms, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 5)},
                            "teacher_chain_kernel": {
                                "kernel": "chain_fwd_kernel (csrc/chain.hip): the frozen teacher's per-token half of a block (output projection + LayerNorm, FFN, "
                                          "LayerNorm, next Q|K|V projection) at H = 256 in one launch, forward only",
@@ -606,6 +623,7 @@ def main():
                                "avg_launch_us": round(chain_ms / max(chain_n, 1) * 1e3, 1), "share_of_kernel_time": round(chain_ms / all_ms, 4),
                                "achieved_tflops": round(O.FLOPS["chain"] / max(chain_ms, 1e-9) / 1e9, 2),
                                "frac_of_mfma_peak": round(O.FLOPS["chain"] / max(chain_ms, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 5),
+                               "pmc_traffic_bytes_per_launch": pmc_chain_traffic(),
                                "bound": "L2 -> CU fill rate: a 32-row tile streams 1.57 MB of weight fragments (2 MFMAs each); one CU takes 58 B/ns "
                                         "(26.5 us for one workgroup on an idle GPU, profiles/micro/chain_timing.hip)"},
                            "launches_per_step": sum(c for t, c in by.values()) // nprof,

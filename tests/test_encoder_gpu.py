@@ -338,3 +338,31 @@ def test_node_inputs_backward_in_shared_launches_matches_the_per_op_sequence():
     assert not torch.equal(res[True][0], base_p)
     ga, gb = res[True][2], res[False][2]
     assert gb.abs().max() > 0 and torch.allclose(ga, gb, rtol=1e-4, atol=1e-5), (ga - gb).abs().max().item()
+
+
+def test_encoder_start_gate_opens_on_the_next_encoder_launch_and_times_out_without_one():
+    """magic_encoder_start_gate: a stream parked on it resumes when another stream's whole-encoder launch has its last workgroup on a CU (the
+    teacher's forward is held back that way), and after its timeout otherwise"""
+    m = student()
+    m.eval()
+    b = synth.make_batch("sap", batch_size=8, seed=3, step=0)
+    bd, plan = synth.batch_to(b, DEV), build_plan(b, "sap", DEV)
+    with torch.no_grad():
+        m(bd, "sap", compute_loss=False, plan=plan)              # warm-up (code objects, allocator)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(side):                                 # no encoder launch follows: the gate gives up after its timeout
+        e0.record()
+        O.encoder_start_gate(2000)
+        e1.record()
+    torch.cuda.synchronize()
+    assert 1.5 < e0.elapsed_time(e1) < 20.0, e0.elapsed_time(e1)
+    with torch.cuda.stream(side):                                 # an encoder launch on the main stream opens it long before the timeout
+        e0.record()
+        O.encoder_start_gate(100000)
+        e1.record()
+    with torch.no_grad():
+        m(bd, "sap", compute_loss=False, plan=plan)
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) < 50.0, e0.elapsed_time(e1)

@@ -201,9 +201,10 @@ int magic_cfp_loss(int dtype, int B, int H, const void* a0, const void* a1, cons
  * candidate-view / masked-token / CLS row selection; backward = same call on the transposed CSR. */
 int magic_csr_gather(int dtype, int n_out, int H, const void* src, const int* ptr, const int* idx, const float* w,
                      void* out, int accumulate, void* stream);
-/* adaptive_pano_fusion (r2r_magic_model_config.json:57): attention pooling of the V views */
+/* adaptive_pano_fusion (r2r_magic_model_config.json:57): attention pooling of the V views.  P != NULL: the same launch also writes the
+ * panorama encoder's attention map averaged over heads, pmean[n, r] = (1/nh) sum_h P[n, h, r], r < inner (what magic_head_mean_fwd computes) */
 int magic_pano_fuse_fwd(int dtype, int N, int V, int H, const void* x, const int* lens, const float* wf, const float* bf,
-                        void* fused, float* probs, void* stream);
+                        void* fused, float* probs, const void* P, int nh, int inner, float* pmean, void* stream);
 int magic_pano_fuse_bwd(int dtype, int N, int V, int H, const void* x, const float* probs, const float* wf, const void* dfused,
                         void* dx, float* dwf, float* dbf, void* stream);
 /* global/local gate + -inf masks + local->global logit fusion (validate_sap contract :503-535) */

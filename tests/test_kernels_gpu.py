@@ -418,7 +418,11 @@ def test_pano_fuse_fwd_bwd(dtype):
     df = rnd(N, H, dtype=dtype, seed=3)
     ref.backward(df.float())
     fused, probs = torch.empty(N, H, dtype=dtype, device=DEV), torch.empty(N, V, device=DEV)
-    O.pano_fuse_fwd(x, lens, wf.detach(), bf.detach(), fused, probs, N, V, H)
+    nh, ldp = 2, 40
+    P = torch.softmax(rnd(N, nh, V, ldp, seed=9).float(), -1).to(dtype)
+    pmean = torch.empty(N, V, ldp, device=DEV)
+    O.pano_fuse_fwd(x, lens, wf.detach(), bf.detach(), fused, probs, N, V, H, P=P, nh=nh, inner=V * ldp, pmean=pmean)     # + the attention map's head mean
+    check(pmean, P.float().mean(1), "head mean riding in the pano fuse launch", rtol=1e-6, atol=1e-7)
     check(fused, ref, "pano fuse fwd", **tol(dtype))
     check(probs, p, "pano fuse probs", **(dict(rtol=1e-4, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-3)))
     dx = torch.zeros(N, V, H, dtype=dtype, device=DEV)

@@ -73,9 +73,17 @@ __global__ __launch_bounds__(256) void csr_gather_multi_kernel(CsrMulti mm) {
 // one block (256 threads) per panorama, V <= 64 views.
 template <typename T>
 __global__ __launch_bounds__(256) void pano_fuse_fwd_kernel(int N, int V, int H, const T* x, const int* lens, const float* wf, const float* bf,
-                                                            T* fused, float* probs) {
+                                                            T* fused, float* probs, const T* P, int nh, int inner, float* pmean) {
   __shared__ float sc[64];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (P) {        // the panorama's attention map averaged over heads (the `img` attention-distillation operand): one launch less per forward
+    const T* pb = P + (long long)n * nh * inner;
+    for (int r = tid; r < inner; r += 256) {
+      float s = 0.f;
+      for (int h = 0; h < nh; ++h) s += to_f(pb[(long long)h * inner + r]);
+      pmean[(long long)n * inner + r] = s / nh;
+    }
+  }
   const T* xb = x + (long long)n * V * H;
   for (int v = wid; v < V; v += 4) {
     float d = 0.f;
@@ -272,13 +280,13 @@ extern "C" int magic_csr_gather_multi(int dtype, int H, int n, const magic_csr_p
 }
 
 extern "C" int magic_pano_fuse_fwd(int dtype, int N, int V, int H, const void* x, const int* lens, const float* wf, const float* bf,
-                                   void* fused, float* probs, void* stream) {
-  if (N <= 0 || V <= 0 || V > 64 || H <= 0) return MAGIC_ERR_ARG;
+                                   void* fused, float* probs, const void* P, int nh, int inner, float* pmean, void* stream) {
+  if (N <= 0 || V <= 0 || V > 64 || H <= 0 || (P && (nh <= 0 || inner <= 0 || !pmean))) return MAGIC_ERR_ARG;
   dim3 grid(N), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DT_BF16) hipLaunchKernelGGL(pano_fuse_fwd_kernel<bf16>, grid, block, 0, st, N, V, H, (const bf16*)x, lens, wf, bf, (bf16*)fused, probs);
-  else if (dtype == DT_F16) hipLaunchKernelGGL(pano_fuse_fwd_kernel<f16>, grid, block, 0, st, N, V, H, (const f16*)x, lens, wf, bf, (f16*)fused, probs);
-  else hipLaunchKernelGGL(pano_fuse_fwd_kernel<float>, grid, block, 0, st, N, V, H, (const float*)x, lens, wf, bf, (float*)fused, probs);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(pano_fuse_fwd_kernel<bf16>, grid, block, 0, st, N, V, H, (const bf16*)x, lens, wf, bf, (bf16*)fused, probs, (const bf16*)P, nh, inner, pmean);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(pano_fuse_fwd_kernel<f16>, grid, block, 0, st, N, V, H, (const f16*)x, lens, wf, bf, (f16*)fused, probs, (const f16*)P, nh, inner, pmean);
+  else hipLaunchKernelGGL(pano_fuse_fwd_kernel<float>, grid, block, 0, st, N, V, H, (const float*)x, lens, wf, bf, (float*)fused, probs, (const float*)P, nh, inner, pmean);
   return launch_status();
 }
 

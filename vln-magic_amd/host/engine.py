@@ -659,8 +659,12 @@ class MagicNet:
         p = self.p
         dt, dp = self.self_stacks_bwd([(ct, p + "lang_encoder.layer.{}.", d_txt, dP_txt),
                                        (cp, p + "img_embeddings.pano_encoder.layer.{}.", d_pano, dP_pano)], on_iter=on_iter)
-        self._text_emb_bwd(ct, plan, dt)
-        self._pano_emb_bwd(cp, plan, dp)
+        # the two embedding LayerNorm backwards (text; panorama sum) are independent: one paired launch
+        from . import lib as _L
+        with _L.group():
+            self._text_emb_bwd(ct, plan, dt)
+            dsum = self._pano_emb_bwd(cp, plan, dp, stage=0)
+        self._pano_emb_bwd(cp, plan, dp, stage=1, dsum=dsum)
 
     def text_bwd(self, c, plan, d_out, dP_init=None):
         p, H = self.p, self.H
@@ -733,17 +737,19 @@ class MagicNet:
         Np, V = c.Np, c.V
         c.out, c.P, c.ldp = c.layers[-1].out, c.layers[-1].P, c.layers[-1].ldp
         c.img_attn = self.new(Np, V, c.ldp, dtype=torch.float32)
-        O.head_mean_fwd(c.P, c.img_attn, Np, self.nh, V * c.ldp)
         c.fused = self.new(Np, H)
         c.fprobs = self.new(Np, V, dtype=torch.float32)
+        hm = dict(P=c.P, nh=self.nh, inner=V * c.ldp, pmean=c.img_attn) if c.P.is_contiguous() else {}      # head-mean of the attention map: same launch
+        if not hm:
+            O.head_mean_fwd(c.P, c.img_attn, Np, self.nh, V * c.ldp)
         if cfg_get(self.cfg, "adaptive_pano_fusion"):
             fl = self.lin(p + "pano_fuse_linear.weight")
-            O.pano_fuse_fwd(c.out, plan["view_lens"], fl.Wm, fl.b, c.fused, c.fprobs, Np, V, H)
+            O.pano_fuse_fwd(c.out, plan["view_lens"], fl.Wm, fl.b, c.fused, c.fprobs, Np, V, H, **hm)
         else:
             # masked mean over the valid views (adaptive_pano_fusion=false, r2r_magic_model_config.json:57) = the attention pooling
             # with a zero scoring vector: softmax of equal scores over the unmasked views is 1/n each
             zw, zb = self._zero_fuse()
-            O.pano_fuse_fwd(c.out, plan["view_lens"], zw, zb, c.fused, c.fprobs, Np, V, H)
+            O.pano_fuse_fwd(c.out, plan["view_lens"], zw, zb, c.fused, c.fprobs, Np, V, H, **hm)
         return c
 
     def _zero_fuse(self):
@@ -776,15 +782,19 @@ class MagicNet:
                 zw, zb = self._zero_fuse()
                 O.pano_fuse_bwd(c.out, c.fprobs, zw, d_fused, d_pano, self.new(H, dtype=torch.float32), self.new(1, dtype=torch.float32), Np, V, H)
 
-    def _pano_emb_bwd(self, c, plan, d):
+    def _pano_emb_bwd(self, c, plan, d, stage=None, dsum=None):
+        """stage None: everything; 0: the sum LayerNorm's backward only (returns its dx; groupable with the text embedding's); 1: the rest"""
         p, H = self.p + "img_embeddings.", self.H
         Np, V = c.Np, c.V
         M = Np * V
-        n3 = self.ln(p + "layer_norm")
-        dsum = self.new(M, H)
-        O.ln_bwd(M, H, d, y=c.X0, gamma=n3.g, beta=n3.b, rstd=c.rstd_x0, dx=dsum, dgamma=n3.dg, dbeta=n3.db, drop_dy=c.edrop,
-                 dtabs=((plan["nav_types"], 0, 0, self.S.g(p + "nav_type_embedding.weight"), 1),
-                        (None, 0, 0, self.S.g(self.p + "embeddings.token_type_embeddings.weight"), 0), None))
+        if stage != 1:
+            n3 = self.ln(p + "layer_norm")
+            dsum = self.new(M, H)
+            O.ln_bwd(M, H, d, y=c.X0, gamma=n3.g, beta=n3.b, rstd=c.rstd_x0, dx=dsum, dgamma=n3.dg, dbeta=n3.db, drop_dy=c.edrop,
+                     dtabs=((plan["nav_types"], 0, 0, self.S.g(p + "nav_type_embedding.weight"), 1),
+                            (None, 0, 0, self.S.g(self.p + "embeddings.token_type_embeddings.weight"), 0), None))
+            if stage == 0:
+                return dsum
         n1 = self.ln(p + "img_layer_norm")
         dP0 = self.new(M, H)
         O.ln_bwd(M, H, dsum, y=c.A1, gamma=n1.g, beta=n1.b, rstd=c.rstd_a1, dx=dP0, dgamma=n1.dg, dbeta=n1.db)

@@ -54,7 +54,7 @@ SIGNATURES = {
     "magic_csr_gather_multi": [i32, i32, i32, vp, vp],
     "magic_smallk_ln_bwd_pair": [i32, i32, vp, vp],
     "magic_csr_gather": [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp],
-    "magic_pano_fuse_fwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "magic_pano_fuse_fwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
     "magic_pano_fuse_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_sap_fuse_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
     "magic_sap_fuse_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],

@@ -681,8 +681,11 @@ def smallk_ln_bwd_pair(H, problems):
     L.call("magic_smallk_ln_bwd_pair", L.dt(problems[0]["dy"].dtype), H, C.addressof(arr), L.stream())
 
 
-def pano_fuse_fwd(x, lens, wf, bf, fused, probs, N, V, H):
-    L.call("magic_pano_fuse_fwd", L.dt(x.dtype), N, V, H, L.P(x), L.P(lens), L.P(wf), L.P(bf), L.P(fused), L.P(probs), L.stream())
+def pano_fuse_fwd(x, lens, wf, bf, fused, probs, N, V, H, P=None, nh=0, inner=0, pmean=None):
+    """P [N, nh, inner] (+ pmean fp32 [N, inner]): the head-mean of the panorama attention map rides in the same launch"""
+    _chk(P is None or (P.dtype == x.dtype and P.is_contiguous() and pmean is not None and pmean.dtype == torch.float32), "pano_fuse head-mean operands")
+    L.call("magic_pano_fuse_fwd", L.dt(x.dtype), N, V, H, L.P(x), L.P(lens), L.P(wf), L.P(bf), L.P(fused), L.P(probs),
+           L.P(P), int(nh), int(inner), L.P(pmean), L.stream())
 
 
 def pano_fuse_bwd(x, probs, wf, dfused, dx, dwf, dbf, N, V, H):

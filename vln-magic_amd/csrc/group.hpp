@@ -8,7 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 
-enum GroupKind { KIND_NONE = 0, KIND_GEMM = 1, KIND_ATTN_FWD = 2, KIND_ATTN_BWD = 3, KIND_LLN = 4, KIND_LNB = 5, KIND_LLB = 7, KIND_CHAIN = 8 };
+enum GroupKind { KIND_NONE = 0, KIND_GEMM = 1, KIND_ATTN_FWD = 2, KIND_ATTN_BWD = 3, KIND_LLN = 4, KIND_LNB = 5, KIND_LLB = 7, KIND_CHAIN = 8, KIND_LNF = 9 };
 
 struct GroupRec { int kind, dtype, variant; alignas(16) unsigned char blob[1024]; };
 #define GROUP_CAP 8
@@ -35,3 +35,4 @@ int launch_lln(int dtype, int ht, const void* pa, const void* pb, hipStream_t st
 int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t st);
 int launch_llb(int dtype, int ht, const void* pa, const void* pb, hipStream_t st);
 int launch_chain(int dtype, int variant, const void* pa, const void* pb, hipStream_t st);
+int launch_lnf(int dtype, int H, const void* pa, const void* pb, hipStream_t st);

@@ -265,6 +265,7 @@ static int launch_one(const GroupRec& r, const GroupRec* other, hipStream_t st) 
     case KIND_LNB: return launch_lnb(r.dtype, r.variant, r.blob, pb, st);
     case KIND_LLB: return launch_llb(r.dtype, r.variant, r.blob, pb, st);
     case KIND_CHAIN: return launch_chain(r.dtype, r.variant, r.blob, pb, st);
+    case KIND_LNF: return launch_lnf(r.dtype, r.variant, r.blob, pb, st);
     default: return MAGIC_ERR_ARG;
   }
 }

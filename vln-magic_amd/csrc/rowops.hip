@@ -43,12 +43,20 @@ __device__ __forceinline__ int tab_row(const TabRef& t, int r) {
 // ---------------------------------------------------------------------------------------------
 // out = LN(in0 + in1 + tab0[..] + tab1[..] + tab2[..]) * gamma + beta      (do_ln)   | plain sum
 // NIT = H / 128 is a template parameter so the per-lane row fragment lives in exactly 2*NIT registers.
+struct LnfParams {
+  int M; const void* in0; const void* in1; TabRef t0, t1, t2; const float* gamma; const float* beta; float eps; void* out; float* rstd_out; int do_ln;
+  DropDesc din, dout; void* out_drop;
+};
 template <typename T, int NIT>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(int M, const T* in0, const T* in1, TabRef t0, TabRef t1, TabRef t2,
-                                                     const float* gamma, const float* beta, float eps, T* out, float* rstd_out, int do_ln,
-                                                     DropDesc din, DropDesc dout, T* out_drop) {
+__device__ __forceinline__ void ln_fwd_body(const LnfParams& pp, const int bid) {
+  const int M = pp.M, do_ln = pp.do_ln;
+  const T* in0 = (const T*)pp.in0; const T* in1 = (const T*)pp.in1;
+  const TabRef t0 = pp.t0, t1 = pp.t1, t2 = pp.t2;
+  const float* gamma = pp.gamma; const float* beta = pp.beta; const float eps = pp.eps;
+  T* out = (T*)pp.out; float* rstd_out = pp.rstd_out; T* out_drop = (T*)pp.out_drop;
+  const DropDesc din = pp.din, dout = pp.dout;
   constexpr int H = NIT * 128;
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, row = bid * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const DropState sin = drop_init(din), sout = drop_init(dout);     // dropout on in0 (dense -> dropout -> +residual) / on the output
   float x[2 * NIT];
@@ -88,6 +96,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, const T* in0, const 
     st2<T>(out + (long long)row * H + c, y0, y1);          // pre-dropout y: the backward recovers xhat from it
     if (sout.on) st2<T>(out_drop + (long long)row * H + c, y0 * drop_mul(sout, (unsigned)(row * H + c)), y1 * drop_mul(sout, (unsigned)(row * H + c + 1)));
   }
+}
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnfParams a) { ln_fwd_body<T, NIT>(a, blockIdx.x); }
+// two independent problems of one width in one launch (lockstep segments / L.group: the text and the panorama embedding norms)
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_fwd_pair_kernel(LnfParams a, LnfParams b, int split) {
+  if ((int)blockIdx.x < split) ln_fwd_body<T, NIT>(a, blockIdx.x);
+  else ln_fwd_body<T, NIT>(b, blockIdx.x - split);
 }
 
 // Backward of the above.  dx (optional) = gradient wrt the pre-LN sum (shared by in0/in1).
@@ -860,11 +876,27 @@ extern "C" int magic_ln_fwd(int dtype, int M, int H, const void* in0, const void
   DropDesc din{(don && site_in0) ? (const unsigned*)drop_seed : nullptr, site_in0, drop_p};
   DropDesc dout{(don && site_out) ? (const unsigned*)drop_seed : nullptr, site_out, drop_p};
   TabRef t0{tab0, idx0, mod0, off0}, t1{tab1, idx1, mod1, off1}, t2{tab2, idx2, mod2, off2};
-  dim3 grid((M + 3) / 4), block(256);
-  hipStream_t st = (hipStream_t)stream;
-#define LNF(TY, NIT) hipLaunchKernelGGL((ln_fwd_kernel<TY, NIT>), grid, block, 0, st, M, (const TY*)in0, (const TY*)in1, t0, t1, t2, gamma, beta, eps, (TY*)out, rstd, do_ln, din, dout, (TY*)out_drop)
-  DISPATCH_NIT(dtype, H, LNF);
+  LnfParams p{M, in0, in1, t0, t1, t2, gamma, beta, eps, out, rstd, do_ln, din, dout, out_drop};
+  if (group_record(KIND_LNF, dtype, H, &p, sizeof(p))) return MAGIC_OK;
+  return launch_lnf(dtype, H, &p, nullptr, (hipStream_t)stream);
+}
+
+int launch_lnf(int dtype, int H, const void* pa, const void* pb, hipStream_t st) {
+  const LnfParams& a = *(const LnfParams*)pa;
+  const int na = (a.M + 3) / 4;
+  dim3 block(256);
+  if (!pb) {
+    dim3 grid(na);
+#define LNF(TY, NIT) hipLaunchKernelGGL((ln_fwd_kernel<TY, NIT>), grid, block, 0, st, a)
+    DISPATCH_NIT(dtype, H, LNF);
 #undef LNF
+  } else {
+    const LnfParams& b = *(const LnfParams*)pb;
+    dim3 grid(na + (b.M + 3) / 4);
+#define LNF2(TY, NIT) hipLaunchKernelGGL((ln_fwd_pair_kernel<TY, NIT>), grid, block, 0, st, a, b, na)
+    DISPATCH_NIT(dtype, H, LNF2);
+#undef LNF2
+  }
   return launch_status();
 }
 

@@ -708,10 +708,11 @@ class MagicNet:
         c.X0, c.rstd_x0 = self.new(M, H), self.new(M, dtype=torch.float32)
         c.edrop = self._dh(p + "dropout")
         c.X0d = self.new(M, H) if c.edrop else None
-        O.ln_fwd(M, H, c.X0, in0=c.A1, in1=c.A2,
-                 tabs=((self.S.w(p + "nav_type_embedding.weight"), plan["nav_types"], 0, 0),
-                       (self.S.w(self.p + "embeddings.token_type_embeddings.weight"), None, 0, 0), None),
-                 gamma=n3.g, beta=n3.b, eps=self.eps, rstd=c.rstd_x0, drop_out=c.edrop, out_drop=c.X0d)
+        with _L.solo():       # (the image LayerNorm above pairs with the text embedding's; this one has no partner in the text segment)
+            O.ln_fwd(M, H, c.X0, in0=c.A1, in1=c.A2,
+                     tabs=((self.S.w(p + "nav_type_embedding.weight"), plan["nav_types"], 0, 0),
+                           (self.S.w(self.p + "embeddings.token_type_embeddings.weight"), None, 0, 0), None),
+                     gamma=n3.g, beta=n3.b, eps=self.eps, rstd=c.rstd_x0, drop_out=c.edrop, out_drop=c.X0d)
         x = c.X0d if c.edrop else c.X0
         c.layers = []
         af = float(Np) * V * V * HD * self.nh

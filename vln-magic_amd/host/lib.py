@@ -253,7 +253,7 @@ def P(t):
 
 
 PROFILE = {"on": False, "events": []}     # bench.py: per-launch HIP-event timing on the launch stream
-PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_linear_lnbwd", "magic_ln_bwd", "magic_chain_fwd"}
+PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_linear_lnbwd", "magic_ln_bwd", "magic_chain_fwd", "magic_ln_fwd"}
 _tls = threading.local()
 
 

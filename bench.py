@@ -8,7 +8,7 @@ backward -> [RCCL all-reduce of the flat gradient] -> grad clip + fused AdamW.  
 (pretrain_src/config/r2r_magic_pretrain.json:49-58).  bf16 MFMA compute, fp32 master weights/optimizer.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run); rank 0 prints ONE
-JSON line.  `roofline` = the dense-contraction (MFMA GEMM) kernel family: algorithmic FLOPs / summed launch
+JSON line.  `roofline` = the Linear-layer contraction family (MFMA GEMM kernels + the teacher's chain kernel): algorithmic FLOPs / summed launch
 durations measured with HIP events on the launch stream in a separate instrumented pass; `cpu_baseline` = the
 CPU oracle (oracle/, a restatement -- the reference's model source is withheld) timed on the host cores.
 """
@@ -203,14 +203,20 @@ def ingest_rate(dev, n_vp=4096, n_pano=290, reps=40):
             "bytes_per_traj_step": 2 * 36 * 768 * 2, "peak_GB_per_s": 8000.0}
 
 
-def pmc_traffic():
-    """HBM-side bytes per GEMM launch.  NOT measured inside this process (PMC collection needs rocprofv3 around it): read from the
-    committed post-processing of the `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
-    (profiles/pmc_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Returns (bytes, source file)."""
+def pmc_traffic(gemm_n=1, chain_n=0):
+    """HBM-side bytes per launch of the roofline family (GEMM kernels + chain kernel, weighted by this run's launch counts).  NOT measured
+    inside this process (PMC collection needs rocprofv3 around it): read from the committed post-processing of the `rocprofv3 --pmc
+    FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (profiles/pmc_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950).  Returns (bytes, source file)."""
     for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return round(json.load(f)["gemm_traffic_bytes_per_launch"]), "profiles/" + name
+                j = json.load(f)
+            g = j["gemm_traffic_bytes_per_launch"]
+            c = j.get("chain_fetch_bytes_per_launch", 0.0) + j.get("chain_write_bytes_per_launch", 0.0)
+            if c and chain_n:
+                return round((g * gemm_n + c * chain_n) / (gemm_n + chain_n)), "profiles/" + name
+            return round(g), "profiles/" + name
         except Exception:
             continue
     return None, None
@@ -591,33 +597,35 @@ def main():
         # achieved = the family's algorithmic FLOPs / the family's SUMMED launch durations (non-overlapped pass), i.e.
         # (FLOPs per launch) / (average launch duration); frac = achieved / dense bf16 MFMA peak.  Reproducible from the committed
         # rocprofv3 --kernel-trace --stats CSV of this command: sum the gemm_* kernels' TotalDurationNs, divide by the executed steps.
-        ach = (flops / nprof) / (gemm_ms / nprof * 1e-3) / 1e12
+        # the roofline object = the Linear-layer contraction family: the GEMM kernels + (since round 3) the chain kernel that took over the frozen
+        # teacher's Linear layers -- the same work rounds 1-2 reported as "the GEMM family" (101 GFLOP per step)
+        fam_flops, fam_ms, fam_n = flops + O.FLOPS["chain"], gemm_ms + chain_ms, gemm_n + chain_n
+        ach = (fam_flops / nprof) / (fam_ms / nprof * 1e-3) / 1e12
+        ach_gemm = (flops / nprof) / (gemm_ms / nprof * 1e-3) / 1e12
         ach_all = (O.FLOPS["total"] / nprof) / (mfma_ms / nprof * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic()
-        roof = {"bound": "mfma", "kernel": "gemm_kernel / gemm_xcd_kernel / gemm_grouped_kernel / gemm_dw_batch_kernel <bf16, NT|NN|TN> (the dominant kernel "
-                                           "family: Linear forward, input and weight gradients, projections)",
+        traffic, traffic_src = pmc_traffic(gemm_n, chain_n)
+        roof = {"bound": "mfma", "kernel": "gemm_kernel / gemm_xcd_kernel / gemm_grouped_kernel / gemm_dw_batch_kernel <bf16, NT|NN|TN> + chain_fwd_kernel<bf16> (the dominant "
+                                           "kernel family: every Linear layer's forward, input and weight gradient; the frozen teacher's run inside chain_fwd_kernel since round 3)",
                 "achieved": round(ach, 3), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5),
                 "traffic": traffic, "traffic_source": (traffic_src + " (offline rocprofv3 --pmc passes of this command; not collected in this run)") if traffic_src else None,
                 "how": "HIP events around every launch on the launch stream, eager pass of the same steps with the captured graphs' launch structure, "
                        "teacher serialised on the main stream, device-side gate so the host runs ahead; family time = SUM of its launch durations",
-                "detail": {"algorithmic_gflop_per_step": round(flops / nprof / 1e9, 2), "gemm_launches_per_step": gemm_n // nprof,
+                "detail": {"family_gflop_per_step": round(fam_flops / nprof / 1e9, 2), "family_launches_per_step": round(fam_n / nprof, 1),
+                           "family_ms_per_step": round(fam_ms / nprof, 3), "family_avg_launch_us": round(fam_ms / max(fam_n, 1) * 1e3, 2),
+                           "family_share_of_kernel_time": round(fam_ms / all_ms, 4),
+                           "gemm_kernels_alone": {"achieved_tflops": round(ach_gemm, 2), "frac": round(ach_gemm / PEAK_BF16_TFLOPS, 5),
+                                                  "note": "round 2 reported these alone (92.3 TFLOP/s for 101 GFLOP); the teacher's large-M GEMMs have left the set"},
+                           "algorithmic_gflop_per_step": round(flops / nprof / 1e9, 2), "gemm_launches_per_step": gemm_n // nprof,
                            "gemm_ms_per_step": round(gemm_ms / nprof, 3), "avg_gemm_launch_us": round(gemm_ms / max(gemm_n, 1) * 1e3, 2),
                            "gemm_share_of_kernel_time": round(gemm_ms / all_ms, 4),
                            "all_dense_contraction_kernels": {
-                               "kernels": "gemm + fused linear+LayerNorm (fwd / bwd) + fused attention (fwd / bwd) + whole-encoder forwards + row-block backward",
+                               "kernels": "gemm + fused linear+LayerNorm (fwd / bwd) + fused attention (fwd / bwd) + whole-encoder forwards + row-block backward + the teacher's chain kernel",
                                "algorithmic_gflop_per_step": round(O.FLOPS["total"] / nprof / 1e9, 2),
                                "gflop_by_family": {k: round(O.FLOPS[k] / nprof / 1e9, 2) for k in ("gemm", "linear_ln", "attn", "enc", "chain")},
                                "ms_per_step": round(mfma_ms / nprof, 3), "share_of_kernel_time": round(mfma_ms / all_ms, 4),
                                "achieved_tflops": round(ach_all, 2), "frac": round(ach_all / PEAK_BF16_TFLOPS, 5)},
                            "whole_step": {"summed_kernel_ms_per_step_serialised": round(all_ms / nprof, 3), "graph_replay_wall_ms_per_step": round(step_ms, 3),
                                           "frac_of_mfma_peak_on_wall": round(O.FLOPS["total"] / nprof / (step_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 5)},
-                           # the work that WAS the GEMM family until round 3 (the teacher's per-token GEMMs now run inside chain_fwd_kernel): the
-                           # round-to-round comparable figure (round 2: 92.3 TFLOP/s for 101 GFLOP per step)
-                           "gemm_family_plus_teacher_chain": {
-                               "algorithmic_gflop_per_step": round((flops + O.FLOPS["chain"]) / nprof / 1e9, 2),
-                               "ms_per_step": round((gemm_ms + chain_ms) / nprof, 3),
-                               "achieved_tflops": round((flops + O.FLOPS["chain"]) / max(gemm_ms + chain_ms, 1e-9) / 1e9, 2),
-                               "frac": round((flops + O.FLOPS["chain"]) / max(gemm_ms + chain_ms, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 5)},
                            "teacher_chain_kernel": {
                                "kernel": "chain_fwd_kernel (csrc/chain.hip): the frozen teacher's per-token half of a block (output projection + LayerNorm, FFN, "
                                          "LayerNorm, next Q|K|V projection) at H = 256 in one launch, forward only",

@@ -56,11 +56,14 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int M, int N, const T* log
 // loads/stores and ONE statistics pass (online max / sum-exp) instead of two, so a row is read twice and written once.  Same
 // contract as ce_rows_kernel (in-place gradient allowed: a thread only rewrites vectors it has read itself, and x[label] is read
 // by everybody before the first block barrier).  Needs ld, ldd multiples of 8 and 16-byte aligned bases; no accumulate.
-template <typename Hh>
-__global__ __launch_bounds__(256) void ce_rows_wide_kernel(int M, int N, const Hh* logits, int ld, const int* labels, int ignore_index,
-                                                           float coef, const float* row_w, float* loss_row, Hh* dlogits, int ldd,
-                                                           float* w_out, float w_rate) {
-  __shared__ float red[8];
+// NT threads per row: 1024 when the launch has few rows (the bench's ~100-130 masked tokens: 256-thread blocks left the chip with four waves on
+// half its CUs for a 26 MB streaming pass: 36 us -> see DESIGN section 5), 256 otherwise.
+template <typename Hh, int NT>
+__global__ __launch_bounds__(NT) void ce_rows_wide_kernel(int M, int N, const Hh* logits, int ld, const int* labels, int ignore_index,
+                                                          float coef, const float* row_w, float* loss_row, Hh* dlogits, int ldd,
+                                                          float* w_out, float w_rate) {
+  constexpr int NWV = NT / 64;
+  __shared__ float red[2 * NWV];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const Hh* x = logits + (long long)row * ld;
   const int lab = labels[row];
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void ce_rows_wide_kernel(int M, int N, const H
   const float xl = ignored ? 0.f : to_f(x[lab]);
   const int nvec = (N + 7) >> 3;
   float mx = -3.0e38f, s = 0.f;
-  for (int v = tid; v < nvec; v += 256) {
+  for (int v = tid; v < nvec; v += NT) {
     const h16x8<Hh> q = *(const h16x8<Hh>*)(x + v * 8);
     float f[8];
 #pragma unroll
@@ -91,10 +94,14 @@ __global__ __launch_bounds__(256) void ce_rows_wide_kernel(int M, int N, const H
     s = s * __expf(mx - nm) + os * __expf(om - nm);
     mx = nm;
   }
-  if (lane == 0) { red[wid] = mx; red[4 + wid] = s; }
+  if (lane == 0) { red[wid] = mx; red[NWV + wid] = s; }
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  s = red[4] * __expf(red[0] - mx) + red[5] * __expf(red[1] - mx) + red[6] * __expf(red[2] - mx) + red[7] * __expf(red[3] - mx);
+  mx = red[0];
+#pragma unroll
+  for (int i = 1; i < NWV; ++i) mx = fmaxf(mx, red[i]);
+  s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) s += red[NWV + i] * __expf(red[i] - mx);
   const float lse = mx + __logf(s);
   const float loss = ignored ? 0.f : lse - xl;
   if (tid == 0) {
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256) void ce_rows_wide_kernel(int M, int N, const H
     const float cf = ignored ? 0.f : coef * (row_w ? row_w[row] : 1.f);
     Hh* d = dlogits + (long long)row * ldd;
     const int dvec = ldd >> 3;
-    for (int v = tid; v < dvec; v += 256) {
+    for (int v = tid; v < dvec; v += NT) {
       h16x8<Hh> g;
       if (v < nvec) {
         const h16x8<Hh> q = *(const h16x8<Hh>*)(x + v * 8);
@@ -555,10 +562,15 @@ extern "C" int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld
   hipStream_t st = (hipStream_t)stream;
   const bool wide = dtype_is16(dtype) && N >= 2048 && !accumulate && (ld % 8) == 0 && (!dlogits || (ldd % 8) == 0) &&
                     (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0;
-  if (wide && dtype == DT_BF16)
-    hipLaunchKernelGGL(ce_rows_wide_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, w_out, w_rate);
+  const bool big = M <= 512;            // few rows: 1024 threads per row
+  if (wide && dtype == DT_BF16 && big)
+    hipLaunchKernelGGL((ce_rows_wide_kernel<bf16, 1024>), grid, dim3(1024), 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, w_out, w_rate);
+  else if (wide && dtype == DT_BF16)
+    hipLaunchKernelGGL((ce_rows_wide_kernel<bf16, 256>), grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, w_out, w_rate);
+  else if (wide && big)
+    hipLaunchKernelGGL((ce_rows_wide_kernel<f16, 1024>), grid, dim3(1024), 0, st, M, N, (const f16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (f16*)dlogits, ldd, w_out, w_rate);
   else if (wide)
-    hipLaunchKernelGGL(ce_rows_wide_kernel<f16>, grid, block, 0, st, M, N, (const f16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (f16*)dlogits, ldd, w_out, w_rate);
+    hipLaunchKernelGGL((ce_rows_wide_kernel<f16, 256>), grid, block, 0, st, M, N, (const f16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (f16*)dlogits, ldd, w_out, w_rate);
   else if (dtype == DT_BF16)
     hipLaunchKernelGGL(ce_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, accumulate, w_out, w_rate);
   else if (dtype == DT_F16)

@@ -205,6 +205,19 @@ int magic_csr_gather(int dtype, int n_out, int H, const void* src, const int* pt
  * panorama encoder's attention map averaged over heads, pmean[n, r] = (1/nh) sum_h P[n, h, r], r < inner (what magic_head_mean_fwd computes) */
 int magic_pano_fuse_fwd(int dtype, int N, int V, int H, const void* x, const int* lens, const float* wf, const float* bf,
                         void* fused, float* probs, const void* P, int nh, int inner, float* pmean, void* stream);
+/* The SAP step's logit fusion + its row losses in ONE launch (one 64-thread workgroup per sample): magic_sap_fuse_fwd, three magic_ce_rows
+ * (global / local / fused logits, gradients coef * (softmax - onehot)), the teacher-sample weights w = exp(-w_rate * CE(t_fused, label)) and the
+ * action-distillation rows of magic_kd_rows (added into dfl) -- same arithmetic as those entry points.  K <= 512, Vp <= 128. */
+typedef struct {
+  int B, K, Vp, use_gate;
+  const float *g_raw, *l_raw, *fuse_raw; const unsigned char *gmask, *lmask; const int* fsrc; const unsigned char* bwmask;
+  float *gl, *ll, *fl;
+  const int *glab, *llab; int ignore_index; float coef;
+  float *rows, *dgl, *dll, *dfl;                 /* rows [3, B]; dgl / dll / dfl NULL: losses only */
+  const float* t_fused; float w_rate; int pad_; float* w_out;      /* t_fused NULL: no teacher; w_out NULL: no sample weights */
+  float T, kd_norm, kd_coef, pad2_; const float* kd_coef_dev; float* kd_rows;     /* kd_rows NULL: no distillation term */
+} magic_sap_loss_params;
+int magic_sap_fuse_loss(const void* params, int nbytes, void* stream);
 int magic_pano_fuse_bwd(int dtype, int N, int V, int H, const void* x, const float* probs, const float* wf, const void* dfused,
                         void* dx, float* dwf, float* dbf, void* stream);
 /* global/local gate + -inf masks + local->global logit fusion (validate_sap contract :503-535) */

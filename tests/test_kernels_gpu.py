@@ -755,3 +755,61 @@ def test_csr_gather_multi_equals_consecutive_gathers():
                            dict(out=out_b, n_out=n_out, src1=src2, csr1=c3)])
     torch.cuda.synchronize()
     assert torch.equal(out_a, ref_a) and torch.equal(out_b, ref_b)
+
+
+@pytest.mark.parametrize("use_gate,hard,pred", [(True, True, True), (False, False, True), (True, True, False), (True, False, False)])
+def test_sap_fuse_loss_equals_the_six_launches_it_replaces(use_gate, hard, pred):
+    """magic_sap_fuse_loss = sap_fuse_fwd + 3 x ce_rows + teacher-sample weights (ce_rows w_out) + kd_rows (accumulated into dfl)"""
+    from magic_amd.host import synth
+    from magic_amd.host.plan import build_plan
+    batch = synth.make_batch("sap", batch_size=7, seed=11, min_len=5, max_len=9, min_steps=2, max_steps=5)
+    plan = build_plan(batch, "sap", DEV)
+    B, K = batch["gmap_step_ids"].shape
+    Vp = 37
+    g_raw, l_raw, fuse_raw = rnd(B, K), rnd(B, Vp, seed=2), rnd(B, seed=3)
+    t_fused = rnd(B, K, seed=4) * 2
+    t_fused[~plan["gmask"].bool()] = float("-inf")
+    ga, la = plan["global_act_labels"], plan["local_act_labels"]
+    coef, T, rate, kcoef = 0.37 / B, 2.0, 0.7, 0.23
+    kdev = torch.tensor([1.7], device=DEV)
+    # the separate launches
+    gl, ll, fl = torch.empty(B, K, device=DEV), torch.empty(B, Vp, device=DEV), torch.empty(B, K, device=DEV)
+    O.sap_fuse_fwd(B, K, Vp, g_raw, l_raw, fuse_raw, plan["gmask"], plan["lmask"], plan["fsrc"], plan["bwmask"], use_gate, gl, ll, fl)
+    rows = torch.empty(3, B, device=DEV)
+    dgl, dll, dfl = torch.empty(B, K, device=DEV), torch.empty(B, Vp, device=DEV), torch.empty(B, K, device=DEV)
+    O.ce_rows(gl, B, K, K, ga, coef=coef, loss_row=rows[0], dlogits=dgl, ldd=K)
+    O.ce_rows(ll, B, Vp, Vp, la, coef=coef, loss_row=rows[1], dlogits=dll, ldd=Vp)
+    O.ce_rows(fl, B, K, K, ga, coef=coef, loss_row=rows[2], dlogits=dfl, ldd=K)
+    w = None
+    if hard:
+        w = torch.empty(B, device=DEV)
+        O.ce_rows(t_fused, B, K, K, ga, w_out=w, w_rate=rate)
+    kdr = None
+    norm = 1.0 / B if hard else 1.0 / (B * K)
+    if pred:
+        kdr = torch.empty(B, device=DEV)
+        O.kd_rows(fl, t_fused, B, K, K, T, w=w, norm=norm, coef=kcoef, coef_dev=kdev, loss_row=kdr, ds=dfl, accumulate=True)
+    # the one launch
+    gl2, ll2, fl2 = torch.empty(B, K, device=DEV), torch.empty(B, Vp, device=DEV), torch.empty(B, K, device=DEV)
+    rows2 = torch.empty(3, B, device=DEV)
+    dgl2, dll2, dfl2 = torch.empty(B, K, device=DEV), torch.empty(B, Vp, device=DEV), torch.empty(B, K, device=DEV)
+    w2 = torch.empty(B, device=DEV) if hard else None
+    kdr2 = torch.empty(B, device=DEV) if pred else None
+    O.sap_fuse_loss(B, K, Vp, g_raw, l_raw, fuse_raw, plan["gmask"], plan["lmask"], plan["fsrc"], plan["bwmask"], use_gate, gl2, ll2, fl2, ga, la, coef, rows2,
+                    dgl=dgl2, dll=dll2, dfl=dfl2, t_fused=t_fused if (hard or pred) else None, w_rate=rate, w_out=w2, T=T, kd_norm=norm, kd_coef=kcoef,
+                    kd_coef_dev=kdev if pred else None, kd_rows=kdr2)
+    torch.cuda.synchronize()
+    for a, b_, nme in ((gl2, gl, "gl"), (ll2, ll, "ll"), (fl2, fl, "fl")):
+        assert torch.equal(a, b_), nme                                     # same arithmetic, element for element
+    tol_ = dict(rtol=2e-6, atol=1e-7)                                       # (the row reductions run in a different order: one wave instead of four)
+    check(rows2, rows, "CE rows", **tol_)
+    for a, b_, nme in ((dgl2, dgl, "dgl"), (dll2, dll, "dll"), (dfl2, dfl, "dfl (+ KD)")):
+        check(a, b_, nme, rtol=2e-5, atol=1e-8)
+    if hard:
+        check(w2, w, "teacher-sample weights", **tol_)
+    if pred:
+        check(kdr2, kdr, "action-distillation rows", rtol=2e-5, atol=1e-8)
+    # losses only (no gradient buffers): the evaluation form
+    rows3 = torch.empty(3, B, device=DEV)
+    O.sap_fuse_loss(B, K, Vp, g_raw, l_raw, fuse_raw, plan["gmask"], plan["lmask"], plan["fsrc"], plan["bwmask"], use_gate, gl2, ll2, fl2, ga, la, coef, rows3)
+    check(rows3, rows, "CE rows without gradients", **tol_)

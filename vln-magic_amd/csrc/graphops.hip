@@ -2,6 +2,7 @@
 // masked-token selection; the backward is the same kernel on the transposed CSR), attention pooling of
 // the 36 views (adaptive_pano_fusion), and the global/local action-logit gate + local->global fusion.
 #include "common.hpp"
+#include <cstring>
 
 // out[n,:] (+)= sum_{e in [ptr[n], ptr[n+1])} w[e] * src[idx[e], :]      one wave per output row
 template <typename T>
@@ -211,6 +212,116 @@ __global__ __launch_bounds__(64) void sap_fuse_fwd_kernel(int B, int K, int Vp, 
   }
 }
 
+// The SAP step's logit fusion AND its row losses in one launch (round 3: every dependent launch of the replayed step costs 6-9 us whatever its
+// work): sap_fuse_fwd + the three cross-entropy rows (global / local / fused logits; ce_rows arithmetic: train_r2r_magic.py:513-520) + the
+// teacher-sample weights exp(-rate CE(teacher fused logits)) + the action-distillation rows (kd_rows arithmetic: optim/kd_loss.py:18-41) for one
+// sample per 64-thread workgroup.  Replaces six launches.
+struct SapLossParams {
+  int B, K, Vp, use_gate;
+  const float *g_raw, *l_raw, *fuse_raw; const unsigned char *gmask, *lmask; const int* fsrc; const unsigned char* bwmask;
+  float *gl, *ll, *fl;
+  const int *glab, *llab; int ignore_index; float coef;
+  float *rows, *dgl, *dll, *dfl;                           // rows [3, B]; gradients may be NULL (no backward)
+  const float* t_fused; float w_rate; int pad_; float* w_out;     // teacher fused logits [B, K] (or NULL); w_out [B] (or NULL: no sample weights)
+  float T, kd_norm, kd_coef, pad2_; const float* kd_coef_dev; float* kd_rows;     // kd_rows NULL: no distillation term
+};
+__device__ __forceinline__ float sap_ce_wave(const float* x, int N, int lab, int ignore_index, float coef, float* d, int lane) {
+  const bool ignored = (lab == ignore_index) || lab < 0 || lab >= N;
+  const float xl = ignored ? 0.f : x[lab];
+  float mx = -3.0e38f;
+  for (int c = lane; c < N; c += 64) mx = fmaxf(mx, x[c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < N; c += 64) s += __expf(x[c] - mx);           // exp(-inf) = 0
+  s = wave_sum(s);
+  const float lse = mx + __logf(s);
+  if (d) {
+    const float cf = ignored ? 0.f : coef;
+    for (int c = lane; c < N; c += 64) d[c] = cf * (__expf(x[c] - lse) - (c == lab ? 1.f : 0.f));
+  }
+  return ignored ? 0.f : lse - xl;
+}
+__global__ __launch_bounds__(64) void sap_fuse_loss_kernel(SapLossParams p) {
+  __shared__ float sl[128];
+  __shared__ float sbw;
+  const int b = blockIdx.x, lane = threadIdx.x, B = p.B, K = p.K, Vp = p.Vp;
+  const float NEG = -__builtin_inff();
+  const float fw = p.use_gate ? 1.f / (1.f + __expf(-p.fuse_raw[b])) : 0.5f;
+  float* gl = p.gl + (long long)b * K; float* ll = p.ll + (long long)b * Vp; float* fl = p.fl + (long long)b * K;
+  float bw = 0.f;
+  for (int j = lane; j < Vp; j += 64) {
+    const float v = p.lmask[b * Vp + j] ? p.l_raw[b * Vp + j] * (1.f - fw) : NEG;
+    ll[j] = v; sl[j] = v;
+    if (p.bwmask[b * Vp + j] && p.lmask[b * Vp + j]) bw += v;
+  }
+  bw = wave_sum(bw);
+  if (lane == 0) sbw = bw;
+  __syncthreads();
+  for (int k = lane; k < K; k += 64) {
+    const float v = p.gmask[b * K + k] ? p.g_raw[b * K + k] * fw : NEG;
+    gl[k] = v;
+    const int s = p.fsrc[b * K + k];
+    float add = 0.f;
+    if (s >= 0) add = sl[s]; else if (s == -2) add = sbw;
+    fl[k] = v + add;
+  }
+  __syncthreads();                                       // the wave's own global writes, read back below by other lanes
+  const int gla = p.glab[b], lla = p.llab[b];
+  const float l0 = sap_ce_wave(gl, K, gla, p.ignore_index, p.coef, p.dgl ? p.dgl + (long long)b * K : nullptr, lane);
+  const float l1 = sap_ce_wave(ll, Vp, lla, p.ignore_index, p.coef, p.dll ? p.dll + (long long)b * Vp : nullptr, lane);
+  float* dfl = p.dfl ? p.dfl + (long long)b * K : nullptr;
+  const float l2 = sap_ce_wave(fl, K, gla, p.ignore_index, p.coef, dfl, lane);
+  if (lane == 0) { p.rows[b] = l0; p.rows[B + b] = l1; p.rows[2 * B + b] = l2; }
+  if (!p.t_fused) return;
+  const float* t = p.t_fused + (long long)b * K;
+  float wr = 1.f;
+  if (p.w_out) {                                         // teacher_sample_hard_mining: exp(-rate * CE(teacher logits, label))
+    wr = __expf(-p.w_rate * sap_ce_wave(t, K, gla, p.ignore_index, 0.f, nullptr, lane));
+    if (lane == 0) p.w_out[b] = wr;
+  }
+  if (!p.kd_rows) return;
+  __syncthreads();                                       // dfl rows written above are read-modify-written below by the same lanes
+  float coef = p.kd_coef;
+  if (p.kd_coef_dev) coef *= p.kd_coef_dev[0];
+  const float invT = 1.0f / p.T;
+  float sv[8], tv[8], ms = -3.0e38f, mt = -3.0e38f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int c = it * 64 + lane;
+    float a = -3.0e38f, q = -3.0e38f;
+    if (c < K) {
+      a = fl[c]; q = t[c];
+      if (a == NEG) a = -1e6f;
+      if (q == NEG) q = -1e6f;
+      a *= invT; q *= invT;
+      ms = fmaxf(ms, a); mt = fmaxf(mt, q);
+    }
+    sv[it] = a; tv[it] = q;
+  }
+  ms = wave_max(ms); mt = wave_max(mt);
+  float zs = 0.f, zt = 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int c = it * 64 + lane;
+    if (c < K) { zs += __expf(sv[it] - ms); zt += __expf(tv[it] - mt); }
+  }
+  zs = wave_sum(zs); zt = wave_sum(zt);
+  const float ls = ms + __logf(zs), lt = mt + __logf(zt);
+  float kl = 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int c = it * 64 + lane;
+    if (c < K) {
+      const float lpt = tv[it] - lt, lps = sv[it] - ls;
+      const float pt = __expf(lpt), ps = __expf(lps);
+      if (pt > 0.f) kl += pt * (lpt - lps);
+      if (dfl) dfl[c] += coef * wr * p.T * (ps - pt) * p.kd_norm;
+    }
+  }
+  kl = wave_sum(kl);
+  if (lane == 0) p.kd_rows[b] = wr * kl * p.T * p.T * p.kd_norm;
+}
+
 // backward: given dgl, dll, dfl (any may be null) -> d g_raw, d l_raw, d fuse_raw
 __global__ __launch_bounds__(64) void sap_fuse_bwd_kernel(int B, int K, int Vp, const float* g_raw, const float* l_raw, const float* fuse_raw,
                                                           const unsigned char* gmask, const unsigned char* lmask, const int* fsrc,
@@ -307,6 +418,18 @@ extern "C" int magic_sap_fuse_fwd(int B, int K, int Vp, const float* g_raw, cons
   if (B <= 0 || K <= 0 || Vp <= 0 || Vp > 128) return MAGIC_ERR_ARG;
   hipLaunchKernelGGL(sap_fuse_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, B, K, Vp, g_raw, l_raw, fuse_raw, gmask, lmask, fsrc, bwmask,
                      (float)use_gate, gl, ll, fl);
+  return launch_status();
+}
+
+extern "C" int magic_sap_fuse_loss(const void* params, int nbytes, void* stream) {
+  if (!params || nbytes != (int)sizeof(SapLossParams)) return MAGIC_ERR_ARG;
+  SapLossParams p;
+  memcpy(&p, params, sizeof(p));
+  if (p.B <= 0 || p.K <= 0 || p.K > 512 || p.Vp <= 0 || p.Vp > 128 || !p.g_raw || !p.l_raw || !p.fuse_raw || !p.gmask || !p.lmask || !p.fsrc || !p.bwmask ||
+      !p.gl || !p.ll || !p.fl || !p.glab || !p.llab || !p.rows) return MAGIC_ERR_ARG;
+  if ((p.w_out || p.kd_rows) && !p.t_fused) return MAGIC_ERR_ARG;
+  if (p.kd_rows && !(p.T > 0.f)) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(sap_fuse_loss_kernel, dim3(p.B), dim3(64), 0, (hipStream_t)stream, p);
   return launch_status();
 }
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "magic_smallk_ln_bwd_pair": [i32, i32, vp, vp],
     "magic_csr_gather": [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp],
     "magic_pano_fuse_fwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
+    "magic_sap_fuse_loss": [vp, i32, vp],
     "magic_pano_fuse_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_sap_fuse_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
     "magic_sap_fuse_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
@@ -137,6 +138,14 @@ class EncSeg(C.Structure):
 class EncParams(C.Structure):
     _fields_ = [("seg", EncSeg * 2), ("nseg", i32), ("p_attn", f32), ("p_hidden", f32), ("eps", f32), ("scale", f32), ("seed", vp),
                 ("sync", vp), ("sync_words", i32), ("pad2_", i32)]
+
+
+class SapLossParams(C.Structure):
+    """mirror of `magic_sap_loss_params` (include/magic_hip.h)"""
+    _fields_ = [("B", i32), ("K", i32), ("Vp", i32), ("use_gate", i32)] + \
+               [(n, vp) for n in ("g_raw", "l_raw", "fuse_raw", "gmask", "lmask", "fsrc", "bwmask", "gl", "ll", "fl", "glab", "llab")] + \
+               [("ignore_index", i32), ("coef", f32)] + [(n, vp) for n in ("rows", "dgl", "dll", "dfl", "t_fused")] + \
+               [("w_rate", f32), ("pad_", i32), ("w_out", vp), ("T", f32), ("kd_norm", f32), ("kd_coef", f32), ("pad2_", f32), ("kd_coef_dev", vp), ("kd_rows", vp)]
 
 
 class ChainParams(C.Structure):

@@ -287,8 +287,10 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                     c.fuse_raw = n.zeros(B, dtype=torch.float32)
                 c.use_gate = use_gate
                 c.gl, c.ll, c.fl = n.new(B, K, dtype=torch.float32), n.new(B, Vp, dtype=torch.float32), n.new(B, K, dtype=torch.float32)
-                O.sap_fuse_fwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, plan["gmask"], plan["lmask"], plan["fsrc"], plan["bwmask"],
-                               use_gate, c.gl, c.ll, c.fl)
+                c.sap_fused = bool(compute_loss and O.SAP_LOSS_FUSED and K <= 512 and Vp <= 128)
+                if not c.sap_fused:           # (with a loss to follow, the logit fusion rides in the loss launch: _losses / O.sap_fuse_loss)
+                    O.sap_fuse_fwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, plan["gmask"], plan["lmask"], plan["fsrc"], plan["bwmask"],
+                                   use_gate, c.gl, c.ll, c.fl)
                 o.update(global_logits=c.gl, local_logits=c.ll, fused_logits=c.fl)
             elif task == "cfp":
                 c.g0, c.v0, c.t0, c.gv0 = n.new(B, H), n.new(B, H), n.new(B, H), n.new(B, H)
@@ -395,6 +397,18 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                     O.linear_dx(ds, pl.W, M, out=d_acc, residual=d_acc)
         c.kd_emb, c.kd_mse = [], []
 
+    def _rw_device(self, rw):
+        """MKRW ability weights as a DEVICE tensor (a captured HIP graph re-reads them every replay)"""
+        if rw is None:
+            rw = [1.0] * 5
+        if torch.is_tensor(rw) and rw.is_cuda:
+            return rw
+        cached = getattr(self, "_rwd_cache", None)
+        key = tuple(float(x) for x in rw)
+        if cached is None or cached[0] != key:
+            self._rwd_cache = cached = (key, torch.tensor(list(key), dtype=torch.float32).to(self.device_))
+        return cached[1]
+
     def _losses(self, c, o, t, rw):
         n, cfg, plan, task = self.net, self.config, c.plan, c.task
         B, L, K, Vp, H = plan["B"], plan["L"], plan["K"], plan["Vp"], n.H
@@ -436,9 +450,27 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             c.dgl, c.dll, c.dfl = (n.new(B, K, dtype=torch.float32), n.new(B, Vp, dtype=torch.float32), n.new(B, K, dtype=torch.float32)) \
                 if train else (None, None, None)
             ga, la = plan["global_act_labels"], plan["local_act_labels"]
-            O.ce_rows(c.gl, B, K, K, ga, coef=scg / B, loss_row=c.rows[0], dlogits=c.dgl, ldd=K)
-            O.ce_rows(c.ll, B, Vp, Vp, la, coef=scg / B, loss_row=c.rows[1], dlogits=c.dll, ldd=Vp)
-            O.ce_rows(c.fl, B, K, K, ga, coef=scg / B, loss_row=c.rows[2], dlogits=c.dfl, ldd=K)
+            c.sap_w = c.kdrows = None
+            if getattr(c, "sap_fused", False):
+                # logit fusion + the three CE rows + teacher-sample weights + action-distillation rows: ONE launch (six before)
+                hard = bool(kd and kdl.get("teacher_sample_hard_mining", False))
+                pred = bool(kd and "predict" in kdl["kdl_tasks"])
+                if hard:
+                    c.sap_w = n.new(B, dtype=torch.float32)
+                if pred:
+                    c.kdrows = n.new(B, dtype=torch.float32)
+                if kd:
+                    rwd = self._rw_device(rw)
+                O.sap_fuse_loss(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, plan["gmask"], plan["lmask"], plan["fsrc"], plan["bwmask"], c.use_gate,
+                                c.gl, c.ll, c.fl, ga, la, scg / B, c.rows, dgl=c.dgl, dll=c.dll, dfl=c.dfl,
+                                t_fused=t["fused_logits"] if (hard or pred) else None,
+                                w_rate=float(kdl["t_sample_preprocess_exp_decay"]) if hard else 0.0, w_out=c.sap_w,
+                                T=float(kdl["kd_temperature"]) if kd else 1.0, kd_norm=(1.0 / B if hard else 1.0 / (B * K)),
+                                kd_coef=alpha * gs, kd_coef_dev=rwd[4:5] if pred else None, kd_rows=c.kdrows)
+            else:
+                O.ce_rows(c.gl, B, K, K, ga, coef=scg / B, loss_row=c.rows[0], dlogits=c.dgl, ldd=K)
+                O.ce_rows(c.ll, B, Vp, Vp, la, coef=scg / B, loss_row=c.rows[1], dlogits=c.dll, ldd=Vp)
+                O.ce_rows(c.fl, B, K, K, ga, coef=scg / B, loss_row=c.rows[2], dlogits=c.dfl, ldd=K)
             sup_rows, sup_w, sup_scale = c.rows, None, 1.0 / B
         elif task == "mlm":
             c.d_x, c.d_gin0 = zz(B * L, H), zz(B * K, H)
@@ -491,16 +523,19 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             # MKRW ability weights as a DEVICE tensor (a captured HIP graph re-reads them every replay)
             if rw is None:
                 rw = [1.0] * 5
-            rwd = rw if torch.is_tensor(rw) and rw.is_cuda else torch.tensor([float(x) for x in rw], dtype=torch.float32).to(self.device_)
+            rwd = self._rw_device(rw)
             rw = [(alpha * gs, rwd[i:i + 1]) for i in range(5)]       # (host factor of the gradient seed, device-side ability weight)
             tasks, types = kdl["kdl_tasks"], kdl["kdl_task_types"]
             emb, att = "emb" in types, "attn" in types
             T = float(kdl["kd_temperature"])
             w = None
             if kdl.get("teacher_sample_hard_mining", False) and task == "sap":
-                w = n.new(B, dtype=torch.float32)
-                O.ce_rows(t["fused_logits"], B, K, K, plan["global_act_labels"], w_out=w,
-                          w_rate=float(kdl["t_sample_preprocess_exp_decay"]))
+                if getattr(c, "sap_w", None) is not None:
+                    w = c.sap_w                  # written by the fused loss launch above
+                else:
+                    w = n.new(B, dtype=torch.float32)
+                    O.ce_rows(t["fused_logits"], B, K, K, plan["global_act_labels"], w_out=w,
+                              w_rate=float(kdl["t_sample_preprocess_exp_decay"]))
             nh_s = n.nh
             nh_t = t["txt_attns"].shape[1]
             Np, V = plan["Np"], plan["V"]
@@ -542,10 +577,13 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 c.dP_pano = n.new(Np, nh_s, V, c.pano.ldp, dtype=torch.float32)
                 O.head_mean_bwd(g_img, c.dP_pano, Np, nh_s, V * c.pano.ldp)
             if "predict" in tasks and task == "sap":
-                c.kdrows = n.new(B, dtype=torch.float32)
-                O.kd_rows(c.fl, t["fused_logits"], B, K, K, T, w=w, norm=(1.0 / B if w is not None else 1.0 / (B * K)),
-                          coef=rw[4][0], coef_dev=rw[4][1], loss_row=c.kdrows, ds=c.dfl, accumulate=True)
-                kd_rows = c.kdrows
+                if getattr(c, "sap_fused", False):
+                    kd_rows = c.kdrows           # (and the gradient is in c.dfl already)
+                else:
+                    c.kdrows = n.new(B, dtype=torch.float32)
+                    O.kd_rows(c.fl, t["fused_logits"], B, K, K, T, w=w, norm=(1.0 / B if w is not None else 1.0 / (B * K)),
+                              coef=rw[4][0], coef_dev=rw[4][1], loss_row=c.kdrows, ds=c.dfl, accumulate=True)
+                    kd_rows = c.kdrows
         # supervised mean, the action-distillation row sum, the ten ability-weighted MAKD terms, their sum and the total: ONE launch
         lo = O.loss_assemble(sup_rows.reshape(-1), sup_w, sup_scale, kd_rows, c.slots, rwd, alpha, kd, n.new(16, dtype=torch.float32))
         res["supervised_loss"] = lo[0]

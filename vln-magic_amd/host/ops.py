@@ -698,6 +698,25 @@ def sap_fuse_fwd(B, K, Vp, g_raw, l_raw, fuse_raw, gmask, lmask, fsrc, bwmask, u
            1 if use_gate else 0, L.P(gl), L.P(ll), L.P(fl), L.stream())
 
 
+SAP_LOSS_FUSED = not os.environ.get("MAGIC_NO_SAP_LOSS_FUSED")
+
+
+def sap_fuse_loss(B, K, Vp, g_raw, l_raw, fuse_raw, gmask, lmask, fsrc, bwmask, use_gate, gl, ll, fl, glab, llab, coef, rows, *, dgl=None, dll=None,
+                  dfl=None, ignore_index=-100, t_fused=None, w_rate=0.0, w_out=None, T=1.0, kd_norm=0.0, kd_coef=0.0, kd_coef_dev=None, kd_rows=None):
+    """sap_fuse_fwd + the three CE rows + teacher-sample weights + action-distillation rows, one launch (csrc/graphops.hip sap_fuse_loss_kernel)"""
+    import ctypes as C
+    _chk(glab.dtype == torch.int32 and llab.dtype == torch.int32 and rows.dtype == torch.float32 and rows.numel() >= 3 * B, "sap_fuse_loss labels int32, rows fp32 [3, B]")
+    _chk(t_fused is None or (t_fused.dtype == torch.float32 and t_fused.is_contiguous() and tuple(t_fused.shape) == (B, K)), "sap_fuse_loss teacher logits fp32 [B, K]")
+    P = L.SapLossParams()
+    P.B, P.K, P.Vp, P.use_gate = B, K, Vp, 1 if use_gate else 0
+    for k, v in (("g_raw", g_raw), ("l_raw", l_raw), ("fuse_raw", fuse_raw), ("gmask", gmask), ("lmask", lmask), ("fsrc", fsrc), ("bwmask", bwmask),
+                 ("gl", gl), ("ll", ll), ("fl", fl), ("glab", glab), ("llab", llab), ("rows", rows), ("dgl", dgl), ("dll", dll), ("dfl", dfl),
+                 ("t_fused", t_fused), ("w_out", w_out), ("kd_coef_dev", kd_coef_dev), ("kd_rows", kd_rows)):
+        setattr(P, k, L.P(v))
+    P.ignore_index, P.coef, P.w_rate, P.T, P.kd_norm, P.kd_coef = int(ignore_index), float(coef), float(w_rate), float(T), float(kd_norm), float(kd_coef)
+    L.call("magic_sap_fuse_loss", C.addressof(P), C.sizeof(P), L.stream())
+
+
 def sap_fuse_bwd(B, K, Vp, g_raw, l_raw, fuse_raw, gmask, lmask, fsrc, bwmask, use_gate, dgl, dll, dfl, dg_raw, dl_raw, dfuse_raw):
     L.call("magic_sap_fuse_bwd", B, K, Vp, L.P(g_raw), L.P(l_raw), L.P(fuse_raw), L.P(gmask), L.P(lmask), L.P(fsrc), L.P(bwmask),
            1 if use_gate else 0, L.P(dgl), L.P(dll), L.P(dfl), L.P(dg_raw), L.P(dl_raw), L.P(dfuse_raw), L.stream())

@@ -9,15 +9,12 @@
 // pretrain_src/config/r2r_magic_pretrain.json:62-87) runs no backward and no dropout, so nothing is saved for one: the FFN
 // pre-activation and the GELU output never leave the CU.
 //
-// One 512-thread workgroup owns 64 rows (four 16-row MFMA tiles; 32 for tiny problems).  Weights are not staged through LDS: every weight
-// element is used by exactly four MFMAs of the workgroup, so each lane loads its B-fragment (8 consecutive k of one weight row, 16 bytes) from
-// L2 straight into registers (the scheme of csrc/encoder.hip at H = 128, where the fragments of a whole stage fit the register file; at
-// H = 256 a workgroup streams 1.6 MB of weights, as ONE sequence of 8-fragment chunks through a ring of three (64 rows) or four (32 rows)
-// register buffers that keeps loading across the stage boundaries).  The stream is bound by what ONE CU takes from L2 (58 B/ns measured:
-// 26.5 us for the 1.57 MB), so the rows per workgroup set the L2 -> CU traffic of the launch: 64-row tiles halve it against 32-row tiles and
-// need half the CUs (text block: 60 workgroups x 57 us against 120 x 39 us; the overlapped step 1.566 -> 1.547 ms).  The FFN's GELU image
-// goes through LDS one 256-column chunk at a time (four chunks, the second product accumulating in registers) so that 64 rows fit: LDS per
-// workgroup 149 KB, one workgroup per CU, up to 256 VGPRs.
+// One 512-thread workgroup owns 32 rows (two 16-row MFMA tiles).  Weights are not staged through LDS: every weight element is used by
+// exactly two MFMAs of the workgroup, so each lane loads its B-fragment (8 consecutive k of one weight row, 16 bytes) from L2 straight
+// into registers (the scheme of csrc/encoder.hip at H = 128, where the fragments of a whole stage fit the register file; at H = 256 a
+// workgroup streams 1.6 MB of weights, as ONE sequence of 8-fragment chunks through a ring of four register buffers that keeps three
+// chunks -- 24 KB per wave, 192 KB per CU -- in flight across the stage boundaries: the stream is bound by the 64 B/clk a CU takes from L2,
+// which needs that much in flight at ~2 us of loaded latency).  LDS per workgroup 118 KB, one workgroup per CU, up to 256 VGPRs.
 // ALL FOUR WEIGHT MATRICES ARE READ IN FRAGMENT ORDER (magic_pack_frag_spans below; the frozen teacher packs them once).
 // Two problems can share one launch (text || panorama encoder, global || local co-attention encoder):
 // group.hpp KIND_CHAIN.
@@ -28,6 +25,7 @@
 #define CH 256
 #define CI 1024
 #define CP 264        // row pitch of the [16][256] images: 528 B = 33 16-byte slots
+#define CG 1032       // row pitch of the [16][1024] GELU image: 2064 B = 129 slots
 
 struct ChainParams {
   int M, ld_in, Np, pad_;
@@ -38,13 +36,14 @@ struct ChainParams {
   float eps; int pad2_;
 };
 
+#define CRT 2          // 16-row tiles per workgroup
+#define CROWS (16 * CRT)
 #define CNB 4          // weight-fragment chunks (8 fragments = 8 KB per wave each) in the register ring: CNB - 1 are in flight ahead of the MFMAs
 
-// LayerNorm over 16 RT rows x 256 columns held as RT x 2 16x16 accumulator tiles per wave (columns (2w + ct) * 16 + c16)
-template <typename Hh, int RT>
-__device__ __forceinline__ void chain_norm(f32x4 (&acc)[RT][2], const float* sPar, const Hh* sR,
+// LayerNorm over CROWS rows x 256 columns held as CRT x 2 16x16 accumulator tiles per wave (columns (2w + ct) * 16 + c16)
+template <typename Hh>
+__device__ __forceinline__ void chain_norm(f32x4 (&acc)[CRT][2], const float* sPar, const Hh* sR,
                                            float* red, Hh* sOut, const int nq, const float eps, const int w, const int lane) {
-  constexpr int ROWS = 16 * RT;
   const int g = lane >> 4, c16 = lane & 15;
   float bv[2], gv[2], btv[2];           // bias | gamma | beta of this lane's two columns: staged in LDS by the prologue (see chain_body)
 #pragma unroll
@@ -52,9 +51,9 @@ __device__ __forceinline__ void chain_norm(f32x4 (&acc)[RT][2], const float* sPa
     const int col = (2 * w + ct) * 16 + c16;
     bv[ct] = sPar[col]; gv[ct] = sPar[CH + col]; btv[ct] = sPar[2 * CH + col];
   }
-  float s[RT][4];
+  float s[CRT][4];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rt * 16 + 4 * g + r;
@@ -64,38 +63,38 @@ __device__ __forceinline__ void chain_norm(f32x4 (&acc)[RT][2], const float* sPa
     }
   if (c16 == 0) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[w * ROWS + rt * 16 + 4 * g + r] = s[rt][r];
+      for (int r = 0; r < 4; ++r) red[w * CROWS + rt * 16 + 4 * g + r] = s[rt][r];
   }
   __syncthreads();
-  float mean[RT][4];
+  float mean[CRT][4];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float t = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * ROWS + rt * 16 + 4 * g + r];
+      for (int ww = 0; ww < NWAVE; ++ww) t += red[ww * CROWS + rt * 16 + 4 * g + r];
       mean[rt][r] = t * (1.0f / CH);
       const float d0 = acc[rt][0][r] - mean[rt][r], d1 = acc[rt][1][r] - mean[rt][r];
       s[rt][r] = g16_sum(d0 * d0 + d1 * d1);
     }
   if (c16 == 0) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[NWAVE * ROWS + w * ROWS + rt * 16 + 4 * g + r] = s[rt][r];
+      for (int r = 0; r < 4; ++r) red[NWAVE * CROWS + w * CROWS + rt * 16 + 4 * g + r] = s[rt][r];
   }
   __syncthreads();
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = rt * 16 + 4 * g + r;
       float t = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < NWAVE; ++ww) t += red[NWAVE * ROWS + ww * ROWS + rr];
+      for (int ww = 0; ww < NWAVE; ++ww) t += red[NWAVE * CROWS + ww * CROWS + rr];
       const float rstd = rsqrtf(t * (1.0f / CH) + eps);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -104,52 +103,45 @@ __device__ __forceinline__ void chain_norm(f32x4 (&acc)[RT][2], const float* sPa
 }
 
 template <typename Hh>
-__device__ __forceinline__ void chain_rows_in(const Hh* src, long long ld, int rows, int nq, Hh* dst, int tid) {
-  // `rows` rows x 256 columns, 16-byte chunks; rows >= nq are zeros
+__device__ __forceinline__ void chain_rows_in(const Hh* src, long long ld, int nq, Hh* dst, int tid) {
+  // CROWS rows x 256 columns, 16-byte chunks; rows >= nq are zeros
   typedef __attribute__((ext_vector_type(4))) unsigned u4;
-  for (int id = tid; id < rows * (CH / 8); id += NWAVE * 64) {
+  for (int id = tid; id < CROWS * (CH / 8); id += NWAVE * 64) {
     const int r = id / (CH / 8), c = (id % (CH / 8)) * 8;
     const u4 v = r < nq ? *(const u4*)(src + r * ld + c) : (u4){0u, 0u, 0u, 0u};
     *(u4*)(dst + r * CP + c) = v;
   }
 }
 
+// The workgroup's weights as ONE stream of chunks of 8 fragments per wave, in the order the stages consume them:
+//   0..1   stage 1  (column tile 2w + i of Wa, 8 k-steps)                10..17 stage 2b (k-steps 4c..4c+3 of column tiles 2w, 2w + 1 of W2)
+//   2..9   stage 2a (column tile 8w + i of W1, 8 k-steps)                18..23 stage 3  (column tile w nct + j of Wp, 8 k-steps; j < nct)
+// (weights do not depend on data: the ring keeps loading across the stage boundaries and their barriers)
 // B fragment (nt, ks) of a weight matrix kept in FRAGMENT ORDER (magic_pack_frag_spans): the 64 lanes' 16 bytes are one contiguous KB.
 // (The row-major form -- lane l reads 16 bytes of weight row l & 15 -- touches 16 cache lines per quarter-wave: measured 12 B/clk per CU.)
 template <typename Hh> __device__ __forceinline__ h16x8<Hh> pfrag(const Hh* __restrict__ Wf, const int K, const int nt, const int ks, const int lane) {
   return *(const h16x8<Hh>*)(Wf + ((long long)(nt * (K >> 5) + ks) * 64 + lane) * 8);
 }
 
-// The workgroup's weights as ONE stream of chunks of 8 fragments per wave, in the order the stages consume them (weights do not depend on
-// data: the ring keeps loading across the stage boundaries and their barriers):
-//   0..1    stage 1: column tile 2w + i of Wa, 8 k-steps
-//   2..17   stage 2, the FFN in FOUR column chunks of 256 intermediate columns (the GELU image of a chunk is [rows][256], so 64-row tiles fit
-//           LDS): per chunk c -- 4c + 2, 4c + 3: column tiles 16c + 2w, 16c + 2w + 1 of W1 (8 k-steps each);
-//           4c + 4, 4c + 5: k-steps 8c .. 8c + 3 and 8c + 4 .. 8c + 7 of column tiles 2w, 2w + 1 of W2
-//   18..23  stage 3: column tile 8j + w of Wp (j < Np / 128), 8 k-steps -- interleaved over the waves so that every 256-column pass of the
-//           output staging holds two tiles of each wave
 template <typename Hh>
 __device__ __forceinline__ void chain_load_chunk(h16x8<Hh> (&b)[8], const int cid, const ChainParams& p, const int w, const int lane, const int nct) {
   if (cid < 2) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag((const Hh*)p.Wa, CH, 2 * w + cid, ks, lane);
+  } else if (cid < 10) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag((const Hh*)p.W1, CH, 8 * w + cid - 2, ks, lane);
   } else if (cid < 18) {
-    const int c = (cid - 2) >> 2, q = (cid - 2) & 3;
-    if (q < 2) {
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag((const Hh*)p.W1, CH, 16 * c + 2 * w + q, ks, lane);
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        b[ks] = pfrag((const Hh*)p.W2, CI, 2 * w, 8 * c + 4 * (q - 2) + ks, lane);
-        b[4 + ks] = pfrag((const Hh*)p.W2, CI, 2 * w + 1, 8 * c + 4 * (q - 2) + ks, lane);
-      }
+    for (int ks = 0; ks < 4; ++ks) {
+      b[ks] = pfrag((const Hh*)p.W2, CI, 2 * w, 4 * (cid - 10) + ks, lane);
+      b[4 + ks] = pfrag((const Hh*)p.W2, CI, 2 * w + 1, 4 * (cid - 10) + ks, lane);
     }
   } else {
     // UNCONDITIONAL (a load the compiler cannot count makes every later wait a full drain): tiles past the projection's width re-read its
     // last tile, a chain without a projection reads Wa's fragments -- valid addresses, unused data
     const Hh* Wq = p.Wp ? (const Hh*)p.Wp : (const Hh*)p.Wa;
-    const int j = cid - 18, nt = p.Wp ? 8 * (j < nct ? j : nct - 1) + w : 2 * w;
+    const int j = cid - 18, nt = p.Wp ? w * nct + (j < nct ? j : nct - 1) : 2 * w;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag(Wq, CH, nt, ks, lane);
   }
@@ -161,45 +153,43 @@ __device__ long long chain_ticks[16];          // wall_clock64 (100 MHz) marks o
 #else
 #define CH_MARK(i)
 #endif
-template <typename Hh, bool FFN, int RT>
+template <typename Hh, bool FFN>
 __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile, unsigned char* smem) {
-  constexpr int ROWS = 16 * RT;
-  constexpr int NB = RT >= 4 ? 3 : CNB;       // ring depth: with four row tiles per fragment the accumulators leave room for three chunks (two in flight)
-  Hh* sIn = (Hh*)smem;                      // [ROWS][CP]  stage-1 input; later the block output y2
-  Hh* sRes = sIn + ROWS * CP;               // [ROWS][CP]  residual of stage 1
-  Hh* sY1 = sRes + ROWS * CP;               // [ROWS][CP]
-  Hh* sG = sY1 + ROWS * CP;                 // [ROWS][CP]  GELU output of one 256-column chunk of the FFN; later the projection's 256-column staging image
-  float* red = (float*)(sG + ROWS * CP);    // [2][8][ROWS]
-  float* sPar = red + 2 * NWAVE * ROWS;     // ba | g1 | b1 | bo2 | g2 | b2 (256 each) | bi (1024) | bp (<= 768): every small parameter, staged ONCE --
+  Hh* sIn = (Hh*)smem;                      // [CROWS][CP]  stage-1 input; later the block output y2
+  Hh* sRes = sIn + CROWS * CP;              // [CROWS][CP]  residual of stage 1
+  Hh* sY1 = sRes + CROWS * CP;              // [CROWS][CP]
+  Hh* sG = sY1 + CROWS * CP;                // [CROWS][CG]  GELU output; later the projection image [CROWS][Np + 8]
+  float* red = (float*)(sG + CROWS * CG);   // [2][8][CROWS]
+  float* sPar = red + 2 * NWAVE * CROWS;    // ba | g1 | b1 | bo2 | g2 | b2 (256 each) | bi (1024) | bp (<= 768): every small parameter, staged ONCE --
                                             // a global load between the weight chunks makes the compiler drain the whole ring (vmcnt(0)) before its use
   const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lane = lane0;
   asm volatile("" : "+v"(lane));
   const int g = lane >> 4, c16 = lane & 15;
-  const int row0 = tile * ROWS, nq = min(ROWS, p.M - row0);
+  const int row0 = tile * CROWS, nq = min(CROWS, p.M - row0);
   const int nct = p.Wp ? (p.Np >> 7) : 0;
   constexpr int NS = FFN ? 24 : 8;          // chunks in this variant's stream; SEQ(s): stream position -> chunk id
 #define SEQ(s) (FFN ? (s) : ((s) < 2 ? (s) : (s) + 16))
-#define AHEAD(s) do { if ((s) + NB - 1 < NS) chain_load_chunk<Hh>(ring[((s) + NB - 1) % NB], SEQ((s) + NB - 1), p, w, lane, nct); } while (0)
+#define AHEAD(s) do { if ((s) + CNB - 1 < NS) chain_load_chunk<Hh>(ring[((s) + CNB - 1) % CNB], SEQ((s) + CNB - 1), p, w, lane, nct); } while (0)
   CH_MARK(0);
-  chain_rows_in((const Hh*)p.in + (long long)row0 * p.ld_in, p.ld_in, ROWS, nq, sIn, tid);
-  chain_rows_in((const Hh*)p.res + (long long)row0 * CH, CH, ROWS, nq, sRes, tid);
+  chain_rows_in((const Hh*)p.in + (long long)row0 * p.ld_in, p.ld_in, nq, sIn, tid);
+  chain_rows_in((const Hh*)p.res + (long long)row0 * CH, CH, nq, sRes, tid);
   if (tid < CH) {
     sPar[tid] = p.ba[tid]; sPar[CH + tid] = p.g1[tid]; sPar[2 * CH + tid] = p.b1[tid];
     if (FFN) { sPar[3 * CH + tid] = p.bo2[tid]; sPar[4 * CH + tid] = p.g2[tid]; sPar[5 * CH + tid] = p.b2[tid]; }
   }
   if (FFN) { sPar[6 * CH + tid] = p.bi[tid]; sPar[6 * CH + 512 + tid] = p.bi[512 + tid]; }
   for (int i = tid; i < nct * 128; i += NWAVE * 64) sPar[6 * CH + CI + i] = p.bp[i];
-  h16x8<Hh> ring[NB][8];
+  h16x8<Hh> ring[CNB][8];
 #pragma unroll
-  for (int s = 0; s < NB - 1; ++s) chain_load_chunk<Hh>(ring[s], SEQ(s), p, w, lane, nct);
+  for (int s = 0; s < CNB - 1; ++s) chain_load_chunk<Hh>(ring[s], SEQ(s), p, w, lane, nct);
   __syncthreads();
   CH_MARK(1);
   // ================= 1: y1 = LayerNorm(in Wa^T + ba + res) =================
   {
-    f32x4 acc[RT][2];
+    f32x4 acc[CRT][2];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { acc[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int rt = 0; rt < CRT; ++rt) { acc[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       AHEAD(i);
@@ -207,96 +197,96 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt][i] = emma(lfrag(sIn, CP, rt * 16, ks * 32, lane), ring[i % NB][ks], acc[rt][i]);
+        for (int rt = 0; rt < CRT; ++rt) acc[rt][i] = emma(lfrag(sIn, CP, rt * 16, ks * 32, lane), ring[i % CNB][ks], acc[rt][i]);
       KSTEP_FENCE();
     }
-    chain_norm<Hh, RT>(acc, sPar, sRes, red, sY1, nq, p.eps, w, lane);
+    chain_norm(acc, sPar, sRes, red, sY1, nq, p.eps, w, lane);
   }
   __syncthreads();
   CH_MARK(2);
   if (p.y1) copy_out(sY1, CP, (Hh*)p.y1 + (long long)row0 * CH, CH, nq, CH, tid);
   const Hh* sLast = sY1;
   if constexpr (FFN) {
-    // ================= 2: y2 = LayerNorm(gelu(y1 W1^T + bi) W2^T + bo2 + y1), the intermediate 256 columns at a time =================
-    f32x4 acc2[RT][2];
+    // ================= 2a: g = gelu(y1 W1^T + bi): 8 column tiles per wave =================
+    {
+      // (the A fragments come from LDS at every use: holding the 16 of a stage in registers next to the ring spilled, and a scratch
+      // access between the weight chunks drains the ring just like any other vector-memory operation)
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { acc2[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {           // this wave's two column tiles of the chunk: g = gelu(y1 W1^T + bi)
-        constexpr int dummy = 0; (void)dummy;
-        AHEAD(2 + 4 * c + q);
-        const int lcol = (2 * w + q) * 16 + c16;
-        const float bfc = sPar[6 * CH + 256 * c + lcol];
+      for (int ct = 0; ct < 8; ++ct) {
+        AHEAD(2 + ct);
+        const int col = (8 * w + ct) * 16 + c16;
+        const float bfc = sPar[6 * CH + col];
         KSTEP_FENCE();
-        f32x4 acc[RT];
+        f32x4 acc[CRT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < CRT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) acc[rt] = emma(lfrag(sY1, CP, rt * 16, ks * 32, lane), ring[(2 + 4 * c + q) % NB][ks], acc[rt]);
+          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(lfrag(sY1, CP, rt * 16, ks * 32, lane), ring[(2 + ct) % CNB][ks], acc[rt]);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sG[(rt * 16 + 4 * g + r) * CP + lcol] = from_f<Hh>(gelu_fast(acc[rt][r] + bfc));
+          for (int r = 0; r < 4; ++r) sG[(rt * 16 + 4 * g + r) * CG + col] = from_f<Hh>(gelu_fast(acc[rt][r] + bfc));
         KSTEP_FENCE();
       }
-      __syncthreads();                        // the chunk's GELU image is complete
+    }
+    __syncthreads();
+    CH_MARK(3);
+    // ================= 2b: y2 = LayerNorm(g W2^T + bo2 + y1): K = 1024 in 8 chunks of 4 k-steps x 2 column tiles =================
+    {
+      f32x4 acc[CRT][2];
 #pragma unroll
-      for (int q = 2; q < 4; ++q) {           // acc2 += g_chunk W2[:, chunk]^T: 8 k-steps in two ring chunks of 4
-        AHEAD(2 + 4 * c + q);
+      for (int rt = 0; rt < CRT; ++rt) { acc[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        AHEAD(10 + ch);
         KSTEP_FENCE();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) {
-            const h16x8<Hh> a = lfrag(sG, CP, rt * 16, (4 * (q - 2) + ks) * 32, lane);
-            acc2[rt][0] = emma(a, ring[(2 + 4 * c + q) % NB][ks], acc2[rt][0]);
-            acc2[rt][1] = emma(a, ring[(2 + 4 * c + q) % NB][4 + ks], acc2[rt][1]);
+          for (int rt = 0; rt < CRT; ++rt) {
+            const h16x8<Hh> a = lfrag(sG, CG, rt * 16, (4 * ch + ks) * 32, lane);
+            acc[rt][0] = emma(a, ring[(10 + ch) % CNB][ks], acc[rt][0]);
+            acc[rt][1] = emma(a, ring[(10 + ch) % CNB][4 + ks], acc[rt][1]);
           }
         KSTEP_FENCE();
       }
-      __syncthreads();                        // every wave is done with the image before the next chunk (or the projection staging) overwrites it
+      chain_norm(acc, sPar + 3 * CH, sY1, red, sIn, nq, p.eps, w, lane);
     }
-    CH_MARK(3);
-    chain_norm<Hh, RT>(acc2, sPar + 3 * CH, sY1, red, sIn, nq, p.eps, w, lane);
     __syncthreads();
     CH_MARK(4);
     copy_out(sIn, CP, (Hh*)p.y2 + (long long)row0 * CH, CH, nq, CH, tid);
     sLast = sIn;
   }
   if (nct) {
-    // ================= 3: proj = y_last Wp^T + bp: column tile 8j + w in step j, staged and written 256 columns (two steps) at a time =================
+    // ================= 3: proj = y_last Wp^T + bp, nct = Np / 128 column tiles per wave =================
     constexpr int S3 = FFN ? 18 : 2;
+    const int pp = p.Np + 8;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       AHEAD(S3 + j);
       if (j < nct) {
-        const int tile_n = 8 * j + w;
+        const int tile_n = w * nct + j;
         const float bpv = sPar[6 * CH + CI + tile_n * 16 + c16];
         KSTEP_FENCE();
-        f32x4 acc[RT];
+        f32x4 acc[CRT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < CRT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) acc[rt] = emma(lfrag(sLast, CP, rt * 16, ks * 32, lane), ring[(S3 + j) % NB][ks], acc[rt]);
+          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(lfrag(sLast, CP, rt * 16, ks * 32, lane), ring[(S3 + j) % CNB][ks], acc[rt]);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sG[(rt * 16 + 4 * g + r) * CP + ((j & 1) * 8 + w) * 16 + c16] = from_f<Hh>(acc[rt][r] + bpv);
+          for (int r = 0; r < 4; ++r) sG[(rt * 16 + 4 * g + r) * pp + tile_n * 16 + c16] = from_f<Hh>(acc[rt][r] + bpv);
       }
       KSTEP_FENCE();
-      if ((j & 1) && j < nct) {               // a 256-column pass is complete (nct is even)
-        __syncthreads();
-        copy_out(sG, CP, (Hh*)p.proj + (long long)row0 * p.Np + 128 * (j - 1), p.Np, nq, 256, tid);
-        __syncthreads();
-      }
     }
+    __syncthreads();
     CH_MARK(5);
+    copy_out(sG, pp, (Hh*)p.proj + (long long)row0 * p.Np, p.Np, nq, p.Np, tid);
   }
   CH_MARK(6);
 #undef SEQ
@@ -306,25 +296,17 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
 // (the two problems as an ARRAY in the kernel-argument segment: `pr.p[which]` becomes scalar loads at a computed offset where they are used;
 // selecting between two by-value structs kept both in SGPRs and spilled 159 of them into vector registers)
 struct ChainPair { ChainParams p[2]; int split; };
-template <typename Hh, int RT>
+template <typename Hh>
 __global__ __launch_bounds__(512) void chain_fwd_kernel(ChainPair pr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
   const int which = (int)blockIdx.x < pr.split ? 0 : 1;
   const ChainParams& p = pr.p[which];
   const int tile = which ? blockIdx.x - pr.split : blockIdx.x;
-  if (p.W1) chain_body<Hh, true, RT>(p, tile, chain_smem);
-  else chain_body<Hh, false, RT>(p, tile, chain_smem);
+  if (p.W1) chain_body<Hh, true>(p, tile, chain_smem);
+  else chain_body<Hh, false>(p, tile, chain_smem);
 }
 
-static size_t chain_lds_bytes(int rt) { return (size_t)(4 * 16 * rt * CP) * 2 + (2 * NWAVE * 16 * rt + 6 * CH + CI + 3 * CH) * sizeof(float); }
-// rows per workgroup: 64 (four MFMA row tiles per weight fragment: half the L2 -> CU weight traffic and half the workgroups of the 32-row
-// form; the FFN's GELU image goes through LDS a 256-column chunk at a time to fit) or 32.  MAGIC_CHAIN_ROWS = 32 | 64 forces one.
-static int chain_rt(long long rows_total) {
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("MAGIC_CHAIN_ROWS"); const int v = e ? atoi(e) : 0; forced = v == 32 ? 2 : v == 64 ? 4 : 0; }
-  if (forced) return forced;
-  return rows_total > 64 ? 4 : 2;
-}
+static size_t chain_lds_bytes() { return (size_t)(3 * CROWS * CP + CROWS * CG) * 2 + (2 * NWAVE * CROWS + 6 * CH + CI + 3 * CH) * sizeof(float); }
 
 static bool chain_valid(const ChainParams& p) {
   if (p.M <= 0 || !p.in || !p.res || !p.Wa || !p.ba || !p.g1 || !p.b1 || p.ld_in < CH || (p.ld_in & 7)) return false;
@@ -339,24 +321,16 @@ int launch_chain(int dtype, int variant, const void* pa_, const void* pb_, hipSt
   ChainPair pr;
   pr.p[0] = *(const ChainParams*)pa_;
   pr.p[1] = pb_ ? *(const ChainParams*)pb_ : pr.p[0];
-  const int rt = chain_rt((long long)pr.p[0].M + (pb_ ? pr.p[1].M : 0)), rows = 16 * rt;
-  const int ta = (pr.p[0].M + rows - 1) / rows, tb = pb_ ? (pr.p[1].M + rows - 1) / rows : 0;
+  const int ta = (pr.p[0].M + CROWS - 1) / CROWS, tb = pb_ ? (pr.p[1].M + CROWS - 1) / CROWS : 0;
   pr.split = ta;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)chain_fwd_kernel<bf16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds_bytes(2));
-    (void)hipFuncSetAttribute((const void*)chain_fwd_kernel<f16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds_bytes(2));
-    (void)hipFuncSetAttribute((const void*)chain_fwd_kernel<bf16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds_bytes(4));
-    (void)hipFuncSetAttribute((const void*)chain_fwd_kernel<f16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds_bytes(4));
-    attr_done = true;
-  }
-  const size_t lds = chain_lds_bytes(rt);
+  static bool attr_done[3] = {false, false, false};
+  const size_t lds = chain_lds_bytes();      // (padding it to 159 KB changes nothing in the overlapped step: co-residency with the student's tiles is not what the teacher costs)
   if (dtype == DT_BF16) {
-    if (rt == 4) hipLaunchKernelGGL((chain_fwd_kernel<bf16, 4>), dim3(ta + tb), dim3(512), lds, st, pr);
-    else hipLaunchKernelGGL((chain_fwd_kernel<bf16, 2>), dim3(ta + tb), dim3(512), lds, st, pr);
+    if (!attr_done[DT_BF16]) { hipFuncSetAttribute((const void*)chain_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[DT_BF16] = true; }
+    hipLaunchKernelGGL(chain_fwd_kernel<bf16>, dim3(ta + tb), dim3(512), lds, st, pr);
   } else {
-    if (rt == 4) hipLaunchKernelGGL((chain_fwd_kernel<f16, 4>), dim3(ta + tb), dim3(512), lds, st, pr);
-    else hipLaunchKernelGGL((chain_fwd_kernel<f16, 2>), dim3(ta + tb), dim3(512), lds, st, pr);
+    if (!attr_done[DT_F16]) { hipFuncSetAttribute((const void*)chain_fwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[DT_F16] = true; }
+    hipLaunchKernelGGL(chain_fwd_kernel<f16>, dim3(ta + tb), dim3(512), lds, st, pr);
   }
   return launch_status();
 }

@@ -162,3 +162,50 @@ def test_chain_rejects_bad_arguments():
     with pytest.raises(L.MagicHipError):          # nothing to write
         O.chain_fwd(x, x, 16, O.pack_frag(w["Wa"]), w["ba"], w["g1"], w["b1"], 1e-12)
     assert not O.chain_ok(torch.float32, H, I) and not O.chain_ok(dtype, 128, 512)
+
+
+def test_fragment_order_copies_follow_the_weights_through_training_steps_and_foreign_optimizers():
+    """ParamStore.f_span / tf_span (round 3): the MFMA-fragment-order copies of W and W^T the whole-encoder / row-block kernels read must equal
+    the row-major 16-bit shadow after (a) the fused AdamW step (which refreshes them in its own launch sequence), (b) a torch optimizer step on
+    the store's parameters (global post-step hook marks the shadows stale; the next forward re-casts and re-lays them out), (c) load_state_dict."""
+    from magic_amd.host import synth
+    from magic_amd.host.plan import build_plan
+    from magic_amd.host.trainer import PretrainStep
+    from tests.test_model_gpu import RW, build
+    frag = lambda W: W.reshape(W.shape[0] // 16, 16, W.shape[1] // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+    _, _, g_t, g_s = build(torch.bfloat16)
+    st = g_s.store
+    assert st.f_spans, "a trainable H = 128 student registers its encoder matrices at construction"
+
+    def consistent():
+        torch.cuda.synchronize()
+        n = 0
+        for off, (rows, cols, flags) in st.f_spans.items():
+            W = st.shadow[off:off + rows * cols].view(rows, cols)
+            if flags & 1:
+                assert torch.equal(st.shadow_f[off:off + rows * cols], frag(W)), (off, rows, cols)
+            if flags & 2:
+                assert torch.equal(st.shadow_tf[off:off + rows * cols], frag(W.t().contiguous())), (off, rows, cols)
+            n += 1
+        return n
+    b = synth.make_batch("sap", batch_size=4, seed=5, step=0, vocab=600, min_len=8, max_len=15, min_steps=2, max_steps=3)
+    bd, plan = synth.batch_to(b, DEV), build_plan(b, "sap", DEV)
+    rw = torch.tensor(RW, device=DEV)
+    tr = PretrainStep(g_s, g_t, lr=1e-3, warmup_steps=1, num_train_steps=10)
+    before = st.shadow.clone()
+    tr.step(bd, "sap", rw=rw, plan=plan)                       # (a)
+    assert consistent() >= 10 and not torch.equal(before, st.shadow)
+    opt = torch.optim.SGD(g_s.parameters(), lr=0.5)             # (b)
+    out = g_s(bd, "sap", compute_loss=True, teacher_outputs=None, plan=plan)
+    out["loss"].backward()
+    mid = st.shadow.clone()
+    opt.step()
+    with torch.no_grad():
+        g_s(bd, "sap", compute_loss=False, plan=plan)           # the forward that follows syncs the shadows
+    assert consistent() >= 10 and not torch.equal(mid, st.shadow)
+    sd = {k: v.clone() * 0.5 for k, v in g_s.state_dict().items()}      # (c)
+    g_s.load_state_dict(sd)
+    with torch.no_grad():
+        g_s(bd, "sap", compute_loss=False, plan=plan)
+    consistent()
+    assert torch.allclose(st.shadow.float(), (st.flat * 1.0).to(torch.bfloat16).float())

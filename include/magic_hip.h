@@ -24,6 +24,10 @@ extern "C" {
 #define MAGIC_ERR_UNSUPPORTED (-3)
 
 int magic_abi_version(void);
+/* Identity of the source set this binary was built from: 16 hex digits + NUL copied into out (len >= 17), a content hash over every
+ * csrc/*.hip with the shared headers and compile flags, gen_fastcall.py and host/lib.py (csrc/build_id.py computes the same number from a
+ * source tree).  host/lib.py refuses a library whose id differs from its tree's; bench.py prints it. */
+int magic_build_id(char* out, int len);
 int magic_device_info(int* cu_count, int* clock_khz, char* arch, int arch_len);
 
 /* Dense contraction C = epi(alpha * op(A) op(B) + bias) [+ residual], batched over (batch = nb*nh) with
@@ -305,8 +309,13 @@ int magic_encoder_params_bytes(void);
 int magic_encoder_fwd(int dtype, const void* params, int nbytes, void* stream);
 /* Scheduling aid for work that runs NEXT TO a training step on another stream (the frozen MAKD teacher's forward): parks `stream` -- one
  * sleeping wave -- until the next magic_encoder_fwd launch of this process has its last workgroup on a CU, or timeout_us (<= 100000) have
- * passed.  The whole-encoder launch wants every CU's LDS; side work that starts first delays its workgroups. */
-int magic_encoder_start_gate(int timeout_us, void* stream);
+ * passed.  The whole-encoder launch wants every CU's LDS; side work that starts first delays its workgroups.  HIP does not promise that two
+ * streams run concurrently, so the gate protects itself: a launch that became resident within the last recent_us opens it at once (the
+ * gate came late), and after 3 consecutive timeouts it switches itself off (an empty launch from then on) until the caller zeroes
+ * `stats` again.  stats: 8 x uint32 of zero-initialised device memory owned by the caller, updated by the gate:
+ * [0] calls, [1] opened while waiting, [2] launch already resident at entry, [3] timeouts, [4] consecutive timeouts, [5] switched off,
+ * [6] calls skipped while off, [7] reserved.  No reference counterpart (torch issues everything on one stream). */
+int magic_encoder_start_gate(int timeout_us, int recent_us, unsigned* stats, void* stream);
 
 /* Cross-modal encoders in one launch (csrc/encoder.hip, xencoder_fwd_kernel): the global (map) and local (viewpoint) co-attention
  * encoders, <= 3 METER BertCrossLayer blocks each (the withheld model's `bert.{global,local}_encoder.encoder.crossattention.N`,

@@ -13,6 +13,33 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Run order (pytest -x stops at the first failure, so WHAT RUNS FIRST decides what a red run still proves):
+#   tier 0  parity against the oracle / the reference-minted golden fixtures / plain fp32 torch math;
+#   tier 1  self-comparisons (a fused kernel against the per-op kernels, graph replay against the eager step, the loaders);
+#   tier 2  multi-process and launcher tests (2 ranks on one card, the bench's own launcher);
+#   tier 3  anything that depends on how the runtime schedules two streams (the start gate).
+# Files keep their alphabetical order inside a tier; a file not listed is tier 1.
+_TIER = {
+    "test_oracle_golden": 0, "test_oracle_model": 0, "test_abi": 0,
+    "test_kernels_gpu": 0, "test_model_gpu": 0, "test_nav_gpu": 0, "test_fullsize_16bit_gpu": 0, "test_fullsize_oracle_gpu": 0,
+    "test_fullsize_gpu": 0, "test_rollout_gpu": 0, "test_rollout_fullsize_gpu": 0, "test_ingest_gpu": 0, "test_icod_gpu": 0,
+    "test_causal_gpu": 0, "test_dropout_gpu": 0, "test_mrc_gpu": 0, "test_sizes_gpu": 0, "test_attn_gpu": 0, "test_chain_gpu": 0,
+    "test_glue_gpu": 0, "test_makd_gpu": 0, "test_bench_contract_gpu": 0,
+    "test_ddp_overlap_gpu": 2, "test_stream_dp_gpu": 2, "test_bench_launch_gpu": 2, "test_bench_launch_cpu": 2,
+}
+_LAST = ("test_encoder_start_gate",)
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def tier(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if item.name.startswith(_LAST):
+            return 3
+        return _TIER.get(mod, 1)
+    order = {id(it): i for i, it in enumerate(items)}
+    items.sort(key=lambda it: (tier(it), order[id(it)]))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -57,6 +57,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.magic_abi_version() == 1
 
 
+def test_library_carries_the_id_of_this_source_tree(monkeypatch):
+    """magic_build_id() == csrc/build_id.py's content hash of the sources: the binary under test is the binary of this tree; a library
+    whose id differs is refused at load"""
+    L.load()
+    assert L.library_build_id() == L.source_build_id() and len(L.library_build_id()) == 16
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "source_build_id", lambda: "0" * 16)
+    with pytest.raises(L.MagicHipError, match="other sources"):
+        L.load()
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(L, "_lib", None)
     monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libmagic_hip.so")
@@ -71,7 +82,7 @@ def test_fastcall_extension_binds_the_same_library_and_checks_arity():
     assert os.path.exists(L.FAST_PATH), "csrc/Makefile builds _magic_fastcall.so next to libmagic_hip.so"
     fast = {n for n, f in L._FN.items() if type(f).__name__ == "builtin_function_or_method"}
     slow = set(L.SIGNATURES) - fast
-    assert slow == {"magic_device_info", "magic_gemm_dw_grouped", "magic_mse_multi"}, slow
+    assert slow == {"magic_device_info", "magic_build_id", "magic_gemm_dw_grouped", "magic_mse_multi"}, slow
     assert L._FN["magic_abi_version"]() == L.load().magic_abi_version() == 1
     for args in ((1, 64, 80, 80), (0, 64, 600, 80), (1, 48, 80, 80), (1, 64, 5000, 80)):       # pure host function: both bindings agree
         assert L._FN["magic_attn_supported"](*args) == L.load().magic_attn_supported(*args)

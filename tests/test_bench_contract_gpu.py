@@ -35,6 +35,18 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert modes["fp32"]["ms_per_step"] > 0 and d["fp32_mode_ms_per_step"] == modes["fp32"]["ms_per_step"]
     assert par["bf16x3"]["max_abs_logit_delta"] < 1e-3 and par["bf16x3"]["argmax_agreement"] == 1.0 and modes["bf16x3"]["ms_per_step"] > 0
     assert par["bf16"]["argmax_agreement"] >= 0.9 and par["bf16"]["worst_oracle_gap_between_flipped_picks"] <= 2 * par["bf16"]["max_abs_logit_delta"] + 1e-9
+    # round 4: the tolerance status of the headline arithmetic at the top level, the parity-clean mode beside it, a 150-step figure, what the
+    # teacher stream's start gate did, the id of the binary, and the RCCL calls of the exchange loaded in a world-1 group
+    assert d["meets_north_star_tolerance"] == (par[d["dtype"]]["max_abs_logit_delta"] < 1e-3 and par[d["dtype"]]["argmax_agreement"] == 1.0)
+    clean = d["parity_clean_mode"]
+    assert clean is not None and clean["max_abs_logit_delta"] < 1e-3 and clean["argmax_agreement"] == 1.0 and clean["ms_per_step"] > 0
+    assert d["steady"]["steps"] == 150 and d["ms_per_step_steady"] == d["steady"]["ms_per_step"] > 0
+    g = d["teacher_gate"]
+    assert g["calls"] >= 4 + 2 + 150 and g["calls"] == g["opened"] + g["already_resident"] + g["timeouts"] + g["skipped"]
+    assert g["disabled"] or g["timeouts"] <= 3 + g["opened"] + g["already_resident"], g       # timeouts never run unbounded: the gate turns itself off
+    from magic_amd.host import lib as L
+    assert d["build_id"] == L.source_build_id()
+    assert d["rccl_smoke"]["ok"] is True and d["rccl_smoke"]["identity_at_world_1"] is True, d["rccl_smoke"]
     cpu = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu, k

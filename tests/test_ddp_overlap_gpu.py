@@ -54,6 +54,29 @@ def _worker(rank, world, port, q):
             a, m = grads[True], grads[False]
             res[task] = (float((a - m).abs().max()), float(m.abs().max()), bool(torch.equal(every[0], every[1])),
                          float((a - m).norm() / m.norm()))
+        # gradient accumulation under data parallelism: accum_steps = 2, the two micro-batches of a window touch different
+        # word-embedding rows.  Overlap ON exchanges the UNION of the window's rows in the last bucket; overlap OFF all-reduces the dense
+        # buffer.  Same weights after the update, bitwise-equal replicas.
+        micro = []
+        for k in range(2):
+            b = synth.make_batch("sap", batch_size=4, seed=500 + 10 * rank + k, step=k, vocab=600, min_len=8, max_len=15, min_steps=2, max_steps=3)
+            micro.append((synth.batch_to(b, dev), build_plan(b, "sap", dev)))
+        assert set(micro[0][1]["emb_rows"].tolist()) - set(micro[1][1]["emb_rows"].tolist()), "the first micro-batch must own some rows"
+        flat = {}
+        for overlap in (True, False):
+            _, _, g_t, g_s = build(torch.float32)
+            tr = PretrainStep(g_s, g_t, lr=1e-3, warmup_steps=2, num_train_steps=10, sparse_embedding_rows=4 * 15, accum_steps=2)
+            tr.sync.overlap = overlap
+            for bd, plan in micro:
+                tr.step(bd, "sap", rw=rw, plan=plan)
+            assert tr.global_step == 1
+            torch.cuda.synchronize()
+            flat[overlap] = g_s.store.flat.detach().cpu().clone()
+        every = [torch.empty_like(flat[True]) for _ in range(world)]
+        dist.all_gather(every, flat[True])
+        a, m = flat[True], flat[False]
+        res["accum2_sap_weights"] = (float((a - m).abs().max()), float(m.abs().max()), bool(torch.equal(every[0], every[1])),
+                                     float((a - m).norm() / m.norm()))
         q.put((rank, res))
     finally:
         dist.destroy_process_group()

@@ -130,3 +130,74 @@ def test_two_rank_gradient_allreduce_param_broadcast_and_task_broadcast():
         assert same_params, f"rank {rank}: parameters differ after broadcast"
         assert ok_sum and ok_mean, f"rank {rank}: all-reduce result wrong"
         assert gscale == 0.5 and task == 2
+
+
+def _worker3(rank, world, port, q):
+    """three ranks, three 'optimizer steps' of two micro-batches each: the flat buffer accumulates both micro-batches' word-embedding rows,
+    the last bucket exchanges the UNION of the window's rows (cap x accum_steps) -- against the dense all-reduce of the same buffers"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from magic_amd.host.config import make_config
+        from magic_amd.host.model_pretrain import pretrain_specs
+        from magic_amd.host.params import ParamStore
+        from magic_amd.host.trainer import EMB_TABLE, GradSync, PretrainStep
+        cfg = make_config(128, teacher_hidden_size=256, vocab_size=300, num_l_layers=3, num_x_layers=1, num_pano_layers=2)
+        store = ParamStore(pretrain_specs(cfg), "cpu", torch.float32, seed=3)
+        off, n, (R, H) = store.offsets[EMB_TABLE]
+        sy = GradSync(store, chunk_elems=5003, overlap=True, sparse_rows_cap=24)
+        win = PretrainStep.__new__(PretrainStep)              # only the window bookkeeping of the trainer (no device, no optimizer)
+        win.accum_steps, win._window_rows = 2, []
+        ok, worst = True, 0.0
+        for step in range(3):
+            gen = torch.Generator().manual_seed(1000 * step + rank)
+            store.grad.zero_()
+            win._window_rows = []
+            for micro in range(2):                            # micro-batches touch different (overlapping) rows, <= cap each
+                g = torch.randn(store.total, generator=gen)
+                rows = torch.randperm(R, generator=gen)[:10 + 3 * rank + micro]
+                tab = g[off:off + n].view(R, H)
+                keep = tab[rows].clone()
+                tab.zero_()
+                tab[rows] = keep
+                store.grad.add_(g)
+                win._window_rows.append(torch.unique(rows))
+            mono = store.grad.clone()
+            dist.all_reduce(mono)
+            touched = win._window_touched()
+            assert touched.numel() > 24 or rank == 0          # the union outgrows ONE micro-batch's cap on ranks 1, 2: cap_scale is needed
+            sy.reduce_bucket(0)
+            sy.reduce_bucket(1)
+            sy.reduce_bucket(2, touched, cap_scale=2)
+            sy.finish()
+            worst = max(worst, float((store.grad - mono).abs().max()))
+            ok = ok and bool(torch.allclose(store.grad, mono, rtol=1e-6, atol=1e-6))
+            every = [torch.empty_like(store.grad) for _ in range(world)]
+            dist.all_gather(every, store.grad)
+            ok = ok and all(bool(torch.equal(every[0], e)) for e in every[1:])          # bitwise-equal replicas
+            # what the round-3 code did (only the LAST micro-batch's rows): rows touched by the first micro-batch alone stay unsummed
+            if step == 0:
+                only_last = win._window_rows[-1]
+                missed = set(touched.tolist()) - set(only_last.tolist())
+                ok = ok and len(missed) > 0
+        win._window_rows = [torch.arange(3), None]            # one dense micro-batch (mlm: tied decoder) makes the window dense
+        ok = ok and win._window_touched() is None
+        q.put((rank, ok, worst))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_three_ranks_three_buckets_sparse_rows_of_an_accumulation_window():
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker3, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, ok, worst in res:
+        assert ok, f"rank {rank}: window-union sparse exchange != dense all-reduce (max diff {worst:.3e}) or replicas differ"

@@ -340,29 +340,98 @@ def test_node_inputs_backward_in_shared_launches_matches_the_per_op_sequence():
     assert gb.abs().max() > 0 and torch.allclose(ga, gb, rtol=1e-4, atol=1e-5), (ga - gb).abs().max().item()
 
 
-def test_encoder_start_gate_opens_on_the_next_encoder_launch_and_times_out_without_one():
+def _streams_overlap(side):
+    """do the main stream and `side` run kernels side by side IN THIS PROCESS?  (HIP maps streams onto a few hardware queues; two streams on
+    one queue serialise.)  Two 3 ms gate waits without an encoder launch: ~3 ms together when they overlap, ~6 ms when they do not."""
+    sa, sb = O.gate_stats_new(DEV), O.gate_stats_new(DEV)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    main = torch.cuda.current_stream()
+    e0.record(main)
+    side.wait_event(e0)
+    with torch.cuda.stream(side):
+        O.encoder_start_gate(sa, 3000, 0)
+    O.encoder_start_gate(sb, 3000, 0)
+    main.wait_stream(side)
+    e1.record(main)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) < 4.5
+
+
+def test_encoder_start_gate_counts_what_it_does_and_switches_itself_off():
     """magic_encoder_start_gate: a stream parked on it resumes when another stream's whole-encoder launch has its last workgroup on a CU (the
-    teacher's forward is held back that way), and after its timeout otherwise"""
+    teacher's forward is held back that way).  Nothing in HIP promises that two streams overlap, so the properties asserted are the ones
+    the product relies on: every outcome is COUNTED, a launch that is already resident opens the gate at once, and after three consecutive
+    timeouts the gate is an empty launch -- a process whose streams serialise pays 3 timeouts, not one per step."""
     m = student()
     m.eval()
     b = synth.make_batch("sap", batch_size=8, seed=3, step=0)
     bd, plan = synth.batch_to(b, DEV), build_plan(b, "sap", DEV)
+    assert m.will_fuse_encoders(plan)
     with torch.no_grad():
         m(bd, "sap", compute_loss=False, plan=plan)              # warm-up (code objects, allocator)
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    st = O.gate_stats_new(DEV)
+
+    # (1) no encoder launch follows: the gate gives up after its timeout and says so
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    with torch.cuda.stream(side):                                 # no encoder launch follows: the gate gives up after its timeout
+    with torch.cuda.stream(side):
         e0.record()
-        O.encoder_start_gate(2000)
+        O.encoder_start_gate(st, 2000, 0)
         e1.record()
     torch.cuda.synchronize()
-    assert 1.5 < e0.elapsed_time(e1) < 20.0, e0.elapsed_time(e1)
-    with torch.cuda.stream(side):                                 # an encoder launch on the main stream opens it long before the timeout
-        e0.record()
-        O.encoder_start_gate(100000)
-        e1.record()
+    r = O.gate_report(st)
+    assert (r["calls"], r["timeouts"], r["consecutive_timeouts"], r["opened"], r["disabled"]) == (1, 1, 1, 0, 0), r
+    assert e0.elapsed_time(e1) > 1.5, e0.elapsed_time(e1)
+
+    # (2) a launch that became resident a moment ago IS the launch the gate was meant to follow: it opens at once (and the run of timeouts ends)
     with torch.no_grad():
         m(bd, "sap", compute_loss=False, plan=plan)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        O.encoder_start_gate(st, 50000, 100000)
     torch.cuda.synchronize()
+    r = O.gate_report(st)
+    assert (r["calls"], r["already_resident"], r["timeouts"], r["consecutive_timeouts"]) == (2, 1, 1, 0), r
+
+    # (3) an encoder launch on the main stream opens a parked gate -- where this process's streams overlap at all; where they do not, the
+    # gate must time out and COUNT it (that is what switches it off in the product)
+    overlap = _streams_overlap(side)
+    seen = []
+    for _ in range(3):                                           # (a host-side stall between the two enqueues may cost one attempt, not the property)
+        st = O.gate_stats_new(DEV)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            O.encoder_start_gate(st, 30000, 0)
+        with torch.no_grad():
+            m(bd, "sap", compute_loss=False, plan=plan)
+        torch.cuda.synchronize()
+        r = O.gate_report(st)
+        assert r["calls"] == 1 and r["opened"] + r["timeouts"] == 1, r
+        seen.append(r["opened"])
+        if r["opened"] or not overlap:
+            break
+    if overlap:
+        assert seen[-1] == 1, ("the streams overlap, yet the gate never saw the encoder launch", seen)
+    print("streams overlap:", overlap, "opened:", seen)
+
+    # (4) three consecutive timeouts switch the gate off: later calls return at once and are counted as skipped
+    st = O.gate_stats_new(DEV)
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            O.encoder_start_gate(st, 500, 0)
+        e0.record()
+        for _ in range(5):
+            O.encoder_start_gate(st, 100000, 0)              # 5 x 100 ms if they waited
+        e1.record()
+    torch.cuda.synchronize()
+    r = O.gate_report(st)
+    assert (r["calls"], r["timeouts"], r["disabled"], r["skipped"]) == (8, 3, 1, 5), r
     assert e0.elapsed_time(e1) < 50.0, e0.elapsed_time(e1)
+    st.zero_()                                                   # the owner re-arms it
+    with torch.cuda.stream(side):
+        O.encoder_start_gate(st, 500, 0)
+    torch.cuda.synchronize()
+    assert O.gate_report(st)["timeouts"] == 1

@@ -107,12 +107,17 @@ __device__ long long enc_ticks[2][16];        // [segment][stage mark] of block 
 #define ENC_MARK(i)
 #endif
 
-// Launches of the encoder kernels that have got their LAST workgroup onto a CU (monotonic; never reset).  magic_encoder_start_gate parks
-// another stream until the count moves: the frozen teacher's forward, which runs next to the student's step on a side stream, then starts
-// once the student's whole-encoder launch has its workgroups resident instead of taking CUs and LDS from under it (bench: 1.615 -> 1.57 ms).
+// Launches of the encoder kernels that have got their LAST workgroup onto a CU (monotonic; never reset) and the 100 MHz tick of the latest
+// one.  magic_encoder_start_gate parks another stream until the count moves: the frozen teacher's forward, which runs next to the student's
+// step on a side stream, then starts once the student's whole-encoder launch has its workgroups resident instead of taking CUs and LDS
+// from under it (bench: 1.615 -> 1.57 ms).
 __device__ unsigned magic_enc_starts;
+__device__ long long magic_enc_start_tick;
 __device__ __forceinline__ void enc_mark_start() {
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) __hip_atomic_fetch_add(&magic_enc_starts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    __hip_atomic_store(&magic_enc_start_tick, (long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&magic_enc_starts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // LDS layout of the per-sample body.  Samples of <= 48 rows (panoramas: 36-38 views) take the COMPACT layout, 76.5 KB: images sized for 48
@@ -872,17 +877,36 @@ static size_t enc_lds_bytes() {
 }
 static size_t enc_lds_bytes_compact() { return (size_t)(2 * 48 * XS + 49 * QS + 6 * 16 * 72) * 2; }      // EncLay<NRT <= 3>
 
-__global__ void enc_start_gate_kernel(long long timeout_ticks) {
+// Nothing in HIP promises that two streams run side by side (they may share a hardware queue; a profiler may serialise them), and a gate
+// that starts AFTER the launch it waits for would sleep for nothing.  So the gate (i) passes at once when a whole-encoder launch became
+// resident within the last `recent_ticks` (that IS the launch it was meant to follow), (ii) counts what it does in `st`, and (iii) switches
+// ITSELF off after GATE_MAX_CONSEC consecutive timeouts: from then on it is an empty launch until the owner zeroes `st` again.
+// st: 0 calls | 1 opened by a launch while waiting | 2 launch already resident at entry | 3 timeouts | 4 consecutive timeouts | 5 disabled
+//     | 6 calls skipped while disabled | 7 reserved
+#define GATE_MAX_CONSEC 3
+__global__ void enc_start_gate_kernel(long long timeout_ticks, long long recent_ticks, unsigned* st) {
   if (threadIdx.x) return;
+  st[0] += 1;
+  if (st[5]) { st[6] += 1; return; }
   const unsigned c0 = __hip_atomic_load(&magic_enc_starts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const long long t0 = wall_clock64();                       // 100 MHz
-  while (__hip_atomic_load(&magic_enc_starts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c0 && wall_clock64() - t0 < timeout_ticks)
+  const long long tm = __hip_atomic_load(&magic_enc_start_tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (c0 != 0 && t0 - tm >= 0 && t0 - tm < recent_ticks) { st[2] += 1; st[4] = 0; return; }
+  while (__hip_atomic_load(&magic_enc_starts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c0) {
+    if (wall_clock64() - t0 >= timeout_ticks) {
+      st[3] += 1;
+      if (++st[4] >= GATE_MAX_CONSEC) st[5] = 1;
+      return;
+    }
     __builtin_amdgcn_s_sleep(32);
+  }
+  st[1] += 1;
+  st[4] = 0;
 }
 // park `stream` (one sleeping wave) until the next whole-encoder launch of this process has all its workgroups on CUs, at most timeout_us
-extern "C" int magic_encoder_start_gate(int timeout_us, void* stream) {
-  if (timeout_us < 0 || timeout_us > 100000) return MAGIC_ERR_ARG;
-  hipLaunchKernelGGL(enc_start_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)timeout_us * 100);
+extern "C" int magic_encoder_start_gate(int timeout_us, int recent_us, unsigned* stats, void* stream) {
+  if (timeout_us < 0 || timeout_us > 100000 || recent_us < 0 || recent_us > 100000 || !stats) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(enc_start_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)timeout_us * 100, (long long)recent_us * 100, stats);
   return launch_status();
 }
 

@@ -17,6 +17,7 @@ vp, i32, i64, f32, u32, u64 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_
 # name -> argument ctypes (mirrors include/magic_hip.h exactly; tests/test_abi.py checks every symbol)
 SIGNATURES = {
     "magic_abi_version": [],
+    "magic_build_id": [vp, i32],
     "magic_device_info": [vp, vp, vp, i32],
     "magic_gemm": [i32, i32, i32, i32, i32, i32, i32, vp, i32, i64, i64, vp, i32, i64, i64, vp, i32, i64, i64, i32, i32,
                    vp, i32, vp, i32, vp, i32, vp, i32, f32, i32, vp, vp],
@@ -73,7 +74,7 @@ SIGNATURES = {
     "magic_encoder_supported": [i32, i32, i32, i32, i32, i32],
     "magic_encoder_params_bytes": [],
     "magic_encoder_fwd": [i32, vp, i32, vp],
-    "magic_encoder_start_gate": [i32, vp],
+    "magic_encoder_start_gate": [i32, i32, vp, vp],
     "magic_chain_supported": [i32, i32, i32],
     "magic_chain_fwd": [i32, vp, i32, vp],
     "magic_xencoder_supported": [i32, i32, i32, i32, i32, i32, i32],
@@ -195,6 +196,35 @@ class MagicHipError(RuntimeError):
     pass
 
 
+def source_build_id():
+    """the id csrc/build_id.py derives from THIS tree's sources (content hashes; None when the sources are not there)"""
+    path = os.path.join(os.path.dirname(_HERE), "csrc", "build_id.py")
+    if not os.path.exists(path):
+        return None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_magic_build_id", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build_id()
+
+
+def library_build_id(lib=None):
+    """the id compiled into the loaded libmagic_hip.so (magic_build_id)"""
+    lib = lib if lib is not None else load()
+    buf = C.create_string_buffer(32)
+    if lib.magic_build_id(buf, 32) != 0:
+        raise MagicHipError("magic_build_id failed")
+    return buf.value.decode()
+
+
+def check_build_id(lib):
+    """a library built from other sources than the tree it sits in is refused (MAGIC_ALLOW_STALE_LIB=1 overrides, for bisecting)"""
+    want, got = source_build_id(), library_build_id(lib)
+    if want is not None and want != got and not os.environ.get("MAGIC_ALLOW_STALE_LIB"):
+        raise MagicHipError(f"{LIB_PATH} was built from other sources (library id {got}, this tree {want}): rebuild with "
+                            "`python __graft_entry__.py` (make -C vln-magic_amd/csrc)")
+
+
 def load():
     """Load the shared library (fails loudly; there is no fallback path)."""
     global _lib
@@ -205,9 +235,12 @@ def load():
                             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise MagicHipError(f"{LIB_PATH} does not export {name}: a stale build -- run `python __graft_entry__.py`")
         fn.argtypes = args
         fn.restype = i32
+    check_build_id(lib)
     _lib = lib
     _bind_fast(lib)
     return lib

@@ -190,6 +190,12 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         O.linear_dx(dZ, l1.W, M, out=d_acc, residual=d_acc, ldc=lda)
 
     # ---- forward ----------------------------------------------------------------------------------------
+    def will_fuse_encoders(self, plan):
+        """does a forward on `plan` run the text + panorama encoders as ONE whole-encoder launch (csrc/encoder.hip)?  The one predicate
+        behind the model's own choice and the teacher stream's start gate (trainer.capture_split, stream_graph)."""
+        n = self.net
+        return bool(n.enc_ok(plan["L"], self.config.num_l_layers) and n.enc_ok(plan["V"], self.config.num_pano_layers))
+
     def forward(self, batch, task, compute_loss=True, teacher_outputs=None, rw=None, plan=None, return_outputs=False, inputs=None):
         n = self.net
         refuse_torch_ddp(self)
@@ -205,7 +211,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         c = Ctx(task=task, plan=plan, inp=inp)
         # the text and panorama encoders are independent: run them on two streams
         # both self-attention encoders as ONE launch (csrc/encoder.hip) when the shapes allow: embeddings first (paired), then the launch
-        fuse = n.enc_ok(plan["L"], self.config.num_l_layers) and n.enc_ok(plan["V"], self.config.num_pano_layers)
+        fuse = self.will_fuse_encoders(plan)
         c.txt, c.pano = self._par(lambda: n.text_fwd(plan, defer=fuse), lambda: n.pano_fwd(plan, inp.feats, inp.loc, defer=fuse))
         if fuse:
             n.encoders_fwd(c.txt, c.pano)

@@ -405,13 +405,28 @@ def encoder_fwd(segs, seed, p_attn, p_hidden, eps, scale):
 
 
 TEACHER_GATE_US = int(os.environ.get("MAGIC_TEACHER_GATE_US", "400"))       # 0: off
+TEACHER_GATE_RECENT_US = int(os.environ.get("MAGIC_TEACHER_GATE_RECENT_US", "150"))
+GATE_FIELDS = ("calls", "opened", "already_resident", "timeouts", "consecutive_timeouts", "disabled", "skipped")
 
 
-def encoder_start_gate(timeout_us=None):
-    """park the current stream until the next whole-encoder launch (another stream's) has its workgroups resident (csrc/encoder.hip)"""
+def gate_stats_new(device):
+    """the 8 counters a start gate keeps (csrc/encoder.hip): zeroed device memory owned by whoever inserts the gate"""
+    return torch.zeros(8, dtype=torch.int32, device=device)
+
+
+def gate_report(stats):
+    """counters of a start gate as a dict (one small device -> host copy: call it at a point that may synchronise)"""
+    v = stats.cpu().tolist()
+    return {k: int(v[i]) for i, k in enumerate(GATE_FIELDS)}
+
+
+def encoder_start_gate(stats, timeout_us=None, recent_us=None):
+    """park the current stream until the next whole-encoder launch (another stream's) has its workgroups resident, a launch of the last
+    `recent_us` counting as that launch; bounded by `timeout_us`; switches itself off after 3 consecutive timeouts (csrc/encoder.hip)"""
     t = TEACHER_GATE_US if timeout_us is None else int(timeout_us)
+    r = TEACHER_GATE_RECENT_US if recent_us is None else int(recent_us)
     if t > 0:
-        L.call("magic_encoder_start_gate", t, L.stream())
+        L.call("magic_encoder_start_gate", t, r, L.P(stats), L.stream())
 
 
 FUSED_CHAIN = not os.environ.get("MAGIC_NO_CHAIN")

@@ -124,9 +124,9 @@ class StreamStep:
         t_cap = time.perf_counter()          # (after the drain: the steps the host had queued ahead are training time, not capture time)
         e.gT = torch.cuda.CUDAGraph()
         with torch.cuda.graph(e.gT, stream=tr.side, capture_error_mode="relaxed"):
-            if tr.student.net.enc_ok(e.plan["L"], tr.student.config.num_l_layers):
+            if tr.student.will_fuse_encoders(e.plan):      # (every bucket of one stream pads to the same L, V: S_i fuses iff this plan does)
                 from . import ops as O
-                O.encoder_start_gate()      # T_{i+1} starts once S_i's whole-encoder launch has its workgroups resident (trainer.capture_split)
+                O.encoder_start_gate(tr.gate)   # T_{i+1} starts once S_i's whole-encoder launch has its workgroups resident (trainer.capture_split)
             e.t_out = tr.teacher_forward(e.batch, task, e.plan)
         e.cs = tr.capture_student((e.batch, task, e.plan), e.t_out, rw=self.rw)      # one graph; data parallel: three + the optimizer's
         e.out = e.cs.out

@@ -185,14 +185,14 @@ class GradSync:
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
 
-    def _sparse_rows(self, row_ids):
+    def _sparse_rows(self, row_ids, cap=None):
         """sum over ranks of the gradient rows `row_ids` (this rank's touched rows: int64 on the device, any order, UNIQUE -- the
         plan's `torch.unique(txt_ids)`) of the word-embedding table: all-gather ids + rows, then every rank rebuilds the touched
         rows as 0 + rank 0's rows + rank 1's rows + ... in rank order.  One rank's ids never collide inside one index_add_, so the
         fp32 sum order is the same on every rank and the replicas stay bitwise identical, as after an all-reduce."""
         off, n, (R, H) = self.table
         tab = self.store.grad[off:off + n].view(R, H)
-        cap = self.sparse_cap
+        cap = self.sparse_cap if cap is None else int(cap)          # THE SAME ON EVERY RANK (gathered buffers are cap-sized)
         ids = torch.zeros(cap, dtype=torch.int64, device=tab.device)
         k = int(row_ids.numel())
         if k > cap:
@@ -209,9 +209,10 @@ class GradSync:
             tab.index_add_(0, all_ids[r * cap:(r + 1) * cap], all_rows[r * cap:(r + 1) * cap])
 
     # ---- per-bucket API (called from inside the backward) ----------------------------------------------------------
-    def reduce_bucket(self, i, touched_rows=None):
+    def reduce_bucket(self, i, touched_rows=None, cap_scale=1):
         """launch bucket i's exchange on the side stream.  touched_rows (last bucket only): device int64 ids of the word-embedding
-        rows this rank's step wrote, or None for a dense table (mlm: the tied decoder touches every row)."""
+        rows this rank's step wrote, or None for a dense table (mlm: the tied decoder touches every row).  cap_scale: the gathered
+        buffers hold cap_scale x sparse_rows_cap rows (gradient accumulation: the rows of cap_scale micro-batches)."""
         if self.world == 1:
             return
         ranges = self.buckets[i]
@@ -226,7 +227,7 @@ class GradSync:
         def run():
             self._ranges(ranges)
             if sparse:
-                self._sparse_rows(touched_rows)
+                self._sparse_rows(touched_rows, cap=self.sparse_cap * cap_scale)
         self._on_side(run)
 
     def all_reduce(self):
@@ -347,6 +348,7 @@ class PretrainStep:
         self.accum_steps = int(accum_steps)
         assert self.accum_steps >= 1
         self._micro = 0
+        self._window_rows = []      # word-embedding rows touched by the micro-batches of the running accumulation window (None: dense)
         # per-step random scalars (MKRW weights, dropout seed) come from ONE launch (csrc/loss.hip step_rng_kernel) keyed by `seed` and a
         # device-side step counter: inside a captured graph every replay advances the counter and so draws fresh values
         self.seed = int(seed)
@@ -355,8 +357,26 @@ class PretrainStep:
             self._rw = torch.ones(5, dtype=torch.float32, device=self.dev)
             self._dseed = torch.zeros(2, dtype=torch.int32, device=self.dev)
             student.dropout_seed = self._dseed
+            # counters of the teacher stream's start gate (csrc/encoder.hip): it switches itself off after 3 consecutive timeouts
+            self.gate = O.gate_stats_new(self.dev)
         self._ss_zeroed = False     # the prologue launch of the running step zeroed the optimizer's gradient-norm accumulator
         self._grad_clean = False    # the previous step's AdamW launch left the gradient buffer zeroed (no fill launch needed)
+
+    def gate_report(self):
+        """what the teacher stream's start gate did so far: calls / opened / already_resident / timeouts / disabled / skipped (synchronises)"""
+        return O.gate_report(self.gate) if self.on_gpu else None
+
+    def gate_reset(self):
+        """re-arm a gate that switched itself off (e.g. after a profiler run that serialised the streams)"""
+        if self.on_gpu:
+            self.gate.zero_()
+
+    def _one_update_per_call(self, what):
+        """the teacher-ahead and captured forms run one optimizer update per call / replay: they never accumulate, so the 1 / accum_steps
+        of `_opt_step` would silently shrink their gradients"""
+        if self.accum_steps != 1:
+            raise NotImplementedError(f"{what} runs one optimizer step per call: gradient accumulation (accum_steps={self.accum_steps}) "
+                                      "is served by step() only")
 
     def _graph_ctx(self, g):
         # relaxed: helper threads launch into the capture (lib.lockstep).  Stream priorities were tried and rejected: a
@@ -388,12 +408,20 @@ class PretrainStep:
         rows = plan.get("emb_rows")
         return rows if rows is not None and rows.numel() > 0 else None      # bucket-padded plans hold an empty placeholder: dense
 
+    def _window_touched(self):
+        """the rows with gradient in the flat buffer at the end of an accumulation window: the UNION over its micro-batches (the buffer
+        accumulates every micro-batch's rows; exchanging only the last one's would leave the others unsummed across ranks), or None
+        (dense) as soon as one micro-batch touched the table densely"""
+        if any(r is None for r in self._window_rows):
+            return None
+        return self._window_rows[0] if len(self._window_rows) == 1 else torch.unique(torch.cat(self._window_rows))
+
     def _bucket_hook(self, task, plan):
         """on_bucket callback for model.backward(): launches each bucket's exchange on the side stream as soon as the explicit
         backward has finished that bucket's gradients (bucket 0 runs under the text / panorama backward)"""
         if self.sync.world == 1 or not self.sync.overlap:
             return None
-        return lambda i, ctx: self.sync.reduce_bucket(i, self._touched_rows(task, plan) if i == 2 else None)
+        return lambda i, ctx: self.sync.reduce_bucket(i, self._window_touched() if i == 2 else None, cap_scale=self.accum_steps)
 
     # ---- the pieces ------------------------------------------------------------------------------------
     def _fwd_bwd(self, batch, task, rw, plan):
@@ -418,6 +446,8 @@ class PretrainStep:
             rw = drawn
         if self._micro == 0:
             self._zero_grad()
+            self._window_rows = []
+        self._window_rows.append(self._touched_rows(task, plan))
         out = st(batch, task, compute_loss=True, teacher_outputs=t_out, rw=rw, plan=plan, inputs=inputs)
         last_micro = self._micro == self.accum_steps - 1
         hook = self._bucket_hook(task, plan) if (last_micro and not torch.cuda.is_current_stream_capturing()) else None
@@ -440,6 +470,7 @@ class PretrainStep:
     def _fwd_bwd_ahead(self, cur, t_cur, nxt, rw=None):
         """student step on cur = (batch, task, plan) against the ready teacher outputs t_cur, while the teacher runs on nxt"""
         st = self.student
+        self._one_update_per_call("step_ahead / capture_ahead")
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
@@ -449,6 +480,7 @@ class PretrainStep:
         if rw is None:
             rw = drawn
         self._zero_grad()
+        self._window_rows = [self._touched_rows(task, plan)]
         out = st(batch, task, compute_loss=True, teacher_outputs=t_cur, rw=rw, plan=plan, inputs=t_cur["inputs"])
         hook = self._bucket_hook(task, plan) if not torch.cuda.is_current_stream_capturing() else None
         st.backward(on_bucket=hook)
@@ -488,6 +520,7 @@ class PretrainStep:
         """the student's step on `cur` against the teacher outputs `t_cur` (static buffers a teacher graph fills): one graph holding the
         whole step on one GPU; under data parallelism three graphs cut where the gradient buckets are final + the optimizer's graph,
         replayed by `replay_student` with the RCCL calls between them"""
+        self._one_update_per_call("capture_student / capture_split")
         full = self.sync.world == 1 and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")
         batch, task, plan = cur
         two = (not full) and self.sync.overlap and not os.environ.get("MAGIC_DDP_ONE_GRAPH")
@@ -564,8 +597,8 @@ class PretrainStep:
         cs = self.capture_student(cur, t_cur, rw=rw, keep=(cur, t_cur, nxt, rw))
         gT = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gT, stream=self.side, capture_error_mode="relaxed"):
-            if self.student.net.enc_ok(nxt[2]["L"], self.student.config.num_l_layers):
-                O.encoder_start_gate()        # the student's whole-encoder launch first: see csrc/encoder.hip magic_encoder_start_gate
+            if self.student.will_fuse_encoders(cur[2]):
+                O.encoder_start_gate(self.gate)   # the student's whole-encoder launch (on `cur`) first: csrc/encoder.hip magic_encoder_start_gate
             t_next = self.teacher_forward(*nxt)
             if t_next_into is not None:
                 copy_teacher_outputs(t_next, t_next_into)

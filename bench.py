@@ -366,6 +366,23 @@ def parity_block(dev):
     return out
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on stdout when its first communicator comes up; the contract is ONE JSON line on stdout.  File-descriptor
+    level (the banner comes from C), restored on exit."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def rccl_smoke_leg(student, batch_size, dev):
     """N = 1 only: every collective the data-parallel exchange issues (trainer.GradSync: chunked fp32 all-reduce of the three gradient buckets,
     all_gather_into_tensor of int64 row ids + fp32 rows for the sparse word-embedding exchange) in a world-size-1 `nccl` (= RCCL) group on
@@ -379,7 +396,11 @@ def rccl_smoke_leg(student, batch_size, dev):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            warm = torch.zeros(8, device=dev)
+            dist.all_reduce(warm)                       # the communicator (and RCCL's banner) comes up with the first collective
+            torch.cuda.synchronize()
         try:
             store = student.store
             store.ensure_grads()
@@ -507,16 +528,19 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        with _stdout_to_stderr():
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("gloo")
     L.load()
     rccl = None
     if world > 1:             # every rank reports in through the data-path backend: the line shows N ranks on N devices really took part
         mine = torch.tensor([rank, local], device=dev, dtype=torch.int64)
         seen = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(seen, mine)
+        with _stdout_to_stderr():           # (RCCL's version banner belongs on stderr: stdout carries the one JSON line)
+            dist.all_gather(seen, mine)
+            torch.cuda.synchronize()
         seen = [t.tolist() for t in seen]
         rccl = {"backend": a.backend, "world": world, "ranks_seen": [r for r, _ in seen], "devices": [d for _, d in seen]}
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]

@@ -70,19 +70,27 @@ LOSS_KEYS = ("txt_emb_loss", "txt_attn_loss", "img_emb_loss", "avg_img_emb_loss"
 
 def nav_makd(t_step, s_out, t_out, proj, acc, *, role="t2s", loss_type="sum", temperature=2.0,
              abilities=("txt", "img", "global", "local", "action"), weights=None, weight_mode="RW",
-             no_feat=False, no_attn=False, no_logit=False, have_targets=True, mse_fn=None, kd_fn=None):
+             no_feat=False, no_attn=False, no_logit=False, have_targets=True, mse_fn=None, kd_fn=None, learned=None):
     """compute_kd_losses (agent.py:546-719) for the mse/mse/kd loss selection of agent_base.py:155-175.
 
     proj: dict of the 5 projection heads (txt_emb_w, kdl_img_w, kdl_avg_img_w, global_cross_w,
     local_cross_w) of the model being *projected* (student for t2s; for s2t the real student's heads
     are applied to the target side, agent.py:571,606-607,647,664).  weights: 5 MKRW scalars (RW) or
     None with weight_mode=None (no adaptive weights: the two img emb terms are halved, :624-625).
+    weight_mode='learned_weight' (:583-586, :616-619, :632-634, :680-686, :712-713): `learned` = the five raw scalars
+    kdl_{txt,img,global,local,predict}_weight of `s_model` (the student for t2s; for s2t the TEACHER model, whose role is the
+    learner, :553-557), each term scaled by softplus(raw); the two image-embedding terms ALSO halved, the image-attention term not.
     acc: dict accumulating the 10 entries (txt entries are assigned, the others added)."""
     if role == "s2t":
         loss_type = "mean"
     w = t_out["sample_weights"]
     hmin = min(s_out["txt_attns"].shape[1], t_out["txt_attns"].shape[1])
-    k = lambda i: (weights[i] if weight_mode == "RW" else 1.0)
+    if weight_mode == "learned_weight":
+        import torch.nn.functional as F
+        lw = [F.softplus(learned[n]) for n in ("kdl_txt_weight", "kdl_img_weight", "kdl_global_weight", "kdl_local_weight", "kdl_predict_weight")]
+        k = lambda i: lw[i]
+    else:
+        k = lambda i: (weights[i] if weight_mode in ("RW", "grad") else 1.0)
 
     def sides(name, s_val, t_val):
         if role == "t2s":
@@ -102,7 +110,7 @@ def nav_makd(t_step, s_out, t_out, proj, acc, *, role="t2s", loss_type="sum", te
     if "img" in abilities:
         a, b = sides("kdl_img_w", s_out["pano_embeds"], t_out["pano_embeds"])
         a2, b2 = sides("kdl_avg_img_w", s_out["pano_fused_embeds"], t_out["pano_fused_embeds"])
-        half = 1.0 if weight_mode == "RW" else 0.5
+        half = 1.0 if weight_mode in ("RW", "grad") else 0.5
         acc["img_emb_loss"] = acc["img_emb_loss"] + feat(a, b) * k(1) * half
         acc["avg_img_emb_loss"] = acc["avg_img_emb_loss"] + feat(a2, b2) * k(1) * half
         acc["img_attn_loss"] = acc["img_attn_loss"] + attn(s_out["img_attns"], t_out["img_attns"]) * k(1)

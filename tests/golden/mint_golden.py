@@ -143,10 +143,19 @@ def mint_agent():
     heads = {n: nn.Linear(Hs, Ht) for n in names}
     student_inner = SimpleNamespace(**heads)
     rw = torch.softmax(rnd(5) / 4.0, -1) * 5
+    # 'learned_weight' (agent.py:583-586, ...): five raw scalars on s_model = the LEARNER's inner model (student for t2s, teacher for s2t);
+    # drawn from their own generator so the cases minted in earlier rounds keep their values
+    g2 = torch.Generator().manual_seed(23)
+    lw_names = ["kdl_txt_weight", "kdl_img_weight", "kdl_global_weight", "kdl_local_weight", "kdl_predict_weight"]
+    lw_student = {n: torch.randn(1, generator=g2) for n in lw_names}
+    lw_teacher = {n: torch.randn(1, generator=g2) for n in lw_names}
+    for n in lw_names:
+        setattr(student_inner, n, nn.Parameter(lw_student[n].clone()))
+    teacher_inner = SimpleNamespace(**{n: nn.Parameter(lw_teacher[n].clone()) for n in lw_names})
     nav_targets = torch.tensor([2, 0, 4, -100])
     plain = lambda o: {k: (dict(v) if isinstance(v, dict) else v) for k, v in o.items()}
     fx = dict(s_out=plain(s_out), t_out=plain(t_out), heads={n: (h.weight.data.clone(), h.bias.data.clone()) for n, h in heads.items()},
-              rw=rw, nav_targets=nav_targets, cases={})
+              rw=rw, nav_targets=nav_targets, cases={}, learned_student=lw_student, learned_teacher=lw_teacher)
 
     def run(t, role, mode, loss_type="sum"):
         args = SimpleNamespace(kd_loss_type=loss_type, kd_ability_types=["txt", "img", "global", "local", "action"],
@@ -155,7 +164,7 @@ def mint_agent():
                                kdl_adaptive_ability_weight_type=mode, kdl_logit_loss="kd",
                                kdl_dkd_alpha=1.0, kdl_dkd_beta=1.0, ignoreid=-100)
         me = SimpleNamespace(args=args, vln_bert=SimpleNamespace(vln_bert=student_inner),
-                             teacher_vln_bert=SimpleNamespace(vln_bert=SimpleNamespace()),
+                             teacher_vln_bert=SimpleNamespace(vln_bert=teacher_inner),
                              kdl_feat_loss=K.mse_loss, kdl_attn_loss=K.mse_loss, kdl_logit_loss=K.kd_loss)
         acc = defaultdict(float)
         if role == "t2s":
@@ -169,6 +178,9 @@ def mint_agent():
             for lt in ("sum", "mean"):
                 fx["cases"][f"t2s_t{t}_{mode}_{lt}"] = run(t, "t2s", mode, lt)
         fx["cases"][f"s2t_t{t}_RW"] = run(t, "s2t", "RW")
+        for lt in ("sum", "mean"):
+            fx["cases"][f"t2s_t{t}_learned_weight_{lt}"] = run(t, "t2s", "learned_weight", lt)
+        fx["cases"][f"s2t_t{t}_learned_weight"] = run(t, "s2t", "learned_weight")
     torch.save(fx, os.path.join(HERE, "makd_agent.pt"))
     print("makd_agent:", list(fx["cases"]))
     sys.path.remove(f"{REF}/map_nav_src")
@@ -546,6 +558,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--nav-loop-only" in sys.argv:
         mint_nav_loop()
+        sys.exit(0)
+    if "--agent-only" in sys.argv:
+        mint_agent()
         sys.exit(0)
     if "--ingest-only" in sys.argv:
         mint_ingest()

@@ -59,11 +59,13 @@ def test_nav_makd_matches_compute_kd_losses(golden_dir):
         parts = name.split("_")
         role, t = parts[0], int(parts[1][1:])
         acc = defaultdict(float)
+        learned = "learned" in name             # 'learned_weight': softplus of the LEARNER's five kdl_*_weight scalars (student: t2s, teacher: s2t)
         if role == "t2s":
-            mode = None if parts[2] == "None" else "RW"
-            got = M.nav_makd(t, s_out, t_out, heads, acc, role="t2s", loss_type=parts[3], weights=rw, weight_mode=mode)
+            mode = "learned_weight" if learned else (None if parts[2] == "None" else "RW")
+            got = M.nav_makd(t, s_out, t_out, heads, acc, role="t2s", loss_type=parts[-1], weights=rw, weight_mode=mode, learned=fx["learned_student"])
         else:
-            got = M.nav_makd(t, t_out, s_out, heads, acc, role="s2t", weights=rw, weight_mode="RW")
+            got = M.nav_makd(t, t_out, s_out, heads, acc, role="s2t", weights=rw, weight_mode="learned_weight" if learned else "RW",
+                             learned=fx["learned_teacher"])
         assert set(got) == set(want), name
         for k in want:
             torch.testing.assert_close(torch.as_tensor(float(got[k])), want[k], rtol=2e-5, atol=1e-6, msg=f"{name}:{k}")

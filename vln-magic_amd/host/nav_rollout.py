@@ -99,7 +99,9 @@ class NavRollout:
     def __init__(self, student, feature_table, teacher=None, kd=None, max_action_len=15, expert_policy="spl", cache_text_kv=True,
                  train_teacher=False):
         """feature_table: [n_viewpoints, 36, D] device tensor in the student's compute dtype (packed once, SURVEY f-2).
-        kd: dict(alpha, temperature, decay) -- MAKD hyper-parameters (run_r2r_kdl_valid.sh:97-104)."""
+        kd: dict(alpha, temperature, decay[, ability_weight]) -- MAKD hyper-parameters (run_r2r_kdl_valid.sh:97-104); ability_weight =
+        args.kdl_adaptive_ability_weight_type: 'RW' (default: the `rw_seq` scalars a caller passes), 'learned_weight' (softplus of the
+        learner model's kdl_*_weight parameters, agent.py:583-586) or None."""
         self.student, self.teacher, self.kd = student, teacher, kd
         self.table = feature_table
         self.T, self.expert = max_action_len, expert_policy
@@ -254,13 +256,15 @@ class NavRollout:
                         t_ce = ce_rows_loss(t_outs["fused_logits"], targets, IGNORE)
                         t_out["sample_weights"] = exponential_decay(t_ce.detach(), self.kd["decay"])
                     if grad:
-                        rw_t = None if rw_seq is None else rw_seq[t]
-                        kdl = compute_kd_losses(t, s_out, t_out, self.heads, kdl, role="t2s", temperature=self.kd["temperature"], weights=rw_t)
+                        learned = self.kd.get("ability_weight") == "learned_weight"
+                        rw_t = None if (rw_seq is None or learned) else rw_seq[t]
+                        kdl = compute_kd_losses(t, s_out, t_out, self.heads, kdl, role="t2s", temperature=self.kd["temperature"], weights=rw_t,
+                                                learned=st.vln_bert if learned else None)
                         if tt_grad:      # reverse direction (agent.py:1026): teacher tensors vs the student's, projected by the student's heads
                             t_ml_loss = t_ml_loss + t_ce.sum()
                             s_out["sample_weights"] = exponential_decay(ce.detach(), self.kd["decay"])
                             t_kdl = compute_kd_losses(t, t_out, s_out, self.heads, t_kdl, role="s2t", temperature=self.kd["temperature"],
-                                                      weights=rw_t)
+                                                      weights=rw_t, learned=te.vln_bert if learned else None)   # s_model = the teacher (:555-556)
                 yield t           # the step is launched; nothing below is needed before its actions are (run_interleaved switches here)
                 a_host = None
                 if needs_action:                                                     # the stepper needs it: one [B] copy

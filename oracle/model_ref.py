@@ -305,6 +305,13 @@ class RefPretrainModel(nn.Module):
         if "mrc" in (getattr(cfg, "pretrain_tasks", None) or ()):      # built only when the task is configured (train_r2r_magic.py:104-107)
             self.image_classifier = nn.Module()                            # RegionClassification(H, image_prob_size)
             self.image_classifier.net = nn.Sequential(nn.Linear(H, H), nn.ReLU(), _ln(H, eps), nn.Linear(H, cfg.image_prob_size))
+        # back-door adjustment blocks (do_back_txt / do_back_img; inputs instr_z_* / img_z_* from the collates, tasks.py:156-164, :441-449):
+        # the navigation oracle's blocks (oracle/causal_ref.py) at the same two places VLNBert applies them; PARITY UNPINNED like the model
+        on = [n for n, f in (("back_txt", "do_back_txt"), ("back_img", "do_back_img")) if getattr(cfg, f, False)]
+        if on:
+            from .causal_ref import RefCausalBlock
+            self.bert.causal = nn.ModuleDict({n: RefCausalBlock(cfg, n, getattr(cfg, f"{n}_dict_size", None) or
+                                                                (cfg.image_feat_size if n == "back_img" else H)) for n in on})
         self.apply(self._init)
         name_modules(self)
 
@@ -325,8 +332,14 @@ class RefPretrainModel(nn.Module):
         txt_masks = seq_mask(batch["txt_lens"], batch["txt_ids"].shape[1])
         o["txt_masks"] = txt_masks
         o["txt_embeds"], o["txt_attns"] = bert.text(batch["txt_ids"], txt_masks)
+        cz = getattr(bert, "causal", {})
+        if "back_txt" in cz and batch.get("instr_z_direction_features") is not None:
+            from .causal_ref import cat_instr_dict
+            o["txt_embeds"] = cz["back_txt"](o["txt_embeds"], *cat_instr_dict(batch))
         pe, pm, pf, pa = bert.panorama(batch["traj_view_img_fts"], batch["traj_loc_fts"],
                                        batch["traj_nav_types"], batch["traj_vp_view_lens"])
+        if "back_img" in cz and batch.get("img_z_features") is not None:      # view embeddings only: the fused embedding stays un-adjusted
+            pe = cz["back_img"](pe, batch["img_z_features"], batch["img_z_pzs"])
         o["pano_embeds"], o["pano_fused_embeds"], o["img_attns"] = pe, pf, pa
         gmap_img = aggregate_gmap(pe, pf, batch)
         o["gmap_masks"] = seq_mask(batch["gmap_lens"], batch["gmap_step_ids"].shape[1])

@@ -114,3 +114,69 @@ def test_bf16_blocks_run_and_dictionary_without_switch_is_refused():
     assert dict(g.named_parameters())["vln_bert.causal.back_txt.value.weight"].grad.abs().max() > 0
     with pytest.raises(ValueError, match="front_txt_feats"):            # do_front_txt is off in this config
         g("language", dict(txt_ids=inp["txt_ids"], txt_masks=inp["txt_masks"], front_txt_feats=dz["front_txt_feats"]))
+
+
+# ---- the PRETRAINING model with its back-door inputs (pretrain_src/data/tasks.py:156-164, :441-449) -----------------------------------------
+def _pretrain_dicts(batch, g, n_dir=5, n_lm=7, n_img=9, H=128, D=768):
+    """the collate's output shape: ONE dictionary repeated over the batch (instruction: direction + landmark entries of the model's width, priors
+    [B, Nz, 1]); the image dictionary repeated over the trajectory's panoramas (`traj_img_len x Nz x 768`, priors `x 1`)"""
+    B, Np = len(batch["traj_step_lens"]), batch["traj_view_img_fts"].shape[0]
+    rep = lambda t, n: t.unsqueeze(0).repeat(n, *([1] * t.dim()))
+    pz = lambda n: torch.softmax(torch.randn(n, generator=g), 0).unsqueeze(-1)
+    batch = dict(batch)
+    batch["instr_z_direction_features"], batch["instr_z_direction_pzs"] = rep(torch.randn(n_dir, H, generator=g), B), rep(pz(n_dir), B)
+    batch["instr_z_landmark_features"], batch["instr_z_landmark_pzs"] = rep(torch.randn(n_lm, H, generator=g), B), rep(pz(n_lm), B)
+    batch["img_z_features"], batch["img_z_pzs"] = rep(torch.randn(n_img, D, generator=g), Np), rep(pz(n_img), Np)
+    return batch
+
+
+@pytest.mark.parametrize("task,method,itype", [("sap", "add", "type_2"), ("mlm", "door", "type_1"), ("cfp", "add", "type_1")])
+def test_pretraining_model_serves_the_back_door_inputs_of_its_collates(task, method, itype):
+    """GlocalTextPathCMTPreTraining with do_back_txt / do_back_img on (off in the shipped config, r2r_magic_model_config.json:60-66): the
+    `instr_z_*` / `img_z_*` keys the collates add are served by the navigation model's blocks at the same two places (text encoder output,
+    panorama view embeddings) -- fp32 engine vs fp64 oracle: every output, every loss term, every parameter gradient incl. the blocks'; and
+    such a key with its switch off raises."""
+    from magic_amd.host import synth
+    from tests.test_model_gpu import RW, build, close, to64, view_outputs
+    extra = dict(do_back_txt=True, do_back_img=True, do_back_txt_type="type_2", do_back_imgobj_type=itype, do_add_method=method)
+    o_t, o_s, g_t, g_s = build(torch.float32, **extra)
+    assert set(g_s.causal_blocks) == {"back_txt", "back_img"} and any(k.startswith("bert.causal.back_img.") for k in g_s.state_dict())
+    g = torch.Generator().manual_seed(11)
+    batch = _pretrain_dicts(synth.make_batch(task, batch_size=5, seed=31, vocab=600, min_len=8, max_len=17, min_steps=2, max_steps=4), g)
+    rw = torch.tensor(RW, dtype=torch.float64)
+    o_t, o_s = o_t.double(), o_s.double()
+    b64 = to64(batch)
+    with torch.no_grad():
+        ot = o_t(b64, task, compute_loss=True)["outputs"]
+    want = o_s(b64, task, compute_loss=True, teacher_outputs=ot, rw=rw)
+    want["loss"].backward()
+    with torch.no_grad():
+        gt = g_t(batch, task, compute_loss=False, return_outputs=True)
+    plan = gt["plan"]
+    for k, v in view_outputs(gt, plan, 256).items():
+        close(v, ot[k], f"teacher {k}", 2e-4, 2e-5)
+    g_s.store.zero_grad()
+    got = g_s(batch, task, compute_loss=True, teacher_outputs=gt, rw=RW, plan=plan)
+    for k, v in view_outputs(got["outputs"], plan, 128).items():
+        close(v, want["outputs"][k], f"student {k}", 2e-4, 2e-5)
+    close(got["supervised_loss"], want["supervised_loss"], "supervised loss", 1e-4, 1e-6)
+    for k, v in want["kdl_terms"].items():
+        close(got["kdl_terms"][k], v, f"kd term {k}", 2e-4, 1e-7)
+    close(got["loss"], want["loss"], "total loss", 1e-4, 1e-6)
+    got["loss"].backward()
+    torch.cuda.synchronize()
+    params = dict(g_s.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in o_s.parameters() if p.grad is not None)
+    n_blocks = 0
+    for name, p in o_s.named_parameters():
+        gr = params[name].grad
+        if p.grad is None:
+            assert gr.abs().max().item() == 0.0, name
+            continue
+        close(gr, p.grad, f"grad {name}", 2e-3, 1e-3 * p.grad.abs().max().item() + 2e-6 * gmax)
+        n_blocks += ".causal." in name and p.grad.abs().max().item() > 0
+    assert n_blocks >= 10, n_blocks                 # both blocks' projections, norms (+ the gate) carried gradient
+    # the same keys into a model whose switches are off: an error, never ignored
+    _, _, _, plain = build(torch.float32)
+    with pytest.raises(ValueError, match="do_back"):
+        plain(batch, task, compute_loss=False)

@@ -58,10 +58,12 @@ def enabled_blocks(cfg):
     return [n for n, flag in BLOCKS.items() if bool(getattr(cfg, flag, False))]
 
 
-def causal_specs(cfg, p):
+def causal_specs(cfg, p, only=None):
     H = cfg.hidden_size
     s = []
     for n in enabled_blocks(cfg):
+        if only is not None and n not in only:
+            continue
         q = f"{p}causal.{n}."
         Dz = dict_width(cfg, n)
         s += [(q + "query.weight", (H, H), "normal"), (q + "query.bias", (H,), "zeros"),
@@ -195,9 +197,9 @@ class CausalBlock(nn.Module):
         return _AddNormFn.apply(x, e, net, net.ln(self._ln_name), net._dh(self._drop_name), self._model[0])
 
 
-def build_blocks(model):
+def build_blocks(model, only=None):
     """attach `model.causal_blocks[name]` for every block the config switches on (none by default: r2r_magic_model_config.json:60-66)"""
-    return {n: CausalBlock(model, n) for n in enabled_blocks(model.config)}
+    return {n: CausalBlock(model, n) for n in enabled_blocks(model.config) if only is None or n in only}
 
 
 def check_inputs(model, mode, batch, keys):

@@ -135,6 +135,10 @@ def _queue_sync(model):
     "Already queued for this pass" is a weak reference to a token only the queued callback holds: when a backward pass raises,
     the engine drops its final callbacks, the token dies with them, and the next pass queues afresh (a sticky flag here would
     silently skip the flush and the data-parallel average for every later pass)."""
+    if getattr(model, "explicit_backward", False):
+        # the pretraining model runs ONE explicit backward per step (model_pretrain.backward): its own deferral / flush / exchange logic
+        # owns the gradients; the causal blocks' small autograd islands inside it must not queue an average of their own
+        return
     pending = _pass_pending(model)
     if NAV_DEFER_DW:
         # the weight-gradient GEMMs of every Function.backward of this autograd pass are queued (operands kept alive) and leave in a

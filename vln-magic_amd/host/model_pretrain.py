@@ -28,6 +28,9 @@ KD_SLOTS = ("txt_emb_loss", "txt_attn_loss", "img_emb_loss", "avg_img_emb_loss",
             "global_emb_loss", "global_attn_loss", "local_emb_loss", "local_attn_loss", "predict_loss")
 
 
+PRETRAIN_CAUSAL = ("back_txt", "back_img")       # the pretraining collates carry no front-door dictionaries
+
+
 def pretrain_specs(cfg):
     H = cfg.hidden_size
     s = trunk_specs(cfg, "bert.")
@@ -42,7 +45,10 @@ def pretrain_specs(cfg):
         s += [("image_classifier.net.0.weight", (H, H), "normal"), ("image_classifier.net.0.bias", (H,), "zeros"),
               ("image_classifier.net.2.weight", (H,), "ones"), ("image_classifier.net.2.bias", (H,), "zeros"),
               ("image_classifier.net.3.weight", (P, H), "normal"), ("image_classifier.net.3.bias", (P,), "zeros")]
-    return s
+    # back-door adjustment blocks (do_back_txt / do_back_img: r2r_magic_model_config.json:60-66, off in the shipped config; their inputs
+    # instr_z_* / img_z_* come from the collates, pretrain_src/data/tasks.py:156-164, :441-449) -- the navigation model's blocks
+    from .causal import causal_specs
+    return s + causal_specs(cfg, "bert.", only=PRETRAIN_CAUSAL)
 
 
 def _dropout_knobs(model, config):
@@ -83,6 +89,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                                 init_std=cfg_get(config, "initializer_range"), seed=seed, requires_grad=trainable)
         self.store.attach_to(self)
         self.net = MagicNet(config, self.store, "bert.")
+        self.prefix, self.explicit_backward = "bert.", True
+        from .causal import build_blocks
+        self.causal_blocks = build_blocks(self, only=PRETRAIN_CAUSAL)        # {} unless config.do_back_txt / do_back_img
         _dropout_knobs(self, config)
         self._anchor = torch.zeros(1, device=self.device_, requires_grad=True)
         self._ctx = None
@@ -190,6 +199,56 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         O.linear_dx(dZ, l1.W, M, out=d_acc, residual=d_acc, ldc=lda)
 
     # ---- forward ----------------------------------------------------------------------------------------
+    def _causal_fwd(self, c, batch, compute_loss):
+        """back-door adjustment of the text encoder's output (instruction z-dictionary) and of the panorama encoder's view embeddings (room-type
+        image dictionary), where VLNBert('language' / 'panorama') applies them (host/model_nav.py): the blocks of host/causal.py
+        are autograd modules, so each runs as a small autograd ISLAND inside the explicit step -- forward on a detached leaf here, its
+        backward (`_causal_bwd`) turns the gradient of the adjusted tensor into the gradient of the encoder output and writes the block's
+        parameter gradients into the store.  The fused panorama embedding stays the un-adjusted one, as in VLNBert('panorama')."""
+        cz, plan, H = self.causal_blocks, c.plan, self.net.H
+        need = {"instr_z_direction_features": "back_txt", "instr_z_landmark_features": "back_txt", "img_z_features": "back_img"}
+        for k, blk in need.items():
+            if batch.get(k) is not None and blk not in cz:
+                from .causal import BLOCKS
+                raise ValueError(f"batch carries {k!r} but config.{BLOCKS[blk]} is off -- the model has no '{blk}' block "
+                                 "(pretrain_src/config/r2r_magic_model_config.json:60-66)")
+        track = bool(compute_loss and self.store.requires_grad and torch.is_grad_enabled())
+        c.islands = []
+
+        def island(block, x2d, shape, z, pz):
+            x0 = x2d.detach().view(shape)
+            with torch.enable_grad() if track else torch.no_grad():
+                if track:
+                    x0.requires_grad_(True)
+                y = block(x0, z, pz)
+            if track:
+                c.islands.append((x0, y))
+            return y.detach().reshape(x2d.shape).contiguous()
+        dv = lambda t: t.to(self.device_)
+        if "back_txt" in cz and (batch.get("instr_z_direction_features") is not None or batch.get("instr_z_landmark_features") is not None):
+            parts = [k for k in ("direction", "landmark") if batch.get(f"instr_z_{k}_features") is not None]      # direction rows first
+            z = torch.cat([dv(batch[f"instr_z_{k}_features"]) for k in parts], 1)
+            pz = torch.cat([dv(batch[f"instr_z_{k}_pzs"]) for k in parts], 1)
+            c.txt_out = island(cz["back_txt"], c.txt.out, (plan["B"], plan["L"], H), z, pz)
+            c.island_txt = len(c.islands) - 1 if track else None
+        if "back_img" in cz and batch.get("img_z_features") is not None:
+            out = island(cz["back_img"], c.pano.out, (plan["Np"], plan["V"], H), dv(batch["img_z_features"]), dv(batch["img_z_pzs"]))
+            c.pano_adj = Ctx(**vars(c.pano))
+            c.pano_adj.out = out
+            c.island_pano = len(c.islands) - 1 if track else None
+
+    def _causal_bwd(self, c):
+        """gradient of the adjusted tensors -> gradient of the encoder outputs, through the islands of `_causal_fwd`"""
+        for name, attr in (("island_txt", "d_txt"), ("island_pano", "d_pano")):
+            i = getattr(c, name, None)
+            if i is None:
+                continue
+            x0, y = c.islands[i]
+            d = getattr(c, attr)
+            torch.autograd.backward(y, d.view(y.shape).to(y.dtype))
+            setattr(c, attr, x0.grad.reshape(d.shape).to(d.dtype).contiguous())
+            x0.grad = None
+
     def will_fuse_encoders(self, plan):
         """does a forward on `plan` run the text + panorama encoders as ONE whole-encoder launch (csrc/encoder.hip)?  The one predicate
         behind the model's own choice and the teacher stream's start gate (trainer.capture_split, stream_graph)."""
@@ -215,13 +274,16 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         c.txt, c.pano = self._par(lambda: n.text_fwd(plan, defer=fuse), lambda: n.pano_fwd(plan, inp.feats, inp.loc, defer=fuse))
         if fuse:
             n.encoders_fwd(c.txt, c.pano)
+        c.txt_out, c.pano_adj = c.txt.out, c.pano
+        if self.causal_blocks or any(batch.get(k) is not None for k in ("instr_z_direction_features", "instr_z_landmark_features", "img_z_features")):
+            self._causal_fwd(c, batch, compute_loss)
         # map-token and viewpoint-token inputs of the cross-modal encoders: one launch for both (gathers + position / step embeddings)
-        c.gin, c.vin = n.nodes_in_fwd(plan, c.pano, inp.gpos if task != "mrc" else None, inp.vpos if task != "mlm" else None)
+        c.gin, c.vin = n.nodes_in_fwd(plan, c.pano_adj, inp.gpos if task != "mrc" else None, inp.vpos if task != "mlm" else None)
         tl, gl_, vl = plan["lens"]["txt"], plan["lens"]["gmap"], [Vp] * B
-        o = dict(txt_embeds=c.txt.out, txt_attns=c.txt.P, pano_embeds=c.pano.out, pano_fused_embeds=c.pano.fused,
+        o = dict(txt_embeds=c.txt_out, txt_attns=c.txt.P, pano_embeds=c.pano_adj.out, pano_fused_embeds=c.pano.fused,
                  img_attns=c.pano.img_attn, plan=plan, inputs=inp)
         if task == "mlm":
-            l2v_args = ("global", plan, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"])
+            l2v_args = ("global", plan, c.txt_out, L, plan["txt_mask"], tl, plan["txt_tokens"], c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"])
             c.l2v = n.cross_fwd_fused([l2v_args])[0] if n.xenc_ok(L, K) else n.cross_fwd(*l2v_args, dist=None)
             o["gmap_embeds"], o["gmap_attns"] = c.l2v.out, c.l2v.P
             nm = plan["n_mask"]
@@ -243,7 +305,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             o["predict"] = c.logits[:, :Vv]
         elif task == "mrc":
             # local branch only; RegionClassification on the masked views of the current viewpoint (validate_mrc :476-500)
-            loc_args = ("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
+            loc_args = ("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp, c.txt_out, L, plan["txt_mask"], tl, plan["txt_tokens"])
             c.loc = n.cross_fwd_fused([loc_args])[0] if n.xenc_ok(Vp, L) else n.cross_fwd(*loc_args)
             o.update(vp_embeds=c.loc.out, vp_attns=c.loc.P)
             nm = plan["n_mrc"]
@@ -260,16 +322,16 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             def _local():
                 vin = c.vin
                 return vin, n.cross_fwd("local", plan, vin.out, Vp, plan["vp_mask"], vl, B * Vp,
-                                        c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])
+                                        c.txt_out, L, plan["txt_mask"], tl, plan["txt_tokens"])
             # global (map) and local (viewpoint) co-attention encoders are independent too: one launch for both when the shapes allow
             if n.xenc_ok(K, L) and n.xenc_ok(Vp, L):
                 c.glob, c.loc = n.cross_fwd_fused([
-                    ("global", plan, c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"], c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], inp.dist),
-                    ("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp, c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"])])
+                    ("global", plan, c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"], c.txt_out, L, plan["txt_mask"], tl, plan["txt_tokens"], inp.dist),
+                    ("local", plan, c.vin.out, Vp, plan["vp_mask"], vl, B * Vp, c.txt_out, L, plan["txt_mask"], tl, plan["txt_tokens"])])
             else:
               c.glob, (c.vin, c.loc) = self._par(
                 lambda: n.cross_fwd("global", plan, c.gin.out, K, plan["gmap_mask"], gl_, plan["gmap_nodes"],
-                                    c.txt.out, L, plan["txt_mask"], tl, plan["txt_tokens"], dist=inp.dist), _local)
+                                    c.txt_out, L, plan["txt_mask"], tl, plan["txt_tokens"], dist=inp.dist), _local)
             o.update(gmap_embeds=c.glob.out, gmap_attns=c.glob.P, vp_embeds=c.loc.out, vp_attns=c.loc.P)
             if task == "sap":
                 from . import lib as _lib
@@ -303,7 +365,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 # the four [CLS]-row selections (fused = map row + viewpoint row) in one launch, the four heads as one grouped launch
                 O.csr_gather_multi(H, [dict(out=c.g0, n_out=B, src1=c.glob.out, csr1=plan["g0"]),
                                        dict(out=c.v0, n_out=B, src1=c.loc.out, csr1=plan["v0"]),
-                                       dict(out=c.t0, n_out=B, src1=c.txt.out, csr1=plan["t0"]),
+                                       dict(out=c.t0, n_out=B, src1=c.txt_out, csr1=plan["t0"]),
                                        dict(out=c.gv0, n_out=B, src1=c.glob.out, csr1=plan["g0"], src2=c.loc.out, csr2=plan["v0"])])
                 from . import lib as _lib
                 with _lib.group():
@@ -738,6 +800,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         c = self._ctx
         n, plan = self.net, c.plan
         fired = []
+        if getattr(c, "islands", None):
+            self._causal_bwd(c)
 
         def on_iter(k):
             if on_cut is not None and k == MID_CUT and not fired:

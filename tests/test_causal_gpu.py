@@ -138,7 +138,8 @@ def test_pretraining_model_serves_the_back_door_inputs_of_its_collates(task, met
     such a key with its switch off raises."""
     from magic_amd.host import synth
     from tests.test_model_gpu import RW, build, close, to64, view_outputs
-    extra = dict(do_back_txt=True, do_back_img=True, do_back_txt_type="type_2", do_back_imgobj_type=itype, do_add_method=method)
+    # (one batch feeds teacher and student: the instruction dictionary has ONE width, here the student's -- `back_txt_dict_size`)
+    extra = dict(do_back_txt=True, do_back_img=True, do_back_txt_type="type_2", do_back_imgobj_type=itype, do_add_method=method, back_txt_dict_size=128)
     o_t, o_s, g_t, g_s = build(torch.float32, **extra)
     assert set(g_s.causal_blocks) == {"back_txt", "back_img"} and any(k.startswith("bert.causal.back_img.") for k in g_s.state_dict())
     g = torch.Generator().manual_seed(11)

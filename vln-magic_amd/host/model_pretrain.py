@@ -246,7 +246,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             x0, y = c.islands[i]
             d = getattr(c, attr)
             torch.autograd.backward(y, d.view(y.shape).to(y.dtype))
-            setattr(c, attr, x0.grad.reshape(d.shape).to(d.dtype).contiguous())
+            # a COPY: without dropout the island's add&norm hands the same tensor to both of its inputs, the deferred weight-gradient
+            # GEMM of the block's output projection keeps reading it until the flush, and the encoder backward below accumulates in place
+            setattr(c, attr, x0.grad.reshape(d.shape).to(d.dtype).clone())
             x0.grad = None
 
     def will_fuse_encoders(self, plan):

@@ -47,10 +47,19 @@ int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,
  * such tiles and a long K loop, 2 = 128x128 whenever M, N >= 128.  Process-wide tuning knob (also MAGIC_GEMM_BIG). */
 int magic_gemm_set_big(int mode);
 
-/* Grouped weight-gradient GEMM: n <= 96 independent problems dW[N,K] (fp32, ldc) += dY[M,N]^T (lda) @ X[M,K] (ldb), db[N] += colsum(dY)
- * in ONE launch (split-K, fp32 atomics).  `d` is a HOST array of n descriptors holding device pointers. */
+/* Grouped weight-gradient GEMM: n <= 96 problems dW[N,K] (fp32, ldc) += dY[M,N]^T (lda) @ X[M,K] (ldb), db[N] += colsum(dY) in ONE
+ * launch, split-K.  `d` is a HOST array of n descriptors holding device pointers.  Replaces the per-parameter `.grad` accumulation of
+ * autograd's Linear backward (torch: `grad_weight = grad_output.t().mm(input)`, one GEMM per layer call).
+ * ws == NULL: the K-splits add into dW with fp32 atomics (the sum then depends on arrival order).
+ * ws != NULL: DETERMINISTIC -- every split stores its 64 x 64 partial into its own slot of `ws`, the workgroup that arrives last at a
+ * tile adds the slots in slot order and does the one read-modify-write of dW; problems with the SAME dW pointer (one Linear called several
+ * times in a step) share that dW's slots, so they too are summed in a fixed order and must agree in N, K, ldc, db.  `ws`: ws_floats >=
+ * magic_gemm_dw_ws_need(...) fp32 words, contents undefined; `counters`: n_counters 32-bit words that are ZERO on entry and zero again
+ * when the launch has finished (zero them once, at allocation); both owned by the caller until the launch completes, not shared with a
+ * launch running concurrently on another stream. */
 typedef struct magic_dw_desc { const void* dY; const void* X; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk; } magic_dw_desc;
-int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, void* stream);
+int magic_gemm_dw_ws_need(int dtype, int n, const magic_dw_desc* d, long long* floats, int* counters);
+int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, float* ws, long long ws_floats, unsigned* counters, int n_counters, void* stream);
 
 /* out = LayerNorm(x[M,K] W[H,K]^T + bias + residual): BertSelfOutput / BertOutput (dense -> add -> LayerNorm) in one launch;
  * H in {128, 256, 384} (a workgroup owns 32 full rows), otherwise MAGIC_ERR_UNSUPPORTED -> magic_gemm + magic_ln_fwd. */

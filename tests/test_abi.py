@@ -82,7 +82,7 @@ def test_fastcall_extension_binds_the_same_library_and_checks_arity():
     assert os.path.exists(L.FAST_PATH), "csrc/Makefile builds _magic_fastcall.so next to libmagic_hip.so"
     fast = {n for n, f in L._FN.items() if type(f).__name__ == "builtin_function_or_method"}
     slow = set(L.SIGNATURES) - fast
-    assert slow == {"magic_device_info", "magic_build_id", "magic_gemm_dw_grouped", "magic_mse_multi"}, slow
+    assert slow == {"magic_device_info", "magic_build_id", "magic_gemm_dw_grouped", "magic_gemm_dw_ws_need", "magic_mse_multi"}, slow
     assert L._FN["magic_abi_version"]() == L.load().magic_abi_version() == 1
     for args in ((1, 64, 80, 80), (0, 64, 600, 80), (1, 48, 80, 80), (1, 64, 5000, 80)):       # pure host function: both bindings agree
         assert L._FN["magic_attn_supported"](*args) == L.load().magic_attn_supported(*args)

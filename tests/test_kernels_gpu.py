@@ -622,6 +622,66 @@ def test_deferred_weight_gradients_many_problems_per_launch(dtype):
             check(db, rb, f"db[{i}]", **t)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_weight_gradient_launch_is_bitwise_reproducible_and_sums_repeated_layers_in_a_fixed_order(dtype):
+    """The deterministic seam of magic_gemm_dw_grouped (csrc/gemm.hip dw_seam): K-splits store partials, the last workgroup at a tile adds them in
+    slot order.  (i) the same queue flushed five times from the same starting buffers gives BITWISE-identical dW and db (the atomic form does
+    not); (ii) one dW queued several times in a launch (a Linear called at every navigator step, the weight-tied MLM decoder) is summed exactly
+    once per problem; (iii) both forms agree with the fp32 reference; (iv) the arrival counters are back at zero after every launch."""
+    g = torch.Generator().manual_seed(9)
+    shapes = [(3840, 128, 512), (3840, 512, 128), (10440, 384, 128), (960, 128, 128), (48, 128, 256), (1776, 24, 40), (3840, 128, 128)]
+    ops_, bufs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dW, db = rnd(N, K, seed=300 + i).contiguous(), (rnd(N, seed=400 + i) if i % 2 == 0 else None)
+        reps = 4 if i in (3, 6) else 1                    # the same Linear used four times: four problems, one dW
+        terms = []
+        for r in range(reps):
+            dy, x = rnd(M, N, dtype=dtype, scale=0.3, seed=1000 + 10 * i + r), rnd(M, K, dtype=dtype, seed=2000 + 10 * i + r)
+            terms.append((dy, x))
+        ops_.append((terms, dW, db, M))
+        bufs.append((dW.clone(), None if db is None else db.clone()))
+
+    def run(det):
+        outs = []
+        for (terms, dW, db, M), (w0, b0) in zip(ops_, bufs):
+            dW.copy_(w0)
+            if db is not None:
+                db.copy_(b0)
+        O.DEFER["queue"].clear()
+        O.defer_dw(True)
+        for terms, dW, db, M in ops_:
+            for dy, x in terms:
+                O.linear_dw(dy, x, dW, db, M)
+        prev = O.DW_DETERMINISTIC
+        O.DW_DETERMINISTIC = det
+        try:
+            O.flush_dw()
+        finally:
+            O.DW_DETERMINISTIC = prev
+        torch.cuda.synchronize()
+        for terms, dW, db, M in ops_:
+            outs.append((dW.clone(), None if db is None else db.clone()))
+        return outs
+    first = run(True)
+    cnt = O.dw_counters(DEV)
+    assert cnt is not None and int(cnt.abs().max()) == 0
+    for _ in range(4):
+        again = run(True)
+        for (a, ab), (b, bb) in zip(first, again):
+            assert torch.equal(a, b) and (ab is None or torch.equal(ab, bb))
+        assert int(cnt.abs().max()) == 0
+    atom = run(False)
+    for i, ((terms, dW, db, M), (w0, b0)) in enumerate(zip(ops_, bufs)):
+        rW = w0 + sum(dy.float().t() @ x.float() for dy, x in terms)
+        t = dict(rtol=1e-4, atol=3e-3) if dtype == torch.float32 else dict(rtol=2e-2, atol=5e-2 * math.sqrt(M * len(terms) / 64) + 1e-2)
+        check(first[i][0], rW, f"deterministic dW[{i}]", **t)
+        check(atom[i][0], rW, f"atomic dW[{i}]", **t)
+        if db is not None:
+            rb = b0 + sum(dy.float().sum(0) for dy, x in terms)
+            check(first[i][1], rb, f"deterministic db[{i}]", **t)
+            check(atom[i][1], rb, f"atomic db[{i}]", **t)
+
+
 @pytest.mark.parametrize("layout,M,N,K", [(0, 200, 384, 128), (1, 77, 128, 512), (2, 96, 132, 300), (0, 64, 64, 1000)])
 def test_fp32_gemm_split_bf16_contraction(layout, M, N, K):
     """magic_set_f32_mfma(1): fp32 operands, a.b = a_hi b_hi + a_hi b_lo + a_lo b_hi on the bf16 matrix cores.  Against fp64: relative

@@ -24,6 +24,8 @@ struct GemmParams {
   float alpha;
   int batch;      // host-side only (grid z = batch * splitk)
   int big;        // host-side only: 128x128 block tile (single launches; grouped / paired launches use 64x64)
+  // deterministic split-K seam of the weight-gradient launch (gemm_dw_batch_kernel; NULL: fp32 atomics): see dw_seam()
+  float* ws; unsigned* cnt; int ws_slot0, cnt0, ws_total, ws_first;
 };
 
 template <typename T> struct TT;
@@ -212,6 +214,68 @@ __device__ __forceinline__ void mma_tile_x3(const float* sA, const float* sB, in
     for (int j = 0; j < NT_; ++j) acc[i][j] = mma_x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
 }
 
+// ---- deterministic split-K seam of the weight gradients --------------------------------------------------------------------------
+// dW tile = sum over the K-splits of every problem that targets this dW (one Linear used T times in a step queues T problems).  With fp32
+// atomics the sum depends on arrival order; here every split STORES its 64 x 64 partial (+ the 64 bias-gradient partials of a bx = 0 tile)
+// into its own slot of a workspace, write-through (`sc1`), every storing wave drains, the workgroup's barrier, ONE agent-scope add on the
+// tile's arrival counter; the workgroup that draws the last ticket reads the slots IN SLOT ORDER (sc1 loads), adds them in that fixed order
+// and does the one read-modify-write of dW (no other workgroup of the launch touches that tile).  The counter is put back to 0 by that
+// workgroup, so the counters need zeroing only once, when they are allocated.  (cdna_hip_programming.md section 6 G16, form R1 with
+// every consumer load sc1.)  Slot layout: element e of thread t at [e * 256 + t], bias partial of row r at [4096 + r].
+#define DW_SLOT (64 * 64 + 64)
+template <int TM, int NE>
+__device__ __forceinline__ void dw_seam(const GemmParams& p, const f32x4 (&acc)[2][2], float bsum, bool do_bgrad, int bx, int by, int sk,
+                                        int tid, int m0, int n0, int wr, int wc, int cr, int cc, int* flag) {
+  static_assert(TM == 64 && NE == 16, "the seam is written for the 64 x 64 tile");
+  const int nxt = (p.N + TM - 1) / TM;
+  const int tile = by * nxt + bx;
+  float* const base = p.ws + ((long long)p.ws_slot0 + (long long)tile * p.ws_total) * DW_SLOT;
+  float* const mine = base + (long long)(p.ws_first + sk) * DW_SLOT;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) __hip_atomic_store(mine + e * 256 + tid, acc[e >> 3][(e >> 2) & 1][e & 3] * p.alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (bx == 0 && tid < TM) __hip_atomic_store(mine + 4096 + tid, do_bgrad ? bsum : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores ...
+  __syncthreads();                                            // ... before one lane signals for the workgroup
+  if (tid == 0) {
+    unsigned* c = p.cnt + p.cnt0 + tile;
+    const unsigned t = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == (unsigned)p.ws_total - 1u);
+    if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (compiler only: keeps the loads below the ticket)
+  float s[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) s[e] = 0.f;
+  for (int q = 0; q < p.ws_total; ++q) {                      // FIXED order: slot 0, 1, 2, ...
+    const float* sl = base + (long long)q * DW_SLOT;
+    float v[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] = __hip_atomic_load(sl + e * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) s[e] += v[e];
+  }
+  float* C = (float*)p.C;
+  float old[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int col = n0 + (wc * 2 + ((e >> 2) & 1)) * 16 + cc, row = m0 + (wr * 2 + (e >> 3)) * 16 + cr + (e & 3);
+    old[e] = (col < p.N && row < p.M) ? C[(long long)row * p.ldc + col] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int col = n0 + (wc * 2 + ((e >> 2) & 1)) * 16 + cc, row = m0 + (wr * 2 + (e >> 3)) * 16 + cr + (e & 3);
+    if (col < p.N && row < p.M) C[(long long)row * p.ldc + col] = old[e] + s[e];
+  }
+  if (bx == 0 && p.bias_grad && tid < TM && m0 + tid < p.M) {
+    float b = 0.f;
+    for (int q = 0; q < p.ws_total; ++q) b += __hip_atomic_load(base + (long long)q * DW_SLOT + 4096 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.bias_grad[m0 + tid] += b;
+  }
+}
+
 // LAYOUT 0: NT (A[M,K], B[N,K]); 1: NN (A[M,K], B[K,N]); 2: TN (A[K,M], B[K,N])
 // NT_: 16x16 MFMA tiles per wave per dimension.  2 -> the 64x64 block tile every small problem uses; 4 -> a 128x128 block tile
 // (64x64 per wave, 16 accumulator tiles) for problems with enough rows and columns: each workgroup then streams half the
@@ -344,6 +408,9 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
         __syncthreads();
       }
     }
+  }
+  if constexpr (LAYOUT == 2 && NT_ == 2 && KG == 1) {
+    if (p.ws) { dw_seam<TM, NE>(p, acc, bsum, do_bgrad, bx, by, sk, tid, m0, n0, wr, wc, cr, cc, (int*)sA); return; }
   }
   if (do_bgrad && tid < TM && m0 + tid < p.M) atomicAdd(p.bias_grad + m0 + tid, bsum);
   if constexpr (KG > 1) {
@@ -723,8 +790,9 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupedParams gp) {
 // the kernel-argument block.  Every dependent launch of the replayed step costs ~9 us whatever its work (8 -> 16 problems per launch:
 // 2.93 -> 2.88 ms per step; 48 compact: 2.79; 96: 2.77), so the step's ~80 weight gradients go out in ONE launch (6.9 KB of kernel arguments).
 #define DW_MAX 96
-struct DwProblem { const void* A; const void* B; float* C; float* bias_grad; int M, N, K, lda, ldb, ldc, splitk, ny8; };
-struct DwBatch { DwProblem p[DW_MAX]; int start[DW_MAX + 1]; int cnt[DW_MAX]; int n; };
+struct DwProblem { const void* A; const void* B; float* C; float* bias_grad; int M, N, K, lda, ldb, ldc, splitk, ny8;
+                   int ws_slot0, cnt0, ws_total, ws_first; };       // deterministic seam (dw_seam): slots / counters of this dW's tile 0
+struct DwBatch { DwProblem p[DW_MAX]; int start[DW_MAX + 1]; int cnt[DW_MAX]; int n; float* ws; unsigned* counters; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_dw_batch_kernel(DwBatch gp) {
@@ -740,6 +808,7 @@ __global__ __launch_bounds__(256) void gemm_dw_batch_kernel(DwBatch gp) {
   p.A = d.A; p.B = d.B; p.C = d.C; p.bias_grad = d.bias_grad;
   p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
   p.nh = 1; p.batch = 1; p.splitk = d.splitk; p.c_f32 = 1; p.accumulate = 1; p.alpha = 1.f;
+  p.ws = gp.ws; p.cnt = gp.counters; p.ws_slot0 = d.ws_slot0; p.cnt0 = d.cnt0; p.ws_total = d.ws_total; p.ws_first = d.ws_first;
   const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM;
   if (d.ny8 < 0) {                   // one K-split per XCD slot group (see gemm_grouped_kernel)
     const int tiles = nx * ny;
@@ -807,7 +876,7 @@ extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N
   if (splitk > 1 && (epilogue != 0 || residual || C2)) return MAGIC_ERR_ARG;
   if (bias_grad && layout != 2) return MAGIC_ERR_ARG;
   if (batch % nh) return MAGIC_ERR_ARG;
-  GemmParams p;
+  GemmParams p = {};
   p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias; p.aux = aux; p.residual = residual; p.bias_grad = bias_grad;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldaux = ldaux; p.ldr = ldr;
   p.sAb = sAb; p.sAh = sAh; p.sBb = sBb; p.sBh = sBh; p.sCb = sCb; p.sCh = sCh;
@@ -1433,13 +1502,50 @@ int launch_llb(int dtype, int ht, const void* pa, const void* pb, hipStream_t st
 // host-visible descriptor of one weight-gradient problem: dW[N,K] (fp32, ldc) += dY[M,N]^T (lda) @ X[M,K] (ldb); db[N] += colsum(dY)
 struct magic_dw_desc { const void* dY; const void* X; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk; };
 
-extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, void* stream) {
+// non-empty K-splits of a problem (gemm_block returns early for a split without k-tiles: such a split never arrives at the seam)
+static int dw_eff_splits(int dtype, int Kred, int splitk) {
+  const int bk = dtype_is16(dtype) ? TT<bf16>::BK : TT<float>::BK;
+  const int ktiles = (Kred + bk - 1) / bk, per = (ktiles + splitk - 1) / splitk;
+  return (ktiles + per - 1) / per;
+}
+// Workspace the deterministic form needs for these problems: `floats` fp32 words of partial slots and `counters` 32-bit arrival counters
+// (zero them ONCE; every launch leaves them zero).  Problems with the same dW pointer form one group: their splits share that dW's slots.
+extern "C" int magic_gemm_dw_ws_need(int dtype, int n, const magic_dw_desc* d, long long* floats, int* counters) {
+  if (n <= 0 || n > DW_MAX || !d || !floats || !counters || !dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  long long slots = 0;
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    int leader = i;
+    for (int j = 0; j < i; ++j) if (d[j].dW == d[i].dW) { leader = j; break; }
+    if (leader != i) continue;
+    int total = 0;
+    for (int j = i; j < n; ++j) if (d[j].dW == d[i].dW) total += dw_eff_splits(dtype, d[j].M, d[j].splitk);
+    const int tiles = ((d[i].K + BN - 1) / BN) * ((d[i].N + BM - 1) / BM);
+    slots += (long long)tiles * total;
+    cnt += tiles;
+  }
+  *floats = slots * DW_SLOT;
+  *counters = cnt;
+  return MAGIC_OK;
+}
+
+extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, float* ws, long long ws_floats, unsigned* counters, int n_counters,
+                                     void* stream) {
   if (n <= 0 || n > DW_MAX || !d) return MAGIC_ERR_ARG;
   if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  if ((ws == nullptr) != (counters == nullptr)) return MAGIC_ERR_ARG;
   const int ve = dtype_is16(dtype) ? 8 : 4;
   DwBatch gp;
   gp.n = n;
+  gp.ws = ws; gp.counters = counters;
+  if (ws) {
+    long long need_f = 0; int need_c = 0;
+    if (magic_gemm_dw_ws_need(dtype, n, d, &need_f, &need_c) != MAGIC_OK || need_f > ws_floats || need_c > n_counters) return MAGIC_ERR_ARG;
+    if (need_f / DW_SLOT > 0x7fffffffLL) return MAGIC_ERR_ARG;
+  }
   int total = 0;
+  long long slot_next = 0;
+  int cnt_next = 0;
   for (int i = 0; i < n; ++i) {
     if (d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0 || d[i].splitk <= 0 || !d[i].dY || !d[i].X || !d[i].dW) return MAGIC_ERR_ARG;
     if (d[i].lda % ve || d[i].ldb % ve || ((uintptr_t)d[i].dY & 15) || ((uintptr_t)d[i].X & 15)) return MAGIC_ERR_ARG;
@@ -1447,6 +1553,29 @@ extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, v
     DwProblem& p = gp.p[i];
     p.A = d[i].dY; p.B = d[i].X; p.C = d[i].dW; p.bias_grad = d[i].db;
     p.M = d[i].N; p.N = d[i].K; p.K = d[i].M; p.lda = d[i].lda; p.ldb = d[i].ldb; p.ldc = d[i].ldc; p.splitk = d[i].splitk;
+    p.ws_slot0 = p.cnt0 = p.ws_total = p.ws_first = 0;
+    if (ws) {
+      // group = every problem with this dW: the leader (first of them) owns the slots, a member's splits follow its predecessors'
+      int leader = i;
+      for (int j = 0; j < i; ++j) if (d[j].dW == d[i].dW) { leader = j; break; }
+      if (leader == i) {
+        int tot = 0;
+        for (int j = i; j < n; ++j) if (d[j].dW == d[i].dW) {
+          if (d[j].N != d[i].N || d[j].K != d[i].K || d[j].ldc != d[i].ldc || d[j].db != d[i].db) return MAGIC_ERR_ARG;
+          tot += dw_eff_splits(dtype, d[j].M, d[j].splitk);
+        }
+        const int tiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+        p.ws_slot0 = (int)slot_next; p.cnt0 = cnt_next; p.ws_total = tot; p.ws_first = 0;
+        slot_next += (long long)tiles * tot;
+        cnt_next += tiles;
+      } else {
+        const DwProblem& l = gp.p[leader];
+        p.ws_slot0 = l.ws_slot0; p.cnt0 = l.cnt0; p.ws_total = l.ws_total;
+        int first = 0;
+        for (int j = leader; j < i; ++j) if (d[j].dW == d[i].dW) first += dw_eff_splits(dtype, d[j].M, d[j].splitk);
+        p.ws_first = first;
+      }
+    }
     const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM, nz = p.splitk;          // same placement rules as group_place()
     gp.start[i] = total;
     if (gemm_xcd_on() && p.splitk >= 8 && nx * ny >= 2) { p.ny8 = -1; gp.cnt[i] = nx * ny * ((nz + 7) / 8 * 8); }

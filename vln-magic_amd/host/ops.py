@@ -5,6 +5,7 @@ torch/CPU fallback.  Shapes are checked on the host before launch (a faulting ke
 whole GPU node down).  `FLOPS` accumulates the algorithmic dense-contraction FLOPs (2*m*n*k with the
 TRUE, unpadded sizes the caller passes via `flop_dims`) for the roofline report.
 """
+import ctypes as C
 import os
 
 import torch
@@ -80,7 +81,7 @@ def linear_dx(dy, W, M, *, out=None, epilogue=0, aux=None, residual=None, lda=No
 
 # measured on the headline step (profiles/micro/splitk_sweep.sh): (target, min_tiles) = (256, 2) 3.34 ms, (128, 8) 3.26 ms, (128, 32) 3.45 ms --
 # fewer, longer splits also write 4x fewer fp32 atomic tiles
-SPLITK = {"target": int(os.environ.get("MAGIC_SPLITK_TARGET", "192")), "min_tiles": int(os.environ.get("MAGIC_SPLITK_MIN_TILES", "12"))}
+SPLITK = {"target": int(os.environ.get("MAGIC_SPLITK_TARGET", "192")), "min_tiles": int(os.environ.get("MAGIC_SPLITK_MIN_TILES", "20"))}
 
 
 def _splitk(tiles, kred):
@@ -144,6 +145,30 @@ DW_GROUP = int(os.environ.get("MAGIC_DW_GROUP", "96"))      # problems per group
 DW_KEEP_BYTES = int(os.environ.get("MAGIC_DW_KEEP_GB", "8")) << 30
 
 
+# Deterministic weight gradients (csrc/gemm.hip dw_seam): the K-splits of a dW tile -- and the several problems one Linear queues when it is
+# called more than once in a step -- are summed in a FIXED order through a workspace instead of fp32 atomics, so two runs of the same step
+# give bitwise-identical weight gradients.  MAGIC_DW_ATOMICS=1 restores the atomic form.  The partial slots are scratch (allocated per
+# launch: the caching allocator / the capturing graph's pool hands the same block back); the arrival counters are persistent per
+# (device, stream) -- zero when allocated, left zero by every launch.
+DW_DETERMINISTIC = not os.environ.get("MAGIC_DW_ATOMICS")
+DW_WS_MAX_BYTES = int(os.environ.get("MAGIC_DW_WS_MAX_MB", "256")) << 20
+DW_COUNTERS = 1 << 17
+_DW_CNT = {}
+
+
+def dw_counters(device=None):
+    """the arrival counters of the deterministic weight-gradient launch for the current stream.  Allocated OUTSIDE graph capture (models
+    call this when they are built): memory taken from a capturing graph's pool would be recycled when that graph dies."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), L.stream())
+    c = _DW_CNT.get(key)
+    if c is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                # first use inside a capture: this launch takes per-call counters (a memset node)
+        c = _DW_CNT[key] = torch.zeros(DW_COUNTERS, dtype=torch.int32, device=dev)
+    return c
+
+
 def flush_dw(group=None, keep_active=False):
     group = group or DW_GROUP
     q = DEFER["queue"]
@@ -158,11 +183,32 @@ def flush_dw(group=None, keep_active=False):
                     BYTES["dw"] += float(M) * (N + K) * dy.element_size() + 4.0 * N * K
             if FLOPS["enabled"]:
                 BYTES["dw_launches"] += 1
-            L.call("magic_gemm_dw_grouped", L.dt(dt), len(chunk), arr, L.stream())
+            dw_grouped(dt, arr, len(chunk), chunk[0][0].device)
     q.clear()
     DEFER["bytes"] = 0
     if not keep_active:
         DEFER["active"] = False
+
+
+def dw_grouped(dt, arr, n, device, deterministic=None):
+    """one grouped weight-gradient launch over the descriptor array `arr` (deterministic unless switched off or its workspace would
+    exceed DW_WS_MAX_BYTES -- MAGIC-L sized launches with one Linear queued 20 times: those fall back to fp32 atomics)"""
+    det = DW_DETERMINISTIC if deterministic is None else deterministic
+    ws = cnt = None
+    nf = nc = 0
+    if det:
+        f, c = C.c_longlong(0), C.c_int(0)
+        rc = L.load().magic_gemm_dw_ws_need(L.dt(dt), n, C.addressof(arr), C.addressof(f), C.addressof(c))      # host-only: no launch
+        if rc != 0:
+            raise L.MagicHipError(f"magic_gemm_dw_ws_need failed: {rc}")
+        nf, nc = int(f.value), int(c.value)
+        if nf * 4 <= DW_WS_MAX_BYTES and nc <= DW_COUNTERS:
+            cnt = dw_counters(device)
+            if cnt is None:
+                cnt = torch.zeros(max(nc, 1), dtype=torch.int32, device=device)
+            ws = torch.empty(max(nf, 1), dtype=torch.float32, device=device)
+    L.call("magic_gemm_dw_grouped", L.dt(dt), n, arr, L.P(ws), nf if ws is not None else 0, L.P(cnt), int(cnt.numel()) if cnt is not None else 0, L.stream())
+    return ws is not None
 
 
 def _linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None, flop_rows=None):

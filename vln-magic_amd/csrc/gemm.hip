@@ -227,6 +227,23 @@ template <int TM, int NE>
 __device__ __forceinline__ void dw_seam(const GemmParams& p, const f32x4 (&acc)[2][2], float bsum, bool do_bgrad, int bx, int by, int sk,
                                         int tid, int m0, int n0, int wr, int wc, int cr, int cc, int* flag) {
   static_assert(TM == 64 && NE == 16, "the seam is written for the 64 x 64 tile");
+  if (p.ws_total == 1) {
+    // ONE contributor to this tile in the whole launch (no K-split, the dW queued once): nothing to order -- plain read-modify-write
+    float* C = (float*)p.C;
+    float old[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int col = n0 + (wc * 2 + ((e >> 2) & 1)) * 16 + cc, row = m0 + (wr * 2 + (e >> 3)) * 16 + cr + (e & 3);
+      old[e] = (col < p.N && row < p.M) ? C[(long long)row * p.ldc + col] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int col = n0 + (wc * 2 + ((e >> 2) & 1)) * 16 + cc, row = m0 + (wr * 2 + (e >> 3)) * 16 + cr + (e & 3);
+      if (col < p.N && row < p.M) C[(long long)row * p.ldc + col] = old[e] + acc[e >> 3][(e >> 2) & 1][e & 3] * p.alpha;
+    }
+    if (do_bgrad && tid < TM && m0 + tid < p.M) p.bias_grad[m0 + tid] += bsum;
+    return;
+  }
   const int nxt = (p.N + TM - 1) / TM;
   const int tile = by * nxt + bx;
   float* const base = p.ws + ((long long)p.ws_slot0 + (long long)tile * p.ws_total) * DW_SLOT;

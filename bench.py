@@ -647,6 +647,7 @@ def main():
         n_steady = 150
         traj_s, dt_s = timed_region(run, n_steady, 0, world, dev)
         steady = {"steps": n_steady, "ms_per_step": round(dt_s / n_steady * 1e3, 3), "trajectory_steps_per_sec": round(traj_s / dt_s, 1)}
+    health = trainer.check_health()          # raises if an in-launch hand-off of the row-split encoder kernels ever gave up
     gate = trainer.gate_report() if (a.mode == "graph" and a.teacher == "split") else None
     if gate is not None:
         gate["timeout_us"], gate["recent_us"] = O.TEACHER_GATE_US, O.TEACHER_GATE_RECENT_US
@@ -791,7 +792,7 @@ def main():
                 "dtype": a.dtype, "data": "synthetic",
                 "ms_per_step_steady": (round((dt - (cap_at[("s", "end")] - cap_at.get(("s", a.warmup), 0.0))) / a.steps * 1e3, 3) if stream_step is not None and a.mode == "stream-graph" and a.teacher != "same"
                                        else (steady["ms_per_step"] if steady is not None else None)),
-                "steady": steady, "teacher_gate": gate, "build_id": L.library_build_id(),
+                "steady": steady, "teacher_gate": gate, "health": health, "build_id": L.library_build_id(),
                 "launch": a.mode if a.mode not in ("stream", "stream-graph") else f"{a.mode}/{a.ingest}/{a.workers}w" + (f"/{stream_step.captures} bucket graphs, {cap_at['end'] - cap_at.get(a.warmup, 0)} of them captured inside the timed steps" if stream_step is not None else ""),
                 "teacher_schedule": ({"split": "one batch ahead of the student, own graph on a side stream", "ahead": "one batch ahead of the student (fork/join inside the step graph)"}.get(a.teacher, "same batch, side stream") if a.mode == "graph" else "same batch, side stream"),
                 "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "

@@ -256,7 +256,11 @@ int magic_loss_assemble(const float* rows, int n_rows, const float* row_w, float
 int magic_sumsq(long long n, const float* g, float* out, void* stream);
 int magic_adamw(long long n, float* p, float* g, float* m, float* v, void* shadow, int shadow_dtype,
                 float lr, float b1, float b2, float eps, float wd, float step_size,
-                const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_grad, void* stream);
+                const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_grad,
+                unsigned* overflow, void* stream);
+/* overflow (may be NULL): a device counter.  When the gradient norm in `sumsq` is not finite (fp16 storage under a static gradient scale)
+ * the update is SKIPPED -- p, m, v untouched, g zeroed when zero_grad -- and the counter incremented: amp.GradScaler.step's behaviour
+ * (train_r2r_magic.py:370-371) instead of NaN weights. */
 /* zero_grad != 0: g is set to 0 after it has been consumed (the next step's accumulators start from zero without a fill launch).
  * magic_sumsq_sched: magic_sumsq that also advances the device-side schedule (magic_sched_step's arithmetic) in the same launch; `out`
  * must already be zero (magic_step_rng's zero_me at the top of the step) */
@@ -325,6 +329,10 @@ int magic_encoder_fwd(int dtype, const void* params, int nbytes, void* stream);
  * [0] calls, [1] opened while waiting, [2] launch already resident at entry, [3] timeouts, [4] consecutive timeouts, [5] switched off,
  * [6] calls skipped while off, [7] reserved.  No reference counterpart (torch issues everything on one stream). */
 int magic_encoder_start_gate(int timeout_us, int recent_us, unsigned* stats, void* stream);
+/* Health of the row-split encoder launches (magic_encoder_fwd / magic_xencoder_fwd with sync != NULL): out[0] = bounded in-launch hand-off
+ * waits that GAVE UP since the process started (sticky; any value but 0 means some activations were computed from rows that never arrived
+ * and the caller must stop), out[1] = whole-encoder launches that became resident.  out: 2 x uint32 of device memory; one tiny launch. */
+int magic_encoder_health(unsigned* out, void* stream);
 
 /* Cross-modal encoders in one launch (csrc/encoder.hip, xencoder_fwd_kernel): the global (map) and local (viewpoint) co-attention
  * encoders, <= 3 METER BertCrossLayer blocks each (the withheld model's `bert.{global,local}_encoder.encoder.crossattention.N`,

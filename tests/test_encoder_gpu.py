@@ -340,6 +340,13 @@ def test_node_inputs_backward_in_shared_launches_matches_the_per_op_sequence():
     assert gb.abs().max() > 0 and torch.allclose(ga, gb, rtol=1e-4, atol=1e-5), (ga - gb).abs().max().item()
 
 
+def test_encoder_health_counts_no_given_up_hand_off_after_the_launches_of_this_file():
+    """the sticky process-wide counter behind trainer.check_health(): every row-split launch so far handed all its rows over"""
+    gave_up, launches = O.encoder_health(DEV)
+    assert gave_up == 0 and launches > 0
+    O.check_encoder_health(DEV)
+
+
 def _streams_overlap(side):
     """do the main stream and `side` run kernels side by side IN THIS PROCESS?  (HIP maps streams onto a few hardware queues; two streams on
     one queue serialise.)  Two 3 ms gate waits without an encoder launch: ~3 ms together when they overlap, ~6 ms when they do not."""

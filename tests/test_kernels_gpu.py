@@ -499,6 +499,35 @@ def test_adamw_clip_and_shadow_match_oracle():
     assert torch.equal(shadow, p.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_adamw_skips_a_step_whose_gradient_norm_is_not_finite(bad):
+    """fp16 storage runs under a STATIC gradient scale: an overflowed activation gradient makes the norm inf / NaN.  The AdamW kernel then
+    skips the update the way amp.GradScaler.step does (train_r2r_magic.py:370-371): weights, moments and shadow untouched, the consumed
+    gradient zeroed, the skip counted -- and the next finite step proceeds from the untouched state."""
+    n = 4099
+    p0, g0 = rnd(n), rnd(n, seed=3)
+    p, m, v = p0.clone(), rnd(n, seed=4).abs() * 0.01, rnd(n, seed=5).abs() * 0.01
+    m0, v0 = m.clone(), v.clone()
+    shadow = p.to(torch.float16)
+    sh0 = shadow.clone()
+    over = torch.zeros(1, dtype=torch.int32, device=DEV)
+    g = g0.clone()
+    g[17] = bad
+    ss = torch.zeros(1, device=DEV)
+    O.sumsq(g, ss)
+    assert not torch.isfinite(ss).item()
+    O.adamw(n, p, g, m, v, shadow, 1e-3, 0.9, 0.98, 1e-6, 0.01, 1e-3, ss, 5.0, 1.0, zero_grad=True, overflow=over)
+    torch.cuda.synchronize()
+    assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0) and torch.equal(shadow, sh0)
+    assert int(over.item()) == 1 and float(g.abs().max()) == 0.0
+    g = g0.clone()
+    ss.zero_()
+    O.sumsq(g, ss)
+    O.adamw(n, p, g, m, v, shadow, 1e-3, 0.9, 0.98, 1e-6, 0.01, 1e-3, ss, 5.0, 1.0, zero_grad=True, overflow=over)
+    torch.cuda.synchronize()
+    assert int(over.item()) == 1 and torch.isfinite(p).all() and not torch.equal(p, p0) and torch.equal(shadow, p.to(torch.float16))
+
+
 def test_cast_roundtrip_and_add():
     x = rnd(1003)
     y = O.cast_to(x, torch.bfloat16)

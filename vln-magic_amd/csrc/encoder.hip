@@ -489,6 +489,14 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(EncParamsT<Hh> p) {
 #define RS_SPIN_MAX (1u << 21)
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((address_space(1))) unsigned gu32_t;
+// A bounded hand-off wait that ran out (a tile of the sample never arrived: the launch was not fully resident -- a grid larger than the chip, a
+// second process holding CUs): the launch's own word (sync[0], zeroed per launch) and a STICKY process-wide count the host reads at a point
+// that may synchronise (magic_encoder_health): the rows that were not handed off make the activations wrong, so a trainer must raise.
+__device__ unsigned magic_enc_gave_up;
+__device__ __forceinline__ void enc_give_up(gu32_t* err) {
+  __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(&magic_enc_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <typename Hh> __device__ __forceinline__ h16x8<Hh> tfrag_clamp(const Hh* s, int pitch, int n0, int k0, int lane, int kmax) {
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
@@ -635,7 +643,7 @@ __device__ __forceinline__ void enc_rs_body(const EncParamsT<Hh>& p, const EncSe
         unsigned spins = 0;
         while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)NRT) {
           __builtin_amdgcn_s_sleep(4);
-          if (++spins > RS_SPIN_MAX) { __hip_atomic_store((gu32_t*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if (++spins > RS_SPIN_MAX) { enc_give_up((gu32_t*)err); break; }
         }
       }
       __syncthreads();
@@ -907,6 +915,20 @@ __global__ void enc_start_gate_kernel(long long timeout_ticks, long long recent_
 extern "C" int magic_encoder_start_gate(int timeout_us, int recent_us, unsigned* stats, void* stream) {
   if (timeout_us < 0 || timeout_us > 100000 || recent_us < 0 || recent_us > 100000 || !stats) return MAGIC_ERR_ARG;
   hipLaunchKernelGGL(enc_start_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)timeout_us * 100, (long long)recent_us * 100, stats);
+  return launch_status();
+}
+
+__global__ void enc_health_kernel(unsigned* out) {
+  if (threadIdx.x == 0) {
+    out[0] = __hip_atomic_load(&magic_enc_gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[1] = __hip_atomic_load(&magic_enc_starts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// out[0] = bounded hand-off waits of the row-split encoder kernels that gave up since the process started (must stay 0), out[1] = whole-encoder
+// launches that became resident.  One tiny launch on `stream`; the caller reads `out` (2 x uint32, device) where it may synchronise.
+extern "C" int magic_encoder_health(unsigned* out, void* stream) {
+  if (!out) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(enc_health_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
   return launch_status();
 }
 
@@ -1555,7 +1577,7 @@ __device__ __forceinline__ void xenc_rs_body(const XParamsT<Hh>& p, const XSegT<
         unsigned spins = 0;
         while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ntile) {
           __builtin_amdgcn_s_sleep(4);
-          if (++spins > RS_SPIN_MAX) { __hip_atomic_store((gu32_t*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if (++spins > RS_SPIN_MAX) { enc_give_up((gu32_t*)err); break; }
         }
       }
       __syncthreads();

@@ -48,9 +48,19 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(long long n, const float* _
 template <typename Hh>
 __global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, float* g, float* m, float* v, Hh* shadow,
                                                     float lr, float b1, float b2, float eps, float wd, float step_size,
-                                                    const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_g) {
+                                                    const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_g,
+                                                    unsigned* overflow) {
   if (lr_ss) { lr = lr_ss[0]; step_size = lr_ss[1]; }     // device-side schedule (HIP-graph replay)
   float clip = gscale;
+  if (sumsq && !isfinite(sumsq[0])) {
+    // an overflowed / NaN gradient (fp16 storage under a static gradient scale: an activation gradient past 65504 becomes inf): SKIP the
+    // update as amp.GradScaler.step does (train_r2r_magic.py:370-371) -- weights and moments untouched, the gradient consumed (zeroed) so
+    // the next step starts clean -- and count it where the host can see it.  Without this, clip = 0 and 0 x inf = NaN poisons p, m, v for good.
+    if (overflow && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(overflow, 1u);
+    if (zero_g)
+      for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) g[i] = 0.f;
+    return;
+  }
   if (sumsq && max_norm > 0.f) {
     const float nrm = sqrtf(sumsq[0]) * gscale;
     clip = gscale * fminf(1.f, max_norm / (nrm + 1e-6f));
@@ -139,15 +149,16 @@ extern "C" int magic_sumsq_sched(long long n, const float* g, float* out, int* s
 
 extern "C" int magic_adamw(long long n, float* p, float* g, float* m, float* v, void* shadow, int shadow_dtype,
                            float lr, float b1, float b2, float eps, float wd, float step_size,
-                           const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_grad, void* stream) {
+                           const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_grad,
+                           unsigned* overflow, void* stream) {
   if (n <= 0 || (shadow && !dtype_is16(shadow_dtype))) return MAGIC_ERR_ARG;
   if (n_decay < 0) n_decay = n;                    // the whole range is one group
   if (shadow && shadow_dtype == DT_F16)
     hipLaunchKernelGGL(adamw_kernel<f16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (f16*)shadow, lr, b1, b2, eps, wd,
-                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad);
+                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad, overflow);
   else
     hipLaunchKernelGGL(adamw_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (bf16*)shadow, lr, b1, b2, eps, wd,
-                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad);
+                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad, overflow);
   return launch_status();
 }
 

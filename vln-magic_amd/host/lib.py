@@ -62,7 +62,7 @@ SIGNATURES = {
     "magic_sap_fuse_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
     "magic_sap_fuse_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "magic_sumsq": [i64, vp, vp, vp],
-    "magic_adamw": [i64, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i64, i32, vp],
+    "magic_adamw": [i64, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i64, i32, vp, vp],
     "magic_sumsq_sched": [i64, vp, vp, vp, f32, i32, i32, f32, f32, vp, vp],
     "magic_sched_step": [vp, f32, i32, i32, f32, f32, vp, vp, vp],
     "magic_add_n": [i32, i64, i32, vp, vp, vp],
@@ -76,6 +76,7 @@ SIGNATURES = {
     "magic_encoder_params_bytes": [],
     "magic_encoder_fwd": [i32, vp, i32, vp],
     "magic_encoder_start_gate": [i32, i32, vp, vp],
+    "magic_encoder_health": [vp, vp],
     "magic_chain_supported": [i32, i32, i32],
     "magic_chain_fwd": [i32, vp, i32, vp],
     "magic_xencoder_supported": [i32, i32, i32, i32, i32, i32, i32],

@@ -453,6 +453,8 @@ class VLNBert(nn.Module):
                 m.__class__ = HipLinear
                 m._net, m._lin = self.net, self.net.lin(f"{self.prefix}{n}.weight")
                 m._owner = (self,)          # tuple: not registered as a sub-module
+        if self.device_.type == "cuda":
+            O.dw_counters(self.device_)
         from .causal import build_blocks
         self.causal_blocks = build_blocks(self)          # plain dict: the blocks' parameters live in the store like every other
         self.register_load_state_dict_post_hook(lambda m, k: setattr(m.store, "shadow_clean", False))

@@ -90,6 +90,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         self.store.attach_to(self)
         self.net = MagicNet(config, self.store, "bert.")
         self.prefix, self.explicit_backward = "bert.", True
+        if self.device_.type == "cuda":
+            O.dw_counters(self.device_)            # the deterministic weight-gradient launch's counters: allocated outside any capture
         from .causal import build_blocks
         self.causal_blocks = build_blocks(self, only=PRETRAIN_CAUSAL)        # {} unless config.do_back_txt / do_back_img
         _dropout_knobs(self, config)

@@ -157,15 +157,17 @@ _DW_CNT = {}
 
 
 def dw_counters(device=None):
-    """the arrival counters of the deterministic weight-gradient launch for the current stream.  Allocated OUTSIDE graph capture (models
-    call this when they are built): memory taken from a capturing graph's pool would be recycled when that graph dies."""
+    """the arrival counters of the deterministic weight-gradient launch: ONE persistent block per device (zero when allocated, left zero by
+    every launch), shared by the eager steps and every captured graph -- weight-gradient launches of one process are stream-ordered (the
+    opt-in side stream MAGIC_DW_SIDE takes per-call counters).  Allocated OUTSIDE graph capture (the models call this when they are built):
+    memory taken from a capturing graph's pool would be recycled when that graph dies.  None: first use inside a capture."""
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), L.stream())
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
     c = _DW_CNT.get(key)
     if c is None:
         if torch.cuda.is_current_stream_capturing():
-            return None                                # first use inside a capture: this launch takes per-call counters (a memset node)
-        c = _DW_CNT[key] = torch.zeros(DW_COUNTERS, dtype=torch.int32, device=dev)
+            return None                                # this launch takes per-call counters (a memset node)
+        c = _DW_CNT[key] = torch.zeros(DW_COUNTERS, dtype=torch.int32, device=torch.device("cuda", key))
     return c
 
 
@@ -203,7 +205,7 @@ def dw_grouped(dt, arr, n, device, deterministic=None):
             raise L.MagicHipError(f"magic_gemm_dw_ws_need failed: {rc}")
         nf, nc = int(f.value), int(c.value)
         if nf * 4 <= DW_WS_MAX_BYTES and nc <= DW_COUNTERS:
-            cnt = dw_counters(device)
+            cnt = dw_counters(device) if SIDE["stream"] is None else None
             if cnt is None:
                 cnt = torch.zeros(max(nc, 1), dtype=torch.int32, device=device)
             ws = torch.empty(max(nf, 1), dtype=torch.float32, device=device)
@@ -473,6 +475,22 @@ def encoder_start_gate(stats, timeout_us=None, recent_us=None):
     r = TEACHER_GATE_RECENT_US if recent_us is None else int(recent_us)
     if t > 0:
         L.call("magic_encoder_start_gate", t, r, L.P(stats), L.stream())
+
+
+def encoder_health(device=None):
+    """(gave_up, launches) of the row-split whole-encoder kernels since the process started; synchronises.  gave_up != 0: a bounded in-launch
+    hand-off wait ran out (the launch was not fully resident) and activations were computed from rows that never arrived -- raise."""
+    out = torch.zeros(2, dtype=torch.int32, device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    L.call("magic_encoder_health", L.P(out), L.stream())
+    v = out.cpu().tolist()
+    return int(v[0]), int(v[1])
+
+
+def check_encoder_health(device=None):
+    gave_up, _ = encoder_health(device)
+    if gave_up:
+        raise L.MagicHipError(f"{gave_up} in-launch hand-off wait(s) of the row-split encoder kernels gave up: the launch was not resident at once "
+                              "(a second process on the card, MAGIC_ENC_RS_ALL with a grid larger than the chip); the activations of those steps are wrong")
 
 
 FUSED_CHAIN = not os.environ.get("MAGIC_NO_CHAIN")
@@ -806,10 +824,11 @@ def sumsq_sched(g, out, step, lr0, warmup, total, b1, b2, lr_ss):
     L.call("magic_sumsq_sched", g.numel(), L.P(g), L.P(out), L.P(step), float(lr0), int(warmup), int(total), float(b1), float(b2), L.P(lr_ss), L.stream())
 
 
-def adamw(n, p, g, m, v, shadow, lr, b1, b2, eps, wd, step_size, sumsq_buf, max_norm, gscale, lr_ss=None, n_decay=-1, zero_grad=False):
-    """n_decay: the first n_decay elements take the weight decay, the rest none (-1: all); zero_grad: g := 0 after use"""
+def adamw(n, p, g, m, v, shadow, lr, b1, b2, eps, wd, step_size, sumsq_buf, max_norm, gscale, lr_ss=None, n_decay=-1, zero_grad=False, overflow=None):
+    """n_decay: the first n_decay elements take the weight decay, the rest none (-1: all); zero_grad: g := 0 after use; overflow: int32[1]
+    device counter of steps skipped because the gradient norm was not finite (fp16: GradScaler's skip, never NaN weights)"""
     L.call("magic_adamw", n, L.P(p), L.P(g), L.P(m), L.P(v), L.P(shadow), L.dt(shadow.dtype) if shadow is not None else 1, float(lr), float(b1), float(b2), float(eps), float(wd),
-           float(step_size), L.P(sumsq_buf), float(max_norm), float(gscale), L.P(lr_ss), int(n_decay), 1 if zero_grad else 0, L.stream())
+           float(step_size), L.P(sumsq_buf), float(max_norm), float(gscale), L.P(lr_ss), int(n_decay), 1 if zero_grad else 0, L.P(overflow), L.stream())
 
 
 def sched_step(step, lr0, warmup, total, b1, b2, lr_ss, zero_me=None):

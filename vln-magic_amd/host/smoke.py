@@ -32,6 +32,7 @@ def run_smoke():
             want = o_s(batch, "sap", teacher_outputs=ot, rw=torch.tensor(rw))
         out = trainer.step(batch, "sap", rw=rw)
         torch.cuda.synchronize()
+        assert trainer.check_health()["skipped_optimizer_steps"] == 0
         got, ref = float(out["loss"]), float(want["loss"])
         assert abs(got - ref) <= tol * max(1.0, abs(ref)), f"smoke loss mismatch ({dtype}): {got} vs oracle {ref}"
         a = out["outputs"]["fused_logits"].float().cpu()

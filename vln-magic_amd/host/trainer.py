@@ -42,11 +42,18 @@ class FusedAdamW:
     def __init__(self, store, lr=5e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, max_grad_norm=5.0, schedule=None):
         self.store, self.lr, self.betas, self.eps, self.wd, self.max_norm = store, lr, betas, eps, weight_decay, max_grad_norm
         self.ss = torch.zeros(1, dtype=torch.float32, device=store.device)
+        # steps the AdamW kernel SKIPPED because the gradient norm was not finite (fp16 storage: an overflowed activation gradient); read
+        # with `skipped_steps()` at a point that may synchronise -- the reference's fp16 option skips such steps too (amp.GradScaler)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=store.device)
         self.t = 0
         self.schedule = schedule
         if schedule is not None:
             self.step_dev = torch.zeros(1, dtype=torch.int32, device=store.device)
             self.lr_ss = torch.zeros(2, dtype=torch.float32, device=store.device)
+
+    def skipped_steps(self):
+        """optimizer steps skipped so far because of a non-finite gradient norm (one device -> host copy)"""
+        return int(self.overflow.item())
 
     def step(self, lr=None, gscale=1.0, ss_zeroed=False, zero_grad=False):
         """ss_zeroed: the gradient-norm accumulator was zeroed earlier in this step (PretrainStep's prologue launch) -- the schedule then
@@ -73,7 +80,7 @@ class FusedAdamW:
         shadow = s.shadow if s.half else None
         # both parameter groups (decay | no decay: contiguous in the flat buffer) in ONE launch
         O.adamw(s.total, s.flat, s.grad, s.m, s.v, shadow, lr, b1, b2, self.eps, self.wd, step_size, self.ss if use_clip else None,
-                self.max_norm if use_clip else 0.0, gscale, lr_ss=lr_ss, n_decay=s.n_decay, zero_grad=zero_grad)
+                self.max_norm if use_clip else 0.0, gscale, lr_ss=lr_ss, n_decay=s.n_decay, zero_grad=zero_grad, overflow=self.overflow)
         s.shadow_clean = True
         if shadow is not None and s.t_spans:           # the AdamW kernel rewrote the bf16 shadow: its transposed copy follows
             s.sync_shadow_t(force=True)
@@ -365,6 +372,13 @@ class PretrainStep:
     def gate_report(self):
         """what the teacher stream's start gate did so far: calls / opened / already_resident / timeouts / disabled / skipped (synchronises)"""
         return O.gate_report(self.gate) if self.on_gpu else None
+
+    def check_health(self):
+        """raise if the run so far computed anything it should not trust: a row-split encoder launch whose in-launch hand-off gave up
+        (csrc/encoder.hip).  Synchronises: call it where a loss is read anyway (logging, validation, checkpoint)."""
+        if self.on_gpu:
+            O.check_encoder_health(self.dev)
+        return {"skipped_optimizer_steps": self.opt.skipped_steps() if self.on_gpu else 0}
 
     def gate_reset(self):
         """re-arm a gate that switched itself off (e.g. after a profiler run that serialised the streams)"""

@@ -221,7 +221,7 @@ __device__ __forceinline__ void mma_tile_x3(const float* sA, const float* sB, in
 // tile's arrival counter; the workgroup that draws the last ticket reads the slots IN SLOT ORDER (sc1 loads), adds them in that fixed order
 // and does the one read-modify-write of dW (no other workgroup of the launch touches that tile).  The counter is put back to 0 by that
 // workgroup, so the counters need zeroing only once, when they are allocated.  (cdna_hip_programming.md section 6 G16, form R1 with
-// every consumer load sc1.)  Slot layout: element e of thread t at [e * 256 + t], bias partial of row r at [4096 + r].
+// every consumer load sc1.)  Slot layout: 16-byte chunk (accumulator tile 2 i + j) of thread t at chunk [(2 i + j) * 256 + t], bias partial of row r at float [4096 + r].
 #define DW_SLOT (64 * 64 + 64)
 template <int TM, int NE>
 __device__ __forceinline__ void dw_seam(const GemmParams& p, const f32x4 (&acc)[2][2], float bsum, bool do_bgrad, int bx, int by, int sk,
@@ -247,10 +247,19 @@ __device__ __forceinline__ void dw_seam(const GemmParams& p, const f32x4 (&acc)[
   const int nxt = (p.N + TM - 1) / TM;
   const int tile = by * nxt + bx;
   float* const base = p.ws + ((long long)p.ws_slot0 + (long long)tile * p.ws_total) * DW_SLOT;
-  float* const mine = base + (long long)(p.ws_first + sk) * DW_SLOT;
+  const int mine = p.ws_first + sk;
+  // 16 bytes per lane and access: accumulator tile (i, j) of thread t at byte ((2 i + j) 256 + t) 16 of the slot; write-through / sc1 both ways
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.ws_total * DW_SLOT * 4, 0x00020000);
+  const int my_off = mine * DW_SLOT * 4;
 #pragma unroll
-  for (int e = 0; e < NE; ++e) __hip_atomic_store(mine + e * 256 + tid, acc[e >> 3][(e >> 2) & 1][e & 3] * p.alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (bx == 0 && tid < TM) __hip_atomic_store(mine + 4096 + tid, do_bgrad ? bsum : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 v = acc[i][j] * p.alpha;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rsrc, my_off + ((2 * i + j) * 256 + tid) * 16, 0, 16);
+    }
+  if (bx == 0 && tid < TM) __hip_atomic_store(base + (long long)mine * DW_SLOT + 4096 + tid, do_bgrad ? bsum : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores ...
   __syncthreads();                                            // ... before one lane signals for the workgroup
   if (tid == 0) {
@@ -263,17 +272,33 @@ __device__ __forceinline__ void dw_seam(const GemmParams& p, const f32x4 (&acc)[
   __syncthreads();
   if (!*flag) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (compiler only: keeps the loads below the ticket)
+  f32x4 sum[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sum[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < p.ws_total; ++q) {                      // FIXED order: slot 0, 1, 2, ... (this workgroup's own slot comes from its registers)
+    f32x4 v[2][2];
+    if (q == mine) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) v[i][j] = acc[i][j] * p.alpha;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          v[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, q * DW_SLOT * 4 + ((2 * i + j) * 256 + tid) * 16, 0, 16));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) sum[i][j] += v[i][j];
+  }
   float s[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) s[e] = 0.f;
-  for (int q = 0; q < p.ws_total; ++q) {                      // FIXED order: slot 0, 1, 2, ...
-    const float* sl = base + (long long)q * DW_SLOT;
-    float v[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) v[e] = __hip_atomic_load(sl + e * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int e = 0; e < NE; ++e) s[e] += v[e];
-  }
+  for (int e = 0; e < NE; ++e) s[e] = sum[e >> 3][(e >> 2) & 1][e & 3];
   float* C = (float*)p.C;
   float old[NE];
 #pragma unroll

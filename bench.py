@@ -130,7 +130,8 @@ def cpu_baseline(tcfg, scfg, batch_size, seconds_budget=30.0, warm=3, timed=10):
             break
     return {"value": round(traj / t_total, 2), "unit": "trajectory-steps/sec", "cores": ncores, "kind": "port",
             "cores_of_the_box": os.cpu_count(), "cores_this_process_may_use": avail,
-            "why_not_all_cores": "torch CPU ops of this size (H=128, <= 10 k rows) scale negatively past ~16 threads (measured in round 1: 32 threads slower than 16)",
+            "why_not_all_cores": "torch CPU ops of this size (H=128, <= 10 k rows) scale negatively past ~16 threads: re-measured in round 4 on the GPU box's 256-core host "
+                                 "(profiles/micro/r04_cpu_threads_scan.txt: 4 / 8 / 16 / 32 / 64 / 128 threads = 239 / 399 / 497 / 271 / 134 / 47 trajectory-steps/s)",
             "sample": f"{warm} warm-up + {steps_done} timed optimizer steps (mlm:sap:cfp cycled) of the same B={batch_size} MAGIC-S+teacher workload, "
                       f"fp32 torch CPU oracle, dropout {pdrop}, {t_total / max(steps_done, 1) * 1e3:.0f} ms/step"}
 

@@ -769,6 +769,22 @@ def main():
         finally:
             L.set_f32_mfma(prev)
         del t2, s2
+        # the same headline arithmetic with the round-3 reduction of the weight gradients (fp32 atomics: faster, not reproducible run to run)
+        prev_det = O.DW_DETERMINISTIC
+        O.DW_DETERMINISTIC = False
+        try:
+            _, _, t5, s5, tr5 = build_models(dtype, dev, a.dropout, world, a.batch)
+            eager_runner(tr5)(min(3, len(pool)))
+            torch.cuda.synchronize()
+            g5 = capture_ring(tr5, pool, a.teacher)
+            torch.cuda.synchronize()
+            traj5, dt5 = timed_region(graph_runner(tr5, g5), a.steps, a.warmup, world, dev)
+            modes["weight_gradient_reduction"] = {
+                "default": "deterministic: K-splits and repeated uses of a dW summed in slot order through a workspace (csrc/gemm.hip dw_seam) -- `value` is measured with it",
+                "with_fp32_atomics": {"ms_per_step": round(dt5 / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj5 / dt5, 1), "select_with": "MAGIC_DW_ATOMICS=1"}}
+            del g5, t5, s5, tr5
+        finally:
+            O.DW_DETERMINISTIC = prev_det
         parity = parity_block(dev)
 
     cpu = None

@@ -382,6 +382,15 @@ __host__ __device__ static inline bool bwd_alias(int NQP, int NKP, int PS, int D
 
 // NW waves per workgroup: 4, or 8 when a side has more than 64 rows (text self-attention, 80 x 80: six 16-row tiles per phase --
 // with 4 waves two of them do two tiles in every phase and the whole workgroup waits for them)
+#ifdef MAGIC_ATTN_TIMING
+// stage clocks of workgroup (0, 0) of the LAST attention-backward launch (100 MHz ticks): profiles/micro/attn_bwd_probe.py
+__device__ long long magic_attn_ticks[8];
+extern "C" int magic_debug_attn_ticks(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(magic_attn_ticks), sizeof(long long) * 8) == hipSuccess ? 0 : -2; }
+#define ATT_MARK(i) do { if (h == 0 && b == 0 && threadIdx.x == 0) magic_attn_ticks[i] = wall_clock64(); } while (0)
+#else
+#define ATT_MARK(i)
+#endif
+
 template <typename T, int NW>
 __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, const int b, unsigned char* smem_raw, float* red) {
   typedef typename AT<T>::vec vec;
@@ -398,6 +407,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
   const bool alias = bwd_alias(NQP, NKP, PS, DS);
   T* sdS = alias ? sV : sP + NQP * PS;           // [NQP][PS]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  ATT_MARK(0);
   load_rows<T>(sQ, (const T*)p.q + (long long)b * p.Nq * p.ldq + h * HD, p.ldq, p.Nq, NQP);
   load_rows<T>(sdO, (const T*)p.dctx + (long long)b * p.Nq * p.H + h * HD, p.H, p.Nq, NQP);
   load_rows<T>(sK, (const T*)p.k + (long long)b * p.Nk * p.ldkv + h * HD, p.ldkv, p.Nk, NKP);
@@ -416,57 +426,71 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
     }
   }
   __syncthreads();
+  ATT_MARK(1);
   // ---- phase 1: dP = dO V^T (+ distillation gradient), dS = P (dP - rowsum(P dP)), scaled; sprel gradients
   const int NT = NKP / 16;
   const DropState ds_ = drop_init(p.drop);
   float a0 = 0.f, a1 = 0.f;
+  // The product is formed TRANSPOSED, dP^T = V dO^T: tile j then holds keys 16 j + 4 g + r (rows) of query qt 16 + c16 (column), i.e. every lane
+  // owns FOUR CONSECUTIVE KEYS of ONE query per tile -- P, the dropped P and dS move through LDS as 8-byte (16-byte: fp32) accesses, the
+  // distillation gradient comes in as one 16-byte load, and the row sum over the keys is 24 in-lane terms + two cross-group steps.  (The
+  // untransposed form owned one key of four queries per register: 2-byte LDS reads and writes, element by element -- 5.3 us of the
+  // kernel's 10.4 at 80 x 80 with dropout on, profiles/micro/attn_bwd_probe.py; now 2.x.)
+  typedef T tv4 __attribute__((ext_vector_type(4)));
   auto dP_mma = [&](const int qt, f32x4 (&acc)[8]) {
-
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < HD / KSTEP; ++ks) {
-      const auto a = fragKC(sdO, DS, qt * 16, ks * KSTEP, lane);
+      const auto bq = fragKC(sdO, DS, qt * 16, ks * KSTEP, lane);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (j < NT) acc[j] = mma(a, fragKC(sV, DS, j * 16, ks * KSTEP, lane), acc[j]);
+        if (j < NT) acc[j] = mma(fragKC(sV, DS, j * 16, ks * KSTEP, lane), bq, acc[j]);
     }
   };
   auto dS_write = [&](const int qt, f32x4 (&acc)[8]) {
+    const int q = qt * 16 + c16;
+    const bool qok = q < p.Nq;
     float pv[8][4];
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    float rs = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (j < NT) {
-        const int key = j * 16 + c16;
+        const int key0 = j * 16 + 4 * g;
+        const tv4 p4 = *(const tv4*)(sP + q * PS + key0);
+        f32x4 init = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.dP_init && qok && key0 < p.Nk) init = *(const f32x4*)(p.dP_init + (prow0 + q) * p.ldp + key0);     // ldp % 8 == 0: 16-byte aligned; pad columns carry zeros
+        tv4 pm = p4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = qt * 16 + 4 * g + r;
-          const bool ok = (q < p.Nq) && (key < p.Nk);
+          const int key = key0 + r;
+          const bool ok = qok && (key < p.Nk);
           float d = acc[j][r];
-          if (p.dP_init && ok) d += p.dP_init[(prow0 + q) * p.ldp + key];
-          const float pp = to_f(sP[q * PS + key]);
+          if (ok) d += init[r];
+          const float pp = to_f(p4[r]);
           if (ds_.on) {               // d is the gradient wrt the DROPPED probabilities: mask it, and leave P*mask in sP for dV
             const float m = ok ? drop_mul(ds_, (unsigned)((prow0 + q) * p.Nk + key)) : 0.f;
             d *= m;
-            sP[q * PS + key] = from_f<T>(pp * m);
+            pm[r] = from_f<T>(pp * m);
           }
-          pv[j][r] = pp; acc[j][r] = d; rs[r] += pp * d;
+          pv[j][r] = pp; acc[j][r] = d; rs += pp * d;
         }
+        if (ds_.on) *(tv4*)(sP + q * PS + key0) = pm;
       }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rs[r] = group16_sum(rs[r]);
+    rs += __shfl_xor(rs, 16, 64);       // the four key groups of a query sit 16 lanes apart
+    rs += __shfl_xor(rs, 32, 64);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (j < NT) {
-        const int key = j * 16 + c16;
+        const int key0 = j * 16 + 4 * g;
+        tv4 o4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = qt * 16 + 4 * g + r;
-          const float ds = pv[j][r] * (acc[j][r] - rs[r]);
-          sdS[q * PS + key] = from_f<T>(ds * p.scale);
-          if (p.dist && q < p.Nq && key < p.Nk) { a0 += ds * p.dist[((long long)b * p.Nq + q) * p.Nk + key]; a1 += ds; }
+          const float ds = pv[j][r] * (acc[j][r] - rs);
+          o4[r] = from_f<T>(ds * p.scale);
+          if (p.dist && qok && key0 + r < p.Nk) { a0 += ds * p.dist[((long long)b * p.Nq + q) * p.Nk + key0 + r]; a1 += ds; }
         }
+        *(tv4*)(sdS + q * PS + key0) = o4;
       }
     };
   if (alias) {
@@ -494,6 +518,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
     atomicAdd(p.dsprel_w, s0);
     atomicAdd(p.dsprel_b, s1);
   }
+  ATT_MARK(2);
   // ---- phase 2: dQ = dS K ; dK = dS^T Q ; dV = P^T dO        (tiles of 16 rows x 64 head dims, round-robin over waves)
   for (int qt = w; qt < NQP / 16; qt += NW) {
     f32x4 o[4];
@@ -512,6 +537,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
         if (q < p.Nq) ((T*)p.dq)[((long long)b * p.Nq + q) * p.lddq + h * HD + jd * 16 + c16] = from_f<T>(o[jd][r]);
       }
   }
+  ATT_MARK(3);
   for (int kt = w; kt < NKP / 16; kt += NW) {
     f32x4 ok_[4], ov[4];
 #pragma unroll
@@ -537,6 +563,11 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
         }
       }
   }
+  ATT_MARK(4);
+#ifdef MAGIC_ATTN_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATT_MARK(5);
+#endif
 }
 
 template <typename T, int NW>

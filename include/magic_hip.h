@@ -139,6 +139,29 @@ typedef struct {
   const void* tab; const int* tab_idx;
 } magic_node_in;
 int magic_node_in_fwd(int dtype, int H, int n, const magic_node_in* d, void* stream);
+
+/* Input stage of the panorama encoder in ONE launch, together with the text-embedding rows (csrc/rowops.hip embed_in_fwd_kernel; round 4):
+ * A1 = LN_img(P0), P0 = img_linear(view features); A2 = LN_loc(loc W^T + b); X0 = LN(A1 + A2 + nav_tab[nav_idx] + tok_tab[0]) and its dropped
+ * copy X0d -- magic_ln_fwd -> magic_smallk_ln_fwd -> magic_ln_fwd of the per-op path with the same rounding points and summation order, so every
+ * saved tensor is bit-identical and the backward kernels read them unchanged.  (The withheld model's `ImageEmbeddings`: img_linear /
+ * img_layer_norm / loc_linear / loc_layer_norm / nav_type_embedding / layer_norm, names per train_r2r_magic.py:189-208; [LINEAGE] DUET.)
+ * tx (may be NULL): a second, independent magic_ln_fwd problem served by the same launch (the text embedding: word + position + token-type
+ * rows, LayerNorm, dropout).  drop: seed == NULL or p <= 0 -> off. */
+typedef struct { const unsigned* seed; unsigned site; float p; } magic_drop_desc;
+typedef struct magic_pano_in {
+  int M, Kin; float eps; int pad_;
+  const void* P0; const float* g1; const float* b1; void* A1; float* rstd1;
+  const float* loc; const float* W; const float* b; const float* g2; const float* b2; void* A2; float* rstd2;
+  const void* nav_tab; const int* nav_idx; const void* tok_tab;
+  const float* g3; const float* b3; void* X0; float* rstd3; void* X0d; magic_drop_desc dout;
+} magic_pano_in;
+typedef struct magic_ln_in {
+  int M, do_ln; const void* in0; const void* in1;
+  const void* tab[3]; const int* idx[3]; int mod[3]; int off[3];
+  const float* gamma; const float* beta; float eps; int pad_; void* out; float* rstd;
+  const unsigned* drop_seed; float drop_p; unsigned site_in0, site_out, pad2_; void* out_drop;
+} magic_ln_in;
+int magic_embed_in_fwd(int dtype, int H, const magic_pano_in* pa, const magic_ln_in* tx, void* stream);
 int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float* x, const void* dy, const void* y,
                         const float* gamma, const float* beta, const float* rstd,
                         float* dW, float* db, float* dgamma, float* dbeta, void* stream);

@@ -302,6 +302,41 @@ def test_node_inputs_in_one_launch_are_bit_identical_to_the_per_op_chain(dtype):
     assert g1.out.abs().max() > 0 and v1.out.abs().max() > 0
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("dtype,H", [(torch.bfloat16, 128), (torch.float16, 128), (torch.float32, 128), (torch.bfloat16, 256), (torch.bfloat16, 768)])
+def test_input_embeddings_in_one_launch_are_bit_identical_to_the_per_op_chain(dtype, H, p_drop):
+    """magic_embed_in_fwd (round 4): the panorama stage's image LayerNorm, location linear + LayerNorm, sum LayerNorm + dropout AND the text embedding's
+    gathers + LayerNorm + dropout in ONE launch behind the image projection -- every tensor the backward reads is bit-identical to
+    magic_ln_fwd -> magic_smallk_ln_fwd -> magic_ln_fwd (+ the text magic_ln_fwd), with the same dropout masks"""
+    cfg = make_config(H, role="student" if H == 128 else "teacher", hidden_dropout_prob=p_drop, attention_probs_dropout_prob=p_drop,
+                      **(dict(teacher_hidden_size=256, kdl=KDL) if H == 128 else {}))
+    m = GlocalTextPathCMTPreTraining(cfg, device=DEV, compute_dtype=dtype, seed=3)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(1)
+        for nme, p in m.named_parameters():
+            if ("LayerNorm" in nme or "layer_norm" in nme) and p.dim() == 1:
+                p.add_((torch.randn(p.shape, generator=g) * 0.1).to(DEV))
+    m.store.shadow_clean = False
+    batch = synth.make_batch("sap", batch_size=7, seed=5, step=0, dup_view_prob=0.3)
+    plan = build_plan(batch, "sap", torch.device(DEV))
+    inp = m._inputs(batch, plan)
+    m.store.sync_shadow()
+    n = m.net
+    seed = torch.tensor([12345, 678], dtype=torch.int32, device=DEV)
+    n.set_dropout(seed if p_drop > 0 else None, p_drop, p_drop)
+    assert n.embed_in_ok()
+    ct0, cp0 = n.text_fwd(plan, defer=True), n.pano_fwd(plan, inp.feats, inp.loc, defer=True)      # per-op: four launches behind the projection
+    if not n.enc_ok(plan["L"], cfg.num_l_layers):          # widths without the whole-encoder launch ran their layers too: only the embeddings matter here
+        pass
+    ct1, cp1 = n.embeds_fwd(plan, inp.feats, inp.loc)
+    torch.cuda.synchronize()
+    for nm in ("E", "rstd_e") + (("Ed",) if p_drop > 0 else ()):
+        assert torch.equal(getattr(ct0, nm), getattr(ct1, nm)), f"text {nm}"
+    for nm in ("A1", "rstd_a1", "A2", "rstd_a2", "X0", "rstd_x0") + (("X0d",) if p_drop > 0 else ()):
+        assert torch.equal(getattr(cp0, nm), getattr(cp1, nm)), f"panorama {nm}"
+    assert ct1.E.float().abs().max() > 0 and cp1.X0.float().abs().max() > 0 and (p_drop == 0 or (cp1.X0d == 0).float().mean() > 0.05)
+
+
 def test_node_inputs_backward_in_shared_launches_matches_the_per_op_sequence():
     """nodes_in_bwd (step-table gradient, both position-embedding backwards as a pair, the three transposed gathers as one launch) against
     vp_in_bwd + gmap_in_bwd: the gathered gradients are bit-identical (same rounding order), the parameter gradients agree to fp32

@@ -550,6 +550,133 @@ __global__ __launch_bounds__(256) void node_in_fwd_kernel(magic_node_in a, magic
   else node_in_body<T, NIT>(b, blockIdx.x - nA);
 }
 
+
+// Input stage of the panorama encoder in ONE launch (round 4), together with the text embedding rows:
+//   A1  = LN_img(P0)                       P0 = img_linear(view features), the GEMM in front of this launch
+//   A2  = LN_loc(loc W^T + b)              loc [M, Kin <= 16] fp32
+//   X0  = LN(A1 + A2 + nav_tab[nav_type] + tok_tab[0])   (+ its dropped copy X0d)
+// i.e. ln_fwd -> smallk_ln_fwd -> ln_fwd of the per-op path (three launches on the critical path in front of the whole-encoder launch) with
+// the SAME rounding points and summation order -- A1 / A2 are rounded to T before the sum, the sum runs in0 + in1 + t0 + t1 as ln_fwd_body's
+// -- so every saved tensor (A1, rstd_a1, A2, rstd_a2, X0, rstd_x0, X0d) is bit-identical and the per-op backward kernels read them unchanged.
+// Blocks >= nA run ln_fwd_body on a second, independent problem (the text embedding: three table gathers + LayerNorm + dropout).
+struct magic_pano_in {
+  int M, Kin; float eps; int pad_;
+  const void* P0; const float* g1; const float* b1; void* A1; float* rstd1;
+  const float* loc; const float* W; const float* b; const float* g2; const float* b2; void* A2; float* rstd2;
+  const void* nav_tab; const int* nav_idx; const void* tok_tab;
+  const float* g3; const float* b3; void* X0; float* rstd3; void* X0d; DropDesc dout;
+};
+template <typename T, int NIT>
+__device__ __forceinline__ void pano_in_body(const magic_pano_in& p, const int bid) {
+  constexpr int H = NIT * 128;
+  const int lane = threadIdx.x & 63, row0 = (bid * 4 + (threadIdx.x >> 6)) * SKF_ROWS, M = p.M, Kin = p.Kin;
+  if (row0 >= M) return;
+  constexpr bool WREG = NIT <= 2;
+  float wr[WREG ? 2 * NIT : 1][16], br[2 * NIT];
+#pragma unroll
+  for (int i = 0; i < 2 * NIT; ++i) {
+    const int c = (i >> 1) * 128 + lane * 2 + (i & 1);
+    br[i] = p.b[c];
+    if constexpr (WREG) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) wr[i][k] = k < Kin ? p.W[c * Kin + k] : 0.f;
+    }
+  }
+  const DropState sout = drop_init(p.dout);
+  for (int rr = 0; rr < SKF_ROWS; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;
+    // ---- A1 = LN_img(P0 row)  (ln_fwd_body with in0 only)
+    float x[2 * NIT], s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      float u, v;
+      ld2<T>((const T*)p.P0 + (long long)row * H + it * 128 + lane * 2, u, v);
+      x[2 * it] = 0.f + u; x[2 * it + 1] = 0.f + v; s += x[2 * it] + x[2 * it + 1];
+    }
+    float mean = wave_sum(s) / H, q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { const float a = x[2 * it] - mean, b = x[2 * it + 1] - mean; q += a * a + b * b; }
+    float rstd = rsqrtf(wave_sum(q) / H + p.eps);
+    if (lane == 0) p.rstd1[row] = rstd;
+    float a1[2 * NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 128 + lane * 2;
+      const float2 g = *(const float2*)(p.g1 + c), b = *(const float2*)(p.b1 + c);
+      const float y0 = (x[2 * it] - mean) * rstd * g.x + b.x, y1 = (x[2 * it + 1] - mean) * rstd * g.y + b.y;
+      st2<T>((T*)p.A1 + (long long)row * H + c, y0, y1);
+      a1[2 * it] = to_f(from_f<T>(y0)); a1[2 * it + 1] = to_f(from_f<T>(y1));
+    }
+    // ---- A2 = LN_loc(loc W^T + b)  (smallk_ln_fwd_kernel)
+    float xr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xr[k] = k < Kin ? p.loc[(long long)row * Kin + k] : 0.f;
+    float z[2 * NIT];
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * NIT; ++i) {
+      float a = br[i];
+      if constexpr (WREG) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += xr[k] * wr[i][k];
+      } else {
+        const int c = (i >> 1) * 128 + lane * 2 + (i & 1);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += (k < Kin) ? xr[k] * p.W[c * Kin + k] : 0.f;
+      }
+      z[i] = a; s += a;
+    }
+    mean = wave_sum(s) / H;
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * NIT; ++i) { const float a = z[i] - mean; q += a * a; }
+    rstd = rsqrtf(wave_sum(q) / H + p.eps);
+    if (lane == 0) p.rstd2[row] = rstd;
+    float a2[2 * NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 128 + lane * 2;
+      const float2 g = *(const float2*)(p.g2 + c), b = *(const float2*)(p.b2 + c);
+      const float y0 = (z[2 * it] - mean) * rstd * g.x + b.x, y1 = (z[2 * it + 1] - mean) * rstd * g.y + b.y;
+      st2<T>((T*)p.A2 + (long long)row * H + c, y0, y1);
+      a2[2 * it] = to_f(from_f<T>(y0)); a2[2 * it + 1] = to_f(from_f<T>(y1));
+    }
+    // ---- X0 = LN(A1 + A2 + nav_tab[nav_type] + tok_tab[0]), X0d = dropout(X0)   (ln_fwd_body with in0, in1, t0, t1)
+    const int nr = p.nav_idx[row];
+    s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 128 + lane * 2;
+      float a = 0.f, b = 0.f, u, v;
+      a += a1[2 * it]; b += a1[2 * it + 1];
+      a += a2[2 * it]; b += a2[2 * it + 1];
+      ld2<T>((const T*)p.nav_tab + (long long)nr * H + c, u, v); a += u; b += v;
+      ld2<T>((const T*)p.tok_tab + c, u, v); a += u; b += v;
+      x[2 * it] = a; x[2 * it + 1] = b; s += a + b;
+    }
+    mean = wave_sum(s) / H;
+    q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { const float a = x[2 * it] - mean, b = x[2 * it + 1] - mean; q += a * a + b * b; }
+    rstd = rsqrtf(wave_sum(q) / H + p.eps);
+    if (lane == 0) p.rstd3[row] = rstd;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 128 + lane * 2;
+      const float2 g = *(const float2*)(p.g3 + c), b = *(const float2*)(p.b3 + c);
+      const float y0 = (x[2 * it] - mean) * rstd * g.x + b.x, y1 = (x[2 * it + 1] - mean) * rstd * g.y + b.y;
+      st2<T>((T*)p.X0 + (long long)row * H + c, y0, y1);
+      if (sout.on) st2<T>((T*)p.X0d + (long long)row * H + c, y0 * drop_mul(sout, (unsigned)(row * H + c)), y1 * drop_mul(sout, (unsigned)(row * H + c + 1)));
+    }
+  }
+}
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void embed_in_fwd_kernel(magic_pano_in a, LnfParams b, int nA) {
+  if ((int)blockIdx.x < nA) pano_in_body<T, NIT>(a, blockIdx.x);
+  else ln_fwd_body<T, NIT>(b, blockIdx.x - nA);
+}
+
 // backward: dW[H,Kin], db[H], dgamma, dbeta (fp32 atomics, block-reduced).  SK_ROWS rows per block (NW waves);
 // dz rows are parked in LDS so the dW outer product is a cooperative (c,k) loop.  Every block ends in H (Kin + 3) same-address atomics,
 // so at H = 128 and M >= 4096 a block takes 64 rows with 16 waves (half as many blocks as the 32-row / 4-wave shape, 4 rows per wave).
@@ -975,6 +1102,46 @@ extern "C" int magic_smallk_ln_fwd(int dtype, int M, int H, int Kin, const float
 #define SKF(TY, NIT) hipLaunchKernelGGL((smallk_ln_fwd_kernel<TY, NIT>), grid, block, 0, st, M, H, Kin, x, W, b, gamma, beta, eps, (TY*)out, rstd)
   DISPATCH_NIT(dtype, H, SKF);
 #undef SKF
+  return launch_status();
+}
+
+
+// public mirror of LnfParams for the second problem of magic_embed_in_fwd (the text embedding rows): same meaning as magic_ln_fwd's arguments
+struct magic_ln_in {
+  int M, do_ln; const void* in0; const void* in1;
+  const void* tab[3]; const int* idx[3]; int mod[3]; int off[3];
+  const float* gamma; const float* beta; float eps; int pad_; void* out; float* rstd;
+  const unsigned* drop_seed; float drop_p; unsigned site_in0, site_out, pad2_; void* out_drop;
+};
+extern "C" int magic_embed_in_fwd(int dtype, int H, const magic_pano_in* pa, const magic_ln_in* tx, void* stream) {
+  if (!okH(H) || !pa) return MAGIC_ERR_ARG;
+  const magic_pano_in& a = *pa;
+  if (a.M <= 0 || a.Kin <= 0 || a.Kin > 16 || (long long)a.M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+  const void* req[] = {a.P0, a.g1, a.b1, a.A1, a.rstd1, a.loc, a.W, a.b, a.g2, a.b2, a.A2, a.rstd2, a.nav_tab, a.nav_idx, a.tok_tab, a.g3, a.b3, a.X0, a.rstd3};
+  for (const void* q : req)
+    if (!q) return MAGIC_ERR_ARG;
+  if (!drop_args_ok(a.dout.seed, a.dout.p) || (a.dout.seed && a.dout.p > 0.f && !a.X0d)) return MAGIC_ERR_ARG;
+  LnfParams b{};
+  int nb = 0;
+  if (tx) {
+    const magic_ln_in& t = *tx;
+    if (t.M <= 0 || !t.out || (t.do_ln && (!t.gamma || !t.beta))) return MAGIC_ERR_ARG;
+    if (!drop_args_ok(t.drop_seed, t.drop_p) || (long long)t.M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+    const bool don = t.drop_p > 0.f;
+    if (don && t.site_out && (!t.out_drop || !t.do_ln)) return MAGIC_ERR_ARG;
+    if (don && t.site_in0 && !t.in0) return MAGIC_ERR_ARG;
+    DropDesc din{(don && t.site_in0) ? t.drop_seed : nullptr, t.site_in0, t.drop_p};
+    DropDesc dout{(don && t.site_out) ? t.drop_seed : nullptr, t.site_out, t.drop_p};
+    TabRef t0{t.tab[0], t.idx[0], t.mod[0], t.off[0]}, t1{t.tab[1], t.idx[1], t.mod[1], t.off[1]}, t2{t.tab[2], t.idx[2], t.mod[2], t.off[2]};
+    b = LnfParams{t.M, t.in0, t.in1, t0, t1, t2, t.gamma, t.beta, t.eps, t.out, t.rstd, t.do_ln, din, dout, t.out_drop};
+    nb = (t.M + 3) / 4;
+  }
+  const int na = (a.M + 4 * SKF_ROWS - 1) / (4 * SKF_ROWS);
+  dim3 grid(na + nb), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define EIF(TY, NIT) hipLaunchKernelGGL((embed_in_fwd_kernel<TY, NIT>), grid, block, 0, st, a, b, na)
+  DISPATCH_NIT(dtype, H, EIF);
+#undef EIF
   return launch_status();
 }
 

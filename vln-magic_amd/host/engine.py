@@ -537,8 +537,8 @@ class MagicNet:
     def _flops_attn(self, lens_q, lens_k):
         return float(sum(a * b for a, b in zip(lens_q, lens_k))) * HD * self.nh
 
-    def text_fwd(self, plan, defer=False):
-        """defer: stop after the embeddings and leave the layers to `encoders_fwd` (one launch shared with the panorama encoder)"""
+    def _text_embed_args(self, plan):
+        """(ctx with the embedding buffers, keyword arguments of the embedding's ln_fwd)"""
         p, H = self.p, self.H
         B, L = plan["B"], plan["L"]
         M = B * L
@@ -547,10 +547,20 @@ class MagicNet:
         c.E, c.rstd_e = self.new(M, H), self.new(M, dtype=torch.float32)
         c.edrop = self._dh(p + "embeddings.dropout")
         c.Ed = self.new(M, H) if c.edrop else None
-        O.ln_fwd(M, H, c.E, tabs=((self.S.w(p + "embeddings.word_embeddings.weight"), plan["txt_ids"], 0, 0),
-                                  (self.S.w(p + "embeddings.position_embeddings.weight"), None, L, 2),
-                                  (self.S.w(p + "embeddings.token_type_embeddings.weight"), None, 0, 0)),
-                 gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_e, drop_out=c.edrop, out_drop=c.Ed)
+        kw = dict(tabs=((self.S.w(p + "embeddings.word_embeddings.weight"), plan["txt_ids"], 0, 0),
+                        (self.S.w(p + "embeddings.position_embeddings.weight"), None, L, 2),
+                        (self.S.w(p + "embeddings.token_type_embeddings.weight"), None, 0, 0)),
+                  gamma=n.g, beta=n.b, eps=self.eps, rstd=c.rstd_e, drop_out=c.edrop, out_drop=c.Ed)
+        return c, M, kw
+
+    def text_fwd(self, plan, defer=False, c=None):
+        """defer: stop after the embeddings and leave the layers to `encoders_fwd` (one launch shared with the panorama encoder);
+        c: the embeddings are done already (`embeds_fwd`)"""
+        p, H = self.p, self.H
+        B, L = plan["B"], plan["L"]
+        if c is None:
+            c, M, kw = self._text_embed_args(plan)
+            O.ln_fwd(M, H, c.E, **kw)
         x = c.Ed if c.edrop else c.E
         c.layers = []
         tl = plan["lens"]["txt"]
@@ -688,31 +698,59 @@ class MagicNet:
                  hot0=0)          # id 0 pads every instruction (pretrain_src/data/tasks.py:116 pad_sequence(..., padding_value=0)); a pure performance hint
 
     # ---- panorama encoder ----------------------------------------------------------------------
-    def pano_fwd(self, plan, feats, loc, defer=False):
-        """feats [Np*V, D] compute dtype; loc [Np*V, 7] fp32.  defer: as text_fwd."""
+    def embeds_fwd(self, plan, feats, loc):
+        """both input embeddings with ONE launch behind the image projection (csrc/rowops.hip embed_in_fwd_kernel): the panorama stage's three
+        LayerNorms + the text embedding's gathers / LayerNorm / dropout -- four launches in front of the whole-encoder launch before.  Returns
+        (text ctx, panorama ctx) as text_fwd / pano_fwd build them up to their embeddings (bit-identical tensors); pass them on as `c=`."""
         p, H = self.p + "img_embeddings.", self.H
         Np, V = plan["Np"], plan["V"]
         M = Np * V
+        ct, Mt, kw = self._text_embed_args(plan)
         c = Ctx(Np=Np, V=V, feats=feats, loc=loc)
         il = self.lin(p + "img_linear.weight")
-        from . import lib as _L
-        with _L.solo():       # (not offered to a lockstep partner: the text encoder's first groupable launch is its QKV projection, as is our next one)
-            P0 = O.linear_fwd(feats, il.W, il.b, M)
-        n1 = self.ln(p + "img_layer_norm")
+        P0 = O.linear_fwd(feats, il.W, il.b, M)
+        n1, n2, n3, ll = self.ln(p + "img_layer_norm"), self.ln(p + "loc_layer_norm"), self.ln(p + "layer_norm"), self.lin(p + "loc_linear.weight")
         c.A1, c.rstd_a1 = self.new(M, H), self.new(M, dtype=torch.float32)
-        O.ln_fwd(M, H, c.A1, in0=P0, gamma=n1.g, beta=n1.b, eps=self.eps, rstd=c.rstd_a1)
-        ll, n2 = self.lin(p + "loc_linear.weight"), self.ln(p + "loc_layer_norm")
         c.A2, c.rstd_a2 = self.new(M, H), self.new(M, dtype=torch.float32)
-        O.smallk_ln_fwd(M, H, ll.K, loc, ll.Wm, ll.b, n2.g, n2.b, self.eps, c.A2, c.rstd_a2)
-        n3 = self.ln(p + "layer_norm")
         c.X0, c.rstd_x0 = self.new(M, H), self.new(M, dtype=torch.float32)
         c.edrop = self._dh(p + "dropout")
         c.X0d = self.new(M, H) if c.edrop else None
-        with _L.solo():       # (the image LayerNorm above pairs with the text embedding's; this one has no partner in the text segment)
-            O.ln_fwd(M, H, c.X0, in0=c.A1, in1=c.A2,
-                     tabs=((self.S.w(p + "nav_type_embedding.weight"), plan["nav_types"], 0, 0),
-                           (self.S.w(self.p + "embeddings.token_type_embeddings.weight"), None, 0, 0), None),
-                     gamma=n3.g, beta=n3.b, eps=self.eps, rstd=c.rstd_x0, drop_out=c.edrop, out_drop=c.X0d)
+        O.embed_in_fwd(H, dict(M=M, Kin=ll.K, eps=self.eps, P0=P0, g1=n1.g, b1=n1.b, A1=c.A1, rstd1=c.rstd_a1, loc=loc, W=ll.Wm, b=ll.b,
+                               g2=n2.g, b2=n2.b, A2=c.A2, rstd2=c.rstd_a2, nav_tab=self.S.w(p + "nav_type_embedding.weight"),
+                               nav_idx=plan["nav_types"], tok_tab=self.S.w(self.p + "embeddings.token_type_embeddings.weight"),
+                               g3=n3.g, b3=n3.b, X0=c.X0, rstd3=c.rstd_x0, X0d=c.X0d, drop=c.edrop),
+                       dict(M=Mt, out=ct.E, **kw))
+        return ct, c
+
+    def embed_in_ok(self):
+        return O.EMBED_IN and self.H in (128, 256, 384, 768)
+
+    def pano_fwd(self, plan, feats, loc, defer=False, c=None):
+        """feats [Np*V, D] compute dtype; loc [Np*V, 7] fp32.  defer: as text_fwd; c: the embeddings are done already (`embeds_fwd`)."""
+        p, H = self.p + "img_embeddings.", self.H
+        Np, V = plan["Np"], plan["V"]
+        M = Np * V
+        if c is None:
+            c = Ctx(Np=Np, V=V, feats=feats, loc=loc)
+            il = self.lin(p + "img_linear.weight")
+            from . import lib as _L
+            with _L.solo():       # (not offered to a lockstep partner: the text encoder's first groupable launch is its QKV projection, as is our next one)
+                P0 = O.linear_fwd(feats, il.W, il.b, M)
+            n1 = self.ln(p + "img_layer_norm")
+            c.A1, c.rstd_a1 = self.new(M, H), self.new(M, dtype=torch.float32)
+            O.ln_fwd(M, H, c.A1, in0=P0, gamma=n1.g, beta=n1.b, eps=self.eps, rstd=c.rstd_a1)
+            ll, n2 = self.lin(p + "loc_linear.weight"), self.ln(p + "loc_layer_norm")
+            c.A2, c.rstd_a2 = self.new(M, H), self.new(M, dtype=torch.float32)
+            O.smallk_ln_fwd(M, H, ll.K, loc, ll.Wm, ll.b, n2.g, n2.b, self.eps, c.A2, c.rstd_a2)
+            n3 = self.ln(p + "layer_norm")
+            c.X0, c.rstd_x0 = self.new(M, H), self.new(M, dtype=torch.float32)
+            c.edrop = self._dh(p + "dropout")
+            c.X0d = self.new(M, H) if c.edrop else None
+            with _L.solo():       # (the image LayerNorm above pairs with the text embedding's; this one has no partner in the text segment)
+                O.ln_fwd(M, H, c.X0, in0=c.A1, in1=c.A2,
+                         tabs=((self.S.w(p + "nav_type_embedding.weight"), plan["nav_types"], 0, 0),
+                               (self.S.w(self.p + "embeddings.token_type_embeddings.weight"), None, 0, 0), None),
+                         gamma=n3.g, beta=n3.b, eps=self.eps, rstd=c.rstd_x0, drop_out=c.edrop, out_drop=c.X0d)
         x = c.X0d if c.edrop else c.X0
         c.layers = []
         af = float(Np) * V * V * HD * self.nh

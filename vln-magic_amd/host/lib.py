@@ -53,6 +53,7 @@ SIGNATURES = {
     "magic_loss_assemble": [vp, i32, vp, f32, vp, i32, vp, vp, f32, i32, vp, vp],
     "magic_cfp_loss": [i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_node_in_fwd": [i32, i32, i32, vp, vp],
+    "magic_embed_in_fwd": [i32, i32, vp, vp, vp],
     "magic_csr_gather_multi": [i32, i32, i32, vp, vp],
     "magic_smallk_ln_bwd_pair": [i32, i32, vp, vp],
     "magic_csr_gather": [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp],
@@ -114,6 +115,25 @@ class NodeIn(C.Structure):
     """mirror of `magic_node_in` (include/magic_hip.h)"""
     _fields_ = ([("M", i32), ("Kin", i32), ("x", vp), ("W", vp), ("b", vp), ("gamma", vp), ("beta", vp), ("eps", f32), ("pad_", i32)]
                 + [(n, vp) for n in NODE_IN_PTRS])
+
+
+class DropD(C.Structure):
+    """mirror of `magic_drop_desc`"""
+    _fields_ = [("seed", vp), ("site", u32), ("p", f32)]
+
+
+class PanoIn(C.Structure):
+    """mirror of `magic_pano_in` (include/magic_hip.h)"""
+    _fields_ = [("M", i32), ("Kin", i32), ("eps", f32), ("pad_", i32)] + \
+               [(n, vp) for n in ("P0", "g1", "b1", "A1", "rstd1", "loc", "W", "b", "g2", "b2", "A2", "rstd2", "nav_tab", "nav_idx", "tok_tab",
+                                  "g3", "b3", "X0", "rstd3", "X0d")] + [("dout", DropD)]
+
+
+class LnIn(C.Structure):
+    """mirror of `magic_ln_in` (include/magic_hip.h)"""
+    _fields_ = [("M", i32), ("do_ln", i32), ("in0", vp), ("in1", vp), ("tab", vp * 3), ("idx", vp * 3), ("mod", i32 * 3), ("off", i32 * 3),
+                ("gamma", vp), ("beta", vp), ("eps", f32), ("pad_", i32), ("out", vp), ("rstd", vp),
+                ("drop_seed", vp), ("drop_p", f32), ("site_in0", u32), ("site_out", u32), ("pad2_", u32), ("out_drop", vp)]
 
 
 class CsrProb(C.Structure):

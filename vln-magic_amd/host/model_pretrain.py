@@ -275,7 +275,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         # the text and panorama encoders are independent: run them on two streams
         # both self-attention encoders as ONE launch (csrc/encoder.hip) when the shapes allow: embeddings first (paired), then the launch
         fuse = self.will_fuse_encoders(plan)
-        c.txt, c.pano = self._par(lambda: n.text_fwd(plan, defer=fuse), lambda: n.pano_fwd(plan, inp.feats, inp.loc, defer=fuse))
+        if n.embed_in_ok():        # both input embeddings in one launch behind the image projection, then the layers
+            ct, cp = n.embeds_fwd(plan, inp.feats, inp.loc)
+            c.txt, c.pano = self._par(lambda: n.text_fwd(plan, defer=fuse, c=ct), lambda: n.pano_fwd(plan, inp.feats, inp.loc, defer=fuse, c=cp))
+        else:
+            c.txt, c.pano = self._par(lambda: n.text_fwd(plan, defer=fuse), lambda: n.pano_fwd(plan, inp.feats, inp.loc, defer=fuse))
         if fuse:
             n.encoders_fwd(c.txt, c.pano)
         c.txt_out, c.pano_adj = c.txt.out, c.pano

@@ -359,6 +359,40 @@ def node_in_fwd(H, problems):
     L.call("magic_node_in_fwd", L.dt(problems[0]["out"].dtype), H, len(problems), __import__("ctypes").addressof(arr), L.stream())
 
 
+EMBED_IN = not os.environ.get("MAGIC_NO_EMBED_IN")
+
+
+def embed_in_fwd(H, pano, text=None):
+    """the panorama encoder's input stage (image LayerNorm, location linear + LayerNorm, sum LayerNorm + dropout) and, optionally, the text
+    embedding's gathers + LayerNorm + dropout as ONE launch (csrc/rowops.hip embed_in_fwd_kernel): bit-identical to ln_fwd -> smallk_ln_fwd ->
+    ln_fwd (+ the text ln_fwd).  pano: dict(M, Kin, eps, P0, g1, b1, A1, rstd1, loc, W, b, g2, b2, A2, rstd2, nav_tab, nav_idx, tok_tab, g3, b3,
+    X0, rstd3[, X0d, drop=(seed, p, site)]); text: the keyword arguments of ln_fwd + M + out."""
+    a = L.PanoIn()
+    a.M, a.Kin, a.eps = int(pano["M"]), int(pano["Kin"]), float(pano["eps"])
+    _chk(pano["loc"].dtype == torch.float32 and pano["loc"].is_contiguous() and pano["nav_idx"].dtype == torch.int32, "embed_in_fwd: loc fp32, nav_idx int32")
+    for k in ("P0", "g1", "b1", "A1", "rstd1", "loc", "W", "b", "g2", "b2", "A2", "rstd2", "nav_tab", "nav_idx", "tok_tab", "g3", "b3", "X0", "rstd3", "X0d"):
+        setattr(a, k, L.P(pano.get(k)))
+    seed, p_, site = _dr(pano.get("drop"))
+    a.dout.seed, a.dout.site, a.dout.p = seed, int(site), float(p_)
+    tp = None
+    if text is not None:
+        t = L.LnIn()
+        t.M, t.do_ln, t.in0, t.in1 = int(text["M"]), 1 if text.get("do_ln", True) else 0, L.P(text.get("in0")), L.P(text.get("in1"))
+        for i, tb in enumerate(text.get("tabs", (None, None, None))):
+            tab, idx, mod, off = _tab(tb)
+            t.tab[i], t.idx[i], t.mod[i], t.off[i] = tab, idx, mod, off
+        t.gamma, t.beta, t.eps, t.out, t.rstd = L.P(text.get("gamma")), L.P(text.get("beta")), float(text.get("eps", 1e-12)), L.P(text["out"]), L.P(text.get("rstd"))
+        d_in, d_out = text.get("drop_in0"), text.get("drop_out")
+        d = d_in if (d_in is not None and d_in[1] > 0) else d_out
+        seed, p_, _ = _dr(d)
+        t.drop_seed, t.drop_p = seed, float(p_)
+        t.site_in0 = int(d_in[2]) if (p_ > 0 and d_in is not None) else 0
+        t.site_out = int(d_out[2]) if (p_ > 0 and d_out is not None) else 0
+        t.out_drop = L.P(text.get("out_drop"))
+        tp = C.addressof(t)
+    L.call("magic_embed_in_fwd", L.dt(pano["X0"].dtype), H, C.addressof(a), tp, L.stream())
+
+
 def smallk_ln_bwd(M, H, Kin, x, dy, y, gamma, beta, rstd, dW, db, dgamma, dbeta):
     L.call("magic_smallk_ln_bwd", L.dt(dy.dtype), M, H, Kin, L.P(x), L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(rstd),
            L.P(dW), L.P(db), L.P(dgamma), L.P(dbeta), L.stream())

@@ -162,6 +162,29 @@ typedef struct magic_ln_in {
   const unsigned* drop_seed; float drop_p; unsigned site_in0, site_out, pad2_; void* out_drop;
 } magic_ln_in;
 int magic_embed_in_fwd(int dtype, int H, const magic_pano_in* pa, const magic_ln_in* tx, void* stream);
+
+/* Backward of that stage in ONE launch (csrc/rowops.hip embed_in_bwd_kernel): magic_ln_bwd (sum LayerNorm: dsum, nav-type / token-type row
+ * gradients) -> magic_ln_bwd (image LayerNorm: dP0, the operand of the image projection's weight gradient) -> magic_smallk_ln_bwd (location
+ * LayerNorm + loc_linear gradients) of the per-op path with the same formulas and rounding points (dP0 bit-identical; parameter gradients to
+ * fp32 summation order), every parameter gradient accumulated in registers and reduced once per block.  H = 128 or 256, Kin <= 8
+ * (magic_embed_in_bwd_supported).  tx (may be NULL): a second, independent magic_ln_bwd problem (the text embedding's LayerNorm + table
+ * scatters) served by the same launch.  dy: gradient of the stage's output; ddy: the output dropout (dy is masked on load). */
+typedef struct magic_pano_in_bwd {
+  int M, Kin, pad0_, pad1_;
+  const void* dy; magic_drop_desc ddy;
+  const void* X0; const float* rstd3; const float* g3; const float* b3; float* dg3; float* db3;
+  const int* nav_idx; float* d_nav; float* d_tok;
+  const void* A1; const float* rstd1; const float* g1; const float* b1; float* dg1; float* db1; void* dP0;
+  const void* A2; const float* rstd2; const float* g2; const float* b2; float* dg2; float* db2;
+  const float* loc; float* dW; float* dbl;
+} magic_pano_in_bwd;
+typedef struct magic_ln_bwd_in {
+  int M, do_ln; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd; void* dx; float* dgamma; float* dbeta;
+  const int* idx[3]; int mod[3]; int off[3]; float* d[3]; int small[3];
+  const unsigned* drop_seed; float drop_p; unsigned site_dy, site_dx; int hot0; void* dxm;
+} magic_ln_bwd_in;
+int magic_embed_in_bwd_supported(int H, int Kin);
+int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa, const magic_ln_bwd_in* tx, void* stream);
 int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float* x, const void* dy, const void* y,
                         const float* gamma, const float* beta, const float* rstd,
                         float* dW, float* db, float* dgamma, float* dbeta, void* stream);

@@ -337,6 +337,44 @@ def test_input_embeddings_in_one_launch_are_bit_identical_to_the_per_op_chain(dt
     assert ct1.E.float().abs().max() > 0 and cp1.X0.float().abs().max() > 0 and (p_drop == 0 or (cp1.X0d == 0).float().mean() > 0.05)
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("task", ["sap", "mlm"])
+def test_input_embeddings_backward_in_one_launch_matches_the_per_op_sequence(task, p_drop, monkeypatch):
+    """magic_embed_in_bwd (round 4): the panorama stage's three LayerNorm backwards (+ nav-type / token-type / loc_linear gradients) and the text
+    embedding's backward in ONE launch, inside a whole training step: same loss (the forward is bit-identical), and every parameter gradient
+    agrees with the per-op sequence to fp32 summation order -- the stage's own parameters, the image projection (its dY operand dP0 is
+    bit-identical) and the embedding tables are named explicitly"""
+    from tests.test_model_gpu import KDL as _K  # noqa: F401
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(O, "EMBED_IN", fused)
+        m = student(p_drop)
+        m.train()
+        batch = synth.make_batch(task, batch_size=7, seed=5, step=0, dup_view_prob=0.3)
+        plan = build_plan(batch, task, torch.device(DEV))
+        m.dropout_seed = torch.tensor([4242, 99], dtype=torch.int32, device=DEV)
+        m.store.ensure_grads()
+        m.store.zero_grad()
+        out = m(synth.batch_to(batch, DEV), task, compute_loss=True, plan=plan)
+        m.backward()
+        torch.cuda.synchronize()
+        res[fused] = (float(out["loss"]), m.store.grad.clone(), m)
+    assert res[True][0] == res[False][0]
+    a, b, m = res[True][1], res[False][1], res[True][2]
+    top = b.abs().max().item()
+    names = ["bert.img_embeddings.img_layer_norm.weight", "bert.img_embeddings.img_layer_norm.bias", "bert.img_embeddings.loc_layer_norm.weight",
+             "bert.img_embeddings.loc_layer_norm.bias", "bert.img_embeddings.layer_norm.weight", "bert.img_embeddings.layer_norm.bias",
+             "bert.img_embeddings.loc_linear.weight", "bert.img_embeddings.loc_linear.bias", "bert.img_embeddings.nav_type_embedding.weight",
+             "bert.img_embeddings.img_linear.weight", "bert.img_embeddings.img_linear.bias", "bert.embeddings.token_type_embeddings.weight",
+             "bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight", "bert.embeddings.LayerNorm.weight"]
+    for nm in names:
+        off, cnt, _ = m.store.offsets[nm]
+        ga, gb = a[off:off + cnt], b[off:off + cnt]
+        assert gb.abs().max().item() > 0, nm
+        assert torch.allclose(ga, gb, rtol=2e-4, atol=2e-6 * top + 1e-5 * gb.abs().max().item()), (nm, (ga - gb).abs().max().item(), gb.abs().max().item())
+    assert torch.allclose(a, b, rtol=1e-3, atol=1e-5 * top), (a - b).abs().max().item()
+
+
 def test_node_inputs_backward_in_shared_launches_matches_the_per_op_sequence():
     """nodes_in_bwd (step-table gradient, both position-embedding backwards as a pair, the three transposed gathers as one launch) against
     vp_in_bwd + gmap_in_bwd: the gathered gradients are bit-identical (same rounding order), the parameter gradients agree to fp32

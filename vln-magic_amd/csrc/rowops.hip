@@ -677,6 +677,204 @@ __global__ __launch_bounds__(256) void embed_in_fwd_kernel(magic_pano_in a, LnfP
   else ln_fwd_body<T, NIT>(b, blockIdx.x - nA);
 }
 
+
+// Backward of the panorama encoder's input stage in ONE launch (round 4), together with the text embedding's LayerNorm backward:
+//   dy (gradient of the stage's output, masked by the output dropout) -> sum-LayerNorm backward -> dsum (rounded to T: the per-op path stores it)
+//     -> nav-type / token-type row gradients, gamma3 / beta3
+//   dsum -> image-LayerNorm backward -> dP0 (operand of the image projection's deferred weight gradient), gamma1 / beta1
+//   dsum -> location-LayerNorm backward -> dz -> dW_loc[H, Kin] += dz^T loc, db_loc += colsum(dz), gamma2 / beta2
+// i.e. magic_ln_bwd -> magic_ln_bwd -> magic_smallk_ln_bwd of the per-op path (three launches at the very end of the backward chain, each
+// ending in its own round of same-address parameter-gradient atomics) with the same formulas and rounding points: dP0 is bit-identical, the
+// parameter gradients agree to fp32 summation order.  Every parameter gradient of the stage -- 11 + Kin vectors of H -- is accumulated in
+// registers over the wave's rows and reduced through LDS four vectors at a time: one round of atomics per block instead of three.
+// Blocks >= nA run ln_bwd_body on a second, independent problem (the text embedding: three table scatters).
+#define PIB_KMAX 8
+struct magic_pano_in_bwd {
+  int M, Kin, pad0_, pad1_;
+  const void* dy; DropDesc ddy;
+  const void* X0; const float* rstd3; const float* g3; const float* b3; float* dg3; float* db3;
+  const int* nav_idx; float* d_nav; float* d_tok;
+  const void* A1; const float* rstd1; const float* g1; const float* b1; float* dg1; float* db1; void* dP0;
+  const void* A2; const float* rstd2; const float* g2; const float* b2; float* dg2; float* db2;
+  const float* loc; float* dW; float* dbl;
+};
+#ifdef PIB_VARIANT
+__device__ long long magic_pib_ticks[8];
+extern "C" int magic_debug_pib_ticks(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(magic_pib_ticks), sizeof(long long) * 8) == hipSuccess ? 0 : -2; }
+#define PIB_MARK(i) do { if (bid == 0 && threadIdx.x == 0) magic_pib_ticks[i] = wall_clock64(); } while (0)
+#else
+#define PIB_MARK(i)
+#endif
+template <typename T, int NIT, int NW>
+__device__ __forceinline__ void pano_in_bwd_body(const magic_pano_in_bwd& p, const int bid, const int nblk, float* red) {
+  constexpr int H = NIT * 128, NT = NW * 64, NS = 11 + PIB_KMAX, E = 2 * NIT;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, M = p.M, Kin = p.Kin;
+  PIB_MARK(0);
+  const DropState sdy = drop_init(p.ddy);
+  // accumulator sets: 0 dg3 | 1 db3 | 2-4 nav rows | 5 token-type row | 6 dg1 | 7 db1 | 8 dg2 | 9 db2 | 10 db_loc | 11.. dW_loc[:, k]
+  float acc[NS][E];
+#pragma unroll
+  for (int q = 0; q < NS; ++q)
+#pragma unroll
+    for (int i = 0; i < E; ++i) acc[q][i] = 0.f;
+  float g3r[E], b3r[E], i3r[E], g1r[E], b1r[E], i1r[E], g2r[E], b2r[E];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 128 + lane * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      g3r[2 * it + e] = p.g3[c + e]; b3r[2 * it + e] = p.b3[c + e]; i3r[2 * it + e] = g3r[2 * it + e] != 0.f ? 1.f / g3r[2 * it + e] : 0.f;
+      g1r[2 * it + e] = p.g1[c + e]; b1r[2 * it + e] = p.b1[c + e]; i1r[2 * it + e] = g1r[2 * it + e] != 0.f ? 1.f / g1r[2 * it + e] : 0.f;
+      g2r[2 * it + e] = p.g2[c + e]; b2r[2 * it + e] = p.b2[c + e];
+    }
+  }
+  // PIB_RPI rows per wave and iteration: their loads (four row vectors, three rstd, the nav id, the location features -- all cold: written by the
+  // forward a millisecond earlier) are issued together, so a wave pays one memory round trip per PIB_RPI rows
+  constexpr int PIB_RPI = 2;
+  PIB_MARK(1);
+  int it_ = 0;
+  for (int base = (bid * NW + wid) * PIB_RPI; base < M; base += nblk * NW * PIB_RPI) {
+    if (it_ < 2) { PIB_MARK(2 + 2 * it_); }
+    float dv[PIB_RPI][E], y3v[PIB_RPI][E], y1v[PIB_RPI][E], y2v[PIB_RPI][E], lxv[PIB_RPI][PIB_KMAX];
+    float rs3v[PIB_RPI], rs1v[PIB_RPI], rs2v[PIB_RPI];
+    int sidv[PIB_RPI];
+#pragma unroll
+    for (int u = 0; u < PIB_RPI; ++u) {
+      const int row = min(base + u, M - 1);          // clamped; rows >= M are skipped below
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 128 + lane * 2;
+        ld2<T>((const T*)p.dy + (long long)row * H + c, dv[u][2 * it], dv[u][2 * it + 1]);
+        ld2<T>((const T*)p.X0 + (long long)row * H + c, y3v[u][2 * it], y3v[u][2 * it + 1]);
+        ld2<T>((const T*)p.A1 + (long long)row * H + c, y1v[u][2 * it], y1v[u][2 * it + 1]);
+        ld2<T>((const T*)p.A2 + (long long)row * H + c, y2v[u][2 * it], y2v[u][2 * it + 1]);
+      }
+      rs3v[u] = p.rstd3[row]; rs1v[u] = p.rstd1[row]; rs2v[u] = p.rstd2[row];
+      sidv[u] = p.nav_idx[row];
+#pragma unroll
+      for (int k = 0; k < PIB_KMAX; ++k) lxv[u][k] = k < Kin ? p.loc[(long long)row * Kin + k] : 0.f;
+    }
+#ifdef PIB_VARIANT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (it_ < 2) { PIB_MARK(3 + 2 * it_); }
+    ++it_;
+#endif
+#pragma unroll
+    for (int u = 0; u < PIB_RPI; ++u) {
+    if (base + u >= M) break;
+    const int row = base + u;
+    float d[E], y3[E], y1[E], y2[E], lx[PIB_KMAX];
+#pragma unroll
+    for (int i = 0; i < E; ++i) { d[i] = dv[u][i]; y3[i] = y3v[u][i]; y1[i] = y1v[u][i]; y2[i] = y2v[u][i]; }
+#pragma unroll
+    for (int k = 0; k < PIB_KMAX; ++k) lx[k] = lxv[u][k];
+    if (sdy.on) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 128 + lane * 2;
+        d[2 * it] *= drop_mul(sdy, (unsigned)(row * H + c)); d[2 * it + 1] *= drop_mul(sdy, (unsigned)(row * H + c + 1));
+      }
+    }
+    const float rs3 = rs3v[u], rs1 = rs1v[u], rs2 = rs2v[u];
+    const int sid = sidv[u];
+    // ---- sum LayerNorm (ln_bwd_body's arithmetic)
+    float s1 = 0.f, s2 = 0.f, ga[E], xa[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      xa[i] = (y3[i] - b3r[i]) * i3r[i];
+      acc[0][i] += d[i] * xa[i]; acc[1][i] += d[i];
+      ga[i] = d[i] * g3r[i];
+      s1 += ga[i]; s2 += ga[i] * xa[i];
+    }
+    float m1 = wave_sum(s1) / H, m2 = wave_sum(s2) / H;
+    float ds[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const float v = rs3 * (ga[i] - m1 - xa[i] * m2);
+      acc[2][i] += sid == 0 ? v : 0.f; acc[3][i] += sid == 1 ? v : 0.f; acc[4][i] += sid == 2 ? v : 0.f;
+      acc[5][i] += v;
+      ds[i] = to_f(from_f<T>(v));                     // the per-op path hands dsum on as a T tensor
+    }
+    // ---- image LayerNorm -> dP0
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      xa[i] = (y1[i] - b1r[i]) * i1r[i];
+      acc[6][i] += ds[i] * xa[i]; acc[7][i] += ds[i];
+      ga[i] = ds[i] * g1r[i];
+      s1 += ga[i]; s2 += ga[i] * xa[i];
+    }
+    m1 = wave_sum(s1) / H; m2 = wave_sum(s2) / H;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      st2<T>((T*)p.dP0 + (long long)row * H + it * 128 + lane * 2, rs1 * (ga[2 * it] - m1 - xa[2 * it] * m2), rs1 * (ga[2 * it + 1] - m1 - xa[2 * it + 1] * m2));
+    // ---- location LayerNorm (smallk_ln_bwd_body's arithmetic) -> dz -> loc_linear gradients
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      xa[i] = g2r[i] != 0.f ? (y2[i] - b2r[i]) / g2r[i] : 0.f;
+      acc[8][i] += ds[i] * xa[i]; acc[9][i] += ds[i];
+      ga[i] = ds[i] * g2r[i];
+      s1 += ga[i]; s2 += ga[i] * xa[i];
+    }
+    m1 = wave_sum(s1) / H; m2 = wave_sum(s2) / H;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const float dz = rs2 * (ga[i] - m1 - xa[i] * m2);
+      acc[10][i] += dz;
+#pragma unroll
+      for (int k = 0; k < PIB_KMAX; ++k) acc[11 + k][i] += dz * lx[k];
+    }
+    }
+  }
+  PIB_MARK(6);
+#if defined(PIB_VARIANT) && PIB_VARIANT == 1
+  if (acc[0][0] == 123.456f) p.dg3[0] = acc[3][1] + acc[12][0] + acc[18][1];      // (timing variant: no tail)
+  return;
+#endif
+  // ---- one round of atomics per block: four accumulator sets at a time through LDS ([NW][4][H])
+  for (int q0 = 0; q0 < 11 + Kin; q0 += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = it * 128 + lane * 2;
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+          if (q == q0 + j) { v0 = acc[q][2 * it]; v1 = acc[q][2 * it + 1]; }
+        red[(wid * 4 + j) * H + c] = v0; red[(wid * 4 + j) * H + c + 1] = v1;
+      }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 4 * H; t += NT) {
+      const int j = t / H, c = t % H, q = q0 + j;
+      if (q < 11 + Kin) {
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) v += red[(ww * 4 + j) * H + c];
+        float* dst = q == 0 ? p.dg3 + c : q == 1 ? p.db3 + c : q <= 4 ? p.d_nav + (long long)(q - 2) * H + c : q == 5 ? p.d_tok + c
+                   : q == 6 ? p.dg1 + c : q == 7 ? p.db1 + c : q == 8 ? p.dg2 + c : q == 9 ? p.db2 + c : q == 10 ? p.dbl + c
+                   : p.dW + (long long)c * Kin + (q - 11);
+#if defined(PIB_VARIANT) && PIB_VARIANT == 2
+        if (v == 123.456f) atomicAdd(dst, v);                                         // (timing variant: no atomics)
+#else
+        if (v != 0.f) atomicAdd(dst, v);
+#endif
+      }
+    }
+    __syncthreads();
+  }
+}
+template <typename T, int NIT, int NW>
+__global__ __launch_bounds__(NW * 64) void embed_in_bwd_kernel(magic_pano_in_bwd a, LnbParams b, int nB) {
+  extern __shared__ __attribute__((aligned(16))) float red_dyn[];
+  // the text problem's blocks come FIRST in the grid: they are the long pole (the word-embedding scatter's atomics) and a block of this kernel
+  // fills a CU (16 waves), so blocks past the 256th wait for a free CU -- behind the panorama blocks they started a whole round late (68 us
+  // for the launch instead of ~35)
+  if ((int)blockIdx.x < nB) ln_bwd_body<T, NIT, NW>(b, blockIdx.x, nB, red_dyn);
+  else pano_in_bwd_body<T, NIT, NW>(a, blockIdx.x - nB, gridDim.x - nB, red_dyn);
+}
+
 // backward: dW[H,Kin], db[H], dgamma, dbeta (fp32 atomics, block-reduced).  SK_ROWS rows per block (NW waves);
 // dz rows are parked in LDS so the dW outer product is a cooperative (c,k) loop.  Every block ends in H (Kin + 3) same-address atomics,
 // so at H = 128 and M >= 4096 a block takes 64 rows with 16 waves (half as many blocks as the 32-row / 4-wave shape, 4 rows per wave).
@@ -1079,6 +1277,65 @@ int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t s
   else if (dtype == DT_F16) { if (nit == 1) LNB1(f16, 1, 16); else if (nit == 2) LNB1(f16, 2, 8); else if (nit == 3) LNB1(f16, 3, 4); else LNB1(f16, 6, 4); }
   else { if (nit == 1) LNB1(float, 1, 16); else if (nit == 2) LNB1(float, 2, 8); else if (nit == 3) LNB1(float, 3, 4); else LNB1(float, 6, 4); }
 #undef LNB1
+  return launch_status();
+}
+
+
+// public mirror of magic_ln_bwd's arguments for the second problem of magic_embed_in_bwd (the text embedding rows)
+struct magic_ln_bwd_in {
+  int M, do_ln; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd; void* dx; float* dgamma; float* dbeta;
+  const int* idx[3]; int mod[3]; int off[3]; float* d[3]; int small[3];
+  const unsigned* drop_seed; float drop_p; unsigned site_dy, site_dx; int hot0; void* dxm;
+};
+extern "C" int magic_embed_in_bwd_supported(int H, int Kin) { return (H == 128 || H == 256) && Kin >= 1 && Kin <= PIB_KMAX; }
+extern "C" int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa, const magic_ln_bwd_in* tx, void* stream) {
+  if (!pa || !dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  const magic_pano_in_bwd& a = *pa;
+  if (!magic_embed_in_bwd_supported(H, a.Kin)) return MAGIC_ERR_UNSUPPORTED;
+  if (a.M <= 0 || (long long)a.M * H > 0xFFFFFFFFll || !drop_args_ok(a.ddy.seed, a.ddy.p)) return MAGIC_ERR_ARG;
+  const void* req[] = {a.dy, a.X0, a.rstd3, a.g3, a.b3, a.dg3, a.db3, a.nav_idx, a.d_nav, a.d_tok, a.A1, a.rstd1, a.g1, a.b1, a.dg1, a.db1, a.dP0,
+                       a.A2, a.rstd2, a.g2, a.b2, a.dg2, a.db2, a.loc, a.dW, a.dbl};
+  for (const void* q : req)
+    if (!q) return MAGIC_ERR_ARG;
+  const int nit = H / 128, nw = lnb_waves(nit);
+  LnbParams b{};
+  int nb = 0;
+  if (tx) {
+    const magic_ln_bwd_in& t = *tx;
+    if (t.M <= 0 || !t.dy || (long long)t.M * H > 0xFFFFFFFFll || !drop_args_ok(t.drop_seed, t.drop_p)) return MAGIC_ERR_ARG;
+    if (t.hot0 >= 0 && (!t.idx[0] || !t.d[0])) return MAGIC_ERR_ARG;
+    const bool don = t.drop_p > 0.f;
+    if (don && t.site_dx && !t.dxm) return MAGIC_ERR_ARG;
+    if (t.do_ln && (!t.y || !t.gamma || !t.beta || !t.rstd)) return MAGIC_ERR_ARG;
+    if ((t.dgamma == nullptr) != (t.dbeta == nullptr)) return MAGIC_ERR_ARG;
+    for (int k = 0; k < 3; ++k)
+      if (t.small[k] && !t.idx[k]) return MAGIC_ERR_ARG;
+    b = LnbParams{t.M, t.dy, t.y, t.gamma, t.beta, t.rstd, t.dx, t.dgamma, t.dbeta,
+                  TabRef{t.d[0], t.idx[0], t.mod[0], t.off[0]}, t.d[0], t.small[0], TabRef{t.d[1], t.idx[1], t.mod[1], t.off[1]}, t.d[1], t.small[1],
+                  TabRef{t.d[2], t.idx[2], t.mod[2], t.off[2]}, t.d[2], t.small[2], t.do_ln,
+                  DropDesc{(don && t.site_dy) ? t.drop_seed : nullptr, t.site_dy, t.drop_p},
+                  (don && t.site_dx) ? t.dxm : nullptr, DropDesc{(don && t.site_dx) ? t.drop_seed : nullptr, t.site_dx, t.drop_p}, t.hot0};
+    nb = lnb_blocks(b, nit);
+  }
+  // one row per wave and iteration; every block ends in (11 + Kin) H atomics and fills a CU: the whole launch is kept to ONE round of the chip
+  int na = (a.M + 2 * nw - 1) / (2 * nw);               // (PIB_RPI = 2 rows per wave and iteration)
+  static int ncu = 0;
+  if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+  int room = ncu - nb > 64 ? ncu - nb : 64;
+  static int cap = -1;
+  // every block ends in (11 + Kin) H same-address-class atomics and those, not the rows, are the launch's time: 256 blocks 51 us, 96 blocks 30 us,
+  // 32 blocks 40 us (profiles/micro/embed_bwd_probe.py) -> 80 blocks by default
+  if (cap < 0) { const char* e = getenv("MAGIC_PIB_BLOCKS"); cap = e ? atoi(e) : 80; }
+  if (cap > 0 && room > cap) room = cap;
+  if (na > room) na = room;
+  const size_t sa = (size_t)nw * 4 * H * sizeof(float), sb = (size_t)(2 * nw + 9) * H * sizeof(float), shm = sa > sb ? sa : sb;
+  dim3 grid(na + nb), block(nw * 64);
+  hipStream_t st = (hipStream_t)stream;
+#define EIB(TY, NIT, NW) hipLaunchKernelGGL((embed_in_bwd_kernel<TY, NIT, NW>), grid, block, shm, st, a, b, nb)
+  if (dtype == DT_BF16) { if (nit == 1) EIB(bf16, 1, 16); else EIB(bf16, 2, 8); }
+  else if (dtype == DT_F16) { if (nit == 1) EIB(f16, 1, 16); else EIB(f16, 2, 8); }
+  else { if (nit == 1) EIB(float, 1, 16); else EIB(float, 2, 8); }
+#undef EIB
   return launch_status();
 }
 

@@ -669,12 +669,34 @@ class MagicNet:
         p = self.p
         dt, dp = self.self_stacks_bwd([(ct, p + "lang_encoder.layer.{}.", d_txt, dP_txt),
                                        (cp, p + "img_embeddings.pano_encoder.layer.{}.", d_pano, dP_pano)], on_iter=on_iter)
+        ll = self.lin(p + "img_embeddings.loc_linear.weight")
+        if O.embed_in_bwd_ok(self.H, ll.K):          # both embedding backwards -- three LayerNorm backwards of the panorama stage + the text one -- in ONE launch
+            return self._embeds_bwd(ct, cp, plan, dt, dp)
         # the two embedding LayerNorm backwards (text; panorama sum) are independent: one paired launch
         from . import lib as _L
         with _L.group():
             self._text_emb_bwd(ct, plan, dt)
             dsum = self._pano_emb_bwd(cp, plan, dp, stage=0)
         self._pano_emb_bwd(cp, plan, dp, stage=1, dsum=dsum)
+
+    def _embeds_bwd(self, ct, cp, plan, dt, dp):
+        """_text_emb_bwd + _pano_emb_bwd as one launch (csrc/rowops.hip embed_in_bwd_kernel) + the image projection's (deferred) weight gradient"""
+        p, H = self.p + "img_embeddings.", self.H
+        M = cp.Np * cp.V
+        n1, n2, n3 = self.ln(p + "img_layer_norm"), self.ln(p + "loc_layer_norm"), self.ln(p + "layer_norm")
+        ll, il = self.lin(p + "loc_linear.weight"), self.lin(p + "img_linear.weight")
+        nt = self.ln(self.p + "embeddings.LayerNorm")
+        dP0 = self.new(M, H)
+        tok_g = self.S.g(self.p + "embeddings.token_type_embeddings.weight")
+        O.embed_in_bwd(H, dict(M=M, Kin=ll.K, dy=dp, drop_dy=cp.edrop, X0=cp.X0, rstd3=cp.rstd_x0, g3=n3.g, b3=n3.b, dg3=n3.dg, db3=n3.db,
+                               nav_idx=plan["nav_types"], d_nav=self.S.g(p + "nav_type_embedding.weight"), d_tok=tok_g,
+                               A1=cp.A1, rstd1=cp.rstd_a1, g1=n1.g, b1=n1.b, dg1=n1.dg, db1=n1.db, dP0=dP0,
+                               A2=cp.A2, rstd2=cp.rstd_a2, g2=n2.g, b2=n2.b, dg2=n2.dg, db2=n2.db, loc=cp.loc, dW=ll.dW, dbl=ll.db),
+                       dict(M=ct.B * ct.L, dy=dt, y=ct.E, gamma=nt.g, beta=nt.b, rstd=ct.rstd_e, dx=None, dgamma=nt.dg, dbeta=nt.db, drop_dy=ct.edrop,
+                            dtabs=((plan["txt_ids"], 0, 0, self.S.g(self.p + "embeddings.word_embeddings.weight"), 0),
+                                   (None, ct.L, 2, self.S.g(self.p + "embeddings.position_embeddings.weight"), 0),
+                                   (None, 0, 0, tok_g, 0)), hot0=0))
+        O.linear_dw(dP0, cp.feats, il.dW, il.db, M)
 
     def text_bwd(self, c, plan, d_out, dP_init=None):
         p, H = self.p, self.H

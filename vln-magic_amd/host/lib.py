@@ -54,6 +54,8 @@ SIGNATURES = {
     "magic_cfp_loss": [i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_node_in_fwd": [i32, i32, i32, vp, vp],
     "magic_embed_in_fwd": [i32, i32, vp, vp, vp],
+    "magic_embed_in_bwd_supported": [i32, i32],
+    "magic_embed_in_bwd": [i32, i32, vp, vp, vp],
     "magic_csr_gather_multi": [i32, i32, i32, vp, vp],
     "magic_smallk_ln_bwd_pair": [i32, i32, vp, vp],
     "magic_csr_gather": [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp],
@@ -134,6 +136,20 @@ class LnIn(C.Structure):
     _fields_ = [("M", i32), ("do_ln", i32), ("in0", vp), ("in1", vp), ("tab", vp * 3), ("idx", vp * 3), ("mod", i32 * 3), ("off", i32 * 3),
                 ("gamma", vp), ("beta", vp), ("eps", f32), ("pad_", i32), ("out", vp), ("rstd", vp),
                 ("drop_seed", vp), ("drop_p", f32), ("site_in0", u32), ("site_out", u32), ("pad2_", u32), ("out_drop", vp)]
+
+
+class PanoInBwd(C.Structure):
+    """mirror of `magic_pano_in_bwd` (include/magic_hip.h)"""
+    _fields_ = [("M", i32), ("Kin", i32), ("pad0_", i32), ("pad1_", i32), ("dy", vp), ("ddy", DropD)] + \
+               [(n, vp) for n in ("X0", "rstd3", "g3", "b3", "dg3", "db3", "nav_idx", "d_nav", "d_tok", "A1", "rstd1", "g1", "b1", "dg1", "db1", "dP0",
+                                  "A2", "rstd2", "g2", "b2", "dg2", "db2", "loc", "dW", "dbl")]
+
+
+class LnBwdIn(C.Structure):
+    """mirror of `magic_ln_bwd_in` (include/magic_hip.h)"""
+    _fields_ = [("M", i32), ("do_ln", i32)] + [(n, vp) for n in ("dy", "y", "gamma", "beta", "rstd", "dx", "dgamma", "dbeta")] + \
+               [("idx", vp * 3), ("mod", i32 * 3), ("off", i32 * 3), ("d", vp * 3), ("small", i32 * 3),
+                ("drop_seed", vp), ("drop_p", f32), ("site_dy", u32), ("site_dx", u32), ("hot0", i32), ("dxm", vp)]
 
 
 class CsrProb(C.Structure):

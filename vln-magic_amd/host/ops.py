@@ -393,6 +393,50 @@ def embed_in_fwd(H, pano, text=None):
     L.call("magic_embed_in_fwd", L.dt(pano["X0"].dtype), H, C.addressof(a), tp, L.stream())
 
 
+_EIB_OK = {}
+
+
+def embed_in_bwd_ok(H, Kin):
+    if not EMBED_IN:
+        return False
+    key = (H, Kin)
+    if key not in _EIB_OK:
+        _EIB_OK[key] = bool(L.load().magic_embed_in_bwd_supported(H, Kin))
+    return _EIB_OK[key]
+
+
+def embed_in_bwd(H, pano, text=None):
+    """backward of the panorama encoder's input stage (sum / image / location LayerNorm backwards, nav-type / token-type / loc_linear gradients)
+    and, optionally, the text embedding's LayerNorm backward + table scatters as ONE launch (csrc/rowops.hip embed_in_bwd_kernel).
+    pano: dict(M, Kin, dy, X0, rstd3, g3, b3, dg3, db3, nav_idx, d_nav, d_tok, A1, rstd1, g1, b1, dg1, db1, dP0, A2, rstd2, g2, b2, dg2, db2,
+    loc, dW, dbl[, drop_dy=(seed, p, site)]); text: the keyword arguments of ln_bwd + M + dy."""
+    a = L.PanoInBwd()
+    a.M, a.Kin = int(pano["M"]), int(pano["Kin"])
+    for k in ("dy", "X0", "rstd3", "g3", "b3", "dg3", "db3", "nav_idx", "d_nav", "d_tok", "A1", "rstd1", "g1", "b1", "dg1", "db1", "dP0",
+              "A2", "rstd2", "g2", "b2", "dg2", "db2", "loc", "dW", "dbl"):
+        setattr(a, k, L.P(pano[k]))
+    seed, p_, site = _dr(pano.get("drop_dy"))
+    a.ddy.seed, a.ddy.site, a.ddy.p = seed, int(site), float(p_)
+    tp = None
+    if text is not None:
+        t = L.LnBwdIn()
+        t.M, t.do_ln = int(text["M"]), 1 if text.get("do_ln", True) else 0
+        for k in ("dy", "y", "gamma", "beta", "rstd", "dx", "dgamma", "dbeta"):
+            setattr(t, k, L.P(text.get(k)))
+        for i, tb in enumerate(text.get("dtabs", (None, None, None))):
+            idx, mod, off, dt_, small = _dtab(tb)
+            t.idx[i], t.mod[i], t.off[i], t.d[i], t.small[i] = idx, mod, off, dt_, small
+        d_dy, d_dx = text.get("drop_dy"), text.get("drop_dx")
+        dd = d_dy if (d_dy is not None and d_dy[1] > 0) else d_dx
+        seed, p_, _ = _dr(dd)
+        t.drop_seed, t.drop_p = seed, float(p_)
+        t.site_dy = int(d_dy[2]) if (p_ > 0 and d_dy is not None) else 0
+        t.site_dx = int(d_dx[2]) if (p_ > 0 and d_dx is not None) else 0
+        t.hot0, t.dxm = int(text.get("hot0", -1)), L.P(text.get("dxm"))
+        tp = C.addressof(t)
+    L.call("magic_embed_in_bwd", L.dt(pano["X0"].dtype), H, C.addressof(a), tp, L.stream())
+
+
 def smallk_ln_bwd(M, H, Kin, x, dy, y, gamma, beta, rstd, dW, db, dgamma, dbeta):
     L.call("magic_smallk_ln_bwd", L.dt(dy.dtype), M, H, Kin, L.P(x), L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(rstd),
            L.P(dW), L.P(db), L.P(dgamma), L.P(dbeta), L.stream())

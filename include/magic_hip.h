@@ -458,6 +458,13 @@ typedef struct { magic_rowbwd_seg seg[2]; int nseg, blocks0; float p_hidden; int
 int magic_rowbwd_supported(int dtype, int H, int I);
 int magic_rowbwd_params_bytes(void);
 int magic_rowbwd(int dtype, const void* params, int nbytes, void* stream);
+/* params.pad1 != 0 (round 4): dg2 / db2 / dg1 / db1 of every segment point at PARTIAL buffers, ceil(M / magic_rowbwd_rows(total rows)) x H
+ * floats each, contents undefined: every workgroup STORES its LayerNorm-gradient sums in its own row instead of adding them into the
+ * parameter gradients with atomics; magic_colsum_add then adds the rows up in block order.  (torch: `LayerNorm.weight.grad` accumulation.) */
+int magic_rowbwd_rows(long long total_rows);
+/* dsts[j][c] += sum over b < nblks[j] of parts[j][b * H + c], c < H, for n <= 96 jobs in one launch (host arrays of device pointers, consumed
+ * before return); the sum runs in block order, so the result is reproducible. */
+int magic_colsum_add(int H, int n, const float* const* parts, float* const* dsts, const int* nblks, void* stream);
 /* dst[off_i .. off_i + rows_i*cols_i) = transpose of the row-major [rows_i, cols_i] bf16 matrix at src[off_i ..), i < n (element
  * offsets into two congruent flat buffers; host arrays, consumed before return): the transposed weight shadow of magic_rowbwd. */
 int magic_transpose_spans(const void* src, void* dst, int n, const long long* offs, const int* rows, const int* cols, void* stream);

@@ -65,7 +65,7 @@ template <typename Hh> __device__ __forceinline__ void load_rows_img(Hh* s, int 
 template <int NRT, typename Hh>
 __device__ __forceinline__ void ln_bwd_rows(f32x4 (&acc)[NRT], const Hh* sY, const float* rstd_g, const float gm, const float bt, float* dgamma,
                                             float* dbeta, float* red, Hh* sSum, Hh* sDense, const int m0, const int M, const DropState& ds,
-                                            const int w, const int lane) {
+                                            const int w, const int lane, const int part_blk = -1) {
   constexpr int RB_ROWS = NRT * 16;
   const int g = lane >> 4, c16 = lane & 15, col = w * 16 + c16;
   const float ig = gm != 0.f ? 1.f / gm : 0.f;
@@ -87,7 +87,13 @@ __device__ __forceinline__ void ln_bwd_rows(f32x4 (&acc)[NRT], const Hh* sY, con
   if (dgamma) {      // fold the four row groups of the wave (lanes 16 apart), one atomic per column and workgroup
     pg += __shfl_xor(pg, 16, 64); pg += __shfl_xor(pg, 32, 64);
     pb += __shfl_xor(pb, 16, 64); pb += __shfl_xor(pb, 32, 64);
-    if (g == 0) { atomicAdd(dgamma + col, pg); atomicAdd(dbeta + col, pb); }
+    if (g == 0) {
+      // part_blk >= 0 (round 4): dgamma / dbeta are PARTIAL buffers [blocks][H] -- this workgroup's sums are stored in its own row and a
+      // column-sum launch (magic_colsum_add) adds them up later in block order: no atomics (240-330 workgroups x 512 same-address-class
+      // atomics per launch were 3 % of the training step), and the LayerNorm gradients of these blocks become reproducible
+      if (part_blk >= 0) { dgamma[(long long)part_blk * EH + col] = pg; dbeta[(long long)part_blk * EH + col] = pb; }
+      else { atomicAdd(dgamma + col, pg); atomicAdd(dbeta + col, pb); }
+    }
   }
   if (c16 == 0) {
 #pragma unroll
@@ -199,7 +205,7 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
       for (int r = 0; r < 4; ++r) acc[i][r] += to_f(sR[(i * 16 + 4 * g + r) * XS + colw]);
     dd.site = sg.site_out;
     const DropState ds = drop_init(dd);
-    ln_bwd_rows<NRT>(acc, sY2, sg.rstd2, gm2, bt2, sg.dg2, sg.db2, red, sFo, sD, m0, M, ds, w, lane);
+    ln_bwd_rows<NRT>(acc, sY2, sg.rstd2, gm2, bt2, sg.dg2, sg.db2, red, sFo, sD, m0, M, ds, w, lane, p.pad1 ? blk : -1);
 #pragma unroll
     for (int it = 0; it < ZIT; ++it) {
       const int id = tid + it * NWAVE * 64, r = id / (EI / 8), c = (id % (EI / 8)) * 8;
@@ -284,7 +290,7 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
     dd.site = sg.site_ao;
     const DropState ds = drop_init(dd);
     // d_aod goes where d_fod was: every wave is past the FFN product (the barrier above) and reads sD no more
-    ln_bwd_rows<NRT>(acc, sY1, sg.rstd1, gm1, bt1, sg.dg1, sg.db1, red, sAo, sD, m0, M, ds, w, lane);
+    ln_bwd_rows<NRT>(acc, sY1, sg.rstd1, gm1, bt1, sg.dg1, sg.db1, red, sAo, sD, m0, M, ds, w, lane, p.pad1 ? blk : -1);
   }
   __syncthreads();                               // d_ao / d_aod images complete
   copy_out(sAo, XS, sg.dao + (long long)m0 * EH, EH, nv, EH, tid);
@@ -332,6 +338,46 @@ static int rbw_ncu() {
   static int n = 0;
   if (!n) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); n = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }
   return n;
+}
+
+// rows per workgroup magic_rowbwd will choose for a launch of `total_rows` rows (all segments): a caller that passes PARTIAL gamma / beta
+// buffers (params.pad1 != 0) sizes them with it -- ceil(M_seg / rows) x H floats per vector
+extern "C" int magic_rowbwd_rows(long long total_rows) { return rbw_rows_env() ? rbw_rows_env() : (total_rows <= 16ll * rbw_ncu() ? 16 : 32); }
+
+// dst_j[c] += sum_b part_j[b][c], b < nblk_j, c < H, in block order (fixed: reproducible), for n <= 96 jobs in one launch: the finisher of the
+// partial-buffer mode of magic_rowbwd.  One 1024-thread workgroup per job: 1024 / H row groups take every (1024 / H)-th block, LDS fold.
+#define CSJ_MAX 96
+struct ColsumJobs { const float* part[CSJ_MAX]; float* dst[CSJ_MAX]; int nblk[CSJ_MAX]; int n; };
+__global__ __launch_bounds__(1024) void colsum_add_kernel(ColsumJobs js, int H) {
+  __shared__ float red[1024];
+  const int j = blockIdx.x, t = threadIdx.x, c = t % H, grp = t / H, ngrp = 1024 / H;
+  const float* part = js.part[j];
+  const int nb = js.nblk[j];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = grp;
+  for (; b + 3 * ngrp < nb; b += 4 * ngrp) {
+    s0 += part[(long long)b * H + c]; s1 += part[(long long)(b + ngrp) * H + c];
+    s2 += part[(long long)(b + 2 * ngrp) * H + c]; s3 += part[(long long)(b + 3 * ngrp) * H + c];
+  }
+  for (; b < nb; b += ngrp) s0 += part[(long long)b * H + c];
+  red[t] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0) {
+    float v = 0.f;
+    for (int g2 = 0; g2 < ngrp; ++g2) v += red[g2 * H + c];
+    js.dst[j][c] += v;
+  }
+}
+extern "C" int magic_colsum_add(int H, int n, const float* const* parts, float* const* dsts, const int* nblks, void* stream) {
+  if (n <= 0 || n > CSJ_MAX || !parts || !dsts || !nblks || H <= 0 || H > 1024 || (1024 % H)) return MAGIC_ERR_ARG;
+  ColsumJobs js;
+  js.n = n;
+  for (int i = 0; i < n; ++i) {
+    if (!parts[i] || !dsts[i] || nblks[i] <= 0) return MAGIC_ERR_ARG;
+    js.part[i] = parts[i]; js.dst[i] = dsts[i]; js.nblk[i] = nblks[i];
+  }
+  hipLaunchKernelGGL(colsum_add_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, js, H);
+  return launch_status();
 }
 
 extern "C" int magic_rowbwd_supported(int dtype, int H, int I) { return dtype_is16(dtype) && H == EH && I == EI; }

@@ -88,6 +88,8 @@ SIGNATURES = {
     "magic_rowbwd_supported": [i32, i32, i32],
     "magic_rowbwd_params_bytes": [],
     "magic_rowbwd": [i32, vp, i32, vp],
+    "magic_rowbwd_rows": [i64],
+    "magic_colsum_add": [i32, i32, vp, vp, vp, vp],
     "magic_transpose_spans": [vp, vp, i32, vp, vp, vp, vp],
     "magic_pack_frag_spans": [vp, vp, i32, vp, vp, vp, vp],
     "magic_layout_spans": [vp, vp, vp, i32, vp, vp, vp, vp, vp],

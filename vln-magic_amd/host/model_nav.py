@@ -155,6 +155,7 @@ def _queue_sync(model):
         model._sync_token = None
         if NAV_DEFER_DW:
             O.flush_dw()
+        O.flush_rbw_parts()           # partial LayerNorm gradients of the row-block backward launches of this pass (no-op when flush_dw ran)
         from .trainer import auto_sync
         auto_sync(model)
     torch.autograd.Variable._execution_engine.queue_callback(_done)

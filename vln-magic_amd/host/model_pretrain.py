@@ -264,6 +264,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         refuse_torch_ddp(self)
         self.store.sync_shadow()
         O.DEFER["queue"].clear(); O.DEFER["bytes"] = 0
+        O.RBW_JOBS.clear()
         if self.store.requires_grad:
             O.defer_dw(False)         # a compute_loss forward that was never followed by backward() left deferral armed
         self._arm_dropout()

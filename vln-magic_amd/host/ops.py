@@ -173,6 +173,7 @@ def dw_counters(device=None):
 
 def flush_dw(group=None, keep_active=False):
     group = group or DW_GROUP
+    flush_rbw_parts()
     q = DEFER["queue"]
     for dt in {e[0].dtype for e in q}:                 # one compute dtype per launch
         part = [e for e in q if e[0].dtype == dt]
@@ -639,18 +640,58 @@ def rowbwd_ok(dtype, H, I):
     return _RBW_OK[key]
 
 
+# LayerNorm gradients of the row-block backward through PARTIAL buffers (csrc/encbwd.hip ln_bwd_rows, magic_colsum_add): every workgroup stores
+# its gamma / beta sums in its own row, one column-sum launch per flush adds them up in block order -- instead of 512 atomics per workgroup
+# (measured: the atomics of the 12 row-block launches were 45 us of the 1.52 ms step).  MAGIC_RBW_ATOMICS=1: the atomic form.
+RBW_PARTIAL = not os.environ.get("MAGIC_RBW_ATOMICS")
+RBW_JOBS = []          # (partial buffer, destination gradient vector, blocks): queued by rowbwd(), launched by flush_rbw_parts()
+
+
+def flush_rbw_parts():
+    """add the queued partial LayerNorm gradients into the parameter gradients (<= 96 vectors per launch); called wherever the weight-gradient
+    queue is flushed, i.e. before anything reads those gradients (bucket exchanges, the gradient norm)"""
+    while RBW_JOBS:
+        # one launch holds each destination at most once (its read-modify-write is not atomic): a parameter used by several queued launches
+        # -- the navigator's per-step backwards share their LayerNorms -- goes out over as many launches, in queue order
+        chunk, rest, seen = [], [], set()
+        for job in RBW_JOBS:
+            key = job[1].data_ptr()
+            if key in seen or len(chunk) == 96:
+                rest.append(job)
+            else:
+                seen.add(key)
+                chunk.append(job)
+        RBW_JOBS[:] = rest
+        n = len(chunk)
+        parts, dsts, nb = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int * n)()
+        for i, (pt, dst, k) in enumerate(chunk):
+            parts[i], dsts[i], nb[i] = pt.data_ptr(), dst.data_ptr(), k
+        L.call("magic_colsum_add", int(chunk[0][1].numel()), n, C.addressof(parts), C.addressof(dsts), C.addressof(nb), L.stream())
+
+
 def rowbwd(segs, seed, p_hidden):
     """segs: 1 or 2 dicts with the fields of magic_rowbwd_seg (tensors) + M + flops: the per-token backward chain of one block per
     segment (csrc/encbwd.hip)"""
-    import ctypes as C
     _chk(1 <= len(segs) <= 2, "rowbwd segments")
     P = L.RbwParams()
     P.nseg, P.p_hidden, P.seed = len(segs), float(p_hidden), L.P(seed)
+    subst = {}
+    if RBW_PARTIAL:
+        rows = int(L.load().magic_rowbwd_rows(sum(int(sg["M"]) for sg in segs)))
+        P.pad1 = 1
+        for i, sg in enumerate(segs):
+            nblk = (int(sg["M"]) + rows - 1) // rows
+            for k in ("dg2", "db2", "dg1", "db1"):
+                dst = sg.get(k)
+                if dst is not None:
+                    pt = torch.empty(nblk * dst.numel(), dtype=torch.float32, device=dst.device)
+                    subst[(i, k)] = pt
+                    RBW_JOBS.append((pt, dst, nblk))
     for i, sg in enumerate(segs):
         S = P.seg[i]
         S.M, S.kt = int(sg["M"]), int(sg.get("kt", 12))
         for k in L.RBW_PTRS:
-            setattr(S, k, L.P(sg.get(k)))
+            setattr(S, k, L.P(subst.get((i, k), sg.get(k))))
         S.site_out, S.site_ao = int(sg.get("site_out", 0)), int(sg.get("site_ao", 0))
         if FLOPS["enabled"]:
             FLOPS["total"] += sg["flops"]

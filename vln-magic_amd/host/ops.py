@@ -153,7 +153,9 @@ DW_KEEP_BYTES = int(os.environ.get("MAGIC_DW_KEEP_GB", "8")) << 30
 DW_DETERMINISTIC = not os.environ.get("MAGIC_DW_ATOMICS")
 DW_WS_MAX_BYTES = int(os.environ.get("MAGIC_DW_WS_MAX_MB", "256")) << 20
 DW_COUNTERS = 1 << 17
+DW_WS_PERSIST_BYTES = int(os.environ.get("MAGIC_DW_WS_PERSIST_MB", "64")) << 20
 _DW_CNT = {}
+_DW_WS = {}
 
 
 def dw_counters(device=None):
@@ -168,7 +170,18 @@ def dw_counters(device=None):
         if torch.cuda.is_current_stream_capturing():
             return None                                # this launch takes per-call counters (a memset node)
         c = _DW_CNT[key] = torch.zeros(DW_COUNTERS, dtype=torch.int32, device=torch.device("cuda", key))
+        # ... and ONE partial-slot workspace shared by every launch that fits it (the headline step needs ~35 MB): a workspace per captured
+        # graph cost each capture a 57 MB pool allocation -- the streamed feed's in-window captures went from 9 to 34 ms apiece
+        _DW_WS[key] = torch.empty(DW_WS_PERSIST_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", key))
     return c
+
+
+def _dw_workspace(nf, device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    w = _DW_WS.get(key)
+    if w is not None and nf <= w.numel() and SIDE["stream"] is None:
+        return w
+    return torch.empty(max(nf, 1), dtype=torch.float32, device=device)
 
 
 def flush_dw(group=None, keep_active=False):
@@ -209,8 +222,8 @@ def dw_grouped(dt, arr, n, device, deterministic=None):
             cnt = dw_counters(device) if SIDE["stream"] is None else None
             if cnt is None:
                 cnt = torch.zeros(max(nc, 1), dtype=torch.int32, device=device)
-            ws = torch.empty(max(nf, 1), dtype=torch.float32, device=device)
-    L.call("magic_gemm_dw_grouped", L.dt(dt), n, arr, L.P(ws), nf if ws is not None else 0, L.P(cnt), int(cnt.numel()) if cnt is not None else 0, L.stream())
+            ws = _dw_workspace(nf, torch.device(device))
+    L.call("magic_gemm_dw_grouped", L.dt(dt), n, arr, L.P(ws), int(ws.numel()) if ws is not None else 0, L.P(cnt), int(cnt.numel()) if cnt is not None else 0, L.stream())
     return ws is not None
 
 

@@ -42,3 +42,4 @@ for _ in range(2):
 torch.cuda.synchronize()
 cProfile.run("iteration(); torch.cuda.synchronize()", "/tmp/nav.prof")
 pstats.Stats("/tmp/nav.prof").sort_stats("tottime").print_stats(40)
+pstats.Stats("/tmp/nav.prof").sort_stats("cumtime").print_stats(70)

@@ -108,6 +108,87 @@ __global__ __launch_bounds__(256) void pano_fuse_fwd_kernel(int N, int V, int H,
   }
 }
 
+
+// The same fusion with every view row read ONCE (round 4): wave w of the panorama's block owns views w, w + 4, ...; a lane keeps its column pairs of
+// those <= 10 rows in registers across the scoring pass, the softmax and the weighted sum (the kernel above reads x twice, the second time as
+// 36 dependent 2-byte loads per thread with half the block idle: 17 us for 290 panoramas, where one round trip to memory is ~3).  Same
+// arithmetic order per view; the weighted sum adds the views of a wave first and the four waves after (fp32: the results differ from the
+// kernel above in the last bits of the fp32 sum, not in what is rounded to T).
+#define PFF_VPW 10
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void pano_fuse_fwd_reg_kernel(int N, int V, const T* x, const int* lens, const float* wf, const float* bf,
+                                                                T* fused, float* probs, const T* P, int nh, int inner, float* pmean) {
+  constexpr int H = NIT * 128;
+  __shared__ float sc[64];
+  __shared__ float part[4][H];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const T* xb = x + (long long)n * V * H;
+  float xv[PFF_VPW][2 * NIT], wr[2 * NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) { wr[2 * it] = wf[it * 128 + lane * 2]; wr[2 * it + 1] = wf[it * 128 + lane * 2 + 1]; }
+#pragma unroll
+  for (int j = 0; j < PFF_VPW; ++j) {
+    const int v = wid + 4 * j;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      xv[j][2 * it] = 0.f; xv[j][2 * it + 1] = 0.f;
+      if (v < V) {
+        if constexpr (sizeof(T) == 2) {
+          const unsigned u = *(const unsigned*)(xb + (long long)v * H + it * 128 + lane * 2);
+          T lo, hi;
+          __builtin_memcpy(&lo, &u, 2); __builtin_memcpy(&hi, (const char*)&u + 2, 2);
+          xv[j][2 * it] = to_f(lo); xv[j][2 * it + 1] = to_f(hi);
+        } else {
+          const float2 u = *(const float2*)(xb + (long long)v * H + it * 128 + lane * 2);
+          xv[j][2 * it] = u.x; xv[j][2 * it + 1] = u.y;
+        }
+      }
+    }
+  }
+  if (P) {        // the panorama's attention map averaged over heads, while the view rows are on their way
+    const T* pb = P + (long long)n * nh * inner;
+    for (int r = tid; r < inner; r += 256) {
+      float s = 0.f;
+      for (int h = 0; h < nh; ++h) s += to_f(pb[(long long)h * inner + r]);
+      pmean[(long long)n * inner + r] = s / nh;
+    }
+  }
+  const int len = lens[n];
+  const float b0 = bf[0];
+#pragma unroll
+  for (int j = 0; j < PFF_VPW; ++j) {
+    const int v = wid + 4 * j;
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * NIT; ++i) d += xv[j][i] * wr[i];
+    d = wave_sum(d);
+    if (lane == 0 && v < V) sc[v] = d + b0 + (v < len ? 0.f : -10000.0f);
+  }
+  __syncthreads();
+  if (wid == 0) {
+    float s = lane < V ? sc[lane] : -3.0e38f;
+    const float mx = wave_max(s);
+    float e = lane < V ? __expf(s - mx) : 0.f;
+    const float z = wave_sum(e);
+    if (lane < V) { sc[lane] = e / z; probs[(long long)n * V + lane] = e / z; }
+  }
+  __syncthreads();
+  float a[2 * NIT];
+#pragma unroll
+  for (int i = 0; i < 2 * NIT; ++i) a[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < PFF_VPW; ++j) {
+    const int v = wid + 4 * j;
+    const float pv = v < V ? sc[v] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * NIT; ++i) a[i] += pv * xv[j][i];
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) { part[wid][it * 128 + lane * 2] = a[2 * it]; part[wid][it * 128 + lane * 2 + 1] = a[2 * it + 1]; }
+  __syncthreads();
+  for (int c = tid; c < H; c += 256) fused[(long long)n * H + c] = from_f<T>((part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
+}
+
 // backward: dx[n,v,:] += p_v * df + ds_v * wf ;  ds_v = p_v (dp_v - sum p dp), dp_v = df . x_v ; dwf, dbf atomics
 // PF_PB panoramas per block, four waves each: wave w of a panorama owns views w, w+4, ... in both passes (a lane owns the column pairs
 // {128 it + 2 lane}); the wf / bf gradients are reduced over the block's waves before ONE atomic per element and block (same-address
@@ -395,6 +476,16 @@ extern "C" int magic_pano_fuse_fwd(int dtype, int N, int V, int H, const void* x
   if (N <= 0 || V <= 0 || V > 64 || H <= 0 || (P && (nh <= 0 || inner <= 0 || !pmean))) return MAGIC_ERR_ARG;
   dim3 grid(N), block(256);
   hipStream_t st = (hipStream_t)stream;
+  static int reg_form = -1;
+  if (reg_form < 0) { const char* e = getenv("MAGIC_PANO_FUSE_REG"); reg_form = e ? atoi(e) : 1; }
+  if (reg_form && V <= 4 * PFF_VPW && (H == 128 || H == 256 || H == 384 || H == 768)) {      // every view row read once, kept in registers
+#define PFR(TY, NIT) hipLaunchKernelGGL((pano_fuse_fwd_reg_kernel<TY, NIT>), grid, block, 0, st, N, V, (const TY*)x, lens, wf, bf, (TY*)fused, probs, (const TY*)P, nh, inner, pmean)
+#define PFR_T(TY) do { if (H == 128) PFR(TY, 1); else if (H == 256) PFR(TY, 2); else if (H == 384) PFR(TY, 3); else PFR(TY, 6); } while (0)
+    if (dtype == DT_BF16) PFR_T(bf16); else if (dtype == DT_F16) PFR_T(f16); else PFR_T(float);
+#undef PFR_T
+#undef PFR
+    return launch_status();
+  }
   if (dtype == DT_BF16) hipLaunchKernelGGL(pano_fuse_fwd_kernel<bf16>, grid, block, 0, st, N, V, H, (const bf16*)x, lens, wf, bf, (bf16*)fused, probs, (const bf16*)P, nh, inner, pmean);
   else if (dtype == DT_F16) hipLaunchKernelGGL(pano_fuse_fwd_kernel<f16>, grid, block, 0, st, N, V, H, (const f16*)x, lens, wf, bf, (f16*)fused, probs, (const f16*)P, nh, inner, pmean);
   else hipLaunchKernelGGL(pano_fuse_fwd_kernel<float>, grid, block, 0, st, N, V, H, (const float*)x, lens, wf, bf, (float*)fused, probs, (const float*)P, nh, inner, pmean);

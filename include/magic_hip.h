@@ -184,7 +184,10 @@ typedef struct magic_ln_bwd_in {
   const unsigned* drop_seed; float drop_p; unsigned site_dy, site_dx; int hot0; void* dxm;
 } magic_ln_bwd_in;
 int magic_embed_in_bwd_supported(int H, int Kin);
-int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa, const magic_ln_bwd_in* tx, void* stream);
+/* cs_*: n_cs <= 96 column-sum jobs (the arguments of magic_colsum_add; their vectors have H columns) served by extra workgroups of the same
+ * launch: every magic_rowbwd launch of a backward pass precedes this one, so its partial LayerNorm gradients can be finished here. */
+int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa, const magic_ln_bwd_in* tx,
+                       int n_cs, const float* const* cs_parts, float* const* cs_dsts, const int* cs_nblks, void* stream);
 int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float* x, const void* dy, const void* y,
                         const float* gamma, const float* beta, const float* rstd,
                         float* dW, float* db, float* dgamma, float* dbeta, void* stream);

@@ -71,7 +71,7 @@ if os.environ.get("PIB_VARIANTS"):       # timing variants of the fused kernel (
         objs = [os.path.join(CS, f) for f in os.listdir(CS) if f.endswith(".o") and f != "rowops.o"]
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(BIN, f"rowops_v{v}.o")] + objs + ["-o", so], check=True)
         lib = C.CDLL(so, mode=os.RTLD_NOW | os.RTLD_DEEPBIND)       # its OWN kernel stubs, not those of the libmagic_hip.so loaded above
-        lib.magic_embed_in_bwd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.magic_embed_in_bwd.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         a = L.PanoInBwd()
         a.M, a.Kin = M, Kin
         for k in ("dy", "X0", "rstd3", "g3", "b3", "dg3", "db3", "nav_idx", "d_nav", "d_tok", "A1", "rstd1", "g1", "b1", "dg1", "db1", "dP0",
@@ -84,7 +84,7 @@ if os.environ.get("PIB_VARIANTS"):       # timing variants of the fused kernel (
         tk = [t[i] for i in range(7)]
         print("   block 0 ticks (us): start->prologue %.2f, it0 loads %.2f, it0 compute %.2f, it1 loads %.2f, it1 compute->end %.2f" %
               ((tk[1] - tk[0]) / 100, (tk[3] - tk[2]) / 100, (tk[4] - tk[3]) / 100, (tk[5] - tk[4]) / 100, (tk[6] - tk[5]) / 100))
-        print(f"  variant {v} ({'no tail' if v == 1 else 'no atomics'})  {timeit(lambda: lib.magic_embed_in_bwd(1, H, C.addressof(a), None, st)):.1f} us")
+        print(f"  variant {v} ({'no tail' if v == 1 else 'no atomics'})  {timeit(lambda: lib.magic_embed_in_bwd(1, H, C.addressof(a), None, 0, None, None, None, st)):.1f} us")
 print(f"text embedding alone (ln_bwd)     {timeit(text_alone):.1f} us")
 print(f"both in one launch                {timeit(lambda: O.embed_in_bwd(H, pano, text)):.1f} us")
 print(f"per-op sequence (3 launches)      {timeit(per_op):.1f} us")

@@ -142,3 +142,30 @@ static inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MAGIC_OK : MAGIC_ERR_LAUNCH;
 }
+
+// dst_j[c] += sum_b part_j[b][c], b < nblk_j, c < H, in block order (reproducible): the finisher of the partial-row LayerNorm gradients of
+// magic_rowbwd (csrc/encbwd.hip), as a standalone launch (magic_colsum_add) or as extra workgroups of magic_embed_in_bwd.  One workgroup per
+// job; blockDim.x / H row groups take every (blockDim.x / H)-th block, LDS fold.  `red`: blockDim.x floats of LDS.
+#define CSJ_MAX 96
+struct ColsumJobs { const float* part[CSJ_MAX]; float* dst[CSJ_MAX]; int nblk[CSJ_MAX]; int n; };
+__device__ __forceinline__ void colsum_body(const ColsumJobs& js, const int j, const int H, float* red) {
+  const int t = threadIdx.x, c = t % H, grp = t / H, ngrp = blockDim.x / H;
+  const float* part = js.part[j];
+  const int nb = js.nblk[j];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (grp < ngrp) {
+    int b = grp;
+    for (; b + 3 * ngrp < nb; b += 4 * ngrp) {
+      s0 += part[(long long)b * H + c]; s1 += part[(long long)(b + ngrp) * H + c];
+      s2 += part[(long long)(b + 2 * ngrp) * H + c]; s3 += part[(long long)(b + 3 * ngrp) * H + c];
+    }
+    for (; b < nb; b += ngrp) s0 += part[(long long)b * H + c];
+  }
+  red[t] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0) {
+    float v = 0.f;
+    for (int g2 = 0; g2 < ngrp; ++g2) v += red[g2 * H + c];
+    js.dst[j][c] += v;
+  }
+}

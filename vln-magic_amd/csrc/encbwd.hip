@@ -346,27 +346,9 @@ extern "C" int magic_rowbwd_rows(long long total_rows) { return rbw_rows_env() ?
 
 // dst_j[c] += sum_b part_j[b][c], b < nblk_j, c < H, in block order (fixed: reproducible), for n <= 96 jobs in one launch: the finisher of the
 // partial-buffer mode of magic_rowbwd.  One 1024-thread workgroup per job: 1024 / H row groups take every (1024 / H)-th block, LDS fold.
-#define CSJ_MAX 96
-struct ColsumJobs { const float* part[CSJ_MAX]; float* dst[CSJ_MAX]; int nblk[CSJ_MAX]; int n; };
 __global__ __launch_bounds__(1024) void colsum_add_kernel(ColsumJobs js, int H) {
   __shared__ float red[1024];
-  const int j = blockIdx.x, t = threadIdx.x, c = t % H, grp = t / H, ngrp = 1024 / H;
-  const float* part = js.part[j];
-  const int nb = js.nblk[j];
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = grp;
-  for (; b + 3 * ngrp < nb; b += 4 * ngrp) {
-    s0 += part[(long long)b * H + c]; s1 += part[(long long)(b + ngrp) * H + c];
-    s2 += part[(long long)(b + 2 * ngrp) * H + c]; s3 += part[(long long)(b + 3 * ngrp) * H + c];
-  }
-  for (; b < nb; b += ngrp) s0 += part[(long long)b * H + c];
-  red[t] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (grp == 0) {
-    float v = 0.f;
-    for (int g2 = 0; g2 < ngrp; ++g2) v += red[g2 * H + c];
-    js.dst[j][c] += v;
-  }
+  colsum_body(js, blockIdx.x, H, red);
 }
 extern "C" int magic_colsum_add(int H, int n, const float* const* parts, float* const* dsts, const int* nblks, void* stream) {
   if (n <= 0 || n > CSJ_MAX || !parts || !dsts || !nblks || H <= 0 || H > 1024 || (1024 % H)) return MAGIC_ERR_ARG;

@@ -866,13 +866,16 @@ __device__ __forceinline__ void pano_in_bwd_body(const magic_pano_in_bwd& p, con
   }
 }
 template <typename T, int NIT, int NW>
-__global__ __launch_bounds__(NW * 64) void embed_in_bwd_kernel(magic_pano_in_bwd a, LnbParams b, int nB) {
+__global__ __launch_bounds__(NW * 64) void embed_in_bwd_kernel(magic_pano_in_bwd a, LnbParams b, int nB, ColsumJobs cs) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
+  // the LAST cs.n workgroups of the grid: the column sums of the row-block backward's partial LayerNorm gradients (csrc/encbwd.hip) -- every
+  // row-block launch of the backward precedes this one, and the launch has CUs to spare
+  if ((int)blockIdx.x >= (int)gridDim.x - cs.n) { colsum_body(cs, blockIdx.x - (gridDim.x - cs.n), NIT * 128, red_dyn); return; }
   // the text problem's blocks come FIRST in the grid: they are the long pole (the word-embedding scatter's atomics) and a block of this kernel
   // fills a CU (16 waves), so blocks past the 256th wait for a free CU -- behind the panorama blocks they started a whole round late (68 us
   // for the launch instead of ~35)
   if ((int)blockIdx.x < nB) ln_bwd_body<T, NIT, NW>(b, blockIdx.x, nB, red_dyn);
-  else pano_in_bwd_body<T, NIT, NW>(a, blockIdx.x - nB, gridDim.x - nB, red_dyn);
+  else pano_in_bwd_body<T, NIT, NW>(a, blockIdx.x - nB, gridDim.x - nB - cs.n, red_dyn);
 }
 
 // backward: dW[H,Kin], db[H], dgamma, dbeta (fp32 atomics, block-reduced).  SK_ROWS rows per block (NW waves);
@@ -1288,8 +1291,16 @@ struct magic_ln_bwd_in {
   const unsigned* drop_seed; float drop_p; unsigned site_dy, site_dx; int hot0; void* dxm;
 };
 extern "C" int magic_embed_in_bwd_supported(int H, int Kin) { return (H == 128 || H == 256) && Kin >= 1 && Kin <= PIB_KMAX; }
-extern "C" int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa, const magic_ln_bwd_in* tx, void* stream) {
+extern "C" int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa, const magic_ln_bwd_in* tx,
+                                  int n_cs, const float* const* cs_parts, float* const* cs_dsts, const int* cs_nblks, void* stream) {
   if (!pa || !dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  if (n_cs < 0 || n_cs > CSJ_MAX || (n_cs > 0 && (!cs_parts || !cs_dsts || !cs_nblks))) return MAGIC_ERR_ARG;
+  ColsumJobs cs;
+  cs.n = n_cs;
+  for (int i = 0; i < n_cs; ++i) {
+    if (!cs_parts[i] || !cs_dsts[i] || cs_nblks[i] <= 0) return MAGIC_ERR_ARG;
+    cs.part[i] = cs_parts[i]; cs.dst[i] = cs_dsts[i]; cs.nblk[i] = cs_nblks[i];
+  }
   const magic_pano_in_bwd& a = *pa;
   if (!magic_embed_in_bwd_supported(H, a.Kin)) return MAGIC_ERR_UNSUPPORTED;
   if (a.M <= 0 || (long long)a.M * H > 0xFFFFFFFFll || !drop_args_ok(a.ddy.seed, a.ddy.p)) return MAGIC_ERR_ARG;
@@ -1329,9 +1340,9 @@ extern "C" int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa,
   if (cap > 0 && room > cap) room = cap;
   if (na > room) na = room;
   const size_t sa = (size_t)nw * 4 * H * sizeof(float), sb = (size_t)(2 * nw + 9) * H * sizeof(float), shm = sa > sb ? sa : sb;
-  dim3 grid(na + nb), block(nw * 64);
+  dim3 grid(na + nb + n_cs), block(nw * 64);
   hipStream_t st = (hipStream_t)stream;
-#define EIB(TY, NIT, NW) hipLaunchKernelGGL((embed_in_bwd_kernel<TY, NIT, NW>), grid, block, shm, st, a, b, nb)
+#define EIB(TY, NIT, NW) hipLaunchKernelGGL((embed_in_bwd_kernel<TY, NIT, NW>), grid, block, shm, st, a, b, nb, cs)
   if (dtype == DT_BF16) { if (nit == 1) EIB(bf16, 1, 16); else EIB(bf16, 2, 8); }
   else if (dtype == DT_F16) { if (nit == 1) EIB(f16, 1, 16); else EIB(f16, 2, 8); }
   else { if (nit == 1) EIB(float, 1, 16); else EIB(float, 2, 8); }

@@ -55,7 +55,7 @@ SIGNATURES = {
     "magic_node_in_fwd": [i32, i32, i32, vp, vp],
     "magic_embed_in_fwd": [i32, i32, vp, vp, vp],
     "magic_embed_in_bwd_supported": [i32, i32],
-    "magic_embed_in_bwd": [i32, i32, vp, vp, vp],
+    "magic_embed_in_bwd": [i32, i32, vp, vp, i32, vp, vp, vp, vp],
     "magic_csr_gather_multi": [i32, i32, i32, vp, vp],
     "magic_smallk_ln_bwd_pair": [i32, i32, vp, vp],
     "magic_csr_gather": [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp],

@@ -408,6 +408,7 @@ def embed_in_fwd(H, pano, text=None):
 
 
 _EIB_OK = {}
+EIB_KEEP = []
 
 
 def embed_in_bwd_ok(H, Kin):
@@ -448,7 +449,25 @@ def embed_in_bwd(H, pano, text=None):
         t.site_dx = int(d_dx[2]) if (p_ > 0 and d_dx is not None) else 0
         t.hot0, t.dxm = int(text.get("hot0", -1)), L.P(text.get("dxm"))
         tp = C.addressof(t)
-    L.call("magic_embed_in_bwd", L.dt(pano["X0"].dtype), H, C.addressof(a), tp, L.stream())
+    # the partial LayerNorm gradients the row-block launches of this backward queued (their vectors are H wide, each destination once) ride along
+    take, keep, seen = [], [], set()
+    for job in RBW_JOBS:
+        key = job[1].data_ptr()
+        if len(take) < 96 and key not in seen and job[1].numel() == H:
+            seen.add(key)
+            take.append(job)
+        else:
+            keep.append(job)
+    if keep:                       # (a destination queued twice: everything goes through flush_rbw_parts, in queue order)
+        take = []
+    else:
+        RBW_JOBS[:] = []
+    n = len(take)
+    parts, dsts, nb = (C.c_void_p * max(n, 1))(), (C.c_void_p * max(n, 1))(), (C.c_int * max(n, 1))()
+    for i, (pt, dst, k) in enumerate(take):
+        parts[i], dsts[i], nb[i] = pt.data_ptr(), dst.data_ptr(), k
+    L.call("magic_embed_in_bwd", L.dt(pano["X0"].dtype), H, C.addressof(a), tp, n, C.addressof(parts), C.addressof(dsts), C.addressof(nb), L.stream())
+    EIB_KEEP[:] = [take]           # the partial buffers stay alive until the next call (the launch reads them asynchronously)
 
 
 def smallk_ln_bwd(M, H, Kin, x, dy, y, gamma, beta, rstd, dW, db, dgamma, dbeta):

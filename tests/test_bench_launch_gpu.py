@@ -25,3 +25,6 @@ def test_bench_two_ranks_one_card_through_self_launcher():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 96
     assert sorted(j["rccl"]["ranks_seen"]) == [0, 1] and j["value"] > 0
+    # two ranks on one card: the trainer must have noticed and kept the launches that need a whole grid resident at once off -- a neighbour's
+    # kernels can take the slots their late workgroups need (bench.py ends with trainer.check_health(), which raises if a hand-off gave up)
+    assert j["health"]["card_shared_with_other_ranks"] is True and j["health"]["row_split_encoder_launches"] is False

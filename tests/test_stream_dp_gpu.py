@@ -44,6 +44,8 @@ def _worker(rank, world, port, q):
             g_s.keep_mlm_logits = False
             tr = PretrainStep(g_s, g_t, lr=5e-5, warmup_steps=2, num_train_steps=40, sparse_embedding_rows=4 * 80)
             assert tr.sync.world == 2 and tr.sync.overlap
+            from magic_amd.host import ops as O
+            assert tr.sync.card_shared and not O.ENC_ROW_SPLIT and not O.XENC_ROW_SPLIT, "both ranks sit on the one card: row-split launches must be off"
             return g_s, tr
         sA, tA = trainer()
         want = []
@@ -66,6 +68,7 @@ def _worker(rank, world, port, q):
                     torch.cuda.synchronize()
                     got.append({k: float(out[k]) for k in ("loss", "supervised_loss", "kdl_loss")})
             assert tB.global_step == len(SCHED)
+            tB.check_health()
             worst = max(abs(g[k] - w[k]) / max(abs(w[k]), 1e-6) for g, w in zip(got, want) for k in g)
             wa, wb = sA.store.flat, sB.store.flat
             every = [torch.empty_like(wb) for _ in range(world)]

@@ -517,6 +517,20 @@ def attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, dctx, B, nh, Nq, Nk, H, scale, dP_init
 FUSED_ENC = not os.environ.get("MAGIC_NO_FUSED_ENC")
 ENC_ROW_SPLIT = os.environ.get("MAGIC_ENC_RS", "1") != "0"      # row-split form of the whole-encoder forward (csrc/encoder.hip, encoder_rs_kernel)
 XENC_ROW_SPLIT = os.environ.get("MAGIC_XENC_RS", "1") != "0"   # the same for the cross-modal encoders (xencoder_rs_kernel)
+CARD_SHARED = [False]
+
+
+def card_is_shared(shared=True):
+    """Tell the launch layer that other processes run kernels on this card (several ranks mapped onto one device: a rehearsal of the
+    data-parallel path on a one-card box).  The row-split encoder launches hand activations between workgroups of ONE launch and need
+    all of them resident at once; a neighbour's kernels can take the slots the late workgroups need, the bounded waits then give up
+    and `check_encoder_health` raises.  On a shared card the one-workgroup-per-sample forms (no waits between workgroups) run instead."""
+    global ENC_ROW_SPLIT, XENC_ROW_SPLIT
+    CARD_SHARED[0] = bool(shared)
+    if shared:
+        ENC_ROW_SPLIT = XENC_ROW_SPLIT = False
+
+
 ENC_SYNC_LAST = [None]                                          # the last launch's sync words (word 0 = 1: a bounded wait gave up) -- tests read it
 _ENC_OK = {}
 

@@ -157,6 +157,7 @@ class GradSync:
         self.store = store
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.chunk = chunk_elems
+        self.card_shared = self._ranks_share_a_card()
         self.stream = torch.cuda.Stream() if (self.world > 1 and store.device.type == "cuda") else None
         self.overlap = (not os.environ.get("MAGIC_DDP_NO_OVERLAP")) if overlap is None else overlap
         g0d, g0n = store.first_offset(LATE_PREFIXES, True), store.first_offset(LATE_PREFIXES, False)
@@ -171,6 +172,27 @@ class GradSync:
         self.table = store.offsets.get(EMB_TABLE)            # (offset, numel, (rows, H)) -- first tensor of the buffer
         self.sparse_cap = sparse_rows_cap
         self._pending = []
+
+    def _ranks_share_a_card(self):
+        """do two ranks of this job sit on one physical device (a rehearsal on a one-card box)?  Then the launch layer must not use the
+        forms that need a whole launch resident at once (ops.card_is_shared): decided once, the same way on every rank, before anything
+        is captured."""
+        dev = self.store.device
+        if self.world == 1 or dev.type != "cuda":
+            return False
+        import hashlib
+        import socket
+        props = torch.cuda.get_device_properties(dev)
+        me = repr((socket.gethostname(), str(getattr(props, "uuid", "")), getattr(props, "pci_domain_id", -1), getattr(props, "pci_bus_id", -1),
+                   getattr(props, "pci_device_id", -1), os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")), dev.index))
+        # a plain int64 all-gather on the device, like every other exchange of this class (no pickled-object collective on the data path)
+        mine = torch.tensor([int.from_bytes(hashlib.sha1(me.encode()).digest()[:7], "big")], dtype=torch.int64, device=dev)
+        seen = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(seen, mine)
+        shared = len({int(t) for t in seen}) < self.world
+        if shared:
+            O.card_is_shared(True)
+        return shared
 
     # ---- primitives ------------------------------------------------------------------------------------------
     def _ranges(self, ranges):
@@ -378,7 +400,8 @@ class PretrainStep:
         (csrc/encoder.hip).  Synchronises: call it where a loss is read anyway (logging, validation, checkpoint)."""
         if self.on_gpu:
             O.check_encoder_health(self.dev)
-        return {"skipped_optimizer_steps": self.opt.skipped_steps() if self.on_gpu else 0}
+        return {"skipped_optimizer_steps": self.opt.skipped_steps() if self.on_gpu else 0, "card_shared_with_other_ranks": self.sync.card_shared,
+                "row_split_encoder_launches": bool(O.ENC_ROW_SPLIT)}
 
     def gate_reset(self):
         """re-arm a gate that switched itself off (e.g. after a profiler run that serialised the streams)"""

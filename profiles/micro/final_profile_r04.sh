@@ -27,7 +27,8 @@ pmc)
   echo pass C done
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_d -- python3 $R/bench.py $EAGER > /dev/null 2> $O/r04_pmc_d.err || exit 1
   echo pass D done
-  python3 $R/profiles/pmc_kernels.py $O/r04_kernel_stats.csv $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d > $O/r04_pmc_kernels.json
+  STATS=$O/r04_kernel_stats.csv; [ -f $STATS ] || STATS=$R/profiles/r04_rocprofv3_kernel_stats.csv      # (a `prof` leg of this call, else the committed one)
+  python3 $R/profiles/pmc_kernels.py $STATS $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d > $O/r04_pmc_kernels.json
   python3 $R/profiles/pmc_traffic.py $O/pmc_c $O/pmc_d 9 > $O/r04_pmc_traffic.json
   rm -rf $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d
   head -c 1500 $O/r04_pmc_kernels.json; echo ;;

@@ -12,9 +12,11 @@
 // One 512-thread workgroup owns 32 rows (two 16-row MFMA tiles).  Weights are not staged through LDS: every weight element is used by
 // exactly two MFMAs of the workgroup, so each lane loads its B-fragment (8 consecutive k of one weight row, 16 bytes) from L2 straight
 // into registers (the scheme of csrc/encoder.hip at H = 128, where the fragments of a whole stage fit the register file; at H = 256 a
-// workgroup streams 1.6 MB of weights, as ONE sequence of 8-fragment chunks through a ring of four register buffers that keeps three
-// chunks -- 24 KB per wave, 192 KB per CU -- in flight across the stage boundaries: the stream is bound by the 64 B/clk a CU takes from L2,
-// which needs that much in flight at ~2 us of loaded latency).  LDS per workgroup 118 KB, one workgroup per CU, up to 256 VGPRs.
+// workgroup streams 1.6 MB of weights, as ONE sequence of 8-fragment chunks through a ring of CNB register buffers that keeps CNB - 1
+// chunks -- 8 KB per wave each -- in flight across the stage boundaries: the stream is bound by the 64 B/clk a CU takes from L2 at ~2 us of
+// loaded latency).  LDS per workgroup 118 KB, one workgroup per CU.  Round 4: CNB 4 -> 3 (227 -> 187 registers): the same 0.71-0.73 ms for
+// the teacher's forward alone, the overlapped training step 8 us faster (profiles/micro/r04_ab_chain_ring.txt) -- the register file a
+// teacher workgroup leaves free is what the student's small kernels on the same CU run in.
 // ALL FOUR WEIGHT MATRICES ARE READ IN FRAGMENT ORDER (magic_pack_frag_spans below; the frozen teacher packs them once).
 // Two problems can share one launch (text || panorama encoder, global || local co-attention encoder):
 // group.hpp KIND_CHAIN.
@@ -38,7 +40,10 @@ struct ChainParams {
 
 #define CRT 2          // 16-row tiles per workgroup
 #define CROWS (16 * CRT)
-#define CNB 4          // weight-fragment chunks (8 fragments = 8 KB per wave each) in the register ring: CNB - 1 are in flight ahead of the MFMAs
+#ifndef CNB
+#define CNB 3          // (4 measured 8 us per training step SLOWER next to the student's stream: 227 instead of 187 registers, same time alone)
+#endif
+//                     weight-fragment chunks (8 fragments = 8 KB per wave each) in the register ring: CNB - 1 are in flight ahead of the MFMAs
 
 // LayerNorm over CROWS rows x 256 columns held as CRT x 2 16x16 accumulator tiles per wave (columns (2w + ct) * 16 + c16)
 template <typename Hh>
@@ -296,8 +301,11 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
 // (the two problems as an ARRAY in the kernel-argument segment: `pr.p[which]` becomes scalar loads at a computed offset where they are used;
 // selecting between two by-value structs kept both in SGPRs and spilled 159 of them into vector registers)
 struct ChainPair { ChainParams p[2]; int split; };
+#ifndef CHAIN_ATTR
+#define CHAIN_ATTR
+#endif
 template <typename Hh>
-__global__ __launch_bounds__(512) void chain_fwd_kernel(ChainPair pr) {
+__global__ __launch_bounds__(512) CHAIN_ATTR void chain_fwd_kernel(ChainPair pr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
   const int which = (int)blockIdx.x < pr.split ? 0 : 1;
   const ChainParams& p = pr.p[which];

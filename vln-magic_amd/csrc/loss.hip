@@ -463,13 +463,22 @@ __global__ __launch_bounds__(1024) void cfp_loss_kernel(int B, int H, const T* a
   }
   __syncthreads();
   // ---- sim = a txt^T / temp: thread owns entries e = tid + 1024 j (r = e / 64, c = e % 64 = lane)
+  // (16-byte LDS reads: the txt row of this lane's column once per 8 features -- pitch H + 8 elements = an odd number of 16-byte slots, so
+  // the 16 lanes of a read phase hit 16 different slots -- and the four a rows as wave-wide broadcasts; one accumulator per entry, features in
+  // order: the bits of the element-by-element loop, which spent the kernel on 2-byte reads four lanes to a bank)
+  {
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < H; k0 += VE) {
+      const vec_t tv = *(const vec_t*)(st + lane * HS + k0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = tid + 1024 * j, r = e >> 6, c = e & 63;
-    float s = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < H; ++k) s += to_f(sa[r * HS + k]) * to_f(st[c * HS + k]);
-    sg[r][c] = s * inv_temp;
+      for (int j = 0; j < 4; ++j) {
+        const vec_t av = *(const vec_t*)(sa + (wave + 16 * j) * HS + k0);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s4[j] += to_f(av[e]) * to_f(tv[e]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sg[wave + 16 * j][lane] = s4[j] * inv_temp;
   }
   __syncthreads();
   // ---- log-sum-exp of every row and every column (entries outside B x B excluded); wave w owns rows / columns w, w+16, ...
@@ -499,6 +508,8 @@ __global__ __launch_bounds__(1024) void cfp_loss_kernel(int B, int H, const T* a
   }
   __syncthreads();
   // ---- d_a = G txt / temp ; partial d_txt = G^T a (fp32 scratch): thread owns output pairs (row o / (H/2), features 2 (o % (H/2)), +1)
+  // (one 4-byte LDS read per operand pair: the two features of a thread are neighbours)
+  typedef __attribute__((ext_vector_type(2))) T vec2_t;
   const int hp = H >> 1;
   for (int o = tid; o < B * hp; o += 1024) {
     const int r = o / hp, h = (o - r * hp) * 2;
@@ -506,8 +517,9 @@ __global__ __launch_bounds__(1024) void cfp_loss_kernel(int B, int H, const T* a
 #pragma unroll 8
     for (int q = 0; q < CFP_B; ++q) {
       const float g1 = sg[r][q], g2 = sg[q][r];
-      ga0 += g1 * to_f(st[q * HS + h]); ga1 += g1 * to_f(st[q * HS + h + 1]);
-      gt0 += g2 * to_f(sa[q * HS + h]); gt1 += g2 * to_f(sa[q * HS + h + 1]);
+      const vec2_t t2 = *(const vec2_t*)(st + q * HS + h), a2v = *(const vec2_t*)(sa + q * HS + h);
+      ga0 += g1 * to_f(t2[0]); ga1 += g1 * to_f(t2[1]);
+      gt0 += g2 * to_f(a2v[0]); gt1 += g2 * to_f(a2v[1]);
     }
     da[(long long)r * H + h] = from_f<T>(ga0 * inv_temp); da[(long long)r * H + h + 1] = from_f<T>(ga1 * inv_temp);
     float* pp = part + (long long)pair * B * H + (long long)r * H + h;

@@ -10,7 +10,9 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmagic_hip.so")
+# MAGIC_LIB_FILE: load another build of the library (same-box A/B of a kernel change: `MAGIC_LIB_FILE=.../libmagic_hip_prev.so
+# MAGIC_ALLOW_STALE_LIB=1 python bench.py ...`); the build-id check still runs against whatever is loaded
+LIB_PATH = os.environ.get("MAGIC_LIB_FILE") or os.path.join(os.path.dirname(_HERE), "libmagic_hip.so")
 
 vp, i32, i64, f32, u32, u64 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint, C.c_ulonglong
 

@@ -650,6 +650,17 @@ def main():
         n_steady = 150
         traj_s, dt_s = timed_region(run, n_steady, 0, world, dev)
         steady = {"steps": n_steady, "ms_per_step": round(dt_s / n_steady * 1e3, 3), "trajectory_steps_per_sec": round(traj_s / dt_s, 1)}
+        # the same replay loop over the resident batches of ONE task at a time (60 steps each): what the student's step of each proxy task
+        # costs (graph i = student step on batch i || teacher forward on batch i + 1, whose task is the next one of the cycle)
+        by_task = {}
+        for task in TASKS:
+            sub = [g for g, (tk, _, _) in zip(graphs, pool) if tk == task]
+            if sub:
+                run_t = graph_runner(trainer, sub)
+                run_t(len(sub))
+                _, dt_t = timed_region(run_t, 60, 0, world, dev)
+                by_task[task] = round(dt_t / 60 * 1e3, 3)
+        steady["ms_per_step_by_task"] = by_task
     health = trainer.check_health()          # raises if an in-launch hand-off of the row-split encoder kernels ever gave up
     gate = trainer.gate_report() if (a.mode == "graph" and a.teacher == "split") else None
     if gate is not None:

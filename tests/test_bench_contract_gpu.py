@@ -41,6 +41,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     clean = d["parity_clean_mode"]
     assert clean is not None and clean["max_abs_logit_delta"] < 1e-3 and clean["argmax_agreement"] == 1.0 and clean["ms_per_step"] > 0
     assert d["steady"]["steps"] == 150 and d["ms_per_step_steady"] == d["steady"]["ms_per_step"] > 0
+    assert set(d["steady"]["ms_per_step_by_task"]) == {"mlm", "sap", "cfp"} and min(d["steady"]["ms_per_step_by_task"].values()) > 0
     g = d["teacher_gate"]
     assert g["calls"] >= 4 + 2 + 150 and g["calls"] == g["opened"] + g["already_resident"] + g["timeouts"] + g["skipped"]
     assert g["disabled"] or g["timeouts"] <= 3 + g["opened"] + g["already_resident"], g       # timeouts never run unbounded: the gate turns itself off

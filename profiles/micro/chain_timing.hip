@@ -15,7 +15,9 @@ int main(int argc, char** argv) {
   P.g2 = (float*)dmalloc(CH * 4, 0x3c); P.b2 = (float*)dmalloc(CH * 4, 0); P.y2 = dmalloc((size_t)M * CH * 2, 0);
   P.Wp = dmalloc(3 * CH * CH * 2, 0x11); P.bp = (float*)dmalloc(3 * CH * 4, 0); P.proj = dmalloc((size_t)M * 3 * CH * 2, 0);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rows = 32; rows <= 64; rows += 32)
   for (int variant = 0; variant < 3; ++variant) {
+    magic_chain_tile_rows(rows);
     ChainParams Q = P;
     if (variant == 1) { Q.Wp = nullptr; }                                  // no projection
     if (variant == 2) { Q.W1 = nullptr; Q.Np = CH; Q.y1 = Q.y2; }          // mini chain: stage 1 + H-wide projection
@@ -26,6 +28,11 @@ int main(int argc, char** argv) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long t[16]; hipMemcpyFromSymbol(t, HIP_SYMBOL(chain_ticks), sizeof(t));
+    if (rows == 64) {
+      printf("M %d rows 64 variant %d: %.1f us per launch; tile 0 (10 ns ticks): prologue %lld, stage-1 products %lld, LayerNorm 1 %lld, FFN (4 chunks) %lld, LayerNorm 2 %lld, y2 store + projection %lld, total %lld\n",
+             M, variant, ms * 1000 / 20, t[1] - t[0], t[7] - t[1], t[2] - t[7], t[3] - t[2], t[4] - t[3], t[6] - t[4], t[6] - t[0]);
+      continue;
+    }
     printf("M %d variant %d (%s): %.1f us per launch; tile 0 (10 ns ticks): rows+params+ring prologue %lld, stage 1 %lld, 2a (8 chunks) %lld, 2b (8 chunks + LN) %lld, y2 store + 3 %lld, tail %lld, total %lld\n",
            M, variant, variant == 0 ? "full" : variant == 1 ? "no projection" : "mini", ms * 1000 / 20,
            t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[6] - t[0]);

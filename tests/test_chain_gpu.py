@@ -52,10 +52,19 @@ def _run(x, res, M, w, dtype, ffn, proj, store_y1):
 TOL = {torch.bfloat16: dict(rtol=2e-2, atol=3e-2), torch.float16: dict(rtol=3e-3, atol=4e-3)}
 
 
+@pytest.fixture(params=[64, 32], ids=["rows64", "rows32"])
+def tile_rows(request):
+    """both forms of the kernel: 64-row tiles on the 32 x 32 x 16 product (the default) and 32-row tiles on 16 x 16 x 32"""
+    before = O.chain_tile_rows()
+    assert O.chain_tile_rows(request.param) == request.param
+    yield request.param
+    O.chain_tile_rows(before)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M", [1, 16, 37, 3840])
+@pytest.mark.parametrize("M", [1, 16, 37, 100, 3840])
 @pytest.mark.parametrize("ffn,n_proj,store_y1", [(True, 768, False), (True, 0, True), (False, 256, True), (False, 512, False), (True, 256, False)])
-def test_chain_matches_fp32_reference(dtype, M, ffn, n_proj, store_y1):
+def test_chain_matches_fp32_reference(dtype, M, ffn, n_proj, store_y1, tile_rows):
     assert O.chain_ok(dtype, H, I)
     g = torch.Generator().manual_seed(M + n_proj)
     w = _weights(g, dtype, max(n_proj, 256))
@@ -72,7 +81,7 @@ def test_chain_matches_fp32_reference(dtype, M, ffn, n_proj, store_y1):
         assert torch.allclose(v.float(), want[k], **TOL[dtype]), f"{k}: max|err| {err:.3e} (ref max {want[k].abs().max().item():.2f})"
 
 
-def test_chain_equals_the_per_op_kernels_it_replaces():
+def test_chain_equals_the_per_op_kernels_it_replaces(tile_rows):
     dtype, M = torch.bfloat16, 3840
     g = torch.Generator().manual_seed(5)
     w = _weights(g, dtype, 768)
@@ -93,7 +102,7 @@ def test_chain_equals_the_per_op_kernels_it_replaces():
         assert diff.max().item() < 0.07 and diff.mean().item() < 2e-3, (name, diff.max().item(), diff.mean().item())
 
 
-def test_two_chains_share_one_launch_and_strided_input():
+def test_two_chains_share_one_launch_and_strided_input(tile_rows):
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(9)
     wa, wb = _weights(g, dtype, 768), _weights(g, dtype, 256)
@@ -112,6 +121,28 @@ def test_two_chains_share_one_launch_and_strided_input():
         for k, v in got.items():
             if v is not None:
                 assert torch.allclose(v.float(), want[k], **TOL[dtype]), k
+
+
+def test_the_two_tile_forms_agree_to_16_bit_rounding():
+    dtype, M = torch.bfloat16, 1000
+    g = torch.Generator().manual_seed(21)
+    w = _weights(g, dtype, 768)
+    x = torch.randn(M, H, generator=g).to(DEV).to(dtype)
+    res = torch.randn(M, H, generator=g).to(DEV).to(dtype)
+    before = O.chain_tile_rows()
+    try:
+        outs = {}
+        for rows in (32, 64):
+            O.chain_tile_rows(rows)
+            outs[rows] = _run(x, res, M, w, dtype, True, True, True)
+            torch.cuda.synchronize()
+    finally:
+        O.chain_tile_rows(before)
+    for k in ("y1", "y2", "proj"):
+        d = (outs[32][k].float() - outs[64][k].float()).abs()
+        assert d.max().item() < 0.07 and d.mean().item() < 1e-3, (k, d.max().item(), d.mean().item())
+    with pytest.raises(L.MagicHipError):
+        O.chain_tile_rows(48)
 
 
 def test_pack_frag_layout():

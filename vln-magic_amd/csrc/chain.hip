@@ -314,6 +314,289 @@ __global__ __launch_bounds__(512) CHAIN_ATTR void chain_fwd_kernel(ChainPair pr)
   else chain_body<Hh, false>(p, tile, chain_smem);
 }
 
+
+// =============================================================================================================================
+// The same chain on 64-ROW tiles with the 32 x 32 x 16 product (round 4).  What a workgroup costs the chip is its CU for the ~27 us it
+// takes to pull the block's 1.57 MB of weights through one CU's L2 port, whatever its row count -- so rows per workgroup set the CU time
+// of the teacher's forward, and that CU time is what the student's stream pays for (profiles/micro/r04_teacher_contention.txt; a timing
+// build with HALF the chain's workgroups ran the overlapped step 45 us faster).  Round 3's 64-row form on the 16 x 16 x 32 product was
+// LDS-bound (four A-fragment reads per weight fragment: 57 us per workgroup); on 32 x 32 x 16 a weight fragment (32 weight rows x 16 k)
+// meets TWO A fragments (32 rows x 16 k each) -- the LDS traffic per weight byte of today's 32-row form at half the workgroups.
+//   * B operand: lane l needs W[32 NT + (l & 31)][16 KS + 8 (l >> 5) .. + 7].  The buffers stay in the 16 x 32 fragment order of
+//     magic_pack_frag_spans: that is chunk (l & 15) + 16 (2 (KS & 1) + (l >> 5)) of fragment (2 NT + ((l >> 4) & 1), KS >> 1) -- every
+//     quarter-wave still reads 256 contiguous bytes, a chunk of 8 k-steps is two contiguous 4 KB runs.
+//   * accumulators: column 32 w + (l & 31) on the lane, rows (i & 3) + 8 (i >> 2) + 4 (l >> 5) in the 16 registers of a 32-row tile.
+//   * the FFN goes through LDS one 256-column chunk of the intermediate at a time (GELU image [64][256]); the second product accumulates
+//     in registers over the four chunks.  LDS 155 KB, one workgroup per CU.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> lfrag32(const Hh* s, int pitch, int row0, int k0, int lane) {
+  return *(const h16x8<Hh>*)(s + (row0 + (lane & 31)) * pitch + k0 + 8 * (lane >> 5));
+}
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> pfrag32(const Hh* __restrict__ Wf, const int K, const int NT, const int KS, const int lane) {
+  const int nt16 = 2 * NT + ((lane >> 4) & 1), l2 = (lane & 15) + 16 * (2 * (KS & 1) + (lane >> 5));
+  return *(const h16x8<Hh>*)(Wf + ((long long)(nt16 * (K >> 5) + (KS >> 1)) * 64 + l2) * 8);
+}
+#define C6ROWS 64
+#define C6RT 2
+#define C6NB 3         // ring depth (chunks of 8 fragments = 8 KB per wave)
+// chunk ids: 0..1 stage 1 (Wa tile w, k-steps 8 id ..) | per FFN chunk c: 2 + 4c, 3 + 4c = W1 tile 8c + w (k-steps 0-7, 8-15),
+// 4 + 4c, 5 + 4c = W2 tile w (k-steps 16c .. 16c + 7, 16c + 8 .. 16c + 15) | 18 + 2j, 19 + 2j = Wp tile 8j + w (j < Np / 256)
+template <typename Hh>
+__device__ __forceinline__ void chain64_load_chunk(h16x8<Hh> (&b)[8], const int cid, const ChainParams& p, const int w, const int lane, const int nj) {
+  if (cid < 2) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag32((const Hh*)p.Wa, CH, w, 8 * cid + ks, lane);
+  } else if (cid < 18) {
+    const int c = (cid - 2) >> 2, q = (cid - 2) & 3;
+    if (q < 2) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag32((const Hh*)p.W1, CH, 8 * c + w, 8 * q + ks, lane);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag32((const Hh*)p.W2, CI, w, 16 * c + 8 * (q - 2) + ks, lane);
+    }
+  } else {
+    // UNCONDITIONAL, as in chain_load_chunk: passes beyond the projection's width re-read its last tile, a chain without one reads Wa
+    const Hh* Wq = p.Wp ? (const Hh*)p.Wp : (const Hh*)p.Wa;
+    const int j = (cid - 18) >> 1, hf = (cid - 18) & 1, nt = p.Wp ? 8 * (j < nj ? j : nj - 1) + w : w;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag32(Wq, CH, nt, 8 * hf + ks, lane);
+  }
+}
+// LayerNorm of 64 rows x 256 columns held as two 32 x 32 accumulator tiles per wave (columns 32 w + (l & 31)): v = acc + bias + residual.
+// Two-pass statistics as chain_norm.  A row's 256 columns sit in 16 half-rows of 16 lanes (8 waves x 2): per pass the 16 partials of every
+// row go to LDS, ONE workgroup barrier, then every wave folds them for itself (lane L: row L) into a wave-private row of statistics -- no
+// second barrier.  red: part1 [16][64] | part2 [16][64] | per-wave statistics [8][64].
+template <typename Hh>
+__device__ __forceinline__ void chain64_norm(f32x16 (&acc)[C6RT], const float* sPar, const Hh* sR, float* red, Hh* sOut, const float eps,
+                                             const int w, const int lane) {
+  const int col = 32 * w + (lane & 31), h = lane >> 5, sub = (lane >> 4) & 1;
+  const float bv = sPar[col], gv = sPar[CH + col], btv = sPar[2 * CH + col];
+  float* part1 = red;
+  float* part2 = red + 16 * C6ROWS;
+  float* stat = red + 32 * C6ROWS + w * C6ROWS;
+#pragma unroll
+  for (int rt = 0; rt < C6RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      acc[rt][i] += bv + to_f(sR[row * CP + col]);
+      const float s = g16_sum(acc[rt][i]);
+      if ((lane & 15) == 0) part1[(2 * w + sub) * C6ROWS + row] = s;
+    }
+  __syncthreads();
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += part1[q * C6ROWS + lane];
+    stat[lane] = t * (1.0f / CH);
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int rt = 0; rt < C6RT; ++rt)
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const f32x4 m4 = *(const f32x4*)(stat + rt * 32 + 8 * i4 + 4 * h);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * i4 + r, row = rt * 32 + r + 8 * i4 + 4 * h;
+        acc[rt][i] -= m4[r];
+        const float s = g16_sum(acc[rt][i] * acc[rt][i]);
+        if ((lane & 15) == 0) part2[(2 * w + sub) * C6ROWS + row] = s;
+      }
+    }
+  __syncthreads();
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += part2[q * C6ROWS + lane];
+    wave_lds_sync();                         // (every lane of the wave has read its means before the row is rewritten)
+    stat[lane] = rsqrtf(t * (1.0f / CH) + eps);
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int rt = 0; rt < C6RT; ++rt)
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const f32x4 r4 = *(const f32x4*)(stat + rt * 32 + 8 * i4 + 4 * h);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * i4 + r, row = rt * 32 + r + 8 * i4 + 4 * h;
+        sOut[row * CP + col] = from_f<Hh>(acc[rt][i] * r4[r] * gv + btv);
+      }
+    }
+}
+template <typename Hh>
+__device__ __forceinline__ void chain64_rows_in(const Hh* src, long long ld, int nq, Hh* dst, int tid) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  for (int id = tid; id < C6ROWS * (CH / 8); id += NWAVE * 64) {
+    const int r = id / (CH / 8), c = (id % (CH / 8)) * 8;
+    const u4 v = r < nq ? *(const u4*)(src + r * ld + c) : (u4){0u, 0u, 0u, 0u};
+    *(u4*)(dst + r * CP + c) = v;
+  }
+}
+template <typename Hh, bool FFN>
+__device__ __forceinline__ void chain64_body(const ChainParams& p, const int tile, unsigned char* smem) {
+  Hh* sIn = (Hh*)smem;                      // [64][CP]  stage-1 input; later the block output y2
+  Hh* sRes = sIn + C6ROWS * CP;             // [64][CP]  residual of stage 1
+  Hh* sY1 = sRes + C6ROWS * CP;             // [64][CP]
+  Hh* sG = sY1 + C6ROWS * CP;               // [64][CP]  GELU image of one 256-column chunk; later the projection's 256-column staging image
+  float* red = (float*)(sG + C6ROWS * CP);  // LayerNorm scratch: see chain64_norm
+  float* sPar = red + 40 * C6ROWS;          // ba | g1 | b1 | bo2 | g2 | b2 (256 each) | bi (1024) | bp (<= 768)
+  const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = lane0;
+  asm volatile("" : "+v"(lane));
+  const int h = lane >> 5, c32 = lane & 31;
+  const int row0 = tile * C6ROWS, nq = min(C6ROWS, p.M - row0);
+  const int nj = p.Wp ? (p.Np >> 8) : 0;     // 256-column passes of the projection
+  constexpr int NS = FFN ? 24 : 8;
+#define SEQ6(s) (FFN ? (s) : ((s) < 2 ? (s) : (s) + 16))
+#define AHEAD6(s) do { if ((s) + C6NB - 1 < NS) chain64_load_chunk<Hh>(ring[((s) + C6NB - 1) % C6NB], SEQ6((s) + C6NB - 1), p, w, lane, nj); } while (0)
+  CH_MARK(0);
+  chain64_rows_in((const Hh*)p.in + (long long)row0 * p.ld_in, p.ld_in, nq, sIn, tid);
+  chain64_rows_in((const Hh*)p.res + (long long)row0 * CH, CH, nq, sRes, tid);
+  if (tid < CH) {
+    sPar[tid] = p.ba[tid]; sPar[CH + tid] = p.g1[tid]; sPar[2 * CH + tid] = p.b1[tid];
+    if (FFN) { sPar[3 * CH + tid] = p.bo2[tid]; sPar[4 * CH + tid] = p.g2[tid]; sPar[5 * CH + tid] = p.b2[tid]; }
+  }
+  if (FFN) { sPar[6 * CH + tid] = p.bi[tid]; sPar[6 * CH + 512 + tid] = p.bi[512 + tid]; }
+  for (int i = tid; i < nj * 256; i += NWAVE * 64) sPar[6 * CH + CI + i] = p.bp[i];
+  h16x8<Hh> ring[C6NB][8];
+#pragma unroll
+  for (int s = 0; s < C6NB - 1; ++s) chain64_load_chunk<Hh>(ring[s], SEQ6(s), p, w, lane, nj);
+  __syncthreads();
+  CH_MARK(1);
+  // ================= 1: y1 = LayerNorm(in Wa^T + ba + res) =================
+  {
+    f32x16 acc[C6RT];
+#pragma unroll
+    for (int rt = 0; rt < C6RT; ++rt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      AHEAD6(i);
+      KSTEP_FENCE();
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int rt = 0; rt < C6RT; ++rt) acc[rt] = mfma32(lfrag32(sIn, CP, rt * 32, (8 * i + ks) * 16, lane), ring[i % C6NB][ks], acc[rt]);
+      KSTEP_FENCE();
+    }
+    CH_MARK(7);
+    chain64_norm(acc, sPar, sRes, red, sY1, p.eps, w, lane);
+  }
+  __syncthreads();
+  CH_MARK(2);
+  if (p.y1) copy_out(sY1, CP, (Hh*)p.y1 + (long long)row0 * CH, CH, nq, CH, tid);
+  const Hh* sLast = sY1;
+  if constexpr (FFN) {
+    f32x16 acc2[C6RT];
+#pragma unroll
+    for (int rt = 0; rt < C6RT; ++rt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc2[rt][i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      Hh* gbuf = (c & 1) ? sRes : sG;
+      // ---- 2a: g[:, 256 c ..] = gelu(y1 W1[256 c ..]^T + bi): this wave's 32 columns
+      {
+        f32x16 acc[C6RT];
+#pragma unroll
+        for (int rt = 0; rt < C6RT; ++rt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
+        const float bfc = sPar[6 * CH + 256 * c + 32 * w + c32];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          AHEAD6(2 + 4 * c + q);
+          KSTEP_FENCE();
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < C6RT; ++rt) acc[rt] = mfma32(lfrag32(sY1, CP, rt * 32, (8 * q + ks) * 16, lane), ring[(2 + 4 * c + q) % C6NB][ks], acc[rt]);
+          KSTEP_FENCE();
+        }
+        // the image alternates between two buffers (the stage-1 residual is dead): the one written now was last read by 2b of chunk c - 2,
+        // which every wave finished before it passed the barrier of chunk c - 1 -- one barrier per chunk
+#pragma unroll
+        for (int rt = 0; rt < C6RT; ++rt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            gbuf[(rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * CP + 32 * w + c32] = from_f<Hh>(gelu_fast(acc[rt][i] + bfc));
+      }
+      __syncthreads();
+      // ---- 2b: acc2 += g[:, 256 c ..] W2[:, 256 c ..]^T
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        AHEAD6(4 + 4 * c + q);
+        KSTEP_FENCE();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int rt = 0; rt < C6RT; ++rt) acc2[rt] = mfma32(lfrag32(gbuf, CP, rt * 32, (8 * q + ks) * 16, lane), ring[(4 + 4 * c + q) % C6NB][ks], acc2[rt]);
+        KSTEP_FENCE();
+      }
+    }
+    CH_MARK(3);
+    chain64_norm(acc2, sPar + 3 * CH, sY1, red, sIn, p.eps, w, lane);
+    __syncthreads();
+    CH_MARK(4);
+    copy_out(sIn, CP, (Hh*)p.y2 + (long long)row0 * CH, CH, nq, CH, tid);
+    sLast = sIn;
+  }
+  if (nj) {
+    // ================= 3: proj = y_last Wp^T + bp, one 256-column pass at a time (this wave's 32 columns of each) =================
+    constexpr int S3 = FFN ? 18 : 2;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      f32x16 acc[C6RT];
+#pragma unroll
+      for (int rt = 0; rt < C6RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        AHEAD6(S3 + 2 * j + q);
+        KSTEP_FENCE();
+        if (j < nj) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < C6RT; ++rt) acc[rt] = mfma32(lfrag32(sLast, CP, rt * 32, (8 * q + ks) * 16, lane), ring[(S3 + 2 * j + q) % C6NB][ks], acc[rt]);
+        }
+        KSTEP_FENCE();
+      }
+      if (j < nj) {
+        const float bpv = sPar[6 * CH + CI + 256 * j + 32 * w + c32];
+        Hh* pbuf = (j & 1) ? sRes : sG;      // alternating staging images: the one written now was copied out two passes ago (one barrier per pass)
+#pragma unroll
+        for (int rt = 0; rt < C6RT; ++rt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            pbuf[(rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * CP + 32 * w + c32] = from_f<Hh>(acc[rt][i] + bpv);
+        __syncthreads();
+        copy_out(pbuf, CP, (Hh*)p.proj + (long long)row0 * p.Np + 256 * j, p.Np, nq, 256, tid);
+      }
+    }
+  }
+  CH_MARK(6);
+#undef SEQ6
+#undef AHEAD6
+}
+template <typename Hh>
+__global__ __launch_bounds__(512) void chain64_fwd_kernel(ChainPair pr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  const int which = (int)blockIdx.x < pr.split ? 0 : 1;
+  const ChainParams& p = pr.p[which];
+  const int tile = which ? blockIdx.x - pr.split : blockIdx.x;
+  if (p.W1) chain64_body<Hh, true>(p, tile, chain_smem);
+  else chain64_body<Hh, false>(p, tile, chain_smem);
+}
+static size_t chain64_lds_bytes() { return (size_t)(4 * C6ROWS * CP) * 2 + (40 * C6ROWS + 6 * CH + CI + 3 * CH) * sizeof(float); }
+
 static size_t chain_lds_bytes() { return (size_t)(3 * CROWS * CP + CROWS * CG) * 2 + (2 * NWAVE * CROWS + 6 * CH + CI + 3 * CH) * sizeof(float); }
 
 static bool chain_valid(const ChainParams& p) {
@@ -324,21 +607,47 @@ static bool chain_valid(const ChainParams& p) {
   return true;
 }
 
+// rows per workgroup: 64 (chain64_fwd_kernel, the default) or 32 (chain_fwd_kernel).  magic_chain_tile_rows(0) reads it, (32 | 64) sets it;
+// MAGIC_CHAIN_ROWS=32 in the environment picks the 32-row form from the start.
+static int chain_rows_cfg = 0;
+extern "C" int magic_chain_tile_rows(int rows) {
+  if (!chain_rows_cfg) { const char* e = getenv("MAGIC_CHAIN_ROWS"); chain_rows_cfg = (e && atoi(e) == 32) ? 32 : 64; }
+  if (rows == 32 || rows == 64) chain_rows_cfg = rows;
+  else if (rows != 0) return MAGIC_ERR_ARG;
+  return chain_rows_cfg;
+}
+
 int launch_chain(int dtype, int variant, const void* pa_, const void* pb_, hipStream_t st) {
   (void)variant;
   ChainPair pr;
   pr.p[0] = *(const ChainParams*)pa_;
   pr.p[1] = pb_ ? *(const ChainParams*)pb_ : pr.p[0];
-  const int ta = (pr.p[0].M + CROWS - 1) / CROWS, tb = pb_ ? (pr.p[1].M + CROWS - 1) / CROWS : 0;
+  // 64-row tiles where the launch has enough 32-row tiles for the halved workgroup count to matter (MAGIC_CHAIN_64_MIN_TILES, default below):
+  // a 64-row workgroup takes 39 us instead of 26 (profiles/micro/r04_chain_timing.txt), so a small launch only gets longer
+  static int min_tiles = -1;
+  if (min_tiles < 0) { const char* e = getenv("MAGIC_CHAIN_64_MIN_TILES"); min_tiles = e ? atoi(e) : 0; }
+  const int t32 = (pr.p[0].M + 31) / 32 + (pb_ ? (pr.p[1].M + 31) / 32 : 0);
+  const int rows = (magic_chain_tile_rows(0) == 64 && t32 >= min_tiles) ? 64 : 32;
+  const int ta = (pr.p[0].M + rows - 1) / rows, tb = pb_ ? (pr.p[1].M + rows - 1) / rows : 0;
   pr.split = ta;
   static bool attr_done[3] = {false, false, false};
-  const size_t lds = chain_lds_bytes();      // (padding it to 159 KB changes nothing in the overlapped step: co-residency with the student's tiles is not what the teacher costs)
+  if (!attr_done[dtype == DT_BF16 ? DT_BF16 : DT_F16]) {
+    if (dtype == DT_BF16) {
+      hipFuncSetAttribute((const void*)chain_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds_bytes());
+      hipFuncSetAttribute((const void*)chain64_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain64_lds_bytes());
+    } else {
+      hipFuncSetAttribute((const void*)chain_fwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds_bytes());
+      hipFuncSetAttribute((const void*)chain64_fwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain64_lds_bytes());
+    }
+    attr_done[dtype == DT_BF16 ? DT_BF16 : DT_F16] = true;
+  }
+  const size_t lds = rows == 64 ? chain64_lds_bytes() : chain_lds_bytes();
   if (dtype == DT_BF16) {
-    if (!attr_done[DT_BF16]) { hipFuncSetAttribute((const void*)chain_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[DT_BF16] = true; }
-    hipLaunchKernelGGL(chain_fwd_kernel<bf16>, dim3(ta + tb), dim3(512), lds, st, pr);
+    if (rows == 64) hipLaunchKernelGGL(chain64_fwd_kernel<bf16>, dim3(ta + tb), dim3(512), lds, st, pr);
+    else hipLaunchKernelGGL(chain_fwd_kernel<bf16>, dim3(ta + tb), dim3(512), lds, st, pr);
   } else {
-    if (!attr_done[DT_F16]) { hipFuncSetAttribute((const void*)chain_fwd_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[DT_F16] = true; }
-    hipLaunchKernelGGL(chain_fwd_kernel<f16>, dim3(ta + tb), dim3(512), lds, st, pr);
+    if (rows == 64) hipLaunchKernelGGL(chain64_fwd_kernel<f16>, dim3(ta + tb), dim3(512), lds, st, pr);
+    else hipLaunchKernelGGL(chain_fwd_kernel<f16>, dim3(ta + tb), dim3(512), lds, st, pr);
   }
   return launch_status();
 }

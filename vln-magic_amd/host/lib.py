@@ -84,6 +84,7 @@ SIGNATURES = {
     "magic_encoder_health": [vp, vp],
     "magic_chain_supported": [i32, i32, i32],
     "magic_chain_fwd": [i32, vp, i32, vp],
+    "magic_chain_tile_rows": [i32],
     "magic_xencoder_supported": [i32, i32, i32, i32, i32, i32, i32],
     "magic_xencoder_params_bytes": [],
     "magic_xencoder_fwd": [i32, vp, i32, vp],

@@ -632,6 +632,13 @@ def chain_ok(dtype, H, I):
     return _CHAIN_OK[key]
 
 
+def chain_tile_rows(rows=0):
+    """rows per workgroup of the teacher's row chain (csrc/chain.hip): 0 = query, 32 | 64 = set (before any graph capture); returns the value in force"""
+    r = L.load().magic_chain_tile_rows(int(rows))
+    _chk(r in (32, 64), "chain_tile_rows: 0, 32 or 64")
+    return r
+
+
 def pack_frag(W):
     """[N, K] 16-bit weight -> the same elements in MFMA-fragment order (flat), as csrc/chain.hip reads them (magic_pack_frag_spans)"""
     import ctypes as C

@@ -438,11 +438,13 @@ int magic_pack_frag_spans(const void* src, void* dst, int n, const long long* of
 int magic_layout_spans(const void* src, void* dst_f, void* dst_tf, int n, const long long* offs, const int* rows, const int* cols,
                        const int* flags, void* stream);
 int magic_chain_fwd(int dtype, const void* params, int nbytes, void* stream);
-/* Rows per workgroup of magic_chain_fwd: 64 (default since round 4: the 32 x 32 x 16 product, two A fragments per weight fragment, half the
- * workgroups and half the L2 -> CU weight traffic per row) or 32 (the round-3 form on 16 x 16 x 32).  rows = 0: query; 32 | 64: set (process-wide,
- * takes effect at the next launch: set it before capturing graphs); returns the value in force, MAGIC_ERR_ARG for anything else.  Both forms
- * read the same fragment-order weights and have the same rounding points; their LayerNorm statistics are summed in a different order
- * (outputs agree to the 16-bit rounding).  MAGIC_CHAIN_ROWS=32 in the environment selects the 32-row form from the start. */
+/* Rows per workgroup of magic_chain_fwd.  64 = the round-4 form (the 32 x 32 x 16 product, two A fragments per weight fragment: half the
+ * workgroups and half the L2 -> CU weight traffic per row, 39 us per workgroup), 32 = the round-3 form on 16 x 16 x 32 (26 us per workgroup),
+ * 1 = by launch size (the default): 64-row tiles for launches with more 32-row tiles than the device has CUs (they would run in two rounds),
+ * 32-row tiles otherwise.  rows = 0: query; 1 | 32 | 64: set (process-wide, takes effect at the next launch: set it before capturing graphs);
+ * returns the setting in force, MAGIC_ERR_ARG for anything else.  Both forms read the same fragment-order weights and have the same rounding
+ * points; their LayerNorm statistics are summed in a different order (outputs agree to the 16-bit rounding).  MAGIC_CHAIN_ROWS=32 | 64 in the
+ * environment fixes the form from the start. */
 int magic_chain_tile_rows(int rows);
 
 /* Backward of the per-token half of a post-LN self-attention block on 32-row blocks (csrc/encbwd.hip): [tail of the next block: dx =

@@ -48,8 +48,8 @@ def main():
            "step_fetch_bytes": ftot * 2.0 / steps, "step_write_bytes": wtot / steps,
            "dw_batch_fetch_bytes_per_launch": sum(v[0] for k, v in fk.items() if "gemm_dw_batch_kernel" in k) * 2.0 / max(sum(v[1] for k, v in fk.items() if "gemm_dw_batch_kernel" in k), 1),
            "dw_batch_write_bytes_per_launch": sum(v[0] for k, v in wk.items() if "gemm_dw_batch_kernel" in k) / max(sum(v[1] for k, v in wk.items() if "gemm_dw_batch_kernel" in k), 1),
-           "chain_fetch_bytes_per_launch": sum(v[0] for k, v in fk.items() if "chain_fwd_kernel" in k) * 2.0 / max(sum(v[1] for k, v in fk.items() if "chain_fwd_kernel" in k), 1),
-           "chain_write_bytes_per_launch": sum(v[0] for k, v in wk.items() if "chain_fwd_kernel" in k) / max(sum(v[1] for k, v in wk.items() if "chain_fwd_kernel" in k), 1),
+           "chain_fetch_bytes_per_launch": sum(v[0] for k, v in fk.items() if "chain_fwd_kernel" in k or "chain64_fwd_kernel" in k) * 2.0 / max(sum(v[1] for k, v in fk.items() if "chain_fwd_kernel" in k or "chain64_fwd_kernel" in k), 1),
+           "chain_write_bytes_per_launch": sum(v[0] for k, v in wk.items() if "chain_fwd_kernel" in k or "chain64_fwd_kernel" in k) / max(sum(v[1] for k, v in wk.items() if "chain_fwd_kernel" in k or "chain64_fwd_kernel" in k), 1),
            "top_fetch_kernels_bytes_per_launch": {k[:60]: round(v[0] * 2.0 / v[1]) for k, v in sorted(fk.items(), key=lambda kv: -kv[1][0])[:6]}}
     print(json.dumps(out, indent=1))
 

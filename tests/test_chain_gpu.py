@@ -54,7 +54,8 @@ TOL = {torch.bfloat16: dict(rtol=2e-2, atol=3e-2), torch.float16: dict(rtol=3e-3
 
 @pytest.fixture(params=[64, 32], ids=["rows64", "rows32"])
 def tile_rows(request):
-    """both forms of the kernel: 64-row tiles on the 32 x 32 x 16 product (the default) and 32-row tiles on 16 x 16 x 32"""
+    """both forms of the kernel, forced: 64-row tiles on the 32 x 32 x 16 product and 32-row tiles on 16 x 16 x 32 (the default setting, 1,
+    picks by launch size)"""
     before = O.chain_tile_rows()
     assert O.chain_tile_rows(request.param) == request.param
     yield request.param
@@ -143,6 +144,23 @@ def test_the_two_tile_forms_agree_to_16_bit_rounding():
         assert d.max().item() < 0.07 and d.mean().item() < 1e-3, (k, d.max().item(), d.mean().item())
     with pytest.raises(L.MagicHipError):
         O.chain_tile_rows(48)
+    # the default setting picks by launch size: more 32-row tiles than CUs -> the 64-row form (same outputs as forcing it), else the 32-row form
+    assert before == 1 or "MAGIC_CHAIN_ROWS" in __import__("os").environ
+    O.chain_tile_rows(1)
+    try:
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        Mbig = 32 * (cus + 3)
+        xb = torch.randn(Mbig, H, generator=g).to(DEV).to(dtype)
+        rb = torch.randn(Mbig, H, generator=g).to(DEV).to(dtype)
+        auto_big, auto_small = _run(xb, rb, Mbig, w, dtype, True, True, True), _run(x, res, M, w, dtype, True, True, True)
+        O.chain_tile_rows(64)
+        f64 = _run(xb, rb, Mbig, w, dtype, True, True, True)
+        torch.cuda.synchronize()
+        for k in ("y1", "y2", "proj"):
+            assert torch.equal(auto_big[k], f64[k]), ("a launch over one round takes the 64-row form", k)
+            assert torch.equal(auto_small[k], outs[32][k]), ("a launch within one round takes the 32-row form", k)
+    finally:
+        O.chain_tile_rows(before)
 
 
 def test_pack_frag_layout():

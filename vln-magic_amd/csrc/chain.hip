@@ -607,12 +607,12 @@ static bool chain_valid(const ChainParams& p) {
   return true;
 }
 
-// rows per workgroup: 64 (chain64_fwd_kernel, the default) or 32 (chain_fwd_kernel).  magic_chain_tile_rows(0) reads it, (32 | 64) sets it;
-// MAGIC_CHAIN_ROWS=32 in the environment picks the 32-row form from the start.
+// rows per workgroup: 1 = by launch size (the default, see launch_chain), 32 = chain_fwd_kernel always, 64 = chain64_fwd_kernel always.
+// magic_chain_tile_rows(0) reads the setting, (1 | 32 | 64) sets it; MAGIC_CHAIN_ROWS=32 | 64 in the environment picks a fixed form from the start.
 static int chain_rows_cfg = 0;
 extern "C" int magic_chain_tile_rows(int rows) {
-  if (!chain_rows_cfg) { const char* e = getenv("MAGIC_CHAIN_ROWS"); chain_rows_cfg = (e && atoi(e) == 32) ? 32 : 64; }
-  if (rows == 32 || rows == 64) chain_rows_cfg = rows;
+  if (!chain_rows_cfg) { const char* e = getenv("MAGIC_CHAIN_ROWS"); const int v = e ? atoi(e) : 1; chain_rows_cfg = (v == 32 || v == 64) ? v : 1; }
+  if (rows == 1 || rows == 32 || rows == 64) chain_rows_cfg = rows;
   else if (rows != 0) return MAGIC_ERR_ARG;
   return chain_rows_cfg;
 }
@@ -622,12 +622,20 @@ int launch_chain(int dtype, int variant, const void* pa_, const void* pb_, hipSt
   ChainPair pr;
   pr.p[0] = *(const ChainParams*)pa_;
   pr.p[1] = pb_ ? *(const ChainParams*)pb_ : pr.p[0];
-  // 64-row tiles where the launch has enough 32-row tiles for the halved workgroup count to matter (MAGIC_CHAIN_64_MIN_TILES, default below):
-  // a 64-row workgroup takes 39 us instead of 26 (profiles/micro/r04_chain_timing.txt), so a small launch only gets longer
+  // 64-row tiles for launches with more 32-row tiles than the chip has CUs (one workgroup per CU: such a launch runs in two rounds of 26 us,
+  // in one of 39 us on 64-row tiles: the text || panorama pairs, 398 tiles at B = 48: 59.5 -> 46.9 us).  A launch that fits in one round
+  // only gets longer on 64-row tiles (3840 rows: 29 -> 43 us) -- its CU time falls by a quarter, but the overlapped training step could not
+  // tell the two policies apart (1.456 vs 1.457 ms, profiles/micro/r04_ab_chain64_threshold.txt), so the default keeps every launch at its
+  // faster form.  MAGIC_CHAIN_64_MIN_TILES overrides the threshold of the by-size setting.
   static int min_tiles = -1;
-  if (min_tiles < 0) { const char* e = getenv("MAGIC_CHAIN_64_MIN_TILES"); min_tiles = e ? atoi(e) : 0; }
+  if (min_tiles < 0) {
+    const char* e = getenv("MAGIC_CHAIN_64_MIN_TILES");
+    hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d);
+    min_tiles = e ? atoi(e) : ((hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256) + 1);
+  }
   const int t32 = (pr.p[0].M + 31) / 32 + (pb_ ? (pr.p[1].M + 31) / 32 : 0);
-  const int rows = (magic_chain_tile_rows(0) == 64 && t32 >= min_tiles) ? 64 : 32;
+  const int cfg = magic_chain_tile_rows(0);
+  const int rows = cfg == 1 ? (t32 >= min_tiles ? 64 : 32) : cfg;
   const int ta = (pr.p[0].M + rows - 1) / rows, tb = pb_ ? (pr.p[1].M + rows - 1) / rows : 0;
   pr.split = ta;
   static bool attr_done[3] = {false, false, false};

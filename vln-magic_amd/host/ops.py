@@ -633,9 +633,10 @@ def chain_ok(dtype, H, I):
 
 
 def chain_tile_rows(rows=0):
-    """rows per workgroup of the teacher's row chain (csrc/chain.hip): 0 = query, 32 | 64 = set (before any graph capture); returns the value in force"""
+    """rows per workgroup of the teacher's row chain (csrc/chain.hip): 0 = query; 1 = by launch size (default: 64-row tiles for launches that
+    would need two rounds of 32-row tiles), 32 | 64 = that form always.  Set before any graph capture.  Returns the setting in force."""
     r = L.load().magic_chain_tile_rows(int(rows))
-    _chk(r in (32, 64), "chain_tile_rows: 0, 32 or 64")
+    _chk(r in (1, 32, 64), "chain_tile_rows: 0, 1, 32 or 64")
     return r
 
 

@@ -693,8 +693,8 @@ def main():
         ach_gemm = (flops / nprof) / (gemm_ms / nprof * 1e-3) / 1e12
         ach_all = (O.FLOPS["total"] / nprof) / (mfma_ms / nprof * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(gemm_n, chain_n)
-        roof = {"bound": "mfma", "kernel": "gemm_kernel / gemm_xcd_kernel / gemm_grouped_kernel / gemm_dw_batch_kernel <bf16, NT|NN|TN> + chain64_fwd_kernel<bf16> (the dominant "
-                                           "kernel family: every Linear layer's forward, input and weight gradient; the frozen teacher's run inside the chain kernel since round 3, on 64-row tiles since round 4)",
+        roof = {"bound": "mfma", "kernel": "gemm_kernel / gemm_xcd_kernel / gemm_grouped_kernel / gemm_dw_batch_kernel <bf16, NT|NN|TN> + chain_fwd_kernel / chain64_fwd_kernel<bf16> (the dominant "
+                                           "kernel family: every Linear layer's forward, input and weight gradient; the frozen teacher's run inside the chain kernels since round 3; launches over one round of CUs on 64-row tiles since round 4)",
                 "achieved": round(ach, 3), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5),
                 "traffic": traffic, "traffic_source": (traffic_src + " (offline rocprofv3 --pmc passes of this command; not collected in this run)") if traffic_src else None,
                 "how": "HIP events around every launch on the launch stream, eager pass of the same steps with the captured graphs' launch structure, "
@@ -716,7 +716,7 @@ def main():
                            "whole_step": {"summed_kernel_ms_per_step_serialised": round(all_ms / nprof, 3), "graph_replay_wall_ms_per_step": round(step_ms, 3),
                                           "frac_of_mfma_peak_on_wall": round(O.FLOPS["total"] / nprof / (step_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 5)},
                            "teacher_chain_kernel": {
-                               "kernel": "chain64_fwd_kernel (csrc/chain.hip; 64-row tiles, 32x32x16 product): the frozen teacher's per-token half of a block (output projection + LayerNorm, FFN, "
+                               "kernel": "chain_fwd_kernel / chain64_fwd_kernel (csrc/chain.hip; 32-row tiles, and 64-row tiles on the 32x32x16 product for launches with more 32-row tiles than CUs): the frozen teacher's per-token half of a block (output projection + LayerNorm, FFN, "
                                          "LayerNorm, next Q|K|V projection) at H = 256 in one launch, forward only",
                                "algorithmic_gflop_per_step": round(O.FLOPS["chain"] / nprof / 1e9, 2), "launches_per_step": round(chain_n / nprof, 1),
                                "avg_launch_us": round(chain_ms / max(chain_n, 1) * 1e3, 1), "share_of_kernel_time": round(chain_ms / all_ms, 4),

@@ -121,6 +121,12 @@ __device__ __forceinline__ void ln_bwd_rows(f32x4 (&acc)[NRT], const Hh* sY, con
 // NRT = row tiles of 16 per workgroup.  2 (32 rows): two workgroups per CU, 128 registers per lane, weight fragments one chunk of four
 // k-steps ahead of their use.  4 (64 rows): one workgroup per CU, 256 registers, a whole product's fragments ahead -- and half the
 // weight bytes streamed from L2 per row (every workgroup streams all 393 KB of the block's matrices).
+#ifdef RBW_TIMING
+__device__ long long rbw_ticks[16];            // wall_clock64 (100 MHz) marks of workgroup 0 (profiles/micro/rowbwd_timing.hip)
+#define RBW_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) rbw_ticks[i] = wall_clock64(); } while (0)
+#else
+#define RBW_MARK(i)
+#endif
 template <int NRT, typename Hh>
 __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned char* rb_smem) {
   constexpr int RB_ROWS = NRT * 16;
@@ -145,6 +151,7 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
   const int kt = sg.kt, ldq = kt * 32;
   DropDesc dd;
   dd.seed = p.seed; dd.p = p.p_hidden;
+  RBW_MARK(0);
   // ---- weights of the first two products + small parameters, issued before anything else
   // (two workgroups per CU = 128 registers per lane: weight fragments arrive in chunks of four k-steps, one chunk ahead of their use)
   h16x8<Hh> wq[12];
@@ -169,6 +176,7 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
     load_rows_img(sD, XS, sg.dfod_in + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
   }
   __syncthreads();
+  RBW_MARK(1);
   // ================= tail: dx = dQKV W_qkv + d_ao -> LayerNorm backward (output norm) =================
   if (tail) {
     f32x4 acc[NRT];
@@ -188,6 +196,7 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
       }
       KSTEP_FENCE();
     }
+    RBW_MARK(2);
     // z rows -> registers now (their round trip hides under the LayerNorm backward); they go into the image once every wave is past
     // the barrier inside ln_bwd_rows, i.e. done reading the dQKV rows
     constexpr int ZIT = RB_ROWS * (EI / 8) / (NWAVE * 64);
@@ -212,9 +221,11 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
       *(h16x8<Hh>*)(sZ + r * GS + c) = zr[it];
     }
     __syncthreads();                             // d_fo / d_fod images and the z image complete
+    RBW_MARK(3);
     copy_out(sFo, XS, sg.dfo + (long long)m0 * EH, EH, nv, EH, tid);
     copy_out(sD, XS, sg.dfod + (long long)m0 * EH, EH, nv, EH, tid);
   }
+  RBW_MARK(4);
   h16x8<Hh> wo[4];
   if (shortm) {
 #pragma unroll
@@ -260,7 +271,9 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
     }
   }
   __syncthreads();                               // d_z image complete
+  RBW_MARK(5);
   copy_out(sZ, GS, sg.dz + (long long)m0 * EI, EI, nv, EI, tid);
+  RBW_MARK(6);
   // ================= d_a = d_z W1 + d_fo -> LayerNorm backward (attention-output norm) =================
   {
     f32x4 acc[NRT];
@@ -287,15 +300,18 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
     for (int i = 0; i < NRT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][r] += to_f(sFo[(i * 16 + 4 * g + r) * XS + colw]);
+    RBW_MARK(7);
     dd.site = sg.site_ao;
     const DropState ds = drop_init(dd);
     // d_aod goes where d_fod was: every wave is past the FFN product (the barrier above) and reads sD no more
     ln_bwd_rows<NRT>(acc, sY1, sg.rstd1, gm1, bt1, sg.dg1, sg.db1, red, sAo, sD, m0, M, ds, w, lane, p.pad1 ? blk : -1);
   }
   __syncthreads();                               // d_ao / d_aod images complete
+  RBW_MARK(8);
   copy_out(sAo, XS, sg.dao + (long long)m0 * EH, EH, nv, EH, tid);
   copy_out(sD, XS, sg.daod + (long long)m0 * EH, EH, nv, EH, tid);
   }
+  RBW_MARK(9);
   // ================= d_ctx = d_aod Wo (short chain: the tail's dense-branch gradient) =================
   {
     f32x4 acc[NRT];
@@ -311,7 +327,9 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
       for (int r = 0; r < 4; ++r) sY2[(i * 16 + 4 * g + r) * XS + colw] = from_f<Hh>(acc[i][r]);
   }
   __syncthreads();
+  RBW_MARK(10);
   copy_out(sY2, XS, sg.dctx + (long long)m0 * EH, EH, nv, EH, tid);
+  RBW_MARK(11);
 }
 
 template <typename Hh> __global__ __launch_bounds__(512, 4) void rowbwd16_kernel(RbwParamsT<Hh> p) {

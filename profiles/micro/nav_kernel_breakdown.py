@@ -1,0 +1,91 @@
+"""Per-(kernel, shape) kernel time + launch count of ONE navigator fine-tuning iteration (bench_nav.py's default workload), and the
+host-side wall time of the same iteration un-instrumented.  HIP events around every launch (lib.PROFILE), shapes = the leading integer
+arguments of the C-ABI call.  `python profiles/micro/nav_kernel_breakdown.py [--icod] [--top 60]`"""
+import argparse
+import collections
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import magic_amd  # noqa: E402,F401
+from magic_amd.host import lib as L  # noqa: E402
+from magic_amd.host.config import make_config  # noqa: E402
+from magic_amd.host.model_nav import VLNBert  # noqa: E402
+from magic_amd.host.nav_rollout import NavRollout  # noqa: E402
+from magic_amd.host.synth_env import SynthNavEnv  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--top", type=int, default=70)
+ap.add_argument("--hidden", type=int, default=768)
+ap.add_argument("--iters", type=int, default=4)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+cfg = make_config(a.hidden, role="teacher", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+model = VLNBert(None, role="student", config=cfg, device=dev, compute_dtype=torch.bfloat16, seed=0)
+model.train()
+opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
+mk = lambda: SynthNavEnv(batch_size=16, n_scans=6, nodes_per_scan=64, seed=1234, instr_len=(100, 512), path_hops=(8, 15))
+env, env2 = mk(), mk()
+table = torch.from_numpy(env.feature_table).to(dev).to(torch.bfloat16)
+ro = NavRollout(model, table, max_action_len=28, expert_policy="ndtw")
+rng = np.random.default_rng(0)
+
+
+def iteration():
+    opt.zero_grad()
+    obs = env.reset(features=False)
+    batch = env.batch
+    r2, r1 = ro.run_interleaved([((env2, env2.reset(batch=batch, features=False)), dict(feedback="sample", train_ml=1.0, sample_draws=rng.uniform(size=(28, 16)))),
+                                 ((env, obs), dict(feedback="teacher", train_ml=0.2))])
+    t_f = time.perf_counter()
+    (r1["loss"] + r2["loss"]).backward()
+    t_b = time.perf_counter()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 40.0)
+    opt.step()
+    return r1["decisions"] + r2["decisions"], t_f, t_b
+
+
+for _ in range(2):
+    iteration()
+torch.cuda.synchronize()
+for _ in range(a.iters):
+    t0 = time.perf_counter()
+    dec, t_f, t_b = iteration()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"iteration: {1e3 * (t2 - t0):.1f} ms wall ({dec} decisions); host: rollouts {1e3 * (t_f - t0):.1f}  backward {1e3 * (t_b - t_f):.1f}  "
+          f"clip+opt {1e3 * (t1 - t_b):.1f}  drain {1e3 * (t2 - t1):.1f}")
+
+L.PROFILE.update(on=True, events=[], shapes=[])
+dec, _, _ = iteration()
+torch.cuda.synchronize()
+L.PROFILE["on"] = False
+by = collections.defaultdict(lambda: [0.0, 0])
+byname = collections.defaultdict(lambda: [0.0, 0])
+sh = L.PROFILE["shapes"]
+plain = [e for e in L.PROFILE["events"] if "+" not in e[0]]
+grouped = [e for e in L.PROFILE["events"] if "+" in e[0]]
+assert len(plain) == len(sh), (len(plain), len(sh))
+for (name, layout, e0, e1), s in zip(plain, sh):
+    t = e0.elapsed_time(e1)
+    k = (name, s)
+    by[k][0] += t; by[k][1] += 1
+    byname[name][0] += t; byname[name][1] += 1
+for name, layout, e0, e1 in grouped:
+    t = e0.elapsed_time(e1)
+    by[(name, ())][0] += t; by[(name, ())][1] += 1
+    byname[name][0] += t; byname[name][1] += 1
+tot = sum(v[0] for v in byname.values())
+n = sum(v[1] for v in byname.values())
+print(f"\ninstrumented iteration: {n} launches, {tot:.1f} ms of kernel time, {dec} decisions")
+print("\n== by entry point ==")
+for k, (t, c) in sorted(byname.items(), key=lambda kv: -kv[1][0]):
+    print(f"{k:28s} {t:8.2f} ms {100 * t / tot:5.1f} %  {c:5d} launches  {1e3 * t / c:7.1f} us avg")
+print("\n== by entry point and leading integer arguments ==")
+for (name, s), (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:a.top]:
+    print(f"{name:24s} {str(s):44s} {t:7.2f} ms {100 * t / tot:5.1f} %  {c:4d} x {1e3 * t / c:7.1f} us")

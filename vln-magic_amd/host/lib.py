@@ -364,6 +364,8 @@ def _raw_call(name, args):
         rc = _fn(name)(*args)
         e1.record()
         PROFILE["events"].append((name, args[1] if name == "magic_gemm" else -1, e0, e1))
+        if PROFILE.get("shapes") is not None:       # profiles/micro/nav_kernel_breakdown.py: leading integer arguments (dtype, sizes) per launch
+            PROFILE["shapes"].append(tuple(a for a in args[:7] if isinstance(a, int) and abs(a) < (1 << 24)))
     else:
         rc = _fn(name)(*args)
     if rc != 0:

@@ -69,7 +69,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=4)                  # (iteration 1 sees the shapes, 2 captures the step instances, 3-4 top the pools up)
+    ap.add_argument("--no-graphs", action="store_true",
+                    help="launch every kernel of the training steps eagerly instead of replaying captured step instances (host/step_graphs.py)")
     ap.add_argument("--batch", type=int, default=16)                  # run_rxr_kdl_valid.sh:39
     ap.add_argument("--hidden", type=int, default=768)                # MAGIC-L
     ap.add_argument("--instr-min", type=int, default=100)
@@ -131,7 +133,8 @@ def main():
         t_opt = torch.optim.AdamW(teacher.parameters(), lr=1e-5)      # agent_base.py:133-139
     kd = dict(alpha=0.5, t_alpha=0.5, temperature=2.0, decay=0.7) if a.icod else None      # run_r2r_kdl_valid.sh:97-104
     ro = NavRollout(model, table, teacher=teacher, kd=kd, train_teacher=a.icod, max_action_len=a.max_action_len,
-                    expert_policy="ndtw" if not a.icod else "spl")     # run_rxr_kdl_valid.sh:29 / run_r2r_kdl_valid.sh:29
+                    expert_policy="ndtw" if not a.icod else "spl",     # run_rxr_kdl_valid.sh:29 / run_r2r_kdl_valid.sh:29
+                    graphs=(a.mode == "train" and not a.no_graphs and not a.fuse_rollouts), Lcap=a.instr_max)
     rng = np.random.default_rng(rank)
 
     gnav = None
@@ -202,6 +205,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    graphs_rep = ro.graph_report() if ro.graphs else None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -258,7 +262,7 @@ def main():
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "views": 36, "feat_dim": 768, "parallelism": f"dp{world}",
                        "decisions_per_iteration": round(dec / a.steps / world, 1)},
             "mode": a.mode + ("/icod" if a.icod else "") + ("/graph" if (a.graph and a.mode == "eval") else ""), "teacher_hidden": a.teacher_hidden if a.icod else None, "ms_per_rollout_step": (round(dt / max(counters["rollout_steps"], 1) * 1e3, 3) if a.mode == "eval" else None),
-            "roofline": roof, "cpu_baseline": cpu, "host_loop": host_loop}))
+            "step_graphs": graphs_rep, "roofline": roof, "cpu_baseline": cpu, "host_loop": host_loop}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--top", type=int, default=70)
 ap.add_argument("--hidden", type=int, default=768)
 ap.add_argument("--iters", type=int, default=4)
+ap.add_argument("--graphs", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = make_config(a.hidden, role="teacher", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
@@ -31,7 +32,7 @@ opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
 mk = lambda: SynthNavEnv(batch_size=16, n_scans=6, nodes_per_scan=64, seed=1234, instr_len=(100, 512), path_hops=(8, 15))
 env, env2 = mk(), mk()
 table = torch.from_numpy(env.feature_table).to(dev).to(torch.bfloat16)
-ro = NavRollout(model, table, max_action_len=28, expert_policy="ndtw")
+ro = NavRollout(model, table, max_action_len=28, expert_policy="ndtw", graphs=a.graphs, Lcap=512)
 rng = np.random.default_rng(0)
 
 
@@ -49,9 +50,11 @@ def iteration():
     return r1["decisions"] + r2["decisions"], t_f, t_b
 
 
-for _ in range(2):
+for _ in range(5 if a.graphs else 2):
+    t0 = time.perf_counter()
     iteration()
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    print(f"warm-up iteration: {1e3 * (time.perf_counter() - t0):.0f} ms", ro.graph_report() if a.graphs else "")
 for _ in range(a.iters):
     t0 = time.perf_counter()
     dec, t_f, t_b = iteration()

@@ -191,7 +191,7 @@ class _LanguageFn(torch.autograd.Function):
         plan = dict(B=B, L=L, txt_ids=txt_ids.reshape(-1).to(torch.int32), txt_mask=txt_masks.to(torch.uint8).contiguous(),
                     lens=dict(txt=lens), txt_tokens=int(sum(lens)))
         c = net.text_fwd(plan)
-        ctx.model, ctx.c, ctx.plan = model, c, plan
+        ctx.model, ctx.c, ctx.plan, ctx.drop = model, c, plan, net.drop
         return c.out.view(B, L, net.H), c.P[..., :L]
 
     @staticmethod
@@ -205,45 +205,67 @@ class _LanguageFn(torch.autograd.Function):
         if d_attn is not None:
             dP = torch.zeros(B, net.nh, L, c.ldp, dtype=torch.float32, device=c.out.device)
             dP[..., :L] = d_attn.float()
-        net.text_bwd(c, ctx.plan, d, dP)
+        cur = net.drop
+        net.drop = ctx.drop                 # the row-block backward regenerates the masks of THIS call (later forwards re-armed net.drop)
+        try:
+            net.text_bwd(c, ctx.plan, d, dP)
+        finally:
+            net.drop = cur
         return None, None, None, None
+
+
+def pano_forward_body(model, view_img_fts, loc_fts, nav_types, view_lens, pano_masks=None):
+    """the panorama segment on the engine: returns (ctx namespace, plan, (pano_embeds, masks, fused, img_attns)).  Plain function: the
+    eager autograd Function below and the captured step instances (host/step_graphs.py) both run it."""
+    net = model.net
+    B, V, D = view_img_fts.shape
+    dev = view_img_fts.device
+    if pano_masks is None:          # index-plan rollouts hand the mask over with the step's other index arrays (no launches here)
+        pano_masks = torch.arange(V, device=dev)[None] < view_lens[:, None]
+    plan = dict(Np=B, V=V, nav_types=_i32(nav_types.reshape(-1)), view_lens=_i32(view_lens), pano_mask=_u8(pano_masks))
+    if view_img_fts.dtype == net.dtype:     # gathered from the HBM feature table in the compute dtype already
+        feats = view_img_fts.detach().reshape(B * V, D).contiguous()
+    else:
+        feats = O.cast_to(view_img_fts.detach().float().reshape(B * V, D).contiguous(), net.dtype)
+    c = net.pano_fwd(plan, feats, loc_fts.detach().float().reshape(B * V, -1).contiguous())
+    c.drop = net.drop                       # the backward's row-block launches regenerate THIS call's masks (a later forward re-arms net.drop)
+    masks = plan["pano_mask"].view(torch.bool)
+    return c, plan, (c.out.view(B, V, net.H), masks, c.fused, c.img_attn[..., :V])
+
+
+def pano_backward_body(model, c, plan, d_emb, d_fused, d_attn):
+    net = model.net
+    Np, V, H = c.Np, c.V, net.H
+    dev = c.out.device
+    d_pano = torch.zeros(Np * V, H, dtype=net.dtype, device=dev) if d_emb is None else d_emb.to(net.dtype).reshape(Np * V, H).clone()
+    df = None if d_fused is None else d_fused.to(net.dtype).contiguous()
+    dP = None
+    if d_attn is not None:
+        g = torch.zeros(Np, V, c.ldp, dtype=torch.float32, device=dev)
+        g[..., :V] = d_attn.float()
+        dP = torch.empty(Np, net.nh, V, c.ldp, dtype=torch.float32, device=dev)
+        O.head_mean_bwd(g, dP, Np, net.nh, V * c.ldp)
+    cur = net.drop
+    net.drop = getattr(c, "drop", cur)
+    try:
+        net.pano_bwd(c, plan, d_pano, df, dP)
+    finally:
+        net.drop = cur
 
 
 class _PanoramaFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, view_img_fts, loc_fts, nav_types, view_lens, pano_masks=None):
-        net = model.net
-        B, V, D = view_img_fts.shape
-        dev = view_img_fts.device
-        if pano_masks is None:          # index-plan rollouts hand the mask over with the step's other index arrays (no launches here)
-            pano_masks = torch.arange(V, device=dev)[None] < view_lens[:, None]
-        plan = dict(Np=B, V=V, nav_types=_i32(nav_types.reshape(-1)), view_lens=_i32(view_lens), pano_mask=_u8(pano_masks))
-        if view_img_fts.dtype == net.dtype:     # gathered from the HBM feature table in the compute dtype already
-            feats = view_img_fts.detach().reshape(B * V, D).contiguous()
-        else:
-            feats = O.cast_to(view_img_fts.detach().float().reshape(B * V, D).contiguous(), net.dtype)
-        c = net.pano_fwd(plan, feats, loc_fts.detach().float().reshape(B * V, -1).contiguous())
+        c, plan, outs = pano_forward_body(model, view_img_fts, loc_fts, nav_types, view_lens, pano_masks)
         ctx.model, ctx.c, ctx.plan = model, c, plan
-        masks = plan["pano_mask"].view(torch.bool)
-        ctx.mark_non_differentiable(masks)
-        return c.out.view(B, V, net.H), masks, c.fused, c.img_attn[..., :V]
+        ctx.mark_non_differentiable(outs[1])
+        return outs
 
     @staticmethod
     def backward(ctx, d_emb, _dm, d_fused, d_attn):
-        net, c = ctx.model.net, ctx.c
-        net.S.ensure_grads()
+        ctx.model.net.S.ensure_grads()
         _queue_sync(ctx.model)
-        Np, V, H = c.Np, c.V, net.H
-        dev = c.out.device
-        d_pano = torch.zeros(Np * V, H, dtype=net.dtype, device=dev) if d_emb is None else d_emb.to(net.dtype).reshape(Np * V, H).clone()
-        df = None if d_fused is None else d_fused.to(net.dtype).contiguous()
-        dP = None
-        if d_attn is not None:
-            g = torch.zeros(Np, V, c.ldp, dtype=torch.float32, device=dev)
-            g[..., :V] = d_attn.float()
-            dP = torch.empty(Np, net.nh, V, c.ldp, dtype=torch.float32, device=dev)
-            O.head_mean_bwd(g, dP, Np, net.nh, V * c.ldp)
-        net.pano_bwd(c, ctx.plan, d_pano, df, dP)
+        pano_backward_body(ctx.model, ctx.c, ctx.plan, d_emb, d_fused, d_attn)
         return None, None, None, None, None, None, None
 
 
@@ -288,13 +310,18 @@ class _TextKVFn(torch.autograd.Function):
     autograd sums them, and this backward runs the projection's weight / input gradients ONCE on the sum."""
 
     @staticmethod
-    def forward(ctx, anchor, model, txt_embeds):
+    def forward(ctx, anchor, model, txt_embeds, out=None):
         net = model.net
         B, L, H = txt_embeds.shape
         M = B * L
         txt = txt_embeds.detach().to(net.dtype).reshape(M, H).contiguous()
         lins = _kv_lins(model)
-        out = net.new(len(lins), M, 2 * H)
+        if out is None:
+            out = net.new(len(lins), M, 2 * H)
+        else:                              # a static home (host/step_graphs.TextSlot): captured step graphs read the cache at a fixed address
+            if tuple(out.shape) != (len(lins), M, 2 * H) or out.dtype != net.dtype or not out.is_contiguous():
+                raise ValueError(f"text_kv: out must be a contiguous {net.dtype} tensor of shape {(len(lins), M, 2 * H)}")
+            out = out.detach()
         for i, kvl in enumerate(lins):
             O.linear_fwd(txt, kvl.W, kvl.b, M, out=out[i])
         ctx.model, ctx.txt, ctx.shape, ctx.in_dtype = model, txt, (B, L, H), txt_embeds.dtype
@@ -312,115 +339,135 @@ class _TextKVFn(torch.autograd.Function):
         for i, kvl in enumerate(_kv_lins(model)):
             O.linear_dw(dkv[i], ctx.txt, kvl.dW, kvl.db, M)
             O.linear_dx(dkv[i], kvl.W, M, out=d_txt, residual=d_txt)
-        return None, None, d_txt.view(B, L, H).to(ctx.in_dtype)
+        return None, None, d_txt.view(B, L, H).to(ctx.in_dtype), None
+
+
+def nav_forward_body(model, gmap_img, vp_img, txt_embeds, b, txt_kv=None):
+    """the navigation segment (both cross-modal encoders + heads + logit fusion) on the engine: returns (ctx namespace, outputs).  Plain
+    function: run by the eager autograd Function below and by the captured step instances (host/step_graphs.py)."""
+    net, p = model.net, model.prefix
+    H = net.H
+    dev = gmap_img.device
+    B, K, _ = gmap_img.shape
+    Vp = vp_img.shape[1]
+    L = txt_embeds.shape[1]
+    txt_masks = b["txt_masks"]
+    hl = b.get("host_lens")          # index-plan rollout: the host already knows every length (no device->host sync)
+    tl, gl_, vl = hl if hl is not None else (txt_masks.sum(1).tolist(), b["gmap_masks"].sum(1).tolist(), b["vp_masks"].sum(1).tolist())
+    plan = dict(B=B, K=K, Vp=Vp, L=L, gmap_step_ids=_i32(b["gmap_step_ids"].reshape(-1)))
+    c = Ctx(plan=plan, B=B, K=K, Vp=Vp, L=L)
+    txt = txt_embeds.detach().to(net.dtype).reshape(B * L, H).contiguous()
+    tmask, gmask_u8, vmask_u8 = _u8(txt_masks), _u8(b["gmap_masks"]), _u8(b["vp_masks"])
+    c.gin, c.vin = net.nodes_in_fwd(plan, None, b["gmap_pos_fts"].float().reshape(B * K, -1).contiguous(),
+                                    b["vp_pos_fts"].float().reshape(B * Vp, -1).contiguous(),
+                                    gimg=gmap_img.detach().to(net.dtype).reshape(B * K, H).contiguous(),
+                                    vimg=vp_img.detach().to(net.dtype).reshape(B * Vp, H).contiguous())
+    nl = net.cfg.num_x_layers
+    kv = None if txt_kv is None else txt_kv.detach()
+    c.has_kv = kv is not None
+    c.glob = net.cross_fwd("global", plan, c.gin.out, K, gmask_u8, gl_, int(sum(gl_)), txt, L, tmask, tl, int(sum(tl)),
+                           dist=b["gmap_pair_dists"].float().contiguous(), kv=None if kv is None else kv[:nl])
+    c.loc = net.cross_fwd("local", plan, c.vin.out, Vp, vmask_u8, vl, int(sum(vl)), txt, L, tmask, tl, int(sum(tl)),
+                          kv=None if kv is None else kv[nl:])
+    # heads
+    c.Yg, c.g_raw = model._cls(p + "global_sap_head.", c.glob.out, B * K)
+    c.Yl, c.l_raw = model._cls(p + "local_sap_head.", c.loc.out, B * Vp)
+    c.use_gate = bool(cfg_get(net.cfg, "glocal_fuse"))
+    if c.use_gate:
+        f1 = net.lin(p + "sap_fuse_linear.net.0.weight")
+        tmp = O.linear_fwd(c.glob.out, f1.W, None, B, lda=K * H, ldb=2 * H, K=H)
+        c.Yf = O.linear_fwd(c.loc.out, f1.W[:, H:], f1.b, B, lda=Vp * H, ldb=2 * H, K=H, residual=tmp)
+        O.dact(c.Yf, c.Yf, 2, out=c.Yf)
+        fln, f2 = net.ln(p + "sap_fuse_linear.net.2"), net.lin(p + "sap_fuse_linear.net.3.weight")
+        c.fuse_raw = net.new(B, dtype=torch.float32)
+        O.lndot_fwd(c.Yf, B, H, fln.g, fln.b, net.eps, f2.Wm, f2.b, c.fuse_raw)
+    else:
+        c.fuse_raw = net.zeros(B, dtype=torch.float32)
+    if b.get("gmap_logit_masks") is not None:      # ~visited & valid, built with the step's other index arrays (host/nav_plan.py)
+        c.gmask = _u8(b["gmap_logit_masks"])
+    else:
+        c.gmask = _u8((~b["gmap_visited_masks"]) & b["gmap_masks"])
+    c.lmask = _u8(b["vp_nav_masks"])
+    if b.get("fusion") is not None:   # (fsrc int32 [B,K], bw uint8 [B,Vp]) already on the device (host/nav_plan.fusion_map)
+        c.fsrc, c.bw = b["fusion"]
+    else:
+        fsrc, bw = nav_fusion_plan(b["gmap_vpids"], b["gmap_visited_masks"], b["vp_cand_vpids"], K, Vp)
+        c.fsrc, c.bw = torch.from_numpy(fsrc).to(dev), torch.from_numpy(bw).to(dev)
+    gl, ll, fl = net.new(B, K, dtype=torch.float32), net.new(B, Vp, dtype=torch.float32), net.new(B, K, dtype=torch.float32)
+    O.sap_fuse_fwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, c.gmask, c.lmask, c.fsrc, c.bw, c.use_gate, gl, ll, fl)
+    # cls_embeds: the [stop]-token summary the agent feeds back as the [MEM] token (agent.py:206-210); open choice O9
+    cls = net.new(B, H)
+    O.csr_gather(c.glob.out, *model._first_rows(B, K, dev), cls, B, H)
+    O.csr_gather(c.loc.out, *model._first_rows(B, Vp, dev), cls, B, H, accumulate=True)
+    c.drop = net.drop
+    return c, (c.glob.out.view(B, K, H), c.loc.out.view(B, Vp, H), c.glob.P[..., :L], c.loc.P[..., :L], cls, gl, ll, fl)
+
+
+def nav_backward_body(model, c, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl):
+    """returns (d_gmap_img [B*K, H], d_vp_img [B*Vp, H], d_txt [B*L, H] or None, dkv [2 nl, B*L, 2H] or None)"""
+    net, p = model.net, model.prefix
+    B, K, Vp, L, H = c.B, c.K, c.Vp, c.L, net.H
+    dev = c.glob.out.device
+    T = net.dtype
+    d_gmap = torch.zeros(B * K, H, dtype=T, device=dev) if d_g is None else d_g.to(T).reshape(B * K, H).clone()
+    d_vp = torch.zeros(B * Vp, H, dtype=T, device=dev) if d_v is None else d_v.to(T).reshape(B * Vp, H).clone()
+    d_txt = torch.zeros(B * L, H, dtype=T, device=dev)
+    if d_cls is not None:
+        dc = d_cls.to(T).contiguous()
+        O.csr_gather(dc, *model._first_rows_T(B, K, dev), d_gmap, B * K, H, accumulate=True)
+        O.csr_gather(dc, *model._first_rows_T(B, Vp, dev), d_vp, B * Vp, H, accumulate=True)
+    if dgl is not None or dll is not None or dfl is not None:
+        f32 = lambda t: None if t is None else torch.nan_to_num(t.float(), nan=0.0, posinf=0.0, neginf=0.0).contiguous()
+        dg, dl, df = net.new(B, K, dtype=torch.float32), net.new(B, Vp, dtype=torch.float32), net.new(B, dtype=torch.float32)
+        O.sap_fuse_bwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, c.gmask, c.lmask, c.fsrc, c.bw, c.use_gate, f32(dgl), f32(dll), f32(dfl), dg, dl, df)
+        model._cls_bwd(p + "global_sap_head.", c.glob.out, c.Yg, dg, B * K, d_gmap)
+        model._cls_bwd(p + "local_sap_head.", c.loc.out, c.Yl, dl, B * Vp, d_vp)
+        if c.use_gate:
+            f1, fln, f2 = net.lin(p + "sap_fuse_linear.net.0.weight"), net.ln(p + "sap_fuse_linear.net.2"), net.lin(p + "sap_fuse_linear.net.3.weight")
+            dZ = net.new(B, H)
+            O.lndot_bwd(c.Yf, B, H, fln.g, fln.b, net.eps, f2.Wm, df, dZ, fln.dg, fln.db, f2.dW, f2.db)
+            O.linear_dw(dZ, c.glob.out, f1.dW, f1.db, B, N=H, K=H, ldb=K * H, ldc=2 * H)
+            O.linear_dw(dZ, c.loc.out, f1.dW[:, H:], None, B, N=H, K=H, ldb=Vp * H, ldc=2 * H)
+            O.linear_dx(dZ, f1.W, B, out=d_gmap, residual=d_gmap, ldb=2 * H, ldc=K * H, N=H, K=H)
+            O.linear_dx(dZ, f1.W[:, H:], B, out=d_vp, residual=d_vp, ldb=2 * H, ldc=Vp * H, N=H, K=H)
+
+    def attn_seed(d, P, Nq):
+        if d is None:
+            return None
+        dP = torch.zeros(B, net.nh, Nq, P.shape[-1], dtype=torch.float32, device=dev)
+        dP[..., :L] = d.float()
+        return dP
+    nl = net.cfg.num_x_layers
+    dkv = net.new(2 * nl, B * L, 2 * H) if c.has_kv else None
+    cur = net.drop
+    net.drop = getattr(c, "drop", cur)      # the row-block backward launches regenerate the masks of THIS call's forward
+    try:
+        d_gin = net.cross_bwd(c.glob, d_gmap, d_txt, attn_seed(d_ga, c.glob.P, K), dkv=None if dkv is None else dkv[:nl])
+        d_vin = net.cross_bwd(c.loc, d_vp, d_txt, attn_seed(d_va, c.loc.P, Vp), dkv=None if dkv is None else dkv[nl:])
+    finally:
+        net.drop = cur
+    net.gmap_in_bwd(c.gin, c.plan, d_gin, None, None)
+    net.vp_in_bwd(c.vin, c.plan, d_vin, None)
+    return d_gin, d_vin, (None if c.has_kv else d_txt), dkv
 
 
 class _NavigationFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, gmap_img, vp_img, txt_embeds, b, txt_kv=None):
-        net, p = model.net, model.prefix
-        H = net.H
-        dev = gmap_img.device
-        B, K, _ = gmap_img.shape
-        Vp = vp_img.shape[1]
-        L = txt_embeds.shape[1]
-        txt_masks = b["txt_masks"]
-        hl = b.get("host_lens")          # index-plan rollout: the host already knows every length (no device->host sync)
-        tl, gl_, vl = hl if hl is not None else (txt_masks.sum(1).tolist(), b["gmap_masks"].sum(1).tolist(), b["vp_masks"].sum(1).tolist())
-        plan = dict(B=B, K=K, Vp=Vp, L=L, gmap_step_ids=_i32(b["gmap_step_ids"].reshape(-1)))
-        c = Ctx(plan=plan, B=B, K=K, Vp=Vp, L=L)
-        txt = txt_embeds.detach().to(net.dtype).reshape(B * L, H).contiguous()
-        tmask, gmask_u8, vmask_u8 = _u8(txt_masks), _u8(b["gmap_masks"]), _u8(b["vp_masks"])
-        c.gin, c.vin = net.nodes_in_fwd(plan, None, b["gmap_pos_fts"].float().reshape(B * K, -1).contiguous(),
-                                        b["vp_pos_fts"].float().reshape(B * Vp, -1).contiguous(),
-                                        gimg=gmap_img.detach().to(net.dtype).reshape(B * K, H).contiguous(),
-                                        vimg=vp_img.detach().to(net.dtype).reshape(B * Vp, H).contiguous())
-        nl = net.cfg.num_x_layers
-        kv = None if txt_kv is None else txt_kv.detach()
-        c.has_kv = kv is not None
-        c.glob = net.cross_fwd("global", plan, c.gin.out, K, gmask_u8, gl_, int(sum(gl_)), txt, L, tmask, tl, int(sum(tl)),
-                               dist=b["gmap_pair_dists"].float().contiguous(), kv=None if kv is None else kv[:nl])
-        c.loc = net.cross_fwd("local", plan, c.vin.out, Vp, vmask_u8, vl, int(sum(vl)), txt, L, tmask, tl, int(sum(tl)),
-                              kv=None if kv is None else kv[nl:])
-        # heads
-        c.Yg, c.g_raw = model._cls(p + "global_sap_head.", c.glob.out, B * K)
-        c.Yl, c.l_raw = model._cls(p + "local_sap_head.", c.loc.out, B * Vp)
-        c.use_gate = bool(cfg_get(net.cfg, "glocal_fuse"))
-        if c.use_gate:
-            f1 = net.lin(p + "sap_fuse_linear.net.0.weight")
-            tmp = O.linear_fwd(c.glob.out, f1.W, None, B, lda=K * H, ldb=2 * H, K=H)
-            c.Yf = O.linear_fwd(c.loc.out, f1.W[:, H:], f1.b, B, lda=Vp * H, ldb=2 * H, K=H, residual=tmp)
-            O.dact(c.Yf, c.Yf, 2, out=c.Yf)
-            fln, f2 = net.ln(p + "sap_fuse_linear.net.2"), net.lin(p + "sap_fuse_linear.net.3.weight")
-            c.fuse_raw = net.new(B, dtype=torch.float32)
-            O.lndot_fwd(c.Yf, B, H, fln.g, fln.b, net.eps, f2.Wm, f2.b, c.fuse_raw)
-        else:
-            c.fuse_raw = net.zeros(B, dtype=torch.float32)
-        if b.get("gmap_logit_masks") is not None:      # ~visited & valid, built with the step's other index arrays (host/nav_plan.py)
-            c.gmask = _u8(b["gmap_logit_masks"])
-        else:
-            c.gmask = _u8((~b["gmap_visited_masks"]) & b["gmap_masks"])
-        c.lmask = _u8(b["vp_nav_masks"])
-        if b.get("fusion") is not None:   # (fsrc int32 [B,K], bw uint8 [B,Vp]) already on the device (host/nav_plan.fusion_map)
-            c.fsrc, c.bw = b["fusion"]
-        else:
-            fsrc, bw = nav_fusion_plan(b["gmap_vpids"], b["gmap_visited_masks"], b["vp_cand_vpids"], K, Vp)
-            c.fsrc, c.bw = torch.from_numpy(fsrc).to(dev), torch.from_numpy(bw).to(dev)
-        gl, ll, fl = net.new(B, K, dtype=torch.float32), net.new(B, Vp, dtype=torch.float32), net.new(B, K, dtype=torch.float32)
-        O.sap_fuse_fwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, c.gmask, c.lmask, c.fsrc, c.bw, c.use_gate, gl, ll, fl)
-        # cls_embeds: the [stop]-token summary the agent feeds back as the [MEM] token (agent.py:206-210); open choice O9
-        cls = net.new(B, H)
-        O.csr_gather(c.glob.out, *model._first_rows(B, K, dev), cls, B, H)
-        O.csr_gather(c.loc.out, *model._first_rows(B, Vp, dev), cls, B, H, accumulate=True)
+        c, outs = nav_forward_body(model, gmap_img, vp_img, txt_embeds, b, txt_kv)
         ctx.model, ctx.c = model, c
         ctx.in_dtypes = (gmap_img.dtype, vp_img.dtype, txt_embeds.dtype)
-        return (c.glob.out.view(B, K, H), c.loc.out.view(B, Vp, H), c.glob.P[..., :L], c.loc.P[..., :L], cls, gl, ll, fl)
+        return outs
 
     @staticmethod
     def backward(ctx, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl):
         model, c = ctx.model, ctx.c
-        net, p = model.net, model.prefix
-        net.S.ensure_grads()
+        model.net.S.ensure_grads()
         _queue_sync(model)
-        B, K, Vp, L, H = c.B, c.K, c.Vp, c.L, net.H
-        dev = c.glob.out.device
-        T = net.dtype
-        d_gmap = torch.zeros(B * K, H, dtype=T, device=dev) if d_g is None else d_g.to(T).reshape(B * K, H).clone()
-        d_vp = torch.zeros(B * Vp, H, dtype=T, device=dev) if d_v is None else d_v.to(T).reshape(B * Vp, H).clone()
-        d_txt = torch.zeros(B * L, H, dtype=T, device=dev)
-        if d_cls is not None:
-            dc = d_cls.to(T).contiguous()
-            O.csr_gather(dc, *model._first_rows_T(B, K, dev), d_gmap, B * K, H, accumulate=True)
-            O.csr_gather(dc, *model._first_rows_T(B, Vp, dev), d_vp, B * Vp, H, accumulate=True)
-        if dgl is not None or dll is not None or dfl is not None:
-            f32 = lambda t: None if t is None else torch.nan_to_num(t.float(), nan=0.0, posinf=0.0, neginf=0.0).contiguous()
-            dg, dl, df = net.new(B, K, dtype=torch.float32), net.new(B, Vp, dtype=torch.float32), net.new(B, dtype=torch.float32)
-            O.sap_fuse_bwd(B, K, Vp, c.g_raw, c.l_raw, c.fuse_raw, c.gmask, c.lmask, c.fsrc, c.bw, c.use_gate, f32(dgl), f32(dll), f32(dfl), dg, dl, df)
-            model._cls_bwd(p + "global_sap_head.", c.glob.out, c.Yg, dg, B * K, d_gmap)
-            model._cls_bwd(p + "local_sap_head.", c.loc.out, c.Yl, dl, B * Vp, d_vp)
-            if c.use_gate:
-                f1, fln, f2 = net.lin(p + "sap_fuse_linear.net.0.weight"), net.ln(p + "sap_fuse_linear.net.2"), net.lin(p + "sap_fuse_linear.net.3.weight")
-                dZ = net.new(B, H)
-                O.lndot_bwd(c.Yf, B, H, fln.g, fln.b, net.eps, f2.Wm, df, dZ, fln.dg, fln.db, f2.dW, f2.db)
-                O.linear_dw(dZ, c.glob.out, f1.dW, f1.db, B, N=H, K=H, ldb=K * H, ldc=2 * H)
-                O.linear_dw(dZ, c.loc.out, f1.dW[:, H:], None, B, N=H, K=H, ldb=Vp * H, ldc=2 * H)
-                O.linear_dx(dZ, f1.W, B, out=d_gmap, residual=d_gmap, ldb=2 * H, ldc=K * H, N=H, K=H)
-                O.linear_dx(dZ, f1.W[:, H:], B, out=d_vp, residual=d_vp, ldb=2 * H, ldc=Vp * H, N=H, K=H)
-
-        def attn_seed(d, P, Nq):
-            if d is None:
-                return None
-            dP = torch.zeros(B, net.nh, Nq, P.shape[-1], dtype=torch.float32, device=dev)
-            dP[..., :L] = d.float()
-            return dP
-        nl = net.cfg.num_x_layers
-        dkv = net.new(2 * nl, B * L, 2 * H) if c.has_kv else None
-        d_gin = net.cross_bwd(c.glob, d_gmap, d_txt, attn_seed(d_ga, c.glob.P, K), dkv=None if dkv is None else dkv[:nl])
-        d_vin = net.cross_bwd(c.loc, d_vp, d_txt, attn_seed(d_va, c.loc.P, Vp), dkv=None if dkv is None else dkv[nl:])
-        net.gmap_in_bwd(c.gin, c.plan, d_gin, None, None)
-        net.vp_in_bwd(c.vin, c.plan, d_vin, None)
+        B, K, Vp, L, H = c.B, c.K, c.Vp, c.L, model.net.H
+        d_gin, d_vin, d_txt, dkv = nav_backward_body(model, c, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl)
         a, b_, t_ = ctx.in_dtypes
-        return (None, None, d_gin.view(B, K, H).to(a), d_vin.view(B, Vp, H).to(b_), None if c.has_kv else d_txt.view(B, L, H).to(t_), None, dkv)
+        return (None, None, d_gin.view(B, K, H).to(a), d_vin.view(B, Vp, H).to(b_), None if d_txt is None else d_txt.view(B, L, H).to(t_), None, dkv)
 
 
 class VLNBert(nn.Module):
@@ -481,11 +528,11 @@ class VLNBert(nn.Module):
         self._first_rows(B, N, dev)
         return self._rows[("t", B, N)]
 
-    def text_kv(self, txt_embeds):
+    def text_kv(self, txt_embeds, out=None):
         """per-episode key/value projections of the instruction for the navigation steps: pass the result as
         `inputs['txt_kv']` of every `vln_bert('navigation', inputs)` call of the episode (optional; identical results)"""
         self.store.sync_shadow()
-        return _TextKVFn.apply(self._anchor, self, txt_embeds)
+        return _TextKVFn.apply(self._anchor, self, txt_embeds, out)
 
     def forward(self, mode, batch):
         refuse_torch_ddp(self)

@@ -66,10 +66,11 @@ class NavPlanner:
     """Host mirror of one rollout: owns the per-episode GraphMaps, emits one plan (dict of numpy arrays) per step."""
 
     def __init__(self, env, obs, feedback="teacher", max_action_len=15, expert_policy="spl", angle_table=None, train=True,
-                 pad_V=0, pad_K=0):
-        """pad_V / pad_K: minimum padded view / map-token counts (static shapes for a HIP-graph step: host/nav_graph.py); padded
-        tokens are masked everywhere, so the valid outputs do not change."""
-        self.pad_V, self.pad_K = pad_V, pad_K
+                 pad_V=0, pad_K=0, k_bucket=1):
+        """pad_V / pad_K: minimum padded view / map-token counts (static shapes for a HIP-graph step: host/nav_graph.py); k_bucket: the
+        map-token count of a step is rounded up to a multiple of it (shape buckets of the captured training steps: host/step_graphs.py);
+        padded tokens are masked everywhere, so the valid outputs do not change."""
+        self.pad_V, self.pad_K, self.k_bucket = pad_V, pad_K, max(1, int(k_bucket))
         self.env, self.obs = env, obs
         self.B = len(obs)
         # feedback: one mode for the batch, or one per episode -- an iteration's teacher-forced and DAgger rollouts
@@ -192,7 +193,7 @@ class NavPlanner:
             vpid_lists.append([None, None] + vis + unv)
             node_ids.append((len(vis), len(unv)))
             lens[i] = 2 + len(vis) + len(unv)
-        K = max(int(lens.max()), self.pad_K)
+        K = max((int(lens.max()) + self.k_bucket - 1) // self.k_bucket * self.k_bucket, self.pad_K)
         Vp = V + 2
         step_ids = np.zeros((B, K), np.int64)
         pos = np.zeros((B, K, 7), np.float32)

@@ -50,9 +50,10 @@ class _LogGather(torch.autograd.Function):
     were copied from (`srcs[i]` occupies log rows [spans[i][0], spans[i][1]))."""
 
     @staticmethod
-    def forward(ctx, log, csr, csr_t, n_out, n_src, spans, *srcs):
+    def forward(ctx, log, csr, csr_t, n_out, n_src, spans, out, *srcs):
         H = log.shape[1]
-        out = torch.empty(n_out, H, dtype=log.dtype, device=log.device)
+        # out: a static buffer to gather into (the input of a captured step instance, host/step_graphs.py) or None
+        out = torch.empty(n_out, H, dtype=log.dtype, device=log.device) if out is None else out.detach()
         O.csr_gather(log, csr[0], csr[1], csr[2], out, n_out, H)
         ctx.csr_t, ctx.n_src, ctx.spans = csr_t, n_src, spans
         ctx.shapes = [s.shape for s in srcs]
@@ -65,7 +66,7 @@ class _LogGather(torch.autograd.Function):
         dlog = torch.empty(ctx.n_src, H, dtype=d_out.dtype, device=d_out.device)
         O.csr_gather(d_out.contiguous(), ctx.csr_t[0], ctx.csr_t[1], ctx.csr_t[2], dlog, ctx.n_src, H)
         grads = [dlog[a:b].view(shp) if b <= ctx.n_src else None for (a, b), shp in zip(ctx.spans, ctx.shapes)]
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 class EmbeddingLog:
@@ -87,29 +88,45 @@ class EmbeddingLog:
             self.srcs.append(x)
             self.spans.append((row0, row0 + n))
 
-    def gather(self, csr, csr_t, n_out, n_src, grad=True):
+    def gather(self, csr, csr_t, n_out, n_src, grad=True, out=None):
         if grad and self.srcs:
-            return _LogGather.apply(self.buf, csr, csr_t, n_out, n_src, list(self.spans), *self.srcs)
-        out = torch.empty(n_out, self.buf.shape[1], dtype=self.buf.dtype, device=self.buf.device)
+            return _LogGather.apply(self.buf, csr, csr_t, n_out, n_src, list(self.spans), out, *self.srcs)
+        if out is None:
+            out = torch.empty(n_out, self.buf.shape[1], dtype=self.buf.dtype, device=self.buf.device)
         O.csr_gather(self.buf, csr[0], csr[1], csr[2], out, n_out, self.buf.shape[1])
         return out
 
 
 class NavRollout:
     def __init__(self, student, feature_table, teacher=None, kd=None, max_action_len=15, expert_policy="spl", cache_text_kv=True,
-                 train_teacher=False):
+                 train_teacher=False, graphs=False, Lcap=None):
         """feature_table: [n_viewpoints, 36, D] device tensor in the student's compute dtype (packed once, SURVEY f-2).
         kd: dict(alpha, temperature, decay[, ability_weight]) -- MAKD hyper-parameters (run_r2r_kdl_valid.sh:97-104); ability_weight =
         args.kdl_adaptive_ability_weight_type: 'RW' (default: the `rw_seq` scalars a caller passes), 'learned_weight' (softplus of the
-        learner model's kdl_*_weight parameters, agent.py:583-586) or None."""
+        learner model's kdl_*_weight parameters, agent.py:583-586) or None.
+        graphs: run the panorama / navigation segments of every TRAINING step as captured HIP graphs on per-step instances
+        (host/step_graphs.py); Lcap = the instruction length the static shapes are built for (args.max_instr_len; longer batches run eagerly)."""
         self.student, self.teacher, self.kd = student, teacher, kd
         self.table = feature_table
         self.T, self.expert = max_action_len, expert_policy
         self.cache_text_kv = cache_text_kv
         self.train_teacher = bool(train_teacher) and teacher is not None      # ICoD co-training (args.train_kdl_teacher)
         self.dev = feature_table.device
+        self.graphs, self.Lcap, self._sg = bool(graphs) and Lcap is not None and cache_text_kv, Lcap, {}
         if teacher is not None:
             self.heads = {n: getattr(student.vln_bert, n) for n in ("txt_emb_w", "kdl_img_w", "kdl_avg_img_w", "global_cross_w", "local_cross_w")}
+
+    def step_graphs(self, model, B):
+        """the model's pools of captured step instances for batches of B episodes (created on first use)"""
+        from .step_graphs import StepGraphs
+        sg = self._sg.get(id(model))
+        if sg is None or sg.B != B:
+            sg = self._sg[id(model)] = StepGraphs(model, self.table, B, self.Lcap)
+        return sg
+
+    def graph_report(self):
+        return {("teacher" if m is self.teacher else "student"): self._sg[id(m)].report() for m in (self.student, self.teacher)
+                if m is not None and id(m) in self._sg}
 
     def _pano_inputs(self, d, plan):
         B, V = plan["B"], plan["V"]
@@ -143,7 +160,7 @@ class NavRollout:
         and launches the next rollout's step while the GPU works, so the per-step action copy of a 'sample' rollout and its planning no
         longer leave the GPU idle (the iteration's teacher-forced and DAgger rollouts: agent_base.py:243-250).  Needs one stepper per
         rollout; the rollouts are independent, so the results equal those of running them one after the other."""
-        gens = [self.steps(*a, **k) for a, k in jobs]
+        gens = [self.steps(*a, **dict(k, slot=k.get("slot", i))) for i, (a, k) in enumerate(jobs)]
         res = [None] * len(gens)
         live = list(range(len(gens)))
         while live:
@@ -155,14 +172,16 @@ class NavRollout:
                     live.remove(i)
         return res
 
-    def steps(self, env, obs, feedback="teacher", train_ml=1.0, rw_seq=None, sample_draws=None, grad=True, record=False, text_copies=1):
+    def steps(self, env, obs, feedback="teacher", train_ml=1.0, rw_seq=None, sample_draws=None, grad=True, record=False, text_copies=1, slot=0):
         """Generator form of one batch of episodes: yields after launching each step, returns the result dict.
 
         feedback / train_ml may be per-episode lists: the two rollouts of a fine-tuning iteration (teacher-forced with ml_weight,
         then 'sample' with weight 1 on the SAME episodes; agent_base.py:243-250) are independent per episode, so they can run as one
         batch of 2B episodes -- half the launches, twice the rows per launch.  text_copies = k: the batch is k copies of the same
         B / k instructions (that case): the text encoder and the K/V projections run once on B / k and are tiled.  The loss is
-        divided by B / text_copies, i.e. it equals the sum of the separate rollouts' losses."""
+        divided by B / text_copies, i.e. it equals the sum of the separate rollouts' losses.
+        slot: which static instruction slot the captured step instances of this rollout read (`graphs=True`): rollouts whose autograd
+        graphs are alive at the same time (the iteration's two) take different slots."""
         st, te, dev = self.student, self.teacher, self.dev
         B = len(obs)
         per_episode = not isinstance(feedback, str)
@@ -171,8 +190,16 @@ class NavRollout:
         Bn = B // text_copies                                    # loss normaliser (the reference's batch_size of ONE rollout)
         w_host = [float(train_ml)] * B if isinstance(train_ml, (int, float)) else [float(x) for x in train_ml]
         w_ml = torch.tensor(w_host, dtype=torch.float32, device=dev)
-        pl = NavPlanner(env, obs, feedback=feedback, max_action_len=self.T, expert_policy=self.expert, train=grad)
+        tt_grad = self.train_teacher and grad
+        use_g = self.graphs and grad and text_copies == 1 and max(len(ob["instr_encoding"]) for ob in obs) <= self.Lcap
+        from .step_graphs import K_BUCKET, V_STATIC
+        pl = NavPlanner(env, obs, feedback=feedback, max_action_len=self.T, expert_policy=self.expert, train=grad,
+                        pad_V=V_STATIC if use_g else 0, k_bucket=K_BUCKET if use_g else 1)
         lang = pl.language()
+        if use_g:                       # static shapes: the instruction padded to Lcap tokens (masked)
+            ids = np.zeros((B, self.Lcap), np.int64)
+            ids[:, :lang["txt_ids"].shape[1]] = lang["txt_ids"]
+            lang = dict(lang, txt_ids=ids)
         ld = to_device(dict(txt_ids=lang["txt_ids"][:Bn]), dev)
         L = lang["txt_ids"].shape[1]
         txt_lens = [int(x) for x in lang["txt_lens"]]
@@ -181,20 +208,38 @@ class NavRollout:
         lin = dict(txt_ids=ld["txt_ids"], txt_masks=u_masks)
         tile = (lambda x, dim=0: torch.cat([x] * text_copies, dim)) if text_copies > 1 else (lambda x, dim=0: x)
         ctxg = torch.enable_grad() if grad else torch.no_grad()
+        sgs = sgt = None
         with ctxg:
+            if use_g:
+                sgs = self.step_graphs(st, B)
+                sgs = sgs if sgs.usable() else None
             txt_embeds, txt_attns = st("language", lin)
-            txt_kv = st.text_kv(txt_embeds) if self.cache_text_kv else None      # once per episode, not once per step
+            if sgs is not None:
+                sl = sgs.text_slot(slot)
+                sl.version += 1
+                sl.masks.copy_(u_masks)
+                txt_kv = st.text_kv(txt_embeds, out=sl.kv)
+            else:
+                txt_kv = st.text_kv(txt_embeds) if self.cache_text_kv else None      # once per episode, not once per step
             txt_embeds, txt_attns = tile(txt_embeds), tile(txt_attns)
             txt_kv = tile(txt_kv, 1) if txt_kv is not None else None
         s_out = dict(txt_embeds=txt_embeds, txt_attns=txt_attns)
         t_out = {}
-        tt_grad = self.train_teacher and grad
         tctx = torch.enable_grad if tt_grad else torch.no_grad
         t_ml_loss, t_kdl = torch.zeros((), dtype=torch.float32, device=dev), {}
         if te is not None:
             with tctx():
+                if use_g and tt_grad:
+                    sgt = self.step_graphs(te, B)
+                    sgt = sgt if sgt.usable() else None
                 t_txt, t_txt_attns = te("language", lin)
-                t_kv = te.text_kv(t_txt) if self.cache_text_kv else None
+                if sgt is not None:
+                    tsl = sgt.text_slot(slot)
+                    tsl.version += 1
+                    tsl.masks.copy_(u_masks)
+                    t_kv = te.text_kv(t_txt, out=tsl.kv)
+                else:
+                    t_kv = te.text_kv(t_txt) if self.cache_text_kv else None
                 t_txt, t_txt_attns = tile(t_txt), tile(t_txt_attns)
                 t_kv = tile(t_kv, 1) if t_kv is not None else None
             t_out = dict(txt_embeds=t_txt, txt_attns=t_txt_attns)
@@ -209,24 +254,38 @@ class NavRollout:
                 plan = pl.begin_pano()
                 decisions += int((~pl.ended).sum())
                 vl = np.asarray(plan["view_lens"])
-                d = to_device(dict(vp_rows=plan["vp_rows"], view_order=plan["view_order"], loc_fts=plan["loc_fts"],
+                pano_arrays = dict(vp_rows=plan["vp_rows"], view_order=plan["view_order"], loc_fts=plan["loc_fts"],
                                    nav_types=np.asarray(plan["nav_types"]).astype(np.int32), view_lens=vl.astype(np.int32),
-                                   pano_masks=np.arange(plan["V"])[None] < vl[:, None]), dev)      # dtypes the kernels read: no casts on the device
-                pin = self._pano_inputs(d, plan)
-                pe, pm, pf, pa = st("panorama", pin)
+                                   pano_masks=np.arange(plan["V"])[None] < vl[:, None])      # dtypes the kernels read: no casts on the device
+                pi = sgs.pano_inst(plan["V"]) if sgs is not None else None
+                tpi = None
+                if te is not None and sgt is not None:
+                    with tctx():
+                        tpi = sgt.pano_inst(plan["V"])
+                d, pin = {}, None
+                if pi is None or (te is not None and tpi is None):
+                    d = to_device(pano_arrays, dev)
+                    pin = self._pano_inputs(d, plan)
+                pe, pm, pf, pa = sgs.run_pano(pi, pano_arrays) if pi is not None else st("panorama", pin)
                 s_out.update(pano_embeds=pe, pano_fused_embeds=pf, img_attns=pa)
                 if te is not None:
                     with tctx():
-                        tpe, _, tpf, tpa = te("panorama", pin)
+                        tpe, _, tpf, tpa = sgt.run_pano(tpi, pano_arrays) if tpi is not None else te("panorama", pin)
                 # the GPU is busy with the panorama encoder(s): build the second half of the plan now
                 plan.update(pl.begin_nav())
-                arrays = {k: plan[k] for k in ("gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists", "gmap_visited_masks", "gmap_masks",
-                                               "vp_pos_fts", "vp_nav_masks", "vp_masks", "fsrc", "bw", "targets")}
-                arrays["gmap_step_ids"] = np.asarray(plan["gmap_step_ids"]).astype(np.int32)
-                arrays["gmap_logit_masks"] = ~np.asarray(plan["gmap_visited_masks"], bool) & np.asarray(plan["gmap_masks"], bool)
-                arrays.update(csr_ptr=plan["csr"][0], csr_idx=plan["csr"][1], csr_w=plan["csr"][2])
+                fixed = {k: plan[k] for k in ("gmap_pos_fts", "gmap_pair_dists", "gmap_masks", "vp_pos_fts", "vp_nav_masks", "vp_masks", "fsrc", "bw")}
+                fixed["gmap_step_ids"] = np.asarray(plan["gmap_step_ids"]).astype(np.int32)
+                fixed["gmap_logit_masks"] = ~np.asarray(plan["gmap_visited_masks"], bool) & np.asarray(plan["gmap_masks"], bool)
+                arrays = dict(targets=plan["targets"], csr_ptr=plan["csr"][0], csr_idx=plan["csr"][1], csr_w=plan["csr"][2])
                 if plan["csr_t"] is not None:
                     arrays.update(csrt_ptr=plan["csr_t"][0], csrt_idx=plan["csr_t"][1], csrt_w=plan["csr_t"][2])
+                ni = sgs.nav_inst(plan["K"], plan["Vp"], slot) if sgs is not None else None
+                tni = None
+                if te is not None and sgt is not None:
+                    with tctx():
+                        tni = sgt.nav_inst(plan["K"], plan["Vp"], slot)
+                if ni is None or (te is not None and tni is None):      # somebody runs this step eagerly: the fixed-shape arrays travel with the rest
+                    arrays.update(fixed, gmap_visited_masks=plan["gmap_visited_masks"])
                 d2 = to_device(arrays, dev)
                 d2["_stage2"] = d2.pop("_stage")
                 d.update(d2)
@@ -234,9 +293,11 @@ class NavRollout:
                 csr_t = (d["csrt_ptr"], d["csrt_idx"], d["csrt_w"]) if plan["csr_t"] is not None else None
                 s_log.put(plan["log_base"], pe)
                 s_log.put(plan["log_fused"], pf)
-                gathered = s_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=grad)
-                nav = self._nav_inputs(d, plan, gathered, txt_embeds, txt_masks, txt_lens, txt_kv)
-                outs = st("navigation", nav)
+                gathered = s_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=grad, out=ni.gathered if ni is not None else None)
+                if ni is not None:
+                    outs = sgs.run_nav(ni, fixed, gathered, txt_kv)
+                else:
+                    outs = st("navigation", self._nav_inputs(d, plan, gathered, txt_embeds, txt_masks, txt_lens, txt_kv))
                 s_log.put(plan["log_cls"], outs["cls_embeds"])
                 logits = outs["fused_logits"]
                 s_out.update(nav_outs=outs, nav_logits=logits)
@@ -249,8 +310,11 @@ class NavRollout:
                         t_out.update(pano_embeds=tpe, pano_fused_embeds=tpf, img_attns=tpa)
                         t_log.put(plan["log_base"], tpe, track=tt_grad)
                         t_log.put(plan["log_fused"], tpf, track=tt_grad)
-                        tg = t_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=tt_grad)
-                        t_outs = te("navigation", self._nav_inputs(d, plan, tg, t_txt, txt_masks, txt_lens, t_kv))
+                        tg = t_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=tt_grad, out=tni.gathered if tni is not None else None)
+                        if tni is not None:
+                            t_outs = sgt.run_nav(tni, fixed, tg, t_kv)
+                        else:
+                            t_outs = te("navigation", self._nav_inputs(d, plan, tg, t_txt, txt_masks, txt_lens, t_kv))
                         t_log.put(plan["log_cls"], t_outs["cls_embeds"], track=tt_grad)
                         t_out.update(nav_outs=t_outs, nav_logits=t_outs["fused_logits"])
                         t_ce = ce_rows_loss(t_outs["fused_logits"], targets, IGNORE)

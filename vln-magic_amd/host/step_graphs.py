@@ -1,0 +1,340 @@
+"""Captured step instances for navigator TRAINING (BASELINE configs 3 and 5).
+
+The fine-tuning iteration (map_nav_src/r2r/agent_base.py:215-296) is two rollouts of up to `max_action_len` steps, each step three model
+calls, then ONE `loss.backward()` over all of them: ~9 000 kernel launches of 5-25 us issued from Python one by one -- the loop was bound by
+the host (launch + allocation + autograd callbacks: 280 ms of host time for 180 ms of kernels, profiles/micro/nav_kernel_breakdown.py).
+
+Here a step's two heavy segments -- the panorama encoder and the navigation segment (both cross-modal encoders + heads + logit fusion) --
+each run as HIP graphs captured once per *instance*:
+
+  * an instance = static input block + forward graph + backward graph(s) + its OWN activation memory (the graphs' private pool).  The
+    activations a forward replay leaves behind must survive until that step's backward, and a rollout has up to `max_action_len` steps in
+    flight, so the pool holds as many instances per shape as steps were ever alive at once (~40-60 for the iteration's two rollouts: a few
+    hundred MB each at H = 768 -- this is what 288 GB of HBM is for); an instance is checked out by a forward call and returned when the
+    autograd node that owns it dies (the iteration's graph is freed);
+  * shapes are static per instance: B episodes, V = 37 views, map tokens K padded to a bucket, instruction padded to `Lcap` tokens -- padded
+    tokens are masked everywhere, so the valid outputs do not change (same contract as host/nav_graph.py);
+  * the step's index arrays are written into the instance's pinned staging block and reach its device block in ONE copy; the gathered map /
+    viewpoint embeddings are written by the log gather straight into the instance's input buffer; the per-episode instruction K/V cache
+    lives in a static `TextSlot`;
+  * each instance wraps its replays in a torch.autograd.Function, so the loop's Python between the calls (embedding log, cross entropy,
+    MAKD terms, sampling) composes with autograd unchanged; the weight-gradient GEMMs of a step's backward leave in grouped launches INSIDE
+    its backward graph;
+  * dropout: the seed pair of an instance is redrawn by a launch inside its forward graph (`magic_step_rng`: counter-hashed, device-side
+    counter), and its backward graph regenerates the masks from the same words.
+
+Numerics are those of the eager path kernel for kernel (the graphs replay the very launches the eager Functions issue);
+tests/test_step_graphs_gpu.py compares losses, trajectories and every parameter gradient of graph-instanced rollouts with the eager ones.
+"""
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops as O
+from .model_nav import _queue_sync, nav_backward_body, nav_forward_body, pano_backward_body, pano_forward_body
+
+K_BUCKET = 16          # map tokens are padded to a multiple of this
+V_STATIC = 37          # views per panorama the instances are built for (36, or 37 when two candidates share a discretised view)
+
+
+def k_bucket(k, step=K_BUCKET):
+    return (int(k) + step - 1) // step * step
+
+
+class _Block:
+    """named fixed-shape arrays at fixed offsets of ONE pinned staging buffer -> ONE device buffer (one H2D copy per use)"""
+
+    def __init__(self, spec, dev):
+        off, self.layout = 0, {}
+        for name, shape, dt in spec:
+            off = (off + 15) & ~15
+            n = int(np.prod(shape)) * np.dtype(dt).itemsize
+            self.layout[name] = (off, n, tuple(shape), np.dtype(dt))
+            off += n
+        off = max((off + 15) & ~15, 16)
+        self.stage = torch.empty(off, dtype=torch.uint8, pin_memory=True)
+        self.stage_np = self.stage.numpy()
+        self.dbuf = torch.zeros(off, dtype=torch.uint8, device=dev)
+        self.d = {}
+        for name, (o, n, shape, dt) in self.layout.items():
+            self.d[name] = self.dbuf[o:o + n].view(getattr(torch, dt.name)).view(shape)
+
+    def upload(self, arrays):
+        st = self.stage_np
+        for k, a in arrays.items():
+            o, n, shape, dt = self.layout[k]
+            a = np.ascontiguousarray(a)
+            if a.dtype == np.bool_:
+                a = a.view(np.uint8)
+            if a.shape != shape:
+                raise ValueError(f"step instance: array {k!r} has shape {a.shape}, the captured shape is {shape}")
+            st[o:o + n] = a.astype(dt, copy=False).reshape(-1).view(np.uint8)
+        self.dbuf.copy_(self.stage, non_blocking=True)
+
+
+class TextSlot:
+    """static home of one rollout's instruction tensors: K/V cache of the 2 x num_x_layers cross-attention layers, key mask, and the
+    (unused on the cached path, shape only) embeddings.  `version` counts its refills: an instance checks at backward time that the slot
+    still holds the episode its forward read."""
+
+    def __init__(self, model, B, Lcap):
+        net, dev = model.net, model.device_
+        nl = 2 * net.cfg.num_x_layers
+        self.B, self.L = B, Lcap
+        self.kv = torch.zeros(nl, B * Lcap, 2 * net.H, dtype=net.dtype, device=dev)
+        self.masks = torch.zeros(B, Lcap, dtype=torch.uint8, device=dev)
+        self.txt = torch.zeros(B, Lcap, net.H, dtype=net.dtype, device=dev)
+        self.version = 0
+
+
+class _Releaser:
+    """dies with the autograd node that holds it: returns the instance to its pool"""
+    __slots__ = ("inst",)
+
+    def __init__(self, inst):
+        self.inst = inst
+
+    def __del__(self):
+        inst = self.inst
+        if inst is not None:
+            inst.busy = False
+
+
+class _Inst:
+    def __init__(self, owner, kind, key):
+        self.owner, self.kind, self.key = owner, kind, key
+        self.busy = False
+        self.block = None
+        self.g_fwd = None
+        self.bwd = {}              # signature -> (static gradient inputs, graph, outputs)
+        self.c = self.plan = self.out = None
+        self.seed = torch.zeros(2, dtype=torch.int32, device=owner.dev)
+        self.slot = self.slot_version = None
+        self.gathered = None
+
+
+class _PanoInstFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, inst):
+        inst.g_fwd.replay()
+        ctx.inst, ctx.rel = inst, _Releaser(inst)
+        outs = tuple(t.detach() for t in inst.out)        # fresh tensor objects over the instance's memory (autograd writes its edges onto them)
+        ctx.mark_non_differentiable(outs[1])
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_emb, _dm, d_fused, d_attn):
+        inst = ctx.inst
+        model = inst.owner.model
+        model.net.S.ensure_grads()
+        _queue_sync(model)
+        inst.owner._run_bwd(inst, ("d_emb", "d_fused", "d_attn"), (d_emb, d_fused, d_attn))
+        return None, None
+
+
+class _NavInstFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, inst, gathered, txt_kv):
+        inst.g_fwd.replay()
+        ctx.inst, ctx.rel = inst, _Releaser(inst)
+        return tuple(t.detach() for t in inst.out)
+
+    @staticmethod
+    def backward(ctx, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl):
+        inst = ctx.inst
+        model = inst.owner.model
+        if inst.slot.version != inst.slot_version:
+            raise RuntimeError("step instance: the instruction slot was refilled (a newer rollout started) before this rollout's backward ran; "
+                               "back-propagate a rollout before starting the next one on the same slot")
+        model.net.S.ensure_grads()
+        _queue_sync(model)
+        if d_cls is None:                     # (the last step's [cls] feeds nothing: one signature for every step)
+            d_cls = inst.owner._zeros_cls(inst)
+        bo = inst.owner._run_bwd(inst, ("d_g", "d_v", "d_ga", "d_va", "d_cls", "dgl", "dll", "dfl"), (d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl))
+        return None, None, bo["d_gathered"], bo["dkv"]
+
+
+class StepGraphs:
+    """per-(model, feature table) pools of captured panorama / navigation step instances"""
+
+    def __init__(self, model, table, B, Lcap, max_instances=160, base_seed=0x5EED5EED):
+        self.model, self.table, self.B, self.Lcap = model, table, int(B), int(Lcap)
+        self.dev = model.device_
+        self.max_instances = max_instances
+        self.pools = {}            # key -> [instances]
+        self.seen = set()          # keys that ran eagerly once (lazy host-side initialisation happens there, never inside a capture)
+        self.slots = {}
+        self.n_inst = 0
+        self.captures = 0
+        self.pool = torch.cuda.graph_pool_handle()
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.base_seed = int(base_seed)
+        self.rng_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._zc = {}
+
+    # ---- bookkeeping -------------------------------------------------------------------------------------------
+    def _mode_key(self):
+        m = self.model
+        return (bool(m.training), float(m.dropout.p), float(m.attention_dropout.p))
+
+    def usable(self):
+        m = self.model
+        return (m.store.requires_grad and torch.is_grad_enabled() and not m.causal_blocks and self.dev.type == "cuda"
+                and not O.FLOPS["enabled"] and not L.PROFILE["on"])
+
+    def text_slot(self, idx):
+        s = self.slots.get(idx)
+        if s is None:
+            s = self.slots[idx] = TextSlot(self.model, self.B, self.Lcap)
+        return s
+
+    def _acquire(self, kind, key, build):
+        """a free instance of `key`, a newly captured one, or None (first sight of the key / pool exhausted: the caller runs eagerly)"""
+        key = (kind,) + key + self._mode_key()
+        lst = self.pools.setdefault(key, [])
+        for inst in lst:
+            if not inst.busy:
+                inst.busy = True
+                return inst
+        if key not in self.seen:
+            self.seen.add(key)
+            return None
+        if self.n_inst >= self.max_instances:
+            return None
+        inst = _Inst(self, kind, key)
+        build(inst)
+        lst.append(inst)
+        self.n_inst += 1
+        inst.busy = True
+        return inst
+
+    def _capture(self, body):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode="relaxed"):
+            body()
+        self.captures += 1
+        return g
+
+    def _arm(self, inst):
+        """inside a forward capture: redraw this instance's seed pair on the device, arm the model's dropout with it"""
+        m = self.model
+        O.step_rng(self.base_seed, self.rng_counter, 1.0, seed_out=inst.seed)
+        m.dropout_seed = inst.seed
+        try:
+            m._arm_dropout()
+        finally:
+            m.dropout_seed = None
+
+    # ---- panorama ------------------------------------------------------------------------------------------------
+    def pano_inst(self, V):
+        if not self.usable() or V != V_STATIC:
+            return None
+        return self._acquire("pano", (self.B, V), self._build_pano)
+
+    def _build_pano(self, inst):
+        B, V = self.B, V_STATIC
+        f32, i32, u8 = np.float32, np.int32, np.uint8
+        inst.block = _Block([("vp_rows", (B,), i32), ("view_order", (B, V), i32), ("loc_fts", (B, V, 7), f32), ("nav_types", (B, V), i32),
+                             ("view_lens", (B,), i32), ("pano_masks", (B, V), u8)], self.dev)
+        d = inst.block.d
+
+        def body():
+            self._arm(inst)
+            fts = torch.empty(B, V, self.table.shape[2], dtype=self.table.dtype, device=self.dev)
+            O.view_gather(self.table, d["vp_rows"], d["view_order"], fts)
+            inst.c, inst.plan, inst.out = pano_forward_body(self.model, fts, d["loc_fts"], d["nav_types"], d["view_lens"], d["pano_masks"].view(torch.bool))
+        self.model.store.sync_shadow()
+        inst.g_fwd = self._capture(body)
+
+    def run_pano(self, inst, arrays):
+        inst.block.upload(arrays)
+        return _PanoInstFn.apply(self.model._anchor, inst)
+
+    # ---- navigation ----------------------------------------------------------------------------------------------
+    def nav_inst(self, K, Vp, slot_idx):
+        if not self.usable() or Vp != V_STATIC + 2 or K % K_BUCKET:
+            return None
+        return self._acquire("nav", (self.B, K, Vp, slot_idx), lambda inst: self._build_nav(inst, K, Vp, slot_idx))
+
+    def _build_nav(self, inst, K, Vp, slot_idx):
+        B, L, m = self.B, self.Lcap, self.model
+        H = m.net.H
+        f32, i32, u8 = np.float32, np.int32, np.uint8
+        inst.block = _Block([("gmap_step_ids", (B, K), i32), ("gmap_pos_fts", (B, K, 7), f32), ("gmap_pair_dists", (B, K, K), f32),
+                             ("gmap_masks", (B, K), u8), ("gmap_logit_masks", (B, K), u8), ("vp_pos_fts", (B, Vp, 14), f32),
+                             ("vp_nav_masks", (B, Vp), u8), ("vp_masks", (B, Vp), u8), ("fsrc", (B, K), i32), ("bw", (B, Vp), u8)], self.dev)
+        inst.gathered = torch.zeros(B * K + B * Vp, H, dtype=m.net.dtype, device=self.dev)
+        inst.slot = slot = self.text_slot(slot_idx)
+        d = inst.block.d
+        m._first_rows(B, K, self.dev)
+        m._first_rows(B, Vp, self.dev)
+        lens = ([L] * B, [K] * B, [Vp] * B)                  # (FLOP accounting only: not counted under graph replay)
+
+        def body():
+            self._arm(inst)
+            b = dict(txt_masks=slot.masks, gmap_masks=d["gmap_masks"], vp_masks=d["vp_masks"], gmap_step_ids=d["gmap_step_ids"],
+                     gmap_pos_fts=d["gmap_pos_fts"], gmap_pair_dists=d["gmap_pair_dists"], gmap_logit_masks=d["gmap_logit_masks"],
+                     vp_pos_fts=d["vp_pos_fts"], vp_nav_masks=d["vp_nav_masks"], host_lens=lens, fusion=(d["fsrc"], d["bw"]))
+            inst.c, inst.out = nav_forward_body(m, inst.gathered[:B * K].view(B, K, H), inst.gathered[B * K:].view(B, Vp, H), slot.txt, b, slot.kv)
+        m.store.sync_shadow()
+        inst.g_fwd = self._capture(body)
+
+    def run_nav(self, inst, arrays, gathered, txt_kv):
+        """gathered: the log gather's output, written into inst.gathered (carries the autograd history of the embeddings); txt_kv: the
+        slot's K/V cache as the autograd tensor `VLNBert.text_kv(..., out=slot.kv)` returned"""
+        if gathered.data_ptr() != inst.gathered.data_ptr():
+            inst.gathered.copy_(gathered.detach())
+        inst.block.upload(arrays)
+        inst.slot_version = inst.slot.version
+        g, v, ga, va, cls, gl, ll, fl = _NavInstFn.apply(self.model._anchor, inst, gathered, txt_kv)
+        return dict(gmap_embeds=g, vp_embeds=v, gmap_attns=ga, vp_attns=va, cls_embeds=cls, global_logits=gl, local_logits=ll, fused_logits=fl)
+
+    def _zeros_cls(self, inst):
+        z = self._zc.get(inst.key)
+        if z is None:
+            z = self._zc[inst.key] = torch.zeros(self.B, self.model.net.H, dtype=self.model.net.dtype, device=self.dev)
+        return z
+
+    # ---- backward --------------------------------------------------------------------------------------------------
+    def _run_bwd(self, inst, names, grads):
+        sig = tuple(g is not None for g in grads)
+        ent = inst.bwd.get(sig)
+        if ent is None:
+            ent = inst.bwd[sig] = self._capture_bwd(inst, names, grads)
+        bi, g, bo = ent
+        for n, t in zip(names, grads):
+            if t is not None:
+                dst = bi[n]
+                dst.copy_(t.reshape(dst.shape))
+        g.replay()
+        return bo
+
+    def _capture_bwd(self, inst, names, grads):
+        m = self.model
+        bi = {n: torch.zeros(t.shape, dtype=t.dtype, device=self.dev) for n, t in zip(names, grads) if t is not None}
+        bo = {}
+        # the weight-gradient GEMMs of this step leave in grouped launches inside its backward graph: isolate the launch layer's queues from
+        # whatever the surrounding autograd pass has queued eagerly
+        saved = (O.DEFER["queue"], O.DEFER["active"], O.DEFER.get("bytes", 0), list(O.RBW_JOBS))
+        O.DEFER["queue"], O.DEFER["bytes"] = [], 0
+        O.RBW_JOBS[:] = []
+
+        def body():
+            O.defer_dw(True)
+            if inst.kind == "pano":
+                pano_backward_body(m, inst.c, inst.plan, bi.get("d_emb"), bi.get("d_fused"), bi.get("d_attn"))
+            else:
+                d_gin, d_vin, _, dkv = nav_backward_body(m, inst.c, *[bi.get(n) for n in names])
+                bo["d_gathered"] = torch.cat([d_gin, d_vin], 0)
+                bo["dkv"] = dkv
+            O.flush_dw()
+        try:
+            g = self._capture(body)
+        finally:
+            O.DEFER["queue"], O.DEFER["active"], O.DEFER["bytes"] = saved[0], saved[1], saved[2]
+            O.RBW_JOBS[:] = saved[3]
+        return bi, g, bo
+
+    def report(self):
+        return {"instances": self.n_inst, "captures": self.captures,
+                "by_key": {"/".join(str(x) for x in k[:5]): len(v) for k, v in self.pools.items() if v}}

@@ -33,6 +33,8 @@ from . import lib as L
 from . import ops as O
 from .model_nav import _queue_sync, nav_backward_body, nav_forward_body, pano_backward_body, pano_forward_body
 
+import os
+_EAGER_BWD = bool(os.environ.get("MAGIC_STEP_GRAPH_EAGER_BWD"))
 K_BUCKET = 16          # map tokens are padded to a multiple of this
 V_STATIC = 37          # views per panorama the instances are built for (36, or 37 when two candidates share a discretised view)
 
@@ -297,6 +299,13 @@ class StepGraphs:
 
     # ---- backward --------------------------------------------------------------------------------------------------
     def _run_bwd(self, inst, names, grads):
+        if _EAGER_BWD:                # debugging aid: the instance's forward replayed from its graph, its backward launched eagerly
+            m = self.model
+            if inst.kind == "pano":
+                pano_backward_body(m, inst.c, inst.plan, *grads)
+                return {}
+            d_gin, d_vin, _, dkv = nav_backward_body(m, inst.c, *grads)
+            return dict(d_gathered=torch.cat([d_gin, d_vin], 0), dkv=dkv)
         sig = tuple(g is not None for g in grads)
         ent = inst.bwd.get(sig)
         if ent is None:

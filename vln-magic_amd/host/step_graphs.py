@@ -113,6 +113,11 @@ class _Inst:
         self.seed = torch.zeros(2, dtype=torch.int32, device=owner.dev)
         self.slot = self.slot_version = None
         self.gathered = None
+        # the graphs of ONE instance share a private memory pool; instances never share one: memory a graph used for temporaries goes back to
+        # its pool after the capture, and a LATER capture into the same pool may place tensors that must stay alive there -- the earlier
+        # graph's next replay would then overwrite another instance's saved activations (graphs of one pool are only safe when they are
+        # replayed in capture order, which steps of interleaved rollouts and their backwards are not)
+        self.pool = torch.cuda.graph_pool_handle()
 
 
 class _PanoInstFn(torch.autograd.Function):
@@ -168,7 +173,6 @@ class StepGraphs:
         self.slots = {}
         self.n_inst = 0
         self.captures = 0
-        self.pool = torch.cuda.graph_pool_handle()
         self.stream = torch.cuda.Stream(device=self.dev)
         self.base_seed = int(base_seed)
         self.rng_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
@@ -210,9 +214,9 @@ class StepGraphs:
         inst.busy = True
         return inst
 
-    def _capture(self, body):
+    def _capture(self, inst, body):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode="relaxed"):
+        with torch.cuda.graph(g, pool=inst.pool, stream=self.stream, capture_error_mode="relaxed"):
             body()
         self.captures += 1
         return g
@@ -246,7 +250,7 @@ class StepGraphs:
             O.view_gather(self.table, d["vp_rows"], d["view_order"], fts)
             inst.c, inst.plan, inst.out = pano_forward_body(self.model, fts, d["loc_fts"], d["nav_types"], d["view_lens"], d["pano_masks"].view(torch.bool))
         self.model.store.sync_shadow()
-        inst.g_fwd = self._capture(body)
+        inst.g_fwd = self._capture(inst, body)
 
     def run_pano(self, inst, arrays):
         inst.block.upload(arrays)
@@ -279,7 +283,7 @@ class StepGraphs:
                      vp_pos_fts=d["vp_pos_fts"], vp_nav_masks=d["vp_nav_masks"], host_lens=lens, fusion=(d["fsrc"], d["bw"]))
             inst.c, inst.out = nav_forward_body(m, inst.gathered[:B * K].view(B, K, H), inst.gathered[B * K:].view(B, Vp, H), slot.txt, b, slot.kv)
         m.store.sync_shadow()
-        inst.g_fwd = self._capture(body)
+        inst.g_fwd = self._capture(inst, body)
 
     def run_nav(self, inst, arrays, gathered, txt_kv):
         """gathered: the log gather's output, written into inst.gathered (carries the autograd history of the embeddings); txt_kv: the
@@ -338,7 +342,7 @@ class StepGraphs:
                 bo["dkv"] = dkv
             O.flush_dw()
         try:
-            g = self._capture(body)
+            g = self._capture(inst, body)
         finally:
             O.DEFER["queue"], O.DEFER["active"], O.DEFER["bytes"] = saved[0], saved[1], saved[2]
             O.RBW_JOBS[:] = saved[3]

@@ -156,7 +156,7 @@ class NavPlanner:
             loc[i, :n] = lf
         vp_rows = np.array([ob["row"] for ob in obs], np.int32)
         self._half = (V, cand_vpids, view_lens, nav_types)
-        return dict(t=t, B=B, V=V, vp_rows=vp_rows, view_order=view_order, loc_fts=loc, nav_types=nav_types, view_lens=view_lens,
+        return dict(t=t, B=B, V=V, V_valid=int(view_lens.max()), vp_rows=vp_rows, view_order=view_order, loc_fts=loc, nav_types=nav_types, view_lens=view_lens,
                     cand_vpids=cand_vpids)
 
     def begin_nav(self):
@@ -270,7 +270,7 @@ class NavPlanner:
         fsrc, bw = fusion_map(vpid_lists, visited, vp_cand, K, Vp)
         targets = self._teacher_action(vpid_lists, visited)
         self._cur = dict(vpids=vpid_lists, no_left=no_left, targets=targets)
-        return dict(K=K, Vp=Vp, log_base=base, log_fused=fused0, log_cls=cls0, log_rows=self.log_rows,
+        return dict(K=K, Vp=Vp, K_valid=int(lens.max()), log_base=base, log_fused=fused0, log_cls=cls0, log_rows=self.log_rows,
                     gmap_vpids=vpid_lists, gmap_lens=lens, gmap_step_ids=step_ids, gmap_pos_fts=pos, gmap_pair_dists=pair,
                     gmap_visited_masks=visited, gmap_masks=gmask, no_vp_left=no_left,
                     vp_pos_fts=vp_pos, vp_nav_masks=vp_nav, vp_masks=vp_masks, vp_cand_vpids=vp_cand,

@@ -45,6 +45,17 @@ def to_device(arrays, dev):
     return out
 
 
+def _extent(x, *ext):
+    """x[:, :ext0, :ext1, ...] (None = the whole dimension): the valid extent of a tensor computed on padded static shapes"""
+    idx = (slice(None),) + tuple(slice(None) if e is None else slice(0, e) for e in ext)
+    return x[idx]
+
+
+def _nav_extent(outs, K, Vp, L):
+    return dict(outs, gmap_embeds=outs["gmap_embeds"][:, :K], vp_embeds=outs["vp_embeds"][:, :Vp], gmap_attns=outs["gmap_attns"][:, :, :K, :L],
+                vp_attns=outs["vp_attns"][:, :, :Vp, :L])
+
+
 class _LogGather(torch.autograd.Function):
     """out[n_out, H] = CSR(ptr, idx, w) x log; backward = transposed CSR, split back onto the step tensors the log rows
     were copied from (`srcs[i]` occupies log rows [spans[i][0], spans[i][1]))."""
@@ -196,6 +207,7 @@ class NavRollout:
         pl = NavPlanner(env, obs, feedback=feedback, max_action_len=self.T, expert_policy=self.expert, train=grad,
                         pad_V=V_STATIC if use_g else 0, k_bucket=K_BUCKET if use_g else 1)
         lang = pl.language()
+        Lt = lang["txt_ids"].shape[1]   # the batch's own padded extent: what the distillation terms are reduced over (kd_loss.py: sums / means run over the padded batch)
         if use_g:                       # static shapes: the instruction padded to Lcap tokens (masked)
             ids = np.zeros((B, self.Lcap), np.int64)
             ids[:, :lang["txt_ids"].shape[1]] = lang["txt_ids"]
@@ -223,7 +235,8 @@ class NavRollout:
                 txt_kv = st.text_kv(txt_embeds) if self.cache_text_kv else None      # once per episode, not once per step
             txt_embeds, txt_attns = tile(txt_embeds), tile(txt_attns)
             txt_kv = tile(txt_kv, 1) if txt_kv is not None else None
-        s_out = dict(txt_embeds=txt_embeds, txt_attns=txt_attns)
+        kdv = (lambda x, *ext: x) if not use_g else _extent      # distillation sees the batch's own extent, not the static shapes' padding
+        s_out = dict(txt_embeds=kdv(txt_embeds, Lt), txt_attns=kdv(txt_attns, None, Lt, Lt))
         t_out = {}
         tctx = torch.enable_grad if tt_grad else torch.no_grad
         t_ml_loss, t_kdl = torch.zeros((), dtype=torch.float32, device=dev), {}
@@ -242,7 +255,7 @@ class NavRollout:
                     t_kv = te.text_kv(t_txt) if self.cache_text_kv else None
                 t_txt, t_txt_attns = tile(t_txt), tile(t_txt_attns)
                 t_kv = tile(t_kv, 1) if t_kv is not None else None
-            t_out = dict(txt_embeds=t_txt, txt_attns=t_txt_attns)
+            t_out = dict(txt_embeds=kdv(t_txt, Lt), txt_attns=kdv(t_txt_attns, None, Lt, Lt))
             t_log = EmbeddingLog(te.net.H, te.net.dtype, dev)
         s_log = EmbeddingLog(st.net.H, st.net.dtype, dev)
         ml_loss = torch.zeros((), dtype=torch.float32, device=dev)
@@ -267,7 +280,8 @@ class NavRollout:
                     d = to_device(pano_arrays, dev)
                     pin = self._pano_inputs(d, plan)
                 pe, pm, pf, pa = sgs.run_pano(pi, pano_arrays) if pi is not None else st("panorama", pin)
-                s_out.update(pano_embeds=pe, pano_fused_embeds=pf, img_attns=pa)
+                Vt = plan["V_valid"]
+                s_out.update(pano_embeds=kdv(pe, Vt), pano_fused_embeds=pf, img_attns=kdv(pa, Vt, Vt))
                 if te is not None:
                     with tctx():
                         tpe, _, tpf, tpa = sgt.run_pano(tpi, pano_arrays) if tpi is not None else te("panorama", pin)
@@ -300,14 +314,15 @@ class NavRollout:
                     outs = st("navigation", self._nav_inputs(d, plan, gathered, txt_embeds, txt_masks, txt_lens, txt_kv))
                 s_log.put(plan["log_cls"], outs["cls_embeds"])
                 logits = outs["fused_logits"]
-                s_out.update(nav_outs=outs, nav_logits=logits)
+                Kt = plan["K_valid"]
+                s_out.update(nav_outs=_nav_extent(outs, Kt, Vt + 2, Lt) if use_g else outs, nav_logits=kdv(logits, Kt))
                 targets = d["targets"]
                 ce = ce_rows_loss(logits, targets, IGNORE)
                 ml_loss = ml_loss + (ce * w_ml).sum()
                 stop_probs.append(torch.softmax(logits.detach(), 1)[:, 0])
                 if te is not None:
                     with tctx():
-                        t_out.update(pano_embeds=tpe, pano_fused_embeds=tpf, img_attns=tpa)
+                        t_out.update(pano_embeds=kdv(tpe, Vt), pano_fused_embeds=tpf, img_attns=kdv(tpa, Vt, Vt))
                         t_log.put(plan["log_base"], tpe, track=tt_grad)
                         t_log.put(plan["log_fused"], tpf, track=tt_grad)
                         tg = t_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=tt_grad, out=tni.gathered if tni is not None else None)
@@ -316,7 +331,7 @@ class NavRollout:
                         else:
                             t_outs = te("navigation", self._nav_inputs(d, plan, tg, t_txt, txt_masks, txt_lens, t_kv))
                         t_log.put(plan["log_cls"], t_outs["cls_embeds"], track=tt_grad)
-                        t_out.update(nav_outs=t_outs, nav_logits=t_outs["fused_logits"])
+                        t_out.update(nav_outs=_nav_extent(t_outs, Kt, Vt + 2, Lt) if use_g else t_outs, nav_logits=kdv(t_outs["fused_logits"], Kt))
                         t_ce = ce_rows_loss(t_outs["fused_logits"], targets, IGNORE)
                         t_out["sample_weights"] = exponential_decay(t_ce.detach(), self.kd["decay"])
                     if grad:

@@ -217,6 +217,17 @@ int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const void* q, int 
                    void* dq, int lddq, void* dk, void* dv, int lddkv,
                    const float* dist, float* dsprel_w, float* dsprel_b,
                    const void* drop_seed, float drop_p, unsigned drop_site, void* stream);
+/* Long keys (128 < Nk <= 512; RxR-length instructions: `max_instr_len` 250, map_nav_src/scripts/run_rxr_kdl_valid.sh:37; text self-attention and
+ * the cross-attention of map / viewpoint tokens to the instruction), 16-bit storage: magic_attn_fwd runs a key-split kernel (one workgroup per
+ * (batch, head, 64-query tile), every wave owns a 64-key slab), and magic_attn_bwd_ks is the fused backward of the same products -- it replaces
+ * the unfused chain (three batched magic_gemm + magic_softmax_bwd + two magic_dropout launches; torch: autograd of
+ * BertSelfAttention.forward).  o = the forward's output ctx [B*Nq, H] (rowsum(P dP) = dO . O, also under dropout); no graph-distance bias, no
+ * dP_init on this path; accumulate_kv != 0: dk / dv are ADDED to (what `txt_kv.grad` accumulation over an episode's steps does in torch).
+ * magic_attn_supported(dtype, Nq, Nk, 2) tells whether it applies. */
+int magic_attn_bwd_ks(int dtype, int B, int nh, int Nq, int Nk, const void* q, int ldq, const void* k, const void* v, int ldkv,
+                      const void* P, int ldp, const void* o, const void* dctx, int H, float scale,
+                      void* dq, int lddq, void* dk, void* dv, int lddkv, int accumulate_kv,
+                      const void* drop_seed, float drop_p, unsigned drop_site, void* stream);
 
 /* ClsPrediction tail (Linear->ReLU->LN->Linear(H,1)): logit = dot(LN(Y), w2) + b2 */
 int magic_lndot_fwd(int dtype, int M, int H, const void* Y, const float* gamma, const float* beta, float eps,

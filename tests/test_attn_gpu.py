@@ -156,6 +156,78 @@ def test_kv_tiled_forward_for_long_keys(dtype, B, nh, Nq, Nk, cross, use_dist, p
     assert torch.allclose(got, want, **to), (got - want).abs().max().item()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,nh,Nq,Nk,cross,p_drop,acc", [(2, 4, 38, 512, True, 0.0, False), (1, 2, 200, 200, False, 0.1, False), (2, 2, 64, 129, True, 0.0, True),
+                                                          (1, 2, 512, 512, False, 0.0, False), (2, 2, 39, 486, True, 0.1, True), (3, 2, 16, 300, True, 0.1, False)])
+def test_key_split_backward_for_long_keys(dtype, B, nh, Nq, Nk, cross, p_drop, acc):
+    """magic_attn_bwd_ks (128 < Nk <= 512, 16-bit storage): dQ / dK / dV of the fused key-split backward against fp32 autograd of the same
+    attention, fed -- as the engine feeds it -- with the P and the output the key-split forward stored; with dropout the reference uses the
+    kernel's own mask; acc: dK / dV are added to what the buffers hold (the per-episode K/V cache gradient collected over the steps);
+    Nq > 64 loops over query tiles inside the workgroup."""
+    assert O.attn_bwd_ks_ok(dtype, Nq, Nk)
+    H = nh * 64
+    g = torch.Generator().manual_seed(Nq * 13 + Nk)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    if cross:
+        qb, kvb = rnd(B * Nq, H).to(dtype), rnd(B * Nk, 2 * H).to(dtype)
+        q, k, v, ldq, ldkv = qb, kvb, kvb[:, H:], H, 2 * H
+    else:
+        qkv = rnd(B * Nq, 3 * H).to(dtype)
+        q, k, v, ldq, ldkv = qkv, qkv[:, H:], qkv[:, 2 * H:], 3 * H, 3 * H
+    kmask = torch.ones(B, Nk, dtype=torch.uint8, device=DEV)
+    kmask[0, Nk - 5:] = 0
+    kmask[B - 1, 1] = 0
+    scale = 1 / math.sqrt(64)
+    ldp = (Nk + 7) // 8 * 8
+    Pm = torch.full((B, nh, Nq, ldp), 7.0, dtype=dtype, device=DEV)
+    Pd = torch.full((B, nh, Nq, ldp), 7.0, dtype=dtype, device=DEV) if p_drop > 0 else None
+    ctx = torch.empty(B * Nq, H, dtype=dtype, device=DEV)
+    seed = torch.tensor([5, 77], dtype=torch.int32, device=DEV)
+    drop = (seed, p_drop, 999) if p_drop > 0 else None
+    O.attn_fwd(q, ldq, k, v, ldkv, Pm, ldp, ctx, B, nh, Nq, Nk, H, scale, kmask=kmask, drop=drop, Pd=Pd)
+    heads = lambda t, N: t.float().reshape(B, N, nh, 64).transpose(1, 2)
+    qh = heads(q[:, :H] if not cross else q, Nq).clone().requires_grad_(True)
+    kh = heads(k[:, :H], Nk).clone().requires_grad_(True)
+    vh = heads(v[:, :H], Nk).clone().requires_grad_(True)
+    p_ref, _ = ref_attention(qh, kh, vh, kmask, None, None, None, scale)
+    if p_drop > 0:
+        ones = torch.ones(B * nh * Nq * Nk, device=DEV)
+        mask = torch.empty_like(ones)
+        O.dropout(ones, mask, B * nh * Nq, Nk, Nk, drop)
+        p_used = p_ref * mask.view(B, nh, Nq, Nk)
+    else:
+        p_used = p_ref
+    o_ref = p_used @ vh
+    assert torch.allclose(ctx.float(), o_ref.detach().transpose(1, 2).reshape(B * Nq, H), rtol=2e-2, atol=2e-2)
+    dO = rnd(B * Nq, H).to(dtype)
+    (o_ref * heads(dO, Nq)).sum().backward()
+    if cross:
+        dq, dkv = torch.zeros(B * Nq, H, dtype=dtype, device=DEV), torch.zeros(B * Nk, 2 * H, dtype=dtype, device=DEV)
+        dk, dv, lddq, lddkv = dkv, dkv[:, H:], H, 2 * H
+    else:
+        dqkv = torch.zeros(B * Nq, 3 * H, dtype=dtype, device=DEV)
+        dq, dk, dv, lddq, lddkv = dqkv, dqkv[:, H:], dqkv[:, 2 * H:], 3 * H, 3 * H
+    base_k = base_v = 0.0
+    if acc:
+        base = (rnd(B * Nk, 2 * H) * 0.5).to(dtype)
+        dk[:, :H] = base[:, :H]
+        dv[:, :H] = base[:, H:]
+        base_k, base_v = base[:, :H].float(), base[:, H:].float()
+    O.attn_bwd_ks(q, ldq, k, v, ldkv, Pm, ldp, ctx, dO, B, nh, Nq, Nk, H, scale, dq, lddq, dk, dv, lddkv, accumulate_kv=acc, drop=drop)
+    torch.cuda.synchronize()
+    unheads = lambda t, N: t.transpose(1, 2).reshape(B * N, H)
+
+    def chk(a, b, name):
+        a, b = a.float().cpu(), b.detach().float().cpu()
+        err = (a - b).abs().max().item()
+        assert torch.allclose(a, b, rtol=3e-2, atol=4e-2 + (3e-2 if acc else 0)), f"{name}: max|err| {err:.3e} (ref {b.abs().max().item():.3e})"
+        cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+        assert cos > 0.999, f"{name}: cosine {cos}"
+    chk(dq[:, :H], unheads(qh.grad, Nq), "dQ")
+    chk(dk[:, :H], unheads(kh.grad, Nk) + base_k, "dK")
+    chk(dv[:, :H], unheads(vh.grad, Nk) + base_v, "dV")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,H,K", [(100, 128, 128), (77, 128, 512), (200, 256, 256), (64, 256, 1024), (33, 384, 384)])
 def test_fused_linear_residual_layernorm(dtype, M, H, K):

@@ -81,6 +81,7 @@ struct AttnParams {
   // attention-probability dropout (BertSelfAttention.dropout): P stays the clean softmax (the backward needs it), the
   // product uses P*mask/(1-p); Pd (optional) receives the dropped probabilities -- what HF/METER return as the attention map
   DropDesc drop; void* Pd;
+  int acc_kv;        // key-split backward: dK / dV are added to the buffers
 };
 
 template <typename T>
@@ -378,6 +379,437 @@ __global__ __launch_bounds__(256) void attn_fwd_pair_kernel(AttnParams a, AttnPa
   attn_fwd_body<T>(p, local % nqt, (local / nqt) % p.nh, local / (nqt * p.nh), smem_dyn);
 }
 
+
+// ---- key-split kernels for long key sequences (128 < Nk <= 512: RxR-length instructions, BASELINE config 5), 16-bit storage ---------
+// The K/V-tiled forward above walks the key tiles one after the other, twice (two-pass softmax): eight dependent load -> barrier -> product
+// rounds per workgroup, 62 us per launch at Nk = 486 for 1 GFLOP (profiles/micro/nav_kernel_breakdown.py), and the backward for such keys
+// was the unfused chain (three batched GEMMs + softmax backward + two dropout launches per attention).  Here ONE workgroup of 8 waves owns a
+// (batch, head, 64-query tile) and EVERY WAVE OWNS A 64-KEY SLAB: all slabs are processed at the same time, the waves meet once to combine
+// their softmax statistics (local max / sum per query, merged as in online softmax) and once to add their partial P V.
+//   forward : S^T = K_w Q^T (a lane owns 4 consecutive keys of one query: 8-byte LDS traffic) -> local stats -> exchange -> P -> the wave's
+//             own K slab becomes its P image -> P (and dropped P) to global in 16-byte rows -> O_w = P_w V_w -> 8-way sum through LDS.
+//   backward: one workgroup per (batch, head), loop over 64-query tiles.  rowsum_q(P dP) = dO_q . O_q (the forward's output, kept for the
+//             output projection's weight gradient) -- also under dropout, since O was formed with the dropped P -- so a slab needs nothing
+//             from the other slabs: dP^T = V_w dO^T with V_w fragments straight from global, dS, dV_w = Pd_w^T dO and dK_w = dS_w^T Q
+//             complete per wave, only dQ = sum_w dS_w K_w is added across the waves.  The P / dS slab image is XOR-swizzled instead of
+//             padded (that is what makes eight 64 x 64 slabs + eight K slabs + Q + dO fit 160 KB).
+//             acc_kv: dK / dV are ADDED to the buffers (the navigator's per-episode K/V cache collects every step's gradient in place).
+#define KS_DS 72
+__device__ __forceinline__ int sw64(int row, int col) { return row * 64 + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7)); }
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> fragKC_sw(const Hh* s, int out0, int k0, int lane) {
+  return *(const h16x8<Hh>*)(s + sw64(out0 + (lane & 15), k0 + 8 * (lane >> 4)));
+}
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> fragOC_sw(const Hh* s, int out0, int k0, int lane) {
+  const int r0 = k0 + 8 * (lane >> 4) + ((lane & 15) >> 2), col = out0 + 4 * (lane & 3);
+  const h16x4<Hh> lo = lds_tr4(s + sw64(r0, col)), hi = lds_tr4(s + sw64(r0 + 4, col));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+#define WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_fwd_ks_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+  typedef typename AT<T>::vec vec;
+  typedef T tv4 __attribute__((ext_vector_type(4)));
+  constexpr int DS = KS_DS;
+  const int NKP = (p.Nk + 63) / 64 * 64, nact = NKP / 64;
+  T* sQ = (T*)smem_dyn;                       // [64][DS]
+  T* sK = sQ + 64 * DS;                       // [NKP][DS]; wave w's 64 rows double as its P image [64 queries][DS]
+  T* sV = sK + NKP * DS;                      // [NKP][DS]
+  float* sst = (float*)(sV + NKP * DS);       // [2][8][64] local max / local sum per (wave, query)
+  float* sred = (float*)sK;                   // [nact][64][64] partial outputs once the products are done
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 64, nq = min(64, p.Nq - q0);
+  const bool act = w < nact;
+  const int kbase = w * 64;
+  load_rows<T>(sQ, (const T*)p.q + ((long long)b * p.Nq + q0) * p.ldq + h * HD, p.ldq, nq, 64);
+  load_rows<T>(sK, (const T*)p.k + (long long)b * p.Nk * p.ldkv + h * HD, p.ldkv, p.Nk, NKP);
+  load_rows<T>(sV, (const T*)p.v + (long long)b * p.Nk * p.ldkv + h * HD, p.ldkv, p.Nk, NKP);
+  __syncthreads();
+  f32x4 acc[4][4];                            // [key tile of the slab][query tile]: rows = keys 16 jk + 4 g + r, column = query 16 jq + c
+  float mloc[4], sloc[4];
+#pragma unroll
+  for (int jq = 0; jq < 4; ++jq) { mloc[jq] = -3.0e38f; sloc[jq] = 0.f; }
+  if (act) {
+#pragma unroll
+    for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) acc[jk][jq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      h16x8<T> bq[4];
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) bq[jq] = fragKC(sQ, DS, jq * 16, ks * 32, lane);
+#pragma unroll
+      for (int jk = 0; jk < 4; ++jk) {
+        const auto a = fragKC(sK, DS, kbase + jk * 16, ks * 32, lane);
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) acc[jk][jq] = mma(a, bq[jq], acc[jk][jq]);
+      }
+    }
+#pragma unroll
+    for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kbase + jk * 16 + 4 * g + r;
+        const bool kv = key < p.Nk;
+        const float mb = (kv && p.kmask && !p.kmask[(long long)b * p.Nk + key]) ? -10000.0f : 0.f;
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+          const float x = acc[jk][jq][r] * p.scale + mb;
+          acc[jk][jq][r] = kv ? x : -3.0e38f;
+        }
+      }
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+      float m = -3.0e38f;
+#pragma unroll
+      for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[jk][jq][r]);
+      m = fmaxf(m, __shfl_xor(m, 16, 64));           // the four key groups of a query sit 16 lanes apart
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float e = 0.f;
+#pragma unroll
+      for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e += (acc[jk][jq][r] > -1.0e38f) ? __expf(acc[jk][jq][r] - m) : 0.f;
+      e += __shfl_xor(e, 16, 64);
+      e += __shfl_xor(e, 32, 64);
+      mloc[jq] = m; sloc[jq] = e;
+    }
+  }
+  if (g == 0) {
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) { sst[w * 64 + jq * 16 + c] = mloc[jq]; sst[512 + w * 64 + jq * 16 + c] = sloc[jq]; }
+  }
+  __syncthreads();
+  f32x4 o[4][4];                              // [query tile][16 head dims]
+  if (act) {
+    float M[4], inv[4];
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+      const int q = jq * 16 + c;
+      float mm = -3.0e38f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) mm = fmaxf(mm, sst[ww * 64 + q]);
+      float t = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) t += sst[512 + ww * 64 + q] * __expf(sst[ww * 64 + q] - mm);
+      M[jq] = mm; inv[jq] = 1.0f / t;
+    }
+    T* sPw = sK + kbase * DS;                 // this wave's K slab is dead (its S^T products are done; no other wave reads it)
+#pragma unroll
+    for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {
+        tv4 o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = acc[jk][jq][r];
+          const float pr = (x > -1.0e38f) ? __expf(x - M[jq]) * inv[jq] : 0.f;
+          acc[jk][jq][r] = pr; o4[r] = from_f<T>(pr);
+        }
+        *(tv4*)(sPw + (jq * 16 + c) * DS + jk * 16 + 4 * g) = o4;
+      }
+    WAVE_FENCE();
+    const long long prow0 = ((long long)b * p.nh + h) * p.Nq + q0;
+    const int ncolw = min(64, p.ldp - kbase);             // columns of this slab inside the row pitch (pad columns hold zeros)
+    if (ncolw > 0) {
+      T* Pg = (T*)p.P + prow0 * p.ldp + kbase;
+      const int cpr = ncolw / 8;
+      for (int id = lane; id < nq * cpr; id += 64) {
+        const int r = id / cpr, cc = (id % cpr) * 8;
+        *(vec*)(Pg + (long long)r * p.ldp + cc) = *(const vec*)(sPw + r * DS + cc);
+      }
+    }
+    const DropState ds_ = drop_init(p.drop);
+    if (ds_.on) {
+      WAVE_FENCE();                                       // the row stores above have read the clean image
+#pragma unroll
+      for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+          const int ql = jq * 16 + c;
+          tv4 o4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kbase + jk * 16 + 4 * g + r;
+            const unsigned idx = (unsigned)((prow0 + ql) * p.Nk + key);
+            const float m = (ql < nq && key < p.Nk) ? drop_mul(ds_, idx) : 0.f;
+            o4[r] = from_f<T>(acc[jk][jq][r] * m);
+          }
+          *(tv4*)(sPw + ql * DS + jk * 16 + 4 * g) = o4;
+        }
+      WAVE_FENCE();
+      if (p.Pd && ncolw > 0) {
+        T* Pg = (T*)p.Pd + prow0 * p.ldp + kbase;
+        const int cpr = ncolw / 8;
+        for (int id = lane; id < nq * cpr; id += 64) {
+          const int r = id / cpr, cc = (id % cpr) * 8;
+          *(vec*)(Pg + (long long)r * p.ldp + cc) = *(const vec*)(sPw + r * DS + cc);
+        }
+      }
+    }
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) o[jq][jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      h16x8<T> bv[4];
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) bv[jd] = fragOC(sV, DS, jd * 16, kbase + ks * 32, lane);
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {
+        const auto a = fragKC(sPw, DS, jq * 16, ks * 32, lane);
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) o[jq][jd] = mma(a, bv[jd], o[jq][jd]);
+      }
+    }
+  }
+  __syncthreads();                            // every wave is done with the K / V / P images: they become the partial outputs
+  if (act) {
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sred[(w * 64 + jq * 16 + 4 * g + r) * 64 + jd * 16 + c] = o[jq][jd][r];
+  }
+  __syncthreads();
+  {
+    const int row = tid >> 3, d0 = (tid & 7) * 8;
+    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    for (int ww = 0; ww < nact; ++ww) {
+      const float* pr = sred + (ww * 64 + row) * 64 + d0;
+      s0 += *(const f32x4*)pr; s1 += *(const f32x4*)(pr + 4);
+    }
+    if (row < nq) {
+      vec ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ov[e] = from_f<T>(s0[e]); ov[4 + e] = from_f<T>(s1[e]); }
+      *(vec*)((T*)p.ctx + ((long long)b * p.Nq + q0 + row) * p.H + h * HD + d0) = ov;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_bwd_ks_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+  typedef typename AT<T>::vec vec;
+  typedef T tv4 __attribute__((ext_vector_type(4)));
+  constexpr int DS = KS_DS, WSLAB = 64 * DS + 64 * 64;     // per wave: K slab [64][DS] + P / dS slab [64 x 64] swizzled (17 408 B >= a 64 x 64 fp32 partial)
+  const int NKP = (p.Nk + 63) / 64 * 64, nact = NKP / 64;
+  T* sQ = (T*)smem_dyn;                       // [64][DS]
+  T* sdO = sQ + 64 * DS;                      // [64][DS]
+  T* slabs = sdO + 64 * DS;                   // [8][WSLAB]
+  float* srs = (float*)(slabs + 8 * WSLAB);   // [64] rowsum(P dP) = dO . O
+  const int tid = threadIdx.x, lane0 = tid & 63, w = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const bool act = w < nact;
+  const int kbase = w * 64;
+  T* sKw = slabs + w * WSLAB;
+  T* sSw = sKw + 64 * DS;
+  const T* Kg = (const T*)p.k + (long long)b * p.Nk * p.ldkv + h * HD;
+  const T* Vg = (const T*)p.v + (long long)b * p.Nk * p.ldkv + h * HD;
+  const DropState ds_ = drop_init(p.drop);
+  for (int q0 = 0; q0 < p.Nq; q0 += 64) {
+    // (the lane id is laundered per tile: hipcc otherwise hoists every per-lane LDS address of the loop body out of the loop and spills ~130 registers)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, c = lane & 15;
+    const int nq = min(64, p.Nq - q0);
+    const long long prow0 = ((long long)b * p.nh + h) * p.Nq + q0;
+    if (q0) __syncthreads();                  // the previous tile's dQ sum has read the slabs
+    load_rows<T>(sQ, (const T*)p.q + ((long long)b * p.Nq + q0) * p.ldq + h * HD, p.ldq, nq, 64);
+    const T* dOg = (const T*)p.dctx + ((long long)b * p.Nq + q0) * p.H + h * HD;
+    load_rows<T>(sdO, dOg, p.H, nq, 64);
+    if (act) {
+      const T* Pg = (const T*)p.P + prow0 * p.ldp;
+      for (int id = lane; id < 64 * 8; id += 64) {
+        const int r = id >> 3, ch = id & 7;
+        vec zk, zp;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { zk[e] = (T)0.0f; zp[e] = (T)0.0f; }
+        if (kbase + r < p.Nk) zk = *(const vec*)(Kg + (long long)(kbase + r) * p.ldkv + ch * 8);
+        if (r < nq && kbase + ch * 8 < p.ldp) zp = *(const vec*)(Pg + (long long)r * p.ldp + kbase + ch * 8);
+        *(vec*)(sKw + r * DS + ch * 8) = zk;
+        *(vec*)(sSw + sw64(r, ch * 8)) = zp;
+      }
+    }
+    {
+      const int r = tid >> 3, ch = tid & 7;
+      float s = 0.f;
+      if (r < nq) {
+        const vec a = *(const vec*)(dOg + (long long)r * p.H + ch * 8);
+        const vec o8 = *(const vec*)((const T*)p.ctx + ((long long)b * p.Nq + q0 + r) * p.H + h * HD + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += to_f(a[e]) * to_f(o8[e]);
+      }
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      if (ch == 0) srs[r] = s;
+    }
+    __syncthreads();
+    f32x4 oq[4][4];
+    if (act) {
+      f32x4 acc[4][4];                        // dP^T: rows = keys 16 jk + 4 g + r of the slab, column = query 16 jq + c
+      h16x8<T> vf[4][2];                      // this wave's V slab as A fragments (row = key, k = head dim), straight from global (L2): dead after this product
+#pragma unroll
+      for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int key = kbase + jk * 16 + c;
+          h16x8<T> z;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) z[e] = (T)0.0f;
+          if (key < p.Nk) z = *(const h16x8<T>*)(Vg + (long long)key * p.ldkv + ks * 32 + 8 * g);
+          vf[jk][ks] = z;
+        }
+#pragma unroll
+      for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) acc[jk][jq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        h16x8<T> bq[4];
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) bq[jq] = fragKC(sdO, DS, jq * 16, ks * 32, lane);
+#pragma unroll
+        for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+          for (int jq = 0; jq < 4; ++jq) acc[jk][jq] = mma(vf[jk][ks], bq[jq], acc[jk][jq]);
+      }
+      tv4 dsr[4][4];
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {
+        const int ql = jq * 16 + c;
+        const bool qok = ql < nq;
+        const float rsq = srs[ql];
+#pragma unroll
+        for (int jk = 0; jk < 4; ++jk) {
+          const int key0 = jk * 16 + 4 * g;
+          const tv4 p4 = *(const tv4*)(sSw + sw64(ql, key0));
+          tv4 pm = p4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kbase + key0 + r;
+            const bool ok = qok && key < p.Nk;
+            float d = acc[jk][jq][r];
+            const float pp = to_f(p4[r]);
+            if (ds_.on) {               // d is the gradient wrt the DROPPED probabilities: mask it, and leave P * mask in the image for dV
+              const float m = ok ? drop_mul(ds_, (unsigned)((prow0 + ql) * p.Nk + key)) : 0.f;
+              d *= m;
+              pm[r] = from_f<T>(pp * m);
+            }
+            dsr[jk][jq][r] = from_f<T>(ok ? pp * (d - rsq) * p.scale : 0.f);
+          }
+          if (ds_.on) *(tv4*)(sSw + sw64(ql, key0)) = pm;
+        }
+      }
+      WAVE_FENCE();
+      const bool addkv = p.acc_kv || q0 > 0;
+      // dV_w = Pd_w^T dO   (rows = this slab's keys)
+#pragma unroll
+      for (int jk = 0; jk < 4; ++jk) {
+        f32x4 ov[4];
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) ov[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+          const auto a = fragOC_sw(sSw, jk * 16, kq * 32, lane);
+#pragma unroll
+          for (int jd = 0; jd < 4; ++jd) ov[jd] = mma(a, fragOC(sdO, DS, jd * 16, kq * 32, lane), ov[jd]);
+        }
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kbase + jk * 16 + 4 * g + r;
+            if (key < p.Nk) {
+              T* dst = (T*)p.dv + ((long long)b * p.Nk + key) * p.lddkv + h * HD + jd * 16 + c;
+              *dst = from_f<T>(addkv ? to_f(*dst) + ov[jd][r] : ov[jd][r]);
+            }
+          }
+      }
+      WAVE_FENCE();                                       // the transposed reads of the dropped P are done: the image becomes dS
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+        for (int jk = 0; jk < 4; ++jk) *(tv4*)(sSw + sw64(jq * 16 + c, jk * 16 + 4 * g)) = dsr[jk][jq];
+      WAVE_FENCE();
+      // dK_w = dS_w^T Q
+#pragma unroll
+      for (int jk = 0; jk < 4; ++jk) {
+        f32x4 ok_[4];
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) ok_[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+          const auto a = fragOC_sw(sSw, jk * 16, kq * 32, lane);
+#pragma unroll
+          for (int jd = 0; jd < 4; ++jd) ok_[jd] = mma(a, fragOC(sQ, DS, jd * 16, kq * 32, lane), ok_[jd]);
+        }
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kbase + jk * 16 + 4 * g + r;
+            if (key < p.Nk) {
+              T* dst = (T*)p.dk + ((long long)b * p.Nk + key) * p.lddkv + h * HD + jd * 16 + c;
+              *dst = from_f<T>(addkv ? to_f(*dst) + ok_[jd][r] : ok_[jd][r]);
+            }
+          }
+      }
+      // this slab's share of dQ = dS_w K_w
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) oq[jq][jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        h16x8<T> bk[4];
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) bk[jd] = fragOC(sKw, DS, jd * 16, ks * 32, lane);
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+          const auto a = fragKC_sw(sSw, jq * 16, ks * 32, lane);
+#pragma unroll
+          for (int jd = 0; jd < 4; ++jd) oq[jq][jd] = mma(a, bk[jd], oq[jq][jd]);
+        }
+      }
+      WAVE_FENCE();                                       // own slabs are dead: they hold this wave's partial dQ from here on
+      float* part = (float*)sKw;
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[(jq * 16 + 4 * g + r) * 64 + jd * 16 + c] = oq[jq][jd][r];
+    }
+    __syncthreads();
+    {
+      const int row = tid >> 3, d0 = (tid & 7) * 8;
+      f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+      for (int ww = 0; ww < nact; ++ww) {
+        const float* pr = (const float*)(slabs + ww * WSLAB) + row * 64 + d0;
+        s0 += *(const f32x4*)pr; s1 += *(const f32x4*)(pr + 4);
+      }
+      if (row < nq) {
+        vec ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ov[e] = from_f<T>(s0[e]); ov[4 + e] = from_f<T>(s1[e]); }
+        *(vec*)((T*)p.dq + ((long long)b * p.Nq + q0 + row) * p.lddq + h * HD + d0) = ov;
+      }
+    }
+  }
+}
+
+static size_t fwd_ks_lds(int Nk) { const int NKP = (Nk + 63) / 64 * 64; return (size_t)(64 + 2 * NKP) * KS_DS * 2 + 4096; }
+static size_t bwd_ks_lds() { return (size_t)(2 * 64 * KS_DS + 8 * (64 * KS_DS + 64 * 64)) * 2 + 256; }
+static bool ks_mode() { static int m = -1; if (m < 0) { const char* e = getenv("MAGIC_ATTN_NO_KS"); m = (e && atoi(e)) ? 0 : 1; } return m == 1; }
+
 __host__ __device__ static inline bool bwd_alias(int NQP, int NKP, int PS, int DS) { return NQP <= 64 && NQP * PS <= NKP * DS; }
 
 // NW waves per workgroup: 4, or 8 when a side has more than 64 rows (text self-attention, 80 x 80: six 16-row tiles per phase --
@@ -609,6 +1041,7 @@ static size_t bwd_lds(int dtype, int Nq, int Nk) {
 // returns 1 if the fused kernels support the shape (host decides fused vs GEMM+softmax path), 0 otherwise
 extern "C" int magic_attn_supported(int dtype, int Nq, int Nk, int backward) {
   if (Nk <= 0 || Nq <= 0) return 0;
+  if (backward == 2) return (dtype_is16(dtype) && Nk > 128 && Nk <= NK_TILED_MAX && ks_mode()) ? 1 : 0;      // key-split fused backward (magic_attn_bwd_ks)
   if (backward) return (Nk <= 128 && Nq <= 128 && bwd_lds(dtype, Nq, Nk) <= LDS_MAX) ? 1 : 0;
   if (Nk > 128) return Nk <= NK_TILED_MAX ? 1 : 0;            // K/V-tiled two-pass forward
   return fwd_lds(dtype, Nk) <= LDS_MAX ? 1 : 0;
@@ -652,7 +1085,12 @@ int launch_attn_fwd(int dtype, int, const void* pa, const void* pb, hipStream_t 
     for (int i = 0; i < (pb ? 2 : 1); ++i) {
       const AttnParams& q = *ps[i];
       dim3 grid((q.Nq + 63) / 64, q.nh, q.B);
-      if (q.Nk > 128) {
+      if (q.Nk > 128 && dtype_is16(dtype) && !q.dist && ks_mode()) {          // key-split: every wave owns a 64-key slab
+        const size_t shm = fwd_ks_lds(q.Nk);
+        dim3 blk(512);
+        if (dtype == DT_BF16) { set_lds(attn_fwd_ks_kernel<bf16>, shm); hipLaunchKernelGGL(attn_fwd_ks_kernel<bf16>, grid, blk, shm, st, q); }
+        else { set_lds(attn_fwd_ks_kernel<f16>, shm); hipLaunchKernelGGL(attn_fwd_ks_kernel<f16>, grid, blk, shm, st, q); }
+      } else if (q.Nk > 128) {
         const size_t shm = fwd_tiled_lds(dtype);
         if (dtype == DT_BF16) { set_lds(attn_fwd_tiled_kernel<bf16>, shm); hipLaunchKernelGGL(attn_fwd_tiled_kernel<bf16>, grid, block, shm, st, q); }
         else if (dtype == DT_F16) { set_lds(attn_fwd_tiled_kernel<f16>, shm); hipLaunchKernelGGL(attn_fwd_tiled_kernel<f16>, grid, block, shm, st, q); }
@@ -702,6 +1140,32 @@ extern "C" int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const vo
   p.drop = DropDesc{drop_p > 0.f ? (const unsigned*)drop_seed : nullptr, drop_site, drop_p};
   if (group_record(KIND_ATTN_BWD, dtype, 0, &p, sizeof(p))) return MAGIC_OK;
   return launch_attn_bwd(dtype, 0, &p, nullptr, (hipStream_t)stream);
+}
+
+
+// Fused backward for long keys (key-split kernel above).  o = the forward's output [B * Nq, H] (rowsum(P dP) = dO . O); no graph-distance
+// bias and no distillation seed on this path (the engine keeps the unfused chain for those); accumulate_kv: dk / dv += instead of =.
+extern "C" int magic_attn_bwd_ks(int dtype, int B, int nh, int Nq, int Nk, const void* q, int ldq, const void* k, const void* v, int ldkv,
+                                 const void* P, int ldp, const void* o, const void* dctx, int H, float scale,
+                                 void* dq, int lddq, void* dk, void* dv, int lddkv, int accumulate_kv,
+                                 const void* drop_seed, float drop_p, unsigned drop_site, void* stream) {
+  int rc = check_common(dtype, B, nh, Nq, Nk, ldq, ldkv, ldp, H);
+  if (rc) return rc;
+  if (!drop_args_ok(drop_seed, drop_p) || (long long)B * nh * Nq * Nk > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+  if (!magic_attn_supported(dtype, Nq, Nk, 2)) return MAGIC_ERR_UNSUPPORTED;
+  if (!o || !dctx || !dq || !dk || !dv || lddq % 8 || lddkv % 8) return MAGIC_ERR_ARG;
+  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)P & 15) || ((uintptr_t)dctx & 15) || ((uintptr_t)o & 15) ||
+      ((uintptr_t)dq & 15)) return MAGIC_ERR_ARG;
+  AttnParams p = {};
+  p.q = q; p.k = k; p.v = v; p.P = (void*)P; p.ctx = (void*)o; p.B = B; p.nh = nh; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldkv = ldkv;
+  p.ldp = ldp; p.H = H; p.scale = scale; p.dctx = dctx; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddkv = lddkv;
+  p.acc_kv = accumulate_kv ? 1 : 0;
+  p.drop = DropDesc{drop_p > 0.f ? (const unsigned*)drop_seed : nullptr, drop_site, drop_p};
+  const size_t shm = bwd_ks_lds();
+  dim3 grid(nh, B), blk(512);
+  if (dtype == DT_BF16) { set_lds(attn_bwd_ks_kernel<bf16>, shm); hipLaunchKernelGGL(attn_bwd_ks_kernel<bf16>, grid, blk, shm, (hipStream_t)stream, p); }
+  else { set_lds(attn_bwd_ks_kernel<f16>, shm); hipLaunchKernelGGL(attn_bwd_ks_kernel<f16>, grid, blk, shm, (hipStream_t)stream, p); }
+  return launch_status();
 }
 
 static int bwd_waves8(const AttnParams& p) {

@@ -244,9 +244,15 @@ class MagicNet:
         return Pm, ctx, ldp, Pu
 
     def _attn_bwd(self, Pm, ldp, d_ctx, q, ldq, k, v, ldkv, dq, lddq, dk, dv, lddkv, Bn, Nq, Nk, dist, dsprel, dP_init, flops,
-                  drop=None, Pu=None):
-        """Pm = clean softmax; under dropout Pu = the dropped probabilities the product used (dP_init = dLoss/dPu)."""
+                  drop=None, Pu=None, o=None, acc_kv=False):
+        """Pm = clean softmax; under dropout Pu = the dropped probabilities the product used (dP_init = dLoss/dPu).  o = the forward's
+        output (long keys: the key-split kernel takes rowsum(P dP) from dO . O); acc_kv: dk / dv are added to (long-key kernel only)."""
         nh, H = self.nh, self.H
+        if FUSED_ATTN and o is not None and dist is None and dP_init is None and O.attn_bwd_ks_ok(self.dtype, Nq, Nk):
+            O.attn_bwd_ks(q, ldq, k, v, ldkv, Pm, ldp, o, d_ctx, Bn, nh, Nq, Nk, H, 1.0 / math.sqrt(HD), dq, lddq, dk, dv, lddkv,
+                          accumulate_kv=acc_kv, flops=flops, drop=drop)
+            return
+        assert not acc_kv, "accumulating dK / dV needs the key-split attention backward"
         if FUSED_ATTN and O.attn_supported(self.dtype, Nq, Nk, True):
             O.attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, d_ctx, Bn, nh, Nq, Nk, H, 1.0 / math.sqrt(HD), dP_init, dq, lddq, dk, dv, lddkv,
                        dist=dist, dsprel_w=dsprel[0] if dsprel else None, dsprel_b=dsprel[1] if dsprel else None, flops=flops, drop=drop)
@@ -366,7 +372,7 @@ class MagicNet:
         dqkv = self.new(M, 3 * H)
         self._attn_bwd(c.Ppre, c.ldp, d_ctx, c.qkv, 3 * H, c.qkv[:, H:], c.qkv[:, 2 * H:], 3 * H,
                        dqkv, 3 * H, dqkv[:, H:], dqkv[:, 2 * H:], 3 * H, Bn, N, N, c.dist, dsprel, dP_init, c.aflops,
-                       c.adrop, c.P if c.adrop else None)
+                       c.adrop, c.P if c.adrop else None, o=c.ctx)
         qkv = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
         O.linear_dw(dqkv, c.x, qkv.dW, qkv.db, M, flop_rows=c.rows)
         return self._dx_into_ln(dqkv, qkv, M, d_ao, fuse, c.rows)
@@ -477,7 +483,7 @@ class MagicNet:
         dq = self.new(Mq, H)
         dkv = dkv_out if c.kv_given else self.new(Mk, 2 * H)
         self._attn_bwd(c.Ppre, c.ldp, d_cctx, c.q, H, c.kv, c.kv[:, H:], 2 * H, dq, H, dkv, dkv[:, H:], 2 * H,
-                       Bn, Nq, Nk, None, None, dP_init, c.cflops, c.adrop, c.P if c.adrop else None)
+                       Bn, Nq, Nk, None, None, dP_init, c.cflops, c.adrop, c.P if c.adrop else None, o=c.cctx)
         ql = self.lin(lp + "crossattention.self.query.weight")
         kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
         O.linear_dw(dq, c.sa.a, ql.dW, ql.db, Mq, flop_rows=c.rows)

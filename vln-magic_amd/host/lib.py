@@ -42,6 +42,7 @@ SIGNATURES = {
     "magic_attn_fwd": [i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, f32, vp, vp, vp, vp, vp, f32, u32, vp, vp],
     "magic_attn_bwd": [i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, f32, vp, vp, i32, vp, vp, i32, vp, vp, vp,
                        vp, f32, u32, vp],
+    "magic_attn_bwd_ks": [i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, vp, i32, f32, vp, i32, vp, vp, i32, i32, vp, f32, u32, vp],
     "magic_head_mean_fwd": [i32, i32, i32, i64, vp, vp, vp],
     "magic_head_mean_bwd": [i32, i32, i64, vp, vp, i32, vp],
     "magic_lndot_fwd": [i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],

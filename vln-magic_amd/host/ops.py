@@ -514,6 +514,23 @@ def attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, dctx, B, nh, Nq, Nk, H, scale, dP_init
            L.P(dP_init), L.P(dq), lddq, L.P(dk), L.P(dv), lddkv, L.P(dist), L.P(dsprel_w), L.P(dsprel_b), *_dr(drop), L.stream())
 
 
+def attn_bwd_ks_ok(dtype, Nq, Nk):
+    """fused backward for long keys (csrc/attention.hip attn_bwd_ks_kernel): 16-bit storage, 128 < Nk <= 512"""
+    key = (dtype, Nq, Nk, 2)
+    if key not in _ATTN_OK:
+        _ATTN_OK[key] = bool(L.load().magic_attn_supported(L.dt(dtype), Nq, Nk, 2))
+    return _ATTN_OK[key]
+
+
+def attn_bwd_ks(q, ldq, k, v, ldkv, Pm, ldp, o, dctx, B, nh, Nq, Nk, H, scale, dq, lddq, dk, dv, lddkv, accumulate_kv=False, flops=0.0, drop=None):
+    """o: the forward's output [B*Nq, H]; accumulate_kv: dk / dv += (the per-episode K/V cache gradient collected over the steps)"""
+    if FLOPS["enabled"]:
+        FLOPS["total"] += 8.0 * flops
+        FLOPS["attn"] += 8.0 * flops
+    L.call("magic_attn_bwd_ks", L.dt(q.dtype), B, nh, Nq, Nk, L.P(q), ldq, L.P(k), L.P(v), ldkv, L.P(Pm), ldp, L.P(o), L.P(dctx), H, float(scale),
+           L.P(dq), lddq, L.P(dk), L.P(dv), lddkv, 1 if accumulate_kv else 0, *_dr(drop), L.stream())
+
+
 FUSED_ENC = not os.environ.get("MAGIC_NO_FUSED_ENC")
 ENC_ROW_SPLIT = os.environ.get("MAGIC_ENC_RS", "1") != "0"      # row-split form of the whole-encoder forward (csrc/encoder.hip, encoder_rs_kernel)
 XENC_ROW_SPLIT = os.environ.get("MAGIC_XENC_RS", "1") != "0"   # the same for the cross-modal encoders (xencoder_rs_kernel)

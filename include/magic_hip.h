@@ -103,9 +103,18 @@ int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void* y, const f
                  const int* idx0, int mod0, int off0, float* d0, int small0,
                  const int* idx1, int mod1, int off1, float* d1, int small1,
                  const int* idx2, int mod2, int off2, float* d2, int small2,
-                 int do_ln, const void* drop_seed, float drop_p, unsigned site_dy, unsigned site_dx, void* dxm, int hot0, void* stream);
+                 int do_ln, const void* drop_seed, float drop_p, unsigned site_dy, unsigned site_dx, void* dxm, int hot0, int pg_partial,
+                 void* stream);
 /* hot0 >= 0: a row of indexed table 0 that a large share of the input rows hit (the padding token id of the word-embedding lookup): its
- * gradient is summed per workgroup in LDS and added with one atomic per element and workgroup (else -1). */
+ * gradient is summed per workgroup in LDS and added with one atomic per element and workgroup (else -1).
+ * pg_partial != 0 (round 5): dgamma / dbeta point at PARTIAL buffers of magic_ln_bwd_blocks(M, H) x H floats each, contents undefined: every
+ * workgroup STORES its gamma / beta sums in its own row instead of adding them into the parameter gradients with same-address atomics (at
+ * H = 768 the atomics were the launch: 17.6 us for 608 rows, 4 us without); magic_colsum_add_v adds the rows up in block order. */
+int magic_ln_bwd_blocks(int M, int H);
+/* dsts[j][c] += sum over b < nblks[j] of parts[j][b * strides[j] + c], c < lens[j], for n <= 96 jobs in one launch (host arrays of device pointers,
+ * consumed before return).  The finisher of every partial-row epilogue (magic_ln_bwd pg_partial, magic_smallk_ln_bwd part); block order:
+ * reproducible; a destination may occur once per launch.  (torch: `param.grad` accumulation of LayerNorm / Linear parameters.) */
+int magic_colsum_add_v(int n, const float* const* parts, float* const* dsts, const int* nblks, const int* lens, const int* strides, void* stream);
 
 /* gamma/beta gradients of one LayerNorm as a column reduction (used when magic_ln_bwd is called with dgamma = dbeta = NULL) */
 int magic_ln_pgrad(int dtype, int M, int H, const void* dy, const void* y, const float* gamma, const float* beta,
@@ -124,7 +133,7 @@ int magic_csr_gather_multi(int dtype, int H, int n, const magic_csr_prob* d, voi
 /* two magic_smallk_ln_bwd problems (d[0], d[1]) in one launch */
 typedef struct {
   int M, Kin; const float* x; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd;
-  float* dW; float* db; float* dgamma; float* dbeta;
+  float* dW; float* db; float* dgamma; float* dbeta; float* part;
 } magic_skb_prob;
 int magic_smallk_ln_bwd_pair(int dtype, int H, const magic_skb_prob* d, void* stream);
 /* Input stage of the cross-modal encoders as ONE launch for 1 or 2 encoders (the map encoder's gmap tokens, the local encoder's viewpoint
@@ -190,7 +199,11 @@ int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa, const magi
                        int n_cs, const float* const* cs_parts, float* const* cs_dsts, const int* cs_nblks, void* stream);
 int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float* x, const void* dy, const void* y,
                         const float* gamma, const float* beta, const float* rstd,
-                        float* dW, float* db, float* dgamma, float* dbeta, void* stream);
+                        float* dW, float* db, float* dgamma, float* dbeta, float* part, void* stream);
+/* part != NULL (round 5): magic_smallk_ln_bwd_blocks(M, H) x H (Kin + 3) floats, contents undefined: every workgroup stores its sums
+ * [dW (H x Kin) | db | dgamma | dbeta] in its own row instead of H (Kin + 3) same-address atomics; finish with magic_colsum_add_v.  The pair
+ * entry picks ONE tile shape from its larger problem: Mmax = that problem's rows (= M for the single-problem entry). */
+int magic_smallk_ln_bwd_blocks(int M, int H, int Mmax);
 
 /* P = softmax(scale*S + (kmask?0:-10000) + sprel_w*dist + sprel_b) over rows of S[B,nh,Nq,ldp] (HF additive
  * mask; graph_sprels bias r2r_magic_model_config.json:28).  bwd writes scale*dS and the 2 sprel_linear grads. */

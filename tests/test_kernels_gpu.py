@@ -902,3 +902,42 @@ def test_sap_fuse_loss_equals_the_six_launches_it_replaces(use_gate, hard, pred)
     rows3 = torch.empty(3, B, device=DEV)
     O.sap_fuse_loss(B, K, Vp, g_raw, l_raw, fuse_raw, plan["gmask"], plan["lmask"], plan["fsrc"], plan["bwmask"], use_gate, gl2, ll2, fl2, ga, la, coef, rows3)
     check(rows3, rows, "CE rows without gradients", **tol_)
+
+
+@pytest.mark.parametrize("H,M", [(768, 608), (384, 100), (768, 5000)])
+def test_partial_row_parameter_gradients_equal_the_atomic_form(H, M):
+    """round 5: inside a backward pass (weight-gradient queue active) the LayerNorm / position-embedding backwards of the wide models store
+    their parameter-gradient sums per workgroup and one column-sum launch (magic_colsum_add_v) finishes them at the flush: same dx, same
+    gradients (fp32 summation order) as the atomic form, and two runs of the partial form are bitwise equal."""
+    import magic_amd.host.ops as O
+    g = torch.Generator().manual_seed(H + M)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    dt = torch.bfloat16
+    dy, y = rnd(M, H).to(dt), rnd(M, H).to(dt)
+    gamma, beta, rstd = 1 + 0.1 * rnd(H), 0.1 * rnd(H), rnd(M).abs() + 0.5
+    Kin = 7
+    x = rnd(M, Kin)
+
+    def run(partial):
+        dx = torch.empty(M, H, dtype=dt, device=DEV)
+        dg, db = torch.full((H,), 0.25, device=DEV), torch.full((H,), -0.5, device=DEV)
+        dW, dbl, dg2, db2 = torch.full((H, Kin), 0.125, device=DEV), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+        O.defer_dw(partial)
+        try:
+            assert O.part_ok(H) == partial
+            O.ln_bwd(M, H, dy, y=y, gamma=gamma, beta=beta, rstd=rstd, dx=dx, dgamma=dg, dbeta=db)
+            O.smallk_ln_bwd(M, H, Kin, x, dy, y, gamma, beta, rstd, dW, dbl, dg2, db2)
+            O.smallk_ln_bwd_pair(H, [dict(M=M, Kin=Kin, x=x, dy=dy, y=y, gamma=gamma, beta=beta, rstd=rstd, dW=dW, db=dbl, dgamma=dg2, dbeta=db2),
+                                     dict(M=M // 3, Kin=Kin, x=x, dy=dy, y=y, gamma=gamma, beta=beta, rstd=rstd, dW=dW, db=dbl, dgamma=dg2, dbeta=db2)])
+            if partial:
+                assert len(O.PART_JOBS) == 2 + 4 + 8
+            O.flush_dw()
+        finally:
+            O.defer_dw(False)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (dx, dg, db, dW, dbl, dg2, db2)]
+    a, b, c = run(False), run(True), run(True)
+    for i, (u, v, w) in enumerate(zip(a, b, c)):
+        sc = max(1.0, u.float().abs().max().item())
+        assert (u.float() - v.float()).abs().max().item() <= 2e-4 * sc, i
+        assert torch.equal(v, w), i

@@ -423,9 +423,33 @@ __global__ __launch_bounds__(512) void attn_fwd_ks_kernel(AttnParams p) {
   const int q0 = blockIdx.x * 64, nq = min(64, p.Nq - q0);
   const bool act = w < nact;
   const int kbase = w * 64;
-  load_rows<T>(sQ, (const T*)p.q + ((long long)b * p.Nq + q0) * p.ldq + h * HD, p.ldq, nq, 64);
-  load_rows<T>(sK, (const T*)p.k + (long long)b * p.Nk * p.ldkv + h * HD, p.ldkv, p.Nk, NKP);
-  load_rows<T>(sV, (const T*)p.v + (long long)b * p.Nk * p.ldkv + h * HD, p.ldkv, p.Nk, NKP);
+  {
+    // every load of the workgroup is issued before the first LDS store: the Q tile (one 16-byte chunk per thread) and, per wave, its OWN 64-key
+    // slabs of K and V (8 + 8 chunks per lane) -- a load -> store -> next-load loop costs one L2 round trip per 8 KB (34 us per launch at Nk = 486)
+    vec zq, zk[8], zv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zq[e] = (T)0.0f;
+    const int qr = tid >> 3, qc = (tid & 7) * 8;
+    if (qr < nq) zq = *(const vec*)((const T*)p.q + ((long long)b * p.Nq + q0 + qr) * p.ldq + h * HD + qc);
+    const T* Kg = (const T*)p.k + (long long)b * p.Nk * p.ldkv + h * HD;
+    const T* Vg = (const T*)p.v + (long long)b * p.Nk * p.ldkv + h * HD;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = kbase + i * 8 + (lane >> 3), cc = (lane & 7) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { zk[i][e] = (T)0.0f; zv[i][e] = (T)0.0f; }
+      if (act && r < p.Nk) { zk[i] = *(const vec*)(Kg + (long long)r * p.ldkv + cc); zv[i] = *(const vec*)(Vg + (long long)r * p.ldkv + cc); }
+    }
+    *(vec*)(sQ + qr * DS + qc) = zq;
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = kbase + i * 8 + (lane >> 3), cc = (lane & 7) * 8;
+        *(vec*)(sK + r * DS + cc) = zk[i];
+        *(vec*)(sV + r * DS + cc) = zv[i];
+      }
+    }
+  }
   __syncthreads();
   f32x4 acc[4][4];                            // [key tile of the slab][query tile]: rows = keys 16 jk + 4 g + r, column = query 16 jq + c
   float mloc[4], sloc[4];
@@ -628,15 +652,20 @@ __global__ __launch_bounds__(512) void attn_bwd_ks_kernel(AttnParams p) {
     load_rows<T>(sdO, dOg, p.H, nq, 64);
     if (act) {
       const T* Pg = (const T*)p.P + prow0 * p.ldp;
-      for (int id = lane; id < 64 * 8; id += 64) {
-        const int r = id >> 3, ch = id & 7;
-        vec zk, zp;
+      vec zk[8], zp[8];                        // all 16 loads of the lane in flight before the first LDS store
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { zk[e] = (T)0.0f; zp[e] = (T)0.0f; }
-        if (kbase + r < p.Nk) zk = *(const vec*)(Kg + (long long)(kbase + r) * p.ldkv + ch * 8);
-        if (r < nq && kbase + ch * 8 < p.ldp) zp = *(const vec*)(Pg + (long long)r * p.ldp + kbase + ch * 8);
-        *(vec*)(sKw + r * DS + ch * 8) = zk;
-        *(vec*)(sSw + sw64(r, ch * 8)) = zp;
+      for (int i = 0; i < 8; ++i) {
+        const int r = i * 8 + (lane >> 3), ch = lane & 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { zk[i][e] = (T)0.0f; zp[i][e] = (T)0.0f; }
+        if (kbase + r < p.Nk) zk[i] = *(const vec*)(Kg + (long long)(kbase + r) * p.ldkv + ch * 8);
+        if (r < nq && kbase + ch * 8 < p.ldp) zp[i] = *(const vec*)(Pg + (long long)r * p.ldp + kbase + ch * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = i * 8 + (lane >> 3), ch = lane & 7;
+        *(vec*)(sKw + r * DS + ch * 8) = zk[i];
+        *(vec*)(sSw + sw64(r, ch * 8)) = zp[i];
       }
     }
     {
@@ -710,7 +739,7 @@ __global__ __launch_bounds__(512) void attn_bwd_ks_kernel(AttnParams p) {
       }
       WAVE_FENCE();
       const bool addkv = p.acc_kv || q0 > 0;
-      // dV_w = Pd_w^T dO   (rows = this slab's keys)
+      // dV_w^T = dO^T Pd_w: formed transposed (rows = head dims, column = key), so a lane owns FOUR CONSECUTIVE HEAD DIMS of one key: 8-byte stores
 #pragma unroll
       for (int jk = 0; jk < 4; ++jk) {
         f32x4 ov[4];
@@ -718,20 +747,21 @@ __global__ __launch_bounds__(512) void attn_bwd_ks_kernel(AttnParams p) {
         for (int jd = 0; jd < 4; ++jd) ov[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kq = 0; kq < 2; ++kq) {
-          const auto a = fragOC_sw(sSw, jk * 16, kq * 32, lane);
+          const auto bp = fragOC_sw(sSw, jk * 16, kq * 32, lane);
 #pragma unroll
-          for (int jd = 0; jd < 4; ++jd) ov[jd] = mma(a, fragOC(sdO, DS, jd * 16, kq * 32, lane), ov[jd]);
+          for (int jd = 0; jd < 4; ++jd) ov[jd] = mma(fragOC(sdO, DS, jd * 16, kq * 32, lane), bp, ov[jd]);
         }
+        const int key = kbase + jk * 16 + c;
+        if (key < p.Nk) {
 #pragma unroll
-        for (int jd = 0; jd < 4; ++jd)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kbase + jk * 16 + 4 * g + r;
-            if (key < p.Nk) {
-              T* dst = (T*)p.dv + ((long long)b * p.Nk + key) * p.lddkv + h * HD + jd * 16 + c;
-              *dst = from_f<T>(addkv ? to_f(*dst) + ov[jd][r] : ov[jd][r]);
-            }
+          for (int jd = 0; jd < 4; ++jd) {
+            tv4* dst = (tv4*)((T*)p.dv + ((long long)b * p.Nk + key) * p.lddkv + h * HD + jd * 16 + 4 * g);
+            tv4 o4;
+            if (addkv) { const tv4 old = *dst; _Pragma("unroll") for (int r = 0; r < 4; ++r) o4[r] = from_f<T>(to_f(old[r]) + ov[jd][r]); }
+            else { _Pragma("unroll") for (int r = 0; r < 4; ++r) o4[r] = from_f<T>(ov[jd][r]); }
+            *dst = o4;
           }
+        }
       }
       WAVE_FENCE();                                       // the transposed reads of the dropped P are done: the image becomes dS
 #pragma unroll
@@ -739,7 +769,7 @@ __global__ __launch_bounds__(512) void attn_bwd_ks_kernel(AttnParams p) {
 #pragma unroll
         for (int jk = 0; jk < 4; ++jk) *(tv4*)(sSw + sw64(jq * 16 + c, jk * 16 + 4 * g)) = dsr[jk][jq];
       WAVE_FENCE();
-      // dK_w = dS_w^T Q
+      // dK_w^T = Q^T dS_w (transposed like dV)
 #pragma unroll
       for (int jk = 0; jk < 4; ++jk) {
         f32x4 ok_[4];
@@ -747,20 +777,21 @@ __global__ __launch_bounds__(512) void attn_bwd_ks_kernel(AttnParams p) {
         for (int jd = 0; jd < 4; ++jd) ok_[jd] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kq = 0; kq < 2; ++kq) {
-          const auto a = fragOC_sw(sSw, jk * 16, kq * 32, lane);
+          const auto bp = fragOC_sw(sSw, jk * 16, kq * 32, lane);
 #pragma unroll
-          for (int jd = 0; jd < 4; ++jd) ok_[jd] = mma(a, fragOC(sQ, DS, jd * 16, kq * 32, lane), ok_[jd]);
+          for (int jd = 0; jd < 4; ++jd) ok_[jd] = mma(fragOC(sQ, DS, jd * 16, kq * 32, lane), bp, ok_[jd]);
         }
+        const int key = kbase + jk * 16 + c;
+        if (key < p.Nk) {
 #pragma unroll
-        for (int jd = 0; jd < 4; ++jd)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kbase + jk * 16 + 4 * g + r;
-            if (key < p.Nk) {
-              T* dst = (T*)p.dk + ((long long)b * p.Nk + key) * p.lddkv + h * HD + jd * 16 + c;
-              *dst = from_f<T>(addkv ? to_f(*dst) + ok_[jd][r] : ok_[jd][r]);
-            }
+          for (int jd = 0; jd < 4; ++jd) {
+            tv4* dst = (tv4*)((T*)p.dk + ((long long)b * p.Nk + key) * p.lddkv + h * HD + jd * 16 + 4 * g);
+            tv4 o4;
+            if (addkv) { const tv4 old = *dst; _Pragma("unroll") for (int r = 0; r < 4; ++r) o4[r] = from_f<T>(to_f(old[r]) + ok_[jd][r]); }
+            else { _Pragma("unroll") for (int r = 0; r < 4; ++r) o4[r] = from_f<T>(ok_[jd][r]); }
+            *dst = o4;
           }
+        }
       }
       // this slab's share of dQ = dS_w K_w
 #pragma unroll

@@ -118,6 +118,7 @@ struct LnbParams {
   DropDesc ddy;               // the forward dropped its OUTPUT: dy is masked on load
   void* dxm; DropDesc ddx;    // the forward dropped its in0: second output dxm = dx * mask (gradient of the dense branch)
   int hot0;                   // >= 0: row of indexed table 0 that very many input rows hit (the padding token): summed per block in LDS
+  int pg_partial;             // != 0: dgamma / dbeta are PARTIAL buffers [blocks][H]: every block stores its sums in its own row (no atomics)
 };
 
 // NW = waves per block.  Every block ends in one same-address atomic per parameter / const-table element, and those serialise in L2
@@ -302,7 +303,8 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
       float v = 0.f;
 #pragma unroll
       for (int ww = 0; ww < NW; ++ww) v += red[(q * NW + ww) * H + cc];
-      atomicAdd((q ? dbeta : dgamma) + cc, v);
+      if (pp.pg_partial) (q ? dbeta : dgamma)[(long long)bid * H + cc] = v;
+      else atomicAdd((q ? dbeta : dgamma) + cc, v);
     }
   }
   if (any_lds) {
@@ -882,7 +884,8 @@ __global__ __launch_bounds__(NW * 64) void embed_in_bwd_kernel(magic_pano_in_bwd
 // dz rows are parked in LDS so the dW outer product is a cooperative (c,k) loop.  Every block ends in H (Kin + 3) same-address atomics,
 // so at H = 128 and M >= 4096 a block takes 64 rows with 16 waves (half as many blocks as the 32-row / 4-wave shape, 4 rows per wave).
 struct SkbParams { int M, Kin; const float* x; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd;
-                   float* dW; float* db; float* dgamma; float* dbeta; };
+                   float* dW; float* db; float* dgamma; float* dbeta;
+                   float* part; };       // != NULL: every block STORES its sums in its own row [H Kin | H | H | H] (dW, db, dgamma, dbeta) instead of the atomics
 template <typename T, int NIT, int NW, int SK_ROWS>
 __device__ __forceinline__ void smallk_ln_bwd_body(const SkbParams& pp, const int bid) {
   constexpr int H = NIT * 128;
@@ -890,6 +893,7 @@ __device__ __forceinline__ void smallk_ln_bwd_body(const SkbParams& pp, const in
   const float* x = pp.x; const T* dy = (const T*)pp.dy; const T* y = (const T*)pp.y;
   const float* gamma = pp.gamma; const float* beta = pp.beta; const float* rstd = pp.rstd;
   float* dW = pp.dW; float* db = pp.db; float* dgamma = pp.dgamma; float* dbeta = pp.dbeta;
+  float* prow = pp.part ? pp.part + (long long)bid * H * (Kin + 3) : nullptr;
   extern __shared__ __attribute__((aligned(16))) float sm[];   // dz[SK_ROWS][H] | xs[SK_ROWS][16] | red[2][NW][H]
   float* dz = sm;
   float* xs = sm + SK_ROWS * H;
@@ -933,13 +937,13 @@ __device__ __forceinline__ void smallk_ln_bwd_body(const SkbParams& pp, const in
     float s = 0.f;
 #pragma unroll 8
     for (int r = 0; r < SK_ROWS; ++r) s += dz[r * H + c] * xs[r * 16 + k];
-    atomicAdd(dW + i, s);
+    if (prow) prow[i] = s; else atomicAdd(dW + i, s);
   }
   for (int c = threadIdx.x; c < H; c += NW * 64) {
     float s = 0.f;
 #pragma unroll 8
     for (int r = 0; r < SK_ROWS; ++r) s += dz[r * H + c];
-    atomicAdd(db + c, s);
+    if (prow) prow[H * Kin + c] = s; else atomicAdd(db + c, s);
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
@@ -954,7 +958,7 @@ __device__ __forceinline__ void smallk_ln_bwd_body(const SkbParams& pp, const in
     float v = 0.f;
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) v += red[(q * NW + ww) * H + cc];
-    atomicAdd((q ? dbeta : dgamma) + cc, v);
+    if (prow) prow[H * (Kin + 1 + q) + cc] = v; else atomicAdd((q ? dbeta : dgamma) + cc, v);
   }
 }
 
@@ -1233,8 +1237,10 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
                             const int* idx0, int mod0, int off0, float* d0, int small0,
                             const int* idx1, int mod1, int off1, float* d1, int small1,
                             const int* idx2, int mod2, int off2, float* d2, int small2,
-                            int do_ln, const void* drop_seed, float drop_p, unsigned site_dy, unsigned site_dx, void* dxm, int hot0, void* stream) {
+                            int do_ln, const void* drop_seed, float drop_p, unsigned site_dy, unsigned site_dx, void* dxm, int hot0, int pg_partial,
+                            void* stream) {
   if (M <= 0 || !okH(H) || !dy || (H != 128 && H != 256 && H != 384 && H != 768)) return MAGIC_ERR_ARG;
+  if (pg_partial && (!do_ln || !dgamma)) return MAGIC_ERR_ARG;
   if (hot0 >= 0 && (!idx0 || !d0)) return MAGIC_ERR_ARG;
   if (!drop_args_ok(drop_seed, drop_p) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
   const bool don = drop_p > 0.f;
@@ -1245,7 +1251,7 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
   LnbParams p{M, dy, y, gamma, beta, rstd, dx, dgamma, dbeta, TabRef{d0, idx0, mod0, off0}, d0, small0, TabRef{d1, idx1, mod1, off1}, d1, small1,
               TabRef{d2, idx2, mod2, off2}, d2, small2, do_ln,
               DropDesc{(don && site_dy) ? (const unsigned*)drop_seed : nullptr, site_dy, drop_p},
-              (don && site_dx) ? dxm : nullptr, DropDesc{(don && site_dx) ? (const unsigned*)drop_seed : nullptr, site_dx, drop_p}, hot0};
+              (don && site_dx) ? dxm : nullptr, DropDesc{(don && site_dx) ? (const unsigned*)drop_seed : nullptr, site_dx, drop_p}, hot0, pg_partial ? 1 : 0};
   const int nit = H / 128;
   if (group_record(KIND_LNB, dtype, nit, &p, sizeof(p))) return MAGIC_OK;
   return launch_lnb(dtype, nit, &p, nullptr, (hipStream_t)stream);
@@ -1259,6 +1265,44 @@ static inline int lnb_blocks(const LnbParams& p, int nit) {
   // with in-kernel gamma/beta grads every block ends in 2H same-address atomics -> cap the grid; without them one row group per wave
   const int cap = p.dgamma ? 512 : 4096;
   return nb > cap ? cap : nb;
+}
+
+// dst_j[c] += sum over b < nblk_j of part_j[b * stride_j + c], c < len_j: the finisher of every "each workgroup stores its partial sums in its own
+// row" epilogue (LayerNorm / position-embedding parameter gradients at the wide model sizes: the same-address fp32 atomics they replace were the
+// launches' whole cost -- ln_bwd 17.6 us for 608 x 768, 4 us without).  Sums run in block order: reproducible.  One launch holds a destination once.
+#define CSV_MAX 96
+struct ColsumVJobs { const float* part[CSV_MAX]; float* dst[CSV_MAX]; int nblk[CSV_MAX]; int len[CSV_MAX]; int stride[CSV_MAX]; int n; };
+__global__ __launch_bounds__(256) void colsum_v_kernel(ColsumVJobs js) {
+  const int j = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= js.len[j]) return;
+  const float* pt = js.part[j] + c;
+  const int nb = js.nblk[j], st = js.stride[j];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nb; b += 4) { s0 += pt[(long long)b * st]; s1 += pt[(long long)(b + 1) * st]; s2 += pt[(long long)(b + 2) * st]; s3 += pt[(long long)(b + 3) * st]; }
+  for (; b < nb; ++b) s0 += pt[(long long)b * st];
+  js.dst[j][c] += (s0 + s1) + (s2 + s3);
+}
+extern "C" int magic_colsum_add_v(int n, const float* const* parts, float* const* dsts, const int* nblks, const int* lens, const int* strides, void* stream) {
+  if (n <= 0 || n > CSV_MAX || !parts || !dsts || !nblks || !lens || !strides) return MAGIC_ERR_ARG;
+  ColsumVJobs js;
+  js.n = n;
+  int mx = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!parts[i] || !dsts[i] || nblks[i] <= 0 || lens[i] <= 0 || strides[i] < lens[i]) return MAGIC_ERR_ARG;
+    js.part[i] = parts[i]; js.dst[i] = dsts[i]; js.nblk[i] = nblks[i]; js.len[i] = lens[i]; js.stride[i] = strides[i];
+    mx = lens[i] > mx ? lens[i] : mx;
+  }
+  hipLaunchKernelGGL(colsum_v_kernel, dim3((mx + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, js);
+  return launch_status();
+}
+
+// workgroups magic_ln_bwd launches for M rows with in-kernel gamma / beta gradients: the row count of its PARTIAL buffers (pg_partial)
+extern "C" int magic_ln_bwd_blocks(int M, int H) {
+  if (M <= 0 || (H != 128 && H != 256 && H != 384 && H != 768)) return MAGIC_ERR_ARG;
+  LnbParams p{};
+  p.M = M; p.dgamma = (float*)1;
+  return lnb_blocks(p, H / 128);
 }
 
 int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t st) {
@@ -1434,10 +1478,18 @@ extern "C" int magic_node_in_fwd(int dtype, int H, int n, const magic_node_in* d
   return launch_status();
 }
 
+// rows per workgroup: 64 rows x 16 waves at H = 128 with many rows; 8 rows x 4 waves for the wide models on few rows (the navigator's
+// M ~ 600 steps at H = 768 ran on 19 workgroups: 58 us per launch); 32 rows x 4 waves otherwise
+static inline int skb_rows(int H, int Mmax) { return (H == 128 && Mmax >= 4096) ? 64 : (H >= 384 && Mmax <= 4096) ? 8 : 32; }
+// workgroups of a problem of M rows in a launch whose largest problem has Mmax rows (the pair entry picks ONE tile shape): rows of `part`
+extern "C" int magic_smallk_ln_bwd_blocks(int M, int H, int Mmax) {
+  return (M <= 0 || Mmax < M || !okH(H)) ? MAGIC_ERR_ARG : (M + skb_rows(H, Mmax) - 1) / skb_rows(H, Mmax);
+}
+
 static int launch_skb(int dtype, int H, const SkbParams& a, const SkbParams* b, hipStream_t st) {
   const int Mmax = b ? (a.M > b->M ? a.M : b->M) : a.M;
-  const bool wide = H == 128 && Mmax >= 4096;   // 64 rows x 16 waves per block; few rows or wider models: 32 rows x 4 waves
-  const int rows = wide ? 64 : 32, nw = wide ? 16 : 4;
+  const int rows = skb_rows(H, Mmax), nw = rows == 64 ? 16 : 4;
+  const bool wide = rows == 64, narrow = rows == 8;
   const int nA = (a.M + rows - 1) / rows, nB = b ? (b->M + rows - 1) / rows : 0;
   dim3 grid(nA + nB), block(nw * 64);
   size_t shm = (size_t)(rows * H + rows * 16 + 2 * nw * H) * sizeof(float);
@@ -1448,7 +1500,7 @@ static int launch_skb(int dtype, int H, const SkbParams& a, const SkbParams* b, 
     hipLaunchKernelGGL((smallk_ln_bwd_kernel<TY, NIT, NW, ROWS>), grid, block, shm, st, a, bb, nA);                            \
   } while (0)
 #define SKB(TY, NIT)                                                                                                         \
-  do { if (NIT == 1 && wide) SKB1(TY, 1, 16, 64); else SKB1(TY, NIT, 4, 32); } while (0)
+  do { if (NIT == 1 && wide) SKB1(TY, 1, 16, 64); else if (NIT >= 3 && narrow) SKB1(TY, NIT, 4, 8); else SKB1(TY, NIT, 4, 32); } while (0)
   DISPATCH_NIT(dtype, H, SKB);
 #undef SKB
 #undef SKB1
@@ -1457,21 +1509,21 @@ static int launch_skb(int dtype, int H, const SkbParams& a, const SkbParams* b, 
 
 extern "C" int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float* x, const void* dy, const void* y,
                                    const float* gamma, const float* beta, const float* rstd,
-                                   float* dW, float* db, float* dgamma, float* dbeta, void* stream) {
+                                   float* dW, float* db, float* dgamma, float* dbeta, float* part, void* stream) {
   if (M <= 0 || !okH(H) || Kin <= 0 || Kin > 16) return MAGIC_ERR_ARG;
-  SkbParams a{M, Kin, x, dy, y, gamma, beta, rstd, dW, db, dgamma, dbeta};
+  SkbParams a{M, Kin, x, dy, y, gamma, beta, rstd, dW, db, dgamma, dbeta, part};
   return launch_skb(dtype, H, a, nullptr, (hipStream_t)stream);
 }
 
 // two position-embedding backwards (map tokens || viewpoint tokens) in one launch; arguments as magic_smallk_ln_bwd, per problem
 struct magic_skb_prob { int M, Kin; const float* x; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd;
-                        float* dW; float* db; float* dgamma; float* dbeta; };
+                        float* dW; float* db; float* dgamma; float* dbeta; float* part; };
 extern "C" int magic_smallk_ln_bwd_pair(int dtype, int H, const magic_skb_prob* d, void* stream) {
   if (!d || !okH(H)) return MAGIC_ERR_ARG;
   SkbParams p[2];
   for (int i = 0; i < 2; ++i) {
     if (d[i].M <= 0 || d[i].Kin <= 0 || d[i].Kin > 16 || !d[i].x || !d[i].dy || !d[i].y || !d[i].dW) return MAGIC_ERR_ARG;
-    p[i] = SkbParams{d[i].M, d[i].Kin, d[i].x, d[i].dy, d[i].y, d[i].gamma, d[i].beta, d[i].rstd, d[i].dW, d[i].db, d[i].dgamma, d[i].dbeta};
+    p[i] = SkbParams{d[i].M, d[i].Kin, d[i].x, d[i].dy, d[i].y, d[i].gamma, d[i].beta, d[i].rstd, d[i].dW, d[i].db, d[i].dgamma, d[i].dbeta, d[i].part};
   }
   return launch_skb(dtype, H, p[0], &p[1], (hipStream_t)stream);
 }

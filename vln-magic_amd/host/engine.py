@@ -469,9 +469,10 @@ class MagicNet:
         c.out = c.ffn.out
         return c
 
-    def cross_layer_bwd(self, lp, c, dout, d_ctx_acc, dsprel=None, dP_init=None, fuse_in=None, dkv_out=None):
+    def cross_layer_bwd(self, lp, c, dout, d_ctx_acc, dsprel=None, dP_init=None, fuse_in=None, dkv_out=None, acc_kv=False):
         """returns dx (plain, or a Pre pair when fuse_in is given); accumulates the gradient wrt the context (other modality)
-        into d_ctx_acc."""
+        into d_ctx_acc.  acc_kv (with a cached K/V projection, `dkv_out`): this step's dK / dV are ADDED to dkv_out -- the per-episode
+        accumulator of the navigator loop -- instead of written."""
         H, Bn, Nq, Nk = self.H, c.Bn, c.Nq, c.Nk
         Mq, Mk = Bn * Nq, Bn * Nk
         c_ln = self._ln_desc(lp + "crossattention.output.LayerNorm", c.c, c.rstd_c, c.hdrop)
@@ -482,8 +483,13 @@ class MagicNet:
         d_cctx = O.linear_dx(d_cod, o.W, Mq, flop_rows=c.rows)
         dq = self.new(Mq, H)
         dkv = dkv_out if c.kv_given else self.new(Mk, 2 * H)
-        self._attn_bwd(c.Ppre, c.ldp, d_cctx, c.q, H, c.kv, c.kv[:, H:], 2 * H, dq, H, dkv, dkv[:, H:], 2 * H,
-                       Bn, Nq, Nk, None, None, dP_init, c.cflops, c.adrop, c.P if c.adrop else None, o=c.cctx)
+        acc = bool(acc_kv and c.kv_given)
+        ks = FUSED_ATTN and dP_init is None and O.attn_bwd_ks_ok(self.dtype, Nq, Nk)
+        dkv_w = self.new(Mk, 2 * H) if (acc and not ks) else dkv      # (no accumulating form of this shape's kernel: own buffer, one add)
+        self._attn_bwd(c.Ppre, c.ldp, d_cctx, c.q, H, c.kv, c.kv[:, H:], 2 * H, dq, H, dkv_w, dkv_w[:, H:], 2 * H,
+                       Bn, Nq, Nk, None, None, dP_init, c.cflops, c.adrop, c.P if c.adrop else None, o=c.cctx, acc_kv=acc and ks)
+        if acc and not ks:
+            O.add_(dkv, dkv_w)
         ql = self.lin(lp + "crossattention.self.query.weight")
         kvl = self.lin(lp + "crossattention.self.key.weight", lp + "crossattention.self.key.bias", rows=2 * H, cols=H)
         O.linear_dw(dq, c.sa.a, ql.dW, ql.db, Mq, flop_rows=c.rows)
@@ -1168,7 +1174,7 @@ class MagicNet:
                 O.add_n(acc, ts[i0:i0 + 8])
         return [s.dx0 for s in st]
 
-    def cross_bwd(self, c, d_out, d_ctx_acc, dP_init=None, dkv=None):
+    def cross_bwd(self, c, d_out, d_ctx_acc, dP_init=None, dkv=None, acc_kv=False):
         if dkv is None and self.rbw_ok() and not any(lc.kv_given for lc in c.layers):
             return self.cross_stacks_bwd([(c, d_out, d_ctx_acc, dP_init)])[0]
         enc = self.p + ("global_encoder." if c.which == "global" else "local_encoder.")
@@ -1178,5 +1184,5 @@ class MagicNet:
         for i in reversed(range(nl)):
             prev = self._out_ln_desc(f"{enc}encoder.crossattention.{i - 1}.", c.layers[i - 1]) if i > 0 else None
             d = self.cross_layer_bwd(f"{enc}encoder.crossattention.{i}.", c.layers[i], d, d_ctx_acc, dsprel, dP_init if i == nl - 1 else None,
-                                     fuse_in=prev, dkv_out=None if dkv is None else dkv[i])
+                                     fuse_in=prev, dkv_out=None if dkv is None else dkv[i], acc_kv=acc_kv)
         return d

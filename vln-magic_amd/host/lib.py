@@ -32,10 +32,13 @@ SIGNATURES = {
     "magic_ln_fwd": [i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, vp, vp, i32,
                      vp, f32, u32, u32, vp, vp],
     "magic_ln_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32,
-                     vp, i32, i32, vp, i32, i32, vp, f32, u32, u32, vp, i32, vp],
+                     vp, i32, i32, vp, i32, i32, vp, f32, u32, u32, vp, i32, i32, vp],
+    "magic_ln_bwd_blocks": [i32, i32],
+    "magic_colsum_add_v": [i32, vp, vp, vp, vp, vp, vp],
+    "magic_smallk_ln_bwd_blocks": [i32, i32, i32],
     "magic_ln_pgrad": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "magic_smallk_ln_fwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp],
-    "magic_smallk_ln_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "magic_smallk_ln_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_softmax_fwd": [i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp],
     "magic_softmax_bwd": [i32, i32, i32, i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
     "magic_attn_supported": [i32, i32, i32, i32],
@@ -166,7 +169,7 @@ class CsrProb(C.Structure):
 
 class SkbProb(C.Structure):
     """mirror of `magic_skb_prob` (include/magic_hip.h)"""
-    _fields_ = [("M", i32), ("Kin", i32)] + [(n, vp) for n in ("x", "dy", "y", "gamma", "beta", "rstd", "dW", "db", "dgamma", "dbeta")]
+    _fields_ = [("M", i32), ("Kin", i32)] + [(n, vp) for n in ("x", "dy", "y", "gamma", "beta", "rstd", "dW", "db", "dgamma", "dbeta", "part")]
 
 
 class EncLayer(C.Structure):

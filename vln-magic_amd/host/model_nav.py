@@ -403,8 +403,9 @@ def nav_forward_body(model, gmap_img, vp_img, txt_embeds, b, txt_kv=None):
     return c, (c.glob.out.view(B, K, H), c.loc.out.view(B, Vp, H), c.glob.P[..., :L], c.loc.P[..., :L], cls, gl, ll, fl)
 
 
-def nav_backward_body(model, c, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl):
-    """returns (d_gmap_img [B*K, H], d_vp_img [B*Vp, H], d_txt [B*L, H] or None, dkv [2 nl, B*L, 2H] or None)"""
+def nav_backward_body(model, c, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl, dkv_acc=None):
+    """returns (d_gmap_img [B*K, H], d_vp_img [B*Vp, H], d_txt [B*L, H] or None, dkv [2 nl, B*L, 2H] or None).  dkv_acc: the episode's
+    accumulator of the cached K/V projection's gradient [2 nl, B*L, 2H]: this step's dK / dV are added to it and None is returned for dkv."""
     net, p = model.net, model.prefix
     B, K, Vp, L, H = c.B, c.K, c.Vp, c.L, net.H
     dev = c.glob.out.device
@@ -438,17 +439,18 @@ def nav_backward_body(model, c, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl):
         dP[..., :L] = d.float()
         return dP
     nl = net.cfg.num_x_layers
-    dkv = net.new(2 * nl, B * L, 2 * H) if c.has_kv else None
+    acc = dkv_acc is not None and c.has_kv
+    dkv = dkv_acc if acc else (net.new(2 * nl, B * L, 2 * H) if c.has_kv else None)
     cur = net.drop
     net.drop = getattr(c, "drop", cur)      # the row-block backward launches regenerate the masks of THIS call's forward
     try:
-        d_gin = net.cross_bwd(c.glob, d_gmap, d_txt, attn_seed(d_ga, c.glob.P, K), dkv=None if dkv is None else dkv[:nl])
-        d_vin = net.cross_bwd(c.loc, d_vp, d_txt, attn_seed(d_va, c.loc.P, Vp), dkv=None if dkv is None else dkv[nl:])
+        d_gin = net.cross_bwd(c.glob, d_gmap, d_txt, attn_seed(d_ga, c.glob.P, K), dkv=None if dkv is None else dkv[:nl], acc_kv=acc)
+        d_vin = net.cross_bwd(c.loc, d_vp, d_txt, attn_seed(d_va, c.loc.P, Vp), dkv=None if dkv is None else dkv[nl:], acc_kv=acc)
     finally:
         net.drop = cur
     net.gmap_in_bwd(c.gin, c.plan, d_gin, None, None)
     net.vp_in_bwd(c.vin, c.plan, d_vin, None)
-    return d_gin, d_vin, (None if c.has_kv else d_txt), dkv
+    return d_gin, d_vin, (None if c.has_kv else d_txt), (None if acc else dkv)
 
 
 class _NavigationFn(torch.autograd.Function):

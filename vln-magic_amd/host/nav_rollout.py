@@ -231,6 +231,7 @@ class NavRollout:
                 sl.version += 1
                 sl.masks.copy_(u_masks)
                 txt_kv = st.text_kv(txt_embeds, out=sl.kv)
+                s_tok = sgs.kv_token(slot, txt_kv)
             else:
                 txt_kv = st.text_kv(txt_embeds) if self.cache_text_kv else None      # once per episode, not once per step
             txt_embeds, txt_attns = tile(txt_embeds), tile(txt_attns)
@@ -251,6 +252,7 @@ class NavRollout:
                     tsl.version += 1
                     tsl.masks.copy_(u_masks)
                     t_kv = te.text_kv(t_txt, out=tsl.kv)
+                    t_tok = sgt.kv_token(slot, t_kv)
                 else:
                     t_kv = te.text_kv(t_txt) if self.cache_text_kv else None
                 t_txt, t_txt_attns = tile(t_txt), tile(t_txt_attns)
@@ -309,7 +311,7 @@ class NavRollout:
                 s_log.put(plan["log_fused"], pf)
                 gathered = s_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=grad, out=ni.gathered if ni is not None else None)
                 if ni is not None:
-                    outs = sgs.run_nav(ni, fixed, gathered, txt_kv)
+                    outs = sgs.run_nav(ni, fixed, gathered, s_tok)
                 else:
                     outs = st("navigation", self._nav_inputs(d, plan, gathered, txt_embeds, txt_masks, txt_lens, txt_kv))
                 s_log.put(plan["log_cls"], outs["cls_embeds"])
@@ -327,7 +329,7 @@ class NavRollout:
                         t_log.put(plan["log_fused"], tpf, track=tt_grad)
                         tg = t_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=tt_grad, out=tni.gathered if tni is not None else None)
                         if tni is not None:
-                            t_outs = sgt.run_nav(tni, fixed, tg, t_kv)
+                            t_outs = sgt.run_nav(tni, fixed, tg, t_tok)
                         else:
                             t_outs = te("navigation", self._nav_inputs(d, plan, tg, t_txt, txt_masks, txt_lens, t_kv))
                         t_log.put(plan["log_cls"], t_outs["cls_embeds"], track=tt_grad)

@@ -338,13 +338,67 @@ def ln_bwd(M, H, dy, *, y=None, gamma=None, beta=None, rstd=None, dx=None, dgamm
     seed, p, _ = _dr(dd)
     s_dy = int(drop_dy[2]) if (p > 0 and drop_dy is not None) else 0
     s_dx = int(drop_dx[2]) if (p > 0 and drop_dx is not None) else 0
-    if do_ln and dgamma is not None and SPLIT_PGRAD and M >= 512:
+    partial = 0
+    if do_ln and dgamma is not None and part_ok(H):
+        # the gamma / beta sums of every workgroup go to its own row of a partial buffer; one column-sum launch per flush adds them up
+        nblk = _ln_blocks(M, H)
+        pt = torch.empty(2, nblk, H, dtype=torch.float32, device=dy.device)
+        PART_JOBS.append((pt[0], dgamma, nblk, H, H))
+        PART_JOBS.append((pt[1], dbeta, nblk, H, H))
+        dgamma, dbeta, partial = pt[0], pt[1], 1
+    elif do_ln and dgamma is not None and SPLIT_PGRAD and M >= 512:
         # row kernel fully parallel (no same-address atomics) + a separate low-contention column reduction
         L.call("magic_ln_pgrad", L.dt(dy.dtype), M, H, L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(dgamma), L.P(dbeta), L.stream())
         dgamma = dbeta = None
     L.call("magic_ln_bwd", L.dt(dy.dtype), M, H, L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(dx),
-           L.P(dgamma), L.P(dbeta), *d0, *d1, *d2, 1 if do_ln else 0, seed, p, s_dy, s_dx, L.P(dxm), int(hot0), L.stream())
+           L.P(dgamma), L.P(dbeta), *d0, *d1, *d2, 1 if do_ln else 0, seed, p, s_dy, s_dx, L.P(dxm), int(hot0), partial, L.stream())
     return dx
+
+
+# Parameter gradients of the row kernels through PARTIAL rows (round 5): at the wide model sizes (H >= 384: MAGIC-B / MAGIC-L) on the few hundred
+# rows of a navigator step, a LayerNorm / position-embedding backward launch was nothing but its same-address fp32 atomics (ln_bwd 17.6 us for
+# 608 x 768 rows, smallk_ln_bwd 58 us).  Inside a backward pass (the weight-gradient queue is active, so a flush is coming) every workgroup stores
+# its sums in its own row and `flush_part_jobs` adds the rows up: one launch per <= 96 vectors, block order, reproducible.
+PART_PG = os.environ.get("MAGIC_LN_PARTIAL", "1") != "0"
+PART_MIN_H = int(os.environ.get("MAGIC_LN_PARTIAL_MIN_H", "384"))
+PART_JOBS = []         # (partial rows [nblk, stride] view, destination vector, nblk, len, stride)
+_LNB = {}
+
+
+def part_ok(H):
+    return PART_PG and H >= PART_MIN_H and DEFER["active"]
+
+
+def _ln_blocks(M, H):
+    k = (M, H)
+    v = _LNB.get(k)
+    if v is None:
+        v = _LNB[k] = int(L.load().magic_ln_bwd_blocks(M, H))
+        _chk(v > 0, "magic_ln_bwd_blocks")
+    return v
+
+
+def flush_part_jobs():
+    while PART_JOBS:
+        chunk, rest, seen = [], [], set()
+        for job in PART_JOBS:             # one launch holds a destination at most once (its read-modify-write is not atomic)
+            key = job[1].data_ptr()
+            if key in seen or len(chunk) == 96:
+                rest.append(job)
+            else:
+                seen.add(key)
+                chunk.append(job)
+        PART_JOBS[:] = rest
+        n = len(chunk)
+        parts, dsts = (C.c_void_p * n)(), (C.c_void_p * n)()
+        nb, ln, st = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+        for i, (pt, dst, k, length, stride) in enumerate(chunk):
+            parts[i], dsts[i], nb[i], ln[i], st[i] = pt.data_ptr(), dst.data_ptr(), k, length, stride
+        L.call("magic_colsum_add_v", n, C.addressof(parts), C.addressof(dsts), C.addressof(nb), C.addressof(ln), C.addressof(st), L.stream())
+        PART_KEEP[:] = [chunk]            # the partial buffers stay alive until the next flush (the launch reads them asynchronously)
+
+
+PART_KEEP = []
 
 
 def smallk_ln_fwd(M, H, Kin, x, W, b, gamma, beta, eps, out, rstd):
@@ -470,9 +524,22 @@ def embed_in_bwd(H, pano, text=None):
     EIB_KEEP[:] = [take]           # the partial buffers stay alive until the next call (the launch reads them asynchronously)
 
 
+def _skb_part(M, Mmax, H, Kin, dW, db, dgamma, dbeta, device):
+    """partial rows [blocks, H (Kin + 3)] of one position-embedding backward + its four column-sum jobs"""
+    nblk = int(L.load().magic_smallk_ln_bwd_blocks(M, H, Mmax))       # (pair launch: the tile shape follows the larger problem)
+    _chk(nblk > 0, "magic_smallk_ln_bwd_blocks")
+    stride = H * (Kin + 3)
+    pt = torch.empty(nblk, stride, dtype=torch.float32, device=device)
+    flat = pt.view(-1)
+    for off, length, dst in ((0, H * Kin, dW), (H * Kin, H, db), (H * (Kin + 1), H, dgamma), (H * (Kin + 2), H, dbeta)):
+        PART_JOBS.append((flat[off:], dst, nblk, length, stride))
+    return pt
+
+
 def smallk_ln_bwd(M, H, Kin, x, dy, y, gamma, beta, rstd, dW, db, dgamma, dbeta):
+    pt = _skb_part(M, M, H, Kin, dW, db, dgamma, dbeta, dy.device) if part_ok(H) else None
     L.call("magic_smallk_ln_bwd", L.dt(dy.dtype), M, H, Kin, L.P(x), L.P(dy), L.P(y), L.P(gamma), L.P(beta), L.P(rstd),
-           L.P(dW), L.P(db), L.P(dgamma), L.P(dbeta), L.stream())
+           L.P(dW), L.P(db), L.P(dgamma), L.P(dbeta), L.P(pt), L.stream())
 
 
 def softmax_fwd(S, Pout, B, nh, Nq, Nk, ldp, scale, kmask=None, dist=None, sprel_w=None, sprel_b=None):
@@ -721,6 +788,7 @@ RBW_JOBS = []          # (partial buffer, destination gradient vector, blocks): 
 def flush_rbw_parts():
     """add the queued partial LayerNorm gradients into the parameter gradients (<= 96 vectors per launch); called wherever the weight-gradient
     queue is flushed, i.e. before anything reads those gradients (bucket exchanges, the gradient norm)"""
+    flush_part_jobs()
     while RBW_JOBS:
         # one launch holds each destination at most once (its read-modify-write is not atomic): a parameter used by several queued launches
         # -- the navigator's per-step backwards share their LayerNorms -- goes out over as many launches, in queue order
@@ -942,11 +1010,14 @@ def smallk_ln_bwd_pair(H, problems):
     import ctypes as C
     _chk(len(problems) == 2, "smallk_ln_bwd_pair takes two problems")
     arr = (L.SkbProb * 2)()
+    Mmax = max(int(q["M"]) for q in problems)
     for j, q in enumerate(problems):
         d = arr[j]
         d.M, d.Kin = int(q["M"]), int(q["Kin"])
         for k in ("x", "dy", "y", "gamma", "beta", "rstd", "dW", "db", "dgamma", "dbeta"):
             setattr(d, k, L.P(q[k]))
+        if part_ok(H):
+            d.part = L.P(_skb_part(d.M, Mmax, H, d.Kin, q["dW"], q["db"], q["dgamma"], q["dbeta"], q["dy"].device))
     L.call("magic_smallk_ln_bwd_pair", L.dt(problems[0]["dy"].dtype), H, C.addressof(arr), L.stream())
 
 

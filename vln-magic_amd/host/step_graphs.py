@@ -86,7 +86,29 @@ class TextSlot:
         self.kv = torch.zeros(nl, B * Lcap, 2 * net.H, dtype=net.dtype, device=dev)
         self.masks = torch.zeros(B, Lcap, dtype=torch.uint8, device=dev)
         self.txt = torch.zeros(B, Lcap, net.H, dtype=net.dtype, device=dev)
+        # the gradient of the K/V cache, collected IN PLACE by every step's backward graph (its attention backwards add their dK / dV here);
+        # handed to the cache projection's backward once, by `_KVJoin`, when the last step's backward has run
+        self.dkv = torch.zeros_like(self.kv)
         self.version = 0
+
+
+class _KVJoin(torch.autograd.Function):
+    """`token = _KVJoin.apply(txt_kv, slot)`: every captured navigation step takes the one-element token as an input (no data: the graphs read the
+    slot's cache at its fixed address) and its backward adds the step's dK / dV into `slot.dkv`.  Autograd runs this node's backward only after
+    every consumer of the token has run, i.e. when the accumulator is complete: it hands the accumulator to the cache projection's backward.
+    (Before: every step returned its own [2 nl, B L, 2H] gradient -- 150 MB at RxR lengths -- and autograd summed them pairwise.)"""
+
+    @staticmethod
+    def forward(ctx, txt_kv, slot):
+        slot.dkv.zero_()
+        ctx.slot, ctx.version = slot, slot.version
+        return torch.zeros(1, dtype=torch.float32, device=txt_kv.device)
+
+    @staticmethod
+    def backward(ctx, d_token):
+        if ctx.slot.version != ctx.version:
+            raise RuntimeError("step instance: the instruction slot was refilled before this rollout's backward ran")
+        return ctx.slot.dkv, None
 
 
 class _Releaser:
@@ -141,7 +163,7 @@ class _PanoInstFn(torch.autograd.Function):
 
 class _NavInstFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, inst, gathered, txt_kv):
+    def forward(ctx, anchor, inst, gathered, token):
         inst.g_fwd.replay()
         ctx.inst, ctx.rel = inst, _Releaser(inst)
         return tuple(t.detach() for t in inst.out)
@@ -158,7 +180,7 @@ class _NavInstFn(torch.autograd.Function):
         if d_cls is None:                     # (the last step's [cls] feeds nothing: one signature for every step)
             d_cls = inst.owner._zeros_cls(inst)
         bo = inst.owner._run_bwd(inst, ("d_g", "d_v", "d_ga", "d_va", "d_cls", "dgl", "dll", "dfl"), (d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl))
-        return None, None, bo["d_gathered"], bo["dkv"]
+        return None, None, bo["d_gathered"], None
 
 
 class StepGraphs:
@@ -285,14 +307,17 @@ class StepGraphs:
         m.store.sync_shadow()
         inst.g_fwd = self._capture(inst, body)
 
-    def run_nav(self, inst, arrays, gathered, txt_kv):
-        """gathered: the log gather's output, written into inst.gathered (carries the autograd history of the embeddings); txt_kv: the
-        slot's K/V cache as the autograd tensor `VLNBert.text_kv(..., out=slot.kv)` returned"""
+    def kv_token(self, slot_idx, txt_kv):
+        """once per rollout, after `txt_kv = model.text_kv(txt_embeds, out=slot.kv)`: the token every step of the rollout passes to run_nav"""
+        return _KVJoin.apply(txt_kv, self.text_slot(slot_idx))
+
+    def run_nav(self, inst, arrays, gathered, token):
+        """gathered: the log gather's output, written into inst.gathered (carries the autograd history of the embeddings); token: kv_token()"""
         if gathered.data_ptr() != inst.gathered.data_ptr():
             inst.gathered.copy_(gathered.detach())
         inst.block.upload(arrays)
         inst.slot_version = inst.slot.version
-        g, v, ga, va, cls, gl, ll, fl = _NavInstFn.apply(self.model._anchor, inst, gathered, txt_kv)
+        g, v, ga, va, cls, gl, ll, fl = _NavInstFn.apply(self.model._anchor, inst, gathered, token)
         return dict(gmap_embeds=g, vp_embeds=v, gmap_attns=ga, vp_attns=va, cls_embeds=cls, global_logits=gl, local_logits=ll, fused_logits=fl)
 
     def _zeros_cls(self, inst):
@@ -308,8 +333,8 @@ class StepGraphs:
             if inst.kind == "pano":
                 pano_backward_body(m, inst.c, inst.plan, *grads)
                 return {}
-            d_gin, d_vin, _, dkv = nav_backward_body(m, inst.c, *grads)
-            return dict(d_gathered=torch.cat([d_gin, d_vin], 0), dkv=dkv)
+            d_gin, d_vin, _, _ = nav_backward_body(m, inst.c, *grads, dkv_acc=inst.slot.dkv)
+            return dict(d_gathered=torch.cat([d_gin, d_vin], 0))
         sig = tuple(g is not None for g in grads)
         ent = inst.bwd.get(sig)
         if ent is None:
@@ -328,24 +353,25 @@ class StepGraphs:
         bo = {}
         # the weight-gradient GEMMs of this step leave in grouped launches inside its backward graph: isolate the launch layer's queues from
         # whatever the surrounding autograd pass has queued eagerly
-        saved = (O.DEFER["queue"], O.DEFER["active"], O.DEFER.get("bytes", 0), list(O.RBW_JOBS))
+        saved = (O.DEFER["queue"], O.DEFER["active"], O.DEFER.get("bytes", 0), list(O.RBW_JOBS), list(O.PART_JOBS))
         O.DEFER["queue"], O.DEFER["bytes"] = [], 0
         O.RBW_JOBS[:] = []
+        O.PART_JOBS[:] = []
 
         def body():
             O.defer_dw(True)
             if inst.kind == "pano":
                 pano_backward_body(m, inst.c, inst.plan, bi.get("d_emb"), bi.get("d_fused"), bi.get("d_attn"))
             else:
-                d_gin, d_vin, _, dkv = nav_backward_body(m, inst.c, *[bi.get(n) for n in names])
+                d_gin, d_vin, _, _ = nav_backward_body(m, inst.c, *[bi.get(n) for n in names], dkv_acc=inst.slot.dkv)
                 bo["d_gathered"] = torch.cat([d_gin, d_vin], 0)
-                bo["dkv"] = dkv
             O.flush_dw()
         try:
             g = self._capture(inst, body)
         finally:
             O.DEFER["queue"], O.DEFER["active"], O.DEFER["bytes"] = saved[0], saved[1], saved[2]
             O.RBW_JOBS[:] = saved[3]
+            O.PART_JOBS[:] = saved[4]
         return bi, g, bo
 
     def report(self):

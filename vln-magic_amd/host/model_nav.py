@@ -342,6 +342,26 @@ class _TextKVFn(torch.autograd.Function):
         return None, None, d_txt.view(B, L, H).to(ctx.in_dtype), None
 
 
+class _fork:
+    """`with _fork(stream) as side: with side: <branch B>; <branch A>`: branch B runs on `stream` (forked from the current stream at entry,
+    joined at exit); stream None: both branches on the current stream, in program order"""
+
+    def __init__(self, stream):
+        self.s = stream
+
+    def __enter__(self):
+        import contextlib
+        if self.s is None:
+            return contextlib.nullcontext()
+        self.s.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.s)
+
+    def __exit__(self, et, ev, tb):
+        if self.s is not None:
+            torch.cuda.current_stream().wait_stream(self.s)
+        return False
+
+
 def nav_forward_body(model, gmap_img, vp_img, txt_embeds, b, txt_kv=None):
     """the navigation segment (both cross-modal encoders + heads + logit fusion) on the engine: returns (ctx namespace, outputs).  Plain
     function: run by the eager autograd Function below and by the captured step instances (host/step_graphs.py)."""
@@ -365,10 +385,15 @@ def nav_forward_body(model, gmap_img, vp_img, txt_embeds, b, txt_kv=None):
     nl = net.cfg.num_x_layers
     kv = None if txt_kv is None else txt_kv.detach()
     c.has_kv = kv is not None
-    c.glob = net.cross_fwd("global", plan, c.gin.out, K, gmask_u8, gl_, int(sum(gl_)), txt, L, tmask, tl, int(sum(tl)),
-                           dist=b["gmap_pair_dists"].float().contiguous(), kv=None if kv is None else kv[:nl])
-    c.loc = net.cross_fwd("local", plan, c.vin.out, Vp, vmask_u8, vl, int(sum(vl)), txt, L, tmask, tl, int(sum(tl)),
-                          kv=None if kv is None else kv[nl:])
+    # the two cross-modal encoders are independent until the heads: on a side stream when the caller provides one (`b["fork"]`: the captured
+    # step instances -- inside a HIP graph the two become parallel branches, and a 600-row GEMM leaves half of the chip to the other encoder)
+    dist_f = b["gmap_pair_dists"].float().contiguous()
+    with _fork(b.get("fork")) as side:
+        with side:
+            c.loc = net.cross_fwd("local", plan, c.vin.out, Vp, vmask_u8, vl, int(sum(vl)), txt, L, tmask, tl, int(sum(tl)),
+                                  kv=None if kv is None else kv[nl:])
+        c.glob = net.cross_fwd("global", plan, c.gin.out, K, gmask_u8, gl_, int(sum(gl_)), txt, L, tmask, tl, int(sum(tl)),
+                               dist=dist_f, kv=None if kv is None else kv[:nl])
     # heads
     c.Yg, c.g_raw = model._cls(p + "global_sap_head.", c.glob.out, B * K)
     c.Yl, c.l_raw = model._cls(p + "local_sap_head.", c.loc.out, B * Vp)
@@ -403,7 +428,7 @@ def nav_forward_body(model, gmap_img, vp_img, txt_embeds, b, txt_kv=None):
     return c, (c.glob.out.view(B, K, H), c.loc.out.view(B, Vp, H), c.glob.P[..., :L], c.loc.P[..., :L], cls, gl, ll, fl)
 
 
-def nav_backward_body(model, c, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl, dkv_acc=None):
+def nav_backward_body(model, c, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl, dkv_acc=None, fork=None):
     """returns (d_gmap_img [B*K, H], d_vp_img [B*Vp, H], d_txt [B*L, H] or None, dkv [2 nl, B*L, 2H] or None).  dkv_acc: the episode's
     accumulator of the cached K/V projection's gradient [2 nl, B*L, 2H]: this step's dK / dV are added to it and None is returned for dkv."""
     net, p = model.net, model.prefix
@@ -444,12 +469,17 @@ def nav_backward_body(model, c, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl, dkv_
     cur = net.drop
     net.drop = getattr(c, "drop", cur)      # the row-block backward launches regenerate the masks of THIS call's forward
     try:
-        d_gin = net.cross_bwd(c.glob, d_gmap, d_txt, attn_seed(d_ga, c.glob.P, K), dkv=None if dkv is None else dkv[:nl], acc_kv=acc)
-        d_vin = net.cross_bwd(c.loc, d_vp, d_txt, attn_seed(d_va, c.loc.P, Vp), dkv=None if dkv is None else dkv[nl:], acc_kv=acc)
+        if fork is not None and not c.has_kv:
+            fork = None                   # (without the K/V cache both encoders add into d_txt: keep them in order)
+        sga, sva = attn_seed(d_ga, c.glob.P, K), attn_seed(d_va, c.loc.P, Vp)
+        with _fork(fork) as side:
+            with side:
+                d_vin = net.cross_bwd(c.loc, d_vp, d_txt, sva, dkv=None if dkv is None else dkv[nl:], acc_kv=acc)
+                net.vp_in_bwd(c.vin, c.plan, d_vin, None)
+            d_gin = net.cross_bwd(c.glob, d_gmap, d_txt, sga, dkv=None if dkv is None else dkv[:nl], acc_kv=acc)
+            net.gmap_in_bwd(c.gin, c.plan, d_gin, None, None)
     finally:
         net.drop = cur
-    net.gmap_in_bwd(c.gin, c.plan, d_gin, None, None)
-    net.vp_in_bwd(c.vin, c.plan, d_vin, None)
     return d_gin, d_vin, (None if c.has_kv else d_txt), (None if acc else dkv)
 
 

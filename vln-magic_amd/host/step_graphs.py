@@ -35,6 +35,7 @@ from .model_nav import _queue_sync, nav_backward_body, nav_forward_body, pano_ba
 
 import os
 _EAGER_BWD = bool(os.environ.get("MAGIC_STEP_GRAPH_EAGER_BWD"))
+FORK = os.environ.get("MAGIC_STEP_GRAPH_FORK", "1") != "0"      # the two cross-modal encoders of a step as parallel branches of its graphs
 K_BUCKET = 16          # map tokens are padded to a multiple of this
 V_STATIC = 37          # views per panorama the instances are built for (36, or 37 when two candidates share a discretised view)
 
@@ -196,6 +197,7 @@ class StepGraphs:
         self.n_inst = 0
         self.captures = 0
         self.stream = torch.cuda.Stream(device=self.dev)
+        self.side = torch.cuda.Stream(device=self.dev) if FORK else None      # second branch of a step graph (global || local cross-modal encoder)
         self.base_seed = int(base_seed)
         self.rng_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._zc = {}
@@ -302,7 +304,7 @@ class StepGraphs:
             self._arm(inst)
             b = dict(txt_masks=slot.masks, gmap_masks=d["gmap_masks"], vp_masks=d["vp_masks"], gmap_step_ids=d["gmap_step_ids"],
                      gmap_pos_fts=d["gmap_pos_fts"], gmap_pair_dists=d["gmap_pair_dists"], gmap_logit_masks=d["gmap_logit_masks"],
-                     vp_pos_fts=d["vp_pos_fts"], vp_nav_masks=d["vp_nav_masks"], host_lens=lens, fusion=(d["fsrc"], d["bw"]))
+                     vp_pos_fts=d["vp_pos_fts"], vp_nav_masks=d["vp_nav_masks"], host_lens=lens, fusion=(d["fsrc"], d["bw"]), fork=self.side)
             inst.c, inst.out = nav_forward_body(m, inst.gathered[:B * K].view(B, K, H), inst.gathered[B * K:].view(B, Vp, H), slot.txt, b, slot.kv)
         m.store.sync_shadow()
         inst.g_fwd = self._capture(inst, body)
@@ -363,7 +365,7 @@ class StepGraphs:
             if inst.kind == "pano":
                 pano_backward_body(m, inst.c, inst.plan, bi.get("d_emb"), bi.get("d_fused"), bi.get("d_attn"))
             else:
-                d_gin, d_vin, _, _ = nav_backward_body(m, inst.c, *[bi.get(n) for n in names], dkv_acc=inst.slot.dkv)
+                d_gin, d_vin, _, _ = nav_backward_body(m, inst.c, *[bi.get(n) for n in names], dkv_acc=inst.slot.dkv, fork=self.side)
                 bo["d_gathered"] = torch.cat([d_gin, d_vin], 0)
             O.flush_dw()
         try:

@@ -22,7 +22,8 @@ opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
 mk = lambda: SynthNavEnv(batch_size=16, n_scans=6, nodes_per_scan=64, seed=1234, instr_len=(100, 512), path_hops=(8, 15))
 env, env2 = mk(), mk()
 table = torch.from_numpy(env.feature_table).to(dev).to(torch.bfloat16)
-ro = NavRollout(model, table, max_action_len=28, expert_policy="ndtw")
+GRAPHS = "--graphs" in sys.argv
+ro = NavRollout(model, table, max_action_len=28, expert_policy="ndtw", graphs=GRAPHS, Lcap=512)
 rng = np.random.default_rng(0)
 
 
@@ -37,7 +38,7 @@ def iteration():
     opt.step()
 
 
-for _ in range(2):
+for _ in range(5 if GRAPHS else 2):
     iteration()
 torch.cuda.synchronize()
 cProfile.run("iteration(); torch.cuda.synchronize()", "/tmp/nav.prof")

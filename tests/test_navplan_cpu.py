@@ -152,3 +152,34 @@ def test_plans_match_reference_loops(feedback, seed):
     stop = [torch.softmax(rs["logits"], 1)[:, 0].numpy() for rs in ref["steps"]]
     traj = pl.finish(stop)
     assert [x["path"] for x in traj] == [x["path"] for x in ref["traj"]]
+
+
+def test_native_planner_helpers_equal_the_python_forms():
+    """csrc/hostplan.c (hop counts of FloydGraph.path, the nDTW expert's table rows) against the Python loops they replace: identical plans --
+    position features (hop counts), expert targets under 'sample' feedback with the ndtw expert -- step by step over whole rollouts."""
+    from magic_amd.host import hostplan
+    if hostplan.lib() is None:
+        pytest.skip("_magic_hostplan.so not built")
+    saved = hostplan._lib
+
+    def plans(native):
+        hostplan._lib = saved if native else None
+        env = _env(21, B=6, path_hops=(3, 5))
+        rng = np.random.default_rng(3)
+        pl = NavPlanner(env, env.reset(features=False), feedback="sample", max_action_len=8, expert_policy="ndtw")
+        out = []
+        for t in range(8):
+            p = pl.begin_step()
+            out.append((p["targets"].copy(), p["gmap_pos_fts"].copy(), p["vp_pos_fts"].copy()))
+            acts = np.array([int(rng.integers(0, int(n))) for n in p["gmap_lens"]])          # arbitrary (valid-token) actions: off-path walks
+            acts = np.where(np.asarray(p["gmap_visited_masks"])[np.arange(len(acts)), acts] | (acts == 1), p["targets"].clip(min=0), acts)
+            if pl.end_step(acts):
+                break
+        return out
+    try:
+        a, b = plans(True), plans(False)
+    finally:
+        hostplan._lib = saved
+    assert len(a) == len(b) >= 3
+    for (ta, ga, va), (tb, gb, vb) in zip(a, b):
+        assert np.array_equal(ta, tb) and np.array_equal(ga, gb) and np.array_equal(va, vb)

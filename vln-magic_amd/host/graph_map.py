@@ -136,6 +136,10 @@ class FloydGraph:
     def hops(self, i):
         """len(path(names[i], names[j])) for every known j, as an int array"""
         n = len(self.names)
+        from . import hostplan
+        out = hostplan.hops_row(self._via, n, i)        # native form of the recursion below (csrc/hostplan.c); None: library not built
+        if out is not None:
+            return out
         memo = {}
 
         def h(a, b):

@@ -99,7 +99,23 @@ class NavPlanner:
             except AttributeError:
                 pass
         self._dtw = {}                             # episode -> (nodes consumed, DTW row) of the walked path
+        self._ref_idx = {}                         # episode -> its ground-truth path as indices of the scan's dense distance table
         self.t = 0
+
+    def _dense_dist(self, scan, dist):
+        """dense copy of env.shortest_distances[scan] for the native expert (built once per scan, kept on the env)"""
+        cache = getattr(self.env, "_dense_dist_cache", None)
+        if cache is None:
+            cache = {}
+            try:
+                self.env._dense_dist_cache = cache
+            except AttributeError:
+                pass
+        dd = cache.get(scan)
+        if dd is None:
+            from .hostplan import DenseDist
+            dd = cache[scan] = DenseDist(dist)
+        return dd
 
 
     # ---- language (agent.py:63-90) -----------------------------------------------------------------------------
@@ -294,8 +310,29 @@ class NavPlanner:
                 best, best_d = IGNORE, float("inf")
                 dist, gt = env.shortest_distances[scan], ob["gt_path"]
                 if self.expert == "ndtw":
+                    from . import hostplan
                     walked = sum(self.traj[i]["path"], [])
                     n0, row = self._dtw.get(i, (0, [0.0] + [math.inf] * len(gt)))
+                    if hostplan.lib() is not None:
+                        # native rows (csrc/hostplan.c: the same recurrence, the same order of additions and comparisons): the walked prefix, then
+                        # every unvisited candidate's connecting path in one call
+                        dd = self._dense_dist(scan, dist)
+                        ref = self._ref_idx.get(i)
+                        if ref is None:
+                            ref = self._ref_idx[i] = np.array([dd.index[v] for v in gt], np.int32)
+                        if len(walked) > n0:
+                            row = hostplan.dtw_extend(dd, row, walked[n0:], ref)
+                        self._dtw[i] = (len(walked), row)
+                        cj = [j for j, v in enumerate(vpids[i]) if j > 1 and not visited[i, j]]
+                        if cj:
+                            sp = env.shortest_paths[scan][cur]
+                            last = hostplan.dtw_cands(dd, row, [sp[vpids[i][j]][1:] for j in cj], ref)
+                            for j, t_last in zip(cj, last):
+                                d = -math.exp(-float(t_last) / (3.0 * len(gt)))
+                                if d < best_d:
+                                    best, best_d = j, d
+                        a[i] = best
+                        continue
                     row = dtw_rows(dist, row, walked[n0:], gt)
                     self._dtw[i] = (len(walked), row)
                 for j, v in enumerate(vpids[i]):

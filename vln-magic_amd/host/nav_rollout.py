@@ -215,7 +215,12 @@ class NavRollout:
         ld = to_device(dict(txt_ids=lang["txt_ids"][:Bn]), dev)
         L = lang["txt_ids"].shape[1]
         txt_lens = [int(x) for x in lang["txt_lens"]]
-        u_masks = (torch.arange(L, device=dev)[None] < torch.as_tensor(lang["txt_lens"][:Bn], device=dev)[:, None])
+        # per-rollout host -> device traffic in ONE pinned copy (a pageable `as_tensor(..., device=)` per step is a synchronous copy: 10 ms per iteration)
+        once = dict(txt_lens=np.asarray(lang["txt_lens"][:Bn], np.int64), is_smp=np.array([f == "sample" for f in fb], np.bool_))
+        if sample_draws is not None:
+            once["draws"] = np.asarray(sample_draws, np.float64)
+        od = to_device(once, dev)
+        u_masks = (torch.arange(L, device=dev)[None] < od["txt_lens"][:, None])
         txt_masks = u_masks.repeat(text_copies, 1) if text_copies > 1 else u_masks
         lin = dict(txt_ids=ld["txt_ids"], txt_masks=u_masks)
         tile = (lambda x, dim=0: torch.cat([x] * text_copies, dim)) if text_copies > 1 else (lambda x, dim=0: x)
@@ -352,10 +357,9 @@ class NavRollout:
                     a_arg = logits.detach().argmax(1)
                     if any(f == "sample" for f in fb):
                         cdf = torch.softmax(logits.detach(), 1).double().cumsum(1)
-                        u = torch.as_tensor(sample_draws[t], dtype=torch.float64, device=dev)
+                        u = od["draws"][t]
                         a_smp = (cdf < (u * cdf[:, -1])[:, None]).sum(1).clamp(max=logits.shape[1] - 1)
-                        is_smp = torch.tensor([f == "sample" for f in fb], device=dev)
-                        a_arg = torch.where(is_smp, a_smp, a_arg)
+                        a_arg = torch.where(od["is_smp"].view(torch.bool), a_smp, a_arg)
                     a_host = a_arg.cpu().numpy()
                 if record:
                     steps.append(dict(logits=logits.detach().float().cpu(), targets=torch.from_numpy(plan["targets"]).clone(),

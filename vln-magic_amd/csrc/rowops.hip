@@ -123,12 +123,15 @@ struct LnbParams {
 
 // NW = waves per block.  Every block ends in one same-address atomic per parameter / const-table element, and those serialise in L2
 // (measured, M = 10.7 k rows, H = 128: 16.8 us with the gamma / beta gradients, 5.6 without): 16 waves per block = 4x fewer blocks.
-template <typename T, int NIT, int NW>
+// TAB = false: no table gradients in this launch (the LayerNorms inside the transformer blocks: 25 of a navigator step's 26 launches).  The
+// table machinery costs 9 x 2 NIT registers per lane even when unused: at H = 768 the general form needs 256 VGPRs (one wave per SIMD:
+// 17.5 us for 608 rows, pure latency), the plain form half of that.
+template <typename T, int NIT, int NW, bool TAB = true>
 __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, const int nblk, float* red) {
   const int M = pp.M, do_ln = pp.do_ln, small0 = pp.small0, small1 = pp.small1, small2 = pp.small2;
   const T* dy = (const T*)pp.dy; const T* y = (const T*)pp.y; T* dx = (T*)pp.dx;
   const float* gamma = pp.gamma; const float* beta = pp.beta; const float* rstd = pp.rstd;
-  float* dgamma = pp.dgamma; float* dbeta = pp.dbeta; float* d0 = pp.d0; float* d1 = pp.d1; float* d2 = pp.d2;
+  float* dgamma = pp.dgamma; float* dbeta = pp.dbeta; float* d0 = TAB ? pp.d0 : nullptr; float* d1 = TAB ? pp.d1 : nullptr; float* d2 = TAB ? pp.d2 : nullptr;
   const TabRef t0 = pp.t0, t1 = pp.t1, t2 = pp.t2;
   const DropState sdy = drop_init(pp.ddy), sdx = drop_init(pp.ddx);
   T* dxm = (T*)pp.dxm;
@@ -328,16 +331,16 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
   }
 }
 
-template <typename T, int NIT, int NW>
+template <typename T, int NIT, int NW, bool TAB = true>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(LnbParams p) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
-  ln_bwd_body<T, NIT, NW>(p, blockIdx.x, gridDim.x, red_dyn);
+  ln_bwd_body<T, NIT, NW, TAB>(p, blockIdx.x, gridDim.x, red_dyn);
 }
-template <typename T, int NIT, int NW>
+template <typename T, int NIT, int NW, bool TAB = true>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_pair_kernel(LnbParams a, LnbParams b, int nA) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
-  if ((int)blockIdx.x < nA) ln_bwd_body<T, NIT, NW>(a, blockIdx.x, nA, red_dyn);
-  else ln_bwd_body<T, NIT, NW>(b, blockIdx.x - nA, gridDim.x - nA, red_dyn);
+  if ((int)blockIdx.x < nA) ln_bwd_body<T, NIT, NW, TAB>(a, blockIdx.x, nA, red_dyn);
+  else ln_bwd_body<T, NIT, NW, TAB>(b, blockIdx.x - nA, gridDim.x - nA, red_dyn);
 }
 
 // gamma/beta gradients of a LayerNorm as a separate column reduction: dgamma[c] += sum_m dy*xhat, dbeta[c] += sum_m dy
@@ -1309,20 +1312,24 @@ int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t s
   const LnbParams& a = *(const LnbParams*)pa;
   const int H = nit * 128;
   const int nw = lnb_waves(nit);
-  const size_t shm = (size_t)(2 * nw + 9) * H * sizeof(float);
   dim3 block(nw * 64);
   const int nA = lnb_blocks(a, nit);
-#define LNB1(TY, NIT, NW)                                                                               \
+  // launches without table gradients (the LayerNorms inside the blocks) take the plain instantiation at the wide sizes
+  const bool tab = a.d0 || a.d1 || a.d2 || (pb && (((const LnbParams*)pb)->d0 || ((const LnbParams*)pb)->d1 || ((const LnbParams*)pb)->d2));
+  const size_t shm = (size_t)(2 * nw + ((nit >= 3 && !tab) ? 0 : 9)) * H * sizeof(float);
+#define LNB2(TY, NIT, NW, TAB)                                                                          \
   do {                                                                                                  \
-    if (!pb) hipLaunchKernelGGL((ln_bwd_kernel<TY, NIT, NW>), dim3(nA), block, shm, st, a);             \
+    if (!pb) hipLaunchKernelGGL((ln_bwd_kernel<TY, NIT, NW, TAB>), dim3(nA), block, shm, st, a);        \
     else {                                                                                              \
       const LnbParams& b = *(const LnbParams*)pb;                                                       \
-      hipLaunchKernelGGL((ln_bwd_pair_kernel<TY, NIT, NW>), dim3(nA + lnb_blocks(b, nit)), block, shm, st, a, b, nA); \
+      hipLaunchKernelGGL((ln_bwd_pair_kernel<TY, NIT, NW, TAB>), dim3(nA + lnb_blocks(b, nit)), block, shm, st, a, b, nA); \
     }                                                                                                   \
   } while (0)
+#define LNB1(TY, NIT, NW) do { if (NIT >= 3 && !tab) LNB2(TY, NIT, NW, false); else LNB2(TY, NIT, NW, true); } while (0)
   if (dtype == DT_BF16) { if (nit == 1) LNB1(bf16, 1, 16); else if (nit == 2) LNB1(bf16, 2, 8); else if (nit == 3) LNB1(bf16, 3, 4); else LNB1(bf16, 6, 4); }
   else if (dtype == DT_F16) { if (nit == 1) LNB1(f16, 1, 16); else if (nit == 2) LNB1(f16, 2, 8); else if (nit == 3) LNB1(f16, 3, 4); else LNB1(f16, 6, 4); }
   else { if (nit == 1) LNB1(float, 1, 16); else if (nit == 2) LNB1(float, 2, 8); else if (nit == 3) LNB1(float, 3, 4); else LNB1(float, 6, 4); }
+#undef LNB2
 #undef LNB1
   return launch_status();
 }

@@ -192,6 +192,7 @@ class _LanguageFn(torch.autograd.Function):
                     lens=dict(txt=lens), txt_tokens=int(sum(lens)))
         c = net.text_fwd(plan)
         ctx.model, ctx.c, ctx.plan, ctx.drop = model, c, plan, net.drop
+        ctx.set_materialize_grads(False)
         return c.out.view(B, L, net.H), c.P[..., :L]
 
     @staticmethod
@@ -258,6 +259,7 @@ class _PanoramaFn(torch.autograd.Function):
     def forward(ctx, anchor, model, view_img_fts, loc_fts, nav_types, view_lens, pano_masks=None):
         c, plan, outs = pano_forward_body(model, view_img_fts, loc_fts, nav_types, view_lens, pano_masks)
         ctx.model, ctx.c, ctx.plan = model, c, plan
+        ctx.set_materialize_grads(False)          # an output the loss does not use arrives as None in backward, not as a zero tensor to push through
         ctx.mark_non_differentiable(outs[1])
         return outs
 
@@ -488,6 +490,9 @@ class _NavigationFn(torch.autograd.Function):
     def forward(ctx, anchor, model, gmap_img, vp_img, txt_embeds, b, txt_kv=None):
         c, outs = nav_forward_body(model, gmap_img, vp_img, txt_embeds, b, txt_kv)
         ctx.model, ctx.c = model, c
+        # an output the loss does not use (the attention maps without attention distillation, the embeddings) arrives as None in backward: with
+        # materialised zeros every step pushed a zero dP through the UNFUSED attention backward of both top layers (found in round 5's profile)
+        ctx.set_materialize_grads(False)
         ctx.in_dtypes = (gmap_img.dtype, vp_img.dtype, txt_embeds.dtype)
         return outs
 

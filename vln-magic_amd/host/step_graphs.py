@@ -148,6 +148,7 @@ class _PanoInstFn(torch.autograd.Function):
     def forward(ctx, anchor, inst):
         inst.g_fwd.replay()
         ctx.inst, ctx.rel = inst, _Releaser(inst)
+        ctx.set_materialize_grads(False)
         outs = tuple(t.detach() for t in inst.out)        # fresh tensor objects over the instance's memory (autograd writes its edges onto them)
         ctx.mark_non_differentiable(outs[1])
         return outs
@@ -167,6 +168,7 @@ class _NavInstFn(torch.autograd.Function):
     def forward(ctx, anchor, inst, gathered, token):
         inst.g_fwd.replay()
         ctx.inst, ctx.rel = inst, _Releaser(inst)
+        ctx.set_materialize_grads(False)
         return tuple(t.detach() for t in inst.out)
 
     @staticmethod

@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=4)                  # (iteration 1 sees the shapes, 2 captures the step instances, 3-4 top the pools up)
+    ap.add_argument("--no-plan-ahead", dest="plan_ahead", action="store_false",
+                    help="plan the teacher-forced rollout step by step inside the iteration instead of one iteration ahead on a helper thread")
     ap.add_argument("--no-graphs", action="store_true",
                     help="launch every kernel of the training steps eagerly instead of replaying captured step instances (host/step_graphs.py)")
     ap.add_argument("--batch", type=int, default=16)                  # run_rxr_kdl_valid.sh:39
@@ -150,13 +152,16 @@ def main():
         return r["decisions"]
     counters = {"rollout_steps": 0}
 
+    pipe = {"ahead": None, "obs": None}
+
     def iteration():
         if a.mode == "eval":
             return eval_iteration()
         opt.zero_grad()
         if t_opt is not None:
             t_opt.zero_grad()
-        obs = env.reset(features=False)
+        ahead = pipe["ahead"]
+        obs = pipe["obs"] if ahead is not None else env.reset(features=False)
         batch = env.batch
         rw = None
         if a.icod:      # MKRW: softmax(randn(5) / rw_temp) * 5 per step (agent.py:866-871)
@@ -171,7 +176,12 @@ def main():
             r2, r1 = ro.run_interleaved([
                 ((env2, env2.reset(batch=batch, features=False)), dict(feedback="sample", train_ml=1.0, rw_seq=rw,
                                                                        sample_draws=rng.uniform(size=(a.max_action_len, a.batch)))),
-                ((env, obs), dict(feedback="teacher", train_ml=0.2, rw_seq=rw))])
+                ((env, obs), dict(feedback="teacher", train_ml=0.2, rw_seq=rw, ahead=ahead))])
+            if a.plan_ahead:
+                # the NEXT batch's teacher-forced rollout needs nothing from the model: its step plans are built on a helper thread while the GPU
+                # runs this iteration's backward (host/nav_rollout.PlanAhead; the reference's PrefetchLoader prepares its next batch the same way)
+                pipe["obs"] = env.reset(features=False)
+                pipe["ahead"] = ro.plan_ahead(env, pipe["obs"])
         else:
             # the two rollouts are independent per episode: one batch of 2B episodes with per-episode feedback and loss weight, text
             # encoded once (tests/test_rollout_gpu.py: same logits, summed loss and gradients as the separate rollouts)

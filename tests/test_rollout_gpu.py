@@ -307,3 +307,34 @@ def _rollout_on_device(env, call):
     finally:
         R.F.cross_entropy = orig_ce
     return logs
+
+
+def test_plans_built_ahead_of_time_drive_the_same_teacher_forced_rollout():
+    """NavRollout.plan_ahead: the step plans of a teacher-forced rollout built on a helper thread before the rollout starts (nothing in them
+    depends on the model) -- same per-step logits, targets, actions, trajectories, loss and gradients as planning step by step."""
+    cfg = make_config(128, role="student", **KW)
+    _, g_s = _pair(cfg, "student", 8)
+    B, T = 4, 6
+    env_a, env_b = _env(37, B=B), _env(37, B=B)
+    batch = [env_a._draw_episode() for _ in range(B)]
+    table = torch.from_numpy(env_a.feature_table).to(DEV)
+    ro = NavRollout(g_s, table, max_action_len=T, expert_policy="ndtw")
+    g_s.store.zero_grad()
+    want = ro.run(env_a, env_a.reset(batch=batch, features=False), feedback="teacher", train_ml=0.2, record=True)
+    want["loss"].backward()
+    torch.cuda.synchronize()
+    gw = g_s.store.grad.clone()
+    obs = env_b.reset(batch=batch, features=False)
+    ahead = ro.plan_ahead(env_b, obs)
+    g_s.store.zero_grad()
+    got = ro.run(env_b, obs, feedback="teacher", train_ml=0.2, record=True, ahead=ahead)
+    got["loss"].backward()
+    torch.cuda.synchronize()
+    assert float(got["loss"].detach()) == float(want["loss"].detach()) and got["decisions"] == want["decisions"]
+    assert len(got["steps"]) == len(want["steps"])
+    for x, y in zip(got["steps"], want["steps"]):
+        assert torch.equal(x["logits"], y["logits"]) and torch.equal(x["targets"], y["targets"]) and x["actions"] == y["actions"]
+    assert [p["path"] for p in got["traj"]] == [p["path"] for p in want["traj"]]
+    assert (g_s.store.grad - gw).abs().max().item() <= 1e-5 * gw.abs().max().item()
+    with pytest.raises(ValueError):
+        ro.run(env_b, env_b.reset(batch=batch, features=False), feedback="sample", sample_draws=np.zeros((T, B)), ahead=ro.plan_ahead(env_b, obs))

@@ -108,6 +108,43 @@ class EmbeddingLog:
         return out
 
 
+class PlanAhead:
+    """The index plans of a TEACHER-FORCED rollout computed ahead of time on a helper thread (`NavRollout.plan_ahead`).  Under teacher forcing
+    nothing the planner does depends on the model -- the actions are the expert's -- so the whole sequence of step plans of the NEXT batch can be
+    built while the GPU runs the current iteration's backward (the main thread is parked inside `loss.backward()` then, the GIL free), the way the
+    reference's PrefetchLoader prepares the next batch (pretrain_src/data/loader.py:78-120).  `steps(..., ahead=...)` consumes the plans."""
+
+    def __init__(self, make_planner):
+        import threading
+        self.planner = self.plans = self.err = None
+        self._make = make_planner
+        self._th = threading.Thread(target=self._run, name="magic-plan-ahead", daemon=True)
+        self._th.start()
+
+    def _run(self):
+        try:
+            pl = self._make()
+            plans = []
+            while True:
+                plan = pl.begin_pano()
+                live = int((~pl.ended).sum())
+                plan.update(pl.begin_nav())
+                done = pl.end_step(None)
+                plan.update(_live=live, _done=done, _actions=list(pl.actions))
+                plans.append(plan)
+                if done or len(plans) >= pl.T:
+                    break
+            self.planner, self.plans = pl, plans
+        except BaseException as e:          # noqa: BLE001 - re-raised by result() on the caller's thread
+            self.err = e
+
+    def result(self):
+        self._th.join()
+        if self.err is not None:
+            raise self.err
+        return self.planner, self.plans
+
+
 class NavRollout:
     def __init__(self, student, feature_table, teacher=None, kd=None, max_action_len=15, expert_policy="spl", cache_text_kv=True,
                  train_teacher=False, graphs=False, Lcap=None):
@@ -134,6 +171,20 @@ class NavRollout:
         if sg is None or sg.B != B:
             sg = self._sg[id(model)] = StepGraphs(model, self.table, B, self.Lcap)
         return sg
+
+    def _use_graphs(self, obs, grad, text_copies):
+        return bool(self.graphs and grad and text_copies == 1 and max(len(ob["instr_encoding"]) for ob in obs) <= self.Lcap)
+
+    def _planner(self, env, obs, feedback, grad, use_g):
+        from .step_graphs import K_BUCKET, V_STATIC
+        return NavPlanner(env, obs, feedback=feedback, max_action_len=self.T, expert_policy=self.expert, train=grad,
+                          pad_V=V_STATIC if use_g else 0, k_bucket=K_BUCKET if use_g else 1)
+
+    def plan_ahead(self, env, obs, grad=True, text_copies=1):
+        """start planning a teacher-forced rollout over (env, obs) on a helper thread; pass the handle as `ahead=` to `steps` / `run` with the
+        SAME env and obs (the helper steps `env` through the episodes: do not touch it until the rollout has consumed the plans)"""
+        use_g = self._use_graphs(obs, grad, text_copies)
+        return PlanAhead(lambda: self._planner(env, obs, "teacher", grad, use_g))
 
     def graph_report(self):
         return {("teacher" if m is self.teacher else "student"): self._sg[id(m)].report() for m in (self.student, self.teacher)
@@ -183,7 +234,8 @@ class NavRollout:
                     live.remove(i)
         return res
 
-    def steps(self, env, obs, feedback="teacher", train_ml=1.0, rw_seq=None, sample_draws=None, grad=True, record=False, text_copies=1, slot=0):
+    def steps(self, env, obs, feedback="teacher", train_ml=1.0, rw_seq=None, sample_draws=None, grad=True, record=False, text_copies=1, slot=0,
+              ahead=None):
         """Generator form of one batch of episodes: yields after launching each step, returns the result dict.
 
         feedback / train_ml may be per-episode lists: the two rollouts of a fine-tuning iteration (teacher-forced with ml_weight,
@@ -192,7 +244,8 @@ class NavRollout:
         B / k instructions (that case): the text encoder and the K/V projections run once on B / k and are tiled.  The loss is
         divided by B / text_copies, i.e. it equals the sum of the separate rollouts' losses.
         slot: which static instruction slot the captured step instances of this rollout read (`graphs=True`): rollouts whose autograd
-        graphs are alive at the same time (the iteration's two) take different slots."""
+        graphs are alive at the same time (the iteration's two) take different slots.
+        ahead: a `plan_ahead` handle for this (env, obs) -- teacher forcing only: the step plans were built ahead of time."""
         st, te, dev = self.student, self.teacher, self.dev
         B = len(obs)
         per_episode = not isinstance(feedback, str)
@@ -202,10 +255,14 @@ class NavRollout:
         w_host = [float(train_ml)] * B if isinstance(train_ml, (int, float)) else [float(x) for x in train_ml]
         w_ml = torch.tensor(w_host, dtype=torch.float32, device=dev)
         tt_grad = self.train_teacher and grad
-        use_g = self.graphs and grad and text_copies == 1 and max(len(ob["instr_encoding"]) for ob in obs) <= self.Lcap
-        from .step_graphs import K_BUCKET, V_STATIC
-        pl = NavPlanner(env, obs, feedback=feedback, max_action_len=self.T, expert_policy=self.expert, train=grad,
-                        pad_V=V_STATIC if use_g else 0, k_bucket=K_BUCKET if use_g else 1)
+        use_g = self._use_graphs(obs, grad, text_copies)
+        plans = None
+        if ahead is not None:
+            if needs_action:
+                raise ValueError("plan_ahead serves teacher-forced rollouts only (any other feedback needs the model's actions step by step)")
+            pl, plans = ahead.result()
+        else:
+            pl = self._planner(env, obs, feedback, grad, use_g)
         lang = pl.language()
         Lt = lang["txt_ids"].shape[1]   # the batch's own padded extent: what the distillation terms are reduced over (kd_loss.py: sums / means run over the padded batch)
         if use_g:                       # static shapes: the instruction padded to Lcap tokens (masked)
@@ -271,8 +328,12 @@ class NavRollout:
         decisions = 0
         with ctxg:
             for t in range(self.T):
-                plan = pl.begin_pano()
-                decisions += int((~pl.ended).sum())
+                if plans is not None:
+                    plan = plans[t]
+                    decisions += plan["_live"]
+                else:
+                    plan = pl.begin_pano()
+                    decisions += int((~pl.ended).sum())
                 vl = np.asarray(plan["view_lens"])
                 pano_arrays = dict(vp_rows=plan["vp_rows"], view_order=plan["view_order"], loc_fts=plan["loc_fts"],
                                    nav_types=np.asarray(plan["nav_types"]).astype(np.int32), view_lens=vl.astype(np.int32),
@@ -293,7 +354,8 @@ class NavRollout:
                     with tctx():
                         tpe, _, tpf, tpa = sgt.run_pano(tpi, pano_arrays) if tpi is not None else te("panorama", pin)
                 # the GPU is busy with the panorama encoder(s): build the second half of the plan now
-                plan.update(pl.begin_nav())
+                if plans is None:
+                    plan.update(pl.begin_nav())
                 fixed = {k: plan[k] for k in ("gmap_pos_fts", "gmap_pair_dists", "gmap_masks", "vp_pos_fts", "vp_nav_masks", "vp_masks", "fsrc", "bw")}
                 fixed["gmap_step_ids"] = np.asarray(plan["gmap_step_ids"]).astype(np.int32)
                 fixed["gmap_logit_masks"] = ~np.asarray(plan["gmap_visited_masks"], bool) & np.asarray(plan["gmap_masks"], bool)
@@ -364,9 +426,9 @@ class NavRollout:
                 if record:
                     steps.append(dict(logits=logits.detach().float().cpu(), targets=torch.from_numpy(plan["targets"]).clone(),
                                       vpids=plan["gmap_vpids"]))
-                done = pl.end_step(a_host)
+                done = plan["_done"] if plans is not None else pl.end_step(a_host)
                 if record:
-                    steps[-1]["actions"] = list(pl.actions)
+                    steps[-1]["actions"] = list(plan["_actions"] if plans is not None else pl.actions)
                 if done:
                     break
         ml = ml_loss / Bn

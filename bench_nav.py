@@ -70,8 +70,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=4)                  # (iteration 1 sees the shapes, 2 captures the step instances, 3-4 top the pools up)
-    ap.add_argument("--no-plan-ahead", dest="plan_ahead", action="store_false",
-                    help="plan the teacher-forced rollout step by step inside the iteration instead of one iteration ahead on a helper thread")
+    ap.add_argument("--plan-ahead", action="store_true",
+                    help="plan the teacher-forced rollout one iteration ahead on a helper thread (NavRollout.plan_ahead) instead of step by step inside "
+                         "the iteration.  Measured round 5: 210 vs 200 ms per iteration -- the helper's Python fights the backward's callbacks for the GIL")
     ap.add_argument("--no-graphs", action="store_true",
                     help="launch every kernel of the training steps eagerly instead of replaying captured step instances (host/step_graphs.py)")
     ap.add_argument("--batch", type=int, default=16)                  # run_rxr_kdl_valid.sh:39

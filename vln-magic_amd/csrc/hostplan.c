@@ -79,3 +79,162 @@ int mp_dtw_extend(const double* D, int nd, const double* row, int G, const int32
   memcpy(out_row, a, (size_t)(G + 1) * sizeof(double));
   return 0;
 }
+
+/* ---- the planner's per-sample loops (host/nav_plan.py NavPlanner.begin_nav / end_step) ------------------------------------------------------
+ * The second half of a step's plan walks every episode's map: visited / unvisited split in arrival order, step ids, pair distances, the
+ * embedding sources of every map token (agent.py:905-924: visited -> the visiting step's fused row, unvisited -> mean of the views that showed
+ * it), the local -> global fusion map ([LINEAGE] DUET navigation forward) and the inputs of the position features (agent.py:175-251,290-328).
+ * As Python over ~30 nodes x 16 episodes it was 2 ms per step -- more than the GPU needs for the step's forward.  The state stays in the numpy
+ * arrays of host/graph_map.FloydGraph / GraphMap and of the planner (registered here by pointer); one call plans the whole batch.
+ * Arithmetic and ORDER of every entry equal the Python form (tests/test_navplan_cpu.py runs both against the oracle). */
+#include <stdlib.h>
+
+typedef struct {
+  double* d; int32_t* via; uint8_t* seen; int ld;          /* FloydGraph._d / _via / _seen (row pitch ld) */
+  double* pos;                                             /* GraphMap.pos_by_id [cap][3] */
+  int64_t* step;                                           /* node_step_ids by dense id */
+  int64_t* fused; int32_t* vcount; int64_t* vrows; int vmax;   /* embedding bookkeeping by dense id */
+} MpEpisode;
+typedef struct { int B; MpEpisode* ep; int16_t* memo; } MpBatch;
+
+void* mp_batch_new(int B) {
+  MpBatch* h = (MpBatch*)calloc(1, sizeof(MpBatch));
+  if (!h) return 0;
+  h->B = B;
+  h->ep = (MpEpisode*)calloc((size_t)B, sizeof(MpEpisode));
+  h->memo = (int16_t*)malloc((size_t)MP_MAXN * MP_MAXN * sizeof(int16_t));
+  if (!h->ep || !h->memo) { free(h->ep); free(h->memo); free(h); return 0; }
+  return h;
+}
+void mp_batch_free(void* hh) {
+  MpBatch* h = (MpBatch*)hh;
+  if (!h) return;
+  free(h->ep); free(h->memo); free(h);
+}
+int mp_batch_set(void* hh, int i, double* d, int32_t* via, uint8_t* seen, int ld, double* pos, int64_t* step, int64_t* fused, int32_t* vcount,
+                 int64_t* vrows, int vmax) {
+  MpBatch* h = (MpBatch*)hh;
+  if (!h || i < 0 || i >= h->B) return -1;
+  MpEpisode* e = &h->ep[i];
+  e->d = d; e->via = via; e->seen = seen; e->ld = ld; e->pos = pos; e->step = step; e->fused = fused; e->vcount = vcount; e->vrows = vrows; e->vmax = vmax;
+  return 0;
+}
+
+/* GraphMap.update_graph for one episode: edges cur -> candidates (straight-line distance of the positions already written to `pos`), then
+ * FloydGraph.update(cur): relax every pair through cur, mark it visited (speaker_utils.py:511-526) */
+int mp_update_graph(void* hh, int i, int n, int cur, const int32_t* cid, int nc) {
+  MpBatch* h = (MpBatch*)hh;
+  if (!h || i < 0 || i >= h->B || n <= 0 || n > MP_MAXN) return -1;
+  MpEpisode* e = &h->ep[i];
+  const int ld = e->ld;
+  const double* p = e->pos + 3 * (size_t)cur;
+  for (int c = 0; c < nc; ++c) {
+    const int j = cid[c];
+    const double* q = e->pos + 3 * (size_t)j;
+    const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+    const double dis = sqrt(dx * dx + dy * dy + dz * dz);
+    if (dis < e->d[(size_t)cur * ld + j]) {
+      e->d[(size_t)cur * ld + j] = e->d[(size_t)j * ld + cur] = dis;
+      e->via[(size_t)cur * ld + j] = e->via[(size_t)j * ld + cur] = -1;
+    }
+  }
+  for (int a = 0; a < n; ++a) {
+    const double dak = e->d[(size_t)a * ld + cur];
+    for (int b = 0; b < n; ++b) {
+      if (a == b) continue;
+      const double c2 = dak + e->d[(size_t)cur * ld + b];
+      if (c2 < e->d[(size_t)a * ld + b]) { e->d[(size_t)a * ld + b] = c2; e->via[(size_t)a * ld + b] = cur; }
+    }
+  }
+  e->seen[cur] = 1;
+  return 0;
+}
+
+int mp_plan_nav(void* hh, int t, int K, int V, const int32_t* n_nodes, const uint8_t* ended, const int32_t* ci, const int32_t* start,
+                const int32_t* cid, const int32_t* coff, long long base, long long fused0, long long prev_cls0,
+                int64_t* step_ids, float* pair, uint8_t* visited, int32_t* fsrc, uint8_t* bw, int32_t* order, int32_t* nv_out,
+                double* tp, double* gd, int64_t* hp, int32_t* seg_off,
+                int64_t* coo_o, int64_t* coo_s, float* coo_w, int coo_cap, int32_t* ncoo_out) {
+  MpBatch* h = (MpBatch*)hh;
+  if (!h) return -1;
+  const int B = h->B, Vp = V + 2;
+  int nco = 0, tot = 0;
+  for (int i = 0; i < B; ++i) {
+    MpEpisode* e = &h->ep[i];
+    const int n = n_nodes[i], ld = e->ld, nc = coff[i + 1] - coff[i];
+    const int32_t* c_i = cid + coff[i];
+    if (n <= 0 || n + 2 > K || n > MP_MAXN || nc > V) return -2;
+    const int cur = ci[i];
+    /* (a) embedding bookkeeping of a live episode: the current viewpoint's fused row, the views that show still-unvisited neighbours */
+    if (!ended[i]) {
+      e->fused[cur] = fused0 + i;
+      e->vcount[cur] = 0;
+      for (int j = 0; j < nc; ++j) {
+        const int k = c_i[j];
+        if (!e->seen[k]) {
+          if (e->vcount[k] >= e->vmax) return -3;
+          e->vrows[(size_t)k * e->vmax + e->vcount[k]++] = base + (long long)i * V + j;
+        }
+      }
+    }
+    /* (b) token order: visited nodes, then unvisited, each in arrival order */
+    int32_t* ord = order + (size_t)i * K;
+    int nv = 0, m = 0;
+    for (int k = 0; k < n; ++k) if (e->seen[k]) ord[m++] = k;
+    nv = m;
+    for (int k = 0; k < n; ++k) if (!e->seen[k]) ord[m++] = k;
+    nv_out[i] = nv;
+    uint8_t* vis = visited + (size_t)i * K;
+    for (int k = 1; k < 2 + nv; ++k) vis[k] = 1;
+    int64_t* sid = step_ids + (size_t)i * K;
+    for (int k = 0; k < n; ++k) sid[2 + k] = e->step[ord[k]];
+    /* (c) inputs of the position features: every map token, the start viewpoint, every candidate -- position, graph distance, hop count */
+    seg_off[i] = tot;
+    if (mp_hops_row(e->via, ld, n, cur, hp + tot, h->memo) != 0) return -4;       /* hops to every node, dense-id order (scratch: reordered below) */
+    {
+      int64_t hrow[MP_MAXN];
+      memcpy(hrow, hp + tot, (size_t)n * sizeof(int64_t));
+      for (int q = 0; q < n + 1 + nc; ++q) {
+        const int k = q < n ? ord[q] : (q == n ? start[i] : c_i[q - n - 1]);
+        tp[3 * (size_t)(tot + q)] = e->pos[3 * (size_t)k]; tp[3 * (size_t)(tot + q) + 1] = e->pos[3 * (size_t)k + 1]; tp[3 * (size_t)(tot + q) + 2] = e->pos[3 * (size_t)k + 2];
+        gd[tot + q] = k == cur ? 0.0 : e->d[(size_t)cur * ld + k];
+        hp[tot + q] = hrow[k];
+      }
+    }
+    tot += n + 1 + nc;
+    /* (d) pair distances between the map tokens (diagonal 0) */
+    float* pr = pair + (size_t)i * K * K;
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b) pr[(size_t)(2 + a) * K + 2 + b] = a == b ? 0.0f : (float)e->d[(size_t)ord[a] * ld + ord[b]];
+    /* (e) embedding sources */
+    if (nco + 2 + n * 2 > coo_cap) return -5;
+    if (t > 0) {
+      coo_o[nco] = (long long)i * K + 1; coo_s[nco] = prev_cls0 + i; coo_w[nco++] = 1.0f;
+      coo_o[nco] = (long long)B * K + (long long)i * Vp + 1; coo_s[nco] = prev_cls0 + i; coo_w[nco++] = 1.0f;
+    }
+    for (int k = 0; k < nv; ++k) { coo_o[nco] = (long long)i * K + 2 + k; coo_s[nco] = e->fused[ord[k]]; coo_w[nco++] = 1.0f; }
+    for (int k = nv; k < n; ++k) {
+      const int nid = ord[k], cnt = e->vcount[nid];
+      if (cnt <= 0) return -6;
+      if (nco + cnt > coo_cap) return -5;
+      const float w = (float)(1.0 / (double)cnt);
+      for (int r = 0; r < cnt; ++r) { coo_o[nco] = (long long)i * K + 2 + k; coo_s[nco] = e->vrows[(size_t)nid * e->vmax + r]; coo_w[nco++] = w; }
+    }
+    /* (f) local -> global logit fusion: views of visited nodes are "backtrack" views; an unvisited node takes the LAST view that shows it */
+    int32_t* fs = fsrc + (size_t)i * K;
+    uint8_t* bwr = bw + (size_t)i * Vp;
+    fs[0] = 0;
+    {
+      int32_t loc_of[MP_MAXN];
+      for (int k = 0; k < n; ++k) loc_of[k] = -2;
+      for (int j = 0; j < nc; ++j) {
+        if (e->seen[c_i[j]]) bwr[2 + j] = 1;
+        else loc_of[c_i[j]] = j + 2;
+      }
+      for (int k = nv; k < n; ++k) fs[2 + k] = loc_of[ord[k]];
+    }
+  }
+  seg_off[B] = tot;
+  *ncoo_out = nco;
+  return 0;
+}

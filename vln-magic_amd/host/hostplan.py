@@ -23,7 +23,13 @@ def lib():
             l.mp_hops_row.argtypes = [vp, i32, i32, i32, vp, vp]
             l.mp_dtw_cands.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, vp, vp]
             l.mp_dtw_extend.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, vp]
-            for f in (l.mp_hops_row, l.mp_dtw_cands, l.mp_dtw_extend):
+            i64 = C.c_longlong
+            l.mp_batch_new.argtypes, l.mp_batch_new.restype = [i32], vp
+            l.mp_batch_free.argtypes, l.mp_batch_free.restype = [vp], None
+            l.mp_batch_set.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32]
+            l.mp_update_graph.argtypes = [vp, i32, i32, i32, vp, i32]
+            l.mp_plan_nav.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64] + [vp] * 11 + [vp, vp, vp, i32, vp]
+            for f in (l.mp_hops_row, l.mp_dtw_cands, l.mp_dtw_extend, l.mp_batch_set, l.mp_update_graph, l.mp_plan_nav):
                 f.restype = i32
             _lib = l
     return _lib
@@ -85,3 +91,46 @@ def dtw_cands(dd, row, paths, ref_idx):
     l.mp_dtw_cands(dd.D.ctypes.data, dd.n, r.ctypes.data, G, ref_idx.ctypes.data, nodes.ctypes.data, offs.ctypes.data, len(paths), out.ctypes.data,
                    tmp.ctypes.data)
     return out[:len(paths)]
+
+
+CAP, VMAX = 128, 64          # nodes per episode / views recorded per unvisited node the native planner state is sized for (csrc/hostplan.c MP_MAXN = 512)
+
+
+class NativeBatch:
+    """the per-episode planner state of one rollout registered with csrc/hostplan.c (mp_batch_*): FloydGraph / GraphMap arrays by pointer +
+    the planner's own by-dense-id arrays (step ids, fused-embedding rows, rows of the views that showed an unvisited node)"""
+
+    def __init__(self, gmaps):
+        l = lib()
+        self.B = len(gmaps)
+        self.h = l.mp_batch_new(self.B)
+        if not self.h:
+            raise MemoryError("mp_batch_new")
+        self.step = np.zeros((self.B, CAP), np.int64)
+        self.fused = np.full((self.B, CAP), -1, np.int64)
+        self.vcount = np.zeros((self.B, CAP), np.int32)
+        self.vrows = np.zeros((self.B, CAP, VMAX), np.int64)
+        self.keys = [None] * self.B
+        self.gmaps = gmaps
+        for i in range(self.B):
+            self.register(i)
+
+    def register(self, i):
+        g = self.gmaps[i]
+        gr = g.graph
+        objs = self.keys[i]
+        if objs is not None and objs[0] is gr._d and objs[1] is gr._via and objs[2] is gr._seen and objs[3] is g.pos_by_id:
+            return                      # (the arrays registered last time are still the graph's: FloydGraph reallocates only when it outgrows its capacity)
+        key = (gr._d.ctypes.data, gr._via.ctypes.data, gr._seen.ctypes.data, g.pos_by_id.ctypes.data)
+        if True:
+            if gr._d.shape[0] > 512 or not (gr._d.flags.c_contiguous and gr._via.flags.c_contiguous and g.pos_by_id.flags.c_contiguous):
+                raise ValueError("native planner: graph arrays must be C-contiguous with at most 512 nodes")
+            lib().mp_batch_set(self.h, i, key[0], key[1], key[2], gr._d.shape[1], key[3], self.step[i].ctypes.data, self.fused[i].ctypes.data,
+                               self.vcount[i].ctypes.data, self.vrows[i].ctypes.data, VMAX)
+            self.keys[i] = (gr._d, gr._via, gr._seen, g.pos_by_id)
+
+    def __del__(self):
+        l, h = _lib, getattr(self, "h", None)
+        if l is not None and h:
+            l.mp_batch_free(h)
+            self.h = None

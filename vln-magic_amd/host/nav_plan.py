@@ -80,8 +80,17 @@ class NavPlanner:
         self.train = train
         self.angle_table = env.angle_table if angle_table is None else angle_table
         self.gmaps = [GraphMap(ob["viewpoint"]) for ob in obs]
-        for g, ob in zip(self.gmaps, obs):
-            g.update_graph(ob)
+        from . import hostplan
+        self.native = None
+        if hostplan.lib() is not None:
+            # native per-sample loops (csrc/hostplan.c): the graph arrays sized once (no reallocation under the registered pointers in the common case)
+            from .graph_map import FloydGraph
+            for g in self.gmaps:
+                g.graph = FloydGraph(cap=hostplan.CAP)
+                g.pos_by_id = np.zeros((hostplan.CAP, 3), np.float64)
+            self.native = hostplan.NativeBatch(self.gmaps)
+        for i, (g, ob) in enumerate(zip(self.gmaps, obs)):
+            self._update_graph(i, g, ob)
         self.traj = [dict(instr_id=ob["instr_id"], path=[[ob["viewpoint"]]]) for ob in obs]
         self.ended = np.zeros(self.B, bool)
         self.just_ended = np.zeros(self.B, bool)
@@ -101,6 +110,36 @@ class NavPlanner:
         self._dtw = {}                             # episode -> (nodes consumed, DTW row) of the walked path
         self._ref_idx = {}                         # episode -> its ground-truth path as indices of the scan's dense distance table
         self.t = 0
+
+    def _update_graph(self, i, g, ob):
+        """GraphMap.update_graph(ob); with the native core the edge / relaxation loops run in C on the same arrays (csrc/hostplan.c mp_update_graph)"""
+        nb = self.native
+        if nb is None:
+            return g.update_graph(ob)
+        gr = g.graph
+        vp = ob["viewpoint"]
+        g.node_positions[vp] = ob["position"]
+        cur = gr._id(vp)
+        cid = []
+        for cc in ob["candidate"]:
+            g.node_positions[cc["viewpointId"]] = cc["position"]
+            cid.append(gr._id(cc["viewpointId"]))
+        n = len(gr.names)
+        if n > g.pos_by_id.shape[0]:
+            grown = np.zeros((max(2 * g.pos_by_id.shape[0], n), 3), np.float64)
+            grown[:g.pos_by_id.shape[0]] = g.pos_by_id
+            g.pos_by_id = grown
+        g.pos_by_id[cur] = ob["position"]
+        if cid:
+            g.pos_by_id[cid] = [cc["position"] for cc in ob["candidate"]]
+        if n > nb.step.shape[1]:
+            raise ValueError(f"native planner: an episode's map grew past {nb.step.shape[1]} nodes")
+        nb.register(i)
+        import ctypes as C
+        ca = (C.c_int32 * max(len(cid), 1))(*cid)
+        from . import hostplan
+        if hostplan.lib().mp_update_graph(nb.h, i, n, cur, ca, len(cid)) != 0:
+            raise RuntimeError("mp_update_graph failed")
 
     def _dense_dist(self, scan, dist):
         """dense copy of env.shortest_distances[scan] for the native expert (built once per scan, kept on the env)"""
@@ -140,6 +179,8 @@ class NavPlanner:
         for i, g in enumerate(gmaps):
             if not self.ended[i]:
                 g.node_step_ids[obs[i]["viewpoint"]] = t + 1          # agent.py:873-875
+                if self.native is not None:
+                    self.native.step[i, g.graph.index[obs[i]["viewpoint"]]] = t + 1
         # -- panorama inputs (agent.py:111-173): candidate views first, then the remaining views in index order
         # (static per (viewpoint, facing view): cached across steps and rollouts)
         cand_vpids, view_lens, per = [], np.zeros(B, np.int64), []
@@ -175,8 +216,102 @@ class NavPlanner:
         return dict(t=t, B=B, V=V, V_valid=int(view_lens.max()), vp_rows=vp_rows, view_order=view_order, loc_fts=loc, nav_types=nav_types, view_lens=view_lens,
                     cand_vpids=cand_vpids)
 
+    def _begin_nav_native(self):
+        """begin_nav with the per-sample loops in C (csrc/hostplan.c mp_plan_nav): same arrays, same entry order"""
+        from . import hostplan
+        t, B, obs, gmaps, nb = self.t, self.B, self.obs, self.gmaps, self.native
+        V, cand_vpids, view_lens, nav_types = self._half
+        base = self.log_rows
+        self.log_base.append(base)
+        self.log_V.append(V)
+        self.log_rows += B * (V + 2)
+        fused0, cls0 = base + B * V, base + B * V + B
+        prev_cls0 = (self.log_base[t - 1] + B * self.log_V[t - 1] + B) if t > 0 else -1
+        n_nodes = np.array([len(g.graph.names) for g in gmaps], np.int32)
+        lens = n_nodes.astype(np.int64) + 2
+        K = max((int(lens.max()) + self.k_bucket - 1) // self.k_bucket * self.k_bucket, self.pad_K)
+        Vp = V + 2
+        ci = np.array([g.graph.index[ob["viewpoint"]] for g, ob in zip(gmaps, obs)], np.int32)
+        start = np.array([g.graph.index[g.start_vp] for g in gmaps], np.int32)
+        flat, coff = [], [0]
+        for g, cv in zip(gmaps, cand_vpids):
+            gix = g.graph.index
+            flat += [gix[c] for c in cv]
+            coff.append(len(flat))
+        cid = np.array(flat if flat else [0], np.int32)
+        coff = np.array(coff, np.int32)
+        ended = self.ended.astype(np.uint8)
+        step_ids = np.zeros((B, K), np.int64)
+        pair = np.zeros((B, K, K), np.float32)
+        visited = np.zeros((B, K), np.uint8)
+        fsrc = np.full((B, K), -1, np.int32)
+        bw = np.zeros((B, Vp), np.uint8)
+        order = np.zeros((B, K), np.int32)
+        nv = np.zeros(B, np.int32)
+        tot_cap = int(n_nodes.sum()) + B + len(flat)
+        tp, gd, hp = np.empty((tot_cap, 3), np.float64), np.empty(tot_cap, np.float64), np.empty(tot_cap + 512, np.int64)
+        seg_off = np.zeros(B + 1, np.int32)
+        coo_cap = 2 * B + int(n_nodes.sum()) + int(nb.vcount.sum()) + len(flat) + 64      # (every recorded view row + this step's new ones)
+        coo_o, coo_s, coo_w = np.empty(coo_cap, np.int64), np.empty(coo_cap, np.int64), np.empty(coo_cap, np.float32)
+        ncoo = np.zeros(1, np.int32)
+        for i in range(B):
+            nb.register(i)
+        if True:
+            rc = hostplan.lib().mp_plan_nav(nb.h, t, K, V, n_nodes.ctypes.data, ended.ctypes.data, ci.ctypes.data, start.ctypes.data, cid.ctypes.data,
+                                            coff.ctypes.data, base, fused0, prev_cls0, step_ids.ctypes.data, pair.ctypes.data, visited.ctypes.data,
+                                            fsrc.ctypes.data, bw.ctypes.data, order.ctypes.data, nv.ctypes.data, tp.ctypes.data, gd.ctypes.data,
+                                            hp.ctypes.data, seg_off.ctypes.data, coo_o.ctypes.data, coo_s.ctypes.data, coo_w.ctypes.data, coo_cap,
+                                            ncoo.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"mp_plan_nav failed ({rc}): a map with more nodes than the step's token count, or more than {hostplan.VMAX} views of one node")
+        visited = visited.view(np.bool_)
+        gmask = np.arange(K)[None] < lens[:, None]
+        gmask[:, 1] = False                                            # [mem] can never be chosen (agent.py:233)
+        vpid_lists, no_left = [], np.zeros(B, bool)
+        for i, g in enumerate(gmaps):
+            gn, n = g.graph.names, int(n_nodes[i])
+            vpid_lists.append([None, None] + [gn[k] for k in order[i, :n].tolist()])
+            no_left[i] = int(nv[i]) == n
+        tot = int(seg_off[B])
+        cur_pos = np.array([g.node_positions[ob["viewpoint"]] for g, ob in zip(gmaps, obs)], np.float64).reshape(B, 3)
+        cur_head = np.array([ob["heading"] for ob in obs], np.float64)
+        rep = np.repeat(np.arange(B), np.diff(seg_off))
+        h, e, d = rel_pos(cur_pos[rep], tp[:tot], base_heading=cur_head[rep], base_elevation=0)
+        feats = np.concatenate([angle_fts(h.astype(np.float32), e.astype(np.float32)),
+                                np.stack([d / MAX_DIST, gd[:tot] / MAX_DIST, hp[:tot] / MAX_STEP], 1).astype(np.float32)], 1)
+        pos = np.zeros((B, K, 7), np.float32)
+        vp_pos = np.zeros((B, Vp, 14), np.float32)
+        pos[:, :2, 1] = pos[:, :2, 3] = 1.0                           # None tokens: angle (0, 0) -> cos = 1, distances 0
+        for i in range(B):                                            # (agent.py:290-328 for the local tokens: start | candidate)
+            o, ng = int(seg_off[i]), int(n_nodes[i])
+            nc = int(coff[i + 1] - coff[i])
+            pos[i, 2:2 + ng] = feats[o:o + ng]
+            vp_pos[i, :, :7] = feats[o + ng]
+            vp_pos[i, 2:2 + nc, 7:] = feats[o + ng + 1:o + ng + 1 + nc]
+        m = int(ncoo[0])
+        vo = (B * K + np.arange(B)[:, None] * Vp + 2 + np.arange(V)[None]).reshape(-1)
+        vs = (base + np.arange(B)[:, None] * V + np.arange(V)[None]).reshape(-1)
+        out_rows = np.concatenate([coo_o[:m], vo])
+        src_rows = np.concatenate([coo_s[:m], vs])
+        w = np.concatenate([coo_w[:m], np.ones(len(vo), np.float32)])
+        n_out = B * K + B * Vp
+        csr = _csr_from_coo(out_rows, src_rows, w, n_out)
+        csr_t = _csr_from_coo(src_rows, out_rows, w, cls0) if self.train else None     # sources are rows < cls0
+        vp_nav = np.concatenate([np.ones((B, 1), bool), np.zeros((B, 1), bool), nav_types == 1], 1)
+        vp_masks = np.arange(Vp)[None] < (view_lens + 2)[:, None]
+        vp_cand = [[None, None] + c for c in cand_vpids]
+        targets = self._teacher_action(vpid_lists, visited)
+        self._cur = dict(vpids=vpid_lists, no_left=no_left, targets=targets)
+        return dict(K=K, Vp=Vp, K_valid=int(lens.max()), log_base=base, log_fused=fused0, log_cls=cls0, log_rows=self.log_rows,
+                    gmap_vpids=vpid_lists, gmap_lens=lens, gmap_step_ids=step_ids, gmap_pos_fts=pos, gmap_pair_dists=pair,
+                    gmap_visited_masks=visited, gmap_masks=gmask, no_vp_left=no_left,
+                    vp_pos_fts=vp_pos, vp_nav_masks=vp_nav, vp_masks=vp_masks, vp_cand_vpids=vp_cand,
+                    csr=csr, csr_t=csr_t, n_out=n_out, fsrc=fsrc, bw=bw, targets=targets)
+
     def begin_nav(self):
         """second half: map / local tokens, embedding sources, fusion map, expert action"""
+        if self.native is not None:
+            return self._begin_nav_native()
         t, B, obs, gmaps = self.t, self.B, self.obs, self.gmaps
         V, cand_vpids, view_lens, nav_types = self._half
         # -- log layout of this step: B*V view rows, B fused rows, B [cls] rows
@@ -377,7 +512,7 @@ class NavPlanner:
         self.obs = obs = self.env._get_obs(features)
         for i, ob in enumerate(obs):
             if not self.ended[i]:
-                self.gmaps[i].update_graph(ob)
+                self._update_graph(i, self.gmaps[i], ob)
         self.ended |= np.array([a is None for a in acts])
         self.actions = acts
         self.t += 1

@@ -153,6 +153,7 @@ def _queue_sync(model):
 
     def _done(tok=tok):
         model._sync_token = None
+        O.join_dw_stream()            # weight-gradient launches of captured step instances (host/step_graphs.py) run on a stream of their own
         if NAV_DEFER_DW:
             O.flush_dw()
         O.flush_rbw_parts()           # partial LayerNorm gradients of the row-block backward launches of this pass (no-op when flush_dw ran)

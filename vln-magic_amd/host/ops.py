@@ -184,7 +184,38 @@ def _dw_workspace(nf, device):
     return torch.empty(max(nf, 1), dtype=torch.float32, device=device)
 
 
+# The weight-gradient stream (round 5): captured step instances (host/step_graphs.py) replay their weight-gradient launches -- grouped dW GEMMs +
+# the column sums of partial parameter-gradient rows -- on ONE side stream per device, behind an event of the step's backward graph, so the
+# chip-filling dW launch runs under the next step's latency-bound chain.  Every read-modify-write of the flat gradient buffer of those steps
+# happens on that stream, in launch order (the deterministic seam's workspace and counters are per device: one stream keeps them safe);
+# `join_dw_stream` (called wherever the eager queue is flushed: the end of the backward pass) makes the current stream wait for it.
+_DW_STREAM = {}
+_DW_PENDING = set()
+
+
+def dw_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    s = _DW_STREAM.get(key)
+    if s is None:
+        s = _DW_STREAM[key] = torch.cuda.Stream(device=torch.device("cuda", key))
+    return s
+
+
+def dw_stream_used(device):
+    _DW_PENDING.add(torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
+
+
+def join_dw_stream():
+    if _DW_PENDING and not torch.cuda.is_current_stream_capturing():
+        cur = torch.cuda.current_stream()
+        for key in list(_DW_PENDING):
+            if key == cur.device.index:
+                cur.wait_stream(_DW_STREAM[key])
+                _DW_PENDING.discard(key)
+
+
 def flush_dw(group=None, keep_active=False):
+    join_dw_stream()
     group = group or DW_GROUP
     flush_rbw_parts()
     q = DEFER["queue"]

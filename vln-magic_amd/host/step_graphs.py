@@ -35,6 +35,7 @@ from .model_nav import _queue_sync, nav_backward_body, nav_forward_body, pano_ba
 
 import os
 _EAGER_BWD = bool(os.environ.get("MAGIC_STEP_GRAPH_EAGER_BWD"))
+DW_SIDE = os.environ.get("MAGIC_STEP_GRAPH_DW_SIDE", "1") != "0"    # a step's weight-gradient launches as their own graph on the weight-gradient stream
 FORK = os.environ.get("MAGIC_STEP_GRAPH_FORK", "1") != "0"      # the two cross-modal encoders of a step as parallel branches of its graphs
 K_BUCKET = 16          # map tokens are padded to a multiple of this
 V_STATIC = 37          # views per panorama the instances are built for (36, or 37 when two candidates share a discretised view)
@@ -343,12 +344,18 @@ class StepGraphs:
         ent = inst.bwd.get(sig)
         if ent is None:
             ent = inst.bwd[sig] = self._capture_bwd(inst, names, grads)
-        bi, g, bo = ent
+        bi, g, bo, g_dw = ent
         for n, t in zip(names, grads):
             if t is not None:
                 dst = bi[n]
                 dst.copy_(t.reshape(dst.shape))
         g.replay()
+        if g_dw is not None:          # this step's weight gradients: on the device's weight-gradient stream, under the next step's backward chain
+            ds = O.dw_stream(self.dev)
+            ds.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ds):
+                g_dw.replay()
+            O.dw_stream_used(self.dev)
         return bo
 
     def _capture_bwd(self, inst, names, grads):
@@ -369,14 +376,20 @@ class StepGraphs:
             else:
                 d_gin, d_vin, _, _ = nav_backward_body(m, inst.c, *[bi.get(n) for n in names], dkv_acc=inst.slot.dkv, fork=self.side)
                 bo["d_gathered"] = torch.cat([d_gin, d_vin], 0)
-            O.flush_dw()
+            if not DW_SIDE:
+                O.flush_dw()
+        g_dw = None
         try:
             g = self._capture(inst, body)
+            if DW_SIDE and (O.DEFER["queue"] or O.PART_JOBS or O.RBW_JOBS):
+                # the step's weight-gradient launches (grouped dW GEMMs over the operands the backward graph leaves in the instance's memory +
+                # the column sums of its partial parameter-gradient rows) as a graph of their own, replayed on the weight-gradient stream
+                g_dw = self._capture(inst, O.flush_dw)
         finally:
             O.DEFER["queue"], O.DEFER["active"], O.DEFER["bytes"] = saved[0], saved[1], saved[2]
             O.RBW_JOBS[:] = saved[3]
             O.PART_JOBS[:] = saved[4]
-        return bi, g, bo
+        return bi, g, bo, g_dw
 
     def report(self):
         return {"instances": self.n_inst, "captures": self.captures,

@@ -35,7 +35,10 @@ from .model_nav import _queue_sync, nav_backward_body, nav_forward_body, pano_ba
 
 import os
 _EAGER_BWD = bool(os.environ.get("MAGIC_STEP_GRAPH_EAGER_BWD"))
-DW_SIDE = os.environ.get("MAGIC_STEP_GRAPH_DW_SIDE", "1") != "0"    # a step's weight-gradient launches as their own graph on the weight-gradient stream
+# a step's weight-gradient launches as their own graph on the weight-gradient stream (ops.dw_stream).  OFF by default: measured neutral on the
+# navigator iteration (183 / 171 ms with, 181 ms without: the chip-filling dW launch and the latency-bound chain slow each other down, as on
+# the pretraining step in round 3)
+DW_SIDE = os.environ.get("MAGIC_STEP_GRAPH_DW_SIDE", "0") != "0"
 FORK = os.environ.get("MAGIC_STEP_GRAPH_FORK", "1") != "0"      # the two cross-modal encoders of a step as parallel branches of its graphs
 K_BUCKET = 16          # map tokens are padded to a multiple of this
 V_STATIC = 37          # views per panorama the instances are built for (36, or 37 when two candidates share a discretised view)
@@ -242,9 +245,19 @@ class StepGraphs:
         return inst
 
     def _capture(self, inst, body):
+        import gc
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=inst.pool, stream=self.stream, capture_error_mode="relaxed"):
-            body()
+        # no automatic garbage collection while the stream is capturing: a collection can run finalizers that talk to the runtime (a dead
+        # rollout's graphs, pinned staging buffers) in the middle of the capture -- seen as an abort in round 5 (torch collects once itself,
+        # BEFORE the capture begins)
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g, pool=inst.pool, stream=self.stream, capture_error_mode="relaxed"):
+                body()
+        finally:
+            if was:
+                gc.enable()
         self.captures += 1
         return g
 

@@ -137,7 +137,7 @@ def main():
     kd = dict(alpha=0.5, t_alpha=0.5, temperature=2.0, decay=0.7) if a.icod else None      # run_r2r_kdl_valid.sh:97-104
     ro = NavRollout(model, table, teacher=teacher, kd=kd, train_teacher=a.icod, max_action_len=a.max_action_len,
                     expert_policy="ndtw" if not a.icod else "spl",     # run_rxr_kdl_valid.sh:29 / run_r2r_kdl_valid.sh:29
-                    graphs=(a.mode == "train" and not a.no_graphs and not a.fuse_rollouts), Lcap=a.instr_max)
+                    graphs=(a.mode == "train" and not a.no_graphs), Lcap=a.instr_max)
     rng = np.random.default_rng(rank)
 
     gnav = None

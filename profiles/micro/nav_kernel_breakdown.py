@@ -23,27 +23,48 @@ ap.add_argument("--top", type=int, default=70)
 ap.add_argument("--hidden", type=int, default=768)
 ap.add_argument("--iters", type=int, default=4)
 ap.add_argument("--graphs", action="store_true")
+ap.add_argument("--icod", action="store_true", help="BASELINE config 3: MAGIC-S student + trainable MAGIC-L teacher, R2R lengths")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-cfg = make_config(a.hidden, role="teacher", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
-model = VLNBert(None, role="student", config=cfg, device=dev, compute_dtype=torch.bfloat16, seed=0)
+teacher = t_opt = kd = None
+if a.icod:
+    from types import SimpleNamespace
+    scfg = make_config(128, role="student", teacher_hidden_size=768, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    model = VLNBert(None, role="student", config=scfg, device=dev, compute_dtype=torch.bfloat16, seed=0)
+    tcfg = make_config(768, role="teacher", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    teacher = VLNBert(SimpleNamespace(train_kdl_teacher=True, train_kdl=True), role="teacher", config=tcfg, device=dev, compute_dtype=torch.bfloat16, seed=1)
+    teacher.train()
+    t_opt = torch.optim.AdamW(teacher.parameters(), lr=1e-5)
+    kd = dict(alpha=0.5, t_alpha=0.5, temperature=2.0, decay=0.7)
+    T, LEN, HOPS = 15, (20, 80), (4, 7)
+else:
+    cfg = make_config(a.hidden, role="teacher", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    model = VLNBert(None, role="student", config=cfg, device=dev, compute_dtype=torch.bfloat16, seed=0)
+    T, LEN, HOPS = 28, (100, 512), (8, 15)
 model.train()
 opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
-mk = lambda: SynthNavEnv(batch_size=16, n_scans=6, nodes_per_scan=64, seed=1234, instr_len=(100, 512), path_hops=(8, 15))
+mk = lambda: SynthNavEnv(batch_size=16, n_scans=6, nodes_per_scan=64, seed=1234, instr_len=LEN, path_hops=HOPS)
 env, env2 = mk(), mk()
 table = torch.from_numpy(env.feature_table).to(dev).to(torch.bfloat16)
-ro = NavRollout(model, table, max_action_len=28, expert_policy="ndtw", graphs=a.graphs, Lcap=512)
+ro = NavRollout(model, table, teacher=teacher, kd=kd, train_teacher=a.icod, max_action_len=T, expert_policy="spl" if a.icod else "ndtw", graphs=a.graphs, Lcap=LEN[1])
 rng = np.random.default_rng(0)
 
 
 def iteration():
     opt.zero_grad()
+    if t_opt is not None:
+        t_opt.zero_grad()
     obs = env.reset(features=False)
     batch = env.batch
-    r2, r1 = ro.run_interleaved([((env2, env2.reset(batch=batch, features=False)), dict(feedback="sample", train_ml=1.0, sample_draws=rng.uniform(size=(28, 16)))),
-                                 ((env, obs), dict(feedback="teacher", train_ml=0.2))])
+    rw = (torch.softmax(torch.randn(T, 5, device=dev) / 4.0, -1) * 5) if a.icod else None
+    r2, r1 = ro.run_interleaved([((env2, env2.reset(batch=batch, features=False)), dict(feedback="sample", train_ml=1.0, rw_seq=rw, sample_draws=rng.uniform(size=(T, 16)))),
+                                 ((env, obs), dict(feedback="teacher", train_ml=0.2, rw_seq=rw))])
     t_f = time.perf_counter()
-    (r1["loss"] + r2["loss"]).backward()
+    (r1["loss"] + r2["loss"]).backward(retain_graph=a.icod)
+    if a.icod:
+        (r1["t_loss"] + r2["t_loss"]).backward()
+        torch.nn.utils.clip_grad_norm_(teacher.parameters(), 40.0)
+        t_opt.step()
     t_b = time.perf_counter()
     torch.nn.utils.clip_grad_norm_(model.parameters(), 40.0)
     opt.step()

@@ -173,7 +173,7 @@ class NavRollout:
         return sg
 
     def _use_graphs(self, obs, grad, text_copies):
-        return bool(self.graphs and grad and text_copies == 1 and max(len(ob["instr_encoding"]) for ob in obs) <= self.Lcap)
+        return bool(self.graphs and grad and max(len(ob["instr_encoding"]) for ob in obs) <= self.Lcap)
 
     def _planner(self, env, obs, feedback, grad, use_g):
         from .step_graphs import K_BUCKET, V_STATIC
@@ -291,13 +291,14 @@ class NavRollout:
             if sgs is not None:
                 sl = sgs.text_slot(slot)
                 sl.version += 1
-                sl.masks.copy_(u_masks)
-                txt_kv = st.text_kv(txt_embeds, out=sl.kv)
+                sl.masks.copy_(txt_masks)
+                txt_embeds, txt_attns = tile(txt_embeds), tile(txt_attns)
+                txt_kv = st.text_kv(txt_embeds, out=sl.kv)            # (text_copies > 1: projected on the tiled rows, into the slot's static cache)
                 s_tok = sgs.kv_token(slot, txt_kv)
             else:
                 txt_kv = st.text_kv(txt_embeds) if self.cache_text_kv else None      # once per episode, not once per step
-            txt_embeds, txt_attns = tile(txt_embeds), tile(txt_attns)
-            txt_kv = tile(txt_kv, 1) if txt_kv is not None else None
+                txt_embeds, txt_attns = tile(txt_embeds), tile(txt_attns)
+                txt_kv = tile(txt_kv, 1) if txt_kv is not None else None
         kdv = (lambda x, *ext: x) if not use_g else _extent      # distillation sees the batch's own extent, not the static shapes' padding
         s_out = dict(txt_embeds=kdv(txt_embeds, Lt), txt_attns=kdv(txt_attns, None, Lt, Lt))
         t_out = {}
@@ -312,13 +313,14 @@ class NavRollout:
                 if sgt is not None:
                     tsl = sgt.text_slot(slot)
                     tsl.version += 1
-                    tsl.masks.copy_(u_masks)
+                    tsl.masks.copy_(txt_masks)
+                    t_txt, t_txt_attns = tile(t_txt), tile(t_txt_attns)
                     t_kv = te.text_kv(t_txt, out=tsl.kv)
                     t_tok = sgt.kv_token(slot, t_kv)
                 else:
                     t_kv = te.text_kv(t_txt) if self.cache_text_kv else None
-                t_txt, t_txt_attns = tile(t_txt), tile(t_txt_attns)
-                t_kv = tile(t_kv, 1) if t_kv is not None else None
+                    t_txt, t_txt_attns = tile(t_txt), tile(t_txt_attns)
+                    t_kv = tile(t_kv, 1) if t_kv is not None else None
             t_out = dict(txt_embeds=kdv(t_txt, Lt), txt_attns=kdv(t_txt_attns, None, Lt, Lt))
             t_log = EmbeddingLog(te.net.H, te.net.dtype, dev)
         s_log = EmbeddingLog(st.net.H, st.net.dtype, dev)

@@ -451,6 +451,18 @@ def secondary_block():
                          "mode": j["mode"], "workload": j["config"]["workload"], "per_gpu_batch": j["config"]["per_gpu_batch"]}
         except Exception as e:          # noqa: BLE001 - the headline line must still print
             out[name] = {"error": repr(e)[:300]}
+    # the data-parallel STRUCTURE on one GPU: the same step as three backward graphs + the optimizer's graph with the bucket collectives of a
+    # world-1 `nccl` group issued between the replays on the exchange stream -- what the cuts and RCCL's launch latency cost, measurable without a node
+    try:
+        r = subprocess.run([py, os.path.join(ROOT, "bench.py"), "--dp-structure", "--warmup", "12", "--steps", "60", "--no-cpu-baseline", "--no-parity",
+                            "--no-secondary", "--no-profile"], capture_output=True, text=True, timeout=300, env=env)
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        out["dp_structure_world1_rccl"] = {"ms_per_step": j["ms_per_step"], "value": j["value"], "unit": j["unit"], "steps": j["steps"],
+                                           "note": "three student graphs cut at the gradient-bucket boundaries + optimizer graph, all_reduce x 3 buckets (chunked) and the two "
+                                                   "all_gather_into_tensor of the sparse word-embedding rows issued on the exchange stream between the replays in a world-1 nccl "
+                                                   "(= RCCL) group: identity at world 1 -- the cost of the structure, not a scaling number (N > 1: unmeasured on hardware)"}
+    except Exception as e:              # noqa: BLE001
+        out["dp_structure_world1_rccl"] = {"error": repr(e)[:300]}
     # SURVEY f-3: the same pretraining step fed from DataLoader workers (NON-resident batches, PCIe-inclusive; never `value`): batches padded to
     # shape buckets, one graph replay per step (host/stream_graph.py)
     try:
@@ -499,6 +511,11 @@ def main():
                          "student's graph trains on batch i (and, with data parallelism, while the gradient all-reduce and the optimizer run); "
                          "ahead: the same overlap as a fork/join inside ONE graph; same: teacher and student forward of the same batch side by "
                          "side (every step runs exactly one teacher forward and one student update in all three)")
+    ap.add_argument("--dp-structure", action="store_true",
+                    help="N = 1 only: time the data-parallel STRUCTURE of the step -- three backward graphs cut where gradient buckets 0 / 1 / 2 are final, "
+                         "the bucket collectives issued on the exchange stream between the replays in a world-1 `nccl` (= RCCL) group (identity at world 1), "
+                         "the optimizer's graph behind the exchange -- next to the single-graph step (run by the default line as a child process: "
+                         "`dp_structure`)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher rehearsal (no GPU needed): rendezvous, the rank roll-call and the one-line relay only, then exit -- what "
                          "tests/test_bench_launch_cpu.py runs on CPU with --backend gloo; the full 2-rank step runs in tests/test_bench_launch_gpu.py")
@@ -536,6 +553,19 @@ def main():
                 dist.init_process_group("nccl", device_id=dev)
             else:
                 dist.init_process_group("gloo")
+    if a.dp_structure:
+        if world != 1:
+            raise SystemExit("--dp-structure is the N = 1 measurement of the data-parallel structure")
+        import socket
+        os.environ["MAGIC_DP_STRUCTURE"] = "1"
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            warm = torch.zeros(8, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
     L.load()
     rccl = None
     if world > 1:             # every rank reports in through the data-path backend: the line shows N ranks on N devices really took part
@@ -830,7 +860,9 @@ def main():
                            "dropout": a.dropout,
                            "global_batch": a.batch * world, "per_gpu_batch": a.batch, "views": 36, "feat_dim": 768, "max_tokens": 80,
                            "parallelism": f"dp{world}", "samples_per_sec": round(a.batch * world * a.steps / dt, 1)},
-                "roofline": roof, "cpu_baseline": cpu, "parity": parity, "modes": modes, "secondary": secondary, "rccl": rccl, "rccl_smoke": rccl_smoke}
+                "roofline": roof, "cpu_baseline": cpu, "parity": parity, "modes": modes, "secondary": secondary, "rccl": rccl, "rccl_smoke": rccl_smoke,
+                "dp_structure_ms_per_step": ((secondary or {}).get("dp_structure_world1_rccl") or {}).get("ms_per_step"),
+                "dp_structure": bool(a.dp_structure)}
         if parity is not None:
             # the north star's bar (|delta action logit| < 1e-3 against the oracle, argmax identical) for the arithmetic this line's `value`
             # was measured in, stated at the top level; and the mode of the SAME kernels that meets it, with its own step time
@@ -856,7 +888,7 @@ def main():
             info["fp16_max_logit_delta"] = parity["fp16"]["max_abs_logit_delta"]
             info["fp16_argmax_agreement"] = parity["fp16"]["argmax_agreement"]
         print(json.dumps(info))
-    if world > 1:
+    if world > 1 or a.dp_structure:
         dist.destroy_process_group()
 
 

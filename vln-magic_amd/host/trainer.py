@@ -156,9 +156,13 @@ class GradSync:
     def __init__(self, store, chunk_elems=8 << 20, overlap=None, sparse_rows_cap=None):
         self.store = store
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # MAGIC_DP_STRUCTURE=1 (bench.py --dp-structure): run the data-parallel STRUCTURE -- three backward graphs cut at the bucket boundaries, the
+        # bucket collectives issued on the exchange stream between the replays, the optimizer's graph behind the exchange -- in a world-1 `nccl`
+        # group, where every collective is the identity: what the cuts and RCCL's launch latency cost is measurable without a second GPU
+        self.force = self.world == 1 and bool(os.environ.get("MAGIC_DP_STRUCTURE")) and dist.is_available() and dist.is_initialized()
         self.chunk = chunk_elems
         self.card_shared = self._ranks_share_a_card()
-        self.stream = torch.cuda.Stream() if (self.world > 1 and store.device.type == "cuda") else None
+        self.stream = torch.cuda.Stream() if ((self.world > 1 or self.force) and store.device.type == "cuda") else None
         self.overlap = (not os.environ.get("MAGIC_DDP_NO_OVERLAP")) if overlap is None else overlap
         g0d, g0n = store.first_offset(LATE_PREFIXES, True), store.first_offset(LATE_PREFIXES, False)
         nd, tot = store.n_decay, store.total
@@ -242,7 +246,7 @@ class GradSync:
         """launch bucket i's exchange on the side stream.  touched_rows (last bucket only): device int64 ids of the word-embedding
         rows this rank's step wrote, or None for a dense table (mlm: the tied decoder touches every row).  cap_scale: the gathered
         buffers hold cap_scale x sparse_rows_cap rows (gradient accumulation: the rows of cap_scale micro-batches)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         ranges = self.buckets[i]
         # an EMPTY id list is not "no rows": bucket-padded plans carry a zero-length placeholder (host/plan.py) -> dense exchange
@@ -261,7 +265,7 @@ class GradSync:
 
     def all_reduce(self):
         """monolithic form: the whole flat buffer after the backward pass; returns the 1/world factor for the optimizer"""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return 1.0
         self._on_side(lambda: self._ranges([(0, self.store.total)]))
         self.join()
@@ -536,7 +540,7 @@ class PretrainStep:
         """HIP-graph form of step_ahead.  t_cur's tensors must stay alive (they are written by the graph captured for the
         previous batch, or by an eager teacher_forward).  t_next_into: optionally copy the teacher outputs for nxt into this
         existing output dict at the end of the graph (closes the ring when a fixed pool of batches is cycled)."""
-        full = self.sync.world == 1 and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")
+        full = self.sync.world == 1 and not self.sync.force and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")
         for b in (cur[0], nxt[0]):
             off = [k for k, v in b.items() if torch.is_tensor(v) and v.device.type != self.dev.type and k not in ("traj_vp_row", "traj_view_order")]
             if off:
@@ -558,7 +562,7 @@ class PretrainStep:
         whole step on one GPU; under data parallelism three graphs cut where the gradient buckets are final + the optimizer's graph,
         replayed by `replay_student` with the RCCL calls between them"""
         self._one_update_per_call("capture_student / capture_split")
-        full = self.sync.world == 1 and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")
+        full = self.sync.world == 1 and not self.sync.force and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")
         batch, task, plan = cur
         two = (not full) and self.sync.overlap and not os.environ.get("MAGIC_DDP_ONE_GRAPH")
         gS = torch.cuda.CUDAGraph()
@@ -692,7 +696,7 @@ class PretrainStep:
         off = [k for k, v in batch.items() if torch.is_tensor(v) and v.device.type != self.dev.type and k not in ("traj_vp_row", "traj_view_order")]
         if off:
             raise ValueError(f"capture() needs the batch resident on {self.dev} (synth.batch_to); host tensors: {off[:4]}...")
-        full = self.sync.world == 1 and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")   # (env: exercise the DP split on 1 GPU)
+        full = self.sync.world == 1 and not self.sync.force and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")   # (env: exercise the DP split on 1 GPU)
         if self.accum_steps != 1:
             raise NotImplementedError("captured steps run one optimizer step per replay: use step() with accum_steps > 1")
         g = torch.cuda.CUDAGraph()

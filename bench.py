@@ -434,7 +434,7 @@ def secondary_block():
     process's measurements are done)"""
     import subprocess
     py, nav = sys.executable, os.path.join(ROOT, "bench_nav.py")
-    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-loop", "--no-profile"]
+    common = ["--steps", "6", "--warmup", "6", "--no-cpu-baseline", "--no-host-loop", "--no-profile"]      # (warm-up: the step instances are captured on first sight of a shape key)
     runs = {"config3_icod_magicL_teacher_magicS_student": ["--icod", "--hidden", "128", "--teacher-hidden", "768", "--instr-min", "20", "--instr-max", "80",
                                                           "--hops-min", "4", "--hops-max", "7", "--max-action-len", "15"],
             "config5_rxr_magicL_navigator_loop": []}
@@ -448,7 +448,8 @@ def secondary_block():
             line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
             j = json.loads(line)
             out[name] = {"value": j["value"], "unit": j["unit"], "ms_per_iteration": j["ms_per_step"], "steps": j["steps"], "dtype": j["dtype"],
-                         "mode": j["mode"], "workload": j["config"]["workload"], "per_gpu_batch": j["config"]["per_gpu_batch"]}
+                         "mode": j["mode"], "workload": j["config"]["workload"], "per_gpu_batch": j["config"]["per_gpu_batch"], "warmup": j["warmup"],
+                         "step_graphs": {k: {kk: vv for kk, vv in v.items() if kk != "by_key"} for k, v in (j.get("step_graphs") or {}).items()}}
         except Exception as e:          # noqa: BLE001 - the headline line must still print
             out[name] = {"error": repr(e)[:300]}
     # the data-parallel STRUCTURE on one GPU: the same step as three backward graphs + the optimizer's graph with the bucket collectives of a

@@ -1,0 +1,40 @@
+#!/bin/bash
+# round-5 measurement set (run through gpurun from the repo root): the default bench line, its rocprofv3 kernel stats (the exact driver
+# command), four PMC passes (MFMA busy / LDS + wave cycles / FETCH_SIZE / WRITE_SIZE; never combined with a trace option), navigator lines.
+#   bash profiles/micro/final_profile_r05.sh [bench|prof|pmc|nav ...]     (default: all)
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+WHAT=${@:-bench prof pmc nav}
+EAGER="--mode eager --steps 6 --warmup 3 --no-cpu-baseline --no-profile --no-parity --no-secondary"
+for w in $WHAT; do
+case $w in
+bench)
+  python3 $R/bench.py > $O/r05_bench.json 2> $O/r05_bench.err || exit 1
+  tail -c 600 $O/r05_bench.json; echo ;;
+prof)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05_prof -- python3 $R/bench.py --no-cpu-baseline --no-parity --no-secondary --no-profile > $O/r05_bench_under_rocprof.json 2> $O/r05_prof.err || exit 1
+  find $O/r05_prof -name "*kernel_stats.csv" -exec cp {} $O/r05_kernel_stats.csv \;
+  find $O/r05_prof -name "*kernel_trace.csv" -delete
+  rm -f $O/r05_prof/*/*.db $O/r05_prof/*.db ;;
+pmc)
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_a -- python3 $R/bench.py $EAGER > /dev/null 2> $O/r05_pmc_a.err || exit 1
+  echo pass A done
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_b -- python3 $R/bench.py $EAGER > /dev/null 2> $O/r05_pmc_b.err || exit 1
+  echo pass B done
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_c -- python3 $R/bench.py $EAGER > /dev/null 2> $O/r05_pmc_c.err || exit 1
+  echo pass C done
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_d -- python3 $R/bench.py $EAGER > /dev/null 2> $O/r05_pmc_d.err || exit 1
+  echo pass D done
+  STATS=$O/r05_kernel_stats.csv; [ -f $STATS ] || STATS=$R/profiles/r05_rocprofv3_kernel_stats.csv      # (a `prof` leg of this call, else the committed one)
+  python3 $R/profiles/pmc_kernels.py $STATS $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d > $O/r05_pmc_kernels.json
+  python3 $R/profiles/pmc_traffic.py $O/pmc_c $O/pmc_d 9 > $O/r05_pmc_traffic.json
+  rm -rf $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d
+  head -c 1500 $O/r05_pmc_kernels.json; echo ;;
+nav)
+  python3 $R/bench_nav.py > $O/r05_bench_nav.json 2> $O/r05_bench_nav.err
+  python3 $R/bench_nav.py --icod --hidden 128 --teacher-hidden 768 --instr-min 20 --instr-max 80 --hops-min 4 --hops-max 7 --max-action-len 15 --no-cpu-baseline --no-host-loop > $O/r05_bench_nav_icod.json 2> $O/r05_bench_nav_icod.err
+  tail -c 300 $O/r05_bench_nav.json; echo; tail -c 300 $O/r05_bench_nav_icod.json; echo ;;
+esac
+done

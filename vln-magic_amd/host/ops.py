@@ -147,9 +147,10 @@ DW_KEEP_BYTES = int(os.environ.get("MAGIC_DW_KEEP_GB", "8")) << 30
 
 # Deterministic weight gradients (csrc/gemm.hip dw_seam): the K-splits of a dW tile -- and the several problems one Linear queues when it is
 # called more than once in a step -- are summed in a FIXED order through a workspace instead of fp32 atomics, so two runs of the same step
-# give bitwise-identical weight gradients.  MAGIC_DW_ATOMICS=1 restores the atomic form.  The partial slots are scratch (allocated per
-# launch: the caching allocator / the capturing graph's pool hands the same block back); the arrival counters are persistent per
-# (device, stream) -- zero when allocated, left zero by every launch.
+# give bitwise-identical weight gradients.  MAGIC_DW_ATOMICS=1 restores the atomic form.  The partial slots and the arrival counters
+# (zero when allocated, left zero by every launch) are ONE persistent pair per device, baked into every captured graph: two launches
+# that use them must never overlap.  `dw_guard` keeps that true across streams: it remembers the stream of the last user (an eager launch,
+# or the replay of a graph that holds such launches) and makes a user on a DIFFERENT stream wait for everything queued on that one.
 DW_DETERMINISTIC = not os.environ.get("MAGIC_DW_ATOMICS")
 DW_WS_MAX_BYTES = int(os.environ.get("MAGIC_DW_WS_MAX_MB", "256")) << 20
 DW_COUNTERS = 1 << 17
@@ -182,6 +183,23 @@ def _dw_workspace(nf, device):
     if w is not None and nf <= w.numel() and SIDE["stream"] is None:
         return w
     return torch.empty(max(nf, 1), dtype=torch.float32, device=device)
+
+
+_DW_LAST = {}
+
+
+def dw_guard(device=None):
+    """order this stream behind the previous user of the device's shared weight-gradient workspace / counters when that was another stream.
+    Called by every eager deterministic launch and in front of every replay of a graph that may hold one (trainer / step_graphs);
+    inside a capture it does nothing -- the replay site guards.  Same stream as last time (the normal case): a dict lookup."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    cur = torch.cuda.current_stream(device)
+    key = cur.device.index
+    last = _DW_LAST.get(key)
+    if last is not None and last != cur:
+        cur.wait_stream(last)
+    _DW_LAST[key] = cur
 
 
 # The weight-gradient stream (round 5): captured step instances (host/step_graphs.py) replay their weight-gradient launches -- grouped dW GEMMs +
@@ -254,6 +272,8 @@ def dw_grouped(dt, arr, n, device, deterministic=None):
             if cnt is None:
                 cnt = torch.zeros(max(nc, 1), dtype=torch.int32, device=device)
             ws = _dw_workspace(nf, torch.device(device))
+            if cnt is _DW_CNT.get(cnt.device.index) or ws is _DW_WS.get(ws.device.index):
+                dw_guard(ws.device)
     L.call("magic_gemm_dw_grouped", L.dt(dt), n, arr, L.P(ws), int(ws.numel()) if ws is not None else 0, L.P(cnt), int(cnt.numel()) if cnt is not None else 0, L.stream())
     return ws is not None
 

@@ -362,11 +362,14 @@ class StepGraphs:
             if t is not None:
                 dst = bi[n]
                 dst.copy_(t.reshape(dst.shape))
+        if g_dw is None:
+            O.dw_guard(self.dev)      # (the backward graph holds the weight-gradient launch: shared workspace + counters, ops.dw_guard)
         g.replay()
         if g_dw is not None:          # this step's weight gradients: on the device's weight-gradient stream, under the next step's backward chain
             ds = O.dw_stream(self.dev)
             ds.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(ds):
+                O.dw_guard(self.dev)
                 g_dw.replay()
             O.dw_stream_used(self.dev)
         return bo

@@ -611,6 +611,7 @@ class PretrainStep:
         """replay a `capture_student` step on the current stream.  touched: this batch's word-embedding row ids (streamed batches: they
         change per replay; default: the captured batch's); between(): called after the last backward graph, before the exchange is
         awaited (replay_split launches the next teacher graph there)"""
+        O.dw_guard()                                   # the graphs hold deterministic weight-gradient launches (shared workspace: ops.dw_guard)
         cs.graph.replay()
         if getattr(cs, "graph2", None) is not None:
             self.sync.reduce_bucket(0)                 # exchange stream: after graph 1, under graphs 2 and 3
@@ -707,6 +708,7 @@ class PretrainStep:
         return CapturedStep(g, out, plan["traj_steps"], full, keep=(batch, plan, rw))
 
     def replay(self, cs):
+        O.dw_guard()
         cs.graph.replay()
         if not cs.full:
             self._optimize()

@@ -82,6 +82,11 @@ __device__ __forceinline__ void ln_fwd_body(const LnfParams& pp, const int bid) 
     for (int it = 0; it < NIT; ++it) st2<T>(out + (long long)row * H + it * 128 + lane * 2, x[2 * it], x[2 * it + 1]);
     return;
   }
+  // gamma / beta requested BEFORE the two wave reductions: after them the loads' latency was the tail of the launch (a step's LayerNorms run on a
+  // few hundred rows: one row per wave, nothing else to hide it behind)
+  float2 gmv[NIT], btv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) { gmv[it] = *(const float2*)(gamma + it * 128 + lane * 2); btv[it] = *(const float2*)(beta + it * 128 + lane * 2); }
   const float mean = wave_sum(s) / H;
   float q = 0.f;
 #pragma unroll
@@ -91,7 +96,7 @@ __device__ __forceinline__ void ln_fwd_body(const LnfParams& pp, const int bid) 
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int c = it * 128 + lane * 2;
-    const float2 g = *(const float2*)(gamma + c), b = *(const float2*)(beta + c);
+    const float2 g = gmv[it], b = btv[it];
     const float y0 = (x[2 * it] - mean) * rstd * g.x + b.x, y1 = (x[2 * it + 1] - mean) * rstd * g.y + b.y;
     st2<T>(out + (long long)row * H + c, y0, y1);          // pre-dropout y: the backward recovers xhat from it
     if (sout.on) st2<T>(out_drop + (long long)row * H + c, y0 * drop_mul(sout, (unsigned)(row * H + c)), y1 * drop_mul(sout, (unsigned)(row * H + c + 1)));
@@ -126,7 +131,7 @@ struct LnbParams {
 // TAB = false: no table gradients in this launch (the LayerNorms inside the transformer blocks: 25 of a navigator step's 26 launches).  The
 // table machinery costs 9 x 2 NIT registers per lane even when unused: at H = 768 the general form needs 256 VGPRs (one wave per SIMD:
 // 17.5 us for 608 rows, pure latency), the plain form half of that.
-template <typename T, int NIT, int NW, bool TAB = true>
+template <typename T, int NIT, int NW, bool TAB = true, int RPI_ = 0>
 __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, const int nblk, float* red) {
   const int M = pp.M, do_ln = pp.do_ln, small0 = pp.small0, small1 = pp.small1, small2 = pp.small2;
   const T* dy = (const T*)pp.dy; const T* y = (const T*)pp.y; T* dx = (T*)pp.dx;
@@ -170,7 +175,7 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
   // grid-stride over groups of RPI rows per wave: the RPI rows' loads are issued together and their wave reductions
   // interleave (ILP), instead of one latency-bound row after another; the grid is capped so the per-block
   // parameter-gradient atomics stay few.
-  constexpr int RPI = NIT <= 2 ? 4 : 2;
+  constexpr int RPI = RPI_ ? RPI_ : (NIT <= 2 ? 4 : 2);
   float gmr[2 * NIT], btr[2 * NIT], igm[2 * NIT];
   if (do_ln) {
 #pragma unroll
@@ -331,10 +336,10 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
   }
 }
 
-template <typename T, int NIT, int NW, bool TAB = true>
+template <typename T, int NIT, int NW, bool TAB = true, int RPI_ = 0>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(LnbParams p) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
-  ln_bwd_body<T, NIT, NW, TAB>(p, blockIdx.x, gridDim.x, red_dyn);
+  ln_bwd_body<T, NIT, NW, TAB, RPI_>(p, blockIdx.x, gridDim.x, red_dyn);
 }
 template <typename T, int NIT, int NW, bool TAB = true>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_pair_kernel(LnbParams a, LnbParams b, int nA) {
@@ -1235,6 +1240,27 @@ int launch_lnf(int dtype, int H, const void* pa, const void* pb, hipStream_t st)
   return launch_status();
 }
 
+static inline int lnb_waves(int nit) { return nit == 1 ? 16 : nit == 2 ? 8 : 4; }      // waves per block (LDS: (2 NW + 9) H floats; registers)
+// H = 768 without table gradients on the few hundred rows of a navigator step (the LayerNorms inside the transformer blocks): `lean` form --
+// MAGIC_LNB_LEAN = "<waves per block><rows per wave>" picks the launch shape of that form.  Measured in a dependent chain over cold operands
+// (profiles/micro/nav_row_probe.py, M = 624): 4 waves x 2 rows 11.0 us, 4 x 1 7.6, 8 x 1 7.7 (half the partial rows of 4 x 1: the default),
+// 8 x 2 12.1 -- a wave's second row is a second memory round trip on the launch's critical path
+static int lnb_lean_cfg() {
+  static int cfg = -1;
+  if (cfg < 0) { const char* e = getenv("MAGIC_LNB_LEAN"); cfg = e ? atoi(e) : 81; if (cfg != 42 && cfg != 41 && cfg != 81 && cfg != 82) cfg = 81; }
+  return cfg;
+}
+static inline bool lnb_lean(const LnbParams& p, int nit) { return nit == 6 && !p.d0 && !p.d1 && !p.d2; }
+static inline int lnb_blocks(const LnbParams& p, int nit, bool single = false) {
+  int rpi = nit <= 2 ? 4 : 2;                 // rows per wave per iteration (ln_bwd_body::RPI)
+  int nw = lnb_waves(nit);
+  if (single && lnb_lean(p, nit)) { nw = lnb_lean_cfg() / 10; rpi = lnb_lean_cfg() % 10; }
+  const int nb = (p.M + nw * rpi - 1) / (nw * rpi);
+  // with in-kernel gamma/beta grads every block ends in 2H same-address atomics -> cap the grid; without them one row group per wave
+  const int cap = p.dgamma ? 512 : 4096;
+  return nb > cap ? cap : nb;
+}
+
 extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void* y, const float* gamma, const float* beta,
                             const float* rstd, void* dx, float* dgamma, float* dbeta,
                             const int* idx0, int mod0, int off0, float* d0, int small0,
@@ -1256,18 +1282,9 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
               DropDesc{(don && site_dy) ? (const unsigned*)drop_seed : nullptr, site_dy, drop_p},
               (don && site_dx) ? dxm : nullptr, DropDesc{(don && site_dx) ? (const unsigned*)drop_seed : nullptr, site_dx, drop_p}, hot0, pg_partial ? 1 : 0};
   const int nit = H / 128;
+  if (pg_partial && group_state().active && lnb_lean(p, nit) && lnb_lean_cfg() != 42) return MAGIC_ERR_ARG;   // (partial rows are sized for a single launch)
   if (group_record(KIND_LNB, dtype, nit, &p, sizeof(p))) return MAGIC_OK;
   return launch_lnb(dtype, nit, &p, nullptr, (hipStream_t)stream);
-}
-
-static inline int lnb_waves(int nit) { return nit == 1 ? 16 : nit == 2 ? 8 : 4; }      // waves per block (LDS: (2 NW + 9) H floats; registers)
-static inline int lnb_blocks(const LnbParams& p, int nit) {
-  const int rpi = nit <= 2 ? 4 : 2;                 // rows per wave per iteration (ln_bwd_body::RPI)
-  const int nw = lnb_waves(nit);
-  const int nb = (p.M + nw * rpi - 1) / (nw * rpi);
-  // with in-kernel gamma/beta grads every block ends in 2H same-address atomics -> cap the grid; without them one row group per wave
-  const int cap = p.dgamma ? 512 : 4096;
-  return nb > cap ? cap : nb;
 }
 
 // dst_j[c] += sum over b < nblk_j of part_j[b * stride_j + c], c < len_j: the finisher of every "each workgroup stores its partial sums in its own
@@ -1305,7 +1322,7 @@ extern "C" int magic_ln_bwd_blocks(int M, int H) {
   if (M <= 0 || (H != 128 && H != 256 && H != 384 && H != 768)) return MAGIC_ERR_ARG;
   LnbParams p{};
   p.M = M; p.dgamma = (float*)1;
-  return lnb_blocks(p, H / 128);
+  return lnb_blocks(p, H / 128, true);
 }
 
 int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t st) {
@@ -1313,9 +1330,21 @@ int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t s
   const int H = nit * 128;
   const int nw = lnb_waves(nit);
   dim3 block(nw * 64);
-  const int nA = lnb_blocks(a, nit);
+  const int nA = lnb_blocks(a, nit, !pb);
   // launches without table gradients (the LayerNorms inside the blocks) take the plain instantiation at the wide sizes
   const bool tab = a.d0 || a.d1 || a.d2 || (pb && (((const LnbParams*)pb)->d0 || ((const LnbParams*)pb)->d1 || ((const LnbParams*)pb)->d2));
+  if (!pb && lnb_lean(a, nit) && lnb_lean_cfg() != 42) {         // single lean launch in another shape
+    const int cfg = lnb_lean_cfg();
+#define LNBL(TY)                                                                                                                                      \
+    do {                                                                                                                                              \
+      if (cfg == 41) hipLaunchKernelGGL((ln_bwd_kernel<TY, 6, 4, false, 1>), dim3(nA), dim3(256), (size_t)8 * H * sizeof(float), st, a);             \
+      else if (cfg == 81) hipLaunchKernelGGL((ln_bwd_kernel<TY, 6, 8, false, 1>), dim3(nA), dim3(512), (size_t)16 * H * sizeof(float), st, a);       \
+      else hipLaunchKernelGGL((ln_bwd_kernel<TY, 6, 8, false, 2>), dim3(nA), dim3(512), (size_t)16 * H * sizeof(float), st, a);                      \
+    } while (0)
+    if (dtype == DT_BF16) LNBL(bf16); else if (dtype == DT_F16) LNBL(f16); else LNBL(float);
+#undef LNBL
+    return launch_status();
+  }
   const size_t shm = (size_t)(2 * nw + ((nit >= 3 && !tab) ? 0 : 9)) * H * sizeof(float);
 #define LNB2(TY, NIT, NW, TAB)                                                                          \
   do {                                                                                                  \
@@ -1333,7 +1362,6 @@ int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t s
 #undef LNB1
   return launch_status();
 }
-
 
 // public mirror of magic_ln_bwd's arguments for the second problem of magic_embed_in_bwd (the text embedding rows)
 struct magic_ln_bwd_in {

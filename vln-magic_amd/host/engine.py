@@ -12,6 +12,7 @@ from types import SimpleNamespace as Ctx
 
 import torch
 
+from . import lanes
 from . import ops as O
 from .config import cfg_get
 
@@ -107,11 +108,30 @@ class Lin:
         self.W = store.w_span(wname, rows, cols)
         self.b = store.master_span(bname, rows)
         self.Wm = store.master_span(wname, rows * cols).view(rows, cols)
-        if store.requires_grad:
-            self.dW = store.g_span(wname, rows * cols).view(rows, cols)
-            self.db = store.g_span(bname, rows)
+        self._bname, self._g = bname, {}
         self.N, self.K = rows, cols
         self._store, self._wname = store, wname
+
+    def _grads(self):
+        """(dW, db) views of the CURRENT lane's flat gradient buffer (host/lanes.py)"""
+        k = lanes.cur
+        v = self._g.get(k)
+        if v is None:
+            st = self._store
+            if not st.requires_grad:
+                return (None, None)
+            v = self._g[k] = (st.g_span(self._wname, self.N * self.K).view(self.N, self.K), st.g_span(self._bname, self.N))
+        elif k:
+            self._store.lane_dirty = True
+        return v
+
+    @property
+    def dW(self):
+        return self._grads()[0]
+
+    @property
+    def db(self):
+        return self._grads()[1]
 
     @property
     def WT(self):
@@ -142,8 +162,26 @@ class Lin:
 class LN:
     def __init__(self, store, wname, bname):
         self.g, self.b = store.master(wname), store.master(bname)
-        if store.requires_grad:
-            self.dg, self.db = store.g(wname), store.g(bname)
+        self._store, self._names, self._g = store, (wname, bname), {}
+
+    def _grads(self):
+        k = lanes.cur
+        v = self._g.get(k)
+        if v is None:
+            if not self._store.requires_grad:
+                return (None, None)
+            v = self._g[k] = (self._store.g(self._names[0]), self._store.g(self._names[1]))
+        elif k:
+            self._store.lane_dirty = True
+        return v
+
+    @property
+    def dg(self):
+        return self._grads()[0]
+
+    @property
+    def db(self):
+        return self._grads()[1]
 
 
 class MagicNet:

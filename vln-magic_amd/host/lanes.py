@@ -1,0 +1,98 @@
+"""Gradient lanes: independent parts of ONE autograd pass on separate HIP streams.
+
+The navigator iteration (agent_base.py:243-250) is two rollouts over the same weights whose step chains are latency-bound (a few hundred rows
+per launch: ~120 of 256 CUs busy, 5 us of dispatch latency between dependent launches).  Their forward and backward chains are independent
+except for ONE thing: both add into the same parameter gradients.  A lane gives a rollout
+
+  * its own stream (lane 0: the ambient stream),
+  * its own flat gradient buffer (params.ParamStore: `g()` / the `Lin` / `LN` handles resolve to the current lane's buffer),
+  * its own workspace + counters of the deterministic weight-gradient launch (ops.dw_counters),
+
+so the two chains can overlap on the GPU with no read-modify-write on shared memory.  The buffers are summed once, in lane order, when the
+backward pass ends (`ParamStore.merge_lanes`, from the end-of-backward callback): the result is the sum the single-stream pass computes, in a
+fixed order.
+
+`cur` is the lane the calling code is working for.  Forward code runs under `use(k, stream)`; every autograd Function that writes parameter
+gradients records `cur` in its forward and re-enters it in its backward (the autograd engine itself runs a node's backward on the stream its
+forward ran on).  One thread at a time: the loop's thread in the forward, the engine's device thread during `backward()`.
+"""
+import contextlib
+
+import torch
+
+cur = 0
+_streams = {}          # (device index, lane) -> torch.cuda.Stream
+_used = {}             # device index -> set of lane streams that have work queued since the last join
+
+
+def stream(device, k):
+    """lane k's stream on `device` (k >= 1; lane 0 is whatever stream is current)"""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(k))
+    s = _streams.get(key)
+    if s is None:
+        s = _streams[key] = torch.cuda.Stream(device=torch.device("cuda", key[0]))
+    return s
+
+
+@contextlib.contextmanager
+def use(k, s=None):
+    """work for lane k (on stream s when given)"""
+    global cur
+    old = cur
+    cur = int(k)
+    try:
+        if s is not None:
+            _used.setdefault(s.device.index, set()).add(s)
+            with torch.cuda.stream(s):
+                yield
+        else:
+            yield
+    finally:
+        cur = old
+
+
+def fork(device, ks):
+    """before the lanes start: their streams wait for everything queued on the current stream"""
+    now = torch.cuda.current_stream(device)
+    for k in ks:
+        if k:
+            stream(device, k).wait_stream(now)
+
+
+def pending(device=None):
+    idx = torch.device(device).index if device is not None else None
+    return any(v for d, v in _used.items() if idx is None or d == idx)
+
+
+def join(device=None, forget=True):
+    """the current stream waits for every lane stream with queued work (no-op inside a capture / without lanes)"""
+    if not _used or torch.cuda.is_current_stream_capturing():
+        return
+    now = torch.cuda.current_stream(device)
+    ss = _used.get(now.device.index)
+    if ss:
+        for s in ss:
+            if s != now:
+                now.wait_stream(s)
+        if forget:
+            ss.clear()
+
+
+def fence(device=None):
+    """two-way: the current stream waits for the lanes, then the lanes wait for the current stream -- around a launch on the current stream
+    that reads tensors the lanes produced and frees them afterwards (the eager weight-gradient flush in the middle of a backward pass)"""
+    if not _used or torch.cuda.is_current_stream_capturing():
+        return None
+    now = torch.cuda.current_stream(device)
+    ss = [s for s in _used.get(now.device.index, ()) if s != now]
+    for s in ss:
+        now.wait_stream(s)
+    return now, ss
+
+
+def fence_end(tok):
+    if tok:
+        now, ss = tok
+        for s in ss:
+            s.wait_stream(now)

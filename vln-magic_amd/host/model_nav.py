@@ -26,6 +26,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import lanes
 from . import ops as O
 from .config import cfg_get, make_config
 from .ddp import refuse_torch_ddp
@@ -49,9 +50,21 @@ def nav_specs(cfg, p="vln_bert."):
     return s + causal_specs(cfg, p)
 
 
+def _lane_bwd(fn):
+    """backward of a Function that writes parameter gradients: re-enter the gradient lane its forward ran in (host/lanes.py; `ctx.lane`)"""
+    def run(ctx, *grads):
+        k = getattr(ctx, "lane", 0)
+        if k == lanes.cur:
+            return fn(ctx, *grads)
+        with lanes.use(k):
+            return fn(ctx, *grads)
+    return run
+
+
 class _HipLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod, anchor=None):
+        ctx.lane = lanes.cur
         net, lin = mod._net, mod._lin
         shp = x.shape
         M = x.numel() // shp[-1]
@@ -61,6 +74,7 @@ class _HipLinearFn(torch.autograd.Function):
         return y.view(*shp[:-1], lin.N)
 
     @staticmethod
+    @_lane_bwd
     def backward(ctx, dy):
         net, lin = ctx.mod._net, ctx.mod._lin
         M = ctx.x.shape[0]
@@ -154,9 +168,11 @@ def _queue_sync(model):
     def _done(tok=tok):
         model._sync_token = None
         O.join_dw_stream()            # weight-gradient launches of captured step instances (host/step_graphs.py) run on a stream of their own
+        lanes.join(model.device_, forget=False)     # the rollouts' gradient lanes ran on streams of their own (host/lanes.py): this stream waits for them
         if NAV_DEFER_DW:
             O.flush_dw()
         O.flush_rbw_parts()           # partial LayerNorm gradients of the row-block backward launches of this pass (no-op when flush_dw ran)
+        model.store.merge_lanes()     # grad += the lanes' buffers, in lane order
         from .trainer import auto_sync
         auto_sync(model)
     torch.autograd.Variable._execution_engine.queue_callback(_done)
@@ -182,6 +198,7 @@ def _zeros_like_shape(t, shape, dtype, device):
 class _LanguageFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, txt_ids, txt_masks):
+        ctx.lane = lanes.cur
         net = model.net
         B, L = txt_ids.shape
         lens = txt_masks.sum(1).tolist()        # (already a host sync: the range check below rides on it)
@@ -197,6 +214,7 @@ class _LanguageFn(torch.autograd.Function):
         return c.out.view(B, L, net.H), c.P[..., :L]
 
     @staticmethod
+    @_lane_bwd
     def backward(ctx, d_out, d_attn):
         net, c = ctx.model.net, ctx.c
         net.S.ensure_grads()
@@ -258,6 +276,7 @@ def pano_backward_body(model, c, plan, d_emb, d_fused, d_attn):
 class _PanoramaFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, view_img_fts, loc_fts, nav_types, view_lens, pano_masks=None):
+        ctx.lane = lanes.cur
         c, plan, outs = pano_forward_body(model, view_img_fts, loc_fts, nav_types, view_lens, pano_masks)
         ctx.model, ctx.c, ctx.plan = model, c, plan
         ctx.set_materialize_grads(False)          # an output the loss does not use arrives as None in backward, not as a zero tensor to push through
@@ -265,6 +284,7 @@ class _PanoramaFn(torch.autograd.Function):
         return outs
 
     @staticmethod
+    @_lane_bwd
     def backward(ctx, d_emb, _dm, d_fused, d_attn):
         ctx.model.net.S.ensure_grads()
         _queue_sync(ctx.model)
@@ -314,6 +334,7 @@ class _TextKVFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, txt_embeds, out=None):
+        ctx.lane = lanes.cur
         net = model.net
         B, L, H = txt_embeds.shape
         M = B * L
@@ -331,6 +352,7 @@ class _TextKVFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lane_bwd
     def backward(ctx, dkv):
         model, net = ctx.model, ctx.model.net
         net.S.ensure_grads()
@@ -489,6 +511,7 @@ def nav_backward_body(model, c, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl, dkv_
 class _NavigationFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, gmap_img, vp_img, txt_embeds, b, txt_kv=None):
+        ctx.lane = lanes.cur
         c, outs = nav_forward_body(model, gmap_img, vp_img, txt_embeds, b, txt_kv)
         ctx.model, ctx.c = model, c
         # an output the loss does not use (the attention maps without attention distillation, the embeddings) arrives as None in backward: with
@@ -498,6 +521,7 @@ class _NavigationFn(torch.autograd.Function):
         return outs
 
     @staticmethod
+    @_lane_bwd
     def backward(ctx, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl):
         model, c = ctx.model, ctx.c
         model.net.S.ensure_grads()

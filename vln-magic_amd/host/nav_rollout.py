@@ -12,10 +12,14 @@ Device->host traffic: none under teacher forcing (the stop probabilities the ref
 and step, :986-996, are kept on the device and read once after the loop); one [B] action vector per step for 'argmax' /
 'sample' (the stepper needs it).
 """
+import contextlib
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import lanes
 from . import ops as O
 from .makd_nav import compute_kd_losses
 from .nav_plan import IGNORE, NavPlanner
@@ -78,6 +82,9 @@ class _LogGather(torch.autograd.Function):
         O.csr_gather(d_out.contiguous(), ctx.csr_t[0], ctx.csr_t[1], ctx.csr_t[2], dlog, ctx.n_src, H)
         grads = [dlog[a:b].view(shp) if b <= ctx.n_src else None for (a, b), shp in zip(ctx.spans, ctx.shapes)]
         return (None, None, None, None, None, None, None, *grads)
+
+
+LANES = os.environ.get("MAGIC_NAV_LANES", "1") != "0"      # the rollouts of `run_interleaved` as gradient lanes on streams of their own
 
 
 class EmbeddingLog:
@@ -225,13 +232,23 @@ class NavRollout:
         gens = [self.steps(*a, **dict(k, slot=k.get("slot", i))) for i, (a, k) in enumerate(jobs)]
         res = [None] * len(gens)
         live = list(range(len(gens)))
+        # gradient lanes (host/lanes.py): with captured step instances every rollout works on its own stream into its own gradient buffer, so
+        # the rollouts' latency-bound chains overlap on the GPU in the forward AND in the one backward pass that follows
+        laned = self.graphs and LANES and len(gens) > 1 and self.dev.type == "cuda" and all(k.get("grad", True) for _, k in jobs)
+        ctx = [contextlib.nullcontext] * len(gens)
+        if laned:
+            lanes.fork(self.dev, range(len(gens)))
+            ctx = [(lambda i=i: lanes.use(i, lanes.stream(self.dev, i) if i else None)) for i in range(len(gens))]
         while live:
             for i in list(live):
                 try:
-                    next(gens[i])
+                    with ctx[i]():
+                        next(gens[i])
                 except StopIteration as e:
                     res[i] = e.value
                     live.remove(i)
+        if laned:
+            lanes.join(self.dev, forget=False)        # the results (losses, logits) are the caller's to use on ITS stream
         return res
 
     def steps(self, env, obs, feedback="teacher", train_ml=1.0, rw_seq=None, sample_draws=None, grad=True, record=False, text_copies=1, slot=0,

@@ -10,6 +10,7 @@ import os
 
 import torch
 
+from . import lanes
 from . import lib as L
 
 # algorithmic FLOPs of the dense contractions, per kernel family ("gemm": magic_gemm / magic_gemm_dw_grouped; "linear_ln": the fused
@@ -165,20 +166,21 @@ def dw_counters(device=None):
     opt-in side stream MAGIC_DW_SIDE takes per-call counters).  Allocated OUTSIDE graph capture (the models call this when they are built):
     memory taken from a capturing graph's pool would be recycled when that graph dies.  None: first use inside a capture."""
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, lanes.cur)                             # one pair per gradient lane (host/lanes.py): lanes run on different streams
     c = _DW_CNT.get(key)
     if c is None:
         if torch.cuda.is_current_stream_capturing():
             return None                                # this launch takes per-call counters (a memset node)
-        c = _DW_CNT[key] = torch.zeros(DW_COUNTERS, dtype=torch.int32, device=torch.device("cuda", key))
+        c = _DW_CNT[key] = torch.zeros(DW_COUNTERS, dtype=torch.int32, device=torch.device("cuda", idx))
         # ... and ONE partial-slot workspace shared by every launch that fits it (the headline step needs ~35 MB): a workspace per captured
         # graph cost each capture a 57 MB pool allocation -- the streamed feed's in-window captures went from 9 to 34 ms apiece
-        _DW_WS[key] = torch.empty(DW_WS_PERSIST_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", key))
+        _DW_WS[key] = torch.empty(DW_WS_PERSIST_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", idx))
     return c
 
 
 def _dw_workspace(nf, device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.index if device.index is not None else torch.cuda.current_device(), lanes.cur)
     w = _DW_WS.get(key)
     if w is not None and nf <= w.numel() and SIDE["stream"] is None:
         return w
@@ -195,7 +197,7 @@ def dw_guard(device=None):
     if torch.cuda.is_current_stream_capturing():
         return
     cur = torch.cuda.current_stream(device)
-    key = cur.device.index
+    key = (cur.device.index, lanes.cur)
     last = _DW_LAST.get(key)
     if last is not None and last != cur:
         cur.wait_stream(last)
@@ -234,6 +236,16 @@ def join_dw_stream():
 
 def flush_dw(group=None, keep_active=False):
     join_dw_stream()
+    # gradient lanes (host/lanes.py): an EAGER flush launches on the current stream over operands every lane's stream produced, into every
+    # lane's gradient buffer -- order it behind the lanes, and the lanes behind it (the operands are freed afterwards)
+    tok = lanes.fence() if (DEFER["queue"] or PART_JOBS or RBW_JOBS) else None
+    try:
+        _flush_dw(group, keep_active)
+    finally:
+        lanes.fence_end(tok)
+
+
+def _flush_dw(group=None, keep_active=False):
     group = group or DW_GROUP
     flush_rbw_parts()
     q = DEFER["queue"]
@@ -272,7 +284,7 @@ def dw_grouped(dt, arr, n, device, deterministic=None):
             if cnt is None:
                 cnt = torch.zeros(max(nc, 1), dtype=torch.int32, device=device)
             ws = _dw_workspace(nf, torch.device(device))
-            if cnt is _DW_CNT.get(cnt.device.index) or ws is _DW_WS.get(ws.device.index):
+            if cnt is _DW_CNT.get((cnt.device.index, lanes.cur)) or ws is _DW_WS.get((ws.device.index, lanes.cur)):
                 dw_guard(ws.device)
     L.call("magic_gemm_dw_grouped", L.dt(dt), n, arr, L.P(ws), int(ws.numel()) if ws is not None else 0, L.P(cnt), int(cnt.numel()) if cnt is not None else 0, L.stream())
     return ws is not None

@@ -13,6 +13,8 @@ import weakref
 import torch
 import torch.nn as nn
 
+from . import lanes
+
 _LIVE = weakref.WeakSet()          # trainable stores with a bf16 shadow: a foreign optimizer's step must mark them stale
 _HOOKED = [False]
 
@@ -80,6 +82,8 @@ class ParamStore:
             self.v = torch.zeros_like(self.flat)
         else:
             self.grad = self.m = self.v = None
+        self.lane_grads = {}           # lane (>= 1) -> a second flat gradient buffer (host/lanes.py); summed into `grad` by merge_lanes()
+        self.lane_dirty = False
         self.half = compute_dtype in (torch.bfloat16, torch.float16)      # 16-bit compute: the MFMA kernels read a shadow copy in that type
         self.shadow = torch.zeros(self.total, dtype=compute_dtype, device=self.device) if self.half else self.flat
         self.shadow_clean = False
@@ -117,8 +121,38 @@ class ParamStore:
         """compute-dtype view (bf16 shadow in bf16 mode, the fp32 master otherwise)"""
         return self._view(self.shadow, name)
 
+    def _gbuf(self):
+        """the flat gradient buffer of the current lane (host/lanes.py; lane 0 = `grad`)"""
+        k = lanes.cur
+        if k == 0:
+            return self.grad
+        b = self.lane_grads.get(k)
+        if b is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ParamStore: a gradient lane must be allocated before a graph capture (ensure_lanes)")
+            b = self.lane_grads[k] = torch.zeros_like(self.grad)
+        self.lane_dirty = True
+        return b
+
+    def ensure_lanes(self, n):
+        """allocate the gradient buffers of lanes 1 .. n-1"""
+        if self.requires_grad:
+            for k in range(1, n):
+                if k not in self.lane_grads:
+                    self.lane_grads[k] = torch.zeros_like(self.grad)
+
+    def merge_lanes(self):
+        """grad += every lane's buffer (lane order), the lane buffers zeroed for the next pass; the caller has ordered the current stream behind the
+        lanes' streams (lanes.join)"""
+        if self.lane_dirty:
+            for k in sorted(self.lane_grads):
+                b = self.lane_grads[k]
+                self.grad.add_(b)
+                b.zero_()
+            self.lane_dirty = False
+
     def g(self, name):
-        return self._view(self.grad, name)
+        return self._view(self._gbuf(), name)
 
     def w_span(self, first, rows, cols):
         """[rows, cols] compute-dtype view starting at `first` spanning consecutive tensors (fused QKV)."""
@@ -201,7 +235,7 @@ class ParamStore:
 
     def g_span(self, first, n):
         off = self.offsets[first][0]
-        return self.grad[off:off + n]
+        return self._gbuf()[off:off + n]
 
     def first_offset(self, prefixes, decay):
         """offset of the first tensor (in storage order, within the weight-decay or the no-decay group) whose name starts with one
@@ -275,3 +309,7 @@ class ParamStore:
 
     def zero_grad(self):
         self.grad.zero_()
+        if self.lane_dirty:               # (a backward pass that raised before its lanes were merged)
+            for b in self.lane_grads.values():
+                b.zero_()
+            self.lane_dirty = False

@@ -29,6 +29,7 @@ tests/test_step_graphs_gpu.py compares losses, trajectories and every parameter 
 import numpy as np
 import torch
 
+from . import lanes
 from . import lib as L
 from . import ops as O
 from .model_nav import _queue_sync, nav_backward_body, nav_forward_body, pano_backward_body, pano_forward_body
@@ -132,6 +133,7 @@ class _Releaser:
 class _Inst:
     def __init__(self, owner, kind, key):
         self.owner, self.kind, self.key = owner, kind, key
+        self.lane = lanes.cur      # the gradient lane (host/lanes.py) whose buffers this instance's backward graphs write
         self.busy = False
         self.block = None
         self.g_fwd = None
@@ -163,7 +165,8 @@ class _PanoInstFn(torch.autograd.Function):
         model = inst.owner.model
         model.net.S.ensure_grads()
         _queue_sync(model)
-        inst.owner._run_bwd(inst, ("d_emb", "d_fused", "d_attn"), (d_emb, d_fused, d_attn))
+        with lanes.use(inst.lane):
+            inst.owner._run_bwd(inst, ("d_emb", "d_fused", "d_attn"), (d_emb, d_fused, d_attn))
         return None, None
 
 
@@ -186,7 +189,8 @@ class _NavInstFn(torch.autograd.Function):
         _queue_sync(model)
         if d_cls is None:                     # (the last step's [cls] feeds nothing: one signature for every step)
             d_cls = inst.owner._zeros_cls(inst)
-        bo = inst.owner._run_bwd(inst, ("d_g", "d_v", "d_ga", "d_va", "d_cls", "dgl", "dll", "dfl"), (d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl))
+        with lanes.use(inst.lane):
+            bo = inst.owner._run_bwd(inst, ("d_g", "d_v", "d_ga", "d_va", "d_cls", "dgl", "dll", "dfl"), (d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl))
         return None, None, bo["d_gathered"], None
 
 
@@ -205,7 +209,8 @@ class StepGraphs:
         self.stream = torch.cuda.Stream(device=self.dev)
         self.side = torch.cuda.Stream(device=self.dev) if FORK else None      # second branch of a step graph (global || local cross-modal encoder)
         self.base_seed = int(base_seed)
-        self.rng_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.rng_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)      # lane 0's; other lanes: _rng()
+        self._rngs = {0: self.rng_counter}
         self._zc = {}
 
     # ---- bookkeeping -------------------------------------------------------------------------------------------
@@ -226,7 +231,7 @@ class StepGraphs:
 
     def _acquire(self, kind, key, build):
         """a free instance of `key`, a newly captured one, or None (first sight of the key / pool exhausted: the caller runs eagerly)"""
-        key = (kind,) + key + self._mode_key()
+        key = (kind,) + key + (lanes.cur,) + self._mode_key()
         lst = self.pools.setdefault(key, [])
         for inst in lst:
             if not inst.busy:
@@ -237,12 +242,22 @@ class StepGraphs:
             return None
         if self.n_inst >= self.max_instances:
             return None
+        self._lane_ready()
         inst = _Inst(self, kind, key)
         build(inst)
         lst.append(inst)
         self.n_inst += 1
         inst.busy = True
         return inst
+
+    def _lane_ready(self):
+        """what a lane's graphs bake in must exist before the first capture for it: its dropout counter, its gradient buffer, the workspace and
+        counters of its weight-gradient launches"""
+        k = lanes.cur
+        if k not in self._rngs:
+            self._rngs[k] = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self.model.store.ensure_lanes(k + 1)
+            O.dw_counters(self.dev)
 
     def _capture(self, inst, body):
         import gc
@@ -264,7 +279,7 @@ class StepGraphs:
     def _arm(self, inst):
         """inside a forward capture: redraw this instance's seed pair on the device, arm the model's dropout with it"""
         m = self.model
-        O.step_rng(self.base_seed, self.rng_counter, 1.0, seed_out=inst.seed)
+        O.step_rng((self.base_seed + 0x9E3779B1 * inst.lane) & 0x7FFFFFFF, self._rngs[inst.lane], 1.0, seed_out=inst.seed)
         m.dropout_seed = inst.seed
         try:
             m._arm_dropout()
@@ -409,4 +424,4 @@ class StepGraphs:
 
     def report(self):
         return {"instances": self.n_inst, "captures": self.captures,
-                "by_key": {"/".join(str(x) for x in k[:5]): len(v) for k, v in self.pools.items() if v}}
+                "by_key": {"/".join(str(x) for x in k[:6]): len(v) for k, v in self.pools.items() if v}}

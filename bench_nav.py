@@ -70,9 +70,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=4)                  # (iteration 1 sees the shapes, 2 captures the step instances, 3-4 top the pools up)
-    ap.add_argument("--plan-ahead", action="store_true",
-                    help="plan the teacher-forced rollout one iteration ahead on a helper thread (NavRollout.plan_ahead) instead of step by step inside "
-                         "the iteration.  Measured round 5: 210 vs 200 ms per iteration -- the helper's Python fights the backward's callbacks for the GIL")
+    ap.add_argument("--plan-ahead", choices=("off", "inline", "thread"), default="off",
+                    help="build the NEXT batch's teacher-forced step plans (model-independent: the actions are the expert's) ahead of time "
+                         "(NavRollout.plan_ahead): inline = on the main thread right after this iteration's backward and optimizer launches, while "
+                         "the GPU drains them; thread = on a helper thread (measured round 5: 210 vs 200 ms per iteration -- the helper's Python "
+                         "fights the backward's callbacks for the GIL); off = step by step inside the iteration (default: with the rollouts on "
+                         "gradient lanes the forward phase is bound by the sampled rollout's step-by-step dependency, not by the host's planning -- inline "
+                         "measured 161.1 vs 161.8 ms per iteration on config 5 and slower on the host-bound ICoD iteration)")
     ap.add_argument("--no-graphs", action="store_true",
                     help="launch every kernel of the training steps eagerly instead of replaying captured step instances (host/step_graphs.py)")
     ap.add_argument("--batch", type=int, default=16)                  # run_rxr_kdl_valid.sh:39
@@ -165,6 +169,7 @@ def main():
         obs = pipe["obs"] if ahead is not None else env.reset(features=False)
         batch = env.batch
         rw = None
+        planned = (not a.fuse_rollouts or a.icod) and not a.sequential_rollouts
         if a.icod:      # MKRW: softmax(randn(5) / rw_temp) * 5 per step (agent.py:866-871)
             rw = torch.softmax(torch.randn(a.max_action_len, 5, device=dev) / 4.0, -1) * 5
         if (not a.fuse_rollouts or a.icod) and a.sequential_rollouts:
@@ -178,7 +183,7 @@ def main():
                 ((env2, env2.reset(batch=batch, features=False)), dict(feedback="sample", train_ml=1.0, rw_seq=rw,
                                                                        sample_draws=rng.uniform(size=(a.max_action_len, a.batch)))),
                 ((env, obs), dict(feedback="teacher", train_ml=0.2, rw_seq=rw, ahead=ahead))])
-            if a.plan_ahead:
+            if a.plan_ahead == "thread":
                 # the NEXT batch's teacher-forced rollout needs nothing from the model: its step plans are built on a helper thread while the GPU
                 # runs this iteration's backward (host/nav_rollout.PlanAhead; the reference's PrefetchLoader prepares its next batch the same way)
                 pipe["obs"] = env.reset(features=False)
@@ -198,6 +203,11 @@ def main():
             t_opt.step()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 40.0)     # agent_base.py:273
         opt.step()
+        if a.plan_ahead == "inline" and planned:
+            # everything above is launched, nothing has been waited for: the host builds the next batch's teacher-forced plans now, under the
+            # GPU's backward + optimizer (the next iteration's first host wait -- the language call's length check -- comes after)
+            pipe["obs"] = env.reset(features=False)
+            pipe["ahead"] = ro.plan_ahead(env, pipe["obs"], thread=False)
         return r1["decisions"] + r2["decisions"]
 
     for _ in range(a.warmup):
@@ -266,7 +276,8 @@ def main():
             "metric": "trajectory-steps/sec (whole node), navigator step loop, MAGIC-L fine-tune", "value": round(dec / dt, 2),
             "unit": "trajectory-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"rollouts": ("one batch of 2B episodes" if (a.fuse_rollouts and not a.icod) else "sequential" if a.sequential_rollouts else "interleaved step by step"),
+            "config": {"plan_ahead": (a.plan_ahead if a.mode != "eval" else None),
+                       "rollouts": ("one batch of 2B episodes" if (a.fuse_rollouts and not a.icod) else "sequential" if a.sequential_rollouts else "interleaved step by step"),
                        "workload": f"navigator loop (agent_base.py:215-296 iteration = teacher-forced + DAgger 'sample' rollout, backward, clip 40, "
                                    f"torch AdamW), VLNBert H={a.hidden} 6+2+3 layers, dropout 0.1, expert ndtw, instructions U{{{a.instr_min}..{a.instr_max}}} tokens, "
                                    f"paths {a.hops_min}..{a.hops_max} hops, max_action_len {a.max_action_len}",

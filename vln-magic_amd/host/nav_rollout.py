@@ -121,12 +121,18 @@ class PlanAhead:
     built while the GPU runs the current iteration's backward (the main thread is parked inside `loss.backward()` then, the GIL free), the way the
     reference's PrefetchLoader prepares the next batch (pretrain_src/data/loader.py:78-120).  `steps(..., ahead=...)` consumes the plans."""
 
-    def __init__(self, make_planner):
+    def __init__(self, make_planner, thread=True):
+        """thread=False: the plans are built right here, on the calling thread -- placed after the iteration's backward and optimizer launches
+        (nothing in between waits for the GPU), the host plans the next batch while the GPU drains them; no second Python thread, no GIL fight"""
         import threading
         self.planner = self.plans = self.err = None
         self._make = make_planner
-        self._th = threading.Thread(target=self._run, name="magic-plan-ahead", daemon=True)
-        self._th.start()
+        self._th = None
+        if thread:
+            self._th = threading.Thread(target=self._run, name="magic-plan-ahead", daemon=True)
+            self._th.start()
+        else:
+            self._run()
 
     def _run(self):
         try:
@@ -146,7 +152,8 @@ class PlanAhead:
             self.err = e
 
     def result(self):
-        self._th.join()
+        if self._th is not None:
+            self._th.join()
         if self.err is not None:
             raise self.err
         return self.planner, self.plans
@@ -187,11 +194,12 @@ class NavRollout:
         return NavPlanner(env, obs, feedback=feedback, max_action_len=self.T, expert_policy=self.expert, train=grad,
                           pad_V=V_STATIC if use_g else 0, k_bucket=K_BUCKET if use_g else 1)
 
-    def plan_ahead(self, env, obs, grad=True, text_copies=1):
-        """start planning a teacher-forced rollout over (env, obs) on a helper thread; pass the handle as `ahead=` to `steps` / `run` with the
-        SAME env and obs (the helper steps `env` through the episodes: do not touch it until the rollout has consumed the plans)"""
+    def plan_ahead(self, env, obs, grad=True, text_copies=1, thread=True):
+        """plan a teacher-forced rollout over (env, obs) ahead of time -- on a helper thread, or (thread=False) here and now; pass the handle
+        as `ahead=` to `steps` / `run` with the SAME env and obs (the planner steps `env` through the episodes: do not touch it until the
+        rollout has consumed the plans)"""
         use_g = self._use_graphs(obs, grad, text_copies)
-        return PlanAhead(lambda: self._planner(env, obs, "teacher", grad, use_g))
+        return PlanAhead(lambda: self._planner(env, obs, "teacher", grad, use_g), thread=thread)
 
     def graph_report(self):
         return {("teacher" if m is self.teacher else "student"): self._sg[id(m)].report() for m in (self.student, self.teacher)

@@ -676,11 +676,14 @@ def main():
                 return traj
         run = run_stream
     traj, dt = timed_region(run, a.steps, a.warmup, world, dev)
-    steady = None
+    steady = gate_now = None
     if a.mode == "graph":       # the driver's K is small (20 steps = 31 ms): the same replay loop over 150 more steps, reported next to it
         n_steady = 150
         traj_s, dt_s = timed_region(run, n_steady, 0, world, dev)
         steady = {"steps": n_steady, "ms_per_step": round(dt_s / n_steady * 1e3, 3), "trajectory_steps_per_sec": round(traj_s / dt_s, 1)}
+        # gate counters and health belong to the headline + steady runs: read them BEFORE the per-task loops below, which replay subsets of the
+        # ring (a student graph then consumes teacher outputs of an unrelated replay, the gate sees another interleaving and may switch itself off)
+        gate_now = trainer.gate_report() if a.teacher == "split" else None
         # the same replay loop over the resident batches of ONE task at a time (60 steps each): what the student's step of each proxy task
         # costs (graph i = student step on batch i || teacher forward on batch i + 1, whose task is the next one of the cycle)
         by_task = {}
@@ -693,7 +696,7 @@ def main():
                 by_task[task] = round(dt_t / 60 * 1e3, 3)
         steady["ms_per_step_by_task"] = by_task
     health = trainer.check_health()          # raises if an in-launch hand-off of the row-split encoder kernels ever gave up
-    gate = trainer.gate_report() if (a.mode == "graph" and a.teacher == "split") else None
+    gate = gate_now
     if gate is not None:
         gate["timeout_us"], gate["recent_us"] = O.TEACHER_GATE_US, O.TEACHER_GATE_RECENT_US
         gate["what"] = ("device-side start gate in front of every teacher graph (csrc/encoder.hip): `opened` = it saw the student's whole-encoder launch "
@@ -785,7 +788,7 @@ def main():
         modes = {nm[dtype]: {"ms_per_step": round(dt / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj / dt, 1)},
                  nm[other]: {"ms_per_step": round(dt2 / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj2 / dt2, 1)},
                  "note": "same batches and schedule, one HIP graph per batch each; fp16 = the bf16 kernels on IEEE half storage (v_mfma_f32_16x16x32_f16, gradient "
-                         "seeds x 4096); fp32 = fp32 storage + exact v_mfma_f32_16x16x4_f32; bf16x3 = fp32 storage, every GEMM contraction as three bf16 MFMAs "
+                         "seeds x the dynamic loss scale, 4096 at start); fp32 = fp32 storage + exact v_mfma_f32_16x16x4_f32; bf16x3 = fp32 storage, every GEMM contraction as three bf16 MFMAs "
                          "on the hi + lo halves of the fp32 operands (lib.set_f32_mfma)"}
         del g2, tr2
         # the 16-bit twin of the headline mode (bf16 <-> fp16: same kernels, same launches, different storage type)
@@ -796,7 +799,15 @@ def main():
         g4 = capture_ring(tr4, pool, a.teacher)
         torch.cuda.synchronize()
         traj4, dt4 = timed_region(graph_runner(tr4, g4), a.steps, a.warmup, world, dev)
-        modes[nm[twin]] = {"ms_per_step": round(dt4 / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj4 / dt4, 1)}
+        traj4s, dt4s = timed_region(graph_runner(tr4, g4), 150, 0, world, dev)          # (the steady form of the headline's `steady` block)
+        modes[nm[twin]] = {"ms_per_step": round(dt4 / a.steps * 1e3, 3), "trajectory_steps_per_sec": round(traj4 / dt4, 1),
+                           "ms_per_step_steady": round(dt4s / 150 * 1e3, 3), "steady_steps": 150}
+        if torch.float16 in (twin, dtype):
+            h = tr4 if twin == torch.float16 else trainer
+            ls = h.opt.loss_scale.tolist() if getattr(h.opt, "loss_scale", None) is not None else None
+            modes["fp16_loss_scale"] = ({"dynamic": True, "scale": ls[0], "clean_steps_in_a_row": int(ls[2]), "skipped_optimizer_steps": h.opt.skipped_steps(),
+                                         "rule": "amp.GradScaler on the device: x0.5 after a skipped step, x2 after 2000 updates in a row (csrc/loss.hip step_rng_kernel)"}
+                                        if ls is not None else {"dynamic": False})
         del g4, t4, s4, tr4
         # third mode: fp32 storage with the split-bf16 contraction (graphs re-captured: the mode is read by the kernels at run time, but a
         # fresh capture keeps the measurement independent of the previous one)
@@ -875,6 +886,8 @@ def main():
             clean = [k for k in ("bf16", "fp16", "bf16x3", "fp32") if k in modes and meets(parity[k])]
             clean.sort(key=lambda k: modes[k]["ms_per_step"])
             info["parity_clean_mode"] = ({"dtype": clean[0], "ms_per_step": modes[clean[0]]["ms_per_step"],
+                                          "ms_per_step_steady": modes[clean[0]].get("ms_per_step_steady", steady["ms_per_step"] if (steady is not None and clean[0] == a.dtype) else None),
+                                          "loss_scale": modes.get("fp16_loss_scale") if clean[0] == "fp16" else None,
                                           "trajectory_steps_per_sec": modes[clean[0]]["trajectory_steps_per_sec"],
                                           "max_abs_logit_delta": parity[clean[0]]["max_abs_logit_delta"],
                                           "argmax_agreement": parity[clean[0]]["argmax_agreement"],

@@ -318,7 +318,16 @@ int magic_sap_fuse_bwd(int B, int K, int Vp, const float* g_raw, const float* l_
 /* Step prologue: the per-step random scalars of a training step in one launch -- MKRW ability weights rw[5] = softmax(randn(5) / rw_temp) * 5
  * (map_nav_src/r2r/agent.py:866-871) and the two 31-bit words that key the counter-based dropout masks; `counter` (one device word) is
  * advanced here, so a replayed HIP graph draws fresh values each step.  seed_out / rw_out: either may be NULL. */
-int magic_step_rng(unsigned long long base_seed, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, float* zero_me, void* stream);
+int magic_step_rng(unsigned long long base_seed, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, float* zero_me,
+                   float* scale_state, float growth, float backoff, int interval, void* stream);
+/* scale_state (may be NULL) = {S, 1 / S, clean steps in a row, pending}: the DYNAMIC LOSS SCALE of fp16 storage, amp.GradScaler's rule
+ * (train_r2r_magic.py:370-371) kept on the device so it works under HIP-graph replay with no host round trip: the prologue launch of a step
+ * reads what the previous step's magic_adamw left in `pending` (1: weights updated, 2: update skipped, the gradient norm was not finite) --
+ * 2: S *= backoff; 1: after `interval` updates in a row S *= growth -- and rewrites S and 1 / S before any loss kernel of the new step runs.
+ * magic_seed_scale(scale_dev): registers (process-wide; NULL clears) the device word every gradient-SEEDING loss launch recorded from now
+ * on multiplies its gradient coefficient by -- magic_ce_rows, magic_softkl_rows, magic_kd_rows, magic_mse, magic_mse_multi, magic_cfp_loss,
+ * magic_sap_fuse_loss; loss VALUES are never scaled.  Pass &scale_state[0]. */
+int magic_seed_scale(const float* scale_dev);
 /* Loss assembly in one launch: sup = row_scale * sum rows[i] (* row_w[i]); slots[9] = sum kd_rows (optional); terms[i] = slots[i] * rw[ability(i)]
  * over the ten MAKD slots (agent.py:546-719: txt, txt, img, img, img, global, global, local, local, action); kdl = sum terms;
  * loss = alpha * kdl + (1 - alpha) * sup (agent.py:1110-1123; has_kd = 0: loss = sup).  out[13] = {sup, terms[10], kdl, loss}. */
@@ -330,7 +339,10 @@ int magic_sumsq(long long n, const float* g, float* out, void* stream);
 int magic_adamw(long long n, float* p, float* g, float* m, float* v, void* shadow, int shadow_dtype,
                 float lr, float b1, float b2, float eps, float wd, float step_size,
                 const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_grad,
-                unsigned* overflow, void* stream);
+                unsigned* overflow, float* scale_state, int* sched_step, void* stream);
+/* scale_state (may be NULL; needs sumsq): the dynamic loss scale's state (magic_step_rng): the gradient pre-scale is multiplied by its 1 / S and
+ * `pending` is set to 1 (updated) / 2 (skipped).  sched_step (may be NULL): the device-side schedule's step word (magic_sumsq_sched /
+ * magic_sched_step); a SKIPPED update takes back this step's advance, as a skipped optimizer.step() under GradScaler leaves the state step. */
 /* overflow (may be NULL): a device counter.  When the gradient norm in `sumsq` is not finite (fp16 storage under a static gradient scale)
  * the update is SKIPPED -- p, m, v untouched, g zeroed when zero_grad -- and the counter incremented: amp.GradScaler.step's behaviour
  * (train_r2r_magic.py:370-371) instead of NaN weights. */

@@ -138,6 +138,9 @@ __device__ __forceinline__ float drop_mul(const DropState& s, unsigned idx) {   
 }
 static inline bool drop_args_ok(const void* seed, float p) { return p >= 0.f && p < 1.f && (p == 0.f || seed != nullptr); }
 
+// the device word every gradient-seeding loss kernel multiplies its gradient coefficient by (loss.hip magic_seed_scale; NULL: none)
+const float* seed_scale_get();
+
 static inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MAGIC_OK : MAGIC_ERR_LAUNCH;

@@ -322,8 +322,9 @@ __device__ __forceinline__ float sap_ce_wave(const float* x, int N, int lab, int
   }
   return ignored ? 0.f : lse - xl;
 }
-__global__ __launch_bounds__(64) void sap_fuse_loss_kernel(SapLossParams p) {
+__global__ __launch_bounds__(64) void sap_fuse_loss_kernel(SapLossParams p, const float* ss) {
   __shared__ float sl[128];
+  if (ss) { p.coef *= ss[0]; p.kd_coef *= ss[0]; }       // dynamic loss scale (loss.hip magic_seed_scale): gradient seeds only
   __shared__ float sbw;
   const int b = blockIdx.x, lane = threadIdx.x, B = p.B, K = p.K, Vp = p.Vp;
   const float NEG = -__builtin_inff();
@@ -520,7 +521,7 @@ extern "C" int magic_sap_fuse_loss(const void* params, int nbytes, void* stream)
       !p.gl || !p.ll || !p.fl || !p.glab || !p.llab || !p.rows) return MAGIC_ERR_ARG;
   if ((p.w_out || p.kd_rows) && !p.t_fused) return MAGIC_ERR_ARG;
   if (p.kd_rows && !(p.T > 0.f)) return MAGIC_ERR_ARG;
-  hipLaunchKernelGGL(sap_fuse_loss_kernel, dim3(p.B), dim3(64), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(sap_fuse_loss_kernel, dim3(p.B), dim3(64), 0, (hipStream_t)stream, p, seed_scale_get());
   return launch_status();
 }
 

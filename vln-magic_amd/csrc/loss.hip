@@ -7,12 +7,21 @@
 #include "common.hpp"
 #include <cstdint>
 
+// Dynamic loss scale (fp16 storage; train_r2r_magic.py:370-371 runs its fp16 option under amp.GradScaler): every kernel of this file -- and
+// the fused SAP loss of graphops.hip -- that SEEDS a gradient multiplies its gradient coefficient (never the loss value) by the device word
+// the host registered with magic_seed_scale(), so the scale can change from step to step under HIP-graph replay with no host round trip.
+// NULL (the default): no scaling.  The word is read at launch RECORD time as a pointer only; its value is read by the kernels.
+static const float* g_seed_scale = nullptr;          // process-wide: helper threads of a lockstep segment launch loss kernels too
+const float* seed_scale_get() { return g_seed_scale; }
+extern "C" int magic_seed_scale(const float* scale_dev) { g_seed_scale = scale_dev; return MAGIC_OK; }
+
 // one block (256 threads) per row; N may be large (MLM vocab 50265).  logits dtype T (f32/bf16), ld given.
 template <typename T>
 __global__ __launch_bounds__(256) void ce_rows_kernel(int M, int N, const T* logits, int ld, const int* labels, int ignore_index,
                                                       float coef, const float* row_w, float* loss_row, T* dlogits, int ldd,
-                                                      int accumulate, float* w_out, float w_rate) {
+                                                      int accumulate, float* w_out, float w_rate, const float* ss) {
   __shared__ float red[8];
+  if (ss) coef *= ss[0];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const T* x = logits + (long long)row * ld;
   const int lab = labels[row];
@@ -61,7 +70,8 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int M, int N, const T* log
 template <typename Hh, int NT>
 __global__ __launch_bounds__(NT) void ce_rows_wide_kernel(int M, int N, const Hh* logits, int ld, const int* labels, int ignore_index,
                                                           float coef, const float* row_w, float* loss_row, Hh* dlogits, int ldd,
-                                                          float* w_out, float w_rate) {
+                                                          float* w_out, float w_rate, const float* ss) {
+  if (ss) coef *= ss[0];
   constexpr int NWV = NT / 64;
   __shared__ float red[2 * NWV];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -136,8 +146,9 @@ __global__ __launch_bounds__(NT) void ce_rows_wide_kernel(int M, int N, const Hh
 // targets fp32 [M, N] (row pitch ldt); one block per row.
 template <typename T>
 __global__ __launch_bounds__(256) void softkl_rows_kernel(int M, int N, const T* logits, int ld, const float* targets, int ldt,
-                                                          float coef, const float* row_w, float* loss_row, T* dlogits, int ldd) {
+                                                          float coef, const float* row_w, float* loss_row, T* dlogits, int ldd, const float* ss) {
   __shared__ float red[12];
+  if (ss) coef *= ss[0];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const T* x = logits + (long long)row * ld;
   const float* t = targets + (long long)row * ldt;
@@ -170,8 +181,9 @@ __global__ __launch_bounds__(256) void softkl_rows_kernel(int M, int N, const T*
 // KD rows: fp32 logits [M,N], N <= 512 (action space).  one wave per row.
 // loss_row = w * sum_j p_t (log p_t - log p_s) * T^2 * norm ;  ds (+)= coef * w * T * (p_s - p_t) * norm
 __global__ __launch_bounds__(256) void kd_rows_kernel(int M, int N, const float* s, const float* t, int ld, float temperature,
-                                                      const float* w, float norm, float coef, const float* coef_dev, float* loss_row, float* ds, int accumulate) {
+                                                      const float* w, float norm, float coef, const float* coef_dev, float* loss_row, float* ds, int accumulate, const float* ss) {
   if (coef_dev) coef *= coef_dev[0];
+  if (ss) coef *= ss[0];
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float NEG = -__builtin_inff();
@@ -225,9 +237,10 @@ __global__ __launch_bounds__(256) void kd_rows_kernel(int M, int N, const float*
 template <typename T, typename G>
 __global__ __launch_bounds__(256) void mse_kernel(long long outer, long long inner, const T* s, long long s_stride, const T* t, long long t_stride,
                                                   const float* w, long long rows_per_w, float norm, float coef, const float* coef_dev, float* loss, G* ds, long long g_stride,
-                                                  int accumulate) {
+                                                  int accumulate, const float* ss) {
   __shared__ float red[4];
   if (coef_dev) coef *= coef_dev[0];
+  if (ss) coef *= ss[0];
   const long long total = outer * inner;
   float acc = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -258,13 +271,14 @@ struct magic_mse_desc {
   // this batch's (outer, inner) -- elements beyond them add nothing to the loss and get a zero gradient -- and norm is multiplied by norm_dev[0]
   const int* valid_dev; const float* norm_dev; long long valid_mod;      // valid_mod > 0: element r of a block is valid iff r % valid_mod < valid_dev[1]
 };
-struct MseMulti { magic_mse_desc d[MSE_MAX]; int start[MSE_MAX + 1]; int vec[MSE_MAX]; int n; };
+struct MseMulti { magic_mse_desc d[MSE_MAX]; int start[MSE_MAX + 1]; int vec[MSE_MAX]; int n; const float* ss; };
 
 #define MSE_NT 1024          // threads per block of the multi-problem launch
 template <typename T, typename G>
-__device__ __forceinline__ void mse_body(const magic_mse_desc& p, int bid, int nblk, float* red) {
+__device__ __forceinline__ void mse_body(const magic_mse_desc& p, int bid, int nblk, float* red, const float* ss) {
   float coef = p.coef;
   if (p.coef_dev) coef *= p.coef_dev[0];
+  if (ss) coef *= ss[0];
   const T* s = (const T*)p.s; const T* t = (const T*)p.t; G* ds = (G*)p.ds;
   const long long total = p.outer * p.inner;
   const long long vo = p.valid_dev ? p.valid_dev[0] : p.outer, vi = p.valid_dev ? p.valid_dev[1] : p.inner;
@@ -296,9 +310,10 @@ __device__ __forceinline__ void mse_body(const magic_mse_desc& p, int bid, int n
 // bf16 problems whose rows are multiples of 8 elements at 16-byte-aligned addresses: 8 elements per lane and iteration, 32-bit index
 // arithmetic, two iterations' loads in flight.
 template <typename Hh, typename G>
-__device__ __forceinline__ void mse_body_v8(const magic_mse_desc& p, int bid, int nblk, float* red) {
+__device__ __forceinline__ void mse_body_v8(const magic_mse_desc& p, int bid, int nblk, float* red, const float* ss) {
   float coef = p.coef;
   if (p.coef_dev) coef *= p.coef_dev[0];
+  if (ss) coef *= ss[0];
   const Hh* s = (const Hh*)p.s; const Hh* t = (const Hh*)p.t; G* ds = (G*)p.ds;
   const unsigned in8 = (unsigned)(p.inner >> 3), tot8 = (unsigned)p.outer * in8, rpw = (unsigned)p.rows_per_w;
   const unsigned stride = (unsigned)nblk * MSE_NT;
@@ -372,10 +387,10 @@ __global__ __launch_bounds__(MSE_NT) void mse_multi_kernel(MseMulti mm) {
   const magic_mse_desc& p = mm.d[i];
   const int bid = blockIdx.x - mm.start[i], nblk = mm.start[i + 1] - mm.start[i];
   // g_f32 bit 0: the gradient is fp32; bit 1: this problem's INPUTS are fp32 as well (the head-mean attention maps) inside a 16-bit launch
-  if constexpr (sizeof(T) == 4) mse_body<float, float>(p, bid, nblk, red);
-  else if (p.g_f32 & 2) mse_body<float, float>(p, bid, nblk, red);
-  else if (mm.vec[i]) { if (p.g_f32 & 1) mse_body_v8<T, float>(p, bid, nblk, red); else mse_body_v8<T, T>(p, bid, nblk, red); }
-  else { if (p.g_f32 & 1) mse_body<T, float>(p, bid, nblk, red); else mse_body<T, T>(p, bid, nblk, red); }
+  if constexpr (sizeof(T) == 4) mse_body<float, float>(p, bid, nblk, red, mm.ss);
+  else if (p.g_f32 & 2) mse_body<float, float>(p, bid, nblk, red, mm.ss);
+  else if (mm.vec[i]) { if (p.g_f32 & 1) mse_body_v8<T, float>(p, bid, nblk, red, mm.ss); else mse_body_v8<T, T>(p, bid, nblk, red, mm.ss); }
+  else { if (p.g_f32 & 1) mse_body<T, float>(p, bid, nblk, red, mm.ss); else mse_body<T, T>(p, bid, nblk, red, mm.ss); }
 }
 
 // Every block ends in ONE atomic on its problem's loss slot, and the slots of a step's terms share a cache line: same-line atomics
@@ -387,6 +402,7 @@ extern "C" int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* 
   if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
   MseMulti mm;
   mm.n = n;
+  mm.ss = g_seed_scale;
   long long work[MSE_MAX], all = 0;
   for (int i = 0; i < n; ++i) {
     if (d[i].outer <= 0 || d[i].inner <= 0 || !d[i].s || !d[i].t || (d[i].w && d[i].rows_per_w <= 0)) return MAGIC_ERR_ARG;
@@ -429,8 +445,9 @@ extern "C" int magic_mse_multi(int dtype, int n, const magic_mse_desc* d, void* 
 #define CFP_B 64
 template <typename T>
 __global__ __launch_bounds__(1024) void cfp_loss_kernel(int B, int H, const T* a0, const T* a1, const T* a2, const T* txt, float inv_temp, float coef,
-                                                        float* rows, T* d0, T* d1, T* d2, T* dtxt, float* part, int* counter) {
+                                                        float* rows, T* d0, T* d1, T* d2, T* dtxt, float* part, int* counter, const float* ss) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cfp_smem[];
+  if (ss) coef *= ss[0];
   constexpr int VE = 16 / (int)sizeof(T);                        // elements per 16-byte vector
   typedef __attribute__((ext_vector_type(VE))) T vec_t;
   const int HS = H + VE;                                         // element pitch: rows stay 16-byte aligned
@@ -558,11 +575,11 @@ extern "C" int magic_cfp_loss(int dtype, int B, int H, const void* a0, const voi
     attr_set = true;
   }
   if (dtype == DT_BF16) hipLaunchKernelGGL(cfp_loss_kernel<bf16>, dim3(3), dim3(1024), shm, st, B, H, (const bf16*)a0, (const bf16*)a1, (const bf16*)a2, (const bf16*)txt,
-                                           1.f / temperature, coef, rows, (bf16*)d0, (bf16*)d1, (bf16*)d2, (bf16*)dtxt, part, counter);
+                                           1.f / temperature, coef, rows, (bf16*)d0, (bf16*)d1, (bf16*)d2, (bf16*)dtxt, part, counter, g_seed_scale);
   else if (dtype == DT_F16) hipLaunchKernelGGL(cfp_loss_kernel<f16>, dim3(3), dim3(1024), shm, st, B, H, (const f16*)a0, (const f16*)a1, (const f16*)a2, (const f16*)txt,
-                                               1.f / temperature, coef, rows, (f16*)d0, (f16*)d1, (f16*)d2, (f16*)dtxt, part, counter);
+                                               1.f / temperature, coef, rows, (f16*)d0, (f16*)d1, (f16*)d2, (f16*)dtxt, part, counter, g_seed_scale);
   else hipLaunchKernelGGL(cfp_loss_kernel<float>, dim3(3), dim3(1024), shm, st, B, H, (const float*)a0, (const float*)a1, (const float*)a2, (const float*)txt,
-                          1.f / temperature, coef, rows, (float*)d0, (float*)d1, (float*)d2, (float*)dtxt, part, counter);
+                          1.f / temperature, coef, rows, (float*)d0, (float*)d1, (float*)d2, (float*)dtxt, part, counter, g_seed_scale);
   return launch_status();
 }
 
@@ -576,19 +593,19 @@ extern "C" int magic_ce_rows(int dtype, int M, int N, const void* logits, int ld
                     (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0;
   const bool big = M <= 512;            // few rows: 1024 threads per row
   if (wide && dtype == DT_BF16 && big)
-    hipLaunchKernelGGL((ce_rows_wide_kernel<bf16, 1024>), grid, dim3(1024), 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, w_out, w_rate);
+    hipLaunchKernelGGL((ce_rows_wide_kernel<bf16, 1024>), grid, dim3(1024), 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, w_out, w_rate, g_seed_scale);
   else if (wide && dtype == DT_BF16)
-    hipLaunchKernelGGL((ce_rows_wide_kernel<bf16, 256>), grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, w_out, w_rate);
+    hipLaunchKernelGGL((ce_rows_wide_kernel<bf16, 256>), grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, w_out, w_rate, g_seed_scale);
   else if (wide && big)
-    hipLaunchKernelGGL((ce_rows_wide_kernel<f16, 1024>), grid, dim3(1024), 0, st, M, N, (const f16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (f16*)dlogits, ldd, w_out, w_rate);
+    hipLaunchKernelGGL((ce_rows_wide_kernel<f16, 1024>), grid, dim3(1024), 0, st, M, N, (const f16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (f16*)dlogits, ldd, w_out, w_rate, g_seed_scale);
   else if (wide)
-    hipLaunchKernelGGL((ce_rows_wide_kernel<f16, 256>), grid, block, 0, st, M, N, (const f16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (f16*)dlogits, ldd, w_out, w_rate);
+    hipLaunchKernelGGL((ce_rows_wide_kernel<f16, 256>), grid, block, 0, st, M, N, (const f16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (f16*)dlogits, ldd, w_out, w_rate, g_seed_scale);
   else if (dtype == DT_BF16)
-    hipLaunchKernelGGL(ce_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, accumulate, w_out, w_rate);
+    hipLaunchKernelGGL(ce_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (bf16*)dlogits, ldd, accumulate, w_out, w_rate, g_seed_scale);
   else if (dtype == DT_F16)
-    hipLaunchKernelGGL(ce_rows_kernel<f16>, grid, block, 0, st, M, N, (const f16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (f16*)dlogits, ldd, accumulate, w_out, w_rate);
+    hipLaunchKernelGGL(ce_rows_kernel<f16>, grid, block, 0, st, M, N, (const f16*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (f16*)dlogits, ldd, accumulate, w_out, w_rate, g_seed_scale);
   else
-    hipLaunchKernelGGL(ce_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (float*)dlogits, ldd, accumulate, w_out, w_rate);
+    hipLaunchKernelGGL(ce_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, labels, ignore_index, coef, row_w, loss_row, (float*)dlogits, ldd, accumulate, w_out, w_rate, g_seed_scale);
   return launch_status();
 }
 
@@ -598,11 +615,11 @@ extern "C" int magic_softkl_rows(int dtype, int M, int N, const void* logits, in
   dim3 grid(M), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL(softkl_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, targets, ldt, coef, row_w, loss_row, (bf16*)dlogits, ldd);
+    hipLaunchKernelGGL(softkl_rows_kernel<bf16>, grid, block, 0, st, M, N, (const bf16*)logits, ld, targets, ldt, coef, row_w, loss_row, (bf16*)dlogits, ldd, g_seed_scale);
   else if (dtype == DT_F16)
-    hipLaunchKernelGGL(softkl_rows_kernel<f16>, grid, block, 0, st, M, N, (const f16*)logits, ld, targets, ldt, coef, row_w, loss_row, (f16*)dlogits, ldd);
+    hipLaunchKernelGGL(softkl_rows_kernel<f16>, grid, block, 0, st, M, N, (const f16*)logits, ld, targets, ldt, coef, row_w, loss_row, (f16*)dlogits, ldd, g_seed_scale);
   else if (dtype == DT_F32)
-    hipLaunchKernelGGL(softkl_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, targets, ldt, coef, row_w, loss_row, (float*)dlogits, ldd);
+    hipLaunchKernelGGL(softkl_rows_kernel<float>, grid, block, 0, st, M, N, (const float*)logits, ld, targets, ldt, coef, row_w, loss_row, (float*)dlogits, ldd, g_seed_scale);
   else return MAGIC_ERR_ARG;
   return launch_status();
 }
@@ -611,7 +628,7 @@ extern "C" int magic_kd_rows(int M, int N, const float* s, const float* t, int l
                              float coef, const float* coef_dev, float* loss_row, float* ds, int accumulate, void* stream) {
   if (M <= 0 || N <= 0 || N > 512 || ld < N || temperature <= 0.f) return MAGIC_ERR_ARG;
   dim3 grid((M + 3) / 4), block(256);
-  hipLaunchKernelGGL(kd_rows_kernel, grid, block, 0, (hipStream_t)stream, M, N, s, t, ld, temperature, w, norm, coef, coef_dev, loss_row, ds, accumulate);
+  hipLaunchKernelGGL(kd_rows_kernel, grid, block, 0, (hipStream_t)stream, M, N, s, t, ld, temperature, w, norm, coef, coef_dev, loss_row, ds, accumulate, g_seed_scale);
   return launch_status();
 }
 
@@ -624,7 +641,7 @@ extern "C" int magic_mse(int dtype, int g_f32, long long outer, long long inner,
   if (blocks > 384) blocks = 384;      // every block ends in ONE atomic on the loss word: keep the fan-in small
   dim3 grid(blocks), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define L(TY, GY) hipLaunchKernelGGL((mse_kernel<TY, GY>), grid, block, 0, st, outer, inner, (const TY*)s, s_stride, (const TY*)t, t_stride, w, rows_per_w, norm, coef, coef_dev, loss, (GY*)ds, g_stride, accumulate)
+#define L(TY, GY) hipLaunchKernelGGL((mse_kernel<TY, GY>), grid, block, 0, st, outer, inner, (const TY*)s, s_stride, (const TY*)t, t_stride, w, rows_per_w, norm, coef, coef_dev, loss, (GY*)ds, g_stride, accumulate, g_seed_scale)
   if (dtype == DT_BF16) { if (g_f32) L(bf16, float); else L(bf16, bf16); }
   else if (dtype == DT_F16) { if (g_f32) L(f16, float); else L(f16, f16); }
   else { L(float, float); }
@@ -640,9 +657,21 @@ extern "C" int magic_mse(int dtype, int g_f32, long long outer, long long inner,
 // Randomness: murmur3-finalised counters keyed by (base_seed, step counter): the counter lives in device memory and is advanced here, so
 // a replayed HIP graph draws fresh values every step; Box-Muller on two uniforms per normal.
 __device__ __forceinline__ unsigned mix32(unsigned x) { x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16; return x; }
-__global__ void step_rng_kernel(unsigned base_lo, unsigned base_hi, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, float* zero_me) {
+// scale_state (NULL: none) = {S, 1 / S, clean optimizer steps since the last change, pending}: the dynamic loss scale of fp16 storage with
+// amp.GradScaler's rule -- `pending` is what the AdamW launch of the step that just ended left (1: it updated the weights, 2: it SKIPPED
+// the update because the gradient norm was not finite, 0: no optimizer step since the last prologue, e.g. a gradient-accumulation
+// micro-step): 2 -> S *= backoff, 1 -> after `interval` clean steps in a row S *= growth.  Runs before any kernel of the new step reads S.
+__global__ void step_rng_kernel(unsigned base_lo, unsigned base_hi, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, float* zero_me,
+                                float* scale_state, float growth, float backoff, int interval) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (zero_me) zero_me[0] = 0.f;               // the gradient-norm accumulator of the step that starts here
+  if (scale_state) {
+    const float pend = scale_state[3];
+    float S = scale_state[0], tr = scale_state[2];
+    if (pend == 2.f) { S = fmaxf(S * backoff, 1.f); tr = 0.f; }
+    else if (pend == 1.f) { tr += 1.f; if (tr >= (float)interval) { S = fminf(S * growth, 16777216.f); tr = 0.f; } }
+    scale_state[0] = S; scale_state[1] = 1.f / S; scale_state[2] = tr; scale_state[3] = 0.f;
+  }
   const unsigned c = counter[0];
   counter[0] = c + 1u;
   auto draw = [&](unsigned k) { return mix32(mix32(base_lo ^ (c * 0x9E3779B1u)) + base_hi + k * 0x85EBCA77u); };
@@ -660,9 +689,12 @@ __global__ void step_rng_kernel(unsigned base_lo, unsigned base_hi, unsigned* co
     for (int i = 0; i < 5; ++i) rw_out[i] = 5.0f * z[i] / s;
   }
 }
-extern "C" int magic_step_rng(unsigned long long base_seed, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, float* zero_me, void* stream) {
+extern "C" int magic_step_rng(unsigned long long base_seed, unsigned* counter, float rw_temp, int* seed_out, float* rw_out, float* zero_me,
+                              float* scale_state, float growth, float backoff, int interval, void* stream) {
   if (!counter || rw_temp <= 0.f || (!seed_out && !rw_out)) return MAGIC_ERR_ARG;
-  hipLaunchKernelGGL(step_rng_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)base_seed, (unsigned)(base_seed >> 32), counter, rw_temp, seed_out, rw_out, zero_me);
+  if (scale_state && (!(growth >= 1.f) || !(backoff > 0.f && backoff <= 1.f) || interval <= 0)) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(step_rng_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned)base_seed, (unsigned)(base_seed >> 32), counter, rw_temp, seed_out, rw_out, zero_me,
+                     scale_state, growth, backoff, interval);
   return launch_status();
 }
 

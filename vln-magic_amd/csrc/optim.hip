@@ -49,10 +49,18 @@ template <typename Hh>
 __global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, float* g, float* m, float* v, Hh* shadow,
                                                     float lr, float b1, float b2, float eps, float wd, float step_size,
                                                     const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_g,
-                                                    unsigned* overflow) {
+                                                    unsigned* overflow, float* scale_state, int* sched_step) {
   if (lr_ss) { lr = lr_ss[0]; step_size = lr_ss[1]; }     // device-side schedule (HIP-graph replay)
+  // dynamic loss scale (fp16 storage; loss.hip step_rng_kernel owns the rule): the gradient buffer holds S x the gradient -- read 1 / S here, leave
+  // `pending` = 1 (updated) or 2 (skipped) for the next step's prologue.  Nothing else reads scale_state between the loss kernels and that prologue.
+  if (scale_state) gscale *= scale_state[1];
+  const bool bad = sumsq && !isfinite(sumsq[0]);
+  if (scale_state && blockIdx.x == 0 && threadIdx.x == 0) scale_state[3] = bad ? 2.f : 1.f;
   float clip = gscale;
-  if (sumsq && !isfinite(sumsq[0])) {
+  if (bad) {
+    // GradScaler.step semantics: a skipped optimizer.step() does not advance the optimizer's state step either -- take back the advance the
+    // schedule launch made for this step (its lr / bias-correction scalars were never used)
+    if (sched_step && blockIdx.x == 0 && threadIdx.x == 0) sched_step[0] -= 1;
     // an overflowed / NaN gradient (fp16 storage under a static gradient scale: an activation gradient past 65504 becomes inf): SKIP the
     // update as amp.GradScaler.step does (train_r2r_magic.py:370-371) -- weights and moments untouched, the gradient consumed (zeroed) so
     // the next step starts clean -- and count it where the host can see it.  Without this, clip = 0 and 0 x inf = NaN poisons p, m, v for good.
@@ -150,15 +158,16 @@ extern "C" int magic_sumsq_sched(long long n, const float* g, float* out, int* s
 extern "C" int magic_adamw(long long n, float* p, float* g, float* m, float* v, void* shadow, int shadow_dtype,
                            float lr, float b1, float b2, float eps, float wd, float step_size,
                            const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_grad,
-                           unsigned* overflow, void* stream) {
+                           unsigned* overflow, float* scale_state, int* sched_step, void* stream) {
   if (n <= 0 || (shadow && !dtype_is16(shadow_dtype))) return MAGIC_ERR_ARG;
+  if (scale_state && !sumsq) return MAGIC_ERR_ARG;        // the skip decision needs the gradient norm
   if (n_decay < 0) n_decay = n;                    // the whole range is one group
   if (shadow && shadow_dtype == DT_F16)
     hipLaunchKernelGGL(adamw_kernel<f16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (f16*)shadow, lr, b1, b2, eps, wd,
-                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad, overflow);
+                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad, overflow, scale_state, sched_step);
   else
     hipLaunchKernelGGL(adamw_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (bf16*)shadow, lr, b1, b2, eps, wd,
-                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad, overflow);
+                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad, overflow, scale_state, sched_step);
   return launch_status();
 }
 

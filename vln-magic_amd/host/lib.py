@@ -55,7 +55,8 @@ SIGNATURES = {
     "magic_kd_rows": [i32, i32, vp, vp, i32, f32, vp, f32, f32, vp, vp, vp, i32, vp],
     "magic_mse": [i32, i32, i64, i64, vp, i64, vp, i64, vp, i64, f32, f32, vp, vp, vp, i64, i32, vp],
     "magic_mse_multi": [i32, i32, vp, vp],
-    "magic_step_rng": [u64, vp, f32, vp, vp, vp, vp],
+    "magic_step_rng": [u64, vp, f32, vp, vp, vp, vp, f32, f32, i32, vp],
+    "magic_seed_scale": [vp],
     "magic_loss_assemble": [vp, i32, vp, f32, vp, i32, vp, vp, f32, i32, vp, vp],
     "magic_cfp_loss": [i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_node_in_fwd": [i32, i32, i32, vp, vp],
@@ -71,7 +72,7 @@ SIGNATURES = {
     "magic_sap_fuse_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
     "magic_sap_fuse_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "magic_sumsq": [i64, vp, vp, vp],
-    "magic_adamw": [i64, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i64, i32, vp, vp],
+    "magic_adamw": [i64, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, vp, f32, f32, vp, i64, i32, vp, vp, vp, vp],
     "magic_sumsq_sched": [i64, vp, vp, vp, f32, i32, i32, f32, f32, vp, vp],
     "magic_sched_step": [vp, f32, i32, i32, f32, f32, vp, vp, vp],
     "magic_add_n": [i32, i64, i32, vp, vp, vp],

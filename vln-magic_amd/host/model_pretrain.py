@@ -71,7 +71,9 @@ class _BackwardHook(torch.autograd.Function):
     def backward(ctx, grad_out):
         ctx.model.backward()
         m = ctx.model
-        if m.grad_scale != 1.0:        # hand autograd's contract back: .grad = grad_out x dLoss/dparam (grad_out: e.g. a GradScaler's factor)
+        if m.loss_scale is not None:   # (dynamic scale: the device word the seeds were multiplied by)
+            m.store.grad.mul_(grad_out.to(torch.float32) * m.loss_scale[1])
+        elif m.grad_scale != 1.0:      # hand autograd's contract back: .grad = grad_out x dLoss/dparam (grad_out: e.g. a GradScaler's factor)
             m.store.grad.mul_(grad_out.to(torch.float32) / m.grad_scale)
         from .trainer import auto_sync
         auto_sync(ctx.model)           # data parallel under an unmodified loop: average the flat gradient buffer here
@@ -107,7 +109,18 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         # (PretrainStep folds 1 / grad_scale into the AdamW kernel's gradient pre-scale; under `loss.backward()` the hook below does).
         # A power of two: exact in every format.  Loss VALUES are never scaled.
         self.grad_scale = 4096.0 if compute_dtype == torch.float16 else 1.0
+        # ... or DYNAMIC (enable_dynamic_loss_scale; trainer.PretrainStep turns it on for fp16): fp32[4] device state {S, 1 / S, clean steps in a
+        # row, pending}; the loss kernels read S from the device (ops.seed_scale), the host coefficients then carry no scale
+        self.loss_scale = None
         self.register_load_state_dict_post_hook(lambda m, k: setattr(m.store, "shadow_clean", False))
+
+    def enable_dynamic_loss_scale(self, init=None):
+        """amp.GradScaler semantics on the device (csrc/loss.hip step_rng_kernel + csrc/optim.hip adamw_kernel): returns the state tensor.
+        init: the first scale (default: the static `grad_scale`; GradScaler's own default is 65536)"""
+        if self.loss_scale is None:
+            S = float(init if init is not None else self.grad_scale)
+            self.loss_scale = torch.tensor([S, 1.0 / S, 0.0, 0.0], dtype=torch.float32, device=self.device_)
+        return self.loss_scale
 
     # ---- HF-style constructor (train_r2r_magic.py:260-277) ------------------------------------------
     @classmethod
@@ -399,7 +412,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         self._ctx = c
         if callable(teacher_outputs):          # teacher forward running on a side stream: join here
             teacher_outputs = teacher_outputs()
-        out = self._losses(c, o, teacher_outputs, rw)
+        scaled = self.loss_scale is not None and self.store.requires_grad
+        if scaled:
+            O.seed_scale(self.loss_scale)          # every gradient-seeding loss launch below multiplies its seed by the device-side scale
+        try:
+            out = self._losses(c, o, teacher_outputs, rw)
+        finally:
+            if scaled:
+                O.seed_scale(None)
         out["outputs"] = o
         if self.store.requires_grad and torch.is_grad_enabled():
             out["loss"] = _BackwardHook.apply(out["loss"], self._anchor, self)
@@ -495,7 +515,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         kd = t is not None and kdl is not None
         alpha = float(kdl["kd_alpha"]) if kd else 0.0
         sc = 1.0 - alpha
-        gs = float(self.grad_scale) if train else 1.0
+        dyn = train and self.loss_scale is not None      # dynamic loss scale: the kernels multiply their seeds by the device word, not the host
+        gs = float(self.grad_scale) if (train and not dyn) else 1.0
         scg = sc * gs                    # coefficient of the supervised gradient seeds (the loss values use sc)
         # every zero-initialised gradient accumulator of the step comes out of ONE zeroed arena per dtype (two fills instead of ~12 tiny ones)
         nm_ = plan["n_mask"] if task == "mlm" else 0

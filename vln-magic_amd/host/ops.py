@@ -1125,10 +1125,18 @@ def sap_fuse_bwd(B, K, Vp, g_raw, l_raw, fuse_raw, gmask, lmask, fsrc, bwmask, u
            1 if use_gate else 0, L.P(dgl), L.P(dll), L.P(dfl), L.P(dg_raw), L.P(dl_raw), L.P(dfuse_raw), L.stream())
 
 
-def step_rng(base_seed, counter, rw_temp, seed_out=None, rw_out=None, zero_me=None):
+def step_rng(base_seed, counter, rw_temp, seed_out=None, rw_out=None, zero_me=None, scale_state=None, growth=2.0, backoff=0.5, interval=2000):
     """per-step random scalars in one launch: dropout seed (int32[2]) and / or MKRW weights (fp32[5]); `counter`: int32[1] device word, advanced;
-    zero_me: one fp32 word set to 0 (the optimizer's gradient-norm accumulator of the step that begins)"""
-    L.call("magic_step_rng", int(base_seed) & 0xFFFFFFFFFFFFFFFF, L.P(counter), float(rw_temp), L.P(seed_out), L.P(rw_out), L.P(zero_me), L.stream())
+    zero_me: one fp32 word set to 0 (the optimizer's gradient-norm accumulator of the step that begins); scale_state: fp32[4] dynamic loss
+    scale {S, 1/S, clean steps, pending} updated by amp.GradScaler's rule from what the previous step's AdamW launch left in `pending`"""
+    L.call("magic_step_rng", int(base_seed) & 0xFFFFFFFFFFFFFFFF, L.P(counter), float(rw_temp), L.P(seed_out), L.P(rw_out), L.P(zero_me),
+           L.P(scale_state), float(growth), float(backoff), int(interval), L.stream())
+
+
+def seed_scale(scale_state):
+    """register (None: clear) the device word the gradient-seeding loss launches recorded from now on multiply their gradient coefficients by
+    (csrc/loss.hip magic_seed_scale): scale_state[0] of the dynamic loss scale"""
+    L.call("magic_seed_scale", L.P(scale_state))
 
 
 def loss_assemble(rows, row_w, row_scale, kd_rows, slots, rw, alpha, has_kd, out):
@@ -1148,11 +1156,15 @@ def sumsq_sched(g, out, step, lr0, warmup, total, b1, b2, lr_ss):
     L.call("magic_sumsq_sched", g.numel(), L.P(g), L.P(out), L.P(step), float(lr0), int(warmup), int(total), float(b1), float(b2), L.P(lr_ss), L.stream())
 
 
-def adamw(n, p, g, m, v, shadow, lr, b1, b2, eps, wd, step_size, sumsq_buf, max_norm, gscale, lr_ss=None, n_decay=-1, zero_grad=False, overflow=None):
+def adamw(n, p, g, m, v, shadow, lr, b1, b2, eps, wd, step_size, sumsq_buf, max_norm, gscale, lr_ss=None, n_decay=-1, zero_grad=False, overflow=None,
+          scale_state=None, sched_step=None):
     """n_decay: the first n_decay elements take the weight decay, the rest none (-1: all); zero_grad: g := 0 after use; overflow: int32[1]
-    device counter of steps skipped because the gradient norm was not finite (fp16: GradScaler's skip, never NaN weights)"""
+    device counter of steps skipped because the gradient norm was not finite (fp16: GradScaler's skip, never NaN weights); scale_state: the
+    dynamic loss scale's fp32[4] (the gradient buffer holds S x the gradient; `pending` is left for the next step's prologue); sched_step: the
+    device-side schedule's step word, taken back by one on a skipped update"""
     L.call("magic_adamw", n, L.P(p), L.P(g), L.P(m), L.P(v), L.P(shadow), L.dt(shadow.dtype) if shadow is not None else 1, float(lr), float(b1), float(b2), float(eps), float(wd),
-           float(step_size), L.P(sumsq_buf), float(max_norm), float(gscale), L.P(lr_ss), int(n_decay), 1 if zero_grad else 0, L.P(overflow), L.stream())
+           float(step_size), L.P(sumsq_buf), float(max_norm), float(gscale), L.P(lr_ss), int(n_decay), 1 if zero_grad else 0, L.P(overflow),
+           L.P(scale_state), L.P(sched_step), L.stream())
 
 
 def sched_step(step, lr0, warmup, total, b1, b2, lr_ss, zero_me=None):

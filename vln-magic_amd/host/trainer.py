@@ -45,6 +45,10 @@ class FusedAdamW:
         # steps the AdamW kernel SKIPPED because the gradient norm was not finite (fp16 storage: an overflowed activation gradient); read
         # with `skipped_steps()` at a point that may synchronise -- the reference's fp16 option skips such steps too (amp.GradScaler)
         self.overflow = torch.zeros(1, dtype=torch.int32, device=store.device)
+        # dynamic loss scale (fp16 storage): the model's fp32[4] state {S, 1/S, clean steps, pending} (model_pretrain.enable_dynamic_loss_scale);
+        # the AdamW launch divides by S and reports updated / skipped in `pending`, the next step's prologue (ops.step_rng) applies GradScaler's
+        # rule.  With it the gradient norm is ALWAYS computed -- clipping or not -- so an overflowed gradient is skipped, never applied.
+        self.loss_scale = None
         self.t = 0
         self.schedule = schedule
         if schedule is not None:
@@ -64,23 +68,26 @@ class FusedAdamW:
         b1, b2 = self.betas
         lr_ss = None
         use_clip = self.max_norm is not None and self.max_norm > 0
-        fused_sched = self.schedule is not None and use_clip and ss_zeroed
+        need_ss = use_clip or self.loss_scale is not None
+        fused_sched = self.schedule is not None and need_ss and ss_zeroed
         if fused_sched:                        # schedule + gradient norm: one launch
             O.sumsq_sched(s.grad, self.ss, self.step_dev, self.lr, self.schedule[0], self.schedule[1], b1, b2, self.lr_ss)
             lr_ss, step_size = self.lr_ss, 0.0
         elif self.schedule is not None:        # (the schedule kernel also zeroes the gradient-norm accumulator of this step)
-            O.sched_step(self.step_dev, self.lr, self.schedule[0], self.schedule[1], b1, b2, self.lr_ss, zero_me=self.ss if use_clip else None)
+            O.sched_step(self.step_dev, self.lr, self.schedule[0], self.schedule[1], b1, b2, self.lr_ss, zero_me=self.ss if need_ss else None)
             lr_ss, step_size = self.lr_ss, 0.0
         else:
+            # (host-side step count: a step the kernel skips still advances `t` here -- the device-side schedule is the one that takes it back)
             step_size = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
-            if use_clip:
+            if need_ss:
                 self.ss.zero_()
-        if use_clip and not fused_sched:
+        if need_ss and not fused_sched:
             O.sumsq(s.grad, self.ss)
         shadow = s.shadow if s.half else None
         # both parameter groups (decay | no decay: contiguous in the flat buffer) in ONE launch
-        O.adamw(s.total, s.flat, s.grad, s.m, s.v, shadow, lr, b1, b2, self.eps, self.wd, step_size, self.ss if use_clip else None,
-                self.max_norm if use_clip else 0.0, gscale, lr_ss=lr_ss, n_decay=s.n_decay, zero_grad=zero_grad, overflow=self.overflow)
+        O.adamw(s.total, s.flat, s.grad, s.m, s.v, shadow, lr, b1, b2, self.eps, self.wd, step_size, self.ss if need_ss else None,
+                self.max_norm if use_clip else 0.0, gscale, lr_ss=lr_ss, n_decay=s.n_decay, zero_grad=zero_grad, overflow=self.overflow,
+                scale_state=self.loss_scale, sched_step=self.step_dev if self.schedule is not None else None)
         s.shadow_clean = True
         if shadow is not None and s.t_spans:           # the AdamW kernel rewrote the bf16 shadow: its transposed copy follows
             s.sync_shadow_t(force=True)
@@ -358,13 +365,18 @@ class CapturedStep:
 class PretrainStep:
     def __init__(self, student, teacher=None, lr=5e-5, betas=(0.9, 0.98), weight_decay=0.01, grad_norm=5.0,
                  warmup_steps=10000, num_train_steps=200000, rw_temp=4.0, seed=0, overlap_teacher=True, overlap_dw=True,
-                 sparse_embedding_rows=None, accum_steps=1):
+                 sparse_embedding_rows=None, accum_steps=1, dynamic_loss_scale=True, loss_scale_init=None, loss_scale_interval=2000):
         """sparse_embedding_rows: an upper bound, THE SAME ON EVERY RANK, on the distinct token ids of one rank's batch (batch size x
         the loader's instruction truncation length, pretrain_src/config/r2r_magic_pretrain.json:7 max_txt_len).  When given, steps
         that touch the word-embedding table only through the instruction lookup exchange rows instead of the dense table."""
         self.student, self.teacher = student, teacher
         self.opt = FusedAdamW(student.store, lr, betas, 1e-6, weight_decay, grad_norm, schedule=(warmup_steps, num_train_steps))
         self.sync = GradSync(student.store, sparse_rows_cap=sparse_embedding_rows)
+        # fp16 storage: amp.GradScaler's dynamic loss scale (train_r2r_magic.py:370-371), kept on the device -- halved after a skipped step, doubled
+        # after `loss_scale_interval` updates in a row; the first scale is the model's static `grad_scale` unless given
+        self.loss_scale_rule = (2.0, 0.5, int(loss_scale_interval))
+        if dynamic_loss_scale and student.store.device.type == "cuda" and getattr(student, "grad_scale", 1.0) != 1.0:
+            self.opt.loss_scale = student.enable_dynamic_loss_scale(loss_scale_init)
         self.rw_temp = rw_temp
         self.dev = student.store.device
         self.on_gpu = self.dev.type == "cuda"
@@ -429,7 +441,9 @@ class PretrainStep:
         device by one launch, so a replayed graph sees fresh values every step.  Returns the weights (a fixed device buffer)."""
         if not self.on_gpu:
             return torch.softmax(torch.randn(5, dtype=torch.float32) / self.rw_temp, dim=-1) * 5
-        O.step_rng(self.seed, self._rng_counter, self.rw_temp, seed_out=self._dseed, rw_out=self._rw, zero_me=self.opt.ss)
+        g, b, n = self.loss_scale_rule
+        O.step_rng(self.seed, self._rng_counter, self.rw_temp, seed_out=self._dseed, rw_out=self._rw, zero_me=self.opt.ss,
+                   scale_state=self.opt.loss_scale, growth=g, backoff=b, interval=n)
         self._ss_zeroed = True
         return self._rw
 
@@ -673,7 +687,8 @@ class PretrainStep:
 
     def _opt_step(self, gscale):
         # fp16: the buffer holds grad_scale x the gradient; accumulation: the sum over accum_steps micro-batches
-        self.opt.step(gscale=gscale / (float(getattr(self.student, "grad_scale", 1.0)) * self.accum_steps),
+        static = 1.0 if self.opt.loss_scale is not None else float(getattr(self.student, "grad_scale", 1.0))      # (dynamic: the kernel reads 1 / S)
+        self.opt.step(gscale=gscale / (static * self.accum_steps),
                       ss_zeroed=self._ss_zeroed, zero_grad=True)
         self._ss_zeroed, self._grad_clean = False, True
 

@@ -730,7 +730,9 @@ def main():
         roof = {"bound": "mfma", "kernel": "gemm_kernel / gemm_xcd_kernel / gemm_grouped_kernel / gemm_dw_batch_kernel <bf16, NT|NN|TN> + chain_fwd_kernel / chain64_fwd_kernel<bf16> (the dominant "
                                            "kernel family: every Linear layer's forward, input and weight gradient; the frozen teacher's run inside the chain kernels since round 3; launches over one round of CUs on 64-row tiles since round 4)",
                 "achieved": round(ach, 3), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5),
-                "traffic": traffic, "traffic_source": (traffic_src + " (offline rocprofv3 --pmc passes of this command; not collected in this run)") if traffic_src else None,
+                "traffic": traffic, "traffic_unit": "bytes per launch of the family (HBM side: rocprofv3 --pmc FETCH_SIZE x 2 [gfx950 reports half the bytes of wide coalesced reads: MI355X_MICROARCH.md 'HBM'] + WRITE_SIZE, counters in KB -> bytes, "
+                                                    "summed over the family's launches of the profiled steps and divided by their count; compare with detail.*algorithmic* bytes per launch)",
+                "traffic_source": (traffic_src + " (offline rocprofv3 --pmc passes of this command; not collected in this run)") if traffic_src else None,
                 "how": "HIP events around every launch on the launch stream, eager pass of the same steps with the captured graphs' launch structure, "
                        "teacher serialised on the main stream, device-side gate so the host runs ahead; family time = SUM of its launch durations",
                 "detail": {"family_gflop_per_step": round(fam_flops / nprof / 1e9, 2), "family_launches_per_step": round(fam_n / nprof, 1),

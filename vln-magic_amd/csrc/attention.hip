@@ -922,7 +922,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
         const int key0 = j * 16 + 4 * g;
         const tv4 p4 = *(const tv4*)(sP + q * PS + key0);
         f32x4 init = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.dP_init && qok && key0 < p.Nk) init = *(const f32x4*)(p.dP_init + (prow0 + q) * p.ldp + key0);     // ldp % 8 == 0: 16-byte aligned; pad columns carry zeros
+        if (p.dP_init && qok && key0 < p.Nk) init = *(const f32x4*)(p.dP_init + (prow0 + q) * p.ldp + key0);     // fp32 rows of pitch ldp (ldp % 4 == 0, check_common) from a 16-byte-aligned base (magic_attn_bwd checks it): 16-byte aligned; pad columns carry zeros
         tv4 pm = p4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1163,7 +1163,7 @@ extern "C" int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const vo
   if (!drop_args_ok(drop_seed, drop_p) || (long long)B * nh * Nq * Nk > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
   if (!magic_attn_supported(dtype, Nq, Nk, 1)) return MAGIC_ERR_UNSUPPORTED;
   if ((dist == nullptr) != (dsprel_w == nullptr) || (dist == nullptr) != (dsprel_b == nullptr)) return MAGIC_ERR_ARG;
-  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)P & 15) || ((uintptr_t)dctx & 15)) return MAGIC_ERR_ARG;
+  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)P & 15) || ((uintptr_t)dctx & 15) || ((uintptr_t)dP_init & 15)) return MAGIC_ERR_ARG;
   AttnParams p = {};
   p.q = q; p.k = k; p.v = v; p.P = (void*)P; p.dist = dist; p.B = B; p.nh = nh; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldkv = ldkv;
   p.ldp = ldp; p.H = H; p.scale = scale; p.dctx = dctx; p.dP_init = dP_init; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddkv = lddkv;

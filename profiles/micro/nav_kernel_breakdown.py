@@ -23,6 +23,7 @@ ap.add_argument("--top", type=int, default=70)
 ap.add_argument("--hidden", type=int, default=768)
 ap.add_argument("--iters", type=int, default=4)
 ap.add_argument("--graphs", action="store_true")
+ap.add_argument("--ahead", action="store_true", help="plan the next batch's teacher-forced rollout right after the optimizer launch (NavRollout.plan_ahead(thread=False))")
 ap.add_argument("--icod", action="store_true", help="BASELINE config 3: MAGIC-S student + trainable MAGIC-L teacher, R2R lengths")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -50,24 +51,44 @@ ro = NavRollout(model, table, teacher=teacher, kd=kd, train_teacher=a.icod, max_
 rng = np.random.default_rng(0)
 
 
+EV = {}
+
+
+def mark(name):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    EV[name] = e
+
+
+PIPE = {"ahead": None, "obs": None}
+
+
 def iteration():
+    mark("start")
     opt.zero_grad()
     if t_opt is not None:
         t_opt.zero_grad()
-    obs = env.reset(features=False)
+    ahead = PIPE["ahead"]
+    obs = PIPE["obs"] if ahead is not None else env.reset(features=False)
     batch = env.batch
     rw = (torch.softmax(torch.randn(T, 5, device=dev) / 4.0, -1) * 5) if a.icod else None
     r2, r1 = ro.run_interleaved([((env2, env2.reset(batch=batch, features=False)), dict(feedback="sample", train_ml=1.0, rw_seq=rw, sample_draws=rng.uniform(size=(T, 16)))),
-                                 ((env, obs), dict(feedback="teacher", train_ml=0.2, rw_seq=rw))])
+                                 ((env, obs), dict(feedback="teacher", train_ml=0.2, rw_seq=rw, ahead=ahead))])
     t_f = time.perf_counter()
+    mark("fwd_end")                  # (the current stream has joined the rollouts' lanes: everything of the forward phase is behind this event)
     (r1["loss"] + r2["loss"]).backward(retain_graph=a.icod)
     if a.icod:
         (r1["t_loss"] + r2["t_loss"]).backward()
         torch.nn.utils.clip_grad_norm_(teacher.parameters(), 40.0)
         t_opt.step()
     t_b = time.perf_counter()
+    mark("bwd_end")
     torch.nn.utils.clip_grad_norm_(model.parameters(), 40.0)
     opt.step()
+    mark("end")
+    if a.ahead:
+        PIPE["obs"] = env.reset(features=False)
+        PIPE["ahead"] = ro.plan_ahead(env, PIPE["obs"], thread=False)
     return r1["decisions"] + r2["decisions"], t_f, t_b
 
 
@@ -76,6 +97,8 @@ for _ in range(5 if a.graphs else 2):
     iteration()
     torch.cuda.synchronize()
     print(f"warm-up iteration: {1e3 * (time.perf_counter() - t0):.0f} ms", ro.graph_report() if a.graphs else "")
+from magic_amd.host import nav_rollout as _NR
+_NR._T["acc"].clear()
 for _ in range(a.iters):
     t0 = time.perf_counter()
     dec, t_f, t_b = iteration()
@@ -83,7 +106,13 @@ for _ in range(a.iters):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"iteration: {1e3 * (t2 - t0):.1f} ms wall ({dec} decisions); host: rollouts {1e3 * (t_f - t0):.1f}  backward {1e3 * (t_b - t_f):.1f}  "
-          f"clip+opt {1e3 * (t1 - t_b):.1f}  drain {1e3 * (t2 - t1):.1f}")
+          f"clip+opt (+ plan-ahead) {1e3 * (t1 - t_b):.1f}  drain {1e3 * (t2 - t1):.1f} | GPU timeline: forward done at {EV['start'].elapsed_time(EV['fwd_end']):.1f} ms, "
+          f"backward done at {EV['start'].elapsed_time(EV['bwd_end']):.1f}, optimizer at {EV['start'].elapsed_time(EV['end']):.1f}")
+
+if _NR._T["on"]:
+    print("host sections of steps() over the timed iterations (ms per iteration):")
+    for k, v in sorted(_NR._T["acc"].items(), key=lambda kv: -kv[1]):
+        print(f"  {k:38s} {1e3 * v / a.iters:7.2f}")
 
 L.PROFILE.update(on=True, events=[], shapes=[])
 dec, _, _ = iteration()

@@ -168,7 +168,7 @@ def _queue_sync(model):
     def _done(tok=tok):
         model._sync_token = None
         O.join_dw_stream()            # weight-gradient launches of captured step instances (host/step_graphs.py) run on a stream of their own
-        lanes.join(model.device_, forget=False)     # the rollouts' gradient lanes ran on streams of their own (host/lanes.py): this stream waits for them
+        lanes.join(getattr(model, "device_", None), forget=False)     # the rollouts' gradient lanes ran on streams of their own (host/lanes.py): this stream waits for them
         if NAV_DEFER_DW:
             O.flush_dw()
         O.flush_rbw_parts()           # partial LayerNorm gradients of the row-block backward launches of this pass (no-op when flush_dw ran)

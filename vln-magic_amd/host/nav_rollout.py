@@ -60,55 +60,126 @@ def _nav_extent(outs, K, Vp, L):
                 vp_attns=outs["vp_attns"][:, :, :Vp, :L])
 
 
-class _LogGather(torch.autograd.Function):
-    """out[n_out, H] = CSR(ptr, idx, w) x log; backward = transposed CSR, split back onto the step tensors the log rows
-    were copied from (`srcs[i]` occupies log rows [spans[i][0], spans[i][1]))."""
+class _GradRows:
+    """holder of an EmbeddingLog's gradient rows: what the autograd nodes keep (never the log itself -- the log holds the tokens, a token's node
+    holding the log would be a reference cycle, and the rollout's autograd graph, with the step instances it owns, would wait for the
+    garbage collector instead of dying with the iteration)"""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+class _LogSrc(torch.autograd.Function):
+    """`tok = _LogSrc.apply(x, log, row0, n)`: x was copied into log rows [row0, row0 + n).  Every later gather of the rollout takes the
+    one-element token as an input (no data) and ADDS its transposed gather into `log.rows.buf` in place; autograd runs this node's backward
+    only after every gather that holds the token has run -- the rows are complete then -- and hands them to x's producer ONCE.
+    (Before: every gather returned a gradient for every earlier step tensor and autograd summed them pairwise: ~T^2 / 2 bf16 add
+    launches per rollout and tensor kind -- 1 226 per iteration at RxR lengths, 4.6 ms of kernel time -- and every gather's backward
+    wrote a full [n_src, H] gradient log, zeros included.)"""
 
     @staticmethod
-    def forward(ctx, log, csr, csr_t, n_out, n_src, spans, out, *srcs):
-        H = log.shape[1]
+    def forward(ctx, x, rows, row0, n):
+        ctx.rows, ctx.span, ctx.shape = rows, (row0, row0 + n), x.shape
+        return torch.empty(1, dtype=torch.float32, device=x.device)
+
+    @staticmethod
+    def backward(ctx, _d):
+        if getattr(ctx, "done", False):
+            raise RuntimeError("a second backward pass through the same rollout's embedding log: its gradient rows are accumulated in place and "
+                               "were handed over by the first pass (run the rollout again, or back-propagate the summed loss once)")
+        ctx.done = True
+        a, b = ctx.span
+        return ctx.rows.buf[a:b].view(ctx.shape), None, None, None
+
+
+class _LogChain(torch.autograd.Function):
+    """`chain_t = _LogChain.apply(chain_{t-1}, *new tokens)`: ONE token per gather instead of one per logged tensor (a gather late in the
+    rollout held ~60 inputs: autograd's per-input bookkeeping was a measurable share of a step's host time).  gather_t holds chain_t; chain_t
+    holds chain_{t-1} and the tokens of the tensors logged since: a tensor's `_LogSrc` node still runs only after every later gather has."""
+
+    @staticmethod
+    def forward(ctx, *toks):
+        ctx.n = len(toks)
+        ctx.set_materialize_grads(False)
+        return torch.empty(1, dtype=torch.float32, device=toks[0].device)
+
+    @staticmethod
+    def backward(ctx, _d):
+        return (None,) * ctx.n
+
+
+class _LogGather(torch.autograd.Function):
+    """out[n_out, H] = CSR(ptr, idx, w) x log; backward = the transposed CSR added into the log's gradient rows (`log.rows.buf`); the step tensors
+    the rows were copied from receive them through their `_LogSrc` tokens."""
+
+    @staticmethod
+    def forward(ctx, buf, rows, csr, csr_t, n_out, n_src, out, *toks):
+        H = buf.shape[1]
         # out: a static buffer to gather into (the input of a captured step instance, host/step_graphs.py) or None
-        out = torch.empty(n_out, H, dtype=log.dtype, device=log.device) if out is None else out.detach()
-        O.csr_gather(log, csr[0], csr[1], csr[2], out, n_out, H)
-        ctx.csr_t, ctx.n_src, ctx.spans = csr_t, n_src, spans
-        ctx.shapes = [s.shape for s in srcs]
-        ctx.H = H
+        out = torch.empty(n_out, H, dtype=buf.dtype, device=buf.device) if out is None else out.detach()
+        O.csr_gather(buf, csr[0], csr[1], csr[2], out, n_out, H)
+        ctx.rows, ctx.csr_t, ctx.n_src, ctx.H = rows, csr_t, n_src, H
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        H = ctx.H
-        dlog = torch.empty(ctx.n_src, H, dtype=d_out.dtype, device=d_out.device)
-        O.csr_gather(d_out.contiguous(), ctx.csr_t[0], ctx.csr_t[1], ctx.csr_t[2], dlog, ctx.n_src, H)
-        grads = [dlog[a:b].view(shp) if b <= ctx.n_src else None for (a, b), shp in zip(ctx.spans, ctx.shapes)]
-        return (None, None, None, None, None, None, None, *grads)
+        if d_out is not None:
+            O.csr_gather(d_out.contiguous(), ctx.csr_t[0], ctx.csr_t[1], ctx.csr_t[2], ctx.rows.buf, ctx.n_src, ctx.H, accumulate=True)
+        return (None,) * len(ctx.needs_input_grad)
+
+
+# host-side section timers of `steps` (MAGIC_NAV_TIMERS=1; profiles/micro/nav_kernel_breakdown.py prints them): where a step's host time goes,
+# without a profiler's per-call overhead.  _tk(name) charges the time since the previous mark to `name`.
+_T = {"on": bool(os.environ.get("MAGIC_NAV_TIMERS")), "acc": {}, "last": 0.0}
+
+
+def _tk(name):
+    if _T["on"]:
+        import time
+        now = time.perf_counter()
+        _T["acc"][name] = _T["acc"].get(name, 0.0) + now - _T["last"]
+        _T["last"] = now
 
 
 LANES = os.environ.get("MAGIC_NAV_LANES", "1") != "0"      # the rollouts of `run_interleaved` as gradient lanes on streams of their own
 
 
 class EmbeddingLog:
-    """append-only [rows, H] device buffer of one model's per-step outputs + the autograd handles of the rows"""
+    """append-only [rows, H] device buffer of one model's per-step outputs (`buf`), its gradient rows (`rows.buf`: the gathers' backwards add into
+    them in place) and the autograd tokens of the tracked rows"""
 
     def __init__(self, H, dtype, dev, rows=4096):
         self.buf = torch.zeros(rows, H, dtype=dtype, device=dev)
-        self.srcs, self.spans = [], []
+        self.rows = _GradRows()                # .buf allocated (zero) with the first tracked rows
+        self.toks = []                         # tokens of the tensors logged since the last gather
+        self.chain = None                      # the token the next gather holds (_LogChain)
+
+    def _grow(self, rows):
+        nb = torch.zeros(max(2 * self.buf.shape[0], rows), self.buf.shape[1], dtype=self.buf.dtype, device=self.buf.device)
+        nb[:self.buf.shape[0]] = self.buf
+        self.buf = nb
+        if self.rows.buf is not None:          # (forward only: no gradient has been written yet)
+            self.rows.buf = torch.zeros_like(nb)
 
     def put(self, row0, x, track=True):
         x2 = x.detach().reshape(-1, self.buf.shape[1])
         n = x2.shape[0]
         if row0 + n > self.buf.shape[0]:
-            nb = torch.zeros(max(2 * self.buf.shape[0], row0 + n), self.buf.shape[1], dtype=self.buf.dtype, device=self.buf.device)
-            nb[:self.buf.shape[0]] = self.buf
-            self.buf = nb
+            self._grow(row0 + n)
         self.buf[row0:row0 + n].copy_(x2)
         if track and x.requires_grad:
-            self.srcs.append(x)
-            self.spans.append((row0, row0 + n))
+            if self.rows.buf is None:
+                self.rows.buf = torch.zeros_like(self.buf)
+            self.toks.append(_LogSrc.apply(x, self.rows, row0, n))
 
     def gather(self, csr, csr_t, n_out, n_src, grad=True, out=None):
-        if grad and self.srcs:
-            return _LogGather.apply(self.buf, csr, csr_t, n_out, n_src, list(self.spans), out, *self.srcs)
+        if grad and (self.toks or self.chain is not None):
+            if self.toks:
+                self.chain = _LogChain.apply(*(([self.chain] if self.chain is not None else []) + self.toks))
+                self.toks = []
+            return _LogGather.apply(self.buf, self.rows, csr, csr_t, n_out, n_src, out, self.chain)
         if out is None:
             out = torch.empty(n_out, self.buf.shape[1], dtype=self.buf.dtype, device=self.buf.device)
         O.csr_gather(self.buf, csr[0], csr[1], csr[2], out, n_out, self.buf.shape[1])
@@ -355,12 +426,14 @@ class NavRollout:
         decisions = 0
         with ctxg:
             for t in range(self.T):
+                _tk("(outside)")
                 if plans is not None:
                     plan = plans[t]
                     decisions += plan["_live"]
                 else:
                     plan = pl.begin_pano()
                     decisions += int((~pl.ended).sum())
+                _tk("begin_pano")
                 vl = np.asarray(plan["view_lens"])
                 pano_arrays = dict(vp_rows=plan["vp_rows"], view_order=plan["view_order"], loc_fts=plan["loc_fts"],
                                    nav_types=np.asarray(plan["nav_types"]).astype(np.int32), view_lens=vl.astype(np.int32),
@@ -380,9 +453,11 @@ class NavRollout:
                 if te is not None:
                     with tctx():
                         tpe, _, tpf, tpa = sgt.run_pano(tpi, pano_arrays) if tpi is not None else te("panorama", pin)
+                _tk("pano arrays + launch")
                 # the GPU is busy with the panorama encoder(s): build the second half of the plan now
                 if plans is None:
                     plan.update(pl.begin_nav())
+                _tk("begin_nav")
                 fixed = {k: plan[k] for k in ("gmap_pos_fts", "gmap_pair_dists", "gmap_masks", "vp_pos_fts", "vp_nav_masks", "vp_masks", "fsrc", "bw")}
                 fixed["gmap_step_ids"] = np.asarray(plan["gmap_step_ids"]).astype(np.int32)
                 fixed["gmap_logit_masks"] = ~np.asarray(plan["gmap_visited_masks"], bool) & np.asarray(plan["gmap_masks"], bool)
@@ -401,6 +476,7 @@ class NavRollout:
                 d.update(d2)
                 csr = (d["csr_ptr"], d["csr_idx"], d["csr_w"])
                 csr_t = (d["csrt_ptr"], d["csrt_idx"], d["csrt_w"]) if plan["csr_t"] is not None else None
+                _tk("nav arrays + to_device")
                 s_log.put(plan["log_base"], pe)
                 s_log.put(plan["log_fused"], pf)
                 gathered = s_log.gather(csr, csr_t, plan["n_out"], plan["log_cls"], grad=grad, out=ni.gathered if ni is not None else None)
@@ -408,6 +484,7 @@ class NavRollout:
                     outs = sgs.run_nav(ni, fixed, gathered, s_tok)
                 else:
                     outs = st("navigation", self._nav_inputs(d, plan, gathered, txt_embeds, txt_masks, txt_lens, txt_kv))
+                _tk("log put/gather + nav launch")
                 s_log.put(plan["log_cls"], outs["cls_embeds"])
                 logits = outs["fused_logits"]
                 Kt = plan["K_valid"]
@@ -440,7 +517,9 @@ class NavRollout:
                             s_out["sample_weights"] = exponential_decay(ce.detach(), self.kd["decay"])
                             t_kdl = compute_kd_losses(t, t_out, s_out, self.heads, t_kdl, role="s2t", temperature=self.kd["temperature"],
                                                       weights=rw_t, learned=te.vln_bert if learned else None)   # s_model = the teacher (:555-556)
+                _tk("loss + distillation terms")
                 yield t           # the step is launched; nothing below is needed before its actions are (run_interleaved switches here)
+                _tk("(outside)")
                 a_host = None
                 if needs_action:                                                     # the stepper needs it: one [B] copy
                     a_arg = logits.detach().argmax(1)
@@ -449,13 +528,16 @@ class NavRollout:
                         u = od["draws"][t]
                         a_smp = (cdf < (u * cdf[:, -1])[:, None]).sum(1).clamp(max=logits.shape[1] - 1)
                         a_arg = torch.where(od["is_smp"].view(torch.bool), a_smp, a_arg)
+                    _tk("action ops")
                     a_host = a_arg.cpu().numpy()
+                    _tk("action copy (waits for the GPU)")
                 if record:
                     steps.append(dict(logits=logits.detach().float().cpu(), targets=torch.from_numpy(plan["targets"]).clone(),
                                       vpids=plan["gmap_vpids"]))
                 done = plan["_done"] if plans is not None else pl.end_step(a_host)
                 if record:
                     steps[-1]["actions"] = list(plan["_actions"] if plans is not None else pl.actions)
+                _tk("end_step")
                 if done:
                     break
         ml = ml_loss / Bn

@@ -60,6 +60,14 @@ int magic_gemm_set_big(int mode);
 typedef struct magic_dw_desc { const void* dY; const void* X; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk; } magic_dw_desc;
 int magic_gemm_dw_ws_need(int dtype, int n, const magic_dw_desc* d, long long* floats, int* counters);
 int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, float* ws, long long ws_floats, unsigned* counters, int n_counters, void* stream);
+/* Weight gradients over MANY row segments per Linear in one launch: dW_p[N, K] += sum_s dY_{p,s}[M_{p,s}, N]^T X_{p,s}[M_{p,s}, K] (and db_p += the column
+ * sums of dY), p < n_prob <= 96, s < n_seg.  dy_tab / x_tab: DEVICE tables [n_prob][n_seg] of operand pointers (16-byte aligned rows: lda / ldb multiples of
+ * 8 elements for the 16-bit types), m_tab: DEVICE [n_prob][n_seg] row counts (0 skips a segment).  One workgroup per 64 x 64 tile of a dW walks all of its
+ * segments with the accumulators in registers and read-modify-writes dW once: no workspace, no atomics, sums in segment order (reproducible).  The
+ * navigator iteration's ~38 calls of every Linear (agent_base.py:243-263: two rollouts, one backward) leave in one launch per <= 96 Linears. */
+typedef struct magic_dwcat_prob { float* dW; float* db; int N, K, lda, ldb, ldc; } magic_dwcat_prob;
+int magic_gemm_dw_cat(int dtype, int n_prob, const magic_dwcat_prob* probs, int n_seg, const void* const* dy_tab, const void* const* x_tab,
+                      const int* m_tab, void* stream);
 
 /* out = LayerNorm(x[M,K] W[H,K]^T + bias + residual): BertSelfOutput / BertOutput (dense -> add -> LayerNorm) in one launch;
  * H in {128, 256, 384} (a workgroup owns 32 full rows), otherwise MAGIC_ERR_UNSUPPORTED -> magic_gemm + magic_ln_fwd. */

@@ -941,3 +941,58 @@ def test_partial_row_parameter_gradients_equal_the_atomic_form(H, M):
         sc = max(1.0, u.float().abs().max().item())
         assert (u.float() - v.float()).abs().max().item() <= 2e-4 * sc, i
         assert torch.equal(v, w), i
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_weight_gradients_over_many_row_segments_in_one_launch(dtype):
+    """magic_gemm_dw_cat (csrc/gemm.hip gemm_dw_cat_kernel): dW_p += sum_s dY_{p,s}^T X_{p,s}, db_p += column sums, for several Linears at once with
+    ragged segment rows (one of them 0: skipped) and shapes that are not multiples of the 64 x 64 tile -- against the fp32 reference, and bitwise
+    reproducible from the same starting buffers (one workgroup per tile, sums in segment order: no atomics)."""
+    import numpy as np
+    shapes = [(768, 768, True), (128, 512, False), (24, 40, True), (768, 7, True), (1, 768, True)]           # (N out, K in, bias)
+    rows = [624, 592, 0, 16, 37, 624]
+    probs, tabs, ref = [], [], []
+    for i, (N, K, hb) in enumerate(shapes):
+        dW, db = rnd(N, K, seed=50 + i).contiguous(), (rnd(N, seed=60 + i) if hb else None)
+        segs = []
+        for s, M in enumerate(rows):
+            Mr = max(M, 1)
+            ld_k = (K + 7) // 8 * 8
+            ld_n = (N + 7) // 8 * 8
+            dy = rnd(Mr, ld_n, dtype=dtype, scale=0.3, seed=1000 + 10 * i + s)
+            x = rnd(Mr, ld_k, dtype=dtype, seed=2000 + 10 * i + s)
+            segs.append((dy, x, M, ld_n, ld_k))
+        probs.append((dW, db, N, K, segs))
+        rw, rb = dW.double().clone(), (db.double().clone() if hb else None)
+        for dy, x, M, ld_n, ld_k in segs:
+            if M:
+                rw += dy[:M, :N].double().t() @ x[:M, :K].double()
+                if hb:
+                    rb += dy[:M, :N].double().sum(0)
+        ref.append((rw, rb))
+    n_seg = len(rows)
+    dy_t = np.array([[sg[0].data_ptr() for sg in p[4]] for p in probs], np.int64)
+    x_t = np.array([[sg[1].data_ptr() for sg in p[4]] for p in probs], np.int64)
+    m_t = np.array([[sg[2] for sg in p[4]] for p in probs], np.int32)
+    d_dy, d_x, d_m = torch.from_numpy(dy_t).to(DEV), torch.from_numpy(x_t).to(DEV), torch.from_numpy(m_t).to(DEV)
+    plist = [(p[0].data_ptr(), p[1].data_ptr() if p[1] is not None else 0, p[2], p[3], p[4][0][3], p[4][0][4], p[0].stride(0)) for p in probs]
+    start = [(p[0].clone(), None if p[1] is None else p[1].clone()) for p in probs]
+
+    def run():
+        for p, (w0, b0) in zip(probs, start):
+            p[0].copy_(w0)
+            if b0 is not None:
+                p[1].copy_(b0)
+        O.dw_cat(dtype, plist, n_seg, d_dy.data_ptr(), d_x.data_ptr(), d_m.data_ptr())
+        torch.cuda.synchronize()
+        return [(p[0].clone(), None if p[1] is None else p[1].clone()) for p in probs]
+    first = run()
+    tol = dict(rtol=2e-3, atol=2e-2) if dtype != torch.float32 else dict(rtol=1e-4, atol=1e-3)
+    for (w, b), (rw, rb), (N, K, hb) in zip(first, ref, shapes):
+        check(w, rw, f"dW cat {N}x{K}", **tol)
+        if hb:
+            check(b, rb, f"db cat {N}", **tol)
+    for _ in range(3):
+        again = run()
+        for (w, b), (w1, b1) in zip(first, again):
+            assert torch.equal(w, w1) and (b is None or torch.equal(b, b1))

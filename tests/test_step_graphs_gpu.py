@@ -111,13 +111,16 @@ def test_backward_graphs_regenerate_the_masks_of_their_own_forward():
     torch.cuda.synchronize()
     g = m.store.grad.clone()
     del r
-    d = torch.randn_like(g)
+    # direction: random, plus a component along the gradient so the derivative is well above the finite difference's noise floor (the fp32 loss
+    # moves by whole ulps: one ulp of 9.0 over 2 eps is ~0.05 here -- a direction nearly orthogonal to the gradient made this check flaky)
+    d = torch.randn(g.shape, device=g.device, generator=torch.Generator(g.device).manual_seed(7))
     d *= (g.abs() > 0)                                             # (text encoder parameters: their masks come from the eager language call)
+    d += g * (d.norm() / g.norm())
     names = [n for n, _ in m.named_parameters() if "lang_encoder" in n or n.startswith("vln_bert.embeddings")]
     for n in names:
         off, cnt, _ = m.store.offsets[n]
         d[off:off + cnt] = 0
-    eps = 1e-3 / d.norm().item()
+    eps = 1e-2 / d.norm().item()
     vals = []
     for sgn in (+1, -1):
         with torch.no_grad():

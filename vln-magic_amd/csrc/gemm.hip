@@ -872,6 +872,129 @@ __global__ __launch_bounds__(256) void gemm_dw_batch_kernel(DwBatch gp) {
   }
 }
 
+// Weight gradients of ONE Linear over MANY row segments in one pass (round 5): dW[N, K] += sum_s dY_s[M_s, N]^T X_s[M_s, K].
+// The navigator iteration calls every Linear once per step and rollout (~38 times): the per-step grouped launch above then read-modify-writes
+// the whole fp32 gradient of the model once per step (528 MB per step at MAGIC-L: the launch's time was that traffic, 207 us x 75 launches
+// per iteration).  Here the step instances keep their dY / X operands (host/step_graphs.py) and ONE launch at the end of the backward pass
+// walks all segments of a problem per output tile with the accumulators in registers: one read-modify-write of dW per iteration, no
+// workspace, no atomics, one workgroup per 64 x 64 tile (a MAGIC-L model has ~20 k of them: the chip is full without splitting K) --
+// segment order = the order the host lists them in, so the sums are reproducible.  Segment tables live in device memory
+// ([n_prob][n_seg] operand pointers and row counts); rows = 0 skips a segment.
+struct magic_dwcat_prob { float* dW; float* db; int N, K, lda, ldb, ldc; };
+struct DwCatProblem { float* C; float* bias_grad; int M, N, lda, ldb, ldc; };        // M = out features (dW rows), N = in features (dW columns)
+struct DwCatBatch { DwCatProblem p[DW_MAX]; int start[DW_MAX + 1]; int n, n_seg; const void* const* dy_tab; const void* const* x_tab; const int* m_tab; };
+
+// NT_ = 2: 64 x 64 tiles; NT_ = 4: 128 x 128 tiles (problems with both dimensions >= 128: twice the MFMA work per byte staged through LDS -- the 64 x 64
+// form ran the MAGIC-L iteration's 3.8 TFLOP at 425 TFLOP/s)
+template <typename T, int NT_>
+__global__ __launch_bounds__(256) void gemm_dw_cat_kernel(DwCatBatch gp) {
+  constexpr int BK = TT<T>::BK, TM = 32 * NT_, SN_ = TT<T>::SN + (TM - 64), NE = NT_ * NT_ * 4, PD = (NT_ == 2) ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) T sA[TM * TT<T>::STRIDE];
+  __shared__ __attribute__((aligned(16))) T sB[TM * TT<T>::STRIDE];
+  const int id = blockIdx.x;
+  int lo = 0, hi = gp.n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (id >= gp.start[mid]) lo = mid; else hi = mid - 1; }
+  const DwCatProblem& d = gp.p[lo];
+  const int local = id - gp.start[lo];
+  const int nx = (d.N + TM - 1) / TM, ny = (d.M + TM - 1) / TM;
+  // XCD-aware placement: consecutive workgroup ids go round the 8 XCDs (a problem's first id is a multiple of 8), so XCD x takes the x-th
+  // eighth of the problem's tiles in row-major order -- the tiles of one row block of dW (same dY panel) and of neighbouring row blocks
+  // (same X panels) meet in ONE L2 instead of eight
+  const int per = (nx * ny + 7) >> 3;
+  const int tile = (local & 7) * per + (local >> 3);
+  if ((local >> 3) >= per || tile >= nx * ny) return;
+  const int bx = tile % nx, by = tile / nx;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+  const int n0 = bx * TM, m0 = by * TM;
+  const void* const* dyt = gp.dy_tab + (long long)lo * gp.n_seg;
+  const void* const* xt = gp.x_tab + (long long)lo * gp.n_seg;
+  const int* mt = gp.m_tab + (long long)lo * gp.n_seg;
+  TileLoader<T, false, TM> la[PD], lb[PD];
+  f32x4 acc[NT_][NT_];
+#pragma unroll
+  for (int i = 0; i < NT_; ++i)
+#pragma unroll
+    for (int j = 0; j < NT_; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool do_bgrad = d.bias_grad != nullptr && bx == 0;
+  // the load stream walks (segment, k-tile) pairs in order; `ls` / `lk` = the pair the NEXT load takes
+  int ls = 0, lk = 0;
+  auto skip_empty = [&]() { while (ls < gp.n_seg && lk * BK >= mt[ls]) { ++ls; lk = 0; } };
+  auto issue = [&](int slot) {          // returns false when the stream is exhausted
+    skip_empty();
+    if (ls >= gp.n_seg) return false;
+    const int rows = mt[ls];
+    la[slot].load((const T*)dyt[ls], d.lda, m0, lk * BK, d.M, rows);
+    lb[slot].load((const T*)xt[ls], d.ldb, n0, lk * BK, d.N, rows);
+    ++lk;
+    return true;
+  };
+  bool live[PD];
+#pragma unroll
+  for (int q = 0; q < PD; ++q) live[q] = issue(q);
+  while (live[0]) {
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+      if (live[q]) {                    // block-uniform
+        la[q].store(sA);
+        lb[q].store(sB);
+        __syncthreads();
+        live[q] = issue(q);
+        mma_tile<false, false, NT_>(sA, sB, wr, wc, lane, acc);
+        if (do_bgrad && tid < TM) {
+          float s = 0.f;
+#pragma unroll 8
+          for (int k = 0; k < BK; ++k) s += to_f(sA[k * SN_ + tid]);
+          bsum += s;
+        }
+        __syncthreads();
+      }
+    }
+    // slots are consumed in order 0, 1, 2, 0, ...: once slot q is dead every later slot of this round and every slot of the next is dead too
+  }
+  const int cr = (lane >> 4) * 4, cc = lane & 15;
+  // element e of a lane: tile (i, j) = (e / (4 NT_), (e / 4) % NT_), register r = e % 4 (gemm_block's map)
+  float old[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int col = n0 + (wc * NT_ + ((e >> 2) % NT_)) * 16 + cc, row = m0 + (wr * NT_ + (e / (4 * NT_))) * 16 + cr + (e & 3);
+    old[e] = (col < d.N && row < d.M) ? d.C[(long long)row * d.ldc + col] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int col = n0 + (wc * NT_ + ((e >> 2) % NT_)) * 16 + cc, row = m0 + (wr * NT_ + (e / (4 * NT_))) * 16 + cr + (e & 3);
+    if (col < d.N && row < d.M) d.C[(long long)row * d.ldc + col] = old[e] + acc[e / (4 * NT_)][(e >> 2) % NT_][e & 3];
+  }
+  if (do_bgrad && tid < TM && m0 + tid < d.M) d.bias_grad[m0 + tid] += bsum;
+}
+
+extern "C" int magic_gemm_dw_cat(int dtype, int n_prob, const magic_dwcat_prob* probs, int n_seg, const void* const* dy_tab, const void* const* x_tab,
+                                 const int* m_tab, void* stream) {
+  if (n_prob <= 0 || n_prob > DW_MAX || !probs || n_seg <= 0 || !dy_tab || !x_tab || !m_tab || !dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  const int ve = dtype_is16(dtype) ? 8 : 4;
+  DwCatBatch gp;
+  gp.n = n_prob; gp.n_seg = n_seg; gp.dy_tab = dy_tab; gp.x_tab = x_tab; gp.m_tab = m_tab;
+  // one tile size per launch: 128 x 128 when every problem has both dimensions >= 128 (the host sorts the wide problems into launches of their own)
+  bool wide = dtype_is16(dtype);
+  for (int i = 0; i < n_prob; ++i) wide = wide && probs[i].N >= 128 && probs[i].K >= 128;
+  const int tm = wide ? 128 : 64;
+  int total = 0;
+  for (int i = 0; i < n_prob; ++i) {
+    const magic_dwcat_prob& q = probs[i];
+    if (!q.dW || q.N <= 0 || q.K <= 0 || q.lda % ve || q.ldb % ve || q.ldc < q.K) return MAGIC_ERR_ARG;
+    DwCatProblem& p = gp.p[i];
+    p.C = q.dW; p.bias_grad = q.db; p.M = q.N; p.N = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+    gp.start[i] = total;
+    total += (((p.N + tm - 1) / tm) * ((p.M + tm - 1) / tm) + 7) / 8 * 8;
+  }
+  for (int i = n_prob; i <= DW_MAX; ++i) gp.start[i] = total;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) { if (wide) hipLaunchKernelGGL((gemm_dw_cat_kernel<bf16, 4>), dim3(total), dim3(256), 0, st, gp); else hipLaunchKernelGGL((gemm_dw_cat_kernel<bf16, 2>), dim3(total), dim3(256), 0, st, gp); }
+  else if (dtype == DT_F16) { if (wide) hipLaunchKernelGGL((gemm_dw_cat_kernel<f16, 4>), dim3(total), dim3(256), 0, st, gp); else hipLaunchKernelGGL((gemm_dw_cat_kernel<f16, 2>), dim3(total), dim3(256), 0, st, gp); }
+  else hipLaunchKernelGGL((gemm_dw_cat_kernel<float, 2>), dim3(total), dim3(256), 0, st, gp);
+  return launch_status();
+}
+
 // Wide-tile selection (bf16; M, N >= 128; the contiguous dimension of each operand a multiple of 8).  Measured on MI355X
 // (profiles/micro/gemm_tile_sweep.py -> profiles/micro/r01_gemm_tile_sweep.txt): the wide tile wins on the forward / input-gradient GEMMs
 // once the output has >= ~192 tiles of 128x128 and K >= 512 (M = 8192 rows at H = 768: 1.4-1.9x over the 64x64 tile, 1.2-1.3x behind

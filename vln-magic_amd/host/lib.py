@@ -57,6 +57,7 @@ SIGNATURES = {
     "magic_mse_multi": [i32, i32, vp, vp],
     "magic_step_rng": [u64, vp, f32, vp, vp, vp, vp, f32, f32, i32, vp],
     "magic_seed_scale": [vp],
+    "magic_gemm_dw_cat": [i32, i32, vp, i32, vp, vp, vp, vp],
     "magic_loss_assemble": [vp, i32, vp, f32, vp, i32, vp, vp, f32, i32, vp, vp],
     "magic_cfp_loss": [i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_node_in_fwd": [i32, i32, i32, vp, vp],
@@ -111,6 +112,11 @@ class DwDesc(C.Structure):
     """mirror of `magic_dw_desc` (include/magic_hip.h)"""
     _fields_ = [("dY", vp), ("X", vp), ("dW", vp), ("db", vp), ("M", i32), ("N", i32), ("K", i32),
                 ("lda", i32), ("ldb", i32), ("ldc", i32), ("splitk", i32)]
+
+
+class DwCatProb(C.Structure):
+    """mirror of `magic_dwcat_prob` (include/magic_hip.h)"""
+    _fields_ = [("dW", vp), ("db", vp), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32)]
 
 
 class MseDesc(C.Structure):

@@ -159,6 +159,9 @@ def _queue_sync(model):
         # few grouped launches from the end-of-backward callback: ~2 400 single launches per navigator iteration become ~25
         if not pending and not O.DEFER["active"]:
             O.DEFER["queue"].clear(); O.DEFER["bytes"] = 0          # anything left by a pass that raised half-way is stale
+            for ref in getattr(model, "_step_graph_sets", ()):
+                if ref() is not None:
+                    del ref()._cat_used[:]
         O.defer_dw(True)
     if pending:
         return
@@ -169,6 +172,10 @@ def _queue_sync(model):
         model._sync_token = None
         O.join_dw_stream()            # weight-gradient launches of captured step instances (host/step_graphs.py) run on a stream of their own
         lanes.join(getattr(model, "device_", None), forget=False)     # the rollouts' gradient lanes ran on streams of their own (host/lanes.py): this stream waits for them
+        for ref in getattr(model, "_step_graph_sets", ()):            # captured step instances: every Linear's weight gradient over all of them, one launch per <= 96
+            sg = ref()
+            if sg is not None:
+                sg.flush_cat()
         if NAV_DEFER_DW:
             O.flush_dw()
         O.flush_rbw_parts()           # partial LayerNorm gradients of the row-block backward launches of this pass (no-op when flush_dw ran)

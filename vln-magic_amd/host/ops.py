@@ -290,6 +290,15 @@ def dw_grouped(dt, arr, n, device, deterministic=None):
     return ws is not None
 
 
+def dw_cat(dt, probs, n_seg, dy_tab, x_tab, m_tab):
+    """dW_p += sum over n_seg row segments of dY^T X for <= 96 Linears in one launch (csrc/gemm.hip gemm_dw_cat_kernel).  probs: [(dW ptr, db ptr, N, K,
+    lda, ldb, ldc)]; dy_tab / x_tab / m_tab: DEVICE addresses of the [len(probs)][n_seg] operand-pointer / row-count tables"""
+    arr = (L.DwCatProb * len(probs))()
+    for j, (dW, db, N, K, lda, ldb, ldc) in enumerate(probs):
+        arr[j] = L.DwCatProb(dW, db or None, N, K, lda, ldb, ldc)
+    L.call("magic_gemm_dw_cat", L.dt(dt), len(probs), C.addressof(arr), int(n_seg), int(dy_tab), int(x_tab), int(m_tab), L.stream())
+
+
 def _linear_dw(dy, x, dW, db, M, *, N=None, K=None, lda=None, ldb=None, ldc=None, flop_rows=None):
     N = N if N is not None else dW.shape[0]
     K = K if K is not None else dW.shape[1]

@@ -40,6 +40,10 @@ _EAGER_BWD = bool(os.environ.get("MAGIC_STEP_GRAPH_EAGER_BWD"))
 # navigator iteration (183 / 171 ms with, 181 ms without: the chip-filling dW launch and the latency-bound chain slow each other down, as on
 # the pretraining step in round 3)
 DW_SIDE = os.environ.get("MAGIC_STEP_GRAPH_DW_SIDE", "0") != "0"
+# the weight gradients of ALL step instances of a backward pass in one launch per <= 96 Linears at the end of the pass (csrc/gemm.hip
+# gemm_dw_cat_kernel): the instances keep their dY / X operands, a Linear's ~38 calls per iteration are summed in registers and its fp32 gradient
+# is read-modify-written once per iteration instead of once per step (MAGIC-L: 528 MB per step was the per-step launch's whole cost)
+DW_CAT = os.environ.get("MAGIC_STEP_GRAPH_DW_CAT", "1") != "0"
 FORK = os.environ.get("MAGIC_STEP_GRAPH_FORK", "1") != "0"      # the two cross-modal encoders of a step as parallel branches of its graphs
 K_BUCKET = 16          # map tokens are padded to a multiple of this
 V_STATIC = 37          # views per panorama the instances are built for (36, or 37 when two candidates share a discretised view)
@@ -149,6 +153,21 @@ class _Inst:
         self.pool = torch.cuda.graph_pool_handle()
 
 
+class _CatEntry:
+    """the weight-gradient problems one backward graph leaves for the pass-end launch: operand tensors (kept alive: they are allocations of the
+    graph's private pool, never reused while this holds them), their addresses and row counts as arrays, and the interned problem keys"""
+    __slots__ = ("keep", "dy", "x", "m", "keys", "dtype")
+
+    def __init__(self, queue, intern):
+        self.keep = list(queue)
+        self.dy = np.array([e[0].data_ptr() for e in queue], np.int64)
+        self.x = np.array([e[1].data_ptr() for e in queue], np.int64)
+        self.m = np.array([e[4] for e in queue], np.int32)
+        self.dtype = queue[0][0].dtype
+        keys = tuple((e[2].data_ptr(), e[3].data_ptr() if e[3] is not None else 0, int(e[5]), int(e[6]), int(e[7]), int(e[8]), int(e[9])) for e in queue)
+        self.keys = intern.setdefault((self.dtype, keys), (self.dtype, keys))      # one object per distinct problem list: grouping is by identity
+
+
 class _PanoInstFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, inst):
@@ -212,6 +231,12 @@ class StepGraphs:
         self.rng_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)      # lane 0's; other lanes: _rng()
         self._rngs = {0: self.rng_counter}
         self._zc = {}
+        self._cat_used, self._cat_intern, self._cat_plan, self._cat_stage = [], {}, {}, None
+        sets = getattr(model, "_step_graph_sets", None)
+        if sets is None:
+            sets = model._step_graph_sets = []
+        import weakref
+        sets.append(weakref.ref(self))
 
     # ---- bookkeeping -------------------------------------------------------------------------------------------
     def _mode_key(self):
@@ -372,7 +397,7 @@ class StepGraphs:
         ent = inst.bwd.get(sig)
         if ent is None:
             ent = inst.bwd[sig] = self._capture_bwd(inst, names, grads)
-        bi, g, bo, g_dw = ent
+        bi, g, bo, g_dw, cat = ent
         for n, t in zip(names, grads):
             if t is not None:
                 dst = bi[n]
@@ -387,6 +412,8 @@ class StepGraphs:
                 O.dw_guard(self.dev)
                 g_dw.replay()
             O.dw_stream_used(self.dev)
+        if cat is not None:
+            self._cat_used.append(cat)
         return bo
 
     def _capture_bwd(self, inst, names, grads):
@@ -407,12 +434,16 @@ class StepGraphs:
             else:
                 d_gin, d_vin, _, _ = nav_backward_body(m, inst.c, *[bi.get(n) for n in names], dkv_acc=inst.slot.dkv, fork=self.side)
                 bo["d_gathered"] = torch.cat([d_gin, d_vin], 0)
-            if not DW_SIDE:
+            if DW_CAT:
+                O.flush_rbw_parts()       # the column sums of partial parameter-gradient rows stay inside the graph; the dW queue is left for flush_cat
+            elif not DW_SIDE:
                 O.flush_dw()
-        g_dw = None
+        g_dw = cat = None
         try:
             g = self._capture(inst, body)
-            if DW_SIDE and (O.DEFER["queue"] or O.PART_JOBS or O.RBW_JOBS):
+            if DW_CAT and O.DEFER["queue"]:
+                cat = _CatEntry(O.DEFER["queue"], self._cat_intern)
+            elif DW_SIDE and (O.DEFER["queue"] or O.PART_JOBS or O.RBW_JOBS):
                 # the step's weight-gradient launches (grouped dW GEMMs over the operands the backward graph leaves in the instance's memory +
                 # the column sums of its partial parameter-gradient rows) as a graph of their own, replayed on the weight-gradient stream
                 g_dw = self._capture(inst, O.flush_dw)
@@ -420,7 +451,74 @@ class StepGraphs:
             O.DEFER["queue"], O.DEFER["active"], O.DEFER["bytes"] = saved[0], saved[1], saved[2]
             O.RBW_JOBS[:] = saved[3]
             O.PART_JOBS[:] = saved[4]
-        return bi, g, bo, g_dw
+        return bi, g, bo, g_dw, cat
+
+    def flush_cat(self):
+        """end of a backward pass (model_nav._queue_sync's callback, after the lanes were joined): every Linear's weight gradient over all the
+        step instances that ran in this pass, <= 96 Linears per launch.  Segment order = the order the instances' backwards ran in."""
+        used, self._cat_used = self._cat_used, []
+        if not used:
+            return
+        groups = {}
+        for c in used:
+            groups.setdefault(id(c.keys), []).append(c)
+        launches, total = [], 0
+        for ents in groups.values():
+            dtype, keys = ents[0].keys
+            plan = self._cat_plan.get(id(ents[0].keys))
+            if plan is None:              # unique dW pointers of this problem list, and which queue entries feed each (a Linear used twice in a step)
+                uniq, cols = {}, []
+                for j, k in enumerate(keys):
+                    if k[0] in uniq:
+                        if keys[uniq[k[0]]][1:] != k[1:]:
+                            raise RuntimeError("step instances: one dW queued with two different shapes")
+                        cols[uniq[k[0]]].append(j)
+                    else:
+                        uniq[k[0]] = len(cols)
+                        cols.append([j])
+                plan = self._cat_plan[id(ents[0].keys)] = ([keys[c[0]] for c in cols], cols, max(len(c) for c in cols))
+            probs, cols, width = plan
+            E = len(ents)
+            DY, X, M = np.stack([c.dy for c in ents]), np.stack([c.x for c in ents]), np.stack([c.m for c in ents])      # [E, n_entries]
+            n_seg = E * width
+            if width == 1:
+                sel = [c[0] for c in cols]
+                dy_t, x_t, m_t = DY[:, sel].T, X[:, sel].T, M[:, sel].T
+            else:
+                dy_t, x_t, m_t = np.zeros((len(cols), n_seg), np.int64), np.zeros((len(cols), n_seg), np.int64), np.zeros((len(cols), n_seg), np.int32)
+                for j, c in enumerate(cols):
+                    k = E * len(c)
+                    dy_t[j, :k], x_t[j, :k], m_t[j, :k] = DY[:, c].reshape(-1), X[:, c].reshape(-1), M[:, c].reshape(-1)
+                dy_t[m_t == 0] = dy_t[0, 0]               # (skipped segments: any valid address)
+                x_t[m_t == 0] = x_t[0, 0]
+            # wide problems (both dimensions >= 128) go in launches of their own: the kernel then works on 128 x 128 tiles
+            wide = [j for j, k in enumerate(probs) if k[2] >= 128 and k[3] >= 128]
+            narrow = [j for j, k in enumerate(probs) if not (k[2] >= 128 and k[3] >= 128)]
+            for idx in (wide, narrow):
+                for a in range(0, len(idx), 96):
+                    sel = idx[a:a + 96]
+                    launches.append((dtype, [probs[j] for j in sel], n_seg, np.ascontiguousarray(dy_t[sel]), np.ascontiguousarray(x_t[sel]),
+                                     np.ascontiguousarray(m_t[sel]), total))
+                    total += len(sel) * n_seg * 20
+                    total = (total + 15) & ~15
+        st = self._cat_stage
+        if st is not None:
+            st[2].synchronize()           # the previous pass's table copy has left the pinned buffer
+        if st is None or st[0].numel() < total:
+            cap = max(total * 2, 1 << 20)
+            st = self._cat_stage = (torch.empty(cap, dtype=torch.uint8, pin_memory=True), torch.empty(cap, dtype=torch.uint8, device=self.dev), torch.cuda.Event())
+        host = st[0].numpy()
+        for dtype, probs, n_seg, dy_t, x_t, m_t, off in launches:
+            n = len(probs) * n_seg
+            host[off:off + 8 * n] = dy_t.reshape(-1).view(np.uint8)
+            host[off + 8 * n:off + 16 * n] = x_t.reshape(-1).view(np.uint8)
+            host[off + 16 * n:off + 20 * n] = m_t.reshape(-1).view(np.uint8)
+        st[1][:total].copy_(st[0][:total], non_blocking=True)
+        st[2].record()
+        base = st[1].data_ptr()
+        for dtype, probs, n_seg, dy_t, x_t, m_t, off in launches:
+            n = len(probs) * n_seg
+            O.dw_cat(dtype, [(k[0], k[1], k[2], k[3], k[4], k[5], k[6]) for k in probs], n_seg, base + off, base + off + 8 * n, base + off + 16 * n)
 
     def report(self):
         return {"instances": self.n_inst, "captures": self.captures,

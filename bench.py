@@ -434,7 +434,7 @@ def secondary_block():
     process's measurements are done)"""
     import subprocess
     py, nav = sys.executable, os.path.join(ROOT, "bench_nav.py")
-    common = ["--steps", "6", "--warmup", "6", "--no-cpu-baseline", "--no-host-loop", "--no-profile"]      # (warm-up: the step instances are captured on first sight of a shape key)
+    common = ["--steps", "10", "--warmup", "10", "--no-cpu-baseline", "--no-host-loop", "--no-profile"]      # (warm-up: the step instances are captured on first sight of a shape key)
     runs = {"config3_icod_magicL_teacher_magicS_student": ["--icod", "--hidden", "128", "--teacher-hidden", "768", "--instr-min", "20", "--instr-max", "80",
                                                           "--hops-min", "4", "--hops-max", "7", "--max-action-len", "15"],
             "config5_rxr_magicL_navigator_loop": []}

@@ -107,6 +107,7 @@ class NavPlanner:
                 env._pano_plan_cache = self._pano_cache
             except AttributeError:
                 pass
+        self._flat = {}                            # episode -> (flattened walked path, [segments consumed])
         self._dtw = {}                             # episode -> (nodes consumed, DTW row) of the walked path
         self._ref_idx = {}                         # episode -> its ground-truth path as indices of the scan's dense distance table
         self.t = 0
@@ -446,7 +447,11 @@ class NavPlanner:
                 dist, gt = env.shortest_distances[scan], ob["gt_path"]
                 if self.expert == "ndtw":
                     from . import hostplan
-                    walked = sum(self.traj[i]["path"], [])
+                    segs = self.traj[i]["path"]                      # the walked path, flattened incrementally (was sum(segs, []): quadratic in the episode's length)
+                    walked, k = self._flat.setdefault(i, ([], [0]))
+                    for p in segs[k[0]:]:
+                        walked.extend(p)
+                    k[0] = len(segs)
                     n0, row = self._dtw.get(i, (0, [0.0] + [math.inf] * len(gt)))
                     if hostplan.lib() is not None:
                         # native rows (csrc/hostplan.c: the same recurrence, the same order of additions and comparisons): the walked prefix, then

@@ -75,12 +75,17 @@ class _Block:
         st = self.stage_np
         for k, a in arrays.items():
             o, n, shape, dt = self.layout[k]
-            a = np.ascontiguousarray(a)
+            if a.__class__ is not np.ndarray:
+                a = np.asarray(a)
             if a.dtype == np.bool_:
                 a = a.view(np.uint8)
             if a.shape != shape:
                 raise ValueError(f"step instance: array {k!r} has shape {a.shape}, the captured shape is {shape}")
-            st[o:o + n] = a.astype(dt, copy=False).reshape(-1).view(np.uint8)
+            if a.dtype != dt:
+                a = a.astype(dt)
+            elif not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a)
+            st[o:o + n] = a.reshape(-1).view(np.uint8)
         self.dbuf.copy_(self.stage, non_blocking=True)
 
 

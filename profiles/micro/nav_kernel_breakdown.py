@@ -99,6 +99,12 @@ for _ in range(5 if a.graphs else 2):
     print(f"warm-up iteration: {1e3 * (time.perf_counter() - t0):.0f} ms", ro.graph_report() if a.graphs else "")
 from magic_amd.host import nav_rollout as _NR
 _NR._T["acc"].clear()
+if os.environ.get("NAV_GC_FREEZE"):
+    import gc
+    gc.collect()
+    gc.freeze()            # the model, the captured instances and their graphs leave the collector's generations: later collections scan only what an iteration made
+import gc as _gc
+_gc.callbacks.append(lambda phase, info: print(f"   [gc] generation {info['generation']} collected {info.get('collected', 0)}", flush=True) if phase == "stop" and info["generation"] >= 1 else None)
 for _ in range(a.iters):
     t0 = time.perf_counter()
     dec, t_f, t_b = iteration()

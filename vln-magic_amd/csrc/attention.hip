@@ -650,6 +650,10 @@ __global__ __launch_bounds__(512) void attn_bwd_ks_kernel(AttnParams p) {
     load_rows<T>(sQ, (const T*)p.q + ((long long)b * p.Nq + q0) * p.ldq + h * HD, p.ldq, nq, 64);
     const T* dOg = (const T*)p.dctx + ((long long)b * p.Nq + q0) * p.H + h * HD;
     load_rows<T>(sdO, dOg, p.H, nq, 64);
+    // a slab whose probabilities are ALL zero for this query tile (keys behind the instruction's padding: exp(-10000 - max) = 0 exactly in fp32)
+    // contributes nothing to dQ, dK or dV: the wave skips its products and -- when accumulating -- the read-modify-write of its 64 keys' gradient
+    // rows (RxR batches pad ~40 % of the 512 cached keys; that traffic was the largest part of a launch)
+    bool live = false;
     if (act) {
       const T* Pg = (const T*)p.P + prow0 * p.ldp;
       vec zk[8], zp[8];                        // all 16 loads of the lane in flight before the first LDS store
@@ -661,12 +665,17 @@ __global__ __launch_bounds__(512) void attn_bwd_ks_kernel(AttnParams p) {
         if (kbase + r < p.Nk) zk[i] = *(const vec*)(Kg + (long long)(kbase + r) * p.ldkv + ch * 8);
         if (r < nq && kbase + ch * 8 < p.ldp) zp[i] = *(const vec*)(Pg + (long long)r * p.ldp + kbase + ch * 8);
       }
+      typedef unsigned uv4 __attribute__((ext_vector_type(4)));
+      unsigned nzb = 0u;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int r = i * 8 + (lane >> 3), ch = lane & 7;
         *(vec*)(sKw + r * DS + ch * 8) = zk[i];
         *(vec*)(sSw + sw64(r, ch * 8)) = zp[i];
+        const uv4 u = __builtin_bit_cast(uv4, zp[i]);
+        nzb |= (u[0] | u[1] | u[2] | u[3]) & 0x7FFF7FFFu;          // (-0 counts as zero)
       }
+      live = __ballot(nzb != 0u) != 0ull;
     }
     {
       const int r = tid >> 3, ch = tid & 7;
@@ -682,7 +691,30 @@ __global__ __launch_bounds__(512) void attn_bwd_ks_kernel(AttnParams p) {
     }
     __syncthreads();
     f32x4 oq[4][4];
-    if (act) {
+    if (act && !live) {
+      // dead slab: a zero share of dQ; in the storing (non-accumulating) form also zero gradient rows for its keys
+      WAVE_FENCE();
+      float* part = (float*)sKw;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) *(f32x4*)(part + (i * 64 + lane) * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (!(p.acc_kv || q0 > 0)) {
+        tv4 z4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z4[r] = from_f<T>(0.f);
+#pragma unroll
+        for (int jk = 0; jk < 4; ++jk) {
+          const int key = kbase + jk * 16 + c;
+          if (key < p.Nk) {
+#pragma unroll
+            for (int jd = 0; jd < 4; ++jd) {
+              *(tv4*)((T*)p.dv + ((long long)b * p.Nk + key) * p.lddkv + h * HD + jd * 16 + 4 * g) = z4;
+              *(tv4*)((T*)p.dk + ((long long)b * p.Nk + key) * p.lddkv + h * HD + jd * 16 + 4 * g) = z4;
+            }
+          }
+        }
+      }
+    }
+    if (act && live) {
       f32x4 acc[4][4];                        // dP^T: rows = keys 16 jk + 4 g + r of the slab, column = query 16 jq + c
       h16x8<T> vf[4][2];                      // this wave's V slab as A fragments (row = key, k = head dim), straight from global (L2): dead after this product
 #pragma unroll

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-WHAT=${@:-bench prof pmc nav}
+WHAT=${@:-bench prof pmc nav navprof}
 EAGER="--mode eager --steps 6 --warmup 3 --no-cpu-baseline --no-profile --no-parity --no-secondary"
 for w in $WHAT; do
 case $w in
@@ -33,8 +33,16 @@ pmc)
   rm -rf $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d
   head -c 1500 $O/r05_pmc_kernels.json; echo ;;
 nav)
-  python3 $R/bench_nav.py > $O/r05_bench_nav.json 2> $O/r05_bench_nav.err
-  python3 $R/bench_nav.py --icod --hidden 128 --teacher-hidden 768 --instr-min 20 --instr-max 80 --hops-min 4 --hops-max 7 --max-action-len 15 --no-cpu-baseline --no-host-loop > $O/r05_bench_nav_icod.json 2> $O/r05_bench_nav_icod.err
+  python3 $R/bench_nav.py --steps 10 --warmup 10 > $O/r05_bench_nav.json 2> $O/r05_bench_nav.err
+  python3 $R/bench_nav.py --icod --hidden 128 --teacher-hidden 768 --instr-min 20 --instr-max 80 --hops-min 4 --hops-max 7 --max-action-len 15 --steps 10 --warmup 10 --no-cpu-baseline --no-host-loop > $O/r05_bench_nav_icod.json 2> $O/r05_bench_nav_icod.err
   tail -c 300 $O/r05_bench_nav.json; echo; tail -c 300 $O/r05_bench_nav_icod.json; echo ;;
+navprof)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05_navprof -- python3 $R/bench_nav.py --steps 4 --warmup 8 --no-cpu-baseline --no-host-loop --no-profile > $O/r05_bench_nav_under_rocprof.json 2> $O/r05_navprof.err || exit 1
+  find $O/r05_navprof -name "*kernel_stats.csv" -exec cp {} $O/r05_kernel_stats_nav.csv \;
+  rm -rf $O/r05_navprof
+  python3 $R/profiles/micro/nav_kernel_breakdown.py --graphs --iters 8 > $O/r05_nav_breakdown.txt 2>&1
+  MAGIC_NAV_TIMERS=1 python3 $R/profiles/micro/nav_kernel_breakdown.py --graphs --iters 6 2>&1 | grep -A12 "^host sections" > $O/r05_nav_host_sections.txt
+  python3 $R/profiles/micro/nav_kernel_breakdown.py --graphs --icod --iters 8 2>&1 | grep "^iteration\|^instrumented" > $O/r05_nav_breakdown_icod.txt
+  grep "^iteration" $O/r05_nav_breakdown.txt | tail -4 ;;
 esac
 done

@@ -42,6 +42,54 @@ class _MSE(torch.autograd.Function):
         return (ctx.ds.float() * g).to(ctx.in_dtype), None, None, None
 
 
+class _MseMulti(torch.autograd.Function):
+    """`vals = _MseMulti.apply(meta, x0, y0, x1, y1, ...)`: up to ten mse_loss terms of one distillation step in ONE launch (csrc/loss.hip
+    mse_multi_kernel) -- vals[i] = k_i * norm_i * sum w (x_i - y_i)^2 with k_i = coef_i * coef_dev_i[0], and the gradient wrt x_i from the same
+    pass.  meta[i] = dict(norm, coef, coef_dev (0-d / 1-element device tensor or None), w (sample weights [outer] or None)).  The navigator's MAKD
+    step (host/makd_nav.compute_kd_losses_fused) calls this once per step and direction instead of nine `_MSE` nodes with their casts,
+    multiplications by the ability weights and running sums."""
+
+    @staticmethod
+    def forward(ctx, meta, *xy):
+        n = len(meta)
+        dev = xy[0].device
+        slots = torch.zeros(n, dtype=torch.float32, device=dev)
+        probs, dss, kv = [], [], []
+        for i, m in enumerate(meta):
+            s, t = xy[2 * i], xy[2 * i + 1]
+            _need_cuda(s, t, m.get("w"))
+            dt = s.dtype if s.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32
+            sc, tc = s.detach().to(dt).contiguous(), t.detach().to(dt).contiguous()
+            outer = sc.shape[0]
+            inner = sc.numel() // outer
+            ds = torch.empty_like(sc) if s.requires_grad else None
+            w = m.get("w")
+            cd = m.get("coef_dev")
+            probs.append(dict(s=sc, t=tc, outer=outer, inner=inner, s_stride=inner, t_stride=inner, w=None if w is None else w.detach().float().contiguous(),
+                              rows_per_w=1, norm=m["norm"], coef=m["coef"], coef_dev=cd, loss=slots[i:i + 1], ds=ds, g_stride=inner))
+            dss.append(ds)
+            kv.append((float(m["coef"]), cd))
+        O.mse_multi(probs)
+        # the VALUES carry the same factors as the gradients: host coefficient x device-side ability weight
+        host = torch.tensor([k[0] for k in kv], dtype=torch.float32).to(dev, non_blocking=True) if any(k[0] != 1.0 for k in kv) else None
+        vals = slots if host is None else slots * host
+        if any(k[1] is not None for k in kv):
+            vals = vals * torch.stack([(k[1].reshape(()) if k[1] is not None else torch.ones((), device=dev)) for k in kv])
+        ctx.dss, ctx.dtypes = dss, [xy[2 * i].dtype for i in range(n)]
+        ctx.set_materialize_grads(False)
+        return vals
+
+    @staticmethod
+    def backward(ctx, g):
+        out = [None]
+        for i, ds in enumerate(ctx.dss):
+            if ds is None or g is None:
+                out += [None, None]
+            else:
+                out += [(ds * g[i]).to(ctx.dtypes[i]), None]
+        return tuple(out)
+
+
 class _CERows(torch.autograd.Function):
     """`F.cross_entropy(logits, targets, ignore_index=..., reduction='none')` of the navigator's step loop (agent_base.py:152 criterion,
     agent.py:1007-1021) as ONE launch: the row losses and the unit gradient softmax(logits) - onehot (zero on ignored rows) come out of the

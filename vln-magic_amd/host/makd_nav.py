@@ -82,3 +82,78 @@ def compute_kd_losses(t, s_out, t_out, heads, acc, *, role="t2s", temperature=2.
             p = K.kd_loss(s_out["nav_logits"], t_out["nav_logits"].detach(), temperature, t_sample_weights=w, loss_type=loss_type)
         add("predict_loss", p * k(4))
     return acc
+
+
+VEC_KEYS = LOSS_KEYS            # order of the running vector of compute_kd_losses_fused
+
+
+def compute_kd_losses_fused(t, s_out, t_out, heads, acc, *, role="t2s", temperature=2.0, weights=None):
+    """compute_kd_losses for the configuration the rollout loop runs (all five abilities, feature + attention + logit terms, MKRW `weights`
+    or none) with the nine mse terms of the step in ONE launch and ONE autograd node (kd_loss._MseMulti) and the running sums as one vector:
+    acc["_vec"] [10] in VEC_KEYS order (`kd_terms(acc)` turns it into the dict compute_kd_losses keeps).  Same values and gradients
+    (tests/test_rollout_gpu.py runs both against the oracle)."""
+    import torch
+    loss_type = "sum" if role == "t2s" else "mean"
+    w = t_out.get("sample_weights")
+    hmin = min(s_out["txt_attns"].shape[1], t_out["txt_attns"].shape[1])
+    half = 1.0 if weights is not None else 0.5
+    sn, tn = s_out["nav_outs"], t_out["nav_outs"]
+    terms = []                                   # (slot, x, y, ability, host coefficient)
+
+    def feat(slot, name, a, b, ab, c=1.0):
+        if role == "t2s":
+            terms.append((slot, heads[name](a), b.detach(), ab, c))
+        else:
+            terms.append((slot, a, heads[name](b).detach(), ab, c))
+
+    def attn(slot, a, b, ab):
+        terms.append((slot, a, b.detach(), ab, 1.0))
+
+    if t == 0:
+        feat(0, "txt_emb_w", s_out["txt_embeds"], t_out["txt_embeds"], 0)
+        attn(1, s_out["txt_attns"][:, :hmin], t_out["txt_attns"][:, :hmin], 0)
+    feat(2, "kdl_img_w", s_out["pano_embeds"], t_out["pano_embeds"], 1, half)
+    feat(3, "kdl_avg_img_w", s_out["pano_fused_embeds"], t_out["pano_fused_embeds"], 1, half)
+    attn(4, s_out["img_attns"], t_out["img_attns"], 1)
+    feat(5, "global_cross_w", sn["gmap_embeds"], tn["gmap_embeds"], 2)
+    attn(6, sn["gmap_attns"][:, :hmin], tn["gmap_attns"][:, :hmin], 2)
+    feat(7, "local_cross_w", sn["vp_embeds"], tn["vp_embeds"], 3)
+    attn(8, sn["vp_attns"][:, :hmin], tn["vp_attns"][:, :hmin], 3)
+    on_dev = weights is not None and torch.is_tensor(weights) and weights.is_cuda
+    meta, xy = [], []
+    for slot, x, y, ab, c in terms:
+        norm = 1.0 if loss_type == "sum" else 1.0 / x.numel()
+        if weights is not None and not on_dev:
+            c = c * float(weights[ab])           # (host-side MKRW scalars)
+        meta.append(dict(norm=norm, coef=c, coef_dev=weights[ab:ab + 1] if on_dev else None, w=w))
+        xy += [x, y]
+    vals = K._MseMulti.apply(meta, *xy)
+    vec = acc.get("_vec")
+    if vec is None:
+        vec = torch.zeros(len(VEC_KEYS), dtype=torch.float32, device=vals.device)
+    idx = _slot_index(tuple(tm[0] for tm in terms), vals.device)
+    p = K.kd_loss(s_out["nav_logits"], t_out["nav_logits"].detach(), temperature, t_sample_weights=w, loss_type=loss_type)
+    if weights is not None:
+        p = p * weights[4]
+    acc["_vec"] = vec.index_add(0, idx, torch.cat([vals, p.reshape(1)]))
+    return acc
+
+
+_SLOT_IDX = {}
+
+
+def _slot_index(slots, dev):
+    key = (slots, str(dev))
+    v = _SLOT_IDX.get(key)
+    if v is None:
+        import torch
+        v = _SLOT_IDX[key] = torch.tensor(list(slots) + [9], dtype=torch.int64, device=dev)
+    return v
+
+
+def kd_terms(acc):
+    """the per-key running sums of either accumulator form as a dict (compute_kd_losses' own form passes through)"""
+    vec = acc.get("_vec") if isinstance(acc, dict) else None
+    if vec is None:
+        return acc
+    return {k: vec[i] for i, k in enumerate(VEC_KEYS)}

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import lanes
 from . import ops as O
-from .makd_nav import compute_kd_losses
+from .makd_nav import compute_kd_losses, compute_kd_losses_fused, kd_terms
 from .nav_plan import IGNORE, NavPlanner
 from .kd_loss import ce_rows_loss, exponential_decay
 
@@ -143,6 +143,7 @@ def _tk(name):
         _T["last"] = now
 
 
+FUSED_MAKD = os.environ.get("MAGIC_NAV_FUSED_MAKD", "1") != "0"      # a step's mse distillation terms in one launch (makd_nav.compute_kd_losses_fused)
 LANES = os.environ.get("MAGIC_NAV_LANES", "1") != "0"      # the rollouts of `run_interleaved` as gradient lanes on streams of their own
 
 
@@ -510,13 +511,19 @@ class NavRollout:
                     if grad:
                         learned = self.kd.get("ability_weight") == "learned_weight"
                         rw_t = None if (rw_seq is None or learned) else rw_seq[t]
-                        kdl = compute_kd_losses(t, s_out, t_out, self.heads, kdl, role="t2s", temperature=self.kd["temperature"], weights=rw_t,
-                                                learned=st.vln_bert if learned else None)
+                        if learned or not FUSED_MAKD:
+                            kdl = compute_kd_losses(t, s_out, t_out, self.heads, kdl, role="t2s", temperature=self.kd["temperature"], weights=rw_t,
+                                                    learned=st.vln_bert if learned else None)
+                        else:            # the step's nine mse terms in one launch / one autograd node, the running sums as one vector
+                            kdl = compute_kd_losses_fused(t, s_out, t_out, self.heads, kdl, role="t2s", temperature=self.kd["temperature"], weights=rw_t)
                         if tt_grad:      # reverse direction (agent.py:1026): teacher tensors vs the student's, projected by the student's heads
                             t_ml_loss = t_ml_loss + t_ce.sum()
                             s_out["sample_weights"] = exponential_decay(ce.detach(), self.kd["decay"])
-                            t_kdl = compute_kd_losses(t, t_out, s_out, self.heads, t_kdl, role="s2t", temperature=self.kd["temperature"],
-                                                      weights=rw_t, learned=te.vln_bert if learned else None)   # s_model = the teacher (:555-556)
+                            if learned or not FUSED_MAKD:
+                                t_kdl = compute_kd_losses(t, t_out, s_out, self.heads, t_kdl, role="s2t", temperature=self.kd["temperature"],
+                                                          weights=rw_t, learned=te.vln_bert if learned else None)   # s_model = the teacher (:555-556)
+                            else:
+                                t_kdl = compute_kd_losses_fused(t, t_out, s_out, self.heads, t_kdl, role="s2t", temperature=self.kd["temperature"], weights=rw_t)
                 _tk("loss + distillation terms")
                 yield t           # the step is launched; nothing below is needed before its actions are (run_interleaved switches here)
                 _tk("(outside)")
@@ -543,6 +550,7 @@ class NavRollout:
         ml = ml_loss / Bn
         kd_sum, total = None, ml
         if te is not None and grad:
+            kdl = kd_terms(kdl)
             kd_sum = sum(kdl.values()) / Bn
             total = self.kd["alpha"] * kd_sum + (1 - self.kd["alpha"]) * ml
         traj = pl.finish(torch.stack(stop_probs).cpu().numpy())
@@ -550,6 +558,7 @@ class NavRollout:
                    steps=steps, planner=pl)
         if tt_grad:
             ta = self.kd.get("t_alpha", self.kd["alpha"])
+            t_kdl = kd_terms(t_kdl)
             out["t_kdl_terms"] = t_kdl
             out["t_loss"] = ta * (sum(t_kdl.values()) * w_host[0]) + (1 - ta) * (t_ml_loss * w_host[0] / Bn)       # (uniform train_ml)
         return out

@@ -87,3 +87,46 @@ def test_learned_ability_weights_receive_the_gradient_the_oracle_autograd_gives(
     for n in LEARNED_NAMES:
         torch.testing.assert_close(lw[n].grad.cpu().double(), lw_ref[n].grad, rtol=5e-5, atol=1e-6, msg=n)
         assert lw_ref[n].grad.abs().item() > 0
+
+
+def test_fused_step_form_matches_the_reference_method_and_the_per_term_gradients(golden_dir):
+    """makd_nav.compute_kd_losses_fused (the step's nine mse terms in ONE launch / ONE autograd node, running sums as a vector -- what the rollout
+    loop calls) against the same golden numbers of the reference's own method ('RW' and unweighted, both directions, t = 0 and t > 0), and its
+    input gradients against the per-term form's."""
+    from magic_amd.host.makd_nav import compute_kd_losses_fused, kd_terms
+    fx, heads, s_out, t_out = _fixture(golden_dir)
+    rw = fx["rw"].to(DEV)
+    n = 0
+    for name, want in fx["cases"].items():
+        parts = name.split("_")
+        role, t = parts[0], int(parts[1][1:])
+        if "learned" in name or (role == "t2s" and parts[-1] != "sum"):
+            continue                       # (the fused form serves the rollout loop's configuration: MKRW or no ability weights, t2s 'sum' / s2t 'mean')
+        weights = None if parts[2] == "None" else rw
+        a, b = (s_out, t_out) if role == "t2s" else (t_out, s_out)
+        got = kd_terms(compute_kd_losses_fused(t, a, b, heads, {}, role=role, temperature=2.0, weights=weights))
+        for k in want:
+            torch.testing.assert_close(torch.as_tensor(float(got[k])), want[k], rtol=3e-5, atol=2e-6, msg=f"{name}:{k}")
+        for k in set(LOSS_KEYS) - set(want):
+            assert float(got[k]) == 0.0, (name, k)
+        n += 1
+    assert n >= 4
+
+    def grads(fn):
+        s2 = {k: ({kk: vv.clone().requires_grad_(vv.is_floating_point()) for kk, vv in v.items()} if isinstance(v, dict)
+                  else (v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() else v)) for k, v in s_out.items()}
+        acc = fn(s2)
+        sum(kd_terms(acc).values()).backward()
+        out = {}
+        for k, v in s2.items():
+            for kk, vv in (v.items() if isinstance(v, dict) else [(None, v)]):
+                if torch.is_tensor(vv) and vv.grad is not None:
+                    out[(k, kk)] = vv.grad
+        return out
+    id_heads = {n_: (lambda x: x) for n_ in heads}              # (identity heads: the fixture's head wrapper detaches its input)
+    same_w = {k: v for k, v in t_out.items()}
+    ga = grads(lambda s2: compute_kd_losses(1, s2, same_w, id_heads, defaultdict(float), role="s2t", temperature=2.0, weights=rw))
+    gb = grads(lambda s2: compute_kd_losses_fused(1, s2, same_w, id_heads, {}, role="s2t", temperature=2.0, weights=rw))
+    assert set(ga) == set(gb) and len(ga) >= 6
+    for k in ga:
+        torch.testing.assert_close(gb[k], ga[k], rtol=1e-5, atol=1e-8, msg=str(k))

@@ -133,6 +133,71 @@ __device__ __forceinline__ void mma_tile16(const Hh* sA, const Hh* sB, int wr, i
       for (int j = 0; j < NT_; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
   }
 }
+// ---- conflict-free LDS images of the 64 x 64 tile (round 5; 16-bit operands) ------------------------------------------------------------------
+// The padded images above cost every gemm_block kernel a constant 1/3 of its LDS cycles in bank conflicts (profiles/r04_pmc_kernels.json): the
+// k-contiguous [out][k] image is read with ds_read_b128, whose 16-lane groups are not contiguous (MI355X_MICROARCH.md, LDS) -- with a 144-byte
+// pitch one pair of lanes per group shares a slot; the natural [k][out] image is read with ds_read_b64_tr_b16, where a 32-lane half reads rows
+// {8g .. 8g+3} of two groups: windows 36 banks apart that overlap pairwise.  MAGIC_GEMM_LDS_SW (default 1, compile time):
+//  * k-contiguous images: rows of exactly 64 elements, the 16-byte chunk c of row r stored at c ^ ((r >> 1) & 7) (the wide-tile kernel's image:
+//    0.000 conflict share measured);
+//  * TN (both operands natural): the contraction's k order is free, so a group g takes rows 4g .. 4g+3 and 16+4g .. 16+4g+3 of a 32-row step -- a half
+//    reads eight CONSECUTIVE rows -- at a pitch of 80 elements (40 banks: eight distinct multiples of 8 mod 64);
+//  * NN's natural B keeps the padded image (its k order is tied to A's ds_read_b128 fragment).
+// Measured (profiles/micro/r05_ab_lds_swizzle.txt, same box, three rounds each): the conflict share of the gemm_block kernels drops from 0.30-0.33 to
+// 0.00, the M ~ 600 / K >= 768 navigator GEMMs (K-group kernel) get 3-6 % faster per launch, the concatenated dW launch 5 % -- and the headline step
+// (K = 128-512, 1-8 k-tiles per launch) gets 6-8 us SLOWER with the swizzled k-contiguous images (the extra address arithmetic of a fragment read
+// sits on a chain that is latency-bound, not LDS-bound) and does not move with the permuted natural images.  Hence the default, mode 4: swizzled
+// k-contiguous images in the K-group kernel only (its launches all have K >= 768), permuted natural images for every TN launch.
+// 0: padded images everywhere; 1: both forms everywhere; 2: swizzled k-contiguous images everywhere; 3: permuted natural images only.
+#ifndef MAGIC_GEMM_LDS_SW
+#define MAGIC_GEMM_LDS_SW 4
+#endif
+#define GB_NATP 80          // pitch of the permuted natural image of a 64-wide tile
+template <typename Hh, bool KC, bool PERM, bool SWK>
+__device__ __forceinline__ void store_sw(const TileLoader<Hh, KC, 64>& l, Hh* s) {
+  constexpr int VE = 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = (threadIdx.x & 255) + 256 * i;
+    if constexpr (KC) {
+      const int row = id >> 3, cv = id & 7;
+      if constexpr (SWK) *(typename TT<Hh>::vec*)(s + row * 64 + ((cv ^ ((row >> 1) & 7)) * VE)) = l.v[i];
+      else *(typename TT<Hh>::vec*)(s + row * TT<Hh>::STRIDE + cv * VE) = l.v[i];
+    } else {
+      constexpr int P = PERM ? GB_NATP : TT<Hh>::SN;
+      const int r = id >> 3, ov = id & 7;
+      *(typename TT<Hh>::vec*)(s + r * P + ov * VE) = l.v[i];
+    }
+  }
+}
+template <bool A_KC, bool B_KC, bool SWK, bool SWP_, typename Hh>
+__device__ __forceinline__ void mma_tile_sw(const Hh* sA, const Hh* sB, int wr, int wc, int lane, f32x4 (&acc)[2][2]) {
+  constexpr bool PERM = !A_KC && !B_KC && SWP_;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  auto rd = [&](const Hh* s, bool kc, int out0, int ks) -> h16x8<Hh> {
+    if (kc) {
+      const int row = out0 + (lane & 15);
+      if constexpr (SWK) return *(const h16x8<Hh>*)(s + row * 64 + (((ks * 4 + g) ^ ((row >> 1) & 7)) * 8));
+      else return *(const h16x8<Hh>*)(s + row * TT<Hh>::STRIDE + ks * 32 + 8 * g);
+    }
+    if (PERM) return lds_tr8(s + (ks * 32 + 4 * g + q) * GB_NATP + out0 + 4 * pp, 16 * GB_NATP);
+    return lds_tr8(s + (ks * 32 + 8 * g + q) * TT<Hh>::SN + out0 + 4 * pp, 4 * TT<Hh>::SN);
+  };
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    h16x8<Hh> a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[i] = rd(sA, A_KC, (wr * 2 + i) * 16, ks);
+      b[i] = rd(sB, B_KC, (wc * 2 + i) * 16, ks);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+  }
+}
+
 template <bool A_KC, bool B_KC, int NT_>
 __device__ __forceinline__ void mma_tile(const bf16* sA, const bf16* sB, int wr, int wc, int lane, f32x4 (&acc)[NT_][NT_]) { mma_tile16<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc); }
 template <bool A_KC, bool B_KC, int NT_>
@@ -326,6 +391,8 @@ __device__ __forceinline__ void dw_seam(const GemmParams& p, const f32x4 (&acc)[
 // accumulators from its own LDS images -- one barrier round advances KG tiles -- and the partial sums are added through LDS at the end.
 // For problems with fewer tiles than CUs and a long K (the M ~ 600 navigator-step GEMMs at H = 768: 120 tiles, 48 K-tiles) the time of
 // a launch is (K-tiles) x (latency of one barrier round); the groups divide the rounds by KG without an fp32 round trip through HBM.
+// elements of one operand image of the 64 x 64 tile: the padded form (64 x 72) or the permuted natural form (64 x 80)
+template <typename T> struct GBI { static constexpr int N = (sizeof(T) == 2 && TT<T>::BK * GB_NATP > BM * TT<T>::STRIDE) ? TT<T>::BK * GB_NATP : BM * TT<T>::STRIDE; };
 template <typename T, int LAYOUT, int NT_ = 2, int KG = 1>
 __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, const int by, const int bzz, T* sA, T* sB) {
   constexpr int BK = TT<T>::BK, STRIDE = TT<T>::STRIDE;
@@ -334,6 +401,11 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
   static_assert(TM * TT<T>::STRIDE >= TT<T>::BK * SN_, "LDS image sizes");
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
   constexpr int NE = NT_ * NT_ * 4;                  // accumulator elements per lane
+  constexpr int SWM = MAGIC_GEMM_LDS_SW;
+  constexpr bool SW16 = sizeof(T) == 2 && NT_ == 2;
+  constexpr bool SWK = SW16 && (SWM == 1 || SWM == 2 || (SWM == 4 && KG > 1));                     // swizzled k-contiguous images
+  constexpr bool SWP = SW16 && (SWM == 1 || SWM == 3 || SWM == 4) && LAYOUT == 2 && KG == 1;     // permuted natural images (both operands natural)
+  constexpr bool SW = SWK || SWP;                                                                     // (every caller's images hold GBI<T>::N elements)
 
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, kg = threadIdx.x >> 8;
   const int wr = wid >> 1, wc = wid & 1;
@@ -428,8 +500,13 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
       if (r + d < rounds) {           // block-uniform
-        la[d].store(sA);
-        lb[d].store(sB);
+        if constexpr (SW) {
+          store_sw<T, A_KC, SWP, SWK>(la[d], sA);
+          store_sw<T, B_KC, SWP, SWK>(lb[d], sB);
+        } else {
+          la[d].store(sA);
+          lb[d].store(sB);
+        }
         __syncthreads();
         if (r + d + PD < rounds) {
           la[d].load(A, p.lda, m0, (kt0 + (r + d + PD) * KG + kg) * BK, p.M, kend);
@@ -438,13 +515,16 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
         if constexpr (sizeof(T) == 4) {
           if (x3) mma_tile_x3<A_KC, B_KC, NT_>((const float*)sA, (const float*)sB, wr, wc, lane, acc);
           else mma_tile<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc);
+        } else if constexpr (SW) {
+          mma_tile_sw<A_KC, B_KC, SWK, SWP>(sA, sB, wr, wc, lane, acc);
         } else {
           mma_tile<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc);
         }
         if (do_bgrad && tid < TM) {
           float s = 0.f;
+          constexpr int NP = SWP ? GB_NATP : SN_;
 #pragma unroll 8
-          for (int k = 0; k < BK; ++k) s += to_f(sA[k * SN_ + tid]);      // TN: A is held as the natural [k][out] image
+          for (int k = 0; k < BK; ++k) s += to_f(sA[k * NP + tid]);      // TN: A is held as the natural [k][out] image
           bsum += s;
         }
         __syncthreads();
@@ -522,8 +602,8 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
 
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) T sA[BM * TT<T>::STRIDE];
-  __shared__ __attribute__((aligned(16))) T sB[BN * TT<T>::STRIDE];
+  __shared__ __attribute__((aligned(16))) T sA[GBI<T>::N];
+  __shared__ __attribute__((aligned(16))) T sB[GBI<T>::N];
   gemm_block<T, LAYOUT>(p, blockIdx.x, blockIdx.y, blockIdx.z, sA, sB);
 }
 
@@ -534,8 +614,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 // padded to a multiple of 8 (the surplus workgroups exit at once).
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_xcd_kernel(GemmParams p, int nx, int ny, int ny8) {
-  __shared__ __attribute__((aligned(16))) T sA[BM * TT<T>::STRIDE];
-  __shared__ __attribute__((aligned(16))) T sB[BN * TT<T>::STRIDE];
+  __shared__ __attribute__((aligned(16))) T sA[GBI<T>::N];
+  __shared__ __attribute__((aligned(16))) T sB[GBI<T>::N];
   const int per_z = nx * ny8;
   const int z = blockIdx.x / per_z, l2 = blockIdx.x - z * per_z;
   const int xcd = l2 & 7, slot = l2 >> 3;
@@ -795,8 +875,8 @@ struct GroupedParams { GemmParams p[GROUP_MAX]; int start[GROUP_MAX + 1]; int cn
 
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupedParams gp) {
-  __shared__ __attribute__((aligned(16))) T sA[BM * TT<T>::STRIDE];
-  __shared__ __attribute__((aligned(16))) T sB[BN * TT<T>::STRIDE];
+  __shared__ __attribute__((aligned(16))) T sA[GBI<T>::N];
+  __shared__ __attribute__((aligned(16))) T sB[GBI<T>::N];
   const int id = blockIdx.x;
   int g = 0;
 #pragma unroll
@@ -838,8 +918,8 @@ struct DwBatch { DwProblem p[DW_MAX]; int start[DW_MAX + 1]; int cnt[DW_MAX]; in
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_dw_batch_kernel(DwBatch gp) {
-  __shared__ __attribute__((aligned(16))) T sA[BM * TT<T>::STRIDE];
-  __shared__ __attribute__((aligned(16))) T sB[BN * TT<T>::STRIDE];
+  __shared__ __attribute__((aligned(16))) T sA[GBI<T>::N];
+  __shared__ __attribute__((aligned(16))) T sB[GBI<T>::N];
   const int id = blockIdx.x;
   int lo = 0, hi = gp.n - 1;                                   // last problem whose first workgroup is <= id (block-uniform)
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (id >= gp.start[mid]) lo = mid; else hi = mid - 1; }
@@ -888,9 +968,17 @@ struct DwCatBatch { DwCatProblem p[DW_MAX]; int start[DW_MAX + 1]; int n, n_seg;
 // form ran the MAGIC-L iteration's 3.8 TFLOP at 425 TFLOP/s)
 template <typename T, int NT_>
 __global__ __launch_bounds__(256) void gemm_dw_cat_kernel(DwCatBatch gp) {
-  constexpr int BK = TT<T>::BK, TM = 32 * NT_, SN_ = TT<T>::SN + (TM - 64), NE = NT_ * NT_ * 4, PD = (NT_ == 2) ? 3 : 2;
-  __shared__ __attribute__((aligned(16))) T sA[TM * TT<T>::STRIDE];
-  __shared__ __attribute__((aligned(16))) T sB[TM * TT<T>::STRIDE];
+  // Both operands are natural [k][out] images read through ds_read_b64_tr_b16.  With gemm_block's pitch (72 / 136 elements) and k order (a 16-lane
+  // group g reads rows 8g .. 8g+3, then 8g+4 .. 8g+7) the eight 32-byte row windows of a 32-lane half sit 36 banks apart and overlap pairwise: every
+  // such read pays half a cycle extra (the constant 1/3 conflict share of every gemm_block kernel, profiles/r04_pmc_kernels.json) and no padding removes
+  // it (rows 0 and 8 of a half collide for every pitch that keeps the windows aligned).  Here BOTH operands are natural, so the contraction's k order
+  // is free: group g takes rows 4g .. 4g+3, then 16+4g .. 16+4g+3 -- a half reads eight CONSECUTIVE rows -- and the pitch is TM + 16 elements
+  // (40 / 72 banks: r x pitch mod 64 = eight distinct multiples of 8): conflict-free.  fp32 operands keep the plain form (dword reads).
+  constexpr bool PERM = sizeof(T) == 2;
+  constexpr int BK = TT<T>::BK, TM = 32 * NT_, SN_ = PERM ? TM + 16 : TT<T>::SN + (TM - 64), NE = NT_ * NT_ * 4, PD = (NT_ == 2) ? 3 : 2;
+  constexpr int IMG = (TM * TT<T>::STRIDE > BK * SN_) ? TM * TT<T>::STRIDE : BK * SN_;
+  __shared__ __attribute__((aligned(16))) T sA[IMG];
+  __shared__ __attribute__((aligned(16))) T sB[IMG];
   const int id = blockIdx.x;
   int lo = 0, hi = gp.n - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (id >= gp.start[mid]) lo = mid; else hi = mid - 1; }
@@ -936,11 +1024,39 @@ __global__ __launch_bounds__(256) void gemm_dw_cat_kernel(DwCatBatch gp) {
 #pragma unroll
     for (int q = 0; q < PD; ++q) {
       if (live[q]) {                    // block-uniform
-        la[q].store(sA);
-        lb[q].store(sB);
+        if constexpr (PERM) {
+          constexpr int VE = TT<T>::VE, VPR = TM / VE;
+#pragma unroll
+          for (int i = 0; i < TM / 32; ++i) {
+            const int id2 = tid + 256 * i, r = id2 / VPR, ov = id2 % VPR;
+            *(typename TT<T>::vec*)(sA + r * SN_ + ov * VE) = la[q].v[i];
+            *(typename TT<T>::vec*)(sB + r * SN_ + ov * VE) = lb[q].v[i];
+          }
+        } else {
+          la[q].store(sA);
+          lb[q].store(sB);
+        }
         __syncthreads();
         live[q] = issue(q);
-        mma_tile<false, false, NT_>(sA, sB, wr, wc, lane, acc);
+        if constexpr (PERM) {
+          const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            h16x8<T> a[NT_], b[NT_];
+            const int r0 = (ks * 32 + 4 * g + qq) * SN_ + 4 * pp;
+#pragma unroll
+            for (int i = 0; i < NT_; ++i) {
+              a[i] = lds_tr8(sA + r0 + (wr * NT_ + i) * 16, 16 * SN_);
+              b[i] = lds_tr8(sB + r0 + (wc * NT_ + i) * 16, 16 * SN_);
+            }
+#pragma unroll
+            for (int i = 0; i < NT_; ++i)
+#pragma unroll
+              for (int j = 0; j < NT_; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+          }
+        } else {
+          mma_tile<false, false, NT_>(sA, sB, wr, wc, lane, acc);
+        }
         if (do_bgrad && tid < TM) {
           float s = 0.f;
 #pragma unroll 8

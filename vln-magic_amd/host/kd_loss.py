@@ -81,12 +81,16 @@ class _MseMulti(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        out = [None]
-        for i, ds in enumerate(ctx.dss):
-            if ds is None or g is None:
-                out += [None, None]
-            else:
-                out += [(ds * g[i]).to(ctx.dtypes[i]), None]
+        n = len(ctx.dss)
+        if g is None:
+            return (None,) * (1 + 2 * n)
+        live = [i for i, ds in enumerate(ctx.dss) if ds is not None]
+        gs = g.unbind(0)                                   # one op: n views
+        # ds_i * g_i for every term in one multi-tensor launch per dtype group instead of n select / mul / cast triples
+        scaled = torch._foreach_mul([ctx.dss[i] for i in live], [gs[i] for i in live]) if live else []
+        out = [None] * (1 + 2 * n)
+        for i, t in zip(live, scaled):
+            out[1 + 2 * i] = t if t.dtype == ctx.dtypes[i] else t.to(ctx.dtypes[i])
         return tuple(out)
 
 

@@ -342,6 +342,16 @@ int magic_seed_scale(const float* scale_dev);
 int magic_loss_assemble(const float* rows, int n_rows, const float* row_w, float row_scale, const float* kd_rows, int n_kd,
                         float* slots, const float* rw, float alpha, int has_kd, float* out, void* stream);
 
+/* Row dot / row gate: s[m] = x[m] . wx (+ e[m] . we) + b0 (+ b1) over rows of H elements (H a multiple of 128, <= 1024; wx / we / b fp32).
+ * mode 0: out_s[m] = s -- the value head's output Linear(512, 1) (`Critic`, agent.py:30,39; [LINEAGE DUET] state2value); mode 1: g = sigmoid(s),
+ * out[m, :] = e[m, :] g, gsave[m] = g -- the 'door' gate of the causal-intervention blocks (parser.py:129-142 do_add_method).  Backward: mode 0
+ * dy fp32 [M] -> dx = dy wx; mode 1 dout [M, H] -> ds = (dout . e) g (1 - g), de = dout g + ds we, dx = ds wx; dwx / dwe [H], db0 / db1 [1]
+ * accumulate (fp32, may be NULL); dx / de may be NULL. */
+int magic_rowgate_fwd(int dtype, int M, int H, int mode, const void* x, const void* e, const float* wx, const float* we,
+                      const float* b0, const float* b1, float* out_s, void* out, float* gsave, void* stream);
+int magic_rowgate_bwd(int dtype, int M, int H, int mode, const void* x, const void* e, const float* wx, const float* we, const float* gsave,
+                      const float* dy, const void* dout, void* dx, void* de, float* dwx, float* dwe, float* db0, float* db1, void* stream);
+
 /* Flat-buffer optimizer: pretrain_src/optim/adamw.py:53-112 + clip_grad_norm_ (grad_norm, r2r_magic_pretrain.json:22) */
 int magic_sumsq(long long n, const float* g, float* out, void* stream);
 int magic_adamw(long long n, float* p, float* g, float* m, float* v, void* shadow, int shadow_dtype,

@@ -1630,6 +1630,109 @@ extern "C" int magic_lndot_bwd(int dtype, int M, int H, const void* Y, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row dot / row gate (round 5): s[m] = x[m] . wx (+ e[m] . we) + b0 (+ b1), one wave per row, H any multiple of 128 up to 1024.
+//   mode 0 (dot):  out_s[m] = s                           -- the value head's 512 -> 1 Linear (`Critic.state2value[3]`, DUET lineage)
+//   mode 1 (gate): g = sigmoid(s), out[m, :] = e[m, :] g  -- the 'door' gate of the causal-intervention blocks (parser.py:129-142 do_add_method)
+// backward: mode 0  dx = dy wx ; mode 1  ds = (dout . e) g (1 - g), de = dout g + ds we, dx = ds wx; parameter gradients per block through LDS, one
+// atomic per element and block (dormant paths: no shipped script calls the value head, no shipped config switches the gate on).
+template <typename T>
+__global__ __launch_bounds__(256) void rowgate_fwd_kernel(int M, int H, int mode, const T* x, const T* e, const float* wx, const float* we,
+                                                          const float* b0, const float* b1, float* out_s, T* out, float* gsave) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float s = 0.f;
+  for (int c = lane * 2; c < H; c += 128) {
+    float a, b;
+    ld2<T>(x + (long long)row * H + c, a, b);
+    s += a * wx[c] + b * wx[c + 1];
+    if (e) { ld2<T>(e + (long long)row * H + c, a, b); s += a * we[c] + b * we[c + 1]; }
+  }
+  s = wave_sum(s) + (b0 ? b0[0] : 0.f) + (b1 ? b1[0] : 0.f);
+  if (mode == 0) { if (lane == 0) out_s[row] = s; return; }
+  const float g = 1.f / (1.f + __expf(-s));
+  if (lane == 0 && gsave) gsave[row] = g;
+  for (int c = lane * 2; c < H; c += 128) {
+    float a, b;
+    ld2<T>(e + (long long)row * H + c, a, b);
+    st2<T>(out + (long long)row * H + c, a * g, b * g);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void rowgate_bwd_kernel(int M, int H, int mode, const T* x, const T* e, const float* wx, const float* we, const float* gsave,
+                                                          const float* dy, const T* dout, T* dx, T* de, float* dwx, float* dwe, float* db0, float* db1) {
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [2][H] + [1]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 2 * H + 1; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float bsum = 0.f;
+  for (int row = blockIdx.x * 4 + wid; row < M; row += gridDim.x * 4) {
+    float ds;
+    float g = 0.f;
+    if (mode == 0) ds = dy[row];
+    else {
+      g = gsave[row];
+      float t = 0.f;
+      for (int c = lane * 2; c < H; c += 128) {
+        float a, b, u, v;
+        ld2<T>(dout + (long long)row * H + c, a, b);
+        ld2<T>(e + (long long)row * H + c, u, v);
+        t += a * u + b * v;
+      }
+      ds = wave_sum(t) * g * (1.f - g);
+    }
+    bsum += ds;
+    for (int c = lane * 2; c < H; c += 128) {
+      float a, b;
+      ld2<T>(x + (long long)row * H + c, a, b);
+      atomicAdd(red + c, ds * a); atomicAdd(red + c + 1, ds * b);
+      if (dx) st2<T>(dx + (long long)row * H + c, ds * wx[c], ds * wx[c + 1]);
+      if (mode == 1) {
+        float u, v, p, q;
+        ld2<T>(e + (long long)row * H + c, u, v);
+        ld2<T>(dout + (long long)row * H + c, p, q);
+        atomicAdd(red + H + c, ds * u); atomicAdd(red + H + c + 1, ds * v);
+        if (de) st2<T>(de + (long long)row * H + c, p * g + ds * we[c], q * g + ds * we[c + 1]);
+      }
+    }
+  }
+  if (lane == 0) atomicAdd(red + 2 * H, bsum);
+  __syncthreads();
+  for (int i = threadIdx.x; i < H; i += 256) {
+    if (dwx && red[i] != 0.f) atomicAdd(dwx + i, red[i]);
+    if (mode == 1 && dwe && red[H + i] != 0.f) atomicAdd(dwe + i, red[H + i]);
+  }
+  if (threadIdx.x == 0) {
+    if (db0) atomicAdd(db0, red[2 * H]);
+    if (db1) atomicAdd(db1, red[2 * H]);
+  }
+}
+extern "C" int magic_rowgate_fwd(int dtype, int M, int H, int mode, const void* x, const void* e, const float* wx, const float* we,
+                                 const float* b0, const float* b1, float* out_s, void* out, float* gsave, void* stream) {
+  if (M <= 0 || H < 128 || H > 1024 || (H % 128) || !x || !wx || (mode != 0 && mode != 1) || !dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  if ((e != nullptr) != (we != nullptr) || (mode == 0 && !out_s) || (mode == 1 && (!e || !out))) return MAGIC_ERR_ARG;
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(rowgate_fwd_kernel<bf16>, grid, block, 0, st, M, H, mode, (const bf16*)x, (const bf16*)e, wx, we, b0, b1, out_s, (bf16*)out, gsave);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(rowgate_fwd_kernel<f16>, grid, block, 0, st, M, H, mode, (const f16*)x, (const f16*)e, wx, we, b0, b1, out_s, (f16*)out, gsave);
+  else hipLaunchKernelGGL(rowgate_fwd_kernel<float>, grid, block, 0, st, M, H, mode, (const float*)x, (const float*)e, wx, we, b0, b1, out_s, (float*)out, gsave);
+  return launch_status();
+}
+extern "C" int magic_rowgate_bwd(int dtype, int M, int H, int mode, const void* x, const void* e, const float* wx, const float* we, const float* gsave,
+                                 const float* dy, const void* dout, void* dx, void* de, float* dwx, float* dwe, float* db0, float* db1, void* stream) {
+  if (M <= 0 || H < 128 || H > 1024 || (H % 128) || !x || !wx || (mode != 0 && mode != 1) || !dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  if ((mode == 0 && !dy) || (mode == 1 && (!e || !we || !gsave || !dout))) return MAGIC_ERR_ARG;
+  int nb = (M + 15) / 16;
+  if (nb > 256) nb = 256;
+  dim3 grid(nb), block(256);
+  const size_t shm = (size_t)(2 * H + 1) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(rowgate_bwd_kernel<bf16>, grid, block, shm, st, M, H, mode, (const bf16*)x, (const bf16*)e, wx, we, gsave, dy, (const bf16*)dout, (bf16*)dx, (bf16*)de, dwx, dwe, db0, db1);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(rowgate_bwd_kernel<f16>, grid, block, shm, st, M, H, mode, (const f16*)x, (const f16*)e, wx, we, gsave, dy, (const f16*)dout, (f16*)dx, (f16*)de, dwx, dwe, db0, db1);
+  else hipLaunchKernelGGL(rowgate_bwd_kernel<float>, grid, block, shm, st, M, H, mode, (const float*)x, (const float*)e, wx, we, gsave, dy, (const float*)dout, (float*)dx, (float*)de, dwx, dwe, db0, db1);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
 // out[r, c] = in[r, c] * mask(site, r*cols + c) / (1-p)   (rows x cols logical, row pitch ld; in may alias out).
 // The unfused attention path (key length > 128) drops its probabilities / masks their gradient with it, and the tests
 // export the masks the fused kernels regenerate (in = ones).

@@ -141,6 +141,39 @@ class _AddNormFn(torch.autograd.Function):
         return d_sum.view(ctx.shape).to(ctx.dt[0]), de.view(ctx.shape).to(ctx.dt[1]), None, None, None, None
 
 
+class _DoorGateFn(torch.autograd.Function):
+    """'door' (parser.py:129-142 do_add_method): e * sigmoid(w_x . x + w_e . e + b_x + b_e) per token as one row-gate launch each way
+    (csrc/rowops.hip magic_rowgate, mode 1); the four gate parameters' gradients land in their slices of the flat gradient buffer"""
+
+    @staticmethod
+    def forward(ctx, x, e, blk):
+        net = blk._net
+        H = net.H
+        names = blk._gate_names
+        S = net.S
+        xc = x.detach().to(net.dtype).reshape(-1, H).contiguous()
+        ec = e.detach().to(net.dtype).reshape(-1, H).contiguous()
+        M = xc.shape[0]
+        out, g = torch.empty_like(ec), torch.empty(M, dtype=torch.float32, device=xc.device)
+        O.rowgate_fwd(1, xc, M, H, S.master(names[0]).view(-1), e=ec, we=S.master(names[2]).view(-1), b0=S.master(names[1]), b1=S.master(names[3]),
+                      out=out, gsave=g)
+        ctx.blk, ctx.x, ctx.e, ctx.g, ctx.shape, ctx.dt = blk, xc, ec, g, e.shape, (x.dtype, e.dtype)
+        return out.view(e.shape).to(e.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        blk = ctx.blk
+        net, names = blk._net, blk._gate_names
+        S, H = net.S, net.H
+        S.ensure_grads()
+        M = ctx.x.shape[0]
+        d = dout.detach().to(net.dtype).reshape(M, H).contiguous()
+        dx, de = torch.empty_like(ctx.x), torch.empty_like(ctx.e)
+        O.rowgate_bwd(1, ctx.x, M, H, S.master(names[0]).view(-1), e=ctx.e, we=S.master(names[2]).view(-1), gsave=ctx.g, dout=d, dx=dx, de=de,
+                      dwx=S.g(names[0]).view(-1), dwe=S.g(names[2]).view(-1), db0=S.g(names[1]), db1=S.g(names[3]))
+        return dx.view(ctx.shape).to(ctx.dt[0]), de.view(ctx.shape).to(ctx.dt[1]), None
+
+
 class CausalBlock(nn.Module):
     """one back-door or front-door adjustment of token features x [B, N, H] against a dictionary z [Nz, Dz] (+ prior pz [Nz])"""
 
@@ -164,10 +197,10 @@ class CausalBlock(nn.Module):
         object.__setattr__(self, "kv", hl("key.weight", "key.bias", rows=2 * H, cols=dict_width(cfg, name)))     # key | value adjacent
         object.__setattr__(self, "o", hl("output.dense.weight", "output.dense.bias"))
         if self.door:
-            # the gate is two H-wide dot products per token: elementwise torch ops on the store's own nn.Parameters (their .grad
-            # are views of the flat gradient buffer, so autograd's accumulation lands where the optimizer and the exchange look)
+            # the gate is two H-wide dot products per token: one row-gate launch each way (_DoorGateFn) on the store's own parameters
             named = dict(model.named_parameters())
             object.__setattr__(self, "_gate", tuple(named[p + n] for n in ("gate_x.weight", "gate_x.bias", "gate_e.weight", "gate_e.bias")))
+            object.__setattr__(self, "_gate_names", tuple(p + n for n in ("gate_x.weight", "gate_x.bias", "gate_e.weight", "gate_e.bias")))
         self._ln_name = p + "output.LayerNorm"
         self._drop_name = p + "output.dropout"
 
@@ -190,10 +223,7 @@ class CausalBlock(nn.Module):
             e = _DictAttnFn.apply(q, k.unsqueeze(0).expand(B, Nz, H), v.unsqueeze(0).expand(B, Nz, H), net)
         e = self.o(e.contiguous())
         if self.door:
-            wx, bx, we, be = self._gate
-            ef = e.float()
-            g = torch.sigmoid((x.float() * wx.view(1, 1, H)).sum(-1, keepdim=True) + (ef * we.view(1, 1, H)).sum(-1, keepdim=True) + bx + be)
-            e = (ef * g).to(e.dtype)
+            e = _DoorGateFn.apply(x, e, self)
         return _AddNormFn.apply(x, e, net, net.ln(self._ln_name), net._dh(self._drop_name), self._model[0])
 
 

@@ -57,6 +57,8 @@ SIGNATURES = {
     "magic_mse_multi": [i32, i32, vp, vp],
     "magic_step_rng": [u64, vp, f32, vp, vp, vp, vp, f32, f32, i32, vp],
     "magic_seed_scale": [vp],
+    "magic_rowgate_fwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "magic_rowgate_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "magic_gemm_dw_cat": [i32, i32, vp, i32, vp, vp, vp, vp],
     "magic_loss_assemble": [vp, i32, vp, f32, vp, i32, vp, vp, f32, i32, vp, vp],
     "magic_cfp_loss": [i32, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp],

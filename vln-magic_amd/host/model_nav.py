@@ -104,7 +104,7 @@ class Critic(nn.Module):
     """`Critic(args)` of the withheld models/model.py (agent.py:30,39): the A2C value head the agent constructs, puts in
     `self.models` / `critic_optimizer` (agent_base.py:116-139) and never calls (`train_rl` is False in every shipped script,
     agent_base.py:241-250).  [LINEAGE DUET] state2value = Linear(H,512) -> ReLU -> Dropout(args.dropout) -> Linear(512,1).
-    The H->512 projection runs on the HIP GEMM (HipLinear); the 512->1 dot of this dormant head is two torch device ops."""
+    The H->512 projection runs on the HIP GEMM (HipLinear), the 512->1 dot on the row-dot launch (csrc/rowops.hip magic_rowgate, mode 0)."""
 
     def __init__(self, args, device="cuda", compute_dtype=torch.bfloat16, seed=0):
         super().__init__()
@@ -129,8 +129,33 @@ class Critic(nn.Module):
     def forward(self, state):
         self.store.sync_shadow()
         h = self.drop(torch.relu(getattr(self.state2value, "0")(state).float()))
-        out = getattr(self.state2value, "3")
-        return (h @ out.weight.t() + out.bias).squeeze()
+        return _RowDotFn.apply(h, self).squeeze()
+
+
+class _RowDotFn(torch.autograd.Function):
+    """the value head's output Linear(512, 1) as one row-dot launch each way (csrc/rowops.hip magic_rowgate, mode 0); weight / bias gradients land
+    in the Critic's flat gradient buffer"""
+
+    @staticmethod
+    def forward(ctx, h, critic):
+        st = critic.store
+        w, b = st.master("state2value.3.weight").view(-1), st.master("state2value.3.bias")
+        x = h.detach().reshape(-1, h.shape[-1]).float().contiguous()
+        M, H = x.shape
+        out = torch.empty(M, dtype=torch.float32, device=x.device)
+        O.rowgate_fwd(0, x, M, H, w, b0=b, out_s=out)
+        ctx.critic, ctx.x, ctx.shape, ctx.in_dtype = critic, x, h.shape, h.dtype
+        return out.view(*h.shape[:-1], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        st = ctx.critic.store
+        st.ensure_grads()
+        M, H = ctx.x.shape
+        dx = torch.empty_like(ctx.x)
+        O.rowgate_bwd(0, ctx.x, M, H, st.master("state2value.3.weight").view(-1), dy=dy.detach().reshape(-1).float().contiguous(), dx=dx,
+                      dwx=st.g("state2value.3.weight").view(-1), db0=st.g("state2value.3.bias"))
+        return dx.view(ctx.shape).to(ctx.in_dtype), None
 
 
 class _PassToken:

@@ -1142,6 +1142,16 @@ def step_rng(base_seed, counter, rw_temp, seed_out=None, rw_out=None, zero_me=No
            L.P(scale_state), float(growth), float(backoff), int(interval), L.stream())
 
 
+def rowgate_fwd(mode, x, M, H, wx, *, e=None, we=None, b0=None, b1=None, out_s=None, out=None, gsave=None):
+    """mode 0: out_s[m] = x[m] . wx + b0; mode 1: out[m] = e[m] * sigmoid(x[m] . wx + e[m] . we + b0 + b1), gsave[m] = the gate (csrc/rowops.hip)"""
+    L.call("magic_rowgate_fwd", L.dt(x.dtype), M, H, mode, L.P(x), L.P(e), L.P(wx), L.P(we), L.P(b0), L.P(b1), L.P(out_s), L.P(out), L.P(gsave), L.stream())
+
+
+def rowgate_bwd(mode, x, M, H, wx, *, e=None, we=None, gsave=None, dy=None, dout=None, dx=None, de=None, dwx=None, dwe=None, db0=None, db1=None):
+    L.call("magic_rowgate_bwd", L.dt(x.dtype), M, H, mode, L.P(x), L.P(e), L.P(wx), L.P(we), L.P(gsave), L.P(dy), L.P(dout), L.P(dx), L.P(de),
+           L.P(dwx), L.P(dwe), L.P(db0), L.P(db1), L.stream())
+
+
 def seed_scale(scale_state):
     """register (None: clear) the device word the gradient-seeding loss launches recorded from now on multiply their gradient coefficients by
     (csrc/loss.hip magic_seed_scale): scale_state[0] of the dynamic loss scale"""

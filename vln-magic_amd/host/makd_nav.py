@@ -98,16 +98,13 @@ def compute_kd_losses_fused(t, s_out, t_out, heads, acc, *, role="t2s", temperat
     hmin = min(s_out["txt_attns"].shape[1], t_out["txt_attns"].shape[1])
     half = 1.0 if weights is not None else 0.5
     sn, tn = s_out["nav_outs"], t_out["nav_outs"]
-    terms = []                                   # (slot, x, y, ability, host coefficient)
+    feats, attns = [], []                        # (slot, head name, learner tensor, target tensor, ability, host coefficient) / (slot, a, b, ability)
 
     def feat(slot, name, a, b, ab, c=1.0):
-        if role == "t2s":
-            terms.append((slot, heads[name](a), b.detach(), ab, c))
-        else:
-            terms.append((slot, a, heads[name](b).detach(), ab, c))
+        feats.append((slot, name, a, b, ab, c))
 
     def attn(slot, a, b, ab):
-        terms.append((slot, a, b.detach(), ab, 1.0))
+        attns.append((slot, a, b.detach(), ab, 1.0))
 
     if t == 0:
         feat(0, "txt_emb_w", s_out["txt_embeds"], t_out["txt_embeds"], 0)
@@ -119,6 +116,16 @@ def compute_kd_losses_fused(t, s_out, t_out, heads, acc, *, role="t2s", temperat
     attn(6, sn["gmap_attns"][:, :hmin], tn["gmap_attns"][:, :hmin], 2)
     feat(7, "local_cross_w", sn["vp_embeds"], tn["vp_embeds"], 3)
     attn(8, sn["vp_attns"][:, :hmin], tn["vp_attns"][:, :hmin], 3)
+    # the projection heads of the step in one autograd node, their GEMMs as grouped launches (model_nav.hip_linear_multi); 't2s' projects the
+    # learner side, 's2t' the (detached) target side
+    from .model_nav import hip_linear_multi
+    mods = [heads[f[1]] for f in feats]
+    proj = hip_linear_multi(mods, [f[2] if role == "t2s" else f[3].detach() for f in feats])
+    terms = []                                   # (slot, x, y, ability, host coefficient)
+    for f, y in zip(feats, proj):
+        terms.append((f[0], y, f[3].detach(), f[4], f[5]) if role == "t2s" else (f[0], f[2], y.detach(), f[4], f[5]))
+    terms += attns
+    terms.sort(key=lambda tm: tm[0])
     on_dev = weights is not None and torch.is_tensor(weights) and weights.is_cuda
     meta, xy = [], []
     for slot, x, y, ab, c in terms:

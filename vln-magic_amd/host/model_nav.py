@@ -89,6 +89,58 @@ class _HipLinearFn(torch.autograd.Function):
         return dx.view(ctx.shape).to(ctx.in_dtype), None, None
 
 
+class _HipLinearMultiFn(torch.autograd.Function):
+    """several independent HipLinear modules applied in one autograd node: `ys = _HipLinearMultiFn.apply(mods, *xs)` -- the forward GEMMs leave as
+    ONE grouped launch (lib.group), so do the input-gradient GEMMs; the weight gradients join the deferred queue as usual.  The MAKD step applies
+    its four or five projection heads this way (host/makd_nav.compute_kd_losses_fused)."""
+
+    @staticmethod
+    def forward(ctx, mods, *xs):
+        from . import lib as L
+        ctx.lane = lanes.cur
+        xcs, shapes = [], []
+        for mod, x in zip(mods, xs):
+            net = mod._net
+            shp = x.shape
+            M = x.numel() // shp[-1]
+            xcs.append(x.detach().to(net.dtype).reshape(M, shp[-1]).contiguous())
+            shapes.append(shp)
+        with L.group():
+            ys = [O.linear_fwd(xc, mod._lin.W, mod._lin.b, xc.shape[0]) for mod, xc in zip(mods, xcs)]
+        ctx.mods, ctx.xcs, ctx.shapes, ctx.in_dtypes = mods, xcs, shapes, [x.dtype for x in xs]
+        ctx.set_materialize_grads(False)
+        return tuple(y.view(*shp[:-1], mod._lin.N) for y, shp, mod in zip(ys, shapes, mods))
+
+    @staticmethod
+    @_lane_bwd
+    def backward(ctx, *dys):
+        from . import lib as L
+        mods = ctx.mods
+        mods[0]._net.S.ensure_grads()
+        owner = getattr(mods[0], "_owner", None)
+        if owner:
+            _queue_sync(owner[0])
+        ds = []
+        for mod, xc, dy in zip(mods, ctx.xcs, dys):
+            if dy is None:
+                ds.append(None)
+                continue
+            d = dy.to(mod._net.dtype).reshape(xc.shape[0], mod._lin.N).contiguous()
+            if mod._net.train:
+                O.linear_dw(d, xc, mod._lin.dW, mod._lin.db, xc.shape[0])
+            ds.append(d)
+        with L.group():
+            dxs = [None if d is None else O.linear_dx(d, mod._lin.W, xc.shape[0]) for mod, xc, d in zip(mods, ctx.xcs, ds)]
+        return (None,) + tuple(None if dx is None else dx.view(shp).to(dt) for dx, shp, dt in zip(dxs, ctx.shapes, ctx.in_dtypes))
+
+
+def hip_linear_multi(mods, xs):
+    """[mod(x) for mod, x in zip(mods, xs)] for HipLinear modules, as one autograd node with grouped GEMM launches; anything else is applied one by one"""
+    if len(mods) > 1 and all(isinstance(m, HipLinear) for m in mods):
+        return list(_HipLinearMultiFn.apply(tuple(mods), *xs))
+    return [m(x) for m, x in zip(mods, xs)]
+
+
 class HipLinear(nn.Module):
     """A Linear whose weight/bias live in the ParamStore; callable like nn.Linear (KD projection heads)."""
 

@@ -94,3 +94,44 @@ def test_fused_schedule_and_gradient_zeroing_follow_the_separate_launches():
         assert torch.allclose(stores[0].shadow.float(), stores[1].shadow.float(), rtol=1e-2, atol=1e-6)
         assert torch.equal(opts[0].lr_ss, opts[1].lr_ss) and int(opts[0].step_dev) == int(opts[1].step_dev) == step + 1
         assert float(stores[1].grad.abs().max()) == 0.0 and float(stores[0].grad.abs().max()) > 0.0
+
+
+def test_dw_guard_orders_streams_that_share_the_weight_gradient_workspace():
+    """ops.dw_guard: the deterministic weight-gradient launch's workspace and counters are one pair per device and gradient lane, baked
+    into every captured graph; a user on ANOTHER stream must wait for everything the previous user's stream has queued.  Same stream, or another
+    lane (own pair): no wait."""
+    import torch
+    from magic_amd.host import lanes
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.randn(4096, 4096, device=DEV)
+    torch.cuda.synchronize()
+    O._DW_LAST.clear()
+    with torch.cuda.stream(a):
+        O.dw_guard()
+        for _ in range(40):                       # tens of milliseconds of work on stream a
+            x = x @ x * 1e-4
+        ev_a = torch.cuda.Event()
+        ev_a.record()
+    with torch.cuda.stream(b):
+        O.dw_guard()                              # another stream, same lane: waits for stream a
+        ev_b = torch.cuda.Event()
+        ev_b.record()
+    ev_b.synchronize()
+    assert ev_a.query(), "stream b passed the guard while stream a's launches were still running"
+    torch.cuda.synchronize()
+    y = torch.randn(4096, 4096, device=DEV)
+    with torch.cuda.stream(a):
+        O.dw_guard()
+        for _ in range(40):
+            y = y @ y * 1e-4
+        ev_a2 = torch.cuda.Event()
+        ev_a2.record()
+    with lanes.use(1, b):
+        O.dw_guard()                              # lane 1 has its own workspace: no ordering against lane 0's stream
+        ev_b2 = torch.cuda.Event()
+        ev_b2.record()
+    ev_b2.synchronize()
+    assert not ev_a2.query(), "a lane with its own workspace was made to wait for another lane's stream"
+    torch.cuda.synchronize()
+    O._DW_LAST.clear()
+    lanes._used.clear()

@@ -77,6 +77,9 @@ def main():
                          "fights the backward's callbacks for the GIL); off = step by step inside the iteration (default: with the rollouts on "
                          "gradient lanes the forward phase is bound by the sampled rollout's step-by-step dependency, not by the host's planning -- inline "
                          "measured 161.1 vs 161.8 ms per iteration on config 5 and slower on the host-bound ICoD iteration)")
+    ap.add_argument("--optimizer", choices=("flat", "torch"), default="flat",
+                    help="flat: trainer.FlatTorchAdamW -- torch.optim.AdamW's arithmetic + clip_grad_norm_ as one sum-of-squares and one update launch "
+                         "over the model's flat buffers; torch: torch.optim.AdamW + torch.nn.utils.clip_grad_norm_ over the parameter list")
     ap.add_argument("--no-graphs", action="store_true",
                     help="launch every kernel of the training steps eagerly instead of replaying captured step instances (host/step_graphs.py)")
     ap.add_argument("--batch", type=int, default=16)                  # run_rxr_kdl_valid.sh:39
@@ -120,7 +123,9 @@ def main():
     if world > 1:
         dist.broadcast(model.store.flat, src=0)
     model.train() if a.mode == "train" else model.eval()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-5)              # agent_base.py:128-129
+    from magic_amd.host.trainer import FlatTorchAdamW
+    mk_opt = (lambda m: FlatTorchAdamW(m.store, lr=1e-5)) if (a.optimizer == "flat" and a.mode != "eval") else (lambda m: torch.optim.AdamW(m.parameters(), lr=1e-5))
+    opt = mk_opt(model)                                               # agent_base.py:128-129
     env = make_env(a, 1234 + rank)
     env2 = make_env(a, 1234 + rank)            # same scans and features (deterministic in the seed): the second rollout's stepper
     table = torch.from_numpy(env.feature_table).to(dev).to(dtype)
@@ -136,8 +141,8 @@ def main():
             dist.broadcast(teacher.store.flat, src=0)
         model.train()
         teacher.train()
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
-        t_opt = torch.optim.AdamW(teacher.parameters(), lr=1e-5)      # agent_base.py:133-139
+        opt = mk_opt(model)
+        t_opt = mk_opt(teacher)                                       # agent_base.py:133-139
     kd = dict(alpha=0.5, t_alpha=0.5, temperature=2.0, decay=0.7) if a.icod else None      # run_r2r_kdl_valid.sh:97-104
     ro = NavRollout(model, table, teacher=teacher, kd=kd, train_teacher=a.icod, max_action_len=a.max_action_len,
                     expert_policy="ndtw" if not a.icod else "spl",     # run_rxr_kdl_valid.sh:29 / run_r2r_kdl_valid.sh:29
@@ -199,10 +204,16 @@ def main():
         (r1["loss"] + r2["loss"]).backward(retain_graph=a.icod)       # agent_base.py:260-263
         if a.icod:
             (r1["t_loss"] + r2["t_loss"]).backward()                  # agent_base.py:268-269
-            torch.nn.utils.clip_grad_norm_(teacher.parameters(), 40.0)
-            t_opt.step()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 40.0)     # agent_base.py:273
-        opt.step()
+            if a.optimizer == "flat":
+                t_opt.step(max_norm=40.0)
+            else:
+                torch.nn.utils.clip_grad_norm_(teacher.parameters(), 40.0)
+                t_opt.step()
+        if a.optimizer == "flat":
+            opt.step(max_norm=40.0)                                  # clip 40 (agent_base.py:273) + AdamW in two launches
+        else:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 40.0)     # agent_base.py:273
+            opt.step()
         if a.plan_ahead == "inline" and planned:
             # everything above is launched, nothing has been waited for: the host builds the next batch's teacher-forced plans now, under the
             # GPU's backward + optimizer (the next iteration's first host wait -- the language call's length check -- comes after)
@@ -279,7 +290,7 @@ def main():
             "config": {"plan_ahead": (a.plan_ahead if a.mode != "eval" else None),
                        "rollouts": ("one batch of 2B episodes" if (a.fuse_rollouts and not a.icod) else "sequential" if a.sequential_rollouts else "interleaved step by step"),
                        "workload": f"navigator loop (agent_base.py:215-296 iteration = teacher-forced + DAgger 'sample' rollout, backward, clip 40, "
-                                   f"torch AdamW), VLNBert H={a.hidden} 6+2+3 layers, dropout 0.1, expert ndtw, instructions U{{{a.instr_min}..{a.instr_max}}} tokens, "
+                                   f"{'torch.optim.AdamW arithmetic on the flat buffers' if a.optimizer == 'flat' else 'torch AdamW'}), VLNBert H={a.hidden} 6+2+3 layers, dropout 0.1, expert ndtw, instructions U{{{a.instr_min}..{a.instr_max}}} tokens, "
                                    f"paths {a.hops_min}..{a.hops_max} hops, max_action_len {a.max_action_len}",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "views": 36, "feat_dim": 768, "parallelism": f"dp{world}",
                        "decisions_per_iteration": round(dec / a.steps / world, 1)},

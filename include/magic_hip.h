@@ -357,7 +357,9 @@ int magic_sumsq(long long n, const float* g, float* out, void* stream);
 int magic_adamw(long long n, float* p, float* g, float* m, float* v, void* shadow, int shadow_dtype,
                 float lr, float b1, float b2, float eps, float wd, float step_size,
                 const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_grad,
-                unsigned* overflow, float* scale_state, int* sched_step, void* stream);
+                unsigned* overflow, float* scale_state, int* sched_step, int decay_first, void* stream);
+/* decay_first != 0: torch.optim.AdamW's order -- p *= 1 - lr wd, then the Adam update (the navigator's optimizer, map_nav_src/r2r/agent_base.py:122-137;
+ * pass step_size = lr sqrt(1 - b2^t) / (1 - b1^t) and eps sqrt(1 - b2^t) for its `sqrt(v / bc2) + eps` denominator); 0: pretrain_src/optim/adamw.py's. */
 /* scale_state (may be NULL; needs sumsq): the dynamic loss scale's state (magic_step_rng): the gradient pre-scale is multiplied by its 1 / S and
  * `pending` is set to 1 (updated) / 2 (skipped).  sched_step (may be NULL): the device-side schedule's step word (magic_sumsq_sched /
  * magic_sched_step); a SKIPPED update takes back this step's advance, as a skipped optimizer.step() under GradScaler leaves the state step. */

@@ -135,3 +135,31 @@ def test_dw_guard_orders_streams_that_share_the_weight_gradient_workspace():
     torch.cuda.synchronize()
     O._DW_LAST.clear()
     lanes._used.clear()
+
+
+def test_flat_torch_adamw_equals_torch_optim_adamw_with_clipping():
+    """trainer.FlatTorchAdamW (the navigator loop's optimizer on the flat buffers: clip + decay-first AdamW in two launches) against
+    torch.optim.AdamW + clip_grad_norm_ over three steps (map_nav_src/r2r/agent_base.py:122-137, :273)."""
+    import torch
+    from magic_amd.host.params import ParamStore
+    from magic_amd.host.trainer import FlatTorchAdamW
+    specs = [("a.weight", (37, 64), "normal"), ("a.bias", (37,), "zeros"), ("n.LayerNorm.weight", (64,), "ones"), ("b.weight", (5, 3), "normal")]
+    st = ParamStore(specs, DEV, torch.float32, seed=3)
+    ref = {n: torch.nn.Parameter(st.master(n).clone()) for n, _, _ in specs}
+    topt = torch.optim.AdamW(list(ref.values()), lr=1e-2)
+    fopt = FlatTorchAdamW(st, lr=1e-2)
+    gen = torch.Generator(DEV).manual_seed(1)
+    for step in range(3):
+        fopt.zero_grad()
+        topt.zero_grad()
+        for n, shape, _ in specs:
+            g = torch.randn(shape, device=DEV, generator=gen) * (30.0 if step == 1 else 0.5)      # step 1: the norm exceeds 40 -> clipped
+            st.g(n).copy_(g)
+            ref[n].grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(list(ref.values()), 40.0)
+        topt.step()
+        fopt.step(max_norm=40.0)
+        torch.cuda.synchronize()
+        for n, _, _ in specs:
+            torch.testing.assert_close(st.master(n), ref[n].data, rtol=2e-6, atol=1e-6, msg=f"step {step} {n}")      # (updates are ~1e-2 per step: 1e-6 is 1e-4 of one)
+        assert float(st.grad.abs().max()) == 0.0               # consumed: the next backward starts from zero

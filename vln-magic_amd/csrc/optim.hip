@@ -49,7 +49,7 @@ template <typename Hh>
 __global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, float* g, float* m, float* v, Hh* shadow,
                                                     float lr, float b1, float b2, float eps, float wd, float step_size,
                                                     const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_g,
-                                                    unsigned* overflow, float* scale_state, int* sched_step) {
+                                                    unsigned* overflow, float* scale_state, int* sched_step, int decay_first) {
   if (lr_ss) { lr = lr_ss[0]; step_size = lr_ss[1]; }     // device-side schedule (HIP-graph replay)
   // dynamic loss scale (fp16 storage; loss.hip step_rng_kernel owns the rule): the gradient buffer holds S x the gradient -- read 1 / S here, leave
   // `pending` = 1 (updated) or 2 (skipped) for the next step's prologue.  Nothing else reads scale_state between the loss kernels and that prologue.
@@ -77,8 +77,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, float
     const float gi = g[i] * clip;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    float pi = p[i] - step_size * mi / (sqrtf(vi) + eps);
-    if (wd > 0.f && i < n_decay) pi -= lr * wd * pi;        // [0, n_decay): the decayed group (optim/misc.py:13-22), the rest: biases / LayerNorm
+    // decay_first: torch.optim.AdamW's order (the navigator's optimizer, map_nav_src/r2r/agent_base.py:122-137): p *= 1 - lr wd, THEN the Adam update;
+    // otherwise the pretraining AdamW's (adamw.py:109-110): the update, then the decay of the updated value
+    float pi = p[i];
+    const bool dec = wd > 0.f && i < n_decay;               // [0, n_decay): the decayed group (optim/misc.py:13-22), the rest: biases / LayerNorm
+    if (dec && decay_first) pi -= lr * wd * pi;
+    pi -= step_size * mi / (sqrtf(vi) + eps);
+    if (dec && !decay_first) pi -= lr * wd * pi;
     m[i] = mi; v[i] = vi; p[i] = pi;
     if (shadow) shadow[i] = (Hh)pi;
     if (zero_g) g[i] = 0.f;             // the next step's accumulators start from zero: saves its 40 MB fill launch
@@ -158,16 +163,16 @@ extern "C" int magic_sumsq_sched(long long n, const float* g, float* out, int* s
 extern "C" int magic_adamw(long long n, float* p, float* g, float* m, float* v, void* shadow, int shadow_dtype,
                            float lr, float b1, float b2, float eps, float wd, float step_size,
                            const float* sumsq, float max_norm, float gscale, const float* lr_ss, long long n_decay, int zero_grad,
-                           unsigned* overflow, float* scale_state, int* sched_step, void* stream) {
+                           unsigned* overflow, float* scale_state, int* sched_step, int decay_first, void* stream) {
   if (n <= 0 || (shadow && !dtype_is16(shadow_dtype))) return MAGIC_ERR_ARG;
   if (scale_state && !sumsq) return MAGIC_ERR_ARG;        // the skip decision needs the gradient norm
   if (n_decay < 0) n_decay = n;                    // the whole range is one group
   if (shadow && shadow_dtype == DT_F16)
     hipLaunchKernelGGL(adamw_kernel<f16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (f16*)shadow, lr, b1, b2, eps, wd,
-                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad, overflow, scale_state, sched_step);
+                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad, overflow, scale_state, sched_step, decay_first);
   else
     hipLaunchKernelGGL(adamw_kernel<bf16>, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, n, p, g, m, v, (bf16*)shadow, lr, b1, b2, eps, wd,
-                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad, overflow, scale_state, sched_step);
+                       step_size, sumsq, max_norm, gscale, lr_ss, n_decay, zero_grad, overflow, scale_state, sched_step, decay_first);
   return launch_status();
 }
 

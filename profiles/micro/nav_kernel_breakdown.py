@@ -35,7 +35,8 @@ if a.icod:
     tcfg = make_config(768, role="teacher", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
     teacher = VLNBert(SimpleNamespace(train_kdl_teacher=True, train_kdl=True), role="teacher", config=tcfg, device=dev, compute_dtype=torch.bfloat16, seed=1)
     teacher.train()
-    t_opt = torch.optim.AdamW(teacher.parameters(), lr=1e-5)
+    from magic_amd.host.trainer import FlatTorchAdamW
+    t_opt = FlatTorchAdamW(teacher.store, lr=1e-5)
     kd = dict(alpha=0.5, t_alpha=0.5, temperature=2.0, decay=0.7)
     T, LEN, HOPS = 15, (20, 80), (4, 7)
 else:
@@ -43,7 +44,8 @@ else:
     model = VLNBert(None, role="student", config=cfg, device=dev, compute_dtype=torch.bfloat16, seed=0)
     T, LEN, HOPS = 28, (100, 512), (8, 15)
 model.train()
-opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
+from magic_amd.host.trainer import FlatTorchAdamW
+opt = FlatTorchAdamW(model.store, lr=1e-5)
 mk = lambda: SynthNavEnv(batch_size=16, n_scans=6, nodes_per_scan=64, seed=1234, instr_len=LEN, path_hops=HOPS)
 env, env2 = mk(), mk()
 table = torch.from_numpy(env.feature_table).to(dev).to(torch.bfloat16)
@@ -79,12 +81,10 @@ def iteration():
     (r1["loss"] + r2["loss"]).backward(retain_graph=a.icod)
     if a.icod:
         (r1["t_loss"] + r2["t_loss"]).backward()
-        torch.nn.utils.clip_grad_norm_(teacher.parameters(), 40.0)
-        t_opt.step()
+        t_opt.step(max_norm=40.0)
     t_b = time.perf_counter()
     mark("bwd_end")
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 40.0)
-    opt.step()
+    opt.step(max_norm=40.0)
     mark("end")
     if a.ahead:
         PIPE["obs"] = env.reset(features=False)

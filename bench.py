@@ -12,6 +12,16 @@ JSON line.  `roofline` = the Linear-layer contraction family (MFMA GEMM kernels 
 durations measured with HIP events on the launch stream in a separate instrumented pass; `cpu_baseline` = the
 CPU oracle (oracle/, a restatement -- the reference's model source is withheld) timed on the host cores.
 """
+import os as _os0
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams on one queue SERIALISE.  The pretraining step keeps main,
+# the teacher's side stream (parked on its start gate while the student's encoder launch goes resident), the gradient-exchange stream and RCCL's
+# internal stream busy at once: with four queues the teacher's stream shared the main stream's queue as soon as a process group existed -- the gate
+# never opened and the data-parallel step ran at 2.16 instead of 1.71-1.75 ms (round 5, --dp-structure).  Read when the HIP runtime initialises, so
+# it is set here, before anything touches the GPU; a value the user exported is kept.  (The navigator loop is the opposite case -- its lanes and
+# forked branches hand work between streams all the time, which is cheaper inside a queue: 139 ms per iteration with 4 queues, 175-187 with 8 -- so
+# bench_nav.py leaves the default, and the navigator legs this script spawns do not inherit the setting.)
+_HWQ_USER = "GPU_MAX_HW_QUEUES" in _os0.environ
+_os0.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import json
 import os
@@ -442,9 +452,12 @@ def secondary_block():
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    nav_env = dict(env)
+    if not _HWQ_USER:
+        nav_env.pop("GPU_MAX_HW_QUEUES", None)          # the navigator loop runs on the default number of hardware queues (see the top of this file)
     for name, extra in runs.items():
         try:
-            r = subprocess.run([py, nav] + common + extra, capture_output=True, text=True, timeout=240, env=env)
+            r = subprocess.run([py, nav] + common + extra, capture_output=True, text=True, timeout=240, env=nav_env)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
             j = json.loads(line)
             out[name] = {"value": j["value"], "unit": j["unit"], "ms_per_iteration": j["ms_per_step"], "steps": j["steps"], "dtype": j["dtype"],
@@ -675,6 +688,12 @@ def main():
                     traj += plan["traj_steps"]
                 return traj
         run = run_stream
+    if a.dp_structure and a.mode == "graph":
+        # RCCL builds its communicator inside the first collectives: let those steps pass, then re-arm the teacher's start gate, so the leg measures
+        # the structure and not the start-up (the gate also re-arms itself after a backoff: csrc/encoder.hip)
+        run(12)
+        torch.cuda.synchronize()
+        trainer.gate_reset()
     traj, dt = timed_region(run, a.steps, a.warmup, world, dev)
     steady = gate_now = None
     if a.mode == "graph":       # the driver's K is small (20 steps = 31 ms): the same replay loop over 150 more steps, reported next to it

@@ -511,6 +511,26 @@ def test_encoder_start_gate_counts_what_it_does_and_switches_itself_off():
     r = O.gate_report(st)
     assert (r["calls"], r["timeouts"], r["disabled"], r["skipped"]) == (8, 3, 1, 5), r
     assert e0.elapsed_time(e1) < 50.0, e0.elapsed_time(e1)
+    # (4b) ... and the gate re-arms itself after a backoff of 32 skipped calls (a transient loss of overlap must not leave it off for the rest of
+    # the run); switched off again, it waits twice as long
+    with torch.cuda.stream(side):
+        for _ in range(27):
+            O.encoder_start_gate(st, 500, 0)                 # skipped calls 6 .. 32: the last one re-arms
+    torch.cuda.synchronize()
+    r = O.gate_report(st)
+    assert (r["skipped"], r["disabled"], r["timeouts"]) == (32, 0, 3), r
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            O.encoder_start_gate(st, 500, 0)                 # no encoder launch: three more timeouts switch it off again
+        for _ in range(63):
+            O.encoder_start_gate(st, 500, 0)                 # backoff 64 now: 63 skipped calls do not re-arm it ...
+    torch.cuda.synchronize()
+    r = O.gate_report(st)
+    assert (r["timeouts"], r["disabled"], r["skipped"]) == (6, 1, 32 + 63), r
+    with torch.cuda.stream(side):
+        O.encoder_start_gate(st, 500, 0)                     # ... the 64th does
+    torch.cuda.synchronize()
+    assert O.gate_report(st)["disabled"] == 0
     st.zero_()                                                   # the owner re-arms it
     with torch.cuda.stream(side):
         O.encoder_start_gate(st, 500, 0)

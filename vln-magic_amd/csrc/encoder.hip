@@ -888,18 +888,28 @@ static size_t enc_lds_bytes_compact() { return (size_t)(2 * 48 * XS + 49 * QS + 
 // Nothing in HIP promises that two streams run side by side (they may share a hardware queue; a profiler may serialise them), and a gate
 // that starts AFTER the launch it waits for would sleep for nothing.  So the gate (i) passes at once when a whole-encoder launch became
 // resident within the last `recent_ticks` (that IS the launch it was meant to follow), (ii) counts what it does in `st`, and (iii) switches
-// ITSELF off after GATE_MAX_CONSEC consecutive timeouts: from then on it is an empty launch until the owner zeroes `st` again.
+// ITSELF off after GATE_MAX_CONSEC consecutive timeouts: from then on it is an empty launch -- and re-arms itself after a backoff of skipped calls
+// (32, doubling to 1024 each time it has to switch off again, back to 32 once it opens): a TRANSIENT loss of overlap -- RCCL building its
+// communicator in the first data-parallel steps, a profiler attached for a while -- no longer leaves the teacher ungated for the rest of the run
+// (round 5: the data-parallel structure ran at 2.15 ms/step for that reason alone), a PERSISTENT one costs three timeouts per 1024 steps.
 // st: 0 calls | 1 opened by a launch while waiting | 2 launch already resident at entry | 3 timeouts | 4 consecutive timeouts | 5 disabled
-//     | 6 calls skipped while disabled | 7 reserved
+//     | 6 calls skipped while disabled | 7 (backoff period << 16) | skipped calls of the current backoff
 #define GATE_MAX_CONSEC 3
 __global__ void enc_start_gate_kernel(long long timeout_ticks, long long recent_ticks, unsigned* st) {
   if (threadIdx.x) return;
   st[0] += 1;
-  if (st[5]) { st[6] += 1; return; }
+  if (st[5]) {
+    st[6] += 1;
+    unsigned period = st[7] >> 16, n = (st[7] & 0xFFFFu) + 1;
+    if (period == 0) period = 32;
+    if (n >= period) { st[5] = 0; st[4] = 0; st[7] = (period < 1024 ? period * 2 : 1024) << 16; }      // re-arm for the next call; the NEXT switch-off waits twice as long
+    else st[7] = (period << 16) | n;
+    return;
+  }
   const unsigned c0 = __hip_atomic_load(&magic_enc_starts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const long long t0 = wall_clock64();                       // 100 MHz
   const long long tm = __hip_atomic_load(&magic_enc_start_tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (c0 != 0 && t0 - tm >= 0 && t0 - tm < recent_ticks) { st[2] += 1; st[4] = 0; return; }
+  if (c0 != 0 && t0 - tm >= 0 && t0 - tm < recent_ticks) { st[2] += 1; st[4] = 0; st[7] = 0; return; }
   while (__hip_atomic_load(&magic_enc_starts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c0) {
     if (wall_clock64() - t0 >= timeout_ticks) {
       st[3] += 1;
@@ -910,6 +920,7 @@ __global__ void enc_start_gate_kernel(long long timeout_ticks, long long recent_
   }
   st[1] += 1;
   st[4] = 0;
+  st[7] = 0;                         // overlap is back: the next switch-off starts from the shortest backoff again
 }
 // park `stream` (one sleeping wave) until the next whole-encoder launch of this process has all its workgroups on CUs, at most timeout_us
 extern "C" int magic_encoder_start_gate(int timeout_us, int recent_us, unsigned* stats, void* stream) {

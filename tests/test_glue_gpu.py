@@ -163,3 +163,47 @@ def test_flat_torch_adamw_equals_torch_optim_adamw_with_clipping():
         for n, _, _ in specs:
             torch.testing.assert_close(st.master(n), ref[n].data, rtol=2e-6, atol=1e-6, msg=f"step {step} {n}")      # (updates are ~1e-2 per step: 1e-6 is 1e-4 of one)
         assert float(st.grad.abs().max()) == 0.0               # consumed: the next backward starts from zero
+
+
+def test_lockstep_segments_alternate_and_pair_inside_a_capture():
+    """lib.lockstep (the two co-attention encoders of a captured pre-training step): the two host threads hand a baton back and forth --
+    never both inside the runtime at once, which is what lost a node from a capturing stream's dependency chain (hipErrorStreamCaptureUnjoined
+    at capture end, intermittently) -- their groupable launches still pair, and the replayed graph computes what the separate launches do"""
+    import threading
+    import time
+
+    from magic_amd.host import lib as L
+    M, N, K, n_calls = 64, 64, 64, 12
+    gen = torch.Generator(DEV).manual_seed(5)
+    A = [torch.randn(M, K, device=DEV, generator=gen).to(torch.bfloat16) for _ in range(2)]
+    W = [[torch.randn(N, K, device=DEV, generator=gen).to(torch.bfloat16) for _ in range(n_calls)] for _ in range(2)]
+    C = [[torch.zeros(M, N, device=DEV, dtype=torch.bfloat16) for _ in range(n_calls)] for _ in range(2)]
+    inside, overlaps, order = [0], [0], []
+    guard = threading.Lock()
+
+    def segment(i):
+        def run():
+            for k in range(n_calls):
+                with guard:
+                    inside[0] += 1
+                    overlaps[0] += inside[0] > 1
+                    order.append(i)
+                time.sleep(0.001)              # a window in which a free-running partner would show up
+                with guard:
+                    inside[0] -= 1
+                O.gemm(0, A[i], W[i][k], C[i][k], M, N, K, K, K, N)      # groupable: offered to the partner
+            return i
+        return run
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="relaxed"):
+        out = L.lockstep(segment(0), segment(1))
+    assert out == (0, 1)
+    assert overlaps[0] == 0, overlaps
+    assert order.count(0) == order.count(1) == n_calls and set(order[:3]) == {0, 1}, order[:8]      # interleaved call by call, not one after the other
+    g.replay()
+    torch.cuda.synchronize()
+    for i in range(2):
+        for k in range(n_calls):
+            ref = A[i].float() @ W[i][k].float().t()
+            assert torch.allclose(C[i][k].float(), ref, rtol=2e-2, atol=2e-1), (i, k)

@@ -442,7 +442,12 @@ class Lockstep:
     """Run two independent, same-structured segments (e.g. the global and the local co-attention encoder) on two host
     threads and issue their groupable kernel calls PAIRWISE: when both threads have arrived at a groupable call, the second
     arriver records both through magic_group_begin/…/magic_group_end, which launches ONE kernel serving both problems.
-    Non-groupable calls launch immediately.  If one segment finishes first (or raises) the other simply continues alone."""
+    Non-groupable calls launch immediately.  If one segment finishes first (or raises) the other simply continues alone.
+
+    The two threads ALTERNATE, they never run at the same time: each holds `cv` for as long as it runs (lib.lockstep) and lets go of it only
+    while it waits for its partner in `submit`.  The segments are issued into a stream that is being captured, and two threads adding
+    nodes to one capturing stream at once can lose one of them from the stream's dependency chain (both read the same last node): the
+    capture then ends with hipErrorStreamCaptureUnjoined -- seen once in some hundred captures before the baton."""
 
     def __init__(self):
         self.cv = threading.Condition()
@@ -512,10 +517,11 @@ def lockstep(fn_a, fn_b):
 
     def worker():
         try:
-            torch.cuda.set_device(dev)
-            _tls.lockstep, _tls.idx = ls, 1
-            with torch.cuda.stream(cur), torch.set_grad_enabled(grad):
-                box["b"] = fn_b()
+            with ls.cv:                # the baton (see Lockstep): runs only while the caller's thread waits in submit() or has finished
+                torch.cuda.set_device(dev)
+                _tls.lockstep, _tls.idx = ls, 1
+                with torch.cuda.stream(cur), torch.set_grad_enabled(grad):
+                    box["b"] = fn_b()
         except BaseException as e:     # noqa: BLE001 - re-raised on the caller's thread
             box["err"] = e
         finally:
@@ -523,10 +529,11 @@ def lockstep(fn_a, fn_b):
             ls.finish(1)
 
     t = threading.Thread(target=worker, name="magic-lockstep")
-    t.start()
     _tls.lockstep, _tls.idx = ls, 0
     try:
-        a = fn_a()
+        with ls.cv:
+            t.start()
+            a = fn_a()
     finally:
         _tls.lockstep = None
         ls.finish(0)

@@ -12,16 +12,12 @@ JSON line.  `roofline` = the Linear-layer contraction family (MFMA GEMM kernels 
 durations measured with HIP events on the launch stream in a separate instrumented pass; `cpu_baseline` = the
 CPU oracle (oracle/, a restatement -- the reference's model source is withheld) timed on the host cores.
 """
-import os as _os0
-# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams on one queue SERIALISE.  The pretraining step keeps main,
-# the teacher's side stream (parked on its start gate while the student's encoder launch goes resident), the gradient-exchange stream and RCCL's
-# internal stream busy at once: with four queues the teacher's stream shared the main stream's queue as soon as a process group existed -- the gate
-# never opened and the data-parallel step ran at 2.16 instead of 1.71-1.75 ms (round 5, --dp-structure).  Read when the HIP runtime initialises, so
-# it is set here, before anything touches the GPU; a value the user exported is kept.  (The navigator loop is the opposite case -- its lanes and
-# forked branches hand work between streams all the time, which is cheaper inside a queue: 139 ms per iteration with 4 queues, 175-187 with 8 -- so
-# bench_nav.py leaves the default, and the navigator legs this script spawns do not inherit the setting.)
-_HWQ_USER = "GPU_MAX_HW_QUEUES" in _os0.environ
-_os0.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Streams and hardware queues.  HIP deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams on one queue run IN ORDER:
+# every side stream of the step (the teacher's, the gradient exchange's, the rollout lanes') is therefore picked by lanes.beside, which measures that the
+# candidate really runs beside the main stream (csrc/encoder.hip magic_stream_probe; the line's `streams` block).  Raising the number of queues instead
+# was measured and rejected (round 5, same box, this script): GPU_MAX_HW_QUEUES=8 left the headline and the data-parallel structure where they are
+# (1.461 / 1.753 ms against 1.463 / 1.733 with the default) but ran the fp16 twin at 2.79 ms instead of 1.48 and the navigator loop at 175-187 ms
+# instead of 139.  The runtime default stays; a value the user exports is passed through untouched.
 import argparse
 import json
 import os
@@ -71,6 +67,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import magic_amd  # noqa: E402,F401
 from magic_amd.host import lib as L  # noqa: E402
+from magic_amd.host import lanes as _lanes  # noqa: E402
 from magic_amd.host import ops as O  # noqa: E402
 from magic_amd.host import synth  # noqa: E402
 from magic_amd.host.config import make_config  # noqa: E402
@@ -453,8 +450,6 @@ def secondary_block():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     nav_env = dict(env)
-    if not _HWQ_USER:
-        nav_env.pop("GPU_MAX_HW_QUEUES", None)          # the navigator loop runs on the default number of hardware queues (see the top of this file)
     for name, extra in runs.items():
         try:
             r = subprocess.run([py, nav] + common + extra, capture_output=True, text=True, timeout=240, env=nav_env)
@@ -886,6 +881,9 @@ def main():
                 "ms_per_step_steady": (round((dt - (cap_at[("s", "end")] - cap_at.get(("s", a.warmup), 0.0))) / a.steps * 1e3, 3) if stream_step is not None and a.mode == "stream-graph" and a.teacher != "same"
                                        else (steady["ms_per_step"] if steady is not None else None)),
                 "steady": steady, "teacher_gate": gate, "health": health, "build_id": L.library_build_id(),
+                "streams": {"hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"), "picked": list(_lanes.probe_log),
+                            "what": "every side stream (teacher, gradient exchange) is picked by lanes.beside: candidates from torch's pool until one is "
+                                    "measured to run beside the main stream (csrc/encoder.hip magic_stream_probe); `tried` = candidates it took"},
                 "launch": a.mode if a.mode not in ("stream", "stream-graph") else f"{a.mode}/{a.ingest}/{a.workers}w" + (f"/{stream_step.captures} bucket graphs, {cap_at['end'] - cap_at.get(a.warmup, 0)} of them captured inside the timed steps" if stream_step is not None else ""),
                 "teacher_schedule": ({"split": "one batch ahead of the student, own graph on a side stream", "ahead": "one batch ahead of the student (fork/join inside the step graph)"}.get(a.teacher, "same batch, side stream") if a.mode == "graph" else "same batch, side stream"),
                 "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "

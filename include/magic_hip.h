@@ -434,6 +434,13 @@ int magic_encoder_fwd(int dtype, const void* params, int nbytes, void* stream);
  * [0] calls, [1] opened while waiting, [2] launch already resident at entry, [3] timeouts, [4] consecutive timeouts, [5] switched off,
  * [6] calls skipped while off, [7] reserved.  No reference counterpart (torch issues everything on one stream). */
 int magic_encoder_start_gate(int timeout_us, int recent_us, unsigned* stats, void* stream);
+/* Do launches on two streams of this process run side by side?  The runtime maps streams onto a few hardware queues; two streams that
+ * share one execute in order, and work meant to overlap (the teacher's graph beside the student's, a rollout lane beside the other, a
+ * gradient exchange beside the backward) then silently serialises.  Launches a bounded waiter (<= timeout_us, 1..100000) on stream_wait
+ * and its release on stream_set; after synchronising both, word2[1] == 1 says the release overtook the waiter (side by side), 2 that the
+ * waiter timed out (in order).  word2: 2 x uint32 of zeroed device memory; both streams idle at the call.  MAGIC_ERR_ARG for equal
+ * streams.  No reference counterpart (torch issues everything on one stream). */
+int magic_stream_probe(unsigned* word2, int timeout_us, void* stream_wait, void* stream_set);
 /* Health of the row-split encoder launches (magic_encoder_fwd / magic_xencoder_fwd with sync != NULL): out[0] = bounded in-launch hand-off
  * waits that GAVE UP since the process started (sticky; any value but 0 means some activations were computed from rows that never arrived
  * and the caller must stop), out[1] = whole-encoder launches that became resident.  out: 2 x uint32 of device memory; one tiny launch. */

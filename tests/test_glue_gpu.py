@@ -207,3 +207,30 @@ def test_lockstep_segments_alternate_and_pair_inside_a_capture():
         for k in range(n_calls):
             ref = A[i].float() @ W[i][k].float().t()
             assert torch.allclose(C[i][k].float(), ref, rtol=2e-2, atol=2e-1), (i, k)
+
+
+def test_side_streams_are_picked_by_measuring_that_they_run_beside_the_main_stream():
+    """lanes.beside / csrc/encoder.hip magic_stream_probe: the runtime deals streams onto a few hardware queues and two streams on one queue run
+    in order; the teacher's stream, the rollout lanes and the gradient-exchange stream are therefore chosen by a measurement, not by luck"""
+    from magic_amd.host import lanes
+    from magic_amd.host import lib as L
+    main = torch.cuda.current_stream()
+    n0 = len(lanes.probe_log)
+    s = lanes.beside([main])
+    assert lanes.probe_log[n0]["found"] and s.cuda_stream != main.cuda_stream
+    assert lanes.runs_beside(s, main) and lanes.runs_beside(main, s)
+    t = lanes.beside([main, s])                                   # (the exchange stream: beside the student's AND the teacher's)
+    assert len({main.cuda_stream, s.cuda_stream, t.cuda_stream}) == 3 and lanes.runs_beside(t, s) and lanes.runs_beside(t, main)
+    # the probe does tell streams that share a queue apart: among torch's 32 pool streams some pair must (there are fewer queues than that)
+    pool, seen = [], set()
+    for _ in range(40):
+        c = torch.cuda.Stream()
+        if c.cuda_stream not in seen:
+            seen.add(c.cuda_stream)
+            pool.append(c)
+    in_order = sum(not lanes.runs_beside(pool[0], c) for c in pool[1:])
+    print(f"{len(pool)} pool streams: {in_order} of {len(pool) - 1} run in order with the first one")
+    assert 0 < in_order < len(pool) - 1
+    w = torch.zeros(2, dtype=torch.int32, device=DEV)
+    with pytest.raises(L.MagicHipError):
+        L.call("magic_stream_probe", L.P(w), 100, s.cuda_stream, s.cuda_stream)

@@ -929,6 +929,31 @@ extern "C" int magic_encoder_start_gate(int timeout_us, int recent_us, unsigned*
   return launch_status();
 }
 
+// Do two streams run SIDE BY SIDE?  The runtime deals its streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and
+// two streams that land on one queue execute in order.  w[0]: the flag, w[1]: 1 = the waiter saw the flag, 2 = it ran out of time.
+__global__ void stream_probe_wait_kernel(long long timeout_ticks, unsigned* w) {
+  if (threadIdx.x) return;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    if (wall_clock64() - t0 >= timeout_ticks) { w[1] = 2; return; }
+    __builtin_amdgcn_s_sleep(32);
+  }
+  w[1] = 1;
+}
+__global__ void stream_probe_set_kernel(unsigned* w) {
+  if (threadIdx.x == 0) __hip_atomic_store(&w[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One waiter (a sleeping wave, at most timeout_us) on `stream_wait`, then the launch that releases it on `stream_set`: on streams that
+// share a hardware queue the release sits behind the waiter and the waiter times out.  word2: 2 x uint32 of ZEROED device memory; the caller
+// synchronises both streams and reads word2[1] (1 = side by side, 2 = in order).  Both streams must be idle when this is called.
+extern "C" int magic_stream_probe(unsigned* word2, int timeout_us, void* stream_wait, void* stream_set) {
+  if (!word2 || timeout_us < 1 || timeout_us > 100000 || stream_wait == stream_set) return MAGIC_ERR_ARG;
+  hipLaunchKernelGGL(stream_probe_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_wait, (long long)timeout_us * 100, word2);
+  if (int rc = launch_status()) return rc;
+  hipLaunchKernelGGL(stream_probe_set_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_set, word2);
+  return launch_status();
+}
+
 __global__ void enc_health_kernel(unsigned* out) {
   if (threadIdx.x == 0) {
     out[0] = __hip_atomic_load(&magic_enc_gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -25,13 +25,57 @@ _streams = {}          # (device index, lane) -> torch.cuda.Stream
 _used = {}             # device index -> set of lane streams that have work queued since the last join
 
 
+PROBE_US = 300         # the probe's waiter gives up after this long (a release on another queue arrives within ~10 us)
+probe_log = []         # one record per `beside` call (bench.py prints them)
+
+
+def runs_beside(a, b):
+    """do launches on streams a and b run side by side (True) or in order (False)?  The runtime deals streams onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, default 4) and two streams on one queue serialise -- csrc/encoder.hip magic_stream_probe.  Drains the device."""
+    from . import lib as L
+    dev = a.device
+    torch.cuda.synchronize(dev)
+    w = torch.zeros(2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.device(dev):
+        L.call("magic_stream_probe", L.P(w), PROBE_US, a.cuda_stream, b.cuda_stream)
+    torch.cuda.synchronize(dev)
+    return int(w[1].item()) == 1
+
+
+def beside(others, device=None, priority=None, tries=16):
+    """a new stream that is PROVEN to run beside every stream in `others` (the teacher's stream beside the student's, a rollout lane beside
+    lane 0, the gradient exchange beside both): torch hands out pool streams round-robin and the runtime deals them onto its hardware
+    queues round-robin, so whether two given streams overlap is otherwise an accident of how many streams were made before them.  Takes
+    candidates from torch's pool until one passes `runs_beside` against all of `others`; if none does in `tries` (one hardware queue, a
+    tool serialising the device) the last candidate is returned and the caller's work runs in order, as it would have.  Outside a capture."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    mk = (lambda: torch.cuda.Stream(device=dev, priority=int(priority))) if priority is not None else (lambda: torch.cuda.Stream(device=dev))
+    if torch.cuda.is_current_stream_capturing():
+        return mk()
+    seen, s = set(), None
+    for n in range(1, tries + 1):
+        s = mk()
+        if s.cuda_stream in seen:            # the pool wrapped around
+            break
+        seen.add(s.cuda_stream)
+        if all(o is not None and s.cuda_stream != o.cuda_stream and runs_beside(s, o) for o in others):
+            probe_log.append(dict(tried=n, found=True))
+            return s
+    probe_log.append(dict(tried=len(seen), found=False))
+    return s
+
+
 def stream(device, k):
-    """lane k's stream on `device` (k >= 1; lane 0 is whatever stream is current)"""
+    """lane k's stream on `device` (k >= 1; lane 0 is whatever stream is current).  Picked to run beside the stream that is current when the
+    lane is first asked for (lane 0's) and beside the lower lanes"""
     dev = torch.device(device)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(k))
     s = _streams.get(key)
     if s is None:
-        s = _streams[key] = torch.cuda.Stream(device=torch.device("cuda", key[0]))
+        d = torch.device("cuda", key[0])
+        lower = [v for (i, kk), v in _streams.items() if i == key[0] and kk < key[1]]
+        s = _streams[key] = beside([torch.cuda.current_stream(d)] + lower, device=d)
     return s
 
 

@@ -90,6 +90,7 @@ SIGNATURES = {
     "magic_encoder_fwd": [i32, vp, i32, vp],
     "magic_encoder_start_gate": [i32, i32, vp, vp],
     "magic_encoder_health": [vp, vp],
+    "magic_stream_probe": [vp, i32, vp, vp],
     "magic_chain_supported": [i32, i32, i32],
     "magic_chain_fwd": [i32, vp, i32, vp],
     "magic_chain_tile_rows": [i32],

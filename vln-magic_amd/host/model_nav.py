@@ -471,6 +471,16 @@ class _fork:
         return False
 
 
+NAV_PAIR = os.environ.get("MAGIC_NAV_PAIR", "0") == "1"
+
+
+def _pair_branches(fork):
+    """pair the two cross-modal encoders' launches (lib.lockstep) instead of forking one onto a side stream: only where a fork was offered (the
+    captured step instances: the branches are independent there) and only inside a capture (eagerly the per-call rendezvous of two host threads
+    costs more than the launches it saves)"""
+    return NAV_PAIR and fork is not None and torch.cuda.is_current_stream_capturing()
+
+
 def nav_forward_body(model, gmap_img, vp_img, txt_embeds, b, txt_kv=None):
     """the navigation segment (both cross-modal encoders + heads + logit fusion) on the engine: returns (ctx namespace, outputs).  Plain
     function: run by the eager autograd Function below and by the captured step instances (host/step_graphs.py)."""
@@ -497,12 +507,22 @@ def nav_forward_body(model, gmap_img, vp_img, txt_embeds, b, txt_kv=None):
     # the two cross-modal encoders are independent until the heads: on a side stream when the caller provides one (`b["fork"]`: the captured
     # step instances -- inside a HIP graph the two become parallel branches, and a 600-row GEMM leaves half of the chip to the other encoder)
     dist_f = b["gmap_pair_dists"].float().contiguous()
-    with _fork(b.get("fork")) as side:
-        with side:
-            c.loc = net.cross_fwd("local", plan, c.vin.out, Vp, vmask_u8, vl, int(sum(vl)), txt, L, tmask, tl, int(sum(tl)),
-                                  kv=None if kv is None else kv[nl:])
-        c.glob = net.cross_fwd("global", plan, c.gin.out, K, gmask_u8, gl_, int(sum(gl_)), txt, L, tmask, tl, int(sum(tl)),
-                               dist=dist_f, kv=None if kv is None else kv[:nl])
+    if _pair_branches(b.get("fork")):
+        # ... or PAIRED: the two encoders have the same launch sequence, so inside a capture two host threads issue them in lockstep and
+        # every groupable launch (GEMM, LayerNorm, attention) of the one goes out together with its twin of the other as ONE kernel
+        from . import lib as _L
+        c.glob, c.loc = _L.lockstep(
+            lambda: net.cross_fwd("global", plan, c.gin.out, K, gmask_u8, gl_, int(sum(gl_)), txt, L, tmask, tl, int(sum(tl)),
+                                  dist=dist_f, kv=None if kv is None else kv[:nl]),
+            lambda: net.cross_fwd("local", plan, c.vin.out, Vp, vmask_u8, vl, int(sum(vl)), txt, L, tmask, tl, int(sum(tl)),
+                                  kv=None if kv is None else kv[nl:]))
+    else:
+        with _fork(b.get("fork")) as side:
+            with side:
+                c.loc = net.cross_fwd("local", plan, c.vin.out, Vp, vmask_u8, vl, int(sum(vl)), txt, L, tmask, tl, int(sum(tl)),
+                                      kv=None if kv is None else kv[nl:])
+            c.glob = net.cross_fwd("global", plan, c.gin.out, K, gmask_u8, gl_, int(sum(gl_)), txt, L, tmask, tl, int(sum(tl)),
+                                   dist=dist_f, kv=None if kv is None else kv[:nl])
     # heads
     c.Yg, c.g_raw = model._cls(p + "global_sap_head.", c.glob.out, B * K)
     c.Yl, c.l_raw = model._cls(p + "local_sap_head.", c.loc.out, B * Vp)
@@ -581,12 +601,26 @@ def nav_backward_body(model, c, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl, dkv_
         if fork is not None and not c.has_kv:
             fork = None                   # (without the K/V cache both encoders add into d_txt: keep them in order)
         sga, sva = attn_seed(d_ga, c.glob.P, K), attn_seed(d_va, c.loc.P, Vp)
-        with _fork(fork) as side:
-            with side:
-                d_vin = net.cross_bwd(c.loc, d_vp, d_txt, sva, dkv=None if dkv is None else dkv[nl:], acc_kv=acc)
-                net.vp_in_bwd(c.vin, c.plan, d_vin, None)
-            d_gin = net.cross_bwd(c.glob, d_gmap, d_txt, sga, dkv=None if dkv is None else dkv[:nl], acc_kv=acc)
-            net.gmap_in_bwd(c.gin, c.plan, d_gin, None, None)
+        if _pair_branches(fork):
+            from . import lib as _L
+
+            def b_loc():
+                d = net.cross_bwd(c.loc, d_vp, d_txt, sva, dkv=None if dkv is None else dkv[nl:], acc_kv=acc)
+                net.vp_in_bwd(c.vin, c.plan, d, None)
+                return d
+
+            def b_glob():
+                d = net.cross_bwd(c.glob, d_gmap, d_txt, sga, dkv=None if dkv is None else dkv[:nl], acc_kv=acc)
+                net.gmap_in_bwd(c.gin, c.plan, d, None, None)
+                return d
+            d_gin, d_vin = _L.lockstep(b_glob, b_loc)
+        else:
+            with _fork(fork) as side:
+                with side:
+                    d_vin = net.cross_bwd(c.loc, d_vp, d_txt, sva, dkv=None if dkv is None else dkv[nl:], acc_kv=acc)
+                    net.vp_in_bwd(c.vin, c.plan, d_vin, None)
+                d_gin = net.cross_bwd(c.glob, d_gmap, d_txt, sga, dkv=None if dkv is None else dkv[:nl], acc_kv=acc)
+                net.gmap_in_bwd(c.gin, c.plan, d_gin, None, None)
     finally:
         net.drop = cur
     return d_gin, d_vin, (None if c.has_kv else d_txt), (None if acc else dkv)

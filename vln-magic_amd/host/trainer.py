@@ -164,14 +164,18 @@ def cu_mask_words(spec, n_cu=256):
     return words
 
 
-def _side_stream(dev):
-    """the frozen teacher's stream.  MAGIC_TEACHER_CUS=N[:pattern] confines it to N compute units (a queue property, honoured under graph
-    replay as long as the graph is launched on this stream): the teacher is off the critical path, its launches then stop taking CUs from
-    the student's in bursts.  Opt-in: see DESIGN.md section 5 for what it measured."""
+def _side_stream(dev, others=()):
+    """the frozen teacher's stream: one that is proven to run BESIDE the student's (and the gradient exchange's) -- lanes.beside: which
+    hardware queue a stream lands on is an accident of how many streams the process made before it, and a teacher stream sharing the
+    student's queue runs in order with it (its start gate then only ever times out).  MAGIC_TEACHER_CUS=N[:pattern] confines it to N
+    compute units instead (a queue property, honoured under graph replay as long as the graph is launched on this stream): the teacher is
+    off the critical path, its launches then stop taking CUs from the student's in bursts.  Opt-in: see DESIGN.md section 5 for what it
+    measured."""
     spec = os.environ.get("MAGIC_TEACHER_CUS")
     if not spec:
+        from . import lanes
         pr = os.environ.get("MAGIC_TEACHER_PRIORITY")
-        return torch.cuda.Stream(priority=int(pr)) if pr else torch.cuda.Stream()
+        return lanes.beside([torch.cuda.current_stream(dev)] + [o for o in others if o is not None], device=dev, priority=int(pr) if pr else None)
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -210,7 +214,10 @@ class GradSync:
         self.force = self.world == 1 and bool(os.environ.get("MAGIC_DP_STRUCTURE")) and dist.is_available() and dist.is_initialized()
         self.chunk = chunk_elems
         self.card_shared = self._ranks_share_a_card()
-        self.stream = torch.cuda.Stream() if ((self.world > 1 or self.force) and store.device.type == "cuda") else None
+        self.stream = None
+        if (self.world > 1 or self.force) and store.device.type == "cuda":
+            from . import lanes
+            self.stream = lanes.beside([torch.cuda.current_stream(store.device)], device=store.device)     # the exchange runs UNDER the backward
         self.overlap = (not os.environ.get("MAGIC_DDP_NO_OVERLAP")) if overlap is None else overlap
         g0d, g0n = store.first_offset(LATE_PREFIXES, True), store.first_offset(LATE_PREFIXES, False)
         nd, tot = store.n_decay, store.total
@@ -423,7 +430,7 @@ class PretrainStep:
         self.on_gpu = self.dev.type == "cuda"
         self.side = None
         if self.on_gpu and teacher is not None and overlap_teacher and not os.environ.get("MAGIC_NO_TEACHER_SIDE"):
-            self.side = _side_stream(self.dev)
+            self.side = _side_stream(self.dev, (self.sync.stream,))
         if self.on_gpu and overlap_dw and O.SIDE["stream"] is None and os.environ.get("MAGIC_DW_SIDE"):   # opt-in: no gain measured on MI355X
             O.SIDE["stream"] = torch.cuda.Stream()       # weight-gradient GEMMs leave the dX critical chain
         self.global_step = 0

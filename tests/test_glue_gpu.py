@@ -102,7 +102,8 @@ def test_dw_guard_orders_streams_that_share_the_weight_gradient_workspace():
     lane (own pair): no wait."""
     import torch
     from magic_amd.host import lanes
-    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    a = lanes.beside([torch.cuda.current_stream()])        # two streams that really run side by side (two pool streams may share a hardware queue:
+    b = lanes.beside([torch.cuda.current_stream(), a])     # the "did not wait" half of this test would then see an ordering nobody asked for)
     x = torch.randn(4096, 4096, device=DEV)
     torch.cuda.synchronize()
     O._DW_LAST.clear()

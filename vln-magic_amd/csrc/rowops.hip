@@ -1282,7 +1282,8 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
               DropDesc{(don && site_dy) ? (const unsigned*)drop_seed : nullptr, site_dy, drop_p},
               (don && site_dx) ? dxm : nullptr, DropDesc{(don && site_dx) ? (const unsigned*)drop_seed : nullptr, site_dx, drop_p}, hot0, pg_partial ? 1 : 0};
   const int nit = H / 128;
-  if (pg_partial && group_state().active && lnb_lean(p, nit) && lnb_lean_cfg() != 42) return MAGIC_ERR_ARG;   // (partial rows are sized for a single launch)
+  // (partial rows are sized for a single launch: a paired launch takes the 4-wave x 2-row shape, 8 rows per workgroup -- fine when the single form has 8 too)
+  if (pg_partial && group_state().active && lnb_lean(p, nit) && (lnb_lean_cfg() / 10) * (lnb_lean_cfg() % 10) != 8) return MAGIC_ERR_ARG;
   if (group_record(KIND_LNB, dtype, nit, &p, sizeof(p))) return MAGIC_OK;
   return launch_lnb(dtype, nit, &p, nullptr, (hipStream_t)stream);
 }

@@ -17,6 +17,7 @@ gradients records `cur` in its forward and re-enters it in its backward (the aut
 forward ran on).  One thread at a time: the loop's thread in the forward, the engine's device thread during `backward()`.
 """
 import contextlib
+import os
 
 import torch
 
@@ -25,6 +26,7 @@ _streams = {}          # (device index, lane) -> torch.cuda.Stream
 _used = {}             # device index -> set of lane streams that have work queued since the last join
 
 
+LANE_PROBE = os.environ.get("MAGIC_LANE_PROBE", "0") == "1"
 PROBE_US = 300         # the probe's waiter gives up after this long (a release on another queue arrives within ~10 us)
 probe_log = []         # one record per `beside` call (bench.py prints them)
 
@@ -74,8 +76,11 @@ def stream(device, k):
     s = _streams.get(key)
     if s is None:
         d = torch.device("cuda", key[0])
-        lower = [v for (i, kk), v in _streams.items() if i == key[0] and kk < key[1]]
-        s = _streams[key] = beside([torch.cuda.current_stream(d)] + lower, device=d)
+        if LANE_PROBE:
+            lower = [v for (i, kk), v in _streams.items() if i == key[0] and kk < key[1]]
+            s = _streams[key] = beside([torch.cuda.current_stream(d)] + lower, device=d)
+        else:
+            s = _streams[key] = torch.cuda.Stream(device=d)
     return s
 
 

@@ -471,7 +471,9 @@ class _fork:
         return False
 
 
-NAV_PAIR = os.environ.get("MAGIC_NAV_PAIR", "0") == "1"
+# measured (profiles/micro/r05_ab_nav_pair.txt, same box, bench_nav.py 10 + 10 iterations): MAGIC-L navigator iteration 142.7 -> 130.4 ms, ICoD iteration
+# 133.5 -> 108.0 ms against the forked form (the same launches as two parallel branches of the step's graph)
+NAV_PAIR = os.environ.get("MAGIC_NAV_PAIR", "1") == "1"
 
 
 def _pair_branches(fork):

@@ -908,6 +908,37 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupedParams gp) {
   }
 }
 
+// K-group form of the grouped launch (the navigator step's PAIRED GEMMs: the map branch's and the viewpoint branch's twin Linears, a few hundred rows
+// each at H = 768): as gemm_kg_kernel, 4 K-groups per workgroup, for launches whose problems all have a long K and together fewer tiles than the
+// chip holds workgroups of this size.  No split-K problems (they take the plain grouped kernel).
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(1024) void gemm_grouped_kg_kernel(GroupedParams gp) {
+  constexpr int IMG = BM * TT<T>::STRIDE;
+  static_assert(2 * KGROUPS * IMG * sizeof(T) >= (KGROUPS - 1) * 16 * 256 * sizeof(float), "reduction buffer");
+  __shared__ __attribute__((aligned(16))) T smem[2 * KGROUPS * IMG];
+  const int id = blockIdx.x;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i) g += (i < gp.n && id >= gp.start[i]) ? 1 : 0;      // block-uniform
+  const GemmParams& p = gp.p[g];
+  const int local = id - gp.start[g];
+  if (local >= gp.cnt[g]) return;
+  const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM;
+  const int ny8 = gp.ny8[g];
+  int bx, by, z;
+  if (ny8 > 0) {
+    const int per_z = nx * ny8;
+    z = local / per_z;
+    const int l2 = local - z * per_z, xcd = l2 & 7, slot = l2 >> 3, lr = slot / nx;
+    bx = slot - lr * nx;
+    by = lr * 8 + xcd;
+    if (by >= ny) return;
+  } else {
+    bx = local % nx; by = (local / nx) % ny; z = local / (nx * ny);
+  }
+  gemm_block<T, LAYOUT, 2, KGROUPS>(p, bx, by, z, smem, smem + KGROUPS * IMG);
+}
+
 // Weight-gradient form with COMPACT descriptors (64 B per problem instead of a 184 B GemmParams): up to DW_MAX problems per launch fit
 // the kernel-argument block.  Every dependent launch of the replayed step costs ~9 us whatever its work (8 -> 16 problems per launch:
 // 2.93 -> 2.88 ms per step; 48 compact: 2.79; 96: 2.77), so the step's ~80 weight gradients go out in ONE launch (6.9 KB of kernel arguments).
@@ -1260,6 +1291,26 @@ int launch_gemm_n(int dtype, int layout, const void* const* ps, int n, hipStream
   for (int i = 0; i < n; ++i) { gp.p[i] = *(const GemmParams*)ps[i]; total += group_place(gp, i, total); }
   for (int i = n; i <= GROUP_MAX; ++i) gp.start[i] = total;
   dim3 grid(total);
+  // every problem with a long K, no split-K, and few tiles in all: the K-group form.  OPT-IN (MAGIC_GEMM_KG_GROUP=1; _TILES moves the bound): back to
+  // back it wins where the single-problem form does (profiles/micro/r05_pair_gemm_probe.txt: 624 + 512 rows x 768 x 768 9.2 vs 10.8 us, K = 3072
+  // 20.5 vs 30.5; past ~224 tiles it loses, 16.2 vs 12.5 us), but the navigator iteration runs two rollout lanes side by side and a launch of
+  // 1024-thread / 72 KB workgroups leaves the other lane's kernels no room on the CUs: 142.0 vs 135.5 ms per iteration
+  static int kgg = -1, kgg_tiles = 224;
+  if (kgg < 0) {
+    const char* e = getenv("MAGIC_GEMM_KG_GROUP"); kgg = e ? atoi(e) : 0;
+    const char* t = getenv("MAGIC_GEMM_KG_GROUP_TILES"); if (t) kgg_tiles = atoi(t);
+  }
+  bool kg_ok = kgg && layout != 2 && total <= kgg_tiles;
+  for (int i = 0; i < n && kg_ok; ++i) kg_ok = gp.p[i].splitk == 1 && gp.p[i].K >= 768 && gp.ny8[i] >= 0;
+  if (kg_ok) {
+    dim3 bk(1024);
+#define LAUNCHGK(TY, L) hipLaunchKernelGGL((gemm_grouped_kg_kernel<TY, L>), grid, bk, 0, st, gp)
+    if (dtype == DT_BF16) { if (layout == 0) LAUNCHGK(bf16, 0); else LAUNCHGK(bf16, 1); }
+    else if (dtype == DT_F16) { if (layout == 0) LAUNCHGK(f16, 0); else LAUNCHGK(f16, 1); }
+    else { if (layout == 0) LAUNCHGK(float, 0); else LAUNCHGK(float, 1); }
+#undef LAUNCHGK
+    return launch_status();
+  }
 #define LAUNCHG(TY, L) hipLaunchKernelGGL((gemm_grouped_kernel<TY, L>), grid, block, 0, st, gp)
   if (dtype == DT_BF16) {
     if (layout == 0) LAUNCHG(bf16, 0); else if (layout == 1) LAUNCHG(bf16, 1); else LAUNCHG(bf16, 2);

@@ -45,6 +45,9 @@ DW_SIDE = os.environ.get("MAGIC_STEP_GRAPH_DW_SIDE", "0") != "0"
 # is read-modify-written once per iteration instead of once per step (MAGIC-L: 528 MB per step was the per-step launch's whole cost)
 DW_CAT = os.environ.get("MAGIC_STEP_GRAPH_DW_CAT", "1") != "0"
 FORK = os.environ.get("MAGIC_STEP_GRAPH_FORK", "1") != "0"      # the two cross-modal encoders of a step as parallel branches of its graphs
+# a panorama step's backward graph on a stream of its own, beside the lane's chain of navigation-step backwards (needs DW_CAT: no weight-gradient
+# launch inside the step graphs)
+PANO_SIDE = os.environ.get("MAGIC_PANO_BWD_STREAM", "auto")      # "auto": nav_rollout.NavRollout decides per model (StepGraphs.pano_side); "0" / "1"
 K_BUCKET = 16          # map tokens are padded to a multiple of this
 V_STATIC = 37          # views per panorama the instances are built for (36, or 37 when two candidates share a discretised view)
 
@@ -189,8 +192,21 @@ class _PanoInstFn(torch.autograd.Function):
         model = inst.owner.model
         model.net.S.ensure_grads()
         _queue_sync(model)
-        with lanes.use(inst.lane):
-            inst.owner._run_bwd(inst, ("d_emb", "d_fused", "d_attn"), (d_emb, d_fused, d_attn))
+        owner = inst.owner
+        if owner.pano_side and DW_CAT:
+            # nothing later in this pass reads what a panorama step's backward writes (its parameter gradients belong to img_embeddings.* alone and
+            # are read when the pass ends; its inputs are features), and the next node on this lane -- the PREVIOUS step's navigation backward --
+            # touches other rows of the embedding log: the replay goes to the lane's panorama stream and the lane's chain carries on beside it
+            s2 = owner.pano_bwd_stream(inst.lane)
+            s2.wait_stream(torch.cuda.current_stream())
+            for t in (d_emb, d_fused, d_attn):
+                if t is not None:
+                    t.record_stream(s2)
+            with lanes.use(inst.lane, s2):
+                owner._run_bwd(inst, ("d_emb", "d_fused", "d_attn"), (d_emb, d_fused, d_attn))
+        else:
+            with lanes.use(inst.lane):
+                owner._run_bwd(inst, ("d_emb", "d_fused", "d_attn"), (d_emb, d_fused, d_attn))
         return None, None
 
 
@@ -237,11 +253,19 @@ class StepGraphs:
         self._rngs = {0: self.rng_counter}
         self._zc = {}
         self._cat_used, self._cat_intern, self._cat_plan, self._cat_stage = [], {}, {}, None
+        self._pbs = {}             # lane -> the stream its panorama steps' backward graphs replay on (PANO_SIDE)
+        self.pano_side = PANO_SIDE == "1"
         sets = getattr(model, "_step_graph_sets", None)
         if sets is None:
             sets = model._step_graph_sets = []
         import weakref
         sets.append(weakref.ref(self))
+
+    def pano_bwd_stream(self, lane):
+        s = self._pbs.get(lane)
+        if s is None:
+            s = self._pbs[lane] = torch.cuda.Stream(device=self.dev)
+        return s
 
     # ---- bookkeeping -------------------------------------------------------------------------------------------
     def _mode_key(self):
@@ -407,7 +431,7 @@ class StepGraphs:
             if t is not None:
                 dst = bi[n]
                 dst.copy_(t.reshape(dst.shape))
-        if g_dw is None:
+        if g_dw is None and not DW_CAT:
             O.dw_guard(self.dev)      # (the backward graph holds the weight-gradient launch: shared workspace + counters, ops.dw_guard)
         g.replay()
         if g_dw is not None:          # this step's weight gradients: on the device's weight-gradient stream, under the next step's backward chain

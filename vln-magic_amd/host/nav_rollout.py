@@ -144,7 +144,7 @@ def _tk(name):
 
 
 FUSED_MAKD = os.environ.get("MAGIC_NAV_FUSED_MAKD", "1") != "0"      # a step's mse distillation terms in one launch (makd_nav.compute_kd_losses_fused)
-PANO_SIDE = os.environ.get("MAGIC_PANO_BWD_STREAM", "auto")      # step_graphs.PANO_SIDE: "auto" = on for a rollout without a teacher model
+PANO_SIDE = os.environ.get("MAGIC_PANO_BWD_STREAM", "auto")      # step_graphs.PANO_SIDE: "auto" = on for the wide models (H >= 384)
 LANES = os.environ.get("MAGIC_NAV_LANES", "1") != "0"      # the rollouts of `run_interleaved` as gradient lanes on streams of their own
 
 
@@ -257,9 +257,11 @@ class NavRollout:
         sg = self._sg.get(id(model))
         if sg is None or sg.B != B:
             sg = self._sg[id(model)] = StepGraphs(model, self.table, B, self.Lcap)
-            # panorama backwards beside the lane's chain: the single-model iteration gains (MAGIC-L navigator 134.9 -> 124.6 ms), the ICoD iteration --
-            # two models' chains per lane already -- loses (114.8 -> 124.9): profiles/micro/r05_ab_pano_side.txt
-            sg.pano_side = PANO_SIDE == "1" or (PANO_SIDE == "auto" and self.teacher is None)
+            # panorama backwards beside the lane's chain: a WIDE model gains (MAGIC-L navigator iteration 134.9 -> 124.6 ms; ICoD with only its MAGIC-L
+            # teacher's panoramas there 120.1 -> 116.7), the MAGIC-S student's few-microsecond kernels lose (ICoD 120 -> 124-145 with the student's, 114.8 ->
+            # 124.9 with both): profiles/micro/r05_ab_pano_side.txt
+            sg.pano_side = (PANO_SIDE == "1" or (PANO_SIDE == "auto" and model.net.H >= 384)
+                            or (PANO_SIDE == "teacher" and model is self.teacher) or (PANO_SIDE == "student" and model is not self.teacher))
         return sg
 
     def _use_graphs(self, obs, grad, text_copies):

@@ -40,6 +40,21 @@ navprof)
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05_navprof -- python3 $R/bench_nav.py --steps 4 --warmup 8 --no-cpu-baseline --no-host-loop --no-profile > $O/r05_bench_nav_under_rocprof.json 2> $O/r05_navprof.err || exit 1
   find $O/r05_navprof -name "*kernel_stats.csv" -exec cp {} $O/r05_kernel_stats_nav.csv \;
   rm -rf $O/r05_navprof
+  # kernels per steady iteration as the profiler counts them (graph replays included; the instrumented pass of bench_nav.py launches eagerly and
+  # cannot see the paired step graphs): the same command with 8 more timed iterations, the difference of the two dispatch counts / 8
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05_navprof2 -- python3 $R/bench_nav.py --steps 12 --warmup 8 --no-cpu-baseline --no-host-loop --no-profile > /dev/null 2> $O/r05_navprof2.err || exit 1
+  find $O/r05_navprof2 -name "*kernel_stats.csv" -exec cp {} $O/r05_kernel_stats_nav12.csv \;
+  rm -rf $O/r05_navprof2
+  python3 - $O/r05_kernel_stats_nav.csv $O/r05_kernel_stats_nav12.csv > $O/r05_nav_launches.txt <<'PY'
+import csv, sys
+def tot(p):
+    rows = list(csv.DictReader(open(p)))
+    return sum(int(r["Calls"]) for r in rows), sum(float(r["TotalDurationNs"]) for r in rows)
+(c4, t4), (c12, t12) = tot(sys.argv[1]), tot(sys.argv[2])
+print(f"rocprofv3 --kernel-trace --stats of bench_nav.py (MAGIC-L navigator iteration), 8 warm-up + 4 timed iterations: {c4} kernel dispatches, {t4 / 1e6:.1f} ms of kernel time;")
+print(f"8 warm-up + 12 timed: {c12} dispatches, {t12 / 1e6:.1f} ms.  Per steady iteration (difference / 8): {(c12 - c4) / 8:.0f} kernel dispatches, {(t12 - t4) / 8e6:.1f} ms of kernel time")
+PY
+  cat $O/r05_nav_launches.txt
   python3 $R/profiles/micro/nav_kernel_breakdown.py --graphs --iters 8 > $O/r05_nav_breakdown.txt 2>&1
   MAGIC_NAV_TIMERS=1 python3 $R/profiles/micro/nav_kernel_breakdown.py --graphs --iters 6 2>&1 | grep -A12 "^host sections" > $O/r05_nav_host_sections.txt
   python3 $R/profiles/micro/nav_kernel_breakdown.py --graphs --icod --iters 8 2>&1 | grep "^iteration\|^instrumented" > $O/r05_nav_breakdown_icod.txt

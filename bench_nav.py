@@ -274,6 +274,9 @@ def main():
                            "avg_gemm_launch_us": round(gemm_ms / max(gemm_n, 1) * 1e3, 2), "gemm_ms": round(gemm_ms, 2),
                            "all_kernels_ms": round(all_ms, 2), "launches": sum(c for t, c in by.values()),
                            "instrumented_iteration_wall_ms": round(wall * 1e3, 1), "decisions": pdec,
+                           "instrumented_pass": "eager per-op launches, a HIP event pair around each: the timed iterations replay captured step graphs in which the "
+                                                "two cross-modal encoders' launches are PAIRED (one grouped kernel per twin pair), so they dispatch fewer kernels than "
+                                                "`launches` -- profiles/r05_nav_launches.txt holds the profiler's count per steady iteration",
                            "top_kernels_share": {k: round(t / all_ms, 4) for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:8]}}}
 
     host_loop = None

@@ -353,6 +353,12 @@ def P(t):
 
 PROFILE = {"on": False, "events": []}     # bench.py: per-launch HIP-event timing on the launch stream
 PAIRABLE = {"magic_gemm", "magic_attn_fwd", "magic_attn_bwd", "magic_linear_ln", "magic_linear_lnbwd", "magic_ln_bwd", "magic_chain_fwd", "magic_ln_fwd"}
+# calls lockstep cannot pair into one kernel but whose twin of the partner segment is independent and as long as the call itself (the key-split
+# attention backward of the two cross-modal encoders: one 512-thread workgroup per (sample, head), 157 KB of LDS, 48 us of single-workgroup latency):
+# when both threads have arrived at one, the partner's goes to the segment pair's side stream and runs BESIDE this thread's.  OPT-IN
+# (MAGIC_LOCKSTEP_FORK=1): measured on the MAGIC-L navigator iteration it LOSES -- 143-193 ms against 129-148 on the same box
+# (profiles/micro/ab_ks_fork_r05.sh): the fork / join edges inside the step graphs cost more than the half round of workgroups they hide
+FORKABLE = {"magic_attn_bwd_ks"} if os.environ.get("MAGIC_LOCKSTEP_FORK", "0") == "1" else set()
 _tls = threading.local()
 
 
@@ -403,7 +409,7 @@ class solo:
 
 def call(name, *args):
     ls = getattr(_tls, "lockstep", None)
-    if ls is not None and name in PAIRABLE and not getattr(_tls, "solo", False):
+    if ls is not None and (name in PAIRABLE or (name in FORKABLE and ls.side is not None)) and not getattr(_tls, "solo", False):
         return ls.submit(_tls.idx, name, args)
     if ls is not None and PROFILE["on"]:
         with ls.cv:            # instrumented pass: keep this launch's event pair free of the partner thread's launches
@@ -450,16 +456,34 @@ class Lockstep:
     nodes to one capturing stream at once can lose one of them from the stream's dependency chain (both read the same last node): the
     capture then ends with hipErrorStreamCaptureUnjoined -- seen once in some hundred captures before the baton."""
 
-    def __init__(self):
+    def __init__(self, side=None):
         self.cv = threading.Condition()
         self.pending = [None, None]
         self.done = [False, False]
         self.gen = 0
         self.pairs = 0
+        self.forks = 0
+        self.side = side              # a stream for the partner's half of a FORKABLE twin (None: forkable calls launch where they are)
 
     def submit(self, idx, name, args):
         other = 1 - idx
         with self.cv:
+            if self.pending[other] is not None and (name in FORKABLE or self.pending[other][0] in FORKABLE):
+                oname, oargs = self.pending[other]
+                if name in FORKABLE and oname in FORKABLE:       # twins: the partner's on the side stream, ours here, joined at once
+                    cur = torch.cuda.current_stream()
+                    self.side.wait_stream(cur)
+                    _raw_call(oname, tuple(oargs[:-1]) + (self.side.cuda_stream,))      # (the last argument of every entry point is its stream)
+                    _raw_call(name, args)
+                    cur.wait_stream(self.side)
+                    self.forks += 1
+                else:                                            # the segments are out of step here: one after the other, segment 0's first
+                    for n_, a_ in (((oname, oargs), (name, args)) if other == 0 else ((name, args), (oname, oargs))):
+                        _raw_call(n_, a_)
+                self.pending[other] = None
+                self.gen += 1
+                self.cv.notify_all()
+                return
             if self.pending[other] is not None:                  # partner is waiting: launch both as one group
                 oname, oargs = self.pending[other]
                 first, second = ((oname, oargs), (name, args)) if other == 0 else ((name, args), (oname, oargs))
@@ -505,12 +529,12 @@ class Lockstep:
             self.cv.notify_all()
 
 
-def lockstep(fn_a, fn_b):
+def lockstep(fn_a, fn_b, side=None):
     """returns (fn_a(), fn_b()) with their groupable launches paired (see Lockstep).  fn_b runs on a helper thread bound to
-    the caller's device and current stream."""
+    the caller's device and current stream.  side: a stream for the partner's half of FORKABLE twins."""
     if getattr(_tls, "lockstep", None) is not None:              # no nesting: run sequentially inside an outer lockstep
         return fn_a(), fn_b()
-    ls = Lockstep()
+    ls = Lockstep(side)
     cur = torch.cuda.current_stream()
     dev = torch.cuda.current_device()
     grad = torch.is_grad_enabled()

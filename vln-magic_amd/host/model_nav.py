@@ -615,7 +615,7 @@ def nav_backward_body(model, c, d_g, d_v, d_ga, d_va, d_cls, dgl, dll, dfl, dkv_
                 d = net.cross_bwd(c.glob, d_gmap, d_txt, sga, dkv=None if dkv is None else dkv[:nl], acc_kv=acc)
                 net.gmap_in_bwd(c.gin, c.plan, d, None, None)
                 return d
-            d_gin, d_vin = _L.lockstep(b_glob, b_loc)
+            d_gin, d_vin = _L.lockstep(b_glob, b_loc, side=fork)
         else:
             with _fork(fork) as side:
                 with side:

@@ -245,11 +245,104 @@ def flush_dw(group=None, keep_active=False):
         lanes.fence_end(tok)
 
 
+# The deferred queue through the TILE-OWNER launch (csrc/gemm.hip gemm_dw_cat_kernel) instead of the split-K launch + deterministic seam: one workgroup
+# per 128 x 128 (64 x 64 for narrow problems) tile of a dW walks all rows of all uses of that Linear with the accumulators in registers -- every dY / X
+# panel is read once per tile row / column, dW is read-modify-written once, nothing goes through a workspace, and the sum order is fixed by
+# construction.  OPT-IN (MAGIC_DW_FLUSH_CAT=1), measured and rejected as the default in round 5: the MAGIC-S step has ~100 Linears of 128 x 128 -- ONE
+# tile each, whose workgroup then walks 30-60 k-tiles alone on its CU: 1.689 vs 1.456 ms/step (`bench.py`, same box; the split-K launch exists for exactly
+# this); on the MAGIC-L navigator iteration (the instruction encoder's dW at the end of the pass) 126-130 vs 126-131 ms: neutral.
+DW_FLUSH_CAT = os.environ.get("MAGIC_DW_FLUSH_CAT", "0") != "0"
+_CAT_TABLES = []           # device tables a captured graph reads: alive for the life of the process; eager flushes reuse a ring of (pinned, device, event)
+_CAT_RING = {"slots": [None] * 8, "turn": 0, "stream": {}}
+
+
+def _cat_tables(host_bytes, device):
+    """device copy of a flush's operand tables.  Eager: pinned slot of a ring -> device, on the current stream.  Inside a capture: uploaded on a
+    stream of its own and waited for on the host (a copy node in front of every replay of the step's weight-gradient launch would sit on the
+    step's critical path); the table then belongs to the graph: kept for good."""
+    n = int(host_bytes.nbytes)
+    dev = torch.device(device)
+    if torch.cuda.is_current_stream_capturing():
+        up = _CAT_RING["stream"].get(dev.index)
+        if up is None:
+            up = _CAT_RING["stream"][dev.index] = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(up):
+            d = torch.empty(n, dtype=torch.uint8, device=dev)
+            d.copy_(torch.from_numpy(host_bytes))
+        up.synchronize()
+        _CAT_TABLES.append(d)
+        return d
+    ring = _CAT_RING
+    i = ring["turn"] = (ring["turn"] + 1) % len(ring["slots"])
+    slot = ring["slots"][i]
+    if slot is not None:
+        slot[2].synchronize()
+    if slot is None or slot[0].numel() < n or slot[1].device != dev:
+        cap = max(2 * n, 1 << 14)
+        slot = ring["slots"][i] = (torch.empty(cap, dtype=torch.uint8, pin_memory=True), torch.empty(cap, dtype=torch.uint8, device=dev), torch.cuda.Event())
+    slot[0].numpy()[:n] = host_bytes
+    slot[1][:n].copy_(slot[0][:n], non_blocking=True)
+    slot[2].record()
+    return slot[1]
+
+
+def _flush_dw_cat(part, dt):
+    """`part`: queue entries of one dtype.  Returns False (nothing launched) when an entry does not fit the tile-owner form."""
+    import numpy as np
+    probs, segs = {}, []
+    for (dy, x, dW, db, M, N, K, lda, ldb, ldc, sk) in part:
+        key = dW.data_ptr()
+        j = probs.get(key)
+        dbp = db.data_ptr() if db is not None else 0
+        if j is None:
+            j = probs[key] = len(segs)
+            segs.append([(key, dbp, int(N), int(K), int(lda), int(ldb), int(ldc)), []])
+        elif segs[j][0] != (key, dbp, int(N), int(K), int(lda), int(ldb), int(ldc)):
+            return False               # one gradient queued with two shapes: leave it to the split-K launch
+        segs[j][1].append((dy.data_ptr(), x.data_ptr(), int(M)))
+        if FLOPS["enabled"]:
+            BYTES["dw"] += float(M) * (N + K) * dy.element_size() + 4.0 * N * K
+    ve = 8 if dt in (torch.bfloat16, torch.float16) else 4
+    for meta, _ in segs:
+        if meta[4] % ve or meta[5] % ve or meta[6] < meta[3]:
+            return False
+    wide = [sg for sg in segs if sg[0][2] >= 128 and sg[0][3] >= 128]
+    narrow = [sg for sg in segs if not (sg[0][2] >= 128 and sg[0][3] >= 128)]
+    launches, total = [], 0
+    for group in (wide, narrow):
+        group.sort(key=lambda sg: -len(sg[1]))                  # problems with equally many uses share a launch: fewer empty segments
+        for a in range(0, len(group), 96):
+            sel = group[a:a + 96]
+            n_seg = max(len(sg[1]) for sg in sel)
+            dy_t, x_t, m_t = np.zeros((len(sel), n_seg), np.int64), np.zeros((len(sel), n_seg), np.int64), np.zeros((len(sel), n_seg), np.int32)
+            for i, (_, uses) in enumerate(sel):
+                for k, (a_, b_, m_) in enumerate(uses):
+                    dy_t[i, k], x_t[i, k], m_t[i, k] = a_, b_, m_
+                dy_t[i, len(uses):], x_t[i, len(uses):] = uses[0][0], uses[0][1]          # (empty segments: any valid address)
+            launches.append(([sg[0] for sg in sel], n_seg, dy_t, x_t, m_t, total))
+            total = (total + len(sel) * n_seg * 20 + 15) & ~15
+    host = np.zeros(max(total, 16), np.uint8)
+    for probs_, n_seg, dy_t, x_t, m_t, off in launches:
+        n = len(probs_) * n_seg
+        host[off:off + 8 * n] = dy_t.reshape(-1).view(np.uint8)
+        host[off + 8 * n:off + 16 * n] = x_t.reshape(-1).view(np.uint8)
+        host[off + 16 * n:off + 20 * n] = m_t.reshape(-1).view(np.uint8)
+    base = _cat_tables(host, part[0][0].device).data_ptr()
+    for probs_, n_seg, dy_t, x_t, m_t, off in launches:
+        n = len(probs_) * n_seg
+        dw_cat(dt, probs_, n_seg, base + off, base + off + 8 * n, base + off + 16 * n)
+        if FLOPS["enabled"]:
+            BYTES["dw_launches"] += 1
+    return True
+
+
 def _flush_dw(group=None, keep_active=False):
     group = group or DW_GROUP
     flush_rbw_parts()
     q = DEFER["queue"]
     for dt in {e[0].dtype for e in q}:                 # one compute dtype per launch
+        if DW_FLUSH_CAT and _flush_dw_cat([e for e in q if e[0].dtype == dt], dt):
+            continue
         part = [e for e in q if e[0].dtype == dt]
         for i in range(0, len(part), group):
             chunk = part[i:i + group]

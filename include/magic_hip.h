@@ -113,6 +113,13 @@ int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void* y, const f
                  const int* idx2, int mod2, int off2, float* d2, int small2,
                  int do_ln, const void* drop_seed, float drop_p, unsigned site_dy, unsigned site_dx, void* dxm, int hot0, int pg_partial,
                  void* stream);
+/* The LayerNorm backward of a prediction head's transform (BertPredictionHeadTransform: dense -> gelu -> LayerNorm -> decoder; the MLM head of
+ * pretrain_src/model/pretrain_cmt.py via train_r2r_magic.py:441-467) together with its two neighbours in the backward chain: dy32 is the fp32
+ * [M, H] accumulator the split-K input gradient of the vocabulary projection leaves (no cast launch), and dx = LayerNorm'(dy) x act'(act_pre)
+ * (no activation-derivative launch; act: 1 = erf gelu, 2 = relu; act_pre: the dense output before the activation, storage dtype).  gamma / beta
+ * gradients are added as magic_ln_bwd does without partial rows.  Replaces cast + magic_ln_bwd + magic_dact. */
+int magic_ln_bwd_tail(int dtype, int M, int H, const float* dy32, const void* y, const float* gamma, const float* beta, const float* rstd,
+                      const void* act_pre, int act, void* dx, float* dgamma, float* dbeta, void* stream);
 /* hot0 >= 0: a row of indexed table 0 that a large share of the input rows hit (the padding token id of the word-embedding lookup): its
  * gradient is summed per workgroup in LDS and added with one atomic per element and workgroup (else -1).
  * pg_partial != 0 (round 5): dgamma / dbeta point at PARTIAL buffers of magic_ln_bwd_blocks(M, H) x H floats each, contents undefined: every

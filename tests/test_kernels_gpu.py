@@ -996,3 +996,49 @@ def test_weight_gradients_over_many_row_segments_in_one_launch(dtype):
         again = run()
         for (w, b), (w1, b1) in zip(first, again):
             assert torch.equal(w, w1) and (b is None or torch.equal(b, b1))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("H,M", [(128, 257), (768, 70), (256, 33), (384, 5)])
+def test_ln_bwd_tail_matches_torch_autograd_and_the_three_separate_launches(dtype, H, M):
+    """magic_ln_bwd_tail (the MLM head's transform, backward): fp32 dy in, dx = LayerNorm'(dy) x gelu'(pre) out, gamma / beta gradients -- against
+    fp32 torch autograd of LayerNorm(gelu(pre)) and against cast + magic_ln_bwd + magic_dact, the launches it replaces"""
+    gen = torch.Generator(DEV).manual_seed(H + M)
+    pre32 = torch.randn(M, H, device=DEV, generator=gen)
+    gamma = (1.0 + 0.1 * torch.randn(H, device=DEV, generator=gen)).contiguous()
+    beta = (0.1 * torch.randn(H, device=DEV, generator=gen)).contiguous()
+    dy32 = torch.randn(M, H, device=DEV, generator=gen).contiguous()
+    pre = pre32.to(dtype)
+    # forward through the library (what the backward recovers xhat from): y = LN(gelu(pre)), rstd
+    act = F.gelu(pre.float()).to(dtype)
+    y, rstd = torch.empty(M, H, device=DEV, dtype=dtype), torch.empty(M, device=DEV, dtype=torch.float32)
+    O.ln_fwd(M, H, y, in0=act, gamma=gamma, beta=beta, eps=1e-12, rstd=rstd)
+    # reference: fp32 autograd on the same rounded operands
+    p = pre.float().clone().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    F.layer_norm(F.gelu(p).to(dtype).float(), (H,), g_, b_, 1e-12).backward(dy32)
+    # fused
+    dx = torch.empty(M, H, device=DEV, dtype=dtype)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    O.ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, pre, 1, dx, dg, db)
+    # the three launches it replaces
+    dg3, db3 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    d_ln = torch.empty(M, H, device=DEV, dtype=dtype)
+    O.ln_bwd(M, H, dy32.to(dtype), y=y, gamma=gamma, beta=beta, rstd=rstd, dx=d_ln, dgamma=dg3, dbeta=db3)
+    dx3 = O.dact(d_ln, pre, 1)
+    torch.cuda.synchronize()
+    tol = 3e-2 if dtype != torch.float32 else 2e-4
+    scale = p.grad.abs().max().item()
+    assert (dx.float() - p.grad).abs().max().item() <= tol * scale, ((dx.float() - p.grad).abs().max().item(), scale)
+    assert (dx.float() - dx3.float()).abs().max().item() <= tol * scale
+    # the fused form never rounds dy / the LayerNorm gradient to 16 bits: it is at least as close to the fp32 reference as the separate launches
+    assert (dx.float() - p.grad).abs().max().item() <= (dx3.float() - p.grad).abs().max().item() * 1.5 + 1e-6
+    for got, ref, sep in ((dg, g_.grad, dg3), (db, b_.grad, db3)):
+        s_ = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= tol * s_ + 1e-5, ((got - ref).abs().max().item(), s_)
+        assert (got - sep).abs().max().item() <= tol * s_ + 1e-5
+    w = torch.zeros(2, device=DEV)
+    with pytest.raises(L.MagicHipError):
+        O.ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, pre, 3, dx, dg, db)             # unknown activation
+    with pytest.raises(L.MagicHipError):
+        L.call("magic_ln_bwd_tail", L.dt(dtype), M, 100, L.P(dy32), L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(pre), 1, L.P(dx), L.P(dg), L.P(db), L.stream())

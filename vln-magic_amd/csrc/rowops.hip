@@ -124,6 +124,9 @@ struct LnbParams {
   void* dxm; DropDesc ddx;    // the forward dropped its in0: second output dxm = dx * mask (gradient of the dense branch)
   int hot0;                   // >= 0: row of indexed table 0 that very many input rows hit (the padding token): summed per block in LDS
   int pg_partial;             // != 0: dgamma / dbeta are PARTIAL buffers [blocks][H]: every block stores its sums in its own row (no atomics)
+  // TAIL instantiation only (magic_ln_bwd_tail: the MLM head's transform): dy arrives as fp32 (the split-K accumulator of the vocabulary
+  // projection's input gradient) and dx leaves multiplied by the derivative of the activation in FRONT of the LayerNorm
+  const float* dy32; const void* act_pre; int act;
 };
 
 // NW = waves per block.  Every block ends in one same-address atomic per parameter / const-table element, and those serialise in L2
@@ -131,7 +134,7 @@ struct LnbParams {
 // TAB = false: no table gradients in this launch (the LayerNorms inside the transformer blocks: 25 of a navigator step's 26 launches).  The
 // table machinery costs 9 x 2 NIT registers per lane even when unused: at H = 768 the general form needs 256 VGPRs (one wave per SIMD:
 // 17.5 us for 608 rows, pure latency), the plain form half of that.
-template <typename T, int NIT, int NW, bool TAB = true, int RPI_ = 0>
+template <typename T, int NIT, int NW, bool TAB = true, int RPI_ = 0, bool TAIL = false>
 __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, const int nblk, float* red) {
   const int M = pp.M, do_ln = pp.do_ln, small0 = pp.small0, small1 = pp.small1, small2 = pp.small2;
   const T* dy = (const T*)pp.dy; const T* y = (const T*)pp.y; T* dx = (T*)pp.dx;
@@ -195,7 +198,12 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int c = it * 128 + lane * 2;
-        ld2<T>(dy + (long long)row * H + c, g[u][2 * it], g[u][2 * it + 1]);
+        if constexpr (TAIL) {
+          const float2 v = *(const float2*)(pp.dy32 + (long long)row * H + c);
+          g[u][2 * it] = v.x; g[u][2 * it + 1] = v.y;
+        } else {
+          ld2<T>(dy + (long long)row * H + c, g[u][2 * it], g[u][2 * it + 1]);
+        }
         if (sdy.on) { g[u][2 * it] *= drop_mul(sdy, (unsigned)(row * H + c)); g[u][2 * it + 1] *= drop_mul(sdy, (unsigned)(row * H + c + 1)); }
         if (do_ln) ld2<T>(y + (long long)row * H + c, xh[u][2 * it], xh[u][2 * it + 1]);
       }
@@ -231,7 +239,17 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
     for (int u = 0; u < RPI; ++u) {
       if (base + u < M) {
         const int row = phys(base + u);
-        if (dx) {
+        if constexpr (TAIL) {
+          const T* pre = (const T*)pp.act_pre;
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int c = it * 128 + lane * 2;
+            float za, zb;
+            ld2<T>(pre + (long long)row * H + c, za, zb);
+            const float da = pp.act == 1 ? dgelu_f(za) : (za > 0.f ? 1.f : 0.f), db = pp.act == 1 ? dgelu_f(zb) : (zb > 0.f ? 1.f : 0.f);
+            st2<T>(dx + (long long)row * H + c, g[u][2 * it] * da, g[u][2 * it + 1] * db);
+          }
+        } else if (dx) {
 #pragma unroll
           for (int it = 0; it < NIT; ++it) st2<T>(dx + (long long)row * H + it * 128 + lane * 2, g[u][2 * it], g[u][2 * it + 1]);
         }
@@ -340,6 +358,12 @@ template <typename T, int NIT, int NW, bool TAB = true, int RPI_ = 0>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(LnbParams p) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
   ln_bwd_body<T, NIT, NW, TAB, RPI_>(p, blockIdx.x, gridDim.x, red_dyn);
+}
+// TAIL: fp32 dy in, dx x act'(pre) out (see LnbParams); no table gradients
+template <typename T, int NIT, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_tail_kernel(LnbParams p) {
+  extern __shared__ __attribute__((aligned(16))) float red_dyn[];
+  ln_bwd_body<T, NIT, NW, false, 0, true>(p, blockIdx.x, gridDim.x, red_dyn);
 }
 template <typename T, int NIT, int NW, bool TAB = true>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_pair_kernel(LnbParams a, LnbParams b, int nA) {
@@ -1361,6 +1385,28 @@ int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t s
   else { if (nit == 1) LNB1(float, 1, 16); else if (nit == 2) LNB1(float, 2, 8); else if (nit == 3) LNB1(float, 3, 4); else LNB1(float, 6, 4); }
 #undef LNB2
 #undef LNB1
+  return launch_status();
+}
+
+// LayerNorm backward of a head's transform in one launch with its neighbours: dy in fp32 (no cast launch), dx = LN'(dy) x act'(pre) (no activation-
+// derivative launch); gamma / beta gradients as magic_ln_bwd's (atomics).  act: 1 gelu (erf), 2 relu.
+extern "C" int magic_ln_bwd_tail(int dtype, int M, int H, const float* dy32, const void* y, const float* gamma, const float* beta, const float* rstd,
+                                 const void* act_pre, int act, void* dx, float* dgamma, float* dbeta, void* stream) {
+  if (M <= 0 || (H != 128 && H != 256 && H != 384 && H != 768) || !dy32 || !y || !gamma || !beta || !rstd || !act_pre || !dx) return MAGIC_ERR_ARG;
+  if ((act != 1 && act != 2) || (dgamma == nullptr) != (dbeta == nullptr) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+  if (((uintptr_t)dy32 & 7) || !dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  LnbParams p{};
+  p.M = M; p.y = y; p.gamma = gamma; p.beta = beta; p.rstd = rstd; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta; p.do_ln = 1; p.hot0 = -1;
+  p.dy32 = dy32; p.act_pre = act_pre; p.act = act;
+  const int nit = H / 128, nw = lnb_waves(nit);
+  const int nb = lnb_blocks(p, nit);
+  const size_t shm = (size_t)(2 * nw) * H * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define LNT(TY, NIT, NW) hipLaunchKernelGGL((ln_bwd_tail_kernel<TY, NIT, NW>), dim3(nb), dim3(NW * 64), shm, st, p)
+#define LNTD(TY) do { if (nit == 1) LNT(TY, 1, 16); else if (nit == 2) LNT(TY, 2, 8); else if (nit == 3) LNT(TY, 3, 4); else LNT(TY, 6, 4); } while (0)
+  if (dtype == DT_BF16) LNTD(bf16); else if (dtype == DT_F16) LNTD(f16); else LNTD(float);
+#undef LNTD
+#undef LNT
   return launch_status();
 }
 

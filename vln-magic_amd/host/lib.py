@@ -33,6 +33,7 @@ SIGNATURES = {
                      vp, f32, u32, u32, vp, vp],
     "magic_ln_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32,
                      vp, i32, i32, vp, i32, i32, vp, f32, u32, u32, vp, i32, i32, vp],
+    "magic_ln_bwd_tail": [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
     "magic_ln_bwd_blocks": [i32, i32],
     "magic_colsum_add_v": [i32, vp, vp, vp, vp, vp, vp],
     "magic_smallk_ln_bwd_blocks": [i32, i32, i32],

@@ -80,6 +80,9 @@ class _BackwardHook(torch.autograd.Function):
         return None, None, None
 
 
+MLM_TAIL_FUSED = os.environ.get("MAGIC_MLM_TAIL_FUSED", "1") != "0"
+
+
 class GlocalTextPathCMTPreTraining(nn.Module):
     def __init__(self, config, device="cuda", compute_dtype=torch.bfloat16, seed=0):
         super().__init__()
@@ -784,11 +787,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             # dx over the 50k-wide vocabulary: split-K into an fp32 accumulator (18 output tiles alone cannot fill 256 CUs)
             d_hm32 = c.d_hm32
             O.gemm(1, dlog, Wemb, d_hm32, nm, H, Vv, c.ldv, H, H, splitk=32, accumulate=True)
-            d_hm = O.cast_to(d_hm32, self.compute_dtype)
             tn = n.ln("mlm_head.predictions.transform.LayerNorm")
-            d_tg = n.new(nm, H)
-            O.ln_bwd(nm, H, d_hm, y=c.hm, gamma=tn.g, beta=tn.b, rstd=c.rstd_hm, dx=d_tg, dgamma=tn.dg, dbeta=tn.db)
-            d_tz = O.dact(d_tg, c.tz, 1)
+            if MLM_TAIL_FUSED:           # cast + LayerNorm backward + gelu' as one launch (the fp32 accumulator is read as it is)
+                d_tz = O.ln_bwd_tail(nm, H, d_hm32, c.hm, tn.g, tn.b, c.rstd_hm, c.tz, 1, n.new(nm, H), tn.dg, tn.db)
+            else:
+                d_hm = O.cast_to(d_hm32, self.compute_dtype)
+                d_tg = n.new(nm, H)
+                O.ln_bwd(nm, H, d_hm, y=c.hm, gamma=tn.g, beta=tn.b, rstd=c.rstd_hm, dx=d_tg, dgamma=tn.dg, dbeta=tn.db)
+                d_tz = O.dact(d_tg, c.tz, 1)
             t = n.lin("mlm_head.predictions.transform.dense.weight")
             O.linear_dw(d_tz, c.hm_in, t.dW, t.db, nm)
             d_hin = O.linear_dx(d_tz, t.W, nm)

@@ -520,6 +520,15 @@ def ln_bwd(M, H, dy, *, y=None, gamma=None, beta=None, rstd=None, dx=None, dgamm
     return dx
 
 
+def ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, act_pre, act, dx, dgamma, dbeta):
+    """LayerNorm backward of a head's transform with fp32 dy in and act'(act_pre) folded into dx (csrc/rowops.hip magic_ln_bwd_tail):
+    cast + ln_bwd + dact as one launch"""
+    _chk(dy32.dtype == torch.float32 and dy32.is_contiguous() and y.dtype == act_pre.dtype == dx.dtype, "ln_bwd_tail operands")
+    L.call("magic_ln_bwd_tail", L.dt(y.dtype), M, H, L.P(dy32), L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(act_pre), int(act), L.P(dx),
+           L.P(dgamma), L.P(dbeta), L.stream())
+    return dx
+
+
 # Parameter gradients of the row kernels through PARTIAL rows (round 5): at the wide model sizes (H >= 384: MAGIC-B / MAGIC-L) on the few hundred
 # rows of a navigator step, a LayerNorm / position-embedding backward launch was nothing but its same-address fp32 atomics (ln_bwd 17.6 us for
 # 608 x 768 rows, smallk_ln_bwd 58 us).  Inside a backward pass (the weight-gradient queue is active, so a flush is coming) every workgroup stores

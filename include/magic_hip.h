@@ -74,6 +74,12 @@ int magic_gemm_dw_cat(int dtype, int n_prob, const magic_dwcat_prob* probs, int 
 int magic_linear_ln(int dtype, int M, int H, int K, const void* x, int lda, const void* W, int ldb, const float* bias,
                     const void* residual, int ldr, const float* gamma, const float* beta, float eps,
                     void* out, float* rstd, const void* drop_seed, float drop_p, unsigned drop_site, void* stream);
+/* dense -> activation -> LayerNorm as one launch: out = LayerNorm(act(x W^T + bias)) (BertPredictionHeadTransform of the MLM head,
+ * pretrain_src/model/pretrain_cmt.py; RegionClassification's Linear / ReLU / LayerNorm of the MRC head).  act: 1 = erf gelu, 2 = relu;
+ * pre_out (optional): the pre-activation x W^T + bias in the storage dtype, pitch H, which the backward's act' reads; rstd (optional) as
+ * magic_linear_ln.  H in {128, 256, 384} (MAGIC_ERR_UNSUPPORTED otherwise: the caller runs magic_gemm + magic_ln_fwd). */
+int magic_linear_act_ln(int dtype, int M, int H, int K, const void* x, int lda, const void* W, int ldb, const float* bias, int act,
+                        void* pre_out, const float* gamma, const float* beta, float eps, void* out, float* rstd, void* stream);
 
 /* Backward twin: input-gradient GEMM + residual + LayerNorm BACKWARD in one launch (H in {128, 256}).
  *   v = x[M,K] @ W[K,H] + residual  (the gradient at the OUTPUT of the LayerNorm whose saved output is y);

@@ -1042,3 +1042,28 @@ def test_ln_bwd_tail_matches_torch_autograd_and_the_three_separate_launches(dtyp
         O.ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, pre, 3, dx, dg, db)             # unknown activation
     with pytest.raises(L.MagicHipError):
         L.call("magic_ln_bwd_tail", L.dt(dtype), M, 100, L.P(dy32), L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(pre), 1, L.P(dx), L.P(dg), L.P(db), L.stream())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("H,K,M,act", [(128, 128, 257, 1), (256, 256, 70, 2), (384, 128, 33, 1), (128, 768, 5, 2)])
+def test_linear_act_ln_matches_torch(dtype, H, K, M, act):
+    """magic_linear_act_ln: LayerNorm(act(x W^T + b)) with the pre-activation kept -- against fp32 torch on the same rounded operands"""
+    gen = torch.Generator(DEV).manual_seed(H + K + M)
+    x = torch.randn(M, K, device=DEV, generator=gen).to(dtype)
+    W = (torch.randn(H, K, device=DEV, generator=gen) / math.sqrt(K)).to(dtype)
+    b = 0.1 * torch.randn(H, device=DEV, generator=gen)
+    gamma, beta = 1.0 + 0.1 * torch.randn(H, device=DEV, generator=gen), 0.1 * torch.randn(H, device=DEV, generator=gen)
+    out, pre = torch.empty(M, H, device=DEV, dtype=dtype), torch.empty(M, H, device=DEV, dtype=dtype)
+    rstd = torch.empty(M, device=DEV, dtype=torch.float32)
+    O.linear_act_ln(x, W, b, M, act, pre, gamma, beta, 1e-12, out, rstd)
+    torch.cuda.synchronize()
+    z = x.float() @ W.float().t() + b
+    a = F.gelu(z) if act == 1 else F.relu(z)
+    ref = F.layer_norm(a, (H,), gamma, beta, 1e-12)
+    tol = 3e-2 if dtype != torch.float32 else 2e-4
+    assert (pre.float() - z).abs().max().item() <= tol * z.abs().max().item()
+    assert (out.float() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    r_ref = torch.rsqrt(a.var(1, unbiased=False) + 1e-12)
+    assert torch.allclose(rstd, r_ref, rtol=2e-2 if dtype != torch.float32 else 1e-3)
+    with pytest.raises(L.MagicHipError):
+        O.linear_act_ln(x, W, b, M, 0, pre, gamma, beta, 1e-12, out, rstd)

@@ -1331,6 +1331,8 @@ struct LlnParams {
   int M, K; const void* X; int lda; const void* W; int ldb; const float* bias; const void* R; int ldr;
   const float* gamma; const float* beta; float eps; void* out; float* rstd_out;
   DropDesc drop;      // hidden dropout between the dense and the residual add (BertSelfOutput / BertOutput)
+  int act;            // magic_linear_act_ln: activation between the dense and the LayerNorm (1 erf gelu, 2 relu; 0 none)
+  void* pre_out;      // ... and where the pre-activation goes (storage dtype, pitch H), for the backward's act'
 };
 
 template <typename T, int HT>      // HT = H / 64 column tiles of 16 per wave (per wave H/4 = 16*HT columns)
@@ -1455,6 +1457,11 @@ __device__ __forceinline__ void linear_ln_body(const LlnParams& pp, const int bi
 #pragma unroll
       for (int j = 0; j < HT; ++j) {
         float v = acc[i][j][r] + bv[j];
+        if (pp.act) {                         // (block-uniform) prediction-head transform: dense -> activation -> LayerNorm
+          const int row = m0 + i * 16 + 4 * g + r;
+          if (pp.pre_out && row < M) ((T*)pp.pre_out)[(long long)row * H + w * WC + j * 16 + c16] = from_f<T>(v);
+          v = pp.act == 1 ? gelu_f(v) : fmaxf(v, 0.f);
+        }
         if (dsn.on) v *= drop_mul(dsn, (unsigned)((m0 + i * 16 + 4 * g + r) * H + w * WC + j * 16 + c16));
         acc[i][j][r] = v + rsd[i][j][r]; t += acc[i][j][r];
       }
@@ -1535,6 +1542,20 @@ extern "C" int magic_linear_ln(int dtype, int M, int H, int K, const void* x, in
   const int ht = H / 64;
   if (group_record(KIND_LLN, dtype, ht, &p, sizeof(p))) return MAGIC_OK;
   return launch_lln(dtype, ht, &p, nullptr, (hipStream_t)stream);
+}
+
+// dense -> activation -> LayerNorm in one launch (BertPredictionHeadTransform of the MLM head; the region classifier's Linear / ReLU / LayerNorm):
+// magic_linear_ln's kernel with the activation applied between the bias and the row statistics, the pre-activation optionally kept for the backward
+extern "C" int magic_linear_act_ln(int dtype, int M, int H, int K, const void* x, int lda, const void* W, int ldb, const float* bias, int act,
+                                   void* pre_out, const float* gamma, const float* beta, float eps, void* out, float* rstd, void* stream) {
+  if (M <= 0 || K <= 0 || !gamma || !beta || !out || (act != 1 && act != 2) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+  if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
+  const int ve = dtype_is16(dtype) ? 8 : 4;
+  if (lda % ve || ldb % ve || ((uintptr_t)x & 15) || ((uintptr_t)W & 15)) return MAGIC_ERR_ARG;
+  if (H != 128 && H != 256 && H != 384) return MAGIC_ERR_UNSUPPORTED;
+  LlnParams p{M, K, x, lda, W, ldb, bias, nullptr, 0, gamma, beta, eps, out, rstd, DropDesc{nullptr, 0u, 0.f}};
+  p.act = act; p.pre_out = pre_out;
+  return launch_lln(dtype, H / 64, &p, nullptr, (hipStream_t)stream);
 }
 
 int launch_lln(int dtype, int ht, const void* pa, const void* pb, hipStream_t st) {

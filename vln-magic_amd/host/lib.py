@@ -27,6 +27,7 @@ SIGNATURES = {
     "magic_gemm_dw_ws_need": [i32, i32, vp, vp, vp],
     "magic_gemm_dw_grouped": [i32, i32, vp, vp, i64, vp, i32, vp],
     "magic_linear_ln": [i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, vp, f32, u32, vp],
+    "magic_linear_act_ln": [i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, f32, vp, vp, vp],
     "magic_linear_lnbwd": [i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, u32, vp],
     "magic_dropout": [i32, i64, i32, i32, vp, vp, vp, f32, u32, vp],
     "magic_ln_fwd": [i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, vp, vp, i32,

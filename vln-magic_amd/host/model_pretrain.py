@@ -316,10 +316,13 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             O.csr_gather(c.l2v.out, *plan["mlm_rows"], c.hm_in, nm, H)
             t = n.lin("mlm_head.predictions.transform.dense.weight")
             c.tz = n.new(nm, H)
-            c.tg = O.linear_fwd(c.hm_in, t.W, t.b, nm, epilogue=1, pre=c.tz)
             tn = n.ln("mlm_head.predictions.transform.LayerNorm")
             c.hm, c.rstd_hm = n.new(nm, H), n.new(nm, dtype=torch.float32)
-            O.ln_fwd(nm, H, c.hm, in0=c.tg, gamma=tn.g, beta=tn.b, eps=n.eps, rstd=c.rstd_hm)
+            if MLM_TAIL_FUSED and O.linear_ln_ok(H, H):      # dense -> gelu -> LayerNorm as one launch
+                O.linear_act_ln(c.hm_in, t.W, t.b, nm, 1, c.tz, tn.g, tn.b, n.eps, c.hm, c.rstd_hm)
+            else:
+                c.tg = O.linear_fwd(c.hm_in, t.W, t.b, nm, epilogue=1, pre=c.tz)
+                O.ln_fwd(nm, H, c.hm, in0=c.tg, gamma=tn.g, beta=tn.b, eps=n.eps, rstd=c.rstd_hm)
             Vv = self.config.vocab_size
             c.ldv = rup(Vv, 8)
             c.logits = n.new(nm, c.ldv)
@@ -337,10 +340,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             c.mx = n.new(nm, H)
             O.csr_gather(c.loc.out, *plan["mrc_rows"], c.mx, nm, H)
             l1, l2 = n.lin("image_classifier.net.0.weight"), n.lin("image_classifier.net.3.weight")
-            c.mY = O.linear_fwd(c.mx, l1.W, l1.b, nm, epilogue=2)
             ln = n.ln("image_classifier.net.2")
             c.mZ, c.m_rstd = n.new(nm, H), n.new(nm, dtype=torch.float32)
-            O.ln_fwd(nm, H, c.mZ, in0=c.mY, gamma=ln.g, beta=ln.b, eps=n.eps, rstd=c.m_rstd)
+            if MLM_TAIL_FUSED and O.linear_ln_ok(H, H):      # Linear -> ReLU -> LayerNorm as one launch; mY keeps the PRE-activation (same relu' mask)
+                c.mY = n.new(nm, H)
+                O.linear_act_ln(c.mx, l1.W, l1.b, nm, 2, c.mY, ln.g, ln.b, n.eps, c.mZ, c.m_rstd)
+            else:
+                c.mY = O.linear_fwd(c.mx, l1.W, l1.b, nm, epilogue=2)
+                O.ln_fwd(nm, H, c.mZ, in0=c.mY, gamma=ln.g, beta=ln.b, eps=n.eps, rstd=c.m_rstd)
             c.mlogits = O.linear_fwd(c.mZ, l2.W, l2.b, nm)
             o["predict"] = c.mlogits
         else:

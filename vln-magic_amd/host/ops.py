@@ -431,6 +431,16 @@ def linear_ln(x, W, b, M, residual, gamma, beta, eps, out, rstd, flop_rows=None,
     return out
 
 
+def linear_act_ln(x, W, b, M, act, pre_out, gamma, beta, eps, out, rstd, flop_rows=None):
+    """out = LayerNorm(act(x @ W^T + b)) in one launch, the pre-activation kept in pre_out (a prediction head's transform; H in {128,256,384});
+    act: 1 gelu, 2 relu"""
+    H, K = W.shape
+    _count(flop_rows if flop_rows is not None else M, H, K, fam="linear_ln")
+    L.call("magic_linear_act_ln", L.dt(x.dtype), M, H, K, L.P(x), x.stride(0), L.P(W), W.stride(0), L.P(b), int(act), L.P(pre_out),
+           L.P(gamma), L.P(beta), float(eps), L.P(out), L.P(rstd), L.stream())
+    return out
+
+
 FUSED_LNB = not os.environ.get("MAGIC_NO_FUSED_LNB")
 
 

@@ -216,7 +216,7 @@ def pmc_traffic(gemm_n=1, chain_n=0):
     inside this process (PMC collection needs rocprofv3 around it): read from the committed post-processing of the `rocprofv3 --pmc
     FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (profiles/pmc_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for gfx950).  Returns (bytes, source file)."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 j = json.load(f)
@@ -232,7 +232,7 @@ def pmc_traffic(gemm_n=1, chain_n=0):
 
 def pmc_dw_fetch():
     """HBM bytes fetched per weight-gradient launch from the committed PMC pass (None if that file does not carry it)"""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get("dw_batch_fetch_bytes_per_launch")
@@ -245,7 +245,7 @@ def pmc_dw_fetch():
 
 def pmc_chain_traffic():
     """HBM bytes (fetched + written) per launch of the teacher's chain kernel from the committed PMC passes, or None"""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 j = json.load(f)

@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(256) void gemm_dw_cat_kernel(DwCatBatch gp) {
   // is free: group g takes rows 4g .. 4g+3, then 16+4g .. 16+4g+3 -- a half reads eight CONSECUTIVE rows -- and the pitch is TM + 16 elements
   // (40 / 72 banks: r x pitch mod 64 = eight distinct multiples of 8): conflict-free.  fp32 operands keep the plain form (dword reads).
   constexpr bool PERM = sizeof(T) == 2;
-  constexpr int BK = TT<T>::BK, TM = 32 * NT_, SN_ = PERM ? TM + 16 : TT<T>::SN + (TM - 64), NE = NT_ * NT_ * 4, PD = (NT_ == 2) ? 3 : 2;
+  constexpr int BK = TT<T>::BK, TM = 32 * NT_, SN_ = PERM ? TM + 16 : TT<T>::SN + (TM - 64), NE = NT_ * NT_ * 4, PD = 3;      // (register-staged prefetch depth; 2 -> 3 on the wide tile: 755 -> 702 us per launch of the MAGIC-L iteration, 228 VGPRs; double-buffered LDS images on top of it: 704, not kept)
   constexpr int IMG = (TM * TT<T>::STRIDE > BK * SN_) ? TM * TT<T>::STRIDE : BK * SN_;
   __shared__ __attribute__((aligned(16))) T sA[IMG];
   __shared__ __attribute__((aligned(16))) T sB[IMG];

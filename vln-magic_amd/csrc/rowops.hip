@@ -365,11 +365,11 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_tail_kernel(LnbParams p) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
   ln_bwd_body<T, NIT, NW, false, 0, true>(p, blockIdx.x, gridDim.x, red_dyn);
 }
-template <typename T, int NIT, int NW, bool TAB = true>
+template <typename T, int NIT, int NW, bool TAB = true, int RPI_ = 0>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_pair_kernel(LnbParams a, LnbParams b, int nA) {
   extern __shared__ __attribute__((aligned(16))) float red_dyn[];
-  if ((int)blockIdx.x < nA) ln_bwd_body<T, NIT, NW, TAB>(a, blockIdx.x, nA, red_dyn);
-  else ln_bwd_body<T, NIT, NW, TAB>(b, blockIdx.x - nA, gridDim.x - nA, red_dyn);
+  if ((int)blockIdx.x < nA) ln_bwd_body<T, NIT, NW, TAB, RPI_>(a, blockIdx.x, nA, red_dyn);
+  else ln_bwd_body<T, NIT, NW, TAB, RPI_>(b, blockIdx.x - nA, gridDim.x - nA, red_dyn);
 }
 
 // gamma/beta gradients of a LayerNorm as a separate column reduction: dgamma[c] += sum_m dy*xhat, dbeta[c] += sum_m dy
@@ -1368,6 +1368,16 @@ int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t s
     } while (0)
     if (dtype == DT_BF16) LNBL(bf16); else if (dtype == DT_F16) LNBL(f16); else LNBL(float);
 #undef LNBL
+    return launch_status();
+  }
+  if (pb && lnb_lean(a, nit) && lnb_lean(*(const LnbParams*)pb, nit) && lnb_lean_cfg() == 81) {
+    // a PAIR of lean launches (the twin LayerNorms of a navigator step's two cross-modal encoders) in the lean shape too: 8 waves x 1 row, the
+    // same 8 rows per workgroup as the 4 x 2 form, so the partial-row buffers keep their size
+    const LnbParams& b = *(const LnbParams*)pb;
+    const int nLA = lnb_blocks(a, nit, true), nLB = lnb_blocks(b, nit, true);
+#define LNBP(TY) hipLaunchKernelGGL((ln_bwd_pair_kernel<TY, 6, 8, false, 1>), dim3(nLA + nLB), dim3(512), (size_t)16 * H * sizeof(float), st, a, b, nLA)
+    if (dtype == DT_BF16) LNBP(bf16); else if (dtype == DT_F16) LNBP(f16); else LNBP(float);
+#undef LNBP
     return launch_status();
   }
   const size_t shm = (size_t)(2 * nw + ((nit >= 3 && !tab) ? 0 : 9)) * H * sizeof(float);

@@ -1291,17 +1291,22 @@ int launch_gemm_n(int dtype, int layout, const void* const* ps, int n, hipStream
   for (int i = 0; i < n; ++i) { gp.p[i] = *(const GemmParams*)ps[i]; total += group_place(gp, i, total); }
   for (int i = n; i <= GROUP_MAX; ++i) gp.start[i] = total;
   dim3 grid(total);
-  // every problem with a long K, no split-K, and few tiles in all: the K-group form.  OPT-IN (MAGIC_GEMM_KG_GROUP=1; _TILES moves the bound): back to
+  // every problem with a long K, no split-K, and few tiles in all: the K-group form.  For every K >= 768 (MAGIC_GEMM_KG_GROUP=2) it was measured and rejected: back to
   // back it wins where the single-problem form does (profiles/micro/r05_pair_gemm_probe.txt: 624 + 512 rows x 768 x 768 9.2 vs 10.8 us, K = 3072
   // 20.5 vs 30.5; past ~224 tiles it loses, 16.2 vs 12.5 us), but the navigator iteration runs two rollout lanes side by side and a launch of
   // 1024-thread / 72 KB workgroups leaves the other lane's kernels no room on the CUs: 142.0 vs 135.5 ms per iteration
-  static int kgg = -1, kgg_tiles = 224;
+  // What stays on by default: launches whose contraction is LONG (K >= 2048: the FFN's second projection forward, its first projection's input
+  // gradient -- 2 of a layer's 12 paired launches), where the K-group form saves a third (30.5 -> 20.5 us) and the crowding is brief.
+  // MAGIC_GEMM_KG_GROUP=0 off, =2 every K >= 768 (the form measured above); _MIN_K / _TILES move the bounds.
+  static int kgg = -1, kgg_tiles = 224, kgg_min_k = 2048;
   if (kgg < 0) {
-    const char* e = getenv("MAGIC_GEMM_KG_GROUP"); kgg = e ? atoi(e) : 0;
+    const char* e = getenv("MAGIC_GEMM_KG_GROUP"); kgg = e ? atoi(e) : 1;
     const char* t = getenv("MAGIC_GEMM_KG_GROUP_TILES"); if (t) kgg_tiles = atoi(t);
+    const char* k = getenv("MAGIC_GEMM_KG_GROUP_MIN_K"); if (k) kgg_min_k = atoi(k);
+    if (kgg == 2) kgg_min_k = 768;
   }
   bool kg_ok = kgg && layout != 2 && total <= kgg_tiles;
-  for (int i = 0; i < n && kg_ok; ++i) kg_ok = gp.p[i].splitk == 1 && gp.p[i].K >= 768 && gp.ny8[i] >= 0;
+  for (int i = 0; i < n && kg_ok; ++i) kg_ok = gp.p[i].splitk == 1 && gp.p[i].K >= kgg_min_k && gp.ny8[i] >= 0;
   if (kg_ok) {
     dim3 bk(1024);
 #define LAUNCHGK(TY, L) hipLaunchKernelGGL((gemm_grouped_kg_kernel<TY, L>), grid, bk, 0, st, gp)

@@ -160,3 +160,42 @@ def test_bf16_iteration_at_magic_l_width_tracks_the_oracle_tensor_by_tensor():
         n += 1
     print(f"[bf16 H=768] {n} sizeable gradient tensors, worst cosine {worst:.5f}, worst logit delta {worst_logit:.2e}")
     assert n > 40 and not low, low
+
+
+def test_paired_and_forked_cross_modal_encoders_give_the_same_iteration():
+    """the two forms a captured navigation step can take -- the map and viewpoint encoders' launches PAIRED into grouped kernels (default) or the two
+    encoders FORKED onto two branches of the step graph (MAGIC_NAV_PAIR=0) -- with the panorama backwards on their own stream or in the lane's chain,
+    are the same arithmetic: fp32 storage, same episodes, same draws -> same trajectories, logits and parameter gradients to summation-order noise"""
+    from magic_amd.host import model_nav
+
+    def run(pair, pano_side):
+        saved = model_nav.NAV_PAIR
+        model_nav.NAV_PAIR = pair
+        try:
+            _, g = _pair(torch.float32, seed=3)
+            env = _env(17)
+            table = torch.from_numpy(env.feature_table).to(DEV)
+            ro = NavRollout(g, table, max_action_len=T, expert_policy="ndtw", graphs=True, Lcap=LCAP)
+            batch = [env._draw_episode() for _ in range(B)]            # (a fresh environment of the same seed: the same episodes in both runs)
+            draws = np.random.default_rng(5).uniform(size=(T, B))
+            for it in range(3):                # eager first sight, capture, replay -- the same batch each time (dropout 0: identical iterations)
+                for sg in ro._sg.values():
+                    sg.pano_side = pano_side
+                r_t, r_s = _engine_iteration(ro, g, 17, batch, draws)
+            rep = ro.graph_report()["student"]
+            assert rep["instances"] >= 4, rep
+            return r_t, r_s, {n: p.grad.detach().float().cpu().clone() for n, p in g.named_parameters() if p.grad is not None}
+        finally:
+            model_nav.NAV_PAIR = saved
+    t1, s1, g1 = run(True, True)
+    t2, s2, g2 = run(False, False)
+    for a, b in ((t1, t2), (s1, s2)):
+        assert [x["path"] for x in a["traj"]] == [x["path"] for x in b["traj"]]
+        assert abs(float(a["loss"].detach()) - float(b["loss"].detach())) <= 1e-5 * abs(float(b["loss"].detach()))
+        for sa, sb in zip(a["steps"], b["steps"]):
+            x, y = torch.nan_to_num(sa["logits"], neginf=0), torch.nan_to_num(sb["logits"], neginf=0)
+            assert (x - y).abs().max().item() < 1e-4
+    gmax = max(v.abs().max().item() for v in g2.values())
+    assert set(g1) == set(g2) and len(g2) > 60
+    for n in g2:
+        assert (g1[n] - g2[n]).abs().max().item() <= 1e-4 * g2[n].abs().max().item() + 1e-6 * gmax, n

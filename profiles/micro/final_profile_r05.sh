@@ -36,6 +36,20 @@ nav)
   python3 $R/bench_nav.py --steps 10 --warmup 10 > $O/r05_bench_nav.json 2> $O/r05_bench_nav.err
   python3 $R/bench_nav.py --icod --hidden 128 --teacher-hidden 768 --instr-min 20 --instr-max 80 --hops-min 4 --hops-max 7 --max-action-len 15 --steps 10 --warmup 10 --no-cpu-baseline --no-host-loop > $O/r05_bench_nav_icod.json 2> $O/r05_bench_nav_icod.err
   tail -c 300 $O/r05_bench_nav.json; echo; tail -c 300 $O/r05_bench_nav_icod.json; echo ;;
+navpmc)
+  # the navigator iteration's kernels under the same four counter passes (graph replays included: the paired / grouped launches are what runs)
+  NAVP="--steps 2 --warmup 6 --no-cpu-baseline --no-host-loop --no-profile"
+  timeout -k 10 280 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/npmc_a -- python3 $R/bench_nav.py $NAVP > /dev/null 2> $O/r05_npmc_a.err || exit 1
+  echo nav pass A done
+  timeout -k 10 280 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/npmc_b -- python3 $R/bench_nav.py $NAVP > /dev/null 2> $O/r05_npmc_b.err || exit 1
+  echo nav pass B done
+  timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/npmc_c -- python3 $R/bench_nav.py $NAVP > /dev/null 2> $O/r05_npmc_c.err || exit 1
+  timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/npmc_d -- python3 $R/bench_nav.py $NAVP > /dev/null 2> $O/r05_npmc_d.err || exit 1
+  echo nav passes C D done
+  STATS=$O/r05_kernel_stats_nav.csv; [ -f $STATS ] || STATS=$R/profiles/r05_rocprofv3_kernel_stats_nav.csv
+  python3 $R/profiles/pmc_kernels.py $STATS $O/npmc_a $O/npmc_b $O/npmc_c $O/npmc_d > $O/r05_pmc_kernels_nav.json
+  rm -rf $O/npmc_a $O/npmc_b $O/npmc_c $O/npmc_d
+  head -c 1200 $O/r05_pmc_kernels_nav.json; echo ;;
 navprof)
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/r05_navprof -- python3 $R/bench_nav.py --steps 4 --warmup 8 --no-cpu-baseline --no-host-loop --no-profile > $O/r05_bench_nav_under_rocprof.json 2> $O/r05_navprof.err || exit 1
   find $O/r05_navprof -name "*kernel_stats.csv" -exec cp {} $O/r05_kernel_stats_nav.csv \;

@@ -26,6 +26,10 @@ from .nav_plan import IGNORE, NavPlanner
 from .kd_loss import ce_rows_loss, exponential_decay
 
 
+_SLOT = 1 << 16
+_RING = {"slots": [], "turn": 0, "used": []}
+
+
 def to_device(arrays, dev):
     """ONE pinned staging buffer + ONE async copy for a dict of numpy arrays; returns device tensors (views of the copy)"""
     metas, off = [], 0
@@ -36,11 +40,28 @@ def to_device(arrays, dev):
         off = (off + 15) & ~15
         metas.append((k, a, off))
         off += a.nbytes
-    stage = torch.empty(max(off, 16), dtype=torch.uint8, pin_memory=(dev.type == "cuda"))
-    sn = stage.numpy()
+    ev = None
+    if dev.type == "cuda" and off <= _SLOT:
+        # a slot of ONE pinned ring instead of a pinned allocation per call (the step loop stages a handful of small arrays per step: the host
+        # allocator's bookkeeping was most of this function); a slot is reused 128 calls later, behind the event of its last copy
+        if not _RING["slots"]:
+            big = torch.empty(128 * _SLOT, dtype=torch.uint8, pin_memory=True)
+            _RING["slots"] = [(big[i * _SLOT:(i + 1) * _SLOT], big[i * _SLOT:(i + 1) * _SLOT].numpy(), torch.cuda.Event()) for i in range(128)]
+            _RING["used"] = [False] * 128
+        i = _RING["turn"] = (_RING["turn"] + 1) % 128
+        slot, sn, ev = _RING["slots"][i]
+        if _RING["used"][i]:
+            ev.synchronize()
+        _RING["used"][i] = True
+        stage = slot[:max(off, 16)]
+    else:
+        stage = torch.empty(max(off, 16), dtype=torch.uint8, pin_memory=(dev.type == "cuda"))
+        sn = stage.numpy()
     for k, a, o in metas:
         sn[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
     buf = stage.to(dev, non_blocking=True)
+    if ev is not None:
+        ev.record()
     out = {}
     for k, a, o in metas:
         t = buf[o:o + a.nbytes].view(getattr(torch, str(a.dtype))).view(a.shape)

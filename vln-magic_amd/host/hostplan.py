@@ -60,6 +60,7 @@ class DenseDist:
             for b, v in row.items():
                 self.D[ia, self.index[b]] = v
         self.n = n
+        self.paths = {}           # (from, to) -> int32 dense indices of shortest_paths[from][to][1:] (filled by the expert as it asks)
 
 
 def dtw_extend(dd, row, nodes, ref_idx):
@@ -91,6 +92,23 @@ def dtw_cands(dd, row, paths, ref_idx):
     l.mp_dtw_cands(dd.D.ctypes.data, dd.n, r.ctypes.data, G, ref_idx.ctypes.data, nodes.ctypes.data, offs.ctypes.data, len(paths), out.ctypes.data,
                    tmp.ctypes.data)
     return out[:len(paths)]
+
+
+def dtw_cands_idx(dd, row, idx_paths, ref_idx):
+    """dtw_cands over paths already given as dense node-index arrays (int32; DenseDist.paths caches them per (from, to): a scan's shortest paths
+    never change, the per-node dict lookups of `dtw_cands` were most of the expert's host time)"""
+    l = lib()
+    G = len(ref_idx)
+    r = np.ascontiguousarray(row, np.float64)
+    n = len(idx_paths)
+    offs = np.zeros(n + 1, np.int32)
+    if n:
+        offs[1:] = np.cumsum([len(p) for p in idx_paths])
+    nodes = np.concatenate(idx_paths) if (n and offs[-1]) else np.zeros(1, np.int32)
+    out = np.empty(max(n, 1), np.float64)
+    tmp = np.empty(2 * (G + 1), np.float64)
+    l.mp_dtw_cands(dd.D.ctypes.data, dd.n, r.ctypes.data, G, ref_idx.ctypes.data, nodes.ctypes.data, offs.ctypes.data, n, out.ctypes.data, tmp.ctypes.data)
+    return out[:n]
 
 
 CAP, VMAX = 128, 64          # nodes per episode / views recorded per unvisited node the native planner state is sized for (csrc/hostplan.c MP_MAXN = 512)

@@ -465,8 +465,14 @@ class NavPlanner:
                         self._dtw[i] = (len(walked), row)
                         cj = [j for j, v in enumerate(vpids[i]) if j > 1 and not visited[i, j]]
                         if cj:
-                            sp = env.shortest_paths[scan][cur]
-                            last = hostplan.dtw_cands(dd, row, [sp[vpids[i][j]][1:] for j in cj], ref)
+                            sp, pc, ix, arrs = env.shortest_paths[scan][cur], dd.paths, dd.index, []
+                            for j in cj:
+                                v = vpids[i][j]
+                                pa = pc.get((cur, v))
+                                if pa is None:
+                                    pa = pc[(cur, v)] = np.array([ix[x] for x in sp[v][1:]], np.int32)
+                                arrs.append(pa)
+                            last = hostplan.dtw_cands_idx(dd, row, arrs, ref)
                             for j, t_last in zip(cj, last):
                                 d = -math.exp(-float(t_last) / (3.0 * len(gt)))
                                 if d < best_d:

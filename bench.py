@@ -261,6 +261,11 @@ def build_models(dtype, dev, dropout, world, batch=48):
     scfg = make_config(128, role="student", teacher_hidden_size=256, kdl=KDL, **dk)  # MAGIC-S: student_* :39-43
     teacher = GlocalTextPathCMTPreTraining(tcfg, device=dev, compute_dtype=dtype, seed=0)
     student = GlocalTextPathCMTPreTraining(scfg, device=dev, compute_dtype=dtype, seed=1)
+    # checkpoint-like small parameters (non-zero biases, LayerNorm gains off 1): the reference's loop never starts from a fresh module (it loads METER's
+    # weights, train_r2r_magic.py:183-209), and with all-zero biases every Linear -> LayerNorm over a zero input row is LayerNorm(0) (rstd 1e6): rounds 1-5
+    # timed steps whose global gradient norm was ~3e5 and whose clip factor was ~1.7e-5.  `health.grad_norm` / `health.clip_factor` / `steady.grad_norm_by_task` now show both.
+    teacher.store.checkpoint_like_(100)
+    student.store.checkpoint_like_(101)
     if world > 1:   # DDP ctor semantics: rank-0 parameters broadcast once (utils/misc.py:62-63)
         dist.broadcast(student.store.flat, src=0)
         dist.broadcast(teacher.store.flat, src=0)
@@ -700,7 +705,7 @@ def main():
         gate_now = trainer.gate_report() if a.teacher == "split" else None
         # the same replay loop over the resident batches of ONE task at a time (60 steps each): what the student's step of each proxy task
         # costs (graph i = student step on batch i || teacher forward on batch i + 1, whose task is the next one of the cycle)
-        by_task = {}
+        by_task, gn_task = {}, {}
         for task in TASKS:
             sub = [g for g, (tk, _, _) in zip(graphs, pool) if tk == task]
             if sub:
@@ -708,7 +713,9 @@ def main():
                 run_t(len(sub))
                 _, dt_t = timed_region(run_t, 60, 0, world, dev)
                 by_task[task] = round(dt_t / 60 * 1e3, 3)
+                gn_task[task] = trainer.opt.grad_norm_report()        # the last replayed step of this loop was a `task` step
         steady["ms_per_step_by_task"] = by_task
+        steady["grad_norm_by_task"] = gn_task
     health = trainer.check_health()          # raises if an in-launch hand-off of the row-split encoder kernels ever gave up
     gate = gate_now
     if gate is not None:

@@ -1,7 +1,8 @@
 """ORACLE (test infrastructure, never shipped): numpy restatement of the reference's per-trajectory panorama token assembly,
 /root/reference/pretrain_src/data/dataset.py:729-772 (`get_traj_pano_fts`), with the helpers it calls from
 data/common.py:77-103 (`get_angle_fts`, `get_view_rel_angles`).  Pinned by tests/golden/ingest.pt, minted by running the
-reference function itself on synthetic candidate tables (tests/golden/mint_golden.py::mint_ingest).
+reference function itself on synthetic candidate tables (tests/golden/mint_golden.py::mint_ingest); `gmap_pos_fts` (dataset.py:553-575)
+by tests/golden/gmap_pos.pt (mint_gmap_pos).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file."""
 import math
 
@@ -32,6 +33,34 @@ def get_angle_fts(headings, elevations, angle_feat_size):
     f = np.vstack([np.sin(headings), np.cos(headings), np.sin(elevations), np.cos(elevations)]).transpose().astype(np.float32)
     rep = angle_feat_size // 4
     return np.concatenate([f] * rep, 1) if rep > 1 else f
+
+
+def vp_rel_pos(a, b, base_heading=0.0, base_elevation=0.0):
+    """common.py:145-162: heading / elevation / distance of position b seen from position a (the simulator's x-y axes are transposed)"""
+    dx, dy, dz = b[0] - a[0], b[1] - a[1], b[2] - a[2]
+    xy = max(np.sqrt(dx ** 2 + dy ** 2), 1e-8)
+    xyz = max(np.sqrt(dx ** 2 + dy ** 2 + dz ** 2), 1e-8)
+    heading = np.arcsin(dx / xy)
+    if b[1] < a[1]:
+        heading = np.pi - heading
+    return heading - base_heading, np.arcsin(dz / xyz) - base_elevation, xyz
+
+
+def gmap_pos_fts(pos_of, dist_of, path_len_of, cur_vp, gmap_vpids, cur_heading, cur_elevation, angle_feat_size=4, max_dist=30, max_step=10):
+    """dataset.py:553-575 (`get_gmap_pos_fts`): 7 features per map node relative to the current viewpoint -- angle features of the relative
+    heading / elevation, then line distance, shortest distance and shortest-path hops, normalised.  The [stop] node (vpid None) takes
+    rel_angles [0, 0] and rel_dists [0, 0, 0], i.e. the row [sin 0, cos 0, sin 0, cos 0, 0, 0, 0] = [0, 1, 0, 1, 0, 0, 0]: NOT a zero row."""
+    ang, dst = [], []
+    for vp in gmap_vpids:
+        if vp is None:
+            ang.append([0, 0])
+            dst.append([0, 0, 0])
+        else:
+            h, e, d = vp_rel_pos(pos_of(cur_vp), pos_of(vp), cur_heading, cur_elevation)
+            ang.append([h, e])
+            dst.append([d / max_dist, dist_of(cur_vp, vp) / max_dist, (path_len_of(cur_vp, vp) - 1) / max_step])
+    ang, dst = np.array(ang).astype(np.float32), np.array(dst).astype(np.float32)
+    return np.concatenate([get_angle_fts(ang[:, 0], ang[:, 1], angle_feat_size), dst], 1)
 
 
 def traj_pano_tokens(view_fts_of, path, cands_of, angle_feat_size=4):

@@ -11,6 +11,7 @@ Import recipe: SURVEY.md Appendix F.  What is minted:
   ops.pt              map_nav_src/utils/ops.py pad_tensors / gen_seq_masks
   nav_loop.pt         map_nav_src/r2r/speaker_utils.py FloydGraph; map_nav_src/r2r/agent.py _language_variable,
                       _panorama_feature_variable_do, _nav_gmap_variable, _nav_vp_variable_mem, _teacher_action
+  gmap_pos.pt         pretrain_src/data/dataset.py get_gmap_pos_fts (incl. the [stop] node's row) on a synthetic scan graph
   zdict.pt            map_nav_src/r2r/data_utils.py LoadZdict (read_*_tsv, load_img_tensor, load_instr_tensor) and
                       map_nav_src/utils/data.py KMeansPicker (read_tim_tsv, seeded K-means + random_pick_front_features) on
                       synthetic TSV rows generated here
@@ -368,6 +369,35 @@ def mint_ingest():
         del sys.modules[k]
 
 
+def mint_gmap_pos():
+    """gmap_pos.pt: R2RTextPathData.get_gmap_pos_fts (pretrain_src/data/dataset.py:553-575) run UNBOUND on a synthetic scan graph: the 7
+    position features of every map node relative to the current viewpoint, INCLUDING the [stop] node (vpid None), whose row the reference
+    builds from rel_angles [0, 0] and rel_dists [0, 0, 0] -> [sin 0, cos 0, sin 0, cos 0, 0, 0, 0]."""
+    sys.path.insert(0, f"{REF}/pretrain_src")
+    stub(["pynvml", "jsonlines", "h5py", "nltk", "lmdb", "msgpack_numpy", "tensorboardX", "easydict", "progressbar"])
+    sys.modules["msgpack_numpy"].patch = lambda: None
+    from data import dataset as DS
+    rng = np.random.default_rng(23)
+    scan = "scanB"
+    vps = [f"vp{i}" for i in range(6)]
+    pos = {v: rng.uniform(-8, 8, 3).astype(np.float64) for v in vps}
+    dist = {a: {b: float(np.linalg.norm(pos[a] - pos[b]) * 1.2) for b in vps} for a in vps}
+    paths = {a: {b: [a] + [f"m{k}" for k in range(int(rng.integers(0, 4)))] + ([b] if b != a else []) for b in vps} for a in vps}
+    fake = SimpleNamespace(graphs={scan: SimpleNamespace(nodes={v: {"position": pos[v]} for v in vps})},
+                           shortest_distances={scan: dist}, shortest_paths={scan: paths}, angle_feat_size=4)
+    cases = []
+    for cur, ids, h, e in (("vp2", [None, "vp0", "vp1", "vp2", "vp4"], 0.0, 0.0), ("vp5", [None, "vp5", "vp3"], 0.7, -0.2), ("vp0", [None], 1.1, 0.3)):
+        out = DS.R2RTextPathData.get_gmap_pos_fts(fake, scan, cur, ids, h, e)
+        cases.append(dict(cur=cur, ids=ids, heading=h, elevation=e, out=torch.from_numpy(np.asarray(out))))
+    torch.save(dict(scan=scan, vps=vps, pos={k: torch.from_numpy(v) for k, v in pos.items()}, dist=dist,
+                    path_len={a: {b: len(paths[a][b]) for b in vps} for a in vps}, max_dist=DS.MAX_DIST, max_step=DS.MAX_STEP, cases=cases),
+               os.path.join(HERE, "gmap_pos.pt"))
+    print("gmap_pos ok", [tuple(c["out"].shape) for c in cases], cases[0]["out"][0].tolist())
+    sys.path.remove(f"{REF}/pretrain_src")
+    for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "data", "optim", "parser")]:
+        del sys.modules[k]
+
+
 def mint_nav_loop():
     """nav_loop.pt: the reference's own FloydGraph (map_nav_src/r2r/speaker_utils.py:501-546) on a fixed edge/update script,
     and GMapNavAgent._language_variable / _panorama_feature_variable_do / _nav_gmap_variable / _nav_vp_variable_mem /
@@ -564,6 +594,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--ingest-only" in sys.argv:
         mint_ingest()
+        sys.exit(0)
+    if "--pretrain-side-only" in sys.argv:
+        mint_pretrain_side()
+        sys.exit(0)
+    if "--gmap-pos-only" in sys.argv:
+        mint_gmap_pos()
         sys.exit(0)
     mint_primitives()
     mint_ops()

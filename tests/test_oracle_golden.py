@@ -332,3 +332,27 @@ def test_nav_builders_match_reference(golden_dir):
         for pol, key in ((None, "tgt_il"), ("spl", "tgt_spl"), ("ndtw", "tgt_ndtw")):
             got = R.teacher_action(env, obs, nav["gmap_vpids"], ended, nav["gmap_visited_masks"], pol is None, t, tr, pol or "spl")
             assert (got == st[key]).all(), (t, key)
+
+
+def test_map_position_features_and_the_stop_node_row_match_reference_get_gmap_pos_fts(golden_dir):
+    """oracle/ingest_ref.gmap_pos_fts vs the reference's own get_gmap_pos_fts (pretrain_src/data/dataset.py:553-575) on a synthetic scan graph, and the
+    synthetic generator's [stop]-node row vs the row the reference builds for vpid None -- [sin 0, cos 0, sin 0, cos 0, 0, 0, 0], not zeros (rounds 1-5
+    of host/synth.py wrote zeros there, which made the benchmarked step's `gmap_pos_embeddings` a LayerNorm of the zero vector)."""
+    import random
+
+    import numpy as np
+    import magic_amd  # noqa: F401
+    from magic_amd.host import synth
+    from oracle import ingest_ref as IR
+    fx = _load(golden_dir, "gmap_pos.pt")
+    pos = {k: v.numpy() for k, v in fx["pos"].items()}
+    for c in fx["cases"]:
+        got = IR.gmap_pos_fts(lambda v: pos[v], lambda a, b: fx["dist"][a][b], lambda a, b: fx["path_len"][a][b], c["cur"], c["ids"],
+                              c["heading"], c["elevation"], max_dist=fx["max_dist"], max_step=fx["max_step"])
+        assert got.dtype == np.float32 and np.array_equal(got, c["out"].numpy()), c["cur"]
+        assert c["ids"][0] is None
+        assert c["out"][0].tolist() == list(synth.STOP_NODE_POS_FTS)
+    s = synth.make_sample(np.random.default_rng(3), random.Random(3), uid=0)
+    assert s["gmap_vpids"][0] is None and s["gmap_pos_fts"][0].tolist() == list(synth.STOP_NODE_POS_FTS)
+    b = synth.make_batch("sap", batch_size=4, seed=9, step=0)
+    assert torch.equal(b["gmap_pos_fts"][:, 0], torch.tensor(synth.STOP_NODE_POS_FTS).expand(4, 7))

@@ -109,6 +109,21 @@ class ParamStore:
                 v.fill_(1.0)
         self.step = 0
 
+    def checkpoint_like_(self, seed, bias_std=0.02, ln_std=0.05):
+        """Small parameters as a trained checkpoint has them rather than as a fresh module does: biases ~ N(0, bias_std), LayerNorm gains
+        1 + N(0, ln_std) -- the recipe of oracle/parity_probe.oracle_models.  The reference never trains from zero biases (its loop starts from METER's
+        RoBERTa / cross-modal weights, pretrain_src/train_r2r_magic.py:183-209), and with them a LayerNorm fed by a Linear over an all-zero
+        input row (padding, eps 1e-12) is LayerNorm(0): rstd = 1e6 and a gradient norm of 1e5 that the clip then turns into a 1e-5 update."""
+        gen = torch.Generator().manual_seed(int(seed))
+        for name, shape, kind in self.specs:
+            v = self.master(name)
+            if name.endswith("bias"):
+                v.copy_(torch.randn(shape, generator=gen) * bias_std)
+            elif kind == "ones":
+                v.add_((torch.randn(shape, generator=gen) * ln_std).to(v.device))
+        self.shadow_clean = False
+        return self
+
     # ---- views ------------------------------------------------------------------------------
     def _view(self, buf, name):
         off, n, shape = self.offsets[name]

@@ -14,6 +14,10 @@ import torch
 
 V_VIEWS = 36
 IMG_DIM = 768
+# the [stop] node's 7 map position features as the reference builds them (pretrain_src/data/dataset.py:557-560 + data/common.py:77-83:
+# rel_angles [0, 0] -> [sin 0, cos 0, sin 0, cos 0], rel_dists [0, 0, 0]); pinned by tests/golden/gmap_pos.pt.  Rounds 1-5 wrote a zero row
+# here, which together with zero-initialised biases made `gmap_pos_embeddings` a LayerNorm of the zero vector (rstd = 1e6) on every sample.
+STOP_NODE_POS_FTS = (0.0, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0)
 
 
 def _angle_fts(rng, n):
@@ -70,7 +74,7 @@ def make_sample(rng, pyrng, *, min_len=20, max_len=80, min_steps=4, max_steps=7,
     gmap_step_ids = [0] + list(range(1, T + 1)) + [0] * len(unvisited)
     gmap_visited = [0] + [1] * T + [0] * len(unvisited)
     gmap_pos = np.concatenate([_angle_fts(rng, K), rng.uniform(0, 1, (K, 3)).astype(np.float32)], 1)
-    gmap_pos[0] = 0
+    gmap_pos[0] = STOP_NODE_POS_FTS
     d = rng.uniform(0, 30, (K, K)).astype(np.float32)
     d = (d + d.T) / 2
     np.fill_diagonal(d, 0)

@@ -59,12 +59,28 @@ class FusedAdamW:
         """optimizer steps skipped so far because of a non-finite gradient norm (one device -> host copy)"""
         return int(self.overflow.item())
 
+    def grad_norm_report(self):
+        """the LAST optimizer step's global gradient norm and the factor clip_grad_norm_ scaled it by (train_r2r_magic.py:373-375), from the device words that
+        step left behind: the sum-of-squares accumulator (zeroed only by the NEXT step's prologue), the pre-scale the update used (1 / world, 1 / static
+        gradient scale, 1 / accumulation) and the dynamic loss scale's 1 / S.  Synchronises.  None before the first step or without a norm."""
+        if self._last_gscale is None or not (self.max_norm or self.loss_scale is not None):
+            return None
+        g = self._last_gscale * (float(self.loss_scale[1].item()) if self.loss_scale is not None else 1.0)
+        nrm = math.sqrt(max(float(self.ss.item()), 0.0)) * g
+        rep = {"grad_norm": float(f"{nrm:.4e}"), "max_grad_norm": self.max_norm}
+        if self.max_norm:
+            rep["clip_factor"] = float(f"{min(1.0, self.max_norm / (nrm + 1e-6)):.4e}") if math.isfinite(nrm) else 0.0
+        return rep
+
+    _last_gscale = None
+
     def step(self, lr=None, gscale=1.0, ss_zeroed=False, zero_grad=False):
         """ss_zeroed: the gradient-norm accumulator was zeroed earlier in this step (PretrainStep's prologue launch) -- the schedule then
         rides in the sum-of-squares launch; zero_grad: the AdamW kernel zeroes the gradient buffer after consuming it"""
         s = self.store
         lr = self.lr if lr is None else lr
         self.t += 1
+        self._last_gscale = float(gscale)
         b1, b2 = self.betas
         lr_ss = None
         use_clip = self.max_norm is not None and self.max_norm > 0
@@ -464,8 +480,10 @@ class PretrainStep:
         (csrc/encoder.hip).  Synchronises: call it where a loss is read anyway (logging, validation, checkpoint)."""
         if self.on_gpu:
             O.check_encoder_health(self.dev)
-        return {"skipped_optimizer_steps": self.opt.skipped_steps() if self.on_gpu else 0, "card_shared_with_other_ranks": self.sync.card_shared,
-                "row_split_encoder_launches": bool(O.ENC_ROW_SPLIT)}
+        h = {"skipped_optimizer_steps": self.opt.skipped_steps() if self.on_gpu else 0, "card_shared_with_other_ranks": self.sync.card_shared,
+             "row_split_encoder_launches": bool(O.ENC_ROW_SPLIT)}
+        h.update((self.opt.grad_norm_report() if self.on_gpu else None) or {})        # grad_norm / clip_factor of the last optimizer step
+        return h
 
     def gate_reset(self):
         """re-arm a gate that switched itself off (e.g. after a profiler run that serialised the streams)"""

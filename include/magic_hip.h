@@ -128,10 +128,10 @@ int magic_ln_bwd_tail(int dtype, int M, int H, const float* dy32, const void* y,
                       const void* act_pre, int act, void* dx, float* dgamma, float* dbeta, void* stream);
 /* hot0 >= 0: a row of indexed table 0 that a large share of the input rows hit (the padding token id of the word-embedding lookup): its
  * gradient is summed per workgroup in LDS and added with one atomic per element and workgroup (else -1).
- * pg_partial != 0 (round 5): dgamma / dbeta point at PARTIAL buffers of magic_ln_bwd_blocks(M, H) x H floats each, contents undefined: every
+ * pg_partial != 0 (round 5): dgamma / dbeta point at PARTIAL buffers of magic_ln_bwd_blocks(M, H, any of d0 / d1 / d2 given) x H floats each, contents undefined: every
  * workgroup STORES its gamma / beta sums in its own row instead of adding them into the parameter gradients with same-address atomics (at
  * H = 768 the atomics were the launch: 17.6 us for 608 rows, 4 us without); magic_colsum_add_v adds the rows up in block order. */
-int magic_ln_bwd_blocks(int M, int H);
+int magic_ln_bwd_blocks(int M, int H, int has_tables);
 /* dsts[j][c] += sum over b < nblks[j] of parts[j][b * strides[j] + c], c < lens[j], for n <= 96 jobs in one launch (host arrays of device pointers,
  * consumed before return).  The finisher of every partial-row epilogue (magic_ln_bwd pg_partial, magic_smallk_ln_bwd part); block order:
  * reproducible; a destination may occur once per launch.  (torch: `param.grad` accumulation of LayerNorm / Linear parameters.) */
@@ -374,8 +374,9 @@ int magic_adamw(long long n, float* p, float* g, float* m, float* v, void* shado
 /* decay_first != 0: torch.optim.AdamW's order -- p *= 1 - lr wd, then the Adam update (the navigator's optimizer, map_nav_src/r2r/agent_base.py:122-137;
  * pass step_size = lr sqrt(1 - b2^t) / (1 - b1^t) and eps sqrt(1 - b2^t) for its `sqrt(v / bc2) + eps` denominator); 0: pretrain_src/optim/adamw.py's. */
 /* scale_state (may be NULL; needs sumsq): the dynamic loss scale's state (magic_step_rng): the gradient pre-scale is multiplied by its 1 / S and
- * `pending` is set to 1 (updated) / 2 (skipped).  sched_step (may be NULL): the device-side schedule's step word (magic_sumsq_sched /
- * magic_sched_step); a SKIPPED update takes back this step's advance, as a skipped optimizer.step() under GradScaler leaves the state step. */
+ * `pending` is set to 1 (updated) / 2 (skipped).  sched_step (may be NULL): the device-side schedule's two step words (magic_sumsq_sched /
+ * magic_sched_step: [0] = global_step, the lr schedule's; [1] = the optimizer's state step, the bias correction's); a SKIPPED update takes back word [1]'s
+ * advance, as a skipped optimizer.step() under GradScaler leaves the state step, and leaves word [0] advanced, as the reference's global_step is. */
 /* overflow (may be NULL): a device counter.  When the gradient norm in `sumsq` is not finite (fp16 storage under a static gradient scale)
  * the update is SKIPPED -- p, m, v untouched, g zeroed when zero_grad -- and the counter incremented: amp.GradScaler.step's behaviour
  * (train_r2r_magic.py:370-371) instead of NaN weights. */
@@ -388,6 +389,7 @@ int magic_sumsq_sched(long long n, const float* g, float* out, int* step, float 
  * < 0: all.  device-side lr schedule + Adam bias correction (optim/sched.py:17-30, adamw.py:97-100) for HIP-graph replay; coef_dev / lr_ss
  * arguments above are optional device scalars multiplied into / replacing the host values; zero_me (optional): one float set to 0 (the
  * gradient-norm accumulator of the step that begins) */
+/* step: int[2] = {global_step, optimizer state step}; lr = lr0 * warmup_linear(global_step), step size = lr sqrt(1 - b2^t) / (1 - b1^t) with t = state step + 1 */
 int magic_sched_step(int* step, float lr0, int warmup, int total, float b1, float b2, float* lr_ss, float* zero_me, void* stream);
 /* shadow (optional): the 16-bit copy of the parameters the MFMA kernels read, rewritten in shadow_dtype (1 | 2).  magic_cast: dtype16 = 1 | 2 names
  * the 16-bit side; to16 != 0: fp32 x -> 16-bit y, else 16-bit x -> fp32 y */

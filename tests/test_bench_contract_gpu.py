@@ -48,6 +48,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     from magic_amd.host import lib as L
     assert d["build_id"] == L.source_build_id()
     assert d["rccl_smoke"]["ok"] is True and d["rccl_smoke"]["identity_at_world_1"] is True, d["rccl_smoke"]
+    # round 6: what the gradients of the timed steps looked like (device words read after the timed region) -- a clip factor of 1e-5 (rounds 1-5: a
+    # LayerNorm of the zero vector under zero-initialised biases) must not hide behind a throughput number again
+    h = d["health"]
+    assert 0.05 < h["grad_norm"] < 500 and 0.01 <= h["clip_factor"] <= 1.0 and h["max_grad_norm"] == 5.0, h
+    for task, gn in d["steady"]["grad_norm_by_task"].items():
+        assert 0.05 < gn["grad_norm"] < 500 and 0.01 <= gn["clip_factor"] <= 1.0, (task, gn)
     cpu = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu, k
@@ -64,3 +70,34 @@ def test_ctypes_binding_path_still_drives_a_full_step(monkeypatch):
         monkeypatch.setitem(L._FN, name, getattr(lib, name))
     assert type(L._FN["magic_gemm"]).__name__ != "builtin_function_or_method"
     S.run_smoke()
+
+
+def test_benchmarked_models_have_healthy_gradients_at_initialisation():
+    """bench.py's models and batches, one eager step per proxy task -- the global gradient norm is O(1-100) (clip_grad_norm_ at 5.0
+    scales by 0.01-1, not by 1e-5), no single parameter tensor holds more than 99 % of the squared norm, and the [stop] node's position row is the
+    reference's [0, 1, 0, 1, 0, 0, 0] (pretrain_src/data/dataset.py:557-560), not zeros."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench as B
+    from magic_amd.host import synth
+    from magic_amd.host.plan import build_plan
+    dev = torch.device("cuda", 0)
+    _, _, teacher, student, trainer = B.build_models(torch.bfloat16, dev, 0.1, 1)
+    bias = [student.store.master(n) for n, _, _ in student.store.specs if n.endswith("bias")]
+    assert all(float(b.abs().max()) > 0 for b in bias), "checkpoint-like init: no all-zero bias vector"
+    for i, task in enumerate(B.TASKS):
+        b = synth.make_batch(task, batch_size=48, seed=1234, step=i)
+        assert b["gmap_pos_fts"][:, 0].tolist() == [list(synth.STOP_NODE_POS_FTS)] * 48
+        plan = build_plan(b, task, dev)
+        trainer._zero_grad()
+        trainer._fwd_bwd(synth.batch_to(b, dev), task, None, plan)
+        torch.cuda.synchronize()
+        g = student.store.grad.double()
+        tot = float(g.pow(2).sum())
+        share = max(float(g[off:off + n].pow(2).sum()) for off, n, _ in student.store.offsets.values()) / tot
+        nrm = tot ** 0.5
+        assert 0.05 < nrm < 500, (task, nrm)
+        assert share < 0.99, (task, share)
+        trainer._optimize()
+        rep = trainer.opt.grad_norm_report()
+        assert abs(rep["grad_norm"] - nrm) < 2e-3 * nrm and 0.01 <= rep["clip_factor"] <= 1.0, (task, rep, nrm)

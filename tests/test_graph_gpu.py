@@ -44,7 +44,7 @@ def test_graph_replay_matches_eager_steps(dtype):
                 out = tr.replay(cs)
                 losses.append(out["loss"].item())
         torch.cuda.synchronize()
-        results[mode] = (losses, g_s.store.flat.clone(), int(tr.opt.step_dev.item()))
+        results[mode] = (losses, g_s.store.flat.clone(), int(tr.opt.step_dev[0].item()))
     le, pe, se = results["eager"]
     lg, pg, sg = results["graph"]
     assert se == sg == len(tasks)

@@ -120,7 +120,7 @@ def _oracle_run(o_t, o_s, steps, skip=()):
             continue                                  # GradScaler: optimizer.step() skipped -- no update, the state step not advanced
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in o_s.parameters()]
         optim_ref.clip_grad_norm(grads, 5.0)
-        lr = optim_ref.get_lr_sched(applied, 1e-3, 2, 10)      # (the device-side schedule counts APPLIED updates)
+        lr = optim_ref.get_lr_sched(step, 1e-3, 2, 10)         # lr follows global_step (skipped steps count), the bias correction the applied updates
         with torch.no_grad():
             optim_ref.adamw_step([p.data for p in o_s.parameters()], grads, state, lr=lr, betas=(0.9, 0.98), eps=1e-6, weight_decay=wds)
         applied += 1
@@ -146,19 +146,20 @@ def test_injected_overflow_is_skipped_then_the_run_follows_the_oracle_optimizer(
     for step, task in enumerate(steps):
         at["step"] = step
         if step == bad_step:
-            before_bad = (g_s.store.flat.clone(), g_s.store.m.clone(), g_s.store.v.clone(), int(trainer.opt.step_dev.item()))
+            before_bad = (g_s.store.flat.clone(), g_s.store.m.clone(), g_s.store.v.clone(), trainer.opt.step_dev.tolist())
         batch = synth.make_batch(task, batch_size=4, seed=77, step=step, vocab=600, min_len=8, max_len=15, min_steps=2, max_steps=3)
         trainer.step(batch, task, rw=RW)
         if step == bad_step:
             torch.cuda.synchronize()
             assert torch.equal(g_s.store.flat, before_bad[0]) and torch.equal(g_s.store.m, before_bad[1]) and torch.equal(g_s.store.v, before_bad[2])
-            assert int(trainer.opt.step_dev.item()) == before_bad[3] and st.tolist()[3] == 2.0
+            # the skipped step: global_step (the lr schedule's word) advanced, the optimizer's state step (bias correction) taken back
+            assert trainer.opt.step_dev.tolist() == [before_bad[3][0] + 1, before_bad[3][1]] and st.tolist()[3] == 2.0
             assert float(g_s.store.grad.abs().max()) == 0.0                   # consumed: the next step starts from zero
         if step == bad_step + 1:
             torch.cuda.synchronize()
             assert st.tolist()[0] == 2048.0                                   # halved by the prologue of the step after the skipped one
     torch.cuda.synchronize()
-    assert trainer.opt.skipped_steps() == 1 and int(trainer.opt.step_dev.item()) == len(steps) - 1
+    assert trainer.opt.skipped_steps() == 1 and trainer.opt.step_dev.tolist() == [len(steps), len(steps) - 1]
     assert torch.isfinite(g_s.store.flat).all()
     _oracle_run(o_t, o_s, steps, skip=(bad_step,))
     got = g_s.state_dict()
@@ -188,4 +189,4 @@ def test_a_scale_that_overflows_recovers_within_a_few_steps():
     assert clean_at is not None and clean_at <= 14, (clean_at, st.tolist())
     assert st.tolist()[0] == 2.0 ** 24 / 2 ** trainer.opt.skipped_steps()
     assert torch.isfinite(g_s.store.flat).all() and not torch.equal(g_s.store.flat, w0)
-    assert int(trainer.opt.step_dev.item()) == 16 - trainer.opt.skipped_steps()
+    assert trainer.opt.step_dev.tolist() == [16, 16 - trainer.opt.skipped_steps()]

@@ -183,3 +183,41 @@ def test_native_planner_helpers_equal_the_python_forms():
     assert len(a) == len(b) >= 3
     for (ta, ga, va), (tb, gb, vb) in zip(a, b):
         assert np.array_equal(ta, tb) and np.array_equal(ga, gb) and np.array_equal(va, vb)
+
+
+def test_native_planner_state_grows_past_its_initial_128_nodes_per_episode():
+    """the C planner's by-dense-id arrays started at 128 nodes per episode and a larger map raised mid-rollout, while the Python planner (the
+    reference's GraphMap, no bound) carried on.  An exploring rollout over a 260-node scan passes 128 map nodes: the native state doubles, re-registers,
+    and every step's plan stays identical to the Python planner's."""
+    from magic_amd.host import hostplan
+    if hostplan.lib() is None:
+        pytest.skip("_magic_hostplan.so not built")
+    saved = hostplan._lib
+    T = 90
+
+    def plans(native):
+        hostplan._lib = saved if native else None
+        env = SynthNavEnv(batch_size=2, n_scans=1, nodes_per_scan=260, seed=5, instr_len=(6, 10), path_hops=(3, 4))
+        pl = NavPlanner(env, env.reset(features=False), feedback="sample", max_action_len=T, expert_policy="spl")
+        out = []
+        for t in range(T):
+            p = pl.begin_step()
+            out.append((p["targets"].copy(), p["gmap_pos_fts"].copy(), p["gmap_pair_dists"].copy(), np.asarray(p["gmap_visited_masks"]).copy(), p["gmap_lens"].copy()))
+            vis = np.asarray(p["gmap_visited_masks"])
+            acts = []
+            for i, n in enumerate(p["gmap_lens"]):          # explore: the LAST unvisited node of the map (the newest frontier), never stop / [mem]
+                free = [k for k in range(2, int(n)) if not vis[i, k]]
+                acts.append(free[-1] if free else 0)
+            if pl.end_step(np.array(acts)):
+                break
+        return out, max(len(g.graph.names) for g in pl.gmaps), (pl.native.step.shape[1] if pl.native is not None else None)
+    try:
+        (a, na, cap), (b, nb_, _) = plans(True), plans(False)
+    finally:
+        hostplan._lib = saved
+    assert na == nb_ and na > 128, (na, nb_)
+    assert cap >= na and cap > hostplan.CAP
+    assert len(a) == len(b) > 20
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v)

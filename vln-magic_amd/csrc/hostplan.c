@@ -12,6 +12,15 @@
 #include <string.h>
 
 #define MP_MAXN 512
+/* bumped whenever an exported signature changes; host/hostplan.py refuses a library that reports another number (a stale .so called through ctypes
+ * with an older mp_plan_nav argument list would write through the wrong pointers without any error).  MP_SRC_ID: sha256 prefix of this file, set by
+ * the Makefile; the binding compares it with the source it sits next to. */
+#define MP_ABI_VERSION 2
+#ifndef MP_SRC_ID
+#define MP_SRC_ID "unset"
+#endif
+int mp_abi_version(void) { return MP_ABI_VERSION; }
+const char* mp_src_id(void) { return MP_SRC_ID; }
 
 static int hops_rec(const int32_t* via, int ld, int a, int b, int16_t* memo, int n) {
   if (a == b) return 0;

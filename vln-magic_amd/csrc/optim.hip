@@ -7,11 +7,16 @@
 
 // sum of squares -> out[0] (atomic, block-reduced); 16-byte loads, four in flight per lane.  1024-thread blocks, at most one per CU:
 // every block ends in an atomic on the SAME address and those serialise in L2 (~20 ns each: 512 blocks spent 10 of 19 us there)
+// step[0] = global_step: drives the learning-rate schedule and ALWAYS advances (the reference sets lr from global_step and counts a step whose
+// update GradScaler skipped, train_r2r_magic.py loop / optim/sched.py); step[1] = the optimizer's state step: drives Adam's bias correction and is
+// taken back by adamw_kernel when it skips (a skipped optimizer.step() leaves state['step'] alone).  Rounds 4-5 kept ONE word for both, so every skip
+// stalled the warm-up / decay by a step.
 struct SchedArgs { int* step; float lr0; int warmup, total; float b1, b2; float* lr_ss; };      // step == nullptr: no schedule work
 __device__ __forceinline__ void sched_advance(const SchedArgs& a) {
   const int gs = a.step[0];          // global_step before this optimizer step
-  const int t = gs + 1;
-  a.step[0] = t;
+  a.step[0] = gs + 1;
+  const int t = a.step[1] + 1;       // the optimizer's state step after this update
+  a.step[1] = t;
   double f = gs < a.warmup ? (double)gs / (double)a.warmup : fmax(0.0, (double)(a.total - gs) / (double)(a.total - a.warmup));
   double lr = (double)a.lr0 * f;
   if (lr <= 0.0) lr = 1e-8;
@@ -58,9 +63,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(long long n, float* p, float
   if (scale_state && blockIdx.x == 0 && threadIdx.x == 0) scale_state[3] = bad ? 2.f : 1.f;
   float clip = gscale;
   if (bad) {
-    // GradScaler.step semantics: a skipped optimizer.step() does not advance the optimizer's state step either -- take back the advance the
-    // schedule launch made for this step (its lr / bias-correction scalars were never used)
-    if (sched_step && blockIdx.x == 0 && threadIdx.x == 0) sched_step[0] -= 1;
+    // GradScaler.step semantics: a skipped optimizer.step() does not advance the optimizer's STATE step -- take back the advance the schedule launch
+    // made for this step (its bias-correction scalars were never used); global_step (sched_step[0], the lr schedule) stays advanced
+    if (sched_step && blockIdx.x == 0 && threadIdx.x == 0) sched_step[1] -= 1;
     // an overflowed / NaN gradient (fp16 storage under a static gradient scale: an activation gradient past 65504 becomes inf): SKIP the
     // update as amp.GradScaler.step does (train_r2r_magic.py:370-371) -- weights and moments untouched, the gradient consumed (zeroed) so
     // the next step starts clean -- and count it where the host can see it.  Without this, clip = 0 and 0 x inf = NaN poisons p, m, v for good.

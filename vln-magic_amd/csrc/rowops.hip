@@ -1342,11 +1342,13 @@ extern "C" int magic_colsum_add_v(int n, const float* const* parts, float* const
   return launch_status();
 }
 
-// workgroups magic_ln_bwd launches for M rows with in-kernel gamma / beta gradients: the row count of its PARTIAL buffers (pg_partial)
-extern "C" int magic_ln_bwd_blocks(int M, int H) {
+// workgroups magic_ln_bwd launches for M rows with in-kernel gamma / beta gradients: the row count of its PARTIAL buffers (pg_partial).  has_tables: the
+// launch also carries table gradients (d0 / d1 / d2) -- those never take the lean shape (MAGIC_LNB_LEAN), whatever it is set to
+extern "C" int magic_ln_bwd_blocks(int M, int H, int has_tables) {
   if (M <= 0 || (H != 128 && H != 256 && H != 384 && H != 768)) return MAGIC_ERR_ARG;
   LnbParams p{};
   p.M = M; p.dgamma = (float*)1;
+  if (has_tables) p.d0 = (float*)1;
   return lnb_blocks(p, H / 128, true);
 }
 

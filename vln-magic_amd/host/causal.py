@@ -32,6 +32,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import lanes
 from . import ops as O
 from .config import cfg_get
 from .engine import HD
@@ -109,7 +110,7 @@ class _AddNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, e, net, ln, drop, owner=None):
-        ctx.owner = owner
+        ctx.owner, ctx.lane = owner, lanes.cur
         shp = x.shape
         H = shp[-1]
         M = x.numel() // H
@@ -124,6 +125,7 @@ class _AddNormFn(torch.autograd.Function):
         return y.view(shp)
 
     @staticmethod
+    @lanes.lane_bwd
     def backward(ctx, dy):
         net, ln = ctx.net, ctx.ln
         y, rstd = ctx.save
@@ -147,6 +149,7 @@ class _DoorGateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, e, blk):
+        ctx.lane = lanes.cur
         net = blk._net
         H = net.H
         names = blk._gate_names
@@ -161,6 +164,7 @@ class _DoorGateFn(torch.autograd.Function):
         return out.view(e.shape).to(e.dtype)
 
     @staticmethod
+    @lanes.lane_bwd
     def backward(ctx, dout):
         blk = ctx.blk
         net, names = blk._net, blk._gate_names

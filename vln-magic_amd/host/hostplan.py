@@ -8,9 +8,32 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-PATH = os.path.join(os.path.dirname(_HERE), "_magic_hostplan.so")
+PATH = os.environ.get("MAGIC_HOSTPLAN_PATH") or os.path.join(os.path.dirname(_HERE), "_magic_hostplan.so")      # (env: the sanitizer build, csrc/Makefile `asan`)
+SRC = os.path.join(os.path.dirname(_HERE), "csrc", "hostplan.c")
+ABI_VERSION = 2              # csrc/hostplan.c MP_ABI_VERSION
 _lib = None
 _tried = False
+
+
+class HostPlanError(RuntimeError):
+    pass
+
+
+def _check(l):
+    """refuse a stale object: ctypes would call an older mp_plan_nav signature with today's argument list and corrupt memory silently"""
+    try:
+        l.mp_abi_version.restype, l.mp_src_id.restype = C.c_int, C.c_char_p
+        abi, sid = int(l.mp_abi_version()), l.mp_src_id().decode()
+    except AttributeError:
+        raise HostPlanError(f"{PATH} predates mp_abi_version(): rebuild (make -C vln-magic_amd/csrc)") from None
+    if abi != ABI_VERSION:
+        raise HostPlanError(f"{PATH} reports ABI {abi}, this tree binds ABI {ABI_VERSION}: rebuild (make -C vln-magic_amd/csrc)")
+    if os.path.exists(SRC):
+        import hashlib
+        with open(SRC, "rb") as f:
+            want = hashlib.sha256(f.read()).hexdigest()[:16]
+        if sid != want:
+            raise HostPlanError(f"{PATH} was built from another csrc/hostplan.c (id {sid}, source {want}): rebuild (make -C vln-magic_amd/csrc)")
 
 
 def lib():
@@ -19,6 +42,7 @@ def lib():
         _tried = True
         if os.path.exists(PATH) and not os.environ.get("MAGIC_NO_HOSTPLAN"):
             l = C.CDLL(PATH)
+            _check(l)
             vp, i32 = C.c_void_p, C.c_int
             l.mp_hops_row.argtypes = [vp, i32, i32, i32, vp, vp]
             l.mp_dtw_cands.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, vp, vp]
@@ -111,7 +135,8 @@ def dtw_cands_idx(dd, row, idx_paths, ref_idx):
     return out[:n]
 
 
-CAP, VMAX = 128, 64          # nodes per episode / views recorded per unvisited node the native planner state is sized for (csrc/hostplan.c MP_MAXN = 512)
+CAP, VMAX = 128, 64          # nodes per episode the native planner state STARTS with (it doubles on demand up to MAXN) / views recorded per unvisited node
+MAXN = 512                   # csrc/hostplan.c MP_MAXN: the most map nodes one episode may hold in the native planner
 
 
 class NativeBatch:
@@ -130,6 +155,26 @@ class NativeBatch:
         self.vrows = np.zeros((self.B, CAP, VMAX), np.int64)
         self.keys = [None] * self.B
         self.gmaps = gmaps
+        for i in range(self.B):
+            self.register(i)
+
+    def grow(self, n):
+        """make room for `n` nodes per episode: the by-dense-id arrays double (contents kept) and every episode re-registers its new rows.  The reference's
+        map has no bound (map_nav_src/r2r/agent.py: GraphMap grows with every observation); RxR rollouts (max_action_len 28, sampled actions) can pass the
+        128 nodes the state starts with."""
+        cap = self.step.shape[1]
+        if n <= cap:
+            return
+        if n > MAXN:
+            raise ValueError(f"native planner: an episode's map grew to {n} nodes, past the {MAXN} the C core is built for (MAGIC_NO_HOSTPLAN=1 selects the Python planner)")
+        new = min(MAXN, max(2 * cap, n))
+
+        def wider(a, fill):
+            b = np.full((a.shape[0], new) + a.shape[2:], fill, a.dtype)
+            b[:, :cap] = a
+            return b
+        self.step, self.fused, self.vcount, self.vrows = wider(self.step, 0), wider(self.fused, -1), wider(self.vcount, 0), wider(self.vrows, 0)
+        self.keys = [None] * self.B
         for i in range(self.B):
             self.register(i)
 

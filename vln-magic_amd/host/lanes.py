@@ -145,3 +145,15 @@ def fence_end(tok):
         now, ss = tok
         for s in ss:
             s.wait_stream(now)
+
+
+def lane_bwd(fn):
+    """backward of an autograd Function that writes parameter gradients: re-enter the gradient lane its forward ran in (the forward records
+    `ctx.lane = lanes.cur`), so its `store.g(...)` handles resolve to that lane's buffer whatever lane the autograd engine happens to run the node from"""
+    def run(ctx, *grads):
+        k = getattr(ctx, "lane", 0)
+        if k == cur:
+            return fn(ctx, *grads)
+        with use(k):
+            return fn(ctx, *grads)
+    return run

@@ -35,7 +35,7 @@ SIGNATURES = {
     "magic_ln_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32,
                      vp, i32, i32, vp, i32, i32, vp, f32, u32, u32, vp, i32, i32, vp],
     "magic_ln_bwd_tail": [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
-    "magic_ln_bwd_blocks": [i32, i32],
+    "magic_ln_bwd_blocks": [i32, i32, i32],
     "magic_colsum_add_v": [i32, vp, vp, vp, vp, vp, vp],
     "magic_smallk_ln_bwd_blocks": [i32, i32, i32],
     "magic_ln_pgrad": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
@@ -305,7 +305,7 @@ def load():
     return lib
 
 
-FAST_PATH = os.path.join(os.path.dirname(LIB_PATH), "_magic_fastcall.so")
+FAST_PATH = os.environ.get("MAGIC_FASTCALL_PATH") or os.path.join(os.path.dirname(LIB_PATH), "_magic_fastcall.so")     # (env: the sanitizer build, csrc/Makefile `asan`)
 _FN = {}          # entry point name -> callable: the generated CPython wrapper when there is one, else the ctypes function
 
 

@@ -50,15 +50,7 @@ def nav_specs(cfg, p="vln_bert."):
     return s + causal_specs(cfg, p)
 
 
-def _lane_bwd(fn):
-    """backward of a Function that writes parameter gradients: re-enter the gradient lane its forward ran in (host/lanes.py; `ctx.lane`)"""
-    def run(ctx, *grads):
-        k = getattr(ctx, "lane", 0)
-        if k == lanes.cur:
-            return fn(ctx, *grads)
-        with lanes.use(k):
-            return fn(ctx, *grads)
-    return run
+_lane_bwd = lanes.lane_bwd        # backward of a Function that writes parameter gradients re-enters the lane its forward ran in (`ctx.lane`)
 
 
 class _HipLinearFn(torch.autograd.Function):
@@ -190,6 +182,7 @@ class _RowDotFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, critic):
+        ctx.lane = lanes.cur
         st = critic.store
         w, b = st.master("state2value.3.weight").view(-1), st.master("state2value.3.bias")
         x = h.detach().reshape(-1, h.shape[-1]).float().contiguous()
@@ -200,6 +193,7 @@ class _RowDotFn(torch.autograd.Function):
         return out.view(*h.shape[:-1], 1)
 
     @staticmethod
+    @_lane_bwd
     def backward(ctx, dy):
         st = ctx.critic.store
         st.ensure_grads()

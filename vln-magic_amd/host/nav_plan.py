@@ -134,7 +134,7 @@ class NavPlanner:
         if cid:
             g.pos_by_id[cid] = [cc["position"] for cc in ob["candidate"]]
         if n > nb.step.shape[1]:
-            raise ValueError(f"native planner: an episode's map grew past {nb.step.shape[1]} nodes")
+            nb.grow(n)              # (doubles up to csrc/hostplan.c's MP_MAXN = 512 nodes per episode; the Python planner has no bound)
         nb.register(i)
         import ctypes as C
         ca = (C.c_int32 * max(len(cid), 1))(*cid)

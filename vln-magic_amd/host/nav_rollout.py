@@ -342,6 +342,10 @@ class NavRollout:
         # gradient lanes (host/lanes.py): with captured step instances every rollout works on its own stream into its own gradient buffer, so
         # the rollouts' latency-bound chains overlap on the GPU in the forward AND in the one backward pass that follows
         laned = self.graphs and LANES and len(gens) > 1 and self.dev.type == "cuda" and all(k.get("grad", True) for _, k in jobs)
+        # ... and only when the step instances ARE usable: a model with causal-intervention blocks runs its steps eagerly (StepGraphs.usable() is False),
+        # and eager autograd nodes on a lane stream are isolated only if every one of them re-enters its lane in backward (model_nav._lane_bwd)
+        if laned and (getattr(self.student, "causal_blocks", None) or (self.train_teacher and getattr(self.teacher, "causal_blocks", None))):
+            laned = False
         ctx = [contextlib.nullcontext] * len(gens)
         if laned:
             lanes.fork(self.dev, range(len(gens)))

@@ -516,7 +516,7 @@ def ln_bwd(M, H, dy, *, y=None, gamma=None, beta=None, rstd=None, dx=None, dgamm
     partial = 0
     if do_ln and dgamma is not None and part_ok(H):
         # the gamma / beta sums of every workgroup go to its own row of a partial buffer; one column-sum launch per flush adds them up
-        nblk = _ln_blocks(M, H)
+        nblk = _ln_blocks(M, H, any(t[3] is not None for t in (d0, d1, d2)))
         pt = torch.empty(2, nblk, H, dtype=torch.float32, device=dy.device)
         PART_JOBS.append((pt[0], dgamma, nblk, H, H))
         PART_JOBS.append((pt[1], dbeta, nblk, H, H))
@@ -553,11 +553,11 @@ def part_ok(H):
     return PART_PG and H >= PART_MIN_H and DEFER["active"]
 
 
-def _ln_blocks(M, H):
-    k = (M, H)
+def _ln_blocks(M, H, has_tables=False):
+    k = (M, H, bool(has_tables))
     v = _LNB.get(k)
     if v is None:
-        v = _LNB[k] = int(L.load().magic_ln_bwd_blocks(M, H))
+        v = _LNB[k] = int(L.load().magic_ln_bwd_blocks(M, H, 1 if has_tables else 0))
         _chk(v > 0, "magic_ln_bwd_blocks")
     return v
 

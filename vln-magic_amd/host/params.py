@@ -324,7 +324,6 @@ class ParamStore:
 
     def zero_grad(self):
         self.grad.zero_()
-        if self.lane_dirty:               # (a backward pass that raised before its lanes were merged)
-            for b in self.lane_grads.values():
-                b.zero_()
-            self.lane_dirty = False
+        for b in self.lane_grads.values():       # always: a replayed lane graph writes its buffer without touching a handle (lane_dirty may be unset), and a
+            b.zero_()                            # pass that raised before its lanes were merged leaves them filled
+        self.lane_dirty = False

@@ -427,6 +427,8 @@ class StepGraphs:
         if ent is None:
             ent = inst.bwd[sig] = self._capture_bwd(inst, names, grads)
         bi, g, bo, g_dw, cat = ent
+        if getattr(inst, "lane", 0):  # the replayed graph writes the lane's gradient buffer through pointers baked in at capture: no handle access marks it
+            self.model.store.lane_dirty = True
         for n, t in zip(names, grads):
             if t is not None:
                 dst = bi[n]
@@ -488,6 +490,8 @@ class StepGraphs:
         used, self._cat_used = self._cat_used, []
         if not used:
             return
+        if self.model.store.lane_grads:       # (the concatenated launch writes dW of whichever lane its entries were captured on)
+            self.model.store.lane_dirty = True
         groups = {}
         for c in used:
             groups.setdefault(id(c.keys), []).append(c)

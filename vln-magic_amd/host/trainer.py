@@ -52,7 +52,9 @@ class FusedAdamW:
         self.t = 0
         self.schedule = schedule
         if schedule is not None:
-            self.step_dev = torch.zeros(1, dtype=torch.int32, device=store.device)
+            # [0] = global_step (the lr schedule's: advances on every step, skipped or not), [1] = the optimizer's state step (Adam's bias correction:
+            # taken back by the AdamW launch when it skips a non-finite step) -- csrc/optim.hip sched_advance
+            self.step_dev = torch.zeros(2, dtype=torch.int32, device=store.device)
             self.lr_ss = torch.zeros(2, dtype=torch.float32, device=store.device)
 
     def skipped_steps(self):
@@ -93,7 +95,8 @@ class FusedAdamW:
             O.sched_step(self.step_dev, self.lr, self.schedule[0], self.schedule[1], b1, b2, self.lr_ss, zero_me=self.ss if need_ss else None)
             lr_ss, step_size = self.lr_ss, 0.0
         else:
-            # (host-side step count: a step the kernel skips still advances `t` here -- the device-side schedule is the one that takes it back)
+            # (host-side scalars, no schedule: the navigator's / the tests' form.  `t` is a host count, so a step the kernel skips still advances the bias
+            # correction here -- knowing would cost a device -> host read per step; fp16 training with loss scaling runs the device-side schedule above)
             step_size = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
             if need_ss:
                 self.ss.zero_()

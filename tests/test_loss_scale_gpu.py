@@ -56,14 +56,14 @@ def test_adamw_divides_by_the_scale_reports_and_takes_the_step_back():
         torch.cuda.synchronize()
         return p, int(over.item())
     ref, _ = run(g0.clone(), None, None)
-    st, step = _state(S), torch.full((1,), 7, dtype=torch.int32, device=DEV)
+    st, step = _state(S), torch.full((2,), 7, dtype=torch.int32, device=DEV)      # {global_step, optimizer state step} (csrc/optim.hip)
     got, over = run(g0 * S, st, step)
     assert torch.allclose(got, ref, rtol=1e-6, atol=1e-7) and over == 0        # S x gradient, divided by S in the kernel (clip norm included)
-    assert st.tolist()[3] == 1.0 and int(step.item()) == 7
+    assert st.tolist()[3] == 1.0 and step.tolist() == [7, 7]
     bad = g0 * S
     bad[5] = float("inf")
     got, over = run(bad, st, step)
-    assert torch.equal(got, p0) and over == 1 and st.tolist()[3] == 2.0 and int(step.item()) == 6      # skipped: the schedule's step taken back
+    assert torch.equal(got, p0) and over == 1 and st.tolist()[3] == 2.0 and step.tolist() == [7, 6]      # skipped: the optimizer's state step taken back, global_step left alone
 
 
 def test_loss_kernels_multiply_their_seeds_by_the_registered_word():

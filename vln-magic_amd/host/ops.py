@@ -1283,7 +1283,8 @@ def sumsq(g, out):
 
 
 def sumsq_sched(g, out, step, lr0, warmup, total, b1, b2, lr_ss):
-    """sumsq + the device-side schedule step in one launch (out must be zero already)"""
+    """sumsq + the device-side schedule step in one launch (out must be zero already); step: int32[2] = {global_step, optimizer state step}"""
+    _chk(step.numel() >= 2 and step.dtype == torch.int32, "schedule step words: int32[2] {global_step, optimizer state step}")
     L.call("magic_sumsq_sched", g.numel(), L.P(g), L.P(out), L.P(step), float(lr0), int(warmup), int(total), float(b1), float(b2), L.P(lr_ss), L.stream())
 
 
@@ -1292,13 +1293,15 @@ def adamw(n, p, g, m, v, shadow, lr, b1, b2, eps, wd, step_size, sumsq_buf, max_
     """n_decay: the first n_decay elements take the weight decay, the rest none (-1: all); zero_grad: g := 0 after use; overflow: int32[1]
     device counter of steps skipped because the gradient norm was not finite (fp16: GradScaler's skip, never NaN weights); scale_state: the
     dynamic loss scale's fp32[4] (the gradient buffer holds S x the gradient; `pending` is left for the next step's prologue); sched_step: the
-    device-side schedule's step word, taken back by one on a skipped update"""
+    device-side schedule's step words int32[2] {global_step, optimizer state step}: a skipped update takes the state step back by one"""
+    _chk(sched_step is None or (sched_step.numel() >= 2 and sched_step.dtype == torch.int32), "schedule step words: int32[2] {global_step, optimizer state step}")
     L.call("magic_adamw", n, L.P(p), L.P(g), L.P(m), L.P(v), L.P(shadow), L.dt(shadow.dtype) if shadow is not None else 1, float(lr), float(b1), float(b2), float(eps), float(wd),
            float(step_size), L.P(sumsq_buf), float(max_norm), float(gscale), L.P(lr_ss), int(n_decay), 1 if zero_grad else 0, L.P(overflow),
            L.P(scale_state), L.P(sched_step), 1 if decay_first else 0, L.stream())
 
 
 def sched_step(step, lr0, warmup, total, b1, b2, lr_ss, zero_me=None):
+    _chk(step.numel() >= 2 and step.dtype == torch.int32, "schedule step words: int32[2] {global_step, optimizer state step}")
     L.call("magic_sched_step", L.P(step), float(lr0), int(warmup), int(total), float(b1), float(b2), L.P(lr_ss), L.P(zero_me), L.stream())
 
 

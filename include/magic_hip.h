@@ -542,9 +542,22 @@ typedef struct {
   const void* WoT;
   void *dfo, *dfod, *dz, *daod, *dao, *dctx;
   unsigned site_out, site_ao;
+  /* round 6 -- the ATTENTION BACKWARD of the block above inside the launch (what magic_attn_bwd did as a launch of its own between two
+   * magic_rowbwd launches: `loss.backward()` through BertSelfAttention, map_nav_src/r2r/agent_base.py:259-262).  mode 0: none (the fields below unused).
+   * mode 1: every workgroup owns 16-row tile (blk % ntile) of sample (blk / ntile) of an encoder whose samples have N <= 96 rows each (M = nsamp x N),
+   *   computes the dQKV rows of block j+1 for its rows from that block's saved qkv_a [M, 3H], clean probabilities P_a [nsamp, 2, N, ldp], attention
+   *   output o_a [M, H] and the d_ctx rows dctx_a [M, H] the previous launch wrote (rowsum(P dP) = dO . O; dP_init: optional fp32 [nsamp, 2, N, ldp]
+   *   gradient wrt the dropped probabilities; attention dropout p_attn / site_attn regenerated), stores them to dqkv_out [M, 3H] (the dY operand of
+   *   dWqkv) and runs the chain above with them as the tail's dQKV (WqkvT_n, dao_n of block j+1 as before; dqkv_n unused).
+   * mode 2: the same attention backward for block 0, then only dfo = dQKV Wqkv + d_ao: the gradient wrt the encoder's input (no LayerNorm). */
+  int mode, N, ntile, ldp;
+  const void* qkv_a; const void* P_a; const void* o_a; const void* dctx_a; const float* dP_init; void* dqkv_out;
+  unsigned site_attn, pad_;
 } magic_rowbwd_seg;
-typedef struct { magic_rowbwd_seg seg[2]; int nseg, blocks0; float p_hidden; int pad1; const unsigned* seed; } magic_rowbwd_params;
+typedef struct { magic_rowbwd_seg seg[2]; int nseg, blocks0; float p_hidden; int pad1; const unsigned* seed; float p_attn, scale; } magic_rowbwd_params;
 int magic_rowbwd_supported(int dtype, int H, int I);
+/* 1 when a segment may carry mode != 0: 16-bit storage, H = 128, FFN 512, 2 heads of 64, samples of N <= 96 rows */
+int magic_rowbwd_attn_supported(int dtype, int H, int I, int nh, int N);
 int magic_rowbwd_params_bytes(void);
 int magic_rowbwd(int dtype, const void* params, int nbytes, void* stream);
 /* params.pad1 != 0 (round 4): dg2 / db2 / dg1 / db1 of every segment point at PARTIAL buffers, ceil(M / magic_rowbwd_rows(total rows)) x H

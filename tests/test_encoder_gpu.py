@@ -234,6 +234,80 @@ def test_rowblock_backward_matches_the_per_op_backward(p_drop):
     print(f"row-block backward vs per-op: cosine {cos:.6f}, rel L2 {rel:.2e}, worst tensor {worst:.2e}")
 
 
+@pytest.mark.parametrize("with_seed", [False, True])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("max_len", [80, 41, 19])
+def test_attention_backward_inside_the_rowblock_launches_matches_the_alternating_launches(max_len, p_drop, with_seed):
+    """round 6 (csrc/encbwd.hip attn_tile_stage): a stack's backward as n + 1 launches -- the attention backward of block j+1 done per 16-row tile of
+    one sample in front of block j's per-token chain, rowsum(P dP) taken as dO . O (+ the distillation seed's term) -- against the round 2-5 structure
+    (magic_rowbwd and magic_attn_bwd alternating) and against the per-op chain: same saved tensors, same upstream gradients, same dropout seed, ragged
+    instruction lengths (5 / 3 / 2 tiles per sample, partial last tiles), 36- and 37-view panoramas, with and without a gradient seeded into the top
+    blocks' attention maps (attention distillation)."""
+    m = student(p_drop)
+    m.train()
+    batch = synth.make_batch("sap", batch_size=7, seed=5, step=0, dup_view_prob=0.3, max_len=max_len, min_len=min(20, max_len - 4))
+    plan = build_plan(batch, "sap", torch.device(DEV))
+    inp = m._inputs(batch, plan)
+    m.store.sync_shadow()
+    n = m.net
+    assert n.rbw_ok() and O.rowbwd_attn_ok(n.dtype, n.H, n.I, n.nh, plan["L"]) and O.rowbwd_attn_ok(n.dtype, n.H, n.I, n.nh, plan["V"])
+    seed = torch.tensor([4321, 99], dtype=torch.int32, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    B, L, H, Np, V = plan["B"], plan["L"], n.H, plan["Np"], plan["V"]
+    d_txt0 = (torch.randn(B * L, H, generator=g) * 0.1).to(DEV).bfloat16()
+    d_pano0 = (torch.randn(Np * V, H, generator=g) * 0.1).to(DEV).bfloat16()
+    d_fused0 = (torch.randn(Np, H, generator=g) * 0.1).to(DEV).bfloat16()
+    res = {}
+    for mode in ("per_op", "alternating", "inside"):
+        O.FUSED_RBW, O.RBW_ATTN = mode != "per_op", mode == "inside"
+        try:
+            n.set_dropout(seed if p_drop > 0 else None, p_drop, p_drop)
+            ct = n.text_fwd(plan)
+            cp = n.pano_fwd(plan, inp.feats, inp.loc)
+            gs = torch.Generator().manual_seed(11)
+            dPt = dPp = None
+            if with_seed:      # fp32 [B, heads, N, ldp] with zero pad columns, as the distillation loss kernels leave it
+                dPt = torch.zeros(B, n.nh, L, ct.ldp)
+                dPt[..., :L] = torch.randn(B, n.nh, L, L, generator=gs) * 0.02
+                dPp = torch.zeros(Np, n.nh, V, cp.ldp)
+                dPp[..., :V] = torch.randn(Np, n.nh, V, V, generator=gs) * 0.02
+                dPt, dPp = dPt.to(DEV), dPp.to(DEV)
+            m.store.zero_grad()
+            O.defer_dw(True)
+            if mode == "per_op":
+                n.text_bwd(ct, plan, d_txt0.clone(), dPt)
+                n.pano_bwd(cp, plan, d_pano0.clone(), d_fused0.clone(), dPp)
+            else:
+                n.encoders_bwd(ct, cp, plan, d_txt0.clone(), dPt, d_pano0.clone(), d_fused0.clone(), dPp)
+            O.flush_dw()
+            torch.cuda.synchronize()
+            res[mode] = m.store.grad.clone()
+        finally:
+            O.FUSED_RBW, O.RBW_ATTN = True, True
+    names = [nm for nm, _ in m.named_parameters() if ("lang_encoder" in nm or "pano_encoder" in nm or "embeddings" in nm)]
+    for ref, tol_all, tol_one in (("alternating", 1.5e-2, 4e-2), ("per_op", 3e-2, 6e-2)):
+        a, b = res["inside"], res[ref]
+        assert torch.isfinite(a).all() and a.abs().max() > 0
+        cos = F.cosine_similarity(a, b, dim=0).item()
+        rel = ((a - b).norm() / b.norm()).item()
+        assert cos > 0.9995 and rel < tol_all, (ref, cos, rel)
+        top = max(b[m.store.offsets[nm][0]:m.store.offsets[nm][0] + m.store.offsets[nm][1]].norm().item() for nm in names)
+        worst = (0.0, "")
+        for nm in names:
+            off, cnt, _ = m.store.offsets[nm]
+            ga, gb = a[off:off + cnt], b[off:off + cnt]
+            if gb.norm() == 0:
+                assert ga.norm() == 0, nm
+                continue
+            if gb.norm().item() < 1e-3 * top:
+                assert ga.norm().item() < 1e-2 * top, nm
+                continue
+            r = ((ga - gb).norm() / gb.norm()).item()
+            worst = max(worst, (r, nm))
+            assert r < tol_one, (ref, nm, r)
+        print(f"attention backward inside the row-block launches vs {ref}: cosine {cos:.6f}, rel L2 {rel:.2e}, worst tensor {worst[0]:.2e} ({worst[1]})")
+
+
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 @pytest.mark.parametrize("task", ["sap", "mlm", "mrc"])
 def test_cross_encoder_rowblock_backward_matches_the_per_op_backward(task, p_drop):

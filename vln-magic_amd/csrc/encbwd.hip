@@ -32,8 +32,15 @@ template <typename Hh> struct RbwSegT {
   const Hh* WoT;                                                                                  // [H, H]
   Hh *dfo, *dfod, *dz, *daod, *dao, *dctx;                        // outputs (dfo / dfod only when the tail runs here)
   unsigned site_out, site_ao;
+  // ---- round 6: the ATTENTION BACKWARD of the block above inside this launch (mode != 0; see attn_tile_stage) ----
+  // mode 1: [attention backward of block j+1 for this workgroup's 16 rows of one sample] -> the chain above with the tail's dQKV taken from LDS;
+  // mode 2: [attention backward of block 0] -> dx0 = dQKV Wqkv + d_ao, written to dfo (the gradient wrt the stack's input), nothing else
+  int mode, N, ntile, ldp;                                         // rows per sample (uniform), 16-row tiles per sample, row pitch of P
+  const Hh* qkv_a; const Hh* P_a; const Hh* o_a; const Hh* dctx_a; const float* dP_init;     // block j+1: [M, 3H], [nsamp, 2, N, ldp], [M, H], [M, H]; optional fp32 seed
+  Hh* dqkv_out;                                                    // [M, 3H]: the dY operand of dWqkv
+  unsigned site_attn, pad_;
 };
-template <typename Hh> struct RbwParamsT { RbwSegT<Hh> seg[2]; int nseg, blocks0; float p_hidden; int pad1; const unsigned* seed; };
+template <typename Hh> struct RbwParamsT { RbwSegT<Hh> seg[2]; int nseg, blocks0; float p_hidden; int pad1; const unsigned* seed; float p_attn, scale; };
 typedef RbwParamsT<bf16> RbwParams; typedef RbwSegT<bf16> RbwSeg;      // host side: pointers only, one layout for both 16-bit types
 
 // exact-enough gelu'(x) = Phi(x) + x phi(x) with the same rational erf as gelu_fast (one exp shared by both terms)
@@ -118,6 +125,149 @@ __device__ __forceinline__ void ln_bwd_rows(f32x4 (&acc)[NRT], const Hh* sY, con
     }
 }
 
+// ---- round 6: attention backward per 16-row tile --------------------------------------------------------------------------------------------
+// The per-token chain of block j and the attention backward of block j+1 used to alternate as two launches per block (magic_rowbwd, magic_attn_bwd:
+// one workgroup per (sample, head) -- 96 workgroups for the text stack) because the attention backward sums over queries.  A 16-row tile of ONE
+// sample can do its share alone, flash-attention style, once d_ctx of the WHOLE sample is in memory (it is: the previous launch wrote it):
+//   as QUERIES (rows R of the tile, all keys):   dP = dO_R V^T (+ seed), mask, dS_R = P_R o (dP - rs) scale, dQ_R = dS_R K
+//   as KEYS    (rows R as keys, all queries):    dS[:, R] the same way from dO (all rows) V_R^T, dK_R = dS[:, R]^T Q, dV_R = (P o mask)[:, R]^T dO
+// with rs_q = sum_k P[q,k] dP[q,k] = dO_q . O_q (+ sum_k (P o mask)[q,k] seed[q,k] when a distillation gradient seeds dP) -- no pass over the keys.
+// dP of the tile's own rows is computed twice (once per role: 1/5 of the products of an 80-token sample); everything else is the tile's own share.
+// Operands: V rows are MFMA A fragments straight from global memory (k = head dim, contiguous); Q, K, dO of the sample sit in LDS images because
+// dQ / dK / dV contract over rows (transposing reads); one head at a time through the same images.  Output: the tile's [16, 3H] dQKV rows in the
+// chain's z image (QS pitch) -- the tail product's A operand -- and in global memory for the deferred dWqkv.
+#define AT_DS 72          // [rows][64] images of one head
+#define AT_PS 104         // [16][<= 96] dS / dS^T / (P o mask)^T tiles
+#define AT_ROWS 96
+static inline size_t attn_stage_lds() { return (size_t)(3 * AT_ROWS * AT_DS + 3 * 16 * AT_PS) * 2 + AT_ROWS * sizeof(float); }
+template <typename Hh>
+__device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const RbwParamsT<Hh>& p, const int b, const int ti, const int nv,
+                                                Hh* sDq, unsigned char* scratch, const int tid) {
+  typedef h16x4<Hh> v4;
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
+  const int N = sg.N, NT = sg.ntile, NK32 = (N + 31) / 32 * 32, ldp = sg.ldp;
+  Hh* sQ = (Hh*)scratch;
+  Hh* sK = sQ + AT_ROWS * AT_DS;
+  Hh* sdO = sK + AT_ROWS * AT_DS;
+  Hh* sdS = sdO + AT_ROWS * AT_DS;          // [16 queries of the tile][keys]
+  Hh* sdST = sdS + 16 * AT_PS;              // [16 keys of the tile][queries]
+  Hh* sPT = sdST + 16 * AT_PS;              // (P o mask)^T, same shape
+  float* sRs = (float*)(sPT + 16 * AT_PS);  // [AT_ROWS]
+  const long long row0 = (long long)b * N;
+  DropDesc dd;
+  dd.seed = p.seed; dd.site = sg.site_attn; dd.p = p.p_attn;
+  const DropState ds = drop_init(dd);
+  h16x8<Hh> zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (Hh)0.0f;
+  // the three small tiles: columns [16 NT, NK32) are contraction padding that no stage writes -- zero everything once
+  for (int id = tid; id < 3 * 16 * AT_PS / 8; id += NWAVE * 64) *(h16x8<Hh>*)(sdS + id * 8) = zero8;
+  for (int h = 0; h < ENH; ++h) {
+    // ---- Q, K, dO of the sample (this head) -> LDS; rs_q = dO_q . O_q (+ seed term) from global rows
+    for (int id = tid; id < NK32 * 8; id += NWAVE * 64) {
+      const int r = id >> 3, c = (id & 7) * 8;
+      h16x8<Hh> vq = zero8, vk = zero8, vo = zero8;
+      if (r < N) {
+        const Hh* base = sg.qkv_a + (row0 + r) * (3 * EH) + h * EHD + c;
+        vq = *(const h16x8<Hh>*)base;
+        vk = *(const h16x8<Hh>*)(base + EH);
+        vo = *(const h16x8<Hh>*)(sg.dctx_a + (row0 + r) * EH + h * EHD + c);
+      }
+      *(h16x8<Hh>*)(sQ + r * AT_DS + c) = vq;
+      *(h16x8<Hh>*)(sK + r * AT_DS + c) = vk;
+      *(h16x8<Hh>*)(sdO + r * AT_DS + c) = vo;
+    }
+    for (int q = tid >> 3; q < NK32; q += NWAVE * 8) {
+      const int l8 = tid & 7;
+      float s = 0.f;
+      if (q < N) {
+        const long long o_ = (row0 + q) * EH + h * EHD + l8 * 8;
+        const h16x8<Hh> a = *(const h16x8<Hh>*)(sg.dctx_a + o_), bb = *(const h16x8<Hh>*)(sg.o_a + o_);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += to_f(a[e]) * to_f(bb[e]);
+        if (sg.dP_init) {                   // + sum_k (P o mask)[q, k] seed[q, k]: the distillation gradient enters dP before the mask
+          const long long prow = ((long long)b * ENH + h) * N + q;
+          for (int c8 = l8 * 8; c8 < ldp; c8 += 64) {
+            const h16x8<Hh> pv = *(const h16x8<Hh>*)(sg.P_a + prow * ldp + c8);
+            const f32x4 i0 = *(const f32x4*)(sg.dP_init + prow * ldp + c8), i1 = *(const f32x4*)(sg.dP_init + prow * ldp + c8 + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int key = c8 + e;
+              if (key < N) {
+                const float m = ds.on ? drop_mul(ds, (unsigned)(prow * N + key)) : 1.f;
+                s += to_f(pv[e]) * m * (e < 4 ? i0[e & 3] : i1[e & 3]);
+              }
+            }
+          }
+        }
+      }
+      s += dpp_mov<DPP_QUAD_XOR1>(s);
+      s += dpp_mov<DPP_QUAD_XOR2>(s);
+      s += dpp_mov<DPP_ROW_HALF_MIRROR>(s);
+      if (l8 == 0) sRs[q] = s;
+    }
+    __syncthreads();
+    // ---- stage A: dP^T tiles (rows = keys, columns = queries: a lane owns four consecutive keys of one query), dS into the role's image
+    for (int job = w; job < 2 * NT; job += NWAVE) {
+      const bool asq = job < NT;
+      const int t = asq ? job : job - NT;
+      const int ktile = asq ? t : ti, qtile = asq ? ti : t;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int vkey = ktile * 16 + c16;
+#pragma unroll
+      for (int ks = 0; ks < EHD / 32; ++ks) {
+        h16x8<Hh> av = zero8;
+        if (vkey < N) av = *(const h16x8<Hh>*)(sg.qkv_a + (row0 + vkey) * (3 * EH) + 2 * EH + h * EHD + ks * 32 + 8 * g);
+        acc = emma(av, lfrag(sdO, AT_DS, qtile * 16, ks * 32, lane), acc);
+      }
+      const int q = qtile * 16 + c16, key0 = ktile * 16 + 4 * g;
+      const bool qok = q < N;
+      const long long prow = ((long long)b * ENH + h) * N + q;
+      v4 p4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p4[r] = (Hh)0.0f;
+      if (qok && key0 < ldp) p4 = *(const v4*)(sg.P_a + prow * ldp + key0);
+      f32x4 init = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (sg.dP_init && qok && key0 < N) init = *(const f32x4*)(sg.dP_init + prow * ldp + key0);
+      const float rsq = sRs[q];
+      v4 o4, pm4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + r;
+        const bool ok = qok && key < N;
+        float d = acc[r] + (ok ? init[r] : 0.f);
+        const float pp = to_f(p4[r]);
+        float pm = pp;
+        if (ds.on) {
+          const float m = ok ? drop_mul(ds, (unsigned)(prow * N + key)) : 0.f;
+          d *= m; pm = pp * m;
+        }
+        o4[r] = from_f<Hh>(pp * (d - rsq) * p.scale);
+        pm4[r] = from_f<Hh>(pm);
+      }
+      if (asq) *(v4*)(sdS + c16 * AT_PS + key0) = o4;
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sdST[(4 * g + r) * AT_PS + q] = o4[r]; sPT[(4 * g + r) * AT_PS + q] = pm4[r]; }
+      }
+    }
+    __syncthreads();
+    // ---- stage B: dQ_R = dS_R K, dK_R = dS[:, R]^T Q, dV_R = (P o mask)[:, R]^T dO: twelve 16 x 16 output tiles over the waves
+    for (int job = w; job < 12; job += NWAVE) {
+      const int prod = job >> 2, jd = job & 3;
+      const Hh* A = prod == 0 ? sdS : (prod == 1 ? sdST : sPT);
+      const Hh* Bm = prod == 0 ? sK : (prod == 1 ? sQ : sdO);
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < NK32 / 32; ++ks) acc = emma(lfrag(A, AT_PS, 0, ks * 32, lane), tfrag(Bm, AT_DS, jd * 16, ks * 32, lane), acc);
+      const int col = prod * EH + h * EHD + jd * 16 + c16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sDq[(4 * g + r) * QS + col] = from_f<Hh>(acc[r]);
+    }
+    __syncthreads();
+  }
+  copy_out(sDq, QS, sg.dqkv_out + (row0 + ti * 16) * (3 * EH), 3 * EH, nv, 3 * EH, tid);
+}
+
 // NRT = row tiles of 16 per workgroup.  2 (32 rows): two workgroups per CU, 128 registers per lane, weight fragments one chunk of four
 // k-steps ahead of their use.  4 (64 rows): one workgroup per CU, 256 registers, a whole product's fragments ahead -- and half the
 // weight bytes streamed from L2 per row (every workgroup streams all 393 KB of the block's matrices).
@@ -127,13 +277,15 @@ __device__ long long rbw_ticks[16];            // wall_clock64 (100 MHz) marks o
 #else
 #define RBW_MARK(i)
 #endif
-template <int NRT, typename Hh>
+template <int NRT, typename Hh, bool ATT = false>
 __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned char* rb_smem) {
   constexpr int RB_ROWS = NRT * 16;
   constexpr bool DEEP = NRT >= 4;
+  static_assert(!ATT || NRT == 1, "the attention stage works on 16-row tiles of one sample");
   int blk = blockIdx.x, sidx = 0;
   if (blk >= p.blocks0) { blk -= p.blocks0; sidx = 1; }
   const RbwSegT<Hh>& sg = p.seg[sidx];
+  const int mode = ATT ? sg.mode : 0;
   Hh* sZ = (Hh*)rb_smem;                   // [32][GS]  z, overwritten in place by d_z
   Hh* sY2 = sZ + RB_ROWS * GS;               // [32][XS]  this block's output (its LayerNorm's y); later the d_ctx staging image
   Hh* sR = sY2 + RB_ROWS * XS;               // [32][XS]  d_ao of the next block (residual of the tail)
@@ -143,15 +295,22 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
   Hh* sAo = sR;                              // [..][XS]  d_ao (the tail's residual image is dead by then)
   float* red = (float*)(sY1 + RB_ROWS * XS);   // [2][8][rows]
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
-  const int m0 = blk * RB_ROWS, M = sg.M;
-  const int nv = min(RB_ROWS, M - m0);
+  const int M = sg.M;
+  // rows of this workgroup: a flat 16 / 32 / 64-row block of the [M, H] buffers, or (mode != 0) 16-row tile blk % ntile of sample blk / ntile
+  int m0 = blk * RB_ROWS, nv = min(RB_ROWS, M - m0);
+  if (mode) { const int b = blk / sg.ntile, ti = blk - b * sg.ntile; m0 = b * sg.N + ti * 16; nv = min(16, sg.N - ti * 16); }
   const int colw = w * 16 + c16;
-  const bool tail = sg.dqkv_n != nullptr;
+  const bool tail = mode ? true : sg.dqkv_n != nullptr;
   const bool shortm = sg.z == nullptr;           // short chain (cross-attention query side): tail -> LayerNorm backward -> output projection
-  const int kt = sg.kt, ldq = kt * 32;
+  const int kt = mode ? 12 : sg.kt, ldq = kt * 32;
   DropDesc dd;
   dd.seed = p.seed; dd.p = p.p_hidden;
   RBW_MARK(0);
+  if (mode) {          // dQKV rows of the block above: computed here, left in the z image's space (QS pitch) where the tail expects them
+    const int b = blk / sg.ntile;
+    attn_tile_stage<Hh>(sg, p, b, blk - b * sg.ntile, nv, sZ, rb_smem + (size_t)RB_ROWS * GS * sizeof(Hh), tid);
+    // (the stage ends on a barrier: its scratch behind the z image is dead and becomes the chain's images below)
+  }
   // ---- weights of the first two products + small parameters, issued before anything else
   // (two workgroups per CU = 128 registers per lane: weight fragments arrive in chunks of four k-steps, one chunk ahead of their use)
   h16x8<Hh> wq[12];
@@ -161,15 +320,16 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
       if (ks < kt) wq[ks] = gfrag(sg.WqkvT_n, ldq, w * 16, ks * 32, lane);
   }
   h16x8<Hh> w2[4][4];
-  const float gm2 = sg.g2[colw], bt2 = sg.b2[colw];
+  const float gm2 = mode == 2 ? 0.f : sg.g2[colw], bt2 = mode == 2 ? 0.f : sg.b2[colw];
   const float gm1 = shortm ? 0.f : sg.g1[colw], bt1 = shortm ? 0.f : sg.b1[colw];     // (the short chain has no second LayerNorm)
   // ---- stage the block's rows: z, a, and either (out, d_ao of the next block) for the tail or the given (d_fo, d_fod)
   // tail: the dQKV rows of the block above pass through the z image's space first (z itself is fetched during the tail's epilogue)
-  if (tail) load_rows_img(sZ, QS, sg.dqkv_n + (long long)m0 * ldq, ldq, RB_ROWS, ldq, nv, tid);
+  if (mode) ;                                    // (the attention stage left the dQKV rows in the image)
+  else if (tail) load_rows_img(sZ, QS, sg.dqkv_n + (long long)m0 * ldq, ldq, RB_ROWS, ldq, nv, tid);
   else load_rows_img(sZ, GS, sg.z + (long long)m0 * EI, EI, RB_ROWS, EI, nv, tid);
   if (!shortm) load_rows_img(sY1, XS, sg.y1 + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
   if (tail) {
-    load_rows_img(sY2, XS, sg.y2 + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
+    if (mode != 2) load_rows_img(sY2, XS, sg.y2 + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
     load_rows_img(sR, XS, sg.dao_n + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
   } else {
     load_rows_img(sFo, XS, sg.dfo_in + (long long)m0 * EH, EH, RB_ROWS, EH, nv, tid);
@@ -197,6 +357,18 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
       KSTEP_FENCE();
     }
     RBW_MARK(2);
+    if (mode == 2) {      // bottom of the stack: dx0 = dQKV Wqkv + d_ao is the gradient wrt the stack's input -- no LayerNorm, nothing below
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = i * 16 + 4 * g + r;
+          sFo[rr * XS + colw] = from_f<Hh>(acc[i][r] + to_f(sR[rr * XS + colw]));
+        }
+      __syncthreads();
+      copy_out(sFo, XS, sg.dfo + (long long)m0 * EH, EH, nv, EH, tid);
+      return;
+    }
     // z rows -> registers now (their round trip hides under the LayerNorm backward); they go into the image once every wave is past
     // the barrier inside ln_bwd_rows, i.e. done reading the dQKV rows
     constexpr int ZIT = RB_ROWS * (EI / 8) / (NWAVE * 64);
@@ -214,7 +386,7 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
       for (int r = 0; r < 4; ++r) acc[i][r] += to_f(sR[(i * 16 + 4 * g + r) * XS + colw]);
     dd.site = sg.site_out;
     const DropState ds = drop_init(dd);
-    ln_bwd_rows<NRT>(acc, sY2, sg.rstd2, gm2, bt2, sg.dg2, sg.db2, red, sFo, sD, m0, M, ds, w, lane, p.pad1 ? blk : -1);
+    ln_bwd_rows<NRT>(acc, sY2, sg.rstd2, gm2, bt2, sg.dg2, sg.db2, red, sFo, sD, m0, m0 + nv, ds, w, lane, p.pad1 ? blk : -1);
 #pragma unroll
     for (int it = 0; it < ZIT; ++it) {
       const int id = tid + it * NWAVE * 64, r = id / (EI / 8), c = (id % (EI / 8)) * 8;
@@ -304,7 +476,7 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
     dd.site = sg.site_ao;
     const DropState ds = drop_init(dd);
     // d_aod goes where d_fod was: every wave is past the FFN product (the barrier above) and reads sD no more
-    ln_bwd_rows<NRT>(acc, sY1, sg.rstd1, gm1, bt1, sg.dg1, sg.db1, red, sAo, sD, m0, M, ds, w, lane, p.pad1 ? blk : -1);
+    ln_bwd_rows<NRT>(acc, sY1, sg.rstd1, gm1, bt1, sg.dg1, sg.db1, red, sAo, sD, m0, m0 + nv, ds, w, lane, p.pad1 ? blk : -1);
   }
   __syncthreads();                               // d_ao / d_aod images complete
   RBW_MARK(8);
@@ -344,6 +516,11 @@ template <typename Hh> __global__ __launch_bounds__(512, 2) void rowbwd64_kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
   rowbwd_body<4>(p, rb_smem);
 }
+// round 6: the 16-row chain with the attention backward of the block above in front (segments with mode != 0)
+template <typename Hh> __global__ __launch_bounds__(512, 4) void rowbwd16a_kernel(RbwParamsT<Hh> p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
+  rowbwd_body<1, Hh, true>(p, rb_smem);
+}
 static size_t rbw_lds_bytes(int rows) { return (size_t)(rows * GS + 5 * rows * XS) * 2 + (size_t)2 * NWAVE * rows * sizeof(float); }
 // rows per workgroup: MAGIC_RBW_ROWS = 16 / 32 / 64 forces one shape; default (0) = 16 rows when that still leaves the launch with no more
 // workgroups than CUs (the text stack alone: 3840 rows = 240 workgroups instead of 120 on 256 CUs), else 32 (measured: 64 rows 51.6 us vs 42.7)
@@ -380,6 +557,8 @@ extern "C" int magic_colsum_add(int H, int n, const float* const* parts, float* 
   return launch_status();
 }
 
+// workgroups a segment of `M` rows takes in a launch with an attention-stage segment (mode != 0: nsamp x ntile; else flat 16-row blocks)
+extern "C" int magic_rowbwd_attn_supported(int dtype, int H, int I, int nh, int N) { return dtype_is16(dtype) && H == EH && I == EI && nh == ENH && N > 0 && N <= AT_ROWS; }
 extern "C" int magic_rowbwd_supported(int dtype, int H, int I) { return dtype_is16(dtype) && H == EH && I == EI; }
 extern "C" int magic_rowbwd_params_bytes() { return (int)sizeof(RbwParams); }
 
@@ -390,12 +569,29 @@ extern "C" int magic_rowbwd(int dtype, const void* params, int nbytes, void* str
   if (p.nseg < 1 || p.nseg > 2 || !drop_args_ok(p.seed, p.p_hidden)) return MAGIC_ERR_ARG;
   int blocks = 0;
   long long total_rows = 0;
-  for (int s = 0; s < p.nseg; ++s) total_rows += p.seg[s].M > 0 ? p.seg[s].M : 0;
-  const int rows = rbw_rows_env() ? rbw_rows_env() : (total_rows <= 16ll * rbw_ncu() ? 16 : 32);
+  bool att = false;
+  for (int s = 0; s < p.nseg; ++s) { total_rows += p.seg[s].M > 0 ? p.seg[s].M : 0; att = att || p.seg[s].mode != 0; }
+  const int rows = att ? 16 : (rbw_rows_env() ? rbw_rows_env() : (total_rows <= 16ll * rbw_ncu() ? 16 : 32));
+  if (att && !drop_args_ok(p.seed, p.p_attn)) return MAGIC_ERR_ARG;
   for (int s = 0; s < 2; ++s) {
     RbwSeg& sg = p.seg[s];
-    if (s >= p.nseg) { sg.M = 0; continue; }
+    if (s >= p.nseg) { sg.M = 0; sg.mode = 0; continue; }
     if (sg.M <= 0 || (long long)sg.M * EI > 0x7FFFFFFFll) return MAGIC_ERR_ARG;
+    if (sg.mode) {                    // attention backward of the block above inside the launch: per-sample 16-row tiles
+      if (sg.mode != 1 && sg.mode != 2) return MAGIC_ERR_ARG;
+      if (sg.N <= 0 || sg.N > AT_ROWS || sg.M % sg.N || sg.ldp < sg.N || sg.ldp % 8 || sg.ntile != (sg.N + 15) / 16) return MAGIC_ERR_ARG;
+      const void* need[] = {sg.qkv_a, sg.P_a, sg.o_a, sg.dctx_a, sg.dqkv_out, sg.WqkvT_n, sg.dao_n, sg.dfo};
+      for (const void* q : need)
+        if (!q || ((uintptr_t)q & 15)) return MAGIC_ERR_ARG;
+      if (((uintptr_t)sg.dP_init & 15) || (long long)(sg.M / sg.N) * ENH * sg.N * sg.N > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+      if (sg.mode == 2) {             // bottom of a stack: attention backward + dx0 only
+        const int nb2 = (sg.M / sg.N) * sg.ntile;
+        if (s == 0) p.blocks0 = nb2;
+        blocks += nb2;
+        continue;
+      }
+      if (!sg.z || !sg.dfod) return MAGIC_ERR_ARG;       // (mode 1 runs the full chain; the short chain keeps its own launches)
+    }
     const void* req[] = {sg.y2, sg.rstd2, sg.g2, sg.b2, sg.WoT, sg.dctx};
     for (const void* q : req)
       if (!q) return MAGIC_ERR_ARG;
@@ -404,15 +600,29 @@ extern "C" int magic_rowbwd(int dtype, const void* params, int nbytes, void* str
       for (const void* q : full)
         if (!q) return MAGIC_ERR_ARG;
     } else if (!sg.dqkv_n) return MAGIC_ERR_ARG;      // the short chain is a tail by definition
-    if (sg.dqkv_n) { if (!sg.WqkvT_n || !sg.dao_n || !sg.dfo || !sg.dfod || (sg.kt != 0 && sg.kt != 4 && sg.kt != 12)) return MAGIC_ERR_ARG; }
+    if (sg.mode) ;
+    else if (sg.dqkv_n) { if (!sg.WqkvT_n || !sg.dao_n || !sg.dfo || !sg.dfod || (sg.kt != 0 && sg.kt != 4 && sg.kt != 12)) return MAGIC_ERR_ARG; }
     else if (!sg.dfo_in || !sg.dfod_in) return MAGIC_ERR_ARG;
     if ((sg.dg2 == nullptr) != (sg.db2 == nullptr) || (sg.dg1 == nullptr) != (sg.db1 == nullptr)) return MAGIC_ERR_ARG;
     const void* al[] = {sg.dqkv_n, sg.WqkvT_n, sg.dao_n, sg.dfo_in, sg.dfod_in, sg.y2, sg.z, sg.W2T, sg.W1T, sg.y1, sg.WoT, sg.dfo, sg.dfod, sg.dz, sg.daod, sg.dao, sg.dctx};
     for (const void* q : al)
       if ((uintptr_t)q & 15) return MAGIC_ERR_ARG;
-    const int nb = (sg.M + rows - 1) / rows;
+    const int nb = sg.mode ? (sg.M / sg.N) * sg.ntile : (sg.M + rows - 1) / rows;
     if (s == 0) p.blocks0 = nb;
     blocks += nb;
+  }
+  if (att) {
+    const size_t rest = rbw_lds_bytes(16) - (size_t)16 * GS * 2;
+    const size_t shm = (size_t)16 * GS * 2 + (attn_stage_lds() > rest ? attn_stage_lds() : rest);
+    static bool attr_a = false;
+    if (!attr_a) {
+      (void)hipFuncSetAttribute((const void*)rowbwd16a_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      (void)hipFuncSetAttribute((const void*)rowbwd16a_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      attr_a = true;
+    }
+    if (dtype == DT_BF16) hipLaunchKernelGGL(rowbwd16a_kernel<bf16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+    else { RbwParamsT<f16> pf; static_assert(sizeof(pf) == sizeof(p), "layout"); memcpy(&pf, &p, sizeof(pf)); hipLaunchKernelGGL(rowbwd16a_kernel<f16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, pf); }
+    return launch_status();
   }
   const size_t shm = rbw_lds_bytes(rows);
   static bool attr_set = false;

@@ -648,6 +648,9 @@ class MagicNet:
         weight gradients queued) -- the data-parallel exchange cuts its buckets there (trainer.GradSync)."""
         from . import lib as L
         H, I = self.H, self.I
+        if all(O.rowbwd_attn_ok(self.dtype, H, I, self.nh, c.layers[-1].sa.N) and O.attn_supported(self.dtype, c.layers[-1].sa.N, c.layers[-1].sa.N, True)
+               for c, _, _, _ in stacks):
+            return self._self_stacks_bwd_fused(stacks, on_iter)
         rounds = 0
         st = []
         for c, fmt, d_top, dP in stacks:
@@ -711,6 +714,78 @@ class MagicNet:
             rounds += 1
             if on_iter is not None:
                 on_iter(rounds)
+        return [s.dx0 for s in st]
+
+    def _self_stacks_bwd_fused(self, stacks, on_iter=None):
+        """self_stacks_bwd with the attention backward INSIDE the row-block launches (round 6, csrc/encbwd.hip attn_tile_stage): a stack of n blocks is
+        n + 1 launches -- [chain of the top block] -> [attention backward of block j+1 + chain of block j] x (n - 1) -> [attention backward of block 0 +
+        the gradient wrt the stack's input] -- instead of 2 n + 1 (chain and attention backward alternating, then a GEMM); the stacks advance together
+        from their tops in shared launches.  Every workgroup owns a 16-row tile of ONE sample and needs the d_ctx rows of its whole sample, which the
+        previous launch wrote: no hand-off inside a launch.  Same saved tensors, same dY operands for the deferred weight gradients."""
+        H, I = self.H, self.I
+        st = []
+        for c, fmt, d_top, dP in stacks:
+            lc = c.layers[-1]
+            st.append(Ctx(c=c, fmt=fmt, nl=len(c.layers), M=lc.sa.Bn * lc.sa.N, dP=dP, d_top=d_top, prev=None, dx0=None))
+        d = self.drop
+        step = 0
+        while any(s.dx0 is None for s in st):
+            segs, act = [], []
+            for s in st:
+                if s.dx0 is not None:
+                    continue
+                nl, M = s.nl, s.M
+                j = nl - 1 - step                     # the block whose per-token chain runs in this launch (-1: none left, only the input gradient)
+                seg, out = dict(M=M), Ctx()
+                flops = 0.0
+                if j >= 0:
+                    lp, lc = s.fmt.format(j), s.c.layers[j]
+                    sa, ffn = lc.sa, lc.ffn
+                    f1, f2, o = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.lin(lp + "attention.output.dense.weight")
+                    n2, n1 = self.ln(lp + "output.LayerNorm"), self.ln(lp + "attention.output.LayerNorm")
+                    out = Ctx(dz=self.new(M, I), daod=self.new(M, H), dao=self.new(M, H), dctx=self.new(M, H), dfo=self.new(M, H), dfod=self.new(M, H))
+                    seg.update(y2=ffn.out, rstd2=ffn.rstd, g2=n2.g, b2=n2.b, z=ffn.z, W2T=f2.WTf, W1T=f1.WTf, y1=sa.a, rstd1=sa.rstd_a,
+                               g1=n1.g, b1=n1.b, dg1=n1.dg, db1=n1.db, WoT=o.WTf, dz=out.dz, daod=out.daod, dao=out.dao, dctx=out.dctx,
+                               dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db,
+                               site_out=ffn.hdrop[2] if ffn.hdrop else 0, site_ao=sa.hdrop[2] if sa.hdrop else 0)
+                    flops += 2.0 * ffn.rows * (2 * H * I + H * H)
+                if step == 0:                         # top block: dx of the output norm = the plain gradient wrt the stack's output (no product)
+                    seg.update(dqkv_n=s.d_top, kt=0, WqkvT_n=f2.WTf, dao_n=s.d_top)
+                    s.d_top = None
+                else:                                 # attention backward of block j + 1 (its d_ctx / d_ao came out of the previous launch), then the tail
+                    up = s.c.layers[j + 1]
+                    sa1 = up.sa
+                    qn = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
+                    out.dqkv = self.new(M, 3 * H)
+                    if j < 0:
+                        out.dx0 = self.new(M, H)
+                    seg.update(mode=1 if j >= 0 else 2, N=sa1.N, ldp=sa1.ldp, qkv_a=sa1.qkv, P_a=sa1.Ppre, o_a=sa1.ctx, dctx_a=s.prev.dctx,
+                               dP_init=s.dP if j + 1 == nl - 1 else None, dqkv_out=out.dqkv, site_attn=sa1.adrop[2] if sa1.adrop else 0,
+                               WqkvT_n=qn.WTf, dao_n=s.prev.dao, **({} if j >= 0 else dict(dfo=out.dx0)))
+                    flops += 2.0 * sa1.rows * 3 * H * H + 8.0 * sa1.aflops
+                seg["flops"] = flops
+                segs.append(seg)
+                act.append((s, j, out))
+            O.rowbwd(segs, d[0] if d else None, d[1] if d else 0.0, p_attn=d[2] if d else 0.0, scale=1.0 / math.sqrt(HD))
+            for s, j, out in act:
+                M = s.M
+                if j >= 0:
+                    lp, lc = s.fmt.format(j), s.c.layers[j]
+                    sa, ffn = lc.sa, lc.ffn
+                    f1, f2, o = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.lin(lp + "attention.output.dense.weight")
+                    O.linear_dw(out.dfod, ffn.g, f2.dW, f2.db, M, flop_rows=ffn.rows)
+                    O.linear_dw(out.dz, ffn.a, f1.dW, f1.db, M, flop_rows=ffn.rows)
+                    O.linear_dw(out.daod, sa.ctx, o.dW, o.db, M, flop_rows=sa.rows)
+                if step > 0:
+                    sa1 = s.c.layers[j + 1].sa
+                    ql = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
+                    O.linear_dw(out.dqkv, sa1.x, ql.dW, ql.db, M, flop_rows=sa1.rows)
+                if j < 0:
+                    s.dx0 = out.dx0
+                s.prev = out
+            step += 1
+            if on_iter is not None and step >= 2:     # after launch k + 1 the top k blocks of every stack have all four weight gradients queued
+                on_iter(step - 1)
         return [s.dx0 for s in st]
 
     def encoders_bwd(self, ct, cp, plan, d_txt, dP_txt, d_pano, d_fused, dP_pano, on_iter=None):

@@ -36,6 +36,7 @@ SIGNATURES = {
                      vp, i32, i32, vp, i32, i32, vp, f32, u32, u32, vp, i32, i32, vp],
     "magic_ln_bwd_tail": [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
     "magic_ln_bwd_blocks": [i32, i32, i32],
+    "magic_rowbwd_attn_supported": [i32, i32, i32, i32, i32],
     "magic_colsum_add_v": [i32, vp, vp, vp, vp, vp, vp],
     "magic_smallk_ln_bwd_blocks": [i32, i32, i32],
     "magic_ln_pgrad": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
@@ -238,13 +239,17 @@ RBW_PTRS = ("dqkv_n", "WqkvT_n", "dao_n", "dfo_in", "dfod_in", "y2", "rstd2", "g
             "y1", "rstd1", "g1", "b1", "dg1", "db1", "WoT", "dfo", "dfod", "dz", "daod", "dao", "dctx")
 
 
+RBW_ATT_PTRS = ("qkv_a", "P_a", "o_a", "dctx_a", "dP_init", "dqkv_out")      # round 6: the attention backward of the block above inside the launch
+
+
 class RbwSeg(C.Structure):
     """mirror of `magic_rowbwd_seg` (include/magic_hip.h)"""
-    _fields_ = [("M", i32), ("kt", i32)] + [(n, vp) for n in RBW_PTRS] + [("site_out", u32), ("site_ao", u32)]
+    _fields_ = ([("M", i32), ("kt", i32)] + [(n, vp) for n in RBW_PTRS] + [("site_out", u32), ("site_ao", u32)] +
+                [("mode", i32), ("N", i32), ("ntile", i32), ("ldp", i32)] + [(n, vp) for n in RBW_ATT_PTRS] + [("site_attn", u32), ("pad_", u32)])
 
 
 class RbwParams(C.Structure):
-    _fields_ = [("seg", RbwSeg * 2), ("nseg", i32), ("blocks0", i32), ("p_hidden", f32), ("pad1", i32), ("seed", vp)]
+    _fields_ = [("seg", RbwSeg * 2), ("nseg", i32), ("blocks0", i32), ("p_hidden", f32), ("pad1", i32), ("seed", vp), ("p_attn", f32), ("scale", f32)]
 
 
 _ERR = {-1: "MAGIC_ERR_ARG", -2: "MAGIC_ERR_LAUNCH", -3: "MAGIC_ERR_UNSUPPORTED"}

@@ -992,18 +992,33 @@ def flush_rbw_parts():
         L.call("magic_colsum_add", int(chunk[0][1].numel()), n, C.addressof(parts), C.addressof(dsts), C.addressof(nb), L.stream())
 
 
-def rowbwd(segs, seed, p_hidden):
+def rowbwd_attn_ok(dtype, H, I, nh, N):
+    """may a rowbwd segment carry the attention backward of the block above (mode 1 / 2)?"""
+    return bool(RBW_ATTN and rowbwd_ok(dtype, H, I) and L.load().magic_rowbwd_attn_supported(L.dt(dtype), H, I, nh, N))
+
+
+# round 6: the attention backward of block j+1 inside the row-block launch of block j (csrc/encbwd.hip attn_tile_stage).  MAGIC_RBW_ATTN=0: the
+# round 2-5 structure (magic_rowbwd and magic_attn_bwd alternating, two launches per block).
+RBW_ATTN = os.environ.get("MAGIC_RBW_ATTN", "1") != "0"
+
+
+def rowbwd(segs, seed, p_hidden, p_attn=0.0, scale=0.125):
     """segs: 1 or 2 dicts with the fields of magic_rowbwd_seg (tensors) + M + flops: the per-token backward chain of one block per
-    segment (csrc/encbwd.hip)"""
+    segment (csrc/encbwd.hip); segments with `mode` 1 / 2 also run the attention backward of the block above (their N / ldp / qkv_a / P_a / o_a /
+    dctx_a / dP_init / dqkv_out / site_attn fields)"""
     _chk(1 <= len(segs) <= 2, "rowbwd segments")
     P = L.RbwParams()
     P.nseg, P.p_hidden, P.seed = len(segs), float(p_hidden), L.P(seed)
+    P.p_attn, P.scale = float(p_attn), float(scale)
+    att = any(int(sg.get("mode", 0)) for sg in segs)
     subst = {}
     if RBW_PARTIAL:
-        rows = int(L.load().magic_rowbwd_rows(sum(int(sg["M"]) for sg in segs)))
+        rows = 16 if att else int(L.load().magic_rowbwd_rows(sum(int(sg["M"]) for sg in segs)))
         P.pad1 = 1
         for i, sg in enumerate(segs):
             nblk = (int(sg["M"]) + rows - 1) // rows
+            if int(sg.get("mode", 0)):
+                nblk = (int(sg["M"]) // int(sg["N"])) * ((int(sg["N"]) + 15) // 16)
             for k in ("dg2", "db2", "dg1", "db1"):
                 dst = sg.get(k)
                 if dst is not None:
@@ -1016,6 +1031,11 @@ def rowbwd(segs, seed, p_hidden):
         for k in L.RBW_PTRS:
             setattr(S, k, L.P(subst.get((i, k), sg.get(k))))
         S.site_out, S.site_ao = int(sg.get("site_out", 0)), int(sg.get("site_ao", 0))
+        S.mode = int(sg.get("mode", 0))
+        if S.mode:
+            S.N, S.ldp, S.ntile, S.site_attn = int(sg["N"]), int(sg["ldp"]), (int(sg["N"]) + 15) // 16, int(sg.get("site_attn", 0))
+            for k in L.RBW_ATT_PTRS:
+                setattr(S, k, L.P(sg.get(k)))
         if FLOPS["enabled"]:
             FLOPS["total"] += sg["flops"]
             FLOPS["enc"] += sg["flops"]

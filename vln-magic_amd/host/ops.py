@@ -1039,7 +1039,8 @@ def rowbwd(segs, seed, p_hidden, p_attn=0.0, scale=0.125):
         if FLOPS["enabled"]:
             FLOPS["total"] += sg["flops"]
             FLOPS["enc"] += sg["flops"]
-    L.call("magic_rowbwd", L.dt(segs[0]["y2"].dtype), C.addressof(P), C.sizeof(P), L.stream())
+    any_t = next(segs[0][k] for k in ("y2", "qkv_a", "dao_n") if segs[0].get(k) is not None)      # (a mode-2 segment has no LayerNorm operands)
+    L.call("magic_rowbwd", L.dt(any_t.dtype), C.addressof(P), C.sizeof(P), L.stream())
 
 
 _XENC_OK = {}

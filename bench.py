@@ -894,7 +894,10 @@ def main():
                 "launch": a.mode if a.mode not in ("stream", "stream-graph") else f"{a.mode}/{a.ingest}/{a.workers}w" + (f"/{stream_step.captures} bucket graphs, {cap_at['end'] - cap_at.get(a.warmup, 0)} of them captured inside the timed steps" if stream_step is not None else ""),
                 "teacher_schedule": ({"split": "one batch ahead of the student, own graph on a side stream", "ahead": "one batch ahead of the student (fork/join inside the step graph)"}.get(a.teacher, "same batch, side stream") if a.mode == "graph" else "same batch, side stream"),
                 "config": {"workload": "MAGIC-S R2R pretrain (train_r2r_magic.py path): student H=128/2 heads/6+2+3 layers + frozen teacher H=256, "
-                                       "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip, student in train() mode",
+                                       "MAKD (txt/img/local/global/predict x emb/attn), tasks mlm:sap:cfp 1:1:1, AdamW+clip, student in train() mode"
+                                       + ("; arithmetic = bf16 storage as BASELINE config 2 names it, which is OUTSIDE the north star's |delta action logit| < 1e-3 against the "
+                                          "oracle (measured ~4e-3: 8 significand bits; `headline_mode_parity`) -- the SAME kernels on fp16 storage meet it and are timed beside "
+                                          "it (`parity_clean_mode`)" if a.dtype == "bf16" else ""),
                            "dropout": a.dropout,
                            "global_batch": a.batch * world, "per_gpu_batch": a.batch, "views": 36, "feat_dim": 768, "max_tokens": 80,
                            "parallelism": f"dp{world}", "samples_per_sec": round(a.batch * world * a.steps / dt, 1)},

@@ -128,7 +128,7 @@ class StreamStep:
                 from . import ops as O
                 O.encoder_start_gate(tr.gate)   # T_{i+1} starts once S_i's whole-encoder launch has its workgroups resident (trainer.capture_split)
             e.t_out = tr.teacher_forward(e.batch, task, e.plan)
-        e.cs = tr.capture_student((e.batch, task, e.plan), e.t_out, rw=self.rw)      # one graph; data parallel: three + the optimizer's
+        e.cs = tr.capture_student((e.batch, task, e.plan), e.t_out, rw=self.rw, rccl_in_graph=False)   # (the touched word-embedding rows change per replay)      # one graph; data parallel: three + the optimizer's
         e.out = e.cs.out
         e.fill = [(DYN_TERMS.index(t), fn) for t, fn in e.plan["dyn"]["fill"].items()]
         e.t_done, e.loaded = torch.cuda.Event(), torch.cuda.Event()

@@ -640,7 +640,7 @@ class PretrainStep:
         cs.t_next = t_next
         return cs
 
-    def capture_student(self, cur, t_cur, rw=None, keep=None):
+    def capture_student(self, cur, t_cur, rw=None, keep=None, rccl_in_graph=True):
         """the student's step on `cur` against the teacher outputs `t_cur` (static buffers a teacher graph fills): one graph holding the
         whole step on one GPU; under data parallelism three graphs cut where the gradient buckets are final + the optimizer's graph,
         replayed by `replay_student` with the RCCL calls between them"""
@@ -648,6 +648,24 @@ class PretrainStep:
         full = self.sync.world == 1 and not self.sync.force and not os.environ.get("MAGIC_FORCE_SPLIT_GRAPH")
         batch, task, plan = cur
         two = (not full) and self.sync.overlap and not os.environ.get("MAGIC_DDP_ONE_GRAPH")
+        # round 6: the bucket collectives INSIDE the step's graph (RCCL is graph-capturable): one graph, no cuts, no eager launches between replays -- the
+        # exchange stream forks off the capturing stream at every bucket boundary and joins it in front of the optimizer's launches.  For steps whose
+        # touched word-embedding rows are fixed at capture time (resident batches, or a dense table); streamed batches, whose row ids change per replay,
+        # keep the cut-graph form below (`rccl_in_graph=False`).  MAGIC_DDP_GRAPH_RCCL=0 selects the cut-graph form everywhere.
+        if two and rccl_in_graph and os.environ.get("MAGIC_DDP_GRAPH_RCCL", "1") != "0" and self.sync.stream is not None:
+            gS = torch.cuda.CUDAGraph()
+            touched = self._touched_rows(task, plan)
+            with self._graph_ctx(gS):
+                drawn = self.mkrw()
+                rw_ = drawn if rw is None else rw
+                self._zero_grad()
+                out = self.student(batch, task, compute_loss=True, teacher_outputs=t_cur, rw=rw_, plan=plan, inputs=t_cur["inputs"])
+                self.student.backward(on_bucket=lambda i, ctx: self.sync.reduce_bucket(i, touched if i == 2 else None))
+                self._opt_step(self.sync.finish())
+            cs = CapturedStep(gS, out, plan["traj_steps"], True, keep=keep if keep is not None else (cur, t_cur, rw, touched))
+            cs.graph2 = cs.graph3 = cs.graph_opt = None
+            cs.touched, cs.rccl_in_graph = touched, True
+            return cs
         gS = torch.cuda.CUDAGraph()
         gS2 = None
         with self._graph_ctx(gS):
@@ -695,6 +713,9 @@ class PretrainStep:
         change per replay; default: the captured batch's); between(): called after the last backward graph, before the exchange is
         awaited (replay_split launches the next teacher graph there)"""
         O.dw_guard()                                   # the graphs hold deterministic weight-gradient launches (shared workspace: ops.dw_guard)
+        if getattr(cs, "rccl_in_graph", False) and touched is not None and touched is not cs.touched:
+            raise ValueError("this step was captured with its bucket collectives (and its touched word-embedding rows) inside the graph: capture it with "
+                             "rccl_in_graph=False to pass per-replay row ids")
         cs.graph.replay()
         if getattr(cs, "graph2", None) is not None:
             self.sync.reduce_bucket(0)                 # exchange stream: after graph 1, under graphs 2 and 3

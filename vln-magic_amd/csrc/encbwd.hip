@@ -162,41 +162,49 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
   for (int e = 0; e < 8; ++e) zero8[e] = (Hh)0.0f;
   // the three small tiles: columns [16 NT, NK32) are contraction padding that no stage writes -- zero everything once
   for (int id = tid; id < 3 * 16 * AT_PS / 8; id += NWAVE * 64) *(h16x8<Hh>*)(sdS + id * 8) = zero8;
-  for (int h = 0; h < ENH; ++h) {
-    // ---- Q, K, dO of the sample (this head) -> LDS; rs_q = dO_q . O_q (+ seed term) from global rows
-    for (int id = tid; id < NK32 * 8; id += NWAVE * 64) {
-      const int r = id >> 3, c = (id & 7) * 8;
-      h16x8<Hh> vq = zero8, vk = zero8, vo = zero8;
+  // Every global operand of a head is REQUESTED before anything waits (a first version loaded, waited, stored, loaded ... through ~7 dependent L2
+  // round trips per head and took 40-70 us per launch where the separate attention backward took 12): the image rows and O rows of head h + 1 are in
+  // flight under head h's stages, the V fragments / P / seed values of a wave's stage-A jobs under the image stores and the first barrier.
+  constexpr int RIT = (AT_ROWS * 8 + NWAVE * 64 - 1) / (NWAVE * 64);       // 16-byte row chunks per thread and image (id = tid + it * 512: row id >> 3, chunk id & 7; rows >= NK32 skipped)
+  static_assert(RIT == 2, "image-row load mapping");
+  h16x8<Hh> rq[RIT], rk[RIT], ro[RIT], rO[RIT];         // Q, K, dO rows of the images; O rows (same (row, chunk) as dO: rs_q = dO_q . O_q needs no second dO load)
+  auto img_issue = [&](const int h) {
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      const int id = tid + it * NWAVE * 64, r = id >> 3, c = (id & 7) * 8;
+      rq[it] = zero8; rk[it] = zero8; ro[it] = zero8; rO[it] = zero8;
       if (r < N) {
         const Hh* base = sg.qkv_a + (row0 + r) * (3 * EH) + h * EHD + c;
-        vq = *(const h16x8<Hh>*)base;
-        vk = *(const h16x8<Hh>*)(base + EH);
-        vo = *(const h16x8<Hh>*)(sg.dctx_a + (row0 + r) * EH + h * EHD + c);
+        rq[it] = *(const h16x8<Hh>*)base;
+        rk[it] = *(const h16x8<Hh>*)(base + EH);
+        ro[it] = *(const h16x8<Hh>*)(sg.dctx_a + (row0 + r) * EH + h * EHD + c);
+        rO[it] = *(const h16x8<Hh>*)(sg.o_a + (row0 + r) * EH + h * EHD + c);
       }
-      *(h16x8<Hh>*)(sQ + r * AT_DS + c) = vq;
-      *(h16x8<Hh>*)(sK + r * AT_DS + c) = vk;
-      *(h16x8<Hh>*)(sdO + r * AT_DS + c) = vo;
     }
-    for (int q = tid >> 3; q < NK32; q += NWAVE * 8) {
-      const int l8 = tid & 7;
+  };
+  auto img_store = [&](const int h) {                    // images + rs_q (8 lanes per row: the lanes of one row are an aligned group of 8)
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      const int id = tid + it * NWAVE * 64, r = id >> 3, c = (id & 7) * 8;
+      if (r < NK32) {
+        *(h16x8<Hh>*)(sQ + r * AT_DS + c) = rq[it];
+        *(h16x8<Hh>*)(sK + r * AT_DS + c) = rk[it];
+        *(h16x8<Hh>*)(sdO + r * AT_DS + c) = ro[it];
+      }
       float s = 0.f;
-      if (q < N) {
-        const long long o_ = (row0 + q) * EH + h * EHD + l8 * 8;
-        const h16x8<Hh> a = *(const h16x8<Hh>*)(sg.dctx_a + o_), bb = *(const h16x8<Hh>*)(sg.o_a + o_);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += to_f(a[e]) * to_f(bb[e]);
-        if (sg.dP_init) {                   // + sum_k (P o mask)[q, k] seed[q, k]: the distillation gradient enters dP before the mask
-          const long long prow = ((long long)b * ENH + h) * N + q;
-          for (int c8 = l8 * 8; c8 < ldp; c8 += 64) {
-            const h16x8<Hh> pv = *(const h16x8<Hh>*)(sg.P_a + prow * ldp + c8);
-            const f32x4 i0 = *(const f32x4*)(sg.dP_init + prow * ldp + c8), i1 = *(const f32x4*)(sg.dP_init + prow * ldp + c8 + 4);
+      for (int e = 0; e < 8; ++e) s += to_f(ro[it][e]) * to_f(rO[it][e]);
+      if (sg.dP_init && r < N) {            // + sum_k (P o mask)[q, k] seed[q, k]: the distillation gradient enters dP before the mask (top block only)
+        const long long prow = ((long long)b * ENH + h) * N + r;
+        for (int c8 = (id & 7) * 8; c8 < ldp; c8 += 64) {
+          const h16x8<Hh> pv = *(const h16x8<Hh>*)(sg.P_a + prow * ldp + c8);
+          const f32x4 i0 = *(const f32x4*)(sg.dP_init + prow * ldp + c8), i1 = *(const f32x4*)(sg.dP_init + prow * ldp + c8 + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int key = c8 + e;
-              if (key < N) {
-                const float m = ds.on ? drop_mul(ds, (unsigned)(prow * N + key)) : 1.f;
-                s += to_f(pv[e]) * m * (e < 4 ? i0[e & 3] : i1[e & 3]);
-              }
+          for (int e = 0; e < 8; ++e) {
+            const int key = c8 + e;
+            if (key < N) {
+              const float m = ds.on ? drop_mul(ds, (unsigned)(prow * N + key)) : 1.f;
+              s += to_f(pv[e]) * m * (e < 4 ? i0[e & 3] : i1[e & 3]);
             }
           }
         }
@@ -204,53 +212,81 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
       s += dpp_mov<DPP_QUAD_XOR1>(s);
       s += dpp_mov<DPP_QUAD_XOR2>(s);
       s += dpp_mov<DPP_ROW_HALF_MIRROR>(s);
-      if (l8 == 0) sRs[q] = s;
+      if ((id & 7) == 0 && r < NK32) sRs[r] = s;
     }
-    __syncthreads();
-    // ---- stage A: dP^T tiles (rows = keys, columns = queries: a lane owns four consecutive keys of one query), dS into the role's image
-    for (int job = w; job < 2 * NT; job += NWAVE) {
+  };
+  // stage-A jobs of this wave: job = w + 8 jj < 2 NT; jobs [0, NT): the tile's rows as QUERIES against key tile job; [NT, 2 NT): as KEYS against query tile job - NT
+  constexpr int AJ = (2 * (AT_ROWS / 16) + NWAVE - 1) / NWAVE;
+  h16x8<Hh> av[AJ][EHD / 32];
+  v4 ap[AJ];
+  f32x4 ai[AJ];
+  auto vp_issue = [&](const int h) {
+#pragma unroll
+    for (int jj = 0; jj < AJ; ++jj) {
+      const int job = w + NWAVE * jj;
       const bool asq = job < NT;
       const int t = asq ? job : job - NT;
       const int ktile = asq ? t : ti, qtile = asq ? ti : t;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int vkey = ktile * 16 + c16;
+      const int vkey = ktile * 16 + c16, q = qtile * 16 + c16, key0 = ktile * 16 + 4 * g;
+      const long long prow = ((long long)b * ENH + h) * N + q;
 #pragma unroll
       for (int ks = 0; ks < EHD / 32; ++ks) {
-        h16x8<Hh> av = zero8;
-        if (vkey < N) av = *(const h16x8<Hh>*)(sg.qkv_a + (row0 + vkey) * (3 * EH) + 2 * EH + h * EHD + ks * 32 + 8 * g);
-        acc = emma(av, lfrag(sdO, AT_DS, qtile * 16, ks * 32, lane), acc);
+        av[jj][ks] = zero8;
+        if (job < 2 * NT && vkey < N) av[jj][ks] = *(const h16x8<Hh>*)(sg.qkv_a + (row0 + vkey) * (3 * EH) + 2 * EH + h * EHD + ks * 32 + 8 * g);
       }
-      const int q = qtile * 16 + c16, key0 = ktile * 16 + 4 * g;
-      const bool qok = q < N;
-      const long long prow = ((long long)b * ENH + h) * N + q;
-      v4 p4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p4[r] = (Hh)0.0f;
-      if (qok && key0 < ldp) p4 = *(const v4*)(sg.P_a + prow * ldp + key0);
-      f32x4 init = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (sg.dP_init && qok && key0 < N) init = *(const f32x4*)(sg.dP_init + prow * ldp + key0);
-      const float rsq = sRs[q];
-      v4 o4, pm4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + r;
-        const bool ok = qok && key < N;
-        float d = acc[r] + (ok ? init[r] : 0.f);
-        const float pp = to_f(p4[r]);
-        float pm = pp;
-        if (ds.on) {
-          const float m = ok ? drop_mul(ds, (unsigned)(prow * N + key)) : 0.f;
-          d *= m; pm = pp * m;
-        }
-        o4[r] = from_f<Hh>(pp * (d - rsq) * p.scale);
-        pm4[r] = from_f<Hh>(pm);
-      }
-      if (asq) *(v4*)(sdS + c16 * AT_PS + key0) = o4;
-      else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { sdST[(4 * g + r) * AT_PS + q] = o4[r]; sPT[(4 * g + r) * AT_PS + q] = pm4[r]; }
+      for (int r = 0; r < 4; ++r) ap[jj][r] = (Hh)0.0f;
+      ai[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (job < 2 * NT && q < N) {
+        if (key0 < ldp) ap[jj] = *(const v4*)(sg.P_a + prow * ldp + key0);
+        if (sg.dP_init && key0 < N) ai[jj] = *(const f32x4*)(sg.dP_init + prow * ldp + key0);
       }
     }
+  };
+  img_issue(0);
+  vp_issue(0);
+  for (int h = 0; h < ENH; ++h) {
+    img_store(h);
+    __syncthreads();
+    if (h + 1 < ENH) img_issue(h + 1);                   // in flight under stages A and B of this head
+    // ---- stage A: dP^T tiles (rows = keys, columns = queries: a lane owns four consecutive keys of one query), dS into the role's image
+#pragma unroll
+    for (int jj = 0; jj < AJ; ++jj) {
+      const int job = w + NWAVE * jj;
+      if (job < 2 * NT) {
+        const bool asq = job < NT;
+        const int t = asq ? job : job - NT;
+        const int ktile = asq ? t : ti, qtile = asq ? ti : t;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < EHD / 32; ++ks) acc = emma(av[jj][ks], lfrag(sdO, AT_DS, qtile * 16, ks * 32, lane), acc);
+        const int q = qtile * 16 + c16, key0 = ktile * 16 + 4 * g;
+        const bool qok = q < N;
+        const long long prow = ((long long)b * ENH + h) * N + q;
+        const float rsq = sRs[q];
+        v4 o4, pm4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + r;
+          const bool ok = qok && key < N;
+          float d = acc[r] + (ok ? ai[jj][r] : 0.f);
+          const float pp = to_f(ap[jj][r]);
+          float pm = pp;
+          if (ds.on) {
+            const float m = ok ? drop_mul(ds, (unsigned)(prow * N + key)) : 0.f;
+            d *= m; pm = pp * m;
+          }
+          o4[r] = from_f<Hh>(pp * (d - rsq) * p.scale);
+          pm4[r] = from_f<Hh>(pm);
+        }
+        if (asq) *(v4*)(sdS + c16 * AT_PS + key0) = o4;
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { sdST[(4 * g + r) * AT_PS + q] = o4[r]; sPT[(4 * g + r) * AT_PS + q] = pm4[r]; }
+        }
+      }
+    }
+    if (h + 1 < ENH) vp_issue(h + 1);                    // in flight under stage B
     __syncthreads();
     // ---- stage B: dQ_R = dS_R K, dK_R = dS[:, R]^T Q, dV_R = (P o mask)[:, R]^T dO: twelve 16 x 16 output tiles over the waves
     for (int job = w; job < 12; job += NWAVE) {

@@ -423,13 +423,20 @@ def rccl_smoke_leg(student, batch_size, dev):
             ref = store.grad.clone()
             sync = GradSync(store, sparse_rows_cap=batch_size * MAX_TOKENS)
             sync.stream = torch.cuda.Stream()
-            for i in range(3):
-                sync._on_side(lambda i=i: sync._ranges(sync.buckets[i]))
             ids = torch.unique(torch.randint(0, 50265, (batch_size * MAX_TOKENS,), device=dev))
-            sync._on_side(lambda: sync._sparse_rows(ids))
-            sync.join()
-            torch.cuda.synchronize()
-            out["identity_at_world_1"] = bool(torch.equal(store.grad, ref))
+            from magic_amd.host import rccl as _rccl
+            direct = _rccl.make(dev)            # round 6: the exchange's own communicator through RCCL's C ABI (host/rccl.py), self-tested
+            out["direct_rccl_c_abi"] = direct is not None
+            same = True
+            for comm in ([None, direct] if direct is not None else [None]):      # torch.distributed's calls, then the direct ones GradSync uses by default
+                sync.rccl = comm
+                for i in range(3):
+                    sync._on_side(lambda i=i: sync._ranges(sync.buckets[i]))
+                sync._on_side(lambda: sync._sparse_rows(ids))
+                sync.join()
+                torch.cuda.synchronize()
+                same = same and bool(torch.equal(store.grad, ref))
+            out["identity_at_world_1"] = same
             out["collectives"] = ["all_reduce fp32 x 3 buckets (chunked)", "all_gather_into_tensor int64 ids", "all_gather_into_tensor fp32 rows"]
             out["bucket_bytes"] = [int(sum(hi - lo for lo, hi in b) * 4) for b in sync.buckets]
             out["ok"] = out["identity_at_world_1"]

@@ -125,6 +125,12 @@ __device__ __forceinline__ void ln_bwd_rows(f32x4 (&acc)[NRT], const Hh* sY, con
     }
 }
 
+#ifdef RBW_TIMING
+__device__ long long rbw_ticks[32];            // wall_clock64 (100 MHz) marks of workgroup 0 (profiles/micro/rowbwd_timing.hip)
+#define RBW_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) rbw_ticks[i] = wall_clock64(); } while (0)
+#else
+#define RBW_MARK(i)
+#endif
 // ---- round 6: attention backward per 16-row tile --------------------------------------------------------------------------------------------
 // The per-token chain of block j and the attention backward of block j+1 used to alternate as two launches per block (magic_rowbwd, magic_attn_bwd:
 // one workgroup per (sample, head) -- 96 workgroups for the text stack) because the attention backward sums over queries.  A 16-row tile of ONE
@@ -168,29 +174,44 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
   constexpr int RIT = (AT_ROWS * 8 + NWAVE * 64 - 1) / (NWAVE * 64);       // 16-byte row chunks per thread and image (id = tid + it * 512: row id >> 3, chunk id & 7; rows >= NK32 skipped)
   static_assert(RIT == 2, "image-row load mapping");
   h16x8<Hh> rq[RIT], rk[RIT], ro[RIT], rO[RIT];         // Q, K, dO rows of the images; O rows (same (row, chunk) as dO: rs_q = dO_q . O_q needs no second dO load)
-  auto img_issue = [&](const int h) {
+  auto do_issue = [&](const int h) {                     // dO and O rows first: stage A needs only them (and the wave's V / P / seed values)
 #pragma unroll
     for (int it = 0; it < RIT; ++it) {
       const int id = tid + it * NWAVE * 64, r = id >> 3, c = (id & 7) * 8;
-      rq[it] = zero8; rk[it] = zero8; ro[it] = zero8; rO[it] = zero8;
+      ro[it] = zero8; rO[it] = zero8;
       if (r < N) {
-        const Hh* base = sg.qkv_a + (row0 + r) * (3 * EH) + h * EHD + c;
-        rq[it] = *(const h16x8<Hh>*)base;
-        rk[it] = *(const h16x8<Hh>*)(base + EH);
         ro[it] = *(const h16x8<Hh>*)(sg.dctx_a + (row0 + r) * EH + h * EHD + c);
         rO[it] = *(const h16x8<Hh>*)(sg.o_a + (row0 + r) * EH + h * EHD + c);
       }
     }
   };
-  auto img_store = [&](const int h) {                    // images + rs_q (8 lanes per row: the lanes of one row are an aligned group of 8)
+  auto qk_issue = [&](const int h) {                     // Q and K rows: operands of stage B only
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      const int id = tid + it * NWAVE * 64, r = id >> 3, c = (id & 7) * 8;
+      rq[it] = zero8; rk[it] = zero8;
+      if (r < N) {
+        const Hh* base = sg.qkv_a + (row0 + r) * (3 * EH) + h * EHD + c;
+        rq[it] = *(const h16x8<Hh>*)base;
+        rk[it] = *(const h16x8<Hh>*)(base + EH);
+      }
+    }
+  };
+  auto qk_store = [&]() {
 #pragma unroll
     for (int it = 0; it < RIT; ++it) {
       const int id = tid + it * NWAVE * 64, r = id >> 3, c = (id & 7) * 8;
       if (r < NK32) {
         *(h16x8<Hh>*)(sQ + r * AT_DS + c) = rq[it];
         *(h16x8<Hh>*)(sK + r * AT_DS + c) = rk[it];
-        *(h16x8<Hh>*)(sdO + r * AT_DS + c) = ro[it];
       }
+    }
+  };
+  auto do_store = [&](const int h) {                     // dO image + rs_q (8 lanes per row: the lanes of one row are an aligned group of 8)
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      const int id = tid + it * NWAVE * 64, r = id >> 3, c = (id & 7) * 8;
+      if (r < NK32) *(h16x8<Hh>*)(sdO + r * AT_DS + c) = ro[it];
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += to_f(ro[it][e]) * to_f(rO[it][e]);
@@ -243,12 +264,14 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
       }
     }
   };
-  img_issue(0);
+  RBW_MARK(16);
+  do_issue(0);
   vp_issue(0);
+  qk_issue(0);
   for (int h = 0; h < ENH; ++h) {
-    img_store(h);
+    do_store(h);
     __syncthreads();
-    if (h + 1 < ENH) img_issue(h + 1);                   // in flight under stages A and B of this head
+    RBW_MARK(17 + 3 * h);
     // ---- stage A: dP^T tiles (rows = keys, columns = queries: a lane owns four consecutive keys of one query), dS into the role's image
 #pragma unroll
     for (int jj = 0; jj < AJ; ++jj) {
@@ -286,8 +309,10 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
         }
       }
     }
-    if (h + 1 < ENH) vp_issue(h + 1);                    // in flight under stage B
+    qk_store();                                          // (arrived under stage A)
+    if (h + 1 < ENH) { do_issue(h + 1); vp_issue(h + 1); qk_issue(h + 1); }      // the next head's operands: in flight under stage B
     __syncthreads();
+    RBW_MARK(18 + 3 * h);
     // ---- stage B: dQ_R = dS_R K, dK_R = dS[:, R]^T Q, dV_R = (P o mask)[:, R]^T dO: twelve 16 x 16 output tiles over the waves
     for (int job = w; job < 12; job += NWAVE) {
       const int prod = job >> 2, jd = job & 3;
@@ -300,25 +325,27 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
       for (int r = 0; r < 4; ++r) sDq[(4 * g + r) * QS + col] = from_f<Hh>(acc[r]);
     }
     __syncthreads();
+    RBW_MARK(19 + 3 * h);
   }
   copy_out(sDq, QS, sg.dqkv_out + (row0 + ti * 16) * (3 * EH), 3 * EH, nv, 3 * EH, tid);
+  RBW_MARK(23);
 }
 
 // NRT = row tiles of 16 per workgroup.  2 (32 rows): two workgroups per CU, 128 registers per lane, weight fragments one chunk of four
 // k-steps ahead of their use.  4 (64 rows): one workgroup per CU, 256 registers, a whole product's fragments ahead -- and half the
 // weight bytes streamed from L2 per row (every workgroup streams all 393 KB of the block's matrices).
-#ifdef RBW_TIMING
-__device__ long long rbw_ticks[16];            // wall_clock64 (100 MHz) marks of workgroup 0 (profiles/micro/rowbwd_timing.hip)
-#define RBW_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) rbw_ticks[i] = wall_clock64(); } while (0)
-#else
-#define RBW_MARK(i)
-#endif
 template <int NRT, typename Hh, bool ATT = false>
 __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned char* rb_smem) {
   constexpr int RB_ROWS = NRT * 16;
   constexpr bool DEEP = NRT >= 4;
   static_assert(!ATT || NRT == 1, "the attention stage works on 16-row tiles of one sample");
   int blk = blockIdx.x, sidx = 0;
+  if (ATT) {
+    // XCD-aware order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, and the 5 tiles of a sample each read the sample's
+    // whole Q / K / V / dO / O -- with consecutive LOGICAL ids on one XCD they meet in one L2 instead of fetching the rows into five of them (speed only)
+    const int G = gridDim.x, x = blk & 7, i = blk >> 3, q8 = G >> 3, r8 = G & 7;
+    blk = x * q8 + min(x, r8) + i;
+  }
   if (blk >= p.blocks0) { blk -= p.blocks0; sidx = 1; }
   const RbwSegT<Hh>& sg = p.seg[sidx];
   const int mode = ATT ? sg.mode : 0;

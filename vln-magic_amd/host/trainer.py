@@ -238,6 +238,12 @@ class GradSync:
             from . import lanes
             self.stream = lanes.beside([torch.cuda.current_stream(store.device)], device=store.device)     # the exchange runs UNDER the backward
         self.overlap = (not os.environ.get("MAGIC_DDP_NO_OVERLAP")) if overlap is None else overlap
+        # round 6: RCCL through its C ABI on the exchange stream (host/rccl.py) -- capturable inside the step's graph, no per-call bookkeeping; None:
+        # torch.distributed's calls (gloo rehearsals, MAGIC_RCCL_DIRECT=0, or a communicator that failed its self-test)
+        self.rccl = None
+        if self.stream is not None:
+            from . import rccl as _rccl
+            self.rccl = _rccl.make(store.device)
         g0d, g0n = store.first_offset(LATE_PREFIXES, True), store.first_offset(LATE_PREFIXES, False)
         nd, tot = store.n_decay, store.total
         first, rest = [(g0d, nd), (g0n, tot)], [(0, g0d), (nd, g0n)]
@@ -275,6 +281,12 @@ class GradSync:
     # ---- primitives ------------------------------------------------------------------------------------------
     def _ranges(self, ranges):
         g = self.store.grad
+        if self.rccl is not None:             # one group launch for all the chunks of the bucket
+            with self.rccl.group():
+                for lo, hi in ranges:
+                    for a in range(lo, hi, self.chunk):
+                        self.rccl.all_reduce_(g[a:min(hi, a + self.chunk)])
+            return
         for lo, hi in ranges:
             for a in range(lo, hi, self.chunk):
                 dist.all_reduce(g[a:min(hi, a + self.chunk)])
@@ -309,8 +321,13 @@ class GradSync:
         rows[k:] = 0                                              # padding slots point at row 0 and carry zeros (x + 0 in any order)
         all_ids = torch.empty(self.world * cap, dtype=torch.int64, device=tab.device)
         all_rows = torch.empty(self.world * cap, H, dtype=tab.dtype, device=tab.device)
-        dist.all_gather_into_tensor(all_ids, ids)
-        dist.all_gather_into_tensor(all_rows, rows)
+        if self.rccl is not None:             # both gathers as one group launch
+            with self.rccl.group():
+                self.rccl.all_gather(all_ids, ids)
+                self.rccl.all_gather(all_rows.view(-1), rows.view(-1))
+        else:
+            dist.all_gather_into_tensor(all_ids, ids)
+            dist.all_gather_into_tensor(all_rows, rows)
         tab.index_fill_(0, row_ids, 0)                            # own contribution comes back through all_rows, in its rank's turn
         for r in range(self.world):
             tab.index_add_(0, all_ids[r * cap:(r + 1) * cap], all_rows[r * cap:(r + 1) * cap])
@@ -652,7 +669,7 @@ class PretrainStep:
         # exchange stream forks off the capturing stream at every bucket boundary and joins it in front of the optimizer's launches.  For steps whose
         # touched word-embedding rows are fixed at capture time (resident batches, or a dense table); streamed batches, whose row ids change per replay,
         # keep the cut-graph form below (`rccl_in_graph=False`).  MAGIC_DDP_GRAPH_RCCL=0 selects the cut-graph form everywhere.
-        if two and rccl_in_graph and os.environ.get("MAGIC_DDP_GRAPH_RCCL", "1") != "0" and self.sync.stream is not None:
+        if two and rccl_in_graph and os.environ.get("MAGIC_DDP_GRAPH_RCCL", "1") != "0" and self.sync.stream is not None and self.sync.rccl is not None:
             gS = torch.cuda.CUDAGraph()
             touched = self._touched_rows(task, plan)
             with self._graph_ctx(gS):

@@ -343,8 +343,10 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
   if (ATT) {
     // XCD-aware order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, and the 5 tiles of a sample each read the sample's
     // whole Q / K / V / dO / O -- with consecutive LOGICAL ids on one XCD they meet in one L2 instead of fetching the rows into five of them (speed only)
-    const int G = gridDim.x, x = blk & 7, i = blk >> 3, q8 = G >> 3, r8 = G & 7;
-    blk = x * q8 + min(x, r8) + i;
+    if (!(p.seg[0].pad_ & 1u)) {            // (bit 0 of seg[0].pad_: MAGIC_RBW_XCD=0, the plain order, for the A/B)
+      const int G = gridDim.x, x = blk & 7, i = blk >> 3, q8 = G >> 3, r8 = G & 7;
+      blk = x * q8 + min(x, r8) + i;
+    }
   }
   if (blk >= p.blocks0) { blk -= p.blocks0; sidx = 1; }
   const RbwSegT<Hh>& sg = p.seg[sidx];
@@ -675,6 +677,9 @@ extern "C" int magic_rowbwd(int dtype, const void* params, int nbytes, void* str
     blocks += nb;
   }
   if (att) {
+    static int xcd_off = -1;
+    if (xcd_off < 0) { const char* e = getenv("MAGIC_RBW_XCD"); xcd_off = (e && atoi(e) == 0) ? 1 : 0; }
+    p.seg[0].pad_ = xcd_off ? 1u : 0u;
     const size_t rest = rbw_lds_bytes(16) - (size_t)16 * GS * 2;
     const size_t shm = (size_t)16 * GS * 2 + (attn_stage_lds() > rest ? attn_stage_lds() : rest);
     static bool attr_a = false;

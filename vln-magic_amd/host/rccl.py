@@ -18,7 +18,7 @@ NCCL_FLOAT32, NCCL_INT64, NCCL_SUM = 7, 4, 0          # rccl.h: ncclDataType_t /
 
 
 class _UniqueId(C.Structure):
-    _fields_ = [("internal", C.c_char * 128)]          # rccl.h NCCL_UNIQUE_ID_BYTES
+    _fields_ = [("internal", C.c_ubyte * 128)]         # rccl.h NCCL_UNIQUE_ID_BYTES (c_ubyte: a c_char array field reads back truncated at the first NUL)
 
 
 class RcclError(RuntimeError):
@@ -70,7 +70,7 @@ class RcclComm:
             _chk(l.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
         # the 128 id bytes travel through the group the launcher's init built (device tensor under `nccl`, host tensor under `gloo`)
         on_dev = dist.get_backend() == "nccl"
-        t = torch.frombuffer(bytearray(bytes(uid.internal) if self.rank == 0 else bytes(128)), dtype=torch.uint8).clone()
+        t = torch.frombuffer(bytearray(C.string_at(C.byref(uid), 128) if self.rank == 0 else bytes(128)), dtype=torch.uint8).clone()
         t = t.to(self.dev) if on_dev else t
         if self.world > 1:
             dist.broadcast(t, src=0)

@@ -174,44 +174,29 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
   constexpr int RIT = (AT_ROWS * 8 + NWAVE * 64 - 1) / (NWAVE * 64);       // 16-byte row chunks per thread and image (id = tid + it * 512: row id >> 3, chunk id & 7; rows >= NK32 skipped)
   static_assert(RIT == 2, "image-row load mapping");
   h16x8<Hh> rq[RIT], rk[RIT], ro[RIT], rO[RIT];         // Q, K, dO rows of the images; O rows (same (row, chunk) as dO: rs_q = dO_q . O_q needs no second dO load)
-  auto do_issue = [&](const int h) {                     // dO and O rows first: stage A needs only them (and the wave's V / P / seed values)
+  auto img_issue = [&](const int h) {
 #pragma unroll
     for (int it = 0; it < RIT; ++it) {
       const int id = tid + it * NWAVE * 64, r = id >> 3, c = (id & 7) * 8;
-      ro[it] = zero8; rO[it] = zero8;
+      rq[it] = zero8; rk[it] = zero8; ro[it] = zero8; rO[it] = zero8;
       if (r < N) {
+        const Hh* base = sg.qkv_a + (row0 + r) * (3 * EH) + h * EHD + c;
+        rq[it] = *(const h16x8<Hh>*)base;
+        rk[it] = *(const h16x8<Hh>*)(base + EH);
         ro[it] = *(const h16x8<Hh>*)(sg.dctx_a + (row0 + r) * EH + h * EHD + c);
         rO[it] = *(const h16x8<Hh>*)(sg.o_a + (row0 + r) * EH + h * EHD + c);
       }
     }
   };
-  auto qk_issue = [&](const int h) {                     // Q and K rows: operands of stage B only
-#pragma unroll
-    for (int it = 0; it < RIT; ++it) {
-      const int id = tid + it * NWAVE * 64, r = id >> 3, c = (id & 7) * 8;
-      rq[it] = zero8; rk[it] = zero8;
-      if (r < N) {
-        const Hh* base = sg.qkv_a + (row0 + r) * (3 * EH) + h * EHD + c;
-        rq[it] = *(const h16x8<Hh>*)base;
-        rk[it] = *(const h16x8<Hh>*)(base + EH);
-      }
-    }
-  };
-  auto qk_store = [&]() {
+  auto img_store = [&](const int h) {                    // images + rs_q (8 lanes per row: the lanes of one row are an aligned group of 8)
 #pragma unroll
     for (int it = 0; it < RIT; ++it) {
       const int id = tid + it * NWAVE * 64, r = id >> 3, c = (id & 7) * 8;
       if (r < NK32) {
         *(h16x8<Hh>*)(sQ + r * AT_DS + c) = rq[it];
         *(h16x8<Hh>*)(sK + r * AT_DS + c) = rk[it];
+        *(h16x8<Hh>*)(sdO + r * AT_DS + c) = ro[it];
       }
-    }
-  };
-  auto do_store = [&](const int h) {                     // dO image + rs_q (8 lanes per row: the lanes of one row are an aligned group of 8)
-#pragma unroll
-    for (int it = 0; it < RIT; ++it) {
-      const int id = tid + it * NWAVE * 64, r = id >> 3, c = (id & 7) * 8;
-      if (r < NK32) *(h16x8<Hh>*)(sdO + r * AT_DS + c) = ro[it];
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += to_f(ro[it][e]) * to_f(rO[it][e]);
@@ -265,13 +250,13 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
     }
   };
   RBW_MARK(16);
-  do_issue(0);
+  img_issue(0);
   vp_issue(0);
-  qk_issue(0);
   for (int h = 0; h < ENH; ++h) {
-    do_store(h);
+    img_store(h);
     __syncthreads();
     RBW_MARK(17 + 3 * h);
+    if (h + 1 < ENH) img_issue(h + 1);                   // in flight under stages A and B of this head
     // ---- stage A: dP^T tiles (rows = keys, columns = queries: a lane owns four consecutive keys of one query), dS into the role's image
 #pragma unroll
     for (int jj = 0; jj < AJ; ++jj) {
@@ -309,8 +294,7 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
         }
       }
     }
-    qk_store();                                          // (arrived under stage A)
-    if (h + 1 < ENH) { do_issue(h + 1); vp_issue(h + 1); qk_issue(h + 1); }      // the next head's operands: in flight under stage B
+    if (h + 1 < ENH) vp_issue(h + 1);                    // in flight under stage B
     __syncthreads();
     RBW_MARK(18 + 3 * h);
     // ---- stage B: dQ_R = dS_R K, dK_R = dS[:, R]^T Q, dV_R = (P o mask)[:, R]^T dO: twelve 16 x 16 output tiles over the waves
@@ -341,9 +325,9 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
   static_assert(!ATT || NRT == 1, "the attention stage works on 16-row tiles of one sample");
   int blk = blockIdx.x, sidx = 0;
   if (ATT) {
-    // XCD-aware order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, and the 5 tiles of a sample each read the sample's
-    // whole Q / K / V / dO / O -- with consecutive LOGICAL ids on one XCD they meet in one L2 instead of fetching the rows into five of them (speed only)
-    if (!(p.seg[0].pad_ & 1u)) {            // (bit 0 of seg[0].pad_: MAGIC_RBW_XCD=0, the plain order, for the A/B)
+    // XCD-aware order (an experiment, off): the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, and the 5 tiles of a sample each
+    // read the sample's whole Q / K / V / dO / O -- with consecutive LOGICAL ids on one XCD they would meet in one L2.  Measured SLOWER in the step.
+    if (p.seg[0].pad_ & 1u) {               // bit 0 of seg[0].pad_: MAGIC_RBW_XCD=1.  OFF by default: measured 1.507 vs 1.458 ms/step on one box (profiles/micro/r06_ab_rbw_xcd.txt)
       const int G = gridDim.x, x = blk & 7, i = blk >> 3, q8 = G >> 3, r8 = G & 7;
       blk = x * q8 + min(x, r8) + i;
     }
@@ -678,7 +662,7 @@ extern "C" int magic_rowbwd(int dtype, const void* params, int nbytes, void* str
   }
   if (att) {
     static int xcd_off = -1;
-    if (xcd_off < 0) { const char* e = getenv("MAGIC_RBW_XCD"); xcd_off = (e && atoi(e) == 0) ? 1 : 0; }
+    if (xcd_off < 0) { const char* e = getenv("MAGIC_RBW_XCD"); xcd_off = (e && atoi(e) == 1) ? 1 : 0; }      // (1 = the XCD-aware order ON)
     p.seg[0].pad_ = xcd_off ? 1u : 0u;
     const size_t rest = rbw_lds_bytes(16) - (size_t)16 * GS * 2;
     const size_t shm = (size_t)16 * GS * 2 + (attn_stage_lds() > rest ? attn_stage_lds() : rest);

@@ -794,6 +794,7 @@ class MagicNet:
         p = self.p
         dt, dp = self.self_stacks_bwd([(ct, p + "lang_encoder.layer.{}.", d_txt, dP_txt),
                                        (cp, p + "img_embeddings.pano_encoder.layer.{}.", d_pano, dP_pano)], on_iter=on_iter)
+        O.join_dw_early()         # (an early weight-gradient flush may hold the tied decoder's dW: the embedding backward adds into the same table)
         ll = self.lin(p + "img_embeddings.loc_linear.weight")
         if O.embed_in_bwd_ok(self.H, ll.K):          # both embedding backwards -- three LayerNorm backwards of the panorama stage + the text one -- in ONE launch
             return self._embeds_bwd(ct, cp, plan, dt, dp)

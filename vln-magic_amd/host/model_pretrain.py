@@ -712,17 +712,26 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             # bucket 0's weight gradients are still QUEUED at this point (phase 1 and the forward's distillation heads defer them):
             # they must be on the stream before the hook makes the exchange stream wait on it, or RCCL reduces the range while the
             # grouped dW kernels still add into it (same order as trainer.capture_split: phase 1; flush; cut)
-            O.flush_dw(keep_active=True)
+            # round 6: on the weight-gradient stream when there is one (ops.flush_dw_early) -- the bucket's dW launch and, behind it, its exchange
+            # (GradSync._on_side waits for that stream too) then run beside the rest of the backward; the main stream never stops for either
+            early = self.device_.type == "cuda" and O.flush_dw_early(self.device_)
+            if not early:
+                O.flush_dw(keep_active=True)
             O.join_side()
             on_bucket(0, c)
 
             def cut():                      # the top MID_CUT blocks of the text / panorama stacks are done: their slice is final once flushed
-                O.flush_dw(keep_active=True)
+                if not (self.device_.type == "cuda" and O.flush_dw_early(self.device_)):
+                    O.flush_dw(keep_active=True)
                 O.join_side()
                 on_bucket(1, c)
             self.backward_phase2(on_cut=cut)
             on_bucket(2, c)
         else:
+            # no exchange to cut for: the weight gradients phase 1 queued (heads, cross-modal encoders, distillation projections) go out NOW on the
+            # weight-gradient stream and run under phase 2's latency-bound chain (ops.flush_dw_early)
+            if self.device_.type == "cuda":
+                O.flush_dw_early(self.device_)
             self.backward_phase2()
 
     @torch.no_grad()

@@ -234,7 +234,38 @@ def join_dw_stream():
                 _DW_PENDING.discard(key)
 
 
+# round 6: an EARLY flush of the weight gradients queued so far (the heads' and the cross-modal encoders', at the boundary between the two phases of the
+# pretraining backward) on the device's weight-gradient stream: the chip-filling grouped launch then runs UNDER the text / panorama stacks' latency-
+# bound row-block chain (240 workgroups on 256 CUs at two per CU: half the chip idles there) instead of in one exposed 133 us launch at the end of the
+# backward.  The flushed operands (and the partial-row buffers of the column sums) stay alive until `join_dw_early`, which every later flush and the
+# embedding backward (whose table-row atomics meet the tied decoder's dW in the word-embedding gradient) call first.  MAGIC_DW_EARLY=0: off.
+DW_EARLY = os.environ.get("MAGIC_DW_EARLY", "1") != "0"
+_EARLY = {"stream": None, "keep": []}
+
+
+def flush_dw_early(device):
+    if not (DW_EARLY and DEFER["active"] and DEFER["queue"]) or lanes.cur != 0:
+        return False
+    cur = torch.cuda.current_stream(device)
+    ds = dw_stream(device)
+    ds.wait_stream(cur)
+    _EARLY["keep"].append((list(DEFER["queue"]), list(RBW_JOBS), list(PART_JOBS)))
+    with torch.cuda.stream(ds):
+        _flush_dw(None, keep_active=True)
+    _EARLY["stream"] = ds
+    return True
+
+
+def join_dw_early():
+    ds = _EARLY["stream"]
+    if ds is not None:
+        torch.cuda.current_stream(ds.device).wait_stream(ds)
+        _EARLY["stream"] = None
+        _EARLY["keep"].clear()
+
+
 def flush_dw(group=None, keep_active=False):
+    join_dw_early()
     join_dw_stream()
     # gradient lanes (host/lanes.py): an EAGER flush launches on the current stream over operands every lane's stream produced, into every
     # lane's gradient buffer -- order it behind the lanes, and the lanes behind it (the operands are freed afterwards)

@@ -297,6 +297,8 @@ class GradSync:
             fn()
             return
         self.stream.wait_stream(torch.cuda.current_stream())
+        if O._EARLY["stream"] is not None:        # the bucket's weight gradients were flushed on the weight-gradient stream (ops.flush_dw_early)
+            self.stream.wait_stream(O._EARLY["stream"])
         with torch.cuda.stream(self.stream):
             fn()
 

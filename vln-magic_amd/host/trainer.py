@@ -469,6 +469,10 @@ class PretrainStep:
         self.side = None
         if self.on_gpu and teacher is not None and overlap_teacher and not os.environ.get("MAGIC_NO_TEACHER_SIDE"):
             self.side = _side_stream(self.dev, (self.sync.stream,))
+        if self.on_gpu and O.DW_EARLY and O._EARLY["use"] is None:
+            # the stream of the mid-backward weight-gradient flush (ops.flush_dw_early): beside the main, the teacher's and the exchange stream
+            from . import lanes as _lanes
+            O._EARLY["use"] = _lanes.beside([torch.cuda.current_stream(self.dev)] + [x for x in (self.side, self.sync.stream) if x is not None], device=self.dev)
         if self.on_gpu and overlap_dw and O.SIDE["stream"] is None and os.environ.get("MAGIC_DW_SIDE"):   # opt-in: no gain measured on MI355X
             O.SIDE["stream"] = torch.cuda.Stream()       # weight-gradient GEMMs leave the dX critical chain
         self.global_step = 0

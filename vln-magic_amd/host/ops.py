@@ -238,8 +238,12 @@ def join_dw_stream():
 # pretraining backward) on the device's weight-gradient stream: the chip-filling grouped launch then runs UNDER the text / panorama stacks' latency-
 # bound row-block chain (240 workgroups on 256 CUs at two per CU: half the chip idles there) instead of in one exposed 133 us launch at the end of the
 # backward.  The flushed operands (and the partial-row buffers of the column sums) stay alive until `join_dw_early`, which every later flush and the
-# embedding backward (whose table-row atomics meet the tied decoder's dW in the word-embedding gradient) call first.  MAGIC_DW_EARLY=0: off.
-DW_EARLY = os.environ.get("MAGIC_DW_EARLY", "1") != "0"
+# embedding backward (whose table-row atomics meet the tied decoder's dW in the word-embedding gradient) call first.
+# MEASURED AND REJECTED as the default (profiles/micro/r06_ab_dw_early.txt, same box, this bench): 1.84-1.86 vs 1.43-1.44 ms/step, and the data-parallel
+# structure 1.88 vs 1.54 -- a fork inside the captured step graph runs on the runtime's own branch streams, which share a hardware queue with the teacher's
+# stream (its start gate timed out on 84-99 of 198 steps), whichever stream the capture forked to (the first version took the weight-gradient stream as
+# it came, the second one picked by lanes.beside: same result).  Opt-in: MAGIC_DW_EARLY=1.
+DW_EARLY = os.environ.get("MAGIC_DW_EARLY", "0") == "1"
 _EARLY = {"stream": None, "keep": [], "use": None}
 # `use`: the stream the early flush runs on -- given by the trainer, which picks one that is MEASURED to run beside the main, the teacher's and the
 # exchange stream (lanes.beside: HIP deals a process's streams onto 4 hardware queues; the first version took the device's weight-gradient stream as

@@ -250,7 +250,7 @@ def test_attention_backward_inside_the_rowblock_launches_matches_the_alternating
     inp = m._inputs(batch, plan)
     m.store.sync_shadow()
     n = m.net
-    assert n.rbw_ok() and O.rowbwd_attn_ok(n.dtype, n.H, n.I, n.nh, plan["L"]) and O.rowbwd_attn_ok(n.dtype, n.H, n.I, n.nh, plan["V"])
+    assert n.rbw_ok() and O.rowbwd_attn_ok(n.dtype, n.H, n.I, n.nh, plan["L"]) and O.rowbwd_attn_ok(n.dtype, n.H, n.I, n.nh, plan["V"])      # (module default: mode 1)
     seed = torch.tensor([4321, 99], dtype=torch.int32, device=DEV)
     g = torch.Generator().manual_seed(3)
     B, L, H, Np, V = plan["B"], plan["L"], n.H, plan["Np"], plan["V"]
@@ -258,8 +258,8 @@ def test_attention_backward_inside_the_rowblock_launches_matches_the_alternating
     d_pano0 = (torch.randn(Np * V, H, generator=g) * 0.1).to(DEV).bfloat16()
     d_fused0 = (torch.randn(Np, H, generator=g) * 0.1).to(DEV).bfloat16()
     res = {}
-    for mode in ("per_op", "alternating", "inside"):
-        O.FUSED_RBW, O.RBW_ATTN = mode != "per_op", mode == "inside"
+    for mode in ("per_op", "alternating", "inside", "hybrid"):      # hybrid = the default: inside once only the text stack is left (MAGIC_RBW_ATTN=1)
+        O.FUSED_RBW, O.RBW_ATTN_MODE = mode != "per_op", {"inside": 2, "hybrid": 1}.get(mode, 0)
         try:
             n.set_dropout(seed if p_drop > 0 else None, p_drop, p_drop)
             ct = n.text_fwd(plan)
@@ -283,14 +283,14 @@ def test_attention_backward_inside_the_rowblock_launches_matches_the_alternating
             torch.cuda.synchronize()
             res[mode] = m.store.grad.clone()
         finally:
-            O.FUSED_RBW, O.RBW_ATTN = True, True
+            O.FUSED_RBW, O.RBW_ATTN_MODE = True, 1
     names = [nm for nm, _ in m.named_parameters() if ("lang_encoder" in nm or "pano_encoder" in nm or "embeddings" in nm)]
-    for ref, tol_all, tol_one in (("alternating", 1.5e-2, 4e-2), ("per_op", 3e-2, 6e-2)):
-        a, b = res["inside"], res[ref]
+    for got, ref, tol_all, tol_one in (("inside", "alternating", 1.5e-2, 4e-2), ("inside", "per_op", 3e-2, 6e-2), ("hybrid", "alternating", 1.5e-2, 4e-2)):
+        a, b = res[got], res[ref]
         assert torch.isfinite(a).all() and a.abs().max() > 0
         cos = F.cosine_similarity(a, b, dim=0).item()
         rel = ((a - b).norm() / b.norm()).item()
-        assert cos > 0.9995 and rel < tol_all, (ref, cos, rel)
+        assert cos > 0.9995 and rel < tol_all, (got, ref, cos, rel)
         top = max(b[m.store.offsets[nm][0]:m.store.offsets[nm][0] + m.store.offsets[nm][1]].norm().item() for nm in names)
         worst = (0.0, "")
         for nm in names:
@@ -304,8 +304,8 @@ def test_attention_backward_inside_the_rowblock_launches_matches_the_alternating
                 continue
             r = ((ga - gb).norm() / gb.norm()).item()
             worst = max(worst, (r, nm))
-            assert r < tol_one, (ref, nm, r)
-        print(f"attention backward inside the row-block launches vs {ref}: cosine {cos:.6f}, rel L2 {rel:.2e}, worst tensor {worst[0]:.2e} ({worst[1]})")
+            assert r < tol_one, (got, ref, nm, r)
+        print(f"attention backward inside the row-block launches ({got}) vs {ref}: cosine {cos:.6f}, rel L2 {rel:.2e}, worst tensor {worst[0]:.2e} ({worst[1]})")
 
 
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])

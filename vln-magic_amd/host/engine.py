@@ -640,152 +640,156 @@ class MagicNet:
         return self.train and O.rowbwd_ok(self.dtype, self.H, self.I)
 
     def self_stacks_bwd(self, stacks, on_iter=None):
-        """stacks: 1 or 2 tuples (ctx with .layers, layer-prefix format, d_top = plain gradient wrt the stack's output, dP_init for
-        the top block's attention map).  Two launches per block and stack pair -- the per-token chain (magic_rowbwd: tail of the
-        block above + FFN + both LayerNorm backwards + output projection) and the attention backward -- instead of five; the two
-        stacks advance together from their tops (text 6 blocks, panorama 2) in shared launches.  Returns the gradients wrt the
-        stacks' inputs.  on_iter(k): called after the k-th round (k = 1, 2, ...: the top k blocks of every stack are done and their
-        weight gradients queued) -- the data-parallel exchange cuts its buckets there (trainer.GradSync)."""
+        """stacks: 1 or 2 tuples (ctx with .layers, layer-prefix format, d_top = plain gradient wrt the stack's output, dP_init for the top block's
+        attention map).  Returns the gradients wrt the stacks' inputs.  on_iter(k): called when the top k blocks of every stack are done and their weight
+        gradients queued -- the data-parallel exchange cuts its buckets there (trainer.GradSync).
+
+        Two launch forms (csrc/encbwd.hip), chosen per step:
+          * ALTERNATING (rounds 2-5): per block the per-token chain (magic_rowbwd: tail of the block above + FFN + both LayerNorm backwards + output
+            projection) and the attention backward (magic_attn_bwd, one workgroup per (sample, head)) as two launches, shared by the stacks that are
+            still running (text 6 blocks || panorama 2): flat 32-row tiles, the right shape for many short samples;
+          * INSIDE (round 6): the attention backward of block j+1 in front of block j's chain in ONE launch, a workgroup per 16-row tile of one sample
+            (attn_tile_stage) -- n + 1 launches for n blocks instead of 2 n + 1.  Taken once a single stack is left and its samples are long enough
+            to fill 16-row tiles (the text stack from its third block down; a panorama's 36 rows would be three tiles with the last nearly empty:
+            measured 146 us for the two shared launches against ~110 for the alternating form, profiles/r06_*).
+        MAGIC_RBW_ATTN=0: alternating everywhere; MAGIC_RBW_ATTN=2: inside for every stack from the top (the first round-6 form)."""
         from . import lib as L
         H, I = self.H, self.I
-        if all(O.rowbwd_attn_ok(self.dtype, H, I, self.nh, c.layers[-1].sa.N) and O.attn_supported(self.dtype, c.layers[-1].sa.N, c.layers[-1].sa.N, True)
-               for c, _, _, _ in stacks):
-            return self._self_stacks_bwd_fused(stacks, on_iter)
-        rounds = 0
         st = []
         for c, fmt, d_top, dP in stacks:
             lc = c.layers[-1]
-            st.append(Ctx(c=c, fmt=fmt, j=len(c.layers) - 1, M=lc.sa.Bn * lc.sa.N, dP=dP, d_top=d_top, pre=None, dqkv=None, dao=None, dx0=None))
+            N = lc.sa.N
+            can = O.rowbwd_attn_ok(self.dtype, H, I, self.nh, N) and O.attn_supported(self.dtype, N, N, True)
+            st.append(Ctx(c=c, fmt=fmt, nl=len(c.layers), j=len(c.layers) - 1, M=lc.sa.Bn * N, N=N, dP=dP, d_top=d_top, dqkv=None, dao=None, dctx=None,
+                          attn_due=None, dx0=None, can=can))
         d = self.drop            # (the LayerNorm backward of each stack's last output norm runs inside the first chain: kt = 0)
-        while any(s.dx0 is None for s in st):
-            segs, act = [], []
-            for s in st:
-                if s.dx0 is not None:
-                    continue
-                j, M = s.j, s.M
-                lp, lc = s.fmt.format(j), s.c.layers[j]
-                sa, ffn = lc.sa, lc.ffn
-                f1, f2, o = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.lin(lp + "attention.output.dense.weight")
-                n2, n1 = self.ln(lp + "output.LayerNorm"), self.ln(lp + "attention.output.LayerNorm")
-                out = Ctx(dz=self.new(M, I), daod=self.new(M, H), dao=self.new(M, H), dctx=self.new(M, H))
-                seg = dict(M=M, y2=ffn.out, rstd2=ffn.rstd, g2=n2.g, b2=n2.b, z=ffn.z, W2T=f2.WTf, W1T=f1.WTf, y1=sa.a, rstd1=sa.rstd_a,
-                           g1=n1.g, b1=n1.b, dg1=n1.dg, db1=n1.db, WoT=o.WTf, dz=out.dz, daod=out.daod, dao=out.dao, dctx=out.dctx,
-                           site_out=ffn.hdrop[2] if ffn.hdrop else 0, site_ao=sa.hdrop[2] if sa.hdrop else 0)
-                flops = 2.0 * ffn.rows * (2 * H * I + H * H)
-                if s.d_top is not None:          # top block: dx of the output norm = the plain gradient wrt the stack's output (no product)
-                    out.dfo, out.dfod = self.new(M, H), self.new(M, H)
-                    seg.update(dqkv_n=s.d_top, kt=0, WqkvT_n=f2.WTf, dao_n=s.d_top, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
-                    s.d_top = None
-                else:                            # tail of block j + 1 runs here
-                    qn = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
-                    out.dfo, out.dfod = self.new(M, H), self.new(M, H)
-                    seg.update(dqkv_n=s.dqkv, WqkvT_n=qn.WTf, dao_n=s.dao, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
-                    flops += 2.0 * ffn.rows * 3 * H * H
-                seg["flops"] = flops
-                segs.append(seg)
-                act.append((s, lp, lc, out, f1, f2, o))
-            O.rowbwd(segs, d[0] if d else None, d[1] if d else 0.0)
-            fused_attn = all(O.attn_supported(self.dtype, lc.sa.N, lc.sa.N, True) for _, _, lc, _, _, _, _ in act)
-            grp = L.group() if (fused_attn and len(act) > 1) else None
-            if grp is not None:
-                grp.__enter__()
-            try:
-                for s, lp, lc, out, f1, f2, o in act:
-                    sa = lc.sa
-                    out.dqkv = self.new(s.M, 3 * H)
-                    self._attn_bwd(sa.Ppre, sa.ldp, out.dctx, sa.qkv, 3 * H, sa.qkv[:, H:], sa.qkv[:, 2 * H:], 3 * H,
-                                   out.dqkv, 3 * H, out.dqkv[:, H:], out.dqkv[:, 2 * H:], 3 * H, sa.Bn, sa.N, sa.N, None, None,
-                                   s.dP if s.j == len(s.c.layers) - 1 else None, sa.aflops, sa.adrop, sa.P if sa.adrop else None)
-            finally:
-                if grp is not None:
-                    grp.__exit__(None, None, None)
-            for s, lp, lc, out, f1, f2, o in act:
-                sa, ffn, M = lc.sa, lc.ffn, s.M
-                ql = self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H)
-                O.linear_dw(out.dfod, ffn.g, f2.dW, f2.db, M, flop_rows=ffn.rows)
-                O.linear_dw(out.dz, ffn.a, f1.dW, f1.db, M, flop_rows=ffn.rows)
-                O.linear_dw(out.daod, sa.ctx, o.dW, o.db, M, flop_rows=sa.rows)
-                O.linear_dw(out.dqkv, sa.x, ql.dW, ql.db, M, flop_rows=sa.rows)
-                s.dqkv, s.dao = out.dqkv, out.dao
-                if s.j == 0:
-                    s.dx0 = O.linear_dx(out.dqkv, ql.W, M, residual=out.dao, flop_rows=sa.rows)
-                else:
-                    s.j -= 1
-            rounds += 1
-            if on_iter is not None:
-                on_iter(rounds)
-        return [s.dx0 for s in st]
+        everywhere = O.RBW_ATTN_MODE == 2
+        done_blocks = 0
 
-    def _self_stacks_bwd_fused(self, stacks, on_iter=None):
-        """self_stacks_bwd with the attention backward INSIDE the row-block launches (round 6, csrc/encbwd.hip attn_tile_stage): a stack of n blocks is
-        n + 1 launches -- [chain of the top block] -> [attention backward of block j+1 + chain of block j] x (n - 1) -> [attention backward of block 0 +
-        the gradient wrt the stack's input] -- instead of 2 n + 1 (chain and attention backward alternating, then a GEMM); the stacks advance together
-        from their tops in shared launches.  Every workgroup owns a 16-row tile of ONE sample and needs the d_ctx rows of its whole sample, which the
-        previous launch wrote: no hand-off inside a launch.  Same saved tensors, same dY operands for the deferred weight gradients."""
-        H, I = self.H, self.I
-        st = []
-        for c, fmt, d_top, dP in stacks:
-            lc = c.layers[-1]
-            st.append(Ctx(c=c, fmt=fmt, nl=len(c.layers), M=lc.sa.Bn * lc.sa.N, dP=dP, d_top=d_top, prev=None, dx0=None))
-        d = self.drop
-        step = 0
+        def lins(s, j):
+            lp = s.fmt.format(j)
+            return (lp, self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.lin(lp + "attention.output.dense.weight"),
+                    self.lin(lp + "attention.self.query.weight", rows=3 * H, cols=H))
+
+        def chain_seg(s, j):
+            """the per-token chain of block j of stack s: segment fields + its output buffers"""
+            lp, f1, f2, o, _ = lins(s, j)
+            lc = s.c.layers[j]
+            sa, ffn, M = lc.sa, lc.ffn, s.M
+            n2, n1 = self.ln(lp + "output.LayerNorm"), self.ln(lp + "attention.output.LayerNorm")
+            out = Ctx(dz=self.new(M, I), daod=self.new(M, H), dao=self.new(M, H), dctx=self.new(M, H), dfo=self.new(M, H), dfod=self.new(M, H))
+            seg = dict(M=M, y2=ffn.out, rstd2=ffn.rstd, g2=n2.g, b2=n2.b, z=ffn.z, W2T=f2.WTf, W1T=f1.WTf, y1=sa.a, rstd1=sa.rstd_a,
+                       g1=n1.g, b1=n1.b, dg1=n1.dg, db1=n1.db, WoT=o.WTf, dz=out.dz, daod=out.daod, dao=out.dao, dctx=out.dctx,
+                       dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db,
+                       site_out=ffn.hdrop[2] if ffn.hdrop else 0, site_ao=sa.hdrop[2] if sa.hdrop else 0)
+            return seg, out, 2.0 * ffn.rows * (2 * H * I + H * H)
+
+        def chain_dw(s, j, out):
+            lp, f1, f2, o, _ = lins(s, j)
+            lc = s.c.layers[j]
+            O.linear_dw(out.dfod, lc.ffn.g, f2.dW, f2.db, s.M, flop_rows=lc.ffn.rows)
+            O.linear_dw(out.dz, lc.ffn.a, f1.dW, f1.db, s.M, flop_rows=lc.ffn.rows)
+            O.linear_dw(out.daod, lc.sa.ctx, o.dW, o.db, s.M, flop_rows=lc.sa.rows)
+
+        def tail_fields(s, j):
+            """the tail of block j + 1 in front of block j's chain: from the plain top gradient, or from dQKV in memory"""
+            if s.d_top is not None:
+                t = dict(dqkv_n=s.d_top, kt=0, WqkvT_n=lins(s, j)[2].WTf, dao_n=s.d_top)
+                s.d_top = None
+                return t, 0.0
+            return dict(dqkv_n=s.dqkv, kt=12, WqkvT_n=lins(s, j + 1)[4].WTf, dao_n=s.dao), 2.0 * s.c.layers[j].ffn.rows * 3 * H * H
+
+        def attn_fields(s, ja, out):
+            """the attention backward of block ja inside a launch (mode 1 / 2): its saved tensors, the d_ctx / d_ao rows the previous launch wrote"""
+            sa1 = s.c.layers[ja].sa
+            out.dqkv = self.new(s.M, 3 * H)
+            return dict(N=sa1.N, ldp=sa1.ldp, qkv_a=sa1.qkv, P_a=sa1.Ppre, o_a=sa1.ctx, dctx_a=s.dctx, dP_init=s.dP if ja == s.nl - 1 else None,
+                        dqkv_out=out.dqkv, site_attn=sa1.adrop[2] if sa1.adrop else 0, WqkvT_n=lins(s, ja)[4].WTf, dao_n=s.dao), \
+                2.0 * sa1.rows * 3 * H * H + 8.0 * sa1.aflops
+
         while any(s.dx0 is None for s in st):
-            segs, act = [], []
-            for s in st:
-                if s.dx0 is not None:
-                    continue
-                nl, M = s.nl, s.M
-                j = nl - 1 - step                     # the block whose per-token chain runs in this launch (-1: none left, only the input gradient)
-                seg, out = dict(M=M), Ctx()
-                flops = 0.0
-                if j >= 0:
-                    lp, lc = s.fmt.format(j), s.c.layers[j]
-                    sa, ffn = lc.sa, lc.ffn
-                    f1, f2, o = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.lin(lp + "attention.output.dense.weight")
-                    n2, n1 = self.ln(lp + "output.LayerNorm"), self.ln(lp + "attention.output.LayerNorm")
-                    out = Ctx(dz=self.new(M, I), daod=self.new(M, H), dao=self.new(M, H), dctx=self.new(M, H), dfo=self.new(M, H), dfod=self.new(M, H))
-                    seg.update(y2=ffn.out, rstd2=ffn.rstd, g2=n2.g, b2=n2.b, z=ffn.z, W2T=f2.WTf, W1T=f1.WTf, y1=sa.a, rstd1=sa.rstd_a,
-                               g1=n1.g, b1=n1.b, dg1=n1.dg, db1=n1.db, WoT=o.WTf, dz=out.dz, daod=out.daod, dao=out.dao, dctx=out.dctx,
-                               dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db,
-                               site_out=ffn.hdrop[2] if ffn.hdrop else 0, site_ao=sa.hdrop[2] if sa.hdrop else 0)
-                    flops += 2.0 * ffn.rows * (2 * H * I + H * H)
-                if step == 0:                         # top block: dx of the output norm = the plain gradient wrt the stack's output (no product)
-                    seg.update(dqkv_n=s.d_top, kt=0, WqkvT_n=f2.WTf, dao_n=s.d_top)
-                    s.d_top = None
-                else:                                 # attention backward of block j + 1 (its d_ctx / d_ao came out of the previous launch), then the tail
-                    up = s.c.layers[j + 1]
-                    sa1 = up.sa
-                    qn = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
-                    out.dqkv = self.new(M, 3 * H)
-                    if j < 0:
-                        out.dx0 = self.new(M, H)
-                    seg.update(mode=1 if j >= 0 else 2, N=sa1.N, ldp=sa1.ldp, qkv_a=sa1.qkv, P_a=sa1.Ppre, o_a=sa1.ctx, dctx_a=s.prev.dctx,
-                               dP_init=s.dP if j + 1 == nl - 1 else None, dqkv_out=out.dqkv, site_attn=sa1.adrop[2] if sa1.adrop else 0,
-                               WqkvT_n=qn.WTf, dao_n=s.prev.dao, **({} if j >= 0 else dict(dfo=out.dx0)))
-                    flops += 2.0 * sa1.rows * 3 * H * H + 8.0 * sa1.aflops
-                seg["flops"] = flops
+            act = [s for s in st if s.dx0 is None]
+            jnow = {id(s): s.j for s in act}
+
+            def defer(s):
+                """will block s.j's attention backward run INSIDE this stack's next launch (instead of as a launch of its own right after this chain)?"""
+                if O.RBW_ATTN_MODE == 0 or not s.can:
+                    return False
+                if everywhere:
+                    return True
+                alone_next = all(x is s or x.dx0 is not None or (jnow[id(x)] == 0 and x.attn_due is None) for x in st)      # the others finish in this step
+                return s.N > 48 and alone_next
+            segs, work = [], []
+            for s in act:
+                j = s.j
+                if s.attn_due is not None:
+                    # [attention backward of block attn_due = j + 1] + [chain of block j], or at the bottom [attention backward of block 0] + dx0
+                    out = Ctx()
+                    af, fl = attn_fields(s, s.attn_due, out)
+                    if j >= 0:
+                        seg, o2, fl2 = chain_seg(s, j)
+                        o2.dqkv = out.dqkv
+                        out, fl = o2, fl + fl2
+                        seg.update(mode=1, **af)
+                    else:
+                        out.dx0 = self.new(s.M, H)
+                        seg = dict(M=s.M, mode=2, dfo=out.dx0, **af)
+                    seg["flops"] = fl
+                    work.append((s, "inside", j, out))
+                else:
+                    # chain of block j with its tail from memory
+                    seg, out, fl = chain_seg(s, j)
+                    tf, fl2 = tail_fields(s, j)
+                    seg.update(tf)
+                    seg["flops"] = fl + fl2
+                    work.append((s, "chain", j, out))
                 segs.append(seg)
-                act.append((s, j, out))
             O.rowbwd(segs, d[0] if d else None, d[1] if d else 0.0, p_attn=d[2] if d else 0.0, scale=1.0 / math.sqrt(HD))
-            for s, j, out in act:
-                M = s.M
-                if j >= 0:
-                    lp, lc = s.fmt.format(j), s.c.layers[j]
-                    sa, ffn = lc.sa, lc.ffn
-                    f1, f2, o = self.lin(lp + "intermediate.dense.weight"), self.lin(lp + "output.dense.weight"), self.lin(lp + "attention.output.dense.weight")
-                    O.linear_dw(out.dfod, ffn.g, f2.dW, f2.db, M, flop_rows=ffn.rows)
-                    O.linear_dw(out.dz, ffn.a, f1.dW, f1.db, M, flop_rows=ffn.rows)
-                    O.linear_dw(out.daod, sa.ctx, o.dW, o.db, M, flop_rows=sa.rows)
-                if step > 0:
-                    sa1 = s.c.layers[j + 1].sa
-                    ql = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
-                    O.linear_dw(out.dqkv, sa1.x, ql.dW, ql.db, M, flop_rows=sa1.rows)
-                if j < 0:
-                    s.dx0 = out.dx0
-                s.prev = out
-            step += 1
-            if on_iter is not None and step >= 2:     # after launch k + 1 the top k blocks of every stack have all four weight gradients queued
-                on_iter(step - 1)
+            sep = []         # chains whose attention backward follows NOW as a launch of its own (shared by the stacks: one grouped launch)
+            for s, kind, j, out in work:
+                if kind == "inside":
+                    ja = s.attn_due
+                    ql = lins(s, ja)[4]
+                    O.linear_dw(out.dqkv, s.c.layers[ja].sa.x, ql.dW, ql.db, s.M, flop_rows=s.c.layers[ja].sa.rows)      # block ja is complete
+                    if j >= 0:
+                        chain_dw(s, j, out)
+                        s.dctx, s.dao, s.attn_due, s.j = out.dctx, out.dao, j, j - 1
+                    else:
+                        s.dx0, s.attn_due = out.dx0, None
+                else:
+                    chain_dw(s, j, out)
+                    s.dctx, s.dao = out.dctx, out.dao
+                    if defer(s):
+                        s.attn_due, s.j = j, j - 1
+                    else:
+                        sep.append((s, j, out))
+            if sep:
+                grp = L.group() if len(sep) > 1 else None
+                if grp is not None:
+                    grp.__enter__()
+                try:
+                    for s, j, out in sep:
+                        sa = s.c.layers[j].sa
+                        out.dqkv = self.new(s.M, 3 * H)
+                        self._attn_bwd(sa.Ppre, sa.ldp, out.dctx, sa.qkv, 3 * H, sa.qkv[:, H:], sa.qkv[:, 2 * H:], 3 * H,
+                                       out.dqkv, 3 * H, out.dqkv[:, H:], out.dqkv[:, 2 * H:], 3 * H, sa.Bn, sa.N, sa.N, None, None,
+                                       s.dP if j == s.nl - 1 else None, sa.aflops, sa.adrop, sa.P if sa.adrop else None)
+                finally:
+                    if grp is not None:
+                        grp.__exit__(None, None, None)
+                for s, j, out in sep:
+                    ql = lins(s, j)[4]
+                    O.linear_dw(out.dqkv, s.c.layers[j].sa.x, ql.dW, ql.db, s.M, flop_rows=s.c.layers[j].sa.rows)
+                    s.dqkv = out.dqkv
+                    if j == 0:
+                        s.dx0 = O.linear_dx(out.dqkv, ql.W, s.M, residual=out.dao, flop_rows=s.c.layers[0].sa.rows)
+                    s.j = j - 1
+            # blocks complete (all four weight gradients queued) in EVERY stack: counted from the top
+            k = min((10 ** 6 if s.dx0 is not None else s.nl - 1 - (s.attn_due if s.attn_due is not None else s.j)) for s in st)      # (attention pending: block attn_due is not complete yet)
+            while done_blocks < min(k, max(s.nl for s in st)):
+                done_blocks += 1
+                if on_iter is not None:
+                    on_iter(done_blocks)
         return [s.dx0 for s in st]
 
     def encoders_bwd(self, ct, cp, plan, d_txt, dP_txt, d_pano, d_fused, dP_pano, on_iter=None):

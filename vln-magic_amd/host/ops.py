@@ -1032,12 +1032,12 @@ def flush_rbw_parts():
 
 def rowbwd_attn_ok(dtype, H, I, nh, N):
     """may a rowbwd segment carry the attention backward of the block above (mode 1 / 2)?"""
-    return bool(RBW_ATTN and rowbwd_ok(dtype, H, I) and L.load().magic_rowbwd_attn_supported(L.dt(dtype), H, I, nh, N))
+    return bool(RBW_ATTN_MODE != 0 and rowbwd_ok(dtype, H, I) and L.load().magic_rowbwd_attn_supported(L.dt(dtype), H, I, nh, N))
 
 
 # round 6: the attention backward of block j+1 inside the row-block launch of block j (csrc/encbwd.hip attn_tile_stage).  MAGIC_RBW_ATTN=0: the
 # round 2-5 structure (magic_rowbwd and magic_attn_bwd alternating, two launches per block).
-RBW_ATTN = os.environ.get("MAGIC_RBW_ATTN", "1") != "0"
+RBW_ATTN_MODE = int(os.environ.get("MAGIC_RBW_ATTN", "1"))      # 0: alternating launches; 1: inside once one long stack is left (default); 2: inside for every stack from its top
 
 
 def rowbwd(segs, seed, p_hidden, p_attn=0.0, scale=0.125):

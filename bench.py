@@ -216,7 +216,7 @@ def pmc_traffic(gemm_n=1, chain_n=0):
     inside this process (PMC collection needs rocprofv3 around it): read from the committed post-processing of the `rocprofv3 --pmc
     FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (profiles/pmc_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for gfx950).  Returns (bytes, source file)."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 j = json.load(f)
@@ -232,7 +232,7 @@ def pmc_traffic(gemm_n=1, chain_n=0):
 
 def pmc_dw_fetch():
     """HBM bytes fetched per weight-gradient launch from the committed PMC pass (None if that file does not carry it)"""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 v = json.load(f).get("dw_batch_fetch_bytes_per_launch")
@@ -245,7 +245,7 @@ def pmc_dw_fetch():
 
 def pmc_chain_traffic():
     """HBM bytes (fetched + written) per launch of the teacher's chain kernel from the committed PMC passes, or None"""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 j = json.load(f)
@@ -479,9 +479,11 @@ def secondary_block():
                             "--no-secondary", "--no-profile"], capture_output=True, text=True, timeout=300, env=env)
         j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         out["dp_structure_world1_rccl"] = {"ms_per_step": j["ms_per_step"], "value": j["value"], "unit": j["unit"], "steps": j["steps"],
-                                           "note": "three student graphs cut at the gradient-bucket boundaries + optimizer graph, all_reduce x 3 buckets (chunked) and the two "
-                                                   "all_gather_into_tensor of the sparse word-embedding rows issued on the exchange stream between the replays in a world-1 nccl "
-                                                   "(= RCCL) group: identity at world 1 -- the cost of the structure, not a scaling number (N > 1: unmeasured on hardware)"}
+                                           "rccl": j.get("dp_rccl"),
+                                           "note": "round 6: ONE graph per step with the bucket collectives INSIDE it -- ncclAllReduce x 3 buckets (one group launch each) and the two "
+                                                   "ncclAllGather of the sparse word-embedding rows (one group launch), issued through RCCL's C ABI (host/rccl.py) on the exchange "
+                                                   "stream the capture forks to at every bucket boundary; world-1 communicator: identity -- the cost of the structure, not a scaling "
+                                                   "number (N > 1: unmeasured on hardware).  Rounds 4-5: three graphs cut at the bucket boundaries + torch.distributed calls between the replays (1.73-1.75 ms)"}
     except Exception as e:              # noqa: BLE001
         out["dp_structure_world1_rccl"] = {"error": repr(e)[:300]}
     # SURVEY f-3: the same pretraining step fed from DataLoader workers (NON-resident batches, PCIe-inclusive; never `value`): batches padded to
@@ -496,6 +498,19 @@ def secondary_block():
                                                 "one H2D record copy + one graph launch per step; the resident-batch headline is `value`"}
     except Exception as e:              # noqa: BLE001
         out["streamed_batches_graph_replay"] = {"error": repr(e)[:300]}
+    # ... and the two together: what ONE RANK of a real data-parallel run executes every step -- streamed batches (DataLoader workers,
+    # bucket graphs) AND the data-parallel structure (bucket graphs cut where the gradient buckets are final, the bucket collectives of a world-1 RCCL
+    # communicator between the replays: the touched word-embedding rows change per batch, so these collectives stay outside the graphs)
+    try:
+        r = subprocess.run([py, os.path.join(ROOT, "bench.py"), "--mode", "stream-graph", "--dp-structure", "--workers", "8", "--warmup", "300", "--steps", "150",
+                            "--no-cpu-baseline", "--no-parity", "--no-secondary"], capture_output=True, text=True, timeout=300, env=env)
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        out["rank_of_a_real_run"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                                     "ms_per_step_without_in_window_captures": j.get("ms_per_step_steady"), "launch": j["launch"],
+                                     "note": "streamed batches (8 DataLoader workers, bucket graphs, feature table in HBM) + the data-parallel structure at world 1 over RCCL "
+                                             "(identity): the per-rank step of an N-GPU run without the bytes on xGMI (N > 1: unmeasured on hardware)"}
+    except Exception as e:              # noqa: BLE001
+        out["rank_of_a_real_run"] = {"error": repr(e)[:300]}
     return out
 
 
@@ -723,6 +738,7 @@ def main():
                 gn_task[task] = trainer.opt.grad_norm_report()        # the last replayed step of this loop was a `task` step
         steady["ms_per_step_by_task"] = by_task
         steady["grad_norm_by_task"] = gn_task
+    trainer_rccl = (trainer.sync.rccl is not None, bool(a.mode == "graph" and getattr(graphs[0], "rccl_in_graph", False)) if a.mode == "graph" else False)
     health = trainer.check_health()          # raises if an in-launch hand-off of the row-split encoder kernels ever gave up
     gate = gate_now
     if gate is not None:
@@ -910,7 +926,8 @@ def main():
                            "parallelism": f"dp{world}", "samples_per_sec": round(a.batch * world * a.steps / dt, 1)},
                 "roofline": roof, "cpu_baseline": cpu, "parity": parity, "modes": modes, "secondary": secondary, "rccl": rccl, "rccl_smoke": rccl_smoke,
                 "dp_structure_ms_per_step": ((secondary or {}).get("dp_structure_world1_rccl") or {}).get("ms_per_step"),
-                "dp_structure": bool(a.dp_structure)}
+                "dp_structure": bool(a.dp_structure),
+                "dp_rccl": ({"direct_c_abi": trainer_rccl[0], "collectives_inside_the_step_graph": trainer_rccl[1]} if a.dp_structure else None)}
         if parity is not None:
             # the north star's bar (|delta action logit| < 1e-3 against the oracle, argmax identical) for the arithmetic this line's `value`
             # was measured in, stated at the top level; and the mode of the SAME kernels that meets it, with its own step time

@@ -200,3 +200,13 @@ def test_packed_loader_record_round_trips():
     samples = [dict(x=i) for i in range(3)]
     pc = PlanCollate(lambda inp: synth.make_batch("sap", batch_size=len(inp), seed=1, vocab=300, min_len=6, max_len=9, min_steps=2, max_steps=3), "sap")
     assert set(pc(samples)) == {"buf", "blob"}
+
+
+def test_direct_rccl_binding_stays_out_of_the_way_without_an_nccl_group():
+    """host/rccl.py: no process group (or a gloo one) -> make() returns None and GradSync keeps torch.distributed; the module itself imports on a CPU box"""
+    import torch
+    from magic_amd.host import rccl
+    assert rccl.make(torch.device("cpu")) is None
+    assert rccl.NCCL_FLOAT32 == 7 and rccl.NCCL_INT64 == 4 and rccl.NCCL_SUM == 0          # rccl.h ncclDataType_t / ncclRedOp_t
+    import ctypes
+    assert ctypes.sizeof(rccl._UniqueId) == 128

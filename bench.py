@@ -437,6 +437,9 @@ def rccl_smoke_leg(student, batch_size, dev):
                 torch.cuda.synchronize()
                 same = same and bool(torch.equal(store.grad, ref))
             out["identity_at_world_1"] = same
+            if direct is not None:      # (an idle communicator keeps RCCL's proxy thread polling: it doubled the host-bound navigator legs that run after this one)
+                sync.rccl = None
+                direct.destroy()
             out["collectives"] = ["all_reduce fp32 x 3 buckets (chunked)", "all_gather_into_tensor int64 ids", "all_gather_into_tensor fp32 rows"]
             out["bucket_bytes"] = [int(sum(hi - lo for lo, hi in b) * 4) for b in sync.buckets]
             out["ok"] = out["identity_at_world_1"]
@@ -956,6 +959,11 @@ def main():
             info["fp16_argmax_agreement"] = parity["fp16"]["argmax_agreement"]
         print(json.dumps(info))
     if world > 1 or a.dp_structure:
+        try:
+            if trainer.sync.rccl is not None:
+                trainer.sync.rccl.destroy()
+        except NameError:       # (the secondary legs deleted the trainer)
+            pass
         dist.destroy_process_group()
 
 

@@ -23,7 +23,7 @@ import sys
 
 CUS, PEAK_TFLOPS, PEAK_GBS = 256, 2500.0, 8000.0
 KEEP = ("chain64_fwd_kernel", "chain_fwd_kernel", "encoder_mix_kernel", "encoder_rs_kernel", "encoder_fwd_kernel", "xencoder_rs_kernel", "xencoder_fwd_kernel",
-        "rowbwd16_kernel", "rowbwd32_kernel", "rowbwd64_kernel", "attn_bwd", "attn_fwd", "gemm_dw_batch_kernel", "gemm_grouped_kernel",
+        "rowbwd16a_kernel", "rowbwd16_kernel", "rowbwd32_kernel", "rowbwd64_kernel", "attn_bwd", "attn_fwd", "gemm_dw_batch_kernel", "gemm_grouped_kernel",
         "gemm_xcd_kernel", "gemm_kernel", "linear_ln", "mlm_", "adamw_kernel", "mse_multi", "ln_bwd", "ln_fwd", "view_gather",
         # the navigator iteration at MAGIC-L width (final_profile_r05.sh navpmc)
         "gemm_kg_kernel", "gemm_wide_kernel", "gemm_dw_cat_kernel", "gemm_grouped_kg_kernel", "smallk_ln", "pano_fuse", "colsum")

@@ -96,6 +96,34 @@ def _worker(rank, world, port, q):
             every = [torch.empty_like(st2.grad) for _ in range(world)]
             dist.all_gather(every, st2.grad)
             ok_bucket = ok_bucket and all(bool(torch.equal(every[0], e)) for e in every[1:])
+        # round 6: the STATIC padded form a captured graph holds for streamed batches (GradSync._sparse_rows_padded): ids first, -1 pads behind them;
+        # row 0 touched on rank 0 only (the pads gather and clear row 0: its own contribution must still come back), an all-pad buffer on the last rank
+        st4 = ParamStore(pretrain_specs(cfg), "cpu", torch.float32, seed=1)
+        gen = torch.Generator().manual_seed(970 + rank)
+        st4.grad.copy_(torch.randn(st4.total, generator=gen))
+        off, n, (R, H) = st4.offsets[EMB_TABLE]
+        touched = torch.randperm(R - 1, generator=gen)[:11 + 3 * rank] + 1
+        if rank == 0:
+            touched = torch.cat([torch.zeros(1, dtype=torch.int64), touched])
+        if rank == world - 1 and world > 2:
+            touched = touched[:0]
+        tab = st4.grad[off:off + n].view(R, H)
+        keep = tab[touched].clone()
+        tab.zero_()
+        tab[touched] = keep
+        mono = st4.grad.clone()
+        dist.all_reduce(mono)
+        sy = GradSync(st4, chunk_elems=4099, overlap=True, sparse_rows_cap=40)
+        ids_pad = torch.full((40,), -1, dtype=torch.int64)
+        ids_pad[:touched.numel()] = touched
+        sy.reduce_bucket(0)
+        sy.reduce_bucket(1)
+        sy.reduce_bucket(2, ids_pad, padded=True)
+        sy.finish()
+        ok_bucket = ok_bucket and bool(torch.allclose(st4.grad, mono, rtol=1e-6, atol=1e-6))
+        every = [torch.empty_like(st4.grad) for _ in range(world)]
+        dist.all_gather(every, st4.grad)
+        ok_bucket = ok_bucket and all(bool(torch.equal(every[0], e)) for e in every[1:])
         # a bucket-padded plan carries an EMPTY id list (host/plan.py): that must mean "dense table", never "no rows"
         st3 = ParamStore(pretrain_specs(cfg), "cpu", torch.float32, seed=1)
         st3.grad.copy_(torch.randn(st3.total, generator=torch.Generator().manual_seed(950 + rank)))

@@ -786,11 +786,20 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                     O.gemm(2, e1, a, d_outs[3], B, H, B, lds, H, H, alpha=it, residual=d_outs[3], ldr=H)
                 O.gemm(1, e2, a, d_outs[3], B, H, B, lds, H, H, alpha=it, residual=d_outs[3], ldr=H)
             d_g0, d_v0, d_t0 = c.d_cls0
-            for (key, src, dsts), d_o in zip((("gmap", c.g0, (d_g0,)), ("vp", c.v0, (d_v0,)), ("fused", c.gv0, (d_g0, d_v0)), ("txt", c.t0, (d_t0,))), d_outs):
+            heads = list(zip((("gmap", c.g0, (d_g0,)), ("vp", c.v0, (d_v0,)), ("fused", c.gv0, (d_g0, d_v0)), ("txt", c.t0, (d_t0,))), d_outs))
+            for (key, src, dsts), d_o in heads:
                 hl = n.lin(f"cfp_heads.{key}.weight")
                 O.linear_dw(d_o, src, hl.dW, hl.db, B)
-                for dst in dsts:
-                    O.linear_dx(d_o, hl.W, B, out=dst, residual=dst)
+            # the five input-gradient GEMMs (48 rows each: 6-10 us apiece on the chain) as TWO grouped launches: the three heads with a destination of their
+            # own, then the fused head's two (they add into the map / viewpoint rows the first launch wrote)
+            from . import lib as _lib
+            for sel in (("gmap", "vp", "txt"), ("fused",)):
+                with _lib.group():
+                    for (key, src, dsts), d_o in heads:
+                        if key in sel:
+                            hl = n.lin(f"cfp_heads.{key}.weight")
+                            for dst in dsts:
+                                O.linear_dx(d_o, hl.W, B, out=dst, residual=dst)
             O.csr_gather_multi(H, [dict(out=c.d_gmap, n_out=B * K, accumulate=True, src1=d_g0, csr1=plan["g0_T"]),
                                    dict(out=c.d_vp, n_out=B * Vp, accumulate=True, src1=d_v0, csr1=plan["v0_T"]),
                                    dict(out=c.d_txt, n_out=B * L, accumulate=True, src1=d_t0, csr1=plan["t0_T"])])

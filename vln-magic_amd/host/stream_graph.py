@@ -128,7 +128,14 @@ class StreamStep:
                 from . import ops as O
                 O.encoder_start_gate(tr.gate)   # T_{i+1} starts once S_i's whole-encoder launch has its workgroups resident (trainer.capture_split)
             e.t_out = tr.teacher_forward(e.batch, task, e.plan)
-        e.cs = tr.capture_student((e.batch, task, e.plan), e.t_out, rw=self.rw, rccl_in_graph=False)   # (the touched word-embedding rows change per replay)      # one graph; data parallel: three + the optimizer's
+        # data parallel: ONE graph with the bucket collectives inside when the exchange runs on the direct RCCL communicator (trainer.capture_student) --
+        # the touched word-embedding rows change per replay, so the graph reads them from a static -1-padded buffer `_stage` refills; else three
+        # graphs cut at the bucket boundaries + the optimizer's, the collectives between the replays
+        e.ids_buf = None
+        if (tr.sync.world > 1 or tr.sync.force) and tr.sync.rccl is not None and task != "mlm" and tr.sync.sparse_cap:
+            e.ids_buf = torch.full((int(tr.sync.sparse_cap),), -1, dtype=torch.int64, device=self.dev)
+            e.ids_host = [torch.full((int(tr.sync.sparse_cap),), -1, dtype=torch.int64).pin_memory() for _ in range(4)]
+        e.cs = tr.capture_student((e.batch, task, e.plan), e.t_out, rw=self.rw, rccl_in_graph=e.ids_buf is not None or task == "mlm", touched_static=e.ids_buf)
         e.out = e.cs.out
         e.fill = [(DYN_TERMS.index(t), fn) for t, fn in e.plan["dyn"]["fill"].items()]
         e.t_done, e.loaded = torch.cuda.Event(), torch.cuda.Event()
@@ -160,12 +167,27 @@ class StreamStep:
         for i, fn in e.fill:
             vo, vi, norm = fn(meta["true"])
             host_i[2 * i], host_i[2 * i + 1], host_f[i] = int(vo), int(vi), float(norm)
+        if getattr(e, "ids_buf", None) is not None:
+            # the graph reads this batch's rows from the entry's static buffer (pads = -1); no ids in the record: every slot a pad -> nothing exchanged
+            # sparsely would be WRONG, so such a record is refused
+            ids = meta.get("touched_ids")
+            if ids is None:
+                raise ValueError("StreamStep (data parallel, collectives inside the graph): records must carry `touched_ids` (loader.pack_bucketed)")
+            host = e.ids_host[e.turn]                 # (this ring slot's previous copies have completed: ev.synchronize() above)
+            k = len(ids)
+            if k > host.numel():
+                raise ValueError(f"sparse embedding exchange: {k} touched rows > cap {host.numel()}")
+            host[:k] = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64))
+            host[k:] = -1
+            e.ids_buf.copy_(host, non_blocking=True)
         e.plan["dyn"]["i"].copy_(host_i, non_blocking=True)
         e.plan["dyn"]["f"].copy_(host_f, non_blocking=True)
         ev.record()
         e.turn = (e.turn + 1) % len(e.ring)
         e.touched = None
-        if self.tr.sync.world > 1 and task != "mlm" and self.tr.sync.sparse_cap and meta.get("touched_ids") is not None:
+        if getattr(e, "ids_buf", None) is not None:
+            pass                                   # (refilled above, under the ring slot's event)
+        elif self.tr.sync.world > 1 and task != "mlm" and self.tr.sync.sparse_cap and meta.get("touched_ids") is not None:
             # the word-embedding rows THIS batch read (the record's own ids, not the captured batch's): trainer.GradSync exchanges those rows
             ids = torch.from_numpy(np.ascontiguousarray(meta["touched_ids"], dtype=np.int64)).pin_memory()
             e.touched, e.keep_ids = ids.to(self.dev, non_blocking=True), ids

@@ -334,8 +334,33 @@ class GradSync:
         for r in range(self.world):
             tab.index_add_(0, all_ids[r * cap:(r + 1) * cap], all_rows[r * cap:(r + 1) * cap])
 
+    def _sparse_rows_padded(self, ids_pad):
+        """`_sparse_rows` over a STATIC id buffer (round 6: the form a captured graph can hold when the touched rows change per replay -- streamed
+        batches): int64 [cap] on the device, this step's unique row ids first, -1 behind them.  Nothing here depends on how many ids are valid: pads
+        gather row 0 with a zero weight and add zeros back into it; `index_fill_` then also clears row 0, whose own contribution (if it was touched
+        on this rank) comes back through the gathered rows like every other row's, and whose gradient is zero otherwise (sparse steps reach the table
+        only through the instruction lookup).  Same rank-order sums as `_sparse_rows`: bitwise-identical replicas."""
+        off, n, (R, H) = self.table
+        tab = self.store.grad[off:off + n].view(R, H)
+        cap = int(ids_pad.numel())
+        valid = ids_pad >= 0
+        idx = ids_pad.clamp_min(0)
+        rows = tab.index_select(0, idx) * valid.to(tab.dtype)[:, None]
+        all_ids = torch.empty(self.world * cap, dtype=torch.int64, device=tab.device)
+        all_rows = torch.empty(self.world * cap, H, dtype=tab.dtype, device=tab.device)
+        if self.rccl is not None:
+            with self.rccl.group():
+                self.rccl.all_gather(all_ids, idx)
+                self.rccl.all_gather(all_rows.view(-1), rows.view(-1))
+        else:
+            dist.all_gather_into_tensor(all_ids, idx)
+            dist.all_gather_into_tensor(all_rows, rows)
+        tab.index_fill_(0, idx, 0)
+        for r in range(self.world):
+            tab.index_add_(0, all_ids[r * cap:(r + 1) * cap], all_rows[r * cap:(r + 1) * cap])
+
     # ---- per-bucket API (called from inside the backward) ----------------------------------------------------------
-    def reduce_bucket(self, i, touched_rows=None, cap_scale=1):
+    def reduce_bucket(self, i, touched_rows=None, cap_scale=1, padded=False):
         """launch bucket i's exchange on the side stream.  touched_rows (last bucket only): device int64 ids of the word-embedding
         rows this rank's step wrote, or None for a dense table (mlm: the tied decoder touches every row).  cap_scale: the gathered
         buffers hold cap_scale x sparse_rows_cap rows (gradient accumulation: the rows of cap_scale micro-batches)."""
@@ -344,7 +369,8 @@ class GradSync:
         ranges = self.buckets[i]
         # an EMPTY id list is not "no rows": bucket-padded plans carry a zero-length placeholder (host/plan.py) -> dense exchange
         last = len(self.buckets) - 1          # the word-embedding table lives in the last bucket
-        sparse = i == last and touched_rows is not None and touched_rows.numel() > 0 and self.table is not None and self.sparse_cap
+        # padded: touched_rows is a static -1-padded id buffer (`_sparse_rows_padded`): always the sparse form, whatever the buffer holds this replay
+        sparse = i == last and touched_rows is not None and (padded or touched_rows.numel() > 0) and self.table is not None and self.sparse_cap
         if sparse:
             off, n, _ = self.table
             assert off == 0 and ranges[0][0] == 0
@@ -352,7 +378,9 @@ class GradSync:
 
         def run():
             self._ranges(ranges)
-            if sparse:
+            if sparse and padded:
+                self._sparse_rows_padded(touched_rows)
+            elif sparse:
                 self._sparse_rows(touched_rows, cap=self.sparse_cap * cap_scale)
         self._on_side(run)
 
@@ -663,7 +691,7 @@ class PretrainStep:
         cs.t_next = t_next
         return cs
 
-    def capture_student(self, cur, t_cur, rw=None, keep=None, rccl_in_graph=True):
+    def capture_student(self, cur, t_cur, rw=None, keep=None, rccl_in_graph=True, touched_static=None):
         """the student's step on `cur` against the teacher outputs `t_cur` (static buffers a teacher graph fills): one graph holding the
         whole step on one GPU; under data parallelism three graphs cut where the gradient buckets are final + the optimizer's graph,
         replayed by `replay_student` with the RCCL calls between them"""
@@ -677,13 +705,16 @@ class PretrainStep:
         # keep the cut-graph form below (`rccl_in_graph=False`).  MAGIC_DDP_GRAPH_RCCL=0 selects the cut-graph form everywhere.
         if two and rccl_in_graph and os.environ.get("MAGIC_DDP_GRAPH_RCCL", "1") != "0" and self.sync.stream is not None and self.sync.rccl is not None:
             gS = torch.cuda.CUDAGraph()
-            touched = self._touched_rows(task, plan)
+            # touched_static: a -1-padded id buffer the caller refills before every replay (streamed batches: GradSync._sparse_rows_padded); else the
+            # resident batch's own rows, fixed for the life of the graph; None / mlm: the dense table
+            padded = touched_static is not None and task != "mlm" and bool(self.sync.sparse_cap)
+            touched = touched_static if padded else self._touched_rows(task, plan)
             with self._graph_ctx(gS):
                 drawn = self.mkrw()
                 rw_ = drawn if rw is None else rw
                 self._zero_grad()
                 out = self.student(batch, task, compute_loss=True, teacher_outputs=t_cur, rw=rw_, plan=plan, inputs=t_cur["inputs"])
-                self.student.backward(on_bucket=lambda i, ctx: self.sync.reduce_bucket(i, touched if i == 2 else None))
+                self.student.backward(on_bucket=lambda i, ctx: self.sync.reduce_bucket(i, touched if i == 2 else None, padded=padded))
                 self._opt_step(self.sync.finish())
             cs = CapturedStep(gS, out, plan["traj_steps"], True, keep=keep if keep is not None else (cur, t_cur, rw, touched))
             cs.graph2 = cs.graph3 = cs.graph_opt = None

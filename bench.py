@@ -741,7 +741,9 @@ def main():
                 gn_task[task] = trainer.opt.grad_norm_report()        # the last replayed step of this loop was a `task` step
         steady["ms_per_step_by_task"] = by_task
         steady["grad_norm_by_task"] = gn_task
-    trainer_rccl = (trainer.sync.rccl is not None, bool(a.mode == "graph" and getattr(graphs[0], "rccl_in_graph", False)) if a.mode == "graph" else False)
+    in_graph = (bool(getattr(graphs[0], "rccl_in_graph", False)) if a.mode == "graph" else
+                bool(stream_step is not None and any(getattr(getattr(e, "cs", None), "rccl_in_graph", False) for e in stream_step.cache.values())))
+    trainer_rccl = (trainer.sync.rccl is not None, in_graph)
     health = trainer.check_health()          # raises if an in-launch hand-off of the row-split encoder kernels ever gave up
     gate = gate_now
     if gate is not None:

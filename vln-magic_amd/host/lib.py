@@ -575,6 +575,28 @@ def lockstep(fn_a, fn_b, side=None):
     return a, box["b"]
 
 
+class capture(torch.cuda.graph):
+    """`torch.cuda.graph` with Python's cyclic garbage collector OFF for the duration of the capture.  torch collects garbage itself right BEFORE a capture
+    begins, but allocations inside a long capture can trigger a collection again, and finalizing an unrelated dead object there (a HIP graph of an earlier
+    test / an evicted bucket graph, an event) runs HIP calls the capturing stream does not permit: the destructor throws, the process aborts ("Fatal Python
+    error: Aborted ... Garbage-collecting", seen once in round 6 in a full GPU suite run, inside StreamStep's capture).  The garbage is collected after the capture ends."""
+
+    def __enter__(self):
+        import gc
+        self._gc_was = gc.isenabled()
+        r = super().__enter__()
+        gc.disable()
+        return r
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return super().__exit__(*exc)
+        finally:
+            if self._gc_was:
+                gc.enable()
+
+
 def set_f32_mfma(mode):
     """contraction arithmetic of the fp32 storage mode: 'exact' (v_mfma_f32_16x16x4_f32) or 'bf16x3' (split-bf16, three bf16 MFMAs per
     product, ~2^-17 relative error).  Process-wide; returns the previous mode."""

@@ -17,6 +17,7 @@ argmax -- is captured ONCE with static shapes and replayed:
 import numpy as np
 import torch
 
+from .lib import capture as _capture
 from . import ops as O
 from .nav_plan import NavPlanner
 
@@ -145,7 +146,7 @@ class GreedyNavigator:
                     self.stream.synchronize()
                     self.log.zero_()
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=self.stream, capture_error_mode="relaxed"):
+                    with _capture(g, stream=self.stream, capture_error_mode="relaxed"):
                         self._step()
                     self.graph = g
                 self.graph.replay()

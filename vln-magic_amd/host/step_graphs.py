@@ -29,6 +29,7 @@ tests/test_step_graphs_gpu.py compares losses, trajectories and every parameter 
 import numpy as np
 import torch
 
+from .lib import capture as _capture
 from . import lanes
 from . import lib as L
 from . import ops as O
@@ -322,7 +323,7 @@ class StepGraphs:
         was = gc.isenabled()
         gc.disable()
         try:
-            with torch.cuda.graph(g, pool=inst.pool, stream=self.stream, capture_error_mode="relaxed"):
+            with _capture(g, pool=inst.pool, stream=self.stream, capture_error_mode="relaxed"):
                 body()
         finally:
             if was:

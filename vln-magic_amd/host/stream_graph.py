@@ -14,6 +14,7 @@ import pickle
 import numpy as np
 import torch
 
+from .lib import capture as _capture
 from .loader import unpack
 from .model_pretrain import DYN_TERMS
 from .plan import check_plan
@@ -123,7 +124,7 @@ class StreamStep:
         torch.cuda.synchronize()
         t_cap = time.perf_counter()          # (after the drain: the steps the host had queued ahead are training time, not capture time)
         e.gT = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(e.gT, stream=tr.side, capture_error_mode="relaxed"):
+        with _capture(e.gT, stream=tr.side, capture_error_mode="relaxed"):
             if tr.student.will_fuse_encoders(e.plan):      # (every bucket of one stream pads to the same L, V: S_i fuses iff this plan does)
                 from . import ops as O
                 O.encoder_start_gate(tr.gate)   # T_{i+1} starts once S_i's whole-encoder launch has its workgroups resident (trainer.capture_split)

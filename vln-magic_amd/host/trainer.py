@@ -19,6 +19,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from .lib import capture as _capture
 from . import ops as O
 from .plan import build_plan
 
@@ -554,7 +555,7 @@ class PretrainStep:
     def _graph_ctx(self, g):
         # relaxed: helper threads launch into the capture (lib.lockstep).  Stream priorities were tried and rejected: a
         # high-priority capture stream for the student chain (teacher at normal priority) made replays 1.7x SLOWER.
-        return torch.cuda.graph(g, capture_error_mode="relaxed")
+        return _capture(g, capture_error_mode="relaxed")
 
     def mkrw(self):
         """MKRW ability weights softmax(randn(5)/rw_temp)*5 (map_nav_src/r2r/agent.py:866-871) AND the step's dropout seed, drawn ON the
@@ -741,13 +742,13 @@ class PretrainStep:
         if two:
             # ... and the text / panorama half is cut once more where the middle bucket is final (two rounds in): graph 2 | graph 3
             gS2, gS3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            state = {"ctx": torch.cuda.graph(gS2, pool=gS.pool(), capture_error_mode="relaxed")}
+            state = {"ctx": _capture(gS2, pool=gS.pool(), capture_error_mode="relaxed")}
             state["ctx"].__enter__()
 
             def cut():
                 O.flush_dw(keep_active=True)
                 state["ctx"].__exit__(None, None, None)
-                state["ctx"] = torch.cuda.graph(gS3, pool=gS.pool(), capture_error_mode="relaxed")
+                state["ctx"] = _capture(gS3, pool=gS.pool(), capture_error_mode="relaxed")
                 state["ctx"].__enter__()
             try:
                 self.student.backward_phase2(on_cut=cut)
@@ -758,7 +759,7 @@ class PretrainStep:
         cs.graph_opt = None
         if two:            # the optimizer's launches as a graph of their own, replayed once the exchange has landed (1 / world is a constant)
             cs.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cs.graph_opt, pool=gS.pool(), capture_error_mode="relaxed"):
+            with _capture(cs.graph_opt, pool=gS.pool(), capture_error_mode="relaxed"):
                 self._opt_step(1.0 / self.sync.world if self.sync.world > 1 else 1.0)
         return cs
 
@@ -796,7 +797,7 @@ class PretrainStep:
         (side stream), replayed concurrently by `replay_split` without a per-step fork/join inside one graph."""
         cs = self.capture_student(cur, t_cur, rw=rw, keep=(cur, t_cur, nxt, rw))
         gT = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gT, stream=self.side, capture_error_mode="relaxed"):
+        with _capture(gT, stream=self.side, capture_error_mode="relaxed"):
             if self.student.will_fuse_encoders(cur[2]):
                 O.encoder_start_gate(self.gate)   # the student's whole-encoder launch (on `cur`) first: csrc/encoder.hip magic_encoder_start_gate
             t_next = self.teacher_forward(*nxt)

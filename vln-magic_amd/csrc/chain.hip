@@ -26,8 +26,33 @@
 
 #define CH 256
 #define CI 1024
+#ifdef CHAIN_LDS_SW
+// round 6 A/B (profiles/micro/r06_ab_chain_lds_sw.txt): XOR-swizzled images for chain_fwd_kernel's A operands.  With the padded pitch (33 / 129 slots) every
+// 16-lane group of a ds_read_b128 fragment read -- lanes {0-3, 12-15 (k group 0), 20-27 (k group 1)} etc. -- has ONE lane pair on the same 16-byte slot
+// (rows r and r' = r + 8 - 16 g differ by the slot the k group adds): 2 cycles per group instead of 1, the kernel's 0.36 LDS-conflict share.  Rows of
+// exactly 256 / 1024 elements with 16-byte chunk c of row r stored at c ^ (r & 15) put the 16 lanes of every group on 16 distinct slots.
+#define KP 256        // (the 32-row kernel's pitches; the 64-row kernel keeps the padded CP below)
+#define KG 1024
+#define CADDR(row, col, pitch) ((row) * (pitch) + (((((col) >> 3) ^ ((row) & 15))) << 3) + ((col) & 7))
+#else
+#define KP 264
+#define KG 1032
+#define CADDR(row, col, pitch) ((row) * (pitch) + (col))
+#endif
 #define CP 264        // row pitch of the [16][256] images: 528 B = 33 16-byte slots
 #define CG 1032       // row pitch of the [16][1024] GELU image: 2064 B = 129 slots
+// A fragment of 16 rows x 32 k from a (possibly swizzled) image
+template <typename Hh> __device__ __forceinline__ h16x8<Hh> cfrag(const Hh* s, int pitch, int row0, int k0, int lane) {
+  return *(const h16x8<Hh>*)(s + CADDR(row0 + (lane & 15), k0 + 8 * (lane >> 4), pitch));
+}
+// cooperative copy of rows x cols from a (possibly swizzled) LDS image to global rows (16-byte vectors)
+template <typename Hh> __device__ __forceinline__ void ccopy_out(const Hh* s, int pitch, Hh* g, long long ldg, int rows, int cols, int tid) {
+  const int cpr = cols / 8;
+  for (int id = tid; id < rows * cpr; id += NWAVE * 64) {
+    const int r = id / cpr, c = (id % cpr) * 8;
+    *(h16x8<Hh>*)(g + (long long)r * ldg + c) = *(const h16x8<Hh>*)(s + CADDR(r, c, pitch));
+  }
+}
 
 struct ChainParams {
   int M, ld_in, Np, pad_;
@@ -63,7 +88,7 @@ __device__ __forceinline__ void chain_norm(f32x4 (&acc)[CRT][2], const float* sP
     for (int r = 0; r < 4; ++r) {
       const int row = rt * 16 + 4 * g + r;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) acc[rt][ct][r] += bv[ct] + to_f(sR[row * CP + (2 * w + ct) * 16 + c16]);
+      for (int ct = 0; ct < 2; ++ct) acc[rt][ct][r] += bv[ct] + to_f(sR[CADDR(row, (2 * w + ct) * 16 + c16, KP)]);
       s[rt][r] = g16_sum(acc[rt][0][r] + acc[rt][1][r]);
     }
   if (c16 == 0) {
@@ -103,7 +128,7 @@ __device__ __forceinline__ void chain_norm(f32x4 (&acc)[CRT][2], const float* sP
       const float rstd = rsqrtf(t * (1.0f / CH) + eps);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
-        sOut[rr * CP + (2 * w + ct) * 16 + c16] = (rr < nq) ? from_f<Hh>((acc[rt][ct][r] - mean[rt][r]) * rstd * gv[ct] + btv[ct]) : (Hh)0.0f;
+        sOut[CADDR(rr, (2 * w + ct) * 16 + c16, KP)] = (rr < nq) ? from_f<Hh>((acc[rt][ct][r] - mean[rt][r]) * rstd * gv[ct] + btv[ct]) : (Hh)0.0f;
     }
 }
 
@@ -114,7 +139,7 @@ __device__ __forceinline__ void chain_rows_in(const Hh* src, long long ld, int n
   for (int id = tid; id < CROWS * (CH / 8); id += NWAVE * 64) {
     const int r = id / (CH / 8), c = (id % (CH / 8)) * 8;
     const u4 v = r < nq ? *(const u4*)(src + r * ld + c) : (u4){0u, 0u, 0u, 0u};
-    *(u4*)(dst + r * CP + c) = v;
+    *(u4*)(dst + CADDR(r, c, KP)) = v;
   }
 }
 
@@ -161,10 +186,10 @@ __device__ long long chain_ticks[16];          // wall_clock64 (100 MHz) marks o
 template <typename Hh, bool FFN>
 __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile, unsigned char* smem) {
   Hh* sIn = (Hh*)smem;                      // [CROWS][CP]  stage-1 input; later the block output y2
-  Hh* sRes = sIn + CROWS * CP;              // [CROWS][CP]  residual of stage 1
-  Hh* sY1 = sRes + CROWS * CP;              // [CROWS][CP]
-  Hh* sG = sY1 + CROWS * CP;                // [CROWS][CG]  GELU output; later the projection image [CROWS][Np + 8]
-  float* red = (float*)(sG + CROWS * CG);   // [2][8][CROWS]
+  Hh* sRes = sIn + CROWS * KP;              // [CROWS][CP]  residual of stage 1
+  Hh* sY1 = sRes + CROWS * KP;              // [CROWS][CP]
+  Hh* sG = sY1 + CROWS * KP;                // [CROWS][CG]  GELU output; later the projection image [CROWS][Np + 8]
+  float* red = (float*)(sG + CROWS * KG);   // [2][8][CROWS]
   float* sPar = red + 2 * NWAVE * CROWS;    // ba | g1 | b1 | bo2 | g2 | b2 (256 each) | bi (1024) | bp (<= 768): every small parameter, staged ONCE --
                                             // a global load between the weight chunks makes the compiler drain the whole ring (vmcnt(0)) before its use
   const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -202,14 +227,14 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-        for (int rt = 0; rt < CRT; ++rt) acc[rt][i] = emma(lfrag(sIn, CP, rt * 16, ks * 32, lane), ring[i % CNB][ks], acc[rt][i]);
+        for (int rt = 0; rt < CRT; ++rt) acc[rt][i] = emma(cfrag(sIn, KP, rt * 16, ks * 32, lane), ring[i % CNB][ks], acc[rt][i]);
       KSTEP_FENCE();
     }
     chain_norm(acc, sPar, sRes, red, sY1, nq, p.eps, w, lane);
   }
   __syncthreads();
   CH_MARK(2);
-  if (p.y1) copy_out(sY1, CP, (Hh*)p.y1 + (long long)row0 * CH, CH, nq, CH, tid);
+  if (p.y1) ccopy_out(sY1, KP, (Hh*)p.y1 + (long long)row0 * CH, CH, nq, CH, tid);
   const Hh* sLast = sY1;
   if constexpr (FFN) {
     // ================= 2a: g = gelu(y1 W1^T + bi): 8 column tiles per wave =================
@@ -228,11 +253,11 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(lfrag(sY1, CP, rt * 16, ks * 32, lane), ring[(2 + ct) % CNB][ks], acc[rt]);
+          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(cfrag(sY1, KP, rt * 16, ks * 32, lane), ring[(2 + ct) % CNB][ks], acc[rt]);
 #pragma unroll
         for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sG[(rt * 16 + 4 * g + r) * CG + col] = from_f<Hh>(gelu_fast(acc[rt][r] + bfc));
+          for (int r = 0; r < 4; ++r) sG[CADDR(rt * 16 + 4 * g + r, col, KG)] = from_f<Hh>(gelu_fast(acc[rt][r] + bfc));
         KSTEP_FENCE();
       }
     }
@@ -251,7 +276,7 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
           for (int rt = 0; rt < CRT; ++rt) {
-            const h16x8<Hh> a = lfrag(sG, CG, rt * 16, (4 * ch + ks) * 32, lane);
+            const h16x8<Hh> a = cfrag(sG, KG, rt * 16, (4 * ch + ks) * 32, lane);
             acc[rt][0] = emma(a, ring[(10 + ch) % CNB][ks], acc[rt][0]);
             acc[rt][1] = emma(a, ring[(10 + ch) % CNB][4 + ks], acc[rt][1]);
           }
@@ -261,7 +286,7 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
     }
     __syncthreads();
     CH_MARK(4);
-    copy_out(sIn, CP, (Hh*)p.y2 + (long long)row0 * CH, CH, nq, CH, tid);
+    ccopy_out(sIn, KP, (Hh*)p.y2 + (long long)row0 * CH, CH, nq, CH, tid);
     sLast = sIn;
   }
   if (nct) {
@@ -281,7 +306,7 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(lfrag(sLast, CP, rt * 16, ks * 32, lane), ring[(S3 + j) % CNB][ks], acc[rt]);
+          for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(cfrag(sLast, KP, rt * 16, ks * 32, lane), ring[(S3 + j) % CNB][ks], acc[rt]);
 #pragma unroll
         for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
@@ -597,7 +622,7 @@ __global__ __launch_bounds__(512) void chain64_fwd_kernel(ChainPair pr) {
 }
 static size_t chain64_lds_bytes() { return (size_t)(4 * C6ROWS * CP) * 2 + (40 * C6ROWS + 6 * CH + CI + 3 * CH) * sizeof(float); }
 
-static size_t chain_lds_bytes() { return (size_t)(3 * CROWS * CP + CROWS * CG) * 2 + (2 * NWAVE * CROWS + 6 * CH + CI + 3 * CH) * sizeof(float); }
+static size_t chain_lds_bytes() { return (size_t)(3 * CROWS * KP + CROWS * KG) * 2 + (2 * NWAVE * CROWS + 6 * CH + CI + 3 * CH) * sizeof(float); }
 
 static bool chain_valid(const ChainParams& p) {
   if (p.M <= 0 || !p.in || !p.res || !p.Wa || !p.ba || !p.g1 || !p.b1 || p.ld_in < CH || (p.ld_in & 7)) return false;

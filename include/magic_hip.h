@@ -553,6 +553,9 @@ typedef struct {
   int mode, N, ntile, ldp;
   const void* qkv_a; const void* P_a; const void* o_a; const void* dctx_a; const float* dP_init; void* dqkv_out;
   unsigned site_attn, pad_;
+  /* graph-distance bias of the map encoder's self-attention (`graph_sprels`, r2r_magic_model_config.json:28): dist [nsamp, N, N] fp32 or NULL (then both
+   * gradient pointers NULL); d sprel_linear.weight / .bias are ADDED (one atomic pair per workgroup), as magic_attn_bwd does */
+  const float* dist; float* dsprel_w; float* dsprel_b;
 } magic_rowbwd_seg;
 typedef struct { magic_rowbwd_seg seg[2]; int nseg, blocks0; float p_hidden; int pad1; const unsigned* seed; float p_attn, scale; } magic_rowbwd_params;
 int magic_rowbwd_supported(int dtype, int H, int I);

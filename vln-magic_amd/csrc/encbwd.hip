@@ -39,6 +39,9 @@ template <typename Hh> struct RbwSegT {
   const Hh* qkv_a; const Hh* P_a; const Hh* o_a; const Hh* dctx_a; const float* dP_init;     // block j+1: [M, 3H], [nsamp, 2, N, ldp], [M, H], [M, H]; optional fp32 seed
   Hh* dqkv_out;                                                    // [M, 3H]: the dY operand of dWqkv
   unsigned site_attn, pad_;
+  // graph-distance bias of the map encoder's self-attention (softmax(... + w dist + b), r2r_magic_model_config.json:28): dist [nsamp, N, N] fp32 or NULL;
+  // its two gradients are added here (one atomic pair per workgroup), as magic_attn_bwd does
+  const float* dist; float* dsprel_w; float* dsprel_b;
 };
 template <typename Hh> struct RbwParamsT { RbwSegT<Hh> seg[2]; int nseg, blocks0; float p_hidden; int pad1; const unsigned* seed; float p_attn, scale; };
 typedef RbwParamsT<bf16> RbwParams; typedef RbwSegT<bf16> RbwSeg;      // host side: pointers only, one layout for both 16-bit types
@@ -249,6 +252,7 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
       }
     }
   };
+  float a0 = 0.f, a1 = 0.f;            // sprel_linear gradients (as-queries role only: every (query, key) pair of the sample exactly once over its tiles)
   RBW_MARK(16);
   img_issue(0);
   vp_issue(0);
@@ -284,8 +288,10 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
             const float m = ok ? drop_mul(ds, (unsigned)(prow * N + key)) : 0.f;
             d *= m; pm = pp * m;
           }
-          o4[r] = from_f<Hh>(pp * (d - rsq) * p.scale);
+          const float dsu = pp * (d - rsq);
+          o4[r] = from_f<Hh>(dsu * p.scale);
           pm4[r] = from_f<Hh>(pm);
+          if (sg.dist && asq && ok) { a0 += dsu * sg.dist[((long long)b * N + q) * N + key]; a1 += dsu; }
         }
         if (asq) *(v4*)(sdS + c16 * AT_PS + key0) = o4;
         else {
@@ -312,6 +318,19 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
     RBW_MARK(19 + 3 * h);
   }
   copy_out(sDq, QS, sg.dqkv_out + (row0 + ti * 16) * (3 * EH), 3 * EH, nv, 3 * EH, tid);
+  if (sg.dist) {                        // (sRs is dead: the head loop ended on a barrier)
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    if (lane == 0) { sRs[w] = a0; sRs[NWAVE + w] = a1; }
+    __syncthreads();
+    if (tid == 0) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NWAVE; ++i) { s0 += sRs[i]; s1 += sRs[NWAVE + i]; }
+      atomicAdd(sg.dsprel_w, s0);
+      atomicAdd(sg.dsprel_b, s1);
+    }
+    __syncthreads();
+  }
   RBW_MARK(23);
 }
 
@@ -633,6 +652,7 @@ extern "C" int magic_rowbwd(int dtype, const void* params, int nbytes, void* str
       for (const void* q : need)
         if (!q || ((uintptr_t)q & 15)) return MAGIC_ERR_ARG;
       if (((uintptr_t)sg.dP_init & 15) || (long long)(sg.M / sg.N) * ENH * sg.N * sg.N > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
+      if ((sg.dist == nullptr) != (sg.dsprel_w == nullptr) || (sg.dist == nullptr) != (sg.dsprel_b == nullptr)) return MAGIC_ERR_ARG;
       if (sg.mode == 2) {             // bottom of a stack: attention backward + dx0 only
         const int nb2 = (sg.M / sg.N) * sg.ntile;
         if (s == 0) p.blocks0 = nb2;

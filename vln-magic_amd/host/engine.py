@@ -1211,7 +1211,21 @@ class MagicNet:
             _, dsprel = self._sprel() if (c.which == "global" and c.dist is not None) else (None, None)
             lc = c.layers[-1]
             st.append(Ctx(c=c, fmt=enc + "encoder.crossattention.{}.", j=len(c.layers) - 1, M=lc.Bn * lc.Nq, Mk=lc.Bn * lc.Nk, dP=dP, d_top=d_top,
-                          d_acc=d_acc, dsprel=dsprel, pre=None, dqkv=None, dao=None, dx0=None))
+                          d_acc=d_acc, dsprel=dsprel, pre=None, dqkv=None, dao=None, dx0=None, due=None))
+        # round 6: a block's SELF-attention backward inside the next launch of its encoder (the full chain of the block below, or at the bottom the
+        # input-gradient product) instead of as a launch of its own: csrc/encbwd.hip attn_tile_stage, one workgroup per 16-row tile of a sample's map /
+        # viewpoint tokens, the graph-distance bias gradients included
+        inside = O.RBW_ATTN_MODE != 0 and all(O.rowbwd_attn_ok(self.dtype, H, I, self.nh, s.c.layers[-1].Nq) and
+                                              O.attn_supported(self.dtype, s.c.layers[-1].Nq, s.c.layers[-1].Nq, True) for s in st)
+
+        def attn_fields(s, lc, W, out_prev):
+            sa = lc.sa
+            out_prev.dqkv = self.new(s.M, 3 * H)
+            f = dict(N=sa.N, ldp=sa.ldp, qkv_a=sa.qkv, P_a=sa.Ppre, o_a=sa.ctx, dctx_a=out_prev.dctx, dqkv_out=out_prev.dqkv,
+                     site_attn=sa.adrop[2] if sa.adrop else 0, WqkvT_n=W.qkv.WTf, dao_n=out_prev.dao)
+            if sa.dist is not None:
+                f.update(dist=sa.dist, dsprel_w=s.dsprel[0], dsprel_b=s.dsprel[1])
+            return f, 2.0 * sa.rows * 3 * H * H + 8.0 * sa.aflops
 
         d = self.drop
         seed, ph = (d[0] if d else None), (d[1] if d else 0.0)
@@ -1237,6 +1251,12 @@ class MagicNet:
                     out.dfo, out.dfod = self.new(M, H), self.new(M, H)
                     seg.update(dqkv_n=s.d_top, kt=0, WqkvT_n=W.f2.WTf, dao_n=s.d_top, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db)
                     s.d_top = None
+                elif s.due is not None:          # the self-attention backward of block j + 1 runs in front of this chain (its short chain left d_ctx / d_ao)
+                    lc1, W1, out1 = s.due
+                    out.dfo, out.dfod = self.new(M, H), self.new(M, H)
+                    af, fl = attn_fields(s, lc1, W1, out1)
+                    seg.update(mode=1, dfo=out.dfo, dfod=out.dfod, dg2=n2.dg, db2=n2.db, **af)
+                    flops += fl
                 else:
                     qn = self.lin(s.fmt.format(j + 1) + "attention.self.query.weight", rows=3 * H, cols=H)
                     out.dfo, out.dfod = self.new(M, H), self.new(M, H)
@@ -1245,7 +1265,12 @@ class MagicNet:
                 seg["flops"] = flops
                 segs.append(seg)
                 act.append((s, lc, W, n1, out))
-            O.rowbwd(segs, seed, ph)                                   # full chain
+            O.rowbwd(segs, seed, ph, p_attn=d[2] if d else 0.0, scale=1.0 / math.sqrt(HD))         # full chain (+ the deferred self-attention backward of the block above)
+            for s in st:
+                if s.due is not None:
+                    lc1, W1, out1 = s.due
+                    O.linear_dw(out1.dqkv, lc1.sa.x, W1.qkv.dW, W1.qkv.db, s.M, flop_rows=lc1.sa.rows)
+                    s.due = None
             top = j == len(st[0].c.layers) - 1
             self._grouped([lambda s=s, lc=lc, out=out: self._attn_bwd(
                 lc.Ppre, lc.ldp, out.dcctx, lc.q, H, lc.kv, lc.kv[:, H:], 2 * H, out.dq, H, out.dkv, out.dkv[:, H:], 2 * H, lc.Bn, lc.Nq, lc.Nk,
@@ -1260,7 +1285,8 @@ class MagicNet:
                                  dg2=n1.dg, db2=n1.db, WoT=W.o.WTf, dfo=out.dao, dfod=out.daod, dctx=out.dctx,
                                  site_out=sa.hdrop[2] if sa.hdrop else 0, flops=2.0 * sa.rows * 2 * H * H))
             O.rowbwd(segs, seed, ph)                                   # short chain
-            self._grouped([lambda s=s, lc=lc, out=out: self._attn_bwd(
+            if not inside:
+              self._grouped([lambda s=s, lc=lc, out=out: self._attn_bwd(
                 lc.sa.Ppre, lc.sa.ldp, out.dctx, lc.sa.qkv, 3 * H, lc.sa.qkv[:, H:], lc.sa.qkv[:, 2 * H:], 3 * H,
                 out.dqkv, 3 * H, out.dqkv[:, H:], out.dqkv[:, 2 * H:], 3 * H, lc.Bn, lc.Nq, lc.Nq, lc.sa.dist, s.dsprel, None, lc.sa.aflops,
                 lc.sa.adrop, lc.sa.P if lc.sa.adrop else None) for s, lc, W, n1, out in act],
@@ -1273,9 +1299,22 @@ class MagicNet:
                 O.linear_dw(out.dq, sa.a, W.cq.dW, W.cq.db, M, flop_rows=lc.rows)
                 O.linear_dw(out.dkv, lc.ctx, W.ckv.dW, W.ckv.db, s.Mk, flop_rows=lc.crow)
                 O.linear_dw(out.daod, sa.ctx, W.o.dW, W.o.db, M, flop_rows=sa.rows)
-                O.linear_dw(out.dqkv, sa.x, W.qkv.dW, W.qkv.db, M, flop_rows=sa.rows)
-                s.dqkv, s.dao = out.dqkv, out.dao
-            if j == 0:
+                if inside:
+                    s.due = (lc, W, out)          # (its dQKV -- and dWqkv -- come out of the next launch of this encoder)
+                else:
+                    O.linear_dw(out.dqkv, sa.x, W.qkv.dW, W.qkv.db, M, flop_rows=sa.rows)
+                    s.dqkv, s.dao = out.dqkv, out.dao
+            if j == 0 and inside:                # bottom: the self-attention backward of block 0 + the gradient wrt the encoders' inputs, one launch
+                segs = []
+                for s, lc, W, n1, out in act:
+                    af, fl = attn_fields(s, lc, W, out)
+                    s.dx0 = self.new(s.M, H)
+                    segs.append(dict(M=s.M, mode=2, dfo=s.dx0, flops=fl, **af))
+                O.rowbwd(segs, seed, ph, p_attn=d[2] if d else 0.0, scale=1.0 / math.sqrt(HD))
+                for s, lc, W, n1, out in act:
+                    O.linear_dw(out.dqkv, lc.sa.x, W.qkv.dW, W.qkv.db, s.M, flop_rows=lc.sa.rows)
+                    s.due = None
+            elif j == 0:
                 def dx0(s, lc, W, out):
                     s.dx0 = O.linear_dx(out.dqkv, W.qkv.W, s.M, residual=out.dao, flop_rows=lc.sa.rows)
                 self._grouped([lambda s=s, lc=lc, W=W, out=out: dx0(s, lc, W, out) for s, lc, W, n1, out in act])

@@ -239,13 +239,15 @@ RBW_PTRS = ("dqkv_n", "WqkvT_n", "dao_n", "dfo_in", "dfod_in", "y2", "rstd2", "g
             "y1", "rstd1", "g1", "b1", "dg1", "db1", "WoT", "dfo", "dfod", "dz", "daod", "dao", "dctx")
 
 
+RBW_DIST_PTRS = ("dist", "dsprel_w", "dsprel_b")          # the map encoder's graph-distance bias: its two gradients come out of the in-launch attention backward
 RBW_ATT_PTRS = ("qkv_a", "P_a", "o_a", "dctx_a", "dP_init", "dqkv_out")      # round 6: the attention backward of the block above inside the launch
 
 
 class RbwSeg(C.Structure):
     """mirror of `magic_rowbwd_seg` (include/magic_hip.h)"""
     _fields_ = ([("M", i32), ("kt", i32)] + [(n, vp) for n in RBW_PTRS] + [("site_out", u32), ("site_ao", u32)] +
-                [("mode", i32), ("N", i32), ("ntile", i32), ("ldp", i32)] + [(n, vp) for n in RBW_ATT_PTRS] + [("site_attn", u32), ("pad_", u32)])
+                [("mode", i32), ("N", i32), ("ntile", i32), ("ldp", i32)] + [(n, vp) for n in RBW_ATT_PTRS] + [("site_attn", u32), ("pad_", u32)] +
+                [(n, vp) for n in RBW_DIST_PTRS])
 
 
 class RbwParams(C.Structure):

@@ -1072,7 +1072,7 @@ def rowbwd(segs, seed, p_hidden, p_attn=0.0, scale=0.125):
         S.mode = int(sg.get("mode", 0))
         if S.mode:
             S.N, S.ldp, S.ntile, S.site_attn = int(sg["N"]), int(sg["ldp"]), (int(sg["N"]) + 15) // 16, int(sg.get("site_attn", 0))
-            for k in L.RBW_ATT_PTRS:
+            for k in L.RBW_ATT_PTRS + L.RBW_DIST_PTRS:
                 setattr(S, k, L.P(sg.get(k)))
         if FLOPS["enabled"]:
             FLOPS["total"] += sg["flops"]

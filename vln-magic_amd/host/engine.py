@@ -1215,7 +1215,11 @@ class MagicNet:
         # round 6: a block's SELF-attention backward inside the next launch of its encoder (the full chain of the block below, or at the bottom the
         # input-gradient product) instead of as a launch of its own: csrc/encbwd.hip attn_tile_stage, one workgroup per 16-row tile of a sample's map /
         # viewpoint tokens, the graph-distance bias gradients included
-        inside = O.RBW_ATTN_MODE != 0 and all(O.rowbwd_attn_ok(self.dtype, H, I, self.nh, s.c.layers[-1].Nq) and
+        # MEASURED AND NOT KEPT as the default (MAGIC_RBW_ATTN=3 selects it; `profiles/micro/r06_ab_rbwattn_cross.txt`): 1.447-1.456 vs 1.431-1.438 ms/step -- a
+        # 22-node map / 39-token viewpoint sample is two / three 16-row tiles, the last nearly empty, so the launch grows by a quarter while the
+        # attention it absorbs is a 13 us launch -- and rowsum(P dP) taken as dO . O (bf16 O) leaves each dS row a rounding residue that the
+        # sprel_linear gradients SUM over all rows (12 % off on `sprel_linear.weight` under dropout; the row-wise form's rows sum to zero exactly)
+        inside = O.RBW_ATTN_MODE == 3 and all(O.rowbwd_attn_ok(self.dtype, H, I, self.nh, s.c.layers[-1].Nq) and
                                               O.attn_supported(self.dtype, s.c.layers[-1].Nq, s.c.layers[-1].Nq, True) for s in st)
 
         def attn_fields(s, lc, W, out_prev):

@@ -149,7 +149,7 @@ __device__ long long rbw_ticks[32];            // wall_clock64 (100 MHz) marks o
 #define AT_PS 104         // [16][<= 96] dS / dS^T / (P o mask)^T tiles
 #define AT_ROWS 96
 static inline size_t attn_stage_lds() { return (size_t)(3 * AT_ROWS * AT_DS + 3 * 16 * AT_PS) * 2 + AT_ROWS * sizeof(float); }
-template <typename Hh>
+template <typename Hh, bool DIST>          // DIST: the graph-distance bias gradients (an instantiation of its own: two more live registers through stage A spill)
 __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const RbwParamsT<Hh>& p, const int b, const int ti, const int nv,
                                                 Hh* sDq, unsigned char* scratch, const int tid) {
   typedef h16x4<Hh> v4;
@@ -291,7 +291,9 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
           const float dsu = pp * (d - rsq);
           o4[r] = from_f<Hh>(dsu * p.scale);
           pm4[r] = from_f<Hh>(pm);
-          if (sg.dist && asq && ok) { a0 += dsu * sg.dist[((long long)b * N + q) * N + key]; a1 += dsu; }
+          if constexpr (DIST) {
+            if (sg.dist && asq && ok) { a0 += dsu * sg.dist[((long long)b * N + q) * N + key]; a1 += dsu; }
+          }
         }
         if (asq) *(v4*)(sdS + c16 * AT_PS + key0) = o4;
         else {
@@ -318,7 +320,7 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
     RBW_MARK(19 + 3 * h);
   }
   copy_out(sDq, QS, sg.dqkv_out + (row0 + ti * 16) * (3 * EH), 3 * EH, nv, 3 * EH, tid);
-  if (sg.dist) {                        // (sRs is dead: the head loop ended on a barrier)
+  if (DIST && sg.dist) {                // (sRs is dead: the head loop ended on a barrier)
     a0 = wave_sum(a0); a1 = wave_sum(a1);
     if (lane == 0) { sRs[w] = a0; sRs[NWAVE + w] = a1; }
     __syncthreads();
@@ -337,7 +339,7 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
 // NRT = row tiles of 16 per workgroup.  2 (32 rows): two workgroups per CU, 128 registers per lane, weight fragments one chunk of four
 // k-steps ahead of their use.  4 (64 rows): one workgroup per CU, 256 registers, a whole product's fragments ahead -- and half the
 // weight bytes streamed from L2 per row (every workgroup streams all 393 KB of the block's matrices).
-template <int NRT, typename Hh, bool ATT = false>
+template <int NRT, typename Hh, int ATT = 0>          // ATT: 0 no attention stage; 1 the stage; 2 the stage with the graph-distance bias gradients
 __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned char* rb_smem) {
   constexpr int RB_ROWS = NRT * 16;
   constexpr bool DEEP = NRT >= 4;
@@ -376,7 +378,7 @@ __device__ __forceinline__ void rowbwd_body(const RbwParamsT<Hh>& p, unsigned ch
   RBW_MARK(0);
   if (mode) {          // dQKV rows of the block above: computed here, left in the z image's space (QS pitch) where the tail expects them
     const int b = blk / sg.ntile;
-    attn_tile_stage<Hh>(sg, p, b, blk - b * sg.ntile, nv, sZ, rb_smem + (size_t)RB_ROWS * GS * sizeof(Hh), tid);
+    attn_tile_stage<Hh, ATT == 2>(sg, p, b, blk - b * sg.ntile, nv, sZ, rb_smem + (size_t)RB_ROWS * GS * sizeof(Hh), tid);
     // (the stage ends on a barrier: its scratch behind the z image is dead and becomes the chain's images below)
   }
   // ---- weights of the first two products + small parameters, issued before anything else
@@ -587,7 +589,11 @@ template <typename Hh> __global__ __launch_bounds__(512, 2) void rowbwd64_kernel
 // round 6: the 16-row chain with the attention backward of the block above in front (segments with mode != 0)
 template <typename Hh> __global__ __launch_bounds__(512, 4) void rowbwd16a_kernel(RbwParamsT<Hh> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
-  rowbwd_body<1, Hh, true>(p, rb_smem);
+  rowbwd_body<1, Hh, 1>(p, rb_smem);
+}
+template <typename Hh> __global__ __launch_bounds__(512, 4) void rowbwd16ad_kernel(RbwParamsT<Hh> p) {      // ... with a graph-distance bias (map encoder)
+  extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
+  rowbwd_body<1, Hh, 2>(p, rb_smem);
 }
 static size_t rbw_lds_bytes(int rows) { return (size_t)(rows * GS + 5 * rows * XS) * 2 + (size_t)2 * NWAVE * rows * sizeof(float); }
 // rows per workgroup: MAGIC_RBW_ROWS = 16 / 32 / 64 forces one shape; default (0) = 16 rows when that still leaves the launch with no more
@@ -690,10 +696,21 @@ extern "C" int magic_rowbwd(int dtype, const void* params, int nbytes, void* str
     if (!attr_a) {
       (void)hipFuncSetAttribute((const void*)rowbwd16a_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       (void)hipFuncSetAttribute((const void*)rowbwd16a_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      (void)hipFuncSetAttribute((const void*)rowbwd16ad_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      (void)hipFuncSetAttribute((const void*)rowbwd16ad_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       attr_a = true;
     }
-    if (dtype == DT_BF16) hipLaunchKernelGGL(rowbwd16a_kernel<bf16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
-    else { RbwParamsT<f16> pf; static_assert(sizeof(pf) == sizeof(p), "layout"); memcpy(&pf, &p, sizeof(pf)); hipLaunchKernelGGL(rowbwd16a_kernel<f16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, pf); }
+    const bool with_dist = (p.seg[0].mode && p.seg[0].dist) || (p.nseg > 1 && p.seg[1].mode && p.seg[1].dist);
+    RbwParamsT<f16> pf;
+    static_assert(sizeof(pf) == sizeof(p), "layout");
+    memcpy(&pf, &p, sizeof(pf));
+    if (with_dist) {
+      if (dtype == DT_BF16) hipLaunchKernelGGL(rowbwd16ad_kernel<bf16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+      else hipLaunchKernelGGL(rowbwd16ad_kernel<f16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, pf);
+    } else {
+      if (dtype == DT_BF16) hipLaunchKernelGGL(rowbwd16a_kernel<bf16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, p);
+      else hipLaunchKernelGGL(rowbwd16a_kernel<f16>, dim3(blocks), dim3(512), shm, (hipStream_t)stream, pf);
+    }
     return launch_status();
   }
   const size_t shm = rbw_lds_bytes(rows);

@@ -149,7 +149,8 @@ __device__ long long rbw_ticks[32];            // wall_clock64 (100 MHz) marks o
 #define AT_PS 104         // [16][<= 96] dS / dS^T / (P o mask)^T tiles
 #define AT_ROWS 96
 static inline size_t attn_stage_lds() { return (size_t)(3 * AT_ROWS * AT_DS + 3 * 16 * AT_PS) * 2 + AT_ROWS * sizeof(float); }
-template <typename Hh, bool DIST>          // DIST: the graph-distance bias gradients (an instantiation of its own: two more live registers through stage A spill)
+template <typename Hh, bool DIST>          // DIST = the FULL form: graph-distance bias gradients + a gradient seeded into the attention map (dP_init).  An instantiation of its own:
+                                           // their live registers through stage A (two sums, two f32x4 seeds) spill in the lean kernel and cost the form its gain
 __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const RbwParamsT<Hh>& p, const int b, const int ti, const int nv,
                                                 Hh* sDq, unsigned char* scratch, const int tid) {
   typedef h16x4<Hh> v4;
@@ -203,7 +204,7 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += to_f(ro[it][e]) * to_f(rO[it][e]);
-      if (sg.dP_init && r < N) {            // + sum_k (P o mask)[q, k] seed[q, k]: the distillation gradient enters dP before the mask (top block only)
+      if (DIST && sg.dP_init && r < N) {    // + sum_k (P o mask)[q, k] seed[q, k]: the distillation gradient enters dP before the mask (top block only)
         const long long prow = ((long long)b * ENH + h) * N + r;
         for (int c8 = (id & 7) * 8; c8 < ldp; c8 += 64) {
           const h16x8<Hh> pv = *(const h16x8<Hh>*)(sg.P_a + prow * ldp + c8);
@@ -228,7 +229,7 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
   constexpr int AJ = (2 * (AT_ROWS / 16) + NWAVE - 1) / NWAVE;
   h16x8<Hh> av[AJ][EHD / 32];
   v4 ap[AJ];
-  f32x4 ai[AJ];
+  f32x4 ai[DIST ? AJ : 1];
   auto vp_issue = [&](const int h) {
 #pragma unroll
     for (int jj = 0; jj < AJ; ++jj) {
@@ -245,10 +246,12 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) ap[jj][r] = (Hh)0.0f;
-      ai[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (DIST) ai[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (job < 2 * NT && q < N) {
         if (key0 < ldp) ap[jj] = *(const v4*)(sg.P_a + prow * ldp + key0);
-        if (sg.dP_init && key0 < N) ai[jj] = *(const f32x4*)(sg.dP_init + prow * ldp + key0);
+        if constexpr (DIST) {
+          if (sg.dP_init && key0 < N) ai[jj] = *(const f32x4*)(sg.dP_init + prow * ldp + key0);
+        }
       }
     }
   };
@@ -281,7 +284,8 @@ __device__ __forceinline__ void attn_tile_stage(const RbwSegT<Hh>& sg, const Rbw
         for (int r = 0; r < 4; ++r) {
           const int key = key0 + r;
           const bool ok = qok && key < N;
-          float d = acc[r] + (ok ? ai[jj][r] : 0.f);
+          float d = acc[r];
+          if constexpr (DIST) d += ok ? ai[jj][r] : 0.f;
           const float pp = to_f(ap[jj][r]);
           float pm = pp;
           if (ds.on) {
@@ -700,7 +704,7 @@ extern "C" int magic_rowbwd(int dtype, const void* params, int nbytes, void* str
       (void)hipFuncSetAttribute((const void*)rowbwd16ad_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       attr_a = true;
     }
-    const bool with_dist = (p.seg[0].mode && p.seg[0].dist) || (p.nseg > 1 && p.seg[1].mode && p.seg[1].dist);
+    const bool with_dist = (p.seg[0].mode && (p.seg[0].dist || p.seg[0].dP_init)) || (p.nseg > 1 && p.seg[1].mode && (p.seg[1].dist || p.seg[1].dP_init));      // the full form
     RbwParamsT<f16> pf;
     static_assert(sizeof(pf) == sizeof(p), "layout");
     memcpy(&pf, &p, sizeof(pf));

@@ -149,6 +149,15 @@ __device__ __forceinline__ void mma_tile16(const Hh* sA, const Hh* sB, int wr, i
 // sits on a chain that is latency-bound, not LDS-bound) and does not move with the permuted natural images.  Hence the default, mode 4: swizzled
 // k-contiguous images in the K-group kernel only (its launches all have K >= 768), permuted natural images for every TN launch.
 // 0: padded images everywhere; 1: both forms everywhere; 2: swizzled k-contiguous images everywhere; 3: permuted natural images only.
+#ifndef DW_EXP
+#define DW_EXP 0          // timing experiments of the weight-gradient loop (profiles/micro/dw_launch_probe.py): 1 no MFMA / LDS reads, 2 no global re-loads, 3 no bias gradient
+#endif
+#ifndef DW_PD
+#define DW_PD 0           // (experiment) register-staged tiles in flight of the TN loop; 0: the default rule
+#endif
+#ifndef DW_WAVES
+#define DW_WAVES 1        // (experiment) amdgpu_waves_per_eu lower bound of gemm_dw_batch_kernel
+#endif
 #ifndef MAGIC_GEMM_LDS_SW
 #define MAGIC_GEMM_LDS_SW 4
 #endif
@@ -170,8 +179,10 @@ __device__ __forceinline__ void store_sw(const TileLoader<Hh, KC, 64>& l, Hh* s)
     }
   }
 }
+// bg (block-uniform; TN only): the wc = 0 waves also multiply their A fragments with a fragment of ones -- every column of accb[i] then holds the
+// column sums of dY over this k-tile (the bias gradient of the tile's 16 rows), 4 MFMAs per k-tile instead of one wave reading 64 LDS rows
 template <bool A_KC, bool B_KC, bool SWK, bool SWP_, typename Hh>
-__device__ __forceinline__ void mma_tile_sw(const Hh* sA, const Hh* sB, int wr, int wc, int lane, f32x4 (&acc)[2][2]) {
+__device__ __forceinline__ void mma_tile_sw(const Hh* sA, const Hh* sB, int wr, int wc, int lane, f32x4 (&acc)[2][2], bool bg, f32x4 (&accb)[2]) {
   constexpr bool PERM = !A_KC && !B_KC && SWP_;
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
   auto rd = [&](const Hh* s, bool kc, int out0, int ks) -> h16x8<Hh> {
@@ -195,6 +206,12 @@ __device__ __forceinline__ void mma_tile_sw(const Hh* sA, const Hh* sB, int wr, 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+    if (bg) {
+      const Hh one = from_f<Hh>(1.f);
+      const h16x8<Hh> ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) accb[i] = mfma16(a[i], ones, accb[i]);
+    }
   }
 }
 
@@ -429,7 +446,7 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
   // Register-staged software pipeline, PD tiles deep: the global loads of tiles kt+1 .. kt+PD-1 are in flight while
   // tile kt is written to LDS and multiplied.  These GEMMs run ~1 block per CU (grids of 100-600 blocks), so a
   // block has to hide HBM/L2 latency itself; hipcc turns the in-order loads into counted s_waitcnt vmcnt(N).
-  constexpr int PD = (NT_ == 2 && KG == 1) ? 3 : 2;      // K-group kernel: 16 waves per CU hide latency, and 1024 threads cap the VGPRs at 128
+  constexpr int PD = (LAYOUT == 2 && DW_PD) ? DW_PD : (NT_ == 2 && KG == 1) ? 3 : 2;      // K-group kernel: 16 waves per CU hide latency, and 1024 threads cap the VGPRs at 128
   TileLoader<T, A_KC, TM> la[PD];
   TileLoader<T, B_KC, TM> lb[PD];
   f32x4 acc[NT_][NT_];
@@ -439,6 +456,8 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
     for (int j = 0; j < NT_; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   const bool do_bgrad = (LAYOUT == 2) && p.bias_grad != nullptr && bx == 0;
+  constexpr bool BG_MFMA = SW && LAYOUT == 2;              // bias gradient on the matrix cores (see mma_tile_sw)
+  f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 
   // round r of group kg works on K-tile kt0 + r * KG + kg; a tile index past the end loads zeros (the loader's k < kend test), so
   // every group executes the same barriers
@@ -508,19 +527,30 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
           lb[d].store(sB);
         }
         __syncthreads();
+#if DW_EXP == 2
+        if (LAYOUT != 2)
+#endif
         if (r + d + PD < rounds) {
           la[d].load(A, p.lda, m0, (kt0 + (r + d + PD) * KG + kg) * BK, p.M, kend);
           lb[d].load(B, p.ldb, n0, (kt0 + (r + d + PD) * KG + kg) * BK, p.N, kend);
         }
+#if DW_EXP == 1
+        if (LAYOUT != 2)
+#endif
+        {
         if constexpr (sizeof(T) == 4) {
           if (x3) mma_tile_x3<A_KC, B_KC, NT_>((const float*)sA, (const float*)sB, wr, wc, lane, acc);
           else mma_tile<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc);
         } else if constexpr (SW) {
-          mma_tile_sw<A_KC, B_KC, SWK, SWP>(sA, sB, wr, wc, lane, acc);
+          mma_tile_sw<A_KC, B_KC, SWK, SWP>(sA, sB, wr, wc, lane, acc, BG_MFMA && do_bgrad && wc == 0, accb);
         } else {
           mma_tile<A_KC, B_KC, NT_>(sA, sB, wr, wc, lane, acc);
         }
-        if (do_bgrad && tid < TM) {
+        }
+#if DW_EXP == 3
+        if (false)
+#endif
+        if (!BG_MFMA && do_bgrad && tid < TM) {
           float s = 0.f;
           constexpr int NP = SWP ? GB_NATP : SN_;
 #pragma unroll 8
@@ -529,6 +559,20 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
         }
         __syncthreads();
       }
+    }
+  }
+  if constexpr (BG_MFMA) {
+    if (do_bgrad) {                    // column 0 of accb[i] -> bsum of thread (row) tid < 64, through LDS (the images are dead after the loop's last barrier)
+      float* red = (float*)sA;
+      if (wc == 0 && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) red[(wr * 2 + i) * 16 + (lane >> 4) * 4 + r4] = accb[i][r4];
+      }
+      __syncthreads();
+      if (tid < TM) bsum = red[tid];
+      __syncthreads();                 // (the seam reuses sA as its flag word)
     }
   }
   if constexpr (LAYOUT == 2 && NT_ == 2 && KG == 1) {
@@ -943,12 +987,15 @@ __global__ __launch_bounds__(1024) void gemm_grouped_kg_kernel(GroupedParams gp)
 // the kernel-argument block.  Every dependent launch of the replayed step costs ~9 us whatever its work (8 -> 16 problems per launch:
 // 2.93 -> 2.88 ms per step; 48 compact: 2.79; 96: 2.77), so the step's ~80 weight gradients go out in ONE launch (6.9 KB of kernel arguments).
 #define DW_MAX 96
+#ifndef DW_EXP
+#define DW_EXP 0
+#endif
 struct DwProblem { const void* A; const void* B; float* C; float* bias_grad; int M, N, K, lda, ldb, ldc, splitk, ny8;
                    int ws_slot0, cnt0, ws_total, ws_first; };       // deterministic seam (dw_seam): slots / counters of this dW's tile 0
 struct DwBatch { DwProblem p[DW_MAX]; int start[DW_MAX + 1]; int cnt[DW_MAX]; int n; float* ws; unsigned* counters; };
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_dw_batch_kernel(DwBatch gp) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_WAVES))) void gemm_dw_batch_kernel(DwBatch gp) {
   __shared__ __attribute__((aligned(16))) T sA[GBI<T>::N];
   __shared__ __attribute__((aligned(16))) T sB[GBI<T>::N];
   const int id = blockIdx.x;
@@ -963,13 +1010,22 @@ __global__ __launch_bounds__(256) void gemm_dw_batch_kernel(DwBatch gp) {
   p.nh = 1; p.batch = 1; p.splitk = d.splitk; p.c_f32 = 1; p.accumulate = 1; p.alpha = 1.f;
   p.ws = gp.ws; p.cnt = gp.counters; p.ws_slot0 = d.ws_slot0; p.cnt0 = d.cnt0; p.ws_total = d.ws_total; p.ws_first = d.ws_first;
   const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM;
-  if (d.ny8 < 0) {                   // one K-split per XCD slot group (see gemm_grouped_kernel)
+  if (d.ny8 == -1) {                 // one K-split per XCD slot group (see gemm_grouped_kernel)
     const int tiles = nx * ny;
     const int xcd = local & 7, slot = local >> 3;
     const int zr = slot / tiles, t = slot - zr * tiles;
     const int z = zr * 8 + xcd;
     if (z >= p.splitk) return;
     gemm_block<T, 2>(p, t % nx, t / nx, z, sA, sB);
+  } else if (d.ny8 == -2) {          // 1, 2 or 4 K-splits: a split's tiles on 8 / splitk neighbouring XCDs, each taking a contiguous run of tile
+    const int tiles = nx * ny;       // columns (or rows) -- see dw_xcd_groups()
+    const int G = 8 / p.splitk, per = (tiles + G - 1) / G;
+    const int xcd = local & 7, slot = local >> 3;
+    const int z = xcd / G, g = xcd - z * G, t = g * per + slot;
+    if (t >= tiles) return;
+    int bx, by;
+    if (nx >= ny) { bx = t / ny; by = t - bx * ny; } else { by = t / nx; bx = t - by * nx; }
+    gemm_block<T, 2>(p, bx, by, z, sA, sB);
   } else if (d.ny8 > 0) {
     const int per_z = nx * d.ny8;
     const int z = local / per_z, l2 = local - z * per_z;
@@ -1887,6 +1943,17 @@ extern "C" int magic_gemm_dw_ws_need(int dtype, int n, const magic_dw_desc* d, l
   return MAGIC_OK;
 }
 
+// Placement of a weight gradient with 1, 2 or 4 K-splits (round 6).  Workgroup id & 7 is the XCD a workgroup lands on, and each XCD has its own L2:
+// the plain (tile, split) order deals the 64 x 64 tiles of one split round-robin over all eight, so every XCD fetches nearly every dY / X panel of
+// the split (the launch requested 2.8x its algorithmic bytes from L2 and missed on 1.9x).  Here split z owns XCDs [z G, (z + 1) G), G = 8 / splitk,
+// and each of them takes a contiguous run of the tiles ordered along the WIDER side of dW: the panels of the narrower operand are fetched G times,
+// those of the wider one once.  MAGIC_DW_XCD_GROUPS=0 restores the old order.
+static bool dw_xcd_groups() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MAGIC_DW_XCD_GROUPS"); v = e ? atoi(e) : 1; }
+  return v != 0 && gemm_xcd_on();
+}
+
 extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, float* ws, long long ws_floats, unsigned* counters, int n_counters,
                                      void* stream) {
   if (n <= 0 || n > DW_MAX || !d) return MAGIC_ERR_ARG;
@@ -1937,6 +2004,7 @@ extern "C" int magic_gemm_dw_grouped(int dtype, int n, const magic_dw_desc* d, f
     const int nx = (p.N + BN - 1) / BN, ny = (p.M + BM - 1) / BM, nz = p.splitk;          // same placement rules as group_place()
     gp.start[i] = total;
     if (gemm_xcd_on() && p.splitk >= 8 && nx * ny >= 2) { p.ny8 = -1; gp.cnt[i] = nx * ny * ((nz + 7) / 8 * 8); }
+    else if (dw_xcd_groups() && (nz == 1 || nz == 2 || nz == 4) && nx * ny >= 2) { p.ny8 = -2; gp.cnt[i] = 8 * ((nx * ny + 8 / nz - 1) / (8 / nz)); }
     else if (gemm_xcd_on() && nx >= 2 && ny >= 16) { p.ny8 = (ny + 7) / 8 * 8; gp.cnt[i] = nx * p.ny8 * nz; }
     else { p.ny8 = 0; gp.cnt[i] = nx * ny * nz; }
     total += (gp.cnt[i] + 7) / 8 * 8;

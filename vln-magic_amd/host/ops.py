@@ -82,7 +82,8 @@ def linear_dx(dy, W, M, *, out=None, epilogue=0, aux=None, residual=None, lda=No
 
 # measured on the headline step (profiles/micro/splitk_sweep.sh): (target, min_tiles) = (256, 2) 3.34 ms, (128, 8) 3.26 ms, (128, 32) 3.45 ms --
 # fewer, longer splits also write 4x fewer fp32 atomic tiles
-SPLITK = {"target": int(os.environ.get("MAGIC_SPLITK_TARGET", "192")), "min_tiles": int(os.environ.get("MAGIC_SPLITK_MIN_TILES", "20"))}
+SPLITK = {"target": int(os.environ.get("MAGIC_SPLITK_TARGET", "192")), "min_tiles": int(os.environ.get("MAGIC_SPLITK_MIN_TILES", "20")),
+          "pow2": {"0": "", "up": "up", "down": "down"}[os.environ.get("MAGIC_SPLITK_POW2", "down")]}
 
 
 def _splitk(tiles, kred):
@@ -95,7 +96,12 @@ def _splitk(tiles, kred):
         # fp32 atomic traffic of the extra splits takes over)
         return int(max(1, min(kred // 1024, 8 if tiles <= 256 else 4)))
     ks = max(1, (kred + 64 * SPLITK["min_tiles"] - 1) // (64 * SPLITK["min_tiles"]))
-    return int(max(1, min(SPLITK["target"] // max(tiles, 1), ks, 64)))
+    sk = int(max(1, min(SPLITK["target"] // max(tiles, 1), ks, 64)))
+    if SPLITK["pow2"] and sk < 8:
+        # 1, 2 or 4 splits: csrc/gemm.hip dw_xcd_groups() then gives each split 8 / sk XCDs of its own ("up": 3 -> 4; "down": 3 -> 2)
+        lo = 1 << (sk.bit_length() - 1)
+        sk = lo if (sk == lo or SPLITK["pow2"] == "down") else 2 * lo
+    return sk
 
 
 SIDE = {"stream": None, "keep": []}     # optional side stream for the weight-gradient GEMMs (off the dX critical chain)

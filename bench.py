@@ -148,8 +148,10 @@ class _StreamSet(torch.utils.data.IterableDataset):
     generation of 30 MB of random features is not part of what is measured) and, per batch, runs the collate
     (`synth.collate`, pinned to tasks.py's) and the host half of the index plan -- the per-batch CPU work of a real loader."""
 
-    def __init__(self, batch_size, seed, n_steps, pool=3, n_vp=0, bucketed=False):
-        self.batch_size, self.seed, self.n_steps, self.pool, self.n_vp, self.bucketed = batch_size, seed, n_steps, pool, n_vp, bucketed
+    def __init__(self, batch_size, seed, n_steps, pool=3, n_vp=0, bucketed=False, epoch=0):
+        """epoch > 0: the stream repeats every `epoch` batches (a multiple of the worker count, so that a batch and its repeat come from the same worker's
+        samples) -- a dataset walked for several epochs, as the reference trains; 0: every batch is a fresh draw"""
+        self.batch_size, self.seed, self.n_steps, self.pool, self.n_vp, self.bucketed, self.epoch = batch_size, seed, n_steps, pool, n_vp, bucketed, int(epoch)
 
     def __iter__(self):
         import random
@@ -166,7 +168,10 @@ class _StreamSet(torch.utils.data.IterableDataset):
             rng = np.random.default_rng([self.seed, wid, j])
             pyrng = random.Random(self.seed * 1000003 + wid * 101 + j)
             pools.append([synth.make_sample(rng, pyrng, vocab=50265, uid=i, **(dict(img_dim=8) if self.n_vp else {})) for i in range(self.batch_size)])
-        for step in range(wid, self.n_steps, nw):
+        if self.epoch and self.epoch % nw:
+            raise ValueError(f"_StreamSet: epoch {self.epoch} is not a multiple of the {nw} workers")
+        for step_ in range(wid, self.n_steps, nw):
+            step = step_ % self.epoch if self.epoch else step_
             task = TASKS[step % 3]
             rng = np.random.default_rng([self.seed, step])
             if self.bucketed:     # ragged like a shuffled dataset: every batch is a fresh draw of samples, so sum T / K / the longest instruction vary
@@ -492,20 +497,21 @@ def secondary_block():
     # SURVEY f-3: the same pretraining step fed from DataLoader workers (NON-resident batches, PCIe-inclusive; never `value`): batches padded to
     # shape buckets, one graph replay per step (host/stream_graph.py)
     try:
-        r = subprocess.run([py, os.path.join(ROOT, "bench.py"), "--mode", "stream-graph", "--workers", "8", "--warmup", "300", "--steps", "150",
+        r = subprocess.run([py, os.path.join(ROOT, "bench.py"), "--mode", "stream-graph", "--workers", "8", "--stream-epoch", "152", "--warmup", "304", "--steps", "150",
                             "--no-cpu-baseline", "--no-parity", "--no-secondary"], capture_output=True, text=True, timeout=300, env=env)
         j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         out["streamed_batches_graph_replay"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
                                                 "ms_per_step_without_in_window_captures": j.get("ms_per_step_steady"),
                                                 "launch": j["launch"], "note": "collate + index plan in 8 DataLoader workers (the reference's n_workers, r2r_magic_pretrain.json:26), feature table in HBM, "
-                                                "one H2D record copy + one graph launch per step; the resident-batch headline is `value`"}
+                                                "one H2D record copy + one graph launch per step; the timed steps are the THIRD pass over a 152-batch epoch (a dataset walked for several "
+                                                "epochs, as the reference trains): every bucket graph they replay was captured during the first; the resident-batch headline is `value`"}
     except Exception as e:              # noqa: BLE001
         out["streamed_batches_graph_replay"] = {"error": repr(e)[:300]}
     # ... and the two together: what ONE RANK of a real data-parallel run executes every step -- streamed batches (DataLoader workers,
     # bucket graphs) AND the data-parallel structure (bucket graphs cut where the gradient buckets are final, the bucket collectives of a world-1 RCCL
     # communicator between the replays: the touched word-embedding rows change per batch, so these collectives stay outside the graphs)
     try:
-        r = subprocess.run([py, os.path.join(ROOT, "bench.py"), "--mode", "stream-graph", "--dp-structure", "--workers", "8", "--warmup", "300", "--steps", "150",
+        r = subprocess.run([py, os.path.join(ROOT, "bench.py"), "--mode", "stream-graph", "--dp-structure", "--workers", "8", "--stream-epoch", "152", "--warmup", "304", "--steps", "150",
                             "--no-cpu-baseline", "--no-parity", "--no-secondary"], capture_output=True, text=True, timeout=300, env=env)
         j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         out["rank_of_a_real_run"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
@@ -538,6 +544,9 @@ def main():
                          "copied one batch ahead on a copy stream (host/loader.py), eager launches: the PCIe-inclusive rate; stream-graph: the same "
                          "feed, batches padded to shape buckets and every step ONE graph replay (host/stream_graph.py; the first batch of a bucket "
                          "pays its capture: use a warm-up that has seen the buckets, e.g. --warmup 150 --steps 150)")
+    ap.add_argument("--stream-epoch", type=int, default=0,
+                    help="--mode stream / stream-graph: the synthetic dataset repeats every N batches (a multiple of --workers); with --warmup >= N the timed "
+                         "steps are a LATER epoch of the same batches -- every bucket graph they need was captured in the first (0: all batches distinct)")
     ap.add_argument("--workers", type=int, default=8, help="--mode stream: DataLoader worker processes (r2r_magic_pretrain.json:26 n_workers)")
     ap.add_argument("--ingest", default="table", choices=["table", "host"],
                     help="--mode stream: 'host' = the reference's way, every batch carries its fp32 view features (30 MB at B=48) from the "
@@ -670,7 +679,8 @@ def main():
     if a.mode in ("stream", "stream-graph"):
         from magic_amd.host.loader import DevicePrefetcher
         n_vp = 4096
-        ds = _StreamSet(a.batch, 1234 + rank, a.warmup + a.steps + 2, n_vp=n_vp if a.ingest == "table" else 0, bucketed=a.mode == "stream-graph")
+        ds = _StreamSet(a.batch, 1234 + rank, a.warmup + a.steps + 2, n_vp=n_vp if a.ingest == "table" else 0, bucketed=a.mode == "stream-graph",
+                        epoch=a.stream_epoch)
         ftab = None
         if a.ingest == "table":
             from magic_amd.host.feature_table import FeatureTable

@@ -19,12 +19,14 @@ arrays; the embeddings themselves never leave HBM:
 Pure numpy: tested on CPU against the reference-style loops (tests/test_navplan_cpu.py).
 """
 import math
+import os
 
 import numpy as np
 
 from .graph_map import MAX_DIST, MAX_STEP, GraphMap, angle_fts, rel_pos
 
 IGNORE = -100
+DEFER_GRAPH = os.environ.get("MAGIC_NAV_DEFER_GRAPH", "1") != "0"      # end_step's graph updates wait until begin_nav (under the panorama launch)
 
 
 def _csr_from_coo(out_rows, src_rows, w, n_out):
@@ -110,6 +112,7 @@ class NavPlanner:
         self._flat = {}                            # episode -> (flattened walked path, [segments consumed])
         self._dtw = {}                             # episode -> (nodes consumed, DTW row) of the walked path
         self._ref_idx = {}                         # episode -> its ground-truth path as indices of the scan's dense distance table
+        self._pending = []                         # (episode, observation) pairs not yet entered into the graphs (end_step -> begin_nav)
         self.t = 0
 
     def _update_graph(self, i, g, ob):
@@ -309,8 +312,14 @@ class NavPlanner:
                     vp_pos_fts=vp_pos, vp_nav_masks=vp_nav, vp_masks=vp_masks, vp_cand_vpids=vp_cand,
                     csr=csr, csr_t=csr_t, n_out=n_out, fsrc=fsrc, bw=bw, targets=targets)
 
+    def _flush_graph_updates(self):
+        pend, self._pending = self._pending, []
+        for i, ob in pend:
+            self._update_graph(i, self.gmaps[i], ob)
+
     def begin_nav(self):
         """second half: map / local tokens, embedding sources, fusion map, expert action"""
+        self._flush_graph_updates()
         if self.native is not None:
             return self._begin_nav_native()
         t, B, obs, gmaps = self.t, self.B, self.obs, self.gmaps
@@ -521,9 +530,11 @@ class NavPlanner:
             if not self.ended[i] and self.just_ended[i]:
                 self.end_obs_vp[i] = obs[i]["viewpoint"]
         self.obs = obs = self.env._get_obs(features)
-        for i, ob in enumerate(obs):
-            if not self.ended[i]:
-                self._update_graph(i, self.gmaps[i], ob)
+        # the new observations enter the episodes' graphs at the start of `begin_nav` (or `finish`), not here: `begin_pano` does not read the graphs, and
+        # the GPU idles from the moment the actions arrive until the next step's panorama launch -- the edge / relaxation work waits under that launch
+        self._pending = [(i, ob) for i, ob in enumerate(obs) if not self.ended[i]]
+        if not DEFER_GRAPH:
+            self._flush_graph_updates()
         self.ended |= np.array([a is None for a in acts])
         self.actions = acts
         self.t += 1
@@ -533,6 +544,7 @@ class NavPlanner:
         """stop_probs[t][b] = softmax(fused_logits)[b, 0] of every step: back-track each episode to its most stop-worthy
         visited node (agent.py:1080-1089; the reference reads the scores with .item() every step -- deferred here, the
         episode's graph does not change after it ended)"""
+        self._flush_graph_updates()
         for i in range(self.B):
             if self.end_obs_vp[i] is None:
                 continue

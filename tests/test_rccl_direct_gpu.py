@@ -28,6 +28,7 @@ with socket.socket() as sk:
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 c = rccl.make(dev)
 assert c is not None and c.world == 1, "direct communicator"
+assert c.graph_ok, "the captured self-test (an all-reduce inside a twice-replayed graph, forked to a side stream) must pass on this box"
 x = torch.randn(1000, device=dev); ref = x.clone()
 c.all_reduce_(x)
 with c.group():

@@ -7,7 +7,10 @@ The communicator is OURS (ncclCommInitRank with an id rank 0 makes and every ran
 the reference's `init_distributed`, pretrain_src/utils/misc.py:57-71, has built that group), on the librccl.so torch itself loaded, so one RCCL runtime
 serves both.  Same semantics as the torch calls it replaces: in-place sum all-reduce of fp32 ranges, all-gather of equal-sized int64 / fp32 blocks.
 One process per GPU; RCCL moves the bytes over xGMI.  `selftest()` all-reduces a vector of ones and checks the world size came back: a communicator
-that does not pass it is dropped and GradSync keeps torch.distributed (the path the 2-rank `gloo` rehearsals exercise)."""
+that does not pass it is dropped and GradSync keeps torch.distributed (the path the 2-rank `gloo` rehearsals exercise); `selftest_captured()` does the
+same inside a captured, twice-replayed graph under a deadline -- only a communicator that passes it ON EVERY RANK (`graph_ok`) gets its collectives
+captured into the step graph, the others issue them between the cut graphs.  N > 1 has never run on hardware in this repository: these two tests are
+what stands between an 8-GPU launch and a hang."""
 import ctypes as C
 import os
 
@@ -39,6 +42,7 @@ def lib():
         l.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
         l.ncclCommInitRank.argtypes = [C.POINTER(vp), C.c_int, _UniqueId, C.c_int]
         l.ncclCommDestroy.argtypes = [vp]
+        l.ncclCommAbort.argtypes, l.ncclCommAbort.restype = [vp], C.c_int
         l.ncclAllReduce.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp, vp]
         l.ncclAllGather.argtypes = [vp, vp, sz, C.c_int, vp, vp]
         l.ncclGroupStart.argtypes, l.ncclGroupEnd.argtypes = [], []
@@ -77,6 +81,7 @@ class RcclComm:
         raw = bytes(t.cpu().tolist())
         C.memmove(C.byref(uid), raw, 128)
         self.comm = C.c_void_p()
+        self.graph_ok = False                     # set by make(): the captured self-test passed on EVERY rank
         with torch.cuda.device(self.dev):
             _chk(l.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
 
@@ -114,6 +119,42 @@ class RcclComm:
         torch.cuda.synchronize(self.dev)
         return bool((x == float(self.world)).all()) and got.view(self.world, 4)[:, 0].tolist() == list(range(self.world))
 
+    def selftest_captured(self, deadline_s=20.0):
+        """the same all-reduce INSIDE a captured HIP graph, forked to a side stream as the step's bucket collectives are (trainer.capture_student), replayed
+        twice: the values must come back world and world^2 within `deadline_s` -- a node whose RCCL cannot be captured (or whose replay hangs) is found out
+        here, at start-up, on a 256 KB vector, not inside the first training step.  False: the caller keeps the cut-graph form.  On a timeout the
+        communicator is ABORTED (ncclCommAbort: its kernels leave their spin loops) and must not be used again."""
+        import time
+        from .lib import capture
+        x = torch.ones(1 << 16, dtype=torch.float32, device=self.dev)
+        side = torch.cuda.Stream(device=self.dev)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(self.dev)
+        with torch.cuda.device(self.dev):
+            try:
+                with capture(g):
+                    cur = torch.cuda.current_stream()
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        with self.group():
+                            self.all_reduce_(x[:1 << 15])
+                            self.all_reduce_(x[1 << 15:])
+                    cur.wait_stream(side)
+            except Exception:              # noqa: BLE001 -- a refused capture is an answer, not an error
+                return False
+            done = torch.cuda.Event()
+            g.replay()
+            g.replay()
+            done.record()
+            t0 = time.monotonic()
+            while not done.query():
+                if time.monotonic() - t0 > deadline_s:
+                    lib().ncclCommAbort(self.comm)
+                    self.comm = None
+                    return False
+                time.sleep(0.002)
+        return bool((x == float(self.world) ** 2).all())
+
     def destroy(self):
         if getattr(self, "comm", None):
             lib().ncclCommDestroy(self.comm)
@@ -124,13 +165,26 @@ def make(device):
     """a self-tested communicator, or None (no `nccl` group / MAGIC_RCCL_DIRECT=0 / anything failed: the caller keeps torch.distributed)"""
     if os.environ.get("MAGIC_RCCL_DIRECT", "1") == "0" or not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
         return None
+    c, ok, why = None, False, ""
     try:
         c = RcclComm(device)
-        if not c.selftest():
-            c.destroy()
-            return None
-        return c
+        ok = c.selftest()
+        if ok:
+            c.graph_ok = c.selftest_captured()
+            ok = c.comm is not None                    # (a timed-out captured test aborted the communicator)
     except Exception as e:              # noqa: BLE001 -- never take the run down: torch.distributed does the same exchange
-        import warnings
-        warnings.warn(f"direct RCCL communicator not available ({e!r}): gradient exchange through torch.distributed")
-        return None
+        ok, why = False, repr(e)
+    # every rank must take the SAME path (a rank on torch.distributed and its peer on the direct communicator would wait for each other for ever):
+    # the verdicts are min-reduced over the group the launcher built
+    flags = torch.tensor([1 if ok else 0, 1 if (ok and c.graph_ok) else 0], dtype=torch.int32, device=torch.device(device))
+    if dist.get_world_size() > 1:
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    all_ok, all_graph = (int(v) for v in flags.tolist())
+    if c is not None and ok and all_ok:
+        c.graph_ok = bool(all_graph)
+        return c
+    if c is not None and ok:
+        c.destroy()
+    import warnings
+    warnings.warn(f"direct RCCL communicator not available on every rank ({why or 'self-test failed'}): gradient exchange through torch.distributed")
+    return None

@@ -133,7 +133,7 @@ class StreamStep:
         # the touched word-embedding rows change per replay, so the graph reads them from a static -1-padded buffer `_stage` refills; else three
         # graphs cut at the bucket boundaries + the optimizer's, the collectives between the replays
         e.ids_buf = None
-        if (tr.sync.world > 1 or tr.sync.force) and tr.sync.rccl is not None and task != "mlm" and tr.sync.sparse_cap:
+        if (tr.sync.world > 1 or tr.sync.force) and tr.sync.rccl is not None and tr.sync.rccl.graph_ok and task != "mlm" and tr.sync.sparse_cap:
             e.ids_buf = torch.full((int(tr.sync.sparse_cap),), -1, dtype=torch.int64, device=self.dev)
             e.ids_host = [torch.full((int(tr.sync.sparse_cap),), -1, dtype=torch.int64).pin_memory() for _ in range(4)]
         e.cs = tr.capture_student((e.batch, task, e.plan), e.t_out, rw=self.rw, rccl_in_graph=e.ids_buf is not None or task == "mlm", touched_static=e.ids_buf)

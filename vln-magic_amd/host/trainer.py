@@ -704,7 +704,7 @@ class PretrainStep:
         # exchange stream forks off the capturing stream at every bucket boundary and joins it in front of the optimizer's launches.  For steps whose
         # touched word-embedding rows are fixed at capture time (resident batches, or a dense table); streamed batches, whose row ids change per replay,
         # keep the cut-graph form below (`rccl_in_graph=False`).  MAGIC_DDP_GRAPH_RCCL=0 selects the cut-graph form everywhere.
-        if two and rccl_in_graph and os.environ.get("MAGIC_DDP_GRAPH_RCCL", "1") != "0" and self.sync.stream is not None and self.sync.rccl is not None:
+        if two and rccl_in_graph and os.environ.get("MAGIC_DDP_GRAPH_RCCL", "1") != "0" and self.sync.stream is not None and self.sync.rccl is not None and self.sync.rccl.graph_ok:
             gS = torch.cuda.CUDAGraph()
             # touched_static: a -1-padded id buffer the caller refills before every replay (streamed batches: GradSync._sparse_rows_padded); else the
             # resident batch's own rows, fixed for the life of the graph; None / mlm: the dense table

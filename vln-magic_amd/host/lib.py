@@ -419,7 +419,7 @@ class solo:
 def call(name, *args):
     ls = getattr(_tls, "lockstep", None)
     if ls is not None and (name in PAIRABLE or (name in FORKABLE and ls.side is not None)) and not getattr(_tls, "solo", False):
-        return ls.submit(_tls.idx, name, args)
+        return ls.submit(ls.index(), name, args)
     if ls is not None and PROFILE["on"]:
         with ls.cv:            # instrumented pass: keep this launch's event pair free of the partner thread's launches
             return _raw_call(name, args)
@@ -474,9 +474,13 @@ class Lockstep:
         self.forks = 0
         self.side = side              # a stream for the partner's half of a FORKABLE twin (None: forkable calls launch where they are)
 
-    def submit(self, idx, name, args):
+    def index(self):
+        return _tls.idx
+
+    def _meet(self, idx, name, args):
+        """the partner is parked at a call: launch both (one group, forked twins, or one after the other); True when that happened"""
         other = 1 - idx
-        with self.cv:
+        if True:
             if self.pending[other] is not None and (name in FORKABLE or self.pending[other][0] in FORKABLE):
                 oname, oargs = self.pending[other]
                 if name in FORKABLE and oname in FORKABLE:       # twins: the partner's on the side stream, ours here, joined at once
@@ -491,8 +495,7 @@ class Lockstep:
                         _raw_call(n_, a_)
                 self.pending[other] = None
                 self.gen += 1
-                self.cv.notify_all()
-                return
+                return True
             if self.pending[other] is not None:                  # partner is waiting: launch both as one group
                 oname, oargs = self.pending[other]
                 first, second = ((oname, oargs), (name, args)) if other == 0 else ((name, args), (oname, oargs))
@@ -519,6 +522,13 @@ class Lockstep:
                 self.pairs += 1
                 self.pending[other] = None
                 self.gen += 1
+                return True
+        return False
+
+    def submit(self, idx, name, args):
+        other = 1 - idx
+        with self.cv:
+            if self._meet(idx, name, args):
                 self.cv.notify_all()
                 return
             if self.done[other]:
@@ -538,11 +548,82 @@ class Lockstep:
             self.cv.notify_all()
 
 
+try:
+    import greenlet as _greenlet
+except ImportError:                       # (the threaded form below needs nothing but the standard library)
+    _greenlet = None
+LOCKSTEP_FORM = os.environ.get("MAGIC_LOCKSTEP", "greenlets" if _greenlet is not None else "threads")
+
+
+class LockstepOneThread(Lockstep):
+    """The same pairing with NO second thread (round 6): the two segments are two greenlets of the calling thread.  A segment that arrives at a groupable call
+    whose twin has not arrived parks the call and switches to the other segment; that one runs until it meets the parked call (both go out as one launch, and
+    it carries on), parks a call of its own (and switches back) or ends.  One thread adds nodes to the capturing stream, in an order that is a function of the
+    two launch sequences alone -- nothing for a baton to protect.  Segments share the thread's torch state (current stream, grad mode): neither changes it
+    around a groupable call (the forked twins' side stream is handled inside `_meet`)."""
+
+    def __init__(self, side=None):
+        super().__init__(side)
+        self.gl = [None, None]
+
+    def index(self):
+        return 0 if _greenlet.getcurrent() is self.gl[0] else 1
+
+    def submit(self, idx, name, args):
+        other = 1 - idx
+        if self._meet(idx, name, args):
+            return
+        if self.done[other]:
+            _raw_call(name, args)
+            return
+        self.pending[idx] = (name, args)
+        self.gl[other].switch()                               # back here once the partner has met this call, parked one of its own, or ended
+        if self.pending[idx] is not None:                     # the partner ended without a twin for it: launch alone
+            self.pending[idx] = None
+            _raw_call(name, args)
+
+
+def _lockstep_one_thread(fn_a, fn_b, side):
+    ls = LockstepOneThread(side)
+    box = {}
+
+    def seg(i, fn):
+        def run():
+            try:
+                box[i] = fn()
+            finally:
+                ls.done[i] = True
+        return run
+    ls.gl = [_greenlet.greenlet(seg(0, fn_a)), _greenlet.greenlet(seg(1, fn_b))]      # both children of this greenlet: an ended segment returns here
+    _tls.lockstep = ls
+    try:
+        while not (ls.gl[0].dead and ls.gl[1].dead):
+            # start / resume the segment that can run: the first, unless it is parked behind a live partner (then the partner is the one mid-flight)
+            nxt = 0 if not ls.gl[0].dead and (ls.pending[0] is None or ls.gl[1].dead) else 1
+            if ls.gl[nxt].dead:
+                nxt = 1 - nxt
+            ls.gl[nxt].switch()
+    except BaseException:
+        for g in ls.gl:                   # unwind the other segment's stack (its `finally` blocks run) before the error leaves
+            if g is not None and not g.dead:
+                try:
+                    g.throw(_greenlet.GreenletExit)
+                except BaseException:     # noqa: BLE001
+                    pass
+        raise
+    finally:
+        _tls.lockstep = None
+    return box[0], box[1]
+
+
 def lockstep(fn_a, fn_b, side=None):
-    """returns (fn_a(), fn_b()) with their groupable launches paired (see Lockstep).  fn_b runs on a helper thread bound to
-    the caller's device and current stream.  side: a stream for the partner's half of FORKABLE twins."""
+    """returns (fn_a(), fn_b()) with their groupable launches paired (see Lockstep).  Default: both segments on the calling thread (LockstepOneThread);
+    MAGIC_LOCKSTEP=threads (or no `greenlet` module): fn_b on a helper thread bound to the caller's device and current stream.  side: a stream for the
+    partner's half of FORKABLE twins."""
     if getattr(_tls, "lockstep", None) is not None:              # no nesting: run sequentially inside an outer lockstep
         return fn_a(), fn_b()
+    if LOCKSTEP_FORM == "greenlets" and _greenlet is not None:
+        return _lockstep_one_thread(fn_a, fn_b, side)
     ls = Lockstep(side)
     cur = torch.cuda.current_stream()
     dev = torch.cuda.current_device()

@@ -26,6 +26,9 @@
 
 #define CH 256
 #define CI 1024
+#ifndef CHAIN_QUARTERS
+#define CHAIN_QUARTERS 0   // 1: the 32-row kernel's FFN one 256-column quarter of the intermediate at a time (81 KB of LDS instead of 129 KB; measured: no gain, profiles/micro/r06_ab_chain_quarters.txt)
+#endif
 #ifdef CHAIN_LDS_SW
 // round 6 A/B (profiles/micro/r06_ab_chain_lds_sw.txt): XOR-swizzled images for chain_fwd_kernel's A operands.  With the padded pitch (33 / 129 slots) every
 // 16-lane group of a ds_read_b128 fragment read -- lanes {0-3, 12-15 (k group 0), 20-27 (k group 1)} etc. -- has ONE lane pair on the same 16-byte slot
@@ -158,6 +161,21 @@ __device__ __forceinline__ void chain_load_chunk(h16x8<Hh> (&b)[8], const int ci
   if (cid < 2) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag((const Hh*)p.Wa, CH, 2 * w + cid, ks, lane);
+#if CHAIN_QUARTERS
+  } else if (cid < 18) {
+    // quarter q of the intermediate (columns 256 q ..): two W1 chunks (this wave's column tiles 16 q + 2 w, + 1), then two W2 chunks (k-steps 8 q .. 8 q + 7)
+    const int q = (cid - 2) >> 2, r = (cid - 2) & 3;
+    if (r < 2) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag((const Hh*)p.W1, CH, 16 * q + 2 * w + r, ks, lane);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        b[ks] = pfrag((const Hh*)p.W2, CI, 2 * w, 8 * q + 4 * (r - 2) + ks, lane);
+        b[4 + ks] = pfrag((const Hh*)p.W2, CI, 2 * w + 1, 8 * q + 4 * (r - 2) + ks, lane);
+      }
+    }
+#else
   } else if (cid < 10) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) b[ks] = pfrag((const Hh*)p.W1, CH, 8 * w + cid - 2, ks, lane);
@@ -167,6 +185,7 @@ __device__ __forceinline__ void chain_load_chunk(h16x8<Hh> (&b)[8], const int ci
       b[ks] = pfrag((const Hh*)p.W2, CI, 2 * w, 4 * (cid - 10) + ks, lane);
       b[4 + ks] = pfrag((const Hh*)p.W2, CI, 2 * w + 1, 4 * (cid - 10) + ks, lane);
     }
+#endif
   } else {
     // UNCONDITIONAL (a load the compiler cannot count makes every later wait a full drain): tiles past the projection's width re-read its
     // last tile, a chain without a projection reads Wa's fragments -- valid addresses, unused data
@@ -185,11 +204,23 @@ __device__ long long chain_ticks[16];          // wall_clock64 (100 MHz) marks o
 #endif
 template <typename Hh, bool FFN>
 __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile, unsigned char* smem) {
+#if CHAIN_QUARTERS
+  // 81 KB (round 6; 129 KB with the whole GELU image): sY1 | sG | sRes | sIn.  The projection image [CROWS][Np + 8] (<= 49.7 KB) takes the three images that
+  // are dead by then: sY1 | sG | sRes after an FFN (its A operand is sIn), sG | sRes | sIn without one (its A operand is sY1).
+  Hh* sY1 = (Hh*)smem;                      // [CROWS][CP]
+  Hh* sG = sY1 + CROWS * KP;                // [CROWS][CP]  GELU output of ONE 256-column quarter of the intermediate
+  Hh* sRes = sG + CROWS * KP;               // [CROWS][CP]  residual of stage 1
+  Hh* sIn = sRes + CROWS * KP;              // [CROWS][CP]  stage-1 input; later the block output y2
+  float* red = (float*)(sIn + CROWS * KP);  // [2][8][CROWS]
+  Hh* sProj = FFN ? sY1 : sG;
+#else
   Hh* sIn = (Hh*)smem;                      // [CROWS][CP]  stage-1 input; later the block output y2
   Hh* sRes = sIn + CROWS * KP;              // [CROWS][CP]  residual of stage 1
   Hh* sY1 = sRes + CROWS * KP;              // [CROWS][CP]
   Hh* sG = sY1 + CROWS * KP;                // [CROWS][CG]  GELU output; later the projection image [CROWS][Np + 8]
   float* red = (float*)(sG + CROWS * KG);   // [2][8][CROWS]
+  Hh* sProj = sG;
+#endif
   float* sPar = red + 2 * NWAVE * CROWS;    // ba | g1 | b1 | bo2 | g2 | b2 (256 each) | bi (1024) | bp (<= 768): every small parameter, staged ONCE --
                                             // a global load between the weight chunks makes the compiler drain the whole ring (vmcnt(0)) before its use
   const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -237,6 +268,59 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
   if (p.y1) ccopy_out(sY1, KP, (Hh*)p.y1 + (long long)row0 * CH, CH, nq, CH, tid);
   const Hh* sLast = sY1;
   if constexpr (FFN) {
+#if CHAIN_QUARTERS
+    // ================= 2: y2 = LayerNorm(gelu(y1 W1^T + bi) W2^T + bo2 + y1), one 256-column QUARTER of the intermediate at a time =================
+    // (round 6: the GELU image of a quarter is 17 KB instead of 66 KB for the whole intermediate -- the workgroup's LDS drops from 129 to 81 KB, which is what
+    // lets a chain workgroup share a CU with a 68 KB row-block backward workgroup of the student instead of taking turns with it; the second product
+    // accumulates in registers over the quarters, as chain64_body does)
+    {
+      f32x4 acc2[CRT][2];
+#pragma unroll
+      for (int rt = 0; rt < CRT; ++rt) { acc2[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // ---- 2a: this wave's two column tiles (16 q + 2 w, + 1) of gelu(y1 W1^T + bi) -> columns 32 w .. 32 w + 31 of the quarter's image
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          AHEAD(2 + 4 * q + ct);
+          const int lcol = (2 * w + ct) * 16 + c16;
+          const float bfc = sPar[6 * CH + 256 * q + lcol];
+          KSTEP_FENCE();
+          f32x4 acc[CRT];
+#pragma unroll
+          for (int rt = 0; rt < CRT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < CRT; ++rt) acc[rt] = emma(cfrag(sY1, KP, rt * 16, ks * 32, lane), ring[(2 + 4 * q + ct) % CNB][ks], acc[rt]);
+#pragma unroll
+          for (int rt = 0; rt < CRT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sG[CADDR(rt * 16 + 4 * g + r, lcol, KP)] = from_f<Hh>(gelu_fast(acc[rt][r] + bfc));
+          KSTEP_FENCE();
+        }
+        __syncthreads();
+        // ---- 2b: y2 += g_q W2[:, 256 q ..]^T: 8 k-steps in two chunks of 4 x 2 column tiles
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          AHEAD(4 + 4 * q + ch);
+          KSTEP_FENCE();
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < CRT; ++rt) {
+              const h16x8<Hh> a = cfrag(sG, KP, rt * 16, (4 * ch + ks) * 32, lane);
+              acc2[rt][0] = emma(a, ring[(4 + 4 * q + ch) % CNB][ks], acc2[rt][0]);
+              acc2[rt][1] = emma(a, ring[(4 + 4 * q + ch) % CNB][4 + ks], acc2[rt][1]);
+            }
+          KSTEP_FENCE();
+        }
+        if (q < 3) __syncthreads();             // every wave is done with this quarter's image before the next one overwrites it
+      }
+      CH_MARK(3);
+      chain_norm(acc2, sPar + 3 * CH, sY1, red, sIn, nq, p.eps, w, lane);
+    }
+#else
     // ================= 2a: g = gelu(y1 W1^T + bi): 8 column tiles per wave =================
     {
       // (the A fragments come from LDS at every use: holding the 16 of a stage in registers next to the ring spilled, and a scratch
@@ -284,6 +368,7 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
       }
       chain_norm(acc, sPar + 3 * CH, sY1, red, sIn, nq, p.eps, w, lane);
     }
+#endif
     __syncthreads();
     CH_MARK(4);
     ccopy_out(sIn, KP, (Hh*)p.y2 + (long long)row0 * CH, CH, nq, CH, tid);
@@ -310,13 +395,13 @@ __device__ __forceinline__ void chain_body(const ChainParams& p, const int tile,
 #pragma unroll
         for (int rt = 0; rt < CRT; ++rt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sG[(rt * 16 + 4 * g + r) * pp + tile_n * 16 + c16] = from_f<Hh>(acc[rt][r] + bpv);
+          for (int r = 0; r < 4; ++r) sProj[(rt * 16 + 4 * g + r) * pp + tile_n * 16 + c16] = from_f<Hh>(acc[rt][r] + bpv);
       }
       KSTEP_FENCE();
     }
     __syncthreads();
     CH_MARK(5);
-    copy_out(sG, pp, (Hh*)p.proj + (long long)row0 * p.Np, p.Np, nq, p.Np, tid);
+    copy_out(sProj, pp, (Hh*)p.proj + (long long)row0 * p.Np, p.Np, nq, p.Np, tid);
   }
   CH_MARK(6);
 #undef SEQ
@@ -622,7 +707,11 @@ __global__ __launch_bounds__(512) void chain64_fwd_kernel(ChainPair pr) {
 }
 static size_t chain64_lds_bytes() { return (size_t)(4 * C6ROWS * CP) * 2 + (40 * C6ROWS + 6 * CH + CI + 3 * CH) * sizeof(float); }
 
+#if CHAIN_QUARTERS
+static size_t chain_lds_bytes() { return (size_t)(4 * CROWS * KP) * 2 + (2 * NWAVE * CROWS + 6 * CH + CI + 3 * CH) * sizeof(float); }
+#else
 static size_t chain_lds_bytes() { return (size_t)(3 * CROWS * KP + CROWS * KG) * 2 + (2 * NWAVE * CROWS + 6 * CH + CI + 3 * CH) * sizeof(float); }
+#endif
 
 static bool chain_valid(const ChainParams& p) {
   if (p.M <= 0 || !p.in || !p.res || !p.Wa || !p.ba || !p.g1 || !p.b1 || p.ld_in < CH || (p.ld_in & 7)) return false;

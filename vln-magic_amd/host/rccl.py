@@ -132,7 +132,7 @@ class RcclComm:
         torch.cuda.synchronize(self.dev)
         with torch.cuda.device(self.dev):
             try:
-                with capture(g):
+                with capture(g, capture_error_mode="relaxed"):      # (the mode the step captures use; other threads -- torch's NCCL watchdog -- keep making HIP calls meanwhile)
                     cur = torch.cuda.current_stream()
                     side.wait_stream(cur)
                     with torch.cuda.stream(side):

@@ -79,6 +79,8 @@ KDL = dict(knowledge_distillation=True, kd_alpha=0.5, kd_temperature=2, teacher_
            t_sample_preprocess_exp_decay=0.7, rw_temp=4, train_teacher=False,
            kdl_tasks=["txt", "img", "local", "global", "predict"], kdl_task_types=["emb", "attn"])   # r2r_magic_pretrain.json:62-87
 TASKS = ["mlm", "sap", "cfp"]
+if os.environ.get("MAGIC_BENCH_TASK_ORDER"):      # (experiments: the same three proxy tasks cycled in another order, e.g. mlm,cfp,sap)
+    TASKS = [t for t in os.environ["MAGIC_BENCH_TASK_ORDER"].split(",") if t in ("mlm", "sap", "cfp")] or TASKS
 MAX_TOKENS = 80                # instruction tokens per sample (synth.make_batch draws U{20..80})
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 

@@ -63,6 +63,44 @@ def gmap_pos_fts(pos_of, dist_of, path_len_of, cur_vp, gmap_vpids, cur_heading, 
     return np.concatenate([get_angle_fts(ang[:, 0], ang[:, 1], angle_feat_size), dst], 1)
 
 
+def gmap_inputs(cands_of, pos_of, dist_of, path_len_of, path, cur_heading, cur_elevation, act_visited_node=False, **kw):
+    """dataset.py:520-552 (`get_gmap_inputs`): the map a trajectory prefix has seen -- [stop] first, then the visited viewpoints in visiting order
+    (step id t + 1), then every candidate seen from them that was never visited, in first-sighting order (step id 0; a candidate visited later is
+    dropped from the frontier); visited mask [0] + [1] * visited + [0] * unvisited (R2R: act_visited_node False); position features relative to
+    the LAST viewpoint; pairwise shortest distances with row / column 0 ([stop]) and the diagonal zero.  cands_of(vp): candidate ids in the
+    reference's dict order."""
+    visited, unvisited = {}, {}
+    for t, vp in enumerate(path):
+        visited[vp] = t + 1
+        unvisited.pop(vp, None)
+        for nxt in cands_of(vp):
+            if nxt not in visited:
+                unvisited[nxt] = 0
+    vpids = [None] + list(visited) + list(unvisited)
+    step_ids = [0] + list(visited.values()) + list(unvisited.values())
+    if act_visited_node:
+        vis = [0] + [1 if vp == path[-1] else 0 for vp in vpids[1:]]
+    else:
+        vis = [0] + [1] * len(visited) + [0] * len(unvisited)
+    pos = gmap_pos_fts(pos_of, dist_of, path_len_of, path[-1], vpids, cur_heading, cur_elevation, **kw)
+    pair = np.zeros((len(vpids), len(vpids)), np.float32)
+    for i in range(1, len(vpids)):
+        for j in range(i + 1, len(vpids)):
+            pair[i, j] = pair[j, i] = dist_of(vpids[i], vpids[j])
+    return vpids, step_ids, vis, pos, pair
+
+
+def vp_pos_fts(pos_of, dist_of, path_len_of, start_vp, cur_vp, cand_vpids, cur_heading, cur_elevation, vp_ft_len, **kw):
+    """dataset.py:555-565 (`get_vp_pos_fts`): [vp_ft_len + 1, 14] -- columns 0..6 of EVERY row ([stop] row 0 included) = the start viewpoint seen from
+    the current one, columns 7..13 of rows 1..len(cand) = the candidates seen from the current one, zeros elsewhere"""
+    cand = gmap_pos_fts(pos_of, dist_of, path_len_of, cur_vp, cand_vpids, cur_heading, cur_elevation, **kw)
+    start = gmap_pos_fts(pos_of, dist_of, path_len_of, cur_vp, [start_vp], cur_heading, cur_elevation, **kw)
+    out = np.zeros((vp_ft_len + 1, 14), np.float32)
+    out[:, :7] = start
+    out[1:len(cand) + 1, 7:] = cand
+    return out
+
+
 def traj_pano_tokens(view_fts_of, path, cands_of, angle_feat_size=4):
     """dataset.py:729-772 with `correct_heading` off (the shipped default).
     view_fts_of(vp) -> [36, D]; cands_of(vp) -> ordered dict {cand_vp: (viewidx, _, d_heading, d_elevation)}.

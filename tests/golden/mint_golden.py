@@ -398,6 +398,43 @@ def mint_gmap_pos():
         del sys.modules[k]
 
 
+def mint_gmap_inputs():
+    """gmap_inputs.pt: R2RTextPathData.get_gmap_inputs (pretrain_src/data/dataset.py:520-552) and get_vp_pos_fts (:555-565) run UNBOUND on a synthetic
+    scan: a walk that revisits the frontier (a candidate seen at step 0 is visited at step 2), both act_visited_node settings."""
+    sys.path.insert(0, f"{REF}/pretrain_src")
+    stub(["pynvml", "jsonlines", "h5py", "nltk", "lmdb", "msgpack_numpy", "tensorboardX", "easydict", "progressbar"])
+    sys.modules["msgpack_numpy"].patch = lambda: None
+    from data import dataset as DS
+    rng = np.random.default_rng(31)
+    scan = "scanC"
+    vps = [f"vp{i}" for i in range(9)]
+    pos = {v: rng.uniform(-8, 8, 3).astype(np.float64) for v in vps}
+    dist = {a: {b: float(np.linalg.norm(pos[a] - pos[b]) * 1.3) for b in vps} for a in vps}
+    paths = {a: {b: [a] + [f"m{k}" for k in range(int(rng.integers(0, 3)))] + ([b] if b != a else []) for b in vps} for a in vps}
+    cand_lists = {"vp0": ["vp1", "vp3", "vp2"], "vp1": ["vp0", "vp2", "vp4"], "vp2": ["vp1", "vp5", "vp0"], "vp3": ["vp0", "vp6"],
+                  "vp4": ["vp1", "vp7"], "vp5": ["vp2", "vp8", "vp4"], "vp6": ["vp3"], "vp7": ["vp4"], "vp8": ["vp5"]}
+    cands = {f"{scan}_{v}": {c: [0, 1.0, 0.0, 0.0] for c in cs} for v, cs in cand_lists.items()}
+    cases = []
+    for avn in (False, True):
+        fake = SimpleNamespace(graphs={scan: SimpleNamespace(nodes={v: {"position": pos[v]} for v in vps})}, scanvp_cands=cands,
+                               shortest_distances={scan: dist}, shortest_paths={scan: paths}, angle_feat_size=4, act_visited_node=avn)
+        fake.get_gmap_pos_fts = lambda *a, _f=fake: DS.R2RTextPathData.get_gmap_pos_fts(_f, *a)
+        for path, h, e in ((["vp0"], 0.0, 0.0), (["vp0", "vp1", "vp2"], 0.4, -0.1), (["vp0", "vp1", "vp2", "vp5", "vp4"], 2.1, 0.2)):
+            ids, steps, vis, posf, pair = DS.R2RTextPathData.get_gmap_inputs(fake, scan, path, h, e)
+            cand_ids = cand_lists[path[-1]]
+            vpf = DS.R2RTextPathData.get_vp_pos_fts(fake, scan, path[0], path[-1], cand_ids, h, e, 36)
+            cases.append(dict(act_visited_node=avn, path=path, heading=h, elevation=e, ids=ids, steps=list(steps), vis=list(vis),
+                              pos=torch.from_numpy(np.asarray(posf)), pair=torch.from_numpy(np.asarray(pair)), cand=cand_ids,
+                              vp_pos=torch.from_numpy(np.asarray(vpf))))
+    torch.save(dict(scan=scan, vps=vps, pos={k: torch.from_numpy(v) for k, v in pos.items()}, dist=dist, cand_lists=cand_lists,
+                    path_len={a: {b: len(paths[a][b]) for b in vps} for a in vps}, max_dist=DS.MAX_DIST, max_step=DS.MAX_STEP, cases=cases),
+               os.path.join(HERE, "gmap_inputs.pt"))
+    print("gmap_inputs ok", [(c["act_visited_node"], len(c["ids"]), tuple(c["vp_pos"].shape)) for c in cases])
+    sys.path.remove(f"{REF}/pretrain_src")
+    for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "data", "optim", "parser")]:
+        del sys.modules[k]
+
+
 def mint_nav_loop():
     """nav_loop.pt: the reference's own FloydGraph (map_nav_src/r2r/speaker_utils.py:501-546) on a fixed edge/update script,
     and GMapNavAgent._language_variable / _panorama_feature_variable_do / _nav_gmap_variable / _nav_vp_variable_mem /
@@ -600,6 +637,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--gmap-pos-only" in sys.argv:
         mint_gmap_pos()
+        sys.exit(0)
+    if "--gmap-inputs-only" in sys.argv:
+        mint_gmap_inputs()
         sys.exit(0)
     mint_primitives()
     mint_ops()

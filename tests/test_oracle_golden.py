@@ -356,3 +356,45 @@ def test_map_position_features_and_the_stop_node_row_match_reference_get_gmap_po
     assert s["gmap_vpids"][0] is None and s["gmap_pos_fts"][0].tolist() == list(synth.STOP_NODE_POS_FTS)
     b = synth.make_batch("sap", batch_size=4, seed=9, step=0)
     assert torch.equal(b["gmap_pos_fts"][:, 0], torch.tensor(synth.STOP_NODE_POS_FTS).expand(4, 7))
+
+
+def test_map_inputs_and_viewpoint_position_features_match_reference_get_gmap_inputs(golden_dir):
+    """oracle/ingest_ref.gmap_inputs / vp_pos_fts vs the reference's own get_gmap_inputs (pretrain_src/data/dataset.py:520-552) and get_vp_pos_fts
+    (:555-565) on a synthetic scan whose walk visits a node it first saw as a candidate: token order ([stop] | visited in visiting order | frontier in
+    first-sighting order), step ids, both visited-mask rules, position features, pair distances (row / column 0 and diagonal zero), and the
+    [vp_ft_len + 1, 14] viewpoint table (start viewpoint in columns 0..6 of EVERY row, candidates in columns 7..13 of rows 1..n) -- bit-exact.  The
+    synthetic generator (host/synth.py) is held to the same layout."""
+    import random
+
+    import numpy as np
+    import magic_amd  # noqa: F401
+    from magic_amd.host import synth
+    from oracle import ingest_ref as IR
+    fx = _load(golden_dir, "gmap_inputs.pt")
+    pos = {k: v.numpy() for k, v in fx["pos"].items()}
+    pos_of, dist_of, len_of = (lambda v: pos[v]), (lambda a, b: fx["dist"][a][b]), (lambda a, b: fx["path_len"][a][b])
+    kw = dict(max_dist=fx["max_dist"], max_step=fx["max_step"])
+    assert len(fx["cases"]) == 6
+    for c in fx["cases"]:
+        ids, steps, vis, p, pair = IR.gmap_inputs(lambda v: fx["cand_lists"][v], pos_of, dist_of, len_of, c["path"], c["heading"], c["elevation"],
+                                                  act_visited_node=c["act_visited_node"], **kw)
+        assert ids == c["ids"] and steps == c["steps"] and vis == c["vis"], c["path"]
+        assert np.array_equal(p, c["pos"].numpy()) and np.array_equal(pair, c["pair"].numpy()) and pair.dtype == np.float32
+        assert not pair[0].any() and not pair[:, 0].any() and not np.diag(pair).any()
+        vp = IR.vp_pos_fts(pos_of, dist_of, len_of, c["path"][0], c["path"][-1], c["cand"], c["heading"], c["elevation"], 36, **kw)
+        assert vp.shape == (37, 14) and np.array_equal(vp, c["vp_pos"].numpy())
+        assert (vp[:, :7] == vp[0, :7]).all() and not vp[0, 7:].any() and not vp[len(c["cand"]) + 1:, 7:].any()
+    long = [c for c in fx["cases"] if len(c["path"]) == 5 and not c["act_visited_node"]][0]
+    assert long["ids"][:6] == [None] + long["path"] and "vp4" not in long["ids"][6:]           # vp4: first a candidate (of vp1), later visited
+    assert long["steps"][:6] == [0, 1, 2, 3, 4, 5] and set(long["steps"][6:]) == {0} and long["vis"] == [0] + [1] * 5 + [0] * (len(long["ids"]) - 6)
+    s = synth.make_sample(np.random.default_rng(4), random.Random(4), uid=0)
+    T = len(s["traj_vpids"])
+    assert s["gmap_vpids"][0] is None and s["gmap_vpids"][1:1 + T] == s["traj_vpids"]
+    assert s["gmap_step_ids"].tolist() == [0] + list(range(1, T + 1)) + [0] * (len(s["gmap_vpids"]) - 1 - T)
+    assert s["gmap_visited_masks"].tolist() == [False] + [True] * T + [False] * (len(s["gmap_vpids"]) - 1 - T)
+    d = s["gmap_pair_dists"]
+    assert not d[0].any() and not d[:, 0].any() and not d.diagonal().any() and torch.equal(d, d.t())
+    vp = s["vp_pos_fts"]
+    nc = len(s["traj_cand_vpids"][-1])
+    assert vp.shape[1] == 14 and (vp[:, :7] == vp[0, :7]).all() and not vp[0, 7:].any() and not vp[nc + 1:, 7:].any() and vp[1:nc + 1, 7:].abs().sum() > 0
+

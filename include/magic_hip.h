@@ -36,6 +36,9 @@ int magic_device_info(int* cu_count, int* clock_khz, char* arch, int arch_len);
  * dQ); 2: TN A[K,M] B[K,N] (dW with split-K fp32 atomics + fused bias gradient, dK, dV).
  * epilogue: 0 none, 1 GELU(erf), 2 ReLU, 3 *gelu'(aux), 4 *relu'(aux).  C2 (optional) receives the
  * pre-activation.  k-contiguous operands need ld % (16/sizeof) == 0 and zero padding up to that multiple. */
+/* splitk < 0 (round 6): |splitk| K-splits, each STORING its partial into its own slab of C -- C is [|splitk|][M][ldc] fp32, no atomics; the consumer adds the
+ * slabs in slab order (magic_ln_bwd_tail with the slab count in `act`): a deterministic split-K.  Plain product only (c_f32, no epilogue / residual / C2 /
+ * bias_grad, batch = nh = 1); a split without k-tiles stores zeros. */
 int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N, int K,
                const void* A, int lda, long long sAb, long long sAh,
                const void* B, int ldb, long long sBb, long long sBh,
@@ -124,6 +127,8 @@ int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void* y, const f
  * [M, H] accumulator the split-K input gradient of the vocabulary projection leaves (no cast launch), and dx = LayerNorm'(dy) x act'(act_pre)
  * (no activation-derivative launch; act: 1 = erf gelu, 2 = relu; act_pre: the dense output before the activation, storage dtype).  gamma / beta
  * gradients are added as magic_ln_bwd does without partial rows.  Replaces cast + magic_ln_bwd + magic_dact. */
+/* act: bits 0..7 the activation in front of the LayerNorm (1 gelu, 2 relu); bits 8.. = S > 0: dy32 holds S slabs of M x H (magic_gemm with splitk = -S) that
+ * are added in slab order on load (round 6). */
 int magic_ln_bwd_tail(int dtype, int M, int H, const float* dy32, const void* y, const float* gamma, const float* beta, const float* rstd,
                       const void* act_pre, int act, void* dx, float* dgamma, float* dbeta, void* stream);
 /* hot0 >= 0: a row of indexed table 0 that a large share of the input rows hit (the padding token id of the word-embedding lookup): its

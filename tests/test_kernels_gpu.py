@@ -1044,6 +1044,52 @@ def test_ln_bwd_tail_matches_torch_autograd_and_the_three_separate_launches(dtyp
         L.call("magic_ln_bwd_tail", L.dt(dtype), M, 100, L.P(dy32), L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(pre), 1, L.P(dx), L.P(dg), L.P(db), L.stream())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,K,S", [(339, 50265, 32), (70, 1000, 5), (33, 4096, 64)])
+def test_split_k_into_slabs_summed_by_the_tail_is_bitwise_reproducible_and_matches_the_atomic_form(dtype, M, K, S):
+    """magic_gemm with splitk = -S (round 6): every K-split STORES its partial into its own fp32 slab, magic_ln_bwd_tail adds the S slabs in slab order -- the
+    MLM head's vocabulary input gradient d_hm = dlogits Wemb without fp32 atomics.  The slab sum equals the fp32 product (and the atomic split-K form) to
+    summation order, splits without k-tiles store zeros (S = 64 over 64 k-tiles of 64: some are empty at K = 4096 only when S exceeds them -- (70, 1000, 5)
+    has ragged last tiles), and four runs give bitwise the same dx; the unused slab count is refused."""
+    H = 128
+    gen = torch.Generator(DEV).manual_seed(M + S)
+    ldv = (K + 7) // 8 * 8
+    dlog = torch.zeros(M, ldv, device=DEV, dtype=dtype)
+    dlog[:, :K] = (torch.randn(M, K, device=DEV, generator=gen) * 0.05).to(dtype)
+    W = (torch.randn(K, H, device=DEV, generator=gen) * 0.1).to(dtype).contiguous()
+    ref = dlog[:, :K].float() @ W.float()
+    slabs = torch.full((S * M, H), float("nan"), device=DEV)               # every element must be stored by its split
+    O.gemm(1, dlog, W, slabs, M, H, K, ldv, H, H, splitk=-S)
+    acc = torch.zeros(M, H, device=DEV)
+    O.gemm(1, dlog, W, acc, M, H, K, ldv, H, H, splitk=S, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(slabs).all()
+    tot = slabs.view(S, M, H).sum(0)
+    scale = ref.abs().max().item()
+    assert (tot - ref).abs().max().item() <= 2e-5 * scale + 1e-6 and (acc - ref).abs().max().item() <= 2e-5 * scale + 1e-6
+    # the consumer: LayerNorm backward of the transform reading the slabs
+    pre = torch.randn(M, H, device=DEV, generator=gen).to(dtype)
+    gamma, beta = (1.0 + 0.1 * torch.randn(H, device=DEV, generator=gen)).contiguous(), (0.1 * torch.randn(H, device=DEV, generator=gen)).contiguous()
+    y, rstd = torch.empty(M, H, device=DEV, dtype=dtype), torch.empty(M, device=DEV, dtype=torch.float32)
+    O.ln_fwd(M, H, y, in0=F.gelu(pre.float()).to(dtype), gamma=gamma, beta=beta, eps=1e-12, rstd=rstd)
+    outs = []
+    for _ in range(4):
+        slabs.fill_(float("nan"))
+        O.gemm(1, dlog, W, slabs, M, H, K, ldv, H, H, splitk=-S)
+        dx, dg, db = torch.empty(M, H, device=DEV, dtype=dtype), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+        O.ln_bwd_tail(M, H, slabs, y, gamma, beta, rstd, pre, 1, dx, dg, db, nslab=S)
+        outs.append(dx.clone())
+    dx1 = torch.empty(M, H, device=DEV, dtype=dtype)
+    O.ln_bwd_tail(M, H, tot.contiguous(), y, gamma, beta, rstd, pre, 1, dx1, torch.zeros(H, device=DEV), torch.zeros(H, device=DEV))
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert (outs[0].float() - dx1.float()).abs().max().item() <= 2e-2 * dx1.float().abs().max().item()
+    with pytest.raises(L.MagicHipError):
+        O.ln_bwd_tail(M, H, slabs, y, gamma, beta, rstd, pre, 1, dx1, dg, db, nslab=S + 1)        # more slabs than the buffer holds
+    with pytest.raises(L.MagicHipError):
+        O.gemm(1, dlog, W, slabs, M, H, K, ldv, H, H, splitk=-S, epilogue=1)                      # slabs: the plain product only
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("H,K,M,act", [(128, 128, 257, 1), (256, 256, 70, 2), (384, 128, 33, 1), (128, 768, 5, 2)])
 def test_linear_act_ln_matches_torch(dtype, H, K, M, act):

@@ -26,6 +26,9 @@ struct GemmParams {
   int big;        // host-side only: 128x128 block tile (single launches; grouped / paired launches use 64x64)
   // deterministic split-K seam of the weight-gradient launch (gemm_dw_batch_kernel; NULL: fp32 atomics): see dw_seam()
   float* ws; unsigned* cnt; int ws_slot0, cnt0, ws_total, ws_first;
+  // deterministic split-K of a plain GEMM (magic_gemm with splitk < 0): split s STORES its partial into slab s of C ([splits][M][ldc] fp32, `slab` elements
+  // apart) instead of adding it with fp32 atomics; the consumer sums the slabs in slab order (magic_ln_bwd_tail)
+  long long slab;
 };
 
 template <typename T> struct TT;
@@ -441,7 +444,7 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
   const int ktiles = (p.K + BK - 1) / BK;
   const int per = (ktiles + p.splitk - 1) / p.splitk;
   const int kt0 = sk * per, kt1 = min(ktiles, kt0 + per);
-  if (kt0 >= kt1 && p.splitk > 1) return;
+  if (kt0 >= kt1 && p.splitk > 1 && !p.slab) return;          // (slab mode: an empty split still stores its zeros)
 
   // Register-staged software pipeline, PD tiles deep: the global loads of tiles kt+1 .. kt+PD-1 are in flight while
   // tile kt is written to LDS and multiplied.  These GEMMs run ~1 block per CU (grids of 100-600 blocks), so a
@@ -629,10 +632,11 @@ __device__ __forceinline__ void gemm_block(const GemmParams& p, const int bx, co
         if (col < p.N && row < p.M) atomicAdd((float*)p.C + coff + (long long)row * p.ldc + col, v[e]);
       }
     } else {
+      float* Cs = (float*)p.C + (long long)sk * p.slab;        // slab 0 when p.slab == 0
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         const int col = col_of(e), row = row_of(e);
-        if (col < p.N && row < p.M) ((float*)p.C)[coff + (long long)row * p.ldc + col] = v[e];
+        if (col < p.N && row < p.M) Cs[coff + (long long)row * p.ldc + col] = v[e];
       }
     }
   } else {
@@ -1233,6 +1237,15 @@ extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N
                           const float* bias, int epilogue, const void* aux, int ldaux,
                           const void* residual, int ldr, void* C2, int ldc2,
                           float alpha, int splitk, float* bias_grad, void* stream) {
+  // splitk < 0: |splitk| K-splits, each STORING its partial into its own slab of C ([|splitk|][M][ldc] fp32, no atomics: the consumer adds the slabs in
+  // order -- deterministic); plain product only (no epilogue / residual / bias gradient), one batch
+  long long slab = 0;
+  if (splitk < 0) {
+    if (!c_f32 || epilogue != 0 || residual || C2 || bias_grad || batch != 1 || nh != 1 || M <= 0 || ldc <= 0) return MAGIC_ERR_ARG;
+    splitk = -splitk;
+    slab = (long long)M * ldc;
+    accumulate = 0;
+  }
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || nh <= 0 || splitk <= 0) return MAGIC_ERR_ARG;
   if (!dtype_ok(dtype)) return MAGIC_ERR_ARG;
   if (layout < 0 || layout > 2) return MAGIC_ERR_ARG;
@@ -1240,7 +1253,7 @@ extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N
   if (lda % ve || ldb % ve || (sAb % ve) || (sAh % ve) || (sBb % ve) || (sBh % ve)) return MAGIC_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return MAGIC_ERR_ARG;
   if (dtype == DT_F32 && !c_f32) return MAGIC_ERR_ARG;
-  if ((accumulate || splitk > 1) && !(c_f32 && accumulate)) return MAGIC_ERR_ARG;
+  if (!slab && (accumulate || splitk > 1) && !(c_f32 && accumulate)) return MAGIC_ERR_ARG;
   if (splitk > 1 && (epilogue != 0 || residual || C2)) return MAGIC_ERR_ARG;
   if (bias_grad && layout != 2) return MAGIC_ERR_ARG;
   if (batch % nh) return MAGIC_ERR_ARG;
@@ -1250,7 +1263,8 @@ extern "C" int magic_gemm(int dtype, int layout, int batch, int nh, int M, int N
   p.sAb = sAb; p.sAh = sAh; p.sBb = sBb; p.sBh = sBh; p.sCb = sCb; p.sCh = sCh;
   p.nh = nh; p.splitk = splitk; p.epilogue = epilogue; p.c_f32 = c_f32; p.accumulate = accumulate; p.alpha = alpha;
   p.batch = batch;
-  p.big = gemm_big_tile(dtype, layout, M, N, K, batch * splitk);
+  p.slab = slab;
+  p.big = slab ? 0 : gemm_big_tile(dtype, layout, M, N, K, batch * splitk);
   if (group_record(KIND_GEMM, dtype, layout, &p, sizeof(p))) return MAGIC_OK;
   return launch_gemm(dtype, layout, &p, nullptr, (hipStream_t)stream);
 }

@@ -127,6 +127,7 @@ struct LnbParams {
   // TAIL instantiation only (magic_ln_bwd_tail: the MLM head's transform): dy arrives as fp32 (the split-K accumulator of the vocabulary
   // projection's input gradient) and dx leaves multiplied by the derivative of the activation in FRONT of the LayerNorm
   const float* dy32; const void* act_pre; int act;
+  int nslab;                  // dy32 = the sum, in slab order, of nslab slabs of M x H (a deterministic split-K accumulator: magic_gemm with splitk < 0)
 };
 
 // NW = waves per block.  Every block ends in one same-address atomic per parameter / const-table element, and those serialise in L2
@@ -199,7 +200,19 @@ __device__ __forceinline__ void ln_bwd_body(const LnbParams& pp, const int bid, 
       for (int it = 0; it < NIT; ++it) {
         const int c = it * 128 + lane * 2;
         if constexpr (TAIL) {
-          const float2 v = *(const float2*)(pp.dy32 + (long long)row * H + c);
+          float2 v = *(const float2*)(pp.dy32 + (long long)row * H + c);
+          // the other slabs eight at a time: eight loads in flight, added in slab order (a fixed order: the sum is reproducible)
+          for (int s0 = 1; s0 < pp.nslab; s0 += 8) {
+            float2 w8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int sl = min(s0 + q, pp.nslab - 1);
+              w8[q] = *(const float2*)(pp.dy32 + ((long long)sl * M + row) * H + c);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (s0 + q < pp.nslab) { v.x += w8[q].x; v.y += w8[q].y; }
+          }
           g[u][2 * it] = v.x; g[u][2 * it + 1] = v.y;
         } else {
           ld2<T>(dy + (long long)row * H + c, g[u][2 * it], g[u][2 * it + 1]);
@@ -1405,11 +1418,15 @@ int launch_lnb(int dtype, int nit, const void* pa, const void* pb, hipStream_t s
 extern "C" int magic_ln_bwd_tail(int dtype, int M, int H, const float* dy32, const void* y, const float* gamma, const float* beta, const float* rstd,
                                  const void* act_pre, int act, void* dx, float* dgamma, float* dbeta, void* stream) {
   if (M <= 0 || (H != 128 && H != 256 && H != 384 && H != 768) || !dy32 || !y || !gamma || !beta || !rstd || !act_pre || !dx) return MAGIC_ERR_ARG;
+  // act: bits 0..7 the activation (1 gelu, 2 relu); bits 8.. = S > 0: dy32 is S slabs of M x H to be added in slab order (magic_gemm with splitk = -S)
+  const int nslab = (act >> 8) > 0 ? (act >> 8) : 1;
+  act &= 0xFF;
+  if (nslab > 256) return MAGIC_ERR_ARG;
   if ((act != 1 && act != 2) || (dgamma == nullptr) != (dbeta == nullptr) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
   if (((uintptr_t)dy32 & 7) || !dtype_ok(dtype)) return MAGIC_ERR_ARG;
   LnbParams p{};
   p.M = M; p.y = y; p.gamma = gamma; p.beta = beta; p.rstd = rstd; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta; p.do_ln = 1; p.hot0 = -1;
-  p.dy32 = dy32; p.act_pre = act_pre; p.act = act;
+  p.dy32 = dy32; p.act_pre = act_pre; p.act = act; p.nslab = nslab;
   const int nit = H / 128, nw = lnb_waves(nit);
   const int nb = lnb_blocks(p, nit);
   const size_t shm = (size_t)(2 * nw) * H * sizeof(float);

@@ -81,6 +81,12 @@ class _BackwardHook(torch.autograd.Function):
 
 
 MLM_TAIL_FUSED = os.environ.get("MAGIC_MLM_TAIL_FUSED", "1") != "0"
+# K-splits of the vocabulary input gradient d_hm = dlogits Wemb (18 output tiles alone cannot fill 256 CUs).  Default: 32 splits, each STORING its partial into its own slab
+# (magic_gemm with splitk < 0), the slabs added in order by the transform's LayerNorm backward (magic_ln_bwd_tail) -- deterministic.  MAGIC_MLM_DX_ATOMICS=1: the
+# round-3 form, fp32 atomics into one accumulator: now and then ONE element of its bf16 cast flips, and every gradient below differs at a bf16 ulp
+# (profiles/micro/r06_det_probe_partial128_b.txt: 233 of 354 tensors).
+MLM_DX_SPLITK = int(os.environ.get("MAGIC_MLM_DX_SPLITK", "32"))
+MLM_DX_ATOMICS = os.environ.get("MAGIC_MLM_DX_ATOMICS", "0") != "0"
 
 
 class GlocalTextPathCMTPreTraining(nn.Module):
@@ -530,8 +536,13 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         scg = sc * gs                    # coefficient of the supervised gradient seeds (the loss values use sc)
         # every zero-initialised gradient accumulator of the step comes out of ONE zeroed arena per dtype (two fills instead of ~12 tiny ones)
         nm_ = plan["n_mask"] if task == "mlm" else 0
-        f32 = n.zeros(16 + nm_ * H, dtype=torch.float32)
-        c.slots, c.d_hm32 = f32[:16], (f32[16:].view(nm_, H) if nm_ else None)
+        c.dx_slabs = MLM_DX_SPLITK if (nm_ and MLM_TAIL_FUSED and not MLM_DX_ATOMICS and MLM_DX_SPLITK > 1) else 0
+        if c.dx_slabs:                     # [splits, n_mask, H] slabs, every element stored by its split: no zeroing
+            f32 = n.zeros(16, dtype=torch.float32)
+            c.slots, c.d_hm32 = f32, n.new(c.dx_slabs * nm_, H, dtype=torch.float32)
+        else:
+            f32 = n.zeros(16 + nm_ * H, dtype=torch.float32)
+            c.slots, c.d_hm32 = f32[:16], (f32[16:].view(nm_, H) if nm_ else None)
         if train:
             rows = [B * L, plan["Np"] * plan["V"], plan["Np"]]                               # d_txt, d_pano, d_fused
             rows += {"sap": [B * K, B * Vp, B * L], "cfp": [B * K, B * Vp, B * L, B, B, B], "mlm": [B * L, B * K], "mrc": [B * Vp]}[task]
@@ -811,10 +822,13 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                         nm, N=Vv, K=H, lda=c.ldv)
             # dx over the 50k-wide vocabulary: split-K into an fp32 accumulator (18 output tiles alone cannot fill 256 CUs)
             d_hm32 = c.d_hm32
-            O.gemm(1, dlog, Wemb, d_hm32, nm, H, Vv, c.ldv, H, H, splitk=32, accumulate=True)
+            if c.dx_slabs:
+                O.gemm(1, dlog, Wemb, d_hm32, nm, H, Vv, c.ldv, H, H, splitk=-c.dx_slabs)
+            else:
+                O.gemm(1, dlog, Wemb, d_hm32, nm, H, Vv, c.ldv, H, H, splitk=MLM_DX_SPLITK, accumulate=True)
             tn = n.ln("mlm_head.predictions.transform.LayerNorm")
-            if MLM_TAIL_FUSED:           # cast + LayerNorm backward + gelu' as one launch (the fp32 accumulator is read as it is)
-                d_tz = O.ln_bwd_tail(nm, H, d_hm32, c.hm, tn.g, tn.b, c.rstd_hm, c.tz, 1, n.new(nm, H), tn.dg, tn.db)
+            if MLM_TAIL_FUSED:           # cast + LayerNorm backward + gelu' as one launch (the fp32 accumulator -- or its slabs -- read as it is)
+                d_tz = O.ln_bwd_tail(nm, H, d_hm32, c.hm, tn.g, tn.b, c.rstd_hm, c.tz, 1, n.new(nm, H), tn.dg, tn.db, nslab=max(1, c.dx_slabs))
             else:
                 d_hm = O.cast_to(d_hm32, self.compute_dtype)
                 d_tg = n.new(nm, H)

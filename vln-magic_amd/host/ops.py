@@ -574,10 +574,13 @@ def ln_bwd(M, H, dy, *, y=None, gamma=None, beta=None, rstd=None, dx=None, dgamm
     return dx
 
 
-def ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, act_pre, act, dx, dgamma, dbeta):
+def ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, act_pre, act, dx, dgamma, dbeta, nslab=1):
     """LayerNorm backward of a head's transform with fp32 dy in and act'(act_pre) folded into dx (csrc/rowops.hip magic_ln_bwd_tail):
-    cast + ln_bwd + dact as one launch"""
+    cast + ln_bwd + dact as one launch.  nslab > 1: dy32 is [nslab, M, H], the slabs of a deterministic split-K product (gemm(..., splitk=-nslab)),
+    added in slab order on load"""
     _chk(dy32.dtype == torch.float32 and dy32.is_contiguous() and y.dtype == act_pre.dtype == dx.dtype, "ln_bwd_tail operands")
+    _chk(1 <= int(nslab) <= 256 and dy32.numel() >= int(nslab) * M * H, "ln_bwd_tail slabs")
+    act = int(act) | ((int(nslab) << 8) if int(nslab) > 1 else 0)
     L.call("magic_ln_bwd_tail", L.dt(y.dtype), M, H, L.P(dy32), L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(act_pre), int(act), L.P(dx),
            L.P(dgamma), L.P(dbeta), L.stream())
     return dx
@@ -588,7 +591,7 @@ def ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, act_pre, act, dx, dgamma, dbet
 # 608 x 768 rows, smallk_ln_bwd 58 us).  Inside a backward pass (the weight-gradient queue is active, so a flush is coming) every workgroup stores
 # its sums in its own row and `flush_part_jobs` adds the rows up: one launch per <= 96 vectors, block order, reproducible.
 PART_PG = os.environ.get("MAGIC_LN_PARTIAL", "1") != "0"
-PART_MIN_H = int(os.environ.get("MAGIC_LN_PARTIAL_MIN_H", "384"))
+PART_MIN_H = int(os.environ.get("MAGIC_LN_PARTIAL_MIN_H", "128"))      # round 6: every width (was 384: the student's LayerNorm / position-embedding gradients went through atomics)
 PART_JOBS = []         # (partial rows [nblk, stride] view, destination vector, nblk, len, stride)
 _LNB = {}
 

@@ -591,7 +591,11 @@ def ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, act_pre, act, dx, dgamma, dbet
 # 608 x 768 rows, smallk_ln_bwd 58 us).  Inside a backward pass (the weight-gradient queue is active, so a flush is coming) every workgroup stores
 # its sums in its own row and `flush_part_jobs` adds the rows up: one launch per <= 96 vectors, block order, reproducible.
 PART_PG = os.environ.get("MAGIC_LN_PARTIAL", "1") != "0"
-PART_MIN_H = int(os.environ.get("MAGIC_LN_PARTIAL_MIN_H", "128"))      # round 6: every width (was 384: the student's LayerNorm / position-embedding gradients went through atomics)
+# MAGIC_DETERMINISTIC=1 (round 6): every reduction that HAS an ordered form takes it -- partial-row parameter gradients at every width (else from H = 384 up, where
+# they are also the faster form) and the MLM head's vocabulary input gradient as split-K slabs (host/model_pretrain.py).  + 11 us per step of the headline cycle
+# (profiles/micro/r06_ab_determinism_cost.txt), 28 / 17 / 18 instead of 37 / 20 / 26 parameter tensors that differ run to run -- not yet 0, so not the default.
+DETERMINISTIC = os.environ.get("MAGIC_DETERMINISTIC", "0") != "0"
+PART_MIN_H = int(os.environ.get("MAGIC_LN_PARTIAL_MIN_H", "128" if DETERMINISTIC else "384"))
 PART_JOBS = []         # (partial rows [nblk, stride] view, destination vector, nblk, len, stride)
 _LNB = {}
 

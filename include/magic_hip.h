@@ -212,6 +212,10 @@ typedef struct magic_pano_in_bwd {
   const void* A1; const float* rstd1; const float* g1; const float* b1; float* dg1; float* db1; void* dP0;
   const void* A2; const float* rstd2; const float* g2; const float* b2; float* dg2; float* db2;
   const float* loc; float* dW; float* dbl;
+  /* round 6: != NULL -> every workgroup STORES its (11 + Kin) H sums in its own row of this buffer (pad0_ rows of pad1_ floats; row layout: dg3 | db3 |
+   * d_nav[3 H] | d_tok | dg1 | db1 | dg2 | db2 | dbl | dW[H Kin], each as its destination is laid out) instead of adding them with atomics; the caller adds
+   * rows 0 .. magic_embed_in_bwd_blocks(...) - 1 up in row order (magic_colsum_add_v).  NULL: the atomic form. */
+  float* part;
 } magic_pano_in_bwd;
 typedef struct magic_ln_bwd_in {
   int M, do_ln; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd; void* dx; float* dgamma; float* dbeta;
@@ -221,6 +225,8 @@ typedef struct magic_ln_bwd_in {
 int magic_embed_in_bwd_supported(int H, int Kin);
 /* cs_*: n_cs <= 96 column-sum jobs (the arguments of magic_colsum_add; their vectors have H columns) served by extra workgroups of the same
  * launch: every magic_rowbwd launch of a backward pass precedes this one, so its partial LayerNorm gradients can be finished here. */
+/* workgroups (= partial rows) of the panorama half for M rows beside nb_text workgroups of the text half (magic_ln_bwd_blocks); partial: with pa->part set */
+int magic_embed_in_bwd_blocks(int M, int H, int nb_text, int partial);
 int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa, const magic_ln_bwd_in* tx,
                        int n_cs, const float* const* cs_parts, float* const* cs_dsts, const int* cs_nblks, void* stream);
 int magic_smallk_ln_bwd(int dtype, int M, int H, int Kin, const float* x, const void* dy, const void* y,

@@ -744,6 +744,10 @@ struct magic_pano_in_bwd {
   const void* A1; const float* rstd1; const float* g1; const float* b1; float* dg1; float* db1; void* dP0;
   const void* A2; const float* rstd2; const float* g2; const float* b2; float* dg2; float* db2;
   const float* loc; float* dW; float* dbl;
+  // round 6: != NULL -> every block STORES its (11 + Kin) H sums in row `block` of this buffer (pad0_ rows of pad1_ floats: dg3 | db3 | d_nav[3 H] | d_tok | dg1 | db1 |
+  // dg2 | db2 | dbl | dW[H Kin], each laid out as its destination) instead of ending in as many same-address atomics; the caller adds the rows up in block order
+  // (magic_colsum_add_v): the atomics WERE the launch's time, and the sums become reproducible
+  float* part;
 };
 #ifdef PIB_VARIANT
 __device__ long long magic_pib_ticks[8];
@@ -899,6 +903,10 @@ __device__ __forceinline__ void pano_in_bwd_body(const magic_pano_in_bwd& p, con
         float v = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) v += red[(ww * 4 + j) * H + c];
+        if (p.part) {                // partial row of this block: vectors 0..10 at q H + c, the location weight at 11 H + c Kin + k (its destination's layout)
+          p.part[(long long)bid * p.pad1_ + (q < 11 ? q * H + c : 11 * H + c * Kin + (q - 11))] = v;
+          continue;
+        }
         float* dst = q == 0 ? p.dg3 + c : q == 1 ? p.db3 + c : q <= 4 ? p.d_nav + (long long)(q - 2) * H + c : q == 5 ? p.d_tok + c
                    : q == 6 ? p.dg1 + c : q == 7 ? p.db1 + c : q == 8 ? p.dg2 + c : q == 9 ? p.db2 + c : q == 10 ? p.dbl + c
                    : p.dW + (long long)c * Kin + (q - 11);
@@ -1330,16 +1338,30 @@ extern "C" int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void*
 // launches' whole cost -- ln_bwd 17.6 us for 608 x 768, 4 us without).  Sums run in block order: reproducible.  One launch holds a destination once.
 #define CSV_MAX 96
 struct ColsumVJobs { const float* part[CSV_MAX]; float* dst[CSV_MAX]; int nblk[CSV_MAX]; int len[CSV_MAX]; int stride[CSV_MAX]; int n; };
+// (round 6: a workgroup owns 64 columns and its four waves a quarter of the rows each, eight loads in flight per lane, combined through LDS in wave order -- one
+// thread per column walking all rows four at a time was a chain of nblk / 4 dependent round trips: 10.9 us for 80 rows x 2.3 k columns, 23.7 us per launch at H = 768)
 __global__ __launch_bounds__(256) void colsum_v_kernel(ColsumVJobs js) {
-  const int j = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= js.len[j]) return;
-  const float* pt = js.part[j] + c;
+  __shared__ float red[4][64];
+  const int j = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+  const int len = js.len[j];
+  if ((int)blockIdx.x * 64 >= len) return;                 // (block-uniform)
   const int nb = js.nblk[j], st = js.stride[j];
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nb; b += 4) { s0 += pt[(long long)b * st]; s1 += pt[(long long)(b + 1) * st]; s2 += pt[(long long)(b + 2) * st]; s3 += pt[(long long)(b + 3) * st]; }
-  for (; b < nb; ++b) s0 += pt[(long long)b * st];
-  js.dst[j][c] += (s0 + s1) + (s2 + s3);
+  const int per = (nb + 3) / 4, b0 = w * per, b1 = min(nb, b0 + per);
+  float s[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s[q] = 0.f;
+  if (c < len) {
+    const float* pt = js.part[j] + c;
+    int b = b0;
+    for (; b + 7 < b1; b += 8) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s[q] += pt[(long long)(b + q) * st];
+    }
+    for (; b < b1; ++b) s[0] += pt[(long long)b * st];
+  }
+  red[w][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (w == 0 && c < len) js.dst[j][c] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 extern "C" int magic_colsum_add_v(int n, const float* const* parts, float* const* dsts, const int* nblks, const int* lens, const int* strides, void* stream) {
   if (n <= 0 || n > CSV_MAX || !parts || !dsts || !nblks || !lens || !strides) return MAGIC_ERR_ARG;
@@ -1351,7 +1373,7 @@ extern "C" int magic_colsum_add_v(int n, const float* const* parts, float* const
     js.part[i] = parts[i]; js.dst[i] = dsts[i]; js.nblk[i] = nblks[i]; js.len[i] = lens[i]; js.stride[i] = strides[i];
     mx = lens[i] > mx ? lens[i] : mx;
   }
-  hipLaunchKernelGGL(colsum_v_kernel, dim3((mx + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, js);
+  hipLaunchKernelGGL(colsum_v_kernel, dim3((mx + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, js);
   return launch_status();
 }
 
@@ -1446,6 +1468,28 @@ struct magic_ln_bwd_in {
   const unsigned* drop_seed; float drop_p; unsigned site_dy, site_dx; int hot0; void* dxm;
 };
 extern "C" int magic_embed_in_bwd_supported(int H, int Kin) { return (H == 128 || H == 256) && Kin >= 1 && Kin <= PIB_KMAX; }
+// workgroups of the panorama half of magic_embed_in_bwd for M rows beside nb_text workgroups of the text half: one row per wave and iteration; with the atomic
+// epilogue every block ends in (11 + Kin) H same-address-class atomics and those, not the rows, are the launch's time (256 blocks 51 us, 96 blocks 30 us, 32
+// blocks 40 us: profiles/micro/embed_bwd_probe.py) -> 80 blocks (MAGIC_PIB_BLOCKS); with partial rows (round 6) 128 blocks (MAGIC_PIB_BLOCKS_PART; 0: bounded by the chip alone -- 24.7-26.9 us
+// for the launch at 80 / 128 / ~200 blocks, the column-sum launch behind it 7.0 / 6.8 / 7.9 us)
+static int pib_blocks(int M, int H, int nb_text, bool partial) {
+  const int nit = H / 128, nw = lnb_waves(nit);
+  int na = (M + 2 * nw - 1) / (2 * nw);               // (PIB_RPI = 2 rows per wave and iteration)
+  static int ncu = 0;
+  if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+  int room = ncu - nb_text > 64 ? ncu - nb_text : 64;
+  static int cap = -1, cap_part = -1;
+  if (cap < 0) { const char* e = getenv("MAGIC_PIB_BLOCKS"); cap = e ? atoi(e) : 80; }
+  if (cap_part < 0) { const char* e = getenv("MAGIC_PIB_BLOCKS_PART"); cap_part = e ? atoi(e) : 128; }
+  const int c = partial ? cap_part : cap;
+  if (c > 0 && room > c) room = c;
+  return na > room ? room : na;
+}
+// the row count of the partial buffer a caller of magic_embed_in_bwd must provide (and the number of rows magic_colsum_add_v then adds up)
+extern "C" int magic_embed_in_bwd_blocks(int M, int H, int nb_text, int partial) {
+  if (M <= 0 || (H != 128 && H != 256) || nb_text < 0) return MAGIC_ERR_ARG;
+  return pib_blocks(M, H, nb_text, partial != 0);
+}
 extern "C" int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa, const magic_ln_bwd_in* tx,
                                   int n_cs, const float* const* cs_parts, float* const* cs_dsts, const int* cs_nblks, void* stream) {
   if (!pa || !dtype_ok(dtype)) return MAGIC_ERR_ARG;
@@ -1483,17 +1527,8 @@ extern "C" int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa,
                   (don && t.site_dx) ? t.dxm : nullptr, DropDesc{(don && t.site_dx) ? t.drop_seed : nullptr, t.site_dx, t.drop_p}, t.hot0};
     nb = lnb_blocks(b, nit);
   }
-  // one row per wave and iteration; every block ends in (11 + Kin) H atomics and fills a CU: the whole launch is kept to ONE round of the chip
-  int na = (a.M + 2 * nw - 1) / (2 * nw);               // (PIB_RPI = 2 rows per wave and iteration)
-  static int ncu = 0;
-  if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-  int room = ncu - nb > 64 ? ncu - nb : 64;
-  static int cap = -1;
-  // every block ends in (11 + Kin) H same-address-class atomics and those, not the rows, are the launch's time: 256 blocks 51 us, 96 blocks 30 us,
-  // 32 blocks 40 us (profiles/micro/embed_bwd_probe.py) -> 80 blocks by default
-  if (cap < 0) { const char* e = getenv("MAGIC_PIB_BLOCKS"); cap = e ? atoi(e) : 80; }
-  if (cap > 0 && room > cap) room = cap;
-  if (na > room) na = room;
+  const int na = pib_blocks(a.M, H, nb, a.part != nullptr);
+  if (a.part && (a.pad0_ < na || a.pad1_ < (11 + a.Kin) * H || ((uintptr_t)a.part & 3))) return MAGIC_ERR_ARG;      // (rows, stride of the partial buffer)
   const size_t sa = (size_t)nw * 4 * H * sizeof(float), sb = (size_t)(2 * nw + 9) * H * sizeof(float), shm = sa > sb ? sa : sb;
   dim3 grid(na + nb + n_cs), block(nw * 64);
   hipStream_t st = (hipStream_t)stream;

@@ -68,6 +68,7 @@ SIGNATURES = {
     "magic_node_in_fwd": [i32, i32, i32, vp, vp],
     "magic_embed_in_fwd": [i32, i32, vp, vp, vp],
     "magic_embed_in_bwd_supported": [i32, i32],
+    "magic_embed_in_bwd_blocks": [i32, i32, i32, i32],
     "magic_embed_in_bwd": [i32, i32, vp, vp, i32, vp, vp, vp, vp],
     "magic_csr_gather_multi": [i32, i32, i32, vp, vp],
     "magic_smallk_ln_bwd_pair": [i32, i32, vp, vp],
@@ -164,7 +165,7 @@ class PanoInBwd(C.Structure):
     """mirror of `magic_pano_in_bwd` (include/magic_hip.h)"""
     _fields_ = [("M", i32), ("Kin", i32), ("pad0_", i32), ("pad1_", i32), ("dy", vp), ("ddy", DropD)] + \
                [(n, vp) for n in ("X0", "rstd3", "g3", "b3", "dg3", "db3", "nav_idx", "d_nav", "d_tok", "A1", "rstd1", "g1", "b1", "dg1", "db1", "dP0",
-                                  "A2", "rstd2", "g2", "b2", "dg2", "db2", "loc", "dW", "dbl")]
+                                  "A2", "rstd2", "g2", "b2", "dg2", "db2", "loc", "dW", "dbl", "part")]
 
 
 class LnBwdIn(C.Structure):

@@ -81,12 +81,12 @@ class _BackwardHook(torch.autograd.Function):
 
 
 MLM_TAIL_FUSED = os.environ.get("MAGIC_MLM_TAIL_FUSED", "1") != "0"
-# K-splits of the vocabulary input gradient d_hm = dlogits Wemb (18 output tiles alone cannot fill 256 CUs): 32 splits.  Default: fp32 atomics into one accumulator
-# (round 3) -- now and then ONE element of its bf16 cast flips between runs, and every gradient below differs at a bf16 ulp (profiles/micro/
-# r06_det_probe_partial128_b.txt: 233 of 354 tensors).  MAGIC_DETERMINISTIC=1 (or MAGIC_MLM_DX_ATOMICS=0): each split STORES its partial into its own slab (magic_gemm with
-# splitk < 0) and the transform's LayerNorm backward adds the slabs in order (magic_ln_bwd_tail): reproducible, + 13-18 us on an mlm step.
+# K-splits of the vocabulary input gradient d_hm = dlogits Wemb (18 output tiles alone cannot fill 256 CUs): 32 splits.  Default (round 6): each split STORES its
+# partial into its own slab (magic_gemm with splitk < 0) and the transform's LayerNorm backward adds the slabs in order (magic_ln_bwd_tail): reproducible, + 13-18 us on
+# an mlm step.  MAGIC_MLM_DX_ATOMICS=1: the round-3 form, fp32 atomics into one accumulator -- whenever launch timing shifts ONE element of its bf16 cast flips between
+# runs and every gradient below differs at a bf16 ulp (233 of 354 tensors: profiles/micro/r06_det_probe_partial128_b.txt), which is not a property to ship for 5 us a step.
 MLM_DX_SPLITK = int(os.environ.get("MAGIC_MLM_DX_SPLITK", "32"))
-MLM_DX_ATOMICS = os.environ.get("MAGIC_MLM_DX_ATOMICS", "0" if O.DETERMINISTIC else "1") != "0"
+MLM_DX_ATOMICS = os.environ.get("MAGIC_MLM_DX_ATOMICS", "0") != "0"
 
 
 class GlocalTextPathCMTPreTraining(nn.Module):

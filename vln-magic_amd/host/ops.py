@@ -591,10 +591,12 @@ def ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, act_pre, act, dx, dgamma, dbet
 # 608 x 768 rows, smallk_ln_bwd 58 us).  Inside a backward pass (the weight-gradient queue is active, so a flush is coming) every workgroup stores
 # its sums in its own row and `flush_part_jobs` adds the rows up: one launch per <= 96 vectors, block order, reproducible.
 PART_PG = os.environ.get("MAGIC_LN_PARTIAL", "1") != "0"
-# MAGIC_DETERMINISTIC=1 (round 6): every reduction that HAS an ordered form takes it -- partial-row parameter gradients at every width (else from H = 384 up, where
-# they are also the faster form) and the MLM head's vocabulary input gradient as split-K slabs (host/model_pretrain.py).  + 11 us per step of the headline cycle
-# (profiles/micro/r06_ab_determinism_cost.txt), 28 / 17 / 18 instead of 37 / 20 / 26 parameter tensors that differ run to run -- not yet 0, so not the default.
-DETERMINISTIC = os.environ.get("MAGIC_DETERMINISTIC", "0") != "0"
+# Round 6: every reduction that HAS an ordered form takes it by default -- the embedding stage's panorama half through partial rows (embed_in_bwd), the MLM head's
+# vocabulary input gradient as split-K slabs (host/model_pretrain.py), and the partial-row parameter gradients at EVERY width (before: from H = 384 up, where they
+# are also the faster form).  17 / 8 / 9 of 354 parameter tensors still differ run to run on sap / mlm / cfp (round 5: 37 / 20 / 26 -- and 233 on mlm whenever launch
+# timing shifted); + 5 us per step of the headline cycle, all of it the MLM slabs (profiles/micro/r06_ab_determinism_cost*.txt).  MAGIC_DETERMINISTIC=0: partial rows
+# from H = 384 only (MAGIC_MLM_DX_ATOMICS=1 / MAGIC_EMBED_BWD_PARTIAL=0 switch the other two back).
+DETERMINISTIC = os.environ.get("MAGIC_DETERMINISTIC", "1") != "0"
 PART_MIN_H = int(os.environ.get("MAGIC_LN_PARTIAL_MIN_H", "128" if DETERMINISTIC else "384"))
 PART_JOBS = []         # (partial rows [nblk, stride] view, destination vector, nblk, len, stride)
 _LNB = {}
@@ -709,6 +711,11 @@ def embed_in_bwd_ok(H, Kin):
     return _EIB_OK[key]
 
 
+# round 6: the panorama half's (11 + Kin) parameter-gradient vectors through partial rows + the flush's column-sum launch instead of one round of same-address atomics
+# per workgroup -- those atomics were the launch's time (csrc/rowops.hip pib_blocks), and the sums become reproducible.  MAGIC_EMBED_BWD_PARTIAL=0: the atomic form.
+EMBED_BWD_PARTIAL = os.environ.get("MAGIC_EMBED_BWD_PARTIAL", "1") != "0"
+
+
 def embed_in_bwd(H, pano, text=None):
     """backward of the panorama encoder's input stage (sum / image / location LayerNorm backwards, nav-type / token-type / loc_linear gradients)
     and, optionally, the text embedding's LayerNorm backward + table scatters as ONE launch (csrc/rowops.hip embed_in_bwd_kernel).
@@ -721,6 +728,20 @@ def embed_in_bwd(H, pano, text=None):
         setattr(a, k, L.P(pano[k]))
     seed, p_, site = _dr(pano.get("drop_dy"))
     a.ddy.seed, a.ddy.site, a.ddy.p = seed, int(site), float(p_)
+    part = None
+    if EMBED_BWD_PARTIAL and PART_PG and DEFER["active"]:
+        Kin, M = int(pano["Kin"]), int(pano["M"])
+        nbt = _ln_blocks(int(text["M"]), H, any(tb is not None and tb[3] is not None for tb in text.get("dtabs", ()))) if text is not None else 0
+        nblk = int(L.load().magic_embed_in_bwd_blocks(M, H, nbt, 1))
+        _chk(nblk > 0, "magic_embed_in_bwd_blocks")
+        stride = (11 + Kin) * H
+        part = torch.empty(nblk, stride, dtype=torch.float32, device=pano["dy"].device)
+        a.part, a.pad0_, a.pad1_ = L.P(part), nblk, stride
+        flat = part.view(-1)
+        for off, length, dst in ((0, H, pano["dg3"]), (H, H, pano["db3"]), (2 * H, min(3 * H, pano["d_nav"].numel()), pano["d_nav"]), (5 * H, H, pano["d_tok"]),
+                                 (6 * H, H, pano["dg1"]), (7 * H, H, pano["db1"]), (8 * H, H, pano["dg2"]), (9 * H, H, pano["db2"]), (10 * H, H, pano["dbl"]),
+                                 (11 * H, H * Kin, pano["dW"])):
+            PART_JOBS.append((flat[off:], dst, nblk, length, stride))
     tp = None
     if text is not None:
         t = L.LnBwdIn()

@@ -127,7 +127,7 @@ int magic_ln_bwd(int dtype, int M, int H, const void* dy, const void* y, const f
  * [M, H] accumulator the split-K input gradient of the vocabulary projection leaves (no cast launch), and dx = LayerNorm'(dy) x act'(act_pre)
  * (no activation-derivative launch; act: 1 = erf gelu, 2 = relu; act_pre: the dense output before the activation, storage dtype).  gamma / beta
  * gradients are added as magic_ln_bwd does without partial rows.  Replaces cast + magic_ln_bwd + magic_dact. */
-/* act: bits 0..7 the activation in front of the LayerNorm (1 gelu, 2 relu); bits 8.. = S > 0: dy32 holds S slabs of M x H (magic_gemm with splitk = -S) that
+/* act: bits 0..5 the activation in front of the LayerNorm (1 gelu, 2 relu); bit 6: dgamma / dbeta are partial buffers [magic_ln_bwd_blocks(M, H, 0)][H]; bits 8.. = S > 0: dy32 holds S slabs of M x H (magic_gemm with splitk = -S) that
  * are added in slab order on load (round 6). */
 int magic_ln_bwd_tail(int dtype, int M, int H, const float* dy32, const void* y, const float* gamma, const float* beta, const float* rstd,
                       const void* act_pre, int act, void* dx, float* dgamma, float* dbeta, void* stream);
@@ -221,6 +221,7 @@ typedef struct magic_ln_bwd_in {
   int M, do_ln; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd; void* dx; float* dgamma; float* dbeta;
   const int* idx[3]; int mod[3]; int off[3]; float* d[3]; int small[3];
   const unsigned* drop_seed; float drop_p; unsigned site_dy, site_dx; int hot0; void* dxm;
+  int partial;   /* round 6: != 0 -> dgamma / dbeta are partial buffers [magic_ln_bwd_blocks(M, H, tables)][H], as magic_ln_bwd's `partial` */
 } magic_ln_bwd_in;
 int magic_embed_in_bwd_supported(int H, int Kin);
 /* cs_*: n_cs <= 96 column-sum jobs (the arguments of magic_colsum_add; their vectors have H columns) served by extra workgroups of the same

@@ -1442,13 +1442,14 @@ extern "C" int magic_ln_bwd_tail(int dtype, int M, int H, const float* dy32, con
   if (M <= 0 || (H != 128 && H != 256 && H != 384 && H != 768) || !dy32 || !y || !gamma || !beta || !rstd || !act_pre || !dx) return MAGIC_ERR_ARG;
   // act: bits 0..7 the activation (1 gelu, 2 relu); bits 8.. = S > 0: dy32 is S slabs of M x H to be added in slab order (magic_gemm with splitk = -S)
   const int nslab = (act >> 8) > 0 ? (act >> 8) : 1;
-  act &= 0xFF;
+  const int partial = (act & 0x40) ? 1 : 0;          // bit 6: dgamma / dbeta are PARTIAL buffers [magic_ln_bwd_blocks(M, H, 0)][H]
+  act &= 0x3F;
   if (nslab > 256) return MAGIC_ERR_ARG;
   if ((act != 1 && act != 2) || (dgamma == nullptr) != (dbeta == nullptr) || (long long)M * H > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
   if (((uintptr_t)dy32 & 7) || !dtype_ok(dtype)) return MAGIC_ERR_ARG;
   LnbParams p{};
   p.M = M; p.y = y; p.gamma = gamma; p.beta = beta; p.rstd = rstd; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta; p.do_ln = 1; p.hot0 = -1;
-  p.dy32 = dy32; p.act_pre = act_pre; p.act = act; p.nslab = nslab;
+  p.dy32 = dy32; p.act_pre = act_pre; p.act = act; p.nslab = nslab; p.pg_partial = (partial && dgamma) ? 1 : 0;
   const int nit = H / 128, nw = lnb_waves(nit);
   const int nb = lnb_blocks(p, nit);
   const size_t shm = (size_t)(2 * nw) * H * sizeof(float);
@@ -1466,6 +1467,7 @@ struct magic_ln_bwd_in {
   int M, do_ln; const void* dy; const void* y; const float* gamma; const float* beta; const float* rstd; void* dx; float* dgamma; float* dbeta;
   const int* idx[3]; int mod[3]; int off[3]; float* d[3]; int small[3];
   const unsigned* drop_seed; float drop_p; unsigned site_dy, site_dx; int hot0; void* dxm;
+  int partial;               // round 6: != 0 -> dgamma / dbeta are PARTIAL buffers [magic_ln_bwd_blocks(M, H, tables)][H] (magic_ln_bwd's `partial`)
 };
 extern "C" int magic_embed_in_bwd_supported(int H, int Kin) { return (H == 128 || H == 256) && Kin >= 1 && Kin <= PIB_KMAX; }
 // workgroups of the panorama half of magic_embed_in_bwd for M rows beside nb_text workgroups of the text half: one row per wave and iteration; with the atomic
@@ -1525,6 +1527,7 @@ extern "C" int magic_embed_in_bwd(int dtype, int H, const magic_pano_in_bwd* pa,
                   TabRef{t.d[2], t.idx[2], t.mod[2], t.off[2]}, t.d[2], t.small[2], t.do_ln,
                   DropDesc{(don && t.site_dy) ? t.drop_seed : nullptr, t.site_dy, t.drop_p},
                   (don && t.site_dx) ? t.dxm : nullptr, DropDesc{(don && t.site_dx) ? t.drop_seed : nullptr, t.site_dx, t.drop_p}, t.hot0};
+    b.pg_partial = (t.partial && t.dgamma) ? 1 : 0;
     nb = lnb_blocks(b, nit);
   }
   const int na = pib_blocks(a.M, H, nb, a.part != nullptr);

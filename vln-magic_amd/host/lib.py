@@ -172,7 +172,7 @@ class LnBwdIn(C.Structure):
     """mirror of `magic_ln_bwd_in` (include/magic_hip.h)"""
     _fields_ = [("M", i32), ("do_ln", i32)] + [(n, vp) for n in ("dy", "y", "gamma", "beta", "rstd", "dx", "dgamma", "dbeta")] + \
                [("idx", vp * 3), ("mod", i32 * 3), ("off", i32 * 3), ("d", vp * 3), ("small", i32 * 3),
-                ("drop_seed", vp), ("drop_p", f32), ("site_dy", u32), ("site_dx", u32), ("hot0", i32), ("dxm", vp)]
+                ("drop_seed", vp), ("drop_p", f32), ("site_dy", u32), ("site_dx", u32), ("hot0", i32), ("dxm", vp), ("partial", i32)]
 
 
 class CsrProb(C.Structure):

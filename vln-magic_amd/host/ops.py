@@ -581,6 +581,12 @@ def ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, act_pre, act, dx, dgamma, dbet
     _chk(dy32.dtype == torch.float32 and dy32.is_contiguous() and y.dtype == act_pre.dtype == dx.dtype, "ln_bwd_tail operands")
     _chk(1 <= int(nslab) <= 256 and dy32.numel() >= int(nslab) * M * H, "ln_bwd_tail slabs")
     act = int(act) | ((int(nslab) << 8) if int(nslab) > 1 else 0)
+    if dgamma is not None and part_ok(H) and H <= 384:          # gamma / beta sums of every workgroup to its own row; the flush's column-sum launch adds them up in order (H = 768: the block count of the lean shape differs)
+        nblk = _ln_blocks(M, H, False)
+        pt = torch.empty(2, nblk, H, dtype=torch.float32, device=dy32.device)
+        PART_JOBS.append((pt[0], dgamma, nblk, H, H))
+        PART_JOBS.append((pt[1], dbeta, nblk, H, H))
+        dgamma, dbeta, act = pt[0], pt[1], act | 0x40
     L.call("magic_ln_bwd_tail", L.dt(y.dtype), M, H, L.P(dy32), L.P(y), L.P(gamma), L.P(beta), L.P(rstd), L.P(act_pre), int(act), L.P(dx),
            L.P(dgamma), L.P(dbeta), L.stream())
     return dx
@@ -593,7 +599,7 @@ def ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, act_pre, act, dx, dgamma, dbet
 PART_PG = os.environ.get("MAGIC_LN_PARTIAL", "1") != "0"
 # Round 6: every reduction that HAS an ordered form takes it by default -- the embedding stage's panorama half through partial rows (embed_in_bwd), the MLM head's
 # vocabulary input gradient as split-K slabs (host/model_pretrain.py), and the partial-row parameter gradients at EVERY width (before: from H = 384 up, where they
-# are also the faster form).  17 / 8 / 9 of 354 parameter tensors still differ run to run on sap / mlm / cfp (round 5: 37 / 20 / 26 -- and 233 on mlm whenever launch
+# are also the faster form).  17 / 4 / 7 of 354 parameter tensors still differ run to run on sap / mlm / cfp (round 5: 37 / 20 / 26 -- and 233 on mlm whenever launch
 # timing shifted); + 5 us per step of the headline cycle, all of it the MLM slabs (profiles/micro/r06_ab_determinism_cost*.txt).  MAGIC_DETERMINISTIC=0: partial rows
 # from H = 384 only (MAGIC_MLM_DX_ATOMICS=1 / MAGIC_EMBED_BWD_PARTIAL=0 switch the other two back).
 DETERMINISTIC = os.environ.get("MAGIC_DETERMINISTIC", "1") != "0"
@@ -758,6 +764,12 @@ def embed_in_bwd(H, pano, text=None):
         t.site_dy = int(d_dy[2]) if (p_ > 0 and d_dy is not None) else 0
         t.site_dx = int(d_dx[2]) if (p_ > 0 and d_dx is not None) else 0
         t.hot0, t.dxm = int(text.get("hot0", -1)), L.P(text.get("dxm"))
+        if text.get("dgamma") is not None and text.get("do_ln", True) and part_ok(H):
+            nbt_ = _ln_blocks(int(text["M"]), H, any(tb is not None and tb[3] is not None for tb in text.get("dtabs", ())))
+            ptt = torch.empty(2, nbt_, H, dtype=torch.float32, device=text["dy"].device)
+            PART_JOBS.append((ptt[0], text["dgamma"], nbt_, H, H))
+            PART_JOBS.append((ptt[1], text["dbeta"], nbt_, H, H))
+            t.dgamma, t.dbeta, t.partial = L.P(ptt[0]), L.P(ptt[1]), 1
         tp = C.addressof(t)
     # the partial LayerNorm gradients the row-block launches of this backward queued (their vectors are H wide, each destination once) ride along
     take, keep, seen = [], [], set()

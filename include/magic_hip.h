@@ -278,9 +278,12 @@ int magic_attn_bwd_ks(int dtype, int B, int nh, int Nq, int Nk, const void* q, i
 /* ClsPrediction tail (Linear->ReLU->LN->Linear(H,1)): logit = dot(LN(Y), w2) + b2 */
 int magic_lndot_fwd(int dtype, int M, int H, const void* Y, const float* gamma, const float* beta, float eps,
                     const float* w2, const float* b2, float* logit, void* stream);
+/* part (round 6; a trailing argument added to this entry point): != NULL -> every workgroup STORES its sums [dgamma | dbeta | dw2 | db2] (3 H + 1 floats) in row
+ * `workgroup` of this buffer (magic_lndot_bwd_blocks(M) rows) instead of adding them with atomics; the caller adds the rows up in order (magic_colsum_add_v). */
+int magic_lndot_bwd_blocks(int M);
 int magic_lndot_bwd(int dtype, int M, int H, const void* Y, const float* gamma, const float* beta, float eps,
                     const float* w2, const float* dlogit, void* dZ, float* dgamma, float* dbeta, float* dw2, float* db2,
-                    void* stream);
+                    float* part, void* stream);
 
 /* Rowwise CE with -inf masks + ignore_index (agent_base.py:152 criterion; validate_* of train_r2r_magic.py),
  * gradient coef*w*(softmax-onehot) in the same pass; w_out = exp(-w_rate*CE) = MKTD weights (agent.py:1013-1020,

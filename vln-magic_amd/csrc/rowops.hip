@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(256) void lndot_fwd_kernel(int M, int H, const T* Y
 template <typename T, int NIT>
 __global__ __launch_bounds__(256) void lndot_bwd_kernel(int M, int H, const T* Y, const float* gamma, const float* beta, float eps,
                                                         const float* w2, const float* dlogit, T* dZ,
-                                                        float* dgamma, float* dbeta, float* dw2, float* db2) {
+                                                        float* dgamma, float* dbeta, float* dw2, float* db2, float* part) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [3][4][H] + [4]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   constexpr int nit = NIT;
@@ -1214,6 +1214,16 @@ __global__ __launch_bounds__(256) void lndot_bwd_kernel(int M, int H, const T* Y
     }
   if (lane == 0) red[12 * H + wid] = adb;     // every lane of the wave holds the same adb
   __syncthreads();
+  if (part) {          // round 6: this block's sums to its own row [dgamma | dbeta | dw2 | db2] (3 H + 1 floats); the caller adds the rows up in block order
+    float* row = part + (long long)blockIdx.x * (3 * H + 1);
+    for (int c = threadIdx.x; c < H; c += 256) {
+      row[c] = red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c];
+      row[H + c] = red[4 * H + c] + red[5 * H + c] + red[6 * H + c] + red[7 * H + c];
+      row[2 * H + c] = red[8 * H + c] + red[9 * H + c] + red[10 * H + c] + red[11 * H + c];
+    }
+    if (threadIdx.x == 0) row[3 * H] = red[12 * H] + red[12 * H + 1] + red[12 * H + 2] + red[12 * H + 3];
+    return;
+  }
   for (int c = threadIdx.x; c < H; c += 256) {
     atomicAdd(dgamma + c, red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c]);
     atomicAdd(dbeta + c, red[4 * H + c] + red[5 * H + c] + red[6 * H + c] + red[7 * H + c]);
@@ -1730,14 +1740,17 @@ extern "C" int magic_lndot_fwd(int dtype, int M, int H, const void* Y, const flo
   return launch_status();
 }
 
+// workgroups (= rows of 3 H + 1 floats of the `part` buffer) magic_lndot_bwd launches for M rows
+extern "C" int magic_lndot_bwd_blocks(int M) { return M > 0 ? (M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS) : MAGIC_ERR_ARG; }
 extern "C" int magic_lndot_bwd(int dtype, int M, int H, const void* Y, const float* gamma, const float* beta, float eps,
                                const float* w2, const float* dlogit, void* dZ, float* dgamma, float* dbeta, float* dw2, float* db2,
-                               void* stream) {
+                               float* part, void* stream) {
   if (M <= 0 || !okH(H)) return MAGIC_ERR_ARG;
+  if (!part && (!dgamma || !dbeta || !dw2 || !db2)) return MAGIC_ERR_ARG;
   dim3 grid((M + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS)), block(256);
   size_t shm = (size_t)(12 * H + 4) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define LDB(TY, NIT) hipLaunchKernelGGL((lndot_bwd_kernel<TY, NIT>), grid, block, shm, st, M, H, (const TY*)Y, gamma, beta, eps, w2, dlogit, (TY*)dZ, dgamma, dbeta, dw2, db2)
+#define LDB(TY, NIT) hipLaunchKernelGGL((lndot_bwd_kernel<TY, NIT>), grid, block, shm, st, M, H, (const TY*)Y, gamma, beta, eps, w2, dlogit, (TY*)dZ, dgamma, dbeta, dw2, db2, part)
   DISPATCH_NIT(dtype, H, LDB);
 #undef LDB
   return launch_status();

@@ -52,7 +52,8 @@ SIGNATURES = {
     "magic_head_mean_fwd": [i32, i32, i32, i64, vp, vp, vp],
     "magic_head_mean_bwd": [i32, i32, i64, vp, vp, i32, vp],
     "magic_lndot_fwd": [i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp],
-    "magic_lndot_bwd": [i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "magic_lndot_bwd": [i32, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "magic_lndot_bwd_blocks": [i32],
     "magic_ce_rows": [i32, i32, i32, vp, i32, vp, i32, f32, vp, vp, vp, i32, i32, vp, f32, vp],
     "magic_softkl_rows": [i32, i32, i32, vp, i32, vp, i32, f32, vp, vp, vp, i32, vp],
     "magic_kd_rows": [i32, i32, vp, vp, i32, f32, vp, f32, f32, vp, vp, vp, i32, vp],

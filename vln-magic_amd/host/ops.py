@@ -599,7 +599,7 @@ def ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, act_pre, act, dx, dgamma, dbet
 PART_PG = os.environ.get("MAGIC_LN_PARTIAL", "1") != "0"
 # Round 6: every reduction that HAS an ordered form takes it by default -- the embedding stage's panorama half through partial rows (embed_in_bwd), the MLM head's
 # vocabulary input gradient as split-K slabs (host/model_pretrain.py), and the partial-row parameter gradients at EVERY width (before: from H = 384 up, where they
-# are also the faster form).  17 / 4 / 7 of 354 parameter tensors still differ run to run on sap / mlm / cfp (round 5: 37 / 20 / 26 -- and 233 on mlm whenever launch
+# are also the faster form).  7 / 4 / 7 of 354 parameter tensors still differ run to run on sap / mlm / cfp (round 5: 37 / 20 / 26 -- and 233 on mlm whenever launch
 # timing shifted); + 5 us per step of the headline cycle, all of it the MLM slabs (profiles/micro/r06_ab_determinism_cost*.txt).  MAGIC_DETERMINISTIC=0: partial rows
 # from H = 384 only (MAGIC_MLM_DX_ATOMICS=1 / MAGIC_EMBED_BWD_PARTIAL=0 switch the other two back).
 DETERMINISTIC = os.environ.get("MAGIC_DETERMINISTIC", "1") != "0"
@@ -1190,8 +1190,16 @@ def lndot_fwd(Y, M, H, gamma, beta, eps, w2, b2, logit):
 
 
 def lndot_bwd(Y, M, H, gamma, beta, eps, w2, dlogit, dZ, dgamma, dbeta, dw2, db2):
+    part = None
+    if part_ok(H):             # (round 6) every workgroup's four sums to its own row, added up in block order by the flush's column-sum launch
+        nblk = int(L.load().magic_lndot_bwd_blocks(int(M)))
+        stride = 3 * H + 1
+        part = torch.empty(nblk, stride, dtype=torch.float32, device=Y.device)
+        flat = part.view(-1)
+        for off, length, dst in ((0, H, dgamma), (H, H, dbeta), (2 * H, H, dw2), (3 * H, 1, db2)):
+            PART_JOBS.append((flat[off:], dst.reshape(-1), nblk, length, stride))
     L.call("magic_lndot_bwd", L.dt(Y.dtype), M, H, L.P(Y), L.P(gamma), L.P(beta), float(eps), L.P(w2), L.P(dlogit), L.P(dZ),
-           L.P(dgamma), L.P(dbeta), L.P(dw2), L.P(db2), L.stream())
+           L.P(dgamma), L.P(dbeta), L.P(dw2), L.P(db2), L.P(part), L.stream())
 
 
 def ce_rows(logits, M, N, ld, labels, *, ignore_index=-100, coef=0.0, row_w=None, loss_row=None, dlogits=None, ldd=0,

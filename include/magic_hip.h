@@ -258,6 +258,8 @@ int magic_attn_fwd(int dtype, int B, int nh, int Nq, int Nk, const void* q, int 
                    void* P, int ldp, void* ctx, int H, float scale, const unsigned char* kmask, const float* dist,
                    const float* sprel_w, const float* sprel_b,
                    const void* drop_seed, float drop_p, unsigned drop_site, void* Pd, void* stream);
+/* dsprel_b NULL with dist and dsprel_w set (round 6): dsprel_w is a partial buffer [B nh][2]; every (sample, head) workgroup STORES its (weight, bias) sums
+ * there instead of adding them with atomics, and the caller adds the pairs up in order (magic_colsum_add_v). */
 int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const void* q, int ldq, const void* k, const void* v, int ldkv,
                    const void* P, int ldp, const void* dctx, int H, float scale, const float* dP_init,
                    void* dq, int lddq, void* dk, void* dv, int lddkv,

@@ -1010,8 +1010,11 @@ __device__ __forceinline__ void attn_bwd_body(const AttnParams& p, const int h, 
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int i = 0; i < NW; ++i) { s0 += red[i]; s1 += red[NW + i]; }
-    atomicAdd(p.dsprel_w, s0);
-    atomicAdd(p.dsprel_b, s1);
+    if (p.dsprel_b) { atomicAdd(p.dsprel_w, s0); atomicAdd(p.dsprel_b, s1); }
+    else {                       // round 6 (dsprel_b NULL): dsprel_w is a PARTIAL buffer [B nh][2] -- this workgroup's pair, added up in order by the caller
+      p.dsprel_w[2 * (b * p.nh + h)] = s0;
+      p.dsprel_w[2 * (b * p.nh + h) + 1] = s1;
+    }
   }
   ATT_MARK(2);
   // ---- phase 2: dQ = dS K ; dK = dS^T Q ; dV = P^T dO        (tiles of 16 rows x 64 head dims, round-robin over waves)
@@ -1194,7 +1197,8 @@ extern "C" int magic_attn_bwd(int dtype, int B, int nh, int Nq, int Nk, const vo
   if (rc) return rc;
   if (!drop_args_ok(drop_seed, drop_p) || (long long)B * nh * Nq * Nk > 0xFFFFFFFFll) return MAGIC_ERR_ARG;
   if (!magic_attn_supported(dtype, Nq, Nk, 1)) return MAGIC_ERR_UNSUPPORTED;
-  if ((dist == nullptr) != (dsprel_w == nullptr) || (dist == nullptr) != (dsprel_b == nullptr)) return MAGIC_ERR_ARG;
+  // dsprel_b NULL with dsprel_w set (round 6): dsprel_w is a partial buffer of 2 B nh floats, every workgroup STORES its (weight, bias) sums; the caller adds them up
+  if ((dist == nullptr) != (dsprel_w == nullptr) || (dsprel_b != nullptr && dist == nullptr)) return MAGIC_ERR_ARG;
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)P & 15) || ((uintptr_t)dctx & 15) || ((uintptr_t)dP_init & 15)) return MAGIC_ERR_ARG;
   AttnParams p = {};
   p.q = q; p.k = k; p.v = v; p.P = (void*)P; p.dist = dist; p.B = B; p.nh = nh; p.Nq = Nq; p.Nk = Nk; p.ldq = ldq; p.ldkv = ldkv;

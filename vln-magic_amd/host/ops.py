@@ -599,7 +599,7 @@ def ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, act_pre, act, dx, dgamma, dbet
 PART_PG = os.environ.get("MAGIC_LN_PARTIAL", "1") != "0"
 # Round 6: every reduction that HAS an ordered form takes it by default -- the embedding stage's panorama half through partial rows (embed_in_bwd), the MLM head's
 # vocabulary input gradient as split-K slabs (host/model_pretrain.py), and the partial-row parameter gradients at EVERY width (before: from H = 384 up, where they
-# are also the faster form).  7 / 4 / 7 of 354 parameter tensors still differ run to run on sap / mlm / cfp (round 5: 37 / 20 / 26 -- and 233 on mlm whenever launch
+# are also the faster form).  5 / 4 / 5 of 354 parameter tensors still differ run to run on sap / mlm / cfp (round 5: 37 / 20 / 26 -- and 233 on mlm whenever launch
 # timing shifted); + 5 us per step of the headline cycle, all of it the MLM slabs (profiles/micro/r06_ab_determinism_cost*.txt).  MAGIC_DETERMINISTIC=0: partial rows
 # from H = 384 only (MAGIC_MLM_DX_ATOMICS=1 / MAGIC_EMBED_BWD_PARTIAL=0 switch the other two back).
 DETERMINISTIC = os.environ.get("MAGIC_DETERMINISTIC", "1") != "0"
@@ -621,7 +621,11 @@ def _ln_blocks(M, H, has_tables=False):
     return v
 
 
+_SPREL = {}            # destination -> [partial buffer [rows, 2], rows used, index of its two jobs in PART_JOBS] of the current flush window (attn_bwd)
+
+
 def flush_part_jobs():
+    _SPREL.clear()
     while PART_JOBS:
         chunk, rest, seen = [], [], set()
         for job in PART_JOBS:             # one launch holds a destination at most once (its read-modify-write is not atomic)
@@ -842,6 +846,27 @@ def attn_fwd(q, ldq, k, v, ldkv, Pm, ldp, ctx, B, nh, Nq, Nk, H, scale, kmask=No
 
 def attn_bwd(q, ldq, k, v, ldkv, Pm, ldp, dctx, B, nh, Nq, Nk, H, scale, dP_init, dq, lddq, dk, dv, lddkv, dist=None, dsprel_w=None,
              dsprel_b=None, flops=0.0, drop=None):
+    if dsprel_w is not None and dsprel_b is not None and part_ok(H):
+        # (round 6) the graph-distance bias gradients: every (sample, head) workgroup stores its pair, the flush's column-sum launch adds them up in order.  The
+        # blocks of one encoder share the two scalars: ONE partial buffer per destination and flush takes the pairs of every block (a column-sum launch
+        # holds a destination once: a buffer per block would mean a launch per block)
+        key = dsprel_w.data_ptr()
+        ent = _SPREL.get(key)
+        rows = B * nh
+        if ent is not None and not (ent[2] + 1 < len(PART_JOBS) and PART_JOBS[ent[2]][0].data_ptr() == ent[0].data_ptr()):
+            ent = None                                   # (the queue was emptied without a flush: host/step_graphs.py)
+        if ent is None or ent[1] + rows > ent[0].shape[0]:
+            pt = torch.empty(max(16 * rows, 1024), 2, dtype=torch.float32, device=dsprel_w.device)
+            ent = _SPREL[key] = [pt, 0, len(PART_JOBS)]
+            flat = pt.view(-1)
+            PART_JOBS.append((flat, dsprel_w.reshape(-1), 0, 1, 2))
+            PART_JOBS.append((flat[1:], dsprel_b.reshape(-1), 0, 1, 2))
+        pt, used, j = ent
+        ent[1] = used + rows
+        for jj in (j, j + 1):
+            a_, d_, _, ln_, st_ = PART_JOBS[jj]
+            PART_JOBS[jj] = (a_, d_, ent[1], ln_, st_)
+        dsprel_w, dsprel_b = pt[used:], None
     if FLOPS["enabled"]:
         FLOPS["total"] += 8.0 * flops
         FLOPS["attn"] += 8.0 * flops

@@ -342,6 +342,9 @@ typedef struct {
   float T, kd_norm, kd_coef, pad2_; const float* kd_coef_dev; float* kd_rows;     /* kd_rows NULL: no distillation term */
 } magic_sap_loss_params;
 int magic_sap_fuse_loss(const void* params, int nbytes, void* stream);
+/* dbf NULL (round 6): dwf is a partial buffer [magic_pano_fuse_bwd_blocks(N)][H + 1]; every workgroup STORES its weight-row and bias sums in its own row instead of
+ * adding them with atomics, the caller adds the rows up in order (magic_colsum_add_v). */
+int magic_pano_fuse_bwd_blocks(int N);
 int magic_pano_fuse_bwd(int dtype, int N, int V, int H, const void* x, const float* probs, const float* wf, const void* dfused,
                         void* dx, float* dwf, float* dbf, void* stream);
 /* global/local gate + -inf masks + local->global logit fusion (validate_sap contract :503-535) */

@@ -252,15 +252,17 @@ __global__ __launch_bounds__(256 * PF_PB) void pano_fuse_bwd_kernel(int N, int V
     red[wave][c] = aw[2 * it]; red[wave][c + 1] = aw[2 * it + 1];
   }
   __syncthreads();
+  // dbf NULL (round 6): dwf is a PARTIAL buffer [blocks][H + 1] -- this block's sums (weight row, then the bias) to its own row, added up in order by the caller
+  float* const prow = dbf ? nullptr : dwf + (long long)blockIdx.x * (H + 1);
   for (int c = tid; c < H; c += 256 * PF_PB) {
     float v = 0.f;
     for (int w = 0; w < PF_PB * 4; ++w) v += red[w][c];
-    atomicAdd(dwf + c, v);
+    if (prow) prow[c] = v; else atomicAdd(dwf + c, v);
   }
   if (tid == 0) {
     float v = 0.f;
     for (int q = 0; q < PF_PB; ++q) v += rb[q];
-    atomicAdd(dbf, v);
+    if (prow) prow[H] = v; else atomicAdd(dbf, v);
   }
 }
 
@@ -493,6 +495,8 @@ extern "C" int magic_pano_fuse_fwd(int dtype, int N, int V, int H, const void* x
   return launch_status();
 }
 
+// workgroups (= rows of H + 1 floats of the partial buffer) magic_pano_fuse_bwd launches for N panoramas
+extern "C" int magic_pano_fuse_bwd_blocks(int N) { return N > 0 ? (N + PF_PB - 1) / PF_PB : MAGIC_ERR_ARG; }
 extern "C" int magic_pano_fuse_bwd(int dtype, int N, int V, int H, const void* x, const float* probs, const float* wf, const void* dfused,
                                    void* dx, float* dwf, float* dbf, void* stream) {
   if (N <= 0 || V <= 0 || V > 64 || H <= 0 || H % 128 || H > 768) return MAGIC_ERR_ARG;

@@ -77,6 +77,7 @@ SIGNATURES = {
     "magic_pano_fuse_fwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
     "magic_sap_fuse_loss": [vp, i32, vp],
     "magic_pano_fuse_bwd": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "magic_pano_fuse_bwd_blocks": [i32],
     "magic_sap_fuse_fwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
     "magic_sap_fuse_bwd": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "magic_sumsq": [i64, vp, vp, vp],

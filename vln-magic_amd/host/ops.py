@@ -599,7 +599,7 @@ def ln_bwd_tail(M, H, dy32, y, gamma, beta, rstd, act_pre, act, dx, dgamma, dbet
 PART_PG = os.environ.get("MAGIC_LN_PARTIAL", "1") != "0"
 # Round 6: every reduction that HAS an ordered form takes it by default -- the embedding stage's panorama half through partial rows (embed_in_bwd), the MLM head's
 # vocabulary input gradient as split-K slabs (host/model_pretrain.py), and the partial-row parameter gradients at EVERY width (before: from H = 384 up, where they
-# are also the faster form).  5 / 4 / 5 of 354 parameter tensors still differ run to run on sap / mlm / cfp (round 5: 37 / 20 / 26 -- and 233 on mlm whenever launch
+# are also the faster form).  4 / 3 / 4 of 354 parameter tensors still differ run to run on sap / mlm / cfp (round 5: 37 / 20 / 26 -- and 233 on mlm whenever launch
 # timing shifted); + 5 us per step of the headline cycle, all of it the MLM slabs (profiles/micro/r06_ab_determinism_cost*.txt).  MAGIC_DETERMINISTIC=0: partial rows
 # from H = 384 only (MAGIC_MLM_DX_ATOMICS=1 / MAGIC_EMBED_BWD_PARTIAL=0 switch the other two back).
 DETERMINISTIC = os.environ.get("MAGIC_DETERMINISTIC", "1") != "0"
@@ -1351,6 +1351,13 @@ def pano_fuse_fwd(x, lens, wf, bf, fused, probs, N, V, H, P=None, nh=0, inner=0,
 
 
 def pano_fuse_bwd(x, probs, wf, dfused, dx, dwf, dbf, N, V, H):
+    if dwf is not None and dbf is not None and part_ok(H):          # (round 6) the fusion Linear's gradients through partial rows, added up in order by the flush
+        nblk = int(L.load().magic_pano_fuse_bwd_blocks(int(N)))
+        pt = torch.empty(nblk, H + 1, dtype=torch.float32, device=x.device)
+        flat = pt.view(-1)
+        PART_JOBS.append((flat, dwf.reshape(-1), nblk, H, H + 1))
+        PART_JOBS.append((flat[H:], dbf.reshape(-1), nblk, 1, H + 1))
+        dwf, dbf = pt, None
     L.call("magic_pano_fuse_bwd", L.dt(x.dtype), N, V, H, L.P(x), L.P(probs), L.P(wf), L.P(dfused), L.P(dx), L.P(dwf), L.P(dbf),
            L.stream())
 
